@@ -1,0 +1,91 @@
+// Symbolic plan for the batched LDL^T of one pattern group.
+//
+// One "group" = all scenario/time blocks K_i of this rank that share one sparsity
+// pattern (and one border pattern A_i).  The plan is computed once on the host
+// (reference analogue: MA27A symbolic per block, parapint/linalg/ma27_interface.py:52-92,
+// plus _get_sc_structure, mpi_explicit_schur_complement.py:228-255) and drives every
+// device kernel.  All instances of the group execute the same plan; the instance index
+// is the SIMD lane ("lane = scenario"), so every value array is laid out
+// [entry][instance] and every access is a coalesced 512-byte wave access.
+//
+// Augmented elimination: the block [[K_i, A_i^T], [A_i, 0]] is factorised with the
+// n_c coupling rows constrained last and never eliminated, so the partial factor
+// directly carries  -A_i K_i^{-1} A_i^T  (the Schur contribution the reference forms
+// column by column at mpi_explicit_schur_complement.py:313-333) and
+// -A_i K_i^{-1} r_i  (mpi_...:381-385).
+//
+// Pivots are static: 1x1 or 2x2, chosen by a minimum-degree ordering constrained so
+// that a node with a (numerically) weak diagonal is only eliminated after a neighbour
+// has given it a diagonal update, or inside a 2x2 pivot.  Storage is "U form":
+//   panel(p) = [ P_p ; U_p ]  with U_p = L_p * P_p  (unscaled columns), inv(P_p) kept
+// separately, so all row chunks of a panel are independent tasks.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace pp {
+
+struct PlanOptions {
+  int acc_doubles = 32;   // LDS accumulator doubles per lane for one factor task (rows*w)
+  int tile = 8;           // register tile edge of the Schur (SYRK) kernel
+  int md_delta_abs = 3;   // minimum-degree tolerance (absolute) for height-aware selection
+  double md_delta_rel = 0.5;   // ... and relative to the current minimum degree
+  double pivot_threshold = 0.01;  // 1x1 pivot accepted if |d| >= threshold * max|row| (MA27 cntl(1) analogue)
+};
+
+// factor task: rows [r0, r1) of panel `piv` (slot numbering: 0..w-1 = pivot block rows)
+struct FTask { int piv, r0, r1, src0, src1; };
+// one descendant pivot k contributing to a task; mslot = slot of the target pivot's
+// first row inside panel k (its w rows are consecutive slots)
+struct FSrc { int k, mslot, run0, run1; };
+// len consecutive rows: panel k slots [src, src+len) -> task-relative rows [dst, dst+len)
+struct Run { int src, dst, len; };
+// Schur tile record: pivot p contributes to tile (ta, tb); slots (or -1) of the tile's
+// coupling rows inside panel p
+struct STileRec { int piv; int slotA[8]; int slotB[8]; };
+
+struct Plan {
+  int n = 0, nc = 0, npiv = 0, ncan = 0;
+  int n_levels = 0;
+  PlanOptions opt;
+  std::vector<int> perm, iperm;          // new->old, old->new (K nodes)
+  std::vector<int> piv_start, piv_w;     // first new column of pivot p, width (1|2)
+  std::vector<int> piv_of_col;           // new column -> pivot
+  std::vector<int> piv_rowptr, rowidx;   // rows below pivot p (new indices; n+c = coupling row c)
+  std::vector<int64_t> piv_uoff;         // panel offset, doubles per lane
+  int64_t usize = 0;                     // doubles per lane in U storage
+  std::vector<int64_t> pos_of_can;       // canonical input entry -> U position
+  std::vector<int> piv_level;            // etree height of pivot
+  // factor schedule
+  std::vector<FTask> ftasks;             // sorted by level
+  std::vector<FSrc> fsrcs;
+  std::vector<Run> runs;
+  std::vector<int> flevel_ptr;           // n_levels+1 -> ftasks
+  // solve schedule
+  std::vector<int> lvl_ptr, lvl_piv;     // pivots by level
+  std::vector<int> sfwd_ptr;             // npiv+1 -> sfwd_k / sfwd_mslot (row pattern of p)
+  std::vector<int> sfwd_k, sfwd_mslot;
+  std::vector<int> crow_ptr, crow_k, crow_slot;  // per coupling row: panels holding it
+  // Schur (SYRK) schedule
+  std::vector<int> stile_a, stile_b, stile_ptr;  // tiles (ta>=tb) and record ranges
+  std::vector<STileRec> stile_rec;
+  // statistics
+  int64_t nnz_L = 0;        // structural entries of L below the pivot blocks
+  int64_t flops_factor = 0; // multiply-adds of the panel updates
+  int64_t flops_schur = 0;  // multiply-adds of the coupling x coupling update
+  int n_2x2 = 0;
+  bool numeric_ordering = false;  // ordered with representative values (else pattern only)
+  std::string error;
+};
+
+// K pattern: unique lower-triangular entries (row >= col), any order; entry e is
+// canonical value e.  Border pattern: entries (coupling row, block column) are canonical
+// values nnzK + e.  vals[ncan]: canonical values of a representative instance used to fix
+// the static pivot sequence (may be null: pattern-only ordering, every entry taken as 1 and
+// absent diagonals as zero).  Returns 0 on success.
+int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK,
+               int nnzB, const int* rowB, const int* colB, const double* vals,
+               const PlanOptions& opt, Plan& plan);
+
+}  // namespace pp

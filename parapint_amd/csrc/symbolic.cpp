@@ -1,0 +1,432 @@
+// Host-side symbolic analysis: static-pivot ordering, panel structure, task schedule.
+// See plan.hpp for the model.  Pure C++ (no HIP), so it is unit-tested on CPU.
+#include "plan.hpp"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <map>
+#include <set>
+#include <tuple>
+#include <utility>
+
+namespace pp {
+namespace {
+
+}  // namespace
+
+int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nnzB, const int* rowB,
+               const int* colB, const double* vals, const PlanOptions& opt, Plan& P) {
+  P = Plan();
+  P.n = n; P.nc = nc; P.opt = opt; P.ncan = nnzK + nnzB;
+  P.numeric_ordering = (vals != nullptr);
+  if (opt.tile != 8) { P.error = "tile must be 8"; return 3; }
+  if (n <= 0) { P.error = "empty block"; return 3; }
+
+  // ---- 1. rows of the augmented matrix (K nodes 0..n-1, coupling nodes n..n+nc-1) with the
+  // representative values; without values every entry counts as 1 and only diagonals that are
+  // present in the pattern count as usable.
+  typedef std::pair<int, double> Ent;
+  std::vector<std::vector<Ent>> row(n);   // off-diagonal entries of the current Schur complement
+  std::vector<double> diag(n, 0.0);
+  for (int e = 0; e < nnzK; ++e) {
+    int i = rowK[e], j = colK[e];
+    if (i < 0 || i >= n || j < 0 || j > i) { P.error = "K entry outside the lower triangle"; return 3; }
+    double v = vals ? vals[e] : 1.0;
+    if (i == j) diag[i] += v;
+    else { row[i].push_back({j, v}); row[j].push_back({i, v}); }
+  }
+  for (int e = 0; e < nnzB; ++e) {
+    int c = rowB[e], j = colB[e];
+    if (c < 0 || c >= nc || j < 0 || j >= n) { P.error = "border entry out of range"; return 3; }
+    row[j].push_back({n + c, vals ? vals[nnzK + e] : 1.0});
+  }
+  for (auto& r : row) {
+    std::sort(r.begin(), r.end(), [](const Ent& a, const Ent& b) { return a.first < b.first; });
+    size_t o = 0;
+    for (size_t t = 0; t < r.size(); ++t) {
+      if (o > 0 && r[o - 1].first == r[t].first) r[o - 1].second += r[t].second;
+      else r[o++] = r[t];
+    }
+    r.resize(o);
+  }
+  const double u_thr = opt.pivot_threshold;
+  // MA27-style threshold test on the current row of K_i.  Coupling entries are left out: the
+  // reference's sub-block solvers pivot on K_i alone (mpi_explicit_schur_complement.py:294),
+  // the border only ever appears as right-hand sides.
+  auto is_strong = [&](int x) -> bool {
+    double m = 0.0;
+    for (auto& e : row[x]) { if (e.first >= n) break; m = std::max(m, std::fabs(e.second)); }
+    double d = std::fabs(diag[x]);
+    return d > 0.0 && d >= u_thr * m;
+  };
+  std::vector<uint8_t> strong(n);
+  for (int i = 0; i < n; ++i) strong[i] = is_strong(i);
+
+  // ---- 2. constrained minimum-degree elimination, carried out numerically on the
+  // representative instance, with static 1x1 / 2x2 pivots.  Height-aware: among the nodes whose
+  // degree is within a tolerance of the minimum, a strong node with the smallest prospective
+  // etree level is taken (chains are then eliminated nested-dissection-like and the level
+  // schedule stays shallow); if the window holds no strong node the minimum-degree weak node is
+  // eliminated in a 2x2 pivot with its largest off-diagonal neighbour.
+  std::vector<uint8_t> eliminated(n, 0);
+  std::vector<int> height(n, 0);  // level the node would get if eliminated now
+  typedef std::tuple<int, int, int> Key;  // (degree, height, node)
+  std::set<Key> q_strong, q_weak;
+  auto key_of = [&](int x) { return Key((int)row[x].size(), height[x], x); };
+  auto q_insert = [&](int x) { (strong[x] ? q_strong : q_weak).insert(key_of(x)); };
+  auto q_erase = [&](int x) { (strong[x] ? q_strong : q_weak).erase(key_of(x)); };
+  for (int i = 0; i < n; ++i) q_insert(i);
+  auto pick = [&](const std::set<Key>& q, int dmin, int dmax) -> int {
+    int best = -1, best_h = 0;
+    for (int d = dmin; d <= dmax; ++d) {
+      auto it = q.lower_bound(Key(d, -1, -1));
+      if (it == q.end()) break;
+      if (std::get<0>(*it) > dmax) break;
+      if (std::get<0>(*it) != d) { d = std::get<0>(*it) - 1; continue; }
+      int h = std::get<1>(*it);
+      if (best < 0 || h < best_h) { best = std::get<2>(*it); best_h = h; }
+    }
+    return best;
+  };
+
+  std::vector<int> order; order.reserve(n);
+  std::vector<std::vector<int>> pstruct;  // node ids at elimination time
+  std::vector<double> lu(n + nc, 0.0), lv(n + nc, 0.0);
+  std::vector<Ent> tmp;
+  std::vector<int> N;
+  P.piv_start.clear(); P.piv_w.clear();
+  while ((int)order.size() < n) {
+    int u = -1, v = -1;
+    {
+      // best 1x1 candidate: a strong node within the tolerance window above the minimum strong
+      // degree, lowest prospective level first
+      int d_s = INT_MAX;
+      if (!q_strong.empty()) {
+        d_s = std::get<0>(*q_strong.begin());
+        u = pick(q_strong, d_s, d_s + std::max(opt.md_delta_abs, (int)(opt.md_delta_rel * d_s)));
+      }
+      // 2x2 candidate: the minimum-degree weak node with its largest off-diagonal neighbour; taken
+      // when no strong node is left, or when the pair is no more expensive than the best 1x1
+      if (!q_weak.empty() && std::get<0>(*q_weak.begin()) < d_s) {
+        int uw = std::get<2>(*q_weak.begin()), vw = -1;
+        double best = -1.0;
+        for (auto& e : row[uw]) {
+          if (e.first >= n) continue;
+          double a = std::fabs(e.second);
+          if (a > best) { best = a; vw = e.first; }
+        }
+        if (vw >= 0) {
+          double det = diag[uw] * diag[vw] - best * best;
+          double ref = std::max(std::fabs(diag[uw] * diag[vw]), best * best);
+          if (!(std::fabs(det) > 1e-12 * ref)) vw = -1;  // numerically singular pair
+        }
+        if (vw >= 0) {
+          // degree of the pair = |N(u) u N(v)| - 2
+          size_t i = 0, j = 0, cnt = 0;
+          const auto &ru = row[uw], &rv = row[vw];
+          while (i < ru.size() || j < rv.size()) {
+            int a = (i < ru.size()) ? ru[i].first : INT_MAX, bb = (j < rv.size()) ? rv[j].first : INT_MAX;
+            if (a == bb) { ++i; ++j; } else if (a < bb) ++i; else ++j;
+            ++cnt;
+          }
+          int d_uv = (int)cnt - 2;
+          if (u < 0 || d_uv <= d_s) { u = uw; v = vw; }
+        } else if (u < 0) {
+          u = uw;  // isolated / singular weak node: 1x1, flagged at run time
+        }
+      }
+    }
+    // neighbourhood of the pivot and its (u, v) columns
+    N.clear();
+    for (auto& e : row[u]) if (e.first != v) { N.push_back(e.first); lu[e.first] = e.second; }
+    double b_uv = 0.0;
+    if (v >= 0) {
+      for (auto& e : row[v]) {
+        if (e.first == u) { b_uv = e.second; continue; }
+        if (lu[e.first] == 0.0 && !std::binary_search(N.begin(), N.end(), e.first)) N.push_back(e.first);
+        lv[e.first] = e.second;
+      }
+      std::sort(N.begin(), N.end());
+      N.erase(std::unique(N.begin(), N.end()), N.end());
+    }
+    // inverse of the pivot block
+    double i00, i01 = 0.0, i11 = 0.0;
+    if (v < 0) {
+      i00 = (diag[u] != 0.0) ? 1.0 / diag[u] : 0.0;
+    } else {
+      double det = diag[u] * diag[v] - b_uv * b_uv;
+      if (det == 0.0) det = 1.0;
+      i00 = diag[v] / det; i01 = -b_uv / det; i11 = diag[u] / det;
+    }
+    const int lvl = (v >= 0) ? std::max(height[u], height[v]) : height[u];
+    q_erase(u); eliminated[u] = 1;
+    if (v >= 0) { q_erase(v); eliminated[v] = 1; }
+    for (int x : N) {
+      if (x >= n) continue;
+      q_erase(x);
+      // w = inv(P) * l_x ; new row_x = row_x - sum_y (l_y . w) over y in N
+      const double wx0 = i00 * lu[x] + i01 * lv[x];
+      const double wx1 = i01 * lu[x] + i11 * lv[x];
+      tmp.clear();
+      tmp.reserve(row[x].size() + N.size());
+      size_t i = 0, j = 0;
+      const auto& rx = row[x];
+      while (i < rx.size() || j < N.size()) {
+        int a = (i < rx.size()) ? rx[i].first : INT32_MAX;
+        int bnode = (j < N.size()) ? N[j] : INT32_MAX;
+        if (a == u || a == v) { ++i; continue; }
+        if (bnode == x) { ++j; continue; }
+        if (a < bnode) { tmp.push_back(rx[i]); ++i; }
+        else {
+          double upd = -(lu[bnode] * wx0 + lv[bnode] * wx1);
+          if (a == bnode) { tmp.push_back({a, rx[i].second + upd}); ++i; ++j; }
+          else { tmp.push_back({bnode, upd}); ++j; }
+        }
+      }
+      row[x].swap(tmp);
+      diag[x] -= lu[x] * wx0 + lv[x] * wx1;
+      height[x] = std::max(height[x], lvl + 1);
+      strong[x] = is_strong(x);
+      q_insert(x);
+    }
+    for (int x : N) { lu[x] = 0.0; lv[x] = 0.0; }
+    P.piv_start.push_back((int)order.size());
+    P.piv_w.push_back(v >= 0 ? 2 : 1);
+    order.push_back(u);
+    if (v >= 0) { order.push_back(v); P.n_2x2++; }
+    pstruct.push_back(N);
+    std::vector<Ent>().swap(row[u]);
+    if (v >= 0) std::vector<Ent>().swap(row[v]);
+  }
+  P.npiv = (int)P.piv_w.size();
+  P.piv_start.push_back(n);
+  P.perm = order;
+  P.iperm.assign(n, -1);
+  for (int k = 0; k < n; ++k) P.iperm[order[k]] = k;
+  P.piv_of_col.assign(n, -1);
+  for (int p = 0; p < P.npiv; ++p)
+    for (int q = 0; q < P.piv_w[p]; ++q) P.piv_of_col[P.piv_start[p] + q] = p;
+
+  // ---- 3. row structures in new indices, closed under pivot pairs
+  std::vector<std::vector<int>> rows(P.npiv);
+  for (int p = 0; p < P.npiv; ++p) {
+    auto& r = rows[p];
+    r.reserve(pstruct[p].size() + 2);
+    for (int x : pstruct[p]) r.push_back(x < n ? P.iperm[x] : x);
+    std::sort(r.begin(), r.end());
+    std::vector<int>().swap(pstruct[p]);
+  }
+  for (int p = 0; p < P.npiv; ++p) {
+    auto& r = rows[p];
+    bool added = false;
+    size_t m = r.size();
+    for (size_t t = 0; t < m; ++t) {
+      int c = r[t];
+      if (c >= n) break;
+      int q = P.piv_of_col[c];
+      if (P.piv_w[q] == 2) {
+        int other = (c == P.piv_start[q]) ? c + 1 : c - 1;
+        if (!std::binary_search(r.begin(), r.begin() + m, other)) { r.push_back(other); added = true; }
+      }
+    }
+    if (added) { std::sort(r.begin(), r.end()); r.erase(std::unique(r.begin(), r.end()), r.end()); }
+    // propagate closure to the parent (first row's pivot): rows beyond the parent's own
+    // columns must appear in the parent's structure
+    if (!r.empty() && r[0] < n) {
+      int par = P.piv_of_col[r[0]];
+      int pend = P.piv_start[par] + P.piv_w[par];
+      auto& rp = rows[par];
+      size_t before = rp.size();
+      for (int c : r) if (c >= pend && !std::binary_search(rp.begin(), rp.begin() + before, c)) rp.push_back(c);
+      if (rp.size() != before) { std::sort(rp.begin(), rp.end()); rp.erase(std::unique(rp.begin(), rp.end()), rp.end()); }
+    }
+  }
+  P.piv_rowptr.assign(P.npiv + 1, 0);
+  P.piv_uoff.assign(P.npiv, 0);
+  for (int p = 0; p < P.npiv; ++p) {
+    P.piv_rowptr[p + 1] = P.piv_rowptr[p] + (int)rows[p].size();
+    P.piv_uoff[p] = P.usize;
+    P.usize += (int64_t)(P.piv_w[p] + (int64_t)rows[p].size()) * P.piv_w[p];
+    P.nnz_L += (int64_t)rows[p].size() * P.piv_w[p];
+  }
+  P.rowidx.reserve(P.piv_rowptr[P.npiv]);
+  for (int p = 0; p < P.npiv; ++p) P.rowidx.insert(P.rowidx.end(), rows[p].begin(), rows[p].end());
+
+  auto slot_in_panel = [&](int p, int r) -> int {  // slot of new row r in panel p, or -1
+    int p0 = P.piv_start[p], w = P.piv_w[p];
+    if (r >= p0 && r < p0 + w) return r - p0;
+    auto it = std::lower_bound(rows[p].begin(), rows[p].end(), r);
+    if (it == rows[p].end() || *it != r) return -1;
+    return w + (int)(it - rows[p].begin());
+  };
+
+  // ---- 4. scatter positions of the canonical input entries
+  P.pos_of_can.assign(P.ncan, -1);
+  for (int e = 0; e < nnzK; ++e) {
+    int i = P.iperm[rowK[e]], j = P.iperm[colK[e]];
+    if (i < j) std::swap(i, j);
+    int p = P.piv_of_col[j];
+    int s = slot_in_panel(p, i);
+    if (s < 0) { P.error = "internal: K entry outside the symbolic structure"; return 3; }
+    P.pos_of_can[e] = P.piv_uoff[p] + (int64_t)s * P.piv_w[p] + (j - P.piv_start[p]);
+  }
+  for (int e = 0; e < nnzB; ++e) {
+    int j = P.iperm[colB[e]];
+    int p = P.piv_of_col[j];
+    int s = slot_in_panel(p, n + rowB[e]);
+    if (s < 0) { P.error = "internal: border entry outside the symbolic structure"; return 3; }
+    P.pos_of_can[nnzK + e] = P.piv_uoff[p] + (int64_t)s * P.piv_w[p] + (j - P.piv_start[p]);
+  }
+
+  // ---- 5. row patterns (which earlier panels hold rows of pivot p) and levels
+  std::vector<std::vector<std::pair<int, int>>> rowpat(P.npiv);  // (k, mslot)
+  for (int k = 0; k < P.npiv; ++k) {
+    const auto& r = rows[k];
+    int last = -1;
+    for (size_t t = 0; t < r.size() && r[t] < n; ++t) {
+      int p = P.piv_of_col[r[t]];
+      if (p == last) continue;
+      last = p;
+      if (r[t] != P.piv_start[p]) { P.error = "internal: pivot rows not closed"; return 3; }
+      rowpat[p].push_back({k, P.piv_w[k] + (int)t});
+    }
+  }
+  P.piv_level.assign(P.npiv, 0);
+  for (int p = 0; p < P.npiv; ++p) {
+    int lv = 0;
+    for (auto& km : rowpat[p]) lv = std::max(lv, P.piv_level[km.first] + 1);
+    P.piv_level[p] = lv;
+    P.n_levels = std::max(P.n_levels, lv + 1);
+  }
+  P.sfwd_ptr.assign(P.npiv + 1, 0);
+  for (int p = 0; p < P.npiv; ++p) {
+    P.sfwd_ptr[p + 1] = P.sfwd_ptr[p] + (int)rowpat[p].size();
+    for (auto& km : rowpat[p]) { P.sfwd_k.push_back(km.first); P.sfwd_mslot.push_back(km.second); }
+  }
+  {
+    std::vector<int> cnt(P.n_levels + 1, 0);
+    for (int p = 0; p < P.npiv; ++p) cnt[P.piv_level[p] + 1]++;
+    for (int l = 0; l < P.n_levels; ++l) cnt[l + 1] += cnt[l];
+    P.lvl_ptr = cnt;
+    P.lvl_piv.assign(P.npiv, 0);
+    std::vector<int> fill(cnt.begin(), cnt.end() - 1);
+    for (int p = 0; p < P.npiv; ++p) P.lvl_piv[fill[P.piv_level[p]]++] = p;
+  }
+
+  // ---- 6. factor tasks (left-looking gathers, chunked by rows)
+  struct TmpTask { FTask t; int level; };
+  std::vector<TmpTask> tasks;
+  std::vector<std::pair<int, int>> map_sd;  // (src slot, dst slot)
+  for (int p = 0; p < P.npiv; ++p) {
+    const int w = P.piv_w[p], p0 = P.piv_start[p];
+    const int f = w + (int)rows[p].size();
+    const int R = std::max(1, opt.acc_doubles / w);
+    const int nchunk = (f + R - 1) / R;
+    std::vector<std::vector<FSrc>> chunk_srcs(nchunk);
+    for (auto& km : rowpat[p]) {
+      const int k = km.first, mslot = km.second, wk = P.piv_w[k];
+      const auto& rk = rows[k];
+      // rows of panel k from slot mslot on -> slots of panel p (two-pointer over sorted lists)
+      map_sd.clear();
+      size_t tp = 0;
+      for (size_t t = (size_t)(mslot - wk); t < rk.size(); ++t) {
+        int r = rk[t];
+        int d;
+        if (r < p0 + w) d = r - p0;
+        else {
+          while (tp < rows[p].size() && rows[p][tp] < r) ++tp;
+          if (tp >= rows[p].size() || rows[p][tp] != r) { P.error = "internal: fill closure violated"; return 3; }
+          d = w + (int)tp;
+        }
+        map_sd.push_back({wk + (int)t, d});
+      }
+      size_t i = 0;
+      while (i < map_sd.size()) {
+        int c = map_sd[i].second / R;
+        FSrc src{k, mslot, (int)P.runs.size(), 0};
+        while (i < map_sd.size() && map_sd[i].second / R == c) {
+          Run run{map_sd[i].first, map_sd[i].second - c * R, 1};
+          ++i;
+          while (i < map_sd.size() && map_sd[i].second / R == c && map_sd[i].first == run.src + run.len &&
+                 map_sd[i].second - c * R == run.dst + run.len) { ++run.len; ++i; }
+          P.runs.push_back(run);
+          P.flops_factor += (int64_t)run.len * wk * w;
+        }
+        src.run1 = (int)P.runs.size();
+        chunk_srcs[c].push_back(src);
+      }
+    }
+    for (int c = 0; c < nchunk; ++c) {
+      TmpTask tt;
+      tt.level = P.piv_level[p];
+      tt.t.piv = p; tt.t.r0 = c * R; tt.t.r1 = std::min(f, (c + 1) * R);
+      tt.t.src0 = (int)P.fsrcs.size();
+      P.fsrcs.insert(P.fsrcs.end(), chunk_srcs[c].begin(), chunk_srcs[c].end());
+      tt.t.src1 = (int)P.fsrcs.size();
+      tasks.push_back(tt);
+    }
+  }
+  std::stable_sort(tasks.begin(), tasks.end(), [](const TmpTask& a, const TmpTask& b) { return a.level < b.level; });
+  P.flevel_ptr.assign(P.n_levels + 1, 0);
+  for (auto& t : tasks) { P.ftasks.push_back(t.t); P.flevel_ptr[t.level + 1]++; }
+  for (int l = 0; l < P.n_levels; ++l) P.flevel_ptr[l + 1] += P.flevel_ptr[l];
+
+  // ---- 7. coupling rows: which panels hold them (forward solve of the Schur rhs)
+  {
+    std::vector<std::vector<std::pair<int, int>>> cr(nc);
+    for (int k = 0; k < P.npiv; ++k) {
+      const auto& r = rows[k];
+      for (size_t t = r.size(); t-- > 0;) {
+        if (r[t] < n) break;
+        cr[r[t] - n].push_back({k, P.piv_w[k] + (int)t});
+      }
+    }
+    P.crow_ptr.assign(nc + 1, 0);
+    for (int c = 0; c < nc; ++c) {
+      P.crow_ptr[c + 1] = P.crow_ptr[c] + (int)cr[c].size();
+      for (auto& ks : cr[c]) { P.crow_k.push_back(ks.first); P.crow_slot.push_back(ks.second); }
+    }
+  }
+
+  // ---- 8. Schur tiles: S -= U_c,p inv(P_p) U_c,p^T over coupling rows, T x T tiles
+  {
+    const int T = opt.tile;
+    std::map<std::pair<int, int>, std::vector<STileRec>> by_tile;
+    for (int p = 0; p < P.npiv; ++p) {
+      const auto& r = rows[p];
+      size_t first = r.size();
+      while (first > 0 && r[first - 1] >= n) --first;
+      if (first == r.size()) continue;
+      // slot lists per touched tile row
+      std::vector<int> tl;           // tile indices
+      std::vector<STileRec> dummy;
+      std::vector<std::vector<int>> slots;
+      for (size_t t = first; t < r.size(); ++t) {
+        int c = r[t] - n, ti = c / T;
+        if (tl.empty() || tl.back() != ti) { tl.push_back(ti); slots.push_back(std::vector<int>(T, -1)); }
+        slots.back()[c % T] = P.piv_w[p] + (int)t;
+      }
+      for (size_t a = 0; a < tl.size(); ++a)
+        for (size_t b = 0; b <= a; ++b) {
+          STileRec rec;
+          rec.piv = p;
+          for (int q = 0; q < T; ++q) { rec.slotA[q] = slots[a][q]; rec.slotB[q] = slots[b][q]; }
+          by_tile[{tl[a], tl[b]}].push_back(rec);
+          int na = 0, nb = 0;
+          for (int q = 0; q < T; ++q) { na += slots[a][q] >= 0; nb += slots[b][q] >= 0; }
+          P.flops_schur += (int64_t)na * nb * P.piv_w[p];
+        }
+    }
+    P.stile_ptr.push_back(0);
+    for (auto& kv : by_tile) {
+      P.stile_a.push_back(kv.first.first);
+      P.stile_b.push_back(kv.first.second);
+      P.stile_rec.insert(P.stile_rec.end(), kv.second.begin(), kv.second.end());
+      P.stile_ptr.push_back((int)P.stile_rec.size());
+    }
+  }
+  return 0;
+}
+
+}  // namespace pp

@@ -1,0 +1,128 @@
+"""Host-side symbolic plan + task schedule, executed by the TEST-ONLY interpreter
+(tests/hostsim) and checked against dense linear algebra.  No GPU needed: this validates
+ordering, static 1x1/2x2 pivots, panel structure, update runs, Schur tiles and the
+forward/backward schedules that the HIP kernels execute verbatim."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from hostsim_util import HostSim
+from parapint_amd.examples.performance.schur_complement.synthetic_kkt import SyntheticKKT
+
+
+def sym_dense(K):
+    Kd = sp.coo_matrix(K).toarray()
+    return np.tril(Kd) + np.tril(Kd, -1).T
+
+
+def check_block(K, A, rtol=1e-9, expect_2x2=None):
+    hs = HostSim(K, A)
+    rc, S, inertia = hs.factor()
+    Kd = sym_dense(K)
+    Ad = sp.coo_matrix(A).toarray()
+    n, nc = hs.n, hs.nc
+    assert rc == 0
+    Sref = -Ad @ np.linalg.solve(Kd, Ad.T)
+    scale = max(1.0, np.abs(Sref).max())
+    assert np.abs(S - Sref).max() <= rtol * scale
+    ev = np.linalg.eigvalsh(Kd)
+    assert inertia == (int((ev > 0).sum()), int((ev < 0).sum()), 0)
+    rng = np.random.default_rng(5)
+    r = rng.normal(size=n)
+    W = hs.forward(r)
+    rc_ref = -Ad @ np.linalg.solve(Kd, r)
+    assert np.abs(W[n:] - rc_ref).max() <= rtol * max(1.0, np.abs(rc_ref).max())
+    xc = rng.normal(size=nc)
+    x = hs.backward(W, xc)
+    xref = np.linalg.solve(Kd, r - Ad.T @ xc)
+    assert np.abs(x - xref).max() <= rtol * max(1.0, np.abs(xref).max())
+    if expect_2x2 is not None:
+        assert (hs.stats['n_2x2'] > 0) == expect_2x2
+    return hs
+
+
+@pytest.mark.parametrize('shape', [(3, 20, 2, 4), (4, 50, 3, 6), (2, 120, 4, 30)])
+def test_synthetic_blocks(shape):
+    m = SyntheticKKT(*shape)
+    hs = check_block(m.block_matrix(0), m.border_matrix())
+    assert hs.stats['n_levels'] < hs.stats['npiv'] // 4      # shallow schedule, not a chain
+
+
+def test_synthetic_c3_shape_plan_is_shallow_and_sparse():
+    m = SyntheticKKT(1, 1000, 4, 200)
+    hs = HostSim(m.block_matrix(0), m.border_matrix())
+    st = hs.stats
+    assert st['n'] == 9200 and st['nc'] == 200
+    assert st['n_levels'] <= 64
+    assert st['nnz_L'] <= 1.5 * 20192          # nnz(tril K_i) = 20 192
+    rc, S, inertia = hs.factor()
+    assert rc == 0 and inertia == (5000, 4200, 0)
+
+
+def random_saddle(n_x, n_c, n_border, seed, zero_h_frac=0.3, density=0.15):
+    rng = np.random.default_rng(seed)
+    h = rng.uniform(0.5, 2.0, size=n_x)
+    h[rng.random(n_x) < zero_h_frac] = 0.0
+    H = sp.diags(h) + 0.0 * sp.eye(n_x)
+    J = sp.random(n_c, n_x, density=density, random_state=seed, data_rvs=lambda k: rng.normal(size=k)).tocsr()
+    # make J full row rank w.h.p. by adding a shifted identity part
+    J = J + sp.eye(n_c, n_x, k=0) * 2.0
+    K = sp.bmat([[H, J.T], [J, None]]).tocoo()
+    K = (K + sp.coo_matrix(([0.0] * (n_x + n_c), (range(n_x + n_c), range(n_x + n_c))), shape=K.shape)).tocoo()
+    cols = rng.choice(n_x + n_c, size=n_border, replace=False)
+    A = sp.coo_matrix((-np.ones(n_border), (np.arange(n_border), cols)), shape=(n_border, n_x + n_c))
+    return K, A
+
+
+@pytest.mark.parametrize('seed,frac', [(0, 0.3), (4, 0.3), (5, 0.3), (7, 0.3), (1, 0.2), (6, 0.2)])
+def test_random_saddle_point_blocks(seed, frac):
+    K, A = random_saddle(40, 15, 6, seed, zero_h_frac=frac)
+    assert np.linalg.cond(sym_dense(K)) < 1e10
+    check_block(K, A, rtol=1e-7)
+
+
+@pytest.mark.parametrize('seed,frac', [(2, 0.3), (3, 0.3), (1, 0.3)])
+def test_singular_saddle_point_blocks_are_flagged(seed, frac):
+    K, A = random_saddle(40, 15, 6, seed, zero_h_frac=frac)
+    assert np.linalg.cond(sym_dense(K)) > 1e14          # structurally rank deficient draw
+    hs = HostSim(K, A)
+    rc, S, inertia = hs.factor()
+    assert rc == 2 and inertia[2] >= 1
+
+
+def test_forced_two_by_two_pivots():
+    # [[0, B], [B^T, 0]] has no usable 1x1 pivot anywhere
+    rng = np.random.default_rng(1)
+    B = np.diag(rng.uniform(1, 2, size=6)) + np.diag(rng.uniform(0.1, 0.3, size=5), 1)
+    K = sp.bmat([[None, sp.coo_matrix(B)], [sp.coo_matrix(B.T), None]]).tocoo()
+    A = sp.coo_matrix(([-1.0, -1.0], ([0, 1], [2, 9])), shape=(2, 12))
+    check_block(K, A, expect_2x2=True)
+
+
+def test_dense_coupling_rows():
+    # every border row touches several block columns with non-unit values
+    rng = np.random.default_rng(3)
+    n = 30
+    M = rng.normal(size=(n, n))
+    K = sp.coo_matrix(M @ M.T + n * np.eye(n))
+    A = sp.random(9, n, density=0.4, random_state=2, data_rvs=lambda k: rng.normal(size=k))
+    check_block(K, A)
+
+
+def test_chunked_panels_small_accumulator():
+    m = SyntheticKKT(2, 60, 3, 24)
+    K, A = m.block_matrix(0), m.border_matrix()
+    hs = HostSim(K, A, acc_doubles=4)          # forces many row chunks per panel
+    rc, S, inertia = hs.factor()
+    Kd = sym_dense(K)
+    Ad = A.toarray()
+    assert np.allclose(S, -Ad @ np.linalg.solve(Kd, Ad.T), rtol=1e-9, atol=1e-9)
+    assert hs.stats['ntasks'] > hs.stats['npiv']
+
+
+def test_singular_block_is_flagged():
+    K = sp.coo_matrix(np.array([[1.0, 1.0, 0], [1.0, 1.0, 0], [0, 0, 2.0]]))
+    A = sp.coo_matrix(([-1.0], ([0], [2])), shape=(1, 3))
+    hs = HostSim(K, A)
+    rc, S, inertia = hs.factor()
+    assert rc == 2 and inertia[2] >= 1
