@@ -1,0 +1,135 @@
+/* parapint_hip.h -- C ABI of the MI355X-native Schur-complement KKT solver.
+ *
+ * Drop-in boundary for the hot path of sandialabs/parapint:
+ *   parapint.linalg.MPISchurComplementLinearSolver  (parapint/linalg/schur_complement/
+ *   mpi_explicit_schur_complement.py:128-452) together with its per-block sub-solvers
+ *   (ma27_interface.py:9-256, mumps_interface.py:11-229, scipy_interface.py:11-67).
+ * The reference has no FFI of its own (it is pure Python over third-party solvers); this
+ * header is what a ctypes binding for that path binds.  Plain pointers and
+ * sizes only; every function returns a LinearSolverStatus value
+ * (parapint/linalg/results.py:4-9): 0 successful, 1 not_enough_memory, 2 singular, 3 error,
+ * 4 warning.  Nothing throws across the ABI; pp_last_error() gives the message.
+ *
+ * Life cycle (one handle per solver object, bound to one HIP device and one stream):
+ *   pp_create -> pp_begin_symbolic -> pp_add_group* -> pp_end_symbolic
+ *             -> { pp_upload_values* -> pp_numeric_local -> [all-reduce of pp_schur_buffer]
+ *                  -> pp_factor_schur -> pp_get_status
+ *                  -> { pp_upload_rhs* -> pp_solve_forward -> [all-reduce of pp_rs_buffer]
+ *                       -> pp_solve_coupling -> pp_solve_backward -> pp_download_solution* }* }*
+ *   -> pp_destroy
+ * The two all-reduces (reference: comm.Allreduce at mpi_...:343 and :387) are issued by the
+ * caller (RCCL through torch.distributed) on the device buffers returned here.
+ *
+ * A "group" is the set of this rank's diagonal blocks K_i that share one sparsity pattern and
+ * one border pattern A_i; all its instances are factorised together, one instance per SIMD lane.
+ */
+#ifndef PARAPINT_HIP_H
+#define PARAPINT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pp_solver* pp_handle;
+
+/* Creates a handle on HIP device `device` (-1: current).  `stream` is a hipStream_t (or NULL for
+ * the default stream) on which every kernel and copy of this handle is enqueued.
+ * Replaces: MPISchurComplementLinearSolver.__init__ (mpi_...:154-163). */
+int pp_create(pp_handle* out, int device, void* stream);
+void pp_destroy(pp_handle h);
+const char* pp_last_error(pp_handle h);
+
+/* ---- symbolic phase: do_symbolic_factorization (mpi_...:165-255) ------------------------- */
+int pp_begin_symbolic(pp_handle h, int n_coupling);
+
+/* One pattern group.
+ *   n, batch            block dimension and number of local blocks with this pattern
+ *   rowK/colK[nnzK]     canonical pattern of tril(K_i): unique entries, row >= col
+ *   rowB/colB[nnzB]     canonical pattern of A_i: (coupling row, block column), unique
+ *   nraw                length of the raw value vector the caller supplies per block
+ *                       (K_i's COO data followed by A_i's COO data, in the caller's order,
+ *                       duplicates and upper-triangle entries allowed -- quirk Q7 of SURVEY.md)
+ *   can_ptr/can_idx     CSR map canonical entry e (0..nnzK+nnzB-1) -> raw positions summed into it
+ *   rep_vals[nnzK+nnzB] canonical values of a representative block used to fix the static pivot
+ *                       sequence (MA27A+MA27B pivot-choice analogue), or NULL (pattern only)
+ * Replaces: per-block sub-solver do_symbolic_factorization (ma27_interface.py:52-92) and
+ * _BorderMatrix (mpi_...:33-58). */
+int pp_add_group(pp_handle h, int n, int batch, int nnzK, const int32_t* rowK, const int32_t* colK,
+                 int nnzB, const int32_t* rowB, const int32_t* colB, int nraw, const int32_t* can_ptr,
+                 const int32_t* can_idx, const double* rep_vals, int* group_out);
+
+/* Builds the plans' device images and allocates all device memory (_get_sc_structure,
+ * mpi_...:228-255: the dense S buffer replaces the sparse COO pattern + sc_data_slices). */
+int pp_end_symbolic(pp_handle h);
+
+/* ---- numeric phase: do_numeric_factorization (mpi_...:257-361) --------------------------- */
+/* Raw values of all instances of a group, [batch][nraw] row-major.  on_device != 0: `raw` is a
+ * device pointer (device-to-device copy); else host memory (async H2D on the handle's stream). */
+int pp_upload_values(pp_handle h, int group, const double* raw, int on_device);
+/* Device pointer of the group's raw value buffer ([batch][nraw]) for producers that assemble
+ * values on the device (no copy needed before pp_numeric_local). */
+double* pp_raw_buffer(pp_handle h, int group);
+
+/* Batched block factorisation + local Schur contribution: K_i = L D L^T for every local block
+ * (mpi_...:292-299) and S_local = -sum_i A_i K_i^{-1} A_i^T (mpi_...:312-333).  Result is left
+ * in the Schur buffer; block inertia and the singular-pivot count ride in its 4-double tail. */
+int pp_numeric_local(pp_handle h);
+
+/* Device buffer of n_c*n_c + 4 doubles: dense column-major S_local followed by
+ * {n_zero_pivots, n_pos, n_neg, reserved} as doubles, so ONE sum all-reduce carries the Schur
+ * complement (mpi_...:343), the status agreement (mpi_...:19-30) and the inertia sums
+ * (mpi_...:427-429).  pp_bind_schur_buffer lets the caller supply that memory (e.g. a torch tensor). */
+double* pp_schur_buffer(pp_handle h);
+int pp_bind_schur_buffer(pp_handle h, double* dev_ptr);
+
+/* S = S_allreduced + Q, dense Bunch-Kaufman LDL^T of S, inertia(S)  (mpi_...:347-361).
+ * Q: dense column-major n_c x n_c on the host (lower triangle read), or NULL for Q = 0. */
+int pp_factor_schur(pp_handle h, const double* Q_host);
+
+/* Synchronises the stream and returns {status, pos, neg, zero} of the whole matrix:
+ * sum of block inertias (all ranks, taken from the all-reduced tail) + inertia(S)
+ * (get_inertia, mpi_...:404-436).  status is 2 (singular) if any pivot was numerically zero. */
+int pp_get_status(pp_handle h, int64_t out[4]);
+
+/* Copies the all-reduced Schur complement (without Q), dense column-major n_c x n_c, to the host. */
+int pp_get_schur(pp_handle h, double* S_host);
+
+/* ---- back-solve: do_back_solve (mpi_...:363-402) ----------------------------------------- */
+/* Right-hand sides of a group's blocks, [batch][n] row-major. */
+int pp_upload_rhs(pp_handle h, int group, const double* rhs, int on_device);
+double* pp_rhs_buffer(pp_handle h, int group);
+/* Forward elimination of all local blocks; leaves r_s_local = -sum_i A_i K_i^{-1} r_i
+ * (mpi_...:381-385) in the rs buffer (n_c doubles, device) for the caller's all-reduce (:387). */
+int pp_solve_forward(pp_handle h);
+double* pp_rs_buffer(pp_handle h);
+int pp_bind_rs_buffer(pp_handle h, double* dev_ptr);
+/* x_c = S^{-1} (r_c + r_s)  (mpi_...:388-391); r_c on the host (n_c doubles, or NULL = 0). */
+int pp_solve_coupling(pp_handle h, const double* rc_host);
+/* x_i = K_i^{-1} (r_i - A_i^T x_c) for all local blocks (mpi_...:393-396), by back substitution. */
+int pp_solve_backward(pp_handle h);
+/* Solutions of a group's blocks, [batch][n] row-major (host, or device if on_device). */
+int pp_download_solution(pp_handle h, int group, double* x, int on_device);
+double* pp_solution_buffer(pp_handle h, int group);
+int pp_get_coupling_solution(pp_handle h, double* xc_host);
+
+/* ---- misc -------------------------------------------------------------------------------- */
+/* increase_memory_allocation (mpi_...:438-452): device storage is sized exactly by the symbolic
+ * phase, so this is a recorded hint only. */
+int pp_increase_memory_allocation(pp_handle h, double factor);
+/* Blocks until the handle's stream is idle. */
+int pp_synchronize(pp_handle h);
+
+/* Per-group plan statistics.  out[16]:
+ *  0 n, 1 n_coupling, 2 batch, 3 n_pivots, 4 n_2x2, 5 n_levels, 6 nnz(L), 7 U doubles per instance,
+ *  8 factor multiply-adds per instance, 9 Schur multiply-adds per instance, 10 factor tasks,
+ *  11 update runs, 12 Schur tiles, 13 Schur tile records, 14 canonical entries, 15 raw entries */
+int pp_group_stats(pp_handle h, int group, int64_t out[16]);
+/* Elimination order of a group (new -> old), n ints. */
+int pp_group_perm(pp_handle h, int group, int32_t* perm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PARAPINT_HIP_H */

@@ -1,0 +1,126 @@
+"""ctypes binding of libparapint_hip.so (the C ABI declared in include/parapint_hip.h).
+
+There is no CPU fallback: if the library is missing or no HIP device is usable the
+product raises.  Build with ``python -c 'import __graft_entry__ as g; g.build()'``.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libparapint_hip.so')
+
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_i64p = ctypes.POINTER(ctypes.c_int64)
+_f64p = ctypes.POINTER(ctypes.c_double)
+
+# name -> (restype, argtypes); every symbol include/parapint_hip.h declares
+SIGNATURES = {
+    'pp_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_void_p]),
+    'pp_destroy': (None, [ctypes.c_void_p]),
+    'pp_last_error': (ctypes.c_char_p, [ctypes.c_void_p]),
+    'pp_begin_symbolic': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    'pp_add_group': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i32p, _i32p,
+                                    ctypes.c_int, _i32p, _i32p, ctypes.c_int, _i32p, _i32p, _f64p,
+                                    ctypes.POINTER(ctypes.c_int)]),
+    'pp_end_symbolic': (ctypes.c_int, [ctypes.c_void_p]),
+    'pp_upload_values': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]),
+    'pp_raw_buffer': (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int]),
+    'pp_numeric_local': (ctypes.c_int, [ctypes.c_void_p]),
+    'pp_schur_buffer': (ctypes.c_void_p, [ctypes.c_void_p]),
+    'pp_bind_schur_buffer': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    'pp_factor_schur': (ctypes.c_int, [ctypes.c_void_p, _f64p]),
+    'pp_get_status': (ctypes.c_int, [ctypes.c_void_p, _i64p]),
+    'pp_get_schur': (ctypes.c_int, [ctypes.c_void_p, _f64p]),
+    'pp_upload_rhs': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]),
+    'pp_rhs_buffer': (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int]),
+    'pp_solve_forward': (ctypes.c_int, [ctypes.c_void_p]),
+    'pp_rs_buffer': (ctypes.c_void_p, [ctypes.c_void_p]),
+    'pp_bind_rs_buffer': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    'pp_solve_coupling': (ctypes.c_int, [ctypes.c_void_p, _f64p]),
+    'pp_solve_backward': (ctypes.c_int, [ctypes.c_void_p]),
+    'pp_download_solution': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]),
+    'pp_solution_buffer': (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int]),
+    'pp_get_coupling_solution': (ctypes.c_int, [ctypes.c_void_p, _f64p]),
+    'pp_increase_memory_allocation': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double]),
+    'pp_synchronize': (ctypes.c_int, [ctypes.c_void_p]),
+    'pp_group_stats': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _i64p]),
+    'pp_group_perm': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _i32p]),
+}
+
+GROUP_STAT_KEYS = ['n', 'n_coupling', 'batch', 'n_pivots', 'n_2x2', 'n_levels', 'nnz_L', 'u_doubles',
+                   'factor_fma', 'schur_fma', 'factor_tasks', 'update_runs', 'schur_tiles', 'schur_tile_records',
+                   'canonical_entries', 'raw_entries']
+
+_lib = None
+
+
+def load_library():
+    """Load libparapint_hip.so and declare every prototype.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError('parapint_amd: %s is not built (run __graft_entry__.build()); '
+                           'there is no CPU fallback for the HIP solver' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if a declared symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def i32(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(_i32p)
+
+
+def f64(a):
+    a = np.ascontiguousarray(a, dtype=np.double)
+    return a, a.ctypes.data_as(_f64p)
+
+
+class NativeSolver(object):
+    """Thin object wrapper over one pp_handle."""
+
+    def __init__(self, device=-1, stream=None):
+        self.lib = load_library()
+        h = ctypes.c_void_p()
+        rc = self.lib.pp_create(ctypes.byref(h), int(device), ctypes.c_void_p(stream or 0))
+        if rc != 0 or not h:
+            raise RuntimeError('parapint_amd: pp_create failed (status %d): no usable HIP device; '
+                               'the solver has no CPU fallback' % rc)
+        self.h = h
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.pp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def error(self):
+        msg = self.lib.pp_last_error(self.h)
+        return msg.decode() if msg else ''
+
+    def check(self, rc, what):
+        if rc != 0:
+            raise NativeError(rc, '%s failed with status %d: %s' % (what, rc, self.error()))
+
+    def group_stats(self, group):
+        out = np.zeros(16, dtype=np.int64)
+        self.check(self.lib.pp_group_stats(self.h, group, out.ctypes.data_as(_i64p)), 'pp_group_stats')
+        return dict(zip(GROUP_STAT_KEYS, [int(v) for v in out]))
+
+
+class NativeError(RuntimeError):
+    def __init__(self, status, msg):
+        RuntimeError.__init__(self, msg)
+        self.status = status

@@ -7,32 +7,19 @@
 #include <vector>
 
 #include "../../parapint_amd/csrc/plan.hpp"
+#include "../../parapint_amd/csrc/dense_bk.hpp"
 
 using pp::Plan;
 
 namespace {
-struct PivInv { double i00, i10, i11; };
-
-// same pivot rule as the device kernel (kernels.hip: invert_pivot)
-inline void invert_pivot(int w, double a, double b, double c, double colmax, double eps, double* inv,
-                         int* pos, int* neg, int* zero) {
-  if (w == 1) {
-    double ref = std::fmax(std::fabs(a), colmax);
-    if (!(std::fabs(a) > eps * ref) || ref == 0.0) { a = (ref > 0 ? eps * ref : 1.0); (*zero)++; }
-    else if (a > 0) (*pos)++; else (*neg)++;
-    inv[0] = 1.0 / a; inv[1] = 0; inv[2] = 0;
-  } else {
-    double det = a * c - b * b;
-    double ref = std::fmax(std::fabs(a * c), b * b);
-    if (!(std::fabs(det) > eps * ref) || ref == 0.0) {
-      (*zero) += 2;
-      det = (ref > 0 ? eps * ref : 1.0);
-      if (ref == 0.0) { a = 1.0; c = 1.0; b = 0.0; }
-    } else if (det < 0) { (*pos)++; (*neg)++; }
-    else if (a > 0) (*pos) += 2; else (*neg) += 2;
-    inv[0] = c / det; inv[1] = -b / det; inv[2] = a / det;
-  }
-}
+struct HostCtx {
+  int tid() const { return 0; }
+  int nthreads() const { return 1; }
+  void sync() {}
+  void argmax(double v, int i, double* vmax, int* imax) { *vmax = v; *imax = i; }
+  double maxval(double v) { return v; }
+  double sum(double v) { return v; }
+};
 }  // namespace
 
 extern "C" {
@@ -117,7 +104,9 @@ int ppsim_factor(void* h, const double* can, double* U, double* Dinv, double* S,
         for (int q = 0; q < w; ++q) colmax = std::fmax(colmax, std::fabs(acc[r * w + q]));
       colmax = std::fmax(colmax, std::fabs(dorig[0]));
       if (w == 2) colmax = std::fmax(colmax, std::fmax(std::fabs(dorig[1]), std::fabs(dorig[2])));
-      invert_pivot(w, a, b, c, colmax, eps, &Dinv[3 * (size_t)p], &pos, &neg, &zero);
+      pp::PivotResult pr = pp::invert_pivot(w, a, b, c, colmax, eps);
+      Dinv[3 * (size_t)p] = pr.i00; Dinv[3 * (size_t)p + 1] = pr.i10; Dinv[3 * (size_t)p + 2] = pr.i11;
+      pos += pr.code & 3; neg += (pr.code >> 2) & 3; zero += (pr.code >> 4) & 3;
     }
     for (int r = 0; r < nr; ++r)
       for (int q = 0; q < w; ++q) U[off + (int64_t)(t.r0 + r) * w + q] = acc[r * w + q];
@@ -202,6 +191,19 @@ void ppsim_backward(void* h, const double* U, const double* Dinv, double* W, dou
     }
   }
   for (int k = 0; k < P.n; ++k) x[P.perm[k]] = W[k];
+}
+
+// dense Bunch-Kaufman on a column-major n x n matrix (lower triangle read); info = (pos, neg, zero)
+void ppsim_bk_factor(int n, double* A, int* ipiv, int* info, double eps) {
+  HostCtx ctx;
+  std::vector<double> work(2 * (size_t)n);
+  pp::BkInfo bi;
+  pp::bk_factor(ctx, n, A, n, ipiv, work.data(), &bi, eps);
+  info[0] = bi.npos; info[1] = bi.nneg; info[2] = bi.nzero;
+}
+void ppsim_bk_solve(int n, const double* A, const int* ipiv, double* b) {
+  HostCtx ctx;
+  pp::bk_solve(ctx, n, A, n, ipiv, b);
 }
 
 }  // extern "C"

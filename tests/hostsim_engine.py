@@ -1,0 +1,144 @@
+"""TEST-ONLY numeric engine for HipSchurComplementLinearSolver built on the host interpreter
+(tests/hostsim).  It lets the CPU suite rehearse the solver class's host logic -- grouping,
+canonicalisation (quirk Q7), ownership, the two all-reduces, status agreement -- on machines
+without a GPU, including world_size-2 gloo runs.  The product never constructs it."""
+import ctypes
+
+import numpy as np
+
+import hostsim_util as hu
+
+
+class _SimGroup(object):
+    pass
+
+
+class HostSimEngine(object):
+    def __init__(self):
+        self.groups = []
+        self.nc = 0
+
+    def symbolic(self, nc, groups):
+        L = hu.lib()
+        self.nc = nc
+        self.groups = []
+        stats = []
+        for g in groups:
+            sg = _SimGroup()
+            sg.g = g
+            rep = None if g.rep_vals is None else np.ascontiguousarray(g.rep_vals, dtype=np.double)
+            sg.keep = [np.ascontiguousarray(a, dtype=np.int32) for a in (g.rowK, g.colK, g.rowB, g.colB)]
+            sg.h = ctypes.c_void_p(L.ppsim_create(g.n, nc, g.rowK.size, hu._ip(sg.keep[0]), hu._ip(sg.keep[1]),
+                                                  g.rowB.size, hu._ip(sg.keep[2]), hu._ip(sg.keep[3]),
+                                                  None if rep is None else hu._dp(rep), 0, -1, ctypes.c_double(-1.0)))
+            err = L.ppsim_error(sg.h)
+            if err:
+                raise RuntimeError(err.decode())
+            st = np.zeros(13, dtype=np.int64)
+            L.ppsim_stats(sg.h, st.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)))
+            sg.usize, sg.npiv = int(st[5]), int(st[2])
+            sg.batch = len(g.blocks)
+            sg.raw = None
+            self.groups.append(sg)
+            stats.append({'n': int(st[0]), 'n_pivots': int(st[2]), 'n_levels': int(st[3]), 'n_2x2': int(st[4]),
+                          'nnz_L': int(st[6])})
+        self.S = np.zeros((nc, nc))
+        self.tail = np.zeros(4)
+        return stats
+
+    def upload_values(self, gid, raw):
+        self.groups[gid].raw = np.array(raw, dtype=np.double, copy=True)
+
+    def numeric_local(self):
+        L = hu.lib()
+        nc = self.nc
+        self.S = np.zeros((nc, nc))
+        inertia = np.zeros(3, dtype=np.int64)
+        for sg in self.groups:
+            g = sg.g
+            sg.U, sg.Dinv = [], []
+            for b in range(sg.batch):
+                can = np.add.reduceat(sg.raw[b][g.can_idx], g.can_ptr[:-1]) if g.can_idx.size else np.zeros(0)
+                U = np.zeros(sg.usize)
+                D = np.zeros(3 * sg.npiv)
+                Sb = np.zeros((nc, nc))
+                L.ppsim_factor(sg.h, hu._dp(np.ascontiguousarray(can)), hu._dp(U), hu._dp(D), hu._dp(Sb),
+                               inertia.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), ctypes.c_double(1e-13))
+                self.S += np.tril(Sb) + np.tril(Sb, -1).T
+                sg.U.append(U)
+                sg.Dinv.append(D)
+        self.tail = np.array([inertia[2], inertia[0], inertia[1], 0.0], dtype=np.double)
+
+    def allreduce_schur(self, comm):
+        if comm.size > 1:
+            buf = comm.allreduce_sum(np.concatenate([self.S.ravel(), self.tail]))
+            self.S = buf[:-4].reshape(self.nc, self.nc)
+            self.tail = buf[-4:]
+
+    def factor_schur(self, Q):
+        self.Sfull = self.S + (0.0 if Q is None else Q)
+        n = self.nc
+        self.A = np.asfortranarray(np.tril(self.Sfull)).copy(order='F')
+        self.ipiv = np.zeros(max(n, 1), dtype=np.int32)
+        self.bk = np.zeros(3, dtype=np.int32)
+        if n > 0:
+            hu.lib().ppsim_bk_factor(n, hu._dp(self.A), hu._ip(self.ipiv), hu._ip(self.bk), ctypes.c_double(1e-14))
+
+    def status(self):
+        pos = int(round(self.tail[1])) + int(self.bk[0])
+        neg = int(round(self.tail[2])) + int(self.bk[1])
+        zero = int(round(self.tail[0])) + int(self.bk[2])
+        return (2 if zero > 0 else 0), pos, neg, zero
+
+    def get_schur(self):
+        return self.S.copy()
+
+    def upload_rhs(self, gid, rhs):
+        self.groups[gid].rhs = np.array(rhs, dtype=np.double, copy=True)
+
+    def solve_forward(self):
+        L = hu.lib()
+        self.rs = np.zeros(self.nc)
+        for sg in self.groups:
+            n = sg.g.n
+            sg.W = []
+            for b in range(sg.batch):
+                W = np.zeros(n + self.nc)
+                L.ppsim_forward(sg.h, hu._dp(sg.U[b]), hu._dp(sg.Dinv[b]), hu._dp(np.ascontiguousarray(sg.rhs[b])), hu._dp(W))
+                self.rs += W[n:]
+                sg.W.append(W)
+
+    def allreduce_rs(self, comm):
+        if comm.size > 1:
+            self.rs = comm.allreduce_sum(self.rs)
+
+    def solve_coupling(self, rc):
+        b = self.rs + (0.0 if rc is None else np.asarray(rc, dtype=np.double))
+        b = np.ascontiguousarray(b, dtype=np.double)
+        if self.nc > 0:
+            hu.lib().ppsim_bk_solve(self.nc, hu._dp(self.A), hu._ip(self.ipiv), hu._dp(b))
+        self.xc = b
+
+    def solve_backward(self):
+        L = hu.lib()
+        for sg in self.groups:
+            n = sg.g.n
+            sg.x = np.zeros((sg.batch, n))
+            for b in range(sg.batch):
+                W = sg.W[b].copy()
+                W[n:] = self.xc
+                x = np.zeros(n)
+                L.ppsim_backward(sg.h, hu._dp(sg.U[b]), hu._dp(sg.Dinv[b]), hu._dp(W), hu._dp(x))
+                sg.x[b] = x
+
+    def download_solution(self, gid, out):
+        out[...] = self.groups[gid].x
+
+    def coupling_solution(self):
+        return self.xc.copy()
+
+    def synchronize(self):
+        pass
+
+    def increase_memory_allocation(self, factor):
+        pass

@@ -15,7 +15,9 @@ def build_hostsim(force=False):
     so = os.path.join(HERE, 'hostsim', 'libpp_hostsim.so')
     srcs = [os.path.join(HERE, 'hostsim', 'hostsim.cpp'),
             os.path.join(ROOT, 'parapint_amd', 'csrc', 'symbolic.cpp'),
-            os.path.join(ROOT, 'parapint_amd', 'csrc', 'plan.hpp')]
+            os.path.join(ROOT, 'parapint_amd', 'csrc', 'plan.hpp'),
+            os.path.join(ROOT, 'parapint_amd', 'csrc', 'pivot.hpp'),
+            os.path.join(ROOT, 'parapint_amd', 'csrc', 'dense_bk.hpp')]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(['g++', '-O2', '-std=c++17', '-shared', '-fPIC', '-o', so, srcs[0], srcs[1]])
     return so
@@ -120,3 +122,15 @@ class HostSim(object):
             lib().ppsim_destroy(self.h)
         except Exception:
             pass
+
+
+def bk_factor_solve(S, rhs, eps=1e-14):
+    """Dense Bunch-Kaufman LDL^T (the algorithm the GPU runs on S) on the host: returns x, inertia."""
+    n = S.shape[0]
+    A = np.asfortranarray(np.tril(S), dtype=np.double).copy(order='F')
+    ipiv = np.zeros(n, dtype=np.int32)
+    info = np.zeros(3, dtype=np.int32)
+    lib().ppsim_bk_factor(n, _dp(A), _ip(ipiv), _ip(info), ctypes.c_double(eps))
+    b = np.ascontiguousarray(rhs, dtype=np.double).copy()
+    lib().ppsim_bk_solve(n, _dp(A), _ip(ipiv), _dp(b))
+    return b, tuple(int(v) for v in info)

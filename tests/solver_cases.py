@@ -1,0 +1,304 @@
+"""Parity cases shared by the CPU (host-interpreter engine) and GPU (HIP engine) suites.
+
+Every case drives HipSchurComplementLinearSolver / HipLDLInterface through the reference's
+LinearSolverInterface surface and checks against the oracle, the reference's golden vectors
+and dense algebra.  `make_engine` returns a fresh engine (None = product default, the GPU)."""
+import numpy as np
+import scipy.sparse as sp
+from scipy.sparse import coo_matrix
+from scipy.sparse.linalg import splu
+
+from oracle.schur_complement import MPISchurComplementLinearSolver as OracleMPISC
+from oracle.subsolvers import ScipyInterface as OracleScipy
+from parapint_amd.examples.performance.schur_complement.synthetic_kkt import SyntheticKKT
+from parapint_amd.linalg.comm import SerialComm
+from parapint_amd.linalg.hip_schur_complement import HipLDLInterface, HipSchurComplementLinearSolver
+from parapint_amd.linalg.results import LinearSolverStatus
+from parapint_amd.sparse.block_containers import BlockMatrix, BlockVector, MPIBlockMatrix, MPIBlockVector
+
+KNOWN_ANSWER = 0.3163456780448639      # parapint/examples/tests/test_examples.py:86, 99
+RESID_TOL = 1e-8                        # BASELINE.json: KKT residual <= 1e-8 vs reference
+
+
+def new_solver(make_engine, n_blocks=0, comm=None):
+    eng = make_engine()
+    return HipSchurComplementLinearSolver(subproblem_solvers={i: None for i in range(n_blocks)},
+                                          schur_complement_solver=None,
+                                          comm=SerialComm() if comm is None else comm, engine=eng)
+
+
+def scaled_residual(K, x, b):
+    K = sp.csr_matrix(K)
+    r = np.abs(K @ x - b).max()
+    return r / (np.abs(K).sum(axis=1).max() * np.abs(x).max() + np.abs(b).max())
+
+
+# ---- 3x3 sub-solver contract (linalg/tests/test_linear_solvers.py:13-23, 63-80) ------------------
+def case_sub_solver_contract(make_engine, golden):
+    mat = coo_matrix(([1, 7, 3, 7, 4, 3, 6], ([0, 0, 0, 1, 1, 2, 2], [0, 1, 2, 0, 1, 0, 2])),
+                     shape=(3, 3), dtype=np.double)
+    zero = mat.copy()
+    zero.data.fill(0)
+    solver = HipLDLInterface(engine=make_engine())
+    assert solver.do_symbolic_factorization(zero).status == LinearSolverStatus.successful
+    assert solver.do_numeric_factorization(mat).status == LinearSolverStatus.successful
+    for x_true, key in (([1., 2., 3.], 'sub3_x1'), ([4., 2., 3.], 'sub3_x2')):
+        x = solver.do_back_solve(mat * np.array(x_true))
+        assert np.allclose(x, x_true)
+        assert np.allclose(x, golden[key], rtol=1e-10, atol=1e-10)
+    assert solver.get_inertia() == tuple(golden['sub3_inertia'])
+    # MA27-wrapper semantics: only the lower triangle is read
+    low = sp.tril(mat).tocoo()
+    solver.do_numeric_factorization(low)
+    assert np.allclose(solver.do_back_solve(mat * np.array([1., 2., 3.])), [1., 2., 3.])
+
+
+# ---- 8x8 bordered system, symmetric variant (quirk Q5) -------------------------------------------
+def build_8x8(mpi, q11, upper=False):
+    k0 = np.array([[1, 0.5], [0.5, 1]])
+    k2 = np.array([[1, 1], [1, 3.]])
+    ks = [k0, np.eye(2), k2]
+    a = [np.array([[0, -1], [0, 0.]]), np.array([[-1, 0], [0, -1.]]), np.array([[0, 0], [-1, 0.]])]
+    if mpi:
+        A = MPIBlockMatrix(4, 4, np.array([[0, 0, 0, -1]] * 4), SerialComm())
+        rhs = MPIBlockVector(4, np.array([0, 0, 0, -1]), SerialComm())
+    else:
+        A = BlockMatrix(4, 4)
+        rhs = BlockVector(4)
+    for i in range(3):
+        A.set_block(i, i, coo_matrix(ks[i]))
+        A.set_block(3, i, coo_matrix(a[i]))
+        if upper:
+            A.set_block(i, 3, coo_matrix(a[i].T))
+    A.set_block(3, 3, coo_matrix(np.array([[0, 0], [0, q11]], dtype=np.double)))
+    for i, v in enumerate(([1, 0], [0, 0], [0, 1], [1, 1])):
+        rhs.set_block(i, np.array(v, dtype=np.double))
+    return A, rhs
+
+
+def case_bordered_8x8(make_engine, golden, mpi):
+    key = 'b8_sym_%s' % ('mpi' if mpi else 'ser')
+    A, rhs = build_8x8(mpi, 1.0 if mpi else 0.0)
+    solver = new_solver(make_engine, 3)
+    assert solver.do_symbolic_factorization(A).status == LinearSolverStatus.successful
+    assert solver.do_numeric_factorization(A).status == LinearSolverStatus.successful
+    x = solver.do_back_solve(rhs)
+    full = golden[key + '_full']
+    x1 = np.linalg.solve(full, golden[key + '_rhs'])
+    assert np.allclose(x1, x.flatten())
+    assert np.allclose(x.flatten(), golden[key + '_x'], rtol=1e-10, atol=1e-10)
+    eig = np.linalg.eigvals(full)
+    inertia = (np.count_nonzero(eig > 0), np.count_nonzero(eig < 0), np.count_nonzero(eig == 0))
+    assert solver.get_inertia() == inertia == tuple(golden[key + '_inertia'])
+    if mpi:
+        assert np.allclose(solver.get_schur_complement(), golden[key + '_S'], rtol=1e-12, atol=1e-12)
+    # the rhs must not be modified (MPI-class behaviour, quirk Q4) and a second numeric + solve works
+    assert np.array_equal(rhs.flatten(), golden[key + '_rhs'])
+    solver.do_numeric_factorization(A)
+    assert np.allclose(x1, solver.do_back_solve(rhs).flatten())
+    # result has the structure of the rhs
+    assert type(x) is type(rhs) and x.nblocks == 4
+
+
+# ---- small synthetic KKTs against the reference's own output -------------------------------------
+def case_small_synthetic(make_engine, golden, shape):
+    N, n_q, m, n_t = shape
+    key = 'syn_%d_%d_%d_%d' % shape
+    model = SyntheticKKT(N, n_q, m, n_t)
+    kkt = model.build_kkt(comm=SerialComm())
+    rhs = model.build_rhs(comm=SerialComm())
+    solver = new_solver(make_engine, N)
+    solver.do_symbolic_factorization(kkt)
+    solver.do_numeric_factorization(kkt)
+    x = solver.do_back_solve(rhs)
+    S = solver.get_schur_complement()
+    Sg = golden[key + '_S']
+    assert np.abs(S - Sg).max() <= 1e-9 * np.abs(Sg).max()
+    xg = golden[key + '_x']
+    assert np.abs(x.flatten() - xg).max() <= 1e-8 * np.abs(xg).max()
+    assert solver.get_inertia() == tuple(golden[key + '_inertia'])
+    assert abs(model.check_result(x) - float(golden[key + '_max_err'][0])) < 1e-8
+    assert len(solver.plan_stats) == 1          # identical patterns -> one batched group
+
+
+# ---- the reference's known answer (examples/tests/test_examples.py:76-99) ------------------------
+def case_known_answer(make_engine, golden):
+    model = SyntheticKKT(3, 500, 12, 10)
+    kkt = model.build_kkt(comm=SerialComm())
+    rhs = model.build_rhs(comm=SerialComm())
+    solver = new_solver(make_engine, 3)
+    solver.do_symbolic_factorization(kkt)
+    solver.do_numeric_factorization(kkt)
+    x = solver.do_back_solve(rhs)
+    err = model.check_result(x)
+    assert abs(err - KNOWN_ANSWER) < 5e-8                 # assertAlmostEqual, 7 places
+    assert abs(err - float(golden['known_answer_psc'][0])) < 1e-9
+    Sg = golden['known_answer_S']
+    assert np.abs(solver.get_schur_complement() - Sg).max() <= 1e-9 * np.abs(Sg).max()
+    assert np.allclose(x.get_block(3), golden['known_answer_xc'], rtol=1e-9, atol=1e-9)
+    K = kkt.tocoo()
+    assert scaled_residual(K, x.flatten(), rhs.flatten()) <= RESID_TOL
+    pos, neg, zero = solver.get_inertia()
+    assert zero == 0 and pos + neg == K.shape[0]
+
+
+# ---- configuration-2-shaped system against the oracle (full-space SuperLU + oracle SC) -----------
+def case_against_oracle(make_engine, shape, iteration=None, check_full_space=True):
+    N, n_q, m, n_t = shape
+    model = SyntheticKKT(N, n_q, m, n_t)
+    kkt = model.build_kkt(comm=SerialComm(), iteration=iteration)
+    rhs = model.build_rhs(comm=SerialComm())
+    solver = new_solver(make_engine, N)
+    solver.do_symbolic_factorization(kkt)
+    res = solver.do_numeric_factorization(kkt)
+    assert res.status == LinearSolverStatus.successful
+    x = solver.do_back_solve(rhs)
+    K = kkt.tocoo().tocsc()
+    b = rhs.flatten()
+    assert scaled_residual(K, x.flatten(), b) <= RESID_TOL
+    n_y = model.n_y
+    pos, neg, zero = solver.get_inertia()
+    # inertia of the synthetic KKT: (n_y + n_q) positive per block (+ n_theta), (n_y + n_theta) negative
+    assert (pos, neg, zero) == (N * (n_y + model.n_q) + n_t, N * (n_y + n_t), 0)
+    if check_full_space:
+        x_ref = splu(K).solve(b)
+        assert np.abs(x.flatten() - x_ref).max() <= 1e-8 * np.abs(x_ref).max()
+    return solver, model
+
+
+def case_oracle_schur(make_engine, shape):
+    """S and x against the oracle's restatement of the reference algorithm (n_c solves per block)."""
+    N, n_q, m, n_t = shape
+    model = SyntheticKKT(N, n_q, m, n_t)
+    kkt = model.build_kkt(comm=SerialComm(), iteration=3)
+    rhs = model.build_rhs(comm=SerialComm())
+    oracle = OracleMPISC({i: OracleScipy() for i in range(N)}, OracleScipy())
+    oracle.do_symbolic_factorization(kkt)
+    oracle.do_numeric_factorization(kkt)
+    x_o = oracle.do_back_solve(rhs)
+    solver = new_solver(make_engine, N)
+    solver.do_symbolic_factorization(kkt)
+    solver.do_numeric_factorization(kkt)
+    x = solver.do_back_solve(rhs)
+    S_o = oracle.schur_complement.toarray()
+    assert np.abs(solver.get_schur_complement() - S_o).max() <= 1e-9 * np.abs(S_o).max()
+    assert np.abs(x.flatten() - x_o.flatten()).max() <= 1e-8 * np.abs(x_o.flatten()).max()
+
+
+# ---- heterogeneous blocks: several pattern groups, nonzero Q, 2x2 pivots, duplicates (Q7) --------
+def random_kkt_block(n_x, n_c, seed, zero_h=0.25):
+    """Sparse saddle-point block [[H, J^T], [J, -1e-3 I]] with some zero Hessian diagonals;
+    redrawn (seed + 100) until it is comfortably nonsingular."""
+    while True:
+        rng = np.random.default_rng(seed)
+        h = rng.uniform(0.5, 2.0, size=n_x)
+        h[rng.random(n_x) < zero_h] = 0.0
+        J = sp.random(n_c, n_x, density=0.2, random_state=seed, data_rvs=lambda k: rng.normal(size=k)) + \
+            2.0 * sp.eye(n_c, n_x)
+        K = sp.bmat([[sp.diags(h), J.T], [J, -1e-3 * sp.eye(n_c)]]).tocoo()
+        if np.linalg.cond(K.toarray()) < 1e6:
+            return K
+        seed += 100
+
+
+def case_heterogeneous(make_engine):
+    rng = np.random.default_rng(11)
+    sizes = [(12, 5), (12, 5), (20, 8), (12, 5), (20, 8), (7, 3)]
+    seeds = [1, 1, 2, 1, 2, 3]                      # equal seed -> equal pattern -> same group
+    nc = 4
+    nb = len(sizes)
+    A = BlockMatrix(nb + 1, nb + 1)
+    rhs = BlockVector(nb + 1)
+    for i, ((n_x, n_c), seed) in enumerate(zip(sizes, seeds)):
+        K = random_kkt_block(n_x, n_c, seed)
+        vals = K.data * rng.uniform(0.8, 1.2, size=K.data.size)
+        K = coo_matrix((vals, (K.row, K.col)), shape=K.shape)
+        K = (K + K.T).tocoo()                       # symmetric values, both triangles
+        if i == 3:                                  # same pattern, shuffled COO order + split duplicates (Q7)
+            perm = rng.permutation(K.nnz)
+            r, c, d = K.row[perm], K.col[perm], K.data[perm]
+            K = coo_matrix((np.concatenate([0.25 * d, 0.75 * d]), (np.concatenate([r, r]), np.concatenate([c, c]))),
+                           shape=K.shape)
+        n = K.shape[0]
+        prng = np.random.default_rng(1000 + seeds[i])            # border pattern fixed per pattern family
+        cols = prng.choice(n, size=3, replace=False)
+        B = coo_matrix((rng.normal(size=3), (prng.choice(nc, size=3), cols)), shape=(nc, n))
+        A.set_block(i, i, K)
+        A.set_block(nb, i, B)
+        rhs.set_block(i, rng.normal(size=n))
+    Q = np.diag([0.5, 0.0, 1.0, 2.0])
+    Q[1, 0] = Q[0, 1] = 0.1
+    A.set_block(nb, nb, coo_matrix(Q))
+    rhs.set_block(nb, rng.normal(size=nc))
+    solver = new_solver(make_engine, nb)
+    solver.do_symbolic_factorization(A)
+    assert solver.do_numeric_factorization(A).status == LinearSolverStatus.successful
+    x = solver.do_back_solve(rhs)
+    assert len(solver.plan_stats) == 3
+    # dense reference of the full symmetric system
+    full = np.zeros(A.shape)
+    off = np.concatenate([[0], np.cumsum(A.row_block_sizes())])
+    for i in range(nb):
+        Kd = A.get_block(i, i).toarray()
+        full[off[i]:off[i + 1], off[i]:off[i + 1]] = np.tril(Kd) + np.tril(Kd, -1).T
+        Bd = A.get_block(nb, i).toarray()
+        full[off[nb]:, off[i]:off[i + 1]] = Bd
+        full[off[i]:off[i + 1], off[nb]:] = Bd.T
+    full[off[nb]:, off[nb]:] = Q
+    x_ref = np.linalg.solve(full, rhs.flatten())
+    assert np.abs(x.flatten() - x_ref).max() <= 1e-8 * np.abs(x_ref).max()
+    ev = np.linalg.eigvalsh(full)
+    assert solver.get_inertia() == (int((ev > 0).sum()), int((ev < 0).sum()), 0)
+    # values change, pattern and COO order change for one block: numeric again
+    K0 = A.get_block(0, 0)
+    perm = rng.permutation(K0.nnz)
+    A.set_block(0, 0, coo_matrix((1.5 * K0.data[perm], (K0.row[perm], K0.col[perm])), shape=K0.shape))
+    full[off[0]:off[1], off[0]:off[1]] *= 1.5
+    solver.do_numeric_factorization(A)
+    x = solver.do_back_solve(rhs)
+    x_ref = np.linalg.solve(full, rhs.flatten())
+    assert np.abs(x.flatten() - x_ref).max() <= 1e-8 * np.abs(x_ref).max()
+
+
+# ---- error behaviour ------------------------------------------------------------------------------
+def case_errors(make_engine):
+    import pytest
+    # non-square block structure -> ValueError (mpi_...:193-195)
+    solver = new_solver(make_engine, 1)
+    bad = BlockMatrix(2, 3)
+    with pytest.raises(ValueError):
+        solver.do_symbolic_factorization(bad)
+    # inertia / back-solve before numeric -> RuntimeError (ma27_interface.py:197-200)
+    A, rhs = build_8x8(False, 0.0)
+    solver = new_solver(make_engine, 3)
+    solver.do_symbolic_factorization(A)
+    with pytest.raises(RuntimeError):
+        solver.get_inertia()
+    # singular block: status when raise_on_error=False, RuntimeError otherwise (mpi_...:301-306)
+    A.set_block(1, 1, coo_matrix(np.array([[1.0, 1.0], [1.0, 1.0]])))
+    solver.do_symbolic_factorization(A)
+    res = solver.do_numeric_factorization(A, raise_on_error=False)
+    assert res.status == LinearSolverStatus.singular
+    assert solver.get_inertia()[2] >= 1
+    with pytest.raises(RuntimeError):
+        solver.do_numeric_factorization(A, raise_on_error=True)
+    # symbolic on a zero-valued copy (quirk Q8), then numeric with the real values
+    A, rhs = build_8x8(False, 0.0)
+    Z = BlockMatrix(4, 4)
+    for i in range(4):
+        for j in range(4):
+            blk = A.get_block(i, j)
+            if blk is not None:
+                z = blk.copy()
+                z.data[:] = 0.0
+                Z.set_block(i, j, z)
+    solver = new_solver(make_engine, 3)
+    solver.do_symbolic_factorization(Z)
+    solver.do_numeric_factorization(A)
+    x = solver.do_back_solve(rhs)
+    full = np.zeros((8, 8))
+    for i in range(3):
+        full[2 * i:2 * i + 2, 2 * i:2 * i + 2] = A.get_block(i, i).toarray()
+        full[6:, 2 * i:2 * i + 2] = A.get_block(3, i).toarray()
+        full[2 * i:2 * i + 2, 6:] = A.get_block(3, i).toarray().T
+    assert np.allclose(full @ x.flatten(), rhs.flatten())

@@ -1,0 +1,41 @@
+"""CPU suite: the solver class's host logic driven through the TEST-ONLY host-interpreter engine
+(the HIP kernels execute the same plan on the GPU; see tests/test_hip_solver.py for parity on device)."""
+import pytest
+
+import solver_cases as sc
+from hostsim_engine import HostSimEngine
+
+
+def make_engine():
+    return HostSimEngine()
+
+
+def test_sub_solver_contract(golden):
+    sc.case_sub_solver_contract(make_engine, golden)
+
+
+@pytest.mark.parametrize('mpi', [False, True])
+def test_bordered_8x8(golden, mpi):
+    sc.case_bordered_8x8(make_engine, golden, mpi)
+
+
+@pytest.mark.parametrize('shape', [(3, 20, 2, 4), (4, 50, 3, 6)])
+def test_small_synthetic(golden, shape):
+    sc.case_small_synthetic(make_engine, golden, shape)
+
+
+def test_known_answer(golden):
+    sc.case_known_answer(make_engine, golden)
+
+
+def test_against_oracle_small():
+    sc.case_against_oracle(make_engine, (6, 60, 3, 12), iteration=2)
+    sc.case_oracle_schur(make_engine, (5, 40, 2, 8))
+
+
+def test_heterogeneous_groups():
+    sc.case_heterogeneous(make_engine)
+
+
+def test_error_behaviour():
+    sc.case_errors(make_engine)

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from hostsim_util import HostSim
+from hostsim_util import HostSim, bk_factor_solve
 from parapint_amd.examples.performance.schur_complement.synthetic_kkt import SyntheticKKT
 
 
@@ -126,3 +126,34 @@ def test_singular_block_is_flagged():
     hs = HostSim(K, A)
     rc, S, inertia = hs.factor()
     assert rc == 2 and inertia[2] >= 1
+
+
+@pytest.mark.parametrize('n,kind', [(1, 'spd'), (2, 'indef'), (7, 'indef'), (40, 'indef'), (40, 'spd'),
+                                    (33, 'zero_diag'), (64, 'kkt')])
+def test_dense_bunch_kaufman(n, kind):
+    rng = np.random.default_rng(n)
+    M = rng.normal(size=(n, n))
+    if kind == 'spd':
+        S = M @ M.T + n * np.eye(n)
+    elif kind == 'indef':
+        S = M + M.T
+    elif kind == 'zero_diag':
+        S = M + M.T
+        np.fill_diagonal(S, 0.0)
+    else:
+        h = n // 2
+        S = np.zeros((n, n))
+        S[:h, :h] = np.diag(rng.uniform(1, 2, size=h))
+        S[h:, :h] = rng.normal(size=(n - h, h))
+        S[:h, h:] = S[h:, :h].T
+    b = rng.normal(size=n)
+    x, inertia = bk_factor_solve(S, b)
+    assert np.allclose(S @ x, b, rtol=1e-9, atol=1e-9)
+    ev = np.linalg.eigvalsh(S)
+    assert inertia == (int((ev > 0).sum()), int((ev < 0).sum()), 0)
+
+
+def test_dense_bunch_kaufman_singular():
+    S = np.array([[1.0, 2.0, 0.0], [2.0, 4.0, 0.0], [0.0, 0.0, 0.0]])
+    x, inertia = bk_factor_solve(S, np.ones(3))
+    assert inertia[2] >= 1
