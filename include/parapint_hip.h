@@ -72,6 +72,11 @@ int pp_upload_values(pp_handle h, int group, const double* raw, int on_device);
  * values on the device (no copy needed before pp_numeric_local). */
 double* pp_raw_buffer(pp_handle h, int group);
 
+/* Zero-copy alternative: make the kernels read the group's raw values directly from a caller-owned
+ * device buffer ([batch][nraw]); NULL restores the library's own buffer.  The buffer must stay
+ * valid until pp_numeric_local has completed on the stream. */
+int pp_bind_raw_buffer(pp_handle h, int group, double* dev_ptr);
+
 /* Batched block factorisation + local Schur contribution: K_i = L D L^T for every local block
  * (mpi_...:292-299) and S_local = -sum_i A_i K_i^{-1} A_i^T (mpi_...:312-333).  Result is left
  * in the Schur buffer; block inertia and the singular-pivot count ride in its 4-double tail. */
@@ -100,6 +105,8 @@ int pp_get_schur(pp_handle h, double* S_host);
 /* Right-hand sides of a group's blocks, [batch][n] row-major. */
 int pp_upload_rhs(pp_handle h, int group, const double* rhs, int on_device);
 double* pp_rhs_buffer(pp_handle h, int group);
+/* Zero-copy alternative for right-hand sides already resident on the device (NULL restores). */
+int pp_bind_rhs_buffer(pp_handle h, int group, double* dev_ptr);
 /* Forward elimination of all local blocks; leaves r_s_local = -sum_i A_i K_i^{-1} r_i
  * (mpi_...:381-385) in the rs buffer (n_c doubles, device) for the caller's all-reduce (:387). */
 int pp_solve_forward(pp_handle h);
@@ -120,6 +127,20 @@ int pp_get_coupling_solution(pp_handle h, double* xc_host);
 int pp_increase_memory_allocation(pp_handle h, double factor);
 /* Blocks until the handle's stream is idle. */
 int pp_synchronize(pp_handle h);
+
+/* Phase timing with HIP events on the handle's stream (measurement only, SURVEY.md section 5.1
+ * timer labels): pp_profile(h, 1) resets and enables, pp_phase_times returns accumulated
+ * milliseconds, kernel launches and bracket counts for the phases
+ *   0 assemble (transpose + scatter)      'form SC/factorize' input
+ *   1 block factorisation levels          'form SC/factorize'
+ *   2 inertia count + Schur tiles/reduce  'form SC/back solve + dot product'
+ *   3 dense S: add Q + Bunch-Kaufman      'factor SC'
+ *   4 forward substitution levels         'back_solve'
+ *   5 coupling rows of the forward sweep  'back_solve'
+ *   6 coupling solve with the S factor    'back_solve'
+ *   7 back substitution levels            'back_solve' */
+int pp_profile(pp_handle h, int enable);
+int pp_phase_times(pp_handle h, double ms_out[8], int32_t launches_out[8], int32_t calls_out[8]);
 
 /* Per-group plan statistics.  out[16]:
  *  0 n, 1 n_coupling, 2 batch, 3 n_pivots, 4 n_2x2, 5 n_levels, 6 nnz(L), 7 U doubles per instance,

@@ -1,0 +1,69 @@
+"""CPU baseline = the oracle's restatement of the reference algorithm, timed.  TEST/BENCH
+INFRASTRUCTURE ONLY (bench.py's ``cpu_baseline`` leg); never on the product path.
+
+Per block exactly what parapint does with its SciPy sub-solver (the one its CI runs):
+  splu(K_i)                                   mpi_explicit_schur_complement.py:292-299, scipy_interface.py:26-31
+  for each nonzero border row r:              mpi_...:313-333
+      x = lu.solve(dense copy of A_i[r, :]);  S[:, r] -= A_i x
+  two more solves + two SpMV for the back-solve   mpi_...:381-396
+Blocks are independent, so the sample is spread over worker processes (one per core) the way the
+reference spreads blocks over MPI ranks; the dense S factorisation and the collectives are
+negligible at these sizes and left out (stated in DESIGN.md).
+"""
+import os
+import time
+
+import numpy as np
+
+
+def _time_blocks(args):
+    n_q, m, n_theta, block_ids, iteration = args
+    from scipy.sparse.linalg import splu
+    from parapint_amd.examples.performance.schur_complement.synthetic_kkt import SyntheticKKT
+    model = SyntheticKKT(max(block_ids) + 1, n_q, m, n_theta, local_blocks=block_ids)
+    A = model.border_matrix().tocsr()
+    nz_rows = np.diff(A.indptr).nonzero()[0]
+    mats = [model.block_matrix(b, iteration).tocsc() for b in block_ids]
+    rhs = [model.block_rhs(b) for b in block_ids]
+    S = np.zeros((n_theta, n_theta))
+    t0 = time.perf_counter()
+    for K, r in zip(mats, rhs):
+        lu = splu(K)
+        col = np.zeros(K.shape[0])
+        for row in nz_rows:
+            lo, hi = A.indptr[row], A.indptr[row + 1]
+            col[A.indices[lo:hi]] += A.data[lo:hi]
+            S[nz_rows, row] -= A.dot(lu.solve(col))[nz_rows]
+            col[A.indices[lo:hi]] -= A.data[lo:hi]
+        contrib = A.dot(lu.solve(r))                      # forward part of the back-solve
+        x = lu.solve(r - A.T.dot(contrib))                # second solve with the coupling correction
+        S[0, 0] += 0.0 * x[0]
+    return time.perf_counter() - t0
+
+
+def run(n_blocks_total, n_q, m, n_theta, blocks_per_worker=6, workers=None, iteration=0):
+    """Returns dict(value=it/s extrapolated to n_blocks_total, cores, sample, seconds)."""
+    import multiprocessing as mp
+    if workers is None:
+        workers = min(os.cpu_count() or 1, 16)
+    jobs = [(n_q, m, n_theta, list(range(w * blocks_per_worker, (w + 1) * blocks_per_worker)), iteration)
+            for w in range(workers)]
+    ctx = mp.get_context('fork')
+    t0 = time.perf_counter()
+    with ctx.Pool(workers) as pool:
+        per_worker = pool.map(_time_blocks, jobs)
+    wall = time.perf_counter() - t0
+    busy = max(per_worker)                                # slowest worker = the parallel time
+    blocks = workers * blocks_per_worker
+    blocks_per_s = blocks / busy
+    return {
+        'value': blocks_per_s / n_blocks_total,
+        'unit': 'it/s',
+        'cores': workers,
+        'kind': 'port',
+        'sample': '%d of %d blocks (%d per worker process), SciPy SuperLU sub-solver, reference algorithm '
+                  '(1 factorisation + %d single-rhs solves + 2 back-solves per block), extrapolated linearly in '
+                  'the block count; slowest worker %.2f s, wall %.2f s' %
+                  (blocks, n_blocks_total, blocks_per_worker, n_theta, busy, wall),
+        'seconds': busy,
+    }

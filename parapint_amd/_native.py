@@ -27,6 +27,7 @@ SIGNATURES = {
     'pp_end_symbolic': (ctypes.c_int, [ctypes.c_void_p]),
     'pp_upload_values': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]),
     'pp_raw_buffer': (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int]),
+    'pp_bind_raw_buffer': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     'pp_numeric_local': (ctypes.c_int, [ctypes.c_void_p]),
     'pp_schur_buffer': (ctypes.c_void_p, [ctypes.c_void_p]),
     'pp_bind_schur_buffer': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
@@ -35,6 +36,7 @@ SIGNATURES = {
     'pp_get_schur': (ctypes.c_int, [ctypes.c_void_p, _f64p]),
     'pp_upload_rhs': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]),
     'pp_rhs_buffer': (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int]),
+    'pp_bind_rhs_buffer': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     'pp_solve_forward': (ctypes.c_int, [ctypes.c_void_p]),
     'pp_rs_buffer': (ctypes.c_void_p, [ctypes.c_void_p]),
     'pp_bind_rs_buffer': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
@@ -45,6 +47,8 @@ SIGNATURES = {
     'pp_get_coupling_solution': (ctypes.c_int, [ctypes.c_void_p, _f64p]),
     'pp_increase_memory_allocation': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double]),
     'pp_synchronize': (ctypes.c_int, [ctypes.c_void_p]),
+    'pp_profile': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    'pp_phase_times': (ctypes.c_int, [ctypes.c_void_p, _f64p, _i32p, _i32p]),
     'pp_group_stats': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _i64p]),
     'pp_group_perm': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _i32p]),
 }
@@ -61,6 +65,10 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own HIP runtime (libamdhip64.so, SONAME libamdhip64.so.7); it must be the
+    # one already mapped when our library is opened so the process holds a single HIP/HSA runtime
+    # (our kernels run on torch's streams and RCCL buffers).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError('parapint_amd: %s is not built (run __graft_entry__.build()); '
                            'there is no CPU fallback for the HIP solver' % LIB_PATH)
@@ -91,8 +99,9 @@ class NativeSolver(object):
         h = ctypes.c_void_p()
         rc = self.lib.pp_create(ctypes.byref(h), int(device), ctypes.c_void_p(stream or 0))
         if rc != 0 or not h:
-            raise RuntimeError('parapint_amd: pp_create failed (status %d): no usable HIP device; '
-                               'the solver has no CPU fallback' % rc)
+            msg = self.lib.pp_last_error(None)
+            raise RuntimeError('parapint_amd: pp_create failed (status %d: %s): no usable HIP device; '
+                               'the solver has no CPU fallback' % (rc, msg.decode() if msg else ''))
         self.h = h
 
     def close(self):

@@ -29,6 +29,7 @@
 namespace {
 
 constexpr int WAVE = 64;
+constexpr int PP_NPHASE = 8;  // assemble, factor, schur, dense, fwd, fwd_coupling, coupling_solve, bwd
 constexpr int BK_THREADS = 512;
 constexpr double PIVOT_EPS = 1e-13;
 constexpr double BK_EPS = 1e-14;
@@ -470,6 +471,7 @@ struct Group {
   std::vector<int> can_ptr, can_idx;
   std::vector<void*> allocs;
   int ntiles = 0;
+  double *raw_own = nullptr, *rhs_own = nullptr;
 };
 
 }  // namespace
@@ -485,6 +487,14 @@ struct pp_solver {
   int *ipiv = nullptr, *bkinfo = nullptr, *counters = nullptr;
   double mem_factor = 1.0;
   std::string err;
+  // optional phase timing (HIP events on the handle's stream)
+  bool profile = false;
+  hipEvent_t ev[PP_NPHASE + 1][2];
+  bool ev_made = false;
+  bool ev_used[PP_NPHASE] = {};
+  double phase_ms[PP_NPHASE] = {};
+  int phase_launches[PP_NPHASE] = {};
+  int phase_calls[PP_NPHASE] = {};
 };
 
 namespace {
@@ -493,6 +503,32 @@ int fail(pp_handle h, int status, const std::string& msg) {
   if (h) h->err = msg;
   return status;
 }
+
+// phase bracket: records events only in profile mode; durations are harvested lazily
+struct PhaseScope {
+  pp_handle h; int ph;
+  PhaseScope(pp_handle h_, int ph_, int launches) : h(h_), ph(ph_) {
+    if (!h->profile) return;
+    if (!h->ev_made) {
+      for (int i = 0; i < PP_NPHASE; ++i) { (void)hipEventCreate(&h->ev[i][0]); (void)hipEventCreate(&h->ev[i][1]); }
+      h->ev_made = true;
+    }
+    if (h->ev_used[ph]) {   // harvest the previous bracket of this phase
+      (void)hipEventSynchronize(h->ev[ph][1]);
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, h->ev[ph][0], h->ev[ph][1]) == hipSuccess) h->phase_ms[ph] += ms;
+      h->ev_used[ph] = false;
+    }
+    h->phase_launches[ph] += launches;
+    h->phase_calls[ph] += 1;
+    (void)hipEventRecord(h->ev[ph][0], h->stream);
+  }
+  ~PhaseScope() {
+    if (!h->profile) return;
+    (void)hipEventRecord(h->ev[ph][1], h->stream);
+    h->ev_used[ph] = true;
+  }
+};
 
 #define PP_HIP(call)                                                                                   \
   do {                                                                                                 \
@@ -540,15 +576,26 @@ void free_globals(pp_handle h) {
 // ==========================================================================================
 extern "C" {
 
+static std::string g_create_error;
+
 int pp_create(pp_handle* out, int device, void* stream) {
   if (!out) return 3;
   *out = nullptr;
   int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return 3;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    g_create_error = std::string("hipGetDeviceCount: ") + hipGetErrorString(e) + " (devices: " + std::to_string(ndev) + ")";
+    return 3;
+  }
   pp_handle h = new pp_solver();
   if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
   h->device = device;
-  if (hipSetDevice(device) != hipSuccess) { delete h; return 3; }
+  e = hipSetDevice(device);
+  if (e != hipSuccess) {
+    g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
+    delete h;
+    return 3;
+  }
   h->stream = (hipStream_t)stream;
   *out = h;
   return 0;
@@ -560,10 +607,12 @@ void pp_destroy(pp_handle h) {
   (void)hipStreamSynchronize(h->stream);
   for (Group* g : h->groups) free_group(g);
   free_globals(h);
+  if (h->ev_made)
+    for (int i = 0; i < PP_NPHASE; ++i) { (void)hipEventDestroy(h->ev[i][0]); (void)hipEventDestroy(h->ev[i][1]); }
   delete h;
 }
 
-const char* pp_last_error(pp_handle h) { return h ? h->err.c_str() : "null handle"; }
+const char* pp_last_error(pp_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 int pp_begin_symbolic(pp_handle h, int n_coupling) {
   if (!h) return 3;
@@ -657,11 +706,13 @@ int pp_end_symbolic(pp_handle h) {
     g->ntiles = (int)P.stile_a.size();
     const size_t bp = (size_t)d.bpad;
     if ((rc = dev_alloc(h, g, &d.raw, (size_t)g->batch * g->nraw))) return rc;
+    g->raw_own = d.raw;
     if ((rc = dev_alloc(h, g, &d.rawT, (size_t)g->nraw * bp))) return rc;
     if ((rc = dev_alloc(h, g, &d.U, (size_t)P.usize * bp))) return rc;
     if ((rc = dev_alloc(h, g, &d.Dinv, (size_t)3 * P.npiv * bp))) return rc;
     if ((rc = dev_alloc(h, g, &d.W, (size_t)(P.n + nc) * bp))) return rc;
     if ((rc = dev_alloc(h, g, &d.rhs, (size_t)g->batch * P.n))) return rc;
+    g->rhs_own = d.rhs;
     if ((rc = dev_alloc(h, g, &d.rhsT, (size_t)P.n * bp))) return rc;
     if ((rc = dev_alloc(h, g, &d.xout, (size_t)g->batch * P.n))) return rc;
     if ((rc = dev_alloc(h, g, &d.Spart, (size_t)d.nchunk * std::max(g->ntiles, 1) * 64))) return rc;
@@ -719,20 +770,29 @@ int pp_numeric_local(pp_handle h) {
   for (Group* g : h->groups) {
     const pp::Plan& P = g->plan;
     GroupDev& d = g->dev;
-    if (d.nraw > 0)
-      hipLaunchKernelGGL(k_transpose_in, dim3((d.nraw + 63) / 64, d.nchunk), dim3(256), 0, st, d.raw, d.rawT, d.batch,
-                         d.nraw, d.bpad);
-    hipLaunchKernelGGL(k_assemble, dim3((unsigned)((P.usize + 3) / 4), d.nchunk), dim3(256), 0, st, d);
-    const size_t lds = (size_t)P.opt.acc_doubles * 64 * sizeof(double);
-    for (int l = 0; l < P.n_levels; ++l) {
-      const int t0 = P.flevel_ptr[l], nt = P.flevel_ptr[l + 1] - t0;
-      if (nt > 0) hipLaunchKernelGGL(k_factor_level, dim3(nt, d.nchunk), dim3(64), lds, st, d, t0, PIVOT_EPS);
+    {
+      PhaseScope ps(h, 0, 2);
+      if (d.nraw > 0)
+        hipLaunchKernelGGL(k_transpose_in, dim3((d.nraw + 63) / 64, d.nchunk), dim3(256), 0, st, d.raw, d.rawT, d.batch,
+                           d.nraw, d.bpad);
+      hipLaunchKernelGGL(k_assemble, dim3((unsigned)((P.usize + 3) / 4), d.nchunk), dim3(256), 0, st, d);
     }
-    hipLaunchKernelGGL(k_count_codes, dim3(std::min(1024, (int)(((size_t)P.npiv * d.bpad + 255) / 256))), dim3(256), 0,
-                       st, d.codes, P.npiv, d.batch, d.bpad, h->counters);
-    if (g->ntiles > 0) {
-      hipLaunchKernelGGL(k_schur_tiles, dim3(g->ntiles, d.nchunk), dim3(64), 0, st, d);
-      hipLaunchKernelGGL(k_schur_reduce, dim3(g->ntiles), dim3(64), 0, st, d, g->ntiles, h->S);
+    {
+      PhaseScope ps(h, 1, P.n_levels);
+      const size_t lds = (size_t)P.opt.acc_doubles * 64 * sizeof(double);
+      for (int l = 0; l < P.n_levels; ++l) {
+        const int t0 = P.flevel_ptr[l], nt = P.flevel_ptr[l + 1] - t0;
+        if (nt > 0) hipLaunchKernelGGL(k_factor_level, dim3(nt, d.nchunk), dim3(64), lds, st, d, t0, PIVOT_EPS);
+      }
+    }
+    {
+      PhaseScope ps(h, 2, 3);
+      hipLaunchKernelGGL(k_count_codes, dim3(std::min(1024, (int)(((size_t)P.npiv * d.bpad + 255) / 256))), dim3(256),
+                         0, st, d.codes, P.npiv, d.batch, d.bpad, h->counters);
+      if (g->ntiles > 0) {
+        hipLaunchKernelGGL(k_schur_tiles, dim3(g->ntiles, d.nchunk), dim3(64), 0, st, d);
+        hipLaunchKernelGGL(k_schur_reduce, dim3(g->ntiles), dim3(64), 0, st, d, g->ntiles, h->S);
+      }
     }
   }
   hipLaunchKernelGGL(k_write_tail, dim3(1), dim3(64), 0, st, h->counters, h->S + (size_t)nc * nc);
@@ -758,6 +818,7 @@ int pp_factor_schur(pp_handle h, const double* Q_host) {
   const size_t nn = (size_t)nc * nc;
   if (nc > 0) {
     if (Q_host) PP_HIP(hipMemcpyAsync(h->Qd, Q_host, nn * sizeof(double), hipMemcpyHostToDevice, st));
+    PhaseScope ps(h, 3, 2);
     hipLaunchKernelGGL(k_add_q, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, h->S, Q_host ? h->Qd : nullptr,
                        h->Sfac, nc);
     hipLaunchKernelGGL(k_bk_factor, dim3(1), dim3(BK_THREADS), 0, st, nc, h->Sfac, h->ipiv, h->work, h->bkinfo);
@@ -817,13 +878,17 @@ int pp_solve_forward(pp_handle h) {
   for (Group* g : h->groups) {
     const pp::Plan& P = g->plan;
     GroupDev& d = g->dev;
-    hipLaunchKernelGGL(k_transpose_in, dim3((P.n + 63) / 64, d.nchunk), dim3(256), 0, st, d.rhs, d.rhsT, d.batch, P.n,
-                       d.bpad);
-    for (int l = 0; l < P.n_levels; ++l) {
-      const int p0 = P.lvl_ptr[l], np = P.lvl_ptr[l + 1] - p0;
-      if (np > 0) hipLaunchKernelGGL(k_fwd_level, dim3(np, d.nchunk), dim3(64), 0, st, d, p0);
+    {
+      PhaseScope ps(h, 4, P.n_levels + 1);
+      hipLaunchKernelGGL(k_transpose_in, dim3((P.n + 63) / 64, d.nchunk), dim3(256), 0, st, d.rhs, d.rhsT, d.batch, P.n,
+                         d.bpad);
+      for (int l = 0; l < P.n_levels; ++l) {
+        const int p0 = P.lvl_ptr[l], np = P.lvl_ptr[l + 1] - p0;
+        if (np > 0) hipLaunchKernelGGL(k_fwd_level, dim3(np, d.nchunk), dim3(64), 0, st, d, p0);
+      }
     }
     if (nc > 0) {
+      PhaseScope ps(h, 5, 2);
       hipLaunchKernelGGL(k_fwd_coupling, dim3(nc, d.nchunk), dim3(64), 0, st, d);
       hipLaunchKernelGGL(k_rs_reduce, dim3((nc + 255) / 256), dim3(256), 0, st, d, h->rs);
     }
@@ -847,6 +912,7 @@ int pp_solve_coupling(pp_handle h, const double* rc_host) {
   const int nc = h->nc;
   if (nc == 0) return 0;
   if (rc_host) PP_HIP(hipMemcpyAsync(h->rcd, rc_host, (size_t)nc * sizeof(double), hipMemcpyHostToDevice, st));
+  PhaseScope ps(h, 6, 1);
   hipLaunchKernelGGL(k_coupling_solve, dim3(1), dim3(BK_THREADS), 0, st, nc, h->Sfac, h->ipiv,
                      rc_host ? h->rcd : nullptr, h->rs, h->xc);
   PP_HIP(hipGetLastError());
@@ -860,6 +926,7 @@ int pp_solve_backward(pp_handle h) {
   for (Group* g : h->groups) {
     const pp::Plan& P = g->plan;
     GroupDev& d = g->dev;
+    PhaseScope ps(h, 7, P.n_levels + 1);
     for (int l = P.n_levels - 1; l >= 0; --l) {
       const int p0 = P.lvl_ptr[l], np = P.lvl_ptr[l + 1] - p0;
       if (np > 0) hipLaunchKernelGGL(k_bwd_level, dim3(np, d.nchunk), dim3(64), 0, st, d, p0, h->xc);
@@ -892,6 +959,46 @@ int pp_get_coupling_solution(pp_handle h, double* xc_host) {
   PP_HIP(hipSetDevice(h->device));
   if (h->nc > 0) PP_HIP(hipMemcpyAsync(xc_host, h->xc, (size_t)h->nc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   PP_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int pp_bind_raw_buffer(pp_handle h, int group, double* dev_ptr) {
+  Group* g = get_group(h, group);
+  if (!g || !h->symbolic_done) return fail(h, 3, "pp_bind_raw_buffer: bad group");
+  g->dev.raw = dev_ptr ? dev_ptr : g->raw_own;
+  return 0;
+}
+
+int pp_bind_rhs_buffer(pp_handle h, int group, double* dev_ptr) {
+  Group* g = get_group(h, group);
+  if (!g || !h->symbolic_done) return fail(h, 3, "pp_bind_rhs_buffer: bad group");
+  g->dev.rhs = dev_ptr ? dev_ptr : g->rhs_own;
+  return 0;
+}
+
+int pp_profile(pp_handle h, int enable) {
+  if (!h) return 3;
+  h->profile = enable != 0;
+  for (int i = 0; i < PP_NPHASE; ++i) {
+    h->phase_ms[i] = 0.0; h->phase_launches[i] = 0; h->phase_calls[i] = 0; h->ev_used[i] = false;
+  }
+  return 0;
+}
+
+int pp_phase_times(pp_handle h, double ms_out[8], int32_t launches_out[8], int32_t calls_out[8]) {
+  if (!h) return 3;
+  PP_HIP(hipSetDevice(h->device));
+  PP_HIP(hipStreamSynchronize(h->stream));
+  for (int i = 0; i < PP_NPHASE; ++i) {
+    if (h->ev_used[i]) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, h->ev[i][0], h->ev[i][1]) == hipSuccess) h->phase_ms[i] += ms;
+      h->ev_used[i] = false;
+    }
+    ms_out[i] = h->phase_ms[i];
+    launches_out[i] = h->phase_launches[i];
+    calls_out[i] = h->phase_calls[i];
+  }
   return 0;
 }
 
