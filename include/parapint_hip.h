@@ -93,6 +93,13 @@ int pp_bind_schur_buffer(pp_handle h, double* dev_ptr);
  * Q: dense column-major n_c x n_c on the host (lower triangle read), or NULL for Q = 0. */
 int pp_factor_schur(pp_handle h, const double* Q_host);
 
+/* Dense policy for S: 0 (default) = blocked LDL^T without pivoting on the fp64 matrix cores,
+ * accepted only when all pivots share one sign (S definite), with the Bunch-Kaufman kernel as the
+ * on-device fallback; 1 = Bunch-Kaufman only.  pp_get_dense_mode reports which factor the last
+ * pp_factor_schur produced (1 = blocked LDL^T accepted, 0 = Bunch-Kaufman). */
+int pp_set_dense_policy(pp_handle h, int policy);
+int pp_get_dense_mode(pp_handle h, int* mode_out);
+
 /* Synchronises the stream and returns {status, pos, neg, zero} of the whole matrix:
  * sum of block inertias (all ranks, taken from the all-reduced tail) + inertia(S)
  * (get_inertia, mpi_...:404-436).  status is 2 (singular) if any pivot was numerically zero. */

@@ -27,20 +27,23 @@
 namespace pp {
 
 struct PlanOptions {
-  int acc_doubles = 32;   // LDS accumulator doubles per lane for one factor task (rows*w)
+  int max_task_entries = 96;   // update entries per factor task (rows of a panel are chunked to fit)
+  int max_task_mults = 62;     // multiplier scalars per factor task (LDS table, 512 B each)
   int tile = 8;           // register tile edge of the Schur (SYRK) kernel
   int md_delta_abs = 3;   // minimum-degree tolerance (absolute) for height-aware selection
   double md_delta_rel = 0.5;   // ... and relative to the current minimum degree
   double pivot_threshold = 0.01;  // 1x1 pivot accepted if |d| >= threshold * max|row| (MA27 cntl(1) analogue)
 };
 
-// factor task: rows [r0, r1) of panel `piv` (slot numbering: 0..w-1 = pivot block rows)
-struct FTask { int piv, r0, r1, src0, src1; };
-// one descendant pivot k contributing to a task; mslot = slot of the target pivot's
-// first row inside panel k (its w rows are consecutive slots)
-struct FSrc { int k, mslot, run0, run1; };
-// len consecutive rows: panel k slots [src, src+len) -> task-relative rows [dst, dst+len)
-struct Run { int src, dst, len; };
+// Factor task = rows [r0, r1) of panel `piv` (slot numbering: 0..w-1 = pivot block rows), in
+// flat scalar form.  Destination scalar d (0 <= d < (r1-r0)*w, U position dst_pos0 + d) is
+//     sum over its entries e of  - src(e) * M[midx(e)]
+// where src(e) is U[pos] (pos >= 0) or the canonical input value ~pos (pos < 0, assembly fused
+// into the factorisation), M[0] = -1 and M[1 + j] = Dinv[d0]*U[u0] (+ Dinv[d1]*U[u1]) is the
+// j-th multiplier scalar of the task (MRec).  All loads of a task are independent.
+struct FTask { int piv, r0, r1, m0, m1, dptr0; };
+struct MRec { int d0, u0, d1, u1; };
+struct FEntry { int src, midx; };
 // Schur tile record: pivot p contributes to tile (ta, tb); slots (or -1) of the tile's
 // coupling rows inside panel p
 struct STileRec { int piv; int slotA[8]; int slotB[8]; };
@@ -55,18 +58,23 @@ struct Plan {
   std::vector<int> piv_rowptr, rowidx;   // rows below pivot p (new indices; n+c = coupling row c)
   std::vector<int64_t> piv_uoff;         // panel offset, doubles per lane
   int64_t usize = 0;                     // doubles per lane in U storage
+  std::vector<int> piv_doff;             // offset of inv(P_p) in Dinv storage: 1 scalar (1x1) or 3 (i00,i10,i11)
+  int dsize = 0;                         // doubles per lane in Dinv storage
   std::vector<int64_t> pos_of_can;       // canonical input entry -> U position
   std::vector<int> piv_level;            // etree height of pivot
   // factor schedule
   std::vector<FTask> ftasks;             // sorted by level
-  std::vector<FSrc> fsrcs;
-  std::vector<Run> runs;
+  std::vector<MRec> mrecs;
+  std::vector<int> fdst_ptr;             // per task (ndst + 1) offsets into fentries, at dptr0
+  std::vector<FEntry> fentries;
   std::vector<int> flevel_ptr;           // n_levels+1 -> ftasks
+  std::vector<int> flevel_maxm;          // per level: max multiplier scalars of a task (LDS sizing)
+  // forward-solve entries: scalar row (new column index c) = b_c - sum U[upos] * z[zcol]
+  std::vector<int> sfwd_eptr;            // n+1 -> sfwd_upos / sfwd_zcol
+  std::vector<int> sfwd_upos, sfwd_zcol;
+  std::vector<int> crow_eptr, crow_upos, crow_zcol;  // same for the coupling rows
   // solve schedule
   std::vector<int> lvl_ptr, lvl_piv;     // pivots by level
-  std::vector<int> sfwd_ptr;             // npiv+1 -> sfwd_k / sfwd_mslot (row pattern of p)
-  std::vector<int> sfwd_k, sfwd_mslot;
-  std::vector<int> crow_ptr, crow_k, crow_slot;  // per coupling row: panels holding it
   // Schur (SYRK) schedule
   std::vector<int> stile_a, stile_b, stile_ptr;  // tiles (ta>=tb) and record ranges
   std::vector<STileRec> stile_rec;

@@ -39,12 +39,11 @@ constexpr double BK_EPS = 1e-14;
 struct GroupDev {
   int n, nc, batch, bpad, nchunk, npiv, nraw;
   int64_t usize;
-  const int *piv_w, *piv_start, *piv_uoff, *piv_rowptr, *rowidx, *perm, *iperm;
-  const int *ftask, *fsrc, *runs;
-  const int *lvl_piv, *sfwd_ptr, *sfwd_k, *sfwd_mslot;
-  const int *crow_ptr, *crow_k, *crow_slot;
+  const int *piv_w, *piv_start, *piv_uoff, *piv_doff, *piv_rowptr, *rowidx, *perm, *iperm;
+  const int *ftask, *mrec, *fdst_ptr, *fent;
+  const int *lvl_piv, *sfwd_eptr, *sfwd_upos, *sfwd_zcol;
+  const int *crow_eptr, *crow_upos, *crow_zcol;
   const int *stile_a, *stile_b, *stile_ptr, *stile_rec;
-  const int *asm_ptr, *asm_idx;
   double *raw, *rawT, *U, *Dinv, *W, *rhs, *rhsT, *xout, *Spart, *rspart;
   unsigned char* codes;
 };
@@ -84,104 +83,106 @@ __global__ __launch_bounds__(256) void k_transpose_out(const double* __restrict_
   }
 }
 
-// U[pos][b] = sum of the raw entries mapped to pos (0 for fill positions)
-__global__ __launch_bounds__(256) void k_assemble(GroupDev g) {
-  const int lane = threadIdx.x & 63;
-  const int64_t pos = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (pos >= g.usize) return;
-  const int b = blockIdx.y * 64 + lane;
-  double v = 0.0;
-  for (int t = g.asm_ptr[pos]; t < g.asm_ptr[pos + 1]; ++t) v += g.rawT[(size_t)g.asm_idx[t] * g.bpad + b];
-  g.U[(size_t)pos * g.bpad + b] = v;
-}
-
 // ------------------------------------------------------------------------------------------
-// One factor task: rows [r0, r1) of panel p gathered from descendant panels (left-looking),
-// accumulators in LDS as [slot][lane]; the chunk holding the pivot block inverts it.
+// One factor task (plan.hpp, FTask): phase A builds the task's multiplier table in LDS
+// (M[0] = -1, M[1+j] = Dinv*U products), phase B streams the flat entry list: every destination
+// scalar is accumulated in a register and written once; all global loads are independent and
+// issued in batches of 8.  Initial values come straight from the transposed input (src < 0).
 __global__ __launch_bounds__(64) void k_factor_level(GroupDev g, int task0, double eps) {
-  extern __shared__ __attribute__((aligned(16))) double acc[];
+  extern __shared__ __attribute__((aligned(16))) double M[];
   const int lane = threadIdx.x;
   const int b = blockIdx.y * 64 + lane;
   const size_t bpad = (size_t)g.bpad;
-  const int* t = g.ftask + 5 * (size_t)(task0 + blockIdx.x);
-  const int p = t[0], r0 = t[1], r1 = t[2], s0 = t[3], s1 = t[4];
+  const int* t = g.ftask + 6 * (size_t)(task0 + blockIdx.x);
+  const int p = t[0], r0 = t[1], r1 = t[2], m0 = t[3], m1 = t[4], dptr0 = t[5];
   const int w = g.piv_w[p];
-  double* Up = g.U + (size_t)g.piv_uoff[p] * bpad + b;
-  const int nr = r1 - r0, nacc = nr * w;
-  for (int i = 0; i < nacc; ++i) acc[i * 64 + lane] = Up[(size_t)(r0 * w + i) * bpad];
-  double d0 = 0.0, d1 = 0.0, d2 = 0.0;
-  if (r0 == 0) {
-    d0 = acc[lane];
-    if (w == 2) { d1 = acc[2 * 64 + lane]; d2 = acc[3 * 64 + lane]; }
-  }
-  for (int s = s0; s < s1; ++s) {
-    const int* src = g.fsrc + 4 * (size_t)s;
-    const int k = src[0], mslot = src[1], run0 = src[2], run1 = src[3];
-    const int wk = g.piv_w[k];
-    const double* Uk = g.U + (size_t)g.piv_uoff[k] * bpad + b;
-    const double* inv = g.Dinv + (size_t)3 * k * bpad + b;
-    const double i00 = inv[0];
-    if (wk == 1) {
-      const double m00 = i00 * Uk[(size_t)mslot * bpad];
-      if (w == 1) {
-        for (int ri = run0; ri < run1; ++ri) {
-          const int* run = g.runs + 3 * (size_t)ri;
-          const int rs = run[0], rd = run[1], len = run[2];
-          for (int j = 0; j < len; ++j) acc[(rd + j) * 64 + lane] -= Uk[(size_t)(rs + j) * bpad] * m00;
-        }
-      } else {
-        const double m01 = i00 * Uk[(size_t)(mslot + 1) * bpad];
-        for (int ri = run0; ri < run1; ++ri) {
-          const int* run = g.runs + 3 * (size_t)ri;
-          const int rs = run[0], rd = run[1], len = run[2];
-          for (int j = 0; j < len; ++j) {
-            const double us = Uk[(size_t)(rs + j) * bpad];
-            acc[((rd + j) * 2) * 64 + lane] -= us * m00;
-            acc[((rd + j) * 2 + 1) * 64 + lane] -= us * m01;
-          }
-        }
+  const double* __restrict__ U = g.U + b;
+  const double* __restrict__ R = g.rawT + b;
+  const double* __restrict__ D = g.Dinv + b;
+  M[lane] = -1.0;
+  {
+    int j = m0;
+    for (; j + 4 <= m1; j += 4) {
+      const int* rec = g.mrec + 4 * (size_t)j;
+      double v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int d0 = rec[4 * i], u0 = rec[4 * i + 1], d1 = rec[4 * i + 2], u1 = rec[4 * i + 3];
+        v[i] = D[(size_t)d0 * bpad] * U[(size_t)u0 * bpad];
+        if (d1 >= 0) v[i] += D[(size_t)d1 * bpad] * U[(size_t)u1 * bpad];
       }
-    } else {
-      const double i10 = inv[bpad], i11 = inv[2 * bpad];
-      const double u0 = Uk[(size_t)(mslot * 2) * bpad], u1 = Uk[(size_t)(mslot * 2 + 1) * bpad];
-      const double m00 = i00 * u0 + i10 * u1, m10 = i10 * u0 + i11 * u1;
-      if (w == 1) {
-        for (int ri = run0; ri < run1; ++ri) {
-          const int* run = g.runs + 3 * (size_t)ri;
-          const int rs = run[0], rd = run[1], len = run[2];
-          for (int j = 0; j < len; ++j) {
-            const double us0 = Uk[(size_t)((rs + j) * 2) * bpad], us1 = Uk[(size_t)((rs + j) * 2 + 1) * bpad];
-            acc[(rd + j) * 64 + lane] -= us0 * m00 + us1 * m10;
-          }
-        }
-      } else {
-        const double v0 = Uk[(size_t)((mslot + 1) * 2) * bpad], v1 = Uk[(size_t)((mslot + 1) * 2 + 1) * bpad];
-        const double m01 = i00 * v0 + i10 * v1, m11 = i10 * v0 + i11 * v1;
-        for (int ri = run0; ri < run1; ++ri) {
-          const int* run = g.runs + 3 * (size_t)ri;
-          const int rs = run[0], rd = run[1], len = run[2];
-          for (int j = 0; j < len; ++j) {
-            const double us0 = Uk[(size_t)((rs + j) * 2) * bpad], us1 = Uk[(size_t)((rs + j) * 2 + 1) * bpad];
-            acc[((rd + j) * 2) * 64 + lane] -= us0 * m00 + us1 * m10;
-            acc[((rd + j) * 2 + 1) * 64 + lane] -= us0 * m01 + us1 * m11;
-          }
-        }
-      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) M[(1 + j - m0 + i) * 64 + lane] = v[i];
+    }
+    for (; j < m1; ++j) {
+      const int* rec = g.mrec + 4 * (size_t)j;
+      double v = D[(size_t)rec[0] * bpad] * U[(size_t)rec[1] * bpad];
+      if (rec[2] >= 0) v += D[(size_t)rec[2] * bpad] * U[(size_t)rec[3] * bpad];
+      M[(1 + j - m0) * 64 + lane] = v;
     }
   }
-  if (r0 == 0) {
-    double colmax = fabs(d0);
-    if (w == 2) colmax = fmax(colmax, fmax(fabs(d1), fabs(d2)));
-    for (int i = w * w; i < nacc; ++i) colmax = fmax(colmax, fabs(acc[i * 64 + lane]));
-    const double a = acc[lane];
-    const double bb = (w == 2) ? acc[2 * 64 + lane] : 0.0;
-    const double c = (w == 2) ? acc[3 * 64 + lane] : 0.0;
-    const pp::PivotResult pr = pp::invert_pivot(w, a, bb, c, colmax, eps);
-    double* invp = g.Dinv + (size_t)3 * p * bpad + b;
-    invp[0] = pr.i00; invp[bpad] = pr.i10; invp[2 * bpad] = pr.i11;
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the table is read by the same wave below
+  const int ndst = (r1 - r0) * w;
+  const int* dp = g.fdst_ptr + dptr0;
+  double* Udst = g.U + ((size_t)g.piv_uoff[p] + (size_t)r0 * w) * bpad + b;
+  const bool diag = (r0 == 0);
+  const int ndiag = diag ? w * w : 0;
+  double pv0 = 0.0, pv2 = 0.0, pv3 = 0.0, tmax_diag = 0.0, colmax = 0.0;
+  double acc = 0.0, tmax = 0.0;
+  int d = 0;
+  const int E1 = dp[ndst];
+  int e = dp[0];
+  int dend = (ndst > 0) ? dp[1] : 0x7fffffff;
+#define PP_FINALIZE()                                                     \
+  do {                                                                    \
+    Udst[(size_t)d * bpad] = acc;                                         \
+    if (d < ndiag) {                                                      \
+      if (d == 0) pv0 = acc; else if (d == 2) pv2 = acc; else if (d == 3) pv3 = acc; \
+      tmax_diag = fmax(tmax_diag, tmax);                                  \
+    } else {                                                              \
+      colmax = fmax(colmax, fabs(acc));                                   \
+    }                                                                     \
+    acc = 0.0; tmax = 0.0; ++d;                                           \
+    dend = (d < ndst) ? dp[d + 1] : 0x7fffffff;                           \
+  } while (0)
+  while (e < E1) {
+    const int* ent = g.fent + 2 * (size_t)e;
+    if (e + 8 <= E1) {
+      double sv[8], mv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int src = ent[2 * i], mi = ent[2 * i + 1];
+        sv[i] = (src >= 0) ? U[(size_t)src * bpad] : R[(size_t)(-1 - src) * bpad];
+        mv[i] = M[mi * 64 + lane];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        while (e + i == dend) PP_FINALIZE();
+        const double term = sv[i] * mv[i];
+        acc -= term;
+        tmax = fmax(tmax, fabs(term));
+      }
+      e += 8;
+    } else {
+      while (e == dend) PP_FINALIZE();
+      const int src = ent[0], mi = ent[1];
+      const double sv = (src >= 0) ? U[(size_t)src * bpad] : R[(size_t)(-1 - src) * bpad];
+      const double term = sv * M[mi * 64 + lane];
+      acc -= term;
+      tmax = fmax(tmax, fabs(term));
+      e += 1;
+    }
+  }
+  while (d < ndst) PP_FINALIZE();
+#undef PP_FINALIZE
+  if (diag) {
+    const pp::PivotResult pr = pp::invert_pivot(w, pv0, (w == 2) ? pv2 : 0.0, (w == 2) ? pv3 : 0.0,
+                                                fmax(colmax, tmax_diag), eps);
+    double* invp = g.Dinv + (size_t)g.piv_doff[p] * bpad + b;
+    invp[0] = pr.i00;
+    if (w == 2) { invp[bpad] = pr.i10; invp[2 * bpad] = pr.i11; }
     g.codes[(size_t)p * bpad + b] = (unsigned char)pr.code;
   }
-  for (int i = 0; i < nacc; ++i) Up[(size_t)(r0 * w + i) * bpad] = acc[i * 64 + lane];
 }
 
 // counters[0..2] += (pos, neg, zero) over all pivots and active instances
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(64) void k_schur_tiles(GroupDev g) {
     const int p = rec[0];
     const int w = g.piv_w[p];
     const double* Up = g.U + (size_t)g.piv_uoff[p] * bpad + b;
-    const double* inv = g.Dinv + (size_t)3 * p * bpad + b;
+    const double* inv = g.Dinv + (size_t)g.piv_doff[p] * bpad + b;
     const double i00 = inv[0];
     double wa0[8], wa1[8], ub0[8], ub1[8];
     if (w == 1) {
@@ -292,13 +293,181 @@ __global__ void k_write_tail(const int* counters, double* tail) {
 
 // Sfac = S + Q (Q lower triangle authoritative, dense column-major; may be null)
 __global__ __launch_bounds__(256) void k_add_q(const double* __restrict__ S, const double* __restrict__ Q,
-                                               double* __restrict__ Sfac, int nc) {
+                                               double* __restrict__ Sfac, double* __restrict__ Sldl, int nc) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (size_t)nc * nc) return;
   const int i = (int)(idx % nc), j = (int)(idx / nc);
   double q = 0.0;
   if (Q) q = (i >= j) ? Q[(size_t)i + (size_t)j * nc] : Q[(size_t)j + (size_t)i * nc];
-  Sfac[idx] = S[idx] + q;
+  const double v = S[idx] + q;
+  Sfac[idx] = v;
+  Sldl[idx] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// Optimistic dense LDL^T of S without pivoting, blocked (panel width 32), one workgroup.
+// The trailing updates run on the fp64 matrix cores (v_mfma_f64_16x16x4_f64): S is a genuine
+// dense symmetric panel.  The result is accepted only if every pivot has the same sign (S
+// definite, where the unpivoted factorisation is unconditionally stable) and no pivot is
+// numerically zero; otherwise mode[0] stays 0 and k_bk_factor (Bunch-Kaufman) takes over on the
+// untouched copy.  At the points the interior-point method accepts, S of a stochastic program
+// is positive definite (Haynsworth: every K_i carries its own negative eigenvalues).
+typedef double double4_t __attribute__((ext_vector_type(4)));
+constexpr int LDL_NB = 32;
+constexpr int LDL_THREADS = 512;
+
+__global__ __launch_bounds__(LDL_THREADS) void k_ldl_blocked(int n, double* __restrict__ A, double* __restrict__ dvec,
+                                                             int* __restrict__ mode, int* __restrict__ info, double eps) {
+  __shared__ double Db[LDL_NB][LDL_NB + 1];
+  __shared__ double dl[LDL_NB];      // pivots of the current panel
+  __shared__ double red[LDL_THREADS / 64];
+  __shared__ int sflags[2];          // [0] bad pivot seen, [1] sign bookkeeping (bit0 pos, bit1 neg)
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nwv = LDL_THREADS / 64;
+  const size_t lda = (size_t)n;
+  // scale for the zero-pivot test: max |diagonal|
+  double loc = 0.0;
+  for (int i = tid; i < n; i += LDL_THREADS) loc = fmax(loc, fabs(A[i + i * lda]));
+  for (int off = 32; off > 0; off >>= 1) loc = fmax(loc, __shfl_xor(loc, off));
+  if (lane == 0) red[wv] = loc;
+  if (tid == 0) { sflags[0] = 0; sflags[1] = 0; }
+  __syncthreads();
+  double anorm = 0.0;
+  for (int q = 0; q < nwv; ++q) anorm = fmax(anorm, red[q]);
+  for (int j0 = 0; j0 < n; j0 += LDL_NB) {
+    const int nb = min(LDL_NB, n - j0), j1 = j0 + nb, m = n - j1;
+    // (1) diagonal block -> LDS, factored by wave 0 (lane = row; LDS ops of one wave are in order)
+    for (int idx = tid; idx < nb * nb; idx += LDL_THREADS) {
+      const int i = idx % nb, j = idx / nb;
+      Db[i][j] = (i >= j) ? A[(j0 + i) + (size_t)(j0 + j) * lda] : 0.0;
+    }
+    __syncthreads();
+    if (wv == 0) {
+      const int i = lane;
+      for (int k = 0; k < nb; ++k) {
+        double d = Db[k][k];
+        if (!(fabs(d) > eps * anorm)) { if (lane == 0) sflags[0] = 1; d = (anorm > 0.0 ? anorm : 1.0); }
+        if (lane == 0) { dl[k] = d; sflags[1] |= (d > 0.0) ? 1 : 2; }
+        if (i > k && i < nb) {
+          const double lik = Db[i][k] / d;
+          for (int j = k + 1; j <= i; ++j) Db[i][j] -= lik * Db[j][k];
+          Db[i][k] = lik;
+        }
+      }
+    }
+    __syncthreads();
+    // write the factored diagonal block back (unit lower L11, pivots on the diagonal)
+    for (int idx = tid; idx < nb * nb; idx += LDL_THREADS) {
+      const int i = idx % nb, j = idx / nb;
+      if (i > j) A[(j0 + i) + (size_t)(j0 + j) * lda] = Db[i][j];
+      else if (i == j) { A[(j0 + i) + (size_t)(j0 + j) * lda] = dl[i]; dvec[j0 + i] = dl[i]; }
+    }
+    // (2) panel: W = A21 L11^{-T} row by row (thread = row), then L21 = W D^{-1}, stored in A
+    if (nb == LDL_NB) {
+      for (int r = tid; r < m; r += LDL_THREADS) {
+        double wrow[LDL_NB];
+#pragma unroll
+        for (int k = 0; k < LDL_NB; ++k) {
+          double v = A[(j1 + r) + (size_t)(j0 + k) * lda];
+#pragma unroll
+          for (int j = 0; j < k; ++j) v -= wrow[j] * Db[k][j];
+          wrow[k] = v;
+          __builtin_amdgcn_sched_barrier(0);   // keep the LDS reads of later columns from being hoisted (register pressure)
+        }
+#pragma unroll
+        for (int k = 0; k < LDL_NB; ++k) A[(j1 + r) + (size_t)(j0 + k) * lda] = wrow[k] / dl[k];
+      }
+    } else {
+      for (int r = tid; r < m; r += LDL_THREADS) {   // ragged last panel: W kept in place, scaled afterwards
+        for (int k = 0; k < nb; ++k) {
+          double v = A[(j1 + r) + (size_t)(j0 + k) * lda];
+          for (int j = 0; j < k; ++j) v -= A[(j1 + r) + (size_t)(j0 + j) * lda] * Db[k][j];
+          A[(j1 + r) + (size_t)(j0 + k) * lda] = v;
+        }
+        for (int k = 0; k < nb; ++k) A[(j1 + r) + (size_t)(j0 + k) * lda] /= dl[k];
+      }
+    }
+    __syncthreads();
+    // (3) trailing update A22 -= L21 D L21^T on 16x16 tiles with fp64 MFMA (lower tiles only)
+    if (m > 0) {
+      const int nt = (m + 15) / 16;
+      const int ntiles = nt * (nt + 1) / 2;
+      const int li = lane & 15, lk = lane >> 4;
+      for (int tix = wv; tix < ntiles; tix += nwv) {
+        // tile index -> (I >= J)
+        int I = (int)((sqrt(8.0 * tix + 1.0) - 1.0) * 0.5);
+        while ((I + 1) * (I + 2) / 2 <= tix) ++I;
+        while (I * (I + 1) / 2 > tix) --I;
+        const int J = tix - I * (I + 1) / 2;
+        const int ra = j1 + 16 * I + li, rb = j1 + 16 * J + li;
+        const bool va = ra < n, vb = rb < n;
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+        for (int kk = 0; kk < nb; kk += 4) {
+          const int k = kk + lk;
+          const bool vk = k < nb;
+          const double a = (va && vk) ? A[ra + (size_t)(j0 + k) * lda] * dl[k] : 0.0;
+          const double b = (vb && vk) ? A[rb + (size_t)(j0 + k) * lda] : 0.0;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+        const int col = j1 + 16 * J + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = j1 + 16 * I + lk + 4 * r;
+          if (row < n && col < n && row >= col) A[row + (size_t)col * lda] -= acc[r];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const bool ok = (sflags[0] == 0) && (sflags[1] == 1 || sflags[1] == 2 || n == 0);
+    mode[0] = ok ? 1 : 0;
+    if (ok) { info[0] = (sflags[1] == 1) ? n : 0; info[1] = (sflags[1] == 2) ? n : 0; info[2] = 0; }
+  }
+}
+
+// x = S^-1 b with the blocked factor (unit lower L in A, pivots in dvec); b is in LDS vector x
+__device__ void ldl_blocked_solve(int n, const double* __restrict__ A, const double* __restrict__ dvec, double* x) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nwv = blockDim.x >> 6;
+  const size_t lda = (size_t)n;
+  for (int j0 = 0; j0 < n; j0 += LDL_NB) {
+    const int nb = min(LDL_NB, n - j0), j1 = j0 + nb;
+    if (wv == 0) {  // unit-lower triangular solve inside the block: lane = row, shuffle broadcast
+      double xi = (lane < nb) ? x[j0 + lane] : 0.0;
+      for (int k = 0; k < nb; ++k) {
+        const double xk = __shfl(xi, k);
+        if (lane > k && lane < nb) xi -= A[(j0 + lane) + (size_t)(j0 + k) * lda] * xk;
+      }
+      if (lane < nb) x[j0 + lane] = xi;
+    }
+    __syncthreads();
+    for (int r = j1 + tid; r < n; r += blockDim.x) {
+      double s = 0.0;
+      for (int k = 0; k < nb; ++k) s += A[r + (size_t)(j0 + k) * lda] * x[j0 + k];
+      x[r] -= s;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < n; i += blockDim.x) x[i] /= dvec[i];
+  __syncthreads();
+  for (int j0 = ((n - 1) / LDL_NB) * LDL_NB; j0 >= 0; j0 -= LDL_NB) {
+    const int nb = min(LDL_NB, n - j0), j1 = j0 + nb;
+    for (int k = wv; k < nb; k += nwv) {  // x[j0+k] -= L[j1:, j0+k]^T x[j1:]
+      double s = 0.0;
+      for (int r = j1 + lane; r < n; r += 64) s += A[r + (size_t)(j0 + k) * lda] * x[r];
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+      if (lane == 0) x[j0 + k] -= s;
+    }
+    __syncthreads();
+    if (wv == 0) {
+      double xi = (lane < nb) ? x[j0 + lane] : 0.0;
+      for (int k = nb - 1; k > 0; --k) {
+        const double xk = __shfl(xi, k);
+        if (lane < k) xi -= A[(j0 + k) + (size_t)(j0 + lane) * lda] * xk;
+      }
+      if (lane < nb) x[j0 + lane] = xi;
+    }
+    __syncthreads();
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -346,9 +515,11 @@ struct TeamCtx {
   }
 };
 
-__global__ __launch_bounds__(BK_THREADS) void k_bk_factor(int n, double* A, int* ipiv, double* work, int* info) {
+__global__ __launch_bounds__(BK_THREADS) void k_bk_factor(int n, double* A, int* ipiv, double* work, int* info,
+                                                          const int* mode) {
   __shared__ double sv[16];
   __shared__ int si[16];
+  if (mode[0] == 1) return;   // the unpivoted blocked factorisation was accepted
   TeamCtx ctx{sv, si};
   pp::BkInfo bi;
   __shared__ pp::BkInfo sbi;
@@ -357,18 +528,43 @@ __global__ __launch_bounds__(BK_THREADS) void k_bk_factor(int n, double* A, int*
   (void)bi;
 }
 
-// xc = S^-1 (rc + rs)
-__global__ __launch_bounds__(BK_THREADS) void k_coupling_solve(int n, const double* A, const int* ipiv,
+// xc = S^-1 (rc + rs): blocked LDL^T factor if it was accepted, else the Bunch-Kaufman factor
+__global__ __launch_bounds__(BK_THREADS) void k_coupling_solve(int n, const double* Abk, const int* ipiv,
+                                                               const double* Aldl, const double* dvec, const int* mode,
                                                                const double* rc, const double* rs, double* xc) {
+  extern __shared__ __attribute__((aligned(16))) double xs[];
   __shared__ double sv[16];
   __shared__ int si[16];
+  if (mode[0] == 1) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) xs[i] = (rc ? rc[i] : 0.0) + rs[i];
+    __syncthreads();
+    ldl_blocked_solve(n, Aldl, dvec, xs);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) xc[i] = xs[i];
+    return;
+  }
   TeamCtx ctx{sv, si};
   for (int i = threadIdx.x; i < n; i += blockDim.x) xc[i] = (rc ? rc[i] : 0.0) + rs[i];
   __syncthreads();
-  pp::bk_solve(ctx, n, A, n, ipiv, xc);
+  pp::bk_solve(ctx, n, Abk, n, ipiv, xc);
 }
 
 // ------------------------------------------------------------------------------------------
+// gather of one scalar row: sum over entries of U[upos] * Z[zcol], loads batched by 8
+__device__ __forceinline__ double gather_row(const int* __restrict__ upos, const int* __restrict__ zcol, int e0, int e1,
+                                             const double* __restrict__ U, const double* __restrict__ Z, size_t bpad) {
+  double s0 = 0.0, s1 = 0.0;
+  int e = e0;
+  for (; e + 8 <= e1; e += 8) {
+    double u[8], z[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { u[i] = U[(size_t)upos[e + i] * bpad]; z[i] = Z[(size_t)zcol[e + i] * bpad]; }
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) { s0 += u[i] * z[i]; s1 += u[i + 1] * z[i + 1]; }
+  }
+  for (; e < e1; ++e) s0 += U[(size_t)upos[e] * bpad] * Z[(size_t)zcol[e] * bpad];
+  return s0 + s1;
+}
+
 // forward substitution of one level: z_p = inv(P_p) (b_p - sum_k U[p,k] z_k)
 __global__ __launch_bounds__(64) void k_fwd_level(GroupDev g, int piv0) {
   const int lane = threadIdx.x;
@@ -376,26 +572,16 @@ __global__ __launch_bounds__(64) void k_fwd_level(GroupDev g, int piv0) {
   const size_t bpad = (size_t)g.bpad;
   const int p = g.lvl_piv[piv0 + blockIdx.x];
   const int w = g.piv_w[p], p0 = g.piv_start[p];
-  double y0 = g.rhsT[(size_t)g.perm[p0] * bpad + b];
-  double y1 = (w == 2) ? g.rhsT[(size_t)g.perm[p0 + 1] * bpad + b] : 0.0;
-  for (int s = g.sfwd_ptr[p]; s < g.sfwd_ptr[p + 1]; ++s) {
-    const int k = g.sfwd_k[s], ms = g.sfwd_mslot[s];
-    const int wk = g.piv_w[k], k0 = g.piv_start[k];
-    const double* Uk = g.U + (size_t)g.piv_uoff[k] * bpad + b;
-    const double z0 = g.W[(size_t)k0 * bpad + b];
-    if (wk == 1) {
-      y0 -= Uk[(size_t)ms * bpad] * z0;
-      if (w == 2) y1 -= Uk[(size_t)(ms + 1) * bpad] * z0;
-    } else {
-      const double z1 = g.W[(size_t)(k0 + 1) * bpad + b];
-      y0 -= Uk[(size_t)(ms * 2) * bpad] * z0 + Uk[(size_t)(ms * 2 + 1) * bpad] * z1;
-      if (w == 2) y1 -= Uk[(size_t)((ms + 1) * 2) * bpad] * z0 + Uk[(size_t)((ms + 1) * 2 + 1) * bpad] * z1;
-    }
-  }
-  const double* inv = g.Dinv + (size_t)3 * p * bpad + b;
+  const double* U = g.U + b;
+  const double* Z = g.W + b;
+  double y0 = g.rhsT[(size_t)g.perm[p0] * bpad + b] -
+              gather_row(g.sfwd_upos, g.sfwd_zcol, g.sfwd_eptr[p0], g.sfwd_eptr[p0 + 1], U, Z, bpad);
+  const double* inv = g.Dinv + (size_t)g.piv_doff[p] * bpad + b;
   if (w == 1) {
     g.W[(size_t)p0 * bpad + b] = inv[0] * y0;
   } else {
+    double y1 = g.rhsT[(size_t)g.perm[p0 + 1] * bpad + b] -
+                gather_row(g.sfwd_upos, g.sfwd_zcol, g.sfwd_eptr[p0 + 1], g.sfwd_eptr[p0 + 2], U, Z, bpad);
     const double i00 = inv[0], i10 = inv[bpad], i11 = inv[2 * bpad];
     g.W[(size_t)p0 * bpad + b] = i00 * y0 + i10 * y1;
     g.W[(size_t)(p0 + 1) * bpad + b] = i10 * y0 + i11 * y1;
@@ -408,15 +594,7 @@ __global__ __launch_bounds__(64) void k_fwd_coupling(GroupDev g) {
   const int b = blockIdx.y * 64 + lane;
   const size_t bpad = (size_t)g.bpad;
   const int c = blockIdx.x;
-  double s = 0.0;
-  for (int t = g.crow_ptr[c]; t < g.crow_ptr[c + 1]; ++t) {
-    const int k = g.crow_k[t], slot = g.crow_slot[t];
-    const int wk = g.piv_w[k], k0 = g.piv_start[k];
-    const double* Uk = g.U + (size_t)g.piv_uoff[k] * bpad + b;
-    if (wk == 1) s -= Uk[(size_t)slot * bpad] * g.W[(size_t)k0 * bpad + b];
-    else s -= Uk[(size_t)(slot * 2) * bpad] * g.W[(size_t)k0 * bpad + b] +
-              Uk[(size_t)(slot * 2 + 1) * bpad] * g.W[(size_t)(k0 + 1) * bpad + b];
-  }
+  double s = -gather_row(g.crow_upos, g.crow_zcol, g.crow_eptr[c], g.crow_eptr[c + 1], g.U + b, g.W + b, bpad);
   if (b >= g.batch) s = 0.0;
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
   if (lane == 0) g.rspart[(size_t)blockIdx.y * g.nc + c] = s;
@@ -440,23 +618,50 @@ __global__ __launch_bounds__(64) void k_bwd_level(GroupDev g, int piv0, const do
   const int nr = g.piv_rowptr[p + 1] - g.piv_rowptr[p];
   const int* ri = g.rowidx + g.piv_rowptr[p];
   const double* Up = g.U + ((size_t)g.piv_uoff[p] + (size_t)w * w) * bpad + b;
-  double g0 = 0.0, g1 = 0.0;
+  const double* Wb = g.W + b;
+  const int n = g.n;
   if (w == 1) {
-    for (int j = 0; j < nr; ++j) {
-      const int r = ri[j];
-      const double x = (r < g.n) ? g.W[(size_t)r * bpad + b] : xc[r - g.n];
-      g0 += Up[(size_t)j * bpad] * x;
+    double g0 = 0.0, g1 = 0.0;
+    int j = 0;
+    for (; j + 8 <= nr; j += 8) {
+      double u[8], x[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = ri[j + i];
+        u[i] = Up[(size_t)(j + i) * bpad];
+        x[i] = (r < n) ? Wb[(size_t)r * bpad] : xc[r - n];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; i += 2) { g0 += u[i] * x[i]; g1 += u[i + 1] * x[i + 1]; }
     }
-    const double inv = g.Dinv[(size_t)3 * p * bpad + b];
-    g.W[(size_t)p0 * bpad + b] -= inv * g0;
-  } else {
-    for (int j = 0; j < nr; ++j) {
+    for (; j < nr; ++j) {
       const int r = ri[j];
-      const double x = (r < g.n) ? g.W[(size_t)r * bpad + b] : xc[r - g.n];
+      g0 += Up[(size_t)j * bpad] * ((r < n) ? Wb[(size_t)r * bpad] : xc[r - n]);
+    }
+    const double inv = g.Dinv[(size_t)g.piv_doff[p] * bpad + b];
+    g.W[(size_t)p0 * bpad + b] -= inv * (g0 + g1);
+  } else {
+    double g0 = 0.0, g1 = 0.0;
+    int j = 0;
+    for (; j + 4 <= nr; j += 4) {
+      double u0[4], u1[4], x[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = ri[j + i];
+        u0[i] = Up[(size_t)((j + i) * 2) * bpad];
+        u1[i] = Up[(size_t)((j + i) * 2 + 1) * bpad];
+        x[i] = (r < n) ? Wb[(size_t)r * bpad] : xc[r - n];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { g0 += u0[i] * x[i]; g1 += u1[i] * x[i]; }
+    }
+    for (; j < nr; ++j) {
+      const int r = ri[j];
+      const double x = (r < n) ? Wb[(size_t)r * bpad] : xc[r - n];
       g0 += Up[(size_t)(j * 2) * bpad] * x;
       g1 += Up[(size_t)(j * 2 + 1) * bpad] * x;
     }
-    const double* inv = g.Dinv + (size_t)3 * p * bpad + b;
+    const double* inv = g.Dinv + (size_t)g.piv_doff[p] * bpad + b;
     const double i00 = inv[0], i10 = inv[bpad], i11 = inv[2 * bpad];
     g.W[(size_t)p0 * bpad + b] -= i00 * g0 + i10 * g1;
     g.W[(size_t)(p0 + 1) * bpad + b] -= i10 * g0 + i11 * g1;
@@ -472,6 +677,7 @@ struct Group {
   std::vector<void*> allocs;
   int ntiles = 0;
   double *raw_own = nullptr, *rhs_own = nullptr;
+  std::vector<size_t> lds_level;
 };
 
 }  // namespace
@@ -482,7 +688,9 @@ struct pp_solver {
   int nc = 0;
   bool symbolic_done = false, numeric_done = false, schur_done = false;
   std::vector<Group*> groups;
-  double *S = nullptr, *S_own = nullptr, *Sfac = nullptr, *Qd = nullptr, *work = nullptr;
+  double *S = nullptr, *S_own = nullptr, *Sfac = nullptr, *Sldl = nullptr, *dvec = nullptr, *Qd = nullptr, *work = nullptr;
+  int* dense_mode = nullptr;
+  int dense_policy = 0;   // 0 auto (optimistic blocked LDL^T, Bunch-Kaufman fallback), 1 Bunch-Kaufman only
   double *rs = nullptr, *rs_own = nullptr, *rcd = nullptr, *xc = nullptr;
   int *ipiv = nullptr, *bkinfo = nullptr, *counters = nullptr;
   double mem_factor = 1.0;
@@ -564,10 +772,11 @@ void free_group(Group* g) {
 }
 
 void free_globals(pp_handle h) {
-  for (void* p : {(void*)h->S_own, (void*)h->Sfac, (void*)h->Qd, (void*)h->work, (void*)h->rs_own, (void*)h->rcd,
+  for (void* p : {(void*)h->S_own, (void*)h->Sfac, (void*)h->Sldl, (void*)h->dvec, (void*)h->dense_mode, (void*)h->Qd, (void*)h->work, (void*)h->rs_own, (void*)h->rcd,
                   (void*)h->xc, (void*)h->ipiv, (void*)h->bkinfo, (void*)h->counters})
     if (p) (void)hipFree(p);
-  h->S = h->S_own = h->Sfac = h->Qd = h->work = h->rs = h->rs_own = h->rcd = h->xc = nullptr;
+  h->S = h->S_own = h->Sfac = h->Sldl = h->dvec = h->Qd = h->work = h->rs = h->rs_own = h->rcd = h->xc = nullptr;
+  h->dense_mode = nullptr;
   h->ipiv = h->bkinfo = h->counters = nullptr;
 }
 
@@ -652,6 +861,8 @@ int pp_add_group(pp_handle h, int n, int batch, int nnzK, const int32_t* rowK, c
 int pp_end_symbolic(pp_handle h) {
   if (!h) return 3;
   PP_HIP(hipSetDevice(h->device));
+  // factor tasks may need a multiplier table larger than the default 64 KiB dynamic-LDS limit
+  (void)hipFuncSetAttribute((const void*)k_factor_level, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const int nc = h->nc;
   for (Group* g : h->groups) {
     const pp::Plan& P = g->plan;
@@ -661,55 +872,74 @@ int pp_end_symbolic(pp_handle h) {
     d.nchunk = d.bpad / WAVE; d.npiv = P.npiv; d.nraw = g->nraw; d.usize = P.usize;
     int rc;
     std::vector<int> uoff(P.piv_uoff.begin(), P.piv_uoff.end());
-    std::vector<int> ftask, fsrc, runs, srec;
-    ftask.reserve(P.ftasks.size() * 5);
-    for (auto& t : P.ftasks) { ftask.insert(ftask.end(), {t.piv, t.r0, t.r1, t.src0, t.src1}); }
-    for (auto& s : P.fsrcs) { fsrc.insert(fsrc.end(), {s.k, s.mslot, s.run0, s.run1}); }
-    for (auto& r : P.runs) { runs.insert(runs.end(), {r.src, r.dst, r.len}); }
+    std::vector<int> ftask, mrec, fdst_ptr, fent, srec;
+    for (auto& m : P.mrecs) { mrec.insert(mrec.end(), {m.d0, m.u0, m.d1, m.u1}); }
+    // expand the canonical initial-value entries into raw-value entries (duplicates are summed)
+    fdst_ptr.reserve(P.fdst_ptr.size());
+    fent.reserve(P.fentries.size() * 2 + 16);
+    ftask.reserve(P.ftasks.size() * 6);
+    for (auto& t : P.ftasks) {
+      const int ndst = (t.r1 - t.r0) * P.piv_w[t.piv];
+      const int new_dptr0 = (int)fdst_ptr.size();
+      for (int dd = 0; dd < ndst; ++dd) {
+        fdst_ptr.push_back((int)(fent.size() / 2));
+        for (int e = P.fdst_ptr[t.dptr0 + dd]; e < P.fdst_ptr[t.dptr0 + dd + 1]; ++e) {
+          const pp::FEntry& fe = P.fentries[e];
+          if (fe.src >= 0) { fent.push_back(fe.src); fent.push_back(fe.midx); }
+          else {
+            const int ce = -1 - fe.src;
+            for (int q = g->can_ptr[ce]; q < g->can_ptr[ce + 1]; ++q) { fent.push_back(-1 - g->can_idx[q]); fent.push_back(fe.midx); }
+          }
+        }
+      }
+      fdst_ptr.push_back((int)(fent.size() / 2));
+      ftask.insert(ftask.end(), {t.piv, t.r0, t.r1, t.m0, t.m1, new_dptr0});
+    }
+    for (int q = 0; q < 16; ++q) fent.push_back(0);   // slack for the unrolled record reads
     for (auto& r : P.stile_rec) {
       srec.push_back(r.piv);
       for (int q = 0; q < 8; ++q) srec.push_back(r.slotA[q]);
       for (int q = 0; q < 8; ++q) srec.push_back(r.slotB[q]);
     }
-    // gather map U position -> raw entries
-    std::vector<int> can_of_pos((size_t)P.usize, -1);
-    for (int e = 0; e < P.ncan; ++e) can_of_pos[(size_t)P.pos_of_can[e]] = e;
-    std::vector<int> asm_ptr((size_t)P.usize + 1, 0), asm_idx;
-    for (int64_t pos = 0; pos < P.usize; ++pos) {
-      int e = can_of_pos[(size_t)pos];
-      if (e >= 0) asm_idx.insert(asm_idx.end(), g->can_idx.begin() + g->can_ptr[e], g->can_idx.begin() + g->can_ptr[e + 1]);
-      asm_ptr[(size_t)pos + 1] = (int)asm_idx.size();
+    g->lds_level.assign(P.n_levels, 0);
+    for (int l = 0; l < P.n_levels; ++l) {
+      g->lds_level[l] = (size_t)(1 + P.flevel_maxm[l]) * 64 * sizeof(double);
+      if (g->lds_level[l] > 160 * 1024) return fail(h, 1, "a factor task needs more than 160 KiB of LDS multipliers");
     }
     if ((rc = dev_upload(h, g, &d.piv_w, P.piv_w))) return rc;
     if ((rc = dev_upload(h, g, &d.piv_start, P.piv_start))) return rc;
     if ((rc = dev_upload(h, g, &d.piv_uoff, uoff))) return rc;
+    if ((rc = dev_upload(h, g, &d.piv_doff, P.piv_doff))) return rc;
     if ((rc = dev_upload(h, g, &d.piv_rowptr, P.piv_rowptr))) return rc;
     if ((rc = dev_upload(h, g, &d.rowidx, P.rowidx))) return rc;
     if ((rc = dev_upload(h, g, &d.perm, P.perm))) return rc;
     if ((rc = dev_upload(h, g, &d.iperm, P.iperm))) return rc;
     if ((rc = dev_upload(h, g, &d.ftask, ftask))) return rc;
-    if ((rc = dev_upload(h, g, &d.fsrc, fsrc))) return rc;
-    if ((rc = dev_upload(h, g, &d.runs, runs))) return rc;
+    if ((rc = dev_upload(h, g, &d.mrec, mrec))) return rc;
+    if ((rc = dev_upload(h, g, &d.fdst_ptr, fdst_ptr))) return rc;
+    if ((rc = dev_upload(h, g, &d.fent, fent))) return rc;
     if ((rc = dev_upload(h, g, &d.lvl_piv, P.lvl_piv))) return rc;
-    if ((rc = dev_upload(h, g, &d.sfwd_ptr, P.sfwd_ptr))) return rc;
-    if ((rc = dev_upload(h, g, &d.sfwd_k, P.sfwd_k))) return rc;
-    if ((rc = dev_upload(h, g, &d.sfwd_mslot, P.sfwd_mslot))) return rc;
-    if ((rc = dev_upload(h, g, &d.crow_ptr, P.crow_ptr))) return rc;
-    if ((rc = dev_upload(h, g, &d.crow_k, P.crow_k))) return rc;
-    if ((rc = dev_upload(h, g, &d.crow_slot, P.crow_slot))) return rc;
+    {
+      std::vector<int> up(P.sfwd_upos), zc(P.sfwd_zcol), cu(P.crow_upos), cz(P.crow_zcol);
+      for (int q = 0; q < 16; ++q) { up.push_back(0); zc.push_back(0); cu.push_back(0); cz.push_back(0); }
+      if ((rc = dev_upload(h, g, &d.sfwd_eptr, P.sfwd_eptr))) return rc;
+      if ((rc = dev_upload(h, g, &d.sfwd_upos, up))) return rc;
+      if ((rc = dev_upload(h, g, &d.sfwd_zcol, zc))) return rc;
+      if ((rc = dev_upload(h, g, &d.crow_eptr, P.crow_eptr))) return rc;
+      if ((rc = dev_upload(h, g, &d.crow_upos, cu))) return rc;
+      if ((rc = dev_upload(h, g, &d.crow_zcol, cz))) return rc;
+    }
     if ((rc = dev_upload(h, g, &d.stile_a, P.stile_a))) return rc;
     if ((rc = dev_upload(h, g, &d.stile_b, P.stile_b))) return rc;
     if ((rc = dev_upload(h, g, &d.stile_ptr, P.stile_ptr))) return rc;
     if ((rc = dev_upload(h, g, &d.stile_rec, srec))) return rc;
-    if ((rc = dev_upload(h, g, &d.asm_ptr, asm_ptr))) return rc;
-    if ((rc = dev_upload(h, g, &d.asm_idx, asm_idx))) return rc;
     g->ntiles = (int)P.stile_a.size();
     const size_t bp = (size_t)d.bpad;
     if ((rc = dev_alloc(h, g, &d.raw, (size_t)g->batch * g->nraw))) return rc;
     g->raw_own = d.raw;
     if ((rc = dev_alloc(h, g, &d.rawT, (size_t)g->nraw * bp))) return rc;
     if ((rc = dev_alloc(h, g, &d.U, (size_t)P.usize * bp))) return rc;
-    if ((rc = dev_alloc(h, g, &d.Dinv, (size_t)3 * P.npiv * bp))) return rc;
+    if ((rc = dev_alloc(h, g, &d.Dinv, (size_t)P.dsize * bp))) return rc;
     if ((rc = dev_alloc(h, g, &d.W, (size_t)(P.n + nc) * bp))) return rc;
     if ((rc = dev_alloc(h, g, &d.rhs, (size_t)g->batch * P.n))) return rc;
     g->rhs_own = d.rhs;
@@ -723,6 +953,10 @@ int pp_end_symbolic(pp_handle h) {
   const size_t nn = (size_t)nc * nc;
   if ((rc = dev_alloc<double>(h, nullptr, &h->S_own, nn + 4))) return rc;
   if ((rc = dev_alloc<double>(h, nullptr, &h->Sfac, nn))) return rc;
+  if ((rc = dev_alloc<double>(h, nullptr, &h->Sldl, nn))) return rc;
+  if ((rc = dev_alloc<double>(h, nullptr, &h->dvec, nc))) return rc;
+  if ((rc = dev_alloc<int>(h, nullptr, &h->dense_mode, 4))) return rc;
+  PP_HIP(hipMemset(h->dense_mode, 0, 4 * sizeof(int)));
   if ((rc = dev_alloc<double>(h, nullptr, &h->Qd, nn))) return rc;
   if ((rc = dev_alloc<double>(h, nullptr, &h->work, 2 * (size_t)nc))) return rc;
   if ((rc = dev_alloc<double>(h, nullptr, &h->rs_own, nc))) return rc;
@@ -771,18 +1005,17 @@ int pp_numeric_local(pp_handle h) {
     const pp::Plan& P = g->plan;
     GroupDev& d = g->dev;
     {
-      PhaseScope ps(h, 0, 2);
+      PhaseScope ps(h, 0, 1);
       if (d.nraw > 0)
         hipLaunchKernelGGL(k_transpose_in, dim3((d.nraw + 63) / 64, d.nchunk), dim3(256), 0, st, d.raw, d.rawT, d.batch,
                            d.nraw, d.bpad);
-      hipLaunchKernelGGL(k_assemble, dim3((unsigned)((P.usize + 3) / 4), d.nchunk), dim3(256), 0, st, d);
     }
     {
       PhaseScope ps(h, 1, P.n_levels);
-      const size_t lds = (size_t)P.opt.acc_doubles * 64 * sizeof(double);
       for (int l = 0; l < P.n_levels; ++l) {
         const int t0 = P.flevel_ptr[l], nt = P.flevel_ptr[l + 1] - t0;
-        if (nt > 0) hipLaunchKernelGGL(k_factor_level, dim3(nt, d.nchunk), dim3(64), lds, st, d, t0, PIVOT_EPS);
+        if (nt > 0)
+          hipLaunchKernelGGL(k_factor_level, dim3(nt, d.nchunk), dim3(64), g->lds_level[l], st, d, t0, PIVOT_EPS);
       }
     }
     {
@@ -818,10 +1051,16 @@ int pp_factor_schur(pp_handle h, const double* Q_host) {
   const size_t nn = (size_t)nc * nc;
   if (nc > 0) {
     if (Q_host) PP_HIP(hipMemcpyAsync(h->Qd, Q_host, nn * sizeof(double), hipMemcpyHostToDevice, st));
-    PhaseScope ps(h, 3, 2);
+    PhaseScope ps(h, 3, 3);
     hipLaunchKernelGGL(k_add_q, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, h->S, Q_host ? h->Qd : nullptr,
-                       h->Sfac, nc);
-    hipLaunchKernelGGL(k_bk_factor, dim3(1), dim3(BK_THREADS), 0, st, nc, h->Sfac, h->ipiv, h->work, h->bkinfo);
+                       h->Sfac, h->Sldl, nc);
+    if (h->dense_policy == 0)
+      hipLaunchKernelGGL(k_ldl_blocked, dim3(1), dim3(LDL_THREADS), 0, st, nc, h->Sldl, h->dvec, h->dense_mode, h->bkinfo,
+                         BK_EPS);
+    else
+      PP_HIP(hipMemsetAsync(h->dense_mode, 0, sizeof(int), st));
+    hipLaunchKernelGGL(k_bk_factor, dim3(1), dim3(BK_THREADS), 0, st, nc, h->Sfac, h->ipiv, h->work, h->bkinfo,
+                       h->dense_mode);
   } else {
     PP_HIP(hipMemsetAsync(h->bkinfo, 0, 4 * sizeof(int), st));
   }
@@ -913,8 +1152,8 @@ int pp_solve_coupling(pp_handle h, const double* rc_host) {
   if (nc == 0) return 0;
   if (rc_host) PP_HIP(hipMemcpyAsync(h->rcd, rc_host, (size_t)nc * sizeof(double), hipMemcpyHostToDevice, st));
   PhaseScope ps(h, 6, 1);
-  hipLaunchKernelGGL(k_coupling_solve, dim3(1), dim3(BK_THREADS), 0, st, nc, h->Sfac, h->ipiv,
-                     rc_host ? h->rcd : nullptr, h->rs, h->xc);
+  hipLaunchKernelGGL(k_coupling_solve, dim3(1), dim3(BK_THREADS), (size_t)nc * sizeof(double), st, nc, h->Sfac, h->ipiv,
+                     h->Sldl, h->dvec, h->dense_mode, rc_host ? h->rcd : nullptr, h->rs, h->xc);
   PP_HIP(hipGetLastError());
   return 0;
 }
@@ -976,6 +1215,21 @@ int pp_bind_rhs_buffer(pp_handle h, int group, double* dev_ptr) {
   return 0;
 }
 
+int pp_set_dense_policy(pp_handle h, int policy) {
+  if (!h) return 3;
+  if (policy != 0 && policy != 1) return fail(h, 3, "dense policy must be 0 (auto) or 1 (Bunch-Kaufman only)");
+  h->dense_policy = policy;
+  return 0;
+}
+
+int pp_get_dense_mode(pp_handle h, int* mode_out) {
+  if (!h || !h->schur_done) return fail(h, 3, "pp_get_dense_mode before pp_factor_schur");
+  PP_HIP(hipSetDevice(h->device));
+  PP_HIP(hipMemcpyAsync(mode_out, h->dense_mode, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  PP_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
 int pp_profile(pp_handle h, int enable) {
   if (!h) return 3;
   h->profile = enable != 0;
@@ -1020,7 +1274,7 @@ int pp_group_stats(pp_handle h, int group, int64_t out[16]) {
   if (!g) return fail(h, 3, "pp_group_stats: bad group");
   const pp::Plan& P = g->plan;
   const int64_t v[16] = {P.n, P.nc, g->batch, P.npiv, P.n_2x2, P.n_levels, P.nnz_L, P.usize, P.flops_factor,
-                         P.flops_schur, (int64_t)P.ftasks.size(), (int64_t)P.runs.size(), (int64_t)P.stile_a.size(),
+                         P.flops_schur, (int64_t)P.ftasks.size(), (int64_t)P.fentries.size(), (int64_t)P.stile_a.size(),
                          (int64_t)P.stile_rec.size(), P.ncan, g->nraw};
   std::memcpy(out, v, sizeof(v));
   return 0;

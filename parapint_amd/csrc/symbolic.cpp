@@ -244,7 +244,10 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
   }
   P.piv_rowptr.assign(P.npiv + 1, 0);
   P.piv_uoff.assign(P.npiv, 0);
+  P.piv_doff.assign(P.npiv, 0);
   for (int p = 0; p < P.npiv; ++p) {
+    P.piv_doff[p] = P.dsize;
+    P.dsize += (P.piv_w[p] == 1) ? 1 : 3;
     P.piv_rowptr[p + 1] = P.piv_rowptr[p] + (int)rows[p].size();
     P.piv_uoff[p] = P.usize;
     P.usize += (int64_t)(P.piv_w[p] + (int64_t)rows[p].size()) * P.piv_w[p];
@@ -299,11 +302,6 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
     P.piv_level[p] = lv;
     P.n_levels = std::max(P.n_levels, lv + 1);
   }
-  P.sfwd_ptr.assign(P.npiv + 1, 0);
-  for (int p = 0; p < P.npiv; ++p) {
-    P.sfwd_ptr[p + 1] = P.sfwd_ptr[p] + (int)rowpat[p].size();
-    for (auto& km : rowpat[p]) { P.sfwd_k.push_back(km.first); P.sfwd_mslot.push_back(km.second); }
-  }
   {
     std::vector<int> cnt(P.n_levels + 1, 0);
     for (int p = 0; p < P.npiv; ++p) cnt[P.piv_level[p] + 1]++;
@@ -314,78 +312,151 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
     for (int p = 0; p < P.npiv; ++p) P.lvl_piv[fill[P.piv_level[p]]++] = p;
   }
 
-  // ---- 6. factor tasks (left-looking gathers, chunked by rows)
-  struct TmpTask { FTask t; int level; };
-  std::vector<TmpTask> tasks;
-  std::vector<std::pair<int, int>> map_sd;  // (src slot, dst slot)
-  for (int p = 0; p < P.npiv; ++p) {
-    const int w = P.piv_w[p], p0 = P.piv_start[p];
-    const int f = w + (int)rows[p].size();
-    const int R = std::max(1, opt.acc_doubles / w);
-    const int nchunk = (f + R - 1) / R;
-    std::vector<std::vector<FSrc>> chunk_srcs(nchunk);
-    for (auto& km : rowpat[p]) {
-      const int k = km.first, mslot = km.second, wk = P.piv_w[k];
-      const auto& rk = rows[k];
-      // rows of panel k from slot mslot on -> slots of panel p (two-pointer over sorted lists)
-      map_sd.clear();
-      size_t tp = 0;
-      for (size_t t = (size_t)(mslot - wk); t < rk.size(); ++t) {
-        int r = rk[t];
-        int d;
-        if (r < p0 + w) d = r - p0;
-        else {
-          while (tp < rows[p].size() && rows[p][tp] < r) ++tp;
-          if (tp >= rows[p].size() || rows[p][tp] != r) { P.error = "internal: fill closure violated"; return 3; }
-          d = w + (int)tp;
-        }
-        map_sd.push_back({wk + (int)t, d});
-      }
-      size_t i = 0;
-      while (i < map_sd.size()) {
-        int c = map_sd[i].second / R;
-        FSrc src{k, mslot, (int)P.runs.size(), 0};
-        while (i < map_sd.size() && map_sd[i].second / R == c) {
-          Run run{map_sd[i].first, map_sd[i].second - c * R, 1};
-          ++i;
-          while (i < map_sd.size() && map_sd[i].second / R == c && map_sd[i].first == run.src + run.len &&
-                 map_sd[i].second - c * R == run.dst + run.len) { ++run.len; ++i; }
-          P.runs.push_back(run);
-          P.flops_factor += (int64_t)run.len * wk * w;
-        }
-        src.run1 = (int)P.runs.size();
-        chunk_srcs[c].push_back(src);
-      }
-    }
-    for (int c = 0; c < nchunk; ++c) {
-      TmpTask tt;
-      tt.level = P.piv_level[p];
-      tt.t.piv = p; tt.t.r0 = c * R; tt.t.r1 = std::min(f, (c + 1) * R);
-      tt.t.src0 = (int)P.fsrcs.size();
-      P.fsrcs.insert(P.fsrcs.end(), chunk_srcs[c].begin(), chunk_srcs[c].end());
-      tt.t.src1 = (int)P.fsrcs.size();
-      tasks.push_back(tt);
-    }
-  }
-  std::stable_sort(tasks.begin(), tasks.end(), [](const TmpTask& a, const TmpTask& b) { return a.level < b.level; });
-  P.flevel_ptr.assign(P.n_levels + 1, 0);
-  for (auto& t : tasks) { P.ftasks.push_back(t.t); P.flevel_ptr[t.level + 1]++; }
-  for (int l = 0; l < P.n_levels; ++l) P.flevel_ptr[l + 1] += P.flevel_ptr[l];
+  // inverse-pivot scalar (t, t') of pivot k in Dinv storage
+  auto dinv_pos = [&](int k, int t, int t2) -> int {
+    if (P.piv_w[k] == 1) return P.piv_doff[k];
+    return P.piv_doff[k] + ((t == t2) ? (t == 0 ? 0 : 2) : 1);
+  };
 
-  // ---- 7. coupling rows: which panels hold them (forward solve of the Schur rhs)
+  // ---- 6. factor tasks in flat scalar form (left-looking gathers, rows chunked by entry count)
   {
+    // canonical entries by U position (assembly is fused into the factor tasks)
+    std::vector<std::pair<int64_t, int>> can_by_pos(P.ncan);
+    for (int e = 0; e < P.ncan; ++e) can_by_pos[e] = {P.pos_of_can[e], e};
+    std::sort(can_by_pos.begin(), can_by_pos.end());
+    size_t can_cursor = 0;  // panels are visited in increasing U position
+    struct TmpTask { FTask t; int level; int nm; };
+    std::vector<TmpTask> tasks;
+    struct SlotEnt { int src; int k; int t; int q; };  // contribution U_k[src row, t] * M_k[t][q] to column q
+    std::vector<std::vector<SlotEnt>> slot_ents;       // per slot of panel p
+    for (int p = 0; p < P.npiv; ++p) {
+      const int w = P.piv_w[p], p0 = P.piv_start[p];
+      const int f = w + (int)rows[p].size();
+      slot_ents.assign(f, {});
+      for (auto& km : rowpat[p]) {
+        const int k = km.first, mslot = km.second, wk = P.piv_w[k];
+        const auto& rk = rows[k];
+        size_t tp = 0;
+        for (size_t t = (size_t)(mslot - wk); t < rk.size(); ++t) {
+          const int r = rk[t];
+          int d;
+          if (r < p0 + w) d = r - p0;
+          else {
+            while (tp < rows[p].size() && rows[p][tp] < r) ++tp;
+            if (tp >= rows[p].size() || rows[p][tp] != r) { P.error = "internal: fill closure violated"; return 3; }
+            d = w + (int)tp;
+          }
+          const int srow = wk + (int)t;
+          for (int tt = 0; tt < wk; ++tt)
+            for (int q = 0; q < w; ++q)
+              slot_ents[d].push_back({(int)(P.piv_uoff[k] + (int64_t)srow * wk + tt), k, tt, q});
+          P.flops_factor += (int64_t)wk * w;
+        }
+      }
+      // initial values: canonical entries located in this panel
+      std::vector<std::vector<int>> init_of_scalar((size_t)f * w);
+      const int64_t u0 = P.piv_uoff[p], u1 = u0 + (int64_t)f * w;
+      while (can_cursor < can_by_pos.size() && can_by_pos[can_cursor].first < u1) {
+        if (can_by_pos[can_cursor].first >= u0)
+          init_of_scalar[(size_t)(can_by_pos[can_cursor].first - u0)].push_back(can_by_pos[can_cursor].second);
+        ++can_cursor;
+      }
+      // chunk the slots; the pivot block (slots 0..w-1) always opens the first chunk
+      int r = 0;
+      while (r < f) {
+        TmpTask tt;
+        tt.level = P.piv_level[p];
+        tt.t.piv = p; tt.t.r0 = r; tt.t.m0 = (int)P.mrecs.size(); tt.t.dptr0 = (int)P.fdst_ptr.size();
+        std::map<std::tuple<int, int, int>, int> mloc;  // (k, t, q) -> local multiplier index
+        int nent = 0;
+        int r_end = r;
+        while (r_end < f) {
+          // cost of adding slot r_end
+          int add_e = (int)slot_ents[r_end].size();
+          for (int q = 0; q < w; ++q) add_e += (int)init_of_scalar[(size_t)r_end * w + q].size();
+          int add_m = 0;
+          for (auto& se : slot_ents[r_end]) if (!mloc.count(std::make_tuple(se.k, se.t, se.q))) ++add_m;  // upper bound
+          const bool must = (r_end == r) || (r == 0 && r_end < w);
+          if (!must && (nent + add_e > opt.max_task_entries || (int)mloc.size() + add_m > opt.max_task_mults)) break;
+          for (auto& se : slot_ents[r_end]) {
+            auto key = std::make_tuple(se.k, se.t, se.q);
+            if (!mloc.count(key)) { int id = (int)mloc.size(); mloc[key] = id; }
+          }
+          nent += add_e;
+          ++r_end;
+        }
+        // multiplier records in local-index order
+        std::vector<MRec> mr(mloc.size());
+        for (auto& kv : mloc) {
+          const int k = std::get<0>(kv.first), t = std::get<1>(kv.first), q = std::get<2>(kv.first);
+          const int wk = P.piv_w[k];
+          // slot of row (p0 + q) inside panel k
+          int ms = -1;
+          for (auto& km : rowpat[p]) if (km.first == k) { ms = km.second; break; }
+          MRec m;
+          m.d0 = dinv_pos(k, t, 0); m.u0 = (int)(P.piv_uoff[k] + (int64_t)(ms + q) * wk + 0);
+          if (wk == 2) { m.d1 = dinv_pos(k, t, 1); m.u1 = (int)(P.piv_uoff[k] + (int64_t)(ms + q) * wk + 1); }
+          else { m.d1 = -1; m.u1 = -1; }
+          mr[kv.second] = m;
+        }
+        P.mrecs.insert(P.mrecs.end(), mr.begin(), mr.end());
+        tt.t.m1 = (int)P.mrecs.size();
+        tt.nm = (int)mr.size();
+        // entries per destination scalar: initial values first (midx 0 = -1), then updates
+        for (int rr = r; rr < r_end; ++rr)
+          for (int q = 0; q < w; ++q) {
+            P.fdst_ptr.push_back((int)P.fentries.size());
+            for (int e : init_of_scalar[(size_t)rr * w + q]) P.fentries.push_back({-1 - e, 0});
+            for (auto& se : slot_ents[rr])
+              if (se.q == q) P.fentries.push_back({se.src, 1 + mloc[std::make_tuple(se.k, se.t, se.q)]});
+          }
+        P.fdst_ptr.push_back((int)P.fentries.size());
+        tt.t.r1 = r_end;
+        tasks.push_back(tt);
+        r = r_end;
+      }
+    }
+    std::stable_sort(tasks.begin(), tasks.end(), [](const TmpTask& a, const TmpTask& b) { return a.level < b.level; });
+    P.flevel_ptr.assign(P.n_levels + 1, 0);
+    P.flevel_maxm.assign(P.n_levels, 0);
+    for (auto& t : tasks) {
+      P.ftasks.push_back(t.t);
+      P.flevel_ptr[t.level + 1]++;
+      P.flevel_maxm[t.level] = std::max(P.flevel_maxm[t.level], t.nm);
+    }
+    for (int l = 0; l < P.n_levels; ++l) P.flevel_ptr[l + 1] += P.flevel_ptr[l];
+  }
+
+  // ---- 7. solve schedules in flat scalar form
+  {
+    // forward: scalar row c (new column) gathers U[c, k-columns] * z[k-columns]
+    P.sfwd_eptr.assign(n + 1, 0);
+    for (int p = 0; p < P.npiv; ++p)
+      for (int q = 0; q < P.piv_w[p]; ++q) {
+        const int c = P.piv_start[p] + q;
+        for (auto& km : rowpat[p]) {
+          const int k = km.first, wk = P.piv_w[k];
+          for (int t = 0; t < wk; ++t) {
+            P.sfwd_upos.push_back((int)(P.piv_uoff[k] + (int64_t)(km.second + q) * wk + t));
+            P.sfwd_zcol.push_back(P.piv_start[k] + t);
+          }
+        }
+        P.sfwd_eptr[c + 1] = (int)P.sfwd_upos.size();
+      }
     std::vector<std::vector<std::pair<int, int>>> cr(nc);
     for (int k = 0; k < P.npiv; ++k) {
       const auto& r = rows[k];
+      const int wk = P.piv_w[k];
       for (size_t t = r.size(); t-- > 0;) {
         if (r[t] < n) break;
-        cr[r[t] - n].push_back({k, P.piv_w[k] + (int)t});
+        for (int tt = 0; tt < wk; ++tt)
+          cr[r[t] - n].push_back({(int)(P.piv_uoff[k] + (int64_t)(wk + (int)t) * wk + tt), P.piv_start[k] + tt});
       }
     }
-    P.crow_ptr.assign(nc + 1, 0);
+    P.crow_eptr.assign(nc + 1, 0);
     for (int c = 0; c < nc; ++c) {
-      P.crow_ptr[c + 1] = P.crow_ptr[c] + (int)cr[c].size();
-      for (auto& ks : cr[c]) { P.crow_k.push_back(ks.first); P.crow_slot.push_back(ks.second); }
+      for (auto& e : cr[c]) { P.crow_upos.push_back(e.first); P.crow_zcol.push_back(e.second); }
+      P.crow_eptr[c + 1] = (int)P.crow_upos.size();
     }
   }
 

@@ -156,6 +156,17 @@ class HipEngine(object):
             self.ns.check(self.lib.pp_factor_schur(self.ns.h, Qp), 'pp_factor_schur')
             self.ns.check(self.lib.pp_synchronize(self.ns.h), 'pp_synchronize')   # Qf must outlive the H2D
 
+    def set_dense_policy(self, policy):
+        """0: optimistic blocked LDL^T (fp64 MFMA) with Bunch-Kaufman fallback; 1: Bunch-Kaufman only."""
+        self.ns.check(self.lib.pp_set_dense_policy(self.ns.h, int(policy)), 'pp_set_dense_policy')
+
+    def dense_mode(self):
+        """1 if the last S factorisation was the accepted blocked LDL^T, 0 if Bunch-Kaufman."""
+        import ctypes
+        m = ctypes.c_int(-1)
+        self.ns.check(self.lib.pp_get_dense_mode(self.ns.h, ctypes.byref(m)), 'pp_get_dense_mode')
+        return int(m.value)
+
     def status(self):
         out = np.zeros(4, dtype=np.int64)
         import ctypes

@@ -25,10 +25,10 @@ struct HostCtx {
 extern "C" {
 
 void* ppsim_create(int n, int nc, int nnzK, const int* rowK, const int* colK, int nnzB, const int* rowB,
-                   const int* colB, const double* vals, int acc_doubles, int delta_abs, double delta_rel) {
+                   const int* colB, const double* vals, int max_entries, int delta_abs, double delta_rel) {
   auto* P = new Plan();
   pp::PlanOptions opt;
-  if (acc_doubles > 0) opt.acc_doubles = acc_doubles;
+  if (max_entries > 0) opt.max_task_entries = max_entries;
   if (delta_abs >= 0) opt.md_delta_abs = delta_abs;
   if (delta_rel >= 0) opt.md_delta_rel = delta_rel;
   int rc = pp::build_plan(n, nc, nnzK, rowK, colK, nnzB, rowB, colB, vals, opt, *P);
@@ -43,8 +43,9 @@ void ppsim_stats(void* h, int64_t* out) {
   Plan& P = *(Plan*)h;
   out[0] = P.n; out[1] = P.nc; out[2] = P.npiv; out[3] = P.n_levels; out[4] = P.n_2x2; out[5] = P.usize;
   out[6] = P.nnz_L; out[7] = P.flops_factor; out[8] = P.flops_schur; out[9] = (int64_t)P.ftasks.size();
-  out[10] = (int64_t)P.runs.size(); out[11] = (int64_t)P.stile_a.size(); out[12] = (int64_t)P.stile_rec.size();
+  out[10] = (int64_t)P.fentries.size(); out[11] = (int64_t)P.stile_a.size(); out[12] = (int64_t)P.stile_rec.size();
 }
+int ppsim_dsize(void* h) { return ((Plan*)h)->dsize; }
 void ppsim_get_perm(void* h, int* perm) { Plan& P = *(Plan*)h; std::memcpy(perm, P.perm.data(), sizeof(int) * P.n); }
 void ppsim_get_levels(void* h, int* lv) { Plan& P = *(Plan*)h; std::memcpy(lv, P.piv_level.data(), sizeof(int) * P.npiv); }
 void ppsim_get_level_task_counts(void* h, int* cnt) {
@@ -52,64 +53,57 @@ void ppsim_get_level_task_counts(void* h, int* cnt) {
   for (int l = 0; l < P.n_levels; ++l) cnt[l] = P.flevel_ptr[l + 1] - P.flevel_ptr[l];
 }
 
+// per task: level, pivot width, rows, number of multiplier scalars, number of entries
+void ppsim_task_profile(void* h, int* out /*5 per task*/) {
+  Plan& P = *(Plan*)h;
+  for (size_t t = 0; t < P.ftasks.size(); ++t) {
+    const auto& ft = P.ftasks[t];
+    const int w = P.piv_w[ft.piv], ndst = (ft.r1 - ft.r0) * w;
+    out[5 * t] = P.piv_level[ft.piv]; out[5 * t + 1] = w; out[5 * t + 2] = ft.r1 - ft.r0;
+    out[5 * t + 3] = ft.m1 - ft.m0; out[5 * t + 4] = P.fdst_ptr[ft.dptr0 + ndst] - P.fdst_ptr[ft.dptr0];
+  }
+}
+
 // One instance.  can: canonical values (ncan).  U: usize, Dinv: 3*npiv, S: nc*nc (row-major,
 // lower filled; contribution -A K^-1 A^T), inertia[3] += (pos, neg, zero).
 int ppsim_factor(void* h, const double* can, double* U, double* Dinv, double* S, int64_t* inertia, double eps) {
   Plan& P = *(Plan*)h;
   std::memset(U, 0, sizeof(double) * P.usize);
-  for (int e = 0; e < P.ncan; ++e) U[P.pos_of_can[e]] += can[e];
-  std::vector<double> acc;
+  std::vector<double> M;
   int pos = 0, neg = 0, zero = 0;
   for (const auto& t : P.ftasks) {
     const int p = t.piv, w = P.piv_w[p];
-    const int64_t off = P.piv_uoff[p];
-    const int nr = t.r1 - t.r0;
-    acc.assign((size_t)nr * w, 0.0);
-    for (int r = 0; r < nr; ++r)
-      for (int q = 0; q < w; ++q) acc[r * w + q] = U[off + (int64_t)(t.r0 + r) * w + q];
-    double dorig[3] = {0, 0, 0};
-    if (t.r0 == 0) { dorig[0] = acc[0]; if (w == 2) { dorig[1] = acc[2]; dorig[2] = acc[3]; } }
-    for (int s = t.src0; s < t.src1; ++s) {
-      const auto& src = P.fsrcs[s];
-      const int k = src.k, wk = P.piv_w[k];
-      const int64_t offk = P.piv_uoff[k];
-      const double* inv = &Dinv[3 * (size_t)k];
-      // M[t][q] = sum_t' inv[t][t'] * U_k[mslot+q][t']
-      double M[2][2] = {{0, 0}, {0, 0}};
-      for (int q = 0; q < w; ++q) {
-        const double* uq = &U[offk + (int64_t)(src.mslot + q) * wk];
-        if (wk == 1) M[0][q] = inv[0] * uq[0];
-        else {
-          M[0][q] = inv[0] * uq[0] + inv[1] * uq[1];
-          M[1][q] = inv[1] * uq[0] + inv[2] * uq[1];
-        }
+    const int64_t dst0 = P.piv_uoff[p] + (int64_t)t.r0 * w;
+    const int ndst = (t.r1 - t.r0) * w;
+    M.assign(1 + (t.m1 - t.m0), -1.0);
+    for (int j = t.m0; j < t.m1; ++j) {
+      const auto& m = P.mrecs[j];
+      double v = Dinv[m.d0] * U[m.u0];
+      if (m.d1 >= 0) v += Dinv[m.d1] * U[m.u1];
+      M[1 + (j - t.m0)] = v;
+    }
+    double piv[4] = {0, 0, 0, 0}, tmax_diag = 0.0, colmax = 0.0;
+    for (int d = 0; d < ndst; ++d) {
+      double acc = 0.0, tmax = 0.0;
+      for (int e = P.fdst_ptr[t.dptr0 + d]; e < P.fdst_ptr[t.dptr0 + d + 1]; ++e) {
+        const auto& fe = P.fentries[e];
+        const double src = (fe.src >= 0) ? U[fe.src] : can[-1 - fe.src];
+        const double term = src * M[fe.midx];
+        acc -= term;
+        tmax = std::fmax(tmax, std::fabs(term));
       }
-      for (int ri = src.run0; ri < src.run1; ++ri) {
-        const auto& run = P.runs[ri];
-        for (int j = 0; j < run.len; ++j) {
-          const double* us = &U[offk + (int64_t)(run.src + j) * wk];
-          double* a = &acc[(size_t)(run.dst + j) * w];
-          for (int q = 0; q < w; ++q) {
-            double v = us[0] * M[0][q];
-            if (wk == 2) v += us[1] * M[1][q];
-            a[q] -= v;
-          }
-        }
-      }
+      U[dst0 + d] = acc;
+      if (t.r0 == 0 && d < w * w) { piv[d] = acc; tmax_diag = std::fmax(tmax_diag, tmax); }
+      else colmax = std::fmax(colmax, std::fabs(acc));
     }
     if (t.r0 == 0) {
-      double a = acc[0], b = (w == 2 ? acc[2] : 0.0), c = (w == 2 ? acc[3] : 0.0);
-      double colmax = 0;
-      for (int r = w; r < nr; ++r)
-        for (int q = 0; q < w; ++q) colmax = std::fmax(colmax, std::fabs(acc[r * w + q]));
-      colmax = std::fmax(colmax, std::fabs(dorig[0]));
-      if (w == 2) colmax = std::fmax(colmax, std::fmax(std::fabs(dorig[1]), std::fabs(dorig[2])));
-      pp::PivotResult pr = pp::invert_pivot(w, a, b, c, colmax, eps);
-      Dinv[3 * (size_t)p] = pr.i00; Dinv[3 * (size_t)p + 1] = pr.i10; Dinv[3 * (size_t)p + 2] = pr.i11;
+      const double a = piv[0], b = (w == 2 ? piv[2] : 0.0), c = (w == 2 ? piv[3] : 0.0);
+      pp::PivotResult pr = pp::invert_pivot(w, a, b, c, std::fmax(colmax, tmax_diag), eps);
+      double* inv = &Dinv[P.piv_doff[p]];
+      inv[0] = pr.i00;
+      if (w == 2) { inv[1] = pr.i10; inv[2] = pr.i11; }
       pos += pr.code & 3; neg += (pr.code >> 2) & 3; zero += (pr.code >> 4) & 3;
     }
-    for (int r = 0; r < nr; ++r)
-      for (int q = 0; q < w; ++q) U[off + (int64_t)(t.r0 + r) * w + q] = acc[r * w + q];
   }
   inertia[0] += pos; inertia[1] += neg; inertia[2] += zero;
   // Schur tiles
@@ -120,7 +114,7 @@ int ppsim_factor(void* h, const double* can, double* U, double* Dinv, double* S,
       const auto& rec = P.stile_rec[r];
       const int p = rec.piv, w = P.piv_w[p];
       const int64_t off = P.piv_uoff[p];
-      const double* inv = &Dinv[3 * (size_t)p];
+      const double* inv = &Dinv[P.piv_doff[p]];
       for (int i = 0; i < T; ++i) {
         if (rec.slotA[i] < 0) continue;
         const double* ua = &U[off + (int64_t)rec.slotA[i] * w];
@@ -146,28 +140,21 @@ int ppsim_factor(void* h, const double* can, double* U, double* Dinv, double* S,
 // forward: W (n+nc) gets permuted rhs in [0,n); on exit W[0,n) = z, W[n+c] = -A K^-1 r contribution
 void ppsim_forward(void* h, const double* U, const double* Dinv, const double* rhs, double* W) {
   Plan& P = *(Plan*)h;
-  for (int k = 0; k < P.n; ++k) W[k] = rhs[P.perm[k]];
   for (int li = 0; li < P.npiv; ++li) {
     const int p = P.lvl_piv[li], w = P.piv_w[p], p0 = P.piv_start[p];
-    double y[2] = {W[p0], w == 2 ? W[p0 + 1] : 0.0};
-    for (int s = P.sfwd_ptr[p]; s < P.sfwd_ptr[p + 1]; ++s) {
-      const int k = P.sfwd_k[s], wk = P.piv_w[k], k0 = P.piv_start[k];
-      for (int q = 0; q < w; ++q) {
-        const double* u = &U[P.piv_uoff[k] + (int64_t)(P.sfwd_mslot[s] + q) * wk];
-        y[q] -= u[0] * W[k0] + (wk == 2 ? u[1] * W[k0 + 1] : 0.0);
-      }
+    double y[2] = {0, 0};
+    for (int q = 0; q < w; ++q) {
+      double acc = rhs[P.perm[p0 + q]];
+      for (int e = P.sfwd_eptr[p0 + q]; e < P.sfwd_eptr[p0 + q + 1]; ++e) acc -= U[P.sfwd_upos[e]] * W[P.sfwd_zcol[e]];
+      y[q] = acc;
     }
-    const double* inv = &Dinv[3 * (size_t)p];
+    const double* inv = &Dinv[P.piv_doff[p]];
     if (w == 1) W[p0] = inv[0] * y[0];
     else { W[p0] = inv[0] * y[0] + inv[1] * y[1]; W[p0 + 1] = inv[1] * y[0] + inv[2] * y[1]; }
   }
   for (int c = 0; c < P.nc; ++c) {
     double s = 0;
-    for (int t = P.crow_ptr[c]; t < P.crow_ptr[c + 1]; ++t) {
-      const int k = P.crow_k[t], wk = P.piv_w[k], k0 = P.piv_start[k];
-      const double* u = &U[P.piv_uoff[k] + (int64_t)P.crow_slot[t] * wk];
-      s -= u[0] * W[k0] + (wk == 2 ? u[1] * W[k0 + 1] : 0.0);
-    }
+    for (int e = P.crow_eptr[c]; e < P.crow_eptr[c + 1]; ++e) s -= U[P.crow_upos[e]] * W[P.crow_zcol[e]];
     W[P.n + c] = s;
   }
 }
@@ -183,7 +170,7 @@ void ppsim_backward(void* h, const double* U, const double* Dinv, double* W, dou
     const double* u = &U[P.piv_uoff[p] + (int64_t)w * w];
     for (int j = 0; j < nr; ++j)
       for (int q = 0; q < w; ++q) g[q] += u[(int64_t)j * w + q] * W[ri[j]];
-    const double* inv = &Dinv[3 * (size_t)p];
+    const double* inv = &Dinv[P.piv_doff[p]];
     if (w == 1) W[p0] -= inv[0] * g[0];
     else {
       W[p0] -= inv[0] * g[0] + inv[1] * g[1];

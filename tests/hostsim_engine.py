@@ -60,7 +60,7 @@ class HostSimEngine(object):
             for b in range(sg.batch):
                 can = np.add.reduceat(sg.raw[b][g.can_idx], g.can_ptr[:-1]) if g.can_idx.size else np.zeros(0)
                 U = np.zeros(sg.usize)
-                D = np.zeros(3 * sg.npiv)
+                D = np.zeros(L.ppsim_dsize(sg.h))
                 Sb = np.zeros((nc, nc))
                 L.ppsim_factor(sg.h, hu._dp(np.ascontiguousarray(can)), hu._dp(U), hu._dp(D), hu._dp(Sb),
                                inertia.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), ctypes.c_double(1e-13))

@@ -70,7 +70,7 @@ class HostSim(object):
         st = np.zeros(13, dtype=np.int64)
         L.ppsim_stats(self.h, st.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)))
         keys = ['n', 'nc', 'npiv', 'n_levels', 'n_2x2', 'usize', 'nnz_L', 'flops_factor', 'flops_schur',
-                'ntasks', 'nruns', 'ntiles', 'ntilerecs']
+                'ntasks', 'nentries', 'ntiles', 'ntilerecs']
         self.stats = dict(zip(keys, [int(v) for v in st]))
 
     def canonical(self, K, A):
@@ -96,7 +96,7 @@ class HostSim(object):
     def factor(self, can=None, eps=1e-13):
         can = self.can0 if can is None else np.ascontiguousarray(can, dtype=np.double)
         self.U = np.zeros(self.stats['usize'])
-        self.Dinv = np.zeros(3 * self.stats['npiv'])
+        self.Dinv = np.zeros(lib().ppsim_dsize(self.h))
         S = np.zeros((self.nc, self.nc))
         inertia = np.zeros(3, dtype=np.int64)
         rc = lib().ppsim_factor(self.h, _dp(can), _dp(self.U), _dp(self.Dinv), _dp(S),

@@ -1,0 +1,89 @@
+"""Worker of tests/test_multirank_gloo.py: one rank of a world_size-2 gloo run on CPU.
+
+Rehearses the N>1 host path of HipSchurComplementLinearSolver -- ownership (Q10), the packed
+S+status all-reduce, the r_s all-reduce, rank-consistent status -- with the TEST-ONLY host
+interpreter standing in for the GPU (the HIP path needs a device; the collectives and the host
+logic are identical)."""
+import os
+import sys
+
+import numpy as np
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+from hostsim_engine import HostSimEngine  # noqa: E402
+from oracle.schur_complement import MPISchurComplementLinearSolver as OracleSC  # noqa: E402
+from oracle.subsolvers import ScipyInterface as OracleScipy  # noqa: E402
+from parapint_amd.examples.performance.schur_complement.synthetic_kkt import (SyntheticKKT,  # noqa: E402
+                                                                              distribute_blocks)
+from parapint_amd.linalg.comm import SerialComm, TorchComm  # noqa: E402
+from parapint_amd.linalg.hip_schur_complement import HipSchurComplementLinearSolver  # noqa: E402
+from parapint_amd.linalg.results import LinearSolverStatus  # noqa: E402
+
+
+def main():
+    dist.init_process_group('gloo')
+    comm = TorchComm()
+    rank, size = comm.rank, comm.size
+    assert size == 2
+    shape = (5, 40, 2, 8)
+    N = shape[0]
+    local = distribute_blocks(N, rank, size)
+    model = SyntheticKKT(*shape, local_blocks=local)
+    kkt = model.build_kkt(comm=comm, iteration=2)
+    rhs = model.build_rhs(comm=comm)
+    solver = HipSchurComplementLinearSolver({i: None for i in local}, None, comm=comm, engine=HostSimEngine())
+    assert solver.do_symbolic_factorization(kkt).status == LinearSolverStatus.successful
+    assert solver.local_block_indices == local
+    assert solver.do_numeric_factorization(kkt).status == LinearSolverStatus.successful
+    x = solver.do_back_solve(rhs)
+    # single-process oracle on the whole system
+    full_model = SyntheticKKT(*shape)
+    okkt = full_model.build_kkt(comm=SerialComm(), iteration=2)
+    orhs = full_model.build_rhs(comm=SerialComm())
+    oracle = OracleSC({i: OracleScipy(compute_inertia=True) for i in range(N)}, OracleScipy(compute_inertia=True))
+    oracle.do_symbolic_factorization(okkt)
+    oracle.do_numeric_factorization(okkt)
+    xo = oracle.do_back_solve(orhs)
+    So = oracle.schur_complement.toarray()
+    assert np.abs(solver.get_schur_complement() - So).max() <= 1e-9 * np.abs(So).max()
+    for ndx in local:
+        ref = np.asarray(xo.get_block(ndx))
+        assert np.abs(np.asarray(x.get_block(ndx)) - ref).max() <= 1e-8 * np.abs(ref).max()
+    for ndx in range(N):
+        if ndx not in local:
+            assert x.get_block(ndx) is None            # non-local blocks stay unset (mpi_...:390-398)
+    assert np.allclose(x.get_block(N), xo.get_block(N), rtol=1e-8, atol=1e-10)
+    assert solver.get_inertia() == oracle.get_inertia()
+    assert abs(model.check_result(x, comm=comm) - full_model.check_result(xo)) < 1e-8
+    # the oracle's own MPI restatement over gloo gives the same S
+    o2 = OracleSC({i: OracleScipy(compute_inertia=True) for i in local}, OracleScipy(compute_inertia=True), comm=comm)
+    o2.do_symbolic_factorization(kkt)
+    o2.do_numeric_factorization(kkt)
+    assert np.abs(o2.schur_complement.toarray() - So).max() <= 1e-10 * np.abs(So).max()
+    assert o2.get_inertia() == oracle.get_inertia()
+
+    # status agreement: a singular block on rank 1 only must be reported by both ranks
+    if rank == 1:
+        from scipy.sparse import coo_matrix
+        K = kkt.get_block(local[0], local[0]).tocoo()
+        d = K.data.copy()
+        d[:] = 0.0
+        kkt.set_block(local[0], local[0], coo_matrix((d, (K.row, K.col)), shape=K.shape))
+    res = solver.do_numeric_factorization(kkt, raise_on_error=False)
+    assert res.status == LinearSolverStatus.singular
+    try:
+        solver.do_numeric_factorization(kkt, raise_on_error=True)
+        raise AssertionError('expected RuntimeError')
+    except RuntimeError:
+        pass
+    dist.barrier()
+    dist.destroy_process_group()
+    print('rank %d ok' % rank)
+
+
+if __name__ == '__main__':
+    main()

@@ -75,3 +75,63 @@ def test_full_size_blocks_property():
     # configuration-3 block shape (n_i = 9200, n_c = 200) on 130 instances: residual + inertia properties
     solver, model = sc.case_against_oracle(make_engine, (130, 1000, 4, 200), iteration=4, check_full_space=False)
     assert solver.plan_stats[0]['n'] == 9200
+
+
+def test_dense_schur_paths_agree():
+    """S of the synthetic KKT is positive definite: the blocked MFMA LDL^T must be accepted and
+    give the same solution as the Bunch-Kaufman kernel (ragged last panel: n_c = 100, 200, 37)."""
+    from parapint_amd.examples.performance.schur_complement.synthetic_kkt import SyntheticKKT
+    from parapint_amd.linalg.comm import SerialComm
+    for shape in [(8, 120, 2, 37), (6, 400, 2, 100), (4, 1000, 2, 200)]:
+        model = SyntheticKKT(*shape)
+        kkt = model.build_kkt(comm=SerialComm(), iteration=1)
+        rhs = model.build_rhs(comm=SerialComm())
+        sols, modes = [], []
+        for policy in (0, 1):
+            solver = sc.new_solver(make_engine, shape[0])
+            solver._eng.set_dense_policy(policy)
+            solver.do_symbolic_factorization(kkt)
+            solver.do_numeric_factorization(kkt)
+            modes.append(solver._eng.dense_mode())
+            x = solver.do_back_solve(rhs)
+            assert sc.scaled_residual(kkt.tocoo(), x.flatten(), rhs.flatten()) <= sc.RESID_TOL
+            sols.append((x.flatten(), solver.get_inertia()))
+        assert modes == [1, 0]
+        assert sols[0][1] == sols[1][1]
+        assert np.abs(sols[0][0] - sols[1][0]).max() <= 1e-9 * np.abs(sols[1][0]).max()
+
+
+def test_indefinite_schur_falls_back_to_bunch_kaufman():
+    # heterogeneous case has an indefinite S + Q: the optimistic factor must be rejected on device
+    import numpy as np
+    from scipy.sparse import coo_matrix
+    from parapint_amd.sparse.block_containers import BlockMatrix, BlockVector
+    rng = np.random.default_rng(3)
+    nb, nc = 3, 40
+    A = BlockMatrix(nb + 1, nb + 1)
+    rhs = BlockVector(nb + 1)
+    full = np.zeros((nb * 30 + nc, nb * 30 + nc))
+    for i in range(nb):
+        M = rng.normal(size=(30, 30))
+        K = M @ M.T + 30 * np.eye(30)
+        B = rng.normal(size=(nc, 30))
+        A.set_block(i, i, coo_matrix(K))
+        A.set_block(nb, i, coo_matrix(B))
+        rhs.set_block(i, rng.normal(size=30))
+        full[30 * i:30 * i + 30, 30 * i:30 * i + 30] = K
+        full[nb * 30:, 30 * i:30 * i + 30] = B
+        full[30 * i:30 * i + 30, nb * 30:] = B.T
+    Q = rng.normal(size=(nc, nc))
+    Q = Q + Q.T                                   # indefinite coupling block
+    A.set_block(nb, nb, coo_matrix(Q))
+    full[nb * 30:, nb * 30:] = Q
+    rhs.set_block(nb, rng.normal(size=nc))
+    solver = sc.new_solver(make_engine, nb)
+    solver.do_symbolic_factorization(A)
+    solver.do_numeric_factorization(A)
+    assert solver._eng.dense_mode() == 0
+    x = solver.do_back_solve(rhs)
+    x_ref = np.linalg.solve(full, rhs.flatten())
+    assert np.abs(x.flatten() - x_ref).max() <= 1e-8 * np.abs(x_ref).max()
+    ev = np.linalg.eigvalsh(full)
+    assert solver.get_inertia() == (int((ev > 0).sum()), int((ev < 0).sum()), 0)

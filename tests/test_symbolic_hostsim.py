@@ -112,7 +112,7 @@ def test_dense_coupling_rows():
 def test_chunked_panels_small_accumulator():
     m = SyntheticKKT(2, 60, 3, 24)
     K, A = m.block_matrix(0), m.border_matrix()
-    hs = HostSim(K, A, acc_doubles=4)          # forces many row chunks per panel
+    hs = HostSim(K, A, acc_doubles=6)          # max 6 entries per task: forces many row chunks per panel
     rc, S, inertia = hs.factor()
     Kd = sym_dense(K)
     Ad = A.toarray()
