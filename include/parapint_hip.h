@@ -93,6 +93,10 @@ int pp_bind_schur_buffer(pp_handle h, double* dev_ptr);
  * Q: dense column-major n_c x n_c on the host (lower triangle read), or NULL for Q = 0. */
 int pp_factor_schur(pp_handle h, const double* Q_host);
 
+/* Number of instance groups whose level sweeps run on separate HIP streams (their top-of-tree
+ * levels are latency-bound; overlapping groups keeps the chip busy).  0 = automatic (default). */
+int pp_set_instance_splits(pp_handle h, int nsplit);
+
 /* Dense policy for S: 0 (default) = blocked LDL^T without pivoting on the fp64 matrix cores,
  * accepted only when all pivots share one sign (S definite), with the Bunch-Kaufman kernel as the
  * on-device fallback; 1 = Bunch-Kaufman only.  pp_get_dense_mode reports which factor the last

@@ -29,6 +29,12 @@ namespace pp {
 struct PlanOptions {
   int max_task_entries = 96;   // update entries per factor task (rows of a panel are chunked to fit)
   int max_task_mults = 62;     // multiplier scalars per factor task (LDS table, 512 B each)
+  // Top of the elimination tree ("tail"): levels holding at most tail_piv_max pivots each are run
+  // inside ONE persistent launch per phase (a workgroup per 64 instances, barrier per level), with
+  // smaller tasks so that the few waves of that workgroup share the work.
+  int tail_piv_max = 48;
+  int tail_task_entries = 48;
+  int tail_task_mults = 30;
   int tile = 8;           // register tile edge of the Schur (SYRK) kernel
   int md_delta_abs = 3;   // minimum-degree tolerance (absolute) for height-aware selection
   double md_delta_rel = 0.5;   // ... and relative to the current minimum degree
@@ -69,6 +75,7 @@ struct Plan {
   std::vector<FEntry> fentries;
   std::vector<int> flevel_ptr;           // n_levels+1 -> ftasks
   std::vector<int> flevel_maxm;          // per level: max multiplier scalars of a task (LDS sizing)
+  int tail_level0 = 0;                   // levels >= tail_level0 form the tail (== n_levels: no tail)
   // forward-solve entries: scalar row (new column index c) = b_c - sum U[upos] * z[zcol]
   std::vector<int> sfwd_eptr;            // n+1 -> sfwd_upos / sfwd_zcol
   std::vector<int> sfwd_upos, sfwd_zcol;

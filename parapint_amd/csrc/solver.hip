@@ -29,6 +29,7 @@
 namespace {
 
 constexpr int WAVE = 64;
+constexpr int PP_MAX_SPLIT = 8;
 constexpr int PP_NPHASE = 8;  // assemble, factor, schur, dense, fwd, fwd_coupling, coupling_solve, bwd
 constexpr int BK_THREADS = 512;
 constexpr double PIVOT_EPS = 1e-13;
@@ -41,7 +42,7 @@ struct GroupDev {
   int64_t usize;
   const int *piv_w, *piv_start, *piv_uoff, *piv_doff, *piv_rowptr, *rowidx, *perm, *iperm;
   const int *ftask, *mrec, *fdst_ptr, *fent;
-  const int *lvl_piv, *sfwd_eptr, *sfwd_upos, *sfwd_zcol;
+  const int *lvl_piv, *lvl_ptr, *sfwd_eptr, *sfwd_upos, *sfwd_zcol;
   const int *crow_eptr, *crow_upos, *crow_zcol;
   const int *stile_a, *stile_b, *stile_ptr, *stile_rec;
   double *raw, *rawT, *U, *Dinv, *W, *rhs, *rhsT, *xout, *Spart, *rspart;
@@ -84,14 +85,20 @@ __global__ __launch_bounds__(256) void k_transpose_out(const double* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
+// Record broadcast: the wave-uniform index records of a task are fetched with ONE coalesced
+// vector load (lane e holds record e) and handed to all lanes with v_readlane, so the global
+// loads of a whole task issue back to back (one memory latency) instead of being chained
+// behind per-batch scalar loads.
+__device__ __forceinline__ int bcast(int v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
+
 // One factor task (plan.hpp, FTask): phase A builds the task's multiplier table in LDS
 // (M[0] = -1, M[1+j] = Dinv*U products), phase B streams the flat entry list: every destination
-// scalar is accumulated in a register and written once; all global loads are independent and
-// issued in batches of 8.  Initial values come straight from the transposed input (src < 0).
-__global__ __launch_bounds__(64) void k_factor_level(GroupDev g, int task0, double eps) {
+// scalar is accumulated in a register and written once.  Initial values come straight from the
+// transposed input (src < 0): assembly is fused into the factorisation.
+__global__ __launch_bounds__(64) void k_factor_level(GroupDev g, int task0, int chunk0, double eps) {
   extern __shared__ __attribute__((aligned(16))) double M[];
   const int lane = threadIdx.x;
-  const int b = blockIdx.y * 64 + lane;
+  const int b = (blockIdx.y + chunk0) * 64 + lane;
   const size_t bpad = (size_t)g.bpad;
   const int* t = g.ftask + 6 * (size_t)(task0 + blockIdx.x);
   const int p = t[0], r0 = t[1], r1 = t[2], m0 = t[3], m1 = t[4], dptr0 = t[5];
@@ -99,40 +106,49 @@ __global__ __launch_bounds__(64) void k_factor_level(GroupDev g, int task0, doub
   const double* __restrict__ U = g.U + b;
   const double* __restrict__ R = g.rawT + b;
   const double* __restrict__ D = g.Dinv + b;
-  M[lane] = -1.0;
-  {
-    int j = m0;
-    for (; j + 4 <= m1; j += 4) {
-      const int* rec = g.mrec + 4 * (size_t)j;
-      double v[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int d0 = rec[4 * i], u0 = rec[4 * i + 1], d1 = rec[4 * i + 2], u1 = rec[4 * i + 3];
-        v[i] = D[(size_t)d0 * bpad] * U[(size_t)u0 * bpad];
-        if (d1 >= 0) v[i] += D[(size_t)d1 * bpad] * U[(size_t)u1 * bpad];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) M[(1 + j - m0 + i) * 64 + lane] = v[i];
-    }
-    for (; j < m1; ++j) {
-      const int* rec = g.mrec + 4 * (size_t)j;
-      double v = D[(size_t)rec[0] * bpad] * U[(size_t)rec[1] * bpad];
-      if (rec[2] >= 0) v += D[(size_t)rec[2] * bpad] * U[(size_t)rec[3] * bpad];
-      M[(1 + j - m0) * 64 + lane] = v;
-    }
-  }
-  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the table is read by the same wave below
   const int ndst = (r1 - r0) * w;
   const int* dp = g.fdst_ptr + dptr0;
+  // destination boundaries: one vector load when they fit in a wave
+  const bool dp_vec = (ndst + 1 <= 64);
+  const int dpv = (dp_vec && lane <= ndst) ? dp[lane] : 0;
+  M[lane] = -1.0;
+  for (int jb = m0; jb < m1; jb += 64) {
+    const int cnt = min(64, m1 - jb);
+    int4 rec = make_int4(0, 0, -1, 0);
+    if (lane < cnt) rec = *reinterpret_cast<const int4*>(g.mrec + 4 * (size_t)(jb + lane));
+#define PP_MGROUP(G)                                                                       \
+  {                                                                                        \
+    int d0[G], u0[G], d1[G], u1[G];                                                        \
+    _Pragma("unroll") for (int i = 0; i < G; ++i) { /* clamped: slots past the end repeat the last record */ \
+      const int q = min(i0 + i, cnt - 1);                                                  \
+      d0[i] = bcast(rec.x, q); u0[i] = bcast(rec.y, q); d1[i] = bcast(rec.z, q); u1[i] = bcast(rec.w, q); \
+    }                                                                                      \
+    double a0[G], b0[G], a1[G], b1[G];                                                     \
+    _Pragma("unroll") for (int i = 0; i < G; ++i) {                                        \
+      a0[i] = D[(size_t)d0[i] * bpad];                                                     \
+      b0[i] = U[(size_t)u0[i] * bpad];                                                     \
+      a1[i] = (d1[i] >= 0) ? D[(size_t)d1[i] * bpad] : 0.0;                                \
+      b1[i] = (d1[i] >= 0) ? U[(size_t)u1[i] * bpad] : 0.0;                                \
+    }                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < G; ++i) {                                        \
+      const double v = a0[i] * b0[i] + a1[i] * b1[i];                                      \
+      if (i0 + i < cnt) M[(1 + jb - m0 + i0 + i) * 64 + lane] = v;                         \
+    }                                                                                      \
+  }
+    int i0 = 0;
+    for (; cnt - i0 > 2; i0 += 8) PP_MGROUP(8)
+    if (i0 < cnt) PP_MGROUP(2)
+#undef PP_MGROUP
+  }
   double* Udst = g.U + ((size_t)g.piv_uoff[p] + (size_t)r0 * w) * bpad + b;
   const bool diag = (r0 == 0);
   const int ndiag = diag ? w * w : 0;
   double pv0 = 0.0, pv2 = 0.0, pv3 = 0.0, tmax_diag = 0.0, colmax = 0.0;
   double acc = 0.0, tmax = 0.0;
   int d = 0;
-  const int E1 = dp[ndst];
-  int e = dp[0];
-  int dend = (ndst > 0) ? dp[1] : 0x7fffffff;
+  const int E0 = dp_vec ? bcast(dpv, 0) : dp[0];
+  const int E1 = dp_vec ? bcast(dpv, ndst) : dp[ndst];
+  int dend = (ndst > 0) ? (dp_vec ? bcast(dpv, 1) : dp[1]) : 0x7fffffff;
 #define PP_FINALIZE()                                                     \
   do {                                                                    \
     Udst[(size_t)d * bpad] = acc;                                         \
@@ -143,35 +159,42 @@ __global__ __launch_bounds__(64) void k_factor_level(GroupDev g, int task0, doub
       colmax = fmax(colmax, fabs(acc));                                   \
     }                                                                     \
     acc = 0.0; tmax = 0.0; ++d;                                           \
-    dend = (d < ndst) ? dp[d + 1] : 0x7fffffff;                           \
+    dend = (d < ndst) ? (dp_vec ? bcast(dpv, d + 1) : dp[d + 1]) : 0x7fffffff; \
   } while (0)
-  while (e < E1) {
-    const int* ent = g.fent + 2 * (size_t)e;
-    if (e + 8 <= E1) {
-      double sv[8], mv[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int src = ent[2 * i], mi = ent[2 * i + 1];
-        sv[i] = (src >= 0) ? U[(size_t)src * bpad] : R[(size_t)(-1 - src) * bpad];
-        mv[i] = M[mi * 64 + lane];
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        while (e + i == dend) PP_FINALIZE();
-        const double term = sv[i] * mv[i];
-        acc -= term;
-        tmax = fmax(tmax, fabs(term));
-      }
-      e += 8;
-    } else {
-      while (e == dend) PP_FINALIZE();
-      const int src = ent[0], mi = ent[1];
-      const double sv = (src >= 0) ? U[(size_t)src * bpad] : R[(size_t)(-1 - src) * bpad];
-      const double term = sv * M[mi * 64 + lane];
-      acc -= term;
-      tmax = fmax(tmax, fabs(term));
-      e += 1;
-    }
+  for (int eb = E0; eb < E1; eb += 64) {
+    const int cnt = min(64, E1 - eb);
+    int2 rec = make_int2(0, 0);
+    if (lane < cnt) rec = *reinterpret_cast<const int2*>(g.fent + 2 * (size_t)(eb + lane));
+#define PP_GROUP(G)                                                                        \
+  {                                                                                        \
+    int src[G], mi[G];                                                                     \
+    _Pragma("unroll") for (int i = 0; i < G; ++i) {                                        \
+      const int q = min(i0 + i, cnt - 1);                                                  \
+      src[i] = bcast(rec.x, q); mi[i] = bcast(rec.y, q);                                   \
+    }                                                                                      \
+    double term[G];                                                                        \
+    {                                                                                      \
+      double sv[G], mv[G];                                                                 \
+      _Pragma("unroll") for (int i = 0; i < G; ++i) {                                      \
+        const double* base = (src[i] >= 0) ? U : R;                                        \
+        const int idx = (src[i] >= 0) ? src[i] : (-1 - src[i]);                            \
+        sv[i] = base[(size_t)idx * bpad];                                                  \
+        mv[i] = M[mi[i] * 64 + lane];                                                      \
+      }                                                                                    \
+      _Pragma("unroll") for (int i = 0; i < G; ++i) term[i] = (i0 + i < cnt) ? sv[i] * mv[i] : 0.0; \
+    }                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < G; ++i) {                                        \
+      if (i0 + i < cnt) {                                                                  \
+        while (eb + i0 + i == dend) PP_FINALIZE();                                         \
+        acc -= term[i];                                                                    \
+        tmax = fmax(tmax, fabs(term[i]));                                                  \
+      }                                                                                    \
+    }                                                                                      \
+  }
+    int i0 = 0;
+    for (; cnt - i0 > 4; i0 += 16) PP_GROUP(16)
+    if (i0 < cnt) PP_GROUP(4)
+#undef PP_GROUP
   }
   while (d < ndst) PP_FINALIZE();
 #undef PP_FINALIZE
@@ -209,19 +232,20 @@ __global__ __launch_bounds__(256) void k_count_codes(const unsigned char* __rest
 }
 
 // ------------------------------------------------------------------------------------------
-// Schur tile: acc[8][8] in registers over all panels holding rows of both tile ranges,
-// then summed over the 64 instances of the wave through LDS.
+// Schur tile: half of an 8x8 tile (8 rows x 4 columns, blockIdx.z selects the column half) in
+// registers over all panels holding rows of both tile ranges, then summed over the 64 instances of
+// the wave through LDS.  Two waves per tile halve the register footprint (4 waves/SIMD).
 __global__ __launch_bounds__(64) void k_schur_tiles(GroupDev g) {
-  __shared__ double red[64][65];
+  __shared__ double red[32][65];
   const int lane = threadIdx.x;
   const int b = blockIdx.y * 64 + lane;
   const size_t bpad = (size_t)g.bpad;
-  const int tile = blockIdx.x;
-  double acc[8][8];
+  const int tile = blockIdx.x, half = blockIdx.z;
+  double acc[8][4];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = 0.0;
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
   for (int r = g.stile_ptr[tile]; r < g.stile_ptr[tile + 1]; ++r) {
     const int* rec = g.stile_rec + 17 * (size_t)r;
     const int p = rec[0];
@@ -229,45 +253,58 @@ __global__ __launch_bounds__(64) void k_schur_tiles(GroupDev g) {
     const double* Up = g.U + (size_t)g.piv_uoff[p] * bpad + b;
     const double* inv = g.Dinv + (size_t)g.piv_doff[p] * bpad + b;
     const double i00 = inv[0];
-    double wa0[8], wa1[8], ub0[8], ub1[8];
     if (w == 1) {
+      double wa0[8], ub0[4];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int sa = rec[1 + i], sb = rec[9 + i];
-        wa0[i] = (sa >= 0) ? Up[(size_t)sa * bpad] * i00 : 0.0;
-        ub0[i] = (sb >= 0) ? Up[(size_t)sb * bpad] : 0.0;
+        const int sa = rec[1 + i];
+        wa0[i] = (sa >= 0) ? Up[(size_t)sa * bpad] : 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int sb = rec[9 + 4 * half + j];
+        ub0[j] = (sb >= 0) ? Up[(size_t)sb * bpad] * i00 : 0.0;
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] -= wa0[i] * ub0[j];
+        for (int j = 0; j < 4; ++j) acc[i][j] -= wa0[i] * ub0[j];
     } else {
       const double i10 = inv[bpad], i11 = inv[2 * bpad];
+      double wa0[8], wa1[8], ub0[4], ub1[4];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int sa = rec[1 + i], sb = rec[9 + i];
+        const int sa = rec[1 + i];
         const double a0 = (sa >= 0) ? Up[(size_t)(sa * 2) * bpad] : 0.0;
         const double a1 = (sa >= 0) ? Up[(size_t)(sa * 2 + 1) * bpad] : 0.0;
         wa0[i] = a0 * i00 + a1 * i10;
         wa1[i] = a0 * i10 + a1 * i11;
-        ub0[i] = (sb >= 0) ? Up[(size_t)(sb * 2) * bpad] : 0.0;
-        ub1[i] = (sb >= 0) ? Up[(size_t)(sb * 2 + 1) * bpad] : 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int sb = rec[9 + 4 * half + j];
+        ub0[j] = (sb >= 0) ? Up[(size_t)(sb * 2) * bpad] : 0.0;
+        ub1[j] = (sb >= 0) ? Up[(size_t)(sb * 2 + 1) * bpad] : 0.0;
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] -= wa0[i] * ub0[j] + wa1[i] * ub1[j];
+        for (int j = 0; j < 4; ++j) acc[i][j] -= wa0[i] * ub0[j] + wa1[i] * ub1[j];
     }
   }
   const double mask = (b < g.batch) ? 1.0 : 0.0;
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) red[i * 8 + j][lane] = acc[i][j] * mask;
+    for (int j = 0; j < 4; ++j) red[i * 4 + j][lane] = acc[i][j] * mask;
   __syncthreads();
-  double s = 0.0;
-  for (int l = 0; l < 64; ++l) s += red[lane][l];
-  g.Spart[((size_t)blockIdx.y * gridDim.x + tile) * 64 + lane] = s;
+  if (lane < 32) {
+    double s = 0.0;
+    for (int l = 0; l < 64; ++l) s += red[lane][l];
+    // entry (i, 4*half + j) of the tile -> slot i*8 + 4*half + j of the 64-entry tile record
+    const int i = lane >> 2, j = lane & 3;
+    g.Spart[((size_t)blockIdx.y * gridDim.x + tile) * 64 + i * 8 + 4 * half + j] = s;
+  }
 }
 
 // S[ci][cj] += sum over chunks of the tile partials (both triangles of the dense S)
@@ -342,18 +379,37 @@ __global__ __launch_bounds__(LDL_THREADS) void k_ldl_blocked(int n, double* __re
     }
     __syncthreads();
     if (wv == 0) {
-      const int i = lane;
-      for (int k = 0; k < nb; ++k) {
-        double d = Db[k][k];
-        if (!(fabs(d) > eps * anorm)) { if (lane == 0) sflags[0] = 1; d = (anorm > 0.0 ? anorm : 1.0); }
-        if (lane == 0) { dl[k] = d; sflags[1] |= (d > 0.0) ? 1 : 2; }
-        if (i > k && i < nb) {
-          const double lik = Db[i][k] / d;
-          for (int j = k + 1; j <= i; ++j) Db[i][j] -= lik * Db[j][k];
-          Db[i][k] = lik;
+      // lane = row of the 32x32 block, the row lives in registers; column k is broadcast with shuffles
+      double row[LDL_NB];
+      const int i = lane & 31;
+#pragma unroll
+      for (int j = 0; j < LDL_NB; ++j) row[j] = (i < nb && j < nb) ? Db[i][j] : ((i == j) ? 1.0 : 0.0);
+      int bad = 0, signs = 0;
+#pragma unroll
+      for (int k = 0; k < LDL_NB; ++k) {
+        const double colk = row[k];
+        double d = __shfl(colk, k);
+        if (k < nb) {
+          if (!(fabs(d) > eps * anorm)) { bad = 1; d = (anorm > 0.0 ? anorm : 1.0); }
+          signs |= (d > 0.0) ? 1 : 2;
         }
+        const double lik = colk / d;
+#pragma unroll
+        for (int j = k + 1; j < LDL_NB; ++j) {
+          const double ajk = __shfl(colk, j);
+          if (i >= j) row[j] -= lik * ajk;
+        }
+        if (i > k) row[k] = lik;
+        else if (i == k) row[k] = d;
       }
+      if (lane < nb) {
+#pragma unroll
+        for (int j = 0; j < LDL_NB; ++j) if (j < nb) Db[lane][j] = row[j];
+      }
+      if (lane == 0) { if (bad) sflags[0] = 1; sflags[1] |= signs; }
     }
+    __syncthreads();
+    if (tid < nb) dl[tid] = Db[tid][tid];
     __syncthreads();
     // write the factored diagonal block back (unit lower L11, pivots on the diagonal)
     for (int idx = tid; idx < nb * nb; idx += LDL_THREADS) {
@@ -401,13 +457,16 @@ __global__ __launch_bounds__(LDL_THREADS) void k_ldl_blocked(int n, double* __re
         const int ra = j1 + 16 * I + li, rb = j1 + 16 * J + li;
         const bool va = ra < n, vb = rb < n;
         double4_t acc = {0.0, 0.0, 0.0, 0.0};
-        for (int kk = 0; kk < nb; kk += 4) {
-          const int k = kk + lk;
+        double av[LDL_NB / 4], bv[LDL_NB / 4];
+#pragma unroll
+        for (int q = 0; q < LDL_NB / 4; ++q) {     // all operand loads first: independent, coalesced
+          const int k = 4 * q + lk;
           const bool vk = k < nb;
-          const double a = (va && vk) ? A[ra + (size_t)(j0 + k) * lda] * dl[k] : 0.0;
-          const double b = (vb && vk) ? A[rb + (size_t)(j0 + k) * lda] : 0.0;
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+          av[q] = (va && vk) ? A[ra + (size_t)(j0 + k) * lda] * dl[k] : 0.0;
+          bv[q] = (vb && vk) ? A[rb + (size_t)(j0 + k) * lda] : 0.0;
         }
+#pragma unroll
+        for (int q = 0; q < LDL_NB / 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
         const int col = j1 + 16 * J + li;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -432,18 +491,24 @@ __device__ void ldl_blocked_solve(int n, const double* __restrict__ A, const dou
   for (int j0 = 0; j0 < n; j0 += LDL_NB) {
     const int nb = min(LDL_NB, n - j0), j1 = j0 + nb;
     if (wv == 0) {  // unit-lower triangular solve inside the block: lane = row, shuffle broadcast
+      double lrow[LDL_NB];
+#pragma unroll
+      for (int k = 0; k < LDL_NB; ++k)
+        lrow[k] = (lane > k && lane < nb) ? A[(j0 + lane) + (size_t)(j0 + k) * lda] : 0.0;
       double xi = (lane < nb) ? x[j0 + lane] : 0.0;
-      for (int k = 0; k < nb; ++k) {
-        const double xk = __shfl(xi, k);
-        if (lane > k && lane < nb) xi -= A[(j0 + lane) + (size_t)(j0 + k) * lda] * xk;
-      }
+#pragma unroll
+      for (int k = 0; k < LDL_NB; ++k) xi -= lrow[k] * __shfl(xi, k);
       if (lane < nb) x[j0 + lane] = xi;
     }
     __syncthreads();
     for (int r = j1 + tid; r < n; r += blockDim.x) {
-      double s = 0.0;
-      for (int k = 0; k < nb; ++k) s += A[r + (size_t)(j0 + k) * lda] * x[j0 + k];
-      x[r] -= s;
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+      for (int k = 0; k < LDL_NB; k += 2) {
+        if (k < nb) s0 += A[r + (size_t)(j0 + k) * lda] * x[j0 + k];
+        if (k + 1 < nb) s1 += A[r + (size_t)(j0 + k + 1) * lda] * x[j0 + k + 1];
+      }
+      x[r] -= s0 + s1;
     }
     __syncthreads();
   }
@@ -459,11 +524,13 @@ __device__ void ldl_blocked_solve(int n, const double* __restrict__ A, const dou
     }
     __syncthreads();
     if (wv == 0) {
+      double lcol[LDL_NB];
+#pragma unroll
+      for (int k = 0; k < LDL_NB; ++k)
+        lcol[k] = (lane < k && k < nb) ? A[(j0 + k) + (size_t)(j0 + lane) * lda] : 0.0;
       double xi = (lane < nb) ? x[j0 + lane] : 0.0;
-      for (int k = nb - 1; k > 0; --k) {
-        const double xk = __shfl(xi, k);
-        if (lane < k) xi -= A[(j0 + k) + (size_t)(j0 + lane) * lda] * xk;
-      }
+#pragma unroll
+      for (int k = LDL_NB - 1; k > 0; --k) xi -= lcol[k] * __shfl(xi, k);
       if (lane < nb) x[j0 + lane] = xi;
     }
     __syncthreads();
@@ -549,43 +616,60 @@ __global__ __launch_bounds__(BK_THREADS) void k_coupling_solve(int n, const doub
 }
 
 // ------------------------------------------------------------------------------------------
-// gather of one scalar row: sum over entries of U[upos] * Z[zcol], loads batched by 8
+// gather of one scalar row: sum over entries of U[upos] * Z[zcol]; the (upos, zcol) records are
+// fetched with one vector load per 64 entries and broadcast, loads issue in groups of 16
 __device__ __forceinline__ double gather_row(const int* __restrict__ upos, const int* __restrict__ zcol, int e0, int e1,
-                                             const double* __restrict__ U, const double* __restrict__ Z, size_t bpad) {
+                                             const double* __restrict__ U, const double* __restrict__ Z, size_t bpad,
+                                             int lane) {
   double s0 = 0.0, s1 = 0.0;
-  int e = e0;
-  for (; e + 8 <= e1; e += 8) {
-    double u[8], z[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { u[i] = U[(size_t)upos[e + i] * bpad]; z[i] = Z[(size_t)zcol[e + i] * bpad]; }
-#pragma unroll
-    for (int i = 0; i < 8; i += 2) { s0 += u[i] * z[i]; s1 += u[i + 1] * z[i + 1]; }
+  for (int eb = e0; eb < e1; eb += 64) {
+    const int cnt = min(64, e1 - eb);
+    int ru = 0, rz = 0;
+    if (lane < cnt) { ru = upos[eb + lane]; rz = zcol[eb + lane]; }
+#define PP_GGROUP(G)                                                                       \
+  {                                                                                        \
+    int iu[G], iz[G];                                                                      \
+    _Pragma("unroll") for (int i = 0; i < G; ++i) {                                        \
+      const int q = min(i0 + i, cnt - 1);                                                  \
+      iu[i] = bcast(ru, q); iz[i] = bcast(rz, q);                                          \
+    }                                                                                      \
+    double u[G], z[G];                                                                     \
+    _Pragma("unroll") for (int i = 0; i < G; ++i) { u[i] = U[(size_t)iu[i] * bpad]; z[i] = Z[(size_t)iz[i] * bpad]; } \
+    _Pragma("unroll") for (int i = 0; i < G; i += 2) {                                     \
+      s0 += (i0 + i < cnt) ? u[i] * z[i] : 0.0;                                            \
+      s1 += (i0 + i + 1 < cnt) ? u[i + 1] * z[i + 1] : 0.0;                                \
+    }                                                                                      \
   }
-  for (; e < e1; ++e) s0 += U[(size_t)upos[e] * bpad] * Z[(size_t)zcol[e] * bpad];
+    int i0 = 0;
+    for (; cnt - i0 > 4; i0 += 16) PP_GGROUP(16)
+    if (i0 < cnt) PP_GGROUP(4)
+#undef PP_GGROUP
+  }
   return s0 + s1;
 }
 
-// forward substitution of one level: z_p = inv(P_p) (b_p - sum_k U[p,k] z_k)
-__global__ __launch_bounds__(64) void k_fwd_level(GroupDev g, int piv0) {
-  const int lane = threadIdx.x;
-  const int b = blockIdx.y * 64 + lane;
+// forward substitution of one pivot: z_p = inv(P_p) (b_p - sum_k U[p,k] z_k)
+__device__ __forceinline__ void fwd_pivot(const GroupDev& g, int p, int lane, int b) {
   const size_t bpad = (size_t)g.bpad;
-  const int p = g.lvl_piv[piv0 + blockIdx.x];
   const int w = g.piv_w[p], p0 = g.piv_start[p];
   const double* U = g.U + b;
   const double* Z = g.W + b;
   double y0 = g.rhsT[(size_t)g.perm[p0] * bpad + b] -
-              gather_row(g.sfwd_upos, g.sfwd_zcol, g.sfwd_eptr[p0], g.sfwd_eptr[p0 + 1], U, Z, bpad);
+              gather_row(g.sfwd_upos, g.sfwd_zcol, g.sfwd_eptr[p0], g.sfwd_eptr[p0 + 1], U, Z, bpad, lane);
   const double* inv = g.Dinv + (size_t)g.piv_doff[p] * bpad + b;
   if (w == 1) {
     g.W[(size_t)p0 * bpad + b] = inv[0] * y0;
   } else {
     double y1 = g.rhsT[(size_t)g.perm[p0 + 1] * bpad + b] -
-                gather_row(g.sfwd_upos, g.sfwd_zcol, g.sfwd_eptr[p0 + 1], g.sfwd_eptr[p0 + 2], U, Z, bpad);
+                gather_row(g.sfwd_upos, g.sfwd_zcol, g.sfwd_eptr[p0 + 1], g.sfwd_eptr[p0 + 2], U, Z, bpad, lane);
     const double i00 = inv[0], i10 = inv[bpad], i11 = inv[2 * bpad];
     g.W[(size_t)p0 * bpad + b] = i00 * y0 + i10 * y1;
     g.W[(size_t)(p0 + 1) * bpad + b] = i10 * y0 + i11 * y1;
   }
+}
+
+__global__ __launch_bounds__(64) void k_fwd_level(GroupDev g, int piv0, int chunk0) {
+  fwd_pivot(g, g.lvl_piv[piv0 + blockIdx.x], threadIdx.x, (blockIdx.y + chunk0) * 64 + threadIdx.x);
 }
 
 // coupling row c: rspart[chunk][c] = - sum over active instances and panels of U[c,k] z_k
@@ -594,7 +678,7 @@ __global__ __launch_bounds__(64) void k_fwd_coupling(GroupDev g) {
   const int b = blockIdx.y * 64 + lane;
   const size_t bpad = (size_t)g.bpad;
   const int c = blockIdx.x;
-  double s = -gather_row(g.crow_upos, g.crow_zcol, g.crow_eptr[c], g.crow_eptr[c + 1], g.U + b, g.W + b, bpad);
+  double s = -gather_row(g.crow_upos, g.crow_zcol, g.crow_eptr[c], g.crow_eptr[c + 1], g.U + b, g.W + b, bpad, lane);
   if (b >= g.batch) s = 0.0;
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
   if (lane == 0) g.rspart[(size_t)blockIdx.y * g.nc + c] = s;
@@ -608,12 +692,9 @@ __global__ __launch_bounds__(256) void k_rs_reduce(GroupDev g, double* __restric
   rs[c] += s;
 }
 
-// back substitution of one level: x_p = z_p - inv(P_p) sum_i U[i,p]^T x_i  (x_i = xc for coupling rows)
-__global__ __launch_bounds__(64) void k_bwd_level(GroupDev g, int piv0, const double* __restrict__ xc) {
-  const int lane = threadIdx.x;
-  const int b = blockIdx.y * 64 + lane;
+// back substitution of one pivot: x_p = z_p - inv(P_p) sum_i U[i,p]^T x_i  (x_i = xc for coupling rows)
+__device__ __forceinline__ void bwd_pivot(const GroupDev& g, int p, int lane, int b, const double* __restrict__ xc) {
   const size_t bpad = (size_t)g.bpad;
-  const int p = g.lvl_piv[piv0 + blockIdx.x];
   const int w = g.piv_w[p], p0 = g.piv_start[p];
   const int nr = g.piv_rowptr[p + 1] - g.piv_rowptr[p];
   const int* ri = g.rowidx + g.piv_rowptr[p];
@@ -622,21 +703,28 @@ __global__ __launch_bounds__(64) void k_bwd_level(GroupDev g, int piv0, const do
   const int n = g.n;
   if (w == 1) {
     double g0 = 0.0, g1 = 0.0;
-    int j = 0;
-    for (; j + 8 <= nr; j += 8) {
-      double u[8], x[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int r = ri[j + i];
-        u[i] = Up[(size_t)(j + i) * bpad];
-        x[i] = (r < n) ? Wb[(size_t)r * bpad] : xc[r - n];
-      }
-#pragma unroll
-      for (int i = 0; i < 8; i += 2) { g0 += u[i] * x[i]; g1 += u[i + 1] * x[i + 1]; }
-    }
-    for (; j < nr; ++j) {
-      const int r = ri[j];
-      g0 += Up[(size_t)j * bpad] * ((r < n) ? Wb[(size_t)r * bpad] : xc[r - n]);
+    for (int jb = 0; jb < nr; jb += 64) {
+      const int cnt = min(64, nr - jb);
+      const int rv = (lane < cnt) ? ri[jb + lane] : 0;
+#define PP_BGROUP(G)                                                                       \
+  {                                                                                        \
+    int rr[G];                                                                             \
+    _Pragma("unroll") for (int i = 0; i < G; ++i) rr[i] = bcast(rv, min(i0 + i, cnt - 1)); \
+    double u[G], x[G];                                                                     \
+    _Pragma("unroll") for (int i = 0; i < G; ++i) {                                        \
+      const int q = min(i0 + i, cnt - 1);                                                  \
+      u[i] = Up[(size_t)(jb + q) * bpad];                                                  \
+      x[i] = (rr[i] < n) ? Wb[(size_t)rr[i] * bpad] : xc[rr[i] - n];                       \
+    }                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < G; i += 2) {                                     \
+      g0 += (i0 + i < cnt) ? u[i] * x[i] : 0.0;                                            \
+      g1 += (i0 + i + 1 < cnt) ? u[i + 1] * x[i + 1] : 0.0;                                \
+    }                                                                                      \
+  }
+      int i0 = 0;
+      for (; cnt - i0 > 4; i0 += 16) PP_BGROUP(16)
+      if (i0 < cnt) PP_BGROUP(4)
+#undef PP_BGROUP
     }
     const double inv = g.Dinv[(size_t)g.piv_doff[p] * bpad + b];
     g.W[(size_t)p0 * bpad + b] -= inv * (g0 + g1);
@@ -668,6 +756,10 @@ __global__ __launch_bounds__(64) void k_bwd_level(GroupDev g, int piv0, const do
   }
 }
 
+__global__ __launch_bounds__(64) void k_bwd_level(GroupDev g, int piv0, int chunk0, const double* __restrict__ xc) {
+  bwd_pivot(g, g.lvl_piv[piv0 + blockIdx.x], threadIdx.x, (blockIdx.y + chunk0) * 64 + threadIdx.x, xc);
+}
+
 // ------------------------------------------------------------------------------------------
 struct Group {
   pp::Plan plan;
@@ -695,6 +787,13 @@ struct pp_solver {
   int *ipiv = nullptr, *bkinfo = nullptr, *counters = nullptr;
   double mem_factor = 1.0;
   std::string err;
+  // Instance groups ("splits"): the level sweeps of disjoint 64-instance chunk ranges are
+  // independent, so they are issued on separate streams; while one split is in its
+  // latency-bound top-of-tree levels the others keep the chip busy.
+  int nsplit_req = 0;   // 0 = automatic
+  hipStream_t aux[PP_MAX_SPLIT] = {};
+  hipEvent_t ev_fork = nullptr, ev_join[PP_MAX_SPLIT] = {};
+  bool aux_made = false;
   // optional phase timing (HIP events on the handle's stream)
   bool profile = false;
   hipEvent_t ev[PP_NPHASE + 1][2];
@@ -745,6 +844,49 @@ struct PhaseScope {
       return fail(h, e_ == hipErrorOutOfMemory ? 1 : 3, std::string(#call) + ": " + hipGetErrorString(e_)); \
     }                                                                                                  \
   } while (0)
+
+// Chunk ranges of the splits of a group with `nchunk` 64-instance chunks.
+struct Splits {
+  int n = 1;
+  int c0[PP_MAX_SPLIT + 1] = {0};
+};
+
+Splits make_splits(pp_handle h, int nchunk) {
+  Splits sp;
+  int want = h->nsplit_req > 0 ? h->nsplit_req : (nchunk >= 8 ? 4 : (nchunk >= 2 ? 2 : 1));
+  want = std::max(1, std::min(std::min(want, PP_MAX_SPLIT), nchunk));
+  sp.n = want;
+  for (int i = 0; i <= want; ++i) sp.c0[i] = (int)((int64_t)nchunk * i / want);
+  return sp;
+}
+
+// fork the handle's stream into sp.n streams (stream 0 of the fan is the handle's own stream)
+int fork_streams(pp_handle h, const Splits& sp, hipStream_t* out) {
+  out[0] = h->stream;
+  if (sp.n == 1) return 0;
+  if (!h->aux_made) {
+    for (int i = 0; i < PP_MAX_SPLIT; ++i) {
+      if (hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking) != hipSuccess) return 3;
+      if (hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming) != hipSuccess) return 3;
+    }
+    if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) return 3;
+    h->aux_made = true;
+  }
+  if (hipEventRecord(h->ev_fork, h->stream) != hipSuccess) return 3;
+  for (int i = 1; i < sp.n; ++i) {
+    out[i] = h->aux[i];
+    if (hipStreamWaitEvent(out[i], h->ev_fork, 0) != hipSuccess) return 3;
+  }
+  return 0;
+}
+
+int join_streams(pp_handle h, const Splits& sp, hipStream_t* st) {
+  for (int i = 1; i < sp.n; ++i) {
+    if (hipEventRecord(h->ev_join[i], st[i]) != hipSuccess) return 3;
+    if (hipStreamWaitEvent(h->stream, h->ev_join[i], 0) != hipSuccess) return 3;
+  }
+  return 0;
+}
 
 template <class T>
 int dev_alloc(pp_handle h, Group* g, T** out, size_t count) {
@@ -818,6 +960,10 @@ void pp_destroy(pp_handle h) {
   free_globals(h);
   if (h->ev_made)
     for (int i = 0; i < PP_NPHASE; ++i) { (void)hipEventDestroy(h->ev[i][0]); (void)hipEventDestroy(h->ev[i][1]); }
+  if (h->aux_made) {
+    for (int i = 0; i < PP_MAX_SPLIT; ++i) { (void)hipStreamDestroy(h->aux[i]); (void)hipEventDestroy(h->ev_join[i]); }
+    (void)hipEventDestroy(h->ev_fork);
+  }
   delete h;
 }
 
@@ -919,6 +1065,7 @@ int pp_end_symbolic(pp_handle h) {
     if ((rc = dev_upload(h, g, &d.fdst_ptr, fdst_ptr))) return rc;
     if ((rc = dev_upload(h, g, &d.fent, fent))) return rc;
     if ((rc = dev_upload(h, g, &d.lvl_piv, P.lvl_piv))) return rc;
+    if ((rc = dev_upload(h, g, &d.lvl_ptr, P.lvl_ptr))) return rc;
     {
       std::vector<int> up(P.sfwd_upos), zc(P.sfwd_zcol), cu(P.crow_upos), cz(P.crow_zcol);
       for (int q = 0; q < 16; ++q) { up.push_back(0); zc.push_back(0); cu.push_back(0); cz.push_back(0); }
@@ -1012,18 +1159,24 @@ int pp_numeric_local(pp_handle h) {
     }
     {
       PhaseScope ps(h, 1, P.n_levels);
+      const Splits sp = make_splits(h, d.nchunk);
+      hipStream_t fan[PP_MAX_SPLIT];
+      if (fork_streams(h, sp, fan)) return fail(h, 3, "stream fork failed");
       for (int l = 0; l < P.n_levels; ++l) {
         const int t0 = P.flevel_ptr[l], nt = P.flevel_ptr[l + 1] - t0;
-        if (nt > 0)
-          hipLaunchKernelGGL(k_factor_level, dim3(nt, d.nchunk), dim3(64), g->lds_level[l], st, d, t0, PIVOT_EPS);
+        if (nt <= 0) continue;
+        for (int q = 0; q < sp.n; ++q)
+          hipLaunchKernelGGL(k_factor_level, dim3(nt, sp.c0[q + 1] - sp.c0[q]), dim3(64), g->lds_level[l], fan[q], d,
+                             t0, sp.c0[q], PIVOT_EPS);
       }
+      if (join_streams(h, sp, fan)) return fail(h, 3, "stream join failed");
     }
     {
       PhaseScope ps(h, 2, 3);
       hipLaunchKernelGGL(k_count_codes, dim3(std::min(1024, (int)(((size_t)P.npiv * d.bpad + 255) / 256))), dim3(256),
                          0, st, d.codes, P.npiv, d.batch, d.bpad, h->counters);
       if (g->ntiles > 0) {
-        hipLaunchKernelGGL(k_schur_tiles, dim3(g->ntiles, d.nchunk), dim3(64), 0, st, d);
+        hipLaunchKernelGGL(k_schur_tiles, dim3(g->ntiles, d.nchunk, 2), dim3(64), 0, st, d);
         hipLaunchKernelGGL(k_schur_reduce, dim3(g->ntiles), dim3(64), 0, st, d, g->ntiles, h->S);
       }
     }
@@ -1121,10 +1274,18 @@ int pp_solve_forward(pp_handle h) {
       PhaseScope ps(h, 4, P.n_levels + 1);
       hipLaunchKernelGGL(k_transpose_in, dim3((P.n + 63) / 64, d.nchunk), dim3(256), 0, st, d.rhs, d.rhsT, d.batch, P.n,
                          d.bpad);
+      // (a persistent one-workgroup-per-chunk kernel for the small top levels was measured slower than
+      // per-level launches: 16 waves on one CU serialise their memory round trips)
+      const Splits sp = make_splits(h, d.nchunk);
+      hipStream_t fan[PP_MAX_SPLIT];
+      if (fork_streams(h, sp, fan)) return fail(h, 3, "stream fork failed");
       for (int l = 0; l < P.n_levels; ++l) {
         const int p0 = P.lvl_ptr[l], np = P.lvl_ptr[l + 1] - p0;
-        if (np > 0) hipLaunchKernelGGL(k_fwd_level, dim3(np, d.nchunk), dim3(64), 0, st, d, p0);
+        if (np <= 0) continue;
+        for (int q = 0; q < sp.n; ++q)
+          hipLaunchKernelGGL(k_fwd_level, dim3(np, sp.c0[q + 1] - sp.c0[q]), dim3(64), 0, fan[q], d, p0, sp.c0[q]);
       }
+      if (join_streams(h, sp, fan)) return fail(h, 3, "stream join failed");
     }
     if (nc > 0) {
       PhaseScope ps(h, 5, 2);
@@ -1166,9 +1327,17 @@ int pp_solve_backward(pp_handle h) {
     const pp::Plan& P = g->plan;
     GroupDev& d = g->dev;
     PhaseScope ps(h, 7, P.n_levels + 1);
-    for (int l = P.n_levels - 1; l >= 0; --l) {
-      const int p0 = P.lvl_ptr[l], np = P.lvl_ptr[l + 1] - p0;
-      if (np > 0) hipLaunchKernelGGL(k_bwd_level, dim3(np, d.nchunk), dim3(64), 0, st, d, p0, h->xc);
+    {
+      const Splits sp = make_splits(h, d.nchunk);
+      hipStream_t fan[PP_MAX_SPLIT];
+      if (fork_streams(h, sp, fan)) return fail(h, 3, "stream fork failed");
+      for (int l = P.n_levels - 1; l >= 0; --l) {
+        const int p0 = P.lvl_ptr[l], np = P.lvl_ptr[l + 1] - p0;
+        if (np <= 0) continue;
+        for (int q = 0; q < sp.n; ++q)
+          hipLaunchKernelGGL(k_bwd_level, dim3(np, sp.c0[q + 1] - sp.c0[q]), dim3(64), 0, fan[q], d, p0, sp.c0[q], h->xc);
+      }
+      if (join_streams(h, sp, fan)) return fail(h, 3, "stream join failed");
     }
     hipLaunchKernelGGL(k_transpose_out, dim3((P.n + 63) / 64, d.nchunk), dim3(256), 0, st, d.W, d.iperm, d.xout,
                        d.batch, P.n, d.bpad);
@@ -1212,6 +1381,13 @@ int pp_bind_rhs_buffer(pp_handle h, int group, double* dev_ptr) {
   Group* g = get_group(h, group);
   if (!g || !h->symbolic_done) return fail(h, 3, "pp_bind_rhs_buffer: bad group");
   g->dev.rhs = dev_ptr ? dev_ptr : g->rhs_own;
+  return 0;
+}
+
+int pp_set_instance_splits(pp_handle h, int nsplit) {
+  if (!h) return 3;
+  if (nsplit < 0 || nsplit > PP_MAX_SPLIT) return fail(h, 3, "instance splits must be 0 (automatic) .. 8");
+  h->nsplit_req = nsplit;
   return 0;
 }
 

@@ -312,6 +312,14 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
     for (int p = 0; p < P.npiv; ++p) P.lvl_piv[fill[P.piv_level[p]]++] = p;
   }
 
+  // tail = trailing run of levels that each hold few pivots
+  P.tail_level0 = P.n_levels;
+  for (int l = P.n_levels - 1; l >= 0; --l) {
+    if (P.lvl_ptr[l + 1] - P.lvl_ptr[l] > opt.tail_piv_max) break;
+    P.tail_level0 = l;
+  }
+  if (P.n_levels - P.tail_level0 < 3) P.tail_level0 = P.n_levels;
+
   // inverse-pivot scalar (t, t') of pivot k in Dinv storage
   auto dinv_pos = [&](int k, int t, int t2) -> int {
     if (P.piv_w[k] == 1) return P.piv_doff[k];
@@ -362,6 +370,9 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
         ++can_cursor;
       }
       // chunk the slots; the pivot block (slots 0..w-1) always opens the first chunk
+      const bool in_tail = P.piv_level[p] >= P.tail_level0;
+      const int cap_e = in_tail ? opt.tail_task_entries : opt.max_task_entries;
+      const int cap_m = in_tail ? opt.tail_task_mults : opt.max_task_mults;
       int r = 0;
       while (r < f) {
         TmpTask tt;
@@ -377,7 +388,7 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
           int add_m = 0;
           for (auto& se : slot_ents[r_end]) if (!mloc.count(std::make_tuple(se.k, se.t, se.q))) ++add_m;  // upper bound
           const bool must = (r_end == r) || (r == 0 && r_end < w);
-          if (!must && (nent + add_e > opt.max_task_entries || (int)mloc.size() + add_m > opt.max_task_mults)) break;
+          if (!must && (nent + add_e > cap_e || (int)mloc.size() + add_m > cap_m)) break;
           for (auto& se : slot_ents[r_end]) {
             auto key = std::make_tuple(se.k, se.t, se.q);
             if (!mloc.count(key)) { int id = (int)mloc.size(); mloc[key] = id; }

@@ -43,6 +43,7 @@ void ppsim_stats(void* h, int64_t* out) {
   Plan& P = *(Plan*)h;
   out[0] = P.n; out[1] = P.nc; out[2] = P.npiv; out[3] = P.n_levels; out[4] = P.n_2x2; out[5] = P.usize;
   out[6] = P.nnz_L; out[7] = P.flops_factor; out[8] = P.flops_schur; out[9] = (int64_t)P.ftasks.size();
+  out[4] = P.n_2x2 + 1000000LL * P.tail_level0;
   out[10] = (int64_t)P.fentries.size(); out[11] = (int64_t)P.stile_a.size(); out[12] = (int64_t)P.stile_rec.size();
 }
 int ppsim_dsize(void* h) { return ((Plan*)h)->dsize; }

@@ -40,7 +40,7 @@ class HostSimEngine(object):
             sg.batch = len(g.blocks)
             sg.raw = None
             self.groups.append(sg)
-            stats.append({'n': int(st[0]), 'n_pivots': int(st[2]), 'n_levels': int(st[3]), 'n_2x2': int(st[4]),
+            stats.append({'n': int(st[0]), 'n_pivots': int(st[2]), 'n_levels': int(st[3]), 'n_2x2': int(st[4]) % 1000000,
                           'nnz_L': int(st[6])})
         self.S = np.zeros((nc, nc))
         self.tail = np.zeros(4)

@@ -72,6 +72,8 @@ class HostSim(object):
         keys = ['n', 'nc', 'npiv', 'n_levels', 'n_2x2', 'usize', 'nnz_L', 'flops_factor', 'flops_schur',
                 'ntasks', 'nentries', 'ntiles', 'ntilerecs']
         self.stats = dict(zip(keys, [int(v) for v in st]))
+        self.stats['tail_level0'] = self.stats['n_2x2'] // 1000000
+        self.stats['n_2x2'] = self.stats['n_2x2'] % 1000000
 
     def canonical(self, K, A):
         Kl = tril(coo_matrix(K)).tocsc()
