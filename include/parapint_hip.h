@@ -93,8 +93,8 @@ int pp_bind_schur_buffer(pp_handle h, double* dev_ptr);
  * Q: dense column-major n_c x n_c on the host (lower triangle read), or NULL for Q = 0. */
 int pp_factor_schur(pp_handle h, const double* Q_host);
 
-/* Number of instance groups whose level sweeps run on separate HIP streams (their top-of-tree
- * levels are latency-bound; overlapping groups keeps the chip busy).  0 = automatic (default). */
+/* Number of instance groups whose level sweeps run on separate HIP streams.  0 = default (one
+ * group: on MI355X / ROCm 7.2 more groups were measured slower, the launches serialise). */
 int pp_set_instance_splits(pp_handle h, int nsplit);
 
 /* Dense policy for S: 0 (default) = blocked LDL^T without pivoting on the fp64 matrix cores,
