@@ -75,6 +75,9 @@ struct Plan {
   std::vector<FEntry> fentries;
   std::vector<int> flevel_ptr;           // n_levels+1 -> ftasks
   std::vector<int> flevel_maxm;          // per level: max multiplier scalars of a task (LDS sizing)
+  std::vector<int> flevel_nbig;          // per level: tasks (sorted last) whose table exceeds max_task_mults
+  std::vector<int> flevel_maxent;        // per level: max entries of a task
+  std::vector<int> slevel_maxent;        // per level: max forward-solve entries of a scalar row
   int tail_level0 = 0;                   // levels >= tail_level0 form the tail (== n_levels: no tail)
   // forward-solve entries: scalar row (new column index c) = b_c - sum U[upos] * z[zcol]
   std::vector<int> sfwd_eptr;            // n+1 -> sfwd_upos / sfwd_zcol

@@ -204,21 +204,80 @@ __global__ __launch_bounds__(64) void k_factor_level(GroupDev g, int task0, int 
     double* invp = g.Dinv + (size_t)g.piv_doff[p] * bpad + b;
     invp[0] = pr.i00;
     if (w == 2) { invp[bpad] = pr.i10; invp[2 * bpad] = pr.i11; }
-    g.codes[(size_t)p * bpad + b] = (unsigned char)pr.code;
+    g.codes[(size_t)p * bpad + b] = (b < g.batch) ? (unsigned char)pr.code : (unsigned char)0;
   }
 }
 
-// counters[0..2] += (pos, neg, zero) over all pivots and active instances
-__global__ __launch_bounds__(256) void k_count_codes(const unsigned char* __restrict__ codes, int npiv, int batch,
-                                                     int bpad, int* counters) {
+// Lean variant for the wide bottom levels of the tree (a few entries per task, tens of thousands
+// of tasks): plain scalar-load record reads, minimal registers; the memory system is kept busy by
+// the sheer number of waves, not by intra-task batching.
+__global__ __launch_bounds__(64) void k_factor_level_lean(GroupDev g, int task0, int chunk0, double eps) {
+  extern __shared__ __attribute__((aligned(16))) double M[];
+  const int lane = threadIdx.x;
+  const int b = (blockIdx.y + chunk0) * 64 + lane;
+  const size_t bpad = (size_t)g.bpad;
+  const int* t = g.ftask + 6 * (size_t)(task0 + blockIdx.x);
+  const int p = t[0], r0 = t[1], r1 = t[2], m0 = t[3], m1 = t[4], dptr0 = t[5];
+  const int w = g.piv_w[p];
+  const double* __restrict__ U = g.U + b;
+  const double* __restrict__ R = g.rawT + b;
+  const double* __restrict__ D = g.Dinv + b;
+  M[lane] = -1.0;
+  for (int j = m0; j < m1; ++j) {
+    const int* rec = g.mrec + 4 * (size_t)j;
+    double v = D[(size_t)rec[0] * bpad] * U[(size_t)rec[1] * bpad];
+    if (rec[2] >= 0) v += D[(size_t)rec[2] * bpad] * U[(size_t)rec[3] * bpad];
+    M[(1 + j - m0) * 64 + lane] = v;
+  }
+  const int ndst = (r1 - r0) * w;
+  const int* dp = g.fdst_ptr + dptr0;
+  double* Udst = g.U + ((size_t)g.piv_uoff[p] + (size_t)r0 * w) * bpad + b;
+  const int ndiag = (r0 == 0) ? w * w : 0;
+  double pv0 = 0.0, pv2 = 0.0, pv3 = 0.0, tmax_diag = 0.0, colmax = 0.0;
+  for (int d = 0; d < ndst; ++d) {
+    double acc = 0.0, tmax = 0.0;
+    for (int e = dp[d]; e < dp[d + 1]; ++e) {
+      const int src = g.fent[2 * (size_t)e], mi = g.fent[2 * (size_t)e + 1];
+      const double sv = (src >= 0) ? U[(size_t)src * bpad] : R[(size_t)(-1 - src) * bpad];
+      const double term = sv * M[mi * 64 + lane];
+      acc -= term;
+      tmax = fmax(tmax, fabs(term));
+    }
+    Udst[(size_t)d * bpad] = acc;
+    if (d < ndiag) {
+      if (d == 0) pv0 = acc; else if (d == 2) pv2 = acc; else if (d == 3) pv3 = acc;
+      tmax_diag = fmax(tmax_diag, tmax);
+    } else {
+      colmax = fmax(colmax, fabs(acc));
+    }
+  }
+  if (r0 == 0) {
+    const pp::PivotResult pr = pp::invert_pivot(w, pv0, (w == 2) ? pv2 : 0.0, (w == 2) ? pv3 : 0.0,
+                                                fmax(colmax, tmax_diag), eps);
+    double* invp = g.Dinv + (size_t)g.piv_doff[p] * bpad + b;
+    invp[0] = pr.i00;
+    if (w == 2) { invp[bpad] = pr.i10; invp[2 * bpad] = pr.i11; }
+    g.codes[(size_t)p * bpad + b] = (b < g.batch) ? (unsigned char)pr.code : (unsigned char)0;
+  }
+}
+
+// counters[0..2] += (pos, neg, zero) over all pivots (codes of padded instances are 0); 16 codes per load
+__global__ __launch_bounds__(256) void k_count_codes(const unsigned char* __restrict__ codes, size_t total16,
+                                                     int* counters) {
   __shared__ int red[3][256];
   int pos = 0, neg = 0, zero = 0;
-  const size_t total = (size_t)npiv * bpad;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int b = (int)(i % bpad);
-    if (b < batch) {
-      const int c = codes[i];
-      pos += c & 3; neg += (c >> 2) & 3; zero += (c >> 4) & 3;
+  const uint4* c4 = reinterpret_cast<const uint4*>(codes);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total16; i += (size_t)gridDim.x * 256) {
+    const uint4 v = c4[i];
+    const unsigned int wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const unsigned int x = wds[q];
+      // per byte: bits 0-1 pos, 2-3 neg, 4-5 zero
+      const unsigned int p2 = x & 0x03030303u, n2 = (x >> 2) & 0x03030303u, z2 = (x >> 4) & 0x03030303u;
+      pos += (int)((p2 * 0x01010101u) >> 24);
+      neg += (int)((n2 * 0x01010101u) >> 24);
+      zero += (int)((z2 * 0x01010101u) >> 24);
     }
   }
   red[0][threadIdx.x] = pos; red[1][threadIdx.x] = neg; red[2][threadIdx.x] = zero;
@@ -422,8 +481,11 @@ __global__ __launch_bounds__(LDL_THREADS) void k_ldl_blocked(int n, double* __re
       for (int r = tid; r < m; r += LDL_THREADS) {
         double wrow[LDL_NB];
 #pragma unroll
+        for (int k = 0; k < LDL_NB; ++k) wrow[k] = A[(j1 + r) + (size_t)(j0 + k) * lda];   // all loads in flight at once
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
         for (int k = 0; k < LDL_NB; ++k) {
-          double v = A[(j1 + r) + (size_t)(j0 + k) * lda];
+          double v = wrow[k];
 #pragma unroll
           for (int j = 0; j < k; ++j) v -= wrow[j] * Db[k][j];
           wrow[k] = v;
@@ -622,6 +684,10 @@ __device__ __forceinline__ double gather_row(const int* __restrict__ upos, const
                                              const double* __restrict__ U, const double* __restrict__ Z, size_t bpad,
                                              int lane) {
   double s0 = 0.0, s1 = 0.0;
+  if (e1 - e0 <= 3) {   // wide bottom levels: one to three entries, plain scalar record reads
+    for (int e = e0; e < e1; ++e) s0 += U[(size_t)upos[e] * bpad] * Z[(size_t)zcol[e] * bpad];
+    return s0;
+  }
   for (int eb = e0; eb < e1; eb += 64) {
     const int cnt = min(64, e1 - eb);
     int ru = 0, rz = 0;
@@ -701,7 +767,15 @@ __device__ __forceinline__ void bwd_pivot(const GroupDev& g, int p, int lane, in
   const double* Up = g.U + ((size_t)g.piv_uoff[p] + (size_t)w * w) * bpad + b;
   const double* Wb = g.W + b;
   const int n = g.n;
-  if (w == 1) {
+  if (w == 1 && nr <= 4) {   // wide bottom levels: short panels, plain scalar index reads
+    double g0 = 0.0;
+    for (int j = 0; j < nr; ++j) {
+      const int r = ri[j];
+      g0 += Up[(size_t)j * bpad] * ((r < n) ? Wb[(size_t)r * bpad] : xc[r - n]);
+    }
+    const double inv = g.Dinv[(size_t)g.piv_doff[p] * bpad + b];
+    g.W[(size_t)p0 * bpad + b] -= inv * g0;
+  } else if (w == 1) {
     double g0 = 0.0, g1 = 0.0;
     for (int jb = 0; jb < nr; jb += 64) {
       const int cnt = min(64, nr - jb);
@@ -1165,16 +1239,32 @@ int pp_numeric_local(pp_handle h) {
       for (int l = 0; l < P.n_levels; ++l) {
         const int t0 = P.flevel_ptr[l], nt = P.flevel_ptr[l + 1] - t0;
         if (nt <= 0) continue;
-        for (int q = 0; q < sp.n; ++q)
-          hipLaunchKernelGGL(k_factor_level, dim3(nt, sp.c0[q + 1] - sp.c0[q]), dim3(64), g->lds_level[l], fan[q], d,
-                             t0, sp.c0[q], PIVOT_EPS);
+        // tasks whose multiplier table exceeds the cap are sorted last and launched apart, so the
+        // bulk of the level keeps a small LDS footprint (occupancy)
+        const int nbig = P.flevel_nbig[l], nsmall = nt - nbig;
+        const size_t lds_small = (size_t)(1 + std::min(P.flevel_maxm[l], P.opt.max_task_mults)) * 64 * sizeof(double);
+        for (int q = 0; q < sp.n; ++q) {
+          const dim3 gy(1, sp.c0[q + 1] - sp.c0[q]);
+          if (nsmall > 0) {
+            if (P.flevel_maxent[l] <= 8 && nbig == 0)
+              hipLaunchKernelGGL(k_factor_level_lean, dim3(nsmall, gy.y), dim3(64), lds_small, fan[q], d, t0, sp.c0[q],
+                                 PIVOT_EPS);
+            else
+              hipLaunchKernelGGL(k_factor_level, dim3(nsmall, gy.y), dim3(64), lds_small, fan[q], d, t0, sp.c0[q],
+                                 PIVOT_EPS);
+          }
+          if (nbig > 0)
+            hipLaunchKernelGGL(k_factor_level, dim3(nbig, gy.y), dim3(64), g->lds_level[l], fan[q], d, t0 + nsmall,
+                               sp.c0[q], PIVOT_EPS);
+        }
       }
       if (join_streams(h, sp, fan)) return fail(h, 3, "stream join failed");
     }
     {
       PhaseScope ps(h, 2, 3);
-      hipLaunchKernelGGL(k_count_codes, dim3(std::min(1024, (int)(((size_t)P.npiv * d.bpad + 255) / 256))), dim3(256),
-                         0, st, d.codes, P.npiv, d.batch, d.bpad, h->counters);
+      const size_t total16 = (size_t)P.npiv * d.bpad / 16;   // bpad is a multiple of 64
+      hipLaunchKernelGGL(k_count_codes, dim3((unsigned)std::min<size_t>(512, (total16 + 255) / 256)), dim3(256), 0, st,
+                         d.codes, total16, h->counters);
       if (g->ntiles > 0) {
         hipLaunchKernelGGL(k_schur_tiles, dim3(g->ntiles, d.nchunk, 2), dim3(64), 0, st, d);
         hipLaunchKernelGGL(k_schur_reduce, dim3(g->ntiles), dim3(64), 0, st, d, g->ntiles, h->S);

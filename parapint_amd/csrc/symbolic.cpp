@@ -427,13 +427,23 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
         r = r_end;
       }
     }
-    std::stable_sort(tasks.begin(), tasks.end(), [](const TmpTask& a, const TmpTask& b) { return a.level < b.level; });
+    std::stable_sort(tasks.begin(), tasks.end(), [&](const TmpTask& a, const TmpTask& b) {
+      if (a.level != b.level) return a.level < b.level;
+      const bool ba = a.nm > opt.max_task_mults, bb = b.nm > opt.max_task_mults;
+      return ba < bb;   // tasks whose multiplier table exceeds the cap go last (launched apart)
+    });
     P.flevel_ptr.assign(P.n_levels + 1, 0);
     P.flevel_maxm.assign(P.n_levels, 0);
+    P.flevel_nbig.assign(P.n_levels, 0);
+    P.flevel_maxent.assign(P.n_levels, 0);
     for (auto& t : tasks) {
       P.ftasks.push_back(t.t);
       P.flevel_ptr[t.level + 1]++;
       P.flevel_maxm[t.level] = std::max(P.flevel_maxm[t.level], t.nm);
+      if (t.nm > opt.max_task_mults) P.flevel_nbig[t.level]++;
+      const int ndst = (t.t.r1 - t.t.r0) * P.piv_w[t.t.piv];
+      const int ne = P.fdst_ptr[t.t.dptr0 + ndst] - P.fdst_ptr[t.t.dptr0];
+      P.flevel_maxent[t.level] = std::max(P.flevel_maxent[t.level], ne);
     }
     for (int l = 0; l < P.n_levels; ++l) P.flevel_ptr[l + 1] += P.flevel_ptr[l];
   }
@@ -464,6 +474,12 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
           cr[r[t] - n].push_back({(int)(P.piv_uoff[k] + (int64_t)(wk + (int)t) * wk + tt), P.piv_start[k] + tt});
       }
     }
+    P.slevel_maxent.assign(P.n_levels, 0);
+    for (int p = 0; p < P.npiv; ++p)
+      for (int q = 0; q < P.piv_w[p]; ++q) {
+        const int c = P.piv_start[p] + q;
+        P.slevel_maxent[P.piv_level[p]] = std::max(P.slevel_maxent[P.piv_level[p]], P.sfwd_eptr[c + 1] - P.sfwd_eptr[c]);
+      }
     P.crow_eptr.assign(nc + 1, 0);
     for (int c = 0; c < nc; ++c) {
       for (auto& e : cr[c]) { P.crow_upos.push_back(e.first); P.crow_zcol.push_back(e.second); }

@@ -46,6 +46,14 @@ void ppsim_stats(void* h, int64_t* out) {
   out[4] = P.n_2x2 + 1000000LL * P.tail_level0;
   out[10] = (int64_t)P.fentries.size(); out[11] = (int64_t)P.stile_a.size(); out[12] = (int64_t)P.stile_rec.size();
 }
+int ppsim_nrowidx(void* h) { return (int)((Plan*)h)->rowidx.size(); }
+void ppsim_get_struct(void* h, int* piv_start, int* piv_w, int* rowptr, int* rowidx) {
+  Plan& P = *(Plan*)h;
+  std::memcpy(piv_start, P.piv_start.data(), sizeof(int) * (P.npiv + 1));
+  std::memcpy(piv_w, P.piv_w.data(), sizeof(int) * P.npiv);
+  std::memcpy(rowptr, P.piv_rowptr.data(), sizeof(int) * (P.npiv + 1));
+  std::memcpy(rowidx, P.rowidx.data(), sizeof(int) * P.rowidx.size());
+}
 int ppsim_dsize(void* h) { return ((Plan*)h)->dsize; }
 void ppsim_get_perm(void* h, int* perm) { Plan& P = *(Plan*)h; std::memcpy(perm, P.perm.data(), sizeof(int) * P.n); }
 void ppsim_get_levels(void* h, int* lv) { Plan& P = *(Plan*)h; std::memcpy(lv, P.piv_level.data(), sizeof(int) * P.npiv); }
@@ -179,6 +187,11 @@ void ppsim_backward(void* h, const double* U, const double* Dinv, double* W, dou
     }
   }
   for (int k = 0; k < P.n; ++k) x[P.perm[k]] = W[k];
+}
+
+// block pivot inversion by static-order sweeps (pivot.hpp): returns the code, inv packed lower
+int ppsim_invert_block(int w, unsigned sub, const double* a, double colmax, double eps, double* inv) {
+  return pp::invert_block(w, sub, a, colmax, eps, inv);
 }
 
 // dense Bunch-Kaufman on a column-major n x n matrix (lower triangle read); info = (pos, neg, zero)
