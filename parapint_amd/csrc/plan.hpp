@@ -24,6 +24,10 @@
 #include <string>
 #include <vector>
 
+#ifndef PP_WMAX
+#define PP_WMAX 4   // widest block pivot (supernode); pivot.hpp / kernels unroll to this bound
+#endif
+
 namespace pp {
 
 struct PlanOptions {
@@ -36,6 +40,9 @@ struct PlanOptions {
   int tail_task_entries = 48;
   int tail_task_mults = 30;
   int tile = 8;           // register tile edge of the Schur (SYRK) kernel
+  int sn_wmax = 1;        // widest supernode (columns); 1 disables merging of sub-pivots (wider blocks need the
+                          // per-source block multiplier path)
+  int sn_tol_rows = 1;    // padded rows tolerated when merging a sub-pivot into its parent
   int md_delta_abs = 3;   // minimum-degree tolerance (absolute) for height-aware selection
   double md_delta_rel = 0.5;   // ... and relative to the current minimum degree
   double pivot_threshold = 0.01;  // 1x1 pivot accepted if |d| >= threshold * max|row| (MA27 cntl(1) analogue)
@@ -48,7 +55,7 @@ struct PlanOptions {
 // into the factorisation), M[0] = -1 and M[1 + j] = Dinv[d0]*U[u0] (+ Dinv[d1]*U[u1]) is the
 // j-th multiplier scalar of the task (MRec).  All loads of a task are independent.
 struct FTask { int piv, r0, r1, m0, m1, dptr0; };
-struct MRec { int d0, u0, d1, u1; };
+struct MRec { int d[PP_WMAX], u[PP_WMAX]; };   // M = sum_t Dinv[d[t]] * U[u[t]]   (d[t] < 0: unused)
 struct FEntry { int src, midx; };
 // Schur tile record: pivot p contributes to tile (ta, tb); slots (or -1) of the tile's
 // coupling rows inside panel p
@@ -59,12 +66,15 @@ struct Plan {
   int n_levels = 0;
   PlanOptions opt;
   std::vector<int> perm, iperm;          // new->old, old->new (K nodes)
-  std::vector<int> piv_start, piv_w;     // first new column of pivot p, width (1|2)
+  std::vector<int> piv_start, piv_w;     // first new column of block pivot (supernode) p, width 1..PP_WMAX
+  std::vector<unsigned> piv_sub;         // bit i: columns i, i+1 of the block form a 2x2 sub-pivot
+  std::vector<int> piv_cslot0, piv_ncrow, piv_lcoff;  // first coupling-row slot, #coupling rows, offset in Lc
+  int64_t lcsize = 0;                    // doubles per lane of the scaled coupling rows Lc
   std::vector<int> piv_of_col;           // new column -> pivot
   std::vector<int> piv_rowptr, rowidx;   // rows below pivot p (new indices; n+c = coupling row c)
   std::vector<int64_t> piv_uoff;         // panel offset, doubles per lane
   int64_t usize = 0;                     // doubles per lane in U storage
-  std::vector<int> piv_doff;             // offset of inv(P_p) in Dinv storage: 1 scalar (1x1) or 3 (i00,i10,i11)
+  std::vector<int> piv_doff;             // offset of inv(P_p) in Dinv storage: w(w+1)/2 scalars, lower triangle by rows
   int dsize = 0;                         // doubles per lane in Dinv storage
   std::vector<int64_t> pos_of_can;       // canonical input entry -> U position
   std::vector<int> piv_level;            // etree height of pivot

@@ -41,12 +41,14 @@ struct GroupDev {
   int n, nc, batch, bpad, nchunk, npiv, nraw;
   int64_t usize;
   const int *piv_w, *piv_start, *piv_uoff, *piv_doff, *piv_rowptr, *rowidx, *perm, *iperm;
+  const int *piv_sub, *piv_cslot0, *piv_ncrow, *piv_lcoff, *lc_piv;
+  int n_lc_piv;
   const int *ftask, *mrec, *fdst_ptr, *fent;
   const int *lvl_piv, *lvl_ptr, *sfwd_eptr, *sfwd_upos, *sfwd_zcol;
   const int *crow_eptr, *crow_upos, *crow_zcol;
   const int *stile_a, *stile_b, *stile_ptr, *stile_rec;
-  double *raw, *rawT, *U, *Dinv, *W, *rhs, *rhsT, *xout, *Spart, *rspart;
-  unsigned char* codes;
+  double *raw, *rawT, *U, *Dinv, *Lc, *W, *rhs, *rhsT, *xout, *Spart, *rspart;
+  unsigned short* codes;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -114,36 +116,42 @@ __global__ __launch_bounds__(64) void k_factor_level(GroupDev g, int task0, int 
   M[lane] = -1.0;
   for (int jb = m0; jb < m1; jb += 64) {
     const int cnt = min(64, m1 - jb);
-    int4 rec = make_int4(0, 0, -1, 0);
-    if (lane < cnt) rec = *reinterpret_cast<const int4*>(g.mrec + 4 * (size_t)(jb + lane));
+    int4 recd = make_int4(-1, -1, -1, -1), recu = make_int4(0, 0, 0, 0);
+    if (lane < cnt) {
+      const int4* rp = reinterpret_cast<const int4*>(g.mrec + 8 * (size_t)(jb + lane));
+      recd = rp[0]; recu = rp[1];
+    }
 #define PP_MGROUP(G)                                                                       \
   {                                                                                        \
-    int d0[G], u0[G], d1[G], u1[G];                                                        \
+    int dd[G][4], uu[G][4];                                                                \
     _Pragma("unroll") for (int i = 0; i < G; ++i) { /* clamped: slots past the end repeat the last record */ \
       const int q = min(i0 + i, cnt - 1);                                                  \
-      d0[i] = bcast(rec.x, q); u0[i] = bcast(rec.y, q); d1[i] = bcast(rec.z, q); u1[i] = bcast(rec.w, q); \
+      dd[i][0] = bcast(recd.x, q); dd[i][1] = bcast(recd.y, q); dd[i][2] = bcast(recd.z, q); dd[i][3] = bcast(recd.w, q); \
+      uu[i][0] = bcast(recu.x, q); uu[i][1] = bcast(recu.y, q); uu[i][2] = bcast(recu.z, q); uu[i][3] = bcast(recu.w, q); \
     }                                                                                      \
-    double a0[G], b0[G], a1[G], b1[G];                                                     \
+    double av[G][4], bv[G][4];                                                             \
+    _Pragma("unroll") for (int i = 0; i < G; ++i)                                          \
+      _Pragma("unroll") for (int t4 = 0; t4 < 4; ++t4) {                                   \
+        av[i][t4] = (dd[i][t4] >= 0) ? D[(size_t)dd[i][t4] * bpad] : 0.0;                  \
+        bv[i][t4] = (dd[i][t4] >= 0) ? U[(size_t)uu[i][t4] * bpad] : 0.0;                  \
+      }                                                                                    \
     _Pragma("unroll") for (int i = 0; i < G; ++i) {                                        \
-      a0[i] = D[(size_t)d0[i] * bpad];                                                     \
-      b0[i] = U[(size_t)u0[i] * bpad];                                                     \
-      a1[i] = (d1[i] >= 0) ? D[(size_t)d1[i] * bpad] : 0.0;                                \
-      b1[i] = (d1[i] >= 0) ? U[(size_t)u1[i] * bpad] : 0.0;                                \
-    }                                                                                      \
-    _Pragma("unroll") for (int i = 0; i < G; ++i) {                                        \
-      const double v = a0[i] * b0[i] + a1[i] * b1[i];                                      \
+      const double v = av[i][0] * bv[i][0] + av[i][1] * bv[i][1] + av[i][2] * bv[i][2] + av[i][3] * bv[i][3]; \
       if (i0 + i < cnt) M[(1 + jb - m0 + i0 + i) * 64 + lane] = v;                         \
     }                                                                                      \
   }
     int i0 = 0;
-    for (; cnt - i0 > 2; i0 += 8) PP_MGROUP(8)
+    for (; cnt - i0 > 2; i0 += 4) PP_MGROUP(4)
     if (i0 < cnt) PP_MGROUP(2)
 #undef PP_MGROUP
   }
   double* Udst = g.U + ((size_t)g.piv_uoff[p] + (size_t)r0 * w) * bpad + b;
   const bool diag = (r0 == 0);
   const int ndiag = diag ? w * w : 0;
-  double pv0 = 0.0, pv2 = 0.0, pv3 = 0.0, tmax_diag = 0.0, colmax = 0.0;
+  double pv[PP_WMAX * PP_WMAX];
+#pragma unroll
+  for (int q = 0; q < PP_WMAX * PP_WMAX; ++q) pv[q] = 0.0;
+  double tmax_diag = 0.0, colmax = 0.0;
   double acc = 0.0, tmax = 0.0;
   int d = 0;
   const int E0 = dp_vec ? bcast(dpv, 0) : dp[0];
@@ -153,7 +161,7 @@ __global__ __launch_bounds__(64) void k_factor_level(GroupDev g, int task0, int 
   do {                                                                    \
     Udst[(size_t)d * bpad] = acc;                                         \
     if (d < ndiag) {                                                      \
-      if (d == 0) pv0 = acc; else if (d == 2) pv2 = acc; else if (d == 3) pv3 = acc; \
+      _Pragma("unroll") for (int q = 0; q < PP_WMAX * PP_WMAX; ++q) if (q == d) pv[q] = acc; \
       tmax_diag = fmax(tmax_diag, tmax);                                  \
     } else {                                                              \
       colmax = fmax(colmax, fabs(acc));                                   \
@@ -199,12 +207,13 @@ __global__ __launch_bounds__(64) void k_factor_level(GroupDev g, int task0, int 
   while (d < ndst) PP_FINALIZE();
 #undef PP_FINALIZE
   if (diag) {
-    const pp::PivotResult pr = pp::invert_pivot(w, pv0, (w == 2) ? pv2 : 0.0, (w == 2) ? pv3 : 0.0,
-                                                fmax(colmax, tmax_diag), eps);
+    double inv[PP_WMAX * (PP_WMAX + 1) / 2];
+    const int code = pp::invert_block(w, g.piv_sub[p], pv, fmax(colmax, tmax_diag), eps, inv);
     double* invp = g.Dinv + (size_t)g.piv_doff[p] * bpad + b;
-    invp[0] = pr.i00;
-    if (w == 2) { invp[bpad] = pr.i10; invp[2 * bpad] = pr.i11; }
-    g.codes[(size_t)p * bpad + b] = (b < g.batch) ? (unsigned char)pr.code : (unsigned char)0;
+#pragma unroll
+    for (int q = 0; q < PP_WMAX * (PP_WMAX + 1) / 2; ++q)
+      if (q < w * (w + 1) / 2) invp[(size_t)q * bpad] = inv[q];
+    g.codes[(size_t)p * bpad + b] = (b < g.batch) ? (unsigned short)code : (unsigned short)0;
   }
 }
 
@@ -224,16 +233,21 @@ __global__ __launch_bounds__(64) void k_factor_level_lean(GroupDev g, int task0,
   const double* __restrict__ D = g.Dinv + b;
   M[lane] = -1.0;
   for (int j = m0; j < m1; ++j) {
-    const int* rec = g.mrec + 4 * (size_t)j;
-    double v = D[(size_t)rec[0] * bpad] * U[(size_t)rec[1] * bpad];
-    if (rec[2] >= 0) v += D[(size_t)rec[2] * bpad] * U[(size_t)rec[3] * bpad];
+    const int* rec = g.mrec + 8 * (size_t)j;
+    double v = D[(size_t)rec[0] * bpad] * U[(size_t)rec[4] * bpad];
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+      if (rec[q] >= 0) v += D[(size_t)rec[q] * bpad] * U[(size_t)rec[4 + q] * bpad];
     M[(1 + j - m0) * 64 + lane] = v;
   }
   const int ndst = (r1 - r0) * w;
   const int* dp = g.fdst_ptr + dptr0;
   double* Udst = g.U + ((size_t)g.piv_uoff[p] + (size_t)r0 * w) * bpad + b;
   const int ndiag = (r0 == 0) ? w * w : 0;
-  double pv0 = 0.0, pv2 = 0.0, pv3 = 0.0, tmax_diag = 0.0, colmax = 0.0;
+  double pv[PP_WMAX * PP_WMAX];
+#pragma unroll
+  for (int q = 0; q < PP_WMAX * PP_WMAX; ++q) pv[q] = 0.0;
+  double tmax_diag = 0.0, colmax = 0.0;
   for (int d = 0; d < ndst; ++d) {
     double acc = 0.0, tmax = 0.0;
     for (int e = dp[d]; e < dp[d + 1]; ++e) {
@@ -245,39 +259,40 @@ __global__ __launch_bounds__(64) void k_factor_level_lean(GroupDev g, int task0,
     }
     Udst[(size_t)d * bpad] = acc;
     if (d < ndiag) {
-      if (d == 0) pv0 = acc; else if (d == 2) pv2 = acc; else if (d == 3) pv3 = acc;
+#pragma unroll
+      for (int q = 0; q < PP_WMAX * PP_WMAX; ++q) if (q == d) pv[q] = acc;
       tmax_diag = fmax(tmax_diag, tmax);
     } else {
       colmax = fmax(colmax, fabs(acc));
     }
   }
   if (r0 == 0) {
-    const pp::PivotResult pr = pp::invert_pivot(w, pv0, (w == 2) ? pv2 : 0.0, (w == 2) ? pv3 : 0.0,
-                                                fmax(colmax, tmax_diag), eps);
+    double inv[PP_WMAX * (PP_WMAX + 1) / 2];
+    const int code = pp::invert_block(w, g.piv_sub[p], pv, fmax(colmax, tmax_diag), eps, inv);
     double* invp = g.Dinv + (size_t)g.piv_doff[p] * bpad + b;
-    invp[0] = pr.i00;
-    if (w == 2) { invp[bpad] = pr.i10; invp[2 * bpad] = pr.i11; }
-    g.codes[(size_t)p * bpad + b] = (b < g.batch) ? (unsigned char)pr.code : (unsigned char)0;
+#pragma unroll
+    for (int q = 0; q < PP_WMAX * (PP_WMAX + 1) / 2; ++q)
+      if (q < w * (w + 1) / 2) invp[(size_t)q * bpad] = inv[q];
+    g.codes[(size_t)p * bpad + b] = (b < g.batch) ? (unsigned short)code : (unsigned short)0;
   }
 }
 
-// counters[0..2] += (pos, neg, zero) over all pivots (codes of padded instances are 0); 16 codes per load
-__global__ __launch_bounds__(256) void k_count_codes(const unsigned char* __restrict__ codes, size_t total16,
+// counters[0..2] += (pos, neg, zero) over all block pivots (codes of padded instances are 0);
+// a code is pos | neg << 4 | zero << 8 in 16 bits, 8 codes per 16-byte load
+__global__ __launch_bounds__(256) void k_count_codes(const unsigned short* __restrict__ codes, size_t total8,
                                                      int* counters) {
   __shared__ int red[3][256];
   int pos = 0, neg = 0, zero = 0;
   const uint4* c4 = reinterpret_cast<const uint4*>(codes);
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total16; i += (size_t)gridDim.x * 256) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (size_t)gridDim.x * 256) {
     const uint4 v = c4[i];
     const unsigned int wds[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const unsigned int x = wds[q];
-      // per byte: bits 0-1 pos, 2-3 neg, 4-5 zero
-      const unsigned int p2 = x & 0x03030303u, n2 = (x >> 2) & 0x03030303u, z2 = (x >> 4) & 0x03030303u;
-      pos += (int)((p2 * 0x01010101u) >> 24);
-      neg += (int)((n2 * 0x01010101u) >> 24);
-      zero += (int)((z2 * 0x01010101u) >> 24);
+      pos += (int)((x & 15u) + ((x >> 16) & 15u));
+      neg += (int)(((x >> 4) & 15u) + ((x >> 20) & 15u));
+      zero += (int)(((x >> 8) & 15u) + ((x >> 24) & 15u));
     }
   }
   red[0][threadIdx.x] = pos; red[1][threadIdx.x] = neg; red[2][threadIdx.x] = zero;
@@ -288,6 +303,42 @@ __global__ __launch_bounds__(256) void k_count_codes(const unsigned char* __rest
     __syncthreads();
   }
   if (threadIdx.x < 3 && red[threadIdx.x][0] != 0) atomicAdd(&counters[threadIdx.x], red[threadIdx.x][0]);
+}
+
+// scaled coupling rows Lc = U_c inv(P_p) of every block pivot that has coupling rows
+// (workgroup = one pivot x 64 instances; consumed by k_schur_tiles)
+__global__ __launch_bounds__(64) void k_lc_scale(GroupDev g) {
+  const int lane = threadIdx.x;
+  const int b = blockIdx.y * 64 + lane;
+  const size_t bpad = (size_t)g.bpad;
+  const int p = g.lc_piv[blockIdx.x];
+  const int w = g.piv_w[p];
+  const double* invp = g.Dinv + (size_t)g.piv_doff[p] * bpad + b;
+  double inv[PP_WMAX][PP_WMAX];
+#pragma unroll
+  for (int i = 0; i < PP_WMAX; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      const double v = (i < w) ? invp[(size_t)(i * (i + 1) / 2 + j) * bpad] : 0.0;
+      inv[i][j] = v; inv[j][i] = v;
+    }
+  const double* Uc = g.U + ((size_t)g.piv_uoff[p] + (size_t)g.piv_cslot0[p] * w) * bpad + b;
+  double* Lc = g.Lc + (size_t)g.piv_lcoff[p] * bpad + b;
+  const int nrow = g.piv_ncrow[p];
+  for (int r = 0; r < nrow; ++r) {
+    double u[PP_WMAX];
+#pragma unroll
+    for (int t = 0; t < PP_WMAX; ++t) u[t] = (t < w) ? Uc[(size_t)(r * w + t) * bpad] : 0.0;
+#pragma unroll
+    for (int t2 = 0; t2 < PP_WMAX; ++t2) {
+      if (t2 < w) {
+        double v = 0.0;
+#pragma unroll
+        for (int t1 = 0; t1 < PP_WMAX; ++t1) v += u[t1] * inv[t1][t2];
+        Lc[(size_t)(r * w + t2) * bpad] = v;
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -310,45 +361,24 @@ __global__ __launch_bounds__(64) void k_schur_tiles(GroupDev g) {
     const int p = rec[0];
     const int w = g.piv_w[p];
     const double* Up = g.U + (size_t)g.piv_uoff[p] * bpad + b;
-    const double* inv = g.Dinv + (size_t)g.piv_doff[p] * bpad + b;
-    const double i00 = inv[0];
-    if (w == 1) {
-      double wa0[8], ub0[4];
+    const double* Lp = g.Lc + (size_t)g.piv_lcoff[p] * bpad + b;
+    const int cs0 = g.piv_cslot0[p];
+    for (int t = 0; t < w; ++t) {
+      double la[8], ub[4];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int sa = rec[1 + i];
-        wa0[i] = (sa >= 0) ? Up[(size_t)sa * bpad] : 0.0;
+        la[i] = (sa >= 0) ? Lp[(size_t)((sa - cs0) * w + t) * bpad] : 0.0;
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int sb = rec[9 + 4 * half + j];
-        ub0[j] = (sb >= 0) ? Up[(size_t)sb * bpad] * i00 : 0.0;
+        ub[j] = (sb >= 0) ? Up[(size_t)(sb * w + t) * bpad] : 0.0;
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] -= wa0[i] * ub0[j];
-    } else {
-      const double i10 = inv[bpad], i11 = inv[2 * bpad];
-      double wa0[8], wa1[8], ub0[4], ub1[4];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int sa = rec[1 + i];
-        const double a0 = (sa >= 0) ? Up[(size_t)(sa * 2) * bpad] : 0.0;
-        const double a1 = (sa >= 0) ? Up[(size_t)(sa * 2 + 1) * bpad] : 0.0;
-        wa0[i] = a0 * i00 + a1 * i10;
-        wa1[i] = a0 * i10 + a1 * i11;
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int sb = rec[9 + 4 * half + j];
-        ub0[j] = (sb >= 0) ? Up[(size_t)(sb * 2) * bpad] : 0.0;
-        ub1[j] = (sb >= 0) ? Up[(size_t)(sb * 2 + 1) * bpad] : 0.0;
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] -= wa0[i] * ub0[j] + wa1[i] * ub1[j];
+        for (int j = 0; j < 4; ++j) acc[i][j] -= la[i] * ub[j];
     }
   }
   const double mask = (b < g.batch) ? 1.0 : 0.0;
@@ -714,23 +744,40 @@ __device__ __forceinline__ double gather_row(const int* __restrict__ upos, const
   return s0 + s1;
 }
 
-// forward substitution of one pivot: z_p = inv(P_p) (b_p - sum_k U[p,k] z_k)
+// forward substitution of one block pivot: z_p = inv(P_p) (b_p - sum_k U[p,k] z_k)
 __device__ __forceinline__ void fwd_pivot(const GroupDev& g, int p, int lane, int b) {
   const size_t bpad = (size_t)g.bpad;
   const int w = g.piv_w[p], p0 = g.piv_start[p];
   const double* U = g.U + b;
   const double* Z = g.W + b;
-  double y0 = g.rhsT[(size_t)g.perm[p0] * bpad + b] -
-              gather_row(g.sfwd_upos, g.sfwd_zcol, g.sfwd_eptr[p0], g.sfwd_eptr[p0 + 1], U, Z, bpad, lane);
   const double* inv = g.Dinv + (size_t)g.piv_doff[p] * bpad + b;
   if (w == 1) {
+    const double y0 = g.rhsT[(size_t)g.perm[p0] * bpad + b] -
+                      gather_row(g.sfwd_upos, g.sfwd_zcol, g.sfwd_eptr[p0], g.sfwd_eptr[p0 + 1], U, Z, bpad, lane);
     g.W[(size_t)p0 * bpad + b] = inv[0] * y0;
-  } else {
-    double y1 = g.rhsT[(size_t)g.perm[p0 + 1] * bpad + b] -
-                gather_row(g.sfwd_upos, g.sfwd_zcol, g.sfwd_eptr[p0 + 1], g.sfwd_eptr[p0 + 2], U, Z, bpad, lane);
-    const double i00 = inv[0], i10 = inv[bpad], i11 = inv[2 * bpad];
-    g.W[(size_t)p0 * bpad + b] = i00 * y0 + i10 * y1;
-    g.W[(size_t)(p0 + 1) * bpad + b] = i10 * y0 + i11 * y1;
+    return;
+  }
+  double y[PP_WMAX];
+#pragma unroll
+  for (int q = 0; q < PP_WMAX; ++q) {
+    y[q] = 0.0;
+    if (q < w)
+      y[q] = g.rhsT[(size_t)g.perm[p0 + q] * bpad + b] -
+             gather_row(g.sfwd_upos, g.sfwd_zcol, g.sfwd_eptr[p0 + q], g.sfwd_eptr[p0 + q + 1], U, Z, bpad, lane);
+  }
+#pragma unroll
+  for (int q = 0; q < PP_WMAX; ++q) {
+    if (q < w) {
+      double z = 0.0;
+#pragma unroll
+      for (int t = 0; t < PP_WMAX; ++t) {
+        if (t < w) {
+          const int hi = q > t ? q : t, lo = q > t ? t : q;
+          z += inv[(size_t)(hi * (hi + 1) / 2 + lo) * bpad] * y[t];
+        }
+      }
+      g.W[(size_t)(p0 + q) * bpad + b] = z;
+    }
   }
 }
 
@@ -803,30 +850,47 @@ __device__ __forceinline__ void bwd_pivot(const GroupDev& g, int p, int lane, in
     const double inv = g.Dinv[(size_t)g.piv_doff[p] * bpad + b];
     g.W[(size_t)p0 * bpad + b] -= inv * (g0 + g1);
   } else {
-    double g0 = 0.0, g1 = 0.0;
-    int j = 0;
-    for (; j + 4 <= nr; j += 4) {
-      double u0[4], u1[4], x[4];
+    double gq[PP_WMAX];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = ri[j + i];
-        u0[i] = Up[(size_t)((j + i) * 2) * bpad];
-        u1[i] = Up[(size_t)((j + i) * 2 + 1) * bpad];
-        x[i] = (r < n) ? Wb[(size_t)r * bpad] : xc[r - n];
+    for (int q = 0; q < PP_WMAX; ++q) gq[q] = 0.0;
+    for (int jb = 0; jb < nr; jb += 64) {
+      const int cnt = min(64, nr - jb);
+      const int rv = (lane < cnt) ? ri[jb + lane] : 0;
+      for (int i0 = 0; i0 < cnt; i0 += 4) {
+        int rr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rr[i] = bcast(rv, min(i0 + i, cnt - 1));
+        double u[4][PP_WMAX], x[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int q0 = min(i0 + i, cnt - 1);
+#pragma unroll
+          for (int q = 0; q < PP_WMAX; ++q) u[i][q] = (q < w) ? Up[(size_t)((jb + q0) * w + q) * bpad] : 0.0;
+          x[i] = (rr[i] < n) ? Wb[(size_t)rr[i] * bpad] : xc[rr[i] - n];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i0 + i < cnt) {
+#pragma unroll
+            for (int q = 0; q < PP_WMAX; ++q) gq[q] += u[i][q] * x[i];
+          }
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { g0 += u0[i] * x[i]; g1 += u1[i] * x[i]; }
-    }
-    for (; j < nr; ++j) {
-      const int r = ri[j];
-      const double x = (r < n) ? Wb[(size_t)r * bpad] : xc[r - n];
-      g0 += Up[(size_t)(j * 2) * bpad] * x;
-      g1 += Up[(size_t)(j * 2 + 1) * bpad] * x;
     }
     const double* inv = g.Dinv + (size_t)g.piv_doff[p] * bpad + b;
-    const double i00 = inv[0], i10 = inv[bpad], i11 = inv[2 * bpad];
-    g.W[(size_t)p0 * bpad + b] -= i00 * g0 + i10 * g1;
-    g.W[(size_t)(p0 + 1) * bpad + b] -= i10 * g0 + i11 * g1;
+#pragma unroll
+    for (int q = 0; q < PP_WMAX; ++q) {
+      if (q < w) {
+        double z = 0.0;
+#pragma unroll
+        for (int t = 0; t < PP_WMAX; ++t) {
+          if (t < w) {
+            const int hi = q > t ? q : t, lo = q > t ? t : q;
+            z += inv[(size_t)(hi * (hi + 1) / 2 + lo) * bpad] * gq[t];
+          }
+        }
+        g.W[(size_t)(p0 + q) * bpad + b] -= z;
+      }
+    }
   }
 }
 
@@ -1093,7 +1157,11 @@ int pp_end_symbolic(pp_handle h) {
     int rc;
     std::vector<int> uoff(P.piv_uoff.begin(), P.piv_uoff.end());
     std::vector<int> ftask, mrec, fdst_ptr, fent, srec;
-    for (auto& m : P.mrecs) { mrec.insert(mrec.end(), {m.d0, m.u0, m.d1, m.u1}); }
+    for (auto& m : P.mrecs) {
+      for (int q = 0; q < PP_WMAX; ++q) mrec.push_back(m.d[q]);
+      for (int q = 0; q < PP_WMAX; ++q) mrec.push_back(m.u[q]);
+    }
+    for (int q = 0; q < 16; ++q) mrec.push_back(-1);
     // expand the canonical initial-value entries into raw-value entries (duplicates are summed)
     fdst_ptr.reserve(P.fdst_ptr.size());
     fent.reserve(P.fentries.size() * 2 + 16);
@@ -1130,6 +1198,16 @@ int pp_end_symbolic(pp_handle h) {
     if ((rc = dev_upload(h, g, &d.piv_start, P.piv_start))) return rc;
     if ((rc = dev_upload(h, g, &d.piv_uoff, uoff))) return rc;
     if ((rc = dev_upload(h, g, &d.piv_doff, P.piv_doff))) return rc;
+    {
+      std::vector<int> sub(P.piv_sub.begin(), P.piv_sub.end()), lcp;
+      for (int p = 0; p < P.npiv; ++p) if (P.piv_lcoff[p] >= 0) lcp.push_back(p);
+      d.n_lc_piv = (int)lcp.size();
+      if ((rc = dev_upload(h, g, &d.piv_sub, sub))) return rc;
+      if ((rc = dev_upload(h, g, &d.piv_cslot0, P.piv_cslot0))) return rc;
+      if ((rc = dev_upload(h, g, &d.piv_ncrow, P.piv_ncrow))) return rc;
+      if ((rc = dev_upload(h, g, &d.piv_lcoff, P.piv_lcoff))) return rc;
+      if ((rc = dev_upload(h, g, &d.lc_piv, lcp))) return rc;
+    }
     if ((rc = dev_upload(h, g, &d.piv_rowptr, P.piv_rowptr))) return rc;
     if ((rc = dev_upload(h, g, &d.rowidx, P.rowidx))) return rc;
     if ((rc = dev_upload(h, g, &d.perm, P.perm))) return rc;
@@ -1161,6 +1239,7 @@ int pp_end_symbolic(pp_handle h) {
     if ((rc = dev_alloc(h, g, &d.rawT, (size_t)g->nraw * bp))) return rc;
     if ((rc = dev_alloc(h, g, &d.U, (size_t)P.usize * bp))) return rc;
     if ((rc = dev_alloc(h, g, &d.Dinv, (size_t)P.dsize * bp))) return rc;
+    if ((rc = dev_alloc(h, g, &d.Lc, (size_t)P.lcsize * bp))) return rc;
     if ((rc = dev_alloc(h, g, &d.W, (size_t)(P.n + nc) * bp))) return rc;
     if ((rc = dev_alloc(h, g, &d.rhs, (size_t)g->batch * P.n))) return rc;
     g->rhs_own = d.rhs;
@@ -1168,7 +1247,7 @@ int pp_end_symbolic(pp_handle h) {
     if ((rc = dev_alloc(h, g, &d.xout, (size_t)g->batch * P.n))) return rc;
     if ((rc = dev_alloc(h, g, &d.Spart, (size_t)d.nchunk * std::max(g->ntiles, 1) * 64))) return rc;
     if ((rc = dev_alloc(h, g, &d.rspart, (size_t)d.nchunk * std::max(nc, 1)))) return rc;
-    if ((rc = dev_alloc(h, g, &d.codes, (size_t)P.npiv * bp))) return rc;
+    if ((rc = dev_alloc(h, g, &d.codes, (size_t)P.npiv * bp))) return rc;   // 16-bit codes
   }
   int rc;
   const size_t nn = (size_t)nc * nc;
@@ -1261,11 +1340,12 @@ int pp_numeric_local(pp_handle h) {
       if (join_streams(h, sp, fan)) return fail(h, 3, "stream join failed");
     }
     {
-      PhaseScope ps(h, 2, 3);
-      const size_t total16 = (size_t)P.npiv * d.bpad / 16;   // bpad is a multiple of 64
-      hipLaunchKernelGGL(k_count_codes, dim3((unsigned)std::min<size_t>(512, (total16 + 255) / 256)), dim3(256), 0, st,
-                         d.codes, total16, h->counters);
+      PhaseScope ps(h, 2, 4);
+      const size_t total8 = (size_t)P.npiv * d.bpad / 8;   // bpad is a multiple of 64
+      hipLaunchKernelGGL(k_count_codes, dim3((unsigned)std::min<size_t>(512, (total8 + 255) / 256)), dim3(256), 0, st,
+                         d.codes, total8, h->counters);
       if (g->ntiles > 0) {
+        if (d.n_lc_piv > 0) hipLaunchKernelGGL(k_lc_scale, dim3(d.n_lc_piv, d.nchunk), dim3(64), 0, st, d);
         hipLaunchKernelGGL(k_schur_tiles, dim3(g->ntiles, d.nchunk, 2), dim3(64), 0, st, d);
         hipLaunchKernelGGL(k_schur_reduce, dim3(g->ntiles), dim3(64), 0, st, d, g->ntiles, h->S);
       }

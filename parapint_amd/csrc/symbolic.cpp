@@ -21,6 +21,7 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
   P.n = n; P.nc = nc; P.opt = opt; P.ncan = nnzK + nnzB;
   P.numeric_ordering = (vals != nullptr);
   if (opt.tile != 8) { P.error = "tile must be 8"; return 3; }
+  if (opt.sn_wmax < 1 || opt.sn_wmax > PP_WMAX) { P.error = "sn_wmax out of range"; return 3; }
   if (n <= 0) { P.error = "empty block"; return 3; }
 
   // ---- 1. rows of the augmented matrix (K nodes 0..n-1, coupling nodes n..n+nc-1) with the
@@ -95,7 +96,7 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
   std::vector<double> lu(n + nc, 0.0), lv(n + nc, 0.0);
   std::vector<Ent> tmp;
   std::vector<int> N;
-  P.piv_start.clear(); P.piv_w.clear();
+  std::vector<int> sp_start, sp_w;   // sub-pivots (1x1 / 2x2) in elimination order
   while ((int)order.size() < n) {
     int u = -1, v = -1;
     {
@@ -191,32 +192,149 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
       q_insert(x);
     }
     for (int x : N) { lu[x] = 0.0; lv[x] = 0.0; }
-    P.piv_start.push_back((int)order.size());
-    P.piv_w.push_back(v >= 0 ? 2 : 1);
+    sp_start.push_back((int)order.size());
+    sp_w.push_back(v >= 0 ? 2 : 1);
     order.push_back(u);
     if (v >= 0) { order.push_back(v); P.n_2x2++; }
     pstruct.push_back(N);
     std::vector<Ent>().swap(row[u]);
     if (v >= 0) std::vector<Ent>().swap(row[v]);
   }
-  P.npiv = (int)P.piv_w.size();
-  P.piv_start.push_back(n);
-  P.perm = order;
+  // ---- 2b. supernodes: a sub-pivot is merged into its elimination-tree parent when their
+  // structures agree up to sn_tol_rows padded rows and the merged width stays <= sn_wmax.  The
+  // merged block is still eliminated in the static sub-pivot order (pivot.hpp, invert_block), so the
+  // arithmetic is that of the sub-pivot sequence; what changes is the schedule: one level per
+  // supernode instead of one per sub-pivot (chains of separator nodes collapse).
+  const int nsp = (int)sp_w.size();
+  sp_start.push_back(n);
+  std::vector<int> pos_of_node(n), sp_of_pos(n);
+  for (int k = 0; k < n; ++k) pos_of_node[order[k]] = k;
+  for (int sidx = 0; sidx < nsp; ++sidx)
+    for (int q = 0; q < sp_w[sidx]; ++q) sp_of_pos[sp_start[sidx] + q] = sidx;
+  std::vector<std::vector<int>> srows(nsp);   // structure of each sub-pivot: positions (K) and n + c
+  for (int sidx = 0; sidx < nsp; ++sidx) {
+    auto& r = srows[sidx];
+    r.reserve(pstruct[sidx].size());
+    for (int x : pstruct[sidx]) r.push_back(x < n ? pos_of_node[x] : x);
+    std::sort(r.begin(), r.end());
+    std::vector<int>().swap(pstruct[sidx]);
+  }
+  std::vector<int> sp_parent(nsp, -1);
+  std::vector<std::vector<int>> sp_children(nsp);
+  for (int sidx = 0; sidx < nsp; ++sidx)
+    if (!srows[sidx].empty() && srows[sidx][0] < n) {
+      sp_parent[sidx] = sp_of_pos[srows[sidx][0]];
+      sp_children[sp_parent[sidx]].push_back(sidx);
+    }
+  std::vector<int> chain_width(sp_w), merged_child(nsp, -1);   // merged_child[q] = child merged into q
+  std::vector<uint8_t> is_merged(nsp, 0);
+  if (opt.sn_wmax > 1) {
+    for (int q = 0; q < nsp; ++q) {
+      int best = -1;
+      const int q0 = sp_start[q], q1 = q0 + sp_w[q];
+      for (int c : sp_children[q]) {
+        if (chain_width[c] + sp_w[q] > opt.sn_wmax) continue;
+        const auto& rc = srows[c];
+        // rows of c beyond q's columns vs rows of q; q's columns inside c's structure
+        int have_cols = 0;
+        size_t ic = 0;
+        while (ic < rc.size() && rc[ic] < q1) { if (rc[ic] >= q0) ++have_cols; ++ic; }
+        int missing = sp_w[q] - have_cols;
+        size_t iq = 0;
+        const auto& rq = srows[q];
+        while (iq < rq.size()) {
+          while (ic < rc.size() && rc[ic] < rq[iq]) ++ic;
+          if (ic >= rc.size() || rc[ic] != rq[iq]) ++missing;
+          ++iq;
+        }
+        if (missing > opt.sn_tol_rows) continue;
+        if (best < 0 || srows[c].size() > srows[best].size()) best = c;
+      }
+      if (best >= 0) { merged_child[q] = best; is_merged[best] = 1; chain_width[q] = chain_width[best] + sp_w[q]; }
+    }
+  }
+  // post-order with chains contiguous: emit(head) = for every member of the chain (bottom up) first
+  // the subtrees of its non-merged children, then the chain itself
+  std::vector<int> sp_seq; sp_seq.reserve(nsp);
+  {
+    struct Frame { int head; std::vector<int> members; size_t mi; size_t ci; };
+    std::vector<Frame> stack;
+    auto make_frame = [&](int head) {
+      Frame f; f.head = head; f.mi = 0; f.ci = 0;
+      for (int x = head; x >= 0; x = merged_child[x]) f.members.push_back(x);
+      std::reverse(f.members.begin(), f.members.end());   // bottom member first
+      return f;
+    };
+    for (int root = 0; root < nsp; ++root) {
+      if (sp_parent[root] >= 0 || is_merged[root]) continue;
+      stack.push_back(make_frame(root));
+      while (!stack.empty()) {
+        Frame& f = stack.back();
+        bool pushed = false;
+        while (f.mi < f.members.size()) {
+          const auto& ch = sp_children[f.members[f.mi]];
+          while (f.ci < ch.size()) {
+            const int c = ch[f.ci++];
+            if (is_merged[c]) continue;          // part of this (or handled as) chain
+            stack.push_back(make_frame(c));
+            pushed = true;
+            break;
+          }
+          if (pushed) break;
+          ++f.mi; f.ci = 0;
+        }
+        if (pushed) continue;
+        for (int x : f.members) sp_seq.push_back(x);
+        stack.pop_back();
+      }
+    }
+    if ((int)sp_seq.size() != nsp) { P.error = "internal: supernode post-order lost sub-pivots"; return 3; }
+  }
+  // supernodes = maximal runs of sp_seq linked by merges; new node order
+  std::vector<int> new_order; new_order.reserve(n);
+  std::vector<std::vector<int>> sn_members;
+  for (size_t i = 0; i < sp_seq.size(); ++i) {
+    const int x = sp_seq[i];
+    if (i > 0 && merged_child[x] == sp_seq[i - 1]) sn_members.back().push_back(x);
+    else sn_members.push_back({x});
+  }
+  P.npiv = (int)sn_members.size();
+  P.piv_start.assign(P.npiv + 1, 0);
+  P.piv_w.assign(P.npiv, 0);
+  P.piv_sub.assign(P.npiv, 0);
+  for (int p = 0; p < P.npiv; ++p) {
+    P.piv_start[p] = (int)new_order.size();
+    int col = 0;
+    for (int x : sn_members[p]) {
+      if (sp_w[x] == 2) P.piv_sub[p] |= 1u << col;
+      for (int q = 0; q < sp_w[x]; ++q) new_order.push_back(order[sp_start[x] + q]);
+      col += sp_w[x];
+    }
+    P.piv_w[p] = col;
+  }
+  P.piv_start[P.npiv] = n;
+  P.perm = new_order;
   P.iperm.assign(n, -1);
-  for (int k = 0; k < n; ++k) P.iperm[order[k]] = k;
+  for (int k = 0; k < n; ++k) P.iperm[new_order[k]] = k;
   P.piv_of_col.assign(n, -1);
   for (int p = 0; p < P.npiv; ++p)
     for (int q = 0; q < P.piv_w[p]; ++q) P.piv_of_col[P.piv_start[p] + q] = p;
 
-  // ---- 3. row structures in new indices, closed under pivot pairs
+  // ---- 3. row structures in new indices (union over the members), closed under supernodes
   std::vector<std::vector<int>> rows(P.npiv);
   for (int p = 0; p < P.npiv; ++p) {
     auto& r = rows[p];
-    r.reserve(pstruct[p].size() + 2);
-    for (int x : pstruct[p]) r.push_back(x < n ? P.iperm[x] : x);
+    const int pend = P.piv_start[p] + P.piv_w[p];
+    for (int x : sn_members[p])
+      for (int v : srows[x]) {
+        const int nv = (v < n) ? P.iperm[order[v]] : v;
+        if (nv >= pend) r.push_back(nv);
+        else if (nv < P.piv_start[p]) { P.error = "internal: supernode structure points backwards"; return 3; }
+      }
     std::sort(r.begin(), r.end());
-    std::vector<int>().swap(pstruct[p]);
+    r.erase(std::unique(r.begin(), r.end()), r.end());
   }
+  for (auto& v : srows) std::vector<int>().swap(v);
   for (int p = 0; p < P.npiv; ++p) {
     auto& r = rows[p];
     bool added = false;
@@ -225,9 +343,9 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
       int c = r[t];
       if (c >= n) break;
       int q = P.piv_of_col[c];
-      if (P.piv_w[q] == 2) {
-        int other = (c == P.piv_start[q]) ? c + 1 : c - 1;
-        if (!std::binary_search(r.begin(), r.begin() + m, other)) { r.push_back(other); added = true; }
+      if (P.piv_w[q] > 1) {
+        for (int o = P.piv_start[q]; o < P.piv_start[q] + P.piv_w[q]; ++o)
+          if (!std::binary_search(r.begin(), r.begin() + m, o)) { r.push_back(o); added = true; }
       }
     }
     if (added) { std::sort(r.begin(), r.end()); r.erase(std::unique(r.begin(), r.end()), r.end()); }
@@ -247,11 +365,23 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
   P.piv_doff.assign(P.npiv, 0);
   for (int p = 0; p < P.npiv; ++p) {
     P.piv_doff[p] = P.dsize;
-    P.dsize += (P.piv_w[p] == 1) ? 1 : 3;
+    P.dsize += P.piv_w[p] * (P.piv_w[p] + 1) / 2;
     P.piv_rowptr[p + 1] = P.piv_rowptr[p] + (int)rows[p].size();
     P.piv_uoff[p] = P.usize;
     P.usize += (int64_t)(P.piv_w[p] + (int64_t)rows[p].size()) * P.piv_w[p];
     P.nnz_L += (int64_t)rows[p].size() * P.piv_w[p];
+  }
+  // scaled coupling rows L_c = U_c inv(P) (consumed by the Schur tiles): one slab per supernode
+  P.piv_cslot0.assign(P.npiv, 0);
+  P.piv_ncrow.assign(P.npiv, 0);
+  P.piv_lcoff.assign(P.npiv, -1);
+  for (int p = 0; p < P.npiv; ++p) {
+    const auto& r = rows[p];
+    size_t first = r.size();
+    while (first > 0 && r[first - 1] >= n) --first;
+    P.piv_cslot0[p] = P.piv_w[p] + (int)first;
+    P.piv_ncrow[p] = (int)(r.size() - first);
+    if (P.piv_ncrow[p] > 0) { P.piv_lcoff[p] = (int)P.lcsize; P.lcsize += (int64_t)P.piv_ncrow[p] * P.piv_w[p]; }
   }
   P.rowidx.reserve(P.piv_rowptr[P.npiv]);
   for (int p = 0; p < P.npiv; ++p) P.rowidx.insert(P.rowidx.end(), rows[p].begin(), rows[p].end());
@@ -321,9 +451,9 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
   if (P.n_levels - P.tail_level0 < 3) P.tail_level0 = P.n_levels;
 
   // inverse-pivot scalar (t, t') of pivot k in Dinv storage
-  auto dinv_pos = [&](int k, int t, int t2) -> int {
-    if (P.piv_w[k] == 1) return P.piv_doff[k];
-    return P.piv_doff[k] + ((t == t2) ? (t == 0 ? 0 : 2) : 1);
+  auto dinv_pos = [&](int k, int t, int t2) -> int {   // packed lower triangle by rows
+    const int hi = std::max(t, t2), lo = std::min(t, t2);
+    return P.piv_doff[k] + hi * (hi + 1) / 2 + lo;
   };
 
   // ---- 6. factor tasks in flat scalar form (left-looking gathers, rows chunked by entry count)
@@ -405,9 +535,10 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
           int ms = -1;
           for (auto& km : rowpat[p]) if (km.first == k) { ms = km.second; break; }
           MRec m;
-          m.d0 = dinv_pos(k, t, 0); m.u0 = (int)(P.piv_uoff[k] + (int64_t)(ms + q) * wk + 0);
-          if (wk == 2) { m.d1 = dinv_pos(k, t, 1); m.u1 = (int)(P.piv_uoff[k] + (int64_t)(ms + q) * wk + 1); }
-          else { m.d1 = -1; m.u1 = -1; }
+          for (int t2 = 0; t2 < PP_WMAX; ++t2) {
+            if (t2 < wk) { m.d[t2] = dinv_pos(k, t, t2); m.u[t2] = (int)(P.piv_uoff[k] + (int64_t)(ms + q) * wk + t2); }
+            else { m.d[t2] = -1; m.u[t2] = -1; }
+          }
           mr[kv.second] = m;
         }
         P.mrecs.insert(P.mrecs.end(), mr.begin(), mr.end());

@@ -22,7 +22,12 @@ struct HostCtx {
 };
 }  // namespace
 
+static int g_sn_wmax = 0, g_sn_tol = -1;
+
 extern "C" {
+
+// test knob: supernode width cap / padded-row tolerance for plans created afterwards (0 / -1: defaults)
+void ppsim_set_supernodes(int wmax, int tol) { g_sn_wmax = wmax; g_sn_tol = tol; }
 
 void* ppsim_create(int n, int nc, int nnzK, const int* rowK, const int* colK, int nnzB, const int* rowB,
                    const int* colB, const double* vals, int max_entries, int delta_abs, double delta_rel) {
@@ -31,6 +36,8 @@ void* ppsim_create(int n, int nc, int nnzK, const int* rowK, const int* colK, in
   if (max_entries > 0) opt.max_task_entries = max_entries;
   if (delta_abs >= 0) opt.md_delta_abs = delta_abs;
   if (delta_rel >= 0) opt.md_delta_rel = delta_rel;
+  if (g_sn_wmax > 0) opt.sn_wmax = g_sn_wmax;
+  if (g_sn_tol >= 0) opt.sn_tol_rows = g_sn_tol;
   int rc = pp::build_plan(n, nc, nnzK, rowK, colK, nnzB, rowB, colB, vals, opt, *P);
   if (rc != 0) { /* keep the plan so the error string can be read */ }
   return P;
@@ -87,11 +94,11 @@ int ppsim_factor(void* h, const double* can, double* U, double* Dinv, double* S,
     M.assign(1 + (t.m1 - t.m0), -1.0);
     for (int j = t.m0; j < t.m1; ++j) {
       const auto& m = P.mrecs[j];
-      double v = Dinv[m.d0] * U[m.u0];
-      if (m.d1 >= 0) v += Dinv[m.d1] * U[m.u1];
+      double v = 0.0;
+      for (int q = 0; q < PP_WMAX; ++q) if (m.d[q] >= 0) v += Dinv[m.d[q]] * U[m.u[q]];
       M[1 + (j - t.m0)] = v;
     }
-    double piv[4] = {0, 0, 0, 0}, tmax_diag = 0.0, colmax = 0.0;
+    double piv[PP_WMAX * PP_WMAX] = {0}, tmax_diag = 0.0, colmax = 0.0;
     for (int d = 0; d < ndst; ++d) {
       double acc = 0.0, tmax = 0.0;
       for (int e = P.fdst_ptr[t.dptr0 + d]; e < P.fdst_ptr[t.dptr0 + d + 1]; ++e) {
@@ -106,34 +113,44 @@ int ppsim_factor(void* h, const double* can, double* U, double* Dinv, double* S,
       else colmax = std::fmax(colmax, std::fabs(acc));
     }
     if (t.r0 == 0) {
-      const double a = piv[0], b = (w == 2 ? piv[2] : 0.0), c = (w == 2 ? piv[3] : 0.0);
-      pp::PivotResult pr = pp::invert_pivot(w, a, b, c, std::fmax(colmax, tmax_diag), eps);
-      double* inv = &Dinv[P.piv_doff[p]];
-      inv[0] = pr.i00;
-      if (w == 2) { inv[1] = pr.i10; inv[2] = pr.i11; }
-      pos += pr.code & 3; neg += (pr.code >> 2) & 3; zero += (pr.code >> 4) & 3;
+      const int code = pp::invert_block(w, P.piv_sub[p], piv, std::fmax(colmax, tmax_diag), eps, &Dinv[P.piv_doff[p]]);
+      pos += code & 15; neg += (code >> 4) & 15; zero += (code >> 8) & 15;
     }
   }
   inertia[0] += pos; inertia[1] += neg; inertia[2] += zero;
-  // Schur tiles
+  // scaled coupling rows Lc = U_c inv(P), then Schur tiles S -= Lc_a U_c_b^T
+  std::vector<double> Lc((size_t)P.lcsize, 0.0);
+  for (int p = 0; p < P.npiv; ++p) {
+    if (P.piv_lcoff[p] < 0) continue;
+    const int w = P.piv_w[p];
+    const double* inv = &Dinv[P.piv_doff[p]];
+    for (int r = 0; r < P.piv_ncrow[p]; ++r) {
+      const double* u = &U[P.piv_uoff[p] + (int64_t)(P.piv_cslot0[p] + r) * w];
+      for (int t2 = 0; t2 < w; ++t2) {
+        double v = 0.0;
+        for (int t1 = 0; t1 < w; ++t1) {
+          const int hi = t1 > t2 ? t1 : t2, lo = t1 > t2 ? t2 : t1;
+          v += u[t1] * inv[hi * (hi + 1) / 2 + lo];
+        }
+        Lc[(size_t)P.piv_lcoff[p] + (size_t)r * w + t2] = v;
+      }
+    }
+  }
   const int T = P.opt.tile, nc = P.nc;
   for (size_t ti = 0; ti < P.stile_a.size(); ++ti) {
     double accS[8][8] = {};
     for (int r = P.stile_ptr[ti]; r < P.stile_ptr[ti + 1]; ++r) {
       const auto& rec = P.stile_rec[r];
       const int p = rec.piv, w = P.piv_w[p];
-      const int64_t off = P.piv_uoff[p];
-      const double* inv = &Dinv[P.piv_doff[p]];
       for (int i = 0; i < T; ++i) {
         if (rec.slotA[i] < 0) continue;
-        const double* ua = &U[off + (int64_t)rec.slotA[i] * w];
-        double wa0, wa1 = 0;
-        if (w == 1) wa0 = ua[0] * inv[0];
-        else { wa0 = ua[0] * inv[0] + ua[1] * inv[1]; wa1 = ua[0] * inv[1] + ua[1] * inv[2]; }
+        const double* la = &Lc[(size_t)P.piv_lcoff[p] + (size_t)(rec.slotA[i] - P.piv_cslot0[p]) * w];
         for (int j = 0; j < T; ++j) {
           if (rec.slotB[j] < 0) continue;
-          const double* ub = &U[off + (int64_t)rec.slotB[j] * w];
-          accS[i][j] -= wa0 * ub[0] + (w == 2 ? wa1 * ub[1] : 0.0);
+          const double* ub = &U[P.piv_uoff[p] + (int64_t)rec.slotB[j] * w];
+          double v = 0.0;
+          for (int t2 = 0; t2 < w; ++t2) v += la[t2] * ub[t2];
+          accS[i][j] -= v;
         }
       }
     }
@@ -151,15 +168,18 @@ void ppsim_forward(void* h, const double* U, const double* Dinv, const double* r
   Plan& P = *(Plan*)h;
   for (int li = 0; li < P.npiv; ++li) {
     const int p = P.lvl_piv[li], w = P.piv_w[p], p0 = P.piv_start[p];
-    double y[2] = {0, 0};
+    double y[PP_WMAX] = {0};
     for (int q = 0; q < w; ++q) {
       double acc = rhs[P.perm[p0 + q]];
       for (int e = P.sfwd_eptr[p0 + q]; e < P.sfwd_eptr[p0 + q + 1]; ++e) acc -= U[P.sfwd_upos[e]] * W[P.sfwd_zcol[e]];
       y[q] = acc;
     }
     const double* inv = &Dinv[P.piv_doff[p]];
-    if (w == 1) W[p0] = inv[0] * y[0];
-    else { W[p0] = inv[0] * y[0] + inv[1] * y[1]; W[p0 + 1] = inv[1] * y[0] + inv[2] * y[1]; }
+    for (int q = 0; q < w; ++q) {
+      double z = 0.0;
+      for (int t = 0; t < w; ++t) { const int hi = q > t ? q : t, lo = q > t ? t : q; z += inv[hi * (hi + 1) / 2 + lo] * y[t]; }
+      W[p0 + q] = z;
+    }
   }
   for (int c = 0; c < P.nc; ++c) {
     double s = 0;
@@ -173,17 +193,17 @@ void ppsim_backward(void* h, const double* U, const double* Dinv, double* W, dou
   Plan& P = *(Plan*)h;
   for (int li = P.npiv - 1; li >= 0; --li) {
     const int p = P.lvl_piv[li], w = P.piv_w[p], p0 = P.piv_start[p];
-    double g[2] = {0, 0};
+    double g[PP_WMAX] = {0};
     const int nr = P.piv_rowptr[p + 1] - P.piv_rowptr[p];
     const int* ri = &P.rowidx[P.piv_rowptr[p]];
     const double* u = &U[P.piv_uoff[p] + (int64_t)w * w];
     for (int j = 0; j < nr; ++j)
       for (int q = 0; q < w; ++q) g[q] += u[(int64_t)j * w + q] * W[ri[j]];
     const double* inv = &Dinv[P.piv_doff[p]];
-    if (w == 1) W[p0] -= inv[0] * g[0];
-    else {
-      W[p0] -= inv[0] * g[0] + inv[1] * g[1];
-      W[p0 + 1] -= inv[1] * g[0] + inv[2] * g[1];
+    for (int q = 0; q < w; ++q) {
+      double z = 0.0;
+      for (int t = 0; t < w; ++t) { const int hi = q > t ? q : t, lo = q > t ? t : q; z += inv[hi * (hi + 1) / 2 + lo] * g[t]; }
+      W[p0 + q] -= z;
     }
   }
   for (int k = 0; k < P.n; ++k) x[P.perm[k]] = W[k];
