@@ -46,6 +46,8 @@ def parse_args():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-boundary', action='store_true')
     ap.add_argument('--profile-steps', type=int, default=5)
+    ap.add_argument('--sn-wmax', type=int, default=0, help='supernode width cap (0: library default)')
+    ap.add_argument('--sn-tol', type=int, default=-1, help='padded rows tolerated when merging (-1: default)')
     return ap.parse_args()
 
 
@@ -93,6 +95,8 @@ def main():
     B = len(local)
     solver = HipSchurComplementLinearSolver({i: None for i in local}, None, comm=comm)
     eng = solver._eng
+    if args.sn_wmax > 0 or args.sn_tol >= 0:
+        eng.set_supernodes(args.sn_wmax, args.sn_tol)
 
     # ---- through the LinearSolverInterface boundary (host buffers in, host buffers out)
     kkt = model.build_kkt(comm=comm, iteration=0)

@@ -93,6 +93,11 @@ int pp_bind_schur_buffer(pp_handle h, double* dev_ptr);
  * Q: dense column-major n_c x n_c on the host (lower triangle read), or NULL for Q = 0. */
 int pp_factor_schur(pp_handle h, const double* Q_host);
 
+/* Block pivots (supernodes) for groups added afterwards: sub-pivot chains of the elimination tree
+ * are merged up to `wmax` columns (1 = off, at most 4) when at most `tol_rows` padded rows result;
+ * 0 / -1 keep the built-in defaults.  Fewer, fatter levels in every sweep. */
+int pp_set_supernodes(pp_handle h, int wmax, int tol_rows);
+
 /* Number of instance groups whose level sweeps run on separate HIP streams.  0 = default (one
  * group: on MI355X / ROCm 7.2 more groups were measured slower, the launches serialise). */
 int pp_set_instance_splits(pp_handle h, int nsplit);

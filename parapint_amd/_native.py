@@ -32,6 +32,7 @@ SIGNATURES = {
     'pp_schur_buffer': (ctypes.c_void_p, [ctypes.c_void_p]),
     'pp_bind_schur_buffer': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     'pp_factor_schur': (ctypes.c_int, [ctypes.c_void_p, _f64p]),
+    'pp_set_supernodes': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     'pp_set_instance_splits': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'pp_set_dense_policy': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'pp_get_dense_mode': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]),

@@ -57,7 +57,7 @@ PP_HD PivotResult invert_pivot(int w, double a, double b, double c, double colma
 #define PP_WMAX 4
 #endif
 
-PP_HD int invert_block(int w, unsigned sub, const double* a /* w*w row-major, lower triangle read */, double colmax,
+PP_HD int invert_block(int w, unsigned sub, const double* a /* row-major with stride PP_WMAX, lower triangle read */, double colmax,
                        double eps, double* inv) {
   double A[PP_WMAX][PP_WMAX];
 #pragma unroll
@@ -65,7 +65,7 @@ PP_HD int invert_block(int w, unsigned sub, const double* a /* w*w row-major, lo
 #pragma unroll
     for (int j = 0; j < PP_WMAX; ++j) {
       const int hi = i > j ? i : j, lo = i > j ? j : i;
-      A[i][j] = (hi < w) ? a[hi * w + lo] : ((i == j) ? 1.0 : 0.0);
+      A[i][j] = (hi < w) ? a[hi * PP_WMAX + lo] : ((i == j) ? 1.0 : 0.0);
     }
   int pos = 0, neg = 0, zero = 0;
   bool second = false;   // current column is the second column of a 2x2 sub-pivot

@@ -31,14 +31,13 @@
 namespace pp {
 
 struct PlanOptions {
-  int max_task_entries = 96;   // update entries per factor task (rows of a panel are chunked to fit)
-  int max_task_mults = 62;     // multiplier scalars per factor task (LDS table, 512 B each)
+  int max_task_entries = 96;   // entries per factor task: smaller panels are one fused task, bigger ones are chunked
+  int scale_task_rows = 32;    // rows per scale task of a big panel
   // Top of the elimination tree ("tail"): levels holding at most tail_piv_max pivots each are run
   // inside ONE persistent launch per phase (a workgroup per 64 instances, barrier per level), with
   // smaller tasks so that the few waves of that workgroup share the work.
   int tail_piv_max = 48;
   int tail_task_entries = 48;
-  int tail_task_mults = 30;
   int tile = 8;           // register tile edge of the Schur (SYRK) kernel
   int sn_wmax = 1;        // widest supernode (columns); 1 disables merging of sub-pivots (wider blocks need the
                           // per-source block multiplier path)
@@ -48,15 +47,20 @@ struct PlanOptions {
   double pivot_threshold = 0.01;  // 1x1 pivot accepted if |d| >= threshold * max|row| (MA27 cntl(1) analogue)
 };
 
-// Factor task = rows [r0, r1) of panel `piv` (slot numbering: 0..w-1 = pivot block rows), in
-// flat scalar form.  Destination scalar d (0 <= d < (r1-r0)*w, U position dst_pos0 + d) is
-//     sum over its entries e of  - src(e) * M[midx(e)]
-// where src(e) is U[pos] (pos >= 0) or the canonical input value ~pos (pos < 0, assembly fused
-// into the factorisation), M[0] = -1 and M[1 + j] = Dinv[d0]*U[u0] (+ Dinv[d1]*U[u1]) is the
-// j-th multiplier scalar of the task (MRec).  All loads of a task are independent.
-struct FTask { int piv, r0, r1, m0, m1, dptr0; };
-struct MRec { int d[PP_WMAX], u[PP_WMAX]; };   // M = sum_t Dinv[d[t]] * U[u[t]]   (d[t] < 0: unused)
-struct FEntry { int src, midx; };
+// Factor schedule ("L form").  For every block pivot p two panels are stored with the same
+// indexing: the unscaled panel U_p = [P_p ; U_p] and the scaled rows L_p = U_p inv(P_p).  An
+// update of destination scalar d is then a pure two-operand gather
+//     acc -= U[e.u] * L[e.l]        (e.u < 0: canonical input value ~e.u; e.l < 0: constant -1)
+// so no per-task multiplier tables are needed and block pivots of any width cost the same per entry.
+// Task kinds:  0 gather chunk of a big panel (stores U, and the term magnitudes of pivot-block
+//                scalars for the zero-pivot test),
+//              1 fused small panel (gather everything, invert the block, scale the rows, store U, L,
+//                inv(P), inertia code),
+//              2 scale chunk of a big panel (inverts the gathered block, L rows = U rows inv(P); the
+//                chunk with r0 == w also stores inv(P) and the inertia code).
+// Per level: one launch of the kind-0/1 tasks, then (if any) one launch of the kind-2 tasks.
+struct FTask { int piv, r0, r1, dptr0, kind; };
+struct FEntry { int u, l; };
 // Schur tile record: pivot p contributes to tile (ta, tb); slots (or -1) of the tile's
 // coupling rows inside panel p
 struct STileRec { int piv; int slotA[8]; int slotB[8]; };
@@ -68,8 +72,7 @@ struct Plan {
   std::vector<int> perm, iperm;          // new->old, old->new (K nodes)
   std::vector<int> piv_start, piv_w;     // first new column of block pivot (supernode) p, width 1..PP_WMAX
   std::vector<unsigned> piv_sub;         // bit i: columns i, i+1 of the block form a 2x2 sub-pivot
-  std::vector<int> piv_cslot0, piv_ncrow, piv_lcoff;  // first coupling-row slot, #coupling rows, offset in Lc
-  int64_t lcsize = 0;                    // doubles per lane of the scaled coupling rows Lc
+  std::vector<int> piv_cslot0, piv_ncrow;  // first coupling-row slot of the panel, number of coupling rows
   std::vector<int> piv_of_col;           // new column -> pivot
   std::vector<int> piv_rowptr, rowidx;   // rows below pivot p (new indices; n+c = coupling row c)
   std::vector<int64_t> piv_uoff;         // panel offset, doubles per lane
@@ -79,15 +82,16 @@ struct Plan {
   std::vector<int64_t> pos_of_can;       // canonical input entry -> U position
   std::vector<int> piv_level;            // etree height of pivot
   // factor schedule
-  std::vector<FTask> ftasks;             // sorted by level
-  std::vector<MRec> mrecs;
-  std::vector<int> fdst_ptr;             // per task (ndst + 1) offsets into fentries, at dptr0
+  std::vector<FTask> ftasks;             // gather / fused tasks sorted by level
+  std::vector<FTask> stasks;             // scale tasks sorted by level
+  std::vector<int> fdst_ptr;             // per gather/fused task (ndst + 1) offsets into fentries, at dptr0
   std::vector<FEntry> fentries;
   std::vector<int> flevel_ptr;           // n_levels+1 -> ftasks
-  std::vector<int> flevel_maxm;          // per level: max multiplier scalars of a task (LDS sizing)
-  std::vector<int> flevel_nbig;          // per level: tasks (sorted last) whose table exceeds max_task_mults
-  std::vector<int> flevel_maxent;        // per level: max entries of a task
-  std::vector<int> slevel_maxent;        // per level: max forward-solve entries of a scalar row
+  std::vector<int> slevel_ptr;           // n_levels+1 -> stasks
+  std::vector<int> piv_boff;             // offset of the pivot block's w*w term magnitudes (Tm storage)
+  int bsize = 0;
+  std::vector<int> flevel_maxent;        // per level: max entries of a gather/fused task
+  std::vector<int> clevel_ptr, clevel_col;  // solve schedule: scalar columns (new indices) by level
   int tail_level0 = 0;                   // levels >= tail_level0 form the tail (== n_levels: no tail)
   // forward-solve entries: scalar row (new column index c) = b_c - sum U[upos] * z[zcol]
   std::vector<int> sfwd_eptr;            // n+1 -> sfwd_upos / sfwd_zcol

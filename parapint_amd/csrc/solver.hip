@@ -7,7 +7,7 @@
 //
 // Kernels (reference function each one replaces):
 //   k_transpose_in / k_assemble   values of K_i, A_i -> panel storage   (MA27B input, ma27_interface.py:124)
-//   k_factor_level                left-looking LDL^T panel updates, static 1x1/2x2 pivots (MA27B)
+//   k_gather_level, k_scale_level left-looking LDL^T in L form, static block pivots (MA27B)
 //   k_count_codes                 inertia / zero-pivot counts           (ma27_interface.py:201-203)
 //   k_schur_tiles, k_schur_reduce S_local = -sum_i A_i K_i^-1 A_i^T     (mpi_explicit_schur_complement.py:312-333)
 //   k_bk_factor                   dense LDL^T of S + Q                  (mpi_...:347-361)
@@ -40,14 +40,13 @@ constexpr double BK_EPS = 1e-14;
 struct GroupDev {
   int n, nc, batch, bpad, nchunk, npiv, nraw;
   int64_t usize;
-  const int *piv_w, *piv_start, *piv_uoff, *piv_doff, *piv_rowptr, *rowidx, *perm, *iperm;
-  const int *piv_sub, *piv_cslot0, *piv_ncrow, *piv_lcoff, *lc_piv;
-  int n_lc_piv;
-  const int *ftask, *mrec, *fdst_ptr, *fent;
-  const int *lvl_piv, *lvl_ptr, *sfwd_eptr, *sfwd_upos, *sfwd_zcol;
+  const int *piv_w, *piv_start, *piv_uoff, *piv_doff, *piv_boff, *piv_sub, *piv_rowptr, *rowidx, *perm, *iperm;
+  const int *piv_of_col;
+  const int *ftask, *stask, *fdst_ptr, *fent;
+  const int *clevel_col, *sfwd_eptr, *sfwd_upos, *sfwd_zcol;
   const int *crow_eptr, *crow_upos, *crow_zcol;
   const int *stile_a, *stile_b, *stile_ptr, *stile_rec;
-  double *raw, *rawT, *U, *Dinv, *Lc, *W, *rhs, *rhsT, *xout, *Spart, *rspart;
+  double *raw, *rawT, *U, *L, *Dinv, *Tm, *Y, *X, *rhs, *rhsT, *xout, *Spart, *rspart;
   unsigned short* codes;
 };
 
@@ -93,103 +92,134 @@ __global__ __launch_bounds__(256) void k_transpose_out(const double* __restrict_
 // behind per-batch scalar loads.
 __device__ __forceinline__ int bcast(int v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
 
-// One factor task (plan.hpp, FTask): phase A builds the task's multiplier table in LDS
-// (M[0] = -1, M[1+j] = Dinv*U products), phase B streams the flat entry list: every destination
-// scalar is accumulated in a register and written once.  Initial values come straight from the
-// transposed input (src < 0): assembly is fused into the factorisation.
-__global__ __launch_bounds__(64) void k_factor_level(GroupDev g, int task0, int chunk0, double eps) {
-  extern __shared__ __attribute__((aligned(16))) double M[];
+// inv(P) packed by rows of the lower triangle
+#define PP_INV(inv, i, j) ((inv)[((i) > (j) ? (i) * ((i) + 1) / 2 + (j) : (j) * ((j) + 1) / 2 + (i))])
+
+// bookkeeping shared by the gather kernels when a destination scalar is complete
+template <int WM>
+struct GatherState {
+  double blk[WM * WM];
+  double inv[WM * (WM + 1) / 2];
+  double rowbuf[WM];
+  double tmax_diag;
+  int slot, q;
+  __device__ __forceinline__ void init(int r0) {
+#pragma unroll
+    for (int i = 0; i < WM * WM; ++i) blk[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < WM * (WM + 1) / 2; ++i) inv[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) rowbuf[i] = 0.0;
+    tmax_diag = 0.0; slot = r0; q = 0;
+  }
+};
+
+// WM = 1: levels whose pivots are all scalar (the wide bottom of the tree) keep a tiny register footprint
+template <int WM>
+__device__ __forceinline__ void finalize_dst(const GroupDev& g, GatherState<WM>& st, int p, int w, int kind, int d,
+                                             double acc, double tmax, double* __restrict__ Udst,
+                                             double* __restrict__ Ldst, size_t bpad, int b, double eps) {
+  Udst[(size_t)d * bpad] = acc;
+  if (st.slot < w) {
+    if (kind == 0) {
+      g.Tm[(size_t)(g.piv_boff[p] + st.slot * w + st.q) * bpad + b] = tmax;
+    } else {
+      const int idx = st.slot * WM + st.q;   // fixed stride: static register indexing
+#pragma unroll
+      for (int i = 0; i < WM * WM; ++i) if (i == idx) st.blk[i] = acc;
+      st.tmax_diag = fmax(st.tmax_diag, tmax);
+    }
+  }
+  if (kind == 1) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i) if (i == st.q) st.rowbuf[i] = acc;
+    if (st.q == w - 1) {
+      if (st.slot == w - 1) {          // pivot block complete: invert it (static sub-pivot order)
+        int code;
+        if (WM == 1) {
+          const pp::PivotResult pr = pp::invert_pivot(1, st.blk[0], 0.0, 0.0, st.tmax_diag, eps);
+          st.inv[0] = pr.i00;
+          code = (pr.code & 3) | (((pr.code >> 2) & 3) << 4) | (((pr.code >> 4) & 3) << 8);
+        } else {
+          code = pp::invert_block(w, g.piv_sub[p], st.blk, st.tmax_diag, eps, st.inv);
+        }
+        double* invp = g.Dinv + (size_t)g.piv_doff[p] * bpad + b;
+#pragma unroll
+        for (int i = 0; i < WM * (WM + 1) / 2; ++i)
+          if (i < w * (w + 1) / 2) invp[(size_t)i * bpad] = st.inv[i];
+        g.codes[(size_t)p * bpad + b] = (b < g.batch) ? (unsigned short)code : (unsigned short)0;
+      } else if (st.slot >= w) {       // a row below the block: L row = U row * inv(P)
+#pragma unroll
+        for (int t2 = 0; t2 < WM; ++t2) {
+          if (t2 < w) {
+            double v = 0.0;
+#pragma unroll
+            for (int t1 = 0; t1 < WM; ++t1)
+              if (t1 < w) v += st.rowbuf[t1] * PP_INV(st.inv, t1, t2);
+            Ldst[(size_t)(d - (w - 1) + t2) * bpad] = v;
+          }
+        }
+      }
+    }
+  }
+  if (++st.q == w) { st.q = 0; ++st.slot; }
+}
+
+// One gather / fused task of the L-form factorisation (plan.hpp, FTask kinds 0 and 1): every
+// destination scalar is acc = -sum U[e.u] * L[e.l] over its entries, accumulated in a register and
+// written once; all global loads of up to 16 entries are in flight together.  Initial values come
+// straight from the transposed input (e.u < 0, e.l < 0): assembly is fused into the factorisation.
+template <int WM>
+__global__ __launch_bounds__(64) void k_gather_level(GroupDev g, int task0, int chunk0, double eps) {
   const int lane = threadIdx.x;
   const int b = (blockIdx.y + chunk0) * 64 + lane;
   const size_t bpad = (size_t)g.bpad;
-  const int* t = g.ftask + 6 * (size_t)(task0 + blockIdx.x);
-  const int p = t[0], r0 = t[1], r1 = t[2], m0 = t[3], m1 = t[4], dptr0 = t[5];
+  const int* t = g.ftask + 5 * (size_t)(task0 + blockIdx.x);
+  const int p = t[0], r0 = t[1], r1 = t[2], dptr0 = t[3], kind = t[4];
   const int w = g.piv_w[p];
   const double* __restrict__ U = g.U + b;
+  const double* __restrict__ Lb = g.L + b;
   const double* __restrict__ R = g.rawT + b;
-  const double* __restrict__ D = g.Dinv + b;
   const int ndst = (r1 - r0) * w;
   const int* dp = g.fdst_ptr + dptr0;
-  // destination boundaries: one vector load when they fit in a wave
   const bool dp_vec = (ndst + 1 <= 64);
   const int dpv = (dp_vec && lane <= ndst) ? dp[lane] : 0;
-  M[lane] = -1.0;
-  for (int jb = m0; jb < m1; jb += 64) {
-    const int cnt = min(64, m1 - jb);
-    int4 recd = make_int4(-1, -1, -1, -1), recu = make_int4(0, 0, 0, 0);
-    if (lane < cnt) {
-      const int4* rp = reinterpret_cast<const int4*>(g.mrec + 8 * (size_t)(jb + lane));
-      recd = rp[0]; recu = rp[1];
-    }
-#define PP_MGROUP(G)                                                                       \
-  {                                                                                        \
-    int dd[G][4], uu[G][4];                                                                \
-    _Pragma("unroll") for (int i = 0; i < G; ++i) { /* clamped: slots past the end repeat the last record */ \
-      const int q = min(i0 + i, cnt - 1);                                                  \
-      dd[i][0] = bcast(recd.x, q); dd[i][1] = bcast(recd.y, q); dd[i][2] = bcast(recd.z, q); dd[i][3] = bcast(recd.w, q); \
-      uu[i][0] = bcast(recu.x, q); uu[i][1] = bcast(recu.y, q); uu[i][2] = bcast(recu.z, q); uu[i][3] = bcast(recu.w, q); \
-    }                                                                                      \
-    double av[G][4], bv[G][4];                                                             \
-    _Pragma("unroll") for (int i = 0; i < G; ++i)                                          \
-      _Pragma("unroll") for (int t4 = 0; t4 < 4; ++t4) {                                   \
-        av[i][t4] = (dd[i][t4] >= 0) ? D[(size_t)dd[i][t4] * bpad] : 0.0;                  \
-        bv[i][t4] = (dd[i][t4] >= 0) ? U[(size_t)uu[i][t4] * bpad] : 0.0;                  \
-      }                                                                                    \
-    _Pragma("unroll") for (int i = 0; i < G; ++i) {                                        \
-      const double v = av[i][0] * bv[i][0] + av[i][1] * bv[i][1] + av[i][2] * bv[i][2] + av[i][3] * bv[i][3]; \
-      if (i0 + i < cnt) M[(1 + jb - m0 + i0 + i) * 64 + lane] = v;                         \
-    }                                                                                      \
-  }
-    int i0 = 0;
-    for (; cnt - i0 > 2; i0 += 4) PP_MGROUP(4)
-    if (i0 < cnt) PP_MGROUP(2)
-#undef PP_MGROUP
-  }
   double* Udst = g.U + ((size_t)g.piv_uoff[p] + (size_t)r0 * w) * bpad + b;
-  const bool diag = (r0 == 0);
-  const int ndiag = diag ? w * w : 0;
-  double pv[PP_WMAX * PP_WMAX];
-#pragma unroll
-  for (int q = 0; q < PP_WMAX * PP_WMAX; ++q) pv[q] = 0.0;
-  double tmax_diag = 0.0, colmax = 0.0;
+  double* Ldst = g.L + ((size_t)g.piv_uoff[p] + (size_t)r0 * w) * bpad + b;
+  GatherState<WM> st;
+  st.init(r0);
   double acc = 0.0, tmax = 0.0;
   int d = 0;
   const int E0 = dp_vec ? bcast(dpv, 0) : dp[0];
   const int E1 = dp_vec ? bcast(dpv, ndst) : dp[ndst];
   int dend = (ndst > 0) ? (dp_vec ? bcast(dpv, 1) : dp[1]) : 0x7fffffff;
-#define PP_FINALIZE()                                                     \
-  do {                                                                    \
-    Udst[(size_t)d * bpad] = acc;                                         \
-    if (d < ndiag) {                                                      \
-      _Pragma("unroll") for (int q = 0; q < PP_WMAX * PP_WMAX; ++q) if (q == d) pv[q] = acc; \
-      tmax_diag = fmax(tmax_diag, tmax);                                  \
-    } else {                                                              \
-      colmax = fmax(colmax, fabs(acc));                                   \
-    }                                                                     \
-    acc = 0.0; tmax = 0.0; ++d;                                           \
-    dend = (d < ndst) ? (dp_vec ? bcast(dpv, d + 1) : dp[d + 1]) : 0x7fffffff; \
+#define PP_FINALIZE()                                                                      \
+  do {                                                                                     \
+    finalize_dst(g, st, p, w, kind, d, acc, tmax, Udst, Ldst, bpad, b, eps);               \
+    acc = 0.0; tmax = 0.0; ++d;                                                            \
+    dend = (d < ndst) ? (dp_vec ? bcast(dpv, d + 1) : dp[d + 1]) : 0x7fffffff;             \
   } while (0)
   for (int eb = E0; eb < E1; eb += 64) {
     const int cnt = min(64, E1 - eb);
-    int2 rec = make_int2(0, 0);
+    int2 rec = make_int2(0, -1);
     if (lane < cnt) rec = *reinterpret_cast<const int2*>(g.fent + 2 * (size_t)(eb + lane));
 #define PP_GROUP(G)                                                                        \
   {                                                                                        \
-    int src[G], mi[G];                                                                     \
+    int eu[G], el[G];                                                                      \
     _Pragma("unroll") for (int i = 0; i < G; ++i) {                                        \
       const int q = min(i0 + i, cnt - 1);                                                  \
-      src[i] = bcast(rec.x, q); mi[i] = bcast(rec.y, q);                                   \
+      eu[i] = bcast(rec.x, q); el[i] = bcast(rec.y, q);                                    \
     }                                                                                      \
     double term[G];                                                                        \
     {                                                                                      \
-      double sv[G], mv[G];                                                                 \
+      double su[G], sl[G];                                                                 \
       _Pragma("unroll") for (int i = 0; i < G; ++i) {                                      \
-        const double* base = (src[i] >= 0) ? U : R;                                        \
-        const int idx = (src[i] >= 0) ? src[i] : (-1 - src[i]);                            \
-        sv[i] = base[(size_t)idx * bpad];                                                  \
-        mv[i] = M[mi[i] * 64 + lane];                                                      \
+        const double* base = (eu[i] >= 0) ? U : R;                                         \
+        const int idx = (eu[i] >= 0) ? eu[i] : (-1 - eu[i]);                               \
+        su[i] = base[(size_t)idx * bpad];                                                  \
+        sl[i] = (el[i] >= 0) ? Lb[(size_t)el[i] * bpad] : -1.0;                            \
       }                                                                                    \
-      _Pragma("unroll") for (int i = 0; i < G; ++i) term[i] = (i0 + i < cnt) ? sv[i] * mv[i] : 0.0; \
+      _Pragma("unroll") for (int i = 0; i < G; ++i) term[i] = (i0 + i < cnt) ? su[i] * sl[i] : 0.0; \
     }                                                                                      \
     _Pragma("unroll") for (int i = 0; i < G; ++i) {                                        \
       if (i0 + i < cnt) {                                                                  \
@@ -206,74 +236,97 @@ __global__ __launch_bounds__(64) void k_factor_level(GroupDev g, int task0, int 
   }
   while (d < ndst) PP_FINALIZE();
 #undef PP_FINALIZE
-  if (diag) {
-    double inv[PP_WMAX * (PP_WMAX + 1) / 2];
-    const int code = pp::invert_block(w, g.piv_sub[p], pv, fmax(colmax, tmax_diag), eps, inv);
-    double* invp = g.Dinv + (size_t)g.piv_doff[p] * bpad + b;
-#pragma unroll
-    for (int q = 0; q < PP_WMAX * (PP_WMAX + 1) / 2; ++q)
-      if (q < w * (w + 1) / 2) invp[(size_t)q * bpad] = inv[q];
-    g.codes[(size_t)p * bpad + b] = (b < g.batch) ? (unsigned short)code : (unsigned short)0;
-  }
 }
 
 // Lean variant for the wide bottom levels of the tree (a few entries per task, tens of thousands
-// of tasks): plain scalar-load record reads, minimal registers; the memory system is kept busy by
-// the sheer number of waves, not by intra-task batching.
-__global__ __launch_bounds__(64) void k_factor_level_lean(GroupDev g, int task0, int chunk0, double eps) {
-  extern __shared__ __attribute__((aligned(16))) double M[];
+// of tasks): plain scalar-load record reads, minimal code; the memory system is kept busy by the
+// sheer number of waves, not by intra-task batching.
+template <int WM>
+__global__ __launch_bounds__(64) void k_gather_level_lean(GroupDev g, int task0, int chunk0, double eps) {
   const int lane = threadIdx.x;
   const int b = (blockIdx.y + chunk0) * 64 + lane;
   const size_t bpad = (size_t)g.bpad;
-  const int* t = g.ftask + 6 * (size_t)(task0 + blockIdx.x);
-  const int p = t[0], r0 = t[1], r1 = t[2], m0 = t[3], m1 = t[4], dptr0 = t[5];
+  const int* t = g.ftask + 5 * (size_t)(task0 + blockIdx.x);
+  const int p = t[0], r0 = t[1], r1 = t[2], dptr0 = t[3], kind = t[4];
   const int w = g.piv_w[p];
   const double* __restrict__ U = g.U + b;
+  const double* __restrict__ Lb = g.L + b;
   const double* __restrict__ R = g.rawT + b;
-  const double* __restrict__ D = g.Dinv + b;
-  M[lane] = -1.0;
-  for (int j = m0; j < m1; ++j) {
-    const int* rec = g.mrec + 8 * (size_t)j;
-    double v = D[(size_t)rec[0] * bpad] * U[(size_t)rec[4] * bpad];
-#pragma unroll
-    for (int q = 1; q < 4; ++q)
-      if (rec[q] >= 0) v += D[(size_t)rec[q] * bpad] * U[(size_t)rec[4 + q] * bpad];
-    M[(1 + j - m0) * 64 + lane] = v;
-  }
   const int ndst = (r1 - r0) * w;
   const int* dp = g.fdst_ptr + dptr0;
   double* Udst = g.U + ((size_t)g.piv_uoff[p] + (size_t)r0 * w) * bpad + b;
-  const int ndiag = (r0 == 0) ? w * w : 0;
-  double pv[PP_WMAX * PP_WMAX];
-#pragma unroll
-  for (int q = 0; q < PP_WMAX * PP_WMAX; ++q) pv[q] = 0.0;
-  double tmax_diag = 0.0, colmax = 0.0;
+  double* Ldst = g.L + ((size_t)g.piv_uoff[p] + (size_t)r0 * w) * bpad + b;
+  GatherState<WM> st;
+  st.init(r0);
   for (int d = 0; d < ndst; ++d) {
     double acc = 0.0, tmax = 0.0;
     for (int e = dp[d]; e < dp[d + 1]; ++e) {
-      const int src = g.fent[2 * (size_t)e], mi = g.fent[2 * (size_t)e + 1];
-      const double sv = (src >= 0) ? U[(size_t)src * bpad] : R[(size_t)(-1 - src) * bpad];
-      const double term = sv * M[mi * 64 + lane];
+      const int eu = g.fent[2 * (size_t)e], el = g.fent[2 * (size_t)e + 1];
+      const double su = (eu >= 0) ? U[(size_t)eu * bpad] : R[(size_t)(-1 - eu) * bpad];
+      const double sl = (el >= 0) ? Lb[(size_t)el * bpad] : -1.0;
+      const double term = su * sl;
       acc -= term;
       tmax = fmax(tmax, fabs(term));
     }
-    Udst[(size_t)d * bpad] = acc;
-    if (d < ndiag) {
-#pragma unroll
-      for (int q = 0; q < PP_WMAX * PP_WMAX; ++q) if (q == d) pv[q] = acc;
-      tmax_diag = fmax(tmax_diag, tmax);
-    } else {
-      colmax = fmax(colmax, fabs(acc));
-    }
+    finalize_dst(g, st, p, w, kind, d, acc, tmax, Udst, Ldst, bpad, b, eps);
   }
-  if (r0 == 0) {
-    double inv[PP_WMAX * (PP_WMAX + 1) / 2];
-    const int code = pp::invert_block(w, g.piv_sub[p], pv, fmax(colmax, tmax_diag), eps, inv);
+}
+
+// Scale task of a big panel (plan.hpp, kind 2): invert the gathered pivot block (every chunk does it
+// redundantly in registers -- it is w*w loads and a few dozen flops), L rows = U rows * inv(P); the
+// chunk that starts right below the block also publishes inv(P) and the inertia code.
+__global__ __launch_bounds__(64) void k_scale_level(GroupDev g, int task0, int chunk0, double eps) {
+  const int lane = threadIdx.x;
+  const int b = (blockIdx.y + chunk0) * 64 + lane;
+  const size_t bpad = (size_t)g.bpad;
+  const int* t = g.stask + 5 * (size_t)(task0 + blockIdx.x);
+  const int p = t[0], r0 = t[1], r1 = t[2];
+  const int w = g.piv_w[p];
+  const double* Up = g.U + (size_t)g.piv_uoff[p] * bpad + b;
+  double* Lp = g.L + (size_t)g.piv_uoff[p] * bpad + b;
+  const double* Tmp = g.Tm + (size_t)g.piv_boff[p] * bpad + b;
+  double blk[PP_WMAX * PP_WMAX], inv[PP_WMAX * (PP_WMAX + 1) / 2];
+  double tmax_diag = 0.0;
+#pragma unroll
+  for (int i = 0; i < PP_WMAX; ++i)
+#pragma unroll
+    for (int j = 0; j < PP_WMAX; ++j) {
+      blk[i * PP_WMAX + j] = 0.0;
+      if (i < w && j < w) {
+        blk[i * PP_WMAX + j] = Up[(size_t)(i * w + j) * bpad];
+        tmax_diag = fmax(tmax_diag, Tmp[(size_t)(i * w + j) * bpad]);
+      }
+    }
+  const int code = pp::invert_block(w, g.piv_sub[p], blk, tmax_diag, eps, inv);
+  if (r0 == w) {
     double* invp = g.Dinv + (size_t)g.piv_doff[p] * bpad + b;
 #pragma unroll
-    for (int q = 0; q < PP_WMAX * (PP_WMAX + 1) / 2; ++q)
-      if (q < w * (w + 1) / 2) invp[(size_t)q * bpad] = inv[q];
+    for (int i = 0; i < PP_WMAX * (PP_WMAX + 1) / 2; ++i)
+      if (i < w * (w + 1) / 2) invp[(size_t)i * bpad] = inv[i];
     g.codes[(size_t)p * bpad + b] = (b < g.batch) ? (unsigned short)code : (unsigned short)0;
+  }
+  for (int r = r0; r < r1; r += 4) {
+    double u[4][PP_WMAX];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int t1 = 0; t1 < PP_WMAX; ++t1)
+        u[i][t1] = (r + i < r1 && t1 < w) ? Up[(size_t)((r + i) * w + t1) * bpad] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (r + i < r1) {
+#pragma unroll
+        for (int t2 = 0; t2 < PP_WMAX; ++t2) {
+          if (t2 < w) {
+            double v = 0.0;
+#pragma unroll
+            for (int t1 = 0; t1 < PP_WMAX; ++t1)
+              if (t1 < w) v += u[i][t1] * PP_INV(inv, t1, t2);
+            Lp[(size_t)((r + i) * w + t2) * bpad] = v;
+          }
+        }
+      }
+    }
   }
 }
 
@@ -305,42 +358,6 @@ __global__ __launch_bounds__(256) void k_count_codes(const unsigned short* __res
   if (threadIdx.x < 3 && red[threadIdx.x][0] != 0) atomicAdd(&counters[threadIdx.x], red[threadIdx.x][0]);
 }
 
-// scaled coupling rows Lc = U_c inv(P_p) of every block pivot that has coupling rows
-// (workgroup = one pivot x 64 instances; consumed by k_schur_tiles)
-__global__ __launch_bounds__(64) void k_lc_scale(GroupDev g) {
-  const int lane = threadIdx.x;
-  const int b = blockIdx.y * 64 + lane;
-  const size_t bpad = (size_t)g.bpad;
-  const int p = g.lc_piv[blockIdx.x];
-  const int w = g.piv_w[p];
-  const double* invp = g.Dinv + (size_t)g.piv_doff[p] * bpad + b;
-  double inv[PP_WMAX][PP_WMAX];
-#pragma unroll
-  for (int i = 0; i < PP_WMAX; ++i)
-#pragma unroll
-    for (int j = 0; j <= i; ++j) {
-      const double v = (i < w) ? invp[(size_t)(i * (i + 1) / 2 + j) * bpad] : 0.0;
-      inv[i][j] = v; inv[j][i] = v;
-    }
-  const double* Uc = g.U + ((size_t)g.piv_uoff[p] + (size_t)g.piv_cslot0[p] * w) * bpad + b;
-  double* Lc = g.Lc + (size_t)g.piv_lcoff[p] * bpad + b;
-  const int nrow = g.piv_ncrow[p];
-  for (int r = 0; r < nrow; ++r) {
-    double u[PP_WMAX];
-#pragma unroll
-    for (int t = 0; t < PP_WMAX; ++t) u[t] = (t < w) ? Uc[(size_t)(r * w + t) * bpad] : 0.0;
-#pragma unroll
-    for (int t2 = 0; t2 < PP_WMAX; ++t2) {
-      if (t2 < w) {
-        double v = 0.0;
-#pragma unroll
-        for (int t1 = 0; t1 < PP_WMAX; ++t1) v += u[t1] * inv[t1][t2];
-        Lc[(size_t)(r * w + t2) * bpad] = v;
-      }
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------
 // Schur tile: half of an 8x8 tile (8 rows x 4 columns, blockIdx.z selects the column half) in
 // registers over all panels holding rows of both tile ranges, then summed over the 64 instances of
@@ -361,14 +378,13 @@ __global__ __launch_bounds__(64) void k_schur_tiles(GroupDev g) {
     const int p = rec[0];
     const int w = g.piv_w[p];
     const double* Up = g.U + (size_t)g.piv_uoff[p] * bpad + b;
-    const double* Lp = g.Lc + (size_t)g.piv_lcoff[p] * bpad + b;
-    const int cs0 = g.piv_cslot0[p];
+    const double* Lp = g.L + (size_t)g.piv_uoff[p] * bpad + b;
     for (int t = 0; t < w; ++t) {
       double la[8], ub[4];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int sa = rec[1 + i];
-        la[i] = (sa >= 0) ? Lp[(size_t)((sa - cs0) * w + t) * bpad] : 0.0;
+        la[i] = (sa >= 0) ? Lp[(size_t)(sa * w + t) * bpad] : 0.0;
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -744,54 +760,25 @@ __device__ __forceinline__ double gather_row(const int* __restrict__ upos, const
   return s0 + s1;
 }
 
-// forward substitution of one block pivot: z_p = inv(P_p) (b_p - sum_k U[p,k] z_k)
-__device__ __forceinline__ void fwd_pivot(const GroupDev& g, int p, int lane, int b) {
+// forward substitution, one scalar row per workgroup: y_c = b_c - sum_k L[c, k] y_k
+// (rows of one block pivot are independent: the block is applied as a whole, by inv(P), in the backward sweep)
+__global__ __launch_bounds__(64) void k_fwd_level(GroupDev g, int col0, int chunk0) {
+  const int lane = threadIdx.x;
+  const int b = (blockIdx.y + chunk0) * 64 + lane;
   const size_t bpad = (size_t)g.bpad;
-  const int w = g.piv_w[p], p0 = g.piv_start[p];
-  const double* U = g.U + b;
-  const double* Z = g.W + b;
-  const double* inv = g.Dinv + (size_t)g.piv_doff[p] * bpad + b;
-  if (w == 1) {
-    const double y0 = g.rhsT[(size_t)g.perm[p0] * bpad + b] -
-                      gather_row(g.sfwd_upos, g.sfwd_zcol, g.sfwd_eptr[p0], g.sfwd_eptr[p0 + 1], U, Z, bpad, lane);
-    g.W[(size_t)p0 * bpad + b] = inv[0] * y0;
-    return;
-  }
-  double y[PP_WMAX];
-#pragma unroll
-  for (int q = 0; q < PP_WMAX; ++q) {
-    y[q] = 0.0;
-    if (q < w)
-      y[q] = g.rhsT[(size_t)g.perm[p0 + q] * bpad + b] -
-             gather_row(g.sfwd_upos, g.sfwd_zcol, g.sfwd_eptr[p0 + q], g.sfwd_eptr[p0 + q + 1], U, Z, bpad, lane);
-  }
-#pragma unroll
-  for (int q = 0; q < PP_WMAX; ++q) {
-    if (q < w) {
-      double z = 0.0;
-#pragma unroll
-      for (int t = 0; t < PP_WMAX; ++t) {
-        if (t < w) {
-          const int hi = q > t ? q : t, lo = q > t ? t : q;
-          z += inv[(size_t)(hi * (hi + 1) / 2 + lo) * bpad] * y[t];
-        }
-      }
-      g.W[(size_t)(p0 + q) * bpad + b] = z;
-    }
-  }
+  const int c = g.clevel_col[col0 + blockIdx.x];
+  const double y = g.rhsT[(size_t)g.perm[c] * bpad + b] -
+                   gather_row(g.sfwd_upos, g.sfwd_zcol, g.sfwd_eptr[c], g.sfwd_eptr[c + 1], g.L + b, g.Y + b, bpad, lane);
+  g.Y[(size_t)c * bpad + b] = y;
 }
 
-__global__ __launch_bounds__(64) void k_fwd_level(GroupDev g, int piv0, int chunk0) {
-  fwd_pivot(g, g.lvl_piv[piv0 + blockIdx.x], threadIdx.x, (blockIdx.y + chunk0) * 64 + threadIdx.x);
-}
-
-// coupling row c: rspart[chunk][c] = - sum over active instances and panels of U[c,k] z_k
+// coupling row c: rspart[chunk][c] = - sum over active instances and panels of L[c,k] y_k
 __global__ __launch_bounds__(64) void k_fwd_coupling(GroupDev g) {
   const int lane = threadIdx.x;
   const int b = blockIdx.y * 64 + lane;
   const size_t bpad = (size_t)g.bpad;
   const int c = blockIdx.x;
-  double s = -gather_row(g.crow_upos, g.crow_zcol, g.crow_eptr[c], g.crow_eptr[c + 1], g.U + b, g.W + b, bpad, lane);
+  double s = -gather_row(g.crow_upos, g.crow_zcol, g.crow_eptr[c], g.crow_eptr[c + 1], g.L + b, g.Y + b, bpad, lane);
   if (b >= g.batch) s = 0.0;
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
   if (lane == 0) g.rspart[(size_t)blockIdx.y * g.nc + c] = s;
@@ -805,25 +792,39 @@ __global__ __launch_bounds__(256) void k_rs_reduce(GroupDev g, double* __restric
   rs[c] += s;
 }
 
-// back substitution of one pivot: x_p = z_p - inv(P_p) sum_i U[i,p]^T x_i  (x_i = xc for coupling rows)
-__device__ __forceinline__ void bwd_pivot(const GroupDev& g, int p, int lane, int b, const double* __restrict__ xc) {
+// back substitution, one scalar column c = (block pivot p, component q) per workgroup:
+//   x_c = (inv(P_p) y_p)_q - sum_i L[i, c] x_i      (x_i = xc for coupling rows)
+__global__ __launch_bounds__(64) void k_bwd_level(GroupDev g, int col0, int chunk0, const double* __restrict__ xc) {
+  const int lane = threadIdx.x;
+  const int b = (blockIdx.y + chunk0) * 64 + lane;
   const size_t bpad = (size_t)g.bpad;
-  const int w = g.piv_w[p], p0 = g.piv_start[p];
+  const int c = g.clevel_col[col0 + blockIdx.x];
+  const int p = g.piv_of_col[c];
+  const int w = g.piv_w[p], p0 = g.piv_start[p], q = c - p0;
   const int nr = g.piv_rowptr[p + 1] - g.piv_rowptr[p];
   const int* ri = g.rowidx + g.piv_rowptr[p];
-  const double* Up = g.U + ((size_t)g.piv_uoff[p] + (size_t)w * w) * bpad + b;
-  const double* Wb = g.W + b;
+  const double* Lp = g.L + ((size_t)g.piv_uoff[p] + (size_t)w * w + q) * bpad + b;   // column q of the rows below the block
+  const double* Xb = g.X + b;
   const int n = g.n;
-  if (w == 1 && nr <= 4) {   // wide bottom levels: short panels, plain scalar index reads
-    double g0 = 0.0;
+  const size_t rstride = (size_t)w * bpad;
+  // z = row q of inv(P) times y_p
+  const double* inv = g.Dinv + (size_t)g.piv_doff[p] * bpad + b;
+  const double* Yp = g.Y + (size_t)p0 * bpad + b;
+  double z = 0.0;
+#pragma unroll
+  for (int t = 0; t < PP_WMAX; ++t) {
+    if (t < w) {
+      const int hi = q > t ? q : t, lo = q > t ? t : q;
+      z += inv[(size_t)(hi * (hi + 1) / 2 + lo) * bpad] * Yp[(size_t)t * bpad];
+    }
+  }
+  double g0 = 0.0, g1 = 0.0;
+  if (nr <= 4) {   // wide bottom levels: short panels, plain scalar index reads
     for (int j = 0; j < nr; ++j) {
       const int r = ri[j];
-      g0 += Up[(size_t)j * bpad] * ((r < n) ? Wb[(size_t)r * bpad] : xc[r - n]);
+      g0 += Lp[(size_t)j * rstride] * ((r < n) ? Xb[(size_t)r * bpad] : xc[r - n]);
     }
-    const double inv = g.Dinv[(size_t)g.piv_doff[p] * bpad + b];
-    g.W[(size_t)p0 * bpad + b] -= inv * g0;
-  } else if (w == 1) {
-    double g0 = 0.0, g1 = 0.0;
+  } else {
     for (int jb = 0; jb < nr; jb += 64) {
       const int cnt = min(64, nr - jb);
       const int rv = (lane < cnt) ? ri[jb + lane] : 0;
@@ -833,9 +834,9 @@ __device__ __forceinline__ void bwd_pivot(const GroupDev& g, int p, int lane, in
     _Pragma("unroll") for (int i = 0; i < G; ++i) rr[i] = bcast(rv, min(i0 + i, cnt - 1)); \
     double u[G], x[G];                                                                     \
     _Pragma("unroll") for (int i = 0; i < G; ++i) {                                        \
-      const int q = min(i0 + i, cnt - 1);                                                  \
-      u[i] = Up[(size_t)(jb + q) * bpad];                                                  \
-      x[i] = (rr[i] < n) ? Wb[(size_t)rr[i] * bpad] : xc[rr[i] - n];                       \
+      const int qq = min(i0 + i, cnt - 1);                                                 \
+      u[i] = Lp[(size_t)(jb + qq) * rstride];                                              \
+      x[i] = (rr[i] < n) ? Xb[(size_t)rr[i] * bpad] : xc[rr[i] - n];                       \
     }                                                                                      \
     _Pragma("unroll") for (int i = 0; i < G; i += 2) {                                     \
       g0 += (i0 + i < cnt) ? u[i] * x[i] : 0.0;                                            \
@@ -847,55 +848,8 @@ __device__ __forceinline__ void bwd_pivot(const GroupDev& g, int p, int lane, in
       if (i0 < cnt) PP_BGROUP(4)
 #undef PP_BGROUP
     }
-    const double inv = g.Dinv[(size_t)g.piv_doff[p] * bpad + b];
-    g.W[(size_t)p0 * bpad + b] -= inv * (g0 + g1);
-  } else {
-    double gq[PP_WMAX];
-#pragma unroll
-    for (int q = 0; q < PP_WMAX; ++q) gq[q] = 0.0;
-    for (int jb = 0; jb < nr; jb += 64) {
-      const int cnt = min(64, nr - jb);
-      const int rv = (lane < cnt) ? ri[jb + lane] : 0;
-      for (int i0 = 0; i0 < cnt; i0 += 4) {
-        int rr[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rr[i] = bcast(rv, min(i0 + i, cnt - 1));
-        double u[4][PP_WMAX], x[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int q0 = min(i0 + i, cnt - 1);
-#pragma unroll
-          for (int q = 0; q < PP_WMAX; ++q) u[i][q] = (q < w) ? Up[(size_t)((jb + q0) * w + q) * bpad] : 0.0;
-          x[i] = (rr[i] < n) ? Wb[(size_t)rr[i] * bpad] : xc[rr[i] - n];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (i0 + i < cnt) {
-#pragma unroll
-            for (int q = 0; q < PP_WMAX; ++q) gq[q] += u[i][q] * x[i];
-          }
-      }
-    }
-    const double* inv = g.Dinv + (size_t)g.piv_doff[p] * bpad + b;
-#pragma unroll
-    for (int q = 0; q < PP_WMAX; ++q) {
-      if (q < w) {
-        double z = 0.0;
-#pragma unroll
-        for (int t = 0; t < PP_WMAX; ++t) {
-          if (t < w) {
-            const int hi = q > t ? q : t, lo = q > t ? t : q;
-            z += inv[(size_t)(hi * (hi + 1) / 2 + lo) * bpad] * gq[t];
-          }
-        }
-        g.W[(size_t)(p0 + q) * bpad + b] -= z;
-      }
-    }
   }
-}
-
-__global__ __launch_bounds__(64) void k_bwd_level(GroupDev g, int piv0, int chunk0, const double* __restrict__ xc) {
-  bwd_pivot(g, g.lvl_piv[piv0 + blockIdx.x], threadIdx.x, (blockIdx.y + chunk0) * 64 + threadIdx.x, xc);
+  g.X[(size_t)c * bpad + b] = z - (g0 + g1);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -907,7 +861,7 @@ struct Group {
   std::vector<void*> allocs;
   int ntiles = 0;
   double *raw_own = nullptr, *rhs_own = nullptr;
-  std::vector<size_t> lds_level;
+  std::vector<int> level_maxw;   // widest block pivot per level (selects the scalar kernel variants)
 };
 
 }  // namespace
@@ -929,6 +883,7 @@ struct pp_solver {
   // independent and can be issued on separate streams.  Measured (C3, 1 GPU, 4 splits): the 4x
   // launches serialise instead of overlapping (254 vs 379 it/s), so the default is one split.
   int nsplit_req = 0;   // 0 = default (1)
+  int sn_wmax = 0, sn_tol = -1;   // supernode options for groups added afterwards (0 / -1: plan defaults)
   hipStream_t aux[PP_MAX_SPLIT] = {};
   hipEvent_t ev_fork = nullptr, ev_join[PP_MAX_SPLIT] = {};
   bool aux_made = false;
@@ -1128,6 +1083,8 @@ int pp_add_group(pp_handle h, int n, int batch, int nnzK, const int32_t* rowK, c
   if (batch <= 0 || n <= 0 || nraw < 0) return fail(h, 3, "bad group dimensions");
   Group* g = new Group();
   pp::PlanOptions opt;
+  if (h->sn_wmax > 0) opt.sn_wmax = h->sn_wmax;
+  if (h->sn_tol >= 0) opt.sn_tol_rows = h->sn_tol;
   int rc = pp::build_plan(n, h->nc, nnzK, rowK, colK, nnzB, rowB, colB, rep_vals, opt, g->plan);
   if (rc != 0) { std::string e = g->plan.error; delete g; return fail(h, rc, "symbolic analysis failed: " + e); }
   const int ncan = nnzK + nnzB;
@@ -1145,8 +1102,6 @@ int pp_add_group(pp_handle h, int n, int batch, int nnzK, const int32_t* rowK, c
 int pp_end_symbolic(pp_handle h) {
   if (!h) return 3;
   PP_HIP(hipSetDevice(h->device));
-  // factor tasks may need a multiplier table larger than the default 64 KiB dynamic-LDS limit
-  (void)hipFuncSetAttribute((const void*)k_factor_level, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const int nc = h->nc;
   for (Group* g : h->groups) {
     const pp::Plan& P = g->plan;
@@ -1156,16 +1111,14 @@ int pp_end_symbolic(pp_handle h) {
     d.nchunk = d.bpad / WAVE; d.npiv = P.npiv; d.nraw = g->nraw; d.usize = P.usize;
     int rc;
     std::vector<int> uoff(P.piv_uoff.begin(), P.piv_uoff.end());
-    std::vector<int> ftask, mrec, fdst_ptr, fent, srec;
-    for (auto& m : P.mrecs) {
-      for (int q = 0; q < PP_WMAX; ++q) mrec.push_back(m.d[q]);
-      for (int q = 0; q < PP_WMAX; ++q) mrec.push_back(m.u[q]);
-    }
-    for (int q = 0; q < 16; ++q) mrec.push_back(-1);
+    g->level_maxw.assign(P.n_levels, 1);
+    for (int pp_ = 0; pp_ < P.npiv; ++pp_)
+      g->level_maxw[P.piv_level[pp_]] = std::max(g->level_maxw[P.piv_level[pp_]], P.piv_w[pp_]);
+    std::vector<int> ftask, stask, fdst_ptr, fent, srec;
     // expand the canonical initial-value entries into raw-value entries (duplicates are summed)
     fdst_ptr.reserve(P.fdst_ptr.size());
     fent.reserve(P.fentries.size() * 2 + 16);
-    ftask.reserve(P.ftasks.size() * 6);
+    ftask.reserve(P.ftasks.size() * 5);
     for (auto& t : P.ftasks) {
       const int ndst = (t.r1 - t.r0) * P.piv_w[t.piv];
       const int new_dptr0 = (int)fdst_ptr.size();
@@ -1173,51 +1126,42 @@ int pp_end_symbolic(pp_handle h) {
         fdst_ptr.push_back((int)(fent.size() / 2));
         for (int e = P.fdst_ptr[t.dptr0 + dd]; e < P.fdst_ptr[t.dptr0 + dd + 1]; ++e) {
           const pp::FEntry& fe = P.fentries[e];
-          if (fe.src >= 0) { fent.push_back(fe.src); fent.push_back(fe.midx); }
+          if (fe.u >= 0) { fent.push_back(fe.u); fent.push_back(fe.l); }
           else {
-            const int ce = -1 - fe.src;
-            for (int q = g->can_ptr[ce]; q < g->can_ptr[ce + 1]; ++q) { fent.push_back(-1 - g->can_idx[q]); fent.push_back(fe.midx); }
+            const int ce = -1 - fe.u;
+            for (int q = g->can_ptr[ce]; q < g->can_ptr[ce + 1]; ++q) { fent.push_back(-1 - g->can_idx[q]); fent.push_back(fe.l); }
           }
         }
       }
       fdst_ptr.push_back((int)(fent.size() / 2));
-      ftask.insert(ftask.end(), {t.piv, t.r0, t.r1, t.m0, t.m1, new_dptr0});
+      ftask.insert(ftask.end(), {t.piv, t.r0, t.r1, new_dptr0, t.kind});
     }
-    for (int q = 0; q < 16; ++q) fent.push_back(0);   // slack for the unrolled record reads
+    for (auto& t : P.stasks) stask.insert(stask.end(), {t.piv, t.r0, t.r1, -1, t.kind});
+    for (int q = 0; q < 16; ++q) { fent.push_back(0); fent.push_back(-1); }   // slack for the vector record reads
     for (auto& r : P.stile_rec) {
       srec.push_back(r.piv);
       for (int q = 0; q < 8; ++q) srec.push_back(r.slotA[q]);
       for (int q = 0; q < 8; ++q) srec.push_back(r.slotB[q]);
-    }
-    g->lds_level.assign(P.n_levels, 0);
-    for (int l = 0; l < P.n_levels; ++l) {
-      g->lds_level[l] = (size_t)(1 + P.flevel_maxm[l]) * 64 * sizeof(double);
-      if (g->lds_level[l] > 160 * 1024) return fail(h, 1, "a factor task needs more than 160 KiB of LDS multipliers");
     }
     if ((rc = dev_upload(h, g, &d.piv_w, P.piv_w))) return rc;
     if ((rc = dev_upload(h, g, &d.piv_start, P.piv_start))) return rc;
     if ((rc = dev_upload(h, g, &d.piv_uoff, uoff))) return rc;
     if ((rc = dev_upload(h, g, &d.piv_doff, P.piv_doff))) return rc;
     {
-      std::vector<int> sub(P.piv_sub.begin(), P.piv_sub.end()), lcp;
-      for (int p = 0; p < P.npiv; ++p) if (P.piv_lcoff[p] >= 0) lcp.push_back(p);
-      d.n_lc_piv = (int)lcp.size();
+      std::vector<int> sub(P.piv_sub.begin(), P.piv_sub.end());
       if ((rc = dev_upload(h, g, &d.piv_sub, sub))) return rc;
-      if ((rc = dev_upload(h, g, &d.piv_cslot0, P.piv_cslot0))) return rc;
-      if ((rc = dev_upload(h, g, &d.piv_ncrow, P.piv_ncrow))) return rc;
-      if ((rc = dev_upload(h, g, &d.piv_lcoff, P.piv_lcoff))) return rc;
-      if ((rc = dev_upload(h, g, &d.lc_piv, lcp))) return rc;
+      if ((rc = dev_upload(h, g, &d.piv_boff, P.piv_boff))) return rc;
+      if ((rc = dev_upload(h, g, &d.piv_of_col, P.piv_of_col))) return rc;
     }
     if ((rc = dev_upload(h, g, &d.piv_rowptr, P.piv_rowptr))) return rc;
     if ((rc = dev_upload(h, g, &d.rowidx, P.rowidx))) return rc;
     if ((rc = dev_upload(h, g, &d.perm, P.perm))) return rc;
     if ((rc = dev_upload(h, g, &d.iperm, P.iperm))) return rc;
     if ((rc = dev_upload(h, g, &d.ftask, ftask))) return rc;
-    if ((rc = dev_upload(h, g, &d.mrec, mrec))) return rc;
+    if ((rc = dev_upload(h, g, &d.stask, stask))) return rc;
     if ((rc = dev_upload(h, g, &d.fdst_ptr, fdst_ptr))) return rc;
     if ((rc = dev_upload(h, g, &d.fent, fent))) return rc;
-    if ((rc = dev_upload(h, g, &d.lvl_piv, P.lvl_piv))) return rc;
-    if ((rc = dev_upload(h, g, &d.lvl_ptr, P.lvl_ptr))) return rc;
+    if ((rc = dev_upload(h, g, &d.clevel_col, P.clevel_col))) return rc;
     {
       std::vector<int> up(P.sfwd_upos), zc(P.sfwd_zcol), cu(P.crow_upos), cz(P.crow_zcol);
       for (int q = 0; q < 16; ++q) { up.push_back(0); zc.push_back(0); cu.push_back(0); cz.push_back(0); }
@@ -1239,8 +1183,10 @@ int pp_end_symbolic(pp_handle h) {
     if ((rc = dev_alloc(h, g, &d.rawT, (size_t)g->nraw * bp))) return rc;
     if ((rc = dev_alloc(h, g, &d.U, (size_t)P.usize * bp))) return rc;
     if ((rc = dev_alloc(h, g, &d.Dinv, (size_t)P.dsize * bp))) return rc;
-    if ((rc = dev_alloc(h, g, &d.Lc, (size_t)P.lcsize * bp))) return rc;
-    if ((rc = dev_alloc(h, g, &d.W, (size_t)(P.n + nc) * bp))) return rc;
+    if ((rc = dev_alloc(h, g, &d.L, (size_t)P.usize * bp))) return rc;
+    if ((rc = dev_alloc(h, g, &d.Tm, (size_t)std::max(P.bsize, 1) * bp))) return rc;
+    if ((rc = dev_alloc(h, g, &d.Y, (size_t)(P.n + nc) * bp))) return rc;
+    if ((rc = dev_alloc(h, g, &d.X, (size_t)P.n * bp))) return rc;
     if ((rc = dev_alloc(h, g, &d.rhs, (size_t)g->batch * P.n))) return rc;
     g->rhs_own = d.rhs;
     if ((rc = dev_alloc(h, g, &d.rhsT, (size_t)P.n * bp))) return rc;
@@ -1317,35 +1263,31 @@ int pp_numeric_local(pp_handle h) {
       if (fork_streams(h, sp, fan)) return fail(h, 3, "stream fork failed");
       for (int l = 0; l < P.n_levels; ++l) {
         const int t0 = P.flevel_ptr[l], nt = P.flevel_ptr[l + 1] - t0;
-        if (nt <= 0) continue;
-        // tasks whose multiplier table exceeds the cap are sorted last and launched apart, so the
-        // bulk of the level keeps a small LDS footprint (occupancy)
-        const int nbig = P.flevel_nbig[l], nsmall = nt - nbig;
-        const size_t lds_small = (size_t)(1 + std::min(P.flevel_maxm[l], P.opt.max_task_mults)) * 64 * sizeof(double);
+        const int s0 = P.slevel_ptr[l], ns = P.slevel_ptr[l + 1] - s0;
         for (int q = 0; q < sp.n; ++q) {
-          const dim3 gy(1, sp.c0[q + 1] - sp.c0[q]);
-          if (nsmall > 0) {
-            if (P.flevel_maxent[l] <= 8 && nbig == 0)
-              hipLaunchKernelGGL(k_factor_level_lean, dim3(nsmall, gy.y), dim3(64), lds_small, fan[q], d, t0, sp.c0[q],
-                                 PIVOT_EPS);
+          const int ny = sp.c0[q + 1] - sp.c0[q];
+          if (nt > 0) {
+            const bool lean = P.flevel_maxent[l] <= 12, scalar = g->level_maxw[l] == 1;
+            if (lean && scalar)
+              hipLaunchKernelGGL(k_gather_level_lean<1>, dim3(nt, ny), dim3(64), 0, fan[q], d, t0, sp.c0[q], PIVOT_EPS);
+            else if (lean)
+              hipLaunchKernelGGL(k_gather_level_lean<PP_WMAX>, dim3(nt, ny), dim3(64), 0, fan[q], d, t0, sp.c0[q], PIVOT_EPS);
+            else if (scalar)
+              hipLaunchKernelGGL(k_gather_level<1>, dim3(nt, ny), dim3(64), 0, fan[q], d, t0, sp.c0[q], PIVOT_EPS);
             else
-              hipLaunchKernelGGL(k_factor_level, dim3(nsmall, gy.y), dim3(64), lds_small, fan[q], d, t0, sp.c0[q],
-                                 PIVOT_EPS);
+              hipLaunchKernelGGL(k_gather_level<PP_WMAX>, dim3(nt, ny), dim3(64), 0, fan[q], d, t0, sp.c0[q], PIVOT_EPS);
           }
-          if (nbig > 0)
-            hipLaunchKernelGGL(k_factor_level, dim3(nbig, gy.y), dim3(64), g->lds_level[l], fan[q], d, t0 + nsmall,
-                               sp.c0[q], PIVOT_EPS);
+          if (ns > 0) hipLaunchKernelGGL(k_scale_level, dim3(ns, ny), dim3(64), 0, fan[q], d, s0, sp.c0[q], PIVOT_EPS);
         }
       }
       if (join_streams(h, sp, fan)) return fail(h, 3, "stream join failed");
     }
     {
-      PhaseScope ps(h, 2, 4);
+      PhaseScope ps(h, 2, 3);
       const size_t total8 = (size_t)P.npiv * d.bpad / 8;   // bpad is a multiple of 64
       hipLaunchKernelGGL(k_count_codes, dim3((unsigned)std::min<size_t>(512, (total8 + 255) / 256)), dim3(256), 0, st,
                          d.codes, total8, h->counters);
       if (g->ntiles > 0) {
-        if (d.n_lc_piv > 0) hipLaunchKernelGGL(k_lc_scale, dim3(d.n_lc_piv, d.nchunk), dim3(64), 0, st, d);
         hipLaunchKernelGGL(k_schur_tiles, dim3(g->ntiles, d.nchunk, 2), dim3(64), 0, st, d);
         hipLaunchKernelGGL(k_schur_reduce, dim3(g->ntiles), dim3(64), 0, st, d, g->ntiles, h->S);
       }
@@ -1450,10 +1392,10 @@ int pp_solve_forward(pp_handle h) {
       hipStream_t fan[PP_MAX_SPLIT];
       if (fork_streams(h, sp, fan)) return fail(h, 3, "stream fork failed");
       for (int l = 0; l < P.n_levels; ++l) {
-        const int p0 = P.lvl_ptr[l], np = P.lvl_ptr[l + 1] - p0;
-        if (np <= 0) continue;
+        const int c0 = P.clevel_ptr[l], ncol = P.clevel_ptr[l + 1] - c0;
+        if (ncol <= 0) continue;
         for (int q = 0; q < sp.n; ++q)
-          hipLaunchKernelGGL(k_fwd_level, dim3(np, sp.c0[q + 1] - sp.c0[q]), dim3(64), 0, fan[q], d, p0, sp.c0[q]);
+          hipLaunchKernelGGL(k_fwd_level, dim3(ncol, sp.c0[q + 1] - sp.c0[q]), dim3(64), 0, fan[q], d, c0, sp.c0[q]);
       }
       if (join_streams(h, sp, fan)) return fail(h, 3, "stream join failed");
     }
@@ -1502,14 +1444,14 @@ int pp_solve_backward(pp_handle h) {
       hipStream_t fan[PP_MAX_SPLIT];
       if (fork_streams(h, sp, fan)) return fail(h, 3, "stream fork failed");
       for (int l = P.n_levels - 1; l >= 0; --l) {
-        const int p0 = P.lvl_ptr[l], np = P.lvl_ptr[l + 1] - p0;
-        if (np <= 0) continue;
+        const int c0 = P.clevel_ptr[l], ncol = P.clevel_ptr[l + 1] - c0;
+        if (ncol <= 0) continue;
         for (int q = 0; q < sp.n; ++q)
-          hipLaunchKernelGGL(k_bwd_level, dim3(np, sp.c0[q + 1] - sp.c0[q]), dim3(64), 0, fan[q], d, p0, sp.c0[q], h->xc);
+          hipLaunchKernelGGL(k_bwd_level, dim3(ncol, sp.c0[q + 1] - sp.c0[q]), dim3(64), 0, fan[q], d, c0, sp.c0[q], h->xc);
       }
       if (join_streams(h, sp, fan)) return fail(h, 3, "stream join failed");
     }
-    hipLaunchKernelGGL(k_transpose_out, dim3((P.n + 63) / 64, d.nchunk), dim3(256), 0, st, d.W, d.iperm, d.xout,
+    hipLaunchKernelGGL(k_transpose_out, dim3((P.n + 63) / 64, d.nchunk), dim3(256), 0, st, d.X, d.iperm, d.xout,
                        d.batch, P.n, d.bpad);
   }
   PP_HIP(hipGetLastError());
@@ -1551,6 +1493,14 @@ int pp_bind_rhs_buffer(pp_handle h, int group, double* dev_ptr) {
   Group* g = get_group(h, group);
   if (!g || !h->symbolic_done) return fail(h, 3, "pp_bind_rhs_buffer: bad group");
   g->dev.rhs = dev_ptr ? dev_ptr : g->rhs_own;
+  return 0;
+}
+
+int pp_set_supernodes(pp_handle h, int wmax, int tol_rows) {
+  if (!h) return 3;
+  if (wmax < 0 || wmax > PP_WMAX) return fail(h, 3, "supernode width must be 0 (default) .. PP_WMAX");
+  h->sn_wmax = wmax;
+  h->sn_tol = tol_rows;
   return 0;
 }
 

@@ -371,17 +371,17 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
     P.usize += (int64_t)(P.piv_w[p] + (int64_t)rows[p].size()) * P.piv_w[p];
     P.nnz_L += (int64_t)rows[p].size() * P.piv_w[p];
   }
-  // scaled coupling rows L_c = U_c inv(P) (consumed by the Schur tiles): one slab per supernode
   P.piv_cslot0.assign(P.npiv, 0);
   P.piv_ncrow.assign(P.npiv, 0);
-  P.piv_lcoff.assign(P.npiv, -1);
+  P.piv_boff.assign(P.npiv, 0);
   for (int p = 0; p < P.npiv; ++p) {
     const auto& r = rows[p];
     size_t first = r.size();
     while (first > 0 && r[first - 1] >= n) --first;
     P.piv_cslot0[p] = P.piv_w[p] + (int)first;
     P.piv_ncrow[p] = (int)(r.size() - first);
-    if (P.piv_ncrow[p] > 0) { P.piv_lcoff[p] = (int)P.lcsize; P.lcsize += (int64_t)P.piv_ncrow[p] * P.piv_w[p]; }
+    P.piv_boff[p] = P.bsize;
+    P.bsize += P.piv_w[p] * P.piv_w[p];
   }
   P.rowidx.reserve(P.piv_rowptr[P.npiv]);
   for (int p = 0; p < P.npiv; ++p) P.rowidx.insert(P.rowidx.end(), rows[p].begin(), rows[p].end());
@@ -450,27 +450,30 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
   }
   if (P.n_levels - P.tail_level0 < 3) P.tail_level0 = P.n_levels;
 
-  // inverse-pivot scalar (t, t') of pivot k in Dinv storage
-  auto dinv_pos = [&](int k, int t, int t2) -> int {   // packed lower triangle by rows
-    const int hi = std::max(t, t2), lo = std::min(t, t2);
-    return P.piv_doff[k] + hi * (hi + 1) / 2 + lo;
-  };
-
-  // ---- 6. factor tasks in flat scalar form (left-looking gathers, rows chunked by entry count)
+  // ---- 6. factor tasks in L form (see plan.hpp): pure (U, L) gathers, fused small panels,
+  // gather + scale chunks for big panels
   {
-    // canonical entries by U position (assembly is fused into the factor tasks)
     std::vector<std::pair<int64_t, int>> can_by_pos(P.ncan);
     for (int e = 0; e < P.ncan; ++e) can_by_pos[e] = {P.pos_of_can[e], e};
     std::sort(can_by_pos.begin(), can_by_pos.end());
     size_t can_cursor = 0;  // panels are visited in increasing U position
-    struct TmpTask { FTask t; int level; int nm; };
-    std::vector<TmpTask> tasks;
-    struct SlotEnt { int src; int k; int t; int q; };  // contribution U_k[src row, t] * M_k[t][q] to column q
-    std::vector<std::vector<SlotEnt>> slot_ents;       // per slot of panel p
+    struct TmpTask { FTask t; int level; };
+    std::vector<TmpTask> gtasks, sctasks;
+    std::vector<std::vector<FEntry>> dst_ents;   // per destination scalar (slot * w + q) of panel p
     for (int p = 0; p < P.npiv; ++p) {
       const int w = P.piv_w[p], p0 = P.piv_start[p];
       const int f = w + (int)rows[p].size();
-      slot_ents.assign(f, {});
+      dst_ents.assign((size_t)f * w, {});
+      // initial values: canonical entries located in this panel
+      const int64_t u0 = P.piv_uoff[p], u1 = u0 + (int64_t)f * w;
+      int64_t total = 0;
+      while (can_cursor < can_by_pos.size() && can_by_pos[can_cursor].first < u1) {
+        if (can_by_pos[can_cursor].first >= u0) {
+          dst_ents[(size_t)(can_by_pos[can_cursor].first - u0)].push_back({-1 - can_by_pos[can_cursor].second, -1});
+          ++total;
+        }
+        ++can_cursor;
+      }
       for (auto& km : rowpat[p]) {
         const int k = km.first, mslot = km.second, wk = P.piv_w[k];
         const auto& rk = rows[k];
@@ -485,103 +488,75 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
             d = w + (int)tp;
           }
           const int srow = wk + (int)t;
-          for (int tt = 0; tt < wk; ++tt)
-            for (int q = 0; q < w; ++q)
-              slot_ents[d].push_back({(int)(P.piv_uoff[k] + (int64_t)srow * wk + tt), k, tt, q});
+          for (int q = 0; q < w; ++q)
+            for (int tt = 0; tt < wk; ++tt)
+              dst_ents[(size_t)d * w + q].push_back({(int)(P.piv_uoff[k] + (int64_t)srow * wk + tt),
+                                                     (int)(P.piv_uoff[k] + (int64_t)(mslot + q) * wk + tt)});
           P.flops_factor += (int64_t)wk * w;
+          total += (int64_t)wk * w;
         }
       }
-      // initial values: canonical entries located in this panel
-      std::vector<std::vector<int>> init_of_scalar((size_t)f * w);
-      const int64_t u0 = P.piv_uoff[p], u1 = u0 + (int64_t)f * w;
-      while (can_cursor < can_by_pos.size() && can_by_pos[can_cursor].first < u1) {
-        if (can_by_pos[can_cursor].first >= u0)
-          init_of_scalar[(size_t)(can_by_pos[can_cursor].first - u0)].push_back(can_by_pos[can_cursor].second);
-        ++can_cursor;
-      }
-      // chunk the slots; the pivot block (slots 0..w-1) always opens the first chunk
       const bool in_tail = P.piv_level[p] >= P.tail_level0;
       const int cap_e = in_tail ? opt.tail_task_entries : opt.max_task_entries;
-      const int cap_m = in_tail ? opt.tail_task_mults : opt.max_task_mults;
-      int r = 0;
-      while (r < f) {
+      auto emit = [&](int r0, int r1, int kind) {
         TmpTask tt;
         tt.level = P.piv_level[p];
-        tt.t.piv = p; tt.t.r0 = r; tt.t.m0 = (int)P.mrecs.size(); tt.t.dptr0 = (int)P.fdst_ptr.size();
-        std::map<std::tuple<int, int, int>, int> mloc;  // (k, t, q) -> local multiplier index
-        int nent = 0;
-        int r_end = r;
-        while (r_end < f) {
-          // cost of adding slot r_end
-          int add_e = (int)slot_ents[r_end].size();
-          for (int q = 0; q < w; ++q) add_e += (int)init_of_scalar[(size_t)r_end * w + q].size();
-          int add_m = 0;
-          for (auto& se : slot_ents[r_end]) if (!mloc.count(std::make_tuple(se.k, se.t, se.q))) ++add_m;  // upper bound
-          const bool must = (r_end == r) || (r == 0 && r_end < w);
-          if (!must && (nent + add_e > cap_e || (int)mloc.size() + add_m > cap_m)) break;
-          for (auto& se : slot_ents[r_end]) {
-            auto key = std::make_tuple(se.k, se.t, se.q);
-            if (!mloc.count(key)) { int id = (int)mloc.size(); mloc[key] = id; }
-          }
-          nent += add_e;
-          ++r_end;
-        }
-        // multiplier records in local-index order
-        std::vector<MRec> mr(mloc.size());
-        for (auto& kv : mloc) {
-          const int k = std::get<0>(kv.first), t = std::get<1>(kv.first), q = std::get<2>(kv.first);
-          const int wk = P.piv_w[k];
-          // slot of row (p0 + q) inside panel k
-          int ms = -1;
-          for (auto& km : rowpat[p]) if (km.first == k) { ms = km.second; break; }
-          MRec m;
-          for (int t2 = 0; t2 < PP_WMAX; ++t2) {
-            if (t2 < wk) { m.d[t2] = dinv_pos(k, t, t2); m.u[t2] = (int)(P.piv_uoff[k] + (int64_t)(ms + q) * wk + t2); }
-            else { m.d[t2] = -1; m.u[t2] = -1; }
-          }
-          mr[kv.second] = m;
-        }
-        P.mrecs.insert(P.mrecs.end(), mr.begin(), mr.end());
-        tt.t.m1 = (int)P.mrecs.size();
-        tt.nm = (int)mr.size();
-        // entries per destination scalar: initial values first (midx 0 = -1), then updates
-        for (int rr = r; rr < r_end; ++rr)
+        tt.t.piv = p; tt.t.r0 = r0; tt.t.r1 = r1; tt.t.kind = kind; tt.t.dptr0 = (int)P.fdst_ptr.size();
+        for (int rr = r0; rr < r1; ++rr)
           for (int q = 0; q < w; ++q) {
             P.fdst_ptr.push_back((int)P.fentries.size());
-            for (int e : init_of_scalar[(size_t)rr * w + q]) P.fentries.push_back({-1 - e, 0});
-            for (auto& se : slot_ents[rr])
-              if (se.q == q) P.fentries.push_back({se.src, 1 + mloc[std::make_tuple(se.k, se.t, se.q)]});
+            const auto& de = dst_ents[(size_t)rr * w + q];
+            P.fentries.insert(P.fentries.end(), de.begin(), de.end());
           }
         P.fdst_ptr.push_back((int)P.fentries.size());
-        tt.t.r1 = r_end;
-        tasks.push_back(tt);
-        r = r_end;
+        gtasks.push_back(tt);
+      };
+      if (total <= opt.max_task_entries) {
+        emit(0, f, 1);                                   // fused small panel
+      } else {
+        int r = 0;
+        while (r < f) {                                  // gather chunks over all slots
+          int nent = 0, r_end = r;
+          while (r_end < f) {
+            int add = 0;
+            for (int q = 0; q < w; ++q) add += (int)dst_ents[(size_t)r_end * w + q].size();
+            if (r_end > r && nent + add > cap_e) break;
+            nent += add;
+            ++r_end;
+          }
+          emit(r, r_end, 0);
+          r = r_end;
+        }
+        const int R = std::max(1, opt.scale_task_rows / w);
+        for (int r0 = w; r0 < f || r0 == w; r0 += R) {   // scale chunks over the rows below the block
+          TmpTask tt;
+          tt.level = P.piv_level[p];
+          tt.t.piv = p; tt.t.r0 = r0; tt.t.r1 = std::min(f, r0 + R); tt.t.kind = 2; tt.t.dptr0 = -1;
+          sctasks.push_back(tt);
+          if (r0 + R >= f) break;
+        }
       }
     }
-    std::stable_sort(tasks.begin(), tasks.end(), [&](const TmpTask& a, const TmpTask& b) {
-      if (a.level != b.level) return a.level < b.level;
-      const bool ba = a.nm > opt.max_task_mults, bb = b.nm > opt.max_task_mults;
-      return ba < bb;   // tasks whose multiplier table exceeds the cap go last (launched apart)
-    });
+    auto by_level = [](const TmpTask& a, const TmpTask& b) { return a.level < b.level; };
+    std::stable_sort(gtasks.begin(), gtasks.end(), by_level);
+    std::stable_sort(sctasks.begin(), sctasks.end(), by_level);
     P.flevel_ptr.assign(P.n_levels + 1, 0);
-    P.flevel_maxm.assign(P.n_levels, 0);
-    P.flevel_nbig.assign(P.n_levels, 0);
+    P.slevel_ptr.assign(P.n_levels + 1, 0);
     P.flevel_maxent.assign(P.n_levels, 0);
-    for (auto& t : tasks) {
+    for (auto& t : gtasks) {
       P.ftasks.push_back(t.t);
       P.flevel_ptr[t.level + 1]++;
-      P.flevel_maxm[t.level] = std::max(P.flevel_maxm[t.level], t.nm);
-      if (t.nm > opt.max_task_mults) P.flevel_nbig[t.level]++;
       const int ndst = (t.t.r1 - t.t.r0) * P.piv_w[t.t.piv];
       const int ne = P.fdst_ptr[t.t.dptr0 + ndst] - P.fdst_ptr[t.t.dptr0];
       P.flevel_maxent[t.level] = std::max(P.flevel_maxent[t.level], ne);
     }
-    for (int l = 0; l < P.n_levels; ++l) P.flevel_ptr[l + 1] += P.flevel_ptr[l];
+    for (auto& t : sctasks) { P.stasks.push_back(t.t); P.slevel_ptr[t.level + 1]++; }
+    for (int l = 0; l < P.n_levels; ++l) { P.flevel_ptr[l + 1] += P.flevel_ptr[l]; P.slevel_ptr[l + 1] += P.slevel_ptr[l]; }
   }
 
-  // ---- 7. solve schedules in flat scalar form
+  // ---- 7. solve schedules: independent scalar rows / columns by level (L form)
   {
-    // forward: scalar row c (new column) gathers U[c, k-columns] * z[k-columns]
+    // forward: y_c = b_c - sum L[c, k-columns] * y[k-columns]
     P.sfwd_eptr.assign(n + 1, 0);
     for (int p = 0; p < P.npiv; ++p)
       for (int q = 0; q < P.piv_w[p]; ++q) {
@@ -595,6 +570,16 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
         }
         P.sfwd_eptr[c + 1] = (int)P.sfwd_upos.size();
       }
+    {
+      std::vector<int> cnt(P.n_levels + 1, 0);
+      for (int p = 0; p < P.npiv; ++p) cnt[P.piv_level[p] + 1] += P.piv_w[p];
+      for (int l = 0; l < P.n_levels; ++l) cnt[l + 1] += cnt[l];
+      P.clevel_ptr = cnt;
+      P.clevel_col.assign(n, 0);
+      std::vector<int> fill(cnt.begin(), cnt.end() - 1);
+      for (int p = 0; p < P.npiv; ++p)
+        for (int q = 0; q < P.piv_w[p]; ++q) P.clevel_col[fill[P.piv_level[p]]++] = P.piv_start[p] + q;
+    }
     std::vector<std::vector<std::pair<int, int>>> cr(nc);
     for (int k = 0; k < P.npiv; ++k) {
       const auto& r = rows[k];
@@ -605,12 +590,6 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
           cr[r[t] - n].push_back({(int)(P.piv_uoff[k] + (int64_t)(wk + (int)t) * wk + tt), P.piv_start[k] + tt});
       }
     }
-    P.slevel_maxent.assign(P.n_levels, 0);
-    for (int p = 0; p < P.npiv; ++p)
-      for (int q = 0; q < P.piv_w[p]; ++q) {
-        const int c = P.piv_start[p] + q;
-        P.slevel_maxent[P.piv_level[p]] = std::max(P.slevel_maxent[P.piv_level[p]], P.sfwd_eptr[c + 1] - P.sfwd_eptr[c]);
-      }
     P.crow_eptr.assign(nc + 1, 0);
     for (int c = 0; c < nc; ++c) {
       for (auto& e : cr[c]) { P.crow_upos.push_back(e.first); P.crow_zcol.push_back(e.second); }

@@ -156,6 +156,10 @@ class HipEngine(object):
             self.ns.check(self.lib.pp_factor_schur(self.ns.h, Qp), 'pp_factor_schur')
             self.ns.check(self.lib.pp_synchronize(self.ns.h), 'pp_synchronize')   # Qf must outlive the H2D
 
+    def set_supernodes(self, wmax, tol_rows):
+        """Block-pivot merging for the next symbolic factorisation (0 / -1: library defaults)."""
+        self.ns.check(self.lib.pp_set_supernodes(self.ns.h, int(wmax), int(tol_rows)), 'pp_set_supernodes')
+
     def set_dense_policy(self, policy):
         """0: optimistic blocked LDL^T (fp64 MFMA) with Bunch-Kaufman fallback; 1: Bunch-Kaufman only."""
         self.ns.check(self.lib.pp_set_dense_policy(self.ns.h, int(policy)), 'pp_set_dense_policy')

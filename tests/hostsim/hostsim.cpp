@@ -69,73 +69,96 @@ void ppsim_get_level_task_counts(void* h, int* cnt) {
   for (int l = 0; l < P.n_levels; ++l) cnt[l] = P.flevel_ptr[l + 1] - P.flevel_ptr[l];
 }
 
-// per task: level, pivot width, rows, number of multiplier scalars, number of entries
+// per gather/fused task: level, pivot width, rows, kind, number of entries
 void ppsim_task_profile(void* h, int* out /*5 per task*/) {
   Plan& P = *(Plan*)h;
   for (size_t t = 0; t < P.ftasks.size(); ++t) {
     const auto& ft = P.ftasks[t];
     const int w = P.piv_w[ft.piv], ndst = (ft.r1 - ft.r0) * w;
     out[5 * t] = P.piv_level[ft.piv]; out[5 * t + 1] = w; out[5 * t + 2] = ft.r1 - ft.r0;
-    out[5 * t + 3] = ft.m1 - ft.m0; out[5 * t + 4] = P.fdst_ptr[ft.dptr0 + ndst] - P.fdst_ptr[ft.dptr0];
+    out[5 * t + 3] = ft.kind; out[5 * t + 4] = P.fdst_ptr[ft.dptr0 + ndst] - P.fdst_ptr[ft.dptr0];
   }
 }
 
-// One instance.  can: canonical values (ncan).  U: usize, Dinv: 3*npiv, S: nc*nc (row-major,
-// lower filled; contribution -A K^-1 A^T), inertia[3] += (pos, neg, zero).
-int ppsim_factor(void* h, const double* can, double* U, double* Dinv, double* S, int64_t* inertia, double eps) {
+namespace {
+// rows [r0, r1) of panel p: L = U inv(P)
+void scale_rows(const Plan& P, int p, int r0, int r1, const double* inv, const double* U, double* L) {
+  const int w = P.piv_w[p];
+  for (int r = std::max(r0, w); r < r1; ++r) {
+    const double* u = &U[P.piv_uoff[p] + (int64_t)r * w];
+    double* l = &L[P.piv_uoff[p] + (int64_t)r * w];
+    for (int t2 = 0; t2 < w; ++t2) {
+      double v = 0.0;
+      for (int t1 = 0; t1 < w; ++t1) {
+        const int hi = t1 > t2 ? t1 : t2, lo = t1 > t2 ? t2 : t1;
+        v += u[t1] * inv[hi * (hi + 1) / 2 + lo];
+      }
+      l[t2] = v;
+    }
+  }
+}
+}  // namespace
+
+// One instance.  can: canonical values (ncan).  U, L: usize, Dinv: dsize, S: nc*nc (row-major, lower filled;
+// contribution -A K^-1 A^T), inertia[3] += (pos, neg, zero).
+int ppsim_factor(void* h, const double* can, double* U, double* L, double* Dinv, double* S, int64_t* inertia,
+                 double eps) {
   Plan& P = *(Plan*)h;
   std::memset(U, 0, sizeof(double) * P.usize);
-  std::vector<double> M;
+  std::memset(L, 0, sizeof(double) * P.usize);
+  std::vector<double> Tm((size_t)std::max(P.bsize, 1), 0.0);
   int pos = 0, neg = 0, zero = 0;
-  for (const auto& t : P.ftasks) {
-    const int p = t.piv, w = P.piv_w[p];
-    const int64_t dst0 = P.piv_uoff[p] + (int64_t)t.r0 * w;
-    const int ndst = (t.r1 - t.r0) * w;
-    M.assign(1 + (t.m1 - t.m0), -1.0);
-    for (int j = t.m0; j < t.m1; ++j) {
-      const auto& m = P.mrecs[j];
-      double v = 0.0;
-      for (int q = 0; q < PP_WMAX; ++q) if (m.d[q] >= 0) v += Dinv[m.d[q]] * U[m.u[q]];
-      M[1 + (j - t.m0)] = v;
-    }
-    double piv[PP_WMAX * PP_WMAX] = {0}, tmax_diag = 0.0, colmax = 0.0;
-    for (int d = 0; d < ndst; ++d) {
-      double acc = 0.0, tmax = 0.0;
-      for (int e = P.fdst_ptr[t.dptr0 + d]; e < P.fdst_ptr[t.dptr0 + d + 1]; ++e) {
-        const auto& fe = P.fentries[e];
-        const double src = (fe.src >= 0) ? U[fe.src] : can[-1 - fe.src];
-        const double term = src * M[fe.midx];
-        acc -= term;
-        tmax = std::fmax(tmax, std::fabs(term));
+  for (int lvl = 0; lvl < P.n_levels; ++lvl) {
+    // launch G: gather chunks and fused small panels
+    for (int ti = P.flevel_ptr[lvl]; ti < P.flevel_ptr[lvl + 1]; ++ti) {
+      const auto& t = P.ftasks[ti];
+      const int p = t.piv, w = P.piv_w[p];
+      const int64_t dst0 = P.piv_uoff[p] + (int64_t)t.r0 * w;
+      const int ndst = (t.r1 - t.r0) * w;
+      double blk[PP_WMAX * PP_WMAX] = {0}, tmax_diag = 0.0, inv[PP_WMAX * (PP_WMAX + 1) / 2] = {0};
+      for (int d = 0; d < ndst; ++d) {
+        double acc = 0.0, tmax = 0.0;
+        for (int e = P.fdst_ptr[t.dptr0 + d]; e < P.fdst_ptr[t.dptr0 + d + 1]; ++e) {
+          const auto& fe = P.fentries[e];
+          const double su = (fe.u >= 0) ? U[fe.u] : can[-1 - fe.u];
+          const double sl = (fe.l >= 0) ? L[fe.l] : -1.0;
+          const double term = su * sl;
+          acc -= term;
+          tmax = std::fmax(tmax, std::fabs(term));
+        }
+        U[dst0 + d] = acc;
+        const int slot = t.r0 + d / w;
+        if (slot < w) {
+          if (t.kind == 0) Tm[P.piv_boff[p] + (slot * w + d % w)] = tmax;
+          else { blk[slot * PP_WMAX + d % w] = acc; tmax_diag = std::fmax(tmax_diag, tmax); }
+        }
+        if (t.kind == 1 && t.r0 + (d + 1) / w == w && (d + 1) % w == 0 && slot == w - 1) {
+          const int code = pp::invert_block(w, P.piv_sub[p], blk, tmax_diag, eps, inv);
+          for (int q = 0; q < w * (w + 1) / 2; ++q) Dinv[P.piv_doff[p] + q] = inv[q];
+          pos += code & 15; neg += (code >> 4) & 15; zero += (code >> 8) & 15;
+        }
       }
-      U[dst0 + d] = acc;
-      if (t.r0 == 0 && d < w * w) { piv[d] = acc; tmax_diag = std::fmax(tmax_diag, tmax); }
-      else colmax = std::fmax(colmax, std::fabs(acc));
+      if (t.kind == 1) scale_rows(P, p, t.r0, t.r1, &Dinv[P.piv_doff[p]], U, L);
     }
-    if (t.r0 == 0) {
-      const int code = pp::invert_block(w, P.piv_sub[p], piv, std::fmax(colmax, tmax_diag), eps, &Dinv[P.piv_doff[p]]);
-      pos += code & 15; neg += (code >> 4) & 15; zero += (code >> 8) & 15;
+    // launch S: scale chunks of big panels
+    for (int ti = P.slevel_ptr[lvl]; ti < P.slevel_ptr[lvl + 1]; ++ti) {
+      const auto& t = P.stasks[ti];
+      const int p = t.piv, w = P.piv_w[p];
+      double blk[PP_WMAX * PP_WMAX] = {0}, tmax_diag = 0.0, inv[PP_WMAX * (PP_WMAX + 1) / 2] = {0};
+      for (int q = 0; q < w * w; ++q) {
+        blk[(q / w) * PP_WMAX + q % w] = U[P.piv_uoff[p] + q];
+        tmax_diag = std::fmax(tmax_diag, Tm[P.piv_boff[p] + q]);
+      }
+      const int code = pp::invert_block(w, P.piv_sub[p], blk, tmax_diag, eps, inv);
+      if (t.r0 == w) {
+        for (int q = 0; q < w * (w + 1) / 2; ++q) Dinv[P.piv_doff[p] + q] = inv[q];
+        pos += code & 15; neg += (code >> 4) & 15; zero += (code >> 8) & 15;
+      }
+      scale_rows(P, p, t.r0, t.r1, inv, U, L);
     }
   }
   inertia[0] += pos; inertia[1] += neg; inertia[2] += zero;
-  // scaled coupling rows Lc = U_c inv(P), then Schur tiles S -= Lc_a U_c_b^T
-  std::vector<double> Lc((size_t)P.lcsize, 0.0);
-  for (int p = 0; p < P.npiv; ++p) {
-    if (P.piv_lcoff[p] < 0) continue;
-    const int w = P.piv_w[p];
-    const double* inv = &Dinv[P.piv_doff[p]];
-    for (int r = 0; r < P.piv_ncrow[p]; ++r) {
-      const double* u = &U[P.piv_uoff[p] + (int64_t)(P.piv_cslot0[p] + r) * w];
-      for (int t2 = 0; t2 < w; ++t2) {
-        double v = 0.0;
-        for (int t1 = 0; t1 < w; ++t1) {
-          const int hi = t1 > t2 ? t1 : t2, lo = t1 > t2 ? t2 : t1;
-          v += u[t1] * inv[hi * (hi + 1) / 2 + lo];
-        }
-        Lc[(size_t)P.piv_lcoff[p] + (size_t)r * w + t2] = v;
-      }
-    }
-  }
+  // Schur tiles S -= L_c,a U_c,b^T over the coupling rows of every panel
   const int T = P.opt.tile, nc = P.nc;
   for (size_t ti = 0; ti < P.stile_a.size(); ++ti) {
     double accS[8][8] = {};
@@ -144,7 +167,7 @@ int ppsim_factor(void* h, const double* can, double* U, double* Dinv, double* S,
       const int p = rec.piv, w = P.piv_w[p];
       for (int i = 0; i < T; ++i) {
         if (rec.slotA[i] < 0) continue;
-        const double* la = &Lc[(size_t)P.piv_lcoff[p] + (size_t)(rec.slotA[i] - P.piv_cslot0[p]) * w];
+        const double* la = &L[P.piv_uoff[p] + (int64_t)rec.slotA[i] * w];
         for (int j = 0; j < T; ++j) {
           if (rec.slotB[j] < 0) continue;
           const double* ub = &U[P.piv_uoff[p] + (int64_t)rec.slotB[j] * w];
@@ -163,55 +186,47 @@ int ppsim_factor(void* h, const double* can, double* U, double* Dinv, double* S,
   return zero > 0 ? 2 : 0;
 }
 
-// forward: W (n+nc) gets permuted rhs in [0,n); on exit W[0,n) = z, W[n+c] = -A K^-1 r contribution
-void ppsim_forward(void* h, const double* U, const double* Dinv, const double* rhs, double* W) {
+// forward: Y (n+nc): Y[c] = b_c - sum L[c,k] Y[k] for c < n in level order; Y[n+c] = -A K^-1 r contribution
+void ppsim_forward(void* h, const double* L, const double* rhs, double* Y) {
   Plan& P = *(Plan*)h;
-  for (int li = 0; li < P.npiv; ++li) {
-    const int p = P.lvl_piv[li], w = P.piv_w[p], p0 = P.piv_start[p];
-    double y[PP_WMAX] = {0};
-    for (int q = 0; q < w; ++q) {
-      double acc = rhs[P.perm[p0 + q]];
-      for (int e = P.sfwd_eptr[p0 + q]; e < P.sfwd_eptr[p0 + q + 1]; ++e) acc -= U[P.sfwd_upos[e]] * W[P.sfwd_zcol[e]];
-      y[q] = acc;
-    }
-    const double* inv = &Dinv[P.piv_doff[p]];
-    for (int q = 0; q < w; ++q) {
-      double z = 0.0;
-      for (int t = 0; t < w; ++t) { const int hi = q > t ? q : t, lo = q > t ? t : q; z += inv[hi * (hi + 1) / 2 + lo] * y[t]; }
-      W[p0 + q] = z;
-    }
+  for (int i = 0; i < P.n; ++i) {
+    const int c = P.clevel_col[i];
+    double acc = rhs[P.perm[c]];
+    for (int e = P.sfwd_eptr[c]; e < P.sfwd_eptr[c + 1]; ++e) acc -= L[P.sfwd_upos[e]] * Y[P.sfwd_zcol[e]];
+    Y[c] = acc;
   }
   for (int c = 0; c < P.nc; ++c) {
     double s = 0;
-    for (int e = P.crow_eptr[c]; e < P.crow_eptr[c + 1]; ++e) s -= U[P.crow_upos[e]] * W[P.crow_zcol[e]];
-    W[P.n + c] = s;
+    for (int e = P.crow_eptr[c]; e < P.crow_eptr[c + 1]; ++e) s -= L[P.crow_upos[e]] * Y[P.crow_zcol[e]];
+    Y[P.n + c] = s;
   }
 }
 
-// backward: W[0,n) = z, W[n..] = x_c on entry; x (original order) on exit
-void ppsim_backward(void* h, const double* U, const double* Dinv, double* W, double* x) {
+// backward: X[c] = (inv(P) y_p)_q - sum_i L[i, c] X[row i]; X[n..] = x_c on entry; x (original order) on exit
+void ppsim_backward(void* h, const double* L, const double* Dinv, const double* Y, double* X, double* x) {
   Plan& P = *(Plan*)h;
-  for (int li = P.npiv - 1; li >= 0; --li) {
-    const int p = P.lvl_piv[li], w = P.piv_w[p], p0 = P.piv_start[p];
-    double g[PP_WMAX] = {0};
+  for (int i = P.n - 1; i >= 0; --i) {
+    const int c = P.clevel_col[i];
+    const int p = P.piv_of_col[c], w = P.piv_w[p], p0 = P.piv_start[p], q = c - p0;
+    const double* inv = &Dinv[P.piv_doff[p]];
+    double z = 0.0;
+    for (int t = 0; t < w; ++t) { const int hi = q > t ? q : t, lo = q > t ? t : q; z += inv[hi * (hi + 1) / 2 + lo] * Y[p0 + t]; }
     const int nr = P.piv_rowptr[p + 1] - P.piv_rowptr[p];
     const int* ri = &P.rowidx[P.piv_rowptr[p]];
-    const double* u = &U[P.piv_uoff[p] + (int64_t)w * w];
-    for (int j = 0; j < nr; ++j)
-      for (int q = 0; q < w; ++q) g[q] += u[(int64_t)j * w + q] * W[ri[j]];
-    const double* inv = &Dinv[P.piv_doff[p]];
-    for (int q = 0; q < w; ++q) {
-      double z = 0.0;
-      for (int t = 0; t < w; ++t) { const int hi = q > t ? q : t, lo = q > t ? t : q; z += inv[hi * (hi + 1) / 2 + lo] * g[t]; }
-      W[p0 + q] -= z;
-    }
+    const double* l = &L[P.piv_uoff[p] + (int64_t)w * w];
+    double g = 0.0;
+    for (int j = 0; j < nr; ++j) g += l[(int64_t)j * w + q] * X[ri[j]];
+    X[c] = z - g;
   }
-  for (int k = 0; k < P.n; ++k) x[P.perm[k]] = W[k];
+  for (int k = 0; k < P.n; ++k) x[P.perm[k]] = X[k];
 }
 
 // block pivot inversion by static-order sweeps (pivot.hpp): returns the code, inv packed lower
 int ppsim_invert_block(int w, unsigned sub, const double* a, double colmax, double eps, double* inv) {
-  return pp::invert_block(w, sub, a, colmax, eps, inv);
+  double blk[PP_WMAX * PP_WMAX] = {0};
+  for (int i = 0; i < w; ++i)
+    for (int j = 0; j < w; ++j) blk[i * PP_WMAX + j] = a[i * w + j];
+  return pp::invert_block(w, sub, blk, colmax, eps, inv);
 }
 
 // dense Bunch-Kaufman on a column-major n x n matrix (lower triangle read); info = (pos, neg, zero)

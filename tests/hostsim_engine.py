@@ -56,16 +56,18 @@ class HostSimEngine(object):
         inertia = np.zeros(3, dtype=np.int64)
         for sg in self.groups:
             g = sg.g
-            sg.U, sg.Dinv = [], []
+            sg.U, sg.Dinv, sg.L = [], [], []
             for b in range(sg.batch):
                 can = np.add.reduceat(sg.raw[b][g.can_idx], g.can_ptr[:-1]) if g.can_idx.size else np.zeros(0)
                 U = np.zeros(sg.usize)
+                Lf = np.zeros(sg.usize)
                 D = np.zeros(L.ppsim_dsize(sg.h))
                 Sb = np.zeros((nc, nc))
-                L.ppsim_factor(sg.h, hu._dp(np.ascontiguousarray(can)), hu._dp(U), hu._dp(D), hu._dp(Sb),
+                L.ppsim_factor(sg.h, hu._dp(np.ascontiguousarray(can)), hu._dp(U), hu._dp(Lf), hu._dp(D), hu._dp(Sb),
                                inertia.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), ctypes.c_double(1e-13))
                 self.S += np.tril(Sb) + np.tril(Sb, -1).T
                 sg.U.append(U)
+                sg.L.append(Lf)
                 sg.Dinv.append(D)
         self.tail = np.array([inertia[2], inertia[0], inertia[1], 0.0], dtype=np.double)
 
@@ -104,7 +106,7 @@ class HostSimEngine(object):
             sg.W = []
             for b in range(sg.batch):
                 W = np.zeros(n + self.nc)
-                L.ppsim_forward(sg.h, hu._dp(sg.U[b]), hu._dp(sg.Dinv[b]), hu._dp(np.ascontiguousarray(sg.rhs[b])), hu._dp(W))
+                L.ppsim_forward(sg.h, hu._dp(sg.L[b]), hu._dp(np.ascontiguousarray(sg.rhs[b])), hu._dp(W))
                 self.rs += W[n:]
                 sg.W.append(W)
 
@@ -125,10 +127,10 @@ class HostSimEngine(object):
             n = sg.g.n
             sg.x = np.zeros((sg.batch, n))
             for b in range(sg.batch):
-                W = sg.W[b].copy()
-                W[n:] = self.xc
+                X = np.zeros(n + self.nc)
+                X[n:] = self.xc
                 x = np.zeros(n)
-                L.ppsim_backward(sg.h, hu._dp(sg.U[b]), hu._dp(sg.Dinv[b]), hu._dp(W), hu._dp(x))
+                L.ppsim_backward(sg.h, hu._dp(sg.L[b]), hu._dp(sg.Dinv[b]), hu._dp(sg.W[b]), hu._dp(X), hu._dp(x))
                 sg.x[b] = x
 
     def download_solution(self, gid, out):

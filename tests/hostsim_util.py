@@ -98,10 +98,11 @@ class HostSim(object):
     def factor(self, can=None, eps=1e-13):
         can = self.can0 if can is None else np.ascontiguousarray(can, dtype=np.double)
         self.U = np.zeros(self.stats['usize'])
+        self.L = np.zeros(self.stats['usize'])
         self.Dinv = np.zeros(lib().ppsim_dsize(self.h))
         S = np.zeros((self.nc, self.nc))
         inertia = np.zeros(3, dtype=np.int64)
-        rc = lib().ppsim_factor(self.h, _dp(can), _dp(self.U), _dp(self.Dinv), _dp(S),
+        rc = lib().ppsim_factor(self.h, _dp(can), _dp(self.U), _dp(self.L), _dp(self.Dinv), _dp(S),
                                 inertia.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), ctypes.c_double(eps))
         S = np.tril(S) + np.tril(S, -1).T
         return rc, S, tuple(int(v) for v in inertia)
@@ -109,14 +110,14 @@ class HostSim(object):
     def forward(self, rhs):
         W = np.zeros(self.n + self.nc)
         rhs = np.ascontiguousarray(rhs, dtype=np.double)
-        lib().ppsim_forward(self.h, _dp(self.U), _dp(self.Dinv), _dp(rhs), _dp(W))
+        lib().ppsim_forward(self.h, _dp(self.L), _dp(rhs), _dp(W))
         return W
 
     def backward(self, W, xc):
-        W = W.copy()
-        W[self.n:] = xc
+        X = np.zeros(self.n + self.nc)
+        X[self.n:] = xc
         x = np.zeros(self.n)
-        lib().ppsim_backward(self.h, _dp(self.U), _dp(self.Dinv), _dp(W), _dp(x))
+        lib().ppsim_backward(self.h, _dp(self.L), _dp(self.Dinv), _dp(np.ascontiguousarray(W)), _dp(X), _dp(x))
         return x
 
     def __del__(self):

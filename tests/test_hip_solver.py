@@ -135,3 +135,17 @@ def test_indefinite_schur_falls_back_to_bunch_kaufman():
     assert np.abs(x.flatten() - x_ref).max() <= 1e-8 * np.abs(x_ref).max()
     ev = np.linalg.eigvalsh(full)
     assert solver.get_inertia() == (int((ev > 0).sum()), int((ev < 0).sum()), 0)
+
+
+@pytest.mark.parametrize('wmax,tol', [(2, 1), (4, 1), (4, 3)])
+def test_block_pivots_on_device(wmax, tol):
+    """Supernodes (merged sub-pivot chains, block pivots up to 4 wide) against the oracle and dense algebra."""
+    def make():
+        from parapint_amd.linalg.hip_schur_complement import HipEngine
+        eng = HipEngine()
+        eng.set_supernodes(wmax, tol)
+        return eng
+    sc.case_oracle_schur(make, (70, 30, 2, 10))
+    sc.case_heterogeneous(make)
+    solver, model = sc.case_against_oracle(make, (16, 400, 4, 100), iteration=2)
+    assert solver.plan_stats[0]['n_levels'] < 30

@@ -157,3 +157,26 @@ def test_dense_bunch_kaufman_singular():
     S = np.array([[1.0, 2.0, 0.0], [2.0, 4.0, 0.0], [0.0, 0.0, 0.0]])
     x, inertia = bk_factor_solve(S, np.ones(3))
     assert inertia[2] >= 1
+
+
+@pytest.mark.parametrize('wmax,tol', [(2, 0), (2, 1), (4, 1), (4, 3)])
+def test_supernodes_block_pivots(wmax, tol):
+    """Block pivots (merged sub-pivot chains) give the same factorisation: S, inertia, solves."""
+    import hostsim_util as hu
+    hu.lib().ppsim_set_supernodes(wmax, tol)
+    try:
+        m = SyntheticKKT(2, 120, 4, 30)
+        hs = check_block(m.block_matrix(0, 2), m.border_matrix())
+        base_levels = hs.stats['n_levels']
+        K, A = random_saddle(40, 15, 6, 0)
+        check_block(K, A, rtol=1e-7)
+        rng = np.random.default_rng(1)
+        B = np.diag(rng.uniform(1, 2, size=6)) + np.diag(rng.uniform(0.1, 0.3, size=5), 1)
+        K2 = sp.bmat([[None, sp.coo_matrix(B)], [sp.coo_matrix(B.T), None]]).tocoo()
+        A2 = sp.coo_matrix(([-1.0, -1.0], ([0, 1], [2, 9])), shape=(2, 12))
+        check_block(K2, A2)
+    finally:
+        hu.lib().ppsim_set_supernodes(0, -1)
+    if tol > 0:
+        hs0 = HostSim(m.block_matrix(0, 2), m.border_matrix())
+        assert base_levels < hs0.stats['n_levels']      # merging shortens the level schedule
