@@ -39,7 +39,7 @@ struct PlanOptions {
   int tail_piv_max = 48;
   int tail_task_entries = 48;
   int tile = 8;           // register tile edge of the Schur (SYRK) kernel
-  int sn_wmax = 1;        // widest supernode (columns); 1 disables merging of sub-pivots (wider blocks need the
+  int sn_wmax = 4;        // widest supernode (columns); 1 disables merging of sub-pivots (wider blocks need the
                           // per-source block multiplier path)
   int sn_tol_rows = 1;    // padded rows tolerated when merging a sub-pivot into its parent
   int md_delta_abs = 3;   // minimum-degree tolerance (absolute) for height-aware selection

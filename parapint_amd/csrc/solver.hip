@@ -95,80 +95,65 @@ __device__ __forceinline__ int bcast(int v, int src_lane) { return __builtin_amd
 // inv(P) packed by rows of the lower triangle
 #define PP_INV(inv, i, j) ((inv)[((i) > (j) ? (i) * ((i) + 1) / 2 + (j) : (j) * ((j) + 1) / 2 + (i))])
 
-// bookkeeping shared by the gather kernels when a destination scalar is complete
+// Inversion of the gathered pivot block and scaling of panel rows [r0, r1): L rows = U rows * inv(P).
+// Used by the scale tasks of big panels and as the closing phase of fused small-panel tasks.
 template <int WM>
-struct GatherState {
-  double blk[WM * WM];
+__device__ __forceinline__ void invert_and_scale(const GroupDev& g, int p, int w, int r0, int r1, double tmax_diag,
+                                                 bool publish, size_t bpad, int b, double eps) {
+  const double* Up = g.U + (size_t)g.piv_uoff[p] * bpad + b;
+  double* Lp = g.L + (size_t)g.piv_uoff[p] * bpad + b;
   double inv[WM * (WM + 1) / 2];
-  double rowbuf[WM];
-  double tmax_diag;
-  int slot, q;
-  __device__ __forceinline__ void init(int r0) {
+  int code;
+  if (WM == 1) {
+    const pp::PivotResult pr = pp::invert_pivot(1, Up[0], 0.0, 0.0, tmax_diag, eps);
+    inv[0] = pr.i00;
+    code = (pr.code & 3) | (((pr.code >> 2) & 3) << 4) | (((pr.code >> 4) & 3) << 8);
+  } else {
+    double blk[PP_WMAX * PP_WMAX];
 #pragma unroll
-    for (int i = 0; i < WM * WM; ++i) blk[i] = 0.0;
+    for (int i = 0; i < PP_WMAX; ++i)
 #pragma unroll
-    for (int i = 0; i < WM * (WM + 1) / 2; ++i) inv[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < WM; ++i) rowbuf[i] = 0.0;
-    tmax_diag = 0.0; slot = r0; q = 0;
+      for (int j = 0; j < PP_WMAX; ++j)
+        blk[i * PP_WMAX + j] = (i < w && j < w) ? Up[(size_t)(i * w + j) * bpad] : 0.0;
+    code = pp::invert_block(w, g.piv_sub[p], blk, tmax_diag, eps, inv);
   }
-};
-
-// WM = 1: levels whose pivots are all scalar (the wide bottom of the tree) keep a tiny register footprint
-template <int WM>
-__device__ __forceinline__ void finalize_dst(const GroupDev& g, GatherState<WM>& st, int p, int w, int kind, int d,
-                                             double acc, double tmax, double* __restrict__ Udst,
-                                             double* __restrict__ Ldst, size_t bpad, int b, double eps) {
-  Udst[(size_t)d * bpad] = acc;
-  if (st.slot < w) {
-    if (kind == 0) {
-      g.Tm[(size_t)(g.piv_boff[p] + st.slot * w + st.q) * bpad + b] = tmax;
-    } else {
-      const int idx = st.slot * WM + st.q;   // fixed stride: static register indexing
+  if (publish) {
+    double* invp = g.Dinv + (size_t)g.piv_doff[p] * bpad + b;
 #pragma unroll
-      for (int i = 0; i < WM * WM; ++i) if (i == idx) st.blk[i] = acc;
-      st.tmax_diag = fmax(st.tmax_diag, tmax);
-    }
+    for (int i = 0; i < WM * (WM + 1) / 2; ++i)
+      if (i < w * (w + 1) / 2) invp[(size_t)i * bpad] = inv[i];
+    g.codes[(size_t)p * bpad + b] = (b < g.batch) ? (unsigned short)code : (unsigned short)0;
   }
-  if (kind == 1) {
+  for (int r = (r0 > w ? r0 : w); r < r1; r += 4) {
+    double u[4][WM];
 #pragma unroll
-    for (int i = 0; i < WM; ++i) if (i == st.q) st.rowbuf[i] = acc;
-    if (st.q == w - 1) {
-      if (st.slot == w - 1) {          // pivot block complete: invert it (static sub-pivot order)
-        int code;
-        if (WM == 1) {
-          const pp::PivotResult pr = pp::invert_pivot(1, st.blk[0], 0.0, 0.0, st.tmax_diag, eps);
-          st.inv[0] = pr.i00;
-          code = (pr.code & 3) | (((pr.code >> 2) & 3) << 4) | (((pr.code >> 4) & 3) << 8);
-        } else {
-          code = pp::invert_block(w, g.piv_sub[p], st.blk, st.tmax_diag, eps, st.inv);
-        }
-        double* invp = g.Dinv + (size_t)g.piv_doff[p] * bpad + b;
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int i = 0; i < WM * (WM + 1) / 2; ++i)
-          if (i < w * (w + 1) / 2) invp[(size_t)i * bpad] = st.inv[i];
-        g.codes[(size_t)p * bpad + b] = (b < g.batch) ? (unsigned short)code : (unsigned short)0;
-      } else if (st.slot >= w) {       // a row below the block: L row = U row * inv(P)
+      for (int t1 = 0; t1 < WM; ++t1)
+        u[i][t1] = (r + i < r1 && t1 < w) ? Up[(size_t)((r + i) * w + t1) * bpad] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (r + i < r1) {
 #pragma unroll
         for (int t2 = 0; t2 < WM; ++t2) {
           if (t2 < w) {
             double v = 0.0;
 #pragma unroll
             for (int t1 = 0; t1 < WM; ++t1)
-              if (t1 < w) v += st.rowbuf[t1] * PP_INV(st.inv, t1, t2);
-            Ldst[(size_t)(d - (w - 1) + t2) * bpad] = v;
+              if (t1 < w) v += u[i][t1] * PP_INV(inv, t1, t2);
+            Lp[(size_t)((r + i) * w + t2) * bpad] = v;
           }
         }
       }
     }
   }
-  if (++st.q == w) { st.q = 0; ++st.slot; }
 }
 
 // One gather / fused task of the L-form factorisation (plan.hpp, FTask kinds 0 and 1): every
 // destination scalar is acc = -sum U[e.u] * L[e.l] over its entries, accumulated in a register and
 // written once; all global loads of up to 16 entries are in flight together.  Initial values come
 // straight from the transposed input (e.u < 0, e.l < 0): assembly is fused into the factorisation.
+// Fused small panels (kind 1) finish with the inversion of their block and the scaling of their rows.
 template <int WM>
 __global__ __launch_bounds__(64) void k_gather_level(GroupDev g, int task0, int chunk0, double eps) {
   const int lane = threadIdx.x;
@@ -185,9 +170,9 @@ __global__ __launch_bounds__(64) void k_gather_level(GroupDev g, int task0, int 
   const bool dp_vec = (ndst + 1 <= 64);
   const int dpv = (dp_vec && lane <= ndst) ? dp[lane] : 0;
   double* Udst = g.U + ((size_t)g.piv_uoff[p] + (size_t)r0 * w) * bpad + b;
-  double* Ldst = g.L + ((size_t)g.piv_uoff[p] + (size_t)r0 * w) * bpad + b;
-  GatherState<WM> st;
-  st.init(r0);
+  double* Tmd = g.Tm + (size_t)g.piv_boff[p] * bpad + b;
+  const int nblk = (r0 < w) ? (w - r0) * w : 0;      // leading destinations that belong to the pivot block
+  double tmax_diag = 0.0;
   double acc = 0.0, tmax = 0.0;
   int d = 0;
   const int E0 = dp_vec ? bcast(dpv, 0) : dp[0];
@@ -195,7 +180,10 @@ __global__ __launch_bounds__(64) void k_gather_level(GroupDev g, int task0, int 
   int dend = (ndst > 0) ? (dp_vec ? bcast(dpv, 1) : dp[1]) : 0x7fffffff;
 #define PP_FINALIZE()                                                                      \
   do {                                                                                     \
-    finalize_dst(g, st, p, w, kind, d, acc, tmax, Udst, Ldst, bpad, b, eps);               \
+    Udst[(size_t)d * bpad] = acc;                                                          \
+    if (d < nblk) {                                                                        \
+      if (kind == 0) Tmd[(size_t)(r0 * w + d) * bpad] = tmax; else tmax_diag = fmax(tmax_diag, tmax); \
+    }                                                                                      \
     acc = 0.0; tmax = 0.0; ++d;                                                            \
     dend = (d < ndst) ? (dp_vec ? bcast(dpv, d + 1) : dp[d + 1]) : 0x7fffffff;             \
   } while (0)
@@ -236,6 +224,7 @@ __global__ __launch_bounds__(64) void k_gather_level(GroupDev g, int task0, int 
   }
   while (d < ndst) PP_FINALIZE();
 #undef PP_FINALIZE
+  if (kind == 1) invert_and_scale<WM>(g, p, w, r0, r1, tmax_diag, true, bpad, b, eps);
 }
 
 // Lean variant for the wide bottom levels of the tree (a few entries per task, tens of thousands
@@ -255,9 +244,10 @@ __global__ __launch_bounds__(64) void k_gather_level_lean(GroupDev g, int task0,
   const int ndst = (r1 - r0) * w;
   const int* dp = g.fdst_ptr + dptr0;
   double* Udst = g.U + ((size_t)g.piv_uoff[p] + (size_t)r0 * w) * bpad + b;
+  double* Tmd = g.Tm + (size_t)g.piv_boff[p] * bpad + b;
   double* Ldst = g.L + ((size_t)g.piv_uoff[p] + (size_t)r0 * w) * bpad + b;
-  GatherState<WM> st;
-  st.init(r0);
+  const int nblk = (r0 < w) ? (w - r0) * w : 0;
+  double tmax_diag = 0.0, inv1 = 0.0;
   for (int d = 0; d < ndst; ++d) {
     double acc = 0.0, tmax = 0.0;
     for (int e = dp[d]; e < dp[d + 1]; ++e) {
@@ -268,8 +258,23 @@ __global__ __launch_bounds__(64) void k_gather_level_lean(GroupDev g, int task0,
       acc -= term;
       tmax = fmax(tmax, fabs(term));
     }
-    finalize_dst(g, st, p, w, kind, d, acc, tmax, Udst, Ldst, bpad, b, eps);
+    Udst[(size_t)d * bpad] = acc;
+    if (WM == 1 && kind == 1) {
+      // scalar pivot, fused panel: destination 0 is the pivot, every later one a row to scale
+      if (d == 0) {
+        const pp::PivotResult pr = pp::invert_pivot(1, acc, 0.0, 0.0, tmax, eps);
+        inv1 = pr.i00;
+        g.Dinv[(size_t)g.piv_doff[p] * bpad + b] = inv1;
+        const int code = (pr.code & 3) | (((pr.code >> 2) & 3) << 4) | (((pr.code >> 4) & 3) << 8);
+        g.codes[(size_t)p * bpad + b] = (b < g.batch) ? (unsigned short)code : (unsigned short)0;
+      } else {
+        Ldst[(size_t)d * bpad] = acc * inv1;
+      }
+    } else if (d < nblk) {
+      if (kind == 0) Tmd[(size_t)(r0 * w + d) * bpad] = tmax; else tmax_diag = fmax(tmax_diag, tmax);
+    }
   }
+  if (WM != 1 && kind == 1) invert_and_scale<WM>(g, p, w, r0, r1, tmax_diag, true, bpad, b, eps);
 }
 
 // Scale task of a big panel (plan.hpp, kind 2): invert the gathered pivot block (every chunk does it
@@ -282,52 +287,12 @@ __global__ __launch_bounds__(64) void k_scale_level(GroupDev g, int task0, int c
   const int* t = g.stask + 5 * (size_t)(task0 + blockIdx.x);
   const int p = t[0], r0 = t[1], r1 = t[2];
   const int w = g.piv_w[p];
-  const double* Up = g.U + (size_t)g.piv_uoff[p] * bpad + b;
-  double* Lp = g.L + (size_t)g.piv_uoff[p] * bpad + b;
   const double* Tmp = g.Tm + (size_t)g.piv_boff[p] * bpad + b;
-  double blk[PP_WMAX * PP_WMAX], inv[PP_WMAX * (PP_WMAX + 1) / 2];
   double tmax_diag = 0.0;
 #pragma unroll
-  for (int i = 0; i < PP_WMAX; ++i)
-#pragma unroll
-    for (int j = 0; j < PP_WMAX; ++j) {
-      blk[i * PP_WMAX + j] = 0.0;
-      if (i < w && j < w) {
-        blk[i * PP_WMAX + j] = Up[(size_t)(i * w + j) * bpad];
-        tmax_diag = fmax(tmax_diag, Tmp[(size_t)(i * w + j) * bpad]);
-      }
-    }
-  const int code = pp::invert_block(w, g.piv_sub[p], blk, tmax_diag, eps, inv);
-  if (r0 == w) {
-    double* invp = g.Dinv + (size_t)g.piv_doff[p] * bpad + b;
-#pragma unroll
-    for (int i = 0; i < PP_WMAX * (PP_WMAX + 1) / 2; ++i)
-      if (i < w * (w + 1) / 2) invp[(size_t)i * bpad] = inv[i];
-    g.codes[(size_t)p * bpad + b] = (b < g.batch) ? (unsigned short)code : (unsigned short)0;
-  }
-  for (int r = r0; r < r1; r += 4) {
-    double u[4][PP_WMAX];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int t1 = 0; t1 < PP_WMAX; ++t1)
-        u[i][t1] = (r + i < r1 && t1 < w) ? Up[(size_t)((r + i) * w + t1) * bpad] : 0.0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (r + i < r1) {
-#pragma unroll
-        for (int t2 = 0; t2 < PP_WMAX; ++t2) {
-          if (t2 < w) {
-            double v = 0.0;
-#pragma unroll
-            for (int t1 = 0; t1 < PP_WMAX; ++t1)
-              if (t1 < w) v += u[i][t1] * PP_INV(inv, t1, t2);
-            Lp[(size_t)((r + i) * w + t2) * bpad] = v;
-          }
-        }
-      }
-    }
-  }
+  for (int i = 0; i < PP_WMAX * PP_WMAX; ++i)
+    if (i < w * w) tmax_diag = fmax(tmax_diag, Tmp[(size_t)i * bpad]);
+  invert_and_scale<PP_WMAX>(g, p, w, r0, r1, tmax_diag, r0 == w, bpad, b, eps);
 }
 
 // counters[0..2] += (pos, neg, zero) over all block pivots (codes of padded instances are 0);
@@ -1257,7 +1222,10 @@ int pp_numeric_local(pp_handle h) {
                            d.nraw, d.bpad);
     }
     {
-      PhaseScope ps(h, 1, P.n_levels);
+      int nlaunch = 0;
+      for (int l = 0; l < P.n_levels; ++l)
+        nlaunch += (P.flevel_ptr[l + 1] > P.flevel_ptr[l]) + (P.slevel_ptr[l + 1] > P.slevel_ptr[l]);
+      PhaseScope ps(h, 1, nlaunch);
       const Splits sp = make_splits(h, d.nchunk);
       hipStream_t fan[PP_MAX_SPLIT];
       if (fork_streams(h, sp, fan)) return fail(h, 3, "stream fork failed");

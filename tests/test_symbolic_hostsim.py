@@ -53,7 +53,7 @@ def test_synthetic_c3_shape_plan_is_shallow_and_sparse():
     hs = HostSim(m.block_matrix(0), m.border_matrix())
     st = hs.stats
     assert st['n'] == 9200 and st['nc'] == 200
-    assert st['n_levels'] <= 64
+    assert st['n_levels'] <= 24
     assert st['nnz_L'] <= 1.75 * 20192         # nnz(tril K_i) = 20 192 (supernode padding included)
     rc, S, inertia = hs.factor()
     assert rc == 0 and inertia == (5000, 4200, 0)
@@ -178,5 +178,9 @@ def test_supernodes_block_pivots(wmax, tol):
     finally:
         hu.lib().ppsim_set_supernodes(0, -1)
     if tol > 0:
-        hs0 = HostSim(m.block_matrix(0, 2), m.border_matrix())
+        hu.lib().ppsim_set_supernodes(1, 0)
+        try:
+            hs0 = HostSim(m.block_matrix(0, 2), m.border_matrix())
+        finally:
+            hu.lib().ppsim_set_supernodes(0, -1)
         assert base_levels < hs0.stats['n_levels']      # merging shortens the level schedule
