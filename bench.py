@@ -248,8 +248,18 @@ def main():
     dom_launches = max(1, phases[dom]['launches_per_step'])
     bytes_per_launch = phase_bytes[dom] * B / dom_launches
     achieved = bytes_per_launch / (dom_ms / dom_launches * 1e-3) / 1e9
+    # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+    # runs of this same command; profiles/pmc_traffic.json) -- valid for the build it was collected on
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+        ph = pmc['phases'].get(dom)
+        if ph and ph['launches_per_step'] > 0 and world == 1 and N == 1024 and n_q == 1000:
+            traffic = ph['hbm_bytes_per_step'] / ph['launches_per_step']
+    except Exception:
+        traffic = None
     roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                 'algorithmic_bytes_per_launch': bytes_per_launch,
                 'avg_launch_us': 1e3 * dom_ms / dom_launches,
                 'whole_iteration': {'bytes': sb['total'] * B, 'GBps': sb['total'] * B / (ms_per_step * 1e-3) / 1e9,

@@ -36,8 +36,11 @@ def load(dirname, counter):
 
 
 def short(name):
-    base = name.split('(')[0].split('::')[-1]
-    return base
+    import re
+    m = re.search(r'(k_[a-z_0-9]+(?:<\d+>)?)', name)
+    if m:
+        return m.group(1)
+    return name.split('(')[0].split('::')[-1].strip() or name[:40]
 
 
 def main():
