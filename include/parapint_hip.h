@@ -165,6 +165,10 @@ int pp_phase_times(pp_handle h, double ms_out[8], int32_t launches_out[8], int32
 int pp_group_stats(pp_handle h, int group, int64_t out[16]);
 /* Elimination order of a group (new -> old), n ints. */
 int pp_group_perm(pp_handle h, int group, int32_t* perm);
+/* Diagnostic: the factor of one instance (block) of a group after pp_numeric_local, in the plan's
+ * panel storage: which = 0 unscaled panels U, 1 scaled rows L (the MA27 factor entries,
+ * ma27_interface.py:124), 2 packed inverses of the block pivots.  count doubles are copied. */
+int pp_get_factor(pp_handle h, int group, int which, int instance, double* out, int64_t count);
 
 #ifdef __cplusplus
 }

@@ -55,6 +55,7 @@ SIGNATURES = {
     'pp_phase_times': (ctypes.c_int, [ctypes.c_void_p, _f64p, _i32p, _i32p]),
     'pp_group_stats': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _i64p]),
     'pp_group_perm': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _i32p]),
+    'pp_get_factor': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f64p, ctypes.c_int64]),
 }
 
 GROUP_STAT_KEYS = ['n', 'n_coupling', 'batch', 'n_pivots', 'n_2x2', 'n_levels', 'nnz_L', 'u_doubles',
@@ -131,6 +132,13 @@ class NativeSolver(object):
         out = np.zeros(16, dtype=np.int64)
         self.check(self.lib.pp_group_stats(self.h, group, out.ctypes.data_as(_i64p)), 'pp_group_stats')
         return dict(zip(GROUP_STAT_KEYS, [int(v) for v in out]))
+
+
+    def get_factor(self, group, which, instance, count):
+        out = np.zeros(int(count), dtype=np.double)
+        self.check(self.lib.pp_get_factor(self.h, int(group), int(which), int(instance), out.ctypes.data_as(_f64p),
+                                          ctypes.c_int64(int(count))), 'pp_get_factor')
+        return out
 
 
 class NativeError(RuntimeError):

@@ -48,10 +48,13 @@ struct PlanOptions {
 };
 
 // Factor schedule ("L form").  For every block pivot p two panels are stored with the same
-// indexing: the unscaled panel U_p = [P_p ; U_p] and the scaled rows L_p = U_p inv(P_p).  An
-// update of destination scalar d is then a pure two-operand gather
-//     acc -= U[e.u] * L[e.l]        (e.u < 0: canonical input value ~e.u; e.l < 0: constant -1)
-// so no per-task multiplier tables are needed and block pivots of any width cost the same per entry.
+// indexing: the unscaled panel U_p = [P_p ; U_p] and the scaled rows L_p = U_p inv(P_p).  The
+// update of a destination ROW (all w columns of the block pivot at once) is a pure gather over
+// row entries e:
+//     acc[q] -= U[e.u] * L[e.l + q * e.wk]   for q < w      (source column t of panel k: U_k[i][t], L_k[p_q][t])
+//     acc[e.q] += input value ~e.u                           (initial-value entry: e.u < 0, e.l < 0)
+// so every U operand is loaded once per row, no per-task multiplier tables are needed and block
+// pivots of any width cost (1 + w) loads per w multiply-adds.
 // Task kinds:  0 gather chunk of a big panel (stores U, and the term magnitudes of pivot-block
 //                scalars for the zero-pivot test),
 //              1 fused small panel (gather everything, invert the block, scale the rows, store U, L,
@@ -60,7 +63,7 @@ struct PlanOptions {
 //                chunk with r0 == w also stores inv(P) and the inertia code).
 // Per level: one launch of the kind-0/1 tasks, then (if any) one launch of the kind-2 tasks.
 struct FTask { int piv, r0, r1, dptr0, kind; };
-struct FEntry { int u, l; };
+struct FEntry { int u, l, wk, q; };
 // Schur tile record: pivot p contributes to tile (ta, tb); slots (or -1) of the tile's
 // coupling rows inside panel p
 struct STileRec { int piv; int slotA[8]; int slotB[8]; };
@@ -84,7 +87,7 @@ struct Plan {
   // factor schedule
   std::vector<FTask> ftasks;             // gather / fused tasks sorted by level
   std::vector<FTask> stasks;             // scale tasks sorted by level
-  std::vector<int> fdst_ptr;             // per gather/fused task (ndst + 1) offsets into fentries, at dptr0
+  std::vector<int> fdst_ptr;             // per gather/fused task (nrows + 1) offsets into fentries, at dptr0
   std::vector<FEntry> fentries;
   std::vector<int> flevel_ptr;           // n_levels+1 -> ftasks
   std::vector<int> slevel_ptr;           // n_levels+1 -> stasks

@@ -41,7 +41,7 @@ struct GroupDev {
   int n, nc, batch, bpad, nchunk, npiv, nraw;
   int64_t usize;
   const int *piv_w, *piv_start, *piv_uoff, *piv_doff, *piv_boff, *piv_sub, *piv_rowptr, *rowidx, *perm, *iperm;
-  const int *piv_of_col;
+  const int *piv_of_col, *rawmap;
   const int *ftask, *stask, *fdst_ptr, *fent;
   const int *clevel_col, *sfwd_eptr, *sfwd_upos, *sfwd_zcol;
   const int *crow_eptr, *crow_upos, *crow_zcol;
@@ -51,9 +51,11 @@ struct GroupDev {
 };
 
 // ------------------------------------------------------------------------------------------
-// [rows][m] row-major  ->  [m][bpad] (instance-interleaved), zero padding for rows >= nrows
+// [rows][m] row-major  ->  [m'][bpad] (instance-interleaved), zero padding for rows >= nrows.
+// rowmap (may be null): entry e of the input goes to output row rowmap[e]; negative = not needed
+// (e.g. the upper-triangle half of a KKT block given with both triangles) and is not written.
 __global__ __launch_bounds__(256) void k_transpose_in(const double* __restrict__ in, double* __restrict__ out,
-                                                      int nrows, int m, int bpad) {
+                                                      const int* __restrict__ rowmap, int nrows, int m, int bpad) {
   __shared__ double tile[64][65];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int e0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
@@ -64,7 +66,10 @@ __global__ __launch_bounds__(256) void k_transpose_in(const double* __restrict__
   __syncthreads();
   for (int r = ty; r < 64; r += 4) {
     const int e = e0 + r, b = b0 + tx;
-    if (e < m) out[(size_t)e * bpad + b] = tile[tx][r];
+    if (e < m) {
+      const int orow = rowmap ? rowmap[e] : e;
+      if (orow >= 0) out[(size_t)orow * bpad + b] = tile[tx][r];
+    }
   }
 }
 
@@ -150,10 +155,12 @@ __device__ __forceinline__ void invert_and_scale(const GroupDev& g, int p, int w
 }
 
 // One gather / fused task of the L-form factorisation (plan.hpp, FTask kinds 0 and 1): every
-// destination scalar is acc = -sum U[e.u] * L[e.l] over its entries, accumulated in a register and
-// written once; all global loads of up to 16 entries are in flight together.  Initial values come
-// straight from the transposed input (e.u < 0, e.l < 0): assembly is fused into the factorisation.
-// Fused small panels (kind 1) finish with the inversion of their block and the scaling of their rows.
+// destination row (all w columns of the block pivot) is acc[q] = -sum U[e.u] * L[e.l + q * e.wk]
+// over its row entries, accumulated in registers and written once; the U operand is loaded once per
+// entry and all global loads of a group of entries are in flight together.  Initial values come
+// straight from the transposed input (e.u < 0, added to column e.q): assembly is fused into the
+// factorisation.  Fused small panels (kind 1) finish with the inversion of their block and the
+// scaling of their rows.
 template <int WM>
 __global__ __launch_bounds__(64) void k_gather_level(GroupDev g, int task0, int chunk0, double eps) {
   const int lane = threadIdx.x;
@@ -161,68 +168,78 @@ __global__ __launch_bounds__(64) void k_gather_level(GroupDev g, int task0, int 
   const size_t bpad = (size_t)g.bpad;
   const int* t = g.ftask + 5 * (size_t)(task0 + blockIdx.x);
   const int p = t[0], r0 = t[1], r1 = t[2], dptr0 = t[3], kind = t[4];
-  const int w = g.piv_w[p];
+  const int w = (WM == 1) ? 1 : g.piv_w[p];
   const double* __restrict__ U = g.U + b;
   const double* __restrict__ Lb = g.L + b;
   const double* __restrict__ R = g.rawT + b;
-  const int ndst = (r1 - r0) * w;
+  const int nrow = r1 - r0;
   const int* dp = g.fdst_ptr + dptr0;
-  const bool dp_vec = (ndst + 1 <= 64);
-  const int dpv = (dp_vec && lane <= ndst) ? dp[lane] : 0;
+  const bool dp_vec = (nrow + 1 <= 64);
+  const int dpv = (dp_vec && lane <= nrow) ? dp[lane] : 0;
   double* Udst = g.U + ((size_t)g.piv_uoff[p] + (size_t)r0 * w) * bpad + b;
-  double* Tmd = g.Tm + (size_t)g.piv_boff[p] * bpad + b;
-  const int nblk = (r0 < w) ? (w - r0) * w : 0;      // leading destinations that belong to the pivot block
+  double* Tmd = g.Tm + ((size_t)g.piv_boff[p] + (size_t)r0 * w) * bpad + b;
+  const int nblk = (r0 < w) ? (w - r0) : 0;          // leading destination rows that belong to the pivot block
   double tmax_diag = 0.0;
-  double acc = 0.0, tmax = 0.0;
+  double acc[WM], tmax[WM];
+#pragma unroll
+  for (int q = 0; q < WM; ++q) { acc[q] = 0.0; tmax[q] = 0.0; }
   int d = 0;
   const int E0 = dp_vec ? bcast(dpv, 0) : dp[0];
-  const int E1 = dp_vec ? bcast(dpv, ndst) : dp[ndst];
-  int dend = (ndst > 0) ? (dp_vec ? bcast(dpv, 1) : dp[1]) : 0x7fffffff;
+  const int E1 = dp_vec ? bcast(dpv, nrow) : dp[nrow];
+  int dend = (nrow > 0) ? (dp_vec ? bcast(dpv, 1) : dp[1]) : 0x7fffffff;
 #define PP_FINALIZE()                                                                      \
   do {                                                                                     \
-    Udst[(size_t)d * bpad] = acc;                                                          \
-    if (d < nblk) {                                                                        \
-      if (kind == 0) Tmd[(size_t)(r0 * w + d) * bpad] = tmax; else tmax_diag = fmax(tmax_diag, tmax); \
+    _Pragma("unroll") for (int q = 0; q < WM; ++q) {                                       \
+      if (q < w) {                                                                         \
+        Udst[(size_t)(d * w + q) * bpad] = acc[q];                                         \
+        if (d < nblk) {                                                                    \
+          if (kind == 0) Tmd[(size_t)(d * w + q) * bpad] = tmax[q]; else tmax_diag = fmax(tmax_diag, tmax[q]); \
+        }                                                                                  \
+      }                                                                                    \
+      acc[q] = 0.0; tmax[q] = 0.0;                                                         \
     }                                                                                      \
-    acc = 0.0; tmax = 0.0; ++d;                                                            \
-    dend = (d < ndst) ? (dp_vec ? bcast(dpv, d + 1) : dp[d + 1]) : 0x7fffffff;             \
+    ++d;                                                                                   \
+    dend = (d < nrow) ? (dp_vec ? bcast(dpv, d + 1) : dp[d + 1]) : 0x7fffffff;             \
   } while (0)
   for (int eb = E0; eb < E1; eb += 64) {
     const int cnt = min(64, E1 - eb);
-    int2 rec = make_int2(0, -1);
-    if (lane < cnt) rec = *reinterpret_cast<const int2*>(g.fent + 2 * (size_t)(eb + lane));
+    int4 rec = make_int4(0, 0, 0, 0);
+    if (lane < cnt) rec = *reinterpret_cast<const int4*>(g.fent + 4 * (size_t)(eb + lane));
 #define PP_GROUP(G)                                                                        \
   {                                                                                        \
-    int eu[G], el[G];                                                                      \
+    int eu[G], el[G], ew[G], eq[G];                                                        \
     _Pragma("unroll") for (int i = 0; i < G; ++i) {                                        \
-      const int q = min(i0 + i, cnt - 1);                                                  \
-      eu[i] = bcast(rec.x, q); el[i] = bcast(rec.y, q);                                    \
+      const int qi = min(i0 + i, cnt - 1);                                                 \
+      eu[i] = bcast(rec.x, qi); el[i] = bcast(rec.y, qi);                                  \
+      if (WM > 1) { ew[i] = bcast(rec.z, qi); eq[i] = bcast(rec.w, qi); } else { ew[i] = 0; eq[i] = 0; } \
     }                                                                                      \
-    double term[G];                                                                        \
-    {                                                                                      \
-      double su[G], sl[G];                                                                 \
-      _Pragma("unroll") for (int i = 0; i < G; ++i) {                                      \
-        const double* base = (eu[i] >= 0) ? U : R;                                         \
-        const int idx = (eu[i] >= 0) ? eu[i] : (-1 - eu[i]);                               \
-        su[i] = base[(size_t)idx * bpad];                                                  \
-        sl[i] = (el[i] >= 0) ? Lb[(size_t)el[i] * bpad] : -1.0;                            \
-      }                                                                                    \
-      _Pragma("unroll") for (int i = 0; i < G; ++i) term[i] = (i0 + i < cnt) ? su[i] * sl[i] : 0.0; \
+    double su[G], sl[G][WM];                                                               \
+    _Pragma("unroll") for (int i = 0; i < G; ++i) {                                        \
+      const double* base = (eu[i] >= 0) ? U : R;                                           \
+      const int idx = (eu[i] >= 0) ? eu[i] : (-1 - eu[i]);                                 \
+      su[i] = base[(size_t)idx * bpad];                                                    \
+      _Pragma("unroll") for (int q = 0; q < WM; ++q)                                       \
+        sl[i][q] = Lb[(size_t)(el[i] + min(q, w - 1) * ew[i]) * bpad];                     \
     }                                                                                      \
     _Pragma("unroll") for (int i = 0; i < G; ++i) {                                        \
       if (i0 + i < cnt) {                                                                  \
         while (eb + i0 + i == dend) PP_FINALIZE();                                         \
-        acc -= term[i];                                                                    \
-        tmax = fmax(tmax, fabs(term[i]));                                                  \
+        _Pragma("unroll") for (int q = 0; q < WM; ++q) {                                   \
+          const double m = (eu[i] >= 0) ? ((q < w) ? sl[i][q] : 0.0) : ((q == eq[i]) ? -1.0 : 0.0); \
+          const double term = su[i] * m;                                                   \
+          acc[q] -= term;                                                                  \
+          tmax[q] = fmax(tmax[q], fabs(term));                                             \
+        }                                                                                  \
       }                                                                                    \
     }                                                                                      \
   }
     int i0 = 0;
-    for (; cnt - i0 > 4; i0 += 16) PP_GROUP(16)
+    constexpr int GB = (WM == 1) ? 16 : 8;
+    for (; cnt - i0 > 4; i0 += GB) PP_GROUP(GB)
     if (i0 < cnt) PP_GROUP(4)
 #undef PP_GROUP
   }
-  while (d < ndst) PP_FINALIZE();
+  while (d < nrow) PP_FINALIZE();
 #undef PP_FINALIZE
   if (kind == 1) invert_and_scale<WM>(g, p, w, r0, r1, tmax_diag, true, bpad, b, eps);
 }
@@ -237,41 +254,56 @@ __global__ __launch_bounds__(64) void k_gather_level_lean(GroupDev g, int task0,
   const size_t bpad = (size_t)g.bpad;
   const int* t = g.ftask + 5 * (size_t)(task0 + blockIdx.x);
   const int p = t[0], r0 = t[1], r1 = t[2], dptr0 = t[3], kind = t[4];
-  const int w = g.piv_w[p];
+  const int w = (WM == 1) ? 1 : g.piv_w[p];
   const double* __restrict__ U = g.U + b;
   const double* __restrict__ Lb = g.L + b;
   const double* __restrict__ R = g.rawT + b;
-  const int ndst = (r1 - r0) * w;
+  const int nrow = r1 - r0;
   const int* dp = g.fdst_ptr + dptr0;
   double* Udst = g.U + ((size_t)g.piv_uoff[p] + (size_t)r0 * w) * bpad + b;
-  double* Tmd = g.Tm + (size_t)g.piv_boff[p] * bpad + b;
+  double* Tmd = g.Tm + ((size_t)g.piv_boff[p] + (size_t)r0 * w) * bpad + b;
   double* Ldst = g.L + ((size_t)g.piv_uoff[p] + (size_t)r0 * w) * bpad + b;
-  const int nblk = (r0 < w) ? (w - r0) * w : 0;
+  const int nblk = (r0 < w) ? (w - r0) : 0;
   double tmax_diag = 0.0, inv1 = 0.0;
-  for (int d = 0; d < ndst; ++d) {
-    double acc = 0.0, tmax = 0.0;
+  for (int d = 0; d < nrow; ++d) {
+    double acc[WM], tmax[WM];
+#pragma unroll
+    for (int q = 0; q < WM; ++q) { acc[q] = 0.0; tmax[q] = 0.0; }
     for (int e = dp[d]; e < dp[d + 1]; ++e) {
-      const int eu = g.fent[2 * (size_t)e], el = g.fent[2 * (size_t)e + 1];
-      const double su = (eu >= 0) ? U[(size_t)eu * bpad] : R[(size_t)(-1 - eu) * bpad];
-      const double sl = (el >= 0) ? Lb[(size_t)el * bpad] : -1.0;
-      const double term = su * sl;
-      acc -= term;
-      tmax = fmax(tmax, fabs(term));
+      // scalar (SMEM) record reads; the operand base is chosen by offset, not by pointer select
+      const int* rp = g.fent + 4 * (size_t)e;
+      const int ex = rp[0], ey = rp[1], ez = rp[2], ew = rp[3];
+      const double su = (ex >= 0) ? U[(size_t)ex * bpad] : R[(size_t)(-1 - ex) * bpad];
+#pragma unroll
+      for (int q = 0; q < WM; ++q) {
+        const double lv = Lb[(size_t)(ey + min(q, w - 1) * ez) * bpad];
+        const double m = (ex >= 0) ? ((q < w) ? lv : 0.0) : ((q == ew) ? -1.0 : 0.0);
+        const double term = su * m;
+        acc[q] -= term;
+        tmax[q] = fmax(tmax[q], fabs(term));
+      }
     }
-    Udst[(size_t)d * bpad] = acc;
+#pragma unroll
+    for (int q = 0; q < WM; ++q)
+      if (q < w) Udst[(size_t)(d * w + q) * bpad] = acc[q];
     if (WM == 1 && kind == 1) {
-      // scalar pivot, fused panel: destination 0 is the pivot, every later one a row to scale
+      // scalar pivot, fused panel: row 0 is the pivot, every later one a row to scale
       if (d == 0) {
-        const pp::PivotResult pr = pp::invert_pivot(1, acc, 0.0, 0.0, tmax, eps);
+        const pp::PivotResult pr = pp::invert_pivot(1, acc[0], 0.0, 0.0, tmax[0], eps);
         inv1 = pr.i00;
         g.Dinv[(size_t)g.piv_doff[p] * bpad + b] = inv1;
         const int code = (pr.code & 3) | (((pr.code >> 2) & 3) << 4) | (((pr.code >> 4) & 3) << 8);
         g.codes[(size_t)p * bpad + b] = (b < g.batch) ? (unsigned short)code : (unsigned short)0;
       } else {
-        Ldst[(size_t)d * bpad] = acc * inv1;
+        Ldst[(size_t)d * bpad] = acc[0] * inv1;
       }
     } else if (d < nblk) {
-      if (kind == 0) Tmd[(size_t)(r0 * w + d) * bpad] = tmax; else tmax_diag = fmax(tmax_diag, tmax);
+#pragma unroll
+      for (int q = 0; q < WM; ++q) {
+        if (q < w) {
+          if (kind == 0) Tmd[(size_t)(d * w + q) * bpad] = tmax[q]; else tmax_diag = fmax(tmax_diag, tmax[q]);
+        }
+      }
     }
   }
   if (WM != 1 && kind == 1) invert_and_scale<WM>(g, p, w, r0, r1, tmax_diag, true, bpad, b, eps);
@@ -826,6 +858,7 @@ struct Group {
   std::vector<void*> allocs;
   int ntiles = 0;
   double *raw_own = nullptr, *rhs_own = nullptr;
+  int nraw_used = 0;
   std::vector<int> level_maxw;   // widest block pivot per level (selects the scalar kernel variants)
 };
 
@@ -1080,29 +1113,37 @@ int pp_end_symbolic(pp_handle h) {
     for (int pp_ = 0; pp_ < P.npiv; ++pp_)
       g->level_maxw[P.piv_level[pp_]] = std::max(g->level_maxw[P.piv_level[pp_]], P.piv_w[pp_]);
     std::vector<int> ftask, stask, fdst_ptr, fent, srec;
+    // raw entries that some canonical entry reads get a compact row in the transposed buffer; the rest
+    // (typically the upper-triangle half) are never written
+    std::vector<int> rawmap((size_t)std::max(g->nraw, 1), -1);
+    int nused = 0;
+    for (int v : g->can_idx) if (rawmap[v] < 0) rawmap[v] = nused++;
+    g->nraw_used = nused;
     // expand the canonical initial-value entries into raw-value entries (duplicates are summed)
     fdst_ptr.reserve(P.fdst_ptr.size());
-    fent.reserve(P.fentries.size() * 2 + 16);
+    fent.reserve(P.fentries.size() * 4 + 64);
     ftask.reserve(P.ftasks.size() * 5);
     for (auto& t : P.ftasks) {
-      const int ndst = (t.r1 - t.r0) * P.piv_w[t.piv];
+      const int nrow = t.r1 - t.r0;
       const int new_dptr0 = (int)fdst_ptr.size();
-      for (int dd = 0; dd < ndst; ++dd) {
-        fdst_ptr.push_back((int)(fent.size() / 2));
+      for (int dd = 0; dd < nrow; ++dd) {
+        fdst_ptr.push_back((int)(fent.size() / 4));
         for (int e = P.fdst_ptr[t.dptr0 + dd]; e < P.fdst_ptr[t.dptr0 + dd + 1]; ++e) {
           const pp::FEntry& fe = P.fentries[e];
-          if (fe.u >= 0) { fent.push_back(fe.u); fent.push_back(fe.l); }
+          if (fe.u >= 0) fent.insert(fent.end(), {fe.u, fe.l, fe.wk, 0});
           else {
+            // the L index of an initial-value record is a dummy (position 0, always valid)
             const int ce = -1 - fe.u;
-            for (int q = g->can_ptr[ce]; q < g->can_ptr[ce + 1]; ++q) { fent.push_back(-1 - g->can_idx[q]); fent.push_back(fe.l); }
+            for (int q = g->can_ptr[ce]; q < g->can_ptr[ce + 1]; ++q)
+              fent.insert(fent.end(), {-1 - rawmap[g->can_idx[q]], 0, 0, fe.q});
           }
         }
       }
-      fdst_ptr.push_back((int)(fent.size() / 2));
+      fdst_ptr.push_back((int)(fent.size() / 4));
       ftask.insert(ftask.end(), {t.piv, t.r0, t.r1, new_dptr0, t.kind});
     }
     for (auto& t : P.stasks) stask.insert(stask.end(), {t.piv, t.r0, t.r1, -1, t.kind});
-    for (int q = 0; q < 16; ++q) { fent.push_back(0); fent.push_back(-1); }   // slack for the vector record reads
+    for (int q = 0; q < 16; ++q) fent.insert(fent.end(), {0, 0, 0, 0});   // slack for the vector record reads
     for (auto& r : P.stile_rec) {
       srec.push_back(r.piv);
       for (int q = 0; q < 8; ++q) srec.push_back(r.slotA[q]);
@@ -1122,6 +1163,7 @@ int pp_end_symbolic(pp_handle h) {
     if ((rc = dev_upload(h, g, &d.rowidx, P.rowidx))) return rc;
     if ((rc = dev_upload(h, g, &d.perm, P.perm))) return rc;
     if ((rc = dev_upload(h, g, &d.iperm, P.iperm))) return rc;
+    if ((rc = dev_upload(h, g, &d.rawmap, rawmap))) return rc;
     if ((rc = dev_upload(h, g, &d.ftask, ftask))) return rc;
     if ((rc = dev_upload(h, g, &d.stask, stask))) return rc;
     if ((rc = dev_upload(h, g, &d.fdst_ptr, fdst_ptr))) return rc;
@@ -1145,7 +1187,7 @@ int pp_end_symbolic(pp_handle h) {
     const size_t bp = (size_t)d.bpad;
     if ((rc = dev_alloc(h, g, &d.raw, (size_t)g->batch * g->nraw))) return rc;
     g->raw_own = d.raw;
-    if ((rc = dev_alloc(h, g, &d.rawT, (size_t)g->nraw * bp))) return rc;
+    if ((rc = dev_alloc(h, g, &d.rawT, (size_t)std::max(g->nraw_used, 1) * bp))) return rc;
     if ((rc = dev_alloc(h, g, &d.U, (size_t)P.usize * bp))) return rc;
     if ((rc = dev_alloc(h, g, &d.Dinv, (size_t)P.dsize * bp))) return rc;
     if ((rc = dev_alloc(h, g, &d.L, (size_t)P.usize * bp))) return rc;
@@ -1218,8 +1260,8 @@ int pp_numeric_local(pp_handle h) {
     {
       PhaseScope ps(h, 0, 1);
       if (d.nraw > 0)
-        hipLaunchKernelGGL(k_transpose_in, dim3((d.nraw + 63) / 64, d.nchunk), dim3(256), 0, st, d.raw, d.rawT, d.batch,
-                           d.nraw, d.bpad);
+        hipLaunchKernelGGL(k_transpose_in, dim3((d.nraw + 63) / 64, d.nchunk), dim3(256), 0, st, d.raw, d.rawT, d.rawmap,
+                           d.batch, d.nraw, d.bpad);
     }
     {
       int nlaunch = 0;
@@ -1235,15 +1277,19 @@ int pp_numeric_local(pp_handle h) {
         for (int q = 0; q < sp.n; ++q) {
           const int ny = sp.c0[q + 1] - sp.c0[q];
           if (nt > 0) {
-            const bool lean = P.flevel_maxent[l] <= 12, scalar = g->level_maxw[l] == 1;
-            if (lean && scalar)
-              hipLaunchKernelGGL(k_gather_level_lean<1>, dim3(nt, ny), dim3(64), 0, fan[q], d, t0, sp.c0[q], PIVOT_EPS);
-            else if (lean)
-              hipLaunchKernelGGL(k_gather_level_lean<PP_WMAX>, dim3(nt, ny), dim3(64), 0, fan[q], d, t0, sp.c0[q], PIVOT_EPS);
-            else if (scalar)
-              hipLaunchKernelGGL(k_gather_level<1>, dim3(nt, ny), dim3(64), 0, fan[q], d, t0, sp.c0[q], PIVOT_EPS);
-            else
-              hipLaunchKernelGGL(k_gather_level<PP_WMAX>, dim3(nt, ny), dim3(64), 0, fan[q], d, t0, sp.c0[q], PIVOT_EPS);
+            const bool lean = P.flevel_maxent[l] <= 12;
+            const int mw = g->level_maxw[l];
+#define PP_LAUNCH_GATHER(K, WM) hipLaunchKernelGGL(K<WM>, dim3(nt, ny), dim3(64), 0, fan[q], d, t0, sp.c0[q], PIVOT_EPS)
+            if (lean) {
+              if (mw == 1) PP_LAUNCH_GATHER(k_gather_level_lean, 1);
+              else if (mw == 2) PP_LAUNCH_GATHER(k_gather_level_lean, 2);
+              else PP_LAUNCH_GATHER(k_gather_level_lean, PP_WMAX);
+            } else {
+              if (mw == 1) PP_LAUNCH_GATHER(k_gather_level, 1);
+              else if (mw == 2) PP_LAUNCH_GATHER(k_gather_level, 2);
+              else PP_LAUNCH_GATHER(k_gather_level, PP_WMAX);
+            }
+#undef PP_LAUNCH_GATHER
           }
           if (ns > 0) hipLaunchKernelGGL(k_scale_level, dim3(ns, ny), dim3(64), 0, fan[q], d, s0, sp.c0[q], PIVOT_EPS);
         }
@@ -1354,8 +1400,8 @@ int pp_solve_forward(pp_handle h) {
     GroupDev& d = g->dev;
     {
       PhaseScope ps(h, 4, P.n_levels + 1);
-      hipLaunchKernelGGL(k_transpose_in, dim3((P.n + 63) / 64, d.nchunk), dim3(256), 0, st, d.rhs, d.rhsT, d.batch, P.n,
-                         d.bpad);
+      hipLaunchKernelGGL(k_transpose_in, dim3((P.n + 63) / 64, d.nchunk), dim3(256), 0, st, d.rhs, d.rhsT,
+                         (const int*)nullptr, d.batch, P.n, d.bpad);
       // (a persistent one-workgroup-per-chunk kernel for the small top levels was measured slower than
       // per-level launches: 16 waves on one CU serialise their memory round trips)
       const Splits sp = make_splits(h, d.nchunk);
@@ -1550,6 +1596,20 @@ int pp_group_perm(pp_handle h, int group, int32_t* perm) {
   Group* g = get_group(h, group);
   if (!g) return fail(h, 3, "pp_group_perm: bad group");
   std::memcpy(perm, g->plan.perm.data(), sizeof(int) * g->plan.n);
+  return 0;
+}
+
+int pp_get_factor(pp_handle h, int group, int which, int instance, double* out, int64_t count) {
+  Group* g = get_group(h, group);
+  if (!g) return fail(h, 3, "pp_get_factor: bad group");
+  const GroupDev& d = g->dev;
+  const double* src = which == 0 ? d.U : which == 1 ? d.L : which == 2 ? d.Dinv : which == 3 ? d.rawT : nullptr;
+  const int64_t rows = which == 2 ? g->plan.dsize : which == 3 ? g->nraw_used : g->plan.usize;
+  if (!src || instance < 0 || instance >= d.batch || count > rows) return fail(h, 3, "pp_get_factor: bad arguments");
+  PP_HIP(hipSetDevice(h->device));
+  PP_HIP(hipStreamSynchronize(h->stream));
+  PP_HIP(hipMemcpy2D(out, sizeof(double), src + instance, sizeof(double) * (size_t)d.bpad, sizeof(double), (size_t)count,
+                     hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -459,17 +459,18 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
     size_t can_cursor = 0;  // panels are visited in increasing U position
     struct TmpTask { FTask t; int level; };
     std::vector<TmpTask> gtasks, sctasks;
-    std::vector<std::vector<FEntry>> dst_ents;   // per destination scalar (slot * w + q) of panel p
+    std::vector<std::vector<FEntry>> row_ents;   // per destination row (slot) of panel p
     for (int p = 0; p < P.npiv; ++p) {
       const int w = P.piv_w[p], p0 = P.piv_start[p];
       const int f = w + (int)rows[p].size();
-      dst_ents.assign((size_t)f * w, {});
+      row_ents.assign((size_t)f, {});
       // initial values: canonical entries located in this panel
       const int64_t u0 = P.piv_uoff[p], u1 = u0 + (int64_t)f * w;
       int64_t total = 0;
       while (can_cursor < can_by_pos.size() && can_by_pos[can_cursor].first < u1) {
         if (can_by_pos[can_cursor].first >= u0) {
-          dst_ents[(size_t)(can_by_pos[can_cursor].first - u0)].push_back({-1 - can_by_pos[can_cursor].second, -1});
+          const int64_t rel = can_by_pos[can_cursor].first - u0;
+          row_ents[(size_t)(rel / w)].push_back({-1 - can_by_pos[can_cursor].second, -1, 0, (int)(rel % w)});
           ++total;
         }
         ++can_cursor;
@@ -488,12 +489,11 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
             d = w + (int)tp;
           }
           const int srow = wk + (int)t;
-          for (int q = 0; q < w; ++q)
-            for (int tt = 0; tt < wk; ++tt)
-              dst_ents[(size_t)d * w + q].push_back({(int)(P.piv_uoff[k] + (int64_t)srow * wk + tt),
-                                                     (int)(P.piv_uoff[k] + (int64_t)(mslot + q) * wk + tt)});
+          for (int tt = 0; tt < wk; ++tt)
+            row_ents[(size_t)d].push_back({(int)(P.piv_uoff[k] + (int64_t)srow * wk + tt),
+                                           (int)(P.piv_uoff[k] + (int64_t)mslot * wk + tt), wk, 0});
           P.flops_factor += (int64_t)wk * w;
-          total += (int64_t)wk * w;
+          total += wk;
         }
       }
       const bool in_tail = P.piv_level[p] >= P.tail_level0;
@@ -502,12 +502,11 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
         TmpTask tt;
         tt.level = P.piv_level[p];
         tt.t.piv = p; tt.t.r0 = r0; tt.t.r1 = r1; tt.t.kind = kind; tt.t.dptr0 = (int)P.fdst_ptr.size();
-        for (int rr = r0; rr < r1; ++rr)
-          for (int q = 0; q < w; ++q) {
-            P.fdst_ptr.push_back((int)P.fentries.size());
-            const auto& de = dst_ents[(size_t)rr * w + q];
-            P.fentries.insert(P.fentries.end(), de.begin(), de.end());
-          }
+        for (int rr = r0; rr < r1; ++rr) {
+          P.fdst_ptr.push_back((int)P.fentries.size());
+          const auto& de = row_ents[(size_t)rr];
+          P.fentries.insert(P.fentries.end(), de.begin(), de.end());
+        }
         P.fdst_ptr.push_back((int)P.fentries.size());
         gtasks.push_back(tt);
       };
@@ -518,8 +517,7 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
         while (r < f) {                                  // gather chunks over all slots
           int nent = 0, r_end = r;
           while (r_end < f) {
-            int add = 0;
-            for (int q = 0; q < w; ++q) add += (int)dst_ents[(size_t)r_end * w + q].size();
+            const int add = (int)row_ents[(size_t)r_end].size();
             if (r_end > r && nent + add > cap_e) break;
             nent += add;
             ++r_end;
@@ -546,8 +544,8 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
     for (auto& t : gtasks) {
       P.ftasks.push_back(t.t);
       P.flevel_ptr[t.level + 1]++;
-      const int ndst = (t.t.r1 - t.t.r0) * P.piv_w[t.t.piv];
-      const int ne = P.fdst_ptr[t.t.dptr0 + ndst] - P.fdst_ptr[t.t.dptr0];
+      const int nrow = t.t.r1 - t.t.r0;
+      const int ne = P.fdst_ptr[t.t.dptr0 + nrow] - P.fdst_ptr[t.t.dptr0];
       P.flevel_maxent[t.level] = std::max(P.flevel_maxent[t.level], ne);
     }
     for (auto& t : sctasks) { P.stasks.push_back(t.t); P.slevel_ptr[t.level + 1]++; }

@@ -131,6 +131,10 @@ class HipEngine(object):
         ns.check(lib.pp_bind_rs_buffer(ns.h, self._rs_t.data_ptr()), 'pp_bind_rs_buffer')
         return [ns.group_stats(i) for i in range(len(groups))]
 
+    def get_factor(self, gid, which, instance, count):
+        """Diagnostic: factor storage of one block (0 = U panels, 1 = L rows, 2 = pivot inverses)."""
+        return self.ns.get_factor(gid, which, instance, count)
+
     def upload_values(self, gid, raw):
         self.ns.check(self.lib.pp_upload_values(self.ns.h, gid, raw.ctypes.data, 0), 'pp_upload_values')
 

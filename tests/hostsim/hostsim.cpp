@@ -74,9 +74,9 @@ void ppsim_task_profile(void* h, int* out /*5 per task*/) {
   Plan& P = *(Plan*)h;
   for (size_t t = 0; t < P.ftasks.size(); ++t) {
     const auto& ft = P.ftasks[t];
-    const int w = P.piv_w[ft.piv], ndst = (ft.r1 - ft.r0) * w;
-    out[5 * t] = P.piv_level[ft.piv]; out[5 * t + 1] = w; out[5 * t + 2] = ft.r1 - ft.r0;
-    out[5 * t + 3] = ft.kind; out[5 * t + 4] = P.fdst_ptr[ft.dptr0 + ndst] - P.fdst_ptr[ft.dptr0];
+    const int w = P.piv_w[ft.piv], nrow = ft.r1 - ft.r0;
+    out[5 * t] = P.piv_level[ft.piv]; out[5 * t + 1] = w; out[5 * t + 2] = nrow;
+    out[5 * t + 3] = ft.kind; out[5 * t + 4] = P.fdst_ptr[ft.dptr0 + nrow] - P.fdst_ptr[ft.dptr0];
   }
 }
 
@@ -113,26 +113,34 @@ int ppsim_factor(void* h, const double* can, double* U, double* L, double* Dinv,
     for (int ti = P.flevel_ptr[lvl]; ti < P.flevel_ptr[lvl + 1]; ++ti) {
       const auto& t = P.ftasks[ti];
       const int p = t.piv, w = P.piv_w[p];
-      const int64_t dst0 = P.piv_uoff[p] + (int64_t)t.r0 * w;
-      const int ndst = (t.r1 - t.r0) * w;
+      const int nrow = t.r1 - t.r0;
       double blk[PP_WMAX * PP_WMAX] = {0}, tmax_diag = 0.0, inv[PP_WMAX * (PP_WMAX + 1) / 2] = {0};
-      for (int d = 0; d < ndst; ++d) {
-        double acc = 0.0, tmax = 0.0;
-        for (int e = P.fdst_ptr[t.dptr0 + d]; e < P.fdst_ptr[t.dptr0 + d + 1]; ++e) {
+      for (int rr = 0; rr < nrow; ++rr) {
+        const int slot = t.r0 + rr;
+        double acc[PP_WMAX] = {0}, tmax[PP_WMAX] = {0};
+        for (int e = P.fdst_ptr[t.dptr0 + rr]; e < P.fdst_ptr[t.dptr0 + rr + 1]; ++e) {
           const auto& fe = P.fentries[e];
-          const double su = (fe.u >= 0) ? U[fe.u] : can[-1 - fe.u];
-          const double sl = (fe.l >= 0) ? L[fe.l] : -1.0;
-          const double term = su * sl;
-          acc -= term;
-          tmax = std::fmax(tmax, std::fabs(term));
+          if (fe.u < 0) {
+            const double v = can[-1 - fe.u];
+            acc[fe.q] += v;
+            tmax[fe.q] = std::fmax(tmax[fe.q], std::fabs(v));
+          } else {
+            const double su = U[fe.u];
+            for (int q = 0; q < w; ++q) {
+              const double term = su * L[fe.l + q * fe.wk];
+              acc[q] -= term;
+              tmax[q] = std::fmax(tmax[q], std::fabs(term));
+            }
+          }
         }
-        U[dst0 + d] = acc;
-        const int slot = t.r0 + d / w;
-        if (slot < w) {
-          if (t.kind == 0) Tm[P.piv_boff[p] + (slot * w + d % w)] = tmax;
-          else { blk[slot * PP_WMAX + d % w] = acc; tmax_diag = std::fmax(tmax_diag, tmax); }
+        for (int q = 0; q < w; ++q) {
+          U[P.piv_uoff[p] + (int64_t)slot * w + q] = acc[q];
+          if (slot < w) {
+            if (t.kind == 0) Tm[P.piv_boff[p] + (slot * w + q)] = tmax[q];
+            else { blk[slot * PP_WMAX + q] = acc[q]; tmax_diag = std::fmax(tmax_diag, tmax[q]); }
+          }
         }
-        if (t.kind == 1 && t.r0 + (d + 1) / w == w && (d + 1) % w == 0 && slot == w - 1) {
+        if (t.kind == 1 && slot == w - 1) {
           const int code = pp::invert_block(w, P.piv_sub[p], blk, tmax_diag, eps, inv);
           for (int q = 0; q < w * (w + 1) / 2; ++q) Dinv[P.piv_doff[p] + q] = inv[q];
           pos += code & 15; neg += (code >> 4) & 15; zero += (code >> 8) & 15;
