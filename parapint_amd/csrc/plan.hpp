@@ -31,13 +31,14 @@
 namespace pp {
 
 struct PlanOptions {
-  int max_task_entries = 96;   // entries per factor task: smaller panels are one fused task, bigger ones are chunked
-  int scale_task_rows = 32;    // rows per scale task of a big panel
+  int max_task_entries = 24;   // entries per gather chunk of a big panel
+  int fuse_task_entries = 24;  // panels with at most this many entries are one fused task (gather + invert + scale)
+  int scale_task_rows = 8;     // rows per scale task of a big panel
   // Top of the elimination tree ("tail"): levels holding at most tail_piv_max pivots each are run
   // inside ONE persistent launch per phase (a workgroup per 64 instances, barrier per level), with
   // smaller tasks so that the few waves of that workgroup share the work.
   int tail_piv_max = 48;
-  int tail_task_entries = 48;
+  int tail_task_entries = 16;
   int tile = 8;           // register tile edge of the Schur (SYRK) kernel
   int sn_wmax = 4;        // widest supernode (columns); 1 disables merging of sub-pivots (wider blocks need the
                           // per-source block multiplier path)

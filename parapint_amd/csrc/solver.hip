@@ -16,8 +16,10 @@
 //   k_bwd_level                   back substitution with x_c            (mpi_...:393-396)
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -353,6 +355,21 @@ __global__ __launch_bounds__(256) void k_count_codes(const unsigned short* __res
     __syncthreads();
   }
   if (threadIdx.x < 3 && red[threadIdx.x][0] != 0) atomicAdd(&counters[threadIdx.x], red[threadIdx.x][0]);
+}
+
+// Status mailbox: block counters (S tail after the all-reduce) + dense-factor counters -> pinned host
+// memory, sequence word last (LinearSolverStatus / get_inertia read-back, mpi_...:19-30, 417-436).
+__global__ void k_publish_status(const double* __restrict__ tail, const int* __restrict__ bk, long long* out,
+                                 long long seq) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const long long zero = (long long)(tail[0] + 0.5) + bk[2];
+    out[1] = (long long)(tail[1] + 0.5) + bk[0];
+    out[2] = (long long)(tail[2] + 0.5) + bk[1];
+    out[3] = zero;
+    out[0] = zero > 0 ? 2 : 0;
+    __threadfence_system();
+    __hip_atomic_store(out + 4, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -875,6 +892,11 @@ struct pp_solver {
   int dense_policy = 0;   // 0 auto (optimistic blocked LDL^T, Bunch-Kaufman fallback), 1 Bunch-Kaufman only
   double *rs = nullptr, *rs_own = nullptr, *rcd = nullptr, *xc = nullptr;
   int *ipiv = nullptr, *bkinfo = nullptr, *counters = nullptr;
+  // status mailbox in pinned, device-mapped host memory: {status, pos, neg, zero, sequence}; the last
+  // kernel of pp_factor_schur writes it, pp_get_status polls the sequence word (no stream sync, no copies)
+  volatile long long* status_host = nullptr;
+  long long* status_dev = nullptr;
+  long long status_seq = 0;
   double mem_factor = 1.0;
   std::string err;
   // Instance groups ("splits"): the level sweeps of disjoint 64-instance chunk ranges are
@@ -1011,6 +1033,9 @@ void free_globals(pp_handle h) {
   h->S = h->S_own = h->Sfac = h->Sldl = h->dvec = h->Qd = h->work = h->rs = h->rs_own = h->rcd = h->xc = nullptr;
   h->dense_mode = nullptr;
   h->ipiv = h->bkinfo = h->counters = nullptr;
+  if (h->status_host) (void)hipHostFree((void*)h->status_host);
+  h->status_host = nullptr;
+  h->status_dev = nullptr;
 }
 
 }  // namespace
@@ -1083,6 +1108,30 @@ int pp_add_group(pp_handle h, int n, int batch, int nnzK, const int32_t* rowK, c
   pp::PlanOptions opt;
   if (h->sn_wmax > 0) opt.sn_wmax = h->sn_wmax;
   if (h->sn_tol >= 0) opt.sn_tol_rows = h->sn_tol;
+  if (const char* tune = std::getenv("PP_PLAN_TUNE")) {
+    // developer knob for schedule experiments: "max_task_entries=48,scale_task_rows=16,..."
+    std::string t(tune);
+    size_t pos = 0;
+    while (pos < t.size()) {
+      size_t end = t.find(',', pos);
+      if (end == std::string::npos) end = t.size();
+      const std::string kv = t.substr(pos, end - pos);
+      const size_t eq = kv.find('=');
+      if (eq != std::string::npos) {
+        const std::string k = kv.substr(0, eq);
+        const double v = std::atof(kv.c_str() + eq + 1);
+        if (k == "max_task_entries") opt.max_task_entries = (int)v;
+        else if (k == "fuse_task_entries") opt.fuse_task_entries = (int)v;
+        else if (k == "scale_task_rows") opt.scale_task_rows = (int)v;
+        else if (k == "tail_task_entries") opt.tail_task_entries = (int)v;
+        else if (k == "tail_piv_max") opt.tail_piv_max = (int)v;
+        else if (k == "md_delta_abs") opt.md_delta_abs = (int)v;
+        else if (k == "md_delta_rel") opt.md_delta_rel = v;
+        else return fail(h, 3, "PP_PLAN_TUNE: unknown key " + k);
+      }
+      pos = end + 1;
+    }
+  }
   int rc = pp::build_plan(n, h->nc, nnzK, rowK, colK, nnzB, rowB, colB, rep_vals, opt, g->plan);
   if (rc != 0) { std::string e = g->plan.error; delete g; return fail(h, rc, "symbolic analysis failed: " + e); }
   const int ncan = nnzK + nnzB;
@@ -1191,6 +1240,8 @@ int pp_end_symbolic(pp_handle h) {
     if ((rc = dev_alloc(h, g, &d.U, (size_t)P.usize * bp))) return rc;
     if ((rc = dev_alloc(h, g, &d.Dinv, (size_t)P.dsize * bp))) return rc;
     if ((rc = dev_alloc(h, g, &d.L, (size_t)P.usize * bp))) return rc;
+    // the pivot-block slots of L are never written (only the rows below the block are): define them once
+    PP_HIP(hipMemset(d.L, 0, (size_t)P.usize * bp * sizeof(double)));
     if ((rc = dev_alloc(h, g, &d.Tm, (size_t)std::max(P.bsize, 1) * bp))) return rc;
     if ((rc = dev_alloc(h, g, &d.Y, (size_t)(P.n + nc) * bp))) return rc;
     if ((rc = dev_alloc(h, g, &d.X, (size_t)P.n * bp))) return rc;
@@ -1218,6 +1269,16 @@ int pp_end_symbolic(pp_handle h) {
   if ((rc = dev_alloc<int>(h, nullptr, &h->ipiv, nc))) return rc;
   if ((rc = dev_alloc<int>(h, nullptr, &h->bkinfo, 4))) return rc;
   if ((rc = dev_alloc<int>(h, nullptr, &h->counters, 4))) return rc;
+  {
+    void* hp = nullptr;
+    void* dp = nullptr;
+    PP_HIP(hipHostMalloc(&hp, 8 * sizeof(long long), hipHostMallocMapped));
+    std::memset(hp, 0, 8 * sizeof(long long));
+    PP_HIP(hipHostGetDevicePointer(&dp, hp, 0));
+    h->status_host = (volatile long long*)hp;
+    h->status_dev = (long long*)dp;
+    h->status_seq = 0;
+  }
   h->S = h->S_own;
   h->rs = h->rs_own;
   PP_HIP(hipMemset(h->S, 0, (nn + 4) * sizeof(double)));
@@ -1345,6 +1406,7 @@ int pp_factor_schur(pp_handle h, const double* Q_host) {
   } else {
     PP_HIP(hipMemsetAsync(h->bkinfo, 0, 4 * sizeof(int), st));
   }
+  hipLaunchKernelGGL(k_publish_status, dim3(1), dim3(64), 0, st, h->S + nn, h->bkinfo, h->status_dev, ++h->status_seq);
   PP_HIP(hipGetLastError());
   h->schur_done = true;
   return 0;
@@ -1353,16 +1415,22 @@ int pp_factor_schur(pp_handle h, const double* Q_host) {
 int pp_get_status(pp_handle h, int64_t out[4]) {
   if (!h || !h->schur_done) return fail(h, 3, "pp_get_status before pp_factor_schur");
   PP_HIP(hipSetDevice(h->device));
-  double tail[4];
-  int bk[4];
-  PP_HIP(hipMemcpyAsync(tail, h->S + (size_t)h->nc * h->nc, sizeof(tail), hipMemcpyDeviceToHost, h->stream));
-  PP_HIP(hipMemcpyAsync(bk, h->bkinfo, sizeof(bk), hipMemcpyDeviceToHost, h->stream));
-  PP_HIP(hipStreamSynchronize(h->stream));
-  const int64_t zero_blocks = (int64_t)(tail[0] + 0.5);
-  out[1] = (int64_t)(tail[1] + 0.5) + bk[0];
-  out[2] = (int64_t)(tail[2] + 0.5) + bk[1];
-  out[3] = zero_blocks + bk[2];
-  out[0] = (out[3] > 0) ? 2 : 0;
+  // poll the mailbox; after a bounded spin fall back to a stream synchronisation (which also surfaces
+  // an asynchronous device error instead of spinning on it)
+  const long long want = h->status_seq;
+  bool seen = false;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (long spin = 0;; ++spin) {
+    if (__atomic_load_n((const long long*)(h->status_host + 4), __ATOMIC_ACQUIRE) == want) { seen = true; break; }
+    if ((spin & 1023) == 1023 &&
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.25) break;
+  }
+  if (!seen) {
+    PP_HIP(hipStreamSynchronize(h->stream));
+    if (__atomic_load_n((const long long*)(h->status_host + 4), __ATOMIC_ACQUIRE) != want)
+      return fail(h, 3, "pp_get_status: status mailbox was not written");
+  }
+  for (int i = 0; i < 4; ++i) out[i] = (int64_t)h->status_host[i];
   return 0;
 }
 

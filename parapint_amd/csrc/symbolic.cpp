@@ -510,7 +510,7 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
         P.fdst_ptr.push_back((int)P.fentries.size());
         gtasks.push_back(tt);
       };
-      if (total <= opt.max_task_entries) {
+      if (total <= opt.fuse_task_entries) {
         emit(0, f, 1);                                   // fused small panel
       } else {
         int r = 0;

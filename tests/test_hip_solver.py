@@ -149,3 +149,37 @@ def test_block_pivots_on_device(wmax, tol):
     sc.case_heterogeneous(make)
     solver, model = sc.case_against_oracle(make, (16, 400, 4, 100), iteration=2)
     assert solver.plan_stats[0]['n_levels'] < 30
+
+
+@pytest.mark.parametrize('wmax', [1, 4])
+def test_device_factor_matches_host_interpreter(wmax):
+    """The factor storage itself (unscaled panels U, scaled rows L = the MA27 factor entries, block-pivot
+    inverses) of every block, read back through pp_get_factor, against the one-instance host interpreter of
+    the same plan (tests/hostsim) -- catches any device-side miscompile or indexing slip that the solution
+    alone could mask.  70 blocks = one full 64-instance wave + a ragged one."""
+    from hostsim_util import HostSim, lib as hostlib
+    from parapint_amd.linalg.hip_schur_complement import HipEngine
+    from parapint_amd.linalg.comm import SerialComm
+    from parapint_amd.examples.performance.schur_complement.synthetic_kkt import SyntheticKKT
+    N = 70
+    model = SyntheticKKT(N, 30, 2, 10)
+    kkt = model.build_kkt(comm=SerialComm(), iteration=2)
+    eng = HipEngine()
+    eng.set_supernodes(wmax, 1)
+    solver = sc.new_solver(lambda: eng, N)
+    solver.do_symbolic_factorization(kkt)
+    solver.do_numeric_factorization(kkt)
+    hostlib().ppsim_set_supernodes(wmax, 1)
+    try:
+        A = model.border_matrix()
+        hs = HostSim(model.block_matrix(0, 2), A)          # the group's plan is made on its first block
+        st = eng.ns.group_stats(0)
+        assert st['u_doubles'] == hs.stats['usize'] and st['n_pivots'] == hs.stats['npiv']
+        for inst in (0, 1, 37, 63, 64, 69):
+            rc, _, _ = hs.factor(hs.canonical(model.block_matrix(inst, 2), A))
+            assert rc == 0
+            for which, ref in ((0, hs.U), (1, hs.L), (2, hs.Dinv)):
+                dev = eng.get_factor(0, which, inst, ref.size)
+                assert np.abs(dev - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max()), (inst, which)
+    finally:
+        hostlib().ppsim_set_supernodes(0, -1)
