@@ -98,6 +98,12 @@ __global__ __launch_bounds__(256) void k_transpose_out(const double* __restrict_
 // loads of a whole task issue back to back (one memory latency) instead of being chained
 // behind per-batch scalar loads.
 __device__ __forceinline__ int bcast(int v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
+// wave-uniform broadcast of a double from a (wave-uniform) lane: two v_readlane_b32, no LDS crossbar
+__device__ __forceinline__ double bcastd(double v, int src_lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
 
 // inv(P) packed by rows of the lower triangle
 #define PP_INV(inv, i, j) ((inv)[((i) > (j) ? (i) * ((i) + 1) / 2 + (j) : (j) * ((j) + 1) / 2 + (i))])
@@ -507,7 +513,7 @@ __global__ __launch_bounds__(LDL_THREADS) void k_ldl_blocked(int n, double* __re
 #pragma unroll
       for (int k = 0; k < LDL_NB; ++k) {
         const double colk = row[k];
-        double d = __shfl(colk, k);
+        double d = bcastd(colk, k);
         if (k < nb) {
           if (!(fabs(d) > eps * anorm)) { bad = 1; d = (anorm > 0.0 ? anorm : 1.0); }
           signs |= (d > 0.0) ? 1 : 2;
@@ -515,11 +521,12 @@ __global__ __launch_bounds__(LDL_THREADS) void k_ldl_blocked(int n, double* __re
         const double lik = colk / d;
 #pragma unroll
         for (int j = k + 1; j < LDL_NB; ++j) {
-          const double ajk = __shfl(colk, j);
+          const double ajk = bcastd(colk, j);
           if (i >= j) row[j] -= lik * ajk;
         }
         if (i > k) row[k] = lik;
         else if (i == k) row[k] = d;
+        __builtin_amdgcn_sched_barrier(0);   // keep the broadcasts of later columns from being hoisted (SGPR pressure)
       }
       if (lane < nb) {
 #pragma unroll
@@ -606,6 +613,158 @@ __global__ __launch_bounds__(LDL_THREADS) void k_ldl_blocked(int n, double* __re
   }
 }
 
+// Register-resident variant for n <= 16 * LDLR_NT (= 208; the reference configurations have n_c = 200):
+// the whole lower triangle lives in the MFMA accumulators of the 8 waves (91 tiles of 16x16, <= 12 per
+// wave) for the entire factorisation, so a trailing update is LDS reads + fp64 MFMAs only -- no global
+// read-modify-write round trips inside the panel loop.  Per 32-column panel: the panel's tiles go to
+// LDS, wave 0 factors the diagonal block in registers (shuffle broadcasts), one thread per row solves
+// the panel against it, the finished columns are streamed to global memory (stores only), and every
+// wave updates the tiles it still owns.  Same acceptance rule and output format as k_ldl_blocked.
+constexpr int LDLR_NT = 13;
+constexpr int LDLR_TPW = 12;
+constexpr int LDLR_LD = 34;   // LDS row stride in doubles: conflict-free MFMA operand reads
+
+__global__ __launch_bounds__(LDL_THREADS) void k_ldl_regs(int n, double* __restrict__ A, double* __restrict__ dvec,
+                                                          int* __restrict__ mode, int* __restrict__ info, double eps) {
+  __shared__ double P[16 * LDLR_NT][LDLR_LD];
+  __shared__ double dl[LDL_NB], rdl[LDL_NB];
+  __shared__ double red[LDL_THREADS / 64];
+  __shared__ int sflags[2];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nwv = LDL_THREADS / 64;
+  const int li = lane & 15, lk = lane >> 4;
+  const size_t lda = (size_t)n;
+  const int nt = (n + 15) / 16, ntt = nt * (nt + 1) / 2;
+  double loc = 0.0;
+  for (int i = tid; i < n; i += LDL_THREADS) loc = fmax(loc, fabs(A[i + i * lda]));
+  // tiles of this wave: t = wv + 8 s  <->  (I >= J), t = I (I + 1) / 2 + J
+  double4_t acc[LDLR_TPW];
+  int tI[LDLR_TPW], tJ[LDLR_TPW];
+#pragma unroll
+  for (int s = 0; s < LDLR_TPW; ++s) {
+    const int t = wv + nwv * s;
+    int I = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((I + 1) * (I + 2) / 2 <= t) ++I;
+    while (I * (I + 1) / 2 > t) --I;
+    tI[s] = (t < ntt) ? I : -1;
+    tJ[s] = t - I * (I + 1) / 2;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * I + lk + 4 * r, col = 16 * tJ[s] + li;
+      acc[s][r] = (t < ntt && row < n && col < n) ? A[row + (size_t)col * lda] : 0.0;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) loc = fmax(loc, __shfl_xor(loc, off));
+  if (lane == 0) red[wv] = loc;
+  if (tid == 0) { sflags[0] = 0; sflags[1] = 0; }
+  __syncthreads();
+  double anorm = 0.0;
+  for (int q = 0; q < nwv; ++q) anorm = fmax(anorm, red[q]);
+  for (int j0 = 0; j0 < n; j0 += LDL_NB) {
+    const int nb = min(LDL_NB, n - j0), j1 = j0 + nb, m = n - j1;
+    // (a) the panel's tiles: accumulators -> LDS (rows relative to j0)
+#pragma unroll
+    for (int s = 0; s < LDLR_TPW; ++s) {
+      const int c0 = 16 * tJ[s] - j0;
+      if (tI[s] >= 0 && c0 >= 0 && c0 < nb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) P[16 * tI[s] + lk + 4 * r - j0][c0 + li] = acc[s][r];
+      }
+    }
+    __syncthreads();
+    // (b) diagonal block by wave 0: lane = row, the row lives in registers, column k is broadcast with
+    // v_readlane.  Mask-free: the strict upper triangle and, in a ragged last panel, rows/columns >= nb
+    // carry don't-care values that never reach a stored result; the unit diagonal is implicit (P[k][k] = 1).
+    if (wv == 0) {
+      double row[LDL_NB];
+      const int i = lane & 31;
+#pragma unroll
+      for (int j = 0; j < LDL_NB; ++j) row[j] = P[i][j];
+      int bad = 0, signs = 0;
+#pragma unroll
+      for (int k = 0; k < LDL_NB; ++k) {
+        const double colk = row[k];
+        double d = bcastd(colk, k);
+        if (k < nb) {
+          if (!(fabs(d) > eps * anorm)) { bad = 1; d = (anorm > 0.0 ? anorm : 1.0); }
+          signs |= (d > 0.0) ? 1 : 2;
+        } else {
+          d = 1.0;
+        }
+        const double rd = 1.0 / d;
+        const double lik = colk * rd;
+#pragma unroll
+        for (int j = k + 1; j < LDL_NB; ++j) row[j] -= lik * bcastd(colk, j);
+        row[k] = lik;
+        if (lane == 0) { dl[k] = d; rdl[k] = rd; }
+        __builtin_amdgcn_sched_barrier(0);   // keep the broadcasts of later columns from being hoisted (SGPR pressure)
+      }
+      if (lane < nb) {
+#pragma unroll
+        for (int j = 0; j < LDL_NB; ++j) P[lane][j] = row[j];
+      }
+      if (lane == 0) { if (bad) sflags[0] = 1; sflags[1] |= signs; }
+    }
+    __syncthreads();
+    // finished diagonal block -> global (unit lower L11, pivots on the diagonal)
+    for (int idx = tid; idx < nb * nb; idx += LDL_THREADS) {
+      const int i = idx % nb, j = idx / nb;
+      if (i > j) A[(j0 + i) + (size_t)(j0 + j) * lda] = P[i][j];
+      else if (i == j) { A[(j0 + i) + (size_t)(j0 + j) * lda] = dl[i]; dvec[j0 + i] = dl[i]; }
+    }
+    // (c) panel: W = A21 L11^{-T} (thread = row), L21 = W D^{-1} -> LDS and global
+    if (tid < m) {
+      const int r = nb + tid;
+      double wrow[LDL_NB];
+#pragma unroll
+      for (int k = 0; k < LDL_NB; ++k) wrow[k] = (k < nb) ? P[r][k] : 0.0;
+#pragma unroll
+      for (int k = 0; k < LDL_NB; ++k) {
+        if (k < nb) {
+          double v = wrow[k];
+#pragma unroll
+          for (int j = 0; j < k; ++j) v -= wrow[j] * P[k][j];
+          wrow[k] = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int k = 0; k < LDL_NB; ++k) {
+        if (k < nb) {
+          const double l = wrow[k] * rdl[k];
+          P[r][k] = l;
+          A[(j0 + r) + (size_t)(j0 + k) * lda] = l;
+        }
+      }
+    }
+    __syncthreads();
+    // (d) trailing update of the tiles still owned: A22 -= (L21 D) L21^T, operands from LDS
+    if (m > 0) {
+#pragma unroll
+      for (int s = 0; s < LDLR_TPW; ++s) {
+        if (tI[s] >= 0 && 16 * tJ[s] >= j1) {
+          const int ra = 16 * tI[s] + li - j0, rb = 16 * tJ[s] + li - j0;
+          double av[LDL_NB / 4], bv[LDL_NB / 4];
+#pragma unroll
+          for (int q = 0; q < LDL_NB / 4; ++q) {
+            const int k = 4 * q + lk;
+            av[q] = -P[ra][k] * dl[k];
+            bv[q] = P[rb][k];
+          }
+#pragma unroll
+          for (int q = 0; q < LDL_NB / 4; ++q) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc[s], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // one tile's operands at a time (register pressure)
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const bool ok = (sflags[0] == 0) && (sflags[1] == 1 || sflags[1] == 2 || n == 0);
+    mode[0] = ok ? 1 : 0;
+    if (ok) { info[0] = (sflags[1] == 1) ? n : 0; info[1] = (sflags[1] == 2) ? n : 0; info[2] = 0; }
+  }
+}
+
 // x = S^-1 b with the blocked factor (unit lower L in A, pivots in dvec); b is in LDS vector x
 __device__ void ldl_blocked_solve(int n, const double* __restrict__ A, const double* __restrict__ dvec, double* x) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nwv = blockDim.x >> 6;
@@ -619,7 +778,7 @@ __device__ void ldl_blocked_solve(int n, const double* __restrict__ A, const dou
         lrow[k] = (lane > k && lane < nb) ? A[(j0 + lane) + (size_t)(j0 + k) * lda] : 0.0;
       double xi = (lane < nb) ? x[j0 + lane] : 0.0;
 #pragma unroll
-      for (int k = 0; k < LDL_NB; ++k) xi -= lrow[k] * __shfl(xi, k);
+      for (int k = 0; k < LDL_NB; ++k) xi -= lrow[k] * bcastd(xi, k);
       if (lane < nb) x[j0 + lane] = xi;
     }
     __syncthreads();
@@ -652,7 +811,7 @@ __device__ void ldl_blocked_solve(int n, const double* __restrict__ A, const dou
         lcol[k] = (lane < k && k < nb) ? A[(j0 + k) + (size_t)(j0 + lane) * lda] : 0.0;
       double xi = (lane < nb) ? x[j0 + lane] : 0.0;
 #pragma unroll
-      for (int k = LDL_NB - 1; k > 0; --k) xi -= lcol[k] * __shfl(xi, k);
+      for (int k = LDL_NB - 1; k > 0; --k) xi -= lcol[k] * bcastd(xi, k);
       if (lane < nb) x[j0 + lane] = xi;
     }
     __syncthreads();
@@ -1397,8 +1556,11 @@ int pp_factor_schur(pp_handle h, const double* Q_host) {
     if (h->dense_policy == 0)
       // (a left-looking variant with the panel resident in LDS was measured no faster: 0.344 vs 0.315 ms at
       // n_c = 200 -- the serial diagonal-block factor dominates both)
-      hipLaunchKernelGGL(k_ldl_blocked, dim3(1), dim3(LDL_THREADS), 0, st, nc, h->Sldl, h->dvec, h->dense_mode, h->bkinfo,
-                         BK_EPS);
+      if (nc <= 16 * LDLR_NT)
+        hipLaunchKernelGGL(k_ldl_regs, dim3(1), dim3(LDL_THREADS), 0, st, nc, h->Sldl, h->dvec, h->dense_mode, h->bkinfo, BK_EPS);
+      else
+        hipLaunchKernelGGL(k_ldl_blocked, dim3(1), dim3(LDL_THREADS), 0, st, nc, h->Sldl, h->dvec, h->dense_mode, h->bkinfo,
+                           BK_EPS);
     else
       PP_HIP(hipMemsetAsync(h->dense_mode, 0, sizeof(int), st));
     hipLaunchKernelGGL(k_bk_factor, dim3(1), dim3(BK_THREADS), 0, st, nc, h->Sfac, h->ipiv, h->work, h->bkinfo,
