@@ -98,6 +98,14 @@ __global__ __launch_bounds__(256) void k_transpose_out(const double* __restrict_
 // loads of a whole task issue back to back (one memory latency) instead of being chained
 // behind per-batch scalar loads.
 __device__ __forceinline__ int bcast(int v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
+// 1/d without the IEEE division sequence: hardware estimate + two Newton steps (<= 1-2 ulp for the
+// well-scaled pivots of the dense factor; not for denormal or near-overflow arguments)
+__device__ __forceinline__ double fast_rcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
+}
 // wave-uniform broadcast of a double from a (wave-uniform) lane: two v_readlane_b32, no LDS crossbar
 __device__ __forceinline__ double bcastd(double v, int src_lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
@@ -616,21 +624,24 @@ __global__ __launch_bounds__(LDL_THREADS) void k_ldl_blocked(int n, double* __re
 // Register-resident variant for n <= 16 * LDLR_NT (= 208; the reference configurations have n_c = 200):
 // the whole lower triangle lives in the MFMA accumulators of the 8 waves (91 tiles of 16x16, <= 12 per
 // wave) for the entire factorisation, so a trailing update is LDS reads + fp64 MFMAs only -- no global
-// read-modify-write round trips inside the panel loop.  Per 32-column panel: the panel's tiles go to
-// LDS, wave 0 factors the diagonal block in registers (shuffle broadcasts), one thread per row solves
-// the panel against it, the finished columns are streamed to global memory (stores only), and every
-// wave updates the tiles it still owns.  Same acceptance rule and output format as k_ldl_blocked.
+// read-modify-write round trips inside the panel loop.  Per 16-column panel (= one tile column): its
+// tiles go to LDS, wave 0 factors the 16x16 diagonal block in registers (column broadcasts through
+// LDS), one thread per row solves the panel against it, the finished columns are streamed to global
+// memory (stores only), and every wave updates the tiles it still owns.  Same acceptance rule and
+// output format as k_ldl_blocked.
 constexpr int LDLR_NT = 13;
-constexpr int LDLR_TPW = 12;
-constexpr int LDLR_LD = 34;   // LDS row stride in doubles: conflict-free MFMA operand reads
+constexpr int LDLR_TPW = 12;  // 8 waves * 12 >= 91 tiles
+constexpr int LDLR_NB = 16;
+constexpr int LDLR_LD = 18;   // LDS row stride in doubles: conflict-free MFMA operand reads
 
 __global__ __launch_bounds__(LDL_THREADS) void k_ldl_regs(int n, double* __restrict__ A, double* __restrict__ dvec,
                                                           int* __restrict__ mode, int* __restrict__ info, double eps) {
   __shared__ double P[16 * LDLR_NT][LDLR_LD];
-  __shared__ double dl[LDL_NB], rdl[LDL_NB];
+  __shared__ double dl[LDLR_NB], rdl[LDLR_NB];
+  __shared__ double colbuf[64], nextbuf[64];
   __shared__ double red[LDL_THREADS / 64];
   __shared__ int sflags[2];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nwv = LDL_THREADS / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = LDL_THREADS / 64;
   const int li = lane & 15, lk = lane >> 4;
   const size_t lda = (size_t)n;
   const int nt = (n + 15) / 16, ntt = nt * (nt + 1) / 2;
@@ -638,18 +649,18 @@ __global__ __launch_bounds__(LDL_THREADS) void k_ldl_regs(int n, double* __restr
   for (int i = tid; i < n; i += LDL_THREADS) loc = fmax(loc, fabs(A[i + i * lda]));
   // tiles of this wave: t = wv + 8 s  <->  (I >= J), t = I (I + 1) / 2 + J
   double4_t acc[LDLR_TPW];
-  int tI[LDLR_TPW], tJ[LDLR_TPW];
+  int tIJ[LDLR_TPW];   // wave-uniform (SGPR): I << 8 | J, or -1
 #pragma unroll
   for (int s = 0; s < LDLR_TPW; ++s) {
     const int t = wv + nwv * s;
     int I = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
     while ((I + 1) * (I + 2) / 2 <= t) ++I;
     while (I * (I + 1) / 2 > t) --I;
-    tI[s] = (t < ntt) ? I : -1;
-    tJ[s] = t - I * (I + 1) / 2;
+    const int J = t - I * (I + 1) / 2;
+    tIJ[s] = (t < ntt) ? ((I << 8) | J) : -1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = 16 * I + lk + 4 * r, col = 16 * tJ[s] + li;
+      const int row = 16 * I + lk + 4 * r, col = 16 * J + li;
       acc[s][r] = (t < ntt && row < n && col < n) ? A[row + (size_t)col * lda] : 0.0;
     }
   }
@@ -659,76 +670,96 @@ __global__ __launch_bounds__(LDL_THREADS) void k_ldl_regs(int n, double* __restr
   __syncthreads();
   double anorm = 0.0;
   for (int q = 0; q < nwv; ++q) anorm = fmax(anorm, red[q]);
-  for (int j0 = 0; j0 < n; j0 += LDL_NB) {
-    const int nb = min(LDL_NB, n - j0), j1 = j0 + nb, m = n - j1;
-    // (a) the panel's tiles: accumulators -> LDS (rows relative to j0)
+  for (int jt_loop = 0; jt_loop < nt; ++jt_loop) {
+    // panel index and per-lane tile coordinates behind optimisation barriers: otherwise the LDS addresses of
+    // all 12 tiles become loop-carried induction variables / hoisted invariants and pin ~100 registers
+    int jt = jt_loop, liv = li, lkv = lk;
+    asm volatile("" : "+s"(jt), "+v"(liv), "+v"(lkv));
+    const int j0 = 16 * jt;
+    const int nb = min(LDLR_NB, n - j0), j1 = j0 + nb, m = n - j1;
+    // (a) the panel's tiles (tile column jt): accumulators -> LDS (rows relative to j0)
 #pragma unroll
     for (int s = 0; s < LDLR_TPW; ++s) {
-      const int c0 = 16 * tJ[s] - j0;
-      if (tI[s] >= 0 && c0 >= 0 && c0 < nb) {
+      if (tIJ[s] >= 0 && (tIJ[s] & 255) == jt) {
+        const int r0 = 16 * ((tIJ[s] >> 8) - jt);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) P[16 * tI[s] + lk + 4 * r - j0][c0 + li] = acc[s][r];
+        for (int r = 0; r < 4; ++r) P[r0 + lkv + 4 * r][liv] = acc[s][r];
       }
     }
     __syncthreads();
-    // (b) diagonal block by wave 0: lane = row, the row lives in registers, column k is broadcast with
-    // v_readlane.  Mask-free: the strict upper triangle and, in a ragged last panel, rows/columns >= nb
-    // carry don't-care values that never reach a stored result; the unit diagonal is implicit (P[k][k] = 1).
-    if (wv == 0) {
-      double row[LDL_NB];
-      const int i = lane & 31;
+    // (b) diagonal block by wave 0: lane = row (16 rows, lanes 16.. duplicate them), the row lives in
+    // registers.  Column k is broadcast through LDS (one write per lane, uniform-address reads; LDS
+    // operations of one wave execute in order).  Pivot k + 1 is final as soon as step k has updated column
+    // k + 1: its reciprocal (v_rcp_f64 + two Newton steps) is started first and overlaps the rest of the
+    // step.  Mask-free: the strict upper triangle and, in a ragged last panel, rows/columns >= nb carry
+    // don't-care values that never reach a stored result; the unit diagonal is implicit.
+    int wv_here = wv;
+    asm volatile("" : "+s"(wv_here));   // opaque: keeps the panel loop from being unswitched on the wave id (two copies
+                                        // of the loop double the accumulator live ranges and spill them)
+    if (wv_here == 0) {
+      double row[LDLR_NB];
+      const int i = lane & 15;
 #pragma unroll
-      for (int j = 0; j < LDL_NB; ++j) row[j] = P[i][j];
+      for (int j = 0; j < LDLR_NB; ++j) row[j] = P[i][j];
       int bad = 0, signs = 0;
+      colbuf[lane] = row[0];
+      double d = colbuf[0];
+      if (!(fabs(d) > eps * anorm)) { bad = 1; d = (anorm > 0.0 ? anorm : 1.0); }
+      signs |= (d > 0.0) ? 1 : 2;
+      double rd = fast_rcp(d);
 #pragma unroll
-      for (int k = 0; k < LDL_NB; ++k) {
+      for (int k = 0; k < LDLR_NB; ++k) {
         const double colk = row[k];
-        double d = bcastd(colk, k);
-        if (k < nb) {
-          if (!(fabs(d) > eps * anorm)) { bad = 1; d = (anorm > 0.0 ? anorm : 1.0); }
-          signs |= (d > 0.0) ? 1 : 2;
-        } else {
-          d = 1.0;
-        }
-        const double rd = 1.0 / d;
         const double lik = colk * rd;
+        if (k > 0) colbuf[lane] = colk;      // (step 0's column is already there)
+        double dn = 1.0, rdn = 1.0;
+        if (k + 1 < LDLR_NB) {
+          row[k + 1] -= lik * colbuf[k + 1];
+          nextbuf[lane] = row[k + 1];
+          dn = nextbuf[k + 1];
+          if (k + 1 < nb) {
+            if (!(fabs(dn) > eps * anorm)) { bad = 1; dn = (anorm > 0.0 ? anorm : 1.0); }
+            signs |= (dn > 0.0) ? 1 : 2;
+          } else {
+            dn = 1.0;
+          }
+          rdn = fast_rcp(dn);
+        }
 #pragma unroll
-        for (int j = k + 1; j < LDL_NB; ++j) row[j] -= lik * bcastd(colk, j);
+        for (int j = k + 2; j < LDLR_NB; ++j) row[j] -= lik * colbuf[j];
         row[k] = lik;
         if (lane == 0) { dl[k] = d; rdl[k] = rd; }
-        __builtin_amdgcn_sched_barrier(0);   // keep the broadcasts of later columns from being hoisted (SGPR pressure)
+        d = dn; rd = rdn;
       }
       if (lane < nb) {
 #pragma unroll
-        for (int j = 0; j < LDL_NB; ++j) P[lane][j] = row[j];
+        for (int j = 0; j < LDLR_NB; ++j) P[lane][j] = row[j];
       }
       if (lane == 0) { if (bad) sflags[0] = 1; sflags[1] |= signs; }
     }
     __syncthreads();
     // finished diagonal block -> global (unit lower L11, pivots on the diagonal)
-    for (int idx = tid; idx < nb * nb; idx += LDL_THREADS) {
-      const int i = idx % nb, j = idx / nb;
+    if (tid < nb * nb) {
+      const int i = tid % nb, j = tid / nb;
       if (i > j) A[(j0 + i) + (size_t)(j0 + j) * lda] = P[i][j];
       else if (i == j) { A[(j0 + i) + (size_t)(j0 + j) * lda] = dl[i]; dvec[j0 + i] = dl[i]; }
     }
     // (c) panel: W = A21 L11^{-T} (thread = row), L21 = W D^{-1} -> LDS and global
     if (tid < m) {
       const int r = nb + tid;
-      double wrow[LDL_NB];
+      double wrow[LDLR_NB];
 #pragma unroll
-      for (int k = 0; k < LDL_NB; ++k) wrow[k] = (k < nb) ? P[r][k] : 0.0;
+      for (int k = 0; k < LDLR_NB; ++k) wrow[k] = P[r][k];
 #pragma unroll
-      for (int k = 0; k < LDL_NB; ++k) {
-        if (k < nb) {
-          double v = wrow[k];
+      for (int k = 1; k < LDLR_NB; ++k) {
+        double v = wrow[k];
 #pragma unroll
-          for (int j = 0; j < k; ++j) v -= wrow[j] * P[k][j];
-          wrow[k] = v;
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < k; ++j) v -= wrow[j] * P[k][j];
+        wrow[k] = v;
+        __builtin_amdgcn_sched_barrier(0);   // keep the LDS reads of later columns from being hoisted (register pressure)
       }
 #pragma unroll
-      for (int k = 0; k < LDL_NB; ++k) {
+      for (int k = 0; k < LDLR_NB; ++k) {
         if (k < nb) {
           const double l = wrow[k] * rdl[k];
           P[r][k] = l;
@@ -741,19 +772,19 @@ __global__ __launch_bounds__(LDL_THREADS) void k_ldl_regs(int n, double* __restr
     if (m > 0) {
 #pragma unroll
       for (int s = 0; s < LDLR_TPW; ++s) {
-        if (tI[s] >= 0 && 16 * tJ[s] >= j1) {
-          const int ra = 16 * tI[s] + li - j0, rb = 16 * tJ[s] + li - j0;
-          double av[LDL_NB / 4], bv[LDL_NB / 4];
+        const int tI = tIJ[s] >> 8, tJ = tIJ[s] & 255;
+        if (tIJ[s] >= 0 && tJ > jt) {
+          const int ra = 16 * (tI - jt) + liv, rb = 16 * (tJ - jt) + liv;
+          double av[LDLR_NB / 4], bv[LDLR_NB / 4];
 #pragma unroll
-          for (int q = 0; q < LDL_NB / 4; ++q) {
-            const int k = 4 * q + lk;
+          for (int q = 0; q < LDLR_NB / 4; ++q) {
+            const int k = 4 * q + lkv;
             av[q] = -P[ra][k] * dl[k];
             bv[q] = P[rb][k];
           }
 #pragma unroll
-          for (int q = 0; q < LDL_NB / 4; ++q) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc[s], 0, 0, 0);
+          for (int q = 0; q < LDLR_NB / 4; ++q) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc[s], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);   // one tile's operands at a time (register pressure)
       }
     }
     __syncthreads();
