@@ -849,6 +849,72 @@ __device__ void ldl_blocked_solve(int n, const double* __restrict__ A, const dou
   }
 }
 
+// Same solve for n <= blockDim.x with one thread per unknown and ONE barrier per 32-column block: thread r
+// keeps its right-hand-side entry in a register and its 32-entry segment of the current block of L
+// (prefetched one block ahead, so no global-memory round trip sits between the dependent blocks).  The
+// wave that owns the block's rows solves it with v_readlane broadcasts, which at the same time applies the
+// block to the other rows of that wave; the remaining waves apply it from LDS after the barrier.
+__device__ void ldl_rows_solve(int n, const double* __restrict__ A, const double* __restrict__ dvec, double* xs) {
+  const int r = threadIdx.x, lane = r & 63, wv = __builtin_amdgcn_readfirstlane(r >> 6);
+  const size_t lda = (size_t)n;
+  const bool act = r < n;
+  double acc = act ? xs[r] : 0.0;
+  const double rd = act ? 1.0 / dvec[r] : 0.0;
+  double cur[LDL_NB], nxt[LDL_NB];
+  // ---- forward: L y = b, blocks ascending; segment = L[r][j0 .. j0+32) below the diagonal
+#define PP_LOAD_FWD(dst, j0_)                                                              \
+  _Pragma("unroll") for (int k = 0; k < LDL_NB; ++k) {                                     \
+    const int c = (j0_) + k;                                                               \
+    dst[k] = (act && c < n && c < r) ? A[r + (size_t)c * lda] : 0.0;                       \
+  }
+  PP_LOAD_FWD(cur, 0)
+  for (int j0 = 0; j0 < n; j0 += LDL_NB) {
+    if (j0 + LDL_NB < n) { PP_LOAD_FWD(nxt, j0 + LDL_NB) }
+    const int bw = j0 >> 6, base = j0 & 63;
+    if (wv == bw) {
+#pragma unroll
+      for (int k = 0; k < LDL_NB; ++k) acc -= cur[k] * bcastd(acc, base + k);
+      if (r >= j0 && r < j0 + LDL_NB && act) xs[r] = acc;
+    }
+    __syncthreads();
+    if (wv != bw && r >= j0 + LDL_NB) {
+#pragma unroll
+      for (int k = 0; k < LDL_NB; ++k) acc -= cur[k] * xs[min(j0 + k, n - 1)];
+    }
+#pragma unroll
+    for (int k = 0; k < LDL_NB; ++k) cur[k] = nxt[k];
+  }
+#undef PP_LOAD_FWD
+  acc *= rd;
+  // ---- backward: L^T x = y, blocks descending; segment = L[j0 .. j0+32)[r] below the diagonal
+#define PP_LOAD_BWD(dst, j0_)                                                              \
+  _Pragma("unroll") for (int k = 0; k < LDL_NB; ++k) {                                     \
+    const int c = (j0_) + k;                                                               \
+    dst[k] = (act && c < n && c > r) ? A[c + (size_t)r * lda] : 0.0;                       \
+  }
+  const int jlast = ((n - 1) / LDL_NB) * LDL_NB;
+  __syncthreads();
+  PP_LOAD_BWD(cur, jlast)
+  for (int j0 = jlast; j0 >= 0; j0 -= LDL_NB) {
+    if (j0 > 0) { PP_LOAD_BWD(nxt, j0 - LDL_NB) }
+    const int bw = j0 >> 6, base = j0 & 63;
+    if (wv == bw) {
+#pragma unroll
+      for (int k = LDL_NB - 1; k >= 0; --k) acc -= cur[k] * bcastd(acc, base + k);
+      if (r >= j0 && r < j0 + LDL_NB && act) xs[r] = acc;
+    }
+    __syncthreads();
+    if (wv != bw && r < j0) {
+#pragma unroll
+      for (int k = 0; k < LDL_NB; ++k) acc -= cur[k] * xs[min(j0 + k, n - 1)];
+    }
+#pragma unroll
+    for (int k = 0; k < LDL_NB; ++k) cur[k] = nxt[k];
+  }
+#undef PP_LOAD_BWD
+  __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------------
 // thread-team context of dense_bk.hpp for one workgroup
 struct TeamCtx {
@@ -917,7 +983,8 @@ __global__ __launch_bounds__(BK_THREADS) void k_coupling_solve(int n, const doub
   if (mode[0] == 1) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) xs[i] = (rc ? rc[i] : 0.0) + rs[i];
     __syncthreads();
-    ldl_blocked_solve(n, Aldl, dvec, xs);
+    if (n <= (int)blockDim.x) ldl_rows_solve(n, Aldl, dvec, xs);
+    else ldl_blocked_solve(n, Aldl, dvec, xs);
     for (int i = threadIdx.x; i < n; i += blockDim.x) xc[i] = xs[i];
     return;
   }
