@@ -185,7 +185,7 @@ def test_device_factor_matches_host_interpreter(wmax):
         hostlib().ppsim_set_supernodes(0, -1)
 
 
-@pytest.mark.parametrize('shape', [(3, 12, 2, 220), (2, 8, 2, 530)])
+@pytest.mark.parametrize('shape', [(3, 220, 2, 220), (2, 530, 2, 530)])
 def test_large_coupling_dimension_paths(shape):
     """n_c above the register-resident dense factor (208) and above one-thread-per-unknown solve (512):
     the blocked global-memory LDL^T and the blocked solve must give the same answers."""
