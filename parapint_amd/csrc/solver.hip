@@ -57,21 +57,41 @@ struct GroupDev {
 // rowmap (may be null): entry e of the input goes to output row rowmap[e]; negative = not needed
 // (e.g. the upper-triangle half of a KKT block given with both triangles) and is not written.
 __global__ __launch_bounds__(256) void k_transpose_in(const double* __restrict__ in, double* __restrict__ out,
-                                                      const int* __restrict__ rowmap, int nrows, int m, int bpad) {
+                                                      const int* __restrict__ rowmap, int nrows, int m, int bpad,
+                                                      int tiles) {
+  // One workgroup walks `tiles` consecutive 64 x 64 tiles along the entry axis: the rows of the input are
+  // read in runs of tiles * 512 bytes, and the loads of the next tile are in flight while the current one
+  // goes out through LDS.
   __shared__ double tile[64][65];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int e0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
-  for (int r = ty; r < 64; r += 4) {
-    const int b = b0 + r, e = e0 + tx;
-    tile[r][tx] = (b < nrows && e < m) ? in[(size_t)b * m + e] : 0.0;
+  const int b0 = blockIdx.y * 64;
+  int e0 = blockIdx.x * 64 * tiles;
+  double v[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int b = b0 + ty + 4 * q, e = e0 + tx;
+    v[q] = (b < nrows && e < m) ? in[(size_t)b * m + e] : 0.0;
   }
-  __syncthreads();
-  for (int r = ty; r < 64; r += 4) {
-    const int e = e0 + r, b = b0 + tx;
-    if (e < m) {
-      const int orow = rowmap ? rowmap[e] : e;
-      if (orow >= 0) out[(size_t)orow * bpad + b] = tile[tx][r];
+  for (int t = 0; t < tiles && e0 < m; ++t, e0 += 64) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tile[ty + 4 * q][tx] = v[q];
+    __syncthreads();
+    if (t + 1 < tiles) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int b = b0 + ty + 4 * q, e = e0 + 64 + tx;
+        v[q] = (b < nrows && e < m) ? in[(size_t)b * m + e] : 0.0;
+      }
     }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int r = ty + 4 * q, e = e0 + r, b = b0 + tx;
+      if (e < m) {
+        const int orow = rowmap ? rowmap[e] : e;
+        if (orow >= 0) out[(size_t)orow * bpad + b] = tile[tx][r];
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -81,13 +101,18 @@ __global__ __launch_bounds__(256) void k_transpose_out(const double* __restrict_
   __shared__ double tile[64][65];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int i0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
-  for (int r = ty; r < 64; r += 4) {
-    const int i = i0 + r;
-    tile[r][tx] = (i < m) ? W[(size_t)iperm[i] * bpad + b0 + tx] : 0.0;
-  }
+  int src[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { const int i = i0 + ty + 4 * q; src[q] = (i < m) ? iperm[i] : -1; }
+  double v[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) v[q] = (src[q] >= 0) ? W[(size_t)src[q] * bpad + b0 + tx] : 0.0;   // all loads in flight
+#pragma unroll
+  for (int q = 0; q < 16; ++q) tile[ty + 4 * q][tx] = v[q];
   __syncthreads();
-  for (int r = ty; r < 64; r += 4) {
-    const int b = b0 + r, i = i0 + tx;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int r = ty + 4 * q, b = b0 + r, i = i0 + tx;
     if (b < nrows && i < m) out[(size_t)b * m + i] = tile[tx][r];
   }
 }
@@ -1278,6 +1303,13 @@ int dev_upload(pp_handle h, Group* g, const T** out, const std::vector<T>& v) {
   return 0;
 }
 
+// tiles per workgroup of k_transpose_in (measured on C3: 1 is fastest -- 0.105 ms against 0.123 at 8; the
+// walk along the row only pays if rows were much longer than the 4 workgroups/CU window already covers)
+int transpose_tiles(int, int) {
+  if (const char* e = std::getenv("PP_TRANSPOSE_TILES")) return std::max(1, std::atoi(e));
+  return 1;
+}
+
 void free_group(Group* g) {
   for (void* p : g->allocs) (void)hipFree(p);
   delete g;
@@ -1578,8 +1610,11 @@ int pp_numeric_local(pp_handle h) {
     {
       PhaseScope ps(h, 0, 1);
       if (d.nraw > 0)
-        hipLaunchKernelGGL(k_transpose_in, dim3((d.nraw + 63) / 64, d.nchunk), dim3(256), 0, st, d.raw, d.rawT, d.rawmap,
-                           d.batch, d.nraw, d.bpad);
+      {
+        const int tiles = transpose_tiles(d.nraw, d.nchunk);
+        hipLaunchKernelGGL(k_transpose_in, dim3((d.nraw + 64 * tiles - 1) / (64 * tiles), d.nchunk), dim3(256), 0, st, d.raw,
+                           d.rawT, d.rawmap, d.batch, d.nraw, d.bpad, tiles);
+      }
     }
     {
       int nlaunch = 0;
@@ -1728,8 +1763,11 @@ int pp_solve_forward(pp_handle h) {
     GroupDev& d = g->dev;
     {
       PhaseScope ps(h, 4, P.n_levels + 1);
-      hipLaunchKernelGGL(k_transpose_in, dim3((P.n + 63) / 64, d.nchunk), dim3(256), 0, st, d.rhs, d.rhsT,
-                         (const int*)nullptr, d.batch, P.n, d.bpad);
+      {
+        const int tiles = transpose_tiles(P.n, d.nchunk);
+        hipLaunchKernelGGL(k_transpose_in, dim3((P.n + 64 * tiles - 1) / (64 * tiles), d.nchunk), dim3(256), 0, st, d.rhs,
+                           d.rhsT, (const int*)nullptr, d.batch, P.n, d.bpad, tiles);
+      }
       // (a persistent one-workgroup-per-chunk kernel for the small top levels was measured slower than
       // per-level launches: 16 waves on one CU serialise their memory round trips)
       const Splits sp = make_splits(h, d.nchunk);
