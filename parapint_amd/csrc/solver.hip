@@ -143,11 +143,16 @@ __device__ __forceinline__ double bcastd(double v, int src_lane) {
 
 // Inversion of the gathered pivot block and scaling of panel rows [r0, r1): L rows = U rows * inv(P).
 // Used by the scale tasks of big panels and as the closing phase of fused small-panel tasks.
+// Task record (ints): piv, r0, r1, dptr0, kind, E0, E1, w, uoff, boff, doff, sub -- everything a task needs
+// in one 48-byte scalar read, so the entry records can be requested without first chasing the per-pivot arrays.
+constexpr int TASK_INTS = 12;
+
 template <int WM>
-__device__ __forceinline__ void invert_and_scale(const GroupDev& g, int p, int w, int r0, int r1, double tmax_diag,
-                                                 bool publish, size_t bpad, int b, double eps) {
-  const double* Up = g.U + (size_t)g.piv_uoff[p] * bpad + b;
-  double* Lp = g.L + (size_t)g.piv_uoff[p] * bpad + b;
+__device__ __forceinline__ void invert_and_scale(const GroupDev& g, int p, int w, int uoff, int doff, unsigned sub,
+                                                 int r0, int r1, double tmax_diag, bool publish, size_t bpad, int b,
+                                                 double eps) {
+  const double* Up = g.U + (size_t)uoff * bpad + b;
+  double* Lp = g.L + (size_t)uoff * bpad + b;
   double inv[WM * (WM + 1) / 2];
   int code;
   if (WM == 1) {
@@ -161,10 +166,10 @@ __device__ __forceinline__ void invert_and_scale(const GroupDev& g, int p, int w
 #pragma unroll
       for (int j = 0; j < PP_WMAX; ++j)
         blk[i * PP_WMAX + j] = (i < w && j < w) ? Up[(size_t)(i * w + j) * bpad] : 0.0;
-    code = pp::invert_block(w, g.piv_sub[p], blk, tmax_diag, eps, inv);
+    code = pp::invert_block(w, sub, blk, tmax_diag, eps, inv);
   }
   if (publish) {
-    double* invp = g.Dinv + (size_t)g.piv_doff[p] * bpad + b;
+    double* invp = g.Dinv + (size_t)doff * bpad + b;
 #pragma unroll
     for (int i = 0; i < WM * (WM + 1) / 2; ++i)
       if (i < w * (w + 1) / 2) invp[(size_t)i * bpad] = inv[i];
@@ -207,9 +212,11 @@ __global__ __launch_bounds__(64) void k_gather_level(GroupDev g, int task0, int 
   const int lane = threadIdx.x;
   const int b = (blockIdx.y + chunk0) * 64 + lane;
   const size_t bpad = (size_t)g.bpad;
-  const int* t = g.ftask + 5 * (size_t)(task0 + blockIdx.x);
-  const int p = t[0], r0 = t[1], r1 = t[2], dptr0 = t[3], kind = t[4];
-  const int w = (WM == 1) ? 1 : g.piv_w[p];
+  const int* t = g.ftask + TASK_INTS * (size_t)(task0 + blockIdx.x);
+  const int p = t[0], r0 = t[1], r1 = t[2], dptr0 = t[3], kind = t[4], E0 = t[5], E1 = t[6];
+  const int w = (WM == 1) ? 1 : t[7];
+  const int uoff = t[8], boff = t[9], doff = t[10];
+  const unsigned sub = (unsigned)t[11];
   const double* __restrict__ U = g.U + b;
   const double* __restrict__ Lb = g.L + b;
   const double* __restrict__ R = g.rawT + b;
@@ -217,16 +224,14 @@ __global__ __launch_bounds__(64) void k_gather_level(GroupDev g, int task0, int 
   const int* dp = g.fdst_ptr + dptr0;
   const bool dp_vec = (nrow + 1 <= 64);
   const int dpv = (dp_vec && lane <= nrow) ? dp[lane] : 0;
-  double* Udst = g.U + ((size_t)g.piv_uoff[p] + (size_t)r0 * w) * bpad + b;
-  double* Tmd = g.Tm + ((size_t)g.piv_boff[p] + (size_t)r0 * w) * bpad + b;
+  double* Udst = g.U + ((size_t)uoff + (size_t)r0 * w) * bpad + b;
+  double* Tmd = g.Tm + ((size_t)boff + (size_t)r0 * w) * bpad + b;
   const int nblk = (r0 < w) ? (w - r0) : 0;          // leading destination rows that belong to the pivot block
   double tmax_diag = 0.0;
   double acc[WM], tmax[WM];
 #pragma unroll
   for (int q = 0; q < WM; ++q) { acc[q] = 0.0; tmax[q] = 0.0; }
   int d = 0;
-  const int E0 = dp_vec ? bcast(dpv, 0) : dp[0];
-  const int E1 = dp_vec ? bcast(dpv, nrow) : dp[nrow];
   int dend = (nrow > 0) ? (dp_vec ? bcast(dpv, 1) : dp[1]) : 0x7fffffff;
 #define PP_FINALIZE()                                                                      \
   do {                                                                                     \
@@ -276,13 +281,14 @@ __global__ __launch_bounds__(64) void k_gather_level(GroupDev g, int task0, int 
   }
     int i0 = 0;
     constexpr int GB = (WM == 1) ? 16 : 8;
+    if (WM > 1 && cnt > 8 && cnt <= 16) { PP_GROUP(16) i0 = 16; }   // a whole small task in ONE round trip
     for (; cnt - i0 > 4; i0 += GB) PP_GROUP(GB)
     if (i0 < cnt) PP_GROUP(4)
 #undef PP_GROUP
   }
   while (d < nrow) PP_FINALIZE();
 #undef PP_FINALIZE
-  if (kind == 1) invert_and_scale<WM>(g, p, w, r0, r1, tmax_diag, true, bpad, b, eps);
+  if (kind == 1) invert_and_scale<WM>(g, p, w, uoff, doff, sub, r0, r1, tmax_diag, true, bpad, b, eps);
 }
 
 // Lean variant for the wide bottom levels of the tree (a few entries per task, tens of thousands
@@ -293,17 +299,19 @@ __global__ __launch_bounds__(64) void k_gather_level_lean(GroupDev g, int task0,
   const int lane = threadIdx.x;
   const int b = (blockIdx.y + chunk0) * 64 + lane;
   const size_t bpad = (size_t)g.bpad;
-  const int* t = g.ftask + 5 * (size_t)(task0 + blockIdx.x);
+  const int* t = g.ftask + TASK_INTS * (size_t)(task0 + blockIdx.x);
   const int p = t[0], r0 = t[1], r1 = t[2], dptr0 = t[3], kind = t[4];
-  const int w = (WM == 1) ? 1 : g.piv_w[p];
+  const int w = (WM == 1) ? 1 : t[7];
+  const int uoff = t[8], boff = t[9], doff = t[10];
+  const unsigned sub = (unsigned)t[11];
   const double* __restrict__ U = g.U + b;
   const double* __restrict__ Lb = g.L + b;
   const double* __restrict__ R = g.rawT + b;
   const int nrow = r1 - r0;
   const int* dp = g.fdst_ptr + dptr0;
-  double* Udst = g.U + ((size_t)g.piv_uoff[p] + (size_t)r0 * w) * bpad + b;
-  double* Tmd = g.Tm + ((size_t)g.piv_boff[p] + (size_t)r0 * w) * bpad + b;
-  double* Ldst = g.L + ((size_t)g.piv_uoff[p] + (size_t)r0 * w) * bpad + b;
+  double* Udst = g.U + ((size_t)uoff + (size_t)r0 * w) * bpad + b;
+  double* Tmd = g.Tm + ((size_t)boff + (size_t)r0 * w) * bpad + b;
+  double* Ldst = g.L + ((size_t)uoff + (size_t)r0 * w) * bpad + b;
   const int nblk = (r0 < w) ? (w - r0) : 0;
   double tmax_diag = 0.0, inv1 = 0.0;
   for (int d = 0; d < nrow; ++d) {
@@ -332,7 +340,7 @@ __global__ __launch_bounds__(64) void k_gather_level_lean(GroupDev g, int task0,
       if (d == 0) {
         const pp::PivotResult pr = pp::invert_pivot(1, acc[0], 0.0, 0.0, tmax[0], eps);
         inv1 = pr.i00;
-        g.Dinv[(size_t)g.piv_doff[p] * bpad + b] = inv1;
+        g.Dinv[(size_t)doff * bpad + b] = inv1;
         const int code = (pr.code & 3) | (((pr.code >> 2) & 3) << 4) | (((pr.code >> 4) & 3) << 8);
         g.codes[(size_t)p * bpad + b] = (b < g.batch) ? (unsigned short)code : (unsigned short)0;
       } else {
@@ -347,7 +355,24 @@ __global__ __launch_bounds__(64) void k_gather_level_lean(GroupDev g, int task0,
       }
     }
   }
-  if (WM != 1 && kind == 1) invert_and_scale<WM>(g, p, w, r0, r1, tmax_diag, true, bpad, b, eps);
+  if (WM != 1 && kind == 1) invert_and_scale<WM>(g, p, w, uoff, doff, sub, r0, r1, tmax_diag, true, bpad, b, eps);
+}
+
+// L values [v0, v1) of a panel of compile-time width W from row values held in registers
+template <int W, int RV>
+__device__ __forceinline__ void scale_held(const double (&u)[RV], const double* inv, double* Lp, int v0, int v1,
+                                           size_t bpad) {
+#pragma unroll
+  for (int i = 0; i < RV; ++i) {
+    if (v0 + i < v1) {
+      constexpr int dummy = 0; (void)dummy;
+      const int t2 = i % W, ib = i - i % W;
+      double v = 0.0;
+#pragma unroll
+      for (int t1 = 0; t1 < W; ++t1) v += u[(ib + t1) < RV ? (ib + t1) : RV - 1] * PP_INV(inv, t1, t2);
+      Lp[(size_t)(v0 + i) * bpad] = v;
+    }
+  }
 }
 
 // Scale task of a big panel (plan.hpp, kind 2): invert the gathered pivot block (every chunk does it
@@ -357,15 +382,61 @@ __global__ __launch_bounds__(64) void k_scale_level(GroupDev g, int task0, int c
   const int lane = threadIdx.x;
   const int b = (blockIdx.y + chunk0) * 64 + lane;
   const size_t bpad = (size_t)g.bpad;
-  const int* t = g.stask + 5 * (size_t)(task0 + blockIdx.x);
-  const int p = t[0], r0 = t[1], r1 = t[2];
-  const int w = g.piv_w[p];
-  const double* Tmp = g.Tm + (size_t)g.piv_boff[p] * bpad + b;
+  const int* t = g.stask + TASK_INTS * (size_t)(task0 + blockIdx.x);
+  const int p = t[0], r0 = t[1], r1 = t[2], w = t[7], uoff = t[8], boff = t[9], doff = t[10];
+  const unsigned sub = (unsigned)t[11];
+  const double* Tmp = g.Tm + (size_t)boff * bpad + b;
+  const double* Up = g.U + (size_t)uoff * bpad + b;
+  double* Lp = g.L + (size_t)uoff * bpad + b;
+  // block, its term magnitudes and the first rows of the chunk are requested together (one round trip)
+  constexpr int RV = 8;   // row values (rows * w) held while the block is inverted
+  double tm[PP_WMAX * PP_WMAX], blk[PP_WMAX * PP_WMAX], u[RV];
+#pragma unroll
+  for (int i = 0; i < PP_WMAX; ++i)
+#pragma unroll
+    for (int j = 0; j < PP_WMAX; ++j) {
+      const bool in = i < w && j < w;
+      const size_t off = (size_t)(in ? i * w + j : 0) * bpad;
+      const double tv = Tmp[off], uv = Up[off];
+      tm[i * PP_WMAX + j] = in ? tv : 0.0;
+      blk[i * PP_WMAX + j] = in ? uv : 0.0;
+    }
+  const int v0 = r0 * w, v1 = r1 * w;      // value range [v0, v1) of this chunk in the panel
+#pragma unroll
+  for (int i = 0; i < RV; ++i) u[i] = Up[(size_t)min(v0 + i, v1 - 1) * bpad];
   double tmax_diag = 0.0;
 #pragma unroll
-  for (int i = 0; i < PP_WMAX * PP_WMAX; ++i)
-    if (i < w * w) tmax_diag = fmax(tmax_diag, Tmp[(size_t)i * bpad]);
-  invert_and_scale<PP_WMAX>(g, p, w, r0, r1, tmax_diag, r0 == w, bpad, b, eps);
+  for (int i = 0; i < PP_WMAX * PP_WMAX; ++i) tmax_diag = fmax(tmax_diag, tm[i]);
+  double inv[PP_WMAX * (PP_WMAX + 1) / 2];
+  const int code = pp::invert_block(w, sub, blk, tmax_diag, eps, inv);
+  if (r0 == w) {
+    double* invp = g.Dinv + (size_t)doff * bpad + b;
+#pragma unroll
+    for (int i = 0; i < PP_WMAX * (PP_WMAX + 1) / 2; ++i)
+      if (i < w * (w + 1) / 2) invp[(size_t)i * bpad] = inv[i];
+    g.codes[(size_t)p * bpad + b] = (b < g.batch) ? (unsigned short)code : (unsigned short)0;
+  }
+  if (v1 - v0 <= RV) {
+    // the common shapes (8 rows x 1, 4 x 2, 2 x 4): rows already in registers
+    if (w == 1) { scale_held<1, RV>(u, inv, Lp, v0, v1, bpad); return; }
+    if (w == 2) { scale_held<2, RV>(u, inv, Lp, v0, v1, bpad); return; }
+    if (w == 4) { scale_held<4, RV>(u, inv, Lp, v0, v1, bpad); return; }
+  }
+  for (int r = r0; r < r1; ++r) {
+    double ur[PP_WMAX];
+#pragma unroll
+    for (int t1 = 0; t1 < PP_WMAX; ++t1) ur[t1] = (t1 < w) ? Up[(size_t)(r * w + t1) * bpad] : 0.0;
+#pragma unroll
+    for (int t2 = 0; t2 < PP_WMAX; ++t2) {
+      if (t2 < w) {
+        double v = 0.0;
+#pragma unroll
+        for (int t1 = 0; t1 < PP_WMAX; ++t1)
+          if (t1 < w) v += ur[t1] * PP_INV(inv, t1, t2);
+        Lp[(size_t)(r * w + t2) * bpad] = v;
+      }
+    }
+  }
 }
 
 // counters[0..2] += (pos, neg, zero) over all block pivots (codes of padded instances are 0);
@@ -1460,7 +1531,7 @@ int pp_end_symbolic(pp_handle h) {
     // expand the canonical initial-value entries into raw-value entries (duplicates are summed)
     fdst_ptr.reserve(P.fdst_ptr.size());
     fent.reserve(P.fentries.size() * 4 + 64);
-    ftask.reserve(P.ftasks.size() * 5);
+    ftask.reserve(P.ftasks.size() * TASK_INTS);
     for (auto& t : P.ftasks) {
       const int nrow = t.r1 - t.r0;
       const int new_dptr0 = (int)fdst_ptr.size();
@@ -1478,9 +1549,13 @@ int pp_end_symbolic(pp_handle h) {
         }
       }
       fdst_ptr.push_back((int)(fent.size() / 4));
-      ftask.insert(ftask.end(), {t.piv, t.r0, t.r1, new_dptr0, t.kind});
+      ftask.insert(ftask.end(), {t.piv, t.r0, t.r1, new_dptr0, t.kind, fdst_ptr[new_dptr0], (int)(fent.size() / 4),
+                                 P.piv_w[t.piv], (int)P.piv_uoff[t.piv], P.piv_boff[t.piv], P.piv_doff[t.piv],
+                                 (int)P.piv_sub[t.piv]});
     }
-    for (auto& t : P.stasks) stask.insert(stask.end(), {t.piv, t.r0, t.r1, -1, t.kind});
+    for (auto& t : P.stasks)
+      stask.insert(stask.end(), {t.piv, t.r0, t.r1, -1, t.kind, 0, 0, P.piv_w[t.piv], (int)P.piv_uoff[t.piv],
+                                 P.piv_boff[t.piv], P.piv_doff[t.piv], (int)P.piv_sub[t.piv]});
     for (int q = 0; q < 16; ++q) fent.insert(fent.end(), {0, 0, 0, 0});   // slack for the vector record reads
     for (auto& r : P.stile_rec) {
       srec.push_back(r.piv);
