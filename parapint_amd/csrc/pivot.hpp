@@ -47,7 +47,7 @@ PP_HD PivotResult invert_pivot(int w, double a, double b, double c, double colma
 }
 
 // ---------------------------------------------------------------------------------------------
-// Block pivot (supernode) of width w <= PP_WMAX made of a static sequence of 1x1 / 2x2 sub-pivots
+// Block pivot (supernode) of width w <= WB (template bound, <= PP_WMAX) made of a static sequence of 1x1 / 2x2 sub-pivots
 // (bit i of `sub` set: columns i, i+1 form a 2x2 sub-pivot).  The symmetric sweep operator is
 // applied sub-pivot by sub-pivot; the values met on the diagonal are exactly the LDL^T pivots of
 // the static sequence, so inertia and the zero-pivot rule are those of invert_pivot.  On exit
@@ -57,66 +57,72 @@ PP_HD PivotResult invert_pivot(int w, double a, double b, double c, double colma
 #define PP_WMAX 4
 #endif
 
-PP_HD int invert_block(int w, unsigned sub, const double* a /* row-major with stride PP_WMAX, lower triangle read */, double colmax,
-                       double eps, double* inv) {
-  double A[PP_WMAX][PP_WMAX];
+template <int WB>
+PP_HD int invert_block_t(int w, unsigned sub, const double* a /* row-major with stride WB, lower triangle read */, double colmax,
+                         double eps, double* inv) {
+  double A[WB][WB];
 #pragma unroll
-  for (int i = 0; i < PP_WMAX; ++i)
+  for (int i = 0; i < WB; ++i)
 #pragma unroll
-    for (int j = 0; j < PP_WMAX; ++j) {
+    for (int j = 0; j < WB; ++j) {
       const int hi = i > j ? i : j, lo = i > j ? j : i;
-      A[i][j] = (hi < w) ? a[hi * PP_WMAX + lo] : ((i == j) ? 1.0 : 0.0);
+      A[i][j] = (hi < w) ? a[hi * WB + lo] : ((i == j) ? 1.0 : 0.0);
     }
   int pos = 0, neg = 0, zero = 0;
   bool second = false;   // current column is the second column of a 2x2 sub-pivot
 #pragma unroll
-  for (int k = 0; k < PP_WMAX; ++k) {
+  for (int k = 0; k < WB; ++k) {
     if (k >= w) continue;
     if (second) { second = false; continue; }
     const bool two = ((sub >> k) & 1u) && (k + 1 < w);
     if (!two) {
       const PivotResult pr = invert_pivot(1, A[k][k], 0.0, 0.0, colmax, eps);
       pos += pr.code & 3; neg += (pr.code >> 2) & 3; zero += (pr.code >> 4) & 3;
-      double l[PP_WMAX];
+      double l[WB];
 #pragma unroll
-      for (int i = 0; i < PP_WMAX; ++i) l[i] = A[i][k] * pr.i00;
+      for (int i = 0; i < WB; ++i) l[i] = A[i][k] * pr.i00;
 #pragma unroll
-      for (int i = 0; i < PP_WMAX; ++i)
+      for (int i = 0; i < WB; ++i)
 #pragma unroll
-        for (int j = 0; j < PP_WMAX; ++j)
+        for (int j = 0; j < WB; ++j)
           if (i != k && j != k) A[i][j] -= l[i] * A[k][j];
 #pragma unroll
-      for (int i = 0; i < PP_WMAX; ++i)
+      for (int i = 0; i < WB; ++i)
         if (i != k) { A[i][k] = l[i]; A[k][i] = l[i]; }
       A[k][k] = -pr.i00;
     } else {
       second = true;
-      const int k1 = k + 1 < PP_WMAX ? k + 1 : k;
+      const int k1 = k + 1 < WB ? k + 1 : k;
       const PivotResult pr = invert_pivot(2, A[k][k], A[k1][k], A[k1][k1], colmax, eps);
       pos += pr.code & 3; neg += (pr.code >> 2) & 3; zero += (pr.code >> 4) & 3;
-      double l0[PP_WMAX], l1[PP_WMAX];
+      double l0[WB], l1[WB];
 #pragma unroll
-      for (int i = 0; i < PP_WMAX; ++i) {
+      for (int i = 0; i < WB; ++i) {
         l0[i] = A[i][k] * pr.i00 + A[i][k1] * pr.i10;
         l1[i] = A[i][k] * pr.i10 + A[i][k1] * pr.i11;
       }
 #pragma unroll
-      for (int i = 0; i < PP_WMAX; ++i)
+      for (int i = 0; i < WB; ++i)
 #pragma unroll
-        for (int j = 0; j < PP_WMAX; ++j)
+        for (int j = 0; j < WB; ++j)
           if (i != k && i != k1 && j != k && j != k1) A[i][j] -= l0[i] * A[k][j] + l1[i] * A[k1][j];
 #pragma unroll
-      for (int i = 0; i < PP_WMAX; ++i)
+      for (int i = 0; i < WB; ++i)
         if (i != k && i != k1) { A[i][k] = l0[i]; A[k][i] = l0[i]; A[i][k1] = l1[i]; A[k1][i] = l1[i]; }
       A[k][k] = -pr.i00; A[k1][k] = -pr.i10; A[k][k1] = -pr.i10; A[k1][k1] = -pr.i11;
     }
   }
 #pragma unroll
-  for (int i = 0; i < PP_WMAX; ++i)
+  for (int i = 0; i < WB; ++i)
 #pragma unroll
-    for (int j = 0; j < PP_WMAX; ++j)
+    for (int j = 0; j < WB; ++j)
       if (j <= i && i < w) inv[i * (i + 1) / 2 + j] = -A[i][j];
   return pos | (neg << 4) | (zero << 8);
+}
+
+// bound = the widest block the build supports
+PP_HD int invert_block(int w, unsigned sub, const double* a /* stride PP_WMAX */, double colmax, double eps, double* inv) {
+  return invert_block_t<PP_WMAX>(w, sub, a, colmax, eps, inv);
 }
 
 }  // namespace pp

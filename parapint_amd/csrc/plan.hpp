@@ -25,7 +25,7 @@
 #include <vector>
 
 #ifndef PP_WMAX
-#define PP_WMAX 4   // widest block pivot (supernode); pivot.hpp / kernels unroll to this bound
+#define PP_WMAX 4   // widest block pivot (supernode); pivot.hpp / kernels are instantiated for bounds 1, 2, 4 (8 builds too)
 #endif
 
 namespace pp {
@@ -40,9 +40,18 @@ struct PlanOptions {
   int tail_piv_max = 48;
   int tail_task_entries = 16;
   int tile = 8;           // register tile edge of the Schur (SYRK) kernel
-  int sn_wmax = 4;        // widest supernode (columns); 1 disables merging of sub-pivots (wider blocks need the
-                          // per-source block multiplier path)
+  int sn_wmax = 4;        // widest supernode (columns) below the top of the tree; 1 disables merging of sub-pivots
   int sn_tol_rows = 1;    // padded rows tolerated when merging a sub-pivot into its parent
+  // Top of the elimination tree: tree heights holding at most sn_tail_pop sub-pivots form dependent chains
+  // (one launch pair per level, latency-bound).  There a sub-pivot is merged into its parent even if up to
+  // sn_tail_tol_frac of the parent's structure has to be padded, up to sn_tail_wmax columns: a few padded
+  // rows in a handful of panels buy a shorter critical path.
+  // MEASURED (C3, PP_WMAX = 8 build): relaxed merging cut 18 levels to 16 but made the factor phase slower
+  // (0.74 -> 1.03 ms at frac 0.25, 1.29 ms at 1.0: 8-wide panels need 2-3x the registers in the gather /
+  // invert kernels and pad the tall coupling panels), so it is off by default (sn_tail_pop = 0).
+  int sn_tail_pop = 0;
+  int sn_tail_wmax = PP_WMAX;
+  double sn_tail_tol_frac = 0.25;
   int md_delta_abs = 3;   // minimum-degree tolerance (absolute) for height-aware selection
   double md_delta_rel = 0.5;   // ... and relative to the current minimum degree
   double pivot_threshold = 0.01;  // 1x1 pivot accepted if |d| >= threshold * max|row| (MA27 cntl(1) analogue)

@@ -160,13 +160,13 @@ __device__ __forceinline__ void invert_and_scale(const GroupDev& g, int p, int w
     inv[0] = pr.i00;
     code = (pr.code & 3) | (((pr.code >> 2) & 3) << 4) | (((pr.code >> 4) & 3) << 8);
   } else {
-    double blk[PP_WMAX * PP_WMAX];
+    double blk[WM * WM];
 #pragma unroll
-    for (int i = 0; i < PP_WMAX; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
-      for (int j = 0; j < PP_WMAX; ++j)
-        blk[i * PP_WMAX + j] = (i < w && j < w) ? Up[(size_t)(i * w + j) * bpad] : 0.0;
-    code = pp::invert_block(w, sub, blk, tmax_diag, eps, inv);
+      for (int j = 0; j < WM; ++j)
+        blk[i * WM + j] = (i < w && j < w) ? Up[(size_t)(i * w + j) * bpad] : 0.0;
+    code = pp::invert_block_t<WM>(w, sub, blk, tmax_diag, eps, inv);
   }
   if (publish) {
     double* invp = g.Dinv + (size_t)doff * bpad + b;
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(64) void k_gather_level(GroupDev g, int task0, int 
   }
     int i0 = 0;
     constexpr int GB = (WM == 1) ? 16 : 8;
-    if (WM > 1 && cnt > 8 && cnt <= 16) { PP_GROUP(16) i0 = 16; }   // a whole small task in ONE round trip
+    if (WM > 1 && WM <= 4 && cnt > 8 && cnt <= 16) { PP_GROUP(16) i0 = 16; }   // a whole small task in ONE round trip
     for (; cnt - i0 > 4; i0 += GB) PP_GROUP(GB)
     if (i0 < cnt) PP_GROUP(4)
 #undef PP_GROUP
@@ -378,6 +378,7 @@ __device__ __forceinline__ void scale_held(const double (&u)[RV], const double* 
 // Scale task of a big panel (plan.hpp, kind 2): invert the gathered pivot block (every chunk does it
 // redundantly in registers -- it is w*w loads and a few dozen flops), L rows = U rows * inv(P); the
 // chunk that starts right below the block also publishes inv(P) and the inertia code.
+template <int WM>
 __global__ __launch_bounds__(64) void k_scale_level(GroupDev g, int task0, int chunk0, double eps) {
   const int lane = threadIdx.x;
   const int b = (blockIdx.y + chunk0) * 64 + lane;
@@ -390,29 +391,29 @@ __global__ __launch_bounds__(64) void k_scale_level(GroupDev g, int task0, int c
   double* Lp = g.L + (size_t)uoff * bpad + b;
   // block, its term magnitudes and the first rows of the chunk are requested together (one round trip)
   constexpr int RV = 8;   // row values (rows * w) held while the block is inverted
-  double tm[PP_WMAX * PP_WMAX], blk[PP_WMAX * PP_WMAX], u[RV];
+  double tm[WM * WM], blk[WM * WM], u[RV];
 #pragma unroll
-  for (int i = 0; i < PP_WMAX; ++i)
+  for (int i = 0; i < WM; ++i)
 #pragma unroll
-    for (int j = 0; j < PP_WMAX; ++j) {
+    for (int j = 0; j < WM; ++j) {
       const bool in = i < w && j < w;
       const size_t off = (size_t)(in ? i * w + j : 0) * bpad;
       const double tv = Tmp[off], uv = Up[off];
-      tm[i * PP_WMAX + j] = in ? tv : 0.0;
-      blk[i * PP_WMAX + j] = in ? uv : 0.0;
+      tm[i * WM + j] = in ? tv : 0.0;
+      blk[i * WM + j] = in ? uv : 0.0;
     }
   const int v0 = r0 * w, v1 = r1 * w;      // value range [v0, v1) of this chunk in the panel
 #pragma unroll
   for (int i = 0; i < RV; ++i) u[i] = Up[(size_t)min(v0 + i, v1 - 1) * bpad];
   double tmax_diag = 0.0;
 #pragma unroll
-  for (int i = 0; i < PP_WMAX * PP_WMAX; ++i) tmax_diag = fmax(tmax_diag, tm[i]);
-  double inv[PP_WMAX * (PP_WMAX + 1) / 2];
-  const int code = pp::invert_block(w, sub, blk, tmax_diag, eps, inv);
+  for (int i = 0; i < WM * WM; ++i) tmax_diag = fmax(tmax_diag, tm[i]);
+  double inv[WM * (WM + 1) / 2];
+  const int code = pp::invert_block_t<WM>(w, sub, blk, tmax_diag, eps, inv);
   if (r0 == w) {
     double* invp = g.Dinv + (size_t)doff * bpad + b;
 #pragma unroll
-    for (int i = 0; i < PP_WMAX * (PP_WMAX + 1) / 2; ++i)
+    for (int i = 0; i < WM * (WM + 1) / 2; ++i)
       if (i < w * (w + 1) / 2) invp[(size_t)i * bpad] = inv[i];
     g.codes[(size_t)p * bpad + b] = (b < g.batch) ? (unsigned short)code : (unsigned short)0;
   }
@@ -421,17 +422,18 @@ __global__ __launch_bounds__(64) void k_scale_level(GroupDev g, int task0, int c
     if (w == 1) { scale_held<1, RV>(u, inv, Lp, v0, v1, bpad); return; }
     if (w == 2) { scale_held<2, RV>(u, inv, Lp, v0, v1, bpad); return; }
     if (w == 4) { scale_held<4, RV>(u, inv, Lp, v0, v1, bpad); return; }
+    if (WM >= 8 && w == 8) { scale_held<(WM >= 8 ? 8 : 1), RV>(u, inv, Lp, v0, v1, bpad); return; }
   }
   for (int r = r0; r < r1; ++r) {
-    double ur[PP_WMAX];
+    double ur[WM];
 #pragma unroll
-    for (int t1 = 0; t1 < PP_WMAX; ++t1) ur[t1] = (t1 < w) ? Up[(size_t)(r * w + t1) * bpad] : 0.0;
+    for (int t1 = 0; t1 < WM; ++t1) ur[t1] = (t1 < w) ? Up[(size_t)(r * w + t1) * bpad] : 0.0;
 #pragma unroll
-    for (int t2 = 0; t2 < PP_WMAX; ++t2) {
+    for (int t2 = 0; t2 < WM; ++t2) {
       if (t2 < w) {
         double v = 0.0;
 #pragma unroll
-        for (int t1 = 0; t1 < PP_WMAX; ++t1)
+        for (int t1 = 0; t1 < WM; ++t1)
           if (t1 < w) v += ur[t1] * PP_INV(inv, t1, t2);
         Lp[(size_t)(r * w + t2) * bpad] = v;
       }
@@ -1485,6 +1487,10 @@ int pp_add_group(pp_handle h, int n, int batch, int nnzK, const int32_t* rowK, c
         else if (k == "scale_task_rows") opt.scale_task_rows = (int)v;
         else if (k == "tail_task_entries") opt.tail_task_entries = (int)v;
         else if (k == "tail_piv_max") opt.tail_piv_max = (int)v;
+        else if (k == "sn_tail_pop") opt.sn_tail_pop = (int)v;
+        else if (k == "sn_tail_wmax") opt.sn_tail_wmax = (int)v;
+        else if (k == "sn_tail_tol_frac") opt.sn_tail_tol_frac = v;
+        else if (k == "sn_wmax") opt.sn_wmax = (int)v;
         else if (k == "md_delta_abs") opt.md_delta_abs = (int)v;
         else if (k == "md_delta_rel") opt.md_delta_rel = v;
         else return fail(h, 3, "PP_PLAN_TUNE: unknown key " + k);
@@ -1711,15 +1717,22 @@ int pp_numeric_local(pp_handle h) {
             if (lean) {
               if (mw == 1) PP_LAUNCH_GATHER(k_gather_level_lean, 1);
               else if (mw == 2) PP_LAUNCH_GATHER(k_gather_level_lean, 2);
+              else if (mw <= 4) PP_LAUNCH_GATHER(k_gather_level_lean, 4);
               else PP_LAUNCH_GATHER(k_gather_level_lean, PP_WMAX);
             } else {
               if (mw == 1) PP_LAUNCH_GATHER(k_gather_level, 1);
               else if (mw == 2) PP_LAUNCH_GATHER(k_gather_level, 2);
+              else if (mw <= 4) PP_LAUNCH_GATHER(k_gather_level, 4);
               else PP_LAUNCH_GATHER(k_gather_level, PP_WMAX);
             }
 #undef PP_LAUNCH_GATHER
           }
-          if (ns > 0) hipLaunchKernelGGL(k_scale_level, dim3(ns, ny), dim3(64), 0, fan[q], d, s0, sp.c0[q], PIVOT_EPS);
+          if (ns > 0) {
+            if (g->level_maxw[l] <= 4)
+              hipLaunchKernelGGL(k_scale_level<4>, dim3(ns, ny), dim3(64), 0, fan[q], d, s0, sp.c0[q], PIVOT_EPS);
+            else
+              hipLaunchKernelGGL(k_scale_level<PP_WMAX>, dim3(ns, ny), dim3(64), 0, fan[q], d, s0, sp.c0[q], PIVOT_EPS);
+          }
         }
       }
       if (join_streams(h, sp, fan)) return fail(h, 3, "stream join failed");

@@ -228,12 +228,32 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
     }
   std::vector<int> chain_width(sp_w), merged_child(nsp, -1);   // merged_child[q] = child merged into q
   std::vector<uint8_t> is_merged(nsp, 0);
+  // tree heights (children precede parents in elimination order) and the "tail": the heights from the
+  // root down that hold at most sn_tail_pop sub-pivots each
+  std::vector<int> sp_height(nsp, 0);
+  int hmax = 0;
+  for (int q = 0; q < nsp; ++q) {
+    for (int c : sp_children[q]) sp_height[q] = std::max(sp_height[q], sp_height[c] + 1);
+    hmax = std::max(hmax, sp_height[q]);
+  }
+  int tail_height = hmax + 1;
+  {
+    std::vector<int> pop(hmax + 1, 0);
+    for (int q = 0; q < nsp; ++q) ++pop[sp_height[q]];
+    while (opt.sn_tail_pop > 0 && tail_height > 0 && pop[tail_height - 1] <= opt.sn_tail_pop) --tail_height;
+  }
+  const int tail_wmax = std::min(std::max(opt.sn_tail_wmax, opt.sn_wmax), PP_WMAX);
   if (opt.sn_wmax > 1) {
     for (int q = 0; q < nsp; ++q) {
       int best = -1;
       const int q0 = sp_start[q], q1 = q0 + sp_w[q];
+      const bool in_tail = sp_height[q] >= tail_height;
+      const int wcap = in_tail ? tail_wmax : opt.sn_wmax;
+      const int tol = in_tail ? std::max(opt.sn_tol_rows,
+                                         (int)(opt.sn_tail_tol_frac * (double)(srows[q].size() + sp_w[q])))
+                              : opt.sn_tol_rows;
       for (int c : sp_children[q]) {
-        if (chain_width[c] + sp_w[q] > opt.sn_wmax) continue;
+        if (chain_width[c] + sp_w[q] > wcap) continue;
         const auto& rc = srows[c];
         // rows of c beyond q's columns vs rows of q; q's columns inside c's structure
         int have_cols = 0;
@@ -247,7 +267,7 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
           if (ic >= rc.size() || rc[ic] != rq[iq]) ++missing;
           ++iq;
         }
-        if (missing > opt.sn_tol_rows) continue;
+        if (missing > tol) continue;
         if (best < 0 || srows[c].size() > srows[best].size()) best = c;
       }
       if (best >= 0) { merged_child[q] = best; is_merged[best] = 1; chain_width[q] = chain_width[best] + sp_w[q]; }

@@ -54,7 +54,7 @@ def test_synthetic_c3_shape_plan_is_shallow_and_sparse():
     st = hs.stats
     assert st['n'] == 9200 and st['nc'] == 200
     assert st['n_levels'] <= 24
-    assert st['nnz_L'] <= 1.75 * 20192         # nnz(tril K_i) = 20 192 (supernode padding included)
+    assert st["nnz_L"] <= 1.75 * 20192         # nnz(tril K_i) = 20 192 (supernode padding included)
     rc, S, inertia = hs.factor()
     assert rc == 0 and inertia == (5000, 4200, 0)
 
