@@ -1,0 +1,80 @@
+#!/usr/bin/env python
+"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes -> profiles/pmc_traffic.json (HBM bytes per launch and per phase).
+
+Usage: python tools/pmc_traffic.py <fetch pass dir> <write pass dir> <raw_entries> <n> <batch> <out.json> [note]
+
+Method (MI355X_MICROARCH.md, section HBM): the two counters are collected in separate passes; values are KiB;
+WRITE_SIZE is exact; FETCH_SIZE under-reports wide coalesced reads on gfx950, so the read side is calibrated on
+k_transpose_in of the same run, whose reads are known exactly (batch * m * 8 bytes per launch, m = raw_entries for
+the value transposition and n for the right-hand-side one; one of each per step).
+"""
+import json
+import re
+import sys
+
+sys.path.insert(0, __file__.rsplit('/', 1)[0])
+from pmc_summary import load, short   # noqa: E402
+
+PHASE_OF = [
+    (r'^k_gather_level', 'factor_levels'), (r'^k_scale_level', 'factor_levels'),
+    (r'^k_count_codes|^k_schur_tiles|^k_schur_reduce', 'schur_tiles'),
+    (r'^k_add_q|^k_ldl_|^k_bk_factor|^k_write_tail|^k_publish_status', 'dense_S'),
+    (r'^k_fwd_level', 'fwd_levels'), (r'^k_fwd_coupling|^k_rs_reduce', 'fwd_coupling'),
+    (r'^k_coupling_solve', 'coupling_solve'), (r'^k_bwd_level|^k_transpose_out', 'bwd_levels'),
+]
+
+
+def main():
+    fetch = load(sys.argv[1], 'FETCH_SIZE')
+    write = load(sys.argv[2], 'WRITE_SIZE')
+    raw_entries, n, batch = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+    out_path = sys.argv[6]
+    note = sys.argv[7] if len(sys.argv) > 7 else ''
+    per = {}
+    for name in set(fetch) | set(write):
+        s = short(name)
+        f, nf = fetch.get(name, [0.0, 0])
+        w, nw = write.get(name, [0.0, 0])
+        e = per.setdefault(s, {'fetch_KiB': 0.0, 'write_KiB': 0.0, 'launches': 0})
+        e['fetch_KiB'] += f
+        e['write_KiB'] += w
+        e['launches'] += max(nf, nw)
+    steps = per['k_publish_status']['launches']          # one per numeric factorisation
+    tr = per['k_transpose_in']
+    known_read_KiB = steps * batch * (raw_entries + n) * 8 / 1024.0
+    calib = known_read_KiB / tr['fetch_KiB']
+    kernels, phases = {}, {}
+    for s, e in sorted(per.items()):
+        if not s.startswith('k_'):
+            continue
+        rd = e['fetch_KiB'] * calib * 1024.0
+        wr = e['write_KiB'] * 1024.0
+        kernels[s] = {'launches_per_step': e['launches'] / steps,
+                      'hbm_read_bytes_per_launch': rd / e['launches'], 'hbm_write_bytes_per_launch': wr / e['launches']}
+        ph = next((p for pat, p in PHASE_OF if re.search(pat, s)), None)
+        if s == 'k_transpose_in':
+            # one launch per step belongs to the value upload (assemble), one to the forward solve
+            share = raw_entries / float(raw_entries + n)
+            for p, sh in (('assemble', share), ('fwd_levels', 1.0 - share)):
+                q = phases.setdefault(p, {'hbm_bytes_per_step': 0.0, 'launches_per_step': 0.0})
+                q['hbm_bytes_per_step'] += (rd + wr) * sh / steps
+                q['launches_per_step'] += 1.0
+            continue
+        if ph:
+            q = phases.setdefault(ph, {'hbm_bytes_per_step': 0.0, 'launches_per_step': 0.0})
+            q['hbm_bytes_per_step'] += (rd + wr) / steps
+            q['launches_per_step'] += e['launches'] / steps
+    total = sum(p['hbm_bytes_per_step'] for p in phases.values())
+    out = {'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) of bench.py '
+                     'at C3 on one MI355X; read side calibrated on k_transpose_in (known byte count) as '
+                     'MI355X_MICROARCH.md section HBM prescribes. ' + note,
+           'steps_in_pass': steps, 'fetch_calibration': calib, 'hbm_bytes_per_step_total': total,
+           'kernels': kernels, 'phases': phases}
+    json.dump(out, open(out_path, 'w'), indent=1)
+    print('steps', steps, 'calibration', round(calib, 4), 'total GB/step', round(total / 1e9, 3))
+    for p, v in sorted(phases.items()):
+        print('  %-16s %8.3f GB/step  %5.1f launches' % (p, v['hbm_bytes_per_step'] / 1e9, v['launches_per_step']))
+
+
+if __name__ == '__main__':
+    main()
