@@ -73,7 +73,7 @@ def main():
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cpu_baseline as cb
-        cpu_baseline = cb.run(N, n_q, m, n_t, blocks_per_worker=6)
+        cpu_baseline = cb.run(N, n_q, m, n_t, blocks_per_worker=max(1, min(64, N // 16)))   # ~10 s on 16 cores at C3
 
     import torch
     import torch.distributed as dist

@@ -46,6 +46,7 @@ def run(n_blocks_total, n_q, m, n_theta, blocks_per_worker=6, workers=None, iter
     import multiprocessing as mp
     if workers is None:
         workers = min(os.cpu_count() or 1, 16)
+    blocks_per_worker = max(1, min(blocks_per_worker, n_blocks_total // workers if n_blocks_total >= workers else 1))
     jobs = [(n_q, m, n_theta, list(range(w * blocks_per_worker, (w + 1) * blocks_per_worker)), iteration)
             for w in range(workers)]
     ctx = mp.get_context('fork')

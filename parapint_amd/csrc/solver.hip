@@ -46,6 +46,7 @@ struct GroupDev {
   const int *piv_of_col, *rawmap;
   const int *ftask, *stask, *fdst_ptr, *fent;
   const int *clevel_col, *sfwd_eptr, *sfwd_upos, *sfwd_zcol;
+  const int *fwd_rec, *bwd_rec;   // per scheduled column, in level order: everything its solve task needs (one scalar read)
   const int *crow_eptr, *crow_upos, *crow_zcol;
   const int *stile_a, *stile_b, *stile_ptr, *stile_rec;
   double *raw, *rawT, *U, *L, *Dinv, *Tm, *Y, *X, *rhs, *rhsT, *xout, *Spart, *rspart;
@@ -1135,9 +1136,10 @@ __global__ __launch_bounds__(64) void k_fwd_level(GroupDev g, int col0, int chun
   const int lane = threadIdx.x;
   const int b = (blockIdx.y + chunk0) * 64 + lane;
   const size_t bpad = (size_t)g.bpad;
-  const int c = g.clevel_col[col0 + blockIdx.x];
-  const double y = g.rhsT[(size_t)g.perm[c] * bpad + b] -
-                   gather_row(g.sfwd_upos, g.sfwd_zcol, g.sfwd_eptr[c], g.sfwd_eptr[c + 1], g.L + b, g.Y + b, bpad, lane);
+  const int* rec = g.fwd_rec + 4 * (size_t)(col0 + blockIdx.x);   // {column, row of the right-hand side, e0, e1}
+  const int c = rec[0];
+  const double y = g.rhsT[(size_t)rec[1] * bpad + b] -
+                   gather_row(g.sfwd_upos, g.sfwd_zcol, rec[2], rec[3], g.L + b, g.Y + b, bpad, lane);
   g.Y[(size_t)c * bpad + b] = y;
 }
 
@@ -1167,18 +1169,16 @@ __global__ __launch_bounds__(64) void k_bwd_level(GroupDev g, int col0, int chun
   const int lane = threadIdx.x;
   const int b = (blockIdx.y + chunk0) * 64 + lane;
   const size_t bpad = (size_t)g.bpad;
-  const int c = g.clevel_col[col0 + blockIdx.x];
-  const int p = g.piv_of_col[c];
-  const int w = g.piv_w[p], p0 = g.piv_start[p], q = c - p0;
-  const int nr = g.piv_rowptr[p + 1] - g.piv_rowptr[p];
-  const int* ri = g.rowidx + g.piv_rowptr[p];
-  const double* Lp = g.L + ((size_t)g.piv_uoff[p] + (size_t)w * w + q) * bpad + b;   // column q of the rows below the block
+  const int* rec = g.bwd_rec + 8 * (size_t)(col0 + blockIdx.x);   // {c, w, q, nr, rowptr, L base, doff, p0}
+  const int c = rec[0], w = rec[1], q = rec[2], nr = rec[3];
+  const int* ri = g.rowidx + rec[4];
+  const double* Lp = g.L + (size_t)rec[5] * bpad + b;   // column q of the rows below the block
   const double* Xb = g.X + b;
   const int n = g.n;
   const size_t rstride = (size_t)w * bpad;
   // z = row q of inv(P) times y_p
-  const double* inv = g.Dinv + (size_t)g.piv_doff[p] * bpad + b;
-  const double* Yp = g.Y + (size_t)p0 * bpad + b;
+  const double* inv = g.Dinv + (size_t)rec[6] * bpad + b;
+  const double* Yp = g.Y + (size_t)rec[7] * bpad + b;
   double z = 0.0;
 #pragma unroll
   for (int t = 0; t < PP_WMAX; ++t) {
@@ -1588,6 +1588,19 @@ int pp_end_symbolic(pp_handle h) {
     if ((rc = dev_upload(h, g, &d.fdst_ptr, fdst_ptr))) return rc;
     if ((rc = dev_upload(h, g, &d.fent, fent))) return rc;
     if ((rc = dev_upload(h, g, &d.clevel_col, P.clevel_col))) return rc;
+    {
+      std::vector<int> frec, brec;
+      frec.reserve(P.clevel_col.size() * 4);
+      brec.reserve(P.clevel_col.size() * 8);
+      for (int c : P.clevel_col) {
+        const int pv = P.piv_of_col[c], w = P.piv_w[pv], q = c - P.piv_start[pv];
+        frec.insert(frec.end(), {c, P.perm[c], P.sfwd_eptr[c], P.sfwd_eptr[c + 1]});
+        brec.insert(brec.end(), {c, w, q, P.piv_rowptr[pv + 1] - P.piv_rowptr[pv], P.piv_rowptr[pv],
+                                 (int)(P.piv_uoff[pv] + (int64_t)w * w + q), P.piv_doff[pv], P.piv_start[pv]});
+      }
+      if ((rc = dev_upload(h, g, &d.fwd_rec, frec))) return rc;
+      if ((rc = dev_upload(h, g, &d.bwd_rec, brec))) return rc;
+    }
     {
       std::vector<int> up(P.sfwd_upos), zc(P.sfwd_zcol), cu(P.crow_upos), cz(P.crow_zcol);
       for (int q = 0; q < 16; ++q) { up.push_back(0); zc.push_back(0); cu.push_back(0); cz.push_back(0); }
