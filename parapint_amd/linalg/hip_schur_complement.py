@@ -72,6 +72,27 @@ def _canonical(row, col, ncols, lower_only):
     return crow, ccol, can_ptr, can_idx
 
 
+class _PatternChanged(Exception):
+    """A block carries entries outside the pattern the plan was made for (e.g. the diagonal blocks the
+    inertia-correction loop adds, interior_point.py:377-378 / sc_ip_interface.py:1736-1757)."""
+
+
+class _UnionMatrix(object):
+    """Minimal block-matrix view (the protocol of SURVEY 8b) over per-block COO matrices; used to re-plan on
+    the union of the old and the new pattern."""
+
+    def __init__(self, nb, blocks, nc):
+        self.bshape = (nb, nb)
+        self._blocks = blocks
+        self._nc = nc
+
+    def get_block(self, i, j):
+        return self._blocks.get((i, j))
+
+    def get_row_size(self, i):
+        return self._nc if i == self.bshape[0] - 1 else self._blocks[(i, i)].shape[0]
+
+
 class _BlockInfo(object):
     __slots__ = ('group', 'slot', 'raw_sig', 'n')
 
@@ -90,6 +111,16 @@ class _Group(object):
         self.staging = None
         self.rhs_staging = None
         self.x_staging = None
+        self.alt_layouts = []               # other raw COO layouts seen: (kr, kc, br, bc, canonical position per entry)
+        self._keyK = None
+        self._keyB = None
+
+    def keys(self):
+        """Sorted int64 keys of the canonical K (column-major tril) and border (row-major) patterns."""
+        if self._keyK is None:
+            self._keyK = self.colK.astype(np.int64) * self.n + self.rowK
+            self._keyB = self.rowB.astype(np.int64) * self.n + self.colB
+        return self._keyK, self._keyB
 
 
 class HipEngine(object):
@@ -345,19 +376,45 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         return all_zero
 
     @staticmethod
-    def _canonical_values(g, raw, kr, kc, br, bc, same_raw):
-        """Canonical values (duplicates summed, upper triangle dropped) of one block."""
+    def _layout_positions(g, kr, kc, br, bc):
+        """Canonical position of every raw entry of a layout that is not the group's reference order (-1: upper
+        triangle, dropped).  Raises _PatternChanged if an entry lies outside the planned pattern."""
+        keyK, keyB = g.keys()
+        low = kr >= kc
+        kk = kc.astype(np.int64) * g.n + kr
+        posK = np.searchsorted(keyK, kk)
+        posK[posK >= keyK.size] = 0
+        okK = keyK[posK] == kk if keyK.size else np.zeros(kk.size, dtype=bool)
+        if np.any(low & ~okK):
+            raise _PatternChanged()
+        posK = np.where(low, posK, -1)
+        kb = br.astype(np.int64) * g.n + bc
+        posB = np.searchsorted(keyB, kb)
+        posB[posB >= keyB.size] = 0
+        okB = keyB[posB] == kb if keyB.size else np.zeros(kb.size, dtype=bool)
+        if not np.all(okB):
+            raise _PatternChanged()
+        return np.concatenate([posK, posB + keyK.size]).astype(np.int64)
+
+    @classmethod
+    def _canonical_values(cls, g, raw, kr, kc, br, bc, same_raw):
+        """Canonical values (duplicates summed, upper triangle dropped) of one block.  Layouts other than the
+        reference order (quirk Q7; a subset of the planned pattern after a re-plan) go through a cached map."""
         if same_raw:
             return np.add.reduceat(raw[g.can_idx], g.can_ptr[:-1]) if g.can_idx.size else np.zeros(0)
-        n = g.n
-        rowK, colK, cpK, ciK = _canonical(kr, kc, n, True)
-        rowB, colB, cpB, ciB = _canonical(br, bc, n, False)
-        if not (np.array_equal(rowK, g.rowK) and np.array_equal(colK, g.colK) and
-                np.array_equal(rowB, g.rowB) and np.array_equal(colB, g.colB)):
-            raise RuntimeError('The nonzero structure of a block changed since symbolic factorization')
-        vK = np.add.reduceat(raw[:kr.size][ciK], cpK[:-1]) if ciK.size else np.zeros(0)
-        vB = np.add.reduceat(raw[kr.size:][ciB], cpB[:-1]) if ciB.size else np.zeros(0)
-        return np.concatenate([vK, vB])
+        pos = None
+        for (akr, akc, abr, abc, apos) in g.alt_layouts:
+            if (akr.size == kr.size and abr.size == br.size and np.array_equal(akr, kr) and np.array_equal(akc, kc) and
+                    np.array_equal(abr, br) and np.array_equal(abc, bc)):
+                pos = apos
+                break
+        if pos is None:
+            pos = cls._layout_positions(g, kr, kc, br, bc)
+            if len(g.alt_layouts) < 4:
+                g.alt_layouts.append((kr.copy(), kc.copy(), br.copy(), bc.copy(), pos))
+        keep = pos >= 0
+        ncan = g.rowK.size + g.rowB.size
+        return np.bincount(pos[keep], weights=raw[keep], minlength=ncan)
 
     def _stage_values(self, matrix):
         last = self.block_dim - 1
@@ -385,6 +442,34 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
 
     def _run_symbolic(self):
         self.plan_stats = self._eng.symbolic(self._nc, self._groups)
+
+    def _replan_union(self, matrix):
+        """New plan on (planned pattern) U (pattern of `matrix`), values of `matrix`; later matrices with either
+        pattern are subsets and need no further planning."""
+        from scipy.sparse import coo_matrix
+        last = self.block_dim - 1
+        blocks = {}
+        for ndx in self.local_block_indices:
+            g = self._binfo[ndx].group
+            n = g.n
+            kr, kc, kd, _ = _coo(matrix.get_block(ndx, ndx))
+            low = kr >= kc
+            rows = np.concatenate([g.rowK, kr[low]])
+            cols = np.concatenate([g.colK, kc[low]])
+            data = np.concatenate([np.zeros(g.rowK.size), kd[low]])
+            blocks[(ndx, ndx)] = coo_matrix((data, (rows, cols)), shape=(n, n))   # duplicates are summed by the plan
+            A = matrix.get_block(last, ndx)
+            if A is None:
+                br, bc, bd = np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int32), np.zeros(0)
+            else:
+                br, bc, bd, _ = _coo(A)
+            rows = np.concatenate([g.rowB, br])
+            cols = np.concatenate([g.colB, bc])
+            data = np.concatenate([np.zeros(g.rowB.size), bd])
+            blocks[(last, ndx)] = coo_matrix((data, (rows, cols)), shape=(self._nc, n))
+        self._build_groups(_UnionMatrix(self.block_dim, blocks, self._nc))
+        self._run_symbolic()
+        self._pattern_only = False
 
     # ------------------------------------------------------------------ interface
     def do_symbolic_factorization(self, matrix, raise_on_error=True, timer=None):
@@ -428,7 +513,13 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         res = LinearSolverResults(LinearSolverStatus.successful)
         timer.start('form SC')
         timer.start('factorize')
-        self._stage_values(matrix)
+        try:
+            self._stage_values(matrix)
+        except _PatternChanged:
+            # entries outside the planned pattern (the inertia-correction loop adds diagonal blocks): plan again
+            # on the union of both patterns, as the reference's MUMPS sub-solver does (mumps_interface.py:82-83)
+            self._replan_union(matrix)
+            self._stage_values(matrix)
         if self._pattern_only:
             # symbolic saw no usable values (quirk Q8): fix the pivot sequence now
             for g in self._groups:

@@ -260,6 +260,93 @@ def case_heterogeneous(make_engine):
     assert np.abs(x.flatten() - x_ref).max() <= 1e-8 * np.abs(x_ref).max()
 
 
+# ---- inertia-correction loop: the regularised KKT has extra diagonal blocks (pattern grows) --------
+def case_inertia_correction_pattern_growth(make_engine):
+    """interior_point.py:364-392 regularises with `kkt.set_block(.., coef * identity)` on blocks that were empty
+    (sc_ip_interface.py:1736-1757) and adds coef*I to the Hessian and to Q: the numeric call then sees a pattern
+    that is a superset of the symbolic one.  MUMPS re-does its analysis (mumps_interface.py:82-83); so do we, once,
+    on the union pattern; afterwards both patterns factorise without further planning."""
+    rng = np.random.default_rng(5)
+    n_x, n_c, nc, nb = 10, 4, 3, 5
+    A = BlockMatrix(nb + 1, nb + 1)
+    rhs = BlockVector(nb + 1)
+    Ks, Js, Hs, Bs = [], [], [], []
+    for i in range(nb):
+        h = rng.uniform(0.5, 2.0, size=n_x)
+        h[rng.random(n_x) < 0.3] = 0.0
+        hidx = np.flatnonzero(h)                                     # Hessian diagonal only where nonzero
+        J = (sp.random(n_c, n_x, density=0.3, random_state=10 + i, data_rvs=lambda k: rng.normal(size=k)) +
+             2.0 * sp.eye(n_c, n_x)).tocoo()
+        H = coo_matrix((h[hidx], (hidx, hidx)), shape=(n_x, n_x))
+        K = sp.bmat([[H, J.T], [J, None]]).tocoo()                  # (2,2) block empty: no diagonal entries there
+        B = coo_matrix((rng.normal(size=nc), (np.arange(nc), rng.choice(n_x, nc, replace=False))),
+                       shape=(nc, n_x + n_c))
+        A.set_block(i, i, K)
+        A.set_block(nb, i, B)
+        rhs.set_block(i, rng.normal(size=n_x + n_c))
+        Ks.append(K); Js.append(J); Hs.append(H); Bs.append(B)
+    A.set_block(nb, nb, coo_matrix((nc, nc)))
+    rhs.set_block(nb, rng.normal(size=nc))
+
+    def dense(Amat, q):
+        off = np.concatenate([[0], np.cumsum([n_x + n_c] * nb), [nb * (n_x + n_c) + nc]])
+        full = np.zeros((off[-1], off[-1]))
+        for i in range(nb):
+            Kd = Amat.get_block(i, i).toarray()
+            full[off[i]:off[i + 1], off[i]:off[i + 1]] = np.tril(Kd) + np.tril(Kd, -1).T
+            Bd = Amat.get_block(nb, i).toarray()
+            full[off[nb]:, off[i]:off[i + 1]] = Bd
+            full[off[i]:off[i + 1], off[nb]:] = Bd.T
+        full[off[nb]:, off[nb]:] = q
+        return full
+
+    def check(Amat, q):
+        full = dense(Amat, q)
+        ev = np.linalg.eigvalsh(full)
+        want = (int((ev > 1e-10).sum()), int((ev < -1e-10).sum()), int((np.abs(ev) <= 1e-10).sum()))
+        res = solver.do_numeric_factorization(Amat, raise_on_error=False)
+        singular_block = False
+        for i in range(nb):                     # the Schur-complement method needs every K_i nonsingular
+            Kd = Amat.get_block(i, i).toarray()
+            sv = np.linalg.svd(np.tril(Kd) + np.tril(Kd, -1).T, compute_uv=False)
+            singular_block = singular_block or sv.min() <= 1e-11 * sv.max()
+        if singular_block or want[2] > 0:
+            # what the reference's sub-solver reports (ma27_interface.py:126-136) and the inertia loop acts on
+            assert res.status == LinearSolverStatus.singular
+            return 'singular'
+        assert res.status == LinearSolverStatus.successful
+        assert solver.get_inertia() == want
+        x = solver.do_back_solve(rhs)
+        x_ref = np.linalg.solve(full, rhs.flatten())
+        assert np.abs(x.flatten() - x_ref).max() <= 1e-8 * np.abs(x_ref).max()
+        return 'ok'
+
+    solver = new_solver(make_engine, nb)
+    solver.do_symbolic_factorization(A)
+    assert check(A, np.zeros((nc, nc))) == 'singular'               # block 0 is singular: the loop regularises
+    for coef in (1e-4, 1e-2):                                        # two retries of the inertia loop
+        R = BlockMatrix(nb + 1, nb + 1)
+        for i in range(nb):
+            Hreg = (Hs[i] + coef * sp.identity(n_x, format='coo')).tocoo()            # regularize_hessian
+            Creg = (-coef) * sp.identity(n_c, format='coo')                             # regularize_equality_gradient
+            R.set_block(i, i, sp.bmat([[Hreg, Js[i].T], [Js[i], Creg]]).tocoo())
+            R.set_block(nb, i, Bs[i])
+        R.set_block(nb, nb, (coef * sp.identity(nc, format='coo')).tocoo())
+        assert check(R, coef * np.eye(nc)) == 'ok'
+    # back to an unregularised matrix (the next IP iteration): a subset of the union pattern, no new plan needed
+    A2 = BlockMatrix(nb + 1, nb + 1)
+    for i in range(nb):
+        K = Ks[i].copy()
+        K.data = K.data * rng.uniform(0.9, 1.1, size=K.data.size)
+        K = ((K + K.T) * 0.5).tocoo()
+        A2.set_block(i, i, K)
+        A2.set_block(nb, i, Bs[i])
+    A2.set_block(nb, nb, coo_matrix((nc, nc)))
+    groups_before = [id(g) for g in solver._groups]
+    check(A2, np.zeros((nc, nc)))
+    assert [id(g) for g in solver._groups] == groups_before        # no re-plan for a subset pattern
+
+
 # ---- error behaviour ------------------------------------------------------------------------------
 def case_errors(make_engine):
     import pytest

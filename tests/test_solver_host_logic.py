@@ -39,3 +39,7 @@ def test_heterogeneous_groups():
 
 def test_error_behaviour():
     sc.case_errors(make_engine)
+
+
+def test_inertia_correction_pattern_growth():
+    sc.case_inertia_correction_pattern_growth(make_engine)
