@@ -81,10 +81,19 @@ def main():
     from parapint_amd.linalg.comm import SerialComm, TorchComm
     from parapint_amd.linalg.hip_schur_complement import HipSchurComplementLinearSolver
 
+    # Rehearsal switch (not the measured configuration): PP_BENCH_REHEARSAL=gloo lets several ranks share the GPUs
+    # that are present and exchange through gloo (host-staged all-reduce), to exercise the N > 1 code path on a
+    # one-GPU box.  The driver's multi-GPU runs use one GPU per rank and RCCL.
+    rehearsal = os.environ.get('PP_BENCH_REHEARSAL', '')
+    if rehearsal:
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        if rehearsal:
+            dist.init_process_group(rehearsal, rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
         comm = TorchComm()
     else:
         comm = SerialComm()
@@ -243,6 +252,8 @@ def main():
     phase_bytes = {'assemble': 8.0 * (2 * st['raw_entries'] + z_K + z_L), 'factor_levels': float(sb['factor']),
                    'schur_tiles': float(sb['schur']), 'fwd_levels': sb['back_solve'] / 2.0,
                    'bwd_levels': sb['back_solve'] / 2.0}
+    if not any(p in phase_bytes for p in phases):
+        raise SystemExit('bench.py needs --profile-steps >= 1 for the roofline entry')
     dom = max((p for p in phases if p in phase_bytes), key=lambda p: phases[p]['ms_per_step'])
     dom_ms = phases[dom]['ms_per_step']
     dom_launches = max(1, phases[dom]['launches_per_step'])
