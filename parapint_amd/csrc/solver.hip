@@ -500,29 +500,38 @@ __global__ __launch_bounds__(64) void k_schur_tiles(GroupDev g) {
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
-  for (int r = g.stile_ptr[tile]; r < g.stile_ptr[tile + 1]; ++r) {
-    const int* rec = g.stile_rec + 17 * (size_t)r;
-    const int p = rec[0];
-    const int w = g.piv_w[p];
-    const double* Up = g.U + (size_t)g.piv_uoff[p] * bpad + b;
-    const double* Lp = g.L + (size_t)g.piv_uoff[p] * bpad + b;
-    for (int t = 0; t < w; ++t) {
-      double la[8], ub[4];
+  // column-step records {w, position of (row 0, column t) of the panel, -, -, slotA[8], slotB[8]}: one per panel
+  // column holding rows of both tile ranges; four steps (48 loads) are in flight together
+  const int r0 = g.stile_ptr[tile], r1 = g.stile_ptr[tile + 1];
+  constexpr int SG = 4;
+  for (int r = r0; r < r1; r += SG) {
+    double la[SG][8], ub[SG][4];
+#pragma unroll
+    for (int s = 0; s < SG; ++s) {
+      const bool live = r + s < r1;
+      const int* rec = g.stile_rec + 20 * (size_t)min(r + s, r1 - 1);
+      const int w = rec[0];
+      const double* Up = g.U + (size_t)rec[1] * bpad + b;
+      const double* Lp = g.L + (size_t)rec[1] * bpad + b;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int sa = rec[1 + i];
-        la[i] = (sa >= 0) ? Lp[(size_t)(sa * w + t) * bpad] : 0.0;
+        const int sa = rec[4 + i];
+        const double v = Lp[(size_t)(max(sa, 0) * w) * bpad];
+        la[s][i] = (sa >= 0 && live) ? v : 0.0;
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int sb = rec[9 + 4 * half + j];
-        ub[j] = (sb >= 0) ? Up[(size_t)(sb * w + t) * bpad] : 0.0;
+        const int sb = rec[12 + 4 * half + j];
+        const double v = Up[(size_t)(max(sb, 0) * w) * bpad];
+        ub[s][j] = (sb >= 0) ? v : 0.0;
       }
+    }
+#pragma unroll
+    for (int s = 0; s < SG; ++s)
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] -= la[i] * ub[j];
-    }
+        for (int j = 0; j < 4; ++j) acc[i][j] -= la[s][i] * ub[s][j];
   }
   const double mask = (b < g.batch) ? 1.0 : 0.0;
 #pragma unroll
@@ -1563,11 +1572,21 @@ int pp_end_symbolic(pp_handle h) {
       stask.insert(stask.end(), {t.piv, t.r0, t.r1, -1, t.kind, 0, 0, P.piv_w[t.piv], (int)P.piv_uoff[t.piv],
                                  P.piv_boff[t.piv], P.piv_doff[t.piv], (int)P.piv_sub[t.piv]});
     for (int q = 0; q < 16; ++q) fent.insert(fent.end(), {0, 0, 0, 0});   // slack for the vector record reads
-    for (auto& r : P.stile_rec) {
-      srec.push_back(r.piv);
-      for (int q = 0; q < 8; ++q) srec.push_back(r.slotA[q]);
-      for (int q = 0; q < 8; ++q) srec.push_back(r.slotB[q]);
+    // tile records (one per panel) -> column-step records (one per panel column), with their own tile pointers
+    std::vector<int> sptr(P.stile_ptr.size(), 0);
+    for (size_t tix = 0; tix + 1 < P.stile_ptr.size(); ++tix) {
+      sptr[tix] = (int)(srec.size() / 20);
+      for (int ri = P.stile_ptr[tix]; ri < P.stile_ptr[tix + 1]; ++ri) {
+        const auto& r = P.stile_rec[ri];
+        const int w = P.piv_w[r.piv];
+        for (int t = 0; t < w; ++t) {
+          srec.insert(srec.end(), {w, (int)(P.piv_uoff[r.piv] + t), r.piv, t});
+          for (int q = 0; q < 8; ++q) srec.push_back(r.slotA[q]);
+          for (int q = 0; q < 8; ++q) srec.push_back(r.slotB[q]);
+        }
+      }
     }
+    if (!sptr.empty()) sptr.back() = (int)(srec.size() / 20);
     if ((rc = dev_upload(h, g, &d.piv_w, P.piv_w))) return rc;
     if ((rc = dev_upload(h, g, &d.piv_start, P.piv_start))) return rc;
     if ((rc = dev_upload(h, g, &d.piv_uoff, uoff))) return rc;
@@ -1613,7 +1632,7 @@ int pp_end_symbolic(pp_handle h) {
     }
     if ((rc = dev_upload(h, g, &d.stile_a, P.stile_a))) return rc;
     if ((rc = dev_upload(h, g, &d.stile_b, P.stile_b))) return rc;
-    if ((rc = dev_upload(h, g, &d.stile_ptr, P.stile_ptr))) return rc;
+    if ((rc = dev_upload(h, g, &d.stile_ptr, sptr))) return rc;
     if ((rc = dev_upload(h, g, &d.stile_rec, srec))) return rc;
     g->ntiles = (int)P.stile_a.size();
     const size_t bp = (size_t)d.bpad;
