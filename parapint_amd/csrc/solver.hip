@@ -729,6 +729,159 @@ __global__ __launch_bounds__(LDL_THREADS) void k_ldl_blocked(int n, double* __re
   }
 }
 
+// Multi-workgroup variant for large n (the 1000 x 1000 S of configuration C5): the same blocked algorithm with
+// the panel and the trailing update spread over the chip, two launches per 32-column panel.
+//   k_dense_anorm   scale of the zero-pivot test (max |diagonal|), clears the acceptance flags
+//   k_dense_panel   every workgroup factors the 32 x 32 diagonal block redundantly in LDS / registers (it is
+//                   tiny) and solves 256 rows of the panel against it; workgroup 0 stores the block and the flags
+//   k_dense_update  A22 -= L21 D L21^T, one 16 x 16 tile per wave on the fp64 matrix cores
+//   k_dense_finish  acceptance rule of k_ldl_blocked -> mode / inertia counters
+constexpr int DN_THREADS = 256;
+
+__global__ __launch_bounds__(256) void k_dense_anorm(int n, const double* __restrict__ A, double* __restrict__ anorm,
+                                                     int* __restrict__ flags) {
+  __shared__ double red[4];
+  double loc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) loc = fmax(loc, fabs(A[i + (size_t)i * n]));
+  for (int off = 32; off > 0; off >>= 1) loc = fmax(loc, __shfl_xor(loc, off));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = loc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    anorm[0] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    flags[0] = 0; flags[1] = 0;
+  }
+}
+
+__global__ __launch_bounds__(DN_THREADS) void k_dense_panel(int n, double* __restrict__ A, double* __restrict__ dvec,
+                                                            const double* __restrict__ anorm_p, int* __restrict__ flags,
+                                                            double* __restrict__ stage, int j0, double eps) {
+  __shared__ double Db[LDL_NB][LDL_NB + 1];
+  __shared__ double dl[LDL_NB];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const size_t lda = (size_t)n;
+  const int nb = min(LDL_NB, n - j0), j1 = j0 + nb, m = n - j1;
+  const double anorm = anorm_p[0];
+  for (int idx = tid; idx < nb * nb; idx += DN_THREADS) {
+    const int i = idx % nb, j = idx / nb;
+    Db[i][j] = (i >= j) ? A[(j0 + i) + (size_t)(j0 + j) * lda] : 0.0;
+  }
+  // this workgroup's row of the panel: requested before the diagonal block is factored
+  const int r = (int)(blockIdx.x - 1) * DN_THREADS + tid;
+  const bool have_row = blockIdx.x > 0 && r < m && nb == LDL_NB;
+  double wrow[LDL_NB];
+#pragma unroll
+  for (int k = 0; k < LDL_NB; ++k) wrow[k] = have_row ? A[(j1 + r) + (size_t)(j0 + k) * lda] : 0.0;
+  __syncthreads();
+  if (wv == 0) {
+    double row[LDL_NB];
+    const int i = lane & 31;
+#pragma unroll
+    for (int j = 0; j < LDL_NB; ++j) row[j] = (i < nb && j < nb) ? Db[i][j] : ((i == j) ? 1.0 : 0.0);
+    int bad = 0, signs = 0;
+#pragma unroll
+    for (int k = 0; k < LDL_NB; ++k) {
+      const double colk = row[k];
+      double d = bcastd(colk, k);
+      if (k < nb) {
+        if (!(fabs(d) > eps * anorm)) { bad = 1; d = (anorm > 0.0 ? anorm : 1.0); }
+        signs |= (d > 0.0) ? 1 : 2;
+      }
+      const double lik = colk / d;
+#pragma unroll
+      for (int j = k + 1; j < LDL_NB; ++j) {
+        const double ajk = bcastd(colk, j);
+        if (i >= j) row[j] -= lik * ajk;
+      }
+      if (i > k) row[k] = lik;
+      else if (i == k) row[k] = d;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (lane < nb) {
+#pragma unroll
+      for (int j = 0; j < LDL_NB; ++j) if (j < nb) Db[lane][j] = row[j];
+    }
+    if (lane == 0 && blockIdx.x == 0) {
+      if (bad) atomicOr(&flags[0], 1);
+      atomicOr(&flags[1], signs);
+    }
+  }
+  __syncthreads();
+  if (tid < nb) dl[tid] = Db[tid][tid];
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    // factored diagonal block (unit lower L11, pivots on the diagonal): the other workgroups of this launch still
+    // read the unfactored block from A, so it goes to a staging tile and k_dense_update copies it in; only the last
+    // panel (no other workgroup, no update launch) is stored directly
+    for (int idx = tid; idx < nb * nb; idx += DN_THREADS) {
+      const int i = idx % nb, j = idx / nb;
+      const double v = (i > j) ? Db[i][j] : ((i == j) ? dl[i] : 0.0);
+      if (m > 0) stage[idx] = v;
+      else if (i >= j) A[(j0 + i) + (size_t)(j0 + j) * lda] = v;
+    }
+    if (tid < nb) dvec[j0 + tid] = dl[tid];
+    return;
+  }
+  if (have_row) {          // W = A21 L11^{-T}, L21 = W D^{-1}
+#pragma unroll
+    for (int k = 0; k < LDL_NB; ++k) {
+      double v = wrow[k];
+#pragma unroll
+      for (int j = 0; j < k; ++j) v -= wrow[j] * Db[k][j];
+      wrow[k] = v;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int k = 0; k < LDL_NB; ++k) A[(j1 + r) + (size_t)(j0 + k) * lda] = wrow[k] / dl[k];
+  }
+}
+
+__global__ __launch_bounds__(DN_THREADS) void k_dense_update(int n, double* __restrict__ A, const double* __restrict__ dvec,
+                                                             const double* __restrict__ stage, int j0) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const size_t lda = (size_t)n;
+  if (blockIdx.x == 0) {   // the factored diagonal block of this panel (staged by k_dense_panel) -> A
+    for (int idx = threadIdx.x; idx < LDL_NB * LDL_NB; idx += DN_THREADS) {
+      const int i = idx % LDL_NB, j = idx / LDL_NB;
+      if (i >= j) A[(j0 + i) + (size_t)(j0 + j) * lda] = stage[idx];
+    }
+  }
+  const int j1 = j0 + LDL_NB, m = n - j1;
+  const int nt = (m + 15) / 16, ntiles = nt * (nt + 1) / 2;
+  const int tix = (int)blockIdx.x * (DN_THREADS / 64) + wv;
+  if (tix >= ntiles) return;
+  const int li = lane & 15, lk = lane >> 4;
+  int I = (int)((sqrt(8.0 * tix + 1.0) - 1.0) * 0.5);
+  while ((I + 1) * (I + 2) / 2 <= tix) ++I;
+  while (I * (I + 1) / 2 > tix) --I;
+  const int J = tix - I * (I + 1) / 2;
+  const int ra = j1 + 16 * I + li, rb = j1 + 16 * J + li;
+  const bool va = ra < n, vb = rb < n;
+  double4_t acc = {0.0, 0.0, 0.0, 0.0};
+  double av[LDL_NB / 4], bv[LDL_NB / 4];
+#pragma unroll
+  for (int q = 0; q < LDL_NB / 4; ++q) {
+    const int k = 4 * q + lk;
+    av[q] = va ? A[ra + (size_t)(j0 + k) * lda] * dvec[j0 + k] : 0.0;
+    bv[q] = vb ? A[rb + (size_t)(j0 + k) * lda] : 0.0;
+  }
+#pragma unroll
+  for (int q = 0; q < LDL_NB / 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
+  const int col = j1 + 16 * J + li;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = j1 + 16 * I + lk + 4 * r;
+    if (row < n && col < n && row >= col) A[row + (size_t)col * lda] -= acc[r];
+  }
+}
+
+__global__ void k_dense_finish(int n, const int* __restrict__ flags, int* __restrict__ mode, int* __restrict__ info) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const bool ok = (flags[0] == 0) && (flags[1] == 1 || flags[1] == 2 || n == 0);
+    mode[0] = ok ? 1 : 0;
+    if (ok) { info[0] = (flags[1] == 1) ? n : 0; info[1] = (flags[1] == 2) ? n : 0; info[2] = 0; }
+  }
+}
+
 // Register-resident variant for n <= 16 * LDLR_NT (= 208; the reference configurations have n_c = 200):
 // the whole lower triangle lives in the MFMA accumulators of the 8 waves (91 tiles of 16x16, <= 12 per
 // wave) for the entire factorisation, so a trailing update is LDS reads + fp64 MFMAs only -- no global
@@ -1809,11 +1962,29 @@ int pp_factor_schur(pp_handle h, const double* Q_host) {
     if (h->dense_policy == 0)
       // (a left-looking variant with the panel resident in LDS was measured no faster: 0.344 vs 0.315 ms at
       // n_c = 200 -- the serial diagonal-block factor dominates both)
-      if (nc <= 16 * LDLR_NT)
+      if (nc <= 16 * LDLR_NT) {
         hipLaunchKernelGGL(k_ldl_regs, dim3(1), dim3(LDL_THREADS), 0, st, nc, h->Sldl, h->dvec, h->dense_mode, h->bkinfo, BK_EPS);
-      else
+      } else if (nc <= 512) {
         hipLaunchKernelGGL(k_ldl_blocked, dim3(1), dim3(LDL_THREADS), 0, st, nc, h->Sldl, h->dvec, h->dense_mode, h->bkinfo,
                            BK_EPS);
+      } else {
+        // large S: panel + trailing update spread over the chip, two launches per 32 columns
+        double* anorm = h->work;                    // (scratch of the Bunch-Kaufman fallback, free until then:
+        double* stage = h->work + 8;                //  2 n_c doubles >= 8 + 32 * 32 for n_c > 512)
+        int* flags = h->dense_mode + 2;
+        hipLaunchKernelGGL(k_dense_anorm, dim3(1), dim3(256), 0, st, nc, h->Sldl, anorm, flags);
+        for (int j0 = 0; j0 < nc; j0 += LDL_NB) {
+          const int m = nc - std::min(nc, j0 + LDL_NB);
+          hipLaunchKernelGGL(k_dense_panel, dim3(1 + (m + DN_THREADS - 1) / DN_THREADS), dim3(DN_THREADS), 0, st, nc,
+                             h->Sldl, h->dvec, anorm, flags, stage, j0, BK_EPS);
+          if (m > 0) {
+            const int nt = (m + 15) / 16, ntiles = nt * (nt + 1) / 2, per = DN_THREADS / 64;
+            hipLaunchKernelGGL(k_dense_update, dim3((ntiles + per - 1) / per), dim3(DN_THREADS), 0, st, nc, h->Sldl,
+                               h->dvec, stage, j0);
+          }
+        }
+        hipLaunchKernelGGL(k_dense_finish, dim3(1), dim3(64), 0, st, nc, flags, h->dense_mode, h->bkinfo);
+      }
     else
       PP_HIP(hipMemsetAsync(h->dense_mode, 0, sizeof(int), st));
     hipLaunchKernelGGL(k_bk_factor, dim3(1), dim3(BK_THREADS), 0, st, nc, h->Sfac, h->ipiv, h->work, h->bkinfo,
