@@ -63,8 +63,9 @@ def run(n_blocks_total, n_q, m, n_theta, blocks_per_worker=6, workers=None, iter
         'cores': workers,
         'kind': 'port',
         'sample': '%d of %d blocks (%d per worker process), SciPy SuperLU sub-solver, reference algorithm '
-                  '(1 factorisation + %d single-rhs solves + 2 back-solves per block), extrapolated linearly in '
-                  'the block count; slowest worker %.2f s, wall %.2f s' %
-                  (blocks, n_blocks_total, blocks_per_worker, n_theta, busy, wall),
+                  '(1 factorisation + %d single-rhs solves + 2 back-solves per block)%s; slowest worker %.2f s, '
+                  'wall %.2f s' %
+                  (blocks, n_blocks_total, blocks_per_worker, n_theta,
+                   '' if blocks >= n_blocks_total else ', extrapolated linearly in the block count', busy, wall),
         'seconds': busy,
     }
