@@ -16,9 +16,11 @@
 //
 // Pivots are static: 1x1 or 2x2, chosen by a minimum-degree ordering constrained so
 // that a node with a (numerically) weak diagonal is only eliminated after a neighbour
-// has given it a diagonal update, or inside a 2x2 pivot.  Storage is "U form":
-//   panel(p) = [ P_p ; U_p ]  with U_p = L_p * P_p  (unscaled columns), inv(P_p) kept
-// separately, so all row chunks of a panel are independent tasks.
+// has given it a diagonal update, or inside a 2x2 pivot; sub-pivots along elimination-tree
+// chains are merged into block pivots (supernodes) of up to PP_WMAX columns.  Storage is
+// "L form" (see FTask below): the unscaled panel [ P_p ; U_p ] and the scaled rows
+// L_p = U_p inv(P_p) with identical indexing, inv(P_p) kept separately, so all row chunks of
+// a panel are independent tasks and every update is a two-operand gather.
 #pragma once
 #include <cstdint>
 #include <string>
@@ -34,9 +36,8 @@ struct PlanOptions {
   int max_task_entries = 24;   // entries per gather chunk of a big panel
   int fuse_task_entries = 24;  // panels with at most this many entries are one fused task (gather + invert + scale)
   int scale_task_rows = 8;     // rows per scale task of a big panel
-  // Top of the elimination tree ("tail"): levels holding at most tail_piv_max pivots each are run
-  // inside ONE persistent launch per phase (a workgroup per 64 instances, barrier per level), with
-  // smaller tasks so that the few waves of that workgroup share the work.
+  // Top of the elimination tree ("tail"): levels holding at most tail_piv_max pivots each get their own task
+  // size (few panels, long rows: shorter tasks give more waves per level).
   int tail_piv_max = 48;
   int tail_task_entries = 16;
   int tile = 8;           // register tile edge of the Schur (SYRK) kernel
