@@ -165,6 +165,15 @@ int pp_phase_times(pp_handle h, double ms_out[8], int32_t launches_out[8], int32
 int pp_group_stats(pp_handle h, int group, int64_t out[16]);
 /* Elimination order of a group (new -> old), n ints. */
 int pp_group_perm(pp_handle h, int group, int32_t* perm);
+/* Inertia-correction fast path (interior_point.py:364-392, interfaces/interface.py:590-619,
+ * sc_ip_interface.py:1736-1757): the regularised KKT differs from the one whose values are resident only by
+ * + delta_w on the diagonal of the Hessian rows and - delta_c on the diagonal of the constraint rows.
+ * pp_set_diagonal_classes (after pp_end_symbolic): cls[n] per row of K_i of the group -- 0 none, 1 Hessian row,
+ * 2 constraint row; every classed row needs its diagonal entry in the planned pattern (status 3 otherwise).
+ * pp_numeric_local_shifted = pp_numeric_local on the resident values with those shifts applied on the device
+ * (no host staging, no H2D); the shift of the coupling block goes into Q of pp_factor_schur as usual. */
+int pp_set_diagonal_classes(pp_handle h, int group, const int8_t* cls);
+int pp_numeric_local_shifted(pp_handle h, double delta_w, double delta_c);
 /* Diagnostic: the factor of one instance (block) of a group after pp_numeric_local, in the plan's
  * panel storage: which = 0 unscaled panels U, 1 scaled rows L (the MA27 factor entries,
  * ma27_interface.py:124), 2 packed inverses of the block pivots.  count doubles are copied. */

@@ -55,6 +55,8 @@ SIGNATURES = {
     'pp_phase_times': (ctypes.c_int, [ctypes.c_void_p, _f64p, _i32p, _i32p]),
     'pp_group_stats': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _i64p]),
     'pp_group_perm': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _i32p]),
+    'pp_set_diagonal_classes': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    'pp_numeric_local_shifted': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_double]),
     'pp_get_factor': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f64p, ctypes.c_int64]),
 }
 

@@ -96,6 +96,17 @@ __global__ __launch_bounds__(256) void k_transpose_in(const double* __restrict__
   }
 }
 
+// Inertia-correction fast path (interior_point.py:364-392, interface.py:590-619): the diagonal entries of the
+// rows of class 1 (Hessian) get + delta_w, those of class 2 (constraints) get - delta_c, directly in the
+// transposed input of values that are already resident.
+__global__ __launch_bounds__(256) void k_shift_diag(double* __restrict__ rawT, const int* __restrict__ rows,
+                                                    const int* __restrict__ cls, int nshift, int bpad, double dw,
+                                                    double dc) {
+  const int j = blockIdx.x, b = blockIdx.y * 256 + threadIdx.x;
+  if (j >= nshift || b >= bpad) return;
+  rawT[(size_t)rows[j] * bpad + b] += (cls[j] == 1) ? dw : -dc;
+}
+
 // out[b][i] = W[iperm[i]][b]
 __global__ __launch_bounds__(256) void k_transpose_out(const double* __restrict__ W, const int* __restrict__ iperm,
                                                        double* __restrict__ out, int nrows, int m, int bpad) {
@@ -1394,6 +1405,9 @@ struct Group {
   double *raw_own = nullptr, *rhs_own = nullptr;
   int nraw_used = 0;
   std::vector<int> level_maxw;   // widest block pivot per level (selects the scalar kernel variants)
+  std::vector<int> diag_can;     // canonical entry of the diagonal (i, i) of K, or -1
+  int nshift = 0;                // rows with a regularisation class (pp_set_diagonal_classes)
+  const int *shift_row = nullptr, *shift_cls = nullptr;   // device: transposed-input row of their diagonal entry, class
 };
 
 }  // namespace
@@ -1414,6 +1428,7 @@ struct pp_solver {
   volatile long long* status_host = nullptr;
   long long* status_dev = nullptr;
   long long status_seq = 0;
+  double shift_w = 0.0, shift_c = 0.0;   // diagonal shifts of the current pp_numeric_local_shifted call (else 0)
   double mem_factor = 1.0;
   std::string err;
   // Instance groups ("splits"): the level sweeps of disjoint 64-instance chunk ranges are
@@ -1663,6 +1678,9 @@ int pp_add_group(pp_handle h, int n, int batch, int nnzK, const int32_t* rowK, c
   int rc = pp::build_plan(n, h->nc, nnzK, rowK, colK, nnzB, rowB, colB, rep_vals, opt, g->plan);
   if (rc != 0) { std::string e = g->plan.error; delete g; return fail(h, rc, "symbolic analysis failed: " + e); }
   const int ncan = nnzK + nnzB;
+  g->diag_can.assign((size_t)n, -1);
+  for (int e = 0; e < nnzK; ++e)
+    if (rowK[e] == colK[e]) g->diag_can[(size_t)rowK[e]] = e;
   g->batch = batch; g->nraw = nraw;
   g->can_ptr.assign(can_ptr, can_ptr + ncan + 1);
   g->can_idx.assign(can_idx, can_idx + can_ptr[ncan]);
@@ -1880,6 +1898,9 @@ int pp_numeric_local(pp_handle h) {
         const int tiles = transpose_tiles(d.nraw, d.nchunk);
         hipLaunchKernelGGL(k_transpose_in, dim3((d.nraw + 64 * tiles - 1) / (64 * tiles), d.nchunk), dim3(256), 0, st, d.raw,
                            d.rawT, d.rawmap, d.batch, d.nraw, d.bpad, tiles);
+        if (g->nshift > 0 && (h->shift_w != 0.0 || h->shift_c != 0.0))
+          hipLaunchKernelGGL(k_shift_diag, dim3(g->nshift, (d.bpad + 255) / 256), dim3(256), 0, st, d.rawT, g->shift_row,
+                             g->shift_cls, g->nshift, d.bpad, h->shift_w, h->shift_c);
       }
     }
     {
@@ -2254,6 +2275,48 @@ int pp_group_perm(pp_handle h, int group, int32_t* perm) {
   if (!g) return fail(h, 3, "pp_group_perm: bad group");
   std::memcpy(perm, g->plan.perm.data(), sizeof(int) * g->plan.n);
   return 0;
+}
+
+int pp_set_diagonal_classes(pp_handle h, int group, const int8_t* cls) {
+  Group* g = get_group(h, group);
+  if (!g || !h->symbolic_done) return fail(h, 3, "pp_set_diagonal_classes: bad group or symbolic phase not finished");
+  PP_HIP(hipSetDevice(h->device));
+  std::vector<int> rows, kinds;
+  for (int i = 0; i < g->plan.n; ++i) {
+    if (cls[i] == 0) continue;
+    if (cls[i] != 1 && cls[i] != 2) return fail(h, 3, "pp_set_diagonal_classes: classes are 0, 1 (Hessian) or 2 (constraint)");
+    const int ce = g->diag_can[(size_t)i];
+    if (ce < 0)
+      return fail(h, 3, "pp_set_diagonal_classes: row " + std::to_string(i) +
+                            " has a class but no diagonal entry in the planned pattern");
+    // the shift goes to the first raw duplicate of the canonical diagonal entry
+    const int raw = g->can_idx[(size_t)g->can_ptr[(size_t)ce]];
+    rows.push_back(-1 - raw);
+    kinds.push_back((int)cls[i]);
+  }
+  // raw index -> compact row of the transposed input (same rule as pp_end_symbolic)
+  {
+    std::vector<int> rawmap((size_t)std::max(g->nraw, 1), -1);
+    int nused = 0;
+    for (int v : g->can_idx) if (rawmap[(size_t)v] < 0) rawmap[(size_t)v] = nused++;
+    for (auto& r : rows) r = rawmap[(size_t)(-1 - r)];
+  }
+  g->nshift = (int)rows.size();
+  int rc;
+  rows.push_back(0); kinds.push_back(0);
+  if ((rc = dev_upload(h, g, &g->shift_row, rows))) return rc;
+  if ((rc = dev_upload(h, g, &g->shift_cls, kinds))) return rc;
+  return 0;
+}
+
+int pp_numeric_local_shifted(pp_handle h, double delta_w, double delta_c) {
+  if (!h) return 3;
+  h->shift_w = delta_w;
+  h->shift_c = delta_c;
+  const int rc = pp_numeric_local(h);
+  h->shift_w = 0.0;
+  h->shift_c = 0.0;
+  return rc;
 }
 
 int pp_get_factor(pp_handle h, int group, int which, int instance, double* out, int64_t count) {

@@ -172,6 +172,14 @@ class HipEngine(object):
     def upload_values_device(self, gid, tensor):
         self.ns.check(self.lib.pp_upload_values(self.ns.h, gid, tensor.data_ptr(), 1), 'pp_upload_values')
 
+    def set_diagonal_classes(self, gid, cls):
+        c = np.ascontiguousarray(cls, dtype=np.int8)
+        self.ns.check(self.lib.pp_set_diagonal_classes(self.ns.h, gid, c.ctypes.data), 'pp_set_diagonal_classes')
+
+    def numeric_local_shifted(self, delta_w, delta_c):
+        self.ns.check(self.lib.pp_numeric_local_shifted(self.ns.h, float(delta_w), float(delta_c)),
+                      'pp_numeric_local_shifted')
+
     def numeric_local(self):
         self.ns.check(self.lib.pp_numeric_local(self.ns.h), 'pp_numeric_local')
 
@@ -298,6 +306,8 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         self._inertia = None
         self._num_status = None
         self._pattern_only = False
+        self._have_classes = False
+        self._last_Q = None
         self.plan_stats = []
 
     # ------------------------------------------------------------------ helpers
@@ -442,6 +452,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
 
     def _run_symbolic(self):
         self.plan_stats = self._eng.symbolic(self._nc, self._groups)
+        self._have_classes = False            # classes are per plan: set_regularization_classes again
 
     def _replan_union(self, matrix):
         """New plan on (planned pattern) U (pattern of `matrix`), values of `matrix`; later matrices with either
@@ -544,6 +555,63 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             if Qc.nnz > 0 and np.any(Qc.data != 0.0):
                 Q = Qc.toarray()
                 Q = np.tril(Q) + np.tril(Q, -1).T          # lower triangle authoritative
+        self._eng.factor_schur(Q)
+        self._last_Q = Q
+        status, pos, neg, zero = self._eng.status()
+        timer.stop('factor SC')
+        self._inertia = (pos, neg, zero)
+        res.status = self._agree_status(LinearSolverStatus(status))
+        self._num_status = res.status
+        if res.status not in _OK and raise_on_error:
+            raise RuntimeError('Numeric factorization unsuccessful; status: ' + str(res.status))
+        return res
+
+    # ------------------------------------------------------------------ inertia-correction fast path
+    def set_regularization_classes(self, classes):
+        """Which rows of every local K_i the inertia-correction loop shifts: ``classes[ndx]`` is an int8 array over
+        the rows of block ndx -- 0 none, 1 Hessian row (+coef, interfaces/interface.py:611-619), 2 constraint row
+        (-coef, interface.py:590-609 / sc_ip_interface.py:1736-1757).  Blocks of one pattern group must agree.
+        Every classed row needs its diagonal entry in the planned pattern (it is there once a regularised matrix has
+        been factorised: the plan is then on the union pattern)."""
+        if self._num_status is None and not self._groups:
+            raise RuntimeError('Perform symbolic factorization first!')
+        for g in self._groups:
+            ref = None
+            for ndx in g.blocks:
+                c = np.ascontiguousarray(classes[ndx], dtype=np.int8)
+                if c.size != g.n:
+                    raise ValueError('classes of block %d have length %d, expected %d' % (ndx, c.size, g.n))
+                if ref is None:
+                    ref = c
+                elif not np.array_equal(ref, c):
+                    raise ValueError('blocks of one pattern group must have identical regularization classes')
+            self._eng.set_diagonal_classes(g.gid, ref)
+        self._have_classes = True
+
+    def refactorize_with_diagonal_shift(self, delta_w, delta_c, coupling_shift=0.0, raise_on_error=True, timer=None):
+        """Numeric factorisation of (the last matrix given to do_numeric_factorization) + delta_w on the classed
+        Hessian diagonals - delta_c on the classed constraint diagonals + coupling_shift * I on the coupling block,
+        from the values already resident on the device: what one retry of the inertia-correction loop
+        (interior_point.py:377-386) needs, without rebuilding, staging or uploading the KKT matrix."""
+        if timer is None:
+            timer = _NullTimer()
+        if self._num_status is None:
+            raise RuntimeError('Perform numeric factorization first!')
+        if not getattr(self, '_have_classes', False):
+            raise RuntimeError('Call set_regularization_classes first!')
+        res = LinearSolverResults(LinearSolverStatus.successful)
+        timer.start('form SC')
+        timer.start('factorize')
+        self._eng.numeric_local_shifted(delta_w, delta_c)
+        timer.stop('factorize')
+        timer.start('communicate')
+        self._eng.allreduce_schur(self.comm)
+        timer.stop('communicate')
+        timer.stop('form SC')
+        timer.start('factor SC')
+        Q = None if self._last_Q is None else self._last_Q.copy()
+        if coupling_shift != 0.0 and self._nc > 0:
+            Q = (np.zeros((self._nc, self._nc)) if Q is None else Q) + coupling_shift * np.eye(self._nc)
         self._eng.factor_schur(Q)
         status, pos, neg, zero = self._eng.status()
         timer.stop('factor SC')

@@ -194,3 +194,69 @@ def test_large_coupling_dimension_paths(shape):
     """n_c above the register-resident dense factor (208) and above one-thread-per-unknown solve (512):
     the blocked global-memory LDL^T and the blocked solve must give the same answers."""
     sc.case_oracle_schur(make_engine, shape)
+
+
+def test_inertia_correction_fast_path_on_device():
+    """one retry of the inertia-correction loop from resident values -- refactorize_with_diagonal_shift
+    (+delta on the Hessian diagonals, -delta on the constraint diagonals, +delta on the coupling block; applied on the
+    device, no staging / H2D) against a fresh numeric factorisation of the regularised matrix built on the host the way
+    interfaces/interface.py:590-619 and sc_ip_interface.py:1736-1757 build it."""
+    import scipy.sparse as sp
+    from scipy.sparse import coo_matrix
+    from parapint_amd.sparse.block_containers import BlockMatrix, BlockVector
+    from parapint_amd.linalg.results import LinearSolverStatus
+    rng = np.random.default_rng(21)
+    n_x, n_c, nc, nb = 12, 5, 4, 70                  # 70 blocks: a full wave + a ragged one
+    H, J, B = [], [], []
+    h0 = rng.uniform(0.5, 2.0, size=n_x)
+    Jp = (sp.random(n_c, n_x, density=0.3, random_state=3, data_rvs=lambda k: rng.normal(size=k)) + 2.0 * sp.eye(n_c, n_x)).tocoo()
+    Bp = coo_matrix((np.ones(nc), (np.arange(nc), rng.choice(n_x, nc, replace=False))), shape=(nc, n_x + n_c))
+    for i in range(nb):
+        H.append(sp.diags(h0 * rng.uniform(0.8, 1.2, size=n_x)).tocoo())
+        J.append(coo_matrix((Jp.data * rng.uniform(0.8, 1.2, size=Jp.nnz), (Jp.row, Jp.col)), shape=Jp.shape))
+        B.append(coo_matrix((rng.normal(size=nc), (Bp.row, Bp.col)), shape=Bp.shape))
+
+    def kkt(dw, dc):
+        A = BlockMatrix(nb + 1, nb + 1)
+        for i in range(nb):
+            Hi = (H[i] + dw * sp.identity(n_x, format='coo')).tocoo()
+            Ci = (-dc) * sp.identity(n_c, format='coo')            # explicit (possibly zero) constraint diagonal
+            A.set_block(i, i, sp.bmat([[Hi, J[i].T], [J[i], Ci]]).tocoo())
+            A.set_block(nb, i, B[i])
+        A.set_block(nb, nb, (dw * sp.identity(nc, format='coo')).tocoo())
+        return A
+
+    rhs = BlockVector(nb + 1)
+    for i in range(nb):
+        rhs.set_block(i, rng.normal(size=n_x + n_c))
+    rhs.set_block(nb, rng.normal(size=nc))
+    classes = {i: np.concatenate([np.ones(n_x, dtype=np.int8), 2 * np.ones(n_c, dtype=np.int8)]) for i in range(nb)}
+
+    fast = sc.new_solver(make_engine, nb)
+    A0 = kkt(0.0, 0.0)
+    fast.do_symbolic_factorization(A0)
+    fast.do_numeric_factorization(A0)
+    fast.set_regularization_classes(classes)
+    for dw, dc in ((1e-4, 1e-4), (1e-2, 1e-2), (1.0, 1e-8)):
+        res = fast.refactorize_with_diagonal_shift(dw, dc, coupling_shift=dw, raise_on_error=False)
+        fresh = sc.new_solver(make_engine, nb)
+        Areg = kkt(dw, dc)
+        fresh.do_symbolic_factorization(Areg)
+        ref = fresh.do_numeric_factorization(Areg, raise_on_error=False)
+        assert res.status == ref.status == LinearSolverStatus.successful
+        assert fast.get_inertia() == fresh.get_inertia()
+        S1, S2 = fast.get_schur_complement(), fresh.get_schur_complement()
+        assert np.abs(S1 - S2).max() <= 1e-12 * max(1.0, np.abs(S2).max())
+        x1, x2 = fast.do_back_solve(rhs).flatten(), fresh.do_back_solve(rhs).flatten()
+        assert np.abs(x1 - x2).max() <= 1e-10 * np.abs(x2).max()
+    # a classed row without a diagonal entry in the plan is refused with a message, not silently skipped
+    A1 = BlockMatrix(nb + 1, nb + 1)
+    for i in range(nb):
+        A1.set_block(i, i, sp.bmat([[H[i], J[i].T], [J[i], None]]).tocoo())
+        A1.set_block(nb, i, B[i])
+    A1.set_block(nb, nb, coo_matrix((nc, nc)))
+    bare = sc.new_solver(make_engine, nb)
+    bare.do_symbolic_factorization(A1)
+    bare.do_numeric_factorization(A1)
+    with pytest.raises(RuntimeError, match='no diagonal entry'):
+        bare.set_regularization_classes(classes)
