@@ -130,6 +130,14 @@ __global__ __launch_bounds__(256) void k_transpose_out(const double* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
+// Workgroup -> (task, chunk): one-dimensional grid with the 64-instance chunk as the fastest index.  Workgroups are
+// dealt round-robin over the 8 XCDs, so with a chunk count that is a multiple of 8 every chunk is always served by
+// the same XCD: the operands that different tasks of a level re-read for that chunk meet in ONE L2 instead of
+// being duplicated in all eight.
+#define PP_TASK_OF_WG(ny) ((int)(blockIdx.x / (unsigned)(ny)))
+#define PP_CHUNK_OF_WG(ny) ((int)(blockIdx.x % (unsigned)(ny)))
+
+// ------------------------------------------------------------------------------------------
 // Record broadcast: the wave-uniform index records of a task are fetched with ONE coalesced
 // vector load (lane e holds record e) and handed to all lanes with v_readlane, so the global
 // loads of a whole task issue back to back (one memory latency) instead of being chained
@@ -220,11 +228,11 @@ __device__ __forceinline__ void invert_and_scale(const GroupDev& g, int p, int w
 // factorisation.  Fused small panels (kind 1) finish with the inversion of their block and the
 // scaling of their rows.
 template <int WM>
-__global__ __launch_bounds__(64) void k_gather_level(GroupDev g, int task0, int chunk0, double eps) {
+__global__ __launch_bounds__(64) void k_gather_level(GroupDev g, int task0, int chunk0, int ny, double eps) {
   const int lane = threadIdx.x;
-  const int b = (blockIdx.y + chunk0) * 64 + lane;
+  const int b = (PP_CHUNK_OF_WG(ny) + chunk0) * 64 + lane;
   const size_t bpad = (size_t)g.bpad;
-  const int* t = g.ftask + TASK_INTS * (size_t)(task0 + blockIdx.x);
+  const int* t = g.ftask + TASK_INTS * (size_t)(task0 + PP_TASK_OF_WG(ny));
   const int p = t[0], r0 = t[1], r1 = t[2], dptr0 = t[3], kind = t[4], E0 = t[5], E1 = t[6];
   const int w = (WM == 1) ? 1 : t[7];
   const int uoff = t[8], boff = t[9], doff = t[10];
@@ -307,11 +315,11 @@ __global__ __launch_bounds__(64) void k_gather_level(GroupDev g, int task0, int 
 // of tasks): plain scalar-load record reads, minimal code; the memory system is kept busy by the
 // sheer number of waves, not by intra-task batching.
 template <int WM>
-__global__ __launch_bounds__(64) void k_gather_level_lean(GroupDev g, int task0, int chunk0, double eps) {
+__global__ __launch_bounds__(64) void k_gather_level_lean(GroupDev g, int task0, int chunk0, int ny, double eps) {
   const int lane = threadIdx.x;
-  const int b = (blockIdx.y + chunk0) * 64 + lane;
+  const int b = (PP_CHUNK_OF_WG(ny) + chunk0) * 64 + lane;
   const size_t bpad = (size_t)g.bpad;
-  const int* t = g.ftask + TASK_INTS * (size_t)(task0 + blockIdx.x);
+  const int* t = g.ftask + TASK_INTS * (size_t)(task0 + PP_TASK_OF_WG(ny));
   const int p = t[0], r0 = t[1], r1 = t[2], dptr0 = t[3], kind = t[4];
   const int w = (WM == 1) ? 1 : t[7];
   const int uoff = t[8], boff = t[9], doff = t[10];
@@ -391,11 +399,11 @@ __device__ __forceinline__ void scale_held(const double (&u)[RV], const double* 
 // redundantly in registers -- it is w*w loads and a few dozen flops), L rows = U rows * inv(P); the
 // chunk that starts right below the block also publishes inv(P) and the inertia code.
 template <int WM>
-__global__ __launch_bounds__(64) void k_scale_level(GroupDev g, int task0, int chunk0, double eps) {
+__global__ __launch_bounds__(64) void k_scale_level(GroupDev g, int task0, int chunk0, int ny, double eps) {
   const int lane = threadIdx.x;
-  const int b = (blockIdx.y + chunk0) * 64 + lane;
+  const int b = (PP_CHUNK_OF_WG(ny) + chunk0) * 64 + lane;
   const size_t bpad = (size_t)g.bpad;
-  const int* t = g.stask + TASK_INTS * (size_t)(task0 + blockIdx.x);
+  const int* t = g.stask + TASK_INTS * (size_t)(task0 + PP_TASK_OF_WG(ny));
   const int p = t[0], r0 = t[1], r1 = t[2], w = t[7], uoff = t[8], boff = t[9], doff = t[10];
   const unsigned sub = (unsigned)t[11];
   const double* Tmp = g.Tm + (size_t)boff * bpad + b;
@@ -503,9 +511,10 @@ __global__ void k_publish_status(const double* __restrict__ tail, const int* __r
 __global__ __launch_bounds__(64) void k_schur_tiles(GroupDev g) {
   __shared__ double red[32][65];
   const int lane = threadIdx.x;
-  const int b = blockIdx.y * 64 + lane;
+  const int chunk = PP_CHUNK_OF_WG(g.nchunk), ntile_all = (int)(gridDim.x / (unsigned)g.nchunk);
+  const int b = chunk * 64 + lane;
   const size_t bpad = (size_t)g.bpad;
-  const int tile = blockIdx.x, half = blockIdx.z;
+  const int tile = PP_TASK_OF_WG(g.nchunk), half = blockIdx.z;
   double acc[8][4];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
@@ -555,7 +564,7 @@ __global__ __launch_bounds__(64) void k_schur_tiles(GroupDev g) {
     for (int l = 0; l < 64; ++l) s += red[lane][l];
     // entry (i, 4*half + j) of the tile -> slot i*8 + 4*half + j of the 64-entry tile record
     const int i = lane >> 2, j = lane & 3;
-    g.Spart[((size_t)blockIdx.y * gridDim.x + tile) * 64 + i * 8 + 4 * half + j] = s;
+    g.Spart[((size_t)chunk * ntile_all + tile) * 64 + i * 8 + 4 * half + j] = s;
   }
 }
 
@@ -1305,11 +1314,11 @@ __device__ __forceinline__ double gather_row(const int* __restrict__ upos, const
 
 // forward substitution, one scalar row per workgroup: y_c = b_c - sum_k L[c, k] y_k
 // (rows of one block pivot are independent: the block is applied as a whole, by inv(P), in the backward sweep)
-__global__ __launch_bounds__(64) void k_fwd_level(GroupDev g, int col0, int chunk0) {
+__global__ __launch_bounds__(64) void k_fwd_level(GroupDev g, int col0, int chunk0, int ny) {
   const int lane = threadIdx.x;
-  const int b = (blockIdx.y + chunk0) * 64 + lane;
+  const int b = (PP_CHUNK_OF_WG(ny) + chunk0) * 64 + lane;
   const size_t bpad = (size_t)g.bpad;
-  const int* rec = g.fwd_rec + 4 * (size_t)(col0 + blockIdx.x);   // {column, row of the right-hand side, e0, e1}
+  const int* rec = g.fwd_rec + 4 * (size_t)(col0 + PP_TASK_OF_WG(ny));   // {column, row of the right-hand side, e0, e1}
   const int c = rec[0];
   const double y = g.rhsT[(size_t)rec[1] * bpad + b] -
                    gather_row(g.sfwd_upos, g.sfwd_zcol, rec[2], rec[3], g.L + b, g.Y + b, bpad, lane);
@@ -1319,13 +1328,14 @@ __global__ __launch_bounds__(64) void k_fwd_level(GroupDev g, int col0, int chun
 // coupling row c: rspart[chunk][c] = - sum over active instances and panels of L[c,k] y_k
 __global__ __launch_bounds__(64) void k_fwd_coupling(GroupDev g) {
   const int lane = threadIdx.x;
-  const int b = blockIdx.y * 64 + lane;
+  const int chunk = PP_CHUNK_OF_WG(g.nchunk);
+  const int b = chunk * 64 + lane;
   const size_t bpad = (size_t)g.bpad;
-  const int c = blockIdx.x;
+  const int c = PP_TASK_OF_WG(g.nchunk);
   double s = -gather_row(g.crow_upos, g.crow_zcol, g.crow_eptr[c], g.crow_eptr[c + 1], g.L + b, g.Y + b, bpad, lane);
   if (b >= g.batch) s = 0.0;
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-  if (lane == 0) g.rspart[(size_t)blockIdx.y * g.nc + c] = s;
+  if (lane == 0) g.rspart[(size_t)chunk * g.nc + c] = s;
 }
 
 __global__ __launch_bounds__(256) void k_rs_reduce(GroupDev g, double* __restrict__ rs) {
@@ -1338,11 +1348,12 @@ __global__ __launch_bounds__(256) void k_rs_reduce(GroupDev g, double* __restric
 
 // back substitution, one scalar column c = (block pivot p, component q) per workgroup:
 //   x_c = (inv(P_p) y_p)_q - sum_i L[i, c] x_i      (x_i = xc for coupling rows)
-__global__ __launch_bounds__(64) void k_bwd_level(GroupDev g, int col0, int chunk0, const double* __restrict__ xc) {
+__global__ __launch_bounds__(64) void k_bwd_level(GroupDev g, int col0, int chunk0, int ny,
+                                                  const double* __restrict__ xc) {
   const int lane = threadIdx.x;
-  const int b = (blockIdx.y + chunk0) * 64 + lane;
+  const int b = (PP_CHUNK_OF_WG(ny) + chunk0) * 64 + lane;
   const size_t bpad = (size_t)g.bpad;
-  const int* rec = g.bwd_rec + 8 * (size_t)(col0 + blockIdx.x);   // {c, w, q, nr, rowptr, L base, doff, p0}
+  const int* rec = g.bwd_rec + 8 * (size_t)(col0 + PP_TASK_OF_WG(ny));   // {c, w, q, nr, rowptr, L base, doff, p0}
   const int c = rec[0], w = rec[1], q = rec[2], nr = rec[3];
   const int* ri = g.rowidx + rec[4];
   const double* Lp = g.L + (size_t)rec[5] * bpad + b;   // column q of the rows below the block
@@ -1919,7 +1930,7 @@ int pp_numeric_local(pp_handle h) {
           if (nt > 0) {
             const bool lean = P.flevel_maxent[l] <= 12;
             const int mw = g->level_maxw[l];
-#define PP_LAUNCH_GATHER(K, WM) hipLaunchKernelGGL(K<WM>, dim3(nt, ny), dim3(64), 0, fan[q], d, t0, sp.c0[q], PIVOT_EPS)
+#define PP_LAUNCH_GATHER(K, WM) hipLaunchKernelGGL(K<WM>, dim3((unsigned)nt * ny), dim3(64), 0, fan[q], d, t0, sp.c0[q], ny, PIVOT_EPS)
             if (lean) {
               if (mw == 1) PP_LAUNCH_GATHER(k_gather_level_lean, 1);
               else if (mw == 2) PP_LAUNCH_GATHER(k_gather_level_lean, 2);
@@ -1935,9 +1946,9 @@ int pp_numeric_local(pp_handle h) {
           }
           if (ns > 0) {
             if (g->level_maxw[l] <= 4)
-              hipLaunchKernelGGL(k_scale_level<4>, dim3(ns, ny), dim3(64), 0, fan[q], d, s0, sp.c0[q], PIVOT_EPS);
+              hipLaunchKernelGGL(k_scale_level<4>, dim3((unsigned)ns * ny), dim3(64), 0, fan[q], d, s0, sp.c0[q], ny, PIVOT_EPS);
             else
-              hipLaunchKernelGGL(k_scale_level<PP_WMAX>, dim3(ns, ny), dim3(64), 0, fan[q], d, s0, sp.c0[q], PIVOT_EPS);
+              hipLaunchKernelGGL(k_scale_level<PP_WMAX>, dim3((unsigned)ns * ny), dim3(64), 0, fan[q], d, s0, sp.c0[q], ny, PIVOT_EPS);
           }
         }
       }
@@ -1949,7 +1960,7 @@ int pp_numeric_local(pp_handle h) {
       hipLaunchKernelGGL(k_count_codes, dim3((unsigned)std::min<size_t>(512, (total8 + 255) / 256)), dim3(256), 0, st,
                          d.codes, total8, h->counters);
       if (g->ntiles > 0) {
-        hipLaunchKernelGGL(k_schur_tiles, dim3(g->ntiles, d.nchunk, 2), dim3(64), 0, st, d);
+        hipLaunchKernelGGL(k_schur_tiles, dim3((unsigned)g->ntiles * d.nchunk, 1, 2), dim3(64), 0, st, d);
         hipLaunchKernelGGL(k_schur_reduce, dim3(g->ntiles), dim3(64), 0, st, d, g->ntiles, h->S);
       }
     }
@@ -2089,13 +2100,14 @@ int pp_solve_forward(pp_handle h) {
         const int c0 = P.clevel_ptr[l], ncol = P.clevel_ptr[l + 1] - c0;
         if (ncol <= 0) continue;
         for (int q = 0; q < sp.n; ++q)
-          hipLaunchKernelGGL(k_fwd_level, dim3(ncol, sp.c0[q + 1] - sp.c0[q]), dim3(64), 0, fan[q], d, c0, sp.c0[q]);
+          hipLaunchKernelGGL(k_fwd_level, dim3((unsigned)ncol * (sp.c0[q + 1] - sp.c0[q])), dim3(64), 0, fan[q], d, c0, sp.c0[q],
+                             sp.c0[q + 1] - sp.c0[q]);
       }
       if (join_streams(h, sp, fan)) return fail(h, 3, "stream join failed");
     }
     if (nc > 0) {
       PhaseScope ps(h, 5, 2);
-      hipLaunchKernelGGL(k_fwd_coupling, dim3(nc, d.nchunk), dim3(64), 0, st, d);
+      hipLaunchKernelGGL(k_fwd_coupling, dim3((unsigned)nc * d.nchunk), dim3(64), 0, st, d);
       hipLaunchKernelGGL(k_rs_reduce, dim3((nc + 255) / 256), dim3(256), 0, st, d, h->rs);
     }
   }
@@ -2141,7 +2153,8 @@ int pp_solve_backward(pp_handle h) {
         const int c0 = P.clevel_ptr[l], ncol = P.clevel_ptr[l + 1] - c0;
         if (ncol <= 0) continue;
         for (int q = 0; q < sp.n; ++q)
-          hipLaunchKernelGGL(k_bwd_level, dim3(ncol, sp.c0[q + 1] - sp.c0[q]), dim3(64), 0, fan[q], d, c0, sp.c0[q], h->xc);
+          hipLaunchKernelGGL(k_bwd_level, dim3((unsigned)ncol * (sp.c0[q + 1] - sp.c0[q])), dim3(64), 0, fan[q], d, c0, sp.c0[q],
+                             sp.c0[q + 1] - sp.c0[q], h->xc);
       }
       if (join_streams(h, sp, fan)) return fail(h, 3, "stream join failed");
     }
