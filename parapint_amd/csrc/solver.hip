@@ -54,6 +54,14 @@ struct GroupDev {
 };
 
 // ------------------------------------------------------------------------------------------
+// Workgroup -> (task, chunk): one-dimensional grid with the 64-instance chunk as the fastest index.  Workgroups are
+// dealt round-robin over the 8 XCDs, so with a chunk count that is a multiple of 8 every chunk is always served by
+// the same XCD: the operands that different tasks of a level re-read for that chunk meet in ONE L2 instead of
+// being duplicated in all eight.
+#define PP_TASK_OF_WG(ny) ((int)(blockIdx.x / (unsigned)(ny)))
+#define PP_CHUNK_OF_WG(ny) ((int)(blockIdx.x % (unsigned)(ny)))
+
+// ------------------------------------------------------------------------------------------
 // [rows][m] row-major  ->  [m'][bpad] (instance-interleaved), zero padding for rows >= nrows.
 // rowmap (may be null): entry e of the input goes to output row rowmap[e]; negative = not needed
 // (e.g. the upper-triangle half of a KKT block given with both triangles) and is not written.
@@ -65,8 +73,9 @@ __global__ __launch_bounds__(256) void k_transpose_in(const double* __restrict__
   // goes out through LDS.
   __shared__ double tile[64][65];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int b0 = blockIdx.y * 64;
-  int e0 = blockIdx.x * 64 * tiles;
+  const int nchunk = bpad / 64;
+  const int b0 = PP_CHUNK_OF_WG(nchunk) * 64;
+  int e0 = PP_TASK_OF_WG(nchunk) * 64 * tiles;
   double v[16];
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
@@ -112,7 +121,8 @@ __global__ __launch_bounds__(256) void k_transpose_out(const double* __restrict_
                                                        double* __restrict__ out, int nrows, int m, int bpad) {
   __shared__ double tile[64][65];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int i0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+  const int nchunk = bpad / 64;
+  const int i0 = PP_TASK_OF_WG(nchunk) * 64, b0 = PP_CHUNK_OF_WG(nchunk) * 64;
   int src[16];
 #pragma unroll
   for (int q = 0; q < 16; ++q) { const int i = i0 + ty + 4 * q; src[q] = (i < m) ? iperm[i] : -1; }
@@ -128,14 +138,6 @@ __global__ __launch_bounds__(256) void k_transpose_out(const double* __restrict_
     if (b < nrows && i < m) out[(size_t)b * m + i] = tile[tx][r];
   }
 }
-
-// ------------------------------------------------------------------------------------------
-// Workgroup -> (task, chunk): one-dimensional grid with the 64-instance chunk as the fastest index.  Workgroups are
-// dealt round-robin over the 8 XCDs, so with a chunk count that is a multiple of 8 every chunk is always served by
-// the same XCD: the operands that different tasks of a level re-read for that chunk meet in ONE L2 instead of
-// being duplicated in all eight.
-#define PP_TASK_OF_WG(ny) ((int)(blockIdx.x / (unsigned)(ny)))
-#define PP_CHUNK_OF_WG(ny) ((int)(blockIdx.x % (unsigned)(ny)))
 
 // ------------------------------------------------------------------------------------------
 // Record broadcast: the wave-uniform index records of a task are fetched with ONE coalesced
@@ -1907,7 +1909,7 @@ int pp_numeric_local(pp_handle h) {
       if (d.nraw > 0)
       {
         const int tiles = transpose_tiles(d.nraw, d.nchunk);
-        hipLaunchKernelGGL(k_transpose_in, dim3((d.nraw + 64 * tiles - 1) / (64 * tiles), d.nchunk), dim3(256), 0, st, d.raw,
+        hipLaunchKernelGGL(k_transpose_in, dim3((unsigned)((d.nraw + 64 * tiles - 1) / (64 * tiles)) * d.nchunk), dim3(256), 0, st, d.raw,
                            d.rawT, d.rawmap, d.batch, d.nraw, d.bpad, tiles);
         if (g->nshift > 0 && (h->shift_w != 0.0 || h->shift_c != 0.0))
           hipLaunchKernelGGL(k_shift_diag, dim3(g->nshift, (d.bpad + 255) / 256), dim3(256), 0, st, d.rawT, g->shift_row,
@@ -2088,7 +2090,7 @@ int pp_solve_forward(pp_handle h) {
       PhaseScope ps(h, 4, P.n_levels + 1);
       {
         const int tiles = transpose_tiles(P.n, d.nchunk);
-        hipLaunchKernelGGL(k_transpose_in, dim3((P.n + 64 * tiles - 1) / (64 * tiles), d.nchunk), dim3(256), 0, st, d.rhs,
+        hipLaunchKernelGGL(k_transpose_in, dim3((unsigned)((P.n + 64 * tiles - 1) / (64 * tiles)) * d.nchunk), dim3(256), 0, st, d.rhs,
                            d.rhsT, (const int*)nullptr, d.batch, P.n, d.bpad, tiles);
       }
       // (a persistent one-workgroup-per-chunk kernel for the small top levels was measured slower than
@@ -2158,7 +2160,7 @@ int pp_solve_backward(pp_handle h) {
       }
       if (join_streams(h, sp, fan)) return fail(h, 3, "stream join failed");
     }
-    hipLaunchKernelGGL(k_transpose_out, dim3((P.n + 63) / 64, d.nchunk), dim3(256), 0, st, d.X, d.iperm, d.xout,
+    hipLaunchKernelGGL(k_transpose_out, dim3((unsigned)((P.n + 63) / 64) * d.nchunk), dim3(256), 0, st, d.X, d.iperm, d.xout,
                        d.batch, P.n, d.bpad);
   }
   PP_HIP(hipGetLastError());
