@@ -49,7 +49,7 @@ struct GroupDev {
   const int *fwd_rec, *bwd_rec;   // per scheduled column, in level order: everything its solve task needs (one scalar read)
   const int *crow_eptr, *crow_upos, *crow_zcol;
   const int *stile_a, *stile_b, *stile_ptr, *stile_rec;
-  double *raw, *rawT, *U, *L, *Dinv, *Tm, *Y, *X, *rhs, *rhsT, *xout, *Spart, *rspart;
+  double *raw, *rawT, *U, *L, *Dinv, *Tm, *Y, *X, *rhs, *xout, *Spart, *rspart;
   unsigned short* codes;
 };
 
@@ -1320,11 +1320,11 @@ __global__ __launch_bounds__(64) void k_fwd_level(GroupDev g, int col0, int chun
   const int lane = threadIdx.x;
   const int b = (PP_CHUNK_OF_WG(ny) + chunk0) * 64 + lane;
   const size_t bpad = (size_t)g.bpad;
-  const int* rec = g.fwd_rec + 4 * (size_t)(col0 + PP_TASK_OF_WG(ny));   // {column, row of the right-hand side, e0, e1}
+  const int* rec = g.fwd_rec + 4 * (size_t)(col0 + PP_TASK_OF_WG(ny));   // {column, -, e0, e1}
   const int c = rec[0];
-  const double y = g.rhsT[(size_t)rec[1] * bpad + b] -
-                   gather_row(g.sfwd_upos, g.sfwd_zcol, rec[2], rec[3], g.L + b, g.Y + b, bpad, lane);
-  g.Y[(size_t)c * bpad + b] = y;
+  // in place: the right-hand side was transposed into Y in the new order (rows of leaf columns are final as they are)
+  double* yc = g.Y + (size_t)c * bpad + b;
+  *yc -= gather_row(g.sfwd_upos, g.sfwd_zcol, rec[2], rec[3], g.L + b, g.Y + b, bpad, lane);
 }
 
 // coupling row c: rspart[chunk][c] = - sum over active instances and panels of L[c,k] y_k
@@ -1419,6 +1419,7 @@ struct Group {
   int nraw_used = 0;
   std::vector<int> level_maxw;   // widest block pivot per level (selects the scalar kernel variants)
   std::vector<int> diag_can;     // canonical entry of the diagonal (i, i) of K, or -1
+  std::vector<uint8_t> fwd_level_has_entries;   // forward-solve levels whose columns have any incoming entry
   int nshift = 0;                // rows with a regularisation class (pp_set_diagonal_classes)
   const int *shift_row = nullptr, *shift_cls = nullptr;   // device: transposed-input row of their diagonal entry, class
 };
@@ -1801,6 +1802,12 @@ int pp_end_symbolic(pp_handle h) {
         brec.insert(brec.end(), {c, w, q, P.piv_rowptr[pv + 1] - P.piv_rowptr[pv], P.piv_rowptr[pv],
                                  (int)(P.piv_uoff[pv] + (int64_t)w * w + q), P.piv_doff[pv], P.piv_start[pv]});
       }
+      g->fwd_level_has_entries.assign((size_t)P.n_levels, 0);
+      for (int l = 0; l < P.n_levels; ++l)
+        for (int q = P.clevel_ptr[l]; q < P.clevel_ptr[l + 1]; ++q) {
+          const int c = P.clevel_col[q];
+          if (P.sfwd_eptr[c + 1] > P.sfwd_eptr[c]) { g->fwd_level_has_entries[(size_t)l] = 1; break; }
+        }
       if ((rc = dev_upload(h, g, &d.fwd_rec, frec))) return rc;
       if ((rc = dev_upload(h, g, &d.bwd_rec, brec))) return rc;
     }
@@ -1833,7 +1840,6 @@ int pp_end_symbolic(pp_handle h) {
     if ((rc = dev_alloc(h, g, &d.X, (size_t)P.n * bp))) return rc;
     if ((rc = dev_alloc(h, g, &d.rhs, (size_t)g->batch * P.n))) return rc;
     g->rhs_own = d.rhs;
-    if ((rc = dev_alloc(h, g, &d.rhsT, (size_t)P.n * bp))) return rc;
     if ((rc = dev_alloc(h, g, &d.xout, (size_t)g->batch * P.n))) return rc;
     if ((rc = dev_alloc(h, g, &d.Spart, (size_t)d.nchunk * std::max(g->ntiles, 1) * 64))) return rc;
     if ((rc = dev_alloc(h, g, &d.rspart, (size_t)d.nchunk * std::max(nc, 1)))) return rc;
@@ -2090,8 +2096,10 @@ int pp_solve_forward(pp_handle h) {
       PhaseScope ps(h, 4, P.n_levels + 1);
       {
         const int tiles = transpose_tiles(P.n, d.nchunk);
+        // the right-hand side goes straight to Y in the new (elimination) order: y is then computed in place and
+        // the columns without incoming entries (level 0) need no launch at all
         hipLaunchKernelGGL(k_transpose_in, dim3((unsigned)((P.n + 64 * tiles - 1) / (64 * tiles)) * d.nchunk), dim3(256), 0, st, d.rhs,
-                           d.rhsT, (const int*)nullptr, d.batch, P.n, d.bpad, tiles);
+                           d.Y, d.iperm, d.batch, P.n, d.bpad, tiles);
       }
       // (a persistent one-workgroup-per-chunk kernel for the small top levels was measured slower than
       // per-level launches: 16 waves on one CU serialise their memory round trips)
@@ -2100,7 +2108,7 @@ int pp_solve_forward(pp_handle h) {
       if (fork_streams(h, sp, fan)) return fail(h, 3, "stream fork failed");
       for (int l = 0; l < P.n_levels; ++l) {
         const int c0 = P.clevel_ptr[l], ncol = P.clevel_ptr[l + 1] - c0;
-        if (ncol <= 0) continue;
+        if (ncol <= 0 || !g->fwd_level_has_entries[(size_t)l]) continue;
         for (int q = 0; q < sp.n; ++q)
           hipLaunchKernelGGL(k_fwd_level, dim3((unsigned)ncol * (sp.c0[q + 1] - sp.c0[q])), dim3(64), 0, fan[q], d, c0, sp.c0[q],
                              sp.c0[q + 1] - sp.c0[q]);
