@@ -43,7 +43,7 @@ struct GroupDev {
   int n, nc, batch, bpad, nchunk, npiv, nraw;
   int64_t usize;
   const int *piv_w, *piv_start, *piv_uoff, *piv_doff, *piv_boff, *piv_sub, *piv_rowptr, *rowidx, *perm, *iperm;
-  const int *piv_of_col, *rawmap;
+  const int *piv_of_col, *rawmap, *raw_tiles;   // raw_tiles: 64-entry tiles of the input with at least one needed entry
   const int *ftask, *stask, *fdst_ptr, *fent;
   const int *clevel_col, *sfwd_eptr, *sfwd_upos, *sfwd_zcol;
   const int *fwd_rec, *bwd_rec;   // per scheduled column, in level order: everything its solve task needs (one scalar read)
@@ -67,7 +67,7 @@ struct GroupDev {
 // (e.g. the upper-triangle half of a KKT block given with both triangles) and is not written.
 __global__ __launch_bounds__(256) void k_transpose_in(const double* __restrict__ in, double* __restrict__ out,
                                                       const int* __restrict__ rowmap, int nrows, int m, int bpad,
-                                                      int tiles) {
+                                                      int tiles, const int* __restrict__ tile_list) {
   // One workgroup walks `tiles` consecutive 64 x 64 tiles along the entry axis: the rows of the input are
   // read in runs of tiles * 512 bytes, and the loads of the next tile are in flight while the current one
   // goes out through LDS.
@@ -75,7 +75,10 @@ __global__ __launch_bounds__(256) void k_transpose_in(const double* __restrict__
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int nchunk = bpad / 64;
   const int b0 = PP_CHUNK_OF_WG(nchunk) * 64;
-  int e0 = PP_TASK_OF_WG(nchunk) * 64 * tiles;
+  // tile_list (may be null): only these 64-entry tiles hold entries that are needed (a KKT block given with both
+  // triangles has whole runs of upper-triangle entries: those tiles are never read)
+  const int tsel = PP_TASK_OF_WG(nchunk);
+  int e0 = (tile_list ? tile_list[tsel] : tsel) * 64 * tiles;
   double v[16];
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
@@ -1420,6 +1423,7 @@ struct Group {
   std::vector<int> level_maxw;   // widest block pivot per level (selects the scalar kernel variants)
   std::vector<int> diag_can;     // canonical entry of the diagonal (i, i) of K, or -1
   std::vector<uint8_t> fwd_level_has_entries;   // forward-solve levels whose columns have any incoming entry
+  int nraw_tiles = 0;            // number of input tiles with needed entries
   int nshift = 0;                // rows with a regularisation class (pp_set_diagonal_classes)
   const int *shift_row = nullptr, *shift_cls = nullptr;   // device: transposed-input row of their diagonal entry, class
 };
@@ -1787,6 +1791,17 @@ int pp_end_symbolic(pp_handle h) {
     if ((rc = dev_upload(h, g, &d.perm, P.perm))) return rc;
     if ((rc = dev_upload(h, g, &d.iperm, P.iperm))) return rc;
     if ((rc = dev_upload(h, g, &d.rawmap, rawmap))) return rc;
+    {
+      std::vector<int> rtiles;
+      for (int t0 = 0; t0 * 64 < g->nraw; ++t0) {
+        bool any = false;
+        for (int e = t0 * 64; e < std::min(g->nraw, t0 * 64 + 64) && !any; ++e) any = rawmap[(size_t)e] >= 0;
+        if (any) rtiles.push_back(t0);
+      }
+      g->nraw_tiles = (int)rtiles.size();
+      rtiles.push_back(0);
+      if ((rc = dev_upload(h, g, &d.raw_tiles, rtiles))) return rc;
+    }
     if ((rc = dev_upload(h, g, &d.ftask, ftask))) return rc;
     if ((rc = dev_upload(h, g, &d.stask, stask))) return rc;
     if ((rc = dev_upload(h, g, &d.fdst_ptr, fdst_ptr))) return rc;
@@ -1915,8 +1930,12 @@ int pp_numeric_local(pp_handle h) {
       if (d.nraw > 0)
       {
         const int tiles = transpose_tiles(d.nraw, d.nchunk);
-        hipLaunchKernelGGL(k_transpose_in, dim3((unsigned)((d.nraw + 64 * tiles - 1) / (64 * tiles)) * d.nchunk), dim3(256), 0, st, d.raw,
-                           d.rawT, d.rawmap, d.batch, d.nraw, d.bpad, tiles);
+        if (tiles == 1 && g->nraw_tiles > 0)
+          hipLaunchKernelGGL(k_transpose_in, dim3((unsigned)g->nraw_tiles * d.nchunk), dim3(256), 0, st, d.raw, d.rawT, d.rawmap,
+                             d.batch, d.nraw, d.bpad, 1, d.raw_tiles);
+        else
+          hipLaunchKernelGGL(k_transpose_in, dim3((unsigned)((d.nraw + 64 * tiles - 1) / (64 * tiles)) * d.nchunk), dim3(256), 0, st,
+                             d.raw, d.rawT, d.rawmap, d.batch, d.nraw, d.bpad, tiles, (const int*)nullptr);
         if (g->nshift > 0 && (h->shift_w != 0.0 || h->shift_c != 0.0))
           hipLaunchKernelGGL(k_shift_diag, dim3(g->nshift, (d.bpad + 255) / 256), dim3(256), 0, st, d.rawT, g->shift_row,
                              g->shift_cls, g->nshift, d.bpad, h->shift_w, h->shift_c);
@@ -2099,7 +2118,7 @@ int pp_solve_forward(pp_handle h) {
         // the right-hand side goes straight to Y in the new (elimination) order: y is then computed in place and
         // the columns without incoming entries (level 0) need no launch at all
         hipLaunchKernelGGL(k_transpose_in, dim3((unsigned)((P.n + 64 * tiles - 1) / (64 * tiles)) * d.nchunk), dim3(256), 0, st, d.rhs,
-                           d.Y, d.iperm, d.batch, P.n, d.bpad, tiles);
+                           d.Y, d.iperm, d.batch, P.n, d.bpad, tiles, (const int*)nullptr);
       }
       // (a persistent one-workgroup-per-chunk kernel for the small top levels was measured slower than
       // per-level launches: 16 waves on one CU serialise their memory round trips)
