@@ -48,6 +48,7 @@ def parse_args():
     ap.add_argument('--profile-steps', type=int, default=5)
     ap.add_argument('--sn-wmax', type=int, default=0, help='supernode width cap (0: library default)')
     ap.add_argument('--sn-tol', type=int, default=-1, help='padded rows tolerated when merging (-1: default)')
+    ap.add_argument('--splits', type=int, default=0, help='instance splits on separate streams (0: library default)')
     return ap.parse_args()
 
 
@@ -106,6 +107,8 @@ def main():
     eng = solver._eng
     if args.sn_wmax > 0 or args.sn_tol >= 0:
         eng.set_supernodes(args.sn_wmax, args.sn_tol)
+    if args.splits > 0:
+        eng.ns.check(eng.lib.pp_set_instance_splits(eng.ns.h, args.splits), 'pp_set_instance_splits')
 
     # ---- through the LinearSolverInterface boundary (host buffers in, host buffers out)
     kkt = model.build_kkt(comm=comm, iteration=0)
