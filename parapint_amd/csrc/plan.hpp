@@ -36,6 +36,7 @@ struct PlanOptions {
   int max_task_entries = 24;   // entries per gather chunk of a big panel
   int fuse_task_entries = 24;  // panels with at most this many entries are one fused task (gather + invert + scale)
   int scale_task_rows = 8;     // rows per scale task of a big panel
+  double row_split_factor = 1.5;  // a row longer than this many task caps is split over the waves of one quad
   // Top of the elimination tree ("tail"): levels holding at most tail_piv_max pivots each get their own task
   // size (few panels, long rows: shorter tasks give more waves per level).
   int tail_piv_max = 48;
@@ -73,7 +74,16 @@ struct PlanOptions {
 //              2 scale chunk of a big panel (inverts the gathered block, L rows = U rows inv(P); the
 //                chunk with r0 == w also stores inv(P) and the inertia code).
 // Per level: one launch of the kind-0/1 tasks, then (if any) one launch of the kind-2 tasks.
-struct FTask { int piv, r0, r1, dptr0, kind; };
+// Gather / fused tasks are executed by workgroups of PP_QUAD waves, one task per wave ("quad"); the task list of a
+// level is a whole number of quads (padded with kind -1 = no-op).  A row whose entry list is long -- the pivot
+// rows of the top panels collect an update from most of their subtree, 50-80 entries against a dozen for the
+// other rows, and the dependent round trips of the longest task set the duration of a launch -- is cut into
+// npieces <= PP_QUAD pieces that fill ONE quad: every wave gathers its piece, the partial sums meet in LDS and
+// the wave of piece 0 adds them in piece order (deterministic) and stores the row.
+#ifndef PP_QUAD
+#define PP_QUAD 4
+#endif
+struct FTask { int piv, r0, r1, dptr0, kind, piece = 0, npieces = 1; };
 struct FEntry { int u, l, wk, q; };
 // Schur tile record: pivot p contributes to tile (ta, tb); slots (or -1) of the tile's
 // coupling rows inside panel p

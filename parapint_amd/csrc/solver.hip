@@ -169,8 +169,9 @@ __device__ __forceinline__ double bcastd(double v, int src_lane) {
 // Inversion of the gathered pivot block and scaling of panel rows [r0, r1): L rows = U rows * inv(P).
 // Used by the scale tasks of big panels and as the closing phase of fused small-panel tasks.
 // Task record (ints): piv, r0, r1, dptr0, kind, E0, E1, w, uoff, boff, doff, sub -- everything a task needs
-// in one 48-byte scalar read, so the entry records can be requested without first chasing the per-pivot arrays.
-constexpr int TASK_INTS = 12;
+// in one scalar read, so the entry records can be requested without first chasing the per-pivot arrays; gather
+// tasks add piece, npieces (plan.hpp: a long row split over the waves of a quad).
+constexpr int TASK_INTS = 16;
 
 template <int WM>
 __device__ __forceinline__ void invert_and_scale(const GroupDev& g, int p, int w, int uoff, int doff, unsigned sub,
@@ -233,12 +234,15 @@ __device__ __forceinline__ void invert_and_scale(const GroupDev& g, int p, int w
 // factorisation.  Fused small panels (kind 1) finish with the inversion of their block and the
 // scaling of their rows.
 template <int WM>
-__global__ __launch_bounds__(64) void k_gather_level(GroupDev g, int task0, int chunk0, int ny, double eps) {
-  const int lane = threadIdx.x;
+__global__ __launch_bounds__(64 * PP_QUAD) void k_gather_level(GroupDev g, int task0, int chunk0, int ny, double eps) {
+  __shared__ double red[PP_QUAD][2 * WM][64];     // partial sums / term magnitudes of a split row
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = (PP_CHUNK_OF_WG(ny) + chunk0) * 64 + lane;
   const size_t bpad = (size_t)g.bpad;
-  const int* t = g.ftask + TASK_INTS * (size_t)(task0 + PP_TASK_OF_WG(ny));
+  const int* t = g.ftask + TASK_INTS * (size_t)(task0 + PP_QUAD * PP_TASK_OF_WG(ny) + wave);
   const int p = t[0], r0 = t[1], r1 = t[2], dptr0 = t[3], kind = t[4], E0 = t[5], E1 = t[6];
+  const int piece = t[12], npieces = t[13];        // npieces is the same for all waves of the workgroup
+  if (kind < 0 && npieces <= 1) return;            // quad padding (in a split quad the padding waves join the barrier)
   const int w = (WM == 1) ? 1 : t[7];
   const int uoff = t[8], boff = t[9], doff = t[10];
   const unsigned sub = (unsigned)t[11];
@@ -260,6 +264,7 @@ __global__ __launch_bounds__(64) void k_gather_level(GroupDev g, int task0, int 
   int dend = (nrow > 0) ? (dp_vec ? bcast(dpv, 1) : dp[1]) : 0x7fffffff;
 #define PP_FINALIZE()                                                                      \
   do {                                                                                     \
+    if (npieces > 1) break;   /* split row: combined below */                             \
     _Pragma("unroll") for (int q = 0; q < WM; ++q) {                                       \
       if (q < w) {                                                                         \
         Udst[(size_t)(d * w + q) * bpad] = acc[q];                                         \
@@ -311,6 +316,24 @@ __global__ __launch_bounds__(64) void k_gather_level(GroupDev g, int task0, int 
     if (i0 < cnt) PP_GROUP(4)
 #undef PP_GROUP
   }
+  if (npieces > 1) {
+    // one long row over the waves of this quad: partial sums meet in LDS, piece 0 adds them in piece order
+#pragma unroll
+    for (int q = 0; q < WM; ++q) { red[wave][q][lane] = acc[q]; red[wave][WM + q][lane] = tmax[q]; }
+    __syncthreads();
+    if (piece == 0 && kind >= 0) {
+#pragma unroll
+      for (int q = 0; q < WM; ++q) {
+        double a = acc[q], m = tmax[q];
+        for (int j = 1; j < npieces; ++j) { a += red[j][q][lane]; m = fmax(m, red[j][WM + q][lane]); }
+        if (q < w) {
+          Udst[(size_t)q * bpad] = a;
+          if (r0 < w) Tmd[(size_t)q * bpad] = m;
+        }
+      }
+    }
+    return;
+  }
   while (d < nrow) PP_FINALIZE();
 #undef PP_FINALIZE
   if (kind == 1) invert_and_scale<WM>(g, p, w, uoff, doff, sub, r0, r1, tmax_diag, true, bpad, b, eps);
@@ -326,6 +349,7 @@ __global__ __launch_bounds__(64) void k_gather_level_lean(GroupDev g, int task0,
   const size_t bpad = (size_t)g.bpad;
   const int* t = g.ftask + TASK_INTS * (size_t)(task0 + PP_TASK_OF_WG(ny));
   const int p = t[0], r0 = t[1], r1 = t[2], dptr0 = t[3], kind = t[4];
+  if (kind < 0) return;                            // quad padding (lean levels have no split rows)
   const int w = (WM == 1) ? 1 : t[7];
   const int uoff = t[8], boff = t[9], doff = t[10];
   const unsigned sub = (unsigned)t[11];
@@ -1688,6 +1712,7 @@ int pp_add_group(pp_handle h, int n, int batch, int nnzK, const int32_t* rowK, c
         else if (k == "sn_wmax") opt.sn_wmax = (int)v;
         else if (k == "md_delta_abs") opt.md_delta_abs = (int)v;
         else if (k == "md_delta_rel") opt.md_delta_rel = v;
+        else if (k == "row_split_factor") opt.row_split_factor = v;
         else return fail(h, 3, "PP_PLAN_TUNE: unknown key " + k);
       }
       pos = end + 1;
@@ -1755,11 +1780,11 @@ int pp_end_symbolic(pp_handle h) {
       fdst_ptr.push_back((int)(fent.size() / 4));
       ftask.insert(ftask.end(), {t.piv, t.r0, t.r1, new_dptr0, t.kind, fdst_ptr[new_dptr0], (int)(fent.size() / 4),
                                  P.piv_w[t.piv], (int)P.piv_uoff[t.piv], P.piv_boff[t.piv], P.piv_doff[t.piv],
-                                 (int)P.piv_sub[t.piv]});
+                                 (int)P.piv_sub[t.piv], t.piece, t.npieces, 0, 0});
     }
     for (auto& t : P.stasks)
       stask.insert(stask.end(), {t.piv, t.r0, t.r1, -1, t.kind, 0, 0, P.piv_w[t.piv], (int)P.piv_uoff[t.piv],
-                                 P.piv_boff[t.piv], P.piv_doff[t.piv], (int)P.piv_sub[t.piv]});
+                                 P.piv_boff[t.piv], P.piv_doff[t.piv], (int)P.piv_sub[t.piv], 0, 1, 0, 0});
     for (int q = 0; q < 16; ++q) fent.insert(fent.end(), {0, 0, 0, 0});   // slack for the vector record reads
     // tile records (one per panel) -> column-step records (one per panel column), with their own tile pointers
     std::vector<int> sptr(P.stile_ptr.size(), 0);
@@ -1958,18 +1983,20 @@ int pp_numeric_local(pp_handle h) {
             const bool lean = P.flevel_maxent[l] <= 12;
             const int mw = g->level_maxw[l];
 #define PP_LAUNCH_GATHER(K, WM) hipLaunchKernelGGL(K<WM>, dim3((unsigned)nt * ny), dim3(64), 0, fan[q], d, t0, sp.c0[q], ny, PIVOT_EPS)
+#define PP_LAUNCH_QUADS(K, WM) hipLaunchKernelGGL(K<WM>, dim3((unsigned)(nt / PP_QUAD) * ny), dim3(64 * PP_QUAD), 0, fan[q], d, t0, sp.c0[q], ny, PIVOT_EPS)
             if (lean) {
               if (mw == 1) PP_LAUNCH_GATHER(k_gather_level_lean, 1);
               else if (mw == 2) PP_LAUNCH_GATHER(k_gather_level_lean, 2);
               else if (mw <= 4) PP_LAUNCH_GATHER(k_gather_level_lean, 4);
               else PP_LAUNCH_GATHER(k_gather_level_lean, PP_WMAX);
             } else {
-              if (mw == 1) PP_LAUNCH_GATHER(k_gather_level, 1);
-              else if (mw == 2) PP_LAUNCH_GATHER(k_gather_level, 2);
-              else if (mw <= 4) PP_LAUNCH_GATHER(k_gather_level, 4);
-              else PP_LAUNCH_GATHER(k_gather_level, PP_WMAX);
+              if (mw == 1) PP_LAUNCH_QUADS(k_gather_level, 1);
+              else if (mw == 2) PP_LAUNCH_QUADS(k_gather_level, 2);
+              else if (mw <= 4) PP_LAUNCH_QUADS(k_gather_level, 4);
+              else PP_LAUNCH_QUADS(k_gather_level, PP_WMAX);
             }
 #undef PP_LAUNCH_GATHER
+#undef PP_LAUNCH_QUADS
           }
           if (ns > 0) {
             if (g->level_maxw[l] <= 4)

@@ -477,7 +477,7 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
     for (int e = 0; e < P.ncan; ++e) can_by_pos[e] = {P.pos_of_can[e], e};
     std::sort(can_by_pos.begin(), can_by_pos.end());
     size_t can_cursor = 0;  // panels are visited in increasing U position
-    struct TmpTask { FTask t; int level; };
+    struct TmpTask { FTask t; int level; int nent = 0; };
     std::vector<TmpTask> gtasks, sctasks;
     std::vector<std::vector<FEntry>> row_ents;   // per destination row (slot) of panel p
     for (int p = 0; p < P.npiv; ++p) {
@@ -518,27 +518,46 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
       }
       const bool in_tail = P.piv_level[p] >= P.tail_level0;
       const int cap_e = in_tail ? opt.tail_task_entries : opt.max_task_entries;
-      auto emit = [&](int r0, int r1, int kind) {
+      auto emit = [&](int r0, int r1, int kind, int piece = 0, int npieces = 1, int e0 = -1, int e1 = -1) {
         TmpTask tt;
         tt.level = P.piv_level[p];
         tt.t.piv = p; tt.t.r0 = r0; tt.t.r1 = r1; tt.t.kind = kind; tt.t.dptr0 = (int)P.fdst_ptr.size();
-        for (int rr = r0; rr < r1; ++rr) {
-          P.fdst_ptr.push_back((int)P.fentries.size());
-          const auto& de = row_ents[(size_t)rr];
-          P.fentries.insert(P.fentries.end(), de.begin(), de.end());
+        tt.t.piece = piece; tt.t.npieces = npieces;
+        const int first = (int)P.fentries.size();
+        if (e0 >= 0) {                                   // entries [e0, e1) of the single row r0
+          P.fdst_ptr.push_back(first);
+          const auto& de = row_ents[(size_t)r0];
+          P.fentries.insert(P.fentries.end(), de.begin() + e0, de.begin() + e1);
+        } else {
+          for (int rr = r0; rr < r1; ++rr) {
+            P.fdst_ptr.push_back((int)P.fentries.size());
+            const auto& de = row_ents[(size_t)rr];
+            P.fentries.insert(P.fentries.end(), de.begin(), de.end());
+          }
         }
         P.fdst_ptr.push_back((int)P.fentries.size());
+        // a piece counts with its whole row: a level that holds split rows must not take the lean (one wave per
+        // task, no combine) kernel
+        tt.nent = (e0 >= 0) ? (int)row_ents[(size_t)r0].size() : (int)P.fentries.size() - first;
         gtasks.push_back(tt);
       };
       if (total <= opt.fuse_task_entries) {
         emit(0, f, 1);                                   // fused small panel
       } else {
+        const int cap_row = std::max(cap_e, (int)(opt.row_split_factor * cap_e));
         int r = 0;
         while (r < f) {                                  // gather chunks over all slots
+          const int sz = (int)row_ents[(size_t)r].size();
+          if (sz > cap_row) {                            // long row: pieces for the waves of one quad
+            const int np = std::min(PP_QUAD, (sz + cap_e - 1) / cap_e), per = (sz + np - 1) / np;
+            for (int j = 0; j < np; ++j) emit(r, r + 1, 0, j, np, std::min(sz, j * per), std::min(sz, (j + 1) * per));
+            ++r;
+            continue;
+          }
           int nent = 0, r_end = r;
           while (r_end < f) {
             const int add = (int)row_ents[(size_t)r_end].size();
-            if (r_end > r && nent + add > cap_e) break;
+            if (add > cap_row || (r_end > r && nent + add > cap_e)) break;
             nent += add;
             ++r_end;
           }
@@ -561,12 +580,32 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
     P.flevel_ptr.assign(P.n_levels + 1, 0);
     P.slevel_ptr.assign(P.n_levels + 1, 0);
     P.flevel_maxent.assign(P.n_levels, 0);
-    for (auto& t : gtasks) {
-      P.ftasks.push_back(t.t);
-      P.flevel_ptr[t.level + 1]++;
-      const int nrow = t.t.r1 - t.t.r0;
-      const int ne = P.fdst_ptr[t.t.dptr0 + nrow] - P.fdst_ptr[t.t.dptr0];
-      P.flevel_maxent[t.level] = std::max(P.flevel_maxent[t.level], ne);
+    // per level: split rows first (each fills one quad, padded with no-ops), then the other tasks packed PP_QUAD
+    // per quad; the level's task count is a whole number of quads
+    {
+      FTask noop; noop.piv = 0; noop.r0 = 0; noop.r1 = 0; noop.dptr0 = 0; noop.kind = -1;
+      size_t i = 0;
+      while (i < gtasks.size()) {
+        const int lvl = gtasks[i].level;
+        size_t j = i;
+        while (j < gtasks.size() && gtasks[j].level == lvl) ++j;
+        const size_t before = P.ftasks.size();
+        for (size_t q = i; q < j; ++q) {
+          if (gtasks[q].t.npieces <= 1) continue;
+          P.ftasks.push_back(gtasks[q].t);
+          if (gtasks[q].t.piece == gtasks[q].t.npieces - 1)
+            for (int pad = gtasks[q].t.npieces; pad < PP_QUAD; ++pad) {
+              FTask z = noop; z.npieces = gtasks[q].t.npieces; z.piece = pad;   // (keeps the quad uniform: all split)
+              P.ftasks.push_back(z);
+            }
+        }
+        for (size_t q = i; q < j; ++q)
+          if (gtasks[q].t.npieces <= 1) P.ftasks.push_back(gtasks[q].t);
+        while ((P.ftasks.size() - before) % PP_QUAD != 0) P.ftasks.push_back(noop);
+        P.flevel_ptr[lvl + 1] += (int)(P.ftasks.size() - before);
+        for (size_t q = i; q < j; ++q) P.flevel_maxent[lvl] = std::max(P.flevel_maxent[lvl], gtasks[q].nent);
+        i = j;
+      }
     }
     for (auto& t : sctasks) { P.stasks.push_back(t.t); P.slevel_ptr[t.level + 1]++; }
     for (int l = 0; l < P.n_levels; ++l) { P.flevel_ptr[l + 1] += P.flevel_ptr[l]; P.slevel_ptr[l + 1] += P.slevel_ptr[l]; }

@@ -74,6 +74,7 @@ void ppsim_task_profile(void* h, int* out /*5 per task*/) {
   Plan& P = *(Plan*)h;
   for (size_t t = 0; t < P.ftasks.size(); ++t) {
     const auto& ft = P.ftasks[t];
+    if (ft.kind < 0) { out[5 * t] = -1; out[5 * t + 1] = 0; out[5 * t + 2] = 0; out[5 * t + 3] = -1; out[5 * t + 4] = 0; continue; }
     const int w = P.piv_w[ft.piv], nrow = ft.r1 - ft.r0;
     out[5 * t] = P.piv_level[ft.piv]; out[5 * t + 1] = w; out[5 * t + 2] = nrow;
     out[5 * t + 3] = ft.kind; out[5 * t + 4] = P.fdst_ptr[ft.dptr0 + nrow] - P.fdst_ptr[ft.dptr0];
@@ -112,9 +113,40 @@ int ppsim_factor(void* h, const double* can, double* U, double* L, double* Dinv,
     // launch G: gather chunks and fused small panels
     for (int ti = P.flevel_ptr[lvl]; ti < P.flevel_ptr[lvl + 1]; ++ti) {
       const auto& t = P.ftasks[ti];
+      if (t.kind < 0) continue;                       // quad padding
       const int p = t.piv, w = P.piv_w[p];
       const int nrow = t.r1 - t.r0;
       double blk[PP_WMAX * PP_WMAX] = {0}, tmax_diag = 0.0, inv[PP_WMAX * (PP_WMAX + 1) / 2] = {0};
+      if (t.npieces > 1) {
+        // one long row gathered by the waves of a quad: partial sums per piece, added in piece order by piece 0
+        if (t.piece != 0) continue;                   // (the pieces follow piece 0 in the task list)
+        double acc[PP_WMAX] = {0}, tmax[PP_WMAX] = {0};
+        for (int j = 0; j < t.npieces; ++j) {
+          const auto& tj = P.ftasks[ti + j];
+          double pa[PP_WMAX] = {0}, pm[PP_WMAX] = {0};
+          for (int e = P.fdst_ptr[tj.dptr0]; e < P.fdst_ptr[tj.dptr0 + 1]; ++e) {
+            const auto& fe = P.fentries[e];
+            if (fe.u < 0) {
+              const double v = can[-1 - fe.u];
+              pa[fe.q] += v;
+              pm[fe.q] = std::fmax(pm[fe.q], std::fabs(v));
+            } else {
+              const double su = U[fe.u];
+              for (int q = 0; q < w; ++q) {
+                const double term = su * L[fe.l + q * fe.wk];
+                pa[q] -= term;
+                pm[q] = std::fmax(pm[q], std::fabs(term));
+              }
+            }
+          }
+          for (int q = 0; q < w; ++q) { acc[q] = (j == 0) ? pa[q] : acc[q] + pa[q]; tmax[q] = std::fmax(tmax[q], pm[q]); }
+        }
+        for (int q = 0; q < w; ++q) {
+          U[P.piv_uoff[p] + (int64_t)t.r0 * w + q] = acc[q];
+          if (t.r0 < w) Tm[P.piv_boff[p] + (t.r0 * w + q)] = tmax[q];
+        }
+        continue;
+      }
       for (int rr = 0; rr < nrow; ++rr) {
         const int slot = t.r0 + rr;
         double acc[PP_WMAX] = {0}, tmax[PP_WMAX] = {0};
