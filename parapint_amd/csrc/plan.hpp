@@ -36,7 +36,7 @@ struct PlanOptions {
   int max_task_entries = 24;   // entries per gather chunk of a big panel
   int fuse_task_entries = 24;  // panels with at most this many entries are one fused task (gather + invert + scale)
   int scale_task_rows = 8;     // rows per scale task of a big panel
-  double row_split_factor = 1.5;  // a row longer than this many task caps is split over the waves of one quad
+  double row_split_factor = 2.0;  // a row longer than this many task caps is split over the waves of one quad
   // Top of the elimination tree ("tail"): levels holding at most tail_piv_max pivots each get their own task
   // size (few panels, long rows: shorter tasks give more waves per level).
   int tail_piv_max = 48;
@@ -114,7 +114,8 @@ struct Plan {
   std::vector<int> slevel_ptr;           // n_levels+1 -> stasks
   std::vector<int> piv_boff;             // offset of the pivot block's w*w term magnitudes (Tm storage)
   int bsize = 0;
-  std::vector<int> flevel_maxent;        // per level: max entries of a gather/fused task
+  std::vector<int> flevel_maxent;        // per level: max entries of a gather/fused task (a piece counts as its whole row)
+  std::vector<int> flevel_nsplit;        // per level: number of split rows (0: the level runs one wave per workgroup)
   std::vector<int> clevel_ptr, clevel_col;  // solve schedule: scalar columns (new indices) by level
   int tail_level0 = 0;                   // levels >= tail_level0 form the tail (== n_levels: no tail)
   // forward-solve entries: scalar row (new column index c) = b_c - sum U[upos] * z[zcol]

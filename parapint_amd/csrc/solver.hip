@@ -233,15 +233,17 @@ __device__ __forceinline__ void invert_and_scale(const GroupDev& g, int p, int w
 // straight from the transposed input (e.u < 0, added to column e.q): assembly is fused into the
 // factorisation.  Fused small panels (kind 1) finish with the inversion of their block and the
 // scaling of their rows.
-template <int WM>
-__global__ __launch_bounds__(64 * PP_QUAD) void k_gather_level(GroupDev g, int task0, int chunk0, int ny, double eps) {
-  __shared__ double red[PP_QUAD][2 * WM][64];     // partial sums / term magnitudes of a split row
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+// NW = waves (tasks) per workgroup: PP_QUAD on the levels that hold split rows, 1 elsewhere (a workgroup keeps its
+// resources until its longest wave ends, so unrelated tasks are better off as workgroups of their own).
+template <int WM, int NW>
+__global__ __launch_bounds__(64 * NW) void k_gather_level(GroupDev g, int task0, int chunk0, int ny, double eps) {
+  __shared__ double red[NW > 1 ? NW : 1][NW > 1 ? 2 * WM : 1][NW > 1 ? 64 : 1];   // partial sums / term magnitudes of a split row
+  const int lane = threadIdx.x & 63, wave = (NW > 1) ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
   const int b = (PP_CHUNK_OF_WG(ny) + chunk0) * 64 + lane;
   const size_t bpad = (size_t)g.bpad;
-  const int* t = g.ftask + TASK_INTS * (size_t)(task0 + PP_QUAD * PP_TASK_OF_WG(ny) + wave);
+  const int* t = g.ftask + TASK_INTS * (size_t)(task0 + NW * PP_TASK_OF_WG(ny) + wave);
   const int p = t[0], r0 = t[1], r1 = t[2], dptr0 = t[3], kind = t[4], E0 = t[5], E1 = t[6];
-  const int piece = t[12], npieces = t[13];        // npieces is the same for all waves of the workgroup
+  const int piece = (NW > 1) ? t[12] : 0, npieces = (NW > 1) ? t[13] : 1;   // npieces is the same for all waves of the workgroup
   if (kind < 0 && npieces <= 1) return;            // quad padding (in a split quad the padding waves join the barrier)
   const int w = (WM == 1) ? 1 : t[7];
   const int uoff = t[8], boff = t[9], doff = t[10];
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(64 * PP_QUAD) void k_gather_level(GroupDev g, int t
   int dend = (nrow > 0) ? (dp_vec ? bcast(dpv, 1) : dp[1]) : 0x7fffffff;
 #define PP_FINALIZE()                                                                      \
   do {                                                                                     \
-    if (npieces > 1) break;   /* split row: combined below */                             \
+    if (NW > 1 && npieces > 1) break;   /* split row: combined below */                   \
     _Pragma("unroll") for (int q = 0; q < WM; ++q) {                                       \
       if (q < w) {                                                                         \
         Udst[(size_t)(d * w + q) * bpad] = acc[q];                                         \
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(64 * PP_QUAD) void k_gather_level(GroupDev g, int t
     if (i0 < cnt) PP_GROUP(4)
 #undef PP_GROUP
   }
-  if (npieces > 1) {
+  if (NW > 1 && npieces > 1) {
     // one long row over the waves of this quad: partial sums meet in LDS, piece 0 adds them in piece order
 #pragma unroll
     for (int q = 0; q < WM; ++q) { red[wave][q][lane] = acc[q]; red[wave][WM + q][lane] = tmax[q]; }
@@ -1982,13 +1984,18 @@ int pp_numeric_local(pp_handle h) {
           if (nt > 0) {
             const bool lean = P.flevel_maxent[l] <= 12;
             const int mw = g->level_maxw[l];
-#define PP_LAUNCH_GATHER(K, WM) hipLaunchKernelGGL(K<WM>, dim3((unsigned)nt * ny), dim3(64), 0, fan[q], d, t0, sp.c0[q], ny, PIVOT_EPS)
-#define PP_LAUNCH_QUADS(K, WM) hipLaunchKernelGGL(K<WM>, dim3((unsigned)(nt / PP_QUAD) * ny), dim3(64 * PP_QUAD), 0, fan[q], d, t0, sp.c0[q], ny, PIVOT_EPS)
+#define PP_LAUNCH_GATHER(K, ...) hipLaunchKernelGGL((K<__VA_ARGS__>), dim3((unsigned)nt * ny), dim3(64), 0, fan[q], d, t0, sp.c0[q], ny, PIVOT_EPS)
+#define PP_LAUNCH_QUADS(K, WM) hipLaunchKernelGGL((K<WM, PP_QUAD>), dim3((unsigned)(nt / PP_QUAD) * ny), dim3(64 * PP_QUAD), 0, fan[q], d, t0, sp.c0[q], ny, PIVOT_EPS)
             if (lean) {
               if (mw == 1) PP_LAUNCH_GATHER(k_gather_level_lean, 1);
               else if (mw == 2) PP_LAUNCH_GATHER(k_gather_level_lean, 2);
               else if (mw <= 4) PP_LAUNCH_GATHER(k_gather_level_lean, 4);
               else PP_LAUNCH_GATHER(k_gather_level_lean, PP_WMAX);
+            } else if (P.flevel_nsplit[l] == 0) {
+              if (mw == 1) PP_LAUNCH_GATHER(k_gather_level, 1, 1);
+              else if (mw == 2) PP_LAUNCH_GATHER(k_gather_level, 2, 1);
+              else if (mw <= 4) PP_LAUNCH_GATHER(k_gather_level, 4, 1);
+              else PP_LAUNCH_GATHER(k_gather_level, PP_WMAX, 1);
             } else {
               if (mw == 1) PP_LAUNCH_QUADS(k_gather_level, 1);
               else if (mw == 2) PP_LAUNCH_QUADS(k_gather_level, 2);

@@ -580,6 +580,7 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
     P.flevel_ptr.assign(P.n_levels + 1, 0);
     P.slevel_ptr.assign(P.n_levels + 1, 0);
     P.flevel_maxent.assign(P.n_levels, 0);
+    P.flevel_nsplit.assign(P.n_levels, 0);
     // per level: split rows first (each fills one quad, padded with no-ops), then the other tasks packed PP_QUAD
     // per quad; the level's task count is a whole number of quads
     {
@@ -593,14 +594,20 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
         for (size_t q = i; q < j; ++q) {
           if (gtasks[q].t.npieces <= 1) continue;
           P.ftasks.push_back(gtasks[q].t);
+          if (gtasks[q].t.piece == 0) P.flevel_nsplit[lvl]++;
           if (gtasks[q].t.piece == gtasks[q].t.npieces - 1)
             for (int pad = gtasks[q].t.npieces; pad < PP_QUAD; ++pad) {
               FTask z = noop; z.npieces = gtasks[q].t.npieces; z.piece = pad;   // (keeps the quad uniform: all split)
               P.ftasks.push_back(z);
             }
         }
+        // unsplit tasks longest first: the waves of a quad then carry similar loads, and the longest tasks of the
+        // level -- which decide when the launch ends -- start first
+        std::vector<size_t> singles;
         for (size_t q = i; q < j; ++q)
-          if (gtasks[q].t.npieces <= 1) P.ftasks.push_back(gtasks[q].t);
+          if (gtasks[q].t.npieces <= 1) singles.push_back(q);
+        std::stable_sort(singles.begin(), singles.end(), [&](size_t a, size_t b) { return gtasks[a].nent > gtasks[b].nent; });
+        for (size_t q : singles) P.ftasks.push_back(gtasks[q].t);
         while ((P.ftasks.size() - before) % PP_QUAD != 0) P.ftasks.push_back(noop);
         P.flevel_ptr[lvl + 1] += (int)(P.ftasks.size() - before);
         for (size_t q = i; q < j; ++q) P.flevel_maxent[lvl] = std::max(P.flevel_maxent[lvl], gtasks[q].nent);
