@@ -55,6 +55,9 @@ class TorchComm(object):
         self.size = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
         self.device_collectives = (self.backend == 'nccl')
+        # issue the data-path collectives even in a one-rank group (lets a one-GPU box exercise the RCCL calls on
+        # the solver's device buffers; a sum over one rank is the identity)
+        self.always_reduce = False
 
     def _host_allreduce(self, arr, op):
         torch = self._torch

@@ -184,7 +184,7 @@ class HipEngine(object):
         self.ns.check(self.lib.pp_numeric_local(self.ns.h), 'pp_numeric_local')
 
     def allreduce_schur(self, comm):
-        if comm.size > 1:
+        if comm.size > 1 or getattr(comm, 'always_reduce', False):
             if comm.device_collectives:
                 comm.allreduce_sum_tensor_(self._S_t)
             else:
@@ -234,7 +234,7 @@ class HipEngine(object):
         self.ns.check(self.lib.pp_solve_forward(self.ns.h), 'pp_solve_forward')
 
     def allreduce_rs(self, comm):
-        if comm.size > 1:
+        if comm.size > 1 or getattr(comm, 'always_reduce', False):
             if comm.device_collectives:
                 comm.allreduce_sum_tensor_(self._rs_t)
             else:

@@ -1,0 +1,67 @@
+"""Worker of tests/test_hip_solver.py::test_rccl_collectives_on_solver_buffers: ONE rank, backend nccl (= RCCL).
+
+A one-GPU box cannot host two RCCL ranks, so this run issues the two data-path all-reduces (S + status tail,
+r_s) over a one-rank RCCL group on the solver's own device buffers and stream: a sum over one rank is the
+identity, so the solve must still match the oracle -- which checks the buffer binding, dtype/size and the
+stream ordering between the solver's kernels and RCCL that the N > 1 runs rely on."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+from oracle.schur_complement import SchurComplementLinearSolver as OracleSC  # noqa: E402
+from oracle.subsolvers import ScipyInterface as OracleScipy  # noqa: E402
+from parapint_amd.examples.performance.schur_complement.synthetic_kkt import SyntheticKKT  # noqa: E402
+from parapint_amd.linalg.comm import SerialComm, TorchComm  # noqa: E402
+from parapint_amd.linalg.hip_schur_complement import HipSchurComplementLinearSolver  # noqa: E402
+from parapint_amd.linalg.results import LinearSolverStatus  # noqa: E402
+
+
+def main():
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
+    comm = TorchComm()
+    assert comm.size == 1 and comm.device_collectives
+    comm.always_reduce = True
+    calls = []
+    plain = comm.allreduce_sum_tensor_
+
+    def counted(t):
+        calls.append((t.numel(), t.is_cuda))
+        return plain(t)
+    comm.allreduce_sum_tensor_ = counted
+    shape = (70, 40, 2, 8)          # two 64-instance chunks, the second one ragged
+    N = shape[0]
+    model = SyntheticKKT(*shape)
+    solver = HipSchurComplementLinearSolver({i: None for i in range(N)}, None, comm=comm)
+    for it in (0, 3):
+        kkt = model.build_kkt(comm=comm, iteration=it)
+        rhs = model.build_rhs(comm=comm)
+        if it == 0:
+            assert solver.do_symbolic_factorization(kkt).status == LinearSolverStatus.successful
+        assert solver.do_numeric_factorization(kkt).status == LinearSolverStatus.successful
+        x = solver.do_back_solve(rhs)
+        okkt = model.build_kkt(comm=SerialComm(), iteration=it)
+        oracle = OracleSC({i: OracleScipy(compute_inertia=True) for i in range(N)}, OracleScipy(compute_inertia=True))
+        oracle.do_symbolic_factorization(okkt)
+        oracle.do_numeric_factorization(okkt)
+        xo = oracle.do_back_solve(model.build_rhs(comm=SerialComm()))
+        for ndx in range(N + 1):
+            ref = np.asarray(xo.get_block(ndx))
+            assert np.abs(np.asarray(x.get_block(ndx)) - ref).max() <= 1e-8 * max(1.0, np.abs(ref).max())
+        assert solver.get_inertia() == oracle.get_inertia()
+    nc = shape[3]
+    assert calls.count((nc * nc + 4, True)) == 2 and calls.count((nc, True)) == 2, calls
+    dist.barrier()
+    dist.destroy_process_group()
+    print('rccl one-rank ok')
+
+
+if __name__ == '__main__':
+    main()

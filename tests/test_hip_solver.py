@@ -260,3 +260,23 @@ def test_inertia_correction_fast_path_on_device():
     bare.do_numeric_factorization(A1)
     with pytest.raises(RuntimeError, match='no diagonal entry'):
         bare.set_regularization_classes(classes)
+
+
+def test_rccl_collectives_on_solver_buffers():
+    """The two data-path all-reduces through RCCL on the solver's own device buffers and stream (one-rank group:
+    a one-GPU box cannot host two RCCL ranks; the two-rank host logic is covered by test_multirank_gloo.py)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(here, 'rccl_worker.py')]
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    text = out.stdout.decode()
+    assert out.returncode == 0, text[-4000:]
+    assert 'rccl one-rank ok' in text
