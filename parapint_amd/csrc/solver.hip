@@ -18,7 +18,6 @@
 
 #include <chrono>
 #include <cstdint>
-#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -1057,25 +1056,28 @@ __global__ __launch_bounds__(LDL_THREADS) void k_ldl_regs(int n, double* __restr
       else if (i == j) { A[(j0 + i) + (size_t)(j0 + j) * lda] = dl[i]; dvec[j0 + i] = dl[i]; }
     }
     // (c) panel: W = A21 L11^{-T} (thread = row), L21 = W D^{-1} -> LDS and global
-    if (tid < m) {
-      const int r = nb + tid;
-      double wrow[LDLR_NB];
+    if (64 * wv_here < m) {   // (whole waves: the L11 broadcasts below are wave-wide)
+      const int r = nb + min(tid, m - 1);
+      // L11 stays in registers, lane k (mod 16) holding its row k; an element reaches the row solves by v_readlane
+      // (no LDS round trip inside the dependent chain of a row solve)
+      double lrow[LDLR_NB], wrow[LDLR_NB];
 #pragma unroll
-      for (int k = 0; k < LDLR_NB; ++k) wrow[k] = P[r][k];
+      for (int k = 0; k < LDLR_NB; ++k) { lrow[k] = P[lane & 15][k]; wrow[k] = P[r][k]; }
 #pragma unroll
       for (int k = 1; k < LDLR_NB; ++k) {
         double v = wrow[k];
 #pragma unroll
-        for (int j = 0; j < k; ++j) v -= wrow[j] * P[k][j];
+        for (int j = 0; j < k; ++j) v -= wrow[j] * bcastd(lrow[j], k);
         wrow[k] = v;
-        __builtin_amdgcn_sched_barrier(0);   // keep the LDS reads of later columns from being hoisted (register pressure)
       }
+      if (tid < m) {
 #pragma unroll
-      for (int k = 0; k < LDLR_NB; ++k) {
-        if (k < nb) {
-          const double l = wrow[k] * rdl[k];
-          P[r][k] = l;
-          A[(j0 + r) + (size_t)(j0 + k) * lda] = l;
+        for (int k = 0; k < LDLR_NB; ++k) {
+          if (k < nb) {
+            const double l = wrow[k] * rdl[k];
+            P[r][k] = l;
+            A[(j0 + r) + (size_t)(j0 + k) * lda] = l;
+          }
         }
       }
     }
@@ -1343,20 +1345,42 @@ __device__ __forceinline__ double gather_row(const int* __restrict__ upos, const
   return s0 + s1;
 }
 
+// Wave team: the NW waves of a workgroup each hold a partial sum of ONE row (a slice of its entry list); the sums
+// meet in LDS and are added in wave order (deterministic).  Returns the total in wave 0 (others: unspecified).
+// The long rows / columns of the top levels -- up to a few hundred entries, one dependent load round per 16 of
+// them -- set the duration of their launches; a team cuts the rounds by NW.
+template <int NW>
+__device__ __forceinline__ double team_sum(double s, double (*red)[64], int wave, int lane) {
+  if (NW == 1) return s;
+  red[wave][lane] = s;
+  __syncthreads();
+  double t = 0.0;
+  if (wave == 0) {
+#pragma unroll
+    for (int k = 0; k < NW; ++k) t += red[k][lane];
+  }
+  return t;
+}
+
 // forward substitution, one scalar row per workgroup: y_c = b_c - sum_k L[c, k] y_k
 // (rows of one block pivot are independent: the block is applied as a whole, by inv(P), in the backward sweep)
-__global__ __launch_bounds__(64) void k_fwd_level(GroupDev g, int col0, int chunk0, int ny) {
-  const int lane = threadIdx.x;
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_fwd_level(GroupDev g, int col0, int chunk0, int ny) {
+  __shared__ double red[NW][64];
+  const int lane = threadIdx.x & 63, wave = (NW > 1) ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
   const int b = (PP_CHUNK_OF_WG(ny) + chunk0) * 64 + lane;
   const size_t bpad = (size_t)g.bpad;
   const int* rec = g.fwd_rec + 4 * (size_t)(col0 + PP_TASK_OF_WG(ny));   // {column, -, e0, e1}
-  const int c = rec[0];
+  const int c = rec[0], e0 = rec[2], ne = rec[3] - rec[2];
+  const int a0 = e0 + (int)((long long)ne * wave / NW), a1 = e0 + (int)((long long)ne * (wave + 1) / NW);
   // in place: the right-hand side was transposed into Y in the new order (rows of leaf columns are final as they are)
   double* yc = g.Y + (size_t)c * bpad + b;
-  *yc -= gather_row(g.sfwd_upos, g.sfwd_zcol, rec[2], rec[3], g.L + b, g.Y + b, bpad, lane);
+  const double s = team_sum<NW>(gather_row(g.sfwd_upos, g.sfwd_zcol, a0, a1, g.L + b, g.Y + b, bpad, lane), red, wave, lane);
+  if (wave == 0) *yc -= s;
 }
 
 // coupling row c: rspart[chunk][c] = - sum over active instances and panels of L[c,k] y_k
+// (one wave per row: 200 rows x 16 chunks fill the chip, and a team of waves per row measured slower here)
 __global__ __launch_bounds__(64) void k_fwd_coupling(GroupDev g) {
   const int lane = threadIdx.x;
   const int chunk = PP_CHUNK_OF_WG(g.nchunk);
@@ -1379,9 +1403,11 @@ __global__ __launch_bounds__(256) void k_rs_reduce(GroupDev g, double* __restric
 
 // back substitution, one scalar column c = (block pivot p, component q) per workgroup:
 //   x_c = (inv(P_p) y_p)_q - sum_i L[i, c] x_i      (x_i = xc for coupling rows)
-__global__ __launch_bounds__(64) void k_bwd_level(GroupDev g, int col0, int chunk0, int ny,
-                                                  const double* __restrict__ xc) {
-  const int lane = threadIdx.x;
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_bwd_level(GroupDev g, int col0, int chunk0, int ny,
+                                                       const double* __restrict__ xc) {
+  __shared__ double red[NW][64];
+  const int lane = threadIdx.x & 63, wave = (NW > 1) ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
   const int b = (PP_CHUNK_OF_WG(ny) + chunk0) * 64 + lane;
   const size_t bpad = (size_t)g.bpad;
   const int* rec = g.bwd_rec + 8 * (size_t)(col0 + PP_TASK_OF_WG(ny));   // {c, w, q, nr, rowptr, L base, doff, p0}
@@ -1392,25 +1418,28 @@ __global__ __launch_bounds__(64) void k_bwd_level(GroupDev g, int col0, int chun
   const int n = g.n;
   const size_t rstride = (size_t)w * bpad;
   // z = row q of inv(P) times y_p
-  const double* inv = g.Dinv + (size_t)rec[6] * bpad + b;
-  const double* Yp = g.Y + (size_t)rec[7] * bpad + b;
   double z = 0.0;
+  if (wave == 0) {
+    const double* inv = g.Dinv + (size_t)rec[6] * bpad + b;
+    const double* Yp = g.Y + (size_t)rec[7] * bpad + b;
 #pragma unroll
-  for (int t = 0; t < PP_WMAX; ++t) {
-    if (t < w) {
-      const int hi = q > t ? q : t, lo = q > t ? t : q;
-      z += inv[(size_t)(hi * (hi + 1) / 2 + lo) * bpad] * Yp[(size_t)t * bpad];
+    for (int t = 0; t < PP_WMAX; ++t) {
+      if (t < w) {
+        const int hi = q > t ? q : t, lo = q > t ? t : q;
+        z += inv[(size_t)(hi * (hi + 1) / 2 + lo) * bpad] * Yp[(size_t)t * bpad];
+      }
     }
   }
+  const int j0 = (int)((long long)nr * wave / NW), j1 = (int)((long long)nr * (wave + 1) / NW);   // this wave's rows
   double g0 = 0.0, g1 = 0.0;
-  if (nr <= 4) {   // wide bottom levels: short panels, plain scalar index reads
+  if (NW == 1 && nr <= 4) {   // wide bottom levels: short panels, plain scalar index reads
     for (int j = 0; j < nr; ++j) {
       const int r = ri[j];
       g0 += Lp[(size_t)j * rstride] * ((r < n) ? Xb[(size_t)r * bpad] : xc[r - n]);
     }
   } else {
-    for (int jb = 0; jb < nr; jb += 64) {
-      const int cnt = min(64, nr - jb);
+    for (int jb = j0; jb < j1; jb += 64) {
+      const int cnt = min(64, j1 - jb);
       const int rv = (lane < cnt) ? ri[jb + lane] : 0;
 #define PP_BGROUP(G)                                                                       \
   {                                                                                        \
@@ -1433,7 +1462,8 @@ __global__ __launch_bounds__(64) void k_bwd_level(GroupDev g, int col0, int chun
 #undef PP_BGROUP
     }
   }
-  g.X[(size_t)c * bpad + b] = z - (g0 + g1);
+  const double s = team_sum<NW>(g0 + g1, red, wave, lane);
+  if (wave == 0) g.X[(size_t)c * bpad + b] = z - s;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1449,6 +1479,7 @@ struct Group {
   std::vector<int> level_maxw;   // widest block pivot per level (selects the scalar kernel variants)
   std::vector<int> diag_can;     // canonical entry of the diagonal (i, i) of K, or -1
   std::vector<uint8_t> fwd_level_has_entries;   // forward-solve levels whose columns have any incoming entry
+  std::vector<int> fwd_level_team, bwd_level_team;   // waves per row / column on each solve level (1, 4 or 16)
   int nraw_tiles = 0;            // number of input tiles with needed entries
   int nshift = 0;                // rows with a regularisation class (pp_set_diagonal_classes)
   const int *shift_row = nullptr, *shift_cls = nullptr;   // device: transposed-input row of their diagonal entry, class
@@ -1850,6 +1881,21 @@ int pp_end_symbolic(pp_handle h) {
           const int c = P.clevel_col[q];
           if (P.sfwd_eptr[c + 1] > P.sfwd_eptr[c]) { g->fwd_level_has_entries[(size_t)l] = 1; break; }
         }
+      // wave teams: a row / column with more than a couple of 16-entry load rounds is shared by 4 or 16 waves
+      // (thresholds measured at C3: 16/48 and 16/64 were slower, 48/128 the same)
+      auto team_of = [](int longest) { return longest > 96 ? 16 : longest > 32 ? 4 : 1; };
+      g->fwd_level_team.assign((size_t)P.n_levels, 1);
+      g->bwd_level_team.assign((size_t)P.n_levels, 1);
+      for (int l = 0; l < P.n_levels; ++l) {
+        int fmax = 0, bmax = 0;
+        for (int q = P.clevel_ptr[l]; q < P.clevel_ptr[l + 1]; ++q) {
+          const int c = P.clevel_col[q], pv = P.piv_of_col[c];
+          fmax = std::max(fmax, P.sfwd_eptr[c + 1] - P.sfwd_eptr[c]);
+          bmax = std::max(bmax, P.piv_rowptr[pv + 1] - P.piv_rowptr[pv]);
+        }
+        g->fwd_level_team[(size_t)l] = team_of(fmax);
+        g->bwd_level_team[(size_t)l] = team_of(bmax);
+      }
       if ((rc = dev_upload(h, g, &d.fwd_rec, frec))) return rc;
       if ((rc = dev_upload(h, g, &d.bwd_rec, brec))) return rc;
     }
@@ -2162,9 +2208,15 @@ int pp_solve_forward(pp_handle h) {
       for (int l = 0; l < P.n_levels; ++l) {
         const int c0 = P.clevel_ptr[l], ncol = P.clevel_ptr[l + 1] - c0;
         if (ncol <= 0 || !g->fwd_level_has_entries[(size_t)l]) continue;
-        for (int q = 0; q < sp.n; ++q)
-          hipLaunchKernelGGL(k_fwd_level, dim3((unsigned)ncol * (sp.c0[q + 1] - sp.c0[q])), dim3(64), 0, fan[q], d, c0, sp.c0[q],
-                             sp.c0[q + 1] - sp.c0[q]);
+        const int team = g->fwd_level_team[(size_t)l];
+        for (int q = 0; q < sp.n; ++q) {
+          const int ny = sp.c0[q + 1] - sp.c0[q];
+#define PP_LAUNCH_FWD(NW) hipLaunchKernelGGL(k_fwd_level<NW>, dim3((unsigned)ncol * ny), dim3(64 * NW), 0, fan[q], d, c0, sp.c0[q], ny)
+          if (team == 16) PP_LAUNCH_FWD(16);
+          else if (team == 4) PP_LAUNCH_FWD(4);
+          else PP_LAUNCH_FWD(1);
+#undef PP_LAUNCH_FWD
+        }
       }
       if (join_streams(h, sp, fan)) return fail(h, 3, "stream join failed");
     }
@@ -2215,9 +2267,15 @@ int pp_solve_backward(pp_handle h) {
       for (int l = P.n_levels - 1; l >= 0; --l) {
         const int c0 = P.clevel_ptr[l], ncol = P.clevel_ptr[l + 1] - c0;
         if (ncol <= 0) continue;
-        for (int q = 0; q < sp.n; ++q)
-          hipLaunchKernelGGL(k_bwd_level, dim3((unsigned)ncol * (sp.c0[q + 1] - sp.c0[q])), dim3(64), 0, fan[q], d, c0, sp.c0[q],
-                             sp.c0[q + 1] - sp.c0[q], h->xc);
+        const int team = g->bwd_level_team[(size_t)l];
+        for (int q = 0; q < sp.n; ++q) {
+          const int ny = sp.c0[q + 1] - sp.c0[q];
+#define PP_LAUNCH_BWD(NW) hipLaunchKernelGGL(k_bwd_level<NW>, dim3((unsigned)ncol * ny), dim3(64 * NW), 0, fan[q], d, c0, sp.c0[q], ny, h->xc)
+          if (team == 16) PP_LAUNCH_BWD(16);
+          else if (team == 4) PP_LAUNCH_BWD(4);
+          else PP_LAUNCH_BWD(1);
+#undef PP_LAUNCH_BWD
+        }
       }
       if (join_streams(h, sp, fan)) return fail(h, 3, "stream join failed");
     }
