@@ -162,6 +162,17 @@ __device__ __forceinline__ double bcastd(double v, int src_lane) {
   return __hiloint2double(hi, lo);
 }
 
+// The same, but not before `dep` is available: ties the two v_readlane to a value of the consuming dependency
+// chain.  The plain builtin is a pure function of a value loaded once, so all broadcasts of a long unrolled solve
+// are hoisted to the top and their 2 x N SGPRs spilled to VGPR lanes and reloaded.
+__device__ __forceinline__ double bcastd_after(double v, int src_lane, double dep) {
+  int lo, hi;
+  asm volatile("v_readlane_b32 %0, %2, %4\n\tv_readlane_b32 %1, %3, %4"
+               : "=&s"(lo), "=&s"(hi)
+               : "v"(__double2loint(v)), "v"(__double2hiint(v)), "s"(src_lane), "v"(dep));
+  return __hiloint2double(hi, lo);
+}
+
 // inv(P) packed by rows of the lower triangle
 #define PP_INV(inv, i, j) ((inv)[((i) > (j) ? (i) * ((i) + 1) / 2 + (j) : (j) * ((j) + 1) / 2 + (i))])
 
@@ -932,6 +943,11 @@ __global__ void k_dense_finish(int n, const int* __restrict__ flags, int* __rest
   }
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's outstanding GLOBAL stores
+// (release fence at workgroup scope): in a loop that streams finished columns to global memory and never reads them
+// back, that puts one global-store round trip (1-2 us) on the critical path of every barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Register-resident variant for n <= 16 * LDLR_NT (= 208; the reference configurations have n_c = 200):
 // the whole lower triangle lives in the MFMA accumulators of the 8 waves (91 tiles of 16x16, <= 12 per
 // wave) for the entire factorisation, so a trailing update is LDS reads + fp64 MFMAs only -- no global
@@ -949,7 +965,6 @@ __global__ __launch_bounds__(LDL_THREADS) void k_ldl_regs(int n, double* __restr
                                                           int* __restrict__ mode, int* __restrict__ info, double eps) {
   __shared__ double P[16 * LDLR_NT][LDLR_LD];
   __shared__ double dl[LDLR_NB], rdl[LDLR_NB];
-  __shared__ double colbuf[64], nextbuf[64];
   __shared__ double red[LDL_THREADS / 64];
   __shared__ int sflags[2];
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = LDL_THREADS / 64;
@@ -997,13 +1012,13 @@ __global__ __launch_bounds__(LDL_THREADS) void k_ldl_regs(int n, double* __restr
         for (int r = 0; r < 4; ++r) P[r0 + lkv + 4 * r][liv] = acc[s][r];
       }
     }
-    __syncthreads();
+    lds_barrier();
     // (b) diagonal block by wave 0: lane = row (16 rows, lanes 16.. duplicate them), the row lives in
-    // registers.  Column k is broadcast through LDS (one write per lane, uniform-address reads; LDS
-    // operations of one wave execute in order).  Pivot k + 1 is final as soon as step k has updated column
+    // registers.  Column k is broadcast with v_readlane from lane k (symmetry: see below) -- an LDS broadcast
+    // costs two ~130-cycle round trips per step.  Pivot k + 1 is final as soon as step k has updated column
     // k + 1: its reciprocal (v_rcp_f64 + two Newton steps) is started first and overlaps the rest of the
-    // step.  Mask-free: the strict upper triangle and, in a ragged last panel, rows/columns >= nb carry
-    // don't-care values that never reach a stored result; the unit diagonal is implicit.
+    // step.  Mask-free: in a ragged last panel rows/columns >= nb carry don't-care values that never reach a
+    // stored result; the unit diagonal is implicit.
     int wv_here = wv;
     asm volatile("" : "+s"(wv_here));   // opaque: keeps the panel loop from being unswitched on the wave id (two copies
                                         // of the loop double the accumulator live ranges and spill them)
@@ -1013,21 +1028,19 @@ __global__ __launch_bounds__(LDL_THREADS) void k_ldl_regs(int n, double* __restr
 #pragma unroll
       for (int j = 0; j < LDLR_NB; ++j) row[j] = P[i][j];
       int bad = 0, signs = 0;
-      colbuf[lane] = row[0];
-      double d = colbuf[0];
+      double d = bcastd(row[0], 0);
       if (!(fabs(d) > eps * anorm)) { bad = 1; d = (anorm > 0.0 ? anorm : 1.0); }
       signs |= (d > 0.0) ? 1 : 2;
       double rd = fast_rcp(d);
 #pragma unroll
       for (int k = 0; k < LDLR_NB; ++k) {
-        const double colk = row[k];
-        const double lik = colk * rd;
-        if (k > 0) colbuf[lane] = colk;      // (step 0's column is already there)
+        // column k of the current block, element j, is A[j][k] = A[k][j]: lane k holds it as row[j] (the strict
+        // upper triangle is kept up to date by the same updates), so it reaches all lanes by v_readlane
+        const double lik = row[k] * rd;
         double dn = 1.0, rdn = 1.0;
         if (k + 1 < LDLR_NB) {
-          row[k + 1] -= lik * colbuf[k + 1];
-          nextbuf[lane] = row[k + 1];
-          dn = nextbuf[k + 1];
+          row[k + 1] -= lik * bcastd(row[k + 1], k);
+          dn = bcastd(row[k + 1], k + 1);
           if (k + 1 < nb) {
             if (!(fabs(dn) > eps * anorm)) { bad = 1; dn = (anorm > 0.0 ? anorm : 1.0); }
             signs |= (dn > 0.0) ? 1 : 2;
@@ -1037,7 +1050,7 @@ __global__ __launch_bounds__(LDL_THREADS) void k_ldl_regs(int n, double* __restr
           rdn = fast_rcp(dn);
         }
 #pragma unroll
-        for (int j = k + 2; j < LDLR_NB; ++j) row[j] -= lik * colbuf[j];
+        for (int j = k + 2; j < LDLR_NB; ++j) row[j] -= lik * bcastd(row[j], k);
         row[k] = lik;
         if (lane == 0) { dl[k] = d; rdl[k] = rd; }
         d = dn; rd = rdn;
@@ -1048,7 +1061,7 @@ __global__ __launch_bounds__(LDL_THREADS) void k_ldl_regs(int n, double* __restr
       }
       if (lane == 0) { if (bad) sflags[0] = 1; sflags[1] |= signs; }
     }
-    __syncthreads();
+    lds_barrier();
     // finished diagonal block -> global (unit lower L11, pivots on the diagonal)
     if (tid < nb * nb) {
       const int i = tid % nb, j = tid / nb;
@@ -1063,12 +1076,11 @@ __global__ __launch_bounds__(LDL_THREADS) void k_ldl_regs(int n, double* __restr
       double lrow[LDLR_NB], wrow[LDLR_NB];
 #pragma unroll
       for (int k = 0; k < LDLR_NB; ++k) { lrow[k] = P[lane & 15][k]; wrow[k] = P[r][k]; }
+      // right-looking order: the updates of one step are independent of each other, only 16 steps are chained
 #pragma unroll
-      for (int k = 1; k < LDLR_NB; ++k) {
-        double v = wrow[k];
+      for (int j = 0; j + 1 < LDLR_NB; ++j) {
 #pragma unroll
-        for (int j = 0; j < k; ++j) v -= wrow[j] * bcastd(lrow[j], k);
-        wrow[k] = v;
+        for (int k = j + 1; k < LDLR_NB; ++k) wrow[k] -= wrow[j] * bcastd_after(lrow[j], k, wrow[j]);
       }
       if (tid < m) {
 #pragma unroll
@@ -1081,7 +1093,7 @@ __global__ __launch_bounds__(LDL_THREADS) void k_ldl_regs(int n, double* __restr
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     // (d) trailing update of the tiles still owned: A22 -= (L21 D) L21^T, operands from LDS
     if (m > 0) {
 #pragma unroll
@@ -1101,7 +1113,7 @@ __global__ __launch_bounds__(LDL_THREADS) void k_ldl_regs(int n, double* __restr
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
   }
   if (tid == 0) {
     const bool ok = (sflags[0] == 0) && (sflags[1] == 1 || sflags[1] == 2 || n == 0);
