@@ -48,12 +48,15 @@ struct PlanOptions {
   // (one launch pair per level, latency-bound).  There a sub-pivot is merged into its parent even if up to
   // sn_tail_tol_frac of the parent's structure has to be padded, up to sn_tail_wmax columns: a few padded
   // rows in a handful of panels buy a shorter critical path.
-  // MEASURED (C3, PP_WMAX = 8 build): relaxed merging cut 18 levels to 16 but made the factor phase slower
-  // (0.74 -> 1.03 ms at frac 0.25, 1.29 ms at 1.0: 8-wide panels need 2-3x the registers in the gather /
-  // invert kernels and pad the tall coupling panels), so it is off by default (sn_tail_pop = 0).
-  int sn_tail_pop = 0;
+  // MEASURED (C3): with 4-wide panels (the default) the greedy bottom-up merge leaves the last chain of the tree as
+  // 2 + 2 columns over 200 / 199 coupling rows; a tolerance of 3 % of the structure merges them: 18 -> 17 levels,
+  // 722 -> 736 it/s (any sn_tail_pop in 4..32 and frac in 0.01..0.1 gives the same plan).  With a PP_WMAX = 8
+  // build, relaxed merging cut 18 levels to 16 but made the factor phase slower (0.74 -> 1.03 ms at frac 0.25,
+  // 1.29 ms at 1.0: 8-wide panels need 2-3x the registers in the gather / invert kernels and pad the tall
+  // coupling panels).
+  int sn_tail_pop = 8;
   int sn_tail_wmax = PP_WMAX;
-  double sn_tail_tol_frac = 0.25;
+  double sn_tail_tol_frac = 0.03;
   int md_delta_abs = 3;   // minimum-degree tolerance (absolute) for height-aware selection
   double md_delta_rel = 0.5;   // ... and relative to the current minimum degree
   double pivot_threshold = 0.01;  // 1x1 pivot accepted if |d| >= threshold * max|row| (MA27 cntl(1) analogue)
