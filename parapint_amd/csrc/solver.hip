@@ -532,17 +532,21 @@ __global__ __launch_bounds__(256) void k_count_codes(const unsigned short* __res
 
 // Status mailbox: block counters (S tail after the all-reduce) + dense-factor counters -> pinned host
 // memory, sequence word last (LinearSolverStatus / get_inertia read-back, mpi_...:19-30, 417-436).
+__device__ __forceinline__ void publish_status(const double* __restrict__ tail, const int* __restrict__ bk,
+                                               long long* out, long long seq) {
+  const long long zero = (long long)(tail[0] + 0.5) + bk[2];
+  out[1] = (long long)(tail[1] + 0.5) + bk[0];
+  out[2] = (long long)(tail[2] + 0.5) + bk[1];
+  out[3] = zero;
+  out[0] = zero > 0 ? 2 : 0;
+  __threadfence_system();
+  __hip_atomic_store(out + 4, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// (n_c = 0: no dense phase; otherwise the last dense kernel, k_bk_factor, publishes)
 __global__ void k_publish_status(const double* __restrict__ tail, const int* __restrict__ bk, long long* out,
                                  long long seq) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    const long long zero = (long long)(tail[0] + 0.5) + bk[2];
-    out[1] = (long long)(tail[1] + 0.5) + bk[0];
-    out[2] = (long long)(tail[2] + 0.5) + bk[1];
-    out[3] = zero;
-    out[0] = zero > 0 ? 2 : 0;
-    __threadfence_system();
-    __hip_atomic_store(out + 4, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+  if (threadIdx.x == 0 && blockIdx.x == 0) publish_status(tail, bk, out, seq);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -610,8 +614,18 @@ __global__ __launch_bounds__(64) void k_schur_tiles(GroupDev g) {
 }
 
 // S[ci][cj] += sum over chunks of the tile partials (both triangles of the dense S)
-__global__ __launch_bounds__(64) void k_schur_reduce(GroupDev g, int ntiles, double* __restrict__ S) {
+__global__ __launch_bounds__(64) void k_schur_reduce(GroupDev g, int ntiles, double* __restrict__ S,
+                                                     const int* __restrict__ counters) {
   const int lane = threadIdx.x, tile = blockIdx.x;
+  // last group of the handle: the inertia counters (complete: k_count_codes ran earlier on this stream) go to
+  // the tail of the S buffer, so that they travel with the all-reduce (saves the one-thread k_write_tail launch)
+  if (counters && tile == 0 && lane == 0) {
+    double* tail = S + (size_t)g.nc * g.nc;
+    tail[0] = (double)counters[2];
+    tail[1] = (double)counters[0];
+    tail[2] = (double)counters[1];
+    tail[3] = 0.0;
+  }
   double s = 0.0;
   for (int c = 0; c < g.nchunk; ++c) s += g.Spart[((size_t)c * ntiles + tile) * 64 + lane];
   const int ci = g.stile_a[tile] * 8 + (lane >> 3), cj = g.stile_b[tile] * 8 + (lane & 7);
@@ -961,7 +975,8 @@ constexpr int LDLR_TPW = 12;  // 8 waves * 12 >= 91 tiles
 constexpr int LDLR_NB = 16;
 constexpr int LDLR_LD = 18;   // LDS row stride in doubles: conflict-free MFMA operand reads
 
-__global__ __launch_bounds__(LDL_THREADS) void k_ldl_regs(int n, double* __restrict__ A, double* __restrict__ dvec,
+__global__ __launch_bounds__(LDL_THREADS) void k_ldl_regs(int n, const double* __restrict__ S, const double* __restrict__ Q,
+                                                          double* __restrict__ A, double* __restrict__ dvec,
                                                           int* __restrict__ mode, int* __restrict__ info, double eps) {
   __shared__ double P[16 * LDLR_NT][LDLR_LD];
   __shared__ double dl[LDLR_NB], rdl[LDLR_NB];
@@ -971,8 +986,10 @@ __global__ __launch_bounds__(LDL_THREADS) void k_ldl_regs(int n, double* __restr
   const int li = lane & 15, lk = lane >> 4;
   const size_t lda = (size_t)n;
   const int nt = (n + 15) / 16, ntt = nt * (nt + 1) / 2;
+  // the input is S + Q (Q: lower triangle authoritative, may be null), read straight from the all-reduced buffer:
+  // no separate add/copy kernel in front of the factorisation; S itself stays untouched for the pivoted fallback
   double loc = 0.0;
-  for (int i = tid; i < n; i += LDL_THREADS) loc = fmax(loc, fabs(A[i + i * lda]));
+  for (int i = tid; i < n; i += LDL_THREADS) loc = fmax(loc, fabs(S[i + i * lda] + (Q ? Q[i + i * lda] : 0.0)));
   // tiles of this wave: t = wv + 8 s  <->  (I >= J), t = I (I + 1) / 2 + J
   double4_t acc[LDLR_TPW];
   int tIJ[LDLR_TPW];   // wave-uniform (SGPR): I << 8 | J, or -1
@@ -987,7 +1004,12 @@ __global__ __launch_bounds__(LDL_THREADS) void k_ldl_regs(int n, double* __restr
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = 16 * I + lk + 4 * r, col = 16 * J + li;
-      acc[s][r] = (t < ntt && row < n && col < n) ? A[row + (size_t)col * lda] : 0.0;
+      double v = 0.0;
+      if (t < ntt && row < n && col < n) {
+        v = S[row + (size_t)col * lda];
+        if (Q) v += (row >= col) ? Q[row + (size_t)col * lda] : Q[col + (size_t)row * lda];
+      }
+      acc[s][r] = v;
     }
   }
   for (int off = 32; off > 0; off >>= 1) loc = fmax(loc, __shfl_xor(loc, off));
@@ -1286,17 +1308,27 @@ struct TeamCtx {
   }
 };
 
-__global__ __launch_bounds__(BK_THREADS) void k_bk_factor(int n, double* A, int* ipiv, double* work, int* info,
-                                                          const int* mode) {
+// Last kernel of the dense phase.  If the unpivoted factorisation was accepted (mode[0] == 1) it only publishes the
+// status; otherwise it builds S + Q in A (Q lower triangle authoritative, may be null) and runs Bunch-Kaufman.
+__global__ __launch_bounds__(BK_THREADS) void k_bk_factor(int n, const double* __restrict__ S, const double* __restrict__ Q,
+                                                          double* A, int* ipiv, double* work, int* info, const int* mode,
+                                                          long long* status_out, long long seq) {
   __shared__ double sv[16];
   __shared__ int si[16];
-  if (mode[0] == 1) return;   // the unpivoted blocked factorisation was accepted
-  TeamCtx ctx{sv, si};
-  pp::BkInfo bi;
-  __shared__ pp::BkInfo sbi;
-  pp::bk_factor(ctx, n, A, n, ipiv, work, &sbi, BK_EPS);
-  if (threadIdx.x == 0) { info[0] = sbi.npos; info[1] = sbi.nneg; info[2] = sbi.nzero; }
-  (void)bi;
+  if (mode[0] != 1) {
+    for (size_t idx = threadIdx.x; idx < (size_t)n * n; idx += BK_THREADS) {
+      const int i = (int)(idx % n), j = (int)(idx / n);
+      double q = 0.0;
+      if (Q) q = (i >= j) ? Q[(size_t)i + (size_t)j * n] : Q[(size_t)j + (size_t)i * n];
+      A[idx] = S[idx] + q;
+    }
+    __syncthreads();
+    TeamCtx ctx{sv, si};
+    __shared__ pp::BkInfo sbi;
+    pp::bk_factor(ctx, n, A, n, ipiv, work, &sbi, BK_EPS);
+    if (threadIdx.x == 0) { info[0] = sbi.npos; info[1] = sbi.nneg; info[2] = sbi.nzero; }
+  }
+  if (threadIdx.x == 0) publish_status(S + (size_t)n * n, info, status_out, seq);
 }
 
 // xc = S^-1 (rc + rs): blocked LDL^T factor if it was accepted, else the Bunch-Kaufman factor
@@ -2007,6 +2039,7 @@ int pp_numeric_local(pp_handle h) {
   const int nc = h->nc;
   PP_HIP(hipMemsetAsync(h->S, 0, ((size_t)nc * nc + 4) * sizeof(double), st));
   PP_HIP(hipMemsetAsync(h->counters, 0, 4 * sizeof(int), st));
+  bool tail_written = false;
   for (Group* g : h->groups) {
     const pp::Plan& P = g->plan;
     GroupDev& d = g->dev;
@@ -2080,11 +2113,14 @@ int pp_numeric_local(pp_handle h) {
                          d.codes, total8, h->counters);
       if (g->ntiles > 0) {
         hipLaunchKernelGGL(k_schur_tiles, dim3((unsigned)g->ntiles * d.nchunk, 1, 2), dim3(64), 0, st, d);
-        hipLaunchKernelGGL(k_schur_reduce, dim3(g->ntiles), dim3(64), 0, st, d, g->ntiles, h->S);
+        const bool last = (g == h->groups.back());
+        hipLaunchKernelGGL(k_schur_reduce, dim3(g->ntiles), dim3(64), 0, st, d, g->ntiles, h->S,
+                           last ? (const int*)h->counters : (const int*)nullptr);
+        tail_written = last;
       }
     }
   }
-  hipLaunchKernelGGL(k_write_tail, dim3(1), dim3(64), 0, st, h->counters, h->S + (size_t)nc * nc);
+  if (!tail_written) hipLaunchKernelGGL(k_write_tail, dim3(1), dim3(64), 0, st, h->counters, h->S + (size_t)nc * nc);
   PP_HIP(hipGetLastError());
   h->numeric_done = true;
   h->schur_done = false;
@@ -2107,14 +2143,18 @@ int pp_factor_schur(pp_handle h, const double* Q_host) {
   const size_t nn = (size_t)nc * nc;
   if (nc > 0) {
     if (Q_host) PP_HIP(hipMemcpyAsync(h->Qd, Q_host, nn * sizeof(double), hipMemcpyHostToDevice, st));
-    PhaseScope ps(h, 3, 3);
-    hipLaunchKernelGGL(k_add_q, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, h->S, Q_host ? h->Qd : nullptr,
-                       h->Sfac, h->Sldl, nc);
+    const double* Qd = Q_host ? h->Qd : nullptr;
+    const bool regs = h->dense_policy == 0 && nc <= 16 * LDLR_NT;
+    PhaseScope ps(h, 3, regs ? 2 : 3);
+    // (the register-resident kernel reads S + Q itself; the global-memory variants work in place on a copy)
+    if (h->dense_policy == 0 && !regs)
+      hipLaunchKernelGGL(k_add_q, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, h->S, Qd, h->Sfac, h->Sldl, nc);
     if (h->dense_policy == 0)
       // (a left-looking variant with the panel resident in LDS was measured no faster: 0.344 vs 0.315 ms at
       // n_c = 200 -- the serial diagonal-block factor dominates both)
       if (nc <= 16 * LDLR_NT) {
-        hipLaunchKernelGGL(k_ldl_regs, dim3(1), dim3(LDL_THREADS), 0, st, nc, h->Sldl, h->dvec, h->dense_mode, h->bkinfo, BK_EPS);
+        hipLaunchKernelGGL(k_ldl_regs, dim3(1), dim3(LDL_THREADS), 0, st, nc, h->S, Qd, h->Sldl, h->dvec, h->dense_mode, h->bkinfo,
+                           BK_EPS);
       } else if (nc <= 512) {
         hipLaunchKernelGGL(k_ldl_blocked, dim3(1), dim3(LDL_THREADS), 0, st, nc, h->Sldl, h->dvec, h->dense_mode, h->bkinfo,
                            BK_EPS);
@@ -2138,12 +2178,13 @@ int pp_factor_schur(pp_handle h, const double* Q_host) {
       }
     else
       PP_HIP(hipMemsetAsync(h->dense_mode, 0, sizeof(int), st));
-    hipLaunchKernelGGL(k_bk_factor, dim3(1), dim3(BK_THREADS), 0, st, nc, h->Sfac, h->ipiv, h->work, h->bkinfo,
-                       h->dense_mode);
+    // Bunch-Kaufman on S + Q if the unpivoted factorisation was not accepted; publishes the status either way
+    hipLaunchKernelGGL(k_bk_factor, dim3(1), dim3(BK_THREADS), 0, st, nc, h->S, Qd, h->Sfac, h->ipiv, h->work, h->bkinfo,
+                       h->dense_mode, h->status_dev, ++h->status_seq);
   } else {
     PP_HIP(hipMemsetAsync(h->bkinfo, 0, 4 * sizeof(int), st));
+    hipLaunchKernelGGL(k_publish_status, dim3(1), dim3(64), 0, st, h->S + nn, h->bkinfo, h->status_dev, ++h->status_seq);
   }
-  hipLaunchKernelGGL(k_publish_status, dim3(1), dim3(64), 0, st, h->S + nn, h->bkinfo, h->status_dev, ++h->status_seq);
   PP_HIP(hipGetLastError());
   h->schur_done = true;
   return 0;
