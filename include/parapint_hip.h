@@ -174,6 +174,14 @@ int pp_group_perm(pp_handle h, int group, int32_t* perm);
  * (no host staging, no H2D); the shift of the coupling block goes into Q of pp_factor_schur as usual. */
 int pp_set_diagonal_classes(pp_handle h, int group, const int8_t* cls);
 int pp_numeric_local_shifted(pp_handle h, double delta_w, double delta_c);
+/* After a numeric factorisation that reported numerically zero pivots: the first instance (slot in the group's
+ * batch) whose block broke down, earliest pivot in elimination order first, or -1 if no block of this group did.
+ * The pivot sequence is static per pattern group and fixed from representative values at symbolic time; MA27, the
+ * reference's sub-solver, pivots dynamically (ma27_interface.py:124-136 only reports singular for a matrix that
+ * is), so the host class uses this to refresh the pivot order from the values that broke it and to factorise once
+ * more before it reports `singular` to the inertia-correction loop. */
+int pp_find_zero_pivot(pp_handle h, int group, int32_t* instance_out);
+
 /* Diagnostic: the factor of one instance (block) of a group after pp_numeric_local, in the plan's
  * panel storage: which = 0 unscaled panels U, 1 scaled rows L (the MA27 factor entries,
  * ma27_interface.py:124), 2 packed inverses of the block pivots.  count doubles are copied. */

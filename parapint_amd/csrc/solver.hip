@@ -2506,6 +2506,22 @@ int pp_numeric_local_shifted(pp_handle h, double delta_w, double delta_c) {
   return rc;
 }
 
+int pp_find_zero_pivot(pp_handle h, int group, int32_t* instance_out) {
+  Group* g = get_group(h, group);
+  if (!g || !instance_out || !h->numeric_done) return fail(h, 3, "pp_find_zero_pivot: bad group or no numeric factorization");
+  const GroupDev& d = g->dev;
+  *instance_out = -1;
+  PP_HIP(hipSetDevice(h->device));
+  PP_HIP(hipStreamSynchronize(h->stream));
+  // rare path (a factorisation that reported numerically zero pivots): the 16-bit codes come to the host as they are
+  std::vector<unsigned short> codes((size_t)g->plan.npiv * d.bpad);
+  PP_HIP(hipMemcpy(codes.data(), d.codes, codes.size() * sizeof(unsigned short), hipMemcpyDeviceToHost));
+  for (int p = 0; p < g->plan.npiv && *instance_out < 0; ++p)        // first pivot in elimination order that broke
+    for (int b = 0; b < d.batch; ++b)
+      if ((codes[(size_t)p * d.bpad + b] >> 8) & 15u) { *instance_out = b; break; }
+  return 0;
+}
+
 int pp_get_factor(pp_handle h, int group, int which, int instance, double* out, int64_t count) {
   Group* g = get_group(h, group);
   if (!g) return fail(h, 3, "pp_get_factor: bad group");

@@ -166,6 +166,14 @@ class HipEngine(object):
         """Diagnostic: factor storage of one block (0 = U panels, 1 = L rows, 2 = pivot inverses)."""
         return self.ns.get_factor(gid, which, instance, count)
 
+    def find_zero_pivot(self, gid):
+        """Slot of the first instance of group gid whose block hit a numerically zero pivot in the last numeric
+        factorisation, or -1."""
+        import ctypes
+        out = ctypes.c_int32(-1)
+        self.ns.check(self.lib.pp_find_zero_pivot(self.ns.h, gid, ctypes.byref(out)), 'pp_find_zero_pivot')
+        return int(out.value)
+
     def upload_values(self, gid, raw):
         self.ns.check(self.lib.pp_upload_values(self.ns.h, gid, raw.ctypes.data, 0), 'pp_upload_values')
 
@@ -307,6 +315,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         self._num_status = None
         self._pattern_only = False
         self._have_classes = False
+        self.pivot_order_refreshes = 0      # numeric factorisations that needed a new static pivot sequence
         self._last_Q = None
         self.plan_stats = []
 
@@ -515,6 +524,36 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         return res
 
     def do_numeric_factorization(self, matrix, raise_on_error=True, timer=None):
+        res = self._numeric_factorization(matrix, timer)
+        if res.status == LinearSolverStatus.singular and self._refresh_pivot_order():
+            # a block broke down under the static pivot sequence: it was fixed from the values the symbolic phase
+            # saw, and these values differ enough to need another one.  MA27 pivots dynamically and would not report
+            # this matrix singular unless it is (ma27_interface.py:124-136), so order again with the values that
+            # broke and factorise once more before the inertia-correction loop is told `singular`.
+            res = self._numeric_factorization(matrix, timer)
+        if res.status not in _OK and raise_on_error:
+            raise RuntimeError('Numeric factorization unsuccessful; status: ' + str(res.status))
+        return res
+
+    def _refresh_pivot_order(self):
+        """New pivot sequences for the groups that hold a broken block, from that block's values.  Collective: every
+        rank learns whether any rank re-planned (all of them then factorise again)."""
+        mine = 0
+        for g in self._groups:
+            slot = self._eng.find_zero_pivot(g.gid)
+            if slot >= 0:
+                raw = g.staging[slot]
+                g.rep_vals = np.add.reduceat(raw[g.can_idx], g.can_ptr[:-1]) if g.can_idx.size else np.zeros(0)
+                mine = 1
+        anyone = mine
+        if self.comm.size > 1:
+            anyone = int(self.comm.allreduce_max(np.array([mine], dtype=np.int64))[0])
+        if mine:
+            self.pivot_order_refreshes += 1
+            self._run_symbolic()
+        return bool(anyone)
+
+    def _numeric_factorization(self, matrix, timer=None):
         if timer is None:
             timer = _NullTimer()
         if self.block_dim == 0:
@@ -562,8 +601,6 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         self._inertia = (pos, neg, zero)
         res.status = self._agree_status(LinearSolverStatus(status))
         self._num_status = res.status
-        if res.status not in _OK and raise_on_error:
-            raise RuntimeError('Numeric factorization unsuccessful; status: ' + str(res.status))
         return res
 
     # ------------------------------------------------------------------ inertia-correction fast path

@@ -57,7 +57,9 @@ class HostSimEngine(object):
         for sg in self.groups:
             g = sg.g
             sg.U, sg.Dinv, sg.L = [], [], []
+            sg.zero_slot = -1
             for b in range(sg.batch):
+                zeros_before = int(inertia[2])
                 can = np.add.reduceat(sg.raw[b][g.can_idx], g.can_ptr[:-1]) if g.can_idx.size else np.zeros(0)
                 U = np.zeros(sg.usize)
                 Lf = np.zeros(sg.usize)
@@ -65,11 +67,16 @@ class HostSimEngine(object):
                 Sb = np.zeros((nc, nc))
                 L.ppsim_factor(sg.h, hu._dp(np.ascontiguousarray(can)), hu._dp(U), hu._dp(Lf), hu._dp(D), hu._dp(Sb),
                                inertia.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), ctypes.c_double(1e-13))
+                if int(inertia[2]) > zeros_before and sg.zero_slot < 0:
+                    sg.zero_slot = b
                 self.S += np.tril(Sb) + np.tril(Sb, -1).T
                 sg.U.append(U)
                 sg.L.append(Lf)
                 sg.Dinv.append(D)
         self.tail = np.array([inertia[2], inertia[0], inertia[1], 0.0], dtype=np.double)
+
+    def find_zero_pivot(self, gid):
+        return self.groups[gid].zero_slot
 
     def allreduce_schur(self, comm):
         if comm.size > 1:

@@ -348,6 +348,90 @@ def case_inertia_correction_pattern_growth(make_engine):
 
 
 # ---- error behaviour ------------------------------------------------------------------------------
+def case_pivot_order_refresh(make_engine):
+    """The pivot sequence is static per pattern group and fixed from the values the symbolic phase saw.  A later
+    matrix with the same pattern can make one of its 1x1 pivots exactly zero although the matrix is nonsingular
+    (here: Hessian diagonals that vanish while the constraint rows keep the KKT block regular).  MA27 pivots
+    dynamically and factorises such a matrix (ma27_interface.py:124-136 reports singular only for a singular one),
+    so the solver must not hand `singular` to the inertia-correction loop: it orders again from the values that
+    broke and factorises once more."""
+    rng = np.random.default_rng(11)
+    n_x, n_c, nc, nb = 8, 3, 2, 6
+    Js, Bs = [], []
+    for i in range(nb):
+        J = (sp.random(n_c, n_x, density=0.4, random_state=30 + i, data_rvs=lambda k: rng.normal(size=k)) +
+             2.0 * sp.eye(n_c, n_x)).tocoo()
+        B = coo_matrix((rng.normal(size=nc), (np.arange(nc), rng.choice(n_x, nc, replace=False))),
+                       shape=(nc, n_x + n_c))
+        Js.append(J); Bs.append(B)
+
+    def kkt(hs):
+        A = BlockMatrix(nb + 1, nb + 1)
+        for i in range(nb):
+            H = coo_matrix((hs[i], (np.arange(n_x), np.arange(n_x))), shape=(n_x, n_x))   # explicit zeros stay
+            A.set_block(i, i, sp.bmat([[H, Js[i].T], [Js[i], None]]).tocoo())
+            A.set_block(nb, i, Bs[i])
+        A.set_block(nb, nb, coo_matrix((nc, nc)))
+        return A
+
+    def dense(A):
+        m = n_x + n_c
+        full = np.zeros((nb * m + nc, nb * m + nc))
+        for i in range(nb):
+            Kd = A.get_block(i, i).toarray()
+            full[i * m:(i + 1) * m, i * m:(i + 1) * m] = np.tril(Kd) + np.tril(Kd, -1).T
+            Bd = A.get_block(nb, i).toarray()
+            full[nb * m:, i * m:(i + 1) * m] = Bd
+            full[i * m:(i + 1) * m, nb * m:] = Bd.T
+        return full
+
+    rhs = BlockVector(nb + 1)
+    for i in range(nb):
+        rhs.set_block(i, rng.normal(size=n_x + n_c))
+    rhs.set_block(nb, rng.normal(size=nc))
+
+    h0 = [rng.uniform(1.0, 3.0, size=n_x) for _ in range(nb)]       # what the symbolic phase sees: all strong
+    h1 = [h.copy() for h in h0]
+
+    def vanish(i, count):
+        # Hessian diagonals of block i that can vanish without making K_i singular (their columns carry constraints)
+        done = 0
+        for j in range(n_x):
+            trial = h1[i].copy()
+            trial[j] = 0.0
+            Kd = sp.bmat([[sp.diags(trial), Js[i].T], [Js[i], None]]).toarray()
+            sv = np.linalg.svd(Kd, compute_uv=False)
+            if Js[i].tocsc()[:, j].nnz > 0 and sv.min() > 1e-3 * sv.max():
+                h1[i] = trial
+                done += 1
+                if done == count:
+                    return
+        raise AssertionError('test setup: no suitable Hessian diagonal in block %d' % i)
+
+    vanish(2, 2)
+    vanish(4, 1)
+    solver = new_solver(make_engine, nb)
+    A0, A1 = kkt(h0), kkt(h1)
+    assert solver.do_symbolic_factorization(A0).status == LinearSolverStatus.successful
+    for A, refreshes in ((A0, 0), (A1, 1), (A1, 1), (A0, 1)):
+        full = dense(A)
+        ev = np.linalg.eigvalsh(full)
+        assert np.abs(ev).min() > 1e-8 * np.abs(ev).max()            # the matrix itself is regular
+        res = solver.do_numeric_factorization(A, raise_on_error=False)
+        assert res.status == LinearSolverStatus.successful
+        assert solver.pivot_order_refreshes == refreshes
+        assert solver.get_inertia() == (int((ev > 0).sum()), int((ev < 0).sum()), 0)
+        x = solver.do_back_solve(rhs)
+        x_ref = np.linalg.solve(full, rhs.flatten())
+        assert np.abs(x.flatten() - x_ref).max() <= 1e-8 * np.abs(x_ref).max()
+    # a singular block is still reported as singular (after one attempt with a fresh order)
+    h2 = [h.copy() for h in h0]
+    A2 = kkt(h2)
+    K = A2.get_block(1, 1).tocoo()
+    A2.set_block(1, 1, coo_matrix((np.zeros(K.nnz), (K.row, K.col)), shape=K.shape))
+    assert solver.do_numeric_factorization(A2, raise_on_error=False).status == LinearSolverStatus.singular
+
+
 def case_errors(make_engine):
     import pytest
     # non-square block structure -> ValueError (mpi_...:193-195)

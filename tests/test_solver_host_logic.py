@@ -43,3 +43,7 @@ def test_error_behaviour():
 
 def test_inertia_correction_pattern_growth():
     sc.case_inertia_correction_pattern_growth(make_engine)
+
+
+def test_pivot_order_refresh_after_static_breakdown():
+    sc.case_pivot_order_refresh(make_engine)
