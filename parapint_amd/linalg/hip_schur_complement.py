@@ -110,7 +110,7 @@ class _Group(object):
         self.rep_vals = None
         self.staging = None
         self.rhs_staging = None
-        self.x_staging = None
+        self.x_shape = None
         self.alt_layouts = []               # other raw COO layouts seen: (kr, kc, br, bc, canonical position per entry)
         self._keyK = None
         self._keyB = None
@@ -389,7 +389,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         for g in groups:
             g.staging = np.zeros((len(g.blocks), g.nraw), dtype=np.double)
             g.rhs_staging = np.zeros((len(g.blocks), g.n), dtype=np.double)
-            g.x_staging = np.zeros((len(g.blocks), g.n), dtype=np.double)
+            g.x_shape = (len(g.blocks), g.n)
         self._groups, self._binfo = groups, binfo
         self._pattern_only = any(g.rep_vals is None for g in groups)
         return all_zero
@@ -676,13 +676,19 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         rc = _flat(rhs.get_block(last)) if self._nc > 0 else None
         self._eng.solve_coupling(rc)
         self._eng.solve_backward()
+        xout = {}
         for g in self._groups:
-            self._eng.download_solution(g.gid, g.x_staging)
+            # one fresh array per group and call: its rows are handed out as the result blocks (no per-block copy;
+            # results of different calls never alias)
+            xout[g.gid] = np.empty(g.x_shape, dtype=np.double)
+            self._eng.download_solution(g.gid, xout[g.gid])
         coupling = self._eng.coupling_solution()
-        result = rhs.copy_structure()
+        # (mpi_...:390 uses copy_structure(); every local block and the coupling block are set below and non-local
+        # blocks stay unset either way, so a container that can skip the zero-filled placeholders is asked to)
+        result = rhs.copy_structure_unset() if hasattr(rhs, 'copy_structure_unset') else rhs.copy_structure()
         for ndx in self.local_block_indices:
             bi = self._binfo[ndx]
-            x = bi.group.x_staging[bi.slot].copy()
+            x = xout[bi.group.gid][bi.slot]
             blk = rhs.get_block(ndx)
             if hasattr(blk, 'get_block'):          # nested BlockVector (quirk Q9)
                 out = blk.copy_structure()

@@ -215,6 +215,11 @@ class BlockVector(object):
                 res._blocks[i] = np.zeros(b.size, dtype=np.double)
         return res
 
+    def copy_structure_unset(self):
+        """Same block layout with every block unset: for callers that set_block() each block they own anyway
+        (zero-filling 75 MB of blocks per back-solve costs 11 ms at 1024 x 9200).  Not a PyNumero method."""
+        return BlockVector(self._nblocks)
+
     def copyfrom(self, other):
         if isinstance(other, BlockVector):
             other = other.flatten()
@@ -325,6 +330,11 @@ class MPIBlockVector(BlockVector):
         if comm is not None and comm.size > 1:
             bs = comm.allreduce_max_int(bs)
         self._block_sizes = [None if s < 0 else int(s) for s in bs]
+
+    def copy_structure_unset(self):
+        res = MPIBlockVector(self._nblocks, self._rank_owner, self._mpiw)
+        res._block_sizes = list(self._block_sizes)
+        return res
 
     def copy_structure(self):
         res = MPIBlockVector(self._nblocks, self._rank_owner, self._mpiw)
