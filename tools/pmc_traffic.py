@@ -39,7 +39,7 @@ def main():
         e['fetch_KiB'] += f
         e['write_KiB'] += w
         e['launches'] += max(nf, nw)
-    steps = per['k_publish_status']['launches']          # one per numeric factorisation
+    steps = per.get('k_bk_factor', per.get('k_publish_status'))['launches']   # one per numeric factorisation
     tr = per['k_transpose_in']
     known_read_KiB = steps * batch * (raw_entries + n) * 8 / 1024.0
     calib = known_read_KiB / tr['fetch_KiB']
