@@ -266,6 +266,18 @@ def test_inertia_correction_fast_path_on_device():
         bare.set_regularization_classes(classes)
 
 
+@pytest.mark.parametrize('method', ['ssc', 'fs'])
+def test_performance_harness_known_answer(method, capsys):
+    """The harness counterpart of examples/performance/schur_complement/main.py on the reference's known-answer
+    configuration (examples/tests/test_examples.py:76-99: 0.3163456780448639)."""
+    from parapint_amd.examples.performance.schur_complement import main as harness
+    res = harness.run(harness.parse_args(['--method', method, '--n_blocks', '3', '--n_q_per_block', '500',
+                                          '--n_y_multiplier', '12']))
+    assert abs(res.max_err - 0.3163456780448639) <= 5e-8
+    out = capsys.readouterr().out
+    assert 'Est Err' in out and 'Num Fact (s)' in out and ('%.10f' % res.max_err) in out
+
+
 def test_rccl_collectives_on_solver_buffers():
     """The two data-path all-reduces through RCCL on the solver's own device buffers and stream (one-rank group:
     a one-GPU box cannot host two RCCL ranks; the two-rank host logic is covered by test_multirank_gloo.py)."""
