@@ -31,6 +31,7 @@ METRIC = 'IP iterations/sec on 1024-scenario stochastic KKT (5k vars/block, 200 
 PHASES = ['assemble', 'factor_levels', 'schur_tiles', 'dense_S', 'fwd_levels', 'fwd_coupling', 'coupling_solve',
           'bwd_levels']
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_MFMA_PEAK_TF = 78.6    # MI355X public spec for fp64 matrix (= fp64 vector) throughput, SURVEY 8d
 
 
 def parse_args():
@@ -279,6 +280,15 @@ def main():
                 'whole_iteration': {'bytes': sb['total'] * B, 'GBps': sb['total'] * B / (ms_per_step * 1e-3) / 1e9,
                                     'frac': sb['total'] * B / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}}
 
+    # dense phase (factorisation of S, replicated on every rank): fp64 MFMA work, SURVEY 8d F_S = n_c^3/3 + 4 n_c^2
+    dense_phase = None
+    if 'dense_S' in phases and n_t > 0:
+        f_s = n_t ** 3 / 3.0 + 4.0 * n_t ** 2
+        tf = f_s / (phases['dense_S']['ms_per_step'] * 1e-3) / 1e12
+        dense_phase = {'flops': f_s, 'ms': phases['dense_S']['ms_per_step'], 'achieved_TFLOPs': tf,
+                       'peak_fp64_mfma_TFLOPs': FP64_MFMA_PEAK_TF, 'frac': tf / FP64_MFMA_PEAK_TF,
+                       'note': 'one workgroup, latency-bound chain of n_c/16 panels; immaterial to the rate at n_c = 200'}
+
     if rank == 0:
         out = {
             'metric': METRIC, 'value': value, 'unit': 'it/s', 'n_gpus': world, 'steps': args.steps,
@@ -291,6 +301,7 @@ def main():
                        'blocks_per_gpu': B, 'parallelism': 'blocks round-robin over %d rank(s); RCCL all-reduce of '
                                                            'S (+status) and r_s' % world},
             'roofline': roofline,
+            'dense_phase': dense_phase,
             'cpu_baseline': cpu_baseline,
             'correct': bool(ok),
             'residual_device_path': worst, 'residual_boundary_path': resid_boundary,
