@@ -174,6 +174,19 @@ int pp_group_perm(pp_handle h, int group, int32_t* perm);
  * (no host staging, no H2D); the shift of the coupling block goes into Q of pp_factor_schur as usual. */
 int pp_set_diagonal_classes(pp_handle h, int group, const int8_t* cls);
 int pp_numeric_local_shifted(pp_handle h, double delta_w, double delta_c);
+/* Host-side helper of the LinearSolverInterface boundary (no device work, no handle): stages the raw COO values of
+ * `nblocks` blocks of one pattern group.  A block whose index arrays (kr, kc: K_i; br, bc: A_i; int32) equal the
+ * group's reference arrays -- the common case: same entry order as at symbolic time -- has its values copied to row
+ * slots[i] of `staging` (row_stride doubles per row: K values, then border values) and same_out[i] = 1; otherwise
+ * same_out[i] = 0 and the caller canonicalises that block itself (the reference tolerates any entry order and
+ * duplicates, quirk Q7: it calls .tocsr()/.tocoo() per block, mpi_...:294, 313-333).  Compare and copy are
+ * memory-bound (0.9 GB per call at C3) and run on `nthreads` host threads. */
+int pp_stage_values(int nblocks, int nthreads, const int32_t* const* kr, const int32_t* const* kc,
+                    const double* const* kd, const int64_t* knnz, const int32_t* const* br, const int32_t* const* bc,
+                    const double* const* bd, const int64_t* bnnz, const int32_t* ref_kr, const int32_t* ref_kc,
+                    int64_t ref_knnz, const int32_t* ref_br, const int32_t* ref_bc, int64_t ref_bnnz, double* staging,
+                    int64_t row_stride, const int32_t* slots, uint8_t* same_out);
+
 /* After a numeric factorisation that reported numerically zero pivots: the first instance (slot in the group's
  * batch) whose block broke down, earliest pivot in elimination order first, or -1 if no block of this group did.
  * The pivot sequence is static per pattern group and fixed from representative values at symbolic time; MA27, the

@@ -57,6 +57,9 @@ SIGNATURES = {
     'pp_group_perm': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _i32p]),
     'pp_set_diagonal_classes': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     'pp_numeric_local_shifted': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_double]),
+    'pp_stage_values': (ctypes.c_int, [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 8 + [ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                        ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     'pp_find_zero_pivot': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _i32p]),
     'pp_get_factor': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f64p, ctypes.c_int64]),
 }

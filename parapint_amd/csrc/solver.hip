@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/parapint_hip.h"
@@ -2504,6 +2505,43 @@ int pp_numeric_local_shifted(pp_handle h, double delta_w, double delta_c) {
   h->shift_w = 0.0;
   h->shift_c = 0.0;
   return rc;
+}
+
+// Host-side staging (no device work): for every block whose raw COO index arrays equal the group's reference
+// arrays, the values go to the block's row of the staging array; same_out[i] tells the caller which blocks it has to
+// canonicalise itself (quirk Q7).  Compare + copy are memory-bound, so they are spread over host threads.
+int pp_stage_values(int nblocks, int nthreads, const int32_t* const* kr, const int32_t* const* kc,
+                    const double* const* kd, const int64_t* knnz, const int32_t* const* br, const int32_t* const* bc,
+                    const double* const* bd, const int64_t* bnnz, const int32_t* ref_kr, const int32_t* ref_kc,
+                    int64_t ref_knnz, const int32_t* ref_br, const int32_t* ref_bc, int64_t ref_bnnz, double* staging,
+                    int64_t row_stride, const int32_t* slots, uint8_t* same_out) {
+  if (nblocks < 0 || !same_out || (nblocks > 0 && (!kr || !kc || !kd || !knnz || !br || !bc || !bd || !bnnz || !staging || !slots)))
+    return 3;
+  if (ref_knnz + ref_bnnz > row_stride) return 3;
+  auto work = [&](int i0, int i1) {
+    for (int i = i0; i < i1; ++i) {
+      bool same = knnz[i] == ref_knnz && bnnz[i] == ref_bnnz;
+      const size_t kb = (size_t)ref_knnz * sizeof(int32_t), bb = (size_t)ref_bnnz * sizeof(int32_t);
+      same = same && (kr[i] == ref_kr || kb == 0 || std::memcmp(kr[i], ref_kr, kb) == 0);
+      same = same && (kc[i] == ref_kc || kb == 0 || std::memcmp(kc[i], ref_kc, kb) == 0);
+      same = same && (br[i] == ref_br || bb == 0 || std::memcmp(br[i], ref_br, bb) == 0);
+      same = same && (bc[i] == ref_bc || bb == 0 || std::memcmp(bc[i], ref_bc, bb) == 0);
+      if (same) {
+        double* row = staging + (size_t)slots[i] * (size_t)row_stride;
+        if (ref_knnz > 0) std::memcpy(row, kd[i], (size_t)ref_knnz * sizeof(double));
+        if (ref_bnnz > 0) std::memcpy(row + ref_knnz, bd[i], (size_t)ref_bnnz * sizeof(double));
+      }
+      same_out[i] = same ? 1 : 0;
+    }
+  };
+  const int nt = std::max(1, std::min(std::min(nthreads, 64), nblocks));
+  if (nt == 1) { work(0, nblocks); return 0; }
+  std::vector<std::thread> pool;
+  pool.reserve((size_t)nt);
+  for (int t = 0; t < nt; ++t)
+    pool.emplace_back(work, (int)((int64_t)nblocks * t / nt), (int)((int64_t)nblocks * (t + 1) / nt));
+  for (auto& th : pool) th.join();
+  return 0;
 }
 
 int pp_find_zero_pivot(pp_handle h, int group, int32_t* instance_out) {

@@ -174,6 +174,35 @@ class HipEngine(object):
         self.ns.check(self.lib.pp_find_zero_pivot(self.ns.h, gid, ctypes.byref(out)), 'pp_find_zero_pivot')
         return int(out.value)
 
+    def stage_values(self, g, items):
+        """items: [(slot, (kr, kc, kd, br, bc, bd))] of one pattern group (int32 / float64, contiguous).  Blocks in
+        the group's reference entry order are copied to their staging rows by the library on host threads; returns
+        one flag per item (False: the caller stages that block itself)."""
+        import os
+        n = len(items)
+        ptr = np.empty((6, n), dtype=np.uint64)
+        nnz = np.empty((2, n), dtype=np.int64)
+        slots = np.empty(n, dtype=np.int32)
+        for i, (slot, arrays) in enumerate(items):
+            for q in range(6):
+                ptr[q, i] = arrays[q].__array_interface__['data'][0]
+            nnz[0, i] = arrays[2].size
+            nnz[1, i] = arrays[5].size
+            slots[i] = slot
+        ref = getattr(g, '_ref32', None)
+        if ref is None:
+            ref = g._ref32 = [np.ascontiguousarray(r, dtype=np.int32) for r in g.raw_refs]
+        same = np.zeros(n, dtype=np.uint8)
+        st = g.staging
+        rc = self.lib.pp_stage_values(n, min(16, os.cpu_count() or 1), ptr[0].ctypes.data, ptr[1].ctypes.data,
+                                      ptr[2].ctypes.data, nnz[0].ctypes.data, ptr[3].ctypes.data, ptr[4].ctypes.data,
+                                      ptr[5].ctypes.data, nnz[1].ctypes.data, ref[0].ctypes.data, ref[1].ctypes.data,
+                                      g.nrawK, ref[2].ctypes.data, ref[3].ctypes.data, g.nraw - g.nrawK,
+                                      st.ctypes.data, st.shape[1], slots.ctypes.data, same.ctypes.data)
+        if rc != 0:
+            raise RuntimeError('pp_stage_values failed with status %d' % rc)
+        return same.astype(bool)
+
     def upload_values(self, gid, raw):
         self.ns.check(self.lib.pp_upload_values(self.ns.h, gid, raw.ctypes.data, 0), 'pp_upload_values')
 
@@ -437,6 +466,8 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
 
     def _stage_values(self, matrix):
         last = self.block_dim - 1
+        fast = getattr(self._eng, 'stage_values', None)     # threaded compare + copy in the library (host only)
+        batches = {}
         for ndx in self.local_block_indices:
             bi = self._binfo[ndx]
             g = bi.group
@@ -446,18 +477,31 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
                 br, bc, bd = np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int32), np.zeros(0)
             else:
                 br, bc, bd, _ = _coo(A)
-            ref = g.raw_refs
-            same = (kd.size == g.nrawK and bd.size == g.nraw - g.nrawK and
-                    (kr is ref[0] or np.array_equal(kr, ref[0])) and (kc is ref[1] or np.array_equal(kc, ref[1])) and
-                    (br is ref[2] or np.array_equal(br, ref[2])) and (bc is ref[3] or np.array_equal(bc, ref[3])))
-            row = g.staging[bi.slot]
-            if same:
-                row[:g.nrawK] = kd
-                row[g.nrawK:] = bd
+            arrays = (kr, kc, kd, br, bc, bd)
+            if fast is not None and all(a.flags.c_contiguous for a in arrays) and \
+                    kr.dtype == kc.dtype == br.dtype == bc.dtype == np.int32 and kd.dtype == bd.dtype == np.float64:
+                batches.setdefault(g.gid, (g, []))[1].append((bi.slot, arrays))
             else:
-                vals = self._canonical_values(g, np.concatenate([kd, bd]), kr, kc, br, bc, False)
-                row[:] = 0.0
-                row[g.can_idx[g.can_ptr[:-1]]] = vals      # canonical sum on the first raw slot of each entry
+                self._stage_block(g, bi.slot, *arrays)
+        for g, items in batches.values():
+            same = fast(g, items)
+            for ok, (slot, arrays) in zip(same, items):
+                if not ok:
+                    self._stage_block(g, slot, *arrays)
+
+    def _stage_block(self, g, slot, kr, kc, kd, br, bc, bd):
+        ref = g.raw_refs
+        same = (kd.size == g.nrawK and bd.size == g.nraw - g.nrawK and
+                (kr is ref[0] or np.array_equal(kr, ref[0])) and (kc is ref[1] or np.array_equal(kc, ref[1])) and
+                (br is ref[2] or np.array_equal(br, ref[2])) and (bc is ref[3] or np.array_equal(bc, ref[3])))
+        row = g.staging[slot]
+        if same:
+            row[:g.nrawK] = kd
+            row[g.nrawK:] = bd
+        else:
+            vals = self._canonical_values(g, np.concatenate([kd, bd]), kr, kc, br, bc, False)
+            row[:] = 0.0
+            row[g.can_idx[g.can_ptr[:-1]]] = vals      # canonical sum on the first raw slot of each entry
 
     def _run_symbolic(self):
         self.plan_stats = self._eng.symbolic(self._nc, self._groups)

@@ -42,3 +42,49 @@ def test_product_package_does_not_import_the_oracle():
             "parapint_amd._native, parapint_amd.examples.performance.schur_complement.synthetic_kkt; "
             "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules), 'oracle imported'" % ROOT)
     subprocess.check_call([sys.executable, '-c', code])
+
+
+def test_host_staging_helper_matches_numpy():
+    """pp_stage_values (host only: runs without a GPU): blocks in the reference entry order are copied to their
+    staging rows, any other block is left to the caller."""
+    import ctypes
+    import numpy as np
+    from parapint_amd import _native
+    lib = _native.load_library()
+    rng = np.random.default_rng(3)
+    nk, nb, nblocks = 1000, 17, 9
+    ref = [rng.integers(0, 50, size=nk).astype(np.int32), rng.integers(0, 50, size=nk).astype(np.int32),
+           rng.integers(0, 5, size=nb).astype(np.int32), rng.integers(0, 50, size=nb).astype(np.int32)]
+    blocks = []
+    for i in range(nblocks):
+        arrs = [ref[0].copy(), ref[1].copy(), rng.normal(size=nk), ref[2].copy(), ref[3].copy(), rng.normal(size=nb)]
+        if i == 2:
+            arrs[0][7] += 1                      # different entry order
+        if i == 5:
+            arrs[4] = arrs[4][::-1].copy()
+        if i == 7:
+            arrs[2] = rng.normal(size=nk - 1)    # different length
+            arrs[0], arrs[1] = arrs[0][:-1].copy(), arrs[1][:-1].copy()
+        blocks.append(arrs)
+    ptr = np.array([[a.__array_interface__['data'][0] for a in blk] for blk in blocks], dtype=np.uint64).T.copy()
+    knnz = np.array([blk[2].size for blk in blocks], dtype=np.int64)
+    bnnz = np.array([blk[5].size for blk in blocks], dtype=np.int64)
+    slots = np.arange(nblocks, dtype=np.int32)[::-1].copy()
+    staging = np.full((nblocks, nk + nb + 3), -7.0)
+    same = np.zeros(nblocks, dtype=np.uint8)
+    for threads in (1, 4):
+        staging[:] = -7.0
+        rc = lib.pp_stage_values(nblocks, threads, ptr[0].ctypes.data, ptr[1].ctypes.data, ptr[2].ctypes.data,
+                                 knnz.ctypes.data, ptr[3].ctypes.data, ptr[4].ctypes.data, ptr[5].ctypes.data,
+                                 bnnz.ctypes.data, ref[0].ctypes.data, ref[1].ctypes.data, nk, ref[2].ctypes.data,
+                                 ref[3].ctypes.data, nb, staging.ctypes.data, staging.shape[1], slots.ctypes.data,
+                                 same.ctypes.data)
+        assert rc == 0
+        assert same.tolist() == [1, 1, 0, 1, 1, 0, 1, 0, 1]
+        for i, blk in enumerate(blocks):
+            row = staging[slots[i]]
+            if same[i]:
+                assert np.array_equal(row[:nk], blk[2]) and np.array_equal(row[nk:nk + nb], blk[5])
+                assert np.all(row[nk + nb:] == -7.0)
+            else:
+                assert np.all(row == -7.0)
