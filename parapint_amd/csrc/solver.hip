@@ -2538,8 +2538,13 @@ int pp_stage_values(int nblocks, int nthreads, const int32_t* const* kr, const i
   if (nt == 1) { work(0, nblocks); return 0; }
   std::vector<std::thread> pool;
   pool.reserve((size_t)nt);
-  for (int t = 0; t < nt; ++t)
-    pool.emplace_back(work, (int)((int64_t)nblocks * t / nt), (int)((int64_t)nblocks * (t + 1) / nt));
+  int started = 0;
+  try {                           // (no exception may cross the C ABI: what could not be started runs here)
+    for (; started < nt; ++started)
+      pool.emplace_back(work, (int)((int64_t)nblocks * started / nt), (int)((int64_t)nblocks * (started + 1) / nt));
+  } catch (...) {
+  }
+  if (started < nt) work((int)((int64_t)nblocks * started / nt), nblocks);
   for (auto& th : pool) th.join();
   return 0;
 }
