@@ -432,6 +432,100 @@ def case_pivot_order_refresh(make_engine):
     assert solver.do_numeric_factorization(A2, raise_on_error=False).status == LinearSolverStatus.singular
 
 
+class RecordingTimer(object):
+    """Stand-in for pyomo.common.timing.HierarchicalTimer: start/stop by label, must nest and balance."""
+
+    def __init__(self):
+        self.stack, self.seen = [], []
+
+    def start(self, name):
+        self.stack.append(name)
+        self.seen.append(name)
+
+    def stop(self, name):
+        assert self.stack and self.stack[-1] == name, (name, self.stack)
+        self.stack.pop()
+
+
+def case_ip_solve_call_pattern(make_engine):
+    """The call sites of the reference (interior_point.py:634-652 try_factorization_and_reallocation, :364-400 the
+    inertia-correction loop, :566 the back-solve) drive the solver through keywords -- ``matrix=kkt,
+    raise_on_error=False, timer=timer`` -- act on ``.status``, ``get_inertia()`` and
+    ``increase_memory_allocation()``, and regularise the matrix between retries.  Restated here as the test driver:
+    an indefinite Hessian with the wrong inertia must come out factorised with exactly n_con negative eigenvalues
+    after a few retries, and the step must solve the regularised system."""
+    rng = np.random.default_rng(21)
+    n_x, n_c, nc, nb = 9, 3, 2, 4
+    Hs, Js, Bs = [], [], []
+    for i in range(nb):
+        h = rng.uniform(0.5, 2.0, size=n_x)
+        h[:2] = -rng.uniform(0.5, 1.0, size=2)                   # negative curvature: wrong inertia without regularisation
+        J = (sp.random(n_c, n_x, density=0.4, random_state=50 + i, data_rvs=lambda k: rng.normal(size=k)) +
+             2.0 * sp.eye(n_c, n_x)).tocoo()
+        B = coo_matrix((rng.normal(size=nc), (np.arange(nc), 2 + rng.choice(n_x - 2, nc, replace=False))),
+                       shape=(nc, n_x + n_c))
+        Hs.append(h); Js.append(J); Bs.append(B)
+
+    def kkt(dw, dc):
+        A = BlockMatrix(nb + 1, nb + 1)
+        for i in range(nb):
+            H = sp.diags(Hs[i] + dw)
+            A.set_block(i, i, sp.bmat([[H, Js[i].T], [Js[i], -dc * sp.eye(n_c)]]).tocoo())
+            A.set_block(nb, i, Bs[i])
+        A.set_block(nb, nb, (dw * sp.eye(nc)).tocoo())
+        return A
+
+    rhs = BlockVector(nb + 1)
+    for i in range(nb):
+        rhs.set_block(i, rng.normal(size=n_x + n_c))
+    rhs.set_block(nb, rng.normal(size=nc))
+    solver = new_solver(make_engine, nb)
+    timer = RecordingTimer()
+
+    def try_factorization_and_reallocation(matrix, symbolic_or_numeric, max_iter=5):
+        method = solver.do_numeric_factorization if symbolic_or_numeric == 'numeric' else \
+            solver.do_symbolic_factorization
+        for count in range(max_iter):
+            res = method(matrix=matrix, raise_on_error=False, timer=timer)
+            if res.status == LinearSolverStatus.not_enough_memory:
+                solver.increase_memory_allocation(2)
+            else:
+                break
+        return res.status, count
+
+    A = kkt(0.0, 0.0)
+    status, _ = try_factorization_and_reallocation(A, 'symbolic')
+    assert status == LinearSolverStatus.successful
+    status, _ = try_factorization_and_reallocation(A, 'numeric')
+    assert status in (LinearSolverStatus.successful, LinearSolverStatus.singular)
+    n_con = nb * n_c                                            # n_eq_constraints + n_ineq_constraints
+    coef, final, retries = 1e-2, 0.0, 0
+    while final <= 1e6:
+        pos = neg = zero = None
+        if status == LinearSolverStatus.successful:
+            pos, neg, zero = solver.get_inertia()
+        if neg == n_con and zero == 0 and status == LinearSolverStatus.successful:
+            break
+        A = kkt(coef, coef)                                     # regularize_equality_gradient(-coef) + regularize_hessian(coef)
+        status, _ = try_factorization_and_reallocation(A, 'numeric')
+        final, coef, retries = coef, coef * 10.0, retries + 1
+    assert retries >= 1 and neg == n_con and zero == 0 and pos == nb * n_x + nc
+    x = solver.do_back_solve(rhs, timer=timer)
+    m = n_x + n_c
+    full = np.zeros((nb * m + nc, nb * m + nc))
+    for i in range(nb):
+        full[i * m:(i + 1) * m, i * m:(i + 1) * m] = A.get_block(i, i).toarray()
+        Bd = A.get_block(nb, i).toarray()
+        full[nb * m:, i * m:(i + 1) * m] = Bd
+        full[i * m:(i + 1) * m, nb * m:] = Bd.T
+    full[nb * m:, nb * m:] = A.get_block(nb, nb).toarray()
+    ev = np.linalg.eigvalsh(full)
+    assert int((ev < 0).sum()) == n_con
+    x_ref = np.linalg.solve(full, rhs.flatten())
+    assert np.abs(x.flatten() - x_ref).max() <= 1e-8 * np.abs(x_ref).max()
+    assert not timer.stack and {'form SC', 'factorize', 'communicate', 'factor SC', 'back_solve'} <= set(timer.seen)
+
+
 def case_errors(make_engine):
     import pytest
     # non-square block structure -> ValueError (mpi_...:193-195)

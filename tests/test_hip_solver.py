@@ -58,6 +58,10 @@ def test_pivot_order_refresh_after_static_breakdown():
     sc.case_pivot_order_refresh(make_engine)
 
 
+def test_ip_solve_call_pattern():
+    sc.case_ip_solve_call_pattern(make_engine)
+
+
 def test_config2_against_full_space_superlu():
     # BASELINE.json configs[1]: 64 scenarios x 2k primal vars/block, 100 coupling vars
     solver, model = sc.case_against_oracle(make_engine, (64, 400, 4, 100), iteration=1)

@@ -47,3 +47,7 @@ def test_inertia_correction_pattern_growth():
 
 def test_pivot_order_refresh_after_static_breakdown():
     sc.case_pivot_order_refresh(make_engine)
+
+
+def test_ip_solve_call_pattern():
+    sc.case_ip_solve_call_pattern(make_engine)
