@@ -1198,67 +1198,68 @@ __device__ void ldl_blocked_solve(int n, const double* __restrict__ A, const dou
   }
 }
 
-// Same solve for n <= blockDim.x with one thread per unknown and ONE barrier per 32-column block: thread r
-// keeps its right-hand-side entry in a register and its 32-entry segment of the current block of L
+// Same solve for n <= blockDim.x with one thread per unknown and ONE barrier per NBS-column block: thread r
+// keeps its right-hand-side entry in a register and its NBS-entry segment of the current block of L
 // (prefetched one block ahead, so no global-memory round trip sits between the dependent blocks).  The
 // wave that owns the block's rows solves it with v_readlane broadcasts, which at the same time applies the
 // block to the other rows of that wave; the remaining waves apply it from LDS after the barrier.
+template <int NBS>
 __device__ void ldl_rows_solve(int n, const double* __restrict__ A, const double* __restrict__ dvec, double* xs) {
   const int r = threadIdx.x, lane = r & 63, wv = __builtin_amdgcn_readfirstlane(r >> 6);
   const size_t lda = (size_t)n;
   const bool act = r < n;
   double acc = act ? xs[r] : 0.0;
   const double rd = act ? 1.0 / dvec[r] : 0.0;
-  double cur[LDL_NB], nxt[LDL_NB];
+  double cur[NBS], nxt[NBS];
   // ---- forward: L y = b, blocks ascending; segment = L[r][j0 .. j0+32) below the diagonal
 #define PP_LOAD_FWD(dst, j0_)                                                              \
-  _Pragma("unroll") for (int k = 0; k < LDL_NB; ++k) {                                     \
+  _Pragma("unroll") for (int k = 0; k < NBS; ++k) {                                     \
     const int c = (j0_) + k;                                                               \
     dst[k] = (act && c < n && c < r) ? A[r + (size_t)c * lda] : 0.0;                       \
   }
   PP_LOAD_FWD(cur, 0)
-  for (int j0 = 0; j0 < n; j0 += LDL_NB) {
-    if (j0 + LDL_NB < n) { PP_LOAD_FWD(nxt, j0 + LDL_NB) }
+  for (int j0 = 0; j0 < n; j0 += NBS) {
+    if (j0 + NBS < n) { PP_LOAD_FWD(nxt, j0 + NBS) }
     const int bw = j0 >> 6, base = j0 & 63;
     if (wv == bw) {
 #pragma unroll
-      for (int k = 0; k < LDL_NB; ++k) acc -= cur[k] * bcastd(acc, base + k);
-      if (r >= j0 && r < j0 + LDL_NB && act) xs[r] = acc;
+      for (int k = 0; k < NBS; ++k) acc -= cur[k] * bcastd(acc, base + k);
+      if (r >= j0 && r < j0 + NBS && act) xs[r] = acc;
     }
     __syncthreads();
-    if (wv != bw && r >= j0 + LDL_NB) {
+    if (wv != bw && r >= j0 + NBS) {
 #pragma unroll
-      for (int k = 0; k < LDL_NB; ++k) acc -= cur[k] * xs[min(j0 + k, n - 1)];
+      for (int k = 0; k < NBS; ++k) acc -= cur[k] * xs[min(j0 + k, n - 1)];
     }
 #pragma unroll
-    for (int k = 0; k < LDL_NB; ++k) cur[k] = nxt[k];
+    for (int k = 0; k < NBS; ++k) cur[k] = nxt[k];
   }
 #undef PP_LOAD_FWD
   acc *= rd;
   // ---- backward: L^T x = y, blocks descending; segment = L[j0 .. j0+32)[r] below the diagonal
 #define PP_LOAD_BWD(dst, j0_)                                                              \
-  _Pragma("unroll") for (int k = 0; k < LDL_NB; ++k) {                                     \
+  _Pragma("unroll") for (int k = 0; k < NBS; ++k) {                                     \
     const int c = (j0_) + k;                                                               \
     dst[k] = (act && c < n && c > r) ? A[c + (size_t)r * lda] : 0.0;                       \
   }
-  const int jlast = ((n - 1) / LDL_NB) * LDL_NB;
+  const int jlast = ((n - 1) / NBS) * NBS;
   __syncthreads();
   PP_LOAD_BWD(cur, jlast)
-  for (int j0 = jlast; j0 >= 0; j0 -= LDL_NB) {
-    if (j0 > 0) { PP_LOAD_BWD(nxt, j0 - LDL_NB) }
+  for (int j0 = jlast; j0 >= 0; j0 -= NBS) {
+    if (j0 > 0) { PP_LOAD_BWD(nxt, j0 - NBS) }
     const int bw = j0 >> 6, base = j0 & 63;
     if (wv == bw) {
 #pragma unroll
-      for (int k = LDL_NB - 1; k >= 0; --k) acc -= cur[k] * bcastd(acc, base + k);
-      if (r >= j0 && r < j0 + LDL_NB && act) xs[r] = acc;
+      for (int k = NBS - 1; k >= 0; --k) acc -= cur[k] * bcastd(acc, base + k);
+      if (r >= j0 && r < j0 + NBS && act) xs[r] = acc;
     }
     __syncthreads();
     if (wv != bw && r < j0) {
 #pragma unroll
-      for (int k = 0; k < LDL_NB; ++k) acc -= cur[k] * xs[min(j0 + k, n - 1)];
+      for (int k = 0; k < NBS; ++k) acc -= cur[k] * xs[min(j0 + k, n - 1)];
     }
 #pragma unroll
-    for (int k = 0; k < LDL_NB; ++k) cur[k] = nxt[k];
+    for (int k = 0; k < NBS; ++k) cur[k] = nxt[k];
   }
 #undef PP_LOAD_BWD
   __syncthreads();
@@ -1333,16 +1334,21 @@ __global__ __launch_bounds__(BK_THREADS) void k_bk_factor(int n, const double* _
 }
 
 // xc = S^-1 (rc + rs): blocked LDL^T factor if it was accepted, else the Bunch-Kaufman factor
-__global__ __launch_bounds__(BK_THREADS) void k_coupling_solve(int n, const double* Abk, const int* ipiv,
-                                                               const double* Aldl, const double* dvec, const int* mode,
-                                                               const double* rc, const double* rs, double* xc) {
+// THREADS x NBS: 512 threads with 32-column segments (n_c <= 512), or 1024 threads with 16-column segments
+// (512 < n_c <= 1024: two 16-entry segments are what 128 VGPRs per thread leave room for; the global-memory
+// fallback ldl_blocked_solve puts three dependent load round trips into each of its 2 n_c / 32 block steps:
+// 0.89 ms at n_c = 1000)
+template <int THREADS, int NBS>
+__global__ __launch_bounds__(THREADS) void k_coupling_solve(int n, const double* Abk, const int* ipiv,
+                                                            const double* Aldl, const double* dvec, const int* mode,
+                                                            const double* rc, const double* rs, double* xc) {
   extern __shared__ __attribute__((aligned(16))) double xs[];
   __shared__ double sv[16];
   __shared__ int si[16];
   if (mode[0] == 1) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) xs[i] = (rc ? rc[i] : 0.0) + rs[i];
     __syncthreads();
-    if (n <= (int)blockDim.x) ldl_rows_solve(n, Aldl, dvec, xs);
+    if (n <= THREADS) ldl_rows_solve<NBS>(n, Aldl, dvec, xs);
     else ldl_blocked_solve(n, Aldl, dvec, xs);
     for (int i = threadIdx.x; i < n; i += blockDim.x) xc[i] = xs[i];
     return;
@@ -2300,8 +2306,12 @@ int pp_solve_coupling(pp_handle h, const double* rc_host) {
   if (nc == 0) return 0;
   if (rc_host) PP_HIP(hipMemcpyAsync(h->rcd, rc_host, (size_t)nc * sizeof(double), hipMemcpyHostToDevice, st));
   PhaseScope ps(h, 6, 1);
-  hipLaunchKernelGGL(k_coupling_solve, dim3(1), dim3(BK_THREADS), (size_t)nc * sizeof(double), st, nc, h->Sfac, h->ipiv,
-                     h->Sldl, h->dvec, h->dense_mode, rc_host ? h->rcd : nullptr, h->rs, h->xc);
+  if (nc > BK_THREADS && nc <= 1024)
+    hipLaunchKernelGGL((k_coupling_solve<1024, 16>), dim3(1), dim3(1024), (size_t)nc * sizeof(double), st, nc, h->Sfac,
+                       h->ipiv, h->Sldl, h->dvec, h->dense_mode, rc_host ? h->rcd : nullptr, h->rs, h->xc);
+  else
+    hipLaunchKernelGGL((k_coupling_solve<BK_THREADS, 32>), dim3(1), dim3(BK_THREADS), (size_t)nc * sizeof(double), st, nc,
+                       h->Sfac, h->ipiv, h->Sldl, h->dvec, h->dense_mode, rc_host ? h->rcd : nullptr, h->rs, h->xc);
   PP_HIP(hipGetLastError());
   return 0;
 }
