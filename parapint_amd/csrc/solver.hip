@@ -1210,58 +1210,101 @@ __device__ void ldl_rows_solve(int n, const double* __restrict__ A, const double
   const bool act = r < n;
   double acc = act ? xs[r] : 0.0;
   const double rd = act ? 1.0 / dvec[r] : 0.0;
-  double cur[NBS], nxt[NBS];
-  // ---- forward: L y = b, blocks ascending; segment = L[r][j0 .. j0+32) below the diagonal
+  // three segment buffers, rotated by unrolling the block loop three times: the segment of block j + 2 is requested
+  // before block j is solved, so a load has two block steps (not the rest of one) to arrive
+  double c0[NBS], c1[NBS], c2[NBS];
+  (void)lane;
+  // ---- forward: L y = b, blocks ascending; segment = L[r][j0 .. j0+NBS) below the diagonal
+  // A wave whose 64 rows all lie below the block needs no per-element predicate (and one whose rows all lie above it
+  // loads nothing): the predicated form costs ~12 instructions per element, which for 8 waves x 32 elements was most
+  // of a block step.  Only the wave that holds the block's own rows takes the predicated path.
+  const int row_lo = 64 * wv, row_hi = 64 * wv + 63;
 #define PP_LOAD_FWD(dst, j0_)                                                              \
-  _Pragma("unroll") for (int k = 0; k < NBS; ++k) {                                     \
-    const int c = (j0_) + k;                                                               \
-    dst[k] = (act && c < n && c < r) ? A[r + (size_t)c * lda] : 0.0;                       \
+  {                                                                                        \
+    const int jl = (j0_);                                                                  \
+    if (row_lo >= jl + NBS && row_hi < n && jl + NBS <= n) {                               \
+      const double* src = A + r + (size_t)jl * lda;                                        \
+      _Pragma("unroll") for (int k = 0; k < NBS; ++k) dst[k] = src[(size_t)k * lda];       \
+    } else if (row_hi < jl || jl >= n) {                                                   \
+      _Pragma("unroll") for (int k = 0; k < NBS; ++k) dst[k] = 0.0;                        \
+    } else {                                                                               \
+      _Pragma("unroll") for (int k = 0; k < NBS; ++k) {                                    \
+        const int c = jl + k;                                                              \
+        dst[k] = (act && c < n && c < r) ? A[r + (size_t)c * lda] : 0.0;                   \
+      }                                                                                    \
+    }                                                                                      \
   }
-  PP_LOAD_FWD(cur, 0)
-  for (int j0 = 0; j0 < n; j0 += NBS) {
-    if (j0 + NBS < n) { PP_LOAD_FWD(nxt, j0 + NBS) }
-    const int bw = j0 >> 6, base = j0 & 63;
-    if (wv == bw) {
-#pragma unroll
-      for (int k = 0; k < NBS; ++k) acc -= cur[k] * bcastd(acc, base + k);
-      if (r >= j0 && r < j0 + NBS && act) xs[r] = acc;
-    }
-    __syncthreads();
-    if (wv != bw && r >= j0 + NBS) {
-#pragma unroll
-      for (int k = 0; k < NBS; ++k) acc -= cur[k] * xs[min(j0 + k, n - 1)];
-    }
-#pragma unroll
-    for (int k = 0; k < NBS; ++k) cur[k] = nxt[k];
+#define PP_STEP_FWD(cur, j0_)                                                              \
+  {                                                                                        \
+    const int jj = (j0_), bw = jj >> 6, base = jj & 63;                                    \
+    if (wv == bw) {                                                                        \
+      _Pragma("unroll") for (int k = 0; k < NBS; ++k) acc -= cur[k] * bcastd(acc, base + k); \
+      if (r >= jj && r < jj + NBS && act) xs[r] = acc;                                     \
+    }                                                                                      \
+    lds_barrier();   /* not __syncthreads(): that would also drain the prefetched global loads */ \
+    if (wv != bw && r >= jj + NBS) {                                                       \
+      _Pragma("unroll") for (int k = 0; k < NBS; ++k) acc -= cur[k] * xs[min(jj + k, n - 1)]; \
+    }                                                                                      \
+  }
+  PP_LOAD_FWD(c0, 0)
+  PP_LOAD_FWD(c1, NBS)
+  for (int j0 = 0; j0 < n; j0 += 3 * NBS) {
+    PP_LOAD_FWD(c2, j0 + 2 * NBS)
+    PP_STEP_FWD(c0, j0)
+    if (j0 + NBS >= n) break;
+    PP_LOAD_FWD(c0, j0 + 3 * NBS)
+    PP_STEP_FWD(c1, j0 + NBS)
+    if (j0 + 2 * NBS >= n) break;
+    PP_LOAD_FWD(c1, j0 + 4 * NBS)
+    PP_STEP_FWD(c2, j0 + 2 * NBS)
   }
 #undef PP_LOAD_FWD
+#undef PP_STEP_FWD
   acc *= rd;
-  // ---- backward: L^T x = y, blocks descending; segment = L[j0 .. j0+32)[r] below the diagonal
+  // ---- backward: L^T x = y, blocks descending; segment = L[j0 .. j0+NBS)[r] below the diagonal
 #define PP_LOAD_BWD(dst, j0_)                                                              \
-  _Pragma("unroll") for (int k = 0; k < NBS; ++k) {                                     \
-    const int c = (j0_) + k;                                                               \
-    dst[k] = (act && c < n && c > r) ? A[c + (size_t)r * lda] : 0.0;                       \
+  {                                                                                        \
+    const int jl = (j0_);                                                                  \
+    if (jl >= 0 && row_hi < jl && jl + NBS <= n) {                                         \
+      const double* src = A + jl + (size_t)r * lda;                                        \
+      _Pragma("unroll") for (int k = 0; k < NBS; ++k) dst[k] = src[k];                     \
+    } else if (jl < 0 || row_lo >= jl + NBS) {                                             \
+      _Pragma("unroll") for (int k = 0; k < NBS; ++k) dst[k] = 0.0;                        \
+    } else {                                                                               \
+      _Pragma("unroll") for (int k = 0; k < NBS; ++k) {                                    \
+        const int c = jl + k;                                                              \
+        dst[k] = (act && c >= 0 && c < n && c > r) ? A[c + (size_t)r * lda] : 0.0;         \
+      }                                                                                    \
+    }                                                                                      \
+  }
+#define PP_STEP_BWD(cur, j0_)                                                              \
+  {                                                                                        \
+    const int jj = (j0_), bw = jj >> 6, base = jj & 63;                                    \
+    if (wv == bw) {                                                                        \
+      _Pragma("unroll") for (int k = NBS - 1; k >= 0; --k) acc -= cur[k] * bcastd(acc, base + k); \
+      if (r >= jj && r < jj + NBS && act) xs[r] = acc;                                     \
+    }                                                                                      \
+    lds_barrier();   /* not __syncthreads(): that would also drain the prefetched global loads */ \
+    if (wv != bw && r < jj) {                                                              \
+      _Pragma("unroll") for (int k = 0; k < NBS; ++k) acc -= cur[k] * xs[min(jj + k, n - 1)]; \
+    }                                                                                      \
   }
   const int jlast = ((n - 1) / NBS) * NBS;
   __syncthreads();
-  PP_LOAD_BWD(cur, jlast)
-  for (int j0 = jlast; j0 >= 0; j0 -= NBS) {
-    if (j0 > 0) { PP_LOAD_BWD(nxt, j0 - NBS) }
-    const int bw = j0 >> 6, base = j0 & 63;
-    if (wv == bw) {
-#pragma unroll
-      for (int k = NBS - 1; k >= 0; --k) acc -= cur[k] * bcastd(acc, base + k);
-      if (r >= j0 && r < j0 + NBS && act) xs[r] = acc;
-    }
-    __syncthreads();
-    if (wv != bw && r < j0) {
-#pragma unroll
-      for (int k = 0; k < NBS; ++k) acc -= cur[k] * xs[min(j0 + k, n - 1)];
-    }
-#pragma unroll
-    for (int k = 0; k < NBS; ++k) cur[k] = nxt[k];
+  PP_LOAD_BWD(c0, jlast)
+  PP_LOAD_BWD(c1, jlast - NBS)
+  for (int j0 = jlast; j0 >= 0; j0 -= 3 * NBS) {
+    PP_LOAD_BWD(c2, j0 - 2 * NBS)
+    PP_STEP_BWD(c0, j0)
+    if (j0 - NBS < 0) break;
+    PP_LOAD_BWD(c0, j0 - 3 * NBS)
+    PP_STEP_BWD(c1, j0 - NBS)
+    if (j0 - 2 * NBS < 0) break;
+    PP_LOAD_BWD(c1, j0 - 4 * NBS)
+    PP_STEP_BWD(c2, j0 - 2 * NBS)
   }
 #undef PP_LOAD_BWD
+#undef PP_STEP_BWD
   __syncthreads();
 }
 
