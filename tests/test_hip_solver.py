@@ -62,6 +62,15 @@ def test_ip_solve_call_pattern():
     sc.case_ip_solve_call_pattern(make_engine)
 
 
+@pytest.mark.parametrize('shape', [(1, 10, 2, 1), (1, 5, 2, 5), (65, 10, 2, 2), (129, 12, 2, 3), (5, 300, 2, 208),
+                                   (3, 300, 2, 209), (2, 600, 2, 513)])
+def test_edge_shapes_against_full_space_superlu(shape):
+    """One block, one coupling variable, n_theta = n_q, a ragged chunk holding a single instance, and the coupling
+    dimensions at which the dense S path changes (208 | 209: register-resident / blocked, 512 | 513: one workgroup /
+    multi-workgroup factorisation and the wide coupling solve)."""
+    sc.case_against_oracle(make_engine, shape, iteration=1)
+
+
 def test_config2_against_full_space_superlu():
     # BASELINE.json configs[1]: 64 scenarios x 2k primal vars/block, 100 coupling vars
     solver, model = sc.case_against_oracle(make_engine, (64, 400, 4, 100), iteration=1)

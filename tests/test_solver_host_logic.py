@@ -28,6 +28,11 @@ def test_known_answer(golden):
     sc.case_known_answer(make_engine, golden)
 
 
+@pytest.mark.parametrize('shape', [(1, 10, 2, 1), (1, 5, 2, 5), (65, 6, 2, 2)])
+def test_edge_shapes(shape):
+    sc.case_against_oracle(make_engine, shape, iteration=1)
+
+
 def test_against_oracle_small():
     sc.case_against_oracle(make_engine, (6, 60, 3, 12), iteration=2)
     sc.case_oracle_schur(make_engine, (5, 40, 2, 8))
