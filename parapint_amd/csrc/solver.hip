@@ -710,7 +710,7 @@ __global__ __launch_bounds__(LDL_THREADS) void k_ldl_blocked(int n, double* __re
           if (!(fabs(d) > eps * anorm)) { bad = 1; d = (anorm > 0.0 ? anorm : 1.0); }
           signs |= (d > 0.0) ? 1 : 2;
         }
-        const double lik = colk / d;
+        const double lik = colk * fast_rcp(d);
 #pragma unroll
         for (int j = k + 1; j < LDL_NB; ++j) {
           const double ajk = bcastd(colk, j);
@@ -751,7 +751,7 @@ __global__ __launch_bounds__(LDL_THREADS) void k_ldl_blocked(int n, double* __re
           __builtin_amdgcn_sched_barrier(0);   // keep the LDS reads of later columns from being hoisted (register pressure)
         }
 #pragma unroll
-        for (int k = 0; k < LDL_NB; ++k) A[(j1 + r) + (size_t)(j0 + k) * lda] = wrow[k] / dl[k];
+        for (int k = 0; k < LDL_NB; ++k) A[(j1 + r) + (size_t)(j0 + k) * lda] = wrow[k] * fast_rcp(dl[k]);
       }
     } else {
       for (int r = tid; r < m; r += LDL_THREADS) {   // ragged last panel: W kept in place, scaled afterwards
@@ -862,7 +862,7 @@ __global__ __launch_bounds__(DN_THREADS) void k_dense_panel(int n, double* __res
         if (!(fabs(d) > eps * anorm)) { bad = 1; d = (anorm > 0.0 ? anorm : 1.0); }
         signs |= (d > 0.0) ? 1 : 2;
       }
-      const double lik = colk / d;
+      const double lik = colk * fast_rcp(d);    // (no IEEE division sequence in the 32-step pivot chain)
 #pragma unroll
       for (int j = k + 1; j < LDL_NB; ++j) {
         const double ajk = bcastd(colk, j);
@@ -907,7 +907,7 @@ __global__ __launch_bounds__(DN_THREADS) void k_dense_panel(int n, double* __res
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int k = 0; k < LDL_NB; ++k) A[(j1 + r) + (size_t)(j0 + k) * lda] = wrow[k] / dl[k];
+    for (int k = 0; k < LDL_NB; ++k) A[(j1 + r) + (size_t)(j0 + k) * lda] = wrow[k] * fast_rcp(dl[k]);
   }
 }
 
