@@ -81,6 +81,11 @@ int pp_bind_raw_buffer(pp_handle h, int group, double* dev_ptr);
  * (mpi_...:292-299) and S_local = -sum_i A_i K_i^{-1} A_i^T (mpi_...:312-333).  Result is left
  * in the Schur buffer; block inertia and the singular-pivot count ride in its 4-double tail. */
 int pp_numeric_local(pp_handle h);
+/* The same in two calls, so that a caller can bracket the reference's timer labels separately
+ * (mpi_...:291-333: 'form SC/factorize' = the block factorisations; 'form SC/back solve' + 'dot product' = the
+ * Schur contributions): pp_numeric_local == pp_numeric_factor_blocks followed by pp_numeric_schur. */
+int pp_numeric_factor_blocks(pp_handle h);
+int pp_numeric_schur(pp_handle h);
 
 /* Device buffer of n_c*n_c + 4 doubles: dense column-major S_local followed by
  * {n_zero_pivots, n_pos, n_neg, reserved} as doubles, so ONE sum all-reduce carries the Schur
@@ -138,9 +143,18 @@ double* pp_solution_buffer(pp_handle h, int group);
 int pp_get_coupling_solution(pp_handle h, double* xc_host);
 
 /* ---- misc -------------------------------------------------------------------------------- */
-/* increase_memory_allocation (mpi_...:438-452): device storage is sized exactly by the symbolic
- * phase, so this is a recorded hint only. */
+/* Memory reallocation protocol (interior_point.py:634-652 try_factorization_and_reallocation; the sub-solver side is
+ * ma27_interface.py:126-131 status -3/-4 -> not_enough_memory and :153-154 iw_factor, a_factor *= factor; reference
+ * test linalg/tests/test_realloc.py:10-61).  The device value storage (factor panels, work vectors) is sized exactly
+ * by the symbolic phase.  pp_set_memory_budget caps it (bytes; 0 = no cap, the default): when the plan needs more
+ * than budget x (product of the factors given to pp_increase_memory_allocation since), pp_end_symbolic still succeeds
+ * and pp_upload_values / pp_numeric_local return 1 (not_enough_memory) without allocating anything, until the caller
+ * has raised the budget.  A real hipErrorOutOfMemory maps to the same status and leaves nothing allocated, so a retry
+ * after memory has been freed elsewhere works the same way.
+ * pp_memory_info: out = {bytes the plan needs, effective budget (0 = none), 1 if the storage is allocated}. */
 int pp_increase_memory_allocation(pp_handle h, double factor);
+int pp_set_memory_budget(pp_handle h, int64_t bytes);
+int pp_memory_info(pp_handle h, int64_t out[3]);
 /* Blocks until the handle's stream is idle. */
 int pp_synchronize(pp_handle h);
 

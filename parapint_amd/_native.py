@@ -29,6 +29,8 @@ SIGNATURES = {
     'pp_raw_buffer': (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int]),
     'pp_bind_raw_buffer': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     'pp_numeric_local': (ctypes.c_int, [ctypes.c_void_p]),
+    'pp_numeric_factor_blocks': (ctypes.c_int, [ctypes.c_void_p]),
+    'pp_numeric_schur': (ctypes.c_int, [ctypes.c_void_p]),
     'pp_schur_buffer': (ctypes.c_void_p, [ctypes.c_void_p]),
     'pp_bind_schur_buffer': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     'pp_factor_schur': (ctypes.c_int, [ctypes.c_void_p, _f64p]),
@@ -50,6 +52,8 @@ SIGNATURES = {
     'pp_solution_buffer': (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int]),
     'pp_get_coupling_solution': (ctypes.c_int, [ctypes.c_void_p, _f64p]),
     'pp_increase_memory_allocation': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double]),
+    'pp_set_memory_budget': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64]),
+    'pp_memory_info': (ctypes.c_int, [ctypes.c_void_p, _i64p]),
     'pp_synchronize': (ctypes.c_int, [ctypes.c_void_p]),
     'pp_profile': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'pp_phase_times': (ctypes.c_int, [ctypes.c_void_p, _f64p, _i32p, _i32p]),

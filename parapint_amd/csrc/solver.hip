@@ -1576,7 +1576,8 @@ struct Group {
   std::vector<int> fwd_level_team, bwd_level_team;   // waves per row / column on each solve level (1, 4 or 16)
   int nraw_tiles = 0;            // number of input tiles with needed entries
   int nshift = 0;                // rows with a regularisation class (pp_set_diagonal_classes)
-  const int *shift_row = nullptr, *shift_cls = nullptr;   // device: transposed-input row of their diagonal entry, class
+  int *shift_row = nullptr, *shift_cls = nullptr;   // device: transposed-input row of their diagonal entry, class
+  std::vector<void*> value_allocs;   // value storage (raw, rawT, U, L, ...): allocated by alloc_value_storage
 };
 
 }  // namespace
@@ -1585,7 +1586,7 @@ struct pp_solver {
   int device = 0;
   hipStream_t stream = nullptr;
   int nc = 0;
-  bool symbolic_done = false, numeric_done = false, schur_done = false;
+  bool symbolic_done = false, blocks_factored = false, numeric_done = false, schur_done = false;
   std::vector<Group*> groups;
   double *S = nullptr, *S_own = nullptr, *Sfac = nullptr, *Sldl = nullptr, *dvec = nullptr, *Qd = nullptr, *work = nullptr;
   int* dense_mode = nullptr;
@@ -1599,6 +1600,9 @@ struct pp_solver {
   long long status_seq = 0;
   double shift_w = 0.0, shift_c = 0.0;   // diagonal shifts of the current pp_numeric_local_shifted call (else 0)
   double mem_factor = 1.0;
+  int64_t mem_budget = 0;        // bytes of device value storage the handle may allocate (0: no limit); scaled by mem_factor
+  int64_t mem_required = 0;      // bytes of value storage the current plan needs
+  bool values_allocated = false;
   std::string err;
   // Instance groups ("splits"): the level sweeps of disjoint 64-instance chunk ranges are
   // independent and can be issued on separate streams.  Measured (C3, 1 GPU, 4 splits): the 4x
@@ -1730,6 +1734,9 @@ int transpose_tiles(int, int) {
 }
 
 void free_group(Group* g) {
+  if (g->shift_row) (void)hipFree(g->shift_row);
+  if (g->shift_cls) (void)hipFree(g->shift_cls);
+  for (void* p : g->value_allocs) (void)hipFree(p);
   for (void* p : g->allocs) (void)hipFree(p);
   delete g;
 }
@@ -1744,6 +1751,89 @@ void free_globals(pp_handle h) {
   if (h->status_host) (void)hipHostFree((void*)h->status_host);
   h->status_host = nullptr;
   h->status_dev = nullptr;
+}
+
+
+// bytes of value storage (everything that scales with batch x factor size) the groups of the handle need
+int64_t value_storage_bytes(pp_handle h) {
+  int64_t total = 0;
+  for (Group* g : h->groups) {
+    const pp::Plan& P = g->plan;
+    const GroupDev& d = g->dev;
+    const int64_t bp = d.bpad;
+    int64_t dbl = (int64_t)g->batch * g->nraw + (int64_t)std::max(g->nraw_used, 1) * bp + 2 * P.usize * bp +
+                  (int64_t)P.dsize * bp + (int64_t)std::max(P.bsize, 1) * bp + (int64_t)(P.n + h->nc) * bp +
+                  (int64_t)P.n * bp + 2 * (int64_t)g->batch * P.n + (int64_t)d.nchunk * std::max(g->ntiles, 1) * 64 +
+                  (int64_t)d.nchunk * std::max(h->nc, 1);
+    total += 8 * dbl + 2 * (int64_t)P.npiv * bp;
+  }
+  return total;
+}
+
+void free_value_storage(Group* g) {
+  for (void* p : g->value_allocs) (void)hipFree(p);
+  g->value_allocs.clear();
+  GroupDev& d = g->dev;
+  d.raw = d.rawT = d.U = d.L = d.Dinv = d.Tm = d.Y = d.X = d.rhs = d.xout = d.Spart = d.rspart = nullptr;
+  d.codes = nullptr;
+  g->raw_own = g->rhs_own = nullptr;
+}
+
+template <class T>
+int value_alloc(pp_handle h, Group* g, T** out, size_t count) {
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(h, e == hipErrorOutOfMemory ? 1 : 3, std::string("hipMalloc: ") + hipGetErrorString(e));
+  }
+  g->value_allocs.push_back(p);
+  *out = (T*)p;
+  return 0;
+}
+
+// Allocates the value storage of every group if it fits the budget; status 1 (not_enough_memory) otherwise, with
+// nothing left allocated (increase_memory_allocation then raises the budget and the next numeric call tries again).
+int alloc_value_storage(pp_handle h) {
+  if (h->values_allocated) return 0;
+  if (h->mem_budget > 0 && (double)h->mem_required > (double)h->mem_budget * h->mem_factor)
+    return fail(h, 1, "device value storage of " + std::to_string(h->mem_required) + " bytes exceeds the budget of " +
+                          std::to_string((int64_t)((double)h->mem_budget * h->mem_factor)) +
+                          " bytes (increase_memory_allocation raises it)");
+  int rc = 0;
+  for (Group* g : h->groups) {
+    const pp::Plan& P = g->plan;
+    GroupDev& d = g->dev;
+    const size_t bp = (size_t)d.bpad;
+    const int nc = h->nc;
+    double* keep_raw = (d.raw && d.raw != g->raw_own) ? d.raw : nullptr;   // caller-bound buffers survive
+    double* keep_rhs = (d.rhs && d.rhs != g->rhs_own) ? d.rhs : nullptr;
+    if ((rc = value_alloc(h, g, &g->raw_own, (size_t)g->batch * g->nraw))) break;
+    if ((rc = value_alloc(h, g, &d.rawT, (size_t)std::max(g->nraw_used, 1) * bp))) break;
+    if ((rc = value_alloc(h, g, &d.U, (size_t)P.usize * bp))) break;
+    if ((rc = value_alloc(h, g, &d.Dinv, (size_t)P.dsize * bp))) break;
+    if ((rc = value_alloc(h, g, &d.L, (size_t)P.usize * bp))) break;
+    // the pivot-block slots of L are never written (only the rows below the block are): define them once
+    if (hipMemset(d.L, 0, (size_t)P.usize * bp * sizeof(double)) != hipSuccess) { rc = fail(h, 3, "hipMemset failed"); break; }
+    if ((rc = value_alloc(h, g, &d.Tm, (size_t)std::max(P.bsize, 1) * bp))) break;
+    if ((rc = value_alloc(h, g, &d.Y, (size_t)(P.n + nc) * bp))) break;
+    if ((rc = value_alloc(h, g, &d.X, (size_t)P.n * bp))) break;
+    if ((rc = value_alloc(h, g, &g->rhs_own, (size_t)g->batch * P.n))) break;
+    if ((rc = value_alloc(h, g, &d.xout, (size_t)g->batch * P.n))) break;
+    if ((rc = value_alloc(h, g, &d.Spart, (size_t)d.nchunk * std::max(g->ntiles, 1) * 64))) break;
+    if ((rc = value_alloc(h, g, &d.rspart, (size_t)d.nchunk * std::max(nc, 1)))) break;
+    if ((rc = value_alloc(h, g, &d.codes, (size_t)P.npiv * bp))) break;   // 16-bit codes
+    d.raw = keep_raw ? keep_raw : g->raw_own;
+    d.rhs = keep_rhs ? keep_rhs : g->rhs_own;
+  }
+  if (rc) {
+    const std::string msg = h->err;
+    for (Group* g : h->groups) free_value_storage(g);
+    h->err = msg;
+    return rc;
+  }
+  h->values_allocated = true;
+  return 0;
 }
 
 }  // namespace
@@ -1802,7 +1892,7 @@ int pp_begin_symbolic(pp_handle h, int n_coupling) {
   h->groups.clear();
   free_globals(h);
   h->nc = n_coupling;
-  h->symbolic_done = h->numeric_done = h->schur_done = false;
+  h->symbolic_done = h->blocks_factored = h->numeric_done = h->schur_done = false;
   return 0;
 }
 
@@ -2008,24 +2098,6 @@ int pp_end_symbolic(pp_handle h) {
     if ((rc = dev_upload(h, g, &d.stile_ptr, sptr))) return rc;
     if ((rc = dev_upload(h, g, &d.stile_rec, srec))) return rc;
     g->ntiles = (int)P.stile_a.size();
-    const size_t bp = (size_t)d.bpad;
-    if ((rc = dev_alloc(h, g, &d.raw, (size_t)g->batch * g->nraw))) return rc;
-    g->raw_own = d.raw;
-    if ((rc = dev_alloc(h, g, &d.rawT, (size_t)std::max(g->nraw_used, 1) * bp))) return rc;
-    if ((rc = dev_alloc(h, g, &d.U, (size_t)P.usize * bp))) return rc;
-    if ((rc = dev_alloc(h, g, &d.Dinv, (size_t)P.dsize * bp))) return rc;
-    if ((rc = dev_alloc(h, g, &d.L, (size_t)P.usize * bp))) return rc;
-    // the pivot-block slots of L are never written (only the rows below the block are): define them once
-    PP_HIP(hipMemset(d.L, 0, (size_t)P.usize * bp * sizeof(double)));
-    if ((rc = dev_alloc(h, g, &d.Tm, (size_t)std::max(P.bsize, 1) * bp))) return rc;
-    if ((rc = dev_alloc(h, g, &d.Y, (size_t)(P.n + nc) * bp))) return rc;
-    if ((rc = dev_alloc(h, g, &d.X, (size_t)P.n * bp))) return rc;
-    if ((rc = dev_alloc(h, g, &d.rhs, (size_t)g->batch * P.n))) return rc;
-    g->rhs_own = d.rhs;
-    if ((rc = dev_alloc(h, g, &d.xout, (size_t)g->batch * P.n))) return rc;
-    if ((rc = dev_alloc(h, g, &d.Spart, (size_t)d.nchunk * std::max(g->ntiles, 1) * 64))) return rc;
-    if ((rc = dev_alloc(h, g, &d.rspart, (size_t)d.nchunk * std::max(nc, 1)))) return rc;
-    if ((rc = dev_alloc(h, g, &d.codes, (size_t)P.npiv * bp))) return rc;   // 16-bit codes
   }
   int rc;
   const size_t nn = (size_t)nc * nc;
@@ -2059,6 +2131,13 @@ int pp_end_symbolic(pp_handle h) {
   PP_HIP(hipMemset(h->rs, 0, std::max<size_t>(nc, 1) * sizeof(double)));
   PP_HIP(hipMemset(h->bkinfo, 0, 4 * sizeof(int)));
   h->symbolic_done = true;
+  // value storage (factor panels, work vectors): sized by the plan; if it does not fit the handle's budget the
+  // symbolic phase still succeeds (the plan is valid) and the numeric phase reports not_enough_memory until
+  // increase_memory_allocation has raised the budget (reference: ma27_interface.py:126-131, 153-154)
+  h->values_allocated = false;
+  h->mem_required = value_storage_bytes(h);
+  (void)alloc_value_storage(h);
+  h->err.clear();
   return 0;
 }
 
@@ -2071,6 +2150,7 @@ int pp_upload_values(pp_handle h, int group, const double* raw, int on_device) {
   Group* g = get_group(h, group);
   if (!g || !h->symbolic_done) return fail(h, 3, "pp_upload_values: bad group or symbolic phase not finished");
   PP_HIP(hipSetDevice(h->device));
+  if (int rc = alloc_value_storage(h)) return rc;
   const size_t bytes = (size_t)g->batch * g->nraw * sizeof(double);
   if (bytes == 0 || raw == g->dev.raw) return 0;
   PP_HIP(hipMemcpyAsync(g->dev.raw, raw, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
@@ -2079,17 +2159,15 @@ int pp_upload_values(pp_handle h, int group, const double* raw, int on_device) {
 
 double* pp_raw_buffer(pp_handle h, int group) {
   Group* g = get_group(h, group);
-  return (g && h->symbolic_done) ? g->dev.raw : nullptr;
+  if (!g || !h->symbolic_done || alloc_value_storage(h)) return nullptr;
+  return g->dev.raw;
 }
 
-int pp_numeric_local(pp_handle h) {
-  if (!h || !h->symbolic_done) return fail(h, 3, "pp_numeric_local before symbolic factorization");
+int pp_numeric_factor_blocks(pp_handle h) {
+  if (!h || !h->symbolic_done) return fail(h, 3, "pp_numeric_factor_blocks before symbolic factorization");
   PP_HIP(hipSetDevice(h->device));
+  if (int rc = alloc_value_storage(h)) return rc;
   hipStream_t st = h->stream;
-  const int nc = h->nc;
-  PP_HIP(hipMemsetAsync(h->S, 0, ((size_t)nc * nc + 4) * sizeof(double), st));
-  PP_HIP(hipMemsetAsync(h->counters, 0, 4 * sizeof(int), st));
-  bool tail_written = false;
   for (Group* g : h->groups) {
     const pp::Plan& P = g->plan;
     GroupDev& d = g->dev;
@@ -2156,6 +2234,25 @@ int pp_numeric_local(pp_handle h) {
       }
       if (join_streams(h, sp, fan)) return fail(h, 3, "stream join failed");
     }
+  }
+  PP_HIP(hipGetLastError());
+  h->blocks_factored = true;
+  h->numeric_done = false;
+  h->schur_done = false;
+  return 0;
+}
+
+int pp_numeric_schur(pp_handle h) {
+  if (!h || !h->symbolic_done || !h->blocks_factored) return fail(h, 3, "pp_numeric_schur before pp_numeric_factor_blocks");
+  PP_HIP(hipSetDevice(h->device));
+  hipStream_t st = h->stream;
+  const int nc = h->nc;
+  PP_HIP(hipMemsetAsync(h->S, 0, ((size_t)nc * nc + 4) * sizeof(double), st));
+  PP_HIP(hipMemsetAsync(h->counters, 0, 4 * sizeof(int), st));
+  bool tail_written = false;
+  for (Group* g : h->groups) {
+    const pp::Plan& P = g->plan;
+    GroupDev& d = g->dev;
     {
       PhaseScope ps(h, 2, 3);
       const size_t total8 = (size_t)P.npiv * d.bpad / 8;   // bpad is a multiple of 64
@@ -2175,6 +2272,11 @@ int pp_numeric_local(pp_handle h) {
   h->numeric_done = true;
   h->schur_done = false;
   return 0;
+}
+
+int pp_numeric_local(pp_handle h) {
+  if (int rc = pp_numeric_factor_blocks(h)) return rc;
+  return pp_numeric_schur(h);
 }
 
 double* pp_schur_buffer(pp_handle h) { return (h && h->symbolic_done) ? h->S : nullptr; }
@@ -2274,6 +2376,7 @@ int pp_upload_rhs(pp_handle h, int group, const double* rhs, int on_device) {
   Group* g = get_group(h, group);
   if (!g || !h->symbolic_done) return fail(h, 3, "pp_upload_rhs: bad group or symbolic phase not finished");
   PP_HIP(hipSetDevice(h->device));
+  if (int rc = alloc_value_storage(h)) return rc;
   const size_t bytes = (size_t)g->batch * g->plan.n * sizeof(double);
   if (rhs == g->dev.rhs) return 0;
   PP_HIP(hipMemcpyAsync(g->dev.rhs, rhs, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
@@ -2282,7 +2385,8 @@ int pp_upload_rhs(pp_handle h, int group, const double* rhs, int on_device) {
 
 double* pp_rhs_buffer(pp_handle h, int group) {
   Group* g = get_group(h, group);
-  return (g && h->symbolic_done) ? g->dev.rhs : nullptr;
+  if (!g || !h->symbolic_done || alloc_value_storage(h)) return nullptr;
+  return g->dev.rhs;
 }
 
 int pp_solve_forward(pp_handle h) {
@@ -2406,7 +2510,8 @@ int pp_download_solution(pp_handle h, int group, double* x, int on_device) {
 
 double* pp_solution_buffer(pp_handle h, int group) {
   Group* g = get_group(h, group);
-  return (g && h->symbolic_done) ? g->dev.xout : nullptr;
+  if (!g || !h->symbolic_done || alloc_value_storage(h)) return nullptr;
+  return g->dev.xout;
 }
 
 int pp_get_coupling_solution(pp_handle h, double* xc_host) {
@@ -2489,7 +2594,24 @@ int pp_phase_times(pp_handle h, double ms_out[8], int32_t launches_out[8], int32
 
 int pp_increase_memory_allocation(pp_handle h, double factor) {
   if (!h) return 3;
+  if (!(factor > 0.0)) return fail(h, 3, "memory allocation factor must be positive");
   h->mem_factor *= factor;
+  return 0;
+}
+
+int pp_set_memory_budget(pp_handle h, int64_t bytes) {
+  if (!h) return 3;
+  if (bytes < 0) return fail(h, 3, "memory budget must be >= 0 (0: no limit)");
+  h->mem_budget = bytes;
+  h->mem_factor = 1.0;
+  return 0;
+}
+
+int pp_memory_info(pp_handle h, int64_t out[3]) {
+  if (!h) return 3;
+  out[0] = h->mem_required;
+  out[1] = h->mem_budget > 0 ? (int64_t)((double)h->mem_budget * h->mem_factor) : 0;
+  out[2] = h->values_allocated ? 1 : 0;
   return 0;
 }
 
@@ -2542,11 +2664,17 @@ int pp_set_diagonal_classes(pp_handle h, int group, const int8_t* cls) {
     for (int v : g->can_idx) if (rawmap[(size_t)v] < 0) rawmap[(size_t)v] = nused++;
     for (auto& r : rows) r = rawmap[(size_t)(-1 - r)];
   }
-  g->nshift = (int)rows.size();
-  int rc;
+  PP_HIP(hipStreamSynchronize(h->stream));      // a previous shifted factorisation may still read the old arrays
+  if (g->shift_row) { (void)hipFree(g->shift_row); g->shift_row = nullptr; }
+  if (g->shift_cls) { (void)hipFree(g->shift_cls); g->shift_cls = nullptr; }
+  g->nshift = 0;
   rows.push_back(0); kinds.push_back(0);
-  if ((rc = dev_upload(h, g, &g->shift_row, rows))) return rc;
-  if ((rc = dev_upload(h, g, &g->shift_cls, kinds))) return rc;
+  int rc;
+  if ((rc = dev_alloc(h, (Group*)nullptr, &g->shift_row, rows.size()))) return rc;
+  if ((rc = dev_alloc(h, (Group*)nullptr, &g->shift_cls, kinds.size()))) return rc;
+  PP_HIP(hipMemcpy(g->shift_row, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice));
+  PP_HIP(hipMemcpy(g->shift_cls, kinds.data(), kinds.size() * sizeof(int), hipMemcpyHostToDevice));
+  g->nshift = (int)rows.size() - 1;
   return 0;
 }
 

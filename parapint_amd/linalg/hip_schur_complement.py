@@ -39,6 +39,46 @@ class _NullTimer(object):
         pass
 
 
+_ROCTX = None
+
+
+def _roctx():
+    """roctx range functions (rocprofv3 --marker-trace shows the reference's timer labels as ranges), or False."""
+    global _ROCTX
+    if _ROCTX is None:
+        _ROCTX = False
+        import os
+        if os.environ.get('PP_ROCTX', '0') not in ('', '0'):
+            import ctypes
+            for name in ('librocprofiler-sdk-roctx.so', 'libroctx64.so'):
+                try:
+                    lib = ctypes.CDLL(name)
+                    lib.roctxRangePushA.argtypes = [ctypes.c_char_p]
+                    _ROCTX = (lib.roctxRangePushA, lib.roctxRangePop)
+                    break
+                except (OSError, AttributeError):
+                    continue
+    return _ROCTX
+
+
+class _Labels(object):
+    """The reference's HierarchicalTimer labels (mpi_...:207-255, 291-360), mirrored as roctx ranges when PP_ROCTX=1."""
+
+    def __init__(self, timer):
+        self._t = _NullTimer() if timer is None else timer
+        self._r = _roctx()
+
+    def start(self, name):
+        self._t.start(name)
+        if self._r:
+            self._r[0](name.encode())
+
+    def stop(self, name):
+        if self._r:
+            self._r[1]()
+        self._t.stop(name)
+
+
 def _flat(v):
     return v.flatten() if hasattr(v, 'get_block') else np.asarray(v, dtype=np.double).ravel()
 
@@ -220,6 +260,23 @@ class HipEngine(object):
     def numeric_local(self):
         self.ns.check(self.lib.pp_numeric_local(self.ns.h), 'pp_numeric_local')
 
+    def numeric_factor_blocks(self):
+        self.ns.check(self.lib.pp_numeric_factor_blocks(self.ns.h), 'pp_numeric_factor_blocks')
+
+    def numeric_schur(self):
+        self.ns.check(self.lib.pp_numeric_schur(self.ns.h), 'pp_numeric_schur')
+
+    def set_memory_budget(self, nbytes):
+        self.ns.check(self.lib.pp_set_memory_budget(self.ns.h, int(nbytes)), 'pp_set_memory_budget')
+
+    def memory_info(self):
+        """(bytes of device value storage the plan needs, effective budget or 0, allocated?)"""
+        import ctypes
+        out = np.zeros(3, dtype=np.int64)
+        self.ns.check(self.lib.pp_memory_info(self.ns.h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))),
+                      'pp_memory_info')
+        return int(out[0]), int(out[1]), bool(out[2])
+
     def allreduce_schur(self, comm):
         if comm.size > 1 or getattr(comm, 'always_reduce', False):
             if comm.device_collectives:
@@ -303,7 +360,14 @@ class HipEngine(object):
         self.ns.check(self.lib.pp_synchronize(self.ns.h), 'pp_synchronize')
 
     def increase_memory_allocation(self, factor):
-        self.lib.pp_increase_memory_allocation(self.ns.h, float(factor))
+        self.ns.check(self.lib.pp_increase_memory_allocation(self.ns.h, float(factor)), 'pp_increase_memory_allocation')
+
+
+# Severity of a status when ranks disagree: the reference lets the first failing status win (mpi_...:19-30,
+# explicit_...:9-13); with one reduction the worst one wins, `warning` being the mildest non-success.
+_SEVERITY = {LinearSolverStatus.successful: 0, LinearSolverStatus.warning: 1, LinearSolverStatus.not_enough_memory: 2,
+             LinearSolverStatus.singular: 3, LinearSolverStatus.error: 4}
+_BY_SEVERITY = {v: k for k, v in _SEVERITY.items()}
 
 
 class HipSchurComplementLinearSolver(LinearSolverInterface):
@@ -329,11 +393,18 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
     def getLoggerName(cls):
         return 'hip_schur_complement'
 
-    def __init__(self, subproblem_solvers=None, schur_complement_solver=None, comm=None, engine=None):
+    def __init__(self, subproblem_solvers=None, schur_complement_solver=None, comm=None, engine=None,
+                 memory_budget_bytes=None):
         self.subproblem_solvers = subproblem_solvers
         self.schur_complement_solver = schur_complement_solver
         self.comm = default_comm() if comm is None else comm
         self._eng = HipEngine() if engine is None else engine
+        # cap on the device value storage (factor panels, work vectors); None = no cap.  A plan that needs more makes
+        # the numeric phase return not_enough_memory until increase_memory_allocation() has raised the cap -- the
+        # reallocation protocol of interior_point.py:634-652 / ma27_interface.py:126-131, 153-154
+        if memory_budget_bytes is not None:
+            self._eng.set_memory_budget(memory_budget_bytes)
+        self._classes = None                # regularisation classes by block index (kept across re-plans)
         self.block_dim = 0
         self.block_matrix = None
         self.local_block_indices = []
@@ -346,6 +417,8 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         self._have_classes = False
         self.pivot_order_refreshes = 0      # numeric factorisations that needed a new static pivot sequence
         self._last_Q = None
+        self._base_Q = None
+        self._last_error = ''
         self.plan_stats = []
 
     # ------------------------------------------------------------------ helpers
@@ -359,11 +432,27 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
                 if own[ndx, ndx] == rank or (own[ndx, ndx] == -1 and rank == 0)]   # mpi_...:199-203
 
     def _agree_status(self, status):
-        """Rank-consistent status (mpi_...:19-30): the worst status of any rank wins."""
+        """Rank-consistent status (mpi_...:19-30): the most severe status of any rank wins."""
         if self.comm.size == 1:
             return status
-        v = int(self.comm.allreduce_max(np.array([status.value], dtype=np.int64))[0])
-        return LinearSolverStatus(v)
+        v = int(self.comm.allreduce_max(np.array([_SEVERITY[status]], dtype=np.int64))[0])
+        return _BY_SEVERITY[v]
+
+    def _guarded(self, res, fn, *args):
+        """Runs an engine step unless an earlier one failed; an exception that carries a C status becomes that status
+        (so `raise_on_error=False` callers -- the reallocation retry and the inertia loop -- get a status, and a rank
+        that failed still reaches the collectives)."""
+        if res.status not in _OK:
+            return None
+        try:
+            return fn(*args)
+        except Exception as err:
+            status = getattr(err, 'status', None)
+            if status is None:
+                raise
+            res.status = LinearSolverStatus(status)
+            self._last_error = str(err)
+            return None
 
     def _build_groups(self, matrix):
         last = self.block_dim - 1
@@ -505,7 +594,19 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
 
     def _run_symbolic(self):
         self.plan_stats = self._eng.symbolic(self._nc, self._groups)
-        self._have_classes = False            # classes are per plan: set_regularization_classes again
+        self._have_classes = False
+        if self._classes is not None:         # classes are per plan: apply them to the new one
+            try:
+                self._apply_classes()
+            except Exception:
+                # a classed row without a diagonal entry in the new plan: the fast path stays off until
+                # set_regularization_classes is called again; the ordinary path is unaffected
+                self._have_classes = False
+
+    def _apply_classes(self):
+        for g in self._groups:
+            self._eng.set_diagonal_classes(g.gid, self._classes[g.blocks[0]])
+        self._have_classes = True
 
     def _replan_union(self, matrix):
         """New plan on (planned pattern) U (pattern of `matrix`), values of `matrix`; later matrices with either
@@ -537,8 +638,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
 
     # ------------------------------------------------------------------ interface
     def do_symbolic_factorization(self, matrix, raise_on_error=True, timer=None):
-        if timer is None:
-            timer = _NullTimer()
+        timer = _Labels(timer)
         nbrows, nbcols = matrix.bshape
         if nbrows != nbcols:
             raise ValueError('The block matrix provided is not square.')
@@ -546,24 +646,24 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         self.local_block_indices = self._local_blocks(matrix)
         self._inertia = None
         self._num_status = None
+        self._classes = None
         res = LinearSolverResults(LinearSolverStatus.successful)
         timer.start('factorize')
-        try:
-            self._build_groups(matrix)
-            self._run_symbolic()
-        except Exception as err:                      # NativeError carries the C status
-            status = getattr(err, 'status', None)
-            if status is None:
-                timer.stop('factorize')
-                raise
-            res.status = LinearSolverStatus(status)
+        self._guarded(res, self._build_groups, matrix)
+        self._guarded(res, self._run_symbolic)
         timer.stop('factorize')
         res.status = self._agree_status(res.status)
         if res.status not in _OK:
             if raise_on_error:
                 raise RuntimeError('Symbolic factorization unsuccessful; status: ' + str(res.status))
             return res
-        timer.start('sc_structure')       # dense S buffer: nothing to gather (mpi_...:228-255)
+        # the structure of S (mpi_...:228-255): the union of the blocks' border cliques is dense for a stochastic
+        # program, so S is a dense n_c x n_c device buffer; the four sub-steps of the reference have no work left
+        timer.start('sc_structure')
+        for label in ('build_border_matrices', 'gather_all_nonzero_elements', 'construct_schur_complement',
+                      'get_sc_data_slices'):
+            timer.start(label)
+            timer.stop(label)
         timer.stop('sc_structure')
         return res
 
@@ -584,6 +684,8 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         rank learns whether any rank re-planned (all of them then factorise again)."""
         mine = 0
         for g in self._groups:
+            if g.staging is None:
+                continue                        # device-resident values: no host copy to order from
             slot = self._eng.find_zero_pivot(g.gid)
             if slot >= 0:
                 raw = g.staging[slot]
@@ -598,15 +700,28 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         return bool(anyone)
 
     def _numeric_factorization(self, matrix, timer=None):
-        if timer is None:
-            timer = _NullTimer()
+        timer = _Labels(timer)
         if self.block_dim == 0:
             raise RuntimeError('Perform symbolic factorization first!')
         self.block_matrix = matrix
-        last = self.block_dim - 1
         res = LinearSolverResults(LinearSolverStatus.successful)
         timer.start('form SC')
         timer.start('factorize')
+        self._guarded(res, self._stage_and_upload, matrix)
+        self._guarded(res, self._eng.numeric_factor_blocks)
+        timer.stop('factorize')
+        # the n_c solves + products per block of the reference (mpi_...:312-333) are the coupling rows of the same
+        # partial factorisation; what is left is their outer products
+        timer.start('back solve')
+        self._guarded(res, self._eng.numeric_schur)
+        timer.stop('back solve')
+        timer.start('dot product')
+        timer.stop('dot product')
+        Q = self._guarded(res, self._coupling_block, matrix)
+        self._base_Q = Q
+        return self._finish_numeric(res, Q, timer)
+
+    def _stage_and_upload(self, matrix):
         try:
             self._stage_values(matrix)
         except _PatternChanged:
@@ -624,13 +739,9 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             self._pattern_only = False
         for g in self._groups:
             self._eng.upload_values(g.gid, g.staging)
-        self._eng.numeric_local()
-        timer.stop('factorize')
-        timer.start('communicate')
-        self._eng.allreduce_schur(self.comm)
-        timer.stop('communicate')
-        timer.stop('form SC')
-        timer.start('factor SC')
+
+    def _coupling_block(self, matrix):
+        last = self.block_dim - 1
         Qb = matrix.get_block(last, last)
         Q = None
         if Qb is not None:
@@ -638,12 +749,48 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             if Qc.nnz > 0 and np.any(Qc.data != 0.0):
                 Q = Qc.toarray()
                 Q = np.tril(Q) + np.tril(Q, -1).T          # lower triangle authoritative
-        self._eng.factor_schur(Q)
+        return Q
+
+    def _finish_numeric(self, res, Q, timer):
+        """Second half of a numeric factorisation, shared with the diagonal-shift fast path: status agreement BEFORE the
+        collective (a rank whose block phase failed must not leave the others waiting in the all-reduce; the reference
+        gathers the sub-solver statuses first, mpi_...:294-305), all-reduce of S, dense factor, status + inertia."""
+        if self.comm.size > 1:
+            res.status = self._agree_status(res.status)
+        if res.status not in _OK:
+            for label in ('communicate',):
+                timer.start(label)
+                timer.stop(label)
+            timer.stop('form SC')
+            self._inertia = None
+            self._num_status = res.status
+            return res
+        timer.start('communicate')
+        for label in ('zeros', 'Barrier'):      # S is zeroed on the device; the collective is stream-ordered
+            timer.start(label)
+            timer.stop(label)
+        timer.start('Allreduce')
+        self._guarded(res, self._eng.allreduce_schur, self.comm)
+        timer.stop('Allreduce')
+        timer.start('add')                      # (+ Q happens inside the dense factor kernel)
+        timer.stop('add')
+        timer.stop('communicate')
+        timer.stop('form SC')
+        timer.start('factor SC')
+        self._guarded(res, self._eng.factor_schur, Q)
         self._last_Q = Q
-        status, pos, neg, zero = self._eng.status()
+        st = self._guarded(res, self._eng.status)
         timer.stop('factor SC')
-        self._inertia = (pos, neg, zero)
-        res.status = self._agree_status(LinearSolverStatus(status))
+        if st is not None:
+            status, pos, neg, zero = st
+            self._inertia = (pos, neg, zero)
+            res.status = LinearSolverStatus(status)
+        else:
+            self._inertia = None
+        # after the all-reduce every rank holds the same block counts and the same S: the device status is already
+        # rank-consistent, only a host-side failure of the dense phase can differ
+        if self.comm.size > 1 and st is None:
+            res.status = self._agree_status(res.status)
         self._num_status = res.status
         return res
 
@@ -656,6 +803,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         been factorised: the plan is then on the union pattern)."""
         if self._num_status is None and not self._groups:
             raise RuntimeError('Perform symbolic factorization first!')
+        keep = {}
         for g in self._groups:
             ref = None
             for ndx in g.blocks:
@@ -666,16 +814,16 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
                     ref = c
                 elif not np.array_equal(ref, c):
                     raise ValueError('blocks of one pattern group must have identical regularization classes')
-            self._eng.set_diagonal_classes(g.gid, ref)
-        self._have_classes = True
+                keep[ndx] = ref
+        self._classes = keep
+        self._apply_classes()
 
     def refactorize_with_diagonal_shift(self, delta_w, delta_c, coupling_shift=0.0, raise_on_error=True, timer=None):
         """Numeric factorisation of (the last matrix given to do_numeric_factorization) + delta_w on the classed
         Hessian diagonals - delta_c on the classed constraint diagonals + coupling_shift * I on the coupling block,
         from the values already resident on the device: what one retry of the inertia-correction loop
         (interior_point.py:377-386) needs, without rebuilding, staging or uploading the KKT matrix."""
-        if timer is None:
-            timer = _NullTimer()
+        timer = _Labels(timer)
         if self._num_status is None:
             raise RuntimeError('Perform numeric factorization first!')
         if not getattr(self, '_have_classes', False):
@@ -683,22 +831,14 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         res = LinearSolverResults(LinearSolverStatus.successful)
         timer.start('form SC')
         timer.start('factorize')
-        self._eng.numeric_local_shifted(delta_w, delta_c)
+        self._guarded(res, self._eng.numeric_local_shifted, delta_w, delta_c)
         timer.stop('factorize')
-        timer.start('communicate')
-        self._eng.allreduce_schur(self.comm)
-        timer.stop('communicate')
-        timer.stop('form SC')
-        timer.start('factor SC')
-        Q = None if self._last_Q is None else self._last_Q.copy()
+        Q = None if self._base_Q is None else self._base_Q.copy()
         if coupling_shift != 0.0 and self._nc > 0:
             Q = (np.zeros((self._nc, self._nc)) if Q is None else Q) + coupling_shift * np.eye(self._nc)
-        self._eng.factor_schur(Q)
-        status, pos, neg, zero = self._eng.status()
-        timer.stop('factor SC')
-        self._inertia = (pos, neg, zero)
-        res.status = self._agree_status(LinearSolverStatus(status))
-        self._num_status = res.status
+        base = self._base_Q
+        res = self._finish_numeric(res, Q, timer)
+        self._base_Q = base                     # shifts are relative to the matrix of the last full factorisation
         if res.status not in _OK and raise_on_error:
             raise RuntimeError('Numeric factorization unsuccessful; status: ' + str(res.status))
         return res

@@ -13,10 +13,24 @@ class _SimGroup(object):
     pass
 
 
+class _StatusError(RuntimeError):
+    """Mirrors parapint_amd._native.NativeError: an exception that carries a LinearSolverStatus value."""
+
+    def __init__(self, status, msg):
+        RuntimeError.__init__(self, msg)
+        self.status = status
+
+
+def hu_status_error(status, msg):
+    return _StatusError(status, msg)
+
+
 class HostSimEngine(object):
     def __init__(self):
         self.groups = []
         self.nc = 0
+        self.budget = None
+        self.mem_factor = 1.0
 
     def symbolic(self, nc, groups):
         L = hu.lib()
@@ -74,6 +88,22 @@ class HostSimEngine(object):
                 sg.L.append(Lf)
                 sg.Dinv.append(D)
         self.tail = np.array([inertia[2], inertia[0], inertia[1], 0.0], dtype=np.double)
+
+    def numeric_factor_blocks(self):
+        """(the interpreter forms the factor and the Schur contribution in one pass)"""
+        if self.budget is not None and self.required_bytes() > self.budget * self.mem_factor:
+            raise hu_status_error(1, 'value storage exceeds the budget')
+        self.numeric_local()
+
+    def numeric_schur(self):
+        pass
+
+    def required_bytes(self):
+        return sum(8 * 2 * sg.usize * sg.batch for sg in self.groups)
+
+    def set_memory_budget(self, nbytes):
+        self.budget = int(nbytes)
+        self.mem_factor = 1.0
 
     def find_zero_pivot(self, gid):
         return self.groups[gid].zero_slot
@@ -150,4 +180,4 @@ class HostSimEngine(object):
         pass
 
     def increase_memory_allocation(self, factor):
-        pass
+        self.mem_factor *= float(factor)

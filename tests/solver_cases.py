@@ -20,11 +20,11 @@ KNOWN_ANSWER = 0.3163456780448639      # parapint/examples/tests/test_examples.p
 RESID_TOL = 1e-8                        # BASELINE.json: KKT residual <= 1e-8 vs reference
 
 
-def new_solver(make_engine, n_blocks=0, comm=None):
+def new_solver(make_engine, n_blocks=0, comm=None, **kwargs):
     eng = make_engine()
     return HipSchurComplementLinearSolver(subproblem_solvers={i: None for i in range(n_blocks)},
                                           schur_complement_solver=None,
-                                          comm=SerialComm() if comm is None else comm, engine=eng)
+                                          comm=SerialComm() if comm is None else comm, engine=eng, **kwargs)
 
 
 def scaled_residual(K, x, b):
@@ -567,3 +567,47 @@ def case_errors(make_engine):
         full[6:, 2 * i:2 * i + 2] = A.get_block(3, i).toarray()
         full[2 * i:2 * i + 2, 6:] = A.get_block(3, i).toarray().T
     assert np.allclose(full @ x.flatten(), rhs.flatten())
+
+
+# ---- memory reallocation protocol (linalg/tests/test_realloc.py:10-61, interior_point.py:634-652) ----------
+def case_reallocation(make_engine, required_bytes):
+    """A solver whose device-storage budget is too small reports not_enough_memory from the numeric phase (status,
+    not an exception, when raise_on_error=False); the caller's loop grows the allocation and tries again."""
+    N = 6
+    model = SyntheticKKT(N, 40, 2, 8)
+    kkt = model.build_kkt(comm=SerialComm(), iteration=1)
+    rhs = model.build_rhs(comm=SerialComm())
+    probe = new_solver(make_engine, N)
+    probe.do_symbolic_factorization(kkt)
+    need = required_bytes(probe)
+    assert need > 0
+    solver = new_solver(make_engine, N, memory_budget_bytes=max(1, need // 3))
+    assert solver.do_symbolic_factorization(matrix=kkt, raise_on_error=False).status == LinearSolverStatus.successful
+    res = solver.do_numeric_factorization(matrix=kkt, raise_on_error=False)
+    assert res.status == LinearSolverStatus.not_enough_memory
+    import pytest
+    with pytest.raises(RuntimeError, match='not_enough_memory'):
+        solver.do_numeric_factorization(kkt)
+    for count in range(5):                              # try_factorization_and_reallocation, max_iter = 5, factor 2
+        res = solver.do_numeric_factorization(matrix=kkt, raise_on_error=False)
+        if res.status == LinearSolverStatus.not_enough_memory:
+            solver.increase_memory_allocation(2)
+        else:
+            break
+    assert res.status == LinearSolverStatus.successful and count == 2
+    x = solver.do_back_solve(rhs)
+    assert scaled_residual(kkt.tocoo(), x.flatten(), rhs.flatten()) <= RESID_TOL
+    n_y = model.n_y
+    assert solver.get_inertia() == (N * (n_y + model.n_q) + 8, N * (n_y + 8), 0)
+    return need
+
+
+def case_status_severity():
+    """One reduction must let the most severe status win: `warning` (enum value 4) may not mask `singular` (2)."""
+    from parapint_amd.linalg import hip_schur_complement as mod
+    order = [LinearSolverStatus.successful, LinearSolverStatus.warning, LinearSolverStatus.not_enough_memory,
+             LinearSolverStatus.singular, LinearSolverStatus.error]
+    ranks = [mod._SEVERITY[st] for st in order]
+    assert ranks == sorted(ranks) and len(set(ranks)) == 5
+    for st in order:
+        assert mod._BY_SEVERITY[mod._SEVERITY[st]] == st

@@ -62,6 +62,13 @@ def test_ip_solve_call_pattern():
     sc.case_ip_solve_call_pattern(make_engine)
 
 
+def test_memory_reallocation_retry_loop():
+    """Device-storage budget too small -> status not_enough_memory from the numeric phase -> the caller's
+    increase_memory_allocation loop -> success (linalg/tests/test_realloc.py:10-61, interior_point.py:634-652)."""
+    need = sc.case_reallocation(make_engine, lambda solver: solver._eng.memory_info()[0])
+    assert need > 1000
+
+
 @pytest.mark.parametrize('shape', [(1, 10, 2, 1), (1, 5, 2, 5), (65, 10, 2, 2), (129, 12, 2, 3), (5, 300, 2, 208),
                                    (3, 300, 2, 209), (2, 600, 2, 513)])
 def test_edge_shapes_against_full_space_superlu(shape):
@@ -96,6 +103,63 @@ def test_full_size_blocks_property():
     # configuration-3 block shape (n_i = 9200, n_c = 200) on 130 instances: residual + inertia properties
     solver, model = sc.case_against_oracle(make_engine, (130, 1000, 4, 200), iteration=4, check_full_space=False)
     assert solver.plan_stats[0]['n'] == 9200
+
+
+def test_full_size_c3_residual_inertia_determinism():
+    """BASELINE.json configs[2] at its full size through the LinearSolverInterface boundary: 1024 blocks x 9200,
+    200 coupling variables; two value sets, scaled residual <= 1e-8 on the assembled system, inertia, bitwise
+    determinism of a repeated factorisation + solve."""
+    from parapint_amd.examples.performance.schur_complement.synthetic_kkt import SyntheticKKT
+    from parapint_amd.linalg.comm import SerialComm
+    N = 1024
+    model = SyntheticKKT(N, 1000, 4, 200)
+    solver = sc.new_solver(make_engine, N)
+    rhs = model.build_rhs(comm=SerialComm())
+    b = rhs.flatten()
+    want = (N * (model.n_y + 1000) + 200, N * (model.n_y + 200), 0)
+    for it in (0, 3):
+        kkt = model.build_kkt(comm=SerialComm(), iteration=it)
+        if it == 0:
+            solver.do_symbolic_factorization(kkt)
+        xs = []
+        for rep in range(2):
+            assert solver.do_numeric_factorization(kkt).status.value == 0
+            xs.append(solver.do_back_solve(rhs).flatten())
+        assert np.array_equal(xs[0], xs[1])
+        assert sc.scaled_residual(kkt.tocoo(), xs[0], b) <= sc.RESID_TOL
+        assert tuple(solver.get_inertia()) == want
+    st = solver.plan_stats[0]
+    assert st['n'] == 9200 and st['batch'] == 1024
+
+
+def test_config5_shaped_blocks():
+    """BASELINE.json configs[4] block shape (n_q = 2000, m = 4: 10 000 primal variables, block dimension 19 000,
+    n_c = 1000: the multi-workgroup dense LDL^T and the 1024-thread coupling solve) on 72 blocks: S on a subset of its
+    columns against the reference algorithm restated with SuperLU (one solve per border row, mpi_...:313-333),
+    residual, inertia."""
+    from scipy.sparse.linalg import splu
+    from parapint_amd.examples.performance.schur_complement.synthetic_kkt import SyntheticKKT
+    from parapint_amd.linalg.comm import SerialComm
+    N, n_q, m, n_t = 72, 2000, 4, 1000
+    model = SyntheticKKT(N, n_q, m, n_t)
+    kkt = model.build_kkt(comm=SerialComm(), iteration=2)
+    rhs = model.build_rhs(comm=SerialComm())
+    solver = sc.new_solver(make_engine, N)
+    solver.do_symbolic_factorization(kkt)
+    assert solver.do_numeric_factorization(kkt).status.value == 0
+    x = solver.do_back_solve(rhs)
+    assert solver.plan_stats[0]['n'] == 19000
+    assert sc.scaled_residual(kkt.tocoo(), x.flatten(), rhs.flatten()) <= sc.RESID_TOL
+    assert tuple(solver.get_inertia()) == (N * (model.n_y + n_q) + n_t, N * (model.n_y + n_t), 0)
+    cols = [0, 1, 137, 500, 998, 999]
+    A = model.border_matrix().tocsr()
+    S_ref = np.zeros((n_t, len(cols)))
+    for ndx in range(N):
+        lu = splu(model.block_matrix(ndx, 2).tocsc())
+        for j, r in enumerate(cols):
+            S_ref[:, j] -= A @ lu.solve(A[r].toarray().ravel())
+    S = solver.get_schur_complement()
+    assert np.abs(S[:, cols] - S_ref).max() <= 1e-9 * np.abs(S_ref).max()
 
 
 def test_dense_schur_paths_agree():
@@ -249,23 +313,44 @@ def test_inertia_correction_fast_path_on_device():
     rhs.set_block(nb, rng.normal(size=nc))
     classes = {i: np.concatenate([np.ones(n_x, dtype=np.int8), 2 * np.ones(n_c, dtype=np.int8)]) for i in range(nb)}
 
+    from oracle.schur_complement import MPISchurComplementLinearSolver as OracleSC
+    from oracle.subsolvers import ScipyInterface as OracleScipy
     fast = sc.new_solver(make_engine, nb)
     A0 = kkt(0.0, 0.0)
     fast.do_symbolic_factorization(A0)
     fast.do_numeric_factorization(A0)
     fast.set_regularization_classes(classes)
+    m = n_x + n_c
     for dw, dc in ((1e-4, 1e-4), (1e-2, 1e-2), (1.0, 1e-8)):
         res = fast.refactorize_with_diagonal_shift(dw, dc, coupling_shift=dw, raise_on_error=False)
-        fresh = sc.new_solver(make_engine, nb)
+        assert res.status == LinearSolverStatus.successful
+        # the regularised matrix assembled the reference's way, solved by the oracle's restatement of the reference
+        # algorithm (n_c solves per block, SuperLU sub-solver) and by dense algebra
         Areg = kkt(dw, dc)
-        fresh.do_symbolic_factorization(Areg)
-        ref = fresh.do_numeric_factorization(Areg, raise_on_error=False)
-        assert res.status == ref.status == LinearSolverStatus.successful
-        assert fast.get_inertia() == fresh.get_inertia()
-        S1, S2 = fast.get_schur_complement(), fresh.get_schur_complement()
-        assert np.abs(S1 - S2).max() <= 1e-12 * max(1.0, np.abs(S2).max())
-        x1, x2 = fast.do_back_solve(rhs).flatten(), fresh.do_back_solve(rhs).flatten()
-        assert np.abs(x1 - x2).max() <= 1e-10 * np.abs(x2).max()
+        oracle = OracleSC({i: OracleScipy() for i in range(nb)}, OracleScipy())
+        oracle.do_symbolic_factorization(Areg)
+        assert oracle.do_numeric_factorization(Areg).status.value == 0
+        S_o = oracle.schur_complement.toarray()                        # all-reduced S without Q (mpi_...:343), as ours
+        S1 = fast.get_schur_complement()
+        assert np.abs(S1 - S_o).max() <= 1e-9 * max(1.0, np.abs(S_o).max())
+        x_o = oracle.do_back_solve(rhs).flatten()
+        full = np.zeros((nb * m + nc, nb * m + nc))
+        for i in range(nb):
+            full[i * m:(i + 1) * m, i * m:(i + 1) * m] = Areg.get_block(i, i).toarray()
+            Bd = Areg.get_block(nb, i).toarray()
+            full[nb * m:, i * m:(i + 1) * m] = Bd
+            full[i * m:(i + 1) * m, nb * m:] = Bd.T
+        full[nb * m:, nb * m:] = dw * np.eye(nc)
+        ev = np.linalg.eigvalsh(full)
+        assert fast.get_inertia() == (int((ev > 0).sum()), int((ev < 0).sum()), 0)
+        x_d = np.linalg.solve(full, rhs.flatten())
+        x1 = fast.do_back_solve(rhs).flatten()
+        assert np.abs(x1 - x_o).max() <= 1e-8 * np.abs(x_o).max()
+        assert np.abs(x1 - x_d).max() <= 1e-8 * np.abs(x_d).max()
+    # the classes survive a new plan (pivot-order refresh / union pattern): the fast path keeps working
+    fast._run_symbolic()
+    fast.do_numeric_factorization(A0)
+    assert fast.refactorize_with_diagonal_shift(1e-3, 1e-3, coupling_shift=1e-3).status == LinearSolverStatus.successful
     # a classed row without a diagonal entry in the plan is refused with a message, not silently skipped
     A1 = BlockMatrix(nb + 1, nb + 1)
     for i in range(nb):

@@ -56,3 +56,11 @@ def test_pivot_order_refresh_after_static_breakdown():
 
 def test_ip_solve_call_pattern():
     sc.case_ip_solve_call_pattern(make_engine)
+
+
+def test_memory_reallocation_retry_loop():
+    sc.case_reallocation(make_engine, lambda solver: solver._eng.required_bytes())
+
+
+def test_status_severity_order():
+    sc.case_status_severity()
