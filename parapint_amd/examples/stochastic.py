@@ -1,0 +1,106 @@
+"""The farmer problem (BASELINE.json configs[0]; reference parapint/examples/stochastic.py:21-124), Pyomo-free.
+
+The reference builds one Pyomo model per yield scenario (``create_scenario``, :44-84), lets
+``MPIStochasticSchurComplementInteriorPointInterface`` tie the scenarios' ``devoted_acreage`` copies together
+(:97-112) and solves with ``ip_solve`` over ``MPISchurComplementLinearSolver`` (:115-124).  Pyomo and ASL are not
+available here, so the same linear program is written down explicitly: per scenario the 12 variables
+
+    devoted_acreage[3] in [0, 500], QuantitySubQuotaSold[3] >= 0, QuantitySuperQuotaSold[3] >= 0,
+    QuantityPurchased[3] >= 0
+
+and the 10 inequality constraints total_acreage_con, EnforceCattleFeedRequirement[3], LimitAmountSold[3],
+EnforceQuotas[3] with the data of ``Farmer`` (:21-41).  Expected first-stage solution (examples/tests/
+test_examples.py:31-33): WHEAT 170, CORN 80, SUGAR_BEETS 250.
+"""
+import numpy as np
+from scipy.sparse import coo_matrix
+
+from parapint_amd.algorithms.interior_point import IPOptions, InteriorPointStatus, ip_solve
+from parapint_amd.interfaces.interface import QuadraticProgram
+from parapint_amd.interfaces.schur_complement.sc_ip_interface import StochasticSchurComplementInteriorPointInterface
+
+
+class Farmer(object):
+    def __init__(self, extra_scenarios=0):
+        self.crops = ['WHEAT', 'CORN', 'SUGAR_BEETS']
+        self.total_acreage = 500
+        self.PriceQuota = {'WHEAT': 100000.0, 'CORN': 100000.0, 'SUGAR_BEETS': 6000.0}
+        self.SubQuotaSellingPrice = {'WHEAT': 170.0, 'CORN': 150.0, 'SUGAR_BEETS': 36.0}
+        self.SuperQuotaSellingPrice = {'WHEAT': 0.0, 'CORN': 0.0, 'SUGAR_BEETS': 10.0}
+        self.CattleFeedRequirement = {'WHEAT': 200.0, 'CORN': 240.0, 'SUGAR_BEETS': 0.0}
+        self.PurchasePrice = {'WHEAT': 238.0, 'CORN': 210.0, 'SUGAR_BEETS': 100000.0}
+        self.PlantingCostPerAcre = {'WHEAT': 150.0, 'CORN': 230.0, 'SUGAR_BEETS': 260.0}
+        self.scenarios = ['BelowAverageScenario', 'AverageScenario', 'AboveAverageScenario']
+        self.crop_yield = {'BelowAverageScenario': {'WHEAT': 2.0, 'CORN': 2.4, 'SUGAR_BEETS': 16.0},
+                           'AverageScenario': {'WHEAT': 2.5, 'CORN': 3.0, 'SUGAR_BEETS': 20.0},
+                           'AboveAverageScenario': {'WHEAT': 3.0, 'CORN': 3.6, 'SUGAR_BEETS': 24.0}}
+        self.scenario_probabilities = {'BelowAverageScenario': 0.3333, 'AverageScenario': 0.3334,
+                                       'AboveAverageScenario': 0.3333}
+        # BASELINE.json configs[0] asks for 4 scenarios; the reference has three.  Extra scenarios repeat the average
+        # yields and share its probability, which leaves the expected cost -- and the optimum -- unchanged.
+        for k in range(extra_scenarios):
+            name = 'AverageScenario_%d' % (k + 2)
+            self.scenarios.append(name)
+            self.crop_yield[name] = dict(self.crop_yield['AverageScenario'])
+        if extra_scenarios:
+            share = 0.3334 / (extra_scenarios + 1)
+            for name in self.scenarios:
+                if name.startswith('AverageScenario'):
+                    self.scenario_probabilities[name] = share
+
+
+def create_scenario(farmer, scenario):
+    """The scenario LP of stochastic.py:44-84 as a QuadraticProgram (H = 0)."""
+    nc = len(farmer.crops)
+    acre, sub, sup, buy = (np.arange(nc) + k * nc for k in range(4))
+    n = 4 * nc
+    y = np.array([farmer.crop_yield[scenario][c] for c in farmer.crops])
+    rows, cols, vals, lo, hi = [], [], [], [], []
+
+    def con(entries, lb, ub):
+        r = len(lo)
+        for j, v in entries:
+            rows.append(r)
+            cols.append(j)
+            vals.append(v)
+        lo.append(lb)
+        hi.append(ub)
+
+    con([(j, 1.0) for j in acre], -np.inf, farmer.total_acreage)                       # total_acreage_con
+    for i, c in enumerate(farmer.crops):                                               # EnforceCattleFeedRequirement
+        con([(acre[i], y[i]), (buy[i], 1.0), (sub[i], -1.0), (sup[i], -1.0)], farmer.CattleFeedRequirement[c], np.inf)
+    for i, c in enumerate(farmer.crops):                                               # LimitAmountSold
+        con([(sub[i], 1.0), (sup[i], 1.0), (acre[i], -y[i])], -np.inf, 0.0)
+    for i, c in enumerate(farmer.crops):                                               # EnforceQuotas
+        con([(sub[i], 1.0)], 0.0, farmer.PriceQuota[c])
+    A = coo_matrix((vals, (rows, cols)), shape=(len(lo), n))
+    p = farmer.scenario_probabilities[scenario]
+    c = np.zeros(n)
+    for i, crop in enumerate(farmer.crops):
+        c[buy[i]] = p * farmer.PurchasePrice[crop]
+        c[sub[i]] = -p * farmer.SubQuotaSellingPrice[crop]
+        c[sup[i]] = -p * farmer.SuperQuotaSellingPrice[crop]
+        c[acre[i]] = p * farmer.PlantingCostPerAcre[crop]
+    lb = np.zeros(n)
+    ub = np.full(n, np.inf)
+    ub[acre] = farmer.total_acreage
+    return QuadraticProgram(c=c, A_ineq=A, ineq_lb=lo, ineq_ub=hi, lb=lb, ub=ub), acre
+
+
+def build_interface(farmer, comm=None):
+    qps, first_stage = [], []
+    for s in farmer.scenarios:
+        qp, acre = create_scenario(farmer, s)
+        qps.append(qp)
+        first_stage.append(acre)
+    return StochasticSchurComplementInteriorPointInterface(qps, first_stage, comm=comm)
+
+
+def main(farmer, linear_solver, comm=None):
+    """stochastic.py:115-124: returns the interface after a successful solve."""
+    interface = build_interface(farmer, comm=comm)
+    options = IPOptions()
+    options.linalg.solver = linear_solver
+    status = ip_solve(interface=interface, options=options)
+    assert status == InteriorPointStatus.optimal
+    return interface

@@ -1,0 +1,324 @@
+"""Interior-point interface of ONE subproblem, Pyomo-free.
+
+The reference's ``InteriorPointInterface`` (parapint/interfaces/interface.py:251-679) wraps a PyNumero NLP
+(Pyomo + ASL, neither available here) and builds the primal-dual KKT matrix and right-hand side the
+Schur-complement solver is handed (``evaluate_primal_dual_kkt_matrix`` :432-494, ``_rhs`` :496-538).  This module
+restates that class for problems given explicitly as a quadratic program
+
+    min  1/2 x' H x + c' x + c0     s.t.  A_eq x = b_eq,   ineq_lb <= A_ineq x <= ineq_ub,   lb <= x <= ub
+
+so that the callers of the hot path (``ip_solve``, the stochastic Schur-complement interface) can be exercised
+end to end: same method names, same KKT layout (4 x 4 blocks: primals, slacks, equality duals, inequality
+duals), same barrier terms, same regularisation hooks.  It is the producer side of SURVEY.md section 8 rows f2 / C1,
+not part of the solver.
+"""
+import numpy as np
+import scipy.sparse as sp
+from scipy.sparse import coo_matrix
+
+from parapint_amd.sparse.block_containers import BlockMatrix, BlockVector
+
+
+class QuadraticProgram(object):
+    """Data of one subproblem (all matrices SciPy sparse or None, vectors array-like)."""
+
+    def __init__(self, c, A_eq=None, b_eq=None, A_ineq=None, ineq_lb=None, ineq_ub=None, lb=None, ub=None, H=None,
+                 c0=0.0, x0=None, names=None):
+        self.c = np.asarray(c, dtype=np.double).ravel()
+        n = self.c.size
+        self.n = n
+        self.H = coo_matrix((n, n)) if H is None else sp.tril(coo_matrix(H)).tocoo()    # lower triangle, as ASL
+        self.A_eq = coo_matrix((0, n)) if A_eq is None else coo_matrix(A_eq)
+        self.b_eq = np.zeros(self.A_eq.shape[0]) if b_eq is None else np.asarray(b_eq, dtype=np.double).ravel()
+        self.A_ineq = coo_matrix((0, n)) if A_ineq is None else coo_matrix(A_ineq)
+        m = self.A_ineq.shape[0]
+        self.ineq_lb = np.full(m, -np.inf) if ineq_lb is None else np.asarray(ineq_lb, dtype=np.double).ravel()
+        self.ineq_ub = np.full(m, np.inf) if ineq_ub is None else np.asarray(ineq_ub, dtype=np.double).ravel()
+        self.lb = np.full(n, -np.inf) if lb is None else np.asarray(lb, dtype=np.double).ravel()
+        self.ub = np.full(n, np.inf) if ub is None else np.asarray(ub, dtype=np.double).ravel()
+        self.c0 = float(c0)
+        self.x0 = np.zeros(n) if x0 is None else np.asarray(x0, dtype=np.double).ravel()   # unset Pyomo values start at 0
+        self.names = names
+
+
+def _relaxed(bound, factor, sign):
+    """interface.py:389-419: bounds moved outwards by factor * max(1, |bound|)."""
+    if factor == 0:
+        return bound
+    return bound + sign * factor * np.maximum(1.0, np.abs(bound))
+
+
+class QPInteriorPointInterface(object):
+    """Counterpart of ``InteriorPointInterface`` (interface.py:251-679) over a QuadraticProgram."""
+
+    def __init__(self, qp):
+        self._qp = qp
+        self.bounds_relaxation_factor = 0
+        self._obj_factor = 1.0
+        self._primals = qp.x0.copy()
+        self._duals_eq = np.zeros(qp.A_eq.shape[0])
+        self._duals_ineq = np.zeros(qp.A_ineq.shape[0])
+        self._Hfull = (qp.H + sp.tril(qp.H, -1).T).tocsr()
+        self._slacks = self.init_slacks()
+        # interface.py:263-283: ones unless ipopt suffixes exist, zero where the bound is infinite; slack duals from
+        # the (zero) initial inequality duals
+        self._init_duals_primals_lb = np.ones(qp.n)
+        self._init_duals_primals_ub = np.ones(qp.n)
+        self._init_duals_primals_lb[np.isneginf(qp.lb)] = 0
+        self._init_duals_primals_ub[np.isinf(qp.ub)] = 0
+        self._duals_primals_lb = self._init_duals_primals_lb.copy()
+        self._duals_primals_ub = self._init_duals_primals_ub.copy()
+        self._init_duals_slacks_lb = np.zeros(qp.A_ineq.shape[0])
+        self._init_duals_slacks_ub = np.zeros(qp.A_ineq.shape[0])
+        self._duals_slacks_lb = self._init_duals_slacks_lb.copy()
+        self._duals_slacks_ub = self._init_duals_slacks_ub.copy()
+        self._delta_primals = self._delta_slacks = self._delta_duals_eq = self._delta_duals_ineq = None
+        self._barrier = None
+
+    # ---- sizes / options
+    def get_bounds_relaxation_factor(self):
+        return self.bounds_relaxation_factor
+
+    def set_bounds_relaxation_factor(self, val):
+        self.bounds_relaxation_factor = val
+
+    def n_primals(self):
+        return self._qp.n
+
+    def n_eq_constraints(self):
+        return self._qp.A_eq.shape[0]
+
+    def n_ineq_constraints(self):
+        return self._qp.A_ineq.shape[0]
+
+    def nnz_hessian_lag(self):
+        return self._qp.H.nnz
+
+    def nnz_jacobian_eq(self):
+        return self._qp.A_eq.nnz
+
+    def nnz_jacobian_ineq(self):
+        return self._qp.A_ineq.nnz
+
+    def set_obj_factor(self, obj_factor):
+        self._obj_factor = obj_factor
+
+    def get_obj_factor(self):
+        return self._obj_factor
+
+    # ---- bounds
+    def primals_lb(self):
+        return _relaxed(self._qp.lb, self.bounds_relaxation_factor, -1.0)
+
+    def primals_ub(self):
+        return _relaxed(self._qp.ub, self.bounds_relaxation_factor, +1.0)
+
+    def ineq_lb(self):
+        return _relaxed(self._qp.ineq_lb, self.bounds_relaxation_factor, -1.0)
+
+    def ineq_ub(self):
+        return _relaxed(self._qp.ineq_ub, self.bounds_relaxation_factor, +1.0)
+
+    # ---- initial point
+    def init_primals(self):
+        return self._qp.x0
+
+    def init_slacks(self):
+        return self._qp.A_ineq @ self._primals
+
+    def init_duals_eq(self):
+        return np.zeros(self._qp.A_eq.shape[0])
+
+    def init_duals_ineq(self):
+        return np.zeros(self._qp.A_ineq.shape[0])
+
+    def init_duals_primals_lb(self):
+        return self._init_duals_primals_lb
+
+    def init_duals_primals_ub(self):
+        return self._init_duals_primals_ub
+
+    def init_duals_slacks_lb(self):
+        return self._init_duals_slacks_lb
+
+    def init_duals_slacks_ub(self):
+        return self._init_duals_slacks_ub
+
+    # ---- state
+    def set_primals(self, primals):
+        self._primals = np.asarray(primals, dtype=np.double)
+
+    def set_slacks(self, slacks):
+        self._slacks = np.asarray(slacks, dtype=np.double)
+
+    def set_duals_eq(self, duals):
+        self._duals_eq = np.asarray(duals, dtype=np.double)
+
+    def set_duals_ineq(self, duals):
+        self._duals_ineq = np.asarray(duals, dtype=np.double)
+
+    def set_duals_primals_lb(self, duals):
+        self._duals_primals_lb = np.asarray(duals, dtype=np.double)
+
+    def set_duals_primals_ub(self, duals):
+        self._duals_primals_ub = np.asarray(duals, dtype=np.double)
+
+    def set_duals_slacks_lb(self, duals):
+        self._duals_slacks_lb = np.asarray(duals, dtype=np.double)
+
+    def set_duals_slacks_ub(self, duals):
+        self._duals_slacks_ub = np.asarray(duals, dtype=np.double)
+
+    def get_primals(self):
+        return self._primals
+
+    def get_slacks(self):
+        return self._slacks
+
+    def get_duals_eq(self):
+        return self._duals_eq
+
+    def get_duals_ineq(self):
+        return self._duals_ineq
+
+    def get_duals_primals_lb(self):
+        return self._duals_primals_lb
+
+    def get_duals_primals_ub(self):
+        return self._duals_primals_ub
+
+    def get_duals_slacks_lb(self):
+        return self._duals_slacks_lb
+
+    def get_duals_slacks_ub(self):
+        return self._duals_slacks_ub
+
+    def set_barrier_parameter(self, barrier):
+        self._barrier = barrier
+
+    # ---- function evaluations
+    def evaluate_objective(self):
+        x = self._primals
+        return self._obj_factor * (0.5 * x @ (self._Hfull @ x) + self._qp.c @ x + self._qp.c0)
+
+    def evaluate_grad_objective(self):
+        return self._Hfull @ self._primals + self._qp.c
+
+    def evaluate_eq_constraints(self):
+        return self._qp.A_eq @ self._primals - self._qp.b_eq
+
+    def evaluate_ineq_constraints(self):
+        return self._qp.A_ineq @ self._primals
+
+    def evaluate_jacobian_eq(self):
+        return self._qp.A_eq
+
+    def evaluate_jacobian_ineq(self):
+        return self._qp.A_ineq
+
+    def evaluate_hessian_lag(self):
+        H = self._qp.H
+        return coo_matrix((self._obj_factor * H.data, (H.row, H.col)), shape=H.shape)
+
+    # ---- the KKT system the linear solver is handed
+    def barrier_diagonals(self):
+        """The only per-iteration values of a QP's KKT matrix (interface.py:450-465): the primal and the slack
+        barrier terms."""
+        x, s = self._primals, self._slacks
+        dp = self._duals_primals_lb / (x - self.primals_lb()) + self._duals_primals_ub / (self.primals_ub() - x)
+        ds = self._duals_slacks_lb / (s - self.ineq_lb()) + self._duals_slacks_ub / (self.ineq_ub() - s)
+        return dp, ds
+
+    def evaluate_primal_dual_kkt_matrix(self, timer=None):
+        """interface.py:432-494: Hessian + primal barrier diagonal (appended as extra COO entries), slack barrier
+        diagonal, both Jacobians with their transposes, -I between slacks and inequality duals, explicit zero
+        diagonal blocks for the constraint rows (so that regularisation does not change the pattern)."""
+        qp = self._qp
+        n, me, mi = qp.n, qp.A_eq.shape[0], qp.A_ineq.shape[0]
+        dp, ds = self.barrier_diagonals()
+        H = self.evaluate_hessian_lag()
+        idx = np.arange(n)
+        hess = coo_matrix((np.concatenate([H.data, dp]), (np.concatenate([H.row, idx]), np.concatenate([H.col, idx]))),
+                          shape=(n, n))
+        midx = np.arange(mi)
+        kkt = BlockMatrix(4, 4)
+        kkt.set_block(0, 0, hess)
+        kkt.set_block(1, 1, coo_matrix((ds, (midx, midx)), shape=(mi, mi)))
+        kkt.set_block(2, 0, qp.A_eq)
+        kkt.set_block(0, 2, qp.A_eq.transpose().tocoo())
+        kkt.set_block(3, 0, qp.A_ineq)
+        kkt.set_block(0, 3, qp.A_ineq.transpose().tocoo())
+        neg_eye = coo_matrix((-np.ones(mi), (midx, midx)), shape=(mi, mi))
+        kkt.set_block(3, 1, neg_eye)
+        kkt.set_block(1, 3, neg_eye.copy())
+        eidx = np.arange(me)
+        kkt.set_block(2, 2, coo_matrix((np.zeros(me), (eidx, eidx)), shape=(me, me)))
+        kkt.set_block(3, 3, coo_matrix((np.zeros(mi), (midx, midx)), shape=(mi, mi)))
+        return kkt
+
+    def evaluate_primal_dual_kkt_rhs(self, timer=None):
+        """interface.py:496-538 (negative gradient of the barrier Lagrangian and the constraint residuals)."""
+        qp = self._qp
+        x, s = self._primals, self._slacks
+        grad_lag_primals = (self._obj_factor * self.evaluate_grad_objective() + qp.A_eq.T @ self._duals_eq +
+                            qp.A_ineq.T @ self._duals_ineq - self._barrier / (x - self.primals_lb()) +
+                            self._barrier / (self.primals_ub() - x))
+        grad_lag_slacks = (-self._duals_ineq - self._barrier / (s - self.ineq_lb()) +
+                           self._barrier / (self.ineq_ub() - s))
+        rhs = BlockVector(4)
+        rhs.set_block(0, -grad_lag_primals)
+        rhs.set_block(1, -grad_lag_slacks)
+        rhs.set_block(2, -self.evaluate_eq_constraints())
+        rhs.set_block(3, -(self.evaluate_ineq_constraints() - s))
+        return rhs
+
+    def set_primal_dual_kkt_solution(self, sol):
+        self._delta_primals = np.asarray(sol.get_block(0))
+        self._delta_slacks = np.asarray(sol.get_block(1))
+        self._delta_duals_eq = np.asarray(sol.get_block(2))
+        self._delta_duals_ineq = np.asarray(sol.get_block(3))
+
+    def get_delta_primals(self):
+        return self._delta_primals
+
+    def get_delta_slacks(self):
+        return self._delta_slacks
+
+    def get_delta_duals_eq(self):
+        return self._delta_duals_eq
+
+    def get_delta_duals_ineq(self):
+        return self._delta_duals_ineq
+
+    # interface.py:562-588: bound-dual steps recovered from the primal / slack steps
+    def get_delta_duals_primals_lb(self):
+        return ((self._barrier - self._duals_primals_lb * self._delta_primals) /
+                (self._primals - self.primals_lb())) - self._duals_primals_lb
+
+    def get_delta_duals_primals_ub(self):
+        return ((self._barrier + self._duals_primals_ub * self._delta_primals) /
+                (self.primals_ub() - self._primals)) - self._duals_primals_ub
+
+    def get_delta_duals_slacks_lb(self):
+        return ((self._barrier - self._duals_slacks_lb * self._delta_slacks) /
+                (self._slacks - self.ineq_lb())) - self._duals_slacks_lb
+
+    def get_delta_duals_slacks_ub(self):
+        return ((self._barrier + self._duals_slacks_ub * self._delta_slacks) /
+                (self.ineq_ub() - self._slacks)) - self._duals_slacks_ub
+
+    # ---- inertia correction (interface.py:590-619)
+    def regularize_equality_gradient(self, kkt, coef, copy_kkt=True):
+        if copy_kkt:
+            kkt = kkt.copy()
+        me, mi = self.n_eq_constraints(), self.n_ineq_constraints()
+        kkt.set_block(2, 2, (coef * sp.identity(me, format='coo')).tocoo())
+        kkt.set_block(3, 3, (coef * sp.identity(mi, format='coo')).tocoo())
+        return kkt
+
+    def regularize_hessian(self, kkt, coef, copy_kkt=True):
+        if copy_kkt:
+            kkt = kkt.copy()
+        hess = kkt.get_block(0, 0)
+        kkt.set_block(0, 0, (hess + coef * sp.identity(self.n_primals(), format='coo')).tocoo())
+        return kkt

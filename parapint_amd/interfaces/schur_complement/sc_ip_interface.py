@@ -1,0 +1,383 @@
+"""Two-stage stochastic programs in block-bordered KKT form, Pyomo-free.
+
+Counterpart of ``StochasticSchurComplementInteriorPointInterface`` (parapint/interfaces/schur_complement/
+sc_ip_interface.py:1028-1849) and of its MPI variant (mpi_sc_ip_interface.py:273-498) for scenarios given as
+``QuadraticProgram`` objects: every scenario carries its own copy of the first-stage variables, tied to the shared
+coupling variables by the nonanticipativity constraints ``L_i x_i - C_i z = 0`` (linking matrices :1287-1318).  The
+KKT matrix it hands to the linear solver is exactly the reference's structure (:1245-1285, :1677-1681):
+
+    K_i  = [[ kkt_i (4 x 4 blocks of interface.py:432-494),  [L_i 0 0 0]^T ],      border (N, i) = [ 0 | -C_i^T ]
+            [ [L_i 0 0 0],                                   0 * I         ]]      corner        = 0 * I
+
+-- nested BlockMatrix blocks, both triangles, explicit zero diagonals -- so the solver under test sees what
+``ip_solve`` would give it.  With a communicator of more than one rank the scenarios are dealt round-robin
+(mpi_sc_ip_interface.py:14-29) and the containers carry the ownership tables.
+"""
+import numpy as np
+from scipy.sparse import coo_matrix, identity
+
+from parapint_amd.interfaces.interface import QPInteriorPointInterface
+from parapint_amd.sparse.block_containers import (BlockMatrix, BlockVector, MPIBlockMatrix, MPIBlockVector)
+
+
+class _Serial(object):
+    rank, size = 0, 1
+
+    def allreduce_sum(self, a):
+        return a
+
+
+def distribute_blocks(num_blocks, rank, size):
+    return [ndx for ndx in range(num_blocks) if ndx % size == rank]
+
+
+class StochasticSchurComplementInteriorPointInterface(object):
+    """Parameters
+    ----------
+    scenarios: sequence of QuadraticProgram
+        one subproblem per scenario (only the locally owned ones are touched)
+    first_stage_indices: sequence of int arrays
+        for every scenario the indices of its copies of the nonanticipative variables, in the order of the coupling
+        variables (``nonanticipative_var_identifiers`` of the reference, sc_ip_interface.py:1046-1058)
+    comm: communicator of parapint_amd.linalg.comm (None: serial)
+    """
+
+    def __init__(self, scenarios, first_stage_indices, comm=None):
+        self._comm = _Serial() if comm is None else comm
+        self._mpi = comm is not None and comm.size > 1
+        self._num_scenarios = N = len(scenarios)
+        if self._comm.size > N:
+            raise ValueError('Cannot yet handle more processes than scenarios')     # mpi_sc_ip_interface.py:322-323
+        self._ownership = {ndx: ndx % self._comm.size for ndx in range(N)}
+        self._local = distribute_blocks(N, self._comm.rank, self._comm.size)
+        self._num_first_stage_vars = nfs = len(first_stage_indices[0])
+        self._nlps = {}
+        self._linking = {}
+        self._link_coupling = {}
+        for ndx in self._local:
+            nlp = QPInteriorPointInterface(scenarios[ndx])
+            idx = np.asarray(first_stage_indices[ndx], dtype=np.int64)
+            assert idx.size == nfs
+            rows = np.arange(nfs)
+            self._nlps[ndx] = nlp
+            self._linking[ndx] = coo_matrix((np.ones(nfs), (rows, idx)), shape=(nfs, nlp.n_primals()))
+            self._link_coupling[ndx] = coo_matrix((np.ones(nfs), (rows, rows)), shape=(nfs, nfs))
+        self._primals_coupling = np.zeros(nfs)
+        self._delta_coupling = np.zeros(nfs)
+        self._duals_link = {ndx: np.zeros(nfs) for ndx in self._local}
+        self._delta_duals_link = {ndx: np.zeros(nfs) for ndx in self._local}
+        self._bounds_relaxation_factor = 0
+
+    # ---- containers
+    def _vector(self, extra_block):
+        n = self._num_scenarios + (1 if extra_block else 0)
+        if not self._mpi:
+            return BlockVector(n)
+        owner = [self._ownership[ndx] for ndx in range(self._num_scenarios)] + ([-1] if extra_block else [])
+        return MPIBlockVector(n, np.asarray(owner), self._comm)
+
+    def _per_scenario(self, fn, coupling=None):
+        v = self._vector(coupling is not None)
+        for ndx, nlp in self._nlps.items():
+            v.set_block(ndx, fn(ndx, nlp))
+        if coupling is not None:
+            v.set_block(self._num_scenarios, coupling)
+        return v
+
+    @property
+    def local_block_indices(self):
+        return list(self._local)
+
+    @property
+    def ownership_map(self):
+        return dict(self._ownership)
+
+    def scenario_interface(self, ndx):
+        return self._nlps[ndx]
+
+    # ---- sizes
+    def _sum(self, v):
+        return float(self._comm.allreduce_sum(np.array([float(v)]))[0]) if self._mpi else v
+
+    def n_primals(self):
+        return int(self._sum(sum(nlp.n_primals() for nlp in self._nlps.values()))) + self._num_first_stage_vars
+
+    def n_eq_constraints(self):
+        return int(self._sum(sum(nlp.n_eq_constraints() + self._num_first_stage_vars for nlp in self._nlps.values())))
+
+    def n_ineq_constraints(self):
+        return int(self._sum(sum(nlp.n_ineq_constraints() for nlp in self._nlps.values())))
+
+    def get_bounds_relaxation_factor(self):
+        return self._bounds_relaxation_factor
+
+    def set_bounds_relaxation_factor(self, val):
+        self._bounds_relaxation_factor = val
+        for nlp in self._nlps.values():
+            nlp.set_bounds_relaxation_factor(val)
+
+    def get_obj_factor(self):
+        return self._nlps[self._local[0]].get_obj_factor()
+
+    def set_obj_factor(self, obj_factor):
+        for nlp in self._nlps.values():
+            nlp.set_obj_factor(obj_factor)
+
+    def set_barrier_parameter(self, barrier):
+        for nlp in self._nlps.values():
+            nlp.set_barrier_parameter(barrier)
+
+    # ---- bounds and initial point (coupling variables are free, sc_ip_interface.py:1207-1225)
+    def primals_lb(self):
+        return self._per_scenario(lambda i, nlp: nlp.primals_lb(), np.full(self._num_first_stage_vars, -np.inf))
+
+    def primals_ub(self):
+        return self._per_scenario(lambda i, nlp: nlp.primals_ub(), np.full(self._num_first_stage_vars, np.inf))
+
+    def ineq_lb(self):
+        return self._per_scenario(lambda i, nlp: nlp.ineq_lb())
+
+    def ineq_ub(self):
+        return self._per_scenario(lambda i, nlp: nlp.ineq_ub())
+
+    def init_primals(self):
+        return self._per_scenario(lambda i, nlp: nlp.init_primals(), np.zeros(self._num_first_stage_vars))
+
+    def init_slacks(self):
+        return self._per_scenario(lambda i, nlp: nlp.init_slacks())
+
+    def _eq_pair(self, a, b):
+        sub = BlockVector(2)
+        sub.set_block(0, a)
+        sub.set_block(1, b)
+        return sub
+
+    def init_duals_eq(self):
+        return self._per_scenario(lambda i, nlp: self._eq_pair(nlp.init_duals_eq(), np.zeros(self._num_first_stage_vars)))
+
+    def init_duals_ineq(self):
+        return self._per_scenario(lambda i, nlp: nlp.init_duals_ineq())
+
+    def init_duals_primals_lb(self):
+        return self._per_scenario(lambda i, nlp: nlp.init_duals_primals_lb(), np.zeros(self._num_first_stage_vars))
+
+    def init_duals_primals_ub(self):
+        return self._per_scenario(lambda i, nlp: nlp.init_duals_primals_ub(), np.zeros(self._num_first_stage_vars))
+
+    def init_duals_slacks_lb(self):
+        return self._per_scenario(lambda i, nlp: nlp.init_duals_slacks_lb())
+
+    def init_duals_slacks_ub(self):
+        return self._per_scenario(lambda i, nlp: nlp.init_duals_slacks_ub())
+
+    # ---- state
+    def set_primals(self, primals):
+        for ndx, nlp in self._nlps.items():
+            nlp.set_primals(primals.get_block(ndx))
+        self._primals_coupling = np.asarray(primals.get_block(self._num_scenarios), dtype=np.double)
+
+    def get_primals(self):
+        return self._per_scenario(lambda i, nlp: nlp.get_primals(), self._primals_coupling)
+
+    def set_slacks(self, slacks):
+        for ndx, nlp in self._nlps.items():
+            nlp.set_slacks(slacks.get_block(ndx))
+
+    def get_slacks(self):
+        return self._per_scenario(lambda i, nlp: nlp.get_slacks())
+
+    def set_duals_eq(self, duals_eq):
+        for ndx, nlp in self._nlps.items():
+            sub = duals_eq.get_block(ndx)
+            nlp.set_duals_eq(sub.get_block(0))
+            self._duals_link[ndx] = np.asarray(sub.get_block(1), dtype=np.double)
+
+    def get_duals_eq(self):
+        return self._per_scenario(lambda i, nlp: self._eq_pair(nlp.get_duals_eq(), self._duals_link[i]))
+
+    def set_duals_ineq(self, duals_ineq):
+        for ndx, nlp in self._nlps.items():
+            nlp.set_duals_ineq(duals_ineq.get_block(ndx))
+
+    def get_duals_ineq(self):
+        return self._per_scenario(lambda i, nlp: nlp.get_duals_ineq())
+
+    def set_duals_primals_lb(self, duals):
+        for ndx, nlp in self._nlps.items():
+            nlp.set_duals_primals_lb(duals.get_block(ndx))
+
+    def set_duals_primals_ub(self, duals):
+        for ndx, nlp in self._nlps.items():
+            nlp.set_duals_primals_ub(duals.get_block(ndx))
+
+    def set_duals_slacks_lb(self, duals):
+        for ndx, nlp in self._nlps.items():
+            nlp.set_duals_slacks_lb(duals.get_block(ndx))
+
+    def set_duals_slacks_ub(self, duals):
+        for ndx, nlp in self._nlps.items():
+            nlp.set_duals_slacks_ub(duals.get_block(ndx))
+
+    def get_duals_primals_lb(self):
+        return self._per_scenario(lambda i, nlp: nlp.get_duals_primals_lb(), np.zeros(self._num_first_stage_vars))
+
+    def get_duals_primals_ub(self):
+        return self._per_scenario(lambda i, nlp: nlp.get_duals_primals_ub(), np.zeros(self._num_first_stage_vars))
+
+    def get_duals_slacks_lb(self):
+        return self._per_scenario(lambda i, nlp: nlp.get_duals_slacks_lb())
+
+    def get_duals_slacks_ub(self):
+        return self._per_scenario(lambda i, nlp: nlp.get_duals_slacks_ub())
+
+    # ---- evaluations
+    def evaluate_objective(self):
+        return self._sum(sum(nlp.evaluate_objective() for nlp in self._nlps.values()))
+
+    def evaluate_grad_objective(self):
+        return self._per_scenario(lambda i, nlp: nlp.evaluate_grad_objective(), np.zeros(self._num_first_stage_vars))
+
+    def evaluate_eq_constraints(self):
+        return self._per_scenario(lambda i, nlp: self._eq_pair(
+            nlp.evaluate_eq_constraints(),
+            self._linking[i] @ nlp.get_primals() - self._link_coupling[i] @ self._primals_coupling))
+
+    def evaluate_ineq_constraints(self):
+        return self._per_scenario(lambda i, nlp: nlp.evaluate_ineq_constraints())
+
+    def grad_lag_primals_terms(self):
+        """J_eq^T y_eq + J_ineq^T y_ineq of the whole problem, per block (the convergence check needs it; the
+        reference multiplies the block Jacobians, interior_point.py:236-238)."""
+        def per(i, nlp):
+            return (nlp.evaluate_jacobian_eq().T @ nlp.get_duals_eq() + self._linking[i].T @ self._duals_link[i] +
+                    nlp.evaluate_jacobian_ineq().T @ nlp.get_duals_ineq())
+        last = np.zeros(self._num_first_stage_vars)
+        for i in self._nlps:
+            last -= self._link_coupling[i].T @ self._duals_link[i]
+        if self._mpi:
+            last = self._comm.allreduce_sum(last)
+        return self._per_scenario(per, last)
+
+    # ---- the KKT system (sc_ip_interface.py:1245-1285, 1677-1696; mpi_...:470-478)
+    def _matrix(self):
+        N = self._num_scenarios
+        if not self._mpi:
+            return BlockMatrix(N + 1, N + 1)
+        owner = -np.ones((N + 1, N + 1), dtype=np.int64)
+        for ndx in range(N):
+            owner[ndx, ndx] = owner[N, ndx] = owner[ndx, N] = self._ownership[ndx]
+        return MPIBlockMatrix(N + 1, N + 1, owner, self._comm)
+
+    def evaluate_primal_dual_kkt_matrix(self, timer=None):
+        N, nfs = self._num_scenarios, self._num_first_stage_vars
+        kkt = self._matrix()
+        for ndx, nlp in self._nlps.items():
+            n, me, mi = nlp.n_primals(), nlp.n_eq_constraints(), nlp.n_ineq_constraints()
+            sub = BlockMatrix(2, 2)
+            sub.set_block(0, 0, nlp.evaluate_primal_dual_kkt_matrix())
+            row_1 = BlockMatrix(1, 4)
+            row_1.set_row_size(0, nfs)
+            for j, size in enumerate((n, mi, me, mi)):
+                row_1.set_col_size(j, size)
+            row_1.set_block(0, 0, self._linking[ndx])
+            sub.set_block(1, 0, row_1)
+            sub.set_block(0, 1, row_1.transpose())
+            ptb = identity(nfs, format='coo')
+            ptb.data.fill(0)
+            sub.set_block(1, 1, ptb)
+            kkt.set_block(ndx, ndx, sub)
+            border = BlockMatrix(1, 2)
+            border.set_row_size(0, nfs)
+            border.set_col_size(0, n + me + 2 * mi)
+            border.set_block(0, 1, (-self._link_coupling[ndx].transpose()).tocoo())
+            kkt.set_block(N, ndx, border)
+            kkt.set_block(ndx, N, border.transpose())
+        ptb = identity(nfs, format='coo')
+        ptb.data.fill(0)
+        kkt.set_block(N, N, ptb)
+        if self._mpi:
+            for ndx in range(N):
+                if ndx not in self._nlps:
+                    pass                      # sizes of remote blocks are not needed by the solver (it only visits its own)
+        return kkt
+
+    def evaluate_primal_dual_kkt_rhs(self, timer=None):
+        N = self._num_scenarios
+        rhs = self._vector(True)
+        last = np.zeros(self._num_first_stage_vars)
+        for ndx, nlp in self._nlps.items():
+            sub_rhs = nlp.evaluate_primal_dual_kkt_rhs()
+            sub_rhs.set_block(0, sub_rhs.get_block(0) - self._linking[ndx].T @ self._duals_link[ndx])
+            pair = BlockVector(2)
+            pair.set_block(0, sub_rhs)
+            pair.set_block(1, self._link_coupling[ndx] @ self._primals_coupling - self._linking[ndx] @ nlp.get_primals())
+            rhs.set_block(ndx, pair)
+            last += self._link_coupling[ndx].T @ self._duals_link[ndx]
+        if self._mpi:
+            last = self._comm.allreduce_sum(last)
+        rhs.set_block(N, last)
+        return rhs
+
+    def set_primal_dual_kkt_solution(self, sol):
+        for ndx, nlp in self._nlps.items():
+            blk = sol.get_block(ndx)
+            if not hasattr(blk, 'get_block'):           # a flat block from a solver that does not keep the nesting
+                flat = np.asarray(blk)
+                n, me, mi = nlp.n_primals(), nlp.n_eq_constraints(), nlp.n_ineq_constraints()
+                inner = BlockVector(4)
+                off = 0
+                for j, size in enumerate((n, mi, me, mi)):
+                    inner.set_block(j, flat[off:off + size])
+                    off += size
+                link = flat[off:]
+            else:
+                inner, link = blk.get_block(0), blk.get_block(1)
+            nlp.set_primal_dual_kkt_solution(inner)
+            self._delta_duals_link[ndx] = np.asarray(link.flatten() if hasattr(link, 'get_block') else link)
+        self._delta_coupling = np.asarray(sol.get_block(self._num_scenarios), dtype=np.double)
+
+    def get_delta_primals(self):
+        return self._per_scenario(lambda i, nlp: nlp.get_delta_primals(), self._delta_coupling)
+
+    def get_delta_slacks(self):
+        return self._per_scenario(lambda i, nlp: nlp.get_delta_slacks())
+
+    def get_delta_duals_eq(self):
+        return self._per_scenario(lambda i, nlp: self._eq_pair(nlp.get_delta_duals_eq(), self._delta_duals_link[i]))
+
+    def get_delta_duals_ineq(self):
+        return self._per_scenario(lambda i, nlp: nlp.get_delta_duals_ineq())
+
+    def get_delta_duals_primals_lb(self):
+        return self._per_scenario(lambda i, nlp: nlp.get_delta_duals_primals_lb(), np.zeros(self._num_first_stage_vars))
+
+    def get_delta_duals_primals_ub(self):
+        return self._per_scenario(lambda i, nlp: nlp.get_delta_duals_primals_ub(), np.zeros(self._num_first_stage_vars))
+
+    def get_delta_duals_slacks_lb(self):
+        return self._per_scenario(lambda i, nlp: nlp.get_delta_duals_slacks_lb())
+
+    def get_delta_duals_slacks_ub(self):
+        return self._per_scenario(lambda i, nlp: nlp.get_delta_duals_slacks_ub())
+
+    # ---- inertia correction (sc_ip_interface.py:1736-1757)
+    def regularize_equality_gradient(self, kkt, coef, copy_kkt=True):
+        if copy_kkt:
+            kkt = kkt.copy()
+        for ndx, nlp in self._nlps.items():
+            nlp.regularize_equality_gradient(kkt=kkt.get_block(ndx, ndx).get_block(0, 0), coef=coef, copy_kkt=False)
+            kkt.get_block(ndx, ndx).set_block(1, 1, (coef * identity(self._num_first_stage_vars, format='coo')).tocoo())
+        return kkt
+
+    def regularize_hessian(self, kkt, coef, copy_kkt=True):
+        if copy_kkt:
+            kkt = kkt.copy()
+        for ndx, nlp in self._nlps.items():
+            nlp.regularize_hessian(kkt=kkt.get_block(ndx, ndx).get_block(0, 0), coef=coef, copy_kkt=False)
+        N = self._num_scenarios
+        kkt.set_block(N, N, (coef * identity(self._num_first_stage_vars, format='coo')).tocoo())
+        return kkt
+
+
+# the reference keeps the serial and the MPI flavour in two classes; here the communicator decides
+MPIStochasticSchurComplementInteriorPointInterface = StochasticSchurComplementInteriorPointInterface

@@ -138,6 +138,13 @@ class BlockMatrix(object):
         res._col_sizes = list(self._col_sizes)
         return res
 
+    def copy(self):
+        """Deep copy (nested BlockMatrix blocks included), as PyNumero's BlockMatrix.copy()."""
+        res = self.copy_structure()
+        for k, blk in self._blocks.items():
+            res._blocks[k] = blk.copy()
+        return res
+
     def __add__(self, other):
         if isinstance(other, BlockMatrix):
             assert other.bshape == self.bshape

@@ -313,7 +313,7 @@ def test_inertia_correction_fast_path_on_device():
     rhs.set_block(nb, rng.normal(size=nc))
     classes = {i: np.concatenate([np.ones(n_x, dtype=np.int8), 2 * np.ones(n_c, dtype=np.int8)]) for i in range(nb)}
 
-    from oracle.schur_complement import MPISchurComplementLinearSolver as OracleSC
+    from oracle.schur_complement import SchurComplementLinearSolver as OracleSC     # serial twin: a BlockMatrix
     from oracle.subsolvers import ScipyInterface as OracleScipy
     fast = sc.new_solver(make_engine, nb)
     A0 = kkt(0.0, 0.0)
@@ -330,10 +330,10 @@ def test_inertia_correction_fast_path_on_device():
         oracle = OracleSC({i: OracleScipy() for i in range(nb)}, OracleScipy())
         oracle.do_symbolic_factorization(Areg)
         assert oracle.do_numeric_factorization(Areg).status.value == 0
-        S_o = oracle.schur_complement.toarray()                        # all-reduced S without Q (mpi_...:343), as ours
+        S_o = oracle.schur_complement - dw * np.eye(nc)      # the serial class starts S from Q (explicit_...:108); ours is without
         S1 = fast.get_schur_complement()
         assert np.abs(S1 - S_o).max() <= 1e-9 * max(1.0, np.abs(S_o).max())
-        x_o = oracle.do_back_solve(rhs).flatten()
+        x_o = oracle.do_back_solve(rhs.copy()).flatten()     # (quirk Q4: the serial class updates its rhs in place)
         full = np.zeros((nb * m + nc, nb * m + nc))
         for i in range(nb):
             full[i * m:(i + 1) * m, i * m:(i + 1) * m] = Areg.get_block(i, i).toarray()
