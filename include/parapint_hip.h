@@ -77,6 +77,28 @@ double* pp_raw_buffer(pp_handle h, int group);
  * valid until pp_numeric_local has completed on the stream. */
 int pp_bind_raw_buffer(pp_handle h, int group, double* dev_ptr);
 
+/* The same for callers that hold the values on the host: only the raw entries some canonical entry reads
+ * (pp_used_raw_entries: ascending raw indices, pp_group_stats out[15] raw entries of which the used ones are counted by
+ * the `capacity` the call needs) are uploaded, [batch][n_used] row-major, rows [row0, row0 + nrows).  A KKT block
+ * handed over with both triangles (interface.py:470-494 sets both Jacobian transposes) has 45 % of its entries unread. */
+int pp_upload_values_compact(pp_handle h, int group, const double* compact, int row0, int nrows, int on_device);
+int pp_used_raw_entries(pp_handle h, int group, int32_t* out, int capacity);
+
+/* ---- f2: KKT values straight from the producer's arrays -------------------------------------------
+ * The interior-point interface changes only a few arrays per iteration -- Hessian values, Jacobian values, the
+ * barrier diagonals z/(x-l) + z/(u-x) (interfaces/interface.py:432-494, sc_ip_interface.py:1677-1681) -- and every
+ * COO entry of K_i / A_i is one of them times +-1, or a constant.  pp_set_value_map (after pp_end_symbolic) fixes
+ * that relation per raw entry e: value(e) = coef_of_raw[e] * source[src_of_raw[e]]  (src_of_raw[e] < 0: the constant
+ * coef_of_raw[e]).  The sources of all instances live in ONE device buffer [nsrc][bpad] (instance index fastest,
+ * bpad = batch rounded up to 64 = pp_group_stats out[2] rounded): pp_source_buffer returns the library's own,
+ * pp_bind_source_buffer makes the kernels read a caller-owned one (NULL: the library's), pp_upload_sources fills the
+ * library's from a [batch][nsrc] array (host or device).  After any of the last two the next pp_numeric_factor_blocks
+ * gathers its input from the sources: no COO assembly, no host staging, no transposition. */
+int pp_set_value_map(pp_handle h, int group, int nsrc, const int32_t* src_of_raw, const double* coef_of_raw);
+double* pp_source_buffer(pp_handle h, int group);
+int pp_bind_source_buffer(pp_handle h, int group, double* dev_ptr);
+int pp_upload_sources(pp_handle h, int group, const double* src, int on_device);
+
 /* Batched block factorisation + local Schur contribution: K_i = L D L^T for every local block
  * (mpi_...:292-299) and S_local = -sum_i A_i K_i^{-1} A_i^T (mpi_...:312-333).  Result is left
  * in the Schur buffer; block inertia and the singular-pivot count ride in its 4-double tail. */
@@ -135,11 +157,17 @@ double* pp_rs_buffer(pp_handle h);
 int pp_bind_rs_buffer(pp_handle h, double* dev_ptr);
 /* x_c = S^{-1} (r_c + r_s)  (mpi_...:388-391); r_c on the host (n_c doubles, or NULL = 0). */
 int pp_solve_coupling(pp_handle h, const double* rc_host);
+/* The same with r_c resident on the device (NULL = 0), and the device address of x_c (n_c doubles). */
+int pp_solve_coupling_dev(pp_handle h, const double* rc_dev);
+double* pp_coupling_solution_buffer(pp_handle h);
+int pp_copy_coupling_solution(pp_handle h, double* dev_ptr);   /* x_c -> caller's device buffer, stream-ordered */
 /* x_i = K_i^{-1} (r_i - A_i^T x_c) for all local blocks (mpi_...:393-396), by back substitution. */
 int pp_solve_backward(pp_handle h);
 /* Solutions of a group's blocks, [batch][n] row-major (host, or device if on_device). */
 int pp_download_solution(pp_handle h, int group, double* x, int on_device);
 double* pp_solution_buffer(pp_handle h, int group);
+/* Makes pp_solve_backward write a group's solutions ([batch][n]) into a caller-owned device buffer (NULL restores). */
+int pp_bind_solution_buffer(pp_handle h, int group, double* dev_ptr);
 int pp_get_coupling_solution(pp_handle h, double* xc_host);
 
 /* ---- misc -------------------------------------------------------------------------------- */
@@ -200,6 +228,28 @@ int pp_stage_values(int nblocks, int nthreads, const int32_t* const* kr, const i
                     const double* const* bd, const int64_t* bnnz, const int32_t* ref_kr, const int32_t* ref_kc,
                     int64_t ref_knnz, const int32_t* ref_br, const int32_t* ref_bc, int64_t ref_bnnz, double* staging,
                     int64_t row_stride, const int32_t* slots, uint8_t* same_out);
+
+/* The same restricted to runs of entries: runs_k / runs_b hold triples {first entry, length, destination offset in the
+ * staging row} over the K data and the border data of a block -- the entries pp_used_raw_entries lists, so that the
+ * staging rows are the compact rows pp_upload_values_compact takes. */
+int pp_stage_values_runs(int nblocks, int nthreads, const int32_t* const* kr, const int32_t* const* kc,
+                         const double* const* kd, const int64_t* knnz, const int32_t* const* br, const int32_t* const* bc,
+                         const double* const* bd, const int64_t* bnnz, const int32_t* ref_kr, const int32_t* ref_kc,
+                         int64_t ref_knnz, const int32_t* ref_br, const int32_t* ref_bc, int64_t ref_bnnz, int nruns_k,
+                         const int64_t* runs_k, int nruns_b, const int64_t* runs_b, double* staging, int64_t row_stride,
+                         const int32_t* slots, uint8_t* same_out);
+/* pp_stage_values_runs + pp_upload_values_compact with the two overlapped: blocks (ascending slots; staging row =
+ * slot, n_used doubles per row, pinned) are staged in slices on host threads and every finished slice is sent with an
+ * asynchronous copy on the handle's stream while the next one is staged. */
+int pp_stage_upload_compact(pp_handle h, int group, int nblocks, int nthreads, const int32_t* const* kr,
+                            const int32_t* const* kc, const double* const* kd, const int64_t* knnz,
+                            const int32_t* const* br, const int32_t* const* bc, const double* const* bd,
+                            const int64_t* bnnz, const int32_t* ref_kr, const int32_t* ref_kc, int64_t ref_knnz,
+                            const int32_t* ref_br, const int32_t* ref_bc, int64_t ref_bnnz, int nruns_k, const int64_t* runs_k,
+                            int nruns_b, const int64_t* runs_b, double* staging, const int32_t* slots, uint8_t* same_out);
+/* Pinned (page-locked) host memory for the staging arrays and result buffers of the host boundary. */
+void* pp_host_alloc(int64_t bytes);
+void pp_host_free(void* p);
 
 /* After a numeric factorisation that reported numerically zero pivots: the first instance (slot in the group's
  * batch) whose block broke down, earliest pivot in elimination order first, or -1 if no block of this group did.

@@ -26,6 +26,27 @@ SIGNATURES = {
                                     ctypes.POINTER(ctypes.c_int)]),
     'pp_end_symbolic': (ctypes.c_int, [ctypes.c_void_p]),
     'pp_upload_values': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]),
+    'pp_upload_values_compact': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_int]),
+    'pp_used_raw_entries': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _i32p, ctypes.c_int]),
+    'pp_set_value_map': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _i32p, _f64p]),
+    'pp_source_buffer': (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int]),
+    'pp_bind_source_buffer': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    'pp_upload_sources': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]),
+    'pp_solve_coupling_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    'pp_coupling_solution_buffer': (ctypes.c_void_p, [ctypes.c_void_p]),
+    'pp_copy_coupling_solution': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    'pp_bind_solution_buffer': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    'pp_stage_values_runs': (ctypes.c_int, [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 8 +
+                             [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                              ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                              ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+    'pp_stage_upload_compact': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 8 +
+                                [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                 ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                 ctypes.c_void_p, ctypes.c_void_p]),
+    'pp_host_alloc': (ctypes.c_void_p, [ctypes.c_int64]),
+    'pp_host_free': (None, [ctypes.c_void_p]),
     'pp_raw_buffer': (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int]),
     'pp_bind_raw_buffer': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     'pp_numeric_local': (ctypes.c_int, [ctypes.c_void_p]),

@@ -108,6 +108,21 @@ __global__ __launch_bounds__(256) void k_transpose_in(const double* __restrict__
   }
 }
 
+// f2 (sc_ip_interface.py:1677-1710, interface.py:432-494): the values of K_i / A_i straight from the
+// producer's arrays.  Every used raw entry r is coef[r] * S[src[r]][b] (src < 0: the constant coef[r]); S is
+// [source][instance], so reads and writes are coalesced and no transposition is needed.
+__global__ __launch_bounds__(256) void k_assemble_sources(const double* __restrict__ S, double* __restrict__ out,
+                                                          const int* __restrict__ src, const double* __restrict__ coef,
+                                                          int nrows, int bpad) {
+  const int nchunk4 = bpad / 64;
+  const int r = PP_TASK_OF_WG(nchunk4) * 4 + (threadIdx.x >> 6);
+  const int b = PP_CHUNK_OF_WG(nchunk4) * 64 + (threadIdx.x & 63);
+  if (r >= nrows) return;
+  const int sidx = src[r];
+  const double c = coef[r];
+  out[(size_t)r * bpad + b] = (sidx >= 0) ? c * S[(size_t)sidx * bpad + b] : c;
+}
+
 // Inertia-correction fast path (interior_point.py:364-392, interface.py:590-619): the diagonal entries of the
 // rows of class 1 (Hessian) get + delta_w, those of class 2 (constraints) get - delta_c, directly in the
 // transposed input of values that are already resident.
@@ -1578,6 +1593,15 @@ struct Group {
   int nshift = 0;                // rows with a regularisation class (pp_set_diagonal_classes)
   int *shift_row = nullptr, *shift_cls = nullptr;   // device: transposed-input row of their diagonal entry, class
   std::vector<void*> value_allocs;   // value storage (raw, rawT, U, L, ...): allocated by alloc_value_storage
+  // where the next numeric factorisation takes its values from
+  enum { IN_RAW = 0, IN_COMPACT = 1, IN_SOURCES = 2 };
+  int input_mode = IN_RAW;
+  std::vector<int> used_raw;         // raw entries some canonical entry reads, ascending: row j of rawT is raw entry used_raw[j]
+  int nsrc = 0;                      // f2 value map: rows of the source buffer
+  int *map_src = nullptr;            // device [nraw_used]: source row of each used raw entry, or -1 (constant)
+  double *map_coef = nullptr;        // device [nraw_used]
+  double *src_own = nullptr, *src = nullptr;   // [nsrc][bpad]
+  double *xout_own = nullptr;
 };
 
 }  // namespace
@@ -1734,6 +1758,7 @@ int transpose_tiles(int, int) {
 }
 
 void free_group(Group* g) {
+  for (void* p : {(void*)g->map_src, (void*)g->map_coef, (void*)g->src_own}) if (p) (void)hipFree(p);
   if (g->shift_row) (void)hipFree(g->shift_row);
   if (g->shift_cls) (void)hipFree(g->shift_cls);
   for (void* p : g->value_allocs) (void)hipFree(p);
@@ -1776,7 +1801,7 @@ void free_value_storage(Group* g) {
   GroupDev& d = g->dev;
   d.raw = d.rawT = d.U = d.L = d.Dinv = d.Tm = d.Y = d.X = d.rhs = d.xout = d.Spart = d.rspart = nullptr;
   d.codes = nullptr;
-  g->raw_own = g->rhs_own = nullptr;
+  g->raw_own = g->rhs_own = g->xout_own = nullptr;
 }
 
 template <class T>
@@ -1819,7 +1844,9 @@ int alloc_value_storage(pp_handle h) {
     if ((rc = value_alloc(h, g, &d.Y, (size_t)(P.n + nc) * bp))) break;
     if ((rc = value_alloc(h, g, &d.X, (size_t)P.n * bp))) break;
     if ((rc = value_alloc(h, g, &g->rhs_own, (size_t)g->batch * P.n))) break;
-    if ((rc = value_alloc(h, g, &d.xout, (size_t)g->batch * P.n))) break;
+    double* keep_x = (d.xout && d.xout != g->xout_own) ? d.xout : nullptr;
+    if ((rc = value_alloc(h, g, &g->xout_own, (size_t)g->batch * P.n))) break;
+    d.xout = keep_x ? keep_x : g->xout_own;
     if ((rc = value_alloc(h, g, &d.Spart, (size_t)d.nchunk * std::max(g->ntiles, 1) * 64))) break;
     if ((rc = value_alloc(h, g, &d.rspart, (size_t)d.nchunk * std::max(nc, 1)))) break;
     if ((rc = value_alloc(h, g, &d.codes, (size_t)P.npiv * bp))) break;   // 16-bit codes
@@ -1971,9 +1998,12 @@ int pp_end_symbolic(pp_handle h) {
     // raw entries that some canonical entry reads get a compact row in the transposed buffer; the rest
     // (typically the upper-triangle half) are never written
     std::vector<int> rawmap((size_t)std::max(g->nraw, 1), -1);
-    int nused = 0;
-    for (int v : g->can_idx) if (rawmap[v] < 0) rawmap[v] = nused++;
-    g->nraw_used = nused;
+    // compact rows follow the raw order, so that a run of needed raw entries is a run of rows: the host boundary
+    // uploads only those ([batch][nraw_used], pp_upload_values_compact) and the transposition needs no row map
+    for (int v : g->can_idx) rawmap[v] = 0;
+    g->used_raw.clear();
+    for (int e = 0; e < g->nraw; ++e) if (rawmap[(size_t)e] == 0) { rawmap[(size_t)e] = (int)g->used_raw.size(); g->used_raw.push_back(e); }
+    g->nraw_used = (int)g->used_raw.size();
     // expand the canonical initial-value entries into raw-value entries (duplicates are summed)
     fdst_ptr.reserve(P.fdst_ptr.size());
     fent.reserve(P.fentries.size() * 4 + 64);
@@ -2151,9 +2181,98 @@ int pp_upload_values(pp_handle h, int group, const double* raw, int on_device) {
   if (!g || !h->symbolic_done) return fail(h, 3, "pp_upload_values: bad group or symbolic phase not finished");
   PP_HIP(hipSetDevice(h->device));
   if (int rc = alloc_value_storage(h)) return rc;
+  g->input_mode = Group::IN_RAW;
   const size_t bytes = (size_t)g->batch * g->nraw * sizeof(double);
   if (bytes == 0 || raw == g->dev.raw) return 0;
   PP_HIP(hipMemcpyAsync(g->dev.raw, raw, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+  return 0;
+}
+
+int pp_upload_values_compact(pp_handle h, int group, const double* compact, int row0, int nrows, int on_device) {
+  Group* g = get_group(h, group);
+  if (!g || !h->symbolic_done) return fail(h, 3, "pp_upload_values_compact: bad group or symbolic phase not finished");
+  if (row0 < 0 || nrows < 0 || row0 + nrows > g->batch) return fail(h, 3, "pp_upload_values_compact: row range outside the batch");
+  PP_HIP(hipSetDevice(h->device));
+  if (int rc = alloc_value_storage(h)) return rc;
+  g->input_mode = Group::IN_COMPACT;
+  const size_t stride = (size_t)g->nraw_used;
+  if (nrows == 0 || stride == 0) return 0;
+  PP_HIP(hipMemcpyAsync(g->raw_own + (size_t)row0 * stride, compact + (size_t)row0 * stride, (size_t)nrows * stride * sizeof(double),
+                        on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+  return 0;
+}
+
+int pp_used_raw_entries(pp_handle h, int group, int32_t* out, int capacity) {
+  Group* g = get_group(h, group);
+  if (!g || !h->symbolic_done) return fail(h, 3, "pp_used_raw_entries: bad group or symbolic phase not finished");
+  if (capacity < (int)g->used_raw.size()) return fail(h, 3, "pp_used_raw_entries: buffer too small");
+  std::memcpy(out, g->used_raw.data(), g->used_raw.size() * sizeof(int));
+  return 0;
+}
+
+int pp_set_value_map(pp_handle h, int group, int nsrc, const int32_t* src_of_raw, const double* coef_of_raw) {
+  Group* g = get_group(h, group);
+  if (!g || !h->symbolic_done) return fail(h, 3, "pp_set_value_map: bad group or symbolic phase not finished");
+  if (nsrc < 0 || !src_of_raw || !coef_of_raw) return fail(h, 3, "pp_set_value_map: bad arguments");
+  PP_HIP(hipSetDevice(h->device));
+  PP_HIP(hipStreamSynchronize(h->stream));
+  std::vector<int> ms(g->used_raw.size() + 1, -1);
+  std::vector<double> mc(g->used_raw.size() + 1, 0.0);
+  for (size_t j = 0; j < g->used_raw.size(); ++j) {
+    const int e = g->used_raw[j];
+    if (src_of_raw[e] >= nsrc) return fail(h, 3, "pp_set_value_map: source row out of range");
+    ms[j] = src_of_raw[e] < 0 ? -1 : src_of_raw[e];
+    mc[j] = coef_of_raw[e];
+  }
+  for (void* p : {(void*)g->map_src, (void*)g->map_coef, (void*)g->src_own}) if (p) (void)hipFree(p);
+  g->map_src = nullptr; g->map_coef = nullptr; g->src_own = nullptr; g->src = nullptr;
+  g->nsrc = nsrc;
+  int rc;
+  if ((rc = dev_alloc(h, (Group*)nullptr, &g->map_src, ms.size()))) return rc;
+  if ((rc = dev_alloc(h, (Group*)nullptr, &g->map_coef, mc.size()))) return rc;
+  PP_HIP(hipMemcpy(g->map_src, ms.data(), ms.size() * sizeof(int), hipMemcpyHostToDevice));
+  PP_HIP(hipMemcpy(g->map_coef, mc.data(), mc.size() * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
+
+double* pp_source_buffer(pp_handle h, int group) {
+  Group* g = get_group(h, group);
+  if (!g || !h->symbolic_done || !g->map_src) return nullptr;
+  if (!g->src_own) {
+    if (dev_alloc(h, (Group*)nullptr, &g->src_own, (size_t)std::max(g->nsrc, 1) * (size_t)g->dev.bpad)) return nullptr;
+    if (hipMemset(g->src_own, 0, (size_t)std::max(g->nsrc, 1) * (size_t)g->dev.bpad * sizeof(double)) != hipSuccess) return nullptr;
+  }
+  if (!g->src) g->src = g->src_own;
+  return g->src_own;
+}
+
+int pp_bind_source_buffer(pp_handle h, int group, double* dev_ptr) {
+  Group* g = get_group(h, group);
+  if (!g || !h->symbolic_done || !g->map_src) return fail(h, 3, "pp_bind_source_buffer: bad group or no value map");
+  if (!dev_ptr && !pp_source_buffer(h, group)) return fail(h, 1, "pp_bind_source_buffer: could not allocate the source buffer");
+  g->src = dev_ptr ? dev_ptr : g->src_own;
+  g->input_mode = Group::IN_SOURCES;
+  return 0;
+}
+
+int pp_upload_sources(pp_handle h, int group, const double* src, int on_device) {
+  Group* g = get_group(h, group);
+  if (!g || !h->symbolic_done || !g->map_src) return fail(h, 3, "pp_upload_sources: bad group or no value map");
+  PP_HIP(hipSetDevice(h->device));
+  if (int rc = alloc_value_storage(h)) return rc;
+  if (!pp_source_buffer(h, group)) return fail(h, 1, "pp_upload_sources: could not allocate the source buffer");
+  // [batch][nsrc] (one row per block, the producer's natural layout on the host) -> [nsrc][bpad]: staged through the
+  // raw buffer (nsrc <= nraw is not required: the copy is done in slabs of whole rows)
+  const size_t per = (size_t)g->nsrc;
+  if (per == 0) { g->src = g->src_own; g->input_mode = Group::IN_SOURCES; return 0; }
+  if (per > (size_t)g->nraw) return fail(h, 3, "pp_upload_sources: more sources than raw entries per block");
+  PP_HIP(hipMemcpyAsync(g->raw_own, src, (size_t)g->batch * per * sizeof(double),
+                        on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_transpose_in, dim3((unsigned)((g->nsrc + 63) / 64) * g->dev.nchunk), dim3(256), 0, h->stream, g->raw_own,
+                     g->src_own, (const int*)nullptr, g->batch, g->nsrc, g->dev.bpad, 1, (const int*)nullptr);
+  PP_HIP(hipGetLastError());
+  g->src = g->src_own;
+  g->input_mode = Group::IN_SOURCES;
   return 0;
 }
 
@@ -2173,7 +2292,14 @@ int pp_numeric_factor_blocks(pp_handle h) {
     GroupDev& d = g->dev;
     {
       PhaseScope ps(h, 0, 1);
-      if (d.nraw > 0)
+      if (g->input_mode == Group::IN_SOURCES && g->nraw_used > 0) {
+        if (!g->src || !g->map_src) return fail(h, 3, "pp_numeric_factor_blocks: no value map / source buffer");
+        hipLaunchKernelGGL(k_assemble_sources, dim3((unsigned)((g->nraw_used + 3) / 4) * d.nchunk), dim3(256), 0, st, g->src,
+                           d.rawT, g->map_src, g->map_coef, g->nraw_used, d.bpad);
+      } else if (g->input_mode == Group::IN_COMPACT && g->nraw_used > 0) {
+        hipLaunchKernelGGL(k_transpose_in, dim3((unsigned)((g->nraw_used + 63) / 64) * d.nchunk), dim3(256), 0, st, g->raw_own,
+                           d.rawT, (const int*)nullptr, d.batch, g->nraw_used, d.bpad, 1, (const int*)nullptr);
+      } else if (d.nraw > 0)
       {
         const int tiles = transpose_tiles(d.nraw, d.nchunk);
         if (tiles == 1 && g->nraw_tiles > 0)
@@ -2182,10 +2308,10 @@ int pp_numeric_factor_blocks(pp_handle h) {
         else
           hipLaunchKernelGGL(k_transpose_in, dim3((unsigned)((d.nraw + 64 * tiles - 1) / (64 * tiles)) * d.nchunk), dim3(256), 0, st,
                              d.raw, d.rawT, d.rawmap, d.batch, d.nraw, d.bpad, tiles, (const int*)nullptr);
-        if (g->nshift > 0 && (h->shift_w != 0.0 || h->shift_c != 0.0))
-          hipLaunchKernelGGL(k_shift_diag, dim3(g->nshift, (d.bpad + 255) / 256), dim3(256), 0, st, d.rawT, g->shift_row,
-                             g->shift_cls, g->nshift, d.bpad, h->shift_w, h->shift_c);
       }
+      if (g->nshift > 0 && (h->shift_w != 0.0 || h->shift_c != 0.0))
+        hipLaunchKernelGGL(k_shift_diag, dim3(g->nshift, (d.bpad + 255) / 256), dim3(256), 0, st, d.rawT, g->shift_row,
+                           g->shift_cls, g->nshift, d.bpad, h->shift_w, h->shift_c);
     }
     {
       int nlaunch = 0;
@@ -2463,6 +2589,40 @@ int pp_solve_coupling(pp_handle h, const double* rc_host) {
   return 0;
 }
 
+int pp_solve_coupling_dev(pp_handle h, const double* rc_dev) {
+  if (!h || !h->schur_done) return fail(h, 3, "pp_solve_coupling_dev before pp_factor_schur");
+  PP_HIP(hipSetDevice(h->device));
+  hipStream_t st = h->stream;
+  const int nc = h->nc;
+  if (nc == 0) return 0;
+  PhaseScope ps(h, 6, 1);
+  if (nc > BK_THREADS && nc <= 1024)
+    hipLaunchKernelGGL((k_coupling_solve<1024, 16>), dim3(1), dim3(1024), (size_t)nc * sizeof(double), st, nc, h->Sfac,
+                       h->ipiv, h->Sldl, h->dvec, h->dense_mode, rc_dev, h->rs, h->xc);
+  else
+    hipLaunchKernelGGL((k_coupling_solve<BK_THREADS, 32>), dim3(1), dim3(BK_THREADS), (size_t)nc * sizeof(double), st, nc,
+                       h->Sfac, h->ipiv, h->Sldl, h->dvec, h->dense_mode, rc_dev, h->rs, h->xc);
+  PP_HIP(hipGetLastError());
+  return 0;
+}
+
+double* pp_coupling_solution_buffer(pp_handle h) { return (h && h->symbolic_done) ? h->xc : nullptr; }
+
+int pp_copy_coupling_solution(pp_handle h, double* dev_ptr) {
+  if (!h || !h->schur_done) return fail(h, 3, "pp_copy_coupling_solution before pp_factor_schur");
+  PP_HIP(hipSetDevice(h->device));
+  if (h->nc > 0) PP_HIP(hipMemcpyAsync(dev_ptr, h->xc, (size_t)h->nc * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  return 0;
+}
+
+int pp_bind_solution_buffer(pp_handle h, int group, double* dev_ptr) {
+  Group* g = get_group(h, group);
+  if (!g || !h->symbolic_done) return fail(h, 3, "pp_bind_solution_buffer: bad group");
+  if (int rc = alloc_value_storage(h)) return rc;
+  g->dev.xout = dev_ptr ? dev_ptr : g->xout_own;
+  return 0;
+}
+
 int pp_solve_backward(pp_handle h) {
   if (!h || !h->schur_done) return fail(h, 3, "pp_solve_backward before pp_factor_schur");
   PP_HIP(hipSetDevice(h->device));
@@ -2526,6 +2686,7 @@ int pp_bind_raw_buffer(pp_handle h, int group, double* dev_ptr) {
   Group* g = get_group(h, group);
   if (!g || !h->symbolic_done) return fail(h, 3, "pp_bind_raw_buffer: bad group");
   g->dev.raw = dev_ptr ? dev_ptr : g->raw_own;
+  g->input_mode = Group::IN_RAW;
   return 0;
 }
 
@@ -2660,8 +2821,7 @@ int pp_set_diagonal_classes(pp_handle h, int group, const int8_t* cls) {
   // raw index -> compact row of the transposed input (same rule as pp_end_symbolic)
   {
     std::vector<int> rawmap((size_t)std::max(g->nraw, 1), -1);
-    int nused = 0;
-    for (int v : g->can_idx) if (rawmap[(size_t)v] < 0) rawmap[(size_t)v] = nused++;
+    for (size_t j = 0; j < g->used_raw.size(); ++j) rawmap[(size_t)g->used_raw[j]] = (int)j;
     for (auto& r : rows) r = rawmap[(size_t)(-1 - r)];
   }
   PP_HIP(hipStreamSynchronize(h->stream));      // a previous shifted factorisation may still read the old arrays
@@ -2691,44 +2851,138 @@ int pp_numeric_local_shifted(pp_handle h, double delta_w, double delta_c) {
 // Host-side staging (no device work): for every block whose raw COO index arrays equal the group's reference
 // arrays, the values go to the block's row of the staging array; same_out[i] tells the caller which blocks it has to
 // canonicalise itself (quirk Q7).  Compare + copy are memory-bound, so they are spread over host threads.
-int pp_stage_values(int nblocks, int nthreads, const int32_t* const* kr, const int32_t* const* kc,
-                    const double* const* kd, const int64_t* knnz, const int32_t* const* br, const int32_t* const* bc,
-                    const double* const* bd, const int64_t* bnnz, const int32_t* ref_kr, const int32_t* ref_kc,
-                    int64_t ref_knnz, const int32_t* ref_br, const int32_t* ref_bc, int64_t ref_bnnz, double* staging,
-                    int64_t row_stride, const int32_t* slots, uint8_t* same_out) {
-  if (nblocks < 0 || !same_out || (nblocks > 0 && (!kr || !kc || !kd || !knnz || !br || !bc || !bd || !bnnz || !staging || !slots)))
-    return 3;
-  if (ref_knnz + ref_bnnz > row_stride) return 3;
-  auto work = [&](int i0, int i1) {
-    for (int i = i0; i < i1; ++i) {
-      bool same = knnz[i] == ref_knnz && bnnz[i] == ref_bnnz;
-      const size_t kb = (size_t)ref_knnz * sizeof(int32_t), bb = (size_t)ref_bnnz * sizeof(int32_t);
-      same = same && (kr[i] == ref_kr || kb == 0 || std::memcmp(kr[i], ref_kr, kb) == 0);
-      same = same && (kc[i] == ref_kc || kb == 0 || std::memcmp(kc[i], ref_kc, kb) == 0);
-      same = same && (br[i] == ref_br || bb == 0 || std::memcmp(br[i], ref_br, bb) == 0);
-      same = same && (bc[i] == ref_bc || bb == 0 || std::memcmp(bc[i], ref_bc, bb) == 0);
-      if (same) {
-        double* row = staging + (size_t)slots[i] * (size_t)row_stride;
-        if (ref_knnz > 0) std::memcpy(row, kd[i], (size_t)ref_knnz * sizeof(double));
-        if (ref_bnnz > 0) std::memcpy(row + ref_knnz, bd[i], (size_t)ref_bnnz * sizeof(double));
+// runs (may be null = everything): triples {first entry, length, destination offset in the row} of the K data and of
+// the border data that are copied -- the entries some canonical entry reads (a KKT block handed over with both
+// triangles has whole runs of upper-triangle entries nobody reads: they are neither staged nor uploaded).
+namespace {
+struct StageArgs {
+  const int32_t* const* kr; const int32_t* const* kc; const double* const* kd; const int64_t* knnz;
+  const int32_t* const* br; const int32_t* const* bc; const double* const* bd; const int64_t* bnnz;
+  const int32_t *ref_kr, *ref_kc; int64_t ref_knnz; const int32_t *ref_br, *ref_bc; int64_t ref_bnnz;
+  int nrunsK; const int64_t* runsK; int nrunsB; const int64_t* runsB;
+  double* staging; int64_t row_stride; const int32_t* slots; uint8_t* same_out;
+};
+
+void stage_range(const StageArgs& a, int i0, int i1) {
+  for (int i = i0; i < i1; ++i) {
+    bool same = a.knnz[i] == a.ref_knnz && a.bnnz[i] == a.ref_bnnz;
+    const size_t kb = (size_t)a.ref_knnz * sizeof(int32_t), bb = (size_t)a.ref_bnnz * sizeof(int32_t);
+    same = same && (a.kr[i] == a.ref_kr || kb == 0 || std::memcmp(a.kr[i], a.ref_kr, kb) == 0);
+    same = same && (a.kc[i] == a.ref_kc || kb == 0 || std::memcmp(a.kc[i], a.ref_kc, kb) == 0);
+    same = same && (a.br[i] == a.ref_br || bb == 0 || std::memcmp(a.br[i], a.ref_br, bb) == 0);
+    same = same && (a.bc[i] == a.ref_bc || bb == 0 || std::memcmp(a.bc[i], a.ref_bc, bb) == 0);
+    if (same) {
+      double* row = a.staging + (size_t)a.slots[i] * (size_t)a.row_stride;
+      if (!a.runsK) {
+        if (a.ref_knnz > 0) std::memcpy(row, a.kd[i], (size_t)a.ref_knnz * sizeof(double));
+        if (a.ref_bnnz > 0) std::memcpy(row + a.ref_knnz, a.bd[i], (size_t)a.ref_bnnz * sizeof(double));
+      } else {
+        for (int r = 0; r < a.nrunsK; ++r)
+          std::memcpy(row + a.runsK[3 * r + 2], a.kd[i] + a.runsK[3 * r], (size_t)a.runsK[3 * r + 1] * sizeof(double));
+        for (int r = 0; r < a.nrunsB; ++r)
+          std::memcpy(row + a.runsB[3 * r + 2], a.bd[i] + a.runsB[3 * r], (size_t)a.runsB[3 * r + 1] * sizeof(double));
       }
-      same_out[i] = same ? 1 : 0;
     }
-  };
-  const int nt = std::max(1, std::min(std::min(nthreads, 64), nblocks));
-  if (nt == 1) { work(0, nblocks); return 0; }
+    a.same_out[i] = same ? 1 : 0;
+  }
+}
+
+void stage_parallel(const StageArgs& a, int i0, int i1, int nthreads) {
+  const int n = i1 - i0;
+  const int nt = std::max(1, std::min(std::min(nthreads, 64), n));
+  if (nt == 1) { stage_range(a, i0, i1); return; }
   std::vector<std::thread> pool;
   pool.reserve((size_t)nt);
   int started = 0;
   try {                           // (no exception may cross the C ABI: what could not be started runs here)
     for (; started < nt; ++started)
-      pool.emplace_back(work, (int)((int64_t)nblocks * started / nt), (int)((int64_t)nblocks * (started + 1) / nt));
+      pool.emplace_back(stage_range, std::cref(a), i0 + (int)((int64_t)n * started / nt), i0 + (int)((int64_t)n * (started + 1) / nt));
   } catch (...) {
   }
-  if (started < nt) work((int)((int64_t)nblocks * started / nt), nblocks);
+  if (started < nt) stage_range(a, i0 + (int)((int64_t)n * started / nt), i1);
   for (auto& th : pool) th.join();
+}
+
+bool stage_args_ok(int nblocks, const StageArgs& a, int64_t need) {
+  if (nblocks < 0 || !a.same_out) return false;
+  if (nblocks > 0 && (!a.kr || !a.kc || !a.kd || !a.knnz || !a.br || !a.bc || !a.bd || !a.bnnz || !a.staging || !a.slots)) return false;
+  if ((a.nrunsK > 0 && !a.runsK) || (a.nrunsB > 0 && !a.runsB)) return false;
+  for (int r = 0; r < a.nrunsK; ++r)
+    if (a.runsK[3 * r] < 0 || a.runsK[3 * r + 1] < 0 || a.runsK[3 * r] + a.runsK[3 * r + 1] > a.ref_knnz || a.runsK[3 * r + 2] < 0 ||
+        a.runsK[3 * r + 2] + a.runsK[3 * r + 1] > a.row_stride) return false;
+  for (int r = 0; r < a.nrunsB; ++r)
+    if (a.runsB[3 * r] < 0 || a.runsB[3 * r + 1] < 0 || a.runsB[3 * r] + a.runsB[3 * r + 1] > a.ref_bnnz || a.runsB[3 * r + 2] < 0 ||
+        a.runsB[3 * r + 2] + a.runsB[3 * r + 1] > a.row_stride) return false;
+  return need <= a.row_stride;
+}
+}  // namespace
+
+int pp_stage_values(int nblocks, int nthreads, const int32_t* const* kr, const int32_t* const* kc,
+                    const double* const* kd, const int64_t* knnz, const int32_t* const* br, const int32_t* const* bc,
+                    const double* const* bd, const int64_t* bnnz, const int32_t* ref_kr, const int32_t* ref_kc,
+                    int64_t ref_knnz, const int32_t* ref_br, const int32_t* ref_bc, int64_t ref_bnnz, double* staging,
+                    int64_t row_stride, const int32_t* slots, uint8_t* same_out) {
+  const StageArgs a{kr, kc, kd, knnz, br, bc, bd, bnnz, ref_kr, ref_kc, ref_knnz, ref_br, ref_bc, ref_bnnz, 0, nullptr, 0,
+                    nullptr, staging, row_stride, slots, same_out};
+  if (!stage_args_ok(nblocks, a, ref_knnz + ref_bnnz)) return 3;
+  stage_parallel(a, 0, nblocks, nthreads);
   return 0;
 }
+
+int pp_stage_values_runs(int nblocks, int nthreads, const int32_t* const* kr, const int32_t* const* kc,
+                         const double* const* kd, const int64_t* knnz, const int32_t* const* br, const int32_t* const* bc,
+                         const double* const* bd, const int64_t* bnnz, const int32_t* ref_kr, const int32_t* ref_kc,
+                         int64_t ref_knnz, const int32_t* ref_br, const int32_t* ref_bc, int64_t ref_bnnz, int nruns_k,
+                         const int64_t* runs_k, int nruns_b, const int64_t* runs_b, double* staging, int64_t row_stride,
+                         const int32_t* slots, uint8_t* same_out) {
+  const StageArgs a{kr, kc, kd, knnz, br, bc, bd, bnnz, ref_kr, ref_kc, ref_knnz, ref_br, ref_bc, ref_bnnz, nruns_k, runs_k,
+                    nruns_b, runs_b, staging, row_stride, slots, same_out};
+  if (!runs_k || !stage_args_ok(nblocks, a, 0)) return 3;
+  stage_parallel(a, 0, nblocks, nthreads);
+  return 0;
+}
+
+// The same with the upload overlapped: the blocks (ascending slots) are staged in slices and every finished slice of
+// rows goes to the device with an asynchronous copy while the host threads stage the next one (the staging array
+// must be pinned for the copies to be asynchronous).  The rows of blocks reported in same_out as not staged are
+// uploaded by the caller afterwards (pp_upload_values_compact on their row range).
+int pp_stage_upload_compact(pp_handle h, int group, int nblocks, int nthreads, const int32_t* const* kr,
+                            const int32_t* const* kc, const double* const* kd, const int64_t* knnz,
+                            const int32_t* const* br, const int32_t* const* bc, const double* const* bd,
+                            const int64_t* bnnz, const int32_t* ref_kr, const int32_t* ref_kc, int64_t ref_knnz,
+                            const int32_t* ref_br, const int32_t* ref_bc, int64_t ref_bnnz, int nruns_k, const int64_t* runs_k,
+                            int nruns_b, const int64_t* runs_b, double* staging, const int32_t* slots, uint8_t* same_out) {
+  Group* g = get_group(h, group);
+  if (!g || !h->symbolic_done) return fail(h, 3, "pp_stage_upload_compact: bad group or symbolic phase not finished");
+  const StageArgs a{kr, kc, kd, knnz, br, bc, bd, bnnz, ref_kr, ref_kc, ref_knnz, ref_br, ref_bc, ref_bnnz, nruns_k, runs_k,
+                    nruns_b, runs_b, staging, (int64_t)g->nraw_used, slots, same_out};
+  if (!runs_k || !stage_args_ok(nblocks, a, 0)) return fail(h, 3, "pp_stage_upload_compact: bad arguments");
+  for (int i = 0; i < nblocks; ++i)
+    if (slots[i] < 0 || slots[i] >= g->batch || (i > 0 && slots[i] <= slots[i - 1]))
+      return fail(h, 3, "pp_stage_upload_compact: slots must be ascending and inside the batch");
+  PP_HIP(hipSetDevice(h->device));
+  if (int rc = alloc_value_storage(h)) return rc;
+  g->input_mode = Group::IN_COMPACT;
+  const int slice = 128;
+  for (int i0 = 0; i0 < nblocks; i0 += slice) {
+    const int i1 = std::min(nblocks, i0 + slice);
+    stage_parallel(a, i0, i1, nthreads);
+    const size_t stride = (size_t)g->nraw_used;
+    const int r0 = slots[i0], r1 = slots[i1 - 1] + 1;
+    if (stride > 0)
+      PP_HIP(hipMemcpyAsync(g->raw_own + (size_t)r0 * stride, staging + (size_t)r0 * stride, (size_t)(r1 - r0) * stride * sizeof(double),
+                            hipMemcpyHostToDevice, h->stream));
+  }
+  return 0;
+}
+
+// pinned host memory for staging arrays / result buffers of the host boundary (hipHostMalloc; NULL on failure)
+void* pp_host_alloc(int64_t bytes) {
+  void* p = nullptr;
+  if (bytes <= 0 || hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return p;
+}
+void pp_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 int pp_find_zero_pivot(pp_handle h, int group, int32_t* instance_out) {
   Group* g = get_group(h, group);

@@ -169,6 +169,44 @@ class SyntheticKKT(object):
         rhs.set_block(N, np.zeros(self.n_theta))
         return rhs
 
+    # ------------------------------------------------------------------ f2: values as device-resident sources
+    def value_map(self):
+        """(nsrc, src, coef) for the COO entries of K_i followed by those of A_i: what the interior-point interface of
+        this problem holds per scenario are the n_y Hessian diagonal values and the nnz(A) Jacobian values
+        (interfaces/interface.py:432-494: hess_block, jac_eq); every KKT entry is one of them times +-1, or the
+        constant +-1 of an identity block."""
+        n_y, n_t = self.n_y, self.n_theta
+        nnzA = self.A.nnz
+        jac = n_y + np.arange(nnzA)
+        def const(k):
+            return -np.ones(k)
+        src = np.concatenate([np.arange(n_y), const(n_y), jac, const(n_t), const(n_y), jac, const(n_t), const(n_t)])
+        coef = np.concatenate([np.ones(n_y), np.ones(n_y), -np.ones(nnzA), np.ones(n_t), np.ones(n_y), -np.ones(nnzA),
+                               np.ones(n_t), -np.ones(n_t)])
+        return n_y + nnzA, src.astype(np.int32), coef
+
+    def block_sources(self, ndx, iteration=None, per_entry=False):
+        """Source vector of block ndx: Hessian diagonal (2 + eps, optionally varying per entry) and Jacobian values."""
+        diag = np.full(self.n_y, 2.0)
+        if iteration is not None:
+            eps = np.random.default_rng(10_000 * int(iteration) + int(ndx)).uniform(0.0, 0.5)
+            diag = diag + eps * (np.linspace(0.5, 1.5, self.n_y) if per_entry else 1.0)
+        return np.concatenate([diag, self.A.tocoo().data])
+
+    def block_values_from_sources(self, sources):
+        """Raw COO values of K_i (the order of block_values) and of A_i from a source vector, on the host."""
+        nsrc, src, coef = self.value_map()
+        vals = coef * np.where(src >= 0, sources[np.maximum(src, 0)], 1.0)
+        return vals[:self.nnz_per_block], vals[self.nnz_per_block:]
+
+    def build_device_kkt(self, comm=None):
+        """DeviceBlockMatrix of the KKT system: host pattern (iteration 0 values) + value maps; the solver's symbolic
+        phase attaches the source tensors, ``set_sources_from_host`` / the caller's kernels fill them."""
+        from parapint_amd.sparse.device_containers import DeviceBlockMatrix
+        nsrc, src, coef = self.value_map()
+        maps = {ndx: (src, coef) for ndx in self.local_blocks}
+        return DeviceBlockMatrix(self.build_kkt(comm=comm, iteration=0), maps, nsrc)
+
     def check_result(self, sol, comm=None):
         """max |q_est - q_true| over local blocks and |x_c - theta| (create_model.py:60-64, 134-143)."""
         max_err = 0.0

@@ -154,6 +154,38 @@ class _Group(object):
         self.alt_layouts = []               # other raw COO layouts seen: (kr, kc, br, bc, canonical position per entry)
         self._keyK = None
         self._keyB = None
+        # compact staging: only the raw entries some canonical entry reads are staged and uploaded
+        self.used = np.unique(can_idx).astype(np.int64) if can_idx.size else np.zeros(0, dtype=np.int64)
+        cpos = -np.ones(max(nraw, 1), dtype=np.int64)
+        cpos[self.used] = np.arange(self.used.size)
+        self.can_cidx = cpos[can_idx] if can_idx.size else np.zeros(0, dtype=np.int64)   # compact position of every raw duplicate
+        self.runsK, self.runsB = self._runs(self.used, nrawK)
+        self.known_ptrs = set()             # data pointers of index arrays verified equal to the reference arrays
+        self.keep_alive = []                # ... and the arrays themselves, so that a pointer cannot be reused
+
+    @staticmethod
+    def _runs(used, nrawK):
+        """Maximal runs of consecutive used raw entries as {source start, length, destination} triples, split at the
+        boundary between the K data and the border data (include/parapint_hip.h: pp_stage_values_runs)."""
+        runsK, runsB = [], []
+        if used.size:
+            brk = np.flatnonzero(np.diff(used) != 1) + 1
+            starts = np.concatenate([[0], brk])
+            ends = np.concatenate([brk, [used.size]])
+            for a, b in zip(starts, ends):
+                e0, e1 = int(used[a]), int(used[b - 1]) + 1
+                if e0 < nrawK < e1:                       # a run across the boundary
+                    runsK.append((e0, nrawK - e0, a))
+                    runsB.append((0, e1 - nrawK, a + nrawK - e0))
+                elif e0 < nrawK:
+                    runsK.append((e0, e1 - e0, a))
+                else:
+                    runsB.append((e0 - nrawK, e1 - e0, a))
+        return (np.asarray(runsK, dtype=np.int64).reshape(-1, 3), np.asarray(runsB, dtype=np.int64).reshape(-1, 3))
+
+    def canonical_from_compact(self, row):
+        """Canonical values (duplicates summed) from one compact staging row."""
+        return np.add.reduceat(row[self.can_cidx], self.can_ptr[:-1]) if self.can_cidx.size else np.zeros(0)
 
     def keys(self):
         """Sorted int64 keys of the canonical K (column-major tril) and border (row-major) patterns."""
@@ -214,34 +246,103 @@ class HipEngine(object):
         self.ns.check(self.lib.pp_find_zero_pivot(self.ns.h, gid, ctypes.byref(out)), 'pp_find_zero_pivot')
         return int(out.value)
 
-    def stage_values(self, g, items):
-        """items: [(slot, (kr, kc, kd, br, bc, bd))] of one pattern group (int32 / float64, contiguous).  Blocks in
-        the group's reference entry order are copied to their staging rows by the library on host threads; returns
-        one flag per item (False: the caller stages that block itself)."""
+    def alloc_pinned(self, shape):
+        """Page-locked host array (zero-filled): H2D / D2H copies from it are asynchronous and run at PCIe speed.  The
+        memory is released when the last view of the array is gone."""
+        import ctypes
+        import weakref
+        n = int(np.prod(shape))
+        ptr = self.lib.pp_host_alloc(ctypes.c_int64(8 * n)) if n > 0 else None
+        if not ptr:
+            return np.zeros(shape, dtype=np.double)          # pageable: slower, still correct
+        buf = (ctypes.c_double * n).from_address(ptr)
+        weakref.finalize(buf, self.lib.pp_host_free, ptr)
+        arr = np.frombuffer(buf, dtype=np.double).reshape(shape)
+        arr[...] = 0.0
+        return arr
+
+    def stage_upload(self, g, items):
+        """items: [(slot, (kr, kc, kd, br, bc, bd))] of one pattern group, ascending slots (int32 / float64 arrays,
+        contiguous).  The needed runs of every block that is in the group's reference entry order go to its compact
+        staging row and on to the device, slice by slice, with the copies overlapping the staging of the next slice
+        (include/parapint_hip.h: pp_stage_upload_compact); returns one flag per item (False: the caller stages and
+        uploads that block itself)."""
+        import ctypes
         import os
         n = len(items)
         ptr = np.empty((6, n), dtype=np.uint64)
         nnz = np.empty((2, n), dtype=np.int64)
         slots = np.empty(n, dtype=np.int32)
-        for i, (slot, arrays) in enumerate(items):
-            for q in range(6):
-                ptr[q, i] = arrays[q].__array_interface__['data'][0]
-            nnz[0, i] = arrays[2].size
-            nnz[1, i] = arrays[5].size
-            slots[i] = slot
         ref = getattr(g, '_ref32', None)
         if ref is None:
             ref = g._ref32 = [np.ascontiguousarray(r, dtype=np.int32) for r in g.raw_refs]
+            g._refptr = [r.ctypes.data for r in ref]
+        known, refptr = g.known_ptrs, g._refptr
+        for i, (slot, arrays) in enumerate(items):
+            for q in range(6):
+                ptr[q, i] = arrays[q].__array_interface__['data'][0]
+            # index arrays already verified against the reference order (same objects as at an earlier call): hand the
+            # library the reference pointers themselves, so that it skips the comparison
+            for q, r in ((0, 0), (1, 1), (3, 2), (4, 3)):
+                if (int(ptr[q, i]), arrays[q].size) in known:
+                    ptr[q, i] = refptr[r]
+            nnz[0, i] = arrays[2].size
+            nnz[1, i] = arrays[5].size
+            slots[i] = slot
         same = np.zeros(n, dtype=np.uint8)
-        st = g.staging
-        rc = self.lib.pp_stage_values(n, min(16, os.cpu_count() or 1), ptr[0].ctypes.data, ptr[1].ctypes.data,
-                                      ptr[2].ctypes.data, nnz[0].ctypes.data, ptr[3].ctypes.data, ptr[4].ctypes.data,
-                                      ptr[5].ctypes.data, nnz[1].ctypes.data, ref[0].ctypes.data, ref[1].ctypes.data,
-                                      g.nrawK, ref[2].ctypes.data, ref[3].ctypes.data, g.nraw - g.nrawK,
-                                      st.ctypes.data, st.shape[1], slots.ctypes.data, same.ctypes.data)
-        if rc != 0:
-            raise RuntimeError('pp_stage_values failed with status %d' % rc)
-        return same.astype(bool)
+        rk, rb = g.runsK, g.runsB
+        rc = self.lib.pp_stage_upload_compact(self.ns.h, g.gid, n, min(16, os.cpu_count() or 1), ptr[0].ctypes.data,
+                                              ptr[1].ctypes.data, ptr[2].ctypes.data, nnz[0].ctypes.data, ptr[3].ctypes.data,
+                                              ptr[4].ctypes.data, ptr[5].ctypes.data, nnz[1].ctypes.data, ref[0].ctypes.data,
+                                              ref[1].ctypes.data, ctypes.c_int64(g.nrawK), ref[2].ctypes.data,
+                                              ref[3].ctypes.data, ctypes.c_int64(g.nraw - g.nrawK), rk.shape[0],
+                                              rk.ctypes.data, rb.shape[0], rb.ctypes.data, g.staging.ctypes.data,
+                                              slots.ctypes.data, same.ctypes.data)
+        self.ns.check(rc, 'pp_stage_upload_compact')
+        ok = same.astype(bool)
+        if len(known) < 8 * n + 64:
+            for i, (slot, arrays) in enumerate(items):
+                if ok[i]:
+                    for q in (0, 1, 3, 4):
+                        key = (arrays[q].__array_interface__['data'][0], arrays[q].size)
+                        if key not in known:
+                            known.add(key)
+                            g.keep_alive.append(arrays[q])
+        return ok
+
+    def upload_values_compact(self, gid, staging, row0=0, nrows=None):
+        nrows = staging.shape[0] - row0 if nrows is None else nrows
+        self.ns.check(self.lib.pp_upload_values_compact(self.ns.h, gid, staging.ctypes.data, int(row0), int(nrows), 0),
+                      'pp_upload_values_compact')
+
+    def set_value_map(self, gid, nsrc, src, coef):
+        s32 = np.ascontiguousarray(src, dtype=np.int32)
+        c64 = np.ascontiguousarray(coef, dtype=np.double)
+        import ctypes
+        self.ns.check(self.lib.pp_set_value_map(self.ns.h, gid, int(nsrc), s32.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                                c64.ctypes.data_as(ctypes.POINTER(ctypes.c_double))), 'pp_set_value_map')
+
+    def new_tensor(self, shape):
+        torch = self._torch
+        return torch.zeros(shape, dtype=torch.float64, device=torch.device('cuda', self.device))
+
+    def bind_source_tensor(self, gid, tensor):
+        self.ns.check(self.lib.pp_bind_source_buffer(self.ns.h, gid, tensor.data_ptr()), 'pp_bind_source_buffer')
+
+    def bind_rhs_tensor(self, gid, tensor):
+        self.ns.check(self.lib.pp_bind_rhs_buffer(self.ns.h, gid, tensor.data_ptr() if tensor is not None else None),
+                      'pp_bind_rhs_buffer')
+
+    def bind_solution_tensor(self, gid, tensor):
+        self.ns.check(self.lib.pp_bind_solution_buffer(self.ns.h, gid, tensor.data_ptr() if tensor is not None else None),
+                      'pp_bind_solution_buffer')
+
+    def solve_coupling_dev(self, tensor):
+        self.ns.check(self.lib.pp_solve_coupling_dev(self.ns.h, tensor.data_ptr() if tensor is not None else None),
+                      'pp_solve_coupling_dev')
+
+    def copy_coupling_solution(self, tensor):
+        self.ns.check(self.lib.pp_copy_coupling_solution(self.ns.h, tensor.data_ptr()), 'pp_copy_coupling_solution')
 
     def upload_values(self, gid, raw):
         self.ns.check(self.lib.pp_upload_values(self.ns.h, gid, raw.ctypes.data, 0), 'pp_upload_values')
@@ -394,7 +495,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         return 'hip_schur_complement'
 
     def __init__(self, subproblem_solvers=None, schur_complement_solver=None, comm=None, engine=None,
-                 memory_budget_bytes=None):
+                 memory_budget_bytes=None, result_buffers=2):
         self.subproblem_solvers = subproblem_solvers
         self.schur_complement_solver = schur_complement_solver
         self.comm = default_comm() if comm is None else comm
@@ -405,6 +506,13 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         if memory_budget_bytes is not None:
             self._eng.set_memory_budget(memory_budget_bytes)
         self._classes = None                # regularisation classes by block index (kept across re-plans)
+        self._device_maps = None            # (nsrc, value maps by block index) of a DeviceBlockMatrix (f2)
+        self._dev_results = []
+        self._dev_turn = 0
+        # do_back_solve hands out views of page-locked result buffers used in turn (D2H at PCIe speed, no 75 MB
+        # allocation per call at the headline size): a result stays valid until `result_buffers` further back-solves
+        # have been made; 0 = a fresh pageable array per call (results never alias)
+        self._result_buffers = max(0, int(result_buffers))
         self.block_dim = 0
         self.block_matrix = None
         self.local_block_indices = []
@@ -504,10 +612,14 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
                     g.rep_vals = vals
             if np.any(kd != 0.0):
                 all_zero = False
+        pinned = getattr(self._eng, 'alloc_pinned', None)
+        alloc = pinned if pinned is not None else (lambda shape: np.zeros(shape, dtype=np.double))
         for g in groups:
-            g.staging = np.zeros((len(g.blocks), g.nraw), dtype=np.double)
-            g.rhs_staging = np.zeros((len(g.blocks), g.n), dtype=np.double)
+            g.staging = alloc((len(g.blocks), g.used.size))        # compact rows: only the entries that are read
+            g.rhs_staging = alloc((len(g.blocks), g.n))
             g.x_shape = (len(g.blocks), g.n)
+            g.x_pool = [alloc(g.x_shape) for _ in range(self._result_buffers)] if pinned is not None else []
+            g.x_turn = 0
         self._groups, self._binfo = groups, binfo
         self._pattern_only = any(g.rep_vals is None for g in groups)
         return all_zero
@@ -554,16 +666,19 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         return np.bincount(pos[keep], weights=raw[keep], minlength=ncan)
 
     def _stage_values(self, matrix):
+        """Values of every local block into the group's compact staging array (pinned), and on to the device."""
         last = self.block_dim - 1
-        fast = getattr(self._eng, 'stage_values', None)     # threaded compare + copy in the library (host only)
+        fast = getattr(self._eng, 'stage_upload', None)     # threaded compare + copy + overlapped H2D in the library
         batches = {}
+        slow = {}
+        empty_i, empty_d = np.zeros(0, dtype=np.int32), np.zeros(0)
         for ndx in self.local_block_indices:
             bi = self._binfo[ndx]
             g = bi.group
             kr, kc, kd, _ = _coo(matrix.get_block(ndx, ndx))
             A = matrix.get_block(last, ndx)
             if A is None:
-                br, bc, bd = np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int32), np.zeros(0)
+                br, bc, bd = empty_i, empty_i, empty_d
             else:
                 br, bc, bd, _ = _coo(A)
             arrays = (kr, kc, kd, br, bc, bd)
@@ -572,11 +687,21 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
                 batches.setdefault(g.gid, (g, []))[1].append((bi.slot, arrays))
             else:
                 self._stage_block(g, bi.slot, *arrays)
+                slow.setdefault(g.gid, (g, []))[1].append(bi.slot)
         for g, items in batches.values():
+            items.sort(key=lambda it: it[0])
             same = fast(g, items)
             for ok, (slot, arrays) in zip(same, items):
                 if not ok:
                     self._stage_block(g, slot, *arrays)
+                    slow.setdefault(g.gid, (g, []))[1].append(slot)
+        if fast is None:
+            for g in self._groups:
+                self._eng.upload_values_compact(g.gid, g.staging)
+        else:
+            for g, slots in slow.values():                   # rows the library did not stage itself
+                for slot in slots:
+                    self._eng.upload_values_compact(g.gid, g.staging, slot, 1)
 
     def _stage_block(self, g, slot, kr, kc, kd, br, bc, bd):
         ref = g.raw_refs
@@ -585,16 +710,20 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
                 (br is ref[2] or np.array_equal(br, ref[2])) and (bc is ref[3] or np.array_equal(bc, ref[3])))
         row = g.staging[slot]
         if same:
-            row[:g.nrawK] = kd
-            row[g.nrawK:] = bd
+            for e0, ln, dst in g.runsK:
+                row[dst:dst + ln] = kd[e0:e0 + ln]
+            for e0, ln, dst in g.runsB:
+                row[dst:dst + ln] = bd[e0:e0 + ln]
         else:
             vals = self._canonical_values(g, np.concatenate([kd, bd]), kr, kc, br, bc, False)
             row[:] = 0.0
-            row[g.can_idx[g.can_ptr[:-1]]] = vals      # canonical sum on the first raw slot of each entry
+            row[g.can_cidx[g.can_ptr[:-1]]] = vals     # canonical sum on the first raw slot of each entry
 
     def _run_symbolic(self):
         self.plan_stats = self._eng.symbolic(self._nc, self._groups)
         self._have_classes = False
+        if self._device_maps is not None:     # value maps are per plan, too
+            self._apply_value_maps()
         if self._classes is not None:         # classes are per plan: apply them to the new one
             try:
                 self._apply_classes()
@@ -602,6 +731,46 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
                 # a classed row without a diagonal entry in the new plan: the fast path stays off until
                 # set_regularization_classes is called again; the ordinary path is unaffected
                 self._have_classes = False
+
+    def _apply_value_maps(self):
+        nsrc, maps = self._device_maps
+        for g in self._groups:
+            src, coef = maps[g.blocks[0]]
+            for ndx in g.blocks[1:]:
+                s2, c2 = maps[ndx]
+                if not (np.array_equal(src, s2) and np.array_equal(coef, c2)):
+                    raise ValueError('blocks of one pattern group must share one value map (block %d differs)' % ndx)
+            if len(src) != g.nraw:
+                raise ValueError('value map of block %d has %d entries, the block has %d' % (g.blocks[0], len(src), g.nraw))
+            self._eng.set_value_map(g.gid, nsrc, src, coef)
+
+    def device_layout(self):
+        """{block index: (group id, lane)} of the local blocks, and {group id: (batch, padded batch, block dimension)}."""
+        layout = {ndx: (bi.group.gid, bi.slot) for ndx, bi in self._binfo.items()}
+        dims = {g.gid: (len(g.blocks), -(-len(g.blocks) // 64) * 64, g.n) for g in self._groups}
+        return layout, dims
+
+    def new_device_vector(self):
+        """A DeviceBlockVector with the structure of this solver's right-hand sides (zero-filled)."""
+        from parapint_amd.sparse.device_containers import DeviceBlockVector
+        layout, dims = self.device_layout()
+        v = DeviceBlockVector(self.block_dim, layout)
+        for gid, (batch, _, n) in dims.items():
+            v.group_tensors[gid] = self._eng.new_tensor((batch, n))
+        v.coupling = self._eng.new_tensor((max(self._nc, 1),))[:self._nc]
+        return v
+
+    def device_vector_from_host(self, bv):
+        import torch
+        v = self.new_device_vector()
+        for g in self._groups:
+            host = np.zeros(g.x_shape)
+            for slot, ndx in enumerate(g.blocks):
+                host[slot] = _flat(bv.get_block(ndx))
+            v.group_tensors[g.gid].copy_(torch.from_numpy(host))
+        if self._nc > 0:
+            v.coupling.copy_(torch.from_numpy(np.ascontiguousarray(_flat(bv.get_block(self.block_dim - 1)))))
+        return v
 
     def _apply_classes(self):
         for g in self._groups:
@@ -647,10 +816,15 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         self._inertia = None
         self._num_status = None
         self._classes = None
+        self._dev_results = []
+        device_matrix = hasattr(matrix, 'value_maps')
+        self._device_maps = (matrix.nsrc, matrix.value_maps) if device_matrix else None
         res = LinearSolverResults(LinearSolverStatus.successful)
         timer.start('factorize')
-        self._guarded(res, self._build_groups, matrix)
+        self._guarded(res, self._build_groups, matrix.pattern if device_matrix else matrix)
         self._guarded(res, self._run_symbolic)
+        if device_matrix:
+            self._guarded(res, self._attach_device_matrix, matrix)
         timer.stop('factorize')
         res.status = self._agree_status(res.status)
         if res.status not in _OK:
@@ -684,12 +858,18 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         rank learns whether any rank re-planned (all of them then factorise again)."""
         mine = 0
         for g in self._groups:
-            if g.staging is None:
-                continue                        # device-resident values: no host copy to order from
             slot = self._eng.find_zero_pivot(g.gid)
             if slot >= 0:
-                raw = g.staging[slot]
-                g.rep_vals = np.add.reduceat(raw[g.can_idx], g.can_ptr[:-1]) if g.can_idx.size else np.zeros(0)
+                t = getattr(g, 'device_sources', None)
+                if self._device_maps is not None and t is not None:
+                    # device-resident values (f2): that instance's sources come to the host once
+                    src, coef = self._device_maps[1][g.blocks[0]]
+                    col = t[:, slot].cpu().numpy()
+                    src = np.asarray(src)
+                    raw = np.asarray(coef, dtype=np.double) * np.where(src >= 0, col[np.maximum(src, 0)], 1.0)
+                    g.rep_vals = np.add.reduceat(raw[g.can_idx], g.can_ptr[:-1]) if g.can_idx.size else np.zeros(0)
+                else:
+                    g.rep_vals = g.canonical_from_compact(g.staging[slot])
                 mine = 1
         anyone = mine
         if self.comm.size > 1:
@@ -707,7 +887,10 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         res = LinearSolverResults(LinearSolverStatus.successful)
         timer.start('form SC')
         timer.start('factorize')
-        self._guarded(res, self._stage_and_upload, matrix)
+        if hasattr(matrix, 'value_maps'):
+            self._guarded(res, self._bind_device_matrix, matrix)      # f2: values are gathered from the device sources
+        else:
+            self._guarded(res, self._stage_and_upload, matrix)
         self._guarded(res, self._eng.numeric_factor_blocks)
         timer.stop('factorize')
         # the n_c solves + products per block of the reference (mpi_...:312-333) are the coupling rows of the same
@@ -717,9 +900,30 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         timer.stop('back solve')
         timer.start('dot product')
         timer.stop('dot product')
-        Q = self._guarded(res, self._coupling_block, matrix)
+        Q = matrix.Q if hasattr(matrix, 'value_maps') else self._guarded(res, self._coupling_block, matrix)
         self._base_Q = Q
         return self._finish_numeric(res, Q, timer)
+
+    def _attach_device_matrix(self, matrix):
+        """Source tensors ([nsrc][padded batch], zero-filled) and the lane order of every group, for the producer."""
+        matrix.sources, matrix.slots = {}, {}
+        for g in self._groups:
+            bpad = -(-len(g.blocks) // 64) * 64
+            matrix.sources[g.gid] = self._eng.new_tensor((matrix.nsrc, bpad))
+            matrix.slots[g.gid] = list(g.blocks)
+        self._bind_device_matrix(matrix)
+
+    def _bind_device_matrix(self, matrix):
+        if self._device_maps is None or matrix.value_maps is not self._device_maps[1]:
+            raise RuntimeError('this matrix was not given to do_symbolic_factorization (value maps differ)')
+        for g in self._groups:
+            t = matrix.sources.get(g.gid)
+            bpad = -(-len(g.blocks) // 64) * 64
+            if t is None or tuple(t.shape) != (matrix.nsrc, bpad) or not t.is_contiguous():
+                raise ValueError('source tensor of group %d must be a contiguous [%d][%d] float64 device tensor' %
+                                 (g.gid, matrix.nsrc, bpad))
+            self._eng.bind_source_tensor(g.gid, t)
+            g.device_sources = t
 
     def _stage_and_upload(self, matrix):
         try:
@@ -733,12 +937,11 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             # symbolic saw no usable values (quirk Q8): fix the pivot sequence now
             for g in self._groups:
                 if g.rep_vals is None:
-                    g.rep_vals = np.add.reduceat(g.staging[0][g.can_idx], g.can_ptr[:-1]) if g.can_idx.size \
-                        else np.zeros(0)
+                    g.rep_vals = g.canonical_from_compact(g.staging[0])
             self._run_symbolic()
             self._pattern_only = False
-        for g in self._groups:
-            self._eng.upload_values(g.gid, g.staging)
+            for g in self._groups:                           # (the new plan's device buffers are empty)
+                self._eng.upload_values_compact(g.gid, g.staging)
 
     def _coupling_block(self, matrix):
         last = self.block_dim - 1
@@ -848,8 +1051,13 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             timer = _NullTimer()
         if self._num_status is None:
             raise RuntimeError('Perform numeric factorization first!')
+        if hasattr(rhs, 'group_tensors'):
+            return self._device_back_solve(rhs, timer)
         timer.start('back_solve')
         last = self.block_dim - 1
+        for g in self._groups:
+            self._eng.bind_rhs_tensor(g.gid, None) if hasattr(self._eng, 'bind_rhs_tensor') else None
+            self._eng.bind_solution_tensor(g.gid, None) if hasattr(self._eng, 'bind_solution_tensor') else None
         for ndx in self.local_block_indices:
             bi = self._binfo[ndx]
             bi.group.rhs_staging[bi.slot] = _flat(rhs.get_block(ndx))
@@ -864,7 +1072,11 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         for g in self._groups:
             # one fresh array per group and call: its rows are handed out as the result blocks (no per-block copy;
             # results of different calls never alias)
-            xout[g.gid] = np.empty(g.x_shape, dtype=np.double)
+            if g.x_pool:
+                xout[g.gid] = g.x_pool[g.x_turn % len(g.x_pool)]
+                g.x_turn += 1
+            else:
+                xout[g.gid] = np.empty(g.x_shape, dtype=np.double)
             self._eng.download_solution(g.gid, xout[g.gid])
         coupling = self._eng.coupling_solution()
         # (mpi_...:390 uses copy_structure(); every local block and the coupling block are set below and non-local
@@ -887,6 +1099,26 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         result.set_block(last, coupling)
         timer.stop('back_solve')
         return result
+
+    def _device_back_solve(self, rhs, timer):
+        """do_back_solve for a DeviceBlockVector: right-hand sides are read where they are, the solution is written
+        into device tensors handed out in turn (valid until `result_buffers` further back-solves); no host copies."""
+        timer.start('back_solve')
+        if not self._dev_results:
+            self._dev_results = [self.new_device_vector() for _ in range(max(1, self._result_buffers))]
+        out = self._dev_results[self._dev_turn % len(self._dev_results)]
+        self._dev_turn += 1
+        for g in self._groups:
+            self._eng.bind_rhs_tensor(g.gid, rhs.group_tensors[g.gid])
+            self._eng.bind_solution_tensor(g.gid, out.group_tensors[g.gid])
+        self._eng.solve_forward()
+        self._eng.allreduce_rs(self.comm)
+        self._eng.solve_coupling_dev(rhs.coupling if self._nc > 0 else None)
+        self._eng.solve_backward()
+        if self._nc > 0:
+            self._eng.copy_coupling_solution(out.coupling)
+        timer.stop('back_solve')
+        return out
 
     def get_inertia(self):
         if self._num_status is None:

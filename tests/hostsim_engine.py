@@ -63,6 +63,15 @@ class HostSimEngine(object):
     def upload_values(self, gid, raw):
         self.groups[gid].raw = np.array(raw, dtype=np.double, copy=True)
 
+    def upload_values_compact(self, gid, compact, row0=0, nrows=None):
+        """Compact rows (only the raw entries some canonical entry reads, solver._Group.used) -> full raw rows."""
+        sg = self.groups[gid]
+        g = sg.g
+        if sg.raw is None or sg.raw.shape != (sg.batch, g.nraw):
+            sg.raw = np.zeros((sg.batch, g.nraw))
+        nrows = compact.shape[0] - row0 if nrows is None else nrows
+        sg.raw[row0:row0 + nrows][:, g.used] = compact[row0:row0 + nrows]
+
     def numeric_local(self):
         L = hu.lib()
         nc = self.nc

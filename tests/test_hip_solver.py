@@ -162,6 +162,56 @@ def test_config5_shaped_blocks():
     assert np.abs(S[:, cols] - S_ref).max() <= 1e-9 * np.abs(S_ref).max()
 
 
+def test_device_resident_matrix_and_vectors_f2():
+    """the KKT values gathered on the device from the interface's own arrays (Hessian diagonal, Jacobian
+    values; value map of sc_ip_interface.py:1677-1681 / interface.py:432-494) and device-resident right-hand sides /
+    solutions, against the host COO path of the same class on the same values: S and x bit for bit (the kernels see
+    identical inputs), and against the assembled system by residual.  70 blocks = a full wave + a ragged one."""
+    import torch
+    from scipy.sparse import coo_matrix
+    from parapint_amd.examples.performance.schur_complement.synthetic_kkt import SyntheticKKT
+    from parapint_amd.linalg.comm import SerialComm
+    from parapint_amd.sparse.block_containers import BlockMatrix
+    N = 70
+    model = SyntheticKKT(N, 30, 2, 10)
+    rhs = model.build_rhs(comm=SerialComm())
+    dev = sc.new_solver(make_engine, N)
+    dk = model.build_device_kkt(comm=SerialComm())
+    assert dev.do_symbolic_factorization(matrix=dk, raise_on_error=False).status.value == 0
+    host = sc.new_solver(make_engine, N)
+    host.do_symbolic_factorization(model.build_kkt(comm=SerialComm(), iteration=0))
+    rhs_dev = dev.device_vector_from_host(rhs)
+    base_sources = dict(dk.sources)
+    for it, per_entry in ((3, False), (4, True)):
+        srcs = {ndx: model.block_sources(ndx, it, per_entry=per_entry) for ndx in range(N)}
+        if per_entry:                                   # a second value set in tensors of its own (what a producer cycles)
+            dk_it = dk.with_sources({gid: torch.zeros_like(t) for gid, t in base_sources.items()})
+        else:
+            dk_it = dk
+        dk_it.set_sources_from_host(srcs)
+        assert dev.do_numeric_factorization(matrix=dk_it, raise_on_error=False).status.value == 0
+        x = dev.do_back_solve(rhs_dev)
+        assert x.get_block(0).is_cuda and x.get_block(N).is_cuda
+        xh = x.to_host(rhs)
+        # the same values through the host boundary
+        kkt = BlockMatrix(N + 1, N + 1)
+        A = model.border_matrix()
+        for ndx in range(N):
+            kv, bv = model.block_values_from_sources(srcs[ndx])
+            kkt.set_block(ndx, ndx, coo_matrix((kv, (model._row, model._col)), shape=(model.block_dim,) * 2))
+            kkt.set_block(N, ndx, coo_matrix((bv, (A.row, A.col)), shape=A.shape))
+        kkt.set_block(N, N, coo_matrix((10, 10)))
+        host.do_numeric_factorization(kkt)
+        x_ref = host.do_back_solve(rhs)
+        assert np.array_equal(dev.get_schur_complement(), host.get_schur_complement())
+        assert np.array_equal(xh.flatten(), x_ref.flatten())
+        assert dev.get_inertia() == host.get_inertia()
+        assert sc.scaled_residual(kkt.tocoo(), xh.flatten(), rhs.flatten()) <= sc.RESID_TOL
+    # a host matrix can still be given to the same solver object afterwards
+    dev.do_numeric_factorization(kkt)
+    assert np.array_equal(dev.do_back_solve(rhs).flatten(), x_ref.flatten())
+
+
 def test_dense_schur_paths_agree():
     """S of the synthetic KKT is positive definite: the blocked MFMA LDL^T must be accepted and
     give the same solution as the Bunch-Kaufman kernel (ragged last panel: n_c = 100, 200, 37)."""

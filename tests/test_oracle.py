@@ -139,3 +139,21 @@ def test_known_answer_full_space_and_schur(golden):
     assert abs(model.check_result(xs) - float(golden['known_answer_psc'][0])) < 1e-10
     assert np.allclose(solver.schur_complement.toarray(), golden['known_answer_S'], rtol=1e-9, atol=1e-9)
     assert np.allclose(xs.get_block(3), golden['known_answer_xc'], rtol=1e-9, atol=1e-9)
+
+
+def test_value_map_of_the_synthetic_kkt_matches_the_assembled_blocks():
+    """f2 parity on the host: gathering every COO entry of K_i and A_i from the interface's arrays through the value
+    map reproduces ``build_kkt()`` entry for entry (per-block and per-iteration values, both value patterns)."""
+    import numpy as np
+    from parapint_amd.examples.performance.schur_complement.synthetic_kkt import SyntheticKKT
+    from parapint_amd.linalg.comm import SerialComm
+    model = SyntheticKKT(4, 25, 3, 6)
+    nsrc, src, coef = model.value_map()
+    N = model.n_blocks
+    for it in (None, 2):
+        kkt = model.build_kkt(comm=SerialComm(), iteration=it)
+        for ndx in range(N):
+            kv, bv = model.block_values_from_sources(model.block_sources(ndx, it))
+            K, A = kkt.get_block(ndx, ndx).tocoo(), kkt.get_block(N, ndx).tocoo()
+            assert src.size == K.nnz + A.nnz and nsrc == model.n_y + model.A.nnz
+            assert np.array_equal(kv, K.data) and np.array_equal(bv, A.data)
