@@ -1,23 +1,28 @@
 #!/usr/bin/env python
 """Benchmark of the hot path: interior-point iterations / second on the synthetic stochastic KKT.
 
-One step = one IP-iteration-equivalent of linear algebra (reference call
-sites parapint/algorithms/interior_point.py:553-567): ONE numeric factorisation on fresh values
-(same pattern) + ONE back-solve, including the status/inertia read-back the IP loop needs.
-Inputs (K_i values of every block for that iteration, right-hand sides) are resident in HBM when
-the timed region starts; the PCIe-inclusive rate through the LinearSolverInterface boundary is
-measured separately and reported in `boundary`.
+One step = one IP-iteration-equivalent of linear algebra (reference call sites
+parapint/algorithms/interior_point.py:553-567): ONE ``do_numeric_factorization`` on fresh values (same pattern) + ONE
+``do_back_solve``, called through the ``LinearSolverInterface`` methods with the reference's keywords, including the
+status / inertia read-back the IP loop needs.  Inputs are resident in HBM when the timed region starts: the matrix
+is a ``DeviceBlockMatrix`` (the interface's own Hessian / Jacobian arrays as device sources + the value map fixed at
+symbolic time), the right-hand side and the solution are ``DeviceBlockVector``s.  Reported beside it:
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+  boundary_host   the same two calls with host SciPy COO blocks in and host vectors out (staging + PCIe inside)
+  device_only     the kernels driven through the C ABI without the Python class
+  cpu_baseline    the reference algorithm (SuperLU sub-solver) on the host cores
 
-Workload: BASELINE.json configs[2] (the one the metric is quoted on): 1024 scenarios x
-(n_q=1000, n_y=4000 -> 5000 primal vars, block dim 9200), 200 coupling variables, sharded
-round-robin over the ranks (strong scaling: the total is fixed).
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3|C2]
+
+For N > 1 the script starts its own N ranks (``python -m torch.distributed.run``) unless it already runs under one.
+Workload C3 = BASELINE.json configs[2] (the one the metric is quoted on): 1024 scenarios x (n_q=1000, n_y=4000 -> 5000
+primal vars, block dim 9200), 200 coupling variables, sharded round-robin over the ranks (strong scaling).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,6 +37,7 @@ PHASES = ['assemble', 'factor_levels', 'schur_tiles', 'dense_S', 'fwd_levels', '
           'bwd_levels']
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_MFMA_PEAK_TF = 78.6    # MI355X public spec for fp64 matrix (= fp64 vector) throughput, SURVEY 8d
+WORKLOADS = {'C3': (1024, 1000, 4, 200), 'C2': (64, 400, 4, 100)}
 
 
 def parse_args():
@@ -39,18 +45,34 @@ def parse_args():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--blocks', type=int, default=1024)
-    ap.add_argument('--n-q', type=int, default=1000)
-    ap.add_argument('--m', type=int, default=4)
-    ap.add_argument('--n-theta', type=int, default=200)
-    ap.add_argument('--value-sets', type=int, default=6, help='distinct pre-staged value sets cycled through')
+    ap.add_argument('--workload', default='C3', choices=sorted(WORKLOADS))
+    ap.add_argument('--blocks', type=int, default=0, help='override the number of scenario blocks')
+    ap.add_argument('--n-q', type=int, default=0)
+    ap.add_argument('--m', type=int, default=0)
+    ap.add_argument('--n-theta', type=int, default=0)
+    ap.add_argument('--value-sets', type=int, default=6, help='distinct device-resident value sets cycled through')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-boundary', action='store_true')
+    ap.add_argument('--boundary-iterations', type=int, default=6)
     ap.add_argument('--profile-steps', type=int, default=5)
     ap.add_argument('--sn-wmax', type=int, default=0, help='supernode width cap (0: library default)')
     ap.add_argument('--sn-tol', type=int, default=-1, help='padded rows tolerated when merging (-1: default)')
-    ap.add_argument('--splits', type=int, default=0, help='instance splits on separate streams (0: library default)')
     return ap.parse_args()
+
+
+def spawn_ranks(n):
+    """Start n ranks of this script the way the driver would (one process per GPU, rendezvous on 127.0.0.1) and hand
+    their exit code on.  Runs before anything touches the GPU."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    return subprocess.call(cmd, env=env)
 
 
 def survey_bytes_per_block(z_K, z_L, n_i, n_c, z_A):
@@ -61,15 +83,33 @@ def survey_bytes_per_block(z_K, z_L, n_i, n_c, z_A):
     return {'factor': b_fac, 'schur': b_sc, 'back_solve': b_bs, 'total': b_fac + b_sc + b_bs}
 
 
+def build_bytes_per_block(st, ex, n_c, batch):
+    """What THIS implementation has to move per block and iteration if every operand crossed HBM exactly once: values
+    only -- the index data (task records, entry lists) is shared by all instances of a pattern group and amortised
+    over the batch.  U and L panels are both stored (2 z_L); the Schur kernel reads only the coupling rows."""
+    z_L, n = st['u_doubles'], st['n']
+    idx = ex['index_bytes'] / max(1, batch)
+    b = {
+        'assemble': 8.0 * (ex['nsrc'] + ex['raw_used']),
+        'factor_levels': 8.0 * (ex['raw_used'] + 2 * z_L + 2 * z_L + ex['dinv_doubles'] + 2 * ex['tm_doubles']) + idx,
+        'schur_tiles': 8.0 * (2 * ex['coupling_entries']) + 8.0 * n_c * n_c * ex['nchunk'] / max(1, batch),
+        'fwd_levels': 8.0 * (2 * n + ex['fwd_entries'] + 2 * n),
+        'fwd_coupling': 8.0 * (ex['crow_entries'] + n),
+        'bwd_levels': 8.0 * ((z_L - ex['tm_doubles']) + ex['dinv_doubles'] + n + 2 * n + 2 * n),
+    }
+    b['total'] = sum(b.values())
+    return b
+
+
 def main():
     args = parse_args()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run for --gpus > 1')
-    N, n_q, m, n_t = args.blocks, args.n_q, args.m, args.n_theta
+    N, n_q, m, n_t = WORKLOADS[args.workload]
+    N, n_q, m, n_t = args.blocks or N, args.n_q or n_q, args.m or m, args.n_theta or n_t
 
     # ---- CPU baseline first: it forks worker processes, so it runs before the GPU is touched
     cpu_baseline = None
@@ -82,6 +122,7 @@ def main():
     from parapint_amd.examples.performance.schur_complement.synthetic_kkt import SyntheticKKT, distribute_blocks
     from parapint_amd.linalg.comm import SerialComm, TorchComm
     from parapint_amd.linalg.hip_schur_complement import HipSchurComplementLinearSolver
+    from parapint_amd.linalg.results import LinearSolverStatus
 
     # Rehearsal switch (not the measured configuration): PP_BENCH_REHEARSAL=gloo lets several ranks share the GPUs
     # that are present and exchange through gloo (host-staged all-reduce), to exercise the N > 1 code path on a
@@ -90,6 +131,7 @@ def main():
     if rehearsal:
         local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
+    backend = 'none'
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if rehearsal:
@@ -97,6 +139,7 @@ def main():
         else:
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
         comm = TorchComm()
+        backend = comm.backend
     else:
         comm = SerialComm()
     dev = torch.device('cuda', local_rank)
@@ -106,44 +149,19 @@ def main():
     B = len(local)
     solver = HipSchurComplementLinearSolver({i: None for i in local}, None, comm=comm)
     eng = solver._eng
+    lib, h = eng.lib, eng.ns.h
     if args.sn_wmax > 0 or args.sn_tol >= 0:
         eng.set_supernodes(args.sn_wmax, args.sn_tol)
-    if args.splits > 0:
-        eng.ns.check(eng.lib.pp_set_instance_splits(eng.ns.h, args.splits), 'pp_set_instance_splits')
+    A = model.border_matrix().tocsr()
+    expected_inertia = (N * (model.n_y + n_q) + n_t, N * (model.n_y + n_t), 0)
 
-    # ---- through the LinearSolverInterface boundary (host buffers in, host buffers out)
-    kkt = model.build_kkt(comm=comm, iteration=0)
-    rhs = model.build_rhs(comm=comm)
-    t0 = time.perf_counter()
-    solver.do_symbolic_factorization(kkt)
-    t_symbolic = time.perf_counter() - t0
-    st = solver.plan_stats[0]
-    boundary = None
-    t0 = time.perf_counter()
-    solver.do_numeric_factorization(kkt)
-    x = solver.do_back_solve(rhs)
-    t_first = time.perf_counter() - t0
-    if not args.no_boundary:
-        ts = []
-        for it in (1, 2, 3):
-            kkt_it = model.build_kkt(comm=comm, iteration=it)
-            if world > 1:
-                dist.barrier()
-            t0 = time.perf_counter()
-            solver.do_numeric_factorization(kkt_it)
-            x = solver.do_back_solve(rhs)
-            ts.append(time.perf_counter() - t0)
-            kkt = kkt_it
-        boundary = {'it_per_s': 1.0 / float(np.median(ts)), 'ms_per_iteration': 1e3 * float(np.median(ts)),
-                    'note': 'host COO blocks in, host vectors out (staging + PCIe H2D/D2H included)'}
-
-    # ---- correctness gate on the last boundary solve: scaled residual, inertia
-    def residual_check(x_blocks, xc, iteration):
-        A = model.border_matrix().tocsr()
+    def residual_check(values_of, x_blocks, xc):
+        """max over the local block rows and the coupling rows of |Kx - b| / (|K|_inf |x|_inf + |b|_inf)."""
+        from scipy.sparse import coo_matrix
         worst = 0.0
         rc_local = np.zeros(n_t)
         for slot, ndx in enumerate(local):
-            K = model.block_matrix(ndx, iteration).tocsr()
+            K = coo_matrix((values_of(ndx), (model._row, model._col)), shape=(model.block_dim,) * 2).tocsr()
             r = model.block_rhs(ndx)
             xi = x_blocks[slot]
             res = K @ xi + A.T @ xc - r
@@ -151,42 +169,72 @@ def main():
             worst = max(worst, float(np.abs(res).max() / scale))
             rc_local += A @ xi
         rc = comm.allreduce_sum(rc_local) if world > 1 else rc_local
-        worst = max(worst, float(np.abs(rc).max() / (np.abs(xc).max() * B + 1e-300)))
+        worst = max(worst, float(np.abs(rc).max() / (np.abs(xc).max() * N + 1e-300)))
         if world > 1:
             worst = float(comm.allreduce_max(np.array([worst]))[0])
         return worst
 
-    last_it = 0 if args.no_boundary else 3
-    xb = [np.asarray(x.get_block(ndx)) for ndx in local]
-    resid_boundary = residual_check(xb, np.asarray(x.get_block(N)), last_it)
-    inertia = solver.get_inertia()
-    expected_inertia = (N * (model.n_y + n_q) + n_t, N * (model.n_y + n_t), 0)
-    ok = resid_boundary <= 1e-8 and tuple(inertia) == expected_inertia
+    # ---- (1) host boundary: SciPy COO blocks in, host vectors out
+    boundary = None
+    resid_boundary = None
+    ok = True
+    if not args.no_boundary:
+        kkt = model.build_kkt(comm=comm, iteration=0)
+        rhs = model.build_rhs(comm=comm)
+        t0 = time.perf_counter()
+        solver.do_symbolic_factorization(kkt)
+        t_symbolic_host = time.perf_counter() - t0
+        solver.do_numeric_factorization(kkt)
+        solver.do_back_solve(rhs)
+        ts = []
+        for it in range(1, args.boundary_iterations + 1):
+            kkt_it = model.build_kkt(comm=comm, iteration=it)
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            solver.do_numeric_factorization(matrix=kkt_it, raise_on_error=False)
+            x = solver.do_back_solve(rhs)
+            ts.append(time.perf_counter() - t0)
+        med = float(np.median(ts))
+        if world > 1:
+            med = float(comm.allreduce_max(np.array([med]))[0])
+        boundary = {'it_per_s': 1.0 / med, 'ms_per_iteration': 1e3 * med, 'iterations': len(ts),
+                    'note': 'host COO blocks in, host vectors out: needed entries staged into pinned memory on host '
+                            'threads with the H2D overlapped, pinned D2H of x; median, max over ranks'}
+        xb = [np.asarray(x.get_block(ndx)) for ndx in local]
+        it_last = args.boundary_iterations
+        resid_boundary = residual_check(lambda ndx: model.block_values(ndx, it_last), xb, np.asarray(x.get_block(N)))
+        ok = ok and resid_boundary <= 1e-8 and tuple(solver.get_inertia()) == expected_inertia
+        del kkt, kkt_it, x, xb
 
-    # ---- device-resident steps: value sets and right-hand sides staged in HBM beforehand
+    # ---- (2) the measured path: device-resident matrix and vectors through the LinearSolverInterface methods
+    dkkt = model.build_device_kkt(comm=comm)
+    t0 = time.perf_counter()
+    res = solver.do_symbolic_factorization(matrix=dkkt, raise_on_error=False)
+    t_symbolic = time.perf_counter() - t0
+    assert res.status == LinearSolverStatus.successful
+    st = solver.plan_stats[0]
+    ex = eng.ns.group_stats_ex(0)
     nsets = max(2, min(args.value_sets, args.steps + args.warmup))
-    base = np.concatenate([model._base, model.border_matrix().data])
-    raw_sets = []
+    base = np.stack([model.block_sources(ndx, None) for ndx in local])            # [B][nsrc]
+    w = np.linspace(0.5, 1.5, model.n_y)
+    bpad = dkkt.sources[0].shape[1]
+    sets = []
     for s in range(nsets):
-        vals = np.tile(base, (B, 1))
-        for slot, ndx in enumerate(local):
-            vals[slot, :model.n_y] = 2.0 + np.random.default_rng(10_000 * (100 + s) + ndx).uniform(0.0, 0.5)
-        raw_sets.append(torch.from_numpy(vals).to(dev))
-    rhs_dev = torch.from_numpy(np.stack([model.block_rhs(ndx) for ndx in local])).to(dev)
-    lib, h = eng.lib, eng.ns.h
-    eng.ns.check(lib.pp_bind_rhs_buffer(h, 0, rhs_dev.data_ptr()), 'pp_bind_rhs_buffer')
+        src = base.copy()
+        for slot, ndx in enumerate(local):       # fresh Hessian values for every block, every entry and every set
+            eps = np.random.default_rng(10_000 * (100 + s) + ndx).uniform(0.0, 0.5)
+            src[slot, :model.n_y] = 2.0 + eps * w
+        t = torch.zeros((dkkt.nsrc, bpad), dtype=torch.float64, device=dev)
+        t[:, :B] = torch.from_numpy(np.ascontiguousarray(src.T)).to(dev)
+        sets.append((dkkt.with_sources({0: t}), src))
+    rhs_host = model.build_rhs(comm=comm)
+    rhs_dev = solver.device_vector_from_host(rhs_host)
 
     def step(k):
-        eng.ns.check(lib.pp_bind_raw_buffer(h, 0, raw_sets[k % nsets].data_ptr()), 'pp_bind_raw_buffer')
-        eng.numeric_local()
-        eng.allreduce_schur(comm)
-        eng.factor_schur(None)
-        status = eng.status()            # status + inertia read-back, as the IP loop needs every iteration
-        eng.solve_forward()
-        eng.allreduce_rs(comm)
-        eng.solve_coupling(None)
-        eng.solve_backward()
-        return status
+        r = solver.do_numeric_factorization(matrix=sets[k % nsets][0], raise_on_error=False)
+        xd = solver.do_back_solve(rhs_dev)
+        return r, xd
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -197,88 +245,116 @@ def main():
     for k in range(args.warmup):
         step(k)
     sync_all()
-    t0 = time.perf_counter()
+    stamps = np.zeros(args.steps + 1)
+    stamps[0] = t0 = time.perf_counter()
     for k in range(args.steps):
-        status = step(args.warmup + k)
+        res, xd = step(args.warmup + k)
+        stamps[k + 1] = time.perf_counter()
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:
         elapsed = float(comm.allreduce_max(np.array([elapsed]))[0])
     ms_per_step = 1e3 * elapsed / args.steps
     value = args.steps / elapsed
+    median_ms = 1e3 * float(np.median(np.diff(stamps)))
 
-    # correctness of the last timed step (device path): download and check
+    # correctness of the last timed step: download and check against the assembled system
     k_last = (args.warmup + args.steps - 1) % nsets
-    xdev = np.zeros((B, model.block_dim))
-    eng.download_solution(0, xdev)
-    xc = eng.coupling_solution()
-    A = model.border_matrix().tocsr()
-    worst = 0.0
-    rc_local = np.zeros(n_t)
-    raw_last = raw_sets[k_last].cpu().numpy()
-    from scipy.sparse import coo_matrix
-    for slot, ndx in enumerate(local):
-        K = coo_matrix((raw_last[slot, :model.nnz_per_block], (model._row, model._col)),
-                       shape=(model.block_dim, model.block_dim)).tocsr()
-        r = model.block_rhs(ndx)
-        res = K @ xdev[slot] + A.T @ xc - r
-        scale = abs(K).sum(axis=1).max() * max(np.abs(xdev[slot]).max(), np.abs(xc).max()) + np.abs(r).max()
-        worst = max(worst, float(np.abs(res).max() / scale))
-        rc_local += A @ xdev[slot]
-    rc = comm.allreduce_sum(rc_local) if world > 1 else rc_local
-    worst = max(worst, float(np.abs(rc).max() / (np.abs(xc).max() * B + 1e-300)))
+    src_last = sets[k_last][1]
+    xh = xd.to_host(rhs_host)
+    xb = [np.asarray(xh.get_block(ndx)) for ndx in local]
+    slot_of = {ndx: slot for slot, ndx in enumerate(local)}
+    resid = residual_check(lambda ndx: model.block_values_from_sources(src_last[slot_of[ndx]])[0], xb,
+                           np.asarray(xh.get_block(N)))
+    inertia = solver.get_inertia()
+    ok = ok and resid <= 1e-8 and res.status == LinearSolverStatus.successful and tuple(inertia) == expected_inertia
+
+    # ---- (3) device only: the same kernels driven through the C ABI without the Python class
+    def raw_step(k):
+        eng.bind_source_tensor(0, sets[k % nsets][0].sources[0])
+        eng.numeric_local()
+        eng.allreduce_schur(comm)
+        eng.factor_schur(None)
+        status = eng.status()
+        eng.solve_forward()
+        eng.allreduce_rs(comm)
+        eng.solve_coupling_dev(None)
+        eng.solve_backward()
+        return status
+    for k in range(3):
+        raw_step(k)
+    sync_all()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        raw_step(k)
+    sync_all()
+    el = time.perf_counter() - t0
     if world > 1:
-        worst = float(comm.allreduce_max(np.array([worst]))[0])
-    ok = ok and worst <= 1e-8 and status[0] == 0 and tuple(status[1:]) == expected_inertia
+        el = float(comm.allreduce_max(np.array([el]))[0])
+    device_only = {'it_per_s': args.steps / el, 'ms_per_step': 1e3 * el / args.steps}
 
     # ---- per-phase device time (HIP events on the solver's stream), separate untimed pass
     import ctypes
-    eng.ns.check(lib.pp_profile(h, 1), 'pp_profile')
-    for k in range(args.profile_steps):
-        step(k)
-    ms = np.zeros(8)
-    launches = np.zeros(8, dtype=np.int32)
-    calls = np.zeros(8, dtype=np.int32)
-    eng.ns.check(lib.pp_phase_times(h, ms.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
-                                    launches.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
-                                    calls.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))), 'pp_phase_times')
-    eng.ns.check(lib.pp_profile(h, 0), 'pp_profile')
     phases = {}
-    for i, name in enumerate(PHASES):
-        if calls[i] > 0:
-            phases[name] = {'ms_per_step': float(ms[i] / args.profile_steps),
-                            'launches_per_step': int(launches[i] // args.profile_steps)}
+    if args.profile_steps > 0:
+        eng.ns.check(lib.pp_profile(h, 1), 'pp_profile')
+        for k in range(args.profile_steps):
+            step(k)
+        ms = np.zeros(8)
+        launches = np.zeros(8, dtype=np.int32)
+        calls = np.zeros(8, dtype=np.int32)
+        eng.ns.check(lib.pp_phase_times(h, ms.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                        launches.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                        calls.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))), 'pp_phase_times')
+        eng.ns.check(lib.pp_profile(h, 0), 'pp_profile')
+        for i, name in enumerate(PHASES):
+            if calls[i] > 0:
+                phases[name] = {'ms_per_step': float(ms[i] / args.profile_steps),
+                                'launches_per_step': int(launches[i] // args.profile_steps)}
 
     # ---- roofline of the dominant kernel class (by device time)
     z_K = st['canonical_entries']
     z_L = st['u_doubles']
     sb = survey_bytes_per_block(z_K, z_L, st['n'], n_t, n_t)
-    phase_bytes = {'assemble': 8.0 * (2 * st['raw_entries'] + z_K + z_L), 'factor_levels': float(sb['factor']),
-                   'schur_tiles': float(sb['schur']), 'fwd_levels': sb['back_solve'] / 2.0,
-                   'bwd_levels': sb['back_solve'] / 2.0}
-    if not any(p in phase_bytes for p in phases):
-        raise SystemExit('bench.py needs --profile-steps >= 1 for the roofline entry')
-    dom = max((p for p in phases if p in phase_bytes), key=lambda p: phases[p]['ms_per_step'])
-    dom_ms = phases[dom]['ms_per_step']
-    dom_launches = max(1, phases[dom]['launches_per_step'])
-    bytes_per_launch = phase_bytes[dom] * B / dom_launches
-    achieved = bytes_per_launch / (dom_ms / dom_launches * 1e-3) / 1e9
-    # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-    # runs of this same command; profiles/pmc_traffic.json) -- valid for the build it was collected on
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
-        ph = pmc['phases'].get(dom)
-        if ph and ph['launches_per_step'] > 0 and world == 1 and N == 1024 and n_q == 1000:
-            traffic = ph['hbm_bytes_per_step'] / ph['launches_per_step']
-    except Exception:
+    bb = build_bytes_per_block(st, ex, n_t, B)
+    survey_phase = {'assemble': 8.0 * (ex['nsrc'] + ex['raw_used']), 'factor_levels': float(sb['factor']),
+                    'schur_tiles': float(sb['schur']), 'fwd_levels': sb['back_solve'] / 2.0,
+                    'bwd_levels': sb['back_solve'] / 2.0}
+    roofline = None
+    if any(p in survey_phase for p in phases):
+        dom = max((p for p in phases if p in survey_phase), key=lambda p: phases[p]['ms_per_step'])
+        dom_ms = phases[dom]['ms_per_step']
+        dom_launches = max(1, phases[dom]['launches_per_step'])
+        bytes_per_launch = survey_phase[dom] * B / dom_launches
+        achieved = bytes_per_launch / (dom_ms / dom_launches * 1e-3) / 1e9
+        # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of
+        # this same command; profiles/pmc_traffic.json) -- valid for the build and workload it was collected on
         traffic = None
-    roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                'algorithmic_bytes_per_launch': bytes_per_launch,
-                'avg_launch_us': 1e3 * dom_ms / dom_launches,
-                'whole_iteration': {'bytes': sb['total'] * B, 'GBps': sb['total'] * B / (ms_per_step * 1e-3) / 1e9,
-                                    'frac': sb['total'] * B / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+        try:
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+            ph = pmc['phases'].get(dom)
+            if ph and ph['launches_per_step'] > 0 and world == 1 and (N, n_q, m, n_t) == WORKLOADS['C3']:
+                traffic = ph['hbm_bytes_per_step'] / ph['launches_per_step']
+        except Exception:
+            traffic = None
+        per_phase = {}
+        for p in phases:
+            if p in bb and phases[p]['ms_per_step'] > 0:
+                gbps = bb[p] * B / (phases[p]['ms_per_step'] * 1e-3) / 1e9
+                per_phase[p] = {'GBps_build_model': gbps, 'frac': gbps / HBM_PEAK_GBS}
+        roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                    'algorithmic_bytes_per_launch': bytes_per_launch, 'avg_launch_us': 1e3 * dom_ms / dom_launches,
+                    'model': 'SURVEY.md 8(d): B_fac = 12 z_K + 12 z_L etc.; build_model = the bytes this implementation '
+                             'moves if every operand crosses HBM once (index data shared by the batch)',
+                    'build_model': {'bytes_per_launch': bb[dom] * B / dom_launches,
+                                    'achieved': bb[dom] * B / (dom_ms * 1e-3) / 1e9,
+                                    'frac': bb[dom] * B / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                    'phases_build_model': per_phase,
+                    'whole_iteration': {'survey_bytes': sb['total'] * B, 'build_bytes': bb['total'] * B,
+                                        'GBps_survey': sb['total'] * B / (ms_per_step * 1e-3) / 1e9,
+                                        'GBps_build': bb['total'] * B / (ms_per_step * 1e-3) / 1e9,
+                                        'frac': bb['total'] * B / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}}
 
     # dense phase (factorisation of S, replicated on every rank): fp64 MFMA work, SURVEY 8d F_S = n_c^3/3 + 4 n_c^2
     dense_phase = None
@@ -287,31 +363,36 @@ def main():
         tf = f_s / (phases['dense_S']['ms_per_step'] * 1e-3) / 1e12
         dense_phase = {'flops': f_s, 'ms': phases['dense_S']['ms_per_step'], 'achieved_TFLOPs': tf,
                        'peak_fp64_mfma_TFLOPs': FP64_MFMA_PEAK_TF, 'frac': tf / FP64_MFMA_PEAK_TF,
-                       'note': 'one workgroup, latency-bound chain of n_c/16 panels; immaterial to the rate at n_c = 200'}
+                       'note': 'one workgroup, latency-bound chain of n_c/16 panels; replicated on every rank'}
 
     if rank == 0:
+        launches = sum(p['launches_per_step'] for p in phases.values()) if phases else None
         out = {
             'metric': METRIC, 'value': value, 'unit': 'it/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'strong',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'C3: %d scenario blocks x (n_q=%d, n_y=%d: %d primal vars, block dim %d), '
-                                   '%d coupling vars; 1 numeric factorisation + 1 back-solve per step, fresh '
-                                   'values each step (%d device-resident value sets cycled)' %
-                                   (N, n_q, model.n_y, n_q + model.n_y, model.block_dim, n_t, nsets),
-                       'blocks_per_gpu': B, 'parallelism': 'blocks round-robin over %d rank(s); RCCL all-reduce of '
-                                                           'S (+status) and r_s' % world},
+            'config': {'workload': '%s: %d scenario blocks x (n_q=%d, n_y=%d: %d primal vars, block dim %d), %d coupling '
+                                   'vars; per step 1 do_numeric_factorization + 1 do_back_solve through the '
+                                   'LinearSolverInterface methods on device-resident containers, fresh values each step '
+                                   '(%d value sets in HBM cycled, every Hessian entry of every block differs)' %
+                                   (args.workload, N, n_q, model.n_y, n_q + model.n_y, model.block_dim, n_t, nsets),
+                       'blocks_per_gpu': B, 'world_size': world, 'collective_backend': backend,
+                       'parallelism': 'blocks round-robin over %d rank(s); all-reduce of [S | status | inertia] and '
+                                      'of r_s' % world},
+            'median_ms_per_step': median_ms,
             'roofline': roofline,
             'dense_phase': dense_phase,
             'cpu_baseline': cpu_baseline,
             'correct': bool(ok),
-            'residual_device_path': worst, 'residual_boundary_path': resid_boundary,
+            'residual': resid, 'residual_boundary_host': resid_boundary,
             'inertia': list(inertia), 'expected_inertia': list(expected_inertia),
-            'phases': phases,
-            'plan': {k: st[k] for k in ('n', 'n_pivots', 'n_2x2', 'n_levels', 'nnz_L', 'u_doubles', 'factor_fma',
-                                        'schur_fma', 'factor_tasks', 'canonical_entries', 'raw_entries')},
-            'survey_bytes_per_block': sb,
-            'symbolic_s': t_symbolic, 'first_numeric_plus_solve_s': t_first,
-            'boundary': boundary,
+            'phases': phases, 'kernel_launches_per_step': launches,
+            'plan': dict({k: st[k] for k in ('n', 'n_pivots', 'n_2x2', 'n_levels', 'nnz_L', 'u_doubles', 'factor_fma',
+                                             'schur_fma', 'factor_tasks', 'canonical_entries', 'raw_entries')}, **ex),
+            'survey_bytes_per_block': sb, 'build_bytes_per_block': bb,
+            'symbolic_s': t_symbolic,
+            'boundary_host': boundary,
+            'device_only': device_only,
         }
         print(json.dumps(out))
     if world > 1:

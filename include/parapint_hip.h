@@ -108,6 +108,11 @@ int pp_numeric_local(pp_handle h);
  * Schur contributions): pp_numeric_local == pp_numeric_factor_blocks followed by pp_numeric_schur. */
 int pp_numeric_factor_blocks(pp_handle h);
 int pp_numeric_schur(pp_handle h);
+/* Status agreement without a collective of its own (mpi_...:19-30, 294-305: the reference gathers the sub-solver
+ * statuses of all ranks before it communicates S).  A rank whose block phase failed on the host side (status 1, 2 or 3)
+ * calls this instead of pp_numeric_schur: its Schur buffer becomes a zero contribution whose tail carries the failure,
+ * the rank still takes part in the all-reduce, and pp_get_status reports the most severe status on every rank. */
+int pp_fail_local(pp_handle h, int status);
 
 /* Device buffer of n_c*n_c + 4 doubles: dense column-major S_local followed by
  * {n_zero_pivots, n_pos, n_neg, reserved} as doubles, so ONE sum all-reduce carries the Schur
@@ -205,6 +210,13 @@ int pp_phase_times(pp_handle h, double ms_out[8], int32_t launches_out[8], int32
  *  8 factor multiply-adds per instance, 9 Schur multiply-adds per instance, 10 factor tasks,
  *  11 update runs, 12 Schur tiles, 13 Schur tile records, 14 canonical entries, 15 raw entries */
 int pp_group_stats(pp_handle h, int group, int64_t out[16]);
+/* More of the same.  out[16]: 0 raw entries read (rows of the transposed input), 1 doubles of packed pivot-block
+ * inverses per instance, 2 doubles of pivot-block term magnitudes, 3 factor entries in coupling rows (what the Schur
+ * kernel reads, per U and per L), 4 bytes of index data shared by all instances of the group, 5 forward-solve entries,
+ * 6 coupling-row entries of the forward sweep, 7 rows of the source buffer (f2), 8 / 9 / 10 kernel launches of the
+ * factorisation levels / forward sweep / backward sweep, 11 padded batch, 12 chunks of 64 instances, 13 Schur tiles,
+ * 14 first level of the tail, 15 reserved. */
+int pp_group_stats_ex(pp_handle h, int group, int64_t out[16]);
 /* Elimination order of a group (new -> old), n ints. */
 int pp_group_perm(pp_handle h, int group, int32_t* perm);
 /* Inertia-correction fast path (interior_point.py:364-392, interfaces/interface.py:590-619,

@@ -52,6 +52,7 @@ SIGNATURES = {
     'pp_numeric_local': (ctypes.c_int, [ctypes.c_void_p]),
     'pp_numeric_factor_blocks': (ctypes.c_int, [ctypes.c_void_p]),
     'pp_numeric_schur': (ctypes.c_int, [ctypes.c_void_p]),
+    'pp_fail_local': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'pp_schur_buffer': (ctypes.c_void_p, [ctypes.c_void_p]),
     'pp_bind_schur_buffer': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     'pp_factor_schur': (ctypes.c_int, [ctypes.c_void_p, _f64p]),
@@ -79,6 +80,7 @@ SIGNATURES = {
     'pp_profile': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'pp_phase_times': (ctypes.c_int, [ctypes.c_void_p, _f64p, _i32p, _i32p]),
     'pp_group_stats': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _i64p]),
+    'pp_group_stats_ex': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _i64p]),
     'pp_group_perm': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _i32p]),
     'pp_set_diagonal_classes': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     'pp_numeric_local_shifted': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_double]),
@@ -164,6 +166,13 @@ class NativeSolver(object):
         self.check(self.lib.pp_group_stats(self.h, group, out.ctypes.data_as(_i64p)), 'pp_group_stats')
         return dict(zip(GROUP_STAT_KEYS, [int(v) for v in out]))
 
+
+    def group_stats_ex(self, group):
+        out = np.zeros(16, dtype=np.int64)
+        self.check(self.lib.pp_group_stats_ex(self.h, group, out.ctypes.data_as(_i64p)), 'pp_group_stats_ex')
+        keys = ['raw_used', 'dinv_doubles', 'tm_doubles', 'coupling_entries', 'index_bytes', 'fwd_entries', 'crow_entries',
+                'nsrc', 'launches_factor', 'launches_fwd', 'launches_bwd', 'bpad', 'nchunk', 'schur_tiles', 'tail_level0']
+        return dict(zip(keys, [int(v) for v in out[:15]]))
 
     def get_factor(self, group, which, instance, count):
         out = np.zeros(int(count), dtype=np.double)

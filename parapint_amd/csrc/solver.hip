@@ -554,7 +554,14 @@ __device__ __forceinline__ void publish_status(const double* __restrict__ tail, 
   out[1] = (long long)(tail[1] + 0.5) + bk[0];
   out[2] = (long long)(tail[2] + 0.5) + bk[1];
   out[3] = zero;
-  out[0] = zero > 0 ? 2 : 0;
+  // tail[3]: host-side failures of any rank, summed by the all-reduce (pp_fail_local: 1 per not_enough_memory,
+  // 1e3 per singular, 1e6 per error); the most severe status wins (error > singular > not_enough_memory)
+  const double hs = tail[3];
+  long long st = zero > 0 ? 2 : 0;
+  if (hs >= 1e6) st = 3;
+  else if (hs >= 1e3) st = 2;
+  else if (hs >= 1.0 && st == 0) st = 1;
+  out[0] = st;
   __threadfence_system();
   __hip_atomic_store(out + 4, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -1622,6 +1629,7 @@ struct pp_solver {
   volatile long long* status_host = nullptr;
   long long* status_dev = nullptr;
   long long status_seq = 0;
+  double fail_code = 0.0;
   double shift_w = 0.0, shift_c = 0.0;   // diagonal shifts of the current pp_numeric_local_shifted call (else 0)
   double mem_factor = 1.0;
   int64_t mem_budget = 0;        // bytes of device value storage the handle may allocate (0: no limit); scaled by mem_factor
@@ -2405,6 +2413,19 @@ int pp_numeric_local(pp_handle h) {
   return pp_numeric_schur(h);
 }
 
+int pp_fail_local(pp_handle h, int status) {
+  if (!h || !h->symbolic_done) return fail(h, 3, "pp_fail_local before symbolic factorization");
+  if (status < 1 || status > 3) return fail(h, 3, "pp_fail_local: status must be 1 (not_enough_memory), 2 (singular) or 3 (error)");
+  PP_HIP(hipSetDevice(h->device));
+  const size_t nn = (size_t)h->nc * h->nc;
+  PP_HIP(hipMemsetAsync(h->S, 0, (nn + 4) * sizeof(double), h->stream));
+  h->fail_code = status == 1 ? 1.0 : status == 2 ? 1e3 : 1e6;
+  PP_HIP(hipMemcpyAsync(h->S + nn + 3, &h->fail_code, sizeof(double), hipMemcpyHostToDevice, h->stream));
+  h->numeric_done = true;       // the Schur buffer is defined (zero contribution): the collective and the dense phase may run
+  h->schur_done = false;
+  return 0;
+}
+
 double* pp_schur_buffer(pp_handle h) { return (h && h->symbolic_done) ? h->S : nullptr; }
 
 int pp_bind_schur_buffer(pp_handle h, double* dev_ptr) {
@@ -2790,6 +2811,29 @@ int pp_group_stats(pp_handle h, int group, int64_t out[16]) {
   const int64_t v[16] = {P.n, P.nc, g->batch, P.npiv, P.n_2x2, P.n_levels, P.nnz_L, P.usize, P.flops_factor,
                          P.flops_schur, (int64_t)P.ftasks.size(), (int64_t)P.fentries.size(), (int64_t)P.stile_a.size(),
                          (int64_t)P.stile_rec.size(), P.ncan, g->nraw};
+  std::memcpy(out, v, sizeof(v));
+  return 0;
+}
+
+int pp_group_stats_ex(pp_handle h, int group, int64_t out[16]) {
+  Group* g = get_group(h, group);
+  if (!g) return fail(h, 3, "pp_group_stats_ex: bad group");
+  const pp::Plan& P = g->plan;
+  int64_t coupling_entries = 0;
+  for (int p = 0; p < P.npiv; ++p) coupling_entries += (int64_t)P.piv_ncrow[p] * P.piv_w[p];
+  int64_t launches_factor = 0, launches_fwd = 1, launches_bwd = 1;
+  for (int l = 0; l < P.n_levels; ++l) {
+    launches_factor += (P.flevel_ptr[l + 1] > P.flevel_ptr[l]) + (P.slevel_ptr[l + 1] > P.slevel_ptr[l]);
+    if (l < (int)g->fwd_level_has_entries.size() && g->fwd_level_has_entries[(size_t)l]) ++launches_fwd;
+    if (P.clevel_ptr[l + 1] > P.clevel_ptr[l]) ++launches_bwd;
+  }
+  const int64_t index_bytes = 4 * ((int64_t)P.fentries.size() * 4 + (int64_t)P.ftasks.size() * TASK_INTS +
+                                   (int64_t)P.stasks.size() * TASK_INTS + (int64_t)P.fdst_ptr.size() +
+                                   2 * (int64_t)P.sfwd_upos.size() + 2 * (int64_t)P.crow_upos.size() + (int64_t)P.rowidx.size() +
+                                   12 * (int64_t)P.n + 20 * (int64_t)P.stile_rec.size() * 4);
+  const int64_t v[16] = {g->nraw_used, P.dsize, P.bsize, coupling_entries, index_bytes, (int64_t)P.sfwd_upos.size(),
+                         (int64_t)P.crow_upos.size(), g->nsrc, launches_factor, launches_fwd, launches_bwd,
+                         (int64_t)g->dev.bpad, (int64_t)g->dev.nchunk, (int64_t)g->ntiles, (int64_t)P.tail_level0, 0};
   std::memcpy(out, v, sizeof(v));
   return 0;
 }

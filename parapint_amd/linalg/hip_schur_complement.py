@@ -367,6 +367,9 @@ class HipEngine(object):
     def numeric_schur(self):
         self.ns.check(self.lib.pp_numeric_schur(self.ns.h), 'pp_numeric_schur')
 
+    def fail_local(self, status):
+        self.ns.check(self.lib.pp_fail_local(self.ns.h, int(status)), 'pp_fail_local')
+
     def set_memory_budget(self, nbytes):
         self.ns.check(self.lib.pp_set_memory_budget(self.ns.h, int(nbytes)), 'pp_set_memory_budget')
 
@@ -958,16 +961,23 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         """Second half of a numeric factorisation, shared with the diagonal-shift fast path: status agreement BEFORE the
         collective (a rank whose block phase failed must not leave the others waiting in the all-reduce; the reference
         gathers the sub-solver statuses first, mpi_...:294-305), all-reduce of S, dense factor, status + inertia."""
-        if self.comm.size > 1:
-            res.status = self._agree_status(res.status)
         if res.status not in _OK:
-            for label in ('communicate',):
-                timer.start(label)
-                timer.stop(label)
-            timer.stop('form SC')
-            self._inertia = None
-            self._num_status = res.status
-            return res
+            if self.comm.size == 1:
+                for label in ('communicate',):
+                    timer.start(label)
+                    timer.stop(label)
+                timer.stop('form SC')
+                self._inertia = None
+                self._num_status = res.status
+                return res
+            # this rank's block phase failed on the host side: it contributes a zero S whose tail carries the failure,
+            # so that the one all-reduce below also agrees the status (no collective of its own, nobody left waiting)
+            local = res.status
+            res.status = LinearSolverStatus.successful
+            self._guarded(res, self._eng.fail_local, local.value if local.value in (1, 2, 3) else 3)
+            if res.status not in _OK:
+                raise RuntimeError('rank %d cannot take part in the collective after a failure: %s' %
+                                   (self.comm.rank, self._last_error))
         timer.start('communicate')
         for label in ('zeros', 'Barrier'):      # S is zeroed on the device; the collective is stream-ordered
             timer.start(label)
@@ -990,8 +1000,8 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             res.status = LinearSolverStatus(status)
         else:
             self._inertia = None
-        # after the all-reduce every rank holds the same block counts and the same S: the device status is already
-        # rank-consistent, only a host-side failure of the dense phase can differ
+        # after the all-reduce every rank holds the same block counts, the same failure tail and the same S: the device
+        # status is rank-consistent as it is; only a host-side failure of the dense phase itself can differ
         if self.comm.size > 1 and st is None:
             res.status = self._agree_status(res.status)
         self._num_status = res.status

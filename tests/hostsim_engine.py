@@ -107,6 +107,10 @@ class HostSimEngine(object):
     def numeric_schur(self):
         pass
 
+    def fail_local(self, status):
+        self.S = np.zeros((self.nc, self.nc))
+        self.tail = np.array([0.0, 0.0, 0.0, {1: 1.0, 2: 1e3, 3: 1e6}[int(status)]])
+
     def required_bytes(self):
         return sum(8 * 2 * sg.usize * sg.batch for sg in self.groups)
 
@@ -136,7 +140,15 @@ class HostSimEngine(object):
         pos = int(round(self.tail[1])) + int(self.bk[0])
         neg = int(round(self.tail[2])) + int(self.bk[1])
         zero = int(round(self.tail[0])) + int(self.bk[2])
-        return (2 if zero > 0 else 0), pos, neg, zero
+        hs = self.tail[3]
+        st = 2 if zero > 0 else 0
+        if hs >= 1e6:
+            st = 3
+        elif hs >= 1e3:
+            st = 2
+        elif hs >= 1.0 and st == 0:
+            st = 1
+        return st, pos, neg, zero
 
     def get_schur(self):
         return self.S.copy()

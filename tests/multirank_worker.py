@@ -80,6 +80,27 @@ def main():
         raise AssertionError('expected RuntimeError')
     except RuntimeError:
         pass
+    # a host-side failure on ONE rank (device storage over budget: status 1) must come back as a status on BOTH ranks --
+    # the failing rank still joins the all-reduce with a zero contribution whose tail carries the failure -- and the
+    # caller's reallocation loop (interior_point.py:634-652), run identically on both ranks, then succeeds
+    kkt2 = model.build_kkt(comm=comm, iteration=1)
+    eng = HostSimEngine()
+    s2 = HipSchurComplementLinearSolver({i: None for i in local}, None, comm=comm, engine=eng)
+    s2.do_symbolic_factorization(kkt2)
+    if rank == 1:
+        eng.set_memory_budget(eng.required_bytes() // 3)
+    for count in range(5):
+        res = s2.do_numeric_factorization(matrix=kkt2, raise_on_error=False)
+        if res.status == LinearSolverStatus.not_enough_memory:
+            s2.increase_memory_allocation(2)
+        else:
+            break
+    assert res.status == LinearSolverStatus.successful and count == 2, (rank, res.status, count)
+    x2 = s2.do_back_solve(rhs)
+    okkt2 = full_model.build_kkt(comm=SerialComm(), iteration=1)
+    oracle.do_numeric_factorization(okkt2)
+    xo2 = oracle.do_back_solve(full_model.build_rhs(comm=SerialComm()))
+    assert np.allclose(x2.get_block(N), xo2.get_block(N), rtol=1e-8, atol=1e-10)
     dist.barrier()
     dist.destroy_process_group()
     print('rank %d ok' % rank)

@@ -199,7 +199,9 @@ def test_device_resident_matrix_and_vectors_f2():
         for ndx in range(N):
             kv, bv = model.block_values_from_sources(srcs[ndx])
             kkt.set_block(ndx, ndx, coo_matrix((kv, (model._row, model._col)), shape=(model.block_dim,) * 2))
-            kkt.set_block(N, ndx, coo_matrix((bv, (A.row, A.col)), shape=A.shape))
+            Ai = coo_matrix((bv, (A.row, A.col)), shape=A.shape)
+            kkt.set_block(N, ndx, Ai)
+            kkt.set_block(ndx, N, Ai.transpose().tocoo())          # (only read by the residual check below)
         kkt.set_block(N, N, coo_matrix((10, 10)))
         host.do_numeric_factorization(kkt)
         x_ref = host.do_back_solve(rhs)
@@ -444,3 +446,42 @@ def test_rccl_collectives_on_solver_buffers():
     text = out.stdout.decode()
     assert out.returncode == 0, text[-4000:]
     assert 'rccl one-rank ok' in text
+
+
+def _run_bench(extra_env, *flags):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.update(extra_env)
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + list(flags), env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=900)
+    text = out.stdout.decode()
+    assert out.returncode == 0, (text[-2000:], out.stderr.decode()[-4000:])
+    line = [ln for ln in text.splitlines() if ln.startswith('{')][-1]
+    return json.loads(line)
+
+
+def test_bench_two_ranks_started_by_the_script_itself():
+    """`python bench.py --gpus 2` starts its own ranks.  With two devices: one GPU per rank over RCCL; on a one-GPU box
+    the two ranks share the device and exchange through gloo (rehearsal of the N > 1 path: ownership, the packed
+    all-reduce with the status tail, max-over-ranks timing, the correctness gate inside the bench)."""
+    import torch
+    two = torch.cuda.device_count() >= 2
+    res = _run_bench({} if two else {'PP_BENCH_REHEARSAL': 'gloo'}, '--gpus', '2', '--workload', 'C2', '--steps', '4',
+                     '--warmup', '2', '--no-cpu-baseline', '--boundary-iterations', '2', '--profile-steps', '1')
+    assert res['n_gpus'] == 2 and res['correct'] is True
+    assert res['config']['world_size'] == 2 and res['config']['blocks_per_gpu'] == 32
+    assert res['config']['collective_backend'] == ('nccl' if two else 'gloo')
+    assert res['residual'] <= 1e-8 and res['inertia'] == res['expected_inertia']
+
+
+def test_bench_single_rank_line_has_the_contract_fields():
+    res = _run_bench({}, '--workload', 'C2', '--steps', '5', '--warmup', '2', '--no-cpu-baseline', '--boundary-iterations', '2')
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'boundary_host', 'device_only'):
+        assert key in res
+    assert res['correct'] is True and res['n_gpus'] == 1 and res['roofline']['bound'] == 'hbm'
+    assert abs(res['value'] * res['ms_per_step'] / 1e3 - 1.0) < 1e-6
