@@ -114,8 +114,8 @@ int pp_numeric_schur(pp_handle h);
  * the rank still takes part in the all-reduce, and pp_get_status reports the most severe status on every rank. */
 int pp_fail_local(pp_handle h, int status);
 
-/* Device buffer of n_c*n_c + 4 doubles: dense column-major S_local followed by
- * {n_zero_pivots, n_pos, n_neg, reserved} as doubles, so ONE sum all-reduce carries the Schur
+/* Device buffer of n_c*n_c + 8 doubles: dense column-major S_local followed by
+ * {n_zero_pivots, n_pos, n_neg, host failures (pp_fail_local), instances with element growth, 3 reserved} as doubles, so ONE sum all-reduce carries the Schur
  * complement (mpi_...:343), the status agreement (mpi_...:19-30) and the inertia sums
  * (mpi_...:427-429).  pp_bind_schur_buffer lets the caller supply that memory (e.g. a torch tensor). */
 double* pp_schur_buffer(pp_handle h);
@@ -270,6 +270,21 @@ void pp_host_free(void* p);
  * is), so the host class uses this to refresh the pivot order from the values that broke it and to factorise once
  * more before it reports `singular` to the inertia-correction loop. */
 int pp_find_zero_pivot(pp_handle h, int group, int32_t* instance_out);
+
+/* Pivot tolerances (MA27 cntl(1), ma27_interface.py:36-47; examples/stochastic.py:120-124 uses 1e-6).
+ *   u_symbolic  threshold of the static pivot choice at symbolic time: a 1x1 pivot is taken only if
+ *               |d| >= u * max|row| on the representative values, else a 2x2 pivot (0: keep 0.01)
+ *   u_runtime   growth guard of every numeric factorisation: MA27's test |d| >= u max|column| is equivalent to
+ *               |l_ij| <= 1/u for the factor entries it produces, which every instance checks as it scales its rows;
+ *               an instance with a larger entry is flagged, counted (pp_get_growth_count, summed over the ranks by the
+ *               S all-reduce) and the factorisation reports status 2, so that the caller can refresh the pivot order
+ *               from that instance (pp_find_growth) exactly as for a zero pivot, or regularise.  0 (the default): the
+ *               guard is not enforced -- the benign 1/mu growth of interior-point matrices (a slack pivot of 1e-9
+ *               against a -1 coupling) would otherwise be reported --, instances beyond 1e8 are only counted
+ * Affects groups added / factorisations started afterwards. */
+int pp_set_pivot_tolerance(pp_handle h, double u_symbolic, double u_runtime);
+int pp_get_growth_count(pp_handle h, int64_t* out);
+int pp_find_growth(pp_handle h, int group, int32_t* instance_out);
 
 /* Diagnostic: the factor of one instance (block) of a group after pp_numeric_local, in the plan's
  * panel storage: which = 0 unscaled panels U, 1 scaled rows L (the MA27 factor entries,

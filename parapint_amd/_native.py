@@ -87,6 +87,9 @@ SIGNATURES = {
     'pp_stage_values': (ctypes.c_int, [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 8 + [ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                         ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+    'pp_set_pivot_tolerance': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_double]),
+    'pp_get_growth_count': (ctypes.c_int, [ctypes.c_void_p, _i64p]),
+    'pp_find_growth': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _i32p]),
     'pp_find_zero_pivot': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _i32p]),
     'pp_get_factor': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f64p, ctypes.c_int64]),
 }

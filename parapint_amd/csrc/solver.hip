@@ -32,6 +32,7 @@ namespace {
 
 constexpr int WAVE = 64;
 constexpr int PP_MAX_SPLIT = 8;
+constexpr int PP_TAIL = 8;    // doubles behind the n_c x n_c Schur block: zero pivots, pos, neg, host failures, growth, reserved
 constexpr int PP_NPHASE = 8;  // assemble, factor, schur, dense, fwd, fwd_coupling, coupling_solve, bwd
 constexpr int BK_THREADS = 512;
 constexpr double PIVOT_EPS = 1e-13;
@@ -41,6 +42,7 @@ constexpr double BK_EPS = 1e-14;
 // device image of one group's plan (all pointers are device memory)
 struct GroupDev {
   int n, nc, batch, bpad, nchunk, npiv, nraw;
+  int const_row;   // initial-value records that point at this row of the input are the constant 1 (f2 sources; -1: none)
   int64_t usize;
   const int *piv_w, *piv_start, *piv_uoff, *piv_doff, *piv_boff, *piv_sub, *piv_rowptr, *rowidx, *perm, *iperm;
   const int *piv_of_col, *rawmap, *raw_tiles;   // raw_tiles: 64-entry tiles of the input with at least one needed entry
@@ -51,6 +53,8 @@ struct GroupDev {
   const int *stile_a, *stile_b, *stile_ptr, *stile_rec;
   double *raw, *rawT, *U, *L, *Dinv, *Tm, *Y, *X, *rhs, *xout, *Spart, *rspart;
   unsigned short* codes;
+  int* growth;      // per instance: 1 if a factor entry exceeded lbound (MA27's threshold test |l_ij| <= 1/u failed)
+  double lbound;    // 1 / u_rt, or +inf
 };
 
 // ------------------------------------------------------------------------------------------
@@ -227,6 +231,7 @@ __device__ __forceinline__ void invert_and_scale(const GroupDev& g, int p, int w
       if (i < w * (w + 1) / 2) invp[(size_t)i * bpad] = inv[i];
     g.codes[(size_t)p * bpad + b] = (b < g.batch) ? (unsigned short)code : (unsigned short)0;
   }
+  bool grow = false;
   for (int r = (r0 > w ? r0 : w); r < r1; r += 4) {
     double u[4][WM];
 #pragma unroll
@@ -245,11 +250,13 @@ __device__ __forceinline__ void invert_and_scale(const GroupDev& g, int p, int w
             for (int t1 = 0; t1 < WM; ++t1)
               if (t1 < w) v += u[i][t1] * PP_INV(inv, t1, t2);
             Lp[(size_t)((r + i) * w + t2) * bpad] = v;
+            grow = grow || fabs(v) > g.lbound;
           }
         }
       }
     }
   }
+  if (grow && b < g.batch) g.growth[b] = 1;
 }
 
 // One gather / fused task of the L-form factorisation (plan.hpp, FTask kinds 0 and 1): every
@@ -314,22 +321,25 @@ __global__ __launch_bounds__(64 * NW) void k_gather_level(GroupDev g, int task0,
     int eu[G], el[G], ew[G], eq[G];                                                        \
     _Pragma("unroll") for (int i = 0; i < G; ++i) {                                        \
       const int qi = min(i0 + i, cnt - 1);                                                 \
-      eu[i] = bcast(rec.x, qi); el[i] = bcast(rec.y, qi);                                  \
-      if (WM > 1) { ew[i] = bcast(rec.z, qi); eq[i] = bcast(rec.w, qi); } else { ew[i] = 0; eq[i] = 0; } \
+      eu[i] = bcast(rec.x, qi); el[i] = bcast(rec.y, qi); ew[i] = bcast(rec.z, qi);        \
+      if (WM > 1) { eq[i] = bcast(rec.w, qi); } else { eq[i] = 0; }                        \
     }                                                                                      \
     double su[G], sl[G][WM];                                                               \
     _Pragma("unroll") for (int i = 0; i < G; ++i) {                                        \
       const double* base = (eu[i] >= 0) ? U : R;                                           \
       const int idx = (eu[i] >= 0) ? eu[i] : (-1 - eu[i]);                                 \
-      su[i] = base[(size_t)idx * bpad];                                                    \
+      const double sv = base[(size_t)((eu[i] < 0 && idx == g.const_row) ? 0 : idx) * bpad]; \
+      su[i] = (eu[i] < 0 && idx == g.const_row) ? 1.0 : sv;                                \
       _Pragma("unroll") for (int q = 0; q < WM; ++q)                                       \
-        sl[i][q] = Lb[(size_t)(el[i] + min(q, w - 1) * ew[i]) * bpad];                     \
+        sl[i][q] = Lb[(size_t)((eu[i] >= 0) ? el[i] + min(q, w - 1) * ew[i] : 0) * bpad];  \
     }                                                                                      \
     _Pragma("unroll") for (int i = 0; i < G; ++i) {                                        \
       if (i0 + i < cnt) {                                                                  \
         while (eb + i0 + i == dend) PP_FINALIZE();                                         \
+        /* initial-value record: (y, z) hold the coefficient of the input entry (1 for plain raw values) */ \
+        const double coef = __hiloint2double(ew[i], el[i]);                                \
         _Pragma("unroll") for (int q = 0; q < WM; ++q) {                                   \
-          const double m = (eu[i] >= 0) ? ((q < w) ? sl[i][q] : 0.0) : ((q == eq[i]) ? -1.0 : 0.0); \
+          const double m = (eu[i] >= 0) ? ((q < w) ? sl[i][q] : 0.0) : ((q == eq[i]) ? -coef : 0.0); \
           const double term = su[i] * m;                                                   \
           acc[q] -= term;                                                                  \
           tmax[q] = fmax(tmax[q], fabs(term));                                             \
@@ -399,11 +409,14 @@ __global__ __launch_bounds__(64) void k_gather_level_lean(GroupDev g, int task0,
       // scalar (SMEM) record reads; the operand base is chosen by offset, not by pointer select
       const int* rp = g.fent + 4 * (size_t)e;
       const int ex = rp[0], ey = rp[1], ez = rp[2], ew = rp[3];
-      const double su = (ex >= 0) ? U[(size_t)ex * bpad] : R[(size_t)(-1 - ex) * bpad];
+      const bool cst = ex < 0 && (-1 - ex) == g.const_row;
+      const double sv = (ex >= 0) ? U[(size_t)ex * bpad] : R[(size_t)(cst ? 0 : -1 - ex) * bpad];
+      const double su = cst ? 1.0 : sv;
+      const double coef = __hiloint2double(ez, ey);     // (initial-value records: coefficient of the input entry)
 #pragma unroll
       for (int q = 0; q < WM; ++q) {
-        const double lv = Lb[(size_t)(ey + min(q, w - 1) * ez) * bpad];
-        const double m = (ex >= 0) ? ((q < w) ? lv : 0.0) : ((q == ew) ? -1.0 : 0.0);
+        const double lv = Lb[(size_t)((ex >= 0) ? ey + min(q, w - 1) * ez : 0) * bpad];
+        const double m = (ex >= 0) ? ((q < w) ? lv : 0.0) : ((q == ew) ? -coef : 0.0);
         const double term = su * m;
         acc[q] -= term;
         tmax[q] = fmax(tmax[q], fabs(term));
@@ -421,7 +434,9 @@ __global__ __launch_bounds__(64) void k_gather_level_lean(GroupDev g, int task0,
         const int code = (pr.code & 3) | (((pr.code >> 2) & 3) << 4) | (((pr.code >> 4) & 3) << 8);
         g.codes[(size_t)p * bpad + b] = (b < g.batch) ? (unsigned short)code : (unsigned short)0;
       } else {
-        Ldst[(size_t)d * bpad] = acc[0] * inv1;
+        const double lv = acc[0] * inv1;
+        Ldst[(size_t)d * bpad] = lv;
+        if (fabs(lv) > g.lbound && b < g.batch) g.growth[b] = 1;
       }
     } else if (d < nblk) {
 #pragma unroll
@@ -437,8 +452,9 @@ __global__ __launch_bounds__(64) void k_gather_level_lean(GroupDev g, int task0,
 
 // L values [v0, v1) of a panel of compile-time width W from row values held in registers
 template <int W, int RV>
-__device__ __forceinline__ void scale_held(const double (&u)[RV], const double* inv, double* Lp, int v0, int v1,
-                                           size_t bpad) {
+__device__ __forceinline__ bool scale_held(const double (&u)[RV], const double* inv, double* Lp, int v0, int v1,
+                                           size_t bpad, double lbound) {
+  bool grow = false;
 #pragma unroll
   for (int i = 0; i < RV; ++i) {
     if (v0 + i < v1) {
@@ -448,8 +464,10 @@ __device__ __forceinline__ void scale_held(const double (&u)[RV], const double* 
 #pragma unroll
       for (int t1 = 0; t1 < W; ++t1) v += u[(ib + t1) < RV ? (ib + t1) : RV - 1] * PP_INV(inv, t1, t2);
       Lp[(size_t)(v0 + i) * bpad] = v;
+      grow = grow || fabs(v) > lbound;
     }
   }
+  return grow;
 }
 
 // Scale task of a big panel (plan.hpp, kind 2): invert the gathered pivot block (every chunk does it
@@ -496,11 +514,18 @@ __global__ __launch_bounds__(64) void k_scale_level(GroupDev g, int task0, int c
   }
   if (v1 - v0 <= RV) {
     // the common shapes (8 rows x 1, 4 x 2, 2 x 4): rows already in registers
-    if (w == 1) { scale_held<1, RV>(u, inv, Lp, v0, v1, bpad); return; }
-    if (w == 2) { scale_held<2, RV>(u, inv, Lp, v0, v1, bpad); return; }
-    if (w == 4) { scale_held<4, RV>(u, inv, Lp, v0, v1, bpad); return; }
-    if (WM >= 8 && w == 8) { scale_held<(WM >= 8 ? 8 : 1), RV>(u, inv, Lp, v0, v1, bpad); return; }
+    bool gr = false, done = true;
+    if (w == 1) gr = scale_held<1, RV>(u, inv, Lp, v0, v1, bpad, g.lbound);
+    else if (w == 2) gr = scale_held<2, RV>(u, inv, Lp, v0, v1, bpad, g.lbound);
+    else if (w == 4) gr = scale_held<4, RV>(u, inv, Lp, v0, v1, bpad, g.lbound);
+    else if (WM >= 8 && w == 8) gr = scale_held<(WM >= 8 ? 8 : 1), RV>(u, inv, Lp, v0, v1, bpad, g.lbound);
+    else done = false;
+    if (done) {
+      if (gr && b < g.batch) g.growth[b] = 1;
+      return;
+    }
   }
+  bool grow = false;
   for (int r = r0; r < r1; ++r) {
     double ur[WM];
 #pragma unroll
@@ -513,17 +538,24 @@ __global__ __launch_bounds__(64) void k_scale_level(GroupDev g, int task0, int c
         for (int t1 = 0; t1 < WM; ++t1)
           if (t1 < w) v += ur[t1] * PP_INV(inv, t1, t2);
         Lp[(size_t)(r * w + t2) * bpad] = v;
+        grow = grow || fabs(v) > g.lbound;
       }
     }
   }
+  if (grow && b < g.batch) g.growth[b] = 1;
 }
 
 // counters[0..2] += (pos, neg, zero) over all block pivots (codes of padded instances are 0);
 // a code is pos | neg << 4 | zero << 8 in 16 bits, 8 codes per 16-byte load
 __global__ __launch_bounds__(256) void k_count_codes(const unsigned short* __restrict__ codes, size_t total8,
-                                                     int* counters) {
+                                                     int* counters, const int* __restrict__ growth, int batch) {
   __shared__ int red[3][256];
   int pos = 0, neg = 0, zero = 0;
+  if (blockIdx.x == 0) {     // instances whose factor showed element growth beyond 1 / u_rt
+    int gr = 0;
+    for (int i = threadIdx.x; i < batch; i += 256) gr += growth[i] != 0;
+    if (gr) atomicAdd(&counters[3], gr);
+  }
   const uint4* c4 = reinterpret_cast<const uint4*>(codes);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (size_t)gridDim.x * 256) {
     const uint4 v = c4[i];
@@ -557,7 +589,9 @@ __device__ __forceinline__ void publish_status(const double* __restrict__ tail, 
   // tail[3]: host-side failures of any rank, summed by the all-reduce (pp_fail_local: 1 per not_enough_memory,
   // 1e3 per singular, 1e6 per error); the most severe status wins (error > singular > not_enough_memory)
   const double hs = tail[3];
-  long long st = zero > 0 ? 2 : 0;
+  const long long growth = (long long)(tail[4] + 0.5);
+  out[5] = growth;
+  long long st = zero > 0 ? 2 : 0;     // (growth: pp_get_status decides, it knows whether the guard is enforced)
   if (hs >= 1e6) st = 3;
   else if (hs >= 1e3) st = 2;
   else if (hs >= 1.0 && st == 0) st = 1;
@@ -648,6 +682,8 @@ __global__ __launch_bounds__(64) void k_schur_reduce(GroupDev g, int ntiles, dou
     tail[1] = (double)counters[0];
     tail[2] = (double)counters[1];
     tail[3] = 0.0;
+    tail[4] = (double)counters[3];
+    tail[5] = tail[6] = tail[7] = 0.0;
   }
   double s = 0.0;
   for (int c = 0; c < g.nchunk; ++c) s += g.Spart[((size_t)c * ntiles + tile) * 64 + lane];
@@ -664,6 +700,8 @@ __global__ void k_write_tail(const int* counters, double* tail) {
     tail[1] = (double)counters[0];
     tail[2] = (double)counters[1];
     tail[3] = 0.0;
+    tail[4] = (double)counters[3];
+    tail[5] = tail[6] = tail[7] = 0.0;
   }
 }
 
@@ -1608,6 +1646,8 @@ struct Group {
   int *map_src = nullptr;            // device [nraw_used]: source row of each used raw entry, or -1 (constant)
   double *map_coef = nullptr;        // device [nraw_used]
   double *src_own = nullptr, *src = nullptr;   // [nsrc][bpad]
+  std::vector<int> fent_host, init_rec;        // entry records as uploaded; positions of the initial-value records
+  int *fent_src = nullptr;                     // device: the same records with the initial-value ones pointing at sources
   double *xout_own = nullptr;
 };
 
@@ -1630,6 +1670,10 @@ struct pp_solver {
   long long* status_dev = nullptr;
   long long status_seq = 0;
   double fail_code = 0.0;
+  double growth_bound = 1e8;     // 1 / u_rt: a factor entry beyond it flags its instance
+  bool growth_fatal = false;     // flagged instances make the factorisation report status 2 (else they are only counted)
+  double pivot_threshold = 0.0;  // symbolic-time threshold u for groups added afterwards (0: plan default)
+  bool no_fused_sources = std::getenv("PP_NO_FUSED_SOURCES") != nullptr;   // measurement switch: assemble the sources first
   double shift_w = 0.0, shift_c = 0.0;   // diagonal shifts of the current pp_numeric_local_shifted call (else 0)
   double mem_factor = 1.0;
   int64_t mem_budget = 0;        // bytes of device value storage the handle may allocate (0: no limit); scaled by mem_factor
@@ -1766,7 +1810,7 @@ int transpose_tiles(int, int) {
 }
 
 void free_group(Group* g) {
-  for (void* p : {(void*)g->map_src, (void*)g->map_coef, (void*)g->src_own}) if (p) (void)hipFree(p);
+  for (void* p : {(void*)g->map_src, (void*)g->map_coef, (void*)g->src_own, (void*)g->fent_src}) if (p) (void)hipFree(p);
   if (g->shift_row) (void)hipFree(g->shift_row);
   if (g->shift_cls) (void)hipFree(g->shift_cls);
   for (void* p : g->value_allocs) (void)hipFree(p);
@@ -1809,6 +1853,7 @@ void free_value_storage(Group* g) {
   GroupDev& d = g->dev;
   d.raw = d.rawT = d.U = d.L = d.Dinv = d.Tm = d.Y = d.X = d.rhs = d.xout = d.Spart = d.rspart = nullptr;
   d.codes = nullptr;
+  d.growth = nullptr;
   g->raw_own = g->rhs_own = g->xout_own = nullptr;
 }
 
@@ -1858,6 +1903,7 @@ int alloc_value_storage(pp_handle h) {
     if ((rc = value_alloc(h, g, &d.Spart, (size_t)d.nchunk * std::max(g->ntiles, 1) * 64))) break;
     if ((rc = value_alloc(h, g, &d.rspart, (size_t)d.nchunk * std::max(nc, 1)))) break;
     if ((rc = value_alloc(h, g, &d.codes, (size_t)P.npiv * bp))) break;   // 16-bit codes
+    if ((rc = value_alloc(h, g, &d.growth, bp))) break;
     d.raw = keep_raw ? keep_raw : g->raw_own;
     d.rhs = keep_rhs ? keep_rhs : g->rhs_own;
   }
@@ -1941,6 +1987,7 @@ int pp_add_group(pp_handle h, int n, int batch, int nnzK, const int32_t* rowK, c
   pp::PlanOptions opt;
   if (h->sn_wmax > 0) opt.sn_wmax = h->sn_wmax;
   if (h->sn_tol >= 0) opt.sn_tol_rows = h->sn_tol;
+  if (h->pivot_threshold > 0.0) opt.pivot_threshold = h->pivot_threshold;
   if (const char* tune = std::getenv("PP_PLAN_TUNE")) {
     // developer knob for schedule experiments: "max_task_entries=48,scale_task_rows=16,..."
     std::string t(tune);
@@ -2003,6 +2050,10 @@ int pp_end_symbolic(pp_handle h) {
     for (int pp_ = 0; pp_ < P.npiv; ++pp_)
       g->level_maxw[P.piv_level[pp_]] = std::max(g->level_maxw[P.piv_level[pp_]], P.piv_w[pp_]);
     std::vector<int> ftask, stask, fdst_ptr, fent, srec;
+    const double one = 1.0;
+    int one_lo, one_hi;
+    { int bits[2]; std::memcpy(bits, &one, sizeof(one)); one_lo = bits[0]; one_hi = bits[1]; }
+    g->init_rec.clear();
     // raw entries that some canonical entry reads get a compact row in the transposed buffer; the rest
     // (typically the upper-triangle half) are never written
     std::vector<int> rawmap((size_t)std::max(g->nraw, 1), -1);
@@ -2028,7 +2079,10 @@ int pp_end_symbolic(pp_handle h) {
             // the L index of an initial-value record is a dummy (position 0, always valid)
             const int ce = -1 - fe.u;
             for (int q = g->can_ptr[ce]; q < g->can_ptr[ce + 1]; ++q)
-              fent.insert(fent.end(), {-1 - rawmap[g->can_idx[q]], 0, 0, fe.q});
+            {
+              g->init_rec.push_back((int)(fent.size() / 4));
+              fent.insert(fent.end(), {-1 - rawmap[g->can_idx[q]], one_lo, one_hi, fe.q});
+            }
           }
         }
       }
@@ -2086,6 +2140,8 @@ int pp_end_symbolic(pp_handle h) {
     if ((rc = dev_upload(h, g, &d.stask, stask))) return rc;
     if ((rc = dev_upload(h, g, &d.fdst_ptr, fdst_ptr))) return rc;
     if ((rc = dev_upload(h, g, &d.fent, fent))) return rc;
+    g->fent_host = fent;
+    d.const_row = -1;
     if ((rc = dev_upload(h, g, &d.clevel_col, P.clevel_col))) return rc;
     {
       std::vector<int> frec, brec;
@@ -2139,7 +2195,7 @@ int pp_end_symbolic(pp_handle h) {
   }
   int rc;
   const size_t nn = (size_t)nc * nc;
-  if ((rc = dev_alloc<double>(h, nullptr, &h->S_own, nn + 4))) return rc;
+  if ((rc = dev_alloc<double>(h, nullptr, &h->S_own, nn + PP_TAIL))) return rc;
   if ((rc = dev_alloc<double>(h, nullptr, &h->Sfac, nn))) return rc;
   if ((rc = dev_alloc<double>(h, nullptr, &h->Sldl, nn))) return rc;
   if ((rc = dev_alloc<double>(h, nullptr, &h->dvec, nc))) return rc;
@@ -2165,7 +2221,7 @@ int pp_end_symbolic(pp_handle h) {
   }
   h->S = h->S_own;
   h->rs = h->rs_own;
-  PP_HIP(hipMemset(h->S, 0, (nn + 4) * sizeof(double)));
+  PP_HIP(hipMemset(h->S, 0, (nn + PP_TAIL) * sizeof(double)));
   PP_HIP(hipMemset(h->rs, 0, std::max<size_t>(nc, 1) * sizeof(double)));
   PP_HIP(hipMemset(h->bkinfo, 0, 4 * sizeof(int)));
   h->symbolic_done = true;
@@ -2240,6 +2296,24 @@ int pp_set_value_map(pp_handle h, int group, int nsrc, const int32_t* src_of_raw
   if ((rc = dev_alloc(h, (Group*)nullptr, &g->map_coef, mc.size()))) return rc;
   PP_HIP(hipMemcpy(g->map_src, ms.data(), ms.size() * sizeof(int), hipMemcpyHostToDevice));
   PP_HIP(hipMemcpy(g->map_coef, mc.data(), mc.size() * sizeof(double), hipMemcpyHostToDevice));
+  // entry records for the fused path: an initial-value record reads its source row directly (row nsrc = the constant
+  // 1) and carries its coefficient, so the factorisation kernels gather from the sources themselves
+  {
+    std::vector<int> fs(g->fent_host);
+    for (int pos : g->init_rec) {
+      const int row = -1 - fs[(size_t)4 * pos];            // compact row of the transposed input
+      const int sidx = ms[(size_t)row];
+      const double c = mc[(size_t)row];
+      int bits[2];
+      std::memcpy(bits, &c, sizeof(c));
+      fs[(size_t)4 * pos] = -1 - (sidx >= 0 ? sidx : nsrc);
+      fs[(size_t)4 * pos + 1] = bits[0];
+      fs[(size_t)4 * pos + 2] = bits[1];
+    }
+    if (g->fent_src) { (void)hipFree(g->fent_src); g->fent_src = nullptr; }
+    if ((rc = dev_alloc(h, (Group*)nullptr, &g->fent_src, fs.size()))) return rc;
+    PP_HIP(hipMemcpy(g->fent_src, fs.data(), fs.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
   return 0;
 }
 
@@ -2297,11 +2371,20 @@ int pp_numeric_factor_blocks(pp_handle h) {
   hipStream_t st = h->stream;
   for (Group* g : h->groups) {
     const pp::Plan& P = g->plan;
-    GroupDev& d = g->dev;
+    GroupDev& d0 = g->dev;
+    bool fused_sources = false;
+    d0.lbound = h->growth_bound > 0.0 ? h->growth_bound : INFINITY;
+    GroupDev d = d0;
+    PP_HIP(hipMemsetAsync(d.growth, 0, (size_t)d.bpad * sizeof(int), st));
     {
       PhaseScope ps(h, 0, 1);
-      if (g->input_mode == Group::IN_SOURCES && g->nraw_used > 0) {
-        if (!g->src || !g->map_src) return fail(h, 3, "pp_numeric_factor_blocks: no value map / source buffer");
+      const bool shifting = g->nshift > 0 && (h->shift_w != 0.0 || h->shift_c != 0.0);
+      fused_sources = g->input_mode == Group::IN_SOURCES && g->fent_src && !shifting && !h->no_fused_sources;
+      if (g->input_mode == Group::IN_SOURCES && (!g->src || !g->map_src))
+        return fail(h, 3, "pp_numeric_factor_blocks: no value map / source buffer");
+      if (fused_sources) {
+        // nothing to assemble: the factorisation kernels read the sources through the entry records
+      } else if (g->input_mode == Group::IN_SOURCES && g->nraw_used > 0) {
         hipLaunchKernelGGL(k_assemble_sources, dim3((unsigned)((g->nraw_used + 3) / 4) * d.nchunk), dim3(256), 0, st, g->src,
                            d.rawT, g->map_src, g->map_coef, g->nraw_used, d.bpad);
       } else if (g->input_mode == Group::IN_COMPACT && g->nraw_used > 0) {
@@ -2321,6 +2404,7 @@ int pp_numeric_factor_blocks(pp_handle h) {
         hipLaunchKernelGGL(k_shift_diag, dim3(g->nshift, (d.bpad + 255) / 256), dim3(256), 0, st, d.rawT, g->shift_row,
                            g->shift_cls, g->nshift, d.bpad, h->shift_w, h->shift_c);
     }
+    if (fused_sources) { d.rawT = g->src; d.fent = g->fent_src; d.const_row = g->nsrc; }
     {
       int nlaunch = 0;
       for (int l = 0; l < P.n_levels; ++l)
@@ -2381,7 +2465,7 @@ int pp_numeric_schur(pp_handle h) {
   PP_HIP(hipSetDevice(h->device));
   hipStream_t st = h->stream;
   const int nc = h->nc;
-  PP_HIP(hipMemsetAsync(h->S, 0, ((size_t)nc * nc + 4) * sizeof(double), st));
+  PP_HIP(hipMemsetAsync(h->S, 0, ((size_t)nc * nc + PP_TAIL) * sizeof(double), st));
   PP_HIP(hipMemsetAsync(h->counters, 0, 4 * sizeof(int), st));
   bool tail_written = false;
   for (Group* g : h->groups) {
@@ -2391,7 +2475,7 @@ int pp_numeric_schur(pp_handle h) {
       PhaseScope ps(h, 2, 3);
       const size_t total8 = (size_t)P.npiv * d.bpad / 8;   // bpad is a multiple of 64
       hipLaunchKernelGGL(k_count_codes, dim3((unsigned)std::min<size_t>(512, (total8 + 255) / 256)), dim3(256), 0, st,
-                         d.codes, total8, h->counters);
+                         d.codes, total8, h->counters, d.growth, d.batch);
       if (g->ntiles > 0) {
         hipLaunchKernelGGL(k_schur_tiles, dim3((unsigned)g->ntiles * d.nchunk, 1, 2), dim3(64), 0, st, d);
         const bool last = (g == h->groups.back());
@@ -2418,7 +2502,7 @@ int pp_fail_local(pp_handle h, int status) {
   if (status < 1 || status > 3) return fail(h, 3, "pp_fail_local: status must be 1 (not_enough_memory), 2 (singular) or 3 (error)");
   PP_HIP(hipSetDevice(h->device));
   const size_t nn = (size_t)h->nc * h->nc;
-  PP_HIP(hipMemsetAsync(h->S, 0, (nn + 4) * sizeof(double), h->stream));
+  PP_HIP(hipMemsetAsync(h->S, 0, (nn + PP_TAIL) * sizeof(double), h->stream));
   h->fail_code = status == 1 ? 1.0 : status == 2 ? 1e3 : 1e6;
   PP_HIP(hipMemcpyAsync(h->S + nn + 3, &h->fail_code, sizeof(double), hipMemcpyHostToDevice, h->stream));
   h->numeric_done = true;       // the Schur buffer is defined (zero contribution): the collective and the dense phase may run
@@ -2508,6 +2592,10 @@ int pp_get_status(pp_handle h, int64_t out[4]) {
       return fail(h, 3, "pp_get_status: status mailbox was not written");
   }
   for (int i = 0; i < 4; ++i) out[i] = (int64_t)h->status_host[i];
+  // element growth beyond 1 / u_runtime, if the caller asked for the guard (pp_set_pivot_tolerance), is reported like a
+  // breakdown: the host class refreshes the static pivot order from the offending instance and, if that does not help,
+  // the inertia-correction loop regularises (MA27 would have re-pivoted).  Every rank sees the same all-reduced count.
+  if (h->growth_fatal && out[0] == 0 && h->status_host[5] > 0) out[0] = 2;
   return 0;
 }
 
@@ -3027,6 +3115,36 @@ void* pp_host_alloc(int64_t bytes) {
   return p;
 }
 void pp_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
+int pp_set_pivot_tolerance(pp_handle h, double u_symbolic, double u_runtime) {
+  if (!h) return 3;
+  if (u_symbolic < 0.0 || u_symbolic > 0.5 || u_runtime < 0.0 || u_runtime > 0.5)
+    return fail(h, 3, "pivot tolerances must lie in [0, 0.5] (0: default / off)");
+  h->pivot_threshold = u_symbolic;
+  h->growth_bound = u_runtime > 0.0 ? 1.0 / u_runtime : 1e8;
+  h->growth_fatal = u_runtime > 0.0;
+  return 0;
+}
+
+int pp_get_growth_count(pp_handle h, int64_t* out) {
+  if (!h || !h->schur_done || !out) return fail(h, 3, "pp_get_growth_count before pp_factor_schur");
+  *out = (int64_t)h->status_host[5];     // (valid once pp_get_status has seen the mailbox of this factorisation)
+  return 0;
+}
+
+int pp_find_growth(pp_handle h, int group, int32_t* instance_out) {
+  Group* g = get_group(h, group);
+  if (!g || !instance_out || !h->numeric_done) return fail(h, 3, "pp_find_growth: bad group or no numeric factorization");
+  const GroupDev& d = g->dev;
+  *instance_out = -1;
+  PP_HIP(hipSetDevice(h->device));
+  PP_HIP(hipStreamSynchronize(h->stream));
+  std::vector<int> flags((size_t)d.bpad);
+  PP_HIP(hipMemcpy(flags.data(), d.growth, flags.size() * sizeof(int), hipMemcpyDeviceToHost));
+  for (int b = 0; b < d.batch; ++b)
+    if (flags[(size_t)b]) { *instance_out = b; break; }
+  return 0;
+}
 
 int pp_find_zero_pivot(pp_handle h, int group, int32_t* instance_out) {
   Group* g = get_group(h, group);

@@ -228,7 +228,7 @@ class HipEngine(object):
         ns.check(lib.pp_end_symbolic(ns.h), 'pp_end_symbolic')
         torch = self._torch
         dev = torch.device('cuda', self.device)
-        self._S_t = torch.zeros(nc * nc + 4, dtype=torch.float64, device=dev)
+        self._S_t = torch.zeros(nc * nc + 8, dtype=torch.float64, device=dev)    # S | status / inertia / growth tail
         self._rs_t = torch.zeros(max(nc, 1), dtype=torch.float64, device=dev)
         ns.check(lib.pp_bind_schur_buffer(ns.h, self._S_t.data_ptr()), 'pp_bind_schur_buffer')
         ns.check(lib.pp_bind_rs_buffer(ns.h, self._rs_t.data_ptr()), 'pp_bind_rs_buffer')
@@ -260,6 +260,24 @@ class HipEngine(object):
         arr = np.frombuffer(buf, dtype=np.double).reshape(shape)
         arr[...] = 0.0
         return arr
+
+    def find_growth(self, gid):
+        """Slot of the first instance of group gid whose factor exceeded the growth bound 1 / u_runtime, or -1."""
+        import ctypes
+        out = ctypes.c_int32(-1)
+        self.ns.check(self.lib.pp_find_growth(self.ns.h, gid, ctypes.byref(out)), 'pp_find_growth')
+        return int(out.value)
+
+    def growth_count(self):
+        """Instances (all ranks) whose last factorisation produced a factor entry beyond the growth bound."""
+        import ctypes
+        out = ctypes.c_int64(0)
+        self.ns.check(self.lib.pp_get_growth_count(self.ns.h, ctypes.byref(out)), 'pp_get_growth_count')
+        return int(out.value)
+
+    def set_pivot_tolerance(self, u_symbolic, u_runtime):
+        self.ns.check(self.lib.pp_set_pivot_tolerance(self.ns.h, float(u_symbolic), float(u_runtime)),
+                      'pp_set_pivot_tolerance')
 
     def stage_upload(self, g, items):
         """items: [(slot, (kr, kc, kd, br, bc, bd))] of one pattern group, ascending slots (int32 / float64 arrays,
@@ -498,7 +516,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         return 'hip_schur_complement'
 
     def __init__(self, subproblem_solvers=None, schur_complement_solver=None, comm=None, engine=None,
-                 memory_budget_bytes=None, result_buffers=2):
+                 memory_budget_bytes=None, result_buffers=2, pivot_tolerance=None, symbolic_pivot_threshold=None):
         self.subproblem_solvers = subproblem_solvers
         self.schur_complement_solver = schur_complement_solver
         self.comm = default_comm() if comm is None else comm
@@ -508,6 +526,16 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         # reallocation protocol of interior_point.py:634-652 / ma27_interface.py:126-131, 153-154
         if memory_budget_bytes is not None:
             self._eng.set_memory_budget(memory_budget_bytes)
+        # MA27's cntl(1) (ma27_interface.py:36-47; examples/stochastic.py:120-124).  `pivot_tolerance` u, if given, is
+        # enforced on every instance of every factorisation as |l_ij| <= 1/u: an instance beyond it makes the
+        # factorisation refresh the static pivot order from that instance's values and, failing that, report `singular`
+        # for the inertia-correction loop to regularise.  Not enforced by default: interior-point matrices grow by 1/mu
+        # benignly (a slack pivot of 1e-9 against its -1 coupling).  `symbolic_pivot_threshold` is the u of the static
+        # 1x1 / 2x2 choice on the representative values (default 0.01).
+        if pivot_tolerance is not None or symbolic_pivot_threshold is not None:
+            self._eng.set_pivot_tolerance(0.0 if symbolic_pivot_threshold is None else symbolic_pivot_threshold,
+                                          0.0 if pivot_tolerance is None else pivot_tolerance)
+        self._growth_guard = bool(pivot_tolerance)
         self._classes = None                # regularisation classes by block index (kept across re-plans)
         self._device_maps = None            # (nsrc, value maps by block index) of a DeviceBlockMatrix (f2)
         self._dev_results = []
@@ -530,6 +558,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         self._last_Q = None
         self._base_Q = None
         self._last_error = ''
+        self.growth_instances = 0           # instances of the last factorisation with a factor entry beyond 1 / u (1e8 if no guard)
         self.plan_stats = []
 
     # ------------------------------------------------------------------ helpers
@@ -862,6 +891,8 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         mine = 0
         for g in self._groups:
             slot = self._eng.find_zero_pivot(g.gid)
+            if slot < 0 and self._growth_guard:
+                slot = self._eng.find_growth(g.gid)     # element growth beyond 1 / pivot_tolerance counts as a breakdown
             if slot >= 0:
                 t = getattr(g, 'device_sources', None)
                 if self._device_maps is not None and t is not None:
@@ -998,6 +1029,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             status, pos, neg, zero = st
             self._inertia = (pos, neg, zero)
             res.status = LinearSolverStatus(status)
+            self.growth_instances = self._eng.growth_count()
         else:
             self._inertia = None
         # after the all-reduce every rank holds the same block counts, the same failure tail and the same S: the device
@@ -1158,10 +1190,19 @@ class HipLDLInterface(LinearSolverInterface):
     def getLoggerName(cls):
         return 'hip_ldl'
 
-    def __init__(self, engine=None):
+    def __init__(self, cntl_options=None, icntl_options=None, iw_factor=1.2, a_factor=2, engine=None):
+        """Same keywords as the reference wrapper (ma27_interface.py:36).  ``cntl_options[1]`` -- MA27's pivot tolerance
+        u -- becomes the run-time growth bound |l_ij| <= 1/u of every factorisation and (if larger than the default
+        0.01) the threshold of the static pivot choice; the other MA27 controls and the workspace factors have no
+        counterpart (storage is sized exactly by the symbolic phase) and are accepted and recorded only."""
         from parapint_amd.sparse.block_containers import BlockMatrix
         self._BlockMatrix = BlockMatrix
-        self._sc = HipSchurComplementLinearSolver(comm=SerialComm(), engine=engine)
+        self.cntl_options = dict(cntl_options or {})
+        self.icntl_options = dict(icntl_options or {})
+        self.iw_factor, self.a_factor = iw_factor, a_factor
+        u = self.cntl_options.get(1)
+        self._sc = HipSchurComplementLinearSolver(comm=SerialComm(), engine=engine, pivot_tolerance=u,
+                                                  symbolic_pivot_threshold=None if u is None else max(min(u, 0.5), 0.01))
         self._dim = None
         self._num_status = None
 

@@ -23,11 +23,20 @@ struct HostCtx {
 }  // namespace
 
 static int g_sn_wmax = 0, g_sn_tol = -1;
+static double g_growth_bound = 1e8, g_pivot_threshold = 0.0;   // as pp_set_pivot_tolerance
+static int g_last_growth = 0, g_growth_fatal = 0;
 
 extern "C" {
 
 // test knob: supernode width cap / padded-row tolerance for plans created afterwards (0 / -1: defaults)
 void ppsim_set_supernodes(int wmax, int tol) { g_sn_wmax = wmax; g_sn_tol = tol; }
+void ppsim_set_pivot_tolerance(double u_symbolic, double u_runtime) {
+  g_pivot_threshold = u_symbolic;
+  g_growth_bound = u_runtime > 0.0 ? 1.0 / u_runtime : 1e8;
+  g_growth_fatal = u_runtime > 0.0;
+}
+int ppsim_growth_fatal() { return g_growth_fatal; }
+int ppsim_last_growth() { return g_last_growth; }
 
 void* ppsim_create(int n, int nc, int nnzK, const int* rowK, const int* colK, int nnzB, const int* rowB,
                    const int* colB, const double* vals, int max_entries, int delta_abs, double delta_rel) {
@@ -38,6 +47,7 @@ void* ppsim_create(int n, int nc, int nnzK, const int* rowK, const int* colK, in
   if (delta_rel >= 0) opt.md_delta_rel = delta_rel;
   if (g_sn_wmax > 0) opt.sn_wmax = g_sn_wmax;
   if (g_sn_tol >= 0) opt.sn_tol_rows = g_sn_tol;
+  if (g_pivot_threshold > 0.0) opt.pivot_threshold = g_pivot_threshold;
   int rc = pp::build_plan(n, nc, nnzK, rowK, colK, nnzB, rowB, colB, vals, opt, *P);
   if (rc != 0) { /* keep the plan so the error string can be read */ }
   return P;
@@ -95,6 +105,7 @@ void scale_rows(const Plan& P, int p, int r0, int r1, const double* inv, const d
         v += u[t1] * inv[hi * (hi + 1) / 2 + lo];
       }
       l[t2] = v;
+      if (g_growth_bound > 0.0 && std::fabs(v) > g_growth_bound) g_last_growth = 1;
     }
   }
 }
@@ -105,6 +116,7 @@ void scale_rows(const Plan& P, int p, int r0, int r1, const double* inv, const d
 int ppsim_factor(void* h, const double* can, double* U, double* L, double* Dinv, double* S, int64_t* inertia,
                  double eps) {
   Plan& P = *(Plan*)h;
+  g_last_growth = 0;
   std::memset(U, 0, sizeof(double) * P.usize);
   std::memset(L, 0, sizeof(double) * P.usize);
   std::vector<double> Tm((size_t)std::max(P.bsize, 1), 0.0);

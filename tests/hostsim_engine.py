@@ -57,7 +57,7 @@ class HostSimEngine(object):
             stats.append({'n': int(st[0]), 'n_pivots': int(st[2]), 'n_levels': int(st[3]), 'n_2x2': int(st[4]) % 1000000,
                           'nnz_L': int(st[6])})
         self.S = np.zeros((nc, nc))
-        self.tail = np.zeros(4)
+        self.tail = np.zeros(8)
         return stats
 
     def upload_values(self, gid, raw):
@@ -77,10 +77,12 @@ class HostSimEngine(object):
         nc = self.nc
         self.S = np.zeros((nc, nc))
         inertia = np.zeros(3, dtype=np.int64)
+        growth = 0
         for sg in self.groups:
             g = sg.g
             sg.U, sg.Dinv, sg.L = [], [], []
             sg.zero_slot = -1
+            sg.growth_slot = -1
             for b in range(sg.batch):
                 zeros_before = int(inertia[2])
                 can = np.add.reduceat(sg.raw[b][g.can_idx], g.can_ptr[:-1]) if g.can_idx.size else np.zeros(0)
@@ -92,11 +94,15 @@ class HostSimEngine(object):
                                inertia.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), ctypes.c_double(1e-13))
                 if int(inertia[2]) > zeros_before and sg.zero_slot < 0:
                     sg.zero_slot = b
+                if L.ppsim_last_growth():
+                    growth += 1
+                    if sg.growth_slot < 0:
+                        sg.growth_slot = b
                 self.S += np.tril(Sb) + np.tril(Sb, -1).T
                 sg.U.append(U)
                 sg.L.append(Lf)
                 sg.Dinv.append(D)
-        self.tail = np.array([inertia[2], inertia[0], inertia[1], 0.0], dtype=np.double)
+        self.tail = np.array([inertia[2], inertia[0], inertia[1], 0.0, growth, 0.0, 0.0, 0.0], dtype=np.double)
 
     def numeric_factor_blocks(self):
         """(the interpreter forms the factor and the Schur contribution in one pass)"""
@@ -109,7 +115,7 @@ class HostSimEngine(object):
 
     def fail_local(self, status):
         self.S = np.zeros((self.nc, self.nc))
-        self.tail = np.array([0.0, 0.0, 0.0, {1: 1.0, 2: 1e3, 3: 1e6}[int(status)]])
+        self.tail = np.array([0.0, 0.0, 0.0, {1: 1.0, 2: 1e3, 3: 1e6}[int(status)], 0.0, 0.0, 0.0, 0.0])
 
     def required_bytes(self):
         return sum(8 * 2 * sg.usize * sg.batch for sg in self.groups)
@@ -118,14 +124,23 @@ class HostSimEngine(object):
         self.budget = int(nbytes)
         self.mem_factor = 1.0
 
+    def growth_count(self):
+        return int(round(self.tail[4]))
+
+    def find_growth(self, gid):
+        return self.groups[gid].growth_slot
+
+    def set_pivot_tolerance(self, u_symbolic, u_runtime):
+        hu.lib().ppsim_set_pivot_tolerance(ctypes.c_double(float(u_symbolic)), ctypes.c_double(float(u_runtime)))
+
     def find_zero_pivot(self, gid):
         return self.groups[gid].zero_slot
 
     def allreduce_schur(self, comm):
         if comm.size > 1:
             buf = comm.allreduce_sum(np.concatenate([self.S.ravel(), self.tail]))
-            self.S = buf[:-4].reshape(self.nc, self.nc)
-            self.tail = buf[-4:]
+            self.S = buf[:-8].reshape(self.nc, self.nc)
+            self.tail = buf[-8:]
 
     def factor_schur(self, Q):
         self.Sfull = self.S + (0.0 if Q is None else Q)
@@ -141,7 +156,7 @@ class HostSimEngine(object):
         neg = int(round(self.tail[2])) + int(self.bk[1])
         zero = int(round(self.tail[0])) + int(self.bk[2])
         hs = self.tail[3]
-        st = 2 if zero > 0 else 0
+        st = 2 if (zero > 0 or (self.growth_count() > 0 and hu.lib().ppsim_growth_fatal())) else 0
         if hs >= 1e6:
             st = 3
         elif hs >= 1e3:

@@ -57,7 +57,7 @@ def main():
             assert np.abs(np.asarray(x.get_block(ndx)) - ref).max() <= 1e-8 * max(1.0, np.abs(ref).max())
         assert solver.get_inertia() == oracle.get_inertia()
     nc = shape[3]
-    assert calls.count((nc * nc + 4, True)) == 2 and calls.count((nc, True)) == 2, calls
+    assert calls.count((nc * nc + 8, True)) == 2 and calls.count((nc, True)) == 2, calls
     dist.barrier()
     dist.destroy_process_group()
     print('rccl one-rank ok')

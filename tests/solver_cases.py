@@ -611,3 +611,77 @@ def case_status_severity():
     assert ranks == sorted(ranks) and len(set(ranks)) == 5
     for st in order:
         assert mod._BY_SEVERITY[mod._SEVERITY[st]] == st
+
+
+# ---- pivot-growth guard (MA27 cntl(1): ma27_interface.py:36-47, examples/stochastic.py:120-124) ----------------------
+def case_growth_guard(make_engine):
+    """The pivot sequence is static per pattern group.  A later matrix in which ONE instance has a Hessian diagonal that is
+    1e-9 of its column (not zero: the zero-pivot rule does not fire) is factorised with an element growth of 1e9 in that
+    instance.  Without a tolerance the factorisation succeeds and only counts the instance; with ``pivot_tolerance`` u the
+    growth |l_ij| > 1/u is treated like a breakdown: the order is refreshed from that instance (a 2x2 pivot takes the weak
+    diagonal) and the solve is accurate to 1e-8 again."""
+    rng = np.random.default_rng(17)
+    n_x, n_c, nc, nb = 8, 3, 2, 5
+    Js, Bs = [], []
+    for i in range(nb):
+        J = (sp.random(n_c, n_x, density=0.4, random_state=70 + i, data_rvs=lambda k: rng.normal(size=k)) +
+             2.0 * sp.eye(n_c, n_x)).tocoo()
+        B = coo_matrix((rng.normal(size=nc), (np.arange(nc), rng.choice(n_x, nc, replace=False))), shape=(nc, n_x + n_c))
+        Js.append(J); Bs.append(B)
+    h0 = [rng.uniform(1.0, 3.0, size=n_x) for _ in range(nb)]
+    h1 = [h.copy() for h in h0]
+    weak = None
+    for j in range(n_x):                               # a Hessian diagonal of block 3 that can nearly vanish safely
+        trial = h1[3].copy()
+        trial[j] = 1e-9
+        Kd = sp.bmat([[sp.diags(trial), Js[3].T], [Js[3], None]]).toarray()
+        sv = np.linalg.svd(Kd, compute_uv=False)
+        if Js[3].tocsc()[:, j].nnz > 0 and sv.min() > 1e-3 * sv.max():
+            h1[3], weak = trial, j
+            break
+    assert weak is not None
+
+    def kkt(hs):
+        A = BlockMatrix(nb + 1, nb + 1)
+        for i in range(nb):
+            H = coo_matrix((hs[i], (np.arange(n_x), np.arange(n_x))), shape=(n_x, n_x))
+            A.set_block(i, i, sp.bmat([[H, Js[i].T], [Js[i], None]]).tocoo())
+            A.set_block(nb, i, Bs[i])
+        A.set_block(nb, nb, coo_matrix((nc, nc)))
+        return A
+
+    m = n_x + n_c
+    A0, A1 = kkt(h0), kkt(h1)
+    full = np.zeros((nb * m + nc, nb * m + nc))
+    for i in range(nb):
+        Kd = A1.get_block(i, i).toarray()
+        full[i * m:(i + 1) * m, i * m:(i + 1) * m] = np.tril(Kd) + np.tril(Kd, -1).T
+        Bd = A1.get_block(nb, i).toarray()
+        full[nb * m:, i * m:(i + 1) * m] = Bd
+        full[i * m:(i + 1) * m, nb * m:] = Bd.T
+    rhs = BlockVector(nb + 1)
+    for i in range(nb):
+        rhs.set_block(i, rng.normal(size=m))
+    rhs.set_block(nb, rng.normal(size=nc))
+    x_ref = np.linalg.solve(full, rhs.flatten())
+    ev = np.linalg.eigvalsh(full)
+    # (1) no tolerance: accepted silently, the instance is counted
+    plain = new_solver(make_engine, nb)
+    plain.do_symbolic_factorization(A0)
+    assert plain.do_numeric_factorization(A1, raise_on_error=False).status == LinearSolverStatus.successful
+    assert plain.pivot_order_refreshes == 0 and plain.growth_instances == 1
+    # (2) MA27's pivot tolerance given: growth beyond 1/u refreshes the order, then the factorisation is clean
+    guarded = new_solver(make_engine, nb, pivot_tolerance=1e-6)
+    try:
+        guarded.do_symbolic_factorization(A0)
+        assert guarded.do_numeric_factorization(A0, raise_on_error=False).status == LinearSolverStatus.successful
+        assert guarded.pivot_order_refreshes == 0
+        res = guarded.do_numeric_factorization(A1, raise_on_error=False)
+        assert res.status == LinearSolverStatus.successful
+        assert guarded.pivot_order_refreshes == 1 and guarded.growth_instances == 0
+        assert guarded.get_inertia() == (int((ev > 0).sum()), int((ev < 0).sum()), 0)
+        x = guarded.do_back_solve(rhs)
+        assert np.abs(x.flatten() - x_ref).max() <= 1e-8 * np.abs(x_ref).max()
+    finally:
+        if hasattr(guarded._eng, 'set_pivot_tolerance'):
+            guarded._eng.set_pivot_tolerance(0.0, 0.0)       # (the host interpreter keeps the tolerance process-wide)

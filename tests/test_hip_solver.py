@@ -485,3 +485,7 @@ def test_bench_single_rank_line_has_the_contract_fields():
         assert key in res
     assert res['correct'] is True and res['n_gpus'] == 1 and res['roofline']['bound'] == 'hbm'
     assert abs(res['value'] * res['ms_per_step'] / 1e3 - 1.0) < 1e-6
+
+
+def test_pivot_growth_guard():
+    sc.case_growth_guard(make_engine)

@@ -64,3 +64,7 @@ def test_memory_reallocation_retry_loop():
 
 def test_status_severity_order():
     sc.case_status_severity()
+
+
+def test_pivot_growth_guard():
+    sc.case_growth_guard(make_engine)
