@@ -10,6 +10,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libparapint_hip.so')
+if os.environ.get('PP_LIB_VARIANT'):      # kernel experiments: an alternative build of the same sources, next to the product library
+    LIB_PATH = os.path.join(_HERE, 'csrc', 'libparapint_hip_%s.so' % os.environ['PP_LIB_VARIANT'])
 
 _i32p = ctypes.POINTER(ctypes.c_int32)
 _i64p = ctypes.POINTER(ctypes.c_int64)

@@ -400,7 +400,7 @@ __global__ __launch_bounds__(64) void k_gather_level_lean(GroupDev g, int task0,
   double* Tmd = g.Tm + ((size_t)boff + (size_t)r0 * w) * bpad + b;
   double* Ldst = g.L + ((size_t)uoff + (size_t)r0 * w) * bpad + b;
   const int nblk = (r0 < w) ? (w - r0) : 0;
-  double tmax_diag = 0.0, inv1 = 0.0;
+  double tmax_diag = 0.0, inv1 = 0.0, lmax = 0.0;
   for (int d = 0; d < nrow; ++d) {
     double acc[WM], tmax[WM];
 #pragma unroll
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(64) void k_gather_level_lean(GroupDev g, int task0,
       } else {
         const double lv = acc[0] * inv1;
         Ldst[(size_t)d * bpad] = lv;
-        if (fabs(lv) > g.lbound && b < g.batch) g.growth[b] = 1;
+        lmax = fmax(lmax, fabs(lv));      // (one flag store per task, below: a store per row cost 36 us per step at C3)
       }
     } else if (d < nblk) {
 #pragma unroll
@@ -447,6 +447,7 @@ __global__ __launch_bounds__(64) void k_gather_level_lean(GroupDev g, int task0,
       }
     }
   }
+  if (WM == 1 && lmax > g.lbound && b < g.batch) g.growth[b] = 1;
   if (WM != 1 && kind == 1) invert_and_scale<WM>(g, p, w, uoff, doff, sub, r0, r1, tmax_diag, true, bpad, b, eps);
 }
 
@@ -548,12 +549,18 @@ __global__ __launch_bounds__(64) void k_scale_level(GroupDev g, int task0, int c
 // counters[0..2] += (pos, neg, zero) over all block pivots (codes of padded instances are 0);
 // a code is pos | neg << 4 | zero << 8 in 16 bits, 8 codes per 16-byte load
 __global__ __launch_bounds__(256) void k_count_codes(const unsigned short* __restrict__ codes, size_t total8,
-                                                     int* counters, const int* __restrict__ growth, int batch) {
+                                                     int* counters, int* __restrict__ growth, int* __restrict__ growth_seen,
+                                                     int batch) {
   __shared__ int red[3][256];
   int pos = 0, neg = 0, zero = 0;
-  if (blockIdx.x == 0) {     // instances whose factor showed element growth beyond 1 / u_rt
-    int gr = 0;
-    for (int i = threadIdx.x; i < batch; i += 256) gr += growth[i] != 0;
+  if (blockIdx.x == 0) {     // instances whose factor showed element growth beyond 1 / u_rt: counted, kept for
+    int gr = 0;              // pp_find_growth and cleared for the next factorisation
+    for (int i = threadIdx.x; i < batch; i += 256) {
+      const int f = growth[i];
+      gr += f != 0;
+      growth_seen[i] = f;
+      if (f) growth[i] = 0;
+    }
     if (gr) atomicAdd(&counters[3], gr);
   }
   const uint4* c4 = reinterpret_cast<const uint4*>(codes);
@@ -1903,7 +1910,8 @@ int alloc_value_storage(pp_handle h) {
     if ((rc = value_alloc(h, g, &d.Spart, (size_t)d.nchunk * std::max(g->ntiles, 1) * 64))) break;
     if ((rc = value_alloc(h, g, &d.rspart, (size_t)d.nchunk * std::max(nc, 1)))) break;
     if ((rc = value_alloc(h, g, &d.codes, (size_t)P.npiv * bp))) break;   // 16-bit codes
-    if ((rc = value_alloc(h, g, &d.growth, bp))) break;
+    if ((rc = value_alloc(h, g, &d.growth, 2 * bp))) break;        // flags of the running factorisation | of the last one
+    if (hipMemset(d.growth, 0, 2 * bp * sizeof(int)) != hipSuccess) { rc = fail(h, 3, "hipMemset failed"); break; }
     d.raw = keep_raw ? keep_raw : g->raw_own;
     d.rhs = keep_rhs ? keep_rhs : g->rhs_own;
   }
@@ -2375,7 +2383,6 @@ int pp_numeric_factor_blocks(pp_handle h) {
     bool fused_sources = false;
     d0.lbound = h->growth_bound > 0.0 ? h->growth_bound : INFINITY;
     GroupDev d = d0;
-    PP_HIP(hipMemsetAsync(d.growth, 0, (size_t)d.bpad * sizeof(int), st));
     {
       PhaseScope ps(h, 0, 1);
       const bool shifting = g->nshift > 0 && (h->shift_w != 0.0 || h->shift_c != 0.0);
@@ -2475,7 +2482,7 @@ int pp_numeric_schur(pp_handle h) {
       PhaseScope ps(h, 2, 3);
       const size_t total8 = (size_t)P.npiv * d.bpad / 8;   // bpad is a multiple of 64
       hipLaunchKernelGGL(k_count_codes, dim3((unsigned)std::min<size_t>(512, (total8 + 255) / 256)), dim3(256), 0, st,
-                         d.codes, total8, h->counters, d.growth, d.batch);
+                         d.codes, total8, h->counters, d.growth, d.growth + d.bpad, d.batch);
       if (g->ntiles > 0) {
         hipLaunchKernelGGL(k_schur_tiles, dim3((unsigned)g->ntiles * d.nchunk, 1, 2), dim3(64), 0, st, d);
         const bool last = (g == h->groups.back());
@@ -3140,7 +3147,7 @@ int pp_find_growth(pp_handle h, int group, int32_t* instance_out) {
   PP_HIP(hipSetDevice(h->device));
   PP_HIP(hipStreamSynchronize(h->stream));
   std::vector<int> flags((size_t)d.bpad);
-  PP_HIP(hipMemcpy(flags.data(), d.growth, flags.size() * sizeof(int), hipMemcpyDeviceToHost));
+  PP_HIP(hipMemcpy(flags.data(), d.growth + d.bpad, flags.size() * sizeof(int), hipMemcpyDeviceToHost));
   for (int b = 0; b < d.batch; ++b)
     if (flags[(size_t)b]) { *instance_out = b; break; }
   return 0;
