@@ -271,6 +271,21 @@ void pp_host_free(void* p);
  * more before it reports `singular` to the inertia-correction loop. */
 int pp_find_zero_pivot(pp_handle h, int group, int32_t* instance_out);
 
+/* ---- f4: vector kernels of the step after the solve, on device-resident vectors ------------------
+ * (parapint/algorithms/interior_point.py:174-317 check_convergence, :655-758 fraction_to_the_boundary, :619-626 the
+ * step).  All pointers are device arrays of n doubles on the handle's device; NULL = that array is absent.
+ * pp_vec_step_stats: one pass over a variable family (x with step dx, bounds xl / xu, bound duals zl / zu with steps
+ * dzl / dzu) -> out = {alpha_primal, alpha_dual, max |(x - xl) zl - mu|, max |(xu - x) zu - mu|}: the
+ * fraction-to-the-boundary step lengths min(1, min -tau (x - xl)/dx over dx < 0, min tau (xu - x)/dx over dx > 0) and
+ * min(1, min -tau z/dz over dz < 0), and the complementarity residuals over the finite bounds.
+ * pp_vec_max_abs: max |v_i| (the infeasibility norms).  pp_vec_axpy: y += alpha x (the step).  Stream-ordered after the
+ * back-solve; the two reductions synchronise to hand their scalars to the host. */
+int pp_vec_step_stats(pp_handle h, int64_t n, const double* x, const double* dx, const double* xl, const double* xu,
+                      const double* zl, const double* dzl, const double* zu, const double* dzu, double tau, double mu,
+                      double out_host[4]);
+int pp_vec_max_abs(pp_handle h, int64_t n, const double* v, double* out_host);
+int pp_vec_axpy(pp_handle h, int64_t n, double alpha, const double* x, double* y);
+
 /* Pivot tolerances (MA27 cntl(1), ma27_interface.py:36-47; examples/stochastic.py:120-124 uses 1e-6).
  *   u_symbolic  threshold of the static pivot choice at symbolic time: a 1x1 pivot is taken only if
  *               |d| >= u * max|row| on the representative values, else a 2x2 pivot (0: keep 0.01)

@@ -89,6 +89,10 @@ SIGNATURES = {
     'pp_stage_values': (ctypes.c_int, [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 8 + [ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                         ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+    'pp_vec_step_stats': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 8 +
+                          [ctypes.c_double, ctypes.c_double, _f64p]),
+    'pp_vec_max_abs': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, _f64p]),
+    'pp_vec_axpy': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
     'pp_set_pivot_tolerance': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_double]),
     'pp_get_growth_count': (ctypes.c_int, [ctypes.c_void_p, _i64p]),
     'pp_find_growth': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _i32p]),

@@ -489,3 +489,48 @@ def test_bench_single_rank_line_has_the_contract_fields():
 
 def test_pivot_growth_guard():
     sc.case_growth_guard(make_engine)
+
+
+def test_device_vector_kernels_f4():
+    """the fused step-statistics kernel, max-norm and step update on device vectors against the restated
+    reference formulas (interior_point.py:655-758 fraction_to_the_boundary, :257-266 bound residuals, :619-626)."""
+    import torch
+    from parapint_amd.algorithms import interior_point as ip
+    from parapint_amd.linalg import device_vector_ops as dv
+    solver = sc.new_solver(make_engine, 1)
+    rng = np.random.default_rng(5)
+    for n in (1, 77, 70 * 9200 + 13):
+        lb = np.where(rng.random(n) < 0.7, rng.uniform(-2.0, 0.0, n), -np.inf)
+        ub = np.where(rng.random(n) < 0.6, rng.uniform(1.0, 3.0, n), np.inf)
+        x = rng.uniform(0.1, 0.9, n)
+        dx = rng.normal(size=n) * 3.0
+        dx[rng.random(n) < 0.05] = 0.0
+        zl = np.where(np.isfinite(lb), rng.uniform(0.01, 2.0, n), 0.0)
+        zu = np.where(np.isfinite(ub), rng.uniform(0.01, 2.0, n), 0.0)
+        dzl, dzu = rng.normal(size=n), rng.normal(size=n)
+        tau, mu = 0.995, 0.1
+        dev = [torch.from_numpy(a).cuda() for a in (x, dx, lb, ub, zl, dzl, zu, dzu)]
+        a_p, a_d, c_l, c_u = dv.step_stats(solver, *dev, tau=tau, barrier=mu)
+        ref_p = min(ip._frac_lb(tau, x, dx, lb), ip._frac_ub(tau, x, dx, ub))
+        ref_d = min(ip._frac_lb(tau, zl, dzl, np.zeros(n)), ip._frac_lb(tau, zu, dzu, np.zeros(n)))
+        fl, fu = np.isfinite(lb), np.isfinite(ub)
+        ref_cl = np.abs((x[fl] - lb[fl]) * zl[fl] - mu).max() if fl.any() else 0.0
+        ref_cu = np.abs((ub[fu] - x[fu]) * zu[fu] - mu).max() if fu.any() else 0.0
+        assert a_p == ref_p and a_d == ref_d          # min / max of identical fp64 expressions: exact
+        assert abs(c_l - ref_cl) <= 1e-15 * max(1.0, ref_cl) and abs(c_u - ref_cu) <= 1e-15 * max(1.0, ref_cu)
+        assert dv.max_abs(solver, dev[1]) == np.abs(dx).max()
+        y = dev[0].clone()
+        dv.axpy_(solver, y, a_p, dev[1])
+        assert np.array_equal(y.cpu().numpy(), x + a_p * dx)
+    # on the solver's own device-resident solution: the step of the synthetic problem is finite and the norms agree
+    from parapint_amd.examples.performance.schur_complement.synthetic_kkt import SyntheticKKT
+    from parapint_amd.linalg.comm import SerialComm
+    model = SyntheticKKT(70, 30, 2, 10)
+    dk = model.build_device_kkt(comm=SerialComm())
+    s2 = sc.new_solver(make_engine, 70)
+    s2.do_symbolic_factorization(dk)
+    dk.set_sources_from_host({ndx: model.block_sources(ndx, 1) for ndx in range(70)})
+    s2.do_numeric_factorization(dk)
+    xd = s2.do_back_solve(s2.device_vector_from_host(model.build_rhs(comm=SerialComm())))
+    t = xd.group_tensors[0]
+    assert dv.max_abs(s2, t) == float(t.abs().max())
