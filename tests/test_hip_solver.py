@@ -521,7 +521,7 @@ def test_device_vector_kernels_f4():
         assert dv.max_abs(solver, dev[1]) == np.abs(dx).max()
         y = dev[0].clone()
         dv.axpy_(solver, y, a_p, dev[1])
-        assert np.array_equal(y.cpu().numpy(), x + a_p * dx)
+        assert np.abs(y.cpu().numpy() - (x + a_p * dx)).max() <= 4e-16 * (1.0 + np.abs(x).max() + a_p * np.abs(dx).max())  # (one fma)
     # on the solver's own device-resident solution: the step of the synthetic problem is finite and the norms agree
     from parapint_amd.examples.performance.schur_complement.synthetic_kkt import SyntheticKKT
     from parapint_amd.linalg.comm import SerialComm
