@@ -60,6 +60,26 @@ int pp_add_group(pp_handle h, int n, int batch, int nnzK, const int32_t* rowK, c
                  int nnzB, const int32_t* rowB, const int32_t* colB, int nraw, const int32_t* can_ptr,
                  const int32_t* can_idx, const double* rep_vals, int* group_out);
 
+/* A group whose instances touch coupling rows of their own (time blocks of a dynamic problem: block t is linked only to
+ * the coupling variables of its two neighbours, sc_ip_interface.py:308-333; scenarios that see a subset of the
+ * first-stage variables): rowB holds LOCAL coupling rows 0 .. nc_loc-1 and cmap[batch][nc_loc] gives, per instance, the
+ * global coupling index of each.  The instances are still factorised together, one per lane; their Schur cliques,
+ * coupling right-hand sides and coupling solutions are scattered / gathered through the map (what the reference does
+ * with sc_data_slices, mpi_...:228-255, 313-333).  cmap = NULL, nc_loc = n_c is pp_add_group. */
+int pp_add_group_mapped(pp_handle h, int n, int batch, int nnzK, const int32_t* rowK, const int32_t* colK, int nnzB,
+                        const int32_t* rowB, const int32_t* colB, int nraw, const int32_t* can_ptr, const int32_t* can_idx,
+                        const double* rep_vals, int nc_loc, const int32_t* cmap, int* group_out);
+
+/* Structure of S, right after pp_begin_symbolic.  mode 0 (default): dense n_c x n_c (the union of the border cliques of a
+ * stochastic program is dense).  mode 1: block-tridiagonal with G diagonal blocks of gs rows (n_c = G * gs; the caller
+ * orders and pads the coupling variables so that every clique and every entry of Q lies in one block or two adjacent
+ * ones -- the banded S of a time-staged problem, mpi_...:88-125).  The Schur buffer is then D[G][gs][gs] | E[G-1][gs][gs]
+ * (E_t = S(block t+1, block t), column-major inside a block) followed by the same 8-double tail, Q is handed over in the
+ * same layout, and S is factorised by a block LDL^T with Bunch-Kaufman inside the blocks; all groups must be mapped.
+ * pp_schur_buffer_doubles: length of the Schur buffer (tail included) for the current structure. */
+int pp_set_coupling_structure(pp_handle h, int mode, int gs, int G);
+int64_t pp_schur_buffer_doubles(pp_handle h);
+
 /* Builds the plans' device images and allocates all device memory (_get_sc_structure,
  * mpi_...:228-255: the dense S buffer replaces the sparse COO pattern + sc_data_slices). */
 int pp_end_symbolic(pp_handle h);

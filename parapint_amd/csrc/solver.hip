@@ -53,6 +53,9 @@ struct GroupDev {
   const int *stile_a, *stile_b, *stile_ptr, *stile_rec;
   double *raw, *rawT, *U, *L, *Dinv, *Tm, *Y, *X, *rhs, *xout, *Spart, *rspart;
   unsigned short* codes;
+  const int* cmapT; // mapped groups: global coupling index of local coupling row c of instance b at [c * bpad + b] (else null)
+  double *Sloc, *XCL;   // mapped groups: per-instance Schur cliques [tile entry][instance], per-instance coupling solution
+  int xs_row, xs_lane;  // address of coupling value c of lane b: c * xs_row + b * xs_lane (uniform: 1, 0 into xc)
   int* growth;      // per instance: 1 if a factor entry exceeded lbound (MA27's threshold test |l_ij| <= 1/u failed)
   double lbound;    // 1 / u_rt, or +inf
 };
@@ -662,6 +665,16 @@ __global__ __launch_bounds__(64) void k_schur_tiles(GroupDev g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] -= la[s][i] * ub[s][j];
   }
+  if (g.cmapT) {
+    // mapped group (time blocks: every instance has coupling rows of its own): no sum over the lanes, the clique of
+    // every instance is kept and scattered by k_scatter_schur
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        g.Sloc[((size_t)tile * 64 + i * 8 + 4 * half + j) * bpad + b] = acc[i][j];
+    return;
+  }
   const double mask = (b < g.batch) ? 1.0 : 0.0;
 #pragma unroll
   for (int i = 0; i < 8; ++i)
@@ -699,6 +712,54 @@ __global__ __launch_bounds__(64) void k_schur_reduce(GroupDev g, int ntiles, dou
     S[(size_t)ci + (size_t)cj * g.nc] += s;
     if (ci != cj) S[(size_t)cj + (size_t)ci * g.nc] += s;
   }
+}
+
+// Mapped groups: S[gi][gj] += clique entry (ci, cj) of instance b, gi = cmap[b][ci].  Target: the dense n_c x n_c S
+// (both triangles) or the block-tridiagonal storage D[G][gs][gs] | E[G-1][gs][gs] (E_t = rows of block t+1 x columns of
+// block t, column-major inside a block).  Entries of different instances may coincide in general: atomic adds.
+struct SchurTarget { double* S; int nc, btd, gs, G; int* err; };
+
+__device__ __forceinline__ void schur_add(const SchurTarget& T, int gi, int gj, double v) {
+  if (!T.btd) {
+    atomicAdd(&T.S[(size_t)gi + (size_t)gj * T.nc], v);
+    if (gi != gj) atomicAdd(&T.S[(size_t)gj + (size_t)gi * T.nc], v);
+    return;
+  }
+  const int bi = gi / T.gs, bj = gj / T.gs, ri = gi % T.gs, rj = gj % T.gs;
+  const size_t g2 = (size_t)T.gs * T.gs;
+  if (bi == bj) {
+    atomicAdd(&T.S[(size_t)bi * g2 + ri + (size_t)rj * T.gs], v);
+    if (gi != gj) atomicAdd(&T.S[(size_t)bi * g2 + rj + (size_t)ri * T.gs], v);
+  } else if (bi == bj + 1) {
+    atomicAdd(&T.S[(size_t)T.G * g2 + (size_t)bj * g2 + ri + (size_t)rj * T.gs], v);
+  } else if (bj == bi + 1) {
+    atomicAdd(&T.S[(size_t)T.G * g2 + (size_t)bi * g2 + rj + (size_t)ri * T.gs], v);
+  } else {
+    T.err[0] = 1;       // a clique that spans non-adjacent blocks: the structure given to pp_set_coupling_structure is wrong
+  }
+}
+
+__global__ __launch_bounds__(64) void k_scatter_schur(GroupDev g, int ntiles, SchurTarget T) {
+  const int lane = threadIdx.x;
+  const int tile = PP_TASK_OF_WG(g.nchunk), b = PP_CHUNK_OF_WG(g.nchunk) * 64 + lane;
+  if (b >= g.batch) return;
+  const size_t bpad = (size_t)g.bpad;
+  const int ta = g.stile_a[tile], tb = g.stile_b[tile];
+  for (int e = 0; e < 64; ++e) {
+    const int ci = ta * 8 + (e >> 3), cj = tb * 8 + (e & 7);
+    if (ci >= g.nc || cj >= g.nc || ci < cj) continue;
+    const double v = g.Sloc[((size_t)tile * 64 + e) * bpad + b];
+    if (v == 0.0) continue;
+    schur_add(T, g.cmapT[(size_t)ci * bpad + b], g.cmapT[(size_t)cj * bpad + b], v);
+  }
+}
+
+// per-instance copy of the coupling solution for the back substitution of a mapped group
+__global__ __launch_bounds__(256) void k_gather_xc(GroupDev g, const double* __restrict__ xc) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)g.nc * g.bpad) return;
+  const int b = (int)(i % g.bpad);
+  g.XCL[i] = (b < g.batch) ? xc[g.cmapT[i]] : 0.0;
 }
 
 __global__ void k_write_tail(const int* counters, double* tail) {
@@ -1443,6 +1504,121 @@ __global__ __launch_bounds__(BK_THREADS) void k_bk_factor(int n, const double* _
   if (threadIdx.x == 0) publish_status(S + (size_t)n * n, info, status_out, seq);
 }
 
+// ------------------------------------------------------------------------------------------
+// Block-tridiagonal S (time-staged problems; the reference factorises a sparse COO S with its sub-solver,
+// mpi_...:88-125, 228-255, 352-361).  Storage: D[G][gs][gs] | E[G-1][gs][gs], E_t = S(block t+1, block t), column-major
+// inside a block.  Block LDL^T: for t = 0 .. G-1: Bunch-Kaufman of the updated D_t, explicit inverse of D_t (gs unit
+// right-hand sides, one workgroup each), X_t = inv(D_t) E_t^T, D_{t+1} -= E_t X_t.  inertia(S) = sum inertia(D_t)
+// (Haynsworth).  The solve is then matrix-vector products only.
+__global__ __launch_bounds__(256) void k_btd_init(size_t n, const double* __restrict__ S, const double* __restrict__ Q,
+                                                  double* __restrict__ F) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) F[i] = S[i] + (Q ? Q[i] : 0.0);
+}
+
+__global__ __launch_bounds__(BK_THREADS) void k_btd_factor_block(int gs, double* D, int* ipiv, double* work, int* info) {
+  __shared__ double sv[16];
+  __shared__ int si[16];
+  __shared__ pp::BkInfo sbi;
+  TeamCtx ctx{sv, si};
+  pp::bk_factor(ctx, gs, D, gs, ipiv, work, &sbi, BK_EPS);
+  if (threadIdx.x == 0) { info[0] = sbi.npos; info[1] = sbi.nneg; info[2] = sbi.nzero; }
+}
+
+// column j of inv(D_t): Bunch-Kaufman solve of the unit vector e_j (one workgroup per column)
+__global__ __launch_bounds__(128) void k_btd_invert(int gs, const double* __restrict__ D, const int* __restrict__ ipiv,
+                                                    double* __restrict__ inv) {
+  __shared__ double sv[16];
+  __shared__ int si[16];
+  double* col = inv + (size_t)blockIdx.x * gs;
+  for (int i = threadIdx.x; i < gs; i += blockDim.x) col[i] = (i == (int)blockIdx.x) ? 1.0 : 0.0;
+  __syncthreads();
+  TeamCtx ctx{sv, si};
+  pp::bk_solve(ctx, gs, D, gs, ipiv, col);
+}
+
+// X = inv E^T   (X[i][j] = sum_k inv[i][k] E[j][k]; all gs x gs, column-major)
+__global__ __launch_bounds__(256) void k_btd_xt(int gs, const double* __restrict__ inv, const double* __restrict__ E,
+                                                double* __restrict__ X) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= gs * gs) return;
+  const int i = idx % gs, j = idx / gs;
+  double s = 0.0;
+  for (int k = 0; k < gs; ++k) s += inv[(size_t)i + (size_t)k * gs] * E[(size_t)j + (size_t)k * gs];
+  X[idx] = s;
+}
+
+// Dn -= E X   (Dn[i][j] -= sum_k E[i][k] X[k][j])
+__global__ __launch_bounds__(256) void k_btd_update(int gs, const double* __restrict__ E, const double* __restrict__ X,
+                                                    double* __restrict__ Dn) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= gs * gs) return;
+  const int i = idx % gs, j = idx / gs;
+  double s = 0.0;
+  for (int k = 0; k < gs; ++k) s += E[(size_t)i + (size_t)k * gs] * X[(size_t)k + (size_t)j * gs];
+  Dn[idx] -= s;
+}
+
+__global__ void k_btd_finish(int G, const int* __restrict__ infos, int* __restrict__ bkinfo, const double* __restrict__ tail,
+                             const int* __restrict__ scatter_err, long long* status_out, long long seq) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int pos = 0, neg = 0, zero = 0;
+  for (int t = 0; t < G; ++t) { pos += infos[4 * t]; neg += infos[4 * t + 1]; zero += infos[4 * t + 2]; }
+  bkinfo[0] = pos; bkinfo[1] = neg; bkinfo[2] = zero;
+  publish_status(tail, bkinfo, status_out, seq);
+  if (scatter_err[0]) { status_out[0] = 3; }
+}
+
+// x = S^-1 (rc + rs) with the block factor: forward c_{t+1} = b_{t+1} - E_t w_t, w_t = inv_t c_t; backward
+// x_t = w_t - X_t x_{t+1}.  One workgroup; thread = row of the current block.
+__global__ __launch_bounds__(512) void k_btd_solve(int gs, int G, const double* __restrict__ F, const double* __restrict__ inv,
+                                                   const double* __restrict__ X, const double* rc, const double* rs,
+                                                   double* __restrict__ w, double* __restrict__ xc) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];   // c (gs) | v (gs)
+  double* c = sh;
+  double* v = sh + gs;
+  const int r = threadIdx.x;
+  const size_t g2 = (size_t)gs * gs;
+  const double* E = F + (size_t)G * g2;
+  for (int t = 0; t < G; ++t) {
+    if (r < gs) {
+      double b = (rc ? rc[(size_t)t * gs + r] : 0.0) + rs[(size_t)t * gs + r];
+      if (t > 0) {               // - E_{t-1} w_{t-1}
+        const double* Et = E + (size_t)(t - 1) * g2;
+        double s = 0.0;
+        for (int k = 0; k < gs; ++k) s += Et[(size_t)r + (size_t)k * gs] * v[k];
+        b -= s;
+      }
+      c[r] = b;
+    }
+    __syncthreads();
+    if (r < gs) {
+      const double* It = inv + (size_t)t * g2;
+      double s = 0.0;
+      for (int k = 0; k < gs; ++k) s += It[(size_t)r + (size_t)k * gs] * c[k];
+      w[(size_t)t * gs + r] = s;
+      v[r] = s;                  // (read by the next block after the barrier below)
+    }
+    __syncthreads();
+  }
+  for (int t = G - 1; t >= 0; --t) {
+    if (r < gs) {
+      double xv = w[(size_t)t * gs + r];
+      if (t < G - 1) {
+        const double* Xt = X + (size_t)t * g2;
+        double s = 0.0;
+        for (int k = 0; k < gs; ++k) s += Xt[(size_t)r + (size_t)k * gs] * c[k];
+        xv -= s;
+      }
+      v[r] = xv;
+      xc[(size_t)t * gs + r] = xv;
+    }
+    __syncthreads();
+    if (r < gs) c[r] = v[r];
+    __syncthreads();
+  }
+}
+
 // xc = S^-1 (rc + rs): blocked LDL^T factor if it was accepted, else the Bunch-Kaufman factor
 // THREADS x NBS: 512 threads with 32-column segments (n_c <= 512), or 1024 threads with 16-column segments
 // (512 < n_c <= 1024: two 16-entry segments are what 128 VGPRs per thread leave room for; the global-memory
@@ -1542,7 +1718,7 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_level(GroupDev g, int col0, int
 
 // coupling row c: rspart[chunk][c] = - sum over active instances and panels of L[c,k] y_k
 // (one wave per row: 200 rows x 16 chunks fill the chip, and a team of waves per row measured slower here)
-__global__ __launch_bounds__(64) void k_fwd_coupling(GroupDev g) {
+__global__ __launch_bounds__(64) void k_fwd_coupling(GroupDev g, double* __restrict__ rs_mapped) {
   const int lane = threadIdx.x;
   const int chunk = PP_CHUNK_OF_WG(g.nchunk);
   const int b = chunk * 64 + lane;
@@ -1550,6 +1726,10 @@ __global__ __launch_bounds__(64) void k_fwd_coupling(GroupDev g) {
   const int c = PP_TASK_OF_WG(g.nchunk);
   double s = -gather_row(g.crow_upos, g.crow_zcol, g.crow_eptr[c], g.crow_eptr[c + 1], g.L + b, g.Y + b, bpad, lane);
   if (b >= g.batch) s = 0.0;
+  if (g.cmapT) {      // mapped group: every instance adds to coupling rows of its own
+    if (b < g.batch && s != 0.0) atomicAdd(&rs_mapped[g.cmapT[(size_t)c * bpad + b]], s);
+    return;
+  }
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
   if (lane == 0) g.rspart[(size_t)chunk * g.nc + c] = s;
 }
@@ -1596,7 +1776,7 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_level(GroupDev g, int col0, int
   if (NW == 1 && nr <= 4) {   // wide bottom levels: short panels, plain scalar index reads
     for (int j = 0; j < nr; ++j) {
       const int r = ri[j];
-      g0 += Lp[(size_t)j * rstride] * ((r < n) ? Xb[(size_t)r * bpad] : xc[r - n]);
+      g0 += Lp[(size_t)j * rstride] * ((r < n) ? Xb[(size_t)r * bpad] : xc[(size_t)(r - n) * g.xs_row + (size_t)b * g.xs_lane]);
     }
   } else {
     for (int jb = j0; jb < j1; jb += 64) {
@@ -1610,7 +1790,7 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_level(GroupDev g, int col0, int
     _Pragma("unroll") for (int i = 0; i < G; ++i) {                                        \
       const int qq = min(i0 + i, cnt - 1);                                                 \
       u[i] = Lp[(size_t)(jb + qq) * rstride];                                              \
-      x[i] = (rr[i] < n) ? Xb[(size_t)rr[i] * bpad] : xc[rr[i] - n];                       \
+      x[i] = (rr[i] < n) ? Xb[(size_t)rr[i] * bpad] : xc[(size_t)(rr[i] - n) * g.xs_row + (size_t)b * g.xs_lane]; \
     }                                                                                      \
     _Pragma("unroll") for (int i = 0; i < G; i += 2) {                                     \
       g0 += (i0 + i < cnt) ? u[i] * x[i] : 0.0;                                            \
@@ -1743,6 +1923,8 @@ struct Group {
   std::vector<int> fent_host, init_rec;        // entry records as uploaded; positions of the initial-value records
   int *fent_src = nullptr;                     // device: the same records with the initial-value ones pointing at sources
   double *xout_own = nullptr;
+  int nc_loc = 0;                    // coupling rows of the group's plan (== n_c unless the group is mapped)
+  std::vector<int> cmap_host;        // mapped group: [batch][nc_loc] global coupling indices
 };
 
 }  // namespace
@@ -1765,6 +1947,10 @@ struct pp_solver {
   long long status_seq = 0;
   double fail_code = 0.0;
   double* vec_part = nullptr;    // scratch of the f4 vector kernels
+  // coupling structure: dense S (default) or block-tridiagonal with G blocks of gs rows (n_c = G * gs)
+  int btd = 0, gs = 0, G = 0;
+  double *btd_fac = nullptr, *btd_inv = nullptr, *btd_x = nullptr, *btd_q = nullptr, *btd_vec = nullptr;
+  int *btd_ipiv = nullptr, *btd_info = nullptr, *scatter_err = nullptr;
   double growth_bound = 1e8;     // 1 / u_rt: a factor entry beyond it flags its instance
   bool growth_fatal = false;     // flagged instances make the factorisation report status 2 (else they are only counted)
   double pivot_threshold = 0.0;  // symbolic-time threshold u for groups added afterwards (0: plan default)
@@ -1794,6 +1980,10 @@ struct pp_solver {
 };
 
 namespace {
+
+size_t schur_doubles(pp_handle h) {
+  return h->btd ? (size_t)(2 * h->G - 1) * h->gs * h->gs : (size_t)h->nc * h->nc;
+}
 
 int fail(pp_handle h, int status, const std::string& msg) {
   if (h) h->err = msg;
@@ -1921,6 +2111,11 @@ void free_globals(pp_handle h) {
   h->dense_mode = nullptr;
   h->ipiv = h->bkinfo = h->counters = nullptr;
   if (h->vec_part) { (void)hipFree(h->vec_part); h->vec_part = nullptr; }
+  for (void* p : {(void*)h->btd_fac, (void*)h->btd_inv, (void*)h->btd_x, (void*)h->btd_vec, (void*)h->btd_ipiv, (void*)h->btd_info,
+                  (void*)h->scatter_err})
+    if (p) (void)hipFree(p);
+  h->btd_fac = h->btd_inv = h->btd_x = h->btd_vec = nullptr;
+  h->btd_ipiv = h->btd_info = h->scatter_err = nullptr;
   if (h->status_host) (void)hipHostFree((void*)h->status_host);
   h->status_host = nullptr;
   h->status_dev = nullptr;
@@ -1935,9 +2130,10 @@ int64_t value_storage_bytes(pp_handle h) {
     const GroupDev& d = g->dev;
     const int64_t bp = d.bpad;
     int64_t dbl = (int64_t)g->batch * g->nraw + (int64_t)std::max(g->nraw_used, 1) * bp + 2 * P.usize * bp +
-                  (int64_t)P.dsize * bp + (int64_t)std::max(P.bsize, 1) * bp + (int64_t)(P.n + h->nc) * bp +
+                  (int64_t)P.dsize * bp + (int64_t)std::max(P.bsize, 1) * bp + (int64_t)(P.n + g->nc_loc) * bp +
                   (int64_t)P.n * bp + 2 * (int64_t)g->batch * P.n + (int64_t)d.nchunk * std::max(g->ntiles, 1) * 64 +
-                  (int64_t)d.nchunk * std::max(h->nc, 1);
+                  (int64_t)d.nchunk * std::max(g->nc_loc, 1) +
+                  (g->cmap_host.empty() ? 0 : ((int64_t)std::max(g->ntiles, 1) * 64 + std::max(g->nc_loc, 1)) * bp);
     total += 8 * dbl + 2 * (int64_t)P.npiv * bp;
   }
   return total;
@@ -1950,6 +2146,7 @@ void free_value_storage(Group* g) {
   d.raw = d.rawT = d.U = d.L = d.Dinv = d.Tm = d.Y = d.X = d.rhs = d.xout = d.Spart = d.rspart = nullptr;
   d.codes = nullptr;
   d.growth = nullptr;
+  d.Sloc = d.XCL = nullptr;
   g->raw_own = g->rhs_own = g->xout_own = nullptr;
 }
 
@@ -1979,7 +2176,7 @@ int alloc_value_storage(pp_handle h) {
     const pp::Plan& P = g->plan;
     GroupDev& d = g->dev;
     const size_t bp = (size_t)d.bpad;
-    const int nc = h->nc;
+    const int nc = g->nc_loc;
     double* keep_raw = (d.raw && d.raw != g->raw_own) ? d.raw : nullptr;   // caller-bound buffers survive
     double* keep_rhs = (d.rhs && d.rhs != g->rhs_own) ? d.rhs : nullptr;
     if ((rc = value_alloc(h, g, &g->raw_own, (size_t)g->batch * g->nraw))) break;
@@ -1998,6 +2195,10 @@ int alloc_value_storage(pp_handle h) {
     d.xout = keep_x ? keep_x : g->xout_own;
     if ((rc = value_alloc(h, g, &d.Spart, (size_t)d.nchunk * std::max(g->ntiles, 1) * 64))) break;
     if ((rc = value_alloc(h, g, &d.rspart, (size_t)d.nchunk * std::max(nc, 1)))) break;
+    if (!g->cmap_host.empty()) {
+      if ((rc = value_alloc(h, g, &d.Sloc, (size_t)std::max(g->ntiles, 1) * 64 * bp))) break;
+      if ((rc = value_alloc(h, g, &d.XCL, (size_t)std::max(nc, 1) * bp))) break;
+    }
     if ((rc = value_alloc(h, g, &d.codes, (size_t)P.npiv * bp))) break;   // 16-bit codes
     if ((rc = value_alloc(h, g, &d.growth, 2 * bp))) break;        // flags of the running factorisation | of the last one
     if (hipMemset(d.growth, 0, 2 * bp * sizeof(int)) != hipSuccess) { rc = fail(h, 3, "hipMemset failed"); break; }
@@ -2070,14 +2271,40 @@ int pp_begin_symbolic(pp_handle h, int n_coupling) {
   h->groups.clear();
   free_globals(h);
   h->nc = n_coupling;
+  h->btd = 0; h->gs = h->G = 0;
   h->symbolic_done = h->blocks_factored = h->numeric_done = h->schur_done = false;
   return 0;
 }
+
+int pp_set_coupling_structure(pp_handle h, int mode, int gs, int G) {
+  if (!h) return 3;
+  if (h->symbolic_done || !h->groups.empty()) return fail(h, 3, "pp_set_coupling_structure: call right after pp_begin_symbolic");
+  if (mode == 0) { h->btd = 0; h->gs = h->G = 0; return 0; }
+  if (mode != 1 || gs < 1 || gs > 512 || G < 1 || (int64_t)gs * G != h->nc)
+    return fail(h, 3, "pp_set_coupling_structure: mode 1 needs n_c = G * gs, 1 <= gs <= 512");
+  h->btd = 1; h->gs = gs; h->G = G;
+  return 0;
+}
+
+int64_t pp_schur_buffer_doubles(pp_handle h) { return h ? (int64_t)(schur_doubles(h) + PP_TAIL) : 0; }
 
 int pp_add_group(pp_handle h, int n, int batch, int nnzK, const int32_t* rowK, const int32_t* colK, int nnzB,
                  const int32_t* rowB, const int32_t* colB, int nraw, const int32_t* can_ptr, const int32_t* can_idx,
                  const double* rep_vals, int* group_out) {
   if (!h) return 3;
+  return pp_add_group_mapped(h, n, batch, nnzK, rowK, colK, nnzB, rowB, colB, nraw, can_ptr, can_idx, rep_vals, h->nc,
+                             nullptr, group_out);
+}
+
+int pp_add_group_mapped(pp_handle h, int n, int batch, int nnzK, const int32_t* rowK, const int32_t* colK, int nnzB,
+                        const int32_t* rowB, const int32_t* colB, int nraw, const int32_t* can_ptr, const int32_t* can_idx,
+                        const double* rep_vals, int nc_loc, const int32_t* cmap, int* group_out) {
+  if (!h) return 3;
+  if (nc_loc < 0 || nc_loc > h->nc) return fail(h, 3, "pp_add_group_mapped: local coupling dimension out of range");
+  if (!cmap && nc_loc != h->nc) return fail(h, 3, "pp_add_group_mapped: a group without a map uses all coupling rows");
+  if (cmap)
+    for (size_t i = 0; i < (size_t)batch * nc_loc; ++i)
+      if (cmap[i] < 0 || cmap[i] >= h->nc) return fail(h, 3, "pp_add_group_mapped: coupling map entry out of range");
   if (h->symbolic_done) return fail(h, 3, "pp_add_group after pp_end_symbolic");
   if (batch <= 0 || n <= 0 || nraw < 0) return fail(h, 3, "bad group dimensions");
   Group* g = new Group();
@@ -2114,7 +2341,9 @@ int pp_add_group(pp_handle h, int n, int batch, int nnzK, const int32_t* rowK, c
       pos = end + 1;
     }
   }
-  int rc = pp::build_plan(n, h->nc, nnzK, rowK, colK, nnzB, rowB, colB, rep_vals, opt, g->plan);
+  g->nc_loc = nc_loc;
+  if (cmap) g->cmap_host.assign(cmap, cmap + (size_t)batch * nc_loc);
+  int rc = pp::build_plan(n, nc_loc, nnzK, rowK, colK, nnzB, rowB, colB, rep_vals, opt, g->plan);
   if (rc != 0) { std::string e = g->plan.error; delete g; return fail(h, rc, "symbolic analysis failed: " + e); }
   const int ncan = nnzK + nnzB;
   g->diag_can.assign((size_t)n, -1);
@@ -2139,7 +2368,8 @@ int pp_end_symbolic(pp_handle h) {
     const pp::Plan& P = g->plan;
     GroupDev& d = g->dev;
     std::memset(&d, 0, sizeof(d));
-    d.n = P.n; d.nc = nc; d.batch = g->batch; d.bpad = (g->batch + WAVE - 1) / WAVE * WAVE;
+    d.n = P.n; d.nc = g->nc_loc; d.batch = g->batch; d.bpad = (g->batch + WAVE - 1) / WAVE * WAVE;
+    d.xs_row = 1; d.xs_lane = 0;
     d.nchunk = d.bpad / WAVE; d.npiv = P.npiv; d.nraw = g->nraw; d.usize = P.usize;
     int rc;
     std::vector<int> uoff(P.piv_uoff.begin(), P.piv_uoff.end());
@@ -2239,6 +2469,14 @@ int pp_end_symbolic(pp_handle h) {
     if ((rc = dev_upload(h, g, &d.fent, fent))) return rc;
     g->fent_host = fent;
     d.const_row = -1;
+    if (!g->cmap_host.empty()) {      // [batch][nc_loc] -> [nc_loc][bpad] (padded lanes repeat instance 0: never used)
+      std::vector<int> cm((size_t)std::max(g->nc_loc, 1) * d.bpad, 0);
+      for (int c = 0; c < g->nc_loc; ++c)
+        for (int b = 0; b < d.bpad; ++b)
+          cm[(size_t)c * d.bpad + b] = g->cmap_host[(size_t)(b < g->batch ? b : 0) * g->nc_loc + c];
+      if ((rc = dev_upload(h, g, &d.cmapT, cm))) return rc;
+      d.xs_row = d.bpad; d.xs_lane = 1;
+    }
     if ((rc = dev_upload(h, g, &d.clevel_col, P.clevel_col))) return rc;
     {
       std::vector<int> frec, brec;
@@ -2291,14 +2529,30 @@ int pp_end_symbolic(pp_handle h) {
     g->ntiles = (int)P.stile_a.size();
   }
   int rc;
-  const size_t nn = (size_t)nc * nc;
+  if (h->btd && (h->G < 1 || h->gs < 1 || h->gs > 512 || (int64_t)h->G * h->gs != nc))
+    return fail(h, 3, "block-tridiagonal coupling structure: need n_c = G * gs with 1 <= gs <= 512");
+  for (Group* g : h->groups)
+    if (h->btd && g->cmap_host.empty() && nc > 0) return fail(h, 3, "block-tridiagonal S needs mapped groups (pp_add_group_mapped)");
+  const size_t nn = schur_doubles(h);
+  const size_t nd = h->btd ? 1 : nn;            // the dense factor copies are not needed for a block-tridiagonal S
   if ((rc = dev_alloc<double>(h, nullptr, &h->S_own, nn + PP_TAIL))) return rc;
-  if ((rc = dev_alloc<double>(h, nullptr, &h->Sfac, nn))) return rc;
-  if ((rc = dev_alloc<double>(h, nullptr, &h->Sldl, nn))) return rc;
+  if ((rc = dev_alloc<double>(h, nullptr, &h->Sfac, nd))) return rc;
+  if ((rc = dev_alloc<double>(h, nullptr, &h->Sldl, nd))) return rc;
+  if ((rc = dev_alloc<int>(h, nullptr, &h->scatter_err, 4))) return rc;
+  PP_HIP(hipMemset(h->scatter_err, 0, 4 * sizeof(int)));
+  if (h->btd) {
+    const size_t g2 = (size_t)h->gs * h->gs;
+    if ((rc = dev_alloc<double>(h, nullptr, &h->btd_fac, nn))) return rc;
+    if ((rc = dev_alloc<double>(h, nullptr, &h->btd_inv, (size_t)h->G * g2))) return rc;
+    if ((rc = dev_alloc<double>(h, nullptr, &h->btd_x, (size_t)std::max(h->G - 1, 1) * g2))) return rc;
+    if ((rc = dev_alloc<double>(h, nullptr, &h->btd_vec, 4 * (size_t)nc + 16))) return rc;
+    if ((rc = dev_alloc<int>(h, nullptr, &h->btd_ipiv, nc))) return rc;
+    if ((rc = dev_alloc<int>(h, nullptr, &h->btd_info, 4 * (size_t)h->G))) return rc;
+  }
   if ((rc = dev_alloc<double>(h, nullptr, &h->dvec, nc))) return rc;
   if ((rc = dev_alloc<int>(h, nullptr, &h->dense_mode, 4))) return rc;
   PP_HIP(hipMemset(h->dense_mode, 0, 4 * sizeof(int)));
-  if ((rc = dev_alloc<double>(h, nullptr, &h->Qd, nn))) return rc;
+  if ((rc = dev_alloc<double>(h, nullptr, &h->Qd, nn))) return rc;       // (dense: n_c x n_c; block-tridiagonal: the layout of S)
   if ((rc = dev_alloc<double>(h, nullptr, &h->work, 2 * (size_t)nc))) return rc;
   if ((rc = dev_alloc<double>(h, nullptr, &h->rs_own, nc))) return rc;
   if ((rc = dev_alloc<double>(h, nullptr, &h->rcd, nc))) return rc;
@@ -2561,7 +2815,7 @@ int pp_numeric_schur(pp_handle h) {
   PP_HIP(hipSetDevice(h->device));
   hipStream_t st = h->stream;
   const int nc = h->nc;
-  PP_HIP(hipMemsetAsync(h->S, 0, ((size_t)nc * nc + PP_TAIL) * sizeof(double), st));
+  PP_HIP(hipMemsetAsync(h->S, 0, (schur_doubles(h) + PP_TAIL) * sizeof(double), st));
   PP_HIP(hipMemsetAsync(h->counters, 0, 4 * sizeof(int), st));
   bool tail_written = false;
   for (Group* g : h->groups) {
@@ -2572,7 +2826,12 @@ int pp_numeric_schur(pp_handle h) {
       const size_t total8 = (size_t)P.npiv * d.bpad / 8;   // bpad is a multiple of 64
       hipLaunchKernelGGL(k_count_codes, dim3((unsigned)std::min<size_t>(512, (total8 + 255) / 256)), dim3(256), 0, st,
                          d.codes, total8, h->counters, d.growth, d.growth + d.bpad, d.batch);
-      if (g->ntiles > 0) {
+      if (g->ntiles > 0 && d.cmapT) {
+        // mapped group: per-instance cliques, scattered into the dense or the block-tridiagonal S
+        hipLaunchKernelGGL(k_schur_tiles, dim3((unsigned)g->ntiles * d.nchunk, 1, 2), dim3(64), 0, st, d);
+        const SchurTarget T{h->S, nc, h->btd, h->gs, h->G, h->scatter_err};
+        hipLaunchKernelGGL(k_scatter_schur, dim3((unsigned)g->ntiles * d.nchunk), dim3(64), 0, st, d, g->ntiles, T);
+      } else if (g->ntiles > 0) {
         hipLaunchKernelGGL(k_schur_tiles, dim3((unsigned)g->ntiles * d.nchunk, 1, 2), dim3(64), 0, st, d);
         const bool last = (g == h->groups.back());
         hipLaunchKernelGGL(k_schur_reduce, dim3(g->ntiles), dim3(64), 0, st, d, g->ntiles, h->S,
@@ -2581,7 +2840,7 @@ int pp_numeric_schur(pp_handle h) {
       }
     }
   }
-  if (!tail_written) hipLaunchKernelGGL(k_write_tail, dim3(1), dim3(64), 0, st, h->counters, h->S + (size_t)nc * nc);
+  if (!tail_written) hipLaunchKernelGGL(k_write_tail, dim3(1), dim3(64), 0, st, h->counters, h->S + schur_doubles(h));
   PP_HIP(hipGetLastError());
   h->numeric_done = true;
   h->schur_done = false;
@@ -2597,7 +2856,7 @@ int pp_fail_local(pp_handle h, int status) {
   if (!h || !h->symbolic_done) return fail(h, 3, "pp_fail_local before symbolic factorization");
   if (status < 1 || status > 3) return fail(h, 3, "pp_fail_local: status must be 1 (not_enough_memory), 2 (singular) or 3 (error)");
   PP_HIP(hipSetDevice(h->device));
-  const size_t nn = (size_t)h->nc * h->nc;
+  const size_t nn = schur_doubles(h);
   PP_HIP(hipMemsetAsync(h->S, 0, (nn + PP_TAIL) * sizeof(double), h->stream));
   h->fail_code = status == 1 ? 1.0 : status == 2 ? 1e3 : 1e6;
   PP_HIP(hipMemcpyAsync(h->S + nn + 3, &h->fail_code, sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -2619,7 +2878,36 @@ int pp_factor_schur(pp_handle h, const double* Q_host) {
   PP_HIP(hipSetDevice(h->device));
   hipStream_t st = h->stream;
   const int nc = h->nc;
-  const size_t nn = (size_t)nc * nc;
+  const size_t nn = schur_doubles(h);
+  if (nc > 0 && h->btd) {
+    // block-tridiagonal S: sequential block LDL^T, Bunch-Kaufman inside the blocks (see k_btd_*)
+    if (Q_host) PP_HIP(hipMemcpyAsync(h->Qd, Q_host, nn * sizeof(double), hipMemcpyHostToDevice, st));
+    const int gs = h->gs, G = h->G;
+    const size_t g2 = (size_t)gs * gs;
+    PhaseScope ps(h, 3, 2 + 4 * G);
+    hipLaunchKernelGGL(k_btd_init, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, nn, h->S, Q_host ? h->Qd : (const double*)nullptr,
+                       h->btd_fac);
+    double* D = h->btd_fac;
+    double* E = h->btd_fac + (size_t)G * g2;
+    const unsigned gb = (unsigned)((g2 + 255) / 256);
+    for (int t = 0; t < G; ++t) {
+      hipLaunchKernelGGL(k_btd_factor_block, dim3(1), dim3(BK_THREADS), 0, st, gs, D + (size_t)t * g2, h->btd_ipiv + (size_t)t * gs,
+                         h->btd_vec, h->btd_info + 4 * (size_t)t);
+      hipLaunchKernelGGL(k_btd_invert, dim3(gs), dim3(128), 0, st, gs, D + (size_t)t * g2, h->btd_ipiv + (size_t)t * gs,
+                         h->btd_inv + (size_t)t * g2);
+      if (t + 1 < G) {
+        hipLaunchKernelGGL(k_btd_xt, dim3(gb), dim3(256), 0, st, gs, h->btd_inv + (size_t)t * g2, E + (size_t)t * g2,
+                           h->btd_x + (size_t)t * g2);
+        hipLaunchKernelGGL(k_btd_update, dim3(gb), dim3(256), 0, st, gs, E + (size_t)t * g2, h->btd_x + (size_t)t * g2,
+                           D + (size_t)(t + 1) * g2);
+      }
+    }
+    hipLaunchKernelGGL(k_btd_finish, dim3(1), dim3(64), 0, st, G, h->btd_info, h->bkinfo, h->S + nn, h->scatter_err, h->status_dev,
+                       ++h->status_seq);
+    PP_HIP(hipGetLastError());
+    h->schur_done = true;
+    return 0;
+  }
   if (nc > 0) {
     if (Q_host) PP_HIP(hipMemcpyAsync(h->Qd, Q_host, nn * sizeof(double), hipMemcpyHostToDevice, st));
     const double* Qd = Q_host ? h->Qd : nullptr;
@@ -2698,7 +2986,7 @@ int pp_get_status(pp_handle h, int64_t out[4]) {
 int pp_get_schur(pp_handle h, double* S_host) {
   if (!h || !h->numeric_done) return fail(h, 3, "pp_get_schur before pp_numeric_local");
   PP_HIP(hipSetDevice(h->device));
-  PP_HIP(hipMemcpyAsync(S_host, h->S, (size_t)h->nc * h->nc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  PP_HIP(hipMemcpyAsync(S_host, h->S, schur_doubles(h) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   PP_HIP(hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -2758,10 +3046,10 @@ int pp_solve_forward(pp_handle h) {
       }
       if (join_streams(h, sp, fan)) return fail(h, 3, "stream join failed");
     }
-    if (nc > 0) {
+    if (d.nc > 0) {
       PhaseScope ps(h, 5, 2);
-      hipLaunchKernelGGL(k_fwd_coupling, dim3((unsigned)nc * d.nchunk), dim3(64), 0, st, d);
-      hipLaunchKernelGGL(k_rs_reduce, dim3((nc + 255) / 256), dim3(256), 0, st, d, h->rs);
+      hipLaunchKernelGGL(k_fwd_coupling, dim3((unsigned)d.nc * d.nchunk), dim3(64), 0, st, d, h->rs);
+      if (!d.cmapT) hipLaunchKernelGGL(k_rs_reduce, dim3((d.nc + 255) / 256), dim3(256), 0, st, d, h->rs);
     }
   }
   PP_HIP(hipGetLastError());
@@ -2783,6 +3071,13 @@ int pp_solve_coupling(pp_handle h, const double* rc_host) {
   const int nc = h->nc;
   if (nc == 0) return 0;
   if (rc_host) PP_HIP(hipMemcpyAsync(h->rcd, rc_host, (size_t)nc * sizeof(double), hipMemcpyHostToDevice, st));
+  if (h->btd) {
+    PhaseScope psb(h, 6, 1);
+    hipLaunchKernelGGL(k_btd_solve, dim3(1), dim3(512), 2 * (size_t)h->gs * sizeof(double), st, h->gs, h->G, h->btd_fac, h->btd_inv,
+                       h->btd_x, rc_host ? h->rcd : nullptr, h->rs, h->btd_vec + 16, h->xc);
+    PP_HIP(hipGetLastError());
+    return 0;
+  }
   PhaseScope ps(h, 6, 1);
   if (nc > BK_THREADS && nc <= 1024)
     hipLaunchKernelGGL((k_coupling_solve<1024, 16>), dim3(1), dim3(1024), (size_t)nc * sizeof(double), st, nc, h->Sfac,
@@ -2800,6 +3095,13 @@ int pp_solve_coupling_dev(pp_handle h, const double* rc_dev) {
   hipStream_t st = h->stream;
   const int nc = h->nc;
   if (nc == 0) return 0;
+  if (h->btd) {
+    PhaseScope psb(h, 6, 1);
+    hipLaunchKernelGGL(k_btd_solve, dim3(1), dim3(512), 2 * (size_t)h->gs * sizeof(double), st, h->gs, h->G, h->btd_fac, h->btd_inv,
+                       h->btd_x, rc_dev, h->rs, h->btd_vec + 16, h->xc);
+    PP_HIP(hipGetLastError());
+    return 0;
+  }
   PhaseScope ps(h, 6, 1);
   if (nc > BK_THREADS && nc <= 1024)
     hipLaunchKernelGGL((k_coupling_solve<1024, 16>), dim3(1), dim3(1024), (size_t)nc * sizeof(double), st, nc, h->Sfac,
@@ -2836,6 +3138,11 @@ int pp_solve_backward(pp_handle h) {
     const pp::Plan& P = g->plan;
     GroupDev& d = g->dev;
     PhaseScope ps(h, 7, P.n_levels + 1);
+    const double* xcp = h->xc;
+    if (d.cmapT && d.nc > 0) {     // mapped group: every instance reads the coupling values of its own rows
+      hipLaunchKernelGGL(k_gather_xc, dim3((unsigned)(((size_t)d.nc * d.bpad + 255) / 256)), dim3(256), 0, st, d, h->xc);
+      xcp = d.XCL;
+    }
     {
       const Splits sp = make_splits(h, d.nchunk);
       hipStream_t fan[PP_MAX_SPLIT];
@@ -2846,7 +3153,7 @@ int pp_solve_backward(pp_handle h) {
         const int team = g->bwd_level_team[(size_t)l];
         for (int q = 0; q < sp.n; ++q) {
           const int ny = sp.c0[q + 1] - sp.c0[q];
-#define PP_LAUNCH_BWD(NW) hipLaunchKernelGGL(k_bwd_level<NW>, dim3((unsigned)ncol * ny), dim3(64 * NW), 0, fan[q], d, c0, sp.c0[q], ny, h->xc)
+#define PP_LAUNCH_BWD(NW) hipLaunchKernelGGL(k_bwd_level<NW>, dim3((unsigned)ncol * ny), dim3(64 * NW), 0, fan[q], d, c0, sp.c0[q], ny, xcp)
           if (team == 16) PP_LAUNCH_BWD(16);
           else if (team == 4) PP_LAUNCH_BWD(4);
           else PP_LAUNCH_BWD(1);

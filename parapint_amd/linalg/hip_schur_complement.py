@@ -134,7 +134,7 @@ class _UnionMatrix(object):
 
 
 class _BlockInfo(object):
-    __slots__ = ('group', 'slot', 'raw_sig', 'n')
+    __slots__ = ('group', 'slot', 'raw_sig', 'n', 'cmap', 'br_cache')
 
 
 class _Group(object):
@@ -213,22 +213,39 @@ class HipEngine(object):
         self._S_t = None
         self._rs_t = None
 
-    def symbolic(self, nc, groups):
+    supports_block_tridiagonal = True
+
+    def symbolic(self, nc, groups, btd=None, cinv=None):
+        """nc: coupling dimension the library works with (padded to G * gs for a block-tridiagonal S); btd = (gs, G) or
+        None; cinv: old -> new coupling order (block-tridiagonal S), applied to the maps of mapped groups."""
+        import ctypes
         ns, lib, N = self.ns, self.lib, self._native
         self.nc = nc
         ns.check(lib.pp_begin_symbolic(ns.h, nc), 'pp_begin_symbolic')
+        if btd is not None:
+            ns.check(lib.pp_set_coupling_structure(ns.h, 1, int(btd[0]), int(btd[1])), 'pp_set_coupling_structure')
         for g in groups:
             keep = [N.i32(g.rowK), N.i32(g.colK), N.i32(g.rowB), N.i32(g.colB), N.i32(g.can_ptr), N.i32(g.can_idx)]
             rep = N.f64(g.rep_vals) if g.rep_vals is not None else (None, None)
-            import ctypes
             gid = ctypes.c_int(-1)
-            ns.check(lib.pp_add_group(ns.h, g.n, len(g.blocks), g.rowK.size, keep[0][1], keep[1][1], g.rowB.size,
-                                      keep[2][1], keep[3][1], g.nraw, keep[4][1], keep[5][1], rep[1],
-                                      ctypes.byref(gid)), 'pp_add_group')
+            cmaps = getattr(g, 'cmaps', None)
+            if cmaps and cmaps[0] is not None:
+                cm = np.stack(cmaps).astype(np.int64) if g.m > 0 else np.zeros((len(cmaps), 0), dtype=np.int64)
+                if cinv is not None:
+                    cm = cinv[cm]
+                cmk = N.i32(cm)
+                ns.check(lib.pp_add_group_mapped(ns.h, g.n, len(g.blocks), g.rowK.size, keep[0][1], keep[1][1], g.rowB.size,
+                                                 keep[2][1], keep[3][1], g.nraw, keep[4][1], keep[5][1], rep[1], int(g.m),
+                                                 cmk[1], ctypes.byref(gid)), 'pp_add_group_mapped')
+            else:
+                ns.check(lib.pp_add_group(ns.h, g.n, len(g.blocks), g.rowK.size, keep[0][1], keep[1][1], g.rowB.size,
+                                          keep[2][1], keep[3][1], g.nraw, keep[4][1], keep[5][1], rep[1],
+                                          ctypes.byref(gid)), 'pp_add_group')
         ns.check(lib.pp_end_symbolic(ns.h), 'pp_end_symbolic')
         torch = self._torch
         dev = torch.device('cuda', self.device)
-        self._S_t = torch.zeros(nc * nc + 8, dtype=torch.float64, device=dev)    # S | status / inertia / growth tail
+        self.schur_doubles = int(lib.pp_schur_buffer_doubles(ns.h)) - 8
+        self._S_t = torch.zeros(self.schur_doubles + 8, dtype=torch.float64, device=dev)   # S | status / inertia / growth tail
         self._rs_t = torch.zeros(max(nc, 1), dtype=torch.float64, device=dev)
         ns.check(lib.pp_bind_schur_buffer(ns.h, self._S_t.data_ptr()), 'pp_bind_schur_buffer')
         ns.check(lib.pp_bind_rs_buffer(ns.h, self._rs_t.data_ptr()), 'pp_bind_rs_buffer')
@@ -415,6 +432,21 @@ class HipEngine(object):
             self.ns.check(self.lib.pp_factor_schur(self.ns.h, Qp), 'pp_factor_schur')
             self.ns.check(self.lib.pp_synchronize(self.ns.h), 'pp_synchronize')   # Qf must outlive the H2D
 
+    def factor_schur_flat(self, Qflat):
+        """Q in the layout of the Schur buffer (block-tridiagonal S), or None."""
+        if Qflat is None:
+            self.ns.check(self.lib.pp_factor_schur(self.ns.h, None), 'pp_factor_schur')
+        else:
+            Qf, Qp = self._native.f64(Qflat)
+            self.ns.check(self.lib.pp_factor_schur(self.ns.h, Qp), 'pp_factor_schur')
+            self.ns.check(self.lib.pp_synchronize(self.ns.h), 'pp_synchronize')
+
+    def get_schur_flat(self):
+        S = np.zeros(self.schur_doubles)
+        _, p = self._native.f64(S)
+        self.ns.check(self.lib.pp_get_schur(self.ns.h, S.ctypes.data_as(type(p))), 'pp_get_schur')
+        return S
+
     def set_supernodes(self, wmax, tol_rows):
         """Block-pivot merging for the next symbolic factorisation (0 / -1: library defaults)."""
         self.ns.check(self.lib.pp_set_supernodes(self.ns.h, int(wmax), int(tol_rows)), 'pp_set_supernodes')
@@ -536,6 +568,10 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             self._eng.set_pivot_tolerance(0.0 if symbolic_pivot_threshold is None else symbolic_pivot_threshold,
                                           0.0 if pivot_tolerance is None else pivot_tolerance)
         self._growth_guard = bool(pivot_tolerance)
+        self._mapped = False                # blocks have local coupling rows + maps (dynamic problems)
+        self._btd = None                    # (block size, blocks) of a block-tridiagonal S, else None: dense
+        self._cperm = self._cinv = None     # ordering of the coupling variables under which S is block tridiagonal
+        self._dense_coupling_limit = 1024   # a mapped S up to this dimension stays dense
         self._classes = None                # regularisation classes by block index (kept across re-plans)
         self._device_maps = None            # (nsrc, value maps by block index) of a DeviceBlockMatrix (f2)
         self._dev_results = []
@@ -600,23 +636,39 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         self._nc = int(nc)
         groups, by_sig, binfo = [], {}, {}
         all_zero = True
+        empty_i, empty_d = np.zeros(0, dtype=np.int32), np.zeros(0)
+        # first pass: which coupling rows does every block touch?  If every block touches all of them (the union of the
+        # cliques of a stochastic program is dense, mpi_...:88-125) the groups are uniform; otherwise (time blocks of a
+        # dynamic problem, scenarios with a subset of the first-stage variables) every block gets LOCAL coupling rows and a
+        # map to the global ones, so that blocks with the same local structure still share one plan and one batch
+        fetched = {}
+        uniform = True
         for ndx in self.local_block_indices:
-            K = matrix.get_block(ndx, ndx)
-            A = matrix.get_block(last, ndx)
-            kr, kc, kd, kshape = _coo(K)
+            kr, kc, kd, kshape = _coo(matrix.get_block(ndx, ndx))
             if kshape[0] != kshape[1]:
                 raise ValueError('Matrix must be square')
-            n = kshape[0]
-            if A is None:
-                br, bc, bd = np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int32), np.zeros(0)
-            else:
-                br, bc, bd, _ = _coo(A)
-            raw_sig = (n, kr.tobytes(), kc.tobytes(), br.tobytes(), bc.tobytes())
+            A = matrix.get_block(last, ndx)
+            br, bc, bd = (empty_i, empty_i, empty_d) if A is None else _coo(A)[:3]
+            used = np.unique(br)
+            if used.size != self._nc:
+                uniform = False
+            fetched[ndx] = (kr, kc, kd, kshape[0], br, bc, bd, used)
+        self._mapped = (not uniform) and self._nc > 0
+        for ndx in self.local_block_indices:
+            kr, kc, kd, n, br, bc, bd, used = fetched[ndx]
+            m = self._nc
+            cmap = None
+            if self._mapped:
+                cmap = used.astype(np.int32)
+                m = cmap.size
+                br_global = br
+                br = np.searchsorted(cmap, br).astype(np.int32)
+            raw_sig = (n, m, kr.tobytes(), kc.tobytes(), br.tobytes(), bc.tobytes())
             g = by_sig.get(raw_sig)
             if g is None:
                 rowK, colK, cpK, ciK = _canonical(kr, kc, n, True)
                 rowB, colB, cpB, ciB = _canonical(br, bc, n, False)
-                can_sig = (n, rowK.tobytes(), colK.tobytes(), rowB.tobytes(), colB.tobytes())
+                can_sig = (n, m, rowK.tobytes(), colK.tobytes(), rowB.tobytes(), colB.tobytes())
                 g = by_sig.get(can_sig)
                 if g is None:
                     can_ptr = np.concatenate([cpK, cpB[1:] + cpK[-1]]).astype(np.int32)
@@ -624,11 +676,15 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
                     g = _Group(n, rowK, colK, rowB, colB, can_ptr, can_idx, kd.size, kd.size + bd.size,
                                (kr.copy(), kc.copy(), br.copy(), bc.copy()))
                     g.gid = len(groups)
+                    g.m = m
+                    g.cmaps = []
                     groups.append(g)
                     by_sig[can_sig] = g
                     by_sig[raw_sig] = g
             bi = _BlockInfo()
             bi.group, bi.slot, bi.n = g, len(g.blocks), n
+            bi.cmap = cmap
+            bi.br_cache = None if cmap is None else ((br_global.__array_interface__['data'][0], br_global.size), br, br_global)
             # blocks whose raw COO order differs from the group's reference order are
             # canonicalised on the host at every numeric call (quirk Q7)
             ref = g.raw_refs
@@ -636,6 +692,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
                           np.array_equal(kr, ref[0]) and np.array_equal(kc, ref[1]) and
                           np.array_equal(br, ref[2]) and np.array_equal(bc, ref[3]))
             g.blocks.append(ndx)
+            g.cmaps.append(cmap)
             binfo[ndx] = bi
             if g.rep_vals is None:
                 raw = np.concatenate([kd, bd])
@@ -644,6 +701,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
                     g.rep_vals = vals
             if np.any(kd != 0.0):
                 all_zero = False
+        self._coupling_structure(matrix, groups)
         pinned = getattr(self._eng, 'alloc_pinned', None)
         alloc = pinned if pinned is not None else (lambda shape: np.zeros(shape, dtype=np.double))
         for g in groups:
@@ -655,6 +713,74 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         self._groups, self._binfo = groups, binfo
         self._pattern_only = any(g.rep_vals is None for g in groups)
         return all_zero
+
+    def _border(self, matrix, ndx):
+        """COO of the border block A_ndx; for mapped groups with the rows in the block's local numbering."""
+        A = matrix.get_block(self.block_dim - 1, ndx)
+        if A is None:
+            return np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int32), np.zeros(0)
+        br, bc, bd = _coo(A)[:3]
+        if not self._mapped:
+            return br, bc, bd
+        bi = self._binfo[ndx]
+        key = (br.__array_interface__['data'][0], br.size)
+        if bi.br_cache is not None and bi.br_cache[0] == key:
+            return bi.br_cache[1], bc, bd
+        loc = np.searchsorted(bi.cmap, br)
+        loc[loc >= max(bi.cmap.size, 1)] = 0
+        if (br.size and bi.cmap.size == 0) or (br.size and np.any(bi.cmap[loc] != br)):
+            raise _PatternChanged()
+        loc = loc.astype(np.int32)
+        bi.br_cache = (key, loc, br)                      # (the global array is kept alive with its pointer)
+        return loc, bc, bd
+
+    def _coupling_structure(self, matrix, groups):
+        """Dense S, or -- for mapped groups whose cliques form a band (the time blocks of a dynamic problem only touch
+        the coupling variables of their own two links) -- an ordering and a block size under which S is block
+        tridiagonal.  The reference keeps S sparse for the same reason (mpi_...:88-125, 228-255).  Collective."""
+        nc = self._nc
+        self._cperm = self._cinv = None
+        self._btd = None
+        if not self._mapped or not getattr(self._eng, 'supports_block_tridiagonal', False) or nc <= self._dense_coupling_limit:
+            return
+        from scipy.sparse import coo_matrix
+        from scipy.sparse.csgraph import reverse_cuthill_mckee
+        # every rank needs the cliques of all blocks: one sum all-reduce of a [blocks][m_max + 1] table
+        nb = self.block_dim - 1
+        mmax = max([g.m for g in groups] + [0])
+        if self.comm.size > 1:
+            mmax = int(self.comm.allreduce_max(np.array([mmax], dtype=np.int64))[0])
+        table = np.zeros((nb, mmax + 1), dtype=np.int64)
+        for g in groups:
+            for ndx, cm in zip(g.blocks, g.cmaps):
+                table[ndx, 0] = cm.size
+                table[ndx, 1:1 + cm.size] = cm + 1
+        if self.comm.size > 1:
+            table = self.comm.allreduce_sum(table.astype(np.double)).astype(np.int64)
+        rows, cols = [np.arange(nc)], [np.arange(nc)]
+        for ndx in range(nb):
+            cm = table[ndx, 1:1 + table[ndx, 0]] - 1
+            rows.append(np.repeat(cm, cm.size))
+            cols.append(np.tile(cm, cm.size))
+        Qb = matrix.get_block(self.block_dim - 1, self.block_dim - 1)
+        if Qb is not None:
+            Qc = Qb.tocoo()
+            rows += [Qc.row, Qc.col]
+            cols += [Qc.col, Qc.row]
+        rows, cols = np.concatenate(rows), np.concatenate(cols)
+        P = coo_matrix((np.ones(rows.size), (rows, cols)), shape=(nc, nc)).tocsr()
+        perm = np.asarray(reverse_cuthill_mckee(P, symmetric_mode=True), dtype=np.int64)     # new -> old
+        inv = np.empty(nc, dtype=np.int64)
+        inv[perm] = np.arange(nc)
+        hb = int(np.abs(inv[rows] - inv[cols]).max())
+        gs = max(hb, 1)
+        G = -(-nc // gs)
+        if gs > 512 or G < 3:
+            return                                      # not banded enough: dense S
+        self._cperm, self._cinv = perm, inv
+        self._cperm_pad = np.concatenate([perm, -np.ones(gs * G - nc, dtype=np.int64)])     # new (padded) -> old, -1: padding
+        self._btd = (gs, G)
+        self._S_pattern = (rows, cols)
 
     @staticmethod
     def _layout_positions(g, kr, kc, br, bc):
@@ -708,11 +834,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             bi = self._binfo[ndx]
             g = bi.group
             kr, kc, kd, _ = _coo(matrix.get_block(ndx, ndx))
-            A = matrix.get_block(last, ndx)
-            if A is None:
-                br, bc, bd = empty_i, empty_i, empty_d
-            else:
-                br, bc, bd, _ = _coo(A)
+            br, bc, bd = self._border(matrix, ndx)
             arrays = (kr, kc, kd, br, bc, bd)
             if fast is not None and all(a.flags.c_contiguous for a in arrays) and \
                     kr.dtype == kc.dtype == br.dtype == bc.dtype == np.int32 and kd.dtype == bd.dtype == np.float64:
@@ -752,7 +874,10 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             row[g.can_cidx[g.can_ptr[:-1]]] = vals     # canonical sum on the first raw slot of each entry
 
     def _run_symbolic(self):
-        self.plan_stats = self._eng.symbolic(self._nc, self._groups)
+        if self._btd is not None:
+            self.plan_stats = self._eng.symbolic(self._btd[0] * self._btd[1], self._groups, btd=self._btd, cinv=self._cinv)
+        else:
+            self.plan_stats = self._eng.symbolic(self._nc, self._groups)
         self._have_classes = False
         if self._device_maps is not None:     # value maps are per plan, too
             self._apply_value_maps()
@@ -829,7 +954,8 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
                 br, bc, bd = np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int32), np.zeros(0)
             else:
                 br, bc, bd, _ = _coo(A)
-            rows = np.concatenate([g.rowB, br])
+            old_rows = g.rowB if not self._mapped else self._binfo[ndx].cmap[g.rowB]     # back to global coupling rows
+            rows = np.concatenate([old_rows, br])
             cols = np.concatenate([g.colB, bc])
             data = np.concatenate([np.zeros(g.rowB.size), bd])
             blocks[(last, ndx)] = coo_matrix((data, (rows, cols)), shape=(self._nc, n))
@@ -977,6 +1103,38 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             for g in self._groups:                           # (the new plan's device buffers are empty)
                 self._eng.upload_values_compact(g.gid, g.staging)
 
+    def _btd_q(self, Q):
+        """Dense symmetric Q (or None) -> the block-tridiagonal layout of the Schur buffer in the permuted order, with a
+        unit diagonal on the padding rows."""
+        gs, G = self._btd
+        g2 = gs * gs
+        flat = np.zeros((2 * G - 1) * g2)
+        pad = np.arange(self._nc, gs * G)
+        flat[(pad // gs) * g2 + (pad % gs) * (gs + 1)] = 1.0
+        if Q is not None:
+            i, j = np.nonzero(Q)
+            v = Q[i, j]
+            pi, pj = self._cinv[i], self._cinv[j]
+            bi_, bj_ = pi // gs, pj // gs
+            same = bi_ == bj_
+            np.add.at(flat, bi_[same] * g2 + (pi[same] % gs) + (pj[same] % gs) * gs, v[same])
+            low = bi_ == bj_ + 1                          # E_t = S(block t+1, block t): only this orientation is stored
+            np.add.at(flat, G * g2 + bj_[low] * g2 + (pi[low] % gs) + (pj[low] % gs) * gs, v[low])
+            if np.any(~same & ~low & (bj_ != bi_ + 1)):
+                raise RuntimeError('coupling block Q has entries outside the block-tridiagonal structure')
+        return flat
+
+    def _to_coupling_order(self, v):
+        """Coupling vector in the caller's order -> the library's (permuted, padded) order."""
+        if self._btd is None:
+            return v
+        out = np.zeros(self._btd[0] * self._btd[1])
+        out[self._cinv] = v
+        return out
+
+    def _from_coupling_order(self, v):
+        return v if self._btd is None else np.ascontiguousarray(v[self._cinv])
+
     def _coupling_block(self, matrix):
         last = self.block_dim - 1
         Qb = matrix.get_block(last, last)
@@ -1021,7 +1179,10 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         timer.stop('communicate')
         timer.stop('form SC')
         timer.start('factor SC')
-        self._guarded(res, self._eng.factor_schur, Q)
+        if self._btd is not None:
+            self._guarded(res, self._eng.factor_schur_flat, self._btd_q(Q))
+        else:
+            self._guarded(res, self._eng.factor_schur, Q)
         self._last_Q = Q
         st = self._guarded(res, self._eng.status)
         timer.stop('factor SC')
@@ -1107,7 +1268,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             self._eng.upload_rhs(g.gid, g.rhs_staging)
         self._eng.solve_forward()
         self._eng.allreduce_rs(self.comm)
-        rc = _flat(rhs.get_block(last)) if self._nc > 0 else None
+        rc = self._to_coupling_order(_flat(rhs.get_block(last))) if self._nc > 0 else None
         self._eng.solve_coupling(rc)
         self._eng.solve_backward()
         xout = {}
@@ -1120,7 +1281,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             else:
                 xout[g.gid] = np.empty(g.x_shape, dtype=np.double)
             self._eng.download_solution(g.gid, xout[g.gid])
-        coupling = self._eng.coupling_solution()
+        coupling = self._from_coupling_order(self._eng.coupling_solution())
         # (mpi_...:390 uses copy_structure(); every local block and the coupling block are set below and non-local
         # blocks stay unset either way, so a container that can skip the zero-filled placeholders is asked to)
         result = rhs.copy_structure_unset() if hasattr(rhs, 'copy_structure_unset') else rhs.copy_structure()
@@ -1155,10 +1316,24 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             self._eng.bind_solution_tensor(g.gid, out.group_tensors[g.gid])
         self._eng.solve_forward()
         self._eng.allreduce_rs(self.comm)
-        self._eng.solve_coupling_dev(rhs.coupling if self._nc > 0 else None)
+        rc_dev = rhs.coupling if self._nc > 0 else None
+        if self._btd is not None and rc_dev is not None:
+            import torch
+            if getattr(self, '_cinv_t', None) is None or self._cinv_t.numel() != self._nc:
+                self._cinv_t = torch.from_numpy(self._cinv).to(rc_dev.device)
+                self._rc_pad = self._eng.new_tensor((self._btd[0] * self._btd[1],))
+                self._xc_pad = self._eng.new_tensor((self._btd[0] * self._btd[1],))
+            self._rc_pad.zero_()
+            self._rc_pad[self._cinv_t] = rc_dev
+            rc_dev = self._rc_pad
+        self._eng.solve_coupling_dev(rc_dev)
         self._eng.solve_backward()
         if self._nc > 0:
-            self._eng.copy_coupling_solution(out.coupling)
+            if self._btd is not None:
+                self._eng.copy_coupling_solution(self._xc_pad)
+                out.coupling.copy_(self._xc_pad[self._cinv_t])
+            else:
+                self._eng.copy_coupling_solution(out.coupling)
         timer.stop('back_solve')
         return out
 
@@ -1171,8 +1346,28 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         self._eng.increase_memory_allocation(factor)
 
     def get_schur_complement(self):
-        """Dense all-reduced S (without Q) -- parity hook (reference: self.schur_complement)."""
-        return self._eng.get_schur()
+        """All-reduced S (without Q) -- parity hook (reference: self.schur_complement): dense array, or for a
+        block-tridiagonal S a SciPy COO matrix in the caller's ordering of the coupling variables."""
+        if self._btd is None:
+            return self._eng.get_schur()
+        from scipy.sparse import coo_matrix
+        gs, G = self._btd
+        g2 = gs * gs
+        flat = self._eng.get_schur_flat()
+        D = flat[:G * g2].reshape(G, gs, gs)              # [t][col][row]
+        E = flat[G * g2:].reshape(G - 1, gs, gs)
+        rows, cols, vals = [], [], []
+        t, c, r = np.nonzero(D)
+        rows.append(t * gs + r); cols.append(t * gs + c); vals.append(D[t, c, r])
+        t, c, r = np.nonzero(E)
+        rows += [(t + 1) * gs + r, t * gs + c]
+        cols += [t * gs + c, (t + 1) * gs + r]
+        vals += [E[t, c, r], E[t, c, r]]
+        rows, cols, vals = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+        keep = (rows < self._nc + 0 * rows) | True
+        pr, pc = np.minimum(rows, gs * G - 1), np.minimum(cols, gs * G - 1)
+        real = (self._cperm_pad[pr] >= 0) & (self._cperm_pad[pc] >= 0)
+        return coo_matrix((vals[real], (self._cperm_pad[pr[real]], self._cperm_pad[pc[real]])), shape=(self._nc, self._nc))
 
 
 # The serial class of the reference (explicit_schur_complement.py:16) is the same algebra without

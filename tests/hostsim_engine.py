@@ -32,7 +32,7 @@ class HostSimEngine(object):
         self.budget = None
         self.mem_factor = 1.0
 
-    def symbolic(self, nc, groups):
+    def symbolic(self, nc, groups, btd=None, cinv=None):
         L = hu.lib()
         self.nc = nc
         self.groups = []
@@ -42,7 +42,11 @@ class HostSimEngine(object):
             sg.g = g
             rep = None if g.rep_vals is None else np.ascontiguousarray(g.rep_vals, dtype=np.double)
             sg.keep = [np.ascontiguousarray(a, dtype=np.int32) for a in (g.rowK, g.colK, g.rowB, g.colB)]
-            sg.h = ctypes.c_void_p(L.ppsim_create(g.n, nc, g.rowK.size, hu._ip(sg.keep[0]), hu._ip(sg.keep[1]),
+            sg.m = getattr(g, 'm', nc)
+            sg.cmaps = getattr(g, 'cmaps', None)
+            if not sg.cmaps or sg.cmaps[0] is None:
+                sg.cmaps = None
+            sg.h = ctypes.c_void_p(L.ppsim_create(g.n, sg.m, g.rowK.size, hu._ip(sg.keep[0]), hu._ip(sg.keep[1]),
                                                   g.rowB.size, hu._ip(sg.keep[2]), hu._ip(sg.keep[3]),
                                                   None if rep is None else hu._dp(rep), 0, -1, ctypes.c_double(-1.0)))
             err = L.ppsim_error(sg.h)
@@ -89,7 +93,7 @@ class HostSimEngine(object):
                 U = np.zeros(sg.usize)
                 Lf = np.zeros(sg.usize)
                 D = np.zeros(L.ppsim_dsize(sg.h))
-                Sb = np.zeros((nc, nc))
+                Sb = np.zeros((sg.m, sg.m))
                 L.ppsim_factor(sg.h, hu._dp(np.ascontiguousarray(can)), hu._dp(U), hu._dp(Lf), hu._dp(D), hu._dp(Sb),
                                inertia.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), ctypes.c_double(1e-13))
                 if int(inertia[2]) > zeros_before and sg.zero_slot < 0:
@@ -98,7 +102,12 @@ class HostSimEngine(object):
                     growth += 1
                     if sg.growth_slot < 0:
                         sg.growth_slot = b
-                self.S += np.tril(Sb) + np.tril(Sb, -1).T
+                Sb = np.tril(Sb) + np.tril(Sb, -1).T
+                if sg.cmaps is None:
+                    self.S += Sb
+                else:
+                    cm = sg.cmaps[b]
+                    self.S[np.ix_(cm, cm)] += Sb
                 sg.U.append(U)
                 sg.L.append(Lf)
                 sg.Dinv.append(D)
@@ -178,9 +187,12 @@ class HostSimEngine(object):
             n = sg.g.n
             sg.W = []
             for b in range(sg.batch):
-                W = np.zeros(n + self.nc)
+                W = np.zeros(n + sg.m)
                 L.ppsim_forward(sg.h, hu._dp(sg.L[b]), hu._dp(np.ascontiguousarray(sg.rhs[b])), hu._dp(W))
-                self.rs += W[n:]
+                if sg.cmaps is None:
+                    self.rs += W[n:]
+                else:
+                    np.add.at(self.rs, sg.cmaps[b], W[n:])
                 sg.W.append(W)
 
     def allreduce_rs(self, comm):
@@ -200,8 +212,8 @@ class HostSimEngine(object):
             n = sg.g.n
             sg.x = np.zeros((sg.batch, n))
             for b in range(sg.batch):
-                X = np.zeros(n + self.nc)
-                X[n:] = self.xc
+                X = np.zeros(n + sg.m)
+                X[n:] = self.xc if sg.cmaps is None else self.xc[sg.cmaps[b]]
                 x = np.zeros(n)
                 L.ppsim_backward(sg.h, hu._dp(sg.L[b]), hu._dp(sg.Dinv[b]), hu._dp(sg.W[b]), hu._dp(X), hu._dp(x))
                 sg.x[b] = x

@@ -685,3 +685,48 @@ def case_growth_guard(make_engine):
     finally:
         if hasattr(guarded._eng, 'set_pivot_tolerance'):
             guarded._eng.set_pivot_tolerance(0.0, 0.0)       # (the host interpreter keeps the tolerance process-wide)
+
+
+# ---- dynamic (time-staged) problems: block-banded S (sc_ip_interface.py:274-357, mpi_...:88-125, 228-255) ------------
+def case_dynamic(make_engine, T, n_s, n_u=2, nfe=3, iteration=1, expect_block_tridiagonal=None, oracle=True, comm=None):
+    """The KKT layout of the reference's dynamic interface on a synthetic linear-quadratic problem: every time block
+    touches only the coupling rows of its own two links, so the blocks of one pattern share a plan through LOCAL
+    coupling rows + per-block maps and S is assembled by scattering their cliques -- dense for small systems,
+    block tridiagonal (after a bandwidth-reducing ordering) for large ones.  Against the oracle's restatement of the
+    reference (sparse S pattern from the union of the cliques), dense algebra where affordable, residual and inertia."""
+    from parapint_amd.examples.performance.schur_complement.dynamic_kkt import SyntheticDynamicKKT
+    model = SyntheticDynamicKKT(T, n_s, n_u, nfe)
+    kkt = model.build_kkt(comm=SerialComm() if comm is None else comm, iteration=iteration)
+    rhs = model.build_rhs(comm=SerialComm() if comm is None else comm)
+    solver = new_solver(make_engine, T)
+    assert solver.do_symbolic_factorization(kkt).status == LinearSolverStatus.successful
+    assert len(solver.plan_stats) == min(T, 3)                 # first, interior and last time blocks: three plans
+    if expect_block_tridiagonal is not None:
+        assert (solver._btd is not None) == expect_block_tridiagonal
+    assert solver.do_numeric_factorization(kkt).status == LinearSolverStatus.successful
+    x = solver.do_back_solve(rhs)
+    K = kkt.tocoo()
+    assert scaled_residual(K, x.flatten(), rhs.flatten()) <= RESID_TOL
+    n_vars = T * model.n_x + n_s * (T - 1)
+    n_cons = T * model.n_eq + 2 * n_s * (T - 1)
+    assert solver.get_inertia() == (n_vars, n_cons, 0)
+    if oracle:
+        oc = OracleMPISC({i: OracleScipy() for i in range(T)}, OracleScipy())
+        oc.do_symbolic_factorization(kkt)
+        oc.do_numeric_factorization(kkt)
+        xo = oc.do_back_solve(rhs).flatten()
+        assert np.abs(x.flatten() - xo).max() <= 1e-8 * np.abs(xo).max()
+        So = sp.coo_matrix(oc.schur_complement).toarray()
+        S = solver.get_schur_complement()
+        S = S.toarray() if sp.issparse(S) else S
+        assert np.abs(S - So).max() <= 1e-9 * np.abs(So).max()
+        assert oc.schur_complement.nnz < So.size or T <= 2       # the reference's S pattern is sparse, too
+    if K.shape[0] <= 3000:
+        xd = np.linalg.solve(K.toarray(), rhs.flatten())
+        assert np.abs(x.flatten() - xd).max() <= 1e-8 * np.abs(xd).max()
+    # a second factorisation with other values on the same plan
+    kkt2 = model.build_kkt(comm=SerialComm() if comm is None else comm, iteration=iteration + 1)
+    assert solver.do_numeric_factorization(kkt2).status == LinearSolverStatus.successful
+    x2 = solver.do_back_solve(rhs)
+    assert scaled_residual(kkt2.tocoo(), x2.flatten(), rhs.flatten()) <= RESID_TOL
+    return solver, model

@@ -534,3 +534,18 @@ def test_device_vector_kernels_f4():
     xd = s2.do_back_solve(s2.device_vector_from_host(model.build_rhs(comm=SerialComm())))
     t = xd.group_tensors[0]
     assert dv.max_abs(s2, t) == float(t.abs().max())
+
+
+@pytest.mark.parametrize('shape', [(2, 3), (6, 4), (70, 5)])
+def test_dynamic_time_blocks_dense_schur(shape):
+    """f3, small: mapped groups scattered into a dense S (n_c <= 1024); 70 time blocks = a full wave + a ragged one."""
+    sc.case_dynamic(make_engine, shape[0], shape[1], expect_block_tridiagonal=False)
+
+
+def test_dynamic_time_blocks_block_tridiagonal_schur():
+    """f3 at BASELINE.json configs[3]'s state dimension: T = 64 time blocks, n_s = 49 (n_c = 6174): ordering by reverse
+    Cuthill-McKee, block-tridiagonal S, block LDL^T with Bunch-Kaufman inside the blocks; against the oracle's
+    restatement of the reference (sparse S), residual and inertia."""
+    solver, model = sc.case_dynamic(make_engine, 64, 49, n_u=2, nfe=4, expect_block_tridiagonal=True)
+    gs, G = solver._btd
+    assert gs <= 160 and G * gs >= model.n_coupling

@@ -68,3 +68,8 @@ def test_status_severity_order():
 
 def test_pivot_growth_guard():
     sc.case_growth_guard(make_engine)
+
+
+@pytest.mark.parametrize('shape', [(2, 3), (6, 4), (9, 5)])
+def test_dynamic_time_blocks_with_local_coupling_maps(shape):
+    sc.case_dynamic(make_engine, shape[0], shape[1])
