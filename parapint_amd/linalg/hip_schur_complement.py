@@ -1188,6 +1188,8 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         timer.stop('factor SC')
         if st is not None:
             status, pos, neg, zero = st
+            if self._btd is not None:
+                pos -= self._btd[0] * self._btd[1] - self._nc        # the unit diagonal of the padding rows
             self._inertia = (pos, neg, zero)
             res.status = LinearSolverStatus(status)
             self.growth_instances = self._eng.growth_count()
