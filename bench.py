@@ -37,7 +37,9 @@ PHASES = ['assemble', 'factor_levels', 'schur_tiles', 'dense_S', 'fwd_levels', '
           'bwd_levels']
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_MFMA_PEAK_TF = 78.6    # MI355X public spec for fp64 matrix (= fp64 vector) throughput, SURVEY 8d
-WORKLOADS = {'C3': (1024, 1000, 4, 200), 'C2': (64, 400, 4, 100)}
+WORKLOADS = {'C3': (1024, 1000, 4, 200), 'C2': (64, 400, 4, 100),
+             # BASELINE.json configs[3]: 512 time blocks x ~4k variables, n_s = 49 states, banded coupling (block-tridiagonal S)
+             'C4': (512, 49, 2, 40)}
 
 
 def parse_args():
@@ -108,12 +110,13 @@ def main():
         sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    dynamic = args.workload == 'C4'
     N, n_q, m, n_t = WORKLOADS[args.workload]
     N, n_q, m, n_t = args.blocks or N, args.n_q or n_q, args.m or m, args.n_theta or n_t
 
     # ---- CPU baseline first: it forks worker processes, so it runs before the GPU is touched
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not dynamic:
         from oracle import cpu_baseline as cb
         cpu_baseline = cb.run(N, n_q, m, n_t, blocks_per_worker=max(1, min(64, N // 16)))   # ~10 s on 16 cores at C3
 
@@ -145,31 +148,62 @@ def main():
     dev = torch.device('cuda', local_rank)
 
     local = distribute_blocks(N, rank, world)
-    model = SyntheticKKT(N, n_q, m, n_t, local_blocks=local)
+    if dynamic:
+        from parapint_amd.examples.performance.schur_complement.dynamic_kkt import SyntheticDynamicKKT
+        model = SyntheticDynamicKKT(N, n_q, m, n_t, local_blocks=local)          # (T, n_s, n_u, nfe)
+        n_c = model.n_coupling
+        expected_inertia = (N * model.n_x + n_q * (N - 1), N * model.n_eq + 2 * n_q * (N - 1), 0)
+        host_kkt = lambda it: model.build_kkt(comm=comm, iteration=it)       # noqa: E731
+        set_sources = lambda s: {ndx: model.block_sources(ndx, 100 + s) for ndx in local}     # noqa: E731
+        host_kkt_of_set = lambda s, srcs: model.build_kkt(comm=comm, iteration=100 + s)       # noqa: E731
+        describe = ('%s: %d time blocks x %d variables (n_s=%d states, n_u=%d controls, %d elements; block dim %d), '
+                    '%d coupling variables (forward-link duals + coupling states), block-tridiagonal S' %
+                    (args.workload, N, model.n_x, n_q, m, n_t, model.block_dim(1), n_c))
+    else:
+        model = SyntheticKKT(N, n_q, m, n_t, local_blocks=local)
+        n_c = n_t
+        expected_inertia = (N * (model.n_y + n_q) + n_t, N * (model.n_y + n_t), 0)
+        host_kkt = lambda it: model.build_kkt(comm=comm, iteration=it)       # noqa: E731
+        w_entry = np.linspace(0.5, 1.5, model.n_y)
+
+        def set_sources(s):       # fresh Hessian values for every block, every entry and every set
+            out = {}
+            for ndx in local:
+                src = model.block_sources(ndx, None)
+                eps = np.random.default_rng(10_000 * (100 + s) + ndx).uniform(0.0, 0.5)
+                src[:model.n_y] = 2.0 + eps * w_entry
+                out[ndx] = src
+            return out
+        host_kkt_of_set = lambda s, srcs: model.build_kkt_from_sources(srcs, comm=comm)       # noqa: E731
+        describe = ('%s: %d scenario blocks x (n_q=%d, n_y=%d: %d primal vars, block dim %d), %d coupling vars' %
+                    (args.workload, N, n_q, model.n_y, n_q + model.n_y, model.block_dim, n_t))
     B = len(local)
     solver = HipSchurComplementLinearSolver({i: None for i in local}, None, comm=comm)
     eng = solver._eng
     lib, h = eng.lib, eng.ns.h
     if args.sn_wmax > 0 or args.sn_tol >= 0:
         eng.set_supernodes(args.sn_wmax, args.sn_tol)
-    A = model.border_matrix().tocsr()
-    expected_inertia = (N * (model.n_y + n_q) + n_t, N * (model.n_y + n_t), 0)
 
-    def residual_check(values_of, x_blocks, xc):
+    def flat(v):
+        return v.flatten() if hasattr(v, 'get_block') else np.asarray(v, dtype=np.double).ravel()
+
+    def residual_check(kkt, x, rhs):
         """max over the local block rows and the coupling rows of |Kx - b| / (|K|_inf |x|_inf + |b|_inf)."""
-        from scipy.sparse import coo_matrix
         worst = 0.0
-        rc_local = np.zeros(n_t)
-        for slot, ndx in enumerate(local):
-            K = coo_matrix((values_of(ndx), (model._row, model._col)), shape=(model.block_dim,) * 2).tocsr()
-            r = model.block_rhs(ndx)
-            xi = x_blocks[slot]
+        xc = flat(x.get_block(N))
+        rc_local = np.zeros(n_c)
+        for ndx in local:
+            K = kkt.get_block(ndx, ndx).tocsr()
+            A = kkt.get_block(N, ndx).tocsr()
+            xi, r = flat(x.get_block(ndx)), flat(rhs.get_block(ndx))
             res = K @ xi + A.T @ xc - r
             scale = abs(K).sum(axis=1).max() * max(np.abs(xi).max(), np.abs(xc).max()) + np.abs(r).max()
             worst = max(worst, float(np.abs(res).max() / scale))
             rc_local += A @ xi
         rc = comm.allreduce_sum(rc_local) if world > 1 else rc_local
-        worst = max(worst, float(np.abs(rc).max() / (np.abs(xc).max() * N + 1e-300)))
+        Qb = kkt.get_block(N, N)
+        rc = rc + (Qb.tocsr() @ xc if Qb is not None else 0.0) - flat(rhs.get_block(N))
+        worst = max(worst, float(np.abs(rc).max() / (np.abs(xc).max() * N + 1.0)))
         if world > 1:
             worst = float(comm.allreduce_max(np.array([worst]))[0])
         return worst
@@ -201,11 +235,9 @@ def main():
         boundary = {'it_per_s': 1.0 / med, 'ms_per_iteration': 1e3 * med, 'iterations': len(ts),
                     'note': 'host COO blocks in, host vectors out: needed entries staged into pinned memory on host '
                             'threads with the H2D overlapped, pinned D2H of x; median, max over ranks'}
-        xb = [np.asarray(x.get_block(ndx)) for ndx in local]
-        it_last = args.boundary_iterations
-        resid_boundary = residual_check(lambda ndx: model.block_values(ndx, it_last), xb, np.asarray(x.get_block(N)))
+        resid_boundary = residual_check(kkt_it, x, rhs)
         ok = ok and resid_boundary <= 1e-8 and tuple(solver.get_inertia()) == expected_inertia
-        del kkt, kkt_it, x, xb
+        del kkt, kkt_it, x
 
     # ---- (2) the measured path: device-resident matrix and vectors through the LinearSolverInterface methods
     dkkt = model.build_device_kkt(comm=comm)
@@ -213,21 +245,20 @@ def main():
     res = solver.do_symbolic_factorization(matrix=dkkt, raise_on_error=False)
     t_symbolic = time.perf_counter() - t0
     assert res.status == LinearSolverStatus.successful
-    st = solver.plan_stats[0]
-    ex = eng.ns.group_stats_ex(0)
+    gmain = max(range(len(solver.plan_stats)), key=lambda i: solver.plan_stats[i]['batch'])     # the largest group
+    st = solver.plan_stats[gmain]
+    ex = eng.ns.group_stats_ex(gmain)
     nsets = max(2, min(args.value_sets, args.steps + args.warmup))
-    base = np.stack([model.block_sources(ndx, None) for ndx in local])            # [B][nsrc]
-    w = np.linspace(0.5, 1.5, model.n_y)
-    bpad = dkkt.sources[0].shape[1]
     sets = []
-    for s in range(nsets):
-        src = base.copy()
-        for slot, ndx in enumerate(local):       # fresh Hessian values for every block, every entry and every set
-            eps = np.random.default_rng(10_000 * (100 + s) + ndx).uniform(0.0, 0.5)
-            src[slot, :model.n_y] = 2.0 + eps * w
-        t = torch.zeros((dkkt.nsrc, bpad), dtype=torch.float64, device=dev)
-        t[:, :B] = torch.from_numpy(np.ascontiguousarray(src.T)).to(dev)
-        sets.append((dkkt.with_sources({0: t}), src))
+    for sidx in range(nsets):
+        srcs = set_sources(sidx)
+        tensors = {}
+        for gid, blocks in dkkt.slots.items():
+            host = np.zeros(tuple(dkkt.sources[gid].shape))
+            for b, ndx in enumerate(blocks):
+                host[:, b] = srcs[ndx]
+            tensors[gid] = torch.from_numpy(host).to(dev)
+        sets.append((dkkt.with_sources(tensors), srcs if sidx == (args.warmup + args.steps - 1) % nsets else None))
     rhs_host = model.build_rhs(comm=comm)
     rhs_dev = solver.device_vector_from_host(rhs_host)
 
@@ -260,21 +291,24 @@ def main():
 
     # correctness of the last timed step: download and check against the assembled system
     k_last = (args.warmup + args.steps - 1) % nsets
-    src_last = sets[k_last][1]
     xh = xd.to_host(rhs_host)
-    xb = [np.asarray(xh.get_block(ndx)) for ndx in local]
-    slot_of = {ndx: slot for slot, ndx in enumerate(local)}
-    resid = residual_check(lambda ndx: model.block_values_from_sources(src_last[slot_of[ndx]])[0], xb,
-                           np.asarray(xh.get_block(N)))
+    resid = residual_check(host_kkt_of_set(k_last, sets[k_last][1]), xh, rhs_host)
     inertia = solver.get_inertia()
     ok = ok and resid <= 1e-8 and res.status == LinearSolverStatus.successful and tuple(inertia) == expected_inertia
 
     # ---- (3) device only: the same kernels driven through the C ABI without the Python class
+    qflat = solver._btd_q(dkkt.Q) if solver._btd is not None else None
+    qdense = None if (dkkt.Q is None or solver._btd is not None) else (dkkt.Q.toarray() if hasattr(dkkt.Q, 'toarray') else dkkt.Q)
+
     def raw_step(k):
-        eng.bind_source_tensor(0, sets[k % nsets][0].sources[0])
+        for gid, t in sets[k % nsets][0].sources.items():
+            eng.bind_source_tensor(gid, t)
         eng.numeric_local()
         eng.allreduce_schur(comm)
-        eng.factor_schur(None)
+        if solver._btd is not None:
+            eng.factor_schur_flat(qflat)
+        else:
+            eng.factor_schur(qdense)
         status = eng.status()
         eng.solve_forward()
         eng.allreduce_rs(comm)
@@ -315,8 +349,9 @@ def main():
     # ---- roofline of the dominant kernel class (by device time)
     z_K = st['canonical_entries']
     z_L = st['u_doubles']
-    sb = survey_bytes_per_block(z_K, z_L, st['n'], n_t, n_t)
-    bb = build_bytes_per_block(st, ex, n_t, B)
+    nc_blk = st['n_coupling']
+    sb = survey_bytes_per_block(z_K, z_L, st['n'], nc_blk, nc_blk)
+    bb = build_bytes_per_block(st, ex, nc_blk, B)
     survey_phase = {'assemble': 8.0 * (ex['nsrc'] + ex['raw_used']), 'factor_levels': float(sb['factor']),
                     'schur_tiles': float(sb['schur']), 'fwd_levels': sb['back_solve'] / 2.0,
                     'bwd_levels': sb['back_solve'] / 2.0}
@@ -333,7 +368,7 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
             ph = pmc['phases'].get(dom)
-            if ph and ph['launches_per_step'] > 0 and world == 1 and (N, n_q, m, n_t) == WORKLOADS['C3']:
+            if ph and ph['launches_per_step'] > 0 and world == 1 and args.workload == 'C3' and (N, n_q, m, n_t) == WORKLOADS['C3']:
                 traffic = ph['hbm_bytes_per_step'] / ph['launches_per_step']
         except Exception:
             traffic = None
@@ -358,8 +393,8 @@ def main():
 
     # dense phase (factorisation of S, replicated on every rank): fp64 MFMA work, SURVEY 8d F_S = n_c^3/3 + 4 n_c^2
     dense_phase = None
-    if 'dense_S' in phases and n_t > 0:
-        f_s = n_t ** 3 / 3.0 + 4.0 * n_t ** 2
+    if 'dense_S' in phases and n_c > 0 and solver._btd is None:
+        f_s = n_c ** 3 / 3.0 + 4.0 * n_c ** 2
         tf = f_s / (phases['dense_S']['ms_per_step'] * 1e-3) / 1e12
         dense_phase = {'flops': f_s, 'ms': phases['dense_S']['ms_per_step'], 'achieved_TFLOPs': tf,
                        'peak_fp64_mfma_TFLOPs': FP64_MFMA_PEAK_TF, 'frac': tf / FP64_MFMA_PEAK_TF,
@@ -371,11 +406,9 @@ def main():
             'metric': METRIC, 'value': value, 'unit': 'it/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'strong',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': '%s: %d scenario blocks x (n_q=%d, n_y=%d: %d primal vars, block dim %d), %d coupling '
-                                   'vars; per step 1 do_numeric_factorization + 1 do_back_solve through the '
+            'config': {'workload': describe + '; per step 1 do_numeric_factorization + 1 do_back_solve through the '
                                    'LinearSolverInterface methods on device-resident containers, fresh values each step '
-                                   '(%d value sets in HBM cycled, every Hessian entry of every block differs)' %
-                                   (args.workload, N, n_q, model.n_y, n_q + model.n_y, model.block_dim, n_t, nsets),
+                                   '(%d value sets in HBM cycled, every Hessian entry of every block differs)' % nsets,
                        'blocks_per_gpu': B, 'world_size': world, 'collective_backend': backend,
                        'parallelism': 'blocks round-robin over %d rank(s); all-reduce of [S | status | inertia] and '
                                       'of r_s' % world},

@@ -153,3 +153,36 @@ class SyntheticDynamicKKT(object):
             rhs.set_block(t, self.block_rhs(t))
         rhs.set_block(T, self.coupling_rhs())
         return rhs
+
+    # ------------------------------------------------------------------ f2: device-resident values
+    def value_map(self, t):
+        """(nsrc, src, coef) for the COO entries of K_t followed by those of A_t: the per-iteration array of this
+        problem is the Hessian diagonal (n_x values per block); the Jacobian of the linear dynamics, the link matrices
+        and the explicit zeros are constants.  Found by assembling the block once with marker values."""
+        key = 0 if t == 0 else (2 if t == self.T - 1 else 1)
+        cache = self.__dict__.setdefault('_maps', {})
+        if key not in cache:
+            marker = 1e9 + np.arange(self.n_x)
+            real = self.hessian_diagonal
+            self.hessian_diagonal = lambda tt, it=None: marker
+            try:
+                kd = self.block_matrix(t).tocoo().data
+            finally:
+                self.hessian_diagonal = real
+            bd = self.border_matrix(t).tocoo().data
+            vals = np.concatenate([kd, bd])
+            is_src = vals > 5e8
+            src = np.where(is_src, np.rint(vals - 1e9), -1).astype(np.int32)
+            coef = np.where(is_src, 1.0, vals)
+            cache[key] = (self.n_x, src, coef)
+        return cache[key]
+
+    def block_sources(self, t, iteration=None):
+        return self.hessian_diagonal(t, iteration)
+
+    def build_device_kkt(self, comm=None):
+        from parapint_amd.sparse.device_containers import DeviceBlockMatrix
+        maps = {t: self.value_map(t)[1:] for t in self.local_blocks}
+        dk = DeviceBlockMatrix(self.build_kkt(comm=comm, iteration=0), maps, self.n_x)
+        dk.Q = self.corner_matrix()                 # (sparse: n_c = 2 n_s (T - 1) can be tens of thousands)
+        return dk

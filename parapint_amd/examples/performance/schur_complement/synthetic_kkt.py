@@ -199,6 +199,15 @@ class SyntheticKKT(object):
         vals = coef * np.where(src >= 0, sources[np.maximum(src, 0)], 1.0)
         return vals[:self.nnz_per_block], vals[self.nnz_per_block:]
 
+    def build_kkt_from_sources(self, sources, comm=None):
+        """Host block matrix whose K_i carry the values of the given source vectors ({block: sources})."""
+        kkt = self.build_kkt(comm=comm, iteration=None)
+        n = self.block_dim
+        for ndx in self.local_blocks:
+            kv, _ = self.block_values_from_sources(sources[ndx])
+            kkt.set_block(ndx, ndx, coo_matrix((kv, (self._row, self._col)), shape=(n, n)))
+        return kkt
+
     def build_device_kkt(self, comm=None):
         """DeviceBlockMatrix of the KKT system: host pattern (iteration 0 values) + value maps; the solver's symbolic
         phase attaches the source tensors, ``set_sources_from_host`` / the caller's kernels fill them."""

