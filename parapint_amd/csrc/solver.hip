@@ -1507,56 +1507,102 @@ __global__ __launch_bounds__(BK_THREADS) void k_bk_factor(int n, const double* _
 // ------------------------------------------------------------------------------------------
 // Block-tridiagonal S (time-staged problems; the reference factorises a sparse COO S with its sub-solver,
 // mpi_...:88-125, 228-255, 352-361).  Storage: D[G][gs][gs] | E[G-1][gs][gs], E_t = S(block t+1, block t), column-major
-// inside a block.  Block LDL^T: for t = 0 .. G-1: Bunch-Kaufman of the updated D_t, explicit inverse of D_t (gs unit
-// right-hand sides, one workgroup each), X_t = inv(D_t) E_t^T, D_{t+1} -= E_t X_t.  inertia(S) = sum inertia(D_t)
-// (Haynsworth).  The solve is then matrix-vector products only.
+// inside a block.  Factorised by BLOCK CYCLIC REDUCTION: at level l (stride s = 2^l) the blocks i = s (2k + 1) are
+// eliminated together -- Bunch-Kaufman of D_i, explicit inverse (gs unit right-hand sides), Y_lo = inv_i S(i, i-s),
+// Y_up = inv_i S(i, i+s), then D_{i-s} -= S(i-s, i) Y_lo, D_{i+s} -= S(i+s, i) Y_up and the new coupling
+// S(i+s, i-s) = -S(i+s, i) Y_lo -- log2 G levels of batched block operations instead of G dependent steps; block 0 is
+// eliminated last.  inertia(S) = sum of the inertias of the eliminated D_i (Haynsworth).  The solve walks the same
+// levels with matrix-vector products only.  slot j of the coupling array holds S(j + s, j) at the current level; the
+// couplings of an eliminated block are copied to Klo / Kup for the solve.
+struct BcrLevel { const int* elim; int ne, s; };
+
 __global__ __launch_bounds__(256) void k_btd_init(size_t n, const double* __restrict__ S, const double* __restrict__ Q,
                                                   double* __restrict__ F) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) F[i] = S[i] + (Q ? Q[i] : 0.0);
 }
 
-__global__ __launch_bounds__(BK_THREADS) void k_btd_factor_block(int gs, double* D, int* ipiv, double* work, int* info) {
+__global__ __launch_bounds__(BK_THREADS) void k_bcr_factor(int gs, BcrLevel lv, double* D, int* ipiv, double* work, int* info) {
   __shared__ double sv[16];
   __shared__ int si[16];
   __shared__ pp::BkInfo sbi;
+  const int i = lv.elim[blockIdx.x];
   TeamCtx ctx{sv, si};
-  pp::bk_factor(ctx, gs, D, gs, ipiv, work, &sbi, BK_EPS);
-  if (threadIdx.x == 0) { info[0] = sbi.npos; info[1] = sbi.nneg; info[2] = sbi.nzero; }
+  pp::bk_factor(ctx, gs, D + (size_t)i * gs * gs, gs, ipiv + (size_t)i * gs, work + (size_t)blockIdx.x * 2 * gs, &sbi, BK_EPS);
+  if (threadIdx.x == 0) { info[4 * i] = sbi.npos; info[4 * i + 1] = sbi.nneg; info[4 * i + 2] = sbi.nzero; }
 }
 
-// column j of inv(D_t): Bunch-Kaufman solve of the unit vector e_j (one workgroup per column)
-__global__ __launch_bounds__(128) void k_btd_invert(int gs, const double* __restrict__ D, const int* __restrict__ ipiv,
+// column j of inv(D_i): Bunch-Kaufman solve of the unit vector e_j (one workgroup per column and block)
+__global__ __launch_bounds__(128) void k_bcr_invert(int gs, BcrLevel lv, const double* __restrict__ D, const int* __restrict__ ipiv,
                                                     double* __restrict__ inv) {
   __shared__ double sv[16];
   __shared__ int si[16];
-  double* col = inv + (size_t)blockIdx.x * gs;
-  for (int i = threadIdx.x; i < gs; i += blockDim.x) col[i] = (i == (int)blockIdx.x) ? 1.0 : 0.0;
+  const int i = lv.elim[blockIdx.y];
+  double* col = inv + (size_t)i * gs * gs + (size_t)blockIdx.x * gs;
+  for (int r = threadIdx.x; r < gs; r += blockDim.x) col[r] = (r == (int)blockIdx.x) ? 1.0 : 0.0;
   __syncthreads();
   TeamCtx ctx{sv, si};
-  pp::bk_solve(ctx, gs, D, gs, ipiv, col);
+  pp::bk_solve(ctx, gs, D + (size_t)i * gs * gs, gs, ipiv + (size_t)i * gs, col);
 }
 
-// X = inv E^T   (X[i][j] = sum_k inv[i][k] E[j][k]; all gs x gs, column-major)
-__global__ __launch_bounds__(256) void k_btd_xt(int gs, const double* __restrict__ inv, const double* __restrict__ E,
-                                                double* __restrict__ X) {
+// Klo_i = S(i, i-s) = slot(i-s)^T ... kept as the slot itself: Klo[i] = slot[i-s] (= S(i, i-s), rows of block i);
+// Kup[i] = slot[i] (= S(i+s, i)).  Ylo = inv_i Klo,  Yup = inv_i Kup^T.
+__global__ __launch_bounds__(256) void k_bcr_keep_y(int gs, int G, BcrLevel lv, const double* __restrict__ inv,
+                                                    const double* __restrict__ slot, double* __restrict__ Klo,
+                                                    double* __restrict__ Kup, double* __restrict__ Ylo, double* __restrict__ Yup) {
+  const int i = lv.elim[blockIdx.y], s = lv.s;
+  const size_t g2 = (size_t)gs * gs;
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= gs * gs) return;
-  const int i = idx % gs, j = idx / gs;
-  double s = 0.0;
-  for (int k = 0; k < gs; ++k) s += inv[(size_t)i + (size_t)k * gs] * E[(size_t)j + (size_t)k * gs];
-  X[idx] = s;
+  const int r = idx % gs, c = idx / gs;
+  const double* I = inv + (size_t)i * g2;
+  if (i - s >= 0) {
+    const double* Sl = slot + (size_t)(i - s) * g2;      // S(i, i-s)
+    Klo[(size_t)i * g2 + idx] = Sl[idx];
+    double a = 0.0;
+    for (int k = 0; k < gs; ++k) a += I[(size_t)r + (size_t)k * gs] * Sl[(size_t)k + (size_t)c * gs];
+    Ylo[(size_t)i * g2 + idx] = a;
+  }
+  if (i + s < G) {
+    const double* Su = slot + (size_t)i * g2;            // S(i+s, i)
+    Kup[(size_t)i * g2 + idx] = Su[idx];
+    double a = 0.0;
+    for (int k = 0; k < gs; ++k) a += I[(size_t)r + (size_t)k * gs] * Su[(size_t)c + (size_t)k * gs];   // inv_i S(i, i+s) = inv_i Kup^T
+    Yup[(size_t)i * g2 + idx] = a;
+  }
 }
 
-// Dn -= E X   (Dn[i][j] -= sum_k E[i][k] X[k][j])
-__global__ __launch_bounds__(256) void k_btd_update(int gs, const double* __restrict__ E, const double* __restrict__ X,
-                                                    double* __restrict__ Dn) {
+// which = 0: D_{i-s} -= Klo_i^T Ylo_i   and the new coupling  slot[i-s] = -Kup_i Ylo_i  (if both neighbours exist)
+// which = 1: D_{i+s} -= Kup_i Yup_i
+__global__ __launch_bounds__(256) void k_bcr_update(int gs, int G, BcrLevel lv, int which, const double* __restrict__ Klo,
+                                                    const double* __restrict__ Kup, const double* __restrict__ Ylo,
+                                                    const double* __restrict__ Yup, double* __restrict__ D, double* __restrict__ slot) {
+  const int i = lv.elim[blockIdx.y], s = lv.s;
+  const size_t g2 = (size_t)gs * gs;
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= gs * gs) return;
-  const int i = idx % gs, j = idx / gs;
-  double s = 0.0;
-  for (int k = 0; k < gs; ++k) s += E[(size_t)i + (size_t)k * gs] * X[(size_t)k + (size_t)j * gs];
-  Dn[idx] -= s;
+  const int r = idx % gs, c = idx / gs;
+  if (which == 0) {
+    if (i - s < 0) return;
+    const double* K = Klo + (size_t)i * g2;
+    const double* Y = Ylo + (size_t)i * g2;
+    double a = 0.0;
+    for (int k = 0; k < gs; ++k) a += K[(size_t)k + (size_t)r * gs] * Y[(size_t)k + (size_t)c * gs];      // (Klo^T Ylo)[r][c]
+    D[(size_t)(i - s) * g2 + idx] -= a;
+    if (i + s < G) {
+      const double* U = Kup + (size_t)i * g2;
+      double b = 0.0;
+      for (int k = 0; k < gs; ++k) b += U[(size_t)r + (size_t)k * gs] * Y[(size_t)k + (size_t)c * gs];    // (Kup Ylo)[r][c]
+      slot[(size_t)(i - s) * g2 + idx] = -b;             // S(i+s, i-s) for the next level (stride 2 s)
+    }
+  } else {
+    if (i + s >= G) return;
+    const double* U = Kup + (size_t)i * g2;
+    const double* Y = Yup + (size_t)i * g2;
+    double a = 0.0;
+    for (int k = 0; k < gs; ++k) a += U[(size_t)r + (size_t)k * gs] * Y[(size_t)k + (size_t)c * gs];      // (Kup Yup)[r][c]
+    D[(size_t)(i + s) * g2 + idx] -= a;
+  }
 }
 
 __global__ void k_btd_finish(int G, const int* __restrict__ infos, int* __restrict__ bkinfo, const double* __restrict__ tail,
@@ -1569,54 +1615,61 @@ __global__ void k_btd_finish(int G, const int* __restrict__ infos, int* __restri
   if (scatter_err[0]) { status_out[0] = 3; }
 }
 
-// x = S^-1 (rc + rs) with the block factor: forward c_{t+1} = b_{t+1} - E_t w_t, w_t = inv_t c_t; backward
-// x_t = w_t - X_t x_{t+1}.  One workgroup; thread = row of the current block.
-__global__ __launch_bounds__(512) void k_btd_solve(int gs, int G, const double* __restrict__ F, const double* __restrict__ inv,
-                                                   const double* __restrict__ X, const double* rc, const double* rs,
-                                                   double* __restrict__ w, double* __restrict__ xc) {
-  extern __shared__ __attribute__((aligned(16))) double sh[];   // c (gs) | v (gs)
-  double* c = sh;
-  double* v = sh + gs;
-  const int r = threadIdx.x;
+// solve, forward part of a level: phase 0: u_i = inv_i b_i (kept in w); phase 1: b_{i-s} -= Klo_i^T u_i;
+// phase 2: b_{i+s} -= Kup_i u_i.  One workgroup per eliminated block, thread = row.
+__global__ __launch_bounds__(512) void k_bcr_fwd(int gs, int G, BcrLevel lv, int phase, const double* __restrict__ inv,
+                                                 const double* __restrict__ Klo, const double* __restrict__ Kup,
+                                                 double* __restrict__ b, double* __restrict__ w) {
+  const int i = lv.elim[blockIdx.x], s = lv.s, r = threadIdx.x;
   const size_t g2 = (size_t)gs * gs;
-  const double* E = F + (size_t)G * g2;
-  for (int t = 0; t < G; ++t) {
-    if (r < gs) {
-      double b = (rc ? rc[(size_t)t * gs + r] : 0.0) + rs[(size_t)t * gs + r];
-      if (t > 0) {               // - E_{t-1} w_{t-1}
-        const double* Et = E + (size_t)(t - 1) * g2;
-        double s = 0.0;
-        for (int k = 0; k < gs; ++k) s += Et[(size_t)r + (size_t)k * gs] * v[k];
-        b -= s;
-      }
-      c[r] = b;
-    }
-    __syncthreads();
-    if (r < gs) {
-      const double* It = inv + (size_t)t * g2;
-      double s = 0.0;
-      for (int k = 0; k < gs; ++k) s += It[(size_t)r + (size_t)k * gs] * c[k];
-      w[(size_t)t * gs + r] = s;
-      v[r] = s;                  // (read by the next block after the barrier below)
-    }
-    __syncthreads();
+  if (r >= gs) return;
+  if (phase == 0) {
+    const double* I = inv + (size_t)i * g2;
+    const double* bi = b + (size_t)i * gs;
+    double a = 0.0;
+    for (int k = 0; k < gs; ++k) a += I[(size_t)r + (size_t)k * gs] * bi[k];
+    w[(size_t)i * gs + r] = a;
+  } else if (phase == 1) {
+    if (i - s < 0) return;
+    const double* K = Klo + (size_t)i * g2;
+    const double* u = w + (size_t)i * gs;
+    double a = 0.0;
+    for (int k = 0; k < gs; ++k) a += K[(size_t)k + (size_t)r * gs] * u[k];
+    b[(size_t)(i - s) * gs + r] -= a;
+  } else {
+    if (i + s >= G) return;
+    const double* U = Kup + (size_t)i * g2;
+    const double* u = w + (size_t)i * gs;
+    double a = 0.0;
+    for (int k = 0; k < gs; ++k) a += U[(size_t)r + (size_t)k * gs] * u[k];
+    b[(size_t)(i + s) * gs + r] -= a;
   }
-  for (int t = G - 1; t >= 0; --t) {
-    if (r < gs) {
-      double xv = w[(size_t)t * gs + r];
-      if (t < G - 1) {
-        const double* Xt = X + (size_t)t * g2;
-        double s = 0.0;
-        for (int k = 0; k < gs; ++k) s += Xt[(size_t)r + (size_t)k * gs] * c[k];
-        xv -= s;
-      }
-      v[r] = xv;
-      xc[(size_t)t * gs + r] = xv;
-    }
-    __syncthreads();
-    if (r < gs) c[r] = v[r];
-    __syncthreads();
+}
+
+// solve, backward part of a level: x_i = u_i - Ylo_i x_{i-s} - Yup_i x_{i+s}
+__global__ __launch_bounds__(512) void k_bcr_bwd(int gs, int G, BcrLevel lv, const double* __restrict__ Ylo,
+                                                 const double* __restrict__ Yup, const double* __restrict__ w,
+                                                 double* __restrict__ x) {
+  const int i = lv.elim[blockIdx.x], s = lv.s, r = threadIdx.x;
+  const size_t g2 = (size_t)gs * gs;
+  if (r >= gs) return;
+  double a = w[(size_t)i * gs + r];
+  if (i - s >= 0) {
+    const double* Y = Ylo + (size_t)i * g2;
+    const double* xs = x + (size_t)(i - s) * gs;
+    for (int k = 0; k < gs; ++k) a -= Y[(size_t)r + (size_t)k * gs] * xs[k];
   }
+  if (i + s < G) {
+    const double* Y = Yup + (size_t)i * g2;
+    const double* xs = x + (size_t)(i + s) * gs;
+    for (int k = 0; k < gs; ++k) a -= Y[(size_t)r + (size_t)k * gs] * xs[k];
+  }
+  x[(size_t)i * gs + r] = a;
+}
+
+__global__ __launch_bounds__(256) void k_bcr_rhs(int n, const double* rc, const double* rs, double* b) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) b[i] = (rc ? rc[i] : 0.0) + rs[i];
 }
 
 // xc = S^-1 (rc + rs): blocked LDL^T factor if it was accepted, else the Bunch-Kaufman factor
@@ -1950,7 +2003,9 @@ struct pp_solver {
   // coupling structure: dense S (default) or block-tridiagonal with G blocks of gs rows (n_c = G * gs)
   int btd = 0, gs = 0, G = 0;
   double *btd_fac = nullptr, *btd_inv = nullptr, *btd_x = nullptr, *btd_q = nullptr, *btd_vec = nullptr;
-  int *btd_ipiv = nullptr, *btd_info = nullptr, *scatter_err = nullptr;
+  double *btd_klo = nullptr, *btd_kup = nullptr, *btd_ylo = nullptr, *btd_yup = nullptr;
+  int *btd_ipiv = nullptr, *btd_info = nullptr, *scatter_err = nullptr, *btd_elim = nullptr;
+  std::vector<int> bcr_off, bcr_ne, bcr_s;     // per level: offset into btd_elim, number of eliminated blocks, stride
   double growth_bound = 1e8;     // 1 / u_rt: a factor entry beyond it flags its instance
   bool growth_fatal = false;     // flagged instances make the factorisation report status 2 (else they are only counted)
   double pivot_threshold = 0.0;  // symbolic-time threshold u for groups added afterwards (0: plan default)
@@ -2112,10 +2167,10 @@ void free_globals(pp_handle h) {
   h->ipiv = h->bkinfo = h->counters = nullptr;
   if (h->vec_part) { (void)hipFree(h->vec_part); h->vec_part = nullptr; }
   for (void* p : {(void*)h->btd_fac, (void*)h->btd_inv, (void*)h->btd_x, (void*)h->btd_vec, (void*)h->btd_ipiv, (void*)h->btd_info,
-                  (void*)h->scatter_err})
+                  (void*)h->scatter_err, (void*)h->btd_klo, (void*)h->btd_kup, (void*)h->btd_ylo, (void*)h->btd_yup, (void*)h->btd_elim})
     if (p) (void)hipFree(p);
-  h->btd_fac = h->btd_inv = h->btd_x = h->btd_vec = nullptr;
-  h->btd_ipiv = h->btd_info = h->scatter_err = nullptr;
+  h->btd_fac = h->btd_inv = h->btd_x = h->btd_vec = h->btd_klo = h->btd_kup = h->btd_ylo = h->btd_yup = nullptr;
+  h->btd_ipiv = h->btd_info = h->scatter_err = h->btd_elim = nullptr;
   if (h->status_host) (void)hipHostFree((void*)h->status_host);
   h->status_host = nullptr;
   h->status_dev = nullptr;
@@ -2544,10 +2599,30 @@ int pp_end_symbolic(pp_handle h) {
     const size_t g2 = (size_t)h->gs * h->gs;
     if ((rc = dev_alloc<double>(h, nullptr, &h->btd_fac, nn))) return rc;
     if ((rc = dev_alloc<double>(h, nullptr, &h->btd_inv, (size_t)h->G * g2))) return rc;
-    if ((rc = dev_alloc<double>(h, nullptr, &h->btd_x, (size_t)std::max(h->G - 1, 1) * g2))) return rc;
-    if ((rc = dev_alloc<double>(h, nullptr, &h->btd_vec, 4 * (size_t)nc + 16))) return rc;
+    if ((rc = dev_alloc<double>(h, nullptr, &h->btd_klo, (size_t)h->G * g2))) return rc;
+    if ((rc = dev_alloc<double>(h, nullptr, &h->btd_kup, (size_t)h->G * g2))) return rc;
+    if ((rc = dev_alloc<double>(h, nullptr, &h->btd_ylo, (size_t)h->G * g2))) return rc;
+    if ((rc = dev_alloc<double>(h, nullptr, &h->btd_yup, (size_t)h->G * g2))) return rc;
+    if ((rc = dev_alloc<double>(h, nullptr, &h->btd_vec, 8 * (size_t)nc + 64))) return rc;    // BK work | b | u
     if ((rc = dev_alloc<int>(h, nullptr, &h->btd_ipiv, nc))) return rc;
     if ((rc = dev_alloc<int>(h, nullptr, &h->btd_info, 4 * (size_t)h->G))) return rc;
+    // cyclic-reduction schedule: level l eliminates the blocks i = s (2k + 1), s = 2^l; block 0 goes last
+    std::vector<int> elim;
+    h->bcr_off.clear(); h->bcr_ne.clear(); h->bcr_s.clear();
+    int sdt = 1;
+    for (; sdt < h->G; sdt *= 2) {
+      h->bcr_off.push_back((int)elim.size());
+      int ne = 0;
+      for (int i = sdt; i < h->G; i += 2 * sdt) { elim.push_back(i); ++ne; }
+      h->bcr_ne.push_back(ne);
+      h->bcr_s.push_back(sdt);
+    }
+    h->bcr_off.push_back((int)elim.size());
+    elim.push_back(0);
+    h->bcr_ne.push_back(1);
+    h->bcr_s.push_back(sdt);
+    if ((rc = dev_alloc<int>(h, nullptr, &h->btd_elim, elim.size()))) return rc;
+    PP_HIP(hipMemcpy(h->btd_elim, elim.data(), elim.size() * sizeof(int), hipMemcpyHostToDevice));
   }
   if ((rc = dev_alloc<double>(h, nullptr, &h->dvec, nc))) return rc;
   if ((rc = dev_alloc<int>(h, nullptr, &h->dense_mode, 4))) return rc;
@@ -2884,22 +2959,24 @@ int pp_factor_schur(pp_handle h, const double* Q_host) {
     if (Q_host) PP_HIP(hipMemcpyAsync(h->Qd, Q_host, nn * sizeof(double), hipMemcpyHostToDevice, st));
     const int gs = h->gs, G = h->G;
     const size_t g2 = (size_t)gs * gs;
-    PhaseScope ps(h, 3, 2 + 4 * G);
+    const int nlev = (int)h->bcr_ne.size();
+    PhaseScope ps(h, 3, 2 + 5 * nlev);
     hipLaunchKernelGGL(k_btd_init, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, nn, h->S, Q_host ? h->Qd : (const double*)nullptr,
                        h->btd_fac);
     double* D = h->btd_fac;
-    double* E = h->btd_fac + (size_t)G * g2;
+    double* slot = h->btd_fac + (size_t)G * g2;
     const unsigned gb = (unsigned)((g2 + 255) / 256);
-    for (int t = 0; t < G; ++t) {
-      hipLaunchKernelGGL(k_btd_factor_block, dim3(1), dim3(BK_THREADS), 0, st, gs, D + (size_t)t * g2, h->btd_ipiv + (size_t)t * gs,
-                         h->btd_vec, h->btd_info + 4 * (size_t)t);
-      hipLaunchKernelGGL(k_btd_invert, dim3(gs), dim3(128), 0, st, gs, D + (size_t)t * g2, h->btd_ipiv + (size_t)t * gs,
-                         h->btd_inv + (size_t)t * g2);
-      if (t + 1 < G) {
-        hipLaunchKernelGGL(k_btd_xt, dim3(gb), dim3(256), 0, st, gs, h->btd_inv + (size_t)t * g2, E + (size_t)t * g2,
-                           h->btd_x + (size_t)t * g2);
-        hipLaunchKernelGGL(k_btd_update, dim3(gb), dim3(256), 0, st, gs, E + (size_t)t * g2, h->btd_x + (size_t)t * g2,
-                           D + (size_t)(t + 1) * g2);
+    for (int l = 0; l < nlev; ++l) {
+      const BcrLevel lv{h->btd_elim + h->bcr_off[(size_t)l], h->bcr_ne[(size_t)l], h->bcr_s[(size_t)l]};
+      hipLaunchKernelGGL(k_bcr_factor, dim3(lv.ne), dim3(BK_THREADS), 0, st, gs, lv, D, h->btd_ipiv, h->btd_vec, h->btd_info);
+      hipLaunchKernelGGL(k_bcr_invert, dim3(gs, lv.ne), dim3(128), 0, st, gs, lv, D, h->btd_ipiv, h->btd_inv);
+      if (l + 1 < nlev) {
+        hipLaunchKernelGGL(k_bcr_keep_y, dim3(gb, lv.ne), dim3(256), 0, st, gs, G, lv, h->btd_inv, slot, h->btd_klo, h->btd_kup,
+                           h->btd_ylo, h->btd_yup);
+        hipLaunchKernelGGL(k_bcr_update, dim3(gb, lv.ne), dim3(256), 0, st, gs, G, lv, 0, h->btd_klo, h->btd_kup, h->btd_ylo,
+                           h->btd_yup, D, slot);
+        hipLaunchKernelGGL(k_bcr_update, dim3(gb, lv.ne), dim3(256), 0, st, gs, G, lv, 1, h->btd_klo, h->btd_kup, h->btd_ylo,
+                           h->btd_yup, D, slot);
       }
     }
     hipLaunchKernelGGL(k_btd_finish, dim3(1), dim3(64), 0, st, G, h->btd_info, h->bkinfo, h->S + nn, h->scatter_err, h->status_dev,
@@ -3073,8 +3150,21 @@ int pp_solve_coupling(pp_handle h, const double* rc_host) {
   if (rc_host) PP_HIP(hipMemcpyAsync(h->rcd, rc_host, (size_t)nc * sizeof(double), hipMemcpyHostToDevice, st));
   if (h->btd) {
     PhaseScope psb(h, 6, 1);
-    hipLaunchKernelGGL(k_btd_solve, dim3(1), dim3(512), 2 * (size_t)h->gs * sizeof(double), st, h->gs, h->G, h->btd_fac, h->btd_inv,
-                       h->btd_x, rc_host ? h->rcd : nullptr, h->rs, h->btd_vec + 16, h->xc);
+    {
+      const int gs = h->gs, G = h->G, nlev = (int)h->bcr_ne.size();
+      double* b = h->btd_vec + 2 * (size_t)nc + 16;
+      double* w = b + nc + 16;
+      hipLaunchKernelGGL(k_bcr_rhs, dim3((nc + 255) / 256), dim3(256), 0, st, nc, rc_host ? h->rcd : nullptr, h->rs, b);
+      for (int l = 0; l < nlev; ++l) {
+        const BcrLevel lv{h->btd_elim + h->bcr_off[(size_t)l], h->bcr_ne[(size_t)l], h->bcr_s[(size_t)l]};
+        for (int phase = 0; phase < (l + 1 < nlev ? 3 : 1); ++phase)
+          hipLaunchKernelGGL(k_bcr_fwd, dim3(lv.ne), dim3(512), 0, st, gs, G, lv, phase, h->btd_inv, h->btd_klo, h->btd_kup, b, w);
+      }
+      for (int l = nlev - 1; l >= 0; --l) {
+        const BcrLevel lv{h->btd_elim + h->bcr_off[(size_t)l], h->bcr_ne[(size_t)l], h->bcr_s[(size_t)l]};
+        hipLaunchKernelGGL(k_bcr_bwd, dim3(lv.ne), dim3(512), 0, st, gs, G, lv, h->btd_ylo, h->btd_yup, w, h->xc);
+      }
+    }
     PP_HIP(hipGetLastError());
     return 0;
   }
@@ -3097,8 +3187,21 @@ int pp_solve_coupling_dev(pp_handle h, const double* rc_dev) {
   if (nc == 0) return 0;
   if (h->btd) {
     PhaseScope psb(h, 6, 1);
-    hipLaunchKernelGGL(k_btd_solve, dim3(1), dim3(512), 2 * (size_t)h->gs * sizeof(double), st, h->gs, h->G, h->btd_fac, h->btd_inv,
-                       h->btd_x, rc_dev, h->rs, h->btd_vec + 16, h->xc);
+    {
+      const int gs = h->gs, G = h->G, nlev = (int)h->bcr_ne.size();
+      double* b = h->btd_vec + 2 * (size_t)nc + 16;
+      double* w = b + nc + 16;
+      hipLaunchKernelGGL(k_bcr_rhs, dim3((nc + 255) / 256), dim3(256), 0, st, nc, rc_dev, h->rs, b);
+      for (int l = 0; l < nlev; ++l) {
+        const BcrLevel lv{h->btd_elim + h->bcr_off[(size_t)l], h->bcr_ne[(size_t)l], h->bcr_s[(size_t)l]};
+        for (int phase = 0; phase < (l + 1 < nlev ? 3 : 1); ++phase)
+          hipLaunchKernelGGL(k_bcr_fwd, dim3(lv.ne), dim3(512), 0, st, gs, G, lv, phase, h->btd_inv, h->btd_klo, h->btd_kup, b, w);
+      }
+      for (int l = nlev - 1; l >= 0; --l) {
+        const BcrLevel lv{h->btd_elim + h->bcr_off[(size_t)l], h->bcr_ne[(size_t)l], h->bcr_s[(size_t)l]};
+        hipLaunchKernelGGL(k_bcr_bwd, dim3(lv.ne), dim3(512), 0, st, gs, G, lv, h->btd_ylo, h->btd_yup, w, h->xc);
+      }
+    }
     PP_HIP(hipGetLastError());
     return 0;
   }
