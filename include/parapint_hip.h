@@ -78,6 +78,10 @@ int pp_add_group_mapped(pp_handle h, int n, int batch, int nnzK, const int32_t* 
  * same layout, and S is factorised by a block LDL^T with Bunch-Kaufman inside the blocks; all groups must be mapped.
  * pp_schur_buffer_doubles: length of the Schur buffer (tail included) for the current structure. */
 int pp_set_coupling_structure(pp_handle h, int mode, int gs, int G);
+/* Elimination order of a block-tridiagonal S: 0 (default) block cyclic reduction -- log2 G levels of batched block
+ * operations --, 1 ascending block order (G dependent steps; the fallback when an odd-even diagonal block is singular:
+ * an indefinite S has singular principal submatrices).  May be changed between factorisations. */
+int pp_set_coupling_schedule(pp_handle h, int sequential);
 int64_t pp_schur_buffer_doubles(pp_handle h);
 
 /* Builds the plans' device images and allocates all device memory (_get_sc_structure,

@@ -30,6 +30,7 @@ SIGNATURES = {
                                            ctypes.c_int, _i32p, _i32p, ctypes.c_int, _i32p, _i32p, _f64p, ctypes.c_int, _i32p,
                                            ctypes.POINTER(ctypes.c_int)]),
     'pp_set_coupling_structure': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    'pp_set_coupling_schedule': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'pp_schur_buffer_doubles': (ctypes.c_int64, [ctypes.c_void_p]),
     'pp_end_symbolic': (ctypes.c_int, [ctypes.c_void_p]),
     'pp_upload_values': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]),

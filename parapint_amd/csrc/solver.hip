@@ -1514,7 +1514,7 @@ __global__ __launch_bounds__(BK_THREADS) void k_bk_factor(int n, const double* _
 // eliminated last.  inertia(S) = sum of the inertias of the eliminated D_i (Haynsworth).  The solve walks the same
 // levels with matrix-vector products only.  slot j of the coupling array holds S(j + s, j) at the current level; the
 // couplings of an eliminated block are copied to Klo / Kup for the solve.
-struct BcrLevel { const int* elim; int ne, s; };
+struct BcrLevel { const int* elim; int ne, s, lo; };   // lo = 0: the lower neighbour i - s is already eliminated (sequential order)
 
 __global__ __launch_bounds__(256) void k_btd_init(size_t n, const double* __restrict__ S, const double* __restrict__ Q,
                                                   double* __restrict__ F) {
@@ -1556,7 +1556,7 @@ __global__ __launch_bounds__(256) void k_bcr_keep_y(int gs, int G, BcrLevel lv, 
   if (idx >= gs * gs) return;
   const int r = idx % gs, c = idx / gs;
   const double* I = inv + (size_t)i * g2;
-  if (i - s >= 0) {
+  if (lv.lo && i - s >= 0) {
     const double* Sl = slot + (size_t)(i - s) * g2;      // S(i, i-s)
     Klo[(size_t)i * g2 + idx] = Sl[idx];
     double a = 0.0;
@@ -1583,7 +1583,7 @@ __global__ __launch_bounds__(256) void k_bcr_update(int gs, int G, BcrLevel lv, 
   if (idx >= gs * gs) return;
   const int r = idx % gs, c = idx / gs;
   if (which == 0) {
-    if (i - s < 0) return;
+    if (!lv.lo || i - s < 0) return;
     const double* K = Klo + (size_t)i * g2;
     const double* Y = Ylo + (size_t)i * g2;
     double a = 0.0;
@@ -1630,7 +1630,7 @@ __global__ __launch_bounds__(512) void k_bcr_fwd(int gs, int G, BcrLevel lv, int
     for (int k = 0; k < gs; ++k) a += I[(size_t)r + (size_t)k * gs] * bi[k];
     w[(size_t)i * gs + r] = a;
   } else if (phase == 1) {
-    if (i - s < 0) return;
+    if (!lv.lo || i - s < 0) return;
     const double* K = Klo + (size_t)i * g2;
     const double* u = w + (size_t)i * gs;
     double a = 0.0;
@@ -1654,7 +1654,7 @@ __global__ __launch_bounds__(512) void k_bcr_bwd(int gs, int G, BcrLevel lv, con
   const size_t g2 = (size_t)gs * gs;
   if (r >= gs) return;
   double a = w[(size_t)i * gs + r];
-  if (i - s >= 0) {
+  if (lv.lo && i - s >= 0) {
     const double* Y = Ylo + (size_t)i * g2;
     const double* xs = x + (size_t)(i - s) * gs;
     for (int k = 0; k < gs; ++k) a -= Y[(size_t)r + (size_t)k * gs] * xs[k];
@@ -2005,7 +2005,8 @@ struct pp_solver {
   double *btd_fac = nullptr, *btd_inv = nullptr, *btd_x = nullptr, *btd_q = nullptr, *btd_vec = nullptr;
   double *btd_klo = nullptr, *btd_kup = nullptr, *btd_ylo = nullptr, *btd_yup = nullptr;
   int *btd_ipiv = nullptr, *btd_info = nullptr, *scatter_err = nullptr, *btd_elim = nullptr;
-  std::vector<int> bcr_off, bcr_ne, bcr_s;     // per level: offset into btd_elim, number of eliminated blocks, stride
+  std::vector<int> bcr_off, bcr_ne, bcr_s, bcr_lo;   // per level: offset into btd_elim, eliminated blocks, stride, lower neighbour live
+  int btd_sequential = 0;
   double growth_bound = 1e8;     // 1 / u_rt: a factor entry beyond it flags its instance
   bool growth_fatal = false;     // flagged instances make the factorisation report status 2 (else they are only counted)
   double pivot_threshold = 0.0;  // symbolic-time threshold u for groups added afterwards (0: plan default)
@@ -2036,6 +2037,8 @@ struct pp_solver {
 
 namespace {
 
+int build_btd_schedule(pp_handle h);
+
 size_t schur_doubles(pp_handle h) {
   return h->btd ? (size_t)(2 * h->G - 1) * h->gs * h->gs : (size_t)h->nc * h->nc;
 }
@@ -2043,6 +2046,43 @@ size_t schur_doubles(pp_handle h) {
 int fail(pp_handle h, int status, const std::string& msg) {
   if (h) h->err = msg;
   return status;
+}
+
+// Elimination schedule of the block-tridiagonal S.  Cyclic reduction (default): level l eliminates the blocks
+// i = s (2k + 1), s = 2^l, block 0 goes last.  Sequential (btd_sequential): one block per level in ascending order, each
+// coupled only to its upper neighbour -- the fallback when a diagonal block of the odd-even order is singular (an
+// indefinite S has singular principal submatrices; the ascending order is the forward sweep of the time-staged problem).
+int build_btd_schedule(pp_handle h) {
+  std::vector<int> elim;
+  h->bcr_off.clear(); h->bcr_ne.clear(); h->bcr_s.clear(); h->bcr_lo.clear();
+  if (h->btd_sequential) {
+    for (int t = 0; t < h->G; ++t) {
+      h->bcr_off.push_back(t); h->bcr_ne.push_back(1); h->bcr_s.push_back(1); h->bcr_lo.push_back(0);
+      elim.push_back(t);
+    }
+  } else {
+    int sdt = 1;
+    for (; sdt < h->G; sdt *= 2) {
+      h->bcr_off.push_back((int)elim.size());
+      int ne = 0;
+      for (int i = sdt; i < h->G; i += 2 * sdt) { elim.push_back(i); ++ne; }
+      h->bcr_ne.push_back(ne);
+      h->bcr_s.push_back(sdt);
+      h->bcr_lo.push_back(1);
+    }
+    h->bcr_off.push_back((int)elim.size());
+    elim.push_back(0);
+    h->bcr_ne.push_back(1);
+    h->bcr_s.push_back(sdt);
+    h->bcr_lo.push_back(1);
+  }
+  if (h->btd_elim) { (void)hipFree(h->btd_elim); h->btd_elim = nullptr; }
+  void* p = nullptr;
+  if (hipMalloc(&p, std::max<size_t>(elim.size(), 1) * sizeof(int)) != hipSuccess) return fail(h, 1, "hipMalloc failed (schedule)");
+  h->btd_elim = (int*)p;
+  if (hipMemcpy(h->btd_elim, elim.data(), elim.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+    return fail(h, 3, "hipMemcpy failed (schedule)");
+  return 0;
 }
 
 // phase bracket: records events only in profile mode; durations are harvested lazily
@@ -2341,6 +2381,17 @@ int pp_set_coupling_structure(pp_handle h, int mode, int gs, int G) {
   return 0;
 }
 
+int pp_set_coupling_schedule(pp_handle h, int sequential) {
+  if (!h) return 3;
+  h->btd_sequential = sequential ? 1 : 0;
+  if (h->symbolic_done && h->btd) {
+    PP_HIP(hipSetDevice(h->device));
+    PP_HIP(hipStreamSynchronize(h->stream));
+    return build_btd_schedule(h);
+  }
+  return 0;
+}
+
 int64_t pp_schur_buffer_doubles(pp_handle h) { return h ? (int64_t)(schur_doubles(h) + PP_TAIL) : 0; }
 
 int pp_add_group(pp_handle h, int n, int batch, int nnzK, const int32_t* rowK, const int32_t* colK, int nnzB,
@@ -2606,23 +2657,7 @@ int pp_end_symbolic(pp_handle h) {
     if ((rc = dev_alloc<double>(h, nullptr, &h->btd_vec, 8 * (size_t)nc + 64))) return rc;    // BK work | b | u
     if ((rc = dev_alloc<int>(h, nullptr, &h->btd_ipiv, nc))) return rc;
     if ((rc = dev_alloc<int>(h, nullptr, &h->btd_info, 4 * (size_t)h->G))) return rc;
-    // cyclic-reduction schedule: level l eliminates the blocks i = s (2k + 1), s = 2^l; block 0 goes last
-    std::vector<int> elim;
-    h->bcr_off.clear(); h->bcr_ne.clear(); h->bcr_s.clear();
-    int sdt = 1;
-    for (; sdt < h->G; sdt *= 2) {
-      h->bcr_off.push_back((int)elim.size());
-      int ne = 0;
-      for (int i = sdt; i < h->G; i += 2 * sdt) { elim.push_back(i); ++ne; }
-      h->bcr_ne.push_back(ne);
-      h->bcr_s.push_back(sdt);
-    }
-    h->bcr_off.push_back((int)elim.size());
-    elim.push_back(0);
-    h->bcr_ne.push_back(1);
-    h->bcr_s.push_back(sdt);
-    if ((rc = dev_alloc<int>(h, nullptr, &h->btd_elim, elim.size()))) return rc;
-    PP_HIP(hipMemcpy(h->btd_elim, elim.data(), elim.size() * sizeof(int), hipMemcpyHostToDevice));
+    if ((rc = build_btd_schedule(h))) return rc;
   }
   if ((rc = dev_alloc<double>(h, nullptr, &h->dvec, nc))) return rc;
   if ((rc = dev_alloc<int>(h, nullptr, &h->dense_mode, 4))) return rc;
@@ -2967,7 +3002,7 @@ int pp_factor_schur(pp_handle h, const double* Q_host) {
     double* slot = h->btd_fac + (size_t)G * g2;
     const unsigned gb = (unsigned)((g2 + 255) / 256);
     for (int l = 0; l < nlev; ++l) {
-      const BcrLevel lv{h->btd_elim + h->bcr_off[(size_t)l], h->bcr_ne[(size_t)l], h->bcr_s[(size_t)l]};
+      const BcrLevel lv{h->btd_elim + h->bcr_off[(size_t)l], h->bcr_ne[(size_t)l], h->bcr_s[(size_t)l], h->bcr_lo[(size_t)l]};
       hipLaunchKernelGGL(k_bcr_factor, dim3(lv.ne), dim3(BK_THREADS), 0, st, gs, lv, D, h->btd_ipiv, h->btd_vec, h->btd_info);
       hipLaunchKernelGGL(k_bcr_invert, dim3(gs, lv.ne), dim3(128), 0, st, gs, lv, D, h->btd_ipiv, h->btd_inv);
       if (l + 1 < nlev) {
@@ -3156,12 +3191,12 @@ int pp_solve_coupling(pp_handle h, const double* rc_host) {
       double* w = b + nc + 16;
       hipLaunchKernelGGL(k_bcr_rhs, dim3((nc + 255) / 256), dim3(256), 0, st, nc, rc_host ? h->rcd : nullptr, h->rs, b);
       for (int l = 0; l < nlev; ++l) {
-        const BcrLevel lv{h->btd_elim + h->bcr_off[(size_t)l], h->bcr_ne[(size_t)l], h->bcr_s[(size_t)l]};
+        const BcrLevel lv{h->btd_elim + h->bcr_off[(size_t)l], h->bcr_ne[(size_t)l], h->bcr_s[(size_t)l], h->bcr_lo[(size_t)l]};
         for (int phase = 0; phase < (l + 1 < nlev ? 3 : 1); ++phase)
           hipLaunchKernelGGL(k_bcr_fwd, dim3(lv.ne), dim3(512), 0, st, gs, G, lv, phase, h->btd_inv, h->btd_klo, h->btd_kup, b, w);
       }
       for (int l = nlev - 1; l >= 0; --l) {
-        const BcrLevel lv{h->btd_elim + h->bcr_off[(size_t)l], h->bcr_ne[(size_t)l], h->bcr_s[(size_t)l]};
+        const BcrLevel lv{h->btd_elim + h->bcr_off[(size_t)l], h->bcr_ne[(size_t)l], h->bcr_s[(size_t)l], h->bcr_lo[(size_t)l]};
         hipLaunchKernelGGL(k_bcr_bwd, dim3(lv.ne), dim3(512), 0, st, gs, G, lv, h->btd_ylo, h->btd_yup, w, h->xc);
       }
     }
@@ -3193,12 +3228,12 @@ int pp_solve_coupling_dev(pp_handle h, const double* rc_dev) {
       double* w = b + nc + 16;
       hipLaunchKernelGGL(k_bcr_rhs, dim3((nc + 255) / 256), dim3(256), 0, st, nc, rc_dev, h->rs, b);
       for (int l = 0; l < nlev; ++l) {
-        const BcrLevel lv{h->btd_elim + h->bcr_off[(size_t)l], h->bcr_ne[(size_t)l], h->bcr_s[(size_t)l]};
+        const BcrLevel lv{h->btd_elim + h->bcr_off[(size_t)l], h->bcr_ne[(size_t)l], h->bcr_s[(size_t)l], h->bcr_lo[(size_t)l]};
         for (int phase = 0; phase < (l + 1 < nlev ? 3 : 1); ++phase)
           hipLaunchKernelGGL(k_bcr_fwd, dim3(lv.ne), dim3(512), 0, st, gs, G, lv, phase, h->btd_inv, h->btd_klo, h->btd_kup, b, w);
       }
       for (int l = nlev - 1; l >= 0; --l) {
-        const BcrLevel lv{h->btd_elim + h->bcr_off[(size_t)l], h->bcr_ne[(size_t)l], h->bcr_s[(size_t)l]};
+        const BcrLevel lv{h->btd_elim + h->bcr_off[(size_t)l], h->bcr_ne[(size_t)l], h->bcr_s[(size_t)l], h->bcr_lo[(size_t)l]};
         hipLaunchKernelGGL(k_bcr_bwd, dim3(lv.ne), dim3(512), 0, st, gs, G, lv, h->btd_ylo, h->btd_yup, w, h->xc);
       }
     }

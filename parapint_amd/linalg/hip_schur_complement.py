@@ -441,6 +441,9 @@ class HipEngine(object):
             self.ns.check(self.lib.pp_factor_schur(self.ns.h, Qp), 'pp_factor_schur')
             self.ns.check(self.lib.pp_synchronize(self.ns.h), 'pp_synchronize')
 
+    def set_coupling_schedule(self, sequential):
+        self.ns.check(self.lib.pp_set_coupling_schedule(self.ns.h, 1 if sequential else 0), 'pp_set_coupling_schedule')
+
     def get_schur_flat(self):
         S = np.zeros(self.schur_doubles)
         _, p = self._native.f64(S)
@@ -570,6 +573,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         self._growth_guard = bool(pivot_tolerance)
         self._mapped = False                # blocks have local coupling rows + maps (dynamic problems)
         self._btd = None                    # (block size, blocks) of a block-tridiagonal S, else None: dense
+        self._btd_sequential = False        # eliminate its blocks in ascending order instead of by cyclic reduction
         self._cperm = self._cinv = None     # ordering of the coupling variables under which S is block tridiagonal
         self._dense_coupling_limit = 1024   # a mapped S up to this dimension stays dense
         self._classes = None                # regularisation classes by block index (kept across re-plans)
@@ -757,14 +761,59 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
                 table[ndx, 1:1 + cm.size] = cm + 1
         if self.comm.size > 1:
             table = self.comm.allreduce_sum(table.astype(np.double)).astype(np.int64)
+        cliques = [table[ndx, 1:1 + table[ndx, 0]] - 1 for ndx in range(nb)]
+        Qb = matrix.get_block(self.block_dim - 1, self.block_dim - 1)
+        Qc = Qb.tocoo() if Qb is not None else None
+        self._btd_sequential = False
+        # (1) natural blocks: the coupling rows every time block touches (merged where blocks overlap) are the diagonal
+        # blocks of S; if Q only links consecutive ones, S is block tridiagonal in that order.  These blocks are what the
+        # problem's own structure makes well-posed (a block's clique is the Schur contribution of ONE K_t), so that the
+        # odd-even elimination order of cyclic reduction meets no singular diagonal block.
+        parent = np.arange(nc)
+
+        def find(a):
+            while parent[a] != a:
+                parent[a] = parent[parent[a]]
+                a = parent[a]
+            return a
+        for cm in cliques:
+            for v in cm[1:]:
+                ra, rb = find(int(cm[0])), find(int(v))
+                if ra != rb:
+                    parent[rb] = ra
+        root = np.array([find(i) for i in range(nc)])
+        atoms, atom_of = np.unique(root, return_inverse=True)
+        na = atoms.size
+        if 3 <= na and Qc is not None:
+            a_r, a_c = atom_of[Qc.row], atom_of[Qc.col]
+            off = a_r != a_c
+            AG = coo_matrix((np.ones(int(off.sum()) + na), (np.concatenate([a_r[off], np.arange(na)]),
+                                                           np.concatenate([a_c[off], np.arange(na)]))), shape=(na, na)).tocsr()
+            aperm = np.asarray(reverse_cuthill_mckee(AG, symmetric_mode=True), dtype=np.int64)
+            apos = np.empty(na, dtype=np.int64)
+            apos[aperm] = np.arange(na)
+            path = (not off.any()) or int(np.abs(apos[a_r[off]] - apos[a_c[off]]).max()) <= 1
+            sizes = np.bincount(atom_of, minlength=na)
+            gs = int(sizes.max())
+            if path and gs <= 512:
+                G = na
+                inv = np.empty(nc, dtype=np.int64)
+                pad_map = -np.ones(G * gs, dtype=np.int64)
+                order = np.argsort(apos[atom_of], kind='stable')          # coupling variables grouped by their atom's position
+                within = np.zeros(nc, dtype=np.int64)
+                start = np.concatenate([[0], np.cumsum(np.bincount(apos[atom_of], minlength=na))])
+                within[order] = np.arange(nc) - start[apos[atom_of][order]]
+                inv = apos[atom_of] * gs + within
+                pad_map[inv] = np.arange(nc)
+                self._cperm, self._cinv, self._cperm_pad = pad_map[pad_map >= 0], inv, pad_map
+                self._btd = (gs, G)
+                return
+        # (2) otherwise: a bandwidth-reducing ordering cut into blocks of the bandwidth, eliminated in ascending order
         rows, cols = [np.arange(nc)], [np.arange(nc)]
-        for ndx in range(nb):
-            cm = table[ndx, 1:1 + table[ndx, 0]] - 1
+        for cm in cliques:
             rows.append(np.repeat(cm, cm.size))
             cols.append(np.tile(cm, cm.size))
-        Qb = matrix.get_block(self.block_dim - 1, self.block_dim - 1)
-        if Qb is not None:
-            Qc = Qb.tocoo()
+        if Qc is not None:
             rows += [Qc.row, Qc.col]
             cols += [Qc.col, Qc.row]
         rows, cols = np.concatenate(rows), np.concatenate(cols)
@@ -780,7 +829,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         self._cperm, self._cinv = perm, inv
         self._cperm_pad = np.concatenate([perm, -np.ones(gs * G - nc, dtype=np.int64)])     # new (padded) -> old, -1: padding
         self._btd = (gs, G)
-        self._S_pattern = (rows, cols)
+        self._btd_sequential = True
 
     @staticmethod
     def _layout_positions(g, kr, kc, br, bc):
@@ -876,6 +925,8 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
     def _run_symbolic(self):
         if self._btd is not None:
             self.plan_stats = self._eng.symbolic(self._btd[0] * self._btd[1], self._groups, btd=self._btd, cinv=self._cinv)
+            if hasattr(self._eng, 'set_coupling_schedule'):
+                self._eng.set_coupling_schedule(self._btd_sequential)
         else:
             self.plan_stats = self._eng.symbolic(self._nc, self._groups)
         self._have_classes = False
@@ -1111,7 +1162,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         gs, G = self._btd
         g2 = gs * gs
         flat = np.zeros((2 * G - 1) * g2)
-        pad = np.arange(self._nc, gs * G)
+        pad = np.flatnonzero(self._cperm_pad < 0)
         flat[(pad // gs) * g2 + (pad % gs) * (gs + 1)] = 1.0
         if Q is not None:
             from scipy.sparse import coo_matrix as _coo_m
@@ -1192,6 +1243,15 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             self._guarded(res, self._eng.factor_schur, Q)
         self._last_Q = Q
         st = self._guarded(res, self._eng.status)
+        if (st is not None and st[0] == 2 and self._btd is not None and not self._btd_sequential and
+                hasattr(self._eng, 'set_coupling_schedule')):
+            # a singular diagonal block in the odd-even order of cyclic reduction does not mean S is singular (S is
+            # indefinite): eliminate in ascending block order instead, and keep doing so (same decision on every rank:
+            # all of them hold the same all-reduced S)
+            self._btd_sequential = True
+            self._guarded(res, self._eng.set_coupling_schedule, True)
+            self._guarded(res, self._eng.factor_schur_flat, self._btd_q(Q))
+            st = self._guarded(res, self._eng.status)
         timer.stop('factor SC')
         if st is not None:
             status, pos, neg, zero = st
