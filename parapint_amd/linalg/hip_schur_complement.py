@@ -793,21 +793,40 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             apos = np.empty(na, dtype=np.int64)
             apos[aperm] = np.arange(na)
             path = (not off.any()) or int(np.abs(apos[a_r[off]] - apos[a_c[off]]).max()) <= 1
-            sizes = np.bincount(atom_of, minlength=na)
-            gs = int(sizes.max())
-            if path and gs <= 512:
-                G = na
-                inv = np.empty(nc, dtype=np.int64)
-                pad_map = -np.ones(G * gs, dtype=np.int64)
-                order = np.argsort(apos[atom_of], kind='stable')          # coupling variables grouped by their atom's position
-                within = np.zeros(nc, dtype=np.int64)
-                start = np.concatenate([[0], np.cumsum(np.bincount(apos[atom_of], minlength=na))])
-                within[order] = np.arange(nc) - start[apos[atom_of][order]]
-                inv = apos[atom_of] * gs + within
-                pad_map[inv] = np.arange(nc)
-                self._cperm, self._cinv, self._cperm_pad = pad_map[pad_map >= 0], inv, pad_map
-                self._btd = (gs, G)
-                return
+            if path:
+                # blocks straddle the cliques: a variable linked by Q to the NEXT clique opens a block, one linked to the
+                # PREVIOUS clique closes the block before -- block p = (forward-linked part of clique p) + (backward-
+                # linked part of clique p + 1), i.e. the pairs Q ties together (for a time-staged problem: the duals of the
+                # forward links of block t with the coupling states z_t).  Diagonal blocks that contain such pairs stay
+                # well conditioned under any elimination order; the cliques themselves do not (a clique block is a
+                # principal submatrix of inv(K_t), rank deficient up to rounding when a time block has few controls).
+                pos_v = apos[atom_of]
+                back = np.zeros(nc, dtype=bool)
+                d = apos[a_c] - apos[a_r]
+                back[Qc.row[d == -1]] = True                       # a Q partner in the previous clique
+                fwd = np.zeros(nc, dtype=bool)
+                fwd[Qc.row[d == 1]] = True
+                blk = np.where(back & ~fwd, pos_v - 1, pos_v)
+                used, blk = np.unique(blk, return_inverse=True)    # drop empty blocks, keep the order
+                G = used.size
+                ok = True
+                for cm in cliques:
+                    if cm.size and int(blk[cm].max() - blk[cm].min()) > 1:
+                        ok = False
+                if ok and int(np.abs(blk[Qc.row] - blk[Qc.col]).max()) <= 1 and G >= 3:
+                    sizes = np.bincount(blk, minlength=G)
+                    gs = int(sizes.max())
+                    if gs <= 512:
+                        order = np.argsort(blk, kind='stable')
+                        start = np.concatenate([[0], np.cumsum(sizes)])
+                        within = np.zeros(nc, dtype=np.int64)
+                        within[order] = np.arange(nc) - start[blk[order]]
+                        inv = blk * gs + within
+                        pad_map = -np.ones(G * gs, dtype=np.int64)
+                        pad_map[inv] = np.arange(nc)
+                        self._cperm, self._cinv, self._cperm_pad = pad_map[pad_map >= 0], inv, pad_map
+                        self._btd = (gs, G)
+                        return
         # (2) otherwise: a bandwidth-reducing ordering cut into blocks of the bandwidth, eliminated in ascending order
         rows, cols = [np.arange(nc)], [np.arange(nc)]
         for cm in cliques:

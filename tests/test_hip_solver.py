@@ -548,4 +548,4 @@ def test_dynamic_time_blocks_block_tridiagonal_schur():
     restatement of the reference (sparse S), residual and inertia."""
     solver, model = sc.case_dynamic(make_engine, 64, 49, n_u=2, nfe=4, expect_block_tridiagonal=True)
     gs, G = solver._btd
-    assert gs == 2 * 49 and G == 64 and not solver._btd_sequential       # natural blocks (the cliques), cyclic reduction
+    assert gs == 2 * 49 and G == 63 and not solver._btd_sequential       # blocks (rho_t, z_t), cyclic reduction
