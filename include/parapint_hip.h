@@ -186,6 +186,12 @@ double* pp_rs_buffer(pp_handle h);
 int pp_bind_rs_buffer(pp_handle h, double* dev_ptr);
 /* x_c = S^{-1} (r_c + r_s)  (mpi_...:388-391); r_c on the host (n_c doubles, or NULL = 0). */
 int pp_solve_coupling(pp_handle h, const double* rc_host);
+/* Native vectors: right-hand sides and solutions of a group as [n][bpad] device arrays (row = the caller's row of the
+ * block, instance index fastest, bpad = batch rounded up to 64) -- the layout every kernel here works in.  The forward
+ * sweep then reads b where the caller keeps it (no transposition, no copy: columns without incoming entries are never
+ * materialised) and the backward sweep writes x in the caller's row order.  Both pointers or neither (NULL, NULL
+ * restores the [batch][n] buffers of pp_upload_rhs / pp_download_solution). */
+int pp_bind_native_vectors(pp_handle h, int group, const double* rhs_dev, double* x_dev);
 /* The same with r_c resident on the device (NULL = 0), and the device address of x_c (n_c doubles). */
 int pp_solve_coupling_dev(pp_handle h, const double* rc_dev);
 double* pp_coupling_solution_buffer(pp_handle h);

@@ -41,6 +41,7 @@ SIGNATURES = {
     'pp_source_buffer': (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int]),
     'pp_bind_source_buffer': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     'pp_upload_sources': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]),
+    'pp_bind_native_vectors': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     'pp_solve_coupling_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     'pp_coupling_solution_buffer': (ctypes.c_void_p, [ctypes.c_void_p]),
     'pp_copy_coupling_solution': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),

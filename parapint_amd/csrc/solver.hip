@@ -53,6 +53,7 @@ struct GroupDev {
   const int *stile_a, *stile_b, *stile_ptr, *stile_rec;
   double *raw, *rawT, *U, *L, *Dinv, *Tm, *Y, *X, *rhs, *xout, *Spart, *rspart;
   unsigned short* codes;
+  const double* rhsN;   // right-hand sides in the native [row][instance] layout (caller order), or null: Y was filled by the transposition
   const int* cmapT; // mapped groups: global coupling index of local coupling row c of instance b at [c * bpad + b] (else null)
   double *Sloc, *XCL;   // mapped groups: per-instance Schur cliques [tile entry][instance], per-instance coupling solution
   int xs_row, xs_lane;  // address of coupling value c of lane b: c * xs_row + b * xs_lane (uniform: 1, 0 into xc)
@@ -1701,12 +1702,16 @@ __global__ __launch_bounds__(THREADS) void k_coupling_solve(int n, const double*
 // ------------------------------------------------------------------------------------------
 // gather of one scalar row: sum over entries of U[upos] * Z[zcol]; the (upos, zcol) records are
 // fetched with one vector load per 64 entries and broadcast, loads issue in groups of 16
+// Z operand of a solve entry: row zc of Y, or -- native right-hand sides, zc < 0 -- row -1 - zc of the caller's
+// right-hand side (a column without incoming entries is never written to Y: y = b there)
+#define PP_ZVAL(zc) (((zc) >= 0) ? Z[(size_t)(zc) * bpad] : RN[(size_t)(-1 - (zc)) * bpad])
+
 __device__ __forceinline__ double gather_row(const int* __restrict__ upos, const int* __restrict__ zcol, int e0, int e1,
-                                             const double* __restrict__ U, const double* __restrict__ Z, size_t bpad,
-                                             int lane) {
+                                             const double* __restrict__ U, const double* __restrict__ Z,
+                                             const double* __restrict__ RN, size_t bpad, int lane) {
   double s0 = 0.0, s1 = 0.0;
   if (e1 - e0 <= 3) {   // wide bottom levels: one to three entries, plain scalar record reads
-    for (int e = e0; e < e1; ++e) s0 += U[(size_t)upos[e] * bpad] * Z[(size_t)zcol[e] * bpad];
+    for (int e = e0; e < e1; ++e) { const int zc = zcol[e]; s0 += U[(size_t)upos[e] * bpad] * PP_ZVAL(zc); }
     return s0;
   }
   for (int eb = e0; eb < e1; eb += 64) {
@@ -1721,7 +1726,7 @@ __device__ __forceinline__ double gather_row(const int* __restrict__ upos, const
       iu[i] = bcast(ru, q); iz[i] = bcast(rz, q);                                          \
     }                                                                                      \
     double u[G], z[G];                                                                     \
-    _Pragma("unroll") for (int i = 0; i < G; ++i) { u[i] = U[(size_t)iu[i] * bpad]; z[i] = Z[(size_t)iz[i] * bpad]; } \
+    _Pragma("unroll") for (int i = 0; i < G; ++i) { u[i] = U[(size_t)iu[i] * bpad]; z[i] = PP_ZVAL(iz[i]); } \
     _Pragma("unroll") for (int i = 0; i < G; i += 2) {                                     \
       s0 += (i0 + i < cnt) ? u[i] * z[i] : 0.0;                                            \
       s1 += (i0 + i + 1 < cnt) ? u[i + 1] * z[i + 1] : 0.0;                                \
@@ -1763,10 +1768,12 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_level(GroupDev g, int col0, int
   const int* rec = g.fwd_rec + 4 * (size_t)(col0 + PP_TASK_OF_WG(ny));   // {column, -, e0, e1}
   const int c = rec[0], e0 = rec[2], ne = rec[3] - rec[2];
   const int a0 = e0 + (int)((long long)ne * wave / NW), a1 = e0 + (int)((long long)ne * (wave + 1) / NW);
-  // in place: the right-hand side was transposed into Y in the new order (rows of leaf columns are final as they are)
+  // in place: the right-hand side was transposed into Y in the new order (rows of leaf columns are final as they are);
+  // native right-hand sides: y_c = b_(original row of c) - s, read where the caller left it
   double* yc = g.Y + (size_t)c * bpad + b;
-  const double s = team_sum<NW>(gather_row(g.sfwd_upos, g.sfwd_zcol, a0, a1, g.L + b, g.Y + b, bpad, lane), red, wave, lane);
-  if (wave == 0) *yc -= s;
+  const double* RN = g.rhsN ? g.rhsN + b : nullptr;
+  const double s = team_sum<NW>(gather_row(g.sfwd_upos, g.sfwd_zcol, a0, a1, g.L + b, g.Y + b, RN, bpad, lane), red, wave, lane);
+  if (wave == 0) *yc = (RN ? RN[(size_t)rec[1] * bpad] : *yc) - s;
 }
 
 // coupling row c: rspart[chunk][c] = - sum over active instances and panels of L[c,k] y_k
@@ -1777,7 +1784,8 @@ __global__ __launch_bounds__(64) void k_fwd_coupling(GroupDev g, double* __restr
   const int b = chunk * 64 + lane;
   const size_t bpad = (size_t)g.bpad;
   const int c = PP_TASK_OF_WG(g.nchunk);
-  double s = -gather_row(g.crow_upos, g.crow_zcol, g.crow_eptr[c], g.crow_eptr[c + 1], g.L + b, g.Y + b, bpad, lane);
+  double s = -gather_row(g.crow_upos, g.crow_zcol, g.crow_eptr[c], g.crow_eptr[c + 1], g.L + b, g.Y + b,
+                         g.rhsN ? g.rhsN + b : nullptr, bpad, lane);
   if (b >= g.batch) s = 0.0;
   if (g.cmapT) {      // mapped group: every instance adds to coupling rows of its own
     if (b < g.batch && s != 0.0) atomicAdd(&rs_mapped[g.cmapT[(size_t)c * bpad + b]], s);
@@ -1815,12 +1823,16 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_level(GroupDev g, int col0, int
   double z = 0.0;
   if (wave == 0) {
     const double* inv = g.Dinv + (size_t)rec[6] * bpad + b;
-    const double* Yp = g.Y + (size_t)rec[7] * bpad + b;
+    // rec[7] = first column p0 of the block, or -1 - p0 if its columns have no incoming entries (native right-hand
+    // sides only: y = b there, read through the permutation from the caller's rows)
+    const int p0 = rec[7] >= 0 ? rec[7] : -1 - rec[7];
+    const double* Yp = g.Y + (size_t)p0 * bpad + b;
 #pragma unroll
     for (int t = 0; t < PP_WMAX; ++t) {
       if (t < w) {
         const int hi = q > t ? q : t, lo = q > t ? t : q;
-        z += inv[(size_t)(hi * (hi + 1) / 2 + lo) * bpad] * Yp[(size_t)t * bpad];
+        const double yv = rec[7] >= 0 ? Yp[(size_t)t * bpad] : g.rhsN[(size_t)g.perm[p0 + t] * bpad + b];
+        z += inv[(size_t)(hi * (hi + 1) / 2 + lo) * bpad] * yv;
       }
     }
   }
@@ -1857,7 +1869,7 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_level(GroupDev g, int col0, int
     }
   }
   const double s = team_sum<NW>(g0 + g1, red, wave, lane);
-  if (wave == 0) g.X[(size_t)c * bpad + b] = z - s;
+  if (wave == 0) g.X[(size_t)c * bpad + b] = (b < g.batch) ? z - s : 0.0;    // (padded lanes of a ragged chunk stay zero)
 }
 
 
@@ -1976,6 +1988,10 @@ struct Group {
   std::vector<int> fent_host, init_rec;        // entry records as uploaded; positions of the initial-value records
   int *fent_src = nullptr;                     // device: the same records with the initial-value ones pointing at sources
   double *xout_own = nullptr;
+  // native [row][instance] vectors (pp_bind_native_vectors): the sweeps read b / write x where the caller keeps them
+  const int *zcolN_f = nullptr, *zcolN_c = nullptr, *brecN = nullptr, *rowidx_o = nullptr;
+  const double* rhs_native = nullptr;
+  double* x_native = nullptr;
   int nc_loc = 0;                    // coupling rows of the group's plan (== n_c unless the group is mapped)
   std::vector<int> cmap_host;        // mapped group: [batch][nc_loc] global coupling indices
 };
@@ -2476,6 +2492,7 @@ int pp_end_symbolic(pp_handle h) {
     std::memset(&d, 0, sizeof(d));
     d.n = P.n; d.nc = g->nc_loc; d.batch = g->batch; d.bpad = (g->batch + WAVE - 1) / WAVE * WAVE;
     d.xs_row = 1; d.xs_lane = 0;
+    d.rhsN = nullptr;
     d.nchunk = d.bpad / WAVE; d.npiv = P.npiv; d.nraw = g->nraw; d.usize = P.usize;
     int rc;
     std::vector<int> uoff(P.piv_uoff.begin(), P.piv_uoff.end());
@@ -2617,6 +2634,24 @@ int pp_end_symbolic(pp_handle h) {
       }
       if ((rc = dev_upload(h, g, &d.fwd_rec, frec))) return rc;
       if ((rc = dev_upload(h, g, &d.bwd_rec, brec))) return rc;
+      // native-vector variants: a column without incoming entries keeps y = b, which then is read from the caller's
+      // right-hand side (row perm[c]) instead of a copy; x is written and read in the caller's row order
+      std::vector<uint8_t> noent((size_t)P.n, 0);
+      for (int c = 0; c < P.n; ++c) noent[(size_t)c] = P.sfwd_eptr[c + 1] == P.sfwd_eptr[c];
+      std::vector<int> zf(P.sfwd_zcol), zc2(P.crow_zcol), brn(brec), ro(P.rowidx);
+      for (auto& z : zf) if (noent[(size_t)z]) z = -1 - P.perm[z];
+      for (auto& z : zc2) if (noent[(size_t)z]) z = -1 - P.perm[z];
+      for (int q = 0; q < 16; ++q) { zf.push_back(0); zc2.push_back(0); }
+      for (size_t i = 0; i < brn.size(); i += 8) {
+        const int p0 = brn[i + 7];
+        brn[i] = P.perm[brn[i]];
+        if (noent[(size_t)p0]) brn[i + 7] = -1 - p0;
+      }
+      for (auto& r : ro) if (r < P.n) r = P.perm[r];
+      if ((rc = dev_upload(h, g, &g->zcolN_f, zf))) return rc;
+      if ((rc = dev_upload(h, g, &g->zcolN_c, zc2))) return rc;
+      if ((rc = dev_upload(h, g, &g->brecN, brn))) return rc;
+      if ((rc = dev_upload(h, g, &g->rowidx_o, ro))) return rc;
     }
     {
       std::vector<int> up(P.sfwd_upos), zc(P.sfwd_zcol), cu(P.crow_upos), cz(P.crow_zcol);
@@ -3129,9 +3164,12 @@ int pp_solve_forward(pp_handle h) {
   for (Group* g : h->groups) {
     const pp::Plan& P = g->plan;
     GroupDev& d = g->dev;
+    const bool native = g->rhs_native != nullptr;
+    GroupDev dn = d;
+    if (native) { dn.rhsN = g->rhs_native; dn.sfwd_zcol = g->zcolN_f; dn.crow_zcol = g->zcolN_c; }
     {
       PhaseScope ps(h, 4, P.n_levels + 1);
-      {
+      if (!native) {
         const int tiles = transpose_tiles(P.n, d.nchunk);
         // the right-hand side goes straight to Y in the new (elimination) order: y is then computed in place and
         // the columns without incoming entries (level 0) need no launch at all
@@ -3149,7 +3187,7 @@ int pp_solve_forward(pp_handle h) {
         const int team = g->fwd_level_team[(size_t)l];
         for (int q = 0; q < sp.n; ++q) {
           const int ny = sp.c0[q + 1] - sp.c0[q];
-#define PP_LAUNCH_FWD(NW) hipLaunchKernelGGL(k_fwd_level<NW>, dim3((unsigned)ncol * ny), dim3(64 * NW), 0, fan[q], d, c0, sp.c0[q], ny)
+#define PP_LAUNCH_FWD(NW) hipLaunchKernelGGL(k_fwd_level<NW>, dim3((unsigned)ncol * ny), dim3(64 * NW), 0, fan[q], dn, c0, sp.c0[q], ny)
           if (team == 16) PP_LAUNCH_FWD(16);
           else if (team == 4) PP_LAUNCH_FWD(4);
           else PP_LAUNCH_FWD(1);
@@ -3160,7 +3198,7 @@ int pp_solve_forward(pp_handle h) {
     }
     if (d.nc > 0) {
       PhaseScope ps(h, 5, 2);
-      hipLaunchKernelGGL(k_fwd_coupling, dim3((unsigned)d.nc * d.nchunk), dim3(64), 0, st, d, h->rs);
+      hipLaunchKernelGGL(k_fwd_coupling, dim3((unsigned)d.nc * d.nchunk), dim3(64), 0, st, dn, h->rs);
       if (!d.cmapT) hipLaunchKernelGGL(k_rs_reduce, dim3((d.nc + 255) / 256), dim3(256), 0, st, d, h->rs);
     }
   }
@@ -3268,6 +3306,16 @@ int pp_bind_solution_buffer(pp_handle h, int group, double* dev_ptr) {
   return 0;
 }
 
+int pp_bind_native_vectors(pp_handle h, int group, const double* rhs_dev, double* x_dev) {
+  Group* g = get_group(h, group);
+  if (!g || !h->symbolic_done) return fail(h, 3, "pp_bind_native_vectors: bad group");
+  if ((rhs_dev == nullptr) != (x_dev == nullptr)) return fail(h, 3, "pp_bind_native_vectors: give both buffers or neither");
+  if (int rc = alloc_value_storage(h)) return rc;
+  g->rhs_native = rhs_dev;
+  g->x_native = x_dev;
+  return 0;
+}
+
 int pp_solve_backward(pp_handle h) {
   if (!h || !h->schur_done) return fail(h, 3, "pp_solve_backward before pp_factor_schur");
   PP_HIP(hipSetDevice(h->device));
@@ -3276,6 +3324,9 @@ int pp_solve_backward(pp_handle h) {
     const pp::Plan& P = g->plan;
     GroupDev& d = g->dev;
     PhaseScope ps(h, 7, P.n_levels + 1);
+    const bool native = g->x_native != nullptr;
+    GroupDev dn = d;
+    if (native) { dn.rhsN = g->rhs_native; dn.bwd_rec = g->brecN; dn.rowidx = g->rowidx_o; dn.X = g->x_native; }
     const double* xcp = h->xc;
     if (d.cmapT && d.nc > 0) {     // mapped group: every instance reads the coupling values of its own rows
       hipLaunchKernelGGL(k_gather_xc, dim3((unsigned)(((size_t)d.nc * d.bpad + 255) / 256)), dim3(256), 0, st, d, h->xc);
@@ -3291,7 +3342,7 @@ int pp_solve_backward(pp_handle h) {
         const int team = g->bwd_level_team[(size_t)l];
         for (int q = 0; q < sp.n; ++q) {
           const int ny = sp.c0[q + 1] - sp.c0[q];
-#define PP_LAUNCH_BWD(NW) hipLaunchKernelGGL(k_bwd_level<NW>, dim3((unsigned)ncol * ny), dim3(64 * NW), 0, fan[q], d, c0, sp.c0[q], ny, xcp)
+#define PP_LAUNCH_BWD(NW) hipLaunchKernelGGL(k_bwd_level<NW>, dim3((unsigned)ncol * ny), dim3(64 * NW), 0, fan[q], dn, c0, sp.c0[q], ny, xcp)
           if (team == 16) PP_LAUNCH_BWD(16);
           else if (team == 4) PP_LAUNCH_BWD(4);
           else PP_LAUNCH_BWD(1);
@@ -3300,8 +3351,9 @@ int pp_solve_backward(pp_handle h) {
       }
       if (join_streams(h, sp, fan)) return fail(h, 3, "stream join failed");
     }
-    hipLaunchKernelGGL(k_transpose_out, dim3((unsigned)((P.n + 63) / 64) * d.nchunk), dim3(256), 0, st, d.X, d.iperm, d.xout,
-                       d.batch, P.n, d.bpad);
+    if (!native)
+      hipLaunchKernelGGL(k_transpose_out, dim3((unsigned)((P.n + 63) / 64) * d.nchunk), dim3(256), 0, st, d.X, d.iperm, d.xout,
+                         d.batch, P.n, d.bpad);
   }
   PP_HIP(hipGetLastError());
   return 0;

@@ -372,6 +372,14 @@ class HipEngine(object):
         self.ns.check(self.lib.pp_bind_solution_buffer(self.ns.h, gid, tensor.data_ptr() if tensor is not None else None),
                       'pp_bind_solution_buffer')
 
+    def bind_native_vectors(self, gid, rhs, x):
+        """[n][padded batch] device tensors the sweeps read b from / write x to (None, None: back to [batch][n] copies)."""
+        for t in (rhs, x):
+            if t is not None and (not t.is_contiguous() or not t.is_cuda or str(t.dtype) != 'torch.float64'):
+                raise ValueError('native vectors must be contiguous float64 device tensors')
+        self.ns.check(self.lib.pp_bind_native_vectors(self.ns.h, gid, rhs.data_ptr() if rhs is not None else None,
+                                                      x.data_ptr() if x is not None else None), 'pp_bind_native_vectors')
+
     def solve_coupling_dev(self, tensor):
         self.ns.check(self.lib.pp_solve_coupling_dev(self.ns.h, tensor.data_ptr() if tensor is not None else None),
                       'pp_solve_coupling_dev')
@@ -982,8 +990,8 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         from parapint_amd.sparse.device_containers import DeviceBlockVector
         layout, dims = self.device_layout()
         v = DeviceBlockVector(self.block_dim, layout)
-        for gid, (batch, _, n) in dims.items():
-            v.group_tensors[gid] = self._eng.new_tensor((batch, n))
+        for gid, (batch, bpad, n) in dims.items():
+            v.group_tensors[gid] = self._eng.new_tensor((n, bpad))
         v.coupling = self._eng.new_tensor((max(self._nc, 1),))[:self._nc]
         return v
 
@@ -991,9 +999,9 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         import torch
         v = self.new_device_vector()
         for g in self._groups:
-            host = np.zeros(g.x_shape)
+            host = np.zeros(tuple(v.group_tensors[g.gid].shape))
             for slot, ndx in enumerate(g.blocks):
-                host[slot] = _flat(bv.get_block(ndx))
+                host[:, slot] = _flat(bv.get_block(ndx))
             v.group_tensors[g.gid].copy_(torch.from_numpy(host))
         if self._nc > 0:
             v.coupling.copy_(torch.from_numpy(np.ascontiguousarray(_flat(bv.get_block(self.block_dim - 1)))))
@@ -1351,9 +1359,9 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             return self._device_back_solve(rhs, timer)
         timer.start('back_solve')
         last = self.block_dim - 1
-        for g in self._groups:
-            self._eng.bind_rhs_tensor(g.gid, None) if hasattr(self._eng, 'bind_rhs_tensor') else None
-            self._eng.bind_solution_tensor(g.gid, None) if hasattr(self._eng, 'bind_solution_tensor') else None
+        if hasattr(self._eng, 'bind_native_vectors'):
+            for g in self._groups:
+                self._eng.bind_native_vectors(g.gid, None, None)
         for ndx in self.local_block_indices:
             bi = self._binfo[ndx]
             bi.group.rhs_staging[bi.slot] = _flat(rhs.get_block(ndx))
@@ -1405,8 +1413,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         out = self._dev_results[self._dev_turn % len(self._dev_results)]
         self._dev_turn += 1
         for g in self._groups:
-            self._eng.bind_rhs_tensor(g.gid, rhs.group_tensors[g.gid])
-            self._eng.bind_solution_tensor(g.gid, out.group_tensors[g.gid])
+            self._eng.bind_native_vectors(g.gid, rhs.group_tensors[g.gid], out.group_tensors[g.gid])
         self._eng.solve_forward()
         self._eng.allreduce_rs(self.comm)
         rc_dev = rhs.coupling if self._nc > 0 else None

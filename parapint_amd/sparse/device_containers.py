@@ -8,8 +8,8 @@ of "sources" per pattern group -- the interface's own Hessian / Jacobian / barri
 coefficient) every COO entry of K_i and A_i is.  The solver gathers its input from the sources
 (include/parapint_hip.h: pp_set_value_map); nothing is assembled, staged or uploaded per iteration.
 
-``DeviceBlockVector`` holds the right-hand sides / solutions of the local blocks as one [batch][n] device array
-per pattern group plus the coupling block, so that the step after the solve (convergence check, fraction to the
+``DeviceBlockVector`` holds the right-hand sides / solutions of the local blocks as one [n][padded batch] device array
+per pattern group (the kernels' own layout: no transposition on either side of the solve) plus the coupling block, so that the step after the solve (convergence check, fraction to the
 boundary, interior_point.py:174-317, 655-758) can run on the device (parapint_amd.linalg.device_vector_ops).
 """
 import numpy as np
@@ -74,8 +74,9 @@ class DeviceBlockMatrix(object):
 
 
 class DeviceBlockVector(object):
-    """Right-hand side / solution on the device: ``group_tensors[gid]`` is [batch][n] (row b = block slots[gid][b]),
-    ``coupling`` is [n_c]."""
+    """Right-hand side / solution on the device in the layout the kernels work in: ``group_tensors[gid]`` is
+    [n][padded batch] (row = row of the block, column b = block slots[gid][b]; include/parapint_hip.h:
+    pp_bind_native_vectors), ``coupling`` is [n_c].  ``get_block(i)`` is a (strided) view of one block."""
 
     def __init__(self, nblocks, layout):
         self._nblocks = int(nblocks)
@@ -91,7 +92,7 @@ class DeviceBlockVector(object):
         if i == self._nblocks - 1:
             return self.coupling
         gid, slot = self.layout[i]
-        return self.group_tensors[gid][slot]
+        return self.group_tensors[gid][:, slot]
 
     def to_host(self, template):
         """Copy into a host block vector with the structure of `template` (a BlockVector / MPIBlockVector)."""
@@ -99,7 +100,7 @@ class DeviceBlockVector(object):
         host = {gid: t.cpu().numpy() for gid, t in self.group_tensors.items()}
         for ndx, (gid, slot) in self.layout.items():
             blk = template.get_block(ndx)
-            x = host[gid][slot]
+            x = np.ascontiguousarray(host[gid][:, slot])
             if hasattr(blk, 'get_block'):
                 sub = blk.copy_structure()
                 sub.copyfrom(x)
