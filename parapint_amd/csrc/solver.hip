@@ -1523,13 +1523,28 @@ __global__ __launch_bounds__(256) void k_btd_init(size_t n, const double* __rest
   if (i < n) F[i] = S[i] + (Q ? Q[i] : 0.0);
 }
 
-__global__ __launch_bounds__(BK_THREADS) void k_bcr_factor(int gs, BcrLevel lv, double* D, int* ipiv, double* work, int* info) {
+// in_lds: the block is factorised in LDS (gs * gs doubles of dynamic shared memory: every one of the gs pivot steps is
+// a handful of LDS round trips instead of global-memory ones) and copied back
+__global__ __launch_bounds__(BK_THREADS) void k_bcr_factor(int gs, BcrLevel lv, double* D, int* ipiv, double* work, int* info,
+                                                           int in_lds) {
+  extern __shared__ __attribute__((aligned(16))) double shD[];
   __shared__ double sv[16];
   __shared__ int si[16];
   __shared__ pp::BkInfo sbi;
   const int i = lv.elim[blockIdx.x];
+  double* Dg = D + (size_t)i * gs * gs;
+  double* A = Dg;
+  if (in_lds) {
+    for (int k = threadIdx.x; k < gs * gs; k += blockDim.x) shD[k] = Dg[k];
+    __syncthreads();
+    A = shD;
+  }
   TeamCtx ctx{sv, si};
-  pp::bk_factor(ctx, gs, D + (size_t)i * gs * gs, gs, ipiv + (size_t)i * gs, work + (size_t)blockIdx.x * 2 * gs, &sbi, BK_EPS);
+  pp::bk_factor(ctx, gs, A, gs, ipiv + (size_t)i * gs, work + (size_t)blockIdx.x * 2 * gs, &sbi, BK_EPS);
+  if (in_lds) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < gs * gs; k += blockDim.x) Dg[k] = shD[k];
+  }
   if (threadIdx.x == 0) { info[4 * i] = sbi.npos; info[4 * i + 1] = sbi.nneg; info[4 * i + 2] = sbi.nzero; }
 }
 
@@ -2023,6 +2038,7 @@ struct pp_solver {
   int *btd_ipiv = nullptr, *btd_info = nullptr, *scatter_err = nullptr, *btd_elim = nullptr;
   std::vector<int> bcr_off, bcr_ne, bcr_s, bcr_lo;   // per level: offset into btd_elim, eliminated blocks, stride, lower neighbour live
   int btd_sequential = 0;
+  bool bcr_lds_attr = false;
   double growth_bound = 1e8;     // 1 / u_rt: a factor entry beyond it flags its instance
   bool growth_fatal = false;     // flagged instances make the factorisation report status 2 (else they are only counted)
   double pivot_threshold = 0.0;  // symbolic-time threshold u for groups added afterwards (0: plan default)
@@ -3036,9 +3052,22 @@ int pp_factor_schur(pp_handle h, const double* Q_host) {
     double* D = h->btd_fac;
     double* slot = h->btd_fac + (size_t)G * g2;
     const unsigned gb = (unsigned)((g2 + 255) / 256);
+    // the diagonal blocks are factorised in LDS when they fit (gs <= 137: 150 KB of the CU's 160 KB)
+    size_t lds_bytes = g2 * sizeof(double);
+    if (lds_bytes > 150 * 1024) lds_bytes = 0;
+    if (lds_bytes > 64 * 1024 && !h->bcr_lds_attr) {
+      if (hipFuncSetAttribute((const void*)k_bcr_factor, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
+        (void)hipGetLastError();
+        lds_bytes = 0;
+      } else {
+        h->bcr_lds_attr = true;
+      }
+    }
+    if (std::getenv("PP_BCR_NO_LDS")) lds_bytes = 0;
     for (int l = 0; l < nlev; ++l) {
       const BcrLevel lv{h->btd_elim + h->bcr_off[(size_t)l], h->bcr_ne[(size_t)l], h->bcr_s[(size_t)l], h->bcr_lo[(size_t)l]};
-      hipLaunchKernelGGL(k_bcr_factor, dim3(lv.ne), dim3(BK_THREADS), 0, st, gs, lv, D, h->btd_ipiv, h->btd_vec, h->btd_info);
+      hipLaunchKernelGGL(k_bcr_factor, dim3(lv.ne), dim3(BK_THREADS), lds_bytes, st, gs, lv, D, h->btd_ipiv, h->btd_vec, h->btd_info,
+                         lds_bytes > 0 ? 1 : 0);
       hipLaunchKernelGGL(k_bcr_invert, dim3(gs, lv.ne), dim3(128), 0, st, gs, lv, D, h->btd_ipiv, h->btd_inv);
       if (l + 1 < nlev) {
         hipLaunchKernelGGL(k_bcr_keep_y, dim3(gb, lv.ne), dim3(256), 0, st, gs, G, lv, h->btd_inv, slot, h->btd_klo, h->btd_kup,
