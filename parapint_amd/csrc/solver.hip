@@ -3064,9 +3064,11 @@ int pp_factor_schur(pp_handle h, const double* Q_host) {
       }
     }
     if (std::getenv("PP_BCR_NO_LDS")) lds_bytes = 0;
+    int bk_threads = 256;        // (measured at C4, gs = 98, S phase per step: 64 threads 15.3 ms, 128 12.1, 256 10.8, 512 11.0)
+    if (const char* e = std::getenv("PP_BCR_THREADS")) bk_threads = std::max(64, std::min(BK_THREADS, std::atoi(e)));
     for (int l = 0; l < nlev; ++l) {
       const BcrLevel lv{h->btd_elim + h->bcr_off[(size_t)l], h->bcr_ne[(size_t)l], h->bcr_s[(size_t)l], h->bcr_lo[(size_t)l]};
-      hipLaunchKernelGGL(k_bcr_factor, dim3(lv.ne), dim3(BK_THREADS), lds_bytes, st, gs, lv, D, h->btd_ipiv, h->btd_vec, h->btd_info,
+      hipLaunchKernelGGL(k_bcr_factor, dim3(lv.ne), dim3(bk_threads), lds_bytes, st, gs, lv, D, h->btd_ipiv, h->btd_vec, h->btd_info,
                          lds_bytes > 0 ? 1 : 0);
       hipLaunchKernelGGL(k_bcr_invert, dim3(gs, lv.ne), dim3(128), 0, st, gs, lv, D, h->btd_ipiv, h->btd_inv);
       if (l + 1 < nlev) {
