@@ -40,9 +40,15 @@ def main():
         e['write_KiB'] += w
         e['launches'] += max(nf, nw)
     steps = per.get('k_bk_factor', per.get('k_publish_status'))['launches']   # one per numeric factorisation
-    tr = per['k_transpose_in']
-    known_read_KiB = steps * batch * (raw_entries + n) * 8 / 1024.0
-    calib = known_read_KiB / tr['fetch_KiB']
+    if 'k_transpose_in' in per:
+        tr = per['k_transpose_in']
+        known_read_KiB = steps * batch * (raw_entries + n) * 8 / 1024.0
+        calib = known_read_KiB / tr['fetch_KiB']
+    else:
+        # the interface path on native device vectors launches no transposition any more: the read-side factor measured
+        # on k_transpose_in in every earlier pass of this code base (profiles/r01_*/, r02_interface/: 1.99) is used
+        calib = float(sys.argv[8]) if len(sys.argv) > 8 else 1.99
+        note += ' (no k_transpose_in in this run: FETCH_SIZE calibration %.2f taken from profiles/r02_interface)' % calib
     kernels, phases = {}, {}
     for s, e in sorted(per.items()):
         if not s.startswith('k_'):
