@@ -3199,7 +3199,9 @@ int pp_solve_forward(pp_handle h) {
     GroupDev dn = d;
     if (native) { dn.rhsN = g->rhs_native; dn.sfwd_zcol = g->zcolN_f; dn.crow_zcol = g->zcolN_c; }
     {
-      PhaseScope ps(h, 4, P.n_levels + 1);
+      int nl = native ? 0 : 1;
+      for (int l = 0; l < P.n_levels; ++l) nl += (P.clevel_ptr[l + 1] > P.clevel_ptr[l]) && g->fwd_level_has_entries[(size_t)l];
+      PhaseScope ps(h, 4, nl);
       if (!native) {
         const int tiles = transpose_tiles(P.n, d.nchunk);
         // the right-hand side goes straight to Y in the new (elimination) order: y is then computed in place and
@@ -3354,8 +3356,10 @@ int pp_solve_backward(pp_handle h) {
   for (Group* g : h->groups) {
     const pp::Plan& P = g->plan;
     GroupDev& d = g->dev;
-    PhaseScope ps(h, 7, P.n_levels + 1);
     const bool native = g->x_native != nullptr;
+    int nlb = native ? 0 : 1;
+    for (int l = 0; l < P.n_levels; ++l) nlb += P.clevel_ptr[l + 1] > P.clevel_ptr[l];
+    PhaseScope ps(h, 7, nlb + ((d.cmapT && d.nc > 0) ? 1 : 0));
     GroupDev dn = d;
     if (native) { dn.rhsN = g->rhs_native; dn.bwd_rec = g->brecN; dn.rowidx = g->rowidx_o; dn.X = g->x_native; }
     const double* xcp = h->xc;
