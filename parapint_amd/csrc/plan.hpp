@@ -60,11 +60,6 @@ struct PlanOptions {
   int md_delta_abs = 3;   // minimum-degree tolerance (absolute) for height-aware selection
   double md_delta_rel = 0.5;   // ... and relative to the current minimum degree
   double pivot_threshold = 0.01;  // 1x1 pivot accepted if |d| >= threshold * max|row| (MA27 cntl(1) analogue)
-  // Top of the elimination tree handled per instance ("tail kernels"): the panels of the levels >= tail_cut -- as many
-  // top levels as fit tail_lds_doubles (U and L of those panels are both kept in LDS by one workgroup per instance) --
-  // are factorised and solved by ONE launch each instead of two / one launch per level.  0 disables.
-  int tail_lds_doubles = 4400;
-  int tail_min_levels = 3;
 };
 
 // Factor schedule ("L form").  For every block pivot p two panels are stored with the same
@@ -96,8 +91,6 @@ struct FEntry { int u, l, wk, q; };
 // Schur tile record: pivot p contributes to tile (ta, tb); slots (or -1) of the tile's
 // coupling rows inside panel p
 struct STileRec { int piv; int slotA[8]; int slotB[8]; };
-// tail (per-instance) factorisation: one destination row (all w columns) of a tail panel; entries [e0, e1) of tent
-struct TRow { int piv, slot, e0, e1; };
 
 struct Plan {
   int n = 0, nc = 0, npiv = 0, ncan = 0;
@@ -137,19 +130,6 @@ struct Plan {
   // Schur (SYRK) schedule
   std::vector<int> stile_a, stile_b, stile_ptr;  // tiles (ta>=tb) and record ranges
   std::vector<STileRec> stile_rec;
-  // tail: levels >= tail_cut (== n_levels: none).  Tail panels have no gather / scale tasks; their rows first collect the
-  // contributions of the levels below the cut and the input values in ONE lane-per-instance launch (the gather tasks of
-  // pseudo-level n_levels: flevel_ptr has n_levels + 2 entries), then one workgroup per instance finishes them level by
-  // level with the tail panels in LDS (positions in a compact per-instance array: piv_toff).
-  int tail_cut = 0;
-  std::vector<int> piv_toff, piv_tboff, piv_tdoff;   // per pivot: offset of its panel / term magnitudes / inverse in the tail arrays, or -1
-  int tsize = 0, tbsize = 0, tdsize = 0;
-  std::vector<int> tail_upos;            // tail panel position -> position in the U / L storage
-  std::vector<int> tail_bpos, tail_dpos; // ... of the term magnitudes (Tm) and of the inverses (Dinv)
-  std::vector<int> tail_piv, tail_piv_ptr;   // tail pivots by level (tail_piv_ptr: n_levels - tail_cut + 1)
-  std::vector<TRow> trows;               // destination rows by level
-  std::vector<int> trow_ptr;             // n_levels - tail_cut + 1 -> trows
-  std::vector<int> tent;                 // entry triples {u (tail position), l (tail position), wk}
   // statistics
   int64_t nnz_L = 0;        // structural entries of L below the pivot blocks
   int64_t flops_factor = 0; // multiply-adds of the panel updates

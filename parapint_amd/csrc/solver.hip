@@ -550,115 +550,6 @@ __global__ __launch_bounds__(64) void k_scale_level(GroupDev g, int task0, int c
   if (grow && b < g.batch) g.growth[b] = 1;
 }
 
-// ------------------------------------------------------------------------------------------
-// Tail of the elimination tree, one workgroup per INSTANCE (plan.hpp: levels >= tail_cut).  The panels of the top
-// levels -- a few thousand doubles per instance -- live in LDS for the whole factorisation of those levels: a level
-// costs a few LDS round trips and three workgroup barriers instead of two kernel launches, and the GPU works on
-// all instances at once whatever the batch size (the level launches above the cut have 1-7 panels each: with a
-// batch of 128 they cannot fill the chip, and the ~5 us per launch is all they cost).
-// In: TPU = the tail rows after the lane-per-instance pass (input values + contributions from below the cut), TPB =
-// their pivot-block term magnitudes, both [instance][.] (transposed copies).  Out: TPU / TPL / TPD = U, L, inv(P) of
-// the tail panels, [instance][.]; inertia codes and growth flags go straight to the per-lane arrays.
-struct TailDev {
-  int nlev, tsize, tbsize, tdsize;
-  const int *tpiv, *tpiv_ptr, *trows, *trow_ptr, *tent, *piv_toff, *piv_tboff, *piv_tdoff;
-  double *TPU, *TPL, *TPD, *TPB;
-};
-
-__global__ __launch_bounds__(256) void k_tail_factor(GroupDev g, TailDev t, double eps) {
-  extern __shared__ __attribute__((aligned(16))) double tail_sh[];
-  __shared__ int s_grow;
-  double* TU = tail_sh;
-  double* TL = TU + t.tsize;
-  double* TB = TL + t.tsize;
-  double* TD = TB + t.tbsize;
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const size_t bpad = (size_t)g.bpad;
-  for (int i = tid; i < t.tsize; i += 256) { TU[i] = t.TPU[(size_t)b * t.tsize + i]; TL[i] = 0.0; }
-  for (int i = tid; i < t.tbsize; i += 256) TB[i] = t.TPB[(size_t)b * t.tbsize + i];
-  if (tid == 0) s_grow = 0;
-  __syncthreads();
-  bool grow = false;
-  for (int tl = 0; tl < t.nlev; ++tl) {
-    const int r0 = t.trow_ptr[tl], r1 = t.trow_ptr[tl + 1];
-    // (1) every destination row of the level: its tail entries
-    for (int ri = r0 + tid; ri < r1; ri += 256) {
-      const int4 rec = *reinterpret_cast<const int4*>(t.trows + 4 * (size_t)ri);   // {pivot, slot, e0, e1}
-      const int p = rec.x, slot = rec.y, w = g.piv_w[p];
-      double* dst = TU + t.piv_toff[p] + slot * w;
-      double* tmd = TB + t.piv_tboff[p] + slot * w;
-      double acc[PP_WMAX], tmax[PP_WMAX];
-#pragma unroll
-      for (int q = 0; q < PP_WMAX; ++q) { acc[q] = (q < w) ? dst[q] : 0.0; tmax[q] = (q < w && slot < w) ? tmd[q] : 0.0; }
-      for (int e = rec.z; e < rec.w; ++e) {
-        const int4 en = *reinterpret_cast<const int4*>(t.tent + 4 * (size_t)e);      // {u, l, wk, -}
-        const double su = TU[en.x];
-#pragma unroll
-        for (int q = 0; q < PP_WMAX; ++q) {
-          if (q < w) {
-            const double term = su * TL[en.y + q * en.z];
-            acc[q] -= term;
-            tmax[q] = fmax(tmax[q], fabs(term));
-          }
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < PP_WMAX; ++q) {
-        if (q < w) {
-          dst[q] = acc[q];
-          if (slot < w) tmd[q] = tmax[q];
-        }
-      }
-    }
-    __syncthreads();
-    // (2) the pivot blocks of the level
-    for (int pi = t.tpiv_ptr[tl] + tid; pi < t.tpiv_ptr[tl + 1]; pi += 256) {
-      const int p = t.tpiv[pi], w = g.piv_w[p];
-      const double* blkp = TU + t.piv_toff[p];
-      const double* tmp = TB + t.piv_tboff[p];
-      double blk[PP_WMAX * PP_WMAX], inv[PP_WMAX * (PP_WMAX + 1) / 2];
-      double tmax_diag = 0.0;
-#pragma unroll
-      for (int i = 0; i < PP_WMAX; ++i)
-#pragma unroll
-        for (int j = 0; j < PP_WMAX; ++j) {
-          const bool in = i < w && j < w;
-          blk[i * PP_WMAX + j] = in ? blkp[i * w + j] : 0.0;
-          if (in) tmax_diag = fmax(tmax_diag, tmp[i * w + j]);
-        }
-      const int code = pp::invert_block_t<PP_WMAX>(w, (unsigned)g.piv_sub[p], blk, tmax_diag, eps, inv);
-      double* invp = TD + t.piv_tdoff[p];
-      for (int i = 0; i < w * (w + 1) / 2; ++i) invp[i] = inv[i];
-      g.codes[(size_t)p * bpad + b] = (unsigned short)code;
-    }
-    __syncthreads();
-    // (3) the rows below the blocks: L = U inv(P)
-    for (int ri = r0 + tid; ri < r1; ri += 256) {
-      const int4 rec = *reinterpret_cast<const int4*>(t.trows + 4 * (size_t)ri);
-      const int p = rec.x, slot = rec.y, w = g.piv_w[p];
-      if (slot < w) continue;
-      const double* u = TU + t.piv_toff[p] + slot * w;
-      double* l = TL + t.piv_toff[p] + slot * w;
-      const double* inv = TD + t.piv_tdoff[p];
-      for (int t2 = 0; t2 < w; ++t2) {
-        double v = 0.0;
-        for (int t1 = 0; t1 < w; ++t1) v += u[t1] * PP_INV(inv, t1, t2);
-        l[t2] = v;
-        grow = grow || fabs(v) > g.lbound;
-      }
-    }
-    __syncthreads();
-  }
-  if (grow) s_grow = 1;
-  for (int i = tid; i < t.tsize; i += 256) {
-    t.TPU[(size_t)b * t.tsize + i] = TU[i];
-    t.TPL[(size_t)b * t.tsize + i] = TL[i];
-  }
-  for (int i = tid; i < t.tdsize; i += 256) t.TPD[(size_t)b * t.tdsize + i] = TD[i];
-  __syncthreads();
-  if (tid == 0 && s_grow) g.growth[b] = 1;
-}
-
 // counters[0..2] += (pos, neg, zero) over all block pivots (codes of padded instances are 0);
 // a code is pos | neg << 4 | zero << 8 in 16 bits, 8 codes per 16-byte load
 __global__ __launch_bounds__(256) void k_count_codes(const unsigned short* __restrict__ codes, size_t total8,
@@ -2116,10 +2007,6 @@ struct Group {
   const int *zcolN_f = nullptr, *zcolN_c = nullptr, *brecN = nullptr, *rowidx_o = nullptr;
   const double* rhs_native = nullptr;
   double* x_native = nullptr;
-  // tail (per-instance) factorisation: device images of the plan's tail records, per-instance buffers
-  TailDev tail = {};
-  const int *tail_upos = nullptr, *tail_bpos = nullptr, *tail_dpos = nullptr;
-  size_t tail_lds = 0;
   int nc_loc = 0;                    // coupling rows of the group's plan (== n_c unless the group is mapped)
   std::vector<int> cmap_host;        // mapped group: [batch][nc_loc] global coupling indices
 };
@@ -2151,7 +2038,7 @@ struct pp_solver {
   int *btd_ipiv = nullptr, *btd_info = nullptr, *scatter_err = nullptr, *btd_elim = nullptr;
   std::vector<int> bcr_off, bcr_ne, bcr_s, bcr_lo;   // per level: offset into btd_elim, eliminated blocks, stride, lower neighbour live
   int btd_sequential = 0;
-  bool bcr_lds_attr = false, tail_lds_attr = false;
+  bool bcr_lds_attr = false;
   double growth_bound = 1e8;     // 1 / u_rt: a factor entry beyond it flags its instance
   bool growth_fatal = false;     // flagged instances make the factorisation report status 2 (else they are only counted)
   double pivot_threshold = 0.0;  // symbolic-time threshold u for groups added afterwards (0: plan default)
@@ -2373,8 +2260,7 @@ int64_t value_storage_bytes(pp_handle h) {
                   (int64_t)P.dsize * bp + (int64_t)std::max(P.bsize, 1) * bp + (int64_t)(P.n + g->nc_loc) * bp +
                   (int64_t)P.n * bp + 2 * (int64_t)g->batch * P.n + (int64_t)d.nchunk * std::max(g->ntiles, 1) * 64 +
                   (int64_t)d.nchunk * std::max(g->nc_loc, 1) +
-                  (g->cmap_host.empty() ? 0 : ((int64_t)std::max(g->ntiles, 1) * 64 + std::max(g->nc_loc, 1)) * bp) +
-                  (int64_t)g->batch * (2 * (int64_t)g->tail.tsize + g->tail.tdsize + g->tail.tbsize);
+                  (g->cmap_host.empty() ? 0 : ((int64_t)std::max(g->ntiles, 1) * 64 + std::max(g->nc_loc, 1)) * bp);
     total += 8 * dbl + 2 * (int64_t)P.npiv * bp;
   }
   return total;
@@ -2388,7 +2274,6 @@ void free_value_storage(Group* g) {
   d.codes = nullptr;
   d.growth = nullptr;
   d.Sloc = d.XCL = nullptr;
-  g->tail.TPU = g->tail.TPL = g->tail.TPD = g->tail.TPB = nullptr;
   g->raw_own = g->rhs_own = g->xout_own = nullptr;
 }
 
@@ -2441,16 +2326,7 @@ int alloc_value_storage(pp_handle h) {
       if ((rc = value_alloc(h, g, &d.Sloc, (size_t)std::max(g->ntiles, 1) * 64 * bp))) break;
       if ((rc = value_alloc(h, g, &d.XCL, (size_t)std::max(nc, 1) * bp))) break;
     }
-    if (g->tail.nlev > 0) {
-      TailDev& t = g->tail;
-      if ((rc = value_alloc(h, g, &t.TPU, (size_t)g->batch * t.tsize))) break;
-      if ((rc = value_alloc(h, g, &t.TPL, (size_t)g->batch * t.tsize))) break;
-      if ((rc = value_alloc(h, g, &t.TPD, (size_t)g->batch * std::max(t.tdsize, 1)))) break;
-      if ((rc = value_alloc(h, g, &t.TPB, (size_t)g->batch * std::max(t.tbsize, 1)))) break;
-    }
     if ((rc = value_alloc(h, g, &d.codes, (size_t)P.npiv * bp))) break;   // 16-bit codes
-    // (the codes of padded lanes are never written by the per-instance tail kernel: defined once)
-    if (hipMemset(d.codes, 0, (size_t)P.npiv * bp * sizeof(unsigned short)) != hipSuccess) { rc = fail(h, 3, "hipMemset failed"); break; }
     if ((rc = value_alloc(h, g, &d.growth, 2 * bp))) break;        // flags of the running factorisation | of the last one
     if (hipMemset(d.growth, 0, 2 * bp * sizeof(int)) != hipSuccess) { rc = fail(h, 3, "hipMemset failed"); break; }
     d.raw = keep_raw ? keep_raw : g->raw_own;
@@ -2574,8 +2450,6 @@ int pp_add_group_mapped(pp_handle h, int n, int batch, int nnzK, const int32_t* 
   if (h->sn_wmax > 0) opt.sn_wmax = h->sn_wmax;
   if (h->sn_tol >= 0) opt.sn_tol_rows = h->sn_tol;
   if (h->pivot_threshold > 0.0) opt.pivot_threshold = h->pivot_threshold;
-  if (cmap) opt.tail_lds_doubles = 0;           // (mapped groups keep the level launches for now)
-  if (const char* e = std::getenv("PP_TAIL_DOUBLES")) opt.tail_lds_doubles = std::max(0, std::atoi(e));
   if (const char* tune = std::getenv("PP_PLAN_TUNE")) {
     // developer knob for schedule experiments: "max_task_entries=48,scale_task_rows=16,..."
     std::string t(tune);
@@ -2638,11 +2512,9 @@ int pp_end_symbolic(pp_handle h) {
     d.nchunk = d.bpad / WAVE; d.npiv = P.npiv; d.nraw = g->nraw; d.usize = P.usize;
     int rc;
     std::vector<int> uoff(P.piv_uoff.begin(), P.piv_uoff.end());
-    g->level_maxw.assign(P.n_levels + 1, 1);      // (+ the pseudo-level of the tail's lane-per-instance pass)
-    for (int pp_ = 0; pp_ < P.npiv; ++pp_) {
+    g->level_maxw.assign(P.n_levels, 1);
+    for (int pp_ = 0; pp_ < P.npiv; ++pp_)
       g->level_maxw[P.piv_level[pp_]] = std::max(g->level_maxw[P.piv_level[pp_]], P.piv_w[pp_]);
-      if (P.piv_level[pp_] >= P.tail_cut) g->level_maxw[P.n_levels] = std::max(g->level_maxw[P.n_levels], P.piv_w[pp_]);
-    }
     std::vector<int> ftask, stask, fdst_ptr, fent, srec;
     const double one = 1.0;
     int one_lo, one_hi;
@@ -2736,29 +2608,6 @@ int pp_end_symbolic(pp_handle h) {
     if ((rc = dev_upload(h, g, &d.fent, fent))) return rc;
     g->fent_host = fent;
     d.const_row = -1;
-    g->tail = TailDev{};
-    if (P.tail_cut < P.n_levels) {
-      TailDev& t = g->tail;
-      t.nlev = P.n_levels - P.tail_cut; t.tsize = P.tsize; t.tbsize = P.tbsize; t.tdsize = P.tdsize;
-      std::vector<int> tr, te;
-      tr.reserve(P.trows.size() * 4);
-      for (auto& r : P.trows) tr.insert(tr.end(), {r.piv, r.slot, r.e0, r.e1});
-      te.reserve(P.tent.size() / 3 * 4 + 4);
-      for (size_t e = 0; e + 2 < P.tent.size(); e += 3) te.insert(te.end(), {P.tent[e], P.tent[e + 1], P.tent[e + 2], 0});
-      te.insert(te.end(), {0, 0, 0, 0});
-      if ((rc = dev_upload(h, g, &t.tpiv, P.tail_piv))) return rc;
-      if ((rc = dev_upload(h, g, &t.tpiv_ptr, P.tail_piv_ptr))) return rc;
-      if ((rc = dev_upload(h, g, &t.trows, tr))) return rc;
-      if ((rc = dev_upload(h, g, &t.trow_ptr, P.trow_ptr))) return rc;
-      if ((rc = dev_upload(h, g, &t.tent, te))) return rc;
-      if ((rc = dev_upload(h, g, &t.piv_toff, P.piv_toff))) return rc;
-      if ((rc = dev_upload(h, g, &t.piv_tboff, P.piv_tboff))) return rc;
-      if ((rc = dev_upload(h, g, &t.piv_tdoff, P.piv_tdoff))) return rc;
-      if ((rc = dev_upload(h, g, &g->tail_upos, P.tail_upos))) return rc;
-      if ((rc = dev_upload(h, g, &g->tail_bpos, P.tail_bpos))) return rc;
-      if ((rc = dev_upload(h, g, &g->tail_dpos, P.tail_dpos))) return rc;
-      g->tail_lds = (size_t)(2 * P.tsize + P.tbsize + P.tdsize) * sizeof(double);
-    }
     if (!g->cmap_host.empty()) {      // [batch][nc_loc] -> [nc_loc][bpad] (padded lanes repeat instance 0: never used)
       std::vector<int> cm((size_t)std::max(g->nc_loc, 1) * d.bpad, 0);
       for (int c = 0; c < g->nc_loc; ++c)
@@ -3069,14 +2918,13 @@ int pp_numeric_factor_blocks(pp_handle h) {
     if (fused_sources) { d.rawT = g->src; d.fent = g->fent_src; d.const_row = g->nsrc; }
     {
       int nlaunch = 0;
-      for (int l = 0; l <= P.n_levels; ++l)
+      for (int l = 0; l < P.n_levels; ++l)
         nlaunch += (P.flevel_ptr[l + 1] > P.flevel_ptr[l]) + (P.slevel_ptr[l + 1] > P.slevel_ptr[l]);
-      if (g->tail.nlev > 0) nlaunch += 6;
       PhaseScope ps(h, 1, nlaunch);
       const Splits sp = make_splits(h, d.nchunk);
       hipStream_t fan[PP_MAX_SPLIT];
       if (fork_streams(h, sp, fan)) return fail(h, 3, "stream fork failed");
-      for (int l = 0; l <= P.n_levels; ++l) {          // (level n_levels: the lane-per-instance pass of the tail panels)
+      for (int l = 0; l < P.n_levels; ++l) {
         const int t0 = P.flevel_ptr[l], nt = P.flevel_ptr[l + 1] - t0;
         const int s0 = P.slevel_ptr[l], ns = P.slevel_ptr[l + 1] - s0;
         for (int q = 0; q < sp.n; ++q) {
@@ -3114,25 +2962,6 @@ int pp_numeric_factor_blocks(pp_handle h) {
         }
       }
       if (join_streams(h, sp, fan)) return fail(h, 3, "stream join failed");
-      if (g->tail.nlev > 0) {
-        // tail: transposed hand-off of the tail rows, one workgroup per instance, and back into the panel storage
-        const TailDev& t = g->tail;
-        hipLaunchKernelGGL(k_transpose_out, dim3((unsigned)((t.tsize + 63) / 64) * d.nchunk), dim3(256), 0, st, d.U, g->tail_upos, t.TPU,
-                           d.batch, t.tsize, d.bpad);
-        hipLaunchKernelGGL(k_transpose_out, dim3((unsigned)((t.tbsize + 63) / 64) * d.nchunk), dim3(256), 0, st, d.Tm, g->tail_bpos, t.TPB,
-                           d.batch, t.tbsize, d.bpad);
-        if (g->tail_lds > 64 * 1024 && !h->tail_lds_attr) {
-          PP_HIP(hipFuncSetAttribute((const void*)k_tail_factor, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-          h->tail_lds_attr = true;
-        }
-        hipLaunchKernelGGL(k_tail_factor, dim3((unsigned)d.batch), dim3(256), g->tail_lds, st, d, t, PIVOT_EPS);
-        hipLaunchKernelGGL(k_transpose_in, dim3((unsigned)((t.tsize + 63) / 64) * d.nchunk), dim3(256), 0, st, t.TPU, d.U, g->tail_upos,
-                           d.batch, t.tsize, d.bpad, 1, (const int*)nullptr);
-        hipLaunchKernelGGL(k_transpose_in, dim3((unsigned)((t.tsize + 63) / 64) * d.nchunk), dim3(256), 0, st, t.TPL, d.L, g->tail_upos,
-                           d.batch, t.tsize, d.bpad, 1, (const int*)nullptr);
-        hipLaunchKernelGGL(k_transpose_in, dim3((unsigned)((t.tdsize + 63) / 64) * d.nchunk), dim3(256), 0, st, t.TPD, d.Dinv, g->tail_dpos,
-                           d.batch, t.tdsize, d.bpad, 1, (const int*)nullptr);
-      }
     }
   }
   PP_HIP(hipGetLastError());

@@ -470,39 +470,6 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
   }
   if (P.n_levels - P.tail_level0 < 3) P.tail_level0 = P.n_levels;
 
-  // ---- 5b. tail: the top levels whose panels fit the LDS budget are handled per instance (plan.hpp)
-  P.tail_cut = P.n_levels;
-  P.piv_toff.assign(P.npiv, -1);
-  P.piv_tboff.assign(P.npiv, -1);
-  P.piv_tdoff.assign(P.npiv, -1);
-  if (opt.tail_lds_doubles > 0) {
-    std::vector<int64_t> lvl_doubles((size_t)P.n_levels, 0);
-    for (int p = 0; p < P.npiv; ++p)
-      lvl_doubles[(size_t)P.piv_level[p]] += (int64_t)(P.piv_w[p] + (int64_t)rows[p].size()) * P.piv_w[p];
-    int64_t acc = 0;
-    int cut = P.n_levels;
-    while (cut > 0 && acc + lvl_doubles[(size_t)cut - 1] <= opt.tail_lds_doubles) { acc += lvl_doubles[(size_t)cut - 1]; --cut; }
-    if (P.n_levels - cut >= opt.tail_min_levels) P.tail_cut = cut;
-  }
-  P.tail_piv_ptr.assign(1, 0);
-  for (int l = P.tail_cut; l < P.n_levels; ++l) {
-    for (int q = P.lvl_ptr[l]; q < P.lvl_ptr[l + 1]; ++q) {
-      const int p = P.lvl_piv[q], w = P.piv_w[p];
-      const int f = w + (int)rows[p].size();
-      P.piv_toff[p] = P.tsize;
-      for (int e = 0; e < f * w; ++e) P.tail_upos.push_back((int)(P.piv_uoff[p] + e));
-      P.tsize += f * w;
-      P.piv_tboff[p] = P.tbsize;
-      for (int e = 0; e < w * w; ++e) P.tail_bpos.push_back(P.piv_boff[p] + e);
-      P.tbsize += w * w;
-      P.piv_tdoff[p] = P.tdsize;
-      for (int e = 0; e < w * (w + 1) / 2; ++e) P.tail_dpos.push_back(P.piv_doff[p] + e);
-      P.tdsize += w * (w + 1) / 2;
-      P.tail_piv.push_back(p);
-    }
-    P.tail_piv_ptr.push_back((int)P.tail_piv.size());
-  }
-
   // ---- 6. factor tasks in L form (see plan.hpp): pure (U, L) gathers, fused small panels,
   // gather + scale chunks for big panels
   {
@@ -513,14 +480,10 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
     struct TmpTask { FTask t; int level; int nent = 0; };
     std::vector<TmpTask> gtasks, sctasks;
     std::vector<std::vector<FEntry>> row_ents;   // per destination row (slot) of panel p
-    std::vector<std::vector<int>> row_tail;      // tail panels: entries {u, l, wk} (tail positions) from tail sources
-    std::vector<std::vector<TRow>> trows_by_level((size_t)(P.n_levels - P.tail_cut));
     for (int p = 0; p < P.npiv; ++p) {
       const int w = P.piv_w[p], p0 = P.piv_start[p];
       const int f = w + (int)rows[p].size();
       row_ents.assign((size_t)f, {});
-      const bool tail_panel = P.piv_level[p] >= P.tail_cut;
-      if (tail_panel) row_tail.assign((size_t)f, {});
       // initial values: canonical entries located in this panel
       const int64_t u0 = P.piv_uoff[p], u1 = u0 + (int64_t)f * w;
       int64_t total = 0;
@@ -546,16 +509,6 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
             d = w + (int)tp;
           }
           const int srow = wk + (int)t;
-          if (tail_panel && P.piv_level[k] >= P.tail_cut) {
-            // source inside the tail: handled per instance, positions in the compact tail arrays
-            for (int tt = 0; tt < wk; ++tt) {
-              row_tail[(size_t)d].push_back(P.piv_toff[k] + srow * wk + tt);
-              row_tail[(size_t)d].push_back(P.piv_toff[k] + mslot * wk + tt);
-              row_tail[(size_t)d].push_back(wk);
-            }
-            P.flops_factor += (int64_t)wk * w;
-            continue;
-          }
           for (int tt = 0; tt < wk; ++tt)
             row_ents[(size_t)d].push_back({(int)(P.piv_uoff[k] + (int64_t)srow * wk + tt),
                                            (int)(P.piv_uoff[k] + (int64_t)mslot * wk + tt), wk, 0});
@@ -588,31 +541,7 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
         tt.nent = (e0 >= 0) ? (int)row_ents[(size_t)r0].size() : (int)P.fentries.size() - first;
         gtasks.push_back(tt);
       };
-      if (tail_panel) {
-        // (a) one lane-per-instance pass collects the input values and the contributions of the levels below the cut:
-        // gather chunks of whole rows (rows are not split here: a row's share from below the cut is short)
-        int r = 0;
-        while (r < f) {
-          int nent = 0, r_end = r;
-          while (r_end < f) {
-            const int add = (int)row_ents[(size_t)r_end].size();
-            if (r_end > r && nent + add > opt.max_task_entries) break;
-            nent += add;
-            ++r_end;
-          }
-          emit(r, r_end, 0);
-          gtasks.back().level = P.n_levels;              // pseudo-level: after every level below the cut
-          r = r_end;
-        }
-        // (b) the tail rows
-        for (int d = 0; d < f; ++d) {
-          TRow tr;
-          tr.piv = p; tr.slot = d; tr.e0 = (int)(P.tent.size() / 3);
-          P.tent.insert(P.tent.end(), row_tail[(size_t)d].begin(), row_tail[(size_t)d].end());
-          tr.e1 = (int)(P.tent.size() / 3);
-          trows_by_level[(size_t)(P.piv_level[p] - P.tail_cut)].push_back(tr);
-        }
-      } else if (total <= opt.fuse_task_entries) {
+      if (total <= opt.fuse_task_entries) {
         emit(0, f, 1);                                   // fused small panel
       } else {
         const int cap_row = std::max(cap_e, (int)(opt.row_split_factor * cap_e));
@@ -648,10 +577,10 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
     auto by_level = [](const TmpTask& a, const TmpTask& b) { return a.level < b.level; };
     std::stable_sort(gtasks.begin(), gtasks.end(), by_level);
     std::stable_sort(sctasks.begin(), sctasks.end(), by_level);
-    P.flevel_ptr.assign(P.n_levels + 2, 0);      // (+ the pseudo-level of the tail's lane-per-instance pass)
-    P.slevel_ptr.assign(P.n_levels + 2, 0);
-    P.flevel_maxent.assign(P.n_levels + 1, 0);
-    P.flevel_nsplit.assign(P.n_levels + 1, 0);
+    P.flevel_ptr.assign(P.n_levels + 1, 0);
+    P.slevel_ptr.assign(P.n_levels + 1, 0);
+    P.flevel_maxent.assign(P.n_levels, 0);
+    P.flevel_nsplit.assign(P.n_levels, 0);
     // per level: split rows first (each fills one quad, padded with no-ops), then the other tasks packed PP_QUAD
     // per quad; the level's task count is a whole number of quads
     {
@@ -686,12 +615,7 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
       }
     }
     for (auto& t : sctasks) { P.stasks.push_back(t.t); P.slevel_ptr[t.level + 1]++; }
-    for (int l = 0; l <= P.n_levels; ++l) { P.flevel_ptr[l + 1] += P.flevel_ptr[l]; P.slevel_ptr[l + 1] += P.slevel_ptr[l]; }
-    P.trow_ptr.assign(1, 0);
-    for (auto& v : trows_by_level) {
-      P.trows.insert(P.trows.end(), v.begin(), v.end());
-      P.trow_ptr.push_back((int)P.trows.size());
-    }
+    for (int l = 0; l < P.n_levels; ++l) { P.flevel_ptr[l + 1] += P.flevel_ptr[l]; P.slevel_ptr[l + 1] += P.slevel_ptr[l]; }
   }
 
   // ---- 7. solve schedules: independent scalar rows / columns by level (L form)

@@ -22,7 +22,7 @@ struct HostCtx {
 };
 }  // namespace
 
-static int g_sn_wmax = 0, g_sn_tol = -1, g_tail_doubles = -1;
+static int g_sn_wmax = 0, g_sn_tol = -1;
 static double g_growth_bound = 1e8, g_pivot_threshold = 0.0;   // as pp_set_pivot_tolerance
 static int g_last_growth = 0, g_growth_fatal = 0;
 
@@ -30,8 +30,6 @@ extern "C" {
 
 // test knob: supernode width cap / padded-row tolerance for plans created afterwards (0 / -1: defaults)
 void ppsim_set_supernodes(int wmax, int tol) { g_sn_wmax = wmax; g_sn_tol = tol; }
-void ppsim_set_tail(int lds_doubles) { g_tail_doubles = lds_doubles; }
-int ppsim_tail_cut(void* h) { return ((Plan*)h)->tail_cut; }
 void ppsim_set_pivot_tolerance(double u_symbolic, double u_runtime) {
   g_pivot_threshold = u_symbolic;
   g_growth_bound = u_runtime > 0.0 ? 1.0 / u_runtime : 1e8;
@@ -49,7 +47,6 @@ void* ppsim_create(int n, int nc, int nnzK, const int* rowK, const int* colK, in
   if (delta_rel >= 0) opt.md_delta_rel = delta_rel;
   if (g_sn_wmax > 0) opt.sn_wmax = g_sn_wmax;
   if (g_sn_tol >= 0) opt.sn_tol_rows = g_sn_tol;
-  if (g_tail_doubles >= 0) opt.tail_lds_doubles = g_tail_doubles;
   if (g_pivot_threshold > 0.0) opt.pivot_threshold = g_pivot_threshold;
   int rc = pp::build_plan(n, nc, nnzK, rowK, colK, nnzB, rowB, colB, vals, opt, *P);
   if (rc != 0) { /* keep the plan so the error string can be read */ }
@@ -124,7 +121,7 @@ int ppsim_factor(void* h, const double* can, double* U, double* L, double* Dinv,
   std::memset(L, 0, sizeof(double) * P.usize);
   std::vector<double> Tm((size_t)std::max(P.bsize, 1), 0.0);
   int pos = 0, neg = 0, zero = 0;
-  for (int lvl = 0; lvl <= P.n_levels; ++lvl) {     // (level n_levels: the lane-per-instance pass of the tail panels)
+  for (int lvl = 0; lvl < P.n_levels; ++lvl) {
     // launch G: gather chunks and fused small panels
     for (int ti = P.flevel_ptr[lvl]; ti < P.flevel_ptr[lvl + 1]; ++ti) {
       const auto& t = P.ftasks[ti];
@@ -210,44 +207,6 @@ int ppsim_factor(void* h, const double* can, double* U, double* L, double* Dinv,
         pos += code & 15; neg += (code >> 4) & 15; zero += (code >> 8) & 15;
       }
       scale_rows(P, p, t.r0, t.r1, inv, U, L);
-    }
-  }
-  // tail: the rows of the top levels are finished level by level from the tail panels themselves (one workgroup per
-  // instance on the device; same order of operations here)
-  for (int tl = 0; tl + P.tail_cut < P.n_levels; ++tl) {
-    for (int ri = P.trow_ptr[tl]; ri < P.trow_ptr[tl + 1]; ++ri) {
-      const pp::TRow& tr = P.trows[ri];
-      const int p = tr.piv, w = P.piv_w[p];
-      double acc[PP_WMAX], tmax[PP_WMAX];
-      for (int q = 0; q < w; ++q) {
-        acc[q] = U[P.piv_uoff[p] + (int64_t)tr.slot * w + q];
-        tmax[q] = tr.slot < w ? Tm[P.piv_boff[p] + tr.slot * w + q] : 0.0;
-      }
-      for (int e = tr.e0; e < tr.e1; ++e) {
-        const double su = U[P.tail_upos[P.tent[3 * e]]];
-        const int wk = P.tent[3 * e + 2];
-        for (int q = 0; q < w; ++q) {
-          const double term = su * L[P.tail_upos[P.tent[3 * e + 1] + q * wk]];
-          acc[q] -= term;
-          tmax[q] = std::fmax(tmax[q], std::fabs(term));
-        }
-      }
-      for (int q = 0; q < w; ++q) {
-        U[P.piv_uoff[p] + (int64_t)tr.slot * w + q] = acc[q];
-        if (tr.slot < w) Tm[P.piv_boff[p] + tr.slot * w + q] = tmax[q];
-      }
-    }
-    for (int pi = P.tail_piv_ptr[tl]; pi < P.tail_piv_ptr[tl + 1]; ++pi) {
-      const int p = P.tail_piv[pi], w = P.piv_w[p];
-      double blk[PP_WMAX * PP_WMAX] = {0}, tmax_diag = 0.0, inv[PP_WMAX * (PP_WMAX + 1) / 2] = {0};
-      for (int q = 0; q < w * w; ++q) {
-        blk[(q / w) * PP_WMAX + q % w] = U[P.piv_uoff[p] + q];
-        tmax_diag = std::fmax(tmax_diag, Tm[P.piv_boff[p] + q]);
-      }
-      const int code = pp::invert_block(w, P.piv_sub[p], blk, tmax_diag, eps, inv);
-      for (int q = 0; q < w * (w + 1) / 2; ++q) Dinv[P.piv_doff[p] + q] = inv[q];
-      pos += code & 15; neg += (code >> 4) & 15; zero += (code >> 8) & 15;
-      scale_rows(P, p, w, w + (P.piv_rowptr[p + 1] - P.piv_rowptr[p]), inv, U, L);
     }
   }
   inertia[0] += pos; inertia[1] += neg; inertia[2] += zero;
