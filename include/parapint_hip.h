@@ -289,6 +289,9 @@ int pp_stage_upload_compact(pp_handle h, int group, int nblocks, int nthreads, c
                             const int64_t* bnnz, const int32_t* ref_kr, const int32_t* ref_kc, int64_t ref_knnz,
                             const int32_t* ref_br, const int32_t* ref_bc, int64_t ref_bnnz, int nruns_k, const int64_t* runs_k,
                             int nruns_b, const int64_t* runs_b, double* staging, const int32_t* slots, uint8_t* same_out);
+/* dst[idx[i]][0 .. row_doubles) = src[i][0 .. row_doubles) on host threads: the right-hand sides of the local blocks into
+ * the rows of their staging array (handle-free, no device work). */
+int pp_copy_rows(int nrows, int nthreads, const double* const* src, const int64_t* idx, double* dst, int64_t row_doubles);
 /* Pinned (page-locked) host memory for the staging arrays and result buffers of the host boundary. */
 void* pp_host_alloc(int64_t bytes);
 void pp_host_free(void* p);

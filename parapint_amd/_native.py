@@ -54,6 +54,7 @@ SIGNATURES = {
                                 [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                  ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                  ctypes.c_void_p, ctypes.c_void_p]),
+    'pp_copy_rows': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
     'pp_host_alloc': (ctypes.c_void_p, [ctypes.c_int64]),
     'pp_host_free': (None, [ctypes.c_void_p]),
     'pp_raw_buffer': (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int]),

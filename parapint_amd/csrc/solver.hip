@@ -3796,6 +3796,28 @@ int pp_stage_upload_compact(pp_handle h, int group, int nblocks, int nthreads, c
   return 0;
 }
 
+// dst[idx[i]][0 .. row_doubles) = src[i][0 .. row_doubles): the right-hand sides of the local blocks into their staging
+// rows, on host threads (75 MB per back-solve at the headline size)
+int pp_copy_rows(int nrows, int nthreads, const double* const* src, const int64_t* idx, double* dst, int64_t row_doubles) {
+  if (nrows < 0 || row_doubles < 0 || (nrows > 0 && (!src || !idx || !dst))) return 3;
+  auto work = [&](int i0, int i1) {
+    for (int i = i0; i < i1; ++i) std::memcpy(dst + (size_t)idx[i] * (size_t)row_doubles, src[i], (size_t)row_doubles * sizeof(double));
+  };
+  const int nt = std::max(1, std::min(std::min(nthreads, 64), nrows));
+  if (nt == 1) { work(0, nrows); return 0; }
+  std::vector<std::thread> pool;
+  pool.reserve((size_t)nt);
+  int started = 0;
+  try {
+    for (; started < nt; ++started)
+      pool.emplace_back(work, (int)((int64_t)nrows * started / nt), (int)((int64_t)nrows * (started + 1) / nt));
+  } catch (...) {
+  }
+  if (started < nt) work((int)((int64_t)nrows * started / nt), nrows);
+  for (auto& th : pool) th.join();
+  return 0;
+}
+
 // pinned host memory for staging arrays / result buffers of the host boundary (hipHostMalloc; NULL on failure)
 void* pp_host_alloc(int64_t bytes) {
   void* p = nullptr;

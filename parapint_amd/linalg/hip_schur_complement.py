@@ -85,6 +85,9 @@ def _flat(v):
 
 def _coo(block):
     """(row, col, data) of a SciPy sparse matrix or (nested) BlockMatrix block."""
+    if getattr(block, 'format', None) == 'coo':          # (1024 blocks per call: skip tocoo() / asarray() when there is nothing to do)
+        d = block.data
+        return block.row, block.col, d if d.dtype == np.double else d.astype(np.double), block.shape
     c = block.tocoo()
     return c.row, c.col, np.asarray(c.data, dtype=np.double), c.shape
 
@@ -160,8 +163,7 @@ class _Group(object):
         cpos[self.used] = np.arange(self.used.size)
         self.can_cidx = cpos[can_idx] if can_idx.size else np.zeros(0, dtype=np.int64)   # compact position of every raw duplicate
         self.runsK, self.runsB = self._runs(self.used, nrawK)
-        self.known_ptrs = set()             # data pointers of index arrays verified equal to the reference arrays
-        self.keep_alive = []                # ... and the arrays themselves, so that a pointer cannot be reused
+        self.known_ptrs = {}                # id(index array) -> array: verified equal to the reference arrays (kept alive)
 
     @staticmethod
     def _runs(used, nrawK):
@@ -312,15 +314,23 @@ class HipEngine(object):
         if ref is None:
             ref = g._ref32 = [np.ascontiguousarray(r, dtype=np.int32) for r in g.raw_refs]
             g._refptr = [r.ctypes.data for r in ref]
-        known, refptr = g.known_ptrs, g._refptr
+        known, refptr = g.known_ptrs, g._refptr           # id(index array) -> the array (kept alive), verified equal to the reference
+        unknown = []
         for i, (slot, arrays) in enumerate(items):
-            for q in range(6):
-                ptr[q, i] = arrays[q].__array_interface__['data'][0]
-            # index arrays already verified against the reference order (same objects as at an earlier call): hand the
-            # library the reference pointers themselves, so that it skips the comparison
+            # index arrays already verified against the reference order (the same objects as at an earlier call): hand
+            # the library the reference pointers themselves, so that it skips the comparison
+            fresh = False
             for q, r in ((0, 0), (1, 1), (3, 2), (4, 3)):
-                if (int(ptr[q, i]), arrays[q].size) in known:
+                a = arrays[q]
+                if id(a) in known:
                     ptr[q, i] = refptr[r]
+                else:
+                    ptr[q, i] = a.ctypes.data
+                    fresh = True
+            if fresh:
+                unknown.append(i)
+            ptr[2, i] = arrays[2].ctypes.data
+            ptr[5, i] = arrays[5].ctypes.data if arrays[5].size else 0
             nnz[0, i] = arrays[2].size
             nnz[1, i] = arrays[5].size
             slots[i] = slot
@@ -335,15 +345,26 @@ class HipEngine(object):
                                               slots.ctypes.data, same.ctypes.data)
         self.ns.check(rc, 'pp_stage_upload_compact')
         ok = same.astype(bool)
-        if len(known) < 8 * n + 64:
-            for i, (slot, arrays) in enumerate(items):
+        if len(known) < 4 * n + 64:           # (one generation of index arrays at most is kept alive)
+            for i in unknown:
                 if ok[i]:
                     for q in (0, 1, 3, 4):
-                        key = (arrays[q].__array_interface__['data'][0], arrays[q].size)
-                        if key not in known:
-                            known.add(key)
-                            g.keep_alive.append(arrays[q])
+                        known[id(items[i][1][q])] = items[i][1][q]
         return ok
+
+    def copy_rows(self, dst, rows):
+        """rows: [(row index of dst, contiguous float64 vector of dst.shape[1] entries)] copied on host threads."""
+        import os
+        n = len(rows)
+        src = np.empty(n, dtype=np.uint64)
+        idx = np.empty(n, dtype=np.int64)
+        for i, (r, v) in enumerate(rows):
+            src[i] = v.ctypes.data
+            idx[i] = r
+        rc = self.lib.pp_copy_rows(n, min(16, os.cpu_count() or 1), src.ctypes.data, idx.ctypes.data, dst.ctypes.data,
+                                   dst.shape[1])
+        if rc != 0:
+            raise RuntimeError('pp_copy_rows failed with status %d' % rc)
 
     def upload_values_compact(self, gid, staging, row0=0, nrows=None):
         nrows = staging.shape[0] - row0 if nrows is None else nrows
@@ -1362,9 +1383,18 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         if hasattr(self._eng, 'bind_native_vectors'):
             for g in self._groups:
                 self._eng.bind_native_vectors(g.gid, None, None)
+        copy_rows = getattr(self._eng, 'copy_rows', None)
+        pending = {}
         for ndx in self.local_block_indices:
             bi = self._binfo[ndx]
-            bi.group.rhs_staging[bi.slot] = _flat(rhs.get_block(ndx))
+            v = rhs.get_block(ndx)
+            if copy_rows is not None and isinstance(v, np.ndarray) and v.dtype == np.double and v.flags.c_contiguous \
+                    and v.size == bi.group.n:
+                pending.setdefault(bi.group.gid, (bi.group, []))[1].append((bi.slot, v))
+            else:
+                bi.group.rhs_staging[bi.slot] = _flat(v)
+        for g, rows in pending.values():
+            copy_rows(g.rhs_staging, rows)                  # 75 MB at the headline size: on the library's host threads
         for g in self._groups:
             self._eng.upload_rhs(g.gid, g.rhs_staging)
         self._eng.solve_forward()
