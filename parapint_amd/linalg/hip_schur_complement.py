@@ -1058,6 +1058,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             cols = np.concatenate([g.colB, bc])
             data = np.concatenate([np.zeros(g.rowB.size), bd])
             blocks[(last, ndx)] = coo_matrix((data, (rows, cols)), shape=(self._nc, n))
+        blocks[(last, last)] = matrix.get_block(last, last)     # (the structure of S depends on the pattern of Q, too)
         self._build_groups(_UnionMatrix(self.block_dim, blocks, self._nc))
         self._run_symbolic()
         self._pattern_only = False

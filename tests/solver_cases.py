@@ -733,3 +733,51 @@ def case_dynamic(make_engine, T, n_s, n_u=2, nfe=3, iteration=1, expect_block_tr
     x2 = solver.do_back_solve(rhs)
     assert scaled_residual(kkt2.tocoo(), x2.flatten(), rhs.flatten()) <= RESID_TOL
     return solver, model
+
+
+def case_dynamic_regularised(make_engine, dense_limit=None):
+    """The inertia-correction loop on a dynamic problem (interior_point.py:364-392 with sc_ip_interface.py:903-933): the
+    regularised KKT has delta on the link-dual diagonals of every time block and on both halves of the coupling block --
+    entries outside the planned pattern -> one re-plan on the union pattern (the structure of S is found again, with the
+    new diagonal of Q), then the retries and the next unregularised matrix factorise on that plan."""
+    import scipy.sparse as sp2
+    from parapint_amd.examples.performance.schur_complement.dynamic_kkt import SyntheticDynamicKKT
+    T, n_s = 10, 3
+    model = SyntheticDynamicKKT(T, n_s, 2, 2)
+    rhs = model.build_rhs(comm=SerialComm())
+    solver = new_solver(make_engine, T)
+    if dense_limit is not None:
+        solver._dense_coupling_limit = dense_limit
+    kkt = model.build_kkt(comm=SerialComm(), iteration=1)
+    solver.do_symbolic_factorization(kkt)
+    assert solver.do_numeric_factorization(kkt).status == LinearSolverStatus.successful
+
+    def regularised(coef):
+        R = model.build_kkt(comm=SerialComm(), iteration=1)
+        for t in range(T):
+            blk = R.get_block(t, t)                                   # [[kkt_t, L^T], [L, 0 * I]]
+            inner = blk.get_block(0, 0)
+            n_x, n_eq = model.n_x, model.n_eq
+            inner.set_block(0, 0, (inner.get_block(0, 0) + coef * sp2.identity(n_x, format='coo')).tocoo())
+            inner.set_block(1, 1, (-coef * sp2.identity(n_eq, format='coo')).tocoo())
+            nb = blk.get_block(1, 1).shape[0]
+            blk.set_block(1, 1, (-coef * sp2.identity(nb, format='coo')).tocoo())
+        R.set_block(T, T, (model.corner_matrix() + coef * sp2.identity(model.n_coupling, format='coo')).tocoo())
+        return R
+    for coef in (1e-6, 1e-3):
+        R = regularised(coef)
+        res = solver.do_numeric_factorization(R, raise_on_error=False)
+        assert res.status == LinearSolverStatus.successful
+        K = R.tocoo().toarray()
+        ev = np.linalg.eigvalsh(K)
+        assert solver.get_inertia() == (int((ev > 0).sum()), int((ev < 0).sum()), 0)
+        x = solver.do_back_solve(rhs)
+        xd = np.linalg.solve(K, rhs.flatten())
+        assert np.abs(x.flatten() - xd).max() <= 1e-8 * np.abs(xd).max()
+    groups_before = [id(g) for g in solver._groups]
+    kkt2 = model.build_kkt(comm=SerialComm(), iteration=2)
+    assert solver.do_numeric_factorization(kkt2).status == LinearSolverStatus.successful
+    assert [id(g) for g in solver._groups] == groups_before          # a subset of the union pattern: no new plan
+    x = solver.do_back_solve(rhs)
+    assert scaled_residual(kkt2.tocoo(), x.flatten(), rhs.flatten()) <= RESID_TOL
+    return solver

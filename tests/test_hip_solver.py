@@ -550,3 +550,9 @@ def test_dynamic_time_blocks_block_tridiagonal_schur():
     solver, model = sc.case_dynamic(make_engine, 64, 49, n_u=2, nfe=4, expect_block_tridiagonal=True)
     gs, G = solver._btd
     assert gs == 2 * 49 and G == 63 and not solver._btd_sequential       # blocks (rho_t, z_t), cyclic reduction
+
+
+@pytest.mark.parametrize('dense_limit', [None, 8])
+def test_dynamic_problem_through_the_inertia_correction_loop(dense_limit):
+    solver = sc.case_dynamic_regularised(make_engine, dense_limit)
+    assert (solver._btd is not None) == (dense_limit is not None)

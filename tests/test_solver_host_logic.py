@@ -81,3 +81,9 @@ def test_dynamic_block_tridiagonal_plumbing_on_the_host():
     solver, model = sc.case_dynamic(make_engine, 12, 4, expect_block_tridiagonal=True, dense_limit=8)
     gs, G = solver._btd
     assert G >= 3 and gs * G >= model.n_coupling
+
+
+@pytest.mark.parametrize('dense_limit', [None, 8])
+def test_dynamic_problem_through_the_inertia_correction_loop(dense_limit):
+    solver = sc.case_dynamic_regularised(make_engine, dense_limit)
+    assert (solver._btd is not None) == (dense_limit is not None)
