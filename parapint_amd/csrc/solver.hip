@@ -272,8 +272,11 @@ __device__ __forceinline__ void invert_and_scale(const GroupDev& g, int p, int w
 // scaling of their rows.
 // NW = waves (tasks) per workgroup: PP_QUAD on the levels that hold split rows, 1 elsewhere (a workgroup keeps its
 // resources until its longest wave ends, so unrelated tasks are better off as workgroups of their own).
+#ifndef PP_X_GATHER_ATTR
+#define PP_X_GATHER_ATTR
+#endif
 template <int WM, int NW>
-__global__ __launch_bounds__(64 * NW) void k_gather_level(GroupDev g, int task0, int chunk0, int ny, double eps) {
+__global__ __launch_bounds__(64 * NW) PP_X_GATHER_ATTR void k_gather_level(GroupDev g, int task0, int chunk0, int ny, double eps) {
   __shared__ double red[NW > 1 ? NW : 1][NW > 1 ? 2 * WM : 1][NW > 1 ? 64 : 1];   // partial sums / term magnitudes of a split row
   const int lane = threadIdx.x & 63, wave = (NW > 1) ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
   const int b = (PP_CHUNK_OF_WG(ny) + chunk0) * 64 + lane;
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(64 * NW) void k_gather_level(GroupDev g, int task0,
     _Pragma("unroll") for (int i = 0; i < G; ++i) {                                        \
       const int qi = min(i0 + i, cnt - 1);                                                 \
       eu[i] = bcast(rec.x, qi); el[i] = bcast(rec.y, qi); ew[i] = bcast(rec.z, qi);        \
-      if (WM > 1) { eq[i] = bcast(rec.w, qi); } else { eq[i] = 0; }                        \
+      if (WM > 1) { eq[i] = bcast(rec.w, qi) & 0xff; } else { eq[i] = 0; }                 \
     }                                                                                      \
     double su[G], sl[G][WM];                                                               \
     _Pragma("unroll") for (int i = 0; i < G; ++i) {                                        \
@@ -352,8 +355,15 @@ __global__ __launch_bounds__(64 * NW) void k_gather_level(GroupDev g, int task0,
     }                                                                                      \
   }
     int i0 = 0;
-    constexpr int GB = (WM == 1) ? 16 : 8;
-    if (WM > 1 && WM <= 4 && cnt > 8 && cnt <= 16) { PP_GROUP(16) i0 = 16; }   // a whole small task in ONE round trip
+    // entries requested together.  MEASURED (C3, round 2): block pivots 2-4 wide with groups of 16 / 8 entries
+    // (80 / 40 operands held) took 203 VGPRs = 2 waves per SIMD, and the wide levels 2-5 (10 000+ waves each) ran at
+    // 2 TB/s; groups of 4 (88 VGPRs, 5 waves per SIMD) cut the gather kernels from 614 to 563 us per step; groups of
+    // 2 (8 waves per SIMD) and of 8 (4 waves) measure the same as 4.
+#ifdef PP_X_GB
+    constexpr int GB = (WM == 1) ? 16 : PP_X_GB;
+#else
+    constexpr int GB = (WM == 1) ? 16 : 4;
+#endif
     for (; cnt - i0 > 4; i0 += GB) PP_GROUP(GB)
     if (i0 < cnt) PP_GROUP(4)
 #undef PP_GROUP
@@ -379,6 +389,231 @@ __global__ __launch_bounds__(64 * NW) void k_gather_level(GroupDev g, int task0,
   while (d < nrow) PP_FINALIZE();
 #undef PP_FINALIZE
   if (kind == 1) invert_and_scale<WM>(g, p, w, uoff, doff, sub, r0, r1, tmax_diag, true, bpad, b, eps);
+}
+
+// The same task, written for few instructions per entry (round 2; the kernel above stays as the comparison build
+// -DPP_X_OLD_GATHER).  MEASURED at C3 (tools/pmc_metrics.sh): the waves of the kernel above issue 1100 VALU + 1300 SALU
+// instructions for ~20 entries and spend 56 % of their life waiting to issue (a 40 KB body of short branchy blocks),
+// 23 % waiting for memory.  Here:
+//   * row ends are marked in the records themselves (bits 8.. of the fourth field = rows that end before this entry),
+//   * operands are addressed as uniform row base + lane offset, so the address arithmetic is scalar,
+//   * the term magnitudes (zero-pivot test) are only tracked in the rows of the pivot block; all other rows are plain
+//     fused multiply-adds,
+//   * initial-value records load one operand, not 1 + w.
+#ifdef PP_X_STAMPS
+// diagnostic build: lane 0 of every wave of ONE launch (the level whose first task is pp_x_stamp_task0) writes 100 MHz
+// timestamps at the stations of its task: [0] start, [1] task record read, [2] first entry records arrived, [3..]
+// after each group of entries, [14] end, [15] hardware id
+__device__ unsigned long long* pp_x_stamps = nullptr;
+__device__ int pp_x_stamp_task0 = -1;
+#define PP_STAMP(k) do { if (stp) stp[(k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PP_STAMP(k) do { } while (0)
+#endif
+// NV = instances per lane (1 or 2).  With 2, a lane owns the instances 2 * lane and 2 * lane + 1 of a 128-instance chunk:
+// every operand request is one 16-byte load per lane, and the record broadcasts, the scalar address arithmetic and the
+// branches of an entry are spent once for two instances (bpad must be a multiple of 128).
+template <int NV>
+__device__ __forceinline__ void ldv(const double* __restrict__ p, double (&out)[NV]) {
+  if (NV == 1) out[0] = *p;
+  else { const double2 t = *reinterpret_cast<const double2*>(p); out[0] = t.x; out[NV - 1] = t.y; }
+}
+template <int NV>
+__device__ __forceinline__ void stv(double* p, const double (&v)[NV]) {
+  if (NV == 1) *p = v[0];
+  else *reinterpret_cast<double2*>(p) = make_double2(v[0], v[NV - 1]);
+}
+
+template <int WM, int NW, int NV>
+__global__ __launch_bounds__(64 * NW) void k_gather_flat(GroupDev g, int task0, int chunk0, int ny, double eps) {
+  __shared__ double red[NW > 1 ? NW : 1][NW > 1 ? 2 * WM * NV : 1][NW > 1 ? 64 : 1];   // partial sums / term magnitudes of a split row
+  const int lane = threadIdx.x & 63, wave = (NW > 1) ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+  const unsigned b = (unsigned)(((PP_CHUNK_OF_WG(ny) + chunk0) * 64 + lane) * NV);    // first instance of this lane
+  const size_t bpad = (size_t)g.bpad;
+  const int* t = g.ftask + TASK_INTS * (size_t)(task0 + NW * PP_TASK_OF_WG(ny) + wave);
+#ifdef PP_X_STAMPS
+  unsigned long long* stp = (pp_x_stamps && task0 == pp_x_stamp_task0 && lane == 0)
+                                ? pp_x_stamps + 16 * ((size_t)blockIdx.x * NW + wave) : nullptr;
+  int stamp_k = 3;
+  PP_STAMP(0);
+#endif
+  const int p = t[0], r0 = t[1], r1 = t[2], kind = t[4], E0 = t[5], E1 = t[6];
+  const int piece = (NW > 1) ? t[12] : 0, npieces = (NW > 1) ? t[13] : 1;   // npieces is the same for all waves of the workgroup
+  if (kind < 0 && npieces <= 1) return;            // quad padding (in a split quad the padding waves join the barrier)
+  const int w = (WM == 1) ? 1 : t[7];
+  const int uoff = t[8], boff = t[9], doff = t[10];
+  const unsigned sub = (unsigned)t[11];
+#ifdef PP_X_STAMPS
+  if (stp) { stp[1] = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(E1 < 0); stp[13] = (unsigned long long)(E1 - E0); }
+#endif
+  const double* __restrict__ Ub = g.U;
+  const double* __restrict__ Lb = g.L;
+  const double* __restrict__ Rb = g.rawT;
+  const int nrow = r1 - r0;
+  double* Udst = g.U + ((size_t)uoff + (size_t)r0 * w) * bpad;     // uniform; lane offset added at the store
+  double* Tmd = g.Tm + ((size_t)boff + (size_t)r0 * w) * bpad;
+  const int nblk = (r0 < w) ? (w - r0) : 0;          // leading destination rows that belong to the pivot block
+  const bool split = NW > 1 && npieces > 1;
+  double tmax_diag[NV];
+  double acc[WM][NV], tmax[WM][NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    tmax_diag[v] = 0.0;
+#pragma unroll
+    for (int q = 0; q < WM; ++q) { acc[q][v] = 0.0; tmax[q][v] = 0.0; }
+  }
+  int d = 0;
+  auto finalize = [&]() {
+    if (!split) {                                    // (split row: combined below)
+#pragma unroll
+      for (int q = 0; q < WM; ++q)
+        if (q < w) stv<NV>(Udst + (size_t)(d * w + q) * bpad + b, acc[q]);
+      if (d < nblk) {
+#pragma unroll
+        for (int q = 0; q < WM; ++q) {
+          if (q < w) {
+            if (kind == 0) stv<NV>(Tmd + (size_t)(d * w + q) * bpad + b, tmax[q]);
+            else {
+#pragma unroll
+              for (int v = 0; v < NV; ++v) tmax_diag[v] = fmax(tmax_diag[v], tmax[q][v]);
+            }
+          }
+#pragma unroll
+          for (int v = 0; v < NV; ++v) tmax[q][v] = 0.0;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < WM; ++q)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[q][v] = 0.0;
+    }
+    ++d;
+  };
+  constexpr int G = (WM == 1) ? 8 : 4;               // entries whose operands are requested together
+  for (int eb = E0; eb < E1; eb += 64) {
+    const int cnt = min(64, E1 - eb);
+    int4 rec = make_int4(0, 0, 0, 0);
+    if (lane < cnt) rec = *reinterpret_cast<const int4*>(g.fent + 4 * (size_t)(eb + lane));
+#ifdef PP_X_STAMPS
+    if (stp && eb == E0) stp[2] = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(bcast(rec.x, 0) == 0x7fffffff);
+#endif
+    for (int i0 = 0; i0 < cnt; i0 += G) {
+      int eu[G], el[G], ew[G], ef[G];
+      double su[G][NV], sl[G][WM][NV];
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        const int qi = min(i0 + i, cnt - 1);
+        eu[i] = bcast(rec.x, qi); el[i] = bcast(rec.y, qi); ew[i] = bcast(rec.z, qi); ef[i] = bcast(rec.w, qi);
+      }
+      // branch-free operand requests (a branch here splits the requests over basic blocks, and the wait-count insertion
+      // then drains all outstanding loads at the joins: two or more round trips per group instead of one).  An
+      // initial-value record requests row 0 of L for its unused operands.
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        const bool prod = eu[i] >= 0;
+        const int idx = prod ? eu[i] : -1 - eu[i];
+        const double* __restrict__ base = prod ? Ub : Rb;
+#if defined(PP_X_NOLOADS)      // timing experiments (wrong results): no operand traffic at all / no L / no U
+        for (int v = 0; v < NV; ++v) su[i][v] = 1.0 + 1e-9 * (double)(idx & 15);
+        for (int q = 0; q < WM; ++q) for (int v = 0; v < NV; ++v) sl[i][q][v] = 1e-3 * (double)((el[i] + q) & 7);
+#elif defined(PP_X_NOL)
+        ldv<NV>(base + (size_t)((!prod && idx == g.const_row) ? 0 : idx) * bpad + b, su[i]);
+        for (int q = 0; q < WM; ++q) for (int v = 0; v < NV; ++v) sl[i][q][v] = 1e-3 * (double)((el[i] + q) & 7);
+#elif defined(PP_X_NOU)
+        for (int v = 0; v < NV; ++v) su[i][v] = 1.0 + 1e-9 * (double)(idx & 15);
+#pragma unroll
+        for (int q = 0; q < WM; ++q)
+          ldv<NV>(Lb + (size_t)(prod ? el[i] + min(q, w - 1) * ew[i] : 0) * bpad + b, sl[i][q]);
+#else
+        ldv<NV>(base + (size_t)((!prod && idx == g.const_row) ? 0 : idx) * bpad + b, su[i]);
+#pragma unroll
+        for (int q = 0; q < WM; ++q)
+          ldv<NV>(Lb + (size_t)(prod ? el[i] + min(q, w - 1) * ew[i] : 0) * bpad + b, sl[i][q]);
+#endif
+      }
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        if (i0 + i < cnt) {
+          for (int nf = ef[i] >> 8; nf > 0; --nf) finalize();
+          if (eu[i] >= 0) {
+            if (d < nblk) {
+#pragma unroll
+              for (int q = 0; q < WM; ++q)
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                  const double term = su[i][v] * ((q < w) ? sl[i][q][v] : 0.0);
+                  acc[q][v] -= term;
+                  tmax[q][v] = fmax(tmax[q][v], fabs(term));
+                }
+            } else {
+#pragma unroll
+              for (int q = 0; q < WM; ++q)     // (q >= w: a duplicate of column w - 1, never stored)
+#pragma unroll
+                for (int v = 0; v < NV; ++v) acc[q][v] = fma(-su[i][v], sl[i][q][v], acc[q][v]);
+            }
+          } else {
+            // initial-value record: (y, z) hold the coefficient of the input entry (1 for plain raw values)
+            const bool cst = (-1 - eu[i] == g.const_row);
+            const double coef = __hiloint2double(ew[i], el[i]);
+            const int eq = ef[i] & 0xff;
+#pragma unroll
+            for (int q = 0; q < WM; ++q) {
+              if (q == eq) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                  const double term = (cst ? 1.0 : su[i][v]) * coef;
+                  acc[q][v] += term;
+                  tmax[q][v] = fmax(tmax[q][v], fabs(term));
+                }
+              }
+            }
+          }
+        }
+      }
+#ifdef PP_X_STAMPS
+      if (stp && stamp_k < 13) { stp[stamp_k] = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(acc[0][0] == 1.2345e300); ++stamp_k; }
+#endif
+    }
+  }
+  if (split) {
+    // one long row over the waves of this quad: partial sums meet in LDS, piece 0 adds them in piece order
+#pragma unroll
+    for (int q = 0; q < WM; ++q)
+#pragma unroll
+      for (int v = 0; v < NV; ++v) { red[wave][q * NV + v][lane] = acc[q][v]; red[wave][(WM + q) * NV + v][lane] = tmax[q][v]; }
+    __syncthreads();
+    if (piece == 0 && kind >= 0) {
+#pragma unroll
+      for (int q = 0; q < WM; ++q) {
+        double a[NV], m[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          a[v] = acc[q][v]; m[v] = tmax[q][v];
+          for (int j = 1; j < npieces; ++j) { a[v] += red[j][q * NV + v][lane]; m[v] = fmax(m[v], red[j][(WM + q) * NV + v][lane]); }
+        }
+        if (q < w) {
+          stv<NV>(Udst + (size_t)q * bpad + b, a);
+          if (r0 < w) stv<NV>(Tmd + (size_t)q * bpad + b, m);
+        }
+      }
+    }
+    return;
+  }
+  while (d < nrow) finalize();
+  if (kind == 1) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+      invert_and_scale<WM>(g, p, w, uoff, doff, sub, r0, r1, tmax_diag[v], true, bpad, (int)b + v, eps);
+  }
+#ifdef PP_X_STAMPS
+  if (stp) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stp[14] = __builtin_amdgcn_s_memrealtime();
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    stp[15] = hw;
+  }
+#endif
 }
 
 // Lean variant for the wide bottom levels of the tree (a few entries per task, tens of thousands
@@ -420,7 +655,7 @@ __global__ __launch_bounds__(64) void k_gather_level_lean(GroupDev g, int task0,
 #pragma unroll
       for (int q = 0; q < WM; ++q) {
         const double lv = Lb[(size_t)((ex >= 0) ? ey + min(q, w - 1) * ez : 0) * bpad];
-        const double m = (ex >= 0) ? ((q < w) ? lv : 0.0) : ((q == ew) ? -coef : 0.0);
+        const double m = (ex >= 0) ? ((q < w) ? lv : 0.0) : ((q == (ew & 0xff)) ? -coef : 0.0);
         const double term = su * m;
         acc[q] -= term;
         tmax[q] = fmax(tmax[q], fabs(term));
@@ -2043,6 +2278,7 @@ struct pp_solver {
   bool growth_fatal = false;     // flagged instances make the factorisation report status 2 (else they are only counted)
   double pivot_threshold = 0.0;  // symbolic-time threshold u for groups added afterwards (0: plan default)
   bool no_fused_sources = std::getenv("PP_NO_FUSED_SOURCES") != nullptr;   // measurement switch: assemble the sources first
+  bool lane_pairs = std::getenv("PP_NO_LANE_PAIRS") == nullptr;   // two instances per lane in the gather kernels (measurement switch)
   double shift_w = 0.0, shift_c = 0.0;   // diagonal shifts of the current pp_numeric_local_shifted call (else 0)
   double mem_factor = 1.0;
   int64_t mem_budget = 0;        // bytes of device value storage the handle may allocate (0: no limit); scaled by mem_factor
@@ -2536,18 +2772,22 @@ int pp_end_symbolic(pp_handle h) {
     for (auto& t : P.ftasks) {
       const int nrow = t.r1 - t.r0;
       const int new_dptr0 = (int)fdst_ptr.size();
+      // fourth field of a record: bits 0-7 the destination column of an initial value, bits 8.. the number of
+      // destination rows that END before this entry (0 inside a row; k_gather_flat closes that many rows first)
+      int cur_row = 0;
       for (int dd = 0; dd < nrow; ++dd) {
         fdst_ptr.push_back((int)(fent.size() / 4));
         for (int e = P.fdst_ptr[t.dptr0 + dd]; e < P.fdst_ptr[t.dptr0 + dd + 1]; ++e) {
           const pp::FEntry& fe = P.fentries[e];
-          if (fe.u >= 0) fent.insert(fent.end(), {fe.u, fe.l, fe.wk, 0});
+          if (fe.u >= 0) { fent.insert(fent.end(), {fe.u, fe.l, fe.wk, (dd - cur_row) << 8}); cur_row = dd; }
           else {
             // the L index of an initial-value record is a dummy (position 0, always valid)
             const int ce = -1 - fe.u;
             for (int q = g->can_ptr[ce]; q < g->can_ptr[ce + 1]; ++q)
             {
               g->init_rec.push_back((int)(fent.size() / 4));
-              fent.insert(fent.end(), {-1 - rawmap[g->can_idx[q]], one_lo, one_hi, fe.q});
+              fent.insert(fent.end(), {-1 - rawmap[g->can_idx[q]], one_lo, one_hi, fe.q | ((dd - cur_row) << 8)});
+              cur_row = dd;
             }
           }
         }
@@ -2930,16 +3170,30 @@ int pp_numeric_factor_blocks(pp_handle h) {
         for (int q = 0; q < sp.n; ++q) {
           const int ny = sp.c0[q + 1] - sp.c0[q];
           if (nt > 0) {
+#ifdef PP_X_LEANMAX
+            const bool lean = P.flevel_maxent[l] <= 12 || (P.flevel_maxent[l] <= PP_X_LEANMAX && P.flevel_nsplit[l] == 0);
+#else
             const bool lean = P.flevel_maxent[l] <= 12;
+#endif
             const int mw = g->level_maxw[l];
 #define PP_LAUNCH_GATHER(K, ...) hipLaunchKernelGGL((K<__VA_ARGS__>), dim3((unsigned)nt * ny), dim3(64), 0, fan[q], d, t0, sp.c0[q], ny, PIVOT_EPS)
 #define PP_LAUNCH_QUADS(K, WM) hipLaunchKernelGGL((K<WM, PP_QUAD>), dim3((unsigned)(nt / PP_QUAD) * ny), dim3(64 * PP_QUAD), 0, fan[q], d, t0, sp.c0[q], ny, PIVOT_EPS)
+            // two instances per lane where the chunks pair up (chunk counts and offsets in units of 128 instances)
+            const bool pair = h->lane_pairs && ny % 2 == 0 && sp.c0[q] % 2 == 0;
+#define PP_LAUNCH_FLAT(WM) do { \
+              if (pair) hipLaunchKernelGGL((k_gather_flat<WM, 1, 2>), dim3((unsigned)nt * (ny / 2)), dim3(64), 0, fan[q], d, t0, sp.c0[q] / 2, ny / 2, PIVOT_EPS); \
+              else hipLaunchKernelGGL((k_gather_flat<WM, 1, 1>), dim3((unsigned)nt * ny), dim3(64), 0, fan[q], d, t0, sp.c0[q], ny, PIVOT_EPS); } while (0)
+#define PP_LAUNCH_FLAT_QUADS(WM) do { \
+              if (pair) hipLaunchKernelGGL((k_gather_flat<WM, PP_QUAD, 2>), dim3((unsigned)(nt / PP_QUAD) * (ny / 2)), dim3(64 * PP_QUAD), 0, fan[q], d, t0, sp.c0[q] / 2, ny / 2, PIVOT_EPS); \
+              else hipLaunchKernelGGL((k_gather_flat<WM, PP_QUAD, 1>), dim3((unsigned)(nt / PP_QUAD) * ny), dim3(64 * PP_QUAD), 0, fan[q], d, t0, sp.c0[q], ny, PIVOT_EPS); } while (0)
             if (lean) {
               if (mw == 1) PP_LAUNCH_GATHER(k_gather_level_lean, 1);
               else if (mw == 2) PP_LAUNCH_GATHER(k_gather_level_lean, 2);
               else if (mw <= 4) PP_LAUNCH_GATHER(k_gather_level_lean, 4);
               else PP_LAUNCH_GATHER(k_gather_level_lean, PP_WMAX);
-            } else if (P.flevel_nsplit[l] == 0) {
+            }
+#ifdef PP_X_OLD_GATHER
+            else if (P.flevel_nsplit[l] == 0) {
               if (mw == 1) PP_LAUNCH_GATHER(k_gather_level, 1, 1);
               else if (mw == 2) PP_LAUNCH_GATHER(k_gather_level, 2, 1);
               else if (mw <= 4) PP_LAUNCH_GATHER(k_gather_level, 4, 1);
@@ -2950,8 +3204,23 @@ int pp_numeric_factor_blocks(pp_handle h) {
               else if (mw <= 4) PP_LAUNCH_QUADS(k_gather_level, 4);
               else PP_LAUNCH_QUADS(k_gather_level, PP_WMAX);
             }
+#else
+            else if (P.flevel_nsplit[l] == 0) {
+              if (mw == 1) PP_LAUNCH_FLAT(1);
+              else if (mw == 2) PP_LAUNCH_FLAT(2);
+              else if (mw <= 4) PP_LAUNCH_FLAT(4);
+              else PP_LAUNCH_FLAT(PP_WMAX);
+            } else {
+              if (mw == 1) PP_LAUNCH_FLAT_QUADS(1);
+              else if (mw == 2) PP_LAUNCH_FLAT_QUADS(2);
+              else if (mw <= 4) PP_LAUNCH_FLAT_QUADS(4);
+              else PP_LAUNCH_FLAT_QUADS(PP_WMAX);
+            }
+#endif
 #undef PP_LAUNCH_GATHER
 #undef PP_LAUNCH_QUADS
+#undef PP_LAUNCH_FLAT
+#undef PP_LAUNCH_FLAT_QUADS
           }
           if (ns > 0) {
             if (g->level_maxw[l] <= 4)
@@ -3590,6 +3859,17 @@ int pp_vec_axpy(pp_handle h, int64_t n, double alpha, const double* x, double* y
   PP_HIP(hipGetLastError());
   return 0;
 }
+
+#ifdef PP_X_STAMPS
+int pp_x_set_stamps(pp_handle h, void* dev_buffer, int level) {
+  const pp::Plan& P = h->groups[0]->plan;
+  const int task0 = (level >= 0 && level < P.n_levels) ? P.flevel_ptr[level] : -1;
+  unsigned long long* ptr = (unsigned long long*)dev_buffer;
+  PP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(pp_x_stamps), &ptr, sizeof(ptr)));
+  PP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(pp_x_stamp_task0), &task0, sizeof(task0)));
+  return P.flevel_ptr[level + 1] - P.flevel_ptr[level];
+}
+#endif
 
 int pp_group_stats_ex(pp_handle h, int group, int64_t out[16]) {
   Group* g = get_group(h, group);

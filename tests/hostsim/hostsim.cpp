@@ -91,6 +91,36 @@ void ppsim_task_profile(void* h, int* out /*5 per task*/) {
   }
 }
 
+// per level (8 ints): fused tasks, gather chunks (pieces counted), split rows, scale tasks, big panels, rows of the big
+// panels (sum), rows of the tallest big panel, longest gather/fused task (entries)
+void ppsim_level_profile(void* h, int* out) {
+  Plan& P = *(Plan*)h;
+  for (int l = 0; l < P.n_levels; ++l) {
+    int* o = out + 8 * l;
+    for (int i = 0; i < 8; ++i) o[i] = 0;
+    int lastp = -1;
+    for (int t = P.flevel_ptr[l]; t < P.flevel_ptr[l + 1]; ++t) {
+      const auto& ft = P.ftasks[t];
+      if (ft.kind < 0) continue;
+      if (ft.kind == 1) o[0]++;
+      else {
+        o[1]++;
+        if (ft.npieces > 1 && ft.piece == 0) o[2]++;
+      }
+    }
+    for (int t = P.slevel_ptr[l]; t < P.slevel_ptr[l + 1]; ++t) {
+      const auto& st = P.stasks[t];
+      o[3]++;
+      if (st.piv != lastp) {
+        lastp = st.piv;
+        const int f = P.piv_w[st.piv] + P.piv_rowptr[st.piv + 1] - P.piv_rowptr[st.piv];
+        o[4]++; o[5] += f; o[6] = std::max(o[6], f);
+      }
+    }
+    o[7] = P.flevel_maxent[l];
+  }
+}
+
 namespace {
 // rows [r0, r1) of panel p: L = U inv(P)
 void scale_rows(const Plan& P, int p, int r0, int r1, const double* inv, const double* U, double* L) {

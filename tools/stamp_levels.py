@@ -1,0 +1,81 @@
+"""Where the waves of one factorisation level spend their time (diagnostic; needs the -DPP_X_STAMPS build of the
+kernel library: csrc/libparapint_hip_stamps.so, selected with PP_LIB_VARIANT=stamps).
+
+    PP_LIB_VARIANT=stamps python tools/stamp_levels.py LEVEL [LEVEL ...]
+
+C3 workload, device-resident values; one warm factorisation, then one with 100 MHz timestamps written by lane 0 of every
+wave of that level's gather launch at: start, task record read, entry records arrived, after every group of entries, end.
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from parapint_amd.examples.performance.schur_complement.synthetic_kkt import SyntheticKKT   # noqa: E402
+from parapint_amd.linalg.comm import SerialComm   # noqa: E402
+from parapint_amd.linalg.hip_schur_complement import HipSchurComplementLinearSolver   # noqa: E402
+
+
+def main():
+    levels = [int(a) for a in sys.argv[1:]] or [3]
+    N, n_q, m, n_t = 1024, 1000, 4, 200
+    model = SyntheticKKT(N, n_q, m, n_t)
+    comm = SerialComm()
+    solver = HipSchurComplementLinearSolver({i: None for i in range(N)}, None, comm=comm)
+    dk = model.build_device_kkt(comm=comm)
+    solver.do_symbolic_factorization(matrix=dk)
+    dk.set_sources_from_host({ndx: model.block_sources(ndx, 3) for ndx in range(N)})
+    for _ in range(3):
+        solver.do_numeric_factorization(matrix=dk)
+    lib, h = solver._eng.lib, solver._eng.ns.h
+    lib.pp_x_set_stamps.restype = ctypes.c_int
+    lib.pp_x_set_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    nmax = 5000 * 16 * 4
+    for level in levels:
+        buf = torch.zeros(nmax * 16, dtype=torch.int64, device='cuda')
+        torch.cuda.synchronize()
+        ntask = lib.pp_x_set_stamps(h, ctypes.c_void_p(buf.data_ptr()), level)
+        solver.do_numeric_factorization(matrix=dk)
+        torch.cuda.synchronize()
+        lib.pp_x_set_stamps(h, None, -1)
+        st = buf.cpu().numpy().reshape(-1, 16)
+        st = st[st[:, 0] > 0]
+        t0 = st[:, 0].min()
+        tick = 0.01      # us per 100 MHz tick
+        life = (st[:, 14] - st[:, 0]) * tick
+        print('== level %d: %d tasks in the launch, %d waves stamped, launch span %.1f us (first start to last end)' %
+              (level, ntask, len(st), (st[:, 14].max() - t0) * tick))
+        print('   wave start offsets (us): p10 %.1f p50 %.1f p90 %.1f max %.1f' %
+              tuple(np.percentile((st[:, 0] - t0) * tick, [10, 50, 90, 100])))
+        print('   wave lifetime (us):      p10 %.1f p50 %.1f p90 %.1f max %.1f   entries per task p50 %d max %d' %
+              (tuple(np.percentile(life, [10, 50, 90, 100])) + (np.median(st[:, 13]), st[:, 13].max())))
+        names = ['task record', 'entry records'] + ['group %d' % k for k in range(10)]
+        prev = st[:, 0]
+        for k, nm in zip(range(1, 13), names):
+            cur = st[:, k]
+            ok = cur > 0
+            if ok.sum() == 0:
+                break
+            dt = (cur[ok] - prev[ok]) * tick
+            print('   %-14s waves %6d  dt p10 %.2f p50 %.2f p90 %.2f max %.2f us' %
+                  ((nm, ok.sum()) + tuple(np.percentile(dt, [10, 50, 90, 100]))))
+            prev = np.where(ok, cur, prev)
+        tail = (st[:, 14] - prev) * tick
+        print('   %-14s waves %6d  dt p10 %.2f p50 %.2f p90 %.2f max %.2f us' %
+              (('stores+end', len(st)) + tuple(np.percentile(tail, [10, 50, 90, 100]))))
+        hw = st[:, 15]
+        cu = (hw >> 8) & 0xf
+        se = (hw >> 13) & 0x7
+        print('   distinct (se, cu) pairs seen: %d' % len(set(zip(se.tolist(), cu.tolist()))))
+        # concurrency: waves alive at the midpoint of the launch
+        mid = t0 + (st[:, 14].max() - t0) // 2
+        print('   waves alive at mid-launch: %d' % int(((st[:, 0] <= mid) & (st[:, 14] >= mid)).sum()))
+
+
+if __name__ == '__main__':
+    main()

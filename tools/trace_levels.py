@@ -5,6 +5,8 @@ rows.sort(key=lambda r: int(r['Start_Timestamp']))
 names = [re.sub(r'\(.*', '', r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '')) for r in rows]
 # find the last full iteration: from the last k_transpose_in whose successor is a gather kernel
 starts = [i for i, n in enumerate(names[:-1]) if n.startswith('k_transpose_in') and names[i + 1].startswith('k_gather')]
+if len(starts) < 2:     # device-resident sources: an iteration starts at the first bottom-level gather after a back solve
+    starts = [i for i, n in enumerate(names[:-1]) if n.startswith('k_gather_level_lean') and not names[i - 1].startswith('k_gather')]
 i0 = starts[-2]
 t0 = int(rows[i0]['Start_Timestamp'])
 prev_end = t0
