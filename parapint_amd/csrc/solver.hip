@@ -32,6 +32,7 @@ namespace {
 
 constexpr int WAVE = 64;
 constexpr int PP_MAX_SPLIT = 8;
+constexpr int PP_CSLOTS = 64;  // the inertia / growth counters are kept in this many slots of 4 ints, summed by the tail writer
 constexpr int PP_TAIL = 8;    // doubles behind the n_c x n_c Schur block: zero pivots, pos, neg, host failures, growth, reserved
 constexpr int PP_NPHASE = 8;  // assemble, factor, schur, dense, fwd, fwd_coupling, coupling_solve, bwd
 constexpr int BK_THREADS = 512;
@@ -856,13 +857,55 @@ __global__ void k_publish_status(const double* __restrict__ tail, const int* __r
 // Schur tile: half of an 8x8 tile (8 rows x 4 columns, blockIdx.z selects the column half) in
 // registers over all panels holding rows of both tile ranges, then summed over the 64 instances of
 // the wave through LDS.  Two waves per tile halve the register footprint (4 waves/SIMD).
-__global__ __launch_bounds__(64) void k_schur_tiles(GroupDev g) {
+// The workgroups in front of the ntile_all * nchunk tile workgroups (z = 0 only) count the inertia codes and collect the
+// growth flags (the work of k_count_codes) beside the tiles instead of in a launch of their own in front of them.
+__global__ __launch_bounds__(64) void k_schur_tiles(GroupDev g, int ntile_all, size_t total8, int* counters) {
   __shared__ double red[32][65];
   const int lane = threadIdx.x;
-  const int chunk = PP_CHUNK_OF_WG(g.nchunk), ntile_all = (int)(gridDim.x / (unsigned)g.nchunk);
+  const unsigned ncb = gridDim.x - (unsigned)(ntile_all * g.nchunk);    // counting workgroups come first in the grid
+  if (blockIdx.x < ncb) {
+    if (blockIdx.z != 0) return;
+    const unsigned cb = blockIdx.x;
+    int cnt[4] = {0, 0, 0, 0};     // pos, neg, zero, growth
+    if (cb == 0) {
+      int* growth_seen = g.growth + g.bpad;
+      for (int i = lane; i < g.batch; i += 64) {
+        const int f = g.growth[i];
+        cnt[3] += f != 0;
+        growth_seen[i] = f;
+        if (f) g.growth[i] = 0;
+      }
+    }
+    const uint4* c4 = reinterpret_cast<const uint4*>(g.codes);
+    const size_t stride = (size_t)ncb * 64;
+    for (size_t i = (size_t)cb * 64 + lane; i < total8; i += 4 * stride) {
+      uint4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = (i + u * stride < total8) ? c4[i + u * stride] : make_uint4(0, 0, 0, 0);   // in flight together
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned int wds[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const unsigned int x = wds[q];
+          cnt[0] += (int)((x & 15u) + ((x >> 16) & 15u));
+          cnt[1] += (int)(((x >> 4) & 15u) + ((x >> 20) & 15u));
+          cnt[2] += (int)(((x >> 8) & 15u) + ((x >> 24) & 15u));
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      for (int off = 32; off > 0; off >>= 1) cnt[q] += __shfl_xor(cnt[q], off);
+      if (lane == 0 && cnt[q] != 0) atomicAdd(&counters[4 * (cb % PP_CSLOTS) + q], cnt[q]);   // (slots: same-address atomics serialise, ~12 ns each)
+    }
+    return;
+  }
+  const unsigned wg = blockIdx.x - ncb;
+  const int chunk = (int)(wg % (unsigned)g.nchunk);
   const int b = chunk * 64 + lane;
   const size_t bpad = (size_t)g.bpad;
-  const int tile = PP_TASK_OF_WG(g.nchunk), half = blockIdx.z;
+  const int tile = (int)(wg / (unsigned)g.nchunk), half = blockIdx.z;
   double acc[8][4];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
@@ -927,26 +970,36 @@ __global__ __launch_bounds__(64) void k_schur_tiles(GroupDev g) {
 }
 
 // S[ci][cj] += sum over chunks of the tile partials (both triangles of the dense S)
+// overwrite: the tiles of this group cover all of S and it is the first group: S = instead of S += (no memset in front)
 __global__ __launch_bounds__(64) void k_schur_reduce(GroupDev g, int ntiles, double* __restrict__ S,
-                                                     const int* __restrict__ counters) {
+                                                     int* __restrict__ counters, int overwrite) {
   const int lane = threadIdx.x, tile = blockIdx.x;
-  // last group of the handle: the inertia counters (complete: k_count_codes ran earlier on this stream) go to
-  // the tail of the S buffer, so that they travel with the all-reduce (saves the one-thread k_write_tail launch)
-  if (counters && tile == 0 && lane == 0) {
-    double* tail = S + (size_t)g.nc * g.nc;
-    tail[0] = (double)counters[2];
-    tail[1] = (double)counters[0];
-    tail[2] = (double)counters[1];
-    tail[3] = 0.0;
-    tail[4] = (double)counters[3];
-    tail[5] = tail[6] = tail[7] = 0.0;
+  // last group of the handle: the inertia counters (complete: the counting workgroups ran in the launch before this
+  // one) go to the tail of the S buffer, so that they travel with the all-reduce, and are cleared for the next
+  // factorisation (saves the one-thread k_write_tail launch and a memset)
+  if (counters && tile == 0) {
+    int4 c = reinterpret_cast<int4*>(counters)[lane];       // PP_CSLOTS == 64: one slot per lane
+    reinterpret_cast<int4*>(counters)[lane] = make_int4(0, 0, 0, 0);
+    for (int off = 32; off > 0; off >>= 1) {
+      c.x += __shfl_xor(c.x, off); c.y += __shfl_xor(c.y, off); c.z += __shfl_xor(c.z, off); c.w += __shfl_xor(c.w, off);
+    }
+    if (lane == 0) {
+      double* tail = S + (size_t)g.nc * g.nc;
+      tail[0] = (double)c.z;
+      tail[1] = (double)c.x;
+      tail[2] = (double)c.y;
+      tail[3] = 0.0;
+      tail[4] = (double)c.w;
+      tail[5] = tail[6] = tail[7] = 0.0;
+    }
   }
   double s = 0.0;
   for (int c = 0; c < g.nchunk; ++c) s += g.Spart[((size_t)c * ntiles + tile) * 64 + lane];
   const int ci = g.stile_a[tile] * 8 + (lane >> 3), cj = g.stile_b[tile] * 8 + (lane & 7);
   if (ci < g.nc && cj < g.nc && ci >= cj) {
-    S[(size_t)ci + (size_t)cj * g.nc] += s;
-    if (ci != cj) S[(size_t)cj + (size_t)ci * g.nc] += s;
+    const size_t lo = (size_t)ci + (size_t)cj * g.nc, up = (size_t)cj + (size_t)ci * g.nc;
+    if (overwrite) { S[lo] = s; if (ci != cj) S[up] = s; }
+    else { S[lo] += s; if (ci != cj) S[up] += s; }
   }
 }
 
@@ -998,13 +1051,16 @@ __global__ __launch_bounds__(256) void k_gather_xc(GroupDev g, const double* __r
   g.XCL[i] = (b < g.batch) ? xc[g.cmapT[i]] : 0.0;
 }
 
-__global__ void k_write_tail(const int* counters, double* tail) {
+__global__ void k_write_tail(int* counters, double* tail) {
   if (threadIdx.x == 0) {
-    tail[0] = (double)counters[2];  // numerically zero pivots
-    tail[1] = (double)counters[0];
-    tail[2] = (double)counters[1];
+    int c[4] = {0, 0, 0, 0};
+    for (int sl = 0; sl < PP_CSLOTS; ++sl)
+      for (int q = 0; q < 4; ++q) { c[q] += counters[4 * sl + q]; counters[4 * sl + q] = 0; }   // (ready for the next factorisation)
+    tail[0] = (double)c[2];  // numerically zero pivots
+    tail[1] = (double)c[0];
+    tail[2] = (double)c[1];
     tail[3] = 0.0;
-    tail[4] = (double)counters[3];
+    tail[4] = (double)c[3];
     tail[5] = tail[6] = tail[7] = 0.0;
   }
 }
@@ -2960,7 +3016,8 @@ int pp_end_symbolic(pp_handle h) {
   if ((rc = dev_alloc<double>(h, nullptr, &h->xc, nc))) return rc;
   if ((rc = dev_alloc<int>(h, nullptr, &h->ipiv, nc))) return rc;
   if ((rc = dev_alloc<int>(h, nullptr, &h->bkinfo, 4))) return rc;
-  if ((rc = dev_alloc<int>(h, nullptr, &h->counters, 4))) return rc;
+  if ((rc = dev_alloc<int>(h, nullptr, &h->counters, 4 * PP_CSLOTS))) return rc;
+  PP_HIP(hipMemset(h->counters, 0, 4 * PP_CSLOTS * sizeof(int)));     // (afterwards cleared by the kernel that writes the tail)
   {
     void* hp = nullptr;
     void* dp = nullptr;
@@ -3245,28 +3302,39 @@ int pp_numeric_schur(pp_handle h) {
   PP_HIP(hipSetDevice(h->device));
   hipStream_t st = h->stream;
   const int nc = h->nc;
-  PP_HIP(hipMemsetAsync(h->S, 0, (schur_doubles(h) + PP_TAIL) * sizeof(double), st));
-  PP_HIP(hipMemsetAsync(h->counters, 0, 4 * sizeof(int), st));
+  // S starts from zero -- unless the first group is a plain (unmapped) one whose tiles cover all of S: its reduction
+  // then stores instead of adding.  The counters are cleared by whoever writes the tail (zero at allocation).
+  bool first_covers = false;
+  if (!h->groups.empty() && !h->btd) {
+    const Group* g0 = h->groups.front();
+    const int nt8 = (nc + 7) / 8;
+    first_covers = g0->ntiles > 0 && !g0->dev.cmapT && g0->ntiles == nt8 * (nt8 + 1) / 2;
+  }
+  if (!first_covers) PP_HIP(hipMemsetAsync(h->S, 0, (schur_doubles(h) + PP_TAIL) * sizeof(double), st));
   bool tail_written = false;
   for (Group* g : h->groups) {
     const pp::Plan& P = g->plan;
     GroupDev& d = g->dev;
     {
-      PhaseScope ps(h, 2, 3);
+      PhaseScope ps(h, 2, g->ntiles > 0 ? 2 : 1);
       const size_t total8 = (size_t)P.npiv * d.bpad / 8;   // bpad is a multiple of 64
-      hipLaunchKernelGGL(k_count_codes, dim3((unsigned)std::min<size_t>(512, (total8 + 255) / 256)), dim3(256), 0, st,
-                         d.codes, total8, h->counters, d.growth, d.growth + d.bpad, d.batch);
+      const unsigned ncb = (unsigned)std::min<size_t>(2048, (total8 + 255) / 256);   // counting workgroups in front of the tiles
       if (g->ntiles > 0 && d.cmapT) {
         // mapped group: per-instance cliques, scattered into the dense or the block-tridiagonal S
-        hipLaunchKernelGGL(k_schur_tiles, dim3((unsigned)g->ntiles * d.nchunk, 1, 2), dim3(64), 0, st, d);
+        hipLaunchKernelGGL(k_schur_tiles, dim3((unsigned)g->ntiles * d.nchunk + ncb, 1, 2), dim3(64), 0, st, d, g->ntiles, total8,
+                           h->counters);
         const SchurTarget T{h->S, nc, h->btd, h->gs, h->G, h->scatter_err};
         hipLaunchKernelGGL(k_scatter_schur, dim3((unsigned)g->ntiles * d.nchunk), dim3(64), 0, st, d, g->ntiles, T);
       } else if (g->ntiles > 0) {
-        hipLaunchKernelGGL(k_schur_tiles, dim3((unsigned)g->ntiles * d.nchunk, 1, 2), dim3(64), 0, st, d);
+        hipLaunchKernelGGL(k_schur_tiles, dim3((unsigned)g->ntiles * d.nchunk + ncb, 1, 2), dim3(64), 0, st, d, g->ntiles, total8,
+                           h->counters);
         const bool last = (g == h->groups.back());
         hipLaunchKernelGGL(k_schur_reduce, dim3(g->ntiles), dim3(64), 0, st, d, g->ntiles, h->S,
-                           last ? (const int*)h->counters : (const int*)nullptr);
+                           last ? h->counters : (int*)nullptr, (first_covers && g == h->groups.front()) ? 1 : 0);
         tail_written = last;
+      } else {
+        hipLaunchKernelGGL(k_count_codes, dim3((unsigned)std::min<size_t>(512, (total8 + 255) / 256)), dim3(256), 0, st,
+                           d.codes, total8, h->counters, d.growth, d.growth + d.bpad, d.batch);
       }
     }
   }
