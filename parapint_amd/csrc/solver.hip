@@ -620,10 +620,10 @@ __global__ __launch_bounds__(64 * NW) void k_gather_flat(GroupDev g, int task0, 
 // Lean variant for the wide bottom levels of the tree (a few entries per task, tens of thousands
 // of tasks): plain scalar-load record reads, minimal code; the memory system is kept busy by the
 // sheer number of waves, not by intra-task batching.
-template <int WM>
+template <int WM, int NV>
 __global__ __launch_bounds__(64) void k_gather_level_lean(GroupDev g, int task0, int chunk0, int ny, double eps) {
   const int lane = threadIdx.x;
-  const int b = (PP_CHUNK_OF_WG(ny) + chunk0) * 64 + lane;
+  const unsigned b = (unsigned)(((PP_CHUNK_OF_WG(ny) + chunk0) * 64 + lane) * NV);    // first instance of this lane
   const size_t bpad = (size_t)g.bpad;
   const int* t = g.ftask + TASK_INTS * (size_t)(task0 + PP_TASK_OF_WG(ny));
   const int p = t[0], r0 = t[1], r1 = t[2], dptr0 = t[3], kind = t[4];
@@ -640,55 +640,85 @@ __global__ __launch_bounds__(64) void k_gather_level_lean(GroupDev g, int task0,
   double* Tmd = g.Tm + ((size_t)boff + (size_t)r0 * w) * bpad + b;
   double* Ldst = g.L + ((size_t)uoff + (size_t)r0 * w) * bpad + b;
   const int nblk = (r0 < w) ? (w - r0) : 0;
-  double tmax_diag = 0.0, inv1 = 0.0, lmax = 0.0;
-  for (int d = 0; d < nrow; ++d) {
-    double acc[WM], tmax[WM];
+  double tmax_diag[NV], inv1[NV], lmax = 0.0;
 #pragma unroll
-    for (int q = 0; q < WM; ++q) { acc[q] = 0.0; tmax[q] = 0.0; }
+  for (int v = 0; v < NV; ++v) { tmax_diag[v] = 0.0; inv1[v] = 0.0; }
+  for (int d = 0; d < nrow; ++d) {
+    double acc[WM][NV], tmax[WM][NV];
+#pragma unroll
+    for (int q = 0; q < WM; ++q)
+#pragma unroll
+      for (int v = 0; v < NV; ++v) { acc[q][v] = 0.0; tmax[q][v] = 0.0; }
     for (int e = dp[d]; e < dp[d + 1]; ++e) {
       // scalar (SMEM) record reads; the operand base is chosen by offset, not by pointer select
       const int* rp = g.fent + 4 * (size_t)e;
       const int ex = rp[0], ey = rp[1], ez = rp[2], ew = rp[3];
       const bool cst = ex < 0 && (-1 - ex) == g.const_row;
-      const double sv = (ex >= 0) ? U[(size_t)ex * bpad] : R[(size_t)(cst ? 0 : -1 - ex) * bpad];
-      const double su = cst ? 1.0 : sv;
+      double sv[NV];
+      ldv<NV>((ex >= 0) ? U + (size_t)ex * bpad : R + (size_t)(cst ? 0 : -1 - ex) * bpad, sv);
       const double coef = __hiloint2double(ez, ey);     // (initial-value records: coefficient of the input entry)
 #pragma unroll
       for (int q = 0; q < WM; ++q) {
-        const double lv = Lb[(size_t)((ex >= 0) ? ey + min(q, w - 1) * ez : 0) * bpad];
-        const double m = (ex >= 0) ? ((q < w) ? lv : 0.0) : ((q == (ew & 0xff)) ? -coef : 0.0);
-        const double term = su * m;
-        acc[q] -= term;
-        tmax[q] = fmax(tmax[q], fabs(term));
+        double lv[NV];
+        ldv<NV>(Lb + (size_t)((ex >= 0) ? ey + min(q, w - 1) * ez : 0) * bpad, lv);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const double m = (ex >= 0) ? ((q < w) ? lv[v] : 0.0) : ((q == (ew & 0xff)) ? -coef : 0.0);
+          const double term = (cst ? 1.0 : sv[v]) * m;
+          acc[q][v] -= term;
+          tmax[q][v] = fmax(tmax[q][v], fabs(term));
+        }
       }
     }
 #pragma unroll
     for (int q = 0; q < WM; ++q)
-      if (q < w) Udst[(size_t)(d * w + q) * bpad] = acc[q];
+      if (q < w) stv<NV>(Udst + (size_t)(d * w + q) * bpad, acc[q]);
     if (WM == 1 && kind == 1) {
       // scalar pivot, fused panel: row 0 is the pivot, every later one a row to scale
       if (d == 0) {
-        const pp::PivotResult pr = pp::invert_pivot(1, acc[0], 0.0, 0.0, tmax[0], eps);
-        inv1 = pr.i00;
-        g.Dinv[(size_t)doff * bpad + b] = inv1;
-        const int code = (pr.code & 3) | (((pr.code >> 2) & 3) << 4) | (((pr.code >> 4) & 3) << 8);
-        g.codes[(size_t)p * bpad + b] = (b < g.batch) ? (unsigned short)code : (unsigned short)0;
+        unsigned short code[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const pp::PivotResult pr = pp::invert_pivot(1, acc[0][v], 0.0, 0.0, tmax[0][v], eps);
+          inv1[v] = pr.i00;
+          const int c = (pr.code & 3) | (((pr.code >> 2) & 3) << 4) | (((pr.code >> 4) & 3) << 8);
+          code[v] = ((int)(b + v) < g.batch) ? (unsigned short)c : (unsigned short)0;
+        }
+        stv<NV>(g.Dinv + (size_t)doff * bpad + b, inv1);
+        if (NV == 1) g.codes[(size_t)p * bpad + b] = code[0];
+        else *reinterpret_cast<unsigned int*>(g.codes + (size_t)p * bpad + b) = (unsigned int)code[0] | ((unsigned int)code[NV - 1] << 16);
       } else {
-        const double lv = acc[0] * inv1;
-        Ldst[(size_t)d * bpad] = lv;
-        lmax = fmax(lmax, fabs(lv));      // (one flag store per task, below: a store per row cost 36 us per step at C3)
+        double lv[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          lv[v] = acc[0][v] * inv1[v];
+          lmax = fmax(lmax, ((int)(b + v) < g.batch) ? fabs(lv[v]) : 0.0);   // (one flag store per task, below: a store per row cost 36 us per step at C3)
+        }
+        stv<NV>(Ldst + (size_t)d * bpad, lv);
       }
     } else if (d < nblk) {
 #pragma unroll
       for (int q = 0; q < WM; ++q) {
         if (q < w) {
-          if (kind == 0) Tmd[(size_t)(d * w + q) * bpad] = tmax[q]; else tmax_diag = fmax(tmax_diag, tmax[q]);
+          if (kind == 0) stv<NV>(Tmd + (size_t)(d * w + q) * bpad, tmax[q]);
+          else {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) tmax_diag[v] = fmax(tmax_diag[v], tmax[q][v]);
+          }
         }
       }
     }
   }
-  if (WM == 1 && lmax > g.lbound && b < g.batch) g.growth[b] = 1;
-  if (WM != 1 && kind == 1) invert_and_scale<WM>(g, p, w, uoff, doff, sub, r0, r1, tmax_diag, true, bpad, b, eps);
+  if (WM == 1 && lmax > g.lbound) {
+    // (which of the two instances of the lane grew is not kept: both are flagged; the guard re-orders from either)
+#pragma unroll
+    for (int v = 0; v < NV; ++v) if ((int)(b + v) < g.batch) g.growth[b + v] = 1;
+  }
+  if (WM != 1 && kind == 1) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+      invert_and_scale<WM>(g, p, w, uoff, doff, sub, r0, r1, tmax_diag[v], true, bpad, (int)b + v, eps);
+  }
 }
 
 // L values [v0, v1) of a panel of compile-time width W from row values held in registers
@@ -2082,6 +2112,90 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_level(GroupDev g, int col0, int
   if (wave == 0) *yc = (RN ? RN[(size_t)rec[1] * bpad] : *yc) - s;
 }
 
+// The wide bottom levels with two instances per lane (chunks of 128 instances, 16-byte accesses): short rows only
+// (the callers use it on levels whose longest row has at most PP_PAIR_MAXROW entries; one wave per row, no team).
+constexpr int PP_PAIR_MAXROW = 8;
+__global__ __launch_bounds__(64) void k_fwd_level_pair(GroupDev g, int col0, int chunk0, int ny) {
+  const int lane = threadIdx.x;
+  const unsigned b = (unsigned)(((PP_CHUNK_OF_WG(ny) + chunk0) * 64 + lane) * 2);
+  const size_t bpad = (size_t)g.bpad;
+  const int* rec = g.fwd_rec + 4 * (size_t)(col0 + PP_TASK_OF_WG(ny));   // {column, original row, e0, e1}
+  const int c = rec[0], e0 = rec[2], e1 = rec[3];
+  const double* __restrict__ Lb = g.L + b;
+  const double* __restrict__ Z = g.Y + b;
+  const double* __restrict__ RN = g.rhsN ? g.rhsN + b : nullptr;
+  double s[2] = {0.0, 0.0};
+  for (int eb = e0; eb < e1; eb += 4) {
+    double u[4][2], z[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = min(eb + i, e1 - 1);
+      const int zc = g.sfwd_zcol[e];
+      ldv<2>(Lb + (size_t)g.sfwd_upos[e] * bpad, u[i]);
+      ldv<2>((zc >= 0) ? Z + (size_t)zc * bpad : RN + (size_t)(-1 - zc) * bpad, z[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (eb + i < e1) { s[0] += u[i][0] * z[i][0]; s[1] += u[i][1] * z[i][1]; }
+    }
+  }
+  double* yc = g.Y + (size_t)c * bpad + b;
+  double y0[2];
+  ldv<2>(RN ? RN + (size_t)rec[1] * bpad : yc, y0);
+  const double out[2] = {y0[0] - s[0], y0[1] - s[1]};
+  stv<2>(yc, out);
+}
+
+__global__ __launch_bounds__(64) void k_bwd_level_pair(GroupDev g, int col0, int chunk0, int ny, const double* __restrict__ xc) {
+  const int lane = threadIdx.x;
+  const unsigned b = (unsigned)(((PP_CHUNK_OF_WG(ny) + chunk0) * 64 + lane) * 2);
+  const size_t bpad = (size_t)g.bpad;
+  const int* rec = g.bwd_rec + 8 * (size_t)(col0 + PP_TASK_OF_WG(ny));   // {c, w, q, nr, rowptr, L base, doff, p0}
+  const int c = rec[0], w = rec[1], q = rec[2], nr = rec[3];
+  const int* ri = g.rowidx + rec[4];
+  const double* Lp = g.L + (size_t)rec[5] * bpad + b;   // column q of the rows below the block
+  const double* Xb = g.X + b;
+  const int n = g.n;
+  const size_t rstride = (size_t)w * bpad;
+  double z[2] = {0.0, 0.0};
+  {
+    const double* inv = g.Dinv + (size_t)rec[6] * bpad + b;
+    const int p0 = rec[7] >= 0 ? rec[7] : -1 - rec[7];
+    const double* Yp = g.Y + (size_t)p0 * bpad + b;
+#pragma unroll
+    for (int t = 0; t < PP_WMAX; ++t) {
+      if (t < w) {
+        const int hi = q > t ? q : t, lo = q > t ? t : q;
+        double yv[2], iv[2];
+        ldv<2>(rec[7] >= 0 ? Yp + (size_t)t * bpad : g.rhsN + (size_t)g.perm[p0 + t] * bpad + b, yv);
+        ldv<2>(inv + (size_t)(hi * (hi + 1) / 2 + lo) * bpad, iv);
+        z[0] += iv[0] * yv[0]; z[1] += iv[1] * yv[1];
+      }
+    }
+  }
+  double s[2] = {0.0, 0.0};
+  for (int jb = 0; jb < nr; jb += 4) {
+    double u[4][2], x[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = min(jb + i, nr - 1);
+      const int r = ri[j];
+      ldv<2>(Lp + (size_t)j * rstride, u[i]);
+      if (r < n) ldv<2>(Xb + (size_t)r * bpad, x[i]);
+      else {
+        x[i][0] = xc[(size_t)(r - n) * g.xs_row + (size_t)b * g.xs_lane];
+        x[i][1] = xc[(size_t)(r - n) * g.xs_row + (size_t)(b + 1) * g.xs_lane];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (jb + i < nr) { s[0] += u[i][0] * x[i][0]; s[1] += u[i][1] * x[i][1]; }
+    }
+  }
+  const double out[2] = {((int)b < g.batch) ? z[0] - s[0] : 0.0, ((int)b + 1 < g.batch) ? z[1] - s[1] : 0.0};
+  stv<2>(g.X + (size_t)c * bpad + b, out);
+}
+
 // coupling row c: rspart[chunk][c] = - sum over active instances and panels of L[c,k] y_k
 // (one wave per row: 200 rows x 16 chunks fill the chip, and a team of waves per row measured slower here)
 __global__ __launch_bounds__(64) void k_fwd_coupling(GroupDev g, double* __restrict__ rs_mapped) {
@@ -2279,6 +2393,7 @@ struct Group {
   std::vector<int> diag_can;     // canonical entry of the diagonal (i, i) of K, or -1
   std::vector<uint8_t> fwd_level_has_entries;   // forward-solve levels whose columns have any incoming entry
   std::vector<int> fwd_level_team, bwd_level_team;   // waves per row / column on each solve level (1, 4 or 16)
+  std::vector<int> fwd_level_maxrow, bwd_level_maxrow;   // longest row / column of the level (entries)
   int nraw_tiles = 0;            // number of input tiles with needed entries
   int nshift = 0;                // rows with a regularisation class (pp_set_diagonal_classes)
   int *shift_row = nullptr, *shift_cls = nullptr;   // device: transposed-input row of their diagonal entry, class
@@ -2934,6 +3049,8 @@ int pp_end_symbolic(pp_handle h) {
       auto team_of = [](int longest) { return longest > 96 ? 16 : longest > 32 ? 4 : 1; };
       g->fwd_level_team.assign((size_t)P.n_levels, 1);
       g->bwd_level_team.assign((size_t)P.n_levels, 1);
+      g->fwd_level_maxrow.assign((size_t)P.n_levels, 0);
+      g->bwd_level_maxrow.assign((size_t)P.n_levels, 0);
       for (int l = 0; l < P.n_levels; ++l) {
         int fmax = 0, bmax = 0;
         for (int q = P.clevel_ptr[l]; q < P.clevel_ptr[l + 1]; ++q) {
@@ -2943,6 +3060,8 @@ int pp_end_symbolic(pp_handle h) {
         }
         g->fwd_level_team[(size_t)l] = team_of(fmax);
         g->bwd_level_team[(size_t)l] = team_of(bmax);
+        g->fwd_level_maxrow[(size_t)l] = fmax;
+        g->bwd_level_maxrow[(size_t)l] = bmax;
       }
       if ((rc = dev_upload(h, g, &d.fwd_rec, frec))) return rc;
       if ((rc = dev_upload(h, g, &d.bwd_rec, brec))) return rc;
@@ -3244,10 +3363,14 @@ int pp_numeric_factor_blocks(pp_handle h) {
               if (pair) hipLaunchKernelGGL((k_gather_flat<WM, PP_QUAD, 2>), dim3((unsigned)(nt / PP_QUAD) * (ny / 2)), dim3(64 * PP_QUAD), 0, fan[q], d, t0, sp.c0[q] / 2, ny / 2, PIVOT_EPS); \
               else hipLaunchKernelGGL((k_gather_flat<WM, PP_QUAD, 1>), dim3((unsigned)(nt / PP_QUAD) * ny), dim3(64 * PP_QUAD), 0, fan[q], d, t0, sp.c0[q], ny, PIVOT_EPS); } while (0)
             if (lean) {
-              if (mw == 1) PP_LAUNCH_GATHER(k_gather_level_lean, 1);
-              else if (mw == 2) PP_LAUNCH_GATHER(k_gather_level_lean, 2);
-              else if (mw <= 4) PP_LAUNCH_GATHER(k_gather_level_lean, 4);
-              else PP_LAUNCH_GATHER(k_gather_level_lean, PP_WMAX);
+#define PP_LAUNCH_LEAN(WM) do { \
+              if (pair) hipLaunchKernelGGL((k_gather_level_lean<WM, 2>), dim3((unsigned)nt * (ny / 2)), dim3(64), 0, fan[q], d, t0, sp.c0[q] / 2, ny / 2, PIVOT_EPS); \
+              else hipLaunchKernelGGL((k_gather_level_lean<WM, 1>), dim3((unsigned)nt * ny), dim3(64), 0, fan[q], d, t0, sp.c0[q], ny, PIVOT_EPS); } while (0)
+              if (mw == 1) PP_LAUNCH_LEAN(1);
+              else if (mw == 2) PP_LAUNCH_LEAN(2);
+              else if (mw <= 4) PP_LAUNCH_LEAN(4);
+              else PP_LAUNCH_LEAN(PP_WMAX);
+#undef PP_LAUNCH_LEAN
             }
 #ifdef PP_X_OLD_GATHER
             else if (P.flevel_nsplit[l] == 0) {
@@ -3560,6 +3683,8 @@ int pp_solve_forward(pp_handle h) {
 #define PP_LAUNCH_FWD(NW) hipLaunchKernelGGL(k_fwd_level<NW>, dim3((unsigned)ncol * ny), dim3(64 * NW), 0, fan[q], dn, c0, sp.c0[q], ny)
           if (team == 16) PP_LAUNCH_FWD(16);
           else if (team == 4) PP_LAUNCH_FWD(4);
+          else if (h->lane_pairs && g->fwd_level_maxrow[(size_t)l] <= PP_PAIR_MAXROW && ny % 2 == 0 && sp.c0[q] % 2 == 0)
+            hipLaunchKernelGGL(k_fwd_level_pair, dim3((unsigned)ncol * (ny / 2)), dim3(64), 0, fan[q], dn, c0, sp.c0[q] / 2, ny / 2);
           else PP_LAUNCH_FWD(1);
 #undef PP_LAUNCH_FWD
         }
@@ -3717,6 +3842,8 @@ int pp_solve_backward(pp_handle h) {
 #define PP_LAUNCH_BWD(NW) hipLaunchKernelGGL(k_bwd_level<NW>, dim3((unsigned)ncol * ny), dim3(64 * NW), 0, fan[q], dn, c0, sp.c0[q], ny, xcp)
           if (team == 16) PP_LAUNCH_BWD(16);
           else if (team == 4) PP_LAUNCH_BWD(4);
+          else if (h->lane_pairs && g->bwd_level_maxrow[(size_t)l] <= PP_PAIR_MAXROW && ny % 2 == 0 && sp.c0[q] % 2 == 0)
+            hipLaunchKernelGGL(k_bwd_level_pair, dim3((unsigned)ncol * (ny / 2)), dim3(64), 0, fan[q], dn, c0, sp.c0[q] / 2, ny / 2, xcp);
           else PP_LAUNCH_BWD(1);
 #undef PP_LAUNCH_BWD
         }
