@@ -121,6 +121,24 @@ void ppsim_level_profile(void* h, int* out) {
   }
 }
 
+// per level (4 ints): most gather chunks (pieces counted) of one big panel, most rows of one gather chunk, big panels
+// with more than 4 / more than 8 gather chunks
+void ppsim_level_teams(void* h, int* out) {
+  Plan& P = *(Plan*)h;
+  for (int l = 0; l < P.n_levels; ++l) {
+    int* o = out + 4 * l;
+    o[0] = o[1] = o[2] = o[3] = 0;
+    std::vector<int> cnt(P.npiv, 0);
+    for (int t = P.flevel_ptr[l]; t < P.flevel_ptr[l + 1]; ++t) {
+      const auto& ft = P.ftasks[t];
+      if (ft.kind != 0) continue;
+      cnt[ft.piv]++;
+      o[1] = std::max(o[1], ft.r1 - ft.r0);
+    }
+    for (int p = 0; p < P.npiv; ++p) { o[0] = std::max(o[0], cnt[p]); o[2] += cnt[p] > 4; o[3] += cnt[p] > 8; }
+  }
+}
+
 namespace {
 // rows [r0, r1) of panel p: L = U inv(P)
 void scale_rows(const Plan& P, int p, int r0, int r1, const double* inv, const double* U, double* L) {

@@ -1,0 +1,52 @@
+#!/bin/bash
+# Run ON THE GPU BOX: everything profiles/<round>_final/ holds, into gpurun_out/<tag>/ (copy what is to be judged into profiles/).
+#   bench_default.json         python bench.py --steps 40            (with cpu_baseline and boundary_host)
+#   kernel_stats.csv, bench_under_rocprof.json    rocprofv3 --kernel-trace --stats of bench.py --steps 20
+#   pmc/*_per_kernel.csv, pmc_traffic.json        separate --pmc FETCH_SIZE / WRITE_SIZE passes
+#   bench_C2.json, bench_C4.json, kernel_stats_C4.csv, bench_128_blocks.json
+tag=${1:-final}
+out=gpurun_out/$tag
+mkdir -p $out/pmc
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+python3 bench.py --steps 40 > $out/bench_default.json 2> $out/bench_default.err || { tail -3 $out/bench_default.err; exit 1; }
+echo "default done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-boundary > $out/bench_under_rocprof.json 2> $out/stats.err || exit 1
+cp $(find $out/stats -name '*kernel_stats.csv' | head -1) $out/kernel_stats.csv
+echo "kernel stats done"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-boundary > $out/bench_fetch.json 2> $out/fetch.err || exit 1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python3 bench.py --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-boundary > $out/bench_write.json 2> $out/write.err || exit 1
+python3 - $out <<'PY'
+import csv, glob, json, os, sys
+sys.path.insert(0, 'tools')
+from pmc_summary import load
+out = sys.argv[1]
+for tag, counter in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
+    per = load(os.path.join(out, 'pmc_' + tag), counter)
+    with open(os.path.join(out, 'pmc', '%s_size_per_kernel.csv' % tag), 'w') as f:
+        w = csv.writer(f, quoting=csv.QUOTE_NONNUMERIC)
+        w.writerow(['Kernel_Name', 'Dispatches', counter + '_sum_KiB'])
+        for name, (v, n) in per.items():
+            w.writerow([name, n, round(v, 3)])
+d = json.loads(open(os.path.join(out, 'bench_fetch.json')).read().strip().splitlines()[-1])
+st = d['plan']
+open(os.path.join(out, 'plan_args.txt'), 'w').write('%d %d %d\n' % (st['raw_entries'], st['n'], d['config']['blocks_per_gpu']))
+PY
+read raw n batch < $out/plan_args.txt
+python3 tools/pmc_traffic.py $out/pmc_fetch $out/pmc_write $raw $n $batch $out/pmc_traffic.json "bench.py --steps 3 --profile-steps 1 under rocprofv3 --pmc (one pass per counter)" || exit 1
+echo "pmc done"
+python3 bench.py --workload C2 --no-cpu-baseline > $out/bench_C2.json 2> $out/c2.err
+python3 bench.py --blocks 128 --no-cpu-baseline --no-boundary > $out/bench_128_blocks.json 2> $out/b128.err
+python3 bench.py --workload C4 --no-cpu-baseline --steps 10 --warmup 2 > $out/bench_C4.json 2> $out/c4.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_C4 -- python3 bench.py --workload C4 --steps 5 --warmup 2 --no-cpu-baseline --no-boundary > $out/bench_C4_under_rocprof.json 2> $out/stats_C4.err && cp $(find $out/stats_C4 -name '*kernel_stats.csv' | head -1) $out/kernel_stats_C4.csv
+find $out -name '*kernel_trace.csv' -delete
+find $out -name '*counter_collection.csv' -delete
+rm -rf $out/stats $out/stats_C4 $out/pmc_fetch $out/pmc_write
+for f in bench_default bench_C2 bench_128_blocks bench_C4; do python3 - $out/$f.json <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print(sys.argv[1], d['value'], d['unit'], d['ms_per_step'], 'correct', d.get('correct'))
+except Exception as e:
+    print(sys.argv[1], 'FAILED', e)
+PY
+done

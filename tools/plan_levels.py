@@ -32,9 +32,12 @@ def main():
     nl = int(st[3])
     out = np.zeros(8 * nl, dtype=np.int32)
     L.ppsim_level_profile(sg.h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
-    print('level  fused  gather  split  scale  bigpanels  rows(sum)  rows(max)  maxent')
-    for lv, row in enumerate(out.reshape(nl, 8)):
-        print('%5d %6d %7d %6d %6d %10d %10d %10d %7d' % ((lv,) + tuple(int(v) for v in row)))
+    teams = np.zeros(4 * nl, dtype=np.int32)
+    L.ppsim_level_teams(sg.h, teams.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+    print('level  fused  gather  split  scale  bigpanels  rows(sum)  rows(max)  maxent | chunks/panel(max)  rows/chunk(max)  panels>4  panels>8')
+    for lv, (row, tm) in enumerate(zip(out.reshape(nl, 8), teams.reshape(nl, 4))):
+        print('%5d %6d %7d %6d %6d %10d %10d %10d %7d | %17d %16d %9d %9d' %
+              ((lv,) + tuple(int(v) for v in row) + tuple(int(v) for v in tm)))
 
 
 if __name__ == '__main__':
