@@ -1413,12 +1413,75 @@ __global__ void k_dense_finish(int n, const int* __restrict__ flags, int* __rest
 // back, that puts one global-store round trip (1-2 us) on the critical path of every barrier.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Broadcast inside a row of 16 lanes without leaving the vector unit: DP-ALU DPP (gfx90a+: 64-bit VOP1/VOP2 operations take
+// row_newbcast:K = "operand 0 comes from lane K of my row of 16").  One v_fmac_f64_dpp replaces two v_readlane_b32 + a
+// v_fma_f64 in the column updates of an in-register triangular factor / solve whose rows live one per lane (all four
+// rows of 16 lanes of the wave holding the same 16 matrix rows).  The s_nop covers the two wait states a DPP read needs
+// behind a VALU write of the same register (the hazard recogniser does not look into inline assembly).
+template <int K>
+__device__ __forceinline__ void fmac_row_bcast(double& acc, double from_lane_k, double mul) {      // acc += from_lane_k[K] * mul
+  asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+               : "+v"(acc) : "v"(from_lane_k), "v"(mul), "n"(K));
+}
+template <int K>
+__device__ __forceinline__ double mov_row_bcast(double from_lane_k) {
+  double r;
+  asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(from_lane_k), "n"(K));
+  return r;
+}
+// steps K.. of the unpivoted LDL^T of a 16 x 16 block, lane (mod 16) = row, row[] in registers (see k_ldl_regs (b))
+template <int K>
+struct DiagSteps {
+  static __device__ __forceinline__ void run(double (&row)[16], double& d, double& rd, int& bad, int& signs, int nb,
+                                             double eps_anorm, double anorm, double* dl, double* rdl, int lane) {
+    const double lik = row[K] * rd;
+    const double nlik = -lik;
+    double dn = 1.0, rdn = 1.0;
+    if constexpr (K + 1 < 16) {
+      fmac_row_bcast<K>(row[K + 1], row[K + 1], nlik);
+      dn = mov_row_bcast<K + 1>(row[K + 1]);
+      if (K + 1 < nb) {
+        if (!(fabs(dn) > eps_anorm)) { bad = 1; dn = (anorm > 0.0 ? anorm : 1.0); }
+        signs |= (dn > 0.0) ? 1 : 2;
+      } else {
+        dn = 1.0;
+      }
+      rdn = fast_rcp(dn);
+    }
+#pragma unroll
+    for (int j = K + 2; j < 16; ++j) fmac_row_bcast<K>(row[j], row[j], nlik);
+    row[K] = lik;
+    if (lane == 0) { dl[K] = d; rdl[K] = rd; }
+    d = dn; rd = rdn;
+    if constexpr (K + 1 < 16) DiagSteps<K + 1>::run(row, d, rd, bad, signs, nb, eps_anorm, anorm, dl, rdl, lane);
+  }
+};
+// W = A21 L11^{-T}, thread = row of A21 (wrow), L11 rows one per lane of every row of 16 lanes (lrow): column J
+template <int J, int K>
+struct PanelSolve {
+  static __device__ __forceinline__ void run(double (&wrow)[16], const double (&lrow)[16], double nwj) {
+    if constexpr (K < 16) {
+      fmac_row_bcast<K>(wrow[K], lrow[J], nwj);        // wrow[K] -= wrow[J] * L11[K][J]
+      PanelSolve<J, K + 1>::run(wrow, lrow, nwj);
+    }
+  }
+};
+template <int J>
+struct PanelSolveCols {
+  static __device__ __forceinline__ void run(double (&wrow)[16], const double (&lrow)[16]) {
+    if constexpr (J + 1 < 16) {
+      PanelSolve<J, J + 1>::run(wrow, lrow, -wrow[J]);
+      PanelSolveCols<J + 1>::run(wrow, lrow);
+    }
+  }
+};
+
 // Register-resident variant for n <= 16 * LDLR_NT (= 208; the reference configurations have n_c = 200):
 // the whole lower triangle lives in the MFMA accumulators of the 8 waves (91 tiles of 16x16, <= 12 per
 // wave) for the entire factorisation, so a trailing update is LDS reads + fp64 MFMAs only -- no global
 // read-modify-write round trips inside the panel loop.  Per 16-column panel (= one tile column): its
-// tiles go to LDS, wave 0 factors the 16x16 diagonal block in registers (column broadcasts through
-// LDS), one thread per row solves the panel against it, the finished columns are streamed to global
+// tiles go to LDS, wave 0 factors the 16x16 diagonal block in registers (column broadcasts inside the rows of 16
+// lanes by DP-ALU DPP, see fmac_row_bcast), one thread per row solves the panel against it, the finished columns are streamed to global
 // memory (stores only), and every wave updates the tiles it still owns.  Same acceptance rule and
 // output format as k_ldl_blocked.
 constexpr int LDLR_NT = 13;
@@ -1426,6 +1489,7 @@ constexpr int LDLR_TPW = 12;  // 8 waves * 12 >= 91 tiles
 constexpr int LDLR_NB = 16;
 constexpr int LDLR_LD = 18;   // LDS row stride in doubles: conflict-free MFMA operand reads
 
+template <bool DPP>
 __global__ __launch_bounds__(LDL_THREADS) void k_ldl_regs(int n, const double* __restrict__ S, const double* __restrict__ Q,
                                                           double* __restrict__ A, double* __restrict__ dvec,
                                                           int* __restrict__ mode, int* __restrict__ info, double eps) {
@@ -1501,10 +1565,13 @@ __global__ __launch_bounds__(LDL_THREADS) void k_ldl_regs(int n, const double* _
 #pragma unroll
       for (int j = 0; j < LDLR_NB; ++j) row[j] = P[i][j];
       int bad = 0, signs = 0;
-      double d = bcastd(row[0], 0);
+      double d = DPP ? mov_row_bcast<0>(row[0]) : bcastd(row[0], 0);
       if (!(fabs(d) > eps * anorm)) { bad = 1; d = (anorm > 0.0 ? anorm : 1.0); }
       signs |= (d > 0.0) ? 1 : 2;
       double rd = fast_rcp(d);
+      if constexpr (DPP) {
+        DiagSteps<0>::run(row, d, rd, bad, signs, nb, eps * anorm, anorm, dl, rdl, lane);
+      } else {
 #pragma unroll
       for (int k = 0; k < LDLR_NB; ++k) {
         // column k of the current block, element j, is A[j][k] = A[k][j]: lane k holds it as row[j] (the strict
@@ -1528,6 +1595,7 @@ __global__ __launch_bounds__(LDL_THREADS) void k_ldl_regs(int n, const double* _
         if (lane == 0) { dl[k] = d; rdl[k] = rd; }
         d = dn; rd = rdn;
       }
+      }
       if (lane < nb) {
 #pragma unroll
         for (int j = 0; j < LDLR_NB; ++j) P[lane][j] = row[j];
@@ -1550,10 +1618,14 @@ __global__ __launch_bounds__(LDL_THREADS) void k_ldl_regs(int n, const double* _
 #pragma unroll
       for (int k = 0; k < LDLR_NB; ++k) { lrow[k] = P[lane & 15][k]; wrow[k] = P[r][k]; }
       // right-looking order: the updates of one step are independent of each other, only 16 steps are chained
+      if constexpr (DPP) {
+        PanelSolveCols<0>::run(wrow, lrow);
+      } else {
 #pragma unroll
-      for (int j = 0; j + 1 < LDLR_NB; ++j) {
+        for (int j = 0; j + 1 < LDLR_NB; ++j) {
 #pragma unroll
-        for (int k = j + 1; k < LDLR_NB; ++k) wrow[k] -= wrow[j] * bcastd_after(lrow[j], k, wrow[j]);
+          for (int k = j + 1; k < LDLR_NB; ++k) wrow[k] -= wrow[j] * bcastd_after(lrow[j], k, wrow[j]);
+        }
       }
       if (tid < m) {
 #pragma unroll
@@ -2449,6 +2521,7 @@ struct pp_solver {
   bool growth_fatal = false;     // flagged instances make the factorisation report status 2 (else they are only counted)
   double pivot_threshold = 0.0;  // symbolic-time threshold u for groups added afterwards (0: plan default)
   bool no_fused_sources = std::getenv("PP_NO_FUSED_SOURCES") != nullptr;   // measurement switch: assemble the sources first
+  bool dense_dpp = std::getenv("PP_NO_DENSE_DPP") == nullptr;           // row broadcasts by DP-ALU DPP in k_ldl_regs (measurement switch)
   bool lane_pairs = std::getenv("PP_NO_LANE_PAIRS") == nullptr;   // two instances per lane in the gather kernels (measurement switch)
   double shift_w = 0.0, shift_c = 0.0;   // diagonal shifts of the current pp_numeric_local_shifted call (else 0)
   double mem_factor = 1.0;
@@ -3558,7 +3631,9 @@ int pp_factor_schur(pp_handle h, const double* Q_host) {
       // (a left-looking variant with the panel resident in LDS was measured no faster: 0.344 vs 0.315 ms at
       // n_c = 200 -- the serial diagonal-block factor dominates both)
       if (nc <= 16 * LDLR_NT) {
-        hipLaunchKernelGGL(k_ldl_regs, dim3(1), dim3(LDL_THREADS), 0, st, nc, h->S, Qd, h->Sldl, h->dvec, h->dense_mode, h->bkinfo,
+        if (h->dense_dpp) hipLaunchKernelGGL(k_ldl_regs<true>, dim3(1), dim3(LDL_THREADS), 0, st, nc, h->S, Qd, h->Sldl, h->dvec, h->dense_mode, h->bkinfo,
+                           BK_EPS);
+        else hipLaunchKernelGGL(k_ldl_regs<false>, dim3(1), dim3(LDL_THREADS), 0, st, nc, h->S, Qd, h->Sldl, h->dvec, h->dense_mode, h->bkinfo,
                            BK_EPS);
       } else if (nc <= 512) {
         hipLaunchKernelGGL(k_ldl_blocked, dim3(1), dim3(LDL_THREADS), 0, st, nc, h->Sldl, h->dvec, h->dense_mode, h->bkinfo,
