@@ -2521,6 +2521,7 @@ struct pp_solver {
   bool growth_fatal = false;     // flagged instances make the factorisation report status 2 (else they are only counted)
   double pivot_threshold = 0.0;  // symbolic-time threshold u for groups added afterwards (0: plan default)
   bool no_fused_sources = std::getenv("PP_NO_FUSED_SOURCES") != nullptr;   // measurement switch: assemble the sources first
+  bool group_streams = std::getenv("PP_NO_GROUP_STREAMS") == nullptr;   // pattern groups side by side on streams of their own (measurement switch)
   bool dense_dpp = std::getenv("PP_NO_DENSE_DPP") == nullptr;           // row broadcasts by DP-ALU DPP in k_ldl_regs (measurement switch)
   bool lane_pairs = std::getenv("PP_NO_LANE_PAIRS") == nullptr;   // two instances per lane in the gather kernels (measurement switch)
   double shift_w = 0.0, shift_c = 0.0;   // diagonal shifts of the current pp_numeric_local_shifted call (else 0)
@@ -2647,17 +2648,54 @@ Splits make_splits(pp_handle h, int nchunk) {
 }
 
 // fork the handle's stream into sp.n streams (stream 0 of the fan is the handle's own stream)
-int fork_streams(pp_handle h, const Splits& sp, hipStream_t* out) {
-  out[0] = h->stream;
-  if (sp.n == 1) return 0;
-  if (!h->aux_made) {
-    for (int i = 0; i < PP_MAX_SPLIT; ++i) {
-      if (hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking) != hipSuccess) return 3;
-      if (hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming) != hipSuccess) return 3;
-    }
-    if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) return 3;
-    h->aux_made = true;
+int make_aux_streams(pp_handle h) {
+  if (h->aux_made) return 0;
+  for (int i = 0; i < PP_MAX_SPLIT; ++i) {
+    if (hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking) != hipSuccess) return 3;
+    if (hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming) != hipSuccess) return 3;
   }
+  if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) return 3;
+  h->aux_made = true;
+  return 0;
+}
+
+// Pattern groups are independent of each other until their results meet (S, r_s): with more than one group, group gi
+// runs on stream gi mod PP_MAX_SPLIT of the handle's auxiliary streams (group 0 on the handle's own), so that the
+// launch chain of a small group -- a single block is 1/64 of one wave per task, but as many launches as a full group --
+// hides beside the others instead of in front of them.  Not while profiling (the phase brackets sit on the handle's
+// stream) and not together with instance splits.
+struct GroupStreams {
+  int n = 1;                       // streams in use (1: everything on the handle's stream)
+  hipStream_t st[PP_MAX_SPLIT];
+};
+
+int fork_group_streams(pp_handle h, GroupStreams& gs) {
+  gs.n = 1;
+  gs.st[0] = h->stream;
+  const int want = (int)std::min<size_t>(h->groups.size(), (size_t)PP_MAX_SPLIT);
+  if (want <= 1 || h->profile || h->nsplit_req > 1 || !h->group_streams) return 0;
+  if (make_aux_streams(h)) return 3;
+  if (hipEventRecord(h->ev_fork, h->stream) != hipSuccess) return 3;
+  for (int i = 1; i < want; ++i) {
+    gs.st[i] = h->aux[i];
+    if (hipStreamWaitEvent(gs.st[i], h->ev_fork, 0) != hipSuccess) return 3;
+  }
+  gs.n = want;
+  return 0;
+}
+
+int join_group_streams(pp_handle h, const GroupStreams& gs) {
+  for (int i = 1; i < gs.n; ++i) {
+    if (hipEventRecord(h->ev_join[i], gs.st[i]) != hipSuccess) return 3;
+    if (hipStreamWaitEvent(h->stream, h->ev_join[i], 0) != hipSuccess) return 3;
+  }
+  return 0;
+}
+
+int fork_streams(pp_handle h, const Splits& sp, hipStream_t* out, hipStream_t base) {
+  out[0] = base;
+  if (sp.n == 1) return 0;
+  if (make_aux_streams(h)) return 3;
   if (hipEventRecord(h->ev_fork, h->stream) != hipSuccess) return 3;
   for (int i = 1; i < sp.n; ++i) {
     out[i] = h->aux[i];
@@ -3369,8 +3407,11 @@ int pp_numeric_factor_blocks(pp_handle h) {
   if (!h || !h->symbolic_done) return fail(h, 3, "pp_numeric_factor_blocks before symbolic factorization");
   PP_HIP(hipSetDevice(h->device));
   if (int rc = alloc_value_storage(h)) return rc;
-  hipStream_t st = h->stream;
-  for (Group* g : h->groups) {
+  GroupStreams gst;
+  if (fork_group_streams(h, gst)) return fail(h, 3, "stream fork failed");
+  for (size_t gi = 0; gi < h->groups.size(); ++gi) {
+    Group* g = h->groups[gi];
+    const hipStream_t st = gst.st[gi % (size_t)gst.n];
     const pp::Plan& P = g->plan;
     GroupDev& d0 = g->dev;
     bool fused_sources = false;
@@ -3412,7 +3453,7 @@ int pp_numeric_factor_blocks(pp_handle h) {
       PhaseScope ps(h, 1, nlaunch);
       const Splits sp = make_splits(h, d.nchunk);
       hipStream_t fan[PP_MAX_SPLIT];
-      if (fork_streams(h, sp, fan)) return fail(h, 3, "stream fork failed");
+      if (fork_streams(h, sp, fan, st)) return fail(h, 3, "stream fork failed");
       for (int l = 0; l < P.n_levels; ++l) {
         const int t0 = P.flevel_ptr[l], nt = P.flevel_ptr[l + 1] - t0;
         const int s0 = P.slevel_ptr[l], ns = P.slevel_ptr[l + 1] - s0;
@@ -3486,6 +3527,7 @@ int pp_numeric_factor_blocks(pp_handle h) {
       if (join_streams(h, sp, fan)) return fail(h, 3, "stream join failed");
     }
   }
+  if (join_group_streams(h, gst)) return fail(h, 3, "stream join failed");
   PP_HIP(hipGetLastError());
   h->blocks_factored = true;
   h->numeric_done = false;
@@ -3727,7 +3769,11 @@ int pp_solve_forward(pp_handle h) {
   hipStream_t st = h->stream;
   const int nc = h->nc;
   PP_HIP(hipMemsetAsync(h->rs, 0, std::max<size_t>(nc, 1) * sizeof(double), st));
-  for (Group* g : h->groups) {
+  GroupStreams gst;
+  if (fork_group_streams(h, gst)) return fail(h, 3, "stream fork failed");
+  for (size_t gi = 0; gi < h->groups.size(); ++gi) {
+    Group* g = h->groups[gi];
+    const hipStream_t st = gst.st[gi % (size_t)gst.n];
     const pp::Plan& P = g->plan;
     GroupDev& d = g->dev;
     const bool native = g->rhs_native != nullptr;
@@ -3748,7 +3794,7 @@ int pp_solve_forward(pp_handle h) {
       // per-level launches: 16 waves on one CU serialise their memory round trips)
       const Splits sp = make_splits(h, d.nchunk);
       hipStream_t fan[PP_MAX_SPLIT];
-      if (fork_streams(h, sp, fan)) return fail(h, 3, "stream fork failed");
+      if (fork_streams(h, sp, fan, st)) return fail(h, 3, "stream fork failed");
       for (int l = 0; l < P.n_levels; ++l) {
         const int c0 = P.clevel_ptr[l], ncol = P.clevel_ptr[l + 1] - c0;
         if (ncol <= 0 || !g->fwd_level_has_entries[(size_t)l]) continue;
@@ -3766,10 +3812,17 @@ int pp_solve_forward(pp_handle h) {
       }
       if (join_streams(h, sp, fan)) return fail(h, 3, "stream join failed");
     }
+  }
+  if (join_group_streams(h, gst)) return fail(h, 3, "stream join failed");
+  // the coupling rows of the groups meet in r_s: one after the other on the handle's stream
+  for (Group* g : h->groups) {
+    GroupDev& d = g->dev;
+    GroupDev dn = d;
+    if (g->rhs_native != nullptr) { dn.rhsN = g->rhs_native; dn.sfwd_zcol = g->zcolN_f; dn.crow_zcol = g->zcolN_c; }
     if (d.nc > 0) {
       PhaseScope ps(h, 5, 2);
-      hipLaunchKernelGGL(k_fwd_coupling, dim3((unsigned)d.nc * d.nchunk), dim3(64), 0, st, dn, h->rs);
-      if (!d.cmapT) hipLaunchKernelGGL(k_rs_reduce, dim3((d.nc + 255) / 256), dim3(256), 0, st, d, h->rs);
+      hipLaunchKernelGGL(k_fwd_coupling, dim3((unsigned)d.nc * d.nchunk), dim3(64), 0, h->stream, dn, h->rs);
+      if (!d.cmapT) hipLaunchKernelGGL(k_rs_reduce, dim3((d.nc + 255) / 256), dim3(256), 0, h->stream, d, h->rs);
     }
   }
   PP_HIP(hipGetLastError());
@@ -3889,8 +3942,11 @@ int pp_bind_native_vectors(pp_handle h, int group, const double* rhs_dev, double
 int pp_solve_backward(pp_handle h) {
   if (!h || !h->schur_done) return fail(h, 3, "pp_solve_backward before pp_factor_schur");
   PP_HIP(hipSetDevice(h->device));
-  hipStream_t st = h->stream;
-  for (Group* g : h->groups) {
+  GroupStreams gst;
+  if (fork_group_streams(h, gst)) return fail(h, 3, "stream fork failed");
+  for (size_t gi = 0; gi < h->groups.size(); ++gi) {
+    Group* g = h->groups[gi];
+    const hipStream_t st = gst.st[gi % (size_t)gst.n];
     const pp::Plan& P = g->plan;
     GroupDev& d = g->dev;
     const bool native = g->x_native != nullptr;
@@ -3907,7 +3963,7 @@ int pp_solve_backward(pp_handle h) {
     {
       const Splits sp = make_splits(h, d.nchunk);
       hipStream_t fan[PP_MAX_SPLIT];
-      if (fork_streams(h, sp, fan)) return fail(h, 3, "stream fork failed");
+      if (fork_streams(h, sp, fan, st)) return fail(h, 3, "stream fork failed");
       for (int l = P.n_levels - 1; l >= 0; --l) {
         const int c0 = P.clevel_ptr[l], ncol = P.clevel_ptr[l + 1] - c0;
         if (ncol <= 0) continue;
@@ -3929,6 +3985,7 @@ int pp_solve_backward(pp_handle h) {
       hipLaunchKernelGGL(k_transpose_out, dim3((unsigned)((P.n + 63) / 64) * d.nchunk), dim3(256), 0, st, d.X, d.iperm, d.xout,
                          d.batch, P.n, d.bpad);
   }
+  if (join_group_streams(h, gst)) return fail(h, 3, "stream join failed");
   PP_HIP(hipGetLastError());
   return 0;
 }
