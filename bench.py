@@ -288,6 +288,7 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = args.steps / elapsed
     median_ms = 1e3 * float(np.median(np.diff(stamps)))
+    mem_max, _, mem_now = eng.memory_info()        # value storage: what the plan needs at most / what this path allocated
 
     # correctness of the last timed step: download and check against the assembled system
     k_last = (args.warmup + args.steps - 1) % nsets
@@ -426,6 +427,7 @@ def main():
             'symbolic_s': t_symbolic,
             'boundary_host': boundary,
             'device_only': device_only,
+            'value_storage_bytes': {'device_resident_path': mem_now, 'with_host_input_and_output_copies': mem_max},
         }
         print(json.dumps(out))
     if world > 1:

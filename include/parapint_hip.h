@@ -214,7 +214,9 @@ int pp_get_coupling_solution(pp_handle h, double* xc_host);
  * and pp_upload_values / pp_numeric_local return 1 (not_enough_memory) without allocating anything, until the caller
  * has raised the budget.  A real hipErrorOutOfMemory maps to the same status and leaves nothing allocated, so a retry
  * after memory has been freed elsewhere works the same way.
- * pp_memory_info: out = {bytes the plan needs, effective budget (0 = none), 1 if the storage is allocated}. */
+ * pp_memory_info: out = {bytes the plan needs at most, effective budget (0 = none), bytes allocated now (0: nothing yet)}:
+ * the [instance][entry] input copy, its transposed form and the [instance][row] copies of right-hand side and solution
+ * are allocated at first use by the input / output forms that need them (host values, host vectors). */
 int pp_increase_memory_allocation(pp_handle h, double factor);
 int pp_set_memory_budget(pp_handle h, int64_t bytes);
 int pp_memory_info(pp_handle h, int64_t out[3]);

@@ -438,12 +438,12 @@ class HipEngine(object):
         self.ns.check(self.lib.pp_set_memory_budget(self.ns.h, int(nbytes)), 'pp_set_memory_budget')
 
     def memory_info(self):
-        """(bytes of device value storage the plan needs, effective budget or 0, allocated?)"""
+        """(bytes of device value storage the plan needs at most, effective budget or 0, bytes allocated now)"""
         import ctypes
         out = np.zeros(3, dtype=np.int64)
         self.ns.check(self.lib.pp_memory_info(self.ns.h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))),
                       'pp_memory_info')
-        return int(out[0]), int(out[1]), bool(out[2])
+        return int(out[0]), int(out[1]), int(out[2])
 
     def allreduce_schur(self, comm):
         if comm.size > 1 or getattr(comm, 'always_reduce', False):
