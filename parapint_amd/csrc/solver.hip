@@ -2774,8 +2774,10 @@ int64_t value_storage_bytes(pp_handle h) {
     const pp::Plan& P = g->plan;
     const GroupDev& d = g->dev;
     const int64_t bp = d.bpad;
+    // (the term magnitudes of the pivot blocks live in the rows of Y: written and read inside the factorisation, Y
+    // only inside a solve)
     int64_t dbl = (int64_t)g->batch * g->nraw + (int64_t)std::max(g->nraw_used, 1) * bp + 2 * P.usize * bp +
-                  (int64_t)P.dsize * bp + (int64_t)std::max(P.bsize, 1) * bp + (int64_t)(P.n + g->nc_loc) * bp +
+                  (int64_t)P.dsize * bp + (int64_t)std::max(P.n + g->nc_loc, std::max(P.bsize, 1)) * bp +
                   (int64_t)P.n * bp + 2 * (int64_t)g->batch * P.n + (int64_t)d.nchunk * std::max(g->ntiles, 1) * 64 +
                   (int64_t)d.nchunk * std::max(g->nc_loc, 1) +
                   (g->cmap_host.empty() ? 0 : ((int64_t)std::max(g->ntiles, 1) * 64 + std::max(g->nc_loc, 1)) * bp);
@@ -2834,9 +2836,8 @@ int alloc_value_storage(pp_handle h) {
     if ((rc = value_alloc(h, g, &d.L, (size_t)P.usize * bp))) break;
     // the pivot-block slots of L are never written (only the rows below the block are): define them once
     if (hipMemset(d.L, 0, (size_t)P.usize * bp * sizeof(double)) != hipSuccess) { rc = fail(h, 3, "hipMemset failed"); break; }
-    if ((rc = value_alloc(h, g, &d.Tm, (size_t)std::max(P.bsize, 1) * bp))) break;
-    if ((rc = value_alloc(h, g, &d.Y, (size_t)(P.n + nc) * bp))) break;
-    if ((rc = value_alloc(h, g, &d.X, (size_t)P.n * bp))) break;
+    if ((rc = value_alloc(h, g, &d.Y, (size_t)std::max(P.n + nc, std::max(P.bsize, 1)) * bp))) break;
+    d.Tm = d.Y;     // term magnitudes of the pivot blocks (gather -> scale of one level) share the rows of the solve vector
     double* keep_x = (d.xout && d.xout != g->xout_own) ? d.xout : nullptr;
     d.xout = keep_x;
     if ((rc = value_alloc(h, g, &d.Spart, (size_t)d.nchunk * std::max(g->ntiles, 1) * 64))) break;
@@ -2862,7 +2863,7 @@ int alloc_value_storage(pp_handle h) {
 }
 
 // The buffers only some input / output forms need (see alloc_value_storage); `which` is a mask.
-enum { OPT_RAW = 1, OPT_RAWT = 2, OPT_RHS = 4, OPT_XOUT = 8 };
+enum { OPT_RAW = 1, OPT_RAWT = 2, OPT_RHS = 4, OPT_XOUT = 8, OPT_X = 16 };
 int ensure_optional(pp_handle h, Group* g, int which) {
   if (int rc = alloc_value_storage(h)) return rc;
   GroupDev& d = g->dev;
@@ -2879,6 +2880,9 @@ int ensure_optional(pp_handle h, Group* g, int which) {
   if ((which & OPT_RHS) && !g->rhs_own) {
     if ((rc = value_alloc(h, g, &g->rhs_own, (size_t)g->batch * P.n))) return rc;
     if (!d.rhs) d.rhs = g->rhs_own;
+  }
+  if ((which & OPT_X) && !d.X) {
+    if ((rc = value_alloc(h, g, &d.X, (size_t)P.n * (size_t)d.bpad))) return rc;
   }
   if ((which & OPT_XOUT) && !g->xout_own) {
     if ((rc = value_alloc(h, g, &g->xout_own, (size_t)g->batch * P.n))) return rc;
@@ -3989,7 +3993,7 @@ int pp_solve_backward(pp_handle h) {
     const pp::Plan& P = g->plan;
     GroupDev& d = g->dev;
     const bool native = g->x_native != nullptr;
-    if (!native && !d.xout) { if (int rc = ensure_optional(h, g, OPT_XOUT)) return rc; }
+    if (!native && (!d.xout || !d.X)) { if (int rc = ensure_optional(h, g, (d.xout ? 0 : OPT_XOUT) | OPT_X)) return rc; }
     int nlb = native ? 0 : 1;
     for (int l = 0; l < P.n_levels; ++l) nlb += P.clevel_ptr[l + 1] > P.clevel_ptr[l];
     PhaseScope ps(h, 7, nlb + ((d.cmapT && d.nc > 0) ? 1 : 0));
@@ -4156,6 +4160,7 @@ int pp_memory_info(pp_handle h, int64_t out[3]) {
       if (!g->rawT_own) allocated -= 8 * (int64_t)std::max(g->nraw_used, 1) * bp;
       if (!g->rhs_own) allocated -= 8 * (int64_t)g->batch * g->plan.n;
       if (!g->xout_own) allocated -= 8 * (int64_t)g->batch * g->plan.n;
+      if (!g->dev.X) allocated -= 8 * (int64_t)g->plan.n * bp;
     }
   }
   out[2] = allocated;
