@@ -5,7 +5,8 @@ from parapint_amd.linalg.comm import SerialComm
 from parapint_amd.linalg.hip_schur_complement import HipSchurComplementLinearSolver
 comm = SerialComm()
 for shape in [(1, 10, 2, 1), (1, 5, 2, 5), (2, 7, 3, 7), (65, 10, 2, 2), (129, 12, 2, 3), (64, 30, 5, 17), (5, 300, 2, 208),
-              (3, 300, 2, 209), (2, 600, 2, 513)]:
+              (3, 300, 2, 209), (2, 600, 2, 513), (128, 40, 3, 9), (191, 25, 2, 6), (193, 25, 4, 16), (256, 60, 3, 33),
+              (320, 20, 2, 5)]:      # (odd and even chunk counts: one and two instances per lane)
     N = shape[0]
     model = SyntheticKKT(*shape)
     solver = HipSchurComplementLinearSolver({i: None for i in range(N)}, None, comm=comm)
