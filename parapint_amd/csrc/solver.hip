@@ -2185,8 +2185,8 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_level(GroupDev g, int col0, int
 }
 
 // The wide bottom levels with two instances per lane (chunks of 128 instances, 16-byte accesses): short rows only
-// (the callers use it on levels whose longest row has at most PP_PAIR_MAXROW entries; one wave per row, no team).
-constexpr int PP_PAIR_MAXROW = 8;
+// (the callers use it on levels whose longest row or column has at most PP_PAIR_MAXROW entries; one wave per row, no team).
+constexpr int PP_PAIR_MAXROW = 16;   // (8: backward sweep 0.194 ms, 16: 0.169, 32: 0.177 at C3)
 __global__ __launch_bounds__(64) void k_fwd_level_pair(GroupDev g, int col0, int chunk0, int ny) {
   const int lane = threadIdx.x;
   const unsigned b = (unsigned)(((PP_CHUNK_OF_WG(ny) + chunk0) * 64 + lane) * 2);
