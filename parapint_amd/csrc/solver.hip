@@ -16,7 +16,9 @@
 //   k_bwd_level                   back substitution with x_c            (mpi_...:393-396)
 #include <hip/hip_runtime.h>
 
+#include <array>
 #include <chrono>
+#include <map>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -31,7 +33,9 @@
 namespace {
 
 constexpr int WAVE = 64;
+typedef double double4_t __attribute__((ext_vector_type(4)));   // accumulator of v_mfma_f64_16x16x4
 constexpr int PP_MAX_SPLIT = 8;
+constexpr int PP_MT_SLICE = 4;  // records (panel columns) of one 16 x 16 Schur tile per work item of k_schur_mfma
 constexpr int PP_CSLOTS = 64;  // the inertia / growth counters are kept in this many slots of 4 ints, summed by the tail writer
 constexpr int PP_TAIL = 8;    // doubles behind the n_c x n_c Schur block: zero pivots, pos, neg, host failures, growth, reserved
 constexpr int PP_NPHASE = 8;  // assemble, factor, schur, dense, fwd, fwd_coupling, coupling_solve, bwd
@@ -52,6 +56,8 @@ struct GroupDev {
   const int *fwd_rec, *bwd_rec;   // per scheduled column, in level order: everything its solve task needs (one scalar read)
   const int *crow_eptr, *crow_upos, *crow_zcol;
   const int *stile_a, *stile_b, *stile_ptr, *stile_rec;
+  const int *mt_a, *mt_b, *mt_rec;   // 16 x 16 tiles of S for the MFMA form of the Schur update (unmapped groups): records of 32 row positions
+  const int *mt_item, *mt_wptr;      // work items {first record, end} (slices of one tile's records), per tile its range of items
   double *raw, *rawT, *U, *L, *Dinv, *Tm, *Y, *X, *rhs, *xout, *Spart, *rspart;
   unsigned short* codes;
   const double* rhsN;   // right-hand sides in the native [row][instance] layout (caller order), or null: Y was filled by the transposition
@@ -884,6 +890,44 @@ __global__ void k_publish_status(const double* __restrict__ tail, const int* __r
 }
 
 // ------------------------------------------------------------------------------------------
+// Inertia codes and growth flags of the group, counted by `ncb` 64-thread workgroups (this is workgroup `cb` of them) into
+// the slotted counters; runs in front of the Schur tile workgroups of the same launch.
+__device__ __forceinline__ void count_codes_block(const GroupDev& g, unsigned cb, unsigned ncb, size_t total8, int* counters, int lane) {
+  int cnt[4] = {0, 0, 0, 0};     // pos, neg, zero, growth
+  if (cb == 0) {
+    int* growth_seen = g.growth + g.bpad;
+    for (int i = lane; i < g.batch; i += 64) {
+      const int f = g.growth[i];
+      cnt[3] += f != 0;
+      growth_seen[i] = f;
+      if (f) g.growth[i] = 0;
+    }
+  }
+  const uint4* c4 = reinterpret_cast<const uint4*>(g.codes);
+  const size_t stride = (size_t)ncb * 64;
+  for (size_t i = (size_t)cb * 64 + lane; i < total8; i += 4 * stride) {
+    uint4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = (i + u * stride < total8) ? c4[i + u * stride] : make_uint4(0, 0, 0, 0);   // in flight together
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned int wds[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned int x = wds[q];
+        cnt[0] += (int)((x & 15u) + ((x >> 16) & 15u));
+        cnt[1] += (int)(((x >> 4) & 15u) + ((x >> 20) & 15u));
+        cnt[2] += (int)(((x >> 8) & 15u) + ((x >> 24) & 15u));
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    for (int off = 32; off > 0; off >>= 1) cnt[q] += __shfl_xor(cnt[q], off);
+    if (lane == 0 && cnt[q] != 0) atomicAdd(&counters[4 * (cb % PP_CSLOTS) + q], cnt[q]);   // (slots: same-address atomics serialise, ~12 ns each)
+  }
+}
+
 // Schur tile: half of an 8x8 tile (8 rows x 4 columns, blockIdx.z selects the column half) in
 // registers over all panels holding rows of both tile ranges, then summed over the 64 instances of
 // the wave through LDS.  Two waves per tile halve the register footprint (4 waves/SIMD).
@@ -895,40 +939,7 @@ __global__ __launch_bounds__(64) void k_schur_tiles(GroupDev g, int ntile_all, s
   const unsigned ncb = gridDim.x - (unsigned)(ntile_all * g.nchunk);    // counting workgroups come first in the grid
   if (blockIdx.x < ncb) {
     if (blockIdx.z != 0) return;
-    const unsigned cb = blockIdx.x;
-    int cnt[4] = {0, 0, 0, 0};     // pos, neg, zero, growth
-    if (cb == 0) {
-      int* growth_seen = g.growth + g.bpad;
-      for (int i = lane; i < g.batch; i += 64) {
-        const int f = g.growth[i];
-        cnt[3] += f != 0;
-        growth_seen[i] = f;
-        if (f) g.growth[i] = 0;
-      }
-    }
-    const uint4* c4 = reinterpret_cast<const uint4*>(g.codes);
-    const size_t stride = (size_t)ncb * 64;
-    for (size_t i = (size_t)cb * 64 + lane; i < total8; i += 4 * stride) {
-      uint4 v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = (i + u * stride < total8) ? c4[i + u * stride] : make_uint4(0, 0, 0, 0);   // in flight together
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const unsigned int wds[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const unsigned int x = wds[q];
-          cnt[0] += (int)((x & 15u) + ((x >> 16) & 15u));
-          cnt[1] += (int)(((x >> 4) & 15u) + ((x >> 20) & 15u));
-          cnt[2] += (int)(((x >> 8) & 15u) + ((x >> 24) & 15u));
-        }
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      for (int off = 32; off > 0; off >>= 1) cnt[q] += __shfl_xor(cnt[q], off);
-      if (lane == 0 && cnt[q] != 0) atomicAdd(&counters[4 * (cb % PP_CSLOTS) + q], cnt[q]);   // (slots: same-address atomics serialise, ~12 ns each)
-    }
+    count_codes_block(g, blockIdx.x, ncb, total8, counters, lane);
     return;
   }
   const unsigned wg = blockIdx.x - ncb;
@@ -1033,6 +1044,120 @@ __global__ __launch_bounds__(64) void k_schur_reduce(GroupDev g, int ntiles, dou
   }
 }
 
+// MFMA form of the Schur update for unmapped groups (round 2).  S = - sum over panel columns and INSTANCES of
+// (coupling part of the L column)(coupling part of the U column)^T: the instance index is a genuine GEMM K dimension
+// -- every operand row is a contiguous [instance] vector -- so a 16 x 16 tile of S over one panel column and the 64
+// instances of a chunk is 16 v_mfma_f64_16x16x4 with K = 4 instances each.  Lane (li, lk) feeds row li of the tile's row
+// (A, from L) and column (B, from U) ranges with the instances 16 lk .. 16 lk + 15 of the chunk (any assignment of
+// instances to K slots is fine as long as A and B agree): 128 contiguous bytes per lane and operand, eight 16-byte
+// loads, and a wave reads each 512-byte row of the chunk exactly once.  Against the register-tile kernel (k_schur_tiles:
+// 12 loads of 8 bytes per lane for 32 multiply-adds) that is a third of the operand traffic per multiply-add and a
+// tenth of the instructions.  Records: per (tile, panel column) the 16 + 16 row positions, -1 where the panel has no row.
+// nsplit waves share the records of a tile; partial tiles go to Spart [chunk][tile][split][256] and are added in fixed order
+// by k_schur_reduce_mfma (deterministic, no atomics).
+__global__ __launch_bounds__(64) void k_schur_mfma(GroupDev g, int nwork_items, size_t total8, int* counters) {
+  const int lane = threadIdx.x;
+  const unsigned nwork = (unsigned)(nwork_items * g.nchunk);
+  const unsigned ncb = gridDim.x - nwork;                                // counting workgroups come first in the grid
+  if (blockIdx.x < ncb) { count_codes_block(g, blockIdx.x, ncb, total8, counters, lane); return; }
+  const unsigned wg = blockIdx.x - ncb;
+  const int chunk = (int)(wg % (unsigned)g.nchunk);
+  const int item = (int)(wg / (unsigned)g.nchunk);       // a slice of at most PP_MT_SLICE records of one tile
+  const int li = lane & 15, lk = lane >> 4;
+  const size_t bpad = (size_t)g.bpad;
+  const int ra = g.mt_item[2 * item], rb = g.mt_item[2 * item + 1];
+  const size_t lane_off = (size_t)chunk * 64 + (size_t)lk * 16;      // first of this lane's 16 instances
+  // instances beyond the batch (ragged last chunk) hold undefined factor values: their K slots are zeroed
+  const int nvalid = min(16, max(0, g.batch - (int)lane_off));
+  double4_t acc = {0.0, 0.0, 0.0, 0.0};
+  for (int r = ra; r < rb; r += 2) {
+    // two records at a time: all their operands are requested before the first multiply
+    int oa[2], ob[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const bool live = r + s < rb;
+      oa[s] = live ? g.mt_rec[(size_t)(r + s) * 32 + li] : -1;
+      ob[s] = live ? g.mt_rec[(size_t)(r + s) * 32 + 16 + li] : -1;
+    }
+    double2 a[2][8], b[2][8];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { a[s][q] = make_double2(0.0, 0.0); b[s][q] = make_double2(0.0, 0.0); }
+      if (oa[s] >= 0) {         // (rows the panel does not have are not requested)
+        const double2* pa = reinterpret_cast<const double2*>(g.L + (size_t)oa[s] * bpad + lane_off);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[s][q] = pa[q];
+      }
+      if (ob[s] >= 0) {
+        const double2* pb = reinterpret_cast<const double2*>(g.U + (size_t)ob[s] * bpad + lane_off);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) b[s][q] = pb[q];
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const double a0 = (2 * q < nvalid) ? a[s][q].x : 0.0, a1 = (2 * q + 1 < nvalid) ? a[s][q].y : 0.0;
+        const double b0 = (2 * q < nvalid) ? b[s][q].x : 0.0, b1 = (2 * q + 1 < nvalid) ? b[s][q].y : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+      }
+    }
+  }
+  // D[row = lk + 4 r][col = li] (see k_ldl_regs): slot (row * 16 + col) of the 256-entry partial tile
+  double* out = g.Spart + ((size_t)chunk * nwork_items + item) * 256;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) out[(lk + 4 * r) * 16 + li] = -acc[r];
+}
+
+// S[ci][cj] (+)= sum over the work items of the tile and the chunks of the partial 16 x 16 tiles (both triangles of the dense
+// S).  Sixteen partial sums per entry (one per residue of the chunk index; fixed order inside: deterministic) meet in LDS
+// and are added as a fixed tree.  Tail as in k_schur_reduce.
+__global__ __launch_bounds__(1024) void k_schur_reduce_mfma(GroupDev g, int nwork_items, double* __restrict__ S,
+                                                            int* __restrict__ counters, int overwrite) {
+  __shared__ double part[4][256];
+  const int tid = threadIdx.x, tile = blockIdx.x, e = tid & 255, sub = tid >> 8;
+  if (counters && tile == 0 && tid < 64) {
+    const int lane = tid;
+    int4 c = reinterpret_cast<int4*>(counters)[lane];       // PP_CSLOTS == 64: one slot per lane
+    reinterpret_cast<int4*>(counters)[lane] = make_int4(0, 0, 0, 0);
+    for (int off = 32; off > 0; off >>= 1) {
+      c.x += __shfl_xor(c.x, off); c.y += __shfl_xor(c.y, off); c.z += __shfl_xor(c.z, off); c.w += __shfl_xor(c.w, off);
+    }
+    if (lane == 0) {
+      double* tail = S + (size_t)g.nc * g.nc;
+      tail[0] = (double)c.z;
+      tail[1] = (double)c.x;
+      tail[2] = (double)c.y;
+      tail[3] = 0.0;
+      tail[4] = (double)c.w;
+      tail[5] = tail[6] = tail[7] = 0.0;
+    }
+  }
+  const int i0 = g.mt_wptr[tile], i1 = g.mt_wptr[tile + 1];
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  for (int c = sub; c < g.nchunk; c += 4) {                  // (the four quarter-sums: chunks 0,4,8,.. / 1,5,9,.. / ...)
+    const double* base = g.Spart + ((size_t)c * nwork_items) * 256 + e;
+    int it = i0;
+    for (; it + 3 < i1; it += 4) {
+      s0 += base[(size_t)it * 256]; s1 += base[(size_t)(it + 1) * 256]; s2 += base[(size_t)(it + 2) * 256]; s3 += base[(size_t)(it + 3) * 256];
+    }
+    for (; it < i1; ++it) s0 += base[(size_t)it * 256];
+  }
+  part[sub][e] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sub != 0) return;
+  const double s = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+  const int ci = g.mt_a[tile] * 16 + (e >> 4), cj = g.mt_b[tile] * 16 + (e & 15);
+  if (ci < g.nc && cj < g.nc && ci >= cj) {
+    const size_t lo = (size_t)ci + (size_t)cj * g.nc, up = (size_t)cj + (size_t)ci * g.nc;
+    if (overwrite) { S[lo] = s; if (ci != cj) S[up] = s; }
+    else { S[lo] += s; if (ci != cj) S[up] += s; }
+  }
+}
+
 // Mapped groups: S[gi][gj] += clique entry (ci, cj) of instance b, gi = cmap[b][ci].  Target: the dense n_c x n_c S
 // (both triangles) or the block-tridiagonal storage D[G][gs][gs] | E[G-1][gs][gs] (E_t = rows of block t+1 x columns of
 // block t, column-major inside a block).  Entries of different instances may coincide in general: atomic adds.
@@ -1116,7 +1241,6 @@ __global__ __launch_bounds__(256) void k_add_q(const double* __restrict__ S, con
 // numerically zero; otherwise mode[0] stays 0 and k_bk_factor (Bunch-Kaufman) takes over on the
 // untouched copy.  At the points the interior-point method accepts, S of a stochastic program
 // is positive definite (Haynsworth: every K_i carries its own negative eigenvalues).
-typedef double double4_t __attribute__((ext_vector_type(4)));
 constexpr int LDL_NB = 32;
 constexpr int LDL_THREADS = 512;
 
@@ -2459,6 +2583,7 @@ struct Group {
   std::vector<int> can_ptr, can_idx;
   std::vector<void*> allocs;
   int ntiles = 0;
+  int nmt = 0, nmt_items = 0;  // 16 x 16 tiles of S with contributions (MFMA form), work items over them
   double *raw_own = nullptr, *rhs_own = nullptr, *rawT_own = nullptr;
   int nraw_used = 0;
   std::vector<int> level_maxw;   // widest block pivot per level (selects the scalar kernel variants)
@@ -2521,6 +2646,7 @@ struct pp_solver {
   bool growth_fatal = false;     // flagged instances make the factorisation report status 2 (else they are only counted)
   double pivot_threshold = 0.0;  // symbolic-time threshold u for groups added afterwards (0: plan default)
   bool no_fused_sources = std::getenv("PP_NO_FUSED_SOURCES") != nullptr;   // measurement switch: assemble the sources first
+  bool schur_mfma = std::getenv("PP_NO_SCHUR_MFMA") == nullptr;   // MFMA form of the Schur update of unmapped groups (measurement switch)
   bool group_streams = std::getenv("PP_NO_GROUP_STREAMS") == nullptr;   // pattern groups side by side on streams of their own (measurement switch)
   bool dense_dpp = std::getenv("PP_NO_DENSE_DPP") == nullptr;           // row broadcasts by DP-ALU DPP in k_ldl_regs (measurement switch)
   bool lane_pairs = std::getenv("PP_NO_LANE_PAIRS") == nullptr;   // two instances per lane in the gather kernels (measurement switch)
@@ -2778,7 +2904,7 @@ int64_t value_storage_bytes(pp_handle h) {
     // only inside a solve)
     int64_t dbl = (int64_t)g->batch * g->nraw + (int64_t)std::max(g->nraw_used, 1) * bp + 2 * P.usize * bp +
                   (int64_t)P.dsize * bp + (int64_t)std::max(P.n + g->nc_loc, std::max(P.bsize, 1)) * bp +
-                  (int64_t)P.n * bp + 2 * (int64_t)g->batch * P.n + (int64_t)d.nchunk * std::max(g->ntiles, 1) * 64 +
+                  (int64_t)P.n * bp + 2 * (int64_t)g->batch * P.n + (int64_t)d.nchunk * std::max(std::max(g->ntiles, 1) * 64, g->nmt_items * 256) +
                   (int64_t)d.nchunk * std::max(g->nc_loc, 1) +
                   (g->cmap_host.empty() ? 0 : ((int64_t)std::max(g->ntiles, 1) * 64 + std::max(g->nc_loc, 1)) * bp);
     total += 8 * dbl + 2 * (int64_t)P.npiv * bp;
@@ -2840,7 +2966,7 @@ int alloc_value_storage(pp_handle h) {
     d.Tm = d.Y;     // term magnitudes of the pivot blocks (gather -> scale of one level) share the rows of the solve vector
     double* keep_x = (d.xout && d.xout != g->xout_own) ? d.xout : nullptr;
     d.xout = keep_x;
-    if ((rc = value_alloc(h, g, &d.Spart, (size_t)d.nchunk * std::max(g->ntiles, 1) * 64))) break;
+    if ((rc = value_alloc(h, g, &d.Spart, (size_t)d.nchunk * (size_t)std::max(std::max(g->ntiles, 1) * 64, g->nmt_items * 256)))) break;
     if ((rc = value_alloc(h, g, &d.rspart, (size_t)d.nchunk * std::max(nc, 1)))) break;
     if (!g->cmap_host.empty()) {
       if ((rc = value_alloc(h, g, &d.Sloc, (size_t)std::max(g->ntiles, 1) * 64 * bp))) break;
@@ -3241,6 +3367,46 @@ int pp_end_symbolic(pp_handle h) {
     if ((rc = dev_upload(h, g, &d.stile_ptr, sptr))) return rc;
     if ((rc = dev_upload(h, g, &d.stile_rec, srec))) return rc;
     g->ntiles = (int)P.stile_a.size();
+    // 16 x 16 tiles for the MFMA form (k_schur_mfma): per (tile pair, panel column) one record with the positions of the
+    // 16 + 16 rows; the records of a tile are cut into work items of at most PP_MT_SLICE records
+    {
+      std::map<std::pair<int, int>, std::vector<int>> by_tile;      // (ta, tb) -> records of 32 ints
+      for (int pv = 0; pv < P.npiv; ++pv) {
+        const int w = P.piv_w[pv];
+        std::vector<int> tl;
+        std::vector<std::array<int, 16>> slots;
+        for (int q = P.piv_rowptr[pv]; q < P.piv_rowptr[pv + 1]; ++q) {
+          const int r = P.rowidx[(size_t)q];
+          if (r < P.n) continue;
+          const int c = r - P.n, ti = c / 16;
+          if (tl.empty() || tl.back() != ti) { tl.push_back(ti); std::array<int, 16> e; e.fill(-1); slots.push_back(e); }
+          slots.back()[(size_t)(c % 16)] = w + (q - P.piv_rowptr[pv]);      // row slot inside the panel
+        }
+        for (size_t a = 0; a < tl.size(); ++a)
+          for (size_t b2 = 0; b2 <= a; ++b2)
+            for (int t = 0; t < w; ++t) {
+              auto& v = by_tile[{tl[a], tl[b2]}];
+              for (int q = 0; q < 16; ++q) v.push_back(slots[a][(size_t)q] < 0 ? -1 : (int)(P.piv_uoff[pv] + (int64_t)slots[a][(size_t)q] * w + t));
+              for (int q = 0; q < 16; ++q) v.push_back(slots[b2][(size_t)q] < 0 ? -1 : (int)(P.piv_uoff[pv] + (int64_t)slots[b2][(size_t)q] * w + t));
+            }
+      }
+      std::vector<int> mta, mtb, mrec, mitem, mwptr{0};
+      for (auto& kv : by_tile) {
+        mta.push_back(kv.first.first); mtb.push_back(kv.first.second);
+        const int r0 = (int)(mrec.size() / 32);
+        mrec.insert(mrec.end(), kv.second.begin(), kv.second.end());
+        const int r1 = (int)(mrec.size() / 32);
+        for (int r = r0; r < r1; r += PP_MT_SLICE) { mitem.push_back(r); mitem.push_back(std::min(r1, r + PP_MT_SLICE)); }
+        mwptr.push_back((int)(mitem.size() / 2));
+      }
+      g->nmt = (int)mta.size();
+      g->nmt_items = (int)(mitem.size() / 2);
+      if ((rc = dev_upload(h, g, &d.mt_a, mta))) return rc;
+      if ((rc = dev_upload(h, g, &d.mt_b, mtb))) return rc;
+      if ((rc = dev_upload(h, g, &d.mt_rec, mrec))) return rc;
+      if ((rc = dev_upload(h, g, &d.mt_item, mitem))) return rc;
+      if ((rc = dev_upload(h, g, &d.mt_wptr, mwptr))) return rc;
+    }
   }
   int rc;
   if (h->btd && (h->G < 1 || h->gs < 1 || h->gs > 512 || (int64_t)h->G * h->gs != nc))
@@ -3603,6 +3769,13 @@ int pp_numeric_schur(pp_handle h) {
                            h->counters);
         const SchurTarget T{h->S, nc, h->btd, h->gs, h->G, h->scatter_err};
         hipLaunchKernelGGL(k_scatter_schur, dim3((unsigned)g->ntiles * d.nchunk), dim3(64), 0, st, d, g->ntiles, T);
+      } else if (g->ntiles > 0 && h->schur_mfma && g->nmt > 0) {
+        hipLaunchKernelGGL(k_schur_mfma, dim3((unsigned)g->nmt_items * d.nchunk + ncb), dim3(64), 0, st, d, g->nmt_items, total8,
+                           h->counters);
+        const bool last = (g == h->groups.back());
+        hipLaunchKernelGGL(k_schur_reduce_mfma, dim3(g->nmt), dim3(1024), 0, st, d, g->nmt_items, h->S,
+                           last ? h->counters : (int*)nullptr, (first_covers && g == h->groups.front()) ? 1 : 0);
+        tail_written = last;
       } else if (g->ntiles > 0) {
         hipLaunchKernelGGL(k_schur_tiles, dim3((unsigned)g->ntiles * d.nchunk + ncb, 1, 2), dim3(64), 0, st, d, g->ntiles, total8,
                            h->counters);

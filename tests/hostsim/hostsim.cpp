@@ -139,6 +139,24 @@ void ppsim_level_teams(void* h, int* out) {
   }
 }
 
+// per pivot: number of coupling rows in its panel
+void ppsim_get_ncrow(void* h, int* out) { Plan& P = *(Plan*)h; std::memcpy(out, P.piv_ncrow.data(), sizeof(int) * P.npiv); }
+
+// solve schedule per level (4 ints): scalar columns, entries of the longest / of all forward rows, rows of the longest column
+void ppsim_solve_levels(void* h, int* out) {
+  Plan& P = *(Plan*)h;
+  for (int l = 0; l < P.n_levels; ++l) {
+    int* o = out + 4 * l;
+    o[0] = P.clevel_ptr[l + 1] - P.clevel_ptr[l]; o[1] = o[2] = o[3] = 0;
+    for (int q = P.clevel_ptr[l]; q < P.clevel_ptr[l + 1]; ++q) {
+      const int c = P.clevel_col[q], pv = P.piv_of_col[c];
+      const int ne = P.sfwd_eptr[c + 1] - P.sfwd_eptr[c];
+      o[1] = std::max(o[1], ne); o[2] += ne;
+      o[3] = std::max(o[3], P.piv_rowptr[pv + 1] - P.piv_rowptr[pv]);
+    }
+  }
+}
+
 namespace {
 // rows [r0, r1) of panel p: L = U inv(P)
 void scale_rows(const Plan& P, int p, int r0, int r1, const double* inv, const double* U, double* L) {

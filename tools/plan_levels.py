@@ -38,6 +38,15 @@ def main():
     for lv, (row, tm) in enumerate(zip(out.reshape(nl, 8), teams.reshape(nl, 4))):
         print('%5d %6d %7d %6d %6d %10d %10d %10d %7d | %17d %16d %9d %9d' %
               ((lv,) + tuple(int(v) for v in row) + tuple(int(v) for v in tm)))
+    solve_levels(L, sg, nl)
+
+
+def solve_levels(L, sg, nl):
+    out = np.zeros(4 * nl, dtype=np.int32)
+    L.ppsim_solve_levels(sg.h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+    print('solve schedule: level  columns  longest fwd row  fwd entries  longest column (rows)')
+    for lv, row in enumerate(out.reshape(nl, 4)):
+        print('%21d %8d %16d %12d %22d' % ((lv,) + tuple(int(v) for v in row)))
 
 
 if __name__ == '__main__':

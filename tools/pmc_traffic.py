@@ -17,7 +17,7 @@ from pmc_summary import load, short   # noqa: E402
 
 PHASE_OF = [
     (r'^k_gather_level|^k_gather_flat', 'factor_levels'), (r'^k_scale_level', 'factor_levels'),
-    (r'^k_count_codes|^k_schur_tiles|^k_schur_reduce', 'schur_tiles'),
+    (r'^k_count_codes|^k_schur_tiles|^k_schur_mfma|^k_schur_reduce', 'schur_tiles'),
     (r'^k_add_q|^k_ldl_|^k_bk_factor|^k_write_tail|^k_publish_status', 'dense_S'),
     (r'^k_fwd_level', 'fwd_levels'), (r'^k_fwd_coupling|^k_rs_reduce', 'fwd_coupling'),
     (r'^k_coupling_solve', 'coupling_solve'), (r'^k_bwd_level|^k_transpose_out', 'bwd_levels'),
