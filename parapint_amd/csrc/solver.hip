@@ -2138,6 +2138,98 @@ __global__ __launch_bounds__(256) void k_bcr_update(int gs, int G, BcrLevel lv, 
   }
 }
 
+// The gs x gs block products of the cyclic reduction on the fp64 matrix cores (round 2): one wave per 16 x 16 tile of
+// the product, v_mfma_f64_16x16x4 over K in steps of 4 (column-major blocks, leading dimension gs; TA / TB: the operand is
+// the transposed block; entries beyond gs are zeros).  Lane (li, lk) supplies A(m0 + li, k0 + lk) and B(k0 + lk, n0 + li);
+// the result lane holds D(m0 + lk + 4 r, n0 + li), r = 0..3 (as in k_ldl_regs).
+template <bool TA, bool TB>
+__device__ __forceinline__ double4_t bcr_gemm_tile(const double* __restrict__ A, const double* __restrict__ B, int gs, int m0,
+                                                   int n0, int li, int lk) {
+  double4_t acc = {0.0, 0.0, 0.0, 0.0};
+  const int m = m0 + li, n = n0 + li;
+  for (int k0 = 0; k0 < gs; k0 += 16) {
+    double a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {            // four K steps requested together
+      const int k = k0 + 4 * u + lk;
+      a[u] = (m < gs && k < gs) ? (TA ? A[(size_t)k + (size_t)m * gs] : A[(size_t)m + (size_t)k * gs]) : 0.0;
+      b[u] = (n < gs && k < gs) ? (TB ? B[(size_t)n + (size_t)k * gs] : B[(size_t)k + (size_t)n * gs]) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// MFMA form of k_bcr_keep_y: grid (tiles, eliminated blocks, 2): z = 0 the lower neighbour (Klo, Ylo), z = 1 the upper one
+__global__ __launch_bounds__(64) void k_bcr_keep_y_mfma(int gs, int G, BcrLevel lv, const double* __restrict__ inv,
+                                                        const double* __restrict__ slot, double* __restrict__ Klo,
+                                                        double* __restrict__ Kup, double* __restrict__ Ylo, double* __restrict__ Yup) {
+  const int i = lv.elim[blockIdx.y], s = lv.s, nt = (gs + 15) / 16;
+  const size_t g2 = (size_t)gs * gs;
+  const int li = threadIdx.x & 15, lk = threadIdx.x >> 4;
+  const int m0 = 16 * (int)(blockIdx.x % nt), n0 = 16 * (int)(blockIdx.x / nt);
+  const double* I = inv + (size_t)i * g2;
+  if (blockIdx.z == 0) {
+    if (!(lv.lo && i - s >= 0)) return;
+    const double* Sl = slot + (size_t)(i - s) * g2;      // S(i, i-s)
+    const double4_t y = bcr_gemm_tile<false, false>(I, Sl, gs, m0, n0, li, lk);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + lk + 4 * r, col = n0 + li;
+      if (row < gs && col < gs) { const size_t idx = (size_t)row + (size_t)col * gs; Ylo[(size_t)i * g2 + idx] = y[r]; Klo[(size_t)i * g2 + idx] = Sl[idx]; }
+    }
+  } else {
+    if (i + s >= G) return;
+    const double* Su = slot + (size_t)i * g2;            // S(i+s, i)
+    const double4_t y = bcr_gemm_tile<false, true>(I, Su, gs, m0, n0, li, lk);       // inv_i Kup^T
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + lk + 4 * r, col = n0 + li;
+      if (row < gs && col < gs) { const size_t idx = (size_t)row + (size_t)col * gs; Yup[(size_t)i * g2 + idx] = y[r]; Kup[(size_t)i * g2 + idx] = Su[idx]; }
+    }
+  }
+}
+
+// MFMA form of k_bcr_update: grid (tiles, eliminated blocks, z); z + zbase = 0: D_{i-s} -= Klo^T Ylo, 1: slot[i-s] = -Kup Ylo,
+// 2: D_{i+s} -= Kup Yup (a launch of its own: D_j is updated from both sides within a level).
+__global__ __launch_bounds__(64) void k_bcr_update_mfma(int gs, int G, BcrLevel lv, const double* __restrict__ Klo,
+                                                        const double* __restrict__ Kup, const double* __restrict__ Ylo,
+                                                        const double* __restrict__ Yup, double* __restrict__ D, double* __restrict__ slot,
+                                                        int zbase) {
+  const int i = lv.elim[blockIdx.y], s = lv.s, nt = (gs + 15) / 16;
+  const size_t g2 = (size_t)gs * gs;
+  const int li = threadIdx.x & 15, lk = threadIdx.x >> 4;
+  const int m0 = 16 * (int)(blockIdx.x % nt), n0 = 16 * (int)(blockIdx.x / nt);
+  const int z = (int)blockIdx.z + zbase;
+  const bool has_lo = lv.lo && i - s >= 0, has_up = i + s < G;
+  double4_t v;
+  double* dst;
+  double sign;
+  bool add;
+  if (z == 0) {
+    if (!has_lo) return;
+    v = bcr_gemm_tile<true, false>(Klo + (size_t)i * g2, Ylo + (size_t)i * g2, gs, m0, n0, li, lk);
+    dst = D + (size_t)(i - s) * g2; sign = -1.0; add = true;
+  } else if (z == 1) {
+    if (!(has_lo && has_up)) return;
+    v = bcr_gemm_tile<false, false>(Kup + (size_t)i * g2, Ylo + (size_t)i * g2, gs, m0, n0, li, lk);
+    dst = slot + (size_t)(i - s) * g2; sign = -1.0; add = false;      // S(i+s, i-s) for the next level (stride 2 s)
+  } else {
+    if (!has_up) return;
+    v = bcr_gemm_tile<false, false>(Kup + (size_t)i * g2, Yup + (size_t)i * g2, gs, m0, n0, li, lk);
+    dst = D + (size_t)(i + s) * g2; sign = -1.0; add = true;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = m0 + lk + 4 * r, col = n0 + li;
+    if (row < gs && col < gs) {
+      const size_t idx = (size_t)row + (size_t)col * gs;
+      dst[idx] = add ? dst[idx] + sign * v[r] : sign * v[r];
+    }
+  }
+}
+
 __global__ void k_btd_finish(int G, const int* __restrict__ infos, int* __restrict__ bkinfo, const double* __restrict__ tail,
                              const int* __restrict__ scatter_err, long long* status_out, long long seq) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -3852,6 +3944,7 @@ int pp_factor_schur(pp_handle h, const double* Q_host) {
       }
     }
     if (std::getenv("PP_BCR_NO_LDS")) lds_bytes = 0;
+    const bool bcr_mfma = std::getenv("PP_NO_BCR_MFMA") == nullptr;    // block products on the matrix cores (measurement switch)
     int bk_threads = 256;        // (measured at C4, gs = 98, S phase per step: 64 threads 15.3 ms, 128 12.1, 256 10.8, 512 11.0)
     if (const char* e = std::getenv("PP_BCR_THREADS")) bk_threads = std::max(64, std::min(BK_THREADS, std::atoi(e)));
     for (int l = 0; l < nlev; ++l) {
@@ -3860,12 +3953,25 @@ int pp_factor_schur(pp_handle h, const double* Q_host) {
                          lds_bytes > 0 ? 1 : 0);
       hipLaunchKernelGGL(k_bcr_invert, dim3(gs, lv.ne), dim3(128), 0, st, gs, lv, D, h->btd_ipiv, h->btd_inv);
       if (l + 1 < nlev) {
+        if (bcr_mfma) {
+          const unsigned nt16 = (unsigned)((gs + 15) / 16);
+          hipLaunchKernelGGL(k_bcr_keep_y_mfma, dim3(nt16 * nt16, lv.ne, 2), dim3(64), 0, st, gs, G, lv, h->btd_inv, slot, h->btd_klo,
+                             h->btd_kup, h->btd_ylo, h->btd_yup);
+          // (z = 0 and z = 2 of different eliminated blocks never meet: block i - s of one is block i + s of another only
+          // across levels; within a level D_j is updated from below by z = 2 of i = j - s and from above by z = 0 of
+          // i = j + s -- two read-modify-writes of the same block: two launches)
+          hipLaunchKernelGGL(k_bcr_update_mfma, dim3(nt16 * nt16, lv.ne, 2), dim3(64), 0, st, gs, G, lv, h->btd_klo, h->btd_kup,
+                             h->btd_ylo, h->btd_yup, D, slot, 0);
+          hipLaunchKernelGGL(k_bcr_update_mfma, dim3(nt16 * nt16, lv.ne, 1), dim3(64), 0, st, gs, G, lv, h->btd_klo, h->btd_kup,
+                             h->btd_ylo, h->btd_yup, D, slot, 2);
+        } else {
         hipLaunchKernelGGL(k_bcr_keep_y, dim3(gb, lv.ne), dim3(256), 0, st, gs, G, lv, h->btd_inv, slot, h->btd_klo, h->btd_kup,
                            h->btd_ylo, h->btd_yup);
         hipLaunchKernelGGL(k_bcr_update, dim3(gb, lv.ne), dim3(256), 0, st, gs, G, lv, 0, h->btd_klo, h->btd_kup, h->btd_ylo,
                            h->btd_yup, D, slot);
         hipLaunchKernelGGL(k_bcr_update, dim3(gb, lv.ne), dim3(256), 0, st, gs, G, lv, 1, h->btd_klo, h->btd_kup, h->btd_ylo,
                            h->btd_yup, D, slot);
+        }
       }
     }
     hipLaunchKernelGGL(k_btd_finish, dim3(1), dim3(64), 0, st, G, h->btd_info, h->bkinfo, h->S + nn, h->scatter_err, h->status_dev,
