@@ -1999,6 +1999,30 @@ struct TeamCtx {
   }
 };
 
+// The same team interface for ONE wave: no workgroup barriers (LDS traffic of a wave is ordered; the fence keeps the
+// compiler from moving accesses across the point), reductions by lane shuffles.
+struct WaveCtx {
+  __device__ int tid() const { return threadIdx.x & 63; }
+  __device__ int nthreads() const { return 64; }
+  __device__ void sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+  __device__ void argmax(double v, int i, double* vmax, int* imax) {
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ov = __shfl_xor(v, off);
+      const int oi = __shfl_xor(i, off);
+      if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+    *vmax = v; *imax = i;
+  }
+  __device__ double maxval(double v) {
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    return v;
+  }
+  __device__ double sum(double v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+  }
+};
+
 // Last kernel of the dense phase.  If the unpivoted factorisation was accepted (mode[0] == 1) it only publishes the
 // status; otherwise it builds S + Q in A (Q lower triangle authoritative, may be null) and runs Bunch-Kaufman.
 __global__ __launch_bounds__(BK_THREADS) void k_bk_factor(int n, const double* __restrict__ S, const double* __restrict__ Q,
@@ -2051,13 +2075,15 @@ __global__ __launch_bounds__(BK_THREADS) void k_bcr_factor(int gs, BcrLevel lv, 
   const int i = lv.elim[blockIdx.x];
   double* Dg = D + (size_t)i * gs * gs;
   double* A = Dg;
+  double* wk = work + (size_t)blockIdx.x * 2 * gs;
   if (in_lds) {
     for (int k = threadIdx.x; k < gs * gs; k += blockDim.x) shD[k] = Dg[k];
     __syncthreads();
     A = shD;
+    wk = shD + (size_t)gs * gs;      // (the two work columns of a 2 x 2 pivot step: LDS as well, not a global round trip per step)
   }
   TeamCtx ctx{sv, si};
-  pp::bk_factor(ctx, gs, A, gs, ipiv + (size_t)i * gs, work + (size_t)blockIdx.x * 2 * gs, &sbi, BK_EPS);
+  pp::bk_factor(ctx, gs, A, gs, ipiv + (size_t)i * gs, wk, &sbi, BK_EPS);
   if (in_lds) {
     __syncthreads();
     for (int k = threadIdx.x; k < gs * gs; k += blockDim.x) Dg[k] = shD[k];
@@ -2076,6 +2102,25 @@ __global__ __launch_bounds__(128) void k_bcr_invert(int gs, BcrLevel lv, const d
   __syncthreads();
   TeamCtx ctx{sv, si};
   pp::bk_solve(ctx, gs, D + (size_t)i * gs * gs, gs, ipiv + (size_t)i * gs, col);
+}
+
+// The same, one WAVE per column (four columns per workgroup), the vector in LDS: the ~2 gs team synchronisations of a
+// solve are wave-level (free) instead of workgroup barriers.  Dynamic LDS: 4 * gs doubles.  (MEASURED at C4, gs = 98:
+// 350 -> 202 us per level; with the factored block in LDS as well -- 16 columns per workgroup, 89 KB -- 220 us: a step is a
+// chain of dependent accesses either way, and the smaller footprint keeps twice as many waves on a CU.)
+__global__ __launch_bounds__(256) void k_bcr_invert_wave(int gs, BcrLevel lv, const double* __restrict__ D, const int* __restrict__ ipiv,
+                                                         double* __restrict__ inv) {
+  extern __shared__ __attribute__((aligned(16))) double shv[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lv.elim[blockIdx.y], c = (int)blockIdx.x * 4 + wave;
+  if (c >= gs) return;
+  double* b = shv + (size_t)wave * gs;
+  for (int r = lane; r < gs; r += 64) b[r] = (r == c) ? 1.0 : 0.0;
+  WaveCtx ctx;
+  ctx.sync();
+  pp::bk_solve(ctx, gs, D + (size_t)i * gs * gs, gs, ipiv + (size_t)i * gs, b);
+  double* col = inv + (size_t)i * gs * gs + (size_t)c * gs;
+  for (int r = lane; r < gs; r += 64) col[r] = b[r];
 }
 
 // Klo_i = S(i, i-s) = slot(i-s)^T ... kept as the slot itself: Klo[i] = slot[i-s] (= S(i, i-s), rows of block i);
@@ -3933,7 +3978,7 @@ int pp_factor_schur(pp_handle h, const double* Q_host) {
     double* slot = h->btd_fac + (size_t)G * g2;
     const unsigned gb = (unsigned)((g2 + 255) / 256);
     // the diagonal blocks are factorised in LDS when they fit (gs <= 137: 150 KB of the CU's 160 KB)
-    size_t lds_bytes = g2 * sizeof(double);
+    size_t lds_bytes = (g2 + 2 * (size_t)gs) * sizeof(double);      // the block and the two work columns of a 2 x 2 pivot step
     if (lds_bytes > 150 * 1024) lds_bytes = 0;
     if (lds_bytes > 64 * 1024 && !h->bcr_lds_attr) {
       if (hipFuncSetAttribute((const void*)k_bcr_factor, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
@@ -3944,14 +3989,16 @@ int pp_factor_schur(pp_handle h, const double* Q_host) {
       }
     }
     if (std::getenv("PP_BCR_NO_LDS")) lds_bytes = 0;
-    const bool bcr_mfma = std::getenv("PP_NO_BCR_MFMA") == nullptr;    // block products on the matrix cores (measurement switch)
+    const bool bcr_mfma = std::getenv("PP_NO_BCR_MFMA") == nullptr;    // block products on the matrix cores, wave-level inverse (measurement switch)
     int bk_threads = 256;        // (measured at C4, gs = 98, S phase per step: 64 threads 15.3 ms, 128 12.1, 256 10.8, 512 11.0)
     if (const char* e = std::getenv("PP_BCR_THREADS")) bk_threads = std::max(64, std::min(BK_THREADS, std::atoi(e)));
     for (int l = 0; l < nlev; ++l) {
       const BcrLevel lv{h->btd_elim + h->bcr_off[(size_t)l], h->bcr_ne[(size_t)l], h->bcr_s[(size_t)l], h->bcr_lo[(size_t)l]};
       hipLaunchKernelGGL(k_bcr_factor, dim3(lv.ne), dim3(bk_threads), lds_bytes, st, gs, lv, D, h->btd_ipiv, h->btd_vec, h->btd_info,
                          lds_bytes > 0 ? 1 : 0);
-      hipLaunchKernelGGL(k_bcr_invert, dim3(gs, lv.ne), dim3(128), 0, st, gs, lv, D, h->btd_ipiv, h->btd_inv);
+      if (bcr_mfma) hipLaunchKernelGGL(k_bcr_invert_wave, dim3((gs + 3) / 4, lv.ne), dim3(256), 4 * (size_t)gs * sizeof(double), st, gs, lv, D,
+                                       h->btd_ipiv, h->btd_inv);
+      else hipLaunchKernelGGL(k_bcr_invert, dim3(gs, lv.ne), dim3(128), 0, st, gs, lv, D, h->btd_ipiv, h->btd_inv);
       if (l + 1 < nlev) {
         if (bcr_mfma) {
           const unsigned nt16 = (unsigned)((gs + 15) / 16);
