@@ -556,3 +556,31 @@ def test_dynamic_time_blocks_block_tridiagonal_schur():
 def test_dynamic_problem_through_the_inertia_correction_loop(dense_limit):
     solver = sc.case_dynamic_regularised(make_engine, dense_limit)
     assert (solver._btd is not None) == (dense_limit is not None)
+
+
+def test_measurement_switches_select_paths_that_agree():
+    """Every round-2 kernel path has a measurement switch that selects its predecessor (one instance per lane, v_readlane
+    broadcasts in the dense LDL^T, register-tile Schur update, pattern groups one after the other, scalar block products of
+    the cyclic reduction, standalone source gather).  With all of them set the odd-shape soak (residual <= 1e-9, exact
+    inertia; one block ... 320 blocks, n_c up to 513) and a block-tridiagonal dynamic case must still pass: the fallbacks
+    stay correct."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ('PP_NO_LANE_PAIRS', 'PP_NO_DENSE_DPP', 'PP_NO_SCHUR_MFMA', 'PP_NO_GROUP_STREAMS', 'PP_NO_BCR_MFMA',
+              'PP_NO_FUSED_SOURCES'):
+        env[k] = '1'
+    env['PYTHONPATH'] = root + os.pathsep + env.get('PYTHONPATH', '')
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'soak_small.py')], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, timeout=900)
+    text = out.stdout.decode()
+    assert out.returncode == 0 and 'small soak ok' in text, text[-3000:]
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import solver_cases as sc\n"
+            "from parapint_amd.linalg.hip_schur_complement import HipEngine\n"
+            "sc.case_dynamic(lambda: HipEngine(), 64, 49, n_u=2, nfe=4, expect_block_tridiagonal=True)\n"
+            "print('dynamic ok')\n") % (root, os.path.join(root, 'tests'))
+    out = subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert out.returncode == 0 and 'dynamic ok' in out.stdout.decode(), out.stdout.decode()[-3000:]
