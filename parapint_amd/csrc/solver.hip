@@ -1999,6 +1999,52 @@ struct TeamCtx {
   }
 };
 
+// TeamCtx for work that lives entirely in LDS: the barriers order LDS traffic only (see lds_barrier: __syncthreads() would
+// also wait for every outstanding global store, a memory round trip on the critical path of each of the ~10 barriers of a
+// pivot step).
+struct TeamCtxLds {
+  double* sv;
+  int* si;
+  __device__ int tid() const { return threadIdx.x; }
+  __device__ int nthreads() const { return blockDim.x; }
+  __device__ void sync() { lds_barrier(); }
+  __device__ void argmax(double v, int i, double* vmax, int* imax) {
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ov = __shfl_xor(v, off);
+      const int oi = __shfl_xor(i, off);
+      if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+    const int wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    lds_barrier();
+    if ((threadIdx.x & 63) == 0) { sv[wv] = v; si[wv] = i; }
+    lds_barrier();
+    double bv = sv[0]; int bi = si[0];
+    for (int q = 1; q < nw; ++q)
+      if (sv[q] > bv || (sv[q] == bv && si[q] < bi)) { bv = sv[q]; bi = si[q]; }
+    *vmax = bv; *imax = bi;
+  }
+  __device__ double maxval(double v) {
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    const int wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    lds_barrier();
+    if ((threadIdx.x & 63) == 0) sv[wv] = v;
+    lds_barrier();
+    double r = sv[0];
+    for (int q = 1; q < nw; ++q) r = fmax(r, sv[q]);
+    return r;
+  }
+  __device__ double sum(double v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    const int wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    lds_barrier();
+    if ((threadIdx.x & 63) == 0) sv[wv] = v;
+    lds_barrier();
+    double r = 0.0;
+    for (int q = 0; q < nw; ++q) r += sv[q];
+    return r;
+  }
+};
+
 // The same team interface for ONE wave: no workgroup barriers (LDS traffic of a wave is ordered; the fence keeps the
 // compiler from moving accesses across the point), reductions by lane shuffles.
 struct WaveCtx {
@@ -2077,16 +2123,19 @@ __global__ __launch_bounds__(BK_THREADS) void k_bcr_factor(int gs, BcrLevel lv, 
   double* A = Dg;
   double* wk = work + (size_t)blockIdx.x * 2 * gs;
   if (in_lds) {
+    // block, the two work columns of a 2 x 2 pivot step and the pivot indices all live in LDS, and the barriers of the
+    // factorisation order LDS traffic only: no global-memory round trip inside the gs pivot steps
     for (int k = threadIdx.x; k < gs * gs; k += blockDim.x) shD[k] = Dg[k];
     __syncthreads();
-    A = shD;
-    wk = shD + (size_t)gs * gs;      // (the two work columns of a 2 x 2 pivot step: LDS as well, not a global round trip per step)
-  }
-  TeamCtx ctx{sv, si};
-  pp::bk_factor(ctx, gs, A, gs, ipiv + (size_t)i * gs, wk, &sbi, BK_EPS);
-  if (in_lds) {
+    int* lpiv = reinterpret_cast<int*>(shD + (size_t)gs * gs + 2 * (size_t)gs);
+    TeamCtxLds ctx{sv, si};
+    pp::bk_factor(ctx, gs, shD, gs, lpiv, shD + (size_t)gs * gs, &sbi, BK_EPS);
     __syncthreads();
     for (int k = threadIdx.x; k < gs * gs; k += blockDim.x) Dg[k] = shD[k];
+    for (int k = threadIdx.x; k < gs; k += blockDim.x) ipiv[(size_t)i * gs + k] = lpiv[k];
+  } else {
+    TeamCtx ctx{sv, si};
+    pp::bk_factor(ctx, gs, A, gs, ipiv + (size_t)i * gs, wk, &sbi, BK_EPS);
   }
   if (threadIdx.x == 0) { info[4 * i] = sbi.npos; info[4 * i + 1] = sbi.nneg; info[4 * i + 2] = sbi.nzero; }
 }
@@ -3978,7 +4027,7 @@ int pp_factor_schur(pp_handle h, const double* Q_host) {
     double* slot = h->btd_fac + (size_t)G * g2;
     const unsigned gb = (unsigned)((g2 + 255) / 256);
     // the diagonal blocks are factorised in LDS when they fit (gs <= 137: 150 KB of the CU's 160 KB)
-    size_t lds_bytes = (g2 + 2 * (size_t)gs) * sizeof(double);      // the block and the two work columns of a 2 x 2 pivot step
+    size_t lds_bytes = (g2 + 3 * (size_t)gs) * sizeof(double);      // the block, the two work columns of a 2 x 2 pivot step, the pivot indices
     if (lds_bytes > 150 * 1024) lds_bytes = 0;
     if (lds_bytes > 64 * 1024 && !h->bcr_lds_attr) {
       if (hipFuncSetAttribute((const void*)k_bcr_factor, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
