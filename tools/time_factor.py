@@ -1,7 +1,7 @@
 """Time of the block factorisation alone (pp_numeric_factor_blocks, no status handling), C3 workload with device-resident
 values: for A/B of kernel builds, including timing experiments whose numbers are wrong on purpose (diagnostic).
 
-    [PP_LIB_VARIANT=name] python tools/time_factor.py [steps]
+    [PP_LIB_VARIANT=name] python tools/time_factor.py [steps [blocks]]
 """
 import os
 import sys
@@ -19,7 +19,7 @@ from parapint_amd.linalg.hip_schur_complement import HipSchurComplementLinearSol
 
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-    N, n_q, m, n_t = 1024, 1000, 4, 200
+    N, n_q, m, n_t = (int(sys.argv[2]) if len(sys.argv) > 2 else 1024), 1000, 4, 200
     model = SyntheticKKT(N, n_q, m, n_t)
     comm = SerialComm()
     solver = HipSchurComplementLinearSolver({i: None for i in range(N)}, None, comm=comm)
