@@ -2334,34 +2334,59 @@ __global__ void k_btd_finish(int G, const int* __restrict__ infos, int* __restri
   if (scatter_err[0]) { status_out[0] = 3; }
 }
 
+// y[r] = sum_k M[r + k gs] v[k] (r < gs <= 512) by all threads of a 512-thread workgroup: the K range is dealt over the
+// blockDim / RP groups of RP = gs rounded up to 64 threads, the partial sums meet in LDS and are added in group order
+// (deterministic).  With thread = row and a loop over all of K only gs of the 512 threads worked, each through gs dependent
+// additions (35 us per launch at gs = 98).  Returns the sum in the threads of group 0 (tid < gs); all threads must call.
+__device__ __forceinline__ double bcr_matvec(const double* __restrict__ M, const double* __restrict__ v, int gs, double (*part)[512]) {
+  const int RP = (gs + 63) / 64 * 64, np = max(1, (int)blockDim.x / RP);
+  const int r = (int)threadIdx.x % RP, grp = (int)threadIdx.x / RP;
+  double a0 = 0.0, a1 = 0.0;
+  if (r < gs && grp < np) {
+    int k = grp;
+    for (; k + np < gs; k += 2 * np) { a0 += M[(size_t)r + (size_t)k * gs] * v[k]; a1 += M[(size_t)r + (size_t)(k + np) * gs] * v[k + np]; }
+    if (k < gs) a0 += M[(size_t)r + (size_t)k * gs] * v[k];
+  }
+  if (grp < np && grp < 8) part[grp][r] = a0 + a1;
+  __syncthreads();
+  double y = 0.0;
+  if (grp == 0 && r < gs)
+    for (int q = 0; q < min(np, 8); ++q) y += part[q][r];
+  __syncthreads();
+  return y;
+}
+// y[r] = sum_k M[k + r gs] v[k] (the transposed block): a wave per row, lanes along k (contiguous), shuffle reduction; the
+// rows r = wave, wave + nwaves, ...  Result of row r in out[r] (LDS), complete after the barrier.
+__device__ __forceinline__ void bcr_matvec_t(const double* __restrict__ M, const double* __restrict__ v, int gs, double* out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int r = wave; r < gs; r += nw) {
+    double a = 0.0;
+    for (int k = lane; k < gs; k += 64) a += M[(size_t)k + (size_t)r * gs] * v[k];
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+    if (lane == 0) out[r] = a;
+  }
+  __syncthreads();
+}
+
 // solve, forward part of a level: phase 0: u_i = inv_i b_i (kept in w); phase 1: b_{i-s} -= Klo_i^T u_i;
-// phase 2: b_{i+s} -= Kup_i u_i.  One workgroup per eliminated block, thread = row.
+// phase 2: b_{i+s} -= Kup_i u_i.  One workgroup per eliminated block.
 __global__ __launch_bounds__(512) void k_bcr_fwd(int gs, int G, BcrLevel lv, int phase, const double* __restrict__ inv,
                                                  const double* __restrict__ Klo, const double* __restrict__ Kup,
                                                  double* __restrict__ b, double* __restrict__ w) {
+  __shared__ double part[8][512];
   const int i = lv.elim[blockIdx.x], s = lv.s, r = threadIdx.x;
   const size_t g2 = (size_t)gs * gs;
-  if (r >= gs) return;
   if (phase == 0) {
-    const double* I = inv + (size_t)i * g2;
-    const double* bi = b + (size_t)i * gs;
-    double a = 0.0;
-    for (int k = 0; k < gs; ++k) a += I[(size_t)r + (size_t)k * gs] * bi[k];
-    w[(size_t)i * gs + r] = a;
+    const double a = bcr_matvec(inv + (size_t)i * g2, b + (size_t)i * gs, gs, part);
+    if (r < gs) w[(size_t)i * gs + r] = a;
   } else if (phase == 1) {
     if (!lv.lo || i - s < 0) return;
-    const double* K = Klo + (size_t)i * g2;
-    const double* u = w + (size_t)i * gs;
-    double a = 0.0;
-    for (int k = 0; k < gs; ++k) a += K[(size_t)k + (size_t)r * gs] * u[k];
-    b[(size_t)(i - s) * gs + r] -= a;
+    bcr_matvec_t(Klo + (size_t)i * g2, w + (size_t)i * gs, gs, part[0]);
+    if (r < gs) b[(size_t)(i - s) * gs + r] -= part[0][r];
   } else {
     if (i + s >= G) return;
-    const double* U = Kup + (size_t)i * g2;
-    const double* u = w + (size_t)i * gs;
-    double a = 0.0;
-    for (int k = 0; k < gs; ++k) a += U[(size_t)r + (size_t)k * gs] * u[k];
-    b[(size_t)(i + s) * gs + r] -= a;
+    const double a = bcr_matvec(Kup + (size_t)i * g2, w + (size_t)i * gs, gs, part);
+    if (r < gs) b[(size_t)(i + s) * gs + r] -= a;
   }
 }
 
@@ -2369,21 +2394,13 @@ __global__ __launch_bounds__(512) void k_bcr_fwd(int gs, int G, BcrLevel lv, int
 __global__ __launch_bounds__(512) void k_bcr_bwd(int gs, int G, BcrLevel lv, const double* __restrict__ Ylo,
                                                  const double* __restrict__ Yup, const double* __restrict__ w,
                                                  double* __restrict__ x) {
+  __shared__ double part[8][512];
   const int i = lv.elim[blockIdx.x], s = lv.s, r = threadIdx.x;
   const size_t g2 = (size_t)gs * gs;
-  if (r >= gs) return;
-  double a = w[(size_t)i * gs + r];
-  if (lv.lo && i - s >= 0) {
-    const double* Y = Ylo + (size_t)i * g2;
-    const double* xs = x + (size_t)(i - s) * gs;
-    for (int k = 0; k < gs; ++k) a -= Y[(size_t)r + (size_t)k * gs] * xs[k];
-  }
-  if (i + s < G) {
-    const double* Y = Yup + (size_t)i * g2;
-    const double* xs = x + (size_t)(i + s) * gs;
-    for (int k = 0; k < gs; ++k) a -= Y[(size_t)r + (size_t)k * gs] * xs[k];
-  }
-  x[(size_t)i * gs + r] = a;
+  double a = (r < gs) ? w[(size_t)i * gs + r] : 0.0;
+  if (lv.lo && i - s >= 0) a -= bcr_matvec(Ylo + (size_t)i * g2, x + (size_t)(i - s) * gs, gs, part);
+  if (i + s < G) a -= bcr_matvec(Yup + (size_t)i * g2, x + (size_t)(i + s) * gs, gs, part);
+  if (r < gs) x[(size_t)i * gs + r] = a;
 }
 
 __global__ __launch_bounds__(256) void k_bcr_rhs(int n, const double* rc, const double* rs, double* b) {
