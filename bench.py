@@ -39,7 +39,10 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_MFMA_PEAK_TF = 78.6    # MI355X public spec for fp64 matrix (= fp64 vector) throughput, SURVEY 8d
 WORKLOADS = {'C3': (1024, 1000, 4, 200), 'C2': (64, 400, 4, 100),
              # BASELINE.json configs[3]: 512 time blocks x ~4k variables, n_s = 49 states, banded coupling (block-tridiagonal S)
-             'C4': (512, 49, 2, 40)}
+             'C4': (512, 49, 2, 40),
+             # BASELINE.json configs[4]: 4096 scenarios x 19 000 rows per KKT block, 1000 coupling variables (meant for 8 GPUs;
+             # --blocks 512 is one rank's share)
+             'C5': (4096, 2000, 4, 1000)}
 
 
 def parse_args():
@@ -85,15 +88,18 @@ def survey_bytes_per_block(z_K, z_L, n_i, n_c, z_A):
     return {'factor': b_fac, 'schur': b_sc, 'back_solve': b_bs, 'total': b_fac + b_sc + b_bs}
 
 
-def build_bytes_per_block(st, ex, n_c, batch):
+def build_bytes_per_block(st, ex, n_c, batch, fused_sources=True):
     """What THIS implementation has to move per block and iteration if every operand crossed HBM exactly once: values
     only -- the index data (task records, entry lists) is shared by all instances of a pattern group and amortised
-    over the batch.  U and L panels are both stored (2 z_L); the Schur kernel reads only the coupling rows."""
+    over the batch.  U and L panels are both stored (2 z_L); the Schur kernel reads only the coupling rows.  With the
+    producer's source arrays read by the leaf kernels themselves (the default for a DeviceBlockMatrix) there is no
+    assembly pass: the factorisation reads the nsrc source values instead of an assembled copy."""
     z_L, n = st['u_doubles'], st['n']
     idx = ex['index_bytes'] / max(1, batch)
     b = {
-        'assemble': 8.0 * (ex['nsrc'] + ex['raw_used']),
-        'factor_levels': 8.0 * (ex['raw_used'] + 2 * z_L + 2 * z_L + ex['dinv_doubles'] + 2 * ex['tm_doubles']) + idx,
+        'assemble': 0.0 if fused_sources else 8.0 * (ex['nsrc'] + ex['raw_used']),
+        'factor_levels': 8.0 * ((ex['nsrc'] if fused_sources else ex['raw_used']) + 2 * z_L + 2 * z_L
+                                + ex['dinv_doubles'] + 2 * ex['tm_doubles']) + idx,
         'schur_tiles': 8.0 * (2 * ex['coupling_entries']) + 8.0 * n_c * n_c * ex['nchunk'] / max(1, batch),
         'fwd_levels': 8.0 * (2 * n + ex['fwd_entries'] + 2 * n),
         'fwd_coupling': 8.0 * (ex['crow_entries'] + n),
@@ -352,8 +358,9 @@ def main():
     z_L = st['u_doubles']
     nc_blk = st['n_coupling']
     sb = survey_bytes_per_block(z_K, z_L, st['n'], nc_blk, nc_blk)
-    bb = build_bytes_per_block(st, ex, nc_blk, B)
-    survey_phase = {'assemble': 8.0 * (ex['nsrc'] + ex['raw_used']), 'factor_levels': float(sb['factor']),
+    fused = phases.get('assemble', {}).get('launches_per_step', 0) == 0     # no assembly kernel ran
+    bb = build_bytes_per_block(st, ex, nc_blk, B, fused_sources=fused)
+    survey_phase = {'assemble': bb['assemble'], 'factor_levels': float(sb['factor']),
                     'schur_tiles': float(sb['schur']), 'fwd_levels': sb['back_solve'] / 2.0,
                     'bwd_levels': sb['back_solve'] / 2.0}
     roofline = None
@@ -375,7 +382,7 @@ def main():
             traffic = None
         per_phase = {}
         for p in phases:
-            if p in bb and phases[p]['ms_per_step'] > 0:
+            if bb.get(p, 0) > 0 and phases[p]['ms_per_step'] > 0:
                 gbps = bb[p] * B / (phases[p]['ms_per_step'] * 1e-3) / 1e9
                 per_phase[p] = {'GBps_build_model': gbps, 'frac': gbps / HBM_PEAK_GBS}
         roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -428,6 +435,8 @@ def main():
             'boundary_host': boundary,
             'device_only': device_only,
             'value_storage_bytes': {'device_resident_path': mem_now, 'with_host_input_and_output_copies': mem_max},
+            'bcr_block_paths': (dict(zip(('unpivoted_ldl_on_matrix_cores', 'bunch_kaufman'), eng.bcr_block_paths()))
+                                if solver._btd is not None else None),
         }
         print(json.dumps(out))
     if world > 1:

@@ -222,6 +222,11 @@ int pp_set_memory_budget(pp_handle h, int64_t bytes);
 int pp_memory_info(pp_handle h, int64_t out[3]);
 /* Blocks until the handle's stream is idle. */
 int pp_synchronize(pp_handle h);
+/* Block-tridiagonal S (time-staged problems; the reference hands the sparse S to its sub-solver, mpi_...:352-361, whose
+ * pivoting is MA27's threshold test, ma27_interface.py:36-47): after pp_factor_schur, out = {diagonal blocks of the cyclic
+ * reduction inverted from an unpivoted LDL^T whose multipliers all passed the threshold test, blocks left to
+ * Bunch-Kaufman}.  Diagnostic (synchronises the stream); {0, 0} when S is dense. */
+int pp_bcr_block_paths(pp_handle h, int32_t out[2]);
 
 /* Phase timing with HIP events on the handle's stream (measurement only, SURVEY.md section 5.1
  * timer labels): pp_profile(h, 1) resets and enables, pp_phase_times returns accumulated

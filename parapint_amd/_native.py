@@ -86,6 +86,7 @@ SIGNATURES = {
     'pp_increase_memory_allocation': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double]),
     'pp_set_memory_budget': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64]),
     'pp_memory_info': (ctypes.c_int, [ctypes.c_void_p, _i64p]),
+    'pp_bcr_block_paths': (ctypes.c_int, [ctypes.c_void_p, _i32p]),
     'pp_synchronize': (ctypes.c_int, [ctypes.c_void_p]),
     'pp_profile': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'pp_phase_times': (ctypes.c_int, [ctypes.c_void_p, _f64p, _i32p, _i32p]),

@@ -2113,12 +2113,13 @@ __global__ __launch_bounds__(256) void k_btd_init(size_t n, const double* __rest
 // in_lds: the block is factorised in LDS (gs * gs doubles of dynamic shared memory: every one of the gs pivot steps is
 // a handful of LDS round trips instead of global-memory ones) and copied back
 __global__ __launch_bounds__(BK_THREADS) void k_bcr_factor(int gs, BcrLevel lv, double* D, int* ipiv, double* work, int* info,
-                                                           int in_lds) {
+                                                           int in_lds, int skip_accepted) {
   extern __shared__ __attribute__((aligned(16))) double shD[];
   __shared__ double sv[16];
   __shared__ int si[16];
   __shared__ pp::BkInfo sbi;
   const int i = lv.elim[blockIdx.x];
+  if (skip_accepted && info[4 * i + 3] == 1) return;      // inverted by k_bcr_ldl_inverse
   double* Dg = D + (size_t)i * gs * gs;
   double* A = Dg;
   double* wk = work + (size_t)blockIdx.x * 2 * gs;
@@ -2137,7 +2138,7 @@ __global__ __launch_bounds__(BK_THREADS) void k_bcr_factor(int gs, BcrLevel lv, 
     TeamCtx ctx{sv, si};
     pp::bk_factor(ctx, gs, A, gs, ipiv + (size_t)i * gs, wk, &sbi, BK_EPS);
   }
-  if (threadIdx.x == 0) { info[4 * i] = sbi.npos; info[4 * i + 1] = sbi.nneg; info[4 * i + 2] = sbi.nzero; }
+  if (threadIdx.x == 0) { info[4 * i] = sbi.npos; info[4 * i + 1] = sbi.nneg; info[4 * i + 2] = sbi.nzero; info[4 * i + 3] = 0; }
 }
 
 // column j of inv(D_i): Bunch-Kaufman solve of the unit vector e_j (one workgroup per column and block)
@@ -2158,11 +2159,12 @@ __global__ __launch_bounds__(128) void k_bcr_invert(int gs, BcrLevel lv, const d
 // 350 -> 202 us per level; with the factored block in LDS as well -- 16 columns per workgroup, 89 KB -- 220 us: a step is a
 // chain of dependent accesses either way, and the smaller footprint keeps twice as many waves on a CU.)
 __global__ __launch_bounds__(256) void k_bcr_invert_wave(int gs, BcrLevel lv, const double* __restrict__ D, const int* __restrict__ ipiv,
-                                                         double* __restrict__ inv) {
+                                                         double* __restrict__ inv, const int* __restrict__ accepted) {
   extern __shared__ __attribute__((aligned(16))) double shv[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lv.elim[blockIdx.y], c = (int)blockIdx.x * 4 + wave;
   if (c >= gs) return;
+  if (accepted && accepted[4 * i + 3] == 1) return;       // inverted by k_bcr_ldl_inverse
   double* b = shv + (size_t)wave * gs;
   for (int r = lane; r < gs; r += 64) b[r] = (r == c) ? 1.0 : 0.0;
   WaveCtx ctx;
@@ -2170,6 +2172,242 @@ __global__ __launch_bounds__(256) void k_bcr_invert_wave(int gs, BcrLevel lv, co
   pp::bk_solve(ctx, gs, D + (size_t)i * gs * gs, gs, ipiv + (size_t)i * gs, b);
   double* col = inv + (size_t)i * gs * gs + (size_t)c * gs;
   for (int r = lane; r < gs; r += 64) col[r] = b[r];
+}
+
+// Fast path of the two kernels above for gs <= 16 * BL_NT: UNPIVOTED blocked LDL^T of D_i on the matrix cores with the
+// whole block in LDS, followed by the explicit inverse from that factor -- one launch per level instead of a
+// Bunch-Kaufman factorisation (gs pivot searches, each a workgroup reduction) and gs wave-level solves.
+//   acceptance (else the block is left to k_bcr_factor / k_bcr_invert_wave, which skip accepted blocks): no pivot below
+//   BK_EPS * max|diagonal| and no multiplier above `lbound` in magnitude -- the 1 x 1 pivots then satisfy the threshold
+//   test |d_k| >= max_i |a_ik| / lbound of the reference's sub-solver (MA27's u, ma27_interface.py:36-47); the blocks of
+//   a time-staged S are quasi-definite ([-P1 *; * P2], link duals and coupling states), which an LDL^T without
+//   interchanges factorises for any ordering.  Pivot signs give the inertia (Haynsworth, as before).
+//   tiles: 16 x 16, row stride BL_LD, tile (I, J), I >= J, at (I (I + 1) / 2 + J) * BL_TILE; T holds A then L, Z = inv(L)
+//   phase 1  right-looking LDL^T: diagonal tile in the registers of wave 0 (DiagSteps), panel rows one per thread
+//            (PanelSolveCols), trailing tiles T(I,J) -= (L_Ip D_p) L_Jp^T by fp64 MFMA, operands and result in LDS
+//   phase 2  Z = inv(L): diagonal tiles by column substitution (lane = column), then by block diagonals t = I - J:
+//            Z_IJ = -Z_II sum_{J <= K < I} L_IK Z_KJ  (the MFMA result layout of the sum IS the operand layout of the second product)
+//   phase 3  inv(D_i) = Z^T D^-1 Z, tile (I, J) = sum_{K >= I} Z_KI^T D_K^-1 Z_KJ, written to both triangles
+constexpr int BL_NT = 7;
+constexpr int BL_LD = 18;
+constexpr int BL_TILE = 16 * BL_LD;
+constexpr int BL_NTT = BL_NT * (BL_NT + 1) / 2;
+constexpr int BL_THREADS = 512;
+constexpr size_t BL_LDS_BYTES = 2 * (size_t)BL_NTT * BL_TILE * sizeof(double);
+
+// C[i][j] += sum_k a(i, k) b(k, j) over one 16-wide k block: av[q] = a(li, 4 q + lk), bv[q] = b(4 q + lk, li);
+// the result register r of lane (li, lk) is C[lk + 4 r][li]
+__device__ __forceinline__ double4_t bl_mma(const double (&av)[4], const double (&bv)[4], double4_t acc) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
+  return acc;
+}
+
+__global__ __launch_bounds__(BL_THREADS) void k_bcr_ldl_inverse(int gs, BcrLevel lv, const double* __restrict__ D,
+                                                                double* __restrict__ inv, int* __restrict__ info, double eps,
+                                                                double lbound) {
+  extern __shared__ __attribute__((aligned(16))) double blsh[];
+  double* T = blsh;
+  double* Z = blsh + (size_t)BL_NTT * BL_TILE;
+  __shared__ double dl[16 * BL_NT], rdl[16 * BL_NT], dmag[16 * BL_NT];
+  __shared__ double red[BL_THREADS / 64];
+  __shared__ int sflags[2], orig[16 * BL_NT];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = BL_THREADS / 64;
+  const int li = lane & 15, lk = lane >> 4;
+  const int i = lv.elim[blockIdx.x];
+  const double* Dg = D + (size_t)i * gs * gs;
+  const int nt = (gs + 15) / 16, ntt = nt * (nt + 1) / 2;
+  // ---- symmetric pre-ordering by decreasing |diagonal| (static, from the values of this factorisation: the coupling
+  // states of a time-staged S carry O(1) diagonals, the link duals nearly none -- states first makes every pivot of
+  // the quasi-definite block its column's largest entry; the acceptance test below judges the result)
+  for (int k = tid; k < 16 * BL_NT; k += BL_THREADS) {
+    dmag[k] = (k < gs) ? fabs(Dg[(size_t)k + (size_t)k * gs]) : -1.0;
+    orig[k] = k;          // (a NaN diagonal leaves ranks unassigned: the identity keeps every index valid, the pivot test rejects)
+  }
+  if (tid == 0) { sflags[0] = 0; sflags[1] = 0; }
+  __syncthreads();
+  double loc = 0.0;
+  for (int k = tid; k < 16 * BL_NT; k += BL_THREADS) {
+    int rank = k;
+    if (k < gs) {
+      const double mk = dmag[k];
+      rank = 0;
+      for (int j = 0; j < gs; ++j) rank += (dmag[j] > mk || (dmag[j] == mk && j < k)) ? 1 : 0;
+      loc = mk;
+    }
+    orig[rank] = k;
+  }
+  for (int off = 32; off > 0; off >>= 1) loc = fmax(loc, __shfl_xor(loc, off));
+  if (lane == 0) red[wv] = loc;
+  __syncthreads();
+  double anorm = 0.0;
+  for (int q = 0; q < nwv; ++q) anorm = fmax(anorm, red[q]);
+  // ---- load: lower tiles (diagonal tiles in full, mirrored from the lower triangle), identity padding
+  for (int idx = tid; idx < ntt * 256; idx += BL_THREADS) {
+    const int t = idx >> 8, e = idx & 255, r = e & 15, c = e >> 4;
+    int I = 0;
+    while ((I + 1) * (I + 2) / 2 <= t) ++I;
+    const int J = t - I * (I + 1) / 2;
+    const int gr = 16 * I + r, gc = 16 * J + c;
+    double v = (gr == gc) ? 1.0 : 0.0;
+    if (gr < gs && gc < gs) {
+      const int o_r = orig[gr], o_c = orig[gc];
+      v = Dg[(size_t)max(o_r, o_c) + (size_t)min(o_r, o_c) * gs];
+    }
+    T[(size_t)t * BL_TILE + r * BL_LD + c] = v;
+  }
+  __syncthreads();
+  // ---- phase 1
+  for (int p = 0; p < nt; ++p) {
+    double* Tpp = T + (size_t)(p * (p + 1) / 2 + p) * BL_TILE;
+    const int nb = min(16, gs - 16 * p), m = 16 * (nt - p - 1);
+    if (wv == 0) {
+      double row[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) row[j] = Tpp[li * BL_LD + j];
+      int bad = 0, signs = 0;
+      double d = mov_row_bcast<0>(row[0]);
+      if (!(fabs(d) > eps * anorm)) { bad = 1; d = (anorm > 0.0 ? anorm : 1.0); }
+      double rd = fast_rcp(d);
+      DiagSteps<0>::run(row, d, rd, bad, signs, nb, eps * anorm, anorm, dl + 16 * p, rdl + 16 * p, lane);
+      bool big = false;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) big = big || (j < li && !(fabs(row[j]) <= lbound));
+      if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) Tpp[lane * BL_LD + j] = row[j];
+      }
+      if (bad || big) sflags[0] = 1;
+    }
+    lds_barrier();
+    if (64 * wv < m) {        // W = A21 L11^{-T} (thread = row of the panel), L21 = W D^-1
+      const int r = min(tid, m - 1);
+      double* Trow = T + (size_t)((p + 1 + (r >> 4)) * (p + 2 + (r >> 4)) / 2 + p) * BL_TILE + (r & 15) * BL_LD;
+      double lrow[16], wrow[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { lrow[k] = Tpp[li * BL_LD + k]; wrow[k] = Trow[k]; }
+      PanelSolveCols<0>::run(wrow, lrow);
+      bool big = false;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        wrow[k] *= rdl[16 * p + k];
+        big = big || !(fabs(wrow[k]) <= lbound);
+      }
+      if (tid < m) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) Trow[k] = wrow[k];
+        if (big) sflags[0] = 1;
+      }
+    }
+    lds_barrier();
+    const int q1 = nt - p - 1, cnt = q1 * (q1 + 1) / 2;
+    for (int idx = wv; idx < cnt; idx += nwv) {
+      int Ir = 0;
+      while ((Ir + 1) * (Ir + 2) / 2 <= idx) ++Ir;
+      const int I = p + 1 + Ir, J = p + 1 + idx - Ir * (Ir + 1) / 2;
+      const double* TIp = T + (size_t)(I * (I + 1) / 2 + p) * BL_TILE;
+      const double* TJp = T + (size_t)(J * (J + 1) / 2 + p) * BL_TILE;
+      double* TIJ = T + (size_t)(I * (I + 1) / 2 + J) * BL_TILE;
+      double av[4], bv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = 4 * q + lk;
+        av[q] = -TIp[li * BL_LD + k] * dl[16 * p + k];
+        bv[q] = TJp[li * BL_LD + k];
+      }
+      double4_t acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = TIJ[(lk + 4 * r) * BL_LD + li];
+      acc = bl_mma(av, bv, acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) TIJ[(lk + 4 * r) * BL_LD + li] = acc[r];
+    }
+    lds_barrier();
+  }
+  const bool ok = sflags[0] == 0;
+  if (!ok) {                                   // left to the pivoted kernels
+    if (tid == 0) info[4 * i + 3] = 0;
+    return;
+  }
+  // ---- phase 2: diagonal tiles of Z
+  if (wv < nt) {
+    const double* Lt = T + (size_t)(wv * (wv + 1) / 2 + wv) * BL_TILE;
+    double z[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = (r == li) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < 15; ++k) {
+#pragma unroll
+      for (int r = k + 1; r < 16; ++r) z[r] -= Lt[r * BL_LD + k] * z[k];
+    }
+    if (lane < 16) {
+      double* Zt = Z + (size_t)(wv * (wv + 1) / 2 + wv) * BL_TILE;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Zt[r * BL_LD + lane] = z[r];
+    }
+  }
+  lds_barrier();
+  for (int t = 1; t < nt; ++t) {
+    const int I = t + wv, J = wv;
+    if (I < nt) {
+      double4_t R = {0.0, 0.0, 0.0, 0.0};
+      for (int K = J; K < I; ++K) {
+        const double* TIK = T + (size_t)(I * (I + 1) / 2 + K) * BL_TILE;
+        const double* ZKJ = Z + (size_t)(K * (K + 1) / 2 + J) * BL_TILE;
+        double av[4], bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          av[q] = TIK[li * BL_LD + 4 * q + lk];
+          bv[q] = ZKJ[(4 * q + lk) * BL_LD + li];
+        }
+        R = bl_mma(av, bv, R);
+      }
+      const double* ZII = Z + (size_t)(I * (I + 1) / 2 + I) * BL_TILE;
+      double av[4], bv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { av[q] = -ZII[li * BL_LD + 4 * q + lk]; bv[q] = R[q]; }
+      double4_t zz = {0.0, 0.0, 0.0, 0.0};
+      zz = bl_mma(av, bv, zz);
+      double* ZIJ = Z + (size_t)(I * (I + 1) / 2 + J) * BL_TILE;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ZIJ[(lk + 4 * r) * BL_LD + li] = zz[r];
+    }
+    lds_barrier();
+  }
+  // ---- phase 3
+  double* X = inv + (size_t)i * gs * gs;
+  for (int t = wv; t < ntt; t += nwv) {
+    int I = 0;
+    while ((I + 1) * (I + 2) / 2 <= t) ++I;
+    const int J = t - I * (I + 1) / 2;
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+    for (int K = I; K < nt; ++K) {
+      const double* ZKI = Z + (size_t)(K * (K + 1) / 2 + I) * BL_TILE;
+      const double* ZKJ = Z + (size_t)(K * (K + 1) / 2 + J) * BL_TILE;
+      double av[4], bv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = 4 * q + lk;
+        av[q] = ZKI[k * BL_LD + li] * rdl[16 * K + k];
+        bv[q] = ZKJ[k * BL_LD + li];
+      }
+      acc = bl_mma(av, bv, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * I + lk + 4 * r, col = 16 * J + li;
+      if (row < gs && col < gs) {
+        const int o_r = orig[row], o_c = orig[col];
+        X[(size_t)o_r + (size_t)o_c * gs] = acc[r];
+        if (I != J) X[(size_t)o_c + (size_t)o_r * gs] = acc[r];
+      }
+    }
+  }
+  if (tid == 0) {
+    int npos = 0, nneg = 0;
+    for (int k = 0; k < gs; ++k) { npos += dl[k] > 0.0; nneg += dl[k] < 0.0; }     // (positions < gs are the block's own rows)
+    info[4 * i] = npos; info[4 * i + 1] = nneg; info[4 * i + 2] = 0; info[4 * i + 3] = 1;
+  }
 }
 
 // Klo_i = S(i, i-s) = slot(i-s)^T ... kept as the slot itself: Klo[i] = slot[i-s] (= S(i, i-s), rows of block i);
@@ -2844,7 +3082,8 @@ struct pp_solver {
   int *btd_ipiv = nullptr, *btd_info = nullptr, *scatter_err = nullptr, *btd_elim = nullptr;
   std::vector<int> bcr_off, bcr_ne, bcr_s, bcr_lo;   // per level: offset into btd_elim, eliminated blocks, stride, lower neighbour live
   int btd_sequential = 0;
-  bool bcr_lds_attr = false;
+  bool bcr_lds_attr = false, bcr_ldl_attr = false;
+  double bcr_lbound = 100.0;     // largest multiplier the unpivoted block factorisation of the cyclic reduction accepts (1 / u, u = 0.01)
   double growth_bound = 1e8;     // 1 / u_rt: a factor entry beyond it flags its instance
   bool growth_fatal = false;     // flagged instances make the factorisation report status 2 (else they are only counted)
   double pivot_threshold = 0.0;  // symbolic-time threshold u for groups added afterwards (0: plan default)
@@ -3829,7 +4068,7 @@ int pp_numeric_factor_blocks(pp_handle h) {
     }
     GroupDev d = d0;
     {
-      PhaseScope ps(h, 0, 1);
+      PhaseScope ps(h, 0, fused_sources ? 0 : 1);
       if (g->input_mode == Group::IN_SOURCES && (!g->src || !g->map_src))
         return fail(h, 3, "pp_numeric_factor_blocks: no value map / source buffer");
       if (fused_sources) {
@@ -4037,7 +4276,7 @@ int pp_factor_schur(pp_handle h, const double* Q_host) {
     const int gs = h->gs, G = h->G;
     const size_t g2 = (size_t)gs * gs;
     const int nlev = (int)h->bcr_ne.size();
-    PhaseScope ps(h, 3, 2 + 5 * nlev);
+    PhaseScope ps(h, 3, 2 + 6 * nlev);
     hipLaunchKernelGGL(k_btd_init, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, nn, h->S, Q_host ? h->Qd : (const double*)nullptr,
                        h->btd_fac);
     double* D = h->btd_fac;
@@ -4056,14 +4295,28 @@ int pp_factor_schur(pp_handle h, const double* Q_host) {
     }
     if (std::getenv("PP_BCR_NO_LDS")) lds_bytes = 0;
     const bool bcr_mfma = std::getenv("PP_NO_BCR_MFMA") == nullptr;    // block products on the matrix cores, wave-level inverse (measurement switch)
+    // unpivoted LDL^T + inverse of the blocks on the matrix cores, Bunch-Kaufman only for the blocks it rejects
+    // (PP_NO_BCR_LDL: measurement switch; needs the matrix-core products for the rest of the level and gs <= 112)
+    bool bcr_ldl = bcr_mfma && gs <= 16 * BL_NT && std::getenv("PP_NO_BCR_LDL") == nullptr;
+    if (bcr_ldl && !h->bcr_ldl_attr) {
+      if (hipFuncSetAttribute((const void*)k_bcr_ldl_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BL_LDS_BYTES) != hipSuccess) {
+        (void)hipGetLastError();
+        bcr_ldl = false;
+      } else {
+        h->bcr_ldl_attr = true;
+      }
+    }
     int bk_threads = 256;        // (measured at C4, gs = 98, S phase per step: 64 threads 15.3 ms, 128 12.1, 256 10.8, 512 11.0)
     if (const char* e = std::getenv("PP_BCR_THREADS")) bk_threads = std::max(64, std::min(BK_THREADS, std::atoi(e)));
     for (int l = 0; l < nlev; ++l) {
       const BcrLevel lv{h->btd_elim + h->bcr_off[(size_t)l], h->bcr_ne[(size_t)l], h->bcr_s[(size_t)l], h->bcr_lo[(size_t)l]};
+      if (bcr_ldl)
+        hipLaunchKernelGGL(k_bcr_ldl_inverse, dim3(lv.ne), dim3(BL_THREADS), BL_LDS_BYTES, st, gs, lv, D, h->btd_inv, h->btd_info, BK_EPS,
+                           h->bcr_lbound);
       hipLaunchKernelGGL(k_bcr_factor, dim3(lv.ne), dim3(bk_threads), lds_bytes, st, gs, lv, D, h->btd_ipiv, h->btd_vec, h->btd_info,
-                         lds_bytes > 0 ? 1 : 0);
+                         lds_bytes > 0 ? 1 : 0, bcr_ldl ? 1 : 0);
       if (bcr_mfma) hipLaunchKernelGGL(k_bcr_invert_wave, dim3((gs + 3) / 4, lv.ne), dim3(256), 4 * (size_t)gs * sizeof(double), st, gs, lv, D,
-                                       h->btd_ipiv, h->btd_inv);
+                                       h->btd_ipiv, h->btd_inv, bcr_ldl ? h->btd_info : (const int*)nullptr);
       else hipLaunchKernelGGL(k_bcr_invert, dim3(gs, lv.ne), dim3(128), 0, st, gs, lv, D, h->btd_ipiv, h->btd_inv);
       if (l + 1 < nlev) {
         if (bcr_mfma) {
@@ -4556,6 +4809,18 @@ int pp_memory_info(pp_handle h, int64_t out[3]) {
     }
   }
   out[2] = allocated;
+  return 0;
+}
+
+int pp_bcr_block_paths(pp_handle h, int32_t out[2]) {
+  if (!h) return 3;
+  out[0] = out[1] = 0;
+  if (!h->btd || !h->schur_done || !h->btd_info) return 0;
+  PP_HIP(hipSetDevice(h->device));
+  std::vector<int> info(4 * (size_t)h->G);
+  PP_HIP(hipMemcpyAsync(info.data(), h->btd_info, info.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  PP_HIP(hipStreamSynchronize(h->stream));
+  for (int t = 0; t < h->G; ++t) out[info[4 * (size_t)t + 3] == 1 ? 0 : 1] += 1;
   return 0;
 }
 

@@ -445,6 +445,15 @@ class HipEngine(object):
                       'pp_memory_info')
         return int(out[0]), int(out[1]), int(out[2])
 
+    def bcr_block_paths(self):
+        """Block-tridiagonal S: (diagonal blocks inverted from the unpivoted LDL^T, blocks left to Bunch-Kaufman) of the
+        last factorisation of S; (0, 0) for a dense S.  Diagnostic, synchronises."""
+        import ctypes
+        out = np.zeros(2, dtype=np.int32)
+        self.ns.check(self.lib.pp_bcr_block_paths(self.ns.h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))),
+                      'pp_bcr_block_paths')
+        return int(out[0]), int(out[1])
+
     def allreduce_schur(self, comm):
         if comm.size > 1 or getattr(comm, 'always_reduce', False):
             if comm.device_collectives:

@@ -550,6 +550,9 @@ def test_dynamic_time_blocks_block_tridiagonal_schur():
     solver, model = sc.case_dynamic(make_engine, 64, 49, n_u=2, nfe=4, expect_block_tridiagonal=True)
     gs, G = solver._btd
     assert gs == 2 * 49 and G == 63 and not solver._btd_sequential       # blocks (rho_t, z_t), cyclic reduction
+    fast, pivoted = solver._eng.bcr_block_paths()
+    assert fast + pivoted == G
+    assert fast > 0          # quasi-definite blocks: the unpivoted matrix-core factorisation passes its threshold test
 
 
 @pytest.mark.parametrize('dense_limit', [None, 8])
@@ -583,4 +586,11 @@ def test_measurement_switches_select_paths_that_agree():
             "sc.case_dynamic(lambda: HipEngine(), 64, 49, n_u=2, nfe=4, expect_block_tridiagonal=True)\n"
             "print('dynamic ok')\n") % (root, os.path.join(root, 'tests'))
     out = subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert out.returncode == 0 and 'dynamic ok' in out.stdout.decode(), out.stdout.decode()[-3000:]
+    # the cyclic reduction with every diagonal block left to Bunch-Kaufman (the path a block takes when the unpivoted
+    # factorisation rejects it), matrix-core products for the rest
+    env2 = dict(os.environ, PP_NO_BCR_LDL='1', PYTHONPATH=env['PYTHONPATH'])
+    code2 = code.replace("print('dynamic ok')", "s = sc.case_dynamic(lambda: HipEngine(), 64, 49, n_u=2, nfe=4, expect_block_tridiagonal=True)[0]\n"
+                                               "assert s._eng.bcr_block_paths() == (0, 63)\nprint('dynamic ok')")
+    out = subprocess.run([sys.executable, '-c', code2], env=env2, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     assert out.returncode == 0 and 'dynamic ok' in out.stdout.decode(), out.stdout.decode()[-3000:]
