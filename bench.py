@@ -304,7 +304,7 @@ def main():
     ok = ok and resid <= 1e-8 and res.status == LinearSolverStatus.successful and tuple(inertia) == expected_inertia
 
     # ---- (3) device only: the same kernels driven through the C ABI without the Python class
-    qflat = solver._btd_q(dkkt.Q) if solver._btd is not None else None
+    qcorner = solver._btd_corner(dkkt.Q) if solver._btd is not None else None
     qdense = None if (dkkt.Q is None or solver._btd is not None) else (dkkt.Q.toarray() if hasattr(dkkt.Q, 'toarray') else dkkt.Q)
 
     def raw_step(k):
@@ -313,7 +313,7 @@ def main():
         eng.numeric_local()
         eng.allreduce_schur(comm)
         if solver._btd is not None:
-            eng.factor_schur_flat(qflat)
+            eng.factor_schur_corner(*qcorner)
         else:
             eng.factor_schur(qdense)
         status = eng.status()

@@ -148,6 +148,11 @@ int pp_bind_schur_buffer(pp_handle h, double* dev_ptr);
 /* S = S_allreduced + Q, dense Bunch-Kaufman LDL^T of S, inertia(S)  (mpi_...:347-361).
  * Q: dense column-major n_c x n_c on the host (lower triangle read), or NULL for Q = 0. */
 int pp_factor_schur(pp_handle h, const double* Q_host);
+/* The same for a block-tridiagonal S (time-staged problems: the reference keeps S and the coupling block sparse,
+ * mpi_...:88-125, 228-255, sc_ip_interface.py:308-357), Q as nnz (position in the layout of the Schur buffer, value)
+ * pairs on the host; duplicates add.  The pairs are uploaded on a stream of their own -- the call does not wait for the
+ * block factorisation still running on the handle's stream -- and the arrays may be reused when it returns. */
+int pp_factor_schur_corner(pp_handle h, int64_t nnz, const int64_t* pos, const double* val);
 
 /* Block pivots (supernodes) for groups added afterwards: sub-pivot chains of the elimination tree
  * are merged up to `wmax` columns (1 = off, at most 4) when at most `tol_rows` padded rows result;

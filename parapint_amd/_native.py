@@ -66,6 +66,7 @@ SIGNATURES = {
     'pp_schur_buffer': (ctypes.c_void_p, [ctypes.c_void_p]),
     'pp_bind_schur_buffer': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     'pp_factor_schur': (ctypes.c_int, [ctypes.c_void_p, _f64p]),
+    'pp_factor_schur_corner': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, _i64p, _f64p]),
     'pp_set_supernodes': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     'pp_set_instance_splits': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'pp_set_dense_policy': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),

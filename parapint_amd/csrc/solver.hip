@@ -18,6 +18,9 @@
 
 #include <array>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <map>
 #include <cstdint>
 #include <cstdlib>
@@ -2104,6 +2107,15 @@ __global__ __launch_bounds__(BK_THREADS) void k_bk_factor(int n, const double* _
 // couplings of an eliminated block are copied to Klo / Kup for the solve.
 struct BcrLevel { const int* elim; int ne, s, lo; };   // lo = 0: the lower neighbour i - s is already eliminated (sequential order)
 
+// F[pos[k]] += val[k]: the coupling block Q of a time-staged problem (sc_ip_interface.py:308-357: -I couplings between
+// link duals and coupling states, regularisation on the diagonal) has a few entries per row -- handed over as
+// (position, value) pairs in the layout of the Schur buffer instead of a flat array of that (tens of MB) size
+__global__ __launch_bounds__(256) void k_corner_add(long long nnz, const long long* __restrict__ pos, const double* __restrict__ val,
+                                                    double* __restrict__ F) {
+  const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (k < nnz) atomicAdd(&F[pos[k]], val[k]);
+}
+
 __global__ __launch_bounds__(256) void k_btd_init(size_t n, const double* __restrict__ S, const double* __restrict__ Q,
                                                   double* __restrict__ F) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -2562,12 +2574,18 @@ __global__ __launch_bounds__(64) void k_bcr_update_mfma(int gs, int G, BcrLevel 
   }
 }
 
-__global__ void k_btd_finish(int G, const int* __restrict__ infos, int* __restrict__ bkinfo, const double* __restrict__ tail,
-                             const int* __restrict__ scatter_err, long long* status_out, long long seq) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(256) void k_btd_finish(int G, const int* __restrict__ infos, int* __restrict__ bkinfo,
+                                                    const double* __restrict__ tail, const int* __restrict__ scatter_err,
+                                                    long long* status_out, long long seq) {
+  __shared__ int part[3][4];
+  if (blockIdx.x != 0) return;
   int pos = 0, neg = 0, zero = 0;
-  for (int t = 0; t < G; ++t) { pos += infos[4 * t]; neg += infos[4 * t + 1]; zero += infos[4 * t + 2]; }
-  bkinfo[0] = pos; bkinfo[1] = neg; bkinfo[2] = zero;
+  for (int t = threadIdx.x; t < G; t += 256) { pos += infos[4 * t]; neg += infos[4 * t + 1]; zero += infos[4 * t + 2]; }
+  for (int off = 32; off > 0; off >>= 1) { pos += __shfl_xor(pos, off); neg += __shfl_xor(neg, off); zero += __shfl_xor(zero, off); }
+  if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = pos; part[1][threadIdx.x >> 6] = neg; part[2][threadIdx.x >> 6] = zero; }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  for (int k = 0; k < 3; ++k) bkinfo[k] = part[k][0] + part[k][1] + part[k][2] + part[k][3];
   publish_status(tail, bkinfo, status_out, seq);
   if (scatter_err[0]) { status_out[0] = 3; }
 }
@@ -3057,6 +3075,56 @@ struct Group {
 
 }  // namespace
 
+// Host threads that enqueue the launches of pattern groups side by side (one per auxiliary group stream; the caller's
+// thread takes stream 0).  A time-staged problem issues ~1000 small launches per step over three streams: with one
+// enqueuing thread the step is bound by the host's launch rate on a slow host (15.3 ms through the interface against
+// 10.5 ms of kernels at C4), not by the GPU.  Created at first use, parked on a condition variable in between.
+struct EnqueuePool {
+  std::vector<std::thread> th;
+  std::mutex m;
+  std::condition_variable cv, cv_done;
+  std::function<void(int)> job;
+  long long gen = 0;
+  int nwork = 0, pending = 0;
+  bool stop = false;
+  void worker(int k, int device) {
+    (void)hipSetDevice(device);
+    long long seen = 0;
+    for (;;) {
+      std::function<void(int)> f;
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return stop || (gen != seen && k <= nwork); });
+        if (stop) return;
+        seen = gen;
+        f = job;
+      }
+      f(k);
+      {
+        std::lock_guard<std::mutex> lk(m);
+        if (--pending == 0) cv_done.notify_all();
+      }
+    }
+  }
+  // runs f(0) on the caller and f(1) .. f(n - 1) on workers; returns when all are done
+  void run(int n, int device, const std::function<void(int)>& f) {
+    while ((int)th.size() < n - 1) { const int k = (int)th.size() + 1; th.emplace_back([this, k, device] { worker(k, device); }); }
+    {
+      std::lock_guard<std::mutex> lk(m);
+      job = f; nwork = n - 1; pending = n - 1; ++gen;
+    }
+    cv.notify_all();
+    f(0);
+    std::unique_lock<std::mutex> lk(m);
+    cv_done.wait(lk, [&] { return pending == 0; });
+  }
+  ~EnqueuePool() {
+    { std::lock_guard<std::mutex> lk(m); stop = true; }
+    cv.notify_all();
+    for (std::thread& t : th) t.join();
+  }
+};
+
 struct pp_solver {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -3089,6 +3157,15 @@ struct pp_solver {
   double pivot_threshold = 0.0;  // symbolic-time threshold u for groups added afterwards (0: plan default)
   bool no_fused_sources = std::getenv("PP_NO_FUSED_SOURCES") != nullptr;   // measurement switch: assemble the sources first
   bool schur_mfma = std::getenv("PP_NO_SCHUR_MFMA") == nullptr;   // MFMA form of the Schur update of unmapped groups (measurement switch)
+  bool enqueue_threads = std::getenv("PP_NO_ENQUEUE_THREADS") == nullptr;   // one enqueuing host thread per group stream (measurement switch)
+  EnqueuePool pool;
+  long long* corner_pos = nullptr;      // sparse Q of a block-tridiagonal S: positions in the Schur layout, values
+  double* corner_val = nullptr;
+  size_t corner_cap = 0;
+  hipEvent_t ev_corner_up = nullptr, ev_corner_done = nullptr;
+  hipStream_t up_stream = nullptr;
+  bool corner_used = false;
+  std::mutex alloc_mu, err_mu;
   bool group_streams = std::getenv("PP_NO_GROUP_STREAMS") == nullptr;   // pattern groups side by side on streams of their own (measurement switch)
   bool dense_dpp = std::getenv("PP_NO_DENSE_DPP") == nullptr;           // row broadcasts by DP-ALU DPP in k_ldl_regs (measurement switch)
   bool lane_pairs = std::getenv("PP_NO_LANE_PAIRS") == nullptr;   // two instances per lane in the gather kernels (measurement switch)
@@ -3125,7 +3202,7 @@ size_t schur_doubles(pp_handle h) {
 }
 
 int fail(pp_handle h, int status, const std::string& msg) {
-  if (h) h->err = msg;
+  if (h) { std::lock_guard<std::mutex> lk(h->err_mu); h->err = msg; }
   return status;
 }
 
@@ -3260,6 +3337,26 @@ int join_group_streams(pp_handle h, const GroupStreams& gs) {
   return 0;
 }
 
+// body(gi) for every group: group gi on the thread of its stream (gi mod gs.n) when the groups run side by side
+template <class F>
+int run_groups(pp_handle h, const GroupStreams& gs, const F& body) {
+  const size_t ng = h->groups.size();
+  if (gs.n <= 1 || !h->enqueue_threads) {
+    for (size_t gi = 0; gi < ng; ++gi)
+      if (int rc = body(gi)) return rc;
+    return 0;
+  }
+  int rcs[PP_MAX_SPLIT] = {0};
+  const int n = gs.n;
+  h->pool.run(n, h->device, [&](int k) {
+    for (size_t gi = (size_t)k; gi < ng; gi += (size_t)n)
+      if (int rc = body(gi)) { rcs[k] = rc; break; }
+  });
+  for (int k = 0; k < n; ++k)
+    if (rcs[k]) return rcs[k];
+  return 0;
+}
+
 int fork_streams(pp_handle h, const Splits& sp, hipStream_t* out, hipStream_t base) {
   out[0] = base;
   if (sp.n == 1) return 0;
@@ -3321,6 +3418,9 @@ void free_globals(pp_handle h) {
                   (void*)h->xc, (void*)h->ipiv, (void*)h->bkinfo, (void*)h->counters})
     if (p) (void)hipFree(p);
   h->S = h->S_own = h->Sfac = h->Sldl = h->dvec = h->Qd = h->work = h->rs = h->rs_own = h->rcd = h->xc = nullptr;
+  if (h->corner_pos) (void)hipFree(h->corner_pos);
+  if (h->corner_val) (void)hipFree(h->corner_val);
+  h->corner_pos = nullptr; h->corner_val = nullptr; h->corner_cap = 0; h->corner_used = false;
   h->dense_mode = nullptr;
   h->ipiv = h->bkinfo = h->counters = nullptr;
   if (h->vec_part) { (void)hipFree(h->vec_part); h->vec_part = nullptr; }
@@ -3433,6 +3533,7 @@ int alloc_value_storage(pp_handle h) {
 // The buffers only some input / output forms need (see alloc_value_storage); `which` is a mask.
 enum { OPT_RAW = 1, OPT_RAWT = 2, OPT_RHS = 4, OPT_XOUT = 8, OPT_X = 16 };
 int ensure_optional(pp_handle h, Group* g, int which) {
+  std::lock_guard<std::mutex> lk(h->alloc_mu);      // (the group loops may run on several enqueuing threads)
   if (int rc = alloc_value_storage(h)) return rc;
   GroupDev& d = g->dev;
   const pp::Plan& P = g->plan;
@@ -3497,6 +3598,7 @@ void pp_destroy(pp_handle h) {
   free_globals(h);
   if (h->ev_made)
     for (int i = 0; i < PP_NPHASE; ++i) { (void)hipEventDestroy(h->ev[i][0]); (void)hipEventDestroy(h->ev[i][1]); }
+  if (h->ev_corner_up) { (void)hipEventDestroy(h->ev_corner_up); (void)hipEventDestroy(h->ev_corner_done); (void)hipStreamDestroy(h->up_stream); }
   if (h->aux_made) {
     for (int i = 0; i < PP_MAX_SPLIT; ++i) { (void)hipStreamDestroy(h->aux[i]); (void)hipEventDestroy(h->ev_join[i]); }
     (void)hipEventDestroy(h->ev_fork);
@@ -3878,7 +3980,9 @@ int pp_end_symbolic(pp_handle h) {
   if ((rc = dev_alloc<double>(h, nullptr, &h->dvec, nc))) return rc;
   if ((rc = dev_alloc<int>(h, nullptr, &h->dense_mode, 4))) return rc;
   PP_HIP(hipMemset(h->dense_mode, 0, 4 * sizeof(int)));
-  if ((rc = dev_alloc<double>(h, nullptr, &h->Qd, nn))) return rc;       // (dense: n_c x n_c; block-tridiagonal: the layout of S)
+  // Q: dense n_c x n_c; for a block-tridiagonal S (the layout of S, tens of MB) only when a caller hands over a flat Q --
+  // the sparse form of pp_factor_schur_corner needs none
+  if (!h->btd && (rc = dev_alloc<double>(h, nullptr, &h->Qd, nn))) return rc;
   if ((rc = dev_alloc<double>(h, nullptr, &h->work, 2 * (size_t)nc))) return rc;
   if ((rc = dev_alloc<double>(h, nullptr, &h->rs_own, nc))) return rc;
   if ((rc = dev_alloc<double>(h, nullptr, &h->rcd, nc))) return rc;
@@ -4050,7 +4154,7 @@ int pp_numeric_factor_blocks(pp_handle h) {
   if (int rc = alloc_value_storage(h)) return rc;
   GroupStreams gst;
   if (fork_group_streams(h, gst)) return fail(h, 3, "stream fork failed");
-  for (size_t gi = 0; gi < h->groups.size(); ++gi) {
+  auto group_body = [&](size_t gi) -> int {
     Group* g = h->groups[gi];
     const hipStream_t st = gst.st[gi % (size_t)gst.n];
     const pp::Plan& P = g->plan;
@@ -4174,7 +4278,9 @@ int pp_numeric_factor_blocks(pp_handle h) {
       }
       if (join_streams(h, sp, fan)) return fail(h, 3, "stream join failed");
     }
-  }
+    return 0;
+  };
+  if (int rc = run_groups(h, gst, group_body)) return rc;
   if (join_group_streams(h, gst)) return fail(h, 3, "stream join failed");
   PP_HIP(hipGetLastError());
   h->blocks_factored = true;
@@ -4264,7 +4370,49 @@ int pp_bind_schur_buffer(pp_handle h, double* dev_ptr) {
   return 0;
 }
 
-int pp_factor_schur(pp_handle h, const double* Q_host) {
+static int factor_schur_impl(pp_handle h, const double* Q_host, long long corner_nnz);
+
+int pp_factor_schur(pp_handle h, const double* Q_host) { return factor_schur_impl(h, Q_host, 0); }
+
+int pp_factor_schur_corner(pp_handle h, int64_t nnz, const int64_t* pos, const double* val) {
+  if (!h || !h->numeric_done) return fail(h, 3, "pp_factor_schur_corner before pp_numeric_local");
+  if (!h->btd) return fail(h, 3, "pp_factor_schur_corner: S is dense (use pp_factor_schur)");
+  if (nnz < 0 || (nnz > 0 && (!pos || !val))) return fail(h, 3, "pp_factor_schur_corner: bad arguments");
+  PP_HIP(hipSetDevice(h->device));
+  const long long nn = (long long)schur_doubles(h);
+  for (int64_t k = 0; k < nnz; ++k)
+    if (pos[k] < 0 || pos[k] >= nn) return fail(h, 3, "pp_factor_schur_corner: position outside the Schur buffer");
+  if (nnz > 0) {
+    // the pairs travel on an upload stream of their own: a copy on the handle's stream would wait behind the block
+    // factorisation that is still running there, and the host with it
+    if (!h->ev_corner_up) {
+      PP_HIP(hipStreamCreateWithFlags(&h->up_stream, hipStreamNonBlocking));
+      PP_HIP(hipEventCreateWithFlags(&h->ev_corner_up, hipEventDisableTiming));
+      PP_HIP(hipEventCreateWithFlags(&h->ev_corner_done, hipEventDisableTiming));
+    }
+    hipStream_t up = h->up_stream;
+    if ((size_t)nnz > h->corner_cap) {
+      PP_HIP(hipStreamSynchronize(h->stream));
+      if (h->corner_pos) (void)hipFree(h->corner_pos);
+      if (h->corner_val) (void)hipFree(h->corner_val);
+      h->corner_pos = nullptr; h->corner_val = nullptr; h->corner_cap = 0;
+      int rc = 0;
+      if ((rc = dev_alloc<long long>(h, nullptr, &h->corner_pos, (size_t)nnz))) return rc;
+      if ((rc = dev_alloc<double>(h, nullptr, &h->corner_val, (size_t)nnz))) return rc;
+      h->corner_cap = (size_t)nnz;
+      h->corner_used = false;
+    }
+    if (h->corner_used) PP_HIP(hipStreamWaitEvent(up, h->ev_corner_done, 0));    // the previous scatter has read them
+    PP_HIP(hipMemcpyAsync(h->corner_pos, pos, (size_t)nnz * sizeof(long long), hipMemcpyHostToDevice, up));
+    PP_HIP(hipMemcpyAsync(h->corner_val, val, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, up));
+    PP_HIP(hipEventRecord(h->ev_corner_up, up));
+    PP_HIP(hipStreamSynchronize(up));            // the caller's arrays are free again when this returns
+    PP_HIP(hipStreamWaitEvent(h->stream, h->ev_corner_up, 0));
+  }
+  return factor_schur_impl(h, nullptr, (long long)nnz);
+}
+
+static int factor_schur_impl(pp_handle h, const double* Q_host, long long corner_nnz) {
   if (!h || !h->numeric_done) return fail(h, 3, "pp_factor_schur before pp_numeric_local");
   PP_HIP(hipSetDevice(h->device));
   hipStream_t st = h->stream;
@@ -4272,6 +4420,9 @@ int pp_factor_schur(pp_handle h, const double* Q_host) {
   const size_t nn = schur_doubles(h);
   if (nc > 0 && h->btd) {
     // block-tridiagonal S: sequential block LDL^T, Bunch-Kaufman inside the blocks (see k_btd_*)
+    if (Q_host && !h->Qd) {
+      if (int rc = dev_alloc<double>(h, nullptr, &h->Qd, nn)) return rc;
+    }
     if (Q_host) PP_HIP(hipMemcpyAsync(h->Qd, Q_host, nn * sizeof(double), hipMemcpyHostToDevice, st));
     const int gs = h->gs, G = h->G;
     const size_t g2 = (size_t)gs * gs;
@@ -4279,6 +4430,12 @@ int pp_factor_schur(pp_handle h, const double* Q_host) {
     PhaseScope ps(h, 3, 2 + 6 * nlev);
     hipLaunchKernelGGL(k_btd_init, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, nn, h->S, Q_host ? h->Qd : (const double*)nullptr,
                        h->btd_fac);
+    if (corner_nnz > 0) {
+      hipLaunchKernelGGL(k_corner_add, dim3((unsigned)((corner_nnz + 255) / 256)), dim3(256), 0, st, corner_nnz, h->corner_pos,
+                         h->corner_val, h->btd_fac);
+      PP_HIP(hipEventRecord(h->ev_corner_done, st));
+      h->corner_used = true;
+    }
     double* D = h->btd_fac;
     double* slot = h->btd_fac + (size_t)G * g2;
     const unsigned gb = (unsigned)((g2 + 255) / 256);
@@ -4340,7 +4497,7 @@ int pp_factor_schur(pp_handle h, const double* Q_host) {
         }
       }
     }
-    hipLaunchKernelGGL(k_btd_finish, dim3(1), dim3(64), 0, st, G, h->btd_info, h->bkinfo, h->S + nn, h->scatter_err, h->status_dev,
+    hipLaunchKernelGGL(k_btd_finish, dim3(1), dim3(256), 0, st, G, h->btd_info, h->bkinfo, h->S + nn, h->scatter_err, h->status_dev,
                        ++h->status_seq);
     PP_HIP(hipGetLastError());
     h->schur_done = true;
@@ -4458,7 +4615,7 @@ int pp_solve_forward(pp_handle h) {
   PP_HIP(hipMemsetAsync(h->rs, 0, std::max<size_t>(nc, 1) * sizeof(double), st));
   GroupStreams gst;
   if (fork_group_streams(h, gst)) return fail(h, 3, "stream fork failed");
-  for (size_t gi = 0; gi < h->groups.size(); ++gi) {
+  auto group_body = [&](size_t gi) -> int {
     Group* g = h->groups[gi];
     const hipStream_t st = gst.st[gi % (size_t)gst.n];
     const pp::Plan& P = g->plan;
@@ -4500,7 +4657,9 @@ int pp_solve_forward(pp_handle h) {
       }
       if (join_streams(h, sp, fan)) return fail(h, 3, "stream join failed");
     }
-  }
+    return 0;
+  };
+  if (int rc = run_groups(h, gst, group_body)) return rc;
   if (join_group_streams(h, gst)) return fail(h, 3, "stream join failed");
   // the coupling rows of the groups meet in r_s: one after the other on the handle's stream
   for (Group* g : h->groups) {
@@ -4632,7 +4791,7 @@ int pp_solve_backward(pp_handle h) {
   PP_HIP(hipSetDevice(h->device));
   GroupStreams gst;
   if (fork_group_streams(h, gst)) return fail(h, 3, "stream fork failed");
-  for (size_t gi = 0; gi < h->groups.size(); ++gi) {
+  auto group_body = [&](size_t gi) -> int {
     Group* g = h->groups[gi];
     const hipStream_t st = gst.st[gi % (size_t)gst.n];
     const pp::Plan& P = g->plan;
@@ -4673,7 +4832,9 @@ int pp_solve_backward(pp_handle h) {
     if (!native)
       hipLaunchKernelGGL(k_transpose_out, dim3((unsigned)((P.n + 63) / 64) * d.nchunk), dim3(256), 0, st, d.X, d.iperm, d.xout,
                          d.batch, P.n, d.bpad);
-  }
+    return 0;
+  };
+  if (int rc = run_groups(h, gst, group_body)) return rc;
   if (join_group_streams(h, gst)) return fail(h, 3, "stream join failed");
   PP_HIP(hipGetLastError());
   return 0;

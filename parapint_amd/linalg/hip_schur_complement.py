@@ -479,6 +479,14 @@ class HipEngine(object):
             self.ns.check(self.lib.pp_factor_schur(self.ns.h, Qp), 'pp_factor_schur')
             self.ns.check(self.lib.pp_synchronize(self.ns.h), 'pp_synchronize')
 
+    def factor_schur_corner(self, pos, val):
+        """Block-tridiagonal S: Q as (position in the Schur layout, value) pairs."""
+        pos = np.ascontiguousarray(pos, dtype=np.int64)
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        import ctypes
+        self.ns.check(self.lib.pp_factor_schur_corner(self.ns.h, int(pos.size), pos.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                                                      val.ctypes.data_as(ctypes.POINTER(ctypes.c_double))), 'pp_factor_schur_corner')
+
     def set_coupling_schedule(self, sequential):
         self.ns.check(self.lib.pp_set_coupling_schedule(self.ns.h, 1 if sequential else 0), 'pp_set_coupling_schedule')
 
@@ -1214,14 +1222,14 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             for g in self._groups:                           # (the new plan's device buffers are empty)
                 self._eng.upload_values_compact(g.gid, g.staging)
 
-    def _btd_q(self, Q):
-        """Dense symmetric Q (or None) -> the block-tridiagonal layout of the Schur buffer in the permuted order, with a
-        unit diagonal on the padding rows."""
+    def _btd_corner(self, Q):
+        """Symmetric sparse Q (or None) -> (positions, values) in the block-tridiagonal layout of the Schur buffer in the
+        permuted order (duplicates add), with a unit diagonal on the padding rows."""
         gs, G = self._btd
         g2 = gs * gs
-        flat = np.zeros((2 * G - 1) * g2)
         pad = np.flatnonzero(self._cperm_pad < 0)
-        flat[(pad // gs) * g2 + (pad % gs) * (gs + 1)] = 1.0
+        pos = [(pad // gs) * g2 + (pad % gs) * (gs + 1)]
+        val = [np.ones(pad.size)]
         if Q is not None:
             from scipy.sparse import coo_matrix as _coo_m
             Qc = _coo_m(Q)
@@ -1229,11 +1237,21 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             pi, pj = self._cinv[i], self._cinv[j]
             bi_, bj_ = pi // gs, pj // gs
             same = bi_ == bj_
-            np.add.at(flat, bi_[same] * g2 + (pi[same] % gs) + (pj[same] % gs) * gs, v[same])
+            pos.append(bi_[same] * g2 + (pi[same] % gs) + (pj[same] % gs) * gs)
+            val.append(v[same])
             low = bi_ == bj_ + 1                          # E_t = S(block t+1, block t): only this orientation is stored
-            np.add.at(flat, G * g2 + bj_[low] * g2 + (pi[low] % gs) + (pj[low] % gs) * gs, v[low])
+            pos.append(G * g2 + bj_[low] * g2 + (pi[low] % gs) + (pj[low] % gs) * gs)
+            val.append(v[low])
             if np.any(~same & ~low & (bj_ != bi_ + 1)):
                 raise RuntimeError('coupling block Q has entries outside the block-tridiagonal structure')
+        return np.concatenate(pos).astype(np.int64), np.concatenate(val).astype(np.float64)
+
+    def _btd_q(self, Q):
+        """The same as one flat array in the layout of the Schur buffer (tests, host interpreter)."""
+        gs, G = self._btd
+        flat = np.zeros((2 * G - 1) * gs * gs)
+        pos, val = self._btd_corner(Q)
+        np.add.at(flat, pos, val)
         return flat
 
     def _to_coupling_order(self, v):
@@ -1296,7 +1314,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         timer.stop('form SC')
         timer.start('factor SC')
         if self._btd is not None:
-            self._guarded(res, self._eng.factor_schur_flat, self._btd_q(Q))
+            self._guarded(res, self._eng.factor_schur_corner, *self._btd_corner(Q))
         else:
             self._guarded(res, self._eng.factor_schur, Q)
         self._last_Q = Q
@@ -1308,7 +1326,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             # all of them hold the same all-reduced S)
             self._btd_sequential = True
             self._guarded(res, self._eng.set_coupling_schedule, True)
-            self._guarded(res, self._eng.factor_schur_flat, self._btd_q(Q))
+            self._guarded(res, self._eng.factor_schur_corner, *self._btd_corner(Q))
             st = self._guarded(res, self._eng.status)
         timer.stop('factor SC')
         if st is not None:

@@ -181,6 +181,12 @@ class HostSimEngine(object):
     def factor_schur_flat(self, Qflat):
         self.factor_schur(None if Qflat is None else self._flat_to_dense(np.asarray(Qflat)))
 
+    def factor_schur_corner(self, pos, val):
+        gs, G = self.btd
+        flat = np.zeros((2 * G - 1) * gs * gs)
+        np.add.at(flat, np.asarray(pos, dtype=np.int64), np.asarray(val, dtype=np.float64))
+        self.factor_schur_flat(flat)
+
     def get_schur_flat(self):
         gs, G = self.btd
         g2 = gs * gs

@@ -50,6 +50,30 @@ def test_error_behaviour():
     sc.case_errors(make_engine)
 
 
+def test_sparse_corner_entry_point_checks_its_arguments():
+    """pp_factor_schur_corner is the block-tridiagonal form of pp_factor_schur: status 3 on a dense S and for positions
+    outside the Schur buffer; the flat and the sparse form of Q give the same factorisation."""
+    from parapint_amd.linalg.comm import SerialComm
+    from parapint_amd.linalg.results import LinearSolverStatus
+    solver, model = sc.case_dynamic(make_engine, 2, 3, expect_block_tridiagonal=False, oracle=False)
+    with pytest.raises(RuntimeError):
+        solver._eng.factor_schur_corner(np.array([0], dtype=np.int64), np.array([1.0]))
+    solver, model = sc.case_dynamic(make_engine, 12, 5, expect_block_tridiagonal=True, oracle=False, dense_limit=8)
+    gs, G = solver._btd
+    with pytest.raises(RuntimeError):
+        solver._eng.factor_schur_corner(np.array([(2 * G - 1) * gs * gs], dtype=np.int64), np.array([1.0]))
+    kkt = model.build_kkt(comm=SerialComm(), iteration=2)
+    rhs = model.build_rhs(comm=SerialComm())
+    assert solver.do_numeric_factorization(kkt).status == LinearSolverStatus.successful
+    x1 = solver.do_back_solve(rhs).flatten()
+    inertia = solver.get_inertia()
+    solver._eng.factor_schur_flat(solver._btd_q(solver._last_Q))           # the flat form on the same all-reduced S
+    assert solver._eng.status()[0] == 0
+    x2 = solver.do_back_solve(rhs).flatten()
+    assert np.abs(x1 - x2).max() <= 1e-12 * np.abs(x1).max()
+    assert solver.get_inertia() == inertia
+
+
 def test_inertia_correction_pattern_growth():
     sc.case_inertia_correction_pattern_growth(make_engine)
 
