@@ -3151,7 +3151,9 @@ struct pp_solver {
   std::vector<int> bcr_off, bcr_ne, bcr_s, bcr_lo;   // per level: offset into btd_elim, eliminated blocks, stride, lower neighbour live
   int btd_sequential = 0;
   bool bcr_lds_attr = false, bcr_ldl_attr = false;
-  double bcr_lbound = 100.0;     // largest multiplier the unpivoted block factorisation of the cyclic reduction accepts (1 / u, u = 0.01)
+  // largest multiplier the unpivoted block factorisation of the cyclic reduction accepts (1 / u, u = 0.01; PP_BCR_LBOUND:
+  // test switch -- a bound below 1 sends some blocks to Bunch-Kaufman and leaves others on the unpivoted path)
+  double bcr_lbound = std::getenv("PP_BCR_LBOUND") ? std::atof(std::getenv("PP_BCR_LBOUND")) : 100.0;
   double growth_bound = 1e8;     // 1 / u_rt: a factor entry beyond it flags its instance
   bool growth_fatal = false;     // flagged instances make the factorisation report status 2 (else they are only counted)
   double pivot_threshold = 0.0;  // symbolic-time threshold u for groups added afterwards (0: plan default)

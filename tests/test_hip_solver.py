@@ -579,6 +579,21 @@ def test_dynamic_time_blocks_block_tridiagonal_schur():
     assert fast > 0          # quasi-definite blocks: the unpivoted matrix-core factorisation passes its threshold test
 
 
+@pytest.mark.parametrize('n_s', [3, 8, 20, 56, 57])
+def test_cyclic_reduction_block_sizes(n_s):
+    """Block sizes gs = 2 n_s around the tile edges of the unpivoted matrix-core path (6: less than one tile, 16: exactly
+    one, 40: ragged, 112: its largest, 114: too large -- Bunch-Kaufman for every block), against the oracle."""
+    solver, model = sc.case_dynamic(make_engine, 12, n_s, n_u=2, nfe=2, expect_block_tridiagonal=True, dense_limit=8)
+    gs, G = solver._btd
+    assert gs == 2 * n_s
+    fast, pivoted = solver._eng.bcr_block_paths()
+    assert fast + pivoted == G
+    if gs > 112:
+        assert fast == 0
+    else:
+        assert fast > 0
+
+
 @pytest.mark.parametrize('dense_limit', [None, 8])
 def test_dynamic_problem_through_the_inertia_correction_loop(dense_limit):
     solver = sc.case_dynamic_regularised(make_engine, dense_limit)
@@ -617,4 +632,11 @@ def test_measurement_switches_select_paths_that_agree():
     code2 = code.replace("print('dynamic ok')", "s = sc.case_dynamic(lambda: HipEngine(), 64, 49, n_u=2, nfe=4, expect_block_tridiagonal=True)[0]\n"
                                                "assert s._eng.bcr_block_paths() == (0, 63)\nprint('dynamic ok')")
     out = subprocess.run([sys.executable, '-c', code2], env=env2, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert out.returncode == 0 and 'dynamic ok' in out.stdout.decode(), out.stdout.decode()[-3000:]
+    # ... and a level whose blocks take different paths: with a multiplier bound of 0.7 the unpivoted factorisation
+    # rejects the blocks whose largest multiplier exceeds it (0.67 ... 0.82 on this problem), the others keep it
+    env3 = dict(os.environ, PP_BCR_LBOUND='0.7', PYTHONPATH=env['PYTHONPATH'])
+    code3 = code.replace("print('dynamic ok')", "s = sc.case_dynamic(lambda: HipEngine(), 64, 49, n_u=2, nfe=4, expect_block_tridiagonal=True)[0]\n"
+                                               "f, p = s._eng.bcr_block_paths()\nassert f + p == 63 and p > 0, (f, p)\nprint('dynamic ok', f, p)")
+    out = subprocess.run([sys.executable, '-c', code3], env=env3, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     assert out.returncode == 0 and 'dynamic ok' in out.stdout.decode(), out.stdout.decode()[-3000:]
