@@ -3,7 +3,7 @@
 #   bench_default.json         python bench.py --steps 40            (with cpu_baseline and boundary_host)
 #   kernel_stats.csv, bench_under_rocprof.json    rocprofv3 --kernel-trace --stats of bench.py --steps 20
 #   pmc/*_per_kernel.csv, pmc_traffic.json        separate --pmc FETCH_SIZE / WRITE_SIZE passes
-#   bench_C2.json, bench_C4.json, kernel_stats_C4.csv, bench_128_blocks.json
+#   bench_C2.json, bench_C4.json, kernel_stats_C4.csv, bench_128_blocks.json, bench_C5.json, bench_C5_512_blocks.json
 tag=${1:-final}
 out=gpurun_out/$tag
 mkdir -p $out/pmc
@@ -38,10 +38,12 @@ python3 bench.py --workload C2 --no-cpu-baseline > $out/bench_C2.json 2> $out/c2
 python3 bench.py --blocks 128 --no-cpu-baseline --no-boundary > $out/bench_128_blocks.json 2> $out/b128.err
 python3 bench.py --workload C4 --no-cpu-baseline --steps 10 --warmup 2 > $out/bench_C4.json 2> $out/c4.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_C4 -- python3 bench.py --workload C4 --steps 5 --warmup 2 --no-cpu-baseline --no-boundary > $out/bench_C4_under_rocprof.json 2> $out/stats_C4.err && cp $(find $out/stats_C4 -name '*kernel_stats.csv' | head -1) $out/kernel_stats_C4.csv
+python3 bench.py --workload C5 --no-cpu-baseline --no-boundary --steps 5 --warmup 2 --value-sets 2 --profile-steps 2 > $out/bench_C5.json 2> $out/c5.err
+python3 bench.py --workload C5 --blocks 512 --no-cpu-baseline --no-boundary --steps 10 --warmup 2 --value-sets 2 --profile-steps 2 > $out/bench_C5_512_blocks.json 2> $out/c5b.err
 find $out -name '*kernel_trace.csv' -delete
 find $out -name '*counter_collection.csv' -delete
 rm -rf $out/stats $out/stats_C4 $out/pmc_fetch $out/pmc_write
-for f in bench_default bench_C2 bench_128_blocks bench_C4; do python3 - $out/$f.json <<'PY'
+for f in bench_default bench_C2 bench_128_blocks bench_C4 bench_C5 bench_C5_512_blocks; do python3 - $out/$f.json <<'PY'
 import json, sys
 try:
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
