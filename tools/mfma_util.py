@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES pass -> MFMA busy cycles per launch of the dense kernels.
 
-Usage: python tools/mfma_util.py <pass dir> <kernel trace csv of a --kernel-trace --stats run> [out.json]
+Usage: python tools/mfma_util.py <pass dir> <kernel trace csv of a --kernel-trace --stats run> [out.json [command]]
 MFMA utilisation of a kernel = busy cycles / (duration x shader clock x SIMDs of the chip); the counter counts
 cycles in which an MFMA is executing, summed over the SIMDs (MI355X_MICROARCH.md, cycle-constants table)."""
 import csv
@@ -35,7 +35,9 @@ def main():
         print('%-28s %10.0f busy cycles/launch  %8.1f us  chip %.5f %%  one CU %.2f %%' %
               (s, per_launch, 1e6 * avg_s, 100 * out[s]['mfma_util_of_chip'], 100 * out[s]['mfma_util_of_one_cu']))
     if len(sys.argv) > 3:
-        json.dump({'source': 'rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace (own pass) of bench.py at C3',
+        json.dump({'source': 'rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace (own pass) of ' +
+                             (sys.argv[4] if len(sys.argv) > 4 else 'bench.py at C3') +
+                             '; durations from a separate --kernel-trace --stats run of the same command',
                    'clock_GHz': CLOCK_GHZ, 'kernels': out}, open(sys.argv[3], 'w'), indent=1)
 
 
