@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <map>
 #include <vector>
 
 #include "../../parapint_amd/csrc/plan.hpp"
@@ -136,6 +137,53 @@ void ppsim_level_teams(void* h, int* out) {
       o[1] = std::max(o[1], ft.r1 - ft.r0);
     }
     for (int p = 0; p < P.npiv; ++p) { o[0] = std::max(o[0], cnt[p]); o[2] += cnt[p] > 4; o[3] += cnt[p] > 8; }
+  }
+}
+
+// Operand loads of the gather tasks per level (3 int64): as scheduled (1 U + w L per product entry), and if the rows of a
+// panel were gathered in groups of up to 4 consecutive rows sharing the L operands of a source column (w L per distinct
+// source column of the group + 1 U per row that has it); third value: product entries.  Diagnostic.
+void ppsim_operand_loads(void* h, long long* out) {
+  Plan& P = *(Plan*)h;
+  for (int l = 0; l < P.n_levels; ++l) {
+    long long* o = out + 3 * l;
+    o[0] = o[1] = o[2] = 0;
+    // rows of one pivot in this level, by row slot: list of L positions (the source column identity)
+    std::map<std::pair<int, int>, std::vector<int>> rows;      // (pivot, row slot) -> l of its product entries
+    for (int t = P.flevel_ptr[l]; t < P.flevel_ptr[l + 1]; ++t) {
+      const auto& ft = P.ftasks[t];
+      if (ft.kind < 0) continue;
+      const int w = P.piv_w[ft.piv];
+      if (ft.npieces > 1) {
+        auto& v = rows[{ft.piv, ft.r0}];
+        for (int e = P.fdst_ptr[ft.dptr0]; e < P.fdst_ptr[ft.dptr0 + 1]; ++e)
+          if (P.fentries[e].u >= 0) { v.push_back(P.fentries[e].l); o[0] += 1 + w; o[2] += 1; }
+        continue;
+      }
+      for (int rr = 0; rr < ft.r1 - ft.r0; ++rr) {
+        auto& v = rows[{ft.piv, ft.r0 + rr}];
+        for (int e = P.fdst_ptr[ft.dptr0 + rr]; e < P.fdst_ptr[ft.dptr0 + rr + 1]; ++e)
+          if (P.fentries[e].u >= 0) { v.push_back(P.fentries[e].l); o[0] += 1 + w; o[2] += 1; }
+      }
+    }
+    auto it = rows.begin();
+    while (it != rows.end()) {
+      const int piv = it->first.first, w = P.piv_w[piv];
+      std::map<int, int> have;                                   // l -> rows of the group that have it
+      int n = 0;
+      int last_slot = it->first.second - 1;
+      while (it != rows.end() && it->first.first == piv && n < 4 && it->first.second >= w && it->first.second == last_slot + 1) {
+        for (int lpos : it->second) have[lpos]++;
+        last_slot = it->first.second;
+        ++n; ++it;
+      }
+      if (n == 0) {                                              // a pivot-block row (kept as it is) or a gap: alone
+        for (int lpos : it->second) { (void)lpos; o[1] += 1 + w; }
+        ++it;
+        continue;
+      }
+      for (auto& kv : have) o[1] += w + kv.second;
+    }
   }
 }
 
