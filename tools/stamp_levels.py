@@ -23,7 +23,7 @@ from parapint_amd.linalg.hip_schur_complement import HipSchurComplementLinearSol
 
 def main():
     levels = [int(a) for a in sys.argv[1:]] or [3]
-    N, n_q, m, n_t = 1024, 1000, 4, 200
+    N, n_q, m, n_t = int(os.environ.get('PP_STAMP_BLOCKS', '1024')), 1000, 4, 200      # (PP_STAMP_BLOCKS=128: one rank's share at 8 GPUs)
     model = SyntheticKKT(N, n_q, m, n_t)
     comm = SerialComm()
     solver = HipSchurComplementLinearSolver({i: None for i in range(N)}, None, comm=comm)
