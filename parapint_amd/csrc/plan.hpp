@@ -62,6 +62,22 @@ struct PlanOptions {
   double pivot_threshold = 0.01;  // 1x1 pivot accepted if |d| >= threshold * max|row| (MA27 cntl(1) analogue)
 };
 
+// Task sizes by batch (instances of the pattern group on this rank).  MEASURED on one MI355X (tools/tune_sweep.sh): with
+// a few chunks of 64 instances a gather launch is a chain of memory round trips per wave, and a wave keeps only so many
+// misses in flight -- tasks of 8 entries and rows split from 0.5 caps on spread the same entries over three times the
+// waves: 128 blocks (one rank's share of C3 at 8 GPUs) 0.589 -> 0.551 ms per step, 256 blocks 0.649 -> 0.627,
+// C2 (64 blocks) 0.518 -> 0.454-0.484; at 512 blocks the gain is 1 % for C3-shaped blocks and a loss of 3-4 % for the
+// denser C4 / C5 blocks (8.30 -> 8.60 ms, 3.09 -> 3.21 ms), at 1024 blocks the larger tasks are as fast and hold less
+// index data: the small sizes up to 256 instances.
+inline void tune_for_batch(PlanOptions& o, int batch) {
+  if (batch > 0 && batch <= 256) {
+    o.max_task_entries = 8;
+    o.tail_task_entries = 8;
+    o.row_split_factor = 0.5;
+  }
+}
+
+
 // Factor schedule ("L form").  For every block pivot p two panels are stored with the same
 // indexing: the unscaled panel U_p = [P_p ; U_p] and the scaled rows L_p = U_p inv(P_p).  The
 // update of a destination ROW (all w columns of the block pivot at once) is a pure gather over

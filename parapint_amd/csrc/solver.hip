@@ -3668,6 +3668,7 @@ int pp_add_group_mapped(pp_handle h, int n, int batch, int nnzK, const int32_t* 
   if (batch <= 0 || n <= 0 || nraw < 0) return fail(h, 3, "bad group dimensions");
   Group* g = new Group();
   pp::PlanOptions opt;
+  pp::tune_for_batch(opt, batch);
   if (h->sn_wmax > 0) opt.sn_wmax = h->sn_wmax;
   if (h->sn_tol >= 0) opt.sn_tol_rows = h->sn_tol;
   if (h->pivot_threshold > 0.0) opt.pivot_threshold = h->pivot_threshold;
@@ -4217,7 +4218,7 @@ int pp_numeric_factor_blocks(pp_handle h) {
 #ifdef PP_X_LEANMAX
             const bool lean = P.flevel_maxent[l] <= 12 || (P.flevel_maxent[l] <= PP_X_LEANMAX && P.flevel_nsplit[l] == 0);
 #else
-            const bool lean = P.flevel_maxent[l] <= 12;
+            const bool lean = P.flevel_maxent[l] <= 12 && P.flevel_nsplit[l] == 0;      // (the lean kernel has no split rows)
 #endif
             const int mw = g->level_maxw[l];
 #define PP_LAUNCH_GATHER(K, ...) hipLaunchKernelGGL((K<__VA_ARGS__>), dim3((unsigned)nt * ny), dim3(64), 0, fan[q], d, t0, sp.c0[q], ny, PIVOT_EPS)

@@ -23,7 +23,7 @@ struct HostCtx {
 };
 }  // namespace
 
-static int g_sn_wmax = 0, g_sn_tol = -1;
+static int g_sn_wmax = 0, g_sn_tol = -1, g_batch_hint = 0;
 static double g_growth_bound = 1e8, g_pivot_threshold = 0.0;   // as pp_set_pivot_tolerance
 static int g_last_growth = 0, g_growth_fatal = 0;
 
@@ -31,6 +31,8 @@ extern "C" {
 
 // test knob: supernode width cap / padded-row tolerance for plans created afterwards (0 / -1: defaults)
 void ppsim_set_supernodes(int wmax, int tol) { g_sn_wmax = wmax; g_sn_tol = tol; }
+// instances of the pattern group the next plans are made for (0: unknown = the large-batch task sizes), plan.hpp:tune_for_batch
+void ppsim_set_batch_hint(int batch) { g_batch_hint = batch; }
 void ppsim_set_pivot_tolerance(double u_symbolic, double u_runtime) {
   g_pivot_threshold = u_symbolic;
   g_growth_bound = u_runtime > 0.0 ? 1.0 / u_runtime : 1e8;
@@ -43,6 +45,7 @@ void* ppsim_create(int n, int nc, int nnzK, const int* rowK, const int* colK, in
                    const int* colB, const double* vals, int max_entries, int delta_abs, double delta_rel) {
   auto* P = new Plan();
   pp::PlanOptions opt;
+  pp::tune_for_batch(opt, g_batch_hint);
   if (max_entries > 0) opt.max_task_entries = max_entries;
   if (delta_abs >= 0) opt.md_delta_abs = delta_abs;
   if (delta_rel >= 0) opt.md_delta_rel = delta_rel;
