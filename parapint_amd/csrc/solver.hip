@@ -6,14 +6,19 @@
 // streaming workload with no divergence.  One 64-thread workgroup = one task x 64 instances.
 //
 // Kernels (reference function each one replaces):
-//   k_transpose_in / k_assemble   values of K_i, A_i -> panel storage   (MA27B input, ma27_interface.py:124)
-//   k_gather_level, k_scale_level left-looking LDL^T in L form, static block pivots (MA27B)
-//   k_count_codes                 inertia / zero-pivot counts           (ma27_interface.py:201-203)
-//   k_schur_tiles, k_schur_reduce S_local = -sum_i A_i K_i^-1 A_i^T     (mpi_explicit_schur_complement.py:312-333)
-//   k_bk_factor                   dense LDL^T of S + Q                  (mpi_...:347-361)
-//   k_fwd_level, k_fwd_coupling   forward substitution, r_s             (mpi_...:381-385; MA27C)
-//   k_coupling_solve              x_c = S^-1 (r_c + r_s)                (mpi_...:388-391)
-//   k_bwd_level                   back substitution with x_c            (mpi_...:393-396)
+//   k_transpose_in / k_assemble_sources   values of K_i, A_i -> panel storage (host / compact inputs; device-resident
+//                                 sources are read by the leaf kernels themselves)   (MA27B input, ma27_interface.py:124)
+//   k_gather_flat, k_gather_level_lean, k_scale_level   left-looking LDL^T in L form, static block pivots (MA27B)
+//   (count workgroups of the Schur launch)   inertia / zero-pivot counts  (ma27_interface.py:201-203)
+//   k_schur_mfma + k_schur_reduce_mfma (k_schur_tiles + k_scatter_schur for mapped groups)
+//                                 S_local = -sum_i A_i K_i^-1 A_i^T     (mpi_explicit_schur_complement.py:312-333)
+//   k_ldl_regs / k_ldl_blocked / k_dense_panel + k_dense_update, k_bk_factor   dense LDL^T of S + Q   (mpi_...:347-361)
+//   k_bcr_ldl_inverse (k_bcr_factor, k_bcr_invert_wave), k_bcr_keep_y_mfma, k_bcr_update_mfma, k_corner_add
+//                                 block-tridiagonal S of time-staged problems: cyclic reduction   (mpi_...:88-125, 352-361)
+//   k_fwd_level(_pair), k_fwd_coupling, k_rs_reduce   forward substitution, r_s   (mpi_...:381-385; MA27C)
+//   k_coupling_solve / k_bcr_fwd + k_bcr_bwd   x_c = S^-1 (r_c + r_s)   (mpi_...:388-391)
+//   k_bwd_level(_pair)            back substitution with x_c            (mpi_...:393-396)
+//   k_step_stats, k_vec_max_abs, k_vec_axpy   vector kernels of the interior-point step (interior_point.py:655-758)
 #include <hip/hip_runtime.h>
 
 #include <array>
