@@ -37,6 +37,7 @@ struct PlanOptions {
   int fuse_task_entries = 24;  // panels with at most this many entries are one fused task (gather + invert + scale)
   int scale_task_rows = 8;     // rows per scale task of a big panel
   double row_split_factor = 2.0;  // a row longer than this many task caps is split over the waves of one quad
+  int task_order = 0;     // unsplit gather tasks of a level: 0 longest first, 1 panel by panel (rows of a panel share their L operands)
   // Top of the elimination tree ("tail"): levels holding at most tail_piv_max pivots each get their own task
   // size (few panels, long rows: shorter tasks give more waves per level).
   int tail_piv_max = 48;

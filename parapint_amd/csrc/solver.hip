@@ -3701,6 +3701,7 @@ int pp_add_group_mapped(pp_handle h, int n, int batch, int nnzK, const int32_t* 
         else if (k == "md_delta_abs") opt.md_delta_abs = (int)v;
         else if (k == "md_delta_rel") opt.md_delta_rel = v;
         else if (k == "row_split_factor") opt.row_split_factor = v;
+        else if (k == "task_order") opt.task_order = (int)v;
         else return fail(h, 3, "PP_PLAN_TUNE: unknown key " + k);
       }
       pos = end + 1;

@@ -606,7 +606,13 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
         std::vector<size_t> singles;
         for (size_t q = i; q < j; ++q)
           if (gtasks[q].t.npieces <= 1) singles.push_back(q);
-        std::stable_sort(singles.begin(), singles.end(), [&](size_t a, size_t b) { return gtasks[a].nent > gtasks[b].nent; });
+        if (opt.task_order == 0)
+          std::stable_sort(singles.begin(), singles.end(), [&](size_t a, size_t b) { return gtasks[a].nent > gtasks[b].nent; });
+        else
+          std::stable_sort(singles.begin(), singles.end(), [&](size_t a, size_t b) {
+            if (gtasks[a].t.piv != gtasks[b].t.piv) return gtasks[a].t.piv < gtasks[b].t.piv;
+            return gtasks[a].t.r0 < gtasks[b].t.r0;
+          });
         for (size_t q : singles) P.ftasks.push_back(gtasks[q].t);
         while ((P.ftasks.size() - before) % PP_QUAD != 0) P.ftasks.push_back(noop);
         P.flevel_ptr[lvl + 1] += (int)(P.ftasks.size() - before);

@@ -17,8 +17,9 @@ from pmc_summary import load, short   # noqa: E402
 
 PHASE_OF = [
     (r'^k_gather_level|^k_gather_flat', 'factor_levels'), (r'^k_scale_level', 'factor_levels'),
-    (r'^k_count_codes|^k_schur_tiles|^k_schur_mfma|^k_schur_reduce', 'schur_tiles'),
-    (r'^k_add_q|^k_ldl_|^k_bk_factor|^k_write_tail|^k_publish_status', 'dense_S'),
+    (r'^k_count_codes|^k_schur_tiles|^k_schur_mfma|^k_schur_reduce|^k_scatter_schur', 'schur_tiles'),
+    (r'^k_bcr_fwd|^k_bcr_bwd|^k_bcr_rhs', 'coupling_solve'),
+    (r'^k_add_q|^k_ldl_|^k_bk_factor|^k_write_tail|^k_publish_status|^k_dense_|^k_bcr_|^k_btd_|^k_corner_add', 'dense_S'),
     (r'^k_fwd_level', 'fwd_levels'), (r'^k_fwd_coupling|^k_rs_reduce', 'fwd_coupling'),
     (r'^k_coupling_solve', 'coupling_solve'), (r'^k_bwd_level|^k_transpose_out', 'bwd_levels'),
 ]
@@ -39,7 +40,7 @@ def main():
         e['fetch_KiB'] += f
         e['write_KiB'] += w
         e['launches'] += max(nf, nw)
-    steps = per.get('k_bk_factor', per.get('k_publish_status'))['launches']   # one per numeric factorisation
+    steps = next(per[k] for k in ('k_bk_factor', 'k_btd_finish', 'k_publish_status') if k in per)['launches']   # one per numeric factorisation
     if 'k_transpose_in' in per:
         tr = per['k_transpose_in']
         known_read_KiB = steps * batch * (raw_entries + n) * 8 / 1024.0
@@ -72,7 +73,7 @@ def main():
             q['launches_per_step'] += e['launches'] / steps
     total = sum(p['hbm_bytes_per_step'] for p in phases.values())
     out = {'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) of bench.py '
-                     'at C3 on one MI355X; read side calibrated on k_transpose_in (known byte count) as '
+                     '(C3 unless the note names another workload) on one MI355X; read side calibrated on k_transpose_in (known byte count) as '
                      'MI355X_MICROARCH.md section HBM prescribes. ' + note,
            'steps_in_pass': steps, 'fetch_calibration': calib, 'hbm_bytes_per_step_total': total,
            'kernels': kernels, 'phases': phases}
