@@ -1120,11 +1120,88 @@ __global__ __launch_bounds__(64) void k_schur_mfma(GroupDev g, int nwork_items, 
   for (int r = 0; r < 4; ++r) out[(lk + 4 * r) * 16 + li] = -acc[r];
 }
 
+// The same with 32 x 32 super-tiles (2 x 2 tiles per wave) for large coupling dimensions (n_c >= PP_MT_WIDE_NC: the
+// 1000 x 1000 S of C5 has 2016 tiles).  A 16 x 16 tile reads 16 + 16 operand rows for 16 matrix instructions per panel
+// column and chunk -- 2 flop per byte, HBM/L2-bound at ~10 TFLOP/s (C5: 23 % MFMA-busy); a super-tile reads 32 + 32 rows
+// for 64.  Records: 64 row positions (A rows of the two row tiles, B rows of the two column tiles); work items
+// {first record, end, super-tile, -}; partial tiles [chunk][item][2 a + b][256].  With the 91 tiles of n_c = 200 the
+// super-tiles were slower (too few waves), hence the threshold.
+constexpr int PP_MT_WIDE_NC = 512;
+__global__ __launch_bounds__(64) void k_schur_mfma_wide(GroupDev g, int nwork_items, size_t total8, int* counters) {
+  const int lane = threadIdx.x;
+  const unsigned nwork = (unsigned)(nwork_items * g.nchunk);
+  const unsigned ncb = gridDim.x - nwork;                                // counting workgroups come first in the grid
+  if (blockIdx.x < ncb) { count_codes_block(g, blockIdx.x, ncb, total8, counters, lane); return; }
+  const unsigned wg = blockIdx.x - ncb;
+  const int chunk = (int)(wg % (unsigned)g.nchunk);
+  const int item = (int)(wg / (unsigned)g.nchunk);
+  const int li = lane & 15, lk = lane >> 4;
+  const size_t bpad = (size_t)g.bpad;
+  const int ra = g.mt_item[4 * item], rb = g.mt_item[4 * item + 1], super = g.mt_item[4 * item + 2];
+  const bool upper_used = g.mt_a[4 * super + 1] >= 0;                 // (false on the diagonal: tile (2 s, 2 s + 1) lies above it)
+  const size_t lane_off = (size_t)chunk * 64 + (size_t)lk * 16;
+  const int nvalid = min(16, max(0, g.batch - (int)lane_off));
+  double4_t acc[2][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) acc[x][y] = double4_t{0.0, 0.0, 0.0, 0.0};
+  for (int r = ra; r < rb; ++r) {
+    int oa[2], ob[2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      oa[x] = g.mt_rec[(size_t)r * 64 + 16 * x + li];
+      ob[x] = g.mt_rec[(size_t)r * 64 + 32 + 16 * x + li];
+    }
+    double2 a[2][8], b[2][8];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { a[x][q] = make_double2(0.0, 0.0); b[x][q] = make_double2(0.0, 0.0); }
+      if (oa[x] >= 0) {
+        const double2* pa = reinterpret_cast<const double2*>(g.L + (size_t)oa[x] * bpad + lane_off);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[x][q] = pa[q];
+      }
+      if (ob[x] >= 0) {
+        const double2* pb = reinterpret_cast<const double2*>(g.U + (size_t)ob[x] * bpad + lane_off);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) b[x][q] = pb[q];
+      }
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (!(2 * q < nvalid)) { a[x][q].x = 0.0; b[x][q].x = 0.0; }
+        if (!(2 * q + 1 < nvalid)) { a[x][q].y = 0.0; b[x][q].y = 0.0; }
+      }
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y) {
+        if (x == 0 && y == 1 && !upper_used) continue;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x][q].x, b[y][q].x, acc[x][y], 0, 0, 0);
+          acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x][q].y, b[y][q].y, acc[x][y], 0, 0, 0);
+        }
+      }
+  }
+  double* out = g.Spart + ((size_t)chunk * nwork_items + item) * 1024;
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(2 * x + y) * 256 + (lk + 4 * r) * 16 + li] = -acc[x][y][r];
+}
+
 // S[ci][cj] (+)= sum over the work items of the tile and the chunks of the partial 16 x 16 tiles (both triangles of the dense
 // S).  Sixteen partial sums per entry (one per residue of the chunk index; fixed order inside: deterministic) meet in LDS
 // and are added as a fixed tree.  Tail as in k_schur_reduce.
 __global__ __launch_bounds__(1024) void k_schur_reduce_mfma(GroupDev g, int nwork_items, double* __restrict__ S,
-                                                            int* __restrict__ counters, int overwrite) {
+                                                            int* __restrict__ counters, int overwrite, int wide) {
   __shared__ double part[4][256];
   const int tid = threadIdx.x, tile = blockIdx.x, e = tid & 255, sub = tid >> 8;
   if (counters && tile == 0 && tid < 64) {
@@ -1144,15 +1221,18 @@ __global__ __launch_bounds__(1024) void k_schur_reduce_mfma(GroupDev g, int nwor
       tail[5] = tail[6] = tail[7] = 0.0;
     }
   }
-  const int i0 = g.mt_wptr[tile], i1 = g.mt_wptr[tile + 1];
+  if (g.mt_a[tile] < 0) return;          // (wide form: the unused quarter of a diagonal super-tile; uniform per workgroup, before any barrier)
+  // wide form: tile = 4 * super-tile + quarter, the items belong to the super-tile, partial tiles [chunk][item][quarter][256]
+  const int i0 = g.mt_wptr[wide ? tile >> 2 : tile], i1 = g.mt_wptr[(wide ? tile >> 2 : tile) + 1];
+  const size_t istride = wide ? 1024 : 256, qoff = wide ? (size_t)(tile & 3) * 256 : 0;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   for (int c = sub; c < g.nchunk; c += 4) {                  // (the four quarter-sums: chunks 0,4,8,.. / 1,5,9,.. / ...)
-    const double* base = g.Spart + ((size_t)c * nwork_items) * 256 + e;
+    const double* base = g.Spart + ((size_t)c * nwork_items) * istride + qoff + e;
     int it = i0;
     for (; it + 3 < i1; it += 4) {
-      s0 += base[(size_t)it * 256]; s1 += base[(size_t)(it + 1) * 256]; s2 += base[(size_t)(it + 2) * 256]; s3 += base[(size_t)(it + 3) * 256];
+      s0 += base[(size_t)it * istride]; s1 += base[(size_t)(it + 1) * istride]; s2 += base[(size_t)(it + 2) * istride]; s3 += base[(size_t)(it + 3) * istride];
     }
-    for (; it < i1; ++it) s0 += base[(size_t)it * 256];
+    for (; it < i1; ++it) s0 += base[(size_t)it * istride];
   }
   part[sub][e] = (s0 + s1) + (s2 + s3);
   __syncthreads();
@@ -3048,6 +3128,7 @@ struct Group {
   std::vector<void*> allocs;
   int ntiles = 0;
   int nmt = 0, nmt_items = 0;  // 16 x 16 tiles of S with contributions (MFMA form), work items over them
+  bool mt_wide = false;        // 32 x 32 super-tiles (k_schur_mfma_wide): nmt counts quarters, a work item holds four partial tiles
   double *raw_own = nullptr, *rhs_own = nullptr, *rawT_own = nullptr;
   int nraw_used = 0;
   std::vector<int> level_maxw;   // widest block pivot per level (selects the scalar kernel variants)
@@ -3453,7 +3534,7 @@ int64_t value_storage_bytes(pp_handle h) {
     // only inside a solve)
     int64_t dbl = (int64_t)g->batch * g->nraw + (int64_t)std::max(g->nraw_used, 1) * bp + 2 * P.usize * bp +
                   (int64_t)P.dsize * bp + (int64_t)std::max(P.n + g->nc_loc, std::max(P.bsize, 1)) * bp +
-                  (int64_t)P.n * bp + 2 * (int64_t)g->batch * P.n + (int64_t)d.nchunk * std::max(std::max(g->ntiles, 1) * 64, g->nmt_items * 256) +
+                  (int64_t)P.n * bp + 2 * (int64_t)g->batch * P.n + (int64_t)d.nchunk * std::max(std::max(g->ntiles, 1) * 64, g->nmt_items * (g->mt_wide ? 1024 : 256)) +
                   (int64_t)d.nchunk * std::max(g->nc_loc, 1) +
                   (g->cmap_host.empty() ? 0 : ((int64_t)std::max(g->ntiles, 1) * 64 + std::max(g->nc_loc, 1)) * bp);
     total += 8 * dbl + 2 * (int64_t)P.npiv * bp;
@@ -3515,7 +3596,7 @@ int alloc_value_storage(pp_handle h) {
     d.Tm = d.Y;     // term magnitudes of the pivot blocks (gather -> scale of one level) share the rows of the solve vector
     double* keep_x = (d.xout && d.xout != g->xout_own) ? d.xout : nullptr;
     d.xout = keep_x;
-    if ((rc = value_alloc(h, g, &d.Spart, (size_t)d.nchunk * (size_t)std::max(std::max(g->ntiles, 1) * 64, g->nmt_items * 256)))) break;
+    if ((rc = value_alloc(h, g, &d.Spart, (size_t)d.nchunk * (size_t)std::max(std::max(g->ntiles, 1) * 64, g->nmt_items * (g->mt_wide ? 1024 : 256))))) break;
     if ((rc = value_alloc(h, g, &d.rspart, (size_t)d.nchunk * std::max(nc, 1)))) break;
     if (!g->cmap_host.empty()) {
       if ((rc = value_alloc(h, g, &d.Sloc, (size_t)std::max(g->ntiles, 1) * 64 * bp))) break;
@@ -3922,7 +4003,54 @@ int pp_end_symbolic(pp_handle h) {
     g->ntiles = (int)P.stile_a.size();
     // 16 x 16 tiles for the MFMA form (k_schur_mfma): per (tile pair, panel column) one record with the positions of the
     // 16 + 16 rows; the records of a tile are cut into work items of at most PP_MT_SLICE records
-    {
+    g->mt_wide = h->nc >= PP_MT_WIDE_NC && std::getenv("PP_NO_WIDE_SCHUR_TILES") == nullptr;
+    if (g->mt_wide) {
+      // 32 x 32 super-tiles (k_schur_mfma_wide): per (super-tile pair, panel column) one record with the positions of the
+      // 32 + 32 rows; mt_a / mt_b per quarter (4 per super-tile, -1: the quarter above the diagonal), items {r0, r1, super, 0}
+      std::map<std::pair<int, int>, std::vector<int>> by_super;
+      for (int pv = 0; pv < P.npiv; ++pv) {
+        const int w = P.piv_w[pv];
+        std::vector<int> sl;
+        std::vector<std::array<int, 32>> slots;
+        for (int q = P.piv_rowptr[pv]; q < P.piv_rowptr[pv + 1]; ++q) {
+          const int r = P.rowidx[(size_t)q];
+          if (r < P.n) continue;
+          const int c = r - P.n, si = c / 32;
+          if (sl.empty() || sl.back() != si) { sl.push_back(si); std::array<int, 32> e; e.fill(-1); slots.push_back(e); }
+          slots.back()[(size_t)(c % 32)] = w + (q - P.piv_rowptr[pv]);
+        }
+        for (size_t a = 0; a < sl.size(); ++a)
+          for (size_t b2 = 0; b2 <= a; ++b2)
+            for (int t = 0; t < w; ++t) {
+              auto& v = by_super[{sl[a], sl[b2]}];
+              for (int q = 0; q < 32; ++q) v.push_back(slots[a][(size_t)q] < 0 ? -1 : (int)(P.piv_uoff[pv] + (int64_t)slots[a][(size_t)q] * w + t));
+              for (int q = 0; q < 32; ++q) v.push_back(slots[b2][(size_t)q] < 0 ? -1 : (int)(P.piv_uoff[pv] + (int64_t)slots[b2][(size_t)q] * w + t));
+            }
+      }
+      std::vector<int> mta, mtb, mrec, mitem, mwptr{0};
+      int super = 0;
+      for (auto& kv : by_super) {
+        for (int x = 0; x < 2; ++x)
+          for (int y = 0; y < 2; ++y) {
+            const int ta = 2 * kv.first.first + x, tb = 2 * kv.first.second + y;
+            mta.push_back(ta >= tb ? ta : -1);
+            mtb.push_back(ta >= tb ? tb : -1);
+          }
+        const int r0 = (int)(mrec.size() / 64);
+        mrec.insert(mrec.end(), kv.second.begin(), kv.second.end());
+        const int r1 = (int)(mrec.size() / 64);
+        for (int r = r0; r < r1; r += PP_MT_SLICE) mitem.insert(mitem.end(), {r, std::min(r1, r + PP_MT_SLICE), super, 0});
+        mwptr.push_back((int)(mitem.size() / 4));
+        ++super;
+      }
+      g->nmt = (int)mta.size();                       // quarters (workgroups of the reduction)
+      g->nmt_items = (int)(mitem.size() / 4);
+      if ((rc = dev_upload(h, g, &d.mt_a, mta))) return rc;
+      if ((rc = dev_upload(h, g, &d.mt_b, mtb))) return rc;
+      if ((rc = dev_upload(h, g, &d.mt_rec, mrec))) return rc;
+      if ((rc = dev_upload(h, g, &d.mt_item, mitem))) return rc;
+      if ((rc = dev_upload(h, g, &d.mt_wptr, mwptr))) return rc;
+    } else {
       std::map<std::pair<int, int>, std::vector<int>> by_tile;      // (ta, tb) -> records of 32 ints
       for (int pv = 0; pv < P.npiv; ++pv) {
         const int w = P.piv_w[pv];
@@ -4327,11 +4455,15 @@ int pp_numeric_schur(pp_handle h) {
         const SchurTarget T{h->S, nc, h->btd, h->gs, h->G, h->scatter_err};
         hipLaunchKernelGGL(k_scatter_schur, dim3((unsigned)g->ntiles * d.nchunk), dim3(64), 0, st, d, g->ntiles, T);
       } else if (g->ntiles > 0 && h->schur_mfma && g->nmt > 0) {
-        hipLaunchKernelGGL(k_schur_mfma, dim3((unsigned)g->nmt_items * d.nchunk + ncb), dim3(64), 0, st, d, g->nmt_items, total8,
-                           h->counters);
+        if (g->mt_wide)
+          hipLaunchKernelGGL(k_schur_mfma_wide, dim3((unsigned)g->nmt_items * d.nchunk + ncb), dim3(64), 0, st, d, g->nmt_items, total8,
+                             h->counters);
+        else
+          hipLaunchKernelGGL(k_schur_mfma, dim3((unsigned)g->nmt_items * d.nchunk + ncb), dim3(64), 0, st, d, g->nmt_items, total8,
+                             h->counters);
         const bool last = (g == h->groups.back());
         hipLaunchKernelGGL(k_schur_reduce_mfma, dim3(g->nmt), dim3(1024), 0, st, d, g->nmt_items, h->S,
-                           last ? h->counters : (int*)nullptr, (first_covers && g == h->groups.front()) ? 1 : 0);
+                           last ? h->counters : (int*)nullptr, (first_covers && g == h->groups.front()) ? 1 : 0, g->mt_wide ? 1 : 0);
         tail_written = last;
       } else if (g->ntiles > 0) {
         hipLaunchKernelGGL(k_schur_tiles, dim3((unsigned)g->ntiles * d.nchunk + ncb, 1, 2), dim3(64), 0, st, d, g->ntiles, total8,
