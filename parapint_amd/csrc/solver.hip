@@ -1733,7 +1733,9 @@ __global__ __launch_bounds__(LDL_THREADS) void k_ldl_regs(int n, const double* _
       const int row = 16 * I + lk + 4 * r, col = 16 * J + li;
       double v = 0.0;
       if (t < ntt && row < n && col < n) {
-        v = S[row + (size_t)col * lda];
+        // S is symmetric in memory (both triangles are written): element (col, row) instead of (row, col) makes the 16
+        // lanes of a row of the wave read 128 contiguous bytes instead of 16 cache lines
+        v = S[col + (size_t)row * lda];
         if (Q) v += (row >= col) ? Q[row + (size_t)col * lda] : Q[col + (size_t)row * lda];
       }
       acc[s][r] = v;
