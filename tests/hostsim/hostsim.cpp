@@ -190,6 +190,13 @@ void ppsim_operand_loads(void* h, long long* out) {
   }
 }
 
+// per pivot: level and width (diagnostics)
+void ppsim_get_piv_level(void* h, int* level, int* width) {
+  Plan& P = *(Plan*)h;
+  std::memcpy(level, P.piv_level.data(), sizeof(int) * P.npiv);
+  std::memcpy(width, P.piv_w.data(), sizeof(int) * P.npiv);
+}
+
 // per pivot: number of coupling rows in its panel
 void ppsim_get_ncrow(void* h, int* out) { Plan& P = *(Plan*)h; std::memcpy(out, P.piv_ncrow.data(), sizeof(int) * P.npiv); }
 
