@@ -23,6 +23,7 @@
 // a panel are independent tasks and every update is a two-operand gather.
 #pragma once
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -61,6 +62,20 @@ struct PlanOptions {
   int md_delta_abs = 3;   // minimum-degree tolerance (absolute) for height-aware selection
   double md_delta_rel = 0.5;   // ... and relative to the current minimum degree
   double pivot_threshold = 0.01;  // 1x1 pivot accepted if |d| >= threshold * max|row| (MA27 cntl(1) analogue)
+  // Elimination order: 0 = one sub-pivot at a time, lowest prospective level first within the degree window
+  // (rounds 1-2 of this project); 1 = rounds of independent clusters of up to sn_wmax columns (symbolic.cpp, step 2);
+  // 2 = both, the cheaper schedule kept (build_plan).
+  int order_mode = 2;
+  // rounds (order_mode 1): a round with at most round_relax_pop candidates lets a sub-pivot join a cluster if it adds
+  // at most max(round_relax_tol_rows, round_relax_tol_frac * |structure|) rows (else sn_tol_rows); a round with more
+  // than round_narrow_pop candidates keeps its clusters at round_narrow_wmax columns
+  int round_relax_pop = 600;
+  int round_relax_tol_rows = 2;
+  double round_relax_tol_frac = 0.05;
+  // 1: pad every panel so that it holds all columns of a block pivot or none (rounds 1-2); 0: single-column entries
+  int close_supernodes = 0;
+  int round_narrow_pop = 1 << 30;
+  int round_narrow_wmax = 2;
 };
 
 // Task sizes by batch (instances of the pattern group on this rank).  MEASURED on one MI355X (tools/tune_sweep.sh): with
@@ -78,6 +93,48 @@ inline void tune_for_batch(PlanOptions& o, int batch) {
   }
 }
 
+// Developer knob for schedule experiments (environment PP_PLAN_TUNE = "max_task_entries=48,scale_task_rows=16,..."),
+// read by the library and by the test interpreter alike.  Returns false and names the key if one is unknown.
+inline bool apply_plan_tune(PlanOptions& opt, const char* tune, std::string& bad_key) {
+  if (!tune) return true;
+  std::string t(tune);
+  size_t pos = 0;
+  while (pos < t.size()) {
+    size_t end = t.find(',', pos);
+    if (end == std::string::npos) end = t.size();
+    const std::string kv = t.substr(pos, end - pos);
+    const size_t eq = kv.find('=');
+    if (eq != std::string::npos) {
+      const std::string k = kv.substr(0, eq);
+      const double v = std::atof(kv.c_str() + eq + 1);
+      if (k == "max_task_entries") opt.max_task_entries = (int)v;
+      else if (k == "fuse_task_entries") opt.fuse_task_entries = (int)v;
+      else if (k == "scale_task_rows") opt.scale_task_rows = (int)v;
+      else if (k == "tail_task_entries") opt.tail_task_entries = (int)v;
+      else if (k == "tail_piv_max") opt.tail_piv_max = (int)v;
+      else if (k == "sn_tail_pop") opt.sn_tail_pop = (int)v;
+      else if (k == "sn_tail_wmax") opt.sn_tail_wmax = (int)v;
+      else if (k == "sn_tail_tol_frac") opt.sn_tail_tol_frac = v;
+      else if (k == "sn_wmax") opt.sn_wmax = (int)v;
+      else if (k == "sn_tol_rows") opt.sn_tol_rows = (int)v;
+      else if (k == "md_delta_abs") opt.md_delta_abs = (int)v;
+      else if (k == "md_delta_rel") opt.md_delta_rel = v;
+      else if (k == "row_split_factor") opt.row_split_factor = v;
+      else if (k == "task_order") opt.task_order = (int)v;
+      else if (k == "order_mode") opt.order_mode = (int)v;
+      else if (k == "close_supernodes") opt.close_supernodes = (int)v;
+      else if (k == "round_relax_pop") opt.round_relax_pop = (int)v;
+      else if (k == "round_relax_tol_rows") opt.round_relax_tol_rows = (int)v;
+      else if (k == "round_relax_tol_frac") opt.round_relax_tol_frac = v;
+      else if (k == "round_narrow_pop") opt.round_narrow_pop = (int)v;
+      else if (k == "round_narrow_wmax") opt.round_narrow_wmax = (int)v;
+      else { bad_key = k; return false; }
+    }
+    pos = end + 1;
+  }
+  return true;
+}
+
 
 // Factor schedule ("L form").  For every block pivot p two panels are stored with the same
 // indexing: the unscaled panel U_p = [P_p ; U_p] and the scaled rows L_p = U_p inv(P_p).  The
@@ -85,6 +142,8 @@ inline void tune_for_batch(PlanOptions& o, int batch) {
 // row entries e:
 //     acc[q] -= U[e.u] * L[e.l + q * e.wk]   for q < w      (source column t of panel k: U_k[i][t], L_k[p_q][t])
 //     acc[e.q] += input value ~e.u                           (initial-value entry: e.u < 0, e.l < 0)
+//     acc[e.q] -= U[e.u] * L[e.l]                            (single-column entry: e.wk == 0 -- the source panel holds
+//                                                             only some of the w columns of the block pivot as rows)
 // so every U operand is loaded once per row, no per-task multiplier tables are needed and block
 // pivots of any width cost (1 + w) loads per w multiply-adds.
 // Task kinds:  0 gather chunk of a big panel (stores U, and the term magnitudes of pivot-block

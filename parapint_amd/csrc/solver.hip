@@ -287,129 +287,9 @@ __device__ __forceinline__ void invert_and_scale(const GroupDev& g, int p, int w
 // scaling of their rows.
 // NW = waves (tasks) per workgroup: PP_QUAD on the levels that hold split rows, 1 elsewhere (a workgroup keeps its
 // resources until its longest wave ends, so unrelated tasks are better off as workgroups of their own).
-#ifndef PP_X_GATHER_ATTR
-#define PP_X_GATHER_ATTR
-#endif
-template <int WM, int NW>
-__global__ __launch_bounds__(64 * NW) PP_X_GATHER_ATTR void k_gather_level(GroupDev g, int task0, int chunk0, int ny, double eps) {
-  __shared__ double red[NW > 1 ? NW : 1][NW > 1 ? 2 * WM : 1][NW > 1 ? 64 : 1];   // partial sums / term magnitudes of a split row
-  const int lane = threadIdx.x & 63, wave = (NW > 1) ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
-  const int b = (PP_CHUNK_OF_WG(ny) + chunk0) * 64 + lane;
-  const size_t bpad = (size_t)g.bpad;
-  const int* t = g.ftask + TASK_INTS * (size_t)(task0 + NW * PP_TASK_OF_WG(ny) + wave);
-  const int p = t[0], r0 = t[1], r1 = t[2], dptr0 = t[3], kind = t[4], E0 = t[5], E1 = t[6];
-  const int piece = (NW > 1) ? t[12] : 0, npieces = (NW > 1) ? t[13] : 1;   // npieces is the same for all waves of the workgroup
-  if (kind < 0 && npieces <= 1) return;            // quad padding (in a split quad the padding waves join the barrier)
-  const int w = (WM == 1) ? 1 : t[7];
-  const int uoff = t[8], boff = t[9], doff = t[10];
-  const unsigned sub = (unsigned)t[11];
-  const double* __restrict__ U = g.U + b;
-  const double* __restrict__ Lb = g.L + b;
-  const double* __restrict__ R = g.rawT + b;
-  const int nrow = r1 - r0;
-  const int* dp = g.fdst_ptr + dptr0;
-  const bool dp_vec = (nrow + 1 <= 64);
-  const int dpv = (dp_vec && lane <= nrow) ? dp[lane] : 0;
-  double* Udst = g.U + ((size_t)uoff + (size_t)r0 * w) * bpad + b;
-  double* Tmd = g.Tm + ((size_t)boff + (size_t)r0 * w) * bpad + b;
-  const int nblk = (r0 < w) ? (w - r0) : 0;          // leading destination rows that belong to the pivot block
-  double tmax_diag = 0.0;
-  double acc[WM], tmax[WM];
-#pragma unroll
-  for (int q = 0; q < WM; ++q) { acc[q] = 0.0; tmax[q] = 0.0; }
-  int d = 0;
-  int dend = (nrow > 0) ? (dp_vec ? bcast(dpv, 1) : dp[1]) : 0x7fffffff;
-#define PP_FINALIZE()                                                                      \
-  do {                                                                                     \
-    if (NW > 1 && npieces > 1) break;   /* split row: combined below */                   \
-    _Pragma("unroll") for (int q = 0; q < WM; ++q) {                                       \
-      if (q < w) {                                                                         \
-        Udst[(size_t)(d * w + q) * bpad] = acc[q];                                         \
-        if (d < nblk) {                                                                    \
-          if (kind == 0) Tmd[(size_t)(d * w + q) * bpad] = tmax[q]; else tmax_diag = fmax(tmax_diag, tmax[q]); \
-        }                                                                                  \
-      }                                                                                    \
-      acc[q] = 0.0; tmax[q] = 0.0;                                                         \
-    }                                                                                      \
-    ++d;                                                                                   \
-    dend = (d < nrow) ? (dp_vec ? bcast(dpv, d + 1) : dp[d + 1]) : 0x7fffffff;             \
-  } while (0)
-  for (int eb = E0; eb < E1; eb += 64) {
-    const int cnt = min(64, E1 - eb);
-    int4 rec = make_int4(0, 0, 0, 0);
-    if (lane < cnt) rec = *reinterpret_cast<const int4*>(g.fent + 4 * (size_t)(eb + lane));
-#define PP_GROUP(G)                                                                        \
-  {                                                                                        \
-    int eu[G], el[G], ew[G], eq[G];                                                        \
-    _Pragma("unroll") for (int i = 0; i < G; ++i) {                                        \
-      const int qi = min(i0 + i, cnt - 1);                                                 \
-      eu[i] = bcast(rec.x, qi); el[i] = bcast(rec.y, qi); ew[i] = bcast(rec.z, qi);        \
-      if (WM > 1) { eq[i] = bcast(rec.w, qi) & 0xff; } else { eq[i] = 0; }                 \
-    }                                                                                      \
-    double su[G], sl[G][WM];                                                               \
-    _Pragma("unroll") for (int i = 0; i < G; ++i) {                                        \
-      const double* base = (eu[i] >= 0) ? U : R;                                           \
-      const int idx = (eu[i] >= 0) ? eu[i] : (-1 - eu[i]);                                 \
-      const double sv = base[(size_t)((eu[i] < 0 && idx == g.const_row) ? 0 : idx) * bpad]; \
-      su[i] = (eu[i] < 0 && idx == g.const_row) ? 1.0 : sv;                                \
-      _Pragma("unroll") for (int q = 0; q < WM; ++q)                                       \
-        sl[i][q] = Lb[(size_t)((eu[i] >= 0) ? el[i] + min(q, w - 1) * ew[i] : 0) * bpad];  \
-    }                                                                                      \
-    _Pragma("unroll") for (int i = 0; i < G; ++i) {                                        \
-      if (i0 + i < cnt) {                                                                  \
-        while (eb + i0 + i == dend) PP_FINALIZE();                                         \
-        /* initial-value record: (y, z) hold the coefficient of the input entry (1 for plain raw values) */ \
-        const double coef = __hiloint2double(ew[i], el[i]);                                \
-        _Pragma("unroll") for (int q = 0; q < WM; ++q) {                                   \
-          const double m = (eu[i] >= 0) ? ((q < w) ? sl[i][q] : 0.0) : ((q == eq[i]) ? -coef : 0.0); \
-          const double term = su[i] * m;                                                   \
-          acc[q] -= term;                                                                  \
-          tmax[q] = fmax(tmax[q], fabs(term));                                             \
-        }                                                                                  \
-      }                                                                                    \
-    }                                                                                      \
-  }
-    int i0 = 0;
-    // entries requested together.  MEASURED (C3, round 2): block pivots 2-4 wide with groups of 16 / 8 entries
-    // (80 / 40 operands held) took 203 VGPRs = 2 waves per SIMD, and the wide levels 2-5 (10 000+ waves each) ran at
-    // 2 TB/s; groups of 4 (88 VGPRs, 5 waves per SIMD) cut the gather kernels from 614 to 563 us per step; groups of
-    // 2 (8 waves per SIMD) and of 8 (4 waves) measure the same as 4.
-#ifdef PP_X_GB
-    constexpr int GB = (WM == 1) ? 16 : PP_X_GB;
-#else
-    constexpr int GB = (WM == 1) ? 16 : 4;
-#endif
-    for (; cnt - i0 > 4; i0 += GB) PP_GROUP(GB)
-    if (i0 < cnt) PP_GROUP(4)
-#undef PP_GROUP
-  }
-  if (NW > 1 && npieces > 1) {
-    // one long row over the waves of this quad: partial sums meet in LDS, piece 0 adds them in piece order
-#pragma unroll
-    for (int q = 0; q < WM; ++q) { red[wave][q][lane] = acc[q]; red[wave][WM + q][lane] = tmax[q]; }
-    __syncthreads();
-    if (piece == 0 && kind >= 0) {
-#pragma unroll
-      for (int q = 0; q < WM; ++q) {
-        double a = acc[q], m = tmax[q];
-        for (int j = 1; j < npieces; ++j) { a += red[j][q][lane]; m = fmax(m, red[j][WM + q][lane]); }
-        if (q < w) {
-          Udst[(size_t)q * bpad] = a;
-          if (r0 < w) Tmd[(size_t)q * bpad] = m;
-        }
-      }
-    }
-    return;
-  }
-  while (d < nrow) PP_FINALIZE();
-#undef PP_FINALIZE
-  if (kind == 1) invert_and_scale<WM>(g, p, w, uoff, doff, sub, r0, r1, tmax_diag, true, bpad, b, eps);
-}
-
-// The same task, written for few instructions per entry (round 2; the kernel above stays as the comparison build
-// -DPP_X_OLD_GATHER).  MEASURED at C3 (tools/pmc_metrics.sh): the waves of the kernel above issue 1100 VALU + 1300 SALU
-// instructions for ~20 entries and spend 56 % of their life waiting to issue (a 40 KB body of short branchy blocks),
-// 23 % waiting for memory.  Here:
+// Written for few instructions per entry (round 2).  MEASURED at C3 (tools/pmc_metrics.sh): the round-1 kernel issued
+// 1100 VALU + 1300 SALU instructions for ~20 entries and spent 56 % of its life waiting to issue (a 40 KB body of short
+// branchy blocks), 23 % waiting for memory.  Here:
 //   * row ends are marked in the records themselves (bits 8.. of the fourth field = rows that end before this entry),
 //   * operands are addressed as uniform row base + lane offset, so the address arithmetic is scalar,
 //   * the term magnitudes (zero-pivot test) are only tracked in the rows of the pivot block; all other rows are plain
@@ -528,30 +408,32 @@ __global__ __launch_bounds__(64 * NW) void k_gather_flat(GroupDev g, int task0, 
         const bool prod = eu[i] >= 0;
         const int idx = prod ? eu[i] : -1 - eu[i];
         const double* __restrict__ base = prod ? Ub : Rb;
-#if defined(PP_X_NOLOADS)      // timing experiments (wrong results): no operand traffic at all / no L / no U
-        for (int v = 0; v < NV; ++v) su[i][v] = 1.0 + 1e-9 * (double)(idx & 15);
-        for (int q = 0; q < WM; ++q) for (int v = 0; v < NV; ++v) sl[i][q][v] = 1e-3 * (double)((el[i] + q) & 7);
-#elif defined(PP_X_NOL)
-        ldv<NV>(base + (size_t)((!prod && idx == g.const_row) ? 0 : idx) * bpad + b, su[i]);
-        for (int q = 0; q < WM; ++q) for (int v = 0; v < NV; ++v) sl[i][q][v] = 1e-3 * (double)((el[i] + q) & 7);
-#elif defined(PP_X_NOU)
-        for (int v = 0; v < NV; ++v) su[i][v] = 1.0 + 1e-9 * (double)(idx & 15);
-#pragma unroll
-        for (int q = 0; q < WM; ++q)
-          ldv<NV>(Lb + (size_t)(prod ? el[i] + min(q, w - 1) * ew[i] : 0) * bpad + b, sl[i][q]);
-#else
         ldv<NV>(base + (size_t)((!prod && idx == g.const_row) ? 0 : idx) * bpad + b, su[i]);
 #pragma unroll
         for (int q = 0; q < WM; ++q)
           ldv<NV>(Lb + (size_t)(prod ? el[i] + min(q, w - 1) * ew[i] : 0) * bpad + b, sl[i][q]);
-#endif
       }
 #pragma unroll
       for (int i = 0; i < G; ++i) {
         if (i0 + i < cnt) {
           for (int nf = ef[i] >> 8; nf > 0; --nf) finalize();
           if (eu[i] >= 0) {
-            if (d < nblk) {
+            if (ew[i] == 0) {
+              // single-column entry (the source panel holds only some columns of this block pivot as rows): all w
+              // requests above went to the one L operand
+              const int eq = ef[i] & 0xff;
+#pragma unroll
+              for (int q = 0; q < WM; ++q) {
+                if (q == eq) {
+#pragma unroll
+                  for (int v = 0; v < NV; ++v) {
+                    const double term = su[i][v] * sl[i][q][v];
+                    acc[q][v] -= term;
+                    if (d < nblk) tmax[q][v] = fmax(tmax[q][v], fabs(term));
+                  }
+                }
+              }
+            } else if (d < nblk) {
 #pragma unroll
               for (int q = 0; q < WM; ++q)
 #pragma unroll
@@ -677,7 +559,8 @@ __global__ __launch_bounds__(64) void k_gather_level_lean(GroupDev g, int task0,
         ldv<NV>(Lb + (size_t)((ex >= 0) ? ey + min(q, w - 1) * ez : 0) * bpad, lv);
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-          const double m = (ex >= 0) ? ((q < w) ? lv[v] : 0.0) : ((q == (ew & 0xff)) ? -coef : 0.0);
+          // (product entry over all w columns; single-column product entry, ez == 0; initial value)
+          const double m = (ex >= 0) ? ((ez != 0 ? q < w : q == (ew & 0xff)) ? lv[v] : 0.0) : ((q == (ew & 0xff)) ? -coef : 0.0);
           const double term = (cst ? 1.0 : sv[v]) * m;
           acc[q][v] -= term;
           tmax[q][v] = fmax(tmax[q][v], fabs(term));
@@ -3760,35 +3643,9 @@ int pp_add_group_mapped(pp_handle h, int n, int batch, int nnzK, const int32_t* 
   if (h->sn_wmax > 0) opt.sn_wmax = h->sn_wmax;
   if (h->sn_tol >= 0) opt.sn_tol_rows = h->sn_tol;
   if (h->pivot_threshold > 0.0) opt.pivot_threshold = h->pivot_threshold;
-  if (const char* tune = std::getenv("PP_PLAN_TUNE")) {
-    // developer knob for schedule experiments: "max_task_entries=48,scale_task_rows=16,..."
-    std::string t(tune);
-    size_t pos = 0;
-    while (pos < t.size()) {
-      size_t end = t.find(',', pos);
-      if (end == std::string::npos) end = t.size();
-      const std::string kv = t.substr(pos, end - pos);
-      const size_t eq = kv.find('=');
-      if (eq != std::string::npos) {
-        const std::string k = kv.substr(0, eq);
-        const double v = std::atof(kv.c_str() + eq + 1);
-        if (k == "max_task_entries") opt.max_task_entries = (int)v;
-        else if (k == "fuse_task_entries") opt.fuse_task_entries = (int)v;
-        else if (k == "scale_task_rows") opt.scale_task_rows = (int)v;
-        else if (k == "tail_task_entries") opt.tail_task_entries = (int)v;
-        else if (k == "tail_piv_max") opt.tail_piv_max = (int)v;
-        else if (k == "sn_tail_pop") opt.sn_tail_pop = (int)v;
-        else if (k == "sn_tail_wmax") opt.sn_tail_wmax = (int)v;
-        else if (k == "sn_tail_tol_frac") opt.sn_tail_tol_frac = v;
-        else if (k == "sn_wmax") opt.sn_wmax = (int)v;
-        else if (k == "md_delta_abs") opt.md_delta_abs = (int)v;
-        else if (k == "md_delta_rel") opt.md_delta_rel = v;
-        else if (k == "row_split_factor") opt.row_split_factor = v;
-        else if (k == "task_order") opt.task_order = (int)v;
-        else return fail(h, 3, "PP_PLAN_TUNE: unknown key " + k);
-      }
-      pos = end + 1;
-    }
+  {
+    std::string bad;
+    if (!pp::apply_plan_tune(opt, std::getenv("PP_PLAN_TUNE"), bad)) { delete g; return fail(h, 3, "PP_PLAN_TUNE: unknown key " + bad); }
   }
   g->nc_loc = nc_loc;
   if (cmap) g->cmap_host.assign(cmap, cmap + (size_t)batch * nc_loc);
@@ -4351,14 +4208,8 @@ int pp_numeric_factor_blocks(pp_handle h) {
         for (int q = 0; q < sp.n; ++q) {
           const int ny = sp.c0[q + 1] - sp.c0[q];
           if (nt > 0) {
-#ifdef PP_X_LEANMAX
-            const bool lean = P.flevel_maxent[l] <= 12 || (P.flevel_maxent[l] <= PP_X_LEANMAX && P.flevel_nsplit[l] == 0);
-#else
             const bool lean = P.flevel_maxent[l] <= 12 && P.flevel_nsplit[l] == 0;      // (the lean kernel has no split rows)
-#endif
             const int mw = g->level_maxw[l];
-#define PP_LAUNCH_GATHER(K, ...) hipLaunchKernelGGL((K<__VA_ARGS__>), dim3((unsigned)nt * ny), dim3(64), 0, fan[q], d, t0, sp.c0[q], ny, PIVOT_EPS)
-#define PP_LAUNCH_QUADS(K, WM) hipLaunchKernelGGL((K<WM, PP_QUAD>), dim3((unsigned)(nt / PP_QUAD) * ny), dim3(64 * PP_QUAD), 0, fan[q], d, t0, sp.c0[q], ny, PIVOT_EPS)
             // two instances per lane where the chunks pair up (chunk counts and offsets in units of 128 instances)
             const bool pair = h->lane_pairs && ny % 2 == 0 && sp.c0[q] % 2 == 0;
 #define PP_LAUNCH_FLAT(WM) do { \
@@ -4377,19 +4228,6 @@ int pp_numeric_factor_blocks(pp_handle h) {
               else PP_LAUNCH_LEAN(PP_WMAX);
 #undef PP_LAUNCH_LEAN
             }
-#ifdef PP_X_OLD_GATHER
-            else if (P.flevel_nsplit[l] == 0) {
-              if (mw == 1) PP_LAUNCH_GATHER(k_gather_level, 1, 1);
-              else if (mw == 2) PP_LAUNCH_GATHER(k_gather_level, 2, 1);
-              else if (mw <= 4) PP_LAUNCH_GATHER(k_gather_level, 4, 1);
-              else PP_LAUNCH_GATHER(k_gather_level, PP_WMAX, 1);
-            } else {
-              if (mw == 1) PP_LAUNCH_QUADS(k_gather_level, 1);
-              else if (mw == 2) PP_LAUNCH_QUADS(k_gather_level, 2);
-              else if (mw <= 4) PP_LAUNCH_QUADS(k_gather_level, 4);
-              else PP_LAUNCH_QUADS(k_gather_level, PP_WMAX);
-            }
-#else
             else if (P.flevel_nsplit[l] == 0) {
               if (mw == 1) PP_LAUNCH_FLAT(1);
               else if (mw == 2) PP_LAUNCH_FLAT(2);
@@ -4401,9 +4239,6 @@ int pp_numeric_factor_blocks(pp_handle h) {
               else if (mw <= 4) PP_LAUNCH_FLAT_QUADS(4);
               else PP_LAUNCH_FLAT_QUADS(PP_WMAX);
             }
-#endif
-#undef PP_LAUNCH_GATHER
-#undef PP_LAUNCH_QUADS
 #undef PP_LAUNCH_FLAT
 #undef PP_LAUNCH_FLAT_QUADS
           }

@@ -5,6 +5,8 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <set>
 #include <tuple>
@@ -15,8 +17,28 @@ namespace {
 
 }  // namespace
 
+static int build_plan_ordered(int n, int nc, int nnzK, const int* rowK, const int* colK, int nnzB, const int* rowB,
+                              const int* colB, const double* vals, const PlanOptions& opt, Plan& P);
+
 int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nnzB, const int* rowB,
                const int* colB, const double* vals, const PlanOptions& opt, Plan& P) {
+  if (opt.order_mode != 2) return build_plan_ordered(n, nc, nnzK, rowK, colK, nnzB, rowB, colB, vals, opt, P);
+  // both elimination orders, the cheaper schedule kept: a level costs its launches (two for the factorisation, one
+  // in each solve sweep, at a floor of 5-8 us each on one MI355X), an entry of the factor its trips through HBM --
+  // about 2500 entries to the level at a thousand instances
+  PlanOptions o = opt;
+  o.order_mode = 1;
+  int rc = build_plan_ordered(n, nc, nnzK, rowK, colK, nnzB, rowB, colB, vals, o, P);
+  Plan Q;
+  o.order_mode = 0;
+  const int rc0 = build_plan_ordered(n, nc, nnzK, rowK, colK, nnzB, rowB, colB, vals, o, Q);
+  auto cost = [](const Plan& x) { return (int64_t)x.n_levels * 2500 + x.usize; };
+  if (rc0 == 0 && (rc != 0 || cost(Q) < cost(P))) { P = std::move(Q); rc = rc0; }
+  return rc;
+}
+
+static int build_plan_ordered(int n, int nc, int nnzK, const int* rowK, const int* colK, int nnzB, const int* rowB,
+                              const int* colB, const double* vals, const PlanOptions& opt, Plan& P) {
   P = Plan();
   P.n = n; P.nc = nc; P.opt = opt; P.ncan = nnzK + nnzB;
   P.numeric_ordering = (vals != nullptr);
@@ -97,48 +119,10 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
   std::vector<Ent> tmp;
   std::vector<int> N;
   std::vector<int> sp_start, sp_w;   // sub-pivots (1x1 / 2x2) in elimination order
-  while ((int)order.size() < n) {
-    int u = -1, v = -1;
-    {
-      // best 1x1 candidate: a strong node within the tolerance window above the minimum strong
-      // degree, lowest prospective level first
-      int d_s = INT_MAX;
-      if (!q_strong.empty()) {
-        d_s = std::get<0>(*q_strong.begin());
-        u = pick(q_strong, d_s, d_s + std::max(opt.md_delta_abs, (int)(opt.md_delta_rel * d_s)));
-      }
-      // 2x2 candidate: the minimum-degree weak node with its largest off-diagonal neighbour; taken
-      // when no strong node is left, or when the pair is no more expensive than the best 1x1
-      if (!q_weak.empty() && std::get<0>(*q_weak.begin()) < d_s) {
-        int uw = std::get<2>(*q_weak.begin()), vw = -1;
-        double best = -1.0;
-        for (auto& e : row[uw]) {
-          if (e.first >= n) continue;
-          double a = std::fabs(e.second);
-          if (a > best) { best = a; vw = e.first; }
-        }
-        if (vw >= 0) {
-          double det = diag[uw] * diag[vw] - best * best;
-          double ref = std::max(std::fabs(diag[uw] * diag[vw]), best * best);
-          if (!(std::fabs(det) > 1e-12 * ref)) vw = -1;  // numerically singular pair
-        }
-        if (vw >= 0) {
-          // degree of the pair = |N(u) u N(v)| - 2
-          size_t i = 0, j = 0, cnt = 0;
-          const auto &ru = row[uw], &rv = row[vw];
-          while (i < ru.size() || j < rv.size()) {
-            int a = (i < ru.size()) ? ru[i].first : INT_MAX, bb = (j < rv.size()) ? rv[j].first : INT_MAX;
-            if (a == bb) { ++i; ++j; } else if (a < bb) ++i; else ++j;
-            ++cnt;
-          }
-          int d_uv = (int)cnt - 2;
-          if (u < 0 || d_uv <= d_s) { u = uw; v = vw; }
-        } else if (u < 0) {
-          u = uw;  // isolated / singular weak node: 1x1, flagged at run time
-        }
-      }
-    }
-    // neighbourhood of the pivot and its (u, v) columns
+  std::vector<int> sp_cluster;       // rounds: cluster of the sub-pivot (consecutive sub-pivots of one cluster form one block pivot)
+  int n_clusters = 0;
+  // numeric elimination of the sub-pivot (u) or (u, v) from the current Schur complement; leaves its structure in N
+  auto eliminate = [&](int u, int v) {
     N.clear();
     for (auto& e : row[u]) if (e.first != v) { N.push_back(e.first); lu[e.first] = e.second; }
     double b_uv = 0.0;
@@ -194,11 +178,150 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
     for (int x : N) { lu[x] = 0.0; lv[x] = 0.0; }
     sp_start.push_back((int)order.size());
     sp_w.push_back(v >= 0 ? 2 : 1);
+    sp_cluster.push_back(n_clusters);
     order.push_back(u);
     if (v >= 0) { order.push_back(v); P.n_2x2++; }
     pstruct.push_back(N);
     std::vector<Ent>().swap(row[u]);
     if (v >= 0) std::vector<Ent>().swap(row[v]);
+  };
+  // largest off-diagonal K neighbour of a weak node that is allowed as its 2x2 partner (or -1)
+  auto partner_of = [&](int uw, const std::vector<int>* blocked, int round) -> int {
+    int vw = -1;
+    double best = -1.0;
+    for (auto& e : row[uw]) {
+      if (e.first >= n) continue;
+      double a = std::fabs(e.second);
+      if (a > best) { best = a; vw = e.first; }
+    }
+    if (vw >= 0) {
+      double det = diag[uw] * diag[vw] - best * best;
+      double ref = std::max(std::fabs(diag[uw] * diag[vw]), best * best);
+      if (!(std::fabs(det) > 1e-12 * ref)) vw = -1;  // numerically singular pair
+    }
+    if (vw >= 0 && blocked && (*blocked)[vw] == round) vw = -1;
+    return vw;
+  };
+  auto pair_degree = [&](int uw, int vw) -> int {   // |N(u) u N(v)| - 2
+    size_t i = 0, j = 0, cnt = 0;
+    const auto &ru = row[uw], &rv = row[vw];
+    while (i < ru.size() || j < rv.size()) {
+      int a = (i < ru.size()) ? ru[i].first : INT_MAX, bb = (j < rv.size()) ? rv[j].first : INT_MAX;
+      if (a == bb) { ++i; ++j; } else if (a < bb) ++i; else ++j;
+      ++cnt;
+    }
+    return (int)cnt - 2;
+  };
+  // one step of the sequential rule: the best 1x1 / 2x2 candidate of the whole remaining graph
+  auto pick_sequential = [&](int& u, int& v) {
+    u = -1; v = -1;
+    // best 1x1 candidate: a strong node within the tolerance window above the minimum strong
+    // degree, lowest prospective level first
+    int d_s = INT_MAX;
+    if (!q_strong.empty()) {
+      d_s = std::get<0>(*q_strong.begin());
+      u = pick(q_strong, d_s, d_s + std::max(opt.md_delta_abs, (int)(opt.md_delta_rel * d_s)));
+    }
+    // 2x2 candidate: the minimum-degree weak node with its largest off-diagonal neighbour; taken
+    // when no strong node is left, or when the pair is no more expensive than the best 1x1
+    if (!q_weak.empty() && std::get<0>(*q_weak.begin()) < d_s) {
+      int uw = std::get<2>(*q_weak.begin());
+      int vw = partner_of(uw, nullptr, 0);
+      if (vw >= 0) {
+        int d_uv = pair_degree(uw, vw);
+        if (u < 0 || d_uv <= d_s) { u = uw; v = vw; }
+      } else if (u < 0) {
+        u = uw;  // isolated / singular weak node: 1x1, flagged at run time
+      }
+    }
+  };
+  if (opt.order_mode == 0) {
+    while ((int)order.size() < n) {
+      int u, v;
+      pick_sequential(u, v);
+      eliminate(u, v);
+      ++n_clusters;
+    }
+  } else {
+    // Rounds of independent clusters.  A round takes, in order of increasing degree, every node of the degree
+    // window that is not adjacent to a cluster already chosen in this round, and grows it along the elimination
+    // tree into a cluster of up to sn_wmax columns: the next sub-pivot is a node of the last structure whose own
+    // row adds at most sn_tol_rows rows to it (the rule by which step 2b merges a sub-pivot into its parent, so
+    // the cluster becomes one block pivot).  The clusters of a round have no edges between them and form one level
+    // of the schedule; what a round leaves are the separators.  On a banded coupling (a chain of bandwidth b) a
+    // round eliminates sn_wmax of every sn_wmax + b nodes, where taking single nodes of lowest height first (the
+    // sequential rule above) eliminates one of b + 1.
+    std::vector<int> blocked(n, -1);
+    std::vector<std::pair<int, int>> cand;   // (degree, node)
+    int round = 0;
+    while ((int)order.size() < n) {
+      int d_s = q_strong.empty() ? INT_MAX : std::get<0>(*q_strong.begin());
+      int d_w = q_weak.empty() ? INT_MAX : std::get<0>(*q_weak.begin());
+      const int d0 = std::min(d_s, d_w);
+      const int limit = d0 + std::max(opt.md_delta_abs, (int)(opt.md_delta_rel * d0));
+      cand.clear();
+      for (auto it = q_strong.begin(); it != q_strong.end() && std::get<0>(*it) <= limit; ++it)
+        cand.push_back({std::get<0>(*it), std::get<2>(*it)});
+      for (auto it = q_weak.begin(); it != q_weak.end() && std::get<0>(*it) <= limit; ++it)
+        cand.push_back({std::get<0>(*it), std::get<2>(*it)});
+      std::sort(cand.begin(), cand.end());
+      // Padding is paid per cluster, a level once: a round with few candidates may pad more (rows a sub-pivot adds
+      // to the structure of the cluster it joins) to take fewer rounds; a round with many keeps its clusters narrow,
+      // because the panels below a wide block pivot are closed under it (every row of a child that holds one of its
+      // columns holds them all).
+      const bool sparse_round = (int)cand.size() <= opt.round_relax_pop;
+      const int wmax_r = ((int)cand.size() > opt.round_narrow_pop) ? std::min(opt.sn_wmax, opt.round_narrow_wmax) : opt.sn_wmax;
+      int taken = 0;
+      for (auto& dc : cand) {
+        int u = dc.second, v = -1;
+        if (eliminated[u] || blocked[u] == round) continue;
+        if (!strong[u]) {
+          v = partner_of(u, &blocked, round);
+          if (v < 0 || pair_degree(u, v) > limit) continue;
+        }
+        int width = (v >= 0) ? 2 : 1;
+        eliminate(u, v);
+        ++taken;
+        // grow the cluster along the chain of parents
+        while (width < wmax_r) {
+          const int base = (int)N.size() - 1;
+          const int tol_r = sparse_round ? std::max(opt.round_relax_tol_rows, (int)(opt.round_relax_tol_frac * (double)N.size()))
+                                         : opt.sn_tol_rows;
+          int bu = -1, bv = -1, bnew = INT_MAX;
+          for (int q : N) {
+            if (q >= n) break;
+            if (blocked[q] == round) continue;
+            const int add = (int)row[q].size() - base;
+            if (add > tol_r || add >= bnew) continue;
+            if (strong[q]) { bu = q; bv = -1; bnew = add; continue; }
+            if (width + 2 > wmax_r) continue;
+            const int q2 = partner_of(q, &blocked, round);
+            if (q2 < 0 || !std::binary_search(N.begin(), N.end(), q2)) continue;
+            const int add2 = pair_degree(q, q2) - ((int)N.size() - 2);
+            if (add2 > tol_r || add2 >= bnew) continue;
+            bu = q; bv = q2; bnew = add2;
+          }
+          if (bu < 0) break;
+          eliminate(bu, bv);
+          width += (bv >= 0) ? 2 : 1;
+        }
+        for (int q : N) { if (q >= n) break; blocked[q] = round; }
+        ++n_clusters;
+        if (std::getenv("PP_DEBUG_ROUNDS")) {
+          fprintf(stderr, "round %d seed %d width %d N:", round, u, width);
+          for (int q : N) fprintf(stderr, " %d", q);
+          fprintf(stderr, "\n");
+        }
+      }
+      if (taken == 0) {
+        // nothing in the window could be taken (weak nodes without a usable partner): one step of the sequential rule
+        int u, v;
+        pick_sequential(u, v);
+        eliminate(u, v);
+        ++n_clusters;
+      }
+      ++round;
+    }
   }
   // ---- 2b. supernodes: a sub-pivot is merged into its elimination-tree parent when their
   // structures agree up to sn_tol_rows padded rows and the merged width stays <= sn_wmax.  The
@@ -252,8 +375,17 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
       const int tol = in_tail ? std::max(opt.sn_tol_rows,
                                          (int)(opt.sn_tail_tol_frac * (double)(srows[q].size() + sp_w[q])))
                               : opt.sn_tol_rows;
+      // columns the later sub-pivots of q's cluster will add to this chain (rounds: they are merged unconditionally)
+      int later = 0;
+      if (opt.order_mode != 0)
+        for (int x = q + 1; x < nsp && sp_cluster[x] == sp_cluster[q]; ++x) later += sp_w[x];
+      if (opt.order_mode != 0 && q > 0 && sp_cluster[q - 1] == sp_cluster[q] && sp_parent[q - 1] == q) {
+        // consecutive sub-pivots of one cluster of the rounds (its growth rule has accepted the padding)
+        merged_child[q] = q - 1; is_merged[q - 1] = 1; chain_width[q] = chain_width[q - 1] + sp_w[q];
+        continue;
+      }
       for (int c : sp_children[q]) {
-        if (chain_width[c] + sp_w[q] > wcap) continue;
+        if (chain_width[c] + sp_w[q] + later > wcap) continue;
         const auto& rc = srows[c];
         // rows of c beyond q's columns vs rows of q; q's columns inside c's structure
         int have_cols = 0;
@@ -331,6 +463,7 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
       col += sp_w[x];
     }
     P.piv_w[p] = col;
+    if (col > PP_WMAX) { P.error = "internal: block pivot wider than PP_WMAX"; return 3; }
   }
   P.piv_start[P.npiv] = n;
   P.perm = new_order;
@@ -340,7 +473,12 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
   for (int p = 0; p < P.npiv; ++p)
     for (int q = 0; q < P.piv_w[p]; ++q) P.piv_of_col[P.piv_start[p] + q] = p;
 
-  // ---- 3. row structures in new indices (union over the members), closed under supernodes
+  // ---- 3. row structures in new indices (union over the members).  With opt.close_supernodes every panel is
+  // closed under the block pivots above it (a row structure that holds one column of a block pivot holds them all:
+  // explicit zeros, so that every update is a whole-row entry); without it (the default) a panel keeps its own
+  // rows and an update into a block pivot of which it holds only some columns is made of single-column entries
+  // (plan.hpp, FEntry).  The panels of the leaves -- most of the storage -- then carry no padding at all, however
+  // wide the block pivots above them are.
   std::vector<std::vector<int>> rows(P.npiv);
   for (int p = 0; p < P.npiv; ++p) {
     auto& r = rows[p];
@@ -357,20 +495,22 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
   for (auto& v : srows) std::vector<int>().swap(v);
   for (int p = 0; p < P.npiv; ++p) {
     auto& r = rows[p];
-    bool added = false;
-    size_t m = r.size();
-    for (size_t t = 0; t < m; ++t) {
-      int c = r[t];
-      if (c >= n) break;
-      int q = P.piv_of_col[c];
-      if (P.piv_w[q] > 1) {
-        for (int o = P.piv_start[q]; o < P.piv_start[q] + P.piv_w[q]; ++o)
-          if (!std::binary_search(r.begin(), r.begin() + m, o)) { r.push_back(o); added = true; }
+    if (opt.close_supernodes) {
+      bool added = false;
+      size_t m = r.size();
+      for (size_t t = 0; t < m; ++t) {
+        int c = r[t];
+        if (c >= n) break;
+        int q = P.piv_of_col[c];
+        if (P.piv_w[q] > 1) {
+          for (int o = P.piv_start[q]; o < P.piv_start[q] + P.piv_w[q]; ++o)
+            if (!std::binary_search(r.begin(), r.begin() + m, o)) { r.push_back(o); added = true; }
+        }
       }
+      if (added) { std::sort(r.begin(), r.end()); r.erase(std::unique(r.begin(), r.end()), r.end()); }
     }
-    if (added) { std::sort(r.begin(), r.end()); r.erase(std::unique(r.begin(), r.end()), r.end()); }
-    // propagate closure to the parent (first row's pivot): rows beyond the parent's own
-    // columns must appear in the parent's structure
+    // fill closure: the rows beyond the parent's own columns (parent = block pivot of the first row) must appear
+    // in the parent's structure (the union over the members of a block pivot and the padding above add rows)
     if (!r.empty() && r[0] < n) {
       int par = P.piv_of_col[r[0]];
       int pend = P.piv_start[par] + P.piv_w[par];
@@ -432,23 +572,23 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
     P.pos_of_can[nnzK + e] = P.piv_uoff[p] + (int64_t)s * P.piv_w[p] + (j - P.piv_start[p]);
   }
 
-  // ---- 5. row patterns (which earlier panels hold rows of pivot p) and levels
-  std::vector<std::vector<std::pair<int, int>>> rowpat(P.npiv);  // (k, mslot)
+  // ---- 5. row patterns (which earlier panels hold rows of pivot p, and which of its columns) and levels
+  struct RowPat { int k, mslot, cnt; int qs[PP_WMAX]; };   // rows mslot .. mslot + cnt - 1 of panel k are the columns qs[] of p
+  std::vector<std::vector<RowPat>> rowpat(P.npiv);
   for (int k = 0; k < P.npiv; ++k) {
     const auto& r = rows[k];
-    int last = -1;
-    for (size_t t = 0; t < r.size() && r[t] < n; ++t) {
-      int p = P.piv_of_col[r[t]];
-      if (p == last) continue;
-      last = p;
-      if (r[t] != P.piv_start[p]) { P.error = "internal: pivot rows not closed"; return 3; }
-      rowpat[p].push_back({k, P.piv_w[k] + (int)t});
+    for (size_t t = 0; t < r.size() && r[t] < n;) {
+      const int p = P.piv_of_col[r[t]];
+      RowPat rp; rp.k = k; rp.mslot = P.piv_w[k] + (int)t; rp.cnt = 0;
+      while (t < r.size() && r[t] < n && P.piv_of_col[r[t]] == p) { rp.qs[rp.cnt++] = r[t] - P.piv_start[p]; ++t; }
+      if (opt.close_supernodes && rp.cnt != P.piv_w[p]) { P.error = "internal: pivot rows not closed"; return 3; }
+      rowpat[p].push_back(rp);
     }
   }
   P.piv_level.assign(P.npiv, 0);
   for (int p = 0; p < P.npiv; ++p) {
     int lv = 0;
-    for (auto& km : rowpat[p]) lv = std::max(lv, P.piv_level[km.first] + 1);
+    for (auto& km : rowpat[p]) lv = std::max(lv, P.piv_level[km.k] + 1);
     P.piv_level[p] = lv;
     P.n_levels = std::max(P.n_levels, lv + 1);
   }
@@ -496,7 +636,8 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
         ++can_cursor;
       }
       for (auto& km : rowpat[p]) {
-        const int k = km.first, mslot = km.second, wk = P.piv_w[k];
+        const int k = km.k, mslot = km.mslot, wk = P.piv_w[k];
+        const bool whole = km.cnt == w;       // panel k holds every column of p: one entry updates a whole row
         const auto& rk = rows[k];
         size_t tp = 0;
         for (size_t t = (size_t)(mslot - wk); t < rk.size(); ++t) {
@@ -509,11 +650,16 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
             d = w + (int)tp;
           }
           const int srow = wk + (int)t;
-          for (int tt = 0; tt < wk; ++tt)
-            row_ents[(size_t)d].push_back({(int)(P.piv_uoff[k] + (int64_t)srow * wk + tt),
-                                           (int)(P.piv_uoff[k] + (int64_t)mslot * wk + tt), wk, 0});
-          P.flops_factor += (int64_t)wk * w;
-          total += wk;
+          for (int tt = 0; tt < wk; ++tt) {
+            const int upos = (int)(P.piv_uoff[k] + (int64_t)srow * wk + tt);
+            if (whole)
+              row_ents[(size_t)d].push_back({upos, (int)(P.piv_uoff[k] + (int64_t)mslot * wk + tt), wk, 0});
+            else
+              for (int j = 0; j < km.cnt; ++j)
+                row_ents[(size_t)d].push_back({upos, (int)(P.piv_uoff[k] + (int64_t)(mslot + j) * wk + tt), 0, km.qs[j]});
+          }
+          P.flops_factor += (int64_t)wk * km.cnt;
+          total += whole ? wk : wk * km.cnt;
         }
       }
       const bool in_tail = P.piv_level[p] >= P.tail_level0;
@@ -632,9 +778,12 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
       for (int q = 0; q < P.piv_w[p]; ++q) {
         const int c = P.piv_start[p] + q;
         for (auto& km : rowpat[p]) {
-          const int k = km.first, wk = P.piv_w[k];
+          const int k = km.k, wk = P.piv_w[k];
+          int j = 0;
+          while (j < km.cnt && km.qs[j] != q) ++j;
+          if (j == km.cnt) continue;            // panel k has no row for this column of p
           for (int t = 0; t < wk; ++t) {
-            P.sfwd_upos.push_back((int)(P.piv_uoff[k] + (int64_t)(km.second + q) * wk + t));
+            P.sfwd_upos.push_back((int)(P.piv_uoff[k] + (int64_t)(km.mslot + j) * wk + t));
             P.sfwd_zcol.push_back(P.piv_start[k] + t);
           }
         }

@@ -52,6 +52,7 @@ void* ppsim_create(int n, int nc, int nnzK, const int* rowK, const int* colK, in
   if (g_sn_wmax > 0) opt.sn_wmax = g_sn_wmax;
   if (g_sn_tol >= 0) opt.sn_tol_rows = g_sn_tol;
   if (g_pivot_threshold > 0.0) opt.pivot_threshold = g_pivot_threshold;
+  { std::string bad; pp::apply_plan_tune(opt, std::getenv("PP_PLAN_TUNE"), bad); }
   int rc = pp::build_plan(n, nc, nnzK, rowK, colK, nnzB, rowB, colB, vals, opt, *P);
   if (rc != 0) { /* keep the plan so the error string can be read */ }
   return P;
@@ -266,6 +267,10 @@ int ppsim_factor(void* h, const double* can, double* U, double* L, double* Dinv,
               const double v = can[-1 - fe.u];
               pa[fe.q] += v;
               pm[fe.q] = std::fmax(pm[fe.q], std::fabs(v));
+            } else if (fe.wk == 0) {
+              const double term = U[fe.u] * L[fe.l];
+              pa[fe.q] -= term;
+              pm[fe.q] = std::fmax(pm[fe.q], std::fabs(term));
             } else {
               const double su = U[fe.u];
               for (int q = 0; q < w; ++q) {
@@ -292,6 +297,10 @@ int ppsim_factor(void* h, const double* can, double* U, double* L, double* Dinv,
             const double v = can[-1 - fe.u];
             acc[fe.q] += v;
             tmax[fe.q] = std::fmax(tmax[fe.q], std::fabs(v));
+          } else if (fe.wk == 0) {
+            const double term = U[fe.u] * L[fe.l];
+            acc[fe.q] -= term;
+            tmax[fe.q] = std::fmax(tmax[fe.q], std::fabs(term));
           } else {
             const double su = U[fe.u];
             for (int q = 0; q < w; ++q) {
