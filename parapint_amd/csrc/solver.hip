@@ -82,7 +82,17 @@ struct GroupDev {
 // the same XCD: the operands that different tasks of a level re-read for that chunk meet in ONE L2 instead of
 // being duplicated in all eight.
 #define PP_TASK_OF_WG(ny) ((int)(blockIdx.x / (unsigned)(ny)))
-#define PP_CHUNK_OF_WG(ny) ((int)(blockIdx.x % (unsigned)(ny)))
+// Workgroups are dealt round-robin over the 8 XCDs, so workgroup x runs on XCD x mod 8.  Kernels with two instances
+// per lane work on chunks of 128 instances (PP_PAIR_OF_WG: pair j = instance chunks 2j, 2j + 1, on XCD j mod 8); the
+// kernels with one instance per lane must place the 64-instance chunks 2j and 2j + 1 on that same XCD, or every
+// hand-over between the two kinds (gather -> scale -> gather, solve levels) crosses XCDs and misses its L2: within a
+// run of 16 workgroups the chunk is 2 (s mod 8) + s / 8 instead of s.
+__device__ __forceinline__ int pp_chunk64_perm(unsigned s, unsigned ny) {
+  return (ny % 16u == 0u) ? (int)((s & ~15u) | ((s & 7u) << 1) | ((s >> 3) & 1u)) : (int)s;
+}
+__device__ __forceinline__ int pp_chunk64_of_wg(unsigned ny) { return pp_chunk64_perm(blockIdx.x % ny, ny); }
+#define PP_CHUNK_OF_WG(ny) pp_chunk64_of_wg((unsigned)(ny))
+#define PP_PAIR_OF_WG(ny) ((int)(blockIdx.x % (unsigned)(ny)))
 
 // ------------------------------------------------------------------------------------------
 // [rows][m] row-major  ->  [m'][bpad] (instance-interleaved), zero padding for rows >= nrows.
@@ -323,7 +333,7 @@ template <int WM, int NW, int NV>
 __global__ __launch_bounds__(64 * NW) void k_gather_flat(GroupDev g, int task0, int chunk0, int ny, double eps) {
   __shared__ double red[NW > 1 ? NW : 1][NW > 1 ? 2 * WM * NV : 1][NW > 1 ? 64 : 1];   // partial sums / term magnitudes of a split row
   const int lane = threadIdx.x & 63, wave = (NW > 1) ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
-  const unsigned b = (unsigned)(((PP_CHUNK_OF_WG(ny) + chunk0) * 64 + lane) * NV);    // first instance of this lane
+  const unsigned b = (unsigned)((((NV == 2 ? PP_PAIR_OF_WG(ny) : PP_CHUNK_OF_WG(ny)) + chunk0) * 64 + lane) * NV);    // first instance of this lane
   const size_t bpad = (size_t)g.bpad;
   const int* t = g.ftask + TASK_INTS * (size_t)(task0 + NW * PP_TASK_OF_WG(ny) + wave);
 #ifdef PP_X_STAMPS
@@ -519,7 +529,7 @@ __global__ __launch_bounds__(64 * NW) void k_gather_flat(GroupDev g, int task0, 
 template <int WM, int NV>
 __global__ __launch_bounds__(64) void k_gather_level_lean(GroupDev g, int task0, int chunk0, int ny, double eps) {
   const int lane = threadIdx.x;
-  const unsigned b = (unsigned)(((PP_CHUNK_OF_WG(ny) + chunk0) * 64 + lane) * NV);    // first instance of this lane
+  const unsigned b = (unsigned)((((NV == 2 ? PP_PAIR_OF_WG(ny) : PP_CHUNK_OF_WG(ny)) + chunk0) * 64 + lane) * NV);    // first instance of this lane
   const size_t bpad = (size_t)g.bpad;
   const int* t = g.ftask + TASK_INTS * (size_t)(task0 + PP_TASK_OF_WG(ny));
   const int p = t[0], r0 = t[1], r1 = t[2], dptr0 = t[3], kind = t[4];
@@ -834,7 +844,7 @@ __global__ __launch_bounds__(64) void k_schur_tiles(GroupDev g, int ntile_all, s
     return;
   }
   const unsigned wg = blockIdx.x - ncb;
-  const int chunk = (int)(wg % (unsigned)g.nchunk);
+  const int chunk = pp_chunk64_perm(wg % (unsigned)g.nchunk, (unsigned)g.nchunk);
   const int b = chunk * 64 + lane;
   const size_t bpad = (size_t)g.bpad;
   const int tile = (int)(wg / (unsigned)g.nchunk), half = blockIdx.z;
@@ -952,7 +962,7 @@ __global__ __launch_bounds__(64) void k_schur_mfma(GroupDev g, int nwork_items, 
   const unsigned ncb = gridDim.x - nwork;                                // counting workgroups come first in the grid
   if (blockIdx.x < ncb) { count_codes_block(g, blockIdx.x, ncb, total8, counters, lane); return; }
   const unsigned wg = blockIdx.x - ncb;
-  const int chunk = (int)(wg % (unsigned)g.nchunk);
+  const int chunk = pp_chunk64_perm(wg % (unsigned)g.nchunk, (unsigned)g.nchunk);
   const int item = (int)(wg / (unsigned)g.nchunk);       // a slice of at most PP_MT_SLICE records of one tile
   const int li = lane & 15, lk = lane >> 4;
   const size_t bpad = (size_t)g.bpad;
@@ -1016,7 +1026,7 @@ __global__ __launch_bounds__(64) void k_schur_mfma_wide(GroupDev g, int nwork_it
   const unsigned ncb = gridDim.x - nwork;                                // counting workgroups come first in the grid
   if (blockIdx.x < ncb) { count_codes_block(g, blockIdx.x, ncb, total8, counters, lane); return; }
   const unsigned wg = blockIdx.x - ncb;
-  const int chunk = (int)(wg % (unsigned)g.nchunk);
+  const int chunk = pp_chunk64_perm(wg % (unsigned)g.nchunk, (unsigned)g.nchunk);
   const int item = (int)(wg / (unsigned)g.nchunk);
   const int li = lane & 15, lk = lane >> 4;
   const size_t bpad = (size_t)g.bpad;
@@ -2742,7 +2752,7 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_level(GroupDev g, int col0, int
 constexpr int PP_PAIR_MAXROW = 16;   // (8: backward sweep 0.194 ms, 16: 0.169, 32: 0.177 at C3)
 __global__ __launch_bounds__(64) void k_fwd_level_pair(GroupDev g, int col0, int chunk0, int ny) {
   const int lane = threadIdx.x;
-  const unsigned b = (unsigned)(((PP_CHUNK_OF_WG(ny) + chunk0) * 64 + lane) * 2);
+  const unsigned b = (unsigned)(((PP_PAIR_OF_WG(ny) + chunk0) * 64 + lane) * 2);
   const size_t bpad = (size_t)g.bpad;
   const int* rec = g.fwd_rec + 4 * (size_t)(col0 + PP_TASK_OF_WG(ny));   // {column, original row, e0, e1}
   const int c = rec[0], e0 = rec[2], e1 = rec[3];
@@ -2773,7 +2783,7 @@ __global__ __launch_bounds__(64) void k_fwd_level_pair(GroupDev g, int col0, int
 
 __global__ __launch_bounds__(64) void k_bwd_level_pair(GroupDev g, int col0, int chunk0, int ny, const double* __restrict__ xc) {
   const int lane = threadIdx.x;
-  const unsigned b = (unsigned)(((PP_CHUNK_OF_WG(ny) + chunk0) * 64 + lane) * 2);
+  const unsigned b = (unsigned)(((PP_PAIR_OF_WG(ny) + chunk0) * 64 + lane) * 2);
   const size_t bpad = (size_t)g.bpad;
   const int* rec = g.bwd_rec + 8 * (size_t)(col0 + PP_TASK_OF_WG(ny));   // {c, w, q, nr, rowptr, L base, doff, p0}
   const int c = rec[0], w = rec[1], q = rec[2], nr = rec[3];
@@ -2840,12 +2850,12 @@ __global__ __launch_bounds__(64) void k_fwd_coupling(GroupDev g, double* __restr
   if (lane == 0) g.rspart[(size_t)chunk * g.nc + c] = s;
 }
 
-__global__ __launch_bounds__(256) void k_rs_reduce(GroupDev g, double* __restrict__ rs) {
+__global__ __launch_bounds__(256) void k_rs_reduce(GroupDev g, double* __restrict__ rs, int store) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= g.nc) return;
   double s = 0.0;
   for (int q = 0; q < g.nchunk; ++q) s += g.rspart[(size_t)q * g.nc + c];
-  rs[c] += s;
+  rs[c] = store ? s : rs[c] + s;     // (the first group stores: no memset of r_s in front of the sweep)
 }
 
 // back substitution, one scalar column c = (block pivot p, component q) per workgroup:
@@ -3704,14 +3714,15 @@ int pp_end_symbolic(pp_handle h) {
     for (auto& t : P.ftasks) {
       const int nrow = t.r1 - t.r0;
       const int new_dptr0 = (int)fdst_ptr.size();
-      // fourth field of a record: bits 0-7 the destination column of an initial value, bits 8.. the number of
+      // fourth field of a record: bits 0-7 the destination column of an initial value or of a single-column product
+      // entry (third field 0), bits 8.. the number of
       // destination rows that END before this entry (0 inside a row; k_gather_flat closes that many rows first)
       int cur_row = 0;
       for (int dd = 0; dd < nrow; ++dd) {
         fdst_ptr.push_back((int)(fent.size() / 4));
         for (int e = P.fdst_ptr[t.dptr0 + dd]; e < P.fdst_ptr[t.dptr0 + dd + 1]; ++e) {
           const pp::FEntry& fe = P.fentries[e];
-          if (fe.u >= 0) { fent.insert(fent.end(), {fe.u, fe.l, fe.wk, (dd - cur_row) << 8}); cur_row = dd; }
+          if (fe.u >= 0) { fent.insert(fent.end(), {fe.u, fe.l, fe.wk, (fe.wk == 0 ? fe.q : 0) | ((dd - cur_row) << 8)}); cur_row = dd; }
           else {
             // the L index of an initial-value record is a dummy (position 0, always valid)
             const int ce = -1 - fe.u;
@@ -3835,9 +3846,14 @@ int pp_end_symbolic(pp_handle h) {
       for (auto& z : zc2) if (noent[(size_t)z]) z = -1 - P.perm[z];
       for (int q = 0; q < 16; ++q) { zf.push_back(0); zc2.push_back(0); }
       for (size_t i = 0; i < brn.size(); i += 8) {
-        const int p0 = brn[i + 7];
+        const int p0 = brn[i + 7], w = brn[i + 1];
         brn[i] = P.perm[brn[i]];
-        if (noent[(size_t)p0]) brn[i + 7] = -1 - p0;
+        // y of the whole block pivot is read from the right-hand side only if NONE of its columns has incoming entries
+        // (then its level was not launched in the forward sweep); a level that was launched has written y for all of
+        // its columns.  (Columns of one block pivot may differ: a panel below may hold only some of them as rows.)
+        bool none = true;
+        for (int t = 0; t < w; ++t) none = none && noent[(size_t)(p0 + t)];
+        if (none) brn[i + 7] = -1 - p0;
       }
       for (auto& r : ro) if (r < P.n) r = P.perm[r];
       if ((rc = dev_upload(h, g, &g->zcolN_f, zf))) return rc;
@@ -4590,7 +4606,11 @@ int pp_solve_forward(pp_handle h) {
   PP_HIP(hipSetDevice(h->device));
   hipStream_t st = h->stream;
   const int nc = h->nc;
-  PP_HIP(hipMemsetAsync(h->rs, 0, std::max<size_t>(nc, 1) * sizeof(double), st));
+  // r_s is zeroed only if some group scatters into it (mapped groups: atomic adds) or if there is nothing to store;
+  // otherwise the reduction of the first group stores (a memset node costs 5-20 us of stream time around its 1.5 us)
+  bool rs_store_first = nc > 0 && !h->groups.empty();
+  for (Group* g : h->groups) rs_store_first = rs_store_first && !g->dev.cmapT && g->dev.nc == nc;
+  if (!rs_store_first) PP_HIP(hipMemsetAsync(h->rs, 0, std::max<size_t>(nc, 1) * sizeof(double), st));
   GroupStreams gst;
   if (fork_group_streams(h, gst)) return fail(h, 3, "stream fork failed");
   auto group_body = [&](size_t gi) -> int {
@@ -4647,7 +4667,9 @@ int pp_solve_forward(pp_handle h) {
     if (d.nc > 0) {
       PhaseScope ps(h, 5, 2);
       hipLaunchKernelGGL(k_fwd_coupling, dim3((unsigned)d.nc * d.nchunk), dim3(64), 0, h->stream, dn, h->rs);
-      if (!d.cmapT) hipLaunchKernelGGL(k_rs_reduce, dim3((d.nc + 255) / 256), dim3(256), 0, h->stream, d, h->rs);
+      if (!d.cmapT)
+        hipLaunchKernelGGL(k_rs_reduce, dim3((d.nc + 255) / 256), dim3(256), 0, h->stream, d, h->rs,
+                           (rs_store_first && g == h->groups.front()) ? 1 : 0);
     }
   }
   PP_HIP(hipGetLastError());
