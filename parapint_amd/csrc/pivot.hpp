@@ -120,6 +120,58 @@ PP_HD int invert_block_t(int w, unsigned sub, const double* a /* row-major with 
   return pos | (neg << 4) | (zero << 8);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Root front (plan.hpp, front_piv): a block pivot of up to WF = 16 columns, the same static sequence of 1x1 / 2x2
+// sub-pivots and the same sweep operator, written the way the device runs it (k_front_invert: one wave per row of A,
+// the pivot rows broadcast through LDS): row i is updated from its own column entries and the OLD pivot row(s); the
+// pivot rows themselves are scaled in place.  A is the full symmetric matrix, row-major with stride WF; inv is
+// packed like invert_block_t's.  This function is the definition the kernel is tested against (tests/hostsim).
+constexpr int PP_WF = 16;
+PP_HD int invert_front(int w, unsigned sub, double* A /* [PP_WF * PP_WF], rows >= w ignored */, double colmax, double eps,
+                       double* inv) {
+  int pos = 0, neg = 0, zero = 0;
+  for (int k = 0; k < w; ++k) {
+    const bool two = ((sub >> k) & 1u) && (k + 1 < w);
+    if (!two) {
+      const PivotResult pr = invert_pivot(1, A[k * PP_WF + k], 0.0, 0.0, colmax, eps);
+      pos += pr.code & 3; neg += (pr.code >> 2) & 3; zero += (pr.code >> 4) & 3;
+      for (int i = 0; i < w; ++i) {
+        if (i == k) continue;
+        const double l = A[i * PP_WF + k] * pr.i00;
+        for (int j = 0; j < w; ++j)
+          if (j != k) A[i * PP_WF + j] -= l * A[k * PP_WF + j];
+        A[i * PP_WF + k] = l;
+      }
+      for (int j = 0; j < w; ++j)
+        if (j != k) A[k * PP_WF + j] = A[k * PP_WF + j] * pr.i00;
+      A[k * PP_WF + k] = -pr.i00;
+    } else {
+      const int k1 = k + 1;
+      const PivotResult pr = invert_pivot(2, A[k * PP_WF + k], A[k1 * PP_WF + k], A[k1 * PP_WF + k1], colmax, eps);
+      pos += pr.code & 3; neg += (pr.code >> 2) & 3; zero += (pr.code >> 4) & 3;
+      for (int i = 0; i < w; ++i) {
+        if (i == k || i == k1) continue;
+        const double l0 = A[i * PP_WF + k] * pr.i00 + A[i * PP_WF + k1] * pr.i10;
+        const double l1 = A[i * PP_WF + k] * pr.i10 + A[i * PP_WF + k1] * pr.i11;
+        for (int j = 0; j < w; ++j)
+          if (j != k && j != k1) A[i * PP_WF + j] -= l0 * A[k * PP_WF + j] + l1 * A[k1 * PP_WF + j];
+        A[i * PP_WF + k] = l0; A[i * PP_WF + k1] = l1;
+      }
+      for (int j = 0; j < w; ++j) {
+        if (j == k || j == k1) continue;
+        const double a0 = A[k * PP_WF + j], a1 = A[k1 * PP_WF + j];
+        A[k * PP_WF + j] = a0 * pr.i00 + a1 * pr.i10;
+        A[k1 * PP_WF + j] = a0 * pr.i10 + a1 * pr.i11;
+      }
+      A[k * PP_WF + k] = -pr.i00; A[k1 * PP_WF + k] = -pr.i10; A[k * PP_WF + k1] = -pr.i10; A[k1 * PP_WF + k1] = -pr.i11;
+      ++k;
+    }
+  }
+  for (int i = 0; i < w; ++i)
+    for (int j = 0; j <= i; ++j) inv[i * (i + 1) / 2 + j] = -A[i * PP_WF + j];
+  return pos | (neg << 4) | (zero << 8);
+}
+
 // bound = the widest block the build supports
 PP_HD int invert_block(int w, unsigned sub, const double* a /* stride PP_WMAX */, double colmax, double eps, double* inv) {
   return invert_block_t<PP_WMAX>(w, sub, a, colmax, eps, inv);

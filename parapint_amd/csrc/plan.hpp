@@ -31,6 +31,9 @@
 #define PP_WMAX 4   // widest block pivot (supernode); pivot.hpp / kernels are instantiated for bounds 1, 2, 4 (8 builds too)
 #endif
 
+// widest root front (its inertia code keeps 4 bits per count, its rows live in the registers of 16 waves)
+#define PP_FRONT_MAX 15
+
 namespace pp {
 
 struct PlanOptions {
@@ -74,6 +77,11 @@ struct PlanOptions {
   double round_relax_tol_frac = 0.05;
   // 1: pad every panel so that it holds all columns of a block pivot or none (rounds 1-2); 0: single-column entries
   int close_supernodes = 0;
+  // root front (symbolic.cpp, step 2c): widest merged chain of the top of the tree (<= PP_FRONT_MAX; <= PP_WMAX: off),
+  // rows of the parent a link may lack, as a fraction of the parent's rows; rows per workgroup of k_scale_wide
+  int front_max = PP_FRONT_MAX;
+  double front_pad_frac = 1.0;
+  int front_scale_rows = 8;
   int round_narrow_pop = 1 << 30;
   int round_narrow_wmax = 2;
 };
@@ -122,6 +130,9 @@ inline bool apply_plan_tune(PlanOptions& opt, const char* tune, std::string& bad
       else if (k == "row_split_factor") opt.row_split_factor = v;
       else if (k == "task_order") opt.task_order = (int)v;
       else if (k == "order_mode") opt.order_mode = (int)v;
+      else if (k == "front_max") opt.front_max = (int)v;
+      else if (k == "front_pad_frac") opt.front_pad_frac = v;
+      else if (k == "front_scale_rows") opt.front_scale_rows = (int)v;
       else if (k == "close_supernodes") opt.close_supernodes = (int)v;
       else if (k == "round_relax_pop") opt.round_relax_pop = (int)v;
       else if (k == "round_relax_tol_rows") opt.round_relax_tol_rows = (int)v;
@@ -162,7 +173,10 @@ inline bool apply_plan_tune(PlanOptions& opt, const char* tune, std::string& bad
 #ifndef PP_QUAD
 #define PP_QUAD 4
 #endif
-struct FTask { int piv, r0, r1, dptr0, kind, piece = 0, npieces = 1; };
+
+// qoff / ws: column slice of the panel the task gathers (ws == w, qoff == 0 except in the root front, whose w > PP_WMAX
+// columns are gathered PP_WMAX at a time).  kind 3: scale chunk of the root front (k_scale_wide).
+struct FTask { int piv, r0, r1, dptr0, kind, piece = 0, npieces = 1, qoff = 0, ws = 0; };
 struct FEntry { int u, l, wk, q; };
 // Schur tile record: pivot p contributes to tile (ta, tb); slots (or -1) of the tile's
 // coupling rows inside panel p
@@ -197,6 +211,11 @@ struct Plan {
   std::vector<int> flevel_nsplit;        // per level: number of split rows (0: the level runs one wave per workgroup)
   std::vector<int> clevel_ptr, clevel_col;  // solve schedule: scalar columns (new indices) by level
   int tail_level0 = 0;                   // levels >= tail_level0 form the tail (== n_levels: no tail)
+  // Root front: the last block pivot when it is wider than PP_WMAX (else -1).  It is alone on the last level; its
+  // gather tasks (column slices) are in ftasks like all others, its pivot block is inverted by k_front_invert and its
+  // rows scaled by k_scale_wide in chunks wtasks (kind 3).
+  int front_piv = -1;
+  std::vector<FTask> wtasks;
   // forward-solve entries: scalar row (new column index c) = b_c - sum U[upos] * z[zcol]
   std::vector<int> sfwd_eptr;            // n+1 -> sfwd_upos / sfwd_zcol
   std::vector<int> sfwd_upos, sfwd_zcol;

@@ -348,6 +348,7 @@ __global__ __launch_bounds__(64 * NW) void k_gather_flat(GroupDev g, int task0, 
   const int w = (WM == 1) ? 1 : t[7];
   const int uoff = t[8], boff = t[9], doff = t[10];
   const unsigned sub = (unsigned)t[11];
+  const int wp = t[14], qoff = t[15];     // width of the whole panel and first column of this task's slice (root front; else w, 0)
 #ifdef PP_X_STAMPS
   if (stp) { stp[1] = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(E1 < 0); stp[13] = (unsigned long long)(E1 - E0); }
 #endif
@@ -355,9 +356,9 @@ __global__ __launch_bounds__(64 * NW) void k_gather_flat(GroupDev g, int task0, 
   const double* __restrict__ Lb = g.L;
   const double* __restrict__ Rb = g.rawT;
   const int nrow = r1 - r0;
-  double* Udst = g.U + ((size_t)uoff + (size_t)r0 * w) * bpad;     // uniform; lane offset added at the store
-  double* Tmd = g.Tm + ((size_t)boff + (size_t)r0 * w) * bpad;
-  const int nblk = (r0 < w) ? (w - r0) : 0;          // leading destination rows that belong to the pivot block
+  double* Udst = g.U + ((size_t)uoff + (size_t)r0 * wp + qoff) * bpad;     // uniform; lane offset added at the store
+  double* Tmd = g.Tm + ((size_t)boff + (size_t)r0 * wp + qoff) * bpad;
+  const int nblk = (r0 < wp) ? (wp - r0) : 0;        // leading destination rows that belong to the pivot block
   const bool split = NW > 1 && npieces > 1;
   double tmax_diag[NV];
   double acc[WM][NV], tmax[WM][NV];
@@ -372,12 +373,12 @@ __global__ __launch_bounds__(64 * NW) void k_gather_flat(GroupDev g, int task0, 
     if (!split) {                                    // (split row: combined below)
 #pragma unroll
       for (int q = 0; q < WM; ++q)
-        if (q < w) stv<NV>(Udst + (size_t)(d * w + q) * bpad + b, acc[q]);
+        if (q < w) stv<NV>(Udst + (size_t)(d * wp + q) * bpad + b, acc[q]);
       if (d < nblk) {
 #pragma unroll
         for (int q = 0; q < WM; ++q) {
           if (q < w) {
-            if (kind == 0) stv<NV>(Tmd + (size_t)(d * w + q) * bpad + b, tmax[q]);
+            if (kind == 0) stv<NV>(Tmd + (size_t)(d * wp + q) * bpad + b, tmax[q]);
             else {
 #pragma unroll
               for (int v = 0; v < NV; ++v) tmax_diag[v] = fmax(tmax_diag[v], tmax[q][v]);
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(64 * NW) void k_gather_flat(GroupDev g, int task0, 
         }
         if (q < w) {
           stv<NV>(Udst + (size_t)q * bpad + b, a);
-          if (r0 < w) stv<NV>(Tmd + (size_t)q * bpad + b, m);
+          if (r0 < wp) stv<NV>(Tmd + (size_t)q * bpad + b, m);
         }
       }
     }
@@ -537,15 +538,16 @@ __global__ __launch_bounds__(64) void k_gather_level_lean(GroupDev g, int task0,
   const int w = (WM == 1) ? 1 : t[7];
   const int uoff = t[8], boff = t[9], doff = t[10];
   const unsigned sub = (unsigned)t[11];
+  const int wp = t[14], qoff = t[15];     // (root front: panel width, first column of the slice; else w, 0)
   const double* __restrict__ U = g.U + b;
   const double* __restrict__ Lb = g.L + b;
   const double* __restrict__ R = g.rawT + b;
   const int nrow = r1 - r0;
   const int* dp = g.fdst_ptr + dptr0;
-  double* Udst = g.U + ((size_t)uoff + (size_t)r0 * w) * bpad + b;
-  double* Tmd = g.Tm + ((size_t)boff + (size_t)r0 * w) * bpad + b;
-  double* Ldst = g.L + ((size_t)uoff + (size_t)r0 * w) * bpad + b;
-  const int nblk = (r0 < w) ? (w - r0) : 0;
+  double* Udst = g.U + ((size_t)uoff + (size_t)r0 * wp + qoff) * bpad + b;
+  double* Tmd = g.Tm + ((size_t)boff + (size_t)r0 * wp + qoff) * bpad + b;
+  double* Ldst = g.L + ((size_t)uoff + (size_t)r0 * wp + qoff) * bpad + b;
+  const int nblk = (r0 < wp) ? (wp - r0) : 0;
   double tmax_diag[NV], inv1[NV], lmax = 0.0;
 #pragma unroll
   for (int v = 0; v < NV; ++v) { tmax_diag[v] = 0.0; inv1[v] = 0.0; }
@@ -579,7 +581,7 @@ __global__ __launch_bounds__(64) void k_gather_level_lean(GroupDev g, int task0,
     }
 #pragma unroll
     for (int q = 0; q < WM; ++q)
-      if (q < w) stv<NV>(Udst + (size_t)(d * w + q) * bpad, acc[q]);
+      if (q < w) stv<NV>(Udst + (size_t)(d * wp + q) * bpad, acc[q]);
     if (WM == 1 && kind == 1) {
       // scalar pivot, fused panel: row 0 is the pivot, every later one a row to scale
       if (d == 0) {
@@ -607,7 +609,7 @@ __global__ __launch_bounds__(64) void k_gather_level_lean(GroupDev g, int task0,
 #pragma unroll
       for (int q = 0; q < WM; ++q) {
         if (q < w) {
-          if (kind == 0) stv<NV>(Tmd + (size_t)(d * w + q) * bpad, tmax[q]);
+          if (kind == 0) stv<NV>(Tmd + (size_t)(d * wp + q) * bpad, tmax[q]);
           else {
 #pragma unroll
             for (int v = 0; v < NV; ++v) tmax_diag[v] = fmax(tmax_diag[v], tmax[q][v]);
@@ -721,6 +723,219 @@ __global__ __launch_bounds__(64) void k_scale_level(GroupDev g, int task0, int c
     }
   }
   if (grow && b < g.batch) g.growth[b] = 1;
+}
+
+// ------------------------------------------------------------------------------------------
+// Root front (plan.hpp, front_piv): the last block pivot, up to PP_FRONT_MAX columns wide.  Its rows were gathered in
+// column slices by the ordinary tasks; k_front_invert inverts the w x w pivot block with the static sequence of
+// 1x1 / 2x2 sub-pivots (pivot.hpp: invert_front is the definition) and k_scale_wide forms L = U inv(P).
+// One workgroup per chunk of 64 instances, lane = instance, wave i = row i of A (16 waves): per sub-pivot the owner(s)
+// of the pivot row(s) test and invert the pivot and publish the OLD row(s) and the inverse through LDS; every other
+// wave updates its row from them, the owners scale theirs.
+struct FrontRec { int piv, w, uoff, boff, doff; unsigned sub; };
+__global__ __launch_bounds__(512) void k_front_invert(GroupDev g, FrontRec fr, double* __restrict__ finv, double eps) {
+  constexpr int WF = pp::PP_WF, RW = 2, NWV = WF / RW;   // rows of A per wave, waves
+  __shared__ double rowk[2][2][WF][64];   // [step parity][first / second pivot row][column][lane]: the pivot rows before the step
+  __shared__ double pinv[2][3][64];       // [step parity]: i00, i10, i11
+  __shared__ double red[NWV][64];
+  __shared__ int cnt[NWV][64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x * 64 + lane;
+  const size_t bpad = (size_t)g.bpad;
+  const int w = fr.w;
+  double A[RW][WF];                       // rows RW wave .. of the block (all columns, both triangles)
+  int codes = 0;                          // inertia counts of the pivots this wave owned: pos | neg << 8 | zero << 16
+  double tm = 0.0;
+#pragma unroll
+  for (int r = 0; r < RW; ++r)
+#pragma unroll
+    for (int j = 0; j < WF; ++j) {
+      const int i = RW * wave + r;
+      const bool in = i < w && j < w;
+      const int hi = i > j ? i : j, lo = i > j ? j : i;       // (the lower triangle of the gathered block is the matrix)
+      const size_t off = (size_t)(in ? hi * w + lo : 0) * bpad + b;
+      const double av = g.U[(size_t)fr.uoff * bpad + off], tv = g.Tm[(size_t)fr.boff * bpad + off];
+      A[r][j] = in ? av : 0.0;
+      tm = fmax(tm, in ? tv : 0.0);
+    }
+#ifdef PP_X_STAMPS
+  unsigned long long* stp = (pp_x_stamps && lane == 0) ? pp_x_stamps + 4000000 + 16 * ((size_t)blockIdx.x * NWV + wave) : nullptr;
+  int stamp_k = 2;
+  if (stp) stp[0] = __builtin_amdgcn_s_memrealtime();
+#endif
+  red[wave][lane] = tm;
+  __syncthreads();
+  double colmax = 0.0;
+#pragma unroll
+  for (int i = 0; i < NWV; ++i) colmax = fmax(colmax, red[i][lane]);
+#ifdef PP_X_STAMPS
+  if (stp) stp[1] = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(colmax == 1.2345e300);
+#endif
+  // The step loop is unrolled: every register index below is a constant (a rolled loop selects the pivot column with
+  // compare / select pairs per element: 1.75 us per step, measured).  One barrier per 1x1 step: the buffers of a
+  // step are written again two steps later, which every wave reaches only through the barrier of the step in between.
+  bool second = false;
+#pragma unroll
+  for (int k = 0; k < PP_FRONT_MAX; ++k) {
+    if (k >= w) continue;                 // (uniform)
+    if (second) { second = false; continue; }
+    const int par = k & 1;
+    constexpr int dummy = 0; (void)dummy;
+    const int k1 = (k + 1 < WF) ? k + 1 : k;
+    const int ow = k / RW, orow = k % RW, ow1 = k1 / RW, orow1 = k1 % RW;     // owners of the pivot rows (constants)
+    const bool two = ((fr.sub >> k) & 1u) && (k + 1 < w);
+    if (!two) {
+      if (wave == ow) {
+#pragma unroll
+        for (int j = 0; j < WF; ++j) rowk[par][0][j][lane] = A[orow][j];
+        const pp::PivotResult pr = pp::invert_pivot(1, A[orow][k], 0.0, 0.0, colmax, eps);
+        pinv[par][0][lane] = pr.i00;
+        codes += (pr.code & 3) | (((pr.code >> 2) & 3) << 8) | (((pr.code >> 4) & 3) << 16);
+      }
+      __syncthreads();
+      const double i00 = pinv[par][0][lane];
+      double rk[WF];
+#pragma unroll
+      for (int j = 0; j < WF; ++j) rk[j] = rowk[par][0][j][lane];
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {      // (the owner's pivot row is overwritten below)
+        const double l = A[r][k] * i00;
+#pragma unroll
+        for (int j = 0; j < WF; ++j)
+          if (j != k) A[r][j] -= l * rk[j];
+        A[r][k] = l;
+      }
+      if (wave == ow) {
+#pragma unroll
+        for (int j = 0; j < WF; ++j) A[orow][j] = (j == k) ? -i00 : rk[j] * i00;
+      }
+    } else {
+      second = true;
+      if (wave == ow) {
+#pragma unroll
+        for (int j = 0; j < WF; ++j) rowk[par][0][j][lane] = A[orow][j];
+      }
+      if (wave == ow1) {
+#pragma unroll
+        for (int j = 0; j < WF; ++j) rowk[par][1][j][lane] = A[orow1][j];
+      }
+      __syncthreads();
+      if (wave == ow) {       // (a, b, c) = A[k][k], A[k1][k], A[k1][k1]
+        const pp::PivotResult pr = pp::invert_pivot(2, A[orow][k], rowk[par][1][k][lane], rowk[par][1][k1][lane], colmax, eps);
+        pinv[par][0][lane] = pr.i00; pinv[par][1][lane] = pr.i10; pinv[par][2][lane] = pr.i11;
+        codes += (pr.code & 3) | (((pr.code >> 2) & 3) << 8) | (((pr.code >> 4) & 3) << 16);
+      }
+      __syncthreads();
+      const double i00 = pinv[par][0][lane], i10 = pinv[par][1][lane], i11 = pinv[par][2][lane];
+      double rk[WF], rk1[WF];
+#pragma unroll
+      for (int j = 0; j < WF; ++j) { rk[j] = rowk[par][0][j][lane]; rk1[j] = rowk[par][1][j][lane]; }
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {      // (the owners' pivot rows are overwritten below)
+        const double l0 = A[r][k] * i00 + A[r][k1] * i10;
+        const double l1 = A[r][k] * i10 + A[r][k1] * i11;
+#pragma unroll
+        for (int j = 0; j < WF; ++j)
+          if (j != k && j != k1) A[r][j] -= l0 * rk[j] + l1 * rk1[j];
+        A[r][k] = l0; A[r][k1] = l1;
+      }
+      if (wave == ow) {
+#pragma unroll
+        for (int j = 0; j < WF; ++j) A[orow][j] = (j == k) ? -i00 : (j == k1) ? -i10 : rk[j] * i00 + rk1[j] * i10;
+      }
+      if (wave == ow1) {
+#pragma unroll
+        for (int j = 0; j < WF; ++j) A[orow1][j] = (j == k) ? -i10 : (j == k1) ? -i11 : rk[j] * i10 + rk1[j] * i11;
+      }
+    }
+#ifdef PP_X_STAMPS
+    if (stp && stamp_k < 15) { stp[stamp_k++] = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(A[0][0] == 1.2345e300); }
+#endif
+  }
+  {
+    // inv(P) = -A: packed by rows of the lower triangle for the solve sweeps, and as a full 16 x 16 matrix (zero beyond
+    // w) for k_scale_wide, whose operand addresses are then constants
+    double* invp = g.Dinv + (size_t)fr.doff * bpad + b;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const int i = RW * wave + r;
+#pragma unroll
+      for (int j = 0; j < WF; ++j) {
+        if (i < w && j <= i) invp[(size_t)(i * (i + 1) / 2 + j) * bpad] = -A[r][j];
+        finv[(size_t)(i * WF + j) * bpad + b] = (i < w && j < w) ? -A[r][j] : 0.0;
+      }
+    }
+  }
+  cnt[wave][lane] = codes;
+  __syncthreads();
+  if (wave == 0) {
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < NWV; ++i) c += cnt[i][lane];
+    const int code = (c & 255) | (((c >> 8) & 255) << 4) | (((c >> 16) & 255) << 8);
+    g.codes[(size_t)fr.piv * bpad + b] = (b < g.batch) ? (unsigned short)code : (unsigned short)0;
+  }
+#ifdef PP_X_STAMPS
+  if (stp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stp[15] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+}
+
+// Rows [r0, r1) of the root front: L rows = U rows * inv(P) with the explicit inverse from k_front_invert (the full,
+// zero-padded 16 x 16 form).  One workgroup of three waves per (chunk of rows, chunk of instances); wave c holds columns
+// 5c .. 5c + 4 of inv(P) in registers (75 values) and forms those entries of every row of the chunk.
+__global__ __launch_bounds__(192) void k_scale_wide(GroupDev g, const int* __restrict__ wtask, FrontRec fr,
+                                                    const double* __restrict__ finv, int ny) {
+  constexpr int WF = PP_FRONT_MAX, CW = 5;
+  const int lane = threadIdx.x & 63, cg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = PP_CHUNK_OF_WG(ny) * 64 + lane;
+  const size_t bpad = (size_t)g.bpad;
+  const int* t = wtask + TASK_INTS * (size_t)PP_TASK_OF_WG(ny);
+  const int r0 = t[1], r1 = t[2], w = fr.w;
+  const int c0 = CW * cg;
+  if (c0 >= w) return;
+#ifdef PP_X_STAMPS
+  unsigned long long* stp = (pp_x_stamps && lane == 0) ? pp_x_stamps + 4500000 + 16 * ((size_t)blockIdx.x * 3 + cg) : nullptr;
+  if (stp) stp[0] = __builtin_amdgcn_s_memrealtime();
+#endif
+  double ic[WF][CW];
+  {
+    const double* p = finv + (size_t)c0 * bpad + b;      // row t1 of the 16 x 16 matrix, columns c0 ..
+#pragma unroll
+    for (int t1 = 0; t1 < WF; ++t1) {
+#pragma unroll
+      for (int q = 0; q < CW; ++q) ic[t1][q] = p[(size_t)q * bpad];
+      p += (size_t)pp::PP_WF * bpad;
+    }
+  }
+  const double* Up = g.U + (size_t)fr.uoff * bpad + b;
+  double* Lp = g.L + (size_t)fr.uoff * bpad + b;
+  double lmax = 0.0;
+#ifdef PP_X_STAMPS
+  if (stp) stp[1] = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(ic[0][0] == 1.2345e300);
+  int stamp_k = 2;
+#endif
+  for (int r = r0; r < r1; ++r) {
+#ifdef PP_X_STAMPS
+    if (stp && stamp_k < 15) stp[stamp_k++] = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(lmax == 1.2345e300);
+#endif
+    double u[WF];
+#pragma unroll
+    for (int t1 = 0; t1 < WF; ++t1) u[t1] = Up[(size_t)(r * w + min(t1, w - 1)) * bpad];    // (columns >= w meet zero rows of inv)
+    double v[CW];
+#pragma unroll
+    for (int q = 0; q < CW; ++q) v[q] = 0.0;
+#pragma unroll
+    for (int t1 = 0; t1 < WF; ++t1)
+#pragma unroll
+      for (int q = 0; q < CW; ++q) v[q] += u[t1] * ic[t1][q];
+#pragma unroll
+    for (int q = 0; q < CW; ++q)
+      if (c0 + q < w) { Lp[(size_t)(r * w + c0 + q) * bpad] = v[q]; lmax = fmax(lmax, fabs(v[q])); }
+  }
+  if (lmax > g.lbound && b < g.batch) g.growth[b] = 1;
+#ifdef PP_X_STAMPS
+  if (stp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stp[15] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 }
 
 // counters[0..2] += (pos, neg, zero) over all block pivots (codes of padded instances are 0);
@@ -2807,6 +3022,13 @@ __global__ __launch_bounds__(64) void k_bwd_level_pair(GroupDev g, int col0, int
         z[0] += iv[0] * yv[0]; z[1] += iv[1] * yv[1];
       }
     }
+    for (int t = PP_WMAX; t < w; ++t) {        // (only the root front is wider than PP_WMAX)
+      const int hi = q > t ? q : t, lo = q > t ? t : q;
+      double yv[2], iv[2];
+      ldv<2>(rec[7] >= 0 ? Yp + (size_t)t * bpad : g.rhsN + (size_t)g.perm[p0 + t] * bpad + b, yv);
+      ldv<2>(inv + (size_t)(hi * (hi + 1) / 2 + lo) * bpad, iv);
+      z[0] += iv[0] * yv[0]; z[1] += iv[1] * yv[1];
+    }
   }
   double s[2] = {0.0, 0.0};
   for (int jb = 0; jb < nr; jb += 4) {
@@ -2889,6 +3111,17 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_level(GroupDev g, int col0, int
         const double yv = rec[7] >= 0 ? Yp[(size_t)t * bpad] : g.rhsN[(size_t)g.perm[p0 + t] * bpad + b];
         z += inv[(size_t)(hi * (hi + 1) / 2 + lo) * bpad] * yv;
       }
+    }
+    if (w > PP_WMAX) {                         // (only the root front: all its loads in flight together)
+      double yv[PP_FRONT_MAX], iv[PP_FRONT_MAX];
+#pragma unroll
+      for (int t = PP_WMAX; t < PP_FRONT_MAX; ++t) {
+        const int tt = min(t, w - 1), hi = q > tt ? q : tt, lo = q > tt ? tt : q;
+        yv[t] = rec[7] >= 0 ? Yp[(size_t)tt * bpad] : g.rhsN[(size_t)g.perm[p0 + tt] * bpad + b];
+        iv[t] = inv[(size_t)(hi * (hi + 1) / 2 + lo) * bpad];
+      }
+#pragma unroll
+      for (int t = PP_WMAX; t < PP_FRONT_MAX; ++t) z += (t < w) ? iv[t] * yv[t] : 0.0;
     }
   }
   const int j0 = (int)((long long)nr * wave / NW), j1 = (int)((long long)nr * (wave + 1) / NW);   // this wave's rows
@@ -3027,6 +3260,8 @@ struct Group {
   double *raw_own = nullptr, *rhs_own = nullptr, *rawT_own = nullptr;
   int nraw_used = 0;
   std::vector<int> level_maxw;   // widest block pivot per level (selects the scalar kernel variants)
+  const int* wtask = nullptr;    // scale chunks of the root front (device), plan.wtasks
+  double* front_inv = nullptr;   // root front: inv(P) as a zero-padded 16 x 16 matrix [entry][instance] (k_front_invert -> k_scale_wide)
   std::vector<int> diag_can;     // canonical entry of the diagonal (i, i) of K, or -1
   std::vector<uint8_t> fwd_level_has_entries;   // forward-solve levels whose columns have any incoming entry
   std::vector<int> fwd_level_team, bwd_level_team;   // waves per row / column on each solve level (1, 4 or 16)
@@ -3690,9 +3925,11 @@ int pp_end_symbolic(pp_handle h) {
     d.nchunk = d.bpad / WAVE; d.npiv = P.npiv; d.nraw = g->nraw; d.usize = P.usize;
     int rc;
     std::vector<int> uoff(P.piv_uoff.begin(), P.piv_uoff.end());
+    // widest column slice of a gather task per level (selects the kernel instantiation; the root front is gathered in
+    // slices of PP_WMAX) and widest block pivot with ordinary scale tasks
     g->level_maxw.assign(P.n_levels, 1);
     for (int pp_ = 0; pp_ < P.npiv; ++pp_)
-      g->level_maxw[P.piv_level[pp_]] = std::max(g->level_maxw[P.piv_level[pp_]], P.piv_w[pp_]);
+      g->level_maxw[P.piv_level[pp_]] = std::max(g->level_maxw[P.piv_level[pp_]], std::min(P.piv_w[pp_], PP_WMAX));
     std::vector<int> ftask, stask, fdst_ptr, fent, srec;
     const double one = 1.0;
     int one_lo, one_hi;
@@ -3737,12 +3974,22 @@ int pp_end_symbolic(pp_handle h) {
       }
       fdst_ptr.push_back((int)(fent.size() / 4));
       ftask.insert(ftask.end(), {t.piv, t.r0, t.r1, new_dptr0, t.kind, fdst_ptr[new_dptr0], (int)(fent.size() / 4),
-                                 P.piv_w[t.piv], (int)P.piv_uoff[t.piv], P.piv_boff[t.piv], P.piv_doff[t.piv],
-                                 (int)P.piv_sub[t.piv], t.piece, t.npieces, 0, 0});
+                                 t.ws > 0 ? t.ws : P.piv_w[t.piv], (int)P.piv_uoff[t.piv], P.piv_boff[t.piv], P.piv_doff[t.piv],
+                                 (int)P.piv_sub[t.piv], t.piece, t.npieces, P.piv_w[t.piv], t.qoff});
     }
     for (auto& t : P.stasks)
       stask.insert(stask.end(), {t.piv, t.r0, t.r1, -1, t.kind, 0, 0, P.piv_w[t.piv], (int)P.piv_uoff[t.piv],
-                                 P.piv_boff[t.piv], P.piv_doff[t.piv], (int)P.piv_sub[t.piv], 0, 1, 0, 0});
+                                 P.piv_boff[t.piv], P.piv_doff[t.piv], (int)P.piv_sub[t.piv], 0, 1, P.piv_w[t.piv], 0});
+    {
+      std::vector<int> wtask;
+      for (auto& t : P.wtasks)
+        wtask.insert(wtask.end(), {t.piv, t.r0, t.r1, -1, t.kind, 0, 0, P.piv_w[t.piv], (int)P.piv_uoff[t.piv],
+                                   P.piv_boff[t.piv], P.piv_doff[t.piv], (int)P.piv_sub[t.piv], 0, 1, P.piv_w[t.piv], 0});
+      g->wtask = nullptr;
+      if (!wtask.empty() && (rc = dev_upload(h, g, &g->wtask, wtask))) return rc;
+      g->front_inv = nullptr;
+      if (P.front_piv >= 0 && (rc = dev_alloc<double>(h, g, &g->front_inv, (size_t)pp::PP_WF * pp::PP_WF * d.bpad))) return rc;
+    }
     for (int q = 0; q < 16; ++q) fent.insert(fent.end(), {0, 0, 0, 0});   // slack for the vector record reads
     // tile records (one per panel) -> column-step records (one per panel column), with their own tile pointers
     std::vector<int> sptr(P.stile_ptr.size(), 0);
@@ -4214,6 +4461,7 @@ int pp_numeric_factor_blocks(pp_handle h) {
       int nlaunch = 0;
       for (int l = 0; l < P.n_levels; ++l)
         nlaunch += (P.flevel_ptr[l + 1] > P.flevel_ptr[l]) + (P.slevel_ptr[l + 1] > P.slevel_ptr[l]);
+      if (P.front_piv >= 0) nlaunch += 1 + (P.wtasks.empty() ? 0 : 1);
       PhaseScope ps(h, 1, nlaunch);
       const Splits sp = make_splits(h, d.nchunk);
       hipStream_t fan[PP_MAX_SPLIT];
@@ -4264,6 +4512,16 @@ int pp_numeric_factor_blocks(pp_handle h) {
             else
               hipLaunchKernelGGL(k_scale_level<PP_WMAX>, dim3((unsigned)ns * ny), dim3(64), 0, fan[q], d, s0, sp.c0[q], ny, PIVOT_EPS);
           }
+        }
+        if (P.front_piv >= 0 && P.piv_level[P.front_piv] == l) {
+          // root front: pivot block inverted by one workgroup per chunk, rows scaled with the explicit inverse
+          if (sp.n != 1) return fail(h, 3, "instance splits are not supported together with a root front");
+          const int fp = P.front_piv;
+          const FrontRec fr = {fp, P.piv_w[fp], (int)P.piv_uoff[fp], P.piv_boff[fp], P.piv_doff[fp], P.piv_sub[fp]};
+          hipLaunchKernelGGL(k_front_invert, dim3((unsigned)d.nchunk), dim3(512), 0, fan[0], d, fr, g->front_inv, PIVOT_EPS);
+          if (!P.wtasks.empty())
+            hipLaunchKernelGGL(k_scale_wide, dim3((unsigned)P.wtasks.size() * d.nchunk), dim3(192), 0, fan[0], d, g->wtask, fr,
+                               g->front_inv, d.nchunk);
         }
       }
       if (join_streams(h, sp, fan)) return fail(h, 3, "stream join failed");
@@ -5067,6 +5325,12 @@ int pp_vec_axpy(pp_handle h, int64_t n, double alpha, const double* x, double* y
 int pp_x_set_stamps(pp_handle h, void* dev_buffer, int level) {
   const pp::Plan& P = h->groups[0]->plan;
   const int task0 = (level >= 0 && level < P.n_levels) ? P.flevel_ptr[level] : -1;
+  if (task0 < 0) {
+    unsigned long long* ptr0 = (unsigned long long*)dev_buffer;
+    PP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(pp_x_stamps), &ptr0, sizeof(ptr0)));
+    PP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(pp_x_stamp_task0), &task0, sizeof(task0)));
+    return 0;
+  }
   unsigned long long* ptr = (unsigned long long*)dev_buffer;
   PP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(pp_x_stamps), &ptr, sizeof(ptr)));
   PP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(pp_x_stamp_task0), &task0, sizeof(task0)));
@@ -5082,7 +5346,8 @@ int pp_group_stats_ex(pp_handle h, int group, int64_t out[16]) {
   for (int p = 0; p < P.npiv; ++p) coupling_entries += (int64_t)P.piv_ncrow[p] * P.piv_w[p];
   int64_t launches_factor = 0, launches_fwd = 1, launches_bwd = 1;
   for (int l = 0; l < P.n_levels; ++l) {
-    launches_factor += (P.flevel_ptr[l + 1] > P.flevel_ptr[l]) + (P.slevel_ptr[l + 1] > P.slevel_ptr[l]);
+    launches_factor += (P.flevel_ptr[l + 1] > P.flevel_ptr[l]) + (P.slevel_ptr[l + 1] > P.slevel_ptr[l]) +
+                       ((P.front_piv >= 0 && P.piv_level[P.front_piv] == l) ? 1 + (P.wtasks.empty() ? 0 : 1) : 0);
     if (l < (int)g->fwd_level_has_entries.size() && g->fwd_level_has_entries[(size_t)l]) ++launches_fwd;
     if (P.clevel_ptr[l + 1] > P.clevel_ptr[l]) ++launches_bwd;
   }

@@ -450,6 +450,68 @@ static int build_plan_ordered(int n, int nc, int nnzK, const int* rowK, const in
     if (i > 0 && merged_child[x] == sp_seq[i - 1]) sn_members.back().push_back(x);
     else sn_members.push_back({x});
   }
+  // ---- 2c. root front: the top of the elimination tree is a chain of block pivots over (nearly) the same rows --
+  // one gather + one scale launch and one launch in each solve sweep per link, all at their floor.  The links are
+  // merged into ONE wide block pivot of up to front_max columns (plan.hpp: front_piv): its rows are gathered in
+  // column slices of PP_WMAX by the ordinary tasks, its pivot block is inverted by a kernel of its own and its rows
+  // are scaled with that explicit inverse.
+  if (opt.front_max > PP_WMAX && sn_members.size() >= 2) {
+    const int nsn = (int)sn_members.size();
+    std::vector<int> sn_of_sp(nsp, -1);
+    for (int i = 0; i < nsn; ++i) for (int x : sn_members[(size_t)i]) sn_of_sp[x] = i;
+    std::vector<int> sn_parent(nsn, -1), sn_height(nsn, 0);
+    std::vector<uint8_t> gone(nsn, 0);
+    for (int i = 0; i < nsn; ++i) {
+      const int par_sp = sp_parent[sn_members[(size_t)i].back()];
+      if (par_sp >= 0) sn_parent[i] = sn_of_sp[par_sp];
+    }
+    for (int i = 0; i < nsn; ++i)       // (children precede their parents)
+      if (sn_parent[i] >= 0) sn_height[sn_parent[i]] = std::max(sn_height[sn_parent[i]], sn_height[i] + 1);
+    auto width_of = [&](const std::vector<int>& m) { int c = 0; for (int x : m) c += sp_w[x]; return c; };
+    auto rows_of = [&](const std::vector<int>& m, int first_pos) {     // structure beyond the columns (elimination positions / n + c)
+      std::vector<int> r;
+      for (int x : m) for (int v : srows[x]) if (v >= n || v >= first_pos) r.push_back(v);
+      std::sort(r.begin(), r.end());
+      r.erase(std::unique(r.begin(), r.end()), r.end());
+      return r;
+    };
+    const int R = nsn - 1;               // the root (last in the post-order) absorbs the chain below it
+    int top_w = width_of(sn_members[(size_t)R]);
+    const int end_pos = sp_start[sn_members[(size_t)R].back()] + sp_w[sn_members[(size_t)R].back()];
+    while (true) {
+      // the child on the critical path: strictly the tallest of the root's children (merging any other child, or one
+      // of several equally tall ones, pads its columns without taking a level off the schedule)
+      int C = -1, second = -1;
+      for (int i = 0; i < R; ++i) {
+        if (gone[i] || sn_parent[i] != R) continue;
+        if (C < 0 || sn_height[i] > sn_height[C]) { second = C; C = i; }
+        else if (second < 0 || sn_height[i] > sn_height[second]) second = i;
+      }
+      if (C < 0 || (second >= 0 && sn_height[second] == sn_height[C])) break;
+      const int wc = width_of(sn_members[(size_t)C]);
+      if (top_w + wc > opt.front_max) break;
+      // rows the child's columns would have to be padded with
+      const std::vector<int> rr = rows_of(sn_members[(size_t)R], end_pos), rc = rows_of(sn_members[(size_t)C], end_pos);
+      size_t missing = 0, ic = 0;
+      for (int v : rr) { while (ic < rc.size() && rc[ic] < v) ++ic; if (ic >= rc.size() || rc[ic] != v) ++missing; }
+      if ((double)missing > opt.front_pad_frac * (double)rr.size() + 8.0) break;
+      std::vector<int> merged(sn_members[(size_t)C]);
+      merged.insert(merged.end(), sn_members[(size_t)R].begin(), sn_members[(size_t)R].end());
+      sn_members[(size_t)R].swap(merged);
+      gone[C] = 1;
+      for (int i = 0; i < R; ++i) if (!gone[i] && sn_parent[i] == C) sn_parent[i] = R;
+      top_w += wc;
+    }
+    {
+      // (the other subtrees of the root stay where they are in the post-order: only the absorbed links leave it; a
+      // merged root of at most PP_WMAX columns is an ordinary block pivot)
+      std::vector<std::vector<int>> kept;
+      kept.reserve(sn_members.size());
+      for (int i = 0; i < nsn; ++i) if (!gone[i]) kept.push_back(std::move(sn_members[(size_t)i]));
+      sn_members.swap(kept);
+      if (top_w > PP_WMAX) P.front_piv = (int)sn_members.size() - 1;
+    }
+  }
   P.npiv = (int)sn_members.size();
   P.piv_start.assign(P.npiv + 1, 0);
   P.piv_w.assign(P.npiv, 0);
@@ -463,7 +525,7 @@ static int build_plan_ordered(int n, int nc, int nnzK, const int* rowK, const in
       col += sp_w[x];
     }
     P.piv_w[p] = col;
-    if (col > PP_WMAX) { P.error = "internal: block pivot wider than PP_WMAX"; return 3; }
+    if (col > PP_WMAX && p != P.front_piv) { P.error = "internal: block pivot wider than PP_WMAX"; return 3; }
   }
   P.piv_start[P.npiv] = n;
   P.perm = new_order;
@@ -573,7 +635,7 @@ static int build_plan_ordered(int n, int nc, int nnzK, const int* rowK, const in
   }
 
   // ---- 5. row patterns (which earlier panels hold rows of pivot p, and which of its columns) and levels
-  struct RowPat { int k, mslot, cnt; int qs[PP_WMAX]; };   // rows mslot .. mslot + cnt - 1 of panel k are the columns qs[] of p
+  struct RowPat { int k, mslot, cnt; int qs[PP_FRONT_MAX]; };   // rows mslot .. mslot + cnt - 1 of panel k are the columns qs[] of p
   std::vector<std::vector<RowPat>> rowpat(P.npiv);
   for (int k = 0; k < P.npiv; ++k) {
     const auto& r = rows[k];
@@ -619,103 +681,125 @@ static int build_plan_ordered(int n, int nc, int nnzK, const int* rowK, const in
     size_t can_cursor = 0;  // panels are visited in increasing U position
     struct TmpTask { FTask t; int level; int nent = 0; };
     std::vector<TmpTask> gtasks, sctasks;
-    std::vector<std::vector<FEntry>> row_ents;   // per destination row (slot) of panel p
+    std::vector<std::vector<FEntry>> row_ents;   // per destination row (slot) of panel p (of its current column slice)
+    std::vector<std::pair<int64_t, int>> pan_can; // canonical entries located in panel p: (position in the panel, entry)
     for (int p = 0; p < P.npiv; ++p) {
       const int w = P.piv_w[p], p0 = P.piv_start[p];
       const int f = w + (int)rows[p].size();
-      row_ents.assign((size_t)f, {});
-      // initial values: canonical entries located in this panel
       const int64_t u0 = P.piv_uoff[p], u1 = u0 + (int64_t)f * w;
-      int64_t total = 0;
+      pan_can.clear();
       while (can_cursor < can_by_pos.size() && can_by_pos[can_cursor].first < u1) {
-        if (can_by_pos[can_cursor].first >= u0) {
-          const int64_t rel = can_by_pos[can_cursor].first - u0;
-          row_ents[(size_t)(rel / w)].push_back({-1 - can_by_pos[can_cursor].second, -1, 0, (int)(rel % w)});
-          ++total;
-        }
+        if (can_by_pos[can_cursor].first >= u0) pan_can.push_back({can_by_pos[can_cursor].first - u0, can_by_pos[can_cursor].second});
         ++can_cursor;
       }
-      for (auto& km : rowpat[p]) {
-        const int k = km.k, mslot = km.mslot, wk = P.piv_w[k];
-        const bool whole = km.cnt == w;       // panel k holds every column of p: one entry updates a whole row
-        const auto& rk = rows[k];
-        size_t tp = 0;
-        for (size_t t = (size_t)(mslot - wk); t < rk.size(); ++t) {
-          const int r = rk[t];
-          int d;
-          if (r < p0 + w) d = r - p0;
-          else {
-            while (tp < rows[p].size() && rows[p][tp] < r) ++tp;
-            if (tp >= rows[p].size() || rows[p][tp] != r) { P.error = "internal: fill closure violated"; return 3; }
-            d = w + (int)tp;
-          }
-          const int srow = wk + (int)t;
-          for (int tt = 0; tt < wk; ++tt) {
-            const int upos = (int)(P.piv_uoff[k] + (int64_t)srow * wk + tt);
-            if (whole)
-              row_ents[(size_t)d].push_back({upos, (int)(P.piv_uoff[k] + (int64_t)mslot * wk + tt), wk, 0});
-            else
-              for (int j = 0; j < km.cnt; ++j)
-                row_ents[(size_t)d].push_back({upos, (int)(P.piv_uoff[k] + (int64_t)(mslot + j) * wk + tt), 0, km.qs[j]});
-          }
-          P.flops_factor += (int64_t)wk * km.cnt;
-          total += whole ? wk : wk * km.cnt;
-        }
-      }
+      // a wide panel (the root front) is gathered in column slices of PP_WMAX: the tasks of a slice are ordinary
+      // gather tasks that store at (row * w + qoff + q); every other panel is one slice
+      const bool wide = w > PP_WMAX;
+      const int nslice = wide ? (w + PP_WMAX - 1) / PP_WMAX : 1;
       const bool in_tail = P.piv_level[p] >= P.tail_level0;
       const int cap_e = in_tail ? opt.tail_task_entries : opt.max_task_entries;
-      auto emit = [&](int r0, int r1, int kind, int piece = 0, int npieces = 1, int e0 = -1, int e1 = -1) {
-        TmpTask tt;
-        tt.level = P.piv_level[p];
-        tt.t.piv = p; tt.t.r0 = r0; tt.t.r1 = r1; tt.t.kind = kind; tt.t.dptr0 = (int)P.fdst_ptr.size();
-        tt.t.piece = piece; tt.t.npieces = npieces;
-        const int first = (int)P.fentries.size();
-        if (e0 >= 0) {                                   // entries [e0, e1) of the single row r0
-          P.fdst_ptr.push_back(first);
-          const auto& de = row_ents[(size_t)r0];
-          P.fentries.insert(P.fentries.end(), de.begin() + e0, de.begin() + e1);
-        } else {
-          for (int rr = r0; rr < r1; ++rr) {
-            P.fdst_ptr.push_back((int)P.fentries.size());
-            const auto& de = row_ents[(size_t)rr];
-            P.fentries.insert(P.fentries.end(), de.begin(), de.end());
+      bool fused = false;
+      for (int sl = 0; sl < nslice; ++sl) {
+        const int qoff = sl * PP_WMAX, ws = wide ? std::min(PP_WMAX, w - qoff) : w;
+        row_ents.assign((size_t)f, {});
+        int64_t total = 0;
+        // initial values
+        for (auto& pc : pan_can) {
+          const int col = (int)(pc.first % w);
+          if (col < qoff || col >= qoff + ws) continue;
+          row_ents[(size_t)(pc.first / w)].push_back({-1 - pc.second, -1, 0, col - qoff});
+          ++total;
+        }
+        for (auto& km : rowpat[p]) {
+          const int k = km.k, mslot = km.mslot, wk = P.piv_w[k];
+          int j0 = 0, j1;
+          while (j0 < km.cnt && km.qs[j0] < qoff) ++j0;
+          j1 = j0;
+          while (j1 < km.cnt && km.qs[j1] < qoff + ws) ++j1;
+          if (j1 == j0) continue;                  // panel k holds no column of this slice
+          const bool whole = (j1 - j0) == ws;      // ... every column of it: one entry updates a whole row
+          const auto& rk = rows[k];
+          size_t tp = 0;
+          for (size_t t = (size_t)(mslot - wk); t < rk.size(); ++t) {
+            const int r = rk[t];
+            int d;
+            if (r < p0 + w) d = r - p0;
+            else {
+              while (tp < rows[p].size() && rows[p][tp] < r) ++tp;
+              if (tp >= rows[p].size() || rows[p][tp] != r) { P.error = "internal: fill closure violated"; return 3; }
+              d = w + (int)tp;
+            }
+            const int srow = wk + (int)t;
+            for (int tt = 0; tt < wk; ++tt) {
+              const int upos = (int)(P.piv_uoff[k] + (int64_t)srow * wk + tt);
+              if (whole)
+                row_ents[(size_t)d].push_back({upos, (int)(P.piv_uoff[k] + (int64_t)(mslot + j0) * wk + tt), wk, 0});
+              else
+                for (int j = j0; j < j1; ++j)
+                  row_ents[(size_t)d].push_back({upos, (int)(P.piv_uoff[k] + (int64_t)(mslot + j) * wk + tt), 0, km.qs[j] - qoff});
+            }
+            P.flops_factor += (int64_t)wk * (j1 - j0);
+            total += whole ? wk : wk * (j1 - j0);
           }
         }
-        P.fdst_ptr.push_back((int)P.fentries.size());
-        // a piece counts with its whole row: a level that holds split rows must not take the lean (one wave per
-        // task, no combine) kernel
-        tt.nent = (e0 >= 0) ? (int)row_ents[(size_t)r0].size() : (int)P.fentries.size() - first;
-        gtasks.push_back(tt);
-      };
-      if (total <= opt.fuse_task_entries) {
-        emit(0, f, 1);                                   // fused small panel
-      } else {
-        const int cap_row = std::max(cap_e, (int)(opt.row_split_factor * cap_e));
-        int r = 0;
-        while (r < f) {                                  // gather chunks over all slots
-          const int sz = (int)row_ents[(size_t)r].size();
-          if (sz > cap_row) {                            // long row: pieces for the waves of one quad
-            const int np = std::min(PP_QUAD, (sz + cap_e - 1) / cap_e), per = (sz + np - 1) / np;
-            for (int j = 0; j < np; ++j) emit(r, r + 1, 0, j, np, std::min(sz, j * per), std::min(sz, (j + 1) * per));
-            ++r;
-            continue;
-          }
-          int nent = 0, r_end = r;
-          while (r_end < f) {
-            const int add = (int)row_ents[(size_t)r_end].size();
-            if (add > cap_row || (r_end > r && nent + add > cap_e)) break;
-            nent += add;
-            ++r_end;
-          }
-          emit(r, r_end, 0);
-          r = r_end;
-        }
-        const int R = std::max(1, opt.scale_task_rows / w);
-        for (int r0 = w; r0 < f || r0 == w; r0 += R) {   // scale chunks over the rows below the block
+        auto emit = [&](int r0, int r1, int kind, int piece = 0, int npieces = 1, int e0 = -1, int e1 = -1) {
           TmpTask tt;
           tt.level = P.piv_level[p];
-          tt.t.piv = p; tt.t.r0 = r0; tt.t.r1 = std::min(f, r0 + R); tt.t.kind = 2; tt.t.dptr0 = -1;
-          sctasks.push_back(tt);
+          tt.t.piv = p; tt.t.r0 = r0; tt.t.r1 = r1; tt.t.kind = kind; tt.t.dptr0 = (int)P.fdst_ptr.size();
+          tt.t.piece = piece; tt.t.npieces = npieces; tt.t.qoff = qoff; tt.t.ws = ws;
+          const int first = (int)P.fentries.size();
+          if (e0 >= 0) {                                   // entries [e0, e1) of the single row r0
+            P.fdst_ptr.push_back(first);
+            const auto& de = row_ents[(size_t)r0];
+            P.fentries.insert(P.fentries.end(), de.begin() + e0, de.begin() + e1);
+          } else {
+            for (int rr = r0; rr < r1; ++rr) {
+              P.fdst_ptr.push_back((int)P.fentries.size());
+              const auto& de = row_ents[(size_t)rr];
+              P.fentries.insert(P.fentries.end(), de.begin(), de.end());
+            }
+          }
+          P.fdst_ptr.push_back((int)P.fentries.size());
+          // a piece counts with its whole row: a level that holds split rows must not take the lean (one wave per
+          // task, no combine) kernel
+          tt.nent = (e0 >= 0) ? (int)row_ents[(size_t)r0].size() : (int)P.fentries.size() - first;
+          gtasks.push_back(tt);
+        };
+        if (!wide && total <= opt.fuse_task_entries) {
+          emit(0, f, 1);                                   // fused small panel
+          fused = true;
+        } else {
+          const int cap_row = std::max(cap_e, (int)(opt.row_split_factor * cap_e));
+          int r = 0;
+          while (r < f) {                                  // gather chunks over all slots
+            const int sz = (int)row_ents[(size_t)r].size();
+            if (sz > cap_row) {                            // long row: pieces for the waves of one quad
+              const int np = std::min(PP_QUAD, (sz + cap_e - 1) / cap_e), per = (sz + np - 1) / np;
+              for (int j = 0; j < np; ++j) emit(r, r + 1, 0, j, np, std::min(sz, j * per), std::min(sz, (j + 1) * per));
+              ++r;
+              continue;
+            }
+            int nent = 0, r_end = r;
+            while (r_end < f) {
+              const int add = (int)row_ents[(size_t)r_end].size();
+              if (add > cap_row || (r_end > r && nent + add > cap_e)) break;
+              nent += add;
+              ++r_end;
+            }
+            emit(r, r_end, 0);
+            r = r_end;
+          }
+        }
+      }
+      if (!fused) {
+        // scale chunks over the rows below the block (the root front: chunks for the workgroups of k_scale_wide)
+        const int R = wide ? opt.front_scale_rows : std::max(1, opt.scale_task_rows / w);
+        for (int r0 = w; r0 < f || r0 == w; r0 += R) {
+          TmpTask tt;
+          tt.level = P.piv_level[p];
+          tt.t.piv = p; tt.t.r0 = r0; tt.t.r1 = std::min(f, r0 + R); tt.t.kind = wide ? 3 : 2; tt.t.dptr0 = -1;
+          tt.t.ws = w;
+          if (wide) P.wtasks.push_back(tt.t); else sctasks.push_back(tt);
           if (r0 + R >= f) break;
         }
       }

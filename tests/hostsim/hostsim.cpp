@@ -251,7 +251,7 @@ int ppsim_factor(void* h, const double* can, double* U, double* L, double* Dinv,
     for (int ti = P.flevel_ptr[lvl]; ti < P.flevel_ptr[lvl + 1]; ++ti) {
       const auto& t = P.ftasks[ti];
       if (t.kind < 0) continue;                       // quad padding
-      const int p = t.piv, w = P.piv_w[p];
+      const int p = t.piv, wp = P.piv_w[p], w = t.ws > 0 ? t.ws : wp, qoff = t.qoff;   // w: columns of the task's slice
       const int nrow = t.r1 - t.r0;
       double blk[PP_WMAX * PP_WMAX] = {0}, tmax_diag = 0.0, inv[PP_WMAX * (PP_WMAX + 1) / 2] = {0};
       if (t.npieces > 1) {
@@ -283,8 +283,8 @@ int ppsim_factor(void* h, const double* can, double* U, double* L, double* Dinv,
           for (int q = 0; q < w; ++q) { acc[q] = (j == 0) ? pa[q] : acc[q] + pa[q]; tmax[q] = std::fmax(tmax[q], pm[q]); }
         }
         for (int q = 0; q < w; ++q) {
-          U[P.piv_uoff[p] + (int64_t)t.r0 * w + q] = acc[q];
-          if (t.r0 < w) Tm[P.piv_boff[p] + (t.r0 * w + q)] = tmax[q];
+          U[P.piv_uoff[p] + (int64_t)t.r0 * wp + qoff + q] = acc[q];
+          if (t.r0 < wp) Tm[P.piv_boff[p] + (t.r0 * wp + qoff + q)] = tmax[q];
         }
         continue;
       }
@@ -311,9 +311,9 @@ int ppsim_factor(void* h, const double* can, double* U, double* L, double* Dinv,
           }
         }
         for (int q = 0; q < w; ++q) {
-          U[P.piv_uoff[p] + (int64_t)slot * w + q] = acc[q];
-          if (slot < w) {
-            if (t.kind == 0) Tm[P.piv_boff[p] + (slot * w + q)] = tmax[q];
+          U[P.piv_uoff[p] + (int64_t)slot * wp + qoff + q] = acc[q];
+          if (slot < wp) {
+            if (t.kind == 0) Tm[P.piv_boff[p] + (slot * wp + qoff + q)] = tmax[q];
             else { blk[slot * PP_WMAX + q] = acc[q]; tmax_diag = std::fmax(tmax_diag, tmax[q]); }
           }
         }
@@ -340,6 +340,21 @@ int ppsim_factor(void* h, const double* can, double* U, double* L, double* Dinv,
         pos += code & 15; neg += (code >> 4) & 15; zero += (code >> 8) & 15;
       }
       scale_rows(P, p, t.r0, t.r1, inv, U, L);
+    }
+    // root front: inversion of its gathered pivot block (k_front_invert), rows scaled with the explicit inverse (k_scale_wide)
+    if (P.front_piv >= 0 && P.piv_level[P.front_piv] == lvl) {
+      const int p = P.front_piv, w = P.piv_w[p];
+      double A[pp::PP_WF * pp::PP_WF] = {0}, tmax_diag = 0.0, finv[pp::PP_WF * (pp::PP_WF + 1) / 2] = {0};
+      for (int i = 0; i < w; ++i)
+        for (int j = 0; j < w; ++j) {
+          const int hi = i > j ? i : j, lo = i > j ? j : i;       // (the lower triangle of the gathered block is the matrix)
+          A[i * pp::PP_WF + j] = U[P.piv_uoff[p] + (int64_t)hi * w + lo];
+          tmax_diag = std::fmax(tmax_diag, Tm[P.piv_boff[p] + hi * w + lo]);
+        }
+      const int code = pp::invert_front(w, P.piv_sub[p], A, tmax_diag, eps, finv);
+      for (int q = 0; q < w * (w + 1) / 2; ++q) Dinv[P.piv_doff[p] + q] = finv[q];
+      pos += code & 15; neg += (code >> 4) & 15; zero += (code >> 8) & 15;
+      for (auto& t : P.wtasks) scale_rows(P, p, t.r0, t.r1, finv, U, L);
     }
   }
   inertia[0] += pos; inertia[1] += neg; inertia[2] += zero;
@@ -412,6 +427,14 @@ int ppsim_invert_block(int w, unsigned sub, const double* a, double colmax, doub
   for (int i = 0; i < w; ++i)
     for (int j = 0; j < w; ++j) blk[i * PP_WMAX + j] = a[i * w + j];
   return pp::invert_block(w, sub, blk, colmax, eps, inv);
+}
+
+// root front: static-order sweeps on a w x w block (row-major, stride w; lower triangle read): code, inv packed lower
+int ppsim_invert_front(int w, unsigned sub, const double* a, double colmax, double eps, double* inv) {
+  double A[pp::PP_WF * pp::PP_WF] = {0};
+  for (int i = 0; i < w; ++i)
+    for (int j = 0; j < w; ++j) { const int hi = i > j ? i : j, lo = i > j ? j : i; A[i * pp::PP_WF + j] = a[hi * w + lo]; }
+  return pp::invert_front(w, sub, A, colmax, eps, inv);
 }
 
 // dense Bunch-Kaufman on a column-major n x n matrix (lower triangle read); info = (pos, neg, zero)

@@ -184,3 +184,86 @@ def test_supernodes_block_pivots(wmax, tol):
         finally:
             hu.lib().ppsim_set_supernodes(0, -1)
         assert base_levels < hs0.stats['n_levels']      # merging shortens the level schedule
+
+
+# Round 3: the symbolic phase has three elimination orders (order_mode 0: one sub-pivot at a time, 1: rounds of
+# independent clusters, 2: the cheaper of the two), panels with or without padding to whole block pivots
+# (close_supernodes; without it updates into a block pivot of which the panel holds only some columns are single-column
+# entries) and a root front (front_max > 4: the chain at the top of the tree as one wide block pivot, inverted and
+# scaled by kernels of its own).  Every combination must give the same S, inertia and solves.
+PLAN_VARIANTS = ['order_mode=0', 'order_mode=1', 'order_mode=0,close_supernodes=1,front_max=4',
+                 'order_mode=1,close_supernodes=1', 'front_max=4', 'front_pad_frac=0.0', 'front_max=9',
+                 'order_mode=1,round_relax_pop=0', 'order_mode=1,round_narrow_pop=10,round_narrow_wmax=2']
+
+
+@pytest.mark.parametrize('tune', PLAN_VARIANTS)
+def test_plan_variants_give_the_same_factorisation(tune, monkeypatch):
+    monkeypatch.setenv('PP_PLAN_TUNE', tune)
+    for shape in [(3, 20, 2, 4), (2, 120, 4, 30)]:
+        m = SyntheticKKT(*shape)
+        check_block(m.block_matrix(0), m.border_matrix())
+    for seed in (0, 4, 5, 7):
+        K, A = random_saddle(40, 15, 6, seed)
+        check_block(K, A, rtol=1e-7)
+    rng = np.random.default_rng(1)
+    B = np.diag(rng.uniform(1, 2, size=6)) + np.diag(rng.uniform(0.1, 0.3, size=5), 1)
+    K2 = sp.bmat([[None, sp.coo_matrix(B)], [sp.coo_matrix(B.T), None]]).tocoo()
+    A2 = sp.coo_matrix(([-1.0, -1.0], ([0, 1], [2, 9])), shape=(2, 12))
+    check_block(K2, A2, expect_2x2=True)
+
+
+def test_root_front_and_single_column_entries_are_exercised():
+    """The C3-shaped block: the default plan has a root front wider than a block pivot, fewer levels and less storage
+    than the round-2 plan (sequential order, padded panels, no front)."""
+    import ctypes
+    import hostsim_util as hu
+    m = SyntheticKKT(1, 1000, 4, 200)
+    hs = HostSim(m.block_matrix(0), m.border_matrix())
+    L = hu.lib()
+    npiv = hs.stats['npiv']
+    nri = L.ppsim_nrowidx(hs.h)
+    ps = np.zeros(npiv + 1, dtype=np.int32); pw = np.zeros(npiv, dtype=np.int32)
+    rp = np.zeros(npiv + 1, dtype=np.int32); ri = np.zeros(nri, dtype=np.int32)
+    ip = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int))      # noqa: E731
+    L.ppsim_get_struct(hs.h, ip(ps), ip(pw), ip(rp), ip(ri))
+    assert pw[:-1].max() <= 4 and 4 < pw[-1] <= 15                  # only the last block pivot is wide
+    assert hs.stats['n_levels'] <= 12
+    assert hs.stats['usize'] <= 40000                                # round 2: 17 levels, 44 329 doubles per instance
+    rc, S, inertia = hs.factor()
+    assert rc == 0 and inertia == (5000, 4200, 0)
+    os_env = __import__('os').environ
+    os_env['PP_PLAN_TUNE'] = 'order_mode=0,close_supernodes=1,front_max=4'
+    try:
+        hs2 = HostSim(m.block_matrix(0), m.border_matrix())
+    finally:
+        del os_env['PP_PLAN_TUNE']
+    assert hs2.stats['n_levels'] >= hs.stats['n_levels'] + 5 and hs2.stats['usize'] > 1.1 * hs.stats['usize']
+    rc2, S2, inertia2 = hs2.factor()
+    assert rc2 == 0 and inertia2 == inertia
+    assert np.abs(S - S2).max() <= 1e-9 * np.abs(S2).max()
+
+
+def test_invert_front_matches_dense_inverse():
+    """pivot.hpp invert_front (the definition k_front_invert is tested against): static 1x1 / 2x2 sweeps on a 13 x 13
+    block give its inverse and inertia."""
+    import ctypes
+    import hostsim_util as hu
+    L = hu.lib()
+    rng = np.random.default_rng(0)
+    for w, sub in [(13, 0), (13, 0b0000000100101), (15, 0b10), (5, 0b1000)]:
+        M = rng.normal(size=(w, w))
+        A = M + M.T + np.diag(rng.uniform(3, 6, size=w) * rng.choice([-1, 1], size=w))
+        for k in range(w):
+            if (sub >> k) & 1:
+                A[k, k] = 0.0                                       # a 2x2 sub-pivot that needs its partner
+        inv = np.zeros(w * (w + 1) // 2)
+        code = L.ppsim_invert_front(w, ctypes.c_uint(sub), A.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                    ctypes.c_double(0.0), ctypes.c_double(1e-13),
+                                    inv.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+        full = np.zeros((w, w))
+        for i in range(w):
+            for j in range(i + 1):
+                full[i, j] = full[j, i] = inv[i * (i + 1) // 2 + j]
+        assert np.abs(full @ A - np.eye(w)).max() < 1e-10
+        ev = np.linalg.eigvalsh(A)
+        assert (code & 15, (code >> 4) & 15, (code >> 8) & 15) == (int((ev > 0).sum()), int((ev < 0).sum()), 0)
