@@ -1,0 +1,76 @@
+"""The interior-point loop with the iterates resident in HBM.
+
+``ip_solve_device`` is parapint/algorithms/interior_point.py:405-631 (restated for host containers in
+``parapint_amd.algorithms.interior_point``) over a device producer
+(``parapint_amd.interfaces.schur_complement.device_sc_ip_interface.DeviceStochasticQPInterface``): the KKT values go from
+the producer's tensors into the factorisation kernels, the right-hand side and the step are ``DeviceBlockVector``s, the
+convergence measures and step lengths are device reductions, and the inertia-correction loop is the reference's own
+(``numeric_factorization`` below is the HOST function, unchanged: ``regularize_*`` return a diagonal shift of the resident
+matrix and ``do_numeric_factorization`` recognises it).  Per iteration the host sees a handful of scalars -- what the
+control flow of the reference's loop needs -- and nothing else leaves the device.
+"""
+import logging
+import time
+
+from parapint_amd.algorithms.interior_point import (IPOptions, InteriorPointStatus, _NullTimer, numeric_factorization,
+                                                    try_factorization_and_reallocation)
+from parapint_amd.linalg.results import LinearSolverStatus
+
+logger = logging.getLogger(__name__)
+
+
+def ip_solve_device(interface, options=None, timer=None, history=None):
+    """Returns (status, iterations).  `history`, if a list, receives per iteration
+    (primal_inf, dual_inf, compl_inf, barrier, alpha_primal, alpha_dual, regularisation)."""
+    if options is None:
+        options = IPOptions()
+    if timer is None:
+        timer = _NullTimer()
+    solver = options.linalg.solver
+    barrier_parameter = options.init_barrier_parameter
+    inertia_coef = options.inertia_correction.init_coef
+    used_inertia_coef = 0
+    t0 = time.time()
+    # symbolic phase once, on the matrix of the processed initial point (interior_point.py:542-552)
+    dk = interface.device_kkt_matrix()
+    sym_status, _ = try_factorization_and_reallocation(dk, solver, options.linalg.reallocation_factor,
+                                                       options.linalg.max_num_reallocations, 'symbolic', timer)
+    if sym_status != LinearSolverStatus.successful:
+        raise RuntimeError('Could not factorize KKT system; linear solver status: ' + str(sym_status))
+    interface.attach(solver, dk)
+    interface.set_barrier_parameter(barrier_parameter)
+    alpha_primal_max = alpha_dual_max = 1
+    logger.info('%-6s%-11s%-11s%-11s%-11s%-11s%-11s%-11s%-11s%-7s', 'Iter', 'Objective', 'Prim Inf', 'Dual Inf',
+                'Comp Inf', 'Barrier', 'Prim Step', 'Dual Step', 'Reg', 'Time')
+    status = InteriorPointStatus.error
+    iterations = 0
+    for _iter in range(options.max_iter):
+        iterations = _iter
+        primal_inf, dual_inf, compl_inf = interface.check_convergence(0, options.error_scaling)
+        if logger.isEnabledFor(logging.INFO):
+            logger.info('%-6d%-11.2e%-11.2e%-11.2e%-11.2e%-11.2e%-11.2e%-11.2e%-11.2e%-7.3f', _iter,
+                        interface.evaluate_objective(), primal_inf, dual_inf, compl_inf, barrier_parameter,
+                        alpha_primal_max, alpha_dual_max, used_inertia_coef, time.time() - t0)
+        if history is not None:
+            history.append((primal_inf, dual_inf, compl_inf, barrier_parameter, alpha_primal_max, alpha_dual_max,
+                            used_inertia_coef))
+        if max(primal_inf, dual_inf, compl_inf) <= options.tol:
+            status = InteriorPointStatus.optimal
+            break
+        primal_inf, dual_inf, compl_inf = interface.check_convergence(barrier_parameter, options.error_scaling)
+        if max(primal_inf, dual_inf, compl_inf) <= options.barrier_decrease * barrier_parameter:
+            barrier_parameter = max(options.minimum_barrier_parameter,
+                                    min(0.5 * barrier_parameter, barrier_parameter ** 1.5))
+        interface.set_barrier_parameter(barrier_parameter)
+        kkt = interface.evaluate_primal_dual_kkt_matrix(timer=timer)      # barrier diagonals -> the solver's sources
+        rhs = interface.evaluate_primal_dual_kkt_rhs(timer=timer)
+        used_inertia_coef = numeric_factorization(interface, kkt, options, inertia_coef, timer)
+        inertia_coef = max(used_inertia_coef * options.inertia_correction.factor_decrease,
+                           options.inertia_correction.init_coef)
+        delta = solver.do_back_solve(rhs)
+        interface.set_primal_dual_kkt_solution(delta)
+        alpha_primal_max, alpha_dual_max = interface.fraction_to_the_boundary(1 - barrier_parameter)
+        if options.unified_step:
+            alpha_primal_max = alpha_dual_max = min(alpha_primal_max, alpha_dual_max)
+        interface.take_step(alpha_primal_max, alpha_dual_max)
+    return status, iterations

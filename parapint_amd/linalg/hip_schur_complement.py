@@ -641,6 +641,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         self._pattern_only = False
         self._have_classes = False
         self.pivot_order_refreshes = 0      # numeric factorisations that needed a new static pivot sequence
+        self.diagonal_shift_refactorizations = 0      # factorisations from resident values + a diagonal shift (f1)
         self._last_Q = None
         self._base_Q = None
         self._last_error = ''
@@ -1117,6 +1118,18 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         return res
 
     def do_numeric_factorization(self, matrix, raise_on_error=True, timer=None):
+        shift = getattr(matrix, 'diagonal_shift', None)
+        if shift is not None and getattr(self, '_have_classes', False) and matrix.base is getattr(self, '_last_device_base', None):
+            # "the last matrix + a diagonal": one retry of the inertia-correction loop (interior_point.py:377-392) from
+            # the values resident on the device -- reached through the reference's unchanged call site
+            return self.refactorize_with_diagonal_shift(shift[0], shift[1], coupling_shift=shift[2],
+                                                        raise_on_error=raise_on_error, timer=timer)
+        if shift is not None and shift != (0.0, 0.0, 0.0):
+            raise RuntimeError('a shifted device matrix needs set_regularization_classes and a factorisation of its base first')
+        if shift is not None:
+            matrix = matrix.base
+        if hasattr(matrix, 'value_maps'):
+            self._last_device_base = matrix
         res = self._numeric_factorization(matrix, timer)
         if res.status == LinearSolverStatus.singular and self._refresh_pivot_order():
             # a block broke down under the static pivot sequence: it was fixed from the values the symbolic phase
@@ -1128,9 +1141,10 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             raise RuntimeError('Numeric factorization unsuccessful; status: ' + str(res.status))
         return res
 
-    def _refresh_pivot_order(self):
-        """New pivot sequences for the groups that hold a broken block, from that block's values.  Collective: every
-        rank learns whether any rank re-planned (all of them then factorise again)."""
+    def _refresh_pivot_order(self, shift=None):
+        """New pivot sequences for the groups that hold a broken block, from that block's values (with `shift` =
+        (delta_w, delta_c): + the diagonal shift of the classed rows, as the regularised matrix of the host path has
+        them).  Collective: every rank learns whether any rank re-planned (all of them then factorise again)."""
         mine = 0
         for g in self._groups:
             slot = self._eng.find_zero_pivot(g.gid)
@@ -1147,6 +1161,13 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
                     g.rep_vals = np.add.reduceat(raw[g.can_idx], g.can_ptr[:-1]) if g.can_idx.size else np.zeros(0)
                 else:
                     g.rep_vals = g.canonical_from_compact(g.staging[slot])
+                if shift is not None and getattr(self, '_classes', None):
+                    cls = self._classes[g.blocks[0]]
+                    nK = g.rowK.size
+                    diag = np.flatnonzero(g.rowK == g.colK)
+                    rows = g.rowK[diag]
+                    g.rep_vals = np.array(g.rep_vals, dtype=np.double)
+                    g.rep_vals[:nK][diag] += np.where(cls[rows] == 1, shift[0], np.where(cls[rows] == 2, -shift[1], 0.0))
                 mine = 1
         anyone = mine
         if self.comm.size > 1:
@@ -1369,7 +1390,8 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         self._classes = keep
         self._apply_classes()
 
-    def refactorize_with_diagonal_shift(self, delta_w, delta_c, coupling_shift=0.0, raise_on_error=True, timer=None):
+    def refactorize_with_diagonal_shift(self, delta_w, delta_c, coupling_shift=0.0, raise_on_error=True, timer=None,
+                                        _retry=False):
         """Numeric factorisation of (the last matrix given to do_numeric_factorization) + delta_w on the classed
         Hessian diagonals - delta_c on the classed constraint diagonals + coupling_shift * I on the coupling block,
         from the values already resident on the device: what one retry of the inertia-correction loop
@@ -1380,6 +1402,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         if not getattr(self, '_have_classes', False):
             raise RuntimeError('Call set_regularization_classes first!')
         res = LinearSolverResults(LinearSolverStatus.successful)
+        self.diagonal_shift_refactorizations += 1
         timer.start('form SC')
         timer.start('factorize')
         self._guarded(res, self._eng.numeric_local_shifted, delta_w, delta_c)
@@ -1395,6 +1418,13 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         base = self._base_Q
         res = self._finish_numeric(res, Q, timer)
         self._base_Q = base                     # shifts are relative to the matrix of the last full factorisation
+        if res.status == LinearSolverStatus.singular and not _retry and self._refresh_pivot_order((delta_w, delta_c)):
+            # as in do_numeric_factorization: a static pivot sequence that broke down is chosen again from the values
+            # (shift included) of the instance that broke, before the caller is told `singular`
+            if getattr(self, '_last_device_base', None) is not None and self._device_maps is not None:
+                self._bind_device_matrix(self._last_device_base)      # (the new plan has device buffers of its own)
+            return self.refactorize_with_diagonal_shift(delta_w, delta_c, coupling_shift=coupling_shift,
+                                                        raise_on_error=raise_on_error, timer=timer, _retry=True)
         if res.status not in _OK and raise_on_error:
             raise RuntimeError('Numeric factorization unsuccessful; status: ' + str(res.status))
         return res

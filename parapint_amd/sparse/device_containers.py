@@ -33,6 +33,8 @@ class DeviceBlockMatrix(object):
         self.sources = {}          # group id -> torch tensor [nsrc][bpad] (float64, device), set by the solver / producer
         self.slots = {}            # group id -> block indices in lane order (instance b of the group = slots[gid][b])
         self.Q = None              # dense host coupling block (or None = zero)
+        self.base = None           # with_diagonal_shift: the matrix the shift is relative to
+        self.diagonal_shift = None # ... and (delta_w, delta_c, coupling_shift)
 
     # the BlockMatrix protocol of SURVEY.md 8b, served by the pattern
     @property
@@ -61,6 +63,23 @@ class DeviceBlockMatrix(object):
         other.sources = dict(sources)
         other.Q = self.Q
         return other
+
+    def with_diagonal_shift(self, delta_w=0.0, delta_c=0.0, coupling_shift=0.0):
+        """The same matrix + delta_w on the Hessian diagonals - delta_c on the constraint diagonals (the rows classed by
+        ``solver.set_regularization_classes``) + coupling_shift * I on the coupling block: what the inertia-correction
+        loop builds with ``regularize_hessian`` / ``regularize_equality_gradient`` (interior_point.py:377-386,
+        interfaces/interface.py:590-619).  ``do_numeric_factorization`` recognises it and factorises from the values that
+        are already on the device."""
+        base = self.base if self.diagonal_shift is not None else self
+        other = DeviceBlockMatrix(base.pattern, base.value_maps, base.nsrc)
+        other.slots, other.sources, other.Q = base.slots, base.sources, base.Q
+        other.base = base
+        other.diagonal_shift = (float(delta_w), float(delta_c), float(coupling_shift))
+        return other
+
+    def copy(self):
+        """(the inertia-correction loop copies the matrix before it regularises it, interior_point.py:383-384)"""
+        return self.with_diagonal_shift(*(self.diagonal_shift or (0.0, 0.0, 0.0)))
 
     def set_sources_from_host(self, per_block):
         """per_block: {block index: source vector (nsrc)} -> the group tensors (test / set-up helper)."""
