@@ -58,6 +58,8 @@ def parse_args():
     ap.add_argument('--value-sets', type=int, default=6, help='distinct device-resident value sets cycled through')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-boundary', action='store_true')
+    ap.add_argument('--no-ip-loop', action='store_true')
+    ap.add_argument('--ip-scenarios', type=int, default=1024)
     ap.add_argument('--boundary-iterations', type=int, default=6)
     ap.add_argument('--profile-steps', type=int, default=5)
     ap.add_argument('--sn-wmax', type=int, default=0, help='supernode width cap (0: library default)')
@@ -184,7 +186,7 @@ def main():
         describe = ('%s: %d scenario blocks x (n_q=%d, n_y=%d: %d primal vars, block dim %d), %d coupling vars' %
                     (args.workload, N, n_q, model.n_y, n_q + model.n_y, model.block_dim, n_t))
     B = len(local)
-    solver = HipSchurComplementLinearSolver({i: None for i in local}, None, comm=comm)
+    solver = HipSchurComplementLinearSolver({i: None for i in local}, None, comm=comm, result_buffers=2)
     eng = solver._eng
     lib, h = eng.lib, eng.ns.h
     if args.sn_wmax > 0 or args.sn_tol >= 0:
@@ -408,6 +410,36 @@ def main():
                        'peak_fp64_mfma_TFLOPs': FP64_MFMA_PEAK_TF, 'frac': tf / FP64_MFMA_PEAK_TF,
                        'note': 'one workgroup, latency-bound chain of n_c/16 panels; replicated on every rank'}
 
+    # ---- interior-point loop with device-resident iterates: a stochastic QP with one pattern
+    # for all scenarios through ip_solve_device -- the KKT values, the right-hand side, the step and the convergence
+    # measures never leave HBM; the inertia-correction retries run from the resident values.  Rank 0, one GPU only.
+    ip_loop = None
+    if rank == 0 and world == 1 and not args.no_ip_loop and args.workload == 'C3' and not args.blocks:
+        from parapint_amd.algorithms.device_interior_point import ip_solve_device
+        from parapint_amd.algorithms.interior_point import IPOptions, InteriorPointStatus
+        from parapint_amd.examples.stochastic_qp import random_stochastic_qp
+        from parapint_amd.interfaces.schur_complement.device_sc_ip_interface import DeviceStochasticQPInterface
+        qps, fsi = random_stochastic_qp(args.ip_scenarios, n=120, n_fs=10, n_eq=30, n_ineq=40, seed=7)
+        ipi = DeviceStochasticQPInterface(qps, fsi)
+        ipo = IPOptions()
+        ipo.linalg.solver = HipSchurComplementLinearSolver({i: None for i in range(len(qps))}, None, comm=SerialComm(),
+                                                           result_buffers=2)
+        hist = []
+        sync_all()
+        t0 = time.perf_counter()
+        ip_status, ip_iters = ip_solve_device(ipi, ipo, history=hist)
+        sync_all()
+        t_ip = time.perf_counter() - t0
+        sv = ipo.linalg.solver
+        ip_loop = {'it_per_s': ip_iters / t_ip, 'iterations': ip_iters, 'seconds': t_ip,
+                   'converged': ip_status == InteriorPointStatus.optimal,
+                   'final_infeasibilities': list(hist[-1][:3]) if hist else None,
+                   'scenarios': len(qps), 'block_dim': ipi.nb, 'n_coupling': ipi.nfs,
+                   'inertia_retries_from_resident_values': sv.diagonal_shift_refactorizations,
+                   'pivot_order_refreshes': sv.pivot_order_refreshes,
+                   'note': 'whole ip_solve_device call: symbolic phase, pivot-order refreshes and all retries included'}
+        ok = ok and ip_loop['converged']
+
     if rank == 0:
         launches = sum(p['launches_per_step'] for p in phases.values()) if phases else None
         out = {
@@ -421,6 +453,10 @@ def main():
                        'parallelism': 'blocks round-robin over %d rank(s); all-reduce of [S | status | inertia] and '
                                       'of r_s' % world},
             'median_ms_per_step': median_ms,
+            # SURVEY 8(d) to the letter: the same step through HOST containers (SciPy COO blocks in, host vectors out;
+            # staging, H2D and D2H inside) -- the rate a caller with the reference's unchanged interfaces sees
+            'value_boundary': (boundary or {}).get('it_per_s'),
+            'ip_loop': ip_loop,
             'roofline': roofline,
             'dense_phase': dense_phase,
             'cpu_baseline': cpu_baseline,

@@ -3168,6 +3168,11 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_level(GroupDev g, int col0, int
 // (interior_point.py:655-758) and the complementarity residuals max |(x - l) z_l - mu|, max |(u - x) z_u - mu| over
 // the finite bounds (interior_point.py:257-266).  Infinite bounds are skipped, as the reference masks them.
 // part[4][gridDim.x]: per-workgroup partial results, combined by k_step_stats_final (deterministic).
+// max / min that PROPAGATE NaN (fmax / fmin drop it): a NaN in a residual or a step must reach the caller's test, as
+// numpy's max does in the reference (interior_point.py:254-301)
+__device__ __forceinline__ double nan_max(double a, double b) { return (a != a || b != b) ? NAN : fmax(a, b); }
+__device__ __forceinline__ double nan_min(double a, double b) { return (a != a || b != b) ? NAN : fmin(a, b); }
+
 __global__ __launch_bounds__(256) void k_step_stats(size_t n, const double* __restrict__ x, const double* __restrict__ dx,
                                                     const double* __restrict__ xl, const double* __restrict__ xu,
                                                     const double* __restrict__ zl, const double* __restrict__ dzl,
@@ -3178,27 +3183,30 @@ __global__ __launch_bounds__(256) void k_step_stats(size_t n, const double* __re
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const double xi = x[i], di = dx ? dx[i] : 0.0;
     const double lo = xl ? xl[i] : -INFINITY, hi = xu ? xu[i] : INFINITY;
-    if (di < 0.0 && lo > -INFINITY) ap = fmin(ap, -tau * (xi - lo) / di);
-    if (di > 0.0 && hi < INFINITY) ap = fmin(ap, tau * (hi - xi) / di);
+    if (di != di || xi != xi) ap = NAN;
+    if (di < 0.0 && lo > -INFINITY) ap = nan_min(ap, -tau * (xi - lo) / di);
+    if (di > 0.0 && hi < INFINITY) ap = nan_min(ap, tau * (hi - xi) / di);
     if (zl) {
       const double z = zl[i], dz = dzl ? dzl[i] : 0.0;
-      if (dz < 0.0) ad = fmin(ad, -tau * z / dz);
-      if (lo > -INFINITY) cl = fmax(cl, fabs((xi - lo) * z - mu));
+      if (dz != dz || z != z) ad = NAN;
+      if (dz < 0.0) ad = nan_min(ad, -tau * z / dz);
+      if (lo > -INFINITY) cl = nan_max(cl, fabs((xi - lo) * z - mu));
     }
     if (zu) {
       const double z = zu[i], dz = dzu ? dzu[i] : 0.0;
-      if (dz < 0.0) ad = fmin(ad, -tau * z / dz);
-      if (hi < INFINITY) cu = fmax(cu, fabs((hi - xi) * z - mu));
+      if (dz != dz || z != z) ad = NAN;
+      if (dz < 0.0) ad = nan_min(ad, -tau * z / dz);
+      if (hi < INFINITY) cu = nan_max(cu, fabs((hi - xi) * z - mu));
     }
   }
   red[0][threadIdx.x] = ap; red[1][threadIdx.x] = ad; red[2][threadIdx.x] = cl; red[3][threadIdx.x] = cu;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
     if ((int)threadIdx.x < s) {
-      red[0][threadIdx.x] = fmin(red[0][threadIdx.x], red[0][threadIdx.x + s]);
-      red[1][threadIdx.x] = fmin(red[1][threadIdx.x], red[1][threadIdx.x + s]);
-      red[2][threadIdx.x] = fmax(red[2][threadIdx.x], red[2][threadIdx.x + s]);
-      red[3][threadIdx.x] = fmax(red[3][threadIdx.x], red[3][threadIdx.x + s]);
+      red[0][threadIdx.x] = nan_min(red[0][threadIdx.x], red[0][threadIdx.x + s]);
+      red[1][threadIdx.x] = nan_min(red[1][threadIdx.x], red[1][threadIdx.x + s]);
+      red[2][threadIdx.x] = nan_max(red[2][threadIdx.x], red[2][threadIdx.x + s]);
+      red[3][threadIdx.x] = nan_max(red[3][threadIdx.x], red[3][threadIdx.x + s]);
     }
     __syncthreads();
   }
@@ -3209,17 +3217,17 @@ __global__ __launch_bounds__(256) void k_step_stats_final(int nparts, const doub
   __shared__ double red[4][256];
   double v[4] = {1.0, 1.0, 0.0, 0.0};
   for (int i = threadIdx.x; i < nparts; i += 256) {
-    v[0] = fmin(v[0], part[i]); v[1] = fmin(v[1], part[(size_t)nparts + i]);
-    v[2] = fmax(v[2], part[2 * (size_t)nparts + i]); v[3] = fmax(v[3], part[3 * (size_t)nparts + i]);
+    v[0] = nan_min(v[0], part[i]); v[1] = nan_min(v[1], part[(size_t)nparts + i]);
+    v[2] = nan_max(v[2], part[2 * (size_t)nparts + i]); v[3] = nan_max(v[3], part[3 * (size_t)nparts + i]);
   }
   for (int q = 0; q < 4; ++q) red[q][threadIdx.x] = v[q];
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
     if ((int)threadIdx.x < s) {
-      red[0][threadIdx.x] = fmin(red[0][threadIdx.x], red[0][threadIdx.x + s]);
-      red[1][threadIdx.x] = fmin(red[1][threadIdx.x], red[1][threadIdx.x + s]);
-      red[2][threadIdx.x] = fmax(red[2][threadIdx.x], red[2][threadIdx.x + s]);
-      red[3][threadIdx.x] = fmax(red[3][threadIdx.x], red[3][threadIdx.x + s]);
+      red[0][threadIdx.x] = nan_min(red[0][threadIdx.x], red[0][threadIdx.x + s]);
+      red[1][threadIdx.x] = nan_min(red[1][threadIdx.x], red[1][threadIdx.x + s]);
+      red[2][threadIdx.x] = nan_max(red[2][threadIdx.x], red[2][threadIdx.x + s]);
+      red[3][threadIdx.x] = nan_max(red[3][threadIdx.x], red[3][threadIdx.x + s]);
     }
     __syncthreads();
   }
@@ -3234,11 +3242,11 @@ __global__ __launch_bounds__(256) void k_vec_axpy(size_t n, double alpha, const 
 __global__ __launch_bounds__(256) void k_vec_max_abs(size_t n, const double* __restrict__ v, double* __restrict__ part) {
   __shared__ double red[256];
   double m = 0.0;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmax(m, fabs(v[i]));
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = nan_max(m, fabs(v[i]));
   red[threadIdx.x] = m;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
+    if ((int)threadIdx.x < s) red[threadIdx.x] = nan_max(red[threadIdx.x], red[threadIdx.x + s]);
     __syncthreads();
   }
   if (threadIdx.x == 0) {     // slot layout of k_step_stats_final: {min, min, max, max}; the result travels in slot 2

@@ -76,10 +76,24 @@ def run(args):
     local = distribute_blocks(n_blocks, comm.rank, comm.size)
     m = SyntheticKKT(n_blocks, args.n_q_per_block, args.n_y_multiplier, args.n_theta, args.A_nnz_per_row,
                      local_blocks=local if args.method == 'psc' else None)
-    if args.method == 'fs':
-        solver = HipLDLInterface()
+    # main.py:75-83: the sub-solver is picked by class.  All three names construct the batched HIP factorisation; the
+    # class decides the single-matrix semantics (MA27: cntl(1) = 1e-6, inertia (n - neg, neg, 0); MUMPS: null pivots in
+    # the inertia; SciPy: no inertia unless asked)
+    from parapint_amd.linalg import InteriorPointMA27Interface, MumpsInterface, ScipyInterface
+    if args.subproblem_solver == 'ma27':
+        linear_solver_class, linear_solver_options = InteriorPointMA27Interface, dict(cntl_options={1: 1e-6})
+    elif args.subproblem_solver == 'mumps':
+        linear_solver_class, linear_solver_options = MumpsInterface, dict()
     else:
-        solver = HipSchurComplementLinearSolver({i: None for i in local}, None, comm=comm)
+        linear_solver_class, linear_solver_options = ScipyInterface, dict(compute_inertia=False)
+    if args.method == 'fs':
+        solver = linear_solver_class(**linear_solver_options)
+    else:
+        # (the block factorisations are one batch on the GPU: the per-block sub-solver objects of the reference's
+        # constructor are accepted and not called; the pivot tolerance of the chosen class applies to the batch)
+        tol = linear_solver_options.get('cntl_options', {}).get(1)
+        solver = HipSchurComplementLinearSolver({i: None for i in local}, None, comm=comm,
+                                                symbolic_pivot_threshold=None if tol is None else max(tol, 0.01))
     res = helper(m, solver, comm, full_space=(args.method == 'fs'))
     method_map = {'fs': 'Full Space', 'ssc': 'Serial Schur-Complement', 'psc': 'Parallel Schur-Complement'}
     if comm.rank == 0:
@@ -102,6 +116,8 @@ def parse_args(argv=None):
     parser.add_argument('--method', type=str, required=True, choices=['fs', 'ssc', 'psc'],
                         help='fs: full space, ssc: serial Schur complement, psc: parallel Schur complement')
     parser.add_argument('--n_blocks', type=int, required=True)
+    parser.add_argument('--subproblem_solver', '--linear_solver', type=str, default='ma27', choices=['ma27', 'mumps', 'scipy'],
+                        help='sub-solver class, as main.py:75-83 (all are served by the HIP factorisation)')
     parser.add_argument('--n_q_per_block', type=int, default=5000)
     parser.add_argument('--n_y_multiplier', type=int, default=120)
     parser.add_argument('--n_theta', type=int, default=10)

@@ -4,7 +4,7 @@ their single-matrix contract)."""
 from .base_linear_solver_interface import LinearSolverInterface
 from .results import LinearSolverResults, LinearSolverStatus
 from .hip_schur_complement import (HipLDLInterface, HipSchurComplementLinearSolver,
-                                   HipSerialSchurComplementLinearSolver)
+                                   HipSerialSchurComplementLinearSolver, MumpsInterface, ScipyInterface)
 
 # the reference's names for the two classes this package replaces
 SchurComplementLinearSolver = HipSerialSchurComplementLinearSolver

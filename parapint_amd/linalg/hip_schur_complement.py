@@ -322,7 +322,12 @@ class HipEngine(object):
             fresh = False
             for q, r in ((0, 0), (1, 1), (3, 2), (4, 3)):
                 a = arrays[q]
-                if id(a) in known:
+                # recognised only in the ROLE it was verified in (K rows / K columns / border rows / border columns), with
+                # its size and a cheap content probe (first, middle, last entry) unchanged: an array object that was
+                # mutated in place or is reused in another role goes through the full comparison again
+                k = known.get((q, id(a)))
+                if k is not None and k[1] == a.size and (a.size == 0 or (k[2] == int(a[0]) and k[3] == int(a[a.size // 2])
+                                                                         and k[4] == int(a[-1]))):
                     ptr[q, i] = refptr[r]
                 else:
                     ptr[q, i] = a.ctypes.data
@@ -349,7 +354,8 @@ class HipEngine(object):
             for i in unknown:
                 if ok[i]:
                     for q in (0, 1, 3, 4):
-                        known[id(items[i][1][q])] = items[i][1][q]
+                        a = items[i][1][q]
+                        known[(q, id(a))] = (a, a.size) + ((int(a[0]), int(a[a.size // 2]), int(a[-1])) if a.size else (0, 0, 0))
         return ok
 
     def copy_rows(self, dst, rows):
@@ -597,7 +603,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         return 'hip_schur_complement'
 
     def __init__(self, subproblem_solvers=None, schur_complement_solver=None, comm=None, engine=None,
-                 memory_budget_bytes=None, result_buffers=2, pivot_tolerance=None, symbolic_pivot_threshold=None):
+                 memory_budget_bytes=None, result_buffers=0, pivot_tolerance=None, symbolic_pivot_threshold=None):
         self.subproblem_solvers = subproblem_solvers
         self.schur_complement_solver = schur_complement_solver
         self.comm = default_comm() if comm is None else comm
@@ -626,9 +632,10 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         self._device_maps = None            # (nsrc, value maps by block index) of a DeviceBlockMatrix (f2)
         self._dev_results = []
         self._dev_turn = 0
-        # do_back_solve hands out views of page-locked result buffers used in turn (D2H at PCIe speed, no 75 MB
-        # allocation per call at the headline size): a result stays valid until `result_buffers` further back-solves
-        # have been made; 0 = a fresh pageable array per call (results never alias)
+        # result_buffers = 0 (default): do_back_solve returns fresh arrays / tensors, as the reference does -- results of
+        # different calls never alias.  result_buffers = k > 0 is an opt-in for callers that consume a result before the
+        # k-th following back-solve (bench.py, the interior-point loops): views of k page-locked host buffers (D2H at
+        # PCIe speed, no 75 MB allocation per call at the headline size) / k device vectors used in turn
         self._result_buffers = max(0, int(result_buffers))
         self.block_dim = 0
         self.block_matrix = None
@@ -704,6 +711,10 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             if used.size != self._nc:
                 uniform = False
             fetched[ndx] = (kr, kc, kd, kshape[0], br, bc, bd, used)
+        # every rank must take the same layout (a mapped rank joins collectives of its own in _coupling_structure, and a
+        # dense and a block-tridiagonal S cannot meet in one all-reduce): one rank's non-uniform blocks decide for all
+        if self.comm.size > 1:
+            uniform = int(self.comm.allreduce_max(np.array([0 if uniform else 1], dtype=np.int64))[0]) == 0
         self._mapped = (not uniform) and self._nc > 0
         for ndx in self.local_block_indices:
             kr, kc, kd, n, br, bc, bd, used = fetched[ndx]
@@ -989,6 +1000,8 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             row[g.can_cidx[g.can_ptr[:-1]]] = vals     # canonical sum on the first raw slot of each entry
 
     def _run_symbolic(self):
+        self._cinv_t = self._rc_pad = self._xc_pad = None      # (device copies of the coupling order: per plan)
+        self._dev_results = []
         if self._btd is not None:
             self.plan_stats = self._eng.symbolic(self._btd[0] * self._btd[1], self._groups, btd=self._btd, cinv=self._cinv)
             if hasattr(self._eng, 'set_coupling_schedule'):
@@ -1226,9 +1239,16 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             g.device_sources = t
 
     def _stage_and_upload(self, matrix):
+        changed = 0
         try:
             self._stage_values(matrix)
         except _PatternChanged:
+            changed = 1
+        if self.comm.size > 1:
+            # the new plan is made collectively (its coupling structure is agreed by all ranks): a rank whose own
+            # blocks still fit the old pattern re-plans with the others
+            changed = int(self.comm.allreduce_max(np.array([changed], dtype=np.int64))[0])
+        if changed:
             # entries outside the planned pattern (the inertia-correction loop adds diagonal blocks): plan again
             # on the union of both patterns, as the reference's MUMPS sub-solver does (mumps_interface.py:82-83)
             self._replan_union(matrix)
@@ -1494,12 +1514,15 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
 
     def _device_back_solve(self, rhs, timer):
         """do_back_solve for a DeviceBlockVector: right-hand sides are read where they are, the solution is written
-        into device tensors handed out in turn (valid until `result_buffers` further back-solves); no host copies."""
+        into a fresh device vector (or, with result_buffers = k > 0, into k vectors handed out in turn); no host copies."""
         timer.start('back_solve')
-        if not self._dev_results:
-            self._dev_results = [self.new_device_vector() for _ in range(max(1, self._result_buffers))]
-        out = self._dev_results[self._dev_turn % len(self._dev_results)]
-        self._dev_turn += 1
+        if self._result_buffers == 0:
+            out = self.new_device_vector()                  # default: results of different calls never alias
+        else:
+            if not self._dev_results:
+                self._dev_results = [self.new_device_vector() for _ in range(self._result_buffers)]
+            out = self._dev_results[self._dev_turn % len(self._dev_results)]
+            self._dev_turn += 1
         for g in self._groups:
             self._eng.bind_native_vectors(g.gid, rhs.group_tensors[g.gid], out.group_tensors[g.gid])
         self._eng.solve_forward()
@@ -1641,3 +1664,87 @@ class HipLDLInterface(LinearSolverInterface):
 
     def increase_memory_allocation(self, factor):
         self._sc.increase_memory_allocation(factor)
+
+
+class MumpsInterface(HipLDLInterface):
+    """The reference's MUMPS wrapper by name and constructor (parapint/linalg/mumps_interface.py:11-229): ``par``,
+    ``comm``, ``cntl_options``, ``icntl_options`` are accepted; CNTL(1) -- MUMPS's relative pivot threshold -- is the run-time
+    growth bound, ICNTL(13) / ICNTL(24) are forced as the reference forces them (exact inertia: null pivots are counted,
+    not perturbed), the pattern may change between numeric calls (the plan is made again on the union, as
+    ``mumps_interface.py:82-83`` re-analyses), and inertia is (n - neg - zero, neg, zero) with the null pivots of
+    INFOG(28) (:122-126).  The workspace protocol (ICNTL(23), :105-115) maps to the device value-storage budget."""
+
+    @classmethod
+    def getLoggerName(cls):
+        return 'mumps'
+
+    def __init__(self, par=1, comm=None, cntl_options=None, icntl_options=None, engine=None, memory_budget_bytes=None):
+        icntl = dict(icntl_options or {})
+        icntl.setdefault(13, 1)
+        icntl.setdefault(24, 0)
+        HipLDLInterface.__init__(self, cntl_options=cntl_options, icntl_options=icntl, engine=engine)
+        self.par, self.mumps_comm = par, comm
+        self._prev_allocation = 0
+        if memory_budget_bytes is not None:
+            self._sc._eng.set_memory_budget(memory_budget_bytes)
+            self._prev_allocation = int(memory_budget_bytes)
+
+    def set_icntl(self, key, value):
+        if key == 13 and value <= 0:
+            raise ValueError('ICNTL(13) must be positive for the MumpsInterface.')
+        if key == 24 and value != 0:
+            raise ValueError('ICNTL(24) must be 0 for the MumpsInterface.')
+        self.icntl_options[key] = value
+
+    def set_cntl(self, key, value):
+        self.cntl_options[key] = value
+
+    def get_icntl(self, key):
+        return self.icntl_options.get(key, 0)
+
+    def get_cntl(self, key):
+        return self.cntl_options.get(key, 0.0)
+
+    def get_infog(self, key):
+        """INFOG(12): negative pivots, INFOG(28): null pivots, INFOG(16) / (18): value storage the plan needs / holds, MB."""
+        if key in (12, 28):
+            pos, neg, zero = self._sc._inertia if self._sc._inertia is not None else (0, 0, 0)
+            return neg if key == 12 else zero
+        if key in (16, 18):
+            need, have, _ = self._sc._eng.memory_info() if hasattr(self._sc._eng, 'memory_info') else (0, 0, 0)
+            return int(round((need if key == 16 else have) / 1e6))
+        raise KeyError('INFOG(%d) has no counterpart' % key)
+
+    get_info = get_infog
+
+    def get_inertia(self):
+        if self._num_status is None:
+            raise RuntimeError('Must call do_numeric_factorization before inertia can be computed')
+        if self._sc._inertia is None:
+            raise RuntimeError('Can only compute inertia if the numeric factorization was successful.')
+        return tuple(int(v) for v in self._sc._inertia)          # null pivots are reported, as INFOG(28) is
+
+    def increase_memory_allocation(self, factor):
+        self._sc.increase_memory_allocation(factor)
+        self._prev_allocation = int(factor * self._prev_allocation) if self._prev_allocation else 1
+        return self._prev_allocation
+
+
+class ScipyInterface(HipLDLInterface):
+    """The reference's SciPy wrapper by name and constructor (parapint/linalg/scipy_interface.py:11-67).  Its general-LU
+    semantics (both triangles read, unsymmetric matrices accepted: quirk Q5) are NOT offered: the lower triangle defines
+    the matrix, as for the MA27 / MUMPS wrappers.  ``compute_inertia`` keeps its meaning: without it ``get_inertia``
+    raises (:64-67)."""
+
+    @classmethod
+    def getLoggerName(cls):
+        return 'scipy'
+
+    def __init__(self, compute_inertia=False, engine=None):
+        HipLDLInterface.__init__(self, engine=engine)
+        self.compute_inertia = compute_inertia
+
+    def get_inertia(self):
+        if not self.compute_inertia:
+            raise RuntimeError('The intertia was not computed during factorization. Set compute_inertia to True.')
+        return HipLDLInterface.get_inertia(self)

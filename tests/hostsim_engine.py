@@ -141,6 +141,9 @@ class HostSimEngine(object):
         self.budget = int(nbytes)
         self.mem_factor = 1.0
 
+    def memory_info(self):
+        return self.required_bytes(), 0 if self.budget is None else int(self.budget * self.mem_factor), 0
+
     def growth_count(self):
         return int(round(self.tail[4]))
 

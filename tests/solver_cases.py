@@ -602,6 +602,71 @@ def case_reallocation(make_engine, required_bytes):
     return need
 
 
+def reference_realloc_matrix(n=10000):
+    """linalg/tests/test_realloc.py:17-33: tridiagonal, 1e-7 on the diagonal, 1e2 beside it -- a matrix that needs a 2x2
+    pivot everywhere."""
+    small_val, big_val = 1e-7, 1e2
+    irn, jcn, ent = [], [], []
+    for i in range(n - 1):
+        irn.extend([i + 1, i, i])
+        jcn.extend([i, i, i + 1])
+        ent.extend([big_val, small_val, big_val])
+    irn.append(n - 1)
+    jcn.append(n - 1)
+    ent.append(small_val)
+    from scipy.sparse import coo_matrix
+    return coo_matrix((np.array(ent), (np.array(irn), np.array(jcn))), shape=(n, n))
+
+
+def case_reference_realloc_matrix(make_engine, n=10000):
+    """The reference's reallocation fixture (linalg/tests/test_realloc.py:10-61) through the sub-solver adapters: a
+    budget below what the plan needs -> not_enough_memory (status, then exception) -> increase_memory_allocation(2) ->
+    success; solution against SuperLU, inertia (n/2, n/2, 0) -- every pivot is a 2x2 one."""
+    import pytest
+    from scipy.sparse.linalg import splu
+    from parapint_amd.linalg import HipLDLInterface, MumpsInterface, ScipyInterface, InteriorPointMA27Interface
+    assert InteriorPointMA27Interface is HipLDLInterface
+    matrix = reference_realloc_matrix(n)
+    rng = np.random.default_rng(0)
+    b = rng.normal(size=n)
+    x_ref = splu(matrix.tocsc()).solve(b)
+    probe = MumpsInterface(engine=make_engine())
+    probe.do_symbolic_factorization(matrix)
+    need = probe._sc._eng.memory_info()[0]
+    assert need > 0
+    for cls, kw in ((MumpsInterface, dict(par=1, comm=None, cntl_options={1: 0.01}, icntl_options={14: 20})),
+                    (HipLDLInterface, dict(cntl_options={1: 1e-6}))):
+        solver = cls(engine=make_engine(), **kw)
+        solver._sc._eng.set_memory_budget(max(1, int(0.6 * need)))
+        solver.do_symbolic_factorization(matrix)
+        res = solver.do_numeric_factorization(matrix, raise_on_error=False)
+        assert res.status == LinearSolverStatus.not_enough_memory
+        with pytest.raises(RuntimeError, match='not_enough_memory'):
+            solver.do_numeric_factorization(matrix)
+        solver.do_symbolic_factorization(matrix)
+        solver.increase_memory_allocation(2)
+        res = solver.do_numeric_factorization(matrix)
+        assert res.status == LinearSolverStatus.successful
+        x = solver.do_back_solve(b)
+        assert np.abs(x - x_ref).max() <= 1e-8 * np.abs(x_ref).max()
+        assert solver.get_inertia() == (n // 2, n // 2, 0)
+        if cls is MumpsInterface:
+            assert solver.get_infog(12) == n // 2 and solver.get_infog(28) == 0
+            assert solver.get_icntl(13) == 1 and solver.get_icntl(24) == 0 and solver.get_icntl(14) == 20
+            with pytest.raises(ValueError):
+                solver.set_icntl(24, 1)
+    sp = ScipyInterface(engine=make_engine())
+    sp.do_symbolic_factorization(matrix)
+    sp.do_numeric_factorization(matrix)
+    assert np.abs(sp.do_back_solve(b) - x_ref).max() <= 1e-8 * np.abs(x_ref).max()
+    with pytest.raises(RuntimeError, match='compute_inertia'):
+        sp.get_inertia()
+    sp2 = ScipyInterface(compute_inertia=True, engine=make_engine())
+    sp2.do_symbolic_factorization(matrix)
+    sp2.do_numeric_factorization(matrix)
+    assert sp2.get_inertia() == (n // 2, n // 2, 0)
+
+
 def case_status_severity():
     """One reduction must let the most severe status win: `warning` (enum value 4) may not mask `singular` (2)."""
     from parapint_amd.linalg import hip_schur_complement as mod

@@ -93,6 +93,41 @@ def test_memory_reallocation_retry_loop():
     assert need > 1000
 
 
+def test_reference_realloc_matrix_through_the_sub_solver_adapters():
+    """The reference's own reallocation fixture (linalg/tests/test_realloc.py:10-61: 10 000 rows, 2x2 pivots everywhere)
+    through MumpsInterface / InteriorPointMA27Interface / ScipyInterface on the device."""
+    sc.case_reference_realloc_matrix(make_engine, n=10000)
+
+
+def test_back_solve_results_do_not_alias():
+    """Default result_buffers = 0: every do_back_solve returns storage of its own (host and device vectors), as the
+    reference does; the rotating pool is an opt-in."""
+    from parapint_amd.examples.performance.schur_complement.synthetic_kkt import SyntheticKKT
+    from parapint_amd.linalg.comm import SerialComm
+    model = SyntheticKKT(6, 30, 2, 5)
+    solver = sc.new_solver(make_engine, 6)
+    kkt = model.build_kkt(comm=SerialComm(), iteration=1)
+    rhs = model.build_rhs(comm=SerialComm())
+    solver.do_symbolic_factorization(kkt)
+    solver.do_numeric_factorization(kkt)
+    xs = [solver.do_back_solve(rhs) for _ in range(4)]
+    keep = xs[0].flatten().copy()
+    rhs2 = model.build_rhs(comm=SerialComm())
+    for ndx in range(6):
+        rhs2.set_block(ndx, 2.0 * np.asarray(rhs2.get_block(ndx)))
+    for _ in range(3):
+        solver.do_back_solve(rhs2)
+    assert np.array_equal(xs[0].flatten(), keep)
+    rd = solver.device_vector_from_host(rhs)
+    d0 = solver.do_back_solve(rd)
+    ref = d0.group_tensors[0].clone()
+    rd2 = solver.device_vector_from_host(rhs2)
+    for _ in range(3):
+        d1 = solver.do_back_solve(rd2)
+    assert d1.group_tensors[0].data_ptr() != d0.group_tensors[0].data_ptr()
+    assert bool((d0.group_tensors[0] == ref).all())
+
+
 @pytest.mark.parametrize('shape', [(1, 10, 2, 1), (1, 5, 2, 5), (65, 10, 2, 2), (129, 12, 2, 3), (5, 300, 2, 208),
                                    (3, 300, 2, 209), (2, 600, 2, 513)])
 def test_edge_shapes_against_full_space_superlu(shape):
@@ -509,6 +544,34 @@ def test_bench_single_rank_line_has_the_contract_fields():
         assert key in res
     assert res['correct'] is True and res['n_gpus'] == 1 and res['roofline']['bound'] == 'hbm'
     assert abs(res['value'] * res['ms_per_step'] / 1e3 - 1.0) < 1e-6
+
+
+def test_bench_c4_full_size_dynamic_workload():
+    """BASELINE.json configs[3] at full size through the bench's own gate: 512 time blocks x ~4k variables, n_s = 49,
+    block-tridiagonal S of dimension 50 078 by cyclic reduction (residual <= 1e-8, inertia exact)."""
+    res = _run_bench({}, '--workload', 'C4', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-boundary',
+                     '--profile-steps', '1')
+    assert res['correct'] is True and res['residual'] <= 1e-8 and res['inertia'] == res['expected_inertia']
+    assert res['config']['blocks_per_gpu'] == 512
+
+
+def test_bench_c5_one_rank_share():
+    """BASELINE.json configs[4], the share of one rank at 8 GPUs: 512 scenarios x 19 000 rows, 1000 coupling variables
+    (dense 1000 x 1000 S on the matrix cores), through the bench's gate."""
+    res = _run_bench({}, '--workload', 'C5', '--blocks', '512', '--steps', '3', '--warmup', '1', '--no-cpu-baseline',
+                     '--no-boundary', '--profile-steps', '1')
+    assert res['correct'] is True and res['residual'] <= 1e-8 and res['inertia'] == res['expected_inertia']
+    assert res['plan']['n'] == 19000 and res['config']['blocks_per_gpu'] == 512
+
+
+def test_bench_line_reports_the_ip_loop_and_the_boundary_rate():
+    """Round 3: the default line carries `ip_loop` (the interior-point loop with device-resident iterates converged) and
+    `value_boundary` (SURVEY 8(d) to the letter: host containers in and out)."""
+    res = _run_bench({}, '--steps', '5', '--warmup', '2', '--no-cpu-baseline', '--boundary-iterations', '2',
+                     '--ip-scenarios', '256', '--profile-steps', '1')
+    assert res['correct'] is True
+    assert res['ip_loop']['converged'] is True and res['ip_loop']['iterations'] > 5 and res['ip_loop']['it_per_s'] > 0
+    assert res['value_boundary'] == res['boundary_host']['it_per_s'] > 0
 
 
 def test_pivot_growth_guard():

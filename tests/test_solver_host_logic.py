@@ -87,3 +87,16 @@ def test_dynamic_block_tridiagonal_plumbing_on_the_host():
 def test_dynamic_problem_through_the_inertia_correction_loop(dense_limit):
     solver = sc.case_dynamic_regularised(make_engine, dense_limit)
     assert (solver._btd is not None) == (dense_limit is not None)
+
+
+def test_reference_realloc_matrix_through_the_sub_solver_adapters():
+    """linalg/tests/test_realloc.py:10-61 (the reference runs it on MUMPS only) on the host interpreter, 2000 rows."""
+    sc.case_reference_realloc_matrix(make_engine, n=2000)
+
+
+def test_harness_sub_solver_switch():
+    """examples/performance/schur_complement/main.py:75-83: the sub-solver is picked by name."""
+    from parapint_amd.examples.performance.schur_complement.main import parse_args
+    assert parse_args(['--method', 'fs', '--n_blocks', '3']).subproblem_solver == 'ma27'
+    assert parse_args(['--method', 'psc', '--n_blocks', '3', '--subproblem_solver', 'mumps']).subproblem_solver == 'mumps'
+    assert parse_args(['--method', 'ssc', '--n_blocks', '3', '--linear_solver', 'scipy']).subproblem_solver == 'scipy'
