@@ -1,0 +1,1109 @@
+// Handle life cycle, symbolic phase (plan -> device images), value / vector uploads and bindings, statistics, host staging.
+#include "common.hpp"
+#include "kernels_transpose.hpp"
+
+namespace {
+
+
+}  // namespace
+
+extern "C" {
+
+static std::string g_create_error;
+
+int pp_create(pp_handle* out, int device, void* stream) {
+  if (!out) return 3;
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    g_create_error = std::string("hipGetDeviceCount: ") + hipGetErrorString(e) + " (devices: " + std::to_string(ndev) + ")";
+    return 3;
+  }
+  pp_handle h = new pp_solver();
+  if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+  h->device = device;
+  e = hipSetDevice(device);
+  if (e != hipSuccess) {
+    g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
+    delete h;
+    return 3;
+  }
+  h->stream = (hipStream_t)stream;
+  *out = h;
+  return 0;
+}
+
+void pp_destroy(pp_handle h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  for (Group* g : h->groups) free_group(g);
+  free_globals(h);
+  if (h->ev_made)
+    for (int i = 0; i < PP_NPHASE; ++i) { (void)hipEventDestroy(h->ev[i][0]); (void)hipEventDestroy(h->ev[i][1]); }
+  if (h->ev_corner_up) { (void)hipEventDestroy(h->ev_corner_up); (void)hipEventDestroy(h->ev_corner_done); (void)hipStreamDestroy(h->up_stream); }
+  if (h->aux_made) {
+    for (int i = 0; i < PP_MAX_SPLIT; ++i) { (void)hipStreamDestroy(h->aux[i]); (void)hipEventDestroy(h->ev_join[i]); }
+    (void)hipEventDestroy(h->ev_fork);
+  }
+  delete h;
+}
+
+const char* pp_last_error(pp_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int pp_begin_symbolic(pp_handle h, int n_coupling) {
+  if (!h) return 3;
+  if (n_coupling < 0) return fail(h, 3, "negative coupling dimension");
+  PP_HIP(hipSetDevice(h->device));
+  PP_HIP(hipStreamSynchronize(h->stream));
+  for (Group* g : h->groups) free_group(g);
+  h->groups.clear();
+  free_globals(h);
+  h->nc = n_coupling;
+  h->btd = 0; h->gs = h->G = 0;
+  h->symbolic_done = h->blocks_factored = h->numeric_done = h->schur_done = false;
+  return 0;
+}
+
+int pp_set_coupling_structure(pp_handle h, int mode, int gs, int G) {
+  if (!h) return 3;
+  if (h->symbolic_done || !h->groups.empty()) return fail(h, 3, "pp_set_coupling_structure: call right after pp_begin_symbolic");
+  if (mode == 0) { h->btd = 0; h->gs = h->G = 0; return 0; }
+  if (mode != 1 || gs < 1 || gs > 512 || G < 1 || (int64_t)gs * G != h->nc)
+    return fail(h, 3, "pp_set_coupling_structure: mode 1 needs n_c = G * gs, 1 <= gs <= 512");
+  h->btd = 1; h->gs = gs; h->G = G;
+  return 0;
+}
+
+int pp_set_coupling_schedule(pp_handle h, int sequential) {
+  if (!h) return 3;
+  h->btd_sequential = sequential ? 1 : 0;
+  if (h->symbolic_done && h->btd) {
+    PP_HIP(hipSetDevice(h->device));
+    PP_HIP(hipStreamSynchronize(h->stream));
+    return build_btd_schedule(h);
+  }
+  return 0;
+}
+
+int64_t pp_schur_buffer_doubles(pp_handle h) { return h ? (int64_t)(schur_doubles(h) + PP_TAIL) : 0; }
+
+int pp_add_group(pp_handle h, int n, int batch, int nnzK, const int32_t* rowK, const int32_t* colK, int nnzB,
+                 const int32_t* rowB, const int32_t* colB, int nraw, const int32_t* can_ptr, const int32_t* can_idx,
+                 const double* rep_vals, int* group_out) {
+  if (!h) return 3;
+  return pp_add_group_mapped(h, n, batch, nnzK, rowK, colK, nnzB, rowB, colB, nraw, can_ptr, can_idx, rep_vals, h->nc,
+                             nullptr, group_out);
+}
+
+int pp_add_group_mapped(pp_handle h, int n, int batch, int nnzK, const int32_t* rowK, const int32_t* colK, int nnzB,
+                        const int32_t* rowB, const int32_t* colB, int nraw, const int32_t* can_ptr, const int32_t* can_idx,
+                        const double* rep_vals, int nc_loc, const int32_t* cmap, int* group_out) {
+  if (!h) return 3;
+  if (nc_loc < 0 || nc_loc > h->nc) return fail(h, 3, "pp_add_group_mapped: local coupling dimension out of range");
+  if (!cmap && nc_loc != h->nc) return fail(h, 3, "pp_add_group_mapped: a group without a map uses all coupling rows");
+  if (cmap)
+    for (size_t i = 0; i < (size_t)batch * nc_loc; ++i)
+      if (cmap[i] < 0 || cmap[i] >= h->nc) return fail(h, 3, "pp_add_group_mapped: coupling map entry out of range");
+  if (h->symbolic_done) return fail(h, 3, "pp_add_group after pp_end_symbolic");
+  if (batch <= 0 || n <= 0 || nraw < 0) return fail(h, 3, "bad group dimensions");
+  Group* g = new Group();
+  pp::PlanOptions opt;
+  pp::tune_for_batch(opt, batch);
+  if (h->sn_wmax > 0) opt.sn_wmax = h->sn_wmax;
+  if (h->sn_tol >= 0) opt.sn_tol_rows = h->sn_tol;
+  if (h->pivot_threshold > 0.0) opt.pivot_threshold = h->pivot_threshold;
+  {
+    std::string bad;
+    if (!pp::apply_plan_tune(opt, std::getenv("PP_PLAN_TUNE"), bad)) { delete g; return fail(h, 3, "PP_PLAN_TUNE: unknown key " + bad); }
+  }
+  g->nc_loc = nc_loc;
+  if (cmap) g->cmap_host.assign(cmap, cmap + (size_t)batch * nc_loc);
+  int rc = pp::build_plan(n, nc_loc, nnzK, rowK, colK, nnzB, rowB, colB, rep_vals, opt, g->plan);
+  if (rc != 0) { std::string e = g->plan.error; delete g; return fail(h, rc, "symbolic analysis failed: " + e); }
+  const int ncan = nnzK + nnzB;
+  g->diag_can.assign((size_t)n, -1);
+  for (int e = 0; e < nnzK; ++e)
+    if (rowK[e] == colK[e]) g->diag_can[(size_t)rowK[e]] = e;
+  g->batch = batch; g->nraw = nraw;
+  g->can_ptr.assign(can_ptr, can_ptr + ncan + 1);
+  g->can_idx.assign(can_idx, can_idx + can_ptr[ncan]);
+  for (int v : g->can_idx)
+    if (v < 0 || v >= nraw) { delete g; return fail(h, 3, "canonical map points outside the raw vector"); }
+  if (g->plan.usize >= (int64_t)1 << 31) { delete g; return fail(h, 1, "panel storage exceeds 2^31 entries per instance"); }
+  h->groups.push_back(g);
+  if (group_out) *group_out = (int)h->groups.size() - 1;
+  return 0;
+}
+
+int pp_end_symbolic(pp_handle h) {
+  if (!h) return 3;
+  PP_HIP(hipSetDevice(h->device));
+  const int nc = h->nc;
+  for (Group* g : h->groups) {
+    const pp::Plan& P = g->plan;
+    GroupDev& d = g->dev;
+    std::memset(&d, 0, sizeof(d));
+    d.n = P.n; d.nc = g->nc_loc; d.batch = g->batch; d.bpad = (g->batch + WAVE - 1) / WAVE * WAVE;
+    d.xs_row = 1; d.xs_lane = 0;
+    d.rhsN = nullptr;
+    d.nchunk = d.bpad / WAVE; d.npiv = P.npiv; d.nraw = g->nraw; d.usize = P.usize;
+    int rc;
+    std::vector<int> uoff(P.piv_uoff.begin(), P.piv_uoff.end());
+    // widest column slice of a gather task per level (selects the kernel instantiation; the root front is gathered in
+    // slices of PP_WMAX) and widest block pivot with ordinary scale tasks
+    g->level_maxw.assign(P.n_levels, 1);
+    for (int pp_ = 0; pp_ < P.npiv; ++pp_)
+      g->level_maxw[P.piv_level[pp_]] = std::max(g->level_maxw[P.piv_level[pp_]], std::min(P.piv_w[pp_], PP_WMAX));
+    std::vector<int> ftask, stask, fdst_ptr, fent, srec;
+    const double one = 1.0;
+    int one_lo, one_hi;
+    { int bits[2]; std::memcpy(bits, &one, sizeof(one)); one_lo = bits[0]; one_hi = bits[1]; }
+    g->init_rec.clear();
+    // raw entries that some canonical entry reads get a compact row in the transposed buffer; the rest
+    // (typically the upper-triangle half) are never written
+    std::vector<int> rawmap((size_t)std::max(g->nraw, 1), -1);
+    // compact rows follow the raw order, so that a run of needed raw entries is a run of rows: the host boundary
+    // uploads only those ([batch][nraw_used], pp_upload_values_compact) and the transposition needs no row map
+    for (int v : g->can_idx) rawmap[v] = 0;
+    g->used_raw.clear();
+    for (int e = 0; e < g->nraw; ++e) if (rawmap[(size_t)e] == 0) { rawmap[(size_t)e] = (int)g->used_raw.size(); g->used_raw.push_back(e); }
+    g->nraw_used = (int)g->used_raw.size();
+    // expand the canonical initial-value entries into raw-value entries (duplicates are summed)
+    fdst_ptr.reserve(P.fdst_ptr.size());
+    fent.reserve(P.fentries.size() * 4 + 64);
+    ftask.reserve(P.ftasks.size() * TASK_INTS);
+    for (auto& t : P.ftasks) {
+      const int nrow = t.r1 - t.r0;
+      const int new_dptr0 = (int)fdst_ptr.size();
+      // fourth field of a record: bits 0-7 the destination column of an initial value or of a single-column product
+      // entry (third field 0), bits 8.. the number of
+      // destination rows that END before this entry (0 inside a row; k_gather_flat closes that many rows first)
+      int cur_row = 0;
+      for (int dd = 0; dd < nrow; ++dd) {
+        fdst_ptr.push_back((int)(fent.size() / 4));
+        for (int e = P.fdst_ptr[t.dptr0 + dd]; e < P.fdst_ptr[t.dptr0 + dd + 1]; ++e) {
+          const pp::FEntry& fe = P.fentries[e];
+          if (fe.u >= 0) { fent.insert(fent.end(), {fe.u, fe.l, fe.wk, (fe.wk == 0 ? fe.q : 0) | ((dd - cur_row) << 8)}); cur_row = dd; }
+          else {
+            // the L index of an initial-value record is a dummy (position 0, always valid)
+            const int ce = -1 - fe.u;
+            for (int q = g->can_ptr[ce]; q < g->can_ptr[ce + 1]; ++q)
+            {
+              g->init_rec.push_back((int)(fent.size() / 4));
+              fent.insert(fent.end(), {-1 - rawmap[g->can_idx[q]], one_lo, one_hi, fe.q | ((dd - cur_row) << 8)});
+              cur_row = dd;
+            }
+          }
+        }
+      }
+      fdst_ptr.push_back((int)(fent.size() / 4));
+      ftask.insert(ftask.end(), {t.piv, t.r0, t.r1, new_dptr0, t.kind, fdst_ptr[new_dptr0], (int)(fent.size() / 4),
+                                 t.ws > 0 ? t.ws : P.piv_w[t.piv], (int)P.piv_uoff[t.piv], P.piv_boff[t.piv], P.piv_doff[t.piv],
+                                 (int)P.piv_sub[t.piv], t.piece, t.npieces, P.piv_w[t.piv], t.qoff});
+    }
+    for (auto& t : P.stasks)
+      stask.insert(stask.end(), {t.piv, t.r0, t.r1, -1, t.kind, 0, 0, P.piv_w[t.piv], (int)P.piv_uoff[t.piv],
+                                 P.piv_boff[t.piv], P.piv_doff[t.piv], (int)P.piv_sub[t.piv], 0, 1, P.piv_w[t.piv], 0});
+    {
+      std::vector<int> wtask;
+      for (auto& t : P.wtasks)
+        wtask.insert(wtask.end(), {t.piv, t.r0, t.r1, -1, t.kind, 0, 0, P.piv_w[t.piv], (int)P.piv_uoff[t.piv],
+                                   P.piv_boff[t.piv], P.piv_doff[t.piv], (int)P.piv_sub[t.piv], 0, 1, P.piv_w[t.piv], 0});
+      g->wtask = nullptr;
+      if (!wtask.empty() && (rc = dev_upload(h, g, &g->wtask, wtask))) return rc;
+      g->front_inv = nullptr;
+      if (P.front_piv >= 0 && (rc = dev_alloc<double>(h, g, &g->front_inv, (size_t)pp::PP_WF * pp::PP_WF * d.bpad))) return rc;
+    }
+    for (int q = 0; q < 16; ++q) fent.insert(fent.end(), {0, 0, 0, 0});   // slack for the vector record reads
+    // tile records (one per panel) -> column-step records (one per panel column), with their own tile pointers
+    std::vector<int> sptr(P.stile_ptr.size(), 0);
+    for (size_t tix = 0; tix + 1 < P.stile_ptr.size(); ++tix) {
+      sptr[tix] = (int)(srec.size() / 20);
+      for (int ri = P.stile_ptr[tix]; ri < P.stile_ptr[tix + 1]; ++ri) {
+        const auto& r = P.stile_rec[ri];
+        const int w = P.piv_w[r.piv];
+        for (int t = 0; t < w; ++t) {
+          srec.insert(srec.end(), {w, (int)(P.piv_uoff[r.piv] + t), r.piv, t});
+          for (int q = 0; q < 8; ++q) srec.push_back(r.slotA[q]);
+          for (int q = 0; q < 8; ++q) srec.push_back(r.slotB[q]);
+        }
+      }
+    }
+    if (!sptr.empty()) sptr.back() = (int)(srec.size() / 20);
+    if ((rc = dev_upload(h, g, &d.piv_w, P.piv_w))) return rc;
+    if ((rc = dev_upload(h, g, &d.piv_start, P.piv_start))) return rc;
+    if ((rc = dev_upload(h, g, &d.piv_uoff, uoff))) return rc;
+    if ((rc = dev_upload(h, g, &d.piv_doff, P.piv_doff))) return rc;
+    {
+      std::vector<int> sub(P.piv_sub.begin(), P.piv_sub.end());
+      if ((rc = dev_upload(h, g, &d.piv_sub, sub))) return rc;
+      if ((rc = dev_upload(h, g, &d.piv_boff, P.piv_boff))) return rc;
+      if ((rc = dev_upload(h, g, &d.piv_of_col, P.piv_of_col))) return rc;
+    }
+    if ((rc = dev_upload(h, g, &d.piv_rowptr, P.piv_rowptr))) return rc;
+    if ((rc = dev_upload(h, g, &d.rowidx, P.rowidx))) return rc;
+    if ((rc = dev_upload(h, g, &d.perm, P.perm))) return rc;
+    if ((rc = dev_upload(h, g, &d.iperm, P.iperm))) return rc;
+    if ((rc = dev_upload(h, g, &d.rawmap, rawmap))) return rc;
+    {
+      std::vector<int> rtiles;
+      for (int t0 = 0; t0 * 64 < g->nraw; ++t0) {
+        bool any = false;
+        for (int e = t0 * 64; e < std::min(g->nraw, t0 * 64 + 64) && !any; ++e) any = rawmap[(size_t)e] >= 0;
+        if (any) rtiles.push_back(t0);
+      }
+      g->nraw_tiles = (int)rtiles.size();
+      rtiles.push_back(0);
+      if ((rc = dev_upload(h, g, &d.raw_tiles, rtiles))) return rc;
+    }
+    if ((rc = dev_upload(h, g, &d.ftask, ftask))) return rc;
+    if ((rc = dev_upload(h, g, &d.stask, stask))) return rc;
+    if ((rc = dev_upload(h, g, &d.fdst_ptr, fdst_ptr))) return rc;
+    if ((rc = dev_upload(h, g, &d.fent, fent))) return rc;
+    g->fent_host = fent;
+    d.const_row = -1;
+    if (!g->cmap_host.empty()) {      // [batch][nc_loc] -> [nc_loc][bpad] (padded lanes repeat instance 0: never used)
+      std::vector<int> cm((size_t)std::max(g->nc_loc, 1) * d.bpad, 0);
+      for (int c = 0; c < g->nc_loc; ++c)
+        for (int b = 0; b < d.bpad; ++b)
+          cm[(size_t)c * d.bpad + b] = g->cmap_host[(size_t)(b < g->batch ? b : 0) * g->nc_loc + c];
+      if ((rc = dev_upload(h, g, &d.cmapT, cm))) return rc;
+      d.xs_row = d.bpad; d.xs_lane = 1;
+    }
+    if ((rc = dev_upload(h, g, &d.clevel_col, P.clevel_col))) return rc;
+    {
+      std::vector<int> frec, brec;
+      frec.reserve(P.clevel_col.size() * 4);
+      brec.reserve(P.clevel_col.size() * 8);
+      for (int c : P.clevel_col) {
+        const int pv = P.piv_of_col[c], w = P.piv_w[pv], q = c - P.piv_start[pv];
+        frec.insert(frec.end(), {c, P.perm[c], P.sfwd_eptr[c], P.sfwd_eptr[c + 1]});
+        brec.insert(brec.end(), {c, w, q, P.piv_rowptr[pv + 1] - P.piv_rowptr[pv], P.piv_rowptr[pv],
+                                 (int)(P.piv_uoff[pv] + (int64_t)w * w + q), P.piv_doff[pv], P.piv_start[pv]});
+      }
+      g->fwd_level_has_entries.assign((size_t)P.n_levels, 0);
+      for (int l = 0; l < P.n_levels; ++l)
+        for (int q = P.clevel_ptr[l]; q < P.clevel_ptr[l + 1]; ++q) {
+          const int c = P.clevel_col[q];
+          if (P.sfwd_eptr[c + 1] > P.sfwd_eptr[c]) { g->fwd_level_has_entries[(size_t)l] = 1; break; }
+        }
+      // wave teams: a row / column with more than a couple of 16-entry load rounds is shared by 4 or 16 waves
+      // (thresholds measured at C3: 16/48 and 16/64 were slower, 48/128 the same)
+      auto team_of = [](int longest) { return longest > 96 ? 16 : longest > 32 ? 4 : 1; };
+      g->fwd_level_team.assign((size_t)P.n_levels, 1);
+      g->bwd_level_team.assign((size_t)P.n_levels, 1);
+      g->fwd_level_maxrow.assign((size_t)P.n_levels, 0);
+      g->bwd_level_maxrow.assign((size_t)P.n_levels, 0);
+      for (int l = 0; l < P.n_levels; ++l) {
+        int fmax = 0, bmax = 0;
+        for (int q = P.clevel_ptr[l]; q < P.clevel_ptr[l + 1]; ++q) {
+          const int c = P.clevel_col[q], pv = P.piv_of_col[c];
+          fmax = std::max(fmax, P.sfwd_eptr[c + 1] - P.sfwd_eptr[c]);
+          bmax = std::max(bmax, P.piv_rowptr[pv + 1] - P.piv_rowptr[pv]);
+        }
+        g->fwd_level_team[(size_t)l] = team_of(fmax);
+        g->bwd_level_team[(size_t)l] = team_of(bmax);
+        g->fwd_level_maxrow[(size_t)l] = fmax;
+        g->bwd_level_maxrow[(size_t)l] = bmax;
+      }
+      if ((rc = dev_upload(h, g, &d.fwd_rec, frec))) return rc;
+      if ((rc = dev_upload(h, g, &d.bwd_rec, brec))) return rc;
+      // native-vector variants: a column without incoming entries keeps y = b, which then is read from the caller's
+      // right-hand side (row perm[c]) instead of a copy; x is written and read in the caller's row order
+      std::vector<uint8_t> noent((size_t)P.n, 0);
+      for (int c = 0; c < P.n; ++c) noent[(size_t)c] = P.sfwd_eptr[c + 1] == P.sfwd_eptr[c];
+      std::vector<int> zf(P.sfwd_zcol), zc2(P.crow_zcol), brn(brec), ro(P.rowidx);
+      for (auto& z : zf) if (noent[(size_t)z]) z = -1 - P.perm[z];
+      for (auto& z : zc2) if (noent[(size_t)z]) z = -1 - P.perm[z];
+      for (int q = 0; q < 16; ++q) { zf.push_back(0); zc2.push_back(0); }
+      for (size_t i = 0; i < brn.size(); i += 8) {
+        const int p0 = brn[i + 7], w = brn[i + 1];
+        brn[i] = P.perm[brn[i]];
+        // y of the whole block pivot is read from the right-hand side only if NONE of its columns has incoming entries
+        // (then its level was not launched in the forward sweep); a level that was launched has written y for all of
+        // its columns.  (Columns of one block pivot may differ: a panel below may hold only some of them as rows.)
+        bool none = true;
+        for (int t = 0; t < w; ++t) none = none && noent[(size_t)(p0 + t)];
+        if (none) brn[i + 7] = -1 - p0;
+      }
+      for (auto& r : ro) if (r < P.n) r = P.perm[r];
+      if ((rc = dev_upload(h, g, &g->zcolN_f, zf))) return rc;
+      if ((rc = dev_upload(h, g, &g->zcolN_c, zc2))) return rc;
+      if ((rc = dev_upload(h, g, &g->brecN, brn))) return rc;
+      if ((rc = dev_upload(h, g, &g->rowidx_o, ro))) return rc;
+    }
+    {
+      std::vector<int> up(P.sfwd_upos), zc(P.sfwd_zcol), cu(P.crow_upos), cz(P.crow_zcol);
+      for (int q = 0; q < 16; ++q) { up.push_back(0); zc.push_back(0); cu.push_back(0); cz.push_back(0); }
+      if ((rc = dev_upload(h, g, &d.sfwd_eptr, P.sfwd_eptr))) return rc;
+      if ((rc = dev_upload(h, g, &d.sfwd_upos, up))) return rc;
+      if ((rc = dev_upload(h, g, &d.sfwd_zcol, zc))) return rc;
+      if ((rc = dev_upload(h, g, &d.crow_eptr, P.crow_eptr))) return rc;
+      if ((rc = dev_upload(h, g, &d.crow_upos, cu))) return rc;
+      if ((rc = dev_upload(h, g, &d.crow_zcol, cz))) return rc;
+    }
+    if ((rc = dev_upload(h, g, &d.stile_a, P.stile_a))) return rc;
+    if ((rc = dev_upload(h, g, &d.stile_b, P.stile_b))) return rc;
+    if ((rc = dev_upload(h, g, &d.stile_ptr, sptr))) return rc;
+    if ((rc = dev_upload(h, g, &d.stile_rec, srec))) return rc;
+    g->ntiles = (int)P.stile_a.size();
+    // 16 x 16 tiles for the MFMA form (k_schur_mfma): per (tile pair, panel column) one record with the positions of the
+    // 16 + 16 rows; the records of a tile are cut into work items of at most PP_MT_SLICE records
+    g->mt_wide = h->nc >= PP_MT_WIDE_NC && std::getenv("PP_NO_WIDE_SCHUR_TILES") == nullptr;
+    if (g->mt_wide) {
+      // 32 x 32 super-tiles (k_schur_mfma_wide): per (super-tile pair, panel column) one record with the positions of the
+      // 32 + 32 rows; mt_a / mt_b per quarter (4 per super-tile, -1: the quarter above the diagonal), items {r0, r1, super, 0}
+      std::map<std::pair<int, int>, std::vector<int>> by_super;
+      for (int pv = 0; pv < P.npiv; ++pv) {
+        const int w = P.piv_w[pv];
+        std::vector<int> sl;
+        std::vector<std::array<int, 32>> slots;
+        for (int q = P.piv_rowptr[pv]; q < P.piv_rowptr[pv + 1]; ++q) {
+          const int r = P.rowidx[(size_t)q];
+          if (r < P.n) continue;
+          const int c = r - P.n, si = c / 32;
+          if (sl.empty() || sl.back() != si) { sl.push_back(si); std::array<int, 32> e; e.fill(-1); slots.push_back(e); }
+          slots.back()[(size_t)(c % 32)] = w + (q - P.piv_rowptr[pv]);
+        }
+        for (size_t a = 0; a < sl.size(); ++a)
+          for (size_t b2 = 0; b2 <= a; ++b2)
+            for (int t = 0; t < w; ++t) {
+              auto& v = by_super[{sl[a], sl[b2]}];
+              for (int q = 0; q < 32; ++q) v.push_back(slots[a][(size_t)q] < 0 ? -1 : (int)(P.piv_uoff[pv] + (int64_t)slots[a][(size_t)q] * w + t));
+              for (int q = 0; q < 32; ++q) v.push_back(slots[b2][(size_t)q] < 0 ? -1 : (int)(P.piv_uoff[pv] + (int64_t)slots[b2][(size_t)q] * w + t));
+            }
+      }
+      std::vector<int> mta, mtb, mrec, mitem, mwptr{0};
+      int super = 0;
+      for (auto& kv : by_super) {
+        for (int x = 0; x < 2; ++x)
+          for (int y = 0; y < 2; ++y) {
+            const int ta = 2 * kv.first.first + x, tb = 2 * kv.first.second + y;
+            mta.push_back(ta >= tb ? ta : -1);
+            mtb.push_back(ta >= tb ? tb : -1);
+          }
+        const int r0 = (int)(mrec.size() / 64);
+        mrec.insert(mrec.end(), kv.second.begin(), kv.second.end());
+        const int r1 = (int)(mrec.size() / 64);
+        for (int r = r0; r < r1; r += PP_MT_SLICE) mitem.insert(mitem.end(), {r, std::min(r1, r + PP_MT_SLICE), super, 0});
+        mwptr.push_back((int)(mitem.size() / 4));
+        ++super;
+      }
+      g->nmt = (int)mta.size();                       // quarters (workgroups of the reduction)
+      g->nmt_items = (int)(mitem.size() / 4);
+      if ((rc = dev_upload(h, g, &d.mt_a, mta))) return rc;
+      if ((rc = dev_upload(h, g, &d.mt_b, mtb))) return rc;
+      if ((rc = dev_upload(h, g, &d.mt_rec, mrec))) return rc;
+      if ((rc = dev_upload(h, g, &d.mt_item, mitem))) return rc;
+      if ((rc = dev_upload(h, g, &d.mt_wptr, mwptr))) return rc;
+    } else {
+      std::map<std::pair<int, int>, std::vector<int>> by_tile;      // (ta, tb) -> records of 32 ints
+      for (int pv = 0; pv < P.npiv; ++pv) {
+        const int w = P.piv_w[pv];
+        std::vector<int> tl;
+        std::vector<std::array<int, 16>> slots;
+        for (int q = P.piv_rowptr[pv]; q < P.piv_rowptr[pv + 1]; ++q) {
+          const int r = P.rowidx[(size_t)q];
+          if (r < P.n) continue;
+          const int c = r - P.n, ti = c / 16;
+          if (tl.empty() || tl.back() != ti) { tl.push_back(ti); std::array<int, 16> e; e.fill(-1); slots.push_back(e); }
+          slots.back()[(size_t)(c % 16)] = w + (q - P.piv_rowptr[pv]);      // row slot inside the panel
+        }
+        for (size_t a = 0; a < tl.size(); ++a)
+          for (size_t b2 = 0; b2 <= a; ++b2)
+            for (int t = 0; t < w; ++t) {
+              auto& v = by_tile[{tl[a], tl[b2]}];
+              for (int q = 0; q < 16; ++q) v.push_back(slots[a][(size_t)q] < 0 ? -1 : (int)(P.piv_uoff[pv] + (int64_t)slots[a][(size_t)q] * w + t));
+              for (int q = 0; q < 16; ++q) v.push_back(slots[b2][(size_t)q] < 0 ? -1 : (int)(P.piv_uoff[pv] + (int64_t)slots[b2][(size_t)q] * w + t));
+            }
+      }
+      std::vector<int> mta, mtb, mrec, mitem, mwptr{0};
+      for (auto& kv : by_tile) {
+        mta.push_back(kv.first.first); mtb.push_back(kv.first.second);
+        const int r0 = (int)(mrec.size() / 32);
+        mrec.insert(mrec.end(), kv.second.begin(), kv.second.end());
+        const int r1 = (int)(mrec.size() / 32);
+        for (int r = r0; r < r1; r += PP_MT_SLICE) { mitem.push_back(r); mitem.push_back(std::min(r1, r + PP_MT_SLICE)); }
+        mwptr.push_back((int)(mitem.size() / 2));
+      }
+      g->nmt = (int)mta.size();
+      g->nmt_items = (int)(mitem.size() / 2);
+      if ((rc = dev_upload(h, g, &d.mt_a, mta))) return rc;
+      if ((rc = dev_upload(h, g, &d.mt_b, mtb))) return rc;
+      if ((rc = dev_upload(h, g, &d.mt_rec, mrec))) return rc;
+      if ((rc = dev_upload(h, g, &d.mt_item, mitem))) return rc;
+      if ((rc = dev_upload(h, g, &d.mt_wptr, mwptr))) return rc;
+    }
+  }
+  int rc;
+  if (h->btd && (h->G < 1 || h->gs < 1 || h->gs > 512 || (int64_t)h->G * h->gs != nc))
+    return fail(h, 3, "block-tridiagonal coupling structure: need n_c = G * gs with 1 <= gs <= 512");
+  for (Group* g : h->groups)
+    if (h->btd && g->cmap_host.empty() && nc > 0) return fail(h, 3, "block-tridiagonal S needs mapped groups (pp_add_group_mapped)");
+  const size_t nn = schur_doubles(h);
+  const size_t nd = h->btd ? 1 : nn;            // the dense factor copies are not needed for a block-tridiagonal S
+  if ((rc = dev_alloc<double>(h, nullptr, &h->S_own, nn + PP_TAIL))) return rc;
+  if ((rc = dev_alloc<double>(h, nullptr, &h->Sfac, nd))) return rc;
+  if ((rc = dev_alloc<double>(h, nullptr, &h->Sldl, nd))) return rc;
+  if ((rc = dev_alloc<int>(h, nullptr, &h->scatter_err, 4))) return rc;
+  PP_HIP(hipMemset(h->scatter_err, 0, 4 * sizeof(int)));
+  if (h->btd) {
+    const size_t g2 = (size_t)h->gs * h->gs;
+    if ((rc = dev_alloc<double>(h, nullptr, &h->btd_fac, nn))) return rc;
+    if ((rc = dev_alloc<double>(h, nullptr, &h->btd_inv, (size_t)h->G * g2))) return rc;
+    if ((rc = dev_alloc<double>(h, nullptr, &h->btd_klo, (size_t)h->G * g2))) return rc;
+    if ((rc = dev_alloc<double>(h, nullptr, &h->btd_kup, (size_t)h->G * g2))) return rc;
+    if ((rc = dev_alloc<double>(h, nullptr, &h->btd_ylo, (size_t)h->G * g2))) return rc;
+    if ((rc = dev_alloc<double>(h, nullptr, &h->btd_yup, (size_t)h->G * g2))) return rc;
+    if ((rc = dev_alloc<double>(h, nullptr, &h->btd_vec, 8 * (size_t)nc + 64))) return rc;    // BK work | b | u
+    if ((rc = dev_alloc<int>(h, nullptr, &h->btd_ipiv, nc))) return rc;
+    if ((rc = dev_alloc<int>(h, nullptr, &h->btd_info, 4 * (size_t)h->G))) return rc;
+    if ((rc = build_btd_schedule(h))) return rc;
+  }
+  if ((rc = dev_alloc<double>(h, nullptr, &h->dvec, nc))) return rc;
+  if ((rc = dev_alloc<int>(h, nullptr, &h->dense_mode, 4))) return rc;
+  PP_HIP(hipMemset(h->dense_mode, 0, 4 * sizeof(int)));
+  // Q: dense n_c x n_c; for a block-tridiagonal S (the layout of S, tens of MB) only when a caller hands over a flat Q --
+  // the sparse form of pp_factor_schur_corner needs none
+  if (!h->btd && (rc = dev_alloc<double>(h, nullptr, &h->Qd, nn))) return rc;
+  if ((rc = dev_alloc<double>(h, nullptr, &h->work, 2 * (size_t)nc))) return rc;
+  if ((rc = dev_alloc<double>(h, nullptr, &h->rs_own, nc))) return rc;
+  if ((rc = dev_alloc<double>(h, nullptr, &h->rcd, nc))) return rc;
+  if ((rc = dev_alloc<double>(h, nullptr, &h->xc, nc))) return rc;
+  if ((rc = dev_alloc<int>(h, nullptr, &h->ipiv, nc))) return rc;
+  if ((rc = dev_alloc<int>(h, nullptr, &h->bkinfo, 4))) return rc;
+  if ((rc = dev_alloc<int>(h, nullptr, &h->counters, 4 * PP_CSLOTS))) return rc;
+  PP_HIP(hipMemset(h->counters, 0, 4 * PP_CSLOTS * sizeof(int)));     // (afterwards cleared by the kernel that writes the tail)
+  {
+    void* hp = nullptr;
+    void* dp = nullptr;
+    PP_HIP(hipHostMalloc(&hp, 8 * sizeof(long long), hipHostMallocMapped));
+    std::memset(hp, 0, 8 * sizeof(long long));
+    PP_HIP(hipHostGetDevicePointer(&dp, hp, 0));
+    h->status_host = (volatile long long*)hp;
+    h->status_dev = (long long*)dp;
+    h->status_seq = 0;
+  }
+  h->S = h->S_own;
+  h->rs = h->rs_own;
+  PP_HIP(hipMemset(h->S, 0, (nn + PP_TAIL) * sizeof(double)));
+  PP_HIP(hipMemset(h->rs, 0, std::max<size_t>(nc, 1) * sizeof(double)));
+  PP_HIP(hipMemset(h->bkinfo, 0, 4 * sizeof(int)));
+  h->symbolic_done = true;
+  // value storage (factor panels, work vectors): sized by the plan; if it does not fit the handle's budget the
+  // symbolic phase still succeeds (the plan is valid) and the numeric phase reports not_enough_memory until
+  // increase_memory_allocation has raised the budget (reference: ma27_interface.py:126-131, 153-154)
+  h->values_allocated = false;
+  h->mem_required = value_storage_bytes(h);
+  (void)alloc_value_storage(h);
+  h->err.clear();
+  return 0;
+}
+
+int pp_upload_values(pp_handle h, int group, const double* raw, int on_device) {
+  Group* g = get_group(h, group);
+  if (!g || !h->symbolic_done) return fail(h, 3, "pp_upload_values: bad group or symbolic phase not finished");
+  PP_HIP(hipSetDevice(h->device));
+  if (int rc = alloc_value_storage(h)) return rc;
+  if (!g->dev.raw) { if (int rc = ensure_optional(h, g, OPT_RAW)) return rc; }
+  g->input_mode = Group::IN_RAW;
+  const size_t bytes = (size_t)g->batch * g->nraw * sizeof(double);
+  if (bytes == 0 || raw == g->dev.raw) return 0;
+  PP_HIP(hipMemcpyAsync(g->dev.raw, raw, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+  return 0;
+}
+
+int pp_upload_values_compact(pp_handle h, int group, const double* compact, int row0, int nrows, int on_device) {
+  Group* g = get_group(h, group);
+  if (!g || !h->symbolic_done) return fail(h, 3, "pp_upload_values_compact: bad group or symbolic phase not finished");
+  if (row0 < 0 || nrows < 0 || row0 + nrows > g->batch) return fail(h, 3, "pp_upload_values_compact: row range outside the batch");
+  PP_HIP(hipSetDevice(h->device));
+  if (int rc = ensure_optional(h, g, OPT_RAW)) return rc;
+  g->input_mode = Group::IN_COMPACT;
+  const size_t stride = (size_t)g->nraw_used;
+  if (nrows == 0 || stride == 0) return 0;
+  PP_HIP(hipMemcpyAsync(g->raw_own + (size_t)row0 * stride, compact + (size_t)row0 * stride, (size_t)nrows * stride * sizeof(double),
+                        on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+  return 0;
+}
+
+int pp_used_raw_entries(pp_handle h, int group, int32_t* out, int capacity) {
+  Group* g = get_group(h, group);
+  if (!g || !h->symbolic_done) return fail(h, 3, "pp_used_raw_entries: bad group or symbolic phase not finished");
+  if (capacity < (int)g->used_raw.size()) return fail(h, 3, "pp_used_raw_entries: buffer too small");
+  std::memcpy(out, g->used_raw.data(), g->used_raw.size() * sizeof(int));
+  return 0;
+}
+
+int pp_set_value_map(pp_handle h, int group, int nsrc, const int32_t* src_of_raw, const double* coef_of_raw) {
+  Group* g = get_group(h, group);
+  if (!g || !h->symbolic_done) return fail(h, 3, "pp_set_value_map: bad group or symbolic phase not finished");
+  if (nsrc < 0 || !src_of_raw || !coef_of_raw) return fail(h, 3, "pp_set_value_map: bad arguments");
+  PP_HIP(hipSetDevice(h->device));
+  PP_HIP(hipStreamSynchronize(h->stream));
+  std::vector<int> ms(g->used_raw.size() + 1, -1);
+  std::vector<double> mc(g->used_raw.size() + 1, 0.0);
+  for (size_t j = 0; j < g->used_raw.size(); ++j) {
+    const int e = g->used_raw[j];
+    if (src_of_raw[e] >= nsrc) return fail(h, 3, "pp_set_value_map: source row out of range");
+    ms[j] = src_of_raw[e] < 0 ? -1 : src_of_raw[e];
+    mc[j] = coef_of_raw[e];
+  }
+  for (void* p : {(void*)g->map_src, (void*)g->map_coef, (void*)g->src_own}) if (p) (void)hipFree(p);
+  g->map_src = nullptr; g->map_coef = nullptr; g->src_own = nullptr; g->src = nullptr;
+  g->nsrc = nsrc;
+  int rc;
+  if ((rc = dev_alloc(h, (Group*)nullptr, &g->map_src, ms.size()))) return rc;
+  if ((rc = dev_alloc(h, (Group*)nullptr, &g->map_coef, mc.size()))) return rc;
+  PP_HIP(hipMemcpy(g->map_src, ms.data(), ms.size() * sizeof(int), hipMemcpyHostToDevice));
+  PP_HIP(hipMemcpy(g->map_coef, mc.data(), mc.size() * sizeof(double), hipMemcpyHostToDevice));
+  // entry records for the fused path: an initial-value record reads its source row directly (row nsrc = the constant
+  // 1) and carries its coefficient, so the factorisation kernels gather from the sources themselves
+  {
+    std::vector<int> fs(g->fent_host);
+    for (int pos : g->init_rec) {
+      const int row = -1 - fs[(size_t)4 * pos];            // compact row of the transposed input
+      const int sidx = ms[(size_t)row];
+      const double c = mc[(size_t)row];
+      int bits[2];
+      std::memcpy(bits, &c, sizeof(c));
+      fs[(size_t)4 * pos] = -1 - (sidx >= 0 ? sidx : nsrc);
+      fs[(size_t)4 * pos + 1] = bits[0];
+      fs[(size_t)4 * pos + 2] = bits[1];
+    }
+    if (g->fent_src) { (void)hipFree(g->fent_src); g->fent_src = nullptr; }
+    if ((rc = dev_alloc(h, (Group*)nullptr, &g->fent_src, fs.size()))) return rc;
+    PP_HIP(hipMemcpy(g->fent_src, fs.data(), fs.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
+double* pp_source_buffer(pp_handle h, int group) {
+  Group* g = get_group(h, group);
+  if (!g || !h->symbolic_done || !g->map_src) return nullptr;
+  if (!g->src_own) {
+    if (dev_alloc(h, (Group*)nullptr, &g->src_own, (size_t)std::max(g->nsrc, 1) * (size_t)g->dev.bpad)) return nullptr;
+    if (hipMemset(g->src_own, 0, (size_t)std::max(g->nsrc, 1) * (size_t)g->dev.bpad * sizeof(double)) != hipSuccess) return nullptr;
+  }
+  if (!g->src) g->src = g->src_own;
+  return g->src_own;
+}
+
+int pp_bind_source_buffer(pp_handle h, int group, double* dev_ptr) {
+  Group* g = get_group(h, group);
+  if (!g || !h->symbolic_done || !g->map_src) return fail(h, 3, "pp_bind_source_buffer: bad group or no value map");
+  if (!dev_ptr && !pp_source_buffer(h, group)) return fail(h, 1, "pp_bind_source_buffer: could not allocate the source buffer");
+  g->src = dev_ptr ? dev_ptr : g->src_own;
+  g->input_mode = Group::IN_SOURCES;
+  return 0;
+}
+
+int pp_upload_sources(pp_handle h, int group, const double* src, int on_device) {
+  Group* g = get_group(h, group);
+  if (!g || !h->symbolic_done || !g->map_src) return fail(h, 3, "pp_upload_sources: bad group or no value map");
+  PP_HIP(hipSetDevice(h->device));
+  if (int rc = ensure_optional(h, g, OPT_RAW)) return rc;       // (host sources are staged through the raw buffer)
+  if (!pp_source_buffer(h, group)) return fail(h, 1, "pp_upload_sources: could not allocate the source buffer");
+  // [batch][nsrc] (one row per block, the producer's natural layout on the host) -> [nsrc][bpad]: staged through the
+  // raw buffer (nsrc <= nraw is not required: the copy is done in slabs of whole rows)
+  const size_t per = (size_t)g->nsrc;
+  if (per == 0) { g->src = g->src_own; g->input_mode = Group::IN_SOURCES; return 0; }
+  if (per > (size_t)g->nraw) return fail(h, 3, "pp_upload_sources: more sources than raw entries per block");
+  PP_HIP(hipMemcpyAsync(g->raw_own, src, (size_t)g->batch * per * sizeof(double),
+                        on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_transpose_in, dim3((unsigned)((g->nsrc + 63) / 64) * g->dev.nchunk), dim3(256), 0, h->stream, g->raw_own,
+                     g->src_own, (const int*)nullptr, g->batch, g->nsrc, g->dev.bpad, 1, (const int*)nullptr);
+  PP_HIP(hipGetLastError());
+  g->src = g->src_own;
+  g->input_mode = Group::IN_SOURCES;
+  return 0;
+}
+
+double* pp_raw_buffer(pp_handle h, int group) {
+  Group* g = get_group(h, group);
+  if (!g || !h->symbolic_done || alloc_value_storage(h)) return nullptr;
+  if (!g->dev.raw && ensure_optional(h, g, OPT_RAW)) return nullptr;
+  return g->dev.raw;
+}
+
+int pp_upload_rhs(pp_handle h, int group, const double* rhs, int on_device) {
+  Group* g = get_group(h, group);
+  if (!g || !h->symbolic_done) return fail(h, 3, "pp_upload_rhs: bad group or symbolic phase not finished");
+  PP_HIP(hipSetDevice(h->device));
+  if (int rc = alloc_value_storage(h)) return rc;
+  if (!g->dev.rhs) { if (int rc = ensure_optional(h, g, OPT_RHS)) return rc; }
+  const size_t bytes = (size_t)g->batch * g->plan.n * sizeof(double);
+  if (rhs == g->dev.rhs) return 0;
+  PP_HIP(hipMemcpyAsync(g->dev.rhs, rhs, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+  return 0;
+}
+
+double* pp_rhs_buffer(pp_handle h, int group) {
+  Group* g = get_group(h, group);
+  if (!g || !h->symbolic_done || alloc_value_storage(h)) return nullptr;
+  if (!g->dev.rhs && ensure_optional(h, g, OPT_RHS)) return nullptr;
+  return g->dev.rhs;
+}
+
+int pp_bind_solution_buffer(pp_handle h, int group, double* dev_ptr) {
+  Group* g = get_group(h, group);
+  if (!g || !h->symbolic_done) return fail(h, 3, "pp_bind_solution_buffer: bad group");
+  if (int rc = alloc_value_storage(h)) return rc;
+  g->dev.xout = dev_ptr ? dev_ptr : g->xout_own;
+  return 0;
+}
+
+int pp_bind_native_vectors(pp_handle h, int group, const double* rhs_dev, double* x_dev) {
+  Group* g = get_group(h, group);
+  if (!g || !h->symbolic_done) return fail(h, 3, "pp_bind_native_vectors: bad group");
+  if ((rhs_dev == nullptr) != (x_dev == nullptr)) return fail(h, 3, "pp_bind_native_vectors: give both buffers or neither");
+  if (int rc = alloc_value_storage(h)) return rc;
+  g->rhs_native = rhs_dev;
+  g->x_native = x_dev;
+  return 0;
+}
+
+int pp_download_solution(pp_handle h, int group, double* x, int on_device) {
+  Group* g = get_group(h, group);
+  if (!g || !h->symbolic_done) return fail(h, 3, "pp_download_solution: bad group");
+  PP_HIP(hipSetDevice(h->device));
+  const size_t bytes = (size_t)g->batch * g->plan.n * sizeof(double);
+  if (!g->dev.xout) return fail(h, 3, "pp_download_solution: no solution in the [instance][row] layout (native vectors bound?)");
+  if (x != g->dev.xout)
+    PP_HIP(hipMemcpyAsync(x, g->dev.xout, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+  if (!on_device) PP_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+double* pp_solution_buffer(pp_handle h, int group) {
+  Group* g = get_group(h, group);
+  if (!g || !h->symbolic_done || alloc_value_storage(h)) return nullptr;
+  if (!g->dev.xout && ensure_optional(h, g, OPT_XOUT)) return nullptr;
+  return g->dev.xout;
+}
+
+int pp_bind_raw_buffer(pp_handle h, int group, double* dev_ptr) {
+  Group* g = get_group(h, group);
+  if (!g || !h->symbolic_done) return fail(h, 3, "pp_bind_raw_buffer: bad group");
+  g->dev.raw = dev_ptr ? dev_ptr : g->raw_own;
+  g->input_mode = Group::IN_RAW;
+  return 0;
+}
+
+int pp_bind_rhs_buffer(pp_handle h, int group, double* dev_ptr) {
+  Group* g = get_group(h, group);
+  if (!g || !h->symbolic_done) return fail(h, 3, "pp_bind_rhs_buffer: bad group");
+  g->dev.rhs = dev_ptr ? dev_ptr : g->rhs_own;
+  return 0;
+}
+
+int pp_set_supernodes(pp_handle h, int wmax, int tol_rows) {
+  if (!h) return 3;
+  if (wmax < 0 || wmax > PP_WMAX) return fail(h, 3, "supernode width must be 0 (default) .. PP_WMAX");
+  h->sn_wmax = wmax;
+  h->sn_tol = tol_rows;
+  return 0;
+}
+
+int pp_set_instance_splits(pp_handle h, int nsplit) {
+  if (!h) return 3;
+  if (nsplit < 0 || nsplit > PP_MAX_SPLIT) return fail(h, 3, "instance splits must be 0 (automatic) .. 8");
+  h->nsplit_req = nsplit;
+  return 0;
+}
+
+int pp_set_dense_policy(pp_handle h, int policy) {
+  if (!h) return 3;
+  if (policy != 0 && policy != 1) return fail(h, 3, "dense policy must be 0 (auto) or 1 (Bunch-Kaufman only)");
+  h->dense_policy = policy;
+  return 0;
+}
+
+int pp_get_dense_mode(pp_handle h, int* mode_out) {
+  if (!h || !h->schur_done) return fail(h, 3, "pp_get_dense_mode before pp_factor_schur");
+  PP_HIP(hipSetDevice(h->device));
+  PP_HIP(hipMemcpyAsync(mode_out, h->dense_mode, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  PP_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int pp_profile(pp_handle h, int enable) {
+  if (!h) return 3;
+  h->profile = enable != 0;
+  for (int i = 0; i < PP_NPHASE; ++i) {
+    h->phase_ms[i] = 0.0; h->phase_launches[i] = 0; h->phase_calls[i] = 0; h->ev_used[i] = false;
+  }
+  return 0;
+}
+
+int pp_phase_times(pp_handle h, double ms_out[8], int32_t launches_out[8], int32_t calls_out[8]) {
+  if (!h) return 3;
+  PP_HIP(hipSetDevice(h->device));
+  PP_HIP(hipStreamSynchronize(h->stream));
+  for (int i = 0; i < PP_NPHASE; ++i) {
+    if (h->ev_used[i]) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, h->ev[i][0], h->ev[i][1]) == hipSuccess) h->phase_ms[i] += ms;
+      h->ev_used[i] = false;
+    }
+    ms_out[i] = h->phase_ms[i];
+    launches_out[i] = h->phase_launches[i];
+    calls_out[i] = h->phase_calls[i];
+  }
+  return 0;
+}
+
+int pp_increase_memory_allocation(pp_handle h, double factor) {
+  if (!h) return 3;
+  if (!(factor > 0.0)) return fail(h, 3, "memory allocation factor must be positive");
+  h->mem_factor *= factor;
+  return 0;
+}
+
+int pp_set_memory_budget(pp_handle h, int64_t bytes) {
+  if (!h) return 3;
+  if (bytes < 0) return fail(h, 3, "memory budget must be >= 0 (0: no limit)");
+  h->mem_budget = bytes;
+  h->mem_factor = 1.0;
+  return 0;
+}
+
+int pp_memory_info(pp_handle h, int64_t out[3]) {
+  if (!h) return 3;
+  out[0] = h->mem_required;
+  out[1] = h->mem_budget > 0 ? (int64_t)((double)h->mem_budget * h->mem_factor) : 0;
+  int64_t allocated = 0;      // what is allocated now: the optional input / output copies only once something used them
+  if (h->values_allocated) {
+    allocated = h->mem_required;
+    for (Group* g : h->groups) {
+      const int64_t bp = g->dev.bpad;
+      if (!g->raw_own) allocated -= 8 * (int64_t)g->batch * g->nraw;
+      if (!g->rawT_own) allocated -= 8 * (int64_t)std::max(g->nraw_used, 1) * bp;
+      if (!g->rhs_own) allocated -= 8 * (int64_t)g->batch * g->plan.n;
+      if (!g->xout_own) allocated -= 8 * (int64_t)g->batch * g->plan.n;
+      if (!g->dev.X) allocated -= 8 * (int64_t)g->plan.n * bp;
+    }
+  }
+  out[2] = allocated;
+  return 0;
+}
+
+int pp_bcr_block_paths(pp_handle h, int32_t out[2]) {
+  if (!h) return 3;
+  out[0] = out[1] = 0;
+  if (!h->btd || !h->schur_done || !h->btd_info) return 0;
+  PP_HIP(hipSetDevice(h->device));
+  std::vector<int> info(4 * (size_t)h->G);
+  PP_HIP(hipMemcpyAsync(info.data(), h->btd_info, info.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  PP_HIP(hipStreamSynchronize(h->stream));
+  for (int t = 0; t < h->G; ++t) out[info[4 * (size_t)t + 3] == 1 ? 0 : 1] += 1;
+  return 0;
+}
+
+int pp_synchronize(pp_handle h) {
+  if (!h) return 3;
+  PP_HIP(hipSetDevice(h->device));
+  PP_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int pp_group_stats(pp_handle h, int group, int64_t out[16]) {
+  Group* g = get_group(h, group);
+  if (!g) return fail(h, 3, "pp_group_stats: bad group");
+  const pp::Plan& P = g->plan;
+  const int64_t v[16] = {P.n, P.nc, g->batch, P.npiv, P.n_2x2, P.n_levels, P.nnz_L, P.usize, P.flops_factor,
+                         P.flops_schur, (int64_t)P.ftasks.size(), (int64_t)P.fentries.size(), (int64_t)P.stile_a.size(),
+                         (int64_t)P.stile_rec.size(), P.ncan, g->nraw};
+  std::memcpy(out, v, sizeof(v));
+  return 0;
+}
+
+int pp_group_stats_ex(pp_handle h, int group, int64_t out[16]) {
+  Group* g = get_group(h, group);
+  if (!g) return fail(h, 3, "pp_group_stats_ex: bad group");
+  const pp::Plan& P = g->plan;
+  int64_t coupling_entries = 0;
+  for (int p = 0; p < P.npiv; ++p) coupling_entries += (int64_t)P.piv_ncrow[p] * P.piv_w[p];
+  int64_t launches_factor = 0, launches_fwd = 1, launches_bwd = 1;
+  for (int l = 0; l < P.n_levels; ++l) {
+    launches_factor += (P.flevel_ptr[l + 1] > P.flevel_ptr[l]) + (P.slevel_ptr[l + 1] > P.slevel_ptr[l]) +
+                       ((P.front_piv >= 0 && P.piv_level[P.front_piv] == l) ? 1 + (P.wtasks.empty() ? 0 : 1) : 0);
+    if (l < (int)g->fwd_level_has_entries.size() && g->fwd_level_has_entries[(size_t)l]) ++launches_fwd;
+    if (P.clevel_ptr[l + 1] > P.clevel_ptr[l]) ++launches_bwd;
+  }
+  const int64_t index_bytes = 4 * ((int64_t)P.fentries.size() * 4 + (int64_t)P.ftasks.size() * TASK_INTS +
+                                   (int64_t)P.stasks.size() * TASK_INTS + (int64_t)P.fdst_ptr.size() +
+                                   2 * (int64_t)P.sfwd_upos.size() + 2 * (int64_t)P.crow_upos.size() + (int64_t)P.rowidx.size() +
+                                   12 * (int64_t)P.n + 20 * (int64_t)P.stile_rec.size() * 4);
+  const int64_t v[16] = {g->nraw_used, P.dsize, P.bsize, coupling_entries, index_bytes, (int64_t)P.sfwd_upos.size(),
+                         (int64_t)P.crow_upos.size(), g->nsrc, launches_factor, launches_fwd, launches_bwd,
+                         (int64_t)g->dev.bpad, (int64_t)g->dev.nchunk, (int64_t)g->ntiles, (int64_t)P.tail_level0, 0};
+  std::memcpy(out, v, sizeof(v));
+  return 0;
+}
+
+int pp_group_perm(pp_handle h, int group, int32_t* perm) {
+  Group* g = get_group(h, group);
+  if (!g) return fail(h, 3, "pp_group_perm: bad group");
+  std::memcpy(perm, g->plan.perm.data(), sizeof(int) * g->plan.n);
+  return 0;
+}
+
+int pp_set_diagonal_classes(pp_handle h, int group, const int8_t* cls) {
+  Group* g = get_group(h, group);
+  if (!g || !h->symbolic_done) return fail(h, 3, "pp_set_diagonal_classes: bad group or symbolic phase not finished");
+  PP_HIP(hipSetDevice(h->device));
+  std::vector<int> rows, kinds;
+  for (int i = 0; i < g->plan.n; ++i) {
+    if (cls[i] == 0) continue;
+    if (cls[i] != 1 && cls[i] != 2) return fail(h, 3, "pp_set_diagonal_classes: classes are 0, 1 (Hessian) or 2 (constraint)");
+    const int ce = g->diag_can[(size_t)i];
+    if (ce < 0)
+      return fail(h, 3, "pp_set_diagonal_classes: row " + std::to_string(i) +
+                            " has a class but no diagonal entry in the planned pattern");
+    // the shift goes to the first raw duplicate of the canonical diagonal entry
+    const int raw = g->can_idx[(size_t)g->can_ptr[(size_t)ce]];
+    rows.push_back(-1 - raw);
+    kinds.push_back((int)cls[i]);
+  }
+  // raw index -> compact row of the transposed input (same rule as pp_end_symbolic)
+  {
+    std::vector<int> rawmap((size_t)std::max(g->nraw, 1), -1);
+    for (size_t j = 0; j < g->used_raw.size(); ++j) rawmap[(size_t)g->used_raw[j]] = (int)j;
+    for (auto& r : rows) r = rawmap[(size_t)(-1 - r)];
+  }
+  PP_HIP(hipStreamSynchronize(h->stream));      // a previous shifted factorisation may still read the old arrays
+  if (g->shift_row) { (void)hipFree(g->shift_row); g->shift_row = nullptr; }
+  if (g->shift_cls) { (void)hipFree(g->shift_cls); g->shift_cls = nullptr; }
+  g->nshift = 0;
+  rows.push_back(0); kinds.push_back(0);
+  int rc;
+  if ((rc = dev_alloc(h, (Group*)nullptr, &g->shift_row, rows.size()))) return rc;
+  if ((rc = dev_alloc(h, (Group*)nullptr, &g->shift_cls, kinds.size()))) return rc;
+  PP_HIP(hipMemcpy(g->shift_row, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice));
+  PP_HIP(hipMemcpy(g->shift_cls, kinds.data(), kinds.size() * sizeof(int), hipMemcpyHostToDevice));
+  g->nshift = (int)rows.size() - 1;
+  return 0;
+}
+
+// Host-side staging (no device work): for every block whose raw COO index arrays equal the group's reference
+// arrays, the values go to the block's row of the staging array; same_out[i] tells the caller which blocks it has to
+// canonicalise itself (quirk Q7).  Compare + copy are memory-bound, so they are spread over host threads.
+// runs (may be null = everything): triples {first entry, length, destination offset in the row} of the K data and of
+// the border data that are copied -- the entries some canonical entry reads (a KKT block handed over with both
+// triangles has whole runs of upper-triangle entries nobody reads: they are neither staged nor uploaded).
+namespace {
+struct StageArgs {
+  const int32_t* const* kr; const int32_t* const* kc; const double* const* kd; const int64_t* knnz;
+  const int32_t* const* br; const int32_t* const* bc; const double* const* bd; const int64_t* bnnz;
+  const int32_t *ref_kr, *ref_kc; int64_t ref_knnz; const int32_t *ref_br, *ref_bc; int64_t ref_bnnz;
+  int nrunsK; const int64_t* runsK; int nrunsB; const int64_t* runsB;
+  double* staging; int64_t row_stride; const int32_t* slots; uint8_t* same_out;
+};
+void stage_range(const StageArgs& a, int i0, int i1) {
+  for (int i = i0; i < i1; ++i) {
+    bool same = a.knnz[i] == a.ref_knnz && a.bnnz[i] == a.ref_bnnz;
+    const size_t kb = (size_t)a.ref_knnz * sizeof(int32_t), bb = (size_t)a.ref_bnnz * sizeof(int32_t);
+    same = same && (a.kr[i] == a.ref_kr || kb == 0 || std::memcmp(a.kr[i], a.ref_kr, kb) == 0);
+    same = same && (a.kc[i] == a.ref_kc || kb == 0 || std::memcmp(a.kc[i], a.ref_kc, kb) == 0);
+    same = same && (a.br[i] == a.ref_br || bb == 0 || std::memcmp(a.br[i], a.ref_br, bb) == 0);
+    same = same && (a.bc[i] == a.ref_bc || bb == 0 || std::memcmp(a.bc[i], a.ref_bc, bb) == 0);
+    if (same) {
+      double* row = a.staging + (size_t)a.slots[i] * (size_t)a.row_stride;
+      if (!a.runsK) {
+        if (a.ref_knnz > 0) std::memcpy(row, a.kd[i], (size_t)a.ref_knnz * sizeof(double));
+        if (a.ref_bnnz > 0) std::memcpy(row + a.ref_knnz, a.bd[i], (size_t)a.ref_bnnz * sizeof(double));
+      } else {
+        for (int r = 0; r < a.nrunsK; ++r)
+          std::memcpy(row + a.runsK[3 * r + 2], a.kd[i] + a.runsK[3 * r], (size_t)a.runsK[3 * r + 1] * sizeof(double));
+        for (int r = 0; r < a.nrunsB; ++r)
+          std::memcpy(row + a.runsB[3 * r + 2], a.bd[i] + a.runsB[3 * r], (size_t)a.runsB[3 * r + 1] * sizeof(double));
+      }
+    }
+    a.same_out[i] = same ? 1 : 0;
+  }
+}
+void stage_parallel(const StageArgs& a, int i0, int i1, int nthreads) {
+  const int n = i1 - i0;
+  const int nt = std::max(1, std::min(std::min(nthreads, 64), n));
+  if (nt == 1) { stage_range(a, i0, i1); return; }
+  std::vector<std::thread> pool;
+  pool.reserve((size_t)nt);
+  int started = 0;
+  try {                           // (no exception may cross the C ABI: what could not be started runs here)
+    for (; started < nt; ++started)
+      pool.emplace_back(stage_range, std::cref(a), i0 + (int)((int64_t)n * started / nt), i0 + (int)((int64_t)n * (started + 1) / nt));
+  } catch (...) {
+  }
+  if (started < nt) stage_range(a, i0 + (int)((int64_t)n * started / nt), i1);
+  for (auto& th : pool) th.join();
+}
+
+bool stage_args_ok(int nblocks, const StageArgs& a, int64_t need) {
+  if (nblocks < 0 || !a.same_out) return false;
+  if (nblocks > 0 && (!a.kr || !a.kc || !a.kd || !a.knnz || !a.br || !a.bc || !a.bd || !a.bnnz || !a.staging || !a.slots)) return false;
+  if ((a.nrunsK > 0 && !a.runsK) || (a.nrunsB > 0 && !a.runsB)) return false;
+  for (int r = 0; r < a.nrunsK; ++r)
+    if (a.runsK[3 * r] < 0 || a.runsK[3 * r + 1] < 0 || a.runsK[3 * r] + a.runsK[3 * r + 1] > a.ref_knnz || a.runsK[3 * r + 2] < 0 ||
+        a.runsK[3 * r + 2] + a.runsK[3 * r + 1] > a.row_stride) return false;
+  for (int r = 0; r < a.nrunsB; ++r)
+    if (a.runsB[3 * r] < 0 || a.runsB[3 * r + 1] < 0 || a.runsB[3 * r] + a.runsB[3 * r + 1] > a.ref_bnnz || a.runsB[3 * r + 2] < 0 ||
+        a.runsB[3 * r + 2] + a.runsB[3 * r + 1] > a.row_stride) return false;
+  return need <= a.row_stride;
+}
+}  // namespace
+
+int pp_stage_values(int nblocks, int nthreads, const int32_t* const* kr, const int32_t* const* kc,
+                    const double* const* kd, const int64_t* knnz, const int32_t* const* br, const int32_t* const* bc,
+                    const double* const* bd, const int64_t* bnnz, const int32_t* ref_kr, const int32_t* ref_kc,
+                    int64_t ref_knnz, const int32_t* ref_br, const int32_t* ref_bc, int64_t ref_bnnz, double* staging,
+                    int64_t row_stride, const int32_t* slots, uint8_t* same_out) {
+  const StageArgs a{kr, kc, kd, knnz, br, bc, bd, bnnz, ref_kr, ref_kc, ref_knnz, ref_br, ref_bc, ref_bnnz, 0, nullptr, 0,
+                    nullptr, staging, row_stride, slots, same_out};
+  if (!stage_args_ok(nblocks, a, ref_knnz + ref_bnnz)) return 3;
+  stage_parallel(a, 0, nblocks, nthreads);
+  return 0;
+}
+
+int pp_stage_values_runs(int nblocks, int nthreads, const int32_t* const* kr, const int32_t* const* kc,
+                         const double* const* kd, const int64_t* knnz, const int32_t* const* br, const int32_t* const* bc,
+                         const double* const* bd, const int64_t* bnnz, const int32_t* ref_kr, const int32_t* ref_kc,
+                         int64_t ref_knnz, const int32_t* ref_br, const int32_t* ref_bc, int64_t ref_bnnz, int nruns_k,
+                         const int64_t* runs_k, int nruns_b, const int64_t* runs_b, double* staging, int64_t row_stride,
+                         const int32_t* slots, uint8_t* same_out) {
+  const StageArgs a{kr, kc, kd, knnz, br, bc, bd, bnnz, ref_kr, ref_kc, ref_knnz, ref_br, ref_bc, ref_bnnz, nruns_k, runs_k,
+                    nruns_b, runs_b, staging, row_stride, slots, same_out};
+  if (!runs_k || !stage_args_ok(nblocks, a, 0)) return 3;
+  stage_parallel(a, 0, nblocks, nthreads);
+  return 0;
+}
+
+// The same with the upload overlapped: the blocks (ascending slots) are staged in slices and every finished slice of
+// rows goes to the device with an asynchronous copy while the host threads stage the next one (the staging array
+// must be pinned for the copies to be asynchronous).  The rows of blocks reported in same_out as not staged are
+// uploaded by the caller afterwards (pp_upload_values_compact on their row range).
+int pp_stage_upload_compact(pp_handle h, int group, int nblocks, int nthreads, const int32_t* const* kr,
+                            const int32_t* const* kc, const double* const* kd, const int64_t* knnz,
+                            const int32_t* const* br, const int32_t* const* bc, const double* const* bd,
+                            const int64_t* bnnz, const int32_t* ref_kr, const int32_t* ref_kc, int64_t ref_knnz,
+                            const int32_t* ref_br, const int32_t* ref_bc, int64_t ref_bnnz, int nruns_k, const int64_t* runs_k,
+                            int nruns_b, const int64_t* runs_b, double* staging, const int32_t* slots, uint8_t* same_out) {
+  Group* g = get_group(h, group);
+  if (!g || !h->symbolic_done) return fail(h, 3, "pp_stage_upload_compact: bad group or symbolic phase not finished");
+  const StageArgs a{kr, kc, kd, knnz, br, bc, bd, bnnz, ref_kr, ref_kc, ref_knnz, ref_br, ref_bc, ref_bnnz, nruns_k, runs_k,
+                    nruns_b, runs_b, staging, (int64_t)g->nraw_used, slots, same_out};
+  if (!runs_k || !stage_args_ok(nblocks, a, 0)) return fail(h, 3, "pp_stage_upload_compact: bad arguments");
+  for (int i = 0; i < nblocks; ++i)
+    if (slots[i] < 0 || slots[i] >= g->batch || (i > 0 && slots[i] <= slots[i - 1]))
+      return fail(h, 3, "pp_stage_upload_compact: slots must be ascending and inside the batch");
+  PP_HIP(hipSetDevice(h->device));
+  if (int rc = ensure_optional(h, g, OPT_RAW)) return rc;
+  g->input_mode = Group::IN_COMPACT;
+  const int slice = 128;
+  for (int i0 = 0; i0 < nblocks; i0 += slice) {
+    const int i1 = std::min(nblocks, i0 + slice);
+    stage_parallel(a, i0, i1, nthreads);
+    const size_t stride = (size_t)g->nraw_used;
+    const int r0 = slots[i0], r1 = slots[i1 - 1] + 1;
+    if (stride > 0)
+      PP_HIP(hipMemcpyAsync(g->raw_own + (size_t)r0 * stride, staging + (size_t)r0 * stride, (size_t)(r1 - r0) * stride * sizeof(double),
+                            hipMemcpyHostToDevice, h->stream));
+  }
+  return 0;
+}
+
+// dst[idx[i]][0 .. row_doubles) = src[i][0 .. row_doubles): the right-hand sides of the local blocks into their staging
+// rows, on host threads (75 MB per back-solve at the headline size)
+int pp_copy_rows(int nrows, int nthreads, const double* const* src, const int64_t* idx, double* dst, int64_t row_doubles) {
+  if (nrows < 0 || row_doubles < 0 || (nrows > 0 && (!src || !idx || !dst))) return 3;
+  auto work = [&](int i0, int i1) {
+    for (int i = i0; i < i1; ++i) std::memcpy(dst + (size_t)idx[i] * (size_t)row_doubles, src[i], (size_t)row_doubles * sizeof(double));
+  };
+  const int nt = std::max(1, std::min(std::min(nthreads, 64), nrows));
+  if (nt == 1) { work(0, nrows); return 0; }
+  std::vector<std::thread> pool;
+  pool.reserve((size_t)nt);
+  int started = 0;
+  try {
+    for (; started < nt; ++started)
+      pool.emplace_back(work, (int)((int64_t)nrows * started / nt), (int)((int64_t)nrows * (started + 1) / nt));
+  } catch (...) {
+  }
+  if (started < nt) work((int)((int64_t)nrows * started / nt), nrows);
+  for (auto& th : pool) th.join();
+  return 0;
+}
+
+// pinned host memory for staging arrays / result buffers of the host boundary (hipHostMalloc; NULL on failure)
+void* pp_host_alloc(int64_t bytes) {
+  void* p = nullptr;
+  if (bytes <= 0 || hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return p;
+}
+
+void pp_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
+int pp_set_pivot_tolerance(pp_handle h, double u_symbolic, double u_runtime) {
+  if (!h) return 3;
+  if (u_symbolic < 0.0 || u_symbolic > 0.5 || u_runtime < 0.0 || u_runtime > 0.5)
+    return fail(h, 3, "pivot tolerances must lie in [0, 0.5] (0: default / off)");
+  h->pivot_threshold = u_symbolic;
+  h->growth_bound = u_runtime > 0.0 ? 1.0 / u_runtime : 1e8;
+  h->growth_fatal = u_runtime > 0.0;
+  return 0;
+}
+
+int pp_get_growth_count(pp_handle h, int64_t* out) {
+  if (!h || !h->schur_done || !out) return fail(h, 3, "pp_get_growth_count before pp_factor_schur");
+  *out = (int64_t)h->status_host[5];     // (valid once pp_get_status has seen the mailbox of this factorisation)
+  return 0;
+}
+
+int pp_find_growth(pp_handle h, int group, int32_t* instance_out) {
+  Group* g = get_group(h, group);
+  if (!g || !instance_out || !h->numeric_done) return fail(h, 3, "pp_find_growth: bad group or no numeric factorization");
+  const GroupDev& d = g->dev;
+  *instance_out = -1;
+  PP_HIP(hipSetDevice(h->device));
+  PP_HIP(hipStreamSynchronize(h->stream));
+  std::vector<int> flags((size_t)d.bpad);
+  PP_HIP(hipMemcpy(flags.data(), d.growth + d.bpad, flags.size() * sizeof(int), hipMemcpyDeviceToHost));
+  for (int b = 0; b < d.batch; ++b)
+    if (flags[(size_t)b]) { *instance_out = b; break; }
+  return 0;
+}
+
+int pp_find_zero_pivot(pp_handle h, int group, int32_t* instance_out) {
+  Group* g = get_group(h, group);
+  if (!g || !instance_out || !h->numeric_done) return fail(h, 3, "pp_find_zero_pivot: bad group or no numeric factorization");
+  const GroupDev& d = g->dev;
+  *instance_out = -1;
+  PP_HIP(hipSetDevice(h->device));
+  PP_HIP(hipStreamSynchronize(h->stream));
+  // rare path (a factorisation that reported numerically zero pivots): the 16-bit codes come to the host as they are
+  std::vector<unsigned short> codes((size_t)g->plan.npiv * d.bpad);
+  PP_HIP(hipMemcpy(codes.data(), d.codes, codes.size() * sizeof(unsigned short), hipMemcpyDeviceToHost));
+  for (int p = 0; p < g->plan.npiv && *instance_out < 0; ++p)        // first pivot in elimination order that broke
+    for (int b = 0; b < d.batch; ++b)
+      if ((codes[(size_t)p * d.bpad + b] >> 8) & 15u) { *instance_out = b; break; }
+  return 0;
+}
+
+int pp_get_factor(pp_handle h, int group, int which, int instance, double* out, int64_t count) {
+  Group* g = get_group(h, group);
+  if (!g) return fail(h, 3, "pp_get_factor: bad group");
+  const GroupDev& d = g->dev;
+  const double* src = which == 0 ? d.U : which == 1 ? d.L : which == 2 ? d.Dinv : which == 3 ? d.rawT : nullptr;
+  if (!src) return fail(h, 3, "pp_get_factor: that array does not exist (fused sources: no transposed input)");
+  const int64_t rows = which == 2 ? g->plan.dsize : which == 3 ? g->nraw_used : g->plan.usize;
+  if (!src || instance < 0 || instance >= d.batch || count > rows) return fail(h, 3, "pp_get_factor: bad arguments");
+  PP_HIP(hipSetDevice(h->device));
+  PP_HIP(hipStreamSynchronize(h->stream));
+  PP_HIP(hipMemcpy2D(out, sizeof(double), src + instance, sizeof(double) * (size_t)d.bpad, sizeof(double), (size_t)count,
+                     hipMemcpyDeviceToHost));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,792 @@
+// Dense S (n_c x n_c, replicated on every rank): optimistic LDL^T on the fp64 matrix cores, Bunch-Kaufman fallback, coupling
+// solve (mpi_explicit_schur_complement.py:347-361, 388-391).
+#include "common.hpp"
+#include "dense_blocks.hpp"
+
+namespace {
+
+// Sfac = S + Q (Q lower triangle authoritative, dense column-major; may be null)
+__global__ __launch_bounds__(256) void k_add_q(const double* __restrict__ S, const double* __restrict__ Q,
+                                               double* __restrict__ Sfac, double* __restrict__ Sldl, int nc) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)nc * nc) return;
+  const int i = (int)(idx % nc), j = (int)(idx / nc);
+  double q = 0.0;
+  if (Q) q = (i >= j) ? Q[(size_t)i + (size_t)j * nc] : Q[(size_t)j + (size_t)i * nc];
+  const double v = S[idx] + q;
+  Sfac[idx] = v;
+  Sldl[idx] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// Optimistic dense LDL^T of S without pivoting, blocked (panel width 32), one workgroup.
+// The trailing updates run on the fp64 matrix cores (v_mfma_f64_16x16x4_f64): S is a genuine
+// dense symmetric panel.  The result is accepted only if every pivot has the same sign (S
+// definite, where the unpivoted factorisation is unconditionally stable) and no pivot is
+// numerically zero; otherwise mode[0] stays 0 and k_bk_factor (Bunch-Kaufman) takes over on the
+// untouched copy.  At the points the interior-point method accepts, S of a stochastic program
+// is positive definite (Haynsworth: every K_i carries its own negative eigenvalues).
+constexpr int LDL_NB = 32;
+constexpr int LDL_THREADS = 512;
+
+__global__ __launch_bounds__(LDL_THREADS) void k_ldl_blocked(int n, double* __restrict__ A, double* __restrict__ dvec,
+                                                             int* __restrict__ mode, int* __restrict__ info, double eps) {
+  __shared__ double Db[LDL_NB][LDL_NB + 1];
+  __shared__ double dl[LDL_NB];      // pivots of the current panel
+  __shared__ double red[LDL_THREADS / 64];
+  __shared__ int sflags[2];          // [0] bad pivot seen, [1] sign bookkeeping (bit0 pos, bit1 neg)
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nwv = LDL_THREADS / 64;
+  const size_t lda = (size_t)n;
+  // scale for the zero-pivot test: max |diagonal|
+  double loc = 0.0;
+  for (int i = tid; i < n; i += LDL_THREADS) loc = fmax(loc, fabs(A[i + i * lda]));
+  for (int off = 32; off > 0; off >>= 1) loc = fmax(loc, __shfl_xor(loc, off));
+  if (lane == 0) red[wv] = loc;
+  if (tid == 0) { sflags[0] = 0; sflags[1] = 0; }
+  __syncthreads();
+  double anorm = 0.0;
+  for (int q = 0; q < nwv; ++q) anorm = fmax(anorm, red[q]);
+  for (int j0 = 0; j0 < n; j0 += LDL_NB) {
+    const int nb = min(LDL_NB, n - j0), j1 = j0 + nb, m = n - j1;
+    // (1) diagonal block -> LDS, factored by wave 0 (lane = row; LDS ops of one wave are in order)
+    for (int idx = tid; idx < nb * nb; idx += LDL_THREADS) {
+      const int i = idx % nb, j = idx / nb;
+      Db[i][j] = (i >= j) ? A[(j0 + i) + (size_t)(j0 + j) * lda] : 0.0;
+    }
+    __syncthreads();
+    if (wv == 0) {
+      // lane = row of the 32x32 block, the row lives in registers; column k is broadcast with shuffles
+      double row[LDL_NB];
+      const int i = lane & 31;
+#pragma unroll
+      for (int j = 0; j < LDL_NB; ++j) row[j] = (i < nb && j < nb) ? Db[i][j] : ((i == j) ? 1.0 : 0.0);
+      int bad = 0, signs = 0;
+#pragma unroll
+      for (int k = 0; k < LDL_NB; ++k) {
+        const double colk = row[k];
+        double d = bcastd(colk, k);
+        if (k < nb) {
+          if (!(fabs(d) > eps * anorm)) { bad = 1; d = (anorm > 0.0 ? anorm : 1.0); }
+          signs |= (d > 0.0) ? 1 : 2;
+        }
+        const double lik = colk * fast_rcp(d);
+#pragma unroll
+        for (int j = k + 1; j < LDL_NB; ++j) {
+          const double ajk = bcastd(colk, j);
+          if (i >= j) row[j] -= lik * ajk;
+        }
+        if (i > k) row[k] = lik;
+        else if (i == k) row[k] = d;
+        __builtin_amdgcn_sched_barrier(0);   // keep the broadcasts of later columns from being hoisted (SGPR pressure)
+      }
+      if (lane < nb) {
+#pragma unroll
+        for (int j = 0; j < LDL_NB; ++j) if (j < nb) Db[lane][j] = row[j];
+      }
+      if (lane == 0) { if (bad) sflags[0] = 1; sflags[1] |= signs; }
+    }
+    __syncthreads();
+    if (tid < nb) dl[tid] = Db[tid][tid];
+    __syncthreads();
+    // write the factored diagonal block back (unit lower L11, pivots on the diagonal)
+    for (int idx = tid; idx < nb * nb; idx += LDL_THREADS) {
+      const int i = idx % nb, j = idx / nb;
+      if (i > j) A[(j0 + i) + (size_t)(j0 + j) * lda] = Db[i][j];
+      else if (i == j) { A[(j0 + i) + (size_t)(j0 + j) * lda] = dl[i]; dvec[j0 + i] = dl[i]; }
+    }
+    // (2) panel: W = A21 L11^{-T} row by row (thread = row), then L21 = W D^{-1}, stored in A
+    if (nb == LDL_NB) {
+      for (int r = tid; r < m; r += LDL_THREADS) {
+        double wrow[LDL_NB];
+#pragma unroll
+        for (int k = 0; k < LDL_NB; ++k) wrow[k] = A[(j1 + r) + (size_t)(j0 + k) * lda];   // all loads in flight at once
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < LDL_NB; ++k) {
+          double v = wrow[k];
+#pragma unroll
+          for (int j = 0; j < k; ++j) v -= wrow[j] * Db[k][j];
+          wrow[k] = v;
+          __builtin_amdgcn_sched_barrier(0);   // keep the LDS reads of later columns from being hoisted (register pressure)
+        }
+#pragma unroll
+        for (int k = 0; k < LDL_NB; ++k) A[(j1 + r) + (size_t)(j0 + k) * lda] = wrow[k] * fast_rcp(dl[k]);
+      }
+    } else {
+      for (int r = tid; r < m; r += LDL_THREADS) {   // ragged last panel: W kept in place, scaled afterwards
+        for (int k = 0; k < nb; ++k) {
+          double v = A[(j1 + r) + (size_t)(j0 + k) * lda];
+          for (int j = 0; j < k; ++j) v -= A[(j1 + r) + (size_t)(j0 + j) * lda] * Db[k][j];
+          A[(j1 + r) + (size_t)(j0 + k) * lda] = v;
+        }
+        for (int k = 0; k < nb; ++k) A[(j1 + r) + (size_t)(j0 + k) * lda] /= dl[k];
+      }
+    }
+    __syncthreads();
+    // (3) trailing update A22 -= L21 D L21^T on 16x16 tiles with fp64 MFMA (lower tiles only)
+    if (m > 0) {
+      const int nt = (m + 15) / 16;
+      const int ntiles = nt * (nt + 1) / 2;
+      const int li = lane & 15, lk = lane >> 4;
+      for (int tix = wv; tix < ntiles; tix += nwv) {
+        // tile index -> (I >= J)
+        int I = (int)((sqrt(8.0 * tix + 1.0) - 1.0) * 0.5);
+        while ((I + 1) * (I + 2) / 2 <= tix) ++I;
+        while (I * (I + 1) / 2 > tix) --I;
+        const int J = tix - I * (I + 1) / 2;
+        const int ra = j1 + 16 * I + li, rb = j1 + 16 * J + li;
+        const bool va = ra < n, vb = rb < n;
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+        double av[LDL_NB / 4], bv[LDL_NB / 4];
+#pragma unroll
+        for (int q = 0; q < LDL_NB / 4; ++q) {     // all operand loads first: independent, coalesced
+          const int k = 4 * q + lk;
+          const bool vk = k < nb;
+          av[q] = (va && vk) ? A[ra + (size_t)(j0 + k) * lda] * dl[k] : 0.0;
+          bv[q] = (vb && vk) ? A[rb + (size_t)(j0 + k) * lda] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < LDL_NB / 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
+        const int col = j1 + 16 * J + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = j1 + 16 * I + lk + 4 * r;
+          if (row < n && col < n && row >= col) A[row + (size_t)col * lda] -= acc[r];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const bool ok = (sflags[0] == 0) && (sflags[1] == 1 || sflags[1] == 2 || n == 0);
+    mode[0] = ok ? 1 : 0;
+    if (ok) { info[0] = (sflags[1] == 1) ? n : 0; info[1] = (sflags[1] == 2) ? n : 0; info[2] = 0; }
+  }
+}
+
+// Multi-workgroup variant for large n (the 1000 x 1000 S of configuration C5): the same blocked algorithm with
+// the panel and the trailing update spread over the chip, two launches per 32-column panel.
+//   k_dense_anorm   scale of the zero-pivot test (max |diagonal|), clears the acceptance flags
+//   k_dense_panel   every workgroup factors the 32 x 32 diagonal block redundantly in LDS / registers (it is
+//                   tiny) and solves 256 rows of the panel against it; workgroup 0 stores the block and the flags
+//   k_dense_update  A22 -= L21 D L21^T, one 16 x 16 tile per wave on the fp64 matrix cores
+//   k_dense_finish  acceptance rule of k_ldl_blocked -> mode / inertia counters
+constexpr int DN_THREADS = 256;
+
+__global__ __launch_bounds__(256) void k_dense_anorm(int n, const double* __restrict__ A, double* __restrict__ anorm,
+                                                     int* __restrict__ flags) {
+  __shared__ double red[4];
+  double loc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) loc = fmax(loc, fabs(A[i + (size_t)i * n]));
+  for (int off = 32; off > 0; off >>= 1) loc = fmax(loc, __shfl_xor(loc, off));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = loc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    anorm[0] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    flags[0] = 0; flags[1] = 0;
+  }
+}
+
+__global__ __launch_bounds__(DN_THREADS) void k_dense_panel(int n, double* __restrict__ A, double* __restrict__ dvec,
+                                                            const double* __restrict__ anorm_p, int* __restrict__ flags,
+                                                            double* __restrict__ stage, int j0, double eps) {
+  __shared__ double Db[LDL_NB][LDL_NB + 1];
+  __shared__ double dl[LDL_NB];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const size_t lda = (size_t)n;
+  const int nb = min(LDL_NB, n - j0), j1 = j0 + nb, m = n - j1;
+  const double anorm = anorm_p[0];
+  for (int idx = tid; idx < nb * nb; idx += DN_THREADS) {
+    const int i = idx % nb, j = idx / nb;
+    Db[i][j] = (i >= j) ? A[(j0 + i) + (size_t)(j0 + j) * lda] : 0.0;
+  }
+  // this workgroup's row of the panel: requested before the diagonal block is factored
+  const int r = (int)(blockIdx.x - 1) * DN_THREADS + tid;
+  const bool have_row = blockIdx.x > 0 && r < m && nb == LDL_NB;
+  double wrow[LDL_NB];
+#pragma unroll
+  for (int k = 0; k < LDL_NB; ++k) wrow[k] = have_row ? A[(j1 + r) + (size_t)(j0 + k) * lda] : 0.0;
+  __syncthreads();
+  if (wv == 0) {
+    double row[LDL_NB];
+    const int i = lane & 31;
+#pragma unroll
+    for (int j = 0; j < LDL_NB; ++j) row[j] = (i < nb && j < nb) ? Db[i][j] : ((i == j) ? 1.0 : 0.0);
+    int bad = 0, signs = 0;
+#pragma unroll
+    for (int k = 0; k < LDL_NB; ++k) {
+      const double colk = row[k];
+      double d = bcastd(colk, k);
+      if (k < nb) {
+        if (!(fabs(d) > eps * anorm)) { bad = 1; d = (anorm > 0.0 ? anorm : 1.0); }
+        signs |= (d > 0.0) ? 1 : 2;
+      }
+      const double lik = colk * fast_rcp(d);    // (no IEEE division sequence in the 32-step pivot chain)
+#pragma unroll
+      for (int j = k + 1; j < LDL_NB; ++j) {
+        const double ajk = bcastd(colk, j);
+        if (i >= j) row[j] -= lik * ajk;
+      }
+      if (i > k) row[k] = lik;
+      else if (i == k) row[k] = d;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (lane < nb) {
+#pragma unroll
+      for (int j = 0; j < LDL_NB; ++j) if (j < nb) Db[lane][j] = row[j];
+    }
+    if (lane == 0 && blockIdx.x == 0) {
+      if (bad) atomicOr(&flags[0], 1);
+      atomicOr(&flags[1], signs);
+    }
+  }
+  __syncthreads();
+  if (tid < nb) dl[tid] = Db[tid][tid];
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    // factored diagonal block (unit lower L11, pivots on the diagonal): the other workgroups of this launch still
+    // read the unfactored block from A, so it goes to a staging tile and k_dense_update copies it in; only the last
+    // panel (no other workgroup, no update launch) is stored directly
+    for (int idx = tid; idx < nb * nb; idx += DN_THREADS) {
+      const int i = idx % nb, j = idx / nb;
+      const double v = (i > j) ? Db[i][j] : ((i == j) ? dl[i] : 0.0);
+      if (m > 0) stage[idx] = v;
+      else if (i >= j) A[(j0 + i) + (size_t)(j0 + j) * lda] = v;
+    }
+    if (tid < nb) dvec[j0 + tid] = dl[tid];
+    return;
+  }
+  if (have_row) {          // W = A21 L11^{-T}, L21 = W D^{-1}
+#pragma unroll
+    for (int k = 0; k < LDL_NB; ++k) {
+      double v = wrow[k];
+#pragma unroll
+      for (int j = 0; j < k; ++j) v -= wrow[j] * Db[k][j];
+      wrow[k] = v;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int k = 0; k < LDL_NB; ++k) A[(j1 + r) + (size_t)(j0 + k) * lda] = wrow[k] * fast_rcp(dl[k]);
+  }
+}
+
+__global__ __launch_bounds__(DN_THREADS) void k_dense_update(int n, double* __restrict__ A, const double* __restrict__ dvec,
+                                                             const double* __restrict__ stage, int j0) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const size_t lda = (size_t)n;
+  if (blockIdx.x == 0) {   // the factored diagonal block of this panel (staged by k_dense_panel) -> A
+    for (int idx = threadIdx.x; idx < LDL_NB * LDL_NB; idx += DN_THREADS) {
+      const int i = idx % LDL_NB, j = idx / LDL_NB;
+      if (i >= j) A[(j0 + i) + (size_t)(j0 + j) * lda] = stage[idx];
+    }
+  }
+  const int j1 = j0 + LDL_NB, m = n - j1;
+  const int nt = (m + 15) / 16, ntiles = nt * (nt + 1) / 2;
+  const int tix = (int)blockIdx.x * (DN_THREADS / 64) + wv;
+  if (tix >= ntiles) return;
+  const int li = lane & 15, lk = lane >> 4;
+  int I = (int)((sqrt(8.0 * tix + 1.0) - 1.0) * 0.5);
+  while ((I + 1) * (I + 2) / 2 <= tix) ++I;
+  while (I * (I + 1) / 2 > tix) --I;
+  const int J = tix - I * (I + 1) / 2;
+  const int ra = j1 + 16 * I + li, rb = j1 + 16 * J + li;
+  const bool va = ra < n, vb = rb < n;
+  double4_t acc = {0.0, 0.0, 0.0, 0.0};
+  double av[LDL_NB / 4], bv[LDL_NB / 4];
+#pragma unroll
+  for (int q = 0; q < LDL_NB / 4; ++q) {
+    const int k = 4 * q + lk;
+    av[q] = va ? A[ra + (size_t)(j0 + k) * lda] * dvec[j0 + k] : 0.0;
+    bv[q] = vb ? A[rb + (size_t)(j0 + k) * lda] : 0.0;
+  }
+#pragma unroll
+  for (int q = 0; q < LDL_NB / 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
+  const int col = j1 + 16 * J + li;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = j1 + 16 * I + lk + 4 * r;
+    if (row < n && col < n && row >= col) A[row + (size_t)col * lda] -= acc[r];
+  }
+}
+
+__global__ void k_dense_finish(int n, const int* __restrict__ flags, int* __restrict__ mode, int* __restrict__ info) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const bool ok = (flags[0] == 0) && (flags[1] == 1 || flags[1] == 2 || n == 0);
+    mode[0] = ok ? 1 : 0;
+    if (ok) { info[0] = (flags[1] == 1) ? n : 0; info[1] = (flags[1] == 2) ? n : 0; info[2] = 0; }
+  }
+}
+
+
+// Register-resident variant for n <= 16 * LDLR_NT (= 208; the reference configurations have n_c = 200):
+// the whole lower triangle lives in the MFMA accumulators of the 8 waves (91 tiles of 16x16, <= 12 per
+// wave) for the entire factorisation, so a trailing update is LDS reads + fp64 MFMAs only -- no global
+// read-modify-write round trips inside the panel loop.  Per 16-column panel (= one tile column): its
+// tiles go to LDS, wave 0 factors the 16x16 diagonal block in registers (column broadcasts inside the rows of 16
+// lanes by DP-ALU DPP, see fmac_row_bcast), one thread per row solves the panel against it, the finished columns are streamed to global
+// memory (stores only), and every wave updates the tiles it still owns.  Same acceptance rule and
+// output format as k_ldl_blocked.
+constexpr int LDLR_NT = 13;
+constexpr int LDLR_TPW = 12;  // 8 waves * 12 >= 91 tiles
+constexpr int LDLR_NB = 16;
+constexpr int LDLR_LD = 18;   // LDS row stride in doubles: conflict-free MFMA operand reads
+
+template <bool DPP>
+__global__ __launch_bounds__(LDL_THREADS) void k_ldl_regs(int n, const double* __restrict__ S, const double* __restrict__ Q,
+                                                          double* __restrict__ A, double* __restrict__ dvec,
+                                                          int* __restrict__ mode, int* __restrict__ info, double eps) {
+  __shared__ double P[16 * LDLR_NT][LDLR_LD];
+  __shared__ double dl[LDLR_NB], rdl[LDLR_NB];
+  __shared__ double red[LDL_THREADS / 64];
+  __shared__ int sflags[2];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = LDL_THREADS / 64;
+  const int li = lane & 15, lk = lane >> 4;
+  const size_t lda = (size_t)n;
+  const int nt = (n + 15) / 16, ntt = nt * (nt + 1) / 2;
+  // the input is S + Q (Q: lower triangle authoritative, may be null), read straight from the all-reduced buffer:
+  // no separate add/copy kernel in front of the factorisation; S itself stays untouched for the pivoted fallback
+  double loc = 0.0;
+  for (int i = tid; i < n; i += LDL_THREADS) loc = fmax(loc, fabs(S[i + i * lda] + (Q ? Q[i + i * lda] : 0.0)));
+  // tiles of this wave: t = wv + 8 s  <->  (I >= J), t = I (I + 1) / 2 + J
+  double4_t acc[LDLR_TPW];
+  int tIJ[LDLR_TPW];   // wave-uniform (SGPR): I << 8 | J, or -1
+#pragma unroll
+  for (int s = 0; s < LDLR_TPW; ++s) {
+    const int t = wv + nwv * s;
+    int I = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((I + 1) * (I + 2) / 2 <= t) ++I;
+    while (I * (I + 1) / 2 > t) --I;
+    const int J = t - I * (I + 1) / 2;
+    tIJ[s] = (t < ntt) ? ((I << 8) | J) : -1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * I + lk + 4 * r, col = 16 * J + li;
+      double v = 0.0;
+      if (t < ntt && row < n && col < n) {
+        // S is symmetric in memory (both triangles are written): element (col, row) instead of (row, col) makes the 16
+        // lanes of a row of the wave read 128 contiguous bytes instead of 16 cache lines
+        v = S[col + (size_t)row * lda];
+        if (Q) v += (row >= col) ? Q[row + (size_t)col * lda] : Q[col + (size_t)row * lda];
+      }
+      acc[s][r] = v;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) loc = fmax(loc, __shfl_xor(loc, off));
+  if (lane == 0) red[wv] = loc;
+  if (tid == 0) { sflags[0] = 0; sflags[1] = 0; }
+  __syncthreads();
+  double anorm = 0.0;
+  for (int q = 0; q < nwv; ++q) anorm = fmax(anorm, red[q]);
+  for (int jt_loop = 0; jt_loop < nt; ++jt_loop) {
+    // panel index and per-lane tile coordinates behind optimisation barriers: otherwise the LDS addresses of
+    // all 12 tiles become loop-carried induction variables / hoisted invariants and pin ~100 registers
+    int jt = jt_loop, liv = li, lkv = lk;
+    asm volatile("" : "+s"(jt), "+v"(liv), "+v"(lkv));
+    const int j0 = 16 * jt;
+    const int nb = min(LDLR_NB, n - j0), j1 = j0 + nb, m = n - j1;
+    // (a) the panel's tiles (tile column jt): accumulators -> LDS (rows relative to j0)
+#pragma unroll
+    for (int s = 0; s < LDLR_TPW; ++s) {
+      if (tIJ[s] >= 0 && (tIJ[s] & 255) == jt) {
+        const int r0 = 16 * ((tIJ[s] >> 8) - jt);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) P[r0 + lkv + 4 * r][liv] = acc[s][r];
+      }
+    }
+    lds_barrier();
+    // (b) diagonal block by wave 0: lane = row (16 rows, lanes 16.. duplicate them), the row lives in
+    // registers.  Column k is broadcast with v_readlane from lane k (symmetry: see below) -- an LDS broadcast
+    // costs two ~130-cycle round trips per step.  Pivot k + 1 is final as soon as step k has updated column
+    // k + 1: its reciprocal (v_rcp_f64 + two Newton steps) is started first and overlaps the rest of the
+    // step.  Mask-free: in a ragged last panel rows/columns >= nb carry don't-care values that never reach a
+    // stored result; the unit diagonal is implicit.
+    int wv_here = wv;
+    asm volatile("" : "+s"(wv_here));   // opaque: keeps the panel loop from being unswitched on the wave id (two copies
+                                        // of the loop double the accumulator live ranges and spill them)
+    if (wv_here == 0) {
+      double row[LDLR_NB];
+      const int i = lane & 15;
+#pragma unroll
+      for (int j = 0; j < LDLR_NB; ++j) row[j] = P[i][j];
+      int bad = 0, signs = 0;
+      double d = DPP ? mov_row_bcast<0>(row[0]) : bcastd(row[0], 0);
+      if (!(fabs(d) > eps * anorm)) { bad = 1; d = (anorm > 0.0 ? anorm : 1.0); }
+      signs |= (d > 0.0) ? 1 : 2;
+      double rd = fast_rcp(d);
+      if constexpr (DPP) {
+        DiagSteps<0>::run(row, d, rd, bad, signs, nb, eps * anorm, anorm, dl, rdl, lane);
+      } else {
+#pragma unroll
+      for (int k = 0; k < LDLR_NB; ++k) {
+        // column k of the current block, element j, is A[j][k] = A[k][j]: lane k holds it as row[j] (the strict
+        // upper triangle is kept up to date by the same updates), so it reaches all lanes by v_readlane
+        const double lik = row[k] * rd;
+        double dn = 1.0, rdn = 1.0;
+        if (k + 1 < LDLR_NB) {
+          row[k + 1] -= lik * bcastd(row[k + 1], k);
+          dn = bcastd(row[k + 1], k + 1);
+          if (k + 1 < nb) {
+            if (!(fabs(dn) > eps * anorm)) { bad = 1; dn = (anorm > 0.0 ? anorm : 1.0); }
+            signs |= (dn > 0.0) ? 1 : 2;
+          } else {
+            dn = 1.0;
+          }
+          rdn = fast_rcp(dn);
+        }
+#pragma unroll
+        for (int j = k + 2; j < LDLR_NB; ++j) row[j] -= lik * bcastd(row[j], k);
+        row[k] = lik;
+        if (lane == 0) { dl[k] = d; rdl[k] = rd; }
+        d = dn; rd = rdn;
+      }
+      }
+      if (lane < nb) {
+#pragma unroll
+        for (int j = 0; j < LDLR_NB; ++j) P[lane][j] = row[j];
+      }
+      if (lane == 0) { if (bad) sflags[0] = 1; sflags[1] |= signs; }
+    }
+    lds_barrier();
+    // finished diagonal block -> global (unit lower L11, pivots on the diagonal)
+    if (tid < nb * nb) {
+      const int i = tid % nb, j = tid / nb;
+      if (i > j) A[(j0 + i) + (size_t)(j0 + j) * lda] = P[i][j];
+      else if (i == j) { A[(j0 + i) + (size_t)(j0 + j) * lda] = dl[i]; dvec[j0 + i] = dl[i]; }
+    }
+    // (c) panel: W = A21 L11^{-T} (thread = row), L21 = W D^{-1} -> LDS and global
+    if (64 * wv_here < m) {   // (whole waves: the L11 broadcasts below are wave-wide)
+      const int r = nb + min(tid, m - 1);
+      // L11 stays in registers, lane k (mod 16) holding its row k; an element reaches the row solves by v_readlane
+      // (no LDS round trip inside the dependent chain of a row solve)
+      double lrow[LDLR_NB], wrow[LDLR_NB];
+#pragma unroll
+      for (int k = 0; k < LDLR_NB; ++k) { lrow[k] = P[lane & 15][k]; wrow[k] = P[r][k]; }
+      // right-looking order: the updates of one step are independent of each other, only 16 steps are chained
+      if constexpr (DPP) {
+        PanelSolveCols<0>::run(wrow, lrow);
+      } else {
+#pragma unroll
+        for (int j = 0; j + 1 < LDLR_NB; ++j) {
+#pragma unroll
+          for (int k = j + 1; k < LDLR_NB; ++k) wrow[k] -= wrow[j] * bcastd_after(lrow[j], k, wrow[j]);
+        }
+      }
+      if (tid < m) {
+#pragma unroll
+        for (int k = 0; k < LDLR_NB; ++k) {
+          if (k < nb) {
+            const double l = wrow[k] * rdl[k];
+            P[r][k] = l;
+            A[(j0 + r) + (size_t)(j0 + k) * lda] = l;
+          }
+        }
+      }
+    }
+    lds_barrier();
+    // (d) trailing update of the tiles still owned: A22 -= (L21 D) L21^T, operands from LDS
+    if (m > 0) {
+#pragma unroll
+      for (int s = 0; s < LDLR_TPW; ++s) {
+        const int tI = tIJ[s] >> 8, tJ = tIJ[s] & 255;
+        if (tIJ[s] >= 0 && tJ > jt) {
+          const int ra = 16 * (tI - jt) + liv, rb = 16 * (tJ - jt) + liv;
+          double av[LDLR_NB / 4], bv[LDLR_NB / 4];
+#pragma unroll
+          for (int q = 0; q < LDLR_NB / 4; ++q) {
+            const int k = 4 * q + lkv;
+            av[q] = -P[ra][k] * dl[k];
+            bv[q] = P[rb][k];
+          }
+#pragma unroll
+          for (int q = 0; q < LDLR_NB / 4; ++q) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc[s], 0, 0, 0);
+        }
+      }
+    }
+    lds_barrier();
+  }
+  if (tid == 0) {
+    const bool ok = (sflags[0] == 0) && (sflags[1] == 1 || sflags[1] == 2 || n == 0);
+    mode[0] = ok ? 1 : 0;
+    if (ok) { info[0] = (sflags[1] == 1) ? n : 0; info[1] = (sflags[1] == 2) ? n : 0; info[2] = 0; }
+  }
+}
+
+// x = S^-1 b with the blocked factor (unit lower L in A, pivots in dvec); b is in LDS vector x
+__device__ void ldl_blocked_solve(int n, const double* __restrict__ A, const double* __restrict__ dvec, double* x) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nwv = blockDim.x >> 6;
+  const size_t lda = (size_t)n;
+  for (int j0 = 0; j0 < n; j0 += LDL_NB) {
+    const int nb = min(LDL_NB, n - j0), j1 = j0 + nb;
+    if (wv == 0) {  // unit-lower triangular solve inside the block: lane = row, shuffle broadcast
+      double lrow[LDL_NB];
+#pragma unroll
+      for (int k = 0; k < LDL_NB; ++k)
+        lrow[k] = (lane > k && lane < nb) ? A[(j0 + lane) + (size_t)(j0 + k) * lda] : 0.0;
+      double xi = (lane < nb) ? x[j0 + lane] : 0.0;
+#pragma unroll
+      for (int k = 0; k < LDL_NB; ++k) xi -= lrow[k] * bcastd(xi, k);
+      if (lane < nb) x[j0 + lane] = xi;
+    }
+    __syncthreads();
+    for (int r = j1 + tid; r < n; r += blockDim.x) {
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+      for (int k = 0; k < LDL_NB; k += 2) {
+        if (k < nb) s0 += A[r + (size_t)(j0 + k) * lda] * x[j0 + k];
+        if (k + 1 < nb) s1 += A[r + (size_t)(j0 + k + 1) * lda] * x[j0 + k + 1];
+      }
+      x[r] -= s0 + s1;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < n; i += blockDim.x) x[i] /= dvec[i];
+  __syncthreads();
+  for (int j0 = ((n - 1) / LDL_NB) * LDL_NB; j0 >= 0; j0 -= LDL_NB) {
+    const int nb = min(LDL_NB, n - j0), j1 = j0 + nb;
+    for (int k = wv; k < nb; k += nwv) {  // x[j0+k] -= L[j1:, j0+k]^T x[j1:]
+      double s = 0.0;
+      for (int r = j1 + lane; r < n; r += 64) s += A[r + (size_t)(j0 + k) * lda] * x[r];
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+      if (lane == 0) x[j0 + k] -= s;
+    }
+    __syncthreads();
+    if (wv == 0) {
+      double lcol[LDL_NB];
+#pragma unroll
+      for (int k = 0; k < LDL_NB; ++k)
+        lcol[k] = (lane < k && k < nb) ? A[(j0 + k) + (size_t)(j0 + lane) * lda] : 0.0;
+      double xi = (lane < nb) ? x[j0 + lane] : 0.0;
+#pragma unroll
+      for (int k = LDL_NB - 1; k > 0; --k) xi -= lcol[k] * bcastd(xi, k);
+      if (lane < nb) x[j0 + lane] = xi;
+    }
+    __syncthreads();
+  }
+}
+
+// Same solve for n <= blockDim.x with one thread per unknown and ONE barrier per NBS-column block: thread r
+// keeps its right-hand-side entry in a register and its NBS-entry segment of the current block of L
+// (prefetched one block ahead, so no global-memory round trip sits between the dependent blocks).  The
+// wave that owns the block's rows solves it with v_readlane broadcasts, which at the same time applies the
+// block to the other rows of that wave; the remaining waves apply it from LDS after the barrier.
+template <int NBS>
+__device__ void ldl_rows_solve(int n, const double* __restrict__ A, const double* __restrict__ dvec, double* xs) {
+  const int r = threadIdx.x, lane = r & 63, wv = __builtin_amdgcn_readfirstlane(r >> 6);
+  const size_t lda = (size_t)n;
+  const bool act = r < n;
+  double acc = act ? xs[r] : 0.0;
+  const double rd = act ? 1.0 / dvec[r] : 0.0;
+  // three segment buffers, rotated by unrolling the block loop three times: the segment of block j + 2 is requested
+  // before block j is solved, so a load has two block steps (not the rest of one) to arrive
+  double c0[NBS], c1[NBS], c2[NBS];
+  (void)lane;
+  // ---- forward: L y = b, blocks ascending; segment = L[r][j0 .. j0+NBS) below the diagonal
+  // A wave whose 64 rows all lie below the block needs no per-element predicate (and one whose rows all lie above it
+  // loads nothing): the predicated form costs ~12 instructions per element, which for 8 waves x 32 elements was most
+  // of a block step.  Only the wave that holds the block's own rows takes the predicated path.
+  const int row_lo = 64 * wv, row_hi = 64 * wv + 63;
+#define PP_LOAD_FWD(dst, j0_)                                                              \
+  {                                                                                        \
+    const int jl = (j0_);                                                                  \
+    if (row_lo >= jl + NBS && row_hi < n && jl + NBS <= n) {                               \
+      const double* src = A + r + (size_t)jl * lda;                                        \
+      _Pragma("unroll") for (int k = 0; k < NBS; ++k) dst[k] = src[(size_t)k * lda];       \
+    } else if (row_hi < jl || jl >= n) {                                                   \
+      _Pragma("unroll") for (int k = 0; k < NBS; ++k) dst[k] = 0.0;                        \
+    } else {                                                                               \
+      _Pragma("unroll") for (int k = 0; k < NBS; ++k) {                                    \
+        const int c = jl + k;                                                              \
+        dst[k] = (act && c < n && c < r) ? A[r + (size_t)c * lda] : 0.0;                   \
+      }                                                                                    \
+    }                                                                                      \
+  }
+#define PP_STEP_FWD(cur, j0_)                                                              \
+  {                                                                                        \
+    const int jj = (j0_), bw = jj >> 6, base = jj & 63;                                    \
+    if (wv == bw) {                                                                        \
+      _Pragma("unroll") for (int k = 0; k < NBS; ++k) acc -= cur[k] * bcastd(acc, base + k); \
+      if (r >= jj && r < jj + NBS && act) xs[r] = acc;                                     \
+    }                                                                                      \
+    lds_barrier();   /* not __syncthreads(): that would also drain the prefetched global loads */ \
+    if (wv != bw && r >= jj + NBS) {                                                       \
+      _Pragma("unroll") for (int k = 0; k < NBS; ++k) acc -= cur[k] * xs[min(jj + k, n - 1)]; \
+    }                                                                                      \
+  }
+  PP_LOAD_FWD(c0, 0)
+  PP_LOAD_FWD(c1, NBS)
+  for (int j0 = 0; j0 < n; j0 += 3 * NBS) {
+    PP_LOAD_FWD(c2, j0 + 2 * NBS)
+    PP_STEP_FWD(c0, j0)
+    if (j0 + NBS >= n) break;
+    PP_LOAD_FWD(c0, j0 + 3 * NBS)
+    PP_STEP_FWD(c1, j0 + NBS)
+    if (j0 + 2 * NBS >= n) break;
+    PP_LOAD_FWD(c1, j0 + 4 * NBS)
+    PP_STEP_FWD(c2, j0 + 2 * NBS)
+  }
+#undef PP_LOAD_FWD
+#undef PP_STEP_FWD
+  acc *= rd;
+  // ---- backward: L^T x = y, blocks descending; segment = L[j0 .. j0+NBS)[r] below the diagonal
+#define PP_LOAD_BWD(dst, j0_)                                                              \
+  {                                                                                        \
+    const int jl = (j0_);                                                                  \
+    if (jl >= 0 && row_hi < jl && jl + NBS <= n) {                                         \
+      const double* src = A + jl + (size_t)r * lda;                                        \
+      _Pragma("unroll") for (int k = 0; k < NBS; ++k) dst[k] = src[k];                     \
+    } else if (jl < 0 || row_lo >= jl + NBS) {                                             \
+      _Pragma("unroll") for (int k = 0; k < NBS; ++k) dst[k] = 0.0;                        \
+    } else {                                                                               \
+      _Pragma("unroll") for (int k = 0; k < NBS; ++k) {                                    \
+        const int c = jl + k;                                                              \
+        dst[k] = (act && c >= 0 && c < n && c > r) ? A[c + (size_t)r * lda] : 0.0;         \
+      }                                                                                    \
+    }                                                                                      \
+  }
+#define PP_STEP_BWD(cur, j0_)                                                              \
+  {                                                                                        \
+    const int jj = (j0_), bw = jj >> 6, base = jj & 63;                                    \
+    if (wv == bw) {                                                                        \
+      _Pragma("unroll") for (int k = NBS - 1; k >= 0; --k) acc -= cur[k] * bcastd(acc, base + k); \
+      if (r >= jj && r < jj + NBS && act) xs[r] = acc;                                     \
+    }                                                                                      \
+    lds_barrier();   /* not __syncthreads(): that would also drain the prefetched global loads */ \
+    if (wv != bw && r < jj) {                                                              \
+      _Pragma("unroll") for (int k = 0; k < NBS; ++k) acc -= cur[k] * xs[min(jj + k, n - 1)]; \
+    }                                                                                      \
+  }
+  const int jlast = ((n - 1) / NBS) * NBS;
+  __syncthreads();
+  PP_LOAD_BWD(c0, jlast)
+  PP_LOAD_BWD(c1, jlast - NBS)
+  for (int j0 = jlast; j0 >= 0; j0 -= 3 * NBS) {
+    PP_LOAD_BWD(c2, j0 - 2 * NBS)
+    PP_STEP_BWD(c0, j0)
+    if (j0 - NBS < 0) break;
+    PP_LOAD_BWD(c0, j0 - 3 * NBS)
+    PP_STEP_BWD(c1, j0 - NBS)
+    if (j0 - 2 * NBS < 0) break;
+    PP_LOAD_BWD(c1, j0 - 4 * NBS)
+    PP_STEP_BWD(c2, j0 - 2 * NBS)
+  }
+#undef PP_LOAD_BWD
+#undef PP_STEP_BWD
+  __syncthreads();
+}
+
+// Last kernel of the dense phase.  If the unpivoted factorisation was accepted (mode[0] == 1) it only publishes the
+// status; otherwise it builds S + Q in A (Q lower triangle authoritative, may be null) and runs Bunch-Kaufman.
+__global__ __launch_bounds__(BK_THREADS) void k_bk_factor(int n, const double* __restrict__ S, const double* __restrict__ Q,
+                                                          double* A, int* ipiv, double* work, int* info, const int* mode,
+                                                          long long* status_out, long long seq) {
+  __shared__ double sv[16];
+  __shared__ int si[16];
+  if (mode[0] != 1) {
+    for (size_t idx = threadIdx.x; idx < (size_t)n * n; idx += BK_THREADS) {
+      const int i = (int)(idx % n), j = (int)(idx / n);
+      double q = 0.0;
+      if (Q) q = (i >= j) ? Q[(size_t)i + (size_t)j * n] : Q[(size_t)j + (size_t)i * n];
+      A[idx] = S[idx] + q;
+    }
+    __syncthreads();
+    TeamCtx ctx{sv, si};
+    __shared__ pp::BkInfo sbi;
+    pp::bk_factor(ctx, n, A, n, ipiv, work, &sbi, BK_EPS);
+    if (threadIdx.x == 0) { info[0] = sbi.npos; info[1] = sbi.nneg; info[2] = sbi.nzero; }
+  }
+  if (threadIdx.x == 0) publish_status(S + (size_t)n * n, info, status_out, seq);
+}
+
+// xc = S^-1 (rc + rs): blocked LDL^T factor if it was accepted, else the Bunch-Kaufman factor
+// THREADS x NBS: 512 threads with 32-column segments (n_c <= 512), or 1024 threads with 16-column segments
+// (512 < n_c <= 1024: two 16-entry segments are what 128 VGPRs per thread leave room for; the global-memory
+// fallback ldl_blocked_solve puts three dependent load round trips into each of its 2 n_c / 32 block steps:
+// 0.89 ms at n_c = 1000)
+template <int THREADS, int NBS>
+__global__ __launch_bounds__(THREADS) void k_coupling_solve(int n, const double* Abk, const int* ipiv,
+                                                            const double* Aldl, const double* dvec, const int* mode,
+                                                            const double* rc, const double* rs, double* xc) {
+  extern __shared__ __attribute__((aligned(16))) double xs[];
+  __shared__ double sv[16];
+  __shared__ int si[16];
+  if (mode[0] == 1) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) xs[i] = (rc ? rc[i] : 0.0) + rs[i];
+    __syncthreads();
+    if (n <= THREADS) ldl_rows_solve<NBS>(n, Aldl, dvec, xs);
+    else ldl_blocked_solve(n, Aldl, dvec, xs);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) xc[i] = xs[i];
+    return;
+  }
+  TeamCtx ctx{sv, si};
+  for (int i = threadIdx.x; i < n; i += blockDim.x) xc[i] = (rc ? rc[i] : 0.0) + rs[i];
+  __syncthreads();
+  pp::bk_solve(ctx, n, Abk, n, ipiv, xc);
+}
+
+
+}  // namespace
+
+int ppi_dense_factor_schur(pp_handle h, const double* Q_host) {
+  hipStream_t st = h->stream;
+  const int nc = h->nc;
+  const size_t nn = schur_doubles(h);
+  {
+    if (Q_host) PP_HIP(hipMemcpyAsync(h->Qd, Q_host, nn * sizeof(double), hipMemcpyHostToDevice, st));
+    const double* Qd = Q_host ? h->Qd : nullptr;
+    const bool regs = h->dense_policy == 0 && nc <= 16 * LDLR_NT;
+    PhaseScope ps(h, 3, regs ? 2 : 3);
+    // (the register-resident kernel reads S + Q itself; the global-memory variants work in place on a copy)
+    if (h->dense_policy == 0 && !regs)
+      hipLaunchKernelGGL(k_add_q, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, h->S, Qd, h->Sfac, h->Sldl, nc);
+    if (h->dense_policy == 0)
+      // (a left-looking variant with the panel resident in LDS was measured no faster: 0.344 vs 0.315 ms at
+      // n_c = 200 -- the serial diagonal-block factor dominates both)
+      if (nc <= 16 * LDLR_NT) {
+        if (h->dense_dpp) hipLaunchKernelGGL(k_ldl_regs<true>, dim3(1), dim3(LDL_THREADS), 0, st, nc, h->S, Qd, h->Sldl, h->dvec, h->dense_mode, h->bkinfo,
+                           BK_EPS);
+        else hipLaunchKernelGGL(k_ldl_regs<false>, dim3(1), dim3(LDL_THREADS), 0, st, nc, h->S, Qd, h->Sldl, h->dvec, h->dense_mode, h->bkinfo,
+                           BK_EPS);
+      } else if (nc <= 512) {
+        hipLaunchKernelGGL(k_ldl_blocked, dim3(1), dim3(LDL_THREADS), 0, st, nc, h->Sldl, h->dvec, h->dense_mode, h->bkinfo,
+                           BK_EPS);
+      } else {
+        // large S: panel + trailing update spread over the chip, two launches per 32 columns
+        double* anorm = h->work;                    // (scratch of the Bunch-Kaufman fallback, free until then:
+        double* stage = h->work + 8;                //  2 n_c doubles >= 8 + 32 * 32 for n_c > 512)
+        int* flags = h->dense_mode + 2;
+        hipLaunchKernelGGL(k_dense_anorm, dim3(1), dim3(256), 0, st, nc, h->Sldl, anorm, flags);
+        for (int j0 = 0; j0 < nc; j0 += LDL_NB) {
+          const int m = nc - std::min(nc, j0 + LDL_NB);
+          hipLaunchKernelGGL(k_dense_panel, dim3(1 + (m + DN_THREADS - 1) / DN_THREADS), dim3(DN_THREADS), 0, st, nc,
+                             h->Sldl, h->dvec, anorm, flags, stage, j0, BK_EPS);
+          if (m > 0) {
+            const int nt = (m + 15) / 16, ntiles = nt * (nt + 1) / 2, per = DN_THREADS / 64;
+            hipLaunchKernelGGL(k_dense_update, dim3((ntiles + per - 1) / per), dim3(DN_THREADS), 0, st, nc, h->Sldl,
+                               h->dvec, stage, j0);
+          }
+        }
+        hipLaunchKernelGGL(k_dense_finish, dim3(1), dim3(64), 0, st, nc, flags, h->dense_mode, h->bkinfo);
+      }
+    else
+      PP_HIP(hipMemsetAsync(h->dense_mode, 0, sizeof(int), st));
+    // Bunch-Kaufman on S + Q if the unpivoted factorisation was not accepted; publishes the status either way
+    hipLaunchKernelGGL(k_bk_factor, dim3(1), dim3(BK_THREADS), 0, st, nc, h->S, Qd, h->Sfac, h->ipiv, h->work, h->bkinfo,
+                       h->dense_mode, h->status_dev, ++h->status_seq);
+  }
+  return 0;
+}
+
+int ppi_dense_coupling_solve(pp_handle h, const double* rc_dev) {
+  hipStream_t st = h->stream;
+  const int nc = h->nc;
+  PhaseScope ps(h, 6, 1);
+  if (nc > BK_THREADS && nc <= 1024)
+    hipLaunchKernelGGL((k_coupling_solve<1024, 16>), dim3(1), dim3(1024), (size_t)nc * sizeof(double), st, nc, h->Sfac,
+                       h->ipiv, h->Sldl, h->dvec, h->dense_mode, rc_dev, h->rs, h->xc);
+  else
+    hipLaunchKernelGGL((k_coupling_solve<BK_THREADS, 32>), dim3(1), dim3(BK_THREADS), (size_t)nc * sizeof(double), st, nc,
+                       h->Sfac, h->ipiv, h->Sldl, h->dvec, h->dense_mode, rc_dev, h->rs, h->xc);
+  PP_HIP(hipGetLastError());
+  return 0;
+}
+

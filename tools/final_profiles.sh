@@ -11,13 +11,13 @@ mkdir -p $out/pmc
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python3 bench.py --steps 40 > $out/bench_default.json 2> $out/bench_default.err || { tail -3 $out/bench_default.err; exit 1; }
 echo "default done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-boundary > $out/bench_under_rocprof.json 2> $out/stats.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-boundary --no-ip-loop > $out/bench_under_rocprof.json 2> $out/stats.err || exit 1
 cp $(find $out/stats -name '*kernel_stats.csv' | head -1) $out/kernel_stats.csv
 echo "kernel stats done"
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $out/pmc_mfma -- python3 bench.py --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-boundary > $out/bench_mfma.json 2> $out/mfma.err \
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $out/pmc_mfma -- python3 bench.py --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-boundary --no-ip-loop > $out/bench_mfma.json 2> $out/mfma.err \
   && python3 tools/mfma_util.py $out/pmc_mfma $(find $out/stats -name '*kernel_trace.csv' | head -1) $out/mfma_util.json "bench.py (C3)"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-boundary > $out/bench_fetch.json 2> $out/fetch.err || exit 1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python3 bench.py --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-boundary > $out/bench_write.json 2> $out/write.err || exit 1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-boundary --no-ip-loop > $out/bench_fetch.json 2> $out/fetch.err || exit 1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python3 bench.py --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-boundary --no-ip-loop > $out/bench_write.json 2> $out/write.err || exit 1
 python3 - $out <<'PY'
 import csv, glob, json, os, sys
 sys.path.insert(0, 'tools')
@@ -38,16 +38,16 @@ read raw n batch < $out/plan_args.txt
 python3 tools/pmc_traffic.py $out/pmc_fetch $out/pmc_write $raw $n $batch $out/pmc_traffic.json "bench.py --steps 3 --profile-steps 1 under rocprofv3 --pmc (one pass per counter)" || exit 1
 echo "pmc done"
 python3 bench.py --workload C2 --no-cpu-baseline > $out/bench_C2.json 2> $out/c2.err
-python3 bench.py --blocks 128 --no-cpu-baseline --no-boundary > $out/bench_128_blocks.json 2> $out/b128.err
+python3 bench.py --blocks 128 --no-cpu-baseline --no-boundary --no-ip-loop > $out/bench_128_blocks.json 2> $out/b128.err
 python3 bench.py --workload C4 --no-cpu-baseline --steps 10 --warmup 2 > $out/bench_C4.json 2> $out/c4.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_C4 -- python3 bench.py --workload C4 --steps 5 --warmup 2 --no-cpu-baseline --no-boundary > $out/bench_C4_under_rocprof.json 2> $out/stats_C4.err && cp $(find $out/stats_C4 -name '*kernel_stats.csv' | head -1) $out/kernel_stats_C4.csv
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $out/pmc_mfma_C4 -- python3 bench.py --workload C4 --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-boundary > $out/bench_mfma_C4.json 2> $out/mfma_C4.err \
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_C4 -- python3 bench.py --workload C4 --steps 5 --warmup 2 --no-cpu-baseline --no-boundary --no-ip-loop > $out/bench_C4_under_rocprof.json 2> $out/stats_C4.err && cp $(find $out/stats_C4 -name '*kernel_stats.csv' | head -1) $out/kernel_stats_C4.csv
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $out/pmc_mfma_C4 -- python3 bench.py --workload C4 --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-boundary --no-ip-loop > $out/bench_mfma_C4.json 2> $out/mfma_C4.err \
   && python3 tools/mfma_util.py $out/pmc_mfma_C4 $(find $out/stats_C4 -name '*kernel_trace.csv' | head -1) $out/mfma_util_C4.json "bench.py --workload C4"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_C5 -- python3 bench.py --workload C5 --blocks 512 --steps 5 --warmup 2 --value-sets 2 --no-cpu-baseline --no-boundary > $out/bench_C5_under_rocprof.json 2> $out/stats_C5.err && cp $(find $out/stats_C5 -name '*kernel_stats.csv' | head -1) $out/kernel_stats_C5_512_blocks.csv
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $out/pmc_mfma_C5 -- python3 bench.py --workload C5 --blocks 512 --steps 3 --warmup 1 --value-sets 2 --profile-steps 1 --no-cpu-baseline --no-boundary > $out/bench_mfma_C5.json 2> $out/mfma_C5.err \
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_C5 -- python3 bench.py --workload C5 --blocks 512 --steps 5 --warmup 2 --value-sets 2 --no-cpu-baseline --no-boundary --no-ip-loop > $out/bench_C5_under_rocprof.json 2> $out/stats_C5.err && cp $(find $out/stats_C5 -name '*kernel_stats.csv' | head -1) $out/kernel_stats_C5_512_blocks.csv
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $out/pmc_mfma_C5 -- python3 bench.py --workload C5 --blocks 512 --steps 3 --warmup 1 --value-sets 2 --profile-steps 1 --no-cpu-baseline --no-boundary --no-ip-loop > $out/bench_mfma_C5.json 2> $out/mfma_C5.err \
   && python3 tools/mfma_util.py $out/pmc_mfma_C5 $(find $out/stats_C5 -name '*kernel_trace.csv' | head -1) $out/mfma_util_C5.json "bench.py --workload C5 --blocks 512"
-python3 bench.py --workload C5 --no-cpu-baseline --no-boundary --steps 5 --warmup 2 --value-sets 2 --profile-steps 2 > $out/bench_C5.json 2> $out/c5.err
-python3 bench.py --workload C5 --blocks 512 --no-cpu-baseline --no-boundary --steps 10 --warmup 2 --value-sets 2 --profile-steps 2 > $out/bench_C5_512_blocks.json 2> $out/c5b.err
+python3 bench.py --workload C5 --no-cpu-baseline --no-boundary --no-ip-loop --steps 5 --warmup 2 --value-sets 2 --profile-steps 2 > $out/bench_C5.json 2> $out/c5.err
+python3 bench.py --workload C5 --blocks 512 --no-cpu-baseline --no-boundary --no-ip-loop --steps 10 --warmup 2 --value-sets 2 --profile-steps 2 > $out/bench_C5_512_blocks.json 2> $out/c5b.err
 find $out -name '*kernel_trace.csv' -delete
 find $out -name '*counter_collection.csv' -delete
 rm -rf $out/stats $out/stats_C4 $out/stats_C5 $out/pmc_fetch $out/pmc_write $out/pmc_mfma $out/pmc_mfma_C4 $out/pmc_mfma_C5

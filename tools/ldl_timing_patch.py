@@ -1,6 +1,6 @@
-"""Diagnostic: write a copy of solver.hip whose k_ldl_regs prints the wall-clock ticks (100 MHz) it spends in its
+"""Diagnostic: write a copy of dense.hip (round 3: the dense kernels' translation unit) whose k_ldl_regs prints the wall-clock ticks (100 MHz) it spends in its
 four per-panel phases (a: tiles -> LDS, b: diagonal block, c: panel solve, d: trailing update).
-usage: python tools/ldl_timing_patch.py <in solver.hip> <out solver.hip>   (build the copy in place of the original,
+usage: python tools/ldl_timing_patch.py <in dense.hip> <out dense.hip>   (build the copy in place of the original,
 run a short bench, restore)"""
 import sys
 s = open(sys.argv[1]).read()
