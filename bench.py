@@ -453,6 +453,7 @@ def main():
                        'parallelism': 'blocks round-robin over %d rank(s); all-reduce of [S | status | inertia] and '
                                       'of r_s' % world},
             'median_ms_per_step': median_ms,
+            'rccl_ranks': int(lib.pp_comm_size(h)),      # > 0: the all-reduces were enqueued by the library (PP_DIRECT_RCCL=1)
             # SURVEY 8(d) to the letter: the same step through HOST containers (SciPy COO blocks in, host vectors out;
             # staging, H2D and D2H inside) -- the rate a caller with the reference's unchanged interfaces sees
             'value_boundary': (boundary or {}).get('it_per_s'),

@@ -346,6 +346,22 @@ int pp_set_pivot_tolerance(pp_handle h, double u_symbolic, double u_runtime);
 int pp_get_growth_count(pp_handle h, int64_t* out);
 int pp_find_growth(pp_handle h, int group, int32_t* instance_out);
 
+/* ---- collectives without a host hop ------------------------------------------------------
+ * The two data-sized exchanges of the path -- the sum all-reduce of [S | status tail] once per numeric factorisation
+ * (mpi_explicit_schur_complement.py:343, with :21 and :427-429 folded into the tail) and of r_s once per back-solve (:387)
+ * -- enqueued by the library itself as RCCL calls on the handle's stream, between its own kernels.  librccl is opened at
+ * run time (the library has no link-time dependency on it).
+ *   pp_comm_unique_id   rank 0: 128 bytes for ncclCommInitRank; the caller broadcasts them (any side channel)
+ *   pp_comm_init        collective over the nranks processes (one per GPU); replaces an earlier communicator
+ *   pp_comm_size        ranks of the handle's communicator, 0 if none
+ *   pp_allreduce_schur  after pp_numeric_local, before pp_factor_schur;  pp_allreduce_rs  after pp_solve_forward
+ * Without a communicator the two calls return 3. */
+int pp_comm_unique_id(uint8_t id_out[128]);
+int pp_comm_init(pp_handle h, int nranks, int rank, const uint8_t id[128]);
+int pp_comm_size(pp_handle h);
+int pp_allreduce_schur(pp_handle h);
+int pp_allreduce_rs(pp_handle h);
+
 /* Diagnostic: the factor of one instance (block) of a group after pp_numeric_local, in the plan's
  * panel storage: which = 0 unscaled panels U, 1 scaled rows L (the MA27 factor entries,
  * ma27_interface.py:124), 2 packed inverses of the block pivots.  count doubles are copied. */

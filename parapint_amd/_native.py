@@ -103,6 +103,11 @@ SIGNATURES = {
                           [ctypes.c_double, ctypes.c_double, _f64p]),
     'pp_vec_max_abs': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, _f64p]),
     'pp_vec_axpy': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
+    'pp_comm_unique_id': (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint8)]),
+    'pp_comm_init': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint8)]),
+    'pp_comm_size': (ctypes.c_int, [ctypes.c_void_p]),
+    'pp_allreduce_schur': (ctypes.c_int, [ctypes.c_void_p]),
+    'pp_allreduce_rs': (ctypes.c_int, [ctypes.c_void_p]),
     'pp_set_pivot_tolerance': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_double]),
     'pp_get_growth_count': (ctypes.c_int, [ctypes.c_void_p, _i64p]),
     'pp_find_growth': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _i32p]),

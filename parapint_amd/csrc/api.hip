@@ -1,11 +1,17 @@
 // Handle life cycle, symbolic phase (plan -> device images), value / vector uploads and bindings, statistics, host staging.
 #include "common.hpp"
+#include <dlfcn.h>
+
+// ncclUniqueId by value (rccl.h: struct { char internal[128]; })
+struct ppd_nccl_id { char internal[128]; };
 #include "kernels_transpose.hpp"
 
 namespace {
 
 
 }  // namespace
+
+namespace { void rccl_release(pp_handle h); }
 
 extern "C" {
 
@@ -47,6 +53,7 @@ void pp_destroy(pp_handle h) {
     for (int i = 0; i < PP_MAX_SPLIT; ++i) { (void)hipStreamDestroy(h->aux[i]); (void)hipEventDestroy(h->ev_join[i]); }
     (void)hipEventDestroy(h->ev_fork);
   }
+  rccl_release(h);
   delete h;
 }
 
@@ -1103,6 +1110,92 @@ int pp_get_factor(pp_handle h, int group, int which, int instance, double* out, 
   PP_HIP(hipStreamSynchronize(h->stream));
   PP_HIP(hipMemcpy2D(out, sizeof(double), src + instance, sizeof(double) * (size_t)d.bpad, sizeof(double), (size_t)count,
                      hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// ---- RCCL, opened at run time (no link-time dependency): the two data-path all-reduces on the handle's stream
+namespace {
+typedef int (*fn_get_id)(void*);
+typedef int (*fn_init_rank)(void**, int, ppd_nccl_id, int);
+typedef int (*fn_destroy)(void*);
+typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef const char* (*fn_errstr)(int);
+struct Rccl {
+  void* lib = nullptr;
+  fn_get_id get_id = nullptr; fn_init_rank init_rank = nullptr; fn_destroy destroy = nullptr;
+  fn_allreduce allreduce = nullptr; fn_errstr errstr = nullptr;
+  bool tried = false;
+};
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+bool rccl_load() {
+  std::lock_guard<std::mutex> lk(g_rccl_mu);
+  if (g_rccl.tried) return g_rccl.allreduce != nullptr;
+  g_rccl.tried = true;
+  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    g_rccl.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (g_rccl.lib) break;
+  }
+  if (!g_rccl.lib) return false;
+  g_rccl.get_id = (fn_get_id)dlsym(g_rccl.lib, "ncclGetUniqueId");
+  g_rccl.init_rank = (fn_init_rank)dlsym(g_rccl.lib, "ncclCommInitRank");
+  g_rccl.destroy = (fn_destroy)dlsym(g_rccl.lib, "ncclCommDestroy");
+  g_rccl.allreduce = (fn_allreduce)dlsym(g_rccl.lib, "ncclAllReduce");
+  g_rccl.errstr = (fn_errstr)dlsym(g_rccl.lib, "ncclGetErrorString");
+  if (!g_rccl.get_id || !g_rccl.init_rank || !g_rccl.destroy || !g_rccl.allreduce) { g_rccl.allreduce = nullptr; return false; }
+  return true;
+}
+void rccl_release(pp_handle h) {
+  if (h->rccl_comm && g_rccl.destroy) (void)g_rccl.destroy(h->rccl_comm);
+  h->rccl_comm = nullptr;
+  h->rccl_ranks = 0;
+}
+std::string rccl_msg(const char* what, int rc) {
+  return std::string(what) + ": " + (g_rccl.errstr ? g_rccl.errstr(rc) : "RCCL error") + " (" + std::to_string(rc) + ")";
+}
+}  // namespace
+
+int pp_comm_unique_id(uint8_t id_out[128]) {
+  if (!id_out || !rccl_load()) return 3;
+  ppd_nccl_id id;
+  if (g_rccl.get_id(&id) != 0) return 3;
+  std::memcpy(id_out, id.internal, 128);
+  return 0;
+}
+
+int pp_comm_init(pp_handle h, int nranks, int rank, const uint8_t id[128]) {
+  if (!h || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(h, 3, "pp_comm_init: bad arguments");
+  if (!rccl_load()) return fail(h, 3, "pp_comm_init: librccl could not be opened");
+  PP_HIP(hipSetDevice(h->device));
+  if (h->rccl_comm) { (void)g_rccl.destroy(h->rccl_comm); h->rccl_comm = nullptr; h->rccl_ranks = 0; }
+  ppd_nccl_id uid;
+  std::memcpy(uid.internal, id, 128);
+  void* comm = nullptr;
+  const int rc = g_rccl.init_rank(&comm, nranks, uid, rank);
+  if (rc != 0) return fail(h, 3, rccl_msg("ncclCommInitRank", rc));
+  h->rccl_comm = comm;
+  h->rccl_ranks = nranks;
+  return 0;
+}
+
+int pp_comm_size(pp_handle h) { return h ? h->rccl_ranks : 0; }
+
+int pp_allreduce_schur(pp_handle h) {
+  if (!h || !h->rccl_comm) return fail(h, 3, "pp_allreduce_schur: no communicator (pp_comm_init)");
+  if (!h->numeric_done) return fail(h, 3, "pp_allreduce_schur before pp_numeric_local");
+  PP_HIP(hipSetDevice(h->device));
+  const size_t count = schur_doubles(h) + PP_TAIL;
+  const int rc = g_rccl.allreduce(h->S, h->S, count, /* ncclDouble */ 8, /* ncclSum */ 0, h->rccl_comm, h->stream);
+  if (rc != 0) return fail(h, 3, rccl_msg("ncclAllReduce(S)", rc));
+  return 0;
+}
+
+int pp_allreduce_rs(pp_handle h) {
+  if (!h || !h->rccl_comm) return fail(h, 3, "pp_allreduce_rs: no communicator (pp_comm_init)");
+  PP_HIP(hipSetDevice(h->device));
+  if (h->nc == 0) return 0;
+  const int rc = g_rccl.allreduce(h->rs, h->rs, (size_t)h->nc, 8, 0, h->rccl_comm, h->stream);
+  if (rc != 0) return fail(h, 3, rccl_msg("ncclAllReduce(r_s)", rc));
   return 0;
 }
 

@@ -319,6 +319,8 @@ struct pp_solver {
   int64_t mem_required = 0;      // bytes of value storage the current plan needs
   bool values_allocated = false;
   std::string err;
+  void* rccl_comm = nullptr;     // ncclComm_t of pp_comm_init (api.hip), or null
+  int rccl_ranks = 0;
   // Instance groups ("splits"): the level sweeps of disjoint 64-instance chunk ranges are
   // independent and can be issued on separate streams.  Measured (C3, 1 GPU, 4 splits): the 4x
   // launches serialise instead of overlapping (254 vs 379 it/s), so the default is one split.

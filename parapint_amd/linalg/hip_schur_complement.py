@@ -460,9 +460,36 @@ class HipEngine(object):
                       'pp_bcr_block_paths')
         return int(out[0]), int(out[1])
 
+    def _direct_rccl(self, comm):
+        """Opt-in (PP_DIRECT_RCCL=1, or comm.direct_rccl = True): the two data-path all-reduces are enqueued by the
+        library itself as RCCL calls on the handle's stream (include/parapint_hip.h: pp_allreduce_schur / pp_allreduce_rs)
+        instead of by torch.distributed between the kernel enqueues.  The communicator is made once per handle from a
+        unique id that rank 0 broadcasts through the torch process group."""
+        import os
+        if not (getattr(comm, 'direct_rccl', False) or os.environ.get('PP_DIRECT_RCCL') == '1'):
+            return False
+        if not getattr(comm, 'device_collectives', False):
+            return False
+        if self.lib.pp_comm_size(self.ns.h) != comm.size:
+            import ctypes
+            torch = self._torch
+            uid = np.zeros(128, dtype=np.uint8)
+            if comm.rank == 0:
+                if self.lib.pp_comm_unique_id(uid.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))) != 0:
+                    raise RuntimeError('pp_comm_unique_id failed (librccl not available)')
+            t = torch.from_numpy(uid).cuda()
+            if comm.size > 1:
+                comm._dist.broadcast(t, src=0, group=comm._group)
+            uid = t.cpu().numpy()
+            self.ns.check(self.lib.pp_comm_init(self.ns.h, int(comm.size), int(comm.rank),
+                                                uid.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))), 'pp_comm_init')
+        return True
+
     def allreduce_schur(self, comm):
         if comm.size > 1 or getattr(comm, 'always_reduce', False):
-            if comm.device_collectives:
+            if self._direct_rccl(comm):
+                self.ns.check(self.lib.pp_allreduce_schur(self.ns.h), 'pp_allreduce_schur')
+            elif comm.device_collectives:
                 comm.allreduce_sum_tensor_(self._S_t)
             else:
                 host = comm.allreduce_sum(self._S_t.cpu().numpy())
@@ -538,7 +565,9 @@ class HipEngine(object):
 
     def allreduce_rs(self, comm):
         if comm.size > 1 or getattr(comm, 'always_reduce', False):
-            if comm.device_collectives:
+            if self._direct_rccl(comm):
+                self.ns.check(self.lib.pp_allreduce_rs(self.ns.h), 'pp_allreduce_rs')
+            elif comm.device_collectives:
                 comm.allreduce_sum_tensor_(self._rs_t)
             else:
                 host = comm.allreduce_sum(self._rs_t.cpu().numpy())

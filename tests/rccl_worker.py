@@ -58,6 +58,21 @@ def main():
         assert solver.get_inertia() == oracle.get_inertia()
     nc = shape[3]
     assert calls.count((nc * nc + 8, True)) == 2 and calls.count((nc, True)) == 2, calls
+    # the same exchanges enqueued by the library itself (include/parapint_hip.h: pp_comm_init, pp_allreduce_schur,
+    # pp_allreduce_rs): communicator from a unique id, RCCL on the handle's stream, no torch.distributed call in between
+    comm.direct_rccl = True
+    del calls[:]
+    solver2 = HipSchurComplementLinearSolver({i: None for i in range(N)}, None, comm=comm)
+    kkt = model.build_kkt(comm=comm, iteration=3)
+    rhs = model.build_rhs(comm=comm)
+    assert solver2.do_symbolic_factorization(kkt).status == LinearSolverStatus.successful
+    assert solver2.do_numeric_factorization(kkt).status == LinearSolverStatus.successful
+    x2 = solver2.do_back_solve(rhs)
+    assert solver2._eng.lib.pp_comm_size(solver2._eng.ns.h) == 1
+    assert not calls, calls                               # torch.distributed was not asked to reduce anything
+    for ndx in range(N + 1):
+        assert np.array_equal(np.asarray(x2.get_block(ndx)), np.asarray(x.get_block(ndx)))
+    assert solver2.get_inertia() == solver.get_inertia()
     dist.barrier()
     dist.destroy_process_group()
     print('rccl one-rank ok')
