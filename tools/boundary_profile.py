@@ -12,7 +12,7 @@ from parapint_amd.linalg.hip_schur_complement import HipSchurComplementLinearSol
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 model = SyntheticKKT(N, 1000, 4, 200)
 comm = SerialComm()
-solver = HipSchurComplementLinearSolver({i: None for i in range(N)}, None, comm=comm)
+solver = HipSchurComplementLinearSolver({i: None for i in range(N)}, None, comm=comm, result_buffers=2)
 kkt = [model.build_kkt(comm=comm, iteration=k) for k in range(3)]
 rhs = model.build_rhs(comm=comm)
 solver.do_symbolic_factorization(kkt[0])
