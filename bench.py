@@ -228,21 +228,37 @@ def main():
         t_symbolic_host = time.perf_counter() - t0
         solver.do_numeric_factorization(kkt)
         solver.do_back_solve(rhs)
+        class _Phases(object):            # (the solver's timer labels, mpi_...:207-255 / 291-360 plus the boundary's own)
+            def __init__(self):
+                self.t, self.open = {}, {}
+
+            def start(self, name):
+                self.open[name] = time.perf_counter()
+
+            def stop(self, name):
+                self.t.setdefault(name, []).append(time.perf_counter() - self.open.pop(name))
+
         ts = []
+        phases = _Phases()
         for it in range(1, args.boundary_iterations + 1):
             kkt_it = model.build_kkt(comm=comm, iteration=it)
             if world > 1:
                 dist.barrier()
             t0 = time.perf_counter()
-            solver.do_numeric_factorization(matrix=kkt_it, raise_on_error=False)
-            x = solver.do_back_solve(rhs)
+            solver.do_numeric_factorization(matrix=kkt_it, raise_on_error=False, timer=phases)
+            x = solver.do_back_solve(rhs, timer=phases)
             ts.append(time.perf_counter() - t0)
         med = float(np.median(ts))
         if world > 1:
             med = float(comm.allreduce_max(np.array([med]))[0])
         boundary = {'it_per_s': 1.0 / med, 'ms_per_iteration': 1e3 * med, 'iterations': len(ts),
+                    'phases_ms': {k: round(1e3 * float(np.median(v)), 3) for k, v in phases.t.items()
+                                  if k in ('values to device', 'factorize', 'form SC', 'factor SC', 'rhs to device', 'solve',
+                                           'solution to host', 'back_solve')},
                     'note': 'host COO blocks in, host vectors out: needed entries staged into pinned memory on host '
-                            'threads with the H2D overlapped, pinned D2H of x; median, max over ranks'}
+                            'threads with the H2D overlapped, pinned D2H of x; median, max over ranks; phases_ms: host '
+                            'wall time between the labels (rank 0; "factorize" contains "values to device", '
+                            '"form SC" contains "factorize", "back_solve" its three parts)'}
         resid_boundary = residual_check(kkt_it, x, rhs)
         ok = ok and resid_boundary <= 1e-8 and tuple(solver.get_inertia()) == expected_inertia
         del kkt, kkt_it, x

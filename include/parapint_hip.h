@@ -301,9 +301,28 @@ int pp_stage_upload_compact(pp_handle h, int group, int nblocks, int nthreads, c
                             const int64_t* bnnz, const int32_t* ref_kr, const int32_t* ref_kc, int64_t ref_knnz,
                             const int32_t* ref_br, const int32_t* ref_bc, int64_t ref_bnnz, int nruns_k, const int64_t* runs_k,
                             int nruns_b, const int64_t* runs_b, double* staging, const int32_t* slots, uint8_t* same_out);
+/* The same for blocks whose index arrays the caller has verified against the reference order at an earlier call (nothing
+ * is compared; kd[i] / bd[i]: ref_knnz / ref_bnnz values), WITHOUT waiting: the arguments are copied, the host threads
+ * stage the rows and send every slice they finish themselves, and the call returns, so that the caller prepares its next
+ * batch of blocks meanwhile.  A second begin first waits for the job in flight; pp_stage_upload_end waits for the last one
+ * and reports the first error.  No other call on the handle in between. */
+int pp_stage_upload_verified_begin(pp_handle h, int group, int nblocks, int nthreads, const double* const* kd,
+                                   const double* const* bd, int64_t ref_knnz, int64_t ref_bnnz, int nruns_k, const int64_t* runs_k,
+                                   int nruns_b, const int64_t* runs_b, double* staging, const int32_t* slots);
+int pp_stage_upload_end(pp_handle h);
 /* dst[idx[i]][0 .. row_doubles) = src[i][0 .. row_doubles) on host threads: the right-hand sides of the local blocks into
  * the rows of their staging array (handle-free, no device work). */
 int pp_copy_rows(int nrows, int nthreads, const double* const* src, const int64_t* idx, double* dst, int64_t row_doubles);
+/* The right-hand sides of ALL blocks of a group (src[i]: the n values of the block in slot i, nrows = batch) through the
+ * pinned staging array [batch][n] to the device; the copy of a slice of rows overlaps the host threads' work on the next
+ * slice.  Replaces pp_copy_rows + pp_upload_rhs on the host boundary of do_back_solve (mpi_...:363-380 reads the blocks
+ * of the right-hand side one by one). */
+int pp_upload_rhs_rows(pp_handle h, int group, int nrows, int nthreads, const double* const* src, double* staging);
+/* The solutions of a group to the host.  dst NULL: one asynchronous copy into the pinned array [batch][n] (synchronise,
+ * pp_synchronize, before reading it).  dst given (pageable [batch][n], e.g. a fresh array per call as mpi_...:390-401
+ * returns one): slices arrive in the pinned array and host threads move each on to dst while the next is in flight;
+ * returns when dst is complete. */
+int pp_download_solution_rows(pp_handle h, int group, int nthreads, double* pinned, double* dst);
 /* Pinned (page-locked) host memory for the staging arrays and result buffers of the host boundary. */
 void* pp_host_alloc(int64_t bytes);
 void pp_host_free(void* p);

@@ -40,14 +40,20 @@ int pp_create(pp_handle* out, int device, void* stream) {
   return 0;
 }
 
+namespace { int stage_job_finish(pp_handle h); }
+
 void pp_destroy(pp_handle h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
+  (void)stage_job_finish(h);
   (void)hipStreamSynchronize(h->stream);
   for (Group* g : h->groups) free_group(g);
   free_globals(h);
   if (h->ev_made)
     for (int i = 0; i < PP_NPHASE; ++i) { (void)hipEventDestroy(h->ev[i][0]); (void)hipEventDestroy(h->ev[i][1]); }
+  for (hipEvent_t e : h->dl_events) (void)hipEventDestroy(e);
+  if (h->stage_stream2) (void)hipStreamDestroy(h->stage_stream2);
+  if (h->stage_ev2) (void)hipEventDestroy(h->stage_ev2);
   if (h->ev_corner_up) { (void)hipEventDestroy(h->ev_corner_up); (void)hipEventDestroy(h->ev_corner_done); (void)hipStreamDestroy(h->up_stream); }
   if (h->aux_made) {
     for (int i = 0; i < PP_MAX_SPLIT; ++i) { (void)hipStreamDestroy(h->aux[i]); (void)hipEventDestroy(h->ev_join[i]); }
@@ -184,15 +190,15 @@ int pp_end_symbolic(pp_handle h) {
     for (auto& t : P.ftasks) {
       const int nrow = t.r1 - t.r0;
       const int new_dptr0 = (int)fdst_ptr.size();
-      // fourth field of a record: bits 0-7 the destination column of an initial value or of a single-column product
-      // entry (third field 0), bits 8.. the number of
+      // fourth field of a record: bits 0-7 the destination column of an initial value, or first column | columns << 4 of
+      // a product entry; bits 8.. the number of
       // destination rows that END before this entry (0 inside a row; k_gather_flat closes that many rows first)
       int cur_row = 0;
       for (int dd = 0; dd < nrow; ++dd) {
         fdst_ptr.push_back((int)(fent.size() / 4));
         for (int e = P.fdst_ptr[t.dptr0 + dd]; e < P.fdst_ptr[t.dptr0 + dd + 1]; ++e) {
           const pp::FEntry& fe = P.fentries[e];
-          if (fe.u >= 0) { fent.insert(fent.end(), {fe.u, fe.l, fe.wk, (fe.wk == 0 ? fe.q : 0) | ((dd - cur_row) << 8)}); cur_row = dd; }
+          if (fe.u >= 0) { fent.insert(fent.end(), {fe.u, fe.l, fe.wk, (fe.q & 255) | ((dd - cur_row) << 8)}); cur_row = dd; }
           else {
             // the L index of an initial-value record is a dummy (position 0, always valid)
             const int ce = -1 - fe.u;
@@ -960,6 +966,38 @@ bool stage_args_ok(int nblocks, const StageArgs& a, int64_t need) {
         a.runsB[3 * r + 2] + a.runsB[3 * r + 1] > a.row_stride) return false;
   return need <= a.row_stride;
 }
+// item(i) for i < nitems on the handle's host threads (items claimed in ascending order), and copy(r0, r1) on the
+// caller's thread for every finished slice of items -- rows slots[i0] .. slots[i1 - 1] (slots null: row i = item i).
+extern "C++" {
+template <class Item, class Copy>
+int sliced_upload(pp_handle h, int nitems, int nthreads, const int32_t* slots, Item item, Copy copy) {
+  if (nitems <= 0) return 0;
+  const int slice = 64, nsl = (nitems + slice - 1) / slice;
+  std::vector<std::atomic<int>> done((size_t)nsl);
+  for (auto& d : done) d.store(0, std::memory_order_relaxed);
+  std::atomic<int> next{0};
+  auto work = [&]() {
+    for (;;) {
+      const int i = next.fetch_add(1, std::memory_order_relaxed);
+      if (i >= nitems) break;
+      item(i);
+      done[(size_t)(i / slice)].fetch_add(1, std::memory_order_release);
+    }
+  };
+  const int nt = std::max(1, std::min(std::min(nthreads, 64), nitems));
+  const int started = nt > 1 ? h->stage_pool.start(nt, work) : 0;
+  if (started == 0) work();
+  hipError_t err = hipSuccess;
+  for (int s = 0; s < nsl; ++s) {
+    const int i0 = s * slice, i1 = std::min(nitems, i0 + slice);
+    while (done[(size_t)s].load(std::memory_order_acquire) < i1 - i0) std::this_thread::yield();
+    if (err == hipSuccess) err = copy(slots ? slots[i0] : i0, slots ? slots[i1 - 1] + 1 : i1);
+  }
+  if (started > 0) h->stage_pool.wait();      // (work refers to this frame)
+  if (err != hipSuccess) return fail(h, 3, std::string("host boundary copy: ") + hipGetErrorString(err));
+  return 0;
+}
+}  // extern "C++"
 }  // namespace
 
 int pp_stage_values(int nblocks, int nthreads, const int32_t* const* kr, const int32_t* const* kc,
@@ -1008,16 +1046,192 @@ int pp_stage_upload_compact(pp_handle h, int group, int nblocks, int nthreads, c
   PP_HIP(hipSetDevice(h->device));
   if (int rc = ensure_optional(h, g, OPT_RAW)) return rc;
   g->input_mode = Group::IN_COMPACT;
-  const int slice = 128;
-  for (int i0 = 0; i0 < nblocks; i0 += slice) {
-    const int i1 = std::min(nblocks, i0 + slice);
-    stage_parallel(a, i0, i1, nthreads);
-    const size_t stride = (size_t)g->nraw_used;
-    const int r0 = slots[i0], r1 = slots[i1 - 1] + 1;
-    if (stride > 0)
-      PP_HIP(hipMemcpyAsync(g->raw_own + (size_t)r0 * stride, staging + (size_t)r0 * stride, (size_t)(r1 - r0) * stride * sizeof(double),
-                            hipMemcpyHostToDevice, h->stream));
+  const size_t stride = (size_t)g->nraw_used;
+  return sliced_upload(h, nblocks, nthreads, slots, [&](int i) { stage_range(a, i, i + 1); },
+                       [&](int r0, int r1) {
+                         return stride == 0 ? hipSuccess
+                                            : hipMemcpyAsync(g->raw_own + (size_t)r0 * stride, staging + (size_t)r0 * stride,
+                                                             (size_t)(r1 - r0) * stride * sizeof(double), hipMemcpyHostToDevice, h->stream);
+                       });
+}
+
+// The same for blocks whose index arrays were verified at an earlier call (nothing is compared), WITHOUT waiting: the
+// arguments are copied, the host threads start staging and send every slice they finish themselves, and the call
+// returns -- the caller prepares its next batch of blocks meanwhile.  A second begin first waits for the job in flight;
+// pp_stage_upload_end waits for the last one and reports the first error.  Nothing else may be enqueued in between.
+namespace {
+struct StageJob {
+  std::vector<const double*> kd, bd;
+  std::vector<int32_t> slots;
+  std::vector<int64_t> runs_k, runs_b;
+  std::vector<std::atomic<int>> done;
+  std::atomic<int> next{0};
+  std::atomic<int> err{0};
+  int nblocks = 0, slice = 64;
+  double *staging = nullptr, *dev = nullptr;
+  size_t stride = 0;
+  int device = 0;
+  hipStream_t stream = nullptr, stream2 = nullptr;
+  void work() {
+    bool device_set = false;
+    for (;;) {
+      const int i = next.fetch_add(1, std::memory_order_relaxed);
+      if (i >= nblocks) break;
+      double* row = staging + (size_t)slots[(size_t)i] * stride;
+      for (size_t r = 0; r + 2 < runs_k.size() + 1; r += 3) std::memcpy(row + runs_k[r + 2], kd[(size_t)i] + runs_k[r], (size_t)runs_k[r + 1] * sizeof(double));
+      for (size_t r = 0; r + 2 < runs_b.size() + 1; r += 3) std::memcpy(row + runs_b[r + 2], bd[(size_t)i] + runs_b[r], (size_t)runs_b[r + 1] * sizeof(double));
+      const int s = i / slice, i0 = s * slice, i1 = std::min(nblocks, i0 + slice);
+      if (done[(size_t)s].fetch_add(1, std::memory_order_acq_rel) + 1 == i1 - i0 && stride > 0) {
+        // the last block of the slice: its rows go to the device (rows of blocks outside the call lie in between only
+        // when the caller mixes paths; they are sent again by whoever stages them)
+        if (!device_set) { (void)hipSetDevice(device); device_set = true; }
+        const size_t r0 = (size_t)slots[(size_t)i0], r1 = (size_t)slots[(size_t)i1 - 1] + 1;
+        const hipError_t e = hipMemcpyAsync(dev + r0 * stride, staging + r0 * stride, (r1 - r0) * stride * sizeof(double), hipMemcpyHostToDevice,
+                                             (stream2 && (s & 1)) ? stream2 : stream);
+        if (e != hipSuccess) { int zero = 0; err.compare_exchange_strong(zero, (int)e); }
+      }
+    }
   }
+};
+int stage_job_finish(pp_handle h) {
+  StageJob* j = (StageJob*)h->stage_job;
+  if (!j) return 0;
+  h->stage_pool.wait();
+  int e = j->err.load();
+  if (j->stream2) {        // what went over the second stream is ordered before the work that follows on the handle's stream
+    hipError_t e2 = hipEventRecord(h->stage_ev2, j->stream2);
+    if (e2 == hipSuccess) e2 = hipStreamWaitEvent(h->stream, h->stage_ev2, 0);
+    if (e == 0 && e2 != hipSuccess) e = (int)e2;
+  }
+  delete j;
+  h->stage_job = nullptr;
+  if (e != 0) return fail(h, 3, std::string("pp_stage_upload_verified_begin: copy failed: ") + hipGetErrorString((hipError_t)e));
+  return 0;
+}
+}  // namespace
+
+int pp_stage_upload_verified_begin(pp_handle h, int group, int nblocks, int nthreads, const double* const* kd,
+                                   const double* const* bd, int64_t ref_knnz, int64_t ref_bnnz, int nruns_k, const int64_t* runs_k,
+                                   int nruns_b, const int64_t* runs_b, double* staging, const int32_t* slots) {
+  Group* g = get_group(h, group);
+  if (!g || !h->symbolic_done) return fail(h, 3, "pp_stage_upload_verified_begin: bad group or symbolic phase not finished");
+  if (int rc = stage_job_finish(h)) return rc;
+  if (nblocks <= 0) return 0;
+  StageArgs a{};
+  a.ref_knnz = ref_knnz; a.ref_bnnz = ref_bnnz;
+  a.nrunsK = nruns_k; a.runsK = runs_k; a.nrunsB = nruns_b; a.runsB = runs_b; a.row_stride = (int64_t)g->nraw_used;
+  uint8_t dummy = 0;
+  a.same_out = &dummy;
+  if (!kd || !bd || !staging || !slots || !runs_k || ref_knnz < 0 || ref_bnnz < 0 || ref_knnz + ref_bnnz != g->nraw || !stage_args_ok(0, a, 0)) return fail(h, 3, "pp_stage_upload_verified_begin: bad arguments");
+  for (int i = 0; i < nblocks; ++i)
+    if (slots[i] < 0 || slots[i] >= g->batch || (i > 0 && slots[i] <= slots[i - 1]) || !kd[i] || (a.ref_bnnz > 0 && nruns_b > 0 && !bd[i]))
+      return fail(h, 3, "pp_stage_upload_verified_begin: slots must be ascending and inside the batch, data pointers non-null");
+  PP_HIP(hipSetDevice(h->device));
+  if (int rc = ensure_optional(h, g, OPT_RAW)) return rc;
+  g->input_mode = Group::IN_COMPACT;
+  StageJob* j = new (std::nothrow) StageJob;
+  if (!j) return fail(h, 3, "pp_stage_upload_verified_begin: out of host memory");
+  try {
+    j->kd.assign(kd, kd + nblocks); j->bd.assign(bd, bd + nblocks); j->slots.assign(slots, slots + nblocks);
+    j->runs_k.assign(runs_k, runs_k + 3 * (size_t)nruns_k);
+    if (nruns_b > 0) j->runs_b.assign(runs_b, runs_b + 3 * (size_t)nruns_b);
+    j->done = std::vector<std::atomic<int>>((size_t)((nblocks + j->slice - 1) / j->slice));
+  } catch (...) { delete j; return fail(h, 3, "pp_stage_upload_verified_begin: out of host memory"); }
+  for (auto& d : j->done) d.store(0, std::memory_order_relaxed);
+  j->nblocks = nblocks; j->staging = staging; j->dev = g->raw_own; j->stride = (size_t)g->nraw_used;
+  j->device = h->device; j->stream = h->stream;
+  static const bool two_streams = std::getenv("PP_STAGE_STREAMS") && std::atoi(std::getenv("PP_STAGE_STREAMS")) == 2;
+  if (two_streams) {
+    if (!h->stage_stream2 && (hipStreamCreateWithFlags(&h->stage_stream2, hipStreamNonBlocking) != hipSuccess ||
+                              hipEventCreateWithFlags(&h->stage_ev2, hipEventDisableTiming) != hipSuccess)) {
+      delete j;
+      return fail(h, 3, "pp_stage_upload_verified_begin: no second copy stream");
+    }
+    // (the copies must not overtake work already queued on the handle's stream that reads the old values)
+    hipError_t e2 = hipEventRecord(h->stage_ev2, h->stream);
+    if (e2 == hipSuccess) e2 = hipStreamWaitEvent(h->stage_stream2, h->stage_ev2, 0);
+    if (e2 != hipSuccess) { delete j; return fail(h, 3, "pp_stage_upload_verified_begin: stream ordering failed"); }
+    j->stream2 = h->stage_stream2;
+  }
+  h->stage_job = j;
+  const int nt = std::max(1, std::min(std::min(nthreads, 64), nblocks));
+  if (h->stage_pool.start(nt, [j]() { j->work(); }) == 0) {      // no thread could be started: here and now
+    j->work();
+    const int e = j->err.load();
+    delete j;
+    h->stage_job = nullptr;
+    if (e != 0) return fail(h, 3, std::string("pp_stage_upload_verified_begin: copy failed: ") + hipGetErrorString((hipError_t)e));
+  }
+  return 0;
+}
+
+int pp_stage_upload_end(pp_handle h) { return h ? stage_job_finish(h) : 3; }
+
+// The right-hand sides of ALL blocks of a group (src[i]: the n values of the block in slot i) through the pinned staging
+// array [batch][n] to the device, the copy of a slice of rows overlapping the host threads' work on the next one.
+int pp_upload_rhs_rows(pp_handle h, int group, int nrows, int nthreads, const double* const* src, double* staging) {
+  Group* g = get_group(h, group);
+  if (!g || !h->symbolic_done) return fail(h, 3, "pp_upload_rhs_rows: bad group or symbolic phase not finished");
+  if (nrows != g->batch || !src || !staging) return fail(h, 3, "pp_upload_rhs_rows: one source row per block of the group is needed");
+  PP_HIP(hipSetDevice(h->device));
+  if (int rc = alloc_value_storage(h)) return rc;
+  if (!g->dev.rhs) { if (int rc = ensure_optional(h, g, OPT_RHS)) return rc; }
+  const size_t n = (size_t)g->plan.n;
+  return sliced_upload(h, nrows, nthreads, nullptr, [&](int i) { std::memcpy(staging + (size_t)i * n, src[i], n * sizeof(double)); },
+                       [&](int r0, int r1) {
+                         return hipMemcpyAsync(g->dev.rhs + (size_t)r0 * n, staging + (size_t)r0 * n, (size_t)(r1 - r0) * n * sizeof(double),
+                                               hipMemcpyHostToDevice, h->stream);
+                       });
+}
+
+// The solutions of a group ([batch][n]) to the host.  dst null: one asynchronous copy into the pinned array (the caller
+// hands out its rows and synchronises, pp_synchronize, before they are read).  dst given (pageable memory, e.g. a fresh
+// array per call): the copy goes slice by slice through the pinned array and host threads move every slice that has
+// arrived on to dst while the next one is in flight (they also take the page faults of a fresh dst, side by side);
+// returns when dst is complete.
+int pp_download_solution_rows(pp_handle h, int group, int nthreads, double* pinned, double* dst) {
+  Group* g = get_group(h, group);
+  if (!g || !h->symbolic_done || !pinned) return fail(h, 3, "pp_download_solution_rows: bad group or no pinned array");
+  if (!g->dev.xout) return fail(h, 3, "pp_download_solution_rows: no solution in the [instance][row] layout (native vectors bound?)");
+  PP_HIP(hipSetDevice(h->device));
+  const size_t n = (size_t)g->plan.n;
+  const int nrows = g->batch;
+  if (!dst) {
+    PP_HIP(hipMemcpyAsync(pinned, g->dev.xout, (size_t)nrows * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    return 0;
+  }
+  const int slice = 64, nsl = (nrows + slice - 1) / slice;
+  while ((int)h->dl_events.size() < nsl) {
+    hipEvent_t e = nullptr;
+    PP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    h->dl_events.push_back(e);
+  }
+  for (int s = 0; s < nsl; ++s) {
+    const size_t r0 = (size_t)s * slice, r1 = std::min((size_t)nrows, r0 + slice);
+    PP_HIP(hipMemcpyAsync(pinned + r0 * n, g->dev.xout + r0 * n, (r1 - r0) * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    PP_HIP(hipEventRecord(h->dl_events[(size_t)s], h->stream));
+  }
+  std::atomic<int> ready{0}, next{0};
+  std::atomic<bool> failed{false};
+  auto work = [&]() {
+    for (;;) {
+      const int i = next.fetch_add(1, std::memory_order_relaxed);
+      if (i >= nrows) break;
+      while (ready.load(std::memory_order_acquire) <= i / slice && !failed.load(std::memory_order_relaxed)) std::this_thread::yield();
+      if (failed.load(std::memory_order_relaxed)) continue;
+      std::memcpy(dst + (size_t)i * n, pinned + (size_t)i * n, n * sizeof(double));
+    }
+  };
+  const int nt = std::max(1, std::min(std::min(nthreads, 64), nrows));
+  const int started = nt > 1 ? h->stage_pool.start(nt, work) : 0;
+  hipError_t err = hipSuccess;
+  for (int s = 0; s < nsl && err == hipSuccess; ++s) {
+    err = hipEventSynchronize(h->dl_events[(size_t)s]);
+    if (err == hipSuccess) ready.store(s + 1, std::memory_order_release);
+  }
+  if (err != hipSuccess) failed.store(true);
+  if (started > 0) h->stage_pool.wait(); else work();
+  if (err != hipSuccess) return fail(h, 3, std::string("pp_download_solution_rows: ") + hipGetErrorString(err));
   return 0;
 }
 
@@ -1150,7 +1364,7 @@ void rccl_release(pp_handle h) {
   h->rccl_comm = nullptr;
   h->rccl_ranks = 0;
 }
-std::string rccl_msg(const char* what, int rc) {
+extern "C++" std::string rccl_msg(const char* what, int rc) {
   return std::string(what) + ": " + (g_rccl.errstr ? g_rccl.errstr(rc) : "RCCL error") + " (" + std::to_string(rc) + ")";
 }
 }  // namespace

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <functional>
@@ -267,6 +268,62 @@ struct EnqueuePool {
   }
 };
 
+// Host threads of the host boundary (staging of the matrix values, right-hand-side rows): started once per handle,
+// parked on a condition variable in between (eight slices x sixteen thread starts per call cost more than the copies they
+// made).  start() returns at once -- the caller issues the copy of every finished slice -- and wait() joins the job.
+struct StagePool {
+  std::vector<std::thread> th;
+  std::mutex m;
+  std::condition_variable cv, cv_done;
+  std::function<void()> job;
+  long long gen = 0;
+  int nwork = 0, pending = 0;
+  bool stop = false;
+  void worker(int k) {
+    long long seen = 0;
+    for (;;) {
+      std::function<void()> f;
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return stop || (gen != seen && k < nwork); });
+        if (stop) return;
+        seen = gen;
+        f = job;
+      }
+      f();
+      {
+        std::lock_guard<std::mutex> lk(m);
+        if (--pending == 0) cv_done.notify_all();
+      }
+    }
+  }
+  // f runs on up to n threads (it claims its work items itself); returns the number of threads that run it (0: none
+  // could be started -- the caller runs f itself)
+  int start(int n, const std::function<void()>& f) {
+    try {
+      while ((int)th.size() < n) { const int k = (int)th.size(); th.emplace_back([this, k] { worker(k); }); }
+    } catch (...) {
+    }
+    n = std::min(n, (int)th.size());
+    if (n == 0) return 0;
+    {
+      std::lock_guard<std::mutex> lk(m);
+      job = f; nwork = n; pending = n; ++gen;
+    }
+    cv.notify_all();
+    return n;
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(m);
+    cv_done.wait(lk, [&] { return pending == 0; });
+  }
+  ~StagePool() {
+    { std::lock_guard<std::mutex> lk(m); stop = true; }
+    cv.notify_all();
+    for (std::thread& t : th) t.join();
+  }
+};
+
 struct pp_solver {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -303,6 +360,11 @@ struct pp_solver {
   bool schur_mfma = std::getenv("PP_NO_SCHUR_MFMA") == nullptr;   // MFMA form of the Schur update of unmapped groups (measurement switch)
   bool enqueue_threads = std::getenv("PP_NO_ENQUEUE_THREADS") == nullptr;   // one enqueuing host thread per group stream (measurement switch)
   EnqueuePool pool;
+  StagePool stage_pool;
+  hipStream_t stage_stream2 = nullptr;   // second copy stream of the staged upload (PP_STAGE_STREAMS=2: measurement switch)
+  hipEvent_t stage_ev2 = nullptr;
+  void* stage_job = nullptr;             // staging job in flight (pp_stage_upload_verified_begin .. pp_stage_upload_end), api.hip
+  std::vector<hipEvent_t> dl_events;      // one per slice of a staged download (pp_download_solution_rows)
   long long* corner_pos = nullptr;      // sparse Q of a block-tridiagonal S: positions in the Schur layout, values
   double* corner_val = nullptr;
   size_t corner_cap = 0;

@@ -182,42 +182,43 @@ __global__ __launch_bounds__(64 * NW) void k_gather_flat(GroupDev g, int task0, 
         ldv<NV>(base + (size_t)((!prod && idx == g.const_row) ? 0 : idx) * bpad + b, su[i]);
 #pragma unroll
         for (int q = 0; q < WM; ++q)
-          ldv<NV>(Lb + (size_t)(prod ? el[i] + min(q, w - 1) * ew[i] : 0) * bpad + b, sl[i][q]);
+          // (column q of a product entry over the columns q0 .. q0 + n - 1 reads row q - q0 of its run; the columns outside
+          // the run repeat an end of it and are not used)
+          ldv<NV>(Lb + (size_t)(prod ? el[i] + min(max(q - (ef[i] & 15), 0), ((ef[i] >> 4) & 15) - 1) * ew[i] : 0) * bpad + b, sl[i][q]);
       }
 #pragma unroll
       for (int i = 0; i < G; ++i) {
         if (i0 + i < cnt) {
           for (int nf = ef[i] >> 8; nf > 0; --nf) finalize();
           if (eu[i] >= 0) {
-            if (ew[i] == 0) {
-              // single-column entry (the source panel holds only some columns of this block pivot as rows): all w
-              // requests above went to the one L operand
-              const int eq = ef[i] & 0xff;
+            // product entry: columns q0 .. q0 + n - 1 of the destination row (all w columns when the source panel holds
+            // the whole block pivot, fewer when it holds only some of its columns as rows)
+            const unsigned q0 = (unsigned)(ef[i] & 15), qn = (unsigned)((ef[i] >> 4) & 15);
+            if (d < nblk) {
 #pragma unroll
               for (int q = 0; q < WM; ++q) {
-                if (q == eq) {
+                if ((unsigned)q - q0 < qn) {
 #pragma unroll
                   for (int v = 0; v < NV; ++v) {
                     const double term = su[i][v] * sl[i][q][v];
                     acc[q][v] -= term;
-                    if (d < nblk) tmax[q][v] = fmax(tmax[q][v], fabs(term));
+                    tmax[q][v] = fmax(tmax[q][v], fabs(term));
                   }
                 }
               }
-            } else if (d < nblk) {
-#pragma unroll
-              for (int q = 0; q < WM; ++q)
-#pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                  const double term = su[i][v] * ((q < w) ? sl[i][q][v] : 0.0);
-                  acc[q][v] -= term;
-                  tmax[q][v] = fmax(tmax[q][v], fabs(term));
-                }
-            } else {
+            } else if (q0 == 0u && qn >= (unsigned)w) {
 #pragma unroll
               for (int q = 0; q < WM; ++q)     // (q >= w: a duplicate of column w - 1, never stored)
 #pragma unroll
                 for (int v = 0; v < NV; ++v) acc[q][v] = fma(-su[i][v], sl[i][q][v], acc[q][v]);
+            } else {
+#pragma unroll
+              for (int q = 0; q < WM; ++q) {
+                if ((unsigned)q - q0 < qn) {
+#pragma unroll
+                  for (int v = 0; v < NV; ++v) acc[q][v] = fma(-su[i][v], sl[i][q][v], acc[q][v]);
+                }
+              }
             }
           } else {
             // initial-value record: (y, z) hold the coefficient of the input entry (1 for plain raw values)
@@ -328,11 +329,12 @@ __global__ __launch_bounds__(64) void k_gather_level_lean(GroupDev g, int task0,
 #pragma unroll
       for (int q = 0; q < WM; ++q) {
         double lv[NV];
-        ldv<NV>(Lb + (size_t)((ex >= 0) ? ey + min(q, w - 1) * ez : 0) * bpad, lv);
+        const int q0 = ew & 15, qn = (ew >> 4) & 15;      // product entry: columns q0 .. q0 + qn - 1
+        ldv<NV>(Lb + (size_t)((ex >= 0) ? ey + min(max(q - q0, 0), qn - 1) * ez : 0) * bpad, lv);
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-          // (product entry over all w columns; single-column product entry, ez == 0; initial value)
-          const double m = (ex >= 0) ? ((ez != 0 ? q < w : q == (ew & 0xff)) ? lv[v] : 0.0) : ((q == (ew & 0xff)) ? -coef : 0.0);
+          // (product entry over a run of columns; initial value into column ew & 0xff)
+          const double m = (ex >= 0) ? (((unsigned)(q - q0) < (unsigned)qn) ? lv[v] : 0.0) : ((q == (ew & 0xff)) ? -coef : 0.0);
           const double term = (cst ? 1.0 : sv[v]) * m;
           acc[q][v] -= term;
           tmax[q][v] = fmax(tmax[q][v], fabs(term));

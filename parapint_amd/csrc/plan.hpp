@@ -151,10 +151,11 @@ inline bool apply_plan_tune(PlanOptions& opt, const char* tune, std::string& bad
 // indexing: the unscaled panel U_p = [P_p ; U_p] and the scaled rows L_p = U_p inv(P_p).  The
 // update of a destination ROW (all w columns of the block pivot at once) is a pure gather over
 // row entries e:
-//     acc[q] -= U[e.u] * L[e.l + q * e.wk]   for q < w      (source column t of panel k: U_k[i][t], L_k[p_q][t])
+//     acc[q0 + j] -= U[e.u] * L[e.l + j * e.wk]   for j < m  (source column t of panel k: U_k[i][t], L_k[p_(q0+j)][t];
+//                                                             e.q = q0 | m << 4: a run of m consecutive columns of the
+//                                                             block pivot -- all w of them when panel k holds the whole
+//                                                             block pivot as rows, fewer when it holds only some)
 //     acc[e.q] += input value ~e.u                           (initial-value entry: e.u < 0, e.l < 0)
-//     acc[e.q] -= U[e.u] * L[e.l]                            (single-column entry: e.wk == 0 -- the source panel holds
-//                                                             only some of the w columns of the block pivot as rows)
 // so every U operand is loaded once per row, no per-task multiplier tables are needed and block
 // pivots of any width cost (1 + w) loads per w multiply-adds.
 // Task kinds:  0 gather chunk of a big panel (stores U, and the term magnitudes of pivot-block

@@ -717,7 +717,7 @@ static int build_plan_ordered(int n, int nc, int nnzK, const int* rowK, const in
           j1 = j0;
           while (j1 < km.cnt && km.qs[j1] < qoff + ws) ++j1;
           if (j1 == j0) continue;                  // panel k holds no column of this slice
-          const bool whole = (j1 - j0) == ws;      // ... every column of it: one entry updates a whole row
+          int nruns = 0;
           const auto& rk = rows[k];
           size_t tp = 0;
           for (size_t t = (size_t)(mslot - wk); t < rk.size(); ++t) {
@@ -732,14 +732,19 @@ static int build_plan_ordered(int n, int nc, int nnzK, const int* rowK, const in
             const int srow = wk + (int)t;
             for (int tt = 0; tt < wk; ++tt) {
               const int upos = (int)(P.piv_uoff[k] + (int64_t)srow * wk + tt);
-              if (whole)
-                row_ents[(size_t)d].push_back({upos, (int)(P.piv_uoff[k] + (int64_t)(mslot + j0) * wk + tt), wk, 0});
-              else
-                for (int j = j0; j < j1; ++j)
-                  row_ents[(size_t)d].push_back({upos, (int)(P.piv_uoff[k] + (int64_t)(mslot + j) * wk + tt), 0, km.qs[j] - qoff});
+              // one entry per run of consecutive columns of the slice that panel k holds (consecutive rows of k)
+              for (int j = j0; j < j1;) {
+                int je = j + 1;
+                while (je < j1 && km.qs[je] == km.qs[je - 1] + 1) ++je;
+                row_ents[(size_t)d].push_back({upos, (int)(P.piv_uoff[k] + (int64_t)(mslot + j) * wk + tt), wk,
+                                               (km.qs[j] - qoff) | ((je - j) << 4)});
+                ++nruns;
+                j = je;
+              }
             }
             P.flops_factor += (int64_t)wk * (j1 - j0);
-            total += whole ? wk : wk * (j1 - j0);
+            total += nruns;
+            nruns = 0;
           }
         }
         auto emit = [&](int r0, int r1, int kind, int piece = 0, int npieces = 1, int e0 = -1, int e1 = -1) {

@@ -134,7 +134,11 @@ class SyntheticKKT(object):
         """(N+1) x (N+1) block KKT.  With ``comm`` an MPIBlockMatrix carrying the
         reference's ownership table (create_model.py:207-235)."""
         N = self.n_blocks
-        border = self.border_matrix()
+        # (the structure of A_i does not change between iterations: one object, as an interface keeps its Jacobian)
+        border = getattr(self, '_border', None)
+        if border is None:
+            border = self._border = self.border_matrix()
+            self._border_t = border.transpose().tocoo()
         if comm is None:
             kkt = BlockMatrix(N + 1, N + 1)
         else:
@@ -150,7 +154,7 @@ class SyntheticKKT(object):
             kkt.set_block(ndx, ndx, self.block_matrix(ndx, iteration))
             kkt.set_block(N, ndx, border)
             if with_upper_border:
-                kkt.set_block(ndx, N, border.transpose().tocoo())
+                kkt.set_block(ndx, N, self._border_t)
         kkt.set_block(N, N, coo_matrix((self.n_theta, self.n_theta)))
         return kkt
 

@@ -22,6 +22,8 @@ What differs underneath:
 Lower triangle of every K_i is authoritative (MA27 semantics, quirk Q5).
 There is no CPU fallback: without the HIP library / a GPU the constructor raises.
 """
+import ctypes
+
 import numpy as np
 
 from parapint_amd.linalg.base_linear_solver_interface import LinearSolverInterface
@@ -77,6 +79,25 @@ class _Labels(object):
         if self._r:
             self._r[1]()
         self._t.stop(name)
+
+
+_S8 = (8,)
+
+
+def _addr(a, _from_buffer=ctypes.c_char.from_buffer, _addressof=ctypes.addressof):
+    """Address of the first element of a contiguous array (a third of the cost of ``a.ctypes.data``; the host boundary
+    asks for two or three thousand of them per call)."""
+    try:
+        return _addressof(_from_buffer(a))
+    except (TypeError, ValueError):          # read-only or empty buffer
+        return a.ctypes.data
+
+
+def _probe(a):
+    """(first, middle, last) entry of an index array: the cheap check that an array recognised by identity was not
+    rewritten in place."""
+    n = a.size
+    return (a.item(0), a.item(n >> 1), a.item(n - 1)) if n else (0, 0, 0)
 
 
 def _flat(v):
@@ -137,7 +158,7 @@ class _UnionMatrix(object):
 
 
 class _BlockInfo(object):
-    __slots__ = ('group', 'slot', 'raw_sig', 'n', 'cmap', 'br_cache')
+    __slots__ = ('group', 'slot', 'raw_sig', 'n', 'cmap', 'br_cache', 'seen')
 
 
 class _Group(object):
@@ -304,17 +325,15 @@ class HipEngine(object):
         staging row and on to the device, slice by slice, with the copies overlapping the staging of the next slice
         (include/parapint_hip.h: pp_stage_upload_compact); returns one flag per item (False: the caller stages and
         uploads that block itself)."""
-        import ctypes
         import os
         n = len(items)
-        ptr = np.empty((6, n), dtype=np.uint64)
-        nnz = np.empty((2, n), dtype=np.int64)
-        slots = np.empty(n, dtype=np.int32)
+        cols = ([], [], [], [], [], [])
+        nnzk, nnzb, slots = [], [], []
         ref = getattr(g, '_ref32', None)
         if ref is None:
             ref = g._ref32 = [np.ascontiguousarray(r, dtype=np.int32) for r in g.raw_refs]
             g._refptr = [r.ctypes.data for r in ref]
-        known, refptr = g.known_ptrs, g._refptr           # id(index array) -> the array (kept alive), verified equal to the reference
+        known, refptr = g.known_ptrs, g._refptr           # (role, id(index array)) -> the array (kept alive), verified equal to the reference
         unknown = []
         for i, (slot, arrays) in enumerate(items):
             # index arrays already verified against the reference order (the same objects as at an earlier call): hand
@@ -326,19 +345,22 @@ class HipEngine(object):
                 # its size and a cheap content probe (first, middle, last entry) unchanged: an array object that was
                 # mutated in place or is reused in another role goes through the full comparison again
                 k = known.get((q, id(a)))
-                if k is not None and k[1] == a.size and (a.size == 0 or (k[2] == int(a[0]) and k[3] == int(a[a.size // 2])
-                                                                         and k[4] == int(a[-1]))):
-                    ptr[q, i] = refptr[r]
+                if k is not None and k[1] == a.size and k[2:] == _probe(a):
+                    cols[q].append(refptr[r])
                 else:
-                    ptr[q, i] = a.ctypes.data
+                    cols[q].append(_addr(a))
                     fresh = True
             if fresh:
                 unknown.append(i)
-            ptr[2, i] = arrays[2].ctypes.data
-            ptr[5, i] = arrays[5].ctypes.data if arrays[5].size else 0
-            nnz[0, i] = arrays[2].size
-            nnz[1, i] = arrays[5].size
-            slots[i] = slot
+            kd, bd = arrays[2], arrays[5]
+            cols[2].append(_addr(kd))
+            cols[5].append(_addr(bd) if bd.size else 0)
+            nnzk.append(kd.size)
+            nnzb.append(bd.size)
+            slots.append(slot)
+        ptr = np.array(cols, dtype=np.uint64)
+        nnz = np.array((nnzk, nnzb), dtype=np.int64)
+        slots = np.array(slots, dtype=np.int32)
         same = np.zeros(n, dtype=np.uint8)
         rk, rb = g.runsK, g.runsB
         rc = self.lib.pp_stage_upload_compact(self.ns.h, g.gid, n, min(16, os.cpu_count() or 1), ptr[0].ctypes.data,
@@ -355,8 +377,42 @@ class HipEngine(object):
                 if ok[i]:
                     for q in (0, 1, 3, 4):
                         a = items[i][1][q]
-                        known[(q, id(a))] = (a, a.size) + ((int(a[0]), int(a[a.size // 2]), int(a[-1])) if a.size else (0, 0, 0))
+                        known[(q, id(a))] = (a, a.size) + _probe(a)
         return ok
+
+    def stage_upload_verified(self, g, slots, kd_ptr, bd_ptr):
+        """The same for blocks whose index arrays are the very objects verified at an earlier call (ascending slots,
+        addresses of their K and border data): nothing is compared, every block is staged and uploaded.  Returns at
+        once -- the library's host threads work while the caller prepares its next batch; stage_upload_end() waits."""
+        import os
+        kd = np.array(kd_ptr, dtype=np.uint64)
+        bd = np.array(bd_ptr, dtype=np.uint64)
+        sl = np.array(slots, dtype=np.int32)
+        rk, rb = g.runsK, g.runsB
+        rc = self.lib.pp_stage_upload_verified_begin(self.ns.h, g.gid, len(slots), min(16, os.cpu_count() or 1), kd.ctypes.data,
+                                                     bd.ctypes.data, ctypes.c_int64(g.nrawK), ctypes.c_int64(g.nraw - g.nrawK),
+                                                     rk.shape[0], rk.ctypes.data, rb.shape[0], rb.ctypes.data,
+                                                     g.staging.ctypes.data, sl.ctypes.data)
+        self.ns.check(rc, 'pp_stage_upload_verified_begin')
+
+    def stage_upload_end(self):
+        self.ns.check(self.lib.pp_stage_upload_end(self.ns.h), 'pp_stage_upload_end')
+
+    def upload_rhs_rows(self, g, vectors):
+        """vectors: one contiguous float64 vector of g.n entries per block of the group, slot order; through the pinned
+        staging array to the device, slice by slice (include/parapint_hip.h: pp_upload_rhs_rows)."""
+        import os
+        src = np.array([_addr(v) for v in vectors], dtype=np.uint64)
+        self.ns.check(self.lib.pp_upload_rhs_rows(self.ns.h, g.gid, len(vectors), min(16, os.cpu_count() or 1),
+                                                  src.ctypes.data, g.rhs_staging.ctypes.data), 'pp_upload_rhs_rows')
+
+    def download_solution_rows(self, g, pinned, out=None):
+        """Solutions of a group into the pinned array (asynchronous: synchronize() before reading), or through it
+        into ``out`` (pageable, complete on return)."""
+        import os
+        self.ns.check(self.lib.pp_download_solution_rows(self.ns.h, g.gid, min(16, os.cpu_count() or 1), pinned.ctypes.data,
+                                                         None if out is None else out.ctypes.data),
+                      'pp_download_solution_rows')
 
     def copy_rows(self, dst, rows):
         """rows: [(row index of dst, contiguous float64 vector of dst.shape[1] entries)] copied on host threads."""
@@ -774,6 +830,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
                     by_sig[raw_sig] = g
             bi = _BlockInfo()
             bi.group, bi.slot, bi.n = g, len(g.blocks), n
+            bi.seen = None
             bi.cmap = cmap
             bi.br_cache = None if cmap is None else ((br_global.__array_interface__['data'][0], br_global.size), br, br_global)
             # blocks whose raw COO order differs from the group's reference order are
@@ -982,28 +1039,87 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         """Values of every local block into the group's compact staging array (pinned), and on to the device."""
         last = self.block_dim - 1
         fast = getattr(self._eng, 'stage_upload', None)     # threaded compare + copy + overlapped H2D in the library
+        verified = getattr(self._eng, 'stage_upload_verified', None) if fast is not None else None
         batches = {}
         slow = {}
-        empty_i, empty_d = np.zeros(0, dtype=np.int32), np.zeros(0)
-        for ndx in self.local_block_indices:
-            bi = self._binfo[ndx]
-            g = bi.group
-            kr, kc, kd, _ = _coo(matrix.get_block(ndx, ndx))
-            br, bc, bd = self._border(matrix, ndx)
-            arrays = (kr, kc, kd, br, bc, bd)
-            if fast is not None and all(a.flags.c_contiguous for a in arrays) and \
-                    kr.dtype == kc.dtype == br.dtype == bc.dtype == np.int32 and kd.dtype == bd.dtype == np.float64:
-                batches.setdefault(g.gid, (g, []))[1].append((bi.slot, arrays))
-            else:
-                self._stage_block(g, bi.slot, *arrays)
-                slow.setdefault(g.gid, (g, []))[1].append(bi.slot)
+        quick = {}
+        get = matrix.get_block
+        binfo = self._binfo
+        started = [False]
+
+        def flush(q):
+            g, slots, kps, bps = q
+            if not slots:
+                return
+            if any(slots[i] >= slots[i + 1] for i in range(len(slots) - 1)):
+                order = sorted(range(len(slots)), key=slots.__getitem__)
+                slots, kps, bps = [slots[i] for i in order], [kps[i] for i in order], [bps[i] for i in order]
+            started[0] = True
+            verified(g, slots, kps, bps)
+            del q[1][:], q[2][:], q[3][:]
+
+        try:
+            for ndx in self.local_block_indices:
+                bi = binfo[ndx]
+                g = bi.group
+                K = get(ndx, ndx)
+                c = bi.seen
+                if c is not None and verified is not None:
+                    # the block's index arrays are the objects an earlier call compared with the group's reference order
+                    # (typical: the interface rewrites .data of the same COO blocks at every iteration, or hands out new
+                    # blocks over shared index arrays): only the two data addresses are needed.  The index arrays are
+                    # probed (first, middle, last entry) for having been rewritten in place.
+                    A = get(last, ndx)
+                    try:
+                        # (.coords: the (row, col) tuple of a SciPy >= 1.13 COO block; .row / .col are properties there)
+                        ck = getattr(K, 'coords', None) or (K.row, K.col)
+                        ca = getattr(A, 'coords', None) or (A.row, A.col)
+                        hit = ck[0] is c[0] and ck[1] is c[1] and ca[0] is c[2] and ca[1] is c[3]
+                    except AttributeError:
+                        hit = False
+                    if hit:
+                        kd, bd = K.data, A.data
+                        if kd.size == c[4] and bd.size == c[5] and kd.dtype.char == 'd' and bd.dtype.char == 'd' and \
+                                kd.strides == _S8 and bd.strides == _S8 and _probe(c[0]) == c[6] and _probe(c[1]) == c[7] and \
+                                _probe(c[2]) == c[8] and _probe(c[3]) == c[9]:
+                            q = quick.get(g.gid)
+                            if q is None:
+                                q = quick[g.gid] = (g, [], [], [])
+                            q[1].append(bi.slot)
+                            q[2].append(_addr(kd))
+                            q[3].append(_addr(bd) if c[5] else 0)
+                            if len(q[1]) == (256 if started[0] else 64):
+                                # on its way while the next blocks are looked at (the library's host threads stage and send)
+                                flush(q)
+                            continue
+                    bi.seen = None
+                kr, kc, kd, _ = _coo(K)
+                br, bc, bd = self._border(matrix, ndx)
+                arrays = (kr, kc, kd, br, bc, bd)
+                if fast is not None and all(a.flags.c_contiguous for a in arrays) and \
+                        kr.dtype == kc.dtype == br.dtype == bc.dtype == np.int32 and kd.dtype == bd.dtype == np.float64:
+                    batches.setdefault(g.gid, (g, []))[1].append((bi.slot, arrays, bi, K))
+                else:
+                    self._stage_block(g, bi.slot, *arrays)
+                    slow.setdefault(g.gid, (g, []))[1].append(bi.slot)
+            for q in quick.values():
+                flush(q)
+        finally:
+            if started[0]:
+                self._eng.stage_upload_end()            # (also on the way out with a changed pattern: no job stays in flight)
         for g, items in batches.values():
             items.sort(key=lambda it: it[0])
-            same = fast(g, items)
-            for ok, (slot, arrays) in zip(same, items):
+            same = fast(g, [it[:2] for it in items])
+            for ok, (slot, arrays, bi, K) in zip(same, items):
                 if not ok:
                     self._stage_block(g, slot, *arrays)
                     slow.setdefault(g.gid, (g, []))[1].append(slot)
+                elif verified is not None and getattr(K, 'format', None) == 'coo':
+                    A = get(last, g.blocks[slot])
+                    if getattr(A, 'format', None) == 'coo' and K.row is arrays[0] and K.col is arrays[1] and \
+                            A.col is arrays[4] and (A.row is arrays[3] or (bi.br_cache is not None and A.row is bi.br_cache[2])):
+                        bi.seen = (K.row, K.col, A.row, A.col, arrays[2].size, arrays[5].size,
+                                   _probe(K.row), _probe(K.col), _probe(A.row), _probe(A.col))
         if fast is None:
             for g in self._groups:
                 self._eng.upload_values_compact(g.gid, g.staging)
@@ -1230,7 +1346,9 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         if hasattr(matrix, 'value_maps'):
             self._guarded(res, self._bind_device_matrix, matrix)      # f2: values are gathered from the device sources
         else:
+            timer.start('values to device')
             self._guarded(res, self._stage_and_upload, matrix)
+            timer.stop('values to device')
         self._guarded(res, self._eng.numeric_factor_blocks)
         timer.stop('factorize')
         # the n_c solves + products per block of the reference (mpi_...:312-333) are the coupling rows of the same
@@ -1491,47 +1609,91 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             for g in self._groups:
                 self._eng.bind_native_vectors(g.gid, None, None)
         copy_rows = getattr(self._eng, 'copy_rows', None)
+        upload_rows = getattr(self._eng, 'upload_rhs_rows', None)
         pending = {}
+        get = rhs.get_block
+        binfo = self._binfo
+        nested = False
+        timer.start('rhs to device')
         for ndx in self.local_block_indices:
-            bi = self._binfo[ndx]
-            v = rhs.get_block(ndx)
-            if copy_rows is not None and isinstance(v, np.ndarray) and v.dtype == np.double and v.flags.c_contiguous \
-                    and v.size == bi.group.n:
-                pending.setdefault(bi.group.gid, (bi.group, []))[1].append((bi.slot, v))
+            bi = binfo[ndx]
+            v = get(ndx)
+            if copy_rows is not None and type(v) is np.ndarray and v.dtype.char == 'd' and v.strides == _S8 and v.size == bi.n:
+                p = pending.get(bi.group.gid)
+                if p is None:
+                    p = pending[bi.group.gid] = (bi.group, [], [])
+                p[1].append(bi.slot)
+                p[2].append(v)
             else:
+                nested = nested or hasattr(v, 'get_block')
                 bi.group.rhs_staging[bi.slot] = _flat(v)
-        for g, rows in pending.values():
-            copy_rows(g.rhs_staging, rows)                  # 75 MB at the headline size: on the library's host threads
+        uploaded = set()
+        for g, slots, vecs in pending.values():
+            if upload_rows is not None and len(slots) == len(g.blocks) and slots == list(range(len(slots))):
+                upload_rows(g, vecs)                        # staged and sent slice by slice, copies overlapping
+                uploaded.add(g.gid)
+            else:
+                copy_rows(g.rhs_staging, list(zip(slots, vecs)))       # 75 MB at the headline size: on the library's host threads
         for g in self._groups:
-            self._eng.upload_rhs(g.gid, g.rhs_staging)
+            if g.gid not in uploaded:
+                self._eng.upload_rhs(g.gid, g.rhs_staging)
+        timer.stop('rhs to device')
+        timer.start('solve')
         self._eng.solve_forward()
         self._eng.allreduce_rs(self.comm)
         rc = self._to_coupling_order(_flat(rhs.get_block(last))) if self._nc > 0 else None
         self._eng.solve_coupling(rc)
         self._eng.solve_backward()
+        timer.stop('solve')
+        timer.start('solution to host')
         xout = {}
+        rows_dl = getattr(self._eng, 'download_solution_rows', None)
+        in_flight = False
         for g in self._groups:
-            # one fresh array per group and call: its rows are handed out as the result blocks (no per-block copy;
-            # results of different calls never alias)
+            # one array per group and call: its rows are handed out as the result blocks (no per-block copy).  Default:
+            # a fresh array, so that results of different calls never alias -- filled through a pinned array by host
+            # threads; result_buffers = k > 0: k pinned arrays handed out in turn, written by the copy engine itself.
             if g.x_pool:
                 xout[g.gid] = g.x_pool[g.x_turn % len(g.x_pool)]
                 g.x_turn += 1
+                if rows_dl is not None:
+                    rows_dl(g, xout[g.gid])                 # asynchronous: the result structure is built meanwhile
+                    in_flight = True
+                else:
+                    self._eng.download_solution(g.gid, xout[g.gid])
             else:
                 xout[g.gid] = np.empty(g.x_shape, dtype=np.double)
-            self._eng.download_solution(g.gid, xout[g.gid])
-        coupling = self._from_coupling_order(self._eng.coupling_solution())
+                if rows_dl is not None and getattr(self._eng, 'alloc_pinned', None) is not None:
+                    if getattr(g, 'x_pinned', None) is None:
+                        g.x_pinned = self._eng.alloc_pinned(g.x_shape)
+                    rows_dl(g, g.x_pinned, xout[g.gid])
+                else:
+                    self._eng.download_solution(g.gid, xout[g.gid])
         # (mpi_...:390 uses copy_structure(); every local block and the coupling block are set below and non-local
         # blocks stay unset either way, so a container that can skip the zero-filled placeholders is asked to)
         result = rhs.copy_structure_unset() if hasattr(rhs, 'copy_structure_unset') else rhs.copy_structure()
-        for ndx in self.local_block_indices:
-            bi = self._binfo[ndx]
-            x = xout[bi.group.gid][bi.slot]
-            blk = rhs.get_block(ndx)
-            if hasattr(blk, 'get_block'):          # nested BlockVector (quirk Q9)
-                out = blk.copy_structure()
-                out.copyfrom(x)
-                x = out
-            result.set_block(ndx, x)
+        set_block = result.set_block
+        if nested:
+            for ndx in self.local_block_indices:
+                bi = binfo[ndx]
+                x = xout[bi.group.gid][bi.slot]
+                blk = get(ndx)
+                if hasattr(blk, 'get_block'):          # nested BlockVector (quirk Q9)
+                    if in_flight:
+                        self._eng.synchronize()
+                        in_flight = False
+                    out = blk.copy_structure()
+                    out.copyfrom(x)
+                    x = out
+                set_block(ndx, x)
+        else:
+            for ndx in self.local_block_indices:
+                bi = binfo[ndx]
+                set_block(ndx, xout[bi.group.gid][bi.slot])
+        coupling = self._from_coupling_order(self._eng.coupling_solution())
+        if in_flight:
+            self._eng.synchronize()
+        timer.stop('solution to host')
         blk = rhs.get_block(last)
         if hasattr(blk, 'get_block'):
             out = blk.copy_structure()

@@ -267,16 +267,13 @@ int ppsim_factor(void* h, const double* can, double* U, double* L, double* Dinv,
               const double v = can[-1 - fe.u];
               pa[fe.q] += v;
               pm[fe.q] = std::fmax(pm[fe.q], std::fabs(v));
-            } else if (fe.wk == 0) {
-              const double term = U[fe.u] * L[fe.l];
-              pa[fe.q] -= term;
-              pm[fe.q] = std::fmax(pm[fe.q], std::fabs(term));
             } else {
               const double su = U[fe.u];
-              for (int q = 0; q < w; ++q) {
-                const double term = su * L[fe.l + q * fe.wk];
-                pa[q] -= term;
-                pm[q] = std::fmax(pm[q], std::fabs(term));
+              const int q0 = fe.q & 15, qn = (fe.q >> 4) & 15;      // a run of columns of the destination row
+              for (int j = 0; j < qn; ++j) {
+                const double term = su * L[fe.l + j * fe.wk];
+                pa[q0 + j] -= term;
+                pm[q0 + j] = std::fmax(pm[q0 + j], std::fabs(term));
               }
             }
           }
@@ -297,16 +294,13 @@ int ppsim_factor(void* h, const double* can, double* U, double* L, double* Dinv,
             const double v = can[-1 - fe.u];
             acc[fe.q] += v;
             tmax[fe.q] = std::fmax(tmax[fe.q], std::fabs(v));
-          } else if (fe.wk == 0) {
-            const double term = U[fe.u] * L[fe.l];
-            acc[fe.q] -= term;
-            tmax[fe.q] = std::fmax(tmax[fe.q], std::fabs(term));
           } else {
             const double su = U[fe.u];
-            for (int q = 0; q < w; ++q) {
-              const double term = su * L[fe.l + q * fe.wk];
-              acc[q] -= term;
-              tmax[q] = std::fmax(tmax[q], std::fabs(term));
+            const int q0 = fe.q & 15, qn = (fe.q >> 4) & 15;      // a run of columns of the destination row
+            for (int j = 0; j < qn; ++j) {
+              const double term = su * L[fe.l + j * fe.wk];
+              acc[q0 + j] -= term;
+              tmax[q0 + j] = std::fmax(tmax[q0 + j], std::fabs(term));
             }
           }
         }
@@ -451,3 +445,27 @@ void ppsim_bk_solve(int n, const double* A, const int* ipiv, double* b) {
 }
 
 }  // extern "C"
+
+extern "C" {
+// per level (4 int64): product entries over all columns of the destination, over a shorter run of columns, initial-value
+// entries, columns covered by the shorter runs -- diagnostic
+void ppsim_entry_kinds(void* h, long long* out) {
+  Plan& P = *(Plan*)h;
+  for (int l = 0; l < P.n_levels; ++l) {
+    long long* o = out + 4 * l;
+    o[0] = o[1] = o[2] = o[3] = 0;
+    for (int t = P.flevel_ptr[l]; t < P.flevel_ptr[l + 1]; ++t) {
+      const auto& ft = P.ftasks[t];
+      if (ft.kind < 0) continue;
+      const int nrow = (ft.npieces > 1) ? 1 : ft.r1 - ft.r0;
+      for (int rr = 0; rr < nrow; ++rr)
+        for (int e = P.fdst_ptr[ft.dptr0 + rr]; e < P.fdst_ptr[ft.dptr0 + rr + 1]; ++e) {
+          const auto& fe = P.fentries[e];
+          if (fe.u < 0) o[2]++;
+          else if (((fe.q >> 4) & 15) == P.piv_w[ft.piv] || (ft.ws > 0 && ((fe.q >> 4) & 15) == ft.ws)) o[0]++;
+          else { o[1]++; o[3] += (fe.q >> 4) & 15; }
+        }
+    }
+  }
+}
+}

@@ -271,3 +271,77 @@ class HostSimEngine(object):
 
     def increase_memory_allocation(self, factor):
         self.mem_factor *= float(factor)
+
+
+class HostSimBoundaryEngine(HostSimEngine):
+    """The host interpreter with the HIP engine's host-boundary entry points (stage_upload, stage_upload_verified,
+    upload_rhs_rows, download_solution_rows, copy_rows, alloc_pinned) restated in numpy over the addresses the solver
+    hands over: the CPU check of the solver's fast paths (which blocks go where, with which pointers)."""
+
+    def __init__(self):
+        super().__init__()
+        self.calls = {'stage_upload': 0, 'stage_upload_verified': 0, 'upload_rhs_rows': 0, 'download_rows_async': 0,
+                      'download_rows_staged': 0, 'copy_rows': 0, 'compared_blocks': 0, 'verified_blocks': 0}
+
+    @staticmethod
+    def _view(addr, n, dtype=np.double):
+        import ctypes
+        if n == 0:
+            return np.zeros(0, dtype=dtype)
+        ct = ctypes.c_double if dtype == np.double else ctypes.c_int32
+        return np.ctypeslib.as_array((ct * n).from_address(int(addr)))
+
+    def alloc_pinned(self, shape):
+        return np.zeros(shape, dtype=np.double)
+
+    def bind_native_vectors(self, gid, rhs, x):
+        pass
+
+    def _stage_row(self, g, slot, kd, bd):
+        row = g.staging[slot]
+        for e0, ln, dst in g.runsK:
+            row[dst:dst + ln] = kd[e0:e0 + ln]
+        for e0, ln, dst in g.runsB:
+            row[dst:dst + ln] = bd[e0:e0 + ln]
+        self.upload_values_compact(g.gid, g.staging, slot, 1)
+
+    def stage_upload(self, g, items):
+        self.calls['stage_upload'] += 1
+        ref = g.raw_refs
+        ok = np.zeros(len(items), dtype=bool)
+        for i, (slot, (kr, kc, kd, br, bc, bd)) in enumerate(items):
+            self.calls['compared_blocks'] += 1
+            same = (kd.size == g.nrawK and bd.size == g.nraw - g.nrawK and np.array_equal(kr, ref[0]) and
+                    np.array_equal(kc, ref[1]) and np.array_equal(br, ref[2]) and np.array_equal(bc, ref[3]))
+            if same:
+                self._stage_row(g, slot, kd, bd)
+            ok[i] = same
+        return ok
+
+    def stage_upload_verified(self, g, slots, kd_ptr, bd_ptr):
+        self.calls['stage_upload_verified'] += 1
+        assert all(a < b for a, b in zip(slots, slots[1:]))
+        for slot, kp, bp in zip(slots, kd_ptr, bd_ptr):
+            self.calls['verified_blocks'] += 1
+            self._stage_row(g, slot, self._view(kp, g.nrawK), self._view(bp, g.nraw - g.nrawK))
+
+    def stage_upload_end(self):
+        self.calls['stage_upload_end'] = self.calls.get('stage_upload_end', 0) + 1
+
+    def copy_rows(self, dst, rows):
+        self.calls['copy_rows'] += 1
+        for r, v in rows:
+            dst[r] = v
+
+    def upload_rhs_rows(self, g, vectors):
+        self.calls['upload_rhs_rows'] += 1
+        assert len(vectors) == len(g.blocks)
+        for i, v in enumerate(vectors):
+            g.rhs_staging[i] = v
+        self.upload_rhs(g.gid, g.rhs_staging)
+
+    def download_solution_rows(self, g, pinned, out=None):
+        self.calls['download_rows_async' if out is None else 'download_rows_staged'] += 1
+        self.download_solution(g.gid, pinned)
+        if out is not None:
+            out[...] = pinned

@@ -846,3 +846,80 @@ def case_dynamic_regularised(make_engine, dense_limit=None):
     x = solver.do_back_solve(rhs)
     assert scaled_residual(kkt2.tocoo(), x.flatten(), rhs.flatten()) <= RESID_TOL
     return solver
+
+
+# ---- host boundary: which blocks take which way to the device --------------------------------------
+def case_boundary_fast_paths(make_engine, calls=None):
+    """do_numeric_factorization / do_back_solve with host blocks, over the ways an interface hands its matrix over:
+    new COO blocks over the same index arrays, the same blocks with .data rewritten in place or replaced, index arrays
+    rewritten in place (a different entry order for the same matrix), both result-buffer modes.  Every result is
+    checked against a dense solve; `calls` (the CPU engine's counters) tells which path the blocks took."""
+    N = 5
+    model = SyntheticKKT(N, 3, 8, 2)
+    comm = SerialComm()
+    rng = np.random.default_rng(5)
+
+    def dense_check(solver, kkt, rhs, x):
+        K = kkt.toarray()
+        b = rhs.flatten()
+        assert scaled_residual(K, x.flatten(), b) <= 1e-10
+
+    for buffers in (0, 2):
+        solver = new_solver(make_engine, N, result_buffers=buffers)
+        eng_calls = getattr(solver._eng, 'calls', None) if calls is None else calls
+        kkt = model.build_kkt(comm=comm, iteration=0)
+        rhs = model.build_rhs(comm=comm)
+        for ndx in range(N):
+            rhs.set_block(ndx, rng.standard_normal(model.block_dim))
+        solver.do_symbolic_factorization(kkt)
+        solver.do_numeric_factorization(kkt)
+        x0 = solver.do_back_solve(rhs)
+        dense_check(solver, kkt, rhs, x0)
+        x0_copy = x0.flatten().copy()
+        # new blocks over the same index arrays
+        kkt1 = model.build_kkt(comm=comm, iteration=1)
+        before = dict(eng_calls) if eng_calls is not None else None
+        solver.do_numeric_factorization(kkt1)
+        x1 = solver.do_back_solve(rhs)
+        dense_check(solver, kkt1, rhs, x1)
+        if eng_calls is not None:
+            assert eng_calls['verified_blocks'] - before['verified_blocks'] == N          # nothing compared again
+            assert eng_calls['compared_blocks'] == before['compared_blocks']
+            assert eng_calls['upload_rhs_rows'] > before['upload_rhs_rows']
+        if buffers == 0:
+            assert np.array_equal(x0.flatten(), x0_copy)       # fresh arrays per call: the earlier result is untouched
+        # the same blocks, .data rewritten in place / replaced by a new array
+        for ndx in range(N):
+            K = kkt1.get_block(ndx, ndx)
+            K.data[:] = model.block_values(ndx, 2)
+        solver.do_numeric_factorization(kkt1)
+        dense_check(solver, kkt1, rhs, solver.do_back_solve(rhs))
+        for ndx in range(N):
+            kkt1.get_block(ndx, ndx).data = np.array(model.block_values(ndx, 3))
+        solver.do_numeric_factorization(kkt1)
+        dense_check(solver, kkt1, rhs, solver.do_back_solve(rhs))
+        # a block in a float32 / strided .data: not taken by address
+        K = kkt1.get_block(1, 1)
+        K.data = np.array(model.block_values(1, 3))[::1].astype(np.float32).astype(np.float64)[::-1][::-1]
+        solver.do_numeric_factorization(kkt1)
+        dense_check(solver, kkt1, rhs, solver.do_back_solve(rhs))
+        # every block with index arrays of its own, then rewritten in place into another entry order (first and last
+        # entry exchanged): found by the probe of the index arrays
+        kkt2 = model.build_kkt(comm=comm, iteration=2)
+        for ndx in range(N):
+            K = kkt2.get_block(ndx, ndx)
+            kkt2.set_block(ndx, ndx, coo_matrix((K.data.copy(), (K.row.copy(), K.col.copy())), shape=K.shape))
+        solver.do_numeric_factorization(kkt2)
+        solver.do_numeric_factorization(kkt2)
+        dense_check(solver, kkt2, rhs, solver.do_back_solve(rhs))
+        K = kkt2.get_block(2, 2)
+        for a in (K.row, K.col, K.data):
+            a[0], a[-1] = a[-1].copy(), a[0].copy()
+        solver.do_numeric_factorization(kkt2)
+        dense_check(solver, kkt2, rhs, solver.do_back_solve(rhs))
+        # right-hand sides that are not plain float64 vectors go the general way
+        rhs2 = model.build_rhs(comm=comm)
+        for ndx in range(N):
+            rhs2.set_block(ndx, rng.standard_normal(model.block_dim))
+        rhs2._blocks[3] = rhs2._blocks[3].astype(np.float32)
+        dense_check(solver, kkt2, rhs2, solver.do_back_solve(rhs2))

@@ -703,3 +703,9 @@ def test_measurement_switches_select_paths_that_agree():
                                                "f, p = s._eng.bcr_block_paths()\nassert f + p == 63 and p > 0, (f, p)\nprint('dynamic ok', f, p)")
     out = subprocess.run([sys.executable, '-c', code3], env=env3, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     assert out.returncode == 0 and 'dynamic ok' in out.stdout.decode(), out.stdout.decode()[-3000:]
+
+
+def test_host_boundary_fast_paths_on_the_device():
+    """Host blocks in, host vectors out through pp_stage_upload_compact / pp_upload_rhs_rows / pp_download_solution_rows
+    (verified index arrays, data rewritten in place, both result-buffer modes), each result against a dense solve."""
+    sc.case_boundary_fast_paths(lambda: None)

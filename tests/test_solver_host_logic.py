@@ -3,7 +3,7 @@
 import pytest
 
 import solver_cases as sc
-from hostsim_engine import HostSimEngine
+from hostsim_engine import HostSimBoundaryEngine, HostSimEngine
 
 
 def make_engine():
@@ -100,3 +100,7 @@ def test_harness_sub_solver_switch():
     assert parse_args(['--method', 'fs', '--n_blocks', '3']).subproblem_solver == 'ma27'
     assert parse_args(['--method', 'psc', '--n_blocks', '3', '--subproblem_solver', 'mumps']).subproblem_solver == 'mumps'
     assert parse_args(['--method', 'ssc', '--n_blocks', '3', '--linear_solver', 'scipy']).subproblem_solver == 'scipy'
+
+
+def test_host_boundary_fast_paths():
+    sc.case_boundary_fast_paths(HostSimBoundaryEngine)
