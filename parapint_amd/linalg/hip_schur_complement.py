@@ -1166,15 +1166,17 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
 
     def _apply_value_maps(self):
         nsrc, maps = self._device_maps
+        checked = getattr(self, '_maps_checked', None) is maps       # (a pivot-order refresh: same maps, same groups)
         for g in self._groups:
             src, coef = maps[g.blocks[0]]
-            for ndx in g.blocks[1:]:
+            for ndx in (() if checked else g.blocks[1:]):
                 s2, c2 = maps[ndx]
-                if not (np.array_equal(src, s2) and np.array_equal(coef, c2)):
+                if not ((s2 is src or np.array_equal(src, s2)) and (c2 is coef or np.array_equal(coef, c2))):
                     raise ValueError('blocks of one pattern group must share one value map (block %d differs)' % ndx)
             if len(src) != g.nraw:
                 raise ValueError('value map of block %d has %d entries, the block has %d' % (g.blocks[0], len(src), g.nraw))
             self._eng.set_value_map(g.gid, nsrc, src, coef)
+        self._maps_checked = maps
 
     def device_layout(self):
         """{block index: (group id, lane)} of the local blocks, and {group id: (batch, padded batch, block dimension)}."""
@@ -1253,6 +1255,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         self._dev_results = []
         device_matrix = hasattr(matrix, 'value_maps')
         self._device_maps = (matrix.nsrc, matrix.value_maps) if device_matrix else None
+        self._maps_checked = None           # (new groups: the maps of their blocks are compared again)
         res = LinearSolverResults(LinearSolverStatus.successful)
         timer.start('factorize')
         self._guarded(res, self._build_groups, matrix.pattern if device_matrix else matrix)
