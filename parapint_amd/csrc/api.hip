@@ -52,8 +52,6 @@ void pp_destroy(pp_handle h) {
   if (h->ev_made)
     for (int i = 0; i < PP_NPHASE; ++i) { (void)hipEventDestroy(h->ev[i][0]); (void)hipEventDestroy(h->ev[i][1]); }
   for (hipEvent_t e : h->dl_events) (void)hipEventDestroy(e);
-  if (h->stage_stream2) (void)hipStreamDestroy(h->stage_stream2);
-  if (h->stage_ev2) (void)hipEventDestroy(h->stage_ev2);
   if (h->ev_corner_up) { (void)hipEventDestroy(h->ev_corner_up); (void)hipEventDestroy(h->ev_corner_done); (void)hipStreamDestroy(h->up_stream); }
   if (h->aux_made) {
     for (int i = 0; i < PP_MAX_SPLIT; ++i) { (void)hipStreamDestroy(h->aux[i]); (void)hipEventDestroy(h->ev_join[i]); }
@@ -1036,6 +1034,7 @@ int pp_stage_upload_compact(pp_handle h, int group, int nblocks, int nthreads, c
                             const int32_t* ref_br, const int32_t* ref_bc, int64_t ref_bnnz, int nruns_k, const int64_t* runs_k,
                             int nruns_b, const int64_t* runs_b, double* staging, const int32_t* slots, uint8_t* same_out) {
   Group* g = get_group(h, group);
+  if (h) { if (int rc = stage_job_finish(h)) return rc; }      // (the host threads serve one job at a time)
   if (!g || !h->symbolic_done) return fail(h, 3, "pp_stage_upload_compact: bad group or symbolic phase not finished");
   const StageArgs a{kr, kc, kd, knnz, br, bc, bd, bnnz, ref_kr, ref_kc, ref_knnz, ref_br, ref_bc, ref_bnnz, nruns_k, runs_k,
                     nruns_b, runs_b, staging, (int64_t)g->nraw_used, slots, same_out};
@@ -1071,7 +1070,7 @@ struct StageJob {
   double *staging = nullptr, *dev = nullptr;
   size_t stride = 0;
   int device = 0;
-  hipStream_t stream = nullptr, stream2 = nullptr;
+  hipStream_t stream = nullptr;
   void work() {
     bool device_set = false;
     for (;;) {
@@ -1086,8 +1085,7 @@ struct StageJob {
         // when the caller mixes paths; they are sent again by whoever stages them)
         if (!device_set) { (void)hipSetDevice(device); device_set = true; }
         const size_t r0 = (size_t)slots[(size_t)i0], r1 = (size_t)slots[(size_t)i1 - 1] + 1;
-        const hipError_t e = hipMemcpyAsync(dev + r0 * stride, staging + r0 * stride, (r1 - r0) * stride * sizeof(double), hipMemcpyHostToDevice,
-                                             (stream2 && (s & 1)) ? stream2 : stream);
+        const hipError_t e = hipMemcpyAsync(dev + r0 * stride, staging + r0 * stride, (r1 - r0) * stride * sizeof(double), hipMemcpyHostToDevice, stream);
         if (e != hipSuccess) { int zero = 0; err.compare_exchange_strong(zero, (int)e); }
       }
     }
@@ -1097,12 +1095,7 @@ int stage_job_finish(pp_handle h) {
   StageJob* j = (StageJob*)h->stage_job;
   if (!j) return 0;
   h->stage_pool.wait();
-  int e = j->err.load();
-  if (j->stream2) {        // what went over the second stream is ordered before the work that follows on the handle's stream
-    hipError_t e2 = hipEventRecord(h->stage_ev2, j->stream2);
-    if (e2 == hipSuccess) e2 = hipStreamWaitEvent(h->stream, h->stage_ev2, 0);
-    if (e == 0 && e2 != hipSuccess) e = (int)e2;
-  }
+  const int e = j->err.load();
   delete j;
   h->stage_job = nullptr;
   if (e != 0) return fail(h, 3, std::string("pp_stage_upload_verified_begin: copy failed: ") + hipGetErrorString((hipError_t)e));
@@ -1140,19 +1133,6 @@ int pp_stage_upload_verified_begin(pp_handle h, int group, int nblocks, int nthr
   for (auto& d : j->done) d.store(0, std::memory_order_relaxed);
   j->nblocks = nblocks; j->staging = staging; j->dev = g->raw_own; j->stride = (size_t)g->nraw_used;
   j->device = h->device; j->stream = h->stream;
-  static const bool two_streams = std::getenv("PP_STAGE_STREAMS") && std::atoi(std::getenv("PP_STAGE_STREAMS")) == 2;
-  if (two_streams) {
-    if (!h->stage_stream2 && (hipStreamCreateWithFlags(&h->stage_stream2, hipStreamNonBlocking) != hipSuccess ||
-                              hipEventCreateWithFlags(&h->stage_ev2, hipEventDisableTiming) != hipSuccess)) {
-      delete j;
-      return fail(h, 3, "pp_stage_upload_verified_begin: no second copy stream");
-    }
-    // (the copies must not overtake work already queued on the handle's stream that reads the old values)
-    hipError_t e2 = hipEventRecord(h->stage_ev2, h->stream);
-    if (e2 == hipSuccess) e2 = hipStreamWaitEvent(h->stage_stream2, h->stage_ev2, 0);
-    if (e2 != hipSuccess) { delete j; return fail(h, 3, "pp_stage_upload_verified_begin: stream ordering failed"); }
-    j->stream2 = h->stage_stream2;
-  }
   h->stage_job = j;
   const int nt = std::max(1, std::min(std::min(nthreads, 64), nblocks));
   if (h->stage_pool.start(nt, [j]() { j->work(); }) == 0) {      // no thread could be started: here and now
@@ -1171,6 +1151,7 @@ int pp_stage_upload_end(pp_handle h) { return h ? stage_job_finish(h) : 3; }
 // array [batch][n] to the device, the copy of a slice of rows overlapping the host threads' work on the next one.
 int pp_upload_rhs_rows(pp_handle h, int group, int nrows, int nthreads, const double* const* src, double* staging) {
   Group* g = get_group(h, group);
+  if (h) { if (int rc = stage_job_finish(h)) return rc; }      // (the host threads serve one job at a time)
   if (!g || !h->symbolic_done) return fail(h, 3, "pp_upload_rhs_rows: bad group or symbolic phase not finished");
   if (nrows != g->batch || !src || !staging) return fail(h, 3, "pp_upload_rhs_rows: one source row per block of the group is needed");
   PP_HIP(hipSetDevice(h->device));
@@ -1191,6 +1172,7 @@ int pp_upload_rhs_rows(pp_handle h, int group, int nrows, int nthreads, const do
 // returns when dst is complete.
 int pp_download_solution_rows(pp_handle h, int group, int nthreads, double* pinned, double* dst) {
   Group* g = get_group(h, group);
+  if (h) { if (int rc = stage_job_finish(h)) return rc; }      // (the host threads serve one job at a time)
   if (!g || !h->symbolic_done || !pinned) return fail(h, 3, "pp_download_solution_rows: bad group or no pinned array");
   if (!g->dev.xout) return fail(h, 3, "pp_download_solution_rows: no solution in the [instance][row] layout (native vectors bound?)");
   PP_HIP(hipSetDevice(h->device));

@@ -361,8 +361,6 @@ struct pp_solver {
   bool enqueue_threads = std::getenv("PP_NO_ENQUEUE_THREADS") == nullptr;   // one enqueuing host thread per group stream (measurement switch)
   EnqueuePool pool;
   StagePool stage_pool;
-  hipStream_t stage_stream2 = nullptr;   // second copy stream of the staged upload (PP_STAGE_STREAMS=2: measurement switch)
-  hipEvent_t stage_ev2 = nullptr;
   void* stage_job = nullptr;             // staging job in flight (pp_stage_upload_verified_begin .. pp_stage_upload_end), api.hip
   std::vector<hipEvent_t> dl_events;      // one per slice of a staged download (pp_download_solution_rows)
   long long* corner_pos = nullptr;      // sparse Q of a block-tridiagonal S: positions in the Schur layout, values

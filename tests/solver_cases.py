@@ -898,6 +898,12 @@ def case_boundary_fast_paths(make_engine, calls=None):
             kkt1.get_block(ndx, ndx).data = np.array(model.block_values(ndx, 3))
         solver.do_numeric_factorization(kkt1)
         dense_check(solver, kkt1, rhs, solver.do_back_solve(rhs))
+        # a read-only data array (its address cannot be taken through the buffer protocol: ndarray.ctypes instead)
+        ro = np.array(model.block_values(0, 3))
+        ro.flags.writeable = False
+        kkt1.get_block(0, 0).data = ro
+        solver.do_numeric_factorization(kkt1)
+        dense_check(solver, kkt1, rhs, solver.do_back_solve(rhs))
         # a block in a float32 / strided .data: not taken by address
         K = kkt1.get_block(1, 1)
         K.data = np.array(model.block_values(1, 3))[::1].astype(np.float32).astype(np.float64)[::-1][::-1]
