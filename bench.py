@@ -408,6 +408,7 @@ def main():
                     'algorithmic_bytes_per_launch': bytes_per_launch, 'avg_launch_us': 1e3 * dom_ms / dom_launches,
                     'model': 'SURVEY.md 8(d): B_fac = 12 z_K + 12 z_L etc.; build_model = the bytes this implementation '
                              'moves if every operand crosses HBM once (index data shared by the batch)',
+                    'frac_model': 'survey',            # (frac above: SURVEY 8(d) bytes; build_model below: this build's own count)
                     'build_model': {'bytes_per_launch': bb[dom] * B / dom_launches,
                                     'achieved': bb[dom] * B / (dom_ms * 1e-3) / 1e9,
                                     'frac': bb[dom] * B / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
@@ -415,7 +416,8 @@ def main():
                     'whole_iteration': {'survey_bytes': sb['total'] * B, 'build_bytes': bb['total'] * B,
                                         'GBps_survey': sb['total'] * B / (ms_per_step * 1e-3) / 1e9,
                                         'GBps_build': bb['total'] * B / (ms_per_step * 1e-3) / 1e9,
-                                        'frac': bb['total'] * B / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+                                        'frac_build_model': bb['total'] * B / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        'frac_survey_model': sb['total'] * B / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}}
 
     # dense phase (factorisation of S, replicated on every rank): fp64 MFMA work, SURVEY 8d F_S = n_c^3/3 + 4 n_c^2
     dense_phase = None
