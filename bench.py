@@ -454,7 +454,7 @@ def main():
                    'final_infeasibilities': list(hist[-1][:3]) if hist else None,
                    'scenarios': len(qps), 'block_dim': ipi.nb, 'n_coupling': ipi.nfs,
                    'inertia_retries_from_resident_values': sv.diagonal_shift_refactorizations,
-                   'pivot_order_refreshes': sv.pivot_order_refreshes,
+                   'pivot_order_refreshes': sv.pivot_order_refreshes, 'refresh_causes': dict(sv.refresh_causes),
                    'note': 'whole ip_solve_device call: symbolic phase, pivot-order refreshes and all retries included'}
         ok = ok and ip_loop['converged']
 

@@ -733,6 +733,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         self._pattern_only = False
         self._have_classes = False
         self.pivot_order_refreshes = 0      # numeric factorisations that needed a new static pivot sequence
+        self.refresh_causes = {'zero_pivot': 0, 'growth': 0}      # ... because of a zero pivot / of element growth in a block
         self.diagonal_shift_refactorizations = 0      # factorisations from resident values + a diagonal shift (f1)
         self._last_Q = None
         self._base_Q = None
@@ -1309,8 +1310,12 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         mine = 0
         for g in self._groups:
             slot = self._eng.find_zero_pivot(g.gid)
-            if slot < 0 and self._growth_guard:
+            if slot >= 0:
+                self.refresh_causes['zero_pivot'] += 1
+            elif self._growth_guard:
                 slot = self._eng.find_growth(g.gid)     # element growth beyond 1 / pivot_tolerance counts as a breakdown
+                if slot >= 0:
+                    self.refresh_causes['growth'] += 1
             if slot >= 0:
                 t = getattr(g, 'device_sources', None)
                 if self._device_maps is not None and t is not None:

@@ -31,8 +31,9 @@ for rep in range(2):
     status, iters = ip_solve_device(ipi, ipo)
     pr.disable()
     sv = ipo.linalg.solver
-    print('run %d: %s, %d iterations in %.3f s; refreshes %d, shifted refactorizations %d' %
-          (rep, status, iters, time.perf_counter() - t0, sv.pivot_order_refreshes, sv.diagonal_shift_refactorizations))
+    print('run %d: %s, %d iterations in %.3f s; refreshes %d %s, shifted refactorizations %d' %
+          (rep, status, iters, time.perf_counter() - t0, sv.pivot_order_refreshes, sv.refresh_causes,
+           sv.diagonal_shift_refactorizations))
 s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(45)
 print(s.getvalue())
