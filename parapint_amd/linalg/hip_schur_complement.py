@@ -708,6 +708,17 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             self._eng.set_pivot_tolerance(0.0 if symbolic_pivot_threshold is None else symbolic_pivot_threshold,
                                           0.0 if pivot_tolerance is None else pivot_tolerance)
         self._growth_guard = bool(pivot_tolerance)
+        # Opt-in (`refresh_thresholds`, e.g. (0.1, 0.3)): a static pivot sequence that has broken down is chosen again
+        # with a STRICTER 1x1 test (more 2x2 pivots) at the first and at every later refresh, as MA27 users raise cntl(1)
+        # when a factorisation turns out fragile (Ipopt: ma27_pivtol -> ma27_pivtolmax).  MEASURED on the QP of
+        # bench.py's ip_loop: with 1024 scenarios 155 iterations / 183 refreshes at 0.01 throughout against 66 / 6 with
+        # (0.1, 0.3) -- but with 256 scenarios 45 / 16 against, depending on rounding noise in the iterates, 46-48 / 6 or
+        # a run that ends in 'Exceeded maximum inertia correction' (2x2 pivots over two primal variables can cancel for
+        # other barrier values; 1x1 pivots on positive diagonals cannot).  Off by default.
+        self._u_user = (0.0 if symbolic_pivot_threshold is None else float(symbolic_pivot_threshold),
+                        0.0 if pivot_tolerance is None else float(pivot_tolerance))
+        self.refresh_thresholds = ()
+        self._u_symbolic_now = self._u_user[0]
         self._mapped = False                # blocks have local coupling rows + maps (dynamic problems)
         self._btd = None                    # (block size, blocks) of a block-tridiagonal S, else None: dense
         self._btd_sequential = False        # eliminate its blocks in ascending order instead of by cyclic reduction
@@ -733,6 +744,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         self._pattern_only = False
         self._have_classes = False
         self.pivot_order_refreshes = 0      # numeric factorisations that needed a new static pivot sequence
+        self.pivot_order_refreshes_since_symbolic = 0
         self.refresh_causes = {'zero_pivot': 0, 'growth': 0}      # ... because of a zero pivot / of element growth in a block
         self.diagonal_shift_refactorizations = 0      # factorisations from resident values + a diagonal shift (f1)
         self._last_Q = None
@@ -1255,6 +1267,10 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         self._classes = None
         self._dev_results = []
         device_matrix = hasattr(matrix, 'value_maps')
+        if getattr(self, '_u_symbolic_now', 0.0) != self._u_user[0] and hasattr(self._eng, 'set_pivot_tolerance'):
+            self._eng.set_pivot_tolerance(*self._u_user)        # (a new problem starts from the caller's threshold again)
+        self._u_symbolic_now = self._u_user[0]
+        self.pivot_order_refreshes_since_symbolic = 0
         self._device_maps = (matrix.nsrc, matrix.value_maps) if device_matrix else None
         self._maps_checked = None           # (new groups: the maps of their blocks are compared again)
         res = LinearSolverResults(LinearSolverStatus.successful)
@@ -1339,7 +1355,14 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         if self.comm.size > 1:
             anyone = int(self.comm.allreduce_max(np.array([mine], dtype=np.int64))[0])
         if mine:
+            steps = self.refresh_thresholds
+            if steps and hasattr(self._eng, 'set_pivot_tolerance'):
+                u = steps[min(self.pivot_order_refreshes_since_symbolic, len(steps) - 1)]
+                if u > max(self._u_symbolic_now, 0.01):
+                    self._u_symbolic_now = u
+                    self._eng.set_pivot_tolerance(u, self._u_user[1])
             self.pivot_order_refreshes += 1
+            self.pivot_order_refreshes_since_symbolic += 1
             self._run_symbolic()
         return bool(anyone)
 

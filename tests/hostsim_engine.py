@@ -31,6 +31,7 @@ class HostSimEngine(object):
         self.nc = 0
         self.budget = None
         self.mem_factor = 1.0
+        hu.lib().ppsim_set_pivot_tolerance(ctypes.c_double(0.0), ctypes.c_double(0.0))   # (process-wide in the interpreter: a new engine starts from the defaults)
 
     supports_block_tridiagonal = True     # (kept as a dense matrix in the permuted, padded ordering: the host logic --
                                           # ordering, padding, flat layouts, the clique table all-reduce -- is the same)

@@ -1,7 +1,7 @@
 """Where the device-resident interior-point loop of bench.py (ip_loop) spends its host time: cProfile of ip_solve_device
 on the bench's stochastic QP (run on the GPU box).
 
-    python tools/ip_profile.py [scenarios]
+    python tools/ip_profile.py [scenarios [symbolic pivot threshold]]
 """
 import cProfile
 import io
@@ -19,11 +19,13 @@ from parapint_amd.linalg.comm import SerialComm                                 
 from parapint_amd.linalg.hip_schur_complement import HipSchurComplementLinearSolver             # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+U_SYM = float(sys.argv[2]) if len(sys.argv) > 2 else None       # threshold of the static 1x1 / 2x2 choice (default 0.01)
 qps, fsi = random_stochastic_qp(N, n=120, n_fs=10, n_eq=30, n_ineq=40, seed=7)
 for rep in range(2):
     ipi = DeviceStochasticQPInterface(qps, fsi)
     ipo = IPOptions()
-    ipo.linalg.solver = HipSchurComplementLinearSolver({i: None for i in range(N)}, None, comm=SerialComm(), result_buffers=2)
+    ipo.linalg.solver = HipSchurComplementLinearSolver({i: None for i in range(N)}, None, comm=SerialComm(), result_buffers=2,
+                                                       symbolic_pivot_threshold=U_SYM)
     pr = cProfile.Profile()
     t0 = time.perf_counter()
     if rep:
@@ -56,7 +58,8 @@ def timed(name):
 
 ipi = DeviceStochasticQPInterface(qps, fsi)
 ipo = IPOptions()
-ipo.linalg.solver = HipSchurComplementLinearSolver({i: None for i in range(N)}, None, comm=SerialComm(), result_buffers=2)
+ipo.linalg.solver = HipSchurComplementLinearSolver({i: None for i in range(N)}, None, comm=SerialComm(), result_buffers=2,
+                                                       symbolic_pivot_threshold=U_SYM)
 lib = ipo.linalg.solver._eng.lib
 saved = {}
 for name in ('pp_begin_symbolic', 'pp_add_group', 'pp_end_symbolic', 'pp_set_value_map', 'pp_bind_schur_buffer', 'pp_find_zero_pivot',
