@@ -130,6 +130,7 @@ inline bool apply_plan_tune(PlanOptions& opt, const char* tune, std::string& bad
       else if (k == "row_split_factor") opt.row_split_factor = v;
       else if (k == "task_order") opt.task_order = (int)v;
       else if (k == "order_mode") opt.order_mode = (int)v;
+      else if (k == "pivot_threshold") opt.pivot_threshold = v;
       else if (k == "front_max") opt.front_max = (int)v;
       else if (k == "front_pad_frac") opt.front_pad_frac = v;
       else if (k == "front_scale_rows") opt.front_scale_rows = (int)v;

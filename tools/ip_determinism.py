@@ -19,9 +19,11 @@ for arg in sys.argv[1:]:
     qps, fsi = random_stochastic_qp(N, n=120, n_fs=10, n_eq=30, n_ineq=40, seed=7)
     ipi = DeviceStochasticQPInterface(qps, fsi)
     ipo = IPOptions()
-    ipo.linalg.solver = HipSchurComplementLinearSolver({i: None for i in range(N)}, None, comm=SerialComm(), result_buffers=2)
-    if os.environ.get('NO_ESCALATION'):
-        ipo.linalg.solver.refresh_thresholds = ()
+    u_sym = float(os.environ['U_SYM']) if os.environ.get('U_SYM') else None       # threshold of the static 1x1 / 2x2 choice
+    ipo.linalg.solver = HipSchurComplementLinearSolver({i: None for i in range(N)}, None, comm=SerialComm(), result_buffers=2,
+                                                       symbolic_pivot_threshold=u_sym)
+    if os.environ.get('ESCALATION'):
+        ipo.linalg.solver.refresh_thresholds = (0.1, 0.3)
     hist = []
     try:
         status, iters = ip_solve_device(ipi, ipo, history=hist)
