@@ -440,12 +440,8 @@ def main():
         qps, fsi = random_stochastic_qp(args.ip_scenarios, n=120, n_fs=10, n_eq=30, n_ineq=40, seed=7)
         ipi = DeviceStochasticQPInterface(qps, fsi)
         ipo = IPOptions()
-        # (symbolic_pivot_threshold: MA27's cntl(1) for the STATIC 1x1 / 2x2 choice.  Barrier diagonals of different
-        # scenarios end up 18 orders of magnitude apart; with the default 0.01 the sequence chosen on one scenario keeps
-        # breaking on others -- 155 iterations / 183 re-orderings for this problem against 67 / 12 at 0.1)
-        ip_u = 0.1
         ipo.linalg.solver = HipSchurComplementLinearSolver({i: None for i in range(len(qps))}, None, comm=SerialComm(),
-                                                           result_buffers=2, symbolic_pivot_threshold=ip_u)
+                                                           result_buffers=2)
         hist = []
         sync_all()
         t0 = time.perf_counter()
@@ -459,7 +455,6 @@ def main():
                    'scenarios': len(qps), 'block_dim': ipi.nb, 'n_coupling': ipi.nfs,
                    'inertia_retries_from_resident_values': sv.diagonal_shift_refactorizations,
                    'pivot_order_refreshes': sv.pivot_order_refreshes, 'refresh_causes': dict(sv.refresh_causes),
-                   'symbolic_pivot_threshold': ip_u,
                    'note': 'whole ip_solve_device call: symbolic phase, pivot-order refreshes and all retries included'}
         ok = ok and ip_loop['converged']
 

@@ -7,14 +7,14 @@ namespace {
 
 template <int WM>
 __device__ __forceinline__ void invert_and_scale(const GroupDev& g, int p, int w, int uoff, int doff, unsigned sub,
-                                                 int r0, int r1, double tmax_diag, bool publish, size_t bpad, int b,
+                                                 int r0, int r1, const double (&tmd)[WM], bool publish, size_t bpad, int b,
                                                  double eps) {
   const double* Up = g.U + (size_t)uoff * bpad + b;
   double* Lp = g.L + (size_t)uoff * bpad + b;
   double inv[WM * (WM + 1) / 2];
   int code;
   if (WM == 1) {
-    const pp::PivotResult pr = pp::invert_pivot(1, Up[0], 0.0, 0.0, tmax_diag, eps);
+    const pp::PivotResult pr = pp::invert_pivot(1, Up[0], 0.0, 0.0, tmd[0], eps);
     inv[0] = pr.i00;
     code = (pr.code & 3) | (((pr.code >> 2) & 3) << 4) | (((pr.code >> 4) & 3) << 8);
   } else {
@@ -24,7 +24,7 @@ __device__ __forceinline__ void invert_and_scale(const GroupDev& g, int p, int w
 #pragma unroll
       for (int j = 0; j < WM; ++j)
         blk[i * WM + j] = (i < w && j < w) ? Up[(size_t)(i * w + j) * bpad] : 0.0;
-    code = pp::invert_block_t<WM>(w, sub, blk, tmax_diag, eps, inv);
+    code = pp::invert_block_t<WM>(w, sub, blk, tmd, eps, inv);
   }
   if (publish) {
     double* invp = g.Dinv + (size_t)doff * bpad + b;
@@ -120,13 +120,12 @@ __global__ __launch_bounds__(64 * NW) void k_gather_flat(GroupDev g, int task0, 
   double* Tmd = g.Tm + ((size_t)boff + (size_t)r0 * wp + qoff) * bpad;
   const int nblk = (r0 < wp) ? (wp - r0) : 0;        // leading destination rows that belong to the pivot block
   const bool split = NW > 1 && npieces > 1;
-  double tmax_diag[NV];
+  double tmd[WM][NV];                                 // fused panels: term magnitudes of the diagonal entries of the pivot block
   double acc[WM][NV], tmax[WM][NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
-    tmax_diag[v] = 0.0;
 #pragma unroll
-    for (int q = 0; q < WM; ++q) { acc[q][v] = 0.0; tmax[q][v] = 0.0; }
+    for (int q = 0; q < WM; ++q) { acc[q][v] = 0.0; tmax[q][v] = 0.0; tmd[q][v] = 0.0; }
   }
   int d = 0;
   auto finalize = [&]() {
@@ -139,9 +138,9 @@ __global__ __launch_bounds__(64 * NW) void k_gather_flat(GroupDev g, int task0, 
         for (int q = 0; q < WM; ++q) {
           if (q < w) {
             if (kind == 0) stv<NV>(Tmd + (size_t)(d * wp + q) * bpad + b, tmax[q]);
-            else {
+            else if (q == d) {                      // (row d of the block: its diagonal entry is column d)
 #pragma unroll
-              for (int v = 0; v < NV; ++v) tmax_diag[v] = fmax(tmax_diag[v], tmax[q][v]);
+              for (int v = 0; v < NV; ++v) tmd[q][v] = tmax[q][v];
             }
           }
 #pragma unroll
@@ -271,8 +270,12 @@ __global__ __launch_bounds__(64 * NW) void k_gather_flat(GroupDev g, int task0, 
   while (d < nrow) finalize();
   if (kind == 1) {
 #pragma unroll
-    for (int v = 0; v < NV; ++v)
-      invert_and_scale<WM>(g, p, w, uoff, doff, sub, r0, r1, tmax_diag[v], true, bpad, (int)b + v, eps);
+    for (int v = 0; v < NV; ++v) {
+      double tv[WM];
+#pragma unroll
+      for (int q = 0; q < WM; ++q) tv[q] = tmd[q][v];
+      invert_and_scale<WM>(g, p, w, uoff, doff, sub, r0, r1, tv, true, bpad, (int)b + v, eps);
+    }
   }
 #ifdef PP_X_STAMPS
   if (stp) {
@@ -309,9 +312,13 @@ __global__ __launch_bounds__(64) void k_gather_level_lean(GroupDev g, int task0,
   double* Tmd = g.Tm + ((size_t)boff + (size_t)r0 * wp + qoff) * bpad + b;
   double* Ldst = g.L + ((size_t)uoff + (size_t)r0 * wp + qoff) * bpad + b;
   const int nblk = (r0 < wp) ? (wp - r0) : 0;
-  double tmax_diag[NV], inv1[NV], lmax = 0.0;
+  double tmd[WM][NV], inv1[NV], lmax = 0.0;           // (tmd: term magnitudes of the diagonal entries of a fused panel's block)
 #pragma unroll
-  for (int v = 0; v < NV; ++v) { tmax_diag[v] = 0.0; inv1[v] = 0.0; }
+  for (int v = 0; v < NV; ++v) {
+    inv1[v] = 0.0;
+#pragma unroll
+    for (int q = 0; q < WM; ++q) tmd[q][v] = 0.0;
+  }
   for (int d = 0; d < nrow; ++d) {
     double acc[WM][NV], tmax[WM][NV];
 #pragma unroll
@@ -372,9 +379,9 @@ __global__ __launch_bounds__(64) void k_gather_level_lean(GroupDev g, int task0,
       for (int q = 0; q < WM; ++q) {
         if (q < w) {
           if (kind == 0) stv<NV>(Tmd + (size_t)(d * wp + q) * bpad, tmax[q]);
-          else {
+          else if (q == d) {
 #pragma unroll
-            for (int v = 0; v < NV; ++v) tmax_diag[v] = fmax(tmax_diag[v], tmax[q][v]);
+            for (int v = 0; v < NV; ++v) tmd[q][v] = tmax[q][v];
           }
         }
       }
@@ -387,8 +394,12 @@ __global__ __launch_bounds__(64) void k_gather_level_lean(GroupDev g, int task0,
   }
   if (WM != 1 && kind == 1) {
 #pragma unroll
-    for (int v = 0; v < NV; ++v)
-      invert_and_scale<WM>(g, p, w, uoff, doff, sub, r0, r1, tmax_diag[v], true, bpad, (int)b + v, eps);
+    for (int v = 0; v < NV; ++v) {
+      double tv[WM];
+#pragma unroll
+      for (int q = 0; q < WM; ++q) tv[q] = tmd[q][v];
+      invert_and_scale<WM>(g, p, w, uoff, doff, sub, r0, r1, tv, true, bpad, (int)b + v, eps);
+    }
   }
 }
 
@@ -428,25 +439,23 @@ __global__ __launch_bounds__(64) void k_scale_level(GroupDev g, int task0, int c
   double* Lp = g.L + (size_t)uoff * bpad + b;
   // block, its term magnitudes and the first rows of the chunk are requested together (one round trip)
   constexpr int RV = 8;   // row values (rows * w) held while the block is inverted
-  double tm[WM * WM], blk[WM * WM], u[RV];
+  double tmd[WM], blk[WM * WM], u[RV];    // (tmd: term magnitudes of the diagonal entries, pivot.hpp)
 #pragma unroll
-  for (int i = 0; i < WM; ++i)
+  for (int i = 0; i < WM; ++i) {
+    const double tv = Tmp[(size_t)(i < w ? i * w + i : 0) * bpad];
+    tmd[i] = (i < w) ? tv : 0.0;
 #pragma unroll
     for (int j = 0; j < WM; ++j) {
       const bool in = i < w && j < w;
-      const size_t off = (size_t)(in ? i * w + j : 0) * bpad;
-      const double tv = Tmp[off], uv = Up[off];
-      tm[i * WM + j] = in ? tv : 0.0;
+      const double uv = Up[(size_t)(in ? i * w + j : 0) * bpad];
       blk[i * WM + j] = in ? uv : 0.0;
     }
+  }
   const int v0 = r0 * w, v1 = r1 * w;      // value range [v0, v1) of this chunk in the panel
 #pragma unroll
   for (int i = 0; i < RV; ++i) u[i] = Up[(size_t)min(v0 + i, v1 - 1) * bpad];
-  double tmax_diag = 0.0;
-#pragma unroll
-  for (int i = 0; i < WM * WM; ++i) tmax_diag = fmax(tmax_diag, tm[i]);
   double inv[WM * (WM + 1) / 2];
-  const int code = pp::invert_block_t<WM>(w, sub, blk, tmax_diag, eps, inv);
+  const int code = pp::invert_block_t<WM>(w, sub, blk, tmd, eps, inv);
   if (r0 == w) {
     double* invp = g.Dinv + (size_t)doff * bpad + b;
 #pragma unroll
@@ -499,7 +508,6 @@ __global__ __launch_bounds__(512) void k_front_invert(GroupDev g, FrontRec fr, d
   constexpr int WF = pp::PP_WF, RW = 2, NWV = WF / RW;   // rows of A per wave, waves
   __shared__ double rowk[2][2][WF][64];   // [step parity][first / second pivot row][column][lane]: the pivot rows before the step
   __shared__ double pinv[2][3][64];       // [step parity]: i00, i10, i11
-  __shared__ double red[NWV][64];
   __shared__ int cnt[NWV][64];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.x * 64 + lane;
@@ -507,31 +515,27 @@ __global__ __launch_bounds__(512) void k_front_invert(GroupDev g, FrontRec fr, d
   const int w = fr.w;
   double A[RW][WF];                       // rows RW wave .. of the block (all columns, both triangles)
   int codes = 0;                          // inertia counts of the pivots this wave owned: pos | neg << 8 | zero << 16
-  double tm = 0.0;
+  double m[RW];                           // largest term summed into the diagonal entry of each row so far (pivot.hpp: tmd)
 #pragma unroll
-  for (int r = 0; r < RW; ++r)
+  for (int r = 0; r < RW; ++r) {
+    const int i = RW * wave + r;
+    m[r] = (i < w) ? g.Tm[((size_t)fr.boff + (size_t)(i * w + i)) * bpad + b] : 0.0;
 #pragma unroll
     for (int j = 0; j < WF; ++j) {
-      const int i = RW * wave + r;
       const bool in = i < w && j < w;
       const int hi = i > j ? i : j, lo = i > j ? j : i;       // (the lower triangle of the gathered block is the matrix)
       const size_t off = (size_t)(in ? hi * w + lo : 0) * bpad + b;
-      const double av = g.U[(size_t)fr.uoff * bpad + off], tv = g.Tm[(size_t)fr.boff * bpad + off];
+      const double av = g.U[(size_t)fr.uoff * bpad + off];
       A[r][j] = in ? av : 0.0;
-      tm = fmax(tm, in ? tv : 0.0);
     }
+  }
 #ifdef PP_X_STAMPS
   unsigned long long* stp = (pp_x_stamps && lane == 0) ? pp_x_stamps + 4000000 + 16 * ((size_t)blockIdx.x * NWV + wave) : nullptr;
   int stamp_k = 2;
   if (stp) stp[0] = __builtin_amdgcn_s_memrealtime();
 #endif
-  red[wave][lane] = tm;
-  __syncthreads();
-  double colmax = 0.0;
-#pragma unroll
-  for (int i = 0; i < NWV; ++i) colmax = fmax(colmax, red[i][lane]);
 #ifdef PP_X_STAMPS
-  if (stp) stp[1] = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(colmax == 1.2345e300);
+  if (stp) stp[1] = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(m[0] == 1.2345e300);
 #endif
   // The step loop is unrolled: every register index below is a constant (a rolled loop selects the pivot column with
   // compare / select pairs per element: 1.75 us per step, measured).  One barrier per 1x1 step: the buffers of a
@@ -550,7 +554,7 @@ __global__ __launch_bounds__(512) void k_front_invert(GroupDev g, FrontRec fr, d
       if (wave == ow) {
 #pragma unroll
         for (int j = 0; j < WF; ++j) rowk[par][0][j][lane] = A[orow][j];
-        const pp::PivotResult pr = pp::invert_pivot(1, A[orow][k], 0.0, 0.0, colmax, eps);
+        const pp::PivotResult pr = pp::invert_pivot(1, A[orow][k], 0.0, 0.0, m[orow], eps);
         pinv[par][0][lane] = pr.i00;
         codes += (pr.code & 3) | (((pr.code >> 2) & 3) << 8) | (((pr.code >> 4) & 3) << 16);
       }
@@ -562,6 +566,8 @@ __global__ __launch_bounds__(512) void k_front_invert(GroupDev g, FrontRec fr, d
 #pragma unroll
       for (int r = 0; r < RW; ++r) {      // (the owner's pivot row is overwritten below)
         const double l = A[r][k] * i00;
+        // (the update of the row's own diagonal entry counts as a term of that sum: column RW wave + r of the pivot row)
+        m[r] = fmax(m[r], fabs(l * rowk[par][0][min(RW * wave + r, WF - 1)][lane]));
 #pragma unroll
         for (int j = 0; j < WF; ++j)
           if (j != k) A[r][j] -= l * rk[j];
@@ -583,7 +589,7 @@ __global__ __launch_bounds__(512) void k_front_invert(GroupDev g, FrontRec fr, d
       }
       __syncthreads();
       if (wave == ow) {       // (a, b, c) = A[k][k], A[k1][k], A[k1][k1]
-        const pp::PivotResult pr = pp::invert_pivot(2, A[orow][k], rowk[par][1][k][lane], rowk[par][1][k1][lane], colmax, eps);
+        const pp::PivotResult pr = pp::invert_pivot(2, A[orow][k], rowk[par][1][k][lane], rowk[par][1][k1][lane], 0.0, eps);
         pinv[par][0][lane] = pr.i00; pinv[par][1][lane] = pr.i10; pinv[par][2][lane] = pr.i11;
         codes += (pr.code & 3) | (((pr.code >> 2) & 3) << 8) | (((pr.code >> 4) & 3) << 16);
       }
@@ -596,6 +602,10 @@ __global__ __launch_bounds__(512) void k_front_invert(GroupDev g, FrontRec fr, d
       for (int r = 0; r < RW; ++r) {      // (the owners' pivot rows are overwritten below)
         const double l0 = A[r][k] * i00 + A[r][k1] * i10;
         const double l1 = A[r][k] * i10 + A[r][k1] * i11;
+        {
+          const int ci = min(RW * wave + r, WF - 1);
+          m[r] = fmax(m[r], fmax(fabs(l0 * rowk[par][0][ci][lane]), fabs(l1 * rowk[par][1][ci][lane])));
+        }
 #pragma unroll
         for (int j = 0; j < WF; ++j)
           if (j != k && j != k1) A[r][j] -= l0 * rk[j] + l1 * rk1[j];

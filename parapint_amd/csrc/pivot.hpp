@@ -53,14 +53,22 @@ PP_HD PivotResult invert_pivot(int w, double a, double b, double c, double colma
 // the static sequence, so inertia and the zero-pivot rule are those of invert_pivot.  On exit
 // `inv` holds inv(A) packed by rows of the lower triangle (t, t' <= t at t(t+1)/2 + t').
 // code: pos | neg << 4 | zero << 8.
+// tmd[i]: the largest magnitude among the terms that were summed into diagonal entry (i, i) when the block was
+// gathered.  The zero test of a 1x1 sub-pivot compares it with the largest term of ITS OWN sum -- the gathered ones and
+// the updates it received inside the block -- as the gather kernels do for a scalar pivot: a pivot is numerically
+// zero when it is rounding noise of what was added up to form it.  (Rounds 1-2 took one bound for the whole block; a
+// block pivot that holds a primal variable with a barrier weight of 1e7 next to a constraint row with -1e-7 then
+// reported the second, perfectly accurate, pivot as zero: round 3)
 #ifndef PP_WMAX
 #define PP_WMAX 4
 #endif
 
 template <int WB>
-PP_HD int invert_block_t(int w, unsigned sub, const double* a /* row-major with stride WB, lower triangle read */, double colmax,
-                         double eps, double* inv) {
-  double A[WB][WB];
+PP_HD int invert_block_t(int w, unsigned sub, const double* a /* row-major with stride WB, lower triangle read */,
+                         const double* tmd /* [WB] */, double eps, double* inv) {
+  double A[WB][WB], m[WB];
+#pragma unroll
+  for (int i = 0; i < WB; ++i) m[i] = (i < w) ? tmd[i] : 0.0;
 #pragma unroll
   for (int i = 0; i < WB; ++i)
 #pragma unroll
@@ -76,11 +84,14 @@ PP_HD int invert_block_t(int w, unsigned sub, const double* a /* row-major with 
     if (second) { second = false; continue; }
     const bool two = ((sub >> k) & 1u) && (k + 1 < w);
     if (!two) {
-      const PivotResult pr = invert_pivot(1, A[k][k], 0.0, 0.0, colmax, eps);
+      const PivotResult pr = invert_pivot(1, A[k][k], 0.0, 0.0, m[k], eps);
       pos += pr.code & 3; neg += (pr.code >> 2) & 3; zero += (pr.code >> 4) & 3;
       double l[WB];
 #pragma unroll
       for (int i = 0; i < WB; ++i) l[i] = A[i][k] * pr.i00;
+#pragma unroll
+      for (int i = 0; i < WB; ++i)
+        if (i != k) m[i] = fmax(m[i], fabs(l[i] * A[k][i]));
 #pragma unroll
       for (int i = 0; i < WB; ++i)
 #pragma unroll
@@ -93,7 +104,7 @@ PP_HD int invert_block_t(int w, unsigned sub, const double* a /* row-major with 
     } else {
       second = true;
       const int k1 = k + 1 < WB ? k + 1 : k;
-      const PivotResult pr = invert_pivot(2, A[k][k], A[k1][k], A[k1][k1], colmax, eps);
+      const PivotResult pr = invert_pivot(2, A[k][k], A[k1][k], A[k1][k1], 0.0, eps);   // (a 2x2 pivot is tested by its determinant)
       pos += pr.code & 3; neg += (pr.code >> 2) & 3; zero += (pr.code >> 4) & 3;
       double l0[WB], l1[WB];
 #pragma unroll
@@ -101,6 +112,9 @@ PP_HD int invert_block_t(int w, unsigned sub, const double* a /* row-major with 
         l0[i] = A[i][k] * pr.i00 + A[i][k1] * pr.i10;
         l1[i] = A[i][k] * pr.i10 + A[i][k1] * pr.i11;
       }
+#pragma unroll
+      for (int i = 0; i < WB; ++i)
+        if (i != k && i != k1) m[i] = fmax(m[i], fmax(fabs(l0[i] * A[k][i]), fabs(l1[i] * A[k1][i])));
 #pragma unroll
       for (int i = 0; i < WB; ++i)
 #pragma unroll
@@ -127,17 +141,20 @@ PP_HD int invert_block_t(int w, unsigned sub, const double* a /* row-major with 
 // pivot rows themselves are scaled in place.  A is the full symmetric matrix, row-major with stride WF; inv is
 // packed like invert_block_t's.  This function is the definition the kernel is tested against (tests/hostsim).
 constexpr int PP_WF = 16;
-PP_HD int invert_front(int w, unsigned sub, double* A /* [PP_WF * PP_WF], rows >= w ignored */, double colmax, double eps,
-                       double* inv) {
+PP_HD int invert_front(int w, unsigned sub, double* A /* [PP_WF * PP_WF], rows >= w ignored */, const double* tmd /* [PP_WF] */,
+                       double eps, double* inv) {
   int pos = 0, neg = 0, zero = 0;
+  double m[PP_WF];
+  for (int i = 0; i < PP_WF; ++i) m[i] = (i < w) ? tmd[i] : 0.0;
   for (int k = 0; k < w; ++k) {
     const bool two = ((sub >> k) & 1u) && (k + 1 < w);
     if (!two) {
-      const PivotResult pr = invert_pivot(1, A[k * PP_WF + k], 0.0, 0.0, colmax, eps);
+      const PivotResult pr = invert_pivot(1, A[k * PP_WF + k], 0.0, 0.0, m[k], eps);
       pos += pr.code & 3; neg += (pr.code >> 2) & 3; zero += (pr.code >> 4) & 3;
       for (int i = 0; i < w; ++i) {
         if (i == k) continue;
         const double l = A[i * PP_WF + k] * pr.i00;
+        m[i] = fmax(m[i], fabs(l * A[k * PP_WF + i]));
         for (int j = 0; j < w; ++j)
           if (j != k) A[i * PP_WF + j] -= l * A[k * PP_WF + j];
         A[i * PP_WF + k] = l;
@@ -147,12 +164,13 @@ PP_HD int invert_front(int w, unsigned sub, double* A /* [PP_WF * PP_WF], rows >
       A[k * PP_WF + k] = -pr.i00;
     } else {
       const int k1 = k + 1;
-      const PivotResult pr = invert_pivot(2, A[k * PP_WF + k], A[k1 * PP_WF + k], A[k1 * PP_WF + k1], colmax, eps);
+      const PivotResult pr = invert_pivot(2, A[k * PP_WF + k], A[k1 * PP_WF + k], A[k1 * PP_WF + k1], 0.0, eps);
       pos += pr.code & 3; neg += (pr.code >> 2) & 3; zero += (pr.code >> 4) & 3;
       for (int i = 0; i < w; ++i) {
         if (i == k || i == k1) continue;
         const double l0 = A[i * PP_WF + k] * pr.i00 + A[i * PP_WF + k1] * pr.i10;
         const double l1 = A[i * PP_WF + k] * pr.i10 + A[i * PP_WF + k1] * pr.i11;
+        m[i] = fmax(m[i], fmax(fabs(l0 * A[k * PP_WF + i]), fabs(l1 * A[k1 * PP_WF + i])));
         for (int j = 0; j < w; ++j)
           if (j != k && j != k1) A[i * PP_WF + j] -= l0 * A[k * PP_WF + j] + l1 * A[k1 * PP_WF + j];
         A[i * PP_WF + k] = l0; A[i * PP_WF + k1] = l1;
@@ -173,8 +191,9 @@ PP_HD int invert_front(int w, unsigned sub, double* A /* [PP_WF * PP_WF], rows >
 }
 
 // bound = the widest block the build supports
-PP_HD int invert_block(int w, unsigned sub, const double* a /* stride PP_WMAX */, double colmax, double eps, double* inv) {
-  return invert_block_t<PP_WMAX>(w, sub, a, colmax, eps, inv);
+PP_HD int invert_block(int w, unsigned sub, const double* a /* stride PP_WMAX */, const double* tmd /* [PP_WMAX] */, double eps,
+                       double* inv) {
+  return invert_block_t<PP_WMAX>(w, sub, a, tmd, eps, inv);
 }
 
 }  // namespace pp

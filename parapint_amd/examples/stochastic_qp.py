@@ -13,13 +13,18 @@ from scipy.sparse import coo_matrix
 from parapint_amd.interfaces.interface import QuadraticProgram
 
 
-def random_stochastic_qp(n_scenarios, n=24, n_fs=4, n_eq=6, n_ineq=8, seed=0):
+def random_stochastic_qp(n_scenarios, n=24, n_fs=4, n_eq=6, n_ineq=8, seed=0, duplicate_eq_row=False):
+    """duplicate_eq_row: the last equality constraint of every scenario is stated twice -- the Jacobian loses rank and the
+    KKT matrix is singular at every iterate, so the inertia-correction loop (interior_point.py:364-392) must regularise the
+    constraint block in every iteration."""
     rng = np.random.default_rng(seed)
     # shared patterns
     hr = np.concatenate([np.arange(n), np.arange(1, n)])
     hc = np.concatenate([np.arange(n), np.arange(0, n - 1)])
     er = np.repeat(np.arange(n_eq), 3)
     ec = np.concatenate([np.sort(rng.choice(n, size=3, replace=False)) for _ in range(n_eq)])
+    if duplicate_eq_row:
+        ec[-3:] = ec[-6:-3]
     ir = np.repeat(np.arange(n_ineq), 3)
     ic = np.concatenate([np.sort(rng.choice(n, size=3, replace=False)) for _ in range(n_ineq)])
     z_star = rng.uniform(1.0, 2.0, size=n_fs)
@@ -31,7 +36,10 @@ def random_stochastic_qp(n_scenarios, n=24, n_fs=4, n_eq=6, n_ineq=8, seed=0):
         r = np.random.default_rng(1000 * seed + i + 1)
         hd = np.concatenate([r.uniform(2.0, 4.0, size=n), r.uniform(-0.4, 0.4, size=n - 1)])
         H = coo_matrix((hd, (hr, hc)), shape=(n, n))
-        Ae = coo_matrix((r.normal(size=er.size), (er, ec)), shape=(n_eq, n))
+        ev = r.normal(size=er.size)
+        if duplicate_eq_row:
+            ev[-3:] = ev[-6:-3]
+        Ae = coo_matrix((ev, (er, ec)), shape=(n_eq, n))
         Ai = coo_matrix((r.normal(size=ir.size), (ir, ic)), shape=(n_ineq, n))
         x_star = r.uniform(1.0, 3.0, size=n)
         x_star[:n_fs] = z_star

@@ -26,6 +26,7 @@ struct HostCtx {
 static int g_sn_wmax = 0, g_sn_tol = -1, g_batch_hint = 0;
 static double g_growth_bound = 1e8, g_pivot_threshold = 0.0;   // as pp_set_pivot_tolerance
 static int g_last_growth = 0, g_growth_fatal = 0;
+static int g_first_zero_piv = -1;      // first block pivot of the last ppsim_factor call that held a numerically zero sub-pivot (diagnostic)
 
 extern "C" {
 
@@ -39,6 +40,7 @@ void ppsim_set_pivot_tolerance(double u_symbolic, double u_runtime) {
   g_growth_fatal = u_runtime > 0.0;
 }
 int ppsim_growth_fatal() { return g_growth_fatal; }
+int ppsim_first_zero_pivot() { return g_first_zero_piv; }
 int ppsim_last_growth() { return g_last_growth; }
 
 void* ppsim_create(int n, int nc, int nnzK, const int* rowK, const int* colK, int nnzB, const int* rowB,
@@ -242,6 +244,7 @@ int ppsim_factor(void* h, const double* can, double* U, double* L, double* Dinv,
                  double eps) {
   Plan& P = *(Plan*)h;
   g_last_growth = 0;
+  g_first_zero_piv = -1;
   std::memset(U, 0, sizeof(double) * P.usize);
   std::memset(L, 0, sizeof(double) * P.usize);
   std::vector<double> Tm((size_t)std::max(P.bsize, 1), 0.0);
@@ -253,7 +256,7 @@ int ppsim_factor(void* h, const double* can, double* U, double* L, double* Dinv,
       if (t.kind < 0) continue;                       // quad padding
       const int p = t.piv, wp = P.piv_w[p], w = t.ws > 0 ? t.ws : wp, qoff = t.qoff;   // w: columns of the task's slice
       const int nrow = t.r1 - t.r0;
-      double blk[PP_WMAX * PP_WMAX] = {0}, tmax_diag = 0.0, inv[PP_WMAX * (PP_WMAX + 1) / 2] = {0};
+      double blk[PP_WMAX * PP_WMAX] = {0}, tmd[PP_WMAX] = {0}, inv[PP_WMAX * (PP_WMAX + 1) / 2] = {0};
       if (t.npieces > 1) {
         // one long row gathered by the waves of a quad: partial sums per piece, added in piece order by piece 0
         if (t.piece != 0) continue;                   // (the pieces follow piece 0 in the task list)
@@ -308,13 +311,14 @@ int ppsim_factor(void* h, const double* can, double* U, double* L, double* Dinv,
           U[P.piv_uoff[p] + (int64_t)slot * wp + qoff + q] = acc[q];
           if (slot < wp) {
             if (t.kind == 0) Tm[P.piv_boff[p] + (slot * wp + qoff + q)] = tmax[q];
-            else { blk[slot * PP_WMAX + q] = acc[q]; tmax_diag = std::fmax(tmax_diag, tmax[q]); }
+            else { blk[slot * PP_WMAX + q] = acc[q]; if (q == slot) tmd[slot] = tmax[q]; }   // (term magnitudes of the diagonal entries)
           }
         }
         if (t.kind == 1 && slot == w - 1) {
-          const int code = pp::invert_block(w, P.piv_sub[p], blk, tmax_diag, eps, inv);
+          const int code = pp::invert_block(w, P.piv_sub[p], blk, tmd, eps, inv);
           for (int q = 0; q < w * (w + 1) / 2; ++q) Dinv[P.piv_doff[p] + q] = inv[q];
           pos += code & 15; neg += (code >> 4) & 15; zero += (code >> 8) & 15;
+          if (((code >> 8) & 15) && g_first_zero_piv < 0) g_first_zero_piv = p;
         }
       }
       if (t.kind == 1) scale_rows(P, p, t.r0, t.r1, &Dinv[P.piv_doff[p]], U, L);
@@ -323,31 +327,33 @@ int ppsim_factor(void* h, const double* can, double* U, double* L, double* Dinv,
     for (int ti = P.slevel_ptr[lvl]; ti < P.slevel_ptr[lvl + 1]; ++ti) {
       const auto& t = P.stasks[ti];
       const int p = t.piv, w = P.piv_w[p];
-      double blk[PP_WMAX * PP_WMAX] = {0}, tmax_diag = 0.0, inv[PP_WMAX * (PP_WMAX + 1) / 2] = {0};
+      double blk[PP_WMAX * PP_WMAX] = {0}, tmd[PP_WMAX] = {0}, inv[PP_WMAX * (PP_WMAX + 1) / 2] = {0};
       for (int q = 0; q < w * w; ++q) {
         blk[(q / w) * PP_WMAX + q % w] = U[P.piv_uoff[p] + q];
-        tmax_diag = std::fmax(tmax_diag, Tm[P.piv_boff[p] + q]);
+        if (q / w == q % w) tmd[q / w] = Tm[P.piv_boff[p] + q];
       }
-      const int code = pp::invert_block(w, P.piv_sub[p], blk, tmax_diag, eps, inv);
+      const int code = pp::invert_block(w, P.piv_sub[p], blk, tmd, eps, inv);
       if (t.r0 == w) {
         for (int q = 0; q < w * (w + 1) / 2; ++q) Dinv[P.piv_doff[p] + q] = inv[q];
         pos += code & 15; neg += (code >> 4) & 15; zero += (code >> 8) & 15;
+          if (((code >> 8) & 15) && g_first_zero_piv < 0) g_first_zero_piv = p;
       }
       scale_rows(P, p, t.r0, t.r1, inv, U, L);
     }
     // root front: inversion of its gathered pivot block (k_front_invert), rows scaled with the explicit inverse (k_scale_wide)
     if (P.front_piv >= 0 && P.piv_level[P.front_piv] == lvl) {
       const int p = P.front_piv, w = P.piv_w[p];
-      double A[pp::PP_WF * pp::PP_WF] = {0}, tmax_diag = 0.0, finv[pp::PP_WF * (pp::PP_WF + 1) / 2] = {0};
+      double A[pp::PP_WF * pp::PP_WF] = {0}, tmd[pp::PP_WF] = {0}, finv[pp::PP_WF * (pp::PP_WF + 1) / 2] = {0};
       for (int i = 0; i < w; ++i)
         for (int j = 0; j < w; ++j) {
           const int hi = i > j ? i : j, lo = i > j ? j : i;       // (the lower triangle of the gathered block is the matrix)
           A[i * pp::PP_WF + j] = U[P.piv_uoff[p] + (int64_t)hi * w + lo];
-          tmax_diag = std::fmax(tmax_diag, Tm[P.piv_boff[p] + hi * w + lo]);
+          if (i == j) tmd[i] = Tm[P.piv_boff[p] + i * w + i];
         }
-      const int code = pp::invert_front(w, P.piv_sub[p], A, tmax_diag, eps, finv);
+      const int code = pp::invert_front(w, P.piv_sub[p], A, tmd, eps, finv);
       for (int q = 0; q < w * (w + 1) / 2; ++q) Dinv[P.piv_doff[p] + q] = finv[q];
       pos += code & 15; neg += (code >> 4) & 15; zero += (code >> 8) & 15;
+          if (((code >> 8) & 15) && g_first_zero_piv < 0) g_first_zero_piv = p;
       for (auto& t : P.wtasks) scale_rows(P, p, t.r0, t.r1, finv, U, L);
     }
   }
@@ -420,7 +426,9 @@ int ppsim_invert_block(int w, unsigned sub, const double* a, double colmax, doub
   double blk[PP_WMAX * PP_WMAX] = {0};
   for (int i = 0; i < w; ++i)
     for (int j = 0; j < w; ++j) blk[i * PP_WMAX + j] = a[i * w + j];
-  return pp::invert_block(w, sub, blk, colmax, eps, inv);
+  double tmd[PP_WMAX];
+  for (int i = 0; i < PP_WMAX; ++i) tmd[i] = colmax;      // (one bound for every diagonal entry)
+  return pp::invert_block(w, sub, blk, tmd, eps, inv);
 }
 
 // root front: static-order sweeps on a w x w block (row-major, stride w; lower triangle read): code, inv packed lower
@@ -428,7 +436,9 @@ int ppsim_invert_front(int w, unsigned sub, const double* a, double colmax, doub
   double A[pp::PP_WF * pp::PP_WF] = {0};
   for (int i = 0; i < w; ++i)
     for (int j = 0; j < w; ++j) { const int hi = i > j ? i : j, lo = i > j ? j : i; A[i * pp::PP_WF + j] = a[hi * w + lo]; }
-  return pp::invert_front(w, sub, A, colmax, eps, inv);
+  double tmd[pp::PP_WF];
+  for (int i = 0; i < pp::PP_WF; ++i) tmd[i] = colmax;
+  return pp::invert_front(w, sub, A, tmd, eps, inv);
 }
 
 // dense Bunch-Kaufman on a column-major n x n matrix (lower triangle read); info = (pos, neg, zero)
