@@ -929,3 +929,39 @@ def case_boundary_fast_paths(make_engine, calls=None):
             rhs2.set_block(ndx, rng.standard_normal(model.block_dim))
         rhs2._blocks[3] = rhs2._blocks[3].astype(np.float32)
         dense_check(solver, kkt2, rhs2, solver.do_back_solve(rhs2))
+
+
+# ---- zero-pivot test inside a block pivot that mixes scales (interior-point KKT blocks) ------------
+def case_mixed_scale_block_pivot(make_engine):
+    """A primal variable with a barrier weight of 3e6 next to a constraint row with -1e-7 on its diagonal: the second
+    pivot of that pair is -1e-7 - a^2 / 3e6 = -1.7e-7, accurate to all digits.  The zero-pivot test must compare it with
+    the terms of ITS OWN sum (pivot.hpp: tmd), not with the largest magnitude of the block pivot it shares with the
+    variable (3e6 x 1e-13 > 1.7e-7: rounds 1-2 reported such matrices singular).  A pivot that really cancels to
+    rounding noise is still reported."""
+    def kkt(d1, c1):
+        # x1, x2 | constraint on x1 (diagonal c1), constraint on x1 and x2
+        rows = [0, 1, 2, 2, 3, 3, 3]
+        cols = [0, 1, 0, 2, 0, 1, 3]
+        vals = [d1, 2.0, 0.4654, c1, 0.1, 0.7, 0.0]
+        low = coo_matrix((vals, (rows, cols)), shape=(4, 4))
+        return (low + sp.tril(low, -1).T).tocoo()
+    for d1, c1 in ((3.2e6, -1e-7), (5.4e7, -3.3e-6), (1.0, -1e-7)):
+        K = kkt(d1, c1)
+        solver = HipLDLInterface(engine=make_engine())
+        assert solver.do_symbolic_factorization(K).status == LinearSolverStatus.successful
+        # the sequence is fixed on these values; other magnitudes of the same pattern then go through it
+        for d1b, c1b in ((d1, c1), (d1 * 1e3, c1), (d1, c1 * 1e-2)):
+            Kb = kkt(d1b, c1b)
+            res = solver.do_numeric_factorization(Kb, raise_on_error=False)
+            assert res.status == LinearSolverStatus.successful, (d1b, c1b)
+            assert solver.get_inertia() == (2, 2, 0)
+            b = np.array([1.0, -2.0, 0.5, 0.25])
+            x = np.asarray(solver.do_back_solve(b))
+            assert scaled_residual(Kb, x, b) <= 1e-12
+    # genuine cancellation: the Schur complement of the first pivot in the second is 1e-17 of its terms
+    low = coo_matrix(([1.0, 1.0, 1.0 + 2.0 ** -52, 3.0], ([0, 1, 1, 2], [0, 0, 1, 2])), shape=(3, 3))
+    K = (low + sp.tril(low, -1).T).tocoo()
+    solver = HipLDLInterface(engine=make_engine())
+    solver.do_symbolic_factorization(K)
+    res = solver.do_numeric_factorization(K, raise_on_error=False)
+    assert res.status == LinearSolverStatus.singular or solver.get_inertia()[2] == 0    # (a 2x2 pivot may have been chosen)

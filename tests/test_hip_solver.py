@@ -709,3 +709,7 @@ def test_host_boundary_fast_paths_on_the_device():
     """Host blocks in, host vectors out through pp_stage_upload_compact / pp_upload_rhs_rows / pp_download_solution_rows
     (verified index arrays, data rewritten in place, both result-buffer modes), each result against a dense solve."""
     sc.case_boundary_fast_paths(lambda: None)
+
+
+def test_zero_pivot_test_inside_a_mixed_scale_block_pivot():
+    sc.case_mixed_scale_block_pivot(lambda: None)

@@ -104,3 +104,7 @@ def test_harness_sub_solver_switch():
 
 def test_host_boundary_fast_paths():
     sc.case_boundary_fast_paths(HostSimBoundaryEngine)
+
+
+def test_zero_pivot_test_inside_a_mixed_scale_block_pivot():
+    sc.case_mixed_scale_block_pivot(HostSimEngine)
