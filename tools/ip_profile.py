@@ -39,6 +39,9 @@ for rep in range(2):
 s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(45)
 print(s.getvalue())
+s = io.StringIO()
+pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(18)
+print(s.getvalue())
 
 # where a pivot-order refresh spends its time inside the library (one more run, the symbolic entry points timed)
 lib = ipo.linalg.solver._eng.lib
