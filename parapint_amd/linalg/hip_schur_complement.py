@@ -745,6 +745,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         self._have_classes = False
         self.pivot_order_refreshes = 0      # numeric factorisations that needed a new static pivot sequence
         self.pivot_order_refreshes_since_symbolic = 0
+        self.refreshes_skipped = 0          # breakdowns reported as `singular` without a new sequence (futile lately)
         self.refresh_causes = {'zero_pivot': 0, 'growth': 0}      # ... because of a zero pivot / of element growth in a block
         self.diagonal_shift_refactorizations = 0      # factorisations from resident values + a diagonal shift (f1)
         self._last_Q = None
@@ -1315,17 +1316,32 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             # this matrix singular unless it is (ma27_interface.py:124-136), so order again with the values that
             # broke and factorise once more before the inertia-correction loop is told `singular`.
             res = self._numeric_factorization(matrix, timer)
+            self._note_refresh_outcome(res.status != LinearSolverStatus.singular)
         if res.status not in _OK and raise_on_error:
             raise RuntimeError('Numeric factorization unsuccessful; status: ' + str(res.status))
         return res
+
+    def _note_refresh_outcome(self, cured):
+        for g in getattr(self, '_refreshed', ()):
+            g.refresh_futile = 0 if cured else getattr(g, 'refresh_futile', 0) + 1
+            g.refresh_skip = 0 if cured else min(2 ** g.refresh_futile - 1, 63)
 
     def _refresh_pivot_order(self, shift=None):
         """New pivot sequences for the groups that hold a broken block, from that block's values (with `shift` =
         (delta_w, delta_c): + the diagonal shift of the classed rows, as the regularised matrix of the host path has
         them).  Collective: every rank learns whether any rank re-planned (all of them then factorise again)."""
         mine = 0
+        self._refreshed = []
         for g in self._groups:
             slot = self._eng.find_zero_pivot(g.gid)
+            if slot >= 0 and getattr(g, 'refresh_skip', 0) > 0:
+                # new sequences for this group have not cured its breakdowns lately: the matrices ARE singular (a
+                # rank-deficient Jacobian: every iterate of an interior-point run), and another symbolic phase per
+                # call -- 0.2 s at C3 -- would change nothing.  After the k-th futile refresh in a row the next
+                # 2^k - 1 breakdowns (at most 63) go to the caller as `singular` at once.
+                g.refresh_skip -= 1
+                self.refreshes_skipped += 1
+                continue
             if slot >= 0:
                 self.refresh_causes['zero_pivot'] += 1
             elif self._growth_guard:
@@ -1351,6 +1367,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
                     g.rep_vals = np.array(g.rep_vals, dtype=np.double)
                     g.rep_vals[:nK][diag] += np.where(cls[rows] == 1, shift[0], np.where(cls[rows] == 2, -shift[1], 0.0))
                 mine = 1
+                self._refreshed.append(g)
         anyone = mine
         if self.comm.size > 1:
             anyone = int(self.comm.allreduce_max(np.array([mine], dtype=np.int64))[0])
@@ -1621,8 +1638,12 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             # (shift included) of the instance that broke, before the caller is told `singular`
             if getattr(self, '_last_device_base', None) is not None and self._device_maps is not None:
                 self._bind_device_matrix(self._last_device_base)      # (the new plan has device buffers of its own)
-            return self.refactorize_with_diagonal_shift(delta_w, delta_c, coupling_shift=coupling_shift,
-                                                        raise_on_error=raise_on_error, timer=timer, _retry=True)
+            res = self.refactorize_with_diagonal_shift(delta_w, delta_c, coupling_shift=coupling_shift,
+                                                       raise_on_error=False, timer=timer, _retry=True)
+            self._note_refresh_outcome(res.status != LinearSolverStatus.singular)
+            if res.status not in _OK and raise_on_error:
+                raise RuntimeError('Numeric factorization unsuccessful; status: ' + str(res.status))
+            return res
         if res.status not in _OK and raise_on_error:
             raise RuntimeError('Numeric factorization unsuccessful; status: ' + str(res.status))
         return res
