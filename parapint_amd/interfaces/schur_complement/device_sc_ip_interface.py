@@ -117,7 +117,20 @@ class DeviceStochasticQPInterface(object):
         h.set_duals_eq(E.unflat(st['duals_eq'])); h.set_duals_ineq(I.unflat(st['duals_ineq']))
         h.set_duals_primals_lb(P.unflat(st['zl'])); h.set_duals_primals_ub(P.unflat(st['zu']))
         h.set_duals_slacks_lb(I.unflat(st['sl'])); h.set_duals_slacks_ub(I.unflat(st['su']))
-        pattern = h.evaluate_primal_dual_kkt_matrix()
+        # One sparsity pattern for all scenarios (checked in __init__): the blocks of scenario 0 at its processed initial
+        # point stand for every scenario -- the solver reads patterns and one representative value set from this
+        # matrix, never the values of the others (those come from the sources on the device).  Evaluating and
+        # converting all 1024 host blocks was 1.0 of the 1.3 s of the whole 1024-scenario solve.
+        pattern = h.evaluate_primal_dual_kkt_matrix(only=(0,))
+        K0, A0 = pattern.get_block(0, 0).tocoo(), pattern.get_block(self.N, 0).tocoo()
+        pattern.set_block(0, 0, K0)
+        pattern.set_block(self.N, 0, A0)
+        A0t = A0.transpose().tocoo()
+        pattern.set_block(0, self.N, A0t)
+        for ndx in range(1, self.N):
+            pattern.set_block(ndx, ndx, K0)
+            pattern.set_block(self.N, ndx, A0)
+            pattern.set_block(ndx, self.N, A0t)
         maps = {ndx: self._value_map for ndx in range(self.N)}
         self._init_state = st
         return DeviceBlockMatrix(pattern, maps, self.nsrc)

@@ -268,10 +268,14 @@ class StochasticSchurComplementInteriorPointInterface(object):
             owner[ndx, ndx] = owner[N, ndx] = owner[ndx, N] = self._ownership[ndx]
         return MPIBlockMatrix(N + 1, N + 1, owner, self._comm)
 
-    def evaluate_primal_dual_kkt_matrix(self, timer=None):
+    def evaluate_primal_dual_kkt_matrix(self, timer=None, only=None):
+        """only: scenario indices to evaluate (default: all local ones) -- for callers that need the blocks of a few
+        scenarios (the device producer reads the common pattern off scenario 0)."""
         N, nfs = self._num_scenarios, self._num_first_stage_vars
         kkt = self._matrix()
         for ndx, nlp in self._nlps.items():
+            if only is not None and ndx not in only:
+                continue
             n, me, mi = nlp.n_primals(), nlp.n_eq_constraints(), nlp.n_ineq_constraints()
             sub = BlockMatrix(2, 2)
             sub.set_block(0, 0, nlp.evaluate_primal_dual_kkt_matrix())

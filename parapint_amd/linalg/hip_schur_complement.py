@@ -791,7 +791,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         last = self.block_dim - 1
         nc = matrix.get_row_size(last) if hasattr(matrix, 'get_row_size') else matrix.get_block(last, last).shape[0]
         self._nc = int(nc)
-        groups, by_sig, binfo = [], {}, {}
+        groups, by_sig, by_ids, same_by_ids, binfo = [], {}, {}, {}, {}
         all_zero = True
         empty_i, empty_d = np.zeros(0, dtype=np.int32), np.zeros(0)
         # first pass: which coupling rows does every block touch?  If every block touches all of them (the union of the
@@ -800,16 +800,22 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         # map to the global ones, so that blocks with the same local structure still share one plan and one batch
         fetched = {}
         uniform = True
+        seen = {}          # (id(K block), id(A block)) -> what was read off them: callers may hand one object to many blocks
         for ndx in self.local_block_indices:
-            kr, kc, kd, kshape = _coo(matrix.get_block(ndx, ndx))
+            Kb, A = matrix.get_block(ndx, ndx), matrix.get_block(last, ndx)
+            hit = seen.get((id(Kb), id(A)))
+            if hit is not None:
+                fetched[ndx] = hit
+                uniform = uniform and hit[7].size == self._nc
+                continue
+            kr, kc, kd, kshape = _coo(Kb)
             if kshape[0] != kshape[1]:
                 raise ValueError('Matrix must be square')
-            A = matrix.get_block(last, ndx)
             br, bc, bd = (empty_i, empty_i, empty_d) if A is None else _coo(A)[:3]
             used = np.unique(br)
             if used.size != self._nc:
                 uniform = False
-            fetched[ndx] = (kr, kc, kd, kshape[0], br, bc, bd, used)
+            fetched[ndx] = seen[(id(Kb), id(A))] = (kr, kc, kd, kshape[0], br, bc, bd, used)
         # every rank must take the same layout (a mapped rank joins collectives of its own in _coupling_structure, and a
         # dense and a block-tridiagonal S cannot meet in one all-reduce): one rank's non-uniform blocks decide for all
         if self.comm.size > 1:
@@ -824,8 +830,14 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
                 m = cmap.size
                 br_global = br
                 br = np.searchsorted(cmap, br).astype(np.int32)
-            raw_sig = (n, m, kr.tobytes(), kc.tobytes(), br.tobytes(), bc.tobytes())
-            g = by_sig.get(raw_sig)
+            # (index arrays shared by many blocks -- one Jacobian structure, one object -- are hashed once)
+            ids = None if self._mapped else (n, m, id(kr), id(kc), id(br), id(bc))
+            g = by_ids.get(ids) if ids is not None else None
+            if g is None:
+                raw_sig = (n, m, kr.tobytes(), kc.tobytes(), br.tobytes(), bc.tobytes())
+                g = by_sig.get(raw_sig)
+                if g is not None and ids is not None:
+                    by_ids[ids] = g
             if g is None:
                 rowK, colK, cpK, ciK = _canonical(kr, kc, n, True)
                 rowB, colB, cpB, ciB = _canonical(br, bc, n, False)
@@ -841,7 +853,9 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
                     g.cmaps = []
                     groups.append(g)
                     by_sig[can_sig] = g
-                    by_sig[raw_sig] = g
+                by_sig[raw_sig] = g
+                if ids is not None:
+                    by_ids[ids] = g
             bi = _BlockInfo()
             bi.group, bi.slot, bi.n = g, len(g.blocks), n
             bi.seen = None
@@ -850,9 +864,14 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             # blocks whose raw COO order differs from the group's reference order are
             # canonicalised on the host at every numeric call (quirk Q7)
             ref = g.raw_refs
-            bi.raw_sig = (kr.size == ref[0].size and br.size == ref[2].size and
-                          np.array_equal(kr, ref[0]) and np.array_equal(kc, ref[1]) and
-                          np.array_equal(br, ref[2]) and np.array_equal(bc, ref[3]))
+            same = same_by_ids.get(ids) if ids is not None else None
+            if same is None:
+                same = (kr.size == ref[0].size and br.size == ref[2].size and
+                        np.array_equal(kr, ref[0]) and np.array_equal(kc, ref[1]) and
+                        np.array_equal(br, ref[2]) and np.array_equal(bc, ref[3]))
+                if ids is not None:
+                    same_by_ids[ids] = same
+            bi.raw_sig = same
             g.blocks.append(ndx)
             g.cmaps.append(cmap)
             binfo[ndx] = bi
