@@ -98,6 +98,11 @@ inline void tune_for_batch(PlanOptions& o, int batch) {
     o.max_task_entries = 8;
     o.tail_task_entries = 8;
     o.row_split_factor = 0.5;
+    // round 3 (after the root front and the column-run entries): panels fused up to 16 entries and scale tasks of 4
+    // rows -- 128 blocks 0.452 -> 0.434 ms, 64 blocks 0.425 -> 0.417, 256 blocks 0.513 -> 0.496, C2 0.403 -> 0.387
+    // (the same sizes change nothing at 1024 blocks: 0.433-0.437 ms of factor levels for fuse 16..32, scale rows 4..8)
+    o.fuse_task_entries = 16;
+    o.scale_task_rows = 4;
   }
 }
 
