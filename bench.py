@@ -61,6 +61,9 @@ def parse_args():
     ap.add_argument('--no-ip-loop', action='store_true')
     ap.add_argument('--ip-scenarios', type=int, default=1024)
     ap.add_argument('--boundary-iterations', type=int, default=6)
+    ap.add_argument('--result-buffers', type=int, default=2,
+                    help='result_buffers of the solver: 2 = results handed out from two buffers in turn (what the timed loop and '
+                         'the interior-point loops do), 0 = the class default, a fresh result per back-solve')
     ap.add_argument('--profile-steps', type=int, default=5)
     ap.add_argument('--sn-wmax', type=int, default=0, help='supernode width cap (0: library default)')
     ap.add_argument('--sn-tol', type=int, default=-1, help='padded rows tolerated when merging (-1: default)')
@@ -186,7 +189,7 @@ def main():
         describe = ('%s: %d scenario blocks x (n_q=%d, n_y=%d: %d primal vars, block dim %d), %d coupling vars' %
                     (args.workload, N, n_q, model.n_y, n_q + model.n_y, model.block_dim, n_t))
     B = len(local)
-    solver = HipSchurComplementLinearSolver({i: None for i in local}, None, comm=comm, result_buffers=2)
+    solver = HipSchurComplementLinearSolver({i: None for i in local}, None, comm=comm, result_buffers=args.result_buffers)
     eng = solver._eng
     lib, h = eng.lib, eng.ns.h
     if args.sn_wmax > 0 or args.sn_tol >= 0:

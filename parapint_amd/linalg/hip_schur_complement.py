@@ -444,6 +444,10 @@ class HipEngine(object):
         torch = self._torch
         return torch.zeros(shape, dtype=torch.float64, device=torch.device('cuda', self.device))
 
+    def new_tensor_uninitialized(self, shape):
+        torch = self._torch
+        return torch.empty(shape, dtype=torch.float64, device=torch.device('cuda', self.device))
+
     def bind_source_tensor(self, gid, tensor):
         self.ns.check(self.lib.pp_bind_source_buffer(self.ns.h, gid, tensor.data_ptr()), 'pp_bind_source_buffer')
 
@@ -1213,17 +1217,23 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
 
     def device_layout(self):
         """{block index: (group id, lane)} of the local blocks, and {group id: (batch, padded batch, block dimension)}."""
-        layout = {ndx: (bi.group.gid, bi.slot) for ndx, bi in self._binfo.items()}
-        dims = {g.gid: (len(g.blocks), -(-len(g.blocks) // 64) * 64, g.n) for g in self._groups}
-        return layout, dims
+        cached = getattr(self, '_layout_cache', None)
+        if cached is None or cached[0] is not self._binfo:       # (a new dict per symbolic phase / re-plan)
+            layout = {ndx: (bi.group.gid, bi.slot) for ndx, bi in self._binfo.items()}
+            dims = {g.gid: (len(g.blocks), -(-len(g.blocks) // 64) * 64, g.n) for g in self._groups}
+            cached = self._layout_cache = (self._binfo, layout, dims)
+        return cached[1], cached[2]
 
-    def new_device_vector(self):
-        """A DeviceBlockVector with the structure of this solver's right-hand sides (zero-filled)."""
+    def new_device_vector(self, zero=True):
+        """A DeviceBlockVector with the structure of this solver's right-hand sides (zero-filled; zero=False: left
+        uninitialised, for a result every entry of which the backward sweep writes)."""
         from parapint_amd.sparse.device_containers import DeviceBlockVector
         layout, dims = self.device_layout()
         v = DeviceBlockVector(self.block_dim, layout)
+        new = self._eng.new_tensor if zero or not hasattr(self._eng, 'new_tensor_uninitialized') else \
+            self._eng.new_tensor_uninitialized
         for gid, (batch, bpad, n) in dims.items():
-            v.group_tensors[gid] = self._eng.new_tensor((n, bpad))
+            v.group_tensors[gid] = new((n, bpad))
         v.coupling = self._eng.new_tensor((max(self._nc, 1),))[:self._nc]
         return v
 
@@ -1779,7 +1789,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         into a fresh device vector (or, with result_buffers = k > 0, into k vectors handed out in turn); no host copies."""
         timer.start('back_solve')
         if self._result_buffers == 0:
-            out = self.new_device_vector()                  # default: results of different calls never alias
+            out = self.new_device_vector(zero=False)        # default: results of different calls never alias
         else:
             if not self._dev_results:
                 self._dev_results = [self.new_device_vector() for _ in range(self._result_buffers)]
