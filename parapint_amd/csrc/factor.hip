@@ -539,14 +539,16 @@ __global__ __launch_bounds__(512) void k_front_invert(GroupDev g, FrontRec fr, d
 #endif
   // The step loop is unrolled: every register index below is a constant (a rolled loop selects the pivot column with
   // compare / select pairs per element: 1.75 us per step, measured).  One barrier per 1x1 step: the buffers of a
-  // step are written again two steps later, which every wave reaches only through the barrier of the step in between.
+  // step are written again two EXECUTED steps later, which every wave reaches only through the barrier of the step in
+  // between.  The buffer parity therefore follows the executed steps (a uniform counter), not k: a 2x2 step skips k + 1,
+  // and k & 1 would hand the step at k + 2 the buffers other waves may still be reading.
   bool second = false;
+  int par = 0;
 #pragma unroll
   for (int k = 0; k < PP_FRONT_MAX; ++k) {
     if (k >= w) continue;                 // (uniform)
     if (second) { second = false; continue; }
-    const int par = k & 1;
-    constexpr int dummy = 0; (void)dummy;
+    par ^= 1;
     const int k1 = (k + 1 < WF) ? k + 1 : k;
     const int ow = k / RW, orow = k % RW, ow1 = k1 / RW, orow1 = k1 % RW;     // owners of the pivot rows (constants)
     const bool two = ((fr.sub >> k) & 1u) && (k + 1 < w);

@@ -22,6 +22,7 @@
 // L_p = U_p inv(P_p) with identical indexing, inv(P_p) kept separately, so all row chunks of
 // a panel are independent tasks and every update is a two-operand gather.
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 #include <string>
@@ -136,7 +137,7 @@ inline bool apply_plan_tune(PlanOptions& opt, const char* tune, std::string& bad
       else if (k == "task_order") opt.task_order = (int)v;
       else if (k == "order_mode") opt.order_mode = (int)v;
       else if (k == "pivot_threshold") opt.pivot_threshold = v;
-      else if (k == "front_max") opt.front_max = (int)v;
+      else if (k == "front_max") opt.front_max = std::min((int)v, (int)PP_FRONT_MAX);   // (k_front_invert / k_scale_wide hold at most PP_FRONT_MAX columns)
       else if (k == "front_pad_frac") opt.front_pad_frac = v;
       else if (k == "front_scale_rows") opt.front_scale_rows = (int)v;
       else if (k == "close_supernodes") opt.close_supernodes = (int)v;

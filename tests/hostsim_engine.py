@@ -306,7 +306,7 @@ class HostSimBoundaryEngine(HostSimEngine):
             row[dst:dst + ln] = bd[e0:e0 + ln]
         self.upload_values_compact(g.gid, g.staging, slot, 1)
 
-    def stage_upload(self, g, items):
+    def stage_upload(self, g, items, full_check=True):
         self.calls['stage_upload'] += 1
         ref = g.raw_refs
         ok = np.zeros(len(items), dtype=bool)

@@ -923,12 +923,54 @@ def case_boundary_fast_paths(make_engine, calls=None):
             a[0], a[-1] = a[-1].copy(), a[0].copy()
         solver.do_numeric_factorization(kkt2)
         dense_check(solver, kkt2, rhs, solver.do_back_solve(rhs))
+        # two INTERIOR entries exchanged in place (row, column and value together: the same matrix in another entry
+        # order; first, middle and last entry untouched): the checksum of the index arrays finds it -- at once while the
+        # arrays fit the per-call byte budget, at the next full check otherwise -- and the block is compared again
+        K = kkt2.get_block(3, 3)
+        i, j = 2, K.row.size - 3
+        assert i != K.row.size >> 1 and j != K.row.size >> 1 and (K.row[i], K.col[i]) != (K.row[j], K.col[j])
+        before = dict(eng_calls) if eng_calls is not None else None
+        for a in (K.row, K.col, K.data):
+            a[i], a[j] = a[j].copy(), a[i].copy()
+        solver.do_numeric_factorization(kkt2)
+        dense_check(solver, kkt2, rhs, solver.do_back_solve(rhs))
+        if eng_calls is not None:
+            assert eng_calls['compared_blocks'] > before['compared_blocks']
+        # ... and with no byte budget: not later than the `pattern_check_interval`-th call
+        solver.pattern_check_bytes, solver.pattern_check_interval = 0, 3
+        K = kkt2.get_block(4, 4)
+        solver.do_numeric_factorization(kkt2)
+        solver._stage_calls = 0
+        for a in (K.row, K.col, K.data):
+            a[i], a[j] = a[j].copy(), a[i].copy()
+        for _ in range(3):
+            solver.do_numeric_factorization(kkt2)
+        dense_check(solver, kkt2, rhs, solver.do_back_solve(rhs))
+        # an interior row index rewritten in place to an entry OUTSIDE the planned pattern: the plan is made again
+        # (or an error is raised) -- never a silent solve against the old pattern
+        kkt3 = model.build_kkt(comm=comm, iteration=1)
+        solver.pattern_check_bytes, solver.pattern_check_interval = 4 << 20, 8
+        for ndx in range(N):
+            K = kkt3.get_block(ndx, ndx)
+            kkt3.set_block(ndx, ndx, coo_matrix((K.data.copy(), (K.row.copy(), K.col.copy())), shape=K.shape))
+        solver.do_numeric_factorization(kkt3)
+        solver.do_numeric_factorization(kkt3)
+        K = kkt3.get_block(1, 1)
+        low = np.flatnonzero(K.row > K.col + 1)
+        e = int(low[len(low) // 2])
+        present = set(zip(K.row.tolist(), K.col.tolist()))
+        newrow = next(r for r in range(int(K.col[e]) + 1, K.shape[0]) if (r, int(K.col[e])) not in present)
+        up = int(np.flatnonzero((K.row == K.col[e]) & (K.col == K.row[e]))[0])     # its mirror in the upper triangle
+        K.row[e] = newrow
+        K.col[up] = newrow
+        solver.do_numeric_factorization(kkt3)
+        dense_check(solver, kkt3, rhs, solver.do_back_solve(rhs))
         # right-hand sides that are not plain float64 vectors go the general way
         rhs2 = model.build_rhs(comm=comm)
         for ndx in range(N):
             rhs2.set_block(ndx, rng.standard_normal(model.block_dim))
         rhs2._blocks[3] = rhs2._blocks[3].astype(np.float32)
-        dense_check(solver, kkt2, rhs2, solver.do_back_solve(rhs2))
+        dense_check(solver, kkt3, rhs2, solver.do_back_solve(rhs2))
 
 
 # ---- zero-pivot test inside a block pivot that mixes scales (interior-point KKT blocks) ------------
