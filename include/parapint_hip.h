@@ -350,6 +350,61 @@ int pp_vec_step_stats(pp_handle h, int64_t n, const double* x, const double* dx,
 int pp_vec_max_abs(pp_handle h, int64_t n, const double* v, double* out_host);
 int pp_vec_axpy(pp_handle h, int64_t n, double alpha, const double* x, double* y);
 
+/* ---- f2 / f4: the interior-point step on device-resident iterates ---------------------------------------
+ * What parapint's interfaces and ip_solve do around the linear solve in every iteration -- barrier diagonals of the KKT
+ * matrix (interfaces/interface.py:450-465), right-hand side (:496-538, schur_complement/sc_ip_interface.py:1683-1696),
+ * bound-dual steps (:562-588), fraction to the boundary (algorithms/interior_point.py:655-758), the step (:619-626) and
+ * the three convergence measures (:174-317) -- for a two-stage stochastic QP whose scenarios sit in HBM in the solver's
+ * own [row][instance] layout.  One pp_ip_group per pattern group of the solver (instance b = block slots[b]):
+ *   W       iterate, rows x(n) | s(mi) | y_eq(me) | y_ineq(mi) | y_link(nfs) | z_l(n) | z_u(n) | s_l(mi) | s_u(mi): the first
+ *           nb = n + 2 mi + me + nfs rows are in the row order of the KKT block (and of rhs / delta)
+ *   bounds  lb(n) | ub(n) | ineq_lb(mi) | ineq_ub(mi) (+-inf = none; relaxed as interface.py:389-419)
+ *   data    c(n) | b_eq(me)
+ *   src     the source tensor the factorisation reads its values from (pp_bind_source_buffer): rows src_dp .. + n and
+ *           src_ds .. + mi receive the barrier diagonals, the Hessian / Jacobian values are read from it
+ *   G       [n][bpad] work rows: grad f + J^T y at the current iterate
+ *   rhs     right-hand side [nb][bpad]; delta: the solution of the KKT system [nb][bpad] (pp_bind_native_vectors)
+ *   prog    n + me + mi + nfs row programs {t0, tH, t1, -} for the rows grad_x L, A_eq x - b, A_ineq x - s, x_fs - z:
+ *           terms [t0, t1) as pairs {source row or -1 (the constant 1), row of W}, the Hessian terms [t0, tH) first
+ * All arrays are [rows][bpad] doubles on the handle's device, bpad a multiple of 64, instances >= batch are padding
+ * (they hold a copy of a real scenario without bounds and are left alone).  At most 8 groups.
+ *   pp_ip_rhs           rows x and s of rhs from G, the iterate and the barrier parameter mu (the other rows are written by
+ *                       pp_ip_residuals)
+ *   pp_ip_step_lengths  alpha_local[2] (device) = this rank's fraction-to-the-boundary step lengths, tau = 1 - mu; the
+ *                       bound-dual steps are formed on the fly from delta
+ *   pp_ip_take_step     iterate += alpha * step with alpha = min over the nranks rows of alpha_table (device, [nranks][2];
+ *                       unified != 0: one length for both); alpha_table == NULL: no step (measures of the initial point).
+ *                       z / dz: coupling variables and their step (device, nfs).  Writes the barrier diagonals into src.
+ *   pp_ip_residuals     G, the constraint rows of rhs, and v_local (device, 8 + nfs): {primal infeasibility, dual
+ *                       infeasibility of the blocks, complementarity at 0 and at mu, sum |bound duals|, sum |constraint
+ *                       duals|, objective, 0, sum over the instances of y_link (nfs)}
+ *   pp_ip_publish       combines the nranks rows of v_table ([nranks][8 + nfs], device; rank order, deterministic) into the
+ *                       coupling right-hand side rhs_coupling (device, nfs) and the mailbox
+ *   pp_ip_wait          blocks until the last pp_ip_publish has run: out = {primal inf, dual inf, compl(0), compl(mu),
+ *                       sum |bound duals|, sum |duals|, objective, alpha_primal, alpha_dual, 0}
+ * All calls are stream-ordered on the handle's stream; only pp_ip_wait synchronises (it polls a pinned mailbox).
+ * Between ranks the caller all-gathers alpha_local -> alpha_table and v_local -> v_table (pp_comm_allgather or any other
+ * transport); with one rank the tables are the local arrays. */
+typedef struct pp_ip_group {
+  int32_t n, mi, me, nfs, batch, bpad, src_dp, src_ds;
+  double* W;
+  const double* bounds;
+  const double* data;
+  double* src;
+  double* G;
+  double* rhs;
+  const double* delta;
+  const int32_t* prog;
+  const int32_t* terms;
+} pp_ip_group;
+int pp_ip_rhs(pp_handle h, int ngroups, const pp_ip_group* groups, double mu);
+int pp_ip_step_lengths(pp_handle h, int ngroups, const pp_ip_group* groups, double tau, double mu, double* alpha_local);
+int pp_ip_take_step(pp_handle h, int ngroups, const pp_ip_group* groups, const double* alpha_table, int nranks, int unified,
+                    double mu, double* z, const double* dz);
+int pp_ip_residuals(pp_handle h, int ngroups, const pp_ip_group* groups, const double* z, double* v_local);
+int pp_ip_publish(pp_handle h, const double* v_table, const double* alpha_table, int nranks, int nfs, double* rhs_coupling);
+int pp_ip_wait(pp_handle h, double out[10]);
+
 /* Pivot tolerances (MA27 cntl(1), ma27_interface.py:36-47; examples/stochastic.py:120-124 uses 1e-6).
  *   u_symbolic  threshold of the static pivot choice at symbolic time: a 1x1 pivot is taken only if
  *               |d| >= u * max|row| on the representative values, else a 2x2 pivot (0: keep 0.01)
@@ -380,6 +435,8 @@ int pp_comm_init(pp_handle h, int nranks, int rank, const uint8_t id[128]);
 int pp_comm_size(pp_handle h);
 int pp_allreduce_schur(pp_handle h);
 int pp_allreduce_rs(pp_handle h);
+/* table[r * count .. ] = src of rank r (device arrays of doubles; the scalars of the interior-point step, above) */
+int pp_comm_allgather(pp_handle h, const double* src, double* table, int64_t count);
 
 /* Diagnostic: the factor of one instance (block) of a group after pp_numeric_local, in the plan's
  * panel storage: which = 0 unscaled panels U, 1 scaled rows L (the MA27 factor entries,

@@ -109,6 +109,16 @@ SIGNATURES = {
                           [ctypes.c_double, ctypes.c_double, _f64p]),
     'pp_vec_max_abs': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, _f64p]),
     'pp_vec_axpy': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
+    'pp_ip_rhs': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_double]),
+    'pp_ip_step_lengths': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_double, ctypes.c_double,
+                                          ctypes.c_void_p]),
+    'pp_ip_take_step': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
+    'pp_ip_residuals': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    'pp_ip_publish': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_void_p]),
+    'pp_ip_wait': (ctypes.c_int, [ctypes.c_void_p, _f64p]),
+    'pp_comm_allgather': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
     'pp_comm_unique_id': (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint8)]),
     'pp_comm_init': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint8)]),
     'pp_comm_size': (ctypes.c_int, [ctypes.c_void_p]),
@@ -120,6 +130,14 @@ SIGNATURES = {
     'pp_find_zero_pivot': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _i32p]),
     'pp_get_factor': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f64p, ctypes.c_int64]),
 }
+
+
+
+class IpGroup(ctypes.Structure):
+    """pp_ip_group of include/parapint_hip.h (one pattern group of the interior-point step on the device)."""
+    _fields_ = [(k, ctypes.c_int32) for k in ('n', 'mi', 'me', 'nfs', 'batch', 'bpad', 'src_dp', 'src_ds')] + \
+               [(k, ctypes.c_void_p) for k in ('W', 'bounds', 'data', 'src', 'G', 'rhs', 'delta', 'prog', 'terms')]
+
 
 GROUP_STAT_KEYS = ['n', 'n_coupling', 'batch', 'n_pivots', 'n_2x2', 'n_levels', 'nnz_L', 'u_doubles',
                    'factor_fma', 'schur_fma', 'factor_tasks', 'update_runs', 'schur_tiles', 'schur_tile_records',

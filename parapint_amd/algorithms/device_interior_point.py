@@ -3,11 +3,14 @@
 ``ip_solve_device`` is parapint/algorithms/interior_point.py:405-631 (restated for host containers in
 ``parapint_amd.algorithms.interior_point``) over a device producer
 (``parapint_amd.interfaces.schur_complement.device_sc_ip_interface.DeviceStochasticQPInterface``): the KKT values go from
-the producer's tensors into the factorisation kernels, the right-hand side and the step are ``DeviceBlockVector``s, the
-convergence measures and step lengths are device reductions, and the inertia-correction loop is the reference's own
-(``numeric_factorization`` below is the HOST function, unchanged: ``regularize_*`` return a diagonal shift of the resident
-matrix and ``do_numeric_factorization`` recognises it).  Per iteration the host sees a handful of scalars -- what the
-control flow of the reference's loop needs -- and nothing else leaves the device.
+the producer's tensors into the factorisation kernels, the right-hand side and the step are ``DeviceBlockVector``s, and
+everything the reference does between two linear solves -- bound-dual steps, fraction to the boundary, the step, the
+convergence measures, the next right-hand side -- is a handful of HIP kernels (``csrc/ipstep.hip``).  The
+inertia-correction loop is the reference's own (``numeric_factorization`` below is the HOST function, unchanged:
+``regularize_*`` return a diagonal shift of the resident matrix and ``do_numeric_factorization`` recognises it).  Per
+iteration the host waits twice -- for the factorisation's status and inertia, and for seven scalars of the new iterate:
+what the control flow of the reference's loop needs -- and nothing else leaves the device.  With more than one rank the
+scenarios are dealt round-robin (mpi_sc_ip_interface.py:14-29) and every rank runs this loop on its own GPU.
 """
 import logging
 import time
@@ -19,9 +22,10 @@ from parapint_amd.linalg.results import LinearSolverStatus
 logger = logging.getLogger(__name__)
 
 
-def ip_solve_device(interface, options=None, timer=None, history=None):
+def ip_solve_device(interface, options=None, timer=None, history=None, stats=None):
     """Returns (status, iterations).  `history`, if a list, receives per iteration
-    (primal_inf, dual_inf, compl_inf, barrier, alpha_primal, alpha_dual, regularisation)."""
+    (primal_inf, dual_inf, compl_inf, barrier, alpha_primal, alpha_dual, regularisation); `stats`, if a dict, the wall
+    time of the symbolic phase + set-up (`setup_s`) and of the iterations (`loop_s`)."""
     if options is None:
         options = IPOptions()
     if timer is None:
@@ -39,6 +43,9 @@ def ip_solve_device(interface, options=None, timer=None, history=None):
         raise RuntimeError('Could not factorize KKT system; linear solver status: ' + str(sym_status))
     interface.attach(solver, dk)
     interface.set_barrier_parameter(barrier_parameter)
+    interface.take_step()                                   # (no step yet: barrier diagonals + measures of the initial point)
+    m = interface.check_convergence(options.error_scaling)
+    t_loop = time.time()
     alpha_primal_max = alpha_dual_max = 1
     logger.info('%-6s%-11s%-11s%-11s%-11s%-11s%-11s%-11s%-11s%-7s', 'Iter', 'Objective', 'Prim Inf', 'Dual Inf',
                 'Comp Inf', 'Barrier', 'Prim Step', 'Dual Step', 'Reg', 'Time')
@@ -46,7 +53,7 @@ def ip_solve_device(interface, options=None, timer=None, history=None):
     iterations = 0
     for _iter in range(options.max_iter):
         iterations = _iter
-        primal_inf, dual_inf, compl_inf = interface.check_convergence(0, options.error_scaling)
+        primal_inf, dual_inf, compl_inf = m['primal_inf'], m['dual_inf'], m['compl_inf']        # check_convergence(barrier=0)
         if logger.isEnabledFor(logging.INFO):
             logger.info('%-6d%-11.2e%-11.2e%-11.2e%-11.2e%-11.2e%-11.2e%-11.2e%-11.2e%-7.3f', _iter,
                         interface.evaluate_objective(), primal_inf, dual_inf, compl_inf, barrier_parameter,
@@ -57,20 +64,25 @@ def ip_solve_device(interface, options=None, timer=None, history=None):
         if max(primal_inf, dual_inf, compl_inf) <= options.tol:
             status = InteriorPointStatus.optimal
             break
-        primal_inf, dual_inf, compl_inf = interface.check_convergence(barrier_parameter, options.error_scaling)
-        if max(primal_inf, dual_inf, compl_inf) <= options.barrier_decrease * barrier_parameter:
+        # check_convergence(barrier=barrier_parameter): the same pass gave the complementarity measure at the barrier
+        if max(primal_inf, dual_inf, m['compl_inf_barrier']) <= options.barrier_decrease * barrier_parameter:
             barrier_parameter = max(options.minimum_barrier_parameter,
                                     min(0.5 * barrier_parameter, barrier_parameter ** 1.5))
         interface.set_barrier_parameter(barrier_parameter)
-        kkt = interface.evaluate_primal_dual_kkt_matrix(timer=timer)      # barrier diagonals -> the solver's sources
+        kkt = interface.evaluate_primal_dual_kkt_matrix(timer=timer)      # (the barrier diagonals are in the solver's sources)
         rhs = interface.evaluate_primal_dual_kkt_rhs(timer=timer)
         used_inertia_coef = numeric_factorization(interface, kkt, options, inertia_coef, timer)
         inertia_coef = max(used_inertia_coef * options.inertia_correction.factor_decrease,
                            options.inertia_correction.init_coef)
         delta = solver.do_back_solve(rhs)
         interface.set_primal_dual_kkt_solution(delta)
-        alpha_primal_max, alpha_dual_max = interface.fraction_to_the_boundary(1 - barrier_parameter)
+        interface.fraction_to_the_boundary(1 - barrier_parameter)
+        interface.take_step(unified=options.unified_step)
+        m = interface.check_convergence(options.error_scaling)
+        alpha_primal_max, alpha_dual_max = m['alpha_primal'], m['alpha_dual']
         if options.unified_step:
             alpha_primal_max = alpha_dual_max = min(alpha_primal_max, alpha_dual_max)
-        interface.take_step(alpha_primal_max, alpha_dual_max)
+    if stats is not None:
+        stats['setup_s'] = t_loop - t0
+        stats['loop_s'] = time.time() - t_loop
     return status, iterations

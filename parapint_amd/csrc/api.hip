@@ -57,6 +57,8 @@ void pp_destroy(pp_handle h) {
     for (int i = 0; i < PP_MAX_SPLIT; ++i) { (void)hipStreamDestroy(h->aux[i]); (void)hipEventDestroy(h->ev_join[i]); }
     (void)hipEventDestroy(h->ev_fork);
   }
+  if (h->ip_part) (void)hipFree(h->ip_part);
+  if (h->ip_mail_host) (void)hipHostFree((void*)h->ip_mail_host);
   rccl_release(h);
   delete h;
 }
@@ -1315,11 +1317,12 @@ typedef int (*fn_get_id)(void*);
 typedef int (*fn_init_rank)(void**, int, ppd_nccl_id, int);
 typedef int (*fn_destroy)(void*);
 typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*fn_allgather)(const void*, void*, size_t, int, void*, hipStream_t);
 typedef const char* (*fn_errstr)(int);
 struct Rccl {
   void* lib = nullptr;
   fn_get_id get_id = nullptr; fn_init_rank init_rank = nullptr; fn_destroy destroy = nullptr;
-  fn_allreduce allreduce = nullptr; fn_errstr errstr = nullptr;
+  fn_allreduce allreduce = nullptr; fn_allgather allgather = nullptr; fn_errstr errstr = nullptr;
   bool tried = false;
 };
 Rccl g_rccl;
@@ -1337,6 +1340,7 @@ bool rccl_load() {
   g_rccl.init_rank = (fn_init_rank)dlsym(g_rccl.lib, "ncclCommInitRank");
   g_rccl.destroy = (fn_destroy)dlsym(g_rccl.lib, "ncclCommDestroy");
   g_rccl.allreduce = (fn_allreduce)dlsym(g_rccl.lib, "ncclAllReduce");
+  g_rccl.allgather = (fn_allgather)dlsym(g_rccl.lib, "ncclAllGather");
   g_rccl.errstr = (fn_errstr)dlsym(g_rccl.lib, "ncclGetErrorString");
   if (!g_rccl.get_id || !g_rccl.init_rank || !g_rccl.destroy || !g_rccl.allreduce) { g_rccl.allreduce = nullptr; return false; }
   return true;
@@ -1392,6 +1396,16 @@ int pp_allreduce_rs(pp_handle h) {
   if (h->nc == 0) return 0;
   const int rc = g_rccl.allreduce(h->rs, h->rs, (size_t)h->nc, 8, 0, h->rccl_comm, h->stream);
   if (rc != 0) return fail(h, 3, rccl_msg("ncclAllReduce(r_s)", rc));
+  return 0;
+}
+
+int pp_comm_allgather(pp_handle h, const double* src, double* table, int64_t count) {
+  if (!h || !h->rccl_comm || !g_rccl.allgather) return fail(h, 3, "pp_comm_allgather: no communicator (pp_comm_init)");
+  if (!src || !table || count < 0) return fail(h, 3, "pp_comm_allgather: bad arguments");
+  PP_HIP(hipSetDevice(h->device));
+  if (count == 0) return 0;
+  const int rc = g_rccl.allgather(src, table, (size_t)count, /* ncclDouble */ 8, h->rccl_comm, h->stream);
+  if (rc != 0) return fail(h, 3, rccl_msg("ncclAllGather", rc));
   return 0;
 }
 

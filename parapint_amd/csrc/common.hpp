@@ -342,6 +342,13 @@ struct pp_solver {
   long long status_seq = 0;
   double fail_code = 0.0;
   double* vec_part = nullptr;    // scratch of the f4 vector kernels
+  // interior-point step on device-resident iterates (ipstep.hip): partials of its reductions, pinned mailbox
+  double* ip_part = nullptr;
+  size_t ip_part_cap = 0;
+  bool ip_step_done = false;
+  volatile double* ip_mail_host = nullptr;
+  double* ip_mail_dev = nullptr;
+  long long ip_seq = 0;
   // coupling structure: dense S (default) or block-tridiagonal with G blocks of gs rows (n_c = G * gs)
   int btd = 0, gs = 0, G = 0;
   double *btd_fac = nullptr, *btd_inv = nullptr, *btd_x = nullptr, *btd_q = nullptr, *btd_vec = nullptr;

@@ -22,11 +22,11 @@ def random_stochastic_qp(n_scenarios, n=24, n_fs=4, n_eq=6, n_ineq=8, seed=0, du
     hr = np.concatenate([np.arange(n), np.arange(1, n)])
     hc = np.concatenate([np.arange(n), np.arange(0, n - 1)])
     er = np.repeat(np.arange(n_eq), 3)
-    ec = np.concatenate([np.sort(rng.choice(n, size=3, replace=False)) for _ in range(n_eq)])
+    ec = np.concatenate([np.sort(rng.choice(n, size=3, replace=False)) for _ in range(n_eq)] + [np.zeros(0, dtype=np.int64)])
     if duplicate_eq_row:
         ec[-3:] = ec[-6:-3]
     ir = np.repeat(np.arange(n_ineq), 3)
-    ic = np.concatenate([np.sort(rng.choice(n, size=3, replace=False)) for _ in range(n_ineq)])
+    ic = np.concatenate([np.sort(rng.choice(n, size=3, replace=False)) for _ in range(n_ineq)] + [np.zeros(0, dtype=np.int64)])
     z_star = rng.uniform(1.0, 2.0, size=n_fs)
     lb = np.zeros(n)
     ub = np.full(n, np.inf)

@@ -2,67 +2,75 @@
 
 The reference's interior-point interfaces rebuild the block KKT matrix and the right-hand side on the host in every
 iteration (parapint/interfaces/interface.py:432-538, schur_complement/sc_ip_interface.py:1677-1710,
-mpi_sc_ip_interface.py:470-478) and hand them to the linear solver as SciPy / PyNumero objects.  For a two-stage
-stochastic QP only the barrier diagonals ``z_l / (x - l) + z_u / (u - x)`` (interface.py:450-465) change between
-iterations; Hessian and Jacobian values are data.  This class keeps the iterates of ALL scenarios in HBM in the solver's
-own [row][instance] layout and
+mpi_sc_ip_interface.py:470-478) and hand them to the linear solver as SciPy / PyNumero objects; ``ip_solve`` then does its
+vector work on PyNumero block vectors (algorithms/interior_point.py:174-317, 553-626, 655-758).  For a two-stage stochastic
+QP only the barrier diagonals ``z_l / (x - l) + z_u / (u - x)`` (interface.py:450-465) change between iterations; Hessian and
+Jacobian values are data.  This class keeps the iterates of this rank's scenarios in HBM in the solver's own [row][instance]
+layout -- one state per pattern group of the solver -- and runs everything around the linear solve as HIP kernels
+(``csrc/ipstep.hip`` through ``parapint_amd.linalg.device_ip_ops``):
 
-  * writes the per-iteration KKT values straight into the source tensor of the solver's ``DeviceBlockMatrix`` (the value
-    map from KKT entry to source is found once, by evaluating the host interface on tagged values),
-  * assembles the right-hand side into a ``DeviceBlockVector`` (interface.py:496-538, sc_ip_interface.py:1683-1696),
-  * recovers the bound-dual steps, the convergence measures and the step lengths on the device
-    (interface.py:562-588, algorithms/interior_point.py:174-317, 655-758; ``parapint_amd.linalg.device_vector_ops``),
-  * expresses the inertia-correction regularisation as a diagonal shift of the resident matrix
-    (interface.py:590-619, sc_ip_interface.py:1736-1757 -> ``DeviceBlockMatrix.with_diagonal_shift``).
+  * ``evaluate_primal_dual_kkt_matrix``: nothing to do -- the step kernel has already written the barrier diagonals where
+    the factorisation kernels read them (the value map from KKT entry to source is found once, by evaluating the host
+    interface on tagged values);
+  * ``evaluate_primal_dual_kkt_rhs``: one elementwise kernel finishes the right-hand side (interface.py:496-538,
+    sc_ip_interface.py:1683-1696) in the ``DeviceBlockVector`` the sweeps read in place;
+  * ``fraction_to_the_boundary`` / ``take_step`` / ``check_convergence``: bound-dual steps (interface.py:562-588), step
+    lengths, the step and the three convergence measures in four kernels + two small reductions; seven scalars reach the
+    host through a pinned mailbox;
+  * inertia correction: a diagonal shift of the resident matrix (interface.py:590-619, sc_ip_interface.py:1736-1757 ->
+    ``DeviceBlockMatrix.with_diagonal_shift``).
 
-It is the producer side of the hot path, not a port of the interface classes: scenarios are given as
-``QuadraticProgram`` objects with one common sparsity pattern (one pattern group), one rank.  The host class
-``StochasticSchurComplementInteriorPointInterface`` stays the specification -- the value map is read off it, the initial
-point comes from it, and ``tests/test_device_ip.py`` compares the iterates of both.
+Scenarios are ``QuadraticProgram`` objects; they may have several sparsity patterns (one state per pattern group) and are
+dealt round-robin over the ranks of the communicator as the reference deals them (mpi_sc_ip_interface.py:14-29).  Between
+ranks the step lengths and the measures + coupling block of the right-hand side are all-gathered and combined in rank
+order on every rank.  The host class ``StochasticSchurComplementInteriorPointInterface`` stays the specification: the value
+map is read off it, and ``tests/test_device_ip.py`` compares the iterates of both.
 """
+import zlib
+
 import numpy as np
 
 from parapint_amd.algorithms import interior_point as host_ip
-from parapint_amd.interfaces.interface import QuadraticProgram
+from parapint_amd.interfaces.interface import QuadraticProgram, _relaxed
 from parapint_amd.interfaces.schur_complement.sc_ip_interface import StochasticSchurComplementInteriorPointInterface
+from parapint_amd.linalg.comm import SerialComm
+from parapint_amd.linalg.device_ip_ops import V_HEAD
+from parapint_amd.sparse.block_containers import BlockMatrix, MPIBlockMatrix
 from parapint_amd.sparse.device_containers import DeviceBlockMatrix
 
 _TAG = 1 << 22          # tags of the five source families are k * _TAG + index + 1 (exact in a double)
 
 
-def _same_pattern(a, b):
-    return a.shape == b.shape and np.array_equal(a.row, b.row) and np.array_equal(a.col, b.col)
+class _PatternGroup(object):
+    """Scenarios of this rank with one sparsity pattern (Hessian, both Jacobians, first-stage indices)."""
 
-
-class DeviceStochasticQPInterface(object):
-    def __init__(self, scenarios, first_stage_indices, bounds_relaxation_factor=1e-8):
-        self.scenarios = list(scenarios)
-        self.N = N = len(self.scenarios)
-        q0 = self.scenarios[0]
-        fs0 = np.asarray(first_stage_indices[0], dtype=np.int64)
-        for q, fs in zip(self.scenarios, first_stage_indices):
-            if not (_same_pattern(q.H, q0.H) and _same_pattern(q.A_eq, q0.A_eq) and _same_pattern(q.A_ineq, q0.A_ineq)
-                    and np.array_equal(np.asarray(fs, dtype=np.int64), fs0)):
-                raise ValueError('the device producer needs scenarios with one common sparsity pattern')
-        self.fs = fs0
-        self.n, self.me, self.mi, self.nfs = q0.n, q0.A_eq.shape[0], q0.A_ineq.shape[0], fs0.size
-        self.nb = self.n + 2 * self.mi + self.me + self.nfs            # dimension of one diagonal block
+    def __init__(self, q0, fs):
+        self.q0, self.fs = q0, np.asarray(fs, dtype=np.int64)
+        self.members = []
+        self.n, self.me, self.mi, self.nfs = q0.n, q0.A_eq.shape[0], q0.A_ineq.shape[0], self.fs.size
+        self.nb = self.n + 2 * self.mi + self.me + self.nfs          # dimension of one diagonal block
         self.nnzH, self.nnzAe, self.nnzAi = q0.H.nnz, q0.A_eq.nnz, q0.A_ineq.nnz
         # source rows: [H | A_eq | A_ineq | primal barrier diagonal | slack barrier diagonal]
         self.off = np.cumsum([0, self.nnzH, self.nnzAe, self.nnzAi, self.n, self.mi])
         self.nsrc = int(self.off[-1])
-        self.host = StochasticSchurComplementInteriorPointInterface(self.scenarios, [fs0] * N)
-        self.host.set_bounds_relaxation_factor(bounds_relaxation_factor)
-        self._relax = bounds_relaxation_factor
-        self._value_map = self._find_value_map()
-        self.barrier = None
-        self.solver = None
+        self.value_map = None
+        self.K0 = self.A0 = self.A0t = None
 
-    # ------------------------------------------------------------------ value map (once, on the host)
-    def _find_value_map(self):
+    def same_pattern(self, q, fs):
+        q0 = self.q0
+
+        def same(a, b):
+            return a.shape == b.shape and (a.row is b.row or np.array_equal(a.row, b.row)) and \
+                (a.col is b.col or np.array_equal(a.col, b.col))
+        return same(q.H, q0.H) and same(q.A_eq, q0.A_eq) and same(q.A_ineq, q0.A_ineq) and \
+            np.array_equal(np.asarray(fs, dtype=np.int64), self.fs)
+
+    # ---- value map (once, on the host)
+    def find_value_map(self):
         """(src, coef) for the COO entries of K_i followed by those of A_i, read off the HOST interface evaluated on
-        tagged values: every Hessian / Jacobian / barrier-diagonal value is replaced by a number that names it."""
-        q0 = self.scenarios[0]
+        tagged values: every Hessian / Jacobian / barrier-diagonal value is replaced by a number that names it -- no
+        second description of the KKT layout to keep in step with interfaces/interface.py."""
+        q0 = self.q0
 
         def tags(k, count):
             return (k * _TAG + 1 + np.arange(count)).astype(np.double)
@@ -83,190 +91,262 @@ class DeviceStochasticQPInterface(object):
         is_src = (fam >= 1) & (fam <= 5) & (a == np.round(a)) & (idx >= 0)
         src = np.where(is_src, self.off[np.clip(fam - 1, 0, 4)] + idx, -1).astype(np.int32)
         coef = np.where(is_src, np.sign(vals), vals)
-        return src, coef
+        self.value_map = (src, coef)
+
+    # ---- row programs of the kernels (include/parapint_hip.h: pp_ip_group.prog / terms)
+    def row_programs(self):
+        """(prog [n + me + mi + nfs][4], terms [nt][2]): for the rows grad_x L, A_eq x - b, A_ineq x - s, x_fs - z the
+        products {source row or -1, row of W} in the order they are summed -- the Hessian terms of a row first."""
+        q, n, mi, me, nfs, off = self.q0, self.n, self.mi, self.me, self.nfs, self.off
+        H, Ae, Ai = q.H, q.A_eq, q.A_ineq
+        x0, yeq0, yin0, yl0 = 0, n + mi, n + mi + me, n + 2 * mi + me      # rows of W
+        offd = np.flatnonzero(H.row != H.col)
+        eH, eAe, eAi, k = np.arange(self.nnzH), np.arange(self.nnzAe), np.arange(self.nnzAi), np.arange(nfs)
+        parts = [   # (program row, source row, row of W, class: 0 Hessian term, 1 other)
+            (H.row, off[0] + eH, x0 + H.col, 0),
+            (H.col[offd], off[0] + offd, x0 + H.row[offd], 0),              # the mirrored upper triangle
+            (Ae.col, off[1] + eAe, yeq0 + Ae.row, 1),                        # A_eq^T y_eq
+            (Ai.col, off[2] + eAi, yin0 + Ai.row, 1),                        # A_ineq^T y_ineq
+            (self.fs, -np.ones(nfs), yl0 + k, 1),                            # L^T y_link
+            (n + Ae.row, off[1] + eAe, x0 + Ae.col, 1),                      # A_eq x
+            (n + me + Ai.row, off[2] + eAi, x0 + Ai.col, 1),                 # A_ineq x
+            (n + me + mi + k, -np.ones(nfs), x0 + self.fs, 1)]               # x_fs
+        prow = np.concatenate([np.asarray(p[0], dtype=np.int64) for p in parts])
+        src = np.concatenate([np.asarray(p[1], dtype=np.int64) for p in parts])
+        wrow = np.concatenate([np.asarray(p[2], dtype=np.int64) for p in parts])
+        cls = np.concatenate([np.full(len(p[0]), p[3], dtype=np.int64) for p in parts])
+        order = np.lexsort((np.arange(prow.size), cls, prow))              # by row, Hessian terms first, then as listed
+        prow, src, wrow, cls = prow[order], src[order], wrow[order], cls[order]
+        nprog = n + me + mi + nfs
+        t0 = np.searchsorted(prow, np.arange(nprog), side='left')
+        t1 = np.searchsorted(prow, np.arange(nprog), side='right')
+        nH = np.bincount(prow[cls == 0], minlength=nprog)[:nprog]
+        prog = np.stack([t0, t0 + nH, t1, np.zeros(nprog, dtype=np.int64)], axis=1).astype(np.int32)
+        terms = np.stack([src, wrow], axis=1).astype(np.int32)
+        return prog, terms
+
+    # ---- processed initial point of one scenario (interior_point.py:433-447, 761-799)
+    def initial_point(self, q, relax):
+        lb, ub = _relaxed(q.lb, relax, -1.0), _relaxed(q.ub, relax, +1.0)
+        ilb, iub = _relaxed(q.ineq_lb, relax, -1.0), _relaxed(q.ineq_ub, relax, +1.0)
+        x = q.x0.copy()
+        s = np.asarray(q.A_ineq @ q.x0, dtype=np.double)            # interface.py: init_slacks at the given point
+        zl, zu = np.ones(self.n), np.ones(self.n)                   # interface.py:263-283 (no ipopt suffixes)
+        zl[np.isneginf(q.lb)] = 0
+        zu[np.isinf(q.ub)] = 0
+        sl, su = np.zeros(self.mi), np.zeros(self.mi)
+        host_ip.process_init(x, lb, ub)
+        host_ip.process_init(s, ilb, iub)
+        host_ip.process_init_duals_lb(zl, lb)
+        host_ip.process_init_duals_ub(zu, ub)
+        host_ip.process_init_duals_lb(sl, ilb)
+        host_ip.process_init_duals_ub(su, iub)
+        return dict(x=x, s=s, zl=zl, zu=zu, sl=sl, su=su, lb=lb, ub=ub, ilb=ilb, iub=iub)
+
+
+class _GroupState(object):
+    """Device state of one pattern group of the SOLVER (its blocks in lane order)."""
+    pass
+
+
+class DeviceStochasticQPInterface(object):
+    """Parameters
+    ----------
+    scenarios: sequence of QuadraticProgram (only this rank's scenarios are touched; the others may be None)
+    first_stage_indices: per scenario the indices of its copies of the first-stage variables, in the order of the
+        coupling variables (sc_ip_interface.py:1046-1058)
+    comm: communicator of parapint_amd.linalg.comm (None: serial); scenario ndx belongs to rank ndx % size
+    """
+
+    def __init__(self, scenarios, first_stage_indices, comm=None, bounds_relaxation_factor=1e-8):
+        self.comm = SerialComm() if comm is None else comm
+        self.scenarios = list(scenarios)
+        self.first_stage_indices = first_stage_indices
+        self.N = N = len(self.scenarios)
+        if self.comm.size > N:
+            raise ValueError('Cannot yet handle more processes than scenarios')     # mpi_sc_ip_interface.py:322-323
+        self.local = [ndx for ndx in range(N) if ndx % self.comm.size == self.comm.rank]
+        self._relax = bounds_relaxation_factor
+        self.nfs = len(first_stage_indices[self.local[0]])
+        # pattern groups of the local scenarios (index arrays shared between scenarios are recognised by identity)
+        self.pattern_groups, self.group_of = [], {}
+        by_ids, by_sig = {}, {}
+        for ndx in self.local:
+            q, fs = self.scenarios[ndx], first_stage_indices[ndx]
+            if len(fs) != self.nfs:
+                raise ValueError('every scenario must carry a copy of every first-stage variable')
+            ids = (q.n, id(q.H.row), id(q.H.col), id(q.A_eq.row), id(q.A_eq.col), id(q.A_ineq.row), id(q.A_ineq.col), id(fs))
+            pg = by_ids.get(ids)
+            if pg is None:
+                fsa = np.asarray(fs, dtype=np.int64)
+                sig = (q.n, q.A_eq.shape[0], q.A_ineq.shape[0]) + tuple(
+                    (a.size, zlib.crc32(np.ascontiguousarray(a))) for a in (q.H.row, q.H.col, q.A_eq.row, q.A_eq.col,
+                                                                           q.A_ineq.row, q.A_ineq.col, fsa))
+                pg = next((g for g in by_sig.get(sig, ()) if g.same_pattern(q, fs)), None)
+                if pg is None:
+                    pg = _PatternGroup(q, fs)
+                    pg.find_value_map()
+                    by_sig.setdefault(sig, []).append(pg)
+                    self.pattern_groups.append(pg)
+                by_ids[ids] = pg
+            pg.members.append(ndx)
+            self.group_of[ndx] = pg
+        self.nsrc = max(pg.nsrc for pg in self.pattern_groups)
+        self._n_eq = self._n_ineq = None
+        self.barrier = None
+        self.solver = None
+        self.measures = None
+        self.states = []
+        self._host = None
+
+    # ------------------------------------------------------------------ the host specification (tests, value map)
+    @property
+    def host(self):
+        """The host interface over the same scenarios (built on demand: tests compare with it)."""
+        if self._host is None:
+            fs = [np.asarray(f, dtype=np.int64) for f in self.first_stage_indices]
+            self._host = StochasticSchurComplementInteriorPointInterface(self.scenarios, fs,
+                                                                         comm=None if self.comm.size == 1 else self.comm)
+            self._host.set_bounds_relaxation_factor(self._relax)
+        return self._host
 
     # ------------------------------------------------------------------ matrix for the symbolic phase
-    def initial_state_host(self):
-        """The processed initial point of ip_solve (interior_point.py:433-447, 761-799) per scenario, on the host."""
-        h = self.host
-        lay = {'primals': host_ip._Layout(h.init_primals(), None), 'ineq': host_ip._Layout(h.init_slacks(), None),
-               'eq': host_ip._Layout(h.init_duals_eq(), None)}
-        P, I, E = lay['primals'], lay['ineq'], lay['eq']
-        st = dict(primals=P.flat(h.init_primals()), slacks=I.flat(h.init_slacks()), duals_eq=E.flat(h.init_duals_eq()),
-                  duals_ineq=I.flat(h.init_duals_ineq()), zl=P.flat(h.init_duals_primals_lb()),
-                  zu=P.flat(h.init_duals_primals_ub()), sl=I.flat(h.init_duals_slacks_lb()),
-                  su=I.flat(h.init_duals_slacks_ub()))
-        plb, pub = P.flat(h.primals_lb()), P.flat(h.primals_ub())
-        ilb, iub = I.flat(h.ineq_lb()), I.flat(h.ineq_ub())
-        host_ip.process_init(st['primals'], plb, pub)
-        host_ip.process_init(st['slacks'], ilb, iub)
-        host_ip.process_init_duals_lb(st['zl'], plb)
-        host_ip.process_init_duals_ub(st['zu'], pub)
-        host_ip.process_init_duals_lb(st['sl'], ilb)
-        host_ip.process_init_duals_ub(st['su'], iub)
-        st.update(plb=plb, pub=pub, ilb=ilb, iub=iub)
-        return st, lay
-
     def device_kkt_matrix(self):
-        """DeviceBlockMatrix for do_symbolic_factorization: the host KKT matrix at the processed initial point is the
-        pattern (its values fix the static pivot order), the value map names the source of every entry."""
-        st, lay = self.initial_state_host()
-        h = self.host
-        P, I, E = lay['primals'], lay['ineq'], lay['eq']
-        h.set_primals(P.unflat(st['primals'])); h.set_slacks(I.unflat(st['slacks']))
-        h.set_duals_eq(E.unflat(st['duals_eq'])); h.set_duals_ineq(I.unflat(st['duals_ineq']))
-        h.set_duals_primals_lb(P.unflat(st['zl'])); h.set_duals_primals_ub(P.unflat(st['zu']))
-        h.set_duals_slacks_lb(I.unflat(st['sl'])); h.set_duals_slacks_ub(I.unflat(st['su']))
-        # One sparsity pattern for all scenarios (checked in __init__): the blocks of scenario 0 at its processed initial
-        # point stand for every scenario -- the solver reads patterns and one representative value set from this
-        # matrix, never the values of the others (those come from the sources on the device).  Evaluating and
-        # converting all 1024 host blocks was 1.0 of the 1.3 s of the whole 1024-scenario solve.
-        pattern = h.evaluate_primal_dual_kkt_matrix(only=(0,))
-        K0, A0 = pattern.get_block(0, 0).tocoo(), pattern.get_block(self.N, 0).tocoo()
-        pattern.set_block(0, 0, K0)
-        pattern.set_block(self.N, 0, A0)
-        A0t = A0.transpose().tocoo()
-        pattern.set_block(0, self.N, A0t)
-        for ndx in range(1, self.N):
-            pattern.set_block(ndx, ndx, K0)
-            pattern.set_block(self.N, ndx, A0)
-            pattern.set_block(ndx, self.N, A0t)
-        maps = {ndx: self._value_map for ndx in range(self.N)}
-        self._init_state = st
+        """DeviceBlockMatrix for do_symbolic_factorization: per pattern group the host KKT blocks of ONE scenario at its
+        processed initial point are the pattern (their values fix the static pivot order) -- the solver reads patterns and
+        one representative value set from this matrix, the values of all scenarios come from the sources on the device --,
+        the value map names the source of every entry."""
+        N, nfs = self.N, self.nfs
+        if self.comm.size > 1:
+            owner = -np.ones((N + 1, N + 1), dtype=np.int64)
+            for ndx in range(N):
+                owner[ndx, ndx] = owner[N, ndx] = owner[ndx, N] = ndx % self.comm.size
+            pattern = MPIBlockMatrix(N + 1, N + 1, owner, self.comm)
+        else:
+            pattern = BlockMatrix(N + 1, N + 1)
+        for pg in self.pattern_groups:
+            q = pg.q0
+            ti = StochasticSchurComplementInteriorPointInterface([q], [pg.fs])
+            ti.set_bounds_relaxation_factor(self._relax)
+            st = pg.initial_point(q, self._relax)
+            nlp = ti.scenario_interface(0)
+            nlp.set_primals(st['x']); nlp.set_slacks(st['s'])
+            nlp.set_duals_primals_lb(st['zl']); nlp.set_duals_primals_ub(st['zu'])
+            nlp.set_duals_slacks_lb(st['sl']); nlp.set_duals_slacks_ub(st['su'])
+            kkt = ti.evaluate_primal_dual_kkt_matrix()
+            pg.K0, pg.A0 = kkt.get_block(0, 0).tocoo(), kkt.get_block(1, 0).tocoo()
+            pg.A0t = pg.A0.transpose().tocoo()
+            for ndx in pg.members:
+                pattern.set_block(ndx, ndx, pg.K0)
+                pattern.set_block(N, ndx, pg.A0)
+                pattern.set_block(ndx, N, pg.A0t)
+        for ndx in self.local:
+            pattern.set_row_size(ndx, self.group_of[ndx].nb)
+            pattern.set_col_size(ndx, self.group_of[ndx].nb)
+        from scipy.sparse import identity
+        corner = identity(nfs, format='coo')
+        corner.data.fill(0)
+        pattern.set_block(N, N, corner)
+        maps = {ndx: self.group_of[ndx].value_map for ndx in self.local}
         return DeviceBlockMatrix(pattern, maps, self.nsrc)
 
     # ------------------------------------------------------------------ state on the device
     def attach(self, solver, dk):
-        """After do_symbolic_factorization(matrix=dk): iterates, data and bounds as [row][instance] tensors in the
-        solver's lane order, constant KKT values into the source tensor, regularisation classes, right-hand side."""
-        import torch
-        if len(dk.slots) != 1:
-            raise ValueError('the device producer handles one pattern group')
+        """After do_symbolic_factorization(matrix=dk): iterates, data and bounds of every pattern group of the solver as
+        [row][instance] tensors in its lane order, constant KKT values into the source tensors, row programs,
+        regularisation classes, right-hand side; then the measures of the initial point."""
         self.solver, self.dk = solver, dk
-        (gid, order), = dk.slots.items()
-        self.gid, self.order = gid, list(order)
-        src = dk.sources[gid]
-        self.bpad, self.B = src.shape[1], len(order)
-        dev = src.device
-        st = self._init_state
-        n, me, mi, nfs, N = self.n, self.me, self.mi, self.nfs, self.N
-        lanes = np.array(self.order + [self.order[0]] * (self.bpad - self.B))      # padded lanes repeat a real scenario ...
-
-        def dev2(per_scenario, rows):
-            a = np.zeros((rows, self.bpad))
-            for b, ndx in enumerate(lanes):
-                a[:, b] = per_scenario(ndx)
-            return torch.from_numpy(a).to(dev)
-
-        def seg(name, size, stride):      # scenario ndx's part of a flat host vector with `stride` entries per scenario
-            v = st[name]
-            return lambda ndx: v[ndx * stride: ndx * stride + size]
-        self.x = dev2(seg('primals', n, n), n)
-        self.s = dev2(seg('slacks', mi, mi), mi)
-        self.yeq = dev2(lambda ndx: st['duals_eq'][ndx * (me + nfs): ndx * (me + nfs) + me], me)
-        self.ylink = dev2(lambda ndx: st['duals_eq'][ndx * (me + nfs) + me: (ndx + 1) * (me + nfs)], nfs)
-        self.yin = dev2(seg('duals_ineq', mi, mi), mi)
-        self.zl, self.zu = dev2(seg('zl', n, n), n), dev2(seg('zu', n, n), n)
-        self.sl, self.su = dev2(seg('sl', mi, mi), mi), dev2(seg('su', mi, mi), mi)
-        self.lb, self.ub = dev2(seg('plb', n, n), n), dev2(seg('pub', n, n), n)
-        self.ilb, self.iub = dev2(seg('ilb', mi, mi), mi), dev2(seg('iub', mi, mi), mi)
-        # ... but carry no bound and no bound dual, so that they never limit a step or enter a norm
-        for t, v in ((self.lb, -np.inf), (self.ub, np.inf), (self.ilb, -np.inf), (self.iub, np.inf),
-                     (self.zl, 0.0), (self.zu, 0.0), (self.sl, 0.0), (self.su, 0.0)):
-            t[:, self.B:] = v
-        self.z = torch.from_numpy(st['primals'][N * n:N * n + nfs].copy()).to(dev)      # coupling variables (free)
-        qs = self.scenarios
-        self.c = dev2(lambda ndx: qs[ndx].c, n)
-        self.beq = dev2(lambda ndx: qs[ndx].b_eq, me)
-        o = self.off
-        self.Hv, self.Aev, self.Aiv = src[o[0]:o[1]], src[o[1]:o[2]], src[o[2]:o[3]]      # views of the source tensor
-        self.dp, self.ds = src[o[3]:o[4]], src[o[4]:o[5]]
-        self.Hv.copy_(dev2(lambda ndx: qs[ndx].H.data, self.nnzH))
-        self.Aev.copy_(dev2(lambda ndx: qs[ndx].A_eq.data, self.nnzAe))
-        self.Aiv.copy_(dev2(lambda ndx: qs[ndx].A_ineq.data, self.nnzAi))
-        q0 = qs[0]
-        ti = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64)).to(dev)      # noqa: E731
-        self.Hr, self.Hc = ti(q0.H.row), ti(q0.H.col)
-        offd = np.flatnonzero(q0.H.row != q0.H.col)
-        self.Hoff = ti(offd)
-        self.Aer, self.Aec = ti(q0.A_eq.row), ti(q0.A_eq.col)
-        self.Air, self.Aic = ti(q0.A_ineq.row), ti(q0.A_ineq.col)
-        self.fsd = ti(self.fs)
-        # inertia correction: +coef on the primal rows, -coef on the constraint rows (equality, inequality, link)
-        cls = np.zeros(self.nb, dtype=np.int8)
-        cls[:n] = 1
-        cls[n + mi:] = 2
-        solver.set_regularization_classes({ndx: cls for ndx in range(N)})
+        self.ops = ops = solver._eng.ip_ops()
+        nfs, P = self.nfs, self.comm.size
         self.rhs = solver.new_device_vector()
-        self._cnt_bounds = float(sum(np.isfinite(st[k]).sum() for k in ('plb', 'pub', 'ilb', 'iub')))
-        self._cnt_duals = float(N * (me + nfs) + N * mi) + self._cnt_bounds
-        self.update_kkt_sources()
+        self.states, descs, classes = [], [], {}
+        counts = np.zeros(5)       # finite bounds, duals, sum of c0, equality rows, inequality rows (this rank)
+        for gid in sorted(dk.slots):
+            order = list(dk.slots[gid])
+            pg = self.group_of[order[0]]
+            if any(self.group_of[ndx] is not pg for ndx in order):
+                raise ValueError('blocks of one solver group come from different pattern groups')
+            src = dk.sources[gid]
+            B, bpad = len(order), int(src.shape[1])
+            n, mi, me, nb, off = pg.n, pg.mi, pg.me, pg.nb, pg.off
+            lanes = order + [order[0]] * (bpad - B)              # padded lanes repeat a real scenario ...
+            W = np.zeros((bpad, nb + 2 * n + 2 * mi))
+            bounds = np.zeros((bpad, 2 * n + 2 * mi))
+            data = np.zeros((bpad, n + me))
+            vals = np.zeros((bpad, int(off[3])))
+            for b, ndx in enumerate(lanes):
+                q = self.scenarios[ndx]
+                st = pg.initial_point(q, self._relax)
+                real = b < B
+                W[b, 0:n], W[b, n:n + mi] = st['x'], st['s']
+                if real:                                          # ... but carry no bound and no bound dual
+                    W[b, nb:nb + n], W[b, nb + n:nb + 2 * n] = st['zl'], st['zu']
+                    W[b, nb + 2 * n:nb + 2 * n + mi], W[b, nb + 2 * n + mi:] = st['sl'], st['su']
+                    bounds[b, 0:n], bounds[b, n:2 * n] = st['lb'], st['ub']
+                    bounds[b, 2 * n:2 * n + mi], bounds[b, 2 * n + mi:] = st['ilb'], st['iub']
+                    counts[0] += sum(np.isfinite(st[k]).sum() for k in ('lb', 'ub', 'ilb', 'iub'))
+                    counts[2] += q.c0
+                else:
+                    bounds[b, 0:n], bounds[b, n:2 * n] = -np.inf, np.inf
+                    bounds[b, 2 * n:2 * n + mi], bounds[b, 2 * n + mi:] = -np.inf, np.inf
+                data[b, 0:n], data[b, n:] = q.c, q.b_eq
+                vals[b, off[0]:off[1]], vals[b, off[1]:off[2]], vals[b, off[2]:off[3]] = q.H.data, q.A_eq.data, q.A_ineq.data
+            counts[1] += B * (me + nfs + mi)
+            counts[3] += B * (me + nfs)
+            counts[4] += B * mi
+            gs = _GroupState()
+            gs.gid, gs.pg, gs.order, gs.B, gs.bpad = gid, pg, order, B, bpad
+            gs.W, gs.bounds, gs.data = ops.rows_from_instances(W), ops.rows_from_instances(bounds), ops.rows_from_instances(data)
+            gs.src = src
+            if off[3] > 0:
+                src[0:int(off[3])] = ops.rows_from_instances(vals)
+            gs.G = ops.zeros((max(n, 1), bpad))
+            prog, terms = pg.row_programs()
+            gs.prog, gs.terms = ops.from_host(prog), ops.from_host(terms if terms.size else np.zeros((1, 2), dtype=np.int32))
+            gs.rhs = self.rhs.group_tensors[gid]
+            descs.append(dict(n=n, mi=mi, me=me, nfs=nfs, batch=B, bpad=bpad, src_dp=int(off[3]), src_ds=int(off[4]),
+                              W=gs.W, bounds=gs.bounds, data=gs.data, src=gs.src, G=gs.G, rhs=gs.rhs, prog=gs.prog,
+                              terms=gs.terms))
+            # inertia correction: +coef on the primal rows, -coef on the constraint rows (equality, inequality, link)
+            cls = np.zeros(nb, dtype=np.int8)
+            cls[:n] = 1
+            cls[n + mi:] = 2
+            for ndx in order:
+                classes[ndx] = cls
+            self.states.append(gs)
+        solver.set_regularization_classes(classes)
+        self._prepared = ops.prepare(descs)
+        self.z = ops.zeros((max(nfs, 1),))                        # coupling variables: free, start at 0
+        nv = V_HEAD + nfs
+        self._alpha_local, self._v_local = ops.zeros((2,)), ops.zeros((nv,))
+        self._alpha_table = self._alpha_local if P == 1 else ops.zeros((P, 2))
+        self._v_table = self._v_local if P == 1 else ops.zeros((P, nv))
+        if P > 1:
+            counts = np.asarray(self.comm.allreduce_sum(counts), dtype=np.double)
+        self._cnt_bounds, self._cnt_duals, self._c0 = float(counts[0]), float(counts[0] + counts[1]), float(counts[2])
+        self._n_eq, self._n_ineq = int(round(counts[3])), int(round(counts[4]))
+        self._have_step = False
 
     # ------------------------------------------------------------------ sizes the loop asks for
     def n_eq_constraints(self):
-        return self.N * (self.me + self.nfs)
+        return self._n_eq
 
     def n_ineq_constraints(self):
-        return self.N * self.mi
+        return self._n_ineq
 
     def set_barrier_parameter(self, barrier):
         self.barrier = float(barrier)
 
-    # ------------------------------------------------------------------ products with the scenario data (shared pattern)
-    def _add_rows(self, out, rows, vals):
-        return out.index_add_(0, rows, vals)
-
-    def _grad_obj(self):
-        import torch
-        g = self.c.clone()
-        if self.nnzH:
-            self._add_rows(g, self.Hr, self.Hv * self.x[self.Hc])
-            if self.Hoff.numel():
-                o = self.Hoff
-                self._add_rows(g, self.Hc[o], self.Hv[o] * self.x[self.Hr[o]])
-        return g
-
-    def _jac_products(self):
-        """A_eq x - b_eq, A_ineq x, and J^T y of one scenario block (equality, link and inequality parts)."""
-        import torch
-        eq = -self.beq.clone()
-        if self.nnzAe:
-            self._add_rows(eq, self.Aer, self.Aev * self.x[self.Aec])
-        ineq = torch.zeros_like(self.s)
-        if self.nnzAi:
-            self._add_rows(ineq, self.Air, self.Aiv * self.x[self.Aic])
-        jt = torch.zeros_like(self.x)
-        if self.nnzAe:
-            self._add_rows(jt, self.Aec, self.Aev * self.yeq[self.Aer])
-        if self.nnzAi:
-            self._add_rows(jt, self.Aic, self.Aiv * self.yin[self.Air])
-        self._add_rows(jt, self.fsd, self.ylink)
-        return eq, ineq, jt
-
     # ------------------------------------------------------------------ the per-iteration producer
-    def update_kkt_sources(self):
-        """interface.py:450-465: the barrier diagonals, written where the factorisation kernels read them."""
-        import torch
-        torch.add(self.zl / (self.x - self.lb), self.zu / (self.ub - self.x), out=self.dp)
-        torch.add(self.sl / (self.s - self.ilb), self.su / (self.iub - self.s), out=self.ds)
-
     def evaluate_primal_dual_kkt_matrix(self, timer=None):
-        self.update_kkt_sources()
+        """interface.py:432-494: the barrier diagonals are where the factorisation kernels read them already (written by
+        the step kernel at the current iterate)."""
         return self.dk
 
     def evaluate_primal_dual_kkt_rhs(self, timer=None):
-        """interface.py:496-538 + sc_ip_interface.py:1683-1696, into the DeviceBlockVector the solver reads in place."""
-        mu = self.barrier
-        eq, ineq, jt = self._jac_products()
-        n, mi, me, nfs = self.n, self.mi, self.me, self.nfs
-        r = self.rhs.group_tensors[self.gid]
-        grad_lag_primals = self._grad_obj() + jt - mu / (self.x - self.lb) + mu / (self.ub - self.x)
-        r[0:n] = -grad_lag_primals
-        r[n:n + mi] = -(-self.yin - mu / (self.s - self.ilb) + mu / (self.iub - self.s))
-        r[n + mi:n + mi + me] = -eq
-        r[n + mi + me:n + 2 * mi + me] = -(ineq - self.s)
-        r[n + 2 * mi + me:] = self.z[:, None] - self.x[self.fsd]
-        self.rhs.coupling.copy_(self.ylink[:, :self.B].sum(dim=1))
+        """interface.py:496-538 + sc_ip_interface.py:1683-1696: the variable rows from grad f + J^T y (left by the
+        residual kernel) and the barrier parameter; the constraint rows and the coupling block are in place already."""
+        self.ops.rhs(self._prepared, self.barrier)
         return self.rhs
 
     def regularize_equality_gradient(self, kkt, coef, copy_kkt=True):
@@ -283,83 +363,51 @@ class DeviceStochasticQPInterface(object):
 
     # ------------------------------------------------------------------ the step after the solve
     def set_primal_dual_kkt_solution(self, delta):
-        """Views of the solution blocks and the bound-dual steps (interface.py:540-588)."""
-        d = delta.group_tensors[self.gid]
-        d[:, self.B:] = 0.0                                  # padded lanes never limit a step
-        n, mi, me = self.n, self.mi, self.me
-        self.dx, self.dsl_ = d[0:n], d[n:n + mi]
-        self.dyeq, self.dyin = d[n + mi:n + mi + me], d[n + mi + me:n + 2 * mi + me]
-        self.dylink = d[n + 2 * mi + me:]
-        self.dz = delta.coupling
-        mu = self.barrier
-        self.dzl = (mu - self.zl * self.dx) / (self.x - self.lb) - self.zl
-        self.dzu = (mu + self.zu * self.dx) / (self.ub - self.x) - self.zu
-        self.dsl = (mu - self.sl * self.dsl_) / (self.s - self.ilb) - self.sl
-        self.dsu = (mu + self.su * self.dsl_) / (self.iub - self.s) - self.su
-        for t in (self.dzl, self.dzu, self.dsl, self.dsu):
-            t[:, self.B:] = 0.0
+        """interface.py:540-588: the step is read where the backward sweep left it; the bound-dual steps are formed on the
+        fly by the kernels that use them."""
+        for gi, gs in enumerate(self.states):
+            self.ops.set_delta(self._prepared, gi, delta.group_tensors[gs.gid])
+        self._dz = delta.coupling
+        self._have_step = True
 
     def fraction_to_the_boundary(self, tau):
-        """interior_point.py:677-758 with the solver's fused kernel (one pass per variable family)."""
-        from parapint_amd.linalg.device_vector_ops import step_stats
-        ap1, ad1, _, _ = step_stats(self.solver, self.x, self.dx, self.lb, self.ub, self.zl, self.dzl, self.zu, self.dzu, tau)
-        ap2 = ad2 = 1.0
-        if self.mi:
-            ap2, ad2, _, _ = step_stats(self.solver, self.s, self.dsl_, self.ilb, self.iub, self.sl, self.dsl, self.su,
-                                        self.dsu, tau)
-        return min(ap1, ap2), min(ad1, ad2)
+        """interior_point.py:677-758: this rank's step lengths, then all ranks' (they stay on the device; the host gets
+        them with the measures)."""
+        self.ops.step_lengths(self._prepared, tau, self.barrier, self._alpha_local)
+        self.ops.allgather(self.comm, self._alpha_local, self._alpha_table)
 
-    def take_step(self, alpha_primal, alpha_dual):
-        """interior_point.py:619-626 (solver kernels for the block vectors, the coupling variables with torch)."""
-        from parapint_amd.linalg.device_vector_ops import axpy_
-        for y, a, x in ((self.x, alpha_primal, self.dx), (self.s, alpha_primal, self.dsl_),
-                        (self.yeq, alpha_dual, self.dyeq), (self.yin, alpha_dual, self.dyin),
-                        (self.ylink, alpha_dual, self.dylink), (self.zl, alpha_dual, self.dzl),
-                        (self.zu, alpha_dual, self.dzu), (self.sl, alpha_dual, self.dsl), (self.su, alpha_dual, self.dsu)):
-            if y.numel():
-                axpy_(self.solver, y, a, x.contiguous())
-        self.z.add_(self.dz, alpha=alpha_primal)
+    def take_step(self, unified=False):
+        """interior_point.py:619-626 with the step lengths of fraction_to_the_boundary; without a step (the initial
+        point) only the barrier diagonals and the elementwise measures are formed."""
+        table = self._alpha_table if self._have_step else None
+        self.ops.take_step(self._prepared, table, self.comm.size, unified, self.barrier, self.z,
+                           self._dz if self._have_step else None)
 
-    def check_convergence(self, barrier, error_scaling):
-        """interior_point.py:174-317: (primal infeasibility, scaled dual infeasibility, scaled complementarity) with ONE
-        transfer of seven scalars."""
-        import torch
-        B = self.B
-        eq, ineq, jt = self._jac_products()
-        link = self.x[self.fsd] - self.z[:, None]
-        glp = self._grad_obj() + jt - self.zl + self.zu
-        glc = -self.ylink[:, :B].sum(dim=1)                  # coupling block of the gradient of the Lagrangian
-        gls = -self.yin - self.sl + self.su
-
-        def mx(t):
-            return t[:, :B].abs().max() if t.numel() else torch.zeros((), dtype=torch.float64, device=self.x.device)
-
-        def compl(x, bound, dual, lower):
-            fin = torch.isfinite(bound)
-            mod = torch.where(fin, bound, torch.zeros_like(bound))
-            r = ((x - mod) if lower else (mod - x)) * dual - barrier
-            return mx(torch.where(fin, r, torch.zeros_like(r)))
-        vals = torch.stack([
-            torch.max(torch.max(mx(eq), mx(link)), mx(ineq - self.s)),
-            torch.max(torch.max(mx(glp), glc.abs().max()), mx(gls)),
-            torch.max(torch.max(compl(self.x, self.lb, self.zl, True), compl(self.x, self.ub, self.zu, False)),
-                      torch.max(compl(self.s, self.ilb, self.sl, True), compl(self.s, self.iub, self.su, False))),
-            self.zl[:, :B].abs().sum() + self.zu[:, :B].abs().sum() + self.sl[:, :B].abs().sum() + self.su[:, :B].abs().sum(),
-            self.yeq[:, :B].abs().sum() + self.ylink[:, :B].abs().sum() + self.yin[:, :B].abs().sum()]).cpu().numpy()
-        primal_inf, dual_inf, cmpl, bound_sum, dual_sum = (float(v) for v in vals)
-        dual_sum += bound_sum
+    def check_convergence(self, error_scaling):
+        """interior_point.py:174-317 at the current iterate, for barrier = 0 and for the current barrier parameter in one
+        pass: ((primal inf, dual inf, complementarity inf at 0), (..., at mu)), scaled as the reference scales them."""
+        ops, P = self.ops, self.comm.size
+        ops.residuals(self._prepared, self.z, self._v_local)
+        ops.allgather(self.comm, self._v_local, self._v_table)
+        ops.publish(self._v_table, self._alpha_table if self._have_step else None, P, self.nfs, self.rhs.coupling)
+        m = ops.wait()
+        bound_sum, dual_sum = float(m[4]), float(m[4] + m[5])
         dual_scaling = max(error_scaling, dual_sum / self._cnt_duals) / error_scaling
         compl_scaling = max(error_scaling, bound_sum / self._cnt_bounds) / error_scaling if self._cnt_bounds > 0 else 1.0
-        return primal_inf, dual_inf / dual_scaling, cmpl / compl_scaling
+        self.measures = dict(primal_inf=float(m[0]), dual_inf=float(m[1]) / dual_scaling, compl_inf=float(m[2]) / compl_scaling,
+                             compl_inf_barrier=float(m[3]) / compl_scaling, objective=float(m[6]) + self._c0,
+                             alpha_primal=float(m[7]), alpha_dual=float(m[8]))
+        return self.measures
 
     def evaluate_objective(self):
-        g = self._grad_obj()
-        c0 = sum(q.c0 for q in self.scenarios)
-        return c0 + float((0.5 * ((g + self.c) * self.x)[:, :self.B]).sum().cpu())      # 1/2 x'Hx + c'x = 1/2 (Hx + 2c)'x
+        return self.measures['objective']
 
     # ------------------------------------------------------------------ results
     def first_stage_solution(self):
-        return self.z.cpu().numpy()
+        return self.ops.to_host(self.z)[:self.nfs].copy()
 
     def scenario_primals(self, ndx):
-        return self.x[:, self.order.index(ndx)].cpu().numpy()
+        for gs in self.states:
+            if ndx in gs.order:
+                return self.ops.to_host(gs.W[:gs.pg.n, gs.order.index(ndx)]).copy()
+        raise KeyError('scenario %d is not on this rank' % ndx)

@@ -15,7 +15,9 @@ injected at construction.  Three implementations:
 Collectives needed: all-reduce(sum) of the Schur buffer
 (+ packed status / inertia words) once per numeric factorisation
 (reference ``:343``, ``:21``, ``:427-429``), all-reduce(sum) of the coupling rhs once
-per back-solve (``:387``).
+per back-solve (``:387``); for the interior-point step on device-resident iterates two
+all-gathers of a handful of scalars per iteration (step lengths; convergence measures and
+the coupling block of the right-hand side, ``mpi_sc_ip_interface.py:470-478``).
 """
 import numpy as np
 
@@ -35,6 +37,9 @@ class SerialComm(object):
 
     def allreduce_sum_tensor_(self, tensor):
         return tensor
+
+    def allgather(self, arr):
+        return np.asarray(arr)[None]
 
     def barrier(self):
         pass
@@ -81,6 +86,21 @@ class TorchComm(object):
         self._dist.all_reduce(tensor, op=self._dist.ReduceOp.SUM, group=self._group)
         return tensor
 
+    def allgather(self, arr):
+        """[size][...] host array of every rank's `arr` (the scalars of the interior-point step, rank order)."""
+        torch = self._torch
+        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.double).copy())
+        if self.device_collectives:
+            t = t.cuda()
+        out = [torch.empty_like(t) for _ in range(self.size)]
+        self._dist.all_gather(out, t, group=self._group)
+        return np.stack([o.cpu().numpy() for o in out])
+
+    def allgather_tensor_(self, table, local):
+        """table[r] = local of rank r (device tensors, RCCL)."""
+        self._dist.all_gather_into_tensor(table.view(-1), local.view(-1), group=self._group)
+        return table
+
     def barrier(self):
         self._dist.barrier(group=self._group)
 
@@ -114,6 +134,12 @@ class MPI4PyComm(object):
         host = tensor.cpu().numpy()
         tensor.copy_(tensor.new_tensor(self.allreduce_sum(host)))
         return tensor
+
+    def allgather(self, arr):
+        a = np.ascontiguousarray(arr, dtype=np.double)
+        out = np.zeros((self.size,) + a.shape)
+        self._comm.Allgather(a, out)
+        return out
 
     def barrier(self):
         self._comm.Barrier()

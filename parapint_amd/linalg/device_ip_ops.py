@@ -1,0 +1,111 @@
+"""Host side of the interior-point step on device-resident iterates (include/parapint_hip.h: pp_ip_*; SURVEY.md section 8
+rows f2 / f4).
+
+``HipIpOps`` binds the six entry points of ``csrc/ipstep.hip`` for one solver handle: barrier diagonals and right-hand side
+(parapint/interfaces/interface.py:450-465, 496-538), bound-dual steps and fraction to the boundary (:562-588,
+algorithms/interior_point.py:655-758), the step (:619-626) and the convergence measures (:174-317) run as kernels on the
+solver's stream over [row][instance] tensors; the scalars the loop's control flow needs come back through a pinned mailbox.
+Between ranks the per-rank scalars are all-gathered (RCCL through the library or ``torch.distributed``; the reference has
+one scalar all-reduce per reduction hidden in PyNumero's MPIBlockVector, and one of the coupling block of the right-hand
+side, mpi_sc_ip_interface.py:470-478) and combined in rank order on every rank, so that all ranks take the same decisions.
+
+The producer (``parapint_amd.interfaces.schur_complement.device_sc_ip_interface``) only talks to this object; the CPU tests
+substitute a numpy restatement of the same entry points (tests/hostsim_engine.py), the product never does.
+"""
+import ctypes
+
+import numpy as np
+
+V_HEAD = 8          # scalars in front of the per-coupling-variable sums in a rank's vector (pp_ip_residuals)
+
+
+class _Prepared(object):
+    """Descriptors of the pattern groups (pp_ip_group array) + the tensors they point to (kept alive)."""
+
+    def __init__(self, arr, descs):
+        self.arr, self.descs, self.n = arr, descs, len(descs)
+        self.delta = [None] * len(descs)
+
+
+class HipIpOps(object):
+    def __init__(self, engine):
+        import torch
+        from parapint_amd import _native
+        self._torch, self._native = torch, _native
+        self.eng = engine
+        self.lib, self.ns = engine.lib, engine.ns
+        self.device = torch.device('cuda', engine.device)
+
+    # ---- buffers
+    def from_host(self, a):
+        """Host array -> device tensor (float64, or int32 for index data)."""
+        a = np.ascontiguousarray(a)
+        return self._torch.from_numpy(a).to(self.device)
+
+    def rows_from_instances(self, a):
+        """[instance][row] host array -> [row][instance] device tensor (the kernels' layout), transposed on the device."""
+        return self._torch.from_numpy(np.ascontiguousarray(a)).to(self.device).t().contiguous()
+
+    def zeros(self, shape):
+        return self._torch.zeros(shape, dtype=self._torch.float64, device=self.device)
+
+    def to_host(self, t):
+        return t.cpu().numpy()
+
+    # ---- descriptors
+    def prepare(self, descs):
+        arr = (self._native.IpGroup * len(descs))()
+        for q, d in zip(arr, descs):
+            for k in ('n', 'mi', 'me', 'nfs', 'batch', 'bpad', 'src_dp', 'src_ds'):
+                setattr(q, k, int(d[k]))
+            for k in ('W', 'bounds', 'data', 'src', 'G', 'rhs', 'prog', 'terms'):
+                t = d[k]
+                if not t.is_contiguous() or not t.is_cuda:
+                    raise ValueError('interior-point step: %s must be a contiguous device tensor' % k)
+                setattr(q, k, t.data_ptr())
+            q.delta = None
+        return _Prepared(arr, descs)
+
+    def set_delta(self, hd, gi, t):
+        if not t.is_contiguous() or tuple(t.shape) != tuple(hd.descs[gi]['rhs'].shape):
+            raise ValueError('interior-point step: the solution of group %d must be a contiguous [n][bpad] tensor' % gi)
+        hd.arr[gi].delta = t.data_ptr()
+        hd.delta[gi] = t                       # (kept alive until it is replaced)
+
+    # ---- the kernels (all stream-ordered on the solver's stream; only wait() synchronises)
+    def rhs(self, hd, mu):
+        self.ns.check(self.lib.pp_ip_rhs(self.ns.h, hd.n, hd.arr, float(mu)), 'pp_ip_rhs')
+
+    def step_lengths(self, hd, tau, mu, alpha_local):
+        self.ns.check(self.lib.pp_ip_step_lengths(self.ns.h, hd.n, hd.arr, float(tau), float(mu), alpha_local.data_ptr()),
+                      'pp_ip_step_lengths')
+
+    def take_step(self, hd, alpha_table, nranks, unified, mu, z, dz):
+        self.ns.check(self.lib.pp_ip_take_step(self.ns.h, hd.n, hd.arr, None if alpha_table is None else alpha_table.data_ptr(),
+                                               int(nranks), 1 if unified else 0, float(mu), z.data_ptr(),
+                                               None if dz is None else dz.data_ptr()), 'pp_ip_take_step')
+
+    def residuals(self, hd, z, v_local):
+        self.ns.check(self.lib.pp_ip_residuals(self.ns.h, hd.n, hd.arr, z.data_ptr(), v_local.data_ptr()), 'pp_ip_residuals')
+
+    def publish(self, v_table, alpha_table, nranks, nfs, rhs_coupling):
+        self.ns.check(self.lib.pp_ip_publish(self.ns.h, v_table.data_ptr(), None if alpha_table is None else alpha_table.data_ptr(),
+                                             int(nranks), int(nfs), rhs_coupling.data_ptr()), 'pp_ip_publish')
+
+    def wait(self):
+        out = np.zeros(10)
+        self.ns.check(self.lib.pp_ip_wait(self.ns.h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double))), 'pp_ip_wait')
+        return out
+
+    # ---- between ranks
+    def allgather(self, comm, local, table):
+        """table[r] = local of rank r (device tensors).  One rank: the caller passes table = local."""
+        if comm.size == 1:
+            return
+        if self.eng._direct_rccl(comm):
+            self.ns.check(self.lib.pp_comm_allgather(self.ns.h, local.data_ptr(), table.data_ptr(),
+                                                     ctypes.c_int64(local.numel())), 'pp_comm_allgather')
+        elif comm.device_collectives:
+            comm.allgather_tensor_(table, local)
+        else:
+            table.copy_(self._torch.from_numpy(comm.allgather(local.cpu().numpy())).reshape(table.shape))

@@ -261,6 +261,7 @@ class HipEngine(object):
         self.nc = 0
         self._S_t = None
         self._rs_t = None
+        self._ip_ops = None
 
     supports_block_tridiagonal = True
 
@@ -299,6 +300,13 @@ class HipEngine(object):
         ns.check(lib.pp_bind_schur_buffer(ns.h, self._S_t.data_ptr()), 'pp_bind_schur_buffer')
         ns.check(lib.pp_bind_rs_buffer(ns.h, self._rs_t.data_ptr()), 'pp_bind_rs_buffer')
         return [ns.group_stats(i) for i in range(len(groups))]
+
+    def ip_ops(self):
+        """The kernels of the interior-point step on device-resident iterates (parapint_amd.linalg.device_ip_ops)."""
+        if self._ip_ops is None:
+            from parapint_amd.linalg.device_ip_ops import HipIpOps
+            self._ip_ops = HipIpOps(self)
+        return self._ip_ops
 
     def get_factor(self, gid, which, instance, count):
         """Diagnostic: factor storage of one block (0 = U panels, 1 = L rows, 2 = pivot inverses)."""
@@ -2046,6 +2054,7 @@ class MumpsInterface(HipLDLInterface):
         HipLDLInterface.__init__(self, cntl_options=cntl_options, icntl_options=icntl, engine=engine)
         self.par, self.mumps_comm = par, comm
         self._prev_allocation = 0
+        self._budget_given = memory_budget_bytes is not None
         if memory_budget_bytes is not None:
             self._sc._eng.set_memory_budget(memory_budget_bytes)
             self._prev_allocation = int(memory_budget_bytes)
@@ -2085,10 +2094,21 @@ class MumpsInterface(HipLDLInterface):
             raise RuntimeError('Can only compute inertia if the numeric factorization was successful.')
         return tuple(int(v) for v in self._sc._inertia)          # null pivots are reported, as INFOG(28) is
 
+    def do_symbolic_factorization(self, matrix, raise_on_error=True, timer=None):
+        res = HipLDLInterface.do_symbolic_factorization(self, matrix, raise_on_error=raise_on_error, timer=timer)
+        if not self._budget_given:
+            self._prev_allocation = self.get_infog(16)          # MB the plan needs (mumps_interface.py:60)
+        return res
+
     def increase_memory_allocation(self, factor):
+        """mumps_interface.py:105-115: the new allocation (ICNTL(23), MB; bytes if the budget was given in bytes) is
+        factor x the previous one (1 if that rounded to zero) and is returned."""
         self._sc.increase_memory_allocation(factor)
-        self._prev_allocation = int(factor * self._prev_allocation) if self._prev_allocation else 1
-        return self._prev_allocation
+        new_allocation = 1 if self._prev_allocation == 0 else factor * self._prev_allocation
+        if not self._budget_given:
+            self.icntl_options[23] = new_allocation
+        self._prev_allocation = new_allocation
+        return new_allocation
 
 
 class ScipyInterface(HipLDLInterface):

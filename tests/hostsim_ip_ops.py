@@ -1,0 +1,221 @@
+"""TEST-ONLY numpy restatement of the interior-point step kernels (parapint_amd/csrc/ipstep.hip; include/parapint_hip.h:
+pp_ip_*), entry point by entry point and operation by operation: the checker of the device kernels (`-m gpu`) and the
+engine under the producer's host logic in the CPU suite (pattern groups, rank distribution, the loop).  Formulas:
+parapint/interfaces/interface.py:450-465, 496-538, 562-588; algorithms/interior_point.py:174-317, 619-626, 655-758.
+The product never imports it."""
+import numpy as np
+
+V_HEAD = 8
+
+
+def nmax(a, b):
+    return np.nan if (a != a or b != b) else max(a, b)
+
+
+def nmin(a, b):
+    return np.nan if (a != a or b != b) else min(a, b)
+
+
+def _amax(a):
+    """max that propagates NaN, 0 for an empty array (the kernels start from 0)."""
+    return float(np.max(a)) if a.size else 0.0
+
+
+class _Prepared(object):
+    def __init__(self, descs):
+        self.descs, self.n = [dict(d) for d in descs], len(descs)
+        for d in self.descs:
+            d['delta'] = None
+
+
+def _views(d):
+    n, mi, me, nfs, B = d['n'], d['mi'], d['me'], d['nfs'], d['batch']
+    nb = n + 2 * mi + me + nfs
+    W, bd = d['W'], d['bounds']
+    return dict(n=n, mi=mi, me=me, nfs=nfs, B=B, nb=nb, W=W,
+                var=W[:n + mi, :B],                                  # x | s
+                lo=np.concatenate([bd[0:n, :B], bd[2 * n:2 * n + mi, :B]]),
+                hi=np.concatenate([bd[n:2 * n, :B], bd[2 * n + mi:, :B]]),
+                zl=np.concatenate([W[nb:nb + n, :B], W[nb + 2 * n:nb + 2 * n + mi, :B]]),
+                zu=np.concatenate([W[nb + n:nb + 2 * n, :B], W[nb + 2 * n + mi:, :B]]))
+
+
+class HostSimIpOps(object):
+    def __init__(self, engine=None):
+        self.mail = None
+        self._step_part = None
+
+    # ---- buffers (numpy arrays stand for the device tensors)
+    def from_host(self, a):
+        return np.array(a)
+
+    def rows_from_instances(self, a):
+        return np.ascontiguousarray(np.asarray(a).T)
+
+    def zeros(self, shape):
+        return np.zeros(shape)
+
+    def to_host(self, t):
+        return np.asarray(t)
+
+    def prepare(self, descs):
+        return _Prepared(descs)
+
+    def set_delta(self, hd, gi, t):
+        assert tuple(t.shape) == tuple(hd.descs[gi]['rhs'].shape)
+        hd.descs[gi]['delta'] = t
+
+    # ---- k_ip_rhs
+    def rhs(self, hd, mu):
+        with np.errstate(all='ignore'):
+            for d in hd.descs:
+                n, mi, me, B = d['n'], d['mi'], d['me'], d['bpad']
+                W, bd = d['W'], d['bounds']
+                x, lo, hi = W[:n], bd[0:n], bd[n:2 * n]
+                d['rhs'][:n] = -((d['G'][:n] - mu / (x - lo)) + mu / (hi - x))
+                s, lo, hi = W[n:n + mi], bd[2 * n:2 * n + mi], bd[2 * n + mi:]
+                yin = W[n + mi + me:n + 2 * mi + me]
+                d['rhs'][n:n + mi] = -((-yin - mu / (s - lo)) + mu / (hi - s))
+
+    # ---- k_ip_stats + k_ip_stats_final
+    def step_lengths(self, hd, tau, mu, alpha_local):
+        ap = ad = 1.0
+        with np.errstate(all='ignore'):
+            for d in hd.descs:
+                v = _views(d)
+                x, lo, hi, zl, zu = v['var'], v['lo'], v['hi'], v['zl'], v['zu']
+                dx = d['delta'][:v['n'] + v['mi'], :v['B']]
+                if np.isnan(dx).any() or np.isnan(x).any():
+                    ap = np.nan
+                m = (dx < 0) & (lo > -np.inf)
+                if m.any():
+                    ap = nmin(ap, float(np.min((-tau * (x - lo) / dx)[m])))
+                m = (dx > 0) & (hi < np.inf)
+                if m.any():
+                    ap = nmin(ap, float(np.min((tau * (hi - x) / dx)[m])))
+                dzl = (mu - zl * dx) / (x - lo) - zl
+                dzu = (mu + zu * dx) / (hi - x) - zu
+                if np.isnan(dzl).any() or np.isnan(zl).any() or np.isnan(dzu).any() or np.isnan(zu).any():
+                    ad = np.nan
+                for z, dz in ((zl, dzl), (zu, dzu)):
+                    m = dz < 0
+                    if m.any():
+                        ad = nmin(ad, float(np.min((-tau * z / dz)[m])))
+        alpha_local[0], alpha_local[1] = ap, ad
+
+    # ---- k_ip_step
+    def take_step(self, hd, alpha_table, nranks, unified, mu, z, dz):
+        step = alpha_table is not None
+        ap = ad = 0.0
+        if step:
+            t = np.asarray(alpha_table).reshape(nranks, 2)
+            ap, ad = float(t[0, 0]), float(t[0, 1])
+            for r in range(1, nranks):
+                ap, ad = nmin(ap, float(t[r, 0])), nmin(ad, float(t[r, 1]))
+            if unified:
+                ap = ad = nmin(ap, ad)
+            nfs = hd.descs[0]['nfs']
+            z[:nfs] = z[:nfs] + ap * np.asarray(dz)[:nfs]
+        c0 = cm = gls = 0.0
+        bsum = dsum = 0.0
+        with np.errstate(all='ignore'):
+            for d in hd.descs:
+                v = _views(d)
+                n, mi, me, nfs, B, nb, W = v['n'], v['mi'], v['me'], v['nfs'], v['B'], v['nb'], v['W']
+                x, lo, hi, zl, zu = v['var'].copy(), v['lo'], v['hi'], v['zl'].copy(), v['zu'].copy()
+                yin = W[n + mi + me:n + 2 * mi + me, :B].copy()
+                if step:
+                    D = d['delta']
+                    dx = D[:n + mi, :B]
+                    dzl = (mu - zl * dx) / (x - lo) - zl
+                    dzu = (mu + zu * dx) / (hi - x) - zu
+                    x = x + ap * dx
+                    zl = zl + ad * dzl
+                    zu = zu + ad * dzu
+                    yin = yin + ad * D[n + mi + me:n + 2 * mi + me, :B]
+                    W[:n + mi, :B] = x
+                    W[nb:nb + n, :B], W[nb + 2 * n:nb + 2 * n + mi, :B] = zl[:n], zl[n:]
+                    W[nb + n:nb + 2 * n, :B], W[nb + 2 * n + mi:, :B] = zu[:n], zu[n:]
+                    W[n + mi + me:n + 2 * mi + me, :B] = yin
+                    for r0, r1 in ((n + mi, n + mi + me), (n + 2 * mi + me, nb)):          # y_eq, y_link
+                        W[r0:r1, :B] = W[r0:r1, :B] + ad * D[r0:r1, :B]
+                diag = zl / (x - lo) + zu / (hi - x)
+                d['src'][d['src_dp']:d['src_dp'] + n, :B] = diag[:n]
+                d['src'][d['src_ds']:d['src_ds'] + mi, :B] = diag[n:]
+                cl, cu = (x - lo) * zl, (hi - x) * zu
+                ml, mu_ = lo > -np.inf, hi < np.inf
+                c0 = nmax(c0, nmax(_amax(np.abs(cl[ml])), _amax(np.abs(cu[mu_]))))
+                cm = nmax(cm, nmax(_amax(np.abs(cl[ml] - mu)), _amax(np.abs(cu[mu_] - mu))))
+                gls = nmax(gls, _amax(np.abs((-yin - zl[n:]) + zu[n:])))
+                bsum += float(np.sum(np.abs(zl) + np.abs(zu)))
+                dsum += float(np.sum(np.abs(yin)) + np.sum(np.abs(W[n + mi:n + mi + me, :B])) +
+                              np.sum(np.abs(W[n + 2 * mi + me:nb, :B])))
+        self._step_part = (c0, cm, gls, bsum, dsum)
+
+    # ---- k_ip_rows + k_ip_local
+    def residuals(self, hd, z, v_local):
+        c0, cm, gls, bsum, dsum = self._step_part
+        pinf, dinf, obj = 0.0, gls, 0.0
+        nfs = hd.descs[0]['nfs']
+        csum = np.zeros(nfs)
+        with np.errstate(all='ignore'):
+            for d in hd.descs:
+                v = _views(d)
+                n, mi, me, B, nb, W, S = v['n'], v['mi'], v['me'], v['B'], v['nb'], v['W'], d['src']
+                prog, terms = np.asarray(d['prog']), np.asarray(d['terms'])
+                nprog = n + me + mi + nfs
+                t0, tH, t1 = prog[:nprog, 0].astype(np.int64), prog[:nprog, 1].astype(np.int64), prog[:nprog, 2].astype(np.int64)
+                bp = W.shape[1]
+                accH, acc = np.zeros((nprog, bp)), np.zeros((nprog, bp))
+                for j in range(int((t1 - t0).max()) if nprog else 0):
+                    rows = np.flatnonzero(t0 + j < t1)
+                    t = t0[rows] + j
+                    s, w = terms[t, 0], terms[t, 1]
+                    term = np.where((s < 0)[:, None], W[w], S[np.maximum(s, 0)] * W[w])
+                    isH = (t < tH[rows])[:, None]
+                    accH[rows] = np.where(isH, accH[rows] + term, accH[rows])
+                    acc[rows] = np.where(isH, acc[rows], acc[rows] + term)
+                cj = d['data'][:n]
+                gH = cj + accH[:n]
+                G = gH + acc[:n]
+                d['G'][:n] = G
+                zl, zu = W[nb:nb + n], W[nb + n:nb + 2 * n]
+                dinf = nmax(dinf, _amax(np.abs((G - zl) + zu)[:, :B]))
+                obj += float(np.sum((W[:n] * (0.5 * accH[:n] + cj))[:, :B]))
+                res_eq = acc[n:n + me] - d['data'][n:n + me]
+                res_in = acc[n + me:n + me + mi] - W[n:n + mi]
+                res_lk = acc[n + me + mi:nprog] - np.asarray(z)[:nfs, None]
+                d['rhs'][n + mi:n + mi + me] = -res_eq
+                d['rhs'][n + mi + me:n + 2 * mi + me] = -res_in
+                d['rhs'][n + 2 * mi + me:nb] = -res_lk
+                for r in (res_eq, res_in, res_lk):
+                    pinf = nmax(pinf, _amax(np.abs(r[:, :B])))
+                csum += np.sum(W[n + 2 * mi + me:nb, :B], axis=1)
+        v_local[:V_HEAD] = (pinf, dinf, c0, cm, bsum, dsum, obj, 0.0)
+        v_local[V_HEAD:V_HEAD + nfs] = csum
+
+    # ---- k_ip_publish + pp_ip_wait
+    def publish(self, v_table, alpha_table, nranks, nfs, rhs_coupling):
+        T = np.asarray(v_table).reshape(nranks, V_HEAD + nfs)
+        s = np.zeros(nfs)
+        for r in range(nranks):
+            s = s + T[r, V_HEAD:]
+        rhs_coupling[:nfs] = s
+        o = [0.0, _amax(np.abs(s)), 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, 1.0]
+        A = None if alpha_table is None else np.asarray(alpha_table).reshape(nranks, 2)
+        for r in range(nranks):
+            for k in range(4):
+                o[k] = nmax(o[k], float(T[r, k]))
+            for k in (4, 5, 6):
+                o[k] = o[k] + float(T[r, k])
+            if A is not None:
+                o[7], o[8] = nmin(o[7], float(A[r, 0])), nmin(o[8], float(A[r, 1]))
+        self.mail = np.array(o + [0.0])
+
+    def wait(self):
+        return self.mail.copy()
+
+    def allgather(self, comm, local, table):
+        if comm.size == 1:
+            return
+        table[...] = np.asarray(comm.allgather(np.asarray(local))).reshape(table.shape)

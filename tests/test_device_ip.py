@@ -27,10 +27,10 @@ def test_value_map_reproduces_the_host_kkt_matrix(problem):
     qps, fs = farmer_qps() if problem == 'farmer' else random_stochastic_qp(5, seed=3)
     it = DeviceStochasticQPInterface(qps, fs)
     dk = it.device_kkt_matrix()
-    host_kkt = it.host.evaluate_primal_dual_kkt_matrix()      # (dk itself carries scenario 0's blocks for every scenario)
-    src, coef = it._value_map
+    host_kkt = it.host.evaluate_primal_dual_kkt_matrix()      # (dk itself carries one scenario's blocks for every scenario of a pattern group)
     N = len(qps)
     for ndx in range(N):
+        src, coef = it.group_of[ndx].value_map
         nlp = it.host.scenario_interface(ndx)
         dp, ds = nlp.barrier_diagonals()
         q = qps[ndx]
@@ -43,7 +43,7 @@ def test_value_map_reproduces_the_host_kkt_matrix(problem):
         Kh, Ah = host_kkt.get_block(ndx, ndx).tocoo(), host_kkt.get_block(N, ndx).tocoo()
         assert np.array_equal(K.row, Kh.row) and np.array_equal(K.col, Kh.col)
         assert np.array_equal(A.row, Ah.row) and np.array_equal(A.col, Ah.col)
-    assert dk.nsrc == it.nsrc and len(src) == ref.size
+    assert dk.nsrc == it.nsrc == max(pg.nsrc for pg in it.pattern_groups) and len(src) == ref.size
 
 
 def test_shifted_device_matrix_bookkeeping():
@@ -159,3 +159,103 @@ def test_rank_deficient_constraints_go_through_the_retries_from_resident_values(
     assert abs(len(rows) - len(hist)) <= 2
     zh = np.asarray(hi.get_primals().get_block(n_scenarios))
     assert np.abs(it.first_stage_solution() - zh).max() <= 1e-5 * max(1.0, np.abs(zh).max())
+
+
+# ---- the kernels of the interior-point step against their numpy restatement (tests/hostsim_ip_ops.py) ------------------
+def _step_problem(seed, shapes):
+    """Random iterates, bounds (some infinite), data, sources and steps for pattern groups of the given
+    (instances, n, n_fs, n_eq, n_ineq); host arrays in the kernels' [row][instance] layout."""
+    from parapint_amd.interfaces.schur_complement.device_sc_ip_interface import _PatternGroup
+    rng = np.random.default_rng(seed)
+    descs = []
+    nfs = shapes[0][2]
+    for gi, (B, n, _, me, mi) in enumerate(shapes):
+        qps, fs = random_stochastic_qp(1, n=n, n_fs=nfs, n_eq=me, n_ineq=mi, seed=seed + gi)
+        pg = _PatternGroup(qps[0], fs[0])
+        prog, terms = pg.row_programs()
+        bpad = -(-B // 64) * 64
+        nb = pg.nb
+        W = rng.uniform(0.5, 2.0, size=(nb + 2 * n + 2 * mi, bpad))
+        W[n + mi:nb] = rng.normal(size=(nb - n - mi, bpad))                      # constraint duals: any sign
+        lo = W[:n + mi] - rng.uniform(0.1, 1.0, size=(n + mi, bpad))
+        hi = W[:n + mi] + rng.uniform(0.1, 1.0, size=(n + mi, bpad))
+        lo[rng.random(lo.shape) < 0.3] = -np.inf
+        hi[rng.random(hi.shape) < 0.3] = np.inf
+        bounds = np.concatenate([lo[:n], hi[:n], lo[n:], hi[n:]])
+        zl = np.concatenate([W[nb:nb + n], W[nb + 2 * n:nb + 2 * n + mi]])
+        zu = np.concatenate([W[nb + n:nb + 2 * n], W[nb + 2 * n + mi:]])
+        zl[~np.isfinite(lo)] = 0.0
+        zu[~np.isfinite(hi)] = 0.0
+        W[nb:nb + n], W[nb + 2 * n:nb + 2 * n + mi] = zl[:n], zl[n:]
+        W[nb + n:nb + 2 * n], W[nb + 2 * n + mi:] = zu[:n], zu[n:]
+        src = np.zeros((pg.nsrc, bpad))
+        src[:pg.off[3]] = rng.normal(size=(pg.off[3], bpad))
+        descs.append(dict(n=n, mi=mi, me=me, nfs=nfs, batch=B, bpad=bpad, src_dp=int(pg.off[3]), src_ds=int(pg.off[4]),
+                          W=W, bounds=bounds, data=rng.normal(size=(n + me, bpad)), src=src, G=np.zeros((n, bpad)),
+                          rhs=np.zeros((nb, bpad)), prog=prog, terms=terms, delta=rng.normal(size=(nb, bpad))))
+    return descs, rng.normal(size=nfs), rng.normal(size=nfs)
+
+
+def _run_step_sequence(ops, descs, z, dz, mu, tau, nranks=1):
+    """take_step (no step) -> residuals -> publish -> rhs -> step lengths -> take_step -> residuals -> publish."""
+    dev = []
+    for d in descs:
+        dd = {k: (ops.from_host(v) if isinstance(v, np.ndarray) else v) for k, v in d.items() if k != 'delta'}
+        dev.append(dd)
+    hd = ops.prepare(dev)
+    nfs = descs[0]['nfs']
+    zt, dzt = ops.from_host(z.copy()), ops.from_host(dz.copy())
+    alpha, v = ops.zeros((2,)), ops.zeros((8 + nfs,))
+    rc = ops.zeros((max(nfs, 1),))
+    out = {}
+    ops.take_step(hd, None, 1, False, mu, zt, None)
+    ops.residuals(hd, zt, v)
+    ops.publish(v, None, 1, nfs, rc)
+    out['mail0'] = ops.wait()
+    out['v0'] = ops.to_host(v).copy()
+    ops.rhs(hd, mu)
+    out['rhs0'] = [ops.to_host(d['rhs']).copy() for d in dev]
+    out['src0'] = [ops.to_host(d['src']).copy() for d in dev]
+    for gi, d in enumerate(descs):
+        ops.set_delta(hd, gi, ops.from_host(d['delta']))
+    ops.step_lengths(hd, tau, mu, alpha)
+    out['alpha'] = ops.to_host(alpha).copy()
+    ops.take_step(hd, alpha, 1, False, mu, zt, dzt)
+    ops.residuals(hd, zt, v)
+    ops.publish(v, alpha, 1, nfs, rc)
+    out['mail1'] = ops.wait()
+    out['W1'] = [ops.to_host(d['W']).copy() for d in dev]
+    out['G1'] = [ops.to_host(d['G']).copy() for d in dev]
+    ops.rhs(hd, mu)
+    out['rhs1'] = [ops.to_host(d['rhs']).copy() for d in dev]
+    out['src1'] = [ops.to_host(d['src']).copy() for d in dev]
+    out['z1'] = ops.to_host(zt).copy()
+    out['rc1'] = ops.to_host(rc).copy()
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shapes', [[(5, 24, 4, 6, 8)], [(70, 33, 5, 9, 0), (3, 12, 5, 4, 7)], [(130, 40, 3, 0, 5)]])
+def test_step_kernels_match_their_numpy_restatement(shapes):
+    """Elementwise results (iterate, barrier diagonals, right-hand side, grad f + J^T y), step lengths and max-norms bit
+    for bit; sums (duals, objective, coupling block) to rounding of a different summation order."""
+    from hostsim_ip_ops import HostSimIpOps
+    from parapint_amd.linalg.hip_schur_complement import HipEngine
+    descs, z, dz = _step_problem(11, shapes)
+    mu, tau = 0.1, 0.9
+    ref = _run_step_sequence(HostSimIpOps(), [dict(d, **{k: v.copy() for k, v in d.items() if isinstance(v, np.ndarray)})
+                                              for d in descs], z, dz, mu, tau)
+    got = _run_step_sequence(HipEngine().ip_ops(), descs, z, dz, mu, tau)
+    assert np.array_equal(got['alpha'], ref['alpha']) and 0.0 < ref['alpha'].min() < 1.0
+    for key in ('rhs0', 'src0', 'W1', 'G1', 'rhs1', 'src1'):
+        for gi, (a, b) in enumerate(zip(got[key], ref[key])):
+            B = shapes[gi][0]
+            assert np.array_equal(a[:, :B], b[:, :B]), (key, gi, np.abs(a[:, :B] - b[:, :B]).max())
+    assert np.array_equal(got['z1'], ref['z1'])
+    for key in ('mail0', 'mail1'):
+        a, b = got[key], ref[key]
+        assert np.array_equal(a[[0, 2, 3, 7, 8]], b[[0, 2, 3, 7, 8]]), (key, a, b)            # max / min: exact
+        # sums, and the dual infeasibility (its coupling part is |sum over the instances of y_link|)
+        assert np.allclose(a[[1, 4, 5, 6]], b[[1, 4, 5, 6]], rtol=1e-13, atol=0.0), (key, a, b)
+    assert np.allclose(got['rc1'], ref['rc1'], rtol=1e-13, atol=1e-13)
+    assert np.allclose(got['v0'], ref['v0'], rtol=1e-13, atol=1e-13)
