@@ -376,8 +376,8 @@ int pp_vec_axpy(pp_handle h, int64_t n, double alpha, const double* x, double* y
  *                       unified != 0: one length for both); alpha_table == NULL: no step (measures of the initial point).
  *                       z / dz: coupling variables and their step (device, nfs).  Writes the barrier diagonals into src.
  *   pp_ip_residuals     G, the constraint rows of rhs, and v_local (device, 8 + nfs): {primal infeasibility, dual
- *                       infeasibility of the blocks, complementarity at 0 and at mu, sum |bound duals|, sum |constraint
- *                       duals|, objective, 0, sum over the instances of y_link (nfs)}
+ *                       infeasibility of the primal rows, complementarity at 0 and at mu, sum |bound duals|, sum |constraint
+ *                       duals|, objective, dual infeasibility of the slack rows, sum over the instances of y_link (nfs)}
  *   pp_ip_publish       combines the nranks rows of v_table ([nranks][8 + nfs], device; rank order, deterministic) into the
  *                       coupling right-hand side rhs_coupling (device, nfs) and the mailbox
  *   pp_ip_wait          blocks until the last pp_ip_publish has run: out = {primal inf, dual inf, compl(0), compl(mu),

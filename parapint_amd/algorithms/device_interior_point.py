@@ -46,6 +46,7 @@ def ip_solve_device(interface, options=None, timer=None, history=None, stats=Non
     interface.take_step()                                   # (no step yet: barrier diagonals + measures of the initial point)
     m = interface.check_convergence(options.error_scaling)
     t_loop = time.time()
+    counter = _torch_op_counter() if stats is not None else None
     alpha_primal_max = alpha_dual_max = 1
     logger.info('%-6s%-11s%-11s%-11s%-11s%-11s%-11s%-11s%-11s%-7s', 'Iter', 'Objective', 'Prim Inf', 'Dual Inf',
                 'Comp Inf', 'Barrier', 'Prim Step', 'Dual Step', 'Reg', 'Time')
@@ -85,4 +86,32 @@ def ip_solve_device(interface, options=None, timer=None, history=None, stats=Non
     if stats is not None:
         stats['setup_s'] = t_loop - t0
         stats['loop_s'] = time.time() - t_loop
+        stats['torch_ops'] = counter.close() if counter is not None else None
     return status, iterations
+
+
+class _torch_op_counter(object):
+    """Counts the torch operators dispatched while it is open (diagnostic: the iterations of the loop are meant to run on
+    the library's kernels alone; None if torch is not importable -- the CPU tests' numpy engines)."""
+
+    def __init__(self):
+        self.count, self._mode = 0, None
+        try:
+            from torch.utils._python_dispatch import TorchDispatchMode
+        except Exception:
+            return
+        outer = self
+
+        class _Mode(TorchDispatchMode):
+            def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+                outer.count += 1
+                return func(*args, **(kwargs or {}))
+        self._mode = _Mode()
+        self._mode.__enter__()
+
+    def close(self):
+        if self._mode is None:
+            return None
+        self._mode.__exit__(None, None, None)
+        self._mode = None
+        return self.count

@@ -22,7 +22,9 @@ __device__ __forceinline__ double nmin(double a, double b) { return (a != a || b
 constexpr int IP_MAXG = 8;        // pattern groups per call
 constexpr int IP_STEP_SLOTS = 5;  // partials of k_ip_step: compl(0), compl(mu), max |grad_s L|, sum |bound duals|, sum |duals|
 constexpr int IP_ROWS_SLOTS = 3;  // partials of k_ip_rows: primal infeasibility, max |grad_x L|, objective
-constexpr int IP_RPW = 4;         // rows per wave in k_ip_rows
+constexpr int IP_RPW = 4;         // rows per wave in k_ip_rows (at least; more when the launch would exceed IP_ROWS_MAXWG workgroups)
+constexpr unsigned IP_EW_MAXWG = 2048;    // workgroups of the elementwise kernels (grid-stride beyond): bounds the partials of
+constexpr unsigned IP_ROWS_MAXWG = 4096;  // the second reduction stage, which one workgroup combines
 
 __device__ __forceinline__ int ip_nb(const pp_ip_group& g) { return g.n + 2 * g.mi + g.me + g.nfs; }
 
@@ -56,15 +58,16 @@ __device__ __forceinline__ VarRows var_rows(const pp_ip_group& g, int r) {
 // for the primals and -y_ineq for the slacks
 __global__ __launch_bounds__(256) void k_ip_rhs(pp_ip_group g, double mu) {
   const size_t bpad = (size_t)g.bpad;
-  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const int r = (int)(e / bpad);
-  const size_t b = e % bpad;
-  if (r >= g.n + g.mi) return;
-  const VarRows v = var_rows(g, r);
-  const double x = g.W[(size_t)r * bpad + b];
-  const double lo = g.bounds[v.lo * bpad + b], hi = g.bounds[v.hi * bpad + b];
-  const double grad = r < g.n ? g.G[(size_t)r * bpad + b] : -g.W[(size_t)(g.n + g.mi + g.me + (r - g.n)) * bpad + b];
-  g.rhs[(size_t)r * bpad + b] = -((grad - mu / (x - lo)) + mu / (hi - x));
+  const size_t total = (size_t)(g.n + g.mi) * bpad;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int r = (int)(e / bpad);
+    const size_t b = e % bpad;
+    const VarRows v = var_rows(g, r);
+    const double x = g.W[(size_t)r * bpad + b];
+    const double lo = g.bounds[v.lo * bpad + b], hi = g.bounds[v.hi * bpad + b];
+    const double grad = r < g.n ? g.G[(size_t)r * bpad + b] : -g.W[(size_t)(g.n + g.mi + g.me + (r - g.n)) * bpad + b];
+    g.rhs[(size_t)r * bpad + b] = -((grad - mu / (x - lo)) + mu / (hi - x));
+  }
 }
 
 // ---- fraction to the boundary (interior_point.py:655-758) with the bound-dual steps of interface.py:562-588 formed on
@@ -73,11 +76,12 @@ __global__ __launch_bounds__(256) void k_ip_stats(pp_ip_group g, double tau, dou
                                                   int nwg) {
   __shared__ double red[2][256];
   const size_t bpad = (size_t)g.bpad;
-  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const int r = (int)(e / bpad);
-  const int b = (int)(e % bpad);
+  const size_t total = (size_t)(g.n + g.mi) * bpad;
   double v[2] = {1.0, 1.0};
-  if (r < g.n + g.mi && b < g.batch) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int r = (int)(e / bpad);
+    const int b = (int)(e % bpad);
+    if (b >= g.batch) continue;
     const VarRows q = var_rows(g, r);
     const double x = g.W[(size_t)r * bpad + b], dx = g.delta[(size_t)r * bpad + b];
     const double lo = g.bounds[q.lo * bpad + b], hi = g.bounds[q.hi * bpad + b];
@@ -123,12 +127,13 @@ __global__ __launch_bounds__(256) void k_ip_step(pp_ip_group g, const double* __
   }
   if (do_z && step && blockIdx.x == 0)
     for (int k = threadIdx.x; k < g.nfs; k += 256) z[k] = z[k] + ap * dz[k];
-  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-  int r = (int)(e / bpad);
-  const int b = (int)(e % bpad);
-  if (r >= g.n + g.mi + g.me) r += g.mi;           // (the y_ineq rows belong to the slack threads)
+  const size_t total = (size_t)(nb - g.mi) * bpad;
   double v[IP_STEP_SLOTS] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  if (r < nb && b < g.batch) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    int r = (int)(e / bpad);
+    const int b = (int)(e % bpad);
+    if (r >= g.n + g.mi + g.me) r += g.mi;         // (the y_ineq rows belong to the slack threads)
+    if (b >= g.batch) continue;
     const size_t at = (size_t)r * bpad + b;
     if (r < g.n + g.mi) {
       const VarRows q = var_rows(g, r);
@@ -146,18 +151,18 @@ __global__ __launch_bounds__(256) void k_ip_step(pp_ip_group g, const double* __
       g.src[(size_t)srow * bpad + b] = zl / (x - lo) + zu / (hi - x);
       if (lo > -INFINITY) { const double c = (x - lo) * zl; v[0] = nmax(v[0], fabs(c)); v[1] = nmax(v[1], fabs(c - mu)); }
       if (hi < INFINITY) { const double c = (hi - x) * zu; v[0] = nmax(v[0], fabs(c)); v[1] = nmax(v[1], fabs(c - mu)); }
-      v[3] = fabs(zl) + fabs(zu);
+      v[3] = v[3] + (fabs(zl) + fabs(zu));
       if (r >= g.n) {
         const size_t ay = (size_t)(g.n + g.mi + g.me + (r - g.n)) * bpad + b;
         double y = g.W[ay];
         if (step) { y = y + ad * g.delta[ay]; g.W[ay] = y; }
-        v[2] = fabs((-y - zl) + zu);
-        v[4] = fabs(y);
+        v[2] = nmax(v[2], fabs((-y - zl) + zu));
+        v[4] = v[4] + fabs(y);
       }
     } else {
       double y = g.W[at];
       if (step) { y = y + ad * g.delta[at]; g.W[at] = y; }
-      v[4] = fabs(y);
+      v[4] = v[4] + fabs(y);
     }
   }
   const int op[IP_STEP_SLOTS] = {1, 1, 1, 2, 2};
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(256) void k_ip_step(pp_ip_group g, const double* __
 // A_ineq x - s, x_fs - z.  One row x 64 instances per wave and step, IP_RPW rows per wave; the terms of a row are
 // wave-uniform {source row, row of W} pairs, requested four at a time.
 __global__ __launch_bounds__(256) void k_ip_rows(pp_ip_group g, const double* __restrict__ z, double* __restrict__ part, int wg0,
-                                                 int nwg) {
+                                                 int nwg, int rpw) {
   __shared__ double red[IP_ROWS_SLOTS][256];
   const size_t bpad = (size_t)g.bpad;
   const int nchunk = g.bpad >> 6;
@@ -182,8 +187,8 @@ __global__ __launch_bounds__(256) void k_ip_rows(pp_ip_group g, const double* __
   const double* __restrict__ W = g.W + b;
   const double* __restrict__ S = g.src + b;
   double v[IP_ROWS_SLOTS] = {0.0, 0.0, 0.0};
-  for (int q = 0; q < IP_RPW; ++q) {
-    const int p = (tile * 4 + wave) * IP_RPW + q;         // (wave-uniform)
+  for (int q = 0; q < rpw; ++q) {
+    const int p = (tile * 4 + wave) * rpw + q;            // (wave-uniform)
     if (p >= nprog) break;
     const int t0 = g.prog[4 * p], tH = g.prog[4 * p + 1], t1 = g.prog[4 * p + 2];
     double accH = 0.0, acc = 0.0;
@@ -232,32 +237,30 @@ __global__ __launch_bounds__(256) void k_ip_rows(pp_ip_group g, const double* __
   if (threadIdx.x < IP_ROWS_SLOTS) part[(size_t)threadIdx.x * nwg + wg0 + blockIdx.x] = red[threadIdx.x][0];
 }
 
-// ---- this rank's scalars: workgroup 0 combines the partials of k_ip_step and k_ip_rows; the others sum the link duals of
-// every coupling variable over the instances of all groups (one row per wave; the coupling block of the right-hand side,
-// sc_ip_interface.py:1694-1696, and of grad L)
+// ---- this rank's scalars: workgroups 0 .. 7 combine one slot each of the partials of k_ip_step and k_ip_rows (fixed order:
+// deterministic); the others sum the link duals of every coupling variable over the instances of all groups (one row per
+// wave; the coupling block of the right-hand side, sc_ip_interface.py:1694-1696, and of grad L)
 struct IpLinks { int ng, nfs; const double* ylink[IP_MAXG]; int batch[IP_MAXG], bpad[IP_MAXG]; };
 __global__ __launch_bounds__(256) void k_ip_local(IpLinks L, int nwg_step, const double* __restrict__ part_step, int nwg_rows,
                                                   const double* __restrict__ part_rows, double* __restrict__ v_local) {
-  __shared__ double red[8][256];
-  if (blockIdx.x == 0) {
-    double v[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};     // primal inf, dual inf, compl(0), compl(mu), sum |z|, sum |y|, objective
-    for (int i = threadIdx.x; i < nwg_step; i += 256) {
-      v[2] = nmax(v[2], part_step[i]); v[3] = nmax(v[3], part_step[(size_t)nwg_step + i]);
-      v[1] = nmax(v[1], part_step[2 * (size_t)nwg_step + i]);
-    }
-    for (int i = threadIdx.x; i < nwg_rows; i += 256) {
-      v[0] = nmax(v[0], part_rows[i]); v[1] = nmax(v[1], part_rows[(size_t)nwg_rows + i]);
-    }
-    // sums: every thread adds its partials in ascending order, the tree below is fixed -> deterministic
-    for (int i = threadIdx.x; i < nwg_step; i += 256) { v[4] = v[4] + part_step[3 * (size_t)nwg_step + i]; v[5] = v[5] + part_step[4 * (size_t)nwg_step + i]; }
-    for (int i = threadIdx.x; i < nwg_rows; i += 256) v[6] = v[6] + part_rows[2 * (size_t)nwg_rows + i];
-    const int op[8] = {1, 1, 1, 1, 2, 2, 2, 2};
-    wg_reduce<8>(red, v, op);
-    if (threadIdx.x < 8) v_local[threadIdx.x] = red[threadIdx.x][0];
+  __shared__ double red[1][256];
+  if (blockIdx.x < 8) {
+    // slot -> entry of v_local: {primal inf, |grad_x L|, compl(0), compl(mu), sum |z|, sum |y|, objective, |grad_s L|}
+    const int slot = blockIdx.x;
+    const bool from_rows = slot == 0 || slot == 1 || slot == 6;
+    const int src_slot = slot == 0 ? 0 : slot == 1 ? 1 : slot == 6 ? 2 : slot == 2 ? 0 : slot == 3 ? 1 : slot == 7 ? 2 : slot == 4 ? 3 : 4;
+    const int n = from_rows ? nwg_rows : nwg_step;
+    const double* p = (from_rows ? part_rows : part_step) + (size_t)src_slot * n;
+    const bool sum = slot >= 4 && slot <= 6;
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) v = sum ? v + p[i] : nmax(v, p[i]);
+    const int op[1] = {sum ? 2 : 1};
+    wg_reduce<1>(red, &v, op);
+    if (threadIdx.x == 0) v_local[slot] = red[0][0];
     return;
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int k = ((int)blockIdx.x - 1) * 4 + wave;
+  const int k = ((int)blockIdx.x - 8) * 4 + wave;
   if (k >= L.nfs) return;
   double s = 0.0;
   for (int gi = 0; gi < L.ng; ++gi) {
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(256) void k_ip_publish(const double* __restrict__ v
     double o[9] = {0.0, red[0][0], 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, 1.0};
     for (int r = 0; r < nranks; ++r) {
       const double* v = v_table + (size_t)r * nv;
-      o[0] = nmax(o[0], v[0]); o[1] = nmax(o[1], v[1]); o[2] = nmax(o[2], v[2]); o[3] = nmax(o[3], v[3]);
+      o[0] = nmax(o[0], v[0]); o[1] = nmax(o[1], nmax(v[1], v[7])); o[2] = nmax(o[2], v[2]); o[3] = nmax(o[3], v[3]);
       o[4] = o[4] + v[4]; o[5] = o[5] + v[5]; o[6] = o[6] + v[6];
       if (alpha_table) { o[7] = nmin(o[7], alpha_table[2 * r]); o[8] = nmin(o[8], alpha_table[2 * r + 1]); }
     }
@@ -322,10 +325,16 @@ int ip_scratch(pp_handle h, size_t doubles) {
   return 0;
 }
 
-unsigned ew_grid(const pp_ip_group& g, int rows) { return (unsigned)(((size_t)rows * g.bpad + 255) / 256); }
+unsigned ew_grid(const pp_ip_group& g, int rows) {
+  return (unsigned)std::min<size_t>(IP_EW_MAXWG, ((size_t)rows * g.bpad + 255) / 256);
+}
+int rows_rpw(const pp_ip_group& g) {       // rows per wave of k_ip_rows
+  const size_t nprog = (size_t)(g.n + g.me + g.mi + g.nfs), nchunk = (size_t)(g.bpad >> 6);
+  return (int)std::max<size_t>(IP_RPW, (nprog * nchunk + 4 * IP_ROWS_MAXWG - 1) / (4 * IP_ROWS_MAXWG));
+}
 unsigned rows_grid(const pp_ip_group& g) {
-  const int nprog = g.n + g.me + g.mi + g.nfs;
-  return (unsigned)((nprog + 4 * IP_RPW - 1) / (4 * IP_RPW)) * (unsigned)(g.bpad >> 6);
+  const int nprog = g.n + g.me + g.mi + g.nfs, rpw = rows_rpw(g);
+  return (unsigned)((nprog + 4 * rpw - 1) / (4 * rpw)) * (unsigned)(g.bpad >> 6);
 }
 
 // Workgroups of the three reducing kernels over these groups, and the scratch they share: the partials of k_ip_step
@@ -412,12 +421,12 @@ int pp_ip_residuals(pp_handle h, int ngroups, const pp_ip_group* g, const double
   L.ng = ngroups; L.nfs = g[0].nfs;
   for (int i = 0; i < ngroups; ++i) {
     const unsigned n = rows_grid(g[i]);
-    if (n) hipLaunchKernelGGL(k_ip_rows, dim3(n), dim3(256), 0, h->stream, g[i], z, part_rows, (int)wg0, (int)nwg_r);
+    if (n) hipLaunchKernelGGL(k_ip_rows, dim3(n), dim3(256), 0, h->stream, g[i], z, part_rows, (int)wg0, (int)nwg_r, rows_rpw(g[i]));
     wg0 += n;
     L.ylink[i] = g[i].W + (size_t)(g[i].n + 2 * g[i].mi + g[i].me) * g[i].bpad;
     L.batch[i] = g[i].batch; L.bpad[i] = g[i].bpad;
   }
-  hipLaunchKernelGGL(k_ip_local, dim3(1 + (L.nfs + 3) / 4), dim3(256), 0, h->stream, L, (int)nwg_s, h->ip_part, (int)nwg_r,
+  hipLaunchKernelGGL(k_ip_local, dim3(8 + (L.nfs + 3) / 4), dim3(256), 0, h->stream, L, (int)nwg_s, h->ip_part, (int)nwg_r,
                      part_rows, v_local);
   PP_HIP(hipGetLastError());
   return 0;

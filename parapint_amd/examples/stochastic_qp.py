@@ -53,3 +53,71 @@ def random_stochastic_qp(n_scenarios, n=24, n_fs=4, n_eq=6, n_ineq=8, seed=0, du
                                           H=coo_matrix((hd / n_scenarios, (hr, hc)), shape=(n, n))))
         first_stage.append(np.arange(n_fs))
     return scenarios, first_stage
+
+
+def c3_stochastic_qp(n_scenarios, n_q=1000, m=4, n_theta=200, seed=0, local=None, active_fraction=0.1):
+    """A two-stage stochastic QP with the block structure of BASELINE.json configs[2] (the synthetic estimation problem of
+    parapint/examples/performance/schur_complement/create_model.py:11-143): per scenario the n_y = m n_q measurements y and the
+    n_q parameters q are the primal variables (5000 at the defaults), ``y - A_i q = 0`` the equality constraints (A_i: m
+    stacked tridiagonal n_q x n_q matrices, values scenario by scenario), the objective is ``sum_k w_ik (y_k - yhat_ik)^2``
+    and the first n_theta parameters are copies of the first-stage variables -- KKT blocks of dimension
+    n_y + n_q + n_y + n_theta = 9200 with 200 coupling variables.  What the reference problem lacks for an interior-point
+    run is added: bounds on all primal variables (two thirds of them finite; a fraction of the parameter bounds active at
+    the solution).  All scenarios share their index arrays (one Jacobian structure, one object).
+
+    local: iterable of the scenario indices to build (default: all); the other entries of the returned list are None."""
+    rng = np.random.default_rng(seed)
+    n_y = m * n_q
+    n = n_y + n_q
+    # A: m tridiagonal blocks stacked; equality rows [I | -A]
+    tri_r = np.concatenate([np.arange(n_q), np.arange(1, n_q), np.arange(n_q - 1)])
+    tri_c = np.concatenate([np.arange(n_q), np.arange(n_q - 1), np.arange(1, n_q)])
+    ar = np.concatenate([k * n_q + tri_r for k in range(m)])
+    ac = np.tile(tri_c, m)
+    a_base = rng.normal(0.0, 5.0, size=ar.size)
+    er = np.concatenate([np.arange(n_y), ar]).astype(np.int32)
+    ec = np.concatenate([np.arange(n_y), n_y + ac]).astype(np.int32)
+    hr = np.arange(n_y, dtype=np.int32)                     # Hessian: diagonal on y
+    theta = rng.normal(5.0, 2.0, size=n_theta)
+    # bounds of the first-stage copies are common to all scenarios
+    lo_t = theta - rng.uniform(0.5, 2.0, size=n_theta)
+    hi_t = theta + rng.uniform(0.5, 2.0, size=n_theta)
+    fs = n_y + np.arange(n_theta)
+    empty_i = coo_matrix((0, n))
+    want = range(n_scenarios) if local is None else local
+    scenarios = [None] * n_scenarios
+    for i in want:
+        r = np.random.default_rng(100003 * seed + i + 1)
+        q_true = r.normal(5.0, 2.0, size=n_q)
+        q_true[:n_theta] = theta
+        a_i = a_base * (1.0 + 0.05 * r.standard_normal(a_base.size))
+        y_true = np.zeros(n_y)
+        np.add.at(y_true, ar, a_i * q_true[ac])
+        yhat = y_true + 0.01 * np.abs(y_true).max() * r.standard_normal(n_y)
+        w = r.uniform(1.0, 1.25, size=n_y)          # (the sum of the scenario objectives, not their mean: the blocks keep
+                                                    # the scaling of the reference problem whatever the number of scenarios)
+        lb, ub = np.full(n, -np.inf), np.full(n, np.inf)
+        span = 4.0 * np.abs(y_true).max()
+        fin = r.random(n_y) < 0.67
+        lb[:n_y][fin] = (yhat - span)[fin]
+        fin = r.random(n_y) < 0.67
+        ub[:n_y][fin] = (yhat + span)[fin]
+        lq = q_true - r.uniform(0.5, 2.0, size=n_q)
+        uq = q_true + r.uniform(0.5, 2.0, size=n_q)
+        act = r.random(n_q) < active_fraction               # bounds that cut the least-squares solution off
+        lq[act] = q_true[act] + 0.02
+        uq[act] = np.maximum(uq[act], lq[act] + 1.0)
+        lq[r.random(n_q) < 0.33] = -np.inf
+        uq[r.random(n_q) < 0.33] = np.inf
+        lq[:n_theta], uq[:n_theta] = lo_t, hi_t
+        lb[n_y:], ub[n_y:] = lq, uq
+        c = np.zeros(n)
+        c[:n_y] = -2.0 * w * yhat
+        q = QuadraticProgram(c=c, A_eq=None, b_eq=np.zeros(n_y), A_ineq=None, lb=lb, ub=ub, H=None,
+                             c0=float(np.sum(w * yhat * yhat)))
+        # (blocks over the shared index arrays; H is lower triangular already)
+        q.H = coo_matrix((2.0 * w, (hr, hr)), shape=(n, n))
+        q.A_eq = coo_matrix((np.concatenate([np.ones(n_y), -a_i]), (er, ec)), shape=(n_y, n))
+        q.A_ineq = empty_i
+        scenarios[i] = q
+    return scenarios, [fs] * n_scenarios

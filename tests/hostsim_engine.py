@@ -346,3 +346,140 @@ class HostSimBoundaryEngine(HostSimEngine):
         self.download_solution(g.gid, pinned)
         if out is not None:
             out[...] = pinned
+
+
+class NpTensor(np.ndarray):
+    """numpy array with the few tensor methods the solver class calls on device containers (CPU tests only)."""
+
+    def is_contiguous(self):
+        return bool(self.flags.c_contiguous)
+
+    def cpu(self):
+        return self
+
+    def numpy(self):
+        return np.asarray(self)
+
+    def numel(self):
+        return int(self.size)
+
+    def copy_(self, other):
+        self[...] = np.asarray(other)
+        return self
+
+    def zero_(self):
+        self[...] = 0.0
+        return self
+
+
+def _tensor(shape):
+    return np.zeros(shape, dtype=np.double).view(NpTensor)
+
+
+class HostSimDeviceEngine(HostSimEngine):
+    """The host interpreter with the device-container entry points of the HIP engine (value maps and source tensors of a
+    DeviceBlockMatrix, [row][instance] right-hand sides and solutions of a DeviceBlockVector, the diagonal-shift fast path,
+    the interior-point step kernels) restated in numpy: the CPU check of the producer's host logic -- pattern groups,
+    rank distribution, the loop -- including world_size-2 gloo runs."""
+
+    def __init__(self):
+        HostSimEngine.__init__(self)
+        self._ops = None
+
+    def ip_ops(self):
+        if self._ops is None:
+            from hostsim_ip_ops import HostSimIpOps
+            self._ops = HostSimIpOps(self)
+        return self._ops
+
+    def symbolic(self, nc, groups, btd=None, cinv=None):
+        stats = HostSimEngine.symbolic(self, nc, groups, btd=btd, cinv=cinv)
+        for sg in self.groups:
+            sg.vmap = sg.sources = sg.classes = None
+            sg.rhs_native = sg.x_native = None
+        self._shift = (0.0, 0.0)
+        return stats
+
+    def new_tensor(self, shape):
+        return _tensor(shape)
+
+    new_tensor_uninitialized = new_tensor
+
+    def set_value_map(self, gid, nsrc, src, coef):
+        self.groups[gid].vmap = (int(nsrc), np.asarray(src, dtype=np.int64), np.asarray(coef, dtype=np.double))
+
+    def bind_source_tensor(self, gid, tensor):
+        self.groups[gid].sources = tensor
+
+    def set_diagonal_classes(self, gid, cls):
+        sg = self.groups[gid]
+        g = sg.g
+        cls = np.asarray(cls, dtype=np.int8)
+        diag = {int(r): k for k, (r, c) in enumerate(zip(g.rowK, g.colK)) if r == c}
+        missing = [r for r in np.flatnonzero(cls) if int(r) not in diag]
+        if missing:
+            raise hu_status_error(3, 'classed row %d has no diagonal entry in the planned pattern' % missing[0])
+        sg.classes = [(diag[int(r)], int(cls[r])) for r in np.flatnonzero(cls)]
+
+    def _raw_from_sources(self):
+        for sg in self.groups:
+            if sg.sources is None or sg.vmap is None:
+                continue
+            nsrc, src, coef = sg.vmap
+            t = np.asarray(sg.sources)
+            vals = np.where((src >= 0)[:, None], t[np.maximum(src, 0), :sg.batch], 1.0) * coef[:, None]
+            sg.raw = np.ascontiguousarray(vals.T)
+
+    def numeric_local(self):
+        dw, dc = self._shift
+        if dw == 0.0 and dc == 0.0:
+            return HostSimEngine.numeric_local(self)
+        # the diagonal shift of the classed rows goes into duplicate raw entries of their diagonal positions: the
+        # canonical sum then carries it, as pp_numeric_local_shifted adds it to the gathered diagonal
+        saved = []
+        for sg in self.groups:
+            g = sg.g
+            saved.append(sg.raw)
+            raw = np.array(sg.raw, copy=True)
+            for can, cl in (sg.classes or ()):
+                first = g.can_idx[g.can_ptr[can]]
+                raw[:, first] += dw if cl == 1 else -dc
+            sg.raw = raw
+        try:
+            HostSimEngine.numeric_local(self)
+        finally:
+            for sg, raw in zip(self.groups, saved):
+                sg.raw = raw
+
+    def numeric_factor_blocks(self):
+        self._raw_from_sources()
+        HostSimEngine.numeric_factor_blocks(self)
+
+    def numeric_local_shifted(self, delta_w, delta_c):
+        self._shift = (float(delta_w), float(delta_c))
+        try:
+            self.numeric_local()
+        finally:
+            self._shift = (0.0, 0.0)
+
+    def bind_native_vectors(self, gid, rhs, x):
+        sg = self.groups[gid]
+        sg.rhs_native, sg.x_native = rhs, x
+
+    def solve_forward(self):
+        for sg in self.groups:
+            if sg.rhs_native is not None:
+                sg.rhs = np.ascontiguousarray(np.asarray(sg.rhs_native)[:, :sg.batch].T)
+        HostSimEngine.solve_forward(self)
+
+    def solve_coupling_dev(self, rc):
+        self.solve_coupling(None if rc is None else np.asarray(rc))
+
+    def solve_backward(self):
+        HostSimEngine.solve_backward(self)
+        for sg in self.groups:
+            if sg.x_native is not None:
+                sg.x_native[:, :sg.batch] = sg.x.T
+
+    def copy_coupling_solution(self, tensor):
+        tensor[...] = self.xc[:tensor.shape[0]]

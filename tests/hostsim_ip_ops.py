@@ -155,7 +155,7 @@ class HostSimIpOps(object):
     # ---- k_ip_rows + k_ip_local
     def residuals(self, hd, z, v_local):
         c0, cm, gls, bsum, dsum = self._step_part
-        pinf, dinf, obj = 0.0, gls, 0.0
+        pinf, dinf, obj = 0.0, 0.0, 0.0
         nfs = hd.descs[0]['nfs']
         csum = np.zeros(nfs)
         with np.errstate(all='ignore'):
@@ -191,7 +191,7 @@ class HostSimIpOps(object):
                 for r in (res_eq, res_in, res_lk):
                     pinf = nmax(pinf, _amax(np.abs(r[:, :B])))
                 csum += np.sum(W[n + 2 * mi + me:nb, :B], axis=1)
-        v_local[:V_HEAD] = (pinf, dinf, c0, cm, bsum, dsum, obj, 0.0)
+        v_local[:V_HEAD] = (pinf, dinf, c0, cm, bsum, dsum, obj, gls)
         v_local[V_HEAD:V_HEAD + nfs] = csum
 
     # ---- k_ip_publish + pp_ip_wait
@@ -206,6 +206,7 @@ class HostSimIpOps(object):
         for r in range(nranks):
             for k in range(4):
                 o[k] = nmax(o[k], float(T[r, k]))
+            o[1] = nmax(o[1], float(T[r, 7]))
             for k in (4, 5, 6):
                 o[k] = o[k] + float(T[r, k])
             if A is not None:

@@ -61,6 +61,161 @@ def test_shifted_device_matrix_bookkeeping():
     assert k3.diagonal_shift == (1e-8 + 1e-7, 1e-7, 1e-7)
 
 
+# ---- the producer and the loop on the CPU engines (numpy restatement of the kernels + the host interpreter) ---------------
+def _cpu_device_loop(qps, fs, comm=None):
+    from hostsim_engine import HostSimDeviceEngine
+    from parapint_amd.algorithms.device_interior_point import ip_solve_device
+    from parapint_amd.algorithms.interior_point import IPOptions, InteriorPointStatus
+    from parapint_amd.linalg.comm import SerialComm
+    from parapint_amd.linalg.hip_schur_complement import HipSchurComplementLinearSolver
+    it = DeviceStochasticQPInterface(qps, fs, comm=comm)
+    options = IPOptions()
+    options.linalg.solver = HipSchurComplementLinearSolver({i: None for i in it.local}, None, comm=comm or SerialComm(),
+                                                           engine=HostSimDeviceEngine())
+    hist = []
+    status, _ = ip_solve_device(it, options, history=hist)
+    assert status == InteriorPointStatus.optimal
+    return it, hist
+
+
+def _oracle_host_loop(qps, fs):
+    """The restated reference loop over the ORACLE's solver classes (the reference algorithm on SuperLU)."""
+    from oracle.schur_complement import SchurComplementLinearSolver as OracleSC
+    from oracle.subsolvers import ScipyInterface as OracleScipy
+    N = len(qps)
+    return host_loop(qps, fs, OracleSC({i: OracleScipy(compute_inertia=True) for i in range(N)},
+                                       OracleScipy(compute_inertia=True)))
+
+
+def _same_run(rows, hist, hi, it, n_scenarios, same_solver=True):
+    """same_solver: both loops factorise with the same solver class and must agree iteration by iteration.  Over the
+    oracle's classes (SuperLU, inertia from dense eigenvalues) the inertia-correction loop regularises an iterate or two
+    that the LDL^T inertia accepts -- the runs part early and must arrive at the same point."""
+    if same_solver:
+        assert len(rows) == len(hist)                            # same number of iterations
+        for r, h in zip(rows, hist):
+            # the host loop prints 3 significant digits: primal / dual / complementarity infeasibility and the barrier
+            # (below 1e-9 the measures are rounding noise of two different summation orders)
+            for a, b in zip(r[2:6], (h[0], h[1], h[2], h[3])):
+                assert abs(a - b) <= 6e-3 * max(abs(a), abs(b)) + 2e-9
+    else:
+        assert abs(len(rows) - len(hist)) <= max(6, len(rows) // 3)
+        for a, b in zip(rows[0][2:6], hist[0][:4]):              # the same initial point and measures
+            assert abs(a - b) <= 6e-3 * max(abs(a), abs(b)) + 2e-9
+    # (two runs that stop at 1e-8 on different paths agree to the accuracy the stopping test gives the variables)
+    tol = 1.0 if same_solver else 50.0
+    zh = np.asarray(hi.get_primals().get_block(n_scenarios))
+    assert np.abs(it.first_stage_solution() - zh).max() <= tol * 1e-7 * max(1.0, np.abs(zh).max())
+    for ndx in (0, n_scenarios - 1):
+        xh = hi.scenario_interface(ndx).get_primals()
+        assert np.abs(it.scenario_primals(ndx) - xh).max() <= tol * 1e-6 * max(1.0, np.abs(xh).max())
+
+
+def _interpreter_host_loop(qps, fs):
+    """The restated reference loop over the product's solver class on the host interpreter (host containers)."""
+    from hostsim_engine import HostSimEngine
+    from parapint_amd.linalg.comm import SerialComm
+    from parapint_amd.linalg.hip_schur_complement import HipSchurComplementLinearSolver
+    return host_loop(qps, fs, HipSchurComplementLinearSolver({i: None for i in range(len(qps))}, None, comm=SerialComm(),
+                                                             engine=HostSimEngine()))
+
+
+def test_device_loop_on_cpu_engines_matches_the_host_loops():
+    qps, fs = random_stochastic_qp(6, seed=2)
+    it, hist = _cpu_device_loop(qps, fs)
+    hi, rows = _interpreter_host_loop(qps, fs)
+    _same_run(rows, hist, hi, it, len(qps))
+    hi, rows = _oracle_host_loop(qps, fs)
+    _same_run(rows, hist, hi, it, len(qps), same_solver=False)
+
+
+def test_two_pattern_groups_on_cpu_engines():
+    from ip_multirank_worker import mixed_scenarios
+    qps, fs = mixed_scenarios()
+    it, hist = _cpu_device_loop(qps, fs)
+    assert len(it.pattern_groups) == 2 and len(it.states) == 2 and it.nsrc == max(pg.nsrc for pg in it.pattern_groups)
+    hi, rows = _interpreter_host_loop(qps, fs)
+    _same_run(rows, hist, hi, it, len(qps))
+    hi, rows = _oracle_host_loop(qps, fs)
+    _same_run(rows, hist, hi, it, len(qps), same_solver=False)
+
+
+def test_row_programs_reproduce_the_host_interface():
+    """grad f + J^T y, the constraint residuals and the right-hand side of the numpy kernels (through the row programs)
+    against the host interface's own evaluation at a random iterate."""
+    from hostsim_ip_ops import HostSimIpOps
+    from parapint_amd.interfaces.schur_complement.device_sc_ip_interface import _PatternGroup
+    from parapint_amd.interfaces.schur_complement.sc_ip_interface import StochasticSchurComplementInteriorPointInterface
+    from parapint_amd.sparse.block_containers import BlockVector
+    rng = np.random.default_rng(9)
+    qps, fs = random_stochastic_qp(3, seed=6)
+    pg = _PatternGroup(qps[0], fs[0])
+    n, mi, me, nfs, nb = pg.n, pg.mi, pg.me, pg.nfs, pg.nb
+    prog, terms = pg.row_programs()
+    B, bpad = 3, 64
+    W = np.zeros((nb + 2 * n + 2 * mi, bpad))
+    W[:, :B] = rng.uniform(0.5, 1.5, size=(W.shape[0], B))
+    bounds = np.zeros((2 * n + 2 * mi, bpad))
+    data = np.zeros((n + me, bpad))
+    src = np.zeros((pg.nsrc, bpad))
+    host = StochasticSchurComplementInteriorPointInterface(qps, fs)
+    host.set_bounds_relaxation_factor(1e-8)
+    z = rng.normal(size=nfs)
+    mu = 0.05
+    for b, q in enumerate(qps):
+        nlp = host.scenario_interface(b)
+        bounds[0:n, b], bounds[n:2 * n, b] = nlp.primals_lb(), nlp.primals_ub()
+        bounds[2 * n:2 * n + mi, b], bounds[2 * n + mi:, b] = nlp.ineq_lb(), nlp.ineq_ub()
+        lo, hi = bounds[0:n, b], bounds[n:2 * n, b]
+        W[0:n, b] = np.where(np.isfinite(lo), lo + 0.7, np.where(np.isfinite(hi), hi - 0.7, W[0:n, b]))
+        data[0:n, b], data[n:, b] = q.c, q.b_eq
+        src[pg.off[0]:pg.off[1], b], src[pg.off[1]:pg.off[2], b], src[pg.off[2]:pg.off[3], b] = q.H.data, q.A_eq.data, q.A_ineq.data
+        nlp.set_primals(W[0:n, b]); nlp.set_slacks(W[n:n + mi, b])
+        nlp.set_duals_eq(W[n + mi:n + mi + me, b]); nlp.set_duals_ineq(W[n + mi + me:n + 2 * mi + me, b])
+        host._duals_link[b] = W[n + 2 * mi + me:nb, b].copy()
+    host._primals_coupling = z.copy()
+    host.set_barrier_parameter(mu)
+    d = dict(n=n, mi=mi, me=me, nfs=nfs, batch=B, bpad=bpad, src_dp=int(pg.off[3]), src_ds=int(pg.off[4]), W=W, bounds=bounds,
+             data=data, src=src, G=np.zeros((n, bpad)), rhs=np.zeros((nb, bpad)), prog=prog, terms=terms)
+    ops = HostSimIpOps()
+    hd = ops.prepare([d])
+    v, rc = np.zeros(8 + nfs), np.zeros(nfs)
+    ops.take_step(hd, None, 1, False, mu, z, None)
+    ops.residuals(hd, z, v)
+    ops.publish(v, None, 1, nfs, rc)
+    ops.rhs(hd, mu)
+    rhs = host.evaluate_primal_dual_kkt_rhs()
+    for b in range(B):
+        ref = rhs.get_block(b).flatten()
+        got = hd.descs[0]['rhs'][:, b]
+        assert np.allclose(got, ref, rtol=1e-12, atol=1e-12), np.abs(got - ref).max()
+    assert np.allclose(rc, rhs.get_block(B), rtol=1e-12, atol=1e-13)
+    obj = sum(host.scenario_interface(b).evaluate_objective() - qps[b].c0 for b in range(B))
+    assert abs(ops.wait()[6] - obj) <= 1e-12 * max(1.0, abs(obj))
+
+
+def test_two_rank_device_loop():
+    """world_size 2 over gloo: rank-distributed scenarios of two sparsity patterns; the iterates, the iteration count and
+    every measure equal those of the one-rank run, and both ranks publish identical scalars."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(here, 'ip_multirank_worker.py')]
+    env = dict(os.environ)
+    env['OMP_NUM_THREADS'] = '1'
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    text = out.stdout.decode()
+    assert out.returncode == 0, text[-4000:]
+    assert 'rank 0 ok' in text and 'rank 1 ok' in text
+
+
 class _Capture(logging.Handler):
     def __init__(self):
         logging.Handler.__init__(self)
@@ -125,17 +280,17 @@ def test_stochastic_qp_device_loop_matches_host_loop(n_scenarios):
     it, hist, _ = device_loop(qps, fs)
     host_solver = HipSchurComplementLinearSolver({i: None for i in range(n_scenarios)}, None, comm=SerialComm())
     hi, rows = host_loop(qps, fs, host_solver)
-    assert len(rows) == len(hist)                                # same number of iterations
-    for r, h in zip(rows, hist):
-        # the host loop prints 3 significant digits: primal / dual / complementarity infeasibility and the barrier
-        # (below 1e-9 the measures are rounding noise of two different summation orders)
-        for a, b in zip(r[2:6], (h[0], h[1], h[2], h[3])):
-            assert abs(a - b) <= 6e-3 * max(abs(a), abs(b)) + 2e-9
-    zh = np.asarray(hi.get_primals().get_block(n_scenarios))
-    assert np.abs(it.first_stage_solution() - zh).max() <= 1e-7 * max(1.0, np.abs(zh).max())
-    for ndx in (0, n_scenarios - 1):
-        xh = hi.scenario_interface(ndx).get_primals()
-        assert np.abs(it.scenario_primals(ndx) - xh).max() <= 1e-6 * max(1.0, np.abs(xh).max())
+    _same_run(rows, hist, hi, it, n_scenarios)
+
+
+@pytest.mark.gpu
+def test_device_loop_against_the_host_loop_over_the_oracle_solver():
+    """8 scenarios: the device loop against the restated reference loop over the ORACLE's solver classes (the reference
+    algorithm on SuperLU, inertia from dense eigenvalues) -- same initial measures, same solution."""
+    qps, fs = random_stochastic_qp(8, seed=2)
+    it, hist, _ = device_loop(qps, fs)
+    hi, rows = _oracle_host_loop(qps, fs)
+    _same_run(rows, hist, hi, it, 8, same_solver=False)
 
 
 @pytest.mark.gpu

@@ -21,10 +21,18 @@ import hostsim_util as hu   # noqa: E402
 
 
 def main():
-    n_q, m, n_t = (int(a) for a in sys.argv[1:4]) if len(sys.argv) >= 4 else (1000, 4, 200)
-    model = SyntheticKKT(2, n_q, m, n_t)
+    args = [a for a in sys.argv[1:] if not a.startswith('--')]
+    n_q, m, n_t = (int(a) for a in args[:3]) if len(args) >= 3 else (1000, 4, 200)
     solver = sc.new_solver(lambda: HostSimEngine(), 2)
-    solver.do_symbolic_factorization(model.build_kkt(comm=SerialComm(), iteration=0))
+    if '--qp' in sys.argv:       # the KKT blocks of the C3-shaped stochastic QP (bounds on the primal variables) at its initial point
+        from parapint_amd.examples.stochastic_qp import c3_stochastic_qp
+        from parapint_amd.interfaces.schur_complement.device_sc_ip_interface import DeviceStochasticQPInterface
+        qps, fs = c3_stochastic_qp(2, n_q=n_q, m=m, n_theta=n_t, seed=1)
+        solver.do_symbolic_factorization(DeviceStochasticQPInterface(qps, fs).device_kkt_matrix().pattern)
+    else:
+        model = SyntheticKKT(2, n_q, m, n_t)
+        solver.do_symbolic_factorization(model.build_kkt(comm=SerialComm(), iteration=0))
+    print(solver.plan_stats[0])
     sg = solver._eng.groups[0]
     L = hu.lib()
     st = np.zeros(13, dtype=np.int64)
