@@ -146,6 +146,19 @@ GROUP_STAT_KEYS = ['n', 'n_coupling', 'batch', 'n_pivots', 'n_2x2', 'n_levels', 
 _lib = None
 
 
+def kernel_source_sha1():
+    """SHA-1 over the kernel sources of the library (csrc/*.hip, *.hpp, *.cpp, in name order): ties measurements that are
+    kept next to the code (profiles/pmc_traffic.json) to the build they were taken on."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(_HERE, 'csrc')
+    for name in sorted(os.listdir(d)):
+        if name.endswith(('.hip', '.hpp', '.cpp')):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), 'rb').read())
+    return h.hexdigest()
+
+
 def load_library():
     """Load libparapint_hip.so and declare every prototype.  Raises if it is not built."""
     global _lib

@@ -383,7 +383,8 @@ class HipEngine(object):
                 if k is not None:
                     hit = memo.get((q, id(a)))
                     if hit is None:
-                        hit = memo[(q, id(a))] = _index_intact(a, k, full_check)
+                        # (blocks arrive here when they are new or were just found changed: always the checksum)
+                        hit = memo[(q, id(a))] = _index_intact(a, k, True)
                     if not hit:
                         k = None
                 if k is not None:

@@ -12,8 +12,11 @@ import json
 import re
 import sys
 
-sys.path.insert(0, __file__.rsplit('/', 1)[0])
+import os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pmc_summary import load, short   # noqa: E402
+from parapint_amd._native import kernel_source_sha1   # noqa: E402
 
 PHASE_OF = [
     (r'^k_gather_level|^k_gather_flat', 'factor_levels'), (r'^k_scale_level|^k_front_invert|^k_scale_wide', 'factor_levels'),
@@ -76,6 +79,7 @@ def main():
                      '(C3 unless the note names another workload) on one MI355X; read side calibrated on k_transpose_in (known byte count) as '
                      'MI355X_MICROARCH.md section HBM prescribes. ' + note,
            'steps_in_pass': steps, 'fetch_calibration': calib, 'hbm_bytes_per_step_total': total,
+           'kernel_source_sha1': kernel_source_sha1(),      # bench.py reports these counters only for the build they were taken on
            'kernels': kernels, 'phases': phases}
     json.dump(out, open(out_path, 'w'), indent=1)
     print('steps', steps, 'calibration', round(calib, 4), 'total GB/step', round(total / 1e9, 3))
