@@ -59,6 +59,8 @@ def parse_args():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-boundary', action='store_true')
     ap.add_argument('--no-ip-loop', action='store_true')
+    ap.add_argument('--no-prefetch', action='store_true',
+                    help='do not announce the right-hand side before the factorisation (solver.prefetch_forward)')
     ap.add_argument('--ip-scenarios', type=int, default=1024)
     ap.add_argument('--boundary-iterations', type=int, default=6)
     ap.add_argument('--result-buffers', type=int, default=2,
@@ -290,6 +292,10 @@ def main():
     rhs_dev = solver.device_vector_from_host(rhs_host)
 
     def step(k):
+        # (as in an interior-point iteration, interior_point.py:553-566, the right-hand side exists before the matrix is
+        # factorised: announcing it lets its forward sweep run beside the dense factorisation of S)
+        if not args.no_prefetch:
+            solver.prefetch_forward(rhs_dev)
         r = solver.do_numeric_factorization(matrix=sets[k % nsets][0], raise_on_error=False)
         xd = solver.do_back_solve(rhs_dev)
         return r, xd
@@ -337,9 +343,13 @@ def main():
             eng.factor_schur_corner(*qcorner)
         else:
             eng.factor_schur(qdense)
+        if not args.no_prefetch:                  # (forward sweep beside the dense phase, status read behind it)
+            eng.solve_forward()
+            eng.allreduce_rs(comm)
         status = eng.status()
-        eng.solve_forward()
-        eng.allreduce_rs(comm)
+        if args.no_prefetch:
+            eng.solve_forward()
+            eng.allreduce_rs(comm)
         eng.solve_coupling_dev(None)
         eng.solve_backward()
         return status
@@ -468,6 +478,7 @@ def main():
                 loop_s, t_ip = float(tt[0]), float(tt[1])
             sv = ipo.linalg.solver
             cur = {'it_per_s': ip_iters / loop_s, 'iterations': ip_iters, 'ms_per_iteration': 1e3 * loop_s / max(ip_iters, 1),
+                   'median_ms_per_iteration': 1e3 * float(np.median(ipst['iteration_s'])) if ipst.get('iteration_s') else None,
                    'loop_seconds': loop_s, 'setup_seconds': t_ip - loop_s, 'it_per_s_whole_call': ip_iters / t_ip,
                    'converged': ip_status == InteriorPointStatus.optimal,
                    'final_infeasibilities': list(hist[-1][:3]) if hist else None,

@@ -194,8 +194,10 @@ int pp_solve_coupling(pp_handle h, const double* rc_host);
 /* Native vectors: right-hand sides and solutions of a group as [n][bpad] device arrays (row = the caller's row of the
  * block, instance index fastest, bpad = batch rounded up to 64) -- the layout every kernel here works in.  The forward
  * sweep then reads b where the caller keeps it (no transposition, no copy: columns without incoming entries are never
- * materialised) and the backward sweep writes x in the caller's row order.  Both pointers or neither (NULL, NULL
- * restores the [batch][n] buffers of pp_upload_rhs / pp_download_solution). */
+ * materialised) and the backward sweep writes x in the caller's row order.  (NULL, NULL) restores the [batch][n]
+ * buffers of pp_upload_rhs / pp_download_solution; (rhs, NULL) is enough for pp_solve_forward -- a forward sweep enqueued
+ * right behind pp_factor_schur overlaps the dense factorisation of S, which the library runs on a stream of its own (the
+ * sweep does not depend on S; pp_solve_coupling joins) -- the solution buffer is bound before pp_solve_backward. */
 int pp_bind_native_vectors(pp_handle h, int group, const double* rhs_dev, double* x_dev);
 /* The same with r_c resident on the device (NULL = 0), and the device address of x_c (n_c doubles). */
 int pp_solve_coupling_dev(pp_handle h, const double* rc_dev);

@@ -52,6 +52,7 @@ def ip_solve_device(interface, options=None, timer=None, history=None, stats=Non
                 'Comp Inf', 'Barrier', 'Prim Step', 'Dual Step', 'Reg', 'Time')
     status = InteriorPointStatus.error
     iterations = 0
+    stamps = [t_loop]
     for _iter in range(options.max_iter):
         iterations = _iter
         primal_inf, dual_inf, compl_inf = m['primal_inf'], m['dual_inf'], m['compl_inf']        # check_convergence(barrier=0)
@@ -72,6 +73,8 @@ def ip_solve_device(interface, options=None, timer=None, history=None, stats=Non
         interface.set_barrier_parameter(barrier_parameter)
         kkt = interface.evaluate_primal_dual_kkt_matrix(timer=timer)      # (the barrier diagonals are in the solver's sources)
         rhs = interface.evaluate_primal_dual_kkt_rhs(timer=timer)
+        if hasattr(solver, 'prefetch_forward'):
+            solver.prefetch_forward(rhs)                 # (the forward sweep rides behind every factorisation of this iteration)
         used_inertia_coef = numeric_factorization(interface, kkt, options, inertia_coef, timer)
         inertia_coef = max(used_inertia_coef * options.inertia_correction.factor_decrease,
                            options.inertia_correction.init_coef)
@@ -83,9 +86,11 @@ def ip_solve_device(interface, options=None, timer=None, history=None, stats=Non
         alpha_primal_max, alpha_dual_max = m['alpha_primal'], m['alpha_dual']
         if options.unified_step:
             alpha_primal_max = alpha_dual_max = min(alpha_primal_max, alpha_dual_max)
+        stamps.append(time.time())
     if stats is not None:
         stats['setup_s'] = t_loop - t0
         stats['loop_s'] = time.time() - t_loop
+        stats['iteration_s'] = [b - a for a, b in zip(stamps, stamps[1:])]
         stats['torch_ops'] = counter.close() if counter is not None else None
     return status, iterations
 

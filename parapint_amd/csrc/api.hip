@@ -46,6 +46,7 @@ void pp_destroy(pp_handle h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   (void)stage_job_finish(h);
+  (void)join_dense(h);
   (void)hipStreamSynchronize(h->stream);
   for (Group* g : h->groups) free_group(g);
   free_globals(h);
@@ -56,6 +57,12 @@ void pp_destroy(pp_handle h) {
   if (h->aux_made) {
     for (int i = 0; i < PP_MAX_SPLIT; ++i) { (void)hipStreamDestroy(h->aux[i]); (void)hipEventDestroy(h->ev_join[i]); }
     (void)hipEventDestroy(h->ev_fork);
+  }
+  if (h->dense_stream) {
+    (void)hipStreamSynchronize(h->dense_stream);
+    (void)hipStreamDestroy(h->dense_stream);
+    (void)hipEventDestroy(h->ev_dense_fork);
+    (void)hipEventDestroy(h->ev_dense_done);
   }
   if (h->ip_part) (void)hipFree(h->ip_part);
   if (h->ip_mail_host) (void)hipHostFree((void*)h->ip_mail_host);
@@ -69,6 +76,7 @@ int pp_begin_symbolic(pp_handle h, int n_coupling) {
   if (!h) return 3;
   if (n_coupling < 0) return fail(h, 3, "negative coupling dimension");
   PP_HIP(hipSetDevice(h->device));
+  if (int rc = join_dense(h)) return rc;
   PP_HIP(hipStreamSynchronize(h->stream));
   for (Group* g : h->groups) free_group(g);
   h->groups.clear();
@@ -499,6 +507,11 @@ int pp_end_symbolic(pp_handle h) {
     h->status_dev = (long long*)dp;
     h->status_seq = 0;
   }
+  if (!h->dense_stream && h->dense_overlap) {     // (stream of the dense phase, dense.hip: made here, not in the first factorisation)
+    PP_HIP(hipStreamCreateWithFlags(&h->dense_stream, hipStreamNonBlocking));
+    PP_HIP(hipEventCreateWithFlags(&h->ev_dense_fork, hipEventDisableTiming));
+    PP_HIP(hipEventCreateWithFlags(&h->ev_dense_done, hipEventDisableTiming));
+  }
   h->S = h->S_own;
   h->rs = h->rs_own;
   PP_HIP(hipMemset(h->S, 0, (nn + PP_TAIL) * sizeof(double)));
@@ -671,7 +684,8 @@ int pp_bind_solution_buffer(pp_handle h, int group, double* dev_ptr) {
 int pp_bind_native_vectors(pp_handle h, int group, const double* rhs_dev, double* x_dev) {
   Group* g = get_group(h, group);
   if (!g || !h->symbolic_done) return fail(h, 3, "pp_bind_native_vectors: bad group");
-  if ((rhs_dev == nullptr) != (x_dev == nullptr)) return fail(h, 3, "pp_bind_native_vectors: give both buffers or neither");
+  // (the right-hand side alone: enough for pp_solve_forward -- a forward sweep enqueued ahead of the back-solve)
+  if (rhs_dev == nullptr && x_dev != nullptr) return fail(h, 3, "pp_bind_native_vectors: a solution buffer needs the right-hand side");
   if (int rc = alloc_value_storage(h)) return rc;
   g->rhs_native = rhs_dev;
   g->x_native = x_dev;
@@ -737,6 +751,7 @@ int pp_set_dense_policy(pp_handle h, int policy) {
 int pp_get_dense_mode(pp_handle h, int* mode_out) {
   if (!h || !h->schur_done) return fail(h, 3, "pp_get_dense_mode before pp_factor_schur");
   PP_HIP(hipSetDevice(h->device));
+  if (int rc = join_dense(h)) return rc;
   PP_HIP(hipMemcpyAsync(mode_out, h->dense_mode, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   PP_HIP(hipStreamSynchronize(h->stream));
   return 0;
@@ -818,6 +833,7 @@ int pp_bcr_block_paths(pp_handle h, int32_t out[2]) {
 int pp_synchronize(pp_handle h) {
   if (!h) return 3;
   PP_HIP(hipSetDevice(h->device));
+  if (int rc = join_dense(h)) return rc;
   PP_HIP(hipStreamSynchronize(h->stream));
   return 0;
 }

@@ -342,6 +342,12 @@ struct pp_solver {
   long long status_seq = 0;
   double fail_code = 0.0;
   double* vec_part = nullptr;    // scratch of the f4 vector kernels
+  // dense phase beside the forward sweep (dense.hip): the one-workgroup factorisation of S runs on a stream of its own,
+  // forked behind the Schur reduction; whoever reads the factor or writes S next joins it (join_dense)
+  hipStream_t dense_stream = nullptr;
+  hipEvent_t ev_dense_fork = nullptr, ev_dense_done = nullptr;
+  bool dense_pending = false;
+  bool dense_overlap = std::getenv("PP_NO_DENSE_OVERLAP") == nullptr;   // (measurement switch)
   // interior-point step on device-resident iterates (ipstep.hip): partials of its reductions, pinned mailbox
   double* ip_part = nullptr;
   size_t ip_part_cap = 0;
@@ -427,6 +433,16 @@ size_t schur_doubles(pp_handle h) {
 int fail(pp_handle h, int status, const std::string& msg) {
   if (h) { std::lock_guard<std::mutex> lk(h->err_mu); h->err = msg; }
   return status;
+}
+
+// The handle's stream waits for a dense factorisation of S that runs on the side stream (no-op otherwise): called by
+// everything that reads the factor of S or overwrites S.
+[[maybe_unused]] int join_dense(pp_handle h) {
+  if (h->dense_pending) {
+    h->dense_pending = false;
+    if (hipStreamWaitEvent(h->stream, h->ev_dense_done, 0) != hipSuccess) return fail(h, 3, "hipStreamWaitEvent failed (dense phase)");
+  }
+  return 0;
 }
 
 // Elimination schedule of the block-tridiagonal S.  Cyclic reduction (default): level l eliminates the blocks

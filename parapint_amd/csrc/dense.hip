@@ -730,6 +730,21 @@ int ppi_dense_factor_schur(pp_handle h, const double* Q_host) {
   hipStream_t st = h->stream;
   const int nc = h->nc;
   const size_t nn = schur_doubles(h);
+  if (int rc = join_dense(h)) return rc;
+  // The one-workgroup factorisations (n_c <= 512) leave the chip idle: they run on a stream of their own, forked here,
+  // so that a forward sweep enqueued behind this call (it does not depend on S) overlaps them; the coupling solve joins.
+  // Not with a host Q (its upload is ordered by the caller on the handle's stream) and not while phases are timed.
+  const bool overlap = h->dense_overlap && !h->profile && !Q_host && h->dense_policy == 0 && nc <= 512;
+  if (overlap) {
+    if (!h->dense_stream) {
+      PP_HIP(hipStreamCreateWithFlags(&h->dense_stream, hipStreamNonBlocking));
+      PP_HIP(hipEventCreateWithFlags(&h->ev_dense_fork, hipEventDisableTiming));
+      PP_HIP(hipEventCreateWithFlags(&h->ev_dense_done, hipEventDisableTiming));
+    }
+    PP_HIP(hipEventRecord(h->ev_dense_fork, h->stream));
+    PP_HIP(hipStreamWaitEvent(h->dense_stream, h->ev_dense_fork, 0));
+    st = h->dense_stream;
+  }
   {
     if (Q_host) PP_HIP(hipMemcpyAsync(h->Qd, Q_host, nn * sizeof(double), hipMemcpyHostToDevice, st));
     const double* Qd = Q_host ? h->Qd : nullptr;
@@ -773,10 +788,15 @@ int ppi_dense_factor_schur(pp_handle h, const double* Q_host) {
     hipLaunchKernelGGL(k_bk_factor, dim3(1), dim3(BK_THREADS), 0, st, nc, h->S, Qd, h->Sfac, h->ipiv, h->work, h->bkinfo,
                        h->dense_mode, h->status_dev, ++h->status_seq);
   }
+  if (overlap) {
+    PP_HIP(hipEventRecord(h->ev_dense_done, st));
+    h->dense_pending = true;
+  }
   return 0;
 }
 
 int ppi_dense_coupling_solve(pp_handle h, const double* rc_dev) {
+  if (int rc = join_dense(h)) return rc;
   hipStream_t st = h->stream;
   const int nc = h->nc;
   PhaseScope ps(h, 6, 1);

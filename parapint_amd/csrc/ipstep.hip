@@ -24,7 +24,7 @@ constexpr int IP_STEP_SLOTS = 5;  // partials of k_ip_step: compl(0), compl(mu),
 constexpr int IP_ROWS_SLOTS = 3;  // partials of k_ip_rows: primal infeasibility, max |grad_x L|, objective
 constexpr int IP_RPW = 4;         // rows per wave in k_ip_rows (at least; more when the launch would exceed IP_ROWS_MAXWG workgroups)
 constexpr unsigned IP_EW_MAXWG = 2048;    // workgroups of the elementwise kernels (grid-stride beyond): bounds the partials of
-constexpr unsigned IP_ROWS_MAXWG = 4096;  // the second reduction stage, which one workgroup combines
+constexpr unsigned IP_ROWS_MAXWG = 16384; // the second reduction stage, which one workgroup per slot combines
 
 __device__ __forceinline__ int ip_nb(const pp_ip_group& g) { return g.n + 2 * g.mi + g.me + g.nfs; }
 

@@ -458,6 +458,7 @@ extern "C" {
 int pp_numeric_schur(pp_handle h) {
   if (!h || !h->symbolic_done || !h->blocks_factored) return fail(h, 3, "pp_numeric_schur before pp_numeric_factor_blocks");
   PP_HIP(hipSetDevice(h->device));
+  if (int rc = join_dense(h)) return rc;          // (S is written below: a dense phase still reading it must be over)
   hipStream_t st = h->stream;
   const int nc = h->nc;
   // S starts from zero -- unless the first group is a plain (unmapped) one whose tiles cover all of S: its reduction
@@ -523,6 +524,7 @@ int pp_fail_local(pp_handle h, int status) {
   if (!h || !h->symbolic_done) return fail(h, 3, "pp_fail_local before symbolic factorization");
   if (status < 1 || status > 3) return fail(h, 3, "pp_fail_local: status must be 1 (not_enough_memory), 2 (singular) or 3 (error)");
   PP_HIP(hipSetDevice(h->device));
+  if (int rc = join_dense(h)) return rc;
   const size_t nn = schur_doubles(h);
   PP_HIP(hipMemsetAsync(h->S, 0, (nn + PP_TAIL) * sizeof(double), h->stream));
   h->fail_code = status == 1 ? 1.0 : status == 2 ? 1e3 : 1e6;
@@ -614,6 +616,7 @@ int pp_get_status(pp_handle h, int64_t out[4]) {
         std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.25) break;
   }
   if (!seen) {
+    if (int rc = join_dense(h)) return rc;
     PP_HIP(hipStreamSynchronize(h->stream));
     if (__atomic_load_n((const long long*)(h->status_host + 4), __ATOMIC_ACQUIRE) != want)
       return fail(h, 3, "pp_get_status: status mailbox was not written");
@@ -629,6 +632,7 @@ int pp_get_status(pp_handle h, int64_t out[4]) {
 int pp_get_schur(pp_handle h, double* S_host) {
   if (!h || !h->numeric_done) return fail(h, 3, "pp_get_schur before pp_numeric_local");
   PP_HIP(hipSetDevice(h->device));
+  if (int rc = join_dense(h)) return rc;
   PP_HIP(hipMemcpyAsync(S_host, h->S, schur_doubles(h) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   PP_HIP(hipStreamSynchronize(h->stream));
   return 0;

@@ -315,6 +315,8 @@ class DeviceStochasticQPInterface(object):
                 classes[ndx] = cls
             self.states.append(gs)
         solver.set_regularization_classes(classes)
+        if hasattr(solver, 'warm_device_results'):
+            solver.warm_device_results()
         self._prepared = ops.prepare(descs)
         self.z = ops.zeros((max(nfs, 1),))                        # coupling variables: free, start at 0
         nv = V_HEAD + nfs

@@ -814,6 +814,8 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         self._layout_cache = None           # (binfo, layout, dims) of device_layout()
         self._cinv_t = self._rc_pad = self._xc_pad = None       # device copies of the coupling order (block-tridiagonal S)
         self._cperm_pad = None
+        self._prefetch_rhs = None           # DeviceBlockVector whose forward sweep rides behind the factorisations (prefetch_forward)
+        self._forward_done_for = None       # ... and the one whose forward sweep the last factorisation has already enqueued
         # Index arrays recognised by identity (the fast paths of the host boundary) are checked for in-place rewrites:
         # size and address at every call; a CRC of their contents at every call for the first `pattern_check_bytes` of
         # distinct arrays (blocks that share their index arrays -- one Jacobian structure, one object -- are always
@@ -1676,6 +1678,13 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         else:
             self._guarded(res, self._eng.factor_schur, Q)
         self._last_Q = Q
+        self._forward_done_for = None
+        if self._prefetch_rhs is not None and res.status in _OK:
+            # the forward sweep of the announced right-hand side does not depend on S: enqueued here, before the host waits
+            # for the status, it runs beside the one-workgroup factorisation of S (a stream of its own in the library)
+            self._guarded(res, self._forward_sweep, self._prefetch_rhs)
+            if res.status in _OK:
+                self._forward_done_for = self._prefetch_rhs
         st = self._guarded(res, self._eng.status)
         if (st is not None and st[0] == 2 and self._btd is not None and not self._btd_sequential and
                 hasattr(self._eng, 'set_coupling_schedule')):
@@ -1882,6 +1891,28 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         timer.stop('back_solve')
         return result
 
+    def warm_device_results(self):
+        """Creates the result vectors of result_buffers > 0 now (set-up time) instead of in the first back-solve."""
+        if self._result_buffers > 0 and not self._dev_results:
+            self._dev_results = [self.new_device_vector() for _ in range(self._result_buffers)]
+
+    def prefetch_forward(self, rhs):
+        """Opt-in for callers that know the right-hand side of the next back-solve before they factorise (an interior-point
+        iteration does): every numeric factorisation from now on enqueues the forward sweep of `rhs` (a DeviceBlockVector,
+        read in place; it must not change until the back-solve) behind its block phase, where it overlaps the dense
+        factorisation of S and the host's wait for the status; ``do_back_solve(rhs)`` with the same object then starts at
+        the coupling solve.  ``prefetch_forward(None)`` ends it; so does a back-solve."""
+        if rhs is not None and not hasattr(rhs, 'group_tensors'):
+            raise ValueError('prefetch_forward takes a DeviceBlockVector')
+        self._prefetch_rhs = rhs
+        self._forward_done_for = None
+
+    def _forward_sweep(self, rhs):
+        for g in self._groups:
+            self._eng.bind_native_vectors(g.gid, rhs.group_tensors[g.gid], None)
+        self._eng.solve_forward()
+        self._eng.allreduce_rs(self.comm)
+
     def _device_back_solve(self, rhs, timer):
         """do_back_solve for a DeviceBlockVector: right-hand sides are read where they are, the solution is written
         into a fresh device vector (or, with result_buffers = k > 0, into k vectors handed out in turn); no host copies."""
@@ -1895,8 +1926,10 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             self._dev_turn += 1
         for g in self._groups:
             self._eng.bind_native_vectors(g.gid, rhs.group_tensors[g.gid], out.group_tensors[g.gid])
-        self._eng.solve_forward()
-        self._eng.allreduce_rs(self.comm)
+        if self._forward_done_for is not rhs:
+            self._eng.solve_forward()
+            self._eng.allreduce_rs(self.comm)
+        self._prefetch_rhs = self._forward_done_for = None
         rc_dev = rhs.coupling if self._nc > 0 else None
         if self._btd is not None and rc_dev is not None:
             import torch

@@ -41,6 +41,7 @@ def main():
                'setup_s': stats['setup_s'], 'loop_s': stats['loop_s'], 'ms_per_iteration': 1e3 * stats['loop_s'] / max(iters, 1),
                'it_per_s_loop': iters / stats['loop_s'], 'it_per_s_whole_call': iters / wall,
                'torch_ops_per_iteration': (stats['torch_ops'] or 0) / max(iters, 1),
+               'iteration_ms': [round(1e3 * v, 3) for v in stats['iteration_s']],
                'refreshes': solver.pivot_order_refreshes, 'retries': solver.diagonal_shift_refactorizations,
                'final': list(hist[-1][:3]), 'plan': {k: solver.plan_stats[0][k] for k in ('n', 'n_levels', 'u_doubles')}}
         print(json.dumps(out), flush=True)
