@@ -52,6 +52,9 @@ def parse_args():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', default='C3', choices=sorted(WORKLOADS))
     ap.add_argument('--blocks', type=int, default=0, help='override the number of scenario blocks')
+    ap.add_argument('--scaling', default='strong', choices=['strong', 'weak'],
+                    help='strong (default, BASELINE.json configs[2]: the blocks of the workload are sharded over the ranks) or '
+                         'weak (every rank gets the full block count of the workload: N x world blocks in total)')
     ap.add_argument('--n-q', type=int, default=0)
     ap.add_argument('--m', type=int, default=0)
     ap.add_argument('--n-theta', type=int, default=0)
@@ -126,6 +129,8 @@ def main():
     dynamic = args.workload == 'C4'
     N, n_q, m, n_t = WORKLOADS[args.workload]
     N, n_q, m, n_t = args.blocks or N, args.n_q or n_q, args.m or m, args.n_theta or n_t
+    if args.scaling == 'weak':
+        N *= world
 
     # ---- CPU baseline first: it forks worker processes, so it runs before the GPU is touched
     cpu_baseline = None
@@ -368,6 +373,7 @@ def main():
     # ---- per-phase device time (HIP events on the solver's stream), separate untimed pass
     import ctypes
     phases = {}
+    collective_us = None
     if args.profile_steps > 0:
         eng.ns.check(lib.pp_profile(h, 1), 'pp_profile')
         for k in range(args.profile_steps):
@@ -379,6 +385,35 @@ def main():
                                         launches.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
                                         calls.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))), 'pp_phase_times')
         eng.ns.check(lib.pp_profile(h, 0), 'pp_profile')
+        # the two data-path collectives by themselves (events on the stream they are enqueued on, around the call the
+        # solver makes -- torch.distributed or the library's own RCCL call): this rank's average and every rank's
+        if world > 1:
+            marks = {'schur': [], 'rs': []}
+            plain = {'schur': eng.allreduce_schur, 'rs': eng.allreduce_rs}
+
+            def timed(name):
+                def call(c):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    plain[name](c)
+                    e1.record()
+                    marks[name].append((e0, e1))
+                return call
+            eng.allreduce_schur, eng.allreduce_rs = timed('schur'), timed('rs')
+            for k in range(max(3, args.profile_steps)):
+                step(k)
+            torch.cuda.synchronize(dev)
+            eng.allreduce_schur, eng.allreduce_rs = plain['schur'], plain['rs']
+            mine = torch.tensor([1e3 * float(np.mean([a.elapsed_time(b) for a, b in marks[k][1:]])) for k in ('schur', 'rs')],
+                                dtype=torch.float64, device=dev)
+            if backend == 'nccl':
+                allr = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(allr, mine)
+                per_rank = [[float(v) for v in t.cpu()] for t in allr]
+            else:
+                per_rank = [[float(v) for v in row] for row in comm.allgather(mine.cpu().numpy())]
+            collective_us = {'allreduce_S_and_status': [r[0] for r in per_rank], 'allreduce_r_s': [r[1] for r in per_rank],
+                             'bytes': [8 * (eng.schur_doubles + 8), 8 * solver._nc]}
         for i, name in enumerate(PHASES):
             if calls[i] > 0:
                 phases[name] = {'ms_per_step': float(ms[i] / args.profile_steps),
@@ -457,7 +492,7 @@ def main():
         from parapint_amd.algorithms.interior_point import IPOptions, InteriorPointStatus
         from parapint_amd.examples.stochastic_qp import c3_stochastic_qp
         from parapint_amd.interfaces.schur_complement.device_sc_ip_interface import DeviceStochasticQPInterface
-        nsc = args.ip_scenarios
+        nsc = args.ip_scenarios * (world if args.scaling == 'weak' else 1)
         mine = [i for i in range(nsc) if i % world == rank]
         qps, fsi = c3_stochastic_qp(nsc, n_q=n_q, m=m, n_theta=n_t, seed=1, local=mine)
         best = None
@@ -501,7 +536,7 @@ def main():
         launches = sum(p['launches_per_step'] for p in phases.values()) if phases else None
         out = {
             'metric': METRIC, 'value': value, 'unit': 'it/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'strong',
+            'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': args.scaling,
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': describe + '; per step 1 do_numeric_factorization + 1 do_back_solve through the '
                                    'LinearSolverInterface methods on device-resident containers, fresh values each step '
@@ -511,6 +546,7 @@ def main():
                                       'of r_s' % world},
             'median_ms_per_step': median_ms,
             'rccl_ranks': int(lib.pp_comm_size(h)),      # > 0: the all-reduces were enqueued by the library (PP_DIRECT_RCCL=1)
+            'collective_us': collective_us,             # per rank: the two data-path all-reduces by themselves (HIP events)
             # SURVEY 8(d) to the letter: the same step through HOST containers (SciPy COO blocks in, host vectors out;
             # staging, H2D and D2H inside) -- the rate a caller with the reference's unchanged interfaces sees
             'value_boundary': (boundary or {}).get('it_per_s'),

@@ -731,10 +731,11 @@ int ppi_dense_factor_schur(pp_handle h, const double* Q_host) {
   const int nc = h->nc;
   const size_t nn = schur_doubles(h);
   if (int rc = join_dense(h)) return rc;
-  // The one-workgroup factorisations (n_c <= 512) leave the chip idle: they run on a stream of their own, forked here,
-  // so that a forward sweep enqueued behind this call (it does not depend on S) overlaps them; the coupling solve joins.
+  // The dense factorisation leaves most of the chip idle (one workgroup for n_c <= 512, a chain of small launches
+  // beyond): it runs on a stream of its own, forked here, so that a forward sweep enqueued behind this call (it does not
+  // depend on S) overlaps it; the coupling solve joins.
   // Not with a host Q (its upload is ordered by the caller on the handle's stream) and not while phases are timed.
-  const bool overlap = h->dense_overlap && !h->profile && !Q_host && h->dense_policy == 0 && nc <= 512;
+  const bool overlap = h->dense_overlap && !h->profile && !Q_host && h->dense_policy == 0;
   if (overlap) {
     if (!h->dense_stream) {
       PP_HIP(hipStreamCreateWithFlags(&h->dense_stream, hipStreamNonBlocking));

@@ -535,6 +535,15 @@ def test_bench_two_ranks_started_by_the_script_itself():
     assert res['config']['world_size'] == 2 and res['config']['blocks_per_gpu'] == 32
     assert res['config']['collective_backend'] == ('nccl' if two else 'gloo')
     assert res['residual'] <= 1e-8 and res['inertia'] == res['expected_inertia']
+    assert len(res['collective_us']['allreduce_S_and_status']) == 2 and min(res['collective_us']['allreduce_r_s']) > 0.0
+    assert res['scaling'] == 'strong'
+    if two:
+        # the same with the library's own RCCL calls on the solver's stream (no torch.distributed in the data path), and
+        # with every rank holding the workload's full block count
+        res = _run_bench({'PP_DIRECT_RCCL': '1'}, '--gpus', '2', '--workload', 'C2', '--steps', '4', '--warmup', '2',
+                         '--no-cpu-baseline', '--no-boundary', '--profile-steps', '1', '--scaling', 'weak')
+        assert res['rccl_ranks'] == 2 and res['correct'] is True and res['scaling'] == 'weak'
+        assert res['config']['blocks_per_gpu'] == 64 and res['residual'] <= 1e-8
 
 
 def test_bench_single_rank_line_has_the_contract_fields():
