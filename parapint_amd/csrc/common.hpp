@@ -362,7 +362,7 @@ struct pp_solver {
   int *btd_ipiv = nullptr, *btd_info = nullptr, *scatter_err = nullptr, *btd_elim = nullptr;
   std::vector<int> bcr_off, bcr_ne, bcr_s, bcr_lo;   // per level: offset into btd_elim, eliminated blocks, stride, lower neighbour live
   int btd_sequential = 0;
-  bool bcr_lds_attr = false, bcr_ldl_attr = false;
+  bool bcr_lds_attr = false, bcr_ldl_attr = false, dn_lds_attr = false;
   // largest multiplier the unpivoted block factorisation of the cyclic reduction accepts (1 / u, u = 0.01; PP_BCR_LBOUND:
   // test switch -- a bound below 1 sends some blocks to Bunch-Kaufman and leaves others on the unpivoted path)
   double bcr_lbound = std::getenv("PP_BCR_LBOUND") ? std::atof(std::getenv("PP_BCR_LBOUND")) : 100.0;

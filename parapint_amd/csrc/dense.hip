@@ -331,22 +331,29 @@ constexpr int LDLR_TPW = 12;  // 8 waves * 12 >= 91 tiles
 constexpr int LDLR_NB = 16;
 constexpr int LDLR_LD = 18;   // LDS row stride in doubles: conflict-free MFMA operand reads
 
-template <bool DPP>
+// BLOCK: the same kernel on a diagonal block (n <= 208 columns) of a larger matrix, in place: A points at the block's
+// first element, lda_in is the leading dimension of the whole matrix, the lower triangle is read (the trailing updates of
+// the blocked algorithm below keep only that one current), the scale of the zero-pivot test comes from the whole matrix
+// (anorm_p) and the acceptance flags are merged into gflags (k_dense_finish decides).
+template <bool DPP, bool BLOCK = false>
 __global__ __launch_bounds__(LDL_THREADS) void k_ldl_regs(int n, const double* __restrict__ S, const double* __restrict__ Q,
                                                           double* __restrict__ A, double* __restrict__ dvec,
-                                                          int* __restrict__ mode, int* __restrict__ info, double eps) {
+                                                          int* __restrict__ mode, int* __restrict__ info, double eps,
+                                                          int lda_in = 0, const double* __restrict__ anorm_p = nullptr,
+                                                          int* __restrict__ gflags = nullptr) {
   __shared__ double P[16 * LDLR_NT][LDLR_LD];
   __shared__ double dl[LDLR_NB], rdl[LDLR_NB];
   __shared__ double red[LDL_THREADS / 64];
   __shared__ int sflags[2];
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = LDL_THREADS / 64;
   const int li = lane & 15, lk = lane >> 4;
-  const size_t lda = (size_t)n;
+  const size_t lda = BLOCK ? (size_t)lda_in : (size_t)n;
   const int nt = (n + 15) / 16, ntt = nt * (nt + 1) / 2;
   // the input is S + Q (Q: lower triangle authoritative, may be null), read straight from the all-reduced buffer:
   // no separate add/copy kernel in front of the factorisation; S itself stays untouched for the pivoted fallback
   double loc = 0.0;
-  for (int i = tid; i < n; i += LDL_THREADS) loc = fmax(loc, fabs(S[i + i * lda] + (Q ? Q[i + i * lda] : 0.0)));
+  if (!BLOCK)
+    for (int i = tid; i < n; i += LDL_THREADS) loc = fmax(loc, fabs(S[i + i * lda] + (Q ? Q[i + i * lda] : 0.0)));
   // tiles of this wave: t = wv + 8 s  <->  (I >= J), t = I (I + 1) / 2 + J
   double4_t acc[LDLR_TPW];
   int tIJ[LDLR_TPW];   // wave-uniform (SGPR): I << 8 | J, or -1
@@ -365,8 +372,12 @@ __global__ __launch_bounds__(LDL_THREADS) void k_ldl_regs(int n, const double* _
       if (t < ntt && row < n && col < n) {
         // S is symmetric in memory (both triangles are written): element (col, row) instead of (row, col) makes the 16
         // lanes of a row of the wave read 128 contiguous bytes instead of 16 cache lines
-        v = S[col + (size_t)row * lda];
-        if (Q) v += (row >= col) ? Q[row + (size_t)col * lda] : Q[col + (size_t)row * lda];
+        if (BLOCK) {
+          v = (row >= col) ? A[row + (size_t)col * lda] : A[col + (size_t)row * lda];
+        } else {
+          v = S[col + (size_t)row * lda];
+          if (Q) v += (row >= col) ? Q[row + (size_t)col * lda] : Q[col + (size_t)row * lda];
+        }
       }
       acc[s][r] = v;
     }
@@ -377,6 +388,7 @@ __global__ __launch_bounds__(LDL_THREADS) void k_ldl_regs(int n, const double* _
   __syncthreads();
   double anorm = 0.0;
   for (int q = 0; q < nwv; ++q) anorm = fmax(anorm, red[q]);
+  if (BLOCK) anorm = anorm_p[0];
   for (int jt_loop = 0; jt_loop < nt; ++jt_loop) {
     // panel index and per-lane tile coordinates behind optimisation barriers: otherwise the LDS addresses of
     // all 12 tiles become loop-carried induction variables / hoisted invariants and pin ~100 registers
@@ -505,9 +517,191 @@ __global__ __launch_bounds__(LDL_THREADS) void k_ldl_regs(int n, const double* _
     lds_barrier();
   }
   if (tid == 0) {
-    const bool ok = (sflags[0] == 0) && (sflags[1] == 1 || sflags[1] == 2 || n == 0);
-    mode[0] = ok ? 1 : 0;
-    if (ok) { info[0] = (sflags[1] == 1) ? n : 0; info[1] = (sflags[1] == 2) ? n : 0; info[2] = 0; }
+    if (BLOCK) {
+      if (sflags[0]) atomicOr(&gflags[0], 1);
+      atomicOr(&gflags[1], sflags[1]);
+    } else {
+      const bool ok = (sflags[0] == 0) && (sflags[1] == 1 || sflags[1] == 2 || n == 0);
+      mode[0] = ok ? 1 : 0;
+      if (ok) { info[0] = (sflags[1] == 1) ? n : 0; info[1] = (sflags[1] == 2) ? n : 0; info[2] = 0; }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Large S (n > 512: the 1000 x 1000 of configuration C5), round 4: right-looking blocked LDL^T with fat panels of
+// DNP = 208 columns (13 tiles: what k_ldl_regs holds in the accumulators of one workgroup).  Per panel three launches:
+//   k_ldl_regs<., BLOCK>   the diagonal block, in place (one workgroup: the serial chain of the factorisation)
+//   k_dn_trsm              L21 = A21 L11^{-T} D^{-1}: 64 rows per workgroup, blocked forward substitution over the 13
+//                          column blocks on the matrix cores (explicit inverses of the 16 x 16 unit diagonal blocks)
+//   k_dn_update            A22 -= (L21 D) L21^T, one 16 x 16 tile per wave, K = 208
+// (round 3: 32-column panels, two launches each, the 32 x 32 diagonal block factorised redundantly by every workgroup:
+// 0.92 ms at n = 1000; the kernels of that form are kept for the measurement switch PP_DENSE_PANEL32.)
+constexpr int DNP = 16 * LDLR_NT;       // panel width
+constexpr int DNT_LD = 18;              // LDS row stride of a 16-column block (conflict-free operand reads, as LDLR_LD)
+
+__global__ __launch_bounds__(256) void k_dn_trsm(int n, double* __restrict__ A, const double* __restrict__ dvec, int J0, int nb) {
+  extern __shared__ double dn_lds[];
+  // W[jb][row][k]: the panel rows of this workgroup, block by block; Li[jb][c][k] = inv(L11[jb, jb])[c][k]
+  double (*W)[64][DNT_LD] = (double (*)[64][DNT_LD])dn_lds;
+  double (*Li)[16][17] = (double (*)[16][17])(dn_lds + (size_t)LDLR_NT * 64 * DNT_LD);
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  const size_t lda = (size_t)n;
+  const int J1 = J0 + nb, m = n - J1, ntb = nb / 16;
+  const int R0 = (int)blockIdx.x * 64;                      // first panel row of this workgroup (relative to J1)
+  // (1) the 64 x 208 rows of A21: coalesced column reads -> LDS, 13 requests of a thread in flight (one at a time, as a
+  // rolled loop issues them, is 52 dependent round trips)
+  {
+    const int r = tid & 63, c0 = tid >> 6;
+    const bool live = R0 + r < m;
+    const double* src = A + (size_t)(J1 + (live ? R0 + r : 0)) + (size_t)J0 * lda;
+    for (int cb = 0; cb < DNP; cb += 52) {
+      double v[13];
+#pragma unroll
+      for (int u = 0; u < 13; ++u) v[u] = src[(size_t)(cb + c0 + 4 * u) * lda];
+#pragma unroll
+      for (int u = 0; u < 13; ++u) { const int c = cb + c0 + 4 * u; W[c >> 4][r][c & 15] = live ? v[u] : 0.0; }
+    }
+  }
+  // (2) inverses of the unit lower 16 x 16 diagonal blocks of L11.  The blocks go to LDS first (one request per thread
+  // and block: a chain of 120 global loads per inverse was most of this kernel); then lane c < 16 of wave (jb mod 4) owns
+  // column c of inv(L_jj): X[i][c] = delta_ic - sum_{k < i} L[i][k] X[k][c], the entries of L broadcast from LDS
+  for (int jb = 0; jb < ntb; ++jb) {
+    const int i = tid & 15, k = tid >> 4;
+    Li[jb][i][k] = A[(size_t)(J0 + 16 * jb + i) + (size_t)(J0 + 16 * jb + k) * lda];
+  }
+  __syncthreads();
+  for (int jb = wv; jb < ntb; jb += 4) {
+    double x[16];
+    if (lane < 16) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        double v = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; ++k) v -= Li[jb][i][k] * x[k];
+        x[i] = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();           // (the block is read by this wave only: overwrite it with its inverse)
+    if (lane < 16) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) Li[jb][i][lane] = x[i];       // Li[jb][row i][column c]
+    }
+  }
+  __syncthreads();
+  // (3) blocked forward substitution; every wave owns 16 rows and never reads another wave's.  The loop over the block
+  // rows is unrolled completely (a panel with rows below it always has LDLR_NT = 13 of them): every L11 operand address
+  // is then a constant offset and the compiler requests the operands of the following block rows (from global memory /
+  // L2) while it works on the current one -- with one memory round trip in front of every block row the kernel took 86 us.
+  const int wr = 16 * wv;
+  const double* Lrow0 = A + (size_t)(J0 + li) + (size_t)(J0 + lk) * lda;      // L11[n = li][k = lk]
+  constexpr int KBMAX = LDLR_NT - 1;
+  // operands of block rows jb + 1 and jb + 2, requested two block rows ahead of their use (B[k][n] = L[16 jb + n][16 kb + k])
+  double b1[KBMAX][4], b2[KBMAX][4];
+#define PP_TRSM_LOAD(dst, JB)                                                                            \
+  _Pragma("unroll") for (int kb_ = 0; kb_ < KBMAX; ++kb_)                                                \
+    if (kb_ < (JB) && (JB) < LDLR_NT)                                                                    \
+      _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                                   \
+        dst[kb_][q_] = Lrow0[(size_t)(16 * (JB)) + (size_t)(16 * kb_ + 4 * q_) * lda];
+  PP_TRSM_LOAD(b1, 1)
+  PP_TRSM_LOAD(b2, 2)
+#pragma unroll
+  for (int jb = 0; jb < LDLR_NT; ++jb) {
+    double4_t acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = W[jb][wr + lk + 4 * r][li];
+    double bc[KBMAX][4];
+    if (jb >= 1) {
+#pragma unroll
+      for (int kb = 0; kb < KBMAX; ++kb) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { bc[kb][q] = b1[kb][q]; b1[kb][q] = b2[kb][q]; }
+      }
+      PP_TRSM_LOAD(b2, jb + 2)
+    }
+    // acc -= sum_kb W_kb (16 x 16) L[jb, kb]^T; four accumulators: a chain of up to 48 dependent matrix instructions on
+    // one accumulator was 23 of the kernel's 43 us (timing builds without the products / without the inverses)
+    double4_t part[3] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+    for (int kb = 0; kb < jb; ++kb) {
+      double av[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) av[q] = -W[kb][wr + li][4 * q + lk];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if ((kb & 3) == 0) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bc[kb][q], acc, 0, 0, 0);
+        else part[(kb & 3) - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bc[kb][q], part[(kb & 3) - 1], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] += (part[0][r] + part[1][r]) + part[2][r];
+    // W_jb = acc inv(L_jj)^T: through LDS into operand layout (own rows only: wave-local ordering suffices)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) W[jb][wr + lk + 4 * r][li] = acc[r];
+    // (LDS operations of one wave execute in order: its own writes are visible to its reads without a wait)
+    double4_t w = {0.0, 0.0, 0.0, 0.0};
+    {
+      double av[4], bv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { av[q] = W[jb][wr + li][4 * q + lk]; bv[q] = Li[jb][li][4 * q + lk]; }   // B[k][n] = inv(L)[n][k]
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], w, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) W[jb][wr + lk + 4 * r][li] = w[r];
+  }
+#undef PP_TRSM_LOAD
+  __syncthreads();
+  // (4) L21 = W D^{-1}: coalesced column writes
+  {
+    const int r = tid & 63, c0 = tid >> 6;
+    if (R0 + r < m) {
+      double* dst = A + (size_t)(J1 + R0 + r) + (size_t)J0 * lda;
+#pragma unroll 13
+      for (int c = c0; c < DNP; c += 4) dst[(size_t)c * lda] = W[c >> 4][r][c & 15] / dvec[J0 + c];
+    }
+  }
+}
+
+__global__ __launch_bounds__(DN_THREADS) void k_dn_update(int n, double* __restrict__ A, const double* __restrict__ dvec, int J0,
+                                                          int nb) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const size_t lda = (size_t)n;
+  const int J1 = J0 + nb, m = n - J1;
+  const int nt = (m + 15) / 16, ntiles = nt * (nt + 1) / 2;
+  const int tix = (int)blockIdx.x * (DN_THREADS / 64) + wv;
+  if (tix >= ntiles) return;
+  const int li = lane & 15, lk = lane >> 4;
+  int I = (int)((sqrt(8.0 * tix + 1.0) - 1.0) * 0.5);
+  while ((I + 1) * (I + 2) / 2 <= tix) ++I;
+  while (I * (I + 1) / 2 > tix) --I;
+  const int J = tix - I * (I + 1) / 2;
+  const int ra = J1 + 16 * I + li, rb = J1 + 16 * J + li;
+  const bool va = ra < n, vb = rb < n;
+  const double* pa = A + (size_t)(va ? ra : J1) + (size_t)(J0 + lk) * lda;
+  const double* pb = A + (size_t)(vb ? rb : J1) + (size_t)(J0 + lk) * lda;
+  const double* pd = dvec + J0 + lk;
+  double4_t acc = {0.0, 0.0, 0.0, 0.0};
+  constexpr int QB = 26;                             // K steps requested together (two rounds cover a 208-column panel)
+  for (int q0 = 0; q0 < nb / 4; q0 += QB) {          // (nb is a multiple of 16 for every panel that has a trailing matrix)
+    double av[QB], bv[QB], dv[QB];
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+      const bool in = q0 + q < nb / 4;
+      const size_t off = (size_t)(4 * (in ? q0 + q : 0)) * lda;
+      av[q] = (in && va) ? pa[off] : 0.0;
+      bv[q] = (in && vb) ? pb[off] : 0.0;
+      dv[q] = in ? pd[4 * (q0 + q)] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < QB; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q] * dv[q], bv[q], acc, 0, 0, 0);
+  }
+  const int col = J1 + 16 * J + li;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = J1 + 16 * I + lk + 4 * r;
+    if (row < n && col < n && row >= col) A[row + (size_t)col * lda] -= acc[r];
   }
 }
 
@@ -766,19 +960,42 @@ int ppi_dense_factor_schur(pp_handle h, const double* Q_host) {
         hipLaunchKernelGGL(k_ldl_blocked, dim3(1), dim3(LDL_THREADS), 0, st, nc, h->Sldl, h->dvec, h->dense_mode, h->bkinfo,
                            BK_EPS);
       } else {
-        // large S: panel + trailing update spread over the chip, two launches per 32 columns
+        // large S: fat panels of 208 columns (diagonal block by the register-resident kernel, panel solve and trailing
+        // update on the matrix cores across the chip); PP_DENSE_PANEL32: the 32-column form of round 3
         double* anorm = h->work;                    // (scratch of the Bunch-Kaufman fallback, free until then:
         double* stage = h->work + 8;                //  2 n_c doubles >= 8 + 32 * 32 for n_c > 512)
         int* flags = h->dense_mode + 2;
         hipLaunchKernelGGL(k_dense_anorm, dim3(1), dim3(256), 0, st, nc, h->Sldl, anorm, flags);
-        for (int j0 = 0; j0 < nc; j0 += LDL_NB) {
-          const int m = nc - std::min(nc, j0 + LDL_NB);
-          hipLaunchKernelGGL(k_dense_panel, dim3(1 + (m + DN_THREADS - 1) / DN_THREADS), dim3(DN_THREADS), 0, st, nc,
-                             h->Sldl, h->dvec, anorm, flags, stage, j0, BK_EPS);
-          if (m > 0) {
-            const int nt = (m + 15) / 16, ntiles = nt * (nt + 1) / 2, per = DN_THREADS / 64;
-            hipLaunchKernelGGL(k_dense_update, dim3((ntiles + per - 1) / per), dim3(DN_THREADS), 0, st, nc, h->Sldl,
-                               h->dvec, stage, j0);
+        static const bool panel32 = std::getenv("PP_DENSE_PANEL32") != nullptr;
+        if (panel32) {
+          for (int j0 = 0; j0 < nc; j0 += LDL_NB) {
+            const int m = nc - std::min(nc, j0 + LDL_NB);
+            hipLaunchKernelGGL(k_dense_panel, dim3(1 + (m + DN_THREADS - 1) / DN_THREADS), dim3(DN_THREADS), 0, st, nc,
+                               h->Sldl, h->dvec, anorm, flags, stage, j0, BK_EPS);
+            if (m > 0) {
+              const int nt = (m + 15) / 16, ntiles = nt * (nt + 1) / 2, per = DN_THREADS / 64;
+              hipLaunchKernelGGL(k_dense_update, dim3((ntiles + per - 1) / per), dim3(DN_THREADS), 0, st, nc, h->Sldl,
+                                 h->dvec, stage, j0);
+            }
+          }
+        } else {
+          const size_t trsm_lds = ((size_t)LDLR_NT * 64 * DNT_LD + (size_t)LDLR_NT * 16 * 17) * sizeof(double);
+          if (!h->dn_lds_attr) {
+            PP_HIP(hipFuncSetAttribute((const void*)k_dn_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)trsm_lds));
+            h->dn_lds_attr = true;
+          }
+          for (int j0 = 0; j0 < nc; j0 += DNP) {
+            const int nb = std::min(DNP, nc - j0), m = nc - j0 - nb;
+            double* blk = h->Sldl + (size_t)j0 + (size_t)j0 * nc;
+            if (h->dense_dpp) hipLaunchKernelGGL((k_ldl_regs<true, true>), dim3(1), dim3(LDL_THREADS), 0, st, nb, blk, (const double*)nullptr, blk,
+                                                 h->dvec + j0, (int*)nullptr, (int*)nullptr, BK_EPS, nc, anorm, flags);
+            else hipLaunchKernelGGL((k_ldl_regs<false, true>), dim3(1), dim3(LDL_THREADS), 0, st, nb, blk, (const double*)nullptr, blk,
+                                    h->dvec + j0, (int*)nullptr, (int*)nullptr, BK_EPS, nc, anorm, flags);
+            if (m > 0) {
+              hipLaunchKernelGGL(k_dn_trsm, dim3((m + 63) / 64), dim3(256), trsm_lds, st, nc, h->Sldl, h->dvec, j0, nb);
+              const int nt = (m + 15) / 16, ntiles = nt * (nt + 1) / 2, per = DN_THREADS / 64;
+              hipLaunchKernelGGL(k_dn_update, dim3((ntiles + per - 1) / per), dim3(DN_THREADS), 0, st, nc, h->Sldl, h->dvec, j0, nb);
+            }
           }
         }
         hipLaunchKernelGGL(k_dense_finish, dim3(1), dim3(64), 0, st, nc, flags, h->dense_mode, h->bkinfo);
