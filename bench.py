@@ -342,7 +342,8 @@ def main():
     def raw_step(k):
         for gid, t in sets[k % nsets][0].sources.items():
             eng.bind_source_tensor(gid, t)
-        eng.numeric_local()
+        eng.numeric_factor_blocks()
+        eng.numeric_schur(side=(not args.no_prefetch) and (world == 1 or eng._direct_rccl(comm)))
         eng.allreduce_schur(comm)
         if solver._btd is not None:
             eng.factor_schur_corner(*qcorner)

@@ -132,6 +132,11 @@ int pp_numeric_local(pp_handle h);
  * Schur contributions): pp_numeric_local == pp_numeric_factor_blocks followed by pp_numeric_schur. */
 int pp_numeric_factor_blocks(pp_handle h);
 int pp_numeric_schur(pp_handle h);
+/* The same with the Schur update -- and the dense factorisation of S that follows it -- on a stream of the library's own,
+ * forked behind the factor levels (side_stream != 0; dense S, at most two pattern groups): a forward sweep enqueued on the
+ * handle's stream after pp_factor_schur then runs beside both.  An all-reduce of S between the two must be the library's
+ * (pp_allreduce_schur); pp_solve_coupling and everything else that reads the factor of S or writes S joins. */
+int pp_numeric_schur_ex(pp_handle h, int side_stream);
 /* Status agreement without a collective of its own (mpi_...:19-30, 294-305: the reference gathers the sub-solver
  * statuses of all ranks before it communicates S).  A rank whose block phase failed on the host side (status 1, 2 or 3)
  * calls this instead of pp_numeric_schur: its Schur buffer becomes a zero contribution whose tail carries the failure,

@@ -68,6 +68,7 @@ SIGNATURES = {
     'pp_numeric_local': (ctypes.c_int, [ctypes.c_void_p]),
     'pp_numeric_factor_blocks': (ctypes.c_int, [ctypes.c_void_p]),
     'pp_numeric_schur': (ctypes.c_int, [ctypes.c_void_p]),
+    'pp_numeric_schur_ex': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'pp_fail_local': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'pp_schur_buffer': (ctypes.c_void_p, [ctypes.c_void_p]),
     'pp_bind_schur_buffer': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),

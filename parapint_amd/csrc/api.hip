@@ -507,7 +507,10 @@ int pp_end_symbolic(pp_handle h) {
     h->status_dev = (long long*)dp;
     h->status_seq = 0;
   }
-  if (!h->dense_stream && h->dense_overlap) {     // (stream of the dense phase, dense.hip: made here, not in the first factorisation)
+  // stream of the dense phase (dense.hip): made here, not in the first factorisation -- and only for a dense S: the
+  // runtime maps streams onto a few hardware queues, and one more stream made the three group streams of a time-staged
+  // problem share a queue (C4: 7.9 -> 11.2 ms per step)
+  if (!h->dense_stream && h->dense_overlap && !h->btd && nc > 0 && h->groups.size() <= 2) {
     PP_HIP(hipStreamCreateWithFlags(&h->dense_stream, hipStreamNonBlocking));
     PP_HIP(hipEventCreateWithFlags(&h->ev_dense_fork, hipEventDisableTiming));
     PP_HIP(hipEventCreateWithFlags(&h->ev_dense_done, hipEventDisableTiming));
@@ -552,6 +555,10 @@ int pp_upload_values_compact(pp_handle h, int group, const double* compact, int 
   if (nrows == 0 || stride == 0) return 0;
   PP_HIP(hipMemcpyAsync(g->raw_own + (size_t)row0 * stride, compact + (size_t)row0 * stride, (size_t)nrows * stride * sizeof(double),
                         on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+  // (rows sent from the staging array the threaded paths use mirror it from now on; anything else breaks the mirror)
+  if (g->staged_row_valid.size() != (size_t)g->batch) g->staged_row_valid.assign((size_t)g->batch, 0);
+  const uint8_t ok = (!on_device && compact == g->stage_host) ? 1 : 0;
+  for (int r = row0; r < row0 + nrows; ++r) g->staged_row_valid[(size_t)r] = ok;
   return 0;
 }
 
@@ -1064,12 +1071,20 @@ int pp_stage_upload_compact(pp_handle h, int group, int nblocks, int nthreads, c
   if (int rc = ensure_optional(h, g, OPT_RAW)) return rc;
   g->input_mode = Group::IN_COMPACT;
   const size_t stride = (size_t)g->nraw_used;
-  return sliced_upload(h, nblocks, nthreads, slots, [&](int i) { stage_range(a, i, i + 1); },
-                       [&](int r0, int r1) {
-                         return stride == 0 ? hipSuccess
-                                            : hipMemcpyAsync(g->raw_own + (size_t)r0 * stride, staging + (size_t)r0 * stride,
-                                                             (size_t)(r1 - r0) * stride * sizeof(double), hipMemcpyHostToDevice, h->stream);
-                       });
+  if (g->staged_row_valid.size() != (size_t)g->batch || g->stage_host != staging) g->staged_row_valid.assign((size_t)g->batch, 0);
+  g->stage_host = staging;
+  // (whole slices are sent: every row in a slice's range mirrors the staging array afterwards -- also the rows of blocks
+  // that were NOT staged, whose stale staging rows the caller overwrites and sends again)
+  for (int i = 0; i < nblocks; ++i) g->staged_row_valid[(size_t)slots[i]] = 0;
+  const int rc = sliced_upload(h, nblocks, nthreads, slots, [&](int i) { stage_range(a, i, i + 1); },
+                               [&](int r0, int r1) {
+                                 return stride == 0 ? hipSuccess
+                                                    : hipMemcpyAsync(g->raw_own + (size_t)r0 * stride, staging + (size_t)r0 * stride,
+                                                                     (size_t)(r1 - r0) * stride * sizeof(double), hipMemcpyHostToDevice, h->stream);
+                               });
+  if (rc == 0)
+    for (int i = 0; i < nblocks; ++i) g->staged_row_valid[(size_t)slots[i]] = same_out[i];
+  return rc;
 }
 
 // The same for blocks whose index arrays were verified at an earlier call (nothing is compared), WITHOUT waiting: the
@@ -1089,22 +1104,72 @@ struct StageJob {
   size_t stride = 0;
   int device = 0;
   hipStream_t stream = nullptr;
+  // Compare while staging: a row whose staged values mirror the device (valid) is compared piece by piece (CH doubles of
+  // the compact row) with the new values; only pieces that differ are copied into the staging row and marked, and a
+  // slice sends the column ranges some row of it marked -- constant Jacobian values (80 % of a C3 block) do not cross
+  // PCIe again.  Rows that do not mirror the device yet are copied and sent whole.
+  static constexpr size_t CH = 512;
+  uint8_t* row_valid = nullptr;          // the group's staged_row_valid
+  size_t nchunk = 0;
+  std::vector<uint8_t> changed;          // [block][chunk]
+  std::atomic<long long> sent_bytes{0};
+  bool compare = true;
+  void stage_run(double* row, const double* src, size_t d, size_t len, bool valid, uint8_t* mark) {
+    size_t p0 = d;
+    const size_t end = d + len;
+    while (p0 < end) {
+      const size_t p1 = std::min(end, (p0 / CH + 1) * CH);
+      const size_t bytes = (p1 - p0) * sizeof(double);
+      if (!valid || std::memcmp(row + p0, src + (p0 - d), bytes) != 0) {
+        std::memcpy(row + p0, src + (p0 - d), bytes);
+        mark[p0 / CH] = 1;
+      }
+      p0 = p1;
+    }
+  }
   void work() {
     bool device_set = false;
     for (;;) {
       const int i = next.fetch_add(1, std::memory_order_relaxed);
       if (i >= nblocks) break;
-      double* row = staging + (size_t)slots[(size_t)i] * stride;
-      for (size_t r = 0; r + 2 < runs_k.size() + 1; r += 3) std::memcpy(row + runs_k[r + 2], kd[(size_t)i] + runs_k[r], (size_t)runs_k[r + 1] * sizeof(double));
-      for (size_t r = 0; r + 2 < runs_b.size() + 1; r += 3) std::memcpy(row + runs_b[r + 2], bd[(size_t)i] + runs_b[r], (size_t)runs_b[r + 1] * sizeof(double));
+      const size_t slot = (size_t)slots[(size_t)i];
+      double* row = staging + slot * stride;
+      const bool valid = compare && row_valid[slot] != 0;
+      uint8_t* mark = changed.data() + (size_t)i * nchunk;
+      for (size_t r = 0; r + 2 < runs_k.size() + 1; r += 3) stage_run(row, kd[(size_t)i] + runs_k[r], (size_t)runs_k[r + 2], (size_t)runs_k[r + 1], valid, mark);
+      for (size_t r = 0; r + 2 < runs_b.size() + 1; r += 3) stage_run(row, bd[(size_t)i] + runs_b[r], (size_t)runs_b[r + 2], (size_t)runs_b[r + 1], valid, mark);
       const int s = i / slice, i0 = s * slice, i1 = std::min(nblocks, i0 + slice);
       if (done[(size_t)s].fetch_add(1, std::memory_order_acq_rel) + 1 == i1 - i0 && stride > 0) {
         // the last block of the slice: its rows go to the device (rows of blocks outside the call lie in between only
         // when the caller mixes paths; they are sent again by whoever stages them)
         if (!device_set) { (void)hipSetDevice(device); device_set = true; }
         const size_t r0 = (size_t)slots[(size_t)i0], r1 = (size_t)slots[(size_t)i1 - 1] + 1;
-        const hipError_t e = hipMemcpyAsync(dev + r0 * stride, staging + r0 * stride, (r1 - r0) * stride * sizeof(double), hipMemcpyHostToDevice, stream);
+        bool all_valid = compare;
+        for (int q = i0; q < i1 && all_valid; ++q) all_valid = row_valid[(size_t)slots[(size_t)q]] != 0;
+        hipError_t e = hipSuccess;
+        if (!all_valid) {
+          e = hipMemcpyAsync(dev + r0 * stride, staging + r0 * stride, (r1 - r0) * stride * sizeof(double), hipMemcpyHostToDevice, stream);
+          sent_bytes.fetch_add((long long)((r1 - r0) * stride * sizeof(double)), std::memory_order_relaxed);
+        } else {
+          // union of the marked pieces over the rows of the slice -> column ranges -> one 2-D copy per range
+          std::vector<uint8_t> u(nchunk, 0);
+          for (int q = i0; q < i1; ++q) {
+            const uint8_t* m = changed.data() + (size_t)q * nchunk;
+            for (size_t c = 0; c < nchunk; ++c) u[c] |= m[c];
+          }
+          for (size_t c = 0; c < nchunk && e == hipSuccess;) {
+            if (!u[c]) { ++c; continue; }
+            size_t c1 = c;
+            while (c1 < nchunk && u[c1]) ++c1;
+            const size_t col0 = c * CH, col1 = std::min(stride, c1 * CH);
+            e = hipMemcpy2DAsync(dev + r0 * stride + col0, stride * sizeof(double), staging + r0 * stride + col0, stride * sizeof(double),
+                                 (col1 - col0) * sizeof(double), r1 - r0, hipMemcpyHostToDevice, stream);
+            sent_bytes.fetch_add((long long)((col1 - col0) * sizeof(double) * (r1 - r0)), std::memory_order_relaxed);
+            c = c1;
+          }
+        }
         if (e != hipSuccess) { int zero = 0; err.compare_exchange_strong(zero, (int)e); }
+        else for (int q = i0; q < i1; ++q) row_valid[(size_t)slots[(size_t)q]] = 1;
       }
     }
   }
@@ -1151,6 +1216,13 @@ int pp_stage_upload_verified_begin(pp_handle h, int group, int nblocks, int nthr
   for (auto& d : j->done) d.store(0, std::memory_order_relaxed);
   j->nblocks = nblocks; j->staging = staging; j->dev = g->raw_own; j->stride = (size_t)g->nraw_used;
   j->device = h->device; j->stream = h->stream;
+  if (g->staged_row_valid.size() != (size_t)g->batch || g->stage_host != staging) g->staged_row_valid.assign((size_t)g->batch, 0);
+  g->stage_host = staging;
+  j->row_valid = g->staged_row_valid.data();
+  j->nchunk = (j->stride + StageJob::CH - 1) / StageJob::CH;
+  static const bool no_compare = std::getenv("PP_NO_STAGE_COMPARE") != nullptr;      // (measurement switch)
+  j->compare = !no_compare;
+  try { j->changed.assign((size_t)nblocks * j->nchunk, 0); } catch (...) { delete j; return fail(h, 3, "pp_stage_upload_verified_begin: out of host memory"); }
   h->stage_job = j;
   const int nt = std::max(1, std::min(std::min(nthreads, 64), nblocks));
   if (h->stage_pool.start(nt, [j]() { j->work(); }) == 0) {      // no thread could be started: here and now
@@ -1401,7 +1473,9 @@ int pp_allreduce_schur(pp_handle h) {
   if (!h->numeric_done) return fail(h, 3, "pp_allreduce_schur before pp_numeric_local");
   PP_HIP(hipSetDevice(h->device));
   const size_t count = schur_doubles(h) + PP_TAIL;
-  const int rc = g_rccl.allreduce(h->S, h->S, count, /* ncclDouble */ 8, /* ncclSum */ 0, h->rccl_comm, h->stream);
+  // (behind the Schur update, wherever it was enqueued)
+  const int rc = g_rccl.allreduce(h->S, h->S, count, /* ncclDouble */ 8, /* ncclSum */ 0, h->rccl_comm,
+                                  h->schur_on_side ? h->dense_stream : h->stream);
   if (rc != 0) return fail(h, 3, rccl_msg("ncclAllReduce(S)", rc));
   return 0;
 }

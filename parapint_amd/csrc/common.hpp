@@ -210,6 +210,10 @@ struct Group {
   const double* rhs_native = nullptr;
   double* x_native = nullptr;
   int nc_loc = 0;                    // coupling rows of the group's plan (== n_c unless the group is mapped)
+  // host boundary: rows of the compact device input that mirror the caller's pinned staging array (same values on both
+  // sides): a later staging pass sends only the column ranges whose values changed (api.hip: StageJob)
+  std::vector<uint8_t> staged_row_valid;
+  const double* stage_host = nullptr;
   std::vector<int> cmap_host;        // mapped group: [batch][nc_loc] global coupling indices
 };
 
@@ -347,6 +351,7 @@ struct pp_solver {
   hipStream_t dense_stream = nullptr;
   hipEvent_t ev_dense_fork = nullptr, ev_dense_done = nullptr;
   bool dense_pending = false;
+  bool schur_on_side = false;    // the Schur update of this factorisation runs on dense_stream (pp_numeric_schur_ex): the dense phase follows it there
   bool dense_overlap = std::getenv("PP_NO_DENSE_OVERLAP") == nullptr;   // (measurement switch)
   // interior-point step on device-resident iterates (ipstep.hip): partials of its reductions, pinned mailbox
   double* ip_part = nullptr;

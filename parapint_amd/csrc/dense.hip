@@ -924,13 +924,19 @@ int ppi_dense_factor_schur(pp_handle h, const double* Q_host) {
   hipStream_t st = h->stream;
   const int nc = h->nc;
   const size_t nn = schur_doubles(h);
-  if (int rc = join_dense(h)) return rc;
+  const bool follow = h->schur_on_side && h->dense_stream && !Q_host && !h->profile;      // the Schur update ran on the dense stream
+  h->schur_on_side = false;
+  if (!follow) { if (int rc = join_dense(h)) return rc; }
   // The dense factorisation leaves most of the chip idle (one workgroup for n_c <= 512, a chain of small launches
   // beyond): it runs on a stream of its own, forked here, so that a forward sweep enqueued behind this call (it does not
   // depend on S) overlaps it; the coupling solve joins.
   // Not with a host Q (its upload is ordered by the caller on the handle's stream) and not while phases are timed.
-  const bool overlap = h->dense_overlap && !h->profile && !Q_host && h->dense_policy == 0;
-  if (overlap) {
+  // (nor with more than two pattern groups: their streams and this one would share hardware queues)
+  const bool overlap = h->dense_overlap && !h->profile && !Q_host && h->dense_policy == 0 && h->groups.size() <= 2;
+  if (follow) {
+    h->dense_pending = false;       // (re-armed below: the handle's stream joins behind the whole dense phase)
+    st = h->dense_stream;
+  } else if (overlap) {
     if (!h->dense_stream) {
       PP_HIP(hipStreamCreateWithFlags(&h->dense_stream, hipStreamNonBlocking));
       PP_HIP(hipEventCreateWithFlags(&h->ev_dense_fork, hipEventDisableTiming));
@@ -1006,7 +1012,7 @@ int ppi_dense_factor_schur(pp_handle h, const double* Q_host) {
     hipLaunchKernelGGL(k_bk_factor, dim3(1), dim3(BK_THREADS), 0, st, nc, h->S, Qd, h->Sfac, h->ipiv, h->work, h->bkinfo,
                        h->dense_mode, h->status_dev, ++h->status_seq);
   }
-  if (overlap) {
+  if (overlap || follow) {
     PP_HIP(hipEventRecord(h->ev_dense_done, st));
     h->dense_pending = true;
   }

@@ -455,11 +455,24 @@ __global__ void k_write_tail(int* counters, double* tail) {
 
 extern "C" {
 
-int pp_numeric_schur(pp_handle h) {
+int pp_numeric_schur(pp_handle h) { return pp_numeric_schur_ex(h, 0); }
+
+int pp_numeric_schur_ex(pp_handle h, int side_stream) {
   if (!h || !h->symbolic_done || !h->blocks_factored) return fail(h, 3, "pp_numeric_schur before pp_numeric_factor_blocks");
   PP_HIP(hipSetDevice(h->device));
   if (int rc = join_dense(h)) return rc;          // (S is written below: a dense phase still reading it must be over)
   hipStream_t st = h->stream;
+  // side_stream: the Schur update (and the dense phase behind it) on the dense stream, forked behind the factor levels, so
+  // that a forward sweep enqueued on the handle's stream right after this call runs beside both
+  // MEASURED AND NOT ADOPTED (round 4, C3): 0.825-0.845 ms per step against 0.798 ms with only the dense phase beside the
+  // forward sweep -- the Schur update (350 MB of coupling rows) and the sweep compete for the same HBM bandwidth.  Opt-in:
+  static const bool want_side = std::getenv("PP_SCHUR_SIDE") != nullptr;
+  h->schur_on_side = side_stream && want_side && h->dense_overlap && h->dense_stream && !h->profile && !h->btd && h->groups.size() <= 2;
+  if (h->schur_on_side) {
+    PP_HIP(hipEventRecord(h->ev_dense_fork, h->stream));
+    PP_HIP(hipStreamWaitEvent(h->dense_stream, h->ev_dense_fork, 0));
+    st = h->dense_stream;
+  }
   const int nc = h->nc;
   // S starts from zero -- unless the first group is a plain (unmapped) one whose tiles cover all of S: its reduction
   // then stores instead of adding.  The counters are cleared by whoever writes the tail (zero at allocation).
@@ -510,6 +523,10 @@ int pp_numeric_schur(pp_handle h) {
   }
   if (!tail_written) hipLaunchKernelGGL(k_write_tail, dim3(1), dim3(64), 0, st, h->counters, h->S + schur_doubles(h));
   PP_HIP(hipGetLastError());
+  if (h->schur_on_side) {
+    PP_HIP(hipEventRecord(h->ev_dense_done, st));
+    h->dense_pending = true;              // (whoever touches S on the handle's stream joins)
+  }
   h->numeric_done = true;
   h->schur_done = false;
   return 0;

@@ -538,8 +538,9 @@ class HipEngine(object):
     def numeric_factor_blocks(self):
         self.ns.check(self.lib.pp_numeric_factor_blocks(self.ns.h), 'pp_numeric_factor_blocks')
 
-    def numeric_schur(self):
-        self.ns.check(self.lib.pp_numeric_schur(self.ns.h), 'pp_numeric_schur')
+    def numeric_schur(self, side=False):
+        """side: on the library's own stream behind the factor levels (a forward sweep enqueued afterwards overlaps it)."""
+        self.ns.check(self.lib.pp_numeric_schur_ex(self.ns.h, 1 if side else 0), 'pp_numeric_schur')
 
     def fail_local(self, status):
         self.ns.check(self.lib.pp_fail_local(self.ns.h, int(status)), 'pp_fail_local')
@@ -1526,7 +1527,13 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         # the n_c solves + products per block of the reference (mpi_...:312-333) are the coupling rows of the same
         # partial factorisation; what is left is their outer products
         timer.start('back solve')
-        self._guarded(res, self._eng.numeric_schur)
+        # with a forward sweep announced (prefetch_forward) the Schur update leaves the handle's stream to it -- unless S is
+        # all-reduced through torch.distributed, which enqueues on that stream
+        side = self._prefetch_rhs is not None and (self.comm.size == 1 or getattr(self._eng, '_direct_rccl', lambda c: False)(self.comm))
+        if side:
+            self._guarded(res, self._eng.numeric_schur, True)
+        else:
+            self._guarded(res, self._eng.numeric_schur)
         timer.stop('back solve')
         timer.start('dot product')
         timer.stop('dot product')

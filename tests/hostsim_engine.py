@@ -128,7 +128,7 @@ class HostSimEngine(object):
             raise hu_status_error(1, 'value storage exceeds the budget')
         self.numeric_local()
 
-    def numeric_schur(self):
+    def numeric_schur(self, side=False):
         pass
 
     def fail_local(self, status):

@@ -923,6 +923,25 @@ def case_boundary_fast_paths(make_engine, calls=None):
             a[0], a[-1] = a[-1].copy(), a[0].copy()
         solver.do_numeric_factorization(kkt2)
         dense_check(solver, kkt2, rhs, solver.do_back_solve(rhs))
+        # values changed in a subset of the entries only (the staging threads compare with what the device already holds and
+        # send the column ranges that differ): first a few entries of two blocks, then one whole block, then nothing at all
+        kkt_s = model.build_kkt(comm=comm, iteration=2)
+        solver.do_numeric_factorization(kkt_s)
+        solver.do_numeric_factorization(kkt_s)
+        for ndx, pos in ((0, (1, 5)), (3, (0,))):
+            K = kkt_s.get_block(ndx, ndx)
+            d = K.data.copy()
+            diag = np.flatnonzero(K.row == K.col)
+            for q in pos:
+                d[diag[q]] *= 1.25
+            K.data = d
+        solver.do_numeric_factorization(kkt_s)
+        dense_check(solver, kkt_s, rhs, solver.do_back_solve(rhs))
+        kkt_s.get_block(2, 2).data = np.array(model.block_values(2, 4))
+        solver.do_numeric_factorization(kkt_s)
+        dense_check(solver, kkt_s, rhs, solver.do_back_solve(rhs))
+        solver.do_numeric_factorization(kkt_s)
+        dense_check(solver, kkt_s, rhs, solver.do_back_solve(rhs))
         # two INTERIOR entries exchanged in place (row, column and value together: the same matrix in another entry
         # order; first, middle and last entry untouched): the checksum of the index arrays finds it -- at once while the
         # arrays fit the per-call byte budget, at the next full check otherwise -- and the block is compared again
