@@ -11,7 +11,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 
-from hostsim_engine import HostSimDeviceEngine  # noqa: E402
+GPU = '--gpu' in sys.argv      # the real kernels, both ranks on the visible device(s), collectives through gloo (rehearsal)
+if not GPU:
+    from hostsim_engine import HostSimDeviceEngine  # noqa: E402
 from parapint_amd.algorithms.device_interior_point import ip_solve_device  # noqa: E402
 from parapint_amd.algorithms.interior_point import IPOptions, InteriorPointStatus  # noqa: E402
 from parapint_amd.examples.stochastic_qp import random_stochastic_qp  # noqa: E402
@@ -32,7 +34,8 @@ def mixed_scenarios():
 def run(comm, qps, fs):
     it = DeviceStochasticQPInterface(qps, fs, comm=comm)
     opt = IPOptions()
-    opt.linalg.solver = HipSchurComplementLinearSolver({i: None for i in it.local}, None, comm=comm, engine=HostSimDeviceEngine())
+    opt.linalg.solver = HipSchurComplementLinearSolver({i: None for i in it.local}, None, comm=comm,
+                                                       engine=None if GPU else HostSimDeviceEngine(), result_buffers=2 if GPU else 0)
     hist = []
     status, iters = ip_solve_device(it, opt, history=hist)
     assert status == InteriorPointStatus.optimal
@@ -41,6 +44,9 @@ def run(comm, qps, fs):
 
 def main():
     dist.init_process_group('gloo')
+    if GPU:
+        import torch
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count())
     comm = TorchComm()
     assert comm.size == 2
     qps, fs = mixed_scenarios()

@@ -194,9 +194,20 @@ def test_row_programs_reproduce_the_host_interface():
     assert abs(ops.wait()[6] - obj) <= 1e-12 * max(1.0, abs(obj))
 
 
+@pytest.mark.gpu
+def test_two_rank_device_loop_on_the_device():
+    """The same with the real kernels: two ranks share the device(s), the collectives (S, r_s, the two all-gathers of the
+    step) go through gloo -- the rehearsal of the N > 1 path a one-GPU box allows."""
+    _two_rank_run('--gpu')
+
+
 def test_two_rank_device_loop():
     """world_size 2 over gloo: rank-distributed scenarios of two sparsity patterns; the iterates, the iteration count and
     every measure equal those of the one-rank run, and both ranks publish identical scalars."""
+    _two_rank_run()
+
+
+def _two_rank_run(*args):
     import os
     import socket
     import subprocess
@@ -207,7 +218,7 @@ def test_two_rank_device_loop():
     port = s.getsockname()[1]
     s.close()
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.join(here, 'ip_multirank_worker.py')]
+           '--master-port', str(port), os.path.join(here, 'ip_multirank_worker.py')] + list(args)
     env = dict(os.environ)
     env['OMP_NUM_THREADS'] = '1'
     out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)

@@ -722,3 +722,37 @@ def test_host_boundary_fast_paths_on_the_device():
 
 def test_zero_pivot_test_inside_a_mixed_scale_block_pivot():
     sc.case_mixed_scale_block_pivot(lambda: None)
+
+
+def test_prefetched_forward_sweep_gives_the_same_solution():
+    """solver.prefetch_forward(rhs): the forward sweep enqueued behind the factorisation (beside the dense phase on its own
+    stream) and the back-solve that starts at the coupling solve give bit for bit the solution of the plain call order; a
+    back-solve with ANOTHER right-hand side falls back to the full sweep; retries re-run the sweep."""
+    import torch
+    from parapint_amd.examples.performance.schur_complement.synthetic_kkt import SyntheticKKT
+    from parapint_amd.linalg.comm import SerialComm
+    from parapint_amd.linalg.hip_schur_complement import HipSchurComplementLinearSolver
+    N = 70
+    model = SyntheticKKT(N, 40, 2, 8)
+    comm = SerialComm()
+    solver = HipSchurComplementLinearSolver({i: None for i in range(N)}, None, comm=comm, result_buffers=0)
+    dk = model.build_device_kkt(comm=comm)
+    solver.do_symbolic_factorization(dk)
+    dk.set_sources_from_host({ndx: model.block_sources(ndx, 1) for ndx in range(N)})
+    rhs = solver.device_vector_from_host(model.build_rhs(comm=comm))
+    other = solver.device_vector_from_host(model.build_rhs(comm=comm))
+    other.group_tensors[0].mul_(2.0)
+    solver.do_numeric_factorization(dk)
+    x_plain = solver.do_back_solve(rhs)
+    x_other = solver.do_back_solve(other)
+    solver.prefetch_forward(rhs)
+    solver.do_numeric_factorization(dk)
+    solver.do_numeric_factorization(dk)                       # (a second factorisation of the iteration: the sweep is redone)
+    x_pre = solver.do_back_solve(rhs)
+    solver.prefetch_forward(rhs)
+    solver.do_numeric_factorization(dk)
+    x_fallback = solver.do_back_solve(other)                  # not the announced vector: full sweep
+    torch.cuda.synchronize()
+    assert torch.equal(x_pre.group_tensors[0], x_plain.group_tensors[0]) and torch.equal(x_pre.coupling, x_plain.coupling)
+    assert torch.equal(x_fallback.group_tensors[0], x_other.group_tensors[0]) and torch.equal(x_fallback.coupling, x_other.coupling)
+    assert solver._prefetch_rhs is None and solver._forward_done_for is None
