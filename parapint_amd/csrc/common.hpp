@@ -368,6 +368,7 @@ struct pp_solver {
   std::vector<int> bcr_off, bcr_ne, bcr_s, bcr_lo;   // per level: offset into btd_elim, eliminated blocks, stride, lower neighbour live
   int btd_sequential = 0;
   bool bcr_lds_attr = false, bcr_ldl_attr = false, dn_lds_attr = false;
+  double* dn_z = nullptr;        // fat-panel dense factor (n_c > 512): inverted diagonal blocks + work vectors of the panel solve (dense.hip)
   // largest multiplier the unpivoted block factorisation of the cyclic reduction accepts (1 / u, u = 0.01; PP_BCR_LBOUND:
   // test switch -- a bound below 1 sends some blocks to Bunch-Kaufman and leaves others on the unpivoted path)
   double bcr_lbound = std::getenv("PP_BCR_LBOUND") ? std::atof(std::getenv("PP_BCR_LBOUND")) : 100.0;
@@ -668,6 +669,7 @@ void free_globals(pp_handle h) {
   h->dense_mode = nullptr;
   h->ipiv = h->bkinfo = h->counters = nullptr;
   if (h->vec_part) { (void)hipFree(h->vec_part); h->vec_part = nullptr; }
+  if (h->dn_z) { (void)hipFree(h->dn_z); h->dn_z = nullptr; }
   for (void* p : {(void*)h->btd_fac, (void*)h->btd_inv, (void*)h->btd_x, (void*)h->btd_vec, (void*)h->btd_ipiv, (void*)h->btd_info,
                   (void*)h->scatter_err, (void*)h->btd_klo, (void*)h->btd_kup, (void*)h->btd_ylo, (void*)h->btd_yup, (void*)h->btd_elim})
     if (p) (void)hipFree(p);

@@ -540,7 +540,14 @@ __global__ __launch_bounds__(LDL_THREADS) void k_ldl_regs(int n, const double* _
 constexpr int DNP = 16 * LDLR_NT;       // panel width
 constexpr int DNT_LD = 18;              // LDS row stride of a 16-column block (conflict-free operand reads, as LDLR_LD)
 
-__global__ __launch_bounds__(256) void k_dn_trsm(int n, double* __restrict__ A, const double* __restrict__ dvec, int J0, int nb) {
+// Workgroups beyond the nrb row blocks of A21 run the same substitution on rows of the IDENTITY (64 each): they produce
+// inv(L11)^T -- the panel's diagonal block inverted, which turns the coupling solve into matrix-vector products
+// (k_dn_fwd / k_dn_bwd) -- in both orientations: Zf[i + k ldz] = Zb[k + i ldz] = inv(L11)[i][k].  The panel is always 208
+// columns wide here (run-time masks for a narrower one turned the unrolled substitution into 189 branches and 400 bytes of
+// scratch per lane: 36 -> 140 us); the last, narrower panel of a matrix is inverted from a copy padded with the identity
+// (k_dn_pad), through this same kernel.
+__global__ __launch_bounds__(256) void k_dn_trsm(int n, double* __restrict__ A, const double* __restrict__ dvec, int J0, int nb,
+                                                 int nrb, double* __restrict__ Zf, double* __restrict__ Zb) {
   extern __shared__ double dn_lds[];
   // W[jb][row][k]: the panel rows of this workgroup, block by block; Li[jb][c][k] = inv(L11[jb, jb])[c][k]
   double (*W)[64][DNT_LD] = (double (*)[64][DNT_LD])dn_lds;
@@ -548,31 +555,32 @@ __global__ __launch_bounds__(256) void k_dn_trsm(int n, double* __restrict__ A, 
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lk = lane >> 4;
   const size_t lda = (size_t)n;
-  const int J1 = J0 + nb, m = n - J1, ntb = nb / 16;
-  const int R0 = (int)blockIdx.x * 64;                      // first panel row of this workgroup (relative to J1)
+  const int J1 = J0 + nb, m = n - J1, ntb = (nb + 15) / 16;
+  const bool ident = (int)blockIdx.x >= nrb;                // rows of the identity instead of rows of A21
+  const int R0 = ((int)blockIdx.x - (ident ? nrb : 0)) * 64;      // first row of this workgroup (relative to J1 / in the identity)
   // (1) the 64 x 208 rows of A21: coalesced column reads -> LDS, 13 requests of a thread in flight (one at a time, as a
   // rolled loop issues them, is 52 dependent round trips)
   {
     const int r = tid & 63, c0 = tid >> 6;
-    const bool live = R0 + r < m;
+    const bool live = !ident && R0 + r < m;
     const double* src = A + (size_t)(J1 + (live ? R0 + r : 0)) + (size_t)J0 * lda;
     for (int cb = 0; cb < DNP; cb += 52) {
       double v[13];
 #pragma unroll
-      for (int u = 0; u < 13; ++u) v[u] = src[(size_t)(cb + c0 + 4 * u) * lda];
+      for (int u = 0; u < 13; ++u) v[u] = ident ? ((R0 + r == cb + c0 + 4 * u) ? 1.0 : 0.0) : src[(size_t)(cb + c0 + 4 * u) * lda];
 #pragma unroll
-      for (int u = 0; u < 13; ++u) { const int c = cb + c0 + 4 * u; W[c >> 4][r][c & 15] = live ? v[u] : 0.0; }
+      for (int u = 0; u < 13; ++u) { const int c = cb + c0 + 4 * u; W[c >> 4][r][c & 15] = (live || ident) ? v[u] : 0.0; }
     }
   }
   // (2) inverses of the unit lower 16 x 16 diagonal blocks of L11.  The blocks go to LDS first (one request per thread
   // and block: a chain of 120 global loads per inverse was most of this kernel); then lane c < 16 of wave (jb mod 4) owns
   // column c of inv(L_jj): X[i][c] = delta_ic - sum_{k < i} L[i][k] X[k][c], the entries of L broadcast from LDS
-  for (int jb = 0; jb < ntb; ++jb) {
+  for (int jb = 0; jb < LDLR_NT; ++jb) {
     const int i = tid & 15, k = tid >> 4;
     Li[jb][i][k] = A[(size_t)(J0 + 16 * jb + i) + (size_t)(J0 + 16 * jb + k) * lda];
   }
   __syncthreads();
-  for (int jb = wv; jb < ntb; jb += 4) {
+  for (int jb = wv; jb < LDLR_NT; jb += 4) {
     double x[16];
     if (lane < 16) {
 #pragma unroll
@@ -653,8 +661,20 @@ __global__ __launch_bounds__(256) void k_dn_trsm(int n, double* __restrict__ A, 
   }
 #undef PP_TRSM_LOAD
   __syncthreads();
-  // (4) L21 = W D^{-1}: coalesced column writes
-  {
+  // (4) identity rows: inv(L11)^T in both orientations;  rows of A21: L21 = W D^{-1}, coalesced column writes
+  if (ident) {
+    // W[.][r][c] = inv(L11)^T [i = R0 + r][c] = inv(L11)[c][i]; both orientations written with the fast index across the
+    // threads (scattered 8-byte stores made this kernel 140 us)
+    {
+      const int r = tid & 63, c0 = tid >> 6, i = R0 + r;
+      if (i < nb)
+        for (int c = c0; c < nb; c += 4) Zb[(size_t)i + (size_t)c * DNP] = W[c >> 4][r][c & 15];
+    }
+    if (tid < nb) {
+      const int c = tid;
+      for (int r = 0; r < 64 && R0 + r < nb; ++r) Zf[(size_t)c + (size_t)(R0 + r) * DNP] = W[c >> 4][r][c & 15];
+    }
+  } else {
     const int r = tid & 63, c0 = tid >> 6;
     if (R0 + r < m) {
       double* dst = A + (size_t)(J1 + R0 + r) + (size_t)J0 * lda;
@@ -662,6 +682,130 @@ __global__ __launch_bounds__(256) void k_dn_trsm(int n, double* __restrict__ A, 
       for (int c = c0; c < DNP; c += 4) dst[(size_t)c * lda] = W[c >> 4][r][c & 15] / dvec[J0 + c];
     }
   }
+}
+
+// Coupling solve with the fat-panel factor (n > 512, accepted unpivoted factorisation): x = L^-T D^-1 L^-1 b panel by panel
+// with the inverted diagonal blocks of k_dn_trsm -- every step a matrix-vector product across the chip instead of a
+// triangular solve in one workgroup (one workgroup for the whole 1000 x 1000 factor: 0.26 ms).
+//   k_dn_fwd   every workgroup forms y_p = inv(L_pp) b_p (redundantly: 208 x 208) and subtracts L[r, p] y_p from its 256
+//              rows below the panel; workgroup 0 stores y_p.  first: b = r_c + r_s is read instead of the work vector.
+//   k_dn_bwdA  partial sums of L[rows, p]^T x over 64-row chunks (fixed layout: deterministic)
+//   k_dn_bwdB  x_p = inv(L_pp)^T (y_p / d - sum of the partials)
+// The nb x nb unit lower diagonal block of the last panel, padded with the identity to 208 x 208 (leading dimension 208)
+__global__ __launch_bounds__(256) void k_dn_pad(int n, const double* __restrict__ A, int J0, int nb, double* __restrict__ P) {
+  const size_t lda = (size_t)n;
+  for (int idx = (int)blockIdx.x * 256 + threadIdx.x; idx < DNP * DNP; idx += (int)gridDim.x * 256) {
+    const int i = idx % DNP, k = idx / DNP;
+    P[idx] = (i < nb && k < nb) ? ((i > k) ? A[(size_t)(J0 + i) + (size_t)(J0 + k) * lda] : (i == k ? 1.0 : 0.0)) : (i == k ? 1.0 : 0.0);
+  }
+}
+
+constexpr int DNS_THREADS = 4 * DNP;      // 832 = 13 waves: 208 outputs x 4 slices of the 208 terms (52 requests per thread, one round trip)
+constexpr int DNS_Q = DNP / 4;
+
+__global__ __launch_bounds__(DNS_THREADS) void k_dn_fwd(int n, const double* __restrict__ A, const double* __restrict__ Zf, int J0, int nb,
+                                                        const double* __restrict__ rc, const double* __restrict__ rs, int first,
+                                                        double* __restrict__ b, double* __restrict__ y, const int* __restrict__ mode) {
+  __shared__ double bp[DNP], yp[DNP], red[4][DNP];
+  if (mode[0] != 1) return;
+  const int tid = threadIdx.x, i = tid % DNP, q = tid / DNP;
+  const size_t lda = (size_t)n;
+  const int J1 = J0 + nb;
+  if (tid < DNP) bp[tid] = tid < nb ? (first ? ((rc ? rc[J0 + tid] : 0.0) + rs[J0 + tid]) : b[J0 + tid]) : 0.0;
+  __syncthreads();
+  {
+    // y_p = inv(L_pp) b_p: thread (i, q) takes the terms k = 52 q .. 52 q + 51 of row i (entries beyond nb are not defined)
+    const double* Zr = Zf + min(i, nb - 1);
+    double z[DNS_Q];
+#pragma unroll
+    for (int u = 0; u < DNS_Q; ++u) z[u] = Zr[(size_t)min(DNS_Q * q + u, nb - 1) * DNP];
+    double sum = 0.0;
+#pragma unroll
+    for (int u = 0; u < DNS_Q; ++u) sum += z[u] * bp[DNS_Q * q + u];          // (bp is zero beyond nb; no select: it would become a branch per term)
+    red[q][i] = sum;
+  }
+  __syncthreads();
+  if (tid < DNP) {
+    const double v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    yp[tid] = tid < nb ? v : 0.0;
+    if (blockIdx.x == 0 && tid < nb) y[J0 + tid] = v;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) return;
+  // rows below the panel: 208 per workgroup, the 208 terms of a row in 4 slices
+  const int r = J1 + ((int)blockIdx.x - 1) * DNP + i;
+  const bool live = r < n;
+  {
+    const double* Lr = A + (size_t)(live ? r : J1) + (size_t)J0 * lda;
+    double l[DNS_Q];
+#pragma unroll
+    for (int u = 0; u < DNS_Q; ++u) l[u] = Lr[(size_t)min(DNS_Q * q + u, nb - 1) * lda];
+    double sum = 0.0;
+#pragma unroll
+    for (int u = 0; u < DNS_Q; ++u) sum += l[u] * yp[DNS_Q * q + u];          // (yp is zero beyond nb)
+    red[q][i] = sum;
+  }
+  __syncthreads();
+  if (tid < DNP && live) {
+    const double acc = first ? ((rc ? rc[r] : 0.0) + rs[r]) : b[r];
+    b[r] = acc - ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
+  }
+}
+
+__global__ __launch_bounds__(DNS_THREADS) void k_dn_bwdA(int n, const double* __restrict__ A, int J0, int nb, const double* __restrict__ x,
+                                                         double* __restrict__ part, const int* __restrict__ mode) {
+  __shared__ double xr[64], red[4][DNP];
+  if (mode[0] != 1) return;
+  const int tid = threadIdx.x, k = tid % DNP, q = tid / DNP;
+  const size_t lda = (size_t)n;
+  const int r0 = J0 + nb + (int)blockIdx.x * 64, nr = min(64, n - r0);
+  if (tid < 64) xr[tid] = tid < nr ? x[r0 + tid] : 0.0;
+  __syncthreads();
+  {
+    const double* Lc = A + (size_t)r0 + (size_t)(J0 + min(k, nb - 1)) * lda;
+    double l[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) l[u] = Lc[min(16 * q + u, nr - 1)];
+    double sum = 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) sum += l[u] * xr[16 * q + u];                 // (xr is zero beyond nr)
+    red[q][k] = sum;
+  }
+  __syncthreads();
+  if (tid < nb) part[(size_t)blockIdx.x * DNP + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+__global__ __launch_bounds__(DNS_THREADS) void k_dn_bwdB(int n, const double* __restrict__ Zb, const double* __restrict__ dvec, int J0, int nb,
+                                                         int nchunk, const double* __restrict__ y, const double* __restrict__ part,
+                                                         double* __restrict__ x, const int* __restrict__ mode) {
+  __shared__ double vp[DNP], red[4][DNP];
+  if (mode[0] != 1) return;
+  const int tid = threadIdx.x, i = tid % DNP, q = tid / DNP;
+  if (tid < DNP) {
+    double t = 0.0;
+    if (tid < nb) {
+      double pv[16];
+#pragma unroll
+      for (int g = 0; g < 16; ++g) pv[g] = g < nchunk ? part[(size_t)g * DNP + tid] : 0.0;       // (at most 13 chunks of 64 rows below a panel)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) t += pv[g];
+    }
+    vp[tid] = tid < nb ? y[J0 + tid] / dvec[J0 + tid] - t : 0.0;
+  }
+  __syncthreads();
+  {
+    // x_i = sum_k inv(L_pp)[k][i] v_k (k >= i; the entries with k < i are exact zeros)
+    const double* Zr = Zb + min(i, nb - 1);
+    double z[DNS_Q];
+#pragma unroll
+    for (int u = 0; u < DNS_Q; ++u) z[u] = Zr[(size_t)min(DNS_Q * q + u, nb - 1) * DNP];
+    double sum = 0.0;
+#pragma unroll
+    for (int u = 0; u < DNS_Q; ++u) sum += z[u] * vp[DNS_Q * q + u];          // (vp is zero beyond nb)
+    red[q][i] = sum;
+  }
+  __syncthreads();
+  if (tid < nb) x[J0 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
 
 __global__ __launch_bounds__(DN_THREADS) void k_dn_update(int n, double* __restrict__ A, const double* __restrict__ dvec, int J0,
@@ -899,10 +1043,11 @@ __global__ __launch_bounds__(BK_THREADS) void k_bk_factor(int n, const double* _
 template <int THREADS, int NBS>
 __global__ __launch_bounds__(THREADS) void k_coupling_solve(int n, const double* Abk, const int* ipiv,
                                                             const double* Aldl, const double* dvec, const int* mode,
-                                                            const double* rc, const double* rs, double* xc) {
+                                                            const double* rc, const double* rs, double* xc, int ldl_done = 0) {
   extern __shared__ __attribute__((aligned(16))) double xs[];
   __shared__ double sv[16];
   __shared__ int si[16];
+  if (mode[0] == 1 && ldl_done) return;         // (solved by the panel kernels, k_dn_fwd / k_dn_bwd)
   if (mode[0] == 1) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) xs[i] = (rc ? rc[i] : 0.0) + rs[i];
     __syncthreads();
@@ -917,6 +1062,12 @@ __global__ __launch_bounds__(THREADS) void k_coupling_solve(int n, const double*
   pp::bk_solve(ctx, n, Abk, n, ipiv, xc);
 }
 
+
+// layout of pp_solver::dn_z: [Zf | Zb] per panel, work vectors b and y (n each), partial sums (16 x 208), padded block
+size_t dn_pad_offset(int nc) {
+  const size_t np = (size_t)(nc + DNP - 1) / DNP;
+  return 2 * np * DNP * DNP + 2 * (size_t)nc + 16 * DNP;
+}
 
 }  // namespace
 
@@ -986,6 +1137,13 @@ int ppi_dense_factor_schur(pp_handle h, const double* Q_host) {
           }
         } else {
           const size_t trsm_lds = ((size_t)LDLR_NT * 64 * DNT_LD + (size_t)LDLR_NT * 16 * 17) * sizeof(double);
+          if (!h->dn_z) {       // inverted diagonal blocks (two orientations per panel) + work vectors of the panel solve
+            const size_t np = (size_t)(nc + DNP - 1) / DNP;
+            void* zp = nullptr;
+            if (hipMalloc(&zp, (dn_pad_offset(nc) + (size_t)DNP * DNP) * sizeof(double)) != hipSuccess)
+              return fail(h, 1, "hipMalloc failed (dense panel inverses)");
+            h->dn_z = (double*)zp;
+          }
           if (!h->dn_lds_attr) {
             PP_HIP(hipFuncSetAttribute((const void*)k_dn_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)trsm_lds));
             h->dn_lds_attr = true;
@@ -997,8 +1155,19 @@ int ppi_dense_factor_schur(pp_handle h, const double* Q_host) {
                                                  h->dvec + j0, (int*)nullptr, (int*)nullptr, BK_EPS, nc, anorm, flags);
             else hipLaunchKernelGGL((k_ldl_regs<false, true>), dim3(1), dim3(LDL_THREADS), 0, st, nb, blk, (const double*)nullptr, blk,
                                     h->dvec + j0, (int*)nullptr, (int*)nullptr, BK_EPS, nc, anorm, flags);
+            // (the workgroups behind the row blocks of A21 invert the diagonal block for the coupling solve; a last panel
+            // narrower than 208 columns from its identity-padded copy)
+            double* Zf = h->dn_z + (size_t)2 * (j0 / DNP) * DNP * DNP;
+            if (nb == DNP) {
+              hipLaunchKernelGGL(k_dn_trsm, dim3((m + 63) / 64 + (DNP + 63) / 64), dim3(256), trsm_lds, st, nc, h->Sldl, h->dvec, j0, nb,
+                                 (m + 63) / 64, Zf, Zf + (size_t)DNP * DNP);
+            } else {
+              double* pad = h->dn_z + dn_pad_offset(nc);
+              hipLaunchKernelGGL(k_dn_pad, dim3(32), dim3(256), 0, st, nc, h->Sldl, j0, nb, pad);
+              hipLaunchKernelGGL(k_dn_trsm, dim3((DNP + 63) / 64), dim3(256), trsm_lds, st, DNP, pad, h->dvec, 0, DNP, 0, Zf,
+                                 Zf + (size_t)DNP * DNP);
+            }
             if (m > 0) {
-              hipLaunchKernelGGL(k_dn_trsm, dim3((m + 63) / 64), dim3(256), trsm_lds, st, nc, h->Sldl, h->dvec, j0, nb);
               const int nt = (m + 15) / 16, ntiles = nt * (nt + 1) / 2, per = DN_THREADS / 64;
               hipLaunchKernelGGL(k_dn_update, dim3((ntiles + per - 1) / per), dim3(DN_THREADS), 0, st, nc, h->Sldl, h->dvec, j0, nb);
             }
@@ -1023,10 +1192,31 @@ int ppi_dense_coupling_solve(pp_handle h, const double* rc_dev) {
   if (int rc = join_dense(h)) return rc;
   hipStream_t st = h->stream;
   const int nc = h->nc;
-  PhaseScope ps(h, 6, 1);
+  static const bool panel32 = std::getenv("PP_DENSE_PANEL32") != nullptr;
+  const bool panels = nc > 512 && h->dn_z && h->dense_policy == 0 && !panel32;
+  PhaseScope ps(h, 6, panels ? 15 : 1);
+  if (panels) {
+    // accepted unpivoted factor (decided on the device: the kernels leave at once otherwise and k_coupling_solve does the
+    // Bunch-Kaufman solve): forward and backward substitution over the 208-column panels, matrix-vector products only
+    const int np = (nc + DNP - 1) / DNP;
+    double* b = h->dn_z + (size_t)2 * np * DNP * DNP;
+    double* y = b + nc;
+    double* part = y + nc;
+    for (int p = 0; p < np; ++p) {
+      const int j0 = p * DNP, nb = std::min(DNP, nc - j0), m = nc - j0 - nb;
+      hipLaunchKernelGGL(k_dn_fwd, dim3(1 + (m + DNP - 1) / DNP), dim3(DNS_THREADS), 0, st, nc, h->Sldl, h->dn_z + (size_t)2 * p * DNP * DNP, j0, nb,
+                         rc_dev, h->rs, p == 0 ? 1 : 0, b, y, h->dense_mode);
+    }
+    for (int p = np - 1; p >= 0; --p) {
+      const int j0 = p * DNP, nb = std::min(DNP, nc - j0), m = nc - j0 - nb, nch = (m + 63) / 64;
+      if (nch > 0) hipLaunchKernelGGL(k_dn_bwdA, dim3(nch), dim3(DNS_THREADS), 0, st, nc, h->Sldl, j0, nb, h->xc, part, h->dense_mode);
+      hipLaunchKernelGGL(k_dn_bwdB, dim3(1), dim3(DNS_THREADS), 0, st, nc, h->dn_z + (size_t)(2 * p + 1) * DNP * DNP, h->dvec, j0, nb, nch, y, part,
+                         h->xc, h->dense_mode);
+    }
+  }
   if (nc > BK_THREADS && nc <= 1024)
     hipLaunchKernelGGL((k_coupling_solve<1024, 16>), dim3(1), dim3(1024), (size_t)nc * sizeof(double), st, nc, h->Sfac,
-                       h->ipiv, h->Sldl, h->dvec, h->dense_mode, rc_dev, h->rs, h->xc);
+                       h->ipiv, h->Sldl, h->dvec, h->dense_mode, rc_dev, h->rs, h->xc, panels ? 1 : 0);
   else
     hipLaunchKernelGGL((k_coupling_solve<BK_THREADS, 32>), dim3(1), dim3(BK_THREADS), (size_t)nc * sizeof(double), st, nc,
                        h->Sfac, h->ipiv, h->Sldl, h->dvec, h->dense_mode, rc_dev, h->rs, h->xc);
