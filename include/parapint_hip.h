@@ -371,8 +371,10 @@ int pp_vec_axpy(pp_handle h, int64_t n, double alpha, const double* x, double* y
  *           src_ds .. + mi receive the barrier diagonals, the Hessian / Jacobian values are read from it
  *   G       [n][bpad] work rows: grad f + J^T y at the current iterate
  *   rhs     right-hand side [nb][bpad]; delta: the solution of the KKT system [nb][bpad] (pp_bind_native_vectors)
- *   prog    n + me + mi + nfs row programs {t0, tH, t1, -} for the rows grad_x L, A_eq x - b, A_ineq x - s, x_fs - z:
- *           terms [t0, t1) as pairs {source row or -1 (the constant 1), row of W}, the Hessian terms [t0, tH) first
+ *   prog    n + me + mi + nfs row programs {t0, tH, t1, o} for the rows grad_x L, A_eq x - b, A_ineq x - s, x_fs - z:
+ *           terms [t0, t1) as pairs {source row or -1 (the constant 1), row of W}, the Hessian terms [t0, tH) first; o: the
+ *           order of execution -- slot s works on row prog[4 s + 3] (a permutation; rows that share source entries close
+ *           together keep the second read of an entry in the L2)
  * All arrays are [rows][bpad] doubles on the handle's device, bpad a multiple of 64, instances >= batch are padding
  * (they hold a copy of a real scenario without bounds and are left alone).  At most 8 groups.
  *   pp_ip_rhs           rows x and s of rhs from G, the iterate and the barrier parameter mu (the other rows are written by

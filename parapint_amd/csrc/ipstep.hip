@@ -188,8 +188,12 @@ __global__ __launch_bounds__(256) void k_ip_rows(pp_ip_group g, const double* __
   const double* __restrict__ S = g.src + b;
   double v[IP_ROWS_SLOTS] = {0.0, 0.0, 0.0};
   for (int q = 0; q < rpw; ++q) {
-    const int p = (tile * 4 + wave) * rpw + q;            // (wave-uniform)
-    if (p >= nprog) break;
+    const int slot = (tile * 4 + wave) * rpw + q;         // (wave-uniform)
+    if (slot >= nprog) break;
+    // rows are worked on in the producer's order (prog[4 slot + 3]): rows that read the same Jacobian entries -- a
+    // constraint row and the gradient rows of its variables -- sit next to each other, so the second read of an entry
+    // meets the L2 instead of HBM
+    const int p = g.prog[4 * slot + 3];
     const int t0 = g.prog[4 * p], tH = g.prog[4 * p + 1], t1 = g.prog[4 * p + 2];
     double accH = 0.0, acc = 0.0;
     int t = t0;

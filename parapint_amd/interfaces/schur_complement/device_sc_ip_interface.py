@@ -121,7 +121,21 @@ class _PatternGroup(object):
         t0 = np.searchsorted(prow, np.arange(nprog), side='left')
         t1 = np.searchsorted(prow, np.arange(nprog), side='right')
         nH = np.bincount(prow[cls == 0], minlength=nprog)[:nprog]
-        prog = np.stack([t0, t0 + nH, t1, np.zeros(nprog, dtype=np.int64)], axis=1).astype(np.int32)
+        # execution order: rows that read the same source entries next to each other (a Jacobian entry is read by its
+        # constraint row and by the gradient row of its variable: reverse Cuthill-McKee on that graph)
+        from scipy.sparse import coo_matrix
+        from scipy.sparse.csgraph import reverse_cuthill_mckee
+        shared = src >= 0
+        by_src = np.argsort(src[shared], kind='stable')
+        ps, ss = prow[shared][by_src], src[shared][by_src]
+        pair = np.flatnonzero(ss[1:] == ss[:-1])
+        if pair.size:
+            a, b = ps[pair], ps[pair + 1]
+            G = coo_matrix((np.ones(2 * a.size), (np.concatenate([a, b]), np.concatenate([b, a]))), shape=(nprog, nprog)).tocsr()
+            order = np.asarray(reverse_cuthill_mckee(G, symmetric_mode=True), dtype=np.int64)
+        else:
+            order = np.arange(nprog)
+        prog = np.stack([t0, t0 + nH, t1, order], axis=1).astype(np.int32)
         terms = np.stack([src, wrow], axis=1).astype(np.int32)
         return prog, terms
 

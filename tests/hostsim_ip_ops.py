@@ -165,6 +165,7 @@ class HostSimIpOps(object):
                 prog, terms = np.asarray(d['prog']), np.asarray(d['terms'])
                 nprog = n + me + mi + nfs
                 t0, tH, t1 = prog[:nprog, 0].astype(np.int64), prog[:nprog, 1].astype(np.int64), prog[:nprog, 2].astype(np.int64)
+                assert np.array_equal(np.sort(prog[:nprog, 3]), np.arange(nprog))      # the execution order is a permutation
                 bp = W.shape[1]
                 accH, acc = np.zeros((nprog, bp)), np.zeros((nprog, bp))
                 for j in range(int((t1 - t0).max()) if nprog else 0):

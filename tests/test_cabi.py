@@ -39,7 +39,9 @@ def test_product_package_does_not_import_the_oracle():
     import subprocess
     import sys
     code = ("import sys; sys.path.insert(0, %r); import parapint_amd.linalg.hip_schur_complement, "
-            "parapint_amd._native, parapint_amd.examples.performance.schur_complement.synthetic_kkt; "
+            "parapint_amd._native, parapint_amd.examples.performance.schur_complement.synthetic_kkt, parapint_amd.linalg.hip_engine, "
+            "parapint_amd.linalg.device_ip_ops, parapint_amd.interfaces.schur_complement.device_sc_ip_interface, "
+            "parapint_amd.algorithms.device_interior_point, parapint_amd.examples.stochastic_qp; "
             "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules), 'oracle imported'" % ROOT)
     subprocess.check_call([sys.executable, '-c', code])
 
