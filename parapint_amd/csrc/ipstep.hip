@@ -173,17 +173,19 @@ __global__ __launch_bounds__(256) void k_ip_step(pp_ip_group g, const double* __
 // ---- the rows that need the scenario data: grad_x L = c + H x + A_eq^T y_eq + A_ineq^T y_ineq + L^T y_link, A_eq x - b,
 // A_ineq x - s, x_fs - z.  One row x 64 instances per wave and step, IP_RPW rows per wave; the terms of a row are
 // wave-uniform {source row, row of W} pairs, requested four at a time.
+// NV instances per lane (2 where the padded batch is a multiple of 128: every operand is one 16-byte load per lane, and
+// the scalar record reads, address arithmetic and branches of a row are spent once for 128 instances).
+template <int NV>
 __global__ __launch_bounds__(256) void k_ip_rows(pp_ip_group g, const double* __restrict__ z, double* __restrict__ part, int wg0,
                                                  int nwg, int rpw) {
   __shared__ double red[IP_ROWS_SLOTS][256];
   const size_t bpad = (size_t)g.bpad;
-  const int nchunk = g.bpad >> 6;
+  const int nchunk = g.bpad / (64 * NV);
   const int chunk = blockIdx.x % nchunk, tile = blockIdx.x / nchunk;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int b = chunk * 64 + lane;
+  const int b = (chunk * 64 + lane) * NV;
   const int nprog = g.n + g.me + g.mi + g.nfs;
   const int nb = ip_nb(g);
-  const bool live = b < g.batch;
   const double* __restrict__ W = g.W + b;
   const double* __restrict__ S = g.src + b;
   double v[IP_ROWS_SLOTS] = {0.0, 0.0, 0.0};
@@ -195,45 +197,77 @@ __global__ __launch_bounds__(256) void k_ip_rows(pp_ip_group g, const double* __
     // meets the L2 instead of HBM
     const int p = g.prog[4 * slot + 3];
     const int t0 = g.prog[4 * p], tH = g.prog[4 * p + 1], t1 = g.prog[4 * p + 2];
-    double accH = 0.0, acc = 0.0;
+    // what the row needs besides its terms is requested first (it does not depend on them)
+    const bool primal = p < g.n;
+    int erow = 0;             // row of the subtrahend: c (primal) / b_eq / s; link rows subtract z[k]
+    const double* ebase = g.data + b;
+    size_t orow;
+    if (primal) { erow = p; orow = 0; }
+    else if (p < g.n + g.me) { erow = g.n + (p - g.n); orow = (size_t)(g.n + g.mi + (p - g.n)); }
+    else if (p < g.n + g.me + g.mi) { erow = g.n + (p - g.n - g.me); ebase = W; orow = (size_t)(g.n + g.mi + g.me + (p - g.n - g.me)); }
+    else { erow = -1; orow = (size_t)(g.n + 2 * g.mi + g.me + (p - g.n - g.me - g.mi)); }
+    double ev[NV], zl[NV], zu[NV], xp[NV];
+    if (erow >= 0) ldv<NV>(ebase + (size_t)erow * bpad, ev);
+    else { const double zk = z[p - g.n - g.me - g.mi];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) ev[i] = zk; }
+    if (primal) {
+      ldv<NV>(W + (size_t)(nb + p) * bpad, zl);
+      ldv<NV>(W + (size_t)(nb + g.n + p) * bpad, zu);
+      ldv<NV>(W + (size_t)p * bpad, xp);
+    }
+    double accH[NV], acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { accH[i] = 0.0; acc[i] = 0.0; }
     int t = t0;
     for (; t + 4 <= t1; t += 4) {
       int s[4], w[4];
-      double a[4], c[4];
+      double a[4][NV], c[4][NV];
 #pragma unroll
       for (int k = 0; k < 4; ++k) { s[k] = g.terms[2 * (t + k)]; w[k] = g.terms[2 * (t + k) + 1]; }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { c[k] = W[(size_t)w[k] * bpad]; a[k] = S[(size_t)(s[k] < 0 ? 0 : s[k]) * bpad]; }
+      for (int k = 0; k < 4; ++k) { ldv<NV>(W + (size_t)w[k] * bpad, c[k]); ldv<NV>(S + (size_t)(s[k] < 0 ? 0 : s[k]) * bpad, a[k]); }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const double term = s[k] < 0 ? c[k] : a[k] * c[k];
-        if (t + k < tH) accH = accH + term; else acc = acc + term;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const double term = s[k] < 0 ? c[k][i] : a[k][i] * c[k][i];
+          if (t + k < tH) accH[i] = accH[i] + term; else acc[i] = acc[i] + term;
+        }
       }
     }
     for (; t < t1; ++t) {
-      const int s = g.terms[2 * t], w = g.terms[2 * t + 1];
-      const double c = W[(size_t)w * bpad];
-      const double term = s < 0 ? c : S[(size_t)s * bpad] * c;
-      if (t < tH) accH = accH + term; else acc = acc + term;
-    }
-    if (p < g.n) {
-      const double cj = g.data[(size_t)p * bpad + b];
-      const double gH = cj + accH;                  // gradient of the objective (interior_point.py:192)
-      const double G = gH + acc;
-      g.G[(size_t)p * bpad + b] = G;
-      const double zl = W[(size_t)(nb + p) * bpad], zu = W[(size_t)(nb + g.n + p) * bpad];
-      if (live) {
-        v[1] = nmax(v[1], fabs((G - zl) + zu));
-        v[2] = v[2] + W[(size_t)p * bpad] * (0.5 * accH + cj);      // 1/2 x'Hx + c'x
+      const int s1 = g.terms[2 * t], w1 = g.terms[2 * t + 1];
+      double c[NV], a[NV];
+      ldv<NV>(W + (size_t)w1 * bpad, c);
+      ldv<NV>(S + (size_t)(s1 < 0 ? 0 : s1) * bpad, a);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const double term = s1 < 0 ? c[i] : a[i] * c[i];
+        if (t < tH) accH[i] = accH[i] + term; else acc[i] = acc[i] + term;
       }
+    }
+    if (primal) {
+      double G[NV];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const double gH = ev[i] + accH[i];                  // gradient of the objective (interior_point.py:192)
+        G[i] = gH + acc[i];
+        if (b + i < g.batch) {
+          v[1] = nmax(v[1], fabs((G[i] - zl[i]) + zu[i]));
+          v[2] = v[2] + xp[i] * (0.5 * accH[i] + ev[i]);      // 1/2 x'Hx + c'x
+        }
+      }
+      stv<NV>(g.G + (size_t)p * bpad + b, G);
     } else {
-      double res;
-      size_t row;
-      if (p < g.n + g.me) { const int i = p - g.n; res = acc - g.data[(size_t)(g.n + i) * bpad + b]; row = g.n + g.mi + i; }
-      else if (p < g.n + g.me + g.mi) { const int i = p - g.n - g.me; res = acc - W[(size_t)(g.n + i) * bpad]; row = g.n + g.mi + g.me + i; }
-      else { const int k = p - g.n - g.me - g.mi; res = acc - z[k]; row = g.n + 2 * g.mi + g.me + k; }
-      g.rhs[row * bpad + b] = -res;
-      if (live) v[0] = nmax(v[0], fabs(res));
+      double out[NV];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const double res = acc[i] - ev[i];
+        out[i] = -res;
+        if (b + i < g.batch) v[0] = nmax(v[0], fabs(res));
+      }
+      stv<NV>(g.rhs + orow * bpad + b, out);
     }
   }
   const int op[IP_ROWS_SLOTS] = {1, 1, 2};
@@ -332,13 +366,14 @@ int ip_scratch(pp_handle h, size_t doubles) {
 unsigned ew_grid(const pp_ip_group& g, int rows) {
   return (unsigned)std::min<size_t>(IP_EW_MAXWG, ((size_t)rows * g.bpad + 255) / 256);
 }
+int rows_nv(const pp_ip_group& g) { return (g.bpad % 128 == 0) ? 2 : 1; }      // instances per lane of k_ip_rows
 int rows_rpw(const pp_ip_group& g) {       // rows per wave of k_ip_rows
-  const size_t nprog = (size_t)(g.n + g.me + g.mi + g.nfs), nchunk = (size_t)(g.bpad >> 6);
+  const size_t nprog = (size_t)(g.n + g.me + g.mi + g.nfs), nchunk = (size_t)(g.bpad / (64 * rows_nv(g)));
   return (int)std::max<size_t>(IP_RPW, (nprog * nchunk + 4 * IP_ROWS_MAXWG - 1) / (4 * IP_ROWS_MAXWG));
 }
 unsigned rows_grid(const pp_ip_group& g) {
   const int nprog = g.n + g.me + g.mi + g.nfs, rpw = rows_rpw(g);
-  return (unsigned)((nprog + 4 * rpw - 1) / (4 * rpw)) * (unsigned)(g.bpad >> 6);
+  return (unsigned)((nprog + 4 * rpw - 1) / (4 * rpw)) * (unsigned)(g.bpad / (64 * rows_nv(g)));
 }
 
 // Workgroups of the three reducing kernels over these groups, and the scratch they share: the partials of k_ip_step
@@ -425,7 +460,8 @@ int pp_ip_residuals(pp_handle h, int ngroups, const pp_ip_group* g, const double
   L.ng = ngroups; L.nfs = g[0].nfs;
   for (int i = 0; i < ngroups; ++i) {
     const unsigned n = rows_grid(g[i]);
-    if (n) hipLaunchKernelGGL(k_ip_rows, dim3(n), dim3(256), 0, h->stream, g[i], z, part_rows, (int)wg0, (int)nwg_r, rows_rpw(g[i]));
+    if (n && rows_nv(g[i]) == 2) hipLaunchKernelGGL(k_ip_rows<2>, dim3(n), dim3(256), 0, h->stream, g[i], z, part_rows, (int)wg0, (int)nwg_r, rows_rpw(g[i]));
+    else if (n) hipLaunchKernelGGL(k_ip_rows<1>, dim3(n), dim3(256), 0, h->stream, g[i], z, part_rows, (int)wg0, (int)nwg_r, rows_rpw(g[i]));
     wg0 += n;
     L.ylink[i] = g[i].W + (size_t)(g[i].n + 2 * g[i].mi + g[i].me) * g[i].bpad;
     L.batch[i] = g[i].batch; L.bpad[i] = g[i].bpad;
