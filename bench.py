@@ -531,7 +531,42 @@ def main():
             del ipi, ipo, sv
         ip_loop = best
         ok = ok and ip_loop['converged']
-        del qps
+        # where an iteration goes (a third, untimed run with the library's phase events on: no dense / forward overlap while
+        # they are) and the step kernels against the HBM roof: algorithmic bytes = every array a kernel has to read or write
+        # once, x instances of this rank
+        ipi = DeviceStochasticQPInterface(qps, fsi, comm=comm)
+        ipo = IPOptions()
+        ipo.linalg.solver = HipSchurComplementLinearSolver({i: None for i in mine}, None, comm=comm, result_buffers=2)
+        slib, sh = ipo.linalg.solver._eng.lib, ipo.linalg.solver._eng.ns.h
+        slib.pp_profile(sh, 1)
+        _, prof_iters = ip_solve_device(ipi, ipo)
+        sync_all()
+        ms8, l8, c8 = np.zeros(8), np.zeros(8, dtype=np.int32), np.zeros(8, dtype=np.int32)
+        ms4, l4, c4 = np.zeros(4), np.zeros(4, dtype=np.int32), np.zeros(4, dtype=np.int32)
+        dp, ip32 = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)
+        slib.pp_phase_times(sh, ms8.ctypes.data_as(dp), l8.ctypes.data_as(ip32), c8.ctypes.data_as(ip32))
+        slib.pp_ip_phase_times(sh, ms4.ctypes.data_as(dp), l4.ctypes.data_as(ip32), c4.ctypes.data_as(ip32))
+        slib.pp_profile(sh, 0)
+        rows = {'rhs': 0.0, 'step_lengths': 0.0, 'take_step': 0.0, 'residuals': 0.0}
+        for gs in ipi.states:
+            pg = gs.pg
+            nv, ny = pg.n + pg.mi, pg.me + pg.nfs
+            rows['rhs'] += gs.B * 5.0 * nv
+            rows['step_lengths'] += gs.B * 6.0 * nv
+            rows['take_step'] += gs.B * (10.0 * nv + 3.0 * pg.mi + 3.0 * ny)
+            rows['residuals'] += gs.B * (pg.nnzH + 2.0 * (pg.nnzAe + pg.nnzAi) + (pg.n + pg.me + 2 * pg.mi + pg.nfs)
+                                         + (pg.n + pg.me) + 3.0 * pg.n + pg.n + (pg.me + pg.mi + pg.nfs))
+        step_kernels = {}
+        for i, name in enumerate(('rhs', 'step_lengths', 'take_step', 'residuals')):
+            if c4[i] > 0 and ms4[i] > 0:
+                t_ms = float(ms4[i]) / int(c4[i])
+                gbps = 8.0 * rows[name] / (t_ms * 1e-3) / 1e9
+                step_kernels[name] = {'ms': t_ms, 'algorithmic_MB': 8.0 * rows[name] / 1e6, 'GBps': gbps, 'frac_of_hbm_peak': gbps / HBM_PEAK_GBS}
+        ip_loop['step_kernels'] = step_kernels
+        ip_loop['step_kernels_ms_per_iteration'] = float(sum(v['ms'] for v in step_kernels.values()))
+        ip_loop['solver_kernels_ms_per_iteration'] = float(ms8.sum()) / max(int(c8[1]), 1)
+        ip_loop['profiled_run'] = {'iterations': prof_iters, 'numeric_factorizations': int(c8[1]), 'back_solves': int(c8[7])}
+        del ipi, ipo, qps
 
     if rank == 0:
         launches = sum(p['launches_per_step'] for p in phases.values()) if phases else None

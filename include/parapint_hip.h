@@ -413,6 +413,9 @@ int pp_ip_take_step(pp_handle h, int ngroups, const pp_ip_group* groups, const d
 int pp_ip_residuals(pp_handle h, int ngroups, const pp_ip_group* groups, const double* z, double* v_local);
 int pp_ip_publish(pp_handle h, const double* v_table, const double* alpha_table, int nranks, int nfs, double* rhs_coupling);
 int pp_ip_wait(pp_handle h, double out[10]);
+/* With pp_profile(h, 1): accumulated device time (HIP events on the handle's stream), launches and calls of {pp_ip_rhs,
+ * pp_ip_step_lengths, pp_ip_take_step, pp_ip_residuals}. */
+int pp_ip_phase_times(pp_handle h, double ms_out[4], int32_t launches_out[4], int32_t calls_out[4]);
 
 /* Pivot tolerances (MA27 cntl(1), ma27_interface.py:36-47; examples/stochastic.py:120-124 uses 1e-6).
  *   u_symbolic  threshold of the static pivot choice at symbolic time: a 1x1 pivot is taken only if

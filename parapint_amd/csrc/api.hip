@@ -783,9 +783,22 @@ int pp_phase_times(pp_handle h, double ms_out[8], int32_t launches_out[8], int32
       if (hipEventElapsedTime(&ms, h->ev[i][0], h->ev[i][1]) == hipSuccess) h->phase_ms[i] += ms;
       h->ev_used[i] = false;
     }
+    if (i >= PP_NPHASE_SOLVER) continue;
     ms_out[i] = h->phase_ms[i];
     launches_out[i] = h->phase_launches[i];
     calls_out[i] = h->phase_calls[i];
+  }
+  return 0;
+}
+
+int pp_ip_phase_times(pp_handle h, double ms_out[4], int32_t launches_out[4], int32_t calls_out[4]) {
+  if (!h) return 3;
+  double ms[8]; int32_t l8[8], c8[8];
+  if (int rc = pp_phase_times(h, ms, l8, c8)) return rc;       // (harvests all brackets)
+  for (int i = 0; i < 4; ++i) {
+    ms_out[i] = h->phase_ms[PP_NPHASE_SOLVER + i];
+    launches_out[i] = h->phase_launches[PP_NPHASE_SOLVER + i];
+    calls_out[i] = h->phase_calls[PP_NPHASE_SOLVER + i];
   }
   return 0;
 }

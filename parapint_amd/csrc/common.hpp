@@ -44,7 +44,8 @@ constexpr int PP_MT_WIDE_NC = 512;   // from this coupling dimension on the Schu
 constexpr int PP_MT_SLICE = 4;  // records (panel columns) of one 16 x 16 Schur tile per work item of k_schur_mfma
 constexpr int PP_CSLOTS = 64;  // the inertia / growth counters are kept in this many slots of 4 ints, summed by the tail writer
 constexpr int PP_TAIL = 8;    // doubles behind the n_c x n_c Schur block: zero pivots, pos, neg, host failures, growth, reserved
-constexpr int PP_NPHASE = 8;  // assemble, factor, schur, dense, fwd, fwd_coupling, coupling_solve, bwd
+constexpr int PP_NPHASE = 12;       // assemble, factor, schur, dense, fwd, fwd_coupling, coupling_solve, bwd (pp_phase_times) +
+constexpr int PP_NPHASE_SOLVER = 8; // the interior-point step: right-hand side, step lengths, step, residuals + scalars (pp_ip_phase_times)
 constexpr int BK_THREADS = 512;
 constexpr double PIVOT_EPS = 1e-13;
 constexpr double BK_EPS = 1e-14;

@@ -397,6 +397,7 @@ extern "C" {
 int pp_ip_rhs(pp_handle h, int ngroups, const pp_ip_group* g, double mu) {
   if (int rc = ip_check(h, ngroups, g, "pp_ip_rhs")) return rc;
   PP_HIP(hipSetDevice(h->device));
+  PhaseScope ps(h, PP_NPHASE_SOLVER + 0, ngroups);
   for (int i = 0; i < ngroups; ++i)
     if (g[i].n + g[i].mi > 0) hipLaunchKernelGGL(k_ip_rhs, dim3(ew_grid(g[i], g[i].n + g[i].mi)), dim3(256), 0, h->stream, g[i], mu);
   PP_HIP(hipGetLastError());
@@ -412,6 +413,7 @@ int pp_ip_step_lengths(pp_handle h, int ngroups, const pp_ip_group* g, double ta
   IpSizes sz;
   if (int rc = ip_sizes(h, ngroups, g, &sz)) return rc;
   const unsigned nwg = sz.nwg_stats;
+  PhaseScope ps(h, PP_NPHASE_SOLVER + 1, ngroups + 1);
   double* part = h->ip_part + (size_t)IP_STEP_SLOTS * sz.nwg_step + (size_t)IP_ROWS_SLOTS * sz.nwg_rows;
   unsigned wg0 = 0;
   for (int i = 0; i < ngroups; ++i) {
@@ -435,6 +437,7 @@ int pp_ip_take_step(pp_handle h, int ngroups, const pp_ip_group* g, const double
   if (int rc = ip_sizes(h, ngroups, g, &sz)) return rc;
   const unsigned nwg_s = sz.nwg_step;
   h->ip_step_done = true;
+  PhaseScope ps(h, PP_NPHASE_SOLVER + 2, ngroups);
   unsigned wg0 = 0;
   for (int i = 0; i < ngroups; ++i) {
     const unsigned n = ew_grid(g[i], g[i].n + g[i].mi + g[i].me + g[i].nfs);
@@ -454,6 +457,7 @@ int pp_ip_residuals(pp_handle h, int ngroups, const pp_ip_group* g, const double
   IpSizes sz;
   if (int rc = ip_sizes(h, ngroups, g, &sz)) return rc;
   const unsigned nwg_s = sz.nwg_step, nwg_r = sz.nwg_rows;
+  PhaseScope ps(h, PP_NPHASE_SOLVER + 3, ngroups + 1);
   double* part_rows = h->ip_part + (size_t)IP_STEP_SLOTS * nwg_s;
   unsigned wg0 = 0;
   IpLinks L;

@@ -100,7 +100,7 @@ class HipIpOps(object):
     # ---- between ranks
     def allgather(self, comm, local, table):
         """table[r] = local of rank r (device tensors).  One rank: the caller passes table = local."""
-        if comm.size == 1:
+        if comm.size == 1 and not getattr(comm, 'always_reduce', False):
             return
         if self.eng._direct_rccl(comm):
             self.ns.check(self.lib.pp_comm_allgather(self.ns.h, local.data_ptr(), table.data_ptr(),

@@ -73,6 +73,24 @@ def main():
     for ndx in range(N + 1):
         assert np.array_equal(np.asarray(x2.get_block(ndx)), np.asarray(x.get_block(ndx)))
     assert solver2.get_inertia() == solver.get_inertia()
+    # the interior-point loop with its two all-gathers issued by the library (pp_comm_allgather) on the one-rank group:
+    # same iterates as the loop without collectives
+    from parapint_amd.algorithms.device_interior_point import ip_solve_device
+    from parapint_amd.algorithms.interior_point import IPOptions, InteriorPointStatus
+    from parapint_amd.examples.stochastic_qp import random_stochastic_qp
+    from parapint_amd.interfaces.schur_complement.device_sc_ip_interface import DeviceStochasticQPInterface
+    qps, fs = random_stochastic_qp(70, seed=3)
+    runs = []
+    for c in (comm, SerialComm()):
+        it = DeviceStochasticQPInterface(qps, fs, comm=c)
+        opt = IPOptions()
+        opt.linalg.solver = HipSchurComplementLinearSolver({i: None for i in range(70)}, None, comm=c, result_buffers=2)
+        hist = []
+        status, iters = ip_solve_device(it, opt, history=hist)
+        assert status == InteriorPointStatus.optimal
+        runs.append((iters, it.first_stage_solution(), opt.linalg.solver))
+    assert runs[0][2]._eng.lib.pp_comm_size(runs[0][2]._eng.ns.h) == 1
+    assert runs[0][0] == runs[1][0] and np.array_equal(runs[0][1], runs[1][1])
     dist.barrier()
     dist.destroy_process_group()
     print('rccl one-rank ok')
