@@ -1404,9 +1404,17 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         return result
 
     def warm_device_results(self):
-        """Creates the result vectors of result_buffers > 0 now (set-up time) instead of in the first back-solve."""
+        """Creates the result vectors of result_buffers > 0 and the library's value storage (factor panels, work vectors:
+        0.85 GB at C3) now -- set-up time -- instead of in the first factorisation and back-solve."""
         if self._result_buffers > 0 and not self._dev_results:
             self._dev_results = [self.new_device_vector() for _ in range(self._result_buffers)]
+        if hasattr(self._eng, 'bind_native_vectors'):
+            try:
+                for g in self._groups:
+                    self._eng.bind_native_vectors(g.gid, None, None)       # (allocates: include/parapint_hip.h, pp_bind_native_vectors)
+            except Exception as err:
+                if getattr(err, 'status', None) is None:
+                    raise              # (over budget: the numeric factorisation reports it, the caller's reallocation loop acts)
 
     def prefetch_forward(self, rhs):
         """Opt-in for callers that know the right-hand side of the next back-solve before they factorise (an interior-point

@@ -579,7 +579,15 @@ def test_bench_line_reports_the_ip_loop_and_the_boundary_rate():
     res = _run_bench({}, '--steps', '5', '--warmup', '2', '--no-cpu-baseline', '--boundary-iterations', '2',
                      '--ip-scenarios', '256', '--profile-steps', '1')
     assert res['correct'] is True
-    assert res['ip_loop']['converged'] is True and res['ip_loop']['iterations'] > 5 and res['ip_loop']['it_per_s'] > 0
+    ipl = res['ip_loop']
+    assert ipl['converged'] is True and ipl['iterations'] > 5 and ipl['it_per_s'] > 0
+    # round 4: the C3-shaped QP (5000 primal variables with bounds per scenario, 200 first-stage variables), every step of
+    # the loop a kernel of the library (no torch operator inside the iterations), step kernels timed against the HBM roof
+    assert ipl['primal_variables_per_scenario'] == 5000 and ipl['block_dim'] == 9200 and ipl['n_coupling'] == 200
+    assert ipl['scenarios'] == 256 and max(ipl['final_infeasibilities']) <= 1e-8 and ipl['torch_ops_per_iteration'] == 0
+    assert ipl['pivot_order_refreshes'] == 0
+    assert set(ipl['step_kernels']) == {'rhs', 'step_lengths', 'take_step', 'residuals'}
+    assert all(0.05 < v['frac_of_hbm_peak'] < 1.0 for v in ipl['step_kernels'].values())
     assert res['value_boundary'] == res['boundary_host']['it_per_s'] > 0
 
 
