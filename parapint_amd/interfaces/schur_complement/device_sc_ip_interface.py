@@ -139,16 +139,27 @@ class _PatternGroup(object):
         terms = np.stack([src, wrow], axis=1).astype(np.int32)
         return prog, terms
 
-    # ---- processed initial point of one scenario (interior_point.py:433-447, 761-799)
-    def initial_point(self, q, relax):
-        lb, ub = _relaxed(q.lb, relax, -1.0), _relaxed(q.ub, relax, +1.0)
-        ilb, iub = _relaxed(q.ineq_lb, relax, -1.0), _relaxed(q.ineq_ub, relax, +1.0)
-        x = q.x0.copy()
-        s = np.asarray(q.A_ineq @ q.x0, dtype=np.double)            # interface.py: init_slacks at the given point
-        zl, zu = np.ones(self.n), np.ones(self.n)                   # interface.py:263-283 (no ipopt suffixes)
-        zl[np.isneginf(q.lb)] = 0
-        zu[np.isinf(q.ub)] = 0
-        sl, su = np.zeros(self.mi), np.zeros(self.mi)
+    # ---- processed initial points (interior_point.py:433-447, 761-799), all scenarios of a group at once
+    def initial_points(self, qs, relax):
+        """Rows = scenarios.  The same elementwise operations as the host loop applies per scenario; the slacks
+        s = A_ineq x0 (interface.py: init_slacks at the given point) are accumulated entry by entry in the order of the
+        COO arrays, as scipy's product does."""
+        from scipy.sparse import csr_matrix
+        stack = lambda name: np.stack([np.asarray(getattr(q, name), dtype=np.double) for q in qs]) \
+            if qs else np.zeros((0, 0))
+        lb, ub = _relaxed(stack('lb'), relax, -1.0), _relaxed(stack('ub'), relax, +1.0)
+        ilb, iub = _relaxed(stack('ineq_lb'), relax, -1.0), _relaxed(stack('ineq_ub'), relax, +1.0)
+        x = stack('x0').copy()
+        Ai = self.q0.A_ineq
+        prod = np.stack([q.A_ineq.data for q in qs]) * x[:, Ai.col]                 # [scenario][entry]
+        by_row = np.argsort(Ai.row, kind='stable')
+        gather = csr_matrix((np.ones(self.nnzAi), by_row, np.searchsorted(Ai.row[by_row], np.arange(self.mi + 1))),
+                            shape=(self.mi, self.nnzAi))
+        s = np.ascontiguousarray((gather @ prod.T).T) if self.mi else np.zeros((len(qs), 0))
+        zl, zu = np.ones_like(x), np.ones_like(x)                   # interface.py:263-283 (no ipopt suffixes)
+        zl[np.isneginf(stack('lb'))] = 0
+        zu[np.isinf(stack('ub'))] = 0
+        sl, su = np.zeros_like(s), np.zeros_like(s)
         host_ip.process_init(x, lb, ub)
         host_ip.process_init(s, ilb, iub)
         host_ip.process_init_duals_lb(zl, lb)
@@ -156,6 +167,9 @@ class _PatternGroup(object):
         host_ip.process_init_duals_lb(sl, ilb)
         host_ip.process_init_duals_ub(su, iub)
         return dict(x=x, s=s, zl=zl, zu=zu, sl=sl, su=su, lb=lb, ub=ub, ilb=ilb, iub=iub)
+
+    def initial_point(self, q, relax):
+        return {k: v[0] for k, v in self.initial_points([q], relax).items()}
 
 
 class _GroupState(object):
@@ -283,37 +297,40 @@ class DeviceStochasticQPInterface(object):
             src = dk.sources[gid]
             B, bpad = len(order), int(src.shape[1])
             n, mi, me, nb, off = pg.n, pg.mi, pg.me, pg.nb, pg.off
-            lanes = order + [order[0]] * (bpad - B)              # padded lanes repeat a real scenario ...
-            W = np.zeros((bpad, nb + 2 * n + 2 * mi))
-            bounds = np.zeros((bpad, 2 * n + 2 * mi))
-            data = np.zeros((bpad, n + me))
-            vals = np.zeros((bpad, int(off[3])))
-            for b, ndx in enumerate(lanes):
-                q = self.scenarios[ndx]
-                st = pg.initial_point(q, self._relax)
-                real = b < B
-                W[b, 0:n], W[b, n:n + mi] = st['x'], st['s']
-                if real:                                          # ... but carry no bound and no bound dual
-                    W[b, nb:nb + n], W[b, nb + n:nb + 2 * n] = st['zl'], st['zu']
-                    W[b, nb + 2 * n:nb + 2 * n + mi], W[b, nb + 2 * n + mi:] = st['sl'], st['su']
-                    bounds[b, 0:n], bounds[b, n:2 * n] = st['lb'], st['ub']
-                    bounds[b, 2 * n:2 * n + mi], bounds[b, 2 * n + mi:] = st['ilb'], st['iub']
-                    counts[0] += sum(np.isfinite(st[k]).sum() for k in ('lb', 'ub', 'ilb', 'iub'))
-                    counts[2] += q.c0
-                else:
-                    bounds[b, 0:n], bounds[b, n:2 * n] = -np.inf, np.inf
-                    bounds[b, 2 * n:2 * n + mi], bounds[b, 2 * n + mi:] = -np.inf, np.inf
-                data[b, 0:n], data[b, n:] = q.c, q.b_eq
-                vals[b, off[0]:off[1]], vals[b, off[1]:off[2]], vals[b, off[2]:off[3]] = q.H.data, q.A_eq.data, q.A_ineq.data
+            qs = [self.scenarios[ndx] for ndx in order]
+            # One host array [lane][x0 | s0 | lb | ub | ineq_lb | ineq_ub | c | b_eq | H, A_eq, A_ineq values], one copy
+            # to the device and one transpose there; the relaxation of the bounds and the processing of the initial
+            # point (interior_point.py:433-447, 761-799) run on the device over all lanes at once.
+            nvb, nbd, nv = n + mi, 2 * n + 2 * mi, int(off[3])
+            raw = np.empty((bpad, nvb + nbd + n + me + nv))
+            for b, q in enumerate(qs):
+                raw[b] = np.concatenate((q.x0, np.asarray(q.A_ineq @ q.x0, dtype=np.double).ravel(),   # init_slacks
+                                         q.lb, q.ub, q.ineq_lb, q.ineq_ub, q.c, q.b_eq, q.H.data, q.A_eq.data, q.A_ineq.data))
+            rb = raw[:B, nvb:nvb + nbd]
+            counts[0] += np.isfinite(rb).sum()
+            counts[2] += sum(q.c0 for q in qs)
+            if bpad > B:                                           # padded lanes repeat a real scenario ...
+                raw[B:] = raw[0]
+                raw[B:, nvb:nvb + n], raw[B:, nvb + n:nvb + 2 * n] = -np.inf, np.inf     # ... but carry no bound (and so
+                raw[B:, nvb + 2 * n:nvb + 2 * n + mi], raw[B:, nvb + 2 * n + mi:nvb + nbd] = -np.inf, np.inf   # no bound dual)
+            R = ops.rows_from_instances(raw)
+            W = ops.zeros((nb + 2 * n + 2 * mi, bpad))
+            W[0:nvb] = R[0:nvb]
+            bounds = ops.zeros((max(nbd, 1), bpad))
+            bounds[0:nbd] = R[nvb:nvb + nbd]
+            ops.relax_bounds(bounds, n, mi, self._relax)
+            ops.process_initial_point(W, bounds, n, mi, nb)
+            data = ops.zeros((max(n + me, 1), bpad))
+            data[0:n + me] = R[nvb + nbd:nvb + nbd + n + me]
+            if nv > 0:
+                src[0:nv] = R[nvb + nbd + n + me:]
+            del R
             counts[1] += B * (me + nfs + mi)
             counts[3] += B * (me + nfs)
             counts[4] += B * mi
             gs = _GroupState()
             gs.gid, gs.pg, gs.order, gs.B, gs.bpad = gid, pg, order, B, bpad
-            gs.W, gs.bounds, gs.data = ops.rows_from_instances(W), ops.rows_from_instances(bounds), ops.rows_from_instances(data)
-            gs.src = src
-            if off[3] > 0:
-                src[0:int(off[3])] = ops.rows_from_instances(vals)
+            gs.W, gs.bounds, gs.data, gs.src = W, bounds, data, src
             gs.G = ops.zeros((max(n, 1), bpad))
             prog, terms = pg.row_programs()
             gs.prog, gs.terms = ops.from_host(prog), ops.from_host(terms if terms.size else np.zeros((1, 2), dtype=np.int32))

@@ -52,6 +52,39 @@ class HipIpOps(object):
     def to_host(self, t):
         return t.cpu().numpy()
 
+    # ---- set-up: bounds and initial point of all lanes at once (elementwise, in place; the same operations in the same
+    # order as parapint/interfaces/interface.py:389-419 and algorithms/interior_point.py:761-799 apply per scenario)
+    def relax_bounds(self, bounds, n, mi, factor):
+        """bounds rows: lb (n) | ub (n) | ineq_lb (mi) | ineq_ub (mi), moved outwards by factor * max(1, |bound|)."""
+        if factor == 0:
+            return
+        for r0, r1, sign in ((0, n, -1.0), (n, 2 * n, 1.0), (2 * n, 2 * n + mi, -1.0), (2 * n + mi, 2 * n + 2 * mi, 1.0)):
+            b = bounds[r0:r1]
+            b.copy_(b + (sign * factor) * self._torch.clamp(b.abs(), min=1.0))
+
+    def process_initial_point(self, W, bounds, n, mi, nb):
+        """W rows x | s (pushed inside their bounds) and z_l | z_u | s_l | s_u from row nb on (1, and 0 where the bound is
+        infinite); raises ValueError on crossed or equal bounds like the host loop."""
+        t = self._torch
+        for v0, cnt, b0, z0 in ((0, n, 0, nb), (n, mi, 2 * n, nb + 2 * n)):
+            if cnt == 0:
+                continue
+            x, lo, hi = W[v0:v0 + cnt], bounds[b0:b0 + cnt], bounds[b0 + cnt:b0 + 2 * cnt]
+            width = hi - lo
+            bad = t.stack(((width < 0).any(), (width == 0).any())).cpu()
+            if bool(bad[0]):
+                raise ValueError('Lower bounds for variables/inequalities should not be larger than upper bounds.')
+            if bool(bad[1]):
+                raise ValueError('Variables and inequalities should not have equal lower and upper bounds.')
+            has_lb, has_ub = t.isfinite(lo), t.isfinite(hi)
+            out = (x >= hi) | (x <= lo)
+            x.copy_(t.where(out & has_lb & ~has_ub, lo + 1,
+                            t.where(out & has_ub & ~has_lb, hi - 1,
+                                    t.where(out & has_lb & has_ub, 0.5 * (lo + hi), x))))
+            zl, zu = W[z0:z0 + cnt], W[z0 + cnt:z0 + 2 * cnt]
+            zl.copy_(t.where(t.isneginf(lo), 0.0, t.where(zl <= 0, 1.0, zl)))
+            zu.copy_(t.where(t.isinf(hi), 0.0, t.where(zu <= 0, 1.0, zu)))
+
     # ---- descriptors
     def prepare(self, descs):
         arr = (self._native.IpGroup * len(descs))()

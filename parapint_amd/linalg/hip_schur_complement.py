@@ -155,8 +155,9 @@ class _Group(object):
         self.raw_refs = raw_refs            # (rowK_raw, colK_raw, rowB_raw, colB_raw) of the reference block
         self.blocks = []                    # block indices, slot order
         self.rep_vals = None
-        self.staging = None
-        self.rhs_staging = None
+        self._alloc = None                  # (shape, pinned if possible) -> zeroed host array; set by the solver
+        self._staging = self._rhs_staging = self._x_pool = None     # host boundary buffers, allocated at first use
+        self.result_buffers = 0
         self.x_shape = None
         self.alt_layouts = []               # other raw COO layouts seen: (kr, kc, br, bc, canonical position per entry)
         self._keyK = None
@@ -172,12 +173,35 @@ class _Group(object):
         self.gid = -1                       # index of the group in the library
         self.m = 0                          # coupling rows of a block of this group (local rows for mapped groups)
         self.cmaps = []                     # per block: local -> global coupling rows (mapped groups), else None
-        self.x_pool, self.x_turn, self.x_pinned = [], 0, None      # result buffers of the host boundary
+        self.x_turn, self.x_pinned = 0, None                       # result buffers of the host boundary
         self.device_sources = None          # [nsrc][padded batch] tensor the factorisation reads its values from (f2)
         self.refresh_futile = 0             # pivot-order refreshes in a row that did not cure a breakdown
         self.refresh_skip = 0               # breakdowns still to be reported `singular` at once (opt-in back-off)
         self.futile_vals = None             # representative values of the last futile refresh
         self._ref32 = self._refptr = None   # int32 copies of raw_refs and their addresses (stage_upload)
+
+    # Buffers of the HOST boundary (page-locked when the engine can: ~12 ms per allocation).  A caller that keeps values,
+    # right-hand sides and solutions on the device (rows f2/f4) never touches them, so they are made at first use.
+    @property
+    def staging(self):
+        """Compact rows: only the entries that are read."""
+        if self._staging is None:
+            self._staging = self._alloc((len(self.blocks), self.used.size))
+        return self._staging
+
+    @property
+    def rhs_staging(self):
+        if self._rhs_staging is None:
+            self._rhs_staging = self._alloc((len(self.blocks), self.n))
+        return self._rhs_staging
+
+    @property
+    def x_pool(self):
+        if self._x_pool is None:
+            self._x_pool = [self._alloc(self.x_shape, pinned_only=True) for _ in range(self.result_buffers)]
+            if any(a is None for a in self._x_pool):
+                self._x_pool = []
+        return self._x_pool
 
     @staticmethod
     def _runs(used, nrawK):
@@ -463,12 +487,14 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
                 all_zero = False
         self._coupling_structure(matrix, groups)
         pinned = getattr(self._eng, 'alloc_pinned', None)
-        alloc = pinned if pinned is not None else (lambda shape: np.zeros(shape, dtype=np.double))
+
+        def alloc(shape, pinned_only=False):
+            if pinned is not None:
+                return pinned(shape)
+            return None if pinned_only else np.zeros(shape, dtype=np.double)
         for g in groups:
-            g.staging = alloc((len(g.blocks), g.used.size))        # compact rows: only the entries that are read
-            g.rhs_staging = alloc((len(g.blocks), g.n))
+            g._alloc, g.result_buffers = alloc, self._result_buffers
             g.x_shape = (len(g.blocks), g.n)
-            g.x_pool = [alloc(g.x_shape) for _ in range(self._result_buffers)] if pinned is not None else []
             g.x_turn = 0
         self._groups, self._binfo = groups, binfo
         self._index_records = {}

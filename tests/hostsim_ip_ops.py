@@ -58,6 +58,22 @@ class HostSimIpOps(object):
     def to_host(self, t):
         return np.asarray(t)
 
+    # ---- set-up (the host loop's own functions, over [row][lane] arrays)
+    def relax_bounds(self, bounds, n, mi, factor):
+        from parapint_amd.interfaces.interface import _relaxed
+        for r0, r1, sign in ((0, n, -1.0), (n, 2 * n, 1.0), (2 * n, 2 * n + mi, -1.0), (2 * n + mi, 2 * n + 2 * mi, 1.0)):
+            bounds[r0:r1] = _relaxed(bounds[r0:r1], factor, sign)
+
+    def process_initial_point(self, W, bounds, n, mi, nb):
+        from parapint_amd.algorithms import interior_point as host_ip
+        for v0, cnt, b0, z0 in ((0, n, 0, nb), (n, mi, 2 * n, nb + 2 * n)):
+            if cnt == 0:
+                continue
+            lo, hi = bounds[b0:b0 + cnt], bounds[b0 + cnt:b0 + 2 * cnt]
+            host_ip.process_init(W[v0:v0 + cnt], lo, hi)
+            host_ip.process_init_duals_lb(W[z0:z0 + cnt], lo)
+            host_ip.process_init_duals_ub(W[z0 + cnt:z0 + 2 * cnt], hi)
+
     def prepare(self, descs):
         return _Prepared(descs)
 

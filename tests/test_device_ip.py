@@ -140,6 +140,40 @@ def test_two_pattern_groups_on_cpu_engines():
     _same_run(rows, hist, hi, it, len(qps), same_solver=False)
 
 
+def test_stacked_initial_points_are_those_of_the_host_loop():
+    """The processed initial point of all scenarios of a pattern group at once (rows = scenarios) against the host
+    interface's per-scenario initialisation and the loop's process_init (interior_point.py:433-447, 761-799): bitwise,
+    with starting points outside and on their bounds, one-sided and free variables."""
+    from parapint_amd.algorithms import interior_point as host_ip
+    from parapint_amd.interfaces.interface import _relaxed
+    qps, fs = random_stochastic_qp(5, n=18, n_fs=3, n_eq=4, n_ineq=6, seed=11)
+    rng = np.random.default_rng(3)
+    for q in qps:
+        q.x0 = rng.normal(size=q.n) * 3
+        q.lb[rng.random(q.n) < 0.3] = -np.inf
+        q.ub[rng.random(q.n) < 0.3] = np.inf
+        on = np.flatnonzero(np.isfinite(q.lb))[:2]
+        q.x0[on] = q.lb[on]                                        # exactly on a bound
+    it = DeviceStochasticQPInterface(qps, fs, bounds_relaxation_factor=1e-8)
+    pg = it.pattern_groups[0]
+    st = pg.initial_points(qps, 1e-8)
+    for b, q in enumerate(qps):
+        lb, ub = _relaxed(q.lb, 1e-8, -1.0), _relaxed(q.ub, 1e-8, +1.0)
+        ilb, iub = _relaxed(q.ineq_lb, 1e-8, -1.0), _relaxed(q.ineq_ub, 1e-8, +1.0)
+        x, s = q.x0.copy(), np.asarray(q.A_ineq @ q.x0, dtype=np.double)
+        zl, zu = np.ones(q.n), np.ones(q.n)
+        zl[np.isneginf(q.lb)] = 0
+        zu[np.isinf(q.ub)] = 0
+        sl, su = np.zeros(s.size), np.zeros(s.size)
+        host_ip.process_init(x, lb, ub); host_ip.process_init(s, ilb, iub)
+        host_ip.process_init_duals_lb(zl, lb); host_ip.process_init_duals_ub(zu, ub)
+        host_ip.process_init_duals_lb(sl, ilb); host_ip.process_init_duals_ub(su, iub)
+        for k, v in dict(x=x, s=s, zl=zl, zu=zu, sl=sl, su=su, lb=lb, ub=ub, ilb=ilb, iub=iub).items():
+            assert np.array_equal(st[k][b], v), (b, k)
+    one = pg.initial_point(qps[2], 1e-8)
+    assert all(np.array_equal(one[k], st[k][2]) for k in st)
+
+
 def test_row_programs_reproduce_the_host_interface():
     """grad f + J^T y, the constraint residuals and the right-hand side of the numpy kernels (through the row programs)
     against the host interface's own evaluation at a random iterate."""
@@ -425,3 +459,42 @@ def test_step_kernels_match_their_numpy_restatement(shapes):
         assert np.allclose(a[[1, 4, 5, 6]], b[[1, 4, 5, 6]], rtol=1e-13, atol=0.0), (key, a, b)
     assert np.allclose(got['rc1'], ref['rc1'], rtol=1e-13, atol=1e-13)
     assert np.allclose(got['v0'], ref['v0'], rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.gpu
+def test_initial_point_processing_on_the_device_matches_the_host_functions():
+    """relax_bounds + process_initial_point over [row][lane] tensors against the host loop's functions on the same
+    arrays (bit for bit): points outside, on and inside their bounds, one-sided, free and padded lanes; crossed and
+    equal bounds raise the host loop's ValueErrors."""
+    from hostsim_ip_ops import HostSimIpOps
+    from parapint_amd.linalg.hip_schur_complement import HipEngine
+    rng = np.random.default_rng(5)
+    n, mi, bpad = 37, 6, 128
+    nb = n + 2 * mi + 3 + 4
+    lo = rng.normal(size=(n + mi, bpad))
+    hi = lo + rng.uniform(0.1, 4.0, size=lo.shape)
+    lo[rng.random(lo.shape) < 0.3] = -np.inf
+    hi[rng.random(hi.shape) < 0.3] = np.inf
+    x = rng.normal(size=lo.shape) * 3
+    on = np.isfinite(lo) & (rng.random(lo.shape) < 0.1)
+    x[on] = lo[on]
+    lo[:, 100:], hi[:, 100:] = -np.inf, np.inf                      # padded lanes
+    W = np.zeros((nb + 2 * n + 2 * mi, bpad))
+    W[:n + mi] = x
+    bounds = np.concatenate([lo[:n], hi[:n], lo[n:], hi[n:]])
+    ref_ops, dev_ops = HostSimIpOps(), HipEngine().ip_ops()
+    Wr, br = W.copy(), bounds.copy()
+    ref_ops.relax_bounds(br, n, mi, 1e-8)
+    ref_ops.process_initial_point(Wr, br, n, mi, nb)
+    Wd, bd = dev_ops.from_host(W), dev_ops.from_host(bounds)
+    dev_ops.relax_bounds(bd, n, mi, 1e-8)
+    dev_ops.process_initial_point(Wd, bd, n, mi, nb)
+    assert np.array_equal(dev_ops.to_host(bd), br) and np.array_equal(dev_ops.to_host(Wd), Wr)
+    assert (Wr[:n] > br[:n]).all() and (Wr[:n] < br[n:2 * n]).all() and not np.array_equal(Wr[:n + mi], x)
+    assert set(np.unique(Wr[nb:])) == {0.0, 1.0} and (Wr[nb:, 100:] == 0).all()
+    for bad, msg in ((-1.0, 'larger than upper'), (0.0, 'equal lower and upper')):
+        b2 = bounds.copy()
+        b2[3, 7], b2[n + 3, 7] = 1.0, 1.0 + bad
+        for ops in (ref_ops, dev_ops):
+            with pytest.raises(ValueError, match=msg):
+                ops.process_initial_point(ops.from_host(W), ops.from_host(b2), n, mi, nb)
