@@ -1,0 +1,55 @@
+"""Worker of tests/test_dynamic_ip.py: one rank of a world_size-2 gloo run of the interior-point loop over the time-block
+(dynamic) Schur-complement interface -- time blocks dealt round-robin (mpi_sc_ip_interface.py:14-29), the coupling block of
+the right-hand side summed over the ranks (:242-250), S and r_s reduced by the solver.  The product's solver class runs on
+the numpy engine standing in for the GPU (`--gpu`: on the device)."""
+import os
+import sys
+
+import numpy as np
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+GPU = '--gpu' in sys.argv
+if not GPU:
+    from hostsim_engine import HostSimEngine  # noqa: E402
+from parapint_amd.examples import dynamics_qp  # noqa: E402
+from parapint_amd.linalg.comm import SerialComm, TorchComm  # noqa: E402
+from parapint_amd.linalg.hip_schur_complement import HipSchurComplementLinearSolver  # noqa: E402
+
+T = 5
+ARGS = dict(nfe_per_block=3, n_states=6, n_controls=2)
+
+
+def run(comm):
+    local = [t for t in range(T) if t % comm.size == comm.rank]
+    solver = HipSchurComplementLinearSolver({t: None for t in local}, None, comm=comm,
+                                            engine=None if GPU else HostSimEngine())
+    return dynamics_qp.main(solver, 0.0, 1.0, T, comm=comm if comm.size > 1 else None, **ARGS)
+
+
+def main():
+    dist.init_process_group('gloo')
+    if GPU:
+        import torch
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count())
+    comm = TorchComm()
+    assert comm.size == 2
+    it = run(comm)
+    ref = run(SerialComm())
+    assert abs(it.evaluate_objective() - ref.evaluate_objective()) <= 1e-9
+    z, zr = it.get_primals().get_block(T), ref.get_primals().get_block(T)
+    assert np.abs(np.asarray(z) - np.asarray(zr)).max() <= 1e-7
+    for t in it.local_block_indices:
+        assert np.abs(it.get_primals().get_block(t) - ref.get_primals().get_block(t)).max() <= 1e-7
+    both = comm.allgather(np.asarray(z, dtype=np.double))
+    assert np.array_equal(both[0], both[1])              # the coupling states are the same numbers on both ranks
+    print('rank %d ok' % comm.rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
