@@ -377,6 +377,14 @@ int pp_vec_axpy(pp_handle h, int64_t n, double alpha, const double* x, double* y
  *           together keep the second read of an entry in the L2)
  * All arrays are [rows][bpad] doubles on the handle's device, bpad a multiple of 64, instances >= batch are padding
  * (they hold a copy of a real scenario without bounds and are left alone).  At most 8 groups.
+ * Time-staged problems (sc_ip_interface.py:13-1026; the coupling block is [rho: multipliers of the forward links | z:
+ * coupling states], ncz of each) use MAPPED groups, zoff != NULL ([2][bpad] int32): link row k of instance b ties coupling
+ * state zoff[b] + k (the nfs rows inside the block: the backward link) resp. zoff[bpad + b] + k (nfw further rows: the
+ * forward link, whose multipliers live in the coupling block -- W carries the instance's copy of them in nfw rows behind
+ * the bound duals, prog has nfw more rows, their residuals go to the rho part of the coupling right-hand side).  Then z
+ * has ncz entries, dz is the coupling solution [d rho | d z], and v_local / v_table rows are 8 + 2 ncz long:
+ * {..., rho rows of the coupling right-hand side (this rank's forward links), z rows (this rank's link duals)}.  Without
+ * a map every instance ties all nfs coupling variables (two-stage stochastic programs), nfw = 0 and ncz is ignored.
  *   pp_ip_rhs           rows x and s of rhs from G, the iterate and the barrier parameter mu (the other rows are written by
  *                       pp_ip_residuals)
  *   pp_ip_step_lengths  alpha_local[2] (device) = this rank's fraction-to-the-boundary step lengths, tau = 1 - mu; the
@@ -387,15 +395,16 @@ int pp_vec_axpy(pp_handle h, int64_t n, double alpha, const double* x, double* y
  *   pp_ip_residuals     G, the constraint rows of rhs, and v_local (device, 8 + nfs): {primal infeasibility, dual
  *                       infeasibility of the primal rows, complementarity at 0 and at mu, sum |bound duals|, sum |constraint
  *                       duals|, objective, dual infeasibility of the slack rows, sum over the instances of y_link (nfs)}
- *   pp_ip_publish       combines the nranks rows of v_table ([nranks][8 + nfs], device; rank order, deterministic) into the
- *                       coupling right-hand side rhs_coupling (device, nfs) and the mailbox
+ *   pp_ip_publish       combines the nranks rows of v_table ([nranks][8 + ncoup], device; rank order, deterministic) into the
+ *                       coupling right-hand side rhs_coupling (device, ncoup = nfs, or 2 ncz for mapped groups) and the
+ *                       mailbox; the entries from dual_from on (0, or ncz) are also -grad L of the coupling variables
  *   pp_ip_wait          blocks until the last pp_ip_publish has run: out = {primal inf, dual inf, compl(0), compl(mu),
  *                       sum |bound duals|, sum |duals|, objective, alpha_primal, alpha_dual, 0}
  * All calls are stream-ordered on the handle's stream; only pp_ip_wait synchronises (it polls a pinned mailbox).
  * Between ranks the caller all-gathers alpha_local -> alpha_table and v_local -> v_table (pp_comm_allgather or any other
  * transport); with one rank the tables are the local arrays. */
 typedef struct pp_ip_group {
-  int32_t n, mi, me, nfs, batch, bpad, src_dp, src_ds;
+  int32_t n, mi, me, nfs, batch, bpad, src_dp, src_ds, nfw, ncz;
   double* W;
   const double* bounds;
   const double* data;
@@ -405,13 +414,15 @@ typedef struct pp_ip_group {
   const double* delta;
   const int32_t* prog;
   const int32_t* terms;
+  const int32_t* zoff;
 } pp_ip_group;
 int pp_ip_rhs(pp_handle h, int ngroups, const pp_ip_group* groups, double mu);
 int pp_ip_step_lengths(pp_handle h, int ngroups, const pp_ip_group* groups, double tau, double mu, double* alpha_local);
 int pp_ip_take_step(pp_handle h, int ngroups, const pp_ip_group* groups, const double* alpha_table, int nranks, int unified,
                     double mu, double* z, const double* dz);
 int pp_ip_residuals(pp_handle h, int ngroups, const pp_ip_group* groups, const double* z, double* v_local);
-int pp_ip_publish(pp_handle h, const double* v_table, const double* alpha_table, int nranks, int nfs, double* rhs_coupling);
+int pp_ip_publish(pp_handle h, const double* v_table, const double* alpha_table, int nranks, int ncoup, int dual_from,
+                  double* rhs_coupling);
 int pp_ip_wait(pp_handle h, double out[10]);
 /* With pp_profile(h, 1): accumulated device time (HIP events on the handle's stream), launches and calls of {pp_ip_rhs,
  * pp_ip_step_lengths, pp_ip_take_step, pp_ip_residuals}. */

@@ -117,7 +117,7 @@ SIGNATURES = {
                                        ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
     'pp_ip_residuals': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     'pp_ip_publish': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
-                                     ctypes.c_void_p]),
+                                     ctypes.c_int, ctypes.c_void_p]),
     'pp_ip_wait': (ctypes.c_int, [ctypes.c_void_p, _f64p]),
     'pp_ip_phase_times': (ctypes.c_int, [ctypes.c_void_p, _f64p, _i32p, _i32p]),
     'pp_comm_allgather': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
@@ -137,8 +137,8 @@ SIGNATURES = {
 
 class IpGroup(ctypes.Structure):
     """pp_ip_group of include/parapint_hip.h (one pattern group of the interior-point step on the device)."""
-    _fields_ = [(k, ctypes.c_int32) for k in ('n', 'mi', 'me', 'nfs', 'batch', 'bpad', 'src_dp', 'src_ds')] + \
-               [(k, ctypes.c_void_p) for k in ('W', 'bounds', 'data', 'src', 'G', 'rhs', 'delta', 'prog', 'terms')]
+    _fields_ = [(k, ctypes.c_int32) for k in ('n', 'mi', 'me', 'nfs', 'batch', 'bpad', 'src_dp', 'src_ds', 'nfw', 'ncz')] + \
+               [(k, ctypes.c_void_p) for k in ('W', 'bounds', 'data', 'src', 'G', 'rhs', 'delta', 'prog', 'terms', 'zoff')]
 
 
 GROUP_STAT_KEYS = ['n', 'n_coupling', 'batch', 'n_pivots', 'n_2x2', 'n_levels', 'nnz_L', 'u_doubles',

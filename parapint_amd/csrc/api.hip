@@ -65,6 +65,7 @@ void pp_destroy(pp_handle h) {
     (void)hipEventDestroy(h->ev_dense_done);
   }
   if (h->ip_part) (void)hipFree(h->ip_part);
+  if (h->ip_cmax) (void)hipFree(h->ip_cmax);
   if (h->ip_mail_host) (void)hipHostFree((void*)h->ip_mail_host);
   rccl_release(h);
   delete h;

@@ -357,6 +357,7 @@ struct pp_solver {
   // interior-point step on device-resident iterates (ipstep.hip): partials of its reductions, pinned mailbox
   double* ip_part = nullptr;
   size_t ip_part_cap = 0;
+  double* ip_cmax = nullptr;   // per-workgroup maxima of k_ip_couple (long coupling blocks)
   bool ip_step_done = false;
   volatile double* ip_mail_host = nullptr;
   double* ip_mail_dev = nullptr;

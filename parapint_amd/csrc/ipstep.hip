@@ -125,8 +125,14 @@ __global__ __launch_bounds__(256) void k_ip_step(pp_ip_group g, const double* __
     for (int q = 1; q < nranks; ++q) { ap = nmin(ap, alpha_table[2 * q]); ad = nmin(ad, alpha_table[2 * q + 1]); }
     if (unified) ap = ad = nmin(ap, ad);
   }
-  if (do_z && step && blockIdx.x == 0)
-    for (int k = threadIdx.x; k < g.nfs; k += 256) z[k] = z[k] + ap * dz[k];
+  // coupling variables: nfs of them, tied by every instance (stochastic programs), or -- mapped groups, time blocks --
+  // ncz coupling states, the second half of the coupling solution [d rho | d z]
+  const bool mapped = g.zoff != nullptr;
+  if (do_z && step && blockIdx.x == 0) {
+    const int nz = mapped ? g.ncz : g.nfs;
+    const double* dzs = mapped ? dz + g.ncz : dz;
+    for (int k = threadIdx.x; k < nz; k += 256) z[k] = z[k] + ap * dzs[k];
+  }
   const size_t total = (size_t)(nb - g.mi) * bpad;
   double v[IP_STEP_SLOTS] = {0.0, 0.0, 0.0, 0.0, 0.0};
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
@@ -165,6 +171,21 @@ __global__ __launch_bounds__(256) void k_ip_step(pp_ip_group g, const double* __
       v[4] = v[4] + fabs(y);
     }
   }
+  if (g.nfw > 0) {
+    // the multipliers of the forward link live in the coupling block (sc_ip_interface.py:308-357); the instance keeps a
+    // copy behind its bound duals (its gradient rows read it) and moves it with the rho part of the coupling solution
+    const size_t yf0 = (size_t)(nb + 2 * g.n + 2 * g.mi);
+    const size_t totalf = (size_t)g.nfw * bpad;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < totalf; e += (size_t)gridDim.x * 256) {
+      const int k = (int)(e / bpad);
+      const int b = (int)(e % bpad);
+      if (b >= g.batch) continue;
+      const size_t at = (yf0 + k) * bpad + b;
+      double y = g.W[at];
+      if (step) { y = y + ad * dz[g.zoff[bpad + b] + k]; g.W[at] = y; }
+      v[4] = v[4] + fabs(y);
+    }
+  }
   const int op[IP_STEP_SLOTS] = {1, 1, 1, 2, 2};
   wg_reduce<IP_STEP_SLOTS>(red, v, op);
   if (threadIdx.x < IP_STEP_SLOTS) part[(size_t)threadIdx.x * nwg + wg0 + blockIdx.x] = red[threadIdx.x][0];
@@ -177,15 +198,16 @@ __global__ __launch_bounds__(256) void k_ip_step(pp_ip_group g, const double* __
 // the scalar record reads, address arithmetic and branches of a row are spent once for 128 instances).
 template <int NV>
 __global__ __launch_bounds__(256) void k_ip_rows(pp_ip_group g, const double* __restrict__ z, double* __restrict__ part, int wg0,
-                                                 int nwg, int rpw) {
+                                                 int nwg, int rpw, double* __restrict__ cpl) {
   __shared__ double red[IP_ROWS_SLOTS][256];
   const size_t bpad = (size_t)g.bpad;
   const int nchunk = g.bpad / (64 * NV);
   const int chunk = blockIdx.x % nchunk, tile = blockIdx.x / nchunk;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int b = (chunk * 64 + lane) * NV;
-  const int nprog = g.n + g.me + g.mi + g.nfs;
+  const int nprog = g.n + g.me + g.mi + g.nfs + g.nfw;
   const int nb = ip_nb(g);
+  const bool mapped = g.zoff != nullptr;
   const double* __restrict__ W = g.W + b;
   const double* __restrict__ S = g.src + b;
   double v[IP_ROWS_SLOTS] = {0.0, 0.0, 0.0};
@@ -206,11 +228,23 @@ __global__ __launch_bounds__(256) void k_ip_rows(pp_ip_group g, const double* __
     else if (p < g.n + g.me) { erow = g.n + (p - g.n); orow = (size_t)(g.n + g.mi + (p - g.n)); }
     else if (p < g.n + g.me + g.mi) { erow = g.n + (p - g.n - g.me); ebase = W; orow = (size_t)(g.n + g.mi + g.me + (p - g.n - g.me)); }
     else { erow = -1; orow = (size_t)(g.n + 2 * g.mi + g.me + (p - g.n - g.me - g.mi)); }
+    // link rows: the nfs rows inside the block, then (time blocks) the nfw rows of the forward link, whose residual
+    // belongs to the coupling block of the right-hand side
+    const int kk = p - g.n - g.me - g.mi;
+    const bool forward = erow < 0 && kk >= g.nfs;
     double ev[NV], zl[NV], zu[NV], xp[NV];
+    int zo[NV];
     if (erow >= 0) ldv<NV>(ebase + (size_t)erow * bpad, ev);
-    else { const double zk = z[p - g.n - g.me - g.mi];
+    else if (!mapped) { const double zk = z[kk];
 #pragma unroll
       for (int i = 0; i < NV; ++i) ev[i] = zk; }
+    else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        zo[i] = g.zoff[(forward ? bpad : (size_t)0) + b + i] + (forward ? kk - g.nfs : kk);
+        ev[i] = z[zo[i]];
+      }
+    }
     if (primal) {
       ldv<NV>(W + (size_t)(nb + p) * bpad, zl);
       ldv<NV>(W + (size_t)(nb + g.n + p) * bpad, zu);
@@ -267,12 +301,32 @@ __global__ __launch_bounds__(256) void k_ip_rows(pp_ip_group g, const double* __
         out[i] = -res;
         if (b + i < g.batch) v[0] = nmax(v[0], fabs(res));
       }
-      stv<NV>(g.rhs + orow * bpad + b, out);
+      if (forward) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) if (b + i < g.batch) cpl[zo[i]] = out[i];
+      } else stv<NV>(g.rhs + orow * bpad + b, out);
     }
   }
   const int op[IP_ROWS_SLOTS] = {1, 1, 2};
   wg_reduce<IP_ROWS_SLOTS>(red, v, op);
   if (threadIdx.x < IP_ROWS_SLOTS) part[(size_t)threadIdx.x * nwg + wg0 + blockIdx.x] = red[threadIdx.x][0];
+}
+
+// ---- mapped groups: the link duals of an instance go to the coupling states of ITS two links (the z rows of the coupling
+// right-hand side, sc_ip_interface.py:857-861).  A coupling state has one backward and one forward link: at most two addends
+// on a zeroed entry, so the order of the atomic adds does not show in the sum.
+__global__ __launch_bounds__(256) void k_ip_links_mapped(pp_ip_group g, double* __restrict__ zpart) {
+  const size_t bpad = (size_t)g.bpad;
+  const size_t total = (size_t)(g.nfs + g.nfw) * bpad;
+  const size_t yb0 = (size_t)(g.n + 2 * g.mi + g.me), yf0 = (size_t)(ip_nb(g) + 2 * g.n + 2 * g.mi);
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int k = (int)(e / bpad);
+    const int b = (int)(e % bpad);
+    if (b >= g.batch) continue;
+    const bool fw = k >= g.nfs;
+    const double y = g.W[(fw ? yf0 + (k - g.nfs) : yb0 + k) * bpad + b];
+    unsafeAtomicAdd(zpart + g.zoff[(fw ? bpad : (size_t)0) + b] + (fw ? k - g.nfs : k), y);
+  }
 }
 
 // ---- this rank's scalars: workgroups 0 .. 7 combine one slot each of the partials of k_ip_step and k_ip_rows (fixed order:
@@ -310,18 +364,44 @@ __global__ __launch_bounds__(256) void k_ip_local(IpLinks L, int nwg_step, const
 }
 
 // ---- all ranks' scalars -> coupling right-hand side + mailbox.  Rows are combined in rank order on every rank: every rank
-// publishes the same numbers (the loop's control flow must agree).
-__global__ __launch_bounds__(256) void k_ip_publish(const double* __restrict__ v_table, const double* __restrict__ alpha_table,
-                                                    int nranks, int nfs, double* __restrict__ rhs_coupling, double* mail,
-                                                    long long seq) {
+// publishes the same numbers (the loop's control flow must agree).  The ncoup entries behind the 8 scalars of a rank are
+// its part of the coupling right-hand side; from entry dual_from on they are also -grad L of the coupling variables.
+__device__ __forceinline__ double couple_entry(const double* __restrict__ v_table, int nranks, int nv, int k) {
+  double s = 0.0;
+  for (int r = 0; r < nranks; ++r) s = s + v_table[(size_t)r * nv + 8 + k];
+  return s;
+}
+
+// long coupling blocks (time-staged problems): the sums on many workgroups, one maximum per workgroup for k_ip_publish
+__global__ __launch_bounds__(256) void k_ip_couple(const double* __restrict__ v_table, int nranks, int ncoup, int dual_from,
+                                                   double* __restrict__ rhs_coupling, double* __restrict__ wgmax) {
   __shared__ double red[1][256];
-  const int nv = 8 + nfs;
+  const int nv = 8 + ncoup;
   double m = 0.0;
-  for (int k = threadIdx.x; k < nfs; k += 256) {
-    double s = 0.0;
-    for (int r = 0; r < nranks; ++r) s = s + v_table[(size_t)r * nv + 8 + k];
+  for (int k = blockIdx.x * 256 + threadIdx.x; k < ncoup; k += gridDim.x * 256) {
+    const double s = couple_entry(v_table, nranks, nv, k);
     rhs_coupling[k] = s;
-    m = nmax(m, fabs(s));           // |grad_z L| = |-sum y_link|
+    if (k >= dual_from) m = nmax(m, fabs(s));
+  }
+  const int op[1] = {1};
+  wg_reduce<1>(red, &m, op);
+  if (threadIdx.x == 0) wgmax[blockIdx.x] = red[0][0];
+}
+
+__global__ __launch_bounds__(256) void k_ip_publish(const double* __restrict__ v_table, const double* __restrict__ alpha_table,
+                                                    int nranks, int ncoup, int dual_from, double* __restrict__ rhs_coupling,
+                                                    const double* __restrict__ wgmax, int nwgmax, double* mail, long long seq) {
+  __shared__ double red[1][256];
+  const int nv = 8 + ncoup;
+  double m = 0.0;
+  if (wgmax) {
+    for (int k = threadIdx.x; k < nwgmax; k += 256) m = nmax(m, wgmax[k]);
+  } else {
+    for (int k = threadIdx.x; k < ncoup; k += 256) {
+      const double s = couple_entry(v_table, nranks, nv, k);
+      rhs_coupling[k] = s;
+      if (k >= dual_from) m = nmax(m, fabs(s));           // |grad_z L| = |-sum of the link duals|
+    }
   }
   const int op[1] = {1};
   wg_reduce<1>(red, &m, op);
@@ -343,9 +423,15 @@ int ip_check(pp_handle h, int ngroups, const pp_ip_group* g, const char* what) {
   if (!h || ngroups < 1 || ngroups > IP_MAXG || !g) return fail(h, 3, std::string(what) + ": bad arguments (1 to 8 groups)");
   for (int i = 0; i < ngroups; ++i) {
     const pp_ip_group& q = g[i];
-    if (q.n < 0 || q.mi < 0 || q.me < 0 || q.nfs < 0 || q.batch < 1 || q.bpad < q.batch || (q.bpad & 63) || q.nfs != g[0].nfs ||
+    if (q.n < 0 || q.mi < 0 || q.me < 0 || q.nfs < 0 || q.batch < 1 || q.bpad < q.batch || (q.bpad & 63) ||
         !q.W || !q.bounds || !q.data || !q.src || !q.G || !q.rhs || !q.prog || !q.terms)
       return fail(h, 3, std::string(what) + ": inconsistent group descriptor");
+    // either every instance ties all nfs coupling variables (no map, the same nfs in every group), or the groups are
+    // mapped: per-instance offsets into ncz coupling states, forward links allowed
+    const bool mapped = q.zoff != nullptr;
+    if (mapped != (g[0].zoff != nullptr) || (!mapped && (q.nfs != g[0].nfs || q.nfw != 0)) ||
+        (mapped && (q.ncz != g[0].ncz || q.ncz < 0 || q.nfw < 0 || q.nfs > q.ncz || q.nfw > q.ncz)))
+      return fail(h, 3, std::string(what) + ": inconsistent coupling description of the groups");
   }
   return 0;
 }
@@ -368,11 +454,11 @@ unsigned ew_grid(const pp_ip_group& g, int rows) {
 }
 int rows_nv(const pp_ip_group& g) { return (g.bpad % 128 == 0) ? 2 : 1; }      // instances per lane of k_ip_rows
 int rows_rpw(const pp_ip_group& g) {       // rows per wave of k_ip_rows
-  const size_t nprog = (size_t)(g.n + g.me + g.mi + g.nfs), nchunk = (size_t)(g.bpad / (64 * rows_nv(g)));
+  const size_t nprog = (size_t)(g.n + g.me + g.mi + g.nfs + g.nfw), nchunk = (size_t)(g.bpad / (64 * rows_nv(g)));
   return (int)std::max<size_t>(IP_RPW, (nprog * nchunk + 4 * IP_ROWS_MAXWG - 1) / (4 * IP_ROWS_MAXWG));
 }
 unsigned rows_grid(const pp_ip_group& g) {
-  const int nprog = g.n + g.me + g.mi + g.nfs, rpw = rows_rpw(g);
+  const int nprog = g.n + g.me + g.mi + g.nfs + g.nfw, rpw = rows_rpw(g);
   return (unsigned)((nprog + 4 * rpw - 1) / (4 * rpw)) * (unsigned)(g.bpad / (64 * rows_nv(g)));
 }
 
@@ -429,7 +515,8 @@ int pp_ip_step_lengths(pp_handle h, int ngroups, const pp_ip_group* g, double ta
 int pp_ip_take_step(pp_handle h, int ngroups, const pp_ip_group* g, const double* alpha_table, int nranks, int unified, double mu,
                     double* z, const double* dz) {
   if (int rc = ip_check(h, ngroups, g, "pp_ip_take_step")) return rc;
-  if (alpha_table && (nranks < 1 || (g[0].nfs > 0 && (!z || !dz)))) return fail(h, 3, "pp_ip_take_step: bad arguments");
+  const int ncoupled = g[0].zoff ? g[0].ncz : g[0].nfs;
+  if (alpha_table && (nranks < 1 || (ncoupled > 0 && (!z || !dz)))) return fail(h, 3, "pp_ip_take_step: bad arguments");
   PP_HIP(hipSetDevice(h->device));
   for (int i = 0; i < ngroups; ++i)
     if (alpha_table && !g[i].delta) return fail(h, 3, "pp_ip_take_step: no step (delta)");
@@ -451,7 +538,8 @@ int pp_ip_take_step(pp_handle h, int ngroups, const pp_ip_group* g, const double
 
 int pp_ip_residuals(pp_handle h, int ngroups, const pp_ip_group* g, const double* z, double* v_local) {
   if (int rc = ip_check(h, ngroups, g, "pp_ip_residuals")) return rc;
-  if (!v_local || (g[0].nfs > 0 && !z)) return fail(h, 3, "pp_ip_residuals: bad arguments");
+  const bool mapped = g[0].zoff != nullptr;
+  if (!v_local || ((mapped ? g[0].ncz : g[0].nfs) > 0 && !z)) return fail(h, 3, "pp_ip_residuals: bad arguments");
   PP_HIP(hipSetDevice(h->device));
   if (!h->ip_step_done) return fail(h, 3, "pp_ip_residuals: call pp_ip_take_step first");
   IpSizes sz;
@@ -461,11 +549,17 @@ int pp_ip_residuals(pp_handle h, int ngroups, const pp_ip_group* g, const double
   double* part_rows = h->ip_part + (size_t)IP_STEP_SLOTS * nwg_s;
   unsigned wg0 = 0;
   IpLinks L;
-  L.ng = ngroups; L.nfs = g[0].nfs;
+  L.ng = ngroups; L.nfs = mapped ? 0 : g[0].nfs;
+  // mapped groups: this rank's part of the coupling right-hand side [rho rows | z rows] starts from zero; the row kernels
+  // store the residuals of the forward links, k_ip_links_mapped adds the link duals
+  double* cpl = v_local + 8;
+  if (mapped && g[0].ncz > 0) PP_HIP(hipMemsetAsync(cpl, 0, (size_t)2 * g[0].ncz * sizeof(double), h->stream));
   for (int i = 0; i < ngroups; ++i) {
     const unsigned n = rows_grid(g[i]);
-    if (n && rows_nv(g[i]) == 2) hipLaunchKernelGGL(k_ip_rows<2>, dim3(n), dim3(256), 0, h->stream, g[i], z, part_rows, (int)wg0, (int)nwg_r, rows_rpw(g[i]));
-    else if (n) hipLaunchKernelGGL(k_ip_rows<1>, dim3(n), dim3(256), 0, h->stream, g[i], z, part_rows, (int)wg0, (int)nwg_r, rows_rpw(g[i]));
+    if (n && rows_nv(g[i]) == 2) hipLaunchKernelGGL(k_ip_rows<2>, dim3(n), dim3(256), 0, h->stream, g[i], z, part_rows, (int)wg0, (int)nwg_r, rows_rpw(g[i]), cpl);
+    else if (n) hipLaunchKernelGGL(k_ip_rows<1>, dim3(n), dim3(256), 0, h->stream, g[i], z, part_rows, (int)wg0, (int)nwg_r, rows_rpw(g[i]), cpl);
+    if (mapped && g[i].nfs + g[i].nfw > 0)
+      hipLaunchKernelGGL(k_ip_links_mapped, dim3(ew_grid(g[i], g[i].nfs + g[i].nfw)), dim3(256), 0, h->stream, g[i], cpl + g[0].ncz);
     wg0 += n;
     L.ylink[i] = g[i].W + (size_t)(g[i].n + 2 * g[i].mi + g[i].me) * g[i].bpad;
     L.batch[i] = g[i].batch; L.bpad[i] = g[i].bpad;
@@ -476,8 +570,10 @@ int pp_ip_residuals(pp_handle h, int ngroups, const pp_ip_group* g, const double
   return 0;
 }
 
-int pp_ip_publish(pp_handle h, const double* v_table, const double* alpha_table, int nranks, int nfs, double* rhs_coupling) {
-  if (!h || !v_table || nranks < 1 || nfs < 0 || (nfs > 0 && !rhs_coupling)) return fail(h, 3, "pp_ip_publish: bad arguments");
+int pp_ip_publish(pp_handle h, const double* v_table, const double* alpha_table, int nranks, int ncoup, int dual_from,
+                  double* rhs_coupling) {
+  if (!h || !v_table || nranks < 1 || ncoup < 0 || dual_from < 0 || dual_from > ncoup || (ncoup > 0 && !rhs_coupling))
+    return fail(h, 3, "pp_ip_publish: bad arguments");
   PP_HIP(hipSetDevice(h->device));
   if (!h->ip_mail_host) {
     void* hp = nullptr;
@@ -489,8 +585,22 @@ int pp_ip_publish(pp_handle h, const double* v_table, const double* alpha_table,
     h->ip_mail_dev = (double*)dp;
     h->ip_seq = 0;
   }
-  hipLaunchKernelGGL(k_ip_publish, dim3(1), dim3(256), 0, h->stream, v_table, alpha_table, nranks, nfs, rhs_coupling,
-                     h->ip_mail_dev, ++h->ip_seq);
+  const double* wgmax = nullptr;
+  int nwgmax = 0;
+  if (ncoup > 2048) {
+    constexpr int MAXWG = 256;
+    if (!h->ip_cmax) {
+      void* p = nullptr;
+      if (hipMalloc(&p, MAXWG * sizeof(double)) != hipSuccess) return fail(h, 1, "hipMalloc failed (interior-point scratch)");
+      h->ip_cmax = (double*)p;
+    }
+    nwgmax = std::min(MAXWG, (ncoup + 255) / 256);
+    hipLaunchKernelGGL(k_ip_couple, dim3(nwgmax), dim3(256), 0, h->stream, v_table, nranks, ncoup, dual_from, rhs_coupling,
+                       h->ip_cmax);
+    wgmax = h->ip_cmax;
+  }
+  hipLaunchKernelGGL(k_ip_publish, dim3(1), dim3(256), 0, h->stream, v_table, alpha_table, nranks, ncoup, dual_from, rhs_coupling,
+                     wgmax, nwgmax, h->ip_mail_dev, ++h->ip_seq);
   PP_HIP(hipGetLastError());
   return 0;
 }

@@ -25,9 +25,12 @@ from parapint_amd.interfaces.schur_complement.sc_ip_interface import MPIDynamicS
 
 class DiffusionControl(MPIDynamicSchurComplementInteriorPointInterface):
     def __init__(self, start_t, end_t, num_time_blocks, nfe_per_block=4, n_states=8, n_controls=2, comm=None,
-                 u_max=1.5, y_max=0.9, rate=4.0, r=1e-2, nu=0.05):
+                 u_max=1.5, y_max=0.9, rate=4.0, r=1e-2, nu=0.05, duplicate_constraint=False):
         self.nfe, self.n_s, self.n_u = int(nfe_per_block), int(n_states), int(n_controls)
         self.u_max, self.y_max, self.rate, self.r, self.nu = u_max, y_max, rate, r, nu
+        # the last dynamics equation of every time block stated twice: a rank-deficient Jacobian, the KKT matrix is
+        # singular at every iterate and the inertia-correction loop (interior_point.py:364-392) has to regularise it
+        self.duplicate_constraint = bool(duplicate_constraint)
         h = 1.0 / (self.n_s + 1)
         self.Lap = diags([np.ones(self.n_s - 1), -2 * np.ones(self.n_s), np.ones(self.n_s - 1)], [-1, 0, 1]).tocoo() / h ** 2 \
             if self.n_s > 1 else coo_matrix(np.array([[-2.0 / h ** 2]]))
@@ -65,6 +68,15 @@ class DiffusionControl(MPIDynamicSchurComplementInteriorPointInterface):
             vals += [np.ones(n_s), -step.data, -dt * self.B.data]
         b.append(np.zeros(n_s * nfe))
         me = n_s * nfe
+        if self.duplicate_constraint:
+            last = me - 1
+            for rr, cc, vv in list(zip(rows, cols, vals))[-3:]:
+                pick = np.asarray(rr) == last
+                rows.append(np.full(int(pick.sum()), me))
+                cols.append(np.asarray(cc)[pick])
+                vals.append(np.asarray(vv)[pick])
+            b.append(np.zeros(1))
+            me += 1
         if add_init_conditions:
             rows.append(me + np.arange(n_s))
             cols.append(self.ys(0))

@@ -44,10 +44,12 @@ _TAG = 1 << 22          # tags of the five source families are k * _TAG + index 
 class _PatternGroup(object):
     """Scenarios of this rank with one sparsity pattern (Hessian, both Jacobians, first-stage indices)."""
 
-    def __init__(self, q0, fs):
-        self.q0, self.fs = q0, np.asarray(fs, dtype=np.int64)
-        self.members = []
-        self.n, self.me, self.mi, self.nfs = q0.n, q0.A_eq.shape[0], q0.A_ineq.shape[0], self.fs.size
+    def __init__(self, q0, fs, ff=(), mapped=False):
+        """mapped: the instances tie different coupling variables (time blocks).  fs: variables of the link whose multipliers sit in the block (nonanticipativity; for a time block the start
+        states); ff: variables of the forward link of a time block (end states; multipliers in the coupling block)."""
+        self.q0, self.fs, self.ff = q0, np.asarray(fs, dtype=np.int64), np.asarray(ff, dtype=np.int64)
+        self.members, self.mapped = [], bool(mapped)
+        self.n, self.me, self.mi, self.nfs, self.nfw = q0.n, q0.A_eq.shape[0], q0.A_ineq.shape[0], self.fs.size, self.ff.size
         self.nb = self.n + 2 * self.mi + self.me + self.nfs          # dimension of one diagonal block
         self.nnzH, self.nnzAe, self.nnzAi = q0.H.nnz, q0.A_eq.nnz, q0.A_ineq.nnz
         # source rows: [H | A_eq | A_ineq | primal barrier diagonal | slack barrier diagonal]
@@ -56,14 +58,14 @@ class _PatternGroup(object):
         self.value_map = None
         self.K0 = self.A0 = self.A0t = None
 
-    def same_pattern(self, q, fs):
+    def same_pattern(self, q, fs, ff=()):
         q0 = self.q0
 
         def same(a, b):
             return a.shape == b.shape and (a.row is b.row or np.array_equal(a.row, b.row)) and \
                 (a.col is b.col or np.array_equal(a.col, b.col))
         return same(q.H, q0.H) and same(q.A_eq, q0.A_eq) and same(q.A_ineq, q0.A_ineq) and \
-            np.array_equal(np.asarray(fs, dtype=np.int64), self.fs)
+            np.array_equal(np.asarray(fs, dtype=np.int64), self.fs) and np.array_equal(np.asarray(ff, dtype=np.int64), self.ff)
 
     # ---- value map (once, on the host)
     def find_value_map(self):
@@ -84,7 +86,7 @@ class _PatternGroup(object):
         nlp = ti.scenario_interface(0)
         nlp.barrier_diagonals = lambda: (tags(4, self.n), tags(5, self.mi))
         kkt = ti.evaluate_primal_dual_kkt_matrix()
-        vals = np.concatenate([kkt.get_block(0, 0).tocoo().data, kkt.get_block(1, 0).tocoo().data])
+        vals = np.concatenate([kkt.get_block(0, 0).tocoo().data, self.border_values(kkt.get_block(1, 0).tocoo())])
         a = np.abs(vals)
         fam = (a // _TAG).astype(np.int64)
         idx = (a % _TAG).astype(np.int64) - 1
@@ -93,31 +95,43 @@ class _PatternGroup(object):
         coef = np.where(is_src, np.sign(vals), vals)
         self.value_map = (src, coef)
 
+    def border_values(self, stochastic_border):
+        """Values of the border block A_i in the order of its COO entries (constants).  Mapped groups: the forward link
+        (+1 on the end states) and then -1 on the multipliers of the backward link, as DeviceDynamicQPInterface._border
+        lists them."""
+        if self.mapped:
+            return np.concatenate([np.ones(self.nfw), -np.ones(self.nfs)])
+        return stochastic_border.data
+
     # ---- row programs of the kernels (include/parapint_hip.h: pp_ip_group.prog / terms)
     def row_programs(self):
         """(prog [n + me + mi + nfs][4], terms [nt][2]): for the rows grad_x L, A_eq x - b, A_ineq x - s, x_fs - z the
         products {source row or -1, row of W} in the order they are summed -- the Hessian terms of a row first."""
-        q, n, mi, me, nfs, off = self.q0, self.n, self.mi, self.me, self.nfs, self.off
+        q, n, mi, me, nfs, nfw, off = self.q0, self.n, self.mi, self.me, self.nfs, self.nfw, self.off
         H, Ae, Ai = q.H, q.A_eq, q.A_ineq
         x0, yeq0, yin0, yl0 = 0, n + mi, n + mi + me, n + 2 * mi + me      # rows of W
+        yf0 = self.nb + 2 * n + 2 * mi              # copies of the forward-link multipliers (behind the bound duals)
         offd = np.flatnonzero(H.row != H.col)
         eH, eAe, eAi, k = np.arange(self.nnzH), np.arange(self.nnzAe), np.arange(self.nnzAi), np.arange(nfs)
+        kf = np.arange(nfw)
         parts = [   # (program row, source row, row of W, class: 0 Hessian term, 1 other)
             (H.row, off[0] + eH, x0 + H.col, 0),
             (H.col[offd], off[0] + offd, x0 + H.row[offd], 0),              # the mirrored upper triangle
             (Ae.col, off[1] + eAe, yeq0 + Ae.row, 1),                        # A_eq^T y_eq
             (Ai.col, off[2] + eAi, yin0 + Ai.row, 1),                        # A_ineq^T y_ineq
             (self.fs, -np.ones(nfs), yl0 + k, 1),                            # L^T y_link
+            (self.ff, -np.ones(nfw), yf0 + kf, 1),                           # L_forward^T rho (time blocks)
             (n + Ae.row, off[1] + eAe, x0 + Ae.col, 1),                      # A_eq x
             (n + me + Ai.row, off[2] + eAi, x0 + Ai.col, 1),                 # A_ineq x
-            (n + me + mi + k, -np.ones(nfs), x0 + self.fs, 1)]               # x_fs
+            (n + me + mi + k, -np.ones(nfs), x0 + self.fs, 1),               # x_fs (start states of a time block)
+            (n + me + mi + nfs + kf, -np.ones(nfw), x0 + self.ff, 1)]        # end states of a time block
         prow = np.concatenate([np.asarray(p[0], dtype=np.int64) for p in parts])
         src = np.concatenate([np.asarray(p[1], dtype=np.int64) for p in parts])
         wrow = np.concatenate([np.asarray(p[2], dtype=np.int64) for p in parts])
         cls = np.concatenate([np.full(len(p[0]), p[3], dtype=np.int64) for p in parts])
         order = np.lexsort((np.arange(prow.size), cls, prow))              # by row, Hessian terms first, then as listed
         prow, src, wrow, cls = prow[order], src[order], wrow[order], cls[order]
-        nprog = n + me + mi + nfs
+        nprog = n + me + mi + nfs + nfw
         t0 = np.searchsorted(prow, np.arange(nprog), side='left')
         t1 = np.searchsorted(prow, np.arange(nprog), side='right')
         nH = np.bincount(prow[cls == 0], minlength=nprog)[:nprog]
@@ -196,27 +210,35 @@ class DeviceStochasticQPInterface(object):
         self.local = [ndx for ndx in range(N) if ndx % self.comm.size == self.comm.rank]
         self._relax = bounds_relaxation_factor
         self.nfs = len(first_stage_indices[self.local[0]])
-        # pattern groups of the local scenarios (index arrays shared between scenarios are recognised by identity)
+        for ndx in self.local:
+            if len(first_stage_indices[ndx]) != self.nfs:
+                raise ValueError('every scenario must carry a copy of every first-stage variable')
+        self._find_pattern_groups({ndx: (first_stage_indices[ndx], None) for ndx in self.local})
+
+    def _find_pattern_groups(self, links):
+        """Pattern groups of the local scenarios / time blocks (index arrays shared between them are recognised by
+        identity); links[ndx] = (variables of the link inside the block, variables of the forward link or None)."""
         self.pattern_groups, self.group_of = [], {}
         by_ids, by_sig = {}, {}
+        none = np.zeros(0, dtype=np.int64)
         for ndx in self.local:
-            q, fs = self.scenarios[ndx], first_stage_indices[ndx]
-            if len(fs) != self.nfs:
-                raise ValueError('every scenario must carry a copy of every first-stage variable')
-            ids = (q.n, id(q.H.row), id(q.H.col), id(q.A_eq.row), id(q.A_eq.col), id(q.A_ineq.row), id(q.A_ineq.col), id(fs))
+            q, (fs, ff) = self.scenarios[ndx], links[ndx]
+            ids = (q.n, id(q.H.row), id(q.H.col), id(q.A_eq.row), id(q.A_eq.col), id(q.A_ineq.row), id(q.A_ineq.col), id(fs),
+                   id(ff))
             pg = by_ids.get(ids)
             if pg is None:
                 fsa = np.asarray(fs, dtype=np.int64)
+                ffa = none if ff is None else np.asarray(ff, dtype=np.int64)
                 sig = (q.n, q.A_eq.shape[0], q.A_ineq.shape[0]) + tuple(
                     (a.size, zlib.crc32(np.ascontiguousarray(a))) for a in (q.H.row, q.H.col, q.A_eq.row, q.A_eq.col,
-                                                                           q.A_ineq.row, q.A_ineq.col, fsa))
-                pg = next((g for g in by_sig.get(sig, ()) if g.same_pattern(q, fs)), None)
+                                                                           q.A_ineq.row, q.A_ineq.col, fsa, ffa))
+                pg = next((g for g in by_sig.get(sig, ()) if g.same_pattern(q, fsa, ffa)), None)
                 if pg is None:
-                    pg = _PatternGroup(q, fs)
+                    pg = _PatternGroup(q, fsa, ffa, mapped=ff is not None)
                     pg.find_value_map()
                     by_sig.setdefault(sig, []).append(pg)
                     self.pattern_groups.append(pg)
-                by_ids[ids] = pg
+                by_ids[ids] = pg                 # (`links` keeps the index arrays alive: their ids stay theirs)
             pg.members.append(ndx)
             self.group_of[ndx] = pg
         self.nsrc = max(pg.nsrc for pg in self.pattern_groups)
@@ -244,7 +266,7 @@ class DeviceStochasticQPInterface(object):
         processed initial point are the pattern (their values fix the static pivot order) -- the solver reads patterns and
         one representative value set from this matrix, the values of all scenarios come from the sources on the device --,
         the value map names the source of every entry."""
-        N, nfs = self.N, self.nfs
+        N = self.N
         if self.comm.size > 1:
             owner = -np.ones((N + 1, N + 1), dtype=np.int64)
             for ndx in range(N):
@@ -265,18 +287,33 @@ class DeviceStochasticQPInterface(object):
             pg.K0, pg.A0 = kkt.get_block(0, 0).tocoo(), kkt.get_block(1, 0).tocoo()
             pg.A0t = pg.A0.transpose().tocoo()
             for ndx in pg.members:
+                A = self._border(pg, ndx)
                 pattern.set_block(ndx, ndx, pg.K0)
-                pattern.set_block(N, ndx, pg.A0)
-                pattern.set_block(ndx, N, pg.A0t)
+                pattern.set_block(N, ndx, A)
+                pattern.set_block(ndx, N, pg.A0t if A is pg.A0 else A.transpose().tocoo())
         for ndx in self.local:
             pattern.set_row_size(ndx, self.group_of[ndx].nb)
             pattern.set_col_size(ndx, self.group_of[ndx].nb)
-        from scipy.sparse import identity
-        corner = identity(nfs, format='coo')
-        corner.data.fill(0)
+        corner, sparse_corner, coupling_classes = self._corner()
         pattern.set_block(N, N, corner)
         maps = {ndx: self.group_of[ndx].value_map for ndx in self.local}
-        return DeviceBlockMatrix(pattern, maps, self.nsrc)
+        dk = DeviceBlockMatrix(pattern, maps, self.nsrc)
+        if sparse_corner:
+            dk.Q = corner
+        dk.coupling_classes = coupling_classes
+        return dk
+
+    def _border(self, pg, ndx):
+        """Border block (coupling rows x rows of the diagonal block) of scenario ndx: the same for a whole pattern group."""
+        return pg.A0
+
+    def _corner(self):
+        """(corner block with explicit zero diagonal, keep it sparse for the solver?, regularisation classes of the
+        coupling rows or None: all of them primal variables)."""
+        from scipy.sparse import identity
+        corner = identity(self.nfs, format='coo')
+        corner.data.fill(0)
+        return corner, False, None
 
     # ------------------------------------------------------------------ state on the device
     def attach(self, solver, dk):
@@ -285,7 +322,7 @@ class DeviceStochasticQPInterface(object):
         regularisation classes, right-hand side; then the measures of the initial point."""
         self.solver, self.dk = solver, dk
         self.ops = ops = solver._eng.ip_ops()
-        nfs, P = self.nfs, self.comm.size
+        P = self.comm.size
         self.rhs = solver.new_device_vector()
         self.states, descs, classes = [], [], {}
         counts = np.zeros(5)       # finite bounds, duals, sum of c0, equality rows, inequality rows (this rank)
@@ -296,7 +333,7 @@ class DeviceStochasticQPInterface(object):
                 raise ValueError('blocks of one solver group come from different pattern groups')
             src = dk.sources[gid]
             B, bpad = len(order), int(src.shape[1])
-            n, mi, me, nb, off = pg.n, pg.mi, pg.me, pg.nb, pg.off
+            n, mi, me, nb, off, nfs, nfw = pg.n, pg.mi, pg.me, pg.nb, pg.off, pg.nfs, pg.nfw
             qs = [self.scenarios[ndx] for ndx in order]
             # One host array [lane][x0 | s0 | lb | ub | ineq_lb | ineq_ub | c | b_eq | H, A_eq, A_ineq values], one copy
             # to the device and one transpose there; the relaxation of the bounds and the processing of the initial
@@ -314,7 +351,7 @@ class DeviceStochasticQPInterface(object):
                 raw[B:, nvb:nvb + n], raw[B:, nvb + n:nvb + 2 * n] = -np.inf, np.inf     # ... but carry no bound (and so
                 raw[B:, nvb + 2 * n:nvb + 2 * n + mi], raw[B:, nvb + 2 * n + mi:nvb + nbd] = -np.inf, np.inf   # no bound dual)
             R = ops.rows_from_instances(raw)
-            W = ops.zeros((nb + 2 * n + 2 * mi, bpad))
+            W = ops.zeros((nb + 2 * n + 2 * mi + nfw, bpad))     # (+ copies of the forward-link multipliers, time blocks)
             W[0:nvb] = R[0:nvb]
             bounds = ops.zeros((max(nbd, 1), bpad))
             bounds[0:nbd] = R[nvb:nvb + nbd]
@@ -325,8 +362,8 @@ class DeviceStochasticQPInterface(object):
             if nv > 0:
                 src[0:nv] = R[nvb + nbd + n + me:]
             del R
-            counts[1] += B * (me + nfs + mi)
-            counts[3] += B * (me + nfs)
+            counts[1] += B * (me + nfs + nfw + mi)
+            counts[3] += B * (me + nfs + nfw)
             counts[4] += B * mi
             gs = _GroupState()
             gs.gid, gs.pg, gs.order, gs.B, gs.bpad = gid, pg, order, B, bpad
@@ -338,6 +375,7 @@ class DeviceStochasticQPInterface(object):
             descs.append(dict(n=n, mi=mi, me=me, nfs=nfs, batch=B, bpad=bpad, src_dp=int(off[3]), src_ds=int(off[4]),
                               W=gs.W, bounds=gs.bounds, data=gs.data, src=gs.src, G=gs.G, rhs=gs.rhs, prog=gs.prog,
                               terms=gs.terms))
+            self._describe_links(descs[-1], gs)
             # inertia correction: +coef on the primal rows, -coef on the constraint rows (equality, inequality, link)
             cls = np.zeros(nb, dtype=np.int8)
             cls[:n] = 1
@@ -349,8 +387,9 @@ class DeviceStochasticQPInterface(object):
         if hasattr(solver, 'warm_device_results'):
             solver.warm_device_results()
         self._prepared = ops.prepare(descs)
-        self.z = ops.zeros((max(nfs, 1),))                        # coupling variables: free, start at 0
-        nv = V_HEAD + nfs
+        self._ncoup, self._dual_from = self._coupling_layout()
+        self.z = ops.zeros((max(self._ncoup - self._dual_from, 1),))         # coupling variables: free, start at 0
+        nv = V_HEAD + self._ncoup
         self._alpha_local, self._v_local = ops.zeros((2,)), ops.zeros((nv,))
         self._alpha_table = self._alpha_local if P == 1 else ops.zeros((P, 2))
         self._v_table = self._v_local if P == 1 else ops.zeros((P, nv))
@@ -359,6 +398,14 @@ class DeviceStochasticQPInterface(object):
         self._cnt_bounds, self._cnt_duals, self._c0 = float(counts[0]), float(counts[0] + counts[1]), float(counts[2])
         self._n_eq, self._n_ineq = int(round(counts[3])), int(round(counts[4]))
         self._have_step = False
+
+    def _coupling_layout(self):
+        """(entries of the coupling block, first entry that is a coupling VARIABLE): all nfs of them here."""
+        return self.nfs, 0
+
+    def _describe_links(self, desc, gs):
+        """Which coupling variables the link rows of a group's instances tie: every instance all of them, in order."""
+        pass
 
     # ------------------------------------------------------------------ sizes the loop asks for
     def n_eq_constraints(self):
@@ -422,7 +469,8 @@ class DeviceStochasticQPInterface(object):
         ops, P = self.ops, self.comm.size
         ops.residuals(self._prepared, self.z, self._v_local)
         ops.allgather(self.comm, self._v_local, self._v_table)
-        ops.publish(self._v_table, self._alpha_table if self._have_step else None, P, self.nfs, self.rhs.coupling)
+        ops.publish(self._v_table, self._alpha_table if self._have_step else None, P, self._ncoup, self._dual_from,
+                    self.rhs.coupling)
         m = ops.wait()
         bound_sum, dual_sum = float(m[4]), float(m[4] + m[5])
         dual_scaling = max(error_scaling, dual_sum / self._cnt_duals) / error_scaling
@@ -437,10 +485,95 @@ class DeviceStochasticQPInterface(object):
 
     # ------------------------------------------------------------------ results
     def first_stage_solution(self):
-        return self.ops.to_host(self.z)[:self.nfs].copy()
+        return self.ops.to_host(self.z)[:self._ncoup - self._dual_from].copy()
 
     def scenario_primals(self, ndx):
         for gs in self.states:
             if ndx in gs.order:
                 return self.ops.to_host(gs.W[:gs.pg.n, gs.order.index(ndx)]).copy()
         raise KeyError('scenario %d is not on this rank' % ndx)
+
+
+class DeviceDynamicQPInterface(DeviceStochasticQPInterface):
+    """The same producer for time-staged problems: device-resident counterpart of
+    ``(MPI)DynamicSchurComplementInteriorPointInterface`` (sc_ip_interface.py:13-1026, mpi_sc_ip_interface.py:32-270) for
+    time blocks given as QuadraticPrograms.  A time block ties its start states to the coupling states before it (backward
+    link, multipliers inside the block) and its end states to the coupling states after it (forward link, multipliers in the
+    coupling block), so the instances of a pattern group tie DIFFERENT coupling variables: the kernels get per-instance
+    offsets (include/parapint_hip.h: mapped groups), every instance carries a copy of the multipliers of its forward link,
+    and the coupling block [rho | z] of the right-hand side is scattered instead of summed over the lanes.
+
+    Parameters
+    ----------
+    time_blocks: sequence over the time blocks of (QuadraticProgram, start states, end states) -- what
+        ``build_model_for_time_block`` returns (sc_ip_interface.py:107-143); entries of other ranks may be None
+    comm: communicator of parapint_amd.linalg.comm (None: serial); time block ndx belongs to rank ndx % size
+    """
+
+    def __init__(self, time_blocks, comm=None, bounds_relaxation_factor=1e-8):
+        self.comm = SerialComm() if comm is None else comm
+        self.time_blocks = list(time_blocks)
+        self.N = T = len(self.time_blocks)
+        if self.comm.size > T:
+            raise ValueError('Cannot yet handle more processes than time blocks')    # mpi_sc_ip_interface.py:79-80
+        self.local = [ndx for ndx in range(T) if ndx % self.comm.size == self.comm.rank]
+        self._relax = bounds_relaxation_factor
+        self.scenarios = [None if blk is None else blk[0] for blk in self.time_blocks]
+        self.num_states = ns = len(self.time_blocks[self.local[0]][1])
+        self.ncz = ns * (T - 1)
+        self.nfs = 2 * self.ncz                       # rows of the coupling block: forward multipliers, coupling states
+        none = np.zeros(0, dtype=np.int64)
+        links = {}
+        for ndx in self.local:
+            _, start, end = self.time_blocks[ndx]
+            if len(start) != ns or len(end) != ns:
+                raise ValueError('every time block must name the same number of start and end states')
+            links[ndx] = (start if ndx != 0 else none, end if ndx != T - 1 else none)
+        self._find_pattern_groups(links)
+
+    @property
+    def host(self):
+        """The host interface over the same time blocks (tests compare with it)."""
+        if self._host is None:
+            from parapint_amd.interfaces.schur_complement.sc_ip_interface import DynamicSchurComplementInteriorPointInterface
+            blocks = self.time_blocks
+
+            class _Given(DynamicSchurComplementInteriorPointInterface):
+                def build_model_for_time_block(self, ndx, start_t, end_t, add_init_conditions):
+                    return blocks[ndx]
+            self._host = _Given(0.0, 1.0, self.N, comm=None if self.comm.size == 1 else self.comm)
+            self._host.set_bounds_relaxation_factor(self._relax)
+        return self._host
+
+    def _border(self, pg, ndx):
+        """(2 ncz x dim K_ndx): +1 of the forward link on the rows rho_ndx, -1 on the multipliers of the backward link on
+        the rows z_{ndx-1} (sc_ip_interface.py:308-327); the entry order is that of _PatternGroup.border_values."""
+        from scipy.sparse import coo_matrix
+        ns, ncz = self.num_states, self.ncz
+        rows = np.concatenate([ns * ndx + np.arange(pg.nfw), ncz + ns * (ndx - 1) + np.arange(pg.nfs)])
+        cols = np.concatenate([pg.ff, pg.n + 2 * pg.mi + pg.me + np.arange(pg.nfs)])
+        return coo_matrix((pg.border_values(None), (rows.astype(np.int64), cols.astype(np.int64))), shape=(2 * ncz, pg.nb))
+
+    def _corner(self):
+        """[[0, -I], [-I, 0]] (:329-357), sparse: 2 n_s (T - 1) rows; the rho rows are constraint rows (class 2)."""
+        from scipy.sparse import coo_matrix
+        m = self.ncz
+        i = np.arange(m)
+        corner = coo_matrix((-np.ones(2 * m), (np.concatenate([m + i, i]), np.concatenate([i, m + i]))), shape=(2 * m, 2 * m))
+        return corner, True, np.concatenate([np.full(m, 2, dtype=np.int8), np.full(m, 1, dtype=np.int8)])
+
+    def _coupling_layout(self):
+        return 2 * self.ncz, self.ncz
+
+    def _describe_links(self, desc, gs):
+        ns, T = self.num_states, self.N
+        lanes = list(gs.order) + [gs.order[0]] * (gs.bpad - gs.B)          # (padded lanes: any valid offsets)
+        zoff = np.zeros((2, gs.bpad), dtype=np.int32)
+        zoff[0] = [ns * (t - 1) if t > 0 else 0 for t in lanes]
+        zoff[1] = [ns * t if t < T - 1 else 0 for t in lanes]
+        gs.zoff = self.ops.from_host(zoff)
+        desc.update(nfw=gs.pg.nfw, ncz=self.ncz, zoff=gs.zoff)
+
+    def coupling_states(self):
+        """The states between the time blocks (n_states * (T - 1)), block after block."""
+        return self.first_stage_solution()

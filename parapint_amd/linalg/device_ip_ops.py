@@ -91,6 +91,12 @@ class HipIpOps(object):
         for q, d in zip(arr, descs):
             for k in ('n', 'mi', 'me', 'nfs', 'batch', 'bpad', 'src_dp', 'src_ds'):
                 setattr(q, k, int(d[k]))
+            q.nfw, q.ncz = int(d.get('nfw', 0)), int(d.get('ncz', 0))
+            zoff = d.get('zoff')                   # mapped groups (time blocks): [2][bpad] int32 offsets into the coupling states
+            if zoff is not None and (not zoff.is_cuda or not zoff.is_contiguous() or zoff.dtype != self._torch.int32 or
+                                     tuple(zoff.shape) != (2, int(d['bpad']))):
+                raise ValueError('interior-point step: zoff must be a contiguous [2][bpad] int32 device tensor')
+            q.zoff = None if zoff is None else zoff.data_ptr()
             for k in ('W', 'bounds', 'data', 'src', 'G', 'rhs', 'prog', 'terms'):
                 t = d[k]
                 if not t.is_contiguous() or not t.is_cuda:
@@ -121,9 +127,9 @@ class HipIpOps(object):
     def residuals(self, hd, z, v_local):
         self.ns.check(self.lib.pp_ip_residuals(self.ns.h, hd.n, hd.arr, z.data_ptr(), v_local.data_ptr()), 'pp_ip_residuals')
 
-    def publish(self, v_table, alpha_table, nranks, nfs, rhs_coupling):
+    def publish(self, v_table, alpha_table, nranks, ncoup, dual_from, rhs_coupling):
         self.ns.check(self.lib.pp_ip_publish(self.ns.h, v_table.data_ptr(), None if alpha_table is None else alpha_table.data_ptr(),
-                                             int(nranks), int(nfs), rhs_coupling.data_ptr()), 'pp_ip_publish')
+                                             int(nranks), int(ncoup), int(dual_from), rhs_coupling.data_ptr()), 'pp_ip_publish')
 
     def wait(self):
         out = np.zeros(10)

@@ -953,7 +953,8 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             # "the last matrix + a diagonal": one retry of the inertia-correction loop (interior_point.py:377-392) from
             # the values resident on the device -- reached through the reference's unchanged call site
             return self.refactorize_with_diagonal_shift(shift[0], shift[1], coupling_shift=shift[2],
-                                                        raise_on_error=raise_on_error, timer=timer)
+                                                        raise_on_error=raise_on_error, timer=timer,
+                                                        coupling_classes=getattr(matrix, 'coupling_classes', None))
         if shift is not None and shift != (0.0, 0.0, 0.0):
             raise RuntimeError('a shifted device matrix needs set_regularization_classes and a factorisation of its base first')
         if shift is not None:
@@ -1275,7 +1276,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         self._apply_classes()
 
     def refactorize_with_diagonal_shift(self, delta_w, delta_c, coupling_shift=0.0, raise_on_error=True, timer=None,
-                                        _retry=False):
+                                        _retry=False, coupling_classes=None):
         """Numeric factorisation of (the last matrix given to do_numeric_factorization) + delta_w on the classed
         Hessian diagonals - delta_c on the classed constraint diagonals + coupling_shift * I on the coupling block,
         from the values already resident on the device: what one retry of the inertia-correction loop
@@ -1292,13 +1293,21 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         self._guarded(res, self._eng.numeric_local_shifted, delta_w, delta_c)
         timer.stop('factorize')
         Q = None if self._base_Q is None else self._base_Q.copy()
-        if coupling_shift != 0.0 and self._nc > 0:
+        # diagonal of the coupling block: + coupling_shift (rows of class 1; all rows without classes), - delta_c (class 2)
+        if coupling_classes is None:
+            cdiag = np.full(self._nc, float(coupling_shift))
+        else:
+            cls = np.asarray(coupling_classes)
+            if cls.shape != (self._nc,):
+                raise ValueError('coupling_classes must name every coupling row')
+            cdiag = np.where(cls == 1, float(coupling_shift), np.where(cls == 2, -float(delta_c), 0.0))
+        if np.any(cdiag != 0.0) and self._nc > 0:
             if self._btd is not None:
                 import scipy.sparse as _sp
-                shift = coupling_shift * _sp.identity(self._nc, format='coo')
+                shift = _sp.diags(cdiag, format='coo')
                 Q = shift if Q is None else (_sp.coo_matrix(Q) + shift).tocoo()
             else:
-                Q = (np.zeros((self._nc, self._nc)) if Q is None else Q) + coupling_shift * np.eye(self._nc)
+                Q = (np.zeros((self._nc, self._nc)) if Q is None else Q) + np.diag(cdiag)
         base = self._base_Q
         res = self._finish_numeric(res, Q, timer)
         self._base_Q = base                     # shifts are relative to the matrix of the last full factorisation
@@ -1313,7 +1322,8 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
                 for g in self._groups:
                     self._eng.upload_values_compact(g.gid, g.staging)
             res = self.refactorize_with_diagonal_shift(delta_w, delta_c, coupling_shift=coupling_shift,
-                                                       raise_on_error=False, timer=timer, _retry=True)
+                                                       raise_on_error=False, timer=timer, _retry=True,
+                                                       coupling_classes=coupling_classes)
             self._note_refresh_outcome(res.status != LinearSolverStatus.singular)
             if res.status not in _OK and raise_on_error:
                 raise RuntimeError('Numeric factorization unsuccessful; status: ' + str(res.status))

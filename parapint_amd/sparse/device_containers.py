@@ -35,6 +35,7 @@ class DeviceBlockMatrix(object):
         self.Q = None              # dense host coupling block (or None = zero)
         self.base = None           # with_diagonal_shift: the matrix the shift is relative to
         self.diagonal_shift = None # ... and (delta_w, delta_c, coupling_shift)
+        self.coupling_classes = None   # int8 per coupling row: 1 gets +coupling_shift, 2 gets -delta_c (None: all 1)
 
     # the BlockMatrix protocol of SURVEY.md 8b, served by the pattern
     @property
@@ -62,17 +63,21 @@ class DeviceBlockMatrix(object):
         other.slots = self.slots
         other.sources = dict(sources)
         other.Q = self.Q
+        other.coupling_classes = self.coupling_classes
         return other
 
     def with_diagonal_shift(self, delta_w=0.0, delta_c=0.0, coupling_shift=0.0):
         """The same matrix + delta_w on the Hessian diagonals - delta_c on the constraint diagonals (the rows classed by
-        ``solver.set_regularization_classes``) + coupling_shift * I on the coupling block: what the inertia-correction
+        ``solver.set_regularization_classes``) + coupling_shift * I on the coupling block (with ``coupling_classes``:
+        + coupling_shift on its rows of class 1, - delta_c on those of class 2 -- the multipliers of the forward links of a
+        time-staged problem live there, sc_ip_interface.py:903-933): what the inertia-correction
         loop builds with ``regularize_hessian`` / ``regularize_equality_gradient`` (interior_point.py:377-386,
         interfaces/interface.py:590-619).  ``do_numeric_factorization`` recognises it and factorises from the values that
         are already on the device."""
         base = self.base if self.diagonal_shift is not None else self
         other = DeviceBlockMatrix(base.pattern, base.value_maps, base.nsrc)
         other.slots, other.sources, other.Q = base.slots, base.sources, base.Q
+        other.coupling_classes = base.coupling_classes
         other.base = base
         other.diagonal_shift = (float(delta_w), float(delta_c), float(coupling_shift))
         return other

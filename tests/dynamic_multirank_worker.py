@@ -13,8 +13,9 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 
 GPU = '--gpu' in sys.argv
+DEVICE_PRODUCER = '--device-producer' in sys.argv     # iterates resident on the (simulated) device, interior-point step kernels
 if not GPU:
-    from hostsim_engine import HostSimEngine  # noqa: E402
+    from hostsim_engine import HostSimDeviceEngine, HostSimEngine  # noqa: E402
 from parapint_amd.examples import dynamics_qp  # noqa: E402
 from parapint_amd.linalg.comm import SerialComm, TorchComm  # noqa: E402
 from parapint_amd.linalg.hip_schur_complement import HipSchurComplementLinearSolver  # noqa: E402
@@ -30,6 +31,37 @@ def run(comm):
     return dynamics_qp.main(solver, 0.0, 1.0, T, comm=comm if comm.size > 1 else None, **ARGS)
 
 
+def run_device(comm):
+    from parapint_amd.algorithms.device_interior_point import ip_solve_device
+    from parapint_amd.algorithms.interior_point import IPOptions, InteriorPointStatus
+    from parapint_amd.interfaces.schur_complement.device_sc_ip_interface import DeviceDynamicQPInterface
+    host = dynamics_qp.DiffusionControl(0.0, 1.0, T, **ARGS)
+    blocks = [host.build_model_for_time_block(t, t / T, (t + 1) / T, t == 0) for t in range(T)]
+    it = DeviceDynamicQPInterface(blocks, comm=comm)
+    opt = IPOptions()
+    opt.linalg.solver = HipSchurComplementLinearSolver({t: None for t in it.local}, None, comm=comm,
+                                                       engine=None if GPU else HostSimDeviceEngine(),
+                                                       result_buffers=2 if GPU else 0)
+    hist = []
+    status, _ = ip_solve_device(it, opt, history=hist)
+    assert status == InteriorPointStatus.optimal
+    return it, hist
+
+
+def main_device(comm):
+    it, hist = run_device(comm)
+    ref, ref_hist = run_device(SerialComm())
+    assert len(hist) == len(ref_hist)
+    for a, b in zip(hist, ref_hist):
+        assert np.allclose(a[:6], b[:6], rtol=1e-6, atol=2e-9), (a, b)
+    assert np.abs(it.coupling_states() - ref.coupling_states()).max() <= 1e-8
+    for t in it.local:
+        assert np.abs(it.scenario_primals(t) - ref.scenario_primals(t)).max() <= 1e-7
+    mine = np.array([v for row in hist for v in row[:6]])
+    both = comm.allgather(mine)
+    assert np.array_equal(both[0], both[1])              # every rank took the same decisions from the same numbers
+
+
 def main():
     dist.init_process_group('gloo')
     if GPU:
@@ -37,6 +69,12 @@ def main():
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count())
     comm = TorchComm()
     assert comm.size == 2
+    if DEVICE_PRODUCER:
+        main_device(comm)
+        print('rank %d ok' % comm.rank)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     it = run(comm)
     ref = run(SerialComm())
     assert abs(it.evaluate_objective() - ref.evaluate_objective()) <= 1e-9

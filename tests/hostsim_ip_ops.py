@@ -37,7 +37,7 @@ def _views(d):
                 lo=np.concatenate([bd[0:n, :B], bd[2 * n:2 * n + mi, :B]]),
                 hi=np.concatenate([bd[n:2 * n, :B], bd[2 * n + mi:, :B]]),
                 zl=np.concatenate([W[nb:nb + n, :B], W[nb + 2 * n:nb + 2 * n + mi, :B]]),
-                zu=np.concatenate([W[nb + n:nb + 2 * n, :B], W[nb + 2 * n + mi:, :B]]))
+                zu=np.concatenate([W[nb + n:nb + 2 * n, :B], W[nb + 2 * n + mi:nb + 2 * n + 2 * mi, :B]]))
 
 
 class HostSimIpOps(object):
@@ -130,8 +130,13 @@ class HostSimIpOps(object):
                 ap, ad = nmin(ap, float(t[r, 0])), nmin(ad, float(t[r, 1]))
             if unified:
                 ap = ad = nmin(ap, ad)
-            nfs = hd.descs[0]['nfs']
-            z[:nfs] = z[:nfs] + ap * np.asarray(dz)[:nfs]
+            d0 = hd.descs[0]
+            if d0.get('zoff') is None:
+                nfs = d0['nfs']
+                z[:nfs] = z[:nfs] + ap * np.asarray(dz)[:nfs]
+            else:                                       # mapped groups: the coupling solution is [d rho | d z]
+                ncz = d0['ncz']
+                z[:ncz] = z[:ncz] + ap * np.asarray(dz)[ncz:2 * ncz]
         c0 = cm = gls = 0.0
         bsum = dsum = 0.0
         with np.errstate(all='ignore'):
@@ -151,10 +156,15 @@ class HostSimIpOps(object):
                     yin = yin + ad * D[n + mi + me:n + 2 * mi + me, :B]
                     W[:n + mi, :B] = x
                     W[nb:nb + n, :B], W[nb + 2 * n:nb + 2 * n + mi, :B] = zl[:n], zl[n:]
-                    W[nb + n:nb + 2 * n, :B], W[nb + 2 * n + mi:, :B] = zu[:n], zu[n:]
+                    W[nb + n:nb + 2 * n, :B], W[nb + 2 * n + mi:nb + 2 * n + 2 * mi, :B] = zu[:n], zu[n:]
                     W[n + mi + me:n + 2 * mi + me, :B] = yin
                     for r0, r1 in ((n + mi, n + mi + me), (n + 2 * mi + me, nb)):          # y_eq, y_link
                         W[r0:r1, :B] = W[r0:r1, :B] + ad * D[r0:r1, :B]
+                    nfw = d.get('nfw', 0)
+                    if nfw:                                 # copies of the forward-link multipliers (coupling block)
+                        yf0 = nb + 2 * n + 2 * mi
+                        idx = np.asarray(d['zoff'])[1, :B][None, :] + np.arange(nfw)[:, None]
+                        W[yf0:yf0 + nfw, :B] = W[yf0:yf0 + nfw, :B] + ad * np.asarray(dz)[idx]
                 diag = zl / (x - lo) + zu / (hi - x)
                 d['src'][d['src_dp']:d['src_dp'] + n, :B] = diag[:n]
                 d['src'][d['src_ds']:d['src_ds'] + mi, :B] = diag[n:]
@@ -166,20 +176,25 @@ class HostSimIpOps(object):
                 bsum += float(np.sum(np.abs(zl) + np.abs(zu)))
                 dsum += float(np.sum(np.abs(yin)) + np.sum(np.abs(W[n + mi:n + mi + me, :B])) +
                               np.sum(np.abs(W[n + 2 * mi + me:nb, :B])))
+                if d.get('nfw', 0):
+                    yf0 = nb + 2 * n + 2 * mi
+                    dsum += float(np.sum(np.abs(W[yf0:yf0 + d['nfw'], :B])))
         self._step_part = (c0, cm, gls, bsum, dsum)
 
     # ---- k_ip_rows + k_ip_local
     def residuals(self, hd, z, v_local):
         c0, cm, gls, bsum, dsum = self._step_part
         pinf, dinf, obj = 0.0, 0.0, 0.0
-        nfs = hd.descs[0]['nfs']
-        csum = np.zeros(nfs)
+        mapped = hd.descs[0].get('zoff') is not None
+        ncz = hd.descs[0].get('ncz', 0)
+        csum = np.zeros(2 * ncz if mapped else hd.descs[0]['nfs'])
         with np.errstate(all='ignore'):
             for d in hd.descs:
                 v = _views(d)
                 n, mi, me, B, nb, W, S = v['n'], v['mi'], v['me'], v['B'], v['nb'], v['W'], d['src']
+                nfs, nfw = d['nfs'], d.get('nfw', 0)
                 prog, terms = np.asarray(d['prog']), np.asarray(d['terms'])
-                nprog = n + me + mi + nfs
+                nprog = n + me + mi + nfs + nfw
                 t0, tH, t1 = prog[:nprog, 0].astype(np.int64), prog[:nprog, 1].astype(np.int64), prog[:nprog, 2].astype(np.int64)
                 assert np.array_equal(np.sort(prog[:nprog, 3]), np.arange(nprog))      # the execution order is a permutation
                 bp = W.shape[1]
@@ -201,24 +216,39 @@ class HostSimIpOps(object):
                 obj += float(np.sum((W[:n] * (0.5 * accH[:n] + cj))[:, :B]))
                 res_eq = acc[n:n + me] - d['data'][n:n + me]
                 res_in = acc[n + me:n + me + mi] - W[n:n + mi]
-                res_lk = acc[n + me + mi:nprog] - np.asarray(z)[:nfs, None]
+                zz = np.asarray(z)
+                if not mapped:
+                    res_lk = acc[n + me + mi:nprog] - zz[:nfs, None]
+                    res_fw = np.zeros((0, W.shape[1]))
+                else:
+                    zo = np.asarray(d['zoff'])
+                    ib = zo[0][None, :] + np.arange(nfs)[:, None]             # coupling state of link row k, lane b
+                    jf = zo[1][None, :] + np.arange(nfw)[:, None]
+                    res_lk = acc[n + me + mi:n + me + mi + nfs] - zz[ib]
+                    res_fw = acc[n + me + mi + nfs:nprog] - zz[jf]
                 d['rhs'][n + mi:n + mi + me] = -res_eq
                 d['rhs'][n + mi + me:n + 2 * mi + me] = -res_in
                 d['rhs'][n + 2 * mi + me:nb] = -res_lk
-                for r in (res_eq, res_in, res_lk):
+                for r in (res_eq, res_in, res_lk, res_fw):
                     pinf = nmax(pinf, _amax(np.abs(r[:, :B])))
-                csum += np.sum(W[n + 2 * mi + me:nb, :B], axis=1)
+                if not mapped:
+                    csum += np.sum(W[n + 2 * mi + me:nb, :B], axis=1)
+                else:
+                    yf0 = nb + 2 * n + 2 * mi
+                    csum[jf[:, :B].ravel()] = -res_fw[:, :B].ravel()            # rho rows: one forward link per entry
+                    np.add.at(csum, ncz + ib[:, :B].ravel(), W[n + 2 * mi + me:nb, :B].ravel())
+                    np.add.at(csum, ncz + jf[:, :B].ravel(), W[yf0:yf0 + nfw, :B].ravel())
         v_local[:V_HEAD] = (pinf, dinf, c0, cm, bsum, dsum, obj, gls)
-        v_local[V_HEAD:V_HEAD + nfs] = csum
+        v_local[V_HEAD:V_HEAD + csum.size] = csum
 
     # ---- k_ip_publish + pp_ip_wait
-    def publish(self, v_table, alpha_table, nranks, nfs, rhs_coupling):
-        T = np.asarray(v_table).reshape(nranks, V_HEAD + nfs)
-        s = np.zeros(nfs)
+    def publish(self, v_table, alpha_table, nranks, ncoup, dual_from, rhs_coupling):
+        T = np.asarray(v_table).reshape(nranks, V_HEAD + ncoup)
+        s = np.zeros(ncoup)
         for r in range(nranks):
             s = s + T[r, V_HEAD:]
-        rhs_coupling[:nfs] = s
-        o = [0.0, _amax(np.abs(s)), 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, 1.0]
+        rhs_coupling[:ncoup] = s
+        o = [0.0, _amax(np.abs(s[dual_from:])), 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, 1.0]
         A = None if alpha_table is None else np.asarray(alpha_table).reshape(nranks, 2)
         for r in range(nranks):
             for k in range(4):

@@ -216,7 +216,7 @@ def test_row_programs_reproduce_the_host_interface():
     v, rc = np.zeros(8 + nfs), np.zeros(nfs)
     ops.take_step(hd, None, 1, False, mu, z, None)
     ops.residuals(hd, z, v)
-    ops.publish(v, None, 1, nfs, rc)
+    ops.publish(v, None, 1, nfs, 0, rc)
     ops.rhs(hd, mu)
     rhs = host.evaluate_primal_dual_kkt_rhs()
     for b in range(B):
@@ -410,7 +410,7 @@ def _run_step_sequence(ops, descs, z, dz, mu, tau, nranks=1):
     out = {}
     ops.take_step(hd, None, 1, False, mu, zt, None)
     ops.residuals(hd, zt, v)
-    ops.publish(v, None, 1, nfs, rc)
+    ops.publish(v, None, 1, nfs, 0, rc)
     out['mail0'] = ops.wait()
     out['v0'] = ops.to_host(v).copy()
     ops.rhs(hd, mu)
@@ -422,7 +422,7 @@ def _run_step_sequence(ops, descs, z, dz, mu, tau, nranks=1):
     out['alpha'] = ops.to_host(alpha).copy()
     ops.take_step(hd, alpha, 1, False, mu, zt, dzt)
     ops.residuals(hd, zt, v)
-    ops.publish(v, alpha, 1, nfs, rc)
+    ops.publish(v, alpha, 1, nfs, 0, rc)
     out['mail1'] = ops.wait()
     out['W1'] = [ops.to_host(d['W']).copy() for d in dev]
     out['G1'] = [ops.to_host(d['G']).copy() for d in dev]

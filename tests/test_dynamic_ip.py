@@ -161,3 +161,143 @@ def test_dynamic_loop_over_the_hip_solver():
     assert abs(it.evaluate_objective() - ref.evaluate_objective()) <= 1e-7
     for t in range(T + 1):
         assert np.abs(np.asarray(it.get_primals().get_block(t)) - np.asarray(ref.get_primals().get_block(t))).max() <= 1e-6
+
+
+# ---- the device-resident producer for time blocks (DeviceDynamicQPInterface; include/parapint_hip.h: mapped groups) -----
+def _time_blocks(T, args):
+    host = dq.DiffusionControl(0.0, 1.0, T, **args)
+    return [host.build_model_for_time_block(t, t / T, (t + 1) / T, t == 0) for t in range(T)]
+
+
+def _device_loop(blocks, engine, comm=None, local=None):
+    from parapint_amd.algorithms.device_interior_point import ip_solve_device
+    from parapint_amd.algorithms.interior_point import IPOptions, InteriorPointStatus
+    from parapint_amd.interfaces.schur_complement.device_sc_ip_interface import DeviceDynamicQPInterface
+    from parapint_amd.linalg.comm import SerialComm
+    from parapint_amd.linalg.hip_schur_complement import HipSchurComplementLinearSolver
+    it = DeviceDynamicQPInterface(blocks, comm=comm)
+    opt = IPOptions()
+    opt.linalg.solver = HipSchurComplementLinearSolver({t: None for t in it.local}, None, comm=comm or SerialComm(),
+                                                       engine=engine, result_buffers=0 if engine is not None else 2)
+    hist, stats = [], {}
+    status, iters = ip_solve_device(it, opt, history=hist, stats=stats)
+    assert status == InteriorPointStatus.optimal
+    return it, hist, stats
+
+
+def _host_history(T, args, solver):
+    """Rows of the host loop's log: iteration, objective, primal / dual / complementarity infeasibility, barrier."""
+    import logging
+    import re
+    rows = []
+
+    class Cap(logging.Handler):
+        def emit(self, record):
+            m = re.match(r'^(\d+)\s+(\S+)\s+(\S+)\s+(\S+)\s+(\S+)\s+(\S+)\s+(\S+)\s+(\S+)\s+(\S+)\s+(\S+)', record.getMessage())
+            if m:
+                rows.append([float(v) for v in m.groups()])
+    log = logging.getLogger('parapint_amd.algorithms.interior_point')
+    cap, old = Cap(), log.level
+    log.addHandler(cap)
+    log.setLevel(logging.INFO)
+    try:
+        it = dq.main(solver, 0.0, 1.0, T, **args)
+    finally:
+        log.removeHandler(cap)
+        log.setLevel(old)
+    return it, rows
+
+
+def _same_iterations(rows, hist, primal_noise=2e-9):
+    """The host loop prints 3 significant digits; below 1e-9 the measures are rounding noise of two summation orders.
+    primal_noise: with a singular KKT matrix regularised by 1e-8 the residual of the constraints after a step is the
+    rounding error of a solve at condition 1e8 and more -- two orders of summation give different noise there."""
+    assert len(rows) == len(hist)
+    for r, h in zip(rows, hist):
+        for k, (a, b) in enumerate(zip(r[2:6], h[:4])):
+            assert abs(a - b) <= 6e-3 * max(abs(a), abs(b)) + (primal_noise if k == 0 else 2e-9), (r, h)
+
+
+def _same_point(it, host, T, tol):
+    z = np.asarray(host.get_primals().get_block(T))
+    assert np.abs(it.coupling_states() - z).max() <= tol
+    for t in it.local:
+        assert np.abs(it.scenario_primals(t) - host.get_primals().get_block(t)).max() <= tol
+
+
+def _product_solver_on_cpu(T):
+    from hostsim_engine import HostSimEngine
+    from parapint_amd.linalg.comm import SerialComm
+    from parapint_amd.linalg.hip_schur_complement import HipSchurComplementLinearSolver
+    return HipSchurComplementLinearSolver({t: None for t in range(T)}, None, comm=SerialComm(), engine=HostSimEngine())
+
+
+def test_device_dynamic_loop_on_cpu_engines_matches_the_host_loop():
+    """Producer + loop on the numpy restatement of the kernels: iteration by iteration the measures of the host loop over
+    the same solver class, the same point at the end, three pattern groups (first, inner, last time blocks)."""
+    from hostsim_engine import HostSimDeviceEngine
+    T = 6
+    it, hist, _ = _device_loop(_time_blocks(T, ARGS), HostSimDeviceEngine())
+    assert sorted(len(pg.members) for pg in it.pattern_groups) == [1, 1, T - 2]
+    assert sorted((pg.nfs, pg.nfw) for pg in it.pattern_groups) == [(0, 8), (8, 0), (8, 8)]
+    host, rows = _host_history(T, ARGS, _product_solver_on_cpu(T))
+    _same_iterations(rows, hist)
+    _same_point(it, host, T, 1e-7)
+    mono, off = _monolithic(T, ARGS)
+    assert abs(it.evaluate_objective() - mono.evaluate_objective()) <= 1e-7
+
+
+def test_device_dynamic_loop_regularises_like_the_host_loop():
+    """A rank-deficient Jacobian in every time block: every iteration goes through the inertia-correction retries -- on the
+    device as diagonal shifts of the resident values, with the rows of the forward multipliers in the coupling block
+    classed as constraint rows (sc_ip_interface.py:903-933)."""
+    from hostsim_engine import HostSimDeviceEngine
+    T, args = 5, dict(ARGS, duplicate_constraint=True)
+    it, hist, _ = _device_loop(_time_blocks(T, args), HostSimDeviceEngine())
+    assert it.solver.diagonal_shift_refactorizations >= len(hist) - 1
+    host, rows = _host_history(T, args, _product_solver_on_cpu(T))
+    assert all(r[9] > 0 for r in rows[1:])                       # the Reg column: every iteration was regularised
+    _same_iterations(rows, hist, primal_noise=1e-6)
+    _same_point(it, host, T, 1e-6)
+
+
+def test_two_rank_device_dynamic_loop():
+    _two_rank_run('--device-producer')
+
+
+@pytest.mark.gpu
+def test_two_rank_device_dynamic_loop_on_the_device():
+    _two_rank_run('--device-producer', '--gpu')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('T,args', [(6, ARGS), (24, dict(nfe_per_block=4, n_states=20, n_controls=3, nu=0.01)),
+                                    (5, dict(ARGS, duplicate_constraint=True))])
+def test_device_dynamic_loop_kernels_match_their_numpy_restatement(T, args):
+    """The same loop on the HIP kernels and on their numpy restatement: the same iterations, measures to rounding (the
+    two solvers sum in different orders), no torch operator in an iteration."""
+    from hostsim_engine import HostSimDeviceEngine
+    blocks = _time_blocks(T, args)
+    it, hist, stats = _device_loop(blocks, None)
+    ref, ref_hist, _ = _device_loop(blocks, HostSimDeviceEngine())
+    regularised = bool(args.get('duplicate_constraint'))
+    # (a retry of the inertia-correction loop sends the shifted corner of the coupling block from the host: the only
+    # torch operators of the loop)
+    assert len(hist) == len(ref_hist) and (stats['torch_ops'] == 0 or regularised)
+    for a, b in zip(hist, ref_hist):
+        assert np.allclose(a[1:6], b[1:6], rtol=1e-6, atol=2e-9), (a, b)
+        assert abs(a[0] - b[0]) <= 1e-6 * abs(b[0]) + (1e-6 if regularised else 2e-9), (a, b)     # see _same_iterations
+    assert np.abs(it.coupling_states() - ref.coupling_states()).max() <= 1e-7
+    for t in range(T):
+        assert np.abs(it.scenario_primals(t) - ref.scenario_primals(t)).max() <= 1e-7
+
+
+@pytest.mark.gpu
+def test_device_dynamic_loop_at_a_longer_horizon_against_the_oracle_solver():
+    """96 time blocks x 30 states (coupling block 5700, block-tridiagonal S on the device) against the host loop over
+    the oracle's solver classes."""
+    T, args = 96, dict(nfe_per_block=4, n_states=30, n_controls=3, nu=0.005)
+    it, hist, stats = _device_loop(_time_blocks(T, args), None)
+    ref = dq.main(_oracle_solver(range(T)), 0.0, 1.0, T, **args)
+    assert abs(it.evaluate_objective() - ref.evaluate_objective()) <= 1e-6
+    _same_point(it, ref, T, 2e-5)
