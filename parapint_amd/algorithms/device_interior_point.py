@@ -92,6 +92,7 @@ def ip_solve_device(interface, options=None, timer=None, history=None, stats=Non
         stats['loop_s'] = time.time() - t_loop
         stats['iteration_s'] = [b - a for a, b in zip(stamps, stamps[1:])]
         stats['torch_ops'] = counter.close() if counter is not None else None
+        stats['torch_op_names'] = dict(counter.names) if counter is not None else None
     return status, iterations
 
 
@@ -100,7 +101,7 @@ class _torch_op_counter(object):
     the library's kernels alone; None if torch is not importable -- the CPU tests' numpy engines)."""
 
     def __init__(self):
-        self.count, self._mode = 0, None
+        self.count, self._mode, self.names = 0, None, {}
         try:
             from torch.utils._python_dispatch import TorchDispatchMode
         except Exception:
@@ -110,6 +111,7 @@ class _torch_op_counter(object):
         class _Mode(TorchDispatchMode):
             def __torch_dispatch__(self, func, types, args=(), kwargs=None):
                 outer.count += 1
+                outer.names[str(func)] = outer.names.get(str(func), 0) + 1
                 return func(*args, **(kwargs or {}))
         self._mode = _Mode()
         self._mode.__enter__()
