@@ -24,8 +24,23 @@ from parapint_amd.interfaces.schur_complement.sc_ip_interface import MPIDynamicS
 
 
 class DiffusionControl(MPIDynamicSchurComplementInteriorPointInterface):
-    def __init__(self, start_t, end_t, num_time_blocks, nfe_per_block=4, n_states=8, n_controls=2, comm=None,
-                 u_max=1.5, y_max=0.9, rate=4.0, r=1e-2, nu=0.05, duplicate_constraint=False):
+    def __init__(self, start_t, end_t, num_time_blocks, nfe_per_block=4, n_states=8, n_controls=2, comm=None, **model):
+        self._configure(nfe_per_block, n_states, n_controls, **model)
+        super(DiffusionControl, self).__init__(start_t, end_t, num_time_blocks, comm=comm)
+
+    @classmethod
+    def time_blocks(cls, start_t, end_t, num_time_blocks, local=None, **problem_args):
+        """[(QuadraticProgram, start states, end states) or None] over the time blocks: what the interface asks
+        build_model_for_time_block for, without the interface (the device-resident producer takes this list); local: the
+        blocks to build (default all)."""
+        self = cls.__new__(cls)
+        self._configure(**problem_args)
+        T, dt = int(num_time_blocks), (end_t - start_t) / num_time_blocks
+        keep = set(range(T)) if local is None else set(local)
+        return [self.build_model_for_time_block(t, dt * t, dt * (t + 1), t == 0) if t in keep else None for t in range(T)]
+
+    def _configure(self, nfe_per_block=4, n_states=8, n_controls=2, u_max=1.5, y_max=0.9, rate=4.0, r=1e-2, nu=0.05,
+                   duplicate_constraint=False):
         self.nfe, self.n_s, self.n_u = int(nfe_per_block), int(n_states), int(n_controls)
         self.u_max, self.y_max, self.rate, self.r, self.nu = u_max, y_max, rate, r, nu
         # the last dynamics equation of every time block stated twice: a rank-deficient Jacobian, the KKT matrix is
@@ -42,7 +57,6 @@ class DiffusionControl(MPIDynamicSchurComplementInteriorPointInterface):
         self.B = coo_matrix(B)
         self.grid = grid
         self.y_init = 0.2 * np.sin(np.pi * grid)
-        super(DiffusionControl, self).__init__(start_t, end_t, num_time_blocks, comm=comm)
 
     # ---- indices inside a time block
     def ys(self, k):

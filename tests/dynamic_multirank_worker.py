@@ -35,8 +35,7 @@ def run_device(comm):
     from parapint_amd.algorithms.device_interior_point import ip_solve_device
     from parapint_amd.algorithms.interior_point import IPOptions, InteriorPointStatus
     from parapint_amd.interfaces.schur_complement.device_sc_ip_interface import DeviceDynamicQPInterface
-    host = dynamics_qp.DiffusionControl(0.0, 1.0, T, **ARGS)
-    blocks = [host.build_model_for_time_block(t, t / T, (t + 1) / T, t == 0) for t in range(T)]
+    blocks = dynamics_qp.DiffusionControl.time_blocks(0.0, 1.0, T, **ARGS)
     it = DeviceDynamicQPInterface(blocks, comm=comm)
     opt = IPOptions()
     opt.linalg.solver = HipSchurComplementLinearSolver({t: None for t in it.local}, None, comm=comm,

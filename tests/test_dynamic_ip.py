@@ -165,8 +165,7 @@ def test_dynamic_loop_over_the_hip_solver():
 
 # ---- the device-resident producer for time blocks (DeviceDynamicQPInterface; include/parapint_hip.h: mapped groups) -----
 def _time_blocks(T, args):
-    host = dq.DiffusionControl(0.0, 1.0, T, **args)
-    return [host.build_model_for_time_block(t, t / T, (t + 1) / T, t == 0) for t in range(T)]
+    return dq.DiffusionControl.time_blocks(0.0, 1.0, T, **args)
 
 
 def _device_loop(blocks, engine, comm=None, local=None):

@@ -577,7 +577,7 @@ def test_bench_line_reports_the_ip_loop_and_the_boundary_rate():
     """Round 3: the default line carries `ip_loop` (the interior-point loop with device-resident iterates converged) and
     `value_boundary` (SURVEY 8(d) to the letter: host containers in and out)."""
     res = _run_bench({}, '--steps', '5', '--warmup', '2', '--no-cpu-baseline', '--boundary-iterations', '2',
-                     '--ip-scenarios', '256', '--profile-steps', '1')
+                     '--ip-scenarios', '256', '--profile-steps', '1', '--ip-time-blocks', '64')
     assert res['correct'] is True
     ipl = res['ip_loop']
     assert ipl['converged'] is True and ipl['iterations'] > 5 and ipl['it_per_s'] > 0
@@ -589,6 +589,10 @@ def test_bench_line_reports_the_ip_loop_and_the_boundary_rate():
     assert set(ipl['step_kernels']) == {'rhs', 'step_lengths', 'take_step', 'residuals'}
     assert all(0.05 < v['frac_of_hbm_peak'] < 1.0 for v in ipl['step_kernels'].values())
     assert res['value_boundary'] == res['boundary_host']['it_per_s'] > 0
+    # the time-staged counterpart (here 64 time blocks of the C4 shape): converged, block-tridiagonal coupling block
+    dyn = res['ip_loop_dynamic']
+    assert dyn['converged'] is True and dyn['time_blocks'] == 64 and dyn['n_coupling'] == 2 * 49 * 63
+    assert dyn['block_dim'] == 4254 and max(dyn['final_infeasibilities']) <= 1e-8 and dyn['torch_ops_per_iteration'] <= 5
 
 
 def test_pivot_growth_guard():

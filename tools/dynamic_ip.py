@@ -22,8 +22,7 @@ def main():
     from parapint_amd.linalg.comm import SerialComm
     from parapint_amd.linalg.hip_schur_complement import HipSchurComplementLinearSolver
     args = dict(nfe_per_block=nfe, n_states=ns, n_controls=nu, nu=0.15 / (ns + 1) ** 2 * T * nfe)    # (stable explicit Euler)
-    host = dq.DiffusionControl(0.0, 1.0, T, **args)
-    blocks = [host.build_model_for_time_block(t, t / T, (t + 1) / T, t == 0) for t in range(T)]
+    blocks = dq.DiffusionControl.time_blocks(0.0, 1.0, T, **args)
     out = dict(time_blocks=T, states=ns, controls=nu, steps_per_block=nfe, block_dim=int(blocks[1][0].n), n_coupling=2 * ns * (T - 1))
     for rep in range(2):
         it = DeviceDynamicQPInterface(blocks)
