@@ -607,9 +607,7 @@ def main():
                    'final_infeasibilities': list(hist[-1][:3]) if hist else None, 'objective': ipi.evaluate_objective(),
                    'time_blocks': Tb, 'time_blocks_per_gpu': len(mine_t), 'states': ns_d, 'primal_variables_per_block': pg.n,
                    'block_dim': pg.nb, 'n_coupling': 2 * ipi.ncz,
-                   'torch_ops_per_iteration': (ipst.get('torch_ops') or 0) / max(ip_iters, 1),
-                   'note': 'the block-tridiagonal coupling solve permutes r_s / x_s with 4 torch operators per back-solve; '
-                           'everything else of an iteration is the library\'s kernels'}
+                   'torch_ops_in_the_loop': ipst.get('torch_ops') or 0}
             if best is None or cur['it_per_s'] > best['it_per_s']:
                 best = cur
             del ipi, ipo

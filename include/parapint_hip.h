@@ -356,6 +356,10 @@ int pp_vec_step_stats(pp_handle h, int64_t n, const double* x, const double* dx,
                       double out_host[4]);
 int pp_vec_max_abs(pp_handle h, int64_t n, const double* v, double* out_host);
 int pp_vec_axpy(pp_handle h, int64_t n, double alpha, const double* x, double* y);
+/* scatter != 0: dst[0..ndst) = 0, dst[idx[i]] = src[i]; else dst[i] = src[idx[i]] (i < n; idx: int64 on the device, the caller
+ * guarantees its range).  The coupling block of a time-staged problem between the caller's ordering and the padded ordering
+ * under which S is block tridiagonal (mpi_explicit_schur_complement.py:88-125). */
+int pp_vec_permute(pp_handle h, int64_t n, const int64_t* idx, const double* src, double* dst, int64_t ndst, int scatter);
 
 /* ---- f2 / f4: the interior-point step on device-resident iterates ---------------------------------------
  * What parapint's interfaces and ip_solve do around the linear solve in every iteration -- barrier diagonals of the KKT

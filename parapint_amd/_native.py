@@ -110,6 +110,8 @@ SIGNATURES = {
                           [ctypes.c_double, ctypes.c_double, _f64p]),
     'pp_vec_max_abs': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, _f64p]),
     'pp_vec_axpy': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
+    'pp_vec_permute': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_int64, ctypes.c_int]),
     'pp_ip_rhs': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_double]),
     'pp_ip_step_lengths': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_double, ctypes.c_double,
                                           ctypes.c_void_p]),

@@ -100,6 +100,17 @@ __global__ __launch_bounds__(256) void k_vec_max_abs(size_t n, const double* __r
 
 }  // namespace
 
+// dst[idx[i]] = src[i] resp. dst[i] = src[idx[i]]: the ordering of the coupling variables under which S is block
+// tridiagonal (padded) <-> the caller's ordering
+__global__ __launch_bounds__(256) void k_vec_scatter(size_t n, const int64_t* __restrict__ idx, const double* __restrict__ src,
+                                                     double* __restrict__ dst) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[idx[i]] = src[i];
+}
+__global__ __launch_bounds__(256) void k_vec_gather(size_t n, const int64_t* __restrict__ idx, const double* __restrict__ src,
+                                                    double* __restrict__ dst) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[idx[i]];
+}
+
 extern "C" {
 
 // ---- f4: vector kernels of the step after the solve (device-resident vectors) ------------------------------------
@@ -161,5 +172,16 @@ int pp_vec_axpy(pp_handle h, int64_t n, double alpha, const double* x, double* y
   return 0;
 }
 
+int pp_vec_permute(pp_handle h, int64_t n, const int64_t* idx, const double* src, double* dst, int64_t ndst, int scatter) {
+  if (!h || n < 0 || ndst < 0 || (n > 0 && (!idx || !src || !dst))) return fail(h, 3, "pp_vec_permute: bad arguments");
+  PP_HIP(hipSetDevice(h->device));
+  if (scatter && ndst > 0) PP_HIP(hipMemsetAsync(dst, 0, (size_t)ndst * sizeof(double), h->stream));
+  if (n == 0) return 0;
+  const dim3 grid((unsigned)std::min<int64_t>(1024, (n + 255) / 256));
+  if (scatter) hipLaunchKernelGGL(k_vec_scatter, grid, dim3(256), 0, h->stream, (size_t)n, idx, src, dst);
+  else hipLaunchKernelGGL(k_vec_gather, grid, dim3(256), 0, h->stream, (size_t)n, idx, src, dst);
+  PP_HIP(hipGetLastError());
+  return 0;
+}
 
 }  // extern "C"

@@ -315,6 +315,20 @@ class HipEngine(object):
     def copy_coupling_solution(self, tensor):
         self.ns.check(self.lib.pp_copy_coupling_solution(self.ns.h, tensor.data_ptr()), 'pp_copy_coupling_solution')
 
+    def index_tensor(self, idx):
+        """int64 index array on the device (for permute)."""
+        torch = self._torch
+        return torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int64)).to(torch.device('cuda', self.device))
+
+    def permute(self, idx_t, src, dst, scatter):
+        """scatter: dst = 0, dst[idx] = src; else dst = src[idx] (stream-ordered on the solver's stream)."""
+        import ctypes
+        n = int(idx_t.numel())
+        if (src.numel() if scatter else dst.numel()) < n or not src.is_contiguous() or not dst.is_contiguous():
+            raise ValueError('permute: operands do not match the index array')
+        self.ns.check(self.lib.pp_vec_permute(self.ns.h, ctypes.c_int64(n), idx_t.data_ptr(), src.data_ptr(), dst.data_ptr(),
+                                              ctypes.c_int64(dst.numel()), 1 if scatter else 0), 'pp_vec_permute')
+
     def upload_values(self, gid, raw):
         self.ns.check(self.lib.pp_upload_values(self.ns.h, gid, raw.ctypes.data, 0), 'pp_upload_values')
 

@@ -1488,20 +1488,19 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         self._prefetch_rhs = self._forward_done_for = None
         rc_dev = rhs.coupling if self._nc > 0 else None
         if self._btd is not None and rc_dev is not None:
-            import torch
+            # r_s into the (padded) ordering under which S is block tridiagonal, x_s back: two small library kernels
             if self._cinv_t is None or self._cinv_t.numel() != self._nc:
-                self._cinv_t = torch.from_numpy(self._cinv).to(rc_dev.device)
+                self._cinv_t = self._eng.index_tensor(self._cinv)
                 self._rc_pad = self._eng.new_tensor((self._btd[0] * self._btd[1],))
                 self._xc_pad = self._eng.new_tensor((self._btd[0] * self._btd[1],))
-            self._rc_pad.zero_()
-            self._rc_pad[self._cinv_t] = rc_dev
+            self._eng.permute(self._cinv_t, rc_dev, self._rc_pad, scatter=True)
             rc_dev = self._rc_pad
         self._eng.solve_coupling_dev(rc_dev)
         self._eng.solve_backward()
         if self._nc > 0:
             if self._btd is not None:
                 self._eng.copy_coupling_solution(self._xc_pad)
-                out.coupling.copy_(self._xc_pad[self._cinv_t])
+                self._eng.permute(self._cinv_t, self._xc_pad, out.coupling, scatter=False)
             else:
                 self._eng.copy_coupling_solution(out.coupling)
         timer.stop('back_solve')

@@ -483,3 +483,14 @@ class HostSimDeviceEngine(HostSimEngine):
 
     def copy_coupling_solution(self, tensor):
         tensor[...] = self.xc[:tensor.shape[0]]
+
+    def index_tensor(self, idx):
+        return np.ascontiguousarray(idx, dtype=np.int64).view(NpTensor)
+
+    def permute(self, idx_t, src, dst, scatter):
+        idx = np.asarray(idx_t)
+        if scatter:
+            dst[...] = 0.0
+            np.asarray(dst)[idx] = np.asarray(src)[:idx.size]
+        else:
+            np.asarray(dst)[:idx.size] = np.asarray(src)[idx]

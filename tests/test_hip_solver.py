@@ -592,7 +592,7 @@ def test_bench_line_reports_the_ip_loop_and_the_boundary_rate():
     # the time-staged counterpart (here 64 time blocks of the C4 shape): converged, block-tridiagonal coupling block
     dyn = res['ip_loop_dynamic']
     assert dyn['converged'] is True and dyn['time_blocks'] == 64 and dyn['n_coupling'] == 2 * 49 * 63
-    assert dyn['block_dim'] == 4254 and max(dyn['final_infeasibilities']) <= 1e-8 and dyn['torch_ops_per_iteration'] <= 5
+    assert dyn['block_dim'] == 4254 and max(dyn['final_infeasibilities']) <= 1e-8 and dyn['torch_ops_in_the_loop'] <= 6
 
 
 def test_pivot_growth_guard():
