@@ -37,6 +37,30 @@ def main():
                                       ms_per_iteration=1e3 * stats['loop_s'] / max(iters, 1), wall_seconds=time.time() - t0,
                                       torch_ops=stats['torch_ops'], torch_op_names=stats['torch_op_names'],
                                       objective=it.evaluate_objective())
+    # where an iteration goes: one more run with the library's phase events on (no overlap between phases while they are)
+    import ctypes
+    import numpy as np
+    it = DeviceDynamicQPInterface(blocks)
+    opt = IPOptions()
+    opt.linalg.solver = HipSchurComplementLinearSolver({t: None for t in range(T)}, None, comm=SerialComm(), result_buffers=2)
+    lib, h = opt.linalg.solver._eng.lib, opt.linalg.solver._eng.ns.h
+    lib.pp_profile(h, 1)
+    _, iters = ip_solve_device(it, opt)
+    torch.cuda.synchronize()
+    ms8, l8, c8 = np.zeros(8), np.zeros(8, dtype=np.int32), np.zeros(8, dtype=np.int32)
+    ms4, l4, c4 = np.zeros(4), np.zeros(4, dtype=np.int32), np.zeros(4, dtype=np.int32)
+    dp, ip32 = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)
+    lib.pp_phase_times(h, ms8.ctypes.data_as(dp), l8.ctypes.data_as(ip32), c8.ctypes.data_as(ip32))
+    lib.pp_ip_phase_times(h, ms4.ctypes.data_as(dp), l4.ctypes.data_as(ip32), c4.ctypes.data_as(ip32))
+    lib.pp_profile(h, 0)
+    names = ('assemble', 'factor_levels', 'schur_tiles', 'dense_S', 'fwd_levels', 'fwd_coupling', 'coupling_solve', 'bwd_levels')
+    out['phases_ms_per_iteration'] = {n: float(ms8[i]) / max(iters, 1) for i, n in enumerate(names)}
+    out['phases_ms_per_iteration'].update({n: float(ms4[i]) / max(iters, 1)
+                                           for i, n in enumerate(('ip_rhs', 'ip_step_lengths', 'ip_take_step', 'ip_residuals'))})
+    out['phase_launches_per_iteration'] = {n: int(l8[i]) // max(iters, 1) for i, n in enumerate(names)}
+    paths = (ctypes.c_int32 * 2)()
+    if hasattr(lib, 'pp_bcr_block_paths') and lib.pp_bcr_block_paths(h, ctypes.cast(paths, ip32)) == 0:
+        out['bcr_blocks_unpivoted_pivoted_last_factorisation'] = [int(paths[0]), int(paths[1])]
     t0 = time.time()
     ref = dq.main(HipSchurComplementLinearSolver({t: None for t in range(T)}, None, comm=SerialComm()), 0.0, 1.0, T, **args)
     out['host_producer'] = dict(wall_seconds=time.time() - t0, objective=ref.evaluate_objective())

@@ -5,6 +5,7 @@
 #   pmc/*_per_kernel.csv, pmc_traffic.json        separate --pmc FETCH_SIZE / WRITE_SIZE passes
 #   bench_C2.json, bench_C4.json, kernel_stats_C4.csv, bench_128_blocks.json, bench_C5.json, bench_C5_512_blocks.json
 #   ip_loop.json, kernel_stats_ip_loop.csv    the interior-point loop at C3 dimensions (tools/ip_c3.py), plain and under rocprofv3 --stats
+#   dynamic_ip_loop.json, kernel_stats_dynamic_ip_loop.csv    the loop of a time-staged problem at the C4 dimensions (tools/dynamic_ip.py)
 #   mfma_util.json, mfma_util_C4.json, mfma_util_C5.json    own --pmc SQ_VALU_MFMA_BUSY_CYCLES passes (matrix-core kernels)
 tag=${1:-final}
 out=gpurun_out/$tag
@@ -40,6 +41,8 @@ python3 tools/pmc_traffic.py $out/pmc_fetch $out/pmc_write $raw $n $batch $out/p
 echo "pmc done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_ip -- python3 tools/ip_c3.py 1024 > $out/ip_loop_under_rocprof.json 2> $out/stats_ip.err && cp $(find $out/stats_ip -name '*kernel_stats.csv' | head -1) $out/kernel_stats_ip_loop.csv
 python3 tools/ip_c3.py 1024 > $out/ip_loop.json 2> $out/ip_loop.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_dyn -- python3 tools/dynamic_ip.py 512 49 2 40 > $out/dynamic_ip_loop_under_rocprof.json 2> $out/stats_dyn.err && cp $(find $out/stats_dyn -name '*kernel_stats.csv' | head -1) $out/kernel_stats_dynamic_ip_loop.csv
+python3 tools/dynamic_ip.py 512 49 2 40 > $out/dynamic_ip_loop.json 2> $out/dynamic_ip_loop.err
 python3 bench.py --workload C2 --no-cpu-baseline > $out/bench_C2.json 2> $out/c2.err
 python3 bench.py --blocks 128 --no-cpu-baseline --no-boundary --no-ip-loop > $out/bench_128_blocks.json 2> $out/b128.err
 python3 bench.py --workload C4 --no-cpu-baseline --steps 10 --warmup 2 > $out/bench_C4.json 2> $out/c4.err
@@ -53,7 +56,7 @@ python3 bench.py --workload C5 --no-cpu-baseline --no-boundary --no-ip-loop --st
 python3 bench.py --workload C5 --blocks 512 --no-cpu-baseline --no-boundary --no-ip-loop --steps 10 --warmup 2 --value-sets 2 --profile-steps 2 > $out/bench_C5_512_blocks.json 2> $out/c5b.err
 find $out -name '*kernel_trace.csv' -delete
 find $out -name '*counter_collection.csv' -delete
-rm -rf $out/stats $out/stats_ip $out/stats_C4 $out/stats_C5 $out/pmc_fetch $out/pmc_write $out/pmc_mfma $out/pmc_mfma_C4 $out/pmc_mfma_C5
+rm -rf $out/stats $out/stats_ip $out/stats_dyn $out/stats_C4 $out/stats_C5 $out/pmc_fetch $out/pmc_write $out/pmc_mfma $out/pmc_mfma_C4 $out/pmc_mfma_C5
 for f in bench_default bench_C2 bench_128_blocks bench_C4 bench_C5 bench_C5_512_blocks; do python3 - $out/$f.json <<'PY'
 import json, sys
 try:
