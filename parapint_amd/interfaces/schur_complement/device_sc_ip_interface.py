@@ -516,6 +516,8 @@ class DeviceDynamicQPInterface(DeviceStochasticQPInterface):
         self.N = T = len(self.time_blocks)
         if self.comm.size > T:
             raise ValueError('Cannot yet handle more processes than time blocks')    # mpi_sc_ip_interface.py:79-80
+        if T < 2:
+            raise ValueError('a time-staged problem needs at least two time blocks (one has no coupling states)')
         self.local = [ndx for ndx in range(T) if ndx % self.comm.size == self.comm.rank]
         self._relax = bounds_relaxation_factor
         self.scenarios = [None if blk is None else blk[0] for blk in self.time_blocks]

@@ -96,6 +96,11 @@ class HipIpOps(object):
             if zoff is not None and (not zoff.is_cuda or not zoff.is_contiguous() or zoff.dtype != self._torch.int32 or
                                      tuple(zoff.shape) != (2, int(d['bpad']))):
                 raise ValueError('interior-point step: zoff must be a contiguous [2][bpad] int32 device tensor')
+            if zoff is not None:
+                # the kernels index the coupling vectors with these offsets: checked once, here, on a host copy
+                zo = zoff.cpu().numpy()
+                if zo.min() < 0 or zo[0].max() + q.nfs > q.ncz or zo[1].max() + q.nfw > q.ncz:
+                    raise ValueError('interior-point step: zoff points outside the %d coupling states' % q.ncz)
             q.zoff = None if zoff is None else zoff.data_ptr()
             for k in ('W', 'bounds', 'data', 'src', 'G', 'rhs', 'prog', 'terms'):
                 t = d[k]

@@ -396,21 +396,22 @@ def _step_problem(seed, shapes):
     return descs, rng.normal(size=nfs), rng.normal(size=nfs)
 
 
-def _run_step_sequence(ops, descs, z, dz, mu, tau, nranks=1):
-    """take_step (no step) -> residuals -> publish -> rhs -> step lengths -> take_step -> residuals -> publish."""
+def _run_step_sequence(ops, descs, z, dz, mu, tau, nranks=1, ncoup=None, dual_from=0):
+    """take_step (no step) -> residuals -> publish -> rhs -> step lengths -> take_step -> residuals -> publish.
+    ncoup / dual_from: rows of the coupling block and where its variables start (mapped groups: 2 ncz, ncz)."""
     dev = []
     for d in descs:
         dd = {k: (ops.from_host(v) if isinstance(v, np.ndarray) else v) for k, v in d.items() if k != 'delta'}
         dev.append(dd)
     hd = ops.prepare(dev)
-    nfs = descs[0]['nfs']
+    nfs = descs[0]['nfs'] if ncoup is None else ncoup
     zt, dzt = ops.from_host(z.copy()), ops.from_host(dz.copy())
     alpha, v = ops.zeros((2,)), ops.zeros((8 + nfs,))
     rc = ops.zeros((max(nfs, 1),))
     out = {}
     ops.take_step(hd, None, 1, False, mu, zt, None)
     ops.residuals(hd, zt, v)
-    ops.publish(v, None, 1, nfs, 0, rc)
+    ops.publish(v, None, 1, nfs, dual_from, rc)
     out['mail0'] = ops.wait()
     out['v0'] = ops.to_host(v).copy()
     ops.rhs(hd, mu)
@@ -422,7 +423,7 @@ def _run_step_sequence(ops, descs, z, dz, mu, tau, nranks=1):
     out['alpha'] = ops.to_host(alpha).copy()
     ops.take_step(hd, alpha, 1, False, mu, zt, dzt)
     ops.residuals(hd, zt, v)
-    ops.publish(v, alpha, 1, nfs, 0, rc)
+    ops.publish(v, alpha, 1, nfs, dual_from, rc)
     out['mail1'] = ops.wait()
     out['W1'] = [ops.to_host(d['W']).copy() for d in dev]
     out['G1'] = [ops.to_host(d['G']).copy() for d in dev]

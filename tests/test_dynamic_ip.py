@@ -246,6 +246,24 @@ def test_device_dynamic_loop_on_cpu_engines_matches_the_host_loop():
     assert abs(it.evaluate_objective() - mono.evaluate_objective()) <= 1e-7
 
 
+def test_device_dynamic_loop_with_two_time_blocks_and_refused_inputs():
+    """Two time blocks: no inner pattern group, one coupling state set; one time block, or more ranks than blocks: refused."""
+    from hostsim_engine import HostSimDeviceEngine
+    from parapint_amd.interfaces.schur_complement.device_sc_ip_interface import DeviceDynamicQPInterface
+    it, hist, _ = _device_loop(_time_blocks(2, ARGS), HostSimDeviceEngine())
+    assert sorted((pg.nfs, pg.nfw) for pg in it.pattern_groups) == [(0, 8), (8, 0)] and it.ncz == 8
+    host, rows = _host_history(2, ARGS, _product_solver_on_cpu(2))
+    _same_iterations(rows, hist)
+    _same_point(it, host, 2, 1e-7)
+    with pytest.raises(ValueError, match='at least two time blocks'):
+        DeviceDynamicQPInterface(_time_blocks(2, ARGS)[:1])
+
+    class Three(object):
+        rank, size = 0, 3
+    with pytest.raises(ValueError, match='more processes than time blocks'):
+        DeviceDynamicQPInterface(_time_blocks(2, ARGS), comm=Three())
+
+
 def test_device_dynamic_loop_regularises_like_the_host_loop():
     """A rank-deficient Jacobian in every time block: every iteration goes through the inertia-correction retries -- on the
     device as diagonal shifts of the resident values, with the rows of the forward multipliers in the coupling block
@@ -317,3 +335,82 @@ def test_device_dynamic_loop_at_a_longer_horizon_against_the_host_producer():
     _same_iterations(rows, hist)
     _same_point(it, host, T, 1e-6)
     assert abs(it.evaluate_objective() - host.evaluate_objective()) <= 1e-8
+
+
+def _mapped_step_problem(seed, ns=5, inner=70, n=33, me=9, mi=4):
+    """Random iterates for three mapped groups laid out like time blocks (first: forward link only, `inner` blocks with
+    both links, last: backward link only) over ncz = ns * (inner + 1) coupling states; host arrays [row][instance]."""
+    from test_device_ip import random_stochastic_qp
+    from parapint_amd.interfaces.schur_complement.device_sc_ip_interface import _PatternGroup
+    rng = np.random.default_rng(seed)
+    T = inner + 2
+    ncz = ns * (T - 1)
+    descs = []
+    for gi, (lanes, has_b, has_f) in enumerate((([0], False, True), (list(range(1, T - 1)), True, True), ([T - 1], True, False))):
+        qps, fs = random_stochastic_qp(1, n=n, n_fs=ns, n_eq=me, n_ineq=mi, seed=seed + gi)
+        fsb = np.asarray(fs[0]) if has_b else np.zeros(0, dtype=np.int64)
+        ff = (np.asarray(fs[0]) + 7) % n if has_f else np.zeros(0, dtype=np.int64)
+        pg = _PatternGroup(qps[0], fsb, ff, mapped=True)
+        prog, terms = pg.row_programs()
+        B = len(lanes)
+        bpad = -(-B // 64) * 64
+        nb, nfw = pg.nb, pg.nfw
+        W = rng.uniform(0.5, 2.0, size=(nb + 2 * n + 2 * mi + nfw, bpad))
+        W[n + mi:nb] = rng.normal(size=(nb - n - mi, bpad))
+        W[nb + 2 * n + 2 * mi:] = rng.normal(size=(nfw, bpad))                 # copies of the forward multipliers
+        lo = W[:n + mi] - rng.uniform(0.1, 1.0, size=(n + mi, bpad))
+        hi = W[:n + mi] + rng.uniform(0.1, 1.0, size=(n + mi, bpad))
+        lo[rng.random(lo.shape) < 0.3] = -np.inf
+        hi[rng.random(hi.shape) < 0.3] = np.inf
+        bounds = np.concatenate([lo[:n], hi[:n], lo[n:], hi[n:]])
+        e = nb + 2 * n + 2 * mi
+        zl = np.concatenate([W[nb:nb + n], W[nb + 2 * n:nb + 2 * n + mi]])
+        zu = np.concatenate([W[nb + n:nb + 2 * n], W[nb + 2 * n + mi:e]])
+        zl[~np.isfinite(lo)] = 0.0
+        zu[~np.isfinite(hi)] = 0.0
+        W[nb:nb + n], W[nb + 2 * n:nb + 2 * n + mi] = zl[:n], zl[n:]
+        W[nb + n:nb + 2 * n], W[nb + 2 * n + mi:e] = zu[:n], zu[n:]
+        src = np.zeros((pg.nsrc, bpad))
+        src[:pg.off[3]] = rng.normal(size=(pg.off[3], bpad))
+        full = lanes + [lanes[0]] * (bpad - B)
+        zoff = np.zeros((2, bpad), dtype=np.int32)
+        zoff[0] = [ns * (t - 1) if t > 0 else 0 for t in full]
+        zoff[1] = [ns * t if t < T - 1 else 0 for t in full]
+        descs.append(dict(n=n, mi=mi, me=me, nfs=pg.nfs, nfw=nfw, ncz=ncz, zoff=zoff, batch=B, bpad=bpad,
+                          src_dp=int(pg.off[3]), src_ds=int(pg.off[4]), W=W, bounds=bounds,
+                          data=rng.normal(size=(n + me, bpad)), src=src, G=np.zeros((n, bpad)), rhs=np.zeros((nb, bpad)),
+                          prog=prog, terms=terms, delta=rng.normal(size=(nb, bpad))))
+    return descs, rng.normal(size=ncz), rng.normal(size=2 * ncz), ncz
+
+
+@pytest.mark.gpu
+def test_mapped_step_kernels_match_their_numpy_restatement():
+    """The step kernels on mapped groups (per-instance coupling offsets, forward multipliers kept per instance, coupling
+    right-hand side scattered) against the numpy restatement: elementwise results, step lengths, max-norms and the
+    scattered coupling rows bit for bit (every coupling entry has at most two addends), sums to rounding."""
+    from hostsim_ip_ops import HostSimIpOps
+    from test_device_ip import _run_step_sequence
+    from parapint_amd.linalg.hip_schur_complement import HipEngine
+    descs, z, dz, ncz = _mapped_step_problem(23)
+    mu, tau = 0.1, 0.9
+    copy = [dict(d, **{k: v.copy() for k, v in d.items() if isinstance(v, np.ndarray)}) for d in descs]
+    ref = _run_step_sequence(HostSimIpOps(), copy, z, dz, mu, tau, ncoup=2 * ncz, dual_from=ncz)
+    got = _run_step_sequence(HipEngine().ip_ops(), descs, z, dz, mu, tau, ncoup=2 * ncz, dual_from=ncz)
+    assert np.array_equal(got['alpha'], ref['alpha']) and 0.0 < ref['alpha'].min() < 1.0
+    for key in ('rhs0', 'src0', 'W1', 'G1', 'rhs1', 'src1'):
+        for gi, (a, b) in enumerate(zip(got[key], ref[key])):
+            B = descs[gi]['batch']
+            assert np.array_equal(a[:, :B], b[:, :B]), (key, gi, np.abs(a[:, :B] - b[:, :B]).max())
+    assert np.array_equal(got['z1'], ref['z1'])
+    assert np.array_equal(got['rc1'], ref['rc1']) and np.array_equal(got['v0'][8:], ref['v0'][8:])     # scattered rows
+    assert np.abs(ref['rc1'][:ncz]).min() > 0 and np.abs(ref['rc1'][ncz:]).min() > 0                  # every entry written
+    for key in ('mail0', 'mail1'):
+        a, b = got[key], ref[key]
+        assert np.array_equal(a[[0, 1, 2, 3, 7, 8]], b[[0, 1, 2, 3, 7, 8]]), (key, a, b)                # max / min: exact
+        assert np.allclose(a[[4, 5, 6]], b[[4, 5, 6]], rtol=1e-13, atol=0.0), (key, a, b)
+    # offsets outside the coupling states are refused before any kernel sees them
+    bad = dict(descs[1], zoff=descs[1]['zoff'].copy())
+    bad['zoff'][1, 3] = ncz - 2
+    ops = HipEngine().ip_ops()
+    with pytest.raises(ValueError, match='outside'):
+        ops.prepare([{k: (ops.from_host(v) if isinstance(v, np.ndarray) else v) for k, v in bad.items() if k != 'delta'}])
