@@ -142,8 +142,6 @@ int pp_add_group_mapped(pp_handle h, int n, int batch, int nnzK, const int32_t* 
   }
   g->nc_loc = nc_loc;
   if (cmap) g->cmap_host.assign(cmap, cmap + (size_t)batch * nc_loc);
-  int rc = pp::build_plan(n, nc_loc, nnzK, rowK, colK, nnzB, rowB, colB, rep_vals, opt, g->plan);
-  if (rc != 0) { std::string e = g->plan.error; delete g; return fail(h, rc, "symbolic analysis failed: " + e); }
   const int ncan = nnzK + nnzB;
   g->diag_can.assign((size_t)n, -1);
   for (int e = 0; e < nnzK; ++e)
@@ -153,7 +151,15 @@ int pp_add_group_mapped(pp_handle h, int n, int batch, int nnzK, const int32_t* 
   g->can_idx.assign(can_idx, can_idx + can_ptr[ncan]);
   for (int v : g->can_idx)
     if (v < 0 || v >= nraw) { delete g; return fail(h, 3, "canonical map points outside the raw vector"); }
-  if (g->plan.usize >= (int64_t)1 << 31) { delete g; return fail(h, 1, "panel storage exceeds 2^31 entries per instance"); }
+  // the plan itself (ordering, pivot sequence, schedule: the expensive part) is built by pp_end_symbolic, all groups of the
+  // handle side by side on host threads -- three pattern groups of a time-staged problem take the time of one
+  PendingPlan* pn = new PendingPlan();
+  pn->n = n; pn->opt = opt;
+  pn->rowK.assign(rowK, rowK + nnzK); pn->colK.assign(colK, colK + nnzK);
+  pn->rowB.assign(rowB, rowB + nnzB); pn->colB.assign(colB, colB + nnzB);
+  if (rep_vals) pn->rep_vals.assign(rep_vals, rep_vals + ncan);
+  pn->have_vals = rep_vals != nullptr;
+  g->pending = pn;
   h->groups.push_back(g);
   if (group_out) *group_out = (int)h->groups.size() - 1;
   return 0;
@@ -163,6 +169,28 @@ int pp_end_symbolic(pp_handle h) {
   if (!h) return 3;
   PP_HIP(hipSetDevice(h->device));
   const int nc = h->nc;
+  {
+    std::vector<Group*> todo;
+    for (Group* g : h->groups) if (g->pending) todo.push_back(g);
+    std::vector<int> rcs(todo.size(), 0);
+    auto build = [&](size_t i) {
+      Group* g = todo[i];
+      PendingPlan& pn = *g->pending;
+      rcs[i] = pp::build_plan(pn.n, g->nc_loc, (int)pn.rowK.size(), pn.rowK.data(), pn.colK.data(), (int)pn.rowB.size(),
+                              pn.rowB.data(), pn.colB.data(), pn.have_vals ? pn.rep_vals.data() : nullptr, pn.opt, g->plan);
+    };
+    if (todo.size() > 1) {
+      std::vector<std::thread> th;
+      for (size_t i = 1; i < todo.size(); ++i) th.emplace_back(build, i);
+      build(0);
+      for (auto& t : th) t.join();
+    } else if (todo.size() == 1) build(0);
+    for (size_t i = 0; i < todo.size(); ++i) { delete todo[i]->pending; todo[i]->pending = nullptr; }
+    for (size_t i = 0; i < todo.size(); ++i) {
+      if (rcs[i] != 0) return fail(h, rcs[i], "symbolic analysis failed: " + todo[i]->plan.error);
+      if (todo[i]->plan.usize >= (int64_t)1 << 31) return fail(h, 1, "panel storage exceeds 2^31 entries per instance");
+    }
+  }
   for (Group* g : h->groups) {
     const pp::Plan& P = g->plan;
     GroupDev& d = g->dev;

@@ -173,7 +173,17 @@ __device__ __forceinline__ void publish_status(const double* __restrict__ tail, 
 
 // (n_c = 0: no dense phase; otherwise the last dense kernel, k_bk_factor, publishes)
 // ------------------------------------------------------------------------------------------
+// inputs of a plan that pp_end_symbolic still has to build (pp_add_group* copies them)
+struct PendingPlan {
+  int n = 0;
+  bool have_vals = false;
+  pp::PlanOptions opt;
+  std::vector<int32_t> rowK, colK, rowB, colB;
+  std::vector<double> rep_vals;
+};
+
 struct Group {
+  PendingPlan* pending = nullptr;
   pp::Plan plan;
   GroupDev dev;
   int batch = 0, nraw = 0;
@@ -657,6 +667,7 @@ void free_group(Group* g) {
   if (g->shift_cls) (void)hipFree(g->shift_cls);
   for (void* p : g->value_allocs) (void)hipFree(p);
   for (void* p : g->allocs) (void)hipFree(p);
+  delete g->pending;
   delete g;
 }
 

@@ -1,6 +1,7 @@
 // Host-side symbolic analysis: static-pivot ordering, panel structure, task schedule.
 // See plan.hpp for the model.  Pure C++ (no HIP), so it is unit-tested on CPU.
 #include "plan.hpp"
+#include <thread>
 
 #include <algorithm>
 #include <climits>
@@ -26,12 +27,15 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
   // both elimination orders, the cheaper schedule kept: a level costs its launches (two for the factorisation, one
   // in each solve sweep, at a floor of 5-8 us each on one MI355X), an entry of the factor its trips through HBM --
   // about 2500 entries to the level at a thousand instances
-  PlanOptions o = opt;
+  // (side by side on two host threads: they share nothing but their read-only inputs)
+  PlanOptions o = opt, o0 = opt;
   o.order_mode = 1;
-  int rc = build_plan_ordered(n, nc, nnzK, rowK, colK, nnzB, rowB, colB, vals, o, P);
+  o0.order_mode = 0;
   Plan Q;
-  o.order_mode = 0;
-  const int rc0 = build_plan_ordered(n, nc, nnzK, rowK, colK, nnzB, rowB, colB, vals, o, Q);
+  int rc0 = 0;
+  std::thread other([&]() { rc0 = build_plan_ordered(n, nc, nnzK, rowK, colK, nnzB, rowB, colB, vals, o0, Q); });
+  int rc = build_plan_ordered(n, nc, nnzK, rowK, colK, nnzB, rowB, colB, vals, o, P);
+  other.join();
   auto cost = [](const Plan& x) { return (int64_t)x.n_levels * 2500 + x.usize; };
   if (rc0 == 0 && (rc != 0 || cost(Q) < cost(P))) { P = std::move(Q); rc = rc0; }
   return rc;

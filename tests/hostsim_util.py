@@ -19,7 +19,7 @@ def build_hostsim(force=False):
             os.path.join(ROOT, 'parapint_amd', 'csrc', 'pivot.hpp'),
             os.path.join(ROOT, 'parapint_amd', 'csrc', 'dense_bk.hpp')]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(['g++', '-O2', '-std=c++17', '-shared', '-fPIC', '-o', so, srcs[0], srcs[1]])
+        subprocess.check_call(['g++', '-O2', '-std=c++17', '-pthread', '-shared', '-fPIC', '-o', so, srcs[0], srcs[1]])
     return so
 
 
