@@ -1,0 +1,241 @@
+"""Optimal control of the viscous Burgers equation through the time-block Schur-complement interface, Pyomo-free.
+
+The reference's ``examples/burgers.py:53-176`` states the problem with Pyomo.DAE (backward differences in time, central
+differences in space, trapezoidal integrals) and hands one Pyomo model per time block to
+``MPIDynamicSchurComplementInteriorPointInterface``.  Pyomo is not available here, so the SAME discretised problem is
+written out by hand as an object with the NLP protocol the reference's ``InteriorPointInterface`` talks to (PyNumero's
+``ExtendedNLP``: sizes, bounds, state, objective / constraints and their derivatives) -- a NONLINEAR problem: Hessian
+and Jacobian values change at every iterate, every interior-point iteration hands the linear solver new values on the
+same pattern.
+
+    variables of a time block [t0, t1] with nt steps, interior grid points x_1 .. x_m (m = nfe_x - 1; y = u = 0 at x = 0, 1):
+        y[k][i], u[k][i],  k = 0 .. nt
+    pde (k = 1 .. nt):  (y[k][i] - y[k-1][i]) / dt - v (y[k][i+1] - 2 y[k][i] + y[k][i-1]) / dx^2
+                        + (y[k][i+1] - y[k][i-1]) / (2 dx) * y[k][i] = r + u[k-1][i]                    (burgers.py:123-132)
+    first block only:   y[0][i] = y0(x_i),  u[0][i] = 0                                                 (:105-121)
+    objective:          1/2 int int (y - y0)^2 + omega u^2 dx dt  (trapezoid)  +  1/4 dx dt omega sum_i u[0][i]^2   (:140-160)
+
+(the last term gives the controls at the start of a block their full weight: the copy of that time node at the end of the
+block before drives nothing and goes to zero).  Start / end states: y[0][:] and y[nt][:] (:168-170).  The boundary values,
+which the reference keeps as variables fixed by equality constraints, are eliminated."""
+import math
+
+import numpy as np
+from scipy.sparse import coo_matrix
+
+from parapint_amd.algorithms.interior_point import IPOptions, InteriorPointStatus, ip_solve
+from parapint_amd.interfaces.schur_complement.sc_ip_interface import MPIDynamicSchurComplementInteriorPointInterface
+
+
+class BurgersNLP(object):
+    def __init__(self, nfe_x, nfe_t, start_t, end_t, add_init_conditions, start_term=True, omega=0.02, v=0.01, r=0.0):
+        self.m = m = int(nfe_x) - 1
+        self.nt = nt = int(nfe_t)
+        self.dx, self.dt = 1.0 / nfe_x, (end_t - start_t) / float(nfe_t)
+        self.omega, self.v, self.r = omega, v, r
+        self.init_conditions, self.start_term = bool(add_init_conditions), bool(start_term)
+        x = (np.arange(m) + 1) * self.dx
+        self.y0 = np.where(x <= 0.5, 1.0, 0.0)                          # _y_init_rule
+        self.n = 2 * (nt + 1) * m
+        self.me = nt * m + (2 * m if add_init_conditions else 0)
+        self._primals = np.zeros(self.n)                               # (Pyomo variables without a value start at 0)
+        self._duals_eq = np.zeros(self.me)
+        self._obj_factor = 1.0
+        # trapezoid weights in time; the objective is 1/2 sum_k w_k dx sum_i [(y - y0)^2 + omega u^2] (+ start term)
+        self.w = np.full(nt + 1, self.dt)
+        self.w[0] = self.w[-1] = 0.5 * self.dt
+        self._patterns()
+
+    # ---- indices
+    def yi(self, k):
+        return k * self.m + np.arange(self.m)
+
+    def ui(self, k):
+        return (self.nt + 1) * self.m + k * self.m + np.arange(self.m)
+
+    def start_states(self):
+        return self.yi(0)
+
+    def end_states(self):
+        return self.yi(self.nt)
+
+    def _patterns(self):
+        m, nt = self.m, self.nt
+        i = np.arange(m)
+        rows, cols, kind = [], [], []           # Jacobian entries in a fixed order; kind names the formula of the value
+        for k in range(1, nt + 1):
+            r0 = (k - 1) * m
+            rows += [r0 + i, r0 + i, r0 + i[:-1], r0 + i[1:], r0 + i]
+            cols += [self.yi(k), self.yi(k - 1), self.yi(k)[1:], self.yi(k)[:-1], self.ui(k - 1)]
+            kind += [np.full(m, 0), np.full(m, 1), np.full(m - 1, 2), np.full(m - 1, 3), np.full(m, 4)]
+        if self.init_conditions:
+            r0 = nt * m
+            rows += [r0 + i, r0 + m + i]
+            cols += [self.yi(0), self.ui(0)]
+            kind += [np.full(m, 5), np.full(m, 5)]
+        self.jrow, self.jcol, self.jkind = (np.concatenate(a).astype(np.int64) for a in (rows, cols, kind))
+        # Hessian of the Lagrangian, lower triangle: the diagonal, then the pairs (y[k][i+1], y[k][i]) of the convective term
+        d = np.arange(self.n)
+        hr, hc = [d], [d]
+        for k in range(1, nt + 1):
+            hr.append(self.yi(k)[1:])
+            hc.append(self.yi(k)[:-1])
+        self.hrow, self.hcol = np.concatenate(hr).astype(np.int64), np.concatenate(hc).astype(np.int64)
+
+    # ---- the NLP protocol
+    def n_primals(self):
+        return self.n
+
+    def n_eq_constraints(self):
+        return self.me
+
+    def n_ineq_constraints(self):
+        return 0
+
+    def nnz_hessian_lag(self):
+        return int(self.hrow.size)
+
+    def nnz_jacobian_eq(self):
+        return int(self.jrow.size)
+
+    def nnz_jacobian_ineq(self):
+        return 0
+
+    def primals_lb(self):
+        return np.full(self.n, -np.inf)
+
+    def primals_ub(self):
+        return np.full(self.n, np.inf)
+
+    def ineq_lb(self):
+        return np.zeros(0)
+
+    def ineq_ub(self):
+        return np.zeros(0)
+
+    def init_primals(self):
+        return np.zeros(self.n)
+
+    def init_duals_eq(self):
+        return np.zeros(self.me)
+
+    def init_duals_ineq(self):
+        return np.zeros(0)
+
+    def set_primals(self, primals):
+        self._primals = np.asarray(primals, dtype=np.double)
+
+    def get_primals(self):
+        return self._primals
+
+    def set_duals_eq(self, duals):
+        self._duals_eq = np.asarray(duals, dtype=np.double)
+
+    def get_duals_eq(self):
+        return self._duals_eq
+
+    def set_duals_ineq(self, duals):
+        pass
+
+    def get_duals_ineq(self):
+        return np.zeros(0)
+
+    def set_obj_factor(self, obj_factor):
+        self._obj_factor = obj_factor
+
+    def get_obj_factor(self):
+        return self._obj_factor
+
+    def _yu(self):
+        m, nt = self.m, self.nt
+        x = self._primals
+        return x[:(nt + 1) * m].reshape(nt + 1, m), x[(nt + 1) * m:].reshape(nt + 1, m)
+
+    def evaluate_objective(self):
+        y, u = self._yu()
+        f = 0.5 * self.dx * float(np.sum(self.w[:, None] * ((y - self.y0) ** 2 + self.omega * u ** 2)))
+        if self.start_term:
+            f += 0.25 * self.dx * self.dt * self.omega * float(np.sum(u[0] ** 2))
+        return f
+
+    def evaluate_grad_objective(self):
+        y, u = self._yu()
+        gy = self.dx * self.w[:, None] * (y - self.y0)
+        gu = self.dx * self.w[:, None] * self.omega * u
+        if self.start_term:
+            gu[0] = gu[0] + 0.5 * self.dx * self.dt * self.omega * u[0]
+        return np.concatenate([gy.ravel(), gu.ravel()])
+
+    def _neighbours(self, yk):
+        up, dn = np.zeros_like(yk), np.zeros_like(yk)
+        up[:-1], dn[1:] = yk[1:], yk[:-1]                      # y[k][i+1], y[k][i-1] (zero at the boundary)
+        return up, dn
+
+    def evaluate_eq_constraints(self):
+        y, u = self._yu()
+        out = []
+        for k in range(1, self.nt + 1):
+            up, dn = self._neighbours(y[k])
+            out.append((y[k] - y[k - 1]) / self.dt - self.v * (up - 2.0 * y[k] + dn) / self.dx ** 2 +
+                       (up - dn) / (2.0 * self.dx) * y[k] - self.r - u[k - 1])
+        if self.init_conditions:
+            out += [y[0] - self.y0, u[0]]
+        return np.concatenate(out)
+
+    def evaluate_ineq_constraints(self):
+        return np.zeros(0)
+
+    def evaluate_jacobian_eq(self):
+        y, _ = self._yu()
+        vals = []
+        for k in range(1, self.nt + 1):
+            up, dn = self._neighbours(y[k])
+            vals += [1.0 / self.dt + 2.0 * self.v / self.dx ** 2 + (up - dn) / (2.0 * self.dx),      # d / d y[k][i]
+                     np.full(self.m, -1.0 / self.dt),                                                # d / d y[k-1][i]
+                     (-self.v / self.dx ** 2 + y[k] / (2.0 * self.dx))[:-1],                         # d / d y[k][i+1]
+                     (-self.v / self.dx ** 2 - y[k] / (2.0 * self.dx))[1:],                          # d / d y[k][i-1]
+                     np.full(self.m, -1.0)]                                                          # d / d u[k-1][i]
+        if self.init_conditions:
+            vals += [np.ones(self.m), np.ones(self.m)]
+        return coo_matrix((np.concatenate(vals), (self.jrow, self.jcol)), shape=(self.me, self.n))
+
+    def evaluate_jacobian_ineq(self):
+        return coo_matrix((0, self.n))
+
+    def evaluate_hessian_lag(self):
+        m, nt = self.m, self.nt
+        diag_y = self.dx * self.w[:, None] * np.ones((nt + 1, m))
+        diag_u = self.dx * self.w[:, None] * self.omega * np.ones((nt + 1, m))
+        if self.start_term:
+            diag_u[0] = diag_u[0] + 0.5 * self.dx * self.dt * self.omega
+        vals = [self._obj_factor * np.concatenate([diag_y.ravel(), diag_u.ravel()])]
+        lam = self._duals_eq[:nt * m].reshape(nt, m)
+        for k in range(1, nt + 1):
+            # d2 c[k][i] / d y[k][i+1] d y[k][i] = 1 / (2 dx),  d2 c[k][i+1] / d y[k][i] d y[k][i+1] = -1 / (2 dx)
+            vals.append((lam[k - 1][:-1] - lam[k - 1][1:]) / (2.0 * self.dx))
+        return coo_matrix((np.concatenate(vals), (self.hrow, self.hcol)), shape=(self.n, self.n))
+
+
+class BurgersInterface(MPIDynamicSchurComplementInteriorPointInterface):
+    """burgers.py:53-176: the interface of the reference's example (same constructor but for the communicator, which is
+    an argument here instead of a module global)."""
+
+    def __init__(self, start_t, end_t, num_time_blocks, nfe_t, nfe_x, comm=None):
+        self.nfe_x = nfe_x
+        self.dt = (end_t - start_t) / float(nfe_t)
+        super(BurgersInterface, self).__init__(start_t=start_t, end_t=end_t, num_time_blocks=num_time_blocks, comm=comm)
+
+    def build_model_for_time_block(self, ndx, start_t, end_t, add_init_conditions):
+        nfe_t = math.ceil((end_t - start_t) / self.dt - 1e-9)
+        nlp = BurgersNLP(self.nfe_x, nfe_t, start_t, end_t, add_init_conditions)
+        return nlp, nlp.start_states(), nlp.end_states()
+
+
+def main(linear_solver, nfe_x=12, nfe_t=16, nblocks=4, comm=None):
+    """burgers.py:202-226 without the plots: returns the interface after a successful solve."""
+    interface = BurgersInterface(start_t=0, end_t=1, num_time_blocks=nblocks, nfe_t=nfe_t, nfe_x=nfe_x, comm=comm)
+    options = IPOptions()
+    options.linalg.solver = linear_solver
+    status = ip_solve(interface=interface, options=options)
+    assert status == InteriorPointStatus.optimal
+    return interface

@@ -48,32 +48,152 @@ def _relaxed(bound, factor, sign):
     return bound + sign * factor * np.maximum(1.0, np.abs(bound))
 
 
-class QPInteriorPointInterface(object):
-    """Counterpart of ``InteriorPointInterface`` (interface.py:251-679) over a QuadraticProgram."""
+class QuadraticProgramNLP(object):
+    """A QuadraticProgram behind the NLP protocol the reference's interface talks to (PyNumero's ``ExtendedNLP``, of which
+    ``PyomoNLP`` / ``AmplNLP`` are the implementations parapint/interfaces/interface.py:253-256 instantiates): sizes,
+    bounds, initial point, the primal / dual state, and the evaluations at that state."""
 
     def __init__(self, qp):
-        self._qp = qp
-        self.bounds_relaxation_factor = 0
+        self.qp = qp
         self._obj_factor = 1.0
         self._primals = qp.x0.copy()
         self._duals_eq = np.zeros(qp.A_eq.shape[0])
         self._duals_ineq = np.zeros(qp.A_ineq.shape[0])
         self._Hfull = (qp.H + sp.tril(qp.H, -1).T).tocsr()
+
+    def n_primals(self):
+        return self.qp.n
+
+    def n_eq_constraints(self):
+        return self.qp.A_eq.shape[0]
+
+    def n_ineq_constraints(self):
+        return self.qp.A_ineq.shape[0]
+
+    def nnz_hessian_lag(self):
+        return self.qp.H.nnz
+
+    def nnz_jacobian_eq(self):
+        return self.qp.A_eq.nnz
+
+    def nnz_jacobian_ineq(self):
+        return self.qp.A_ineq.nnz
+
+    def primals_lb(self):
+        return self.qp.lb
+
+    def primals_ub(self):
+        return self.qp.ub
+
+    def ineq_lb(self):
+        return self.qp.ineq_lb
+
+    def ineq_ub(self):
+        return self.qp.ineq_ub
+
+    def init_primals(self):
+        return self.qp.x0
+
+    def init_duals_eq(self):
+        return np.zeros(self.qp.A_eq.shape[0])
+
+    def init_duals_ineq(self):
+        return np.zeros(self.qp.A_ineq.shape[0])
+
+    def set_primals(self, primals):
+        self._primals = np.asarray(primals, dtype=np.double)
+
+    def get_primals(self):
+        return self._primals
+
+    def set_duals_eq(self, duals):
+        self._duals_eq = np.asarray(duals, dtype=np.double)
+
+    def get_duals_eq(self):
+        return self._duals_eq
+
+    def set_duals_ineq(self, duals):
+        self._duals_ineq = np.asarray(duals, dtype=np.double)
+
+    def get_duals_ineq(self):
+        return self._duals_ineq
+
+    def set_obj_factor(self, obj_factor):
+        self._obj_factor = obj_factor
+
+    def get_obj_factor(self):
+        return self._obj_factor
+
+    def evaluate_objective(self):
+        x = self._primals
+        return self._obj_factor * (0.5 * x @ (self._Hfull @ x) + self.qp.c @ x + self.qp.c0)
+
+    def evaluate_grad_objective(self):
+        return self._Hfull @ self._primals + self.qp.c
+
+    def evaluate_eq_constraints(self):
+        return self.qp.A_eq @ self._primals - self.qp.b_eq
+
+    def evaluate_ineq_constraints(self):
+        return self.qp.A_ineq @ self._primals
+
+    def evaluate_jacobian_eq(self):
+        return self.qp.A_eq
+
+    def evaluate_jacobian_ineq(self):
+        return self.qp.A_ineq
+
+    def evaluate_hessian_lag(self):
+        H = self.qp.H
+        return coo_matrix((self._obj_factor * H.data, (H.row, H.col)), shape=H.shape)
+
+
+class InteriorPointInterface(object):
+    """Counterpart of ``InteriorPointInterface`` (interface.py:251-679) over ANY object with the NLP protocol it uses
+    there (``self._nlp``: PyNumero's ExtendedNLP -- a ``PyomoNLP`` / ``AmplNLP`` where Pyomo is installed, a
+    ``QuadraticProgramNLP``, or a hand-written class such as parapint_amd/examples/burgers.py): nonlinear problems
+    re-evaluate Hessian and Jacobians at every iterate, exactly as the reference does (:432-494).
+
+    The Hessian of the Lagrangian may come as its lower triangle (ASL's convention, kept by QuadraticProgram) or in
+    full; the linear solvers of this package read the lower triangle."""
+
+    def __init__(self, nlp):
+        self._nlp = nlp
+        self.bounds_relaxation_factor = 0
         self._slacks = self.init_slacks()
+        n, mi = nlp.n_primals(), nlp.n_ineq_constraints()
         # interface.py:263-283: ones unless ipopt suffixes exist, zero where the bound is infinite; slack duals from
-        # the (zero) initial inequality duals
-        self._init_duals_primals_lb = np.ones(qp.n)
-        self._init_duals_primals_ub = np.ones(qp.n)
-        self._init_duals_primals_lb[np.isneginf(qp.lb)] = 0
-        self._init_duals_primals_ub[np.isinf(qp.ub)] = 0
+        # the initial inequality duals according to their sign
+        self._init_duals_primals_lb = np.ones(n)
+        self._init_duals_primals_ub = np.ones(n)
+        self._init_duals_primals_lb[np.isneginf(np.asarray(nlp.primals_lb()))] = 0
+        self._init_duals_primals_ub[np.isinf(np.asarray(nlp.primals_ub()))] = 0
         self._duals_primals_lb = self._init_duals_primals_lb.copy()
         self._duals_primals_ub = self._init_duals_primals_ub.copy()
-        self._init_duals_slacks_lb = np.zeros(qp.A_ineq.shape[0])
-        self._init_duals_slacks_ub = np.zeros(qp.A_ineq.shape[0])
+        yi = np.asarray(nlp.init_duals_ineq(), dtype=np.double).reshape(mi)
+        self._init_duals_slacks_lb = np.where(yi < 0, 0.0, yi)
+        self._init_duals_slacks_ub = np.where(yi > 0, 0.0, yi) * -1.0 + 0.0
         self._duals_slacks_lb = self._init_duals_slacks_lb.copy()
         self._duals_slacks_ub = self._init_duals_slacks_ub.copy()
         self._delta_primals = self._delta_slacks = self._delta_duals_eq = self._delta_duals_ineq = None
         self._barrier = None
+
+    # the state lives in the NLP object, as in the reference
+    @property
+    def _primals(self):
+        return self._nlp.get_primals()
+
+    @property
+    def _duals_eq(self):
+        return self._nlp.get_duals_eq()
+
+    @property
+    def _duals_ineq(self):
+        return self._nlp.get_duals_ineq()
+
+    @property
+    def _obj_factor(self):
+        return self._nlp.get_obj_factor()
 
     # ---- sizes / options
     def get_bounds_relaxation_factor(self):
@@ -83,54 +203,54 @@ class QPInteriorPointInterface(object):
         self.bounds_relaxation_factor = val
 
     def n_primals(self):
-        return self._qp.n
+        return self._nlp.n_primals()
 
     def n_eq_constraints(self):
-        return self._qp.A_eq.shape[0]
+        return self._nlp.n_eq_constraints()
 
     def n_ineq_constraints(self):
-        return self._qp.A_ineq.shape[0]
+        return self._nlp.n_ineq_constraints()
 
     def nnz_hessian_lag(self):
-        return self._qp.H.nnz
+        return self._nlp.nnz_hessian_lag()
 
     def nnz_jacobian_eq(self):
-        return self._qp.A_eq.nnz
+        return self._nlp.nnz_jacobian_eq()
 
     def nnz_jacobian_ineq(self):
-        return self._qp.A_ineq.nnz
+        return self._nlp.nnz_jacobian_ineq()
 
     def set_obj_factor(self, obj_factor):
-        self._obj_factor = obj_factor
+        self._nlp.set_obj_factor(obj_factor)
 
     def get_obj_factor(self):
-        return self._obj_factor
+        return self._nlp.get_obj_factor()
 
     # ---- bounds
     def primals_lb(self):
-        return _relaxed(self._qp.lb, self.bounds_relaxation_factor, -1.0)
+        return _relaxed(np.asarray(self._nlp.primals_lb()), self.bounds_relaxation_factor, -1.0)
 
     def primals_ub(self):
-        return _relaxed(self._qp.ub, self.bounds_relaxation_factor, +1.0)
+        return _relaxed(np.asarray(self._nlp.primals_ub()), self.bounds_relaxation_factor, +1.0)
 
     def ineq_lb(self):
-        return _relaxed(self._qp.ineq_lb, self.bounds_relaxation_factor, -1.0)
+        return _relaxed(np.asarray(self._nlp.ineq_lb()), self.bounds_relaxation_factor, -1.0)
 
     def ineq_ub(self):
-        return _relaxed(self._qp.ineq_ub, self.bounds_relaxation_factor, +1.0)
+        return _relaxed(np.asarray(self._nlp.ineq_ub()), self.bounds_relaxation_factor, +1.0)
 
     # ---- initial point
     def init_primals(self):
-        return self._qp.x0
+        return self._nlp.init_primals()
 
     def init_slacks(self):
-        return self._qp.A_ineq @ self._primals
+        return self._nlp.evaluate_ineq_constraints()              # (interface.py:324-326: at the NLP's current point)
 
     def init_duals_eq(self):
-        return np.zeros(self._qp.A_eq.shape[0])
+        return self._nlp.init_duals_eq()
 
     def init_duals_ineq(self):
-        return np.zeros(self._qp.A_ineq.shape[0])
+        return self._nlp.init_duals_ineq()
 
     def init_duals_primals_lb(self):
         return self._init_duals_primals_lb
@@ -146,16 +266,16 @@ class QPInteriorPointInterface(object):
 
     # ---- state
     def set_primals(self, primals):
-        self._primals = np.asarray(primals, dtype=np.double)
+        self._nlp.set_primals(np.asarray(primals, dtype=np.double))
 
     def set_slacks(self, slacks):
         self._slacks = np.asarray(slacks, dtype=np.double)
 
     def set_duals_eq(self, duals):
-        self._duals_eq = np.asarray(duals, dtype=np.double)
+        self._nlp.set_duals_eq(np.asarray(duals, dtype=np.double))
 
     def set_duals_ineq(self, duals):
-        self._duals_ineq = np.asarray(duals, dtype=np.double)
+        self._nlp.set_duals_ineq(np.asarray(duals, dtype=np.double))
 
     def set_duals_primals_lb(self, duals):
         self._duals_primals_lb = np.asarray(duals, dtype=np.double)
@@ -198,27 +318,25 @@ class QPInteriorPointInterface(object):
 
     # ---- function evaluations
     def evaluate_objective(self):
-        x = self._primals
-        return self._obj_factor * (0.5 * x @ (self._Hfull @ x) + self._qp.c @ x + self._qp.c0)
+        return self._nlp.evaluate_objective()
 
     def evaluate_grad_objective(self):
-        return self._Hfull @ self._primals + self._qp.c
+        return self._nlp.evaluate_grad_objective()
 
     def evaluate_eq_constraints(self):
-        return self._qp.A_eq @ self._primals - self._qp.b_eq
+        return self._nlp.evaluate_eq_constraints()
 
     def evaluate_ineq_constraints(self):
-        return self._qp.A_ineq @ self._primals
+        return self._nlp.evaluate_ineq_constraints()
 
     def evaluate_jacobian_eq(self):
-        return self._qp.A_eq
+        return self._nlp.evaluate_jacobian_eq()
 
     def evaluate_jacobian_ineq(self):
-        return self._qp.A_ineq
+        return self._nlp.evaluate_jacobian_ineq()
 
     def evaluate_hessian_lag(self):
-        H = self._qp.H
-        return coo_matrix((self._obj_factor * H.data, (H.row, H.col)), shape=H.shape)
+        return self._nlp.evaluate_hessian_lag()
 
     # ---- the KKT system the linear solver is handed
     def barrier_diagonals(self):
@@ -233,10 +351,10 @@ class QPInteriorPointInterface(object):
         """interface.py:432-494: Hessian + primal barrier diagonal (appended as extra COO entries), slack barrier
         diagonal, both Jacobians with their transposes, -I between slacks and inequality duals, explicit zero
         diagonal blocks for the constraint rows (so that regularisation does not change the pattern)."""
-        qp = self._qp
-        n, me, mi = qp.n, qp.A_eq.shape[0], qp.A_ineq.shape[0]
+        n, me, mi = self.n_primals(), self.n_eq_constraints(), self.n_ineq_constraints()
         dp, ds = self.barrier_diagonals()
-        H = self.evaluate_hessian_lag()
+        H = coo_matrix(self.evaluate_hessian_lag())
+        A_eq, A_ineq = coo_matrix(self.evaluate_jacobian_eq()), coo_matrix(self.evaluate_jacobian_ineq())
         idx = np.arange(n)
         hess = coo_matrix((np.concatenate([H.data, dp]), (np.concatenate([H.row, idx]), np.concatenate([H.col, idx]))),
                           shape=(n, n))
@@ -244,10 +362,10 @@ class QPInteriorPointInterface(object):
         kkt = BlockMatrix(4, 4)
         kkt.set_block(0, 0, hess)
         kkt.set_block(1, 1, coo_matrix((ds, (midx, midx)), shape=(mi, mi)))
-        kkt.set_block(2, 0, qp.A_eq)
-        kkt.set_block(0, 2, qp.A_eq.transpose().tocoo())
-        kkt.set_block(3, 0, qp.A_ineq)
-        kkt.set_block(0, 3, qp.A_ineq.transpose().tocoo())
+        kkt.set_block(2, 0, A_eq)
+        kkt.set_block(0, 2, A_eq.transpose().tocoo())
+        kkt.set_block(3, 0, A_ineq)
+        kkt.set_block(0, 3, A_ineq.transpose().tocoo())
         neg_eye = coo_matrix((-np.ones(mi), (midx, midx)), shape=(mi, mi))
         kkt.set_block(3, 1, neg_eye)
         kkt.set_block(1, 3, neg_eye.copy())
@@ -258,10 +376,10 @@ class QPInteriorPointInterface(object):
 
     def evaluate_primal_dual_kkt_rhs(self, timer=None):
         """interface.py:496-538 (negative gradient of the barrier Lagrangian and the constraint residuals)."""
-        qp = self._qp
         x, s = self._primals, self._slacks
-        grad_lag_primals = (self._obj_factor * self.evaluate_grad_objective() + qp.A_eq.T @ self._duals_eq +
-                            qp.A_ineq.T @ self._duals_ineq - self._barrier / (x - self.primals_lb()) +
+        A_eq, A_ineq = self.evaluate_jacobian_eq(), self.evaluate_jacobian_ineq()
+        grad_lag_primals = (self._obj_factor * self.evaluate_grad_objective() + A_eq.T @ self._duals_eq +
+                            A_ineq.T @ self._duals_ineq - self._barrier / (x - self.primals_lb()) +
                             self._barrier / (self.primals_ub() - x))
         grad_lag_slacks = (-self._duals_ineq - self._barrier / (s - self.ineq_lb()) +
                            self._barrier / (self.ineq_ub() - s))
@@ -322,3 +440,12 @@ class QPInteriorPointInterface(object):
         hess = kkt.get_block(0, 0)
         kkt.set_block(0, 0, (hess + coef * sp.identity(self.n_primals(), format='coo')).tocoo())
         return kkt
+
+
+class QPInteriorPointInterface(InteriorPointInterface):
+    """The interface over a QuadraticProgram (the Pyomo-free stand-in for a Pyomo model in the tests, the examples and
+    the device-resident producers)."""
+
+    def __init__(self, qp):
+        self._qp = qp
+        super(QPInteriorPointInterface, self).__init__(QuadraticProgramNLP(qp))

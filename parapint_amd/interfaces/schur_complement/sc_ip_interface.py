@@ -16,8 +16,14 @@ KKT matrix it hands to the linear solver is exactly the reference's structure (:
 import numpy as np
 from scipy.sparse import coo_matrix, identity
 
-from parapint_amd.interfaces.interface import QPInteriorPointInterface
+from parapint_amd.interfaces.interface import InteriorPointInterface, QPInteriorPointInterface, QuadraticProgram
 from parapint_amd.sparse.block_containers import (BlockMatrix, BlockVector, MPIBlockMatrix, MPIBlockVector)
+
+
+def _interface_of(model):
+    """The single-problem interface of one scenario / time block: a QuadraticProgram, or any object with the NLP protocol
+    of interfaces/interface.py (where the reference wraps a Pyomo model, sc_ip_interface.py:156, 1166)."""
+    return QPInteriorPointInterface(model) if isinstance(model, QuadraticProgram) else InteriorPointInterface(model)
 
 
 class _Serial(object):
@@ -55,7 +61,7 @@ class StochasticSchurComplementInteriorPointInterface(object):
         self._linking = {}
         self._link_coupling = {}
         for ndx in self._local:
-            nlp = QPInteriorPointInterface(scenarios[ndx])
+            nlp = _interface_of(scenarios[ndx])
             idx = np.asarray(first_stage_indices[ndx], dtype=np.int64)
             assert idx.size == nfs
             rows = np.arange(nfs)
@@ -422,7 +428,7 @@ class DynamicSchurComplementInteriorPointInterface(StochasticSchurComplementInte
         for ndx in self._local:                                   # mpi_sc_ip_interface.py:178-215
             qp, start_states, end_states = self.build_model_for_time_block(
                 ndx=ndx, start_t=delta_t * ndx, end_t=delta_t * (ndx + 1), add_init_conditions=(ndx == 0))
-            self._nlps[ndx] = nlp = QPInteriorPointInterface(qp)
+            self._nlps[ndx] = nlp = _interface_of(qp)
             assert len(start_states) == len(end_states)
             if self._num_states is not None:
                 assert self._num_states == len(start_states)

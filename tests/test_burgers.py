@@ -1,0 +1,125 @@
+"""A NONLINEAR time-staged problem through the reference's interfaces: optimal control of the viscous Burgers equation
+(parapint/examples/burgers.py:53-176 restated by hand as an NLP object, parapint_amd/examples/burgers.py), i.e.
+``InteriorPointInterface`` over the NLP protocol (interfaces/interface.py:251-679) under
+``MPIDynamicSchurComplementInteriorPointInterface`` -- Hessian and Jacobian values change at every iterate."""
+import numpy as np
+import pytest
+
+from parapint_amd.examples import burgers as bg
+
+
+def _oracle_solver(blocks):
+    from oracle.schur_complement import SchurComplementLinearSolver as OracleSC
+    from oracle.subsolvers import ScipyInterface as OracleScipy
+    return OracleSC({i: OracleScipy(compute_inertia=True) for i in blocks}, OracleScipy(compute_inertia=True))
+
+
+def test_burgers_nlp_derivatives_against_finite_differences():
+    for init in (True, False):
+        nlp = bg.BurgersNLP(8, 3, 0.0, 0.25, init)
+        rng = np.random.default_rng(0)
+        x, lam = rng.normal(size=nlp.n_primals()), rng.normal(size=nlp.n_eq_constraints())
+        nlp.set_primals(x)
+        nlp.set_duals_eq(lam)
+        g, J = nlp.evaluate_grad_objective(), nlp.evaluate_jacobian_eq().toarray()
+        H = nlp.evaluate_hessian_lag().toarray()
+        assert np.array_equal(H, np.tril(H)) and nlp.nnz_hessian_lag() == nlp.evaluate_hessian_lag().nnz
+        H = H + np.tril(H, -1).T
+
+        def at(z, fn):
+            nlp.set_primals(z)
+            return fn()
+        eps, E = 1e-6, np.eye(nlp.n_primals())
+        gn = np.array([(at(x + eps * e, nlp.evaluate_objective) - at(x - eps * e, nlp.evaluate_objective)) / (2 * eps) for e in E])
+        Jn = np.array([(at(x + eps * e, nlp.evaluate_eq_constraints) - at(x - eps * e, nlp.evaluate_eq_constraints)) / (2 * eps)
+                       for e in E]).T
+        gl = lambda: nlp.evaluate_grad_objective() + nlp.evaluate_jacobian_eq().T @ lam
+        Hn = np.array([(at(x + eps * e, gl) - at(x - eps * e, gl)) / (2 * eps) for e in E]).T
+        assert np.abs(g - gn).max() <= 1e-8 and np.abs(J - Jn).max() <= 1e-7 and np.abs(H - Hn).max() <= 1e-7
+
+
+def _monolithic(nfe_x, nfe_t):
+    """The whole horizon as ONE NLP (no time blocks, plain trapezoid objective) through the same loop."""
+    from parapint_amd.algorithms.interior_point import IPOptions, InteriorPointStatus, ip_solve
+    from parapint_amd.interfaces.schur_complement.sc_ip_interface import StochasticSchurComplementInteriorPointInterface
+    nlp = bg.BurgersNLP(nfe_x, nfe_t, 0.0, 1.0, True, start_term=False)
+    mono = StochasticSchurComplementInteriorPointInterface([nlp], [[0]])
+    opt = IPOptions()
+    opt.linalg.solver = _oracle_solver([0])
+    assert ip_solve(mono, opt) == InteriorPointStatus.optimal
+    return mono, nlp
+
+
+def _same_as_monolithic(it, mono, nlp, T, nfe_t, tol):
+    nb, m = nfe_t // T, nlp.m
+    x = mono.get_primals().get_block(0)
+    Y, U = x[:(nfe_t + 1) * m].reshape(nfe_t + 1, m), x[(nfe_t + 1) * m:].reshape(nfe_t + 1, m)
+    assert abs(it.evaluate_objective() - mono.evaluate_objective()) <= tol
+    for t in it.local_block_indices:
+        xb = np.asarray(it.get_primals().get_block(t))
+        y, u = xb[:(nb + 1) * m].reshape(nb + 1, m), xb[(nb + 1) * m:].reshape(nb + 1, m)
+        assert np.abs(y - Y[t * nb:(t + 1) * nb + 1]).max() <= tol
+        assert np.abs(u[:nb] - U[t * nb:(t + 1) * nb]).max() <= tol
+        assert np.abs(u[nb]).max() <= tol             # the copy of the end node's control drives nothing
+    z = np.asarray(it.get_primals().get_block(T))
+    for t in range(T - 1):
+        assert np.abs(z[m * t:m * (t + 1)] - Y[(t + 1) * nb]).max() <= tol
+    assert np.abs(Y).max() > 0.5 and np.abs(U).max() > 0.05       # (a non-trivial state and control)
+
+
+def test_burgers_time_blocks_match_the_monolithic_problem():
+    T, nfe_x, nfe_t = 4, 8, 12
+    it = bg.main(_oracle_solver(range(T)), nfe_x=nfe_x, nfe_t=nfe_t, nblocks=T)
+    mono, nlp = _monolithic(nfe_x, nfe_t)
+    _same_as_monolithic(it, mono, nlp, T, nfe_t, 1e-7)
+
+
+def test_burgers_over_the_product_solver_on_the_cpu_engine():
+    from hostsim_engine import HostSimEngine
+    from parapint_amd.linalg.comm import SerialComm
+    from parapint_amd.linalg.hip_schur_complement import HipSchurComplementLinearSolver
+    T, nfe_x, nfe_t = 3, 7, 9
+    solver = HipSchurComplementLinearSolver({t: None for t in range(T)}, None, comm=SerialComm(), engine=HostSimEngine())
+    it = bg.main(solver, nfe_x=nfe_x, nfe_t=nfe_t, nblocks=T)
+    mono, nlp = _monolithic(nfe_x, nfe_t)
+    _same_as_monolithic(it, mono, nlp, T, nfe_t, 1e-6)      # (two runs that stop at 1e-8 on different paths)
+
+
+def _trajectory(it, T, nfe_t, m):
+    """States y over the whole horizon from the time blocks (the shared time nodes once)."""
+    nb = nfe_t // T
+    rows = []
+    for t in range(T):
+        xb = np.asarray(it.get_primals().get_block(t))
+        y = xb[:(nb + 1) * m].reshape(nb + 1, m)
+        rows.append(y if t == 0 else y[1:])
+    return np.concatenate(rows)
+
+
+@pytest.mark.gpu
+def test_burgers_over_the_hip_solver():
+    """New Hessian and Jacobian values from the host at every iteration (the SURVEY 8(d) boundary with values that change
+    everywhere): 6 time blocks against the same loop over the oracle's solver classes; then 16 and 8 time blocks over the
+    same 128 steps x 39 grid points (coupling blocks 1170 -- block-tridiagonal S -- and 546): the optimal trajectory does
+    not depend on where the horizon is cut."""
+    from parapint_amd.linalg.comm import SerialComm
+    from parapint_amd.linalg.hip_schur_complement import HipSchurComplementLinearSolver
+
+    def hip(T):
+        return HipSchurComplementLinearSolver({t: None for t in range(T)}, None, comm=SerialComm())
+    T, nfe_x, nfe_t = 6, 16, 24
+    it = bg.main(hip(T), nfe_x=nfe_x, nfe_t=nfe_t, nblocks=T)
+    ref = bg.main(_oracle_solver(range(T)), nfe_x=nfe_x, nfe_t=nfe_t, nblocks=T)
+    assert abs(it.evaluate_objective() - ref.evaluate_objective()) <= 1e-8
+    # (the controls are weakly determined -- their curvature is omega dx dt ~ 5e-5 --, so two runs that stop at a scaled
+    # dual infeasibility of 1e-8 agree in them to ~1e-4; the states follow the controls through the dynamics)
+    for t in range(T + 1):
+        assert np.abs(np.asarray(it.get_primals().get_block(t)) - np.asarray(ref.get_primals().get_block(t))).max() <= 2e-4
+    nfe_x, nfe_t = 40, 128
+    s16, s8 = hip(16), hip(8)
+    a = bg.main(s16, nfe_x=nfe_x, nfe_t=nfe_t, nblocks=16)
+    b = bg.main(s8, nfe_x=nfe_x, nfe_t=nfe_t, nblocks=8)
+    assert s16._btd is not None and s8._btd is None
+    assert abs(a.evaluate_objective() - b.evaluate_objective()) <= 1e-8
+    ya, yb = _trajectory(a, 16, nfe_t, nfe_x - 1), _trajectory(b, 8, nfe_t, nfe_x - 1)
+    assert ya.shape == yb.shape == (nfe_t + 1, nfe_x - 1) and np.abs(ya - yb).max() <= 2e-4 and np.abs(ya).max() > 0.5
