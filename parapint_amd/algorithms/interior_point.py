@@ -90,6 +90,12 @@ class _Layout(object):
     def __init__(self, template, comm):
         self.template = template
         self.comm = comm
+        self.plain = not hasattr(template, 'nblocks')         # a single problem's interface hands plain arrays
+        if self.plain:
+            self.size = int(np.asarray(template).size)
+            self.slices = []
+            self.counted = np.ones(self.size, dtype=bool)
+            return
         owner = getattr(template, 'rank_ownership', None)
         self.slices = []
         off = 0
@@ -107,6 +113,8 @@ class _Layout(object):
         self.counted = np.concatenate(counted) if counted else np.zeros(0, dtype=bool)
 
     def flat(self, bv):
+        if self.plain:
+            return np.array(bv, dtype=np.double).ravel()
         if self.size == 0:
             return np.zeros(0)
         parts = []
@@ -116,6 +124,8 @@ class _Layout(object):
         return np.concatenate(parts).astype(np.double, copy=True)
 
     def unflat(self, arr):
+        if self.plain:
+            return np.array(arr, dtype=np.double)
         t = self.template
         out = t.copy_structure_unset() if hasattr(t, 'copy_structure_unset') else t.copy_structure()
         for i, a, b in self.slices:

@@ -148,6 +148,118 @@ class QuadraticProgramNLP(object):
         return coo_matrix((self._obj_factor * H.data, (H.row, H.col)), shape=H.shape)
 
 
+class CallbackNLP(object):
+    """A nonlinear program given by plain functions, behind the NLP protocol (no Pyomo, no ASL):
+
+        min f(x)   s.t.  c_eq(x) = 0,  ineq_lb <= c_ineq(x) <= ineq_ub,  lb <= x <= ub
+
+    grad(x), jac_eq(x), jac_ineq(x) return the gradient and SciPy sparse Jacobians (the same pattern at every x);
+    hess_lag(x, y_eq, y_ineq, obj_factor) the Hessian of obj_factor f + y_eq' c_eq + y_ineq' c_ineq (lower triangle or
+    full).  Omitted constraint functions mean no such constraints."""
+
+    def __init__(self, x0, f, grad, hess_lag, c_eq=None, jac_eq=None, c_ineq=None, jac_ineq=None, ineq_lb=None, ineq_ub=None,
+                 lb=None, ub=None):
+        self._x0 = np.asarray(x0, dtype=np.double).ravel()
+        n = self._x0.size
+        self._f, self._grad, self._hess = f, grad, hess_lag
+        self._c_eq = c_eq if c_eq is not None else (lambda x: np.zeros(0))
+        self._jac_eq = jac_eq if jac_eq is not None else (lambda x: coo_matrix((0, n)))
+        self._c_ineq = c_ineq if c_ineq is not None else (lambda x: np.zeros(0))
+        self._jac_ineq = jac_ineq if jac_ineq is not None else (lambda x: coo_matrix((0, n)))
+        self._primals = self._x0.copy()
+        me, mi = np.asarray(self._c_eq(self._x0)).size, np.asarray(self._c_ineq(self._x0)).size
+        self._duals_eq, self._duals_ineq = np.zeros(me), np.zeros(mi)
+        self._lb = np.full(n, -np.inf) if lb is None else np.asarray(lb, dtype=np.double).ravel()
+        self._ub = np.full(n, np.inf) if ub is None else np.asarray(ub, dtype=np.double).ravel()
+        self._ineq_lb = np.full(mi, -np.inf) if ineq_lb is None else np.asarray(ineq_lb, dtype=np.double).ravel()
+        self._ineq_ub = np.full(mi, np.inf) if ineq_ub is None else np.asarray(ineq_ub, dtype=np.double).ravel()
+        self._obj_factor = 1.0
+
+    def n_primals(self):
+        return self._x0.size
+
+    def n_eq_constraints(self):
+        return self._duals_eq.size
+
+    def n_ineq_constraints(self):
+        return self._duals_ineq.size
+
+    def nnz_hessian_lag(self):
+        return coo_matrix(self.evaluate_hessian_lag()).nnz
+
+    def nnz_jacobian_eq(self):
+        return coo_matrix(self.evaluate_jacobian_eq()).nnz
+
+    def nnz_jacobian_ineq(self):
+        return coo_matrix(self.evaluate_jacobian_ineq()).nnz
+
+    def primals_lb(self):
+        return self._lb
+
+    def primals_ub(self):
+        return self._ub
+
+    def ineq_lb(self):
+        return self._ineq_lb
+
+    def ineq_ub(self):
+        return self._ineq_ub
+
+    def init_primals(self):
+        return self._x0
+
+    def init_duals_eq(self):
+        return np.zeros(self._duals_eq.size)
+
+    def init_duals_ineq(self):
+        return np.zeros(self._duals_ineq.size)
+
+    def set_primals(self, primals):
+        self._primals = np.asarray(primals, dtype=np.double)
+
+    def get_primals(self):
+        return self._primals
+
+    def set_duals_eq(self, duals):
+        self._duals_eq = np.asarray(duals, dtype=np.double)
+
+    def get_duals_eq(self):
+        return self._duals_eq
+
+    def set_duals_ineq(self, duals):
+        self._duals_ineq = np.asarray(duals, dtype=np.double)
+
+    def get_duals_ineq(self):
+        return self._duals_ineq
+
+    def set_obj_factor(self, obj_factor):
+        self._obj_factor = obj_factor
+
+    def get_obj_factor(self):
+        return self._obj_factor
+
+    def evaluate_objective(self):
+        return float(self._f(self._primals))
+
+    def evaluate_grad_objective(self):
+        return np.asarray(self._grad(self._primals), dtype=np.double)
+
+    def evaluate_eq_constraints(self):
+        return np.asarray(self._c_eq(self._primals), dtype=np.double)
+
+    def evaluate_ineq_constraints(self):
+        return np.asarray(self._c_ineq(self._primals), dtype=np.double)
+
+    def evaluate_jacobian_eq(self):
+        return coo_matrix(self._jac_eq(self._primals))
+
+    def evaluate_jacobian_ineq(self):
+        return coo_matrix(self._jac_ineq(self._primals))
+
+    def evaluate_hessian_lag(self):
+        return coo_matrix(self._hess(self._primals, self._duals_eq, self._duals_ineq, self._obj_factor))
+
+
 class InteriorPointInterface(object):
     """Counterpart of ``InteriorPointInterface`` (interface.py:251-679) over ANY object with the NLP protocol it uses
     there (``self._nlp``: PyNumero's ExtendedNLP -- a ``PyomoNLP`` / ``AmplNLP`` where Pyomo is installed, a
@@ -337,6 +449,10 @@ class InteriorPointInterface(object):
 
     def evaluate_hessian_lag(self):
         return self._nlp.evaluate_hessian_lag()
+
+    def grad_lag_primals_terms(self):
+        """J_eq^T y_eq + J_ineq^T y_ineq (the convergence check of the loop needs it, interior_point.py:236-238)."""
+        return (self.evaluate_jacobian_eq().T @ self._duals_eq + self.evaluate_jacobian_ineq().T @ self._duals_ineq)
 
     # ---- the KKT system the linear solver is handed
     def barrier_diagonals(self):

@@ -264,6 +264,47 @@ class StochasticSchurComplementInteriorPointInterface(object):
             last = self._comm.allreduce_sum(last)
         return self._per_scenario(per, last)
 
+    def _jacobian(self, rows_of, eq):
+        """Block Jacobian with one block row per scenario / time block and one block column more for the coupling
+        variables (sc_ip_interface.py:243-272, 1245-1270); rows_of(ndx, nlp) -> (diagonal block, coupling block)."""
+        N = self._num_scenarios
+        if self._mpi:
+            owner = -np.ones((N, N + 1), dtype=np.int64)
+            for ndx in range(N):
+                owner[ndx, ndx] = owner[ndx, N] = self._ownership[ndx]
+            jac = MPIBlockMatrix(N, N + 1, owner, self._comm)
+        else:
+            jac = BlockMatrix(N, N + 1)
+        jac.set_col_size(N, self._num_first_stage_vars)
+        for ndx, nlp in self._nlps.items():
+            diag, coupling = rows_of(ndx, nlp)
+            jac.set_block(ndx, ndx, diag)
+            if coupling is not None:
+                jac.set_block(ndx, N, coupling)
+        return jac
+
+    def _stack(self, mats, ncols):
+        sub = BlockMatrix(len(mats), 1)
+        sub.set_col_size(0, ncols)
+        for k, m in enumerate(mats):
+            sub.set_row_size(k, m.shape[0])
+            if m.shape[0]:
+                sub.set_block(k, 0, coo_matrix(m))
+        return sub
+
+    def evaluate_jacobian_eq(self):
+        """Rows: per scenario [its equality constraints | nonanticipativity L x - C z] (:1245-1260)."""
+        nfs = self._num_first_stage_vars
+
+        def rows(ndx, nlp):
+            me = nlp.n_eq_constraints()
+            return (self._stack([nlp.evaluate_jacobian_eq(), self._linking[ndx]], nlp.n_primals()),
+                    self._stack([coo_matrix((me, nfs)), -self._link_coupling[ndx]], nfs))
+        return self._jacobian(rows, True)
+
+    def evaluate_jacobian_ineq(self):
+        return self._jacobian(lambda ndx, nlp: (coo_matrix(nlp.evaluate_jacobian_ineq()), None), False)
+
     # ---- the KKT system (sc_ip_interface.py:1245-1285, 1677-1696; mpi_...:470-478)
     def _matrix(self):
         N = self._num_scenarios
@@ -511,6 +552,17 @@ class DynamicSchurComplementInteriorPointInterface(StochasticSchurComplementInte
             return (nlp.evaluate_jacobian_eq().T @ nlp.get_duals_eq() + self._link_backward[i].T @ self._duals_backward[i] +
                     self._link_forward[i].T @ self._duals_forward[i] + nlp.evaluate_jacobian_ineq().T @ nlp.get_duals_ineq())
         return self._per_scenario(per, -self._coupling_duals_term())
+
+    def evaluate_jacobian_eq(self):
+        """Rows: per time block [its equality constraints | backward link Lb x - Lbc z | forward link Lf x - Lfc z]
+        (:243-272, 753-765)."""
+        ncz = self._num_first_stage_vars
+
+        def rows(ndx, nlp):
+            me = nlp.n_eq_constraints()
+            return (self._stack([nlp.evaluate_jacobian_eq(), self._link_backward[ndx], self._link_forward[ndx]], nlp.n_primals()),
+                    self._stack([coo_matrix((me, ncz)), -self._link_backward_coupling[ndx], -self._link_forward_coupling[ndx]], ncz))
+        return self._jacobian(rows, True)
 
     # ---- the KKT system (:274-357, 839-862; mpi_...:242-250)
     def _forward_rows(self, ndx):

@@ -1,0 +1,84 @@
+"""The reference's dynamics example (parapint/examples/dynamics.py) against the known answers its own test holds
+(examples/tests/test_examples.py:38-58, tests/golden/dynamics_example_controls.json): pins the restated time-block
+interface + interior-point loop over the oracle's solver classes, then the product's solver class (numpy engine, HIP
+library) and the device-resident producer against the same nine numbers."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from parapint_amd.examples import dynamics as dy
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = {int(b): {int(t): v for t, v in d.items()}
+        for b, d in json.load(open(os.path.join(HERE, 'golden', 'dynamics_example_controls.json')))['p'].items()}
+
+
+def _check(p_of_block, places=7):
+    """unittest's assertAlmostEqual(a, b) of the reference's test: round(a - b, 7) == 0."""
+    for ndx, gold in GOLD.items():
+        p = p_of_block(ndx)
+        for t, v in gold.items():
+            assert round(p[t] - v, places) == 0, (ndx, t, p[t], v)
+
+
+def _oracle_solver(blocks):
+    from oracle.schur_complement import SchurComplementLinearSolver as OracleSC
+    from oracle.subsolvers import ScipyInterface as OracleScipy
+    return OracleSC({i: OracleScipy(compute_inertia=True) for i in blocks}, OracleScipy(compute_inertia=True))
+
+
+def test_dynamics_example_reproduces_the_reference_values_over_the_oracle_solver():
+    """ScipyInterface(compute_inertia=True) sub-solvers, as the reference's test configures them."""
+    it = dy.main(_oracle_solver(range(3)))
+    _check(it.p)
+    assert max(it.p(0).values()) <= 2.0 + 1e-7                   # p <= 2 is active at t = 10
+
+
+def test_dynamics_example_over_the_product_solver_on_the_cpu_engine():
+    from hostsim_engine import HostSimEngine
+    from parapint_amd.linalg.comm import SerialComm
+    from parapint_amd.linalg.hip_schur_complement import HipSchurComplementLinearSolver
+    it = dy.main(HipSchurComplementLinearSolver({t: None for t in range(3)}, None, comm=SerialComm(), engine=HostSimEngine()))
+    _check(it.p)
+
+
+def _device_loop(engine):
+    from parapint_amd.algorithms.device_interior_point import ip_solve_device
+    from parapint_amd.algorithms.interior_point import IPOptions, InteriorPointStatus
+    from parapint_amd.interfaces.schur_complement.device_sc_ip_interface import DeviceDynamicQPInterface
+    from parapint_amd.linalg.comm import SerialComm
+    from parapint_amd.linalg.hip_schur_complement import HipSchurComplementLinearSolver
+    blocks, times = [], {}
+    for ndx in range(3):
+        qp, x_times, p_times = dy.build_time_block(t0=30 * ndx, delta_t=1, num_finite_elements=30,
+                                                   constant_control_duration=10, time_scale=0.1)
+        blocks.append((qp, [0], [30]))
+        times[ndx] = (x_times, p_times)
+    it = DeviceDynamicQPInterface(blocks)
+    opt = IPOptions()
+    opt.linalg.solver = HipSchurComplementLinearSolver({t: None for t in range(3)}, None, comm=SerialComm(), engine=engine,
+                                                       result_buffers=0 if engine is not None else 2)
+    status, _ = ip_solve_device(it, opt)
+    assert status == InteriorPointStatus.optimal
+
+    def p(ndx):
+        x_times, p_times = times[ndx]
+        v = it.scenario_primals(ndx)
+        return {t: float(v[len(x_times) + i]) for i, t in enumerate(p_times)}
+    return p
+
+
+def test_dynamics_example_through_the_device_producer_on_cpu_engines():
+    from hostsim_engine import HostSimDeviceEngine
+    _check(_device_loop(HostSimDeviceEngine()))
+
+
+@pytest.mark.gpu
+def test_dynamics_example_over_the_hip_solver_and_the_device_producer():
+    from parapint_amd.linalg.comm import SerialComm
+    from parapint_amd.linalg.hip_schur_complement import HipSchurComplementLinearSolver
+    it = dy.main(HipSchurComplementLinearSolver({t: None for t in range(3)}, None, comm=SerialComm()))
+    _check(it.p)
+    _check(_device_loop(None))
