@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 
 GPU = '--gpu' in sys.argv
+REFERENCE_EXAMPLE = '--reference-example' in sys.argv     # parapint/examples/dynamics.py on 3 ranks, its test's known answers
 DEVICE_PRODUCER = '--device-producer' in sys.argv     # iterates resident on the (simulated) device, interior-point step kernels
 if not GPU:
     from hostsim_engine import HostSimDeviceEngine, HostSimEngine  # noqa: E402
@@ -61,12 +62,33 @@ def main_device(comm):
     assert np.array_equal(both[0], both[1])              # every rank took the same decisions from the same numbers
 
 
+def main_reference_example(comm):
+    """examples/tests/test_examples.py:38-58 (three processes, one time block each): every rank checks the optimal
+    controls of its own time block against the values the reference's test holds."""
+    import json
+    from parapint_amd.examples import dynamics as dy
+    assert comm.size == 3
+    gold = json.load(open(os.path.join(HERE, 'golden', 'dynamics_example_controls.json')))['p']
+    solver = HipSchurComplementLinearSolver({comm.rank: None}, None, comm=comm, engine=None if GPU else HostSimEngine())
+    it = dy.main(solver, comm=comm)
+    assert it.local_block_indices == [comm.rank]
+    p = it.p(comm.rank)
+    for t, v in gold[str(comm.rank)].items():
+        assert round(p[int(t)] - v, 7) == 0, (comm.rank, t, p[int(t)], v)
+
+
 def main():
     dist.init_process_group('gloo')
     if GPU:
         import torch
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count())
     comm = TorchComm()
+    if REFERENCE_EXAMPLE:
+        main_reference_example(comm)
+        print('rank %d ok' % comm.rank)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     assert comm.size == 2
     if DEVICE_PRODUCER:
         main_device(comm)

@@ -82,3 +82,23 @@ def test_dynamics_example_over_the_hip_solver_and_the_device_producer():
     it = dy.main(HipSchurComplementLinearSolver({t: None for t in range(3)}, None, comm=SerialComm()))
     _check(it.p)
     _check(_device_loop(None))
+
+
+def test_dynamics_example_on_three_ranks():
+    """The reference runs this test with three MPI processes, one time block each (test_examples.py:35-58): here three
+    gloo ranks over the product's solver class on the numpy engine; every rank checks its block's known answers."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '3', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(HERE, 'dynamic_multirank_worker.py'), '--reference-example']
+    env = dict(os.environ)
+    env['OMP_NUM_THREADS'] = '1'
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    text = out.stdout.decode()
+    assert out.returncode == 0, text[-4000:]
+    assert all('rank %d ok' % r in text for r in range(3))

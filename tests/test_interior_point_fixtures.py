@@ -119,6 +119,10 @@ def _known_answers(make_solver):
 
 def test_known_answers_over_the_oracle_scipy_interface():
     _known_answers(_scipy_solver)
+    # examples/tests/test_examples.py:10-16 (examples/interior_point.py)
+    from parapint_amd.examples import interior_point as ex
+    x = ex.main(linear_solver=_scipy_solver()).get_primals()
+    assert round(x[0] - 0, 7) == 0 and round(x[1] - 1, 7) == 0
 
 
 def test_known_answers_over_the_product_ldl_interface_on_the_cpu_engine():
