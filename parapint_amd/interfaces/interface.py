@@ -470,6 +470,13 @@ class InteriorPointInterface(object):
         n, me, mi = self.n_primals(), self.n_eq_constraints(), self.n_ineq_constraints()
         dp, ds = self.barrier_diagonals()
         H = coo_matrix(self.evaluate_hessian_lag())
+        low, up = H.row > H.col, H.row < H.col
+        if low.any() != up.any():
+            # one triangle only (ASL's convention, QuadraticProgram's): the KKT matrix carries both, as the one PyNumero
+            # hands the reference's solvers does -- a general-LU sub-solver (ScipyInterface) factorises it as given
+            off = low if low.any() else up
+            H = coo_matrix((np.concatenate([H.data, H.data[off]]), (np.concatenate([H.row, H.col[off]]),
+                                                                     np.concatenate([H.col, H.row[off]]))), shape=H.shape)
         A_eq, A_ineq = coo_matrix(self.evaluate_jacobian_eq()), coo_matrix(self.evaluate_jacobian_ineq())
         idx = np.arange(n)
         hess = coo_matrix((np.concatenate([H.data, dp]), (np.concatenate([H.row, idx]), np.concatenate([H.col, idx]))),
