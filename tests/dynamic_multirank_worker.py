@@ -72,6 +72,8 @@ def main_reference_example(comm):
     solver = HipSchurComplementLinearSolver({comm.rank: None}, None, comm=comm, engine=None if GPU else HostSimEngine())
     it = dy.main(solver, comm=comm)
     assert it.local_block_indices == [comm.rank]
+    J = it.evaluate_jacobian_eq()              # (rank-distributed containers: this rank's block row only)
+    assert J.bshape == (3, 4) and J.get_block(comm.rank, comm.rank).shape == (30 + (comm.rank > 0) + (comm.rank < 2), 34)
     p = it.p(comm.rank)
     for t, v in gold[str(comm.rank)].items():
         assert round(p[int(t)] - v, 7) == 0, (comm.rank, t, p[int(t)], v)
