@@ -1,9 +1,13 @@
 """GPU parity suite: the product path (HIP kernels through the C ABI) against the reference's
 golden vectors, the oracle and dense algebra.  Run on the GPU box with ``pytest -m gpu``."""
+import os
+
 import numpy as np
 import pytest
 
 import solver_cases as sc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 pytestmark = pytest.mark.gpu
 
@@ -129,7 +133,8 @@ def test_back_solve_results_do_not_alias():
 
 
 @pytest.mark.parametrize('shape', [(1, 10, 2, 1), (1, 5, 2, 5), (65, 10, 2, 2), (129, 12, 2, 3), (5, 300, 2, 208),
-                                   (3, 300, 2, 209), (2, 600, 2, 513)])
+                                   (3, 300, 2, 209), (2, 600, 2, 513), (2, 800, 2, 730), (2, 1000, 2, 1000),
+                                   (2, 1001, 2, 1001)])
 def test_edge_shapes_against_full_space_superlu(shape):
     """One block, one coupling variable, n_theta = n_q, a ragged chunk holding a single instance, and the coupling
     dimensions at which the dense S path changes (208 | 209: register-resident / blocked, 512 | 513: one workgroup /
