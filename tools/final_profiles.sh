@@ -41,6 +41,7 @@ python3 tools/pmc_traffic.py $out/pmc_fetch $out/pmc_write $raw $n $batch $out/p
 echo "pmc done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_ip -- python3 tools/ip_c3.py 1024 > $out/ip_loop_under_rocprof.json 2> $out/stats_ip.err && cp $(find $out/stats_ip -name '*kernel_stats.csv' | head -1) $out/kernel_stats_ip_loop.csv
 python3 tools/ip_c3.py 1024 > $out/ip_loop.json 2> $out/ip_loop.err
+bash tools/ip_step_traffic.sh $tag/ip_traffic > $out/ip_step_traffic.log 2>&1 && cp $out/ip_traffic/ip_step_traffic.json $out/ip_step_traffic.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_dyn -- python3 tools/dynamic_ip.py 512 49 2 40 > $out/dynamic_ip_loop_under_rocprof.json 2> $out/stats_dyn.err && cp $(find $out/stats_dyn -name '*kernel_stats.csv' | head -1) $out/kernel_stats_dynamic_ip_loop.csv
 python3 tools/dynamic_ip.py 512 49 2 40 > $out/dynamic_ip_loop.json 2> $out/dynamic_ip_loop.err
 python3 bench.py --workload C2 --no-cpu-baseline > $out/bench_C2.json 2> $out/c2.err
