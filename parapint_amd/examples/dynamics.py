@@ -96,10 +96,26 @@ class Problem(MPIDynamicSchurComplementInteriorPointInterface):
         return {t: float(v[len(x_times) + i]) for i, t in enumerate(p_times)}
 
 
-def main(linear_solver, comm=None, **problem):
+def _solver_from_class(subproblem_solver_class, subproblem_solver_options, blocks, comm=None):
+    """The reference's examples build their linear solver from a sub-solver class and its options
+    (``MPISchurComplementLinearSolver(subproblem_solvers={ndx: cls(**opts)}, schur_complement_solver=cls(**opts))``,
+    e.g. examples/dynamics.py:166-168); the same call builds this package's class of that name."""
+    from parapint_amd.linalg import MPISchurComplementLinearSolver
+    from parapint_amd.linalg.comm import SerialComm
+    opts = subproblem_solver_options or {}
+    return MPISchurComplementLinearSolver(subproblem_solvers={ndx: subproblem_solver_class(**opts) for ndx in blocks},
+                                          schur_complement_solver=subproblem_solver_class(**opts),
+                                          comm=SerialComm() if comm is None else comm)
+
+
+def main(linear_solver=None, comm=None, subproblem_solver_class=None, subproblem_solver_options=None, show_plot=False, **problem):
     """dynamics.py:153-180 (without the plot): the default problem -- 90 finite elements, 3 time blocks, the control
-    constant over 10 -- through ``ip_solve``; returns the interface."""
+    constant over 10 -- through ``ip_solve``; returns the interface.  Either a ready linear solver or, as the reference's
+    signature has it, ``subproblem_solver_class`` + ``subproblem_solver_options``."""
     interface = Problem(comm=comm, **problem)
+    if linear_solver is None:
+        linear_solver = _solver_from_class(subproblem_solver_class, subproblem_solver_options,
+                                           interface.local_block_indices, comm)
     options = IPOptions()
     options.linalg.solver = linear_solver
     status = ip_solve(interface=interface, options=options)

@@ -96,9 +96,14 @@ def build_interface(farmer, comm=None):
     return StochasticSchurComplementInteriorPointInterface(qps, first_stage, comm=comm)
 
 
-def main(farmer, linear_solver, comm=None):
-    """stochastic.py:115-124: returns the interface after a successful solve."""
+def main(farmer, linear_solver=None, comm=None, subproblem_solver_class=None, subproblem_solver_options=None):
+    """stochastic.py:115-124: returns the interface after a successful solve.  Either a ready linear solver or, as the
+    reference's signature has it, ``subproblem_solver_class`` + ``subproblem_solver_options``."""
     interface = build_interface(farmer, comm=comm)
+    if linear_solver is None:
+        from parapint_amd.examples.dynamics import _solver_from_class
+        linear_solver = _solver_from_class(subproblem_solver_class, subproblem_solver_options,
+                                           interface.local_block_indices, comm)
     options = IPOptions()
     options.linalg.solver = linear_solver
     status = ip_solve(interface=interface, options=options)

@@ -1564,11 +1564,23 @@ class HipLDLInterface(LinearSolverInterface):
         self.cntl_options = dict(cntl_options or {})
         self.icntl_options = dict(icntl_options or {})
         self.iw_factor, self.a_factor = iw_factor, a_factor
-        u = self.cntl_options.get(1)
-        self._sc = HipSchurComplementLinearSolver(comm=SerialComm(), engine=engine, pivot_tolerance=u,
-                                                  symbolic_pivot_threshold=None if u is None else max(min(u, 0.5), 0.01))
+        self._engine_arg = engine
+        self._sc_made = None
         self._dim = None
         self._num_status = None
+
+    @property
+    def _sc(self):
+        """The one-block solver behind this interface, created at first use: the reference's callers build one sub-solver
+        object per block (``{ndx: InteriorPointMA27Interface(...) for ndx in ...}``) and hand them to the Schur-complement
+        solver, which here factorises all blocks as one batch and never calls them -- such placeholders must not each
+        open a device handle."""
+        if self._sc_made is None:
+            u = self.cntl_options.get(1)
+            self._sc_made = HipSchurComplementLinearSolver(
+                comm=SerialComm(), engine=self._engine_arg, pivot_tolerance=u,
+                symbolic_pivot_threshold=None if u is None else max(min(u, 0.5), 0.01))
+        return self._sc_made
 
     def _wrap(self, matrix):
         from scipy.sparse import coo_matrix

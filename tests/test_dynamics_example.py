@@ -76,6 +76,26 @@ def test_dynamics_example_through_the_device_producer_on_cpu_engines():
 
 
 @pytest.mark.gpu
+def test_examples_called_the_way_the_reference_tests_call_them():
+    """examples/tests/test_examples.py:18-58 with the package name exchanged: ``main(subproblem_solver_class=...,
+    subproblem_solver_options=...)`` builds ``MPISchurComplementLinearSolver`` from per-block sub-solver objects, which here
+    are placeholders of the batched factorisation (they open no device handle of their own)."""
+    import parapint_amd
+    from parapint_amd import linalg
+    from parapint_amd.examples import stochastic
+    interface = dy.main(subproblem_solver_class=linalg.ScipyInterface, subproblem_solver_options={'compute_inertia': True},
+                        show_plot=False)
+    _check(interface.p)
+    farmer = stochastic.Farmer()
+    interface = stochastic.main(farmer=farmer, subproblem_solver_class=linalg.ScipyInterface,
+                                subproblem_solver_options={'compute_inertia': True})
+    acreage = np.asarray(interface.get_primals().get_block(len(farmer.scenarios)))
+    assert np.abs(acreage - np.array([170.0, 80.0, 250.0])).max() < 5e-6          # WHEAT, CORN, SUGAR_BEETS (5 places)
+    placeholder = linalg.InteriorPointMA27Interface(cntl_options={1: 1e-6})
+    assert placeholder._sc_made is None                                           # (no device handle until it is used)
+
+
+@pytest.mark.gpu
 def test_dynamics_example_over_the_hip_solver_and_the_device_producer():
     from parapint_amd.linalg.comm import SerialComm
     from parapint_amd.linalg.hip_schur_complement import HipSchurComplementLinearSolver
