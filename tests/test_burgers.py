@@ -123,3 +123,21 @@ def test_burgers_over_the_hip_solver():
     assert abs(a.evaluate_objective() - b.evaluate_objective()) <= 1e-8
     ya, yb = _trajectory(a, 16, nfe_t, nfe_x - 1), _trajectory(b, 8, nfe_t, nfe_x - 1)
     assert ya.shape == yb.shape == (nfe_t + 1, nfe_x - 1) and np.abs(ya - yb).max() <= 2e-4 and np.abs(ya).max() > 0.5
+
+
+@pytest.mark.gpu
+def test_burgers_at_the_dimensions_of_baseline_configuration_4():
+    """BASELINE.json configs[3] to the letter: the Burgers discretisation with 512 time blocks x 4018 variables (nfe_x = 50,
+    40 time steps per block), 49 states between the blocks, coupling block 50 078 with block-tridiagonal S, through
+    ``ip_solve`` with new Hessian / Jacobian values from the host at every iteration.  The loop's own convergence test (primal,
+    dual and complementarity infeasibility <= 1e-8 of the WHOLE problem, evaluated by the interface) is the check."""
+    from parapint_amd.linalg.comm import SerialComm
+    from parapint_amd.linalg.hip_schur_complement import HipSchurComplementLinearSolver
+    T = 512
+    solver = HipSchurComplementLinearSolver({t: None for t in range(T)}, None, comm=SerialComm(), result_buffers=2)
+    it = bg.main(solver, nfe_x=50, nfe_t=T * 40, nblocks=T)
+    assert solver._btd is not None and solver._nc == 2 * 49 * 511
+    assert it.scenario_interface(1).n_primals() == 4018
+    y = _trajectory(it, T, T * 40, 49)
+    assert y.shape == (T * 40 + 1, 49) and np.isfinite(y).all() and 0.9 <= np.abs(y).max() <= 1.1
+    assert 0.0 < it.evaluate_objective() < 0.1
