@@ -138,7 +138,10 @@ class BlockMatrix(object):
             rows, cols, data = np.zeros(0, dtype=idt), np.zeros(0, dtype=idt), np.zeros(0, dtype=np.double)
         if len(_STRUCTURES) >= _STRUCTURES_MAX:
             _STRUCTURES.pop(next(iter(_STRUCTURES)))                # (oldest signature first)
-        _STRUCTURES.setdefault(sig, []).append(([(lf.row.copy(), lf.col.copy()) for lf, _, _ in leaves], rows, cols))
+        known = _STRUCTURES.setdefault(sig, [])
+        if len(known) >= 8:                                         # (patterns that differ only in their indices: keep the last few)
+            known.pop(0)
+        known.append(([(lf.row.copy(), lf.col.copy()) for lf, _, _ in leaves], rows, cols))
         return coo_matrix((data, (rows, cols)), shape=shape, copy=False)
 
     def tocsr(self):
