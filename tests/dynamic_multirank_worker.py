@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 
 GPU = '--gpu' in sys.argv
+FIXTURES = '--fixtures' in sys.argv       # interfaces/schur_complement/tests/test_mpi_sc_ip_interface.py on 3 ranks
 REFERENCE_EXAMPLE = '--reference-example' in sys.argv     # parapint/examples/dynamics.py on 3 ranks, its test's known answers
 DEVICE_PRODUCER = '--device-producer' in sys.argv     # iterates resident on the (simulated) device, interior-point step kernels
 if not GPU:
@@ -62,6 +63,27 @@ def main_device(comm):
     assert np.array_equal(both[0], both[1])              # every rank took the same decisions from the same numbers
 
 
+def main_fixtures(comm):
+    """test_mpi_sc_ip_interface.py:164-486: the hand-set state through the rank-distributed containers; every rank checks
+    the sizes, the objective (summed over the ranks), its own block of the right-hand side and the coupling block (summed
+    over the ranks: forward-link residuals and the gradient of the Lagrangian with respect to the coupling states)."""
+    import math
+    import test_sc_ip_interface_fixtures as fx
+    assert comm.size == 3
+    it = fx.make_interface(comm)
+    assert it.local_block_indices == [comm.rank]
+    assert it.n_primals() == 14 and it.n_eq_constraints() == 10 and it.n_ineq_constraints() == 0
+    s = lambda t: math.sin(fx.TS * t) + 1
+    expected_obj = sum(0.5 * (a - s(a)) ** 2 + 0.5 * (b - s(b)) ** 2 for a, b in zip(range(0, 6), range(1, 7)))
+    assert abs(it.evaluate_objective() - expected_obj) <= 1e-12
+    rhs, want = it.evaluate_primal_dual_kkt_rhs(), fx.expected_rhs()
+    offsets = [0, 6, 13, 20, 24]                       # blocks 0, 1, 2 and the coupling block in the flat vector
+    mine = np.asarray(rhs.get_block(comm.rank).flatten())
+    assert np.allclose(mine, want[offsets[comm.rank]:offsets[comm.rank + 1]])
+    last = rhs.get_block(3)
+    assert np.allclose(np.asarray(last.flatten() if hasattr(last, 'get_block') else last), want[20:24])
+
+
 def main_reference_example(comm):
     """examples/tests/test_examples.py:38-58 (three processes, one time block each): every rank checks the optimal
     controls of its own time block against the values the reference's test holds."""
@@ -85,8 +107,8 @@ def main():
         import torch
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count())
     comm = TorchComm()
-    if REFERENCE_EXAMPLE:
-        main_reference_example(comm)
+    if FIXTURES or REFERENCE_EXAMPLE:
+        (main_fixtures if FIXTURES else main_reference_example)(comm)
         print('rank %d ok' % comm.rank)
         dist.barrier()
         dist.destroy_process_group()

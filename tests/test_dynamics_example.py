@@ -104,9 +104,19 @@ def test_dynamics_example_over_the_hip_solver_and_the_device_producer():
     _check(_device_loop(None))
 
 
+def test_interface_fixtures_on_three_ranks():
+    """interfaces/schur_complement/tests/test_mpi_sc_ip_interface.py:164-486: the interface-level known answers through
+    the rank-distributed containers, three gloo ranks."""
+    _three_ranks('--fixtures')
+
+
 def test_dynamics_example_on_three_ranks():
     """The reference runs this test with three MPI processes, one time block each (test_examples.py:35-58): here three
     gloo ranks over the product's solver class on the numpy engine; every rank checks its block's known answers."""
+    _three_ranks('--reference-example')
+
+
+def _three_ranks(mode):
     import socket
     import subprocess
     import sys
@@ -115,7 +125,7 @@ def test_dynamics_example_on_three_ranks():
     port = s.getsockname()[1]
     s.close()
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '3', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.join(HERE, 'dynamic_multirank_worker.py'), '--reference-example']
+           '--master-port', str(port), os.path.join(HERE, 'dynamic_multirank_worker.py'), mode]
     env = dict(os.environ)
     env['OMP_NUM_THREADS'] = '1'
     out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)

@@ -22,11 +22,13 @@ def _bv(blocks):
     return v
 
 
-@pytest.fixture(scope='module')
-def interface():
+def make_interface(comm=None):
     """setUpClass of the reference's TestSCIPInterface (:152-247): x[t] = t, p = 0.5 / 1 / 1.5, duals of the block's own
-    constraints 1..6, link duals = block index, upper-bound dual of p = block index, coupling states 3 and 6."""
-    it = dy.Problem(num_finite_elements=6, constant_control_duration=2, time_scale=TS, num_time_blocks=3, p_ub=1.75)
+    constraints 1..6, link duals = block index, upper-bound dual of p = block index, coupling states 3 and 6.  With a
+    communicator: the MPI flavour (test_mpi_sc_ip_interface.py:164-293), every rank sets the blocks it owns."""
+    it = dy.Problem(num_finite_elements=6, constant_control_duration=2, time_scale=TS, num_time_blocks=3, p_ub=1.75, comm=comm)
+    if comm is not None and comm.size > 1:
+        return _set_state_distributed(it)
     T = 3
     primals = [[0, 1, 2, 0.5], [2, 3, 4, 1], [4, 5, 6, 1.5], [3, 6]]
     own = [[1, 2], [3, 4], [5, 6]]
@@ -44,6 +46,50 @@ def interface():
     it.set_duals_primals_ub(_bv([[0, 0, 0, ndx] for ndx in range(T)] + [np.zeros(2)]))
     it.set_barrier_parameter(BARRIER)
     return it
+
+
+@pytest.fixture(scope='module')
+def interface():
+    return make_interface()
+
+
+def _set_state_distributed(it):
+    """The same state through the rank-distributed containers: a rank sets the blocks it owns and the (replicated)
+    coupling block."""
+    T = 3
+    primals = [[0, 1, 2, 0.5], [2, 3, 4, 1], [4, 5, 6, 1.5], [3, 6]]
+    own = [[1, 2], [3, 4], [5, 6]]
+
+    def vec(extra, per_block, last=None):
+        v = it._vector(extra)
+        for ndx in it.local_block_indices:
+            b = per_block(ndx)
+            v.set_block(ndx, b if hasattr(b, 'get_block') else np.asarray(b, dtype=np.double))
+        if extra:
+            v.set_block(T, np.asarray(last, dtype=np.double))
+        return v
+    it.set_primals(vec(True, lambda n: primals[n], primals[T]))
+    it.set_duals_eq(vec(False, lambda n: _bv([own[n], np.zeros(0) if n == 0 else np.ones(1) * n,
+                                              np.zeros(0) if n == T - 1 else np.ones(1) * n])))
+    for name in ('duals_ineq', 'duals_slacks_lb', 'duals_slacks_ub'):
+        getattr(it, 'set_' + name)(vec(False, lambda n: np.zeros(0)))
+    it.set_duals_primals_lb(vec(True, lambda n: np.zeros(4), np.zeros(2)))
+    it.set_duals_primals_ub(vec(True, lambda n: [0, 0, 0, n], np.zeros(2)))
+    it.set_barrier_parameter(BARRIER)
+    return it
+
+
+def expected_rhs():
+    """:402-450, in the flat order [block 0 | block 1 | block 2 | coupling block]."""
+    s, b = (lambda t: math.sin(TS * t) + 1), BARRIER
+    return -np.array([
+        1 * (0 - s(0)) + (-1) * 1, 2 * (1 - s(1)) + 2 * 1 + (-1) * 2, 1 * (2 - s(2)) + 2 * 2 + 1 * 0,
+        0 + (-1) * 1 + (-1) * 2 + b / (1.75 - 0.5), 1 - (0 + (0.5 - 1)), 2 - (1 + (0.5 - 2)),
+        1 * (2 - s(2)) + (-1) * 3 + 1 * 1, 2 * (3 - s(3)) + 2 * 3 + (-1) * 4, 1 * (4 - s(4)) + 2 * 4 + 1 * 1,
+        0 + (-1) * 3 + (-1) * 4 + b / (1.75 - 1.0), 3 - (2 + (1 - 3)), 4 - (3 + (1 - 4)), 2 - 3,
+        1 * (4 - s(4)) + (-1) * 5 + 1 * 2, 2 * (5 - s(5)) + 2 * 5 + (-1) * 6, 1 * (6 - s(6)) + 2 * 6,
+        0 + (-1) * 5 + (-1) * 6 + b / (1.75 - 1.5), 5 - (4 + (1.5 - 5)), 6 - (5 + (1.5 - 6)), 4 - 6,
+        2 - 3, 4 - 6, 0 + (-1) * 1 + (-1) * 0, 0 + (-1) * 2 + (-1) * 1])
 
 
 def _flat(v):
@@ -98,15 +144,7 @@ def test_constraints_and_jacobian(interface):
 def test_primal_dual_kkt_rhs(interface):
     """:402-450: per block [grad L of its variables | its constraints | backward link], then the coupling block
     [forward links of blocks 0, 1 | grad L of the coupling states]."""
-    s, b = (lambda t: math.sin(TS * t) + 1), BARRIER
-    expected = -np.array([
-        1 * (0 - s(0)) + (-1) * 1, 2 * (1 - s(1)) + 2 * 1 + (-1) * 2, 1 * (2 - s(2)) + 2 * 2 + 1 * 0,
-        0 + (-1) * 1 + (-1) * 2 + b / (1.75 - 0.5), 1 - (0 + (0.5 - 1)), 2 - (1 + (0.5 - 2)),
-        1 * (2 - s(2)) + (-1) * 3 + 1 * 1, 2 * (3 - s(3)) + 2 * 3 + (-1) * 4, 1 * (4 - s(4)) + 2 * 4 + 1 * 1,
-        0 + (-1) * 3 + (-1) * 4 + b / (1.75 - 1.0), 3 - (2 + (1 - 3)), 4 - (3 + (1 - 4)), 2 - 3,
-        1 * (4 - s(4)) + (-1) * 5 + 1 * 2, 2 * (5 - s(5)) + 2 * 5 + (-1) * 6, 1 * (6 - s(6)) + 2 * 6,
-        0 + (-1) * 5 + (-1) * 6 + b / (1.75 - 1.5), 5 - (4 + (1.5 - 5)), 6 - (5 + (1.5 - 6)), 4 - 6,
-        2 - 3, 4 - 6, 0 + (-1) * 1 + (-1) * 0, 0 + (-1) * 2 + (-1) * 1])
+    expected = expected_rhs()
     got = _flat(interface.evaluate_primal_dual_kkt_rhs())
     assert got.size == 24 and np.allclose(got, expected)
 
