@@ -41,6 +41,7 @@ class BurgersNLP(object):
         self._primals = np.zeros(self.n)                               # (Pyomo variables without a value start at 0)
         self._duals_eq = np.zeros(self.me)
         self._obj_factor = 1.0
+        self._cache = {}
         # trapezoid weights in time; the objective is 1/2 sum_k w_k dx sum_i [(y - y0)^2 + omega u^2] (+ start term)
         self.w = np.full(nt + 1, self.dt)
         self.w[0] = self.w[-1] = 0.5 * self.dt
@@ -124,12 +125,14 @@ class BurgersNLP(object):
 
     def set_primals(self, primals):
         self._primals = np.asarray(primals, dtype=np.double)
+        self._cache = {}                    # evaluations are kept until the state changes (as PyNumero's NLP classes do)
 
     def get_primals(self):
         return self._primals
 
     def set_duals_eq(self, duals):
         self._duals_eq = np.asarray(duals, dtype=np.double)
+        self._cache.pop('hess', None)
 
     def get_duals_eq(self):
         return self._duals_eq
@@ -142,6 +145,7 @@ class BurgersNLP(object):
 
     def set_obj_factor(self, obj_factor):
         self._obj_factor = obj_factor
+        self._cache.pop('hess', None)
 
     def get_obj_factor(self):
         return self._obj_factor
@@ -172,6 +176,11 @@ class BurgersNLP(object):
         return up, dn
 
     def evaluate_eq_constraints(self):
+        if 'c' not in self._cache:
+            self._cache['c'] = self._eq_constraints()
+        return self._cache['c']
+
+    def _eq_constraints(self):
         y, u = self._yu()
         out = []
         for k in range(1, self.nt + 1):
@@ -186,6 +195,11 @@ class BurgersNLP(object):
         return np.zeros(0)
 
     def evaluate_jacobian_eq(self):
+        if 'jac' not in self._cache:
+            self._cache['jac'] = self._jacobian_eq()
+        return self._cache['jac']
+
+    def _jacobian_eq(self):
         y, _ = self._yu()
         vals = []
         for k in range(1, self.nt + 1):
@@ -203,6 +217,11 @@ class BurgersNLP(object):
         return coo_matrix((0, self.n))
 
     def evaluate_hessian_lag(self):
+        if 'hess' not in self._cache:
+            self._cache['hess'] = self._hessian_lag()
+        return self._cache['hess']
+
+    def _hessian_lag(self):
         m, nt = self.m, self.nt
         diag_y = self.dx * self.w[:, None] * np.ones((nt + 1, m))
         diag_u = self.dx * self.w[:, None] * self.omega * np.ones((nt + 1, m))

@@ -6,6 +6,8 @@
 #   bench_C2.json, bench_C4.json, kernel_stats_C4.csv, bench_128_blocks.json, bench_C5.json, bench_C5_512_blocks.json
 #   ip_loop.json, kernel_stats_ip_loop.csv    the interior-point loop at C3 dimensions (tools/ip_c3.py), plain and under rocprofv3 --stats
 #   dynamic_ip_loop.json, kernel_stats_dynamic_ip_loop.csv    the loop of a time-staged problem at the C4 dimensions (tools/dynamic_ip.py)
+#   burgers_ip_configuration_4.json    BASELINE configs[3] to the letter through ip_solve with the host producer (tools/burgers_ip.py)
+#   ip_step_traffic.json    counter traffic of the interior-point step kernels (tools/ip_step_traffic.sh)
 #   mfma_util.json, mfma_util_C4.json, mfma_util_C5.json    own --pmc SQ_VALU_MFMA_BUSY_CYCLES passes (matrix-core kernels)
 tag=${1:-final}
 out=gpurun_out/$tag
@@ -44,6 +46,7 @@ python3 tools/ip_c3.py 1024 > $out/ip_loop.json 2> $out/ip_loop.err
 bash tools/ip_step_traffic.sh $tag/ip_traffic > $out/ip_step_traffic.log 2>&1 && cp $out/ip_traffic/ip_step_traffic.json $out/ip_step_traffic.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_dyn -- python3 tools/dynamic_ip.py 512 49 2 40 > $out/dynamic_ip_loop_under_rocprof.json 2> $out/stats_dyn.err && cp $(find $out/stats_dyn -name '*kernel_stats.csv' | head -1) $out/kernel_stats_dynamic_ip_loop.csv
 python3 tools/dynamic_ip.py 512 49 2 40 > $out/dynamic_ip_loop.json 2> $out/dynamic_ip_loop.err
+python3 tools/burgers_ip.py 512 50 40 > $out/burgers_ip_configuration_4.json 2> $out/burgers_ip.err
 python3 bench.py --workload C2 --no-cpu-baseline > $out/bench_C2.json 2> $out/c2.err
 python3 bench.py --blocks 128 --no-cpu-baseline --no-boundary --no-ip-loop > $out/bench_128_blocks.json 2> $out/b128.err
 python3 bench.py --workload C4 --no-cpu-baseline --steps 10 --warmup 2 > $out/bench_C4.json 2> $out/c4.err
