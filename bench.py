@@ -621,6 +621,42 @@ def main():
         except Exception as exc:     # (an auxiliary measurement: reported, never a reason to lose the headline line)
             ip_loop_dynamic = {'converged': False, 'error': '%s: %s' % (type(exc).__name__, exc)}
 
+    # ---- BASELINE.json configs[3] to the letter: the Burgers discretisation (parapint/examples/burgers.py) with 512 time blocks x
+    # 4018 variables (nfe_x = 50, 40 time steps per block), 49 states between the blocks -- a NONLINEAR problem, iterates
+    # resident on the device, the model's functions evaluated there by the example's device model (torch operations: the model
+    # is the caller's code, as Pyomo's is for the reference), everything else the library's kernels
+    ip_loop_burgers = None
+    if not args.no_ip_loop_dynamic and not args.no_ip_loop and args.workload in ('C3', 'C4') and not args.blocks and world == 1:
+        try:
+            from parapint_amd.algorithms.device_interior_point import ip_solve_device
+            from parapint_amd.algorithms.interior_point import IPOptions, InteriorPointStatus
+            from parapint_amd.examples import burgers
+            Tb = args.ip_time_blocks
+            best = None
+            for rep in range(2):
+                ipi = burgers.device_interface(50, Tb * 40, Tb)
+                ipo = IPOptions()
+                ipo.linalg.solver = HipSchurComplementLinearSolver({t: None for t in range(Tb)}, None, comm=comm, result_buffers=2)
+                hist, ipst = [], {}
+                sync_all()
+                t0 = time.perf_counter()
+                ip_status, ip_iters = ip_solve_device(ipi, ipo, history=hist, stats=ipst)
+                sync_all()
+                t_ip = time.perf_counter() - t0
+                pg = max(ipi.pattern_groups, key=lambda g: len(g.members))
+                cur = {'it_per_s': ip_iters / ipst['loop_s'], 'iterations': ip_iters,
+                       'ms_per_iteration': 1e3 * ipst['loop_s'] / max(ip_iters, 1), 'loop_seconds': ipst['loop_s'],
+                       'setup_seconds': t_ip - ipst['loop_s'], 'converged': ip_status == InteriorPointStatus.optimal,
+                       'final_infeasibilities': list(hist[-1][:3]) if hist else None, 'objective': ipi.evaluate_objective(),
+                       'time_blocks': Tb, 'variables_per_block': pg.n, 'block_dim': pg.nb, 'n_coupling': 2 * ipi.ncz,
+                       'torch_ops_of_the_model': ipst.get('torch_ops')}
+                if best is None or cur['it_per_s'] > best['it_per_s']:
+                    best = cur
+                del ipi, ipo
+            ip_loop_burgers = best
+        except Exception as exc:
+            ip_loop_burgers = {'converged': False, 'error': '%s: %s' % (type(exc).__name__, exc)}
+
     if rank == 0:
         launches = sum(p['launches_per_step'] for p in phases.values()) if phases else None
         out = {
@@ -641,6 +677,7 @@ def main():
             'value_boundary': (boundary or {}).get('it_per_s'),
             'ip_loop': ip_loop,
             'ip_loop_dynamic': ip_loop_dynamic,
+            'ip_loop_burgers': ip_loop_burgers,
             'roofline': roofline,
             'dense_phase': dense_phase,
             'cpu_baseline': cpu_baseline,

@@ -389,6 +389,10 @@ int pp_vec_permute(pp_handle h, int64_t n, const int64_t* idx, const double* src
  * has ncz entries, dz is the coupling solution [d rho | d z], and v_local / v_table rows are 8 + 2 ncz long:
  * {..., rho rows of the coupling right-hand side (this rank's forward links), z rows (this rank's link duals)}.  Without
  * a map every instance ties all nfs coupling variables (two-stage stochastic programs), nfw = 0 and ncz is ignored.
+ * Nonlinear models (obj_row >= 0): the caller evaluates its model at the iterate before pp_ip_residuals and leaves grad f in
+ * data rows 0 .. n - 1, -c_eq(x) in rows n .. n + me - 1, the objective value of every instance in row obj_row, the current
+ * Hessian-of-the-Lagrangian and Jacobian values in src; the row programs then carry no Hessian terms.  obj_row = -1: a QP
+ * (data = c | b_eq, objective 1/2 x'Hx + c'x from the row programs).
  *   pp_ip_rhs           rows x and s of rhs from G, the iterate and the barrier parameter mu (the other rows are written by
  *                       pp_ip_residuals)
  *   pp_ip_step_lengths  alpha_local[2] (device) = this rank's fraction-to-the-boundary step lengths, tau = 1 - mu; the
@@ -408,7 +412,7 @@ int pp_vec_permute(pp_handle h, int64_t n, const int64_t* idx, const double* src
  * Between ranks the caller all-gathers alpha_local -> alpha_table and v_local -> v_table (pp_comm_allgather or any other
  * transport); with one rank the tables are the local arrays. */
 typedef struct pp_ip_group {
-  int32_t n, mi, me, nfs, batch, bpad, src_dp, src_ds, nfw, ncz;
+  int32_t n, mi, me, nfs, batch, bpad, src_dp, src_ds, nfw, ncz, obj_row, reserved;
   double* W;
   const double* bounds;
   const double* data;

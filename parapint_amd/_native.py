@@ -139,7 +139,7 @@ SIGNATURES = {
 
 class IpGroup(ctypes.Structure):
     """pp_ip_group of include/parapint_hip.h (one pattern group of the interior-point step on the device)."""
-    _fields_ = [(k, ctypes.c_int32) for k in ('n', 'mi', 'me', 'nfs', 'batch', 'bpad', 'src_dp', 'src_ds', 'nfw', 'ncz')] + \
+    _fields_ = [(k, ctypes.c_int32) for k in ('n', 'mi', 'me', 'nfs', 'batch', 'bpad', 'src_dp', 'src_ds', 'nfw', 'ncz', 'obj_row', 'reserved')] + \
                [(k, ctypes.c_void_p) for k in ('W', 'bounds', 'data', 'src', 'G', 'rhs', 'delta', 'prog', 'terms', 'zoff')]
 
 

@@ -214,6 +214,13 @@ __global__ __launch_bounds__(256) void k_ip_rows(pp_ip_group g, const double* __
   for (int q = 0; q < rpw; ++q) {
     const int slot = (tile * 4 + wave) * rpw + q;         // (wave-uniform)
     if (slot >= nprog) break;
+    if (slot == 0 && g.obj_row >= 0) {
+      // nonlinear model: the instance's objective value comes from the model's own evaluation (a row of `data`); the
+      // gradient rows then hold grad f and the constraint rows -c(x) instead of the linear / constant terms of a QP
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        if (b + i < g.batch) v[2] = v[2] + g.data[(size_t)g.obj_row * bpad + b + i];
+    }
     // rows are worked on in the producer's order (prog[4 slot + 3]): rows that read the same Jacobian entries -- a
     // constraint row and the gradient rows of its variables -- sit next to each other, so the second read of an entry
     // meets the L2 instead of HBM
@@ -289,7 +296,7 @@ __global__ __launch_bounds__(256) void k_ip_rows(pp_ip_group g, const double* __
         G[i] = gH + acc[i];
         if (b + i < g.batch) {
           v[1] = nmax(v[1], fabs((G[i] - zl[i]) + zu[i]));
-          v[2] = v[2] + xp[i] * (0.5 * accH[i] + ev[i]);      // 1/2 x'Hx + c'x
+          if (g.obj_row < 0) v[2] = v[2] + xp[i] * (0.5 * accH[i] + ev[i]);      // 1/2 x'Hx + c'x
         }
       }
       stv<NV>(g.G + (size_t)p * bpad + b, G);

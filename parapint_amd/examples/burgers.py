@@ -235,6 +235,90 @@ class BurgersNLP(object):
         return coo_matrix((np.concatenate(vals), (self.hrow, self.hcol)), shape=(self.n, self.n))
 
 
+class BurgersDeviceModel(object):
+    """The functions of ``BurgersNLP`` evaluated for all time blocks of a pattern group at once on [row][lane] arrays (lane =
+    time block) that stay on the device: the model side of ``DeviceDynamicNLPInterface`` (what Pyomo / ASL evaluate for the
+    reference at every iterate).  Written against the array operations numpy and torch share, so the same code serves the
+    numpy engines of the CPU tests and device tensors; a dozen elementwise operations over the group's arrays per call."""
+
+    def __init__(self, nlps, bpad):
+        q = nlps[0]
+        for o in nlps:
+            if (o.m, o.nt, o.dt, o.dx, o.omega, o.v, o.r, o.init_conditions, o.start_term) != \
+                    (q.m, q.nt, q.dt, q.dx, q.omega, q.v, q.r, q.init_conditions, q.start_term):
+                raise ValueError('the time blocks of a pattern group must share their discretisation')
+        self.q = q
+        self._consts = None
+
+    def _constants(self, like):
+        if self._consts is None:
+            q = self.q
+            to = (lambda a: like.new_tensor(a)) if hasattr(like, 'new_tensor') else (lambda a: np.asarray(a, dtype=np.double))
+            self._consts = (to(q.y0.reshape(1, q.m, 1)), to(q.w.reshape(q.nt + 1, 1, 1)))
+        return self._consts
+
+    def evaluate(self, W, src, data, layout):
+        q = self.q
+        m, nt, dt, dx, om, v, r = q.m, q.nt, q.dt, q.dx, q.omega, q.v, q.r
+        n, bp = layout['n'], W.shape[1]
+        y0, w = self._constants(W)
+        Y = W[0:(nt + 1) * m].reshape(nt + 1, m, bp)
+        U = W[(nt + 1) * m:n].reshape(nt + 1, m, bp)
+        lam = W[layout['y_eq']:layout['y_eq'] + nt * m].reshape(nt, m, bp)
+        # grad f
+        data[0:(nt + 1) * m].reshape(nt + 1, m, bp)[...] = dx * w * (Y - y0)
+        gU = data[(nt + 1) * m:n].reshape(nt + 1, m, bp)
+        gU[...] = dx * w * om * U
+        if q.start_term:
+            gU[0] = gU[0] + 0.5 * dx * dt * om * U[0]
+        # -c(x): the discretised equation at the time nodes 1 .. nt, then the initial conditions
+        Yk = Y[1:]
+        up, dn = Yk * 0.0, Yk * 0.0
+        up[:, :-1], dn[:, 1:] = Yk[:, 1:], Yk[:, :-1]
+        conv = (up - dn) / (2.0 * dx)
+        c = (Yk - Y[:-1]) / dt - v * (up - 2.0 * Yk + dn) / dx ** 2 + conv * Yk - r - U[:-1]
+        data[n:n + nt * m].reshape(nt, m, bp)[...] = -c
+        if q.init_conditions:
+            data[n + nt * m:n + nt * m + m] = -(Y[0] - y0[0])
+            data[n + nt * m + m:n + nt * m + 2 * m] = -U[0]
+        # objective value of every lane
+        f = 0.5 * dx * (w * ((Y - y0) ** 2 + om * U ** 2)).sum(0).sum(0)
+        if q.start_term:
+            f = f + 0.25 * dx * dt * om * (U[0] ** 2).sum(0)
+        data[layout['obj_row']] = f
+        # Jacobian values in the entry order of BurgersNLP._patterns (per time node: d/dy[k][i], d/dy[k-1][i],
+        # d/dy[k][i+1], d/dy[k][i-1], d/du[k-1][i]; the rows of the initial conditions are constant)
+        per = 5 * m - 2
+        J = src[layout['jac']:layout['jac'] + nt * per].reshape(nt, per, bp)
+        J[:, 0:m] = 1.0 / dt + 2.0 * v / dx ** 2 + conv
+        J[:, m:2 * m] = -1.0 / dt
+        J[:, 2 * m:3 * m - 1] = (-v / dx ** 2 + Yk / (2.0 * dx))[:, :-1]
+        J[:, 3 * m - 1:4 * m - 2] = (-v / dx ** 2 - Yk / (2.0 * dx))[:, 1:]
+        J[:, 4 * m - 2:per] = -1.0
+        # Hessian of the Lagrangian: the diagonal is constant (the objective's weights, written at set-up); the
+        # convective term couples y[k][i+1] and y[k][i] with (lambda[k][i] - lambda[k][i+1]) / (2 dx)
+        Hs = src[layout['hess'] + n:layout['hess'] + n + nt * (m - 1)].reshape(nt, m - 1, bp)
+        Hs[...] = (lam[:, :-1] - lam[:, 1:]) / (2.0 * dx)
+
+
+def device_interface(nfe_x, nfe_t, nblocks, comm=None, start_t=0.0, end_t=1.0):
+    """``BurgersInterface`` with device-resident iterates: the same time blocks handed to ``DeviceDynamicNLPInterface``
+    together with their device model."""
+    from parapint_amd.interfaces.schur_complement.device_sc_ip_interface import DeviceDynamicNLPInterface
+    T = int(nblocks)
+    size, rank = (1, 0) if comm is None else (comm.size, comm.rank)
+    per = nfe_t // T
+    delta = (end_t - start_t) / T
+    blocks = []
+    for t in range(T):
+        if t % size != rank:
+            blocks.append(None)
+            continue
+        nlp = BurgersNLP(nfe_x, per, delta * t, delta * (t + 1), t == 0)
+        blocks.append((nlp, nlp.start_states(), nlp.end_states()))
+    return DeviceDynamicNLPInterface(blocks, BurgersDeviceModel, comm=comm)
+
+
 class BurgersInterface(MPIDynamicSchurComplementInteriorPointInterface):
     """burgers.py:53-176: the interface of the reference's example (same constructor but for the communicator, which is
     an argument here instead of a module global)."""

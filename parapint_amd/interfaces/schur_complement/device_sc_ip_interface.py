@@ -49,6 +49,7 @@ class _PatternGroup(object):
         states); ff: variables of the forward link of a time block (end states; multipliers in the coupling block)."""
         self.q0, self.fs, self.ff = q0, np.asarray(fs, dtype=np.int64), np.asarray(ff, dtype=np.int64)
         self.members, self.mapped = [], bool(mapped)
+        self.nonlinear = False              # the model's own evaluation supplies grad f and c(x): no Hessian terms in the row programs
         self.n, self.me, self.mi, self.nfs, self.nfw = q0.n, q0.A_eq.shape[0], q0.A_ineq.shape[0], self.fs.size, self.ff.size
         self.nb = self.n + 2 * self.mi + self.me + self.nfs          # dimension of one diagonal block
         self.nnzH, self.nnzAe, self.nnzAi = q0.H.nnz, q0.A_eq.nnz, q0.A_ineq.nnz
@@ -125,6 +126,10 @@ class _PatternGroup(object):
             (n + me + Ai.row, off[2] + eAi, x0 + Ai.col, 1),                 # A_ineq x
             (n + me + mi + k, -np.ones(nfs), x0 + self.fs, 1),               # x_fs (start states of a time block)
             (n + me + mi + nfs + kf, -np.ones(nfw), x0 + self.ff, 1)]        # end states of a time block
+        if self.nonlinear:
+            # the model's own evaluation supplies grad f (instead of c + H x) and -c_eq(x) (instead of A_eq x - b): the
+            # gradient rows keep J^T y and the link duals, the constraint rows no terms at all, the link rows theirs
+            parts = [parts[2], parts[3], parts[4], parts[5], parts[8], parts[9]]
         prow = np.concatenate([np.asarray(p[0], dtype=np.int64) for p in parts])
         src = np.concatenate([np.asarray(p[1], dtype=np.int64) for p in parts])
         wrow = np.concatenate([np.asarray(p[2], dtype=np.int64) for p in parts])
@@ -579,3 +584,71 @@ class DeviceDynamicQPInterface(DeviceStochasticQPInterface):
     def coupling_states(self):
         """The states between the time blocks (n_states * (T - 1)), block after block."""
         return self.first_stage_solution()
+
+
+class DeviceDynamicNLPInterface(DeviceDynamicQPInterface):
+    """Time-staged NONLINEAR problems with device-resident iterates: the producer of ``DeviceDynamicQPInterface`` with the
+    model's functions evaluated by the caller's DEVICE MODEL instead of being read off constant QP data (what Pyomo / ASL
+    do for the reference, interfaces/interface.py:432-538, here on the device so that the iterate never leaves it).
+
+    time_blocks: per time block (nlp, start states, end states) -- objects with the NLP protocol of interfaces/interface.py
+        (equality constraints and bounds; what ``build_model_for_time_block`` returns).  They give sizes, bounds, the
+        initial point and the sparsity patterns (Hessian of the Lagrangian: lower triangle in the order of
+        ``evaluate_hessian_lag()``, Jacobian in the order of ``evaluate_jacobian_eq()``).
+    device_model: callable (nlps of a pattern group in lane order, padded batch) -> object with
+        ``evaluate(W, src, data, layout)`` that, from the primals W[0:n] and the equality multipliers
+        W[layout['y_eq']:...] of every lane, writes the Hessian values into src[layout['hess']:...], the Jacobian
+        values into src[layout['jac']:...], grad f into data[0:n], -c_eq(x) into data[n:n+me] and the objective value of
+        every lane into data[layout['obj_row']] -- all [row][lane] arrays; called after every step, on the solver's stream.
+    """
+
+    def __init__(self, time_blocks, device_model, comm=None, bounds_relaxation_factor=1e-8):
+        from scipy.sparse import coo_matrix, tril
+        self._device_model = device_model
+        self._nlps = {}
+        blocks = []
+        for ndx, blk in enumerate(time_blocks):
+            if blk is None:
+                blocks.append(None)
+                continue
+            nlp, start, end = blk
+            if nlp.n_ineq_constraints() != 0:
+                raise NotImplementedError('device-resident nonlinear models: equality constraints and bounds only')
+            self._nlps[ndx] = nlp
+            # the QP that shares the model's patterns and its values at the initial point (pattern, pivot order, first values)
+            x0 = np.asarray(nlp.init_primals(), dtype=np.double)
+            nlp.set_primals(x0)
+            nlp.set_duals_eq(np.asarray(nlp.init_duals_eq(), dtype=np.double))
+            H, A = coo_matrix(nlp.evaluate_hessian_lag()), coo_matrix(nlp.evaluate_jacobian_eq())
+            if np.any(H.row < H.col):
+                raise ValueError('evaluate_hessian_lag() of a device-resident model must return the lower triangle')
+            qp = QuadraticProgram(c=np.asarray(nlp.evaluate_grad_objective(), dtype=np.double), A_eq=A,
+                                  b_eq=A @ x0 - np.asarray(nlp.evaluate_eq_constraints(), dtype=np.double),
+                                  lb=nlp.primals_lb(), ub=nlp.primals_ub(), H=None, x0=x0)
+            qp.H = H                                             # (entry order kept: the device model writes values in it)
+            blocks.append((qp, start, end))
+        DeviceDynamicQPInterface.__init__(self, blocks, comm=comm, bounds_relaxation_factor=bounds_relaxation_factor)
+        for pg in self.pattern_groups:
+            pg.nonlinear = True
+
+    def _describe_links(self, desc, gs):
+        DeviceDynamicQPInterface._describe_links(self, desc, gs)
+        pg, ops = gs.pg, self.ops
+        # one more data row: the objective value of every lane, from the model's own evaluation
+        data = ops.zeros((pg.n + pg.me + 1, gs.bpad))
+        data[0:pg.n + pg.me] = gs.data[0:pg.n + pg.me]
+        gs.data = data
+        desc.update(data=data, obj_row=pg.n + pg.me)
+        lanes = list(gs.order) + [gs.order[0]] * (gs.bpad - gs.B)
+        gs.model = self._device_model([self._nlps[t] for t in lanes], gs.bpad)
+        gs.layout = dict(n=pg.n, me=pg.me, y_eq=pg.n + pg.mi, hess=int(pg.off[0]), jac=int(pg.off[1]), obj_row=pg.n + pg.me,
+                         batch=gs.B, bpad=gs.bpad)
+
+    def attach(self, solver, dk):
+        DeviceDynamicQPInterface.attach(self, solver, dk)
+        self._c0 = 0.0                                           # (the objective comes whole from the model)
+
+    def take_step(self, unified=False):
+        DeviceDynamicQPInterface.take_step(self, unified)
+        for gs in self.states:                                   # the model at the new iterate, before the residual kernels
+            gs.model.evaluate(gs.W, gs.src, gs.data, gs.layout)

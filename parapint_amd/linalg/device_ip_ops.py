@@ -92,6 +92,9 @@ class HipIpOps(object):
             for k in ('n', 'mi', 'me', 'nfs', 'batch', 'bpad', 'src_dp', 'src_ds'):
                 setattr(q, k, int(d[k]))
             q.nfw, q.ncz = int(d.get('nfw', 0)), int(d.get('ncz', 0))
+            q.obj_row, q.reserved = int(d.get('obj_row', -1)), 0
+            if q.obj_row >= int(d['data'].shape[0]):
+                raise ValueError('interior-point step: obj_row is outside the data rows')
             zoff = d.get('zoff')                   # mapped groups (time blocks): [2][bpad] int32 offsets into the coupling states
             if zoff is not None and (not zoff.is_cuda or not zoff.is_contiguous() or zoff.dtype != self._torch.int32 or
                                      tuple(zoff.shape) != (2, int(d['bpad']))):

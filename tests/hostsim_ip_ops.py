@@ -213,7 +213,10 @@ class HostSimIpOps(object):
                 d['G'][:n] = G
                 zl, zu = W[nb:nb + n], W[nb + n:nb + 2 * n]
                 dinf = nmax(dinf, _amax(np.abs((G - zl) + zu)[:, :B]))
-                obj += float(np.sum((W[:n] * (0.5 * accH[:n] + cj))[:, :B]))
+                if d.get('obj_row', -1) >= 0:                    # nonlinear model: the objective value is a data row
+                    obj += float(np.sum(d['data'][d['obj_row'], :B]))
+                else:
+                    obj += float(np.sum((W[:n] * (0.5 * accH[:n] + cj))[:, :B]))
                 res_eq = acc[n:n + me] - d['data'][n:n + me]
                 res_in = acc[n + me:n + me + mi] - W[n:n + mi]
                 zz = np.asarray(z)

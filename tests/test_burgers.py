@@ -141,3 +141,113 @@ def test_burgers_at_the_dimensions_of_baseline_configuration_4():
     y = _trajectory(it, T, T * 40, 49)
     assert y.shape == (T * 40 + 1, 49) and np.isfinite(y).all() and 0.9 <= np.abs(y).max() <= 1.1
     assert 0.0 < it.evaluate_objective() < 0.1
+
+
+# ---- device-resident iterates for the nonlinear problem (DeviceDynamicNLPInterface + BurgersDeviceModel) -----------------
+def _device_nlp_loop(T, nfe_x, nfe_t, engine, comm=None):
+    from parapint_amd.algorithms.device_interior_point import ip_solve_device
+    from parapint_amd.algorithms.interior_point import IPOptions, InteriorPointStatus
+    from parapint_amd.linalg.comm import SerialComm
+    from parapint_amd.linalg.hip_schur_complement import HipSchurComplementLinearSolver
+    it = bg.device_interface(nfe_x, nfe_t, T, comm=comm)
+    opt = IPOptions()
+    opt.linalg.solver = HipSchurComplementLinearSolver({t: None for t in it.local}, None, comm=comm or SerialComm(), engine=engine,
+                                                       result_buffers=0 if engine is not None else 2)
+    hist, stats = [], {}
+    status, iters = ip_solve_device(it, opt, history=hist, stats=stats)
+    assert status == InteriorPointStatus.optimal
+    return it, hist, stats
+
+
+def _host_rows(T, nfe_x, nfe_t, solver):
+    import logging
+    import re
+    rows = []
+
+    class Cap(logging.Handler):
+        def emit(self, record):
+            m = re.match(r'^(\d+)\s+(\S+)\s+(\S+)\s+(\S+)\s+(\S+)\s+(\S+)', record.getMessage())
+            if m:
+                rows.append([float(v) for v in m.groups()])
+    log = logging.getLogger('parapint_amd.algorithms.interior_point')
+    cap, old = Cap(), log.level
+    log.addHandler(cap)
+    log.setLevel(logging.INFO)
+    try:
+        it = bg.main(solver, nfe_x=nfe_x, nfe_t=nfe_t, nblocks=T)
+    finally:
+        log.removeHandler(cap)
+        log.setLevel(old)
+    return it, rows
+
+
+def test_device_model_matches_the_nlp_object():
+    """BurgersDeviceModel on [row][lane] arrays against BurgersNLP lane by lane: grad f, -c(x), objective, Jacobian and
+    Hessian values in the NLP's entry order (bit for bit where the operation order is the same, else to rounding)."""
+    rng = np.random.default_rng(4)
+    for init in (False, True):
+        nlps = [bg.BurgersNLP(9, 4, 0.25, 0.5, init) for _ in range(3)]
+        q = nlps[0]
+        n, me, bp = q.n_primals(), q.n_eq_constraints(), 4
+        X, Lm = rng.normal(size=(n, bp)), rng.normal(size=(me, bp))
+        nh, nj = q.nnz_hessian_lag(), q.nnz_jacobian_eq()
+        W = np.zeros((n + me, bp))
+        W[:n], W[n:] = X, Lm
+        src, data = np.zeros((nh + nj, bp)), np.zeros((n + me + 1, bp))
+        # (constants the producer writes at set-up: the Hessian diagonal and the Jacobian of the initial conditions)
+        for b in range(bp):
+            o = nlps[b % 3]
+            o.set_primals(X[:, b]); o.set_duals_eq(Lm[:, b])
+            src[:n, b] = o.evaluate_hessian_lag().data[:n]
+            src[nh:, b] = o.evaluate_jacobian_eq().data
+        src[n:nh] = 7.0
+        src[nh:nh + q.nt * (5 * q.m - 2)] = 7.0
+        bg.BurgersDeviceModel(nlps, bp).evaluate(W, src, data, dict(n=n, me=me, y_eq=n, hess=0, jac=nh, obj_row=n + me))
+        for b in range(bp):
+            o = nlps[b % 3]
+            o.set_primals(X[:, b]); o.set_duals_eq(Lm[:, b])
+            assert np.allclose(data[:n, b], o.evaluate_grad_objective(), rtol=1e-14, atol=0)
+            assert np.allclose(data[n:n + me, b], -o.evaluate_eq_constraints(), rtol=1e-12, atol=1e-13)
+            assert abs(data[n + me, b] - o.evaluate_objective()) <= 1e-12 * max(1.0, abs(o.evaluate_objective()))
+            assert np.allclose(src[:nh, b], o.evaluate_hessian_lag().data, rtol=1e-13, atol=0)
+            assert np.allclose(src[nh:, b], o.evaluate_jacobian_eq().data, rtol=1e-13, atol=0)
+
+
+def test_device_nonlinear_loop_on_cpu_engines_matches_the_host_loop():
+    """The nonlinear problem with device-resident iterates (numpy engines): the iterations of the host loop over the NLP
+    objects, measure for measure, and the same point."""
+    from hostsim_engine import HostSimDeviceEngine, HostSimEngine
+    from parapint_amd.linalg.comm import SerialComm
+    from parapint_amd.linalg.hip_schur_complement import HipSchurComplementLinearSolver
+    T, nfe_x, nfe_t = 4, 8, 12
+    it, hist, _ = _device_nlp_loop(T, nfe_x, nfe_t, HostSimDeviceEngine())
+    host, rows = _host_rows(T, nfe_x, nfe_t, HipSchurComplementLinearSolver({t: None for t in range(T)}, None, comm=SerialComm(),
+                                                                           engine=HostSimEngine()))
+    assert len(rows) == len(hist)
+    for r, h in zip(rows, hist):
+        for a, b in zip(r[2:6], h[:4]):
+            assert abs(a - b) <= 6e-3 * max(abs(a), abs(b)) + 2e-9, (r, h)
+    assert abs(it.evaluate_objective() - host.evaluate_objective()) <= 1e-12
+    for t in range(T):
+        assert np.abs(it.scenario_primals(t) - np.asarray(host.get_primals().get_block(t))).max() <= 1e-10
+    assert np.abs(it.coupling_states() - np.asarray(host.get_primals().get_block(T))).max() <= 1e-10
+
+
+@pytest.mark.gpu
+def test_device_nonlinear_loop_on_the_device():
+    """The same on the HIP kernels (the model's functions are torch operations on the resident tensors -- the model is the
+    caller's code, as Pyomo's is for the reference; the producer's own steps dispatch none): 16 time blocks x 8 steps x 39 grid
+    points against the numpy engines, then BASELINE configs[3] to the letter against the host producer's optimum."""
+    from hostsim_engine import HostSimDeviceEngine
+    T, nfe_x, nfe_t = 16, 40, 128
+    it, hist, stats = _device_nlp_loop(T, nfe_x, nfe_t, None)
+    ref, ref_hist, _ = _device_nlp_loop(T, nfe_x, nfe_t, HostSimDeviceEngine())
+    assert len(hist) == len(ref_hist)
+    for a, b in zip(hist, ref_hist):
+        assert np.allclose(a[:4], b[:4], rtol=1e-6, atol=2e-9), (a, b)
+    for t in range(T):
+        assert np.abs(it.scenario_primals(t) - ref.scenario_primals(t)).max() <= 1e-7
+    T = 512
+    it, hist, stats = _device_nlp_loop(T, 50, T * 40, None)
+    assert len(hist) <= 8 and max(hist[-1][:3]) <= 1e-8 and it.pattern_groups[1].n == 4018 and 2 * it.ncz == 50078
+    assert 0.0 < it.evaluate_objective() < 0.1

@@ -598,6 +598,10 @@ def test_bench_line_reports_the_ip_loop_and_the_boundary_rate():
     dyn = res['ip_loop_dynamic']
     assert dyn['converged'] is True and dyn['time_blocks'] == 64 and dyn['n_coupling'] == 2 * 49 * 63
     assert dyn['block_dim'] == 4254 and max(dyn['final_infeasibilities']) <= 1e-8 and dyn['torch_ops_in_the_loop'] <= 6
+    # and BASELINE configs[3] itself (the nonlinear Burgers discretisation; here 64 of its 512 time blocks)
+    bur = res['ip_loop_burgers']
+    assert bur['converged'] is True and bur['variables_per_block'] == 4018 and bur['n_coupling'] == 2 * 49 * 63
+    assert max(bur['final_infeasibilities']) <= 1e-8 and bur['iterations'] <= 8
 
 
 def test_pivot_growth_guard():
