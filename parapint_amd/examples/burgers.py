@@ -244,24 +244,28 @@ class BurgersDeviceModel(object):
     def __init__(self, nlps, bpad):
         q = nlps[0]
         for o in nlps:
-            if (o.m, o.nt, o.dt, o.dx, o.omega, o.v, o.r, o.init_conditions, o.start_term) != \
-                    (q.m, q.nt, q.dt, q.dx, q.omega, q.v, q.r, q.init_conditions, q.start_term):
+            if (o.m, o.nt, o.dx, o.omega, o.v, o.r, o.init_conditions, o.start_term) != \
+                    (q.m, q.nt, q.dx, q.omega, q.v, q.r, q.init_conditions, q.start_term) or not math.isclose(o.dt, q.dt, rel_tol=1e-12):
                 raise ValueError('the time blocks of a pattern group must share their discretisation')
         self.q = q
+        # the time step of every lane as its own NLP object computed it (blocks of equal length differ in the last bits)
+        self._dt = np.array([o.dt for o in nlps], dtype=np.double).reshape(1, 1, len(nlps))
+        self._w = np.stack([o.w for o in nlps], axis=1).reshape(q.nt + 1, 1, len(nlps))
         self._consts = None
 
     def _constants(self, like):
         if self._consts is None:
             q = self.q
             to = (lambda a: like.new_tensor(a)) if hasattr(like, 'new_tensor') else (lambda a: np.asarray(a, dtype=np.double))
-            self._consts = (to(q.y0.reshape(1, q.m, 1)), to(q.w.reshape(q.nt + 1, 1, 1)))
+            self._consts = (to(q.y0.reshape(1, q.m, 1)), to(self._w), to(self._dt))
         return self._consts
 
     def evaluate(self, W, src, data, layout):
         q = self.q
-        m, nt, dt, dx, om, v, r = q.m, q.nt, q.dt, q.dx, q.omega, q.v, q.r
+        m, nt, dx, om, v, r = q.m, q.nt, q.dx, q.omega, q.v, q.r
         n, bp = layout['n'], W.shape[1]
-        y0, w = self._constants(W)
+        y0, w, dt = self._constants(W)             # (dt: [1][1][lane], w: [time node][1][lane])
+        dt0 = dt[0]                                # [1][lane]
         Y = W[0:(nt + 1) * m].reshape(nt + 1, m, bp)
         U = W[(nt + 1) * m:n].reshape(nt + 1, m, bp)
         lam = W[layout['y_eq']:layout['y_eq'] + nt * m].reshape(nt, m, bp)
@@ -270,7 +274,7 @@ class BurgersDeviceModel(object):
         gU = data[(nt + 1) * m:n].reshape(nt + 1, m, bp)
         gU[...] = dx * w * om * U
         if q.start_term:
-            gU[0] = gU[0] + 0.5 * dx * dt * om * U[0]
+            gU[0] = gU[0] + 0.5 * dx * dt0 * om * U[0]
         # -c(x): the discretised equation at the time nodes 1 .. nt, then the initial conditions
         Yk = Y[1:]
         up, dn = Yk * 0.0, Yk * 0.0
@@ -284,7 +288,7 @@ class BurgersDeviceModel(object):
         # objective value of every lane
         f = 0.5 * dx * (w * ((Y - y0) ** 2 + om * U ** 2)).sum(0).sum(0)
         if q.start_term:
-            f = f + 0.25 * dx * dt * om * (U[0] ** 2).sum(0)
+            f = f + 0.25 * dx * dt0[0] * om * (U[0] ** 2).sum(0)
         data[layout['obj_row']] = f
         # Jacobian values in the entry order of BurgersNLP._patterns (per time node: d/dy[k][i], d/dy[k-1][i],
         # d/dy[k][i+1], d/dy[k][i-1], d/du[k-1][i]; the rows of the initial conditions are constant)

@@ -15,6 +15,7 @@ sys.path.insert(0, HERE)
 GPU = '--gpu' in sys.argv
 FIXTURES = '--fixtures' in sys.argv       # interfaces/schur_complement/tests/test_mpi_sc_ip_interface.py on 3 ranks
 REFERENCE_EXAMPLE = '--reference-example' in sys.argv     # parapint/examples/dynamics.py on 3 ranks, its test's known answers
+NONLINEAR = '--nonlinear' in sys.argv         # the Burgers problem through DeviceDynamicNLPInterface on two ranks
 DEVICE_PRODUCER = '--device-producer' in sys.argv     # iterates resident on the (simulated) device, interior-point step kernels
 if not GPU:
     from hostsim_engine import HostSimDeviceEngine, HostSimEngine  # noqa: E402
@@ -47,6 +48,31 @@ def run_device(comm):
     status, _ = ip_solve_device(it, opt, history=hist)
     assert status == InteriorPointStatus.optimal
     return it, hist
+
+
+def main_nonlinear(comm):
+    from parapint_amd.algorithms.device_interior_point import ip_solve_device
+    from parapint_amd.algorithms.interior_point import IPOptions, InteriorPointStatus
+    from parapint_amd.examples import burgers as bg
+
+    def run_with(c):
+        it = bg.device_interface(7, 10, 5, comm=None if c.size == 1 else c)
+        opt = IPOptions()
+        opt.linalg.solver = HipSchurComplementLinearSolver({t: None for t in it.local}, None, comm=c,
+                                                           engine=None if GPU else HostSimDeviceEngine(),
+                                                           result_buffers=2 if GPU else 0)
+        hist = []
+        status, _ = ip_solve_device(it, opt, history=hist)
+        assert status == InteriorPointStatus.optimal
+        return it, hist
+    it, hist = run_with(comm)
+    ref, ref_hist = run_with(SerialComm())
+    assert len(hist) == len(ref_hist)
+    for a, b in zip(hist, ref_hist):
+        assert np.allclose(a[:4], b[:4], rtol=1e-6, atol=2e-9), (a, b)
+    assert np.abs(it.coupling_states() - ref.coupling_states()).max() <= 1e-8
+    for t in it.local:
+        assert np.abs(it.scenario_primals(t) - ref.scenario_primals(t)).max() <= 1e-8
 
 
 def main_device(comm):
@@ -114,8 +140,8 @@ def main():
         dist.destroy_process_group()
         return
     assert comm.size == 2
-    if DEVICE_PRODUCER:
-        main_device(comm)
+    if DEVICE_PRODUCER or NONLINEAR:
+        (main_nonlinear if NONLINEAR else main_device)(comm)
         print('rank %d ok' % comm.rank)
         dist.barrier()
         dist.destroy_process_group()

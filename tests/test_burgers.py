@@ -202,7 +202,8 @@ def test_device_model_matches_the_nlp_object():
             src[nh:, b] = o.evaluate_jacobian_eq().data
         src[n:nh] = 7.0
         src[nh:nh + q.nt * (5 * q.m - 2)] = 7.0
-        bg.BurgersDeviceModel(nlps, bp).evaluate(W, src, data, dict(n=n, me=me, y_eq=n, hess=0, jac=nh, obj_row=n + me))
+        bg.BurgersDeviceModel([nlps[b % 3] for b in range(bp)], bp).evaluate(W, src, data, dict(n=n, me=me, y_eq=n, hess=0, jac=nh,
+                                                                                            obj_row=n + me))
         for b in range(bp):
             o = nlps[b % 3]
             o.set_primals(X[:, b]); o.set_duals_eq(Lm[:, b])
@@ -251,3 +252,25 @@ def test_device_nonlinear_loop_on_the_device():
     it, hist, stats = _device_nlp_loop(T, 50, T * 40, None)
     assert len(hist) <= 8 and max(hist[-1][:3]) <= 1e-8 and it.pattern_groups[1].n == 4018 and 2 * it.ncz == 50078
     assert 0.0 < it.evaluate_objective() < 0.1
+
+
+def test_device_nonlinear_loop_on_two_ranks():
+    """Time blocks of the nonlinear problem dealt over two gloo ranks (numpy engines): the iterations and the point of the
+    one-rank run."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(here, 'dynamic_multirank_worker.py'), '--nonlinear']
+    env = dict(os.environ)
+    env['OMP_NUM_THREADS'] = '1'
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    text = out.stdout.decode()
+    assert out.returncode == 0, text[-4000:]
+    assert 'rank 0 ok' in text and 'rank 1 ok' in text
