@@ -603,7 +603,7 @@ class DeviceDynamicNLPInterface(DeviceDynamicQPInterface):
     """
 
     def __init__(self, time_blocks, device_model, comm=None, bounds_relaxation_factor=1e-8):
-        from scipy.sparse import coo_matrix, tril
+        from scipy.sparse import coo_matrix
         self._device_model = device_model
         self._nlps = {}
         blocks = []
