@@ -436,6 +436,33 @@ def _run_step_sequence(ops, descs, z, dz, mu, tau, nranks=1, ncoup=None, dual_fr
 
 
 @pytest.mark.gpu
+def test_step_kernels_with_a_model_supplied_objective_row():
+    """obj_row >= 0 (nonlinear models: the objective value of every instance is a data row the caller's model wrote) on
+    groups WITHOUT a coupling map: the objective of the mailbox is the sum of that row over the instances of all groups,
+    everything else as for a QP."""
+    from hostsim_ip_ops import HostSimIpOps
+    from parapint_amd.linalg.hip_schur_complement import HipEngine
+    shapes = [(70, 33, 5, 9, 0), (3, 12, 5, 4, 7)]
+    descs, z, dz = _step_problem(19, shapes)
+    rng = np.random.default_rng(2)
+    for d in descs:
+        extra = rng.normal(size=(1, d['data'].shape[1]))
+        d['data'] = np.concatenate([d['data'], extra])
+        d['obj_row'] = d['data'].shape[0] - 1
+    want = sum(float(d['data'][d['obj_row'], :d['batch']].sum()) for d in descs)
+    mu, tau = 0.1, 0.9
+    ref = _run_step_sequence(HostSimIpOps(), [dict(d, **{k: v.copy() for k, v in d.items() if isinstance(v, np.ndarray)})
+                                              for d in descs], z, dz, mu, tau)
+    got = _run_step_sequence(HipEngine().ip_ops(), descs, z, dz, mu, tau)
+    for key in ('mail0', 'mail1'):
+        assert abs(got[key][6] - want) <= 1e-12 * max(1.0, abs(want)) and abs(ref[key][6] - want) <= 1e-12 * max(1.0, abs(want))
+        assert np.array_equal(got[key][[0, 2, 3, 7, 8]], ref[key][[0, 2, 3, 7, 8]])
+    for key in ('W1', 'G1', 'rhs1', 'src1'):
+        for gi, (a, b) in enumerate(zip(got[key], ref[key])):
+            assert np.array_equal(a[:, :shapes[gi][0]], b[:, :shapes[gi][0]])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('shapes', [[(5, 24, 4, 6, 8)], [(70, 33, 5, 9, 0), (3, 12, 5, 4, 7)], [(130, 40, 3, 0, 5)]])
 def test_step_kernels_match_their_numpy_restatement(shapes):
     """Elementwise results (iterate, barrier diagonals, right-hand side, grad f + J^T y), step lengths and max-norms bit
