@@ -586,53 +586,44 @@ class DeviceDynamicQPInterface(DeviceStochasticQPInterface):
         return self.first_stage_solution()
 
 
-class DeviceDynamicNLPInterface(DeviceDynamicQPInterface):
-    """Time-staged NONLINEAR problems with device-resident iterates: the producer of ``DeviceDynamicQPInterface`` with the
-    model's functions evaluated by the caller's DEVICE MODEL instead of being read off constant QP data (what Pyomo / ASL
-    do for the reference, interfaces/interface.py:432-538, here on the device so that the iterate never leaves it).
+class _DeviceModelMixin(object):
+    """What turns one of the QP producers into the producer of a NONLINEAR problem class: the constant QP data are replaced
+    by what the caller's DEVICE MODEL writes after every step (the functions Pyomo / ASL evaluate for the reference at every
+    iterate, interfaces/interface.py:432-538, here on the device so that the iterate never leaves it).
 
-    time_blocks: per time block (nlp, start states, end states) -- objects with the NLP protocol of interfaces/interface.py
-        (equality constraints and bounds; what ``build_model_for_time_block`` returns).  They give sizes, bounds, the
-        initial point and the sparsity patterns (Hessian of the Lagrangian: lower triangle in the order of
-        ``evaluate_hessian_lag()``, Jacobian in the order of ``evaluate_jacobian_eq()``).
-    device_model: callable (nlps of a pattern group in lane order, padded batch) -> object with
+    The subproblems are objects with the NLP protocol of interfaces/interface.py (equality constraints and bounds); they
+    give sizes, bounds, the initial point and the sparsity patterns (Hessian of the Lagrangian: lower triangle in the order
+    of ``evaluate_hessian_lag()``, Jacobian in the order of ``evaluate_jacobian_eq()``).
+    device_model: callable (NLP objects of a pattern group in lane order, padded batch) -> object with
         ``evaluate(W, src, data, layout)`` that, from the primals W[0:n] and the equality multipliers
-        W[layout['y_eq']:...] of every lane, writes the Hessian values into src[layout['hess']:...], the Jacobian
-        values into src[layout['jac']:...], grad f into data[0:n], -c_eq(x) into data[n:n+me] and the objective value of
-        every lane into data[layout['obj_row']] -- all [row][lane] arrays; called after every step, on the solver's stream.
-    """
+        W[layout['y_eq']:...] of every lane, writes the Hessian values into src[layout['hess']:...], the Jacobian values
+        into src[layout['jac']:...], grad f into data[0:n], -c_eq(x) into data[n:n+me] and the objective value of every
+        lane into data[layout['obj_row']] -- all [row][lane] arrays; called after every step, on the solver's stream."""
 
-    def __init__(self, time_blocks, device_model, comm=None, bounds_relaxation_factor=1e-8):
+    @staticmethod
+    def _qp_standin(nlp):
+        """The QP that shares the model's patterns and its values at the initial point (pattern, pivot order, first values)."""
         from scipy.sparse import coo_matrix
-        self._device_model = device_model
-        self._nlps = {}
-        blocks = []
-        for ndx, blk in enumerate(time_blocks):
-            if blk is None:
-                blocks.append(None)
-                continue
-            nlp, start, end = blk
-            if nlp.n_ineq_constraints() != 0:
-                raise NotImplementedError('device-resident nonlinear models: equality constraints and bounds only')
-            self._nlps[ndx] = nlp
-            # the QP that shares the model's patterns and its values at the initial point (pattern, pivot order, first values)
-            x0 = np.asarray(nlp.init_primals(), dtype=np.double)
-            nlp.set_primals(x0)
-            nlp.set_duals_eq(np.asarray(nlp.init_duals_eq(), dtype=np.double))
-            H, A = coo_matrix(nlp.evaluate_hessian_lag()), coo_matrix(nlp.evaluate_jacobian_eq())
-            if np.any(H.row < H.col):
-                raise ValueError('evaluate_hessian_lag() of a device-resident model must return the lower triangle')
-            qp = QuadraticProgram(c=np.asarray(nlp.evaluate_grad_objective(), dtype=np.double), A_eq=A,
-                                  b_eq=A @ x0 - np.asarray(nlp.evaluate_eq_constraints(), dtype=np.double),
-                                  lb=nlp.primals_lb(), ub=nlp.primals_ub(), H=None, x0=x0)
-            qp.H = H                                             # (entry order kept: the device model writes values in it)
-            blocks.append((qp, start, end))
-        DeviceDynamicQPInterface.__init__(self, blocks, comm=comm, bounds_relaxation_factor=bounds_relaxation_factor)
+        if nlp.n_ineq_constraints() != 0:
+            raise NotImplementedError('device-resident nonlinear models: equality constraints and bounds only')
+        x0 = np.asarray(nlp.init_primals(), dtype=np.double)
+        nlp.set_primals(x0)
+        nlp.set_duals_eq(np.asarray(nlp.init_duals_eq(), dtype=np.double))
+        H, A = coo_matrix(nlp.evaluate_hessian_lag()), coo_matrix(nlp.evaluate_jacobian_eq())
+        if np.any(H.row < H.col):
+            raise ValueError('evaluate_hessian_lag() of a device-resident model must return the lower triangle')
+        qp = QuadraticProgram(c=np.asarray(nlp.evaluate_grad_objective(), dtype=np.double), A_eq=A,
+                              b_eq=A @ x0 - np.asarray(nlp.evaluate_eq_constraints(), dtype=np.double),
+                              lb=nlp.primals_lb(), ub=nlp.primals_ub(), H=None, x0=x0)
+        qp.H = H                                             # (entry order kept: the device model writes values in it)
+        return qp
+
+    def _mark_nonlinear(self):
         for pg in self.pattern_groups:
             pg.nonlinear = True
 
     def _describe_links(self, desc, gs):
-        DeviceDynamicQPInterface._describe_links(self, desc, gs)
+        super(_DeviceModelMixin, self)._describe_links(desc, gs)
         pg, ops = gs.pg, self.ops
         # one more data row: the objective value of every lane, from the model's own evaluation
         data = ops.zeros((pg.n + pg.me + 1, gs.bpad))
@@ -645,10 +636,41 @@ class DeviceDynamicNLPInterface(DeviceDynamicQPInterface):
                          batch=gs.B, bpad=gs.bpad)
 
     def attach(self, solver, dk):
-        DeviceDynamicQPInterface.attach(self, solver, dk)
+        super(_DeviceModelMixin, self).attach(solver, dk)
         self._c0 = 0.0                                           # (the objective comes whole from the model)
 
     def take_step(self, unified=False):
-        DeviceDynamicQPInterface.take_step(self, unified)
+        super(_DeviceModelMixin, self).take_step(unified)
         for gs in self.states:                                   # the model at the new iterate, before the residual kernels
             gs.model.evaluate(gs.W, gs.src, gs.data, gs.layout)
+
+
+class DeviceStochasticNLPInterface(_DeviceModelMixin, DeviceStochasticQPInterface):
+    """Two-stage stochastic programs with NONLINEAR scenario problems and device-resident iterates (see _DeviceModelMixin).
+    scenarios: NLP objects (entries of other ranks may be None); first_stage_indices as for DeviceStochasticQPInterface."""
+
+    def __init__(self, scenarios, first_stage_indices, device_model, comm=None, bounds_relaxation_factor=1e-8):
+        self._device_model = device_model
+        self._nlps = {ndx: nlp for ndx, nlp in enumerate(scenarios) if nlp is not None}
+        qps = [None if nlp is None else self._qp_standin(nlp) for nlp in scenarios]
+        DeviceStochasticQPInterface.__init__(self, qps, first_stage_indices, comm=comm,
+                                             bounds_relaxation_factor=bounds_relaxation_factor)
+        self._mark_nonlinear()
+
+
+class DeviceDynamicNLPInterface(_DeviceModelMixin, DeviceDynamicQPInterface):
+    """Time-staged NONLINEAR problems with device-resident iterates (see _DeviceModelMixin): time_blocks per time block
+    (nlp, start states, end states) -- what ``build_model_for_time_block`` returns; entries of other ranks may be None."""
+
+    def __init__(self, time_blocks, device_model, comm=None, bounds_relaxation_factor=1e-8):
+        self._device_model = device_model
+        self._nlps, blocks = {}, []
+        for ndx, blk in enumerate(time_blocks):
+            if blk is None:
+                blocks.append(None)
+                continue
+            nlp, start, end = blk
+            self._nlps[ndx] = nlp
+            blocks.append((self._qp_standin(nlp), start, end))
+        DeviceDynamicQPInterface.__init__(self, blocks, comm=comm, bounds_relaxation_factor=bounds_relaxation_factor)
+        self._mark_nonlinear()
