@@ -436,6 +436,16 @@ int pp_ip_wait(pp_handle h, double out[10]);
  * pp_ip_step_lengths, pp_ip_take_step, pp_ip_residuals}. */
 int pp_ip_phase_times(pp_handle h, double ms_out[4], int32_t launches_out[4], int32_t calls_out[4]);
 
+/* A caller's device model in HIP, shipped with the library for the example parapint_amd/examples/burgers.py (csrc/example_burgers.hip):
+ * the functions of the discretised Burgers control problem (parapint/examples/burgers.py:63-176) for all time blocks of a pattern
+ * group, on the arrays of pp_ip_group with obj_row >= 0 -- grad f and -c(x) into data, the objective of every lane into row
+ * obj_row, Jacobian and Hessian-of-the-Lagrangian values into src.  stream: the HIP stream to enqueue on (the solver's);
+ * dt_lane [bpad], w [nt + 1][bpad], y0 [m], scratch [(nt + 1) bpad] doubles on the device.  Not part of the solver. */
+int pp_example_burgers_model(void* stream, int m, int nt, int n, int bpad, int y_eq, int hess, int jac, int obj_row,
+                             int init_conditions, int start_term, double dx, double omega, double v, double r,
+                             const double* dt_lane, const double* w, const double* y0, const double* W, double* src, double* data,
+                             double* scratch);
+
 /* Pivot tolerances (MA27 cntl(1), ma27_interface.py:36-47; examples/stochastic.py:120-124 uses 1e-6).
  *   u_symbolic  threshold of the static pivot choice at symbolic time: a 1x1 pivot is taken only if
  *               |d| >= u * max|row| on the representative values, else a 2x2 pivot (0: keep 0.01)

@@ -112,6 +112,7 @@ SIGNATURES = {
     'pp_vec_axpy': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
     'pp_vec_permute': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_int64, ctypes.c_int]),
+    'pp_example_burgers_model': (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_int] * 10 + [ctypes.c_double] * 4 + [ctypes.c_void_p] * 7),
     'pp_ip_rhs': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_double]),
     'pp_ip_step_lengths': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_double, ctypes.c_double,
                                           ctypes.c_void_p]),

@@ -19,6 +19,7 @@ same pattern.
 block before drives nothing and goes to zero).  Start / end states: y[0][:] and y[nt][:] (:168-170).  The boundary values,
 which the reference keeps as variables fixed by equality constraints, are eliminated."""
 import math
+import os
 
 import numpy as np
 from scipy.sparse import coo_matrix
@@ -239,7 +240,7 @@ class BurgersDeviceModel(object):
     """The functions of ``BurgersNLP`` evaluated for all time blocks of a pattern group at once on [row][lane] arrays (lane =
     time block) that stay on the device: the model side of ``DeviceDynamicNLPInterface`` (what Pyomo / ASL evaluate for the
     reference at every iterate).  Written against the array operations numpy and torch share, so the same code serves the
-    numpy engines of the CPU tests and device tensors; a dozen elementwise operations over the group's arrays per call."""
+    numpy engines of the CPU tests and device tensors; on the device the same functions run as one hand-written HIP kernel."""
 
     def __init__(self, nlps, bpad):
         q = nlps[0]
@@ -252,6 +253,7 @@ class BurgersDeviceModel(object):
         self._dt = np.array([o.dt for o in nlps], dtype=np.double).reshape(1, 1, len(nlps))
         self._w = np.stack([o.w for o in nlps], axis=1).reshape(q.nt + 1, 1, len(nlps))
         self._consts = None
+        self._hip = None
 
     def _constants(self, like):
         if self._consts is None:
@@ -261,6 +263,43 @@ class BurgersDeviceModel(object):
         return self._consts
 
     def evaluate(self, W, src, data, layout):
+        """Device tensors: the model as ONE hand-written HIP pass over the iterate (csrc/example_burgers.hip, through the
+        library's C ABI on the current stream -- the solver's); numpy arrays, or PP_BURGERS_TORCH_MODEL set: the array form
+        below (a hundred elementwise operations), which is also the kernel's checker."""
+        if hasattr(W, 'is_cuda') and W.is_cuda and not os.environ.get('PP_BURGERS_TORCH_MODEL'):
+            return self._evaluate_hip(W, src, data, layout)
+        return self._evaluate(W, src, data, layout)
+
+    def _evaluate_hip(self, W, src, data, layout):
+        import ctypes
+        import torch
+        from parapint_amd import _native
+        q = self.q
+        m, nt, n, bp = q.m, q.nt, layout['n'], int(W.shape[1])
+        per = 5 * m - 2
+        # the kernel indexes these arrays itself: shapes are checked here, on the host
+        if (n != 2 * (nt + 1) * m or bp % 64 or len(self._dt.ravel()) != bp or int(src.shape[1]) != bp or int(data.shape[1]) != bp
+                or int(W.shape[0]) < layout['y_eq'] + nt * m or int(data.shape[0]) <= layout['obj_row']
+                or int(data.shape[0]) < n + nt * m + (2 * m if q.init_conditions else 0)
+                or int(src.shape[0]) < max(layout['jac'] + nt * per, layout['hess'] + n + nt * (m - 1))
+                or not (W.is_contiguous() and src.is_contiguous() and data.is_contiguous())):
+            raise ValueError('Burgers device model: arrays do not match the model')
+        if self._hip is None:
+            dev = W.device
+            self._hip = (torch.from_numpy(np.ascontiguousarray(self._dt.ravel())).to(dev),
+                         torch.from_numpy(np.ascontiguousarray(self._w.reshape(nt + 1, bp))).to(dev),
+                         torch.from_numpy(np.ascontiguousarray(q.y0)).to(dev),
+                         torch.zeros((nt + 1) * bp, dtype=torch.float64, device=dev), _native.load_library())
+        dt, w, y0, scratch, lib = self._hip
+        rc = lib.pp_example_burgers_model(ctypes.c_void_p(torch.cuda.current_stream(W.device).cuda_stream), m, nt, n, bp,
+                                          int(layout['y_eq']), int(layout['hess']), int(layout['jac']), int(layout['obj_row']),
+                                          1 if q.init_conditions else 0, 1 if q.start_term else 0, float(q.dx), float(q.omega),
+                                          float(q.v), float(q.r), dt.data_ptr(), w.data_ptr(), y0.data_ptr(), W.data_ptr(),
+                                          src.data_ptr(), data.data_ptr(), scratch.data_ptr())
+        if rc != 0:
+            raise RuntimeError('pp_example_burgers_model failed (%d)' % rc)
+
+    def _evaluate(self, W, src, data, layout):
         q = self.q
         m, nt, dx, om, v, r = q.m, q.nt, q.dx, q.omega, q.v, q.r
         n, bp = layout['n'], W.shape[1]

@@ -274,3 +274,38 @@ def test_device_nonlinear_loop_on_two_ranks():
     text = out.stdout.decode()
     assert out.returncode == 0, text[-4000:]
     assert 'rank 0 ok' in text and 'rank 1 ok' in text
+
+
+@pytest.mark.gpu
+def test_hip_model_kernel_matches_the_array_form():
+    """csrc/example_burgers.hip against the array form of the model: bit for bit against its numpy evaluation (the same
+    operations in the same order; the objective sums in another order), to rounding against its torch evaluation on the same
+    device tensors (torch divides by a scalar through its reciprocal)."""
+    import torch
+    rng = np.random.default_rng(9)
+    for init in (False, True):
+        bp = 128
+        nlps = [bg.BurgersNLP(12, 5, 0.1 * b, 0.1 * (b + 1), init) for b in range(bp)]
+        q = nlps[0]
+        n, me = q.n_primals(), q.n_eq_constraints()
+        nh, nj = q.nnz_hessian_lag(), q.nnz_jacobian_eq()
+        Wh = rng.normal(size=(n + me + 3, bp))
+        layout = dict(n=n, me=me, y_eq=n, hess=0, jac=nh, obj_row=n + me)
+        outs = []
+        for mode in ('numpy', 'torch', 'hip'):
+            model = bg.BurgersDeviceModel(nlps, bp)
+            if mode == 'numpy':
+                W, src, data = Wh.copy(), np.full((nh + nj + 2, bp), 7.0), np.full((n + me + 1, bp), 7.0)
+                model._evaluate(W, src, data, layout)
+                outs.append((src, data))
+                continue
+            W = torch.from_numpy(Wh).cuda()
+            src = torch.full((nh + nj + 2, bp), 7.0, dtype=torch.float64, device='cuda')
+            data = torch.full((n + me + 1, bp), 7.0, dtype=torch.float64, device='cuda')
+            (model._evaluate if mode == 'torch' else model.evaluate)(W, src, data, layout)
+            torch.cuda.synchronize()
+            outs.append((src.cpu().numpy(), data.cpu().numpy()))
+        (sn, dn), (st, dt_), (sh, dh) = outs
+        assert np.array_equal(sh, sn) and np.array_equal(dh[:n + me], dn[:n + me])
+        assert np.allclose(dh[n + me], dn[n + me], rtol=1e-13, atol=0.0)
+        assert np.allclose(sh, st, rtol=1e-12, atol=1e-12) and np.allclose(dh, dt_, rtol=1e-12, atol=1e-12)
