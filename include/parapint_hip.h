@@ -40,6 +40,9 @@ typedef struct pp_solver* pp_handle;
 int pp_create(pp_handle* out, int device, void* stream);
 void pp_destroy(pp_handle h);
 const char* pp_last_error(pp_handle h);
+/* SHA-1 of the kernel sources (parapint_amd/csrc) this library was built from: the loader refuses a library whose stamp
+ * differs from the sources beside it (a stale build).  No reference counterpart (a build-system guard). */
+const char* pp_source_sha1(void);
 
 /* ---- symbolic phase: do_symbolic_factorization (mpi_...:165-255) ------------------------- */
 int pp_begin_symbolic(pp_handle h, int n_coupling);

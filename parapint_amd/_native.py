@@ -112,6 +112,7 @@ SIGNATURES = {
     'pp_vec_axpy': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
     'pp_vec_permute': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_int64, ctypes.c_int]),
+    'pp_source_sha1': (ctypes.c_char_p, []),
     'pp_example_burgers_model': (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_int] * 10 + [ctypes.c_double] * 4 + [ctypes.c_void_p] * 7),
     'pp_ip_rhs': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_double]),
     'pp_ip_step_lengths': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_double, ctypes.c_double,
@@ -181,6 +182,10 @@ def load_library():
         fn = getattr(lib, name)   # AttributeError if a declared symbol is not exported
         fn.restype = restype
         fn.argtypes = argtypes
+    built_from = lib.pp_source_sha1().decode()
+    if built_from != kernel_source_sha1():
+        raise RuntimeError('parapint_amd: %s was built from other sources than the ones in %s (stamp %s): rebuild it with '
+                           '__graft_entry__.build()' % (LIB_PATH, os.path.join(_HERE, 'csrc'), built_from))
     _lib = lib
     return lib
 

@@ -25,6 +25,21 @@ def test_header_symbols_are_exported_and_bound():
     assert sorted(_native.SIGNATURES) == names
 
 
+def test_a_library_older_than_its_sources_is_refused(monkeypatch):
+    """The loader compares the library's build stamp with the sources beside it: an edited kernel without a rebuild
+    (the library on the GPU box is the one built here) raises instead of running."""
+    import pytest
+    import __graft_entry__ as entry
+    entry.build()
+    from parapint_amd import _native
+    lib = _native.load_library()
+    assert lib.pp_source_sha1().decode() == _native.kernel_source_sha1()
+    monkeypatch.setattr(_native, '_lib', None)
+    monkeypatch.setattr(_native, 'kernel_source_sha1', lambda: 'edited')
+    with pytest.raises(RuntimeError, match='rebuild'):
+        _native.load_library()
+
+
 def test_product_fails_loudly_without_gpu():
     import pytest
     import torch
