@@ -195,6 +195,12 @@ int pp_bind_rhs_buffer(pp_handle h, int group, double* dev_ptr);
 /* Forward elimination of all local blocks; leaves r_s_local = -sum_i A_i K_i^{-1} r_i
  * (mpi_...:381-385) in the rs buffer (n_c doubles, device) for the caller's all-reduce (:387). */
 int pp_solve_forward(pp_handle h);
+/* The same with a promise: rhs_before_factor != 0 states that the bound right-hand side (pp_bind_native_vectors) was
+ * complete before the block factorisation of this step was enqueued -- the situation of an interior-point iteration
+ * (interior_point.py:553-566: the right-hand side exists before the matrix is factorised).  With several pattern groups
+ * and a block-tridiagonal S the sweep of each group is then ordered behind the factorisation of that group only and
+ * overlaps the Schur update and the factorisation of S.  0: as pp_solve_forward. */
+int pp_solve_forward_ex(pp_handle h, int rhs_before_factor);
 double* pp_rs_buffer(pp_handle h);
 int pp_bind_rs_buffer(pp_handle h, double* dev_ptr);
 /* x_c = S^{-1} (r_c + r_s)  (mpi_...:388-391); r_c on the host (n_c doubles, or NULL = 0). */

@@ -84,6 +84,7 @@ SIGNATURES = {
     'pp_rhs_buffer': (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int]),
     'pp_bind_rhs_buffer': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     'pp_solve_forward': (ctypes.c_int, [ctypes.c_void_p]),
+    'pp_solve_forward_ex': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'pp_rs_buffer': (ctypes.c_void_p, [ctypes.c_void_p]),
     'pp_bind_rs_buffer': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     'pp_solve_coupling': (ctypes.c_int, [ctypes.c_void_p, _f64p]),

@@ -58,6 +58,7 @@ void pp_destroy(pp_handle h) {
     for (int i = 0; i < PP_MAX_SPLIT; ++i) { (void)hipStreamDestroy(h->aux[i]); (void)hipEventDestroy(h->ev_join[i]); }
     (void)hipEventDestroy(h->ev_fork);
   }
+  if (h->ev_blocks_done) (void)hipEventDestroy(h->ev_blocks_done);
   if (h->dense_stream) {
     (void)hipStreamSynchronize(h->dense_stream);
     (void)hipStreamDestroy(h->dense_stream);

@@ -402,6 +402,11 @@ struct pp_solver {
   bool corner_used = false;
   std::mutex alloc_mu, err_mu;
   bool group_streams = std::getenv("PP_NO_GROUP_STREAMS") == nullptr;   // pattern groups side by side on streams of their own (measurement switch)
+  // forward sweep of an announced right-hand side behind the block factorisation of its own group instead of behind the
+  // Schur update and the factorisation of S (pp_solve_forward_ex; measurement switch)
+  bool fwd_early = std::getenv("PP_NO_EARLY_FORWARD") == nullptr;
+  hipEvent_t ev_blocks_done = nullptr;   // recorded on the handle's stream behind the join of the groups' factorisations
+  bool blocks_done_valid = false;
   bool dense_dpp = std::getenv("PP_NO_DENSE_DPP") == nullptr;           // row broadcasts by DP-ALU DPP in k_ldl_regs (measurement switch)
   bool lane_pairs = std::getenv("PP_NO_LANE_PAIRS") == nullptr;   // two instances per lane in the gather kernels (measurement switch)
   double shift_w = 0.0, shift_c = 0.0;   // diagonal shifts of the current pp_numeric_local_shifted call (else 0)

@@ -840,6 +840,12 @@ int pp_numeric_factor_blocks(pp_handle h) {
   };
   if (int rc = run_groups(h, gst, group_body)) return rc;
   if (join_group_streams(h, gst)) return fail(h, 3, "stream join failed");
+  h->blocks_done_valid = false;
+  if (gst.n > 1) {            // what an early forward sweep of the handle's own groups waits for (pp_solve_forward_ex)
+    if (!h->ev_blocks_done) PP_HIP(hipEventCreateWithFlags(&h->ev_blocks_done, hipEventDisableTiming));
+    PP_HIP(hipEventRecord(h->ev_blocks_done, h->stream));
+    h->blocks_done_valid = true;
+  }
   PP_HIP(hipGetLastError());
   h->blocks_factored = true;
   h->numeric_done = false;

@@ -476,8 +476,9 @@ class HipEngine(object):
     def upload_rhs(self, gid, rhs):
         self.ns.check(self.lib.pp_upload_rhs(self.ns.h, gid, rhs.ctypes.data, 0), 'pp_upload_rhs')
 
-    def solve_forward(self):
-        self.ns.check(self.lib.pp_solve_forward(self.ns.h), 'pp_solve_forward')
+    def solve_forward(self, early=False):
+        """early: the bound right-hand side was complete before this step's factorisation was enqueued (pp_solve_forward_ex)."""
+        self.ns.check(self.lib.pp_solve_forward_ex(self.ns.h, 1 if early else 0), 'pp_solve_forward')
 
     def allreduce_rs(self, comm):
         if comm.size > 1 or getattr(comm, 'always_reduce', False):

@@ -346,6 +346,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         self._cperm_pad = None
         self._prefetch_rhs = None           # DeviceBlockVector whose forward sweep rides behind the factorisations (prefetch_forward)
         self._forward_done_for = None       # ... and the one whose forward sweep the last factorisation has already enqueued
+        self._prefetch_before_factor = False   # the announcement preceded the block phase of the running factorisation
         # Index arrays recognised by identity (the fast paths of the host boundary) are checked for in-place rewrites:
         # size and address at every call; a CRC of their contents at every call for the first `pattern_check_bytes` of
         # distinct arrays (blocks that share their index arrays -- one Jacobian structure, one object -- are always
@@ -1047,6 +1048,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         self.block_matrix = matrix
         res = LinearSolverResults(LinearSolverStatus.successful)
         timer.start('form SC')
+        self._prefetch_before_factor = self._prefetch_rhs is not None       # (announced before the block phase is enqueued)
         timer.start('factorize')
         if hasattr(matrix, 'value_maps'):
             self._guarded(res, self._bind_device_matrix, matrix)      # f2: values are gathered from the device sources
@@ -1221,7 +1223,9 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         if self._prefetch_rhs is not None and res.status in _OK:
             # the forward sweep of the announced right-hand side does not depend on S: enqueued here, before the host waits
             # for the status, it runs beside the one-workgroup factorisation of S (a stream of its own in the library)
-            self._guarded(res, self._forward_sweep, self._prefetch_rhs)
+            # (announced before the factorisation was enqueued: with several pattern groups and a block-tridiagonal S each
+            # group's sweep follows its own block factorisation, beside the Schur update and the cyclic reduction)
+            self._guarded(res, self._forward_sweep, self._prefetch_rhs, self._prefetch_before_factor)
             if res.status in _OK:
                 self._forward_done_for = self._prefetch_rhs
         st = self._guarded(res, self._eng.status)
@@ -1289,6 +1293,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         res = LinearSolverResults(LinearSolverStatus.successful)
         self.diagonal_shift_refactorizations += 1
         timer.start('form SC')
+        self._prefetch_before_factor = self._prefetch_rhs is not None       # (announced before the block phase is enqueued)
         timer.start('factorize')
         self._guarded(res, self._eng.numeric_local_shifted, delta_w, delta_c)
         timer.stop('factorize')
@@ -1461,12 +1466,13 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         if rhs is not None and not hasattr(rhs, 'group_tensors'):
             raise ValueError('prefetch_forward takes a DeviceBlockVector')
         self._prefetch_rhs = rhs
+        self._prefetch_before_factor = False
         self._forward_done_for = None
 
-    def _forward_sweep(self, rhs):
+    def _forward_sweep(self, rhs, early=False):
         for g in self._groups:
             self._eng.bind_native_vectors(g.gid, rhs.group_tensors[g.gid], None)
-        self._eng.solve_forward()
+        self._eng.solve_forward(early=early)
         self._eng.allreduce_rs(self.comm)
 
     def _device_back_solve(self, rhs, timer):

@@ -223,7 +223,7 @@ class HostSimEngine(object):
     def upload_rhs(self, gid, rhs):
         self.groups[gid].rhs = np.array(rhs, dtype=np.double, copy=True)
 
-    def solve_forward(self):
+    def solve_forward(self, early=False):
         L = hu.lib()
         self.rs = np.zeros(self.nc)
         for sg in self.groups:
@@ -466,7 +466,7 @@ class HostSimDeviceEngine(HostSimEngine):
         sg = self.groups[gid]
         sg.rhs_native, sg.x_native = rhs, x
 
-    def solve_forward(self):
+    def solve_forward(self, early=False):
         for sg in self.groups:
             if sg.rhs_native is not None:
                 sg.rhs = np.ascontiguousarray(np.asarray(sg.rhs_native)[:, :sg.batch].T)
