@@ -577,6 +577,17 @@ def main():
     # states between them, coupling block 2 * 49 * 511 = 50 078 with block-tridiagonal S): diffusion control, every time
     # block a QP of 2089 primal variables (KKT block 4254), iterates resident and rank-distributed by time block
     # (DeviceDynamicQPInterface; SURVEY.md section 8 rows f2 + f3)
+    # (what the line reports from the main handle; the handle itself is released in front of the time-staged loops: they run
+    # three pattern groups on three streams, and the streams of a live handle beside them share the hardware queues --
+    # measured: the Burgers loop 10.3 ms per iteration with the handle alive, 8.3 ms without)
+    rccl_ranks = int(lib.pp_comm_size(h))
+    bcr_paths = (dict(zip(('unpivoted_ldl_on_matrix_cores', 'bunch_kaufman'), eng.bcr_block_paths()))
+                 if solver._btd is not None else None)
+    if not args.no_ip_loop_dynamic and not args.no_ip_loop:
+        import gc
+        sync_all()
+        eng.ns.close()
+        gc.collect()
     ip_loop_dynamic = None
     if not args.no_ip_loop_dynamic and not args.no_ip_loop and args.workload in ('C3', 'C4') and not args.blocks \
             and (world == 1 or args.ip_loop_dynamic_all_ranks):
@@ -670,7 +681,7 @@ def main():
                        'parallelism': 'blocks round-robin over %d rank(s); all-reduce of [S | status | inertia] and '
                                       'of r_s' % world},
             'median_ms_per_step': median_ms,
-            'rccl_ranks': int(lib.pp_comm_size(h)),      # > 0: the all-reduces were enqueued by the library (PP_DIRECT_RCCL=1)
+            'rccl_ranks': rccl_ranks,      # > 0: the all-reduces were enqueued by the library (PP_DIRECT_RCCL=1)
             'collective_us': collective_us,             # per rank: the two data-path all-reduces by themselves (HIP events)
             # SURVEY 8(d) to the letter: the same step through HOST containers (SciPy COO blocks in, host vectors out;
             # staging, H2D and D2H inside) -- the rate a caller with the reference's unchanged interfaces sees
@@ -692,8 +703,7 @@ def main():
             'boundary_host': boundary,
             'device_only': device_only,
             'value_storage_bytes': {'device_resident_path': mem_now, 'with_host_input_and_output_copies': mem_max},
-            'bcr_block_paths': (dict(zip(('unpivoted_ldl_on_matrix_cores', 'bunch_kaufman'), eng.bcr_block_paths()))
-                                if solver._btd is not None else None),
+            'bcr_block_paths': bcr_paths,
         }
         print(json.dumps(out))
     if world > 1:

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(BL_THREADS) void k_bcr_ldl_inverse(int gs, BcrLevel
   double* Z = blsh + (size_t)BL_NTT * BL_TILE;
   __shared__ double dl[16 * BL_NT], rdl[16 * BL_NT], dmag[16 * BL_NT];
   __shared__ double red[BL_THREADS / 64];
-  __shared__ int sflags[2], orig[16 * BL_NT];
+  __shared__ int sflags[2], orig[16 * BL_NT], rotf[8 * BL_NT];
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = BL_THREADS / 64;
   const int li = lane & 15, lk = lane >> 4;
   const int i = lv.elim[blockIdx.x];
@@ -142,12 +142,55 @@ __global__ __launch_bounds__(BL_THREADS) void k_bcr_ldl_inverse(int gs, BcrLevel
   // ---- symmetric pre-ordering by decreasing |diagonal| (static, from the values of this factorisation: the coupling
   // states of a time-staged S carry O(1) diagonals, the link duals nearly none -- states first makes every pivot of
   // the quasi-definite block its column's largest entry; the acceptance test below judges the result)
+  // ---- pair rotations (in front of the ordering): rows k and k + h, h = gs / 2, are a link dual and the coupling state it
+  // multiplies; where the entry between them outweighs their diagonals (a quadratic program whose dynamics leave both the
+  // dual block and the state block of S nearly empty: [[-p, -1], [-1, q]] with p, q << 1) no ordering of 1 x 1 pivots is
+  // stable, but the orthogonal congruence with R = [[1, 1], [1, -1]] / sqrt(2) on that pair turns it into
+  // [[(q - p) / 2 - 1, .], [., (q - p) / 2 + 1]]: D' = H D H with H = H^T = H^-1 the direct sum of R (rotated pairs) and 1,
+  // inv(D) = H inv(D') H, same inertia.  A pair whose diagonals carry it (the nonlinear Burgers blocks: p = 15..70) is left
+  // alone.  MEASURED on the blocks of real interior-point runs: largest multiplier 1e2..inf -> < 0.4.
+  const int h2 = gs / 2;
+  if (tid == 0) { sflags[0] = 0; sflags[1] = 0; }
+  __syncthreads();
   for (int k = tid; k < 16 * BL_NT; k += BL_THREADS) {
     dmag[k] = (k < gs) ? fabs(Dg[(size_t)k + (size_t)k * gs]) : -1.0;
     orig[k] = k;          // (a NaN diagonal leaves ranks unassigned: the identity keeps every index valid, the pivot test rejects)
+    if (k < h2) {
+      const double a = Dg[(size_t)k + (size_t)k * gs], c = Dg[(size_t)(k + h2) + (size_t)(k + h2) * gs];
+      const double b = Dg[(size_t)(k + h2) + (size_t)k * gs];
+      const bool rot = fabs(b) > 0.5 * fmax(fabs(a), fabs(c));
+      rotf[k] = rot ? 1 : 0;
+      if (rot) sflags[1] = 1;
+    }
   }
-  if (tid == 0) { sflags[0] = 0; sflags[1] = 0; }
   __syncthreads();
+  const bool anyrot = sflags[1] != 0;
+  if (anyrot) {
+    for (int k = tid; k < h2; k += BL_THREADS) {
+      if (rotf[k]) {
+        const double a = Dg[(size_t)k + (size_t)k * gs], c = Dg[(size_t)(k + h2) + (size_t)(k + h2) * gs];
+        const double b = Dg[(size_t)(k + h2) + (size_t)k * gs];
+        dmag[k] = fabs(0.5 * (a + c) + b);
+        dmag[k + h2] = fabs(0.5 * (a + c) - b);
+      }
+    }
+    __syncthreads();
+  }
+  // entry (r, c) of H D H (r, c: labels of D); hcoef: the coefficient of the label itself, its partner's is 1 / sqrt(2)
+  auto rotated = [&](int r) { return r < 2 * h2 && rotf[r < h2 ? r : r - h2] != 0; };
+  auto entry = [&](int r, int c) -> double {
+    const bool rr = anyrot && rotated(r), rc = anyrot && rotated(c);
+    auto D1 = [&](int x, int y) { return Dg[(size_t)max(x, y) + (size_t)min(x, y) * gs]; };
+    if (!rr && !rc) return D1(r, c);
+    const double sq = 0.70710678118654752440;
+    const int pr = r < h2 ? r + h2 : r - h2, pc = c < h2 ? c + h2 : c - h2;
+    const double hr = rr ? (r < h2 ? sq : -sq) : 1.0, hc = rc ? (c < h2 ? sq : -sq) : 1.0;
+    double v = hr * hc * D1(r, c);
+    if (rr) v += sq * hc * D1(pr, c);
+    if (rc) v += hr * sq * D1(r, pc);
+    if (rr && rc) v += 0.5 * D1(pr, pc);
+    return v;
+  };
   double loc = 0.0;
   for (int k = tid; k < 16 * BL_NT; k += BL_THREADS) {
     int rank = k;
@@ -172,10 +215,7 @@ __global__ __launch_bounds__(BL_THREADS) void k_bcr_ldl_inverse(int gs, BcrLevel
     const int J = t - I * (I + 1) / 2;
     const int gr = 16 * I + r, gc = 16 * J + c;
     double v = (gr == gc) ? 1.0 : 0.0;
-    if (gr < gs && gc < gs) {
-      const int o_r = orig[gr], o_c = orig[gc];
-      v = Dg[(size_t)max(o_r, o_c) + (size_t)min(o_r, o_c) * gs];
-    }
+    if (gr < gs && gc < gs) v = entry(orig[gr], orig[gc]);
     T[(size_t)t * BL_TILE + r * BL_LD + c] = v;
   }
   __syncthreads();
@@ -323,6 +363,34 @@ __global__ __launch_bounds__(BL_THREADS) void k_bcr_ldl_inverse(int gs, BcrLevel
         X[(size_t)o_r + (size_t)o_c * gs] = acc[r];
         if (I != J) X[(size_t)o_c + (size_t)o_r * gs] = acc[r];
       }
+    }
+  }
+  if (anyrot) {
+    // inv(D) = H inv(D') H, in place on the 2 x 2 cells (pair I) x (pair J) of the inverse just written (each cell by one
+    // thread; the waves of a workgroup share their compute unit's cache, the barrier orders the stores above)
+    __syncthreads();
+    const double sq = 0.70710678118654752440;
+    for (int cell = tid; cell < h2 * h2; cell += BL_THREADS) {
+      const int I = cell / h2, J = cell - I * h2;
+      const bool ri = rotf[I] != 0, rj = rotf[J] != 0;
+      if (!ri && !rj) continue;
+      double* x00 = X + (size_t)I + (size_t)J * gs;
+      double* x10 = X + (size_t)(I + h2) + (size_t)J * gs;
+      double* x01 = X + (size_t)I + (size_t)(J + h2) * gs;
+      double* x11 = X + (size_t)(I + h2) + (size_t)(J + h2) * gs;
+      double a = *x00, b = *x01, c = *x10, d = *x11;
+      if (ri) { const double t0 = sq * (a + c), t1 = sq * (a - c), u0 = sq * (b + d), u1 = sq * (b - d); a = t0; c = t1; b = u0; d = u1; }
+      if (rj) { const double t0 = sq * (a + b), t1 = sq * (a - b), u0 = sq * (c + d), u1 = sq * (c - d); a = t0; b = t1; c = u0; d = u1; }
+      *x00 = a; *x01 = b; *x10 = c; *x11 = d;
+    }
+    if ((gs & 1) && tid < h2 && rotf[tid]) {       // the unpaired last row and column against the rotated pairs
+      const int I = tid, L = gs - 1;
+      double* r0 = X + (size_t)I + (size_t)L * gs;
+      double* r1 = X + (size_t)(I + h2) + (size_t)L * gs;
+      double* c0 = X + (size_t)L + (size_t)I * gs;
+      double* c1 = X + (size_t)L + (size_t)(I + h2) * gs;
+      const double a = *r0, b = *r1, c = *c0, d = *c1;
+      *r0 = sq * (a + b); *r1 = sq * (a - b); *c0 = sq * (c + d); *c1 = sq * (c - d);
     }
   }
   if (tid == 0) {
