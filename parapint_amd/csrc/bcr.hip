@@ -110,6 +110,13 @@ __global__ __launch_bounds__(256) void k_bcr_invert_wave(int gs, BcrLevel lv, co
 //   phase 2  Z = inv(L): diagonal tiles by column substitution (lane = column), then by block diagonals t = I - J:
 //            Z_IJ = -Z_II sum_{J <= K < I} L_IK Z_KJ  (the MFMA result layout of the sum IS the operand layout of the second product)
 //   phase 3  inv(D_i) = Z^T D^-1 Z, tile (I, J) = sum_{K >= I} Z_KI^T D_K^-1 Z_KJ, written to both triangles
+// pair rotation threshold (k_bcr_ldl_inverse): rotate where |entry between the pair| > theta * max |its diagonals|.
+// MEASURED on the blocks of three interior-point runs at every level of the cyclic reduction (largest multiplier of the
+// ordered unpivoted factorisation): theta 0.5 -- 1e11 on the reduced blocks of a 96-block quadratic program where only
+// 22..26 of 30 pairs rotate; 0.25 / 0.1 / 0.05 -- at most 0.6 / 0.77 / 0.94 on all of them (Burgers: no pair rotates down
+// to 0.1, its link duals carry 15..70 on the diagonal; at 0.05 one does, harmlessly).  A pair with |diagonal| >> |entry|
+// must NOT rotate (the second rotated pivot is 2 entry^2 / diagonal).
+constexpr double BL_ROT_THETA = 0.1;
 constexpr int BL_NT = 7;
 constexpr int BL_LD = 18;
 constexpr int BL_TILE = 16 * BL_LD;
@@ -148,7 +155,8 @@ __global__ __launch_bounds__(BL_THREADS) void k_bcr_ldl_inverse(int gs, BcrLevel
   // stable, but the orthogonal congruence with R = [[1, 1], [1, -1]] / sqrt(2) on that pair turns it into
   // [[(q - p) / 2 - 1, .], [., (q - p) / 2 + 1]]: D' = H D H with H = H^T = H^-1 the direct sum of R (rotated pairs) and 1,
   // inv(D) = H inv(D') H, same inertia.  A pair whose diagonals carry it (the nonlinear Burgers blocks: p = 15..70) is left
-  // alone.  MEASURED on the blocks of real interior-point runs: largest multiplier 1e2..inf -> < 0.4.
+  // alone (BL_ROT_THETA).  MEASURED on the blocks of real interior-point runs: largest multiplier
+  // 1e2..inf -> < 1.
   const int h2 = gs / 2;
   if (tid == 0) { sflags[0] = 0; sflags[1] = 0; }
   __syncthreads();
@@ -158,7 +166,7 @@ __global__ __launch_bounds__(BL_THREADS) void k_bcr_ldl_inverse(int gs, BcrLevel
     if (k < h2) {
       const double a = Dg[(size_t)k + (size_t)k * gs], c = Dg[(size_t)(k + h2) + (size_t)(k + h2) * gs];
       const double b = Dg[(size_t)(k + h2) + (size_t)k * gs];
-      const bool rot = fabs(b) > 0.5 * fmax(fabs(a), fabs(c));
+      const bool rot = fabs(b) > BL_ROT_THETA * fmax(fabs(a), fabs(c));
       rotf[k] = rot ? 1 : 0;
       if (rot) sflags[1] = 1;
     }

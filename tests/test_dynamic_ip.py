@@ -181,6 +181,7 @@ def _device_loop(blocks, engine, comm=None, local=None):
     hist, stats = [], {}
     status, iters = ip_solve_device(it, opt, history=hist, stats=stats)
     assert status == InteriorPointStatus.optimal
+    stats['solver'] = opt.linalg.solver
     return it, hist, stats
 
 
@@ -335,6 +336,11 @@ def test_device_dynamic_loop_at_a_longer_horizon_against_the_host_producer():
     T, args = 96, dict(nfe_per_block=4, n_states=30, n_controls=3, nu=0.005)
     it, hist, stats = _device_loop(_time_blocks(T, args), None)
     assert stats['torch_ops'] <= 6, stats['torch_op_names']      # (set-up of the permutation; none per iteration)
+    # the diagonal blocks of this S carry next to nothing on their diagonals (link duals AND coupling states of a quadratic
+    # program): with the pair rotations of k_bcr_ldl_inverse every one of them still takes the unpivoted matrix-core path in
+    # the last factorisation of the run (round 3: none of them did)
+    fast, pivoted = stats['solver']._eng.bcr_block_paths()
+    assert (fast, pivoted) == (T - 1, 0), (fast, pivoted)
     host, rows = _host_history(T, args, HipSchurComplementLinearSolver({t: None for t in range(T)}, None, comm=SerialComm()))
     _same_iterations(rows, hist)
     _same_point(it, host, T, 1e-6)
