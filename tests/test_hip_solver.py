@@ -777,3 +777,34 @@ def test_prefetched_forward_sweep_gives_the_same_solution():
     assert torch.equal(x_pre.group_tensors[0], x_plain.group_tensors[0]) and torch.equal(x_pre.coupling, x_plain.coupling)
     assert torch.equal(x_fallback.group_tensors[0], x_other.group_tensors[0]) and torch.equal(x_fallback.coupling, x_other.coupling)
     assert solver._prefetch_rhs is None and solver._forward_done_for is None
+
+
+def test_prefetched_forward_sweep_of_a_time_staged_problem_gives_the_same_solution():
+    """The same for three pattern groups and a block-tridiagonal S (pp_solve_forward_ex: every group's sweep behind the
+    factorisation of that group, on its stream, beside the Schur update and the cyclic reduction; the groups of the handle's
+    own stream on an auxiliary one): bit for bit the solution of the plain call order, also after the values changed."""
+    import torch
+    from parapint_amd.examples.performance.schur_complement.dynamic_kkt import SyntheticDynamicKKT
+    from parapint_amd.linalg.comm import SerialComm
+    from parapint_amd.linalg.hip_schur_complement import HipSchurComplementLinearSolver
+    T = 40
+    model = SyntheticDynamicKKT(T, 20, 2, 3)
+    comm = SerialComm()
+    solver = HipSchurComplementLinearSolver({i: None for i in range(T)}, None, comm=comm, result_buffers=0)
+    solver._dense_coupling_limit = 8              # (block-tridiagonal S at this small size)
+    dk = model.build_device_kkt(comm=comm)
+    solver.do_symbolic_factorization(dk)
+    assert solver._btd is not None and len(solver._groups) == 3
+    rhs = solver.device_vector_from_host(model.build_rhs(comm=comm))
+    for it in (1, 2):
+        dk.set_sources_from_host({ndx: model.block_sources(ndx, it) for ndx in range(T)})
+        solver.do_numeric_factorization(dk)
+        x_plain = solver.do_back_solve(rhs)
+        solver.prefetch_forward(rhs)
+        solver.do_numeric_factorization(dk)
+        x_pre = solver.do_back_solve(rhs)
+        torch.cuda.synchronize()
+        for gid in x_plain.group_tensors:
+            assert torch.equal(x_pre.group_tensors[gid], x_plain.group_tensors[gid])
+        assert torch.equal(x_pre.coupling, x_plain.coupling)
+        assert float(x_plain.coupling.abs().max()) > 0.0
