@@ -117,6 +117,11 @@ __global__ __launch_bounds__(256) void k_bcr_invert_wave(int gs, BcrLevel lv, co
 // to 0.1, its link duals carry 15..70 on the diagonal; at 0.05 one does, harmlessly).  A pair with |diagonal| >> |entry|
 // must NOT rotate (the second rotated pivot is 2 entry^2 / diagonal).
 constexpr double BL_ROT_THETA = 0.1;
+// ... and only in a block that holds at least one pair with |entry| > BL_ROT_NEED * max |its diagonals| (a block whose pairs
+// all carry diagonals of the size of the entry -- the synthetic C4 blocks -- factorises as it is, and the rotation costs
+// 6-19 us of the kernel's 55: 4 x the loads of the block and a pass over its inverse).  Same scan: 0.5 ... 1.4 give the same
+// largest multipliers as rotating everywhere (<= 0.94; 1.6 at the first iterate of one run, unrotated); 2.0 misses blocks.
+constexpr double BL_ROT_NEED = 0.7;
 constexpr int BL_NT = 7;
 constexpr int BL_LD = 18;
 constexpr int BL_TILE = 16 * BL_LD;
@@ -166,18 +171,18 @@ __global__ __launch_bounds__(BL_THREADS) void k_bcr_ldl_inverse(int gs, BcrLevel
     if (k < h2) {
       const double a = Dg[(size_t)k + (size_t)k * gs], c = Dg[(size_t)(k + h2) + (size_t)(k + h2) * gs];
       const double b = Dg[(size_t)(k + h2) + (size_t)k * gs];
-      const bool rot = fabs(b) > BL_ROT_THETA * fmax(fabs(a), fabs(c));
-      rotf[k] = rot ? 1 : 0;
-      if (rot) sflags[1] = 1;
+      rotf[k] = 0;
+      if (fabs(b) > BL_ROT_NEED * fmax(fabs(a), fabs(c))) sflags[1] = 1;      // this block needs its pairs rotated
     }
   }
   __syncthreads();
   const bool anyrot = sflags[1] != 0;
   if (anyrot) {
     for (int k = tid; k < h2; k += BL_THREADS) {
-      if (rotf[k]) {
-        const double a = Dg[(size_t)k + (size_t)k * gs], c = Dg[(size_t)(k + h2) + (size_t)(k + h2) * gs];
-        const double b = Dg[(size_t)(k + h2) + (size_t)k * gs];
+      const double a = Dg[(size_t)k + (size_t)k * gs], c = Dg[(size_t)(k + h2) + (size_t)(k + h2) * gs];
+      const double b = Dg[(size_t)(k + h2) + (size_t)k * gs];
+      if (fabs(b) > BL_ROT_THETA * fmax(fabs(a), fabs(c))) {
+        rotf[k] = 1;
         dmag[k] = fabs(0.5 * (a + c) + b);
         dmag[k + h2] = fabs(0.5 * (a + c) - b);
       }
@@ -477,6 +482,20 @@ __device__ __forceinline__ double4_t bcr_gemm_tile(const double* __restrict__ A,
                                                    int n0, int li, int lk) {
   double4_t acc = {0.0, 0.0, 0.0, 0.0};
   const int m = m0 + li, n = n0 + li;
+  if (gs <= 16 * BL_NT) {
+    // blocks of the unpivoted path (gs <= 112): the operands of ALL K steps are requested before the first product -- one
+    // memory round trip per tile instead of one per 16 K steps (round 4: the level-0 products of C4 315 -> see DESIGN.md)
+    double a[4 * BL_NT], b[4 * BL_NT];
+#pragma unroll
+    for (int u = 0; u < 4 * BL_NT; ++u) {
+      const int k = 4 * u + lk;
+      a[u] = (m < gs && k < gs) ? (TA ? A[(size_t)k + (size_t)m * gs] : A[(size_t)m + (size_t)k * gs]) : 0.0;
+      b[u] = (n < gs && k < gs) ? (TB ? B[(size_t)n + (size_t)k * gs] : B[(size_t)k + (size_t)n * gs]) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4 * BL_NT; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+    return acc;
+  }
   for (int k0 = 0; k0 < gs; k0 += 16) {
     double a[4], b[4];
 #pragma unroll
