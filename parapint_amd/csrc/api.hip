@@ -134,6 +134,7 @@ int pp_add_group_mapped(pp_handle h, int n, int batch, int nnzK, const int32_t* 
   Group* g = new Group();
   pp::PlanOptions opt;
   pp::tune_for_batch(opt, batch);
+  if (cmap) pp::tune_for_mapped_group(opt, batch);
   if (h->sn_wmax > 0) opt.sn_wmax = h->sn_wmax;
   if (h->sn_tol >= 0) opt.sn_tol_rows = h->sn_tol;
   if (h->pivot_threshold > 0.0) opt.pivot_threshold = h->pivot_threshold;

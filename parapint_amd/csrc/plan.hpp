@@ -70,6 +70,9 @@ struct PlanOptions {
   // (rounds 1-2 of this project); 1 = rounds of independent clusters of up to sn_wmax columns (symbolic.cpp, step 2);
   // 2 = both, the cheaper schedule kept (build_plan).
   int order_mode = 2;
+  // order_mode 2: tolerance windows (md_delta_abs, md_delta_rel) planned besides the configured one -- 1: (1, 0.2),
+  // 2: also (8, 1.0) -- the cheapest schedule kept (tune_for_mapped_group)
+  int order_candidates = 0;
   // rounds (order_mode 1): a round with at most round_relax_pop candidates lets a sub-pivot join a cluster if it adds
   // at most max(round_relax_tol_rows, round_relax_tol_frac * |structure|) rows (else sn_tol_rows); a round with more
   // than round_narrow_pop candidates keeps its clusters at round_narrow_wmax columns
@@ -107,6 +110,20 @@ inline void tune_for_batch(PlanOptions& o, int batch) {
   }
 }
 
+// Pattern groups with coupling rows of their own per instance (pp_add_group_mapped: the time blocks of a dynamic problem) are
+// deep chains -- 60 ... 100 levels -- whose depth and fill depend on the tolerance window of the minimum-degree order far more
+// than those of a scenario block: the KKT block of the time-staged quadratic program of examples/dynamics_qp.py orders into
+// 96 levels / 150 k factor entries with the default window (3, 0.5), 68 / 127 k with (1, 0.2) and 83 / 155 k with (8, 1.0), while
+// the C3 scenario block goes from 11 levels to 209 with (1, 0.2).  For a mapped group of more than one chunk the two other
+// windows are planned besides (build_plan: all of them side by side on host threads) and the cheapest schedule is kept; the
+// Burgers and the synthetic C4 blocks keep the default (63 ... 66 levels under all three).
+inline void tune_for_mapped_group(PlanOptions& o, int batch) {
+  if (batch > 64) {
+    static const char* e = std::getenv("PP_ORDER_CANDIDATES");
+    o.order_candidates = e ? std::atoi(e) : 2;
+  }
+}
+
 // Developer knob for schedule experiments (environment PP_PLAN_TUNE = "max_task_entries=48,scale_task_rows=16,..."),
 // read by the library and by the test interpreter alike.  Returns false and names the key if one is unknown.
 inline bool apply_plan_tune(PlanOptions& opt, const char* tune, std::string& bad_key) {
@@ -135,6 +152,7 @@ inline bool apply_plan_tune(PlanOptions& opt, const char* tune, std::string& bad
       else if (k == "md_delta_rel") opt.md_delta_rel = v;
       else if (k == "row_split_factor") opt.row_split_factor = v;
       else if (k == "task_order") opt.task_order = (int)v;
+      else if (k == "order_candidates") opt.order_candidates = (int)v;
       else if (k == "order_mode") opt.order_mode = (int)v;
       else if (k == "pivot_threshold") opt.pivot_threshold = v;
       else if (k == "front_max") opt.front_max = std::min((int)v, (int)PP_FRONT_MAX);   // (k_front_invert / k_scale_wide hold at most PP_FRONT_MAX columns)

@@ -27,18 +27,34 @@ int build_plan(int n, int nc, int nnzK, const int* rowK, const int* colK, int nn
   // both elimination orders, the cheaper schedule kept: a level costs its launches (two for the factorisation, one
   // in each solve sweep, at a floor of 5-8 us each on one MI355X), an entry of the factor its trips through HBM --
   // about 2500 entries to the level at a thousand instances
-  // (side by side on two host threads: they share nothing but their read-only inputs)
-  PlanOptions o = opt, o0 = opt;
-  o.order_mode = 1;
-  o0.order_mode = 0;
-  Plan Q;
-  int rc0 = 0;
-  std::thread other([&]() { rc0 = build_plan_ordered(n, nc, nnzK, rowK, colK, nnzB, rowB, colB, vals, o0, Q); });
-  int rc = build_plan_ordered(n, nc, nnzK, rowK, colK, nnzB, rowB, colB, vals, o, P);
-  other.join();
+  // (side by side on host threads: they share nothing but their read-only inputs; opt.order_candidates: other tolerance
+  // windows of the minimum-degree order besides, plan.hpp tune_for_mapped_group)
+  std::vector<PlanOptions> variants;
+  for (int c = 0; c <= std::max(0, std::min(opt.order_candidates, 2)); ++c) {
+    for (int mode = 1; mode >= 0; --mode) {
+      PlanOptions o = opt;
+      o.order_mode = mode;
+      if (c == 1) { o.md_delta_abs = 1; o.md_delta_rel = 0.2; }
+      if (c == 2) { o.md_delta_abs = 8; o.md_delta_rel = 1.0; }
+      variants.push_back(o);
+    }
+  }
+  std::vector<Plan> plans(variants.size());
+  std::vector<int> rcs(variants.size(), 0);
+  {
+    std::vector<std::thread> others;
+    for (size_t v = 1; v < variants.size(); ++v)
+      others.emplace_back([&, v]() { rcs[v] = build_plan_ordered(n, nc, nnzK, rowK, colK, nnzB, rowB, colB, vals, variants[v], plans[v]); });
+    rcs[0] = build_plan_ordered(n, nc, nnzK, rowK, colK, nnzB, rowB, colB, vals, variants[0], plans[0]);
+    for (auto& t : others) t.join();
+  }
   auto cost = [](const Plan& x) { return (int64_t)x.n_levels * 2500 + x.usize; };
-  if (rc0 == 0 && (rc != 0 || cost(Q) < cost(P))) { P = std::move(Q); rc = rc0; }
-  return rc;
+  size_t best = 0;                      // (ties: the configured window, the round-based order first)
+  for (size_t v = 1; v < variants.size(); ++v)
+    if (rcs[v] == 0 && (rcs[best] != 0 || cost(plans[v]) < cost(plans[best]))) best = v;
+  P = std::move(plans[best]);
+  P.opt.order_candidates = opt.order_candidates;
+  return rcs[best];
 }
 
 static int build_plan_ordered(int n, int nc, int nnzK, const int* rowK, const int* colK, int nnzB, const int* rowB,

@@ -23,7 +23,7 @@ struct HostCtx {
 };
 }  // namespace
 
-static int g_sn_wmax = 0, g_sn_tol = -1, g_batch_hint = 0;
+static int g_sn_wmax = 0, g_sn_tol = -1, g_batch_hint = 0, g_mapped_hint = 0;
 static double g_growth_bound = 1e8, g_pivot_threshold = 0.0;   // as pp_set_pivot_tolerance
 static int g_last_growth = 0, g_growth_fatal = 0;
 static int g_first_zero_piv = -1;      // first block pivot of the last ppsim_factor call that held a numerically zero sub-pivot (diagnostic)
@@ -34,6 +34,8 @@ extern "C" {
 void ppsim_set_supernodes(int wmax, int tol) { g_sn_wmax = wmax; g_sn_tol = tol; }
 // instances of the pattern group the next plans are made for (0: unknown = the large-batch task sizes), plan.hpp:tune_for_batch
 void ppsim_set_batch_hint(int batch) { g_batch_hint = batch; }
+// the next plans are made for a group with coupling rows of its own per instance (plan.hpp:tune_for_mapped_group)
+void ppsim_set_mapped_hint(int mapped) { g_mapped_hint = mapped; }
 void ppsim_set_pivot_tolerance(double u_symbolic, double u_runtime) {
   g_pivot_threshold = u_symbolic;
   g_growth_bound = u_runtime > 0.0 ? 1.0 / u_runtime : 1e8;
@@ -48,6 +50,7 @@ void* ppsim_create(int n, int nc, int nnzK, const int* rowK, const int* colK, in
   auto* P = new Plan();
   pp::PlanOptions opt;
   pp::tune_for_batch(opt, g_batch_hint);
+  if (g_mapped_hint) pp::tune_for_mapped_group(opt, g_batch_hint);
   if (max_entries > 0) opt.max_task_entries = max_entries;
   if (delta_abs >= 0) opt.md_delta_abs = delta_abs;
   if (delta_rel >= 0) opt.md_delta_rel = delta_rel;

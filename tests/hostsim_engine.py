@@ -54,10 +54,12 @@ class HostSimEngine(object):
             elif cinv is not None:
                 sg.cmaps = [cinv[np.asarray(cm, dtype=np.int64)] for cm in sg.cmaps]
             L.ppsim_set_batch_hint(len(g.blocks))            # the task sizes the device library picks for this batch
+            L.ppsim_set_mapped_hint(1 if sg.cmaps is not None else 0)     # ... and its choice among elimination orders
             sg.h = ctypes.c_void_p(L.ppsim_create(g.n, sg.m, g.rowK.size, hu._ip(sg.keep[0]), hu._ip(sg.keep[1]),
                                                   g.rowB.size, hu._ip(sg.keep[2]), hu._ip(sg.keep[3]),
                                                   None if rep is None else hu._dp(rep), 0, -1, ctypes.c_double(-1.0)))
             L.ppsim_set_batch_hint(0)
+            L.ppsim_set_mapped_hint(0)
             err = L.ppsim_error(sg.h)
             if err:
                 raise RuntimeError(err.decode())
