@@ -651,6 +651,45 @@ __global__ __launch_bounds__(512) void k_bcr_fwd(int gs, int G, BcrLevel lv, int
   }
 }
 
+// The three phases above in ONE launch per level (round 4), by pulling instead of pushing: workgroup e of ne + 1 owns the
+// SURVIVING block j between the eliminated blocks i_lo = elim[e - 1] and i_up = elim[e] (ascending, 2 s apart: j = i_up - s =
+// i_lo + s; the ends have one neighbour).  It forms u = inv b of both neighbours itself -- every u twice, by its two
+// neighbours, bit for bit alike; the owner of i_up keeps it in w for the backward part -- and subtracts Klo^T u_up, then
+// Kup u_lo from b_j: the order of the phases, hence the same sums.  Eliminated blocks' b are only read at their level.
+// C4: 28 launches of 11 us -> 10 (the S solve is on the critical path of every time-staged back-solve).
+__global__ __launch_bounds__(512) void k_bcr_fwd_fused(int gs, int G, BcrLevel lv, const double* __restrict__ inv,
+                                                       const double* __restrict__ Klo, const double* __restrict__ Kup,
+                                                       double* __restrict__ b, double* __restrict__ w) {
+  __shared__ double part[8][512];
+  __shared__ double ulo[512], t1[512];
+  const int e = blockIdx.x, s = lv.s, r = threadIdx.x;
+  const size_t g2 = (size_t)gs * gs;
+  const int i_up = (e < lv.ne) ? lv.elim[e] : -1, i_lo = (e > 0) ? lv.elim[e - 1] : -1;
+  const int j = (i_up >= 0) ? i_up - s : i_lo + s;
+  const bool from_up = i_up >= 0 && lv.lo && j >= 0;                 // b_j -= Klo_{i_up}^T u_{i_up}
+  const bool from_lo = i_lo >= 0 && i_lo + s == j && j < G;          // b_j -= Kup_{i_lo} u_{i_lo}
+  if (i_up >= 0) {
+    const double a = bcr_matvec(inv + (size_t)i_up * g2, b + (size_t)i_up * gs, gs, part);
+    if (r < gs) w[(size_t)i_up * gs + r] = a;
+  }
+  if (from_lo) {
+    const double a = bcr_matvec(inv + (size_t)i_lo * g2, b + (size_t)i_lo * gs, gs, part);
+    if (r < gs) ulo[r] = a;
+  }
+  __syncthreads();                                                     // (w of this workgroup and ulo are read below)
+  if (!from_up && !from_lo) return;
+  double bj = (r < gs) ? b[(size_t)j * gs + r] : 0.0;
+  if (from_up) {
+    bcr_matvec_t(Klo + (size_t)i_up * g2, w + (size_t)i_up * gs, gs, t1);
+    if (r < gs) bj -= t1[r];
+  }
+  if (from_lo) {
+    const double a = bcr_matvec(Kup + (size_t)i_lo * g2, ulo, gs, part);
+    if (r < gs) bj -= a;
+  }
+  if (r < gs) b[(size_t)j * gs + r] = bj;
+}
+
 // solve, backward part of a level: x_i = u_i - Ylo_i x_{i-s} - Yup_i x_{i+s}
 __global__ __launch_bounds__(512) void k_bcr_bwd(int gs, int G, BcrLevel lv, const double* __restrict__ Ylo,
                                                  const double* __restrict__ Yup, const double* __restrict__ w,
@@ -776,6 +815,10 @@ int ppi_btd_coupling_solve(pp_handle h, const double* rc_dev) {
       hipLaunchKernelGGL(k_bcr_rhs, dim3((nc + 255) / 256), dim3(256), 0, st, nc, rc_dev, h->rs, b);
       for (int l = 0; l < nlev; ++l) {
         const BcrLevel lv{h->btd_elim + h->bcr_off[(size_t)l], h->bcr_ne[(size_t)l], h->bcr_s[(size_t)l], h->bcr_lo[(size_t)l]};
+        static const bool three_phases = std::getenv("PP_BCR_FWD_PHASES") != nullptr;     // (measurement switch)
+        if (!three_phases && gs <= 512)
+          hipLaunchKernelGGL(k_bcr_fwd_fused, dim3(lv.ne + 1), dim3(512), 0, st, gs, G, lv, h->btd_inv, h->btd_klo, h->btd_kup, b, w);
+        else
         for (int phase = 0; phase < (l + 1 < nlev ? 3 : 1); ++phase)
           hipLaunchKernelGGL(k_bcr_fwd, dim3(lv.ne), dim3(512), 0, st, gs, G, lv, phase, h->btd_inv, h->btd_klo, h->btd_kup, b, w);
       }

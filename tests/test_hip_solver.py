@@ -705,7 +705,7 @@ def test_measurement_switches_select_paths_that_agree():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
     for k in ('PP_NO_LANE_PAIRS', 'PP_NO_DENSE_DPP', 'PP_NO_SCHUR_MFMA', 'PP_NO_GROUP_STREAMS', 'PP_NO_BCR_MFMA',
-              'PP_NO_FUSED_SOURCES'):
+              'PP_NO_FUSED_SOURCES', 'PP_BCR_FWD_PHASES', 'PP_NO_EARLY_FORWARD'):
         env[k] = '1'
     env['PYTHONPATH'] = root + os.pathsep + env.get('PYTHONPATH', '')
     out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'soak_small.py')], env=env, stdout=subprocess.PIPE,
