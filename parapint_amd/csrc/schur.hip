@@ -436,6 +436,22 @@ __global__ __launch_bounds__(64) void k_scatter_schur(GroupDev g, int ntiles, Sc
   }
 }
 
+// The same for a group of a few instances (the single first / last time block of a dynamic problem): lane = entry of the
+// tile, loop over the instances -- with lane = instance one lane walks the 64 entries of a tile alone (41-90 us for ONE block,
+// twice per step on the handle's stream between the factorisation and the reduction of S).
+__global__ __launch_bounds__(64) void k_scatter_schur_few(GroupDev g, int ntiles, SchurTarget T) {
+  const int e = threadIdx.x, tile = blockIdx.x;
+  const size_t bpad = (size_t)g.bpad;
+  const int ta = g.stile_a[tile], tb = g.stile_b[tile];
+  const int ci = ta * 8 + (e >> 3), cj = tb * 8 + (e & 7);
+  if (ci >= g.nc || cj >= g.nc || ci < cj) return;
+  for (int b = 0; b < g.batch; ++b) {
+    const double v = g.Sloc[((size_t)tile * 64 + e) * bpad + b];
+    if (v == 0.0) continue;
+    schur_add(T, g.cmapT[(size_t)ci * bpad + b], g.cmapT[(size_t)cj * bpad + b], v);
+  }
+}
+
 __global__ void k_write_tail(int* counters, double* tail) {
   if (threadIdx.x == 0) {
     int c[4] = {0, 0, 0, 0};
@@ -496,7 +512,8 @@ int pp_numeric_schur_ex(pp_handle h, int side_stream) {
         hipLaunchKernelGGL(k_schur_tiles, dim3((unsigned)g->ntiles * d.nchunk + ncb, 1, 2), dim3(64), 0, st, d, g->ntiles, total8,
                            h->counters);
         const SchurTarget T{h->S, nc, h->btd, h->gs, h->G, h->scatter_err};
-        hipLaunchKernelGGL(k_scatter_schur, dim3((unsigned)g->ntiles * d.nchunk), dim3(64), 0, st, d, g->ntiles, T);
+        if (d.batch <= 8) hipLaunchKernelGGL(k_scatter_schur_few, dim3((unsigned)g->ntiles), dim3(64), 0, st, d, g->ntiles, T);
+        else hipLaunchKernelGGL(k_scatter_schur, dim3((unsigned)g->ntiles * d.nchunk), dim3(64), 0, st, d, g->ntiles, T);
       } else if (g->ntiles > 0 && h->schur_mfma && g->nmt > 0) {
         if (g->mt_wide)
           hipLaunchKernelGGL(k_schur_mfma_wide, dim3((unsigned)g->nmt_items * d.nchunk + ncb), dim3(64), 0, st, d, g->nmt_items, total8,
