@@ -389,6 +389,11 @@ def ip_solve(interface, options=None, timer=None):
             if sym_status != LinearSolverStatus.successful:
                 raise RuntimeError('Could not factorize KKT system; linear solver status: ' + str(sym_status))
         timer.start('numeric')
+        if hasattr(solver, 'prefetch_forward') and hasattr(rhs, 'group_tensors'):
+            # (extension of this package's solver class, a no-op for every other LinearSolverInterface: the right-hand side
+            # of this iteration exists before the matrix is factorised -- interior_point.py:553-566 -- so a device-resident
+            # one is announced and its forward sweep runs beside the dense factorisation of S)
+            solver.prefetch_forward(rhs)
         used_inertia_coef = numeric_factorization(interface, kkt, options, inertia_coef, timer)
         inertia_coef = max(used_inertia_coef * options.inertia_correction.factor_decrease,
                            options.inertia_correction.init_coef)

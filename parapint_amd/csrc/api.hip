@@ -65,6 +65,7 @@ void pp_destroy(pp_handle h) {
     (void)hipEventDestroy(h->ev_dense_fork);
     (void)hipEventDestroy(h->ev_dense_done);
   }
+  if (h->ev_coll_side) (void)hipEventDestroy(h->ev_coll_side);
   if (h->ip_part) (void)hipFree(h->ip_part);
   if (h->ip_cmax) (void)hipFree(h->ip_cmax);
   if (h->ip_mail_host) (void)hipHostFree((void*)h->ip_mail_host);
@@ -569,6 +570,7 @@ int pp_upload_values(pp_handle h, int group, const double* raw, int on_device) {
   if (int rc = alloc_value_storage(h)) return rc;
   if (!g->dev.raw) { if (int rc = ensure_optional(h, g, OPT_RAW)) return rc; }
   g->input_mode = Group::IN_RAW;
+  if (g->dev.raw == g->raw_own) invalidate_stage_mirror(g);     // ([batch][nraw] over the buffer the compact rows mirror)
   const size_t bytes = (size_t)g->batch * g->nraw * sizeof(double);
   if (bytes == 0 || raw == g->dev.raw) return 0;
   PP_HIP(hipMemcpyAsync(g->dev.raw, raw, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
@@ -675,6 +677,7 @@ int pp_upload_sources(pp_handle h, int group, const double* src, int on_device) 
   const size_t per = (size_t)g->nsrc;
   if (per == 0) { g->src = g->src_own; g->input_mode = Group::IN_SOURCES; return 0; }
   if (per > (size_t)g->nraw) return fail(h, 3, "pp_upload_sources: more sources than raw entries per block");
+  invalidate_stage_mirror(g);                                    // (staged through raw_own)
   PP_HIP(hipMemcpyAsync(g->raw_own, src, (size_t)g->batch * per * sizeof(double),
                         on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(k_transpose_in, dim3((unsigned)((g->nsrc + 63) / 64) * g->dev.nchunk), dim3(256), 0, h->stream, g->raw_own,
@@ -689,6 +692,7 @@ double* pp_raw_buffer(pp_handle h, int group) {
   Group* g = get_group(h, group);
   if (!g || !h->symbolic_done || alloc_value_storage(h)) return nullptr;
   if (!g->dev.raw && ensure_optional(h, g, OPT_RAW)) return nullptr;
+  if (g->dev.raw == g->raw_own) invalidate_stage_mirror(g);     // (the caller writes into it)
   return g->dev.raw;
 }
 
@@ -1521,6 +1525,22 @@ int pp_allreduce_schur(pp_handle h) {
   const int rc = g_rccl.allreduce(h->S, h->S, count, /* ncclDouble */ 8, /* ncclSum */ 0, h->rccl_comm,
                                   h->schur_on_side ? h->dense_stream : h->stream);
   if (rc != 0) return fail(h, 3, rccl_msg("ncclAllReduce(S)", rc));
+  if (h->schur_on_side) {
+    // every other collective of this communicator goes to the handle's stream: order them behind this one (two
+    // collectives of one communicator in flight on two streams may be executed in different orders by different ranks)
+    if (!h->ev_coll_side) PP_HIP(hipEventCreateWithFlags(&h->ev_coll_side, hipEventDisableTiming));
+    PP_HIP(hipEventRecord(h->ev_coll_side, h->dense_stream));
+    h->coll_side_pending = true;
+  }
+  return 0;
+}
+
+// collectives on the handle's stream wait for a collective that was enqueued on the side stream
+static int order_behind_side_collective(pp_handle h) {
+  if (h->coll_side_pending) {
+    PP_HIP(hipStreamWaitEvent(h->stream, h->ev_coll_side, 0));
+    h->coll_side_pending = false;
+  }
   return 0;
 }
 
@@ -1528,6 +1548,7 @@ int pp_allreduce_rs(pp_handle h) {
   if (!h || !h->rccl_comm) return fail(h, 3, "pp_allreduce_rs: no communicator (pp_comm_init)");
   PP_HIP(hipSetDevice(h->device));
   if (h->nc == 0) return 0;
+  if (int rc = order_behind_side_collective(h)) return rc;
   const int rc = g_rccl.allreduce(h->rs, h->rs, (size_t)h->nc, 8, 0, h->rccl_comm, h->stream);
   if (rc != 0) return fail(h, 3, rccl_msg("ncclAllReduce(r_s)", rc));
   return 0;
@@ -1538,6 +1559,7 @@ int pp_comm_allgather(pp_handle h, const double* src, double* table, int64_t cou
   if (!src || !table || count < 0) return fail(h, 3, "pp_comm_allgather: bad arguments");
   PP_HIP(hipSetDevice(h->device));
   if (count == 0) return 0;
+  if (int rc = order_behind_side_collective(h)) return rc;
   const int rc = g_rccl.allgather(src, table, (size_t)count, /* ncclDouble */ 8, h->rccl_comm, h->stream);
   if (rc != 0) return fail(h, 3, rccl_msg("ncclAllGather", rc));
   return 0;

@@ -368,7 +368,10 @@ struct pp_solver {
   double* ip_part = nullptr;
   size_t ip_part_cap = 0;
   double* ip_cmax = nullptr;   // per-workgroup maxima of k_ip_couple (long coupling blocks)
+  hipEvent_t ev_coll_side = nullptr;        // behind a collective enqueued on the side stream (pp_allreduce_schur with the Schur update there)
+  bool coll_side_pending = false;
   bool ip_step_done = false;
+  unsigned ip_step_layout[3] = {0, 0, 0};   // workgroup counts (step, rows, stats) of the last pp_ip_take_step
   volatile double* ip_mail_host = nullptr;
   double* ip_mail_dev = nullptr;
   long long ip_seq = 0;
@@ -718,7 +721,15 @@ int64_t value_storage_bytes(pp_handle h) {
   return total;
 }
 
+// The compare-while-staging path (api.hip: pp_stage_upload_verified_begin) sends only the pieces of a row that differ
+// from the pinned staging row, trusting staged_row_valid to say that raw_own mirrors that row.  Every other writer of
+// raw_own (pp_upload_values, pp_upload_sources, a caller holding pp_raw_buffer) and the release of the buffer end the mirror.
+inline void invalidate_stage_mirror(Group* g) {
+  std::fill(g->staged_row_valid.begin(), g->staged_row_valid.end(), (uint8_t)0);
+}
+
 void free_value_storage(Group* g) {
+  invalidate_stage_mirror(g);
   for (void* p : g->value_allocs) (void)hipFree(p);
   g->value_allocs.clear();
   GroupDev& d = g->dev;

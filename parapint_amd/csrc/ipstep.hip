@@ -447,10 +447,11 @@ int ip_check(pp_handle h, int ngroups, const pp_ip_group* g, const char* what) {
 int ip_scratch(pp_handle h, size_t doubles) {
   if (h->ip_part_cap >= doubles) return 0;
   PP_HIP(hipStreamSynchronize(h->stream));
-  if (h->ip_part) (void)hipFree(h->ip_part);
-  h->ip_part = nullptr; h->ip_part_cap = 0;
   void* p = nullptr;
   if (hipMalloc(&p, doubles * sizeof(double)) != hipSuccess) return fail(h, 1, "hipMalloc failed (interior-point scratch)");
+  // (the partials k_ip_step left for pp_ip_residuals survive a growth of the buffer)
+  if (h->ip_part && h->ip_part_cap) PP_HIP(hipMemcpy(p, h->ip_part, h->ip_part_cap * sizeof(double), hipMemcpyDeviceToDevice));
+  if (h->ip_part) (void)hipFree(h->ip_part);
   h->ip_part = (double*)p;
   h->ip_part_cap = doubles;
   return 0;
@@ -531,12 +532,16 @@ int pp_ip_take_step(pp_handle h, int ngroups, const pp_ip_group* g, const double
   if (int rc = ip_sizes(h, ngroups, g, &sz)) return rc;
   const unsigned nwg_s = sz.nwg_step;
   h->ip_step_done = true;
+  // pp_ip_residuals combines the partials left here: it must see the same slot layout (same groups, same grids)
+  h->ip_step_layout[0] = sz.nwg_step; h->ip_step_layout[1] = sz.nwg_rows; h->ip_step_layout[2] = sz.nwg_stats;
   PhaseScope ps(h, PP_NPHASE_SOLVER + 2, ngroups);
   unsigned wg0 = 0;
+  bool z_moved = false;                      // the coupling variables move with the first launch that has a grid
   for (int i = 0; i < ngroups; ++i) {
     const unsigned n = ew_grid(g[i], g[i].n + g[i].mi + g[i].me + g[i].nfs);
     if (n) hipLaunchKernelGGL(k_ip_step, dim3(n), dim3(256), 0, h->stream, g[i], alpha_table, nranks, unified, mu, z, dz,
-                              i == 0 ? 1 : 0, h->ip_part, (int)wg0, (int)nwg_s);
+                              z_moved ? 0 : 1, h->ip_part, (int)wg0, (int)nwg_s);
+    if (n) z_moved = true;
     wg0 += n;
   }
   PP_HIP(hipGetLastError());
@@ -552,6 +557,8 @@ int pp_ip_residuals(pp_handle h, int ngroups, const pp_ip_group* g, const double
   IpSizes sz;
   if (int rc = ip_sizes(h, ngroups, g, &sz)) return rc;
   const unsigned nwg_s = sz.nwg_step, nwg_r = sz.nwg_rows;
+  if (h->ip_step_layout[0] != sz.nwg_step || h->ip_step_layout[1] != sz.nwg_rows || h->ip_step_layout[2] != sz.nwg_stats)
+    return fail(h, 3, "pp_ip_residuals: not the group list pp_ip_take_step was called with (the step partials have another layout)");
   PhaseScope ps(h, PP_NPHASE_SOLVER + 3, ngroups + 1);
   double* part_rows = h->ip_part + (size_t)IP_STEP_SLOTS * nwg_s;
   unsigned wg0 = 0;

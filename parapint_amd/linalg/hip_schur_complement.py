@@ -1228,6 +1228,13 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             self._guarded(res, self._forward_sweep, self._prefetch_rhs, self._prefetch_before_factor)
             if res.status in _OK:
                 self._forward_done_for = self._prefetch_rhs
+        elif self._prefetch_rhs is not None and self.comm.size > 1:
+            # a host-side failure of THIS rank's S phase (e.g. an allocation of the dense factorisation): the other ranks
+            # enqueue the all-reduce of r_s of the announced sweep now -- join it, so that the collectives stay paired
+            try:
+                self._eng.allreduce_rs(self.comm)
+            except Exception:
+                pass
         st = self._guarded(res, self._eng.status)
         if (st is not None and st[0] == 2 and self._btd is not None and not self._btd_sequential and
                 hasattr(self._eng, 'set_coupling_schedule')):
@@ -1251,7 +1258,10 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         # after the all-reduce every rank holds the same block counts, the same failure tail and the same S: the device
         # status is rank-consistent as it is; only a host-side failure of the dense phase itself can differ
         if self.comm.size > 1 and st is None:
-            res.status = self._agree_status(res.status)
+            # (the other ranks read a successful status from their mailboxes and make no further collective in which this
+            # failure could be agreed: end loudly instead of returning a status only this rank holds)
+            raise RuntimeError('rank %d: the factorisation of S failed on the host side (%s; status %s); the other ranks '
+                               'cannot learn of it' % (self.comm.rank, self._last_error, res.status))
         self._num_status = res.status
         return res
 

@@ -554,8 +554,10 @@ def test_bench_two_ranks_started_by_the_script_itself():
 def test_bench_single_rank_line_has_the_contract_fields():
     res = _run_bench({}, '--workload', 'C2', '--steps', '5', '--warmup', '2', '--no-cpu-baseline', '--boundary-iterations', '2')
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
-                'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'boundary_host', 'device_only'):
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'boundary_host', 'device_only',
+                'value_no_prefetch', 'ms_per_step_no_prefetch'):
         assert key in res
+    assert res['value_no_prefetch'] > 0
     assert res['correct'] is True and res['n_gpus'] == 1 and res['roofline']['bound'] == 'hbm'
     assert abs(res['value'] * res['ms_per_step'] / 1e3 - 1.0) < 1e-6
 
@@ -739,6 +741,43 @@ def test_host_boundary_fast_paths_on_the_device():
     """Host blocks in, host vectors out through pp_stage_upload_compact / pp_upload_rhs_rows / pp_download_solution_rows
     (verified index arrays, data rewritten in place, both result-buffer modes), each result against a dense solve."""
     sc.case_boundary_fast_paths(lambda: None)
+
+
+def test_switching_input_forms_between_factorisations_ends_the_staging_mirror():
+    """C-ABI callers may mix input forms: after compact rows were staged (the device mirrors the pinned staging rows and the
+    compare-while-staging path sends only pieces that differ), pp_upload_values / a write through pp_raw_buffer overwrite
+    the same device buffer.  The next staged factorisation of UNCHANGED host values must send every row again."""
+    import ctypes
+    import numpy as np
+    from parapint_amd.examples.performance.schur_complement.synthetic_kkt import SyntheticKKT
+    from parapint_amd.linalg.comm import SerialComm
+    N = 5
+    model = SyntheticKKT(N, 3, 8, 2)
+    comm = SerialComm()
+    solver = sc.new_solver(lambda: None, N)
+    kkt = model.build_kkt(comm=comm, iteration=1)
+    rhs = model.build_rhs(comm=comm)
+    solver.do_symbolic_factorization(kkt)
+    solver.do_numeric_factorization(kkt)
+    solver.do_numeric_factorization(kkt)            # (second call: verified index arrays, rows mirror the device)
+    x_ref = solver.do_back_solve(rhs).flatten().copy()
+    eng = solver._eng
+    g = solver._groups[0]
+    for clobber in ('pp_upload_values', 'pp_raw_buffer'):
+        junk = np.full(N * g.nraw, 7.25)
+        if clobber == 'pp_upload_values':
+            eng.ns.check(eng.lib.pp_upload_values(eng.ns.h, g.gid, junk.ctypes.data, 0), clobber)
+        else:
+            dev_ptr = eng.lib.pp_raw_buffer(eng.ns.h, g.gid)
+            assert dev_ptr
+            import torch
+            torch.cuda.synchronize()
+            hip = ctypes.CDLL('libamdhip64.so')
+            assert hip.hipMemcpy(ctypes.c_void_p(dev_ptr), junk.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(junk.nbytes), 1) == 0
+        solver.do_numeric_factorization(kkt)        # same host values as the staging rows hold
+        x = solver.do_back_solve(rhs).flatten()
+        assert np.array_equal(x, x_ref), clobber
+        assert sc.scaled_residual(kkt.toarray(), x, rhs.flatten()) <= 1e-10
 
 
 def test_zero_pivot_test_inside_a_mixed_scale_block_pivot():
