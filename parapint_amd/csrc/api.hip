@@ -208,7 +208,27 @@ int pp_end_symbolic(pp_handle h) {
     // slices of PP_WMAX) and widest block pivot with ordinary scale tasks
     g->level_maxw.assign(P.n_levels, 1);
     for (int pp_ = 0; pp_ < P.npiv; ++pp_)
-      g->level_maxw[P.piv_level[pp_]] = std::max(g->level_maxw[P.piv_level[pp_]], std::min(P.piv_w[pp_], PP_WMAX));
+      g->level_maxw[P.piv_flevel[pp_]] = std::max(g->level_maxw[P.piv_flevel[pp_]], std::min(P.piv_w[pp_], PP_WMAX));
+    {
+      // chain fronts: header and panel records, LDS need per level
+      std::vector<int> chdr, cpan;
+      g->chain_lds.assign((size_t)P.n_levels, 0);
+      for (size_t c = 0; c < P.chain_m.size(); ++c) {
+        chdr.insert(chdr.end(), {P.chain_m[c], P.chain_w[c], P.chain_ptr[c + 1] - P.chain_ptr[c], P.chain_ptr[c], 0, 0, 0, 0});
+        for (int t = P.chain_ptr[c]; t < P.chain_ptr[c + 1]; ++t) {
+          const int cp = P.chain_piv[t], cw = P.piv_w[cp];
+          cpan.insert(cpan.end(), {cp, cw, (int)P.piv_uoff[cp], P.piv_boff[cp], P.piv_doff[cp], (int)P.piv_sub[cp], P.chain_col0[t],
+                                   cw + (P.piv_rowptr[cp + 1] - P.piv_rowptr[cp])});
+        }
+        const size_t doubles = (size_t)P.chain_m[c] * ((size_t)(P.chain_w[c] | 1) + 4) + (size_t)P.chain_w[c] + 16;
+        g->chain_lds[(size_t)P.chain_level[c]] = std::max(g->chain_lds[(size_t)P.chain_level[c]], doubles * sizeof(double));
+      }
+      d.chain_hdr = d.chain_pan = nullptr;
+      if (!chdr.empty()) {
+        if ((rc = dev_upload(h, g, &d.chain_hdr, chdr))) return rc;
+        if ((rc = dev_upload(h, g, &d.chain_pan, cpan))) return rc;
+      }
+    }
     std::vector<int> ftask, stask, fdst_ptr, fent, srec;
     const double one = 1.0;
     int one_lo, one_hi;
@@ -255,6 +275,49 @@ int pp_end_symbolic(pp_handle h) {
       ftask.insert(ftask.end(), {t.piv, t.r0, t.r1, new_dptr0, t.kind, fdst_ptr[new_dptr0], (int)(fent.size() / 4),
                                  t.ws > 0 ? t.ws : P.piv_w[t.piv], (int)P.piv_uoff[t.piv], P.piv_boff[t.piv], P.piv_doff[t.piv],
                                  (int)P.piv_sub[t.piv], t.piece, t.npieces, P.piv_w[t.piv], t.qoff});
+    }
+    // tile tasks: their initial values as ordinary records in fent (the fused-source form rewrites them with the others),
+    // their source-panel records with absent rows / columns pointing at the zero rows behind the panels
+    // device form of the source-panel records: one STEP of 8 ints per source column {U position of row i x 4, L position of
+    // column q x 4} (absent: the zero rows behind the panels), every task's steps padded to a multiple of PP_TILE_DEPTH with
+    // all-zero steps -- a uniform, branch-free stream for the software pipeline of k_gather_tiles
+    std::vector<int> ttask, trec;
+    if (!P.ttasks.empty() && (uint64_t)(P.usize + PP_WMAX) * (uint64_t)d.nchunk >= ((uint64_t)1 << 32))
+      return fail(h, 1, "tile tasks: panel storage x instance chunks exceeds 2^32 (PP_PLAN_TUNE chain_tiles=0 plans without them)");
+    const int nck = d.nchunk;                 // operand rows in units of 64 doubles: position x chunks
+    const int zpos = (int)P.usize;
+    for (auto& t : P.ttasks) {
+      const int s0 = (int)(trec.size() / 8);
+      for (int r = t.te0; r < t.te1 && t.kind >= 0; ++r) {
+        const int* rec = &P.trec[(size_t)r * PP_TREC_INTS];
+        for (int k = 0; k < rec[0]; ++k)
+          for (int q = 1; q <= 8; ++q) trec.push_back((int)((unsigned)(rec[q] < 0 ? zpos : rec[q] + k) * (unsigned)nck));
+      }
+      while ((trec.size() / 8 - (size_t)s0) % PP_TILE_DEPTH != 0)
+        for (int q = 0; q < 8; ++q) trec.push_back((int)((unsigned)zpos * (unsigned)nck));
+      const int s1 = (int)(trec.size() / 8);
+      const int nrow = t.r1 - t.r0;
+      const int e0 = (int)(fent.size() / 4);
+      int cur_row = 0;
+      for (int dd = 0; dd < nrow && t.kind >= 0; ++dd)
+        for (int e = P.fdst_ptr[t.dptr0 + dd]; e < P.fdst_ptr[t.dptr0 + dd + 1]; ++e) {
+          const pp::FEntry& fe = P.fentries[e];
+          if (fe.u >= 0) continue;
+          const int ce = -1 - fe.u;
+          for (int q = g->can_ptr[ce]; q < g->can_ptr[ce + 1]; ++q) {
+            g->init_rec.push_back((int)(fent.size() / 4));
+            fent.insert(fent.end(), {-1 - rawmap[g->can_idx[q]], one_lo, one_hi, fe.q | ((dd - cur_row) << 8)});
+            cur_row = dd;
+          }
+        }
+      ttask.insert(ttask.end(), {t.piv, t.r0, t.r1, s0, t.kind, e0, (int)(fent.size() / 4), t.ws > 0 ? t.ws : P.piv_w[t.piv],
+                                 (int)P.piv_uoff[t.piv], P.piv_boff[t.piv], s1, 0, t.piece, t.npieces, P.piv_w[t.piv], t.qoff});
+    }
+    for (int q = 0; q < 16 * PP_TILE_DEPTH; ++q) trec.push_back((int)((unsigned)zpos * (unsigned)nck));   // (the pipeline reads up to 2 PP_TILE_DEPTH - 2 steps ahead)
+    d.ttask = d.trec = nullptr;
+    if (!ttask.empty()) {
+      if ((rc = dev_upload(h, g, &d.ttask, ttask))) return rc;
+      if ((rc = dev_upload(h, g, &d.trec, trec))) return rc;
     }
     for (auto& t : P.stasks)
       stask.insert(stask.end(), {t.piv, t.r0, t.r1, -1, t.kind, 0, 0, P.piv_w[t.piv], (int)P.piv_uoff[t.piv],
@@ -913,7 +976,8 @@ int pp_group_stats_ex(pp_handle h, int group, int64_t out[16]) {
   int64_t launches_factor = 0, launches_fwd = 1, launches_bwd = 1;
   for (int l = 0; l < P.n_levels; ++l) {
     launches_factor += (P.flevel_ptr[l + 1] > P.flevel_ptr[l]) + (P.slevel_ptr[l + 1] > P.slevel_ptr[l]) +
-                       ((P.front_piv >= 0 && P.piv_level[P.front_piv] == l) ? 1 + (P.wtasks.empty() ? 0 : 1) : 0);
+                       ((P.front_piv >= 0 && P.piv_flevel[P.front_piv] == l) ? 1 + (P.wtasks.empty() ? 0 : 1) : 0) +
+                       (P.chain_lvl_ptr[l + 1] > P.chain_lvl_ptr[l]) + (P.tlevel_ptr[l + 1] > P.tlevel_ptr[l]);
     if (l < (int)g->fwd_level_has_entries.size() && g->fwd_level_has_entries[(size_t)l]) ++launches_fwd;
     if (P.clevel_ptr[l + 1] > P.clevel_ptr[l]) ++launches_bwd;
   }

@@ -71,6 +71,8 @@ struct GroupDev {
   const int* cmapT; // mapped groups: global coupling index of local coupling row c of instance b at [c * bpad + b] (else null)
   double *Sloc, *XCL;   // mapped groups: per-instance Schur cliques [tile entry][instance], per-instance coupling solution
   int xs_row, xs_lane;  // address of coupling value c of lane b: c * xs_row + b * xs_lane (uniform: 1, 0 into xc)
+  const int *ttask, *trec;            // tile tasks (plan.hpp, kind 4) and their source-panel records
+  const int *chain_hdr, *chain_pan;   // chain fronts (plan.hpp): per front {m, W, panels, first panel record}, per panel {piv, w, uoff, boff, doff, sub, col0, f}
   int* growth;      // per instance: 1 if a factor entry exceeded lbound (MA27's threshold test |l_ij| <= 1/u failed)
   double lbound;    // 1 / u_rt, or +inf
 };
@@ -195,6 +197,7 @@ struct Group {
   double *raw_own = nullptr, *rhs_own = nullptr, *rawT_own = nullptr;
   int nraw_used = 0;
   std::vector<int> level_maxw;   // widest block pivot per level (selects the scalar kernel variants)
+  std::vector<size_t> chain_lds;   // per factor level: dynamic LDS bytes of its chain fronts (k_chain_front), 0 if none
   const int* wtask = nullptr;    // scale chunks of the root front (device), plan.wtasks
   double* front_inv = nullptr;   // root front: inv(P) as a zero-padded 16 x 16 matrix [entry][instance] (k_front_invert -> k_scale_wide)
   std::vector<int> diag_can;     // canonical entry of the diagonal (i, i) of K, or -1
@@ -382,7 +385,7 @@ struct pp_solver {
   int *btd_ipiv = nullptr, *btd_info = nullptr, *scatter_err = nullptr, *btd_elim = nullptr;
   std::vector<int> bcr_off, bcr_ne, bcr_s, bcr_lo;   // per level: offset into btd_elim, eliminated blocks, stride, lower neighbour live
   int btd_sequential = 0;
-  bool bcr_lds_attr = false, bcr_ldl_attr = false, dn_lds_attr = false;
+  bool bcr_lds_attr = false, bcr_ldl_attr = false, dn_lds_attr = false, chain_lds_attr = false;
   double* dn_z = nullptr;        // fat-panel dense factor (n_c > 512): inverted diagonal blocks + work vectors of the panel solve (dense.hip)
   // largest multiplier the unpivoted block factorisation of the cyclic reduction accepts (1 / u, u = 0.01; PP_BCR_LBOUND:
   // test switch -- a bound below 1 sends some blocks to Bunch-Kaufman and leaves others on the unpivoted path)
@@ -711,7 +714,7 @@ int64_t value_storage_bytes(pp_handle h) {
     const int64_t bp = d.bpad;
     // (the term magnitudes of the pivot blocks live in the rows of Y: written and read inside the factorisation, Y
     // only inside a solve)
-    int64_t dbl = (int64_t)g->batch * g->nraw + (int64_t)std::max(g->nraw_used, 1) * bp + 2 * P.usize * bp +
+    int64_t dbl = (int64_t)g->batch * g->nraw + (int64_t)std::max(g->nraw_used, 1) * bp + 2 * (P.usize + PP_WMAX) * bp +
                   (int64_t)P.dsize * bp + (int64_t)std::max(P.n + g->nc_loc, std::max(P.bsize, 1)) * bp +
                   (int64_t)P.n * bp + 2 * (int64_t)g->batch * P.n + (int64_t)d.nchunk * std::max(std::max(g->ntiles, 1) * 64, g->nmt_items * (g->mt_wide ? 1024 : 256)) +
                   (int64_t)d.nchunk * std::max(g->nc_loc, 1) +
@@ -774,11 +777,13 @@ int alloc_value_storage(pp_handle h) {
     // requirement here, once.
     double* keep_raw = (d.raw && d.raw != g->raw_own) ? d.raw : nullptr;   // caller-bound buffers survive
     double* keep_rhs = (d.rhs && d.rhs != g->rhs_own) ? d.rhs : nullptr;
-    if ((rc = value_alloc(h, g, &d.U, (size_t)P.usize * bp))) break;
+    // (PP_WMAX zero rows behind the panels of U and of L: what a tile record names for a row or column its source lacks)
+    if ((rc = value_alloc(h, g, &d.U, (size_t)(P.usize + PP_WMAX) * bp))) break;
     if ((rc = value_alloc(h, g, &d.Dinv, (size_t)P.dsize * bp))) break;
-    if ((rc = value_alloc(h, g, &d.L, (size_t)P.usize * bp))) break;
+    if ((rc = value_alloc(h, g, &d.L, (size_t)(P.usize + PP_WMAX) * bp))) break;
     // the pivot-block slots of L are never written (only the rows below the block are): define them once
-    if (hipMemset(d.L, 0, (size_t)P.usize * bp * sizeof(double)) != hipSuccess) { rc = fail(h, 3, "hipMemset failed"); break; }
+    if (hipMemset(d.L, 0, (size_t)(P.usize + PP_WMAX) * bp * sizeof(double)) != hipSuccess) { rc = fail(h, 3, "hipMemset failed"); break; }
+    if (hipMemset(d.U + (size_t)P.usize * bp, 0, (size_t)PP_WMAX * bp * sizeof(double)) != hipSuccess) { rc = fail(h, 3, "hipMemset failed"); break; }
     if ((rc = value_alloc(h, g, &d.Y, (size_t)std::max(P.n + nc, std::max(P.bsize, 1)) * bp))) break;
     d.Tm = d.Y;     // term magnitudes of the pivot blocks (gather -> scale of one level) share the rows of the solve vector
     double* keep_x = (d.xout && d.xout != g->xout_own) ? d.xout : nullptr;

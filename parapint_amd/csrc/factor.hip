@@ -497,6 +497,293 @@ __global__ __launch_bounds__(64) void k_scale_level(GroupDev g, int task0, int c
 }
 
 // ------------------------------------------------------------------------------------------
+// Tile task (plan.hpp, kind 4): PP_TILE_ROWS consecutive rows of a panel gathered together against whole source panels.
+// Device form (api.hip): a stream of STEPS, one per source column: {U position of the tile's row i x 4, L position of the
+// panel's column q x 4} (a row or column the source lacks points at the zero rows behind the panels) = 4 + 4 operand loads
+// for 16 multiply-adds, against 1 + w loads per w multiply-adds and a 16-byte record per source column of every ROW in the
+// row tasks.  The stream is uniform and branch-free (every task padded to a multiple of PP_TILE_DEPTH steps with all-zero
+// steps), so the loop is a software pipeline: the operands of step s + PP_TILE_DEPTH - 1 are requested before the
+// multiply-adds of step s (MEASURED, C4, the first form of this kernel -- one record per source panel, its 32 loads
+// requested, waited for and used: 1.8 us per record at 2 waves per SIMD, every launch a chain of such round trips).
+// The rows of a chain front's panels are dense against the fronts below them: that is where these tasks are planned.
+// A long tile is cut into pieces by source panels (the waves of one workgroup); partial sums meet in LDS and wave 0 adds
+// them in piece order.  Initial values come through ordinary records (fent: the fused-source form is applied to them like
+// to all others).  Term magnitudes are kept for the diagonal entries of pivot-block rows (what the zero-pivot test reads):
+// a tile that holds pivot rows starts at row 0 of its panel, so the diagonal entry of tile row i is column i.
+template <bool PIVT>
+__device__ __forceinline__ void tile_stream(const int* __restrict__ trec, int s0, int s1, const double* __restrict__ Ub,
+                                            const double* __restrict__ Lb, unsigned b, double (&acc)[PP_TILE_ROWS][PP_WMAX],
+                                            double (&tm)[PP_TILE_ROWS]) {
+  constexpr int TR = PP_TILE_ROWS, WM = PP_WMAX, D = PP_TILE_DEPTH;
+  // a step's eight operand rows are given in units of 64 doubles (position x chunks of the group: api.hip), so an address
+  // is base + (row << 6): no multiplication; the records of D steps are read together (two scalar loads)
+  double u[D][TR], l[D][WM];
+  const unsigned lane_bytes = b * 8u;
+  // (uniform row base + 32-bit lane offset: the loads take their base from scalar registers, no 64-bit vector address each)
+  auto request = [&](int slot, const int (&rp)[TR + WM]) {
+#pragma unroll
+    for (int i = 0; i < TR; ++i)
+      u[slot][i] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(Ub + ((size_t)(unsigned)rp[i] << 6)) + lane_bytes);
+#pragma unroll
+    for (int q = 0; q < WM; ++q)
+      l[slot][q] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(Lb + ((size_t)(unsigned)rp[TR + q] << 6)) + lane_bytes);
+  };
+  {
+    int rec[D - 1][TR + WM];
+#pragma unroll
+    for (int j = 0; j < D - 1; ++j)
+#pragma unroll
+      for (int q = 0; q < TR + WM; ++q) rec[j][q] = trec[(TR + WM) * (size_t)(s0 + j) + q];
+#pragma unroll
+    for (int j = 0; j < D - 1; ++j) request(j, rec[j]);
+  }
+  for (int s = s0; s < s1; s += D) {
+    int rec[D][TR + WM];                        // steps s + D - 1 .. s + 2 D - 2
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+#pragma unroll
+      for (int q = 0; q < TR + WM; ++q) rec[j][q] = trec[(TR + WM) * (size_t)(s + D - 1 + j) + q];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      request((j + D - 1) % D, rec[j]);
+      // (without the barriers the scheduler hoists the requests of all D steps to the top of the iteration and sinks their
+      // multiply-adds to its end, behind a wait for ALL loads: the pipeline is drained at every iteration)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TR; ++i) {
+#pragma unroll
+        for (int q = 0; q < WM; ++q) acc[i][q] = fma(-u[j][i], l[j][q], acc[i][q]);
+        if (PIVT) tm[i] = fmax(tm[i], fabs(u[j][i] * l[j][i]));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_gather_tiles(GroupDev g, int task0, int ny, double eps) {
+  constexpr int TR = PP_TILE_ROWS, WM = PP_WMAX;
+  static_assert(TR == WM, "the diagonal entry of tile row i is column i");
+  __shared__ double red[NW > 1 ? NW - 1 : 1][TR * WM + TR][64];
+  const int lane = threadIdx.x & 63, wave = (NW > 1) ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+  const unsigned b = (unsigned)(PP_CHUNK_OF_WG(ny) * 64 + lane);
+  const size_t bpad = (size_t)g.bpad;
+  const int* t = g.ttask + TASK_INTS * (size_t)(task0 + NW * PP_TASK_OF_WG(ny) + wave);
+  const int r0 = t[1], r1 = t[2], s0 = t[3], kind = t[4], E0 = t[5], E1 = t[6], w = t[7], uoff = t[8], boff = t[9], s1 = t[10];
+  const int npieces = (NW > 1) ? t[13] : 1;
+  const int wp = t[14], qoff = t[15];
+  if (kind < 0 && npieces <= 1) return;            // quad padding (in a split quad the padding waves join the barrier)
+  const double* __restrict__ Rb = g.rawT + b;
+  double acc[TR][WM], tm[TR];
+#pragma unroll
+  for (int i = 0; i < TR; ++i) {
+    tm[i] = 0.0;
+#pragma unroll
+    for (int q = 0; q < WM; ++q) acc[i][q] = 0.0;
+  }
+  const bool pivt = r0 < wp;                       // (uniform) the tile holds rows of the pivot block: r0 == 0, qoff == 0
+  if (kind >= 0) {
+    // initial values (scalar record reads: a handful per tile)
+    int d = 0;
+    for (int e = E0; e < E1; ++e) {
+      const int* rp = g.fent + 4 * (size_t)e;
+      const int ex = rp[0], ey = rp[1], ez = rp[2], ew = rp[3];
+      d += ew >> 8;
+      const int q = ew & 0xff;
+      const bool cst = (-1 - ex) == g.const_row;
+      const double coef = __hiloint2double(ez, ey);
+      const double v = (cst ? 1.0 : Rb[(size_t)(cst ? 0 : -1 - ex) * bpad]) * coef;
+#pragma unroll
+      for (int i = 0; i < TR; ++i) {
+        if (i == d) {
+#pragma unroll
+          for (int qq = 0; qq < WM; ++qq)
+            if (qq == q) acc[i][qq] += v;
+          if (pivt && q == i) tm[i] = fmax(tm[i], fabs(v));
+        }
+      }
+    }
+    if (pivt) tile_stream<true>(g.trec, s0, s1, g.U, g.L, b, acc, tm);
+    else tile_stream<false>(g.trec, s0, s1, g.U, g.L, b, acc, tm);
+  }
+  if (NW > 1 && npieces > 1) {
+    if (wave > 0) {
+#pragma unroll
+      for (int i = 0; i < TR; ++i) {
+#pragma unroll
+        for (int q = 0; q < WM; ++q) red[wave - 1][i * WM + q][lane] = acc[i][q];
+        red[wave - 1][TR * WM + i][lane] = tm[i];
+      }
+    }
+    __syncthreads();
+    if (wave > 0 || kind < 0) return;
+    for (int j = 1; j < npieces; ++j) {
+#pragma unroll
+      for (int i = 0; i < TR; ++i) {
+#pragma unroll
+        for (int q = 0; q < WM; ++q) acc[i][q] += red[j - 1][i * WM + q][lane];
+        tm[i] = fmax(tm[i], red[j - 1][TR * WM + i][lane]);
+      }
+    }
+  }
+  double* Ud = g.U + ((size_t)uoff + (size_t)r0 * wp + qoff) * bpad + b;
+#pragma unroll
+  for (int i = 0; i < TR; ++i) {
+    if (r0 + i < r1) {
+#pragma unroll
+      for (int q = 0; q < WM; ++q)
+        if (q < w) Ud[(size_t)(i * wp + q) * bpad] = acc[i][q];
+      if (pivt && i < wp)
+        g.Tm[((size_t)boff + (size_t)i * wp + (size_t)i) * bpad + b] = tm[i];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Chain front (plan.hpp, PlanOptions::chain_fronts): a chain of block pivots whose row sets nest exactly -- one dense
+// supernode that the <= PP_WMAX-column panels cut into dependent levels (the time blocks of a dynamic problem: fronts of
+// 100-170 rows, four columns per level, 10-14 levels each).  The rows of ALL its panels have gathered their contributions
+// from outside the chain (ordinary tasks, one launch); here ONE workgroup per instance holds the front's pivot columns in
+// LDS and runs the panels one after the other: inversion of the pivot block (pivot.hpp, the same static sequence of 1x1 /
+// 2x2 sub-pivots and the same zero-pivot rule as the level kernels), L rows = U rows inv(P), update of the later panels'
+// columns  F[r][c] -= sum_k U_p[r][k] L_p[c][k]  (every row and column of a later panel is a row of this one), term
+// magnitudes of the later diagonal entries tracked for their zero-pivot tests.  The results go to the same U / L / Dinv /
+// codes storage, so the Schur update and the solve sweeps do not know the difference (tests/hostsim mirrors the sums).
+// Instances are dealt so that the eight that share a 64-byte sector of every [entry][instance] row run on one XCD at
+// about the same time: their strided 8-byte accesses meet in that XCD's L2.
+// LDS: F[m][W | 1], Lp[m][4] (scaled rows of the current panel), tmd[W], in doubles.
+__global__ __launch_bounds__(256) void k_chain_front(GroupDev g, int front0, double eps) {
+  extern __shared__ __attribute__((aligned(16))) double fsh[];
+  const int tid = threadIdx.x;
+  const unsigned j = blockIdx.x % (unsigned)g.bpad;
+  const int fi = front0 + (int)(blockIdx.x / (unsigned)g.bpad);
+  const int b = (int)((j & 7u) * ((unsigned)g.bpad >> 3) + (j >> 3));
+  const int* H = g.chain_hdr + 8 * (size_t)fi;
+  const int m = H[0], W = H[1], npan = H[2];
+  const int* PR = g.chain_pan + 8 * (size_t)H[3];
+  const int LD = W | 1;
+  double* F = fsh;
+  double* Lp = F + (size_t)m * LD;
+  double* tmd = Lp + 4 * (size_t)m;
+  const size_t bpad = (size_t)g.bpad;
+  for (int i = 0; i < npan; ++i) {
+    const int* R = PR + 8 * i;
+    const int w = R[1], boff = R[3], c0 = R[6], f = R[7];
+    const double* Up = g.U + (size_t)R[2] * bpad + b;
+    double* Fp = F + (size_t)c0 * LD + c0;
+#pragma unroll 4
+    for (int idx = tid; idx < f * w; idx += 256) {
+      const int t = idx / w, q = idx - t * w;
+#if defined(PP_X_CHAIN) && PP_X_CHAIN == 3
+      Fp[t * LD + q] = (t == q) ? 1.0 : 0.01;
+#else
+      Fp[t * LD + q] = Up[(size_t)idx * bpad];
+#endif
+    }
+    if (tid < w) tmd[c0 + tid] = g.Tm[((size_t)boff + (size_t)(tid * w + tid)) * bpad + b];
+  }
+  __syncthreads();
+  bool grow = false;
+  for (int i = 0; i < npan; ++i) {
+    const int* R = PR + 8 * i;
+    const int p = R[0], w = R[1], doff = R[4], c0 = R[6], f = R[7];
+    const unsigned sub = (unsigned)R[5];
+    double inv[PP_WMAX * (PP_WMAX + 1) / 2];
+    {
+      // (every thread inverts the block from LDS broadcasts: no hand-over, no barrier)
+      double blk[PP_WMAX * PP_WMAX], tv[PP_WMAX];
+#pragma unroll
+      for (int a = 0; a < PP_WMAX; ++a) {
+        tv[a] = (a < w) ? tmd[c0 + min(a, w - 1)] : 0.0;
+#pragma unroll
+        for (int c = 0; c < PP_WMAX; ++c) {
+          const bool in = a < w && c < w;
+          const double v = F[(size_t)(c0 + (in ? a : 0)) * LD + c0 + (in ? c : 0)];
+          blk[a * PP_WMAX + c] = in ? v : 0.0;
+        }
+      }
+      const int code = pp::invert_block_t<PP_WMAX>(w, sub, blk, tv, eps, inv);
+      if (tid == 0) {
+        double* invp = g.Dinv + (size_t)doff * bpad + b;
+#pragma unroll
+        for (int q = 0; q < PP_WMAX * (PP_WMAX + 1) / 2; ++q)
+          if (q < w * (w + 1) / 2) invp[(size_t)q * bpad] = inv[q];
+        g.codes[(size_t)p * bpad + b] = (b < g.batch) ? (unsigned short)code : (unsigned short)0;
+      }
+    }
+    {
+      double* Ug = g.U + (size_t)R[2] * bpad + b;
+      double* Lg = g.L + (size_t)R[2] * bpad + b;
+      for (int t = tid; t < f; t += 256) {
+        const double* fr = F + (size_t)(c0 + t) * LD + c0;
+        double u[PP_WMAX];
+#pragma unroll
+        for (int q = 0; q < PP_WMAX; ++q) u[q] = (q < w) ? fr[min(q, w - 1)] : 0.0;
+#if !defined(PP_X_CHAIN) || PP_X_CHAIN != 2
+#pragma unroll
+        for (int q = 0; q < PP_WMAX; ++q)
+          if (q < w) Ug[(size_t)(t * w + q) * bpad] = u[q];
+#endif
+        if (t >= w) {
+#pragma unroll
+          for (int t2 = 0; t2 < PP_WMAX; ++t2) {
+            if (t2 < w) {
+              double v = 0.0;
+#pragma unroll
+              for (int t1 = 0; t1 < PP_WMAX; ++t1)
+                if (t1 < w) v += u[t1] * PP_INV(inv, t1, t2);
+#if !defined(PP_X_CHAIN) || PP_X_CHAIN != 2
+              Lg[(size_t)(t * w + t2) * bpad] = v;
+#endif
+              Lp[(size_t)(c0 + t) * 4 + t2] = v;
+              grow = grow || fabs(v) > g.lbound;
+            }
+          }
+        }
+      }
+    }
+    if (i + 1 == npan) break;
+    __syncthreads();
+#if defined(PP_X_CHAIN) && PP_X_CHAIN == 1
+    continue;
+#endif
+    {
+      // later columns [c1, W) of the rows [c1, m), four columns of one row per thread
+      const int c1 = c0 + w, nr = m - c1, ncg = (W - c1 + 3) >> 2;
+      for (int idx = tid; idx < nr * ncg; idx += 256) {
+        const int cg = idx / nr, r = c1 + (idx - cg * nr), C0 = c1 + 4 * cg;
+        if (r < C0 - (PP_WMAX - 1)) continue;      // (above the first row of the panel that holds column C0: not part of any panel)
+        double* fr = F + (size_t)r * LD;
+        double acc[4], u[PP_WMAX];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) acc[cc] = fr[min(C0 + cc, W - 1)];
+#pragma unroll
+        for (int k = 0; k < PP_WMAX; ++k) u[k] = (k < w) ? fr[c0 + min(k, w - 1)] : 0.0;
+        double tm = 0.0;
+#pragma unroll
+        for (int k = 0; k < PP_WMAX; ++k) {
+          if (k < w) {
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+              const double l = Lp[(size_t)min(C0 + cc, W - 1) * 4 + k];
+              const double term = u[k] * l;
+              acc[cc] -= term;
+              if (C0 + cc == r) tm = fmax(tm, fabs(term));
+            }
+          }
+        }
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+          if (C0 + cc < W) fr[C0 + cc] = acc[cc];
+        if (r >= C0 && r < C0 + 4 && r < W) tmd[r] = fmax(tmd[r], tm);
+      }
+    }
+    __syncthreads();
+  }
+  if (grow && b < g.batch) g.growth[b] = 1;
+}
+
+// ------------------------------------------------------------------------------------------
 // Root front (plan.hpp, front_piv): the last block pivot, up to PP_FRONT_MAX columns wide.  Its rows were gathered in
 // column slices by the ordinary tasks; k_front_invert inverts the w x w pivot block with the static sequence of
 // 1x1 / 2x2 sub-pivots (pivot.hpp: invert_front is the definition) and k_scale_wide forms L = U inv(P).
@@ -772,6 +1059,7 @@ int pp_numeric_factor_blocks(pp_handle h) {
       for (int l = 0; l < P.n_levels; ++l)
         nlaunch += (P.flevel_ptr[l + 1] > P.flevel_ptr[l]) + (P.slevel_ptr[l + 1] > P.slevel_ptr[l]);
       if (P.front_piv >= 0) nlaunch += 1 + (P.wtasks.empty() ? 0 : 1);
+      for (int l = 0; l < P.n_levels; ++l) nlaunch += (P.chain_lvl_ptr[l + 1] > P.chain_lvl_ptr[l]) + (P.tlevel_ptr[l + 1] > P.tlevel_ptr[l]);
       PhaseScope ps(h, 1, nlaunch);
       const Splits sp = make_splits(h, d.nchunk);
       hipStream_t fan[PP_MAX_SPLIT];
@@ -823,7 +1111,30 @@ int pp_numeric_factor_blocks(pp_handle h) {
               hipLaunchKernelGGL(k_scale_level<PP_WMAX>, dim3((unsigned)ns * ny), dim3(64), 0, fan[q], d, s0, sp.c0[q], ny, PIVOT_EPS);
           }
         }
-        if (P.front_piv >= 0 && P.piv_level[P.front_piv] == l) {
+        if (P.tlevel_ptr[l + 1] > P.tlevel_ptr[l]) {
+          // tile tasks of this level (the rows of its chain fronts), quads of tasks
+          if (sp.n != 1) return fail(h, 3, "instance splits are not supported together with tile tasks");
+          const int tt0 = P.tlevel_ptr[l], ntq = (P.tlevel_ptr[l + 1] - tt0) / PP_QUAD;
+          hipLaunchKernelGGL((k_gather_tiles<PP_QUAD>), dim3((unsigned)ntq * (unsigned)d.nchunk), dim3(64 * PP_QUAD), 0, fan[0], d, tt0,
+                             d.nchunk, PIVOT_EPS);
+        }
+        if (P.chain_lvl_ptr[l + 1] > P.chain_lvl_ptr[l]) {
+          // chain fronts of this level: one workgroup per (front, instance)
+          if (sp.n != 1) return fail(h, 3, "instance splits are not supported together with chain fronts");
+          const size_t lds = g->chain_lds[(size_t)l];
+          if (lds > 64 * 1024 && !h->chain_lds_attr) {
+            std::lock_guard<std::mutex> lk(h->alloc_mu);
+            if (!h->chain_lds_attr) {
+              if (hipFuncSetAttribute((const void*)k_chain_front, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return fail(h, 3, "hipFuncSetAttribute failed (chain fronts)");
+              h->chain_lds_attr = true;
+            }
+          }
+          const int nfr = P.chain_lvl_ptr[l + 1] - P.chain_lvl_ptr[l];
+          hipLaunchKernelGGL(k_chain_front, dim3((unsigned)nfr * (unsigned)d.bpad), dim3(256), lds, fan[0], d, P.chain_lvl_ptr[l],
+                             PIVOT_EPS);
+        }
+        if (P.front_piv >= 0 && P.piv_flevel[P.front_piv] == l) {
           // root front: pivot block inverted by one workgroup per chunk, rows scaled with the explicit inverse
           if (sp.n != 1) return fail(h, 3, "instance splits are not supported together with a root front");
           const int fp = P.front_piv;

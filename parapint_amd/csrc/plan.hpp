@@ -88,6 +88,24 @@ struct PlanOptions {
   int front_scale_rows = 8;
   int round_narrow_pop = 1 << 30;
   int round_narrow_wmax = 2;
+  // Chain fronts (symbolic.cpp, step 5b): a chain of block pivots p_1 -> p_2 -> ... in which every panel's rows are exactly
+  // the columns and rows of the next one is ONE dense supernode that the <= PP_WMAX-column panels cut into dependent
+  // levels (a time block of a dynamic problem: fronts of 100-170 rows eliminated four columns per level, 10-14 levels
+  // each).  Such a chain of at least chain_min_panels panels, at most chain_wmax columns and chain_lds_doubles of front
+  // storage is factorised in ONE level: its rows gather their contributions from outside the chain by the ordinary tasks
+  // (one launch), then one workgroup per instance holds the front's pivot columns in LDS and runs the panels one after
+  // the other (k_chain_front: block inversion, scaling, update of the later panels' columns).  0 disables.
+  int chain_fronts = 1;
+  int chain_min_panels = 3;
+  int chain_min_rows = 32;           // rows of the front (a chain of tiny panels is not worth a workgroup per instance)
+  int chain_wmax = 64;
+  int chain_lds_doubles = 18000;     // m * (W + 1) + 4 m + ...: 144 KB of the 160 KB of a compute unit
+  // Tile tasks: the rows of a chain front's panels are dense against their sources (the fronts below), so they are
+  // gathered four rows at a time against whole SOURCE PANELS -- one record per (tile of 4 rows, source panel): its <= 4
+  // columns are 4 + 4 operand loads for 16 multiply-adds each, against 1 + 4 loads per 4 multiply-adds and a record per
+  // source column of the row tasks (k_gather_tiles).  tile_task_records: records per piece of a tile (<= PP_QUAD pieces).
+  int chain_tiles = 1;
+  int tile_task_records = 24;
 };
 
 // Task sizes by batch (instances of the pattern group on this rank).  MEASURED on one MI355X (tools/tune_sweep.sh): with
@@ -164,6 +182,13 @@ inline bool apply_plan_tune(PlanOptions& opt, const char* tune, std::string& bad
       else if (k == "round_relax_tol_frac") opt.round_relax_tol_frac = v;
       else if (k == "round_narrow_pop") opt.round_narrow_pop = (int)v;
       else if (k == "round_narrow_wmax") opt.round_narrow_wmax = (int)v;
+      else if (k == "chain_fronts") opt.chain_fronts = (int)v;
+      else if (k == "chain_min_panels") opt.chain_min_panels = (int)v;
+      else if (k == "chain_min_rows") opt.chain_min_rows = (int)v;
+      else if (k == "chain_wmax") opt.chain_wmax = (int)v;
+      else if (k == "chain_lds_doubles") opt.chain_lds_doubles = (int)v;
+      else if (k == "chain_tiles") opt.chain_tiles = (int)v;
+      else if (k == "tile_task_records") opt.tile_task_records = (int)v;
       else { bad_key = k; return false; }
     }
     pos = end + 1;
@@ -202,7 +227,13 @@ inline bool apply_plan_tune(PlanOptions& opt, const char* tune, std::string& bad
 
 // qoff / ws: column slice of the panel the task gathers (ws == w, qoff == 0 except in the root front, whose w > PP_WMAX
 // columns are gathered PP_WMAX at a time).  kind 3: scale chunk of the root front (k_scale_wide).
-struct FTask { int piv, r0, r1, dptr0, kind, piece = 0, npieces = 1, qoff = 0, ws = 0; };
+// kind 4: tile task (PlanOptions::chain_tiles): rows [r0, r1) (<= PP_TILE_ROWS) of a panel against the source panels
+// trec[te0 .. te1) (device form); its per-row entry lists (dptr0, as for kind 0: the initial values in piece 0, the
+// product entries of this piece's sources) are what the host interpreter runs and where the device takes the initial values.
+#define PP_TILE_ROWS 4
+#define PP_TILE_DEPTH 2      // steps (source columns) in flight per wave in k_gather_tiles
+#define PP_TREC_INTS 12
+struct FTask { int piv, r0, r1, dptr0, kind, piece = 0, npieces = 1, qoff = 0, ws = 0, te0 = 0, te1 = 0; };
 struct FEntry { int u, l, wk, q; };
 // Schur tile record: pivot p contributes to tile (ta, tb); slots (or -1) of the tile's
 // coupling rows inside panel p
@@ -242,6 +273,19 @@ struct Plan {
   // rows scaled by k_scale_wide in chunks wtasks (kind 3).
   int front_piv = -1;
   std::vector<FTask> wtasks;
+  // Chain fronts (PlanOptions::chain_fronts): front c = panels chain_piv[chain_ptr[c] .. chain_ptr[c + 1]) in elimination
+  // order, chain_col0[.] = first column of each inside the front; chain_m / chain_w = rows (pivot columns included) and
+  // pivot columns of the front; chain_level = the factor level at which its rows are gathered and the front is run.
+  // piv_chain[p] = front of pivot p or -1.  piv_flevel[p] = level of p in the FACTOR schedule (== piv_level[p] for a plan
+  // without chain fronts; all panels of a chain share one); piv_level keeps the dependency levels the solve sweeps use.
+  std::vector<int> chain_ptr, chain_piv, chain_col0, chain_m, chain_w, chain_level, piv_chain, piv_flevel;
+  std::vector<int> chain_lvl_ptr;        // n_levels + 1 -> fronts (sorted by level)
+  // tile tasks (kind 4), sorted by level in whole quads like ftasks; records {w_k, U position of row i (k = 0) x 4, L position
+  // of column q x 4, 0, 0, 0}: positions >= usize name the PP_WMAX zero rows behind the panels (a row or column the source lacks)
+  std::vector<FTask> ttasks;
+  std::vector<int> tlevel_ptr;           // n_levels + 1 -> ttasks
+  std::vector<int> trec;
+  int n_flevels = 0;                     // levels of the factor schedule that hold anything
   // forward-solve entries: scalar row (new column index c) = b_c - sum U[upos] * z[zcol]
   std::vector<int> sfwd_eptr;            // n+1 -> sfwd_upos / sfwd_zcol
   std::vector<int> sfwd_upos, sfwd_zcol;

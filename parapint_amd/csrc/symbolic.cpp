@@ -684,6 +684,88 @@ static int build_plan_ordered(int n, int nc, int nnzK, const int* rowK, const in
     for (int p = 0; p < P.npiv; ++p) P.lvl_piv[fill[P.piv_level[p]]++] = p;
   }
 
+  // ---- 5b. chain fronts (plan.hpp, PlanOptions::chain_fronts): chains p -> q in which the rows of p are exactly the
+  // columns and the rows of q (q = the block pivot of p's first row; with the fill closure of step 3 the sizes decide)
+  P.piv_chain.assign(P.npiv, -1);
+  P.piv_flevel = P.piv_level;
+  P.chain_ptr.assign(1, 0);
+  if (opt.chain_fronts) {
+    std::vector<int> next(P.npiv, -1), prev(P.npiv, -1);
+    for (int p = 0; p < P.npiv; ++p) {
+      const auto& r = rows[p];
+      if (r.empty() || r[0] >= n || P.piv_w[p] > PP_WMAX) continue;
+      const int q = P.piv_of_col[r[0]];
+      if (P.piv_w[q] > PP_WMAX || prev[q] >= 0) continue;
+      if (r.size() != (size_t)P.piv_w[q] + rows[q].size()) continue;
+      next[p] = q; prev[q] = p;
+    }
+    std::vector<int> ch;
+    for (int h = 0; h < P.npiv; ++h) {
+      if (prev[h] >= 0 || next[h] < 0) continue;            // heads of chains
+      ch.clear();
+      for (int q = h; q >= 0; q = next[q]) ch.push_back(q);
+      size_t i = 0;
+      while (i < ch.size()) {                               // cut into fronts that fit the width and LDS bounds
+        const int64_t m0 = P.piv_w[ch[i]] + (int64_t)rows[ch[i]].size();
+        int W = 0;
+        size_t j = i;
+        while (j < ch.size() && W + P.piv_w[ch[j]] <= opt.chain_wmax &&
+               m0 * (W + P.piv_w[ch[j]] + 1) + 6 * m0 + 64 <= opt.chain_lds_doubles) { W += P.piv_w[ch[j]]; ++j; }
+        if (j == i) { ++i; continue; }                      // (this panel alone does not fit: it stays an ordinary panel)
+        if ((int)(j - i) >= opt.chain_min_panels && m0 >= opt.chain_min_rows) {
+          const int c = (int)P.chain_m.size();
+          int col0 = 0;
+          for (size_t t = i; t < j; ++t) {
+            P.chain_piv.push_back(ch[t]); P.chain_col0.push_back(col0); col0 += P.piv_w[ch[t]]; P.piv_chain[ch[t]] = c;
+          }
+          P.chain_ptr.push_back((int)P.chain_piv.size());
+          P.chain_m.push_back((int)m0); P.chain_w.push_back(W); P.chain_level.push_back(0);
+        }
+        i = j;
+      }
+    }
+    // factor levels: the panels of a front share the level at which everything OUTSIDE the front that any of them
+    // gathers from is complete.  (A pivot that depends on a member is a later member or follows the last one, and a source
+    // of a member from outside precedes it: pivots in ascending order see every level they need.)
+    const int nfr = (int)P.chain_m.size();
+    if (nfr > 0) {
+      std::vector<int>& fl = P.piv_flevel;
+      for (int p = 0; p < P.npiv; ++p) {
+        const int c = P.piv_chain[p];
+        int lv = 0;
+        for (auto& km : rowpat[p]) {
+          if (c >= 0 && P.piv_chain[km.k] == c) continue;
+          if (fl[km.k] < 0) { P.error = "internal: chain front level order"; return 3; }
+          lv = std::max(lv, fl[km.k] + 1);
+        }
+        if (c < 0) { fl[p] = lv; continue; }
+        P.chain_level[c] = std::max(P.chain_level[c], lv);
+        fl[p] = -1;
+        if (p == P.chain_piv[P.chain_ptr[c + 1] - 1])
+          for (int t = P.chain_ptr[c]; t < P.chain_ptr[c + 1]; ++t) fl[P.chain_piv[t]] = P.chain_level[c];
+      }
+      // fronts in level order
+      std::vector<int> ord(nfr);
+      for (int c = 0; c < nfr; ++c) ord[c] = c;
+      std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return P.chain_level[a] < P.chain_level[b]; });
+      std::vector<int> nptr(1, 0), npiv, ncol0, nm, nw, nlv;
+      for (int c2 = 0; c2 < nfr; ++c2) {
+        const int c = ord[c2];
+        for (int t = P.chain_ptr[c]; t < P.chain_ptr[c + 1]; ++t) {
+          npiv.push_back(P.chain_piv[t]); ncol0.push_back(P.chain_col0[t]); P.piv_chain[P.chain_piv[t]] = c2;
+        }
+        nptr.push_back((int)npiv.size());
+        nm.push_back(P.chain_m[c]); nw.push_back(P.chain_w[c]); nlv.push_back(P.chain_level[c]);
+      }
+      P.chain_ptr = nptr; P.chain_piv = npiv; P.chain_col0 = ncol0; P.chain_m = nm; P.chain_w = nw; P.chain_level = nlv;
+    }
+  }
+  P.n_flevels = 0;
+  for (int p = 0; p < P.npiv; ++p) P.n_flevels = std::max(P.n_flevels, P.piv_flevel[p] + 1);
+  P.chain_lvl_ptr.assign(P.n_levels + 1, 0);
+  for (size_t c = 0; c < P.chain_level.size(); ++c) P.chain_lvl_ptr[P.chain_level[c] + 1]++;
+  for (int l = 0; l < P.n_levels; ++l) P.chain_lvl_ptr[l + 1] += P.chain_lvl_ptr[l];
+
   // tail = trailing run of levels that each hold few pivots
   P.tail_level0 = P.n_levels;
   for (int l = P.n_levels - 1; l >= 0; --l) {
@@ -700,8 +782,12 @@ static int build_plan_ordered(int n, int nc, int nnzK, const int* rowK, const in
     std::sort(can_by_pos.begin(), can_by_pos.end());
     size_t can_cursor = 0;  // panels are visited in increasing U position
     struct TmpTask { FTask t; int level; int nent = 0; };
-    std::vector<TmpTask> gtasks, sctasks;
+    std::vector<TmpTask> gtasks, sctasks, tgtasks;
     std::vector<std::vector<FEntry>> row_ents;   // per destination row (slot) of panel p (of its current column slice)
+    // tile tasks: the sources of the current slice -- which of its rows hold which destination slots, which hold the columns
+    struct SrcInfo { int k, wk; int lrow[PP_WMAX]; std::vector<std::pair<int, int>> rows; };   // rows: (destination slot, row of k)
+    std::vector<SrcInfo> srcs;
+    std::vector<std::vector<int>> row_src;       // per entry of row_ents: its source (index into srcs), -1 for an initial value
     std::vector<std::pair<int64_t, int>> pan_can; // canonical entries located in panel p: (position in the panel, entry)
     for (int p = 0; p < P.npiv; ++p) {
       const int w = P.piv_w[p], p0 = P.piv_start[p];
@@ -719,19 +805,27 @@ static int build_plan_ordered(int n, int nc, int nnzK, const int* rowK, const in
       const bool in_tail = P.piv_level[p] >= P.tail_level0;
       const int cap_e = in_tail ? opt.tail_task_entries : opt.max_task_entries;
       bool fused = false;
+      const int chain = P.piv_chain[p];         // member of a chain front: contributions of earlier members are the front kernel's
       for (int sl = 0; sl < nslice; ++sl) {
         const int qoff = sl * PP_WMAX, ws = wide ? std::min(PP_WMAX, w - qoff) : w;
         row_ents.assign((size_t)f, {});
+        const bool tiled = chain >= 0 && opt.chain_tiles && !wide;
+        if (tiled) { row_src.assign((size_t)f, {}); srcs.clear(); }
         int64_t total = 0;
         // initial values
         for (auto& pc : pan_can) {
           const int col = (int)(pc.first % w);
           if (col < qoff || col >= qoff + ws) continue;
           row_ents[(size_t)(pc.first / w)].push_back({-1 - pc.second, -1, 0, col - qoff});
+          if (tiled) row_src[(size_t)(pc.first / w)].push_back(-1);
           ++total;
         }
         for (auto& km : rowpat[p]) {
           const int k = km.k, mslot = km.mslot, wk = P.piv_w[k];
+          if (chain >= 0 && P.piv_chain[k] == chain) {       // (inside the front: every row of p, all its columns)
+            P.flops_factor += (int64_t)f * w * wk;
+            continue;
+          }
           int j0 = 0, j1;
           while (j0 < km.cnt && km.qs[j0] < qoff) ++j0;
           j1 = j0;
@@ -740,6 +834,12 @@ static int build_plan_ordered(int n, int nc, int nnzK, const int* rowK, const in
           int nruns = 0;
           const auto& rk = rows[k];
           size_t tp = 0;
+          if (tiled) {
+            SrcInfo si; si.k = k; si.wk = wk;
+            for (int q = 0; q < PP_WMAX; ++q) si.lrow[q] = -1;
+            for (int j = j0; j < j1; ++j) si.lrow[km.qs[j] - qoff] = mslot + j;
+            srcs.push_back(si);
+          }
           for (size_t t = (size_t)(mslot - wk); t < rk.size(); ++t) {
             const int r = rk[t];
             int d;
@@ -750,6 +850,7 @@ static int build_plan_ordered(int n, int nc, int nnzK, const int* rowK, const in
               d = w + (int)tp;
             }
             const int srow = wk + (int)t;
+            if (tiled) srcs.back().rows.push_back({d, srow});
             for (int tt = 0; tt < wk; ++tt) {
               const int upos = (int)(P.piv_uoff[k] + (int64_t)srow * wk + tt);
               // one entry per run of consecutive columns of the slice that panel k holds (consecutive rows of k)
@@ -758,6 +859,7 @@ static int build_plan_ordered(int n, int nc, int nnzK, const int* rowK, const in
                 while (je < j1 && km.qs[je] == km.qs[je - 1] + 1) ++je;
                 row_ents[(size_t)d].push_back({upos, (int)(P.piv_uoff[k] + (int64_t)(mslot + j) * wk + tt), wk,
                                                (km.qs[j] - qoff) | ((je - j) << 4)});
+                if (tiled) row_src[(size_t)d].push_back((int)srcs.size() - 1);
                 ++nruns;
                 j = je;
               }
@@ -769,7 +871,7 @@ static int build_plan_ordered(int n, int nc, int nnzK, const int* rowK, const in
         }
         auto emit = [&](int r0, int r1, int kind, int piece = 0, int npieces = 1, int e0 = -1, int e1 = -1) {
           TmpTask tt;
-          tt.level = P.piv_level[p];
+          tt.level = P.piv_flevel[p];
           tt.t.piv = p; tt.t.r0 = r0; tt.t.r1 = r1; tt.t.kind = kind; tt.t.dptr0 = (int)P.fdst_ptr.size();
           tt.t.piece = piece; tt.t.npieces = npieces; tt.t.qoff = qoff; tt.t.ws = ws;
           const int first = (int)P.fentries.size();
@@ -790,7 +892,55 @@ static int build_plan_ordered(int n, int nc, int nnzK, const int* rowK, const in
           tt.nent = (e0 >= 0) ? (int)row_ents[(size_t)r0].size() : (int)P.fentries.size() - first;
           gtasks.push_back(tt);
         };
-        if (!wide && total <= opt.fuse_task_entries) {
+        if (tiled) {
+          // tile tasks: PP_TILE_ROWS consecutive slots against the source panels that hold any of them, cut into pieces
+          // of tile_task_records sources; every piece carries the entries of its rows from its own sources (piece 0 the
+          // initial values as well)
+          std::vector<int> ts;
+          for (int r0 = 0; r0 < f; r0 += PP_TILE_ROWS) {
+            const int r1 = std::min(f, r0 + PP_TILE_ROWS);
+            ts.clear();
+            for (size_t si = 0; si < srcs.size(); ++si) {
+              const auto& rw = srcs[si].rows;
+              auto it = std::lower_bound(rw.begin(), rw.end(), std::make_pair(r0, -1));
+              if (it != rw.end() && it->first < r1) ts.push_back((int)si);
+            }
+            const int nrec = (int)ts.size();
+            const int np = std::max(1, std::min(PP_QUAD, (nrec + opt.tile_task_records - 1) / std::max(1, opt.tile_task_records)));
+            const int per = (nrec + np - 1) / np;
+            for (int j = 0; j < np; ++j) {
+              const int a = std::min(nrec, j * per), b = std::min(nrec, (j + 1) * per);
+              TmpTask tt;
+              tt.level = P.piv_flevel[p];
+              tt.t.piv = p; tt.t.r0 = r0; tt.t.r1 = r1; tt.t.kind = 4; tt.t.dptr0 = (int)P.fdst_ptr.size();
+              tt.t.piece = j; tt.t.npieces = np; tt.t.qoff = qoff; tt.t.ws = ws;
+              tt.t.te0 = (int)(P.trec.size() / PP_TREC_INTS);
+              for (int x = a; x < b; ++x) {
+                const SrcInfo& s = srcs[(size_t)ts[(size_t)x]];
+                int rec[PP_TREC_INTS] = {s.wk, -1, -1, -1, -1, -1, -1, -1, -1, 0, 0, 0};
+                auto it = std::lower_bound(s.rows.begin(), s.rows.end(), std::make_pair(r0, -1));
+                for (; it != s.rows.end() && it->first < r1; ++it)
+                  rec[1 + it->first - r0] = (int)(P.piv_uoff[s.k] + (int64_t)it->second * s.wk);
+                for (int q = 0; q < ws; ++q)
+                  if (s.lrow[q] >= 0) rec[5 + q] = (int)(P.piv_uoff[s.k] + (int64_t)s.lrow[q] * s.wk);
+                P.trec.insert(P.trec.end(), rec, rec + PP_TREC_INTS);
+              }
+              tt.t.te1 = (int)(P.trec.size() / PP_TREC_INTS);
+              const int s_lo = (a < b) ? ts[(size_t)a] : 0, s_hi = (a < b) ? ts[(size_t)b - 1] : -1;
+              const int first = (int)P.fentries.size();
+              for (int rr = r0; rr < r1; ++rr) {
+                P.fdst_ptr.push_back((int)P.fentries.size());
+                const auto& de = row_ents[(size_t)rr];
+                const auto& ds = row_src[(size_t)rr];
+                for (size_t e = 0; e < de.size(); ++e)
+                  if ((ds[e] < 0 && j == 0) || (ds[e] >= s_lo && ds[e] <= s_hi)) P.fentries.push_back(de[e]);
+              }
+              P.fdst_ptr.push_back((int)P.fentries.size());
+              tt.nent = (int)P.fentries.size() - first;
+              tgtasks.push_back(tt);
+            }
+          }
+        } else if (!wide && chain < 0 && total <= opt.fuse_task_entries) {
           emit(0, f, 1);                                   // fused small panel
           fused = true;
         } else {
@@ -816,12 +966,12 @@ static int build_plan_ordered(int n, int nc, int nnzK, const int* rowK, const in
           }
         }
       }
-      if (!fused) {
+      if (!fused && chain < 0) {
         // scale chunks over the rows below the block (the root front: chunks for the workgroups of k_scale_wide)
         const int R = wide ? opt.front_scale_rows : std::max(1, opt.scale_task_rows / w);
         for (int r0 = w; r0 < f || r0 == w; r0 += R) {
           TmpTask tt;
-          tt.level = P.piv_level[p];
+          tt.level = P.piv_flevel[p];
           tt.t.piv = p; tt.t.r0 = r0; tt.t.r1 = std::min(f, r0 + R); tt.t.kind = wide ? 3 : 2; tt.t.dptr0 = -1;
           tt.t.ws = w;
           if (wide) P.wtasks.push_back(tt.t); else sctasks.push_back(tt);
@@ -876,6 +1026,37 @@ static int build_plan_ordered(int n, int nc, int nnzK, const int* rowK, const in
       }
     }
     for (auto& t : sctasks) { P.stasks.push_back(t.t); P.slevel_ptr[t.level + 1]++; }
+    // tile tasks by level: split tiles fill one quad each (padded), the others are packed PP_QUAD per quad
+    P.tlevel_ptr.assign(P.n_levels + 1, 0);
+    {
+      std::stable_sort(tgtasks.begin(), tgtasks.end(), by_level);
+      FTask noop; noop.piv = 0; noop.r0 = 0; noop.r1 = 0; noop.dptr0 = 0; noop.kind = -1;
+      size_t i = 0;
+      while (i < tgtasks.size()) {
+        const int lvl = tgtasks[i].level;
+        size_t j = i;
+        while (j < tgtasks.size() && tgtasks[j].level == lvl) ++j;
+        const size_t before = P.ttasks.size();
+        for (size_t q = i; q < j; ++q) {
+          if (tgtasks[q].t.npieces <= 1) continue;
+          P.ttasks.push_back(tgtasks[q].t);
+          if (tgtasks[q].t.piece == tgtasks[q].t.npieces - 1)
+            for (int pad = tgtasks[q].t.npieces; pad < PP_QUAD; ++pad) {
+              FTask z = noop; z.npieces = tgtasks[q].t.npieces; z.piece = pad;
+              P.ttasks.push_back(z);
+            }
+        }
+        std::vector<size_t> singles;
+        for (size_t q = i; q < j; ++q)
+          if (tgtasks[q].t.npieces <= 1) singles.push_back(q);
+        std::stable_sort(singles.begin(), singles.end(), [&](size_t a, size_t b) { return tgtasks[a].t.te1 - tgtasks[a].t.te0 > tgtasks[b].t.te1 - tgtasks[b].t.te0; });
+        for (size_t q : singles) P.ttasks.push_back(tgtasks[q].t);
+        while ((P.ttasks.size() - before) % PP_QUAD != 0) P.ttasks.push_back(noop);
+        P.tlevel_ptr[lvl + 1] += (int)(P.ttasks.size() - before);
+        i = j;
+      }
+      for (int l = 0; l < P.n_levels; ++l) P.tlevel_ptr[l + 1] += P.tlevel_ptr[l];
+    }
     for (int l = 0; l < P.n_levels; ++l) { P.flevel_ptr[l + 1] += P.flevel_ptr[l]; P.slevel_ptr[l + 1] += P.slevel_ptr[l]; }
   }
 

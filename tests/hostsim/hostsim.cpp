@@ -82,6 +82,38 @@ void ppsim_get_struct(void* h, int* piv_start, int* piv_w, int* rowptr, int* row
   std::memcpy(rowidx, P.rowidx.data(), sizeof(int) * P.rowidx.size());
 }
 int ppsim_dsize(void* h) { return ((Plan*)h)->dsize; }
+// chain fronts: out[0] = fronts, out[1] = panels in fronts, out[2] = factor levels, out[3] = widest front, out[4] = most rows
+void ppsim_chain_stats(void* h, int* out) {
+  Plan& P = *(Plan*)h;
+  out[0] = (int)P.chain_m.size(); out[1] = (int)P.chain_piv.size(); out[2] = P.n_flevels; out[3] = 0; out[4] = 0;
+  for (size_t c = 0; c < P.chain_m.size(); ++c) { out[3] = std::max(out[3], P.chain_w[c]); out[4] = std::max(out[4], P.chain_m[c]); }
+}
+// tile tasks: out[0] = tasks (no padding), out[1] = records, out[2] = operand rows present in the records (of 8 per record),
+// out[3] = product entries of the tile tasks' rows, out[4] = multiply-adds of those entries, out[5] = multiply-adds of the records
+void ppsim_tile_stats(void* h, long long* out) {
+  Plan& P = *(Plan*)h;
+  for (int i = 0; i < 6; ++i) out[i] = 0;
+  for (auto& t : P.ttasks) {
+    if (t.kind < 0) continue;
+    out[0]++;
+    for (int r = t.te0; r < t.te1; ++r) {
+      const int* rec = &P.trec[(size_t)r * PP_TREC_INTS];
+      int pres = 0;
+      for (int q = 1; q <= 8; ++q) pres += rec[q] >= 0;
+      out[1]++; out[2] += pres; out[5] += 16LL * rec[0];
+    }
+    for (int rr = 0; rr < t.r1 - t.r0; ++rr)
+      for (int e = P.fdst_ptr[t.dptr0 + rr]; e < P.fdst_ptr[t.dptr0 + rr + 1]; ++e)
+        if (P.fentries[e].u >= 0) { out[3]++; out[4] += (P.fentries[e].q >> 4) & 15; }
+  }
+}
+// per front: level, panels, m, W  (4 ints each)
+void ppsim_chain_fronts(void* h, int* out) {
+  Plan& P = *(Plan*)h;
+  for (size_t c = 0; c < P.chain_m.size(); ++c) {
+    out[4 * c] = P.chain_level[c]; out[4 * c + 1] = P.chain_ptr[c + 1] - P.chain_ptr[c]; out[4 * c + 2] = P.chain_m[c]; out[4 * c + 3] = P.chain_w[c];
+  }
+}
 void ppsim_get_perm(void* h, int* perm) { Plan& P = *(Plan*)h; std::memcpy(perm, P.perm.data(), sizeof(int) * P.n); }
 void ppsim_get_levels(void* h, int* lv) { Plan& P = *(Plan*)h; std::memcpy(lv, P.piv_level.data(), sizeof(int) * P.npiv); }
 void ppsim_get_level_task_counts(void* h, int* cnt) {
@@ -326,6 +358,44 @@ int ppsim_factor(void* h, const double* can, double* U, double* L, double* Dinv,
       }
       if (t.kind == 1) scale_rows(P, p, t.r0, t.r1, &Dinv[P.piv_doff[p]], U, L);
     }
+    // tile tasks (k_gather_tiles): up to PP_TILE_ROWS rows of a panel, cut into pieces by source panels; partial sums per
+    // piece, added in piece order
+    for (int ti = P.tlevel_ptr[lvl]; ti < P.tlevel_ptr[lvl + 1]; ++ti) {
+      const auto& t = P.ttasks[ti];
+      if (t.kind < 0 || t.piece != 0) continue;
+      const int p = t.piv, wp = P.piv_w[p], w = t.ws > 0 ? t.ws : wp, qoff = t.qoff;
+      const int nrow = t.r1 - t.r0;
+      double acc[PP_TILE_ROWS][PP_WMAX] = {{0}}, tmax[PP_TILE_ROWS][PP_WMAX] = {{0}};
+      for (int j = 0; j < t.npieces; ++j) {
+        const auto& tj = P.ttasks[ti + j];
+        for (int rr = 0; rr < nrow; ++rr) {
+          double pa[PP_WMAX] = {0}, pm[PP_WMAX] = {0};
+          for (int e = P.fdst_ptr[tj.dptr0 + rr]; e < P.fdst_ptr[tj.dptr0 + rr + 1]; ++e) {
+            const auto& fe = P.fentries[e];
+            if (fe.u < 0) {
+              const double v = can[-1 - fe.u];
+              pa[fe.q] += v;
+              pm[fe.q] = std::fmax(pm[fe.q], std::fabs(v));
+            } else {
+              const double su = U[fe.u];
+              const int q0 = fe.q & 15, qn = (fe.q >> 4) & 15;
+              for (int jj = 0; jj < qn; ++jj) {
+                const double term = su * L[fe.l + jj * fe.wk];
+                pa[q0 + jj] -= term;
+                pm[q0 + jj] = std::fmax(pm[q0 + jj], std::fabs(term));
+              }
+            }
+          }
+          for (int q = 0; q < w; ++q) { acc[rr][q] = (j == 0) ? pa[q] : acc[rr][q] + pa[q]; tmax[rr][q] = std::fmax(tmax[rr][q], pm[q]); }
+        }
+      }
+      for (int rr = 0; rr < nrow; ++rr)
+        for (int q = 0; q < w; ++q) {
+          const int slot = t.r0 + rr;
+          U[P.piv_uoff[p] + (int64_t)slot * wp + qoff + q] = acc[rr][q];
+          if (slot < wp) Tm[P.piv_boff[p] + (slot * wp + qoff + q)] = tmax[rr][q];
+        }
+    }
     // launch S: scale chunks of big panels
     for (int ti = P.slevel_ptr[lvl]; ti < P.slevel_ptr[lvl + 1]; ++ti) {
       const auto& t = P.stasks[ti];
@@ -343,8 +413,41 @@ int ppsim_factor(void* h, const double* can, double* U, double* L, double* Dinv,
       }
       scale_rows(P, p, t.r0, t.r1, inv, U, L);
     }
+    // chain fronts of this level (k_chain_front): the panels of a front one after the other -- block inversion, scaling,
+    // update of the later panels' gathered values by this panel (every row of a later panel is a row of this one)
+    for (int c = P.chain_lvl_ptr[lvl]; c < P.chain_lvl_ptr[lvl + 1]; ++c) {
+      for (int ti = P.chain_ptr[c]; ti < P.chain_ptr[c + 1]; ++ti) {
+        const int p = P.chain_piv[ti], w = P.piv_w[p], c0 = P.chain_col0[ti];
+        const int f = w + (P.piv_rowptr[p + 1] - P.piv_rowptr[p]);
+        double blk[PP_WMAX * PP_WMAX] = {0}, tmd[PP_WMAX] = {0}, inv[PP_WMAX * (PP_WMAX + 1) / 2] = {0};
+        for (int q = 0; q < w * w; ++q) {
+          blk[(q / w) * PP_WMAX + q % w] = U[P.piv_uoff[p] + q];
+          if (q / w == q % w) tmd[q / w] = Tm[P.piv_boff[p] + q];
+        }
+        const int code = pp::invert_block(w, P.piv_sub[p], blk, tmd, eps, inv);
+        for (int q = 0; q < w * (w + 1) / 2; ++q) Dinv[P.piv_doff[p] + q] = inv[q];
+        pos += code & 15; neg += (code >> 4) & 15; zero += (code >> 8) & 15;
+        if (((code >> 8) & 15) && g_first_zero_piv < 0) g_first_zero_piv = p;
+        scale_rows(P, p, w, f, inv, U, L);
+        for (int tj = ti + 1; tj < P.chain_ptr[c + 1]; ++tj) {
+          const int pj = P.chain_piv[tj], wj = P.piv_w[pj], cj = P.chain_col0[tj];
+          const int fj = wj + (P.piv_rowptr[pj + 1] - P.piv_rowptr[pj]);
+          for (int sl = 0; sl < fj; ++sl)
+            for (int q = 0; q < wj; ++q) {
+              const int tr = cj + sl - c0, tc = cj + q - c0;       // slots of the row and of the column in panel p
+              double acc = U[P.piv_uoff[pj] + (int64_t)sl * wj + q];
+              for (int k = 0; k < w; ++k) {
+                const double term = U[P.piv_uoff[p] + (int64_t)tr * w + k] * L[P.piv_uoff[p] + (int64_t)tc * w + k];
+                acc -= term;
+                if (sl < wj && q == sl) Tm[P.piv_boff[pj] + sl * wj + sl] = std::fmax(Tm[P.piv_boff[pj] + sl * wj + sl], std::fabs(term));
+              }
+              U[P.piv_uoff[pj] + (int64_t)sl * wj + q] = acc;
+            }
+        }
+      }
+    }
     // root front: inversion of its gathered pivot block (k_front_invert), rows scaled with the explicit inverse (k_scale_wide)
-    if (P.front_piv >= 0 && P.piv_level[P.front_piv] == lvl) {
+    if (P.front_piv >= 0 && P.piv_flevel[P.front_piv] == lvl) {
       const int p = P.front_piv, w = P.piv_w[p];
       double A[pp::PP_WF * pp::PP_WF] = {0}, tmd[pp::PP_WF] = {0}, finv[pp::PP_WF * (pp::PP_WF + 1) / 2] = {0};
       for (int i = 0; i < w; ++i)

@@ -386,6 +386,45 @@ def test_device_factor_matches_host_interpreter(wmax):
         hostlib().ppsim_set_supernodes(0, -1)
 
 
+@pytest.mark.parametrize('shape', [(72, 16, 2, 8), (12, 49, 2, 6)])
+def test_chain_front_factor_matches_host_interpreter(shape):
+    """Round 5: the panels of a chain front (plan.hpp) are factorised by k_chain_front -- one workgroup per instance, the
+    front's pivot columns in LDS -- into the SAME U / L / pivot-inverse storage the level kernels fill.  Every instance of
+    the interior time blocks (one full wave + a ragged one / a few) against the host interpreter of the same plan, which
+    mirrors the front kernel's sums; S, solution and inertia of the whole problem against the oracle besides."""
+    import ctypes
+    from hostsim_util import HostSim, lib as hostlib, _ip
+    T, n_s, n_u, nfe = shape
+    solver, model = sc.case_dynamic(make_engine, T, n_s, n_u=n_u, nfe=nfe)
+    eng = solver._eng
+    g = max(solver._groups, key=lambda q: len(q.blocks))
+    assert len(g.blocks) == T - 2
+    L = hostlib()
+    L.ppsim_set_batch_hint(len(g.blocks))
+    L.ppsim_set_mapped_hint(1)
+    try:
+        def block(t, it):
+            A = model.border_matrix(t).tocsr()
+            return model.block_matrix(t, it).tocoo(), A[np.unique(A.tocoo().row), :]
+        K0, A0 = block(g.blocks[0], 1)                   # (the plan is made on the group's first block at the symbolic phase)
+        hs = HostSim(K0, A0)
+        st = eng.ns.group_stats(g.gid)
+        assert st['u_doubles'] == hs.stats['usize'] and st['n_pivots'] == hs.stats['npiv']
+        cs = np.zeros(5, dtype=np.int32)
+        L.ppsim_chain_stats(hs.h, _ip(cs))
+        assert cs[0] >= 1 and cs[2] < hs.stats['n_levels']          # chain fronts exist and shorten the factor schedule
+        for slot in sorted(set((0, 1, len(g.blocks) // 2, len(g.blocks) - 1))):
+            K, A = block(g.blocks[slot], 2)               # (case_dynamic's last factorisation: iteration + 1)
+            rc, _, _ = hs.factor(hs.canonical(K, A))
+            assert rc == 0
+            for which, ref in ((0, hs.U), (1, hs.L), (2, hs.Dinv)):
+                dev = eng.get_factor(g.gid, which, slot, ref.size)
+                assert np.abs(dev - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max()), (slot, which)
+    finally:
+        L.ppsim_set_batch_hint(0)
+        L.ppsim_set_mapped_hint(0)
+
+
 @pytest.mark.parametrize('shape', [(3, 220, 2, 220), (2, 530, 2, 530)])
 def test_large_coupling_dimension_paths(shape):
     """n_c above the register-resident dense factor (208) and above one-thread-per-unknown solve (512):

@@ -267,3 +267,48 @@ def test_invert_front_matches_dense_inverse():
         assert np.abs(full @ A - np.eye(w)).max() < 1e-10
         ev = np.linalg.eigvalsh(A)
         assert (code & 15, (code >> 4) & 15, (code >> 8) & 15) == (int((ev > 0).sum()), int((ev < 0).sum()), 0)
+
+
+def _time_block(T, n_s, n_u, nfe, t=1):
+    from parapint_amd.examples.performance.schur_complement.dynamic_kkt import SyntheticDynamicKKT
+    model = SyntheticDynamicKKT(T, n_s, n_u, nfe)
+    K = model.block_matrix(t, 1).tocoo()
+    A = model.border_matrix(t).tocsr()
+    return K, A[np.unique(A.tocoo().row), :]
+
+
+@pytest.mark.parametrize('shape', [(8, 49, 2, 4), (72, 16, 2, 8), (6, 30, 3, 10)])
+@pytest.mark.parametrize('tune', ['', 'chain_wmax=8,chain_min_panels=2,chain_min_rows=8', 'chain_lds_doubles=1500'])
+def test_chain_fronts_of_time_blocks(shape, tune, monkeypatch):
+    """Round 5: chains of block pivots whose row sets nest exactly (the dense supernodes of a time block) are scheduled
+    as ONE factor level (plan.hpp: chain fronts).  The interpreter mirrors the front kernel's sums; the result is the
+    factorisation of the same matrix (S, inertia, both sweeps against dense algebra), with fewer factor levels than
+    dependency levels; narrow / LDS-bounded fronts cut a chain into several."""
+    import ctypes
+    import hostsim_util as hu
+    if tune:
+        monkeypatch.setenv('PP_PLAN_TUNE', tune)
+    L = hu.lib()
+    L.ppsim_set_batch_hint(shape[0] - 2)
+    L.ppsim_set_mapped_hint(1)
+    try:
+        K, A = _time_block(*shape)
+        hs = HostSim(K, A)
+        st = np.zeros(5, dtype=np.int32)
+        L.ppsim_chain_stats(hs.h, st.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+        assert st[0] >= 1 and st[1] >= 2 and st[2] < hs.stats['n_levels']
+        if 'chain_wmax=8' in tune:
+            assert st[3] <= 8
+        check_block(K, A)
+        monkeypatch.setenv('PP_PLAN_TUNE', 'chain_fronts=0')
+        hs0 = HostSim(K, A)
+        L.ppsim_chain_stats(hs0.h, st.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+        assert st[0] == 0 and st[2] == hs0.stats['n_levels']
+        # same storage layout, same factor to rounding
+        hs.factor(); hs0.factor()
+        assert hs.stats['usize'] == hs0.stats['usize']
+        for a, b in ((hs.U, hs0.U), (hs.L, hs0.L), (hs.Dinv, hs0.Dinv)):
+            assert np.abs(a - b).max() <= 1e-11 * max(1.0, np.abs(b).max())
+    finally:
+        L.ppsim_set_batch_hint(0)
+        L.ppsim_set_mapped_hint(0)
