@@ -104,6 +104,8 @@ struct PlanOptions {
   // gathered four rows at a time against whole SOURCE PANELS -- one record per (tile of 4 rows, source panel): its <= 4
   // columns are 4 + 4 operand loads for 16 multiply-adds each, against 1 + 4 loads per 4 multiply-adds and a record per
   // source column of the row tasks (k_gather_tiles).  tile_task_records: records per piece of a tile (<= PP_QUAD pieces).
+  int batch_hint = 0;                // instances of the group (tune_for_batch)
+  int chain_min_batch = 1;           // instances a pattern group needs for chain fronts (PP_PLAN_TUNE experiments)
   int chain_tiles = 1;
   int tile_task_records = 24;
 };
@@ -116,6 +118,7 @@ struct PlanOptions {
 // denser C4 / C5 blocks (8.30 -> 8.60 ms, 3.09 -> 3.21 ms), at 1024 blocks the larger tasks are as fast and hold less
 // index data: the small sizes up to 256 instances.
 inline void tune_for_batch(PlanOptions& o, int batch) {
+  o.batch_hint = batch;
   if (batch > 0 && batch <= 256) {
     o.max_task_entries = 8;
     o.tail_task_entries = 8;
@@ -188,6 +191,7 @@ inline bool apply_plan_tune(PlanOptions& opt, const char* tune, std::string& bad
       else if (k == "chain_wmax") opt.chain_wmax = (int)v;
       else if (k == "chain_lds_doubles") opt.chain_lds_doubles = (int)v;
       else if (k == "chain_tiles") opt.chain_tiles = (int)v;
+      else if (k == "chain_min_batch") opt.chain_min_batch = (int)v;
       else if (k == "tile_task_records") opt.tile_task_records = (int)v;
       else { bad_key = k; return false; }
     }

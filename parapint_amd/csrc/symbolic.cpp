@@ -689,7 +689,7 @@ static int build_plan_ordered(int n, int nc, int nnzK, const int* rowK, const in
   P.piv_chain.assign(P.npiv, -1);
   P.piv_flevel = P.piv_level;
   P.chain_ptr.assign(1, 0);
-  if (opt.chain_fronts) {
+  if (opt.chain_fronts && (opt.batch_hint <= 0 || opt.batch_hint >= opt.chain_min_batch)) {
     std::vector<int> next(P.npiv, -1), prev(P.npiv, -1);
     for (int p = 0; p < P.npiv; ++p) {
       const auto& r = rows[p];

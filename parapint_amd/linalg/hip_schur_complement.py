@@ -340,6 +340,16 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         self.refresh_backoff = False
         self._last_device_base = None       # DeviceBlockMatrix of the last full factorisation (diagonal-shift fast path)
         self._refreshed = []                # groups whose pivot order the last refresh chose again
+        # Instances of ONE pattern group that need incompatible static pivot sequences (MA27 pivots every block on its own
+        # values, ma27_interface.py:110-140): when the sequence chosen from instance A breaks on instance B and the one
+        # chosen from B breaks on A, the group is split -- the conflicting blocks move to a VARIANT of the pattern group
+        # (same pattern, a plan of its own from its own first block).  Host containers only: the lane layout of device
+        # containers belongs to their producer.  max_pivot_repairs bounds the extra factorisations of one call.
+        self.split_conflicting_groups = True
+        self.max_pivot_repairs = 6
+        self.max_group_variants = 3
+        self.group_splits = 0               # blocks moved to a variant group so far
+        self._variant = {}                  # block index -> variant of its pattern group (0: none)
         self._maps_checked = None           # value maps already compared block by block
         self._layout_cache = None           # (binfo, layout, dims) of device_layout()
         self._cinv_t = self._rc_pad = self._xc_pad = None       # device copies of the coupling order (block-tridiagonal S)
@@ -435,17 +445,18 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
                 br_global = br
                 br = np.searchsorted(cmap, br).astype(np.int32)
             # (index arrays shared by many blocks -- one Jacobian structure, one object -- are hashed once)
-            ids = None if self._mapped else (n, m, id(kr), id(kc), id(br), id(bc))
+            var = self._variant.get(ndx, 0)      # (a block moved out of its pattern group: a group of its own kind)
+            ids = None if self._mapped else (n, m, id(kr), id(kc), id(br), id(bc), var)
             g = by_ids.get(ids) if ids is not None else None
             if g is None:
-                raw_sig = (n, m, kr.tobytes(), kc.tobytes(), br.tobytes(), bc.tobytes())
+                raw_sig = (n, m, kr.tobytes(), kc.tobytes(), br.tobytes(), bc.tobytes(), var)
                 g = by_sig.get(raw_sig)
                 if g is not None and ids is not None:
                     by_ids[ids] = g
             if g is None:
                 rowK, colK, cpK, ciK = _canonical(kr, kc, n, True)
                 rowB, colB, cpB, ciB = _canonical(br, bc, n, False)
-                can_sig = (n, m, rowK.tobytes(), colK.tobytes(), rowB.tobytes(), colB.tobytes())
+                can_sig = (n, m, rowK.tobytes(), colK.tobytes(), rowB.tobytes(), colB.tobytes(), var)
                 g = by_sig.get(can_sig)
                 if g is None:
                     can_ptr = np.concatenate([cpK, cpB[1:] + cpK[-1]]).astype(np.int32)
@@ -923,6 +934,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             self._eng.set_pivot_tolerance(*self._u_user)        # (a new problem starts from the caller's threshold again)
         self._u_symbolic_now = self._u_user[0]
         self.pivot_order_refreshes_since_symbolic = 0
+        self._variant = {}
         self._last_device_base = None
         self._device_maps = (matrix.nsrc, matrix.value_maps) if device_matrix else None
         self._maps_checked = None           # (new groups: the maps of their blocks are compared again)
@@ -970,6 +982,12 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             # broke and factorise once more before the inertia-correction loop is told `singular`.
             res = self._numeric_factorization(matrix, timer)
             self._note_refresh_outcome(res.status != LinearSolverStatus.singular)
+            repairs = 0
+            while (res.status == LinearSolverStatus.singular and self.split_conflicting_groups and
+                   not hasattr(matrix, 'value_maps') and repairs < self.max_pivot_repairs and self._split_conflicting(matrix)):
+                # the new sequence broke on ANOTHER instance of the group: two instances that need different sequences
+                repairs += 1
+                res = self._numeric_factorization(matrix, timer)
         if res.status not in _OK and raise_on_error:
             raise RuntimeError('Numeric factorization unsuccessful; status: ' + str(res.status))
         return res
@@ -1024,6 +1042,7 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
                     self.refreshes_skipped += 1
                     continue
                 g.rep_vals = vals
+                g.refresh_block = g.blocks[slot]
                 mine = 1
                 self._refreshed.append(g)
         anyone = mine
@@ -1040,6 +1059,48 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             self.pivot_order_refreshes_since_symbolic += 1
             self._run_symbolic()
         return bool(anyone)
+
+    def _split_conflicting(self, matrix):
+        """After a refresh: a group whose new sequence (planned from block A) broke on a block B != A holds instances that
+        need different sequences.  B moves to the next variant of the pattern group (the blocks of a variant share one plan,
+        made from the first of them), the groups are built and planned again on the values of `matrix`.  Returns whether
+        anything moved.  A block that breaks under the sequence planned from ITSELF is singular: nothing to split.
+        Collective (the coupling structure is agreed by all ranks when the groups are rebuilt)."""
+        moved = 0
+        for g in self._groups:
+            if len(g.blocks) < 2:
+                continue
+            slot = self._eng.find_zero_pivot(g.gid)
+            if slot < 0:
+                continue
+            ndx = g.blocks[slot]
+            planned_from = getattr(g, 'refresh_block', g.blocks[0])
+            if ndx == planned_from:
+                continue
+            v = self._variant.get(ndx, 0) + 1
+            if v >= self.max_group_variants:
+                continue
+            self._variant[ndx] = v
+            moved += 1
+        anyone = moved
+        if self.comm.size > 1:
+            anyone = int(self.comm.allreduce_max(np.array([moved], dtype=np.int64))[0])
+        if not anyone:
+            return False
+        self.group_splits += moved
+        planned = {ndx: getattr(self._binfo[ndx].group, 'refresh_block', None) for ndx in self.local_block_indices}
+        self._build_groups(matrix)
+        for g in self._groups:                         # (a group keeps the block its sequence was planned from, if it still holds it)
+            keep = planned.get(g.blocks[0])
+            g.refresh_block = keep if keep in g.blocks else g.blocks[0]
+            if keep in g.blocks and keep != g.blocks[0]:
+                slot = g.blocks.index(keep)
+                kr, kc, kd, _ = _coo(matrix.get_block(keep, keep))
+                br, bc, bd = self._border(matrix, keep)
+                g.rep_vals = self._canonical_values(g, np.concatenate([kd, bd]), kr, kc, br, bc, self._binfo[keep].raw_sig)
+        self._run_symbolic()
+        self._pattern_only = False
+        return True
 
     def _numeric_factorization(self, matrix, timer=None):
         timer = _Labels(timer)

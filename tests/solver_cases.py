@@ -432,6 +432,67 @@ def case_pivot_order_refresh(make_engine):
     assert solver.do_numeric_factorization(A2, raise_on_error=False).status == LinearSolverStatus.singular
 
 
+def case_conflicting_pivots(make_engine, nb=6):
+    """Two instances of ONE pattern group that need incompatible static pivot sequences (MA27 pivots every block on its
+    own values, ma27_interface.py:110-140).  K = [[h1, 0, j1], [0, h2, j2], [j1, j2, 0]] (+ a well-conditioned tail so that
+    the blocks are not tiny): type A has h1 = 0, j1 = 1, j2 = 0, h2 = 1 -- the constraint row must pair with x1 --, type
+    B has h2 = 0, j2 = 1, j1 = 0, h1 = 1 -- it must pair with x2, and x1 is a plain pivot.  The sequence planned from an A
+    block meets an exactly singular 2 x 2 pivot in a B block and vice versa.  Expected: status successful (the group is
+    split into two variants), x against a dense solve, exact inertia."""
+    rng = np.random.default_rng(3)
+    n_t = 5                                     # tail variables (diagonal + a coupling to x1, x2)
+    n = 3 + n_t
+    nc = 2
+    rows = [0, 1, 2, 2, 2] + list(range(3, n)) + [3, 4]
+    cols = [0, 1, 0, 1, 2] + list(range(3, n)) + [0, 1]
+
+    def block(kind, i):
+        h1, h2, j1, j2 = (0.0, 1.0, 1.0, 0.0) if kind == 'A' else (1.0, 0.0, 0.0, 1.0)
+        tail = 2.0 + rng.random(n_t) + 0.1 * i
+        vals = [h1, h2, j1, j2, 0.0] + list(tail) + [0.0, 0.0]      # (x1, x2 and the constraint row get nothing from the tail)
+        r, c, v = np.array(rows), np.array(cols), np.array(vals)
+        off = r != c                              # (both triangles, explicit zeros kept: one pattern for both types)
+        return coo_matrix((np.concatenate([v, v[off]]), (np.concatenate([r, c[off]]), np.concatenate([c, r[off]]))), shape=(n, n))
+
+    kinds = ['A', 'B', 'A', 'B', 'B', 'A'][:nb]
+    A = BlockMatrix(nb + 1, nb + 1)
+    Bs = coo_matrix((np.array([1.0, -1.0]), (np.array([0, 1]), np.array([3, 5]))), shape=(nc, n))
+    for i, kd in enumerate(kinds):
+        A.set_block(i, i, block(kd, i))
+        A.set_block(nb, i, Bs)
+        A.set_block(i, nb, Bs.T.tocoo())
+    A.set_block(nb, nb, coo_matrix((np.array([4.0, 5.0]), (np.arange(nc), np.arange(nc))), shape=(nc, nc)))
+    rhs = BlockVector(nb + 1)
+    for i in range(nb):
+        rhs.set_block(i, rng.normal(size=n))
+    rhs.set_block(nb, rng.normal(size=nc))
+    full = A.toarray()
+    ev = np.linalg.eigvalsh(full)
+    assert np.abs(ev).min() > 1e-8 * np.abs(ev).max()
+    solver = new_solver(make_engine, nb)
+    assert solver.do_symbolic_factorization(A).status == LinearSolverStatus.successful
+    assert len(solver.plan_stats) == 1                                # one pattern group
+    for it in range(2):
+        res = solver.do_numeric_factorization(A, raise_on_error=False)
+        assert res.status == LinearSolverStatus.successful
+        assert solver.get_inertia() == (int((ev > 0).sum()), int((ev < 0).sum()), 0)
+        x = solver.do_back_solve(rhs)
+        x_ref = np.linalg.solve(full, rhs.flatten())
+        assert np.abs(x.flatten() - x_ref).max() <= 1e-8 * np.abs(x_ref).max()
+        assert scaled_residual(A.tocoo(), x.flatten(), rhs.flatten()) <= RESID_TOL
+    assert solver.group_splits >= 1 and len(solver.plan_stats) == 2   # two variants of the pattern, nothing reported singular
+    splits = solver.group_splits
+    # the split persists: the next factorisation needs no repair
+    assert solver.do_numeric_factorization(A, raise_on_error=False).status == LinearSolverStatus.successful
+    assert solver.group_splits == splits
+    # with the fallback off the caller is told `singular` (what round 4 did)
+    solver2 = new_solver(make_engine, nb)
+    solver2.split_conflicting_groups = False
+    solver2.do_symbolic_factorization(A)
+    assert solver2.do_numeric_factorization(A, raise_on_error=False).status == LinearSolverStatus.singular
+    return solver
+
+
 class RecordingTimer(object):
     """Stand-in for pyomo.common.timing.HierarchicalTimer: start/stop by label, must nest and balance."""
 

@@ -54,6 +54,11 @@ def test_pivot_order_refresh_after_static_breakdown():
     sc.case_pivot_order_refresh(make_engine)
 
 
+def test_instances_of_one_group_that_need_different_pivot_sequences():
+    """Round 5: the group is split into variants instead of reporting a regular matrix singular (ma27_interface.py:110-140)."""
+    sc.case_conflicting_pivots(make_engine)
+
+
 def test_ip_solve_call_pattern():
     sc.case_ip_solve_call_pattern(make_engine)
 

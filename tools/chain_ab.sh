@@ -12,7 +12,7 @@ f = glob.glob(sys.argv[1] + '/*/*kernel_trace.csv')[0]
 d = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     n = r['Kernel_Name']
-    for key in ('k_chain_front', 'k_chain_in', 'k_chain_out'):
+    for key in ("k_chain_front", "k_chain_xpose<false>", "k_chain_xpose<true>", "k_gather_tiles"):
         if key in n:
             d[(key, int(r['Grid_Size_X']) // int(r['Workgroup_Size_X']))].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
 for k in sorted(d): print('  ', k, len(d[k]), 'avg %.1f us' % (sum(d[k]) / len(d[k])))
