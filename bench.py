@@ -556,6 +556,11 @@ def main():
                    'torch_ops_per_iteration': (ipst.get('torch_ops') or 0) / max(ip_iters, 1),
                    'inertia_retries_from_resident_values': sv.diagonal_shift_refactorizations,
                    'pivot_order_refreshes': sv.pivot_order_refreshes, 'refresh_causes': dict(sv.refresh_causes),
+                   # collectives of one iteration: the all-reduce of [S | status] and of r_s (the solver's) + two all-gathers
+                   # of a handful of scalars (step lengths; convergence measures + this rank's coupling right-hand side) --
+                   # two dependent reductions with the step between them; rccl_ranks > 0: all four enqueued by the library
+                   'collectives_per_iteration': 4 if world > 1 else 0,
+                   'rccl_ranks': int(sv._eng.lib.pp_comm_size(sv._eng.ns.h)),
                    'note': 'it_per_s: iterations / wall time of the loop (barrier diagonals, right-hand side, numeric '
                            'factorisation with its inertia check, back-solve, step lengths, step, convergence measures), max '
                            'over ranks; the one-off symbolic phase and set-up are setup_seconds (it_per_s_whole_call includes them)'}
@@ -713,7 +718,7 @@ def main():
             # announced (solver.prefetch_forward) before the factorisation; `value_no_prefetch`: the same K steps in the
             # reference's plain call order (interior_point.py:553-566), what an unaware caller sees
             'value_no_prefetch': value_no_prefetch, 'ms_per_step_no_prefetch': ms_no_prefetch,
-            'rccl_ranks': rccl_ranks,      # > 0: the all-reduces were enqueued by the library (PP_DIRECT_RCCL=1)
+            'rccl_ranks': rccl_ranks,      # > 0: the all-reduces were enqueued by the library (the default for >= 2 RCCL ranks)
             'collective_us': collective_us,             # per rank: the two data-path all-reduces by themselves (HIP events)
             # SURVEY 8(d) to the letter: the same step through HOST containers (SciPy COO blocks in, host vectors out;
             # staging, H2D and D2H inside) -- the rate a caller with the reference's unchanged interfaces sees

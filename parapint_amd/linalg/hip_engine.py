@@ -377,26 +377,43 @@ class HipEngine(object):
         return int(out[0]), int(out[1])
 
     def _direct_rccl(self, comm):
-        """Opt-in (PP_DIRECT_RCCL=1, or comm.direct_rccl = True): the two data-path all-reduces are enqueued by the
-        library itself as RCCL calls on the handle's stream (include/parapint_hip.h: pp_allreduce_schur / pp_allreduce_rs)
-        instead of by torch.distributed between the kernel enqueues.  The communicator is made once per handle from a
-        unique id that rank 0 broadcasts through the torch process group."""
+        """The two data-path all-reduces (and the all-gathers of the interior-point step) are enqueued by the library itself
+        as RCCL calls on the handle's stream (include/parapint_hip.h: pp_allreduce_schur / pp_allreduce_rs /
+        pp_comm_allgather) instead of by torch.distributed between the kernel enqueues.  Round 5: the DEFAULT for a
+        communicator with device collectives and at least two ranks (PP_DIRECT_RCCL=0 or comm.direct_rccl = False keeps the
+        torch.distributed calls; PP_DIRECT_RCCL=1 / comm.direct_rccl = True also takes a one-rank group through RCCL).  The
+        communicator is made once per handle from a unique id that rank 0 broadcasts through the torch process group; if
+        librccl cannot be opened the torch path is used."""
         import os
-        if not (getattr(comm, 'direct_rccl', False) or os.environ.get('PP_DIRECT_RCCL') == '1'):
-            return False
         if not getattr(comm, 'device_collectives', False):
+            return False
+        want = getattr(comm, 'direct_rccl', None)
+        env = os.environ.get('PP_DIRECT_RCCL')
+        if want is False or env == '0':
+            return False
+        if not (want is True or env == '1' or comm.size >= 2):
+            return False
+        if getattr(self, '_rccl_unavailable', False):
             return False
         if self.lib.pp_comm_size(self.ns.h) != comm.size:
             import ctypes
             torch = self._torch
             uid = np.zeros(128, dtype=np.uint8)
+            ok = 1
             if comm.rank == 0:
                 if self.lib.pp_comm_unique_id(uid.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))) != 0:
-                    raise RuntimeError('pp_comm_unique_id failed (librccl not available)')
-            t = torch.from_numpy(uid).cuda()
+                    if want is True or env == '1':
+                        raise RuntimeError('pp_comm_unique_id failed (librccl not available)')
+                    ok = 0
+            # (rank 0 tells the others whether it has an id: all ranks take the same path)
+            t = torch.from_numpy(np.concatenate([uid, np.array([ok], dtype=np.uint8)])).cuda()
             if comm.size > 1:
                 comm._dist.broadcast(t, src=0, group=comm._group)
-            uid = t.cpu().numpy()
+            got = t.cpu().numpy()
+            if got[128] == 0:
+                self._rccl_unavailable = True
+                return False
+            uid = np.ascontiguousarray(got[:128])
             self.ns.check(self.lib.pp_comm_init(self.ns.h, int(comm.size), int(comm.rank),
                                                 uid.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))), 'pp_comm_init')
         return True
