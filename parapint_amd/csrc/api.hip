@@ -211,10 +211,21 @@ int pp_end_symbolic(pp_handle h) {
       g->level_maxw[P.piv_flevel[pp_]] = std::max(g->level_maxw[P.piv_flevel[pp_]], std::min(P.piv_w[pp_], PP_WMAX));
     {
       // chain fronts: header and panel records, LDS need per level
-      std::vector<int> chdr, cpan;
+      std::vector<int> chdr, cpan, ccol, ccolN;
       g->chain_lds.assign((size_t)P.n_levels, 0);
       for (size_t c = 0; c < P.chain_m.size(); ++c) {
-        chdr.insert(chdr.end(), {P.chain_m[c], P.chain_w[c], P.chain_ptr[c + 1] - P.chain_ptr[c], P.chain_ptr[c], 0, 0, 0, 0});
+        // ([4]: first entry of the front's columns in chain_col / chain_colN (new column index / caller's row of it),
+        // [5], [6]: the rows below the front's pivots = the rows of its last panel: offset into rowidx, count)
+        {
+          const int plast = P.chain_piv[(size_t)P.chain_ptr[c + 1] - 1];
+          chdr.insert(chdr.end(), {P.chain_m[c], P.chain_w[c], P.chain_ptr[c + 1] - P.chain_ptr[c], P.chain_ptr[c], (int)ccol.size(),
+                                   P.piv_rowptr[plast], P.piv_rowptr[plast + 1] - P.piv_rowptr[plast], 0});
+          for (int t = P.chain_ptr[c]; t < P.chain_ptr[c + 1]; ++t)
+            for (int q = 0; q < P.piv_w[P.chain_piv[t]]; ++q) {
+              ccol.push_back(P.piv_start[P.chain_piv[t]] + q);
+              ccolN.push_back(P.perm[P.piv_start[P.chain_piv[t]] + q]);
+            }
+        }
         for (int t = P.chain_ptr[c]; t < P.chain_ptr[c + 1]; ++t) {
           const int cp = P.chain_piv[t], cw = P.piv_w[cp];
           cpan.insert(cpan.end(), {cp, cw, (int)P.piv_uoff[cp], P.piv_boff[cp], P.piv_doff[cp], (int)P.piv_sub[cp], P.chain_col0[t],
@@ -223,10 +234,13 @@ int pp_end_symbolic(pp_handle h) {
         const size_t doubles = (size_t)P.chain_m[c] * ((size_t)(P.chain_w[c] | 1) + 4) + (size_t)P.chain_w[c] + 16;
         g->chain_lds[(size_t)P.chain_level[c]] = std::max(g->chain_lds[(size_t)P.chain_level[c]], doubles * sizeof(double));
       }
-      d.chain_hdr = d.chain_pan = nullptr;
+      d.chain_hdr = d.chain_pan = d.chain_col = nullptr;
+      g->chain_colN = nullptr;
       if (!chdr.empty()) {
         if ((rc = dev_upload(h, g, &d.chain_hdr, chdr))) return rc;
         if ((rc = dev_upload(h, g, &d.chain_pan, cpan))) return rc;
+        if ((rc = dev_upload(h, g, &d.chain_col, ccol))) return rc;
+        if ((rc = dev_upload(h, g, &g->chain_colN, ccolN))) return rc;
       }
     }
     std::vector<int> ftask, stask, fdst_ptr, fent, srec;
@@ -396,14 +410,24 @@ int pp_end_symbolic(pp_handle h) {
       for (int c : P.clevel_col) {
         const int pv = P.piv_of_col[c], w = P.piv_w[pv], q = c - P.piv_start[pv];
         frec.insert(frec.end(), {c, P.perm[c], P.sfwd_eptr[c], P.sfwd_eptr[c + 1]});
-        brec.insert(brec.end(), {c, w, q, P.piv_rowptr[pv + 1] - P.piv_rowptr[pv], P.piv_rowptr[pv],
-                                 (int)(P.piv_uoff[pv] + (int64_t)w * w + q), P.piv_doff[pv], P.piv_start[pv]});
+        // (chain sweeps: a column of a chain front takes only the rows below the front's pivots here -- the last m - W rows
+        // of its panel; the later columns of the front are k_chain_bwd's)
+        int nr = P.piv_rowptr[pv + 1] - P.piv_rowptr[pv], j0 = 0;
+        if (P.chain_sweeps_on && P.piv_chain[pv] >= 0) {
+          const int fc = P.piv_chain[pv];
+          j0 = nr - (P.chain_m[(size_t)fc] - P.chain_w[(size_t)fc]);
+        }
+        brec.insert(brec.end(), {c, w, q, nr - j0, P.piv_rowptr[pv] + j0,
+                                 (int)(P.piv_uoff[pv] + (int64_t)(w + j0) * w + q), P.piv_doff[pv], P.piv_start[pv]});
       }
+      // (chain sweeps: a column of a chain front always takes part in its level's launch -- its y is written to Y even
+      // without contributions from outside the front, where k_chain_fwd finishes it)
+      auto in_front = [&](int c) { return P.chain_sweeps_on && P.piv_chain[P.piv_of_col[c]] >= 0; };
       g->fwd_level_has_entries.assign((size_t)P.n_levels, 0);
       for (int l = 0; l < P.n_levels; ++l)
         for (int q = P.clevel_ptr[l]; q < P.clevel_ptr[l + 1]; ++q) {
           const int c = P.clevel_col[q];
-          if (P.sfwd_eptr[c + 1] > P.sfwd_eptr[c]) { g->fwd_level_has_entries[(size_t)l] = 1; break; }
+          if (P.sfwd_eptr[c + 1] > P.sfwd_eptr[c] || in_front(c)) { g->fwd_level_has_entries[(size_t)l] = 1; break; }
         }
       // wave teams: a row / column with more than a couple of 16-entry load rounds is shared by 4 or 16 waves
       // (thresholds measured at C3: 16/48 and 16/64 were slower, 48/128 the same)
@@ -429,7 +453,7 @@ int pp_end_symbolic(pp_handle h) {
       // native-vector variants: a column without incoming entries keeps y = b, which then is read from the caller's
       // right-hand side (row perm[c]) instead of a copy; x is written and read in the caller's row order
       std::vector<uint8_t> noent((size_t)P.n, 0);
-      for (int c = 0; c < P.n; ++c) noent[(size_t)c] = P.sfwd_eptr[c + 1] == P.sfwd_eptr[c];
+      for (int c = 0; c < P.n; ++c) noent[(size_t)c] = P.sfwd_eptr[c + 1] == P.sfwd_eptr[c] && !in_front(c);
       std::vector<int> zf(P.sfwd_zcol), zc2(P.crow_zcol), brn(brec), ro(P.rowidx);
       for (auto& z : zf) if (noent[(size_t)z]) z = -1 - P.perm[z];
       for (auto& z : zc2) if (noent[(size_t)z]) z = -1 - P.perm[z];

@@ -72,6 +72,7 @@ struct GroupDev {
   double *Sloc, *XCL;   // mapped groups: per-instance Schur cliques [tile entry][instance], per-instance coupling solution
   int xs_row, xs_lane;  // address of coupling value c of lane b: c * xs_row + b * xs_lane (uniform: 1, 0 into xc)
   const int *ttask, *trec;            // tile tasks (plan.hpp, kind 4) and their source-panel records
+  const int *chain_col;               // chain fronts: the columns of every front (new index; the native backward sweep gets the caller's rows)
   const int *chain_hdr, *chain_pan;   // chain fronts (plan.hpp): per front {m, W, panels, first panel record}, per panel {piv, w, uoff, boff, doff, sub, col0, f}
   int* growth;      // per instance: 1 if a factor entry exceeded lbound (MA27's threshold test |l_ij| <= 1/u failed)
   double lbound;    // 1 / u_rt, or +inf
@@ -197,6 +198,7 @@ struct Group {
   double *raw_own = nullptr, *rhs_own = nullptr, *rawT_own = nullptr;
   int nraw_used = 0;
   std::vector<int> level_maxw;   // widest block pivot per level (selects the scalar kernel variants)
+  const int* chain_colN = nullptr;  // chain fronts: caller's row of every front column (native vectors)
   std::vector<size_t> chain_lds;   // per factor level: dynamic LDS bytes of its chain fronts (k_chain_front), 0 if none
   const int* wtask = nullptr;    // scale chunks of the root front (device), plan.wtasks
   double* front_inv = nullptr;   // root front: inv(P) as a zero-padded 16 x 16 matrix [entry][instance] (k_front_invert -> k_scale_wide)
@@ -385,7 +387,7 @@ struct pp_solver {
   int *btd_ipiv = nullptr, *btd_info = nullptr, *scatter_err = nullptr, *btd_elim = nullptr;
   std::vector<int> bcr_off, bcr_ne, bcr_s, bcr_lo;   // per level: offset into btd_elim, eliminated blocks, stride, lower neighbour live
   int btd_sequential = 0;
-  bool bcr_lds_attr = false, bcr_ldl_attr = false, dn_lds_attr = false, chain_lds_attr = false;
+  bool bcr_lds_attr = false, bcr_ldl_attr = false, dn_lds_attr = false, chain_lds_attr = false, chain_bwd_attr = false;
   double* dn_z = nullptr;        // fat-panel dense factor (n_c > 512): inverted diagonal blocks + work vectors of the panel solve (dense.hip)
   // largest multiplier the unpivoted block factorisation of the cyclic reduction accepts (1 / u, u = 0.01; PP_BCR_LBOUND:
   // test switch -- a bound below 1 sends some blocks to Bunch-Kaufman and leaves others on the unpivoted path)

@@ -99,11 +99,14 @@ struct PlanOptions {
   int chain_min_panels = 3;
   int chain_min_rows = 32;           // rows of the front (a chain of tiny panels is not worth a workgroup per instance)
   int chain_wmax = 64;
-  int chain_lds_doubles = 18000;     // m * (W + 1) + 4 m + ...: 144 KB of the 160 KB of a compute unit
+  int chain_lds_doubles = 9000;      // m * (W + 1) + 4 m + ...: 72 KB -- two fronts per compute unit (MEASURED at C4: 18000, one per unit, 159 against 162 it/s)
   // Tile tasks: the rows of a chain front's panels are dense against their sources (the fronts below), so they are
   // gathered four rows at a time against whole SOURCE PANELS -- one record per (tile of 4 rows, source panel): its <= 4
   // columns are 4 + 4 operand loads for 16 multiply-adds each, against 1 + 4 loads per 4 multiply-adds and a record per
   // source column of the row tasks (k_gather_tiles).  tile_task_records: records per piece of a tile (<= PP_QUAD pieces).
+  // chain fronts in the solve sweeps: the columns of a front are one level; the contributions of outside panels come
+  // through the ordinary row / column tasks, the panels of the front are walked by k_chain_fwd / k_chain_bwd
+  int chain_sweeps = 1;
   int batch_hint = 0;                // instances of the group (tune_for_batch)
   int chain_min_batch = 1;           // instances a pattern group needs for chain fronts (PP_PLAN_TUNE experiments)
   int chain_tiles = 1;
@@ -191,6 +194,7 @@ inline bool apply_plan_tune(PlanOptions& opt, const char* tune, std::string& bad
       else if (k == "chain_wmax") opt.chain_wmax = (int)v;
       else if (k == "chain_lds_doubles") opt.chain_lds_doubles = (int)v;
       else if (k == "chain_tiles") opt.chain_tiles = (int)v;
+      else if (k == "chain_sweeps") opt.chain_sweeps = (int)v;
       else if (k == "chain_min_batch") opt.chain_min_batch = (int)v;
       else if (k == "tile_task_records") opt.tile_task_records = (int)v;
       else { bad_key = k; return false; }
@@ -271,6 +275,8 @@ struct Plan {
   std::vector<int> flevel_maxent;        // per level: max entries of a gather/fused task (a piece counts as its whole row)
   std::vector<int> flevel_nsplit;        // per level: number of split rows (0: the level runs one wave per workgroup)
   std::vector<int> clevel_ptr, clevel_col;  // solve schedule: scalar columns (new indices) by level
+  std::vector<int> clevel_nchain;        // per level: columns of chain fronts (the last ones of the level's list)
+  bool chain_sweeps_on = false;          // the sweeps use the factor levels and the chain kernels (PlanOptions::chain_sweeps)
   int tail_level0 = 0;                   // levels >= tail_level0 form the tail (== n_levels: no tail)
   // Root front: the last block pivot when it is wider than PP_WMAX (else -1).  It is alone on the last level; its
   // gather tasks (column slices) are in ftasks like all others, its pivot block is inverted by k_front_invert and its

@@ -280,6 +280,117 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_level(GroupDev g, int col0, int
 }
 
 
+// ------------------------------------------------------------------------------------------
+// Chain fronts in the sweeps (plan.hpp, PlanOptions::chain_sweeps).  The columns of a front form ONE level: what they
+// receive from panels outside the front comes through the ordinary row tasks of that level (forward: k_fwd_level over the
+// outside entries only), the dependencies between the front's own panels -- one sweep level each without these kernels:
+// 10-16 launches at their floor per front -- are walked inside one workgroup per (front, chunk of 64 instances), lane =
+// instance, the front's part of the vector in LDS.
+// Forward: y of panel i is final once the earlier panels are applied; then every later column c of the front gets
+// y_c -= sum_k L_i[row of c][k] y_(i, k) (its waves take the columns NW apart).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_chain_fwd(GroupDev g, int front0, int ny) {
+  __shared__ double yl[64][64];                     // [front column][lane]   (PlanOptions::chain_wmax <= 64)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int fi = front0 + (int)(blockIdx.x / (unsigned)ny);
+  const unsigned b = (unsigned)((blockIdx.x % (unsigned)ny) * 64 + lane);
+  const size_t bpad = (size_t)g.bpad;
+  const int* H = g.chain_hdr + 8 * (size_t)fi;
+  const int W = H[1], npan = H[2];
+  const int* PR = g.chain_pan + 8 * (size_t)H[3];
+  const int* col = g.chain_col + H[4];
+  for (int c = wave; c < W; c += NW) yl[c][lane] = g.Y[(size_t)col[c] * bpad + b];
+  __syncthreads();
+  for (int i = 0; i + 1 < npan; ++i) {
+    const int* R = PR + 8 * i;
+    const int w = R[1], c0 = R[6], c1 = c0 + w;
+    const double* Lp = g.L + (size_t)R[2] * bpad + b;
+    double yk[PP_WMAX];
+#pragma unroll
+    for (int k = 0; k < PP_WMAX; ++k) yk[k] = (k < w) ? yl[c0 + min(k, w - 1)][lane] : 0.0;
+    // (the operands of four columns requested together: one round trip instead of four)
+    for (int cb = c1 + wave; cb < W; cb += 4 * NW) {
+      double l[4][PP_WMAX];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int t = min(cb + j * NW, W - 1) - c0;     // the row of the column in panel i
+#pragma unroll
+        for (int k = 0; k < PP_WMAX; ++k) l[j][k] = Lp[(size_t)(t * w + min(k, w - 1)) * bpad];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = cb + j * NW;
+        if (c < W) {
+          double acc = yl[c][lane];
+#pragma unroll
+          for (int k = 0; k < PP_WMAX; ++k)
+            if (k < w) acc -= l[j][k] * yk[k];
+          yl[c][lane] = acc;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  for (int c = wave; c < W; c += NW) g.Y[(size_t)col[c] * bpad + b] = yl[c][lane];
+}
+
+// Backward: the ordinary column tasks of the level have left  x_c = (inv(P_p) y_p)_q - sum over the rows BELOW THE FRONT'S
+// PIVOTS of L_p[t][q] x(row t)  in X for every column of the front (their records name only those rows: the bulk of the
+// panel, streamed by one workgroup per column across the chip); what is left is the triangular part inside the front.  The
+// panels are taken in reverse: x_(p, q) -= sum over the rows t of panel p that are later columns of the front of
+// L_p[t][q] x(that column) -- the rows spread over the waves, partial sums through LDS in wave order (deterministic), wave q
+// finishes column q.  LDS: xl[W][64], red[NW][PP_WMAX][64].
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_chain_bwd(GroupDev g, int front0, int ny, const int* __restrict__ colX) {
+  __shared__ double xl[64][64];                     // [front column][lane]   (PlanOptions::chain_wmax <= 64)
+  __shared__ double red[NW][PP_WMAX][64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int fi = front0 + (int)(blockIdx.x / (unsigned)ny);
+  const int b = (int)((blockIdx.x % (unsigned)ny) * 64 + lane);
+  const size_t bpad = (size_t)g.bpad;
+  const int* H = g.chain_hdr + 8 * (size_t)fi;
+  const int W = H[1], npan = H[2];
+  const int* PR = g.chain_pan + 8 * (size_t)H[3];
+  const int* cx = colX + H[4];
+  for (int c = wave; c < W; c += NW) xl[c][lane] = g.X[(size_t)cx[c] * bpad + b];
+  __syncthreads();
+  for (int i = npan - 2; i >= 0; --i) {             // (the last panel has no later column of the front below it)
+    const int* R = PR + 8 * i;
+    const int w = R[1], c0 = R[6], nint = W - c0;   // rows [w, nint) of the panel are the later columns of the front
+    const double* Lp = g.L + (size_t)R[2] * bpad + b;
+    double s[PP_WMAX];
+#pragma unroll
+    for (int q = 0; q < PP_WMAX; ++q) s[q] = 0.0;
+    // (the rows of a wave four at a time: sixteen operand requests in flight)
+    for (int tb = w + wave; tb < nint; tb += 4 * NW) {
+      double l[4][PP_WMAX], xv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int t = min(tb + j * NW, nint - 1);
+#pragma unroll
+        for (int q = 0; q < PP_WMAX; ++q) l[j][q] = Lp[(size_t)(t * w + min(q, w - 1)) * bpad];
+        xv[j] = (tb + j * NW < nint) ? xl[c0 + t][lane] : 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < PP_WMAX; ++q) s[q] += l[j][q] * xv[j];
+    }
+#pragma unroll
+    for (int q = 0; q < PP_WMAX; ++q) red[wave][q][lane] = s[q];
+    __syncthreads();
+    if (wave < w) {
+      const int q = wave;
+      double tot = 0.0;
+      for (int j = 0; j < NW; ++j) tot += red[j][q][lane];
+      const double x = (b < g.batch) ? xl[c0 + q][lane] - tot : 0.0;
+      xl[c0 + q][lane] = x;
+      g.X[(size_t)cx[c0 + q] * bpad + b] = x;
+    }
+    __syncthreads();
+  }
+}
+
 // per-instance copy of the coupling solution for the back substitution of a mapped group
 __global__ __launch_bounds__(256) void k_gather_xc(GroupDev g, const double* __restrict__ xc) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -360,6 +471,11 @@ int pp_solve_forward_ex(pp_handle h, int rhs_before_factor) {
             hipLaunchKernelGGL(k_fwd_level_pair, dim3((unsigned)ncol * (ny / 2)), dim3(64), 0, fan[q], dn, c0, sp.c0[q] / 2, ny / 2);
           else PP_LAUNCH_FWD(1);
 #undef PP_LAUNCH_FWD
+        }
+        if (P.chain_sweeps_on && P.chain_lvl_ptr[l + 1] > P.chain_lvl_ptr[l]) {
+          if (sp.n != 1) return fail(h, 3, "instance splits are not supported together with chain fronts");
+          hipLaunchKernelGGL(k_chain_fwd<8>, dim3((unsigned)(P.chain_lvl_ptr[l + 1] - P.chain_lvl_ptr[l]) * (unsigned)d.nchunk),
+                             dim3(64 * 8), 0, fan[0], dn, P.chain_lvl_ptr[l], d.nchunk);
         }
       }
       if (join_streams(h, sp, fan)) return fail(h, 3, "stream join failed");
@@ -473,7 +589,8 @@ int pp_solve_backward(pp_handle h) {
       hipStream_t fan[PP_MAX_SPLIT];
       if (fork_streams(h, sp, fan, st)) return fail(h, 3, "stream fork failed");
       for (int l = P.n_levels - 1; l >= 0; --l) {
-        const int c0 = P.clevel_ptr[l], ncol = P.clevel_ptr[l + 1] - c0;
+        const int c0 = P.clevel_ptr[l];
+        const int ncol = P.clevel_ptr[l + 1] - c0;
         if (ncol <= 0) continue;
         const int team = g->bwd_level_team[(size_t)l];
         for (int q = 0; q < sp.n; ++q) {
@@ -485,6 +602,12 @@ int pp_solve_backward(pp_handle h) {
             hipLaunchKernelGGL(k_bwd_level_pair, dim3((unsigned)ncol * (ny / 2)), dim3(64), 0, fan[q], dn, c0, sp.c0[q] / 2, ny / 2, xcp);
           else PP_LAUNCH_BWD(1);
 #undef PP_LAUNCH_BWD
+        }
+        if (P.chain_sweeps_on && P.chain_lvl_ptr[l + 1] > P.chain_lvl_ptr[l]) {
+          // (the columns of the level's fronts have their part from below the fronts: now the triangle inside each front)
+          if (sp.n != 1) return fail(h, 3, "instance splits are not supported together with chain fronts");
+          hipLaunchKernelGGL(k_chain_bwd<8>, dim3((unsigned)(P.chain_lvl_ptr[l + 1] - P.chain_lvl_ptr[l]) * (unsigned)d.nchunk),
+                             dim3(64 * 8), 0, fan[0], dn, P.chain_lvl_ptr[l], d.nchunk, native ? g->chain_colN : d.chain_col);
         }
       }
       if (join_streams(h, sp, fan)) return fail(h, 3, "stream join failed");

@@ -1069,6 +1069,8 @@ static int build_plan_ordered(int n, int nc, int nnzK, const int* rowK, const in
         const int c = P.piv_start[p] + q;
         for (auto& km : rowpat[p]) {
           const int k = km.k, wk = P.piv_w[k];
+          // (a column of a chain front gets the contributions of the front's earlier panels from the front's own sweep kernel)
+          if (opt.chain_sweeps && P.piv_chain[p] >= 0 && P.piv_chain[k] == P.piv_chain[p]) continue;
           int j = 0;
           while (j < km.cnt && km.qs[j] != q) ++j;
           if (j == km.cnt) continue;            // panel k has no row for this column of p
@@ -1080,14 +1082,26 @@ static int build_plan_ordered(int n, int nc, int nnzK, const int* rowK, const in
         P.sfwd_eptr[c + 1] = (int)P.sfwd_upos.size();
       }
     {
+      // levels of the sweeps: the dependency levels -- or, with chain fronts whose own kernels run their panels one after
+      // the other (chain_sweeps), the levels of the factor schedule: a front's columns share one.  Within a level the
+      // columns outside fronts come first (the backward sweep launches only those: clevel_nchain counts the others).
+      const bool cs = opt.chain_sweeps && !P.chain_m.empty();
+      const std::vector<int>& lv = cs ? P.piv_flevel : P.piv_level;
       std::vector<int> cnt(P.n_levels + 1, 0);
-      for (int p = 0; p < P.npiv; ++p) cnt[P.piv_level[p] + 1] += P.piv_w[p];
+      for (int p = 0; p < P.npiv; ++p) cnt[lv[p] + 1] += P.piv_w[p];
       for (int l = 0; l < P.n_levels; ++l) cnt[l + 1] += cnt[l];
       P.clevel_ptr = cnt;
       P.clevel_col.assign(n, 0);
+      P.clevel_nchain.assign(P.n_levels, 0);
       std::vector<int> fill(cnt.begin(), cnt.end() - 1);
-      for (int p = 0; p < P.npiv; ++p)
-        for (int q = 0; q < P.piv_w[p]; ++q) P.clevel_col[fill[P.piv_level[p]]++] = P.piv_start[p] + q;
+      for (int pass = 0; pass < 2; ++pass)
+        for (int p = 0; p < P.npiv; ++p) {
+          const bool in_front = cs && P.piv_chain[p] >= 0;
+          if ((pass == 1) != in_front) continue;
+          for (int q = 0; q < P.piv_w[p]; ++q) P.clevel_col[fill[lv[p]]++] = P.piv_start[p] + q;
+          if (in_front) P.clevel_nchain[lv[p]] += P.piv_w[p];
+        }
+      P.chain_sweeps_on = cs;
     }
     std::vector<std::vector<std::pair<int, int>>> cr(nc);
     for (int k = 0; k < P.npiv; ++k) {

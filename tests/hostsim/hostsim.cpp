@@ -499,6 +499,18 @@ void ppsim_forward(void* h, const double* L, const double* rhs, double* Y) {
     const int c = P.clevel_col[i];
     double acc = rhs[P.perm[c]];
     for (int e = P.sfwd_eptr[c]; e < P.sfwd_eptr[c + 1]; ++e) acc -= L[P.sfwd_upos[e]] * Y[P.sfwd_zcol[e]];
+    const int pv = P.piv_of_col[c], fr = P.piv_chain[pv];
+    if (P.chain_sweeps_on && fr >= 0) {
+      // (k_chain_fwd: the earlier panels of the front, in order; column c is row c0_j + q - c0_i of panel i)
+      int tj = P.chain_ptr[fr];
+      while (P.chain_piv[tj] != pv) ++tj;
+      const int cf = P.chain_col0[tj] + (c - P.piv_start[pv]);
+      for (int ti = P.chain_ptr[fr]; ti < tj; ++ti) {
+        const int pi = P.chain_piv[ti], wi = P.piv_w[pi];
+        const int64_t row = P.piv_uoff[pi] + (int64_t)(cf - P.chain_col0[ti]) * wi;
+        for (int k = 0; k < wi; ++k) acc -= L[row + k] * Y[P.piv_start[pi] + k];
+      }
+    }
     Y[c] = acc;
   }
   for (int c = 0; c < P.nc; ++c) {
