@@ -41,6 +41,7 @@ constexpr int WAVE = 64;
 typedef double double4_t __attribute__((ext_vector_type(4)));   // accumulator of v_mfma_f64_16x16x4
 constexpr int PP_MAX_SPLIT = 8;
 constexpr int PP_MT_WIDE_NC = 512;   // from this coupling dimension on the Schur update works on 32 x 32 super-tiles (k_schur_mfma_wide)
+constexpr int PP_SCHUR_SLICES = 4;   // mapped groups: workgroups that share the records of one Schur tile (partial cliques in slots of Sloc)
 constexpr int PP_MT_SLICE = 4;  // records (panel columns) of one 16 x 16 Schur tile per work item of k_schur_mfma
 constexpr int PP_CSLOTS = 64;  // the inertia / growth counters are kept in this many slots of 4 ints, summed by the tail writer
 constexpr int PP_TAIL = 8;    // doubles behind the n_c x n_c Schur block: zero pivots, pos, neg, host failures, growth, reserved
@@ -720,7 +721,7 @@ int64_t value_storage_bytes(pp_handle h) {
                   (int64_t)P.dsize * bp + (int64_t)std::max(P.n + g->nc_loc, std::max(P.bsize, 1)) * bp +
                   (int64_t)P.n * bp + 2 * (int64_t)g->batch * P.n + (int64_t)d.nchunk * std::max(std::max(g->ntiles, 1) * 64, g->nmt_items * (g->mt_wide ? 1024 : 256)) +
                   (int64_t)d.nchunk * std::max(g->nc_loc, 1) +
-                  (g->cmap_host.empty() ? 0 : ((int64_t)std::max(g->ntiles, 1) * 64 + std::max(g->nc_loc, 1)) * bp);
+                  (g->cmap_host.empty() ? 0 : ((int64_t)PP_SCHUR_SLICES * std::max(g->ntiles, 1) * 64 + std::max(g->nc_loc, 1)) * bp);
     total += 8 * dbl + 2 * (int64_t)P.npiv * bp;
   }
   return total;
@@ -793,7 +794,7 @@ int alloc_value_storage(pp_handle h) {
     if ((rc = value_alloc(h, g, &d.Spart, (size_t)d.nchunk * (size_t)std::max(std::max(g->ntiles, 1) * 64, g->nmt_items * (g->mt_wide ? 1024 : 256))))) break;
     if ((rc = value_alloc(h, g, &d.rspart, (size_t)d.nchunk * std::max(nc, 1)))) break;
     if (!g->cmap_host.empty()) {
-      if ((rc = value_alloc(h, g, &d.Sloc, (size_t)std::max(g->ntiles, 1) * 64 * bp))) break;
+      if ((rc = value_alloc(h, g, &d.Sloc, (size_t)PP_SCHUR_SLICES * std::max(g->ntiles, 1) * 64 * bp))) break;
       if ((rc = value_alloc(h, g, &d.XCL, (size_t)std::max(nc, 1) * bp))) break;
     }
     if ((rc = value_alloc(h, g, &d.codes, (size_t)P.npiv * bp))) break;   // 16-bit codes

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(64) void k_schur_tiles(GroupDev g, int ntile_all, s
   const int lane = threadIdx.x;
   const unsigned ncb = gridDim.x - (unsigned)(ntile_all * g.nchunk);    // counting workgroups come first in the grid
   if (blockIdx.x < ncb) {
-    if (blockIdx.z != 0) return;
+    if (blockIdx.z != 0 || blockIdx.y != 0) return;
     count_codes_block(g, blockIdx.x, ncb, total8, counters, lane);
     return;
   }
@@ -113,14 +113,19 @@ __global__ __launch_bounds__(64) void k_schur_tiles(GroupDev g, int ntile_all, s
     for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
   // column-step records {w, position of (row 0, column t) of the panel, -, -, slotA[8], slotB[8]}: one per panel
   // column holding rows of both tile ranges; four steps (48 loads) are in flight together
-  const int r0 = g.stile_ptr[tile], r1 = g.stile_ptr[tile + 1];
+  // (mapped groups: gridDim.y workgroups share a tile's records -- every instance keeps a clique of its own, so a tile is
+  // 64 lanes x one wave whatever the batch is, and the 512 time blocks of C4 gave 1456 waves of 280 us; the slices leave
+  // partial cliques in slots of their own, k_scatter_schur adds them)
+  const int rs0 = g.stile_ptr[tile], rs1 = g.stile_ptr[tile + 1];
+  const int r0 = rs0 + (int)((long long)(rs1 - rs0) * blockIdx.y / gridDim.y);
+  const int r1 = rs0 + (int)((long long)(rs1 - rs0) * (blockIdx.y + 1) / gridDim.y);
   constexpr int SG = 4;
   for (int r = r0; r < r1; r += SG) {
     double la[SG][8], ub[SG][4];
 #pragma unroll
     for (int s = 0; s < SG; ++s) {
       const bool live = r + s < r1;
-      const int* rec = g.stile_rec + 20 * (size_t)min(r + s, r1 - 1);
+      const int* rec = g.stile_rec + 20 * (size_t)max(min(r + s, r1 - 1), rs0);
       const int w = rec[0];
       const double* Up = g.U + (size_t)rec[1] * bpad + b;
       const double* Lp = g.L + (size_t)rec[1] * bpad + b;
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(64) void k_schur_tiles(GroupDev g, int ntile_all, s
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        g.Sloc[((size_t)tile * 64 + i * 8 + 4 * half + j) * bpad + b] = acc[i][j];
+        g.Sloc[(((size_t)blockIdx.y * ntile_all + tile) * 64 + i * 8 + 4 * half + j) * bpad + b] = acc[i][j];
     return;
   }
   const double mask = (b < g.batch) ? 1.0 : 0.0;
@@ -421,16 +426,20 @@ __device__ __forceinline__ void schur_add(const SchurTarget& T, int gi, int gj, 
   }
 }
 
+// (blockIdx.y: one of eight slices of the tile's 64 entries -- a lane that walks all 64 alone is a chain of 64 load ->
+// atomic round trips: 180 us for the 512 time blocks of C4, MEASURED)
 __global__ __launch_bounds__(64) void k_scatter_schur(GroupDev g, int ntiles, SchurTarget T) {
   const int lane = threadIdx.x;
   const int tile = PP_TASK_OF_WG(g.nchunk), b = PP_CHUNK_OF_WG(g.nchunk) * 64 + lane;
   if (b >= g.batch) return;
   const size_t bpad = (size_t)g.bpad;
   const int ta = g.stile_a[tile], tb = g.stile_b[tile];
-  for (int e = 0; e < 64; ++e) {
+  for (int e = 8 * (int)blockIdx.y; e < 8 * (int)blockIdx.y + 8; ++e) {
     const int ci = ta * 8 + (e >> 3), cj = tb * 8 + (e & 7);
     if (ci >= g.nc || cj >= g.nc || ci < cj) continue;
-    const double v = g.Sloc[((size_t)tile * 64 + e) * bpad + b];
+    double v = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < PP_SCHUR_SLICES; ++sl) v += g.Sloc[(((size_t)sl * ntiles + tile) * 64 + e) * bpad + b];
     if (v == 0.0) continue;
     schur_add(T, g.cmapT[(size_t)ci * bpad + b], g.cmapT[(size_t)cj * bpad + b], v);
   }
@@ -446,7 +455,9 @@ __global__ __launch_bounds__(64) void k_scatter_schur_few(GroupDev g, int ntiles
   const int ci = ta * 8 + (e >> 3), cj = tb * 8 + (e & 7);
   if (ci >= g.nc || cj >= g.nc || ci < cj) return;
   for (int b = 0; b < g.batch; ++b) {
-    const double v = g.Sloc[((size_t)tile * 64 + e) * bpad + b];
+    double v = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < PP_SCHUR_SLICES; ++sl) v += g.Sloc[(((size_t)sl * ntiles + tile) * 64 + e) * bpad + b];
     if (v == 0.0) continue;
     schur_add(T, g.cmapT[(size_t)ci * bpad + b], g.cmapT[(size_t)cj * bpad + b], v);
   }
@@ -509,11 +520,11 @@ int pp_numeric_schur_ex(pp_handle h, int side_stream) {
       const unsigned ncb = (unsigned)std::min<size_t>(2048, (total8 + 255) / 256);   // counting workgroups in front of the tiles
       if (g->ntiles > 0 && d.cmapT) {
         // mapped group: per-instance cliques, scattered into the dense or the block-tridiagonal S
-        hipLaunchKernelGGL(k_schur_tiles, dim3((unsigned)g->ntiles * d.nchunk + ncb, 1, 2), dim3(64), 0, st, d, g->ntiles, total8,
-                           h->counters);
+        hipLaunchKernelGGL(k_schur_tiles, dim3((unsigned)g->ntiles * d.nchunk + ncb, PP_SCHUR_SLICES, 2), dim3(64), 0, st, d, g->ntiles,
+                           total8, h->counters);
         const SchurTarget T{h->S, nc, h->btd, h->gs, h->G, h->scatter_err};
         if (d.batch <= 8) hipLaunchKernelGGL(k_scatter_schur_few, dim3((unsigned)g->ntiles), dim3(64), 0, st, d, g->ntiles, T);
-        else hipLaunchKernelGGL(k_scatter_schur, dim3((unsigned)g->ntiles * d.nchunk), dim3(64), 0, st, d, g->ntiles, T);
+        else hipLaunchKernelGGL(k_scatter_schur, dim3((unsigned)g->ntiles * d.nchunk, 8), dim3(64), 0, st, d, g->ntiles, T);
       } else if (g->ntiles > 0 && h->schur_mfma && g->nmt > 0) {
         if (g->mt_wide)
           hipLaunchKernelGGL(k_schur_mfma_wide, dim3((unsigned)g->nmt_items * d.nchunk + ncb), dim3(64), 0, st, d, g->nmt_items, total8,
