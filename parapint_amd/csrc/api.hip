@@ -141,7 +141,7 @@ int pp_add_group_mapped(pp_handle h, int n, int batch, int nnzK, const int32_t* 
   if (h->pivot_threshold > 0.0) opt.pivot_threshold = h->pivot_threshold;
   {
     std::string bad;
-    if (!pp::apply_plan_tune(opt, std::getenv("PP_PLAN_TUNE"), bad)) { delete g; return fail(h, 3, "PP_PLAN_TUNE: unknown key " + bad); }
+    if (!pp::apply_plan_tune(opt, pp::env_switch("PP_PLAN_TUNE"), bad)) { delete g; return fail(h, 3, "PP_PLAN_TUNE: unknown key " + bad); }
   }
   g->nc_loc = nc_loc;
   if (cmap) g->cmap_host.assign(cmap, cmap + (size_t)batch * nc_loc);
@@ -491,7 +491,7 @@ int pp_end_symbolic(pp_handle h) {
     g->ntiles = (int)P.stile_a.size();
     // 16 x 16 tiles for the MFMA form (k_schur_mfma): per (tile pair, panel column) one record with the positions of the
     // 16 + 16 rows; the records of a tile are cut into work items of at most PP_MT_SLICE records
-    g->mt_wide = h->nc >= PP_MT_WIDE_NC && std::getenv("PP_NO_WIDE_SCHUR_TILES") == nullptr;
+    g->mt_wide = h->nc >= PP_MT_WIDE_NC && pp::env_switch("PP_NO_WIDE_SCHUR_TILES") == nullptr;
     if (g->mt_wide) {
       // 32 x 32 super-tiles (k_schur_mfma_wide): per (super-tile pair, panel column) one record with the positions of the
       // 32 + 32 rows; mt_a / mt_b per quarter (4 per super-tile, -1: the quarter above the diagonal), items {r0, r1, super, 0}
@@ -1356,7 +1356,7 @@ int pp_stage_upload_verified_begin(pp_handle h, int group, int nblocks, int nthr
   g->stage_host = staging;
   j->row_valid = g->staged_row_valid.data();
   j->nchunk = (j->stride + StageJob::CH - 1) / StageJob::CH;
-  static const bool no_compare = std::getenv("PP_NO_STAGE_COMPARE") != nullptr;      // (measurement switch)
+  static const bool no_compare = pp::env_switch("PP_NO_STAGE_COMPARE") != nullptr;      // (measurement switch)
   j->compare = !no_compare;
   try { j->changed.assign((size_t)nblocks * j->nchunk, 0); } catch (...) { delete j; return fail(h, 3, "pp_stage_upload_verified_begin: out of host memory"); }
   h->stage_job = j;

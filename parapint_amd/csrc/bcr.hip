@@ -747,11 +747,11 @@ int ppi_btd_factor_schur(pp_handle h, const double* Q_host, long long corner_nnz
         h->bcr_lds_attr = true;
       }
     }
-    if (std::getenv("PP_BCR_NO_LDS")) lds_bytes = 0;
-    const bool bcr_mfma = std::getenv("PP_NO_BCR_MFMA") == nullptr;    // block products on the matrix cores, wave-level inverse (measurement switch)
+    if (pp::env_switch("PP_BCR_NO_LDS")) lds_bytes = 0;
+    const bool bcr_mfma = pp::env_switch("PP_NO_BCR_MFMA") == nullptr;    // block products on the matrix cores, wave-level inverse (measurement switch)
     // unpivoted LDL^T + inverse of the blocks on the matrix cores, Bunch-Kaufman only for the blocks it rejects
     // (PP_NO_BCR_LDL: measurement switch; needs the matrix-core products for the rest of the level and gs <= 112)
-    bool bcr_ldl = bcr_mfma && gs <= 16 * BL_NT && std::getenv("PP_NO_BCR_LDL") == nullptr;
+    bool bcr_ldl = bcr_mfma && gs <= 16 * BL_NT && pp::env_switch("PP_NO_BCR_LDL") == nullptr;
     if (bcr_ldl && !h->bcr_ldl_attr) {
       if (hipFuncSetAttribute((const void*)k_bcr_ldl_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BL_LDS_BYTES) != hipSuccess) {
         (void)hipGetLastError();
@@ -761,7 +761,7 @@ int ppi_btd_factor_schur(pp_handle h, const double* Q_host, long long corner_nnz
       }
     }
     int bk_threads = 256;        // (measured at C4, gs = 98, S phase per step: 64 threads 15.3 ms, 128 12.1, 256 10.8, 512 11.0)
-    if (const char* e = std::getenv("PP_BCR_THREADS")) bk_threads = std::max(64, std::min(BK_THREADS, std::atoi(e)));
+    if (const char* e = pp::env_switch("PP_BCR_THREADS")) bk_threads = std::max(64, std::min(BK_THREADS, std::atoi(e)));
     for (int l = 0; l < nlev; ++l) {
       const BcrLevel lv{h->btd_elim + h->bcr_off[(size_t)l], h->bcr_ne[(size_t)l], h->bcr_s[(size_t)l], h->bcr_lo[(size_t)l]};
       if (bcr_ldl)
@@ -815,7 +815,7 @@ int ppi_btd_coupling_solve(pp_handle h, const double* rc_dev) {
       hipLaunchKernelGGL(k_bcr_rhs, dim3((nc + 255) / 256), dim3(256), 0, st, nc, rc_dev, h->rs, b);
       for (int l = 0; l < nlev; ++l) {
         const BcrLevel lv{h->btd_elim + h->bcr_off[(size_t)l], h->bcr_ne[(size_t)l], h->bcr_s[(size_t)l], h->bcr_lo[(size_t)l]};
-        static const bool three_phases = std::getenv("PP_BCR_FWD_PHASES") != nullptr;     // (measurement switch)
+        static const bool three_phases = pp::env_switch("PP_BCR_FWD_PHASES") != nullptr;     // (measurement switch)
         if (!three_phases && gs <= 512)
           hipLaunchKernelGGL(k_bcr_fwd_fused, dim3(lv.ne + 1), dim3(512), 0, st, gs, G, lv, h->btd_inv, h->btd_klo, h->btd_kup, b, w);
         else

@@ -369,7 +369,7 @@ struct pp_solver {
   hipEvent_t ev_dense_fork = nullptr, ev_dense_done = nullptr;
   bool dense_pending = false;
   bool schur_on_side = false;    // the Schur update of this factorisation runs on dense_stream (pp_numeric_schur_ex): the dense phase follows it there
-  bool dense_overlap = std::getenv("PP_NO_DENSE_OVERLAP") == nullptr;   // (measurement switch)
+  bool dense_overlap = pp::env_switch("PP_NO_DENSE_OVERLAP") == nullptr;   // (measurement switch)
   // interior-point step on device-resident iterates (ipstep.hip): partials of its reductions, pinned mailbox
   double* ip_part = nullptr;
   size_t ip_part_cap = 0;
@@ -392,13 +392,13 @@ struct pp_solver {
   double* dn_z = nullptr;        // fat-panel dense factor (n_c > 512): inverted diagonal blocks + work vectors of the panel solve (dense.hip)
   // largest multiplier the unpivoted block factorisation of the cyclic reduction accepts (1 / u, u = 0.01; PP_BCR_LBOUND:
   // test switch -- a bound below 1 sends some blocks to Bunch-Kaufman and leaves others on the unpivoted path)
-  double bcr_lbound = std::getenv("PP_BCR_LBOUND") ? std::atof(std::getenv("PP_BCR_LBOUND")) : 100.0;
+  double bcr_lbound = pp::env_switch("PP_BCR_LBOUND") ? std::atof(pp::env_switch("PP_BCR_LBOUND")) : 100.0;
   double growth_bound = 1e8;     // 1 / u_rt: a factor entry beyond it flags its instance
   bool growth_fatal = false;     // flagged instances make the factorisation report status 2 (else they are only counted)
   double pivot_threshold = 0.0;  // symbolic-time threshold u for groups added afterwards (0: plan default)
-  bool no_fused_sources = std::getenv("PP_NO_FUSED_SOURCES") != nullptr;   // measurement switch: assemble the sources first
-  bool schur_mfma = std::getenv("PP_NO_SCHUR_MFMA") == nullptr;   // MFMA form of the Schur update of unmapped groups (measurement switch)
-  bool enqueue_threads = std::getenv("PP_NO_ENQUEUE_THREADS") == nullptr;   // one enqueuing host thread per group stream (measurement switch)
+  bool no_fused_sources = pp::env_switch("PP_NO_FUSED_SOURCES") != nullptr;   // measurement switch: assemble the sources first
+  bool schur_mfma = pp::env_switch("PP_NO_SCHUR_MFMA") == nullptr;   // MFMA form of the Schur update of unmapped groups (measurement switch)
+  bool enqueue_threads = pp::env_switch("PP_NO_ENQUEUE_THREADS") == nullptr;   // one enqueuing host thread per group stream (measurement switch)
   EnqueuePool pool;
   StagePool stage_pool;
   void* stage_job = nullptr;             // staging job in flight (pp_stage_upload_verified_begin .. pp_stage_upload_end), api.hip
@@ -410,14 +410,14 @@ struct pp_solver {
   hipStream_t up_stream = nullptr;
   bool corner_used = false;
   std::mutex alloc_mu, err_mu;
-  bool group_streams = std::getenv("PP_NO_GROUP_STREAMS") == nullptr;   // pattern groups side by side on streams of their own (measurement switch)
+  bool group_streams = pp::env_switch("PP_NO_GROUP_STREAMS") == nullptr;   // pattern groups side by side on streams of their own (measurement switch)
   // forward sweep of an announced right-hand side behind the block factorisation of its own group instead of behind the
   // Schur update and the factorisation of S (pp_solve_forward_ex; measurement switch)
-  bool fwd_early = std::getenv("PP_NO_EARLY_FORWARD") == nullptr;
+  bool fwd_early = pp::env_switch("PP_NO_EARLY_FORWARD") == nullptr;
   hipEvent_t ev_blocks_done = nullptr;   // recorded on the handle's stream behind the join of the groups' factorisations
   bool blocks_done_valid = false;
-  bool dense_dpp = std::getenv("PP_NO_DENSE_DPP") == nullptr;           // row broadcasts by DP-ALU DPP in k_ldl_regs (measurement switch)
-  bool lane_pairs = std::getenv("PP_NO_LANE_PAIRS") == nullptr;   // two instances per lane in the gather kernels (measurement switch)
+  bool dense_dpp = pp::env_switch("PP_NO_DENSE_DPP") == nullptr;           // row broadcasts by DP-ALU DPP in k_ldl_regs (measurement switch)
+  bool lane_pairs = pp::env_switch("PP_NO_LANE_PAIRS") == nullptr;   // two instances per lane in the gather kernels (measurement switch)
   double shift_w = 0.0, shift_c = 0.0;   // diagonal shifts of the current pp_numeric_local_shifted call (else 0)
   double mem_factor = 1.0;
   int64_t mem_budget = 0;        // bytes of device value storage the handle may allocate (0: no limit); scaled by mem_factor
@@ -671,7 +671,7 @@ int dev_upload(pp_handle h, Group* g, const T** out, const std::vector<T>& v) {
 // tiles per workgroup of k_transpose_in (measured on C3: 1 is fastest -- 0.105 ms against 0.123 at 8; the
 // walk along the row only pays if rows were much longer than the 4 workgroups/CU window already covers)
 int transpose_tiles(int, int) {
-  if (const char* e = std::getenv("PP_TRANSPOSE_TILES")) return std::max(1, std::atoi(e));
+  if (const char* e = pp::env_switch("PP_TRANSPOSE_TILES")) return std::max(1, std::atoi(e));
   return 1;
 }
 

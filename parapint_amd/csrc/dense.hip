@@ -1123,7 +1123,7 @@ int ppi_dense_factor_schur(pp_handle h, const double* Q_host) {
         double* stage = h->work + 8;                //  2 n_c doubles >= 8 + 32 * 32 for n_c > 512)
         int* flags = h->dense_mode + 2;
         hipLaunchKernelGGL(k_dense_anorm, dim3(1), dim3(256), 0, st, nc, h->Sldl, anorm, flags);
-        static const bool panel32 = std::getenv("PP_DENSE_PANEL32") != nullptr;
+        static const bool panel32 = pp::env_switch("PP_DENSE_PANEL32") != nullptr;
         if (panel32) {
           for (int j0 = 0; j0 < nc; j0 += LDL_NB) {
             const int m = nc - std::min(nc, j0 + LDL_NB);
@@ -1192,7 +1192,7 @@ int ppi_dense_coupling_solve(pp_handle h, const double* rc_dev) {
   if (int rc = join_dense(h)) return rc;
   hipStream_t st = h->stream;
   const int nc = h->nc;
-  static const bool panel32 = std::getenv("PP_DENSE_PANEL32") != nullptr;
+  static const bool panel32 = pp::env_switch("PP_DENSE_PANEL32") != nullptr;
   const bool panels = nc > 512 && h->dn_z && h->dense_policy == 0 && !panel32;
   PhaseScope ps(h, 6, panels ? 15 : 1);
   if (panels) {

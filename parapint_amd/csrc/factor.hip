@@ -78,16 +78,6 @@ __device__ __forceinline__ void invert_and_scale(const GroupDev& g, int p, int w
 //   * the term magnitudes (zero-pivot test) are only tracked in the rows of the pivot block; all other rows are plain
 //     fused multiply-adds,
 //   * initial-value records load one operand, not 1 + w.
-#ifdef PP_X_STAMPS
-// diagnostic build: lane 0 of every wave of ONE launch (the level whose first task is pp_x_stamp_task0) writes 100 MHz
-// timestamps at the stations of its task: [0] start, [1] task record read, [2] first entry records arrived, [3..]
-// after each group of entries, [14] end, [15] hardware id
-__device__ unsigned long long* pp_x_stamps = nullptr;
-__device__ int pp_x_stamp_task0 = -1;
-#define PP_STAMP(k) do { if (stp) stp[(k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define PP_STAMP(k) do { } while (0)
-#endif
 
 template <int WM, int NW, int NV>
 __global__ __launch_bounds__(64 * NW) void k_gather_flat(GroupDev g, int task0, int chunk0, int ny, double eps) {
@@ -96,12 +86,6 @@ __global__ __launch_bounds__(64 * NW) void k_gather_flat(GroupDev g, int task0, 
   const unsigned b = (unsigned)((((NV == 2 ? PP_PAIR_OF_WG(ny) : PP_CHUNK_OF_WG(ny)) + chunk0) * 64 + lane) * NV);    // first instance of this lane
   const size_t bpad = (size_t)g.bpad;
   const int* t = g.ftask + TASK_INTS * (size_t)(task0 + NW * PP_TASK_OF_WG(ny) + wave);
-#ifdef PP_X_STAMPS
-  unsigned long long* stp = (pp_x_stamps && task0 == pp_x_stamp_task0 && lane == 0)
-                                ? pp_x_stamps + 16 * ((size_t)blockIdx.x * NW + wave) : nullptr;
-  int stamp_k = 3;
-  PP_STAMP(0);
-#endif
   const int p = t[0], r0 = t[1], r1 = t[2], kind = t[4], E0 = t[5], E1 = t[6];
   const int piece = (NW > 1) ? t[12] : 0, npieces = (NW > 1) ? t[13] : 1;   // npieces is the same for all waves of the workgroup
   if (kind < 0 && npieces <= 1) return;            // quad padding (in a split quad the padding waves join the barrier)
@@ -109,9 +93,6 @@ __global__ __launch_bounds__(64 * NW) void k_gather_flat(GroupDev g, int task0, 
   const int uoff = t[8], boff = t[9], doff = t[10];
   const unsigned sub = (unsigned)t[11];
   const int wp = t[14], qoff = t[15];     // width of the whole panel and first column of this task's slice (root front; else w, 0)
-#ifdef PP_X_STAMPS
-  if (stp) { stp[1] = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(E1 < 0); stp[13] = (unsigned long long)(E1 - E0); }
-#endif
   const double* __restrict__ Ub = g.U;
   const double* __restrict__ Lb = g.L;
   const double* __restrict__ Rb = g.rawT;
@@ -159,9 +140,6 @@ __global__ __launch_bounds__(64 * NW) void k_gather_flat(GroupDev g, int task0, 
     const int cnt = min(64, E1 - eb);
     int4 rec = make_int4(0, 0, 0, 0);
     if (lane < cnt) rec = *reinterpret_cast<const int4*>(g.fent + 4 * (size_t)(eb + lane));
-#ifdef PP_X_STAMPS
-    if (stp && eb == E0) stp[2] = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(bcast(rec.x, 0) == 0x7fffffff);
-#endif
     for (int i0 = 0; i0 < cnt; i0 += G) {
       int eu[G], el[G], ew[G], ef[G];
       double su[G][NV], sl[G][WM][NV];
@@ -238,9 +216,6 @@ __global__ __launch_bounds__(64 * NW) void k_gather_flat(GroupDev g, int task0, 
           }
         }
       }
-#ifdef PP_X_STAMPS
-      if (stp && stamp_k < 13) { stp[stamp_k] = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(acc[0][0] == 1.2345e300); ++stamp_k; }
-#endif
     }
   }
   if (split) {
@@ -277,15 +252,6 @@ __global__ __launch_bounds__(64 * NW) void k_gather_flat(GroupDev g, int task0, 
       invert_and_scale<WM>(g, p, w, uoff, doff, sub, r0, r1, tv, true, bpad, (int)b + v, eps);
     }
   }
-#ifdef PP_X_STAMPS
-  if (stp) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    stp[14] = __builtin_amdgcn_s_memrealtime();
-    unsigned hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    stp[15] = hw;
-  }
-#endif
 }
 
 // Lean variant for the wide bottom levels of the tree (a few entries per task, tens of thousands
@@ -674,11 +640,7 @@ __global__ __launch_bounds__(256) void k_chain_front(GroupDev g, int front0, dou
 #pragma unroll 4
     for (int idx = tid; idx < f * w; idx += 256) {
       const int t = idx / w, q = idx - t * w;
-#if defined(PP_X_CHAIN) && PP_X_CHAIN == 3
-      Fp[t * LD + q] = (t == q) ? 1.0 : 0.01;
-#else
       Fp[t * LD + q] = Up[(size_t)idx * bpad];
-#endif
     }
     if (tid < w) tmd[c0 + tid] = g.Tm[((size_t)boff + (size_t)(tid * w + tid)) * bpad + b];
   }
@@ -719,11 +681,9 @@ __global__ __launch_bounds__(256) void k_chain_front(GroupDev g, int front0, dou
         double u[PP_WMAX];
 #pragma unroll
         for (int q = 0; q < PP_WMAX; ++q) u[q] = (q < w) ? fr[min(q, w - 1)] : 0.0;
-#if !defined(PP_X_CHAIN) || PP_X_CHAIN != 2
 #pragma unroll
         for (int q = 0; q < PP_WMAX; ++q)
           if (q < w) Ug[(size_t)(t * w + q) * bpad] = u[q];
-#endif
         if (t >= w) {
 #pragma unroll
           for (int t2 = 0; t2 < PP_WMAX; ++t2) {
@@ -732,9 +692,7 @@ __global__ __launch_bounds__(256) void k_chain_front(GroupDev g, int front0, dou
 #pragma unroll
               for (int t1 = 0; t1 < PP_WMAX; ++t1)
                 if (t1 < w) v += u[t1] * PP_INV(inv, t1, t2);
-#if !defined(PP_X_CHAIN) || PP_X_CHAIN != 2
               Lg[(size_t)(t * w + t2) * bpad] = v;
-#endif
               Lp[(size_t)(c0 + t) * 4 + t2] = v;
               grow = grow || fabs(v) > g.lbound;
             }
@@ -744,9 +702,6 @@ __global__ __launch_bounds__(256) void k_chain_front(GroupDev g, int front0, dou
     }
     if (i + 1 == npan) break;
     __syncthreads();
-#if defined(PP_X_CHAIN) && PP_X_CHAIN == 1
-    continue;
-#endif
     {
       // later columns [c1, W) of the rows [c1, m), four columns of one row per thread
       const int c1 = c0 + w, nr = m - c1, ncg = (W - c1 + 3) >> 2;
@@ -816,14 +771,6 @@ __global__ __launch_bounds__(512) void k_front_invert(GroupDev g, FrontRec fr, d
       A[r][j] = in ? av : 0.0;
     }
   }
-#ifdef PP_X_STAMPS
-  unsigned long long* stp = (pp_x_stamps && lane == 0) ? pp_x_stamps + 4000000 + 16 * ((size_t)blockIdx.x * NWV + wave) : nullptr;
-  int stamp_k = 2;
-  if (stp) stp[0] = __builtin_amdgcn_s_memrealtime();
-#endif
-#ifdef PP_X_STAMPS
-  if (stp) stp[1] = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(m[0] == 1.2345e300);
-#endif
   // The step loop is unrolled: every register index below is a constant (a rolled loop selects the pivot column with
   // compare / select pairs per element: 1.75 us per step, measured).  One barrier per 1x1 step: the buffers of a
   // step are written again two EXECUTED steps later, which every wave reaches only through the barrier of the step in
@@ -909,9 +856,6 @@ __global__ __launch_bounds__(512) void k_front_invert(GroupDev g, FrontRec fr, d
         for (int j = 0; j < WF; ++j) A[orow1][j] = (j == k) ? -i10 : (j == k1) ? -i11 : rk[j] * i10 + rk1[j] * i11;
       }
     }
-#ifdef PP_X_STAMPS
-    if (stp && stamp_k < 15) { stp[stamp_k++] = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(A[0][0] == 1.2345e300); }
-#endif
   }
   {
     // inv(P) = -A: packed by rows of the lower triangle for the solve sweeps, and as a full 16 x 16 matrix (zero beyond
@@ -936,9 +880,6 @@ __global__ __launch_bounds__(512) void k_front_invert(GroupDev g, FrontRec fr, d
     const int code = (c & 255) | (((c >> 8) & 255) << 4) | (((c >> 16) & 255) << 8);
     g.codes[(size_t)fr.piv * bpad + b] = (b < g.batch) ? (unsigned short)code : (unsigned short)0;
   }
-#ifdef PP_X_STAMPS
-  if (stp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stp[15] = __builtin_amdgcn_s_memrealtime(); }
-#endif
 }
 
 // Rows [r0, r1) of the root front: L rows = U rows * inv(P) with the explicit inverse from k_front_invert (the full,
@@ -954,10 +895,6 @@ __global__ __launch_bounds__(192) void k_scale_wide(GroupDev g, const int* __res
   const int r0 = t[1], r1 = t[2], w = fr.w;
   const int c0 = CW * cg;
   if (c0 >= w) return;
-#ifdef PP_X_STAMPS
-  unsigned long long* stp = (pp_x_stamps && lane == 0) ? pp_x_stamps + 4500000 + 16 * ((size_t)blockIdx.x * 3 + cg) : nullptr;
-  if (stp) stp[0] = __builtin_amdgcn_s_memrealtime();
-#endif
   double ic[WF][CW];
   {
     const double* p = finv + (size_t)c0 * bpad + b;      // row t1 of the 16 x 16 matrix, columns c0 ..
@@ -971,14 +908,7 @@ __global__ __launch_bounds__(192) void k_scale_wide(GroupDev g, const int* __res
   const double* Up = g.U + (size_t)fr.uoff * bpad + b;
   double* Lp = g.L + (size_t)fr.uoff * bpad + b;
   double lmax = 0.0;
-#ifdef PP_X_STAMPS
-  if (stp) stp[1] = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(ic[0][0] == 1.2345e300);
-  int stamp_k = 2;
-#endif
   for (int r = r0; r < r1; ++r) {
-#ifdef PP_X_STAMPS
-    if (stp && stamp_k < 15) stp[stamp_k++] = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(lmax == 1.2345e300);
-#endif
     double u[WF];
 #pragma unroll
     for (int t1 = 0; t1 < WF; ++t1) u[t1] = Up[(size_t)(r * w + min(t1, w - 1)) * bpad];    // (columns >= w meet zero rows of inv)
@@ -994,9 +924,6 @@ __global__ __launch_bounds__(192) void k_scale_wide(GroupDev g, const int* __res
       if (c0 + q < w) { Lp[(size_t)(r * w + c0 + q) * bpad] = v[q]; lmax = fmax(lmax, fabs(v[q])); }
   }
   if (lmax > g.lbound && b < g.batch) g.growth[b] = 1;
-#ifdef PP_X_STAMPS
-  if (stp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stp[15] = __builtin_amdgcn_s_memrealtime(); }
-#endif
 }
 
 
@@ -1164,21 +1091,5 @@ int pp_numeric_factor_blocks(pp_handle h) {
   return 0;
 }
 
-#ifdef PP_X_STAMPS
-int pp_x_set_stamps(pp_handle h, void* dev_buffer, int level) {
-  const pp::Plan& P = h->groups[0]->plan;
-  const int task0 = (level >= 0 && level < P.n_levels) ? P.flevel_ptr[level] : -1;
-  if (task0 < 0) {
-    unsigned long long* ptr0 = (unsigned long long*)dev_buffer;
-    PP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(pp_x_stamps), &ptr0, sizeof(ptr0)));
-    PP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(pp_x_stamp_task0), &task0, sizeof(task0)));
-    return 0;
-  }
-  unsigned long long* ptr = (unsigned long long*)dev_buffer;
-  PP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(pp_x_stamps), &ptr, sizeof(ptr)));
-  PP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(pp_x_stamp_task0), &task0, sizeof(task0)));
-  return P.flevel_ptr[level + 1] - P.flevel_ptr[level];
-}
-#endif
 
 }  // extern "C"

@@ -28,6 +28,8 @@
 #include <string>
 #include <vector>
 
+#include "switches.hpp"
+
 #ifndef PP_WMAX
 #define PP_WMAX 4   // widest block pivot (supernode); pivot.hpp / kernels are instantiated for bounds 1, 2, 4 (8 builds too)
 #endif
@@ -143,7 +145,7 @@ inline void tune_for_batch(PlanOptions& o, int batch) {
 // Burgers and the synthetic C4 blocks keep the default (63 ... 66 levels under all three).
 inline void tune_for_mapped_group(PlanOptions& o, int batch) {
   if (batch > 64) {
-    static const char* e = std::getenv("PP_ORDER_CANDIDATES");
+    static const char* e = pp::env_switch("PP_ORDER_CANDIDATES");
     o.order_candidates = e ? std::atoi(e) : 2;
   }
 }

@@ -493,7 +493,7 @@ int pp_numeric_schur_ex(pp_handle h, int side_stream) {
   // that a forward sweep enqueued on the handle's stream right after this call runs beside both
   // MEASURED AND NOT ADOPTED (round 4, C3): 0.825-0.845 ms per step against 0.798 ms with only the dense phase beside the
   // forward sweep -- the Schur update (350 MB of coupling rows) and the sweep compete for the same HBM bandwidth.  Opt-in:
-  static const bool want_side = std::getenv("PP_SCHUR_SIDE") != nullptr;
+  static const bool want_side = pp::env_switch("PP_SCHUR_SIDE") != nullptr;
   h->schur_on_side = side_stream && want_side && h->dense_overlap && h->dense_stream && !h->profile && !h->btd && h->groups.size() <= 2;
   if (h->schur_on_side) {
     PP_HIP(hipEventRecord(h->ev_dense_fork, h->stream));

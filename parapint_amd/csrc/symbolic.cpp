@@ -327,7 +327,7 @@ static int build_plan_ordered(int n, int nc, int nnzK, const int* rowK, const in
         }
         for (int q : N) { if (q >= n) break; blocked[q] = round; }
         ++n_clusters;
-        if (std::getenv("PP_DEBUG_ROUNDS")) {
+        if (pp::env_switch("PP_DEBUG_ROUNDS")) {
           fprintf(stderr, "round %d seed %d width %d N:", round, u, width);
           for (int q : N) fprintf(stderr, " %d", q);
           fprintf(stderr, "\n");

@@ -3,8 +3,8 @@ MA27 / MUMPS / SciPy sub-solver wrappers are replaced by the batched HIP factori
 their single-matrix contract)."""
 from .base_linear_solver_interface import LinearSolverInterface
 from .results import LinearSolverResults, LinearSolverStatus
-from .hip_schur_complement import (HipLDLInterface, HipSchurComplementLinearSolver,
-                                   HipSerialSchurComplementLinearSolver, MumpsInterface, ScipyInterface)
+from .hip_schur_complement import HipSchurComplementLinearSolver, HipSerialSchurComplementLinearSolver
+from .sub_solvers import HipLDLInterface, MumpsInterface, ScipyInterface
 
 # the reference's names for the two classes this package replaces
 SchurComplementLinearSolver = HipSerialSchurComplementLinearSolver

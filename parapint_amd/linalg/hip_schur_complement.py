@@ -30,219 +30,14 @@ from parapint_amd.linalg.results import LinearSolverResults, LinearSolverStatus
 
 _OK = (LinearSolverStatus.successful, LinearSolverStatus.warning)
 
-
-class _NullTimer(object):
-    def start(self, name):
-        pass
-
-    def stop(self, name):
-        pass
+from parapint_amd.linalg._solver_support import (HipEngine, _BY_SEVERITY, _S8, _SEVERITY, _BlockInfo, _Group, _Labels,  # noqa: F401
+                                                  _NullTimer, _PatternChanged, _UnionMatrix, _addr, _canonical, _coo, _flat,
+                                                  _index_intact, _index_record, _roctx)
+from parapint_amd.linalg.coupling_structure import CouplingStructureMixin
+from parapint_amd.linalg.pivot_repair import PivotRepairMixin
 
 
-_ROCTX = None
-
-
-def _roctx():
-    """roctx range functions (rocprofv3 --marker-trace shows the reference's timer labels as ranges), or False."""
-    global _ROCTX
-    if _ROCTX is None:
-        _ROCTX = False
-        import os
-        if os.environ.get('PP_ROCTX', '0') not in ('', '0'):
-            import ctypes
-            for name in ('librocprofiler-sdk-roctx.so', 'libroctx64.so'):
-                try:
-                    lib = ctypes.CDLL(name)
-                    lib.roctxRangePushA.argtypes = [ctypes.c_char_p]
-                    _ROCTX = (lib.roctxRangePushA, lib.roctxRangePop)
-                    break
-                except (OSError, AttributeError):
-                    continue
-    return _ROCTX
-
-
-class _Labels(object):
-    """The reference's HierarchicalTimer labels (mpi_...:207-255, 291-360), mirrored as roctx ranges when PP_ROCTX=1."""
-
-    def __init__(self, timer):
-        self._t = _NullTimer() if timer is None else timer
-        self._r = _roctx()
-
-    def start(self, name):
-        self._t.start(name)
-        if self._r:
-            self._r[0](name.encode())
-
-    def stop(self, name):
-        if self._r:
-            self._r[1]()
-        self._t.stop(name)
-
-
-from parapint_amd.linalg.hip_engine import (HipEngine, _S8, _addr, _checksum, _index_intact,  # noqa: F401 (HipEngine: re-exported)
-                                            _index_record)
-
-
-def _flat(v):
-    return v.flatten() if hasattr(v, 'get_block') else np.asarray(v, dtype=np.double).ravel()
-
-
-def _coo(block):
-    """(row, col, data) of a SciPy sparse matrix or (nested) BlockMatrix block."""
-    if getattr(block, 'format', None) == 'coo':          # (1024 blocks per call: skip tocoo() / asarray() when there is nothing to do)
-        d = block.data
-        return block.row, block.col, d if d.dtype == np.double else d.astype(np.double), block.shape
-    c = block.tocoo()
-    return c.row, c.col, np.asarray(c.data, dtype=np.double), c.shape
-
-
-def _canonical(row, col, ncols, lower_only):
-    """Unique (sorted) pattern of the entries kept, and the CSR map canonical -> raw indices."""
-    if lower_only:
-        idx = np.flatnonzero(row >= col)
-        key = col[idx].astype(np.int64) * ncols + row[idx]        # column-major order of tril
-    else:
-        idx = np.arange(row.size)
-        key = row.astype(np.int64) * ncols + col
-    order = np.argsort(key, kind='stable')
-    ks = key[order]
-    first = np.ones(ks.size, dtype=bool)
-    first[1:] = ks[1:] != ks[:-1]
-    starts = np.flatnonzero(first)
-    can_ptr = np.concatenate([starts, [ks.size]]).astype(np.int32)
-    can_idx = idx[order].astype(np.int32)
-    uk = ks[first]
-    if lower_only:
-        crow, ccol = (uk % ncols).astype(np.int32), (uk // ncols).astype(np.int32)
-    else:
-        crow, ccol = (uk // ncols).astype(np.int32), (uk % ncols).astype(np.int32)
-    return crow, ccol, can_ptr, can_idx
-
-
-class _PatternChanged(Exception):
-    """A block carries entries outside the pattern the plan was made for (e.g. the diagonal blocks the
-    inertia-correction loop adds, interior_point.py:377-378 / sc_ip_interface.py:1736-1757)."""
-
-
-class _UnionMatrix(object):
-    """Minimal block-matrix view (the protocol of SURVEY 8b) over per-block COO matrices; used to re-plan on
-    the union of the old and the new pattern."""
-
-    def __init__(self, nb, blocks, nc):
-        self.bshape = (nb, nb)
-        self._blocks = blocks
-        self._nc = nc
-
-    def get_block(self, i, j):
-        return self._blocks.get((i, j))
-
-    def get_row_size(self, i):
-        return self._nc if i == self.bshape[0] - 1 else self._blocks[(i, i)].shape[0]
-
-
-class _BlockInfo(object):
-    __slots__ = ('group', 'slot', 'raw_sig', 'n', 'cmap', 'br_cache', 'seen')
-
-
-class _Group(object):
-    """Host-side description of one pattern group (blocks sharing tril(K_i) and A_i patterns)."""
-
-    def __init__(self, n, rowK, colK, rowB, colB, can_ptr, can_idx, nrawK, nraw, raw_refs):
-        self.n = n
-        self.rowK, self.colK, self.rowB, self.colB = rowK, colK, rowB, colB
-        self.can_ptr, self.can_idx = can_ptr, can_idx
-        self.nrawK, self.nraw = nrawK, nraw
-        self.raw_refs = raw_refs            # (rowK_raw, colK_raw, rowB_raw, colB_raw) of the reference block
-        self.blocks = []                    # block indices, slot order
-        self.rep_vals = None
-        self._alloc = None                  # (shape, pinned if possible) -> zeroed host array; set by the solver
-        self._staging = self._rhs_staging = self._x_pool = None     # host boundary buffers, allocated at first use
-        self.result_buffers = 0
-        self.x_shape = None
-        self.alt_layouts = []               # other raw COO layouts seen: (kr, kc, br, bc, canonical position per entry)
-        self._keyK = None
-        self._keyB = None
-        # compact staging: only the raw entries some canonical entry reads are staged and uploaded
-        self.used = np.unique(can_idx).astype(np.int64) if can_idx.size else np.zeros(0, dtype=np.int64)
-        cpos = -np.ones(max(nraw, 1), dtype=np.int64)
-        cpos[self.used] = np.arange(self.used.size)
-        self.can_cidx = cpos[can_idx] if can_idx.size else np.zeros(0, dtype=np.int64)   # compact position of every raw duplicate
-        self.runsK, self.runsB = self._runs(self.used, nrawK)
-        self.known_ptrs = {}                # id(index array) -> array: verified equal to the reference arrays (kept alive)
-        # set by the solver class (all state a group can carry is named here)
-        self.gid = -1                       # index of the group in the library
-        self.m = 0                          # coupling rows of a block of this group (local rows for mapped groups)
-        self.cmaps = []                     # per block: local -> global coupling rows (mapped groups), else None
-        self.x_turn, self.x_pinned = 0, None                       # result buffers of the host boundary
-        self.device_sources = None          # [nsrc][padded batch] tensor the factorisation reads its values from (f2)
-        self.refresh_futile = 0             # pivot-order refreshes in a row that did not cure a breakdown
-        self.refresh_skip = 0               # breakdowns still to be reported `singular` at once (opt-in back-off)
-        self.futile_vals = None             # representative values of the last futile refresh
-        self._ref32 = self._refptr = None   # int32 copies of raw_refs and their addresses (stage_upload)
-
-    # Buffers of the HOST boundary (page-locked when the engine can: ~12 ms per allocation).  A caller that keeps values,
-    # right-hand sides and solutions on the device (rows f2/f4) never touches them, so they are made at first use.
-    @property
-    def staging(self):
-        """Compact rows: only the entries that are read."""
-        if self._staging is None:
-            self._staging = self._alloc((len(self.blocks), self.used.size))
-        return self._staging
-
-    @property
-    def rhs_staging(self):
-        if self._rhs_staging is None:
-            self._rhs_staging = self._alloc((len(self.blocks), self.n))
-        return self._rhs_staging
-
-    @property
-    def x_pool(self):
-        if self._x_pool is None:
-            self._x_pool = [self._alloc(self.x_shape, pinned_only=True) for _ in range(self.result_buffers)]
-            if any(a is None for a in self._x_pool):
-                self._x_pool = []
-        return self._x_pool
-
-    @staticmethod
-    def _runs(used, nrawK):
-        """Maximal runs of consecutive used raw entries as {source start, length, destination} triples, split at the
-        boundary between the K data and the border data (include/parapint_hip.h: pp_stage_values_runs)."""
-        runsK, runsB = [], []
-        if used.size:
-            brk = np.flatnonzero(np.diff(used) != 1) + 1
-            starts = np.concatenate([[0], brk])
-            ends = np.concatenate([brk, [used.size]])
-            for a, b in zip(starts, ends):
-                e0, e1 = int(used[a]), int(used[b - 1]) + 1
-                if e0 < nrawK < e1:                       # a run across the boundary
-                    runsK.append((e0, nrawK - e0, a))
-                    runsB.append((0, e1 - nrawK, a + nrawK - e0))
-                elif e0 < nrawK:
-                    runsK.append((e0, e1 - e0, a))
-                else:
-                    runsB.append((e0 - nrawK, e1 - e0, a))
-        return (np.asarray(runsK, dtype=np.int64).reshape(-1, 3), np.asarray(runsB, dtype=np.int64).reshape(-1, 3))
-
-    def canonical_from_compact(self, row):
-        """Canonical values (duplicates summed) from one compact staging row."""
-        return np.add.reduceat(row[self.can_cidx], self.can_ptr[:-1]) if self.can_cidx.size else np.zeros(0)
-
-    def keys(self):
-        """Sorted int64 keys of the canonical K (column-major tril) and border (row-major) patterns."""
-        if self._keyK is None:
-            self._keyK = self.colK.astype(np.int64) * self.n + self.rowK
-            self._keyB = self.rowB.astype(np.int64) * self.n + self.colB
-        return self._keyK, self._keyB
-
-
-# Severity of a status when ranks disagree: the reference lets the first failing status win (mpi_...:19-30,
-# explicit_...:9-13); with one reduction the worst one wins, `warning` being the mildest non-success.
-_SEVERITY = {LinearSolverStatus.successful: 0, LinearSolverStatus.warning: 1, LinearSolverStatus.not_enough_memory: 2,
-             LinearSolverStatus.singular: 3, LinearSolverStatus.error: 4}
-_BY_SEVERITY = {v: k for k, v in _SEVERITY.items()}
-
-
-class HipSchurComplementLinearSolver(LinearSolverInterface):
+class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, LinearSolverInterface):
     """Solve A x = b for block-bordered-diagonal symmetric A (lower border supplied)::
 
           K1          transpose(A1)
@@ -532,118 +327,6 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         loc = loc.astype(np.int32)
         bi.br_cache = (key, loc, br)                      # (the global array is kept alive with its pointer)
         return loc, bc, bd
-
-    def _coupling_structure(self, matrix, groups):
-        """Dense S, or -- for mapped groups whose cliques form a band (the time blocks of a dynamic problem only touch
-        the coupling variables of their own two links) -- an ordering and a block size under which S is block
-        tridiagonal.  The reference keeps S sparse for the same reason (mpi_...:88-125, 228-255).  Collective."""
-        nc = self._nc
-        self._cperm = self._cinv = None
-        self._btd = None
-        if not self._mapped or not getattr(self._eng, 'supports_block_tridiagonal', False) or nc <= self._dense_coupling_limit:
-            return
-        from scipy.sparse import coo_matrix
-        from scipy.sparse.csgraph import reverse_cuthill_mckee
-        # every rank needs the cliques of all blocks: one sum all-reduce of a [blocks][m_max + 1] table
-        nb = self.block_dim - 1
-        mmax = max([g.m for g in groups] + [0])
-        if self.comm.size > 1:
-            mmax = int(self.comm.allreduce_max(np.array([mmax], dtype=np.int64))[0])
-        table = np.zeros((nb, mmax + 1), dtype=np.int64)
-        for g in groups:
-            for ndx, cm in zip(g.blocks, g.cmaps):
-                table[ndx, 0] = cm.size
-                table[ndx, 1:1 + cm.size] = cm + 1
-        if self.comm.size > 1:
-            table = self.comm.allreduce_sum(table.astype(np.double)).astype(np.int64)
-        cliques = [table[ndx, 1:1 + table[ndx, 0]] - 1 for ndx in range(nb)]
-        Qb = matrix.get_block(self.block_dim - 1, self.block_dim - 1)
-        Qc = Qb.tocoo() if Qb is not None else None
-        self._btd_sequential = False
-        # (1) natural blocks: the coupling rows every time block touches (merged where blocks overlap) are the diagonal
-        # blocks of S; if Q only links consecutive ones, S is block tridiagonal in that order.  These blocks are what the
-        # problem's own structure makes well-posed (a block's clique is the Schur contribution of ONE K_t), so that the
-        # odd-even elimination order of cyclic reduction meets no singular diagonal block.
-        parent = np.arange(nc)
-
-        def find(a):
-            while parent[a] != a:
-                parent[a] = parent[parent[a]]
-                a = parent[a]
-            return a
-        for cm in cliques:
-            for v in cm[1:]:
-                ra, rb = find(int(cm[0])), find(int(v))
-                if ra != rb:
-                    parent[rb] = ra
-        root = np.array([find(i) for i in range(nc)])
-        atoms, atom_of = np.unique(root, return_inverse=True)
-        na = atoms.size
-        if 3 <= na and Qc is not None:
-            a_r, a_c = atom_of[Qc.row], atom_of[Qc.col]
-            off = a_r != a_c
-            AG = coo_matrix((np.ones(int(off.sum()) + na), (np.concatenate([a_r[off], np.arange(na)]),
-                                                           np.concatenate([a_c[off], np.arange(na)]))), shape=(na, na)).tocsr()
-            aperm = np.asarray(reverse_cuthill_mckee(AG, symmetric_mode=True), dtype=np.int64)
-            apos = np.empty(na, dtype=np.int64)
-            apos[aperm] = np.arange(na)
-            path = (not off.any()) or int(np.abs(apos[a_r[off]] - apos[a_c[off]]).max()) <= 1
-            if path:
-                # blocks straddle the cliques: a variable linked by Q to the NEXT clique opens a block, one linked to the
-                # PREVIOUS clique closes the block before -- block p = (forward-linked part of clique p) + (backward-
-                # linked part of clique p + 1), i.e. the pairs Q ties together (for a time-staged problem: the duals of the
-                # forward links of block t with the coupling states z_t).  Diagonal blocks that contain such pairs stay
-                # well conditioned under any elimination order; the cliques themselves do not (a clique block is a
-                # principal submatrix of inv(K_t), rank deficient up to rounding when a time block has few controls).
-                pos_v = apos[atom_of]
-                back = np.zeros(nc, dtype=bool)
-                d = apos[a_c] - apos[a_r]
-                back[Qc.row[d == -1]] = True                       # a Q partner in the previous clique
-                fwd = np.zeros(nc, dtype=bool)
-                fwd[Qc.row[d == 1]] = True
-                blk = np.where(back & ~fwd, pos_v - 1, pos_v)
-                used, blk = np.unique(blk, return_inverse=True)    # drop empty blocks, keep the order
-                G = used.size
-                ok = True
-                for cm in cliques:
-                    if cm.size and int(blk[cm].max() - blk[cm].min()) > 1:
-                        ok = False
-                if ok and int(np.abs(blk[Qc.row] - blk[Qc.col]).max()) <= 1 and G >= 3:
-                    sizes = np.bincount(blk, minlength=G)
-                    gs = int(sizes.max())
-                    if gs <= 512:
-                        order = np.argsort(blk, kind='stable')
-                        start = np.concatenate([[0], np.cumsum(sizes)])
-                        within = np.zeros(nc, dtype=np.int64)
-                        within[order] = np.arange(nc) - start[blk[order]]
-                        inv = blk * gs + within
-                        pad_map = -np.ones(G * gs, dtype=np.int64)
-                        pad_map[inv] = np.arange(nc)
-                        self._cperm, self._cinv, self._cperm_pad = pad_map[pad_map >= 0], inv, pad_map
-                        self._btd = (gs, G)
-                        return
-        # (2) otherwise: a bandwidth-reducing ordering cut into blocks of the bandwidth, eliminated in ascending order
-        rows, cols = [np.arange(nc)], [np.arange(nc)]
-        for cm in cliques:
-            rows.append(np.repeat(cm, cm.size))
-            cols.append(np.tile(cm, cm.size))
-        if Qc is not None:
-            rows += [Qc.row, Qc.col]
-            cols += [Qc.col, Qc.row]
-        rows, cols = np.concatenate(rows), np.concatenate(cols)
-        P = coo_matrix((np.ones(rows.size), (rows, cols)), shape=(nc, nc)).tocsr()
-        perm = np.asarray(reverse_cuthill_mckee(P, symmetric_mode=True), dtype=np.int64)     # new -> old
-        inv = np.empty(nc, dtype=np.int64)
-        inv[perm] = np.arange(nc)
-        hb = int(np.abs(inv[rows] - inv[cols]).max())
-        gs = max(hb, 1)
-        G = -(-nc // gs)
-        if gs > 512 or G < 3:
-            return                                      # not banded enough: dense S
-        self._cperm, self._cinv = perm, inv
-        self._cperm_pad = np.concatenate([perm, -np.ones(gs * G - nc, dtype=np.int64)])     # new (padded) -> old, -1: padding
-        self._btd = (gs, G)
-        self._btd_sequential = True
 
     @staticmethod
     def _layout_positions(g, kr, kc, br, bc):
@@ -992,116 +675,6 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             raise RuntimeError('Numeric factorization unsuccessful; status: ' + str(res.status))
         return res
 
-    def _note_refresh_outcome(self, cured):
-        for g in self._refreshed:
-            g.refresh_futile = 0 if cured else g.refresh_futile + 1
-            g.futile_vals = None if cured else g.rep_vals
-            if self.refresh_backoff:
-                g.refresh_skip = 0 if cured else min(2 ** g.refresh_futile - 1, 63)
-
-    def _refresh_pivot_order(self, shift=None):
-        """New pivot sequences for the groups that hold a broken block, from that block's values (with `shift` =
-        (delta_w, delta_c): + the diagonal shift of the classed rows, as the regularised matrix of the host path has
-        them).  Collective: every rank learns whether any rank re-planned (all of them then factorise again)."""
-        mine = 0
-        self._refreshed = []
-        for g in self._groups:
-            slot = self._eng.find_zero_pivot(g.gid)
-            if slot >= 0 and g.refresh_skip > 0:
-                # (refresh_backoff, opt-in) new sequences for this group have not cured its breakdowns lately: after the
-                # k-th futile refresh in a row the next 2^k - 1 breakdowns (at most 63) go to the caller as `singular`
-                g.refresh_skip -= 1
-                self.refreshes_skipped += 1
-                continue
-            if slot >= 0:
-                self.refresh_causes['zero_pivot'] += 1
-            elif self._growth_guard:
-                slot = self._eng.find_growth(g.gid)     # element growth beyond 1 / pivot_tolerance counts as a breakdown
-                if slot >= 0:
-                    self.refresh_causes['growth'] += 1
-            if slot >= 0:
-                t = g.device_sources
-                if self._device_maps is not None and t is not None:
-                    # device-resident values (f2): that instance's sources come to the host once
-                    src, coef = self._device_maps[1][g.blocks[0]]
-                    col = t[:, slot].cpu().numpy()
-                    src = np.asarray(src)
-                    raw = np.asarray(coef, dtype=np.double) * np.where(src >= 0, col[np.maximum(src, 0)], 1.0)
-                    vals = np.add.reduceat(raw[g.can_idx], g.can_ptr[:-1]) if g.can_idx.size else np.zeros(0)
-                else:
-                    vals = g.canonical_from_compact(g.staging[slot])
-                if shift is not None and self._classes:
-                    cls = self._classes[g.blocks[0]]
-                    nK = g.rowK.size
-                    diag = np.flatnonzero(g.rowK == g.colK)
-                    rows = g.rowK[diag]
-                    vals = np.array(vals, dtype=np.double)
-                    vals[:nK][diag] += np.where(cls[rows] == 1, shift[0], np.where(cls[rows] == 2, -shift[1], 0.0))
-                if g.futile_vals is not None and g.futile_vals.shape == vals.shape and np.array_equal(g.futile_vals, vals):
-                    # exactly the values the last refresh was planned from, and that plan broke on them as well
-                    self.refreshes_skipped += 1
-                    continue
-                g.rep_vals = vals
-                g.refresh_block = g.blocks[slot]
-                mine = 1
-                self._refreshed.append(g)
-        anyone = mine
-        if self.comm.size > 1:
-            anyone = int(self.comm.allreduce_max(np.array([mine], dtype=np.int64))[0])
-        if mine:
-            steps = self.refresh_thresholds
-            if steps and hasattr(self._eng, 'set_pivot_tolerance'):
-                u = steps[min(self.pivot_order_refreshes_since_symbolic, len(steps) - 1)]
-                if u > max(self._u_symbolic_now, 0.01):
-                    self._u_symbolic_now = u
-                    self._eng.set_pivot_tolerance(u, self._u_user[1])
-            self.pivot_order_refreshes += 1
-            self.pivot_order_refreshes_since_symbolic += 1
-            self._run_symbolic()
-        return bool(anyone)
-
-    def _split_conflicting(self, matrix):
-        """After a refresh: a group whose new sequence (planned from block A) broke on a block B != A holds instances that
-        need different sequences.  B moves to the next variant of the pattern group (the blocks of a variant share one plan,
-        made from the first of them), the groups are built and planned again on the values of `matrix`.  Returns whether
-        anything moved.  A block that breaks under the sequence planned from ITSELF is singular: nothing to split.
-        Collective (the coupling structure is agreed by all ranks when the groups are rebuilt)."""
-        moved = 0
-        for g in self._groups:
-            if len(g.blocks) < 2:
-                continue
-            slot = self._eng.find_zero_pivot(g.gid)
-            if slot < 0:
-                continue
-            ndx = g.blocks[slot]
-            planned_from = getattr(g, 'refresh_block', g.blocks[0])
-            if ndx == planned_from:
-                continue
-            v = self._variant.get(ndx, 0) + 1
-            if v >= self.max_group_variants:
-                continue
-            self._variant[ndx] = v
-            moved += 1
-        anyone = moved
-        if self.comm.size > 1:
-            anyone = int(self.comm.allreduce_max(np.array([moved], dtype=np.int64))[0])
-        if not anyone:
-            return False
-        self.group_splits += moved
-        planned = {ndx: getattr(self._binfo[ndx].group, 'refresh_block', None) for ndx in self.local_block_indices}
-        self._build_groups(matrix)
-        for g in self._groups:                         # (a group keeps the block its sequence was planned from, if it still holds it)
-            keep = planned.get(g.blocks[0])
-            g.refresh_block = keep if keep in g.blocks else g.blocks[0]
-            if keep in g.blocks and keep != g.blocks[0]:
-                slot = g.blocks.index(keep)
-                kr, kc, kd, _ = _coo(matrix.get_block(keep, keep))
-                br, bc, bd = self._border(matrix, keep)
-                g.rep_vals = self._canonical_values(g, np.concatenate([kd, bd]), kr, kc, br, bc, self._binfo[keep].raw_sig)
-        self._run_symbolic()
-        self._pattern_only = False
-        return True
-
     def _numeric_factorization(self, matrix, timer=None):
         timer = _Labels(timer)
         if self.block_dim == 0:
@@ -1183,46 +756,6 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
             self._pattern_only = False
             for g in self._groups:                           # (the new plan's device buffers are empty)
                 self._eng.upload_values_compact(g.gid, g.staging)
-
-    def _btd_corner(self, Q):
-        """Symmetric sparse Q (or None) -> (positions, values) in the block-tridiagonal layout of the Schur buffer in the
-        permuted order (duplicates add), with a unit diagonal on the padding rows."""
-        gs, G = self._btd
-        g2 = gs * gs
-        pad = np.flatnonzero(self._cperm_pad < 0)
-        pos = [(pad // gs) * g2 + (pad % gs) * (gs + 1)]
-        val = [np.ones(pad.size)]
-        if Q is not None:
-            from scipy.sparse import coo_matrix as _coo_m
-            Qc = _coo_m(Q)
-            i, j, v = Qc.row, Qc.col, Qc.data
-            pi, pj = self._cinv[i], self._cinv[j]
-            bi_, bj_ = pi // gs, pj // gs
-            same = bi_ == bj_
-            pos.append(bi_[same] * g2 + (pi[same] % gs) + (pj[same] % gs) * gs)
-            val.append(v[same])
-            low = bi_ == bj_ + 1                          # E_t = S(block t+1, block t): only this orientation is stored
-            pos.append(G * g2 + bj_[low] * g2 + (pi[low] % gs) + (pj[low] % gs) * gs)
-            val.append(v[low])
-            if np.any(~same & ~low & (bj_ != bi_ + 1)):
-                raise RuntimeError('coupling block Q has entries outside the block-tridiagonal structure')
-        return np.concatenate(pos).astype(np.int64), np.concatenate(val).astype(np.float64)
-
-    def _btd_q(self, Q):
-        """The same as one flat array in the layout of the Schur buffer (tests, host interpreter)."""
-        gs, G = self._btd
-        flat = np.zeros((2 * G - 1) * gs * gs)
-        pos, val = self._btd_corner(Q)
-        np.add.at(flat, pos, val)
-        return flat
-
-    def _to_coupling_order(self, v):
-        """Coupling vector in the caller's order -> the library's (permuted, padded) order."""
-        if self._btd is None:
-            return v
-        out = np.zeros(self._btd[0] * self._btd[1])
-        out[self._cinv] = v
-        return out
 
     def _from_coupling_order(self, v):
         return v if self._btd is None else np.ascontiguousarray(v[self._cinv])
@@ -1615,195 +1148,14 @@ class HipSchurComplementLinearSolver(LinearSolverInterface):
         real = (self._cperm_pad[pr] >= 0) & (self._cperm_pad[pc] >= 0)
         return coo_matrix((vals[real], (self._cperm_pad[pr[real]], self._cperm_pad[pc[real]])), shape=(self._nc, self._nc))
 
-
 # The serial class of the reference (explicit_schur_complement.py:16) is the same algebra without
 # ownership: a BlockMatrix has no rank_ownership, so every block is local.
 HipSerialSchurComplementLinearSolver = HipSchurComplementLinearSolver
 
 
-class HipLDLInterface(LinearSolverInterface):
-    """Single-matrix sub-solver with the MA27 wrapper's semantics
-    (parapint/linalg/ma27_interface.py:9-256): tril is authoritative, inertia is
-    (n - neg, neg, 0) on success, singular matrices come back as LinearSolverStatus.singular.
-    Implemented as a one-block, zero-coupling instance of the batched solver."""
-
-    @classmethod
-    def getLoggerName(cls):
-        return 'hip_ldl'
-
-    def __init__(self, cntl_options=None, icntl_options=None, iw_factor=1.2, a_factor=2, engine=None):
-        """Same keywords as the reference wrapper (ma27_interface.py:36).  ``cntl_options[1]`` -- MA27's pivot tolerance
-        u -- becomes the run-time growth bound |l_ij| <= 1/u of every factorisation and (if larger than the default
-        0.01) the threshold of the static pivot choice; the other MA27 controls and the workspace factors have no
-        counterpart (storage is sized exactly by the symbolic phase) and are accepted and recorded only."""
-        from parapint_amd.sparse.block_containers import BlockMatrix
-        self._BlockMatrix = BlockMatrix
-        self.cntl_options = dict(cntl_options or {})
-        self.icntl_options = dict(icntl_options or {})
-        self.iw_factor, self.a_factor = iw_factor, a_factor
-        self._engine_arg = engine
-        self._sc_made = None
-        self._dim = None
-        self._num_status = None
-
-    @property
-    def _sc(self):
-        """The one-block solver behind this interface, created at first use: the reference's callers build one sub-solver
-        object per block (``{ndx: InteriorPointMA27Interface(...) for ndx in ...}``) and hand them to the Schur-complement
-        solver, which here factorises all blocks as one batch and never calls them -- such placeholders must not each
-        open a device handle."""
-        if self._sc_made is None:
-            u = self.cntl_options.get(1)
-            self._sc_made = HipSchurComplementLinearSolver(
-                comm=SerialComm(), engine=self._engine_arg, pivot_tolerance=u,
-                symbolic_pivot_threshold=None if u is None else max(min(u, 0.5), 0.01))
-        return self._sc_made
-
-    def _wrap(self, matrix):
-        from scipy.sparse import coo_matrix
-        n = matrix.shape[0]
-        bm = self._BlockMatrix(2, 2)
-        bm.set_block(0, 0, matrix)
-        bm.set_block(1, 0, coo_matrix((0, n)))
-        bm.set_block(1, 1, coo_matrix((0, 0)))
-        return bm
-
-    def do_symbolic_factorization(self, matrix, raise_on_error=True, timer=None):
-        self._num_status = None
-        nrows, ncols = matrix.shape
-        if nrows != ncols:
-            raise ValueError('Matrix must be square')
-        self._dim = nrows
-        return self._sc.do_symbolic_factorization(self._wrap(matrix), raise_on_error=raise_on_error, timer=timer)
-
-    def do_numeric_factorization(self, matrix, raise_on_error=True, timer=None):
-        if self._dim is None:
-            raise RuntimeError('Perform symbolic factorization first!')
-        nrows, ncols = matrix.shape
-        if nrows != ncols:
-            raise ValueError('Matrix must be square')
-        if nrows != self._dim:
-            raise ValueError('Matrix dimensions do not match the dimensions of '
-                             'the matrix used for symbolic factorization')
-        res = self._sc.do_numeric_factorization(self._wrap(matrix), raise_on_error=raise_on_error, timer=timer)
-        self._num_status = res.status
-        return res
-
-    def do_back_solve(self, rhs):
-        from parapint_amd.sparse.block_containers import BlockVector
-        flat = _flat(rhs)
-        bv = BlockVector(2)
-        bv.set_block(0, flat)
-        bv.set_block(1, np.zeros(0))
-        x = self._sc.do_back_solve(bv).get_block(0)
-        if hasattr(rhs, 'get_block'):
-            out = rhs.copy_structure()
-            out.copyfrom(x)
-            return out
-        return x
-
-    def get_inertia(self):
-        if self._num_status is None:
-            raise RuntimeError('Must call do_numeric_factorization before inertia can be computed')
-        if self._num_status != LinearSolverStatus.successful:
-            raise RuntimeError('Can only compute inertia if the numeric factorization was successful.')
-        return self._sc.get_inertia()
-
-    def increase_memory_allocation(self, factor):
-        self._sc.increase_memory_allocation(factor)
-
-
-class MumpsInterface(HipLDLInterface):
-    """The reference's MUMPS wrapper by name and constructor (parapint/linalg/mumps_interface.py:11-229): ``par``,
-    ``comm``, ``cntl_options``, ``icntl_options`` are accepted; CNTL(1) -- MUMPS's relative pivot threshold -- is the run-time
-    growth bound, ICNTL(13) / ICNTL(24) are forced as the reference forces them (exact inertia: null pivots are counted,
-    not perturbed), the pattern may change between numeric calls (the plan is made again on the union, as
-    ``mumps_interface.py:82-83`` re-analyses), and inertia is (n - neg - zero, neg, zero) with the null pivots of
-    INFOG(28) (:122-126).  The workspace protocol (ICNTL(23), :105-115) maps to the device value-storage budget."""
-
-    @classmethod
-    def getLoggerName(cls):
-        return 'mumps'
-
-    def __init__(self, par=1, comm=None, cntl_options=None, icntl_options=None, engine=None, memory_budget_bytes=None):
-        icntl = dict(icntl_options or {})
-        icntl.setdefault(13, 1)
-        icntl.setdefault(24, 0)
-        HipLDLInterface.__init__(self, cntl_options=cntl_options, icntl_options=icntl, engine=engine)
-        self.par, self.mumps_comm = par, comm
-        self._prev_allocation = 0
-        self._budget_given = memory_budget_bytes is not None
-        if memory_budget_bytes is not None:
-            self._sc._eng.set_memory_budget(memory_budget_bytes)
-            self._prev_allocation = int(memory_budget_bytes)
-
-    def set_icntl(self, key, value):
-        if key == 13 and value <= 0:
-            raise ValueError('ICNTL(13) must be positive for the MumpsInterface.')
-        if key == 24 and value != 0:
-            raise ValueError('ICNTL(24) must be 0 for the MumpsInterface.')
-        self.icntl_options[key] = value
-
-    def set_cntl(self, key, value):
-        self.cntl_options[key] = value
-
-    def get_icntl(self, key):
-        return self.icntl_options.get(key, 0)
-
-    def get_cntl(self, key):
-        return self.cntl_options.get(key, 0.0)
-
-    def get_infog(self, key):
-        """INFOG(12): negative pivots, INFOG(28): null pivots, INFOG(16) / (18): value storage the plan needs / holds, MB."""
-        if key in (12, 28):
-            pos, neg, zero = self._sc._inertia if self._sc._inertia is not None else (0, 0, 0)
-            return neg if key == 12 else zero
-        if key in (16, 18):
-            need, have, _ = self._sc._eng.memory_info() if hasattr(self._sc._eng, 'memory_info') else (0, 0, 0)
-            return int(round((need if key == 16 else have) / 1e6))
-        raise KeyError('INFOG(%d) has no counterpart' % key)
-
-    get_info = get_infog
-
-    def get_inertia(self):
-        if self._num_status is None:
-            raise RuntimeError('Must call do_numeric_factorization before inertia can be computed')
-        if self._sc._inertia is None:
-            raise RuntimeError('Can only compute inertia if the numeric factorization was successful.')
-        return tuple(int(v) for v in self._sc._inertia)          # null pivots are reported, as INFOG(28) is
-
-    def do_symbolic_factorization(self, matrix, raise_on_error=True, timer=None):
-        res = HipLDLInterface.do_symbolic_factorization(self, matrix, raise_on_error=raise_on_error, timer=timer)
-        if not self._budget_given:
-            self._prev_allocation = self.get_infog(16)          # MB the plan needs (mumps_interface.py:60)
-        return res
-
-    def increase_memory_allocation(self, factor):
-        """mumps_interface.py:105-115: the new allocation (ICNTL(23), MB; bytes if the budget was given in bytes) is
-        factor x the previous one (1 if that rounded to zero) and is returned."""
-        self._sc.increase_memory_allocation(factor)
-        new_allocation = 1 if self._prev_allocation == 0 else factor * self._prev_allocation
-        if not self._budget_given:
-            self.icntl_options[23] = new_allocation
-        self._prev_allocation = new_allocation
-        return new_allocation
-
-
-class ScipyInterface(HipLDLInterface):
-    """The reference's SciPy wrapper by name and constructor (parapint/linalg/scipy_interface.py:11-67).  Its general-LU
-    semantics (both triangles read, unsymmetric matrices accepted: quirk Q5) are NOT offered: the lower triangle defines
-    the matrix, as for the MA27 / MUMPS wrappers.  ``compute_inertia`` keeps its meaning: without it ``get_inertia``
-    raises (:64-67)."""
-
-    @classmethod
-    def getLoggerName(cls):
-        return 'scipy'
-
-    def __init__(self, compute_inertia=False, engine=None):
-        HipLDLInterface.__init__(self, engine=engine)
-        self.compute_inertia = compute_inertia
-
-    def get_inertia(self):
-        if not self.compute_inertia:
-            raise RuntimeError('The intertia was not computed during factorization. Set compute_inertia to True.')
-        return HipLDLInterface.get_inertia(self)
+def __getattr__(name):
+    # (the single-matrix adapters live in sub_solvers.py, which imports this module: resolved on first use)
+    if name in ('HipLDLInterface', 'MumpsInterface', 'ScipyInterface'):
+        from parapint_amd.linalg import sub_solvers
+        return getattr(sub_solvers, name)
+    raise AttributeError(name)

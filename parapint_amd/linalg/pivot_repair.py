@@ -1,0 +1,120 @@
+"""Static pivot sequences that break down on later values: refresh and group splitting (mixin of
+HipSchurComplementLinearSolver).  MA27 pivots every block dynamically on its own values (ma27_interface.py:110-140) and
+reports `singular` only for a singular matrix; the batched factorisation fixes one sequence per pattern group, so a
+breakdown is first answered by a new sequence from the values that broke, and -- when two instances of one group need
+different sequences -- by splitting the group into variants."""
+import numpy as np
+
+from parapint_amd.linalg._solver_support import _coo
+
+
+class PivotRepairMixin(object):
+    def _note_refresh_outcome(self, cured):
+        for g in self._refreshed:
+            g.refresh_futile = 0 if cured else g.refresh_futile + 1
+            g.futile_vals = None if cured else g.rep_vals
+            if self.refresh_backoff:
+                g.refresh_skip = 0 if cured else min(2 ** g.refresh_futile - 1, 63)
+
+    def _refresh_pivot_order(self, shift=None):
+        """New pivot sequences for the groups that hold a broken block, from that block's values (with `shift` =
+        (delta_w, delta_c): + the diagonal shift of the classed rows, as the regularised matrix of the host path has
+        them).  Collective: every rank learns whether any rank re-planned (all of them then factorise again)."""
+        mine = 0
+        self._refreshed = []
+        for g in self._groups:
+            slot = self._eng.find_zero_pivot(g.gid)
+            if slot >= 0 and g.refresh_skip > 0:
+                # (refresh_backoff, opt-in) new sequences for this group have not cured its breakdowns lately: after the
+                # k-th futile refresh in a row the next 2^k - 1 breakdowns (at most 63) go to the caller as `singular`
+                g.refresh_skip -= 1
+                self.refreshes_skipped += 1
+                continue
+            if slot >= 0:
+                self.refresh_causes['zero_pivot'] += 1
+            elif self._growth_guard:
+                slot = self._eng.find_growth(g.gid)     # element growth beyond 1 / pivot_tolerance counts as a breakdown
+                if slot >= 0:
+                    self.refresh_causes['growth'] += 1
+            if slot >= 0:
+                t = g.device_sources
+                if self._device_maps is not None and t is not None:
+                    # device-resident values (f2): that instance's sources come to the host once
+                    src, coef = self._device_maps[1][g.blocks[0]]
+                    col = t[:, slot].cpu().numpy()
+                    src = np.asarray(src)
+                    raw = np.asarray(coef, dtype=np.double) * np.where(src >= 0, col[np.maximum(src, 0)], 1.0)
+                    vals = np.add.reduceat(raw[g.can_idx], g.can_ptr[:-1]) if g.can_idx.size else np.zeros(0)
+                else:
+                    vals = g.canonical_from_compact(g.staging[slot])
+                if shift is not None and self._classes:
+                    cls = self._classes[g.blocks[0]]
+                    nK = g.rowK.size
+                    diag = np.flatnonzero(g.rowK == g.colK)
+                    rows = g.rowK[diag]
+                    vals = np.array(vals, dtype=np.double)
+                    vals[:nK][diag] += np.where(cls[rows] == 1, shift[0], np.where(cls[rows] == 2, -shift[1], 0.0))
+                if g.futile_vals is not None and g.futile_vals.shape == vals.shape and np.array_equal(g.futile_vals, vals):
+                    # exactly the values the last refresh was planned from, and that plan broke on them as well
+                    self.refreshes_skipped += 1
+                    continue
+                g.rep_vals = vals
+                g.refresh_block = g.blocks[slot]
+                mine = 1
+                self._refreshed.append(g)
+        anyone = mine
+        if self.comm.size > 1:
+            anyone = int(self.comm.allreduce_max(np.array([mine], dtype=np.int64))[0])
+        if mine:
+            steps = self.refresh_thresholds
+            if steps and hasattr(self._eng, 'set_pivot_tolerance'):
+                u = steps[min(self.pivot_order_refreshes_since_symbolic, len(steps) - 1)]
+                if u > max(self._u_symbolic_now, 0.01):
+                    self._u_symbolic_now = u
+                    self._eng.set_pivot_tolerance(u, self._u_user[1])
+            self.pivot_order_refreshes += 1
+            self.pivot_order_refreshes_since_symbolic += 1
+            self._run_symbolic()
+        return bool(anyone)
+
+    def _split_conflicting(self, matrix):
+        """After a refresh: a group whose new sequence (planned from block A) broke on a block B != A holds instances that
+        need different sequences.  B moves to the next variant of the pattern group (the blocks of a variant share one plan,
+        made from the first of them), the groups are built and planned again on the values of `matrix`.  Returns whether
+        anything moved.  A block that breaks under the sequence planned from ITSELF is singular: nothing to split.
+        Collective (the coupling structure is agreed by all ranks when the groups are rebuilt)."""
+        moved = 0
+        for g in self._groups:
+            if len(g.blocks) < 2:
+                continue
+            slot = self._eng.find_zero_pivot(g.gid)
+            if slot < 0:
+                continue
+            ndx = g.blocks[slot]
+            planned_from = getattr(g, 'refresh_block', g.blocks[0])
+            if ndx == planned_from:
+                continue
+            v = self._variant.get(ndx, 0) + 1
+            if v >= self.max_group_variants:
+                continue
+            self._variant[ndx] = v
+            moved += 1
+        anyone = moved
+        if self.comm.size > 1:
+            anyone = int(self.comm.allreduce_max(np.array([moved], dtype=np.int64))[0])
+        if not anyone:
+            return False
+        self.group_splits += moved
+        planned = {ndx: getattr(self._binfo[ndx].group, 'refresh_block', None) for ndx in self.local_block_indices}
+        self._build_groups(matrix)
+        for g in self._groups:                         # (a group keeps the block its sequence was planned from, if it still holds it)
+            keep = planned.get(g.blocks[0])
+            g.refresh_block = keep if keep in g.blocks else g.blocks[0]
+            if keep in g.blocks and keep != g.blocks[0]:
+                slot = g.blocks.index(keep)
+                kr, kc, kd, _ = _coo(matrix.get_block(keep, keep))
+                br, bc, bd = self._border(matrix, keep)
+                g.rep_vals = self._canonical_values(g, np.concatenate([kd, bd]), kr, kc, br, bc, self._binfo[keep].raw_sig)
+        self._run_symbolic()
+        self._pattern_only = False
+        return True

@@ -16,6 +16,7 @@ def build_hostsim(force=False):
     srcs = [os.path.join(HERE, 'hostsim', 'hostsim.cpp'),
             os.path.join(ROOT, 'parapint_amd', 'csrc', 'symbolic.cpp'),
             os.path.join(ROOT, 'parapint_amd', 'csrc', 'plan.hpp'),
+            os.path.join(ROOT, 'parapint_amd', 'csrc', 'switches.hpp'),
             os.path.join(ROOT, 'parapint_amd', 'csrc', 'pivot.hpp'),
             os.path.join(ROOT, 'parapint_amd', 'csrc', 'dense_bk.hpp')]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):

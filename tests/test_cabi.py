@@ -105,3 +105,23 @@ def test_host_staging_helper_matches_numpy():
                 assert np.all(row[nk + nb:] == -7.0)
             else:
                 assert np.all(row == -7.0)
+
+
+def test_environment_switches_are_listed_in_one_table():
+    """Round 5 (code health): the library reads its environment switches through pp::env_switch only, whose table
+    (csrc/switches.hpp) names and describes each one; no other getenv in the sources."""
+    import glob
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, 'parapint_amd', 'csrc')
+    table = open(os.path.join(csrc, 'switches.hpp')).read()
+    listed = set(re.findall(r'\{"(PP_[A-Z0-9_]+)",', table))
+    assert len(listed) >= 20
+    asked = set()
+    for f in glob.glob(os.path.join(csrc, '*.hip')) + glob.glob(os.path.join(csrc, '*.hpp')) + glob.glob(os.path.join(csrc, '*.cpp')):
+        text = open(f).read()
+        if not f.endswith('switches.hpp'):
+            assert 'getenv' not in text, f
+        asked |= set(re.findall(r'env_switch\("(PP_[A-Z0-9_]+)"\)', text))
+    assert asked <= listed, asked - listed
