@@ -113,6 +113,12 @@ struct PlanOptions {
   int chain_min_batch = 1;           // instances a pattern group needs for chain fronts (PP_PLAN_TUNE experiments)
   int chain_tiles = 1;
   int tile_task_records = 24;
+  // ... and for any other panel whose rows are dense against their sources (the coupling rows of the top panels of a
+  // scenario block): a panel with at least tile_min_entries product entries whose tile form requests at most
+  // tile_load_ratio of the operands of its row form
+  int tile_panels = 0;
+  int tile_min_entries = 256;
+  double tile_load_ratio = 0.7;
 };
 
 // Task sizes by batch (instances of the pattern group on this rank).  MEASURED on one MI355X (tools/tune_sweep.sh): with
@@ -197,6 +203,9 @@ inline bool apply_plan_tune(PlanOptions& opt, const char* tune, std::string& bad
       else if (k == "chain_lds_doubles") opt.chain_lds_doubles = (int)v;
       else if (k == "chain_tiles") opt.chain_tiles = (int)v;
       else if (k == "chain_sweeps") opt.chain_sweeps = (int)v;
+      else if (k == "tile_panels") opt.tile_panels = (int)v;
+      else if (k == "tile_min_entries") opt.tile_min_entries = (int)v;
+      else if (k == "tile_load_ratio") opt.tile_load_ratio = v;
       else if (k == "chain_min_batch") opt.chain_min_batch = (int)v;
       else if (k == "tile_task_records") opt.tile_task_records = (int)v;
       else { bad_key = k; return false; }

@@ -809,7 +809,10 @@ static int build_plan_ordered(int n, int nc, int nnzK, const int* rowK, const in
       for (int sl = 0; sl < nslice; ++sl) {
         const int qoff = sl * PP_WMAX, ws = wide ? std::min(PP_WMAX, w - qoff) : w;
         row_ents.assign((size_t)f, {});
-        const bool tiled = chain >= 0 && opt.chain_tiles && !wide;
+        // tile tasks: always for the panels of a chain front (dense by construction); for any other panel (tile_panels)
+        // when they request clearly fewer operands than the row tasks would (decided below, once the entries are known)
+        const bool tile_sure = chain >= 0 && opt.chain_tiles && !wide;
+        bool tiled = tile_sure || (opt.tile_panels && !wide);
         if (tiled) { row_src.assign((size_t)f, {}); srcs.clear(); }
         int64_t total = 0;
         // initial values
@@ -892,6 +895,22 @@ static int build_plan_ordered(int n, int nc, int nnzK, const int* rowK, const in
           tt.nent = (e0 >= 0) ? (int)row_ents[(size_t)r0].size() : (int)P.fentries.size() - first;
           gtasks.push_back(tt);
         };
+        if (tiled && !tile_sure) {
+          // operand requests of the row tasks (1 + columns per entry) against those of tile tasks (8 per source column of
+          // every (tile, source panel) pair); small panels stay with the row tasks (fused with their scaling, or one launch)
+          int64_t row_loads = 0, tile_loads = 0, prod = 0;
+          for (int rr = 0; rr < f; ++rr)
+            for (auto& fe : row_ents[(size_t)rr])
+              if (fe.u >= 0) { row_loads += 1 + ((fe.q >> 4) & 15); ++prod; }
+          for (auto& si : srcs) {
+            int last_tile = -1;
+            for (auto& rw : si.rows) {
+              const int tl = rw.first / PP_TILE_ROWS;
+              if (tl != last_tile) { tile_loads += 8 * (int64_t)si.wk; last_tile = tl; }
+            }
+          }
+          tiled = prod >= opt.tile_min_entries && (double)tile_loads <= opt.tile_load_ratio * (double)row_loads;
+        }
         if (tiled) {
           // tile tasks: PP_TILE_ROWS consecutive slots against the source panels that hold any of them, cut into pieces
           // of tile_task_records sources; every piece carries the entries of its rows from its own sources (piece 0 the

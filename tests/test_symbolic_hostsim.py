@@ -193,7 +193,9 @@ def test_supernodes_block_pivots(wmax, tol):
 # scaled by kernels of its own).  Every combination must give the same S, inertia and solves.
 PLAN_VARIANTS = ['order_mode=0', 'order_mode=1', 'order_mode=0,close_supernodes=1,front_max=4',
                  'order_mode=1,close_supernodes=1', 'front_max=4', 'front_pad_frac=0.0', 'front_max=9',
-                 'order_mode=1,round_relax_pop=0', 'order_mode=1,round_narrow_pop=10,round_narrow_wmax=2']
+                 'order_mode=1,round_relax_pop=0', 'order_mode=1,round_narrow_pop=10,round_narrow_wmax=2',
+                 # round 5: tile tasks for every panel that qualifies / for every big panel whatever the ratio
+                 'tile_panels=1,tile_min_entries=8', 'tile_panels=1,tile_min_entries=1,tile_load_ratio=100,tile_task_records=3']
 
 
 @pytest.mark.parametrize('tune', PLAN_VARIANTS)

@@ -50,6 +50,7 @@ python3 tools/burgers_ip.py 512 50 40 > $out/burgers_ip_configuration_4.json 2> 
 python3 bench.py --workload C2 --no-cpu-baseline > $out/bench_C2.json 2> $out/c2.err
 python3 bench.py --blocks 128 --no-cpu-baseline --no-boundary --no-ip-loop > $out/bench_128_blocks.json 2> $out/b128.err
 python3 bench.py --workload C4 --no-cpu-baseline --steps 10 --warmup 2 > $out/bench_C4.json 2> $out/c4.err
+bash tools/pmc_traffic_run.sh $tag/pmc_C4 --workload C4 --no-ip-loop > $out/pmc_traffic_C4.log 2>&1 && cp $out/pmc_C4/pmc_traffic.json $out/pmc_traffic_C4.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_C4 -- python3 bench.py --workload C4 --steps 5 --warmup 2 --no-cpu-baseline --no-boundary --no-ip-loop > $out/bench_C4_under_rocprof.json 2> $out/stats_C4.err && cp $(find $out/stats_C4 -name '*kernel_stats.csv' | head -1) $out/kernel_stats_C4.csv
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $out/pmc_mfma_C4 -- python3 bench.py --workload C4 --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-boundary --no-ip-loop > $out/bench_mfma_C4.json 2> $out/mfma_C4.err \
   && python3 tools/mfma_util.py $out/pmc_mfma_C4 $(find $out/stats_C4 -name '*kernel_trace.csv' | head -1) $out/mfma_util_C4.json "bench.py --workload C4"

@@ -19,12 +19,13 @@ from pmc_summary import load, short   # noqa: E402
 from parapint_amd._native import kernel_source_sha1   # noqa: E402
 
 PHASE_OF = [
-    (r'^k_gather_level|^k_gather_flat', 'factor_levels'), (r'^k_scale_level|^k_front_invert|^k_scale_wide', 'factor_levels'),
+    (r'^k_gather_level|^k_gather_flat|^k_gather_tiles|^k_chain_front', 'factor_levels'),
+    (r'^k_scale_level|^k_front_invert|^k_scale_wide', 'factor_levels'),
     (r'^k_count_codes|^k_schur_tiles|^k_schur_mfma|^k_schur_reduce|^k_scatter_schur', 'schur_tiles'),
     (r'^k_bcr_fwd|^k_bcr_bwd|^k_bcr_rhs', 'coupling_solve'),
     (r'^k_add_q|^k_ldl_|^k_bk_factor|^k_write_tail|^k_publish_status|^k_dense_|^k_bcr_|^k_btd_|^k_corner_add', 'dense_S'),
-    (r'^k_fwd_level', 'fwd_levels'), (r'^k_fwd_coupling|^k_rs_reduce', 'fwd_coupling'),
-    (r'^k_coupling_solve', 'coupling_solve'), (r'^k_bwd_level|^k_transpose_out', 'bwd_levels'),
+    (r'^k_fwd_level|^k_chain_fwd', 'fwd_levels'), (r'^k_fwd_coupling|^k_rs_reduce', 'fwd_coupling'),
+    (r'^k_coupling_solve', 'coupling_solve'), (r'^k_bwd_level|^k_chain_bwd|^k_transpose_out', 'bwd_levels'),
 ]
 
 
