@@ -618,9 +618,46 @@ __global__ __launch_bounds__(64 * NW) void k_gather_tiles(GroupDev g, int task0,
 // Instances are dealt so that the eight that share a 64-byte sector of every [entry][instance] row run on one XCD at
 // about the same time: their strided 8-byte accesses meet in that XCD's L2.
 // LDS: F[m][W | 1], Lp[m][4] (scaled rows of the current panel), tmd[W], in doubles.
-__global__ __launch_bounds__(256) void k_chain_front(GroupDev g, int front0, double eps) {
+// (a barrier that orders LDS traffic only: __syncthreads() would also wait for the outstanding global stores of U and L,
+// which are never read back here)
+__device__ __forceinline__ void chain_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Pivot block of panel (w, sub) at front column c0: inverted by every lane of ONE wave from LDS broadcasts (pivot.hpp: the
+// static sub-pivots and zero-pivot rule of the level kernels); lane 0 leaves inv(P) (packed) and the inertia code in LDS
+// for the workgroup and writes them to the factor storage.
+__device__ __forceinline__ void chain_invert(const GroupDev& g, const double* F, int LD, const double* tmd, int c0, int w, unsigned sub,
+                                             int p, int doff, double eps, double* sinv, size_t bpad, int b, int lane) {
+  double blk[PP_WMAX * PP_WMAX], tv[PP_WMAX], inv[PP_WMAX * (PP_WMAX + 1) / 2];
+#pragma unroll
+  for (int a = 0; a < PP_WMAX; ++a) {
+    tv[a] = (a < w) ? tmd[c0 + min(a, w - 1)] : 0.0;
+#pragma unroll
+    for (int c = 0; c < PP_WMAX; ++c) {
+      const bool in = a < w && c < w;
+      const double v = F[(size_t)(c0 + (in ? a : 0)) * LD + c0 + (in ? c : 0)];
+      blk[a * PP_WMAX + c] = in ? v : 0.0;
+    }
+  }
+  const int code = pp::invert_block_t<PP_WMAX>(w, sub, blk, tv, eps, inv);
+  if (lane == 0) {
+    double* invp = g.Dinv + (size_t)doff * bpad + b;
+#pragma unroll
+    for (int q = 0; q < PP_WMAX * (PP_WMAX + 1) / 2; ++q) {
+      sinv[q] = inv[q];
+      if (q < w * (w + 1) / 2) invp[(size_t)q * bpad] = inv[q];
+    }
+    g.codes[(size_t)p * bpad + b] = (b < g.batch) ? (unsigned short)code : (unsigned short)0;
+  }
+}
+
+// Round 5, second form: the inversion of the NEXT panel's pivot block leaves the critical path.  After the rows of panel i
+// are scaled, wave 0 alone applies panel i to the w x w pivot block of panel i + 1 and inverts it, while the other waves
+// apply panel i to everything else; one barrier later every thread reads inv(P_(i+1)) from LDS.  (Per-station stamps of the
+// first form, one workgroup, 16 panels: invert 1.2-1.6 us + scale 0.9 + update 1.9-3.1 per panel, all in sequence.)
+template <int CHAIN_THREADS>
+__global__ __launch_bounds__(CHAIN_THREADS) void k_chain_front(GroupDev g, int front0, double eps) {
   extern __shared__ __attribute__((aligned(16))) double fsh[];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned j = blockIdx.x % (unsigned)g.bpad;
   const int fi = front0 + (int)(blockIdx.x / (unsigned)g.bpad);
   const int b = (int)((j & 7u) * ((unsigned)g.bpad >> 3) + (j >> 3));
@@ -631,6 +668,7 @@ __global__ __launch_bounds__(256) void k_chain_front(GroupDev g, int front0, dou
   double* F = fsh;
   double* Lp = F + (size_t)m * LD;
   double* tmd = Lp + 4 * (size_t)m;
+  double* sinv = tmd + W;                        // inv(P) of the panel about to be scaled (packed, 10 doubles)
   const size_t bpad = (size_t)g.bpad;
   for (int i = 0; i < npan; ++i) {
     const int* R = PR + 8 * i;
@@ -638,45 +676,26 @@ __global__ __launch_bounds__(256) void k_chain_front(GroupDev g, int front0, dou
     const double* Up = g.U + (size_t)R[2] * bpad + b;
     double* Fp = F + (size_t)c0 * LD + c0;
 #pragma unroll 4
-    for (int idx = tid; idx < f * w; idx += 256) {
+    for (int idx = tid; idx < f * w; idx += CHAIN_THREADS) {
       const int t = idx / w, q = idx - t * w;
       Fp[t * LD + q] = Up[(size_t)idx * bpad];
     }
     if (tid < w) tmd[c0 + tid] = g.Tm[((size_t)boff + (size_t)(tid * w + tid)) * bpad + b];
   }
-  __syncthreads();
+  chain_barrier();
+  if (wave == 0) chain_invert(g, F, LD, tmd, PR[6], PR[1], (unsigned)PR[5], PR[0], PR[4], eps, sinv, bpad, b, lane);
+  chain_barrier();
   bool grow = false;
   for (int i = 0; i < npan; ++i) {
     const int* R = PR + 8 * i;
-    const int p = R[0], w = R[1], doff = R[4], c0 = R[6], f = R[7];
-    const unsigned sub = (unsigned)R[5];
+    const int w = R[1], c0 = R[6], f = R[7];
     double inv[PP_WMAX * (PP_WMAX + 1) / 2];
-    {
-      // (every thread inverts the block from LDS broadcasts: no hand-over, no barrier)
-      double blk[PP_WMAX * PP_WMAX], tv[PP_WMAX];
 #pragma unroll
-      for (int a = 0; a < PP_WMAX; ++a) {
-        tv[a] = (a < w) ? tmd[c0 + min(a, w - 1)] : 0.0;
-#pragma unroll
-        for (int c = 0; c < PP_WMAX; ++c) {
-          const bool in = a < w && c < w;
-          const double v = F[(size_t)(c0 + (in ? a : 0)) * LD + c0 + (in ? c : 0)];
-          blk[a * PP_WMAX + c] = in ? v : 0.0;
-        }
-      }
-      const int code = pp::invert_block_t<PP_WMAX>(w, sub, blk, tv, eps, inv);
-      if (tid == 0) {
-        double* invp = g.Dinv + (size_t)doff * bpad + b;
-#pragma unroll
-        for (int q = 0; q < PP_WMAX * (PP_WMAX + 1) / 2; ++q)
-          if (q < w * (w + 1) / 2) invp[(size_t)q * bpad] = inv[q];
-        g.codes[(size_t)p * bpad + b] = (b < g.batch) ? (unsigned short)code : (unsigned short)0;
-      }
-    }
+    for (int q = 0; q < PP_WMAX * (PP_WMAX + 1) / 2; ++q) inv[q] = sinv[q];
     {
       double* Ug = g.U + (size_t)R[2] * bpad + b;
       double* Lg = g.L + (size_t)R[2] * bpad + b;
-      for (int t = tid; t < f; t += 256) {
+      for (int t = tid; t < f; t += CHAIN_THREADS) {
         const double* fr = F + (size_t)(c0 + t) * LD + c0;
         double u[PP_WMAX];
 #pragma unroll
@@ -701,11 +720,35 @@ __global__ __launch_bounds__(256) void k_chain_front(GroupDev g, int front0, dou
       }
     }
     if (i + 1 == npan) break;
-    __syncthreads();
-    {
-      // later columns [c1, W) of the rows [c1, m), four columns of one row per thread
-      const int c1 = c0 + w, nr = m - c1, ncg = (W - c1 + 3) >> 2;
-      for (int idx = tid; idx < nr * ncg; idx += 256) {
+    chain_barrier();
+    const int c1 = c0 + w;
+    const int* Rn = R + 8;
+    const int wn = Rn[1];                        // next panel: columns [c1, c1 + wn), its pivot block = rows [c1, c1 + wn)
+    if (wave == 0) {
+      // critical path: panel i applied to the pivot block of panel i + 1 (lane (a, c) one entry), then its inversion
+      if (lane < PP_WMAX * PP_WMAX) {
+        const int a = lane / PP_WMAX, c = lane % PP_WMAX;
+        if (a < wn && c < wn) {
+          double* fr = F + (size_t)(c1 + a) * LD;
+          double acc = fr[c1 + c], tm = 0.0;
+#pragma unroll
+          for (int k = 0; k < PP_WMAX; ++k) {
+            if (k < w) {
+              const double term = fr[c0 + k] * Lp[(size_t)(c1 + c) * 4 + k];
+              acc -= term;
+              tm = fmax(tm, fabs(term));
+            }
+          }
+          fr[c1 + c] = acc;
+          if (a == c) tmd[c1 + a] = fmax(tmd[c1 + a], tm);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (one wave: its LDS operations complete in order)
+      chain_invert(g, F, LD, tmd, c1, wn, (unsigned)Rn[5], Rn[0], Rn[4], eps, sinv, bpad, b, lane);
+    } else {
+      // everything else of the later columns [c1, W) of the rows [c1, m), four columns of one row per thread
+      const int nr = m - c1, ncg = (W - c1 + 3) >> 2;
+      for (int idx = tid - 64; idx < nr * ncg; idx += CHAIN_THREADS - 64) {
         const int cg = idx / nr, r = c1 + (idx - cg * nr), C0 = c1 + 4 * cg;
         if (r < C0 - (PP_WMAX - 1)) continue;      // (above the first row of the panel that holds column C0: not part of any panel)
         double* fr = F + (size_t)r * LD;
@@ -727,13 +770,14 @@ __global__ __launch_bounds__(256) void k_chain_front(GroupDev g, int front0, dou
             }
           }
         }
+        const bool nextblk = r < c1 + wn;             // (rows of the next pivot block: its wn columns are wave 0's)
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc)
-          if (C0 + cc < W) fr[C0 + cc] = acc[cc];
-        if (r >= C0 && r < C0 + 4 && r < W) tmd[r] = fmax(tmd[r], tm);
+          if (C0 + cc < W && !(nextblk && C0 + cc < c1 + wn)) fr[C0 + cc] = acc[cc];
+        if (r >= C0 && r < C0 + 4 && r < W && !nextblk) tmd[r] = fmax(tmd[r], tm);
       }
     }
-    __syncthreads();
+    chain_barrier();
   }
   if (grow && b < g.batch) g.growth[b] = 1;
 }
@@ -1052,14 +1096,19 @@ int pp_numeric_factor_blocks(pp_handle h) {
           if (lds > 64 * 1024 && !h->chain_lds_attr) {
             std::lock_guard<std::mutex> lk(h->alloc_mu);
             if (!h->chain_lds_attr) {
-              if (hipFuncSetAttribute((const void*)k_chain_front, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+              if (hipFuncSetAttribute((const void*)k_chain_front<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                  hipFuncSetAttribute((const void*)k_chain_front<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
                 return fail(h, 3, "hipFuncSetAttribute failed (chain fronts)");
               h->chain_lds_attr = true;
             }
           }
           const int nfr = P.chain_lvl_ptr[l + 1] - P.chain_lvl_ptr[l];
-          hipLaunchKernelGGL(k_chain_front, dim3((unsigned)nfr * (unsigned)d.bpad), dim3(256), lds, fan[0], d, P.chain_lvl_ptr[l],
-                             PIVOT_EPS);
+          // (MEASURED at C4: one front of 512 instances 105 -> 59 us with 512 threads per workgroup, six fronts 188 -> 286 us --
+          // half as many workgroups are resident: the wider workgroup where the launch does not fill the chip anyway)
+          if ((size_t)nfr * (size_t)d.bpad <= 512)
+            hipLaunchKernelGGL(k_chain_front<512>, dim3((unsigned)nfr * (unsigned)d.bpad), dim3(512), lds, fan[0], d, P.chain_lvl_ptr[l], PIVOT_EPS);
+          else
+            hipLaunchKernelGGL(k_chain_front<256>, dim3((unsigned)nfr * (unsigned)d.bpad), dim3(256), lds, fan[0], d, P.chain_lvl_ptr[l], PIVOT_EPS);
         }
         if (P.front_piv >= 0 && P.piv_flevel[P.front_piv] == l) {
           // root front: pivot block inverted by one workgroup per chunk, rows scaled with the explicit inverse
