@@ -124,6 +124,14 @@ class SyntheticKKT(object):
         it = np.arange(n_t)
         return coo_matrix((-np.ones(n_t), (it, 2 * self.n_y + self.n_q + it)), shape=(n_t, self.block_dim))
 
+    def constant_entries(self):
+        """{block: (constK, constA)}: the entries of K_i.data / A_i.data that do not depend on `iteration` -- everything but
+        the (2 + eps) I block (HipSchurComplementLinearSolver.declare_constant_entries)."""
+        cK = np.ones(self.nnz_per_block, dtype=bool)
+        cK[:self._n_diag] = False
+        cA = np.ones(self.n_theta, dtype=bool)
+        return {ndx: (cK, cA) for ndx in self.local_blocks}
+
     def block_rhs(self, ndx):
         rhs = np.zeros(self.block_dim)
         rhs[:self.n_y] = 2.0 * self.y_hat[ndx]

@@ -152,6 +152,7 @@ class _Group(object):
         self.refresh_skip = 0               # breakdowns still to be reported `singular` at once (opt-in back-off)
         self.futile_vals = None             # representative values of the last futile refresh
         self._ref32 = self._refptr = None   # int32 copies of raw_refs and their addresses (stage_upload)
+        self.var_runs = None                # (runsK, runsB) over the entries not declared constant (declare_constant_entries)
 
     # Buffers of the HOST boundary (page-locked when the engine can: ~12 ms per allocation).  A caller that keeps values,
     # right-hand sides and solutions on the device (rows f2/f4) never touches them, so they are made at first use.
@@ -177,24 +178,38 @@ class _Group(object):
         return self._x_pool
 
     @staticmethod
-    def _runs(used, nrawK):
+    def _runs(used, nrawK, select=None, gap=0):
         """Maximal runs of consecutive used raw entries as {source start, length, destination} triples, split at the
-        boundary between the K data and the border data (include/parapint_hip.h: pp_stage_values_runs)."""
+        boundary between the K data and the border data (include/parapint_hip.h: pp_stage_values_runs).  select (bool per
+        used entry): runs over the selected entries only -- destinations stay positions in the whole compact row; two
+        selected entries at most `gap` unselected USED entries apart stay in one run (pp_set_variable_runs)."""
         runsK, runsB = [], []
         if used.size:
-            brk = np.flatnonzero(np.diff(used) != 1) + 1
-            starts = np.concatenate([[0], brk])
-            ends = np.concatenate([brk, [used.size]])
-            for a, b in zip(starts, ends):
-                e0, e1 = int(used[a]), int(used[b - 1]) + 1
-                if e0 < nrawK < e1:                       # a run across the boundary
-                    runsK.append((e0, nrawK - e0, a))
-                    runsB.append((0, e1 - nrawK, a + nrawK - e0))
-                elif e0 < nrawK:
-                    runsK.append((e0, e1 - e0, a))
-                else:
-                    runsB.append((e0 - nrawK, e1 - e0, a))
+            pos = np.arange(used.size) if select is None else np.flatnonzero(select)
+            if pos.size:
+                raw = used[pos]
+                draw, dpos = np.diff(raw), np.diff(pos)
+                brk = np.flatnonzero((draw != dpos) | (dpos > gap + 1)) + 1
+                starts = np.concatenate([[0], brk])
+                ends = np.concatenate([brk, [pos.size]])
+                for a, b in zip(starts, ends):
+                    e0, e1, d = int(raw[a]), int(raw[b - 1]) + 1, int(pos[a])
+                    if e0 < nrawK < e1:                       # a run across the boundary
+                        runsK.append((e0, nrawK - e0, d))
+                        runsB.append((0, e1 - nrawK, d + nrawK - e0))
+                    elif e0 < nrawK:
+                        runsK.append((e0, e1 - e0, d))
+                    else:
+                        runsB.append((e0 - nrawK, e1 - e0, d))
         return (np.asarray(runsK, dtype=np.int64).reshape(-1, 3), np.asarray(runsB, dtype=np.int64).reshape(-1, 3))
+
+    def variable_runs(self, constant, gap=16):
+        """Runs over the used raw entries outside `constant` (bool per raw entry, K data then border data), or None when
+        nothing that is read is constant."""
+        keep = ~np.asarray(constant, dtype=bool)[self.used]
+        if keep.all():
+            return None
+        return self._runs(self.used, self.nrawK, select=keep, gap=gap)
 
     def canonical_from_compact(self, row):
         """Canonical values (duplicates summed) from one compact staging row."""

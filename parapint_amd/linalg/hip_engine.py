@@ -236,6 +236,16 @@ class HipEngine(object):
                                                      g.staging.ctypes.data, sl.ctypes.data)
         self.ns.check(rc, 'pp_stage_upload_verified_begin')
 
+    def set_variable_runs(self, g, runs, check=False):
+        """runs: (runsK, runsB) over the entries not declared constant, or None (no declaration) --
+        include/parapint_hip.h: pp_set_variable_runs."""
+        if runs is None:
+            self.ns.check(self.lib.pp_set_variable_runs(self.ns.h, g.gid, -1, None, 0, None, 0), 'pp_set_variable_runs')
+            return
+        rk, rb = (np.ascontiguousarray(r, dtype=np.int64) for r in runs)
+        self.ns.check(self.lib.pp_set_variable_runs(self.ns.h, g.gid, rk.shape[0], rk.ctypes.data, rb.shape[0], rb.ctypes.data,
+                                                    1 if check else 0), 'pp_set_variable_runs')
+
     def stage_upload_end(self):
         self.ns.check(self.lib.pp_stage_upload_end(self.ns.h), 'pp_stage_upload_end')
 
@@ -414,8 +424,31 @@ class HipEngine(object):
                 self._rccl_unavailable = True
                 return False
             uid = np.ascontiguousarray(got[:128])
-            self.ns.check(self.lib.pp_comm_init(self.ns.h, int(comm.size), int(comm.rank),
-                                                uid.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))), 'pp_comm_init')
+            ok = 1
+            try:
+                self.ns.check(self.lib.pp_comm_init(self.ns.h, int(comm.size), int(comm.rank),
+                                                    uid.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))), 'pp_comm_init')
+                # one all-gather of the rank numbers through the new communicator: it must return 0 .. size - 1
+                mine = torch.full((1,), float(comm.rank), dtype=torch.float64, device='cuda')
+                table = torch.full((comm.size,), -1.0, dtype=torch.float64, device='cuda')
+                torch.cuda.synchronize()          # (the two fills ran on torch's stream, the gather runs on the handle's)
+                self.ns.check(self.lib.pp_comm_allgather(self.ns.h, mine.data_ptr(), table.data_ptr(), ctypes.c_int64(1)),
+                              'pp_comm_allgather')
+                self.ns.check(self.lib.pp_synchronize(self.ns.h), 'pp_synchronize')
+                if not bool((table.cpu() == torch.arange(comm.size, dtype=torch.float64)).all()):
+                    ok = 0
+            except Exception:
+                if want is True or env == '1':
+                    raise
+                ok = 0
+            if comm.size > 1:
+                # (all ranks take the same path: one rank's failure sends everybody to torch.distributed)
+                flag = torch.tensor([ok], dtype=torch.int32, device='cuda')
+                comm._dist.all_reduce(flag, op=comm._dist.ReduceOp.MIN, group=comm._group)
+                ok = int(flag.item())
+            if not ok:
+                self._rccl_unavailable = True
+                return False
         return True
 
     def allreduce_schur(self, comm):

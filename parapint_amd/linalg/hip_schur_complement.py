@@ -34,6 +34,10 @@ from parapint_amd.linalg._solver_support import (HipEngine, _BY_SEVERITY, _S8, _
                                                   _NullTimer, _PatternChanged, _UnionMatrix, _addr, _canonical, _coo, _flat,
                                                   _index_intact, _index_record, _roctx)
 from parapint_amd.linalg.coupling_structure import CouplingStructureMixin
+from parapint_amd.sparse.block_containers import BlockMatrix as _BlockMatrix, MPIBlockMatrix as _MPIBlockMatrix
+
+_OWN_MATRICES = (_BlockMatrix, _MPIBlockMatrix)     # (exact types: their get_block is a dictionary lookup)
+_F8 = np.dtype(np.float64)
 from parapint_amd.linalg.pivot_repair import PivotRepairMixin
 
 
@@ -98,6 +102,8 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
         self._cperm = self._cinv = None     # ordering of the coupling variables under which S is block tridiagonal
         self._dense_coupling_limit = 1024   # a mapped S up to this dimension stays dense
         self._classes = None                # regularisation classes by block index (kept across re-plans)
+        self._constant_entries = None       # declare_constant_entries: {block index: (constK, constA)} (kept across re-plans)
+        self._constant_check = None
         self._device_maps = None            # (nsrc, value maps by block index) of a DeviceBlockMatrix (f2)
         self._dev_results = []
         self._dev_turn = 0
@@ -161,6 +167,7 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
         self.pattern_check_bytes = 4 << 20
         self._stage_calls = 0
         self._index_records = {}            # id(index array) -> (array, size, address, checksum)
+        self._index_sets = {}               # ids of a block's four index arrays -> the tuple of them (shared by blocks)
 
     # ------------------------------------------------------------------ helpers
     def _local_blocks(self, matrix):
@@ -305,6 +312,7 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
             g.x_turn = 0
         self._groups, self._binfo = groups, binfo
         self._index_records = {}
+        self._index_sets = {}
         self._pattern_only = any(g.rep_vals is None for g in groups)
         return all_zero
 
@@ -382,6 +390,9 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
         started = [False]
         self._stage_calls += 1
         full = self.pattern_check_interval > 0 and self._stage_calls % self.pattern_check_interval == 0
+        recheck = [g for g in self._groups if g.var_runs is not None] if full and self._constant_check is None else ()
+        for g in recheck:                                   # (this call also compares the entries declared constant)
+            self._eng.set_variable_runs(g, g.var_runs, True)
         records, memo = self._index_records, {}
         budget = [self.pattern_check_bytes]
 
@@ -407,41 +418,54 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
             verified(g, slots, kps, bps)
             del q[1][:], q[2][:], q[3][:]
 
+        # (blocks of the package's own containers: the dictionary behind get_block, one call frame less per block)
+        table = getattr(matrix, '_blocks', None) if type(matrix) in _OWN_MATRICES else None
+        tget = table.get if isinstance(table, dict) else None
+        setok = {}                      # id(tuple of a block's four index arrays) -> all four are intact
+        nflush = 64
         try:
             for ndx in self.local_block_indices:
                 bi = binfo[ndx]
                 g = bi.group
-                K = get(ndx, ndx)
+                K = tget((ndx, ndx)) if tget is not None else get(ndx, ndx)
                 c = bi.seen
                 if c is not None and verified is not None:
                     # the block's index arrays are the objects an earlier call compared with the group's reference order
                     # (typical: the interface rewrites .data of the same COO blocks at every iteration, or hands out new
                     # blocks over shared index arrays): only the two data addresses are needed.  The index arrays are
                     # checked for having been rewritten in place: size and address at every call, a checksum of their
-                    # contents at every `pattern_check_interval`-th call (once per array object and call).
-                    A = get(last, ndx)
+                    # contents at every `pattern_check_interval`-th call (once per array object and call; blocks that
+                    # share all four arrays share the answer).
+                    A = tget((last, ndx)) if tget is not None else get(last, ndx)
                     try:
                         # (.coords: the (row, col) tuple of a SciPy >= 1.13 COO block; .row / .col are properties there)
-                        ck = getattr(K, 'coords', None) or (K.row, K.col)
-                        ca = getattr(A, 'coords', None) or (A.row, A.col)
+                        try:
+                            ck, ca = K.coords, A.coords
+                        except AttributeError:
+                            ck, ca = (K.row, K.col), (A.row, A.col)
                         hit = ck[0] is c[0] and ck[1] is c[1] and ca[0] is c[2] and ca[1] is c[3]
                     except AttributeError:
                         hit = False
                     if hit:
                         kd, bd = K.data, A.data
-                        if kd.size == c[4] and bd.size == c[5] and kd.dtype.char == 'd' and bd.dtype.char == 'd' and \
-                                kd.strides == _S8 and bd.strides == _S8 and intact(c[0]) and intact(c[1]) and \
-                                intact(c[2]) and intact(c[3]):
-                            q = quick.get(g.gid)
-                            if q is None:
-                                q = quick[g.gid] = (g, [], [], [])
-                            q[1].append(bi.slot)
-                            q[2].append(_addr(kd))
-                            q[3].append(_addr(bd) if c[5] else 0)
-                            if len(q[1]) == (256 if started[0] else 64):
-                                # on its way while the next blocks are looked at (the library's host threads stage and send)
-                                flush(q)
-                            continue
+                        if kd.size == c[4] and bd.size == c[5] and kd.dtype is _F8 and bd.dtype is _F8 and \
+                                kd.strides == _S8 and bd.strides == _S8:
+                            cs = c[6]
+                            ok = setok.get(id(cs))
+                            if ok is None:
+                                ok = setok[id(cs)] = intact(cs[0]) and intact(cs[1]) and intact(cs[2]) and intact(cs[3])
+                            if ok:
+                                q = quick.get(g.gid)
+                                if q is None:
+                                    q = quick[g.gid] = (g, [], [], [])
+                                q[1].append(bi.slot)
+                                q[2].append(_addr(kd))
+                                q[3].append(_addr(bd) if c[5] else 0)
+                                if len(q[1]) == nflush:
+                                    # on its way while the next blocks are looked at (the library's host threads stage and send)
+                                    flush(q)
+                                    nflush = 256
+                                continue
                     bi.seen = None
                 kr, kc, kd, _ = _coo(K)
                 br, bc, bd = self._border(matrix, ndx)
@@ -455,8 +479,12 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
             for q in quick.values():
                 flush(q)
         finally:
-            if started[0]:
-                self._eng.stage_upload_end()            # (also on the way out with a changed pattern: no job stays in flight)
+            try:
+                if started[0]:
+                    self._eng.stage_upload_end()        # (also on the way out with a changed pattern: no job stays in flight)
+            finally:
+                for g in recheck:
+                    self._eng.set_variable_runs(g, g.var_runs, False)
         for g, items in batches.values():
             items.sort(key=lambda it: it[0])
             same = fast(g, [it[:2] for it in items], full)
@@ -468,7 +496,9 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
                     A = get(last, g.blocks[slot])
                     if getattr(A, 'format', None) == 'coo' and K.row is arrays[0] and K.col is arrays[1] and \
                             A.col is arrays[4] and (A.row is arrays[3] or (bi.br_cache is not None and A.row is bi.br_cache[2])):
-                        bi.seen = (K.row, K.col, A.row, A.col, arrays[2].size, arrays[5].size)
+                        four = (K.row, K.col, A.row, A.col)
+                        four = self._index_sets.setdefault(tuple(map(id, four)), four)      # one tuple per set of arrays
+                        bi.seen = four + (arrays[2].size, arrays[5].size, four)
                         for a in bi.seen[:4]:
                             if not memo.get(id(a), False):       # (verified equal to the reference order just now)
                                 records[id(a)] = _index_record(a)
@@ -516,6 +546,50 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
                 # a classed row without a diagonal entry in the new plan: the fast path stays off until
                 # set_regularization_classes is called again; the ordinary path is unaffected
                 self._have_classes = False
+        if self._constant_entries is not None:       # (library groups are made anew by every plan)
+            self._apply_constant_entries()
+
+    def declare_constant_entries(self, constant, check=None):
+        """An interface whose Jacobian or Hessian values do not change between numeric factorisations (linear constraints, a
+        QP: the reference's interfaces hand all of them over again at every iteration, parapint/interfaces/interface.py:
+        evaluate_primal_dual_kkt_matrix) says so here, after do_symbolic_factorization; the declaration holds (over re-plans
+        and pivot-order refreshes, too) until it is withdrawn (constant = None) or the next do_symbolic_factorization.
+
+        constant: {block index: (constK, constA)} -- bool per entry of the block's K_ii.data and of its border A_i.data, in
+        the order of the blocks handed to do_symbolic_factorization (None / missing block: nothing constant).  A pattern
+        group takes the entries constant in ALL its blocks; groups whose blocks come in different entry orders ignore the
+        declaration.  Effect: the host boundary compares and copies the other entries only (host COO blocks in; the device
+        interface has its value maps for that).  check=True: every pass also compares the constant entries and the
+        factorisation reports an error if one changed; default: at every `pattern_check_interval`-th call."""
+        if not getattr(self, '_groups', None) or getattr(self, 'plan_stats', None) is None:
+            raise RuntimeError('declare_constant_entries: call do_symbolic_factorization first')
+        self._constant_entries = None if constant is None else dict(constant)
+        self._constant_check = check
+        self._apply_constant_entries()
+
+    def _apply_constant_entries(self):
+        setter = getattr(self._eng, 'set_variable_runs', None)
+        if setter is None:
+            return
+        decl = self._constant_entries
+        for g in self._groups:
+            runs = None
+            if decl is not None and all(self._binfo[ndx].raw_sig and decl.get(ndx) is not None for ndx in g.blocks):
+                nK, nB = g.nrawK, g.nraw - g.nrawK
+                mask = np.ones(g.nraw, dtype=bool)
+                for ndx in g.blocks:
+                    cK, cA = decl[ndx]
+                    cK = np.zeros(nK, dtype=bool) if cK is None else np.asarray(cK, dtype=bool).ravel()
+                    cA = np.zeros(nB, dtype=bool) if cA is None else np.asarray(cA, dtype=bool).ravel()
+                    if cK.size != nK or cA.size != nB:
+                        mask = None
+                        break
+                    mask[:nK] &= cK
+                    mask[nK:] &= cA
+                if mask is not None:
+                    runs = g.variable_runs(mask)
+            g.var_runs = runs
+            setter(g, runs, bool(self._constant_check))
 
     def _apply_value_maps(self):
         nsrc, maps = self._device_maps
@@ -611,6 +685,7 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
         self._inertia = None
         self._num_status = None
         self._classes = None
+        self._constant_entries = None       # (declarations are about the entries of ONE symbolic phase)
         self._dev_results = []
         device_matrix = hasattr(matrix, 'value_maps')
         if self._u_symbolic_now != self._u_user[0] and hasattr(self._eng, 'set_pivot_tolerance'):

@@ -910,6 +910,93 @@ def case_dynamic_regularised(make_engine, dense_limit=None):
 
 
 # ---- host boundary: which blocks take which way to the device --------------------------------------
+def case_constant_entries(make_engine, calls=None):
+    """declare_constant_entries: the producer names the entries that do not change between numeric factorisations (all but
+    the Hessian diagonal of the synthetic KKT system); later factorisations look at the others only and give the results
+    of an undeclared solver; a declaration that does not hold is reported (check=True: at once; default: at every
+    `pattern_check_interval`-th call, and the values handed over are used all the same); re-plans and a new symbolic
+    phase keep / end the declaration."""
+    N = 6
+    model = SyntheticKKT(N, 3, 8, 2)
+    comm = SerialComm()
+    rhs = model.build_rhs(comm=comm)
+    rng = np.random.default_rng(11)
+    for ndx in range(N):
+        rhs.set_block(ndx, rng.standard_normal(model.block_dim))
+    plain = new_solver(make_engine, N)
+    decl = new_solver(make_engine, N)
+    eng_calls = getattr(decl._eng, 'calls', None) if calls is None else calls
+    try:
+        decl.declare_constant_entries(model.constant_entries())
+        raise AssertionError('a declaration before the symbolic phase must be refused')
+    except RuntimeError:
+        pass
+    kkt = model.build_kkt(comm=comm, iteration=0)
+    for s in (plain, decl):
+        s.do_symbolic_factorization(kkt)
+    decl.declare_constant_entries(model.constant_entries())
+    assert all(g.var_runs is not None for g in decl._groups)
+    nvar = sum(int(g.var_runs[0][:, 1].sum() + g.var_runs[1][:, 1].sum()) for g in decl._groups)
+    assert model.n_y <= nvar < model.nnz_per_block // 2                # (the diagonal plus the gaps closed between its runs)
+    for it in range(0, 5):
+        k = model.build_kkt(comm=comm, iteration=it)
+        before = dict(eng_calls) if eng_calls is not None else None
+        for s in (plain, decl):
+            assert s.do_numeric_factorization(k).status == LinearSolverStatus.successful
+        xp, xd = plain.do_back_solve(rhs), decl.do_back_solve(rhs)
+        assert np.array_equal(xp.flatten(), xd.flatten())
+        assert scaled_residual(k.toarray(), xd.flatten(), rhs.flatten()) <= 1e-10
+        if eng_calls is not None and it >= 2 and 'variable_entries' in eng_calls:
+            # the declared solver touched the variable entries only (rows staged whole at the first verified pass)
+            assert eng_calls['variable_entries'] - before.get('variable_entries', 0) == N * nvar
+    # a declaration that does not hold: a Jacobian entry of block 2 changes
+    k = model.build_kkt(comm=comm, iteration=7)
+    K2 = k.get_block(2, 2)
+    K2.data = K2.data.copy()
+    def pair(q):
+        # an entry below the diagonal (read, declared constant) and its mirror image above (the check is of the full matrix)
+        e = int(np.flatnonzero(model._row > model._col)[q])
+        m = int(np.flatnonzero((model._row == model._col[e]) & (model._col == model._row[e]))[0])
+        return [e, m]
+
+    e_const = pair(3)
+    K2.data[e_const] *= 1.25
+    decl.declare_constant_entries(model.constant_entries(), check=True)
+    k_ok = model.build_kkt(comm=comm, iteration=6)
+    assert decl.do_numeric_factorization(k_ok).status == LinearSolverStatus.successful
+    res = decl.do_numeric_factorization(k, raise_on_error=False)
+    assert res.status == LinearSolverStatus.error and 'declared constant' in decl._last_error
+    # ... the values were sent all the same: the next call (same matrix) is clean and solves the changed system
+    assert decl.do_numeric_factorization(k).status == LinearSolverStatus.successful
+    x = decl.do_back_solve(rhs)
+    assert scaled_residual(k.toarray(), x.flatten(), rhs.flatten()) <= 1e-10
+    # default: found at the `pattern_check_interval`-th call
+    decl.declare_constant_entries(model.constant_entries())
+    decl.pattern_check_interval = 3
+    K2.data[e_const] *= 0.8
+    seen = []
+    for rep in range(3):
+        seen.append(decl.do_numeric_factorization(k, raise_on_error=False).status)
+    assert seen.count(LinearSolverStatus.error) == 1, seen
+    decl.pattern_check_interval = 8
+    # withdrawn: every entry is looked at again
+    decl.declare_constant_entries(None)
+    assert all(g.var_runs is None for g in decl._groups)
+    K2.data[pair(5)] *= 1.5
+    assert decl.do_numeric_factorization(k).status == LinearSolverStatus.successful
+    x = decl.do_back_solve(rhs)
+    assert scaled_residual(k.toarray(), x.flatten(), rhs.flatten()) <= 1e-10
+    # a new symbolic phase ends a declaration
+    decl.declare_constant_entries(model.constant_entries())
+    decl.do_symbolic_factorization(kkt)
+    assert all(g.var_runs is None for g in decl._groups)
+    # masks of the wrong length (another problem's) are ignored
+    bad = {ndx: (np.ones(5, dtype=bool), None) for ndx in range(N)}
+    decl.declare_constant_entries(bad)
+    assert all(g.var_runs is None for g in decl._groups)
+    assert decl.do_numeric_factorization(kkt).status == LinearSolverStatus.successful
+
+
 def case_boundary_fast_paths(make_engine, calls=None):
     """do_numeric_factorization / do_back_solve with host blocks, over the ways an interface hands its matrix over:
     new COO blocks over the same index arrays, the same blocks with .data rewritten in place or replaced, index arrays

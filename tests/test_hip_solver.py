@@ -599,9 +599,10 @@ def test_bench_single_rank_line_has_the_contract_fields():
     res = _run_bench({}, '--workload', 'C2', '--steps', '5', '--warmup', '2', '--no-cpu-baseline', '--boundary-iterations', '2')
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
                 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'boundary_host', 'device_only',
-                'value_no_prefetch', 'ms_per_step_no_prefetch'):
+                'value_no_prefetch', 'ms_per_step_no_prefetch', 'value_boundary_constant_declared'):
         assert key in res
-    assert res['value_no_prefetch'] > 0
+    assert res['value_no_prefetch'] > 0 and res['value_boundary_constant_declared'] > 0
+    assert res['boundary_host_constant_declared']['residual'] <= 1e-8
     assert res['correct'] is True and res['n_gpus'] == 1 and res['roofline']['bound'] == 'hbm'
     assert abs(res['value'] * res['ms_per_step'] / 1e3 - 1.0) < 1e-6
 
@@ -785,6 +786,12 @@ def test_host_boundary_fast_paths_on_the_device():
     """Host blocks in, host vectors out through pp_stage_upload_compact / pp_upload_rhs_rows / pp_download_solution_rows
     (verified index arrays, data rewritten in place, both result-buffer modes), each result against a dense solve."""
     sc.case_boundary_fast_paths(lambda: None)
+
+
+def test_entries_declared_constant_by_the_producer_on_the_device():
+    """declare_constant_entries -> pp_set_variable_runs: rows whose staged copy mirrors the device are compared and copied
+    over the variable entries only; same results as an undeclared solver; a declaration that does not hold is reported."""
+    sc.case_constant_entries(lambda: None)
 
 
 def test_switching_input_forms_between_factorisations_ends_the_staging_mirror():

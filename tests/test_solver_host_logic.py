@@ -111,5 +111,9 @@ def test_host_boundary_fast_paths():
     sc.case_boundary_fast_paths(HostSimBoundaryEngine)
 
 
+def test_entries_declared_constant_by_the_producer():
+    sc.case_constant_entries(HostSimBoundaryEngine)
+
+
 def test_zero_pivot_test_inside_a_mixed_scale_block_pivot():
     sc.case_mixed_scale_block_pivot(HostSimEngine)

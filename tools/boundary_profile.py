@@ -24,6 +24,8 @@ solver = HipSchurComplementLinearSolver({i: None for i in range(N)}, None, comm=
 kkt = model.build_kkt(comm=comm, iteration=0)
 rhs = model.build_rhs(comm=comm)
 solver.do_symbolic_factorization(kkt)
+if os.environ.get('PP_DECLARE_CONSTANT') == '1':
+    solver.declare_constant_entries(model.constant_entries())
 for it in (1, 2):
     k = model.build_kkt(comm=comm, iteration=it)
     solver.do_numeric_factorization(k)
