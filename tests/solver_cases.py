@@ -995,6 +995,26 @@ def case_constant_entries(make_engine, calls=None):
     decl.declare_constant_entries(bad)
     assert all(g.var_runs is None for g in decl._groups)
     assert decl.do_numeric_factorization(kkt).status == LinearSolverStatus.successful
+    # a declaration outlives a re-plan only where it still describes the entries: the regularised matrix of an
+    # inertia-correction step has entries outside the planned pattern -> one re-plan on the union pattern, whose raw layout
+    # is not the declared one any more -> the declaration is dropped for those groups, every entry is read
+    decl.declare_constant_entries(model.constant_entries())
+    assert all(g.var_runs is not None for g in decl._groups)
+    assert decl.do_numeric_factorization(model.build_kkt(comm=comm, iteration=1)).status == LinearSolverStatus.successful
+    reg = model.build_kkt(comm=comm, iteration=2)
+    n = model.block_dim
+    for ndx in range(N):
+        K = reg.get_block(ndx, ndx)
+        d = np.concatenate([np.zeros(model.n_y + model.n_q), -1e-3 * np.ones(n - model.n_y - model.n_q)])
+        reg.set_block(ndx, ndx, (K + sp.diags(d)).tocoo())
+    assert decl.do_numeric_factorization(reg).status == LinearSolverStatus.successful
+    assert all(g.var_runs is None for g in decl._groups)
+    x = decl.do_back_solve(rhs)
+    assert scaled_residual(reg.toarray(), x.flatten(), rhs.flatten()) <= 1e-10
+    back = model.build_kkt(comm=comm, iteration=3)               # a subset of the union pattern again
+    assert decl.do_numeric_factorization(back).status == LinearSolverStatus.successful
+    x = decl.do_back_solve(rhs)
+    assert scaled_residual(back.toarray(), x.flatten(), rhs.flatten()) <= 1e-10
 
 
 def case_boundary_fast_paths(make_engine, calls=None):
