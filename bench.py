@@ -234,6 +234,7 @@ def main():
     # ---- (1) host boundary: SciPy COO blocks in, host vectors out
     boundary = None
     declared = None
+    flat_plain = flat_declared = None
     resid_boundary = None
     ok = True
     if not args.no_boundary:
@@ -254,16 +255,17 @@ def main():
             def stop(self, name):
                 self.t.setdefault(name, []).append(time.perf_counter() - self.open.pop(name))
 
-        def boundary_loop(first):
+        def boundary_loop(first, flat=False):
             ts = []
             phases = _Phases()
             kkt_it = x = None
             for it in range(first, first + args.boundary_iterations):
                 kkt_it = model.build_kkt(comm=comm, iteration=it)
+                handed = HostValueMatrix(kkt, model.flat_values(iteration=it)) if flat else kkt_it
                 if world > 1:
                     dist.barrier()
                 t0 = time.perf_counter()
-                solver.do_numeric_factorization(matrix=kkt_it, raise_on_error=False, timer=phases)
+                solver.do_numeric_factorization(matrix=handed, raise_on_error=False, timer=phases)
                 x = solver.do_back_solve(rhs, timer=phases)
                 ts.append(time.perf_counter() - t0)
             med = float(np.median(ts))
@@ -288,8 +290,30 @@ def main():
                         'phases_ms': phase_table(phases_d), 'residual': resid_d,
                         'note': 'as boundary_host, after solver.declare_constant_entries(...): the Jacobian and identity '
                                 'entries of the synthetic KKT system are not compared or copied again (pp_set_variable_runs)'}
+            # ... and with the values handed over as the rows of one flat array over the symbolic phase's pattern object
+            # (HostValueMatrix: one staging call per pattern group instead of a walk over 2 x N SciPy objects)
+            if hasattr(model, 'flat_values'):
+                from parapint_amd.sparse.host_value_matrix import HostValueMatrix
+                med_f, ts_f, phases_f, kkt_f, x_f = boundary_loop(201, flat=True)
+                resid_f = residual_check(kkt_f, x_f, rhs)
+                ok = ok and resid_f <= 1e-8 and tuple(solver.get_inertia()) == expected_inertia
+                flat_declared = {'it_per_s': 1.0 / med_f, 'ms_per_iteration': 1e3 * med_f, 'phases_ms': phase_table(phases_f),
+                                 'residual': resid_f}
+                del kkt_f, x_f
             solver.declare_constant_entries(None)
             del kkt_d, x_d
+        if hasattr(model, 'flat_values') and hasattr(model, 'constant_entries'):
+            from parapint_amd.sparse.host_value_matrix import HostValueMatrix
+            med_f, ts_f, phases_f, kkt_f, x_f = boundary_loop(301, flat=True)
+            resid_f = residual_check(kkt_f, x_f, rhs)
+            ok = ok and resid_f <= 1e-8 and tuple(solver.get_inertia()) == expected_inertia
+            flat_plain = {'it_per_s': 1.0 / med_f, 'ms_per_iteration': 1e3 * med_f, 'iterations': len(ts_f),
+                          'phases_ms': phase_table(phases_f), 'residual': resid_f,
+                          'constant_declared': flat_declared,
+                          'note': 'as boundary_host, the values handed over as HostValueMatrix(pattern, [blocks][entries]) '
+                                  '(opt-in container: flat value vectors over the pattern object of the symbolic phase); '
+                                  'constant_declared: the same after solver.declare_constant_entries(...)'}
+            del kkt_f, x_f
         med, ts, phases, kkt_it, x = boundary_loop(1)
         boundary = {'it_per_s': 1.0 / med, 'ms_per_iteration': 1e3 * med, 'iterations': len(ts),
                     'phases_ms': phase_table(phases),
@@ -747,6 +771,7 @@ def main():
             # staging, H2D and D2H inside) -- the rate a caller with the reference's unchanged interfaces sees
             'value_boundary': (boundary or {}).get('it_per_s'),
             'value_boundary_constant_declared': (declared or {}).get('it_per_s'),
+            'value_boundary_flat_values': (flat_plain or {}).get('it_per_s'),
             'ip_loop': ip_loop,
             'ip_loop_dynamic': ip_loop_dynamic,
             'ip_loop_burgers': ip_loop_burgers,
@@ -761,7 +786,7 @@ def main():
                                              'schur_fma', 'factor_tasks', 'canonical_entries', 'raw_entries')}, **ex),
             'survey_bytes_per_block': sb, 'build_bytes_per_block': bb,
             'symbolic_s': t_symbolic,
-            'boundary_host': boundary, 'boundary_host_constant_declared': declared,
+            'boundary_host': boundary, 'boundary_host_constant_declared': declared, 'boundary_host_flat_values': flat_plain,
             'device_only': device_only,
             'value_storage_bytes': {'device_resident_path': mem_now, 'with_host_input_and_output_copies': mem_max},
             'bcr_block_paths': bcr_paths,

@@ -132,6 +132,15 @@ class SyntheticKKT(object):
         cA = np.ones(self.n_theta, dtype=bool)
         return {ndx: (cK, cA) for ndx in self.local_blocks}
 
+    def flat_values(self, iteration=None):
+        """[owned blocks][nnz(K_i) + nnz(A_i)]: the values of build_kkt(iteration) as the rows of one array (K data, then the
+        border's) -- parapint_amd.sparse.host_value_matrix.HostValueMatrix."""
+        out = np.empty((len(self.local_blocks), self.nnz_per_block + self.n_theta))
+        for i, ndx in enumerate(self.local_blocks):
+            out[i, :self.nnz_per_block] = self.block_values(ndx, iteration)
+        out[:, self.nnz_per_block:] = -1.0
+        return out
+
     def block_rhs(self, ndx):
         rhs = np.zeros(self.block_dim)
         rhs[:self.n_y] = 2.0 * self.y_hat[ndx]

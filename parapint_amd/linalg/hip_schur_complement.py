@@ -511,6 +511,83 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
                 for slot in slots:
                     self._eng.upload_values_compact(g.gid, g.staging, slot, 1)
 
+    def _stage_flat_values(self, matrix):
+        """Values of a HostValueMatrix (one flat vector per block: K data then A data, over the pattern object the symbolic
+        phase saw) into the staging arrays and on to the device.  A pattern group whose blocks all come in the group's
+        reference entry order is staged by ONE library call when the vectors are the rows of one 2-D array (addresses by
+        arithmetic), else with one address per block; blocks in another entry order (after a re-plan on a union pattern)
+        are canonicalised on the host like any other block."""
+        pat = matrix.pattern
+        if pat is not self._symbolic_pattern:
+            raise RuntimeError('this HostValueMatrix is not over the matrix given to do_symbolic_factorization')
+        vals = matrix.flat_values
+        verified = getattr(self._eng, 'stage_upload_verified', None)
+        self._stage_calls += 1
+        full = self.pattern_check_interval > 0 and self._stage_calls % self.pattern_check_interval == 0
+        recheck = [g for g in self._groups if g.var_runs is not None] if full and self._constant_check is None else ()
+        for g in recheck:
+            self._eng.set_variable_runs(g, g.var_runs, True)
+        two_d = isinstance(vals, np.ndarray)
+        if two_d:
+            if vals.ndim != 2 or vals.dtype != _F8 or vals.strides[1] != 8 or vals.shape[0] != len(self.local_block_indices):
+                raise ValueError('flat_values: a 2-D array must be float64 [owned blocks][entries] with contiguous rows')
+            rows_of = self._flat_rows.get('rows')
+            if rows_of is None:
+                rows_of = self._flat_rows['rows'] = {ndx: i for i, ndx in enumerate(self.local_block_indices)}
+        started = False
+        slow = []
+        try:
+            for g in self._groups:
+                nK, nB = g.nrawK, g.nraw - g.nrawK
+                cached = self._flat_rows.get(g.gid)
+                if cached is None or cached[0] is not g:
+                    same = all(self._binfo[ndx].raw_sig for ndx in g.blocks)
+                    rows = np.array([rows_of[ndx] for ndx in g.blocks], dtype=np.int64) if two_d else None
+                    cached = self._flat_rows[g.gid] = (g, same, rows)
+                _, same, rows = cached
+                if two_d and rows is None:
+                    rows = np.array([rows_of[ndx] for ndx in g.blocks], dtype=np.int64)
+                    self._flat_rows[g.gid] = (g, same, rows)
+                if verified is None or not same or (two_d and vals.shape[1] != g.nraw):
+                    slow.append(g)
+                    continue
+                if two_d:
+                    kd = (vals.ctypes.data + rows * vals.strides[0]).astype(np.uint64)
+                else:
+                    addrs = []
+                    for ndx in g.blocks:
+                        v = vals[ndx]
+                        if type(v) is not np.ndarray or v.dtype is not _F8 or v.strides != _S8 or v.size != g.nraw:
+                            addrs = None
+                            break
+                        addrs.append(_addr(v))
+                    if addrs is None:
+                        slow.append(g)
+                        continue
+                    kd = np.array(addrs, dtype=np.uint64)
+                bd = kd + np.uint64(8 * nK) if nB else np.zeros(kd.size, dtype=np.uint64)
+                started = True
+                verified(g, np.arange(len(g.blocks), dtype=np.int32), kd, bd)
+        finally:
+            try:
+                if started:
+                    self._eng.stage_upload_end()
+            finally:
+                for g in recheck:
+                    self._eng.set_variable_runs(g, g.var_runs, False)
+        last = self.block_dim - 1
+        for g in slow:
+            nK = None
+            for slot, ndx in enumerate(g.blocks):
+                v = vals[rows_of[ndx]] if two_d else vals[ndx]
+                v = np.ascontiguousarray(v, dtype=np.double).ravel()
+                kr, kc, kd0, _ = _coo(pat.get_block(ndx, ndx))
+                br, bc, _bd = self._border(pat, ndx)
+                if v.size != kd0.size + _bd.size:
+                    raise ValueError('flat_values: block %d has %d entries, its pattern has %d' % (ndx, v.size, kd0.size + _bd.size))
+                self._stage_block(g, slot, kr, kc, v[:kd0.size], br, bc, v[kd0.size:])
+            self._eng.upload_values_compact(g.gid, g.staging)
+
     def _stage_block(self, g, slot, kr, kc, kd, br, bc, bd):
         ref = g.raw_refs
         same = (kd.size == g.nrawK and bd.size == g.nraw - g.nrawK and
@@ -695,6 +772,8 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
         self._variant = {}
         self._last_device_base = None
         self._device_maps = (matrix.nsrc, matrix.value_maps) if device_matrix else None
+        self._symbolic_pattern = getattr(matrix, 'pattern', matrix)      # (HostValueMatrix: values over this very object)
+        self._flat_rows = {}
         self._maps_checked = None           # (new groups: the maps of their blocks are compared again)
         res = LinearSolverResults(LinearSolverStatus.successful)
         timer.start('factorize')
@@ -741,8 +820,16 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
             res = self._numeric_factorization(matrix, timer)
             self._note_refresh_outcome(res.status != LinearSolverStatus.singular)
             repairs = 0
+            # (a HostValueMatrix is spelled out as COO blocks for the rebuild of the groups: rare, and the values matter)
+            spelled = [None]
+
+            def with_values():
+                if spelled[0] is None:
+                    spelled[0] = matrix.to_block_matrix() if getattr(matrix, 'flat_values', None) is not None else matrix
+                return spelled[0]
             while (res.status == LinearSolverStatus.singular and self.split_conflicting_groups and
-                   not hasattr(matrix, 'value_maps') and repairs < self.max_pivot_repairs and self._split_conflicting(matrix)):
+                   not hasattr(matrix, 'value_maps') and repairs < self.max_pivot_repairs and
+                   self._split_conflicting(with_values())):
                 # the new sequence broke on ANOTHER instance of the group: two instances that need different sequences
                 repairs += 1
                 res = self._numeric_factorization(matrix, timer)
@@ -809,8 +896,12 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
 
     def _stage_and_upload(self, matrix):
         changed = 0
+        flat = hasattr(matrix, 'flat_values') and matrix.flat_values is not None
         try:
-            self._stage_values(matrix)
+            if flat:
+                self._stage_flat_values(matrix)
+            else:
+                self._stage_values(matrix.pattern if hasattr(matrix, 'flat_values') else matrix)
         except _PatternChanged:
             changed = 1
         if self.comm.size > 1:
@@ -820,6 +911,8 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
         if changed:
             # entries outside the planned pattern (the inertia-correction loop adds diagonal blocks): plan again
             # on the union of both patterns, as the reference's MUMPS sub-solver does (mumps_interface.py:82-83)
+            if flat:
+                raise RuntimeError('HostValueMatrix: the pattern object was modified after the symbolic factorisation')
             self._replan_union(matrix)
             self._stage_values(matrix)
         if self._pattern_only:

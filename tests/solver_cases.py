@@ -1017,6 +1017,91 @@ def case_constant_entries(make_engine, calls=None):
     assert scaled_residual(back.toarray(), x.flatten(), rhs.flatten()) <= 1e-10
 
 
+def case_flat_values(make_engine, calls=None):
+    """HostValueMatrix: the pattern object of the symbolic phase + one flat value vector per block (the rows of one 2-D
+    array, or a dictionary of vectors).  Same results as the COO blocks with the same values; one staging call per pattern
+    group for the 2-D form; works with a declaration of constant entries, after a re-plan on a union pattern (blocks are then
+    canonicalised on the host), with a coupling block of its own; a matrix over another pattern object is refused."""
+    from parapint_amd.sparse.host_value_matrix import HostValueMatrix
+    N = 7
+    model = SyntheticKKT(N, 3, 8, 2)
+    comm = SerialComm()
+    rhs = model.build_rhs(comm=comm)
+    rng = np.random.default_rng(3)
+    for ndx in range(N):
+        rhs.set_block(ndx, rng.standard_normal(model.block_dim))
+    ref = new_solver(make_engine, N)
+    flat = new_solver(make_engine, N)
+    eng_calls = getattr(flat._eng, 'calls', None) if calls is None else calls
+    pattern = model.build_kkt(comm=comm, iteration=0)
+    ref.do_symbolic_factorization(pattern)
+    flat.do_symbolic_factorization(HostValueMatrix(pattern))            # (the wrapped pattern ...)
+    assert flat.do_numeric_factorization(HostValueMatrix(pattern)).status == LinearSolverStatus.successful   # ... and its own values
+    x = flat.do_back_solve(rhs)
+    assert scaled_residual(pattern.toarray(), x.flatten(), rhs.flatten()) <= 1e-10
+    for it, form in ((1, '2d'), (2, 'dict'), (3, '2d'), (4, 'strided')):
+        kkt = model.build_kkt(comm=comm, iteration=it)
+        vals = model.flat_values(iteration=it)
+        if form == 'dict':
+            vals = {ndx: vals[i].copy() for i, ndx in enumerate(range(N))}
+        elif form == 'strided':
+            wide = np.zeros((N, vals.shape[1] + 5))
+            wide[:, :vals.shape[1]] = vals
+            vals = wide[:, :vals.shape[1]]                     # rows contiguous, row stride larger than a row
+        before = dict(eng_calls) if eng_calls is not None else None
+        assert ref.do_numeric_factorization(kkt).status == LinearSolverStatus.successful
+        hv = HostValueMatrix(pattern, vals)
+        assert flat.do_numeric_factorization(hv).status == LinearSolverStatus.successful
+        xr, xf = ref.do_back_solve(rhs), flat.do_back_solve(rhs)
+        assert np.array_equal(xr.flatten(), xf.flatten())
+        assert flat.get_inertia() == ref.get_inertia()
+        assert np.array_equal(hv.to_block_matrix().toarray(), kkt.toarray())
+        if eng_calls is not None and form != 'dict':
+            # one staging call for the one pattern group (the reference solver's blocks went one by one or in batches)
+            # (the reference solver shares the counters only when `calls` is given: its blocks go in batches of 64)
+            assert 1 <= eng_calls['stage_upload_verified'] - before['stage_upload_verified'] <= 2
+            assert eng_calls['verified_blocks'] - before['verified_blocks'] in (N, 2 * N)
+    # with a declaration of constant entries
+    flat.declare_constant_entries(model.constant_entries())
+    for it in (5, 6, 7):
+        kkt = model.build_kkt(comm=comm, iteration=it)
+        ref.do_numeric_factorization(kkt)
+        assert flat.do_numeric_factorization(HostValueMatrix(pattern, model.flat_values(iteration=it))).status == \
+            LinearSolverStatus.successful
+        assert np.array_equal(ref.do_back_solve(rhs).flatten(), flat.do_back_solve(rhs).flatten())
+    # a coupling block of its own
+    Q = coo_matrix(np.diag([0.5, 0.25]))
+    kkt = model.build_kkt(comm=comm, iteration=8)
+    kkt.set_block(N, N, Q)
+    ref.do_numeric_factorization(kkt)
+    flat.do_numeric_factorization(HostValueMatrix(pattern, model.flat_values(iteration=8), Q=Q))
+    xf = flat.do_back_solve(rhs)
+    assert np.array_equal(ref.do_back_solve(rhs).flatten(), xf.flatten())
+    assert scaled_residual(kkt.toarray(), xf.flatten(), rhs.flatten()) <= 1e-10
+    # another pattern object, a wrong shape
+    other = model.build_kkt(comm=comm, iteration=0)
+    for bad in (HostValueMatrix(other, model.flat_values(iteration=1)), HostValueMatrix(pattern, np.zeros((N, 3)))):
+        try:
+            flat.do_numeric_factorization(bad)
+            raise AssertionError('refused matrices must raise')
+        except (RuntimeError, ValueError) as err:
+            assert 'HostValueMatrix' in str(err) or 'flat_values' in str(err), str(err)
+    # after a re-plan on a union pattern (a regularised COO matrix in between) the flat form still works: its blocks are
+    # then in another entry order than the new plan's and are canonicalised on the host
+    reg = model.build_kkt(comm=comm, iteration=9)
+    n = model.block_dim
+    for ndx in range(N):
+        K = reg.get_block(ndx, ndx)
+        d = np.concatenate([np.zeros(model.n_y + model.n_q), -1e-3 * np.ones(n - model.n_y - model.n_q)])
+        reg.set_block(ndx, ndx, (K + sp.diags(d)).tocoo())
+    assert flat.do_numeric_factorization(reg).status == LinearSolverStatus.successful
+    kkt = model.build_kkt(comm=comm, iteration=10)
+    assert flat.do_numeric_factorization(HostValueMatrix(pattern, model.flat_values(iteration=10))).status == \
+        LinearSolverStatus.successful
+    x = flat.do_back_solve(rhs)
+    assert scaled_residual(kkt.toarray(), x.flatten(), rhs.flatten()) <= 1e-10
+
+
 def case_boundary_fast_paths(make_engine, calls=None):
     """do_numeric_factorization / do_back_solve with host blocks, over the ways an interface hands its matrix over:
     new COO blocks over the same index arrays, the same blocks with .data rewritten in place or replaced, index arrays

@@ -599,10 +599,12 @@ def test_bench_single_rank_line_has_the_contract_fields():
     res = _run_bench({}, '--workload', 'C2', '--steps', '5', '--warmup', '2', '--no-cpu-baseline', '--boundary-iterations', '2')
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
                 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'boundary_host', 'device_only',
-                'value_no_prefetch', 'ms_per_step_no_prefetch', 'value_boundary_constant_declared'):
+                'value_no_prefetch', 'ms_per_step_no_prefetch', 'value_boundary_constant_declared',
+                'value_boundary_flat_values'):
         assert key in res
     assert res['value_no_prefetch'] > 0 and res['value_boundary_constant_declared'] > 0
     assert res['boundary_host_constant_declared']['residual'] <= 1e-8
+    assert res['boundary_host_flat_values']['residual'] <= 1e-8 and res['boundary_host_flat_values']['constant_declared']['residual'] <= 1e-8
     assert res['correct'] is True and res['n_gpus'] == 1 and res['roofline']['bound'] == 'hbm'
     assert abs(res['value'] * res['ms_per_step'] / 1e3 - 1.0) < 1e-6
 
@@ -792,6 +794,12 @@ def test_entries_declared_constant_by_the_producer_on_the_device():
     """declare_constant_entries -> pp_set_variable_runs: rows whose staged copy mirrors the device are compared and copied
     over the variable entries only; same results as an undeclared solver; a declaration that does not hold is reported."""
     sc.case_constant_entries(lambda: None)
+
+
+def test_flat_value_vectors_over_the_symbolic_pattern_on_the_device():
+    """HostValueMatrix (one flat value vector per block over the pattern object of the symbolic phase): a pattern group is
+    staged by one pp_stage_upload_verified_begin call; results equal those of the COO blocks with the same values."""
+    sc.case_flat_values(lambda: None)
 
 
 def test_switching_input_forms_between_factorisations_ends_the_staging_mirror():

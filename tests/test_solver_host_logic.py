@@ -115,5 +115,9 @@ def test_entries_declared_constant_by_the_producer():
     sc.case_constant_entries(HostSimBoundaryEngine)
 
 
+def test_flat_value_vectors_over_the_symbolic_pattern():
+    sc.case_flat_values(HostSimBoundaryEngine)
+
+
 def test_zero_pivot_test_inside_a_mixed_scale_block_pivot():
     sc.case_mixed_scale_block_pivot(HostSimEngine)
