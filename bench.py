@@ -124,6 +124,101 @@ def build_bytes_per_block(st, ex, n_c, batch, fused_sources=True):
     return b
 
 
+def host_boundary_section(solver, model, comm, world, dist, iterations, residual_check, expected_inertia):
+    """SURVEY 8(d) to the letter: host SciPy COO blocks in, host vectors out -- and the two opt-in variants of handing the
+    values over (constant entries declared; flat value vectors).  Returns (boundary, declared, flat_plain, residual, ok,
+    seconds of the symbolic phase)."""
+    boundary = declared = flat_plain = flat_declared = None
+    ok = True
+    kkt = model.build_kkt(comm=comm, iteration=0)
+    rhs = model.build_rhs(comm=comm)
+    t0 = time.perf_counter()
+    solver.do_symbolic_factorization(kkt)
+    t_symbolic_host = time.perf_counter() - t0
+    solver.do_numeric_factorization(kkt)
+    solver.do_back_solve(rhs)
+    class _Phases(object):            # (the solver's timer labels, mpi_...:207-255 / 291-360 plus the boundary's own)
+        def __init__(self):
+            self.t, self.open = {}, {}
+
+        def start(self, name):
+            self.open[name] = time.perf_counter()
+
+        def stop(self, name):
+            self.t.setdefault(name, []).append(time.perf_counter() - self.open.pop(name))
+
+    def boundary_loop(first, flat=False):
+        ts = []
+        phases = _Phases()
+        kkt_it = x = None
+        for it in range(first, first + iterations):
+            kkt_it = model.build_kkt(comm=comm, iteration=it)
+            handed = HostValueMatrix(kkt, model.flat_values(iteration=it)) if flat else kkt_it
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            solver.do_numeric_factorization(matrix=handed, raise_on_error=False, timer=phases)
+            x = solver.do_back_solve(rhs, timer=phases)
+            ts.append(time.perf_counter() - t0)
+        med = float(np.median(ts))
+        if world > 1:
+            med = float(comm.allreduce_max(np.array([med]))[0])
+        return med, ts, phases, kkt_it, x
+
+    def phase_table(phases):
+        return {k: round(1e3 * float(np.median(v)), 3) for k, v in phases.t.items()
+                if k in ('values to device', 'factorize', 'form SC', 'factor SC', 'rhs to device', 'solve',
+                         'solution to host', 'back_solve')}
+
+    # the same loop with the entries that do not depend on the iteration declared constant by the producer (an
+    # interface with linear constraints knows them: solver.declare_constant_entries) -- a second number, `value_boundary`
+    # stays the undeclared one
+    if hasattr(model, 'constant_entries') and hasattr(solver, 'declare_constant_entries'):
+        solver.declare_constant_entries(model.constant_entries())
+        med_d, ts_d, phases_d, kkt_d, x_d = boundary_loop(101)
+        resid_d = residual_check(kkt_d, x_d, rhs)
+        ok = ok and resid_d <= 1e-8 and tuple(solver.get_inertia()) == expected_inertia
+        declared = {'it_per_s': 1.0 / med_d, 'ms_per_iteration': 1e3 * med_d, 'iterations': len(ts_d),
+                    'phases_ms': phase_table(phases_d), 'residual': resid_d,
+                    'note': 'as boundary_host, after solver.declare_constant_entries(...): the Jacobian and identity '
+                            'entries of the synthetic KKT system are not compared or copied again (pp_set_variable_runs)'}
+        # ... and with the values handed over as the rows of one flat array over the symbolic phase's pattern object
+        # (HostValueMatrix: one staging call per pattern group instead of a walk over 2 x N SciPy objects)
+        if hasattr(model, 'flat_values'):
+            from parapint_amd.sparse.host_value_matrix import HostValueMatrix
+            med_f, ts_f, phases_f, kkt_f, x_f = boundary_loop(201, flat=True)
+            resid_f = residual_check(kkt_f, x_f, rhs)
+            ok = ok and resid_f <= 1e-8 and tuple(solver.get_inertia()) == expected_inertia
+            flat_declared = {'it_per_s': 1.0 / med_f, 'ms_per_iteration': 1e3 * med_f, 'phases_ms': phase_table(phases_f),
+                             'residual': resid_f}
+            del kkt_f, x_f
+        solver.declare_constant_entries(None)
+        del kkt_d, x_d
+    if hasattr(model, 'flat_values') and hasattr(model, 'constant_entries'):
+        from parapint_amd.sparse.host_value_matrix import HostValueMatrix
+        med_f, ts_f, phases_f, kkt_f, x_f = boundary_loop(301, flat=True)
+        resid_f = residual_check(kkt_f, x_f, rhs)
+        ok = ok and resid_f <= 1e-8 and tuple(solver.get_inertia()) == expected_inertia
+        flat_plain = {'it_per_s': 1.0 / med_f, 'ms_per_iteration': 1e3 * med_f, 'iterations': len(ts_f),
+                      'phases_ms': phase_table(phases_f), 'residual': resid_f,
+                      'constant_declared': flat_declared,
+                      'note': 'as boundary_host, the values handed over as HostValueMatrix(pattern, [blocks][entries]) '
+                              '(opt-in container: flat value vectors over the pattern object of the symbolic phase); '
+                              'constant_declared: the same after solver.declare_constant_entries(...)'}
+        del kkt_f, x_f
+    med, ts, phases, kkt_it, x = boundary_loop(1)
+    boundary = {'it_per_s': 1.0 / med, 'ms_per_iteration': 1e3 * med, 'iterations': len(ts),
+                'phases_ms': phase_table(phases),
+                'note': 'host COO blocks in, host vectors out: needed entries staged into pinned memory on host '
+                        'threads with the H2D overlapped, pinned D2H of x; median, max over ranks; phases_ms: host '
+                        'wall time between the labels (rank 0; "factorize" contains "values to device", '
+                        '"form SC" contains "factorize", "back_solve" its three parts)'}
+    resid_boundary = residual_check(kkt_it, x, rhs)
+    ok = ok and resid_boundary <= 1e-8 and tuple(solver.get_inertia()) == expected_inertia
+    del kkt, kkt_it, x
+    return boundary, declared, flat_plain, resid_boundary, ok, t_symbolic_host
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -234,96 +329,12 @@ def main():
     # ---- (1) host boundary: SciPy COO blocks in, host vectors out
     boundary = None
     declared = None
-    flat_plain = flat_declared = None
+    flat_plain = None
     resid_boundary = None
     ok = True
     if not args.no_boundary:
-        kkt = model.build_kkt(comm=comm, iteration=0)
-        rhs = model.build_rhs(comm=comm)
-        t0 = time.perf_counter()
-        solver.do_symbolic_factorization(kkt)
-        t_symbolic_host = time.perf_counter() - t0
-        solver.do_numeric_factorization(kkt)
-        solver.do_back_solve(rhs)
-        class _Phases(object):            # (the solver's timer labels, mpi_...:207-255 / 291-360 plus the boundary's own)
-            def __init__(self):
-                self.t, self.open = {}, {}
-
-            def start(self, name):
-                self.open[name] = time.perf_counter()
-
-            def stop(self, name):
-                self.t.setdefault(name, []).append(time.perf_counter() - self.open.pop(name))
-
-        def boundary_loop(first, flat=False):
-            ts = []
-            phases = _Phases()
-            kkt_it = x = None
-            for it in range(first, first + args.boundary_iterations):
-                kkt_it = model.build_kkt(comm=comm, iteration=it)
-                handed = HostValueMatrix(kkt, model.flat_values(iteration=it)) if flat else kkt_it
-                if world > 1:
-                    dist.barrier()
-                t0 = time.perf_counter()
-                solver.do_numeric_factorization(matrix=handed, raise_on_error=False, timer=phases)
-                x = solver.do_back_solve(rhs, timer=phases)
-                ts.append(time.perf_counter() - t0)
-            med = float(np.median(ts))
-            if world > 1:
-                med = float(comm.allreduce_max(np.array([med]))[0])
-            return med, ts, phases, kkt_it, x
-
-        def phase_table(phases):
-            return {k: round(1e3 * float(np.median(v)), 3) for k, v in phases.t.items()
-                    if k in ('values to device', 'factorize', 'form SC', 'factor SC', 'rhs to device', 'solve',
-                             'solution to host', 'back_solve')}
-
-        # the same loop with the entries that do not depend on the iteration declared constant by the producer (an
-        # interface with linear constraints knows them: solver.declare_constant_entries) -- a second number, `value_boundary`
-        # stays the undeclared one
-        if hasattr(model, 'constant_entries') and hasattr(solver, 'declare_constant_entries'):
-            solver.declare_constant_entries(model.constant_entries())
-            med_d, ts_d, phases_d, kkt_d, x_d = boundary_loop(101)
-            resid_d = residual_check(kkt_d, x_d, rhs)
-            ok = ok and resid_d <= 1e-8 and tuple(solver.get_inertia()) == expected_inertia
-            declared = {'it_per_s': 1.0 / med_d, 'ms_per_iteration': 1e3 * med_d, 'iterations': len(ts_d),
-                        'phases_ms': phase_table(phases_d), 'residual': resid_d,
-                        'note': 'as boundary_host, after solver.declare_constant_entries(...): the Jacobian and identity '
-                                'entries of the synthetic KKT system are not compared or copied again (pp_set_variable_runs)'}
-            # ... and with the values handed over as the rows of one flat array over the symbolic phase's pattern object
-            # (HostValueMatrix: one staging call per pattern group instead of a walk over 2 x N SciPy objects)
-            if hasattr(model, 'flat_values'):
-                from parapint_amd.sparse.host_value_matrix import HostValueMatrix
-                med_f, ts_f, phases_f, kkt_f, x_f = boundary_loop(201, flat=True)
-                resid_f = residual_check(kkt_f, x_f, rhs)
-                ok = ok and resid_f <= 1e-8 and tuple(solver.get_inertia()) == expected_inertia
-                flat_declared = {'it_per_s': 1.0 / med_f, 'ms_per_iteration': 1e3 * med_f, 'phases_ms': phase_table(phases_f),
-                                 'residual': resid_f}
-                del kkt_f, x_f
-            solver.declare_constant_entries(None)
-            del kkt_d, x_d
-        if hasattr(model, 'flat_values') and hasattr(model, 'constant_entries'):
-            from parapint_amd.sparse.host_value_matrix import HostValueMatrix
-            med_f, ts_f, phases_f, kkt_f, x_f = boundary_loop(301, flat=True)
-            resid_f = residual_check(kkt_f, x_f, rhs)
-            ok = ok and resid_f <= 1e-8 and tuple(solver.get_inertia()) == expected_inertia
-            flat_plain = {'it_per_s': 1.0 / med_f, 'ms_per_iteration': 1e3 * med_f, 'iterations': len(ts_f),
-                          'phases_ms': phase_table(phases_f), 'residual': resid_f,
-                          'constant_declared': flat_declared,
-                          'note': 'as boundary_host, the values handed over as HostValueMatrix(pattern, [blocks][entries]) '
-                                  '(opt-in container: flat value vectors over the pattern object of the symbolic phase); '
-                                  'constant_declared: the same after solver.declare_constant_entries(...)'}
-            del kkt_f, x_f
-        med, ts, phases, kkt_it, x = boundary_loop(1)
-        boundary = {'it_per_s': 1.0 / med, 'ms_per_iteration': 1e3 * med, 'iterations': len(ts),
-                    'phases_ms': phase_table(phases),
-                    'note': 'host COO blocks in, host vectors out: needed entries staged into pinned memory on host '
-                            'threads with the H2D overlapped, pinned D2H of x; median, max over ranks; phases_ms: host '
-                            'wall time between the labels (rank 0; "factorize" contains "values to device", '
-                            '"form SC" contains "factorize", "back_solve" its three parts)'}
-        resid_boundary = residual_check(kkt_it, x, rhs)
-        ok = ok and resid_boundary <= 1e-8 and tuple(solver.get_inertia()) == expected_inertia
-        del kkt, kkt_it, x
+        boundary, declared, flat_plain, resid_boundary, ok, t_symbolic_host = host_boundary_section(
+            solver, model, comm, world, dist, args.boundary_iterations, residual_check, expected_inertia)
 
     # ---- (2) the measured path: device-resident matrix and vectors through the LinearSolverInterface methods
     dkkt = model.build_device_kkt(comm=comm)

@@ -119,5 +119,33 @@ def test_flat_value_vectors_over_the_symbolic_pattern():
     sc.case_flat_values(HostSimBoundaryEngine)
 
 
+def test_bench_host_boundary_section_on_the_host_engine():
+    """bench.py's host-boundary legs (COO blocks; constant entries declared; flat value vectors, with and without the
+    declaration) with the solver class on the host-simulation engine: every leg returns a rate, a residual and the phases."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    from parapint_amd.examples.performance.schur_complement.synthetic_kkt import SyntheticKKT
+    from parapint_amd.linalg.comm import SerialComm
+    N = 6
+    model = SyntheticKKT(N, 3, 8, 2)
+    comm = SerialComm()
+    solver = sc.new_solver(HostSimBoundaryEngine, N)
+
+    def residual_check(kkt, x, rhs):
+        return sc.scaled_residual(kkt.toarray(), x.flatten(), rhs.flatten())
+    expected = (N * (model.n_y + model.n_q) + model.n_theta, N * (model.n_y + model.n_theta), 0)
+    boundary, declared, flat_plain, resid, ok, t_sym = bench.host_boundary_section(solver, model, comm, 1, None, 3,
+                                                                                  residual_check, expected)
+    assert ok and resid <= 1e-10 and t_sym > 0
+    for leg in (boundary, declared, flat_plain, flat_plain['constant_declared']):
+        assert leg['it_per_s'] > 0 and 'values to device' in leg['phases_ms'] and 'solve' in leg['phases_ms']
+    assert declared['residual'] <= 1e-10 and flat_plain['residual'] <= 1e-10
+    assert all(g.var_runs is None for g in solver._groups)              # (the declaration was withdrawn again)
+
+
 def test_zero_pivot_test_inside_a_mixed_scale_block_pivot():
     sc.case_mixed_scale_block_pivot(HostSimEngine)
