@@ -66,6 +66,23 @@ def main():
     assert np.abs(o2.schur_complement.toarray() - So).max() <= 1e-10 * np.abs(So).max()
     assert o2.get_inertia() == oracle.get_inertia()
 
+    # flat value vectors over the pattern object (HostValueMatrix): row i = the i-th block THIS rank owns; with the
+    # producer's declaration of its constant entries
+    from parapint_amd.sparse.host_value_matrix import HostValueMatrix
+    solver.declare_constant_entries(model.constant_entries())
+    for it in (4, 5):
+        assert solver.do_numeric_factorization(HostValueMatrix(kkt, model.flat_values(iteration=it))).status == \
+            LinearSolverStatus.successful
+        xf = solver.do_back_solve(rhs)
+        k_it = model.build_kkt(comm=comm, iteration=it)
+        assert solver.do_numeric_factorization(k_it).status == LinearSolverStatus.successful
+        xk = solver.do_back_solve(rhs)
+        for ndx in local:
+            assert np.array_equal(np.asarray(xf.get_block(ndx)), np.asarray(xk.get_block(ndx)))
+        assert np.array_equal(np.asarray(xf.get_block(N)), np.asarray(xk.get_block(N)))
+    solver.declare_constant_entries(None)
+    assert solver.do_numeric_factorization(kkt).status == LinearSolverStatus.successful
+
     # status agreement: a singular block on rank 1 only must be reported by both ranks
     if rank == 1:
         from scipy.sparse import coo_matrix
