@@ -147,5 +147,18 @@ def test_bench_host_boundary_section_on_the_host_engine():
     assert all(g.var_runs is None for g in solver._groups)              # (the declaration was withdrawn again)
 
 
+def test_random_systems_in_random_input_forms():
+    """A slice of tools/fuzz_solver.py: random block-bordered systems (several pattern groups, mapped or uniform coupling),
+    six factorisations each with the values handed over in changing forms, every solve against dense algebra."""
+    import os
+    import sys
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools')
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    import fuzz_solver
+    bad = [r for r in (fuzz_solver.one(seed) for seed in range(120)) if r is not None]
+    assert not bad, bad
+
+
 def test_zero_pivot_test_inside_a_mixed_scale_block_pivot():
     sc.case_mixed_scale_block_pivot(HostSimEngine)
