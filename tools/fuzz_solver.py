@@ -5,7 +5,11 @@ vectors as a dictionary / one array, constant entries declared and withdrawn, en
 solve is checked against dense algebra (scaled residual <= 1e-9, inertia from the eigenvalues).  Systems that ARE singular
 (or have a singular diagonal block, which the reference's block factorisation cannot take either) must be reported so.
 
-    python tools/fuzz_solver.py FIRST_SEED COUNT [PROCESSES]      (20 000 seeds: 2 minutes on two cores; round 5: none failed)
+    python tools/fuzz_solver.py FIRST_SEED COUNT [PROCESSES] [--hard]     (20 000 seeds: 2 minutes on two cores)
+
+--hard: zero Hessian entries (2 x 2 pivots) and Jacobian entries scaled by up to 1e-7 per instance and iteration (pivot
+sequences that differ between the instances of a group: refreshes, variants); accuracy is then asked for relative to the
+condition number, systems beyond 1e7 are skipped.
 """
 import os
 import sys
@@ -35,7 +39,7 @@ def block_values(pat, h, jvals):
     return v[pat['perm']]
 
 
-def one(seed):
+def one(seed, hard=False):
     rng = np.random.default_rng(seed)
     import solver_cases as sc
     from hostsim_engine import HostSimBoundaryEngine
@@ -70,9 +74,26 @@ def one(seed):
     bvals = [rng.normal(size=brows[i].size) + 1.0 for i in range(N)]
     Qd = rng.uniform(0.5, 1.5, size=nc) if rng.random() < 0.5 else None
 
+    hzero = [rng.random(p['n_x']) < 0.3 for p in pats] if hard else None
+
     def values(it):
         r = np.random.default_rng(1000 * seed + it)
-        return [r.uniform(0.5, 2.0, size=pats[which[i]]['n_x']) for i in range(N)]
+        hs = [r.uniform(0.5, 2.0, size=pats[which[i]]['n_x']) for i in range(N)]
+        if hard:
+            for i in range(N):
+                hs[i][hzero[which[i]]] = 0.0
+        return hs
+
+    def jac(it, i):
+        if not hard:
+            return jblock[i]
+        r = np.random.default_rng(77 * seed + 13 * it + i)
+        j = jblock[i].copy()
+        k = int(r.integers(0, 4))
+        if k:
+            sel = r.choice(j.size, size=min(k, j.size), replace=False)
+            j[sel] *= 10.0 ** r.uniform(-7, 0, size=sel.size)
+        return j
 
     extra = {}
 
@@ -81,7 +102,7 @@ def one(seed):
         hs = values(it)
         for i in range(N):
             p = pats[which[i]]
-            v = block_values(p, hs[i], jblock[i])
+            v = block_values(p, hs[i], jac(it, i))
             rows, cols = p['rows'], p['cols']
             if grown and i in extra:
                 er, ec, evl = extra[i]
@@ -123,7 +144,7 @@ def one(seed):
                 if declared:
                     solver.declare_constant_entries(None)
                     declared = False
-            if form == 'declare' and not declared:
+            if form == 'declare' and not declared and not hard:
                 mask = {}
                 for i in range(N):
                     p = pats[which[i]]
@@ -155,9 +176,17 @@ def one(seed):
             x = solver.do_back_solve(rhs)
             Kd = kkt.toarray()
             r = sc.scaled_residual(Kd, x.flatten(), rhs.flatten())
-            if not r <= 1e-9:
-                return (seed, 'residual', r, form, it)
             ev = np.linalg.eigvalsh(Kd)
+            if hard:
+                cond = np.abs(ev).max() / max(np.abs(ev).min(), 1e-300)
+                bcond = max(np.abs(b).max() / max(np.abs(b).min(), 1e-300)
+                            for b in (np.linalg.eigvalsh(kkt.get_block(i, i).toarray()) for i in range(N)))
+                if max(cond, bcond) > 1e7:
+                    continue
+                if not r <= 1e-9 * max(cond, bcond):
+                    return (seed, 'residual', r, cond, bcond, form, it)
+            elif not r <= 1e-9:
+                return (seed, 'residual', r, form, it)
             if np.abs(ev).min() <= 1e-9 * np.abs(ev).max():
                 continue                              # (numerically singular: the sign of a rounding-level eigenvalue is not defined)
             inertia = (int((ev > 0).sum()), int((ev < 0).sum()), 0)
@@ -169,13 +198,19 @@ def one(seed):
     return None
 
 
+def one_hard(seed):
+    return one(seed, hard=True)
+
+
 if __name__ == '__main__':
+    hard_mode = '--hard' in sys.argv
+    sys.argv = [a for a in sys.argv if a != '--hard']
     from multiprocessing import Pool
     s0, n = int(sys.argv[1]), int(sys.argv[2])
     t0 = time.time()
     bad = []
     with Pool(int(sys.argv[3]) if len(sys.argv) > 3 else 2) as p:
-        for i, r in enumerate(p.imap_unordered(one, range(s0, s0 + n), chunksize=4)):
+        for i, r in enumerate(p.imap_unordered(one_hard if hard_mode else one, range(s0, s0 + n), chunksize=4)):
             if r is not None:
                 bad.append(r); print(r, flush=True)
             if (i + 1) % 100 == 0:
