@@ -181,7 +181,7 @@ def host_boundary_section(solver, model, comm, world, dist, iterations, residual
         declared = {'it_per_s': 1.0 / med_d, 'ms_per_iteration': 1e3 * med_d, 'iterations': len(ts_d),
                     'phases_ms': phase_table(phases_d), 'residual': resid_d,
                     'note': 'as boundary_host, after solver.declare_constant_entries(...): the Jacobian and identity '
-                            'entries of the synthetic KKT system are not compared or copied again (pp_set_variable_runs)'}
+                            'entries of the synthetic KKT system are not compared or copied again (the staging threads get the runs of the other entries only)'}
         # ... and with the values handed over as the rows of one flat array over the symbolic phase's pattern object
         # (HostValueMatrix: one staging call per pattern group instead of a walk over 2 x N SciPy objects)
         if hasattr(model, 'flat_values'):

@@ -326,16 +326,6 @@ int pp_stage_upload_verified_begin(pp_handle h, int group, int nblocks, int nthr
                                    const double* const* bd, int64_t ref_knnz, int64_t ref_bnnz, int nruns_k, const int64_t* runs_k,
                                    int nruns_b, const int64_t* runs_b, double* staging, const int32_t* slots);
 int pp_stage_upload_end(pp_handle h);
-
-/* Entries a producer declares CONSTANT between numeric factorisations (the Jacobian of linear constraints, the Hessian of
- * a QP: the reference's interfaces re-evaluate them at every iteration, parapint/interfaces/interface.py:
- * evaluate_primal_dual_kkt_matrix, and its sub-solvers read all of them again).  runs_k / runs_b: (first raw entry, length,
- * destination in the compact row) triples like those of pp_stage_upload_verified_begin, over the entries that MAY change;
- * a later pp_stage_upload_verified_begin compares and copies these runs only for rows whose staged copy mirrors the
- * device, the full runs for every other row.  check != 0: the staging passes also compare the constant entries, send
- * what differs and make pp_stage_upload_end fail with status 3 (a declaration that does not hold).  nruns_k < 0 withdraws
- * the declaration; a symbolic phase ends it (groups are made anew). */
-int pp_set_variable_runs(pp_handle h, int group, int nruns_k, const int64_t* runs_k, int nruns_b, const int64_t* runs_b, int check);
 /* dst[idx[i]][0 .. row_doubles) = src[i][0 .. row_doubles) on host threads: the right-hand sides of the local blocks into
  * the rows of their staging array (handle-free, no device work). */
 int pp_copy_rows(int nrows, int nthreads, const double* const* src, const int64_t* idx, double* dst, int64_t row_doubles);

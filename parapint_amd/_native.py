@@ -125,7 +125,6 @@ SIGNATURES = {
                                      ctypes.c_int, ctypes.c_void_p]),
     'pp_ip_wait': (ctypes.c_int, [ctypes.c_void_p, _f64p]),
     'pp_ip_phase_times': (ctypes.c_int, [ctypes.c_void_p, _f64p, _i32p, _i32p]),
-    'pp_set_variable_runs': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]),
     'pp_comm_allgather': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
     'pp_comm_unique_id': (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint8)]),
     'pp_comm_init': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint8)]),

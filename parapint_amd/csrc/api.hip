@@ -1250,33 +1250,18 @@ struct StageJob {
   std::vector<uint8_t> changed;          // [block][chunk]
   std::atomic<long long> sent_bytes{0};
   bool compare = true;
-  // pp_set_variable_runs: valid rows look at these runs only (have_var); check_constants: afterwards at the full runs, too
-  // -- whatever differs then is an entry declared constant (copied all the same, and reported by pp_stage_upload_end)
-  std::vector<int64_t> var_k, var_b;
-  bool have_var = false, check_constants = false;
-  std::atomic<int> constant_changed{0};
-  bool stage_run(double* row, const double* src, size_t d, size_t len, bool valid, uint8_t* mark) {
+  void stage_run(double* row, const double* src, size_t d, size_t len, bool valid, uint8_t* mark) {
     size_t p0 = d;
     const size_t end = d + len;
-    bool any = false;
     while (p0 < end) {
       const size_t p1 = std::min(end, (p0 / CH + 1) * CH);
       const size_t bytes = (p1 - p0) * sizeof(double);
       if (!valid || std::memcmp(row + p0, src + (p0 - d), bytes) != 0) {
         std::memcpy(row + p0, src + (p0 - d), bytes);
         mark[p0 / CH] = 1;
-        any = true;
       }
       p0 = p1;
     }
-    return any;
-  }
-  bool stage_runs(double* row, const double* k, const double* b, const std::vector<int64_t>& rk, const std::vector<int64_t>& rb,
-                  bool valid, uint8_t* mark) {
-    bool any = false;
-    for (size_t r = 0; r + 2 < rk.size() + 1; r += 3) any |= stage_run(row, k + rk[r], (size_t)rk[r + 2], (size_t)rk[r + 1], valid, mark);
-    for (size_t r = 0; r + 2 < rb.size() + 1; r += 3) any |= stage_run(row, b + rb[r], (size_t)rb[r + 2], (size_t)rb[r + 1], valid, mark);
-    return any;
   }
   void work() {
     bool device_set = false;
@@ -1287,13 +1272,8 @@ struct StageJob {
       double* row = staging + slot * stride;
       const bool valid = compare && row_valid[slot] != 0;
       uint8_t* mark = changed.data() + (size_t)i * nchunk;
-      if (valid && have_var) {
-        (void)stage_runs(row, kd[(size_t)i], bd[(size_t)i], var_k, var_b, true, mark);
-        if (check_constants && stage_runs(row, kd[(size_t)i], bd[(size_t)i], runs_k, runs_b, true, mark))
-          constant_changed.store(1, std::memory_order_relaxed);
-      } else {
-        (void)stage_runs(row, kd[(size_t)i], bd[(size_t)i], runs_k, runs_b, valid, mark);
-      }
+      for (size_t r = 0; r + 2 < runs_k.size() + 1; r += 3) stage_run(row, kd[(size_t)i] + runs_k[r], (size_t)runs_k[r + 2], (size_t)runs_k[r + 1], valid, mark);
+      for (size_t r = 0; r + 2 < runs_b.size() + 1; r += 3) stage_run(row, bd[(size_t)i] + runs_b[r], (size_t)runs_b[r + 2], (size_t)runs_b[r + 1], valid, mark);
       const int s = i / slice, i0 = s * slice, i1 = std::min(nblocks, i0 + slice);
       if (done[(size_t)s].fetch_add(1, std::memory_order_acq_rel) + 1 == i1 - i0 && stride > 0) {
         // the last block of the slice: its rows go to the device (rows of blocks outside the call lie in between only
@@ -1335,46 +1315,12 @@ int stage_job_finish(pp_handle h) {
   if (!j) return 0;
   h->stage_pool.wait();
   const int e = j->err.load();
-  const bool constant_changed = j->constant_changed.load() != 0;
   delete j;
   h->stage_job = nullptr;
   if (e != 0) return fail(h, 3, std::string("pp_stage_upload_verified_begin: copy failed: ") + hipGetErrorString((hipError_t)e));
-  // (the new values are on the device all the same: the factorisation that follows is of the matrix handed over)
-  if (constant_changed) return fail(h, 3, "staging: an entry declared constant (pp_set_variable_runs) has changed since it was staged");
   return 0;
 }
 }  // namespace
-
-// Runs (e0, length, destination) -- a subset of the runs pp_stage_upload_verified_begin is given -- over the raw entries
-// whose values may change between numeric factorisations; everything outside them is declared constant by the producer
-// until the next symbolic phase (the Jacobian of linear constraints, the Hessian of a QP).  A staging pass looks at these
-// runs only, for rows whose staged copy mirrors the device; check != 0: it also compares the rest and pp_stage_upload_end
-// fails with status 3 if a constant entry differs (the new values are sent all the same).  nruns_k < 0: no declaration.
-int pp_set_variable_runs(pp_handle h, int group, int nruns_k, const int64_t* runs_k, int nruns_b, const int64_t* runs_b, int check) {
-  Group* g = get_group(h, group);
-  if (!g || !h->symbolic_done) return fail(h, 3, "pp_set_variable_runs: bad group or symbolic phase not finished");
-  if (int rc = stage_job_finish(h)) return rc;
-  if (nruns_k < 0) {
-    g->var_runs_k.clear(); g->var_runs_b.clear();
-    g->have_var_runs = g->check_constants = false;
-    return 0;
-  }
-  if ((nruns_k > 0 && !runs_k) || nruns_b < 0 || (nruns_b > 0 && !runs_b)) return fail(h, 3, "pp_set_variable_runs: bad arguments");
-  const int64_t nk = (int64_t)g->nraw, stride = (int64_t)g->nraw_used;
-  for (int pass = 0; pass < 2; ++pass) {
-    const int64_t* r = pass ? runs_b : runs_k;
-    for (int i = 0; i < (pass ? nruns_b : nruns_k); ++i)
-      if (r[3 * i] < 0 || r[3 * i + 1] <= 0 || r[3 * i + 2] < 0 || r[3 * i] + r[3 * i + 1] > nk || r[3 * i + 2] + r[3 * i + 1] > stride)
-        return fail(h, 3, "pp_set_variable_runs: run outside the block's entries or the compact row");
-  }
-  try {
-    g->var_runs_k.assign(runs_k, runs_k + 3 * (size_t)nruns_k);
-    g->var_runs_b.assign(runs_b, runs_b + 3 * (size_t)nruns_b);
-  } catch (...) { g->have_var_runs = false; return fail(h, 3, "pp_set_variable_runs: out of host memory"); }
-  g->have_var_runs = true;
-  g->check_constants = check != 0;
-  return 0;
-}
 
 int pp_stage_upload_verified_begin(pp_handle h, int group, int nblocks, int nthreads, const double* const* kd,
                                    const double* const* bd, int64_t ref_knnz, int64_t ref_bnnz, int nruns_k, const int64_t* runs_k,
@@ -1397,8 +1343,6 @@ int pp_stage_upload_verified_begin(pp_handle h, int group, int nblocks, int nthr
   g->input_mode = Group::IN_COMPACT;
   StageJob* j = new (std::nothrow) StageJob;
   if (!j) return fail(h, 3, "pp_stage_upload_verified_begin: out of host memory");
-  // (a small batch in four slices at least: the first copies leave while the other rows are still compared)
-  j->slice = std::max(8, std::min(64, (nblocks + 3) / 4));
   try {
     j->kd.assign(kd, kd + nblocks); j->bd.assign(bd, bd + nblocks); j->slots.assign(slots, slots + nblocks);
     j->runs_k.assign(runs_k, runs_k + 3 * (size_t)nruns_k);
@@ -1414,17 +1358,6 @@ int pp_stage_upload_verified_begin(pp_handle h, int group, int nblocks, int nthr
   j->nchunk = (j->stride + StageJob::CH - 1) / StageJob::CH;
   static const bool no_compare = pp::env_switch("PP_NO_STAGE_COMPARE") != nullptr;      // (measurement switch)
   j->compare = !no_compare;
-  if (g->have_var_runs && j->compare) {
-    // (sources shorter than a run's end cannot be told here any better than for the full runs: same bound, the block's
-    // reference entry counts)
-    bool ok = true;
-    for (size_t r = 0; r + 2 < g->var_runs_k.size() + 1 && ok; r += 3) ok = g->var_runs_k[r] + g->var_runs_k[r + 1] <= ref_knnz;
-    for (size_t r = 0; r + 2 < g->var_runs_b.size() + 1 && ok; r += 3) ok = g->var_runs_b[r] + g->var_runs_b[r + 1] <= ref_bnnz;
-    if (!ok) { delete j; return fail(h, 3, "pp_stage_upload_verified_begin: a variable run ends behind the block's entries"); }
-    try { j->var_k = g->var_runs_k; j->var_b = g->var_runs_b; } catch (...) { delete j; return fail(h, 3, "pp_stage_upload_verified_begin: out of host memory"); }
-    j->have_var = true;
-    j->check_constants = g->check_constants;
-  }
   try { j->changed.assign((size_t)nblocks * j->nchunk, 0); } catch (...) { delete j; return fail(h, 3, "pp_stage_upload_verified_begin: out of host memory"); }
   h->stage_job = j;
   const int nt = std::max(1, std::min(std::min(nthreads, 64), nblocks));

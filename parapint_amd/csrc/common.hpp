@@ -231,11 +231,6 @@ struct Group {
   // sides): a later staging pass sends only the column ranges whose values changed (api.hip: StageJob)
   std::vector<uint8_t> staged_row_valid;
   const double* stage_host = nullptr;
-  // Runs of the raw entries a producer has NOT declared constant (pp_set_variable_runs): a row whose staged values mirror
-  // the device is compared and copied over these runs only; rows that do not are staged over the full runs.
-  std::vector<int64_t> var_runs_k, var_runs_b;
-  bool have_var_runs = false;
-  bool check_constants = false;          // the next staging passes also compare the constant entries (and report a change)
   std::vector<int> cmap_host;        // mapped group: [batch][nc_loc] global coupling indices
 };
 

@@ -153,6 +153,8 @@ class _Group(object):
         self.futile_vals = None             # representative values of the last futile refresh
         self._ref32 = self._refptr = None   # int32 copies of raw_refs and their addresses (stage_upload)
         self.var_runs = None                # (runsK, runsB) over the entries not declared constant (declare_constant_entries)
+        self.const_src = self.const_dst = None     # raw entry / compact position of the read entries that ARE declared constant
+        self.full_rows = None               # per slot: the staging row holds every entry of its block (made with the staging array)
 
     # Buffers of the HOST boundary (page-locked when the engine can: ~12 ms per allocation).  A caller that keeps values,
     # right-hand sides and solutions on the device (rows f2/f4) never touches them, so they are made at first use.
@@ -161,6 +163,7 @@ class _Group(object):
         """Compact rows: only the entries that are read."""
         if self._staging is None:
             self._staging = self._alloc((len(self.blocks), self.used.size))
+            self.full_rows = np.zeros(len(self.blocks), dtype=bool)      # rows that hold EVERY entry of their block
         return self._staging
 
     @property
@@ -182,7 +185,7 @@ class _Group(object):
         """Maximal runs of consecutive used raw entries as {source start, length, destination} triples, split at the
         boundary between the K data and the border data (include/parapint_hip.h: pp_stage_values_runs).  select (bool per
         used entry): runs over the selected entries only -- destinations stay positions in the whole compact row; two
-        selected entries at most `gap` unselected USED entries apart stay in one run (pp_set_variable_runs)."""
+        selected entries at most `gap` unselected USED entries apart stay in one run (declare_constant_entries)."""
         runsK, runsB = [], []
         if used.size:
             pos = np.arange(used.size) if select is None else np.flatnonzero(select)
@@ -205,10 +208,13 @@ class _Group(object):
 
     def variable_runs(self, constant, gap=16):
         """Runs over the used raw entries outside `constant` (bool per raw entry, K data then border data), or None when
-        nothing that is read is constant."""
+        nothing that is read is constant.  Also remembers which read entries are constant (raw entry, compact position)."""
         keep = ~np.asarray(constant, dtype=bool)[self.used]
         if keep.all():
+            self.const_src = self.const_dst = None
             return None
+        self.const_dst = np.flatnonzero(~keep)
+        self.const_src = self.used[self.const_dst]
         return self._runs(self.used, self.nrawK, select=keep, gap=gap)
 
     def canonical_from_compact(self, row):

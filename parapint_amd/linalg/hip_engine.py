@@ -221,30 +221,23 @@ class HipEngine(object):
                             memo[(q, id(a))] = True
         return ok
 
-    def stage_upload_verified(self, g, slots, kd_ptr, bd_ptr):
+    def stage_upload_verified(self, g, slots, kd_ptr, bd_ptr, runs=None):
         """The same for blocks whose index arrays are the very objects verified at an earlier call (ascending slots,
         addresses of their K and border data): nothing is compared, every block is staged and uploaded.  Returns at
-        once -- the library's host threads work while the caller prepares its next batch; stage_upload_end() waits."""
+        once -- the library's host threads work while the caller prepares its next batch; stage_upload_end() waits.
+        runs: (runsK, runsB) other than the group's -- a subset of them, for rows whose other entries the staging row
+        already holds (solver.declare_constant_entries)."""
         import os
         kd = np.array(kd_ptr, dtype=np.uint64)
         bd = np.array(bd_ptr, dtype=np.uint64)
         sl = np.array(slots, dtype=np.int32)
-        rk, rb = g.runsK, g.runsB
+        rk, rb = (g.runsK, g.runsB) if runs is None else (np.ascontiguousarray(runs[0], dtype=np.int64),
+                                                         np.ascontiguousarray(runs[1], dtype=np.int64))
         rc = self.lib.pp_stage_upload_verified_begin(self.ns.h, g.gid, len(slots), min(16, os.cpu_count() or 1), kd.ctypes.data,
                                                      bd.ctypes.data, ctypes.c_int64(g.nrawK), ctypes.c_int64(g.nraw - g.nrawK),
                                                      rk.shape[0], rk.ctypes.data, rb.shape[0], rb.ctypes.data,
                                                      g.staging.ctypes.data, sl.ctypes.data)
         self.ns.check(rc, 'pp_stage_upload_verified_begin')
-
-    def set_variable_runs(self, g, runs, check=False):
-        """runs: (runsK, runsB) over the entries not declared constant, or None (no declaration) --
-        include/parapint_hip.h: pp_set_variable_runs."""
-        if runs is None:
-            self.ns.check(self.lib.pp_set_variable_runs(self.ns.h, g.gid, -1, None, 0, None, 0), 'pp_set_variable_runs')
-            return
-        rk, rb = (np.ascontiguousarray(r, dtype=np.int64) for r in runs)
-        self.ns.check(self.lib.pp_set_variable_runs(self.ns.h, g.gid, rk.shape[0], rk.ctypes.data, rb.shape[0], rb.ctypes.data,
-                                                    1 if check else 0), 'pp_set_variable_runs')
 
     def stage_upload_end(self):
         self.ns.check(self.lib.pp_stage_upload_end(self.ns.h), 'pp_stage_upload_end')

@@ -390,9 +390,8 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
         started = [False]
         self._stage_calls += 1
         full = self.pattern_check_interval > 0 and self._stage_calls % self.pattern_check_interval == 0
-        recheck = [g for g in self._groups if g.var_runs is not None] if full and self._constant_check is None else ()
-        for g in recheck:                                   # (this call also compares the entries declared constant)
-            self._eng.set_variable_runs(g, g.var_runs, True)
+        violations = []                 # blocks whose entries declared constant changed (declare_constant_entries, check=True)
+        check_now = bool(self._constant_check)
         records, memo = self._index_records, {}
         budget = [self.pattern_check_bytes]
 
@@ -415,7 +414,7 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
                 order = sorted(range(len(slots)), key=slots.__getitem__)
                 slots, kps, bps = [slots[i] for i in order], [kps[i] for i in order], [bps[i] for i in order]
             started[0] = True
-            verified(g, slots, kps, bps)
+            self._send_verified(g, slots, kps, bps, full)
             del q[1][:], q[2][:], q[3][:]
 
         # (blocks of the package's own containers: the dictionary behind get_block, one call frame less per block)
@@ -455,6 +454,15 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
                             if ok is None:
                                 ok = setok[id(cs)] = intact(cs[0]) and intact(cs[1]) and intact(cs[2]) and intact(cs[3])
                             if ok:
+                                if check_now and g.const_src is not None and g.full_rows is not None and g.full_rows[bi.slot]:
+                                    # (check=True: the entries declared constant against the staging row -- a debugging aid)
+                                    src, nK = g.const_src, g.nrawK
+                                    k_part = src < nK
+                                    row = g.staging[bi.slot]
+                                    if not (np.array_equal(kd[src[k_part]], row[g.const_dst[k_part]]) and
+                                            np.array_equal(bd[src[~k_part] - nK], row[g.const_dst[~k_part]])):
+                                        violations.append(ndx)
+                                        g.full_rows[bi.slot] = False         # (staged over every entry below)
                                 q = quick.get(g.gid)
                                 if q is None:
                                     q = quick[g.gid] = (g, [], [], [])
@@ -479,16 +487,14 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
             for q in quick.values():
                 flush(q)
         finally:
-            try:
-                if started[0]:
-                    self._eng.stage_upload_end()        # (also on the way out with a changed pattern: no job stays in flight)
-            finally:
-                for g in recheck:
-                    self._eng.set_variable_runs(g, g.var_runs, False)
+            if started[0]:
+                self._eng.stage_upload_end()            # (also on the way out with a changed pattern: no job stays in flight)
         for g, items in batches.values():
             items.sort(key=lambda it: it[0])
             same = fast(g, [it[:2] for it in items], full)
             for ok, (slot, arrays, bi, K) in zip(same, items):
+                if ok:
+                    g.full_rows[slot] = True             # (the library staged every entry of the row)
                 if not ok:
                     self._stage_block(g, slot, *arrays)
                     slow.setdefault(g.gid, (g, []))[1].append(slot)
@@ -510,6 +516,39 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
             for g, slots in slow.values():                   # rows the library did not stage itself
                 for slot in slots:
                     self._eng.upload_values_compact(g.gid, g.staging, slot, 1)
+        self._report_constant_violations(violations)
+
+    def _report_constant_violations(self, violations):
+        if violations:
+            # (every entry of these blocks was staged all the same: the factorisation that follows is of the matrix handed over)
+            err = RuntimeError('staging: entries declared constant (declare_constant_entries) have changed in block(s) %s'
+                               % violations[:8])
+            err.status = 3
+            raise err
+
+    def _send_verified(self, g, slots, kps, bps, every_entry):
+        """One batch of verified blocks to the library's staging threads: over the entries not declared constant for rows
+        whose staging row holds every entry of its block already, over all entries otherwise (and, every_entry, for all rows:
+        the periodic pass that lets a declaration that does not hold heal)."""
+        verified = self._eng.stage_upload_verified
+        _ = g.staging                                       # (allocates the rows and their flags)
+        fr = g.full_rows
+        idx = np.asarray(slots, dtype=np.int64)
+        if g.var_runs is None or every_entry:
+            verified(g, slots, kps, bps)
+            fr[idx] = True
+            return
+        have = fr[idx]
+        if have.all():
+            verified(g, slots, kps, bps, g.var_runs)
+        elif not have.any():
+            verified(g, slots, kps, bps)
+            fr[idx] = True
+        else:
+            kps, bps = np.asarray(kps, dtype=np.uint64), np.asarray(bps, dtype=np.uint64)
+            verified(g, idx[~have], kps[~have], bps[~have])           # (a second begin waits for the first job)
+            fr[idx[~have]] = True
+            verified(g, idx[have], kps[have], bps[have], g.var_runs)
 
     def _stage_flat_values(self, matrix):
         """Values of a HostValueMatrix (one flat vector per block: K data then A data, over the pattern object the symbolic
@@ -524,9 +563,6 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
         verified = getattr(self._eng, 'stage_upload_verified', None)
         self._stage_calls += 1
         full = self.pattern_check_interval > 0 and self._stage_calls % self.pattern_check_interval == 0
-        recheck = [g for g in self._groups if g.var_runs is not None] if full and self._constant_check is None else ()
-        for g in recheck:
-            self._eng.set_variable_runs(g, g.var_runs, True)
         two_d = isinstance(vals, np.ndarray)
         if two_d:
             if vals.ndim != 2 or vals.dtype != _F8 or vals.strides[1] != 8 or vals.shape[0] != len(self.local_block_indices):
@@ -536,6 +572,7 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
                 rows_of = self._flat_rows['rows'] = {ndx: i for i, ndx in enumerate(self.local_block_indices)}
         started = False
         slow = []
+        violations = []
         try:
             for g in self._groups:
                 nK, nB = g.nrawK, g.nraw - g.nrawK
@@ -567,14 +604,18 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
                     kd = np.array(addrs, dtype=np.uint64)
                 bd = kd + np.uint64(8 * nK) if nB else np.zeros(kd.size, dtype=np.uint64)
                 started = True
-                verified(g, np.arange(len(g.blocks), dtype=np.int32), kd, bd)
+                if self._constant_check and g.const_src is not None and g.full_rows is not None:
+                    src, dst = g.const_src, g.const_dst
+                    for slot, ndx in enumerate(g.blocks):
+                        if g.full_rows[slot]:
+                            v = vals[rows[slot]] if two_d else vals[ndx]
+                            if not np.array_equal(v[src], g.staging[slot][dst]):
+                                violations.append(ndx)
+                                g.full_rows[slot] = False
+                self._send_verified(g, np.arange(len(g.blocks), dtype=np.int32), kd, bd, full)
         finally:
-            try:
-                if started:
-                    self._eng.stage_upload_end()
-            finally:
-                for g in recheck:
-                    self._eng.set_variable_runs(g, g.var_runs, False)
+            if started:
+                self._eng.stage_upload_end()
         last = self.block_dim - 1
         for g in slow:
             nK = None
@@ -587,6 +628,7 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
                     raise ValueError('flat_values: block %d has %d entries, its pattern has %d' % (ndx, v.size, kd0.size + _bd.size))
                 self._stage_block(g, slot, kr, kc, v[:kd0.size], br, bc, v[kd0.size:])
             self._eng.upload_values_compact(g.gid, g.staging)
+        self._report_constant_violations(violations)
 
     def _stage_block(self, g, slot, kr, kc, kd, br, bc, bd):
         ref = g.raw_refs
@@ -594,6 +636,7 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
                 (kr is ref[0] or np.array_equal(kr, ref[0])) and (kc is ref[1] or np.array_equal(kc, ref[1])) and
                 (br is ref[2] or np.array_equal(br, ref[2])) and (bc is ref[3] or np.array_equal(bc, ref[3])))
         row = g.staging[slot]
+        g.full_rows[slot] = True                    # (every entry of the block is written below)
         if same:
             for e0, ln, dst in g.runsK:
                 row[dst:dst + ln] = kd[e0:e0 + ln]
@@ -635,9 +678,12 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
         constant: {block index: (constK, constA)} -- bool per entry of the block's K_ii.data and of its border A_i.data, in
         the order of the blocks handed to do_symbolic_factorization (None / missing block: nothing constant).  A pattern
         group takes the entries constant in ALL its blocks; groups whose blocks come in different entry orders ignore the
-        declaration.  Effect: the host boundary compares and copies the other entries only (host COO blocks in; the device
-        interface has its value maps for that).  check=True: every pass also compares the constant entries and the
-        factorisation reports an error if one changed; default: at every `pattern_check_interval`-th call."""
+        declaration.  Effect: for a block whose staging row already holds all its entries the library's staging threads are
+        given the runs of the OTHER entries only (pp_stage_upload_verified_begin: compare and copy) -- host COO blocks or flat
+        value vectors in; the device interface has its value maps for that.  At every `pattern_check_interval`-th call every
+        entry is staged again (a declaration that does not hold heals there); check=True (a debugging aid, on the host):
+        the declared entries are compared with the staging rows at every call, what changed is staged in full and the
+        factorisation returns an error status that names the blocks."""
         if not getattr(self, '_groups', None) or getattr(self, 'plan_stats', None) is None:
             raise RuntimeError('declare_constant_entries: call do_symbolic_factorization first')
         self._constant_entries = None if constant is None else dict(constant)
@@ -645,9 +691,6 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
         self._apply_constant_entries()
 
     def _apply_constant_entries(self):
-        setter = getattr(self._eng, 'set_variable_runs', None)
-        if setter is None:
-            return
         decl = self._constant_entries
         for g in self._groups:
             runs = None
@@ -665,8 +708,9 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
                     mask[nK:] &= cA
                 if mask is not None:
                     runs = g.variable_runs(mask)
+            if runs is None:
+                g.const_src = g.const_dst = None
             g.var_runs = runs
-            setter(g, runs, bool(self._constant_check))
 
     def _apply_value_maps(self):
         nsrc, maps = self._device_maps

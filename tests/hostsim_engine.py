@@ -321,48 +321,27 @@ class HostSimBoundaryEngine(HostSimEngine):
             ok[i] = same
         return ok
 
-    def set_variable_runs(self, g, runs, check=False):
-        # (pp_set_variable_runs: rows staged once through the verified path are compared / copied over these runs only)
-        self.calls['set_variable_runs'] = self.calls.get('set_variable_runs', 0) + 1
-        sg = self.groups[g.gid]
-        sg.var_runs, sg.check_constants = runs, bool(check)
-
-    def stage_upload_verified(self, g, slots, kd_ptr, bd_ptr):
+    def stage_upload_verified(self, g, slots, kd_ptr, bd_ptr, runs=None):
+        # (runs: the subset of the group's runs the library is to look at -- the rest of the row is in g.staging already)
         self.calls['stage_upload_verified'] += 1
+        slots = [int(v) for v in slots]
         assert all(a < b for a, b in zip(slots, slots[1:]))
-        sg = self.groups[g.gid]
-        runs = getattr(sg, 'var_runs', None)
-        if getattr(sg, 'mirror', None) is None or sg.mirror[0] is not g.staging:
-            sg.mirror = (g.staging, set())                    # slots whose staging row equals what the engine holds
-        changed = False
         for slot, kp, bp in zip(slots, kd_ptr, bd_ptr):
             self.calls['verified_blocks'] += 1
-            kd, bd = self._view(kp, g.nrawK), self._view(bp, g.nraw - g.nrawK)
-            if runs is not None and slot in sg.mirror[1]:
+            kd, bd = self._view(int(kp), g.nrawK), self._view(int(bp), g.nraw - g.nrawK)
+            if runs is None:
+                self._stage_row(g, slot, kd, bd)
+            else:
                 self.calls['variable_entries'] = self.calls.get('variable_entries', 0) + int(runs[0][:, 1].sum() + runs[1][:, 1].sum())
                 row = g.staging[slot]
                 for e0, ln, dst in runs[0]:
                     row[dst:dst + ln] = kd[e0:e0 + ln]
                 for e0, ln, dst in runs[1]:
                     row[dst:dst + ln] = bd[e0:e0 + ln]
-                if sg.check_constants:
-                    after = row.copy()
-                    self._stage_row(g, slot, kd, bd)
-                    changed = changed or not np.array_equal(after, g.staging[slot])
-                else:
-                    self.upload_values_compact(g.gid, g.staging, slot, 1)
-            else:
-                self._stage_row(g, slot, kd, bd)
-                sg.mirror[1].add(slot)
-        self._constant_changed = getattr(self, '_constant_changed', False) or changed
+                self.upload_values_compact(g.gid, g.staging, slot, 1)
 
     def stage_upload_end(self):
         self.calls['stage_upload_end'] = self.calls.get('stage_upload_end', 0) + 1
-        if getattr(self, '_constant_changed', False):
-            self._constant_changed = False
-            err = RuntimeError('staging: an entry declared constant (pp_set_variable_runs) has changed since it was staged')
-            err.status = 3
-            raise err
 
     def copy_rows(self, dst, rows):
         self.calls['copy_rows'] += 1

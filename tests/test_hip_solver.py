@@ -791,8 +791,9 @@ def test_host_boundary_fast_paths_on_the_device():
 
 
 def test_entries_declared_constant_by_the_producer_on_the_device():
-    """declare_constant_entries -> pp_set_variable_runs: rows whose staged copy mirrors the device are compared and copied
-    over the variable entries only; same results as an undeclared solver; a declaration that does not hold is reported."""
+    """declare_constant_entries: pp_stage_upload_verified_begin is given the runs of the variable entries only for rows whose
+    staging row holds every entry already; same results as an undeclared solver; check=True reports a declaration that does
+    not hold, the periodic full pass heals it."""
     sc.case_constant_entries(lambda: None)
 
 
