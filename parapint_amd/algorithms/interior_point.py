@@ -394,7 +394,14 @@ def ip_solve(interface, options=None, timer=None):
             # of this iteration exists before the matrix is factorised -- interior_point.py:553-566 -- so a device-resident
             # one is announced and its forward sweep runs beside the dense factorisation of S)
             solver.prefetch_forward(rhs)
-        used_inertia_coef = numeric_factorization(interface, kkt, options, inertia_coef, timer)
+        try:
+            used_inertia_coef = numeric_factorization(interface, kkt, options, inertia_coef, timer)
+        except Exception:
+            # (the announcement ends with the back-solve; a factorisation that raises never gets there -- withdraw it, or
+            # whoever reuses the solver sweeps a stale vector behind its next factorisation)
+            if hasattr(solver, 'prefetch_forward'):
+                solver.prefetch_forward(None)
+            raise
         inertia_coef = max(used_inertia_coef * options.inertia_correction.factor_decrease,
                            options.inertia_correction.init_coef)
         timer.stop('numeric')

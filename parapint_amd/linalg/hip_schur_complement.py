@@ -869,7 +869,7 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
 
             def with_values():
                 if spelled[0] is None:
-                    spelled[0] = matrix.to_block_matrix() if getattr(matrix, 'flat_values', None) is not None else matrix
+                    spelled[0] = matrix.to_block_matrix(self.local_block_indices) if getattr(matrix, 'flat_values', None) is not None else matrix
                 return spelled[0]
             while (res.status == LinearSolverStatus.singular and self.split_conflicting_groups and
                    not hasattr(matrix, 'value_maps') and repairs < self.max_pivot_repairs and
@@ -940,6 +940,7 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
 
     def _stage_and_upload(self, matrix):
         changed = 0
+        failed = None
         flat = hasattr(matrix, 'flat_values') and matrix.flat_values is not None
         try:
             if flat:
@@ -948,10 +949,19 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
                 self._stage_values(matrix.pattern if hasattr(matrix, 'flat_values') else matrix)
         except _PatternChanged:
             changed = 1
+        except Exception as err:
+            # a failure that carries a C status (a violated constant-entry declaration, a staging call that failed) on
+            # THIS rank: the others are on their way into the collective below -- join it first, fail afterwards (the
+            # status then reaches the all-reduce of S through _guarded / fail_local like any other host-side failure)
+            if getattr(err, 'status', None) is None or self.comm.size == 1:
+                raise
+            failed = err
         if self.comm.size > 1:
             # the new plan is made collectively (its coupling structure is agreed by all ranks): a rank whose own
             # blocks still fit the old pattern re-plans with the others
             changed = int(self.comm.allreduce_max(np.array([changed], dtype=np.int64))[0])
+        if failed is not None and not changed:
+            raise failed
         if changed:
             # entries outside the planned pattern (the inertia-correction loop adds diagonal blocks): plan again
             # on the union of both patterns, as the reference's MUMPS sub-solver does (mumps_interface.py:82-83)

@@ -112,7 +112,7 @@ class BlockMatrix(object):
                 out.append((blk if getattr(blk, 'format', None) == 'coo' else blk.tocoo(), r0 + int(roff[i]), c0 + int(coff[j])))
         return out
 
-    def tocoo(self):
+    def tocoo(self, copy_index=False):
         """Flat COO matrix.  The interior-point interfaces build a NEW nested matrix at every iteration with the same
         structure (interface.py:432-494, sc_ip_interface.py:839-843), and the solver flattens one per block: the index
         arrays of a structure seen before are not built again -- the leaves' index arrays are compared with remembered
@@ -121,7 +121,11 @@ class BlockMatrix(object):
         HIP solver's staging) sees one pattern object for all blocks and iterations.  The returned index arrays are shared
         between all matrices of that structure and are therefore READ-ONLY (numpy raises on an in-place change such as
         ``coo.row += offset`` or ``coo.sum_duplicates()``; take a copy first); they are int32 while the dimension allows it
-        (widen before forming ``row * n + col``)."""
+        (widen before forming ``row * n + col``).  ``tocoo(copy_index=True)``: private, writable index arrays -- what
+        PyNumero's BlockMatrix.tocoo() returns -- for callers that change them in place."""
+        if copy_index:
+            shared = self.tocoo()
+            return coo_matrix((shared.data, (shared.row.copy(), shared.col.copy())), shape=shared.shape, copy=False)
         leaves = self._leaves(0, 0, [])
         shape = self.shape
         sig = (shape,) + tuple((r, c, lf.nnz) + lf.shape for lf, r, c in leaves)

@@ -80,6 +80,30 @@ def main():
         for ndx in local:
             assert np.array_equal(np.asarray(xf.get_block(ndx)), np.asarray(xk.get_block(ndx)))
         assert np.array_equal(np.asarray(xf.get_block(N)), np.asarray(xk.get_block(N)))
+    # a declaration that does not hold on ONE rank (check=True): that rank's staging fails with a status BEFORE the
+    # collective that agrees on a changed pattern -- it must still join it, and both ranks must report the error
+    # (the engine with the host-boundary entry points: the check sits on the verified fast path)
+    from hostsim_engine import HostSimBoundaryEngine
+    sv = HipSchurComplementLinearSolver({i: None for i in local}, None, comm=comm, engine=HostSimBoundaryEngine())
+    assert sv.do_symbolic_factorization(kkt).status == LinearSolverStatus.successful
+    sv.declare_constant_entries(model.constant_entries(), check=True)
+    for it in (5, 6):
+        assert sv.do_numeric_factorization(model.build_kkt(comm=comm, iteration=it)).status == LinearSolverStatus.successful
+    k_bad = model.build_kkt(comm=comm, iteration=7)
+    if rank == 1:
+        Kb = k_bad.get_block(local[0], local[0])
+        Kb.data = Kb.data.copy()
+        e = int(np.flatnonzero(model._row > model._col)[3])
+        m = int(np.flatnonzero((model._row == model._col[e]) & (model._col == model._row[e]))[0])
+        Kb.data[[e, m]] *= 1.25
+    res = sv.do_numeric_factorization(k_bad, raise_on_error=False)
+    assert res.status == LinearSolverStatus.error, (rank, res.status)
+    assert sv.do_numeric_factorization(k_bad).status == LinearSolverStatus.successful     # (the values were staged in full)
+    xv = sv.do_back_solve(rhs)
+    solver.declare_constant_entries(None)
+    assert solver.do_numeric_factorization(k_bad).status == LinearSolverStatus.successful
+    xw = solver.do_back_solve(rhs)
+    assert np.array_equal(np.asarray(xv.get_block(N)), np.asarray(xw.get_block(N)))
     solver.declare_constant_entries(None)
     assert solver.do_numeric_factorization(kkt).status == LinearSolverStatus.successful
 
