@@ -39,9 +39,10 @@ from parapint_amd.sparse.block_containers import BlockMatrix as _BlockMatrix, MP
 _OWN_MATRICES = (_BlockMatrix, _MPIBlockMatrix)     # (exact types: their get_block is a dictionary lookup)
 _F8 = np.dtype(np.float64)
 from parapint_amd.linalg.pivot_repair import PivotRepairMixin
+from parapint_amd.linalg.solution_check import SolutionCheckMixin
 
 
-class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, LinearSolverInterface):
+class HipSchurComplementLinearSolver(PivotRepairMixin, SolutionCheckMixin, CouplingStructureMixin, LinearSolverInterface):
     """Solve A x = b for block-bordered-diagonal symmetric A (lower border supplied)::
 
           K1          transpose(A1)
@@ -125,7 +126,7 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
         self.pivot_order_refreshes = 0      # numeric factorisations that needed a new static pivot sequence
         self.pivot_order_refreshes_since_symbolic = 0
         self.refreshes_skipped = 0          # breakdowns reported as `singular` without a new sequence (futile lately)
-        self.refresh_causes = {'zero_pivot': 0, 'growth': 0}      # ... because of a zero pivot / of element growth in a block
+        self.refresh_causes = {'zero_pivot': 0, 'growth': 0, 'residual': 0}      # ... because of a zero pivot / of element growth in a block
         self.diagonal_shift_refactorizations = 0      # factorisations from resident values + a diagonal shift (f1)
         self._last_Q = None
         self._base_Q = None
@@ -168,6 +169,7 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
         self._stage_calls = 0
         self._index_records = {}            # id(index array) -> (array, size, address, checksum)
         self._index_sets = {}               # ids of a block's four index arrays -> the tuple of them (shared by blocks)
+        self._init_solution_check()         # every back-solve is checked on the device, refined, repaired (solution_check.py)
 
     # ------------------------------------------------------------------ helpers
     def _local_blocks(self, matrix):
@@ -855,6 +857,7 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
             matrix = matrix.base
         if hasattr(matrix, 'value_maps'):
             self._last_device_base = matrix
+        self._last_factor_call = ('full', matrix)
         res = self._numeric_factorization(matrix, timer)
         if res.status == LinearSolverStatus.singular and self._refresh_pivot_order():
             # a block broke down under the static pivot sequence: it was fixed from the values the symbolic phase
@@ -1117,6 +1120,7 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
         if not self._have_classes:
             raise RuntimeError('Call set_regularization_classes first!')
         res = LinearSolverResults(LinearSolverStatus.successful)
+        self._last_factor_call = ('shift', (delta_w, delta_c, coupling_shift, coupling_classes))
         self.diagonal_shift_refactorizations += 1
         timer.start('form SC')
         self._prefetch_before_factor = self._prefetch_rhs is not None       # (announced before the block phase is enqueued)
@@ -1163,13 +1167,15 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
             raise RuntimeError('Numeric factorization unsuccessful; status: ' + str(res.status))
         return res
 
-    def do_back_solve(self, rhs, timer=None):
+    def do_back_solve(self, rhs, timer=None, _repairs=None):
         if timer is None:
             timer = _NullTimer()
         if self._num_status is None:
             raise RuntimeError('Perform numeric factorization first!')
+        if _repairs is None:
+            _repairs = self.max_solve_repairs
         if hasattr(rhs, 'group_tensors'):
-            return self._device_back_solve(rhs, timer)
+            return self._device_back_solve(rhs, timer, _repairs)
         timer.start('back_solve')
         last = self.block_dim - 1
         if hasattr(self._eng, 'bind_native_vectors'):
@@ -1211,6 +1217,15 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
         rc = self._to_coupling_order(_flat(rhs.get_block(last))) if self._nc > 0 else None
         self._eng.solve_coupling(rc)
         self._eng.solve_backward()
+        if self._checking():
+            # (solution_check.py: residual of every local block on the device, refinement, a new pivot sequence if need be)
+            bad = self._verify_solution()
+            if bad is not None:
+                if _repairs > 0 and self._repair_after_inaccurate_solve(bad):
+                    timer.stop('solve')
+                    timer.stop('back_solve')
+                    return self.do_back_solve(rhs, timer, _repairs - 1)
+                self._give_up_on_solution(bad)
         timer.stop('solve')
         timer.start('solution to host')
         xout = {}
@@ -1301,7 +1316,7 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
         self._eng.solve_forward(early=early)
         self._eng.allreduce_rs(self.comm)
 
-    def _device_back_solve(self, rhs, timer):
+    def _device_back_solve(self, rhs, timer, _repairs=0):
         """do_back_solve for a DeviceBlockVector: right-hand sides are read where they are, the solution is written
         into a fresh device vector (or, with result_buffers = k > 0, into k vectors handed out in turn); no host copies."""
         timer.start('back_solve')
@@ -1329,6 +1344,15 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, CouplingStructureMixin, L
             rc_dev = self._rc_pad
         self._eng.solve_coupling_dev(rc_dev)
         self._eng.solve_backward()
+        if self._checking():
+            bad = self._verify_solution()
+            if bad is not None:
+                if _repairs > 0 and self._repair_after_inaccurate_solve(bad):
+                    timer.stop('back_solve')
+                    if self._result_buffers > 0:
+                        self._dev_turn -= 1            # (the same result vector again)
+                    return self._device_back_solve(rhs, timer, _repairs - 1)
+                self._give_up_on_solution(bad)
         if self._nc > 0:
             if self._btd is not None:
                 self._eng.copy_coupling_solution(self._xc_pad)

@@ -16,23 +16,32 @@ class PivotRepairMixin(object):
             if self.refresh_backoff:
                 g.refresh_skip = 0 if cured else min(2 ** g.refresh_futile - 1, 63)
 
-    def _refresh_pivot_order(self, shift=None):
+    def _refresh_pivot_order(self, shift=None, forced=None):
         """New pivot sequences for the groups that hold a broken block, from that block's values (with `shift` =
         (delta_w, delta_c): + the diagonal shift of the classed rows, as the regularised matrix of the host path has
-        them).  Collective: every rank learns whether any rank re-planned (all of them then factorise again)."""
+        them).  forced: {group id: slot} -- instances whose back-solve turned out inaccurate (solution_check.py): their groups
+        are planned again from them whatever the factorisation reported.  Collective: every rank learns whether any rank
+        re-planned (all of them then factorise again)."""
         mine = 0
         self._refreshed = []
         for g in self._groups:
-            slot = self._eng.find_zero_pivot(g.gid)
-            if slot >= 0 and g.refresh_skip > 0:
+            slot = -1 if not forced else int(forced.get(g.gid, -1))
+            if slot >= 0:
+                self.refresh_causes['residual'] = self.refresh_causes.get('residual', 0) + 1
+            else:
+                slot = self._eng.find_zero_pivot(g.gid)
+                if slot >= 0:
+                    slot = -2 - slot           # (marks "found by the zero-pivot search" for the bookkeeping below)
+            if slot <= -2 and g.refresh_skip > 0:
                 # (refresh_backoff, opt-in) new sequences for this group have not cured its breakdowns lately: after the
                 # k-th futile refresh in a row the next 2^k - 1 breakdowns (at most 63) go to the caller as `singular`
                 g.refresh_skip -= 1
                 self.refreshes_skipped += 1
                 continue
-            if slot >= 0:
+            if slot <= -2:
+                slot = -2 - slot
                 self.refresh_causes['zero_pivot'] += 1
-            elif self._growth_guard:
+            elif slot < 0 and self._growth_guard:
                 slot = self._eng.find_growth(g.gid)     # element growth beyond 1 / pivot_tolerance counts as a breakdown
                 if slot >= 0:
                     self.refresh_causes['growth'] += 1

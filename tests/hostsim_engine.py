@@ -96,6 +96,7 @@ class HostSimEngine(object):
         for sg in self.groups:
             g = sg.g
             sg.U, sg.Dinv, sg.L = [], [], []
+            sg.can = []                   # canonical values of the factorisation (the residual check reads them)
             sg.zero_slot = -1
             sg.growth_slot = -1
             for b in range(sg.batch):
@@ -122,6 +123,7 @@ class HostSimEngine(object):
                 sg.U.append(U)
                 sg.L.append(Lf)
                 sg.Dinv.append(D)
+                sg.can.append(np.array(can, dtype=np.double))
         self.tail = np.array([inertia[2], inertia[0], inertia[1], 0.0, growth, 0.0, 0.0, 0.0], dtype=np.double)
 
     def numeric_factor_blocks(self):
@@ -265,6 +267,63 @@ class HostSimEngine(object):
 
     def download_solution(self, gid, out):
         out[...] = self.groups[gid].x
+
+    # ---- a-posteriori check and refinement (csrc/refine.hip: pp_residual, pp_refine_begin / _end) ---------------------
+    def residual(self, store=False):
+        """(rho, group, slot) of the worst local instance: rho = max |b - K x - A^T x_c| / max (|K||x| + |A^T x_c| + |b|)
+        over the rows of a block, from the canonical values of the last factorisation."""
+        worst = (0.0, -1, -1)
+        for gid, sg in enumerate(self.groups):
+            g = sg.g
+            nK = g.rowK.size
+            i, j = np.asarray(g.rowK, dtype=np.int64), np.asarray(g.colK, dtype=np.int64)
+            off = i != j
+            br, bc = np.asarray(g.rowB, dtype=np.int64), np.asarray(g.colB, dtype=np.int64)
+            if store:
+                sg.R = np.zeros((sg.batch, g.n))
+            for b in range(sg.batch):
+                can, x, rhs = sg.can[b], sg.x[b], np.asarray(sg.rhs[b], dtype=np.double)
+                xc = self.xc if sg.cmaps is None else self.xc[sg.cmaps[b]]
+                r = np.array(rhs, copy=True)
+                s = np.abs(rhs)
+                t = can[:nK] * x[j]
+                np.subtract.at(r, i, t)
+                np.add.at(s, i, np.abs(t))
+                t = can[:nK][off] * x[i[off]]
+                np.subtract.at(r, j[off], t)
+                np.add.at(s, j[off], np.abs(t))
+                if br.size:
+                    t = can[nK:] * xc[br]
+                    np.subtract.at(r, bc, t)
+                    np.add.at(s, bc, np.abs(t))
+                if store:
+                    sg.R[b] = r
+                rm = np.abs(r).max() if r.size else 0.0
+                sm = s.max() if s.size else 0.0
+                rho = 0.0 if rm == 0.0 else (rm / sm if sm > 0.0 and np.isfinite(rm) else np.inf)
+                if rho > worst[0] or worst[1] < 0:
+                    worst = (float(rho), gid, b)
+        return worst
+
+    def refine_begin(self):
+        self._refine_saved = (self.xc.copy(), [(sg.rhs, sg.x.copy(), getattr(sg, 'rhs_native', None), getattr(sg, 'x_native', None))
+                                               for sg in self.groups])
+        for sg in self.groups:
+            sg.rhs = sg.R
+            if hasattr(sg, 'rhs_native'):
+                sg.rhs_native = sg.x_native = None
+
+    def refine_end(self):
+        xc, saved = self._refine_saved
+        self._refine_saved = None
+        self.xc = xc + self.xc
+        for sg, (rhs, x, rn, xn) in zip(self.groups, saved):
+            sg.rhs = rhs
+            sg.x = x + sg.x
+            if hasattr(sg, 'rhs_native'):
+                sg.rhs_native, sg.x_native = rn, xn
+                if xn is not None:
+                    xn[:, :sg.batch] = sg.x.T
 
     def coupling_solution(self):
         return self.xc.copy()

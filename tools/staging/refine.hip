@@ -1,0 +1,477 @@
+// A-posteriori check of a back-solve and iterative refinement (round 6).
+//
+// The reference's sub-solvers pivot every block on its own values (MA27: parapint/linalg/ma27_interface.py:36-47, 110-140;
+// SuperLU: scipy_interface.py:26-31) -- a back-solve of theirs is backward stable whatever the values.  The batched
+// factorisation here fixes ONE pivot sequence per pattern group (plan.hpp), so the accuracy of a solve is checked where
+// it can be seen: r_i = b_i - K_i x_i - A_i^T x_c for every local block, from the values the factorisation read (the
+// transposed input, or the producer's source arrays through the value map), per instance as
+//     rho_b = max_rows |r| / max_rows (sum_j |K_ij| |x_j| + |A^T x_c| + |b|)      (a row-wise backward error),
+// the worst instance published to a pinned mailbox.  The coupling rows b_c - sum_i A_i x_i - Q x_c hold in exact arithmetic
+// whatever the block factors are (S, r_s and the backward sweep use the SAME factors), but an unstable pivot sequence
+// amplifies their rounding errors: this unit forms sum_i A_i x_i and sum_i |A_i| |x_i| over the local blocks and hands them
+// (with x_c and b_c) to the host class through the same mailbox, which adds Q x_c -- a few n_c-vectors -- after the
+// all-reduce that also agrees the verdict between the ranks.  The host class (hip_schur_complement.py, solution_check.py)
+// reads rho after every back-solve, runs correction solves K d = r through the same sweeps while rho is above its
+// refinement threshold, and treats a solve that stays above 1e-8 as a breakdown of the pivot sequence (new sequence
+// from that instance, factorise, solve again) -- never as a result.
+//
+// Layout: rows in the plan's elimination order, one wave = ROWS consecutive rows x 64 (or 128) instances; the records
+// {value row, x row} are wave-uniform (scalar loads), every operand access is a coalesced 512-byte (1 KB) request.
+// HBM-bound: every read value of K once per triangle it belongs to (C3: 36 k records per block = 301 MB of operand
+// requests per 1024 blocks, of which the values are 167 MB unique), x and b once plus the gathers the L2 serves.
+#include "common.hpp"
+#include "kernels_transpose.hpp"
+
+namespace {
+
+constexpr int RES_ROWS = 8;         // rows per wave
+
+__device__ __forceinline__ unsigned long long dbits(double v) { return (unsigned long long)__double_as_longlong(v); }
+
+// NV instances per lane (as in factor.hip).  vrow < 0: the constant 1 (value-map form: source row == const_row is
+// rewritten to -1 at build time).  xcol >= 0: row of X; xcol < 0: coupling value -1 - xcol (xc / per-instance XCL).
+template <int NV>
+__global__ __launch_bounds__(64) void k_residual(GroupDev g, const int* __restrict__ rptr, const int* __restrict__ vrow,
+                                                 const double* __restrict__ coef, const int* __restrict__ xcol,
+                                                 const int* __restrict__ brow, const double* __restrict__ V,
+                                                 const double* __restrict__ B, const double* __restrict__ X,
+                                                 const double* __restrict__ xc, double* __restrict__ Rout,
+                                                 const int* __restrict__ rrow, unsigned long long* __restrict__ rmax,
+                                                 unsigned long long* __restrict__ smax, int ny) {
+  const int lane = threadIdx.x;
+  const unsigned b = (unsigned)(((blockIdx.x % (unsigned)ny) * 64 + lane) * NV);
+  const int c0 = (int)(blockIdx.x / (unsigned)ny) * RES_ROWS;
+  const int c1 = min(c0 + RES_ROWS, g.n);
+  const size_t bpad = (size_t)g.bpad;
+  const double* __restrict__ Vb = V + b;
+  const double* __restrict__ Xb = X + b;
+  double rm[NV], sm[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) { rm[v] = 0.0; sm[v] = 0.0; }
+  for (int c = c0; c < c1; ++c) {
+    const int e0 = rptr[c], e1 = rptr[c + 1];
+    double bv[NV];
+    ldv<NV>(B + (size_t)(brow ? brow[c] : c) * bpad + b, bv);
+    double acc[NV], aab[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) { acc[v] = 0.0; aab[v] = 0.0; }
+    for (int eb = e0; eb < e1; eb += 4) {
+      double kv[4][NV], xv[4][NV], cf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int e = min(eb + i, e1 - 1);
+        const int vr = vrow[e], xr = xcol[e];
+        cf[i] = (eb + i < e1) ? (coef ? coef[e] : 1.0) : 0.0;
+        if (vr >= 0) ldv<NV>(Vb + (size_t)vr * bpad, kv[i]);
+        else {
+#pragma unroll
+          for (int v = 0; v < NV; ++v) kv[i][v] = 1.0;
+        }
+        if (xr >= 0) ldv<NV>(Xb + (size_t)xr * bpad, xv[i]);
+        else {
+#pragma unroll
+          for (int v = 0; v < NV; ++v) xv[i][v] = xc[(size_t)(-1 - xr) * g.xs_row + (size_t)(b + v) * g.xs_lane];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const double t = cf[i] * kv[i][v] * xv[i][v];
+          acc[v] += t;
+          aab[v] += fabs(t);
+        }
+      }
+    }
+    double r[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const bool live = (int)(b + v) < g.batch;
+      r[v] = live ? bv[v] - acc[v] : 0.0;
+      // (a NaN anywhere in x makes |r| NaN: fmax would drop it, so it is turned into +inf here -- never a silent pass)
+      const double ar = (r[v] == r[v]) ? fabs(r[v]) : INFINITY;
+      rm[v] = fmax(rm[v], ar);
+      sm[v] = fmax(sm[v], live ? aab[v] + fabs(bv[v]) : 0.0);
+    }
+    if (Rout) stv<NV>(Rout + (size_t)(rrow ? rrow[c] : c) * bpad + b, r);
+  }
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    if ((int)(b + v) < g.batch) {
+      // (non-negative doubles order like their bit patterns; +inf is the largest)
+      atomicMax(rmax + b + v, dbits(rm[v]));
+      atomicMax(smax + b + v, dbits(sm[v]));
+    }
+  }
+}
+
+
+// Coupling rows: per (local coupling row c, chunk) one wave forms sum_e A[c, j_e] x_(j_e) and the same with absolute values
+// over its 64 instances; uniform groups reduce over the lanes into part[chunk][2][nc] (summed by k_border_sum), mapped groups
+// add every instance's term to its own global coupling row.
+__global__ __launch_bounds__(64) void k_border_ax(GroupDev g, const int* __restrict__ bptr, const int* __restrict__ vrow,
+                                                  const double* __restrict__ coef, const int* __restrict__ xcol,
+                                                  const double* __restrict__ V, const double* __restrict__ X,
+                                                  double* __restrict__ part, double* __restrict__ out, int nc_glob) {
+  const int lane = threadIdx.x;
+  const int chunk = (int)(blockIdx.x % (unsigned)g.nchunk), c = (int)(blockIdx.x / (unsigned)g.nchunk);
+  const int b = chunk * 64 + lane;
+  const size_t bpad = (size_t)g.bpad;
+  double s = 0.0, a = 0.0;
+  for (int e = bptr[c]; e < bptr[c + 1]; ++e) {
+    const int vr = vrow[e];
+    const double t = (coef ? coef[e] : 1.0) * (vr >= 0 ? V[(size_t)vr * bpad + b] : 1.0) * X[(size_t)xcol[e] * bpad + b];
+    s += t; a += fabs(t);
+  }
+  if (b >= g.batch) { s = 0.0; a = 0.0; }
+  if (g.cmapT) {
+    if (b < g.batch) {
+      const int r = g.cmapT[(size_t)c * bpad + b];
+      if (s != 0.0 || a != 0.0) { atomicAdd(out + r, s); atomicAdd(out + nc_glob + r, a); }
+    }
+    return;
+  }
+  for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); a += __shfl_xor(a, off); }
+  if (lane == 0) { part[((size_t)chunk * 2) * g.nc + c] = s; part[((size_t)chunk * 2 + 1) * g.nc + c] = a; }
+}
+
+__global__ __launch_bounds__(256) void k_border_sum(GroupDev g, const double* __restrict__ part, double* __restrict__ out, int nc_glob) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= g.nc) return;
+  double s = 0.0, a = 0.0;
+  for (int q = 0; q < g.nchunk; ++q) { s += part[((size_t)q * 2) * g.nc + c]; a += part[((size_t)q * 2 + 1) * g.nc + c]; }
+  out[c] += s; out[nc_glob + c] += a;        // (groups one after the other on the handle's stream: deterministic)
+}
+
+// One workgroup per group: rho_b = rmax_b / smax_b (0 / 0 = 0), the worst instance of the group against the best so far
+// in `best` {rho, group, slot}; resets the per-instance maxima; the last group's launch publishes to the mailbox.
+__global__ __launch_bounds__(256) void k_residual_reduce(unsigned long long* __restrict__ rmax, unsigned long long* __restrict__ smax,
+                                                         int batch, int gid, int first, int last, double* __restrict__ best,
+                                                         double* mail, long long seq, int nc, const double* __restrict__ xc,
+                                                         const double* __restrict__ ax, const double* __restrict__ bc) {
+  __shared__ double srho[256];
+  __shared__ int sslot[256];
+  double rho = 0.0;
+  int slot = -1;
+  for (int b = threadIdx.x; b < batch; b += 256) {
+    const double r = __longlong_as_double((long long)rmax[b]), s = __longlong_as_double((long long)smax[b]);
+    rmax[b] = 0ull; smax[b] = 0ull;
+    const double q = (r == 0.0) ? 0.0 : ((s > 0.0 && r == r) ? r / s : INFINITY);
+    if (q > rho || slot < 0) { rho = q; slot = b; }
+  }
+  srho[threadIdx.x] = rho; sslot[threadIdx.x] = slot;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      const double o = srho[threadIdx.x + off];
+      const int os = sslot[threadIdx.x + off];
+      // (ties go to the lower slot: deterministic)
+      if (os >= 0 && (sslot[threadIdx.x] < 0 || o > srho[threadIdx.x] || (o == srho[threadIdx.x] && os < sslot[threadIdx.x]))) {
+        srho[threadIdx.x] = o; sslot[threadIdx.x] = os;
+      }
+    }
+    __syncthreads();
+  }
+  if (last) {
+    // the coupling vectors of the check: x_c | sum A x | sum |A||x| | b_c (mailbox rows behind the header)
+    for (int c = threadIdx.x; c < nc; c += 256) {
+      mail[8 + c] = xc[c];
+      mail[8 + nc + c] = ax[c];
+      mail[8 + 2 * (size_t)nc + c] = ax[nc + c];
+      mail[8 + 3 * (size_t)nc + c] = bc ? bc[c] : 0.0;
+    }
+    __threadfence_system();
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    double brho = first ? -1.0 : best[0];
+    if (srho[0] > brho) { best[0] = srho[0]; best[1] = (double)gid; best[2] = (double)sslot[0]; brho = srho[0]; }
+    if (last) {
+      mail[0] = best[0]; mail[1] = best[1]; mail[2] = best[2];
+      __threadfence_system();
+      __hip_atomic_store(reinterpret_cast<long long*>(mail) + 3, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// dst[rd(c)][b] += src[rs(c)][b]  (c < n; null maps = identity) -- the correction of a refinement step
+__global__ __launch_bounds__(256) void k_add_rows(double* __restrict__ dst, const int* __restrict__ rd,
+                                                  const double* __restrict__ src, const int* __restrict__ rs, int n, int bpad) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)n * bpad) return;
+  const int c = (int)(i / (size_t)bpad), b = (int)(i % (size_t)bpad);
+  dst[(size_t)(rd ? rd[c] : c) * bpad + b] += src[(size_t)(rs ? rs[c] : c) * bpad + b];
+}
+
+__global__ __launch_bounds__(256) void k_add_vec(double* __restrict__ dst, const double* __restrict__ src, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] += src[i];
+}
+
+__global__ __launch_bounds__(256) void k_gather_xc_refine(GroupDev g, const double* __restrict__ xc) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)g.nc * g.bpad) return;
+  const int b = (int)(i % g.bpad);
+  g.XCL[i] = (b < g.batch) ? xc[g.cmapT[i]] : 0.0;
+}
+
+}  // namespace
+
+// Records of the residual rows of one group (api.hip: pp_end_symbolic).  Row c (elimination order) of
+// [K_i | A_i^T]: every canonical lower entry (i, j) of K gives x_j to row i and, off the diagonal, x_i to row j; every
+// border entry (coupling row r, column j) gives xc_r to row j.  A canonical entry is the sum of its raw entries.
+int ppi_build_residual_records(pp_handle h, Group* g, const std::vector<int>& rawmap, const int32_t* rowK, const int32_t* colK,
+                               int nnzK, const int32_t* rowB, const int32_t* colB, int nnzB) {
+  const pp::Plan& P = g->plan;
+  const int n = P.n;
+  std::vector<std::vector<std::array<int, 2>>> rows((size_t)n);      // {canonical entry, x column (new) or -1 - coupling row}
+  for (int e = 0; e < nnzK; ++e) {
+    const int i = P.iperm[(size_t)rowK[e]], j = P.iperm[(size_t)colK[e]];
+    rows[(size_t)i].push_back({e, j});
+    if (i != j) rows[(size_t)j].push_back({e, i});
+  }
+  for (int e = 0; e < nnzB; ++e) rows[(size_t)P.iperm[(size_t)colB[e]]].push_back({nnzK + e, -1 - rowB[e]});
+  std::vector<int> ptr((size_t)n + 1, 0), vraw, xnew, xold;
+  for (int c = 0; c < n; ++c) {
+    for (auto& rc : rows[(size_t)c])
+      for (int q = g->can_ptr[(size_t)rc[0]]; q < g->can_ptr[(size_t)rc[0] + 1]; ++q) {
+        vraw.push_back(rawmap[(size_t)g->can_idx[(size_t)q]]);
+        xnew.push_back(rc[1]);
+        xold.push_back(rc[1] >= 0 ? P.perm[(size_t)rc[1]] : rc[1]);
+      }
+    ptr[(size_t)c + 1] = (int)vraw.size();
+  }
+  g->res_ne = (int)vraw.size();
+  g->res_vraw_host = vraw;
+  {
+    // the border by (local) coupling row: sum_e A[c, j] x_j
+    const int ncl = g->nc_loc;
+    std::vector<std::vector<std::array<int, 2>>> brows((size_t)std::max(ncl, 1));
+    for (int e = 0; e < nnzB; ++e) brows[(size_t)rowB[e]].push_back({nnzK + e, P.iperm[(size_t)colB[e]]});
+    std::vector<int> bptr((size_t)ncl + 1, 0), bv, bxn, bxo;
+    for (int c = 0; c < ncl; ++c) {
+      for (auto& rc2 : brows[(size_t)c])
+        for (int q = g->can_ptr[(size_t)rc2[0]]; q < g->can_ptr[(size_t)rc2[0] + 1]; ++q) {
+          bv.push_back(rawmap[(size_t)g->can_idx[(size_t)q]]);
+          bxn.push_back(rc2[1]);
+          bxo.push_back(P.perm[(size_t)rc2[1]]);
+        }
+      bptr[(size_t)c + 1] = (int)bv.size();
+    }
+    g->res_bne = (int)bv.size();
+    g->res_bvraw_host = bv;
+    int rcb;
+    if ((rcb = dev_upload(h, g, &g->res_bptr, bptr))) return rcb;
+    if ((rcb = dev_upload(h, g, &g->res_bvraw, bv))) return rcb;
+    if ((rcb = dev_upload(h, g, &g->res_bxnew, bxn))) return rcb;
+    if ((rcb = dev_upload(h, g, &g->res_bxold, bxo))) return rcb;
+    if ((rcb = dev_alloc(h, g, &g->res_bpart, (size_t)2 * std::max(ncl, 1) * (size_t)g->dev.nchunk))) return rcb;
+  }
+  for (int q = 0; q < 4; ++q) { vraw.push_back(0); xnew.push_back(0); xold.push_back(0); }
+  int rc;
+  if ((rc = dev_upload(h, g, &g->res_ptr, ptr))) return rc;
+  if ((rc = dev_upload(h, g, &g->res_vraw, vraw))) return rc;
+  if ((rc = dev_upload(h, g, &g->res_xnew, xnew))) return rc;
+  if ((rc = dev_upload(h, g, &g->res_xold, xold))) return rc;
+  if ((rc = dev_alloc(h, g, &g->res_rmax, (size_t)g->dev.bpad))) return rc;
+  if ((rc = dev_alloc(h, g, &g->res_smax, (size_t)g->dev.bpad))) return rc;
+  PP_HIP(hipMemset(g->res_rmax, 0, (size_t)g->dev.bpad * sizeof(unsigned long long)));
+  PP_HIP(hipMemset(g->res_smax, 0, (size_t)g->dev.bpad * sizeof(unsigned long long)));
+  return 0;
+}
+
+// The same records over the producer's source rows (api.hip: pp_set_value_map; ms / mc: source row or -1 and
+// coefficient of every compact row of the transposed input).
+int ppi_residual_value_map(pp_handle h, Group* g, const std::vector<int>& ms, const std::vector<double>& mc) {
+  std::vector<int> vs((size_t)g->res_ne + 4, 0);
+  std::vector<double> cs((size_t)g->res_ne + 4, 0.0);
+  for (int e = 0; e < g->res_ne; ++e) {
+    const int row = g->res_vraw_host[(size_t)e];
+    vs[(size_t)e] = ms[(size_t)row];        // (-1: the constant)
+    cs[(size_t)e] = mc[(size_t)row];
+  }
+  std::vector<int> bvs((size_t)g->res_bne + 1, 0);
+  std::vector<double> bcs((size_t)g->res_bne + 1, 0.0);
+  for (int e = 0; e < g->res_bne; ++e) {
+    const int row = g->res_bvraw_host[(size_t)e];
+    bvs[(size_t)e] = ms[(size_t)row];
+    bcs[(size_t)e] = mc[(size_t)row];
+  }
+  for (void* p : {(void*)g->res_vsrc, (void*)g->res_csrc, (void*)g->res_bvsrc, (void*)g->res_bcsrc}) if (p) (void)hipFree(p);
+  g->res_vsrc = g->res_bvsrc = nullptr; g->res_csrc = g->res_bcsrc = nullptr;
+  int rc;
+  if ((rc = dev_alloc(h, (Group*)nullptr, &g->res_vsrc, vs.size()))) return rc;
+  if ((rc = dev_alloc(h, (Group*)nullptr, &g->res_csrc, cs.size()))) return rc;
+  if ((rc = dev_alloc(h, (Group*)nullptr, &g->res_bvsrc, bvs.size()))) return rc;
+  if ((rc = dev_alloc(h, (Group*)nullptr, &g->res_bcsrc, bcs.size()))) return rc;
+  PP_HIP(hipMemcpy(g->res_vsrc, vs.data(), vs.size() * sizeof(int), hipMemcpyHostToDevice));
+  PP_HIP(hipMemcpy(g->res_csrc, cs.data(), cs.size() * sizeof(double), hipMemcpyHostToDevice));
+  PP_HIP(hipMemcpy(g->res_bvsrc, bvs.data(), bvs.size() * sizeof(int), hipMemcpyHostToDevice));
+  PP_HIP(hipMemcpy(g->res_bcsrc, bcs.data(), bcs.size() * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" {
+
+int pp_residual(pp_handle h, int store, const double* bc_dev) {
+  if (!h || !h->schur_done) return fail(h, 3, "pp_residual before a back-solve");
+  PP_HIP(hipSetDevice(h->device));
+  const int nc = h->nc;
+  if (!h->resid_host) {
+    void* hp = nullptr;
+    void* dp = nullptr;
+    const size_t doubles = 8 + 4 * (size_t)std::max(nc, 1);
+    PP_HIP(hipHostMalloc(&hp, doubles * sizeof(double), hipHostMallocMapped));
+    std::memset(hp, 0, doubles * sizeof(double));
+    PP_HIP(hipHostGetDevicePointer(&dp, hp, 0));
+    h->resid_host = (volatile double*)hp;
+    h->resid_dev = (double*)dp;
+    if (int rc = dev_alloc<double>(h, nullptr, &h->resid_best, 4)) return rc;
+    if (int rc = dev_alloc<double>(h, nullptr, &h->resid_ax, 2 * (size_t)std::max(nc, 1))) return rc;
+  }
+  const hipStream_t st = h->stream;
+  const size_t ng = h->groups.size();
+  ++h->resid_seq;
+  PP_HIP(hipMemsetAsync(h->resid_ax, 0, 2 * (size_t)std::max(nc, 1) * sizeof(double), st));
+  if (ng == 0) {                 // no local block: x_c and b_c only, an empty (passing) block result
+    hipLaunchKernelGGL(k_residual_reduce, dim3(1), dim3(256), 0, st, (unsigned long long*)nullptr, (unsigned long long*)nullptr, 0, -1, 1, 1,
+                       h->resid_best, h->resid_dev, h->resid_seq, nc, (const double*)h->xc, (const double*)h->resid_ax, bc_dev);
+    PP_HIP(hipGetLastError());
+    return 0;
+  }
+  for (size_t gi = 0; gi < ng; ++gi) {
+    Group* g = h->groups[gi];
+    GroupDev d = g->dev;
+    const pp::Plan& P = g->plan;
+    const bool native = g->x_native != nullptr && g->rhs_native != nullptr;
+    if (!native && (!d.X || !d.rhs)) return fail(h, 3, "pp_residual: no right-hand side / solution of the last back-solve");
+    const double* V;
+    const int* vrow;
+    const double* coef = nullptr;
+    if (g->last_fused) {
+      if (!g->res_vsrc || !g->src) return fail(h, 3, "pp_residual: no value map / source buffer");
+      V = g->src; vrow = g->res_vsrc; coef = g->res_csrc;
+    } else {
+      if (!d.rawT) return fail(h, 3, "pp_residual: the values of the last factorisation are gone");
+      V = d.rawT; vrow = g->res_vraw;
+    }
+    const double *B, *X;
+    const int *xcol, *brow;
+    if (native) { B = g->rhs_native; X = g->x_native; xcol = g->res_xold; brow = d.perm; }
+    else {
+      // b was consumed by the forward sweep (y is computed in place): transposed into Y again, elimination order
+      const int tiles = transpose_tiles(P.n, d.nchunk);
+      hipLaunchKernelGGL(k_transpose_in, dim3((unsigned)((P.n + 64 * tiles - 1) / (64 * tiles)) * d.nchunk), dim3(256), 0, st, d.rhs,
+                         d.Y, d.iperm, d.batch, P.n, d.bpad, tiles, (const int*)nullptr);
+      B = d.Y; X = d.X; xcol = g->res_xnew; brow = nullptr;
+    }
+    double* Rout = nullptr;
+    if (store) {
+      if (!g->res_R) {
+        std::lock_guard<std::mutex> lk(h->alloc_mu);
+        if (int rc = value_alloc(h, g, &g->res_R, (size_t)P.n * (size_t)d.bpad)) return rc;
+        if (int rc = value_alloc(h, g, &g->res_D, (size_t)P.n * (size_t)d.bpad)) return rc;
+      }
+      Rout = g->res_R;               // caller's row order: the correction solve runs on native vectors
+    }
+    const double* xcp = (d.cmapT && d.nc > 0) ? d.XCL : h->xc;
+    const unsigned ntask = (unsigned)((P.n + RES_ROWS - 1) / RES_ROWS);
+    if (h->lane_pairs && d.nchunk % 2 == 0)
+      hipLaunchKernelGGL(k_residual<2>, dim3(ntask * (unsigned)(d.nchunk / 2)), dim3(64), 0, st, d, g->res_ptr, vrow, coef, xcol, brow, V,
+                         B, X, xcp, Rout, d.perm, g->res_rmax, g->res_smax, d.nchunk / 2);
+    else
+      hipLaunchKernelGGL(k_residual<1>, dim3(ntask * (unsigned)d.nchunk), dim3(64), 0, st, d, g->res_ptr, vrow, coef, xcol, brow, V,
+                         B, X, xcp, Rout, d.perm, g->res_rmax, g->res_smax, d.nchunk);
+    if (d.nc > 0) {
+      // sum_i A_i x_i of this group's instances into the handle's coupling vectors
+      const int* bvr = g->last_fused ? g->res_bvsrc : g->res_bvraw;
+      const double* bcf = g->last_fused ? g->res_bcsrc : nullptr;
+      hipLaunchKernelGGL(k_border_ax, dim3((unsigned)d.nc * (unsigned)d.nchunk), dim3(64), 0, st, d, g->res_bptr, bvr, bcf,
+                         native ? g->res_bxold : g->res_bxnew, V, X, g->res_bpart, h->resid_ax, nc);
+      if (!d.cmapT)
+        hipLaunchKernelGGL(k_border_sum, dim3((unsigned)((d.nc + 255) / 256)), dim3(256), 0, st, d, (const double*)g->res_bpart, h->resid_ax, nc);
+    }
+    hipLaunchKernelGGL(k_residual_reduce, dim3(1), dim3(256), 0, st, g->res_rmax, g->res_smax, d.batch, (int)gi, gi == 0 ? 1 : 0,
+                       gi + 1 == ng ? 1 : 0, h->resid_best, h->resid_dev, h->resid_seq, nc, (const double*)h->xc, (const double*)h->resid_ax,
+                       bc_dev);
+  }
+  PP_HIP(hipGetLastError());
+  return 0;
+}
+
+int pp_residual_result(pp_handle h, double out[4], double* coupling_out) {
+  if (!h || !h->resid_host || h->resid_seq == 0) return fail(h, 3, "pp_residual_result before pp_residual");
+  PP_HIP(hipSetDevice(h->device));
+  const volatile long long* seq = reinterpret_cast<volatile long long*>(h->resid_host) + 3;
+  const auto t0 = std::chrono::steady_clock::now();
+  int spins = 0;
+  while (__atomic_load_n(const_cast<const long long*>(seq), __ATOMIC_ACQUIRE) != h->resid_seq) {
+    if (++spins % 4096 == 0) {
+      if (hipStreamQuery(h->stream) == hipSuccess && __atomic_load_n(const_cast<const long long*>(seq), __ATOMIC_ACQUIRE) != h->resid_seq) {
+        // the stream has drained and the mailbox is still stale: a launch failed
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) return fail(h, 3, "pp_residual_result: the check did not run");
+      }
+    }
+  }
+  out[0] = h->resid_host[0]; out[1] = h->resid_host[1]; out[2] = h->resid_host[2]; out[3] = 0.0;
+  if (coupling_out)       // x_c | sum A x | sum |A||x| | b_c, n_c doubles each
+    for (size_t i = 0; i < 4 * (size_t)h->nc; ++i) coupling_out[i] = h->resid_host[8 + i];
+  return 0;
+}
+
+// Correction solve of a refinement step: between begin and end the sweeps (pp_solve_forward, the caller's all-reduce of
+// r_s, pp_solve_coupling_dev(NULL), pp_solve_backward) run on the stored residual (pp_residual(h, 1)) as right-hand side
+// and write the correction d; end adds d to the solution of the back-solve (and its coupling part to x_c) and restores
+// the caller's vectors.
+int pp_refine_begin(pp_handle h) {
+  if (!h || !h->schur_done) return fail(h, 3, "pp_refine_begin before a back-solve");
+  if (h->refining) return fail(h, 3, "pp_refine_begin: a correction solve is already open");
+  PP_HIP(hipSetDevice(h->device));
+  for (Group* g : h->groups)
+    if (!g->res_R || !g->res_D) return fail(h, 3, "pp_refine_begin: no stored residual (pp_residual(h, 1) first)");
+  if (h->nc > 0) {
+    if (!h->xc_save) { if (int rc = dev_alloc<double>(h, nullptr, &h->xc_save, (size_t)h->nc)) return rc; }
+    PP_HIP(hipMemcpyAsync(h->xc_save, h->xc, (size_t)h->nc * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  }
+  for (Group* g : h->groups) {
+    g->save_rhs_native = g->rhs_native;
+    g->save_x_native = g->x_native;
+    g->rhs_native = g->res_R;
+    g->x_native = g->res_D;
+  }
+  h->refining = true;
+  return 0;
+}
+
+int pp_refine_end(pp_handle h) {
+  if (!h || !h->refining) return fail(h, 3, "pp_refine_end without pp_refine_begin");
+  PP_HIP(hipSetDevice(h->device));
+  const hipStream_t st = h->stream;
+  h->refining = false;
+  if (h->nc > 0) {
+    hipLaunchKernelGGL(k_add_vec, dim3((unsigned)((h->nc + 255) / 256)), dim3(256), 0, st, h->xc, h->xc_save, h->nc);
+  }
+  for (Group* g : h->groups) {
+    GroupDev& d = g->dev;
+    const pp::Plan& P = g->plan;
+    g->rhs_native = g->save_rhs_native;
+    g->x_native = g->save_x_native;
+    const bool native = g->x_native != nullptr;
+    const unsigned nb = (unsigned)(((size_t)P.n * d.bpad + 255) / 256);
+    if (native) {
+      hipLaunchKernelGGL(k_add_rows, dim3(nb), dim3(256), 0, st, g->x_native, (const int*)nullptr, (const double*)g->res_D, (const int*)nullptr,
+                         P.n, d.bpad);
+    } else {
+      // x lives in X in elimination order; d came back in the caller's row order
+      hipLaunchKernelGGL(k_add_rows, dim3(nb), dim3(256), 0, st, d.X, (const int*)nullptr, (const double*)g->res_D, d.perm, P.n, d.bpad);
+      hipLaunchKernelGGL(k_transpose_out, dim3((unsigned)((P.n + 63) / 64) * d.nchunk), dim3(256), 0, st, d.X, d.iperm, d.xout,
+                         d.batch, P.n, d.bpad);
+    }
+    if (d.cmapT && d.nc > 0)
+      hipLaunchKernelGGL(k_gather_xc_refine, dim3((unsigned)(((size_t)d.nc * d.bpad + 255) / 256)), dim3(256), 0, st, d, h->xc);
+  }
+  PP_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"
