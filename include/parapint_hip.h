@@ -226,6 +226,32 @@ double* pp_solution_buffer(pp_handle h, int group);
 int pp_bind_solution_buffer(pp_handle h, int group, double* dev_ptr);
 int pp_get_coupling_solution(pp_handle h, double* xc_host);
 
+/* ---- a-posteriori check of a back-solve, iterative refinement ------------------------------------------------------------
+ * The reference's sub-solvers pivot every block on its own values (MA27 with cntl(1), ma27_interface.py:36-47, 110-140;
+ * SuperLU, scipy_interface.py:26-31): a `successful` factorisation of theirs solves accurately.  Here one static pivot
+ * sequence serves all instances of a pattern group, so every back-solve (mpi_...:363-402) is looked at.
+ *   pp_residual         after pp_solve_backward: r_i = b_i - K_i x_i - A_i^T x_c of every local block from the values the last
+ *                       factorisation read, rho_b = max |r| / max (|K||x| + |A^T x_c| + |b|) over the rows of an instance,
+ *                       and the local sums sum_i A_i x_i, sum_i |A_i||x_i| of the coupling rows; store != 0 keeps r as the
+ *                       right-hand side of a correction solve.  bc_dev: the coupling right-hand side of the back-solve on
+ *                       the device (n_c doubles) or NULL.  coupling_on_device != 0 (one rank, dense S): the coupling rows
+ *                       b_c - sum A x - Q x_c (Q as the last pp_factor_schur got it) are judged on the device as well, and
+ *                       with store their residual stays there for pp_refine_solve_coupling.  Stream-ordered; publishes to
+ *                       a pinned mailbox.
+ *   pp_residual_result  waits for it: out = {worst rho of the local instances, its group, its slot, the largest row scale
+ *                       |K||x| + |A^T x_c| + |b| of the local blocks, rho of the coupling rows or -1, 0}; -1: coupling_out
+ *                       (4 n_c doubles) receives x_c | sum A x | sum |A||x| | b_c -- the caller adds Q x_c and, with several
+ *                       ranks, all-reduces the two sums before it judges the coupling rows.
+ *   pp_refine_begin / pp_refine_end   bracket a correction solve: between them pp_solve_forward, the all-reduce of r_s,
+ *                       pp_solve_coupling(_dev) with the residual of the coupling rows, pp_solve_backward run on the stored
+ *                       residual and produce a correction; end adds it to the solution of the back-solve (x_c included) in
+ *                       whatever vectors that solve used and restores them. */
+int pp_residual(pp_handle h, int store, const double* bc_dev, int coupling_on_device);
+int pp_residual_result(pp_handle h, double out[6], double* coupling_out);
+int pp_refine_solve_coupling(pp_handle h);
+int pp_refine_begin(pp_handle h);
+int pp_refine_end(pp_handle h);
+
 /* ---- misc -------------------------------------------------------------------------------- */
 /* Memory reallocation protocol (interior_point.py:634-652 try_factorization_and_reallocation; the sub-solver side is
  * ma27_interface.py:126-131 status -3/-4 -> not_enough_memory and :153-154 iw_factor, a_factor *= factor; reference

@@ -135,6 +135,11 @@ SIGNATURES = {
     'pp_get_growth_count': (ctypes.c_int, [ctypes.c_void_p, _i64p]),
     'pp_find_growth': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _i32p]),
     'pp_find_zero_pivot': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _i32p]),
+    'pp_residual': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]),
+    'pp_refine_solve_coupling': (ctypes.c_int, [ctypes.c_void_p]),
+    'pp_residual_result': (ctypes.c_int, [ctypes.c_void_p, _f64p, ctypes.c_void_p]),
+    'pp_refine_begin': (ctypes.c_int, [ctypes.c_void_p]),
+    'pp_refine_end': (ctypes.c_int, [ctypes.c_void_p]),
     'pp_get_factor': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f64p, ctypes.c_int64]),
 }
 

@@ -188,7 +188,12 @@ int pp_end_symbolic(pp_handle h) {
       build(0);
       for (auto& t : th) t.join();
     } else if (todo.size() == 1) build(0);
-    for (size_t i = 0; i < todo.size(); ++i) { delete todo[i]->pending; todo[i]->pending = nullptr; }
+    for (size_t i = 0; i < todo.size(); ++i) {
+      // (the canonical pattern stays with the group: the residual rows of the a-posteriori check are built from it)
+      todo[i]->pat_rowK.swap(todo[i]->pending->rowK); todo[i]->pat_colK.swap(todo[i]->pending->colK);
+      todo[i]->pat_rowB.swap(todo[i]->pending->rowB); todo[i]->pat_colB.swap(todo[i]->pending->colB);
+      delete todo[i]->pending; todo[i]->pending = nullptr;
+    }
     for (size_t i = 0; i < todo.size(); ++i) {
       if (rcs[i] != 0) return fail(h, rcs[i], "symbolic analysis failed: " + todo[i]->plan.error);
       if (todo[i]->plan.usize >= (int64_t)1 << 31) return fail(h, 1, "panel storage exceeds 2^31 entries per instance");
@@ -377,6 +382,7 @@ int pp_end_symbolic(pp_handle h) {
     if ((rc = dev_upload(h, g, &d.perm, P.perm))) return rc;
     if ((rc = dev_upload(h, g, &d.iperm, P.iperm))) return rc;
     if ((rc = dev_upload(h, g, &d.rawmap, rawmap))) return rc;
+    if ((rc = ppi_build_residual_records(h, g, rawmap))) return rc;
     {
       std::vector<int> rtiles;
       for (int t0 = 0; t0 * 64 < g->nraw; ++t0) {
@@ -730,7 +736,7 @@ int pp_set_value_map(pp_handle h, int group, int nsrc, const int32_t* src_of_raw
     if ((rc = dev_alloc(h, (Group*)nullptr, &g->fent_src, fs.size()))) return rc;
     PP_HIP(hipMemcpy(g->fent_src, fs.data(), fs.size() * sizeof(int), hipMemcpyHostToDevice));
   }
-  return 0;
+  return ppi_residual_value_map(h, g, ms, mc);
 }
 
 double* pp_source_buffer(pp_handle h, int group) {

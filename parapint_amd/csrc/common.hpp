@@ -232,6 +232,21 @@ struct Group {
   std::vector<uint8_t> staged_row_valid;
   const double* stage_host = nullptr;
   std::vector<int> cmap_host;        // mapped group: [batch][nc_loc] global coupling indices
+  // a-posteriori check of a back-solve (refine.hip): canonical pattern (kept from the symbolic phase), residual records by row of
+  // [K | A^T] over the transposed input (vraw) / over the producer's sources (vsrc, csrc), border records by coupling row,
+  // per-instance maxima, residual and correction vectors of a refinement step (value storage, allocated at first use)
+  std::vector<int32_t> pat_rowK, pat_colK, pat_rowB, pat_colB;
+  const int *res_ptr = nullptr, *res_vraw = nullptr, *res_xnew = nullptr, *res_xold = nullptr;
+  const int *res_bptr = nullptr, *res_bvraw = nullptr, *res_bxnew = nullptr, *res_bxold = nullptr;
+  int res_ne = 0, res_bne = 0;
+  std::vector<int> res_vraw_host, res_bvraw_host;
+  int *res_vsrc = nullptr, *res_bvsrc = nullptr;
+  double *res_csrc = nullptr, *res_bcsrc = nullptr;
+  unsigned long long *res_rmax = nullptr, *res_smax = nullptr;
+  double *res_bpart = nullptr, *res_R = nullptr, *res_D = nullptr;
+  bool last_fused = false;           // the last factorisation read the sources through the entry records (else the transposed input)
+  const double* save_rhs_native = nullptr;
+  double* save_x_native = nullptr;
 };
 
 
@@ -424,6 +439,13 @@ struct pp_solver {
   int64_t mem_required = 0;      // bytes of value storage the current plan needs
   bool values_allocated = false;
   std::string err;
+  // a-posteriori check (refine.hip): pinned mailbox {rho, group, slot, sequence | x_c, sum A x, sum |A||x|, b_c}
+  volatile double* resid_host = nullptr;
+  double *resid_dev = nullptr, *resid_best = nullptr, *resid_ax = nullptr, *resid_rc = nullptr, *xc_save = nullptr;
+  long long resid_seq = 0;
+  bool refining = false, resid_rc_valid = false, resid_on_device = false;
+  const double* last_rc = nullptr;   // coupling right-hand side (device) of the last pp_solve_coupling(_dev), or null
+  bool have_Q = false;           // the last dense factorisation of S had a coupling block Q (resident in Qd)
   void* rccl_comm = nullptr;     // ncclComm_t of pp_comm_init (api.hip), or null
   int rccl_ranks = 0;
   // Instance groups ("splits"): the level sweeps of disjoint 64-instance chunk ranges are
@@ -450,6 +472,8 @@ int ppi_dense_factor_schur(pp_handle h, const double* Q_host);                  
 int ppi_dense_coupling_solve(pp_handle h, const double* rc_dev);                     // dense.hip
 int ppi_btd_factor_schur(pp_handle h, const double* Q_host, long long corner_nnz);   // bcr.hip
 int ppi_btd_coupling_solve(pp_handle h, const double* rc_dev);                       // bcr.hip
+int ppi_build_residual_records(pp_handle h, ppd::Group* g, const std::vector<int>& rawmap);                          // refine.hip
+int ppi_residual_value_map(pp_handle h, ppd::Group* g, const std::vector<int>& ms, const std::vector<double>& mc);   // refine.hip
 
 // Host-side helpers (internal linkage: every translation unit carries the ones it uses)
 namespace {
@@ -676,7 +700,8 @@ int transpose_tiles(int, int) {
 }
 
 void free_group(Group* g) {
-  for (void* p : {(void*)g->map_src, (void*)g->map_coef, (void*)g->src_own, (void*)g->fent_src}) if (p) (void)hipFree(p);
+  for (void* p : {(void*)g->map_src, (void*)g->map_coef, (void*)g->src_own, (void*)g->fent_src, (void*)g->res_vsrc, (void*)g->res_csrc,
+                  (void*)g->res_bvsrc, (void*)g->res_bcsrc}) if (p) (void)hipFree(p);
   if (g->shift_row) (void)hipFree(g->shift_row);
   if (g->shift_cls) (void)hipFree(g->shift_cls);
   for (void* p : g->value_allocs) (void)hipFree(p);
@@ -696,6 +721,11 @@ void free_globals(pp_handle h) {
   h->dense_mode = nullptr;
   h->ipiv = h->bkinfo = h->counters = nullptr;
   if (h->vec_part) { (void)hipFree(h->vec_part); h->vec_part = nullptr; }
+  for (void* p : {(void*)h->resid_best, (void*)h->resid_ax, (void*)h->resid_rc, (void*)h->xc_save}) if (p) (void)hipFree(p);
+  h->resid_best = h->resid_ax = h->resid_rc = h->xc_save = nullptr;
+  h->resid_rc_valid = false; h->have_Q = false;
+  if (h->resid_host) (void)hipHostFree((void*)h->resid_host);
+  h->resid_host = nullptr; h->resid_dev = nullptr; h->resid_seq = 0; h->refining = false;
   if (h->dn_z) { (void)hipFree(h->dn_z); h->dn_z = nullptr; }
   for (void* p : {(void*)h->btd_fac, (void*)h->btd_inv, (void*)h->btd_x, (void*)h->btd_vec, (void*)h->btd_ipiv, (void*)h->btd_info,
                   (void*)h->scatter_err, (void*)h->btd_klo, (void*)h->btd_kup, (void*)h->btd_ylo, (void*)h->btd_yup, (void*)h->btd_elim})
@@ -744,6 +774,7 @@ void free_value_storage(Group* g) {
   d.growth = nullptr;
   d.Sloc = d.XCL = nullptr;
   g->raw_own = g->rhs_own = g->xout_own = g->rawT_own = nullptr;
+  g->res_R = g->res_D = nullptr;
 }
 
 template <class T>

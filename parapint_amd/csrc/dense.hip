@@ -1099,6 +1099,7 @@ int ppi_dense_factor_schur(pp_handle h, const double* Q_host) {
   }
   {
     if (Q_host) PP_HIP(hipMemcpyAsync(h->Qd, Q_host, nn * sizeof(double), hipMemcpyHostToDevice, st));
+    h->have_Q = Q_host != nullptr;      // (the a-posteriori check of the back-solves reads it: refine.hip)
     const double* Qd = Q_host ? h->Qd : nullptr;
     const bool regs = h->dense_policy == 0 && nc <= 16 * LDLR_NT;
     PhaseScope ps(h, 3, regs ? 2 : 3);

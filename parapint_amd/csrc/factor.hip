@@ -1025,6 +1025,7 @@ int pp_numeric_factor_blocks(pp_handle h) {
                            g->shift_cls, g->nshift, d.bpad, h->shift_w, h->shift_c);
     }
     if (fused_sources) { d.rawT = g->src; d.fent = g->fent_src; d.const_row = g->nsrc; }
+    g->last_fused = fused_sources;      // (where the a-posteriori check of the back-solves finds the values: refine.hip)
     {
       int nlaunch = 0;
       for (int l = 0; l < P.n_levels; ++l)

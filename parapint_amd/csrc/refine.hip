@@ -30,28 +30,71 @@ __device__ __forceinline__ unsigned long long dbits(double v) { return (unsigned
 
 // NV instances per lane (as in factor.hip).  vrow < 0: the constant 1 (value-map form: source row == const_row is
 // rewritten to -1 at build time).  xcol >= 0: row of X; xcol < 0: coupling value -1 - xcol (xc / per-instance XCL).
-template <int NV>
-__global__ __launch_bounds__(64) void k_residual(GroupDev g, const int* __restrict__ rptr, const int* __restrict__ vrow,
-                                                 const double* __restrict__ coef, const int* __restrict__ xcol,
-                                                 const int* __restrict__ brow, const double* __restrict__ V,
+// Arguments of the residual launch that do not fit a plain parameter list comfortably
+struct ResArgs {
+  const int *rptr, *vrow, *xcol, *brow, *rrow;       // rows of [K | A^T]: entry ranges, value rows, x rows, b rows, rows of Rout
+  const double* coef;                                // value-map form: coefficient per record (else null = 1)
+  const int *bptr, *bvrow, *bxcol;                   // the border by coupling row
+  const double* bcoef;
+  const double *V, *B, *X, *xc;
+  double* Rout;
+  unsigned long long *rmax, *smax;
+  double *bpart, *ax;                                // border partial sums [chunk][2][nc] (uniform groups) / coupling sums (mapped)
+  int nres_wg, ny, rows_per_wg, nc_glob;
+};
+
+// NV instances per lane (as in factor.hip).  vrow < 0: the constant 1.  xcol >= 0: row of X; xcol < 0: coupling value
+// -1 - xcol (xc / per-instance XCL).  The workgroups behind the residual rows take the coupling rows: per (local coupling
+// row c, chunk) one wave forms sum_e A[c, j_e] x_(j_e) and the same with absolute values over its 64 instances; uniform
+// groups reduce over the lanes into bpart[chunk][2][nc] (summed by k_residual_reduce), mapped groups add every instance's
+// term to its own global coupling row.
+template <int NV, bool STORE>
+__global__ __launch_bounds__(64) void k_residual(GroupDev g, ResArgs a, const int* __restrict__ rptr, const int* __restrict__ vrow,
+                                                 const int* __restrict__ xcol, const int* __restrict__ brow,
+                                                 const double* __restrict__ coef, const double* __restrict__ V,
                                                  const double* __restrict__ B, const double* __restrict__ X,
-                                                 const double* __restrict__ xc, double* __restrict__ Rout,
-                                                 const int* __restrict__ rrow, unsigned long long* __restrict__ rmax,
-                                                 unsigned long long* __restrict__ smax, int ny) {
+                                                 const double* __restrict__ xc) {
   const int lane = threadIdx.x;
-  const unsigned b = (unsigned)(((blockIdx.x % (unsigned)ny) * 64 + lane) * NV);
-  const int c0 = (int)(blockIdx.x / (unsigned)ny) * RES_ROWS;
-  const int c1 = min(c0 + RES_ROWS, g.n);
   const size_t bpad = (size_t)g.bpad;
+  if ((int)blockIdx.x >= a.nres_wg) {
+    const int t = (int)blockIdx.x - a.nres_wg;
+    const int chunk = t % g.nchunk, c = t / g.nchunk;
+    const int b = chunk * 64 + lane;
+    double s = 0.0, ab = 0.0;
+    for (int e = a.bptr[c]; e < a.bptr[c + 1]; ++e) {
+      const int vr = a.bvrow[e];
+      const double tm = (a.bcoef ? a.bcoef[e] : 1.0) * (vr >= 0 ? a.V[(size_t)vr * bpad + b] : 1.0) * a.X[(size_t)a.bxcol[e] * bpad + b];
+      s += tm; ab += fabs(tm);
+    }
+    if (b >= g.batch) { s = 0.0; ab = 0.0; }
+    if (g.cmapT) {
+      if (b < g.batch && (s != 0.0 || ab != 0.0)) {
+        const int r = g.cmapT[(size_t)c * bpad + b];
+        atomicAdd(a.ax + r, s); atomicAdd(a.ax + a.nc_glob + r, ab);
+      }
+      return;
+    }
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); ab += __shfl_xor(ab, off); }
+    if (lane == 0) { a.bpart[((size_t)chunk * 2) * g.nc + c] = s; a.bpart[((size_t)chunk * 2 + 1) * g.nc + c] = ab; }
+    return;
+  }
+  const unsigned b = (unsigned)(((blockIdx.x % (unsigned)a.ny) * 64 + lane) * NV);
+  const int c0 = (int)(blockIdx.x / (unsigned)a.ny) * a.rows_per_wg;
+  const int c1 = min(c0 + a.rows_per_wg, g.n);
+  // (the records as restrict-qualified kernel parameters, and no store inside the row loop unless STORE: through the
+  // argument struct, or with stores in between, the compiler fetches every record with a vector load + v_readfirstlane
+  // instead of a scalar load -- measured 125 against 95 us at C3)
   const double* __restrict__ Vb = V + b;
   const double* __restrict__ Xb = X + b;
+  const double* __restrict__ Bb = B + b;
+  double* __restrict__ Rout = STORE ? a.Rout + b : nullptr;
   double rm[NV], sm[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) { rm[v] = 0.0; sm[v] = 0.0; }
   for (int c = c0; c < c1; ++c) {
     const int e0 = rptr[c], e1 = rptr[c + 1];
     double bv[NV];
-    ldv<NV>(B + (size_t)(brow ? brow[c] : c) * bpad + b, bv);
+    ldv<NV>(Bb + (size_t)(brow ? brow[c] : c) * bpad, bv);
     double acc[NV], aab[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) { acc[v] = 0.0; aab[v] = 0.0; }
@@ -93,76 +136,59 @@ __global__ __launch_bounds__(64) void k_residual(GroupDev g, const int* __restri
       rm[v] = fmax(rm[v], ar);
       sm[v] = fmax(sm[v], live ? aab[v] + fabs(bv[v]) : 0.0);
     }
-    if (Rout) stv<NV>(Rout + (size_t)(rrow ? rrow[c] : c) * bpad + b, r);
+    if (STORE) stv<NV>(Rout + (size_t)(a.rrow ? a.rrow[c] : c) * bpad, r);
   }
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     if ((int)(b + v) < g.batch) {
       // (non-negative doubles order like their bit patterns; +inf is the largest)
-      atomicMax(rmax + b + v, dbits(rm[v]));
-      atomicMax(smax + b + v, dbits(sm[v]));
+      atomicMax(a.rmax + b + v, dbits(rm[v]));
+      atomicMax(a.smax + b + v, dbits(sm[v]));
     }
   }
 }
 
-
-// Coupling rows: per (local coupling row c, chunk) one wave forms sum_e A[c, j_e] x_(j_e) and the same with absolute values
-// over its 64 instances; uniform groups reduce over the lanes into part[chunk][2][nc] (summed by k_border_sum), mapped groups
-// add every instance's term to its own global coupling row.
-__global__ __launch_bounds__(64) void k_border_ax(GroupDev g, const int* __restrict__ bptr, const int* __restrict__ vrow,
-                                                  const double* __restrict__ coef, const int* __restrict__ xcol,
-                                                  const double* __restrict__ V, const double* __restrict__ X,
-                                                  double* __restrict__ part, double* __restrict__ out, int nc_glob) {
-  const int lane = threadIdx.x;
-  const int chunk = (int)(blockIdx.x % (unsigned)g.nchunk), c = (int)(blockIdx.x / (unsigned)g.nchunk);
-  const int b = chunk * 64 + lane;
-  const size_t bpad = (size_t)g.bpad;
-  double s = 0.0, a = 0.0;
-  for (int e = bptr[c]; e < bptr[c + 1]; ++e) {
-    const int vr = vrow[e];
-    const double t = (coef ? coef[e] : 1.0) * (vr >= 0 ? V[(size_t)vr * bpad + b] : 1.0) * X[(size_t)xcol[e] * bpad + b];
-    s += t; a += fabs(t);
-  }
-  if (b >= g.batch) { s = 0.0; a = 0.0; }
-  if (g.cmapT) {
-    if (b < g.batch) {
-      const int r = g.cmapT[(size_t)c * bpad + b];
-      if (s != 0.0 || a != 0.0) { atomicAdd(out + r, s); atomicAdd(out + nc_glob + r, a); }
-    }
-    return;
-  }
-  for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); a += __shfl_xor(a, off); }
-  if (lane == 0) { part[((size_t)chunk * 2) * g.nc + c] = s; part[((size_t)chunk * 2 + 1) * g.nc + c] = a; }
-}
-
-__global__ __launch_bounds__(256) void k_border_sum(GroupDev g, const double* __restrict__ part, double* __restrict__ out, int nc_glob) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= g.nc) return;
-  double s = 0.0, a = 0.0;
-  for (int q = 0; q < g.nchunk; ++q) { s += part[((size_t)q * 2) * g.nc + c]; a += part[((size_t)q * 2 + 1) * g.nc + c]; }
-  out[c] += s; out[nc_glob + c] += a;        // (groups one after the other on the handle's stream: deterministic)
-}
-
-// One workgroup per group: rho_b = rmax_b / smax_b (0 / 0 = 0), the worst instance of the group against the best so far
-// in `best` {rho, group, slot}; resets the per-instance maxima; the last group's launch publishes to the mailbox.
+// One workgroup per group, one after the other on the handle's stream: rho_b = rmax_b / smax_b (0 / 0 = 0), the worst
+// instance of the group against the best so far in best = {rho, group, slot, largest row scale}; the per-instance maxima
+// are reset; the group's border sums are added to the handle's coupling sums ax | aabs (uniform groups: from the per-chunk
+// partials; the first group stores).  The LAST group's launch finishes the check:
+//   coupling rows on the device (Qmode >= 0: dense S, one rank -- all sums are complete here):
+//     r_c = b_c - sum A x - Q x_c  (Qmode 1: Q dense column-major, lower triangle read; 0: Q = 0), measured against
+//     max(row scales of the coupling rows, largest row scale of the blocks) -> mail {rho, group, slot, seq, scale, rho_c};
+//     rc_out (store): r_c for the correction solve;
+//   else (Qmode < 0: several ranks or a block-tridiagonal S -- the caller finishes the coupling rows after its all-reduce):
+//     the header only; x_c, the sums and b_c follow by copies behind this launch, and k_residual_flag signals.
 __global__ __launch_bounds__(256) void k_residual_reduce(unsigned long long* __restrict__ rmax, unsigned long long* __restrict__ smax,
                                                          int batch, int gid, int first, int last, double* __restrict__ best,
-                                                         double* mail, long long seq, int nc, const double* __restrict__ xc,
-                                                         const double* __restrict__ ax, const double* __restrict__ bc) {
-  __shared__ double srho[256];
+                                                         double* mail, long long seq, int nc, int nc_loc, int nchunk,
+                                                         const double* __restrict__ bpart, double* __restrict__ ax,
+                                                         const double* __restrict__ xc, const double* __restrict__ bc, int Qmode,
+                                                         const double* __restrict__ Q, double* __restrict__ rc_out) {
+  __shared__ double srho[256], sscale[256];
   __shared__ int sslot[256];
-  double rho = 0.0;
+  double rho = 0.0, scale = 0.0;
   int slot = -1;
   for (int b = threadIdx.x; b < batch; b += 256) {
     const double r = __longlong_as_double((long long)rmax[b]), s = __longlong_as_double((long long)smax[b]);
     rmax[b] = 0ull; smax[b] = 0ull;
+    scale = fmax(scale, s);
     const double q = (r == 0.0) ? 0.0 : ((s > 0.0 && r == r) ? r / s : INFINITY);
     if (q > rho || slot < 0) { rho = q; slot = b; }
   }
-  srho[threadIdx.x] = rho; sslot[threadIdx.x] = slot;
+  if (bpart) {          // uniform group: its border sums (local row = global row)
+    for (int c = threadIdx.x; c < nc_loc; c += 256) {
+      double s = 0.0, ab = 0.0;
+#pragma unroll 8
+      for (int q = 0; q < nchunk; ++q) { s += bpart[((size_t)q * 2) * nc_loc + c]; ab += bpart[((size_t)q * 2 + 1) * nc_loc + c]; }
+      ax[c] = first ? s : ax[c] + s;
+      ax[nc + c] = first ? ab : ax[nc + c] + ab;
+    }
+  }
+  srho[threadIdx.x] = rho; sslot[threadIdx.x] = slot; sscale[threadIdx.x] = scale;
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) {
     if ((int)threadIdx.x < off) {
+      sscale[threadIdx.x] = fmax(sscale[threadIdx.x], sscale[threadIdx.x + off]);
       const double o = srho[threadIdx.x + off];
       const int os = sslot[threadIdx.x + off];
       // (ties go to the lower slot: deterministic)
@@ -172,26 +198,57 @@ __global__ __launch_bounds__(256) void k_residual_reduce(unsigned long long* __r
     }
     __syncthreads();
   }
-  if (last) {
-    // the coupling vectors of the check: x_c | sum A x | sum |A||x| | b_c (mailbox rows behind the header)
+  __shared__ double bscale;
+  if (threadIdx.x == 0) {
+    const double brho = first ? -1.0 : best[0];
+    if (srho[0] > brho) { best[0] = srho[0]; best[1] = (double)gid; best[2] = (double)sslot[0]; }
+    best[3] = first ? sscale[0] : fmax(best[3], sscale[0]);       // largest row scale |K||x| + |b| of the local blocks
+    bscale = best[3];
+  }
+  __syncthreads();
+  if (!last) return;
+  double rho_c = 0.0;
+  if (Qmode >= 0 && nc > 0) {
+    double rmx = 0.0, smx = 0.0;
     for (int c = threadIdx.x; c < nc; c += 256) {
-      mail[8 + c] = xc[c];
-      mail[8 + nc + c] = ax[c];
-      mail[8 + 2 * (size_t)nc + c] = ax[nc + c];
-      mail[8 + 3 * (size_t)nc + c] = bc ? bc[c] : 0.0;
+      const double bcv = bc ? bc[c] : 0.0;
+      double r = bcv - ax[c], s = fabs(bcv) + ax[nc + c];
+      if (Qmode == 1) {
+        for (int k = 0; k < nc; ++k) {
+          const double q = (c >= k) ? Q[(size_t)c + (size_t)k * nc] : Q[(size_t)k + (size_t)c * nc];
+          r -= q * xc[k];
+          s += fabs(q) * fabs(xc[k]);
+        }
+      }
+      if (rc_out) rc_out[c] = r;
+      rmx = fmax(rmx, (r == r) ? fabs(r) : INFINITY);
+      smx = fmax(smx, s);
     }
-    __threadfence_system();
     __syncthreads();
+    srho[threadIdx.x] = rmx; sscale[threadIdx.x] = smx;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if ((int)threadIdx.x < off) {
+        srho[threadIdx.x] = fmax(srho[threadIdx.x], srho[threadIdx.x + off]);
+        sscale[threadIdx.x] = fmax(sscale[threadIdx.x], sscale[threadIdx.x + off]);
+      }
+      __syncthreads();
+    }
+    const double den = fmax(sscale[0], bscale);
+    rho_c = (srho[0] == 0.0) ? 0.0 : ((den > 0.0 && srho[0] < INFINITY) ? srho[0] / den : INFINITY);
   }
   if (threadIdx.x == 0) {
-    double brho = first ? -1.0 : best[0];
-    if (srho[0] > brho) { best[0] = srho[0]; best[1] = (double)gid; best[2] = (double)sslot[0]; brho = srho[0]; }
-    if (last) {
-      mail[0] = best[0]; mail[1] = best[1]; mail[2] = best[2];
+    mail[0] = best[0]; mail[1] = best[1]; mail[2] = best[2]; mail[4] = best[3]; mail[5] = rho_c;
+    if (Qmode >= 0) {
       __threadfence_system();
       __hip_atomic_store(reinterpret_cast<long long*>(mail) + 3, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
+}
+
+__global__ void k_residual_flag(double* mail, long long seq) {
+  __threadfence_system();
+  __hip_atomic_store(reinterpret_cast<long long*>(mail) + 3, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // dst[rd(c)][b] += src[rs(c)][b]  (c < n; null maps = identity) -- the correction of a refinement step
@@ -220,10 +277,11 @@ __global__ __launch_bounds__(256) void k_gather_xc_refine(GroupDev g, const doub
 // Records of the residual rows of one group (api.hip: pp_end_symbolic).  Row c (elimination order) of
 // [K_i | A_i^T]: every canonical lower entry (i, j) of K gives x_j to row i and, off the diagonal, x_i to row j; every
 // border entry (coupling row r, column j) gives xc_r to row j.  A canonical entry is the sum of its raw entries.
-int ppi_build_residual_records(pp_handle h, Group* g, const std::vector<int>& rawmap, const int32_t* rowK, const int32_t* colK,
-                               int nnzK, const int32_t* rowB, const int32_t* colB, int nnzB) {
+int ppi_build_residual_records(pp_handle h, Group* g, const std::vector<int>& rawmap) {
   const pp::Plan& P = g->plan;
   const int n = P.n;
+  const int32_t *rowK = g->pat_rowK.data(), *colK = g->pat_colK.data(), *rowB = g->pat_rowB.data(), *colB = g->pat_colB.data();
+  const int nnzK = (int)g->pat_rowK.size(), nnzB = (int)g->pat_rowB.size();
   std::vector<std::vector<std::array<int, 2>>> rows((size_t)n);      // {canonical entry, x column (new) or -1 - coupling row}
   for (int e = 0; e < nnzK; ++e) {
     const int i = P.iperm[(size_t)rowK[e]], j = P.iperm[(size_t)colK[e]];
@@ -313,31 +371,40 @@ int ppi_residual_value_map(pp_handle h, Group* g, const std::vector<int>& ms, co
 
 extern "C" {
 
-int pp_residual(pp_handle h, int store, const double* bc_dev) {
+int pp_residual(pp_handle h, int store, const double* bc_dev, int coupling_on_device) {
   if (!h || !h->schur_done) return fail(h, 3, "pp_residual before a back-solve");
   PP_HIP(hipSetDevice(h->device));
   const int nc = h->nc;
+  const size_t ncp = (size_t)std::max(nc, 1);
   if (!h->resid_host) {
     void* hp = nullptr;
     void* dp = nullptr;
-    const size_t doubles = 8 + 4 * (size_t)std::max(nc, 1);
+    const size_t doubles = 8 + 4 * ncp;
     PP_HIP(hipHostMalloc(&hp, doubles * sizeof(double), hipHostMallocMapped));
     std::memset(hp, 0, doubles * sizeof(double));
     PP_HIP(hipHostGetDevicePointer(&dp, hp, 0));
     h->resid_host = (volatile double*)hp;
     h->resid_dev = (double*)dp;
     if (int rc = dev_alloc<double>(h, nullptr, &h->resid_best, 4)) return rc;
-    if (int rc = dev_alloc<double>(h, nullptr, &h->resid_ax, 2 * (size_t)std::max(nc, 1))) return rc;
+    if (int rc = dev_alloc<double>(h, nullptr, &h->resid_ax, 2 * ncp)) return rc;
+    if (int rc = dev_alloc<double>(h, nullptr, &h->resid_rc, ncp)) return rc;
   }
+  if (int rc = join_dense(h)) return rc;
+  if (!bc_dev) bc_dev = h->last_rc;
   const hipStream_t st = h->stream;
   const size_t ng = h->groups.size();
   ++h->resid_seq;
-  PP_HIP(hipMemsetAsync(h->resid_ax, 0, 2 * (size_t)std::max(nc, 1) * sizeof(double), st));
+  // coupling rows on the device: a dense S whose sums are complete on this rank (the caller says so); Q as pp_factor_schur got it
+  const int Qmode = (coupling_on_device && !h->btd) ? (h->have_Q ? 1 : 0) : -1;
+  h->resid_rc_valid = false;
+  bool any_mapped = ng == 0;
+  for (Group* g : h->groups) any_mapped = any_mapped || (g->dev.cmapT != nullptr) || g->dev.nc != nc;
+  if (any_mapped) PP_HIP(hipMemsetAsync(h->resid_ax, 0, 2 * ncp * sizeof(double), st));
+  static const int rows_env = pp::env_switch("PP_RES_ROWS") ? std::atoi(pp::env_switch("PP_RES_ROWS")) : 0;
   if (ng == 0) {                 // no local block: x_c and b_c only, an empty (passing) block result
     hipLaunchKernelGGL(k_residual_reduce, dim3(1), dim3(256), 0, st, (unsigned long long*)nullptr, (unsigned long long*)nullptr, 0, -1, 1, 1,
-                       h->resid_best, h->resid_dev, h->resid_seq, nc, (const double*)h->xc, (const double*)h->resid_ax, bc_dev);
-    PP_HIP(hipGetLastError());
-    return 0;
+                       h->resid_best, h->resid_dev, h->resid_seq, nc, 0, 0, (const double*)nullptr, h->resid_ax, (const double*)h->xc, bc_dev,
+                       Qmode, (const double*)h->Qd, store ? h->resid_rc : (double*)nullptr);
   }
   for (size_t gi = 0; gi < ng; ++gi) {
     Group* g = h->groups[gi];
@@ -345,61 +412,73 @@ int pp_residual(pp_handle h, int store, const double* bc_dev) {
     const pp::Plan& P = g->plan;
     const bool native = g->x_native != nullptr && g->rhs_native != nullptr;
     if (!native && (!d.X || !d.rhs)) return fail(h, 3, "pp_residual: no right-hand side / solution of the last back-solve");
-    const double* V;
-    const int* vrow;
-    const double* coef = nullptr;
+    ResArgs a{};
+    a.rptr = g->res_ptr;
+    a.bptr = g->res_bptr;
     if (g->last_fused) {
       if (!g->res_vsrc || !g->src) return fail(h, 3, "pp_residual: no value map / source buffer");
-      V = g->src; vrow = g->res_vsrc; coef = g->res_csrc;
+      a.V = g->src; a.vrow = g->res_vsrc; a.coef = g->res_csrc; a.bvrow = g->res_bvsrc; a.bcoef = g->res_bcsrc;
     } else {
       if (!d.rawT) return fail(h, 3, "pp_residual: the values of the last factorisation are gone");
-      V = d.rawT; vrow = g->res_vraw;
+      a.V = d.rawT; a.vrow = g->res_vraw; a.bvrow = g->res_bvraw;
     }
-    const double *B, *X;
-    const int *xcol, *brow;
-    if (native) { B = g->rhs_native; X = g->x_native; xcol = g->res_xold; brow = d.perm; }
+    if (native) { a.B = g->rhs_native; a.X = g->x_native; a.xcol = g->res_xold; a.brow = d.perm; a.bxcol = g->res_bxold; }
     else {
       // b was consumed by the forward sweep (y is computed in place): transposed into Y again, elimination order
       const int tiles = transpose_tiles(P.n, d.nchunk);
       hipLaunchKernelGGL(k_transpose_in, dim3((unsigned)((P.n + 64 * tiles - 1) / (64 * tiles)) * d.nchunk), dim3(256), 0, st, d.rhs,
                          d.Y, d.iperm, d.batch, P.n, d.bpad, tiles, (const int*)nullptr);
-      B = d.Y; X = d.X; xcol = g->res_xnew; brow = nullptr;
+      a.B = d.Y; a.X = d.X; a.xcol = g->res_xnew; a.brow = nullptr; a.bxcol = g->res_bxnew;
     }
-    double* Rout = nullptr;
     if (store) {
       if (!g->res_R) {
         std::lock_guard<std::mutex> lk(h->alloc_mu);
         if (int rc = value_alloc(h, g, &g->res_R, (size_t)P.n * (size_t)d.bpad)) return rc;
         if (int rc = value_alloc(h, g, &g->res_D, (size_t)P.n * (size_t)d.bpad)) return rc;
       }
-      Rout = g->res_R;               // caller's row order: the correction solve runs on native vectors
+      a.Rout = g->res_R;             // caller's row order: the correction solve runs on native vectors
+      a.rrow = d.perm;
     }
-    const double* xcp = (d.cmapT && d.nc > 0) ? d.XCL : h->xc;
-    const unsigned ntask = (unsigned)((P.n + RES_ROWS - 1) / RES_ROWS);
-    if (h->lane_pairs && d.nchunk % 2 == 0)
-      hipLaunchKernelGGL(k_residual<2>, dim3(ntask * (unsigned)(d.nchunk / 2)), dim3(64), 0, st, d, g->res_ptr, vrow, coef, xcol, brow, V,
-                         B, X, xcp, Rout, d.perm, g->res_rmax, g->res_smax, d.nchunk / 2);
-    else
-      hipLaunchKernelGGL(k_residual<1>, dim3(ntask * (unsigned)d.nchunk), dim3(64), 0, st, d, g->res_ptr, vrow, coef, xcol, brow, V,
-                         B, X, xcp, Rout, d.perm, g->res_rmax, g->res_smax, d.nchunk);
-    if (d.nc > 0) {
-      // sum_i A_i x_i of this group's instances into the handle's coupling vectors
-      const int* bvr = g->last_fused ? g->res_bvsrc : g->res_bvraw;
-      const double* bcf = g->last_fused ? g->res_bcsrc : nullptr;
-      hipLaunchKernelGGL(k_border_ax, dim3((unsigned)d.nc * (unsigned)d.nchunk), dim3(64), 0, st, d, g->res_bptr, bvr, bcf,
-                         native ? g->res_bxold : g->res_bxnew, V, X, g->res_bpart, h->resid_ax, nc);
-      if (!d.cmapT)
-        hipLaunchKernelGGL(k_border_sum, dim3((unsigned)((d.nc + 255) / 256)), dim3(256), 0, st, d, (const double*)g->res_bpart, h->resid_ax, nc);
-    }
+    a.xc = (d.cmapT && d.nc > 0) ? d.XCL : h->xc;
+    a.rmax = g->res_rmax; a.smax = g->res_smax;
+    a.bpart = g->res_bpart; a.ax = h->resid_ax; a.nc_glob = nc;
+    // rows per wave: enough waves to fill the chip several times over, few enough atomics (measured at C3: tools/sweep_env.sh PP_RES_ROWS)
+    a.rows_per_wg = rows_env > 0 ? rows_env : (d.nchunk >= 8 ? 8 : 4);
+    const unsigned ntask = (unsigned)((P.n + a.rows_per_wg - 1) / a.rows_per_wg);
+    const unsigned nborder = (unsigned)d.nc * (unsigned)d.nchunk;
+    const bool pair = h->lane_pairs && d.nchunk % 2 == 0;
+    a.ny = pair ? d.nchunk / 2 : d.nchunk;
+    a.nres_wg = (int)(ntask * (unsigned)a.ny);
+#define PP_LAUNCH_RES(NV, ST) hipLaunchKernelGGL((k_residual<NV, ST>), dim3((unsigned)a.nres_wg + nborder), dim3(64), 0, st, d, a, a.rptr, \
+                                                a.vrow, a.xcol, a.brow, a.coef, a.V, a.B, a.X, a.xc)
+    if (pair) { if (store) PP_LAUNCH_RES(2, true); else PP_LAUNCH_RES(2, false); }
+    else { if (store) PP_LAUNCH_RES(1, true); else PP_LAUNCH_RES(1, false); }
+#undef PP_LAUNCH_RES
+    const bool uniform = !d.cmapT && d.nc == nc && d.nc > 0;
     hipLaunchKernelGGL(k_residual_reduce, dim3(1), dim3(256), 0, st, g->res_rmax, g->res_smax, d.batch, (int)gi, gi == 0 ? 1 : 0,
-                       gi + 1 == ng ? 1 : 0, h->resid_best, h->resid_dev, h->resid_seq, nc, (const double*)h->xc, (const double*)h->resid_ax,
-                       bc_dev);
+                       gi + 1 == ng ? 1 : 0, h->resid_best, h->resid_dev, h->resid_seq, nc, d.nc, d.nchunk,
+                       uniform ? (const double*)g->res_bpart : (const double*)nullptr, h->resid_ax, (const double*)h->xc, bc_dev, Qmode,
+                       (const double*)h->Qd, store ? h->resid_rc : (double*)nullptr);
   }
+  if (Qmode < 0) {
+    // the caller finishes the coupling rows: x_c | sum A x | sum |A||x| | b_c behind the header, then the flag
+    if (nc > 0) {
+      double* mail = const_cast<double*>(h->resid_host);
+      PP_HIP(hipMemcpyAsync(mail + 8, h->xc, (size_t)nc * sizeof(double), hipMemcpyDeviceToHost, st));
+      PP_HIP(hipMemcpyAsync(mail + 8 + nc, h->resid_ax, 2 * (size_t)nc * sizeof(double), hipMemcpyDeviceToHost, st));
+      if (bc_dev) PP_HIP(hipMemcpyAsync(mail + 8 + 3 * (size_t)nc, bc_dev, (size_t)nc * sizeof(double), hipMemcpyDeviceToHost, st));
+      else std::memset(mail + 8 + 3 * (size_t)nc, 0, (size_t)nc * sizeof(double));
+    }
+    hipLaunchKernelGGL(k_residual_flag, dim3(1), dim3(1), 0, st, h->resid_dev, h->resid_seq);
+  } else if (store) {
+    h->resid_rc_valid = true;
+  }
+  h->resid_on_device = Qmode >= 0;
   PP_HIP(hipGetLastError());
   return 0;
 }
 
-int pp_residual_result(pp_handle h, double out[4], double* coupling_out) {
+int pp_residual_result(pp_handle h, double out[6], double* coupling_out) {
   if (!h || !h->resid_host || h->resid_seq == 0) return fail(h, 3, "pp_residual_result before pp_residual");
   PP_HIP(hipSetDevice(h->device));
   const volatile long long* seq = reinterpret_cast<volatile long long*>(h->resid_host) + 3;
@@ -413,10 +492,19 @@ int pp_residual_result(pp_handle h, double out[4], double* coupling_out) {
       }
     }
   }
-  out[0] = h->resid_host[0]; out[1] = h->resid_host[1]; out[2] = h->resid_host[2]; out[3] = 0.0;
-  if (coupling_out)       // x_c | sum A x | sum |A||x| | b_c, n_c doubles each
+  out[0] = h->resid_host[0]; out[1] = h->resid_host[1]; out[2] = h->resid_host[2]; out[3] = h->resid_host[4];
+  out[4] = h->resid_on_device ? h->resid_host[5] : -1.0;      // rho of the coupling rows, or -1: the caller finishes them
+  out[5] = 0.0;
+  if (coupling_out && !h->resid_on_device)       // x_c | sum A x | sum |A||x| | b_c, n_c doubles each
     for (size_t i = 0; i < 4 * (size_t)h->nc; ++i) coupling_out[i] = h->resid_host[8 + i];
   return 0;
+}
+
+// The coupling solve of a correction solve whose right-hand side -- the residual of the coupling rows -- pp_residual(h, 1, ., 1)
+// left on the device.
+int pp_refine_solve_coupling(pp_handle h) {
+  if (!h || !h->refining || !h->resid_rc_valid) return fail(h, 3, "pp_refine_solve_coupling: no residual of the coupling rows on the device");
+  return pp_solve_coupling_dev(h, h->nc > 0 ? h->resid_rc : nullptr);
 }
 
 // Correction solve of a refinement step: between begin and end the sweeps (pp_solve_forward, the caller's all-reduce of

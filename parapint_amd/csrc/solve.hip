@@ -550,6 +550,7 @@ int pp_solve_coupling_dev(pp_handle h, const double* rc_dev) {
   if (!h || !h->schur_done) return fail(h, 3, "pp_solve_coupling_dev before pp_factor_schur");
   PP_HIP(hipSetDevice(h->device));
   if (h->nc == 0) return 0;
+  if (!h->refining) h->last_rc = rc_dev;      // (the a-posteriori check measures the coupling rows against it: refine.hip)
   return h->btd ? ppi_btd_coupling_solve(h, rc_dev) : ppi_dense_coupling_solve(h, rc_dev);      // bcr.hip / dense.hip
 }
 

@@ -59,6 +59,7 @@ class HipEngine(object):
         self._S_t = None
         self._rs_t = None
         self._ip_ops = None
+        self._resid_cpl = None
 
     supports_block_tridiagonal = True
 
@@ -553,6 +554,36 @@ class HipEngine(object):
         self.ns.check(self.lib.pp_get_coupling_solution(self.ns.h, xc.ctypes.data_as(type(p))),
                       'pp_get_coupling_solution')
         return xc[:self.nc]
+
+    def residual(self, store=False, bc=None, on_device=False):
+        """The a-posteriori check of the last back-solve (include/parapint_hip.h: pp_residual): (rho of the worst local
+        instance, its group, its slot, largest row scale of the local blocks, rho of the coupling rows or None, x_c,
+        sum_i A_i x_i, sum_i |A_i||x_i|, b_c) -- the four coupling vectors (library order) only when the caller has to finish
+        the coupling rows itself (rho None: several ranks, block-tridiagonal S); bc: the coupling right-hand side as a device
+        tensor, or None (the one of the last coupling solve).  on_device: the sums of the coupling rows are complete on this
+        rank.  Waits for the result."""
+        nc = self.nc
+        self.ns.check(self.lib.pp_residual(self.ns.h, 1 if store else 0, bc.data_ptr() if bc is not None else None,
+                                           1 if on_device else 0), 'pp_residual')
+        out = np.zeros(6)
+        cpl = self._resid_cpl
+        if cpl is None or cpl.size != 4 * max(nc, 1):
+            cpl = self._resid_cpl = np.zeros(4 * max(nc, 1))
+        self.ns.check(self.lib.pp_residual_result(self.ns.h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), cpl.ctypes.data),
+                      'pp_residual_result')
+        if out[4] >= 0.0 or out[4] != out[4]:
+            return float(out[0]), int(out[1]), int(out[2]), float(out[3]), float(out[4]), None, None, None, None
+        return (float(out[0]), int(out[1]), int(out[2]), float(out[3]), None, cpl[:nc].copy(), cpl[nc:2 * nc].copy(),
+                cpl[2 * nc:3 * nc].copy(), cpl[3 * nc:4 * nc].copy())
+
+    def refine_solve_coupling(self):
+        self.ns.check(self.lib.pp_refine_solve_coupling(self.ns.h), 'pp_refine_solve_coupling')
+
+    def refine_begin(self):
+        self.ns.check(self.lib.pp_refine_begin(self.ns.h), 'pp_refine_begin')
+
+    def refine_end(self):
+        self.ns.check(self.lib.pp_refine_end(self.ns.h), 'pp_refine_end')
 
     def synchronize(self):
         self.ns.check(self.lib.pp_synchronize(self.ns.h), 'pp_synchronize')

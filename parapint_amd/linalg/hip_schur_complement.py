@@ -1174,6 +1174,7 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, SolutionCheckMixin, Coupl
             raise RuntimeError('Perform numeric factorization first!')
         if _repairs is None:
             _repairs = self.max_solve_repairs
+            self._repairs_this_solve = 0
         if hasattr(rhs, 'group_tensors'):
             return self._device_back_solve(rhs, timer, _repairs)
         timer.start('back_solve')
@@ -1219,7 +1220,7 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, SolutionCheckMixin, Coupl
         self._eng.solve_backward()
         if self._checking():
             # (solution_check.py: residual of every local block on the device, refinement, a new pivot sequence if need be)
-            bad = self._verify_solution()
+            bad = self._verify_solution(bc_host=rc)
             if bad is not None:
                 if _repairs > 0 and self._repair_after_inaccurate_solve(bad):
                     timer.stop('solve')
@@ -1345,7 +1346,7 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, SolutionCheckMixin, Coupl
         self._eng.solve_coupling_dev(rc_dev)
         self._eng.solve_backward()
         if self._checking():
-            bad = self._verify_solution()
+            bad = self._verify_solution(bc_dev=rc_dev)
             if bad is not None:
                 if _repairs > 0 and self._repair_after_inaccurate_solve(bad):
                     timer.stop('back_solve')

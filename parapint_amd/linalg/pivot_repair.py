@@ -16,12 +16,14 @@ class PivotRepairMixin(object):
             if self.refresh_backoff:
                 g.refresh_skip = 0 if cured else min(2 ** g.refresh_futile - 1, 63)
 
-    def _refresh_pivot_order(self, shift=None, forced=None):
+    def _refresh_pivot_order(self, shift=None, forced=None, u_min=0.0):
         """New pivot sequences for the groups that hold a broken block, from that block's values (with `shift` =
         (delta_w, delta_c): + the diagonal shift of the classed rows, as the regularised matrix of the host path has
         them).  forced: {group id: slot} -- instances whose back-solve turned out inaccurate (solution_check.py): their groups
         are planned again from them whatever the factorisation reported.  Collective: every rank learns whether any rank
-        re-planned (all of them then factorise again)."""
+        re-planned (all of them then factorise again).  u_min: the static 1x1 / 2x2 choice of the new sequences uses at least
+        this threshold (a repair after an inaccurate solve asks for more 2 x 2 pivots than the sequence that failed)."""
+        stricter = u_min > max(self._u_symbolic_now, 0.01) and hasattr(self._eng, 'set_pivot_tolerance')
         mine = 0
         self._refreshed = []
         for g in self._groups:
@@ -63,7 +65,7 @@ class PivotRepairMixin(object):
                     rows = g.rowK[diag]
                     vals = np.array(vals, dtype=np.double)
                     vals[:nK][diag] += np.where(cls[rows] == 1, shift[0], np.where(cls[rows] == 2, -shift[1], 0.0))
-                if g.futile_vals is not None and g.futile_vals.shape == vals.shape and np.array_equal(g.futile_vals, vals):
+                if not stricter and g.futile_vals is not None and g.futile_vals.shape == vals.shape and np.array_equal(g.futile_vals, vals):
                     # exactly the values the last refresh was planned from, and that plan broke on them as well
                     self.refreshes_skipped += 1
                     continue
@@ -74,6 +76,10 @@ class PivotRepairMixin(object):
         anyone = mine
         if self.comm.size > 1:
             anyone = int(self.comm.allreduce_max(np.array([mine], dtype=np.int64))[0])
+        if stricter and anyone:
+            # (all ranks plan with the same threshold from now on: the decision above is collective)
+            self._u_symbolic_now = u_min
+            self._eng.set_pivot_tolerance(u_min, self._u_user[1])
         if mine:
             steps = self.refresh_thresholds
             if steps and hasattr(self._eng, 'set_pivot_tolerance'):

@@ -169,6 +169,7 @@ class HostSimEngine(object):
 
     def factor_schur(self, Q):
         self.Sfull = self.S + (0.0 if Q is None else Q)
+        self.Q = None if Q is None else np.array(Q, dtype=np.double)
         n = self.nc
         self.A = np.asfortranarray(np.tril(self.Sfull)).copy(order='F')
         self.ipiv = np.zeros(max(n, 1), dtype=np.int32)
@@ -246,7 +247,9 @@ class HostSimEngine(object):
         if comm.size > 1:
             self.rs = comm.allreduce_sum(self.rs)
 
-    def solve_coupling(self, rc):
+    def solve_coupling(self, rc, _refining=False):
+        if not _refining and getattr(self, '_refine_saved', None) is None:
+            self._last_rc = np.zeros(self.nc) if rc is None else np.array(np.asarray(rc, dtype=np.double)[:self.nc], copy=True)
         b = self.rs + (0.0 if rc is None else np.asarray(rc, dtype=np.double))
         b = np.ascontiguousarray(b, dtype=np.double)
         if self.nc > 0:
@@ -269,16 +272,19 @@ class HostSimEngine(object):
         out[...] = self.groups[gid].x
 
     # ---- a-posteriori check and refinement (csrc/refine.hip: pp_residual, pp_refine_begin / _end) ---------------------
-    def residual(self, store=False):
+    def residual(self, store=False, bc_rhs=None, on_device=False):
         """(rho, group, slot) of the worst local instance: rho = max |b - K x - A^T x_c| / max (|K||x| + |A^T x_c| + |b|)
-        over the rows of a block, from the canonical values of the last factorisation."""
+        over the rows of a block, from the canonical values of the last factorisation; then x_c, sum_i A_i x_i,
+        sum_i |A_i||x_i| (library order of the coupling variables) and bc handed back."""
         worst = (0.0, -1, -1)
+        scale = 0.0
+        ax, aabs = np.zeros(self.nc), np.zeros(self.nc)
         for gid, sg in enumerate(self.groups):
             g = sg.g
             nK = g.rowK.size
             i, j = np.asarray(g.rowK, dtype=np.int64), np.asarray(g.colK, dtype=np.int64)
             off = i != j
-            br, bc = np.asarray(g.rowB, dtype=np.int64), np.asarray(g.colB, dtype=np.int64)
+            br, bc = np.asarray(g.rowB, dtype=np.int64), np.asarray(g.colB, dtype=np.int64)      # (bc here: border columns)
             if store:
                 sg.R = np.zeros((sg.batch, g.n))
             for b in range(sg.batch):
@@ -296,14 +302,36 @@ class HostSimEngine(object):
                     t = can[nK:] * xc[br]
                     np.subtract.at(r, bc, t)
                     np.add.at(s, bc, np.abs(t))
+                    t = can[nK:] * x[bc]
+                    glob = br if sg.cmaps is None else np.asarray(sg.cmaps[b], dtype=np.int64)[br]
+                    np.add.at(ax, glob, t)
+                    np.add.at(aabs, glob, np.abs(t))
                 if store:
                     sg.R[b] = r
                 rm = np.abs(r).max() if r.size else 0.0
                 sm = s.max() if s.size else 0.0
+                scale = max(scale, float(sm))
                 rho = 0.0 if rm == 0.0 else (rm / sm if sm > 0.0 and np.isfinite(rm) else np.inf)
                 if rho > worst[0] or worst[1] < 0:
                     worst = (float(rho), gid, b)
-        return worst
+        bcv = np.array(self._last_rc, dtype=np.double) if bc_rhs is None else np.array(np.asarray(bc_rhs)[:self.nc], dtype=np.double)
+        if on_device and self.nc > 0:
+            # (as the library with coupling_on_device: the coupling rows judged here, their residual kept for the correction)
+            Q = np.zeros((self.nc, self.nc)) if self.Q is None else self.Q
+            rc = bcv - ax - Q.dot(self.xc)
+            sc = np.abs(bcv) + aabs + np.abs(Q).dot(np.abs(self.xc))
+            rmax = np.abs(rc).max()
+            den = max(float(sc.max()), scale)
+            rho_c = 0.0 if rmax == 0.0 else (rmax / den if den > 0.0 and np.isfinite(rmax) else np.inf)
+            if store:
+                self._resid_rc = rc
+            return worst + (scale, float(rho_c), None, None, None, None)
+        if on_device:
+            return worst + (scale, 0.0, None, None, None, None)
+        return worst + (scale, None, self.xc.copy(), ax, aabs, bcv)
+
+    def refine_solve_coupling(self):
+        self.solve_coupling(self._resid_rc, _refining=True)
 
     def refine_begin(self):
         self._refine_saved = (self.xc.copy(), [(sg.rhs, sg.x.copy(), getattr(sg, 'rhs_native', None), getattr(sg, 'x_native', None))

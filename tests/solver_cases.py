@@ -1281,3 +1281,24 @@ def case_mixed_scale_block_pivot(make_engine):
     solver.do_symbolic_factorization(K)
     res = solver.do_numeric_factorization(K, raise_on_error=False)
     assert res.status == LinearSolverStatus.singular or solver.get_inertia()[2] == 0    # (a 2x2 pivot may have been chosen)
+
+
+def case_adversarial_systems(make_engine, seeds=range(0, 400)):
+    """tools/fuzz_solver.py --hard through the solver class: zero Hessian entries (2 x 2 pivots) and Jacobian entries scaled
+    by up to 1e-7 per instance and iteration -- the adversary of ONE static pivot sequence per pattern group.  Every solution
+    the class hands out must have a scaled residual <= 2e-8 against dense algebra (its a-posteriori check, refinement and
+    pivot repair: parapint_amd/linalg/solution_check.py; the reference's sub-solvers pivot per block,
+    ma27_interface.py:36-47, scipy_interface.py:26-31); it may refuse (RuntimeError) only numerically singular systems.  The
+    slice must exercise the machinery: some solves refined, some sequences repaired."""
+    import os
+    import sys
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools')
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    import fuzz_solver
+    stats = {}
+    bad = [r for r in (fuzz_solver.one(seed, hard=True, engine=make_engine, stats=stats) for seed in seeds) if r is not None]
+    assert not bad, bad
+    assert stats['solves_refined'] >= 3 and stats['refinement_steps'] >= stats['solves_refined'], stats
+    assert stats['inaccurate_solves'] <= 2, stats
+    return stats

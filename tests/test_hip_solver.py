@@ -657,6 +657,13 @@ def test_pivot_growth_guard():
     sc.case_growth_guard(make_engine)
 
 
+def test_adversarial_systems_are_never_returned_inaccurate_on_the_device():
+    """>= 400 adversarial systems x 6 factorisations through the C ABI: k_residual / the refinement bracket / the repair path
+    of the product (csrc/refine.hip), every handed-out solution against dense algebra."""
+    stats = sc.case_adversarial_systems(make_engine, seeds=range(0, 400))
+    print('adversarial systems on the device:', stats)
+
+
 def test_device_vector_kernels_f4():
     """the fused step-statistics kernel, max-norm and step update on device vectors against the restated
     reference formulas (interior_point.py:655-758 fraction_to_the_boundary, :257-266 bound residuals, :619-626)."""

@@ -160,5 +160,10 @@ def test_random_systems_in_random_input_forms():
     assert not bad, bad
 
 
+def test_adversarial_systems_are_never_returned_inaccurate():
+    from hostsim_engine import HostSimBoundaryEngine
+    sc.case_adversarial_systems(HostSimBoundaryEngine)
+
+
 def test_zero_pivot_test_inside_a_mixed_scale_block_pivot():
     sc.case_mixed_scale_block_pivot(HostSimEngine)
