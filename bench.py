@@ -63,6 +63,8 @@ def parse_args():
     ap.add_argument('--no-boundary', action='store_true')
     ap.add_argument('--no-ip-loop', action='store_true')
     ap.add_argument('--no-ip-loop-dynamic', action='store_true')
+    ap.add_argument('--no-shares', action='store_true',
+                    help='skip the one-rank shares of an 8-GPU run (C3: 128 blocks, C5: 512 blocks) the default line reports')
     ap.add_argument('--ip-loop-dynamic-all-ranks', action='store_true',
                     help='run the time-staged loop with more than one rank too (default: one rank only -- an auxiliary '
                          'measurement must not be able to stall the headline line of a multi-rank run)')
@@ -251,6 +253,11 @@ def main():
     rehearsal = os.environ.get('PP_BENCH_REHEARSAL', '')
     if rehearsal:
         local_rank = local_rank % max(1, torch.cuda.device_count())
+    elif world > torch.cuda.device_count():
+        # (one process per GPU over RCCL: two ranks on one device cannot form a communicator -- say so instead of failing
+        # inside ncclCommInitRank; PP_BENCH_REHEARSAL=gloo shares the devices that are there over gloo)
+        sys.exit('bench.py --gpus %d: only %d HIP device(s) visible (one rank per GPU; PP_BENCH_REHEARSAL=gloo rehearses '
+                 'several ranks on fewer devices over gloo)' % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     backend = 'none'
     if world > 1:
@@ -410,6 +417,33 @@ def main():
         value_no_prefetch, ms_no_prefetch = args.steps / el_np, 1e3 * el_np / args.steps
         res, xd = step(args.warmup + args.steps - 1)          # (the checked step below is the announced form again)
         sync_all()
+    # the same K announced steps WITHOUT the a-posteriori check of the back-solves (solver.residual_check = False: what
+    # rounds 1-5 timed as `value`): the price of never handing out an unchecked solution is value_unchecked - value
+    solver.residual_check = False
+    for k in range(min(3, args.warmup)):
+        step(k)
+    sync_all()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+    sync_all()
+    el_un = time.perf_counter() - t0
+    if world > 1:
+        el_un = float(comm.allreduce_max(np.array([el_un]))[0])
+    solver.residual_check = True
+    res, xd = step(args.warmup + args.steps - 1)              # (the checked step below is a checked one again)
+    sync_all()
+    solution_check = {'on': True, 'value_unchecked': args.steps / el_un, 'ms_per_step_unchecked': 1e3 * el_un / args.steps,
+                      'cost_ms_per_step': ms_per_step - 1e3 * el_un / args.steps,
+                      'backward_error_last_step': solver.last_residual, 'refine_tolerance': solver.refine_tolerance,
+                      'residual_tolerance': solver.residual_tolerance, 'solves_refined': solver.solves_refined,
+                      'refinement_steps': solver.refinement_steps, 'solve_repairs': solver.solve_repairs,
+                      'collectives_per_step': 3 if world > 1 else 0,        # [S | status], r_s, the agreement of this check
+                      'check_collective': (None if world == 1 else 'library RCCL all-reduce on the solver stream'
+                                           if (solver._btd is None and eng._direct_rccl(comm)) else 'host all-reduce through the communicator'),
+                      'note': 'every do_back_solve ends with the residual of all block rows and of the coupling rows on the '
+                              'device (csrc/refine.hip) and one host read; refinement / a new pivot sequence follow only above '
+                              'the tolerances (parapint_amd/linalg/solution_check.py)'}
     mem_max, _, mem_now = eng.memory_info()        # value storage: what the plan needs at most / what this path allocated
 
     # correctness of the last timed step: download and check against the assembled system
@@ -759,6 +793,24 @@ def main():
         except Exception as exc:
             ip_loop_burgers = {'converged': False, 'error': '%s: %s' % (type(exc).__name__, exc)}
 
+    # ---- what ONE rank of an 8-GPU run holds (strong scaling of the two sharded configurations): 128 blocks of C3, 512 of C5,
+    # as separate one-GPU runs of this script -- the small-share regime is latency-bound and a target of its own
+    shares = None
+    if rank == 0 and world == 1 and args.workload == 'C3' and not args.blocks and not args.no_shares and not args.no_ip_loop:
+        import subprocess
+        shares = {}
+        for key, extra in (('C3_128_blocks', ['--blocks', '128']),
+                           ('C5_512_blocks', ['--workload', 'C5', '--blocks', '512', '--value-sets', '2', '--steps', '10', '--warmup', '2'])):
+            try:
+                cp = subprocess.run([sys.executable, os.path.abspath(__file__), '--no-cpu-baseline', '--no-boundary', '--no-ip-loop',
+                                     '--no-shares'] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+                d = json.loads(cp.stdout.decode().strip().splitlines()[-1])
+                shares[key] = {'ms_per_step': d['ms_per_step'], 'ms_per_step_no_prefetch': d['ms_per_step_no_prefetch'],
+                               'ms_per_step_unchecked': d['solution_check']['ms_per_step_unchecked'], 'correct': d['correct'],
+                               'phases_ms': {k: v['ms_per_step'] for k, v in d['phases'].items()},
+                               'kernel_launches_per_step': d['kernel_launches_per_step']}
+            except Exception as exc:
+                shares[key] = {'error': '%s: %s' % (type(exc).__name__, exc)}
     if rank == 0:
         launches = sum(p['launches_per_step'] for p in phases.values()) if phases else None
         out = {
@@ -776,6 +828,8 @@ def main():
             # announced (solver.prefetch_forward) before the factorisation; `value_no_prefetch`: the same K steps in the
             # reference's plain call order (interior_point.py:553-566), what an unaware caller sees
             'value_no_prefetch': value_no_prefetch, 'ms_per_step_no_prefetch': ms_no_prefetch,
+            'value_unchecked': solution_check['value_unchecked'], 'solution_check': solution_check,
+            'shares': shares,
             'rccl_ranks': rccl_ranks,      # > 0: the all-reduces were enqueued by the library (the default for >= 2 RCCL ranks)
             'collective_us': collective_us,             # per rank: the two data-path all-reduces by themselves (HIP events)
             # SURVEY 8(d) to the letter: the same step through HOST containers (SciPy COO blocks in, host vectors out;

@@ -236,10 +236,13 @@ int pp_get_coupling_solution(pp_handle h, double* xc_host);
  *                       right-hand side of a correction solve.  bc_dev: the coupling right-hand side of the back-solve on
  *                       the device (n_c doubles) or NULL.  coupling_on_device != 0 (one rank, dense S): the coupling rows
  *                       b_c - sum A x - Q x_c (Q as the last pp_factor_schur got it) are judged on the device as well, and
- *                       with store their residual stays there for pp_refine_solve_coupling.  Stream-ordered; publishes to
- *                       a pinned mailbox.
+ *                       with store their residual stays there for pp_refine_solve_coupling.  coupling_on_device == 2:
+ *                       several ranks with the library's communicator (pp_comm_init) -- the sums of the coupling rows and one
+ *                       slot per rank for its block result meet in ONE all-reduce on the handle's stream, every rank
+ *                       finishes identically (collective).  Stream-ordered; publishes to a pinned mailbox.
  *   pp_residual_result  waits for it: out = {worst rho of the local instances, its group, its slot, the largest row scale
- *                       |K||x| + |A^T x_c| + |b| of the local blocks, rho of the coupling rows or -1, 0}; -1: coupling_out
+ *                       |K||x| + |A^T x_c| + |b| of the blocks, rho of the coupling rows or -1, worst rho of the instances of
+ *                       ALL ranks (coupling_on_device == 2; else out[0])}; -1: coupling_out
  *                       (4 n_c doubles) receives x_c | sum A x | sum |A||x| | b_c -- the caller adds Q x_c and, with several
  *                       ranks, all-reduces the two sums before it judges the coupling rows.
  *   pp_refine_begin / pp_refine_end   bracket a correction solve: between them pp_solve_forward, the all-reduce of r_s,

@@ -1605,6 +1605,7 @@ int pp_comm_init(pp_handle h, int nranks, int rank, const uint8_t id[128]) {
   if (rc != 0) return fail(h, 3, rccl_msg("ncclCommInitRank", rc));
   h->rccl_comm = comm;
   h->rccl_ranks = nranks;
+  h->rccl_rank = rank;
   return 0;
 }
 
@@ -1645,6 +1646,16 @@ int pp_allreduce_rs(pp_handle h) {
   if (int rc = order_behind_side_collective(h)) return rc;
   const int rc = g_rccl.allreduce(h->rs, h->rs, (size_t)h->nc, 8, 0, h->rccl_comm, h->stream);
   if (rc != 0) return fail(h, 3, rccl_msg("ncclAllReduce(r_s)", rc));
+  return 0;
+}
+
+// (refine.hip: the sums of the coupling rows and one slot per rank of the a-posteriori check, in place, on the handle's stream)
+int ppi_allreduce_sum(pp_handle h, double* buf, size_t count) {
+  if (!h || !h->rccl_comm) return fail(h, 3, "ppi_allreduce_sum: no communicator (pp_comm_init)");
+  if (count == 0) return 0;
+  if (int rc = order_behind_side_collective(h)) return rc;
+  const int rc = g_rccl.allreduce(buf, buf, count, 8, 0, h->rccl_comm, h->stream);
+  if (rc != 0) return fail(h, 3, rccl_msg("ncclAllReduce(check)", rc));
   return 0;
 }
 

@@ -447,7 +447,7 @@ struct pp_solver {
   const double* last_rc = nullptr;   // coupling right-hand side (device) of the last pp_solve_coupling(_dev), or null
   bool have_Q = false;           // the last dense factorisation of S had a coupling block Q (resident in Qd)
   void* rccl_comm = nullptr;     // ncclComm_t of pp_comm_init (api.hip), or null
-  int rccl_ranks = 0;
+  int rccl_ranks = 0, rccl_rank = 0;
   // Instance groups ("splits"): the level sweeps of disjoint 64-instance chunk ranges are
   // independent and can be issued on separate streams.  Measured (C3, 1 GPU, 4 splits): the 4x
   // launches serialise instead of overlapping (254 vs 379 it/s), so the default is one split.
@@ -472,6 +472,7 @@ int ppi_dense_factor_schur(pp_handle h, const double* Q_host);                  
 int ppi_dense_coupling_solve(pp_handle h, const double* rc_dev);                     // dense.hip
 int ppi_btd_factor_schur(pp_handle h, const double* Q_host, long long corner_nnz);   // bcr.hip
 int ppi_btd_coupling_solve(pp_handle h, const double* rc_dev);                       // bcr.hip
+extern "C" int ppi_allreduce_sum(pp_handle h, double* buf, size_t count);            // api.hip (RCCL on the handle's stream)
 int ppi_build_residual_records(pp_handle h, ppd::Group* g, const std::vector<int>& rawmap);                          // refine.hip
 int ppi_residual_value_map(pp_handle h, ppd::Group* g, const std::vector<int>& ms, const std::vector<double>& mc);   // refine.hip
 

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void k_residual_reduce(unsigned long long* __r
     bscale = best[3];
   }
   __syncthreads();
-  if (!last) return;
+  if (!last || Qmode == -2) return;
   double rho_c = 0.0;
   if (Qmode >= 0 && nc > 0) {
     double rmx = 0.0, smx = 0.0;
@@ -238,11 +238,67 @@ __global__ __launch_bounds__(256) void k_residual_reduce(unsigned long long* __r
     rho_c = (srho[0] == 0.0) ? 0.0 : ((den > 0.0 && srho[0] < INFINITY) ? srho[0] / den : INFINITY);
   }
   if (threadIdx.x == 0) {
-    mail[0] = best[0]; mail[1] = best[1]; mail[2] = best[2]; mail[4] = best[3]; mail[5] = rho_c;
+    mail[0] = best[0]; mail[1] = best[1]; mail[2] = best[2]; mail[4] = best[3]; mail[5] = rho_c; mail[6] = best[0];
     if (Qmode >= 0) {
       __threadfence_system();
       __hip_atomic_store(reinterpret_cast<long long*>(mail) + 3, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+  }
+}
+
+// Several ranks, the library's communicator: this rank's block result into its slot pair behind the coupling sums (the
+// other slots zero), so that ONE sum all-reduce carries the sums of the coupling rows and every rank's block result ...
+__global__ __launch_bounds__(64) void k_residual_slots(const double* __restrict__ best, double* __restrict__ ax, int nc, int nranks, int rank) {
+  for (int r = threadIdx.x; r < nranks; r += 64) {
+    ax[2 * (size_t)nc + 2 * r] = (r == rank) ? fmin(best[0], 1e300) : 0.0;
+    ax[2 * (size_t)nc + 2 * r + 1] = (r == rank) ? fmin(best[3], 1e300) : 0.0;
+  }
+}
+
+// ... and every rank finishes identically from the all-reduced buffer: the worst block of any rank, the coupling rows
+// r_c = b_c - sum A x - Q x_c against max(their row scales, the largest block row scale of any rank).
+__global__ __launch_bounds__(256) void k_residual_finish(const double* __restrict__ best, double* mail, long long seq, int nc, int nranks,
+                                                         const double* __restrict__ ax, const double* __restrict__ xc,
+                                                         const double* __restrict__ bc, int Qmode, const double* __restrict__ Q,
+                                                         double* __restrict__ rc_out) {
+  __shared__ double sr[256], ss[256];
+  double rall = 0.0, sall = 0.0;
+  for (int r = threadIdx.x; r < nranks; r += 256) { rall = fmax(rall, ax[2 * (size_t)nc + 2 * r]); sall = fmax(sall, ax[2 * (size_t)nc + 2 * r + 1]); }
+  double rmx = 0.0, smx = 0.0;
+  for (int c = threadIdx.x; c < nc; c += 256) {
+    const double bcv = bc ? bc[c] : 0.0;
+    double r = bcv - ax[c], s = fabs(bcv) + ax[nc + c];
+    if (Qmode == 1) {
+      for (int k = 0; k < nc; ++k) {
+        const double q = (c >= k) ? Q[(size_t)c + (size_t)k * nc] : Q[(size_t)k + (size_t)c * nc];
+        r -= q * xc[k];
+        s += fabs(q) * fabs(xc[k]);
+      }
+    }
+    if (rc_out) rc_out[c] = r;
+    rmx = fmax(rmx, (r == r) ? fabs(r) : INFINITY);
+    smx = fmax(smx, s);
+  }
+  sr[threadIdx.x] = rall; ss[threadIdx.x] = sall;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) { sr[threadIdx.x] = fmax(sr[threadIdx.x], sr[threadIdx.x + off]); ss[threadIdx.x] = fmax(ss[threadIdx.x], ss[threadIdx.x + off]); }
+    __syncthreads();
+  }
+  const double rho_all = sr[0], scale_all = ss[0];
+  __syncthreads();
+  sr[threadIdx.x] = rmx; ss[threadIdx.x] = smx;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) { sr[threadIdx.x] = fmax(sr[threadIdx.x], sr[threadIdx.x + off]); ss[threadIdx.x] = fmax(ss[threadIdx.x], ss[threadIdx.x + off]); }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double den = fmax(ss[0], scale_all);
+    const double rho_c = (sr[0] == 0.0) ? 0.0 : ((den > 0.0 && sr[0] < INFINITY) ? sr[0] / den : INFINITY);
+    mail[0] = best[0]; mail[1] = best[1]; mail[2] = best[2]; mail[4] = scale_all; mail[5] = rho_c; mail[6] = rho_all;
+    __threadfence_system();
+    __hip_atomic_store(reinterpret_cast<long long*>(mail) + 3, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -386,7 +442,7 @@ int pp_residual(pp_handle h, int store, const double* bc_dev, int coupling_on_de
     h->resid_host = (volatile double*)hp;
     h->resid_dev = (double*)dp;
     if (int rc = dev_alloc<double>(h, nullptr, &h->resid_best, 4)) return rc;
-    if (int rc = dev_alloc<double>(h, nullptr, &h->resid_ax, 2 * ncp)) return rc;
+    if (int rc = dev_alloc<double>(h, nullptr, &h->resid_ax, 2 * ncp + 2 * 1024)) return rc;      // (+ a slot pair per rank)
     if (int rc = dev_alloc<double>(h, nullptr, &h->resid_rc, ncp)) return rc;
   }
   if (int rc = join_dense(h)) return rc;
@@ -395,7 +451,11 @@ int pp_residual(pp_handle h, int store, const double* bc_dev, int coupling_on_de
   const size_t ng = h->groups.size();
   ++h->resid_seq;
   // coupling rows on the device: a dense S whose sums are complete on this rank (the caller says so); Q as pp_factor_schur got it
-  const int Qmode = (coupling_on_device && !h->btd) ? (h->have_Q ? 1 : 0) : -1;
+  // coupling_on_device == 2: several ranks whose sums meet through the library's communicator (one all-reduce, below)
+  const bool ranks = coupling_on_device == 2 && !h->btd && h->rccl_comm && h->rccl_ranks >= 1 && h->rccl_ranks <= 1024;
+  if (coupling_on_device == 2 && !ranks) return fail(h, 3, "pp_residual: no communicator for the check across ranks (pp_comm_init), or a block-tridiagonal S");
+  const int Qfin = (coupling_on_device && !h->btd) ? (h->have_Q ? 1 : 0) : -1;
+  const int Qmode = ranks ? -2 : Qfin;
   h->resid_rc_valid = false;
   bool any_mapped = ng == 0;
   for (Group* g : h->groups) any_mapped = any_mapped || (g->dev.cmapT != nullptr) || g->dev.nc != nc;
@@ -460,7 +520,14 @@ int pp_residual(pp_handle h, int store, const double* bc_dev, int coupling_on_de
                        uniform ? (const double*)g->res_bpart : (const double*)nullptr, h->resid_ax, (const double*)h->xc, bc_dev, Qmode,
                        (const double*)h->Qd, store ? h->resid_rc : (double*)nullptr);
   }
-  if (Qmode < 0) {
+  if (ranks) {
+    if (ng == 0) PP_HIP(hipMemsetAsync(h->resid_best, 0, 4 * sizeof(double), st));
+    hipLaunchKernelGGL(k_residual_slots, dim3(1), dim3(64), 0, st, (const double*)h->resid_best, h->resid_ax, nc, h->rccl_ranks, h->rccl_rank);
+    if (int rc = ppi_allreduce_sum(h, h->resid_ax, 2 * (size_t)nc + 2 * (size_t)h->rccl_ranks)) return rc;
+    hipLaunchKernelGGL(k_residual_finish, dim3(1), dim3(256), 0, st, (const double*)h->resid_best, h->resid_dev, h->resid_seq, nc, h->rccl_ranks,
+                       (const double*)h->resid_ax, (const double*)h->xc, bc_dev, Qfin, (const double*)h->Qd, store ? h->resid_rc : (double*)nullptr);
+    if (store) h->resid_rc_valid = true;
+  } else if (Qmode < 0) {
     // the caller finishes the coupling rows: x_c | sum A x | sum |A||x| | b_c behind the header, then the flag
     if (nc > 0) {
       double* mail = const_cast<double*>(h->resid_host);
@@ -473,7 +540,7 @@ int pp_residual(pp_handle h, int store, const double* bc_dev, int coupling_on_de
   } else if (store) {
     h->resid_rc_valid = true;
   }
-  h->resid_on_device = Qmode >= 0;
+  h->resid_on_device = Qmode >= 0 || ranks;
   PP_HIP(hipGetLastError());
   return 0;
 }
@@ -494,7 +561,7 @@ int pp_residual_result(pp_handle h, double out[6], double* coupling_out) {
   }
   out[0] = h->resid_host[0]; out[1] = h->resid_host[1]; out[2] = h->resid_host[2]; out[3] = h->resid_host[4];
   out[4] = h->resid_on_device ? h->resid_host[5] : -1.0;      // rho of the coupling rows, or -1: the caller finishes them
-  out[5] = 0.0;
+  out[5] = h->resid_on_device ? h->resid_host[6] : h->resid_host[0];      // worst block of ANY rank (coupling_on_device == 2), else this rank's
   if (coupling_out && !h->resid_on_device)       // x_c | sum A x | sum |A||x| | b_c, n_c doubles each
     for (size_t i = 0; i < 4 * (size_t)h->nc; ++i) coupling_out[i] = h->resid_host[8 + i];
   return 0;

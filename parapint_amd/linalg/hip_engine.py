@@ -403,20 +403,24 @@ class HipEngine(object):
             import ctypes
             torch = self._torch
             uid = np.zeros(128, dtype=np.uint8)
-            ok = 1
-            if comm.rank == 0:
-                if self.lib.pp_comm_unique_id(uid.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))) != 0:
-                    if want is True or env == '1':
-                        raise RuntimeError('pp_comm_unique_id failed (librccl not available)')
-                    ok = 0
-            # (rank 0 tells the others whether it has an id: all ranks take the same path)
+            # EVERY rank first finds out whether it can open librccl at all (an id of its own, thrown away) and the ranks
+            # agree on that through the torch group: ncclCommInitRank is collective -- a rank that cannot call it would
+            # leave the others waiting inside it, where no later flag can reach them
+            ok = 1 if self.lib.pp_comm_unique_id(uid.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))) == 0 else 0
+            if comm.size > 1:
+                can = torch.tensor([ok], dtype=torch.int32, device='cuda')
+                comm._dist.all_reduce(can, op=comm._dist.ReduceOp.MIN, group=comm._group)
+                ok = int(can.item())
+            if not ok:
+                if want is True or env == '1':
+                    raise RuntimeError('pp_comm_unique_id failed on some rank (librccl not available)')
+                self._rccl_unavailable = True
+                return False
+            # (rank 0's id is the communicator's)
             t = torch.from_numpy(np.concatenate([uid, np.array([ok], dtype=np.uint8)])).cuda()
             if comm.size > 1:
                 comm._dist.broadcast(t, src=0, group=comm._group)
             got = t.cpu().numpy()
-            if got[128] == 0:
-                self._rccl_unavailable = True
-                return False
             uid = np.ascontiguousarray(got[:128])
             ok = 1
             try:
@@ -560,11 +564,12 @@ class HipEngine(object):
         instance, its group, its slot, largest row scale of the local blocks, rho of the coupling rows or None, x_c,
         sum_i A_i x_i, sum_i |A_i||x_i|, b_c) -- the four coupling vectors (library order) only when the caller has to finish
         the coupling rows itself (rho None: several ranks, block-tridiagonal S); bc: the coupling right-hand side as a device
-        tensor, or None (the one of the last coupling solve).  on_device: the sums of the coupling rows are complete on this
-        rank.  Waits for the result."""
+        tensor, or None (the one of the last coupling solve).  on_device: 1 -- the sums of the coupling rows are complete on
+        this rank; 2 -- several ranks, the sums and the block results meet in one all-reduce of the library's communicator
+        (collective; the returned rho of the coupling rows then also covers the worst block of any rank).  Waits for the result."""
         nc = self.nc
         self.ns.check(self.lib.pp_residual(self.ns.h, 1 if store else 0, bc.data_ptr() if bc is not None else None,
-                                           1 if on_device else 0), 'pp_residual')
+                                           int(on_device)), 'pp_residual')
         out = np.zeros(6)
         cpl = self._resid_cpl
         if cpl is None or cpl.size != 4 * max(nc, 1):
@@ -572,7 +577,10 @@ class HipEngine(object):
         self.ns.check(self.lib.pp_residual_result(self.ns.h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), cpl.ctypes.data),
                       'pp_residual_result')
         if out[4] >= 0.0 or out[4] != out[4]:
-            return float(out[0]), int(out[1]), int(out[2]), float(out[3]), float(out[4]), None, None, None, None
+            # (rho of the coupling rows AND of the worst block of any rank: max of the two is the verdict, the same on every rank)
+            rho_rows = float(out[4]) if out[4] == out[4] else np.inf
+            rho_all = float(out[5]) if out[5] == out[5] else np.inf
+            return float(out[0]), int(out[1]), int(out[2]), float(out[3]), max(rho_rows, rho_all), None, None, None, None
         return (float(out[0]), int(out[1]), int(out[2]), float(out[3]), None, cpl[:nc].copy(), cpl[nc:2 * nc].copy(),
                 cpl[2 * nc:3 * nc].copy(), cpl[3 * nc:4 * nc].copy())
 

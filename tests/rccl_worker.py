@@ -70,9 +70,34 @@ def main():
     x2 = solver2.do_back_solve(rhs)
     assert solver2._eng.lib.pp_comm_size(solver2._eng.ns.h) == 1
     assert not calls, calls                               # torch.distributed was not asked to reduce anything
+    # ... the a-posteriori check of the back-solve included: the sums of its coupling rows and the per-rank block results
+    # went through ONE all-reduce of the library's communicator (pp_residual with coupling_on_device = 2)
+    assert solver2.last_residual is not None and solver2.last_residual <= 1e-12 and solver2._eng.lib.pp_comm_size(solver2._eng.ns.h) == 1
+    assert solver.last_residual is not None and abs(solver2.last_residual - solver.last_residual) <= 1e-13
     for ndx in range(N + 1):
         assert np.array_equal(np.asarray(x2.get_block(ndx)), np.asarray(x.get_block(ndx)))
     assert solver2.get_inertia() == solver.get_inertia()
+    # librccl that cannot be opened on some rank (here: the id call made to fail) is agreed BEFORE the collective set-up of
+    # the communicator and sends the handle to the torch.distributed collectives -- nobody is left inside ncclCommInitRank
+    solver3 = HipSchurComplementLinearSolver({i: None for i in range(N)}, None, comm=comm)
+    lib3 = solver3._eng.lib
+    real_id = lib3.pp_comm_unique_id
+    lib3.pp_comm_unique_id = lambda *a: 3
+    try:
+        two = type('TwoRanks', (), {})()          # what a two-rank group asks of the engine (its collectives stubbed: one process)
+        two.rank, two.size, two.device_collectives, two.direct_rccl, two._group = 0, 2, True, None, None
+        two._dist = type('D', (), {'all_reduce': staticmethod(lambda *a, **k: None),
+                                   'broadcast': staticmethod(lambda *a, **k: None), 'ReduceOp': dist.ReduceOp})()
+        assert solver3._eng._direct_rccl(two) is False and solver3._eng._rccl_unavailable is True
+    finally:
+        lib3.pp_comm_unique_id = real_id
+    comm.direct_rccl = None
+    assert solver3.do_symbolic_factorization(kkt).status == LinearSolverStatus.successful
+    assert solver3.do_numeric_factorization(kkt).status == LinearSolverStatus.successful
+    x3 = solver3.do_back_solve(rhs)
+    for ndx in range(N + 1):
+        assert np.array_equal(np.asarray(x3.get_block(ndx)), np.asarray(x.get_block(ndx)))
+    comm.direct_rccl = True
     # the interior-point loop with its two all-gathers issued by the library (pp_comm_allgather) on the one-rank group:
     # same iterates as the loop without collectives
     from parapint_amd.algorithms.device_interior_point import ip_solve_device

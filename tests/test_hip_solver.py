@@ -586,6 +586,9 @@ def test_bench_two_ranks_started_by_the_script_itself():
     assert res['residual'] <= 1e-8 and res['inertia'] == res['expected_inertia']
     assert len(res['collective_us']['allreduce_S_and_status']) == 2 and min(res['collective_us']['allreduce_r_s']) > 0.0
     assert res['scaling'] == 'strong'
+    # the collectives of one step: [S | status], r_s, and the agreement of the a-posteriori check (coupling sums + one slot per rank)
+    assert res['solution_check']['on'] is True and res['solution_check']['collectives_per_step'] == 3
+    assert res['solution_check']['backward_error_last_step'] <= 1e-10
     if two:
         # the same with the library's own RCCL calls on the solver's stream (no torch.distributed in the data path), and
         # with every rank holding the workload's full block count
@@ -593,6 +596,18 @@ def test_bench_two_ranks_started_by_the_script_itself():
                          '--no-cpu-baseline', '--no-boundary', '--profile-steps', '1', '--scaling', 'weak')
         assert res['rccl_ranks'] == 2 and res['correct'] is True and res['scaling'] == 'weak'
         assert res['config']['blocks_per_gpu'] == 64 and res['residual'] <= 1e-8
+        assert res['solution_check']['check_collective'] == 'library RCCL all-reduce on the solver stream'
+    else:
+        # one process per GPU: more ranks than devices is refused with a clear message (not inside ncclCommInitRank)
+        import os
+        import subprocess
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = {k: v for k, v in os.environ.items() if k != 'PP_BENCH_REHEARSAL'}
+        out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--workload', 'C2', '--steps', '2',
+                              '--no-cpu-baseline', '--no-boundary', '--no-ip-loop'], env=env, stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, timeout=600)
+        assert out.returncode != 0 and 'HIP device(s) visible' in out.stderr.decode()
 
 
 def test_bench_single_rank_line_has_the_contract_fields():
@@ -600,8 +615,11 @@ def test_bench_single_rank_line_has_the_contract_fields():
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
                 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'boundary_host', 'device_only',
                 'value_no_prefetch', 'ms_per_step_no_prefetch', 'value_boundary_constant_declared',
-                'value_boundary_flat_values'):
+                'value_boundary_flat_values', 'value_unchecked', 'solution_check', 'shares'):
         assert key in res
+    # the timed steps are CHECKED steps (every back-solve ends with the residual on the device); the unchecked rate beside it
+    assert res['solution_check']['on'] is True and res['solution_check']['backward_error_last_step'] <= 1e-10
+    assert res['value_unchecked'] > 0.9 * res['value']
     assert res['value_no_prefetch'] > 0 and res['value_boundary_constant_declared'] > 0
     assert res['boundary_host_constant_declared']['residual'] <= 1e-8
     assert res['boundary_host_flat_values']['residual'] <= 1e-8 and res['boundary_host_flat_values']['constant_declared']['residual'] <= 1e-8
