@@ -421,6 +421,7 @@ struct pp_solver {
   long long* corner_pos = nullptr;      // sparse Q of a block-tridiagonal S: positions in the Schur layout, values
   double* corner_val = nullptr;
   size_t corner_cap = 0;
+  long long corner_nnz = -1;            // pairs of the last pp_factor_schur_corner (the a-posteriori check reads them), -1: none
   hipEvent_t ev_corner_up = nullptr, ev_corner_done = nullptr;
   hipStream_t up_stream = nullptr;
   bool corner_used = false;
@@ -718,7 +719,7 @@ void free_globals(pp_handle h) {
   h->S = h->S_own = h->Sfac = h->Sldl = h->dvec = h->Qd = h->work = h->rs = h->rs_own = h->rcd = h->xc = nullptr;
   if (h->corner_pos) (void)hipFree(h->corner_pos);
   if (h->corner_val) (void)hipFree(h->corner_val);
-  h->corner_pos = nullptr; h->corner_val = nullptr; h->corner_cap = 0; h->corner_used = false;
+  h->corner_pos = nullptr; h->corner_val = nullptr; h->corner_cap = 0; h->corner_used = false; h->corner_nnz = -1;
   h->dense_mode = nullptr;
   h->ipiv = h->bkinfo = h->counters = nullptr;
   if (h->vec_part) { (void)hipFree(h->vec_part); h->vec_part = nullptr; }

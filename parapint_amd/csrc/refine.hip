@@ -260,14 +260,15 @@ __global__ __launch_bounds__(64) void k_residual_slots(const double* __restrict_
 __global__ __launch_bounds__(256) void k_residual_finish(const double* __restrict__ best, double* mail, long long seq, int nc, int nranks,
                                                          const double* __restrict__ ax, const double* __restrict__ xc,
                                                          const double* __restrict__ bc, int Qmode, const double* __restrict__ Q,
-                                                         double* __restrict__ rc_out) {
+                                                         double* rc_out, const double* s_pre) {
   __shared__ double sr[256], ss[256];
-  double rall = 0.0, sall = 0.0;
+  double rall = nranks > 0 ? 0.0 : best[0], sall = nranks > 0 ? 0.0 : best[3];      // (one rank: its own block result)
   for (int r = threadIdx.x; r < nranks; r += 256) { rall = fmax(rall, ax[2 * (size_t)nc + 2 * r]); sall = fmax(sall, ax[2 * (size_t)nc + 2 * r + 1]); }
   double rmx = 0.0, smx = 0.0;
   for (int c = threadIdx.x; c < nc; c += 256) {
     const double bcv = bc ? bc[c] : 0.0;
-    double r = bcv - ax[c], s = fabs(bcv) + ax[nc + c];
+    // (Qmode 2, sparse Q of a block-tridiagonal S: k_corner_rc_init / _apply have formed r and its scale in rc_out / s_pre)
+    double r = (Qmode == 2) ? rc_out[c] : bcv - ax[c], s = (Qmode == 2) ? s_pre[c] : fabs(bcv) + ax[nc + c];
     if (Qmode == 1) {
       for (int k = 0; k < nc; ++k) {
         const double q = (c >= k) ? Q[(size_t)c + (size_t)k * nc] : Q[(size_t)k + (size_t)c * nc];
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(256) void k_residual_finish(const double* __restric
         s += fabs(q) * fabs(xc[k]);
       }
     }
-    if (rc_out) rc_out[c] = r;
+    if (rc_out && Qmode != 2) rc_out[c] = r;
     rmx = fmax(rmx, (r == r) ? fabs(r) : INFINITY);
     smx = fmax(smx, s);
   }
@@ -299,6 +300,37 @@ __global__ __launch_bounds__(256) void k_residual_finish(const double* __restric
     mail[0] = best[0]; mail[1] = best[1]; mail[2] = best[2]; mail[4] = scale_all; mail[5] = rho_c; mail[6] = rho_all;
     __threadfence_system();
     __hip_atomic_store(reinterpret_cast<long long*>(mail) + 3, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// Block-tridiagonal S: Q as the (position in the Schur layout, value) pairs pp_factor_schur_corner got -- D[G][gs][gs] (both
+// triangles of a diagonal block are listed) | E[G-1][gs][gs] with E_t = S(block t + 1, block t) listed once.
+__global__ __launch_bounds__(256) void k_corner_rc_init(int nc, const double* __restrict__ bc, const double* __restrict__ ax,
+                                                        double* __restrict__ r, double* __restrict__ s) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= nc) return;
+  const double bcv = bc ? bc[c] : 0.0;
+  r[c] = bcv - ax[c];
+  s[c] = fabs(bcv) + ax[nc + c];
+}
+__global__ __launch_bounds__(256) void k_corner_rc_apply(long long nnz, const long long* __restrict__ pos, const double* __restrict__ val,
+                                                         int gs, int G, const double* __restrict__ xc, double* __restrict__ r,
+                                                         double* __restrict__ s) {
+  const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (k >= nnz) return;
+  const long long g2 = (long long)gs * gs, p = pos[k];
+  const double v = val[k];
+  if (v == 0.0) return;
+  if (p < (long long)G * g2) {
+    const int t = (int)(p / g2), c = (int)((p % g2) / gs), rr = (int)(p % gs);
+    const int row = t * gs + rr, col = t * gs + c;
+    atomicAdd(r + row, -v * xc[col]); atomicAdd(s + row, fabs(v) * fabs(xc[col]));
+  } else {
+    const long long q = p - (long long)G * g2;
+    const int t = (int)(q / g2), c = (int)((q % g2) / gs), rr = (int)(q % gs);
+    const int row = (t + 1) * gs + rr, col = t * gs + c;
+    atomicAdd(r + row, -v * xc[col]); atomicAdd(s + row, fabs(v) * fabs(xc[col]));
+    atomicAdd(r + col, -v * xc[row]); atomicAdd(s + col, fabs(v) * fabs(xc[row]));
   }
 }
 
@@ -443,7 +475,7 @@ int pp_residual(pp_handle h, int store, const double* bc_dev, int coupling_on_de
     h->resid_dev = (double*)dp;
     if (int rc = dev_alloc<double>(h, nullptr, &h->resid_best, 4)) return rc;
     if (int rc = dev_alloc<double>(h, nullptr, &h->resid_ax, 2 * ncp + 2 * 1024)) return rc;      // (+ a slot pair per rank)
-    if (int rc = dev_alloc<double>(h, nullptr, &h->resid_rc, ncp)) return rc;
+    if (int rc = dev_alloc<double>(h, nullptr, &h->resid_rc, 2 * ncp)) return rc;         // r_c | its row scales
   }
   if (int rc = join_dense(h)) return rc;
   if (!bc_dev) bc_dev = h->last_rc;
@@ -452,10 +484,14 @@ int pp_residual(pp_handle h, int store, const double* bc_dev, int coupling_on_de
   ++h->resid_seq;
   // coupling rows on the device: a dense S whose sums are complete on this rank (the caller says so); Q as pp_factor_schur got it
   // coupling_on_device == 2: several ranks whose sums meet through the library's communicator (one all-reduce, below)
-  const bool ranks = coupling_on_device == 2 && !h->btd && h->rccl_comm && h->rccl_ranks >= 1 && h->rccl_ranks <= 1024;
-  if (coupling_on_device == 2 && !ranks) return fail(h, 3, "pp_residual: no communicator for the check across ranks (pp_comm_init), or a block-tridiagonal S");
-  const int Qfin = (coupling_on_device && !h->btd) ? (h->have_Q ? 1 : 0) : -1;
-  const int Qmode = ranks ? -2 : Qfin;
+  const bool ranks = coupling_on_device == 2 && h->rccl_comm && h->rccl_ranks >= 1 && h->rccl_ranks <= 1024;
+  if (coupling_on_device == 2 && !ranks) return fail(h, 3, "pp_residual: no communicator for the check across ranks (pp_comm_init)");
+  // Q: dense (1) / none (0) as the last pp_factor_schur got it; block-tridiagonal S: the pairs of pp_factor_schur_corner (2);
+  // a block-tridiagonal S factorised from a flat Q leaves the coupling rows to the caller
+  int Qfin = -1;
+  if (coupling_on_device) Qfin = h->btd ? (h->corner_nnz >= 0 ? 2 : -1) : (h->have_Q ? 1 : 0);
+  if (coupling_on_device && Qfin < 0) return fail(h, 3, "pp_residual: no Q on the device for the coupling rows (block-tridiagonal S factorised from a flat Q)");
+  const int Qmode = (ranks || Qfin == 2) ? -2 : Qfin;
   h->resid_rc_valid = false;
   bool any_mapped = ng == 0;
   for (Group* g : h->groups) any_mapped = any_mapped || (g->dev.cmapT != nullptr) || g->dev.nc != nc;
@@ -520,12 +556,22 @@ int pp_residual(pp_handle h, int store, const double* bc_dev, int coupling_on_de
                        uniform ? (const double*)g->res_bpart : (const double*)nullptr, h->resid_ax, (const double*)h->xc, bc_dev, Qmode,
                        (const double*)h->Qd, store ? h->resid_rc : (double*)nullptr);
   }
-  if (ranks) {
-    if (ng == 0) PP_HIP(hipMemsetAsync(h->resid_best, 0, 4 * sizeof(double), st));
-    hipLaunchKernelGGL(k_residual_slots, dim3(1), dim3(64), 0, st, (const double*)h->resid_best, h->resid_ax, nc, h->rccl_ranks, h->rccl_rank);
-    if (int rc = ppi_allreduce_sum(h, h->resid_ax, 2 * (size_t)nc + 2 * (size_t)h->rccl_ranks)) return rc;
-    hipLaunchKernelGGL(k_residual_finish, dim3(1), dim3(256), 0, st, (const double*)h->resid_best, h->resid_dev, h->resid_seq, nc, h->rccl_ranks,
-                       (const double*)h->resid_ax, (const double*)h->xc, bc_dev, Qfin, (const double*)h->Qd, store ? h->resid_rc : (double*)nullptr);
+  if (ranks || Qfin == 2) {
+    if (ranks) {
+      hipLaunchKernelGGL(k_residual_slots, dim3(1), dim3(64), 0, st, (const double*)h->resid_best, h->resid_ax, nc, h->rccl_ranks, h->rccl_rank);
+      if (int rc = ppi_allreduce_sum(h, h->resid_ax, 2 * (size_t)nc + 2 * (size_t)h->rccl_ranks)) return rc;
+    }
+    if (Qfin == 2 && nc > 0) {
+      hipLaunchKernelGGL(k_corner_rc_init, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, st, nc, bc_dev, (const double*)h->resid_ax,
+                         h->resid_rc, h->resid_rc + nc);
+      if (h->corner_nnz > 0)
+        hipLaunchKernelGGL(k_corner_rc_apply, dim3((unsigned)((h->corner_nnz + 255) / 256)), dim3(256), 0, st, (long long)h->corner_nnz,
+                           (const long long*)h->corner_pos, (const double*)h->corner_val, h->gs, h->G, (const double*)h->xc, h->resid_rc,
+                           h->resid_rc + nc);
+    }
+    hipLaunchKernelGGL(k_residual_finish, dim3(1), dim3(256), 0, st, (const double*)h->resid_best, h->resid_dev, h->resid_seq, nc,
+                       ranks ? h->rccl_ranks : 0, (const double*)h->resid_ax, (const double*)h->xc, bc_dev, Qfin, (const double*)h->Qd,
+                       (store || Qfin == 2) ? h->resid_rc : (double*)nullptr, (const double*)(h->resid_rc + nc));
     if (store) h->resid_rc_valid = true;
   } else if (Qmode < 0) {
     // the caller finishes the coupling rows: x_c | sum A x | sum |A||x| | b_c behind the header, then the flag
@@ -540,7 +586,7 @@ int pp_residual(pp_handle h, int store, const double* bc_dev, int coupling_on_de
   } else if (store) {
     h->resid_rc_valid = true;
   }
-  h->resid_on_device = Qmode >= 0 || ranks;
+  h->resid_on_device = Qfin >= 0;
   PP_HIP(hipGetLastError());
   return 0;
 }

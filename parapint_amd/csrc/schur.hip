@@ -589,7 +589,10 @@ int pp_bind_schur_buffer(pp_handle h, double* dev_ptr) {
 
 static int factor_schur_impl(pp_handle h, const double* Q_host, long long corner_nnz);
 
-int pp_factor_schur(pp_handle h, const double* Q_host) { return factor_schur_impl(h, Q_host, 0); }
+int pp_factor_schur(pp_handle h, const double* Q_host) {
+  if (h) h->corner_nnz = (h->btd && Q_host) ? -1 : 0;        // (a flat Q of a block-tridiagonal S is not kept in pair form)
+  return factor_schur_impl(h, Q_host, 0);
+}
 
 int pp_factor_schur_corner(pp_handle h, int64_t nnz, const int64_t* pos, const double* val) {
   if (!h || !h->numeric_done) return fail(h, 3, "pp_factor_schur_corner before pp_numeric_local");
@@ -626,6 +629,7 @@ int pp_factor_schur_corner(pp_handle h, int64_t nnz, const int64_t* pos, const d
     PP_HIP(hipStreamSynchronize(up));            // the caller's arrays are free again when this returns
     PP_HIP(hipStreamWaitEvent(h->stream, h->ev_corner_up, 0));
   }
+  h->corner_nnz = (long long)nnz;
   return factor_schur_impl(h, nullptr, (long long)nnz);
 }
 

@@ -56,12 +56,11 @@ class SolutionCheckMixin(object):
         finished here from the sums the engine formed (n_c-vectors; with several ranks one sum all-reduce carries them and --
         one slot per rank -- the block results, so every rank takes the same decision)."""
         on_device = 0
-        if self._btd is None:
-            direct = getattr(self._eng, '_direct_rccl', None)
-            if direct is not None and (self.comm.size > 1 or getattr(self.comm, 'always_reduce', False)) and direct(self.comm):
-                on_device = 2        # (the library's communicator: one all-reduce on its stream, no host collective)
-            elif self.comm.size == 1:
-                on_device = 1
+        direct = getattr(self._eng, '_direct_rccl', None)
+        if direct is not None and (self.comm.size > 1 or getattr(self.comm, 'always_reduce', False)) and direct(self.comm):
+            on_device = 2        # (the library's communicator: one all-reduce on its stream, no host collective)
+        elif self.comm.size == 1:
+            on_device = 1
         rb, gid, slot, scale, rho_c, xc, ax, aabs, bcd = self._eng.residual(store, self._check_bc_dev, on_device)
         if not rb == rb:
             rb = np.inf
