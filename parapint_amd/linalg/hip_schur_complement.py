@@ -1345,7 +1345,17 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, SolutionCheckMixin, Coupl
             rc_dev = self._rc_pad
         self._eng.solve_coupling_dev(rc_dev)
         self._eng.solve_backward()
+
+        def hand_over_coupling():
+            if self._nc > 0:
+                if self._btd is not None:
+                    self._eng.copy_coupling_solution(self._xc_pad)
+                    self._eng.permute(self._cinv_t, self._xc_pad, out.coupling, scatter=False)
+                else:
+                    self._eng.copy_coupling_solution(out.coupling)
+        hand_over_coupling()             # (enqueued before the host waits for the verdict below; again after a refinement)
         if self._checking():
+            before = self.refinement_steps
             bad = self._verify_solution(bc_dev=rc_dev)
             if bad is not None:
                 if _repairs > 0 and self._repair_after_inaccurate_solve(bad):
@@ -1354,12 +1364,8 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, SolutionCheckMixin, Coupl
                         self._dev_turn -= 1            # (the same result vector again)
                     return self._device_back_solve(rhs, timer, _repairs - 1)
                 self._give_up_on_solution(bad)
-        if self._nc > 0:
-            if self._btd is not None:
-                self._eng.copy_coupling_solution(self._xc_pad)
-                self._eng.permute(self._cinv_t, self._xc_pad, out.coupling, scatter=False)
-            else:
-                self._eng.copy_coupling_solution(out.coupling)
+            if self.refinement_steps != before:
+                hand_over_coupling()
         timer.stop('back_solve')
         return out
 

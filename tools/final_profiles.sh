@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run ON THE GPU BOX: everything profiles/<round>_final/ holds, into gpurun_out/<tag>/ (copy what is to be judged into profiles/).
-#   bench_default.json         python bench.py --steps 40            (with cpu_baseline and boundary_host)
+#   bench_default.json         python bench.py --steps 40            (with cpu_baseline, boundary_host, shares; written AFTER the PMC passes so that roofline.traffic carries this build's counters)
 #   kernel_stats.csv, bench_under_rocprof.json    rocprofv3 --kernel-trace --stats of bench.py --steps 20
 #   pmc/*_per_kernel.csv, pmc_traffic.json        separate --pmc FETCH_SIZE / WRITE_SIZE passes
 #   bench_C2.json, bench_C4.json, kernel_stats_C4.csv, bench_128_blocks.json, bench_C5.json, bench_C5_512_blocks.json
@@ -13,8 +13,6 @@ tag=${1:-final}
 out=gpurun_out/$tag
 mkdir -p $out/pmc
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python3 bench.py --steps 40 > $out/bench_default.json 2> $out/bench_default.err || { tail -3 $out/bench_default.err; exit 1; }
-echo "default done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-boundary --no-ip-loop > $out/bench_under_rocprof.json 2> $out/stats.err || exit 1
 cp $(find $out/stats -name '*kernel_stats.csv' | head -1) $out/kernel_stats.csv
 echo "kernel stats done"
@@ -41,6 +39,10 @@ PY
 read raw n batch < $out/plan_args.txt
 python3 tools/pmc_traffic.py $out/pmc_fetch $out/pmc_write $raw $n $batch $out/pmc_traffic.json "bench.py --steps 3 --profile-steps 1 under rocprofv3 --pmc (one pass per counter)" || exit 1
 echo "pmc done"
+# the default line AFTER the counter passes, with their summary in place: roofline.traffic is then stamped with this build's hash
+cp $out/pmc_traffic.json profiles/pmc_traffic.json
+python3 bench.py --steps 40 > $out/bench_default.json 2> $out/bench_default.err || { tail -3 $out/bench_default.err; exit 1; }
+echo "default done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_ip -- python3 tools/ip_c3.py 1024 > $out/ip_loop_under_rocprof.json 2> $out/stats_ip.err && cp $(find $out/stats_ip -name '*kernel_stats.csv' | head -1) $out/kernel_stats_ip_loop.csv
 python3 tools/ip_c3.py 1024 > $out/ip_loop.json 2> $out/ip_loop.err
 bash tools/ip_step_traffic.sh $tag/ip_traffic > $out/ip_step_traffic.log 2>&1 && cp $out/ip_traffic/ip_step_traffic.json $out/ip_step_traffic.json
