@@ -26,6 +26,7 @@ PHASE_OF = [
     (r'^k_add_q|^k_ldl_|^k_bk_factor|^k_write_tail|^k_publish_status|^k_dense_|^k_bcr_|^k_btd_|^k_corner_add', 'dense_S'),
     (r'^k_fwd_level|^k_chain_fwd', 'fwd_levels'), (r'^k_fwd_coupling|^k_rs_reduce', 'fwd_coupling'),
     (r'^k_coupling_solve', 'coupling_solve'), (r'^k_bwd_level|^k_chain_bwd|^k_transpose_out', 'bwd_levels'),
+    (r'^k_residual|^k_corner_rc', 'solution_check'),
 ]
 
 
