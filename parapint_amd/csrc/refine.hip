@@ -24,7 +24,7 @@
 
 namespace {
 
-constexpr int RES_ROWS = 8;         // rows per wave
+constexpr int RES_NW = 8;           // waves per workgroup: their per-instance maxima meet in LDS, one atomic per lane and workgroup
 
 __device__ __forceinline__ unsigned long long dbits(double v) { return (unsigned long long)__double_as_longlong(v); }
 
@@ -49,15 +49,16 @@ struct ResArgs {
 // groups reduce over the lanes into bpart[chunk][2][nc] (summed by k_residual_reduce), mapped groups add every instance's
 // term to its own global coupling row.
 template <int NV, bool STORE>
-__global__ __launch_bounds__(64) void k_residual(GroupDev g, ResArgs a, const int* __restrict__ rptr, const int* __restrict__ vrow,
+__global__ __launch_bounds__(64 * RES_NW) void k_residual(GroupDev g, ResArgs a, const int* __restrict__ rptr, const int* __restrict__ vrow,
                                                  const int* __restrict__ xcol, const int* __restrict__ brow,
                                                  const double* __restrict__ coef, const double* __restrict__ V,
                                                  const double* __restrict__ B, const double* __restrict__ X,
                                                  const double* __restrict__ xc) {
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const size_t bpad = (size_t)g.bpad;
   if ((int)blockIdx.x >= a.nres_wg) {
-    const int t = (int)blockIdx.x - a.nres_wg;
+    const int t = ((int)blockIdx.x - a.nres_wg) * RES_NW + wave;
+    if (t >= g.nc * g.nchunk) return;
     const int chunk = t % g.nchunk, c = t / g.nchunk;
     const int b = chunk * 64 + lane;
     double s = 0.0, ab = 0.0;
@@ -78,8 +79,9 @@ __global__ __launch_bounds__(64) void k_residual(GroupDev g, ResArgs a, const in
     if (lane == 0) { a.bpart[((size_t)chunk * 2) * g.nc + c] = s; a.bpart[((size_t)chunk * 2 + 1) * g.nc + c] = ab; }
     return;
   }
+  __shared__ double red[RES_NW][2 * NV][64];
   const unsigned b = (unsigned)(((blockIdx.x % (unsigned)a.ny) * 64 + lane) * NV);
-  const int c0 = (int)(blockIdx.x / (unsigned)a.ny) * a.rows_per_wg;
+  const int c0 = ((int)(blockIdx.x / (unsigned)a.ny) * RES_NW + wave) * a.rows_per_wg;
   const int c1 = min(c0 + a.rows_per_wg, g.n);
   // (the records as restrict-qualified kernel parameters, and no store inside the row loop unless STORE: through the
   // argument struct, or with stores in between, the compiler fetches every record with a vector load + v_readfirstlane
@@ -139,7 +141,12 @@ __global__ __launch_bounds__(64) void k_residual(GroupDev g, ResArgs a, const in
     if (STORE) stv<NV>(Rout + (size_t)(a.rrow ? a.rrow[c] : c) * bpad, r);
   }
 #pragma unroll
+  for (int v = 0; v < NV; ++v) { red[wave][v][lane] = rm[v]; red[wave][NV + v][lane] = sm[v]; }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
   for (int v = 0; v < NV; ++v) {
+    for (int k = 1; k < RES_NW; ++k) { rm[v] = fmax(rm[v], red[k][v][lane]); sm[v] = fmax(sm[v], red[k][NV + v][lane]); }
     if ((int)(b + v) < g.batch) {
       // (non-negative doubles order like their bit patterns; +inf is the largest)
       atomicMax(a.rmax + b + v, dbits(rm[v]));
@@ -377,16 +384,49 @@ int ppi_build_residual_records(pp_handle h, Group* g, const std::vector<int>& ra
     if (i != j) rows[(size_t)j].push_back({e, i});
   }
   for (int e = 0; e < nnzB; ++e) rows[(size_t)P.iperm[(size_t)colB[e]]].push_back({nnzK + e, -1 - rowB[e]});
-  std::vector<int> ptr((size_t)n + 1, 0), vraw, xnew, xold;
-  for (int c = 0; c < n; ++c) {
+  // Order of execution: reverse Cuthill-McKee on the graph of K.  Every off-diagonal value serves two rows (i and j), every
+  // x_j the rows of j's neighbours: with the two rows in one task or in neighbouring ones (which run on the same XCD at
+  // about the same time) the second request meets the line in the L2.  MEASURED at C3 (rocprofv3 --pmc FETCH_SIZE):
+  // elimination order 500 MB past the L2 per launch against 281 MB of distinct operands.
+  std::vector<int> order;
+  {
+    order.reserve((size_t)n);
+    std::vector<int> deg((size_t)n, 0);
+    for (int c = 0; c < n; ++c) deg[(size_t)c] = (int)rows[(size_t)c].size();
+    std::vector<char> seen((size_t)n, 0);
+    std::vector<int> by_deg((size_t)n);
+    for (int c = 0; c < n; ++c) by_deg[(size_t)c] = c;
+    std::stable_sort(by_deg.begin(), by_deg.end(), [&](int a2, int b2) { return deg[(size_t)a2] < deg[(size_t)b2]; });
+    std::vector<int> nb;
+    for (int start : by_deg) {
+      if (seen[(size_t)start]) continue;
+      size_t head = order.size();
+      order.push_back(start); seen[(size_t)start] = 1;
+      while (head < order.size()) {
+        const int c = order[head++];
+        nb.clear();
+        for (auto& rc : rows[(size_t)c]) if (rc[1] >= 0 && !seen[(size_t)rc[1]]) { seen[(size_t)rc[1]] = 1; nb.push_back(rc[1]); }
+        std::stable_sort(nb.begin(), nb.end(), [&](int a2, int b2) { return deg[(size_t)a2] < deg[(size_t)b2]; });
+        order.insert(order.end(), nb.begin(), nb.end());
+      }
+    }
+    std::reverse(order.begin(), order.end());
+  }
+  std::vector<int> ptr((size_t)n + 1, 0), vraw, xnew, xold, brow_new((size_t)n), brow_old((size_t)n);
+  for (int pos = 0; pos < n; ++pos) {
+    const int c = order[(size_t)pos];
+    brow_new[(size_t)pos] = c;
+    brow_old[(size_t)pos] = P.perm[(size_t)c];
     for (auto& rc : rows[(size_t)c])
       for (int q = g->can_ptr[(size_t)rc[0]]; q < g->can_ptr[(size_t)rc[0] + 1]; ++q) {
         vraw.push_back(rawmap[(size_t)g->can_idx[(size_t)q]]);
         xnew.push_back(rc[1]);
         xold.push_back(rc[1] >= 0 ? P.perm[(size_t)rc[1]] : rc[1]);
       }
-    ptr[(size_t)c + 1] = (int)vraw.size();
+    ptr[(size_t)pos + 1] = (int)vraw.size();
   }
+  if (int rcb = dev_upload(h, g, &g->res_brow_new, brow_new)) return rcb;
+  if (int rcb = dev_upload(h, g, &g->res_brow_old, brow_old)) return rcb;
   g->res_ne = (int)vraw.size();
   g->res_vraw_host = vraw;
   {
@@ -518,13 +558,13 @@ int pp_residual(pp_handle h, int store, const double* bc_dev, int coupling_on_de
       if (!d.rawT) return fail(h, 3, "pp_residual: the values of the last factorisation are gone");
       a.V = d.rawT; a.vrow = g->res_vraw; a.bvrow = g->res_bvraw;
     }
-    if (native) { a.B = g->rhs_native; a.X = g->x_native; a.xcol = g->res_xold; a.brow = d.perm; a.bxcol = g->res_bxold; }
+    if (native) { a.B = g->rhs_native; a.X = g->x_native; a.xcol = g->res_xold; a.brow = g->res_brow_old; a.bxcol = g->res_bxold; }
     else {
       // b was consumed by the forward sweep (y is computed in place): transposed into Y again, elimination order
       const int tiles = transpose_tiles(P.n, d.nchunk);
       hipLaunchKernelGGL(k_transpose_in, dim3((unsigned)((P.n + 64 * tiles - 1) / (64 * tiles)) * d.nchunk), dim3(256), 0, st, d.rhs,
                          d.Y, d.iperm, d.batch, P.n, d.bpad, tiles, (const int*)nullptr);
-      a.B = d.Y; a.X = d.X; a.xcol = g->res_xnew; a.brow = nullptr; a.bxcol = g->res_bxnew;
+      a.B = d.Y; a.X = d.X; a.xcol = g->res_xnew; a.brow = g->res_brow_new; a.bxcol = g->res_bxnew;
     }
     if (store) {
       if (!g->res_R) {
@@ -533,19 +573,19 @@ int pp_residual(pp_handle h, int store, const double* bc_dev, int coupling_on_de
         if (int rc = value_alloc(h, g, &g->res_D, (size_t)P.n * (size_t)d.bpad)) return rc;
       }
       a.Rout = g->res_R;             // caller's row order: the correction solve runs on native vectors
-      a.rrow = d.perm;
+      a.rrow = g->res_brow_old;
     }
     a.xc = (d.cmapT && d.nc > 0) ? d.XCL : h->xc;
     a.rmax = g->res_rmax; a.smax = g->res_smax;
     a.bpart = g->res_bpart; a.ax = h->resid_ax; a.nc_glob = nc;
     // rows per wave: enough waves to fill the chip several times over, few enough atomics (measured at C3: tools/sweep_env.sh PP_RES_ROWS)
-    a.rows_per_wg = rows_env > 0 ? rows_env : (d.nchunk >= 8 ? 8 : 4);
-    const unsigned ntask = (unsigned)((P.n + a.rows_per_wg - 1) / a.rows_per_wg);
-    const unsigned nborder = (unsigned)d.nc * (unsigned)d.nchunk;
+    a.rows_per_wg = rows_env > 0 ? rows_env : 2;          // (x RES_NW = 8 waves: 16 rows per workgroup.  MEASURED at C3, kernel alone: 1 wave x 8 rows 97 us; reverse Cuthill-McKee order 4 x 8 rows 83.5; 8 x 2 rows 69.1; 16 x 2 rows 78.1; 16 x 1 94.9)
+    const unsigned ntask = (unsigned)((P.n + a.rows_per_wg * RES_NW - 1) / (a.rows_per_wg * RES_NW));
+    const unsigned nborder = ((unsigned)d.nc * (unsigned)d.nchunk + RES_NW - 1) / RES_NW;
     const bool pair = h->lane_pairs && d.nchunk % 2 == 0;
     a.ny = pair ? d.nchunk / 2 : d.nchunk;
     a.nres_wg = (int)(ntask * (unsigned)a.ny);
-#define PP_LAUNCH_RES(NV, ST) hipLaunchKernelGGL((k_residual<NV, ST>), dim3((unsigned)a.nres_wg + nborder), dim3(64), 0, st, d, a, a.rptr, \
+#define PP_LAUNCH_RES(NV, ST) hipLaunchKernelGGL((k_residual<NV, ST>), dim3((unsigned)a.nres_wg + nborder), dim3(64 * RES_NW), 0, st, d, a, a.rptr, \
                                                 a.vrow, a.xcol, a.brow, a.coef, a.V, a.B, a.X, a.xc)
     if (pair) { if (store) PP_LAUNCH_RES(2, true); else PP_LAUNCH_RES(2, false); }
     else { if (store) PP_LAUNCH_RES(1, true); else PP_LAUNCH_RES(1, false); }
