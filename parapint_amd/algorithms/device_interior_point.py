@@ -78,9 +78,22 @@ def ip_solve_device(interface, options=None, timer=None, history=None, stats=Non
         used_inertia_coef = numeric_factorization(interface, kkt, options, inertia_coef, timer)
         inertia_coef = max(used_inertia_coef * options.inertia_correction.factor_decrease,
                            options.inertia_correction.init_coef)
-        delta = solver.do_back_solve(rhs)
-        interface.set_primal_dual_kkt_solution(delta)
-        interface.fraction_to_the_boundary(1 - barrier_parameter)
+        if hasattr(solver, 'do_back_solve_deferred'):
+            # (this package's solver class: the a-posteriori check of the back-solve is enqueued with it, the step lengths --
+            # which only READ the solution -- are enqueued behind it, and only then the host waits for the verdict: the
+            # stream stays busy meanwhile.  A solution the check had to refine or solve again gets its step lengths again.)
+            delta = solver.do_back_solve_deferred(rhs)
+            interface.set_primal_dual_kkt_solution(delta)
+            interface.fraction_to_the_boundary(1 - barrier_parameter)
+            confirmed = solver.confirm_solution()
+            if solver.solution_changed_on_confirm:
+                delta = confirmed
+                interface.set_primal_dual_kkt_solution(delta)
+                interface.fraction_to_the_boundary(1 - barrier_parameter)
+        else:
+            delta = solver.do_back_solve(rhs)
+            interface.set_primal_dual_kkt_solution(delta)
+            interface.fraction_to_the_boundary(1 - barrier_parameter)
         interface.take_step(unified=options.unified_step)
         m = interface.check_convergence(options.error_scaling)
         alpha_primal_max, alpha_dual_max = m['alpha_primal'], m['alpha_dual']

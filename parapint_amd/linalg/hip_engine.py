@@ -59,7 +59,7 @@ class HipEngine(object):
         self._S_t = None
         self._rs_t = None
         self._ip_ops = None
-        self._resid_cpl = None
+        self._resid_cpl = self._resid_out = self._resid_ptrs = None
 
     supports_block_tridiagonal = True
 
@@ -559,23 +559,26 @@ class HipEngine(object):
                       'pp_get_coupling_solution')
         return xc[:self.nc]
 
-    def residual(self, store=False, bc=None, on_device=False):
-        """The a-posteriori check of the last back-solve (include/parapint_hip.h: pp_residual): (rho of the worst local
-        instance, its group, its slot, largest row scale of the local blocks, rho of the coupling rows or None, x_c,
-        sum_i A_i x_i, sum_i |A_i||x_i|, b_c) -- the four coupling vectors (library order) only when the caller has to finish
-        the coupling rows itself (rho None: several ranks, block-tridiagonal S); bc: the coupling right-hand side as a device
-        tensor, or None (the one of the last coupling solve).  on_device: 1 -- the sums of the coupling rows are complete on
-        this rank; 2 -- several ranks, the sums and the block results meet in one all-reduce of the library's communicator
-        (collective; the returned rho of the coupling rows then also covers the worst block of any rank).  Waits for the result."""
-        nc = self.nc
+    def residual_begin(self, store=False, bc=None, on_device=False):
+        """Enqueues the a-posteriori check of the last back-solve (include/parapint_hip.h: pp_residual) behind it on the
+        solver's stream; residual_end() waits for its result.  bc: the coupling right-hand side as a device tensor, or None
+        (the one of the last coupling solve).  on_device: 1 -- the sums of the coupling rows are complete on this rank; 2 --
+        several ranks, the sums and the block results meet in one all-reduce of the library's communicator (collective)."""
         self.ns.check(self.lib.pp_residual(self.ns.h, 1 if store else 0, bc.data_ptr() if bc is not None else None,
                                            int(on_device)), 'pp_residual')
-        out = np.zeros(6)
+
+    def residual_end(self):
+        """(rho of the worst local instance, its group, its slot, largest row scale of the blocks, rho of the coupling rows --
+        and, on_device = 2, of the worst block of any rank -- or None, x_c, sum_i A_i x_i, sum_i |A_i||x_i|, b_c): the four
+        coupling vectors (library order) only when the caller has to finish the coupling rows itself (rho None)."""
+        nc = self.nc
+        out = self._resid_out
         cpl = self._resid_cpl
         if cpl is None or cpl.size != 4 * max(nc, 1):
             cpl = self._resid_cpl = np.zeros(4 * max(nc, 1))
-        self.ns.check(self.lib.pp_residual_result(self.ns.h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), cpl.ctypes.data),
-                      'pp_residual_result')
+            out = self._resid_out = np.zeros(6)
+            self._resid_ptrs = (out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), cpl.ctypes.data)
+        self.ns.check(self.lib.pp_residual_result(self.ns.h, self._resid_ptrs[0], self._resid_ptrs[1]), 'pp_residual_result')
         if out[4] >= 0.0 or out[4] != out[4]:
             # (rho of the coupling rows AND of the worst block of any rank: max of the two is the verdict, the same on every rank)
             rho_rows = float(out[4]) if out[4] == out[4] else np.inf
@@ -583,6 +586,10 @@ class HipEngine(object):
             return float(out[0]), int(out[1]), int(out[2]), float(out[3]), max(rho_rows, rho_all), None, None, None, None
         return (float(out[0]), int(out[1]), int(out[2]), float(out[3]), None, cpl[:nc].copy(), cpl[nc:2 * nc].copy(),
                 cpl[2 * nc:3 * nc].copy(), cpl[3 * nc:4 * nc].copy())
+
+    def residual(self, store=False, bc=None, on_device=False):
+        self.residual_begin(store, bc, on_device)
+        return self.residual_end()
 
     def refine_solve_coupling(self):
         self.ns.check(self.lib.pp_refine_solve_coupling(self.ns.h), 'pp_refine_solve_coupling')

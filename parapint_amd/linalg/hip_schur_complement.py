@@ -169,6 +169,8 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, SolutionCheckMixin, Coupl
         self._stage_calls = 0
         self._index_records = {}            # id(index array) -> (array, size, address, checksum)
         self._index_sets = {}               # ids of a block's four index arrays -> the tuple of them (shared by blocks)
+        self._deferred_solve = None         # (do_back_solve_deferred: the back-solve whose verdict confirm_solution() still has to collect)
+        self.solution_changed_on_confirm = False
         self._init_solution_check()         # every back-solve is checked on the device, refined, repaired (solution_check.py)
 
     # ------------------------------------------------------------------ helpers
@@ -844,6 +846,8 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, SolutionCheckMixin, Coupl
         return res
 
     def do_numeric_factorization(self, matrix, raise_on_error=True, timer=None):
+        if self._deferred_solve is not None:
+            self.confirm_solution()         # (a deferred back-solve is never left unjudged: its factors are still in place here)
         shift = getattr(matrix, 'diagonal_shift', None)
         if shift is not None and self._have_classes and matrix.base is self._last_device_base:
             # "the last matrix + a diagonal": one retry of the inertia-correction loop (interior_point.py:377-392) from
@@ -1172,6 +1176,8 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, SolutionCheckMixin, Coupl
             timer = _NullTimer()
         if self._num_status is None:
             raise RuntimeError('Perform numeric factorization first!')
+        if self._deferred_solve is not None:
+            self.confirm_solution()
         if _repairs is None:
             _repairs = self.max_solve_repairs
             self._repairs_this_solve = 0
@@ -1317,7 +1323,44 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, SolutionCheckMixin, Coupl
         self._eng.solve_forward(early=early)
         self._eng.allreduce_rs(self.comm)
 
-    def _device_back_solve(self, rhs, timer, _repairs=0):
+    def do_back_solve_deferred(self, rhs, timer=None):
+        """do_back_solve for a DeviceBlockVector WITHOUT the wait for its a-posteriori check: everything, the check included,
+        is enqueued and the result vector returned; ``confirm_solution()`` then waits for the verdict and refines / repairs
+        in place as do_back_solve would have.  For callers that have further work to enqueue which only READS the solution (an
+        interior-point iteration: the step lengths) and must not lose the stream while the host waits.  The solution may be
+        handed on or modified only after confirm_solution(); every other entry point of the solver confirms first."""
+        if not hasattr(rhs, 'group_tensors'):
+            return self.do_back_solve(rhs, timer)
+        if self._num_status is None:
+            raise RuntimeError('Perform numeric factorization first!')
+        self.confirm_solution()
+        self._repairs_this_solve = 0
+        return self._device_back_solve(rhs, _NullTimer() if timer is None else timer, self.max_solve_repairs, defer=True)
+
+    def confirm_solution(self):
+        """Collects the verdict of a deferred back-solve (refinement / repair as in do_back_solve); returns its result vector
+        (the same object unless a repair had to solve again into a fresh one), or None if nothing was pending.
+        ``solution_changed_on_confirm`` tells whether the vector's contents changed."""
+        pend, self._deferred_solve = self._deferred_solve, None
+        self.solution_changed_on_confirm = False
+        if pend is None:
+            return None
+        rhs, out, rc_dev, repairs, hand_over = pend
+        before = (self.refinement_steps, self.solve_repairs)
+        bad = self._verify_solution(bc_dev=rc_dev, begun=True)
+        if bad is not None:
+            if repairs > 0 and self._repair_after_inaccurate_solve(bad):
+                if self._result_buffers > 0:
+                    self._dev_turn -= 1            # (the same result vector again)
+                out = self._device_back_solve(rhs, _NullTimer(), repairs - 1)
+            else:
+                self._give_up_on_solution(bad)
+        elif self.refinement_steps != before[0]:
+            hand_over()
+        self.solution_changed_on_confirm = (self.refinement_steps, self.solve_repairs) != before
+        return out
+
+    def _device_back_solve(self, rhs, timer, _repairs=0, defer=False):
         """do_back_solve for a DeviceBlockVector: right-hand sides are read where they are, the solution is written
         into a fresh device vector (or, with result_buffers = k > 0, into k vectors handed out in turn); no host copies."""
         timer.start('back_solve')
@@ -1354,6 +1397,12 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, SolutionCheckMixin, Coupl
                 else:
                     self._eng.copy_coupling_solution(out.coupling)
         hand_over_coupling()             # (enqueued before the host waits for the verdict below; again after a refinement)
+        if defer and self._checking():
+            self._check_bc_host, self._check_bc_dev = None, rc_dev
+            self._rho_begin()
+            self._deferred_solve = (rhs, out, rc_dev, _repairs, hand_over_coupling)
+            timer.stop('back_solve')
+            return out
         if self._checking():
             before = self.refinement_steps
             bad = self._verify_solution(bc_dev=rc_dev)

@@ -47,21 +47,27 @@ class SolutionCheckMixin(object):
         self._repairs_this_solve = 0
 
     def _checking(self):
-        return (self.residual_check and hasattr(self._eng, 'residual') and self._groups is not None and
+        return (self.residual_check and hasattr(self._eng, 'residual_begin') and self._groups is not None and
                 self._num_status in (LinearSolverStatus.successful, LinearSolverStatus.warning))
 
-    def _rho(self, store=False):
-        """Backward error of the solution in the engine's vectors: (max over the block rows of all ranks and over the
-        coupling rows, this rank's (rho of its worst block, group, slot)).  The coupling rows b_c - sum_i A_i x_i - Q x_c are
-        finished here from the sums the engine formed (n_c-vectors; with several ranks one sum all-reduce carries them and --
-        one slot per rank -- the block results, so every rank takes the same decision)."""
+    def _rho_begin(self, store=False):
+        """Enqueues the check behind the back-solve (no wait): _rho(begun=True) collects it."""
         on_device = 0
         direct = getattr(self._eng, '_direct_rccl', None)
         if direct is not None and (self.comm.size > 1 or getattr(self.comm, 'always_reduce', False)) and direct(self.comm):
             on_device = 2        # (the library's communicator: one all-reduce on its stream, no host collective)
         elif self.comm.size == 1:
             on_device = 1
-        rb, gid, slot, scale, rho_c, xc, ax, aabs, bcd = self._eng.residual(store, self._check_bc_dev, on_device)
+        self._eng.residual_begin(store, self._check_bc_dev, on_device)
+
+    def _rho(self, store=False, begun=False):
+        """Backward error of the solution in the engine's vectors: (max over the block rows of all ranks and over the
+        coupling rows, this rank's (rho of its worst block, group, slot)).  The coupling rows b_c - sum_i A_i x_i - Q x_c are
+        finished here from the sums the engine formed (n_c-vectors; with several ranks one sum all-reduce carries them and --
+        one slot per rank -- the block results, so every rank takes the same decision)."""
+        if not begun:
+            self._rho_begin(store)
+        rb, gid, slot, scale, rho_c, xc, ax, aabs, bcd = self._eng.residual_end()
         if not rb == rb:
             rb = np.inf
         self._check_rc = None
@@ -99,13 +105,13 @@ class SolutionCheckMixin(object):
             self._check_rc = rc
         return rho, (rb, gid, slot)
 
-    def _verify_solution(self, bc_host=None, bc_dev=None):
+    def _verify_solution(self, bc_host=None, bc_dev=None, begun=False):
         """After the backward sweep: check, refine.  bc_host / bc_dev: the coupling right-hand side of the back-solve in the
         library's order (numpy array / device tensor; both None: zero).  Returns None if the solution in the engine's
         vectors is accurate, else this rank's (rho of its worst block, group, slot)."""
         self._check_bc_host, self._check_bc_dev = bc_host, bc_dev
         try:
-            rho, mine = self._rho()
+            rho, mine = self._rho(begun=begun)
             self.last_residual_first = rho
             steps = 0
             while rho > self.refine_tolerance and np.isfinite(rho) and steps < self.max_refinement_steps:

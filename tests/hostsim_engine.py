@@ -330,6 +330,13 @@ class HostSimEngine(object):
             return worst + (scale, 0.0, None, None, None, None)
         return worst + (scale, None, self.xc.copy(), ax, aabs, bcv)
 
+    def residual_begin(self, store=False, bc_rhs=None, on_device=False):
+        self._resid_pending = self.residual(store, bc_rhs, on_device)
+
+    def residual_end(self):
+        out, self._resid_pending = self._resid_pending, None
+        return out
+
     def refine_solve_coupling(self):
         self.solve_coupling(self._resid_rc, _refining=True)
 

@@ -1302,3 +1302,58 @@ def case_adversarial_systems(make_engine, seeds=range(0, 400)):
     assert stats['solves_refined'] >= 3 and stats['refinement_steps'] >= stats['solves_refined'], stats
     assert stats['inaccurate_solves'] <= 2, stats
     return stats
+
+
+def case_refinement_fixture(make_engine, device_vectors=False):
+    """tests/golden/refinement_case.npz: the pivot sequence of the symbolic phase solves the later matrix with a backward error
+    of 0.48; do_back_solve must hand out the refined solution (<= 1e-8 against dense algebra, counted in the solver's
+    statistics) -- through host containers, through device vectors, and through do_back_solve_deferred + confirm_solution,
+    which must give the very same vector."""
+    import os
+    from scipy.sparse import coo_matrix
+    from parapint_amd.sparse.block_containers import BlockMatrix, BlockVector
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'refinement_case.npz'))
+    N = int(d['N'])
+
+    def matrix(tag):
+        m = BlockMatrix(N + 1, N + 1)
+        for i in range(N + 1):
+            for j in range(N + 1):
+                key = '%s_%d_%d_val' % (tag, i, j)
+                if key in d:
+                    pre = '%s_%d_%d_' % (tag, i, j)
+                    m.set_block(i, j, coo_matrix((d[pre + 'val'], (d[pre + 'row'], d[pre + 'col'])), shape=tuple(d[pre + 'shape'])))
+        return m
+    sym, num = matrix('sym'), matrix('num')
+    rhs = BlockVector(N + 1)
+    for i in range(N + 1):
+        rhs.set_block(i, d['rhs_%d' % i])
+    Kd = num.toarray()
+    Kd = np.tril(Kd) + np.tril(Kd, -1).T
+    x_ref = np.linalg.solve(Kd, rhs.flatten())
+    solver = new_solver(make_engine, N, result_buffers=2 if device_vectors else 0)
+    assert solver.do_symbolic_factorization(sym).status == LinearSolverStatus.successful
+    assert solver.do_numeric_factorization(num).status == LinearSolverStatus.successful
+    if not device_vectors:
+        x = solver.do_back_solve(rhs)
+        assert solver.last_residual_first > 1e-3 and solver.last_residual <= 1e-8 and solver.refinement_steps >= 1
+        assert scaled_residual(Kd, x.flatten(), rhs.flatten()) <= 1e-8
+        assert np.abs(x.flatten() - x_ref).max() <= 1e-6 * np.abs(x_ref).max()
+        # unchecked, the same factors hand out the inaccurate solution (what rounds 1-5 did)
+        solver.residual_check = False
+        x_bad = solver.do_back_solve(rhs)
+        assert scaled_residual(Kd, x_bad.flatten(), rhs.flatten()) > 1e-4
+        return
+    rd = solver.device_vector_from_host(rhs)
+    x1 = solver.do_back_solve(rd).to_host(rhs).flatten()
+    steps = solver.refinement_steps
+    assert steps >= 1 and solver.last_residual <= 1e-8 and scaled_residual(Kd, x1, rhs.flatten()) <= 1e-8
+    xd = solver.do_back_solve_deferred(rd)
+    assert solver._deferred_solve is not None
+    confirmed = solver.confirm_solution()
+    assert confirmed is xd and solver.solution_changed_on_confirm and solver.refinement_steps == 2 * steps
+    assert np.array_equal(confirmed.to_host(rhs).flatten(), x1)
+    # a pending verdict is collected by whatever the caller does next with the solver
+    solver.do_back_solve_deferred(rd)
+    assert solver.do_numeric_factorization(num).status == LinearSolverStatus.successful and solver._deferred_solve is None
+    assert solver.refinement_steps == 3 * steps

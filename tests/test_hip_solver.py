@@ -675,6 +675,13 @@ def test_pivot_growth_guard():
     sc.case_growth_guard(make_engine)
 
 
+@pytest.mark.parametrize('device_vectors', [False, True])
+def test_inaccurate_pivot_sequence_is_refined_on_the_device(device_vectors):
+    """tests/golden/refinement_case.npz through the C ABI: pp_residual finds the backward error of 0.48, the correction solves
+    of pp_refine_begin / _end bring it below 1e-8 -- host containers, device vectors, the deferred form."""
+    sc.case_refinement_fixture(make_engine, device_vectors=device_vectors)
+
+
 def test_adversarial_systems_are_never_returned_inaccurate_on_the_device():
     """>= 400 adversarial systems x 6 factorisations through the C ABI: k_residual / the refinement bracket / the repair path
     of the product (csrc/refine.hip), every handed-out solution against dense algebra."""

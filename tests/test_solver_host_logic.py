@@ -160,6 +160,15 @@ def test_random_systems_in_random_input_forms():
     assert not bad, bad
 
 
+def test_inaccurate_pivot_sequence_is_refined_host_containers():
+    sc.case_refinement_fixture(HostSimEngine)
+
+
+def test_inaccurate_pivot_sequence_is_refined_device_vectors_blocking_and_deferred():
+    from hostsim_engine import HostSimDeviceEngine
+    sc.case_refinement_fixture(HostSimDeviceEngine, device_vectors=True)
+
+
 def test_adversarial_systems_are_never_returned_inaccurate():
     from hostsim_engine import HostSimBoundaryEngine
     sc.case_adversarial_systems(HostSimBoundaryEngine)
