@@ -1472,13 +1472,51 @@ int pp_copy_rows(int nrows, int nthreads, const double* const* src, const int64_
 }
 
 // pinned host memory for staging arrays / result buffers of the host boundary (hipHostMalloc; NULL on failure)
+// (bounded: page-locked memory is taken from what the whole machine can use -- a caller that keeps asking, e.g. many
+// solver objects with result pools, gets NULL beyond PP_PINNED_LIMIT_MB (default 16 GiB per process) and falls back to
+// pageable arrays, instead of driving the host out of lockable memory)
+namespace {
+std::mutex g_pin_mu;
+std::map<void*, int64_t> g_pin_sizes;
+int64_t g_pin_total = 0;
+int64_t pin_limit() {
+  static const int64_t lim = [] {
+    const char* e = pp::env_switch("PP_PINNED_LIMIT_MB");
+    const int64_t mb = e ? std::atoll(e) : 16384;
+    return (mb > 0 ? mb : 16384) * (int64_t)1048576;
+  }();
+  return lim;
+}
+}  // namespace
+
 void* pp_host_alloc(int64_t bytes) {
   void* p = nullptr;
-  if (bytes <= 0 || hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (bytes <= 0) return nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    if (g_pin_total + bytes > pin_limit()) return nullptr;
+    g_pin_total += bytes;
+  }
+  if (hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    g_pin_total -= bytes;
+    return nullptr;
+  }
+  std::lock_guard<std::mutex> lk(g_pin_mu);
+  g_pin_sizes[p] = bytes;
   return p;
 }
 
-void pp_host_free(void* p) { if (p) (void)hipHostFree(p); }
+void pp_host_free(void* p) {
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    auto it = g_pin_sizes.find(p);
+    if (it != g_pin_sizes.end()) { g_pin_total -= it->second; g_pin_sizes.erase(it); }
+  }
+  (void)hipHostFree(p);
+}
 
 int pp_set_pivot_tolerance(pp_handle h, double u_symbolic, double u_runtime) {
   if (!h) return 3;

@@ -671,6 +671,28 @@ def test_bench_line_reports_the_ip_loop_and_the_boundary_rate():
     assert max(bur['final_infeasibilities']) <= 1e-8 and bur['iterations'] <= 8
 
 
+def test_pinned_host_memory_is_bounded():
+    """pp_host_alloc hands out at most PP_PINNED_LIMIT_MB of page-locked memory per process (NULL beyond: the engine's
+    pageable fallback) and gives freed memory back to the budget."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import ctypes, numpy as np\n"
+        "from parapint_amd.linalg.hip_engine import HipEngine\n"
+        "e = HipEngine(); lib = e.lib\n"
+        "a = lib.pp_host_alloc(ctypes.c_int64(3 << 20)); assert a\n"
+        "b = lib.pp_host_alloc(ctypes.c_int64(2 << 20)); assert not b          # 3 + 2 MiB > 4 MiB\n"
+        "lib.pp_host_free(a)\n"
+        "c = lib.pp_host_alloc(ctypes.c_int64(4 << 20)); assert c; lib.pp_host_free(c)\n"
+        "big = e.alloc_pinned((1 << 20,)); assert big.shape == (1 << 20,) and float(big.sum()) == 0.0   # 8 MiB: pageable fallback\n"
+        "print('pinned cap ok')\n") % root
+    env = dict(os.environ, PP_PINNED_LIMIT_MB='4')
+    out = subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert out.returncode == 0 and 'pinned cap ok' in out.stdout.decode(), out.stdout.decode()[-2000:]
+
+
 def test_pivot_growth_guard():
     sc.case_growth_guard(make_engine)
 
