@@ -530,7 +530,8 @@ int pp_residual(pp_handle h, int store, const double* bc_dev, int coupling_on_de
   // a block-tridiagonal S factorised from a flat Q leaves the coupling rows to the caller
   int Qfin = -1;
   if (coupling_on_device) Qfin = h->btd ? (h->corner_nnz >= 0 ? 2 : -1) : (h->have_Q ? 1 : 0);
-  if (coupling_on_device && Qfin < 0) return fail(h, 3, "pp_residual: no Q on the device for the coupling rows (block-tridiagonal S factorised from a flat Q)");
+  // (a block-tridiagonal S factorised from a flat Q: one rank hands the coupling rows to the caller, as with coupling_on_device = 0)
+  if (ranks && Qfin < 0) return fail(h, 3, "pp_residual: no Q on the device for the coupling rows (block-tridiagonal S factorised from a flat Q)");
   const int Qmode = (ranks || Qfin == 2) ? -2 : Qfin;
   h->resid_rc_valid = false;
   bool any_mapped = ng == 0;
