@@ -166,6 +166,7 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, SolutionCheckMixin, Coupl
         # of them (1: every call; 0: never beyond the byte budget).
         self.pattern_check_interval = 8
         self.pattern_check_bytes = 4 << 20
+        self.constant_sample_blocks = 8     # declare_constant_entries(check=None): blocks per group and call whose declared entries are compared
         self._stage_calls = 0
         self._index_records = {}            # id(index array) -> (array, size, address, checksum)
         self._index_sets = {}               # ids of a block's four index arrays -> the tuple of them (shared by blocks)
@@ -394,8 +395,13 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, SolutionCheckMixin, Coupl
         started = [False]
         self._stage_calls += 1
         full = self.pattern_check_interval > 0 and self._stage_calls % self.pattern_check_interval == 0
-        violations = []                 # blocks whose entries declared constant changed (declare_constant_entries, check=True)
+        violations = []                 # blocks whose entries declared constant changed (declare_constant_entries)
         check_now = bool(self._constant_check)
+        # check=None (default): a rotating sample -- every `stride`-th block of a group, another residue at every call -- is
+        # compared on the host (8 blocks of 1024 at C3: 0.1 ms); a producer that changes a "constant" for all its blocks is
+        # caught at once, a single deviating block within `stride` calls (and heals at the periodic full staging either way)
+        sampled = self._constant_check is None and self._constant_entries is not None
+        sample_n = self.constant_sample_blocks
         records, memo = self._index_records, {}
         budget = [self.pattern_check_bytes]
 
@@ -458,7 +464,11 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, SolutionCheckMixin, Coupl
                             if ok is None:
                                 ok = setok[id(cs)] = intact(cs[0]) and intact(cs[1]) and intact(cs[2]) and intact(cs[3])
                             if ok:
-                                if check_now and g.const_src is not None and g.full_rows is not None and g.full_rows[bi.slot]:
+                                look = check_now
+                                if sampled and not look and sample_n > 0:
+                                    stride = max(1, len(g.blocks) // sample_n)
+                                    look = bi.slot % stride == self._stage_calls % stride
+                                if look and g.const_src is not None and g.full_rows is not None and g.full_rows[bi.slot]:
                                     # (check=True: the entries declared constant against the staging row -- a debugging aid)
                                     src, nK = g.const_src, g.nrawK
                                     k_part = src < nK
@@ -608,9 +618,13 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, SolutionCheckMixin, Coupl
                     kd = np.array(addrs, dtype=np.uint64)
                 bd = kd + np.uint64(8 * nK) if nB else np.zeros(kd.size, dtype=np.uint64)
                 started = True
-                if self._constant_check and g.const_src is not None and g.full_rows is not None:
+                sampled = self._constant_check is None and self._constant_entries is not None and self.constant_sample_blocks > 0
+                if (self._constant_check or sampled) and g.const_src is not None and g.full_rows is not None:
                     src, dst = g.const_src, g.const_dst
+                    stride = max(1, len(g.blocks) // self.constant_sample_blocks) if sampled else 1
                     for slot, ndx in enumerate(g.blocks):
+                        if sampled and slot % stride != self._stage_calls % stride:
+                            continue
                         if g.full_rows[slot]:
                             v = vals[rows[slot]] if two_d else vals[ndx]
                             if not np.array_equal(v[src], g.staging[slot][dst]):
@@ -685,9 +699,11 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, SolutionCheckMixin, Coupl
         declaration.  Effect: for a block whose staging row already holds all its entries the library's staging threads are
         given the runs of the OTHER entries only (pp_stage_upload_verified_begin: compare and copy) -- host COO blocks or flat
         value vectors in; the device interface has its value maps for that.  At every `pattern_check_interval`-th call every
-        entry is staged again (a declaration that does not hold heals there); check=True (a debugging aid, on the host):
-        the declared entries are compared with the staging rows at every call, what changed is staged in full and the
-        factorisation returns an error status that names the blocks."""
+        entry is staged again (a declaration that does not hold heals there).  check=None (default): at every call the declared
+        entries of a rotating sample of blocks (`constant_sample_blocks` = 8 per group) are compared with the staging rows on the
+        host -- a producer that changes a "constant" for all its blocks is caught at the first call; check=True: all blocks at
+        every call (a debugging aid); check=False: none.  What changed is staged in full and the factorisation returns an error
+        status that names the blocks."""
         if not getattr(self, '_groups', None) or getattr(self, 'plan_stats', None) is None:
             raise RuntimeError('declare_constant_entries: call do_symbolic_factorization first')
         self._constant_entries = None if constant is None else dict(constant)

@@ -970,8 +970,28 @@ def case_constant_entries(make_engine, calls=None):
     assert decl.do_numeric_factorization(k).status == LinearSolverStatus.successful
     x = decl.do_back_solve(rhs)
     assert scaled_residual(k.toarray(), x.flatten(), rhs.flatten()) <= 1e-10
-    # default: every `pattern_check_interval`-th call stages every entry again -- a declaration that does not hold heals there
+    # default (check=None): a rotating sample of blocks is compared at every call -- with six blocks every one of them, so the
+    # violation is reported at once, and the values handed over are used all the same
     decl.declare_constant_entries(model.constant_entries())
+    assert decl.do_numeric_factorization(k).status == LinearSolverStatus.successful           # (same values as staged: clean)
+    K2.data[e_const] *= 1.1
+    res = decl.do_numeric_factorization(k, raise_on_error=False)
+    assert res.status == LinearSolverStatus.error and 'declared constant' in decl._last_error
+    assert decl.do_numeric_factorization(k).status == LinearSolverStatus.successful
+    assert scaled_residual(k.toarray(), decl.do_back_solve(rhs).flatten(), rhs.flatten()) <= 1e-10
+    # ... with many blocks per group only `constant_sample_blocks` of them per call (a rotating residue class)
+    decl.constant_sample_blocks = 2             # stride 3: blocks {0, 3}, {1, 4}, {2, 5} in turn
+    hits = 0
+    for rep in range(3):
+        K2.data[e_const] *= 1.1
+        hits += decl.do_numeric_factorization(k, raise_on_error=False).status == LinearSolverStatus.error
+        decl.do_numeric_factorization(k, raise_on_error=False)      # (the call after a report stages block 2 in full: clean again)
+    assert 1 <= hits <= 3
+    decl.constant_sample_blocks = 8
+    # check=False: no comparison -- every `pattern_check_interval`-th call stages every entry again, a declaration that does
+    # not hold heals there
+    decl.declare_constant_entries(model.constant_entries(), check=False)
+    assert decl.do_numeric_factorization(k).status == LinearSolverStatus.successful
     decl.pattern_check_interval = 3
     K2.data[e_const] *= 0.8
     decl._stage_calls = 0                       # (the third call from here is the one that stages every entry)
