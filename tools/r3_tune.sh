@@ -7,8 +7,8 @@ for a in "$@"; do
   if [ "$var" = base ]; then unset PP_LIB_VARIANT; else export PP_LIB_VARIANT=$var; fi
   tag=$(echo $a | tr ',=.:' '____')
   for blocks in 0 128; do
-    PP_PLAN_TUNE=$v timeout -k 10 300 python bench.py --no-cpu-baseline --no-boundary --blocks $blocks --steps 30 > gpurun_out/r3_tune/b${blocks}_$tag.json 2> gpurun_out/r3_tune/b${blocks}_$tag.err || { echo "$a FAILED"; tail -3 gpurun_out/r3_tune/b${blocks}_$tag.err; continue; }
-    python - <<PY
+    PP_PLAN_TUNE=$v timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-boundary --no-ip-loop --no-shares --blocks $blocks --steps 30 > gpurun_out/r3_tune/b${blocks}_$tag.json 2> gpurun_out/r3_tune/b${blocks}_$tag.err || { echo "$a FAILED"; tail -3 gpurun_out/r3_tune/b${blocks}_$tag.err; continue; }
+    python3 - <<PY
 import json
 d=json.loads(open("gpurun_out/r3_tune/b${blocks}_$tag.json").read().strip().splitlines()[-1])
 ph=d['phases']
