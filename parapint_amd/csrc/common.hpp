@@ -239,7 +239,7 @@ struct Group {
   const int *res_ptr = nullptr, *res_vraw = nullptr, *res_xnew = nullptr, *res_xold = nullptr;
   const int *res_brow_new = nullptr, *res_brow_old = nullptr;      // row (elimination order / caller's order) of every position of the execution order
   const int *res_bptr = nullptr, *res_bvraw = nullptr, *res_bxnew = nullptr, *res_bxold = nullptr;
-  int res_ne = 0, res_bne = 0;
+  int res_ne = 0, res_bne = 0, res_nrows = 0;
   std::vector<int> res_vraw_host, res_bvraw_host;
   int *res_vsrc = nullptr, *res_bvsrc = nullptr;
   double *res_csrc = nullptr, *res_bcsrc = nullptr;

@@ -40,7 +40,7 @@ struct ResArgs {
   double* Rout;
   unsigned long long *rmax, *smax;
   double *bpart, *ax;                                // border partial sums [chunk][2][nc] (uniform groups) / coupling sums (mapped)
-  int nres_wg, ny, rows_per_wg, nc_glob;
+  int nres_wg, ny, rows_per_wg, nc_glob, nrows;      // nrows: rows the check evaluates (positions of the execution order)
 };
 
 // NV instances per lane (as in factor.hip).  vrow < 0: the constant 1.  xcol >= 0: row of X; xcol < 0: coupling value
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(64 * RES_NW) void k_residual(GroupDev g, ResArgs a,
   __shared__ double red[RES_NW][2 * NV][64];
   const unsigned b = (unsigned)(((blockIdx.x % (unsigned)a.ny) * 64 + lane) * NV);
   const int c0 = ((int)(blockIdx.x / (unsigned)a.ny) * RES_NW + wave) * a.rows_per_wg;
-  const int c1 = min(c0 + a.rows_per_wg, g.n);
+  const int c1 = min(c0 + a.rows_per_wg, a.nrows);
   // (the records as restrict-qualified kernel parameters, and no store inside the row loop unless STORE: through the
   // argument struct, or with stores in between, the compiler fetches every record with a vector load + v_readfirstlane
   // instead of a scalar load -- measured 125 against 95 us at C3)
@@ -412,8 +412,26 @@ int ppi_build_residual_records(pp_handle h, Group* g, const std::vector<int>& ra
     }
     std::reverse(order.begin(), order.end());
   }
-  std::vector<int> ptr((size_t)n + 1, 0), vraw, xnew, xold, brow_new((size_t)n), brow_old((size_t)n);
-  for (int pos = 0; pos < n; ++pos) {
+  // Rows that hold by construction are not evaluated: a 1 x 1 pivot column c without incoming entries (a leaf of the
+  // elimination tree: d_c = K_cc, l_ic = K_ic / d_c over exactly its neighbours, y_c = b_c) gets
+  // x_c = b_c / d_c - sum_i l_ic x_i from the backward sweep, so b_c - K_cc x_c - sum_i K_ic x_i is the rounding of these few
+  // operations whatever the other pivots did -- relative to the row's own terms always O(eps).  (C3: 4000 of 9200 rows, 22 %
+  // of the records; a refinement step leaves them at zero: the residual vector is cleared when it is allocated.)
+  {
+    std::vector<int> kept;
+    kept.reserve((size_t)n);
+    for (int c : order) {
+      const int pv = P.piv_of_col[(size_t)c];
+      const bool exact = P.piv_w[(size_t)pv] == 1 && P.sfwd_eptr[(size_t)c + 1] == P.sfwd_eptr[(size_t)c] &&
+                         (P.piv_chain.empty() || P.piv_chain[(size_t)pv] < 0) && pv != P.front_piv;
+      if (!exact) kept.push_back(c);
+    }
+    order.swap(kept);
+  }
+  const int nrows = (int)order.size();
+  g->res_nrows = nrows;
+  std::vector<int> ptr((size_t)nrows + 1, 0), vraw, xnew, xold, brow_new((size_t)std::max(nrows, 1)), brow_old((size_t)std::max(nrows, 1));
+  for (int pos = 0; pos < nrows; ++pos) {
     const int c = order[(size_t)pos];
     brow_new[(size_t)pos] = c;
     brow_old[(size_t)pos] = P.perm[(size_t)c];
@@ -572,6 +590,7 @@ int pp_residual(pp_handle h, int store, const double* bc_dev, int coupling_on_de
         std::lock_guard<std::mutex> lk(h->alloc_mu);
         if (int rc = value_alloc(h, g, &g->res_R, (size_t)P.n * (size_t)d.bpad)) return rc;
         if (int rc = value_alloc(h, g, &g->res_D, (size_t)P.n * (size_t)d.bpad)) return rc;
+        PP_HIP(hipMemsetAsync(g->res_R, 0, (size_t)P.n * (size_t)d.bpad * sizeof(double), st));      // (rows that are not evaluated stay zero)
       }
       a.Rout = g->res_R;             // caller's row order: the correction solve runs on native vectors
       a.rrow = g->res_brow_old;
@@ -580,15 +599,17 @@ int pp_residual(pp_handle h, int store, const double* bc_dev, int coupling_on_de
     a.rmax = g->res_rmax; a.smax = g->res_smax;
     a.bpart = g->res_bpart; a.ax = h->resid_ax; a.nc_glob = nc;
     // rows per wave: enough waves to fill the chip several times over, few enough atomics (measured at C3: tools/sweep_env.sh PP_RES_ROWS)
-    a.rows_per_wg = rows_env > 0 ? rows_env : 2;          // (x RES_NW = 8 waves: 16 rows per workgroup.  MEASURED at C3, kernel alone: 1 wave x 8 rows 97 us; reverse Cuthill-McKee order 4 x 8 rows 83.5; 8 x 2 rows 69.1; 16 x 2 rows 78.1; 16 x 1 94.9)
-    const unsigned ntask = (unsigned)((P.n + a.rows_per_wg * RES_NW - 1) / (a.rows_per_wg * RES_NW));
+    a.rows_per_wg = rows_env > 0 ? rows_env : 1;          // (x RES_NW = 8 waves: 8 rows per workgroup.  MEASURED at C3, kernel alone: 1 wave x 8 rows 97 us; reverse Cuthill-McKee order 4 x 8 rows 83.5; 8 x 2 rows 69.1; 16 x 2 rows 78.1; 16 x 1 94.9; without the rows that hold by construction 8 x 1 / 2 / 3 / 4 rows: 51.6 / 56.2 / 55.0 / 57.7)
+    a.nrows = g->res_nrows;
+    const unsigned ntask = (unsigned)((g->res_nrows + a.rows_per_wg * RES_NW - 1) / (a.rows_per_wg * RES_NW));
     const unsigned nborder = ((unsigned)d.nc * (unsigned)d.nchunk + RES_NW - 1) / RES_NW;
     const bool pair = h->lane_pairs && d.nchunk % 2 == 0;
     a.ny = pair ? d.nchunk / 2 : d.nchunk;
     a.nres_wg = (int)(ntask * (unsigned)a.ny);
 #define PP_LAUNCH_RES(NV, ST) hipLaunchKernelGGL((k_residual<NV, ST>), dim3((unsigned)a.nres_wg + nborder), dim3(64 * RES_NW), 0, st, d, a, a.rptr, \
                                                 a.vrow, a.xcol, a.brow, a.coef, a.V, a.B, a.X, a.xc)
-    if (pair) { if (store) PP_LAUNCH_RES(2, true); else PP_LAUNCH_RES(2, false); }
+    if ((unsigned)a.nres_wg + nborder == 0u) {}          // (every row holds by construction and there is no coupling row: nothing to launch)
+    else if (pair) { if (store) PP_LAUNCH_RES(2, true); else PP_LAUNCH_RES(2, false); }
     else { if (store) PP_LAUNCH_RES(1, true); else PP_LAUNCH_RES(1, false); }
 #undef PP_LAUNCH_RES
     const bool uniform = !d.cmapT && d.nc == nc && d.nc > 0;
