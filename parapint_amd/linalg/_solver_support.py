@@ -154,6 +154,7 @@ class _Group(object):
         self._ref32 = self._refptr = None   # int32 copies of raw_refs and their addresses (stage_upload)
         self.var_runs = None                # (runsK, runsB) over the entries not declared constant (declare_constant_entries)
         self.const_src = self.const_dst = None     # raw entry / compact position of the read entries that ARE declared constant
+        self.const_parts = None
         self.full_rows = None               # per slot: the staging row holds every entry of its block (made with the staging array)
 
     # Buffers of the HOST boundary (page-locked when the engine can: ~12 ms per allocation).  A caller that keeps values,
@@ -215,6 +216,9 @@ class _Group(object):
             return None
         self.const_dst = np.flatnonzero(~keep)
         self.const_src = self.used[self.const_dst]
+        # (split once into the K part and the border part: the per-call comparison of sampled blocks indexes with these)
+        k_part = self.const_src < self.nrawK
+        self.const_parts = (self.const_src[k_part], self.const_dst[k_part], self.const_src[~k_part] - self.nrawK, self.const_dst[~k_part])
         return self._runs(self.used, self.nrawK, select=keep, gap=gap)
 
     def canonical_from_compact(self, row):

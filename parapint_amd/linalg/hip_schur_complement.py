@@ -166,7 +166,7 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, SolutionCheckMixin, Coupl
         # of them (1: every call; 0: never beyond the byte budget).
         self.pattern_check_interval = 8
         self.pattern_check_bytes = 4 << 20
-        self.constant_sample_blocks = 8     # declare_constant_entries(check=None): blocks per group and call whose declared entries are compared
+        self.constant_sample_blocks = 2     # declare_constant_entries(check=None): blocks per group and call whose declared entries are compared (0.1 ms each at C3)
         self._stage_calls = 0
         self._index_records = {}            # id(index array) -> (array, size, address, checksum)
         self._index_sets = {}               # ids of a block's four index arrays -> the tuple of them (shared by blocks)
@@ -398,10 +398,11 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, SolutionCheckMixin, Coupl
         violations = []                 # blocks whose entries declared constant changed (declare_constant_entries)
         check_now = bool(self._constant_check)
         # check=None (default): a rotating sample -- every `stride`-th block of a group, another residue at every call -- is
-        # compared on the host (8 blocks of 1024 at C3: 0.1 ms); a producer that changes a "constant" for all its blocks is
+        # compared on the host (2 blocks of 1024 at C3: 0.2 ms); a producer that changes a "constant" for all its blocks is
         # caught at once, a single deviating block within `stride` calls (and heals at the periodic full staging either way)
         sampled = self._constant_check is None and self._constant_entries is not None
         sample_n = self.constant_sample_blocks
+        sample_slots = {}
         records, memo = self._index_records, {}
         budget = [self.pattern_check_bytes]
 
@@ -465,16 +466,18 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, SolutionCheckMixin, Coupl
                                 ok = setok[id(cs)] = intact(cs[0]) and intact(cs[1]) and intact(cs[2]) and intact(cs[3])
                             if ok:
                                 look = check_now
-                                if sampled and not look and sample_n > 0:
-                                    stride = max(1, len(g.blocks) // sample_n)
-                                    look = bi.slot % stride == self._stage_calls % stride
+                                if sampled and not look:
+                                    ss = sample_slots.get(g.gid)
+                                    if ss is None:          # (this call's residue class of the group's slots)
+                                        stride = max(1, len(g.blocks) // max(sample_n, 1))
+                                        ss = sample_slots[g.gid] = frozenset(range(self._stage_calls % stride, len(g.blocks), stride)) \
+                                            if sample_n > 0 else frozenset()
+                                    look = bi.slot in ss
                                 if look and g.const_src is not None and g.full_rows is not None and g.full_rows[bi.slot]:
                                     # (check=True: the entries declared constant against the staging row -- a debugging aid)
-                                    src, nK = g.const_src, g.nrawK
-                                    k_part = src < nK
+                                    sK, dK, sB, dB = g.const_parts
                                     row = g.staging[bi.slot]
-                                    if not (np.array_equal(kd[src[k_part]], row[g.const_dst[k_part]]) and
-                                            np.array_equal(bd[src[~k_part] - nK], row[g.const_dst[~k_part]])):
+                                    if not (np.array_equal(kd[sK], row[dK]) and np.array_equal(bd[sB], row[dB])):
                                         violations.append(ndx)
                                         g.full_rows[bi.slot] = False         # (staged over every entry below)
                                 q = quick.get(g.gid)
@@ -700,7 +703,7 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, SolutionCheckMixin, Coupl
         given the runs of the OTHER entries only (pp_stage_upload_verified_begin: compare and copy) -- host COO blocks or flat
         value vectors in; the device interface has its value maps for that.  At every `pattern_check_interval`-th call every
         entry is staged again (a declaration that does not hold heals there).  check=None (default): at every call the declared
-        entries of a rotating sample of blocks (`constant_sample_blocks` = 8 per group) are compared with the staging rows on the
+        entries of a rotating sample of blocks (`constant_sample_blocks` = 2 per group) are compared with the staging rows on the
         host -- a producer that changes a "constant" for all its blocks is caught at the first call; check=True: all blocks at
         every call (a debugging aid); check=False: none.  What changed is staged in full and the factorisation returns an error
         status that names the blocks."""

@@ -970,8 +970,9 @@ def case_constant_entries(make_engine, calls=None):
     assert decl.do_numeric_factorization(k).status == LinearSolverStatus.successful
     x = decl.do_back_solve(rhs)
     assert scaled_residual(k.toarray(), x.flatten(), rhs.flatten()) <= 1e-10
-    # default (check=None): a rotating sample of blocks is compared at every call -- with six blocks every one of them, so the
+    # default (check=None): a rotating sample of blocks is compared at every call -- with a sample of six all of them, so the
     # violation is reported at once, and the values handed over are used all the same
+    decl.constant_sample_blocks = 6
     decl.declare_constant_entries(model.constant_entries())
     assert decl.do_numeric_factorization(k).status == LinearSolverStatus.successful           # (same values as staged: clean)
     K2.data[e_const] *= 1.1
@@ -987,7 +988,7 @@ def case_constant_entries(make_engine, calls=None):
         hits += decl.do_numeric_factorization(k, raise_on_error=False).status == LinearSolverStatus.error
         decl.do_numeric_factorization(k, raise_on_error=False)      # (the call after a report stages block 2 in full: clean again)
     assert 1 <= hits <= 3
-    decl.constant_sample_blocks = 8
+    decl.constant_sample_blocks = 2
     # check=False: no comparison -- every `pattern_check_interval`-th call stages every entry again, a declaration that does
     # not hold heals there
     decl.declare_constant_entries(model.constant_entries(), check=False)
