@@ -836,7 +836,8 @@ def main():
             'metric': METRIC, 'value': value, 'unit': 'it/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': args.scaling,
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': describe + '; per step 1 do_numeric_factorization + 1 do_back_solve through the '
+            'config': {'workload': describe + '; per step 1 do_numeric_factorization + 1 do_back_solve (every back-solve '
+                                   'checked on the device before it returns: value_unchecked is the step without) through the '
                                    'LinearSolverInterface methods on device-resident containers, fresh values each step '
                                    '(%d value sets in HBM cycled, every Hessian entry of every block differs)' % nsets,
                        'blocks_per_gpu': B, 'world_size': world, 'collective_backend': backend,
