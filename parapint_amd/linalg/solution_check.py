@@ -110,10 +110,10 @@ class SolutionCheckMixin(object):
         library's order (numpy array / device tensor; both None: zero).  Returns None if the solution in the engine's
         vectors is accurate, else this rank's (rho of its worst block, group, slot)."""
         self._check_bc_host, self._check_bc_dev = bc_host, bc_dev
+        steps = 0
         try:
             rho, mine = self._rho(begun=begun)
             self.last_residual_first = rho
-            steps = 0
             while rho > self.refine_tolerance and np.isfinite(rho) and steps < self.max_refinement_steps:
                 if steps == 0:
                     rho, mine = self._rho(store=True)        # (the same residual once more, kept as the right-hand side)
