@@ -379,6 +379,21 @@ class HostSimBoundaryEngine(HostSimEngine):
         super().__init__()
         self.calls = {'stage_upload': 0, 'stage_upload_verified': 0, 'upload_rhs_rows': 0, 'download_rows_async': 0,
                       'download_rows_staged': 0, 'copy_rows': 0, 'compared_blocks': 0, 'verified_blocks': 0}
+        # the library's view of the staging rows, kept apart from the solver's own flags (_Group.full_rows): a row holds every
+        # entry of its block once all runs were staged into it or the solver wrote it whole and sent it; a subset of the runs
+        # (declare_constant_entries) may only be staged into such a row
+        self._rows_whole = {}
+
+    def _whole_flags(self, gid, staging):
+        rec = self._rows_whole.get(gid)
+        if rec is None or rec[0] is not staging:
+            rec = self._rows_whole[gid] = (staging, np.zeros(staging.shape[0], dtype=bool))
+        return rec[1]
+
+    def upload_values_compact(self, gid, compact, row0=0, nrows=None):
+        n = compact.shape[0] - row0 if nrows is None else nrows
+        self._whole_flags(gid, compact)[row0:row0 + n] = True
+        super().upload_values_compact(gid, compact, row0, nrows)
 
     @staticmethod
     def _view(addr, n, dtype=np.double):
@@ -400,7 +415,7 @@ class HostSimBoundaryEngine(HostSimEngine):
             row[dst:dst + ln] = kd[e0:e0 + ln]
         for e0, ln, dst in g.runsB:
             row[dst:dst + ln] = bd[e0:e0 + ln]
-        self.upload_values_compact(g.gid, g.staging, slot, 1)
+        self.upload_values_compact(g.gid, g.staging, slot, 1)      # (marks the row whole)
 
     def stage_upload(self, g, items, full_check=True):
         self.calls['stage_upload'] += 1
@@ -427,6 +442,9 @@ class HostSimBoundaryEngine(HostSimEngine):
                 self._stage_row(g, slot, kd, bd)
             else:
                 self.calls['variable_entries'] = self.calls.get('variable_entries', 0) + int(runs[0][:, 1].sum() + runs[1][:, 1].sum())
+                if not self._whole_flags(g.gid, g.staging)[slot]:
+                    raise AssertionError('a subset of the runs staged into row %d of group %d, which does not hold every entry '
+                                         'of its block' % (slot, g.gid))
                 row = g.staging[slot]
                 for e0, ln, dst in runs[0]:
                     row[dst:dst + ln] = kd[e0:e0 + ln]

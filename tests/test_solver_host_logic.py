@@ -119,6 +119,35 @@ def test_flat_value_vectors_over_the_symbolic_pattern():
     sc.case_flat_values(HostSimBoundaryEngine)
 
 
+def test_host_engine_refuses_a_subset_of_runs_for_a_row_that_is_not_whole():
+    """The interpreter keeps its own record of which staging rows hold every entry of their block (what the library's
+    staging rows are to the product): a solver whose flags claim more than that -- here set by hand -- is caught when it
+    hands over the runs of the variable entries only."""
+    import numpy as np
+    from parapint_amd.examples.performance.schur_complement.synthetic_kkt import SyntheticKKT
+    from parapint_amd.linalg.comm import SerialComm
+    N = 4
+    model = SyntheticKKT(N, 3, 8, 2)
+    comm = SerialComm()
+    solver = sc.new_solver(HostSimBoundaryEngine, N)
+    solver.do_symbolic_factorization(model.build_kkt(comm=comm, iteration=0))
+    solver.declare_constant_entries(model.constant_entries())
+    k = model.build_kkt(comm=comm, iteration=0)
+    solver.do_numeric_factorization(k)                      # (first pass: index arrays compared, rows staged whole)
+    solver.do_numeric_factorization(k)
+    whole = [rec[1].copy() for rec in solver._eng._rows_whole.values()]
+    assert whole and all(w.all() for w in whole)
+    for g in solver._groups:                                # a new staging array whose rows the solver wrongly takes for whole
+        g._staging = None
+        _ = g.staging
+        g.full_rows[:] = True
+    try:
+        solver.do_numeric_factorization(k)
+        raise AssertionError('the subset of runs went into rows that hold nothing')
+    except AssertionError as e:
+        assert 'does not hold every entry' in str(e)
+
+
 def test_bench_host_boundary_section_on_the_host_engine():
     """bench.py's host-boundary legs (COO blocks; constant entries declared; flat value vectors, with and without the
     declaration) with the solver class on the host-simulation engine: every leg returns a rate, a residual and the phases."""
