@@ -1,0 +1,133 @@
+"""Unsymmetric diagonal blocks: the general-LU semantics of the reference's ``ScipyInterface`` (both triangles read, any
+square matrix accepted: parapint/linalg/scipy_interface.py:26-31; the reference's own tests of the Schur-complement solver
+use such blocks: linalg/schur_complement/tests/test_explicit_schur_complement.py:15-31, test_mpi_explicit_schur_complement.py)
+carried by the symmetric kernels of this package.
+
+The system the reference solves with LU sub-solvers is ``M x = b``, ``M = [[K, A^T], [A, Q]]`` with K block diagonal and
+not necessarily symmetric (its right border is always the transpose of the last block row: mpi_...:33-125).  M x = b
+together with M^T y = 0 is the SYMMETRIC system
+
+    [ 0    M ] [y]   [b]
+    [ M^T  0 ] [x] = [0]
+
+and, with the unknowns of every block kept together -- (y_i, x_i) per diagonal block, (y_c, x_c) for the coupling
+variables --, it has the block-bordered shape of the original again:
+
+    diagonal block i   [[0, K_i], [K_i^T, 0]]        border block i   [[0, A_i], [A_i, 0]]        corner   [[0, Q], [Q^T, 0]]
+
+at twice the dimensions.  It is factorised and solved by the symmetric path unchanged (every pivot of it is a 2 x 2 or
+4 x 4 block: the static pivot choice pairs row i of y with a column of x, which is an LU pivot of K_i); the a-posteriori
+check of every back-solve (solution_check.py) holds for it as for any other system.  y = 0 is discarded.
+
+What is NOT carried over: the inertia.  The reference's ScipyInterface counts eigenvalues of the unsymmetric matrix with a
+dense eigensolver on the host (scipy_interface.py:39-44); the embedded matrix has inertia (N, N, 0) whatever M is, so
+``get_inertia`` raises for a factorisation that went this way.  Symmetric input never comes here.
+"""
+import numpy as np
+from scipy.sparse import coo_matrix
+
+from parapint_amd.sparse.block_containers import BlockMatrix, BlockVector, MPIBlockMatrix, MPIBlockVector
+
+
+def is_symmetric(m):
+    """Exactly symmetric (duplicates summed): what decides between the symmetric path and the embedding."""
+    if m is None:
+        return True
+    if m.shape[0] != m.shape[1]:
+        return False
+    c = m.tocsr()
+    d = c - c.T
+    return d.nnz == 0 or not np.any(d.data != 0.0)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def embed_square(K):
+    """n x n  ->  [[0, K], [K^T, 0]]  (2n x 2n, both triangles)."""
+    K = K.tocoo()
+    n = K.shape[0]
+    r, c, d = K.row, K.col, np.asarray(K.data, dtype=np.double)
+    return coo_matrix((np.concatenate([d, d]), (_i32(np.concatenate([r, c + n])), _i32(np.concatenate([c + n, r])))),
+                      shape=(2 * n, 2 * n))
+
+
+def embed_border(A):
+    """n_c x n  ->  [[0, A], [A, 0]]  (2 n_c x 2n)."""
+    A = A.tocoo()
+    nc, n = A.shape
+    r, c, d = A.row, A.col, np.asarray(A.data, dtype=np.double)
+    return coo_matrix((np.concatenate([d, d]), (_i32(np.concatenate([r, r + nc])), _i32(np.concatenate([c + n, c])))),
+                      shape=(2 * nc, 2 * n))
+
+
+def _size(getter, i):
+    try:
+        return getter(i)
+    except Exception:
+        return None
+
+
+def embed_matrix(matrix, local_blocks):
+    """The block-bordered matrix of the module docstring for the diagonal / border blocks in `local_blocks` (this rank's)
+    and the corner; same block grid and ownership table as `matrix`."""
+    nb = matrix.bshape[0]
+    last = nb - 1
+    own = getattr(matrix, 'rank_ownership', None)
+    out = BlockMatrix(nb, nb) if own is None else MPIBlockMatrix(nb, nb, np.asarray(own), getattr(matrix, 'mpi_comm', None))
+    for i in range(nb):
+        s = _size(matrix.get_row_size, i)
+        if s is not None:
+            out.set_row_size(i, 2 * int(s))
+        s = _size(matrix.get_col_size, i)
+        if s is not None:
+            out.set_col_size(i, 2 * int(s))
+    for ndx in local_blocks:
+        out.set_block(ndx, ndx, embed_square(matrix.get_block(ndx, ndx)))
+        A = matrix.get_block(last, ndx)
+        if A is not None:
+            out.set_block(last, ndx, embed_border(A))
+    Q = matrix.get_block(last, last)
+    if Q is not None:
+        out.set_block(last, last, embed_square(Q))
+    return out
+
+
+def _flat(v):
+    return v.flatten() if hasattr(v, 'flatten') and hasattr(v, 'get_block') else np.asarray(v, dtype=np.double).ravel()
+
+
+def embed_vector(rhs, local_blocks, nb):
+    """b  ->  (b_i, 0) per block."""
+    own = getattr(rhs, 'rank_ownership', None)
+    out = BlockVector(nb) if own is None else MPIBlockVector(nb, list(np.asarray(own)), getattr(rhs, 'mpi_comm', None))
+    for ndx in list(local_blocks) + [nb - 1]:
+        b = _flat(rhs.get_block(ndx))
+        out.set_block(ndx, np.concatenate([b, np.zeros(b.size)]))
+    return out
+
+
+def extract_solution(xbar, rhs, local_blocks, nb):
+    """(y_i, x_i) per block  ->  x, in the structure of `rhs` (nested block vectors keep their structure: quirk Q9)."""
+    result = rhs.copy_structure_unset() if hasattr(rhs, 'copy_structure_unset') else rhs.copy_structure()
+    for ndx in list(local_blocks) + [nb - 1]:
+        v = np.asarray(xbar.get_block(ndx))
+        x = np.array(v[v.size // 2:])
+        blk = rhs.get_block(ndx)
+        if hasattr(blk, 'get_block'):
+            o = blk.copy_structure()
+            o.copyfrom(x)
+            x = o
+        result.set_block(ndx, x)
+    return result
+
+
+def residual_of_multipliers(xbar, local_blocks, nb):
+    """max |y| over this rank's blocks: zero up to rounding for a regular M (a diagnostic the tests read)."""
+    m = 0.0
+    for ndx in list(local_blocks) + [nb - 1]:
+        v = np.asarray(xbar.get_block(ndx))
+        if v.size:
+            m = max(m, float(np.abs(v[:v.size // 2]).max()))
+    return m

@@ -39,6 +39,7 @@ from parapint_amd.sparse.block_containers import BlockMatrix as _BlockMatrix, MP
 _OWN_MATRICES = (_BlockMatrix, _MPIBlockMatrix)     # (exact types: their get_block is a dictionary lookup)
 _F8 = np.dtype(np.float64)
 from parapint_amd.linalg.pivot_repair import PivotRepairMixin
+from parapint_amd.linalg import general_blocks
 from parapint_amd.linalg.solution_check import SolutionCheckMixin
 
 
@@ -66,9 +67,21 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, SolutionCheckMixin, Coupl
         return 'hip_schur_complement'
 
     def __init__(self, subproblem_solvers=None, schur_complement_solver=None, comm=None, engine=None,
-                 memory_budget_bytes=None, result_buffers=0, pivot_tolerance=None, symbolic_pivot_threshold=None):
+                 memory_budget_bytes=None, result_buffers=0, pivot_tolerance=None, symbolic_pivot_threshold=None,
+                 general_blocks=None):
         self.subproblem_solvers = subproblem_solvers
         self.schur_complement_solver = schur_complement_solver
+        # General-LU semantics (general_blocks.py): the sub-solver objects the reference's callers hand over are never
+        # called here, but a ScipyInterface among them says what the caller expects of unsymmetric blocks -- SuperLU reads
+        # both triangles (scipy_interface.py:26-31).  On that route every host matrix is looked at (exact symmetry of the
+        # local diagonal blocks and of the corner, O(nnz) on the host, agreed across the ranks) and an unsymmetric one is
+        # factorised through its symmetric embedding; symmetric matrices and every other route take the path below.
+        if general_blocks is None:
+            subs = list(subproblem_solvers.values()) if isinstance(subproblem_solvers, dict) else list(subproblem_solvers or [])
+            general_blocks = any(getattr(o, 'general_lu', False) for o in subs + [schur_complement_solver])
+        self._general_route = bool(general_blocks)
+        self._general_mode = None           # True: the last symbolic / numeric phase went through the embedding
+        self._general_inner = None
         self.comm = default_comm() if comm is None else comm
         self._eng = HipEngine() if engine is None else engine
         # cap on the device value storage (factor panels, work vectors); None = no cap.  A plan that needs more makes
@@ -820,12 +833,17 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, SolutionCheckMixin, Coupl
 
     # ------------------------------------------------------------------ interface
     def do_symbolic_factorization(self, matrix, raise_on_error=True, timer=None):
-        timer = _Labels(timer)
         nbrows, nbcols = matrix.bshape
         if nbrows != nbcols:
             raise ValueError('The block matrix provided is not square.')
         self.block_dim = nbrows
         self.local_block_indices = self._local_blocks(matrix)
+        self._general_mode = self._unsymmetric_anywhere(matrix)
+        if self._general_mode:
+            self._inertia = self._num_status = None
+            return self._general_solver().do_symbolic_factorization(
+                general_blocks.embed_matrix(matrix, self.local_block_indices), raise_on_error=raise_on_error, timer=timer)
+        timer = _Labels(timer)
         self._inertia = None
         self._num_status = None
         self._classes = None
@@ -865,6 +883,20 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, SolutionCheckMixin, Coupl
         return res
 
     def do_numeric_factorization(self, matrix, raise_on_error=True, timer=None):
+        if self._general_route and self._general_mode is not None:
+            unsym = self._unsymmetric_anywhere(matrix)
+            if unsym != self._general_mode:
+                # (the values have turned (un)symmetric since the symbolic phase: the other path's symbolic phase, on this
+                # matrix -- same pattern by the interface's contract)
+                res = self.do_symbolic_factorization(matrix, raise_on_error=raise_on_error)
+                if res.status not in _OK:
+                    return res
+            if unsym:
+                res = self._general_inner.do_numeric_factorization(
+                    general_blocks.embed_matrix(matrix, self.local_block_indices), raise_on_error=raise_on_error, timer=timer)
+                self._num_status = res.status
+                self._inertia = None
+                return res
         if self._deferred_solve is not None:
             self.confirm_solution()         # (a deferred back-solve is never left unjudged: its factors are still in place here)
         shift = getattr(matrix, 'diagonal_shift', None)
@@ -1191,6 +1223,13 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, SolutionCheckMixin, Coupl
         return res
 
     def do_back_solve(self, rhs, timer=None, _repairs=None):
+        if self._general_mode:
+            if self._num_status is None:
+                raise RuntimeError('Perform numeric factorization first!')
+            loc, nb = self.local_block_indices, self.block_dim
+            xbar = self._general_inner.do_back_solve(general_blocks.embed_vector(rhs, loc, nb), timer=timer)
+            self.last_multiplier_norm = general_blocks.residual_of_multipliers(xbar, loc, nb)
+            return general_blocks.extract_solution(xbar, rhs, loc, nb)
         if timer is None:
             timer = _NullTimer()
         if self._num_status is None:
@@ -1440,10 +1479,36 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, SolutionCheckMixin, Coupl
     def get_inertia(self):
         if self._num_status is None:
             raise RuntimeError('Must call do_numeric_factorization before inertia can be computed')
+        if self._general_mode:
+            raise RuntimeError('the last matrix was not symmetric: it was factorised through its symmetric embedding '
+                               '(general_blocks.py), whose inertia says nothing about it -- the reference counts the eigenvalues '
+                               'of such a matrix on the host (scipy_interface.py:39-44), which this package does not do')
         return self._inertia
 
     def increase_memory_allocation(self, factor):
         self._eng.increase_memory_allocation(factor)
+
+    # ---- general-LU semantics on the ScipyInterface route (general_blocks.py) ----
+
+    def _unsymmetric_anywhere(self, matrix):
+        """Collective on the general route: does any rank hold a diagonal block (or the corner) that is not symmetric?"""
+        if not self._general_route or hasattr(matrix, 'value_maps') or hasattr(matrix, 'flat_values') or \
+                hasattr(matrix, 'diagonal_shift'):
+            return False
+        last = matrix.bshape[0] - 1
+        mine = any(not general_blocks.is_symmetric(matrix.get_block(ndx, ndx)) for ndx in self.local_block_indices) or \
+            not general_blocks.is_symmetric(matrix.get_block(last, last))
+        if self.comm.size > 1:
+            mine = bool(self.comm.allreduce_max(np.array([1 if mine else 0], dtype=np.int64))[0])
+        return mine
+
+    def _general_solver(self):
+        if self._general_inner is None:
+            u0, u1 = self._u_user
+            self._general_inner = HipSchurComplementLinearSolver(
+                comm=self.comm, engine=self._eng, general_blocks=False, pivot_tolerance=u1 or None,
+                symbolic_pivot_threshold=u0 or None)
+        return self._general_inner
 
     def get_schur_complement(self):
         """All-reduced S (without Q) -- parity hook (reference: self.schur_complement): dense array, or for a

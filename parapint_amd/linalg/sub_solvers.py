@@ -1,6 +1,6 @@
 """Single-matrix sub-solver interfaces by the reference's names, over the same HIP kernels:
 ``HipLDLInterface`` (= parapint.linalg.InteriorPointMA27Interface, ma27_interface.py:9-256), ``MumpsInterface``
-(mumps_interface.py:11-229) and ``ScipyInterface`` (scipy_interface.py:11-67; symmetric matrices only -- see INTEGRATION.md).
+(mumps_interface.py:11-229) and ``ScipyInterface`` (scipy_interface.py:11-67; unsymmetric matrices through general_blocks.py).
 Each is a one-block, zero-coupling instance of the batched solver."""
 import numpy as np
 
@@ -46,7 +46,8 @@ class HipLDLInterface(LinearSolverInterface):
             u = self.cntl_options.get(1)
             self._sc_made = HipSchurComplementLinearSolver(
                 comm=SerialComm(), engine=self._engine_arg, pivot_tolerance=u,
-                symbolic_pivot_threshold=None if u is None else max(min(u, 0.5), 0.01))
+                symbolic_pivot_threshold=None if u is None else max(min(u, 0.5), 0.01),
+                general_blocks=getattr(self, 'general_lu', False))
         return self._sc_made
 
     def _wrap(self, matrix):
@@ -180,10 +181,15 @@ class MumpsInterface(HipLDLInterface):
 
 
 class ScipyInterface(HipLDLInterface):
-    """The reference's SciPy wrapper by name and constructor (parapint/linalg/scipy_interface.py:11-67).  Its general-LU
-    semantics (both triangles read, unsymmetric matrices accepted: quirk Q5) are NOT offered: the lower triangle defines
-    the matrix, as for the MA27 / MUMPS wrappers.  ``compute_inertia`` keeps its meaning: without it ``get_inertia``
-    raises (:64-67)."""
+    """The reference's SciPy wrapper by name and constructor (parapint/linalg/scipy_interface.py:11-67), with its
+    general-LU semantics for the SOLVE (both triangles read, any square matrix accepted: quirk Q5): a matrix that is not
+    exactly symmetric is factorised through its symmetric embedding (general_blocks.py), a symmetric one as the MA27 /
+    MUMPS wrappers do.  ``compute_inertia`` keeps its meaning -- without it ``get_inertia`` raises (:64-67) --, but the
+    inertia of an unsymmetric matrix (the reference: eigenvalues counted by a dense eigensolver on the host, :39-44) is
+    not offered: ``get_inertia`` raises after such a factorisation.  Handing objects of this class to the Schur-complement
+    solver as its ``subproblem_solvers`` selects the same semantics for the blocks of a block-bordered matrix."""
+
+    general_lu = True
 
     @classmethod
     def getLoggerName(cls):

@@ -163,6 +163,38 @@ def main():
     assert np.abs(np.asarray(x3.get_block(T)) - xd[off[T]:]).max() <= 1e-8 * np.abs(xd).max()
     ev = np.linalg.eigvalsh(Kd)
     assert s3.get_inertia() == (int((ev > 0).sum()), int((ev < 0).sum()), 0)
+    # general-LU semantics (general_blocks.py): ScipyInterface objects as sub-solvers, ONE diagonal block -- on rank 1 -- not
+    # symmetric: both ranks must take the embedding (the decision is an all-reduce), and the solution is that of the oracle's
+    # LU sub-solvers on the same matrix
+    from parapint_amd.linalg import ScipyInterface as HipScipy
+    kg = model.build_kkt(comm=comm, iteration=3)
+    okg = full_model.build_kkt(comm=SerialComm(), iteration=3)
+    odd = distribute_blocks(N, 1, size)[0]
+    up = model._row < model._col
+    for mat, mine in ((kg, rank == 1), (okg, True)):
+        if mine:
+            Kg = mat.get_block(odd, odd)
+            Kg.data = Kg.data.copy()
+            Kg.data[up] *= 1.5
+    e5 = HostSimEngine()
+    s5 = HipSchurComplementLinearSolver({i: HipScipy(engine=e5) for i in local}, HipScipy(engine=e5), comm=comm, engine=e5)
+    assert s5.do_symbolic_factorization(kg).status == LinearSolverStatus.successful
+    assert s5._general_mode is True
+    assert s5.do_numeric_factorization(kg).status == LinearSolverStatus.successful
+    x5 = s5.do_back_solve(rhs)
+    oracle.do_numeric_factorization(okg)
+    xo5 = oracle.do_back_solve(orhs)
+    for ndx in local:
+        ref = np.asarray(xo5.get_block(ndx))
+        assert np.abs(np.asarray(x5.get_block(ndx)) - ref).max() <= 1e-8 * np.abs(ref).max()
+    assert np.allclose(x5.get_block(N), xo5.get_block(N), rtol=1e-8, atol=1e-10)
+    assert type(x5) is type(rhs) and all(x5.get_block(ndx) is None for ndx in range(N) if ndx not in local)
+    # ... and the symmetric matrix again through the same object: the symmetric path, with its inertia
+    assert s5.do_numeric_factorization(model.build_kkt(comm=comm, iteration=2)).status == LinearSolverStatus.successful
+    assert s5._general_mode is False
+    oracle.do_numeric_factorization(okkt)
+    assert s5.get_inertia() == oracle.get_inertia()
+    assert np.allclose(s5.do_back_solve(rhs).get_block(N), xo.get_block(N), rtol=1e-8, atol=1e-10)
     dist.barrier()
     dist.destroy_process_group()
     print('rank %d ok' % rank)

@@ -100,6 +100,118 @@ def case_bordered_8x8(make_engine, golden, mpi):
     assert type(x) is type(rhs) and x.nblocks == 4
 
 
+# ---- 8x8 bordered system as the reference's tests state it: unsymmetric diagonal blocks (quirk Q5) -----------------
+def build_8x8_original(mpi, q11):
+    """linalg/schur_complement/tests/test_explicit_schur_complement.py:15-31, test_mpi_explicit_schur_complement.py: the
+    diagonal blocks [[1, 1], [0, 1]] and [[1, 0], [1, 1]] are not symmetric; the reference solves them with SuperLU."""
+    A, rhs = build_8x8(mpi, q11)
+    A.set_block(0, 0, coo_matrix(np.array([[1, 1], [0, 1.]])))
+    A.set_block(2, 2, coo_matrix(np.array([[1, 0], [1, 1.]])))
+    return A, rhs
+
+
+def case_bordered_8x8_original(make_engine, golden, mpi):
+    """The reference's own inputs through the ScipyInterface route of this package (general_blocks.py): the solution is
+    the reference's (tests/golden: generated by the reference's solver classes), the inertia is not offered."""
+    from parapint_amd.linalg import ScipyInterface
+    key = 'b8_unsym_%s' % ('mpi' if mpi else 'ser')
+    A, rhs = build_8x8_original(mpi, 1.0 if mpi else 0.0)
+    full = A.toarray()
+    full[:6, 6:] = full[6:, :6].T
+    assert np.array_equal(full, golden[key + '_full'])          # (the very matrix the reference's test solves)
+    eng = make_engine()
+    solver = HipSchurComplementLinearSolver(subproblem_solvers={i: ScipyInterface(compute_inertia=True, engine=eng) for i in range(3)},
+                                            schur_complement_solver=ScipyInterface(compute_inertia=True, engine=eng),
+                                            comm=SerialComm(), engine=eng)
+    assert solver.do_symbolic_factorization(A).status == LinearSolverStatus.successful
+    assert solver.do_numeric_factorization(A).status == LinearSolverStatus.successful
+    x = solver.do_back_solve(rhs)
+    x1 = np.linalg.solve(golden[key + '_full'], golden[key + '_rhs'])
+    assert np.allclose(x1, x.flatten())
+    assert np.allclose(x.flatten(), golden[key + '_x'], rtol=1e-10, atol=1e-10)
+    assert solver.last_multiplier_norm <= 1e-12
+    assert np.array_equal(rhs.flatten(), golden[key + '_rhs'])
+    assert type(x) is type(rhs) and x.nblocks == 4
+    try:
+        solver.get_inertia()
+        raise AssertionError('the inertia of an unsymmetric matrix is not offered')
+    except RuntimeError as e:
+        assert 'not symmetric' in str(e)
+    # a second numeric factorisation + solve on the same object (test_mpi_...:113-115)
+    solver.do_numeric_factorization(A)
+    assert np.allclose(x1, solver.do_back_solve(rhs).flatten())
+    # the same object with the symmetric variant of the system: the symmetric path again, inertia and all
+    As, rhs_s = build_8x8(mpi, 1.0 if mpi else 0.0)
+    ks = 'b8_sym_%s' % ('mpi' if mpi else 'ser')
+    assert solver.do_numeric_factorization(As).status == LinearSolverStatus.successful
+    assert np.allclose(solver.do_back_solve(rhs_s).flatten(), golden[ks + '_x'], rtol=1e-10, atol=1e-10)
+    assert solver.get_inertia() == tuple(golden[ks + '_inertia'])
+    # ... and back
+    assert solver.do_numeric_factorization(A).status == LinearSolverStatus.successful
+    assert np.allclose(solver.do_back_solve(rhs).flatten(), golden[key + '_x'], rtol=1e-10, atol=1e-10)
+    # without ScipyInterface objects nothing is looked at: the lower triangle defines a symmetric matrix (MA27's reading) --
+    # for this input a singular one ([[1, 1], [1, 1]] from the last diagonal block)
+    plain = new_solver(make_engine, 3)
+    plain.do_symbolic_factorization(A)
+    assert plain.do_numeric_factorization(A, raise_on_error=False).status == LinearSolverStatus.singular
+
+
+def case_general_blocks_random(make_engine, seeds=range(6)):
+    """Random unsymmetric block-bordered systems (sparse diagonal blocks with an unsymmetric PATTERN, unsymmetric corner)
+    against a dense solve of the matrix the reference's classes define: [[K, A^T], [A, Q]]; the single-matrix
+    ScipyInterface on an unsymmetric and on a triangular matrix."""
+    from parapint_amd.linalg import ScipyInterface
+    for seed in seeds:
+        rng = np.random.default_rng(100 + seed)
+        nb, n, nc = 3 + seed % 3, 12 + 3 * seed, 3 + seed % 4
+        A = BlockMatrix(nb + 1, nb + 1)
+        rhs = BlockVector(nb + 1)
+        N = nb * n + nc
+        full = np.zeros((N, N))
+        for i in range(nb):
+            K = sp.random(n, n, density=0.25, random_state=int(rng.integers(1 << 30)), format='coo')
+            K = (K + sp.diags(2.0 + rng.random(n))).tocoo()
+            Bd = sp.random(nc, n, density=0.3, random_state=int(rng.integers(1 << 30)), format='coo')
+            A.set_block(i, i, K)
+            A.set_block(nb, i, Bd)
+            full[i * n:(i + 1) * n, i * n:(i + 1) * n] = K.toarray()
+            full[nb * n:, i * n:(i + 1) * n] = Bd.toarray()
+            full[i * n:(i + 1) * n, nb * n:] = Bd.toarray().T
+            rhs.set_block(i, rng.standard_normal(n))
+        Q = rng.standard_normal((nc, nc)) + 4.0 * np.eye(nc)
+        A.set_block(nb, nb, coo_matrix(Q))
+        full[nb * n:, nb * n:] = Q
+        rhs.set_block(nb, rng.standard_normal(nc))
+        eng = make_engine()
+        solver = HipSchurComplementLinearSolver(subproblem_solvers={i: ScipyInterface(engine=eng) for i in range(nb)},
+                                                schur_complement_solver=ScipyInterface(engine=eng), comm=SerialComm(), engine=eng)
+        assert solver.do_symbolic_factorization(A).status == LinearSolverStatus.successful
+        assert solver.do_numeric_factorization(A).status == LinearSolverStatus.successful
+        x = solver.do_back_solve(rhs)
+        assert scaled_residual(full, x.flatten(), rhs.flatten()) <= 1e-10, (seed, scaled_residual(full, x.flatten(), rhs.flatten()))
+        assert solver.last_multiplier_norm <= 1e-8 * max(1.0, np.abs(x.flatten()).max())
+    rng = np.random.default_rng(7)
+    M = (sp.random(30, 30, density=0.2, random_state=3) + sp.diags(3.0 + rng.random(30))).tocoo()
+    one = ScipyInterface(compute_inertia=True, engine=make_engine())
+    assert one.do_symbolic_factorization(M).status == LinearSolverStatus.successful
+    assert one.do_numeric_factorization(M).status == LinearSolverStatus.successful
+    b = rng.standard_normal(30)
+    assert scaled_residual(M, one.do_back_solve(b), b) <= 1e-12
+    try:
+        one.get_inertia()
+        raise AssertionError('the inertia of an unsymmetric matrix is not offered')
+    except RuntimeError:
+        pass
+    T = sp.tril(M).tocoo()          # (SuperLU reads what it is given: a triangular matrix is a triangular system)
+    assert one.do_numeric_factorization(T).status == LinearSolverStatus.successful
+    assert scaled_residual(T, one.do_back_solve(b), b) <= 1e-12
+    Ssym = (M + M.T).tocoo()        # the symmetric path of the same object: inertia is back
+    assert one.do_numeric_factorization(Ssym).status == LinearSolverStatus.successful
+    assert scaled_residual(Ssym, one.do_back_solve(b), b) <= 1e-12
+    eig = np.linalg.eigvalsh(Ssym.toarray())
+    assert one.get_inertia() == (int((eig > 0).sum()), int((eig < 0).sum()), 0)
+
+
 # ---- small synthetic KKTs against the reference's own output -------------------------------------
 def case_small_synthetic(make_engine, golden, shape):
     N, n_q, m, n_t = shape

@@ -32,6 +32,15 @@ def test_bordered_8x8(golden, mpi):
     sc.case_bordered_8x8(make_engine, golden, mpi)
 
 
+@pytest.mark.parametrize('mpi', [False, True])
+def test_bordered_8x8_with_the_unsymmetric_blocks_of_the_reference_tests(golden, mpi):
+    sc.case_bordered_8x8_original(make_engine, golden, mpi)
+
+
+def test_unsymmetric_blocks_through_the_scipy_interface_route():
+    sc.case_general_blocks_random(make_engine)
+
+
 @pytest.mark.parametrize('shape', [(3, 20, 2, 4), (4, 50, 3, 6)])
 def test_small_synthetic(golden, shape):
     sc.case_small_synthetic(make_engine, golden, shape)

@@ -1,6 +1,6 @@
 """Per-queue timeline of the last full step of a bench run from a rocprofv3 kernel-trace csv (diagnostic): for workloads
 whose pattern groups run on streams of their own (C4) -- which queue holds the critical path, and which kernels fill it.
-usage: trace_streams.py <kernel_trace.csv> [max lines per queue]"""
+usage: trace_streams.py <kernel_trace.csv> [max lines per queue [step index]]"""
 import collections
 import csv
 import re
@@ -11,9 +11,10 @@ rows.sort(key=lambda r: int(r['Start_Timestamp']))
 limit = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 short = lambda n: re.sub(r'\(.*', '', n.replace('(anonymous namespace)::', '').replace('void ', ''))
 names = [short(r['Kernel_Name']) for r in rows]
-# a step starts at the first factor launch (gather) that follows a backward-sweep launch in start order
-starts = [i for i in range(1, len(rows)) if names[i].startswith('k_gather') and not names[i].startswith('k_gather_xc') and names[i - 1].startswith('k_bwd')]
-a, b = (starts[-2], starts[-1]) if len(starts) > 1 else (0, len(rows))
+# a step starts at the first factor launch (gather) that follows a launch of the end of a back-solve (backward sweep, hand-over copy, check) in start order
+starts = [i for i in range(1, len(rows)) if names[i].startswith('k_gather') and not names[i].startswith('k_gather_xc') and (names[i - 1].startswith(('k_bwd', 'k_residual', '__amd_rocclr_copy', 'k_transpose_out', 'k_copy')))]
+which = int(sys.argv[3]) if len(sys.argv) > 3 else -2       # (third argument: which step of the run, in start order; default the last full one)
+a, b = (starts[which], starts[which + 1] if which + 1 != 0 and which + 1 < len(starts) else starts[-1]) if len(starts) > 1 else (0, len(rows))
 step = rows[a:b]
 t0 = int(step[0]['Start_Timestamp'])
 qkey = 'Queue_Id' if 'Queue_Id' in step[0] else 'Stream_Id'
