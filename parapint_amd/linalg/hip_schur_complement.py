@@ -1169,6 +1169,9 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, SolutionCheckMixin, Coupl
         Hessian diagonals - delta_c on the classed constraint diagonals + coupling_shift * I on the coupling block,
         from the values already resident on the device: what one retry of the inertia-correction loop
         (interior_point.py:377-386) needs, without rebuilding, staging or uploading the KKT matrix."""
+        if self._general_mode:
+            raise RuntimeError('refactorize_with_diagonal_shift: the last matrix went through the symmetric embedding of an '
+                               'unsymmetric matrix (general_blocks.py), which has no regularisation classes')
         timer = _Labels(timer)
         if self._num_status is None:
             raise RuntimeError('Perform numeric factorization first!')
@@ -1513,6 +1516,13 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, SolutionCheckMixin, Coupl
     def get_schur_complement(self):
         """All-reduced S (without Q) -- parity hook (reference: self.schur_complement): dense array, or for a
         block-tridiagonal S a SciPy COO matrix in the caller's ordering of the coupling variables."""
+        if self._general_mode:
+            # (general_blocks.py: the embedded system's S is [[0, S], [S', 0]] with S = -sum A K^-1 A^T the reference's and
+            # S' the same with K^-T)
+            Sbar = self._general_inner.get_schur_complement()
+            Sbar = Sbar.toarray() if hasattr(Sbar, 'toarray') else np.asarray(Sbar)
+            nc = Sbar.shape[0] // 2
+            return np.array(Sbar[:nc, nc:])
         if self._btd is None:
             return self._eng.get_schur()
         from scipy.sparse import coo_matrix

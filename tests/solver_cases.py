@@ -131,6 +131,8 @@ def case_bordered_8x8_original(make_engine, golden, mpi):
     assert np.allclose(x.flatten(), golden[key + '_x'], rtol=1e-10, atol=1e-10)
     assert solver.last_multiplier_norm <= 1e-12
     assert np.array_equal(rhs.flatten(), golden[key + '_rhs'])
+    if mpi:           # (the reference's S = -sum A K^-1 A^T, read out of the embedded system's coupling block)
+        assert np.allclose(solver.get_schur_complement(), golden[key + '_S'], rtol=1e-12, atol=1e-12)
     assert type(x) is type(rhs) and x.nblocks == 4
     try:
         solver.get_inertia()
