@@ -744,6 +744,95 @@ def case_errors(make_engine):
     assert np.allclose(full @ x.flatten(), rhs.flatten())
 
 
+def case_singular_schur_complement(make_engine):
+    """Quirk Q3: every block regular, S = Q - sum A K^-1 A^T exactly zero.  The reference's MPI class raises here whatever
+    the caller asked for (mpi_...:358), its serial class passes the flag (explicit_...:127); this class returns the status
+    with raise_on_error=False (what the inertia-correction loop needs) and raises otherwise."""
+    import pytest
+    A = BlockMatrix(3, 3)
+    for i in range(2):
+        A.set_block(i, i, coo_matrix(np.array([[2.0]])))
+        A.set_block(2, i, coo_matrix(np.array([[1.0]])))
+    A.set_block(2, 2, coo_matrix(np.array([[1.0]])))
+    solver = new_solver(make_engine, 2)
+    assert solver.do_symbolic_factorization(A).status == LinearSolverStatus.successful
+    res = solver.do_numeric_factorization(A, raise_on_error=False)
+    assert res.status == LinearSolverStatus.singular
+    with pytest.raises(RuntimeError):
+        solver.do_numeric_factorization(A, raise_on_error=True)
+    A.set_block(2, 2, coo_matrix(np.array([[3.0]])))          # S = 2: regular again, same object
+    assert solver.do_numeric_factorization(A).status == LinearSolverStatus.successful
+    rhs = BlockVector(3)
+    for i, v in enumerate((1.0, 2.0, 3.0)):
+        rhs.set_block(i, np.array([v]))
+    x = solver.do_back_solve(rhs).flatten()
+    full = np.array([[2.0, 0, 1], [0, 2.0, 1], [1, 1, 3.0]])
+    assert np.allclose(full @ x, rhs.flatten())
+    assert solver.get_inertia() == (3, 0, 0)
+
+
+def case_nested_blocks(make_engine):
+    """Quirk Q9: diagonal blocks that are nested BlockMatrix objects ([[H, J^T], [J, -D]], as sc_ip_interface.py hands them
+    over) and right-hand-side blocks that are nested BlockVectors give the results of the flat form, in the structure of the
+    right-hand side (mpi_...:384, 395; ma27_interface.py:169-182)."""
+    N = 3
+    model = SyntheticKKT(N, 6, 2, 3)
+    comm = SerialComm()
+    flat_kkt = model.build_kkt(comm=comm, iteration=1)
+    flat_rhs = model.build_rhs(comm=comm)
+    rng = np.random.default_rng(5)
+    for ndx in range(N + 1):
+        flat_rhs.set_block(ndx, rng.standard_normal(flat_rhs.get_block(ndx).size))
+    ny = model.n_y
+    nested = BlockMatrix(N + 1, N + 1)
+    nrhs = BlockVector(N + 1)
+    for ndx in range(N):
+        K = flat_kkt.get_block(ndx, ndx).tocsr()
+        n = K.shape[0]
+        kb = BlockMatrix(2, 2)
+        kb.set_block(0, 0, K[:ny, :ny].tocoo())
+        kb.set_block(0, 1, K[:ny, ny:].tocoo())
+        kb.set_block(1, 0, K[ny:, :ny].tocoo())
+        kb.set_block(1, 1, K[ny:, ny:].tocoo())
+        nested.set_block(ndx, ndx, kb)
+        Ab = flat_kkt.get_block(N, ndx).tocsr()
+        ab = BlockMatrix(1, 2)
+        ab.set_block(0, 0, Ab[:, :ny].tocoo())
+        ab.set_block(0, 1, Ab[:, ny:].tocoo())
+        nested.set_block(N, ndx, ab)
+        v = flat_rhs.get_block(ndx)
+        vb = BlockVector(2)
+        vb.set_block(0, v[:ny].copy())
+        vb.set_block(1, v[ny:].copy())
+        nrhs.set_block(ndx, vb)
+        assert n == model.block_dim
+    Q = flat_kkt.get_block(N, N)
+    if Q is not None:
+        nested.set_block(N, N, Q)
+    cb = BlockVector(1)
+    cb.set_block(0, flat_rhs.get_block(N).copy())
+    nrhs.set_block(N, cb)
+    xs = []
+    for kkt, rhs in ((flat_kkt, flat_rhs), (nested, nrhs)):
+        solver = new_solver(make_engine, N)
+        assert solver.do_symbolic_factorization(kkt).status == LinearSolverStatus.successful
+        assert solver.do_numeric_factorization(kkt).status == LinearSolverStatus.successful
+        xs.append(solver.do_back_solve(rhs))
+    xf, xn = xs
+    assert np.array_equal(xf.flatten(), xn.flatten())
+    F = flat_kkt.toarray()
+    nK = N * model.block_dim
+    F[:nK, nK:] = F[nK:, :nK].T
+    assert scaled_residual(F, xn.flatten(), flat_rhs.flatten()) <= 1e-10
+    for ndx in range(N):
+        blk = xn.get_block(ndx)
+        assert hasattr(blk, 'get_block') and blk.nblocks == 2 and blk.get_block(0).size == ny
+    assert hasattr(xn.get_block(N), 'get_block') and xn.get_block(N).nblocks == 1
+    assert not hasattr(xf.get_block(0), 'get_block')
+    # the nested right-hand side is left as it was
+    assert np.array_equal(nrhs.flatten(), flat_rhs.flatten())
+
+
 # ---- memory reallocation protocol (linalg/tests/test_realloc.py:10-61, interior_point.py:634-652) ----------
 def case_reallocation(make_engine, required_bytes):
     """A solver whose device-storage budget is too small reports not_enough_memory from the numeric phase (status,

@@ -63,6 +63,14 @@ def test_error_behaviour():
     sc.case_errors(make_engine)
 
 
+def test_singular_schur_complement_is_a_status_when_asked_for_one():
+    sc.case_singular_schur_complement(make_engine)
+
+
+def test_nested_block_matrices_and_vectors():
+    sc.case_nested_blocks(make_engine)
+
+
 def test_sparse_corner_entry_point_checks_its_arguments():
     """pp_factor_schur_corner is the block-tridiagonal form of pp_factor_schur: status 3 on a dense S and for positions
     outside the Schur buffer; the flat and the sparse form of Q give the same factorisation."""

@@ -55,6 +55,14 @@ def test_error_behaviour():
     sc.case_errors(make_engine)
 
 
+def test_singular_schur_complement_is_a_status_when_asked_for_one():
+    sc.case_singular_schur_complement(make_engine)
+
+
+def test_nested_block_matrices_and_vectors():
+    sc.case_nested_blocks(make_engine)
+
+
 def test_inertia_correction_pattern_growth():
     sc.case_inertia_correction_pattern_growth(make_engine)
 
