@@ -163,6 +163,53 @@ def main():
     assert np.abs(np.asarray(x3.get_block(T)) - xd[off[T]:]).max() <= 1e-8 * np.abs(xd).max()
     ev = np.linalg.eigvalsh(Kd)
     assert s3.get_inertia() == (int((ev > 0).sum()), int((ev < 0).sum()), 0)
+    # the reference's own MPI test (test_mpi_explicit_schur_complement.py:22-115): the 8x8 system with Q = [[0, 0], [0, 1]],
+    # ownership (ndx - rank) % size == 0, solution and inertia against the golden vectors of the reference's solver, a
+    # second numeric factorisation + solve on the same object; symmetric variant through the plain route, the unsymmetric
+    # original through ScipyInterface objects
+    from scipy.sparse import coo_matrix as _coo8
+    from parapint_amd.sparse.block_containers import MPIBlockMatrix, MPIBlockVector
+    from parapint_amd.linalg import ScipyInterface as _HipScipy
+    golden = np.load(os.path.join(HERE, 'golden', 'reference_vectors.npz'))
+    own8 = np.array([[-1] * 4 for _ in range(4)])
+    owners = [0, 1, 0]                     # (ndx - rank) % 2 == 0
+    for i in range(3):
+        own8[i, i] = owners[i]
+        own8[3, i] = owners[i]
+    mine8 = [i for i in range(3) if owners[i] == rank]
+    for variant in ('sym', 'unsym'):
+        if variant == 'sym':
+            ks = [np.array([[1, 0.5], [0.5, 1]]), np.eye(2), np.array([[1, 1], [1, 3.]])]
+        else:
+            ks = [np.array([[1, 1], [0, 1.]]), np.eye(2), np.array([[1, 0], [1, 1.]])]
+        a8 = [np.array([[0, -1], [0, 0.]]), np.array([[-1, 0], [0, -1.]]), np.array([[0, 0], [-1, 0.]])]
+        A8 = MPIBlockMatrix(4, 4, own8, comm)
+        r8 = MPIBlockVector(4, np.array(owners + [-1]), comm)
+        for i in mine8:
+            A8.set_block(i, i, _coo8(ks[i]))
+            A8.set_block(3, i, _coo8(a8[i]))
+        A8.set_block(3, 3, _coo8(np.array([[0, 0], [0, 1.0]])))
+        for i in range(4):
+            A8.set_row_size(i, 2)
+            A8.set_col_size(i, 2)
+        vals8 = ([1, 0], [0, 0], [0, 1], [1, 1])
+        for i in mine8 + [3]:
+            r8.set_block(i, np.array(vals8[i], dtype=np.double))
+        e8 = HostSimEngine()
+        subs = {i: (_HipScipy(compute_inertia=True, engine=e8) if variant == 'unsym' else None) for i in mine8}
+        s8 = HipSchurComplementLinearSolver(subs, _HipScipy(compute_inertia=True, engine=e8) if variant == 'unsym' else None,
+                                            comm=comm, engine=e8)
+        assert s8.do_symbolic_factorization(A8).status == LinearSolverStatus.successful
+        assert s8.local_block_indices == mine8
+        key = 'b8_%s_mpi' % variant
+        for _ in range(2):
+            assert s8.do_numeric_factorization(A8).status == LinearSolverStatus.successful
+            x8 = s8.do_back_solve(r8)
+            for i in mine8 + [3]:
+                assert np.allclose(np.asarray(x8.get_block(i)), golden[key + '_x'][2 * i:2 * i + 2], rtol=1e-10, atol=1e-10), (variant, i)
+        assert np.allclose(s8.get_schur_complement(), golden[key + '_S'], rtol=1e-12, atol=1e-12)
+        if variant == 'sym':
+            assert s8.get_inertia() == tuple(golden[key + '_inertia'])
     # general-LU semantics (general_blocks.py): ScipyInterface objects as sub-solvers, ONE diagonal block -- on rank 1 -- not
     # symmetric: both ranks must take the embedding (the decision is an all-reduce), and the solution is that of the oracle's
     # LU sub-solvers on the same matrix

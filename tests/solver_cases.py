@@ -39,14 +39,18 @@ def case_sub_solver_contract(make_engine, golden):
                      shape=(3, 3), dtype=np.double)
     zero = mat.copy()
     zero.data.fill(0)
-    solver = HipLDLInterface(engine=make_engine())
-    assert solver.do_symbolic_factorization(zero).status == LinearSolverStatus.successful
-    assert solver.do_numeric_factorization(mat).status == LinearSolverStatus.successful
-    for x_true, key in (([1., 2., 3.], 'sub3_x1'), ([4., 2., 3.], 'sub3_x2')):
-        x = solver.do_back_solve(mat * np.array(x_true))
-        assert np.allclose(x, x_true)
-        assert np.allclose(x, golden[key], rtol=1e-10, atol=1e-10)
-    assert solver.get_inertia() == tuple(golden['sub3_inertia'])
+    # (the reference runs the same body for its SciPy, MUMPS and MA27 wrappers: test_linear_solvers.py:82-99)
+    from parapint_amd.linalg import MumpsInterface, ScipyInterface
+    for make in (lambda: MumpsInterface(engine=make_engine()), lambda: ScipyInterface(compute_inertia=True, engine=make_engine()),
+                 lambda: HipLDLInterface(engine=make_engine())):
+        solver = make()
+        assert solver.do_symbolic_factorization(zero).status == LinearSolverStatus.successful
+        assert solver.do_numeric_factorization(mat).status == LinearSolverStatus.successful
+        for x_true, key in (([1., 2., 3.], 'sub3_x1'), ([4., 2., 3.], 'sub3_x2')):
+            x = solver.do_back_solve(mat * np.array(x_true))
+            assert np.allclose(x, x_true)
+            assert np.allclose(x, golden[key], rtol=1e-10, atol=1e-10)
+        assert solver.get_inertia() == tuple(golden['sub3_inertia'])
     # MA27-wrapper semantics: only the lower triangle is read
     low = sp.tril(mat).tocoo()
     solver.do_numeric_factorization(low)
