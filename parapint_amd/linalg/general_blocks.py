@@ -29,15 +29,25 @@ from scipy.sparse import coo_matrix
 from parapint_amd.sparse.block_containers import BlockMatrix, BlockVector, MPIBlockMatrix, MPIBlockVector
 
 
+SYMMETRY_TOLERANCE = 1e-13     # |a_ij - a_ji| <= SYMMETRY_TOLERANCE * max|a|: the two triangles of a KKT block assembled separately
+
+
 def is_symmetric(m):
-    """Exactly symmetric (duplicates summed): what decides between the symmetric path and the embedding."""
+    """Symmetric up to rounding (duplicates summed): what decides between the symmetric path -- lower triangle, inertia --
+    and the embedding.  A matrix whose triangles differ in the last bits (assembled separately) must not lose its inertia
+    over it; a difference beyond SYMMETRY_TOLERANCE is a different matrix and SuperLU would solve that one."""
     if m is None:
         return True
     if m.shape[0] != m.shape[1]:
         return False
     c = m.tocsr()
     d = c - c.T
-    return d.nnz == 0 or not np.any(d.data != 0.0)
+    if d.nnz == 0:
+        return True
+    dmax = np.abs(d.data).max()
+    if dmax == 0.0:
+        return True
+    return bool(dmax <= SYMMETRY_TOLERANCE * np.abs(c.data).max())
 
 
 def _i32(a):

@@ -73,7 +73,7 @@ class HipSchurComplementLinearSolver(PivotRepairMixin, SolutionCheckMixin, Coupl
         self.schur_complement_solver = schur_complement_solver
         # General-LU semantics (general_blocks.py): the sub-solver objects the reference's callers hand over are never
         # called here, but a ScipyInterface among them says what the caller expects of unsymmetric blocks -- SuperLU reads
-        # both triangles (scipy_interface.py:26-31).  On that route every host matrix is looked at (exact symmetry of the
+        # both triangles (scipy_interface.py:26-31).  On that route every host matrix is looked at (symmetry up to rounding of the
         # local diagonal blocks and of the corner, O(nnz) on the host, agreed across the ranks) and an unsymmetric one is
         # factorised through its symmetric embedding; symmetric matrices and every other route take the path below.
         if general_blocks is None:

@@ -211,6 +211,13 @@ def case_general_blocks_random(make_engine, seeds=range(6)):
     T = sp.tril(M).tocoo()          # (SuperLU reads what it is given: a triangular matrix is a triangular system)
     assert one.do_numeric_factorization(T).status == LinearSolverStatus.successful
     assert scaled_residual(T, one.do_back_solve(b), b) <= 1e-12
+    # triangles that differ in the last bits (assembled separately) are the symmetric path: the inertia stays available
+    from parapint_amd.linalg import general_blocks
+    Sy = (M + M.T).tocsr()
+    noisy = (sp.tril(Sy) + sp.triu(Sy, 1) * (1.0 + 2e-16)).tocoo()
+    assert general_blocks.is_symmetric(noisy) and not general_blocks.is_symmetric((sp.tril(Sy) + sp.triu(Sy, 1) * (1.0 + 1e-9)).tocoo())
+    assert one.do_numeric_factorization(noisy).status == LinearSolverStatus.successful
+    assert one.get_inertia()[2] == 0
     Ssym = (M + M.T).tocoo()        # the symmetric path of the same object: inertia is back
     assert one.do_numeric_factorization(Ssym).status == LinearSolverStatus.successful
     assert scaled_residual(Ssym, one.do_back_solve(b), b) <= 1e-12
