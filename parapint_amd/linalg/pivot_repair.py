@@ -114,24 +114,6 @@ class PivotRepairMixin(object):
                 continue
             self._variant[ndx] = v
             moved += 1
-        return self._rebuild_after_moves(matrix, moved)
-
-    def _split_inaccurate(self, matrix, gid, slot):
-        """After a repair that did not cure (solution_check.py): the instance whose back-solve is STILL inaccurate, under a
-        sequence planned from another instance of its group, moves to the next variant of the pattern group -- the two need
-        different sequences, as in _split_conflicting, only that the symptom is a residual and not a zero pivot.  Collective."""
-        moved = 0
-        for g in self._groups:
-            if gid is None or g.gid != gid:
-                continue
-            if len(g.blocks) >= 2 and 0 <= slot < len(g.blocks):
-                ndx = g.blocks[slot]
-                if ndx != getattr(g, 'refresh_block', g.blocks[0]) and self._variant.get(ndx, 0) + 1 < self.max_group_variants:
-                    self._variant[ndx] = self._variant.get(ndx, 0) + 1
-                    moved = 1
-        return self._rebuild_after_moves(matrix, moved)
-
-    def _rebuild_after_moves(self, matrix, moved):
         anyone = moved
         if self.comm.size > 1:
             anyone = int(self.comm.allreduce_max(np.array([moved], dtype=np.int64))[0])

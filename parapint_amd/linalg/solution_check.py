@@ -31,9 +31,9 @@ class SolutionCheckMixin(object):
     refine_tolerance = 1e-10
     residual_tolerance = 1e-8
     max_refinement_steps = 2
-    max_solve_repairs = 3           # new pivot sequences (the second and third may move the wrong instance to a group of its own) + factorisations one back-solve may ask for
+    max_solve_repairs = 2           # new pivot sequences + factorisations one back-solve may ask for
     on_inaccurate_solve = 'raise'   # or 'warn'
-    repair_thresholds = (0.1, 0.3, 0.3)  # threshold u of the static 1x1 / 2x2 choice for the 1st, 2nd, ... repair of one back-solve
+    repair_thresholds = (0.1, 0.3)  # threshold u of the static 1x1 / 2x2 choice for the 1st, 2nd, ... repair of one back-solve
 
     def _init_solution_check(self):
         self.last_residual = None           # rho of the last back-solve as handed out (max over the ranks)
@@ -157,25 +157,8 @@ class SolutionCheckMixin(object):
         # the sequence that failed was chosen with the threshold in force: the next one takes more 2 x 2 pivots (MA27 users
         # raise cntl(1) when a factorisation turns out fragile; Ipopt: ma27_pivtol -> ma27_pivtolmax)
         u_next = self.repair_thresholds[min(self._repairs_this_solve, len(self.repair_thresholds) - 1)]
-        first = self._repairs_this_solve == 0
         self._repairs_this_solve += 1
-        split = False
-        if not first and last[0] == 'full' and self.split_conflicting_groups and not hasattr(last[1], 'value_maps'):
-            # a new sequence (from the then-worst instance) was tried already and another instance -- or the same -- is
-            # inaccurate now: instances of one group that need different sequences.  The one that is wrong moves to a
-            # variant group of its own kind (host containers only: with device containers the lanes belong to the producer)
-            matrix = last[1]
-            if getattr(matrix, 'flat_values', None) is not None:
-                matrix = matrix.to_block_matrix(self.local_block_indices)
-            if hasattr(self._eng, 'set_pivot_tolerance') and u_next > max(self._u_symbolic_now, 0.01):
-                self._u_symbolic_now = u_next
-                self._eng.set_pivot_tolerance(u_next, self._u_user[1])
-            gid, slot = (int(mine[1]), int(mine[2])) if forced else (None, -1)
-            split = self._split_inaccurate(matrix, gid, slot)
-            if split:
-                self.refresh_causes['residual'] = self.refresh_causes.get('residual', 0) + 1
-                self._refreshed = []
-        if not split and not self._refresh_pivot_order(shift, forced=forced, u_min=u_next):
+        if not self._refresh_pivot_order(shift, forced=forced, u_min=u_next):
             return False
         self.solve_repairs += 1
         if last[0] == 'full':
