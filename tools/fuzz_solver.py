@@ -185,6 +185,13 @@ def one(seed, hard=False, engine=None, stats=None):
                 sv = np.linalg.svd(Kd, compute_uv=False)
                 if sv.min() <= 1e-10 * sv.max():
                     return None
+                # ... and for a numerically singular DIAGONAL BLOCK: the Schur-complement method -- the reference's as much as
+                # this one -- forms K_i^-1 A_i^T, whatever the condition of the whole system (seed 42408 --hard on the device:
+                # whole system 9e3, one block 3e15)
+                for i in range(N):
+                    bs = np.linalg.svd(kkt.get_block(i, i).toarray(), compute_uv=False)
+                    if bs.min() <= 1e-10 * bs.max():
+                        return None
                 return (seed, 'refused', str(err)[:120], float(sv.max() / sv.min()), form, it)
             r = sc.scaled_residual(Kd, x.flatten(), rhs.flatten())
             ev = np.linalg.eigvalsh(Kd)
