@@ -523,17 +523,18 @@ int pp_residual(pp_handle h, int store, const double* bc_dev, int coupling_on_de
   const int nc = h->nc;
   const size_t ncp = (size_t)std::max(nc, 1);
   if (!h->resid_host) {
+    // (the device buffers first: the mailbox pointer is what says "allocated", so a failure half-way is retried as a whole)
+    if (!h->resid_best) { if (int rc = dev_alloc<double>(h, nullptr, &h->resid_best, 4)) return rc; }
+    if (!h->resid_ax) { if (int rc = dev_alloc<double>(h, nullptr, &h->resid_ax, 2 * ncp + 2 * 1024)) return rc; }      // (+ a slot pair per rank)
+    if (!h->resid_rc) { if (int rc = dev_alloc<double>(h, nullptr, &h->resid_rc, 2 * ncp)) return rc; }         // r_c | its row scales
     void* hp = nullptr;
     void* dp = nullptr;
     const size_t doubles = 8 + 4 * ncp;
     PP_HIP(hipHostMalloc(&hp, doubles * sizeof(double), hipHostMallocMapped));
     std::memset(hp, 0, doubles * sizeof(double));
-    PP_HIP(hipHostGetDevicePointer(&dp, hp, 0));
-    h->resid_host = (volatile double*)hp;
+    if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) { (void)hipHostFree(hp); return fail(h, 3, "hipHostGetDevicePointer failed (check mailbox)"); }
     h->resid_dev = (double*)dp;
-    if (int rc = dev_alloc<double>(h, nullptr, &h->resid_best, 4)) return rc;
-    if (int rc = dev_alloc<double>(h, nullptr, &h->resid_ax, 2 * ncp + 2 * 1024)) return rc;      // (+ a slot pair per rank)
-    if (int rc = dev_alloc<double>(h, nullptr, &h->resid_rc, 2 * ncp)) return rc;         // r_c | its row scales
+    h->resid_host = (volatile double*)hp;
   }
   if (int rc = join_dense(h)) return rc;
   if (!bc_dev) bc_dev = h->last_rc;
@@ -599,7 +600,12 @@ int pp_residual(pp_handle h, int store, const double* bc_dev, int coupling_on_de
     a.rmax = g->res_rmax; a.smax = g->res_smax;
     a.bpart = g->res_bpart; a.ax = h->resid_ax; a.nc_glob = nc;
     // rows per wave: enough waves to fill the chip several times over, few enough atomics (measured at C3: tools/sweep_env.sh PP_RES_ROWS)
-    a.rows_per_wg = rows_env > 0 ? rows_env : 1;          // (x RES_NW = 8 waves: 8 rows per workgroup.  MEASURED at C3, kernel alone: 1 wave x 8 rows 97 us; reverse Cuthill-McKee order 4 x 8 rows 83.5; 8 x 2 rows 69.1; 16 x 2 rows 78.1; 16 x 1 94.9; without the rows that hold by construction 8 x 1 / 2 / 3 / 4 rows: 51.6 / 56.2 / 55.0 / 57.7)
+    // (x RES_NW = 8 waves: 8 rows per workgroup.  MEASURED at C3, kernel alone: 1 wave x 8 rows 97 us; reverse Cuthill-McKee order
+    // 4 x 8 rows 83.5; 8 x 2 rows 69.1; 16 x 2 rows 78.1; 16 x 1 94.9; without the rows that hold by construction 8 x 1 / 2 / 3 / 4
+    // rows: 51.6 / 56.2 / 55.0 / 57.7.  With few instances the launch is not bound by bandwidth but by the chain of atomic maxima on
+    // each instance's word (one per workgroup and instance): 128 blocks 31.6 / 21.5 / 17.3 / 18.8 / 34.2 us for 1 / 2 / 4 / 8 / 16 rows
+    // per wave, 256 blocks 32.4 / 25.2 / 20.9 / 21.9 / 37.0, 512 blocks 37.7 / 35.0 / 32.9 / 36.2 / 41.0: four rows up to 8 chunks)
+    a.rows_per_wg = rows_env > 0 ? rows_env : (d.nchunk <= 8 ? 4 : 1);
     a.nrows = g->res_nrows;
     const unsigned ntask = (unsigned)((g->res_nrows + a.rows_per_wg * RES_NW - 1) / (a.rows_per_wg * RES_NW));
     const unsigned nborder = ((unsigned)d.nc * (unsigned)d.nchunk + RES_NW - 1) / RES_NW;

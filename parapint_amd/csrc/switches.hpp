@@ -38,7 +38,7 @@ static constexpr EnvSwitch kEnvSwitches[] = {
     {"PP_BCR_THREADS", "cyclic reduction: threads of the Bunch-Kaufman workgroup (integer)"},
     {"PP_BCR_FWD_PHASES", "cyclic reduction solve: the three-launch forward part of round 3"},
     {"PP_PINNED_LIMIT_MB", "pp_host_alloc: page-locked host memory one process may hold through the library (MiB, default 16384); beyond it NULL -> the caller's pageable fallback"},
-    {"PP_RES_ROWS", "a-posteriori check (refine.hip): residual rows per wave (integer; default 1, eight waves per workgroup)"},
+    {"PP_RES_ROWS", "a-posteriori check (refine.hip): residual rows per wave (integer; default 4 up to 8 chunks of 64 instances, else 1; eight waves per workgroup)"},
     {"PP_BCR_LBOUND", "cyclic reduction: largest multiplier the unpivoted block factorisation accepts (default 100 = 1 / u; used by the tests to mix both paths in one level)"},
 };
 
